@@ -1,0 +1,235 @@
+/*
+ * linrad_hip.h -- C ABI of liblinrad_hip.so, the MI355X (gfx950) implementation of
+ * Linrad's wideband hot path  fft1 -> timf2(+blank1) -> fft2 -> mix1.
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types cross this boundary.
+ * Every entry point stands in for one `void f(void)` stage function of the
+ * reference (fventuri/linrad) and is called from the same place the reference's
+ * clFFT/cuFFT offload hooks in (fft1.c:3519-3553, wcw.c:535-575, 1174-1183).
+ * The reference passes state through global ring pointers; here the caller hands
+ * the same variables over in `lrh_ptrs` (in/out) and the stage advances exactly
+ * the ones the reference function advances (citations on each field).
+ *
+ * All rings are DEVICE resident (PCIe cannot carry them);
+ * `lrh_export` copies a span of any ring back for the GUI / tests.
+ *
+ * Return value: 0 on success, negative LRH_E* otherwise (the Linrad-side caller
+ * maps them to lirerr(146x), convention lxsys.c:494-505).
+ */
+#ifndef LINRAD_HIP_H
+#define LINRAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRH_ABI_VERSION 1
+
+enum {
+  LRH_OK = 0,
+  LRH_EINVAL = -1,    /* bad argument / unsupported configuration            */
+  LRH_ENOMEM = -2,    /* device or host allocation failed                     */
+  LRH_EDEVICE = -3,   /* HIP runtime error (no device, launch failure, ...)   */
+  LRH_ESTATE = -4,    /* call out of order (e.g. table not set)               */
+  LRH_ERANGE = -5     /* frequency outside mix1 range (lirerr 1211/1212, mix1.c:787-796) */
+};
+
+/* Sizes and parameters. Names follow the reference globals / genparm[] slots. */
+typedef struct lrh_config {
+  int struct_size;              /* sizeof(lrh_config), ABI check                                   */
+  int device;                   /* HIP device ordinal                                              */
+  int rx_rf_channels;           /* ui.rx_rf_channels; 1 per context (channels shard one per GPU)   */
+  /* fft1 (fft1.c:413-650, buf.c:193-304) */
+  int fft1_n;                   /* log2 fft1_size, 6..15 (buf.c:335)                               */
+  int fft1_sinpow;              /* genparm[FIRST_FFT_SINPOW] 0..9 (fft0.c:812-921)                 */
+  int fft1_gain;                /* genparm[FIRST_FFT_GAIN] (fft1.c:4653-4671)                      */
+  int fft1_direction;           /* +1 / -1 (fft1.c:3660-3679)                                      */
+  int fft_avg1num;              /* wg.fft_avg1num (fft1.c:4507-4520)                               */
+  int fft_avg2num;              /* wg_fft_avg2num (fft1.c:4526-4605)                               */
+  int timf1_bytes;              /* input ring size, power of two (buf.c:744-770)                   */
+  int max_fft1n;                /* fft1_float ring length in transforms, pow2 >= 8 (buf.c:671-693) */
+  int fft1_sumsq_bufsize;       /* floats, pow2 multiple of fft1_size (buf.c:698-737)              */
+  int wg_xpoints;               /* wg.xpoints, sets the slow-average recalc stride (fft1.c:4571)   */
+  int slowsum_fresh_recalc;     /* fresh_recalc of fft1.c:4546-4567 (2, 4 or 8)                    */
+  /* timf2 (timf2.c:31-208, 689-1065) */
+  int bckfft_att_n;             /* genparm[FIRST_BCKFFT_ATT_N]                                     */
+  int timf2pow_size;            /* samples in the timf2 ring, pow2 (buf.c:371-399)                 */
+  /* blank1 (blank1.c:684-1603, buf.c:337-346,418-431,2083-2086, hires_graph.c:1157-1162) */
+  int stupid_bln_mode;          /* hg.stupid_bln_mode 0/1                                          */
+  float stupid_bln_factor;      /* hg.stupid_bln_factor                                            */
+  int blnfit_range;             /* 48 uncalibrated                                                 */
+  int blanker_pulsewidth;       /* 0 uncalibrated                                                  */
+  int timf2_noise_floor_avgnum;
+  int blanker_info_update_interval;
+  int blanker_min_points;       /* min_delay_time*ui.rx_ad_speed (blank1.c:712)                    */
+  int timf2_noise_floor;        /* start value, 200 (buf.c:418)                                    */
+  /* fft2 (fft2.c:86-141, 647-815, 1821-1846) */
+  int fft2_n;                   /* log2 fft2_size                                                  */
+  int fft2_sinpow;              /* genparm[SECOND_FFT_SINPOW]                                      */
+  int max_fft2n;                /* fft2_float ring length in transforms (buf.c:459-471)            */
+  int waterfall_avgnum;         /* wg.waterfall_avgnum                                             */
+  int wf_first_xpoint;          /* hgwat_first_xpoint                                              */
+  int wf_xpixels;               /* wg_xpixels                                                      */
+  int wf_mode;                  /* 1: one point per pixel; k>1: hgwat_xpoints_per_pixel=k (max of
+                                   group); k<0: hgwat_pixels_per_xpoint=-k (interpolate)           */
+  int wf_lines;                 /* lines kept in wg_waterf (wg_waterf_size/wg_xpixels)             */
+  /* mix1 (mix1.c:55-262, 781-861, 934-993) */
+  int mix1_bandwidth_reduction_n; /* genparm[MIX1_BANDWIDTH_REDUCTION_N]: mix1.n = fft2_n - this   */
+  int timf3_size;               /* floats per mix1 channel, pow2 (buf.c:640-663)                   */
+  float fftx_points_per_hz;     /* fft2 bins per Hz (seldef.h:219)                                 */
+  float mix1_lowest_fq, mix1_highest_fq;
+  /* execution */
+  int max_batch;                /* largest `batch` any call will pass                              */
+  int reserved[8];
+} lrh_config;
+
+/*
+ * The reference's global ring pointers, owned by the caller, passed in/out.
+ * A stage advances only the fields the reference function it replaces advances.
+ */
+typedef struct lrh_ptrs {
+  /* advanced by the caller, like wideband_dsp does (wcw.c:1036-1047) */
+  int timf1p_px;                /* bytes                                                           */
+  int fft1_pa, fft1_na, fft1_nm;
+  /* fft1_c (fft1.c:4507-4523) */
+  int fft1_nb, fft1_pb;
+  int fft1_sumsq_pa, fft1_sumsq_counter, fft1_liminfo_cnt, fft1_sumsq_recalc;
+  /* make_timf2 (timf2.c:127-128, 205-207) */
+  int fft1_px, fft1_nx;
+  int timf2_pa;
+  int fft1_lowlevel_points;
+  float fft1_lowlevel_fraction;
+  /* first_noise_blanker (blank1.c:1458-1476, 1550-1601) */
+  int timf2p_fit, timf2_pn2;
+  int timf2_cleared_points_unused;  /* device-side; read with lrh_get_blanker_state             */
+  int timf2_blanker_points;
+  int blanker_info_update_counter;
+  /* make_fft2 (fft2.c:672, 1831-1845) */
+  int timf2_px;
+  int fft2_na, fft2_pa, fft2_nb, fft2_nm;
+  int wg_waterf_sum_counter, wg_waterf_ptr, fft2_liminfo_cnt;
+  /* fft2_mix1_fixed (mix1.c:991-992) */
+  int fft2_nx, timf3_pa;
+  int reserved[8];
+} lrh_ptrs;
+
+/* device-resident blanker scalars (blnkdef.h:18-33, globdef.h:983) read back on demand */
+typedef struct lrh_blanker_state {
+  int timf2_noise_floor;            /* signed int, truncating recursion (blank1.c:1583)            */
+  unsigned int stupid_bln_limit;
+  float timf2_despiked_pwr[2];
+  float timf2_despiked_pwrinc[2];
+  float stupid_blanker_rate;
+  int timf2_cleared_points;         /* since the last info update                                  */
+  int last_call_cleared;            /* cleared_points of the most recent call                      */
+  int slow_path_calls;              /* calls that fell back to the exact serial scan               */
+} lrh_blanker_state;
+
+/* mix1 phase bookkeeping (seldef.h:205-214), host side, double-checked against mix1.c:781-861 */
+typedef struct lrh_mix1_state {
+  double mix1_selfreq;              /* < 0: channel not selected (mix1_clear)                      */
+  int mix1_point, mix1_old_point;
+  float mix1_phase, mix1_phase_step, mix1_phase_rot, mix1_old_phase;
+} lrh_mix1_state;
+
+typedef enum lrh_ring {
+  LRH_RING_TIMF1 = 0,           /* int16                                                           */
+  LRH_RING_FFT1_FLOAT,          /* float [max_fft1n][N1][2]                                        */
+  LRH_RING_FFT1_SUMSQ,          /* float [fft1_sumsq_bufsize]                                      */
+  LRH_RING_FFT1_SLOWSUM,        /* float [N1]                                                      */
+  LRH_RING_TIMF2_FLOAT,         /* float [timf2pow_size][4] {wRe,wIm,sRe,sIm}                      */
+  LRH_RING_TIMF2_PWR,           /* float [timf2pow_size]                                           */
+  LRH_RING_FFT2_FLOAT,          /* float [max_fft2n][N2][2]                                        */
+  LRH_RING_FFT2_POWER,          /* float [max_fft2n][N2]                                           */
+  LRH_RING_FFT2_POWERSUM,       /* float [N2]                                                      */
+  LRH_RING_WG_WATERF,           /* int16 [wf_lines][wf_xpixels]                                    */
+  LRH_RING_TIMF3_FLOAT,         /* float [timf3_size]                                              */
+  LRH_RING_COUNT
+} lrh_ring;
+
+typedef struct lrh_ctx lrh_ctx;
+
+/* ---- lifetime: replaces cufftPlanMany/cudaMalloc at wcw.c:553-575 and the never-freed
+        buffers / destroy_clFFT_plan at wcw.c:1174-1183 ---- */
+int  lrh_abi_version(void);
+int  lrh_config_defaults(lrh_config *cfg, int fft1_n, int fft2_n);     /* fills reference defaults (uivar.c:371) */
+int  lrh_open(const lrh_config *cfg, lrh_ctx **out);
+void lrh_close(lrh_ctx *ctx);
+const char *lrh_last_error(const lrh_ctx *ctx);
+int  lrh_get_derived(const lrh_ctx *ctx, int *fft1_interleave_points, int *fft2_interleave_points,
+                     int *mix1_size, int *mix1_interleave_points, int *timf3_block);
+void lrh_ptrs_init(const lrh_ctx *ctx, lrh_ptrs *p);                    /* zero start state (buf.c:400-408) */
+
+/* ---- tables the control plane owns ---- */
+int lrh_set_filtercorr(lrh_ctx *ctx, const float *fft1_filtercorr /* 2*N1, NULL: uncalibrated default
+                                                                     of clear_fft1_filtercorr, fft1.c:4673-4724 */);
+int lrh_set_liminfo(lrh_ctx *ctx, const float *liminfo /* N1 floats, 0 = weak (timf2.c:50) */);
+int lrh_set_waterfall_yfac(lrh_ctx *ctx, const float *wg_waterf_yfac /* N1 floats, NULL: make_wg_yfac default */);
+int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "fft1_window","fft2_window",
+                                                                     "mix1_fqwin","fft1_filtercorr","wg_waterf_yfac" */
+
+/* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
+int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */
+void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                         /* for device-resident producers */
+
+/* ---- stages ---- */
+/* fft1_b (fft1def.h:363; fft1.c:3302, mode 7 semantics fft1.c:413-447 + fft0.c:161 + fft1.c:637) for `batch`
+   consecutive blocks; block i reads at timf1p_ref + i*timf1_blockbytes and writes transform
+   (fft1_pa/fft1_block + i) & fft1n_mask. The filter correction of fft1_c (fft1.c:4119-4127) is applied
+   in the store epilogue. The caller advances timf1p_px / fft1_pa / fft1_na as wcw.c:1036-1047. */
+int lrh_fft1_b(lrh_ctx *ctx, int timf1p_ref, int fft1_pa, int batch);
+/* fft1_c (fft1def.h:364; fft1.c:4085-4524): power accumulation into fft1_sumsq, slow average
+   (update_fft1_slowsum fft1.c:4526-4605 + new_fft1_averages wide_graph.c:1003-1052), fft1_nb/pb advance. */
+int lrh_fft1_c(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* make_timf2 (fft1def.h:349; timf2.c:31-208, 689-1065) */
+int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* first_noise_blanker (fft2def.h:64; blank1.c:684-1603), stupid blanker + noise statistics */
+int lrh_first_noise_blanker(lrh_ctx *ctx, lrh_ptrs *p);
+/* make_fft2 until FFT2_COMPLETE (fft2def.h:61; fft2.c:52-1848, mode 15), `batch` transforms.
+   The caller checks (timf2_pn2-timf2_px) >= 4*N2 per transform as wcw.c:265-275 does. */
+int lrh_make_fft2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* fft2_mix1_fixed (fft2def.h:62; mix1.c:934-993 + set_mix1_phases mix1.c:781-861 + do_mix1 mix1.c:55-195) */
+int lrh_fft2_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+int lrh_set_mix1_selfreq(lrh_ctx *ctx, double fq);        /* mix1_selfreq[0]; <0 deselects               */
+int lrh_get_mix1_state(lrh_ctx *ctx, lrh_mix1_state *st);
+
+/* Whole wideband chain for `nblocks` fft1 blocks in the order of wideband_dsp's single-CPU branch
+   (wcw.c:1036-1118), batched `batch` blocks at a time: the blanker and fft2/mix1 run once per batch. */
+int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
+
+/* ---- host-visible side outputs ---- */
+int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems); /* synchronous */
+int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                                   /* synchronous */
+int lrh_sync(lrh_ctx *ctx);
+
+/* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
+int lrh_timer_start(lrh_ctx *ctx);
+int lrh_timer_stop(lrh_ctx *ctx, float *elapsed_ms);      /* synchronises on the stop event */
+/* per-kernel accumulated time since the last reset, measured with hipEvents around each launch when enabled */
+int lrh_profile_enable(lrh_ctx *ctx, int on);
+int lrh_profile_get(lrh_ctx *ctx, const char *kernel, double *total_ms, long *launches);
+
+/* ---- deterministic test signal (the build's own generator; role of internal_generator rxin.c:43-188).
+        Host code, no GPU needed. Interleaved int16 I,Q. ---- */
+typedef struct lrh_synth {
+  uint64_t seed;
+  float noise_sigma;            /* LSB per component                                              */
+  int ncarriers;
+  float carrier_bin[16];        /* cycles per fft_size samples                                     */
+  float carrier_amp[16];        /* LSB                                                             */
+  int fft_size;                 /* reference size for carrier_bin                                  */
+  int pulse_period;             /* samples; 0: none                                                */
+  int pulse_len;
+  float pulse_amp;
+  float chan_phase;             /* radians applied to carriers (multi-channel sky phase)           */
+} lrh_synth;
+void lrh_synth_defaults(lrh_synth *s, int fft1_size, int channel);       /* SURVEY.md 8(d) signal */
+int  lrh_synth_iq(const lrh_synth *s, int64_t first_sample, int64_t nsamples, int16_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINRAD_HIP_H */

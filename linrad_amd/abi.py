@@ -1,0 +1,280 @@
+"""ctypes mirror of include/linrad_hip.h (the C ABI of liblinrad_hip.so).
+
+This is the reference-side binding stub a maintainer would write for any C ABI: the
+structs, the prototypes, and a thin object wrapper whose methods are named after the
+reference stage functions they replace (fft1_b, fft1_c, make_timf2, first_noise_blanker,
+make_fft2, fft2_mix1_fixed).  It is parametrised on the symbol prefix so that
+tests can drive the CPU oracle (prefix ``lro``) through the very same calls.
+"""
+import ctypes as C
+import numpy as np
+
+LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2, -3, -4, -5
+
+(RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
+ RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT) = range(11)
+_RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16}
+
+
+class LrhConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int), ("device", C.c_int), ("rx_rf_channels", C.c_int),
+        ("fft1_n", C.c_int), ("fft1_sinpow", C.c_int), ("fft1_gain", C.c_int), ("fft1_direction", C.c_int),
+        ("fft_avg1num", C.c_int), ("fft_avg2num", C.c_int), ("timf1_bytes", C.c_int), ("max_fft1n", C.c_int),
+        ("fft1_sumsq_bufsize", C.c_int), ("wg_xpoints", C.c_int), ("slowsum_fresh_recalc", C.c_int),
+        ("bckfft_att_n", C.c_int), ("timf2pow_size", C.c_int),
+        ("stupid_bln_mode", C.c_int), ("stupid_bln_factor", C.c_float), ("blnfit_range", C.c_int),
+        ("blanker_pulsewidth", C.c_int), ("timf2_noise_floor_avgnum", C.c_int),
+        ("blanker_info_update_interval", C.c_int), ("blanker_min_points", C.c_int), ("timf2_noise_floor", C.c_int),
+        ("fft2_n", C.c_int), ("fft2_sinpow", C.c_int), ("max_fft2n", C.c_int), ("waterfall_avgnum", C.c_int),
+        ("wf_first_xpoint", C.c_int), ("wf_xpixels", C.c_int), ("wf_mode", C.c_int), ("wf_lines", C.c_int),
+        ("mix1_bandwidth_reduction_n", C.c_int), ("timf3_size", C.c_int), ("fftx_points_per_hz", C.c_float),
+        ("mix1_lowest_fq", C.c_float), ("mix1_highest_fq", C.c_float),
+        ("max_batch", C.c_int), ("reserved", C.c_int * 8),
+    ]
+
+
+class LrhPtrs(C.Structure):
+    _fields_ = [
+        ("timf1p_px", C.c_int), ("fft1_pa", C.c_int), ("fft1_na", C.c_int), ("fft1_nm", C.c_int),
+        ("fft1_nb", C.c_int), ("fft1_pb", C.c_int),
+        ("fft1_sumsq_pa", C.c_int), ("fft1_sumsq_counter", C.c_int), ("fft1_liminfo_cnt", C.c_int),
+        ("fft1_sumsq_recalc", C.c_int),
+        ("fft1_px", C.c_int), ("fft1_nx", C.c_int), ("timf2_pa", C.c_int),
+        ("fft1_lowlevel_points", C.c_int), ("fft1_lowlevel_fraction", C.c_float),
+        ("timf2p_fit", C.c_int), ("timf2_pn2", C.c_int), ("timf2_cleared_points_unused", C.c_int),
+        ("timf2_blanker_points", C.c_int), ("blanker_info_update_counter", C.c_int),
+        ("timf2_px", C.c_int), ("fft2_na", C.c_int), ("fft2_pa", C.c_int), ("fft2_nb", C.c_int), ("fft2_nm", C.c_int),
+        ("wg_waterf_sum_counter", C.c_int), ("wg_waterf_ptr", C.c_int), ("fft2_liminfo_cnt", C.c_int),
+        ("fft2_nx", C.c_int), ("timf3_pa", C.c_int), ("reserved", C.c_int * 8),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class LrhBlankerState(C.Structure):
+    _fields_ = [
+        ("timf2_noise_floor", C.c_int), ("stupid_bln_limit", C.c_uint),
+        ("timf2_despiked_pwr", C.c_float * 2), ("timf2_despiked_pwrinc", C.c_float * 2),
+        ("stupid_blanker_rate", C.c_float), ("timf2_cleared_points", C.c_int),
+        ("last_call_cleared", C.c_int), ("slow_path_calls", C.c_int),
+    ]
+
+
+class LrhMix1State(C.Structure):
+    _fields_ = [
+        ("mix1_selfreq", C.c_double), ("mix1_point", C.c_int), ("mix1_old_point", C.c_int),
+        ("mix1_phase", C.c_float), ("mix1_phase_step", C.c_float), ("mix1_phase_rot", C.c_float),
+        ("mix1_old_phase", C.c_float),
+    ]
+
+
+class LrhSynth(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("noise_sigma", C.c_float), ("ncarriers", C.c_int),
+        ("carrier_bin", C.c_float * 16), ("carrier_amp", C.c_float * 16), ("fft_size", C.c_int),
+        ("pulse_period", C.c_int), ("pulse_len", C.c_int), ("pulse_amp", C.c_float), ("chan_phase", C.c_float),
+    ]
+
+
+def default_config(fft1_n, fft2_n, **kw):
+    """Reference defaults (weak-signal CW row of uivar.c:371; sizing rules of buf.c) for given sizes."""
+    N1, N2 = 1 << fft1_n, 1 << fft2_n
+    c = LrhConfig()
+    c.struct_size = C.sizeof(LrhConfig)
+    c.device = 0
+    c.rx_rf_channels = 1
+    c.fft1_n, c.fft1_sinpow, c.fft1_gain, c.fft1_direction = fft1_n, 2, 27, 1
+    c.fft_avg1num, c.fft_avg2num = 5, 4
+    c.max_fft1n = 8
+    c.fft1_sumsq_bufsize = 8 * N1
+    c.wg_xpoints, c.slowsum_fresh_recalc = N1 - 1, 2
+    c.bckfft_att_n = 6
+    c.timf2pow_size = 8 * max(N1, N2)
+    c.timf1_bytes = 16 * N1 * 4
+    c.stupid_bln_mode, c.stupid_bln_factor = 1, 5.0
+    c.blnfit_range, c.blanker_pulsewidth = 48, 0
+    c.timf2_noise_floor_avgnum, c.blanker_info_update_interval = 32, 4
+    c.blanker_min_points = N2 // 3
+    c.timf2_noise_floor = 200
+    c.fft2_n, c.fft2_sinpow, c.max_fft2n = fft2_n, 2, 4
+    c.waterfall_avgnum, c.wf_first_xpoint, c.wf_xpixels, c.wf_mode, c.wf_lines = 2, 0, min(N2, 1024), 1, 8
+    c.mix1_bandwidth_reduction_n = 6
+    c.timf3_size = 32 * max(8, N2 >> 6)
+    c.fftx_points_per_hz, c.mix1_lowest_fq, c.mix1_highest_fq = 1.0, 0.0, float(N2)
+    c.max_batch = 64
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+class LrhError(RuntimeError):
+    pass
+
+
+class StageAPI:
+    """Object wrapper over the C ABI; ``prefix`` is 'lrh' (HIP product) or 'lro' (CPU oracle, tests only)."""
+
+    def __init__(self, lib, prefix, cfg):
+        self.lib, self.prefix, self.cfg = lib, prefix, cfg
+        self._f = lambda name: getattr(lib, f"{prefix}_{name}")
+        vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+        self._proto("open", [C.POINTER(LrhConfig), C.POINTER(vp)])
+        self._proto("close", [vp], None)
+        self._proto("ptrs_init", [vp, C.POINTER(LrhPtrs)], None)
+        self._proto("get_derived", [vp, ip, ip, ip, ip, ip])
+        self._proto("set_filtercorr", [vp, fp])
+        self._proto("set_liminfo", [vp, fp])
+        self._proto("set_waterfall_yfac", [vp, fp])
+        self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
+        self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
+        self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
+        for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed"):
+            self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
+        self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
+        self._proto("set_mix1_selfreq", [vp, C.c_double])
+        self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
+        self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
+        self._proto("export", [vp, C.c_int, vp, C.c_size_t, C.c_size_t])
+        self._proto("get_blanker_state", [vp, C.POINTER(LrhBlankerState)])
+        self.ctx = vp()
+        rc = self._f("open")(C.byref(cfg), C.byref(self.ctx))
+        if rc != 0:
+            raise LrhError(f"{prefix}_open failed rc={rc}")
+        self.p = LrhPtrs()
+        self._f("ptrs_init")(self.ctx, C.byref(self.p))
+        d = [C.c_int() for _ in range(5)]
+        self._f("get_derived")(self.ctx, *[C.byref(x) for x in d])
+        (self.fft1_interleave_points, self.fft2_interleave_points, self.mix1_size,
+         self.mix1_interleave_points, self.timf3_block) = [x.value for x in d]
+        self.N1, self.N2 = 1 << cfg.fft1_n, 1 << cfg.fft2_n
+        self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * 4
+
+    def _proto(self, name, argtypes, restype=C.c_int):
+        f = self._f(name)
+        f.argtypes, f.restype = argtypes, restype
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise LrhError(f"{self.prefix}_{what} rc={rc}")
+
+    def close(self):
+        if self.ctx:
+            self._f("close")(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _fptr(a):
+        return a.ctypes.data_as(C.POINTER(C.c_float))
+
+    # ---- tables
+    def set_filtercorr(self, fc=None):
+        if fc is None:
+            self._chk(self._f("set_filtercorr")(self.ctx, None), "set_filtercorr")
+        else:
+            fc = np.ascontiguousarray(fc, np.float32)
+            assert fc.size == 2 * self.N1
+            self._chk(self._f("set_filtercorr")(self.ctx, self._fptr(fc)), "set_filtercorr")
+
+    def set_liminfo(self, lim):
+        lim = np.ascontiguousarray(lim, np.float32)
+        assert lim.size == self.N1
+        self._chk(self._f("set_liminfo")(self.ctx, self._fptr(lim)), "set_liminfo")
+
+    def set_waterfall_yfac(self, y=None):
+        if y is None:
+            self._chk(self._f("set_waterfall_yfac")(self.ctx, None), "set_waterfall_yfac")
+        else:
+            y = np.ascontiguousarray(y, np.float32)
+            assert y.size == self.N1
+            self._chk(self._f("set_waterfall_yfac")(self.ctx, self._fptr(y)), "set_waterfall_yfac")
+
+    def get_table(self, name, count):
+        out = np.zeros(count, np.float32)
+        n = self._f("get_table")(self.ctx, name.encode(), self._fptr(out), count)
+        if n < 0:
+            raise LrhError(f"get_table({name}) rc={n}")
+        return out[:n]
+
+    # ---- producer
+    def timf1_write(self, iq, byte_offset=0):
+        iq = np.ascontiguousarray(iq, np.int16)
+        self._chk(self._f("timf1_write")(self.ctx, iq.ctypes.data_as(C.c_void_p), int(byte_offset), int(iq.nbytes)),
+                  "timf1_write")
+
+    # ---- stages (names = reference functions)
+    def fft1_b(self, batch=1):
+        """fft1_b for `batch` blocks, then the caller-side pointer advance of wcw.c:1036-1047."""
+        p = self.p
+        self._chk(self._f("fft1_b")(self.ctx, p.timf1p_px, p.fft1_pa, batch), "fft1_b")
+        block = 2 * self.N1
+        p.timf1p_px = (p.timf1p_px + batch * self.timf1_blockbytes) & (self.cfg.timf1_bytes - 1)
+        p.fft1_pa = (p.fft1_pa + batch * block) & (self.cfg.max_fft1n * block - 1)
+        p.fft1_na = p.fft1_pa // block
+        p.fft1_nm = min(p.fft1_nm + batch, self.cfg.max_fft1n - 1)
+
+    def fft1_c(self, batch=1):
+        self._chk(self._f("fft1_c")(self.ctx, C.byref(self.p), batch), "fft1_c")
+
+    def make_timf2(self, batch=1):
+        self._chk(self._f("make_timf2")(self.ctx, C.byref(self.p), batch), "make_timf2")
+
+    def first_noise_blanker(self):
+        self._chk(self._f("first_noise_blanker")(self.ctx, C.byref(self.p)), "first_noise_blanker")
+
+    def make_fft2(self, batch=1):
+        self._chk(self._f("make_fft2")(self.ctx, C.byref(self.p), batch), "make_fft2")
+
+    def fft2_mix1_fixed(self, batch=1):
+        self._chk(self._f("fft2_mix1_fixed")(self.ctx, C.byref(self.p), batch), "fft2_mix1_fixed")
+
+    def fft2_available(self):
+        """number of fft2 transforms the released timf2 data allows (wcw.c:265-275)"""
+        p = self.p
+        size = 4 * self.cfg.timf2pow_size
+        avail = (p.timf2_pn2 - p.timf2_px + size) & (size - 1)
+        if avail < 4 * self.N2:
+            return 0
+        return 1 + (avail - 4 * self.N2) // (4 * (self.N2 - self.fft2_interleave_points))
+
+    def set_mix1_selfreq(self, fq):
+        self._chk(self._f("set_mix1_selfreq")(self.ctx, float(fq)), "set_mix1_selfreq")
+
+    def mix1_state(self):
+        st = LrhMix1State()
+        self._chk(self._f("get_mix1_state")(self.ctx, C.byref(st)), "get_mix1_state")
+        return st
+
+    def wideband_dsp(self, nblocks, batch):
+        self._chk(self._f("wideband_dsp")(self.ctx, C.byref(self.p), nblocks, batch), "wideband_dsp")
+
+    # ---- outputs
+    def ring_size(self, ring):
+        c = self.cfg
+        return {RING_TIMF1: c.timf1_bytes // 2, RING_FFT1_FLOAT: c.max_fft1n * 2 * self.N1,
+                RING_FFT1_SUMSQ: c.fft1_sumsq_bufsize, RING_FFT1_SLOWSUM: self.N1,
+                RING_TIMF2_FLOAT: 4 * c.timf2pow_size, RING_TIMF2_PWR: c.timf2pow_size,
+                RING_FFT2_FLOAT: c.max_fft2n * 2 * self.N2, RING_FFT2_POWER: c.max_fft2n * self.N2,
+                RING_FFT2_POWERSUM: self.N2, RING_WG_WATERF: c.wf_lines * c.wf_xpixels,
+                RING_TIMF3_FLOAT: c.timf3_size}[ring]
+
+    def export(self, ring, offset=0, count=None):
+        if count is None:
+            count = self.ring_size(ring) - offset
+        out = np.zeros(count, _RING_DTYPE.get(ring, np.float32))
+        self._chk(self._f("export")(self.ctx, ring, out.ctypes.data_as(C.c_void_p), offset, count), "export")
+        return out
+
+    def blanker_state(self):
+        st = LrhBlankerState()
+        self._chk(self._f("get_blanker_state")(self.ctx, C.byref(st)), "get_blanker_state")
+        return st

@@ -1,0 +1,783 @@
+/*
+ * linrad_oracle.c -- TEST INFRASTRUCTURE ONLY (see linrad_oracle.h).
+ *
+ * Plain-C float32 restatement of the reference hot path.  Every function cites the
+ * reference lines it follows (paths relative to fventuri/linrad).  Not a copy: the
+ * reference keeps state in ~80 globals and unrolls each FFT variant by hand; here
+ * one context owns the rings and two generic radix-2 kernels do all transforms.
+ * Where the order of float operations decides the result (butterflies, phase
+ * accumulators, truncating conversions) the reference order is kept on purpose.
+ */
+#include "linrad_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PI_L 3.1415926535897932   /* globdef.h:93 */
+#define NATLOG 2.718281828459045
+#define FFT1_SMALL 0.00000001F    /* globdef.h:88 */
+#define FFT2_WATERFALL_ZERO 0.012 /* graphcal.h:8 */
+
+typedef struct { float sin, cos; } cosin_t;   /* COSIN_TABLE, globdef.h */
+
+struct lro_ctx {
+  lrh_config cfg;
+  int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
+  /* tables */
+  cosin_t *fft1tab, *fft2tab, *mix1tab;
+  float *fft1_window;          /* mode-1 storage, fft0.c:907-920 */
+  float *fft1_inverted_window; /* mode 3 */
+  float *fft1_filtercorr;      /* 2*N1 */
+  float *fft1_desired;
+  float *fft2_window;          /* mode 4, N2 */
+  float *mix1_fqwin;           /* mode 5, Nm/2+1 */
+  float *wg_waterf_yfac;       /* N1 */
+  float *liminfo;
+  /* rings */
+  int16_t *timf1;
+  float *fft1_float, *fft1_sumsq, *fft1_slowsum;
+  float *timf2_float, *timf2_pwr;
+  float *fft2_float, *fft2_power, *fft2_powersum;
+  int16_t *wg_waterf;
+  float *timf3_float;
+  float *tmp;                  /* scratch, 8*max(N1,N2) floats */
+  /* masks */
+  int fft1n_mask, fft1_mask, fft1_sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
+  /* blanker scalars (blnkvar.c) */
+  lrh_blanker_state bs;
+  /* mix1 scalars (selvar.c) */
+  lrh_mix1_state ms;
+  double old_mix1_selfreq;
+};
+
+/* ------------------------------------------------------------------ tables */
+
+/* make_sincos, fft0.c:1263-1284: angle accumulated in double, stored as float */
+static void make_sincos(int size, cosin_t *tab)
+{
+  double x = 0, step = (double)(PI_L / (size / 2));
+  for (int i = 0; i < size / 2; i++) { tab[i].sin = (float)sin(x); tab[i].cos = (float)cos(x); x += step; }
+}
+
+/* make_window, fft0.c:812-921.  mo: 1 interleaved half storage, 3 inverted, 4 full symmetric,
+   5 erfc edge (sz/2+1 points).  n: sin power 1..7, 8 Gaussian, 9 erfc. */
+void lro_make_window(int mo, int sz, int n, float *win)
+{
+  double x, z, sumsq = 0, e1, e2;
+  int i, size = sz;
+  if (mo == 5) {
+    e1 = 3.2; e2 = 13.0 / sz;
+    for (i = 0; i <= sz / 2; i++) { win[i] = 0.5F * (float)erfc(e1); e1 -= e2; }
+    return;
+  }
+  if (n == 0) return;
+  z = n;
+  float *h = (float *)malloc(sizeof(float) * (size / 2 + 1));
+  if (n == 9) {
+    e1 = 4.4; e2 = 40.0 / size; if (size < 128) e2 /= 1.5; if (size < 64) e2 /= 1.7;
+    for (i = 0; i <= size / 2; i++) { h[i] = 0.5F * (float)erfc(e1); sumsq += h[i] * h[i]; e1 -= e2; }
+  } else if (n == 8) {
+    e1 = 0; e2 = 9.8 / size;
+    for (i = size / 2; i >= 0; i--) { h[i] = (float)pow(NATLOG, -e1 * e1); sumsq += h[i] * h[i]; e1 += e2; }
+  } else {
+    x = 0;
+    for (i = 0; i <= size / 2; i++) { h[i] = (float)pow(sin(x), z); sumsq += h[i] * h[i]; x += PI_L / size; }
+  }
+  if (mo == 3) {                       /* inverted window over size/2+1 points, fft0.c:883-891 */
+    win[0] = 1;
+    for (i = 1; i <= size / 2; i++) win[i] = 1 / h[i];
+    free(h); return;
+  }
+  z = 1 / sqrt(2 * sumsq / size);      /* unit mean square, fft0.c:892-896 */
+  for (i = 0; i <= size / 2; i++) h[i] *= (float)z;
+  if (mo == 4) {
+    for (i = 0; i <= size / 2; i++) win[i] = h[i];
+    for (i = size / 2 + 1; i < size; i++) win[i] = h[size - i];
+  } else {                             /* mo 1: win[2i]=w[i], win[2i+1]=w[N/2-i], fft0.c:907-920 */
+    for (i = 0; i < size / 2; i++) { win[2 * i] = h[i]; win[2 * i + 1] = h[size / 2 - i]; }
+  }
+  free(h);
+}
+
+/* make_interleave_ratio, buf.c:113-136 */
+static float interleave_ratio(int sinpow)
+{
+  if (sinpow == 0) return 0;
+  if (sinpow == 9) return 0.625f;
+  if (sinpow == 8) return 0.8f;
+  return (float)(2 * asin(pow(0.5, 1.0 / sinpow)) / PI_L);
+}
+
+/* clear_fft1_filtercorr + make_filcorrstart, fft1.c:4653-4724 (int16 IQ input, complex fft) */
+static void default_filtercorr(lro_ctx *c)
+{
+  int N = c->N1;
+  float start = 150 * (float)N * (float)pow((double)N, -0.4);
+  start = (float)c->cfg.fft1_gain / start;
+  for (int i = 0; i < N; i++) { c->fft1_desired[i] = 1; c->fft1_filtercorr[2 * i] = start; c->fft1_filtercorr[2 * i + 1] = 0; }
+  float t1 = 0.125F * (float)PI_L, t2 = 0, t3;
+  int i = 0, k = N - 1;
+  while (t2 < 0.5 * PI_L) {
+    t3 = (float)(sin(t2) * sin(t2));
+    c->fft1_desired[i] = t3; c->fft1_filtercorr[2 * i] = t3 * start;
+    c->fft1_desired[k] = t3; c->fft1_filtercorr[2 * k] = t3 * start;
+    t2 += t1; i++; k--;
+  }
+}
+
+/* make_wg_yfac, wide_graph.c:955-1001, second-fft branch, 1 channel, float fft2 */
+static void default_yfac(lro_ctx *c)
+{
+  float t1 = (float)(FFT2_WATERFALL_ZERO) / ((float)c->N2 * (float)c->N1);
+  t1 /= (float)sqrt((float)(c->cfg.waterfall_avgnum));
+  t1 *= (float)(1 << (2 * c->cfg.bckfft_att_n));
+  t1 *= (float)(1 + 1 / (0.5 + c->cfg.fft1_sinpow));
+  for (int i = 0; i < c->N1; i++)
+    c->wg_waterf_yfac[i] = (c->fft1_desired[i] > 0.3162278) ? t1 / (float)pow(c->fft1_desired[i], 2.0) : t1 * 10;
+  c->wg_waterf_yfac[0] = t1; c->wg_waterf_yfac[c->N1 - 1] = t1;
+}
+
+/* ------------------------------------------------------------------ FFT kernels */
+
+static unsigned bitrev(unsigned v, int n) { unsigned r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (v & 1); v >>= 1; } return r; }
+
+/* Radix-2 decimation in frequency, natural in -> bit-reversed out, twiddle e^{+j s theta} from a float table
+   (the loop of bulk_of_dif fft0.c:161-195 / fftback fft0.c:481-518 / big_fftforward fft0.c:753-793, all stages).
+   stride = nch*2 floats per point, so two interleaved streams can share one pass (timf2.c:689). */
+static void dif_stages(int N, int n, float *x, const cosin_t *tab, int sgn, int stride)
+{
+  int half = N / 2, inc = 1;
+  for (int st = 0; st < n; st++) {
+    for (int base = 0; base < N; base += 2 * half) {
+      int it = 0;
+      for (int a = base; a < base + half; a++) {
+        int b = a + half;
+        float *pa = x + (size_t)a * stride, *pb = x + (size_t)b * stride;
+        float t1 = pa[0], t2 = pb[0], t3 = pa[1], t4 = pb[1];
+        float x1 = t1 - t2, x2 = t3 - t4;
+        pa[0] = t1 + t2; pa[1] = t3 + t4;
+        float co = tab[it].cos, si = tab[it].sin;
+        if (sgn > 0) { pb[0] = co * x1 - si * x2; pb[1] = si * x1 + co * x2; }
+        else         { pb[0] = co * x1 + si * x2; pb[1] = -si * x1 + co * x2; }
+        it += inc;
+      }
+    }
+    inc *= 2; half /= 2;
+  }
+}
+
+static void bitrev_inplace(int N, int n, float *x, int stride)
+{
+  for (unsigned i = 0; i < (unsigned)N; i++) {
+    unsigned j = bitrev(i, n);
+    if (j > i) for (int k = 0; k < 2; k++) { float t = x[(size_t)i * stride + k]; x[(size_t)i * stride + k] = x[(size_t)j * stride + k]; x[(size_t)j * stride + k] = t; }
+  }
+}
+
+void lro_fft_forward(int n, float *x)
+{
+  int N = 1 << n; cosin_t *tab = malloc(sizeof(cosin_t) * (N / 2 + 1)); make_sincos(N, tab);
+  dif_stages(N, n, x, tab, -1, 2); bitrev_inplace(N, n, x, 2); free(tab);
+}
+void lro_fft_backward(int n, float *x)
+{
+  int N = 1 << n; cosin_t *tab = malloc(sizeof(cosin_t) * (N / 2 + 1)); make_sincos(N, tab);
+  dif_stages(N, n, x, tab, +1, 2); bitrev_inplace(N, n, x, 2); free(tab);
+}
+
+/* ------------------------------------------------------------------ open / close */
+
+static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static void *zal(size_t n) { return calloc(n + 64, 1); }
+
+int lro_open(const lrh_config *cfg, lro_ctx **out)
+{
+  if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
+  if (cfg->rx_rf_channels != 1) return LRH_EINVAL;
+  if (cfg->fft1_n < 6 || cfg->fft1_n > 16 || cfg->fft2_n < 6 || cfg->fft2_n > 22) return LRH_EINVAL;
+  if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) ||
+      !ispow2(cfg->timf2pow_size) || !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size)) return LRH_EINVAL;
+  lro_ctx *c = zal(sizeof(*c)); if (!c) return LRH_ENOMEM;
+  c->cfg = *cfg;
+  int N1 = c->N1 = 1 << cfg->fft1_n, N2 = c->N2 = 1 << cfg->fft2_n;
+  /* buf.c:303-304 */
+  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe; c->M1 = N1 - c->I1;
+  /* buf.c:432-455: mix1 first, fft2 interleave re-derived from it */
+  c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;
+  c->Nm = 1 << c->mix1_n;
+  c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im;
+  c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;
+  if (cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2) { free(c); return LRH_EINVAL; }
+  if (!(c->Im == 0 || c->Im == c->Mm)) { free(c); return LRH_EINVAL; }   /* crossover-window mix1 (mix1.c:196-270): not restated yet */
+  c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->fft1_sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
+  c->timf2pow_mask = cfg->timf2pow_size - 1; c->timf2_mask = 4 * cfg->timf2pow_size - 1; c->fft2n_mask = cfg->max_fft2n - 1;
+  c->timf3_mask = cfg->timf3_size - 1; c->timf1_bytemask = cfg->timf1_bytes - 1;
+  int NM = N1 > N2 ? N1 : N2;
+  c->fft1tab = zal(sizeof(cosin_t) * N1); c->fft2tab = zal(sizeof(cosin_t) * N2); c->mix1tab = zal(sizeof(cosin_t) * c->Nm);
+  c->fft1_window = zal(4 * (N1 + 8)); c->fft1_inverted_window = zal(4 * (N1 + 8)); c->fft1_filtercorr = zal(8 * N1);
+  c->fft1_desired = zal(4 * N1); c->fft2_window = zal(4 * (N2 + 8)); c->mix1_fqwin = zal(4 * (c->Nm + 8));
+  c->wg_waterf_yfac = zal(4 * N1); c->liminfo = zal(4 * N1);
+  c->timf1 = zal(cfg->timf1_bytes); c->fft1_float = zal(sizeof(float) * cfg->max_fft1n * 2 * N1);
+  c->fft1_sumsq = zal(4 * (size_t)cfg->fft1_sumsq_bufsize); c->fft1_slowsum = zal(4 * N1);
+  c->timf2_float = zal(16 * (size_t)cfg->timf2pow_size); c->timf2_pwr = zal(4 * (size_t)cfg->timf2pow_size);
+  c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
+  c->fft2_powersum = zal(4 * N2);
+  c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
+  c->timf3_float = zal(4 * (size_t)cfg->timf3_size + 16 * c->Nm);
+  c->tmp = zal(sizeof(float) * 8 * NM);
+  make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
+  if (cfg->fft1_sinpow) lro_make_window(1, N1, cfg->fft1_sinpow, c->fft1_window);
+  if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) lro_make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
+  if (cfg->fft2_sinpow) lro_make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
+  lro_make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
+  default_filtercorr(c); default_yfac(c);
+  /* blanker start state: buf.c:418-431, hires_graph.c:1157-1162 */
+  c->bs.timf2_noise_floor = cfg->timf2_noise_floor;
+  c->bs.timf2_despiked_pwr[0] = (float)cfg->timf2_noise_floor; c->bs.timf2_despiked_pwrinc[0] = 1;
+  c->bs.timf2_despiked_pwr[1] = 0; c->bs.timf2_despiked_pwrinc[1] = 0;
+  c->bs.stupid_bln_limit = (unsigned int)((float)cfg->timf2_noise_floor * cfg->stupid_bln_factor);
+  c->ms.mix1_selfreq = -1; c->ms.mix1_point = -1; c->old_mix1_selfreq = -1;
+  *out = c; return LRH_OK;
+}
+
+void lro_close(lro_ctx *c)
+{
+  if (!c) return;
+  void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
+                c->fft2_window, c->mix1_fqwin, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
+                c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp };
+  for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
+  free(c);
+}
+
+void lro_ptrs_init(const lro_ctx *c, lrh_ptrs *p)
+{
+  memset(p, 0, sizeof(*p));
+  p->fft1_lowlevel_fraction = .75f;    /* buf.c:343 */
+  p->fft1_sumsq_recalc = 0;            /* set_fft1_endpoints, fft1.c:4646 */
+  (void)c;
+}
+
+int lro_get_derived(const lro_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t3b)
+{
+  if (i1) *i1 = c->I1; if (i2) *i2 = c->I2; if (ms) *ms = c->Nm; if (mi) *mi = c->Im; if (t3b) *t3b = 2 * c->Mm;
+  return LRH_OK;
+}
+
+int lro_set_filtercorr(lro_ctx *c, const float *fc) { if (fc) memcpy(c->fft1_filtercorr, fc, 8 * c->N1); else default_filtercorr(c); return LRH_OK; }
+int lro_set_liminfo(lro_ctx *c, const float *l) { memcpy(c->liminfo, l, 4 * c->N1); return LRH_OK; }
+int lro_set_waterfall_yfac(lro_ctx *c, const float *y) { if (y) memcpy(c->wg_waterf_yfac, y, 4 * c->N1); else default_yfac(c); return LRH_OK; }
+
+int lro_get_table(lro_ctx *c, const char *name, float *dst, int count)
+{
+  const float *src = NULL; int n = 0;
+  if (!strcmp(name, "fft1_window")) { src = c->fft1_window; n = c->N1; }
+  else if (!strcmp(name, "fft2_window")) { src = c->fft2_window; n = c->N2; }
+  else if (!strcmp(name, "mix1_fqwin")) { src = c->mix1_fqwin; n = c->Nm / 2 + 1; }
+  else if (!strcmp(name, "fft1_filtercorr")) { src = c->fft1_filtercorr; n = 2 * c->N1; }
+  else if (!strcmp(name, "wg_waterf_yfac")) { src = c->wg_waterf_yfac; n = c->N1; }
+  else if (!strcmp(name, "fft1_inverted_window")) { src = c->fft1_inverted_window; n = c->N1 / 2 + 1; }
+  else return LRH_EINVAL;
+  if (count > n) count = n;
+  memcpy(dst, src, 4 * (size_t)count); return count;
+}
+
+int lro_timf1_write(lro_ctx *c, const void *src, int off, int nbytes)
+{
+  const char *s = src; char *d = (char *)c->timf1;
+  for (int i = 0; i < nbytes; i++) d[(off + i) & c->timf1_bytemask] = s[i];
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ fft1 */
+
+/* fft1_b mode 7: fft1win_dif_one (fft1.c:413-447) + bulk_of_dif (fft0.c:161) + dif_permute_one (fft1.c:637-650),
+   then the direction flip of fft1.c:3660-3679.  Result: out[k] = conj(FFT(x*w))[(k - N/2) mod N]. */
+static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
+{
+  int N = c->N1, n = c->cfg.fft1_n, nn = N / 2;
+  int m = c->timf1_bytemask / 2;
+  int p0 = timf1p_ref / 2; p0 = (p0 - c->I1 * 2 + m + 1) & m;
+  int pa = p0, pb = (pa + N) & m;
+  float *z = c->tmp;
+  int win = c->cfg.fft1_sinpow != 0;
+  for (int ia = 0; ia < nn; ia++) {           /* window, negate Q, natural order */
+    float wa = win ? c->fft1_window[2 * ia] : 1.0f, wb = win ? c->fft1_window[2 * ia + 1] : 1.0f;
+    float t1 = c->timf1[pa] * wa, t2 = c->timf1[pa + 1] * wa;
+    float t3 = c->timf1[pb] * wb, t4 = c->timf1[pb + 1] * wb;
+    z[2 * ia] = t1; z[2 * ia + 1] = -t2; z[2 * (ia + nn)] = t3; z[2 * (ia + nn) + 1] = -t4;
+    pa = (pa + 2) & m; pb = (pb + 2) & m;
+  }
+  dif_stages(N, n, z, c->fft1tab, +1, 2);
+  for (unsigned i = 0; i < (unsigned)N; i++) {   /* bit reversal + half swap: make_permute(1,..) fft0.c:1147-1207 */
+    unsigned k = (bitrev(i, n) + nn) & (N - 1);
+    out[2 * k] = z[2 * i]; out[2 * k + 1] = z[2 * i + 1];
+  }
+  if (c->cfg.fft1_direction < 0) {              /* fft1.c:3660-3679 with fft1_first_sym_point = 0 */
+    for (int ib = 1, ic = N - 1; ib < nn; ib++, ic--) {
+      float t1 = out[2 * ic], t2 = out[2 * ic + 1];
+      out[2 * ic + 1] = out[2 * ib]; out[2 * ic] = out[2 * ib + 1];
+      out[2 * ib + 1] = t1; out[2 * ib] = t2;
+    }
+    float t = out[2 * nn]; out[2 * nn] = out[2 * nn + 1]; out[2 * nn + 1] = t;
+    t = out[0]; out[0] = out[1]; out[1] = t;
+  }
+}
+
+int lro_fft1_b(lro_ctx *c, int timf1p_ref, int fft1_pa, int batch)
+{
+  int blockbytes = c->M1 * 4;
+  for (int b = 0; b < batch; b++) {
+    int nb = ((fft1_pa / (2 * c->N1)) + b) & c->fft1n_mask;
+    float *out = c->fft1_float + (size_t)nb * 2 * c->N1;
+    fft1_one(c, (timf1p_ref + b * blockbytes) & c->timf1_bytemask, out);
+    /* filter correction of fft1_c (fft1.c:4119-4127), applied here like the HIP path does */
+    const float *fc = c->fft1_filtercorr;
+    for (int i = 0; i < c->N1; i++) {
+      float t1 = out[2 * i] * fc[2 * i] - out[2 * i + 1] * fc[2 * i + 1];
+      out[2 * i + 1] = out[2 * i + 1] * fc[2 * i] + out[2 * i] * fc[2 * i + 1];
+      out[2 * i] = t1;
+    }
+  }
+  return LRH_OK;
+}
+
+/* new_fft1_averages, wide_graph.c:1003-1032 */
+static void new_fft1_averages(lro_ctx *c, int ptr, int ia, int ib)
+{
+  int N = c->N1, a2 = c->cfg.fft_avg2num;
+  int p0 = (ptr - (a2 - 1) * N + c->cfg.fft1_sumsq_bufsize) & c->fft1_sumsq_mask;
+  for (int i = ia; i <= ib; i++) c->fft1_slowsum[i] = c->fft1_sumsq[p0 + i];
+  p0 = (p0 + N) & c->fft1_sumsq_mask;
+  for (int m = 1; m < a2; m++) {
+    for (int i = ia; i <= ib; i++) { c->fft1_slowsum[i] += c->fft1_sumsq[p0 + i]; if (c->fft1_slowsum[i] < FFT1_SMALL) c->fft1_slowsum[i] = FFT1_SMALL; }
+    p0 = (p0 + N) & c->fft1_sumsq_mask;
+  }
+}
+
+/* update_fft1_slowsum, fft1.c:4526-4605 (no correlation, change_fft1_flag clear) */
+static void update_fft1_slowsum(lro_ctx *c, lrh_ptrs *p)
+{
+  int N = c->N1, first = 0, last = N - 1;
+  int pa = p->fft1_sumsq_pa;
+  int pb = (pa - c->cfg.fft_avg2num * N + c->cfg.fft1_sumsq_bufsize) & c->fft1_sumsq_mask;
+  if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = first;
+  int ia = p->fft1_sumsq_recalc;
+  p->fft1_sumsq_recalc += c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
+  if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
+  new_fft1_averages(c, pa, ia, p->fft1_sumsq_recalc);
+  for (int i = first; i < ia; i++) {
+    c->fft1_slowsum[i] += c->fft1_sumsq[pa + i] - c->fft1_sumsq[pb + i];
+    if (c->fft1_slowsum[i] < FFT1_SMALL) c->fft1_slowsum[i] = FFT1_SMALL;
+  }
+  for (int i = p->fft1_sumsq_recalc + 1; i <= last; i++) {
+    c->fft1_slowsum[i] += c->fft1_sumsq[pa + i] - c->fft1_sumsq[pb + i];
+    if (c->fft1_slowsum[i] < FFT1_SMALL) c->fft1_slowsum[i] = FFT1_SMALL;
+  }
+}
+
+/* fft1_c, fft1.c:4085-4201 + 4507-4523 (1 channel, fft1afc_flag <= 0); the complex multiply already done in lro_fft1_b */
+int lro_fft1_c(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  int N = c->N1;
+  for (int b = 0; b < batch; b++) {
+    const float *z = c->fft1_float + (size_t)p->fft1_nb * 2 * N;
+    float *sum = c->fft1_sumsq + p->fft1_sumsq_pa;
+    if (p->fft1_sumsq_counter == 0) for (int i = 0; i < N; i++) sum[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1];
+    else                            for (int i = 0; i < N; i++) sum[i] += z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1];
+    p->fft1_sumsq_counter++;
+    if (p->fft1_sumsq_counter >= c->cfg.fft_avg1num) {
+      p->fft1_sumsq_counter = 0;
+      update_fft1_slowsum(c, p);
+      p->fft1_liminfo_cnt++;
+      p->fft1_sumsq_pa = (p->fft1_sumsq_pa + N) & c->fft1_sumsq_mask;
+    }
+    p->fft1_nb = (p->fft1_nb + 1) & c->fft1n_mask;
+    p->fft1_pb = p->fft1_nb * 2 * N;
+  }
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ timf2 */
+
+/* make_timf2 (timf2.c:31-75,127-128,205-207) + fft1back_one (timf2.c:689-967: DFT with e^{-j} kernel on the
+   weak and the strong stream at once) + fft1back_fp_finish (timf2.c:970-1064) */
+int lro_make_timf2(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  int N = c->N1, n = c->cfg.fft1_n;
+  float ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
+  for (int b = 0; b < batch; b++) {
+    const float *x = c->fft1_float + p->fft1_px;
+    float *s = c->tmp;                       /* {wRe,wIm,sRe,sIm} per bin */
+    int lowlevel = 0;
+    for (int i = 0; i < N; i++) {
+      if (c->liminfo[i] == 0) { lowlevel++; s[4 * i] = x[2 * i]; s[4 * i + 1] = x[2 * i + 1]; s[4 * i + 2] = 0; s[4 * i + 3] = 0; }
+      else { s[4 * i] = 0; s[4 * i + 1] = 0; s[4 * i + 2] = x[2 * i]; s[4 * i + 3] = x[2 * i + 1]; }
+    }
+    dif_stages(N, n, s, c->fft1tab, -1, 4); dif_stages(N, n, s + 2, c->fft1tab, -1, 4);
+    bitrev_inplace(N, n, s, 4); bitrev_inplace(N, n, s + 2, 4);
+    int p0 = p->timf2_pa, pp = p0 / 4, m = c->timf2_mask;
+    float *tf = c->timf2_float, *pw = c->timf2_pwr;
+    if (c->I1 == 0) {                         /* timf2.c:986-1000 */
+      for (int i = 0; i < N; i++) {
+        int q = (p0 + 4 * i) & m;
+        for (int k = 0; k < 4; k++) tf[q + k] = ampfac * s[4 * i + k];
+        pw[q / 4] = tf[q] * tf[q] + tf[q + 1] * tf[q + 1];
+      }
+    } else if (c->I1 == N / 2) {              /* sin^2: overlap-add, timf2.c:1003-1026 */
+      int k = N / 2;
+      for (int i = 0; i < k; i++) {
+        for (int j = 0; j < 4; j++) tf[p0 + j] += ampfac * s[4 * i + j];
+        pw[pp] = tf[p0] * tf[p0] + tf[p0 + 1] * tf[p0 + 1];
+        pp++; p0 += 4;
+      }
+      p0 &= m;
+      for (int i = 4 * k; i < 4 * N; i++) { tf[p0] = s[i] * ampfac; p0++; }
+    } else {                                  /* other windows: centre part x inverted window, timf2.c:1031-1061 */
+      int ia = c->I1 / 2, ib = N / 2, kk = ia * 4;
+      for (int i = ia; i < ib; i++) {
+        float t1 = c->fft1_inverted_window[i] * ampfac;
+        for (int j = 0; j < 4; j++) tf[p0 + j] = t1 * s[kk + j];
+        pw[p0 >> 2] = tf[p0] * tf[p0] + tf[p0 + 1] * tf[p0 + 1];
+        p0 = (p0 + 4) & m; kk += 4;
+      }
+      for (int i = ib; i > ia; i--) {
+        float t1 = c->fft1_inverted_window[i] * ampfac;
+        for (int j = 0; j < 4; j++) tf[p0 + j] = t1 * s[kk + j];
+        pw[p0 >> 2] = tf[p0] * tf[p0] + tf[p0 + 1] * tf[p0 + 1];
+        p0 = (p0 + 4) & m; kk += 4;
+      }
+    }
+    p->fft1_px = (p->fft1_px + 2 * N) & c->fft1_mask;
+    p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
+    p->fft1_lowlevel_points = lowlevel;
+    p->fft1_lowlevel_fraction = 0.02 * (49 * p->fft1_lowlevel_fraction + lowlevel / ((float)(N - 1)));
+    p->timf2_pa = (p->timf2_pa + 4 * c->M1) & m;
+  }
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ blanker */
+
+/* first_noise_blanker, blank1.c:684-715 (range, rate limit), 1003-1087 (stupid blanker, 1 channel float),
+   1458-1603 (pointers, every-4th-sample noise statistics, threshold update). Clever blanker needs a pulse
+   calibration and is forced off without one (hires_graph.c:1196). */
+int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
+{
+  const int mm = 4, mask = c->timf2pow_mask;
+  lrh_blanker_state *s = &c->bs;
+  float *pw = c->timf2_pwr, *tf = c->timf2_float;
+  int pbeg = p->timf2p_fit;
+  int pend = (p->timf2_pa / mm - c->cfg.blnfit_range + mask) & mask;
+  pend &= 0xfffffffc;
+  int total = (pend - pbeg + 1 + mask) & mask;
+  if (total < c->cfg.blanker_min_points) return LRH_OK;
+  int cleared = 0;
+  if (c->cfg.stupid_bln_mode != 0) {
+    unsigned int nfl = s->stupid_bln_limit;
+    int p0 = pbeg, ifirst = 0, pk = p0;
+    int clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1, clr2 = c->cfg.blanker_pulsewidth + 1;
+    float pulmax = 0, totnoise = (float)s->timf2_noise_floor;
+    while (p0 != pend) {
+      p0 = (p0 + 1) & mask;
+      if (pw[p0] > nfl) {
+        if (ifirst == 0) pk = p0;
+        if (pw[p0] > pulmax) pulmax = pw[p0];
+        ifirst++;
+        cleared++;
+        pw[p0] = 0; tf[4 * p0] = 0; tf[4 * p0 + 1] = 0;
+      } else if (ifirst != 0) {
+        ifirst = 0;
+        float t1 = pulmax / totnoise;
+        pulmax = 0;
+        if (t1 > 4) {
+          if (t1 > 10000) t1 = 10000;          /* 40 dB cap */
+          t1 = sqrt(t1) / 100;
+          int pa = pk, i = clr1 * t1 + 0.5;
+          for (int j = 0; j < i; j++) { pa = (pa + mask) & mask; pw[pa] = 0; tf[4 * pa] = 0; tf[4 * pa + 1] = 0; cleared++; }
+          pa = p0; i = clr2 * t1 + 0.5;
+          for (int j = 0; j < i; j++) { pw[pa] = 0; tf[4 * pa] = 0; tf[4 * pa + 1] = 0; pa = (pa + 1) & mask; cleared++; }
+        }
+      }
+    }
+  }
+  s->last_call_cleared = cleared;
+  p->timf2p_fit = pend;                       /* blank1.c:1464 */
+  p->timf2_pn2 = mm * pend;
+  int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
+  s->timf2_cleared_points += cleared;
+  p->timf2_blanker_points += m;
+  if (p->timf2_blanker_points == 0) return LRH_OK;
+  int k = m - cleared; if (k < m / 25) k = m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
+  float t1 = 0;
+  for (int p0 = pbeg; p0 != p->timf2p_fit;) { p0 = (p0 + 4) & mask; t1 += pw[p0]; }
+  t1 /= k; if (t1 < 10) t1 = 10;
+  s->timf2_despiked_pwrinc[0] += t1;
+  p->blanker_info_update_counter++;
+  if (p->blanker_info_update_counter >= c->cfg.blanker_info_update_interval) {
+    if (p->fft1_lowlevel_fraction < 0.1) { p->blanker_info_update_counter--; return LRH_OK; }
+    int iv = c->cfg.blanker_info_update_interval;
+    s->timf2_despiked_pwr[0] = s->timf2_despiked_pwrinc[0] / (iv * p->fft1_lowlevel_fraction);
+    s->timf2_despiked_pwr[1] = s->timf2_despiked_pwrinc[1] / (iv * p->fft1_lowlevel_fraction);
+    s->stupid_blanker_rate = 100. * (float)s->timf2_cleared_points / p->timf2_blanker_points;
+    if (s->stupid_blanker_rate > 99) s->stupid_blanker_rate = 99;
+    s->timf2_noise_floor = (s->timf2_despiked_pwr[0] + s->timf2_despiked_pwr[1]) / 1;
+    if (c->cfg.stupid_bln_mode == 1) {
+      if (s->stupid_blanker_rate > 20) {
+        if (s->timf2_noise_floor < 30) s->timf2_noise_floor = 30;
+        t1 = 0.01 * pow(s->stupid_blanker_rate - 20.0, 2.);
+        if (t1 > 10) t1 = 10;
+        s->timf2_noise_floor *= 1 + t1;
+      } else {
+        int an = c->cfg.timf2_noise_floor_avgnum;
+        s->timf2_noise_floor = ((an - 1) * s->timf2_noise_floor + t1) / an;
+      }
+      s->stupid_bln_limit = s->timf2_noise_floor * c->cfg.stupid_bln_factor;
+    }
+    p->blanker_info_update_counter = 0;
+    s->timf2_despiked_pwrinc[0] = 1; s->timf2_despiked_pwrinc[1] = 1;
+    s->timf2_cleared_points = 0; p->timf2_blanker_points = 0;
+  }
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ fft2 */
+
+/* waterfall geometry shared by harness, oracle and product (see DESIGN.md "waterfall line") */
+static void wf_geometry(const lro_ctx *c, int *hg_xpp, int *hg_ppx, int *wg_xpp, int *wg_ppx, int *wg_first)
+{
+  int r = c->N2 / c->N1; if (r < 1) r = 1;
+  int mode = c->cfg.wf_mode;
+  if (mode == 1) { *hg_xpp = 1; *hg_ppx = 1; } else if (mode > 1) { *hg_xpp = mode; *hg_ppx = 0; } else { *hg_xpp = 0; *hg_ppx = -mode; }
+  if (*hg_xpp > 0 && *hg_xpp >= r) { *wg_xpp = *hg_xpp / r; *wg_ppx = 0; }
+  else { *wg_xpp = 0; *wg_ppx = *hg_ppx > 0 ? *hg_ppx * r : r / (*hg_xpp > 0 ? *hg_xpp : 1); if (*wg_ppx < 1) *wg_ppx = 1; }
+  *wg_first = c->cfg.wf_first_xpoint / r;
+}
+
+/* FFT2_WATERFALL_LINE, fft2.c:707-815: short y = 1000*log10(powersum*yfac), clamp +-32767 */
+static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p)
+{
+  int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
+  int npix = c->cfg.wf_xpixels, siz = c->N2;
+  int16_t *line = c->wg_waterf + p->wg_waterf_ptr;
+  const float *ps = c->fft2_powersum, *yf = c->wg_waterf_yfac;
+  float a2 = 1, a3; int y, itab, i;
+  if (wx > 0) a2 = wx; else a2 = 1. / wp;
+  a3 = wfirst + 0.5 * a2;
+  if (hx == 1 || hp == 1) {
+    i = c->cfg.wf_first_xpoint;
+    for (int ix = 0; ix < npix; ix++) {
+      itab = a3; a3 += a2;
+      y = 1000. * log10(ps[i] * yf[itab]);
+      if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+      line[ix] = y; i++;
+    }
+  } else if (hx == 0) {                       /* interpolate, fft2.c:739-783 */
+    float yval, r1, der;
+    i = c->cfg.wf_first_xpoint; itab = a3; a3 += a2;
+    y = 1000. * log10(ps[i] * yf[itab]); yval = y;
+    if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+    line[0] = y; i++;
+    int mlim = npix - hp, ix, k;
+    for (ix = 0; ix < mlim; ix += hp) {
+      itab = a3; a3 += a2;
+      r1 = 1000. * log10(ps[i] * yf[itab]); der = (r1 - yval) / hp;
+      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; if (y < -32767) y = -32767; if (y > 32767) y = 32767; line[k] = y; }
+      yval = r1; i++;
+    }
+    if (i < siz) {
+      itab = a3;
+      r1 = 1000. * log10(ps[i] * yf[itab]); der = (r1 - yval) / hp;
+      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; if (y < -32767) y = -32767; if (y > 32767) y = 32767; if (k < npix) line[k] = y; }
+    }
+  } else {                                    /* max over a group, fft2.c:784-811 */
+    int ia = c->cfg.wf_first_xpoint, ib = ia + hx;
+    for (int ix = 0; ix < npix; ix++) {
+      float r2 = 0;
+      for (i = ia; i < ib; i++) { float r1 = ps[i]; if (r1 > r2) r2 = r1; }
+      itab = a3; a3 += a2;
+      float a1 = yf[itab];
+      y = 1000. * log10(a1 * r2);
+      if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+      line[ix] = y;
+      ia = ib; ib += hx; if (ib >= siz) ib = siz;
+    }
+  }
+  /* update_wg_waterf, fft1.c:104-113 */
+  p->wg_waterf_ptr -= npix; if (p->wg_waterf_ptr < 0) p->wg_waterf_ptr += c->cfg.wf_lines * npix;
+  p->wg_waterf_sum_counter = 0;
+  p->fft2_liminfo_cnt++;
+}
+
+/* make_fft2 mode 15 until FFT2_COMPLETE: fft2.c:86-141 (load, window, big_fftforward), 647-705 (power),
+   707-815 (waterfall), 1831-1845 (pointers) */
+int lro_make_fft2(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  int N = c->N2, n = c->cfg.fft2_n, mask = c->timf2_mask;
+  for (int b = 0; b < batch; b++) {
+    float *z = c->fft2_float + (size_t)2 * p->fft2_na * N;
+    int p0 = p->timf2_px;
+    const float *tf = c->timf2_float;
+    if (c->cfg.fft2_sinpow != 0)
+      for (int i = 0; i < N; i++) { z[2 * i] = c->fft2_window[i] * (tf[p0] + tf[p0 + 2]); z[2 * i + 1] = c->fft2_window[i] * (tf[p0 + 1] + tf[p0 + 3]); p0 = (p0 + 4) & mask; }
+    else
+      for (int i = 0; i < N; i++) { z[2 * i] = tf[p0] + tf[p0 + 2]; z[2 * i + 1] = tf[p0 + 1] + tf[p0 + 3]; p0 = (p0 + 4) & mask; }
+    dif_stages(N, n, z, c->fft2tab, +1, 2); bitrev_inplace(N, n, z, 2);
+    float *pwra = c->fft2_power + (size_t)p->fft2_na * N;
+    if (p->wg_waterf_sum_counter == 0) for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] = pwra[i]; }
+    else                               for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] += pwra[i]; }
+    p->wg_waterf_sum_counter++;
+    if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) fft2_waterfall_line(c, p);
+    p->timf2_px = (p->timf2_px + 4 * c->M2) & mask;
+    p->fft2_na = (p->fft2_na + 1) & c->fft2n_mask;
+    p->fft2_pa = 2 * p->fft2_na * N;
+    p->fft2_nb = (p->fft2_nb + 1) & c->fft2n_mask;
+    if (p->fft2_nm != c->fft2n_mask) p->fft2_nm++;
+  }
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ mix1 */
+
+int lro_set_mix1_selfreq(lro_ctx *c, double fq) { c->ms.mix1_selfreq = fq; return LRH_OK; }
+int lro_get_mix1_state(lro_ctx *c, lrh_mix1_state *st) { *st = c->ms; return LRH_OK; }
+
+/* set_mix1_phases, mix1.c:781-861 (float branch) */
+static int set_mix1_phases(lro_ctx *c, float fq)
+{
+  lrh_mix1_state *s = &c->ms;
+  if (fq < c->cfg.mix1_lowest_fq || fq > c->cfg.mix1_highest_fq) return LRH_ERANGE;
+  int size = c->Nm;
+  float t1 = fq * c->cfg.fftx_points_per_hz, t2;
+  int pnt = t1 + 0.5;
+  int k = pnt % size;
+  t2 = size * (pnt / size);
+  t2 = t1 - t2 - k;
+  t2 = t2 - (int)(t2);
+  s->mix1_phase_rot = t2 * 2 * PI_L / size;
+  k = (k * c->Mm) % size;
+  s->mix1_old_phase = s->mix1_phase;
+  s->mix1_phase += s->mix1_phase_step;
+  s->mix1_phase_step = k * 2 * PI_L / size;
+  s->mix1_old_point = (s->mix1_point != -1) ? s->mix1_point : pnt;
+  s->mix1_point = pnt;
+  if (s->mix1_phase > PI_L) s->mix1_phase -= 2 * PI_L;
+  if (s->mix1_phase < PI_L) s->mix1_phase += 2 * PI_L;    /* reference quirk: keeps phase in [pi,3pi) */
+  return LRH_OK;
+}
+
+/* fft2_mix1_fixed (mix1.c:934-993) + do_mix1 (mix1.c:55-195; dfq forced to 0 at mix1.c:103) */
+int lro_fft2_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  int Nm = c->Nm, n = Nm, n2 = 2 * Nm, N2 = c->N2;
+  int ratio = N2 / c->N1; if (ratio < 1) ratio = 1;
+  int nn = 2 * ratio;
+  int block = 2 * c->Mm;
+  lrh_mix1_state *s = &c->ms;
+  for (int b = 0; b < batch; b++) {
+    float *tmp = c->tmp, *t3 = c->timf3_float;
+    if (s->mix1_selfreq >= 0) {
+      int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
+      int k = s->mix1_point * 2;
+      int lim = nn * (c->N1 - 1); if (lim > 2 * N2) lim = 2 * N2;   /* clamp only bites when N2 < N1 */
+      int ib = n; if (ib > lim - k) ib = lim - k; if (ib < 0) ib = 0;
+      const float *z = c->fft2_float + k + (size_t)2 * p->fft2_nx * N2;
+      for (int i = 0; i < ib; i++) tmp[i] = z[i];
+      for (int i = ib; i < n; i++) tmp[i] = 0;
+      k -= n2; ib = n; if (ib < -k) ib = -k; if (ib > n2) ib = n2;
+      for (int i = n; i < ib; i++) tmp[i] = 0;
+      z = c->fft2_float + k + (size_t)2 * p->fft2_nx * N2;
+      for (int i = ib; i < n2; i++) tmp[i] = z[i];
+      /* frequency-domain window, mix1.c:113-135 */
+      int i = 0, j = Nm - 1, w = Nm / 2 - 1;
+      float t1 = c->mix1_fqwin[w]; tmp[0] *= t1; tmp[1] *= t1; i++;
+      while (j > i) { t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1; tmp[2 * j] *= t1; tmp[2 * j + 1] *= t1; j--; w--; i++; }
+      t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1;
+      /* fftback, fft0.c:481-533 */
+      dif_stages(Nm, c->mix1_n, tmp, c->mix1tab, -1, 2); bitrev_inplace(Nm, c->mix1_n, tmp, 2);
+      int pa = p->timf3_pa;
+      float t2 = s->mix1_phase_rot; t1 = s->mix1_phase;
+      if (c->Im == 0) {                        /* mix1.c:141-155 */
+        for (i = 0; i < 2 * Nm; i += 2) {
+          float sn = sin(t1), cs = cos(t1);
+          t3[pa + i] = cs * tmp[i] - sn * tmp[i + 1]; t3[pa + i + 1] = cs * tmp[i + 1] + sn * tmp[i];
+          t1 += t2;
+        }
+        s->mix1_phase = t1;
+      } else {                                 /* sin^2, 50 % overlap: mix1.c:161-195 */
+        float r1 = s->mix1_old_phase;
+        float r2 = t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm;
+        for (i = 0; i < Nm; i += 2) {
+          float sn = sin(t1), cs = cos(t1), rs = sin(r1), rc2 = cos(r1);
+          float a1 = t3[pa + i], a2 = t3[pa + i + 1];
+          t3[pa + i] = rc2 * a1 - rs * a2 + cs * tmp[i] - sn * tmp[i + 1];
+          t3[pa + i + 1] = rc2 * a2 + rs * a1 + cs * tmp[i + 1] + sn * tmp[i];
+          r1 += r2; t1 += t2;
+        }
+        s->mix1_phase = t1;
+        pa = ((p->timf3_pa + block) & c->timf3_mask) - block;
+        for (i = Nm; i < 2 * Nm; i++) t3[pa + i] = tmp[i];
+      }
+    } else {                                   /* mix1_clear, mix1.c:766-779 */
+      for (int i = 0; i < block; i++) t3[p->timf3_pa + i] = 0;
+    }
+    p->timf3_pa = (p->timf3_pa + block) & c->timf3_mask;
+    p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
+  }
+  return LRH_OK;
+}
+
+/* ------------------------------------------------------------------ orchestration */
+
+/* single-CPU branch of wideband_dsp, wcw.c:1036-1118, batched */
+int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
+{
+  int rc;
+  while (nblocks > 0) {
+    int B = nblocks < batch ? nblocks : batch;
+    if ((rc = lro_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4) & c->timf1_bytemask;
+    p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
+    p->fft1_na = p->fft1_pa / (2 * c->N1);
+    for (int i = 0; i < B; i++) if (p->fft1_nm != c->fft1n_mask) p->fft1_nm++;
+    if ((rc = lro_fft1_c(c, p, B))) return rc;
+    if ((rc = lro_make_timf2(c, p, B))) return rc;
+    if ((rc = lro_first_noise_blanker(c, p))) return rc;
+    int avail = ((p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask);
+    int k = 0;
+    if (avail >= 4 * c->N2) k = 1 + (avail - 4 * c->N2) / (4 * c->M2);
+    while (k > 0) {
+      int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+      if ((rc = lro_make_fft2(c, p, kb))) return rc;
+      if ((rc = lro_fft2_mix1_fixed(c, p, kb))) return rc;
+      k -= kb;
+    }
+    nblocks -= B;
+  }
+  return LRH_OK;
+}
+
+int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
+{
+  const void *src; size_t esz = 4, total;
+  switch (ring) {
+    case LRH_RING_TIMF1: src = c->timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;
+    case LRH_RING_FFT1_FLOAT: src = c->fft1_float; total = (size_t)c->cfg.max_fft1n * 2 * c->N1; break;
+    case LRH_RING_FFT1_SUMSQ: src = c->fft1_sumsq; total = c->cfg.fft1_sumsq_bufsize; break;
+    case LRH_RING_FFT1_SLOWSUM: src = c->fft1_slowsum; total = c->N1; break;
+    case LRH_RING_TIMF2_FLOAT: src = c->timf2_float; total = 4 * (size_t)c->cfg.timf2pow_size; break;
+    case LRH_RING_TIMF2_PWR: src = c->timf2_pwr; total = c->cfg.timf2pow_size; break;
+    case LRH_RING_FFT2_FLOAT: src = c->fft2_float; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
+    case LRH_RING_FFT2_POWER: src = c->fft2_power; total = (size_t)c->cfg.max_fft2n * c->N2; break;
+    case LRH_RING_FFT2_POWERSUM: src = c->fft2_powersum; total = c->N2; break;
+    case LRH_RING_WG_WATERF: src = c->wg_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
+    case LRH_RING_TIMF3_FLOAT: src = c->timf3_float; total = c->cfg.timf3_size; break;
+    default: return LRH_EINVAL;
+  }
+  if (off + cnt > total) return LRH_EINVAL;
+  memcpy(dst, (const char *)src + off * esz, cnt * esz);
+  return LRH_OK;
+}
+
+int lro_get_blanker_state(lro_ctx *c, lrh_blanker_state *st) { *st = c->bs; return LRH_OK; }

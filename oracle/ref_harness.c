@@ -1,0 +1,396 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+ *
+ * Head-less driver for the *compiled reference* (fventuri/linrad C sources under
+ * /root/reference, compiled where they lie by oracle/Makefile into oracle/_ref/).
+ * It owns the rings and the ~80 globals the reference hot path reads, feeds
+ * recorded/synthetic int16 IQ through the reference's own functions in the
+ * order the single-CPU branch of wideband_dsp uses (wcw.c:1036-1118):
+ *
+ *   fft1_b -> fft1_c -> make_timf2 -> first_noise_blanker -> make_fft2* -> fft2_mix1_fixed
+ *
+ * and dumps every stage ring + scalar state into one container file that
+ * tests/golden/make_golden.py turns into the committed fixtures.
+ *
+ * Nothing here is reference source: the reference is linked, not copied.
+ * Stubs below stand in for GUI/thread entry points of the same program
+ * (lirerr, lir_sched_yield, awake_screen, ...), as SURVEY.md Appendix C found.
+ *
+ * usage: ref_harness key=value ... (see parse section); writes out=<file>.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "globdef.h"
+#include "uidef.h"
+#include "fft1def.h"
+#include "fft2def.h"
+#include "fft3def.h"
+#include "screendef.h"
+#include "sigdef.h"
+#include "seldef.h"
+#include "blnkdef.h"
+#include "thrdef.h"
+#include "graphcal.h"
+
+/* ---- stand-ins for GUI / OS entry points of the reference program ---- */
+int harness_err = 0;
+void lirerr(int e) { fprintf(stderr, "lirerr(%d)\n", e); harness_err = e; }
+void lir_sched_yield(void) {}
+void awake_screen(void) {}
+void lir_pixwrite(int x, int y, char *s) { (void)x; (void)y; (void)s; }
+void lir_text(int x, int y, char *s) { (void)x; (void)y; (void)s; }
+void settextcolor(unsigned char c) { (void)c; }
+void lir_mutex_lock(int n) { (void)n; }
+void lir_mutex_unlock(int n) { (void)n; }
+void lir_sleep(int us) { (void)us; }
+
+/* prototypes of reference functions not in the headers we include */
+void fft1_b(int timf1p_ref, float *out, float *tmp, int gpu_handle_number);
+void fft1_c(void);
+void make_timf2(void);
+void first_noise_blanker(void);
+void make_fft2(void);
+void fft2_mix1_fixed(void);
+void clear_fft1_filtercorr(void);
+void make_permute(int mo, int nz, int sz, unsigned short int *perm);
+void make_bigpermute(int mo, int nz, int sz, unsigned int *perm);
+void make_sincos(int mo, int sz, COSIN_TABLE *tab);
+void init_fft(int mo, int nz, int sz, COSIN_TABLE *tab, unsigned short int *perm);
+void set_fft1_endpoints(void);
+
+/* ---- container writer ---- */
+static FILE *fo;
+static void put(const char *name, const char *dtype, const void *p, size_t count, size_t esz)
+{
+  char nm[32]; char dt[4];
+  memset(nm, 0, 32); strncpy(nm, name, 31);
+  memset(dt, 0, 4); strncpy(dt, dtype, 3);
+  uint64_t c = count;
+  fwrite(nm, 1, 32, fo); fwrite(dt, 1, 4, fo); fwrite(&c, 8, 1, fo);
+  fwrite(p, esz, count, fo);
+}
+#define PUTF(n, p, c) put(n, "f4", p, c, 4)
+#define PUTI(n, p, c) put(n, "i4", p, c, 4)
+
+static void *zalloc(size_t n) { void *p = calloc(n + 64, 1); if (!p) { fprintf(stderr, "oom\n"); exit(2);} return p; }
+
+static const char *arg(int argc, char **argv, const char *k, const char *def)
+{
+  size_t l = strlen(k);
+  for (int i = 1; i < argc; i++) if (!strncmp(argv[i], k, l) && argv[i][l] == '=') return argv[i] + l + 1;
+  return def;
+}
+#define AI(k, d) atoi(arg(argc, argv, k, #d))
+#define AF(k, d) atof(arg(argc, argv, k, #d))
+
+/* per-block scalar trace */
+#define TR_COLS 16
+int main(int argc, char **argv)
+{
+  int n1 = AI("n1", 10), sinpow1 = AI("sinpow1", 2);
+  int n2 = AI("n2", 12), sinpow2 = AI("sinpow2", 2);
+  int mixred = AI("mixred", 6);
+  int att_n = AI("att_n", 6), gain = AI("gain", 27);
+  int avg1 = AI("avg1num", 5), avg2 = AI("avg2num", 4);
+  int nblk = AI("nblk", 32);
+  int ring_log2 = AI("timf1_log2", 0);          /* 0: auto */
+  int timf2pow_log2 = AI("timf2pow_log2", 0);   /* 0: auto = 8*N2 */
+  int maxfft1n = AI("max_fft1n", 8), maxfft2n = AI("max_fft2n", 4);
+  int sumsq_blocks = AI("sumsq_blocks", 8);
+  int stupid = AI("stupid", 1);
+  int bln_interval = AI("bln_interval", 4), bln_avgnum = AI("bln_avgnum", 32);
+  int bln_minpts = AI("bln_minpts", -1);
+  int pulsewidth = AI("pulsewidth", 0), fitrange = AI("blnfit_range", 48);
+  int noise_floor0 = AI("noise_floor", 200);
+  double fq = AF("fq", -1.0);                    /* selected frequency in fft2 bins; <0: none */
+  int wf_avg = AI("wf_avgnum", 2);               /* fft2 spectra per waterfall line */
+  int wf_first = AI("wf_first", 0), wf_pix = AI("wf_pixels", 0);
+  int wf_mode = AI("wf_mode", 1);                /* 1: 1:1, k>1: k points/pixel (max), k<0: -k pixels/point (interp) */
+  int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
+  const char *fin = arg(argc, argv, "in", NULL);
+  const char *flim = arg(argc, argv, "liminfo", NULL);
+  const char *fout = arg(argc, argv, "out", "ref_dump.bin");
+  int N1 = 1 << n1, N2 = 1 << n2;
+  if (!fin) { fprintf(stderr, "need in=<int16 iq file>\n"); return 2; }
+  fo = fopen(fout, "wb"); if (!fo) { perror(fout); return 2; }
+
+  /* ---- ui / genparm ---- */
+  memset(&ui, 0, sizeof(ui));
+  ui.rx_input_mode = IQ_DATA; ui.rx_rf_channels = 1; ui.rx_ad_channels = 2;
+  ui.sample_shift = 0; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
+  genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
+  genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
+  genparm[SECOND_FFT_ENABLE] = 1; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
+  genparm[SECOND_FFT_SINPOW] = sinpow2; genparm[SECOND_FFT_VERNR] = 0; /* -> fft_cntrl[15] */
+  genparm[SECOND_FFT_ATT_N] = 8; genparm[MAX_NO_OF_SPURS] = 0; genparm[AFC_ENABLE] = 0; genparm[AFC_LOCK_RANGE] = 0;
+  genparm[MIX1_BANDWIDTH_REDUCTION_N] = mixred; genparm[MIX1_NO_OF_CHANNELS] = 1;
+  fft1mode = (ui.rx_input_mode & (TWO_CHANNELS + IQ_DATA)) / 2;
+  rx_channels = 1; twice_rxchan = 2; sw_onechan = 1; swfloat = 1; swmmx_fft2 = 0; swmmx_fft1 = 0;
+  kill_all_flag = 0; lir_status = 0; fft1_correlation_flag = 0; fft1afc_flag = 0; no_of_spurs = 0;
+  ampinfo_flag = 0; audio_dump_flag = 0; fft1_use_gpu = 0; fft1_calibrate_flag = 0; fft1_direction = 1;
+  yieldflag_wdsp_fft1 = 0; yieldflag_timf2_fft1 = 0; yieldflag_fft2_fft2 = 0; yieldflag_ndsp_mix1 = 0;
+
+  /* ---- fft1 sizes and tables (buf.c:193-304, 1395-1459) ---- */
+  fft1_n = n1; fft1_size = N1; fft1_block = 2 * N1; fft1_muln = 1; fft1_mulblock = fft1_block;
+  {
+    /* interleave: reference formula buf.c:303-304 with make_interleave_ratio (buf.c:113-136) */
+    double ratio = 0;
+    if (sinpow1 != 0) ratio = (sinpow1 == 9) ? 0.625 : (sinpow1 == 8) ? 0.8 : 2 * asin(pow(0.5, 1.0 / sinpow1)) / PI_L;
+    fft1_interleave_ratio = (float)ratio;
+    fft1_interleave_points = 1 + fft1_interleave_ratio * fft1_size;
+    fft1_interleave_points &= 0xfffe;
+  }
+  fft1_new_points = N1 - fft1_interleave_points;
+  max_fft1n = maxfft1n; fft1n_mask = max_fft1n - 1; fft1_mask = max_fft1n * fft1_block - 1;
+  fft1_float = zalloc(sizeof(float) * max_fft1n * fft1_block);
+  fft1tab = zalloc(sizeof(COSIN_TABLE) * N1);
+  fft1_permute = zalloc(sizeof(short) * N1 * 2);
+  fft1_window = zalloc(sizeof(float) * (N1 + 32));
+  fft1_filtercorr = (float *)zalloc(sizeof(float) * (2 * N1 + 32)) + 8;
+  fft1_desired = zalloc(sizeof(float) * N1);
+  fftw_tmp = zalloc(sizeof(float) * (4 * N1 + 64));
+  make_sincos(1, N1, fft1tab);
+  make_permute(1, n1, N1, fft1_permute);
+  make_window(1, N1, sinpow1, fft1_window);
+  clear_fft1_filtercorr();
+
+  /* timf1 input ring */
+  FILE *fi = fopen(fin, "rb"); if (!fi) { perror(fin); return 2; }
+  fseek(fi, 0, SEEK_END); long inbytes = ftell(fi); fseek(fi, 0, SEEK_SET);
+  timf1_bytes = 1; while (timf1_bytes < inbytes) timf1_bytes <<= 1;
+  if (ring_log2) timf1_bytes = 1 << ring_log2;
+  timf1_bytemask = timf1_bytes - 1;
+  timf1_char = zalloc(timf1_bytes); timf1_short_int = (short *)timf1_char; timf1_int = (int *)timf1_char;
+  {
+    /* file longer than the ring simply wraps, as a producer would */
+    char *tmpb = malloc(inbytes); if (fread(tmpb, 1, inbytes, fi) != (size_t)inbytes) return 2;
+    for (long i = 0; i < inbytes; i++) timf1_char[i & timf1_bytemask] = tmpb[i];
+    free(tmpb);
+  }
+  fclose(fi);
+  timf1_blockbytes = fft1_new_points * 4;
+  timf1p_px = 0;
+
+  /* spectrum averaging (fft1_c, update_fft1_slowsum) */
+  wg.fft_avg1num = avg1; wg_fft_avg2num = avg2; wg.first_xpoint = 0; wg.xpoints = N1 - 1;
+  wg.waterfall_avgnum = wf_avg; wg.spek_avgnum = avg1 * avg2;
+  fft1_sumsq_bufsize = sumsq_blocks * N1; fft1_sumsq_mask = fft1_sumsq_bufsize - 1;
+  fft1_sumsq = zalloc(sizeof(float) * fft1_sumsq_bufsize);
+  fft1_slowsum = zalloc(sizeof(float) * N1);
+  fft1_sumsq_pa = 0; fft1_sumsq_counter = 0; change_fft1_flag = 0; latest_wg_spectrum = 0;
+  set_fft1_endpoints();            /* fft1_first_point=0, last=N1-1, recalc pointer, sym points */
+  fft1_pa = fft1_pb = fft1_px = 0; fft1_na = fft1_nb = fft1_nx = 0; fft1_nm = 0; fft1_liminfo_cnt = 0;
+  ag_pa = 0; ag_mask = 1023;
+
+  /* ---- timf2 / back transform (buf.c:371-430, 1297-1345) ---- */
+  fft2_n = n2; fft2_size = N2;
+  timf2pow_size = timf2pow_log2 ? (1 << timf2pow_log2) : 8 * (N2 > N1 ? N2 : N1);
+  timf2pow_mask = timf2pow_size - 1; timf2_size = 4 * timf2pow_size; timf2_mask = timf2_size - 1;
+  timf2_input_block = fft1_new_points * 4;
+  timf2_pa = timf2_px = timf2_pn1 = timf2_pn2 = timf2_pb = timf2_pc = timf2_pt = 0; timf2p_fit = 0;
+  timf2_float = zalloc(sizeof(float) * (timf2_size + 8 * N1));
+  timf2_pwr_float = zalloc(sizeof(float) * (timf2pow_size + 2 * N1));
+  timf2_tmp = zalloc(sizeof(float) * 8 * N1);
+  fft1_split_float = zalloc(sizeof(float) * 8 * N1);
+  fft1_back_scramble = zalloc(sizeof(short) * N1);
+  fft1_inverted_window = zalloc(sizeof(float) * (N1 + 32));
+  liminfo = zalloc(sizeof(float) * N1);
+  make_permute(0, n1, N1, fft1_back_scramble);
+  fft1_backtab = fft1tab;
+  if (sinpow1 != 2 && sinpow1 != 0) make_window(3, N1, sinpow1, fft1_inverted_window);
+  fft1_lowlevel_fraction = .75f;
+  float *limrecs = NULL; long nlimrec = 0;
+  if (flim) {
+    FILE *fl = fopen(flim, "rb"); if (!fl) { perror(flim); return 2; }
+    fseek(fl, 0, SEEK_END); long lb = ftell(fl); fseek(fl, 0, SEEK_SET);
+    nlimrec = lb / (4 * N1); limrecs = malloc(lb);
+    if (fread(limrecs, 1, lb, fl) != (size_t)lb) return 2;
+    fclose(fl);
+    memcpy(liminfo, limrecs, 4 * N1);
+  }
+
+  /* ---- blanker (buf.c:337-346, 418-431, 2083-2086; hires_graph.c:1157-1162) ---- */
+  memset(&hg, 0, sizeof(hg));
+  timf2_noise_floor_avgnum = bln_avgnum; blanker_info_update_interval = bln_interval; blanker_info_update_counter = 0;
+  timf2_noise_floor = noise_floor0; timf2_despiked_pwr[0] = timf2_noise_floor; timf2_despiked_pwrinc[0] = 1;
+  timf2_despiked_pwr[1] = 0; timf2_despiked_pwrinc[1] = 0;
+  timf2_fitted_pulses = 0; timf2_cleared_points = 0; timf2_blanker_points = 0;
+  clever_blanker_rate = 0; stupid_blanker_rate = 0;
+  hg.stupid_bln_mode = stupid; hg.clever_bln_mode = 0; hg.stupid_bln_factor = 5; hg.clever_bln_factor = 10;
+  hg.stupid_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.stupid_bln_factor);
+  hg.clever_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.clever_bln_factor);
+  hg.timf2_oscilloscope = 0;
+  blnfit_range = fitrange; blanker_pulsewidth = pulsewidth;
+  blanker_flag = zalloc(timf2pow_size + 64);
+  min_delay_time = (bln_minpts >= 0) ? (float)bln_minpts : (float)N2 / 3.0f;   /* x ui.rx_ad_speed(=1), buf.c:500-509 */
+  timf2_oscilloscope_counter = 0; timf2_oscilloscope_maxpoint = 0; timf2_oscilloscope_maxval_float = 0;
+  timf2_oscilloscope_powermax_float = 0; timf2_show_pointer = -1; timf2_oscilloscope_interval = 15;
+
+  /* ---- fft2 (mode 15) ---- */
+  fft2_float = zalloc(sizeof(float) * 2 * N2 * maxfft2n);
+  max_fft2n = maxfft2n; fft2n_mask = max_fft2n - 1;
+  fft2_tab = zalloc(sizeof(COSIN_TABLE) * N2);
+  fft2_bigpermute = zalloc(sizeof(int) * N2);
+  fft2_window = zalloc(sizeof(float) * (N2 + 32));
+  fft2_power_float = zalloc(sizeof(float) * N2 * maxfft2n);
+  fft2_powersum_float = zalloc(sizeof(float) * N2);
+  make_bigpermute(fft_cntrl[FFT2_CURMODE].permute, n2, N2, fft2_bigpermute);
+  make_sincos(1, N2, fft2_tab);
+  if (sinpow2 != 0) make_window(fft_cntrl[FFT2_CURMODE].window, N2, sinpow2, fft2_window);
+  fft2_pa = 0; fft2_na = fft2_nb = fft2_nx = fft2_nm = 0; fft2_liminfo_cnt = 0;
+  hg_redraw_counter = 0; hg.spek_avgnum = 1 << 30; fft2_blocktime = 0;
+  fft2_to_fft1_ratio = N2 / N1; if (fft2_to_fft1_ratio < 1) fft2_to_fft1_ratio = 1;
+
+  /* mix1 sizes first: fft2 interleave is re-derived from mix1 (buf.c:432-455) */
+  mix1.n = n2 - mixred; if (mix1.n < 3) mix1.n = 3; mix1.size = 1 << mix1.n;
+  {
+    double ratio = 0;
+    if (sinpow2 != 0) ratio = (sinpow2 == 9) ? 0.625 : (sinpow2 == 8) ? 0.8 : 2 * asin(pow(0.5, 1.0 / sinpow2)) / PI_L;
+    fft2_interleave_ratio = (float)ratio;
+    mix1.interleave_points = fft2_interleave_ratio * mix1.size;
+    mix1.interleave_points &= 0xfffffffe;
+    fft2_interleave_points = mix1.interleave_points * (fft2_size / mix1.size);
+    fft2_new_points = fft2_size - fft2_interleave_points;
+    mix1.new_points = mix1.size - mix1.interleave_points;
+  }
+  timf2_output_block = 4 * fft2_new_points;
+
+  /* waterfall line from fft2 (fft2.c:707-815) */
+  wg_xpixels = wf_pix ? wf_pix : (N2 < 1024 ? N2 : 1024);
+  hgwat_first_xpoint = wf_first;
+  if (wf_mode == 1) { hgwat_xpoints_per_pixel = 1; hgwat_pixels_per_xpoint = 1; }
+  else if (wf_mode > 1) { hgwat_xpoints_per_pixel = wf_mode; hgwat_pixels_per_xpoint = 0; }
+  else { hgwat_xpoints_per_pixel = 0; hgwat_pixels_per_xpoint = -wf_mode; }
+  /* a2 in fft2.c:713-722 is the step in fft1 bins per pixel */
+  if (hgwat_xpoints_per_pixel >= fft2_to_fft1_ratio && hgwat_xpoints_per_pixel > 0)
+    { wg.xpoints_per_pixel = hgwat_xpoints_per_pixel / fft2_to_fft1_ratio; wg.pixels_per_xpoint = 0; }
+  else
+    { wg.xpoints_per_pixel = 0;
+      wg.pixels_per_xpoint = hgwat_pixels_per_xpoint > 0 ? hgwat_pixels_per_xpoint * fft2_to_fft1_ratio
+                                                         : fft2_to_fft1_ratio / (hgwat_xpoints_per_pixel > 0 ? hgwat_xpoints_per_pixel : 1);
+      if (wg.pixels_per_xpoint < 1) wg.pixels_per_xpoint = 1; }
+  wg.first_xpoint = wf_first / fft2_to_fft1_ratio;
+  wg_waterf_size = 8 * wg_xpixels; wg_waterf = zalloc(2 * wg_waterf_size + 64); wg_waterf_ptr = 0;
+  wg_waterf_yfac = zalloc(sizeof(float) * (N1 + 8));
+  {
+    /* make_wg_yfac (wide_graph.c:955-1001), second-fft branch, uncalibrated fft1_desired */
+    float t1 = (float)(FFT2_WATERFALL_ZERO) / ((float)fft2_size * (float)fft1_size);
+    t1 /= (float)sqrt((float)(wg.waterfall_avgnum));
+    t1 *= (float)(1 << (2 * genparm[FIRST_BCKFFT_ATT_N]));
+    t1 *= (float)(1 + 1 / (0.5 + genparm[FIRST_FFT_SINPOW]));
+    for (int i = 0; i < N1; i++)
+      wg_waterf_yfac[i] = (fft1_desired[i] > 0.3162278) ? t1 / (float)pow(fft1_desired[i], 2.0) : t1 * 10;
+    wg_waterf_yfac[0] = t1; wg_waterf_yfac[N1 - 1] = t1;
+  }
+  wg_waterf_sum_counter = 0;
+
+  /* ---- mix1 (buf.c:55-111, 1297; mix1.c:781-861) ---- */
+  mix1.table = zalloc(sizeof(COSIN_TABLE) * mix1.size);
+  mix1.permute = zalloc(sizeof(short) * mix1.size * 2);
+  mix1.window = zalloc(sizeof(float) * (mix1.size + 32));
+  mix1.cos2win = zalloc(sizeof(float) * (mix1.size + 32));
+  mix1.sin2win = zalloc(sizeof(float) * (mix1.size + 32));
+  mix1_fqwin = zalloc(sizeof(float) * (mix1.size + 32));
+  make_window(5, mix1.size, 4, mix1_fqwin);
+  if (sinpow2 != 0 && sinpow2 != 2) make_window(3, mix1.size, sinpow2, mix1.window);
+  init_fft(0, mix1.n, mix1.size, mix1.table, mix1.permute);
+  mix1.crossover_points = 0;
+  fftn_tmp = zalloc(sizeof(float) * (4 * mix1.size + 64));
+  timf3_block = 2 * mix1.new_points;
+  timf3_size = 16 * 2 * mix1.size; timf3_mask = timf3_size - 1;
+  timf3_float = zalloc(sizeof(float) * (2 * timf3_size + 4 * mix1.size));
+  timf3_pa = timf3_px = timf3_py = 0;
+  fftx_points_per_hz = 1.0f; mix1_lowest_fq = 0; mix1_highest_fq = (float)N2;
+  mix1_selfreq[0] = fq; old_mix1_selfreq = fq; mix1_point[0] = -1;
+  mix1_phase[0] = 0; mix1_phase_step[0] = 0; mix1_phase_rot[0] = 0; mix1_old_phase[0] = 0; mix1_old_point[0] = 0;
+
+  /* ---- dump tables ---- */
+  {
+    int hdr[24] = { n1, N1, fft1_interleave_points, n2, N2, fft2_interleave_points, (int)mix1.n, (int)mix1.size,
+                    (int)mix1.interleave_points, att_n, gain, avg1, avg2, nblk, timf2pow_size, max_fft1n, max_fft2n,
+                    fft1_sumsq_bufsize, timf1_bytes, timf3_size, wg_xpixels, hgwat_first_xpoint, wf_mode, wf_avg };
+    PUTI("hdr", hdr, 24);
+    PUTF("fft1_window", fft1_window, N1);
+    put("fft1_permute", "u2", fft1_permute, N1, 2);
+    PUTF("fft1tab", fft1tab, N1);                     /* N1/2 {sin,cos} pairs */
+    PUTF("fft1_filtercorr", fft1_filtercorr, 2 * N1);
+    PUTF("fft1_desired", fft1_desired, N1);
+    put("fft1_back_scramble", "u2", fft1_back_scramble, N1, 2);
+    PUTF("fft1_inverted_window", fft1_inverted_window, N1 / 2 + 1);
+    PUTF("fft2_window", fft2_window, N2);
+    PUTF("mix1_fqwin", mix1_fqwin, mix1.size / 2 + 1);
+    PUTF("wg_waterf_yfac", wg_waterf_yfac, N1);
+  }
+
+  /* ---- run ---- */
+  float *trace = zalloc(sizeof(float) * TR_COLS * nblk);
+  int *itrace = zalloc(sizeof(int) * TR_COLS * nblk);
+  int nfft2 = 0; int nwf = 0;
+  size_t max_fft2_calls = (size_t)nblk * (size_t)(fft1_new_points / (fft2_new_points > 0 ? fft2_new_points : 1) + 2) + 64;
+  float *mixtrace = zalloc(sizeof(float) * 8 * max_fft2_calls);
+  short *wf_lines = zalloc(2 * (size_t)wg_xpixels * max_fft2_calls);
+  float *fft1_first = zalloc(sizeof(float) * 2 * N1);    /* fft1_b output of block 0 before fft1_c */
+  for (int b = 0; b < nblk && !harness_err; b++) {
+    if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
+      long r = b / lim_every; if (r >= nlimrec) r = nlimrec - 1;
+      memcpy(liminfo, limrecs + r * N1, 4 * N1);
+    }
+    fft1_b(timf1p_px, &fft1_float[fft1_pa], fftw_tmp, 0);
+    if (b == 0) memcpy(fft1_first, &fft1_float[fft1_pa], 8 * N1);
+    timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
+    fft1_pa = (fft1_pa + fft1_mulblock) & fft1_mask;
+    fft1_na = fft1_pa / fft1_block;
+    if (fft1_nm != fft1n_mask) fft1_nm++;
+    while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
+    int pbeg = timf2p_fit;
+    first_noise_blanker();
+    while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * fft2_size) {
+      int wptr = wg_waterf_ptr;
+      make_fft2_status = FFT2_NOT_ACTIVE;
+      while (make_fft2_status != FFT2_COMPLETE) make_fft2();
+      if (wg_waterf_ptr != wptr) { memcpy(wf_lines + (size_t)nwf * wg_xpixels, wg_waterf + wptr, 2 * wg_xpixels); nwf++; }
+      if (fq >= 0) {
+        fft2_mix1_fixed();
+        float *m = mixtrace + 8 * nfft2;
+        m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
+        m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft2_nx;
+      } else {
+        fft2_nx = (fft2_nx + 1) & fft2n_mask;
+      }
+      nfft2++;
+    }
+    float *t = trace + TR_COLS * b; int *it = itrace + TR_COLS * b;
+    t[0] = (float)timf2_noise_floor; t[1] = (float)hg.stupid_bln_limit; t[2] = stupid_blanker_rate;
+    t[3] = timf2_despiked_pwr[0]; t[4] = timf2_despiked_pwrinc[0]; t[5] = fft1_lowlevel_fraction;
+    it[0] = timf2_pa; it[1] = timf2p_fit; it[2] = timf2_pn2; it[3] = timf2_px; it[4] = pbeg;
+    it[5] = timf2_cleared_points; it[6] = timf2_blanker_points; it[7] = blanker_info_update_counter;
+    it[8] = fft2_na; it[9] = fft1_sumsq_pa; it[10] = fft1_sumsq_counter; it[11] = fft1_lowlevel_points;
+    it[12] = timf2_noise_floor; it[13] = (int)hg.stupid_bln_limit; it[14] = nfft2; it[15] = fft1_liminfo_cnt;
+  }
+
+  /* ---- dump results ---- */
+  PUTF("fft1_first_raw", fft1_first, 2 * N1);
+  PUTF("fft1_float", fft1_float, (size_t)max_fft1n * fft1_block);
+  PUTF("fft1_sumsq", fft1_sumsq, fft1_sumsq_bufsize);
+  PUTF("fft1_slowsum", fft1_slowsum, N1);
+  PUTF("timf2_float", timf2_float, timf2_size);
+  PUTF("timf2_pwr_float", timf2_pwr_float, timf2pow_size);
+  PUTF("fft2_float", fft2_float, (size_t)2 * N2 * max_fft2n);
+  PUTF("fft2_power_float", fft2_power_float, (size_t)N2 * max_fft2n);
+  PUTF("fft2_powersum_float", fft2_powersum_float, N2);
+  PUTF("timf3_float", timf3_float, timf3_size);
+  put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);
+  PUTF("trace", trace, (size_t)TR_COLS * nblk);
+  PUTI("itrace", itrace, (size_t)TR_COLS * nblk);
+  PUTF("mixtrace", mixtrace, (size_t)8 * (nfft2 > 0 ? nfft2 : 1));
+  {
+    int fin_[12] = { fft1_pa, fft1_nb, fft1_nx, timf2_pa, timf2p_fit, timf2_pn2, timf2_px, fft2_na, fft2_nx, timf3_pa, nfft2, nwf };
+    PUTI("final", fin_, 12);
+  }
+  fclose(fo);
+  return harness_err ? 3 : 0;
+}

@@ -1,0 +1,136 @@
+"""Shared parity machinery: run a refcases case through any StageAPI (oracle or HIP) and compare with a golden."""
+import os
+
+import numpy as np
+
+from linrad_amd import abi
+from refcases import case_params, lrh_config
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+RINGS = [(abi.RING_FFT1_FLOAT, "fft1_float"), (abi.RING_FFT1_SUMSQ, "fft1_sumsq"),
+         (abi.RING_FFT1_SLOWSUM, "fft1_slowsum"), (abi.RING_TIMF2_FLOAT, "timf2_float"),
+         (abi.RING_TIMF2_PWR, "timf2_pwr_float"), (abi.RING_FFT2_FLOAT, "fft2_float"),
+         (abi.RING_FFT2_POWER, "fft2_power_float"), (abi.RING_FFT2_POWERSUM, "fft2_powersum_float"),
+         (abi.RING_TIMF3_FLOAT, "timf3_float")]
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+
+
+def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
+    """Drive the case block by block in the reference call pattern (ref_harness.c main loop)."""
+    d = case_params(name)
+    g = golden if golden is not None else load_golden(name)
+    iq, lim = g["iq"], g["liminfo"]
+    if stupid is not None:
+        d["stupid"] = stupid
+    cfg = lrh_config(d, iq, **cfg_kw)
+    api = open_fn(cfg)
+    api.timf1_write(iq)
+    api.set_liminfo(lim)
+    api.set_mix1_selfreq(d["fq"])
+    itrace, wf_lines, mixtrace = [], [], []
+    nblk = d["nblk"]
+    b = 0
+    while b < nblk:
+        B = min(batch, nblk - b)
+        api.fft1_b(B)
+        api.fft1_c(B)
+        api.make_timf2(B)
+        api.first_noise_blanker()
+        k = api.fft2_available()
+        for _ in range(k):
+            wptr = api.p.wg_waterf_ptr
+            api.make_fft2(1)
+            if api.p.wg_waterf_ptr != wptr:
+                wf_lines.append(api.export(abi.RING_WG_WATERF, wptr, cfg.wf_xpixels))
+            api.fft2_mix1_fixed(1)
+            ms = api.mix1_state()
+            mixtrace.append([ms.mix1_point, ms.mix1_phase, ms.mix1_phase_rot, ms.mix1_phase_step,
+                             ms.mix1_old_phase, ms.mix1_old_point, api.p.timf3_pa, api.p.fft2_nx])
+        bs = api.blanker_state()
+        p = api.p
+        itrace.append([p.timf2_pa, p.timf2p_fit, p.timf2_pn2, p.timf2_px, bs.timf2_noise_floor,
+                       bs.stupid_bln_limit, p.fft2_na, p.fft1_sumsq_pa, p.fft1_sumsq_counter,
+                       p.fft1_lowlevel_points, p.fft1_liminfo_cnt])
+        b += B
+    out = {key: api.export(ring) for ring, key in RINGS}
+    out["itrace"] = np.array(itrace, np.int64)
+    out["wf_lines"] = np.array(wf_lines, np.int16).reshape(-1, cfg.wf_xpixels)
+    out["mixtrace"] = np.array(mixtrace, np.float64).reshape(-1, 8)
+    out["lowlevel_fraction"] = api.p.fft1_lowlevel_fraction
+    out["cfg"] = cfg
+    out["api"] = api
+    return out
+
+
+def relerr(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    ct = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = a.astype(ct), b.astype(ct)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def golden_itrace(g):
+    """columns of the reference trace matching run_case's itrace"""
+    it = g["itrace"].reshape(-1, 16)
+    return np.stack([it[:, 0], it[:, 1], it[:, 2], it[:, 3], it[:, 12], it[:, 13], it[:, 8], it[:, 9], it[:, 10],
+                     it[:, 11], it[:, 15]], axis=1).astype(np.int64)
+
+
+def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_mismatch=0.03, floor_slack=0):
+    """Assert parity of every ring, pointer trace and quantised line with the reference's output.
+
+    Float rings: relative RMS error <= tol (north_star: 1e-5).  Weak-band products (timf3) are also held to an
+    absolute bound tied to the float32 resolution of the full-band signal they are cut from.
+    Pointers / call pattern: exact.  Blanker: identical cleared-sample set.  Quantised waterfall bins: exact except
+    where the pre-rounding value sits within float32 noise of an integer boundary (|diff| <= 1 there).
+    """
+    rep = {}
+    gi, oi = golden_itrace(g), out["itrace"]
+    assert gi.shape == oi.shape, (gi.shape, oi.shape)
+    ptr_cols = [0, 1, 2, 3, 6, 7, 8, 9, 10]
+    assert np.array_equal(gi[:, ptr_cols], oi[:, ptr_cols]), "ring pointer trace differs from reference"
+    dfloor = np.abs(gi[:, 4] - oi[:, 4]).max()
+    rep["noise_floor_maxdiff"] = int(dfloor)
+    assert dfloor <= floor_slack, f"timf2_noise_floor trace differs by {dfloor}"
+    if floor_slack == 0:
+        assert np.array_equal(gi[:, 5], oi[:, 5]), "stupid_bln_limit trace differs"
+    for _, key in RINGS:
+        e = relerr(out[key], g[key][:out[key].size])
+        rep[key] = e
+        if key == "timf3_float":
+            # band-limited product: allow float32 noise of the wide-band spectrum it was cut from
+            cfg = out["cfg"]
+            n2 = 1 << cfg.fft2_n
+            wide = np.linalg.norm(g["fft2_float"].astype(np.float64)) / np.sqrt(cfg.max_fft2n)
+            nm = n2 >> cfg.mix1_bandwidth_reduction_n
+            floor = 4 * 6e-8 * wide * np.sqrt(nm / n2) * np.sqrt(out[key].size / nm / 2) * np.sqrt(nm)
+            err = np.linalg.norm(out[key].astype(np.float64) - g[key].astype(np.float64))
+            assert e <= tol or err <= floor, f"{key}: rel {e:.3e}, abs {err:.3e} > floor {floor:.3e}"
+        else:
+            assert e <= tol, f"{key}: relative RMS error {e:.3e} > {tol}"
+    if check_blanker_exact:
+        a, b = out["timf2_pwr_float"] == 0, g["timf2_pwr_float"] == 0
+        inter, union = np.sum(a & b), max(np.sum(a | b), 1)
+        rep["cleared_jaccard"] = float(inter / union)
+        assert np.array_equal(a, b), f"cleared-sample set differs (Jaccard {inter / union:.6f})"
+    gw, ow = g["wf_lines"].reshape(-1, out["cfg"].wf_xpixels), out["wf_lines"]
+    assert gw.shape == ow.shape, (gw.shape, ow.shape)
+    if gw.size:
+        diff = np.abs(gw.astype(np.int32) - ow.astype(np.int32))
+        rep["wf_mismatch_frac"] = float(np.mean(diff != 0))
+        rep["wf_maxdiff"] = int(diff.max())
+        # float32 FFT noise is set by the strongest bin: a bin D dB below it carries a relative power error of
+        # about 1e-6*10^(D/20), i.e. 434*that in 0.01 dB counts.  Exact +-1 within 60 dB of the peak.
+        allowed = 1 + np.floor(434e-6 * 10.0 ** ((gw.max() - gw.astype(np.float64)) / 2000.0))
+        assert np.all(diff <= allowed), f"waterfall bins differ by up to {diff.max()} (beyond float32 noise)"
+        assert np.mean(diff != 0) <= wf_max_mismatch, f"{np.mean(diff != 0):.4f} of waterfall bins differ"
+    gm, om = g["mixtrace"].reshape(-1, 8), out["mixtrace"]
+    if om.size:
+        assert np.array_equal(gm[:len(om), [0, 5, 6, 7]], om[:, [0, 5, 6, 7]]), "mix1 point / pointer trace differs"
+        assert np.allclose(gm[:len(om), 1:5], om[:, 1:5], rtol=0, atol=2e-6), "mix1 phase bookkeeping differs"
+    return rep

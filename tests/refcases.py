@@ -1,0 +1,123 @@
+"""Parity cases shared by tests/golden/make_golden.py (which runs the compiled reference here) and the tests.
+
+A case = sizes + call pattern + seeded input.  The same dict builds the reference-harness command line and the
+LrhConfig for the oracle / HIP path, so all three run the same job.
+"""
+import numpy as np
+
+from linrad_amd.abi import default_config
+
+
+def level_gain(n1, att_n, sigma=64.0, target_pwr=400.0):
+    """FIRST_FFT_GAIN from the level plan of SURVEY.md 8(d): weak-noise power in timf2_pwr ~ target."""
+    N1 = 1 << n1
+    A = 1.0 / np.sqrt(3.0 / 8.0)
+    g_per_gain = A * N1 * 2.0 ** (-att_n) / (150.0 * N1 ** 0.6)
+    # power = 2*sigma^2*g^2
+    g = np.sqrt(target_pwr / (2 * sigma * sigma))
+    return max(1, int(round(g / g_per_gain)))
+
+
+CASES = {
+    # small, fully stored golden: every ring wraps at least once
+    "n8_n10": dict(n1=8, n2=10, mixred=4, nblk=96, avg1num=3, avg2num=3, att_n=2, bln_interval=3, bln_avgnum=8,
+                   fq=333.37, wf_avgnum=2, wf_mode=1, seed=11, timf2pow_log2=13, sumsq_blocks=8,
+                   strong=[(-40.25, 9000.0), (100.0, 5000.0), (17.0, 900.0)], weak=[(77.5, 60.0), (-90.0, 30.0)],
+                   pulse_period=997, lim_halfwidth=3),
+    # mid size, stored as projections + strided samples
+    "n10_n12": dict(n1=10, n2=12, mixred=6, nblk=80, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                    fq=2200.3, wf_avgnum=2, wf_mode=2, seed=12, timf2pow_log2=15, sumsq_blocks=8,
+                    strong=[(-300.25, 9000.0), (37.0, 1000.0), (200.5, 300.0)], weak=[(-100.0, 50.0), (411.3, 25.0)],
+                    pulse_period=1999, lim_halfwidth=3),
+    # N2 < N1 (BASELINE.json config 2 shape, scaled down), no-window fft2 exercises interleave 0 in mix1
+    "n11_n9_nowin2": dict(n1=11, n2=9, mixred=4, nblk=40, avg1num=4, avg2num=2, att_n=5, bln_interval=4, bln_avgnum=16,
+                          fq=100.2, wf_avgnum=3, wf_mode=-2, seed=13, timf2pow_log2=14, sumsq_blocks=4,
+                          sinpow2=0, strong=[(512.5, 7000.0), (-200.0, 700.0)], weak=[(300.0, 40.0)], pulse_period=3001,
+                          lim_halfwidth=4),
+    # other fft1 window (sin^3): centre-part x inverted-window branch of timf2, interleave from formula
+    "n9_n11_sin3": dict(n1=9, n2=11, mixred=5, nblk=64, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
+                        fq=900.0, wf_avgnum=1, wf_mode=1, seed=14, timf2pow_log2=14, sumsq_blocks=4,
+                        sinpow1=3, strong=[(60.0, 8000.0), (-111.0, 500.0)], weak=[(150.5, 45.0)], pulse_period=0,
+                        lim_halfwidth=3),
+}
+
+
+def case_params(name):
+    d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
+             pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3)
+    d.update(CASES[name])
+    if d["gain"] is None:
+        d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"])
+    return d
+
+
+def interleave(n, sinpow):
+    if sinpow == 0:
+        return 0
+    ratio = 0.625 if sinpow == 9 else 0.8 if sinpow == 8 else 2 * np.arcsin(0.5 ** (1.0 / sinpow)) / np.pi
+    return int(1 + np.float32(ratio) * (1 << n)) & 0xfffe
+
+
+def make_input(d):
+    """Seeded synthetic IQ: noise + carriers + impulses (numpy; only used for the small parity cases)."""
+    N1 = 1 << d["n1"]
+    M1 = N1 - interleave(d["n1"], d["sinpow1"])
+    n = M1 * d["nblk"] + 2 * N1
+    rng = np.random.default_rng(d["seed"])
+    t = np.arange(n)
+    x = rng.normal(0, d["sigma"], n) + 1j * rng.normal(0, d["sigma"], n)
+    for k, a in d["strong"] + d["weak"]:
+        x += a * np.exp(2j * np.pi * k * t / N1 + 1j * rng.uniform(0, 6.28))
+    if d["pulse_period"]:
+        for s in range(d["pulse_period"] // 2, n - d["pulse_len"], d["pulse_period"]):
+            x[s:s + d["pulse_len"]] += d["pulse_amp"] * np.exp(1j * rng.uniform(0, 6.28))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(x.real), -32767, 32767)
+    iq[1::2] = np.clip(np.round(x.imag), -32767, 32767)
+    return iq
+
+
+def make_liminfo(d):
+    """strong/weak routing table: bins within lim_halfwidth of a strong carrier are marked strong (input to the path)."""
+    N1 = 1 << d["n1"]
+    lim = np.zeros(N1, np.float32)
+    for k, _ in d["strong"]:
+        c = int(round(N1 // 2 + k))
+        lim[max(0, c - d["lim_halfwidth"]):c + d["lim_halfwidth"] + 1] = 1.0
+    return lim
+
+
+def timf1_bytes_for(d, iq):
+    b = 1
+    while b < iq.nbytes:
+        b <<= 1
+    return b
+
+
+def lrh_config(d, iq, **kw):
+    N1, N2 = 1 << d["n1"], 1 << d["n2"]
+    wfpix = d["wf_pixels"] or min(N2, 1024)
+    c = default_config(
+        d["n1"], d["n2"], fft1_sinpow=d["sinpow1"], fft2_sinpow=d["sinpow2"], fft1_gain=d["gain"],
+        fft_avg1num=d["avg1num"], fft_avg2num=d["avg2num"], timf1_bytes=timf1_bytes_for(d, iq),
+        max_fft1n=d["max_fft1n"], max_fft2n=d["max_fft2n"], fft1_sumsq_bufsize=d["sumsq_blocks"] * N1,
+        bckfft_att_n=d["att_n"], timf2pow_size=1 << d["timf2pow_log2"], stupid_bln_mode=d["stupid"],
+        blnfit_range=d["blnfit_range"], blanker_pulsewidth=d["pulsewidth"],
+        timf2_noise_floor_avgnum=d["bln_avgnum"], blanker_info_update_interval=d["bln_interval"],
+        blanker_min_points=N2 // 3, timf2_noise_floor=d["noise_floor"],
+        waterfall_avgnum=d["wf_avgnum"], wf_first_xpoint=d["wf_first"], wf_xpixels=wfpix, wf_mode=d["wf_mode"],
+        wf_lines=8, mix1_bandwidth_reduction_n=d["mixred"],
+        timf3_size=16 * 2 * max(8, 1 << (d["n2"] - d["mixred"])),
+        fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2), max_batch=64)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def harness_args(d, infile, limfile, outfile):
+    keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
+            "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
+            "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2"]
+    a = [f"{k}={d[k]}" for k in keys]
+    a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
+    return a
