@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of complex IQ through fft1 -> timf2(+blank1) -> fft2 -> mix1 on MI355X, % of HBM roofline,
+with the CPU oracle timed beside it (BASELINE.json metric; contract in the task description).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--fft2-n 12]
+
+One process per GPU (torch.distributed.run for N > 1): every rank runs its own RF channel (weak scaling, no data-path
+collective); the only exchange is the all-reduce of the per-bin channel power sums (fft1.c:4138 semantics).
+A "step" = lrh_wideband_dsp over one batch of B fft1 blocks of synthetic int16 IQ already resident in the device ring.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from linrad_amd import abi  # noqa: E402
+from linrad_amd.workload import (ALG_BYTES, ALG_BYTES_CHAIN, HBM_PEAK_GBS, chain_config, strong_liminfo)  # noqa: E402
+
+
+def setup_receiver(cfg, channel, open_fn, synth_mod):
+    N1 = 1 << cfg.fft1_n
+    rx = open_fn(cfg)
+    s = synth_mod.synth_defaults(N1, channel)
+    nring = cfg.timf1_bytes // 4
+    rx.timf1_write(synth_mod.synth_iq(s, 0, nring))
+    rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
+    rx.set_mix1_selfreq(0.31 * (1 << cfg.fft2_n) + 0.3)
+    return rx
+
+
+def cpu_baseline(args, fft1_n, fft2_n):
+    """The oracle (C restatement of the reference path, -O2 -ffast-math, 1 thread) on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import open_oracle
+    from linrad_amd import lib as hiplib
+    nblk = args.cpu_blocks
+    cfg = chain_config(fft1_n, fft2_n, batch=min(32, nblk))
+    rx = setup_receiver(cfg, 0, open_oracle, hiplib)
+    M1 = (1 << fft1_n) // 2
+    rx.wideband_dsp(min(32, nblk), cfg.max_batch)          # warm the caches / tables
+    t0 = time.perf_counter()
+    rx.wideband_dsp(nblk, cfg.max_batch)
+    dt = time.perf_counter() - t0
+    return {"value": round(nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload, 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--fft1-n", type=int, default=14)
+    ap.add_argument("--fft2-n", type=int, default=12)
+    ap.add_argument("--cpu-blocks", type=int, default=6144)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from linrad_amd import lib as hiplib
+
+    cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
+    N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
+    rx = setup_receiver(cfg, rank, hiplib.open_hip, hiplib)
+    samples_per_step = args.batch * M1
+    xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+
+    def step():
+        rx.wideband_dsp(args.batch, args.batch)
+        if world > 1:
+            # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
+            pa = (rx.p.fft1_sumsq_pa - N1) & (cfg.fft1_sumsq_bufsize - 1)
+            rx.export_device(abi.RING_FFT1_SUMSQ, xchg.data_ptr(), pa, N1)
+            dist.all_reduce(xchg)
+
+    def barrier():
+        rx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    rx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = rx.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_samples = world * args.steps * samples_per_step
+    value = total_samples / dt / 1e6
+
+    # ---- per-kernel timing with HIP events on the context stream (rank 0), same steps
+    roof = None
+    stages = {}
+    if rank == 0:
+        rx.profile_enable(True)
+        for _ in range(max(3, min(args.steps, 10))):
+            rx.wideband_dsp(args.batch, args.batch)
+        rx.sync()
+        for k in ("fft1", "sumsq", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1"):
+            ms, n = rx.profile_get(k)
+            if n:
+                stages[k] = {"ms_total": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 2)}
+        rx.profile_enable(False)
+        dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
+        nsteps_prof = stages["fft1"]["launches"]
+        launches_per_step = stages[dom]["launches"] / nsteps_prof
+        alg_bytes_launch = ALG_BYTES[dom] * samples_per_step / launches_per_step
+        avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] / 1e3
+        achieved = alg_bytes_launch / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+                "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
+                "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(args, args.fft1_n, args.fft2_n)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        bs = rx.blanker_state()
+        out = {
+            "metric": "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 1 channel/GPU complex-int16 IQ, fft1_size={N1} sin^2 50% overlap, "
+                                   f"timf2 + stupid blanker, fft2_size={N2} sin^2, mix1 size {N2 >> 6}; "
+                                   f"{args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
+                       "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "channels": world,
+                       "parallelism": f"1 RF channel per GPU x{world}"},
+            "event_ms_per_step": round(ev_ms / args.steps, 4),
+            "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+            "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
+                        "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -203,6 +203,9 @@ int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
 /* ---- host-visible side outputs ---- */
 int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems); /* synchronous */
 int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                                   /* synchronous */
+/* same span, device-to-device into a caller-owned device buffer (e.g. the RCCL exchange buffer of the
+   cross-channel power sum, fft1.c:4138); synchronous on the context stream */
+int lrh_export_device(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);
 int lrh_sync(lrh_ctx *ctx);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */

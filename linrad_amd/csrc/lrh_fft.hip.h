@@ -1,0 +1,175 @@
+// lrh_fft.hip.h -- workgroup-cooperative complex FFT for gfx950 (CDNA4, wave64).
+//
+// One workgroup transforms one length-N sequence.  Every thread keeps P points in
+// registers for the whole transform; a pass is a radix-16/8/4/2 Stockham butterfly done
+// entirely in registers, and between passes the points are redistributed through LDS
+// (float2 cells, ds_write_b64 / ds_read_b64, one pad cell per 16 to spread the strided
+// scatter of the first exchange over all banks).  N = 16384 uses 1024 threads x 16 points
+// and 136 KiB of the CU's 160 KiB LDS; the first pass reads straight from global memory
+// and the last pass leaves natural-order results in registers, so a length-16384
+// transform costs three LDS round trips instead of the reference's fourteen radix-2
+// sweeps over a 128 KiB array (fft0.c:161-195).
+//
+// Index scheme (natural order in, natural order out, no bit reversal):
+//   pass with radix R, completed length p, butterfly i in [0, N/R):
+//     k = i mod p,  inputs  x[i + s*N/R] * w^(s),  w = exp(-+2 pi j k/(p R)),
+//     outputs y[(i-k)*R + k + q*p] = sum_s (...) exp(-+2 pi j s q / R)
+//   thread tid owns butterflies i = tid + m*T (T = N/P threads, m < P/R).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lrh {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -j (DIR = -1, forward) or +j (DIR = +1)
+template <int DIR> __device__ __forceinline__ float2 mulj(float2 a) { return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x); }
+template <int DIR> __device__ __forceinline__ float2 tw_dir(float2 w) { return DIR < 0 ? w : make_float2(w.x, -w.y); }
+
+template <int DIR> __device__ __forceinline__ void bfly2(float2 &a, float2 &b) { float2 t = csub(a, b); a = cadd(a, b); b = t; }
+
+// 4-point DFT, outputs in natural order: a,b,c,d <- X0..X3 of inputs x0..x3 = a,b,c,d
+template <int DIR> __device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+  float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mulj<DIR>(csub(b, d));
+  a = cadd(s0, s2); c = csub(s0, s2); b = cadd(s1, s3); d = csub(s1, s3);
+}
+
+#define LRH_C8 0.70710678118654752440f
+#define LRH_C16A 0.92387953251128675613f /* cos(pi/8) */
+#define LRH_S16A 0.38268343236508977173f /* sin(pi/8) */
+
+// exp(DIR * 2 pi j * e / 16), e in 0..9 (only the values the 4x4 split needs)
+template <int DIR, int E> __device__ __forceinline__ float2 w16()
+{
+  constexpr float c[10] = {1.f, LRH_C16A, LRH_C8, LRH_S16A, 0.f, -LRH_S16A, -LRH_C8, -LRH_C16A, -1.f, -LRH_C16A};
+  constexpr float s[10] = {0.f, LRH_S16A, LRH_C8, LRH_C16A, 1.f, LRH_C16A, LRH_C8, LRH_S16A, 0.f, -LRH_S16A};
+  return make_float2(c[E], DIR < 0 ? -s[E] : s[E]);
+}
+
+// R-point DFT of u[0..R) in place, natural order
+template <int DIR, int R> struct Dft;
+template <int DIR> struct Dft<DIR, 2> { __device__ __forceinline__ static void run(float2 *u) { bfly2<DIR>(u[0], u[1]); } };
+template <int DIR> struct Dft<DIR, 4> { __device__ __forceinline__ static void run(float2 *u) { bfly4<DIR>(u[0], u[1], u[2], u[3]); } };
+template <int DIR> struct Dft<DIR, 8> {
+  __device__ __forceinline__ static void run(float2 *u)
+  {
+    // s = 4a+b: radix-2 over a, twiddle w8^(b c), radix-4 over b; output index c + 2d
+    float2 y[8];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { float2 p = u[b], q = u[b + 4]; y[b] = cadd(p, q); y[4 + b] = csub(p, q); }   // y[c*4+b]
+    y[4 + 1] = cmul(y[4 + 1], make_float2(LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
+    y[4 + 2] = mulj<DIR>(y[4 + 2]);
+    y[4 + 3] = cmul(y[4 + 3], make_float2(-LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      bfly4<DIR>(y[c * 4 + 0], y[c * 4 + 1], y[c * 4 + 2], y[c * 4 + 3]);
+#pragma unroll
+      for (int d = 0; d < 4; d++) u[c + 2 * d] = y[c * 4 + d];
+    }
+  }
+};
+template <int DIR> struct Dft<DIR, 16> {
+  __device__ __forceinline__ static void run(float2 *u)
+  {
+    // s = 4a+b: radix-4 over a (b fixed), twiddle w16^(b c), radix-4 over b; output index c + 4d
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4<DIR>(u[b], u[b + 4], u[b + 8], u[b + 12]);   // u[4c+b] = y[b][c]
+    u[4 * 1 + 1] = cmul(u[4 * 1 + 1], w16<DIR, 1>());
+    u[4 * 1 + 2] = cmul(u[4 * 1 + 2], w16<DIR, 2>());
+    u[4 * 1 + 3] = cmul(u[4 * 1 + 3], w16<DIR, 3>());
+    u[4 * 2 + 1] = cmul(u[4 * 2 + 1], w16<DIR, 2>());
+    u[4 * 2 + 2] = mulj<DIR>(u[4 * 2 + 2]);
+    u[4 * 2 + 3] = cmul(u[4 * 2 + 3], w16<DIR, 6>());
+    u[4 * 3 + 1] = cmul(u[4 * 3 + 1], w16<DIR, 3>());
+    u[4 * 3 + 2] = cmul(u[4 * 3 + 2], w16<DIR, 6>());
+    u[4 * 3 + 3] = cmul(u[4 * 3 + 3], w16<DIR, 9>());
+    float2 v[16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      bfly4<DIR>(u[4 * c + 0], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);          // over b -> d
+#pragma unroll
+      for (int d = 0; d < 4; d++) v[c + 4 * d] = u[4 * c + d];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) u[q] = v[q];
+  }
+};
+
+// ---- compile-time pass plan -------------------------------------------------------------
+template <int LOG2N, int P> struct FftPlan {
+  static constexpr int N = 1 << LOG2N;
+  static constexpr int T = N / P;                       // threads per workgroup
+  static constexpr int MAXLOG = (P >= 16) ? 4 : 2;      // log2 of the largest radix
+  static constexpr int FULL = LOG2N / MAXLOG;
+  static constexpr int REM = LOG2N % MAXLOG;
+  static constexpr int NPASS = FULL + (REM ? 1 : 0);
+  __host__ __device__ static constexpr int radix(int pass) { return pass < FULL ? (1 << MAXLOG) : (1 << REM); }
+  __host__ __device__ static constexpr int done(int pass) { int p = 1; for (int i = 0; i < pass; i++) p *= radix(i); return p; }
+  static constexpr int R0 = FULL > 0 ? (1 << MAXLOG) : (1 << REM);
+  static constexpr int RL = REM ? (1 << REM) : (1 << MAXLOG);
+  static constexpr int LDS_CELLS = N + (N >> 4);        // float2 cells incl. padding
+  static_assert(P % R0 == 0 && P % RL == 0, "P must be a multiple of every radix");
+};
+
+__device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
+
+// Register layout contract of BlockFft::run:
+//   in : x[m*R0 + s] = input[(tid + m*T) + s*(N/R0)]      m < P/R0, s < R0
+//   out: x[m*RL + q] = output[(tid + m*T) + q*(N/RL)]     m < P/RL, q < RL
+// tw[m] = exp(-2 pi j m / N), m in [0, N) (forward table; DIR=+1 conjugates it).
+// `lds` must hold FftPlan::LDS_CELLS float2. The caller must __syncthreads() before reusing lds.
+template <int LOG2N, int P, int DIR> struct BlockFft {
+  using Plan = FftPlan<LOG2N, P>;
+  static constexpr int N = Plan::N, T = Plan::T;
+
+  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid)
+  {
+    constexpr int R = Plan::radix(PASS);
+    constexpr int p = Plan::done(PASS);
+    constexpr int NB = P / R;                            // butterflies per thread
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      float2 *u = &x[m * R];
+      if constexpr (p > 1) {
+        const int i = tid + m * T;
+        const int k = i & (p - 1);
+        const int base = k * (N / (p * R));
+#pragma unroll
+        for (int s = 1; s < R; s++) u[s] = cmul(u[s], tw_dir<DIR>(tw[s * base]));
+      }
+      Dft<DIR, R>::run(u);
+    }
+    if constexpr (PASS + 1 < Plan::NPASS) {
+      constexpr int R2 = Plan::radix(PASS + 1);
+      constexpr int NB2 = P / R2;
+      if constexpr (PASS > 0) __syncthreads();           // previous exchange's reads are done
+#pragma unroll
+      for (int m = 0; m < NB; m++) {
+        const int i = tid + m * T;
+        const int k = i & (p - 1);
+        const int j = (i - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; q++) lds[lds_pad(j + q * p)] = x[m * R + q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < NB2; m++) {
+        const int i = tid + m * T;
+#pragma unroll
+        for (int s = 0; s < R2; s++) x[m * R2 + s] = lds[lds_pad(i + s * (N / R2))];
+      }
+      pass<PASS + 1>(x, lds, tw, tid);
+    }
+  }
+
+  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid) { pass<0>(x, lds, tw, tid); }
+};
+
+// points per thread for a given size: 16 from N = 1024 up, 4 below
+__host__ __device__ constexpr int points_per_thread(int log2n) { return log2n >= 10 ? 16 : 4; }
+
+__host__ __device__ constexpr int fft_threads(int log2n) { return (1 << log2n) / points_per_thread(log2n); }
+
+}  // namespace lrh

@@ -1,0 +1,816 @@
+// lrh_host.hip -- C ABI (include/linrad_hip.h) over the HIP kernels: context, device rings, tables, and the
+// pointer bookkeeping the reference keeps in globals (citations per function).  Host code only; no CPU fallback:
+// every stage launches HIP kernels and fails with LRH_EDEVICE when there is no usable GPU.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/linrad_hip.h"
+#include "lrh_kernels.hip.h"
+
+namespace lrh {
+hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st);
+hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st);
+hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st);
+hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st);
+hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st);
+hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
+hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
+hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
+hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
+hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
+}  // namespace lrh
+using namespace lrh;
+
+#define PI_L 3.1415926535897932
+#define NATLOG 2.718281828459045
+#define FFT2_WATERFALL_ZERO 0.012
+#define LRH_NSTAGE 4
+#define LRH_BLN_PARTIALS 256
+
+struct ProfEntry { double ms = 0; long n = 0; };
+struct ProfPending { std::string name; hipEvent_t e0, e1; };
+
+struct lrh_ctx {
+  lrh_config cfg;
+  int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
+  int timf2_mode;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // device tables
+  float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
+  float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr;
+  unsigned int *d_pack_cur = nullptr, *d_pack_prev = nullptr;
+  int *d_wf_itab = nullptr;
+  // device rings
+  short2 *d_timf1 = nullptr;
+  float2 *d_fft1 = nullptr; float *d_sumsq = nullptr, *d_slowsum = nullptr;
+  float4 *d_timf2 = nullptr; float *d_pwr = nullptr; unsigned int *d_blnbits = nullptr;
+  float2 *d_fft2 = nullptr; float *d_power2 = nullptr, *d_powersum2 = nullptr, *d_wf_scratch = nullptr;
+  int16_t *d_waterf = nullptr;
+  float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
+  float *d_ph = nullptr;              // phase tables [LRH_NSTAGE][2][max_fft2 batch][half]
+  BlankState *d_bst = nullptr; float *d_partials = nullptr;
+  // host tables (reference layouts, for lrh_get_table)
+  std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
+  std::vector<unsigned int> h_pack;
+  bool have_liminfo = false;
+  // pinned staging for mix1 phases
+  float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
+  // mix1 scalars
+  lrh_mix1_state ms;
+  // masks
+  int fft1n_mask, fft1_mask, sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
+  // timers / profiling
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool prof = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
+
+// ------------------------------------------------------------------------------------------------ profiling
+struct ProfScope {
+  lrh_ctx *c; const char *name; hipEvent_t e0 = nullptr, e1 = nullptr;
+  static hipEvent_t get(lrh_ctx *c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+  ProfScope(lrh_ctx *c_, const char *n) : c(c_), name(n) { if (c->prof) { e0 = get(c); e1 = get(c); hipEventRecord(e0, c->stream); } }
+  ~ProfScope() { if (c->prof) { hipEventRecord(e1, c->stream); c->prof_pend.push_back({name, e0, e1}); } }
+};
+static void prof_collect(lrh_ctx *c)
+{
+  for (auto &p : c->prof_pend) {
+    hipEventSynchronize(p.e1);
+    float ms = 0; hipEventElapsedTime(&ms, p.e0, p.e1);
+    auto &t = c->prof_tot[p.name]; t.ms += ms; t.n++;
+    c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1);
+  }
+  c->prof_pend.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ tables
+// make_window (fft0.c:812-921): half window h[0..size/2], sin^n (n 1..7), Gaussian (8), erfc (9); unit mean square
+static void half_window(int size, int n, std::vector<float> &h, bool normalise)
+{
+  h.assign(size / 2 + 1, 0.f);
+  double sumsq = 0, x, e1, e2, z = n;
+  if (n == 9) {
+    e1 = 4.4; e2 = 40.0 / size; if (size < 128) e2 /= 1.5; if (size < 64) e2 /= 1.7;
+    for (int i = 0; i <= size / 2; i++) { h[i] = 0.5F * (float)erfc(e1); sumsq += h[i] * h[i]; e1 -= e2; }
+  } else if (n == 8) {
+    e1 = 0; e2 = 9.8 / size;
+    for (int i = size / 2; i >= 0; i--) { h[i] = (float)pow(NATLOG, -e1 * e1); sumsq += h[i] * h[i]; e1 += e2; }
+  } else {
+    x = 0;
+    for (int i = 0; i <= size / 2; i++) { h[i] = (float)pow(sin(x), z); sumsq += h[i] * h[i]; x += PI_L / size; }
+  }
+  if (normalise) { z = 1 / sqrt(2 * sumsq / size); for (int i = 0; i <= size / 2; i++) h[i] *= (float)z; }
+}
+
+static float interleave_ratio(int sinpow)   // make_interleave_ratio, buf.c:113-136
+{
+  if (sinpow == 0) return 0;
+  if (sinpow == 9) return 0.625f;
+  if (sinpow == 8) return 0.8f;
+  return (float)(2 * asin(pow(0.5, 1.0 / sinpow)) / PI_L);
+}
+
+static void default_filtercorr(lrh_ctx *c)  // clear_fft1_filtercorr + make_filcorrstart, fft1.c:4653-4724
+{
+  int N = c->N1;
+  float start = 150 * (float)N * (float)pow((double)N, -0.4);
+  start = (float)c->cfg.fft1_gain / start;
+  c->h_filtercorr.assign(2 * N, 0.f); c->h_desired.assign(N, 1.f);
+  for (int i = 0; i < N; i++) c->h_filtercorr[2 * i] = start;
+  float t1 = 0.125F * (float)PI_L, t2 = 0, t3;
+  int i = 0, k = N - 1;
+  while (t2 < 0.5 * PI_L) {
+    t3 = (float)(sin(t2) * sin(t2));
+    c->h_desired[i] = t3; c->h_filtercorr[2 * i] = t3 * start;
+    c->h_desired[k] = t3; c->h_filtercorr[2 * k] = t3 * start;
+    t2 += t1; i++; k--;
+  }
+}
+
+static void default_yfac(lrh_ctx *c)        // make_wg_yfac, wide_graph.c:955-1001 (second fft, float, 1 channel)
+{
+  float t1 = (float)(FFT2_WATERFALL_ZERO) / ((float)c->N2 * (float)c->N1);
+  t1 /= (float)sqrt((float)(c->cfg.waterfall_avgnum));
+  t1 *= (float)(1 << (2 * c->cfg.bckfft_att_n));
+  t1 *= (float)(1 + 1 / (0.5 + c->cfg.fft1_sinpow));
+  c->h_yfac.assign(c->N1, 0.f);
+  for (int i = 0; i < c->N1; i++)
+    c->h_yfac[i] = (c->h_desired[i] > 0.3162278) ? t1 / (float)pow(c->h_desired[i], 2.0) : t1 * 10;
+  c->h_yfac[0] = t1; c->h_yfac[c->N1 - 1] = t1;
+}
+
+static void make_twiddles(int N, std::vector<float2> &tw)
+{
+  tw.resize(N);
+  for (int m = 0; m < N; m++) { double a = 2 * PI_L * m / N; tw[m] = make_float2((float)cos(a), (float)-sin(a)); }
+}
+
+static void wf_geometry(const lrh_ctx *c, int *hx, int *hp, int *wx, int *wp, int *wfirst)
+{
+  int r = c->N2 / c->N1; if (r < 1) r = 1;
+  int mode = c->cfg.wf_mode;
+  if (mode == 1) { *hx = 1; *hp = 1; } else if (mode > 1) { *hx = mode; *hp = 0; } else { *hx = 0; *hp = -mode; }
+  if (*hx > 0 && *hx >= r) { *wx = *hx / r; *wp = 0; }
+  else { *wx = 0; *wp = *hp > 0 ? *hp * r : r / (*hx > 0 ? *hx : 1); if (*wp < 1) *wp = 1; }
+  *wfirst = c->cfg.wf_first_xpoint / r;
+}
+
+template <typename T> static int dev_alloc(lrh_ctx *c, T **p, size_t count, bool zero = true)
+{
+  hipError_t e = hipMalloc((void **)p, count * sizeof(T) + 256);
+  if (e != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc", e);
+  if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + 256, c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
+  return LRH_OK;
+}
+template <typename T> static int upload(lrh_ctx *c, T *dst, const T *src, size_t count)
+{
+  HIPCHK(c, hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return LRH_OK;
+}
+static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------------------ API
+extern "C" {
+
+int lrh_abi_version(void) { return LRH_ABI_VERSION; }
+
+int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
+{
+  if (!c) return LRH_EINVAL;
+  memset(c, 0, sizeof *c);
+  int N1 = 1 << fft1_n, N2 = 1 << fft2_n, NM = N1 > N2 ? N1 : N2;
+  c->struct_size = (int)sizeof *c; c->device = 0; c->rx_rf_channels = 1;
+  c->fft1_n = fft1_n; c->fft1_sinpow = 2; c->fft1_gain = 2000; c->fft1_direction = 1;   /* uivar.c:371 */
+  c->fft_avg1num = 5; c->fft_avg2num = 4; c->timf1_bytes = 64 * N1 * 4; c->max_fft1n = 32;
+  c->fft1_sumsq_bufsize = 8 * N1; c->wg_xpoints = N1 - 1; c->slowsum_fresh_recalc = 2;
+  c->bckfft_att_n = 6; c->timf2pow_size = 8 * NM;
+  c->stupid_bln_mode = 1; c->stupid_bln_factor = 5; c->blnfit_range = 48; c->blanker_pulsewidth = 0;
+  c->timf2_noise_floor_avgnum = 32; c->blanker_info_update_interval = 4; c->blanker_min_points = N2 / 3; c->timf2_noise_floor = 200;
+  c->fft2_n = fft2_n; c->fft2_sinpow = 2; c->max_fft2n = 4; c->waterfall_avgnum = 2; c->wf_first_xpoint = 0;
+  c->wf_xpixels = N2 < 1024 ? N2 : 1024; c->wf_mode = 1; c->wf_lines = 8;
+  c->mix1_bandwidth_reduction_n = 6; c->timf3_size = 32 * ((N2 >> 6) > 8 ? (N2 >> 6) : 8);
+  c->fftx_points_per_hz = 1.0f; c->mix1_lowest_fq = 0; c->mix1_highest_fq = (float)N2; c->max_batch = 16;
+  return LRH_OK;
+}
+
+void lrh_close(lrh_ctx *c)
+{
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+                  c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2, c->d_pwr,
+                  c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
+                  c->d_ph, c->d_bst, c->d_partials };
+  for (void *p : dev) if (p) hipFree(p);
+  if (c->h_ph) hipHostFree(c->h_ph);
+  for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
+  for (auto &p : c->prof_pend) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  if (c->t0) hipEventDestroy(c->t0);
+  if (c->t1) hipEventDestroy(c->t1);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *lrh_last_error(const lrh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int lrh_open(const lrh_config *cfg, lrh_ctx **out)
+{
+  if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
+  *out = nullptr;
+  if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
+  if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 14) return LRH_EINVAL;
+  if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
+      !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
+  lrh_ctx *c = new lrh_ctx();
+  memset(c->ph_ev, 0, sizeof c->ph_ev);
+  c->cfg = *cfg;
+  const int N1 = c->N1 = 1 << cfg->fft1_n, N2 = c->N2 = 1 << cfg->fft2_n;
+  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe; c->M1 = N1 - c->I1;     // buf.c:303-304
+  c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;          // buf.c:432-434
+  c->Nm = 1 << c->mix1_n;
+  c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im; // buf.c:451-452
+  c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;                                                       // buf.c:453-455
+  c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
+  bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
+             cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
+             !(c->Im == 0 || c->Im == c->Mm) || cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
+             (size_t)cfg->max_batch * c->M1 + N1 > (size_t)cfg->timf2pow_size;
+  if (bad) { delete c; return LRH_EINVAL; }
+  c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
+  c->timf2pow_mask = cfg->timf2pow_size - 1; c->timf2_mask = 4 * cfg->timf2pow_size - 1; c->fft2n_mask = cfg->max_fft2n - 1;
+  c->timf3_mask = cfg->timf3_size - 1; c->timf1_bytemask = cfg->timf1_bytes - 1;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  hipEventCreate(&c->t0); hipEventCreate(&c->t1);
+  int rc = LRH_OK;
+#define A(call) do { if (rc == LRH_OK) rc = (call); } while (0)
+  // ---- tables
+  std::vector<float> h, win1(N1, 1.0f), inv1(N1, 1.0f);
+  c->h_window1_ref.assign(N1, 0.f); c->h_invwin1_ref.assign(N1 / 2 + 1, 0.f);
+  if (cfg->fft1_sinpow) {
+    half_window(N1, cfg->fft1_sinpow, h, true);
+    for (int i = 0; i <= N1 / 2; i++) win1[i] = h[i];
+    for (int i = N1 / 2 + 1; i < N1; i++) win1[i] = h[N1 - i];
+    for (int i = 0; i < N1 / 2; i++) { c->h_window1_ref[2 * i] = h[i]; c->h_window1_ref[2 * i + 1] = h[N1 / 2 - i]; }   // fft0.c:907-920
+    if (cfg->fft1_sinpow != 2) {                                       // make_window(3,..) fft0.c:883-891
+      half_window(N1, cfg->fft1_sinpow, h, false);
+      c->h_invwin1_ref[0] = 1; for (int i = 1; i <= N1 / 2; i++) c->h_invwin1_ref[i] = 1 / h[i];
+      for (int i = 0; i <= N1 / 2; i++) inv1[i] = c->h_invwin1_ref[i];
+      for (int i = N1 / 2 + 1; i < N1; i++) inv1[i] = c->h_invwin1_ref[N1 - i];
+    }
+  }
+  c->h_window2.assign(N2, 1.0f);
+  if (cfg->fft2_sinpow) {
+    half_window(N2, cfg->fft2_sinpow, h, true);
+    for (int i = 0; i <= N2 / 2; i++) c->h_window2[i] = h[i];
+    for (int i = N2 / 2 + 1; i < N2; i++) c->h_window2[i] = h[N2 - i];
+  }
+  c->h_fqwin.assign(c->Nm / 2 + 1, 0.f);
+  { double e1 = 3.2, e2 = 13.0 / c->Nm; for (int i = 0; i <= c->Nm / 2; i++) { c->h_fqwin[i] = 0.5F * (float)erfc(e1); e1 -= e2; } }   // fft0.c:818-827
+  default_filtercorr(c); default_yfac(c);
+  std::vector<float2> tw1, tw2, twm; make_twiddles(N1, tw1); make_twiddles(N2, tw2); make_twiddles(c->Nm, twm);
+  // waterfall yfac index per pixel / data point, accumulated in float like fft2.c:713-729
+  int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
+  std::vector<int> itab(cfg->wf_xpixels + 4);
+  { float a2 = 1, a3; if (wx > 0) a2 = wx; else a2 = 1. / wp; a3 = wfirst + 0.5 * a2;
+    for (size_t i = 0; i < itab.size(); i++) { int t = a3; if (t < 0) t = 0; if (t > N1 - 1) t = N1 - 1; itab[i] = t; a3 += a2; } }
+  A(dev_alloc(c, &c->d_window1, N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
+  A(dev_alloc(c, &c->d_fqwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_yfac, N1)); A(dev_alloc(c, &c->d_filtercorr, N1));
+  A(dev_alloc(c, &c->d_tw1, N1)); A(dev_alloc(c, &c->d_tw2, N2)); A(dev_alloc(c, &c->d_twm, c->Nm));
+  A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
+  // ---- rings
+  A(dev_alloc(c, &c->d_timf1, cfg->timf1_bytes / 4)); A(dev_alloc(c, &c->d_fft1, (size_t)cfg->max_fft1n * N1));
+  A(dev_alloc(c, &c->d_sumsq, cfg->fft1_sumsq_bufsize)); A(dev_alloc(c, &c->d_slowsum, N1));
+  A(dev_alloc(c, &c->d_timf2, cfg->timf2pow_size)); A(dev_alloc(c, &c->d_pwr, cfg->timf2pow_size));
+  A(dev_alloc(c, &c->d_blnbits, cfg->timf2pow_size / 32 + 64));
+  A(dev_alloc(c, &c->d_fft2, (size_t)cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_power2, (size_t)cfg->max_fft2n * N2));
+  A(dev_alloc(c, &c->d_powersum2, N2)); A(dev_alloc(c, &c->d_wf_scratch, (size_t)(cfg->max_fft2n + 1) * N2));
+  A(dev_alloc(c, &c->d_waterf, (size_t)cfg->wf_lines * cfg->wf_xpixels + 64));
+  A(dev_alloc(c, &c->d_timf3, cfg->timf3_size / 2 + c->Nm)); A(dev_alloc(c, &c->d_mix_scratch, (size_t)cfg->max_fft2n * c->Nm));
+  c->ph_stride = (size_t)2 * cfg->max_fft2n * c->Nm;
+  A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
+  A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * LRH_BLN_PARTIALS));
+  if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
+  for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
+  if (rc == LRH_OK) {
+    hipStreamSynchronize(c->stream);
+    A(upload(c, c->d_window1, win1.data(), N1)); A(upload(c, c->d_invwin1, inv1.data(), N1));
+    A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
+    A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
+    A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
+    A(upload(c, c->d_wf_itab, itab.data(), itab.size()));
+    BlankState bs; memset(&bs, 0, sizeof bs);                          // buf.c:418-431, hires_graph.c:1157-1162
+    bs.noise_floor = cfg->timf2_noise_floor; bs.despiked_pwr[0] = (float)cfg->timf2_noise_floor; bs.despiked_pwrinc[0] = 1;
+    bs.limit = (unsigned int)((float)cfg->timf2_noise_floor * cfg->stupid_bln_factor);
+    A(upload(c, c->d_bst, &bs, 1));
+  }
+#undef A
+  if (rc != LRH_OK) { lrh_close(c); return rc; }
+  c->ms.mix1_selfreq = -1; c->ms.mix1_point = -1; c->ms.mix1_old_point = 0;
+  c->ms.mix1_phase = c->ms.mix1_phase_step = c->ms.mix1_phase_rot = c->ms.mix1_old_phase = 0;
+  // all-weak routing until the control plane supplies liminfo
+  std::vector<float> lim(N1, 0.f);
+  *out = c;
+  rc = lrh_set_liminfo(c, lim.data());
+  if (rc == LRH_OK && hipMemcpy(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice) != hipSuccess) rc = LRH_EDEVICE;
+  c->have_liminfo = false;
+  if (rc != LRH_OK) { *out = nullptr; lrh_close(c); }
+  return rc;
+}
+
+int lrh_get_derived(const lrh_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t3b)
+{
+  if (!c) return LRH_EINVAL;
+  if (i1) *i1 = c->I1; if (i2) *i2 = c->I2; if (ms) *ms = c->Nm; if (mi) *mi = c->Im; if (t3b) *t3b = 2 * c->Mm;
+  return LRH_OK;
+}
+
+void lrh_ptrs_init(const lrh_ctx *c, lrh_ptrs *p)
+{
+  (void)c; memset(p, 0, sizeof *p);
+  p->fft1_lowlevel_fraction = .75f;        // buf.c:343
+}
+
+int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
+{
+  if (!c) return LRH_EINVAL;
+  if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, c->h_filtercorr.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
+int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
+{
+  if (!c || !liminfo) return LRH_EINVAL;
+  // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
+  const int P = c->cfg.fft1_n >= 10 ? 16 : 4, R0 = P >= 16 ? 16 : 4;
+  const int nb = c->N1 / R0;
+  std::vector<unsigned int> pack(c->N1, 0u);
+  int low = 0;
+  for (int i = 0; i < nb; i++) {
+    unsigned int m = 0;
+    for (int s = 0; s < R0; s++) if (liminfo[i + s * nb] == 0) m |= 1u << s;
+    pack[i] = m;
+  }
+  for (int i = 0; i < c->N1; i++) if (liminfo[i] == 0) low++;
+  // d_pack_prev (routing of the transform before the next batch) is rolled forward by lrh_make_timf2
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->h_pack = pack;
+  HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->cfg.reserved[0] = low;                // fft1_lowlevel_points for this table (timf2.c:37-52)
+  c->have_liminfo = true;
+  return LRH_OK;
+}
+
+int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
+{
+  if (!c) return LRH_EINVAL;
+  if (y) c->h_yfac.assign(y, y + c->N1); else default_yfac(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_yfac, c->h_yfac.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
+int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
+{
+  if (!c || !name || !dst) return LRH_EINVAL;
+  const std::vector<float> *src = nullptr;
+  if (!strcmp(name, "fft1_window")) src = &c->h_window1_ref;
+  else if (!strcmp(name, "fft2_window")) src = &c->h_window2;
+  else if (!strcmp(name, "mix1_fqwin")) src = &c->h_fqwin;
+  else if (!strcmp(name, "fft1_filtercorr")) src = &c->h_filtercorr;
+  else if (!strcmp(name, "wg_waterf_yfac")) src = &c->h_yfac;
+  else if (!strcmp(name, "fft1_inverted_window")) src = &c->h_invwin1_ref;
+  else return LRH_EINVAL;
+  if (count > (int)src->size()) count = (int)src->size();
+  memcpy(dst, src->data(), 4 * (size_t)count);
+  return count;
+}
+
+int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
+{
+  if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
+  off &= c->timf1_bytemask;
+  const char *s = (const char *)src; char *d = (char *)c->d_timf1;
+  int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
+  HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream));
+  if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
+  return LRH_OK;
+}
+void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
+
+// ---------------------------------------------------------------------------------------------- fft1
+int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
+{
+  if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  Fft1Args a;
+  a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / 4 - 1;
+  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / 4 - c->I1) & a.ring_mask;     // fft1.c:421-426
+  a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
+  a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
+  ProfScope ps(c, "fft1");
+  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->stream));
+  return LRH_OK;
+}
+
+// fft1_c: power sums (fft1.c:4115-4171), counters (fft1.c:4507-4523), slow average (fft1.c:4526-4605)
+int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  const int N = c->N1, avg1 = c->cfg.fft_avg1num;
+  SumsqArgs sa; sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.ngroups = 0;
+  SlowsumArgs ua; ua.sumsq = c->d_sumsq; ua.slowsum = c->d_slowsum; ua.n = N; ua.bufsize = c->cfg.fft1_sumsq_bufsize; ua.avg2 = c->cfg.fft_avg2num; ua.nupd = 0;
+  auto flush = [&]() -> int {
+    if (sa.ngroups) { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->stream)); sa.ngroups = 0; }
+    if (ua.nupd) { ProfScope ps(c, "slowsum"); HIPCHK(c, launch_slowsum(ua, c->stream)); ua.nupd = 0; }
+    return LRH_OK;
+  };
+  int b = 0;
+  while (b < batch) {
+    int take = avg1 - p->fft1_sumsq_counter; if (take > batch - b) take = batch - b;
+    GroupDesc &g = sa.g[sa.ngroups++];
+    g.first_nb = p->fft1_nb; g.count = take; g.dst = p->fft1_sumsq_pa; g.accumulate = p->fft1_sumsq_counter != 0;
+    p->fft1_sumsq_counter += take;
+    p->fft1_nb = (p->fft1_nb + take) & c->fft1n_mask; p->fft1_pb = p->fft1_nb * 2 * N;
+    b += take;
+    if (p->fft1_sumsq_counter >= avg1) {
+      p->fft1_sumsq_counter = 0;
+      // update_fft1_slowsum window bookkeeping (fft1.c:4568-4573)
+      const int last = N - 1;
+      if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
+      SlowDesc &u = ua.u[ua.nupd++];
+      u.pa = p->fft1_sumsq_pa; u.ia = p->fft1_sumsq_recalc;
+      p->fft1_sumsq_recalc += c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
+      if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
+      u.ib = p->fft1_sumsq_recalc;
+      p->fft1_liminfo_cnt++;
+      p->fft1_sumsq_pa = (p->fft1_sumsq_pa + N) & c->sumsq_mask;
+      // the slow sum of group e reads sumsq written by this launch: keep launches ordered group by group
+      int rc = flush(); if (rc) return rc;
+    }
+    if (sa.ngroups == LRH_MAX_GROUPS) { int rc = flush(); if (rc) return rc; }
+  }
+  return flush();
+}
+
+// ---------------------------------------------------------------------------------------------- timf2
+int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  Timf2Args a;
+  a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
+  a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
+  a.timf2 = c->d_timf2; a.pwr = c->d_pwr; a.pa_first = p->timf2_pa / 4; a.mask = c->timf2pow_mask; a.step = c->M1;
+  a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
+  a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
+  { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->stream)); }
+  // from now on the previous transform was routed with the current table
+  HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
+  const int low = c->cfg.reserved[0];
+  for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
+    p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
+    p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
+    p->fft1_lowlevel_points = low;
+    p->fft1_lowlevel_fraction = 0.02 * (49 * p->fft1_lowlevel_fraction + low / ((float)(c->N1 - 1)));
+    p->timf2_pa = (p->timf2_pa + 4 * c->M1) & c->timf2_mask;
+  }
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- blanker
+int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
+{
+  if (!c || !p) return LRH_EINVAL;
+  const int mask = c->timf2pow_mask;
+  const int pbeg = p->timf2p_fit;
+  int pend = (p->timf2_pa / 4 - c->cfg.blnfit_range + mask) & mask;     // blank1.c:705-710
+  pend &= 0xfffffffc;
+  const int total = (pend - pbeg + 1 + mask) & mask;
+  if (total < c->cfg.blanker_min_points) return LRH_OK;                  // rate limit, blank1.c:712-715
+  BlankArgs a; memset(&a, 0, sizeof a);
+  a.pwr = c->d_pwr; a.timf2 = c->d_timf2; a.mask_bits = c->d_blnbits; a.mask = mask;
+  a.pbeg = pbeg; a.total = (pend - pbeg) & mask;
+  a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
+  a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials;
+  p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
+  const int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
+  p->timf2_blanker_points += m;
+  a.m = m; a.nstat = a.total / 4; a.blanker_points = p->timf2_blanker_points;
+  a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < LRH_BLN_PARTIALS ? a.nstat / 4096 : LRH_BLN_PARTIALS);
+  a.interval = c->cfg.blanker_info_update_interval; a.avgnum = c->cfg.timf2_noise_floor_avgnum; a.factor = c->cfg.stupid_bln_factor;
+  a.lowlevel_fraction = p->fft1_lowlevel_fraction;
+  p->blanker_info_update_counter++;                                      // blank1.c:1550-1601
+  a.do_update = 0;
+  if (p->blanker_info_update_counter >= a.interval) {
+    if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
+    else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
+  }
+  ProfScope ps(c, "blanker");
+  HIPCHK(c, launch_blanker(a, c->cfg.timf2pow_size / 32, c->stream));
+  return LRH_OK;
+}
+
+int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
+{
+  if (!c || !st) return LRH_EINVAL;
+  BlankState bs;
+  HIPCHK(c, hipMemcpyAsync(&bs, c->d_bst, sizeof bs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  st->timf2_noise_floor = bs.noise_floor; st->stupid_bln_limit = bs.limit;
+  st->timf2_despiked_pwr[0] = bs.despiked_pwr[0]; st->timf2_despiked_pwr[1] = bs.despiked_pwr[1];
+  st->timf2_despiked_pwrinc[0] = bs.despiked_pwrinc[0]; st->timf2_despiked_pwrinc[1] = bs.despiked_pwrinc[1];
+  st->stupid_blanker_rate = bs.stupid_rate; st->timf2_cleared_points = bs.cleared_acc;
+  st->last_call_cleared = bs.last_cleared; st->slow_path_calls = bs.slow_calls;
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fft2
+int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  const int N = c->N2;
+  Fft2Args a;
+  a.timf2 = c->d_timf2; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
+  a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
+  { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
+  Powersum2Args s;
+  s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
+  s.powersum = c->d_powersum2; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
+  { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->stream)); }
+  const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
+  if (nlines > 0) {
+    int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
+    WaterfallArgs w;
+    w.ps = c->d_wf_scratch; w.yfac = c->d_yfac; w.itab = c->d_wf_itab; w.line = c->d_waterf;
+    w.npix = c->cfg.wf_xpixels; w.first = c->cfg.wf_first_xpoint; w.siz = N; w.hx = hx; w.hp = hp;
+    w.ptr0 = p->wg_waterf_ptr; w.wf_size = c->cfg.wf_lines * c->cfg.wf_xpixels; w.line_stride = N;
+    ProfScope ps(c, "waterfall");
+    HIPCHK(c, launch_waterfall(w, nlines, c->stream));
+  }
+  for (int b = 0; b < batch; b++) {                                      // fft2.c:672, 703-705, 813-815, 1831-1845
+    p->wg_waterf_sum_counter++;
+    if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) {
+      p->wg_waterf_ptr -= c->cfg.wf_xpixels; if (p->wg_waterf_ptr < 0) p->wg_waterf_ptr += c->cfg.wf_lines * c->cfg.wf_xpixels;
+      p->wg_waterf_sum_counter = 0; p->fft2_liminfo_cnt++;
+    }
+    p->timf2_px = (p->timf2_px + 4 * c->M2) & c->timf2_mask;
+    p->fft2_na = (p->fft2_na + 1) & c->fft2n_mask; p->fft2_pa = 2 * p->fft2_na * N;
+    p->fft2_nb = (p->fft2_nb + 1) & c->fft2n_mask;
+    if (p->fft2_nm != c->fft2n_mask) p->fft2_nm++;
+  }
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- mix1
+int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
+int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
+
+// set_mix1_phases, mix1.c:781-861 (float branch; the double branch belongs to correlation mode)
+static int set_mix1_phases(lrh_ctx *c, float fq)
+{
+  lrh_mix1_state *s = &c->ms;
+  if (fq < c->cfg.mix1_lowest_fq || fq > c->cfg.mix1_highest_fq) return LRH_ERANGE;
+  const int size = c->Nm;
+  float t1 = fq * c->cfg.fftx_points_per_hz, t2;
+  int pnt = (int)(t1 + 0.5);
+  int k = pnt % size;
+  t2 = (float)(size * (pnt / size));
+  t2 = t1 - t2 - k;
+  t2 = t2 - (int)(t2);
+  s->mix1_phase_rot = (float)(t2 * 2 * PI_L / size);
+  k = (k * c->Mm) % size;
+  s->mix1_old_phase = s->mix1_phase;
+  s->mix1_phase += s->mix1_phase_step;
+  s->mix1_phase_step = (float)(k * 2 * PI_L / size);
+  s->mix1_old_point = (s->mix1_point != -1) ? s->mix1_point : pnt;
+  s->mix1_point = pnt;
+  if (s->mix1_phase > PI_L) s->mix1_phase = (float)(s->mix1_phase - 2 * PI_L);
+  if (s->mix1_phase < PI_L) s->mix1_phase = (float)(s->mix1_phase + 2 * PI_L);     // reference quirk (mix1.c:859-860)
+  return LRH_OK;
+}
+
+int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  const int Nm = c->Nm, overlap = c->Im != 0, half = overlap ? Nm / 2 : Nm, block2 = c->Mm;     // block in complex samples
+  lrh_mix1_state *s = &c->ms;
+  const int selected = s->mix1_selfreq >= 0;
+  Mix1OutArgs o; memset(&o, 0, sizeof o);
+  o.timf3 = c->d_timf3; o.mask2 = c->cfg.timf3_size / 2 - 1; o.pa_first = p->timf3_pa / 2; o.block = block2;
+  o.nm = Nm; o.overlap = overlap; o.selected = selected; o.scratch = c->d_mix_scratch;
+  if (selected) {
+    // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
+    const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
+    HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
+    float *hn = c->h_ph + slot * c->ph_stride, *ho = hn + (size_t)batch * half;
+    int point = 0;
+    for (int b = 0; b < batch; b++) {
+      int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
+      point = s->mix1_point;
+      float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
+      if (!overlap) {
+        for (int i = 0; i < half; i++) { hn[(size_t)b * half + i] = t1; t1 += t2; }
+      } else {
+        float r1 = s->mix1_old_phase;
+        float r2 = (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm);
+        for (int i = 0; i < half; i++) { hn[(size_t)b * half + i] = t1; ho[(size_t)b * half + i] = r1; r1 += r2; t1 += t2; }
+      }
+      s->mix1_phase = t1;
+    }
+    float *dn = c->d_ph + slot * c->ph_stride;
+    HIPCHK(c, hipMemcpyAsync(dn, hn, sizeof(float) * 2 * (size_t)batch * half, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream));
+    o.ph_new = dn; o.ph_old = dn + (size_t)batch * half;
+    Mix1Args a;
+    a.fft2 = c->d_fft2; a.n2 = c->N2; a.first_nx = p->fft2_nx; a.nx_mask = c->fft2n_mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
+    a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm;
+    int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+    a.lim_hi = ratio * (c->N1 - 1); if (a.lim_hi > c->N2) a.lim_hi = c->N2;       // mix1.c:957 (nn*fft1_last_point)/2 bins
+    ProfScope ps(c, "mix1");
+    HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->stream));
+    HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+  } else {
+    ProfScope ps(c, "mix1");
+    HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+  }
+  for (int b = 0; b < batch; b++) {                                      // mix1.c:991-992
+    p->timf3_pa = (p->timf3_pa + 2 * block2) & c->timf3_mask;
+    p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
+  }
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- orchestration
+// single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round
+int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  int rc;
+  while (nblocks > 0) {
+    const int B = nblocks < batch ? nblocks : batch;
+    if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4) & c->timf1_bytemask;
+    p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
+    p->fft1_na = p->fft1_pa / (2 * c->N1);
+    p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
+    if ((rc = lrh_fft1_c(c, p, B))) return rc;
+    if ((rc = lrh_make_timf2(c, p, B))) return rc;
+    if ((rc = lrh_first_noise_blanker(c, p))) return rc;
+    const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
+    int k = 0;
+    if (avail >= 4 * c->N2) k = 1 + (avail - 4 * c->N2) / (4 * c->M2);
+    while (k > 0) {
+      const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+      if ((rc = lrh_make_fft2(c, p, kb))) return rc;
+      if ((rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
+      k -= kb;
+    }
+    nblocks -= B;
+  }
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- outputs
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind);
+int lrh_export(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost); }
+int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice); }
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind)
+{
+  if (!c || !dst) return LRH_EINVAL;
+  const void *src; size_t esz = 4, total;
+  switch (ring) {
+    case LRH_RING_TIMF1: src = c->d_timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;
+    case LRH_RING_FFT1_FLOAT: src = c->d_fft1; total = (size_t)c->cfg.max_fft1n * 2 * c->N1; break;
+    case LRH_RING_FFT1_SUMSQ: src = c->d_sumsq; total = c->cfg.fft1_sumsq_bufsize; break;
+    case LRH_RING_FFT1_SLOWSUM: src = c->d_slowsum; total = c->N1; break;
+    case LRH_RING_TIMF2_FLOAT: src = c->d_timf2; total = 4 * (size_t)c->cfg.timf2pow_size; break;
+    case LRH_RING_TIMF2_PWR: src = c->d_pwr; total = c->cfg.timf2pow_size; break;
+    case LRH_RING_FFT2_FLOAT: src = c->d_fft2; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
+    case LRH_RING_FFT2_POWER: src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2; break;
+    case LRH_RING_FFT2_POWERSUM: src = c->d_powersum2; total = c->N2; break;
+    case LRH_RING_WG_WATERF: src = c->d_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
+    case LRH_RING_TIMF3_FLOAT: src = c->d_timf3; total = c->cfg.timf3_size; break;
+    default: return LRH_EINVAL;
+  }
+  if (off + cnt > total) return LRH_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(dst, (const char *)src + off * esz, cnt * esz, kind, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
+int lrh_sync(lrh_ctx *c) { if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return LRH_OK; }
+
+int lrh_timer_start(lrh_ctx *c) { if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
+int lrh_timer_stop(lrh_ctx *c, float *ms)
+{
+  if (!c || !ms) return LRH_EINVAL;
+  HIPCHK(c, hipEventRecord(c->t1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->t1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+  return LRH_OK;
+}
+int lrh_profile_enable(lrh_ctx *c, int on)
+{
+  if (!c) return LRH_EINVAL;
+  prof_collect(c); c->prof = on != 0; c->prof_tot.clear();
+  return LRH_OK;
+}
+int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *launches)
+{
+  if (!c || !kernel) return LRH_EINVAL;
+  prof_collect(c);
+  auto it = c->prof_tot.find(kernel);
+  if (total_ms) *total_ms = it == c->prof_tot.end() ? 0 : it->second.ms;
+  if (launches) *launches = it == c->prof_tot.end() ? 0 : it->second.n;
+  return LRH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- test signal
+static inline uint64_t splitmix64(uint64_t &x) { uint64_t z = (x += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+struct Xo { uint64_t s[4]; uint64_t next() { uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
+            double uni() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); } };
+
+void lrh_synth_defaults(lrh_synth *s, int fft1_size, int channel)
+{
+  memset(s, 0, sizeof *s);
+  s->seed = 0x4C494E52ULL + (uint64_t)channel; s->noise_sigma = 64.0f; s->fft_size = fft1_size;
+  const float bins[8] = {-6000, -3111, -517, 37, 1024, 2999.5f, 4500, 7000};
+  const float amps[8] = {8000, 50, 200, 1000, 100, 300, 20, 4000};
+  s->ncarriers = 8;
+  for (int i = 0; i < 8; i++) { s->carrier_bin[i] = bins[i] * (float)fft1_size / 16384.0f; s->carrier_amp[i] = amps[i]; }
+  s->pulse_period = 9973; s->pulse_len = 3; s->pulse_amp = 20000.0f; s->chan_phase = 0.7f * channel;
+}
+
+// Position-addressable: any (first_sample, nsamples) window of the same infinite sequence gives the same bytes.
+int lrh_synth_iq(const lrh_synth *s, int64_t first, int64_t n, int16_t *dst)
+{
+  if (!s || !dst || n < 0 || s->ncarriers < 0 || s->ncarriers > 16 || s->fft_size <= 0) return LRH_EINVAL;
+  const int64_t BLK = 4096;
+  for (int64_t pos = first; pos < first + n;) {
+    const int64_t blk = pos >= 0 ? pos / BLK : -((-pos + BLK - 1) / BLK);
+    const int64_t b0 = blk * BLK;
+    int64_t e = b0 + BLK; if (e > first + n) e = first + n;
+    uint64_t sm = s->seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(blk + 0x100000));
+    Xo g; for (int i = 0; i < 4; i++) g.s[i] = splitmix64(sm);
+    double cr[16], ci[16], wr[16], wi[16];
+    for (int k = 0; k < s->ncarriers; k++) {
+      const double cyc = (double)s->carrier_bin[k] / s->fft_size;
+      double ph = cyc * (double)b0; ph -= floor(ph);   // phase at the block start, in cycles
+      const double a = 2 * PI_L * ph + s->chan_phase;
+      cr[k] = s->carrier_amp[k] * cos(a); ci[k] = s->carrier_amp[k] * sin(a);
+      wr[k] = cos(2 * PI_L * cyc); wi[k] = sin(2 * PI_L * cyc);
+    }
+    for (int64_t i = b0; i < e; i++) {
+      // Box-Muller on the block's own stream: every sample of the block is drawn whether or not it is requested
+      const double u1 = g.uni(), u2 = g.uni();
+      const double r = s->noise_sigma * sqrt(-2.0 * log(u1));
+      double re = r * cos(2 * PI_L * u2), im = r * sin(2 * PI_L * u2);
+      for (int k = 0; k < s->ncarriers; k++) {
+        re += cr[k]; im += ci[k];
+        const double t = cr[k] * wr[k] - ci[k] * wi[k]; ci[k] = cr[k] * wi[k] + ci[k] * wr[k]; cr[k] = t;
+      }
+      if (s->pulse_period > 0 && i >= 0) {
+        const int64_t pi = i / s->pulse_period, off = i - pi * s->pulse_period;
+        if (off < s->pulse_len) {
+          uint64_t h = s->seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(pi + 1)); const double pa = 2 * PI_L * ((splitmix64(h) >> 11) * (1.0 / 9007199254740992.0));
+          re += s->pulse_amp * cos(pa); im += s->pulse_amp * sin(pa);
+        }
+      }
+      if (i >= pos) {
+        double a = nearbyint(re), b = nearbyint(im);
+        if (a > 32767) a = 32767; if (a < -32767) a = -32767; if (b > 32767) b = 32767; if (b < -32767) b = -32767;
+        dst[2 * (i - first)] = (int16_t)a; dst[2 * (i - first) + 1] = (int16_t)b;
+      }
+    }
+    pos = e;
+  }
+  return LRH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,607 @@
+// lrh_kernels.hip -- hand-written HIP kernels (gfx950) for Linrad's wideband hot path.
+//
+//   k_fft1       fft1_b (fft1.c:413-447, fft0.c:161-195, fft1.c:637-650) + filter correction of fft1_c (fft1.c:4119-4127)
+//   k_sumsq      power accumulation of fft1_c (fft1.c:4115-4171), one averaging group per blockIdx.y
+//   k_slowsum    update_fft1_slowsum (fft1.c:4526-4605) + new_fft1_averages (wide_graph.c:1003-1032)
+//   k_timf2      make_timf2 + fft1back_one + fft1back_fp_finish (timf2.c:31-75, 689-967, 970-1064)
+//   k_blank_*    stupid blanker + noise statistics of first_noise_blanker (blank1.c:1003-1087, 1458-1601)
+//   k_fft2       make_fft2 mode 15 (fft2.c:91-141, 647-670)
+//   k_powersum2 / k_waterfall   fft2.c:655-670, 707-815
+//   k_mix1_back / k_mix1_out    fft2_mix1_fixed + do_mix1 (mix1.c:934-993, 55-195)
+//
+// All spectra / time functions live in device rings; every kernel is HBM-bound, so the design rule is one pass
+// per stage with everything element-wise fused into the transform's load or store.
+#include "lrh_fft.hip.h"
+#include "lrh_kernels.hip.h"
+
+namespace lrh {
+
+// =====================================================================================================
+// fft1
+// =====================================================================================================
+template <int LOG2N>
+__global__ __launch_bounds__(fft_threads(LOG2N)) void k_fft1(Fft1Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int p0 = a.p0_first + b * a.step;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int idx = (tid + m * T) + s * (N / R0);
+      const short2 v = a.timf1[(p0 + idx) & a.ring_mask];
+      const float w = a.window[idx];
+      // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
+      x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));
+    }
+  BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
+  float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k = (tid + m * T) + q * (N / RL);
+      int kk = (k + N / 2) & (N - 1);                 // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
+      float2 v = x[m * RL + q];
+      if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
+      out[kk] = cmul(v, a.filtercorr[kk]);
+    }
+}
+
+// =====================================================================================================
+// fft1_c power sums and slow average
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_sumsq(SumsqArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const GroupDesc g = a.g[blockIdx.y];
+  float acc = g.accumulate ? a.sumsq[g.dst + i] : 0.0f;
+  for (int j = 0; j < g.count; j++) {
+    const float2 z = a.spec[(size_t)((g.first_nb + j) & a.nb_mask) * a.n + i];
+    const float pw = z.x * z.x + z.y * z.y;
+    acc = (j == 0 && !g.accumulate) ? pw : acc + pw;
+  }
+  a.sumsq[g.dst + i] = acc;
+}
+
+#define LRH_FFT1_SMALL 0.00000001F
+__global__ __launch_bounds__(256) void k_slowsum(SlowsumArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int mask = a.bufsize - 1;
+  float slow = a.slowsum[i];
+  for (int e = 0; e < a.nupd; e++) {
+    const SlowDesc u = a.u[e];
+    if (i >= u.ia && i <= u.ib) {                      // from scratch over the window (wide_graph.c:1016-1031)
+      int p0 = (u.pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
+      slow = a.sumsq[p0 + i];
+      p0 = (p0 + a.n) & mask;
+      for (int m = 1; m < a.avg2; m++) {
+        slow += a.sumsq[p0 + i];
+        if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL;
+        p0 = (p0 + a.n) & mask;
+      }
+    } else {                                           // sliding update (fft1.c:4574-4583)
+      const int pb = (u.pa - a.avg2 * a.n + a.bufsize) & mask;
+      slow += a.sumsq[u.pa + i] - a.sumsq[pb + i];
+      if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL;
+    }
+  }
+  a.slowsum[i] = slow;
+}
+
+// =====================================================================================================
+// timf2: strong/weak split, two back transforms, window handling, power
+// =====================================================================================================
+// sin^2 window, 50 % overlap: the reference adds the first half of transform t onto the stored second half of
+// transform t-1 (timf2.c:1003-1026).  Second half of DFT(S)[n + N/2] = DFT(S (-1)^k)[n], so
+//     out_t[n] = ampfac * DFT( S_t + (-1)^k S_{t-1} )[n],  n < N/2
+// i.e. one transform of the combined spectrum, written once -- no read-modify-write of the timf2 ring.
+template <int LOG2N, int MODE>
+__global__ __launch_bounds__(fft_threads(LOG2N)) void k_timf2(Timf2Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid0 = threadIdx.x, b = blockIdx.x;
+  const float2 *cur = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+  const float2 *prv = a.spec + (size_t)((a.first_nb + b - 1) & a.nb_mask) * N;
+  // weak/strong routing flags, packed by the host per first-pass butterfly: bit s of pack[i] is set when bin
+  // i + s*(N/R0) is weak (liminfo == 0, timf2.c:50).  One dword per thread instead of R0 float loads.
+  const unsigned int *packp = (b == 0) ? a.pack_prev : a.pack_cur;
+  const int pa = a.pa_first + b * a.step;
+  // weak stream (st = 0) then strong stream (st = 1), one at a time: 16 points/thread of one stream is all the
+  // register file holds at 1024 threads.  The spectra are re-read for the second stream (L2 hits).
+#pragma unroll 1
+  for (int st = 0; st < 2; st++) {
+    // opaque per-iteration copy of the thread index: without it LICM hoists every address and LDS index of the
+    // transform out of this two-trip loop and parks them in ~200 VGPRs (spills at 1024 threads)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    float2 x[P];
+#pragma unroll
+    for (int m = 0; m < P / R0; m++) {
+      const unsigned int sel = st ? 0u : 0xffffffffu;
+      const unsigned int mc = a.pack_cur[tid + m * T] ^ ~sel;     // bit set -> bin belongs to this stream
+      const unsigned int mp = packp[tid + m * T] ^ ~sel;
+#pragma unroll
+      for (int s = 0; s < R0; s++) {
+        const int k = (tid + m * T) + s * (N / R0);
+        float2 v = cur[k];
+        if (!((mc >> s) & 1u)) v = make_float2(0.f, 0.f);
+        if constexpr (MODE == 1) {
+          float2 pv = prv[k];
+          if (!((mp >> s) & 1u)) pv = make_float2(0.f, 0.f);
+          v = (k & 1) ? csub(v, pv) : cadd(v, pv);
+        }
+        x[m * R0 + s] = v;
+      }
+    }
+    if (st) __syncthreads();
+    BlockFft<LOG2N, P, -1>::run(x, lds, a.tw, tid);
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int n = (tid + m * T) + q * (N / RL);
+        float amp = a.ampfac; int pos; bool keep;
+        if constexpr (MODE == 1) { keep = n < N / 2; pos = n; }
+        else if constexpr (MODE == 0) { keep = true; pos = n; }
+        else {                                            // centre part x inverted window (timf2.c:1031-1061)
+          keep = (n >= a.ia) && (n < N - a.ia); pos = n - a.ia; amp = a.invwin[n] * a.ampfac;
+        }
+        if (keep) {
+          const float2 v = x[m * RL + q];
+          const float2 o = make_float2(amp * v.x, amp * v.y);
+          const int r = (pa + pos) & a.mask;
+          reinterpret_cast<float2 *>(&a.timf2[r])[st] = o;
+          if (st == 0) a.pwr[r] = o.x * o.x + o.y * o.y;  // weak power only (timf2.c:1010-1012)
+        }
+      }
+  }
+}
+
+// =====================================================================================================
+// blanker
+// =====================================================================================================
+// The reference scan is serial (blank1.c:1023-1086): a run of samples above the limit is cleared, and when it
+// ends a guard of i_after samples *ahead* is zeroed too, so later samples are tested against modified data.
+// Exact parallel form: a lane owns LRH_BLN_CHUNK samples but starts its replay at the nearest earlier point
+// where the serial state is provably clean (G >= clr2 consecutive samples at or below the limit, or the start
+// of the call), so every decision equals the serial one.  Decisions go to a bit mask; k_blank_apply zeroes the
+// data afterwards (the scan itself only reads), which also keeps lanes from racing on guard samples.
+#define LRH_BLN_CHUNK 64
+#define LRH_BLN_BACK (4 * LRH_BLN_CHUNK)
+
+__device__ __forceinline__ void bln_setbit(unsigned int *bits, int p) { atomicOr(&bits[p >> 5], 1u << (p & 31)); }
+
+__device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, float totnoise, int *ib, int *ia)
+{
+  float t1 = pulmax / totnoise;
+  *ib = 0; *ia = 0;
+  if (t1 > 4) {
+    if (t1 > 10000) t1 = 10000;                        // 40 dB cap (blank1.c:1056-1057)
+    t1 = (float)(sqrt((double)t1) / 100);
+    *ib = (int)((float)a.clr1 * t1 + 0.5);
+    *ia = (int)((float)a.clr2 * t1 + 0.5);
+    return 1;
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
+{
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int cs = c * LRH_BLN_CHUNK + 1;
+  if (cs > a.total) return;
+  const int ce = min(cs + LRH_BLN_CHUNK - 1, a.total);
+  const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
+  const int G = max(a.clr2, 1);
+  int s = 1;
+  {
+    int run = 0, steps = 0, q = cs - 1; bool found = false;
+    while (q >= 1) {
+      const float v = a.pwr[(a.pbeg + q) & a.mask];
+      if (v > nfl) run = 0; else if (++run >= G) { found = true; break; }
+      q--;
+      if (++steps > LRH_BLN_BACK) break;
+    }
+    if (found) s = q + G;
+    else if (q >= 1) { a.st->need_slow = 1; return; }  // no clean point in reach: exact serial pass takes over
+  }
+  int ifirst = 0, pk = 0, erase_end = 0, cnt = 0;
+  float pulmax = 0;
+  for (int q = s; q <= ce; q++) {
+    const int p = (a.pbeg + q) & a.mask;
+    const float v = a.pwr[p];
+    if (v > nfl && q >= erase_end) {
+      if (ifirst == 0) pk = q;
+      if (v > pulmax) pulmax = v;
+      ifirst++;
+      if (q >= cs) { bln_setbit(a.mask_bits, p); cnt++; }
+    } else if (ifirst != 0) {
+      ifirst = 0;
+      int ib, ia;
+      const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
+      pulmax = 0;
+      if (ext) {
+        if (q >= cs) {
+          for (int j = 1; j <= ib; j++) bln_setbit(a.mask_bits, (a.pbeg + pk - j) & a.mask);
+          for (int j = 0; j < ia; j++) bln_setbit(a.mask_bits, (a.pbeg + q + j) & a.mask);
+          cnt += ib + ia;
+        }
+        erase_end = q + ia;
+      }
+    }
+  }
+  if (cnt) atomicAdd(&a.st->call_cleared, cnt);
+}
+
+// exact serial replay, only when a lane of k_blank_scan could not find a clean restart point
+__global__ void k_blank_serial(BlankArgs a)
+{
+  if (!a.st->need_slow) return;
+  a.st->need_slow = 0; a.st->slow_calls++;
+  for (int q = 1 - a.clr1 - 32; q <= a.total + a.clr2 + 32; q++) a.mask_bits[((a.pbeg + q) & a.mask) >> 5] = 0;
+  const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
+  int ifirst = 0, pk = 0, erase_end = 0, cnt = 0; float pulmax = 0;
+  for (int q = 1; q <= a.total; q++) {
+    const int p = (a.pbeg + q) & a.mask;
+    const float v = a.pwr[p];
+    if (v > nfl && q >= erase_end) {
+      if (ifirst == 0) pk = q;
+      if (v > pulmax) pulmax = v;
+      ifirst++; a.mask_bits[p >> 5] |= 1u << (p & 31); cnt++;
+    } else if (ifirst != 0) {
+      ifirst = 0;
+      int ib, ia;
+      const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
+      pulmax = 0;
+      if (ext) {
+        for (int j = 1; j <= ib; j++) { const int r = (a.pbeg + pk - j) & a.mask; a.mask_bits[r >> 5] |= 1u << (r & 31); }
+        for (int j = 0; j < ia; j++) { const int r = (a.pbeg + q + j) & a.mask; a.mask_bits[r >> 5] |= 1u << (r & 31); }
+        cnt += ib + ia; erase_end = q + ia;
+      }
+    }
+  }
+  a.st->call_cleared = cnt;
+}
+
+// one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word
+__global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word, int nwords, int word_mask)
+{
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const int wi = (first_word + w) & word_mask;
+  unsigned int bits = a.mask_bits[wi];
+  if (!bits) return;
+  a.mask_bits[wi] = 0;
+  while (bits) {
+    const int bpos = __ffs(bits) - 1; bits &= bits - 1;
+    const int p = wi * 32 + bpos;
+    a.pwr[p] = 0;
+    float2 *wk = reinterpret_cast<float2 *>(&a.timf2[p]);
+    *wk = make_float2(0.f, 0.f);                        // weak part only (blank1.c:1043-1045)
+  }
+}
+
+// every-4th-sample power sum (blank1.c:1493-1497) as fixed-order partial sums
+__global__ __launch_bounds__(256) void k_blank_stats(BlankArgs a)
+{
+  __shared__ double red[256];
+  const int per = (a.nstat + a.npartials - 1) / a.npartials;
+  const int j0 = blockIdx.x * per, j1 = min(j0 + per, a.nstat);
+  double acc = 0;
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) acc += (double)a.pwr[(a.pbeg + 4 * (j + 1)) & a.mask];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) reinterpret_cast<double *>(a.partials)[blockIdx.x] = red[0];
+}
+
+// scalar bookkeeping of blank1.c:1472-1601 (1 channel); host supplies everything that does not depend on data
+__global__ void k_blank_update(BlankArgs a)
+{
+  BlankState *s = a.st;
+  const int cleared = s->call_cleared;
+  s->call_cleared = 0;
+  s->last_cleared = cleared;
+  s->cleared_acc += cleared;
+  double tot = 0;
+  for (int i = 0; i < a.npartials; i++) tot += reinterpret_cast<double *>(a.partials)[i];
+  int k = a.m - cleared; if (k < a.m / 25) k = a.m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
+  float t1 = (float)tot;
+  t1 /= k; if (t1 < 10) t1 = 10;
+  s->despiked_pwrinc[0] += t1;
+  if (!a.do_update) return;
+  s->despiked_pwr[0] = s->despiked_pwrinc[0] / (a.interval * a.lowlevel_fraction);
+  s->despiked_pwr[1] = s->despiked_pwrinc[1] / (a.interval * a.lowlevel_fraction);
+  float rate = (float)(100. * (double)(float)s->cleared_acc / (double)a.blanker_points);
+  if (rate > 99) rate = 99;
+  s->stupid_rate = rate;
+  int nf = (int)((s->despiked_pwr[0] + s->despiked_pwr[1]) / 1);
+  if (a.mode == 1) {
+    if (rate > 20) {
+      if (nf < 30) nf = 30;
+      t1 = (float)(0.01 * pow((double)rate - 20.0, 2.));
+      if (t1 > 10) t1 = 10;
+      nf = (int)((float)nf * (1 + t1));
+    } else {
+      nf = (int)(((float)((a.avgnum - 1) * nf) + t1) / (float)a.avgnum);
+    }
+    s->limit = (unsigned int)((float)nf * a.factor);
+  }
+  s->noise_floor = nf;
+  s->despiked_pwrinc[0] = 1; s->despiked_pwrinc[1] = 1;
+  s->cleared_acc = 0;
+}
+
+// =====================================================================================================
+// fft2 (one workgroup per transform, N2 <= 16384)
+// =====================================================================================================
+template <int LOG2N>
+__global__ __launch_bounds__(fft_threads(LOG2N)) void k_fft2(Fft2Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int px = a.px_first + b * a.step;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int idx = (tid + m * T) + s * (N / R0);
+      const float4 v = a.timf2[(px + idx) & a.mask];
+      const float w = a.window[idx];
+      x[m * R0 + s] = make_float2(w * (v.x + v.z), w * (v.y + v.w));   // weak + strong (fft2.c:100-105)
+    }
+  BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
+  const int na = (a.first_na + b) & a.na_mask;
+  float2 *out = a.out + (size_t)na * N;
+  float *pw = a.power + (size_t)na * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k = (tid + m * T) + q * (N / RL);
+      const float2 v = x[m * RL + q];
+      out[k] = v;
+      pw[k] = v.x * v.x + v.y * v.y;
+    }
+}
+
+// fft2_powersum_float over a batch in transform order; completed waterfall groups are parked in wf_scratch
+__global__ __launch_bounds__(256) void k_powersum2(Powersum2Args a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  int cnt = a.counter, line = 0;
+  float acc = cnt > 0 ? a.powersum[i] : 0.f;
+  for (int b = 0; b < a.count; b++) {
+    const float pw = a.power[(size_t)((a.first_na + b) & a.na_mask) * a.n + i];
+    acc = (cnt == 0) ? pw : acc + pw;
+    if (++cnt >= a.avgnum) { a.wf_scratch[(size_t)line * a.n + i] = acc; line++; cnt = 0; }
+  }
+  a.powersum[i] = acc;
+}
+
+// one waterfall line, 0.01 dB shorts (fft2.c:707-812); itab[] holds the reference's float-accumulated yfac index
+__global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
+{
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  {
+    const int l = blockIdx.y;
+    int ptr = a.ptr0 - l * a.npix;
+    ptr %= a.wf_size; if (ptr < 0) ptr += a.wf_size;   // update_wg_waterf, fft1.c:104-113
+    a.line += ptr; a.ps += (size_t)l * a.line_stride;
+  }
+  if (a.hx == 1 || a.hp == 1) {
+    if (t >= a.npix) return;
+    int y = (int)(1000. * log10((double)(a.ps[a.first + t] * a.yfac[a.itab[t]])));
+    if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+    a.line[t] = (int16_t)y;
+  } else if (a.hx == 0) {
+    // segment t covers pixels t*hp+1 .. t*hp+hp between data points t and t+1
+    const int nseg = (a.npix - a.hp + a.hp - 1) / a.hp;      // loop count of fft2.c:752
+    const int i1 = a.first + t + 1;
+    const bool tail = (t == nseg) && (i1 < a.siz);
+    if (t > nseg || (t == nseg && !tail)) return;
+    const int i0 = a.first + t;
+    float y0 = (float)(1000. * log10((double)(a.ps[i0] * a.yfac[a.itab[t]])));
+    if (t == 0) {
+      int y = (int)(1000. * log10((double)(a.ps[i0] * a.yfac[a.itab[0]])));
+      y0 = (float)y;                                        // yval=y with y already an int (fft2.c:745-746)
+      if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+      a.line[0] = (int16_t)y;
+    }
+    const float r1 = (float)(1000. * log10((double)(a.ps[i1] * a.yfac[a.itab[t + 1]])));
+    const float der = (r1 - y0) / a.hp;
+    float yval = y0;
+    for (int k = t * a.hp + 1; k <= t * a.hp + a.hp; k++) {
+      yval = yval + der;
+      int y = (int)yval;
+      if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+      if (k < a.npix) a.line[k] = (int16_t)y;
+    }
+  } else {
+    if (t >= a.npix) return;
+    int ia = a.first + t * a.hx, ib = ia + a.hx;
+    // reference clamps ib to siz once it reaches it (fft2.c:807-809)
+    if (ia > a.siz) ia = a.siz; if (ib >= a.siz) ib = a.siz;
+    float r2 = 0;
+    for (int i = ia; i < ib; i++) { const float r1 = a.ps[i]; if (r1 > r2) r2 = r1; }
+    int y = (int)(1000. * log10((double)(a.yfac[a.itab[t]] * r2)));
+    if (y < -32767) y = -32767; if (y > 32767) y = 32767;
+    a.line[t] = (int16_t)y;
+  }
+}
+
+// =====================================================================================================
+// mix1
+// =====================================================================================================
+// gather mix1.size bins around mix1_point (mix1.c:955-983), frequency-domain window (mix1.c:113-135), fftback (fft0.c:481)
+template <int LOG2N>
+__global__ __launch_bounds__(fft_threads(LOG2N)) void k_mix1_back(Mix1Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float2 *z = a.fft2 + (size_t)((a.first_nx + b) & a.nx_mask) * a.n2;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int i = (tid + m * T) + s * (N / R0);
+      const int off = i < N / 2 ? i : i - N;                // upper half first, then the lower half
+      const int bin = a.point + off;
+      const int d = off < 0 ? -off : off;
+      const float w = a.fqwin[d == 0 ? N / 2 - 1 : N / 2 - d];
+      float2 v = make_float2(0.f, 0.f);
+      // upper half is cut at the band edge, lower half at bin 0 (mix1.c:956-958, 971-973)
+      if (off >= 0 ? (bin < a.lim_hi) : (bin >= 0)) v = z[bin];
+      x[m * R0 + s] = make_float2(v.x * w, v.y * w);
+    }
+  BlockFft<LOG2N, P, -1>::run(x, lds, a.tw, tid);
+  float2 *o = a.scratch + (size_t)b * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) o[(tid + m * T) + q * (N / RL)] = x[m * RL + q];
+}
+
+// rotate + overlap into timf3 (mix1.c:141-195); phases come from the host's float recursion
+__global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
+{
+  const int half = a.overlap ? a.nm / 2 : a.nm;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= half) return;
+  const int pos = (a.pa_first + b * a.block + i) & a.mask2;
+  if (!a.selected) { a.timf3[pos] = make_float2(0.f, 0.f); return; }     // mix1_clear
+  const float2 nw = a.scratch[(size_t)b * a.nm + i];
+  const float t1 = a.ph_new[(size_t)b * half + i];
+  const float t3 = (float)sin((double)t1), t4 = (float)cos((double)t1);
+  if (!a.overlap) {
+    a.timf3[pos] = make_float2(t4 * nw.x - t3 * nw.y, t4 * nw.y + t3 * nw.x);
+    return;
+  }
+  const float2 old = (b == 0) ? a.timf3[pos] : a.scratch[(size_t)(b - 1) * a.nm + half + i];
+  const float r1 = a.ph_old[(size_t)b * half + i];
+  const float r3 = (float)sin((double)r1), r4 = (float)cos((double)r1);
+  a.timf3[pos] = make_float2(r4 * old.x - r3 * old.y + t4 * nw.x - t3 * nw.y,
+                             r4 * old.y + r3 * old.x + t4 * nw.y + t3 * nw.x);
+  if (b == batch - 1)                                        // raw second half parked at the next block (mix1.c:188-194)
+    a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + half + i];
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+#define LRH_DISPATCH(KERNEL, LOG2N, LO, HI, ...)                                                             \
+  switch (LOG2N) {                                                                                           \
+    case 3: if constexpr (LO <= 3) { KERNEL(3, __VA_ARGS__); } break;                                                  \
+    case 4: if constexpr (LO <= 4) { KERNEL(4, __VA_ARGS__); } break;                                                  \
+    case 5: if constexpr (LO <= 5) { KERNEL(5, __VA_ARGS__); } break;                                                  \
+    case 6: KERNEL(6, __VA_ARGS__); break;                                                                   \
+    case 7: KERNEL(7, __VA_ARGS__); break;                                                                   \
+    case 8: KERNEL(8, __VA_ARGS__); break;                                                                   \
+    case 9: KERNEL(9, __VA_ARGS__); break;                                                                   \
+    case 10: KERNEL(10, __VA_ARGS__); break;                                                                 \
+    case 11: KERNEL(11, __VA_ARGS__); break;                                                                 \
+    case 12: KERNEL(12, __VA_ARGS__); break;                                                                 \
+    case 13: KERNEL(13, __VA_ARGS__); break;                                                                 \
+    case 14: KERNEL(14, __VA_ARGS__); break;                                                                 \
+    default: return hipErrorInvalidValue;                                                                    \
+  }
+
+#define LRH_LAUNCH_FFT1(L, a, batch, st) \
+  hipLaunchKernelGGL((k_fft1<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+#define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
+  do {                                                                                                      \
+    if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(batch), dim3(fft_threads(L)), 0, st, a);      \
+    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0>), dim3(batch), dim3(fft_threads(L)), 0, st, a); \
+    else hipLaunchKernelGGL((k_timf2<L, 2>), dim3(batch), dim3(fft_threads(L)), 0, st, a);                  \
+  } while (0)
+#define LRH_LAUNCH_FFT2(L, a, batch, st) \
+  hipLaunchKernelGGL((k_fft2<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+#define LRH_LAUNCH_MIX1(L, a, batch, st) \
+  hipLaunchKernelGGL((k_mix1_back<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+
+hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_FFT1, log2n, 6, 14, a, batch, st);
+  return hipGetLastError();
+}
+hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
+  return hipGetLastError();
+}
+hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
+  return hipGetLastError();
+}
+hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_MIX1, log2n, 3, 14, a, batch, st);
+  return hipGetLastError();
+}
+hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st)
+{
+  const int half = a.overlap ? a.nm / 2 : a.nm;
+  hipLaunchKernelGGL(k_mix1_out, dim3((half + 255) / 256, batch), dim3(256), 0, st, a, batch);
+  return hipGetLastError();
+}
+hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_sumsq, dim3((a.n + 255) / 256, a.ngroups), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_slowsum, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_powersum2, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
+{
+  int work = a.npix;
+  if (!(a.hx == 1 || a.hp == 1) && a.hx == 0) work = (a.npix - a.hp + a.hp - 1) / a.hp + 1;
+  hipLaunchKernelGGL(k_waterfall, dim3((work + 255) / 256, nlines), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st)
+{
+  if (a.mode != 0) {
+    const int nchunks = (a.total + LRH_BLN_CHUNK - 1) / LRH_BLN_CHUNK;
+    hipLaunchKernelGGL(k_blank_scan, dim3((nchunks + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
+    const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
+    const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
+    hipLaunchKernelGGL(k_blank_apply, dim3((nwords + 255) / 256), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
+  }
+  hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(1), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace lrh

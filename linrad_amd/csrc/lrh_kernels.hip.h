@@ -1,0 +1,98 @@
+// lrh_kernels.hip.h -- argument blocks shared by the kernels (lrh_kernels.hip) and the host side (lrh_host.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lrh {
+
+#define LRH_MAX_GROUPS 32          /* averaging groups / waterfall lines described per launch */
+
+// ---- fft1_b (+ filter correction of fft1_c) ----
+struct Fft1Args {
+  const short2 *timf1;      // interleaved int16 I,Q ring
+  int ring_mask;            // in complex samples
+  int p0_first;             // first sample of transform 0 = timf1p_ref/4 - I1 (fft1.c:421-426)
+  int step;                 // new samples per transform (M1)
+  const float *window;      // natural order, N1 (all ones when sinpow = 0)
+  const float2 *filtercorr; // N1
+  const float2 *tw;         // exp(-2 pi j m/N1)
+  float2 *out;              // fft1_float ring
+  int first_nb, nb_mask;
+  int direction;
+};
+
+// ---- fft1_c power sums ----
+struct GroupDesc { int first_nb; int count; int dst; int accumulate; };
+struct SumsqArgs {
+  const float2 *spec; int nb_mask; int n; float *sumsq; int ngroups; GroupDesc g[LRH_MAX_GROUPS];
+};
+struct SlowDesc { int pa; int ia; int ib; };
+struct SlowsumArgs {
+  const float *sumsq; float *slowsum; int n; int bufsize; int avg2; int nupd; SlowDesc u[LRH_MAX_GROUPS];
+};
+
+// ---- make_timf2 ----
+struct Timf2Args {
+  const float2 *spec; int first_nb, nb_mask;
+  const unsigned int *pack_cur, *pack_prev;   // packed weak flags for the batch / for the transform before it
+  const float2 *tw;
+  float4 *timf2; float *pwr; int pa_first; int mask; int step;
+  int mode;                 // 0: no window, 1: sin^2 overlap-add, 2: centre part x inverted window
+  int ia;                   // interleave/2 for mode 2
+  const float *invwin;      // natural order N1 (mode 2)
+  float ampfac;
+};
+
+// ---- blanker ----
+struct BlankState {          // device resident; mirrors lrh_blanker_state + scratch
+  int noise_floor; unsigned int limit;
+  float despiked_pwr[2]; float despiked_pwrinc[2];
+  float stupid_rate; int cleared_acc; int last_cleared; int slow_calls;
+  int call_cleared;          // scratch: cleared_points of the running call (atomic)
+  int need_slow;             // scratch: a lane found no clean restart point
+};
+struct BlankArgs {
+  float *pwr; float4 *timf2; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
+  int pbeg, total;          // positions pbeg+1 .. pbeg+total are scanned
+  int clr1, clr2;
+  int mode;                 // stupid_bln_mode
+  BlankState *st;
+  float *partials; int npartials;
+  // statistics / update (blank1.c:1472-1601)
+  int m; int nstat;         // m: points counted; nstat: samples in the every-4th sum
+  int blanker_points;       // timf2_blanker_points after adding m
+  int do_update; float lowlevel_fraction; int interval; int avgnum; float factor;
+};
+
+// ---- fft2 ----
+struct Fft2Args {
+  const float4 *timf2; int mask; int px_first; int step;
+  const float *window; const float2 *tw;
+  float2 *out; float *power; int first_na, na_mask;
+};
+struct Powersum2Args {
+  const float *power; int na_mask; int first_na; int count; int n;
+  float *powersum; float *wf_scratch; int counter; int avgnum;
+};
+struct WaterfallArgs {
+  const float *ps; const float *yfac; const int *itab; int16_t *line;
+  int npix; int first; int siz; int hx; int hp;
+  int ptr0; int wf_size; int line_stride;   // line l goes to wg_waterf[(ptr0 - l*npix) mod wf_size], reads ps + l*line_stride
+};
+
+// ---- mix1 ----
+struct Mix1Args {
+  const float2 *fft2; int n2; int first_nx, nx_mask;
+  const float *fqwin; const float2 *tw;
+  float2 *scratch;           // [batch][Nm] raw back transforms
+  int point; int lim_hi;     // bins >= lim_hi are zeroed (mix1.c:957-958), bins < 0 zeroed
+  int nm;
+};
+struct Mix1OutArgs {
+  const float2 *scratch; const float *ph_new, *ph_old;
+  float2 *timf3; int mask2;  // timf3 mask in complex samples
+  int pa_first; int block;   // in complex samples
+  int nm; int overlap; int selected;
+};
+
+}  // namespace lrh

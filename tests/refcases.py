@@ -108,7 +108,7 @@ def lrh_config(d, iq, **kw):
         waterfall_avgnum=d["wf_avgnum"], wf_first_xpoint=d["wf_first"], wf_xpixels=wfpix, wf_mode=d["wf_mode"],
         wf_lines=8, mix1_bandwidth_reduction_n=d["mixred"],
         timf3_size=16 * 2 * max(8, 1 << (d["n2"] - d["mixred"])),
-        fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2), max_batch=64)
+        fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2), max_batch=4)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

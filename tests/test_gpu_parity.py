@@ -1,0 +1,77 @@
+"""GPU: the HIP path (through the C ABI of liblinrad_hip.so) against the reference's golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from paritylib import RINGS, compare_with_golden, load_golden, relerr, run_case
+from refcases import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _open_hip(cfg):
+    from linrad_amd.lib import open_hip
+    return open_hip(cfg)
+
+
+def _open_oracle(cfg):
+    from oracle_binding import open_oracle
+    return open_oracle(cfg)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hip_matches_reference_golden(name):
+    """Same call pattern as the compiled reference, block by block; tolerance 1e-5 relative RMS (north_star)."""
+    g = load_golden(name)
+    out = run_case(_open_hip, name, golden=g)
+    floor_same = np.array_equal(out["itrace"][:, 4], g["itrace"].reshape(-1, 16)[:, 12])
+    rep = compare_with_golden(out, g, tol=1e-5, check_blanker_exact=floor_same, floor_slack=0 if floor_same else 1,
+                              mask_pending_timf2=out["api"].fft1_interleave_points == out["api"].N1 // 2)
+    print(name, rep)
+
+
+@pytest.mark.parametrize("name", ["n8_n10", "n9_n11_sin3", "n11_n9_nowin2"])
+def test_hip_timf2_without_blanker(name):
+    g = load_golden(name)
+    out = run_case(_open_hip, name, golden=g, stupid=0)
+    a, b = out["timf2_float"].copy(), g["timf2_float_noblank"].copy()
+    api = out["api"]
+    if api.fft1_interleave_points == api.N1 // 2:      # pending raw second half beyond timf2_pa: see paritylib
+        idx = (api.p.timf2_pa + np.arange(4 * (api.N1 // 2))) % a.size
+        a[idx] = 0
+        b[idx] = 0
+    assert relerr(a, b) < 1e-5
+    assert relerr(out["timf2_pwr_float"], g["timf2_pwr_float_noblank"]) < 1e-5
+
+
+@pytest.mark.parametrize("name,batch", [("n8_n10", 4), ("n10_n12", 3), ("n11_n9_nowin2", 4)])
+def test_hip_batched_matches_oracle(name, batch):
+    """Batched launches (several fft1 blocks per call, blanker once per batch) against the oracle run the same way."""
+    g = load_golden(name)
+    a = run_case(_open_hip, name, golden=g, batch=batch)
+    b = run_case(_open_oracle, name, golden=g, batch=batch)
+    assert np.array_equal(a["itrace"][:, [0, 1, 2, 3, 6, 7, 8, 9, 10]], b["itrace"][:, [0, 1, 2, 3, 6, 7, 8, 9, 10]])
+    assert np.abs(a["itrace"][:, 4] - b["itrace"][:, 4]).max() <= 1
+    for _, key in RINGS:
+        if key == "timf3_float":
+            continue
+        x, y = a[key], b[key]
+        if key == "timf2_float" and a["api"].fft1_interleave_points == a["api"].N1 // 2:
+            idx = (a["api"].p.timf2_pa + np.arange(4 * (a["api"].N1 // 2))) % x.size
+            x, y = x.copy(), y.copy()
+            x[idx] = 0
+            y[idx] = 0
+        assert relerr(x, y) < 1e-5, key
+    if np.array_equal(a["itrace"][:, 4], b["itrace"][:, 4]):
+        assert np.array_equal(a["timf2_pwr_float"] == 0, b["timf2_pwr_float"] == 0)
+    assert np.abs(a["wf_lines"].astype(int) - b["wf_lines"].astype(int)).max() <= 2
+
+
+def test_hip_tables_match_reference():
+    for name in CASES:
+        g = load_golden(name)
+        out = run_case(_open_hip, name, golden=g)
+        api = out["api"]
+        for t in ("fft1_window", "fft2_window", "mix1_fqwin", "fft1_filtercorr", "wg_waterf_yfac"):
+            got = api.get_table(t, g[t].size)
+            # host tables are built by clang without -ffast-math: allow the last bit against the gcc -ffast-math reference
+            assert np.allclose(got, g[t][:got.size], rtol=3e-7, atol=0), (name, t)
