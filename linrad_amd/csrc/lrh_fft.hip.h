@@ -98,6 +98,16 @@ template <int DIR> struct Dft<DIR, 16> {
 };
 
 // ---- compile-time pass plan -------------------------------------------------------------
+// points per thread: 16 from N = 1024 up, 4 below.
+// Measured on MI355X (round 1): 32 points/thread + half-round exchanges at N = 16384 (512 threads, 68 KiB LDS, two
+// workgroups per CU) needs > 128 VGPRs, spills ~130 registers and runs 1.7-2.2x SLOWER than 16 points x 1024
+// threads with one workgroup per CU; the half-round path stays available (fft_halves) but is not selected.
+__host__ __device__ constexpr int points_per_thread(int log2n) { return log2n >= 10 ? 16 : 4; }
+__host__ __device__ constexpr int fft_halves(int log2n) { return 1; }
+__host__ __device__ constexpr int fft_threads(int log2n) { return (1 << log2n) / points_per_thread(log2n); }
+// waves per SIMD to ask for in __launch_bounds__ (N = 8192: two 512-thread workgroups per CU)
+__host__ __device__ constexpr int fft_min_waves(int log2n) { return log2n == 13 ? 4 : 1; }
+
 template <int LOG2N, int P> struct FftPlan {
   static constexpr int N = 1 << LOG2N;
   static constexpr int T = N / P;                       // threads per workgroup
@@ -105,12 +115,14 @@ template <int LOG2N, int P> struct FftPlan {
   static constexpr int FULL = LOG2N / MAXLOG;
   static constexpr int REM = LOG2N % MAXLOG;
   static constexpr int NPASS = FULL + (REM ? 1 : 0);
+  static constexpr int HALVES = fft_halves(LOG2N);
   __host__ __device__ static constexpr int radix(int pass) { return pass < FULL ? (1 << MAXLOG) : (1 << REM); }
   __host__ __device__ static constexpr int done(int pass) { int p = 1; for (int i = 0; i < pass; i++) p *= radix(i); return p; }
   static constexpr int R0 = FULL > 0 ? (1 << MAXLOG) : (1 << REM);
   static constexpr int RL = REM ? (1 << REM) : (1 << MAXLOG);
-  static constexpr int LDS_CELLS = N + (N >> 4);        // float2 cells incl. padding
+  static constexpr int LDS_CELLS = (N + (N >> 4)) / HALVES;   // float2 cells incl. padding
   static_assert(P % R0 == 0 && P % RL == 0, "P must be a multiple of every radix");
+  static_assert(HALVES == 1 || ((P / R0) % 2 == 0 && (P / RL) % 2 == 0), "half-round exchange needs an even butterfly count");
 };
 
 __device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
@@ -120,9 +132,14 @@ __device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
 //   out: x[m*RL + q] = output[(tid + m*T) + q*(N/RL)]     m < P/RL, q < RL
 // tw[m] = exp(-2 pi j m / N), m in [0, N) (forward table; DIR=+1 conjugates it).
 // `lds` must hold FftPlan::LDS_CELLS float2. The caller must __syncthreads() before reusing lds.
+//
+// Half-round exchange (HALVES = 2): output cell p*(a*R+q)+k of butterfly i = a*p+k lies in the lower half of the
+// sequence exactly when i < N/(2R), i.e. for the first half of every thread's butterflies, and the next pass reads
+// cell i' + s*N/R' from the lower half exactly for s < R'/2.  So the redistribution splits into two independent
+// rounds that each move N/2 cells through the same N/2-cell buffer.
 template <int LOG2N, int P, int DIR> struct BlockFft {
   using Plan = FftPlan<LOG2N, P>;
-  static constexpr int N = Plan::N, T = Plan::T;
+  static constexpr int N = Plan::N, T = Plan::T, HALVES = Plan::HALVES;
 
   template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid)
   {
@@ -136,40 +153,64 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
         const int i = tid + m * T;
         const int k = i & (p - 1);
         const int base = k * (N / (p * R));
+        if constexpr (R == 16) {
+          // w^(4a+b) = w^(4a) * w^b: six table gathers instead of fifteen, one extra rounding
+          float2 wl[4], wh[4];
 #pragma unroll
-        for (int s = 1; s < R; s++) u[s] = cmul(u[s], tw_dir<DIR>(tw[s * base]));
+          for (int b = 1; b < 4; b++) { wl[b] = tw_dir<DIR>(tw[b * base]); wh[b] = tw_dir<DIR>(tw[4 * b * base]); }
+#pragma unroll
+          for (int s = 1; s < 16; s++) {
+            const int a = s >> 2, b = s & 3;
+            const float2 w = a == 0 ? wl[b] : (b == 0 ? wh[a] : cmul(wh[a], wl[b]));
+            u[s] = cmul(u[s], w);
+          }
+        } else if constexpr (R == 8) {
+          float2 wl[4];
+#pragma unroll
+          for (int b = 1; b < 4; b++) wl[b] = tw_dir<DIR>(tw[b * base]);
+          const float2 w4 = tw_dir<DIR>(tw[4 * base]);
+#pragma unroll
+          for (int s = 1; s < 8; s++) {
+            const float2 w = s < 4 ? wl[s] : (s == 4 ? w4 : cmul(w4, wl[s - 4]));
+            u[s] = cmul(u[s], w);
+          }
+        } else {
+#pragma unroll
+          for (int s = 1; s < R; s++) u[s] = cmul(u[s], tw_dir<DIR>(tw[s * base]));
+        }
       }
       Dft<DIR, R>::run(u);
     }
     if constexpr (PASS + 1 < Plan::NPASS) {
       constexpr int R2 = Plan::radix(PASS + 1);
       constexpr int NB2 = P / R2;
-      if constexpr (PASS > 0) __syncthreads();           // previous exchange's reads are done
+      float2 xn[P];
 #pragma unroll
-      for (int m = 0; m < NB; m++) {
-        const int i = tid + m * T;
-        const int k = i & (p - 1);
-        const int j = (i - k) * R + k;
+      for (int h = 0; h < HALVES; h++) {
+        if (PASS > 0 || h > 0) __syncthreads();          // reads of the previous round are done
 #pragma unroll
-        for (int q = 0; q < R; q++) lds[lds_pad(j + q * p)] = x[m * R + q];
+        for (int m = h * NB / HALVES; m < (h + 1) * NB / HALVES; m++) {
+          const int i = tid + m * T;
+          const int k = i & (p - 1);
+          const int j = (i - k) * R + k - h * (N / 2);
+#pragma unroll
+          for (int q = 0; q < R; q++) lds[lds_pad(j + q * p)] = x[m * R + q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < NB2; m++) {
+          const int i = tid + m * T - h * (N / 2);
+#pragma unroll
+          for (int s = h * R2 / HALVES; s < (h + 1) * R2 / HALVES; s++) xn[m * R2 + s] = lds[lds_pad(i + s * (N / R2))];
+        }
       }
-      __syncthreads();
 #pragma unroll
-      for (int m = 0; m < NB2; m++) {
-        const int i = tid + m * T;
-#pragma unroll
-        for (int s = 0; s < R2; s++) x[m * R2 + s] = lds[lds_pad(i + s * (N / R2))];
-      }
+      for (int e = 0; e < P; e++) x[e] = xn[e];
       pass<PASS + 1>(x, lds, tw, tid);
     }
   }
 
   __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid) { pass<0>(x, lds, tw, tid); }
 };
-
-// points per thread for a given size: 16 from N = 1024 up, 4 below
-__host__ __device__ constexpr int points_per_thread(int log2n) { return log2n >= 10 ? 16 : 4; }
-
-__host__ __device__ constexpr int fft_threads(int log2n) { return (1 << log2n) / points_per_thread(log2n); }
 
 }  // namespace lrh

@@ -51,7 +51,7 @@ struct lrh_ctx {
   short2 *d_timf1 = nullptr;
   float2 *d_fft1 = nullptr; float *d_sumsq = nullptr, *d_slowsum = nullptr;
   float4 *d_timf2 = nullptr; float *d_pwr = nullptr; unsigned int *d_blnbits = nullptr;
-  float2 *d_fft2 = nullptr; float *d_power2 = nullptr, *d_powersum2 = nullptr, *d_wf_scratch = nullptr;
+  float2 *d_fft2 = nullptr; float *d_power2 = nullptr, *d_powersum2 = nullptr, *d_powersum2_alt = nullptr, *d_wf_scratch = nullptr;
   int16_t *d_waterf = nullptr;
   float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
   float *d_ph = nullptr;              // phase tables [LRH_NSTAGE][2][max_fft2 batch][half]
@@ -218,7 +218,7 @@ void lrh_close(lrh_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2, c->d_pwr,
-                  c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
+                  c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -306,7 +306,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   A(dev_alloc(c, &c->d_timf2, cfg->timf2pow_size)); A(dev_alloc(c, &c->d_pwr, cfg->timf2pow_size));
   A(dev_alloc(c, &c->d_blnbits, cfg->timf2pow_size / 32 + 64));
   A(dev_alloc(c, &c->d_fft2, (size_t)cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_power2, (size_t)cfg->max_fft2n * N2));
-  A(dev_alloc(c, &c->d_powersum2, N2)); A(dev_alloc(c, &c->d_wf_scratch, (size_t)(cfg->max_fft2n + 1) * N2));
+  A(dev_alloc(c, &c->d_powersum2, N2)); A(dev_alloc(c, &c->d_powersum2_alt, N2)); A(dev_alloc(c, &c->d_wf_scratch, (size_t)(cfg->max_fft2n + 1) * N2));
   A(dev_alloc(c, &c->d_waterf, (size_t)cfg->wf_lines * cfg->wf_xpixels + 64));
   A(dev_alloc(c, &c->d_timf3, cfg->timf3_size / 2 + c->Nm)); A(dev_alloc(c, &c->d_mix_scratch, (size_t)cfg->max_fft2n * c->Nm));
   c->ph_stride = (size_t)2 * cfg->max_fft2n * c->Nm;
@@ -366,7 +366,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 {
   if (!c || !liminfo) return LRH_EINVAL;
   // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
-  const int P = c->cfg.fft1_n >= 10 ? 16 : 4, R0 = P >= 16 ? 16 : 4;
+  const int R0 = c->cfg.fft1_n >= 10 ? 16 : 4;        // first-pass radix of the N1 transform (lrh_fft.hip.h)
   const int nb = c->N1 / R0;
   std::vector<unsigned int> pack(c->N1, 0u);
   int low = 0;
@@ -442,40 +442,30 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  const int N = c->N1, avg1 = c->cfg.fft_avg1num;
-  SumsqArgs sa; sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.ngroups = 0;
-  SlowsumArgs ua; ua.sumsq = c->d_sumsq; ua.slowsum = c->d_slowsum; ua.n = N; ua.bufsize = c->cfg.fft1_sumsq_bufsize; ua.avg2 = c->cfg.fft_avg2num; ua.nupd = 0;
-  auto flush = [&]() -> int {
-    if (sa.ngroups) { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->stream)); sa.ngroups = 0; }
-    if (ua.nupd) { ProfScope ps(c, "slowsum"); HIPCHK(c, launch_slowsum(ua, c->stream)); ua.nupd = 0; }
-    return LRH_OK;
-  };
-  int b = 0;
-  while (b < batch) {
-    int take = avg1 - p->fft1_sumsq_counter; if (take > batch - b) take = batch - b;
-    GroupDesc &g = sa.g[sa.ngroups++];
-    g.first_nb = p->fft1_nb; g.count = take; g.dst = p->fft1_sumsq_pa; g.accumulate = p->fft1_sumsq_counter != 0;
-    p->fft1_sumsq_counter += take;
-    p->fft1_nb = (p->fft1_nb + take) & c->fft1n_mask; p->fft1_pb = p->fft1_nb * 2 * N;
-    b += take;
-    if (p->fft1_sumsq_counter >= avg1) {
-      p->fft1_sumsq_counter = 0;
-      // update_fft1_slowsum window bookkeeping (fft1.c:4568-4573)
-      const int last = N - 1;
+  const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
+  if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
+    return fail(c, LRH_EINVAL, "fft1_sumsq ring too short for this batch");
+  SumsqArgs sa;
+  sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.sumsq_mask = c->sumsq_mask;
+  sa.first_nb = p->fft1_nb; sa.batch = batch; sa.avg = avg1; sa.c0 = p->fft1_sumsq_counter; sa.pa0 = p->fft1_sumsq_pa;
+  { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->stream)); }
+  const int nupd = (p->fft1_sumsq_counter + batch) / avg1;              // groups completed by this batch
+  if (nupd > 0) {
+    SlowsumArgs ua;
+    ua.sumsq = c->d_sumsq; ua.slowsum = c->d_slowsum; ua.n = N; ua.bufsize = c->cfg.fft1_sumsq_bufsize; ua.avg2 = c->cfg.fft_avg2num;
+    ua.nupd = nupd; ua.pa0 = p->fft1_sumsq_pa; ua.recalc0 = p->fft1_sumsq_recalc; ua.step = c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
+    ProfScope ps(c, "slowsum");
+    HIPCHK(c, launch_slowsum(ua, c->stream));
+    for (int e = 0; e < nupd; e++) {                                     // same recursion as the kernel (fft1.c:4568-4573)
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
-      SlowDesc &u = ua.u[ua.nupd++];
-      u.pa = p->fft1_sumsq_pa; u.ia = p->fft1_sumsq_recalc;
-      p->fft1_sumsq_recalc += c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
-      if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
-      u.ib = p->fft1_sumsq_recalc;
-      p->fft1_liminfo_cnt++;
-      p->fft1_sumsq_pa = (p->fft1_sumsq_pa + N) & c->sumsq_mask;
-      // the slow sum of group e reads sumsq written by this launch: keep launches ordered group by group
-      int rc = flush(); if (rc) return rc;
+      p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
     }
-    if (sa.ngroups == LRH_MAX_GROUPS) { int rc = flush(); if (rc) return rc; }
+    p->fft1_liminfo_cnt += nupd;
+    p->fft1_sumsq_pa = (p->fft1_sumsq_pa + nupd * N) & c->sumsq_mask;
   }
-  return flush();
+  p->fft1_sumsq_counter = (p->fft1_sumsq_counter + batch) % avg1;
+  p->fft1_nb = (p->fft1_nb + batch) & c->fft1n_mask; p->fft1_pb = p->fft1_nb * 2 * N;
+  return LRH_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- timf2
@@ -560,7 +550,8 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
-  s.powersum = c->d_powersum2; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
+  s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
+  { float *t = c->d_powersum2; c->d_powersum2 = c->d_powersum2_alt; c->d_powersum2_alt = t; }   // ping-pong: group 0 reads while the last group writes
   { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->stream)); }
   const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
   if (nlines > 0) {

@@ -20,7 +20,7 @@ namespace lrh {
 // fft1
 // =====================================================================================================
 template <int LOG2N>
-__global__ __launch_bounds__(fft_threads(LOG2N)) void k_fft1(Fft1Args a)
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft1(Fft1Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
@@ -60,27 +60,47 @@ __global__ __launch_bounds__(256) void k_sumsq(SumsqArgs a)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const GroupDesc g = a.g[blockIdx.y];
-  float acc = g.accumulate ? a.sumsq[g.dst + i] : 0.0f;
-  for (int j = 0; j < g.count; j++) {
-    const float2 z = a.spec[(size_t)((g.first_nb + j) & a.nb_mask) * a.n + i];
+  const int g = blockIdx.y;
+  const int start = g == 0 ? 0 : g * a.avg - a.c0;
+  int count = a.avg - (g == 0 ? a.c0 : 0);
+  if (count > a.batch - start) count = a.batch - start;
+  const bool accumulate = g == 0 && a.c0 > 0;
+  float *dst = a.sumsq + ((a.pa0 + g * a.n) & a.sumsq_mask);
+  float acc = accumulate ? dst[i] : 0.0f;
+  for (int j = 0; j < count; j++) {
+    const float2 z = a.spec[(size_t)((a.first_nb + start + j) & a.nb_mask) * a.n + i];
     const float pw = z.x * z.x + z.y * z.y;
-    acc = (j == 0 && !g.accumulate) ? pw : acc + pw;
+    acc = (j == 0 && !accumulate) ? pw : acc + pw;      // "=" for the first spectrum of a group, "+=" after (fft1.c:4126, 4169)
   }
-  a.sumsq[g.dst + i] = acc;
+  dst[i] = acc;
 }
 
 #define LRH_FFT1_SMALL 0.00000001F
-__global__ __launch_bounds__(256) void k_slowsum(SlowsumArgs a)
+__global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n) return;
-  const int mask = a.bufsize - 1;
-  float slow = a.slowsum[i];
+  const int mask = a.bufsize - 1, last = a.n - 1;
+  // Every update recomputes a rolling window of bins from scratch (fft1.c:4567-4573), which overwrites the running
+  // value there.  The value after the batch therefore depends only on the bin's last refresh and the sliding
+  // updates after it: find that update first (integer bookkeeping only), then replay from it.
+  int e_start = 0, recalc = a.recalc0, recalc_at_start = a.recalc0; bool refreshed = false;
   for (int e = 0; e < a.nupd; e++) {
-    const SlowDesc u = a.u[e];
-    if (i >= u.ia && i <= u.ib) {                      // from scratch over the window (wide_graph.c:1016-1031)
-      int p0 = (u.pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
+    const int before = recalc;
+    if (recalc == last) recalc = 0;
+    const int ia = recalc;
+    recalc += a.step; if (recalc > last) recalc = last;
+    if (i >= ia && i <= recalc) { e_start = e; recalc_at_start = before; refreshed = true; }
+  }
+  float slow = refreshed ? 0.f : a.slowsum[i];
+  recalc = recalc_at_start;
+  for (int e = e_start; e < a.nupd; e++) {
+    const int pa = (a.pa0 + e * a.n) & mask;
+    if (recalc == last) recalc = 0;
+    const int ia = recalc;
+    recalc += a.step; if (recalc > last) recalc = last;
+    if (i >= ia && i <= recalc) {                      // from scratch over the window (wide_graph.c:1016-1031)
+      int p0 = (pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
       slow = a.sumsq[p0 + i];
       p0 = (p0 + a.n) & mask;
       for (int m = 1; m < a.avg2; m++) {
@@ -89,8 +109,8 @@ __global__ __launch_bounds__(256) void k_slowsum(SlowsumArgs a)
         p0 = (p0 + a.n) & mask;
       }
     } else {                                           // sliding update (fft1.c:4574-4583)
-      const int pb = (u.pa - a.avg2 * a.n + a.bufsize) & mask;
-      slow += a.sumsq[u.pa + i] - a.sumsq[pb + i];
+      const int pb = (pa - a.avg2 * a.n + a.bufsize) & mask;
+      slow += a.sumsq[pa + i] - a.sumsq[pb + i];
       if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL;
     }
   }
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(256) void k_slowsum(SlowsumArgs a)
 //     out_t[n] = ampfac * DFT( S_t + (-1)^k S_{t-1} )[n],  n < N/2
 // i.e. one transform of the combined spectrum, written once -- no read-modify-write of the timf2 ring.
 template <int LOG2N, int MODE>
-__global__ __launch_bounds__(fft_threads(LOG2N)) void k_timf2(Timf2Args a)
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_timf2(Timf2Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
@@ -197,8 +217,26 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
   return 0;
 }
 
+__device__ __forceinline__ int bln_lds(int idx) { return idx + (idx >> 6); }   // lane stride 65 floats: conflict-free
+
 __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 {
+  // the workgroup's 256 chunks plus the look-back halo, staged once with coalesced loads
+  constexpr int TILE = 256 * LRH_BLN_CHUNK + LRH_BLN_BACK;
+  __shared__ float tile[TILE + TILE / 64 + 4];
+  const int q0 = blockIdx.x * 256 * LRH_BLN_CHUNK + 1 - LRH_BLN_BACK;      // sequence position of tile[0]
+  static_assert(TILE % (256 * 13) == 0, "staging loop is unrolled 13 loads deep");
+  for (int i0 = 0; i0 < TILE; i0 += 256 * 13) {          // 13 independent loads in flight per thread
+    float v[13];
+#pragma unroll
+    for (int u = 0; u < 13; u++) {
+      const int q = q0 + i0 + u * 256 + threadIdx.x;
+      v[u] = (q >= 1 && q <= a.total) ? a.pwr[(a.pbeg + q) & a.mask] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 13; u++) tile[bln_lds(i0 + u * 256 + threadIdx.x)] = v[u];
+  }
+  __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int cs = c * LRH_BLN_CHUNK + 1;
   if (cs > a.total) return;
@@ -209,10 +247,10 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   {
     int run = 0, steps = 0, q = cs - 1; bool found = false;
     while (q >= 1) {
-      const float v = a.pwr[(a.pbeg + q) & a.mask];
+      const float v = tile[bln_lds(q - q0)];
       if (v > nfl) run = 0; else if (++run >= G) { found = true; break; }
       q--;
-      if (++steps > LRH_BLN_BACK) break;
+      if (++steps >= LRH_BLN_BACK) break;
     }
     if (found) s = q + G;
     else if (q >= 1) { a.st->need_slow = 1; return; }  // no clean point in reach: exact serial pass takes over
@@ -221,7 +259,7 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   float pulmax = 0;
   for (int q = s; q <= ce; q++) {
     const int p = (a.pbeg + q) & a.mask;
-    const float v = a.pwr[p];
+    const float v = tile[bln_lds(q - q0)];
     if (v > nfl && q >= erase_end) {
       if (ifirst == 0) pk = q;
       if (v > pulmax) pulmax = v;
@@ -310,13 +348,16 @@ __global__ __launch_bounds__(256) void k_blank_stats(BlankArgs a)
 // scalar bookkeeping of blank1.c:1472-1601 (1 channel); host supplies everything that does not depend on data
 __global__ void k_blank_update(BlankArgs a)
 {
+  // partial sums in a fixed order: lane l adds partials l, l+64, ..., then a butterfly over the wave
+  double tot = 0;
+  for (int i = threadIdx.x; i < a.npartials; i += 64) tot += reinterpret_cast<double *>(a.partials)[i];
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+  if (threadIdx.x != 0) return;
   BlankState *s = a.st;
   const int cleared = s->call_cleared;
   s->call_cleared = 0;
   s->last_cleared = cleared;
   s->cleared_acc += cleared;
-  double tot = 0;
-  for (int i = 0; i < a.npartials; i++) tot += reinterpret_cast<double *>(a.partials)[i];
   int k = a.m - cleared; if (k < a.m / 25) k = a.m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
   float t1 = (float)tot;
   t1 /= k; if (t1 < 10) t1 = 10;
@@ -348,7 +389,7 @@ __global__ void k_blank_update(BlankArgs a)
 // fft2 (one workgroup per transform, N2 <= 16384)
 // =====================================================================================================
 template <int LOG2N>
-__global__ __launch_bounds__(fft_threads(LOG2N)) void k_fft2(Fft2Args a)
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft2(Fft2Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
@@ -381,19 +422,25 @@ __global__ __launch_bounds__(fft_threads(LOG2N)) void k_fft2(Fft2Args a)
     }
 }
 
-// fft2_powersum_float over a batch in transform order; completed waterfall groups are parked in wf_scratch
+// fft2_powersum_float (fft2.c:655-670): group g = one waterfall averaging period; complete groups are parked in
+// wf_scratch for k_waterfall, the last (possibly partial) group is what fft2_powersum_float holds afterwards.
 __global__ __launch_bounds__(256) void k_powersum2(Powersum2Args a)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  int cnt = a.counter, line = 0;
-  float acc = cnt > 0 ? a.powersum[i] : 0.f;
-  for (int b = 0; b < a.count; b++) {
-    const float pw = a.power[(size_t)((a.first_na + b) & a.na_mask) * a.n + i];
-    acc = (cnt == 0) ? pw : acc + pw;
-    if (++cnt >= a.avgnum) { a.wf_scratch[(size_t)line * a.n + i] = acc; line++; cnt = 0; }
+  const int g = blockIdx.y;
+  const int start = g == 0 ? 0 : g * a.avgnum - a.counter;
+  int count = a.avgnum - (g == 0 ? a.counter : 0);
+  const bool complete = count <= a.count - start;
+  if (!complete) count = a.count - start;
+  const bool accumulate = g == 0 && a.counter > 0;
+  float acc = accumulate ? a.powersum_in[i] : 0.f;
+  for (int b = 0; b < count; b++) {
+    const float pw = a.power[(size_t)((a.first_na + start + b) & a.na_mask) * a.n + i];
+    acc = (b == 0 && !accumulate) ? pw : acc + pw;
   }
-  a.powersum[i] = acc;
+  if (complete) a.wf_scratch[(size_t)g * a.n + i] = acc;
+  if (g == (int)gridDim.y - 1) a.powersum_out[i] = acc;
 }
 
 // one waterfall line, 0.01 dB shorts (fft2.c:707-812); itab[] holds the reference's float-accumulated yfac index
@@ -452,7 +499,7 @@ __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
 // =====================================================================================================
 // gather mix1.size bins around mix1_point (mix1.c:955-983), frequency-domain window (mix1.c:113-135), fftback (fft0.c:481)
 template <int LOG2N>
-__global__ __launch_bounds__(fft_threads(LOG2N)) void k_mix1_back(Mix1Args a)
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mix1_back(Mix1Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
@@ -569,17 +616,19 @@ hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st)
 }
 hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_sumsq, dim3((a.n + 255) / 256, a.ngroups), dim3(256), 0, st, a);
+  const int ngroups = (a.c0 + a.batch + a.avg - 1) / a.avg;
+  hipLaunchKernelGGL(k_sumsq, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_slowsum, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_slowsum, dim3((a.n + 63) / 64), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_powersum2, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+  const int ngroups = (a.counter + a.count + a.avgnum - 1) / a.avgnum;
+  hipLaunchKernelGGL(k_powersum2, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
@@ -600,7 +649,7 @@ hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st)
     hipLaunchKernelGGL(k_blank_apply, dim3((nwords + 255) / 256), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
   }
   hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(1), 0, st, a);
+  hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -5,7 +5,6 @@
 
 namespace lrh {
 
-#define LRH_MAX_GROUPS 32          /* averaging groups / waterfall lines described per launch */
 
 // ---- fft1_b (+ filter correction of fft1_c) ----
 struct Fft1Args {
@@ -22,13 +21,15 @@ struct Fft1Args {
 };
 
 // ---- fft1_c power sums ----
-struct GroupDesc { int first_nb; int count; int dst; int accumulate; };
+// Averaging groups are derived in-kernel: group g covers transforms [g*avg - c0, ...) of the batch (the first one
+// continues a group started by an earlier call when c0 > 0) and lands in sumsq block (pa0 + g*n) & mask.
 struct SumsqArgs {
-  const float2 *spec; int nb_mask; int n; float *sumsq; int ngroups; GroupDesc g[LRH_MAX_GROUPS];
+  const float2 *spec; int nb_mask; int n; float *sumsq; int sumsq_mask;
+  int first_nb; int batch; int avg; int c0; int pa0;
 };
-struct SlowDesc { int pa; int ia; int ib; };
 struct SlowsumArgs {
-  const float *sumsq; float *slowsum; int n; int bufsize; int avg2; int nupd; SlowDesc u[LRH_MAX_GROUPS];
+  const float *sumsq; float *slowsum; int n; int bufsize; int avg2;
+  int nupd; int pa0; int recalc0; int step;
 };
 
 // ---- make_timf2 ----
@@ -72,7 +73,7 @@ struct Fft2Args {
 };
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
-  float *powersum; float *wf_scratch; int counter; int avgnum;
+  const float *powersum_in; float *powersum_out; float *wf_scratch; int counter; int avgnum;
 };
 struct WaterfallArgs {
   const float *ps; const float *yfac; const int *itab; int16_t *line;

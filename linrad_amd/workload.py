@@ -29,7 +29,7 @@ def chain_config(fft1_n=14, fft2_n=12, batch=256, device=0, fq_bin=None):
     cfg = default_config(
         fft1_n, fft2_n, device=device, fft1_gain=level_gain(fft1_n, 6), bckfft_att_n=6,
         timf1_bytes=pow2(4 * (samples_per_batch + 2 * N1)) * 2, max_fft1n=pow2(2 * batch),
-        fft1_sumsq_bufsize=8 * N1, timf2pow_size=pow2(4 * max(samples_per_batch, 2 * N2)),
+        fft1_sumsq_bufsize=pow2(batch // 5 + 4 + 4) * N1, timf2pow_size=pow2(4 * max(samples_per_batch, 2 * N2)),
         max_fft2n=pow2(k_fft2), waterfall_avgnum=8, wf_xpixels=min(N2, 1024), wf_lines=64,
         timf2_noise_floor_avgnum=avgnum, blanker_info_update_interval=max(1, avgnum // 8),
         blanker_min_points=N2 // 3, mix1_bandwidth_reduction_n=6,
