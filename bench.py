@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from linrad_amd import abi  # noqa: E402
+from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newest_sumsq_block  # noqa: E402
 from linrad_amd.workload import (ALG_BYTES, ALG_BYTES_CHAIN, HBM_PEAK_GBS, chain_config, strong_liminfo)  # noqa: E402
 
 
@@ -54,9 +55,9 @@ def cpu_baseline(args, fft1_n, fft2_n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fft1-n", type=int, default=14)
     ap.add_argument("--fft2-n", type=int, default=12)
     ap.add_argument("--cpu-blocks", type=int, default=6144)
@@ -76,7 +77,7 @@ def main():
 
     cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
     N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
-    rx = setup_receiver(cfg, rank, hiplib.open_hip, hiplib)
+    rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
     samples_per_step = args.batch * M1
     xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
 
@@ -84,9 +85,8 @@ def main():
         rx.wideband_dsp(args.batch, args.batch)
         if world > 1:
             # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
-            pa = (rx.p.fft1_sumsq_pa - N1) & (cfg.fft1_sumsq_bufsize - 1)
-            rx.export_device(abi.RING_FFT1_SUMSQ, xchg.data_ptr(), pa, N1)
-            dist.all_reduce(xchg)
+            rx.export_device(abi.RING_FFT1_SUMSQ, xchg.data_ptr(), newest_sumsq_block(rx), N1)
+            cross_channel_power_sum(xchg, dist)
 
     def barrier():
         rx.sync()

@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py -- one RF channel per rank, all-reduce of the channel power sums."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from linrad_amd import abi
+    from linrad_amd.lib import synth_defaults, synth_iq
+    from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newest_sumsq_block
+    from linrad_amd.workload import chain_config, strong_liminfo
+    from oracle_binding import open_oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = chain_config(fft1_n=10, fft2_n=8, batch=8)
+    s = synth_defaults(1 << cfg.fft1_n, channel_of_rank(rank))
+    rx = open_oracle(cfg)                       # CPU stand-in for the per-GPU receiver; same StageAPI
+    rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+    rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
+    rx.wideband_dsp(10, 5)                      # completes two averaging periods (fft_avg1num = 5)
+    own = rx.export(abi.RING_FFT1_SUMSQ, newest_sumsq_block(rx), rx.N1)
+    t = torch.from_numpy(own.copy())
+    cross_channel_power_sum(t, dist)
+    gathered = [torch.zeros(rx.N1) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(own.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, t.numpy(), [g.numpy() for g in gathered]))
+
+
+def test_two_channel_power_sum_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    (_, sum0, parts0), (_, sum1, parts1) = res
+    # both ranks hold the same cross-channel sum, equal to the two per-channel spectra added (fft1.c:4145)
+    assert np.array_equal(sum0, sum1)
+    assert np.allclose(sum0, parts0[0] + parts0[1], rtol=1e-6)
+    # the channels really are different signals (independent noise, rotated carriers)
+    assert not np.allclose(parts0[0], parts0[1], rtol=1e-3)
+    assert np.all(sum0 >= 0) and np.count_nonzero(sum0) >= sum0.size - 2      # the two edge bins are filtered to zero
