@@ -140,7 +140,7 @@ typedef enum lrh_ring {
   LRH_RING_FFT1_FLOAT,          /* float [max_fft1n][N1][2]                                        */
   LRH_RING_FFT1_SUMSQ,          /* float [fft1_sumsq_bufsize]                                      */
   LRH_RING_FFT1_SLOWSUM,        /* float [N1]                                                      */
-  LRH_RING_TIMF2_FLOAT,         /* float [timf2pow_size][4] {wRe,wIm,sRe,sIm}                      */
+  LRH_RING_TIMF2_FLOAT,         /* float [timf2pow_size][4] {wRe,wIm,sRe,sIm}; offset/count multiples of 4 */
   LRH_RING_TIMF2_PWR,           /* float [timf2pow_size]                                           */
   LRH_RING_FFT2_FLOAT,          /* float [max_fft2n][N2][2]                                        */
   LRH_RING_FFT2_POWER,          /* float [max_fft2n][N2]                                           */

@@ -141,42 +141,65 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
   using Plan = FftPlan<LOG2N, P>;
   static constexpr int N = Plan::N, T = Plan::T, HALVES = Plan::HALVES;
 
-  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid)
+  // twiddles of one pass, fetched before the LDS exchange that feeds it so their L2 latency hides behind the exchange
+  template <int PASS> struct Tw {
+    static constexpr int R = Plan::radix(PASS);
+    static constexpr int PER = R == 16 ? 6 : (R == 8 ? 4 : R - 1);
+    static constexpr int NB = P / R;
+    float2 w[PER * NB > 0 ? PER * NB : 1];
+  };
+  template <int PASS> __device__ __forceinline__ static void load_tw(Tw<PASS> &t, const float2 *__restrict__ tw, int tid)
   {
     constexpr int R = Plan::radix(PASS);
     constexpr int p = Plan::done(PASS);
-    constexpr int NB = P / R;                            // butterflies per thread
+    constexpr int NB = P / R, PER = Tw<PASS>::PER;
+    if constexpr (p > 1) {
 #pragma unroll
-    for (int m = 0; m < NB; m++) {
-      float2 *u = &x[m * R];
-      if constexpr (p > 1) {
+      for (int m = 0; m < NB; m++) {
         const int i = tid + m * T;
         const int k = i & (p - 1);
         const int base = k * (N / (p * R));
         if constexpr (R == 16) {
-          // w^(4a+b) = w^(4a) * w^b: six table gathers instead of fifteen, one extra rounding
-          float2 wl[4], wh[4];
 #pragma unroll
-          for (int b = 1; b < 4; b++) { wl[b] = tw_dir<DIR>(tw[b * base]); wh[b] = tw_dir<DIR>(tw[4 * b * base]); }
+          for (int b = 1; b < 4; b++) { t.w[m * PER + b - 1] = tw_dir<DIR>(tw[b * base]); t.w[m * PER + 2 + b] = tw_dir<DIR>(tw[4 * b * base]); }
+        } else if constexpr (R == 8) {
+#pragma unroll
+          for (int b = 1; b < 4; b++) t.w[m * PER + b - 1] = tw_dir<DIR>(tw[b * base]);
+          t.w[m * PER + 3] = tw_dir<DIR>(tw[4 * base]);
+        } else {
+#pragma unroll
+          for (int s = 1; s < R; s++) t.w[m * PER + s - 1] = tw_dir<DIR>(tw[s * base]);
+        }
+      }
+    }
+  }
+
+  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid, const Tw<PASS> &t)
+  {
+    constexpr int R = Plan::radix(PASS);
+    constexpr int p = Plan::done(PASS);
+    constexpr int NB = P / R, PER = Tw<PASS>::PER;       // butterflies per thread
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      float2 *u = &x[m * R];
+      if constexpr (p > 1) {
+        if constexpr (R == 16) {
+          // w^(4a+b) = w^(4a) * w^b: six table gathers instead of fifteen, one extra rounding
 #pragma unroll
           for (int s = 1; s < 16; s++) {
             const int a = s >> 2, b = s & 3;
-            const float2 w = a == 0 ? wl[b] : (b == 0 ? wh[a] : cmul(wh[a], wl[b]));
+            const float2 w = a == 0 ? t.w[m * PER + b - 1] : (b == 0 ? t.w[m * PER + 2 + a] : cmul(t.w[m * PER + 2 + a], t.w[m * PER + b - 1]));
             u[s] = cmul(u[s], w);
           }
         } else if constexpr (R == 8) {
-          float2 wl[4];
-#pragma unroll
-          for (int b = 1; b < 4; b++) wl[b] = tw_dir<DIR>(tw[b * base]);
-          const float2 w4 = tw_dir<DIR>(tw[4 * base]);
 #pragma unroll
           for (int s = 1; s < 8; s++) {
-            const float2 w = s < 4 ? wl[s] : (s == 4 ? w4 : cmul(w4, wl[s - 4]));
+            const float2 w = s < 4 ? t.w[m * PER + s - 1] : (s == 4 ? t.w[m * PER + 3] : cmul(t.w[m * PER + 3], t.w[m * PER + s - 5]));
             u[s] = cmul(u[s], w);
           }
         } else {
 #pragma unroll
-          for (int s = 1; s < R; s++) u[s] = cmul(u[s], tw_dir<DIR>(tw[s * base]));
+          for (int s = 1; s < R; s++) u[s] = cmul(u[s], t.w[m * PER + s - 1]);
         }
       }
       Dft<DIR, R>::run(u);
@@ -184,6 +207,8 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
     if constexpr (PASS + 1 < Plan::NPASS) {
       constexpr int R2 = Plan::radix(PASS + 1);
       constexpr int NB2 = P / R2;
+      Tw<PASS + 1> tn;
+      load_tw<PASS + 1>(tn, tw, tid);
       float2 xn[P];
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
@@ -206,11 +231,15 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
       }
 #pragma unroll
       for (int e = 0; e < P; e++) x[e] = xn[e];
-      pass<PASS + 1>(x, lds, tw, tid);
+      pass<PASS + 1>(x, lds, tw, tid, tn);
     }
   }
 
-  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid) { pass<0>(x, lds, tw, tid); }
+  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid) { Tw<0> t0; pass<0>(x, lds, tw, tid, t0); }
 };
+
+// XCD-aware block order (8 XCDs, blocks dealt round-robin): consecutive work items go to blocks b, b+8, b+16 ...
+// so neighbours in time (which share half their input) run on the same XCD and meet in its L2.  Speed only.
+__device__ __forceinline__ int xcd_order(int b, int nb) { return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3); }
 
 }  // namespace lrh

@@ -40,6 +40,7 @@ struct lrh_ctx {
   lrh_config cfg;
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
+  int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;
   std::string err;
   // device tables
@@ -50,7 +51,7 @@ struct lrh_ctx {
   // device rings
   short2 *d_timf1 = nullptr;
   float2 *d_fft1 = nullptr; float *d_sumsq = nullptr, *d_slowsum = nullptr;
-  float4 *d_timf2 = nullptr; float *d_pwr = nullptr; unsigned int *d_blnbits = nullptr;
+  float2 *d_timf2w = nullptr, *d_timf2s = nullptr; float *d_pwr = nullptr; unsigned int *d_blnbits = nullptr;   // timf2 kept planar on the device
   float2 *d_fft2 = nullptr; float *d_power2 = nullptr, *d_powersum2 = nullptr, *d_powersum2_alt = nullptr, *d_wf_scratch = nullptr;
   int16_t *d_waterf = nullptr;
   float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
@@ -217,7 +218,7 @@ void lrh_close(lrh_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
-                  c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2, c->d_pwr,
+                  c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials };
   for (void *p : dev) if (p) hipFree(p);
@@ -251,6 +252,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im; // buf.c:451-452
   c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;                                                       // buf.c:453-455
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
+  if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
              cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
              !(c->Im == 0 || c->Im == c->Mm) || cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
@@ -303,7 +305,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   // ---- rings
   A(dev_alloc(c, &c->d_timf1, cfg->timf1_bytes / 4)); A(dev_alloc(c, &c->d_fft1, (size_t)cfg->max_fft1n * N1));
   A(dev_alloc(c, &c->d_sumsq, cfg->fft1_sumsq_bufsize)); A(dev_alloc(c, &c->d_slowsum, N1));
-  A(dev_alloc(c, &c->d_timf2, cfg->timf2pow_size)); A(dev_alloc(c, &c->d_pwr, cfg->timf2pow_size));
+  A(dev_alloc(c, &c->d_timf2w, cfg->timf2pow_size)); A(dev_alloc(c, &c->d_timf2s, cfg->timf2pow_size)); A(dev_alloc(c, &c->d_pwr, cfg->timf2pow_size));
   A(dev_alloc(c, &c->d_blnbits, cfg->timf2pow_size / 32 + 64));
   A(dev_alloc(c, &c->d_fft2, (size_t)cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_power2, (size_t)cfg->max_fft2n * N2));
   A(dev_alloc(c, &c->d_powersum2, N2)); A(dev_alloc(c, &c->d_powersum2_alt, N2)); A(dev_alloc(c, &c->d_wf_scratch, (size_t)(cfg->max_fft2n + 1) * N2));
@@ -433,6 +435,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.p0_first = ((timf1p_ref & c->timf1_bytemask) / 4 - c->I1) & a.ring_mask;     // fft1.c:421-426
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
+  a.xcd = c->xcd_mask & 1; a.batch = batch;
   ProfScope ps(c, "fft1");
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->stream));
   return LRH_OK;
@@ -475,9 +478,10 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
   a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
-  a.timf2 = c->d_timf2; a.pwr = c->d_pwr; a.pa_first = p->timf2_pa / 4; a.mask = c->timf2pow_mask; a.step = c->M1;
+  a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.pwr = c->d_pwr; a.pa_first = p->timf2_pa / 4; a.mask = c->timf2pow_mask; a.step = c->M1;
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
+  a.xcd = (c->xcd_mask >> 1) & 1;
   { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->stream)); }
   // from now on the previous transform was routed with the current table
   HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
@@ -503,7 +507,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   const int total = (pend - pbeg + 1 + mask) & mask;
   if (total < c->cfg.blanker_min_points) return LRH_OK;                  // rate limit, blank1.c:712-715
   BlankArgs a; memset(&a, 0, sizeof a);
-  a.pwr = c->d_pwr; a.timf2 = c->d_timf2; a.mask_bits = c->d_blnbits; a.mask = mask;
+  a.pwr = c->d_pwr; a.timf2w = c->d_timf2w; a.mask_bits = c->d_blnbits; a.mask = mask;
   a.pbeg = pbeg; a.total = (pend - pbeg) & mask;
   a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
   a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials;
@@ -545,8 +549,9 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   const int N = c->N2;
   Fft2Args a;
-  a.timf2 = c->d_timf2; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
+  a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
   a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
+  a.xcd = (c->xcd_mask >> 2) & 1;
   { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
@@ -699,7 +704,17 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_FFT1_FLOAT: src = c->d_fft1; total = (size_t)c->cfg.max_fft1n * 2 * c->N1; break;
     case LRH_RING_FFT1_SUMSQ: src = c->d_sumsq; total = c->cfg.fft1_sumsq_bufsize; break;
     case LRH_RING_FFT1_SLOWSUM: src = c->d_slowsum; total = c->N1; break;
-    case LRH_RING_TIMF2_FLOAT: src = c->d_timf2; total = 4 * (size_t)c->cfg.timf2pow_size; break;
+    case LRH_RING_TIMF2_FLOAT: {
+      // the device keeps weak and strong planar; rebuild the reference layout {wRe,wIm,sRe,sIm} per sample
+      total = 4 * (size_t)c->cfg.timf2pow_size;
+      if (off + cnt > total || (off & 3) || (cnt & 3)) return LRH_EINVAL;
+      const size_t s0 = off / 4, ns = cnt / 4;
+      if (ns == 0) return LRH_OK;
+      HIPCHK(c, hipMemcpy2DAsync(dst, 16, c->d_timf2w + s0, 8, 8, ns, kind, c->stream));
+      HIPCHK(c, hipMemcpy2DAsync((char *)dst + 8, 16, c->d_timf2s + s0, 8, 8, ns, kind, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return LRH_OK;
+    }
     case LRH_RING_TIMF2_PWR: src = c->d_pwr; total = c->cfg.timf2pow_size; break;
     case LRH_RING_FFT2_FLOAT: src = c->d_fft2; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
     case LRH_RING_FFT2_POWER: src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2; break;

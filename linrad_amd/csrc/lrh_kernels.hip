@@ -26,31 +26,52 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   using Plan = FftPlan<LOG2N, P>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   __shared__ float2 lds[Plan::LDS_CELLS];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int p0 = a.p0_first + b * a.step;
-  float2 x[P];
+  const int tid0 = threadIdx.x;
+  // Persistent workgroups: with one 136 KiB workgroup per CU at N = 16384 nothing else can overlap the store tail
+  // of transform t with the loads of transform t+1, so each workgroup walks over several transforms itself and
+  // fetches the raw samples of the next one before it starts computing the current one.
+  short2 nxt[P];
+  auto fetch = [&](int bi, int tid) {
+    const int p0 = a.p0_first + bi * a.step;
 #pragma unroll
-  for (int m = 0; m < P / R0; m++)
+    for (int m = 0; m < P / R0; m++)
 #pragma unroll
-    for (int s = 0; s < R0; s++) {
-      const int idx = (tid + m * T) + s * (N / R0);
-      const short2 v = a.timf1[(p0 + idx) & a.ring_mask];
-      const float w = a.window[idx];
-      // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
-      x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));
-    }
-  BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
-  float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+      for (int s = 0; s < R0; s++) nxt[m * R0 + s] = a.timf1[(p0 + (tid + m * T) + s * (N / R0)) & a.ring_mask];
+  };
+  int bi = blockIdx.x;
+  if (bi < a.batch) fetch(a.xcd ? xcd_order(bi, a.batch) : bi, tid0);
+#pragma unroll 1
+  for (; bi < a.batch; bi += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                        // keep index math inside the loop (see k_timf2)
+    const int b = a.xcd ? xcd_order(bi, a.batch) : bi;
+    float2 x[P];
 #pragma unroll
-  for (int m = 0; m < P / RL; m++)
+    for (int m = 0; m < P / R0; m++)
 #pragma unroll
-    for (int q = 0; q < RL; q++) {
-      const int k = (tid + m * T) + q * (N / RL);
-      int kk = (k + N / 2) & (N - 1);                 // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
-      float2 v = x[m * RL + q];
-      if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
-      out[kk] = cmul(v, a.filtercorr[kk]);
-    }
+      for (int s = 0; s < R0; s++) {
+        const int idx = (tid + m * T) + s * (N / R0);
+        const short2 v = nxt[m * R0 + s];
+        const float w = a.window[idx];
+        // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
+        x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));
+      }
+    const int bn = bi + gridDim.x;
+    if (bn < a.batch) fetch(a.xcd ? xcd_order(bn, a.batch) : bn, tid);
+    BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
+    float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int k = (tid + m * T) + q * (N / RL);
+        int kk = (k + N / 2) & (N - 1);                 // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
+        float2 v = x[m * RL + q];
+        if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
+        out[kk] = cmul(v, a.filtercorr[kk]);
+      }
+    __syncthreads();                                     // LDS is reused by the next transform
+  }
 }
 
 // =====================================================================================================
@@ -131,7 +152,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
   using Plan = FftPlan<LOG2N, P>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   __shared__ float2 lds[Plan::LDS_CELLS];
-  const int tid0 = threadIdx.x, b = blockIdx.x;
+  const int tid0 = threadIdx.x, b = a.xcd ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const float2 *cur = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
   const float2 *prv = a.spec + (size_t)((a.first_nb + b - 1) & a.nb_mask) * N;
   // weak/strong routing flags, packed by the host per first-pass butterfly: bit s of pack[i] is set when bin
@@ -155,11 +176,12 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
 #pragma unroll
       for (int s = 0; s < R0; s++) {
         const int k = (tid + m * T) + s * (N / R0);
-        float2 v = cur[k];
-        if (!((mc >> s) & 1u)) v = make_float2(0.f, 0.f);
+        // bins routed to the other stream are not even fetched: the strong stream usually touches a few lines only
+        float2 v = make_float2(0.f, 0.f);
+        if ((mc >> s) & 1u) v = cur[k];
         if constexpr (MODE == 1) {
-          float2 pv = prv[k];
-          if (!((mp >> s) & 1u)) pv = make_float2(0.f, 0.f);
+          float2 pv = make_float2(0.f, 0.f);
+          if ((mp >> s) & 1u) pv = prv[k];
           v = (k & 1) ? csub(v, pv) : cadd(v, pv);
         }
         x[m * R0 + s] = v;
@@ -182,8 +204,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
           const float2 v = x[m * RL + q];
           const float2 o = make_float2(amp * v.x, amp * v.y);
           const int r = (pa + pos) & a.mask;
-          reinterpret_cast<float2 *>(&a.timf2[r])[st] = o;
-          if (st == 0) a.pwr[r] = o.x * o.x + o.y * o.y;  // weak power only (timf2.c:1010-1012)
+          if (st == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
+          else a.timf2s[r] = o;
         }
       }
   }
@@ -326,8 +348,7 @@ __global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word
     const int bpos = __ffs(bits) - 1; bits &= bits - 1;
     const int p = wi * 32 + bpos;
     a.pwr[p] = 0;
-    float2 *wk = reinterpret_cast<float2 *>(&a.timf2[p]);
-    *wk = make_float2(0.f, 0.f);                        // weak part only (blank1.c:1043-1045)
+    a.timf2w[p] = make_float2(0.f, 0.f);                // weak part only (blank1.c:1043-1045)
   }
 }
 
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   using Plan = FftPlan<LOG2N, P>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   __shared__ float2 lds[Plan::LDS_CELLS];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = threadIdx.x, b = a.xcd ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int px = a.px_first + b * a.step;
   float2 x[P];
 #pragma unroll
@@ -403,9 +424,10 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
 #pragma unroll
     for (int s = 0; s < R0; s++) {
       const int idx = (tid + m * T) + s * (N / R0);
-      const float4 v = a.timf2[(px + idx) & a.mask];
+      const int r = (px + idx) & a.mask;
+      const float2 vw = a.timf2w[r], vs = a.timf2s[r];
       const float w = a.window[idx];
-      x[m * R0 + s] = make_float2(w * (v.x + v.z), w * (v.y + v.w));   // weak + strong (fft2.c:100-105)
+      x[m * R0 + s] = make_float2(w * (vw.x + vs.x), w * (vw.y + vs.y));   // weak + strong (fft2.c:100-105)
     }
   BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
   const int na = (a.first_na + b) & a.na_mask;
@@ -576,7 +598,7 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
   }
 
 #define LRH_LAUNCH_FFT1(L, a, batch, st) \
-  hipLaunchKernelGGL((k_fft1<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+  hipLaunchKernelGGL((k_fft1<L>), dim3(persistent_grid(L, batch)), dim3(fft_threads(L)), 0, st, a)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
     if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(batch), dim3(fft_threads(L)), 0, st, a);      \
@@ -587,6 +609,16 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
   hipLaunchKernelGGL((k_fft2<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
 #define LRH_LAUNCH_MIX1(L, a, batch, st) \
   hipLaunchKernelGGL((k_mix1_back<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+
+// workgroups that fit on the chip at once for an N = 2^log2n transform kernel (LDS and thread limits, 256 CUs)
+static int persistent_grid(int log2n, int batch)
+{
+  const int n = 1 << log2n, threads = fft_threads(log2n);
+  const int lds = (n + (n >> 4)) * 8 / fft_halves(log2n);
+  int per_cu = 160 * 1024 / lds; if (per_cu > 2048 / threads) per_cu = 2048 / threads; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+  const int g = 256 * per_cu;
+  return batch < g ? batch : g;
+}
 
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
 {

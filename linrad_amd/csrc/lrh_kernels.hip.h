@@ -18,6 +18,8 @@ struct Fft1Args {
   float2 *out;              // fft1_float ring
   int first_nb, nb_mask;
   int direction;
+  int xcd;                  // XCD-aware block order on/off
+  int batch;                // transforms in this launch (workgroups are persistent)
 };
 
 // ---- fft1_c power sums ----
@@ -37,11 +39,12 @@ struct Timf2Args {
   const float2 *spec; int first_nb, nb_mask;
   const unsigned int *pack_cur, *pack_prev;   // packed weak flags for the batch / for the transform before it
   const float2 *tw;
-  float4 *timf2; float *pwr; int pa_first; int mask; int step;
+  float2 *timf2w, *timf2s; float *pwr; int pa_first; int mask; int step;   // planar weak / strong rings
   int mode;                 // 0: no window, 1: sin^2 overlap-add, 2: centre part x inverted window
   int ia;                   // interleave/2 for mode 2
   const float *invwin;      // natural order N1 (mode 2)
   float ampfac;
+  int xcd;
 };
 
 // ---- blanker ----
@@ -53,7 +56,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   int need_slow;             // scratch: a lane found no clean restart point
 };
 struct BlankArgs {
-  float *pwr; float4 *timf2; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
+  float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
   int pbeg, total;          // positions pbeg+1 .. pbeg+total are scanned
   int clr1, clr2;
   int mode;                 // stupid_bln_mode
@@ -67,9 +70,10 @@ struct BlankArgs {
 
 // ---- fft2 ----
 struct Fft2Args {
-  const float4 *timf2; int mask; int px_first; int step;
+  const float2 *timf2w, *timf2s; int mask; int px_first; int step;
   const float *window; const float2 *tw;
   float2 *out; float *power; int first_na, na_mask;
+  int xcd;
 };
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
