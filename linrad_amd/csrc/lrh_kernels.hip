@@ -246,6 +246,8 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   // the workgroup's 256 chunks plus the look-back halo, staged once with coalesced loads
   constexpr int TILE = 256 * LRH_BLN_CHUNK + LRH_BLN_BACK;
   __shared__ float tile[TILE + TILE / 64 + 4];
+  __shared__ int wg_cnt;
+  if (threadIdx.x == 0) wg_cnt = 0;
   const int q0 = blockIdx.x * 256 * LRH_BLN_CHUNK + 1 - LRH_BLN_BACK;      // sequence position of tile[0]
   static_assert(TILE % (256 * 13) == 0, "staging loop is unrolled 13 loads deep");
   for (int i0 = 0; i0 < TILE; i0 += 256 * 13) {          // 13 independent loads in flight per thread
@@ -261,12 +263,12 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int cs = c * LRH_BLN_CHUNK + 1;
-  if (cs > a.total) return;
   const int ce = min(cs + LRH_BLN_CHUNK - 1, a.total);
   const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
   const int G = max(a.clr2, 1);
   int s = 1;
-  {
+  bool live = cs <= a.total;
+  if (live) {
     int run = 0, steps = 0, q = cs - 1; bool found = false;
     while (q >= 1) {
       const float v = tile[bln_lds(q - q0)];
@@ -275,11 +277,11 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
       if (++steps >= LRH_BLN_BACK) break;
     }
     if (found) s = q + G;
-    else if (q >= 1) { a.st->need_slow = 1; return; }  // no clean point in reach: exact serial pass takes over
+    else if (q >= 1) { a.st->need_slow = 1; live = false; }  // no clean point in reach: exact serial pass takes over
   }
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0;
   float pulmax = 0;
-  for (int q = s; q <= ce; q++) {
+  for (int q = s; live && q <= ce; q++) {
     const int p = (a.pbeg + q) & a.mask;
     const float v = tile[bln_lds(q - q0)];
     if (v > nfl && q >= erase_end) {
@@ -302,7 +304,10 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
       }
     }
   }
-  if (cnt) atomicAdd(&a.st->call_cleared, cnt);
+  // one global atomic per workgroup instead of one per lane
+  if (cnt) atomicAdd(&wg_cnt, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_cnt) atomicAdd(&a.st->call_cleared, wg_cnt);
 }
 
 // exact serial replay, only when a lane of k_blank_scan could not find a clean restart point
