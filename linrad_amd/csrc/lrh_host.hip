@@ -18,6 +18,7 @@ hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st);
 hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st);
 hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st);
 hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st);
+hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st);
 hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
@@ -45,7 +46,7 @@ struct lrh_ctx {
   std::string err;
   // device tables
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
-  float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr;
+  float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
   unsigned int *d_pack_cur = nullptr, *d_pack_prev = nullptr;
   int *d_wf_itab = nullptr;
   // device rings
@@ -220,7 +221,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials };
+                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
@@ -239,7 +240,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   *out = nullptr;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
-  if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 14) return LRH_EINVAL;
+  if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
       !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
   lrh_ctx *c = new lrh_ctx();
@@ -301,6 +302,13 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   A(dev_alloc(c, &c->d_window1, N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
   A(dev_alloc(c, &c->d_fqwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_yfac, N1)); A(dev_alloc(c, &c->d_filtercorr, N1));
   A(dev_alloc(c, &c->d_tw1, N1)); A(dev_alloc(c, &c->d_tw2, N2)); A(dev_alloc(c, &c->d_twm, c->Nm));
+  const int fft2_la = cfg->fft2_n - cfg->fft2_n / 2, fft2_lb = cfg->fft2_n / 2;      // four-step split NA x NB
+  std::vector<float2> tw2a, tw2b;
+  if (cfg->fft2_n > 14) {
+    make_twiddles(1 << fft2_la, tw2a); make_twiddles(1 << fft2_lb, tw2b);
+    A(dev_alloc(c, &c->d_tw2a, tw2a.size())); A(dev_alloc(c, &c->d_tw2b, tw2b.size()));
+    A(dev_alloc(c, &c->d_fft2_scratch, (size_t)cfg->max_fft2n * N2, false));
+  }
   A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
   // ---- rings
   A(dev_alloc(c, &c->d_timf1, cfg->timf1_bytes / 4)); A(dev_alloc(c, &c->d_fft1, (size_t)cfg->max_fft1n * N1));
@@ -322,6 +330,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
+    if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
     A(upload(c, c->d_wf_itab, itab.data(), itab.size()));
     BlankState bs; memset(&bs, 0, sizeof bs);                          // buf.c:418-431, hires_graph.c:1157-1162
     bs.noise_floor = cfg->timf2_noise_floor; bs.despiked_pwr[0] = (float)cfg->timf2_noise_floor; bs.despiked_pwrinc[0] = 1;
@@ -552,7 +561,15 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
   a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
   a.xcd = (c->xcd_mask >> 2) & 1;
-  { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
+  if (c->cfg.fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
+  else {
+    Fft2BigArgs g;
+    g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
+    g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
+    g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
+    ProfScope ps(c, "fft2");
+    HIPCHK(c, launch_fft2_big(c->cfg.fft2_n, g, batch, c->stream));
+  }
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;

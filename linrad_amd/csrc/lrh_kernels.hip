@@ -449,6 +449,93 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     }
 }
 
+// ---- fft2 for N2 > 16384: four-step through an HBM scratch -----------------------------------------------------
+// n = NB*n1 + n2, k = k1 + NA*k2:  X[k] = sum_n2 [ w_N^(n2 k1) * sum_n1 z[NB n1 + n2] w_NA^(n1 k1) ] w_NB^(n2 k2).
+// Both steps transform along the strided index of a 16-wide tile, threads laid out tile-column-fastest, so every
+// global access is a full 128-byte line (16 x float2).  Step A transposes its result through LDS so that step B
+// finds scratch[n2][k1] with k1 contiguous.
+#define LRH_TILE 16
+__host__ __device__ constexpr int sub_ppt(int log2l) { return log2l >= 9 ? 8 : 4; }   // 64 threads per sub-transform
+
+template <int LA, int LB>
+__global__ __launch_bounds__(1024) void k_fft2_cols(Fft2BigArgs a)
+{
+  constexpr int P = sub_ppt(LA);
+  using Plan = FftPlan<LA, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;               // odd column stride: tile columns land on different banks
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int b = blockIdx.y, n2 = blockIdx.x * LRH_TILE + c;
+  const int px = a.px_first + b * a.step;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int n1 = (l + m * T) + s * (NA / R0);
+      const int n = NB * n1 + n2;
+      const int r = (px + n) & a.mask;
+      const float2 vw = a.timf2w[r], vs = a.timf2s[r];
+      const float w = a.window[n];
+      x[m * R0 + s] = make_float2(w * (vw.x + vs.x), w * (vw.y + vs.y));
+    }
+  float2 *col = lds + c * CS;
+  BlockFft<LA, P, +1>::run(x, col, a.tw_a, l);
+  __syncthreads();
+  // twiddle w_N^(n2 k1) (e^{+j}: conjugate of the forward table), then park as col[k1]
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k1 = (l + m * T) + q * (NA / RL);
+      const float2 w = a.tw_big[(n2 * k1) & (NA * NB - 1)];
+      col[k1] = cmul(x[m * RL + q], make_float2(w.x, -w.y));
+    }
+  __syncthreads();
+  // store scratch[n2][k1], k1 fastest: thread t handles k1 = t mod NA of tile row t / NA, 1024/NA rows per sweep
+  float2 *sc = a.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
+  for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
+    const int cc = e / NA, k1 = e - cc * NA;
+    sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+  }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
+{
+  constexpr int P = sub_ppt(LB);
+  using Plan = FftPlan<LB, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int b = blockIdx.y, k1 = blockIdx.x * LRH_TILE + c;
+  const float2 *sc = a.scratch + (size_t)b * NA * NB;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int n2 = (l + m * T) + s * (NB / R0);
+      x[m * R0 + s] = sc[(size_t)n2 * NA + k1];
+    }
+  BlockFft<LB, P, +1>::run(x, lds + c * CS, a.tw_b, l);
+  const int na = (a.first_na + b) & a.na_mask;
+  float2 *out = a.out + (size_t)na * NA * NB;
+  float *pw = a.power + (size_t)na * NA * NB;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k2 = (l + m * T) + q * (NB / RL);
+      const int k = k1 + NA * k2;
+      const float2 v = x[m * RL + q];
+      out[k] = v;
+      pw[k] = v.x * v.x + v.y * v.y;
+    }
+}
+
 // fft2_powersum_float (fft2.c:655-670): group g = one waterfall averaging period; complete groups are parked in
 // wf_scratch for k_waterfall, the last (possibly partial) group is what fft2_powersum_float holds afterwards.
 __global__ __launch_bounds__(256) void k_powersum2(Powersum2Args a)
@@ -638,6 +725,22 @@ hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st
 hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st)
 {
   LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
+  return hipGetLastError();
+}
+template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a, int batch, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  hipLaunchKernelGGL((k_fft2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+}
+hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st)
+{
+  switch (log2n) {
+    case 15: launch_fft2_big_t<8, 7>(a, batch, st); break;
+    case 16: launch_fft2_big_t<8, 8>(a, batch, st); break;
+    case 17: launch_fft2_big_t<9, 8>(a, batch, st); break;
+    case 18: launch_fft2_big_t<9, 9>(a, batch, st); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st)

@@ -75,6 +75,14 @@ struct Fft2Args {
   float2 *out; float *power; int first_na, na_mask;
   int xcd;
 };
+// four-step fft2 (N2 > 16384): N2 = NA*NB, column transforms of length NA, twiddle, row transforms of length NB
+struct Fft2BigArgs {
+  const float2 *timf2w, *timf2s; int mask; int px_first; int step;
+  const float *window;
+  const float2 *tw_a, *tw_b, *tw_big;         // forward tables of size NA, NB and N2
+  float2 *scratch;                            // [batch][NB][NA]
+  float2 *out; float *power; int first_na, na_mask;
+};
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
   const float *powersum_in; float *powersum_out; float *wf_scratch; int counter; int avgnum;

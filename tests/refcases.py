@@ -39,12 +39,17 @@ CASES = {
                         fq=900.0, wf_avgnum=1, wf_mode=1, seed=14, timf2pow_log2=14, sumsq_blocks=4,
                         sinpow1=3, strong=[(60.0, 8000.0), (-111.0, 500.0)], weak=[(150.5, 45.0)], pulse_period=0,
                         lim_halfwidth=3),
+    # fft2 larger than one workgroup's LDS: the four-step path (N2 = 32768 = 256 x 128), reference-consistent N2 = 4*N1
+    "n13_n15_big2": dict(n1=13, n2=15, mixred=6, nblk=24, avg1num=4, avg2num=2, att_n=6, bln_interval=2, bln_avgnum=4,
+                         fq=9000.4, wf_avgnum=1, wf_mode=4, seed=15, timf2pow_log2=18, sumsq_blocks=8,
+                         strong=[(2048.0, 8000.0), (-1000.5, 600.0)], weak=[(500.0, 40.0)], pulse_period=7919,
+                         lim_halfwidth=3, golden_stride=11),
 }
 
 
 def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
-             pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3)
+             pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1)
     d.update(CASES[name])
     if d["gain"] is None:
         d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"])

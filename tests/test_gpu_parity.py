@@ -29,18 +29,18 @@ def test_hip_matches_reference_golden(name):
     print(name, rep)
 
 
-@pytest.mark.parametrize("name", ["n8_n10", "n9_n11_sin3", "n11_n9_nowin2"])
+@pytest.mark.parametrize("name", ["n8_n10", "n9_n11_sin3", "n11_n9_nowin2", "n13_n15_big2"])
 def test_hip_timf2_without_blanker(name):
     g = load_golden(name)
     out = run_case(_open_hip, name, golden=g, stupid=0)
+    st = int(g["__stride"]) if "__stride" in g else 1
     a, b = out["timf2_float"].copy(), g["timf2_float_noblank"].copy()
     api = out["api"]
+    keep = np.ones(a.size, bool)
     if api.fft1_interleave_points == api.N1 // 2:      # pending raw second half beyond timf2_pa: see paritylib
-        idx = (api.p.timf2_pa + np.arange(4 * (api.N1 // 2))) % a.size
-        a[idx] = 0
-        b[idx] = 0
-    assert relerr(a, b) < 1e-5
-    assert relerr(out["timf2_pwr_float"], g["timf2_pwr_float_noblank"]) < 1e-5
+        keep[(api.p.timf2_pa + np.arange(4 * (api.N1 // 2))) % a.size] = False
+    assert relerr((a * keep)[::st], b * keep[::st]) < 1e-5
+    assert relerr(out["timf2_pwr_float"][::st], g["timf2_pwr_float_noblank"]) < 1e-5
 
 
 @pytest.mark.parametrize("name,batch", [("n8_n10", 4), ("n10_n12", 3), ("n11_n9_nowin2", 4)])
