@@ -79,3 +79,16 @@ def test_hip_tables_match_reference():
             ref = g[t][:got.size]
             bad = np.abs(got - ref) > 1e-6 * np.abs(ref)
             assert not bad.any(), (name, t, np.nonzero(bad)[0][:5], got[bad][:5], ref[bad][:5])
+
+
+def test_c_host_driver_runs():
+    """examples/lrh_stream.c: the plain-C producer + wideband loop over the C ABI (built by __graft_entry__.build())."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "lrh_stream")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "linrad_amd", "csrc"), "example"])
+    out = subprocess.run([exe, "12", "14", "0.5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Msamples/s" in out.stdout and "blanker: noise floor" in out.stdout
