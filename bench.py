@@ -69,7 +69,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("LRH_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -79,11 +80,12 @@ def main():
     N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
     samples_per_step = args.batch * M1
-    xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+    use_dist = dist is not None
+    xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if use_dist else None
 
     def step():
         rx.wideband_dsp(args.batch, args.batch)
-        if world > 1:
+        if use_dist:
             # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
             rx.export_device(abi.RING_FFT1_SUMSQ, xchg.data_ptr(), newest_sumsq_block(rx), N1)
             cross_channel_power_sum(xchg, dist)
@@ -91,7 +93,7 @@ def main():
     def barrier():
         rx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -104,7 +106,7 @@ def main():
     ev_ms = rx.timer_stop()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -138,7 +140,7 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(args, args.fft1_n, args.fft2_n)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

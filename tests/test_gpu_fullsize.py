@@ -1,0 +1,134 @@
+"""GPU, BASELINE.json full sizes (fft1_size 16384; fft2_size 4096 and 65536): parity with the oracle on a bounded run and
+size-independent properties of the chain (reconstruction identity, linearity, tone -> bin, Parseval)."""
+import numpy as np
+import pytest
+
+from linrad_amd import abi
+from linrad_amd.workload import chain_config, strong_liminfo
+
+pytestmark = pytest.mark.gpu
+N1 = 16384
+
+
+def _hip(cfg):
+    from linrad_amd.lib import open_hip
+    return open_hip(cfg)
+
+
+def _oracle(cfg):
+    from oracle_binding import open_oracle
+    return open_oracle(cfg)
+
+
+def _relerr(a, b):
+    ct = np.complex128 if (np.iscomplexobj(a) or np.iscomplexobj(b)) else np.float64
+    a, b = np.asarray(a).astype(ct), np.asarray(b).astype(ct)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _feed(rx, iq, lim=None, fq=None):
+    rx.timf1_write(iq)
+    if lim is not None:
+        rx.set_liminfo(lim)
+    if fq is not None:
+        rx.set_mix1_selfreq(fq)
+
+
+@pytest.mark.parametrize("fft2_n", [12, 16])
+def test_fullsize_chain_matches_oracle(fft2_n):
+    """48 fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (float32 tolerance 1e-5)."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(14, fft2_n, batch=16)
+    s = synth_defaults(N1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 14)
+    fq = 0.31 * (1 << fft2_n) + 0.3
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        _feed(rx, iq, lim, fq)
+        rx.wideband_dsp(48, 16)
+        r = {k: rx.export(ring) for ring, k in ((abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"),
+                                                (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_PWR, "pwr"),
+                                                (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"),
+                                                (abi.RING_TIMF3_FLOAT, "timf3"), (abi.RING_WG_WATERF, "wf"))}
+        r["p"] = rx.p.as_dict()
+        r["bs"] = rx.blanker_state()
+        res.append(r)
+    h, o = res
+    ints = [k for k, v in h["p"].items() if isinstance(v, int)]
+    assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
+    assert abs(h["bs"].timf2_noise_floor - o["bs"].timf2_noise_floor) <= 1
+    for k in ("fft1", "sumsq", "slowsum", "fft2", "ps2"):
+        assert _relerr(h[k], o[k]) < 1e-5, k
+    assert _relerr(h["pwr"], o["pwr"]) < 5e-5          # despiked power: float32 floor of the cleaned pulses remains
+    assert _relerr(h["timf3"], o["timf3"]) < 2e-5
+    d = np.abs(h["wf"].astype(int) - o["wf"].astype(int))
+    assert d.max() <= 2 and (d != 0).mean() < 0.05
+
+
+def test_fullsize_reconstruction_identity():
+    """SURVEY 8a identity 2: after fft1 -> make_timf2 (sin^2 windows) weak+strong = g * conj(x[n]) * (-1)^n."""
+    cfg = chain_config(14, 12, batch=16, )
+    cfg.stupid_bln_mode = 0
+    rng = np.random.default_rng(5)
+    nblk = 32
+    n = nblk * (N1 // 2) + 2 * N1
+    x = rng.integers(-3000, 3000, n) + 1j * rng.integers(-3000, 3000, n)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2], iq[1::2] = x.real, x.imag
+    rx = _hip(cfg)
+    gain = 0.01
+    rx.set_filtercorr(np.tile(np.array([gain, 0], np.float32), N1))       # flat filter: the identity is exact
+    lim = np.zeros(N1, np.float32)
+    lim[::7] = 1                                                          # arbitrary routing must not matter for w+s
+    _feed(rx, iq, lim)
+    rx.fft1_b(16), rx.fft1_c(16), rx.make_timf2(16)
+    rx.fft1_b(16), rx.fft1_c(16), rx.make_timf2(16)
+    t2 = rx.export(abi.RING_TIMF2_FLOAT, 0, 4 * rx.p.timf2_pa // 4).reshape(-1, 4)
+    got = (t2[:, 0] + t2[:, 2]) + 1j * (t2[:, 1] + t2[:, 3])
+    M1, I1 = N1 // 2, N1 // 2
+    win = rx.get_table("fft1_window", 2)                                  # mode-1 storage: w[0], w[N/2] (fft0.c:907-920)
+    A = float(win[0] + win[1])                                            # w[n] + w[n+N/2], constant for sin^2 (~1/sqrt(3/8))
+    g = A * N1 * gain / 64.0                                              # window normalisation * N1 * filter * 2^-ATT_N
+    # output sample m of block b is input sample b*M1 + m - I1 (first transform starts I1 before the ring origin)
+    idx = np.arange(M1, got.size)                                         # skip the first block (zeros before the origin)
+    src = idx - I1
+    sign = np.where(idx % 2 == 0, 1.0, -1.0)
+    want = g * np.conj(x[src]) * sign
+    assert _relerr(got[idx], want) < 2e-6
+
+
+def test_fullsize_linearity_and_tone_bins():
+    cfg = chain_config(14, 12, batch=16)
+    cfg.stupid_bln_mode = 0
+    n = 16 * (N1 // 2) + 2 * N1
+    t = np.arange(n)
+    f = 1234.0 / N1                                                       # cycles per sample
+    def run(x):
+        iq = np.empty(2 * n, np.int16)
+        iq[0::2], iq[1::2] = np.round(x.real), np.round(x.imag)
+        rx = _hip(cfg)
+        _feed(rx, iq)
+        rx.wideband_dsp(16, 16)
+        last2 = rx.p.fft2_na - 1                                          # newest transforms: past the start-up ramp
+        return (rx.export(abi.RING_FFT1_FLOAT, 15 * 2 * N1, 2 * N1), rx.export(abi.RING_FFT2_FLOAT, last2 * 2 * 4096, 2 * 4096),
+                rx)
+    rng = np.random.default_rng(6)
+    a = np.round(rng.normal(0, 500, n)) + 1j * np.round(rng.normal(0, 500, n))
+    b = np.round(2000 * np.exp(2j * np.pi * f * t))                       # integers so that a+b is exactly representable
+    fa, ga, _ = run(a)
+    fb, gb, rxb = run(b)
+    fab, gab, _ = run(a + b)
+    e1, e2 = _relerr(fab, fa + fb), _relerr(gab, ga + gb)
+    assert e1 < 1e-5 and e2 < 1e-5, (e1, e2)                              # linear up to float32 rounding
+    # a tone at +f cycles/sample peaks at bin N/2 + f*N in both spectra
+    p1 = fb[0::2] ** 2 + fb[1::2] ** 2
+    p2 = gb[0::2] ** 2 + gb[1::2] ** 2
+    assert int(np.argmax(p1)) == N1 // 2 + 1234
+    assert int(np.argmax(p2)) == 2048 + round(f * 4096)
+    # Parseval: power of the fft2 spectrum = N2 * power of the windowed time function it was made from
+    start = rxb.p.timf2_px - 4 * (4096 - rxb.fft2_interleave_points)     # where the newest transform began (fft2.c:1832)
+    t2 = rxb.export(abi.RING_TIMF2_FLOAT, start, 4 * 4096).reshape(-1, 4)
+    z = ((t2[:, 0] + t2[:, 2]) + 1j * (t2[:, 1] + t2[:, 3])) * rxb.get_table("fft2_window", 4096)
+    assert abs(p2.sum() / (4096 * np.sum(np.abs(z) ** 2)) - 1) < 1e-5
