@@ -83,7 +83,11 @@ typedef struct lrh_config {
   float mix1_lowest_fq, mix1_highest_fq;
   /* execution */
   int max_batch;                /* largest `batch` any call will pass                              */
-  int reserved[8];
+  int second_fft_enable;        /* genparm[SECOND_FFT_ENABLE]; 0: fft1 -> fft1_c -> fft1_mix1_fixed, mix1 sized
+                                   from fft1 (buf.c:316-332); the reference's own default (uivar.c:371)  */
+  int timf2_blockpower_block;   /* floats per S/N-meter block (baseb_graph.c:1330); 0: powersum unused   */
+  int timf2_blockpower_size;    /* ring length, pow2 (buf.c:409-412)                                     */
+  int reserved[5];
 } lrh_config;
 
 /*
@@ -111,9 +115,11 @@ typedef struct lrh_ptrs {
   int timf2_px;
   int fft2_na, fft2_pa, fft2_nb, fft2_nm;
   int wg_waterf_sum_counter, wg_waterf_ptr, fft2_liminfo_cnt;
-  /* fft2_mix1_fixed (mix1.c:991-992) */
+  /* fft2_mix1_fixed (mix1.c:991-992); fft1_mix1_fixed advances fft1_nx/fft1_px/timf3_pa (mix1.c:1039-1041) */
   int fft2_nx, timf3_pa;
-  int reserved[8];
+  /* compute_timf2_powersum (wcw.c:84-137) */
+  int timf2_pb, timf2_blockpower_pa;
+  int reserved[6];
 } lrh_ptrs;
 
 /* device-resident blanker scalars (blnkdef.h:18-33, globdef.h:983) read back on demand */
@@ -147,6 +153,7 @@ typedef enum lrh_ring {
   LRH_RING_FFT2_POWERSUM,       /* float [N2]                                                      */
   LRH_RING_WG_WATERF,           /* int16 [wf_lines][wf_xpixels]                                    */
   LRH_RING_TIMF3_FLOAT,         /* float [timf3_size]                                              */
+  LRH_RING_TIMF2_BLOCKPOWER,    /* float [timf2_blockpower_size]                                   */
   LRH_RING_COUNT
 } lrh_ring;
 
@@ -193,6 +200,11 @@ int lrh_first_noise_blanker(lrh_ctx *ctx, lrh_ptrs *p);
 int lrh_make_fft2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
 /* fft2_mix1_fixed (fft2def.h:62; mix1.c:934-993 + set_mix1_phases mix1.c:781-861 + do_mix1 mix1.c:55-195) */
 int lrh_fft2_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* fft1_mix1_fixed (fft2def.h / mix1.c:995-1042): the second-fft-disabled chain picks mix1.size bins straight from
+   fft1_float at fft1_px; needs second_fft_enable == 0 */
+int lrh_fft1_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* compute_timf2_powersum (wcw.c:80-138): weak-signal power per block of released timf2 data, for the S/N meter */
+int lrh_compute_timf2_powersum(lrh_ctx *ctx, lrh_ptrs *p);
 int lrh_set_mix1_selfreq(lrh_ctx *ctx, double fq);        /* mix1_selfreq[0]; <0 deselects               */
 int lrh_get_mix1_state(lrh_ctx *ctx, lrh_mix1_state *st);
 

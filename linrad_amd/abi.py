@@ -12,7 +12,8 @@ import numpy as np
 LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2, -3, -4, -5
 
 (RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
- RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT) = range(11)
+ RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT,
+ RING_TIMF2_BLOCKPOWER) = range(12)
 _RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16}
 
 
@@ -30,7 +31,8 @@ class LrhConfig(C.Structure):
         ("wf_first_xpoint", C.c_int), ("wf_xpixels", C.c_int), ("wf_mode", C.c_int), ("wf_lines", C.c_int),
         ("mix1_bandwidth_reduction_n", C.c_int), ("timf3_size", C.c_int), ("fftx_points_per_hz", C.c_float),
         ("mix1_lowest_fq", C.c_float), ("mix1_highest_fq", C.c_float),
-        ("max_batch", C.c_int), ("reserved", C.c_int * 8),
+        ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
+        ("timf2_blockpower_size", C.c_int), ("reserved", C.c_int * 5),
     ]
 
 
@@ -46,7 +48,8 @@ class LrhPtrs(C.Structure):
         ("timf2_blanker_points", C.c_int), ("blanker_info_update_counter", C.c_int),
         ("timf2_px", C.c_int), ("fft2_na", C.c_int), ("fft2_pa", C.c_int), ("fft2_nb", C.c_int), ("fft2_nm", C.c_int),
         ("wg_waterf_sum_counter", C.c_int), ("wg_waterf_ptr", C.c_int), ("fft2_liminfo_cnt", C.c_int),
-        ("fft2_nx", C.c_int), ("timf3_pa", C.c_int), ("reserved", C.c_int * 8),
+        ("fft2_nx", C.c_int), ("timf3_pa", C.c_int), ("timf2_pb", C.c_int), ("timf2_blockpower_pa", C.c_int),
+        ("reserved", C.c_int * 6),
     ]
 
     def as_dict(self):
@@ -104,6 +107,8 @@ def default_config(fft1_n, fft2_n, **kw):
     c.timf3_size = 32 * max(8, N2 >> 6)
     c.fftx_points_per_hz, c.mix1_lowest_fq, c.mix1_highest_fq = 1.0, 0.0, float(N2)
     c.max_batch = 64
+    c.second_fft_enable = 1
+    c.timf2_blockpower_block, c.timf2_blockpower_size = 4 * 64, 1024
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -132,9 +137,10 @@ class StageAPI:
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
         self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
-        for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed"):
+        for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
+        self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
         self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
         self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
@@ -237,6 +243,12 @@ class StageAPI:
     def fft2_mix1_fixed(self, batch=1):
         self._chk(self._f("fft2_mix1_fixed")(self.ctx, C.byref(self.p), batch), "fft2_mix1_fixed")
 
+    def fft1_mix1_fixed(self, batch=1):
+        self._chk(self._f("fft1_mix1_fixed")(self.ctx, C.byref(self.p), batch), "fft1_mix1_fixed")
+
+    def compute_timf2_powersum(self):
+        self._chk(self._f("compute_timf2_powersum")(self.ctx, C.byref(self.p)), "compute_timf2_powersum")
+
     def fft2_available(self):
         """number of fft2 transforms the released timf2 data allows (wcw.c:265-275)"""
         p = self.p
@@ -265,7 +277,7 @@ class StageAPI:
                 RING_TIMF2_FLOAT: 4 * c.timf2pow_size, RING_TIMF2_PWR: c.timf2pow_size,
                 RING_FFT2_FLOAT: c.max_fft2n * 2 * self.N2, RING_FFT2_POWER: c.max_fft2n * self.N2,
                 RING_FFT2_POWERSUM: self.N2, RING_WG_WATERF: c.wf_lines * c.wf_xpixels,
-                RING_TIMF3_FLOAT: c.timf3_size}[ring]
+                RING_TIMF3_FLOAT: c.timf3_size, RING_TIMF2_BLOCKPOWER: c.timf2_blockpower_size}[ring]
 
     def export(self, ring, offset=0, count=None):
         if count is None:

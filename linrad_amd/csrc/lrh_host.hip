@@ -25,6 +25,7 @@ hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
 hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
+hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 }  // namespace lrh
 using namespace lrh;
 
@@ -41,6 +42,9 @@ struct lrh_ctx {
   lrh_config cfg;
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
+  int lowlevel_points = 0;   // liminfo[i]==0 count of the table in force (timf2.c:37-52)
+  int mix_cap = 0;           // transforms per mix1 launch the scratch buffers hold
+  float *d_blockpower = nullptr;
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;
   std::string err;
@@ -211,6 +215,7 @@ int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
   c->wf_xpixels = N2 < 1024 ? N2 : 1024; c->wf_mode = 1; c->wf_lines = 8;
   c->mix1_bandwidth_reduction_n = 6; c->timf3_size = 32 * ((N2 >> 6) > 8 ? (N2 >> 6) : 8);
   c->fftx_points_per_hz = 1.0f; c->mix1_lowest_fq = 0; c->mix1_highest_fq = (float)N2; c->max_batch = 16;
+  c->second_fft_enable = 1; c->timf2_blockpower_block = 0; c->timf2_blockpower_size = 1024;
   return LRH_OK;
 }
 
@@ -221,7 +226,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch };
+                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
@@ -242,16 +247,26 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
   if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
-      !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
+      !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || (cfg->timf2_blockpower_block > 0 && !ispow2(cfg->timf2_blockpower_size)) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
   lrh_ctx *c = new lrh_ctx();
   memset(c->ph_ev, 0, sizeof c->ph_ev);
   c->cfg = *cfg;
   const int N1 = c->N1 = 1 << cfg->fft1_n, N2 = c->N2 = 1 << cfg->fft2_n;
-  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe; c->M1 = N1 - c->I1;     // buf.c:303-304
-  c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;          // buf.c:432-434
-  c->Nm = 1 << c->mix1_n;
-  c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im; // buf.c:451-452
-  c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;                                                       // buf.c:453-455
+  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe;                           // buf.c:303-304
+  if (cfg->second_fft_enable) {
+    c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;          // buf.c:432-434
+    c->Nm = 1 << c->mix1_n;
+    c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im; // buf.c:451-452
+    c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;                                                       // buf.c:453-455
+  } else {                                   // buf.c:315-327: mix1 sized from fft1, fft1 interleave re-derived from it
+    c->mix1_n = cfg->fft1_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;
+    c->Nm = 1 << c->mix1_n;
+    c->Im = (int)(interleave_ratio(cfg->fft1_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im;
+    c->I1 = c->Im * (N1 / c->Nm);
+    c->I2 = 0; c->M2 = N2;
+  }
+  c->M1 = N1 - c->I1;
+  c->mix_cap = cfg->max_fft2n > cfg->max_batch ? cfg->max_fft2n : cfg->max_batch;
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
   if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
@@ -318,8 +333,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   A(dev_alloc(c, &c->d_fft2, (size_t)cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_power2, (size_t)cfg->max_fft2n * N2));
   A(dev_alloc(c, &c->d_powersum2, N2)); A(dev_alloc(c, &c->d_powersum2_alt, N2)); A(dev_alloc(c, &c->d_wf_scratch, (size_t)(cfg->max_fft2n + 1) * N2));
   A(dev_alloc(c, &c->d_waterf, (size_t)cfg->wf_lines * cfg->wf_xpixels + 64));
-  A(dev_alloc(c, &c->d_timf3, cfg->timf3_size / 2 + c->Nm)); A(dev_alloc(c, &c->d_mix_scratch, (size_t)cfg->max_fft2n * c->Nm));
-  c->ph_stride = (size_t)2 * cfg->max_fft2n * c->Nm;
+  A(dev_alloc(c, &c->d_timf3, cfg->timf3_size / 2 + c->Nm)); A(dev_alloc(c, &c->d_mix_scratch, (size_t)c->mix_cap * c->Nm));
+  A(dev_alloc(c, &c->d_blockpower, cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
+  c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * LRH_BLN_PARTIALS));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
@@ -392,7 +408,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   c->h_pack = pack;
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->cfg.reserved[0] = low;                // fft1_lowlevel_points for this table (timf2.c:37-52)
+  c->lowlevel_points = low;
   c->have_liminfo = true;
   return LRH_OK;
 }
@@ -472,7 +488,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
       p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
     }
-    p->fft1_liminfo_cnt += nupd;
+    if (c->cfg.second_fft_enable) p->fft1_liminfo_cnt += nupd;          // fft1.c:4515-4518
     p->fft1_sumsq_pa = (p->fft1_sumsq_pa + nupd * N) & c->sumsq_mask;
   }
   p->fft1_sumsq_counter = (p->fft1_sumsq_counter + batch) % avg1;
@@ -494,7 +510,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->stream)); }
   // from now on the previous transform was routed with the current table
   HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
-  const int low = c->cfg.reserved[0];
+  const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
     p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
     p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
@@ -627,9 +643,9 @@ static int set_mix1_phases(lrh_ctx *c, float fq)
   return LRH_OK;
 }
 
-int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
+// shared by fft2_mix1_fixed (mix1.c:934-993) and fft1_mix1_fixed (mix1.c:995-1042): src ring of transforms of `n2` bins
+static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi)
 {
-  if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   const int Nm = c->Nm, overlap = c->Im != 0, half = overlap ? Nm / 2 : Nm, block2 = c->Mm;     // block in complex samples
   lrh_mix1_state *s = &c->ms;
   const int selected = s->mix1_selfreq >= 0;
@@ -660,10 +676,8 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
     HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream));
     o.ph_new = dn; o.ph_old = dn + (size_t)batch * half;
     Mix1Args a;
-    a.fft2 = c->d_fft2; a.n2 = c->N2; a.first_nx = p->fft2_nx; a.nx_mask = c->fft2n_mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
-    a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm;
-    int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
-    a.lim_hi = ratio * (c->N1 - 1); if (a.lim_hi > c->N2) a.lim_hi = c->N2;       // mix1.c:957 (nn*fft1_last_point)/2 bins
+    a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
+    a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
     ProfScope ps(c, "mix1");
     HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->stream));
     HIPCHK(c, launch_mix1_out(o, batch, c->stream));
@@ -671,10 +685,50 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
     ProfScope ps(c, "mix1");
     HIPCHK(c, launch_mix1_out(o, batch, c->stream));
   }
-  for (int b = 0; b < batch; b++) {                                      // mix1.c:991-992
-    p->timf3_pa = (p->timf3_pa + 2 * block2) & c->timf3_mask;
-    p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
-  }
+  p->timf3_pa = (p->timf3_pa + batch * 2 * block2) & c->timf3_mask;      // mix1.c:991 / 1039
+  return LRH_OK;
+}
+
+int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_fixed needs second_fft_enable");
+  int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+  int lim_hi = ratio * (c->N1 - 1); if (lim_hi > c->N2) lim_hi = c->N2;       // mix1.c:957 (nn*fft1_last_point)/2 bins
+  int rc = mix1_run(c, p, batch, c->d_fft2, c->N2, p->fft2_nx, c->fft2n_mask, lim_hi);
+  if (rc) return rc;
+  p->fft2_nx = (p->fft2_nx + batch) & c->fft2n_mask;                          // mix1.c:992
+  return LRH_OK;
+}
+
+int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_fixed needs second_fft_enable == 0");
+  int rc = mix1_run(c, p, batch, c->d_fft1, c->N1, (p->fft1_px / (2 * c->N1)) & c->fft1n_mask, c->fft1n_mask, c->N1 - 1);   // mix1.c:1017-1019
+  if (rc) return rc;
+  p->fft1_nx = (p->fft1_nx + batch) & c->fft1n_mask;                          // mix1.c:1040-1041
+  p->fft1_px = (p->fft1_px + batch * 2 * c->N1) & c->fft1_mask;
+  return LRH_OK;
+}
+
+// compute_timf2_powersum, wcw.c:80-138
+int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
+{
+  if (!c || !p) return LRH_EINVAL;
+  const int blk = c->cfg.timf2_blockpower_block;
+  if (blk <= 0 || (blk & 3)) return fail(c, LRH_ESTATE, "timf2_blockpower_block not configured");
+  const int avail = (p->timf2_pn2 - p->timf2_pb + 4 * c->cfg.timf2pow_size) & c->timf2_mask;
+  int n = 0;
+  if (avail > blk) n = (avail - 1) / blk;                                     // loop count of wcw.c:84
+  if (n <= 0) return LRH_OK;
+  BlockpowerArgs a;
+  a.timf2w = c->d_timf2w; a.mask = c->timf2pow_mask; a.first = p->timf2_pb / 4; a.block = blk / 4;
+  a.out = c->d_blockpower; a.out_mask = c->cfg.timf2_blockpower_size - 1; a.out_first = p->timf2_blockpower_pa;
+  ProfScope ps(c, "blockpower");
+  HIPCHK(c, launch_blockpower(a, n, c->stream));
+  p->timf2_pb = (p->timf2_pb + n * blk) & c->timf2_mask;
+  p->timf2_blockpower_pa = (p->timf2_blockpower_pa + n) & (c->cfg.timf2_blockpower_size - 1);
   return LRH_OK;
 }
 
@@ -692,6 +746,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     p->fft1_na = p->fft1_pa / (2 * c->N1);
     p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
     if ((rc = lrh_fft1_c(c, p, B))) return rc;
+    if (!c->cfg.second_fft_enable) {           // wcw.c:1049-1081: fft1_c, then the narrowband side's fft1_mix1_fixed
+      if ((rc = lrh_fft1_mix1_fixed(c, p, B))) return rc;
+      nblocks -= B;
+      continue;
+    }
     if ((rc = lrh_make_timf2(c, p, B))) return rc;
     if ((rc = lrh_first_noise_blanker(c, p))) return rc;
     const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
@@ -738,6 +797,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_FFT2_POWERSUM: src = c->d_powersum2; total = c->N2; break;
     case LRH_RING_WG_WATERF: src = c->d_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
     case LRH_RING_TIMF3_FLOAT: src = c->d_timf3; total = c->cfg.timf3_size; break;
+    case LRH_RING_TIMF2_BLOCKPOWER: src = c->d_blockpower; total = c->cfg.timf2_blockpower_size; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

@@ -669,6 +669,19 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
     a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + half + i];
 }
 
+// weak-signal power per block of released timf2 data (wcw.c:84-113), one workgroup per block
+__global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
+{
+  __shared__ double red[256];
+  const int base = a.first + blockIdx.x * a.block;
+  double acc = 0;
+  for (int i = threadIdx.x; i < a.block; i += 256) { const float2 v = a.timf2w[(base + i) & a.mask]; acc += (double)(v.x * v.x + v.y * v.y); }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) a.out[(a.out_first + blockIdx.x) & a.out_mask] = (float)red[0];
+}
+
 // =====================================================================================================
 // launchers
 // =====================================================================================================
@@ -752,6 +765,11 @@ hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st)
 {
   const int half = a.overlap ? a.nm / 2 : a.nm;
   hipLaunchKernelGGL(k_mix1_out, dim3((half + 255) / 256, batch), dim3(256), 0, st, a, batch);
+  return hipGetLastError();
+}
+hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_blockpower, dim3(nblocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st)

@@ -95,7 +95,7 @@ struct WaterfallArgs {
 
 // ---- mix1 ----
 struct Mix1Args {
-  const float2 *fft2; int n2; int first_nx, nx_mask;
+  const float2 *fft2; int n2; int first_nx, nx_mask;   // source ring: fft2_float (or fft1_float when the second fft is off)
   const float *fqwin; const float2 *tw;
   float2 *scratch;           // [batch][Nm] raw back transforms
   int point; int lim_hi;     // bins >= lim_hi are zeroed (mix1.c:957-958), bins < 0 zeroed
@@ -107,5 +107,8 @@ struct Mix1OutArgs {
   int pa_first; int block;   // in complex samples
   int nm; int overlap; int selected;
 };
+
+// ---- compute_timf2_powersum (wcw.c:80-138) ----
+struct BlockpowerArgs { const float2 *timf2w; int mask; int first; int block; float *out; int out_mask; int out_first; };
 
 }  // namespace lrh

@@ -41,6 +41,7 @@ struct lro_ctx {
   float *fft2_float, *fft2_power, *fft2_powersum;
   int16_t *wg_waterf;
   float *timf3_float;
+  float *timf2_blockpower;
   float *tmp;                  /* scratch, 8*max(N1,N2) floats */
   /* masks */
   int fft1n_mask, fft1_mask, fft1_sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
@@ -202,12 +203,22 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->cfg = *cfg;
   int N1 = c->N1 = 1 << cfg->fft1_n, N2 = c->N2 = 1 << cfg->fft2_n;
   /* buf.c:303-304 */
-  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe; c->M1 = N1 - c->I1;
-  /* buf.c:432-455: mix1 first, fft2 interleave re-derived from it */
-  c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;
-  c->Nm = 1 << c->mix1_n;
-  c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im;
-  c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;
+  c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe;
+  if (cfg->second_fft_enable) {
+    /* buf.c:432-455: mix1 first, fft2 interleave re-derived from it */
+    c->mix1_n = cfg->fft2_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;
+    c->Nm = 1 << c->mix1_n;
+    c->Im = (int)(interleave_ratio(cfg->fft2_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im;
+    c->I2 = c->Im * (N2 / c->Nm); c->M2 = N2 - c->I2;
+  } else {
+    /* buf.c:315-327: mix1 sized from fft1, fft1 interleave re-derived so it divides evenly */
+    c->mix1_n = cfg->fft1_n - cfg->mix1_bandwidth_reduction_n; if (c->mix1_n < 3) c->mix1_n = 3;
+    c->Nm = 1 << c->mix1_n;
+    c->Im = (int)(interleave_ratio(cfg->fft1_sinpow) * c->Nm); c->Im &= 0xfffffffe; c->Mm = c->Nm - c->Im;
+    c->I1 = c->Im * (N1 / c->Nm);
+    c->I2 = 0; c->M2 = N2;
+  }
+  c->M1 = N1 - c->I1;
   if (cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2) { free(c); return LRH_EINVAL; }
   if (!(c->Im == 0 || c->Im == c->Mm)) { free(c); return LRH_EINVAL; }   /* crossover-window mix1 (mix1.c:196-270): not restated yet */
   c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->fft1_sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
@@ -225,6 +236,7 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
   c->timf3_float = zal(4 * (size_t)cfg->timf3_size + 16 * c->Nm);
+  c->timf2_blockpower = zal(4 * (size_t)(cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
   c->tmp = zal(sizeof(float) * 8 * NM);
   make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
   if (cfg->fft1_sinpow) lro_make_window(1, N1, cfg->fft1_sinpow, c->fft1_window);
@@ -246,7 +258,7 @@ void lro_close(lro_ctx *c)
   if (!c) return;
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
-                c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp };
+                c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -390,7 +402,7 @@ int lro_fft1_c(lro_ctx *c, lrh_ptrs *p, int batch)
     if (p->fft1_sumsq_counter >= c->cfg.fft_avg1num) {
       p->fft1_sumsq_counter = 0;
       update_fft1_slowsum(c, p);
-      p->fft1_liminfo_cnt++;
+      if (c->cfg.second_fft_enable) p->fft1_liminfo_cnt++;      /* fft1.c:4515-4518 */
       p->fft1_sumsq_pa = (p->fft1_sumsq_pa + N) & c->fft1_sumsq_mask;
     }
     p->fft1_nb = (p->fft1_nb + 1) & c->fft1n_mask;
@@ -667,63 +679,97 @@ static int set_mix1_phases(lro_ctx *c, float fq)
   return LRH_OK;
 }
 
-/* fft2_mix1_fixed (mix1.c:934-993) + do_mix1 (mix1.c:55-195; dfq forced to 0 at mix1.c:103) */
+/* gather of fft2_mix1_fixed (mix1.c:955-983) / fft1_mix1_fixed (mix1.c:1015-1030) + do_mix1 (mix1.c:55-195; dfq forced
+   to 0 at mix1.c:103).  z: first float of the source transform, lim: float index limit mm*nn*fft1_last_point. */
+static int mix1_block(lro_ctx *c, lrh_ptrs *p, const float *zbase, int lim)
+{
+  int Nm = c->Nm, n = Nm, n2 = 2 * Nm, block = 2 * c->Mm;
+  lrh_mix1_state *s = &c->ms;
+  float *tmp = c->tmp, *t3 = c->timf3_float;
+  if (s->mix1_selfreq >= 0) {
+    int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
+    int k = s->mix1_point * 2;
+    int ib = n; if (ib > lim - k) ib = lim - k; if (ib < 0) ib = 0;
+    const float *z = zbase + k;
+    for (int i = 0; i < ib; i++) tmp[i] = z[i];
+    for (int i = ib; i < n; i++) tmp[i] = 0;
+    k -= n2; ib = n; if (ib < -k) ib = -k; if (ib > n2) ib = n2;
+    for (int i = n; i < ib; i++) tmp[i] = 0;
+    z = zbase + k;
+    for (int i = ib; i < n2; i++) tmp[i] = z[i];
+    /* frequency-domain window, mix1.c:113-135 */
+    int i = 0, j = Nm - 1, w = Nm / 2 - 1;
+    float t1 = c->mix1_fqwin[w]; tmp[0] *= t1; tmp[1] *= t1; i++;
+    while (j > i) { t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1; tmp[2 * j] *= t1; tmp[2 * j + 1] *= t1; j--; w--; i++; }
+    t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1;
+    /* fftback, fft0.c:481-533 */
+    dif_stages(Nm, c->mix1_n, tmp, c->mix1tab, -1, 2); bitrev_inplace(Nm, c->mix1_n, tmp, 2);
+    int pa = p->timf3_pa;
+    float t2 = s->mix1_phase_rot; t1 = s->mix1_phase;
+    if (c->Im == 0) {                        /* mix1.c:141-155 */
+      for (i = 0; i < 2 * Nm; i += 2) {
+        float sn = sin(t1), cs = cos(t1);
+        t3[pa + i] = cs * tmp[i] - sn * tmp[i + 1]; t3[pa + i + 1] = cs * tmp[i + 1] + sn * tmp[i];
+        t1 += t2;
+      }
+      s->mix1_phase = t1;
+    } else {                                 /* sin^2, 50 % overlap: mix1.c:161-195 */
+      float r1 = s->mix1_old_phase;
+      float r2 = t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm;
+      for (i = 0; i < Nm; i += 2) {
+        float sn = sin(t1), cs = cos(t1), rs = sin(r1), rc2 = cos(r1);
+        float a1 = t3[pa + i], a2 = t3[pa + i + 1];
+        t3[pa + i] = rc2 * a1 - rs * a2 + cs * tmp[i] - sn * tmp[i + 1];
+        t3[pa + i + 1] = rc2 * a2 + rs * a1 + cs * tmp[i + 1] + sn * tmp[i];
+        r1 += r2; t1 += t2;
+      }
+      s->mix1_phase = t1;
+      pa = ((p->timf3_pa + block) & c->timf3_mask) - block;
+      for (i = Nm; i < 2 * Nm; i++) t3[pa + i] = tmp[i];
+    }
+  } else {                                   /* mix1_clear, mix1.c:766-779 */
+    for (int i = 0; i < block; i++) t3[p->timf3_pa + i] = 0;
+  }
+  p->timf3_pa = (p->timf3_pa + block) & c->timf3_mask;
+  return LRH_OK;
+}
+
 int lro_fft2_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
 {
-  int Nm = c->Nm, n = Nm, n2 = 2 * Nm, N2 = c->N2;
-  int ratio = N2 / c->N1; if (ratio < 1) ratio = 1;
-  int nn = 2 * ratio;
-  int block = 2 * c->Mm;
-  lrh_mix1_state *s = &c->ms;
+  if (!c->cfg.second_fft_enable) return LRH_ESTATE;
+  int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+  int lim = 2 * ratio * (c->N1 - 1); if (lim > 2 * c->N2) lim = 2 * c->N2;   /* clamp only bites when N2 < N1 */
   for (int b = 0; b < batch; b++) {
-    float *tmp = c->tmp, *t3 = c->timf3_float;
-    if (s->mix1_selfreq >= 0) {
-      int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
-      int k = s->mix1_point * 2;
-      int lim = nn * (c->N1 - 1); if (lim > 2 * N2) lim = 2 * N2;   /* clamp only bites when N2 < N1 */
-      int ib = n; if (ib > lim - k) ib = lim - k; if (ib < 0) ib = 0;
-      const float *z = c->fft2_float + k + (size_t)2 * p->fft2_nx * N2;
-      for (int i = 0; i < ib; i++) tmp[i] = z[i];
-      for (int i = ib; i < n; i++) tmp[i] = 0;
-      k -= n2; ib = n; if (ib < -k) ib = -k; if (ib > n2) ib = n2;
-      for (int i = n; i < ib; i++) tmp[i] = 0;
-      z = c->fft2_float + k + (size_t)2 * p->fft2_nx * N2;
-      for (int i = ib; i < n2; i++) tmp[i] = z[i];
-      /* frequency-domain window, mix1.c:113-135 */
-      int i = 0, j = Nm - 1, w = Nm / 2 - 1;
-      float t1 = c->mix1_fqwin[w]; tmp[0] *= t1; tmp[1] *= t1; i++;
-      while (j > i) { t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1; tmp[2 * j] *= t1; tmp[2 * j + 1] *= t1; j--; w--; i++; }
-      t1 = c->mix1_fqwin[w]; tmp[2 * i] *= t1; tmp[2 * i + 1] *= t1;
-      /* fftback, fft0.c:481-533 */
-      dif_stages(Nm, c->mix1_n, tmp, c->mix1tab, -1, 2); bitrev_inplace(Nm, c->mix1_n, tmp, 2);
-      int pa = p->timf3_pa;
-      float t2 = s->mix1_phase_rot; t1 = s->mix1_phase;
-      if (c->Im == 0) {                        /* mix1.c:141-155 */
-        for (i = 0; i < 2 * Nm; i += 2) {
-          float sn = sin(t1), cs = cos(t1);
-          t3[pa + i] = cs * tmp[i] - sn * tmp[i + 1]; t3[pa + i + 1] = cs * tmp[i + 1] + sn * tmp[i];
-          t1 += t2;
-        }
-        s->mix1_phase = t1;
-      } else {                                 /* sin^2, 50 % overlap: mix1.c:161-195 */
-        float r1 = s->mix1_old_phase;
-        float r2 = t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm;
-        for (i = 0; i < Nm; i += 2) {
-          float sn = sin(t1), cs = cos(t1), rs = sin(r1), rc2 = cos(r1);
-          float a1 = t3[pa + i], a2 = t3[pa + i + 1];
-          t3[pa + i] = rc2 * a1 - rs * a2 + cs * tmp[i] - sn * tmp[i + 1];
-          t3[pa + i + 1] = rc2 * a2 + rs * a1 + cs * tmp[i + 1] + sn * tmp[i];
-          r1 += r2; t1 += t2;
-        }
-        s->mix1_phase = t1;
-        pa = ((p->timf3_pa + block) & c->timf3_mask) - block;
-        for (i = Nm; i < 2 * Nm; i++) t3[pa + i] = tmp[i];
-      }
-    } else {                                   /* mix1_clear, mix1.c:766-779 */
-      for (int i = 0; i < block; i++) t3[p->timf3_pa + i] = 0;
-    }
-    p->timf3_pa = (p->timf3_pa + block) & c->timf3_mask;
+    int rc = mix1_block(c, p, c->fft2_float + (size_t)2 * p->fft2_nx * c->N2, lim); if (rc) return rc;
     p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
+  }
+  return LRH_OK;
+}
+
+/* fft1_mix1_fixed, mix1.c:995-1042 */
+int lro_fft1_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (c->cfg.second_fft_enable) return LRH_ESTATE;
+  for (int b = 0; b < batch; b++) {
+    int rc = mix1_block(c, p, c->fft1_float + p->fft1_px, 2 * (c->N1 - 1)); if (rc) return rc;
+    p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
+    p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
+  }
+  return LRH_OK;
+}
+
+/* compute_timf2_powersum, wcw.c:80-138 (1 channel, float) */
+int lro_compute_timf2_powersum(lro_ctx *c, lrh_ptrs *p)
+{
+  int blk = c->cfg.timf2_blockpower_block;
+  if (blk <= 0) return LRH_ESTATE;
+  while (((p->timf2_pn2 - p->timf2_pb + 4 * c->cfg.timf2pow_size) & c->timf2_mask) > blk) {
+    int i = p->timf2_pb;
+    p->timf2_pb = (p->timf2_pb + blk) & c->timf2_mask;
+    float t1 = 0;
+    while (i != p->timf2_pb) { t1 += c->timf2_float[i] * c->timf2_float[i] + c->timf2_float[i + 1] * c->timf2_float[i + 1]; i = (i + 4) & c->timf2_mask; }
+    c->timf2_blockpower[p->timf2_blockpower_pa] = t1;
+    p->timf2_blockpower_pa = (p->timf2_blockpower_pa + 1) & (c->cfg.timf2_blockpower_size - 1);
   }
   return LRH_OK;
 }
@@ -742,6 +788,11 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     p->fft1_na = p->fft1_pa / (2 * c->N1);
     for (int i = 0; i < B; i++) if (p->fft1_nm != c->fft1n_mask) p->fft1_nm++;
     if ((rc = lro_fft1_c(c, p, B))) return rc;
+    if (!c->cfg.second_fft_enable) {            /* wcw.c:1049-1081 + narrowband loop: fft1_mix1_fixed per transform */
+      if ((rc = lro_fft1_mix1_fixed(c, p, B))) return rc;
+      nblocks -= B;
+      continue;
+    }
     if ((rc = lro_make_timf2(c, p, B))) return rc;
     if ((rc = lro_first_noise_blanker(c, p))) return rc;
     int avail = ((p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask);
@@ -773,6 +824,7 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
     case LRH_RING_FFT2_POWERSUM: src = c->fft2_powersum; total = c->N2; break;
     case LRH_RING_WG_WATERF: src = c->wg_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
     case LRH_RING_TIMF3_FLOAT: src = c->timf3_float; total = c->cfg.timf3_size; break;
+    case LRH_RING_TIMF2_BLOCKPOWER: src = c->timf2_blockpower; total = c->cfg.timf2_blockpower_size; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

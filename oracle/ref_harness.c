@@ -55,6 +55,8 @@ void make_timf2(void);
 void first_noise_blanker(void);
 void make_fft2(void);
 void fft2_mix1_fixed(void);
+void fft1_mix1_fixed(void);
+void compute_timf2_powersum(void);
 void clear_fft1_filtercorr(void);
 void make_permute(int mo, int nz, int sz, unsigned short int *perm);
 void make_bigpermute(int mo, int nz, int sz, unsigned int *perm);
@@ -110,6 +112,8 @@ int main(int argc, char **argv)
   int wf_avg = AI("wf_avgnum", 2);               /* fft2 spectra per waterfall line */
   int wf_first = AI("wf_first", 0), wf_pix = AI("wf_pixels", 0);
   int wf_mode = AI("wf_mode", 1);                /* 1: 1:1, k>1: k points/pixel (max), k<0: -k pixels/point (interp) */
+  int second = AI("second_fft", 1);              /* genparm[SECOND_FFT_ENABLE] */
+  int bp_block = AI("blockpower_block", 0), bp_size = AI("blockpower_size", 1024);
   int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
   const char *fin = arg(argc, argv, "in", NULL);
   const char *flim = arg(argc, argv, "liminfo", NULL);
@@ -124,7 +128,7 @@ int main(int argc, char **argv)
   ui.sample_shift = 0; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
   genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
-  genparm[SECOND_FFT_ENABLE] = 1; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
+  genparm[SECOND_FFT_ENABLE] = second; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
   genparm[SECOND_FFT_SINPOW] = sinpow2; genparm[SECOND_FFT_VERNR] = 0; /* -> fft_cntrl[15] */
   genparm[SECOND_FFT_ATT_N] = 8; genparm[MAX_NO_OF_SPURS] = 0; genparm[AFC_ENABLE] = 0; genparm[AFC_LOCK_RANGE] = 0;
   genparm[MIX1_BANDWIDTH_REDUCTION_N] = mixred; genparm[MIX1_NO_OF_CHANNELS] = 1;
@@ -143,6 +147,13 @@ int main(int argc, char **argv)
     fft1_interleave_ratio = (float)ratio;
     fft1_interleave_points = 1 + fft1_interleave_ratio * fft1_size;
     fft1_interleave_points &= 0xfffe;
+    if (!second) {               /* buf.c:315-327: mix1 sized from fft1, interleave re-derived from it */
+      mix1.n = n1 - mixred; if (mix1.n < 3) mix1.n = 3; mix1.size = 1 << mix1.n;
+      mix1.interleave_points = fft1_interleave_ratio * mix1.size;
+      mix1.interleave_points &= 0xfffffffe;
+      fft1_interleave_points = mix1.interleave_points * (fft1_size / mix1.size);
+      mix1.new_points = mix1.size - mix1.interleave_points;
+    }
   }
   fft1_new_points = N1 - fft1_interleave_points;
   max_fft1n = maxfft1n; fft1n_mask = max_fft1n - 1; fft1_mask = max_fft1n * fft1_block - 1;
@@ -246,8 +257,8 @@ int main(int argc, char **argv)
   fft2_to_fft1_ratio = N2 / N1; if (fft2_to_fft1_ratio < 1) fft2_to_fft1_ratio = 1;
 
   /* mix1 sizes first: fft2 interleave is re-derived from mix1 (buf.c:432-455) */
-  mix1.n = n2 - mixred; if (mix1.n < 3) mix1.n = 3; mix1.size = 1 << mix1.n;
-  {
+  if (second) { mix1.n = n2 - mixred; if (mix1.n < 3) mix1.n = 3; mix1.size = 1 << mix1.n; }
+  if (second) {
     double ratio = 0;
     if (sinpow2 != 0) ratio = (sinpow2 == 9) ? 0.625 : (sinpow2 == 8) ? 0.8 : 2 * asin(pow(0.5, 1.0 / sinpow2)) / PI_L;
     fft2_interleave_ratio = (float)ratio;
@@ -304,7 +315,9 @@ int main(int argc, char **argv)
   timf3_size = 16 * 2 * mix1.size; timf3_mask = timf3_size - 1;
   timf3_float = zalloc(sizeof(float) * (2 * timf3_size + 4 * mix1.size));
   timf3_pa = timf3_px = timf3_py = 0;
-  fftx_points_per_hz = 1.0f; mix1_lowest_fq = 0; mix1_highest_fq = (float)N2;
+  fftx_points_per_hz = 1.0f; mix1_lowest_fq = 0; mix1_highest_fq = (float)(second ? N2 : N1);
+  timf2_blockpower_block = bp_block; timf2_blockpower_size = bp_size; timf2_blockpower_mask = bp_size - 1;
+  timf2_blockpower = zalloc(sizeof(float) * 2 * bp_size); timf2_blockpower_pa = 0; timf2_pb = 0;
   mix1_selfreq[0] = fq; old_mix1_selfreq = fq; mix1_point[0] = -1;
   mix1_phase[0] = 0; mix1_phase_step[0] = 0; mix1_phase_rot[0] = 0; mix1_old_phase[0] = 0; mix1_old_point[0] = 0;
 
@@ -345,9 +358,23 @@ int main(int argc, char **argv)
     fft1_pa = (fft1_pa + fft1_mulblock) & fft1_mask;
     fft1_na = fft1_pa / fft1_block;
     if (fft1_nm != fft1n_mask) fft1_nm++;
+    if (!second) {               /* second fft disabled: fft1_c, then the narrowband thread's fft1_mix1_fixed */
+      while (fft1_na != fft1_nb) fft1_c();
+      if (fq >= 0) {
+        fft1_mix1_fixed();
+        float *m = mixtrace + 8 * nfft2;
+        m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
+        m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft1_nx;
+        nfft2++;
+      }
+      int *it0 = itrace + TR_COLS * b;
+      it0[9] = fft1_sumsq_pa; it0[10] = fft1_sumsq_counter; it0[15] = fft1_liminfo_cnt; it0[14] = nfft2; it0[8] = fft1_nx;
+      continue;
+    }
     while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
     int pbeg = timf2p_fit;
     first_noise_blanker();
+    if (bp_block > 0) compute_timf2_powersum();
     while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * fft2_size) {
       int wptr = wg_waterf_ptr;
       make_fft2_status = FFT2_NOT_ACTIVE;
@@ -383,6 +410,8 @@ int main(int argc, char **argv)
   PUTF("fft2_power_float", fft2_power_float, (size_t)N2 * max_fft2n);
   PUTF("fft2_powersum_float", fft2_powersum_float, N2);
   PUTF("timf3_float", timf3_float, timf3_size);
+  PUTF("timf2_blockpower", timf2_blockpower, bp_size);
+  { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);
   PUTF("trace", trace, (size_t)TR_COLS * nblk);
   PUTI("itrace", itrace, (size_t)TR_COLS * nblk);

@@ -28,7 +28,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["hdr", "fft1_window", "fft1_filtercorr", "fft2_window", "mix1_fqwin", "wg_waterf_yfac",
         "fft1_inverted_window", "fft1_first_raw", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
         "timf2_pwr_float", "fft2_float", "fft2_power_float", "fft2_powersum_float", "timf3_float", "wf_lines",
-        "trace", "itrace", "mixtrace", "final"]
+        "trace", "itrace", "mixtrace", "final", "timf2_blockpower", "blockpower_ptrs"]
 
 
 def run_case(name, **override):

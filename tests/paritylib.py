@@ -34,12 +34,27 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
     itrace, wf_lines, mixtrace = [], [], []
     nblk = d["nblk"]
     b = 0
+    while b < nblk and not d["second_fft"]:
+        # second fft disabled: fft1_b -> fft1_c -> fft1_mix1_fixed (ref_harness.c, !second branch)
+        B = min(batch, nblk - b)
+        api.fft1_b(B)
+        api.fft1_c(B)
+        for _ in range(B):
+            api.fft1_mix1_fixed(1)
+            ms = api.mix1_state()
+            mixtrace.append([ms.mix1_point, ms.mix1_phase, ms.mix1_phase_rot, ms.mix1_phase_step,
+                             ms.mix1_old_phase, ms.mix1_old_point, api.p.timf3_pa, api.p.fft1_nx])
+        p = api.p
+        itrace.append([0, 0, 0, 0, 0, 0, p.fft1_nx, p.fft1_sumsq_pa, p.fft1_sumsq_counter, 0, p.fft1_liminfo_cnt])
+        b += B
     while b < nblk:
         B = min(batch, nblk - b)
         api.fft1_b(B)
         api.fft1_c(B)
         api.make_timf2(B)
         api.first_noise_blanker()
+        if d["blockpower_block"]:
+            api.compute_timf2_powersum()
         k = api.fft2_available()
         for _ in range(k):
             wptr = api.p.wg_waterf_ptr
@@ -57,6 +72,9 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
                        p.fft1_lowlevel_points, p.fft1_liminfo_cnt])
         b += B
     out = {key: api.export(ring) for ring, key in RINGS}
+    if d["blockpower_block"]:
+        out["timf2_blockpower"] = api.export(abi.RING_TIMF2_BLOCKPOWER)
+        out["blockpower_ptrs"] = np.array([api.p.timf2_blockpower_pa, api.p.timf2_pb])
     out["itrace"] = np.array(itrace, np.int64)
     out["wf_lines"] = np.array(wf_lines, np.int16).reshape(-1, cfg.wf_xpixels)
     out["mixtrace"] = np.array(mixtrace, np.float64).reshape(-1, 8)
@@ -91,6 +109,12 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
     where the pre-rounding value sits within float32 noise of an integer boundary (|diff| <= 1 there).
     """
     rep = {}
+    rep = {}
+    if "timf2_blockpower" in out:
+        assert np.array_equal(out["blockpower_ptrs"], g["blockpower_ptrs"]), "timf2 powersum pointers differ"
+        e = relerr(out["timf2_blockpower"], g["timf2_blockpower"])
+        rep["timf2_blockpower"] = e
+        assert e <= tol, f"timf2_blockpower: {e:.3e}"
     gi, oi = golden_itrace(g), out["itrace"]
     assert gi.shape == oi.shape, (gi.shape, oi.shape)
     ptr_cols = [0, 1, 2, 3, 6, 7, 8, 9, 10]
@@ -126,7 +150,9 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
         if key == "timf2_pwr_float" and "timf2_pwr_float_noblank" in g:
             # power of the despiked weak signal: judge the error against the scale of the signal the transform
             # actually carried (pulses included), like every other ring
-            e = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(g["timf2_pwr_float_noblank"].astype(np.float64)))
+            den = np.linalg.norm(g["timf2_pwr_float_noblank"].astype(np.float64))
+            num = np.linalg.norm(a.astype(np.float64) - b)
+            e = 0.0 if num == 0 else float(num / max(den, 1e-300))
         out.setdefault("_cmp", {})[key] = (a, b)
         rep[key] = e
         if key == "timf3_float":

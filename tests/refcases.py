@@ -28,7 +28,7 @@ CASES = {
     "n10_n12": dict(n1=10, n2=12, mixred=6, nblk=80, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
                     fq=2200.3, wf_avgnum=2, wf_mode=2, seed=12, timf2pow_log2=15, sumsq_blocks=8,
                     strong=[(-300.25, 9000.0), (37.0, 1000.0), (200.5, 300.0)], weak=[(-100.0, 50.0), (411.3, 25.0)],
-                    pulse_period=1999, lim_halfwidth=3),
+                    pulse_period=1999, lim_halfwidth=3, blockpower_block=4 * 96),
     # N2 < N1 (BASELINE.json config 2 shape, scaled down), no-window fft2 exercises interleave 0 in mix1
     "n11_n9_nowin2": dict(n1=11, n2=9, mixred=4, nblk=40, avg1num=4, avg2num=2, att_n=5, bln_interval=4, bln_avgnum=16,
                           fq=100.2, wf_avgnum=3, wf_mode=-2, seed=13, timf2pow_log2=14, sumsq_blocks=4,
@@ -44,12 +44,17 @@ CASES = {
                          fq=9000.4, wf_avgnum=1, wf_mode=4, seed=15, timf2pow_log2=18, sumsq_blocks=8,
                          strong=[(2048.0, 8000.0), (-1000.5, 600.0)], weak=[(500.0, 40.0)], pulse_period=7919,
                          lim_halfwidth=3, golden_stride=11),
+    # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
+    "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
+                         fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
+                         strong=[(-100.0, 3000.0)], weak=[(188.3, 400.0)], pulse_period=0, lim_halfwidth=3),
 }
 
 
 def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
-             pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1)
+             pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
+             second_fft=1, blockpower_block=0, blockpower_size=1024)
     d.update(CASES[name])
     if d["gain"] is None:
         d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"])
@@ -112,8 +117,10 @@ def lrh_config(d, iq, **kw):
         blanker_min_points=N2 // 3, timf2_noise_floor=d["noise_floor"],
         waterfall_avgnum=d["wf_avgnum"], wf_first_xpoint=d["wf_first"], wf_xpixels=wfpix, wf_mode=d["wf_mode"],
         wf_lines=8, mix1_bandwidth_reduction_n=d["mixred"],
-        timf3_size=16 * 2 * max(8, 1 << (d["n2"] - d["mixred"])),
-        fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2), max_batch=4)
+        timf3_size=16 * 2 * max(8, 1 << ((d["n2"] if d["second_fft"] else d["n1"]) - d["mixred"])),
+        fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2 if d["second_fft"] else N1), max_batch=4,
+        second_fft_enable=d["second_fft"], timf2_blockpower_block=d["blockpower_block"],
+        timf2_blockpower_size=d["blockpower_size"])
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -122,7 +129,8 @@ def lrh_config(d, iq, **kw):
 def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
-            "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2"]
+            "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
+            "blockpower_block", "blockpower_size"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
