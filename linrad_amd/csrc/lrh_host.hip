@@ -337,7 +337,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   A(dev_alloc(c, &c->d_blockpower, cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
-  A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * LRH_BLN_PARTIALS));
+  A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 16384 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
   if (rc == LRH_OK) {
@@ -545,6 +545,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   a.lowlevel_fraction = p->fft1_lowlevel_fraction;
   p->blanker_info_update_counter++;                                      // blank1.c:1550-1601
   a.do_update = 0;
+  { const char *e = getenv("LRH_BLN_DEBUG"); a.debug = e ? atoi(e) : 0; }
   if (p->blanker_info_update_counter >= a.interval) {
     if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
     else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }

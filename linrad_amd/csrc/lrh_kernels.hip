@@ -241,14 +241,21 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
 
 __device__ __forceinline__ int bln_lds(int idx) { return idx + (idx >> 6); }   // lane stride 65 floats: conflict-free
 
+#define LRH_BLN_TILE (256 * LRH_BLN_CHUNK)
+#define LRH_BLN_WORDS (LRH_BLN_TILE / 32 + 2)
+
 __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 {
   // the workgroup's 256 chunks plus the look-back halo, staged once with coalesced loads
-  constexpr int TILE = 256 * LRH_BLN_CHUNK + LRH_BLN_BACK;
+  constexpr int TILE = LRH_BLN_TILE + LRH_BLN_BACK;
   __shared__ float tile[TILE + TILE / 64 + 4];
+  __shared__ unsigned int wbits[LRH_BLN_WORDS];         // decisions for the ring words this tile overlaps
   __shared__ int wg_cnt;
+  __shared__ double wg_sum[4];
   if (threadIdx.x == 0) wg_cnt = 0;
-  const int q0 = blockIdx.x * 256 * LRH_BLN_CHUNK + 1 - LRH_BLN_BACK;      // sequence position of tile[0]
+  for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) wbits[i] = 0;
+  const int qt = blockIdx.x * LRH_BLN_TILE + 1;          // first sequence position owned by this tile
+  const int q0 = qt - LRH_BLN_BACK;                      // sequence position of tile[0]
   static_assert(TILE % (256 * 13) == 0, "staging loop is unrolled 13 loads deep");
   for (int i0 = 0; i0 < TILE; i0 += 256 * 13) {          // 13 independent loads in flight per thread
     float v[13];
@@ -261,6 +268,16 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
     for (int u = 0; u < 13; u++) tile[bln_lds(i0 + u * 256 + threadIdx.x)] = v[u];
   }
   __syncthreads();
+  if (a.debug == 1) return;
+  // ring word that holds the tile's first position; bits of positions inside [w0*32, (w0+WORDS)*32) go to LDS
+  const int w0 = ((a.pbeg + qt) & a.mask) >> 5;
+  const int nwords_ring = (a.mask + 1) >> 5;
+  auto setbit = [&](int q) {
+    const int p = (a.pbeg + q) & a.mask;
+    const int w = ((p >> 5) - w0 + nwords_ring) & (nwords_ring - 1);
+    if (w < LRH_BLN_WORDS) atomicOr(&wbits[w], 1u << (p & 31));
+    else atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31));  // guard reaching into a neighbour tile (rare)
+  };
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int cs = c * LRH_BLN_CHUNK + 1;
   const int ce = min(cs + LRH_BLN_CHUNK - 1, a.total);
@@ -281,14 +298,14 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   }
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0;
   float pulmax = 0;
-  for (int q = s; live && q <= ce; q++) {
-    const int p = (a.pbeg + q) & a.mask;
-    const float v = tile[bln_lds(q - q0)];
+  double s4 = 0;                                         // every-4th-sample power of the chunk before clearing
+  for (int q = (cs + 3) & ~3; q <= ce; q += 4) s4 += (double)tile[bln_lds(q - q0)];   // also for lanes the slow path redoes
+  auto step = [&](int q, float v) {
     if (v > nfl && q >= erase_end) {
       if (ifirst == 0) pk = q;
       if (v > pulmax) pulmax = v;
       ifirst++;
-      if (q >= cs) { bln_setbit(a.mask_bits, p); cnt++; }
+      if (q >= cs) { setbit(q); cnt++; }
     } else if (ifirst != 0) {
       ifirst = 0;
       int ib, ia;
@@ -296,18 +313,42 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
       pulmax = 0;
       if (ext) {
         if (q >= cs) {
-          for (int j = 1; j <= ib; j++) bln_setbit(a.mask_bits, (a.pbeg + pk - j) & a.mask);
-          for (int j = 0; j < ia; j++) bln_setbit(a.mask_bits, (a.pbeg + q + j) & a.mask);
+          for (int j = 1; j <= ib; j++) setbit(pk - j);
+          for (int j = 0; j < ia; j++) setbit(q + j);
           cnt += ib + ia;
         }
         erase_end = q + ia;
       }
     }
+  };
+  if (live) {
+    for (int q = s; q < cs; q++) step(q, tile[bln_lds(q - q0)]);        // replay from the clean point (usually empty)
+    for (int qb = cs; qb <= ce; qb += 16) {                              // own chunk, 16 LDS reads in flight
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] = tile[bln_lds(qb + u - q0)];
+#pragma unroll
+      for (int u = 0; u < 16; u++) if (qb + u <= ce) step(qb + u, v[u]);
+    }
   }
-  // one global atomic per workgroup instead of one per lane
+  // one global atomic per workgroup for the count; chunk sums reduced in a fixed order
   if (cnt) atomicAdd(&wg_cnt, cnt);
+  for (int off = 32; off > 0; off >>= 1) s4 += __shfl_xor(s4, off);
+  if ((threadIdx.x & 63) == 0) wg_sum[threadIdx.x >> 6] = s4;
   __syncthreads();
-  if (threadIdx.x == 0 && wg_cnt) atomicAdd(&a.st->call_cleared, wg_cnt);
+  if (threadIdx.x == 0) {
+    if (wg_cnt) atomicAdd(&a.st->call_cleared, wg_cnt);
+    reinterpret_cast<double *>(a.partials)[blockIdx.x] = (wg_sum[0] + wg_sum[1]) + (wg_sum[2] + wg_sum[3]);
+  }
+  // publish the decision words: interior words are owned by this tile alone (the mask is all zero between calls);
+  // words within guard reach of either end can also be touched by the neighbours, so they are merged atomically
+  const int edge = (max(a.clr1, a.clr2) >> 5) + 2;
+  for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) {
+    const unsigned int wv = wbits[i];
+    if (!wv) continue;
+    const int wi = (w0 + i) & (nwords_ring - 1);
+    if (i < edge || i >= LRH_BLN_TILE / 32 - edge) atomicOr(&a.mask_bits[wi], wv); else a.mask_bits[wi] = wv;
+  }
 }
 
 // exact serial replay, only when a lane of k_blank_scan could not find a clean restart point
@@ -340,21 +381,32 @@ __global__ void k_blank_serial(BlankArgs a)
   a.st->call_cleared = cnt;
 }
 
-// one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word
+// one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word, and report how much
+// every-4th-sample power was removed (the noise statistic of blank1.c:1493-1497 is taken after clearing)
 __global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word, int nwords, int word_mask)
 {
+  __shared__ double red[4];
   const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const int wi = (first_word + w) & word_mask;
-  unsigned int bits = a.mask_bits[wi];
-  if (!bits) return;
-  a.mask_bits[wi] = 0;
-  while (bits) {
-    const int bpos = __ffs(bits) - 1; bits &= bits - 1;
-    const int p = wi * 32 + bpos;
-    a.pwr[p] = 0;
-    a.timf2w[p] = make_float2(0.f, 0.f);                // weak part only (blank1.c:1043-1045)
+  double removed = 0;
+  if (w < nwords) {
+    const int wi = (first_word + w) & word_mask;
+    unsigned int bits = a.mask_bits[wi];
+    if (bits) {
+      a.mask_bits[wi] = 0;
+      while (bits) {
+        const int bpos = __ffs(bits) - 1; bits &= bits - 1;
+        const int p = wi * 32 + bpos;
+        const int q = (p - a.pbeg) & a.mask;              // sequence position 1..total (guards may fall outside)
+        if ((q & 3) == 0 && q >= 4 && q <= a.total) removed += (double)a.pwr[p];
+        a.pwr[p] = 0;
+        a.timf2w[p] = make_float2(0.f, 0.f);              // weak part only (blank1.c:1043-1045)
+      }
+    }
   }
+  for (int off = 32; off > 0; off >>= 1) removed += __shfl_xor(removed, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = removed;
+  __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<double *>(a.partials)[a.npartials + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // every-4th-sample power sum (blank1.c:1493-1497) as fixed-order partial sums
@@ -375,11 +427,22 @@ __global__ __launch_bounds__(256) void k_blank_stats(BlankArgs a)
 __global__ void k_blank_update(BlankArgs a)
 {
   // partial sums in a fixed order: lane l adds partials l, l+64, ..., then a butterfly over the wave
+  __shared__ double wsum[4];
   double tot = 0;
-  for (int i = threadIdx.x; i < a.npartials; i += 64) tot += reinterpret_cast<double *>(a.partials)[i];
+  for (int i = threadIdx.x; i < a.npartials; i += 256) tot += reinterpret_cast<double *>(a.partials)[i];
+  for (int i = threadIdx.x; i < a.nremoved; i += 256) tot -= reinterpret_cast<double *>(a.partials)[a.npartials + i];
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   BlankState *s = a.st;
+  if (a.debug == 3) {
+    double sa = 0, sr = 0;
+    for (int i = 0; i < a.npartials; i++) sa += reinterpret_cast<double *>(a.partials)[i];
+    for (int i = 0; i < a.nremoved; i++) sr += reinterpret_cast<double *>(a.partials)[a.npartials + i];
+    printf("blank_update: npartials %d nremoved %d all %.1f removed %.1f tot %.1f m %d cleared %d total %d\n", a.npartials, a.nremoved, sa, sr, tot, a.m, s->call_cleared, a.total);
+  }
   const int cleared = s->call_cleared;
   s->call_cleared = 0;
   s->last_cleared = cleared;
@@ -796,18 +859,22 @@ hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
   hipLaunchKernelGGL(k_waterfall, dim3((work + 255) / 256, nlines), dim3(256), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st)
+hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 {
+  BlankArgs a = a0;
+  const int ntiles = (a.total + LRH_BLN_TILE - 1) / LRH_BLN_TILE;
+  const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
+  const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
   if (a.mode != 0) {
-    const int nchunks = (a.total + LRH_BLN_CHUNK - 1) / LRH_BLN_CHUNK;
-    hipLaunchKernelGGL(k_blank_scan, dim3((nchunks + 255) / 256), dim3(256), 0, st, a);
+    a.npartials = ntiles; a.nremoved = (nwords + 255) / 256;
+    hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
-    const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
-    const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
-    hipLaunchKernelGGL(k_blank_apply, dim3((nwords + 255) / 256), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
+    hipLaunchKernelGGL(k_blank_apply, dim3(a.nremoved), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
+  } else {
+    a.nremoved = 0;
+    hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);
   }
-  hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -61,11 +61,12 @@ struct BlankArgs {
   int clr1, clr2;
   int mode;                 // stupid_bln_mode
   BlankState *st;
-  float *partials; int npartials;
+  float *partials; int npartials; int nremoved;   // doubles: [npartials] sums, then [nremoved] removed power
   // statistics / update (blank1.c:1472-1601)
   int m; int nstat;         // m: points counted; nstat: samples in the every-4th sum
   int blanker_points;       // timf2_blanker_points after adding m
   int do_update; float lowlevel_fraction; int interval; int avgnum; float factor;
+  int debug;                // tuning experiments only (LRH_BLN_DEBUG), 0 in normal operation
 };
 
 // ---- fft2 ----
