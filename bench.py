@@ -35,6 +35,20 @@ def setup_receiver(cfg, channel, open_fn, synth_mod):
     return rx
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this very command, FETCH doubled as the gfx950 guide prescribes); None when
+    the run's workload is not the profiled one."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        w = t["workload"]
+        if (w["fft1_n"], w["fft2_n"], w["batch"]) != (args.fft1_n, args.fft2_n, args.batch):
+            return None
+        return t["kernels"][kernel]["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(args, fft1_n, fft2_n):
     """The oracle (C restatement of the reference path, -O2 -ffast-math, 1 thread) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -133,7 +147,7 @@ def main():
         avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] / 1e3
         achieved = alg_bytes_launch / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, args),
                 "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                 "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
                 "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
