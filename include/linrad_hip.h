@@ -87,7 +87,10 @@ typedef struct lrh_config {
                                    from fft1 (buf.c:316-332); the reference's own default (uivar.c:371)  */
   int timf2_blockpower_block;   /* floats per S/N-meter block (baseb_graph.c:1330); 0: powersum unused   */
   int timf2_blockpower_size;    /* ring length, pow2 (buf.c:409-412)                                     */
-  int reserved[5];
+  int timf1_frame_channels;     /* RF channels interleaved in one timf1 frame {I0,Q0,I1,Q1,..} (ui.rx_ad_channels/2,
+                                   fft1.c:2052-2055); 0/1: single channel                                 */
+  int timf1_channel_index;      /* which of them this context (this GPU) processes                        */
+  int reserved[3];
 } lrh_config;
 
 /*

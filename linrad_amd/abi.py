@@ -32,7 +32,8 @@ class LrhConfig(C.Structure):
         ("mix1_bandwidth_reduction_n", C.c_int), ("timf3_size", C.c_int), ("fftx_points_per_hz", C.c_float),
         ("mix1_lowest_fq", C.c_float), ("mix1_highest_fq", C.c_float),
         ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
-        ("timf2_blockpower_size", C.c_int), ("reserved", C.c_int * 5),
+        ("timf2_blockpower_size", C.c_int), ("timf1_frame_channels", C.c_int), ("timf1_channel_index", C.c_int),
+        ("reserved", C.c_int * 3),
     ]
 
 
@@ -157,7 +158,7 @@ class StageAPI:
         (self.fft1_interleave_points, self.fft2_interleave_points, self.mix1_size,
          self.mix1_interleave_points, self.timf3_block) = [x.value for x in d]
         self.N1, self.N2 = 1 << cfg.fft1_n, 1 << cfg.fft2_n
-        self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * 4
+        self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * 4 * max(1, cfg.timf1_frame_channels)
 
     def _proto(self, name, argtypes, restype=C.c_int):
         f = self._f(name)

@@ -66,6 +66,7 @@ struct lrh_ctx {
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
   bool have_liminfo = false;
+  bool pack_prev_stale = false;   // d_pack_prev differs from d_pack_cur (a new liminfo table arrived since the last make_timf2)
   // pinned staging for mix1 phases
   float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
   // mix1 scalars
@@ -245,6 +246,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   *out = nullptr;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
+  if (cfg->timf1_frame_channels > 1 && (!ispow2(cfg->timf1_frame_channels) || cfg->timf1_channel_index < 0 || cfg->timf1_channel_index >= cfg->timf1_frame_channels)) return LRH_EINVAL;
   if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
       !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || (cfg->timf2_blockpower_block > 0 && !ispow2(cfg->timf2_blockpower_size)) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
@@ -409,6 +411,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->lowlevel_points = low;
+  c->pack_prev_stale = true;
   c->have_liminfo = true;
   return LRH_OK;
 }
@@ -456,8 +459,11 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 {
   if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   Fft1Args a;
+  const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / 4 - 1;
-  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / 4 - c->I1) & a.ring_mask;     // fft1.c:421-426
+  a.chan_count = C; a.chan_index = C > 1 ? c->cfg.timf1_channel_index : 0;
+  // first sample of the transform, per channel: ref/2 - 2*C*I1 shorts (fft1.c:421-426; 2-ch: fft1.c:2052-2055)
+  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / (4 * C) - c->I1) & (a.ring_mask / C);
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
@@ -509,7 +515,10 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.xcd = (c->xcd_mask >> 1) & 1;
   { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->stream)); }
   // from now on the previous transform was routed with the current table
-  HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
+  if (c->pack_prev_stale) {
+    HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
+    c->pack_prev_stale = false;
+  }
   const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
     p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
@@ -742,7 +751,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   while (nblocks > 0) {
     const int B = nblocks < batch ? nblocks : batch;
     if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
-    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4) & c->timf1_bytemask;
+    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4 * (c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1)) & c->timf1_bytemask;
     p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
     p->fft1_na = p->fft1_pa / (2 * c->N1);
     p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;

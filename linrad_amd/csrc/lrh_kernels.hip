@@ -36,7 +36,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
 #pragma unroll
     for (int m = 0; m < P / R0; m++)
 #pragma unroll
-      for (int s = 0; s < R0; s++) nxt[m * R0 + s] = a.timf1[(p0 + (tid + m * T) + s * (N / R0)) & a.ring_mask];
+      for (int s = 0; s < R0; s++) nxt[m * R0 + s] = a.timf1[((p0 + (tid + m * T) + s * (N / R0)) * a.chan_count + a.chan_index) & a.ring_mask];
   };
   int bi = blockIdx.x;
   if (bi < a.batch) fetch(a.xcd ? xcd_order(bi, a.batch) : bi, tid0);

@@ -20,6 +20,7 @@ struct Fft1Args {
   int direction;
   int xcd;                  // XCD-aware block order on/off
   int batch;                // transforms in this launch (workgroups are persistent)
+  int chan_count, chan_index; // frame layout {I0,Q0,I1,Q1,...}: sample s of this channel is short2 s*chan_count+chan_index
 };
 
 // ---- fft1_c power sums ----

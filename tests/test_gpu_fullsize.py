@@ -132,3 +132,29 @@ def test_fullsize_linearity_and_tone_bins():
     t2 = rxb.export(abi.RING_TIMF2_FLOAT, start, 4 * 4096).reshape(-1, 4)
     z = ((t2[:, 0] + t2[:, 2]) + 1j * (t2[:, 1] + t2[:, 3])) * rxb.get_table("fft2_window", 4096)
     assert abs(p2.sum() / (4096 * np.sum(np.abs(z) ** 2)) - 1) < 1e-5
+
+
+def test_interleaved_two_channel_frames_shard_per_context():
+    """timf1 frames {I0,Q0,I1,Q1} (ui.rx_ad_channels = 4, fft1.c:2052-2055): each context picks its own channel and must
+    equal the single-channel chain run on that channel's samples alone."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    n1, n2 = 11, 9
+    base = chain_config(n1, n2, batch=8)
+    nsamp = base.timf1_bytes // 4
+    chans = [synth_iq(synth_defaults(1 << n1, ch), 0, nsamp).reshape(-1, 2) for ch in (0, 1)]
+    inter = np.empty((nsamp, 4), np.int16)
+    inter[:, 0:2], inter[:, 2:4] = chans[0], chans[1]
+    lim = strong_liminfo(synth_defaults(1 << n1, 0), n1)
+    for ch in (0, 1):
+        cfg2 = chain_config(n1, n2, batch=8)
+        cfg2.timf1_bytes = 2 * base.timf1_bytes
+        cfg2.timf1_frame_channels, cfg2.timf1_channel_index = 2, ch
+        rx2 = _hip(cfg2)
+        _feed(rx2, inter.ravel(), lim, 200.3)
+        rx2.wideband_dsp(24, 8)
+        rx1 = _oracle(base)
+        _feed(rx1, chans[ch].ravel(), lim, 200.3)
+        rx1.wideband_dsp(24, 8)
+        assert rx2.p.timf1p_px == 2 * rx1.p.timf1p_px
+        for ring in (abi.RING_FFT1_FLOAT, abi.RING_FFT2_FLOAT, abi.RING_TIMF3_FLOAT):
+            assert _relerr(rx2.export(ring), rx1.export(ring)) < 2e-5, (ch, ring)
