@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fft1-n", type=int, default=14)
     ap.add_argument("--fft2-n", type=int, default=12)
-    ap.add_argument("--cpu-blocks", type=int, default=6144)
+    ap.add_argument("--cpu-blocks", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -90,7 +90,13 @@ typedef struct lrh_config {
   int timf1_frame_channels;     /* RF channels interleaved in one timf1 frame {I0,Q0,I1,Q1,..} (ui.rx_ad_channels/2,
                                    fft1.c:2052-2055); 0/1: single channel                                 */
   int timf1_channel_index;      /* which of them this context (this GPU) processes                        */
-  int reserved[3];
+  /* fft3 + mix2 (fft3.c:215-283, mix2.c:83-176): baseband filter / decimator behind mix1; fft3_n = 0 disables */
+  int fft3_n;                   /* log2 fft3_size (baseb_graph.c:3332-3376), <= 14                         */
+  int fft3_sinpow;              /* genparm[THIRD_FFT_SINPOW]; mix2 supports 2 (50 % overlap-add) and 0     */
+  int mix2_n;                   /* log2 mix2.size (baseb_graph.c:1302-1323), <= fft3_n                     */
+  int max_fft3n;                /* fft3 ring length in transforms (fft3_totsiz/fft3_block), pow2          */
+  int baseband_size;            /* baseb_raw ring, complex samples, pow2                                   */
+  int reserved[6];
 } lrh_config;
 
 /*
@@ -122,6 +128,8 @@ typedef struct lrh_ptrs {
   int fft2_nx, timf3_pa;
   /* compute_timf2_powersum (wcw.c:84-137) */
   int timf2_pb, timf2_blockpower_pa;
+  /* make_fft3_all (fft3.c:784,797) and fft3_mix2 (mix2.c:1079,2057-2059) */
+  int timf3_px, fft3_pa, fft3_px, baseb_pa;
   int reserved[6];
 } lrh_ptrs;
 
@@ -157,6 +165,8 @@ typedef enum lrh_ring {
   LRH_RING_WG_WATERF,           /* int16 [wf_lines][wf_xpixels]                                    */
   LRH_RING_TIMF3_FLOAT,         /* float [timf3_size]                                              */
   LRH_RING_TIMF2_BLOCKPOWER,    /* float [timf2_blockpower_size]                                   */
+  LRH_RING_FFT3,                /* float [max_fft3n][fft3_size][2]                                 */
+  LRH_RING_BASEB_RAW,           /* float [baseband_size][2]                                        */
   LRH_RING_COUNT
 } lrh_ring;
 
@@ -206,6 +216,14 @@ int lrh_fft2_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
 /* fft1_mix1_fixed (fft2def.h / mix1.c:995-1042): the second-fft-disabled chain picks mix1.size bins straight from
    fft1_float at fft1_px; needs second_fft_enable == 0 */
 int lrh_fft1_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* make_fft3_all, transform part (fft3def.h; fft3.c:215-283): windowed e^{+j} transform of timf3 at timf3_px with DC at
+   fft3_size/2, `batch` transforms spaced fft3_new_points; the GUI power averages of fft3.c:470-760 are not built */
+int lrh_make_fft3_all(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* fft3_mix2, mixer_mode 1 part (mix2.c:145-176): mix2.size bins around fft3_size/2 times bg_filterfunc, fftback,
+   overlap-add into baseb_raw.  PARITY UNPINNED against the reference: fft3_mix2 cannot be run head-less (it continues
+   into the demodulators); checked against the oracle restatement only. */
+int lrh_fft3_mix2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+int lrh_set_bg_filterfunc(lrh_ctx *ctx, const float *bg_filterfunc /* fft3_size floats (baseb_graph.c:1246) */);
 /* compute_timf2_powersum (wcw.c:80-138): weak-signal power per block of released timf2 data, for the S/N meter */
 int lrh_compute_timf2_powersum(lrh_ctx *ctx, lrh_ptrs *p);
 int lrh_set_mix1_selfreq(lrh_ctx *ctx, double fq);        /* mix1_selfreq[0]; <0 deselects               */

@@ -13,7 +13,7 @@ LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2,
 
 (RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
  RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT,
- RING_TIMF2_BLOCKPOWER) = range(12)
+ RING_TIMF2_BLOCKPOWER, RING_FFT3, RING_BASEB_RAW) = range(14)
 _RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16}
 
 
@@ -33,7 +33,8 @@ class LrhConfig(C.Structure):
         ("mix1_lowest_fq", C.c_float), ("mix1_highest_fq", C.c_float),
         ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
         ("timf2_blockpower_size", C.c_int), ("timf1_frame_channels", C.c_int), ("timf1_channel_index", C.c_int),
-        ("reserved", C.c_int * 3),
+        ("fft3_n", C.c_int), ("fft3_sinpow", C.c_int), ("mix2_n", C.c_int), ("max_fft3n", C.c_int),
+        ("baseband_size", C.c_int), ("reserved", C.c_int * 6),
     ]
 
 
@@ -50,6 +51,7 @@ class LrhPtrs(C.Structure):
         ("timf2_px", C.c_int), ("fft2_na", C.c_int), ("fft2_pa", C.c_int), ("fft2_nb", C.c_int), ("fft2_nm", C.c_int),
         ("wg_waterf_sum_counter", C.c_int), ("wg_waterf_ptr", C.c_int), ("fft2_liminfo_cnt", C.c_int),
         ("fft2_nx", C.c_int), ("timf3_pa", C.c_int), ("timf2_pb", C.c_int), ("timf2_blockpower_pa", C.c_int),
+        ("timf3_px", C.c_int), ("fft3_pa", C.c_int), ("fft3_px", C.c_int), ("baseb_pa", C.c_int),
         ("reserved", C.c_int * 6),
     ]
 
@@ -110,6 +112,7 @@ def default_config(fft1_n, fft2_n, **kw):
     c.max_batch = 64
     c.second_fft_enable = 1
     c.timf2_blockpower_block, c.timf2_blockpower_size = 4 * 64, 1024
+    c.fft3_n, c.fft3_sinpow, c.mix2_n, c.max_fft3n, c.baseband_size = 0, 2, 0, 8, 4096
     for k, v in kw.items():
         if not hasattr(c, k):
             raise AttributeError(k)
@@ -138,10 +141,11 @@ class StageAPI:
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
         self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
-        for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed"):
+        for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed", "make_fft3_all", "fft3_mix2"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
+        self._proto("set_bg_filterfunc", [vp, fp])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
         self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
         self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
@@ -158,6 +162,15 @@ class StageAPI:
         (self.fft1_interleave_points, self.fft2_interleave_points, self.mix1_size,
          self.mix1_interleave_points, self.timf3_block) = [x.value for x in d]
         self.N1, self.N2 = 1 << cfg.fft1_n, 1 << cfg.fft2_n
+        # fft3 / mix2 sizes (baseb_graph.c:636-645)
+        self.fft3_interleave_points = 0
+        if cfg.fft3_n:
+            ratio = 0.0 if cfg.fft3_sinpow == 0 else (0.625 if cfg.fft3_sinpow == 9 else 0.8 if cfg.fft3_sinpow == 8 else
+                                                     2 * np.arcsin(0.5 ** (1.0 / cfg.fft3_sinpow)) / np.pi)
+            m2 = 1 << cfg.mix2_n
+            mi = int(np.float32(ratio) * m2) & ~1
+            self.mix2_interleave_points = mi
+            self.fft3_interleave_points = mi * ((1 << cfg.fft3_n) // m2)
         self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * 4 * max(1, cfg.timf1_frame_channels)
 
     def _proto(self, name, argtypes, restype=C.c_int):
@@ -247,6 +260,27 @@ class StageAPI:
     def fft1_mix1_fixed(self, batch=1):
         self._chk(self._f("fft1_mix1_fixed")(self.ctx, C.byref(self.p), batch), "fft1_mix1_fixed")
 
+    def make_fft3_all(self, batch=1):
+        self._chk(self._f("make_fft3_all")(self.ctx, C.byref(self.p), batch), "make_fft3_all")
+
+    def fft3_mix2(self, batch=1):
+        self._chk(self._f("fft3_mix2")(self.ctx, C.byref(self.p), batch), "fft3_mix2")
+
+    def set_bg_filterfunc(self, f):
+        f = np.ascontiguousarray(f, np.float32)
+        assert f.size == (1 << self.cfg.fft3_n)
+        self._chk(self._f("set_bg_filterfunc")(self.ctx, self._fptr(f)), "set_bg_filterfunc")
+
+    def fft3_available(self):
+        """transforms make_fft3_all may run now (do_fft3 loop condition, fft3.c:54-55)"""
+        c, p = self.cfg, self.p
+        n3 = 1 << c.fft3_n
+        have = (p.timf3_pa - p.timf3_px + c.timf3_size) & (c.timf3_size - 1)
+        if have < 2 * n3:
+            return 0
+        new3 = n3 - self.fft3_interleave_points
+        return 1 + (have - 2 * n3) // (2 * new3)
+
     def compute_timf2_powersum(self):
         self._chk(self._f("compute_timf2_powersum")(self.ctx, C.byref(self.p)), "compute_timf2_powersum")
 
@@ -278,7 +312,9 @@ class StageAPI:
                 RING_TIMF2_FLOAT: 4 * c.timf2pow_size, RING_TIMF2_PWR: c.timf2pow_size,
                 RING_FFT2_FLOAT: c.max_fft2n * 2 * self.N2, RING_FFT2_POWER: c.max_fft2n * self.N2,
                 RING_FFT2_POWERSUM: self.N2, RING_WG_WATERF: c.wf_lines * c.wf_xpixels,
-                RING_TIMF3_FLOAT: c.timf3_size, RING_TIMF2_BLOCKPOWER: c.timf2_blockpower_size}[ring]
+                RING_TIMF3_FLOAT: c.timf3_size, RING_TIMF2_BLOCKPOWER: c.timf2_blockpower_size,
+                RING_FFT3: c.max_fft3n * 2 * (1 << c.fft3_n) if c.fft3_n else 0,
+                RING_BASEB_RAW: 2 * c.baseband_size}[ring]
 
     def export(self, ring, offset=0, count=None):
         if count is None:

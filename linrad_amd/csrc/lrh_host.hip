@@ -26,6 +26,8 @@ hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
+hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
+hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
 }  // namespace lrh
 using namespace lrh;
 
@@ -45,6 +47,10 @@ struct lrh_ctx {
   int lowlevel_points = 0;   // liminfo[i]==0 count of the table in force (timf2.c:37-52)
   int mix_cap = 0;           // transforms per mix1 launch the scratch buffers hold
   float *d_blockpower = nullptr;
+  // fft3 / mix2
+  int N3 = 0, I3 = 0, M3 = 0, Nm2 = 0, Im2 = 0, Mm2 = 0;
+  float *d_window3 = nullptr, *d_bgfilt = nullptr; float2 *d_tw3 = nullptr, *d_twm2 = nullptr, *d_fft3 = nullptr, *d_baseb = nullptr, *d_mix2_scratch = nullptr;
+  std::vector<float> h_window3_ref;
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;
   std::string err;
@@ -217,6 +223,7 @@ int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
   c->mix1_bandwidth_reduction_n = 6; c->timf3_size = 32 * ((N2 >> 6) > 8 ? (N2 >> 6) : 8);
   c->fftx_points_per_hz = 1.0f; c->mix1_lowest_fq = 0; c->mix1_highest_fq = (float)N2; c->max_batch = 16;
   c->second_fft_enable = 1; c->timf2_blockpower_block = 0; c->timf2_blockpower_size = 1024;
+  c->fft3_n = 0; c->fft3_sinpow = 2; c->mix2_n = 0; c->max_fft3n = 8; c->baseband_size = 4096;
   return LRH_OK;
 }
 
@@ -227,7 +234,8 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower };
+                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
@@ -269,6 +277,13 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   }
   c->M1 = N1 - c->I1;
   c->mix_cap = cfg->max_fft2n > cfg->max_batch ? cfg->max_fft2n : cfg->max_batch;
+  if (cfg->fft3_n > 0) {                                        // baseb_graph.c:636-645
+    if (cfg->fft3_n < 6 || cfg->fft3_n > 14 || cfg->mix2_n < 3 || cfg->mix2_n > cfg->fft3_n || !ispow2(cfg->max_fft3n) || !ispow2(cfg->baseband_size)) { delete c; return LRH_EINVAL; }
+    c->N3 = 1 << cfg->fft3_n; c->Nm2 = 1 << cfg->mix2_n;
+    c->Im2 = (int)(interleave_ratio(cfg->fft3_sinpow) * c->Nm2); c->Im2 &= 0xfffffffe; c->Mm2 = c->Nm2 - c->Im2;
+    c->I3 = c->Im2 * (c->N3 / c->Nm2); c->M3 = c->N3 - c->I3;
+    if (!(c->Im2 == 0 || c->Im2 == c->Mm2) || cfg->timf3_size < 4 * c->N3 || cfg->baseband_size < 4 * c->Nm2) { delete c; return LRH_EINVAL; }
+  }
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
   if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
@@ -337,6 +352,20 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   A(dev_alloc(c, &c->d_waterf, (size_t)cfg->wf_lines * cfg->wf_xpixels + 64));
   A(dev_alloc(c, &c->d_timf3, cfg->timf3_size / 2 + c->Nm)); A(dev_alloc(c, &c->d_mix_scratch, (size_t)c->mix_cap * c->Nm));
   A(dev_alloc(c, &c->d_blockpower, cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
+  std::vector<float> win3; std::vector<float2> tw3, twm2;
+  if (c->N3) {
+    win3.assign(c->N3, 1.0f); c->h_window3_ref.assign(c->N3, 0.f);
+    if (cfg->fft3_sinpow) {
+      half_window(c->N3, cfg->fft3_sinpow, h, true);
+      for (int i = 0; i <= c->N3 / 2; i++) win3[i] = h[i];
+      for (int i = c->N3 / 2 + 1; i < c->N3; i++) win3[i] = h[c->N3 - i];
+      for (int i = 0; i < c->N3 / 2; i++) { c->h_window3_ref[2 * i] = h[i]; c->h_window3_ref[2 * i + 1] = h[c->N3 / 2 - i]; }
+    }
+    make_twiddles(c->N3, tw3); make_twiddles(c->Nm2, twm2);
+    A(dev_alloc(c, &c->d_window3, c->N3)); A(dev_alloc(c, &c->d_bgfilt, c->N3)); A(dev_alloc(c, &c->d_tw3, c->N3)); A(dev_alloc(c, &c->d_twm2, c->Nm2));
+    A(dev_alloc(c, &c->d_fft3, (size_t)cfg->max_fft3n * c->N3)); A(dev_alloc(c, &c->d_baseb, (size_t)cfg->baseband_size + 2 * c->Nm2));
+    A(dev_alloc(c, &c->d_mix2_scratch, (size_t)cfg->max_fft3n * c->Nm2));
+  }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 16384 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
@@ -349,6 +378,11 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
     if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
+    if (c->N3) {
+      std::vector<float> ones(c->N3, 1.0f);
+      A(upload(c, c->d_window3, win3.data(), c->N3)); A(upload(c, c->d_bgfilt, ones.data(), c->N3));
+      A(upload(c, c->d_tw3, tw3.data(), c->N3)); A(upload(c, c->d_twm2, twm2.data(), c->Nm2));
+    }
     A(upload(c, c->d_wf_itab, itab.data(), itab.size()));
     BlankState bs; memset(&bs, 0, sizeof bs);                          // buf.c:418-431, hires_graph.c:1157-1162
     bs.noise_floor = cfg->timf2_noise_floor; bs.despiked_pwr[0] = (float)cfg->timf2_noise_floor; bs.despiked_pwrinc[0] = 1;
@@ -384,6 +418,7 @@ void lrh_ptrs_init(const lrh_ctx *c, lrh_ptrs *p)
 
 int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c) return LRH_EINVAL;
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
   HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, c->h_filtercorr.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
@@ -393,6 +428,7 @@ int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 
 int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !liminfo) return LRH_EINVAL;
   // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
   const int R0 = c->cfg.fft1_n >= 10 ? 16 : 4;        // first-pass radix of the N1 transform (lrh_fft.hip.h)
@@ -418,6 +454,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 
 int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c) return LRH_EINVAL;
   if (y) c->h_yfac.assign(y, y + c->N1); else default_yfac(c);
   HIPCHK(c, hipMemcpyAsync(c->d_yfac, c->h_yfac.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
@@ -435,6 +472,7 @@ int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
   else if (!strcmp(name, "fft1_filtercorr")) src = &c->h_filtercorr;
   else if (!strcmp(name, "wg_waterf_yfac")) src = &c->h_yfac;
   else if (!strcmp(name, "fft1_inverted_window")) src = &c->h_invwin1_ref;
+  else if (!strcmp(name, "fft3_window")) src = &c->h_window3_ref;
   else return LRH_EINVAL;
   if (count > (int)src->size()) count = (int)src->size();
   memcpy(dst, src->data(), 4 * (size_t)count);
@@ -443,6 +481,7 @@ int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
 
 int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
@@ -457,6 +496,7 @@ void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 // ---------------------------------------------------------------------------------------------- fft1
 int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
@@ -475,6 +515,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 // fft1_c: power sums (fft1.c:4115-4171), counters (fft1.c:4507-4523), slow average (fft1.c:4526-4605)
 int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
   if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
@@ -505,6 +546,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 // ---------------------------------------------------------------------------------------------- timf2
 int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
@@ -533,6 +575,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 // ---------------------------------------------------------------------------------------------- blanker
 int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p) return LRH_EINVAL;
   const int mask = c->timf2pow_mask;
   const int pbeg = p->timf2p_fit;
@@ -566,6 +609,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 
 int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !st) return LRH_EINVAL;
   BlankState bs;
   HIPCHK(c, hipMemcpyAsync(&bs, c->d_bst, sizeof bs, hipMemcpyDeviceToHost, c->stream));
@@ -581,6 +625,7 @@ int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
 // ---------------------------------------------------------------------------------------------- fft2
 int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   const int N = c->N2;
   Fft2Args a;
@@ -661,7 +706,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
   const int selected = s->mix1_selfreq >= 0;
   Mix1OutArgs o; memset(&o, 0, sizeof o);
   o.timf3 = c->d_timf3; o.mask2 = c->cfg.timf3_size / 2 - 1; o.pa_first = p->timf3_pa / 2; o.block = block2;
-  o.nm = Nm; o.overlap = overlap; o.selected = selected; o.scratch = c->d_mix_scratch;
+  o.nm = Nm; o.overlap = overlap; o.selected = selected; o.scratch = c->d_mix_scratch; o.rotate = 1;
   if (selected) {
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
@@ -701,6 +746,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
 
 int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_fixed needs second_fft_enable");
   int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
@@ -713,6 +759,7 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 
 int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_fixed needs second_fft_enable == 0");
   int rc = mix1_run(c, p, batch, c->d_fft1, c->N1, (p->fft1_px / (2 * c->N1)) & c->fft1n_mask, c->fft1n_mask, c->N1 - 1);   // mix1.c:1017-1019
@@ -722,9 +769,57 @@ int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
   return LRH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- fft3 / mix2
+int lrh_set_bg_filterfunc(lrh_ctx *c, const float *f)
+{
+  if (!c || !f) return LRH_EINVAL;
+  if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
+  hipSetDevice(c->cfg.device);
+  HIPCHK(c, hipMemcpyAsync(c->d_bgfilt, f, 4 * c->N3, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
+int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1) return LRH_EINVAL;
+  if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
+  if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  Fft3Args a;
+  a.timf3 = c->d_timf3; a.mask = c->cfg.timf3_size / 2 - 1; a.px_first = p->timf3_px / 2; a.step = c->M3;
+  a.window = c->d_window3; a.tw = c->d_tw3; a.out = c->d_fft3;
+  a.first_slot = p->fft3_pa / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
+  { ProfScope ps(c, "fft3"); HIPCHK(c, launch_fft3(c->cfg.fft3_n, a, batch, c->stream)); }
+  p->timf3_px = (p->timf3_px + batch * 2 * c->M3) & c->timf3_mask;                      // fft3.c:784
+  p->fft3_pa = (p->fft3_pa + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // fft3.c:797
+  return LRH_OK;
+}
+
+int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c || !p || batch < 1) return LRH_EINVAL;
+  if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
+  if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  Mix2Args a;
+  a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
+  a.filt = c->d_bgfilt; a.tw = c->d_twm2; a.scratch = c->d_mix2_scratch; a.nm = c->Nm2;
+  Mix1OutArgs o; memset(&o, 0, sizeof o);
+  o.scratch = c->d_mix2_scratch; o.timf3 = c->d_baseb; o.mask2 = c->cfg.baseband_size - 1; o.pa_first = p->baseb_pa; o.block = c->Mm2;
+  o.nm = c->Nm2; o.overlap = c->Im2 != 0; o.selected = 1; o.rotate = 0;
+  ProfScope ps(c, "mix2");
+  HIPCHK(c, launch_mix2_back(c->cfg.mix2_n, a, batch, c->stream));
+  HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+  p->baseb_pa = (p->baseb_pa + batch * c->Mm2) & (c->cfg.baseband_size - 1);             // mix2.c:1079, 2057
+  p->fft3_px = (p->fft3_px + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // mix2.c:2058
+  return LRH_OK;
+}
+
 // compute_timf2_powersum, wcw.c:80-138
 int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !p) return LRH_EINVAL;
   const int blk = c->cfg.timf2_blockpower_block;
   if (blk <= 0 || (blk & 3)) return fail(c, LRH_ESTATE, "timf2_blockpower_block not configured");
@@ -784,6 +879,7 @@ int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t c
 static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind)
 {
   if (!c || !dst) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
   const void *src; size_t esz = 4, total;
   switch (ring) {
     case LRH_RING_TIMF1: src = c->d_timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;
@@ -808,6 +904,8 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_WG_WATERF: src = c->d_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
     case LRH_RING_TIMF3_FLOAT: src = c->d_timf3; total = c->cfg.timf3_size; break;
     case LRH_RING_TIMF2_BLOCKPOWER: src = c->d_blockpower; total = c->cfg.timf2_blockpower_size; break;
+    case LRH_RING_FFT3: src = c->d_fft3; total = (size_t)c->cfg.max_fft3n * 2 * c->N3; break;
+    case LRH_RING_BASEB_RAW: src = c->d_baseb; total = 2 * (size_t)c->cfg.baseband_size; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;
@@ -816,11 +914,12 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
   return LRH_OK;
 }
 
-int lrh_sync(lrh_ctx *c) { if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return LRH_OK; }
+int lrh_sync(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return LRH_OK; }
 
-int lrh_timer_start(lrh_ctx *c) { if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
+int lrh_timer_start(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
 int lrh_timer_stop(lrh_ctx *c, float *ms)
 {
+  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || !ms) return LRH_EINVAL;
   HIPCHK(c, hipEventRecord(c->t1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->t1));

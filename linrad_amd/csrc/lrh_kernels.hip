@@ -717,6 +717,13 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
   const int pos = (a.pa_first + b * a.block + i) & a.mask2;
   if (!a.selected) { a.timf3[pos] = make_float2(0.f, 0.f); return; }     // mix1_clear
   const float2 nw = a.scratch[(size_t)b * a.nm + i];
+  if (!a.rotate) {                                           // mix2: baseb_raw += first half, raw second half parked
+    if (!a.overlap) { a.timf3[pos] = nw; return; }
+    const float2 old = (b == 0) ? a.timf3[pos] : a.scratch[(size_t)(b - 1) * a.nm + half + i];
+    a.timf3[pos] = make_float2(old.x + nw.x, old.y + nw.y);
+    if (b == batch - 1) a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + half + i];
+    return;
+  }
   const float t1 = a.ph_new[(size_t)b * half + i];
   const float t3 = (float)sin((double)t1), t4 = (float)cos((double)t1);
   if (!a.overlap) {
@@ -730,6 +737,66 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
                              r4 * old.y + r3 * old.x + t4 * nw.y + t3 * nw.x);
   if (b == batch - 1)                                        // raw second half parked at the next block (mix1.c:188-194)
     a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + half + i];
+}
+
+// make_fft3_all, transform part (fft3.c:240-283): window, e^{+j} transform (no conjugation), DC moved to N/2
+template <int LOG2N>
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft3(Fft3Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int px = a.px_first + b * a.step;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int idx = (tid + m * T) + s * (N / R0);
+      const float2 v = a.timf3[(px + idx) & a.mask];
+      const float w = a.window[idx];
+      x[m * R0 + s] = make_float2(v.x * w, v.y * w);
+    }
+  BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
+  float2 *out = a.out + (size_t)((a.first_slot + b) & a.slot_mask) * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k = (tid + m * T) + q * (N / RL);
+      out[(k + N / 2) & (N - 1)] = x[m * RL + q];
+    }
+}
+
+// fft3_mix2 mixer_mode 1 (mix2.c:145-157): mix2.size bins around fft3_size/2 times bg_filterfunc, fftback
+template <int LOG2N>
+__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mix2_back(Mix2Args a)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  __shared__ float2 lds[Plan::LDS_CELLS];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float2 *z = a.fft3 + (size_t)((a.first_slot + b) & a.slot_mask) * a.n3;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int i = (tid + m * T) + s * (N / R0);
+      const int bin = a.n3 / 2 + (i < N / 2 ? i : i - N);     // positive offsets first, then -N/2..-1
+      const float2 v = z[bin];
+      const float w = a.filt[bin];
+      x[m * R0 + s] = make_float2(v.x * w, v.y * w);
+    }
+  BlockFft<LOG2N, P, -1>::run(x, lds, a.tw, tid);
+  float2 *o = a.scratch + (size_t)b * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) o[(tid + m * T) + q * (N / RL)] = x[m * RL + q];
 }
 
 // weak-signal power per block of released timf2 data (wcw.c:84-113), one workgroup per block
@@ -822,6 +889,18 @@ hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream
 hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st)
 {
   LRH_DISPATCH(LRH_LAUNCH_MIX1, log2n, 3, 14, a, batch, st);
+  return hipGetLastError();
+}
+#define LRH_LAUNCH_FFT3(L, a, batch, st) hipLaunchKernelGGL((k_fft3<L>), dim3(batch), dim3(fft_threads(L)), 0, st, a)
+#define LRH_LAUNCH_MIX2(L, a, batch, st) hipLaunchKernelGGL((k_mix2_back<L>), dim3(batch), dim3(fft_threads(L)), 0, st, a)
+hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_FFT3, log2n, 6, 14, a, batch, st);
+  return hipGetLastError();
+}
+hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st)
+{
+  LRH_DISPATCH(LRH_LAUNCH_MIX2, log2n, 3, 14, a, batch, st);
   return hipGetLastError();
 }
 hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st)

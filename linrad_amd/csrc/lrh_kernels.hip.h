@@ -108,6 +108,18 @@ struct Mix1OutArgs {
   float2 *timf3; int mask2;  // timf3 mask in complex samples
   int pa_first; int block;   // in complex samples
   int nm; int overlap; int selected;
+  int rotate;                // 1: mix1 (phase rotation, mix1.c:172-186); 0: mix2 plain overlap-add (mix2.c:158-168)
+};
+
+// ---- fft3 / mix2 (fft3.c:240-283, mix2.c:145-176) ----
+struct Fft3Args {
+  const float2 *timf3; int mask; int px_first; int step;
+  const float *window; const float2 *tw;
+  float2 *out; int first_slot, slot_mask;
+};
+struct Mix2Args {
+  const float2 *fft3; int n3; int first_slot, slot_mask;
+  const float *filt; const float2 *tw; float2 *scratch; int nm;
 };
 
 // ---- compute_timf2_powersum (wcw.c:80-138) ----

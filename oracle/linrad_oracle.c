@@ -42,6 +42,10 @@ struct lro_ctx {
   int16_t *wg_waterf;
   float *timf3_float;
   float *timf2_blockpower;
+  /* fft3 / mix2 */
+  int N3, I3, M3, Nm2, Im2, Mm2;
+  cosin_t *fft3tab, *mix2tab;
+  float *fft3_window, *fft3, *bg_filterfunc, *baseb_raw;
   float *tmp;                  /* scratch, 8*max(N1,N2) floats */
   /* masks */
   int fft1n_mask, fft1_mask, fft1_sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
@@ -237,7 +241,21 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
   c->timf3_float = zal(4 * (size_t)cfg->timf3_size + 16 * c->Nm);
   c->timf2_blockpower = zal(4 * (size_t)(cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
-  c->tmp = zal(sizeof(float) * 8 * NM);
+  if (cfg->fft3_n > 0) {
+    /* baseb_graph.c:636-645: mix2 interleave first, fft3 interleave re-derived from it */
+    if (cfg->mix2_n < 3 || cfg->mix2_n > cfg->fft3_n || !ispow2(cfg->max_fft3n) || !ispow2(cfg->baseband_size)) { free(c); return LRH_EINVAL; }
+    c->N3 = 1 << cfg->fft3_n; c->Nm2 = 1 << cfg->mix2_n;
+    c->Im2 = (int)(interleave_ratio(cfg->fft3_sinpow) * c->Nm2); c->Im2 &= 0xfffffffe; c->Mm2 = c->Nm2 - c->Im2;
+    c->I3 = c->Im2 * (c->N3 / c->Nm2); c->M3 = c->N3 - c->I3;
+    if (!(c->Im2 == 0 || c->Im2 == c->Mm2)) { free(c); return LRH_EINVAL; }
+    c->fft3tab = zal(sizeof(cosin_t) * c->N3); c->mix2tab = zal(sizeof(cosin_t) * c->Nm2);
+    c->fft3_window = zal(4 * (c->N3 + 8)); c->fft3 = zal(sizeof(float) * 2 * c->N3 * cfg->max_fft3n);
+    c->bg_filterfunc = zal(4 * c->N3); c->baseb_raw = zal(8 * (size_t)cfg->baseband_size + 16 * c->Nm2);
+    make_sincos(c->N3, c->fft3tab); make_sincos(c->Nm2, c->mix2tab);
+    if (cfg->fft3_sinpow) lro_make_window(1, c->N3, cfg->fft3_sinpow, c->fft3_window);     /* baseb_graph.c:3680 */
+    for (int i = 0; i < c->N3; i++) c->bg_filterfunc[i] = 1.0f;
+  }
+  c->tmp = zal(sizeof(float) * 8 * (NM > (1 << cfg->fft3_n) ? NM : (1 << cfg->fft3_n)));
   make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
   if (cfg->fft1_sinpow) lro_make_window(1, N1, cfg->fft1_sinpow, c->fft1_window);
   if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) lro_make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
@@ -258,7 +276,8 @@ void lro_close(lro_ctx *c)
   if (!c) return;
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
-                c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower };
+                c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -290,6 +309,7 @@ int lro_get_table(lro_ctx *c, const char *name, float *dst, int count)
   else if (!strcmp(name, "fft1_filtercorr")) { src = c->fft1_filtercorr; n = 2 * c->N1; }
   else if (!strcmp(name, "wg_waterf_yfac")) { src = c->wg_waterf_yfac; n = c->N1; }
   else if (!strcmp(name, "fft1_inverted_window")) { src = c->fft1_inverted_window; n = c->N1 / 2 + 1; }
+  else if (!strcmp(name, "fft3_window")) { src = c->fft3_window; n = c->N3; }
   else return LRH_EINVAL;
   if (count > n) count = n;
   memcpy(dst, src, 4 * (size_t)count); return count;
@@ -774,6 +794,61 @@ int lro_compute_timf2_powersum(lro_ctx *c, lrh_ptrs *p)
   return LRH_OK;
 }
 
+/* ------------------------------------------------------------------ fft3 / mix2 */
+
+int lro_set_bg_filterfunc(lro_ctx *c, const float *f) { if (!c->N3) return LRH_ESTATE; memcpy(c->bg_filterfunc, f, 4 * c->N3); return LRH_OK; }
+
+/* make_fft3_all, 1 channel, transform part (fft3.c:240-283): window (mode-1 storage), e^{+j} radix-2 DIF without the
+   conjugation fft1 applies, permute with half swap (DC at N/2); pointers fft3.c:784, 797 */
+int lro_make_fft3_all(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c->N3) return LRH_ESTATE;
+  int N = c->N3, n = c->cfg.fft3_n, nn = N / 2, m = c->timf3_mask;
+  for (int b = 0; b < batch; b++) {
+    float *z = c->tmp, *out = c->fft3 + p->fft3_pa;
+    int pa = p->timf3_px, pb = (pa + N) & m;
+    int win = c->cfg.fft3_sinpow != 0;
+    for (int ia = 0; ia < nn; ia++) {
+      float wa = win ? c->fft3_window[2 * ia] : 1.0f, wb = win ? c->fft3_window[2 * ia + 1] : 1.0f;
+      z[2 * ia] = c->timf3_float[pa] * wa; z[2 * ia + 1] = c->timf3_float[pa + 1] * wa;
+      z[2 * (ia + nn)] = c->timf3_float[pb] * wb; z[2 * (ia + nn) + 1] = c->timf3_float[pb + 1] * wb;
+      pa = (pa + 2) & m; pb = (pb + 2) & m;
+    }
+    dif_stages(N, n, z, c->fft3tab, +1, 2);
+    for (unsigned i = 0; i < (unsigned)N; i++) { unsigned k = (bitrev(i, n) + nn) & (N - 1); out[2 * k] = z[2 * i]; out[2 * k + 1] = z[2 * i + 1]; }
+    p->timf3_px = (p->timf3_px + 2 * c->M3) & m;
+    p->fft3_pa = (p->fft3_pa + 2 * N) & (c->cfg.max_fft3n * 2 * N - 1);
+  }
+  return LRH_OK;
+}
+
+/* fft3_mix2, mixer_mode 1 (mix2.c:145-176) + pointers (mix2.c:1079, 2057-2059).  PARITY UNPINNED: the reference function
+   cannot be run head-less, this restates the 30 lines directly. */
+int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
+{
+  if (!c->N3) return LRH_ESTATE;
+  int N = c->N3, size = c->Nm2, sizhalf = size / 2, nn = 2 * (size - 1), bmask = c->cfg.baseband_size - 1;
+  for (int b = 0; b < batch; b++) {
+    float *tmp = c->tmp;
+    const float *f3 = c->fft3;
+    int p0 = p->fft3_px + N, k = N / 2;
+    for (int i = 0; i < sizhalf; i++) { tmp[2 * i] = f3[p0 + 2 * i] * c->bg_filterfunc[k + i]; tmp[2 * i + 1] = f3[p0 + 2 * i + 1] * c->bg_filterfunc[k + i]; }
+    for (int i = 0; i < sizhalf; i++) { tmp[nn - 2 * i] = f3[p0 - 2 * i - 2] * c->bg_filterfunc[k - i - 1]; tmp[nn - 2 * i + 1] = f3[p0 - 2 * i - 1] * c->bg_filterfunc[k - i - 1]; }
+    dif_stages(size, c->cfg.mix2_n, tmp, c->mix2tab, -1, 2); bitrev_inplace(size, c->cfg.mix2_n, tmp, 2);
+    float *br = c->baseb_raw;
+    if (c->Im2 != 0) {                                   /* THIRD_FFT_SINPOW == 2: 50 % overlap-add */
+      for (int i = 0; i < sizhalf; i++) { br[2 * p->baseb_pa + 2 * i] += tmp[2 * i]; br[2 * p->baseb_pa + 2 * i + 1] += tmp[2 * i + 1]; }
+      int q = (p->baseb_pa + sizhalf) & bmask;
+      for (int i = 0; i < size; i++) br[2 * q + i] = tmp[size + i];
+    } else {                                             /* no window: transforms simply follow each other */
+      for (int i = 0; i < 2 * size; i++) br[2 * p->baseb_pa + i] = tmp[i];
+    }
+    p->baseb_pa = (p->baseb_pa + c->Mm2) & bmask;
+    p->fft3_px = (p->fft3_px + 2 * N) & (c->cfg.max_fft3n * 2 * N - 1);
+  }
+  return LRH_OK;
+}
+
 /* ------------------------------------------------------------------ orchestration */
 
 /* single-CPU branch of wideband_dsp, wcw.c:1036-1118, batched */
@@ -825,6 +900,8 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
     case LRH_RING_WG_WATERF: src = c->wg_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
     case LRH_RING_TIMF3_FLOAT: src = c->timf3_float; total = c->cfg.timf3_size; break;
     case LRH_RING_TIMF2_BLOCKPOWER: src = c->timf2_blockpower; total = c->cfg.timf2_blockpower_size; break;
+    case LRH_RING_FFT3: src = c->fft3; total = (size_t)c->cfg.max_fft3n * 2 * c->N3; break;
+    case LRH_RING_BASEB_RAW: src = c->baseb_raw; total = 2 * (size_t)c->cfg.baseband_size; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

@@ -57,6 +57,7 @@ void make_fft2(void);
 void fft2_mix1_fixed(void);
 void fft1_mix1_fixed(void);
 void compute_timf2_powersum(void);
+void make_fft3_all(void);
 void clear_fft1_filtercorr(void);
 void make_permute(int mo, int nz, int sz, unsigned short int *perm);
 void make_bigpermute(int mo, int nz, int sz, unsigned int *perm);
@@ -114,6 +115,7 @@ int main(int argc, char **argv)
   int wf_mode = AI("wf_mode", 1);                /* 1: 1:1, k>1: k points/pixel (max), k<0: -k pixels/point (interp) */
   int second = AI("second_fft", 1);              /* genparm[SECOND_FFT_ENABLE] */
   int bp_block = AI("blockpower_block", 0), bp_size = AI("blockpower_size", 1024);
+  int n3 = AI("fft3_n", 0), sinpow3 = AI("fft3_sinpow", 2), nm2 = AI("mix2_n", 0), maxfft3n = AI("max_fft3n", 8);
   int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
   const char *fin = arg(argc, argv, "in", NULL);
   const char *flim = arg(argc, argv, "liminfo", NULL);
@@ -321,6 +323,35 @@ int main(int argc, char **argv)
   mix1_selfreq[0] = fq; old_mix1_selfreq = fq; mix1_point[0] = -1;
   mix1_phase[0] = 0; mix1_phase_step[0] = 0; mix1_phase_rot[0] = 0; mix1_old_phase[0] = 0; mix1_old_point[0] = 0;
 
+  /* ---- fft3 (baseb_graph.c:636-645, 3369-3409, 3679-3680): transform part of make_fft3_all only ---- */
+  int nfft3 = 0;
+  if (n3 > 0) {
+    fft3_n = n3; fft3_size = 1 << n3;
+    mix2.n = nm2; mix2.size = 1 << nm2;
+    {
+      double ratio = 0;
+      if (sinpow3 != 0) ratio = (sinpow3 == 9) ? 0.625 : (sinpow3 == 8) ? 0.8 : 2 * asin(pow(0.5, 1.0 / sinpow3)) / PI_L;
+      fft3_interleave_ratio = (float)ratio;
+      mix2.interleave_points = fft3_interleave_ratio * mix2.size;
+      mix2.interleave_points &= 0xfffffffe;
+      mix2.new_points = mix2.size - mix2.interleave_points;
+      fft3_interleave_points = mix2.interleave_points * (fft3_size / mix2.size);
+      fft3_new_points = fft3_size - fft3_interleave_points;
+    }
+    genparm[THIRD_FFT_SINPOW] = sinpow3;
+    fft3_block = fft3_size * 2; fft3_totsiz = fft3_block * maxfft3n; fft3_mask = fft3_totsiz - 1;
+    fft3 = zalloc(sizeof(float) * fft3_totsiz); fft3_tmp = zalloc(sizeof(float) * (4 * fft3_size + 64));
+    fft3_tab = zalloc(sizeof(COSIN_TABLE) * fft3_size); fft3_permute = zalloc(sizeof(short) * fft3_size * 2);
+    fft3_window = zalloc(sizeof(float) * (fft3_size + 32));
+    init_fft(1, fft3_n, fft3_size, fft3_tab, fft3_permute);
+    make_window(1, fft3_size, sinpow3, fft3_window);
+    fft3_pa = fft3_px = 0; timf3_px = 0; yieldflag_ndsp_fft3 = 0;
+    thread_command_flag[THREAD_FFT3] = THRFLAG_ACTIVE;
+    memset(&bg, 0, sizeof(bg)); bg.fft_avgnum = 1; bg.waterfall_avgnum = 1 << 30;
+    bg_xpoints = 0; bg_show_pa = 0; bg_first_xpoint = 0; fft3_slowsum_recalc = 0; fft3_slowsum_cnt = 0; fft3_show_size = 1;
+    bg_avg_counter = 0; bg_filter_points = 0; bg_waterf_sum_counter = 0;
+  }
+
   /* ---- dump tables ---- */
   {
     int hdr[24] = { n1, N1, fft1_interleave_points, n2, N2, fft2_interleave_points, (int)mix1.n, (int)mix1.size,
@@ -339,6 +370,9 @@ int main(int argc, char **argv)
     PUTF("wg_waterf_yfac", wg_waterf_yfac, N1);
   }
 
+#define RUN_FFT3() do { if (n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * fft3_size && \
+      ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) { make_fft3_all(); nfft3++; \
+      fft3_px = (fft3_px + fft3_block) & fft3_mask; /* consumer side (fft3_mix2, mix2.c:2058) not run head-less */ } } while (0)
   /* ---- run ---- */
   float *trace = zalloc(sizeof(float) * TR_COLS * nblk);
   int *itrace = zalloc(sizeof(int) * TR_COLS * nblk);
@@ -366,6 +400,7 @@ int main(int argc, char **argv)
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
         m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft1_nx;
         nfft2++;
+        RUN_FFT3();
       }
       int *it0 = itrace + TR_COLS * b;
       it0[9] = fft1_sumsq_pa; it0[10] = fft1_sumsq_counter; it0[15] = fft1_liminfo_cnt; it0[14] = nfft2; it0[8] = fft1_nx;
@@ -385,6 +420,7 @@ int main(int argc, char **argv)
         float *m = mixtrace + 8 * nfft2;
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
         m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft2_nx;
+        RUN_FFT3();
       } else {
         fft2_nx = (fft2_nx + 1) & fft2n_mask;
       }
@@ -410,6 +446,8 @@ int main(int argc, char **argv)
   PUTF("fft2_power_float", fft2_power_float, (size_t)N2 * max_fft2n);
   PUTF("fft2_powersum_float", fft2_powersum_float, N2);
   PUTF("timf3_float", timf3_float, timf3_size);
+  if (n3 > 0) { PUTF("fft3", fft3, fft3_totsiz); PUTF("fft3_window", fft3_window, fft3_size);
+    int f3[4] = { nfft3, fft3_pa, timf3_px, fft3_interleave_points }; PUTI("fft3_ptrs", f3, 4); }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);
   { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);

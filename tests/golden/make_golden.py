@@ -28,7 +28,8 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["hdr", "fft1_window", "fft1_filtercorr", "fft2_window", "mix1_fqwin", "wg_waterf_yfac",
         "fft1_inverted_window", "fft1_first_raw", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
         "timf2_pwr_float", "fft2_float", "fft2_power_float", "fft2_powersum_float", "timf3_float", "wf_lines",
-        "trace", "itrace", "mixtrace", "final", "timf2_blockpower", "blockpower_ptrs"]
+        "trace", "itrace", "mixtrace", "final", "timf2_blockpower", "blockpower_ptrs", "fft3", "fft3_window",
+        "fft3_ptrs"]
 
 
 def run_case(name, **override):
@@ -52,7 +53,7 @@ def main():
         d, iq, lim, ref = run_case(name)
         # second run with the blanker off: timf2 ring straight out of make_timf2
         _, _, _, ref_nb = run_case(name, stupid=0)
-        out = {k: ref[k] for k in KEEP}
+        out = {k: ref[k] for k in KEEP if k in ref}
         out["timf2_float_noblank"] = ref_nb["timf2_float"]
         out["timf2_pwr_float_noblank"] = ref_nb["timf2_pwr_float"]
         stride = d.get("golden_stride", 1)

@@ -31,6 +31,9 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
     api.timf1_write(iq)
     api.set_liminfo(lim)
     api.set_mix1_selfreq(d["fq"])
+    if d["fft3_n"]:
+        n3 = 1 << d["fft3_n"]
+        api.set_bg_filterfunc(np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))   # stand-in for make_bg_filter
     itrace, wf_lines, mixtrace = [], [], []
     nblk = d["nblk"]
     b = 0
@@ -62,6 +65,11 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
             if api.p.wg_waterf_ptr != wptr:
                 wf_lines.append(api.export(abi.RING_WG_WATERF, wptr, cfg.wf_xpixels))
             api.fft2_mix1_fixed(1)
+            if d["fft3_n"]:
+                k3 = api.fft3_available()
+                if k3:
+                    api.make_fft3_all(k3)
+                    api.fft3_mix2(k3)
             ms = api.mix1_state()
             mixtrace.append([ms.mix1_point, ms.mix1_phase, ms.mix1_phase_rot, ms.mix1_phase_step,
                              ms.mix1_old_phase, ms.mix1_old_point, api.p.timf3_pa, api.p.fft2_nx])
@@ -72,6 +80,10 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
                        p.fft1_lowlevel_points, p.fft1_liminfo_cnt])
         b += B
     out = {key: api.export(ring) for ring, key in RINGS}
+    if d["fft3_n"]:
+        out["fft3"] = api.export(abi.RING_FFT3)
+        out["baseb_raw"] = api.export(abi.RING_BASEB_RAW)
+        out["fft3_ptrs"] = np.array([api.p.fft3_pa, api.p.timf3_px, api.fft3_interleave_points])
     if d["blockpower_block"]:
         out["timf2_blockpower"] = api.export(abi.RING_TIMF2_BLOCKPOWER)
         out["blockpower_ptrs"] = np.array([api.p.timf2_blockpower_pa, api.p.timf2_pb])
@@ -110,6 +122,16 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
     """
     rep = {}
     rep = {}
+    if "fft3" in out:
+        assert np.array_equal(out["fft3_ptrs"], g["fft3_ptrs"][1:]), "fft3 pointers differ"
+        a, b = out["fft3"].astype(np.float64), g["fft3"].astype(np.float64)
+        # band-limited product of mix1: same float32 floor argument as timf3
+        n2 = 1 << out["cfg"].fft2_n
+        wide = np.linalg.norm(g["fft2_float"].astype(np.float64)) / np.sqrt(out["cfg"].max_fft2n)
+        floor = 16 * 6e-8 * wide * np.sqrt(a.size / (2.0 * n2))
+        e = relerr(a, b)
+        rep["fft3"] = e
+        assert e <= tol or np.linalg.norm(a - b) <= floor, f"fft3: rel {e:.3e}"
     if "timf2_blockpower" in out:
         assert np.array_equal(out["blockpower_ptrs"], g["blockpower_ptrs"]), "timf2 powersum pointers differ"
         e = relerr(out["timf2_blockpower"], g["timf2_blockpower"])

@@ -44,6 +44,11 @@ CASES = {
                          fq=9000.4, wf_avgnum=1, wf_mode=4, seed=15, timf2pow_log2=18, sumsq_blocks=8,
                          strong=[(2048.0, 8000.0), (-1000.5, 600.0)], weak=[(500.0, 40.0)], pulse_period=7919,
                          lim_halfwidth=3, golden_stride=11),
+    # fft3 behind mix1 (make_fft3_all transform part pinned by the reference; mix2 filter/decimate vs the oracle only)
+    "n10_n12_fft3": dict(n1=10, n2=12, mixred=5, nblk=120, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                         fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
+                         strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
+                         pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
@@ -54,7 +59,7 @@ CASES = {
 def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
-             second_fft=1, blockpower_block=0, blockpower_size=1024)
+             second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8)
     d.update(CASES[name])
     if d["gain"] is None:
         d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"])
@@ -120,7 +125,8 @@ def lrh_config(d, iq, **kw):
         timf3_size=16 * 2 * max(8, 1 << ((d["n2"] if d["second_fft"] else d["n1"]) - d["mixred"])),
         fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2 if d["second_fft"] else N1), max_batch=4,
         second_fft_enable=d["second_fft"], timf2_blockpower_block=d["blockpower_block"],
-        timf2_blockpower_size=d["blockpower_size"])
+        timf2_blockpower_size=d["blockpower_size"], fft3_n=d["fft3_n"], fft3_sinpow=d["fft3_sinpow"], mix2_n=d["mix2_n"],
+        max_fft3n=d["max_fft3n"], baseband_size=4096)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -130,7 +136,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
