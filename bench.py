@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--rounds", type=int, default=4, help="batches of --batch fft1 blocks per step (pipelined on two streams)")
     ap.add_argument("--fft1-n", type=int, default=14)
     ap.add_argument("--fft2-n", type=int, default=12)
     ap.add_argument("--cpu-blocks", type=int, default=16384)
@@ -93,12 +94,12 @@ def main():
     cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
     N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
-    samples_per_step = args.batch * M1
+    samples_per_step = args.batch * args.rounds * M1
     use_dist = dist is not None
     xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if use_dist else None
 
     def step():
-        rx.wideband_dsp(args.batch, args.batch)
+        rx.wideband_dsp(args.batch * args.rounds, args.batch)
         if use_dist:
             # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
             rx.export_device(abi.RING_FFT1_SUMSQ, xchg.data_ptr(), newest_sumsq_block(rx), N1)
@@ -132,6 +133,9 @@ def main():
     stages = {}
     if rank == 0:
         rx.profile_enable(True)
+        rx.wideband_dsp(args.batch, args.batch)                # first serial pass after the two-stream run: discarded
+        rx.sync()
+        rx.profile_enable(True)                                # resets the accumulators
         for _ in range(max(3, min(args.steps, 10))):
             rx.wideband_dsp(args.batch, args.batch)
         rx.sync()
@@ -143,7 +147,7 @@ def main():
         dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
         nsteps_prof = stages["fft1"]["launches"]
         launches_per_step = stages[dom]["launches"] / nsteps_prof
-        alg_bytes_launch = ALG_BYTES[dom] * samples_per_step / launches_per_step
+        alg_bytes_launch = ALG_BYTES[dom] * (args.batch * M1) / launches_per_step      # the profiling loop runs single batches
         avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] / 1e3
         achieved = alg_bytes_launch / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -166,8 +170,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: 1 channel/GPU complex-int16 IQ, fft1_size={N1} sin^2 50% overlap, "
                                    f"timf2 + stupid blanker, fft2_size={N2} sin^2, mix1 size {N2 >> 6}; "
-                                   f"{args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
-                       "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "channels": world,
+                                   f"{args.rounds} x {args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
+                       "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "rounds_per_step": args.rounds, "channels": world,
                        "parallelism": f"1 RF channel per GPU x{world}"},
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "roofline": roof, "cpu_baseline": cpu, "stages": stages,

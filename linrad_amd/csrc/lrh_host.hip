@@ -52,7 +52,12 @@ struct lrh_ctx {
   float *d_window3 = nullptr, *d_bgfilt = nullptr; float2 *d_tw3 = nullptr, *d_twm2 = nullptr, *d_fft3 = nullptr, *d_baseb = nullptr, *d_mix2_scratch = nullptr;
   std::vector<float> h_window3_ref;
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
+  hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
+  hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
+  hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
+  bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
+  int pipeline = 1;                  // LRH_PIPELINE=0 turns the two-stream schedule off
   std::string err;
   // device tables
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
@@ -101,8 +106,8 @@ struct ProfScope {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
     hipEvent_t e; hipEventCreate(&e); return e;
   }
-  ProfScope(lrh_ctx *c_, const char *n) : c(c_), name(n) { if (c->prof) { e0 = get(c); e1 = get(c); hipEventRecord(e0, c->stream); } }
-  ~ProfScope() { if (c->prof) { hipEventRecord(e1, c->stream); c->prof_pend.push_back({name, e0, e1}); } }
+  ProfScope(lrh_ctx *c_, const char *n) : c(c_), name(n) { if (c->prof) { e0 = get(c); e1 = get(c); hipEventRecord(e0, c->cur); } }
+  ~ProfScope() { if (c->prof) { hipEventRecord(e1, c->cur); c->prof_pend.push_back({name, e0, e1}); } }
 };
 static void prof_collect(lrh_ctx *c)
 {
@@ -231,6 +236,8 @@ void lrh_close(lrh_ctx *c)
 {
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1] }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -297,7 +304,10 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
-  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  c->cur = c->stream;
+  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1] }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (const char *e2 = getenv("LRH_PIPELINE")) c->pipeline = atoi(e2);
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
   int rc = LRH_OK;
 #define A(call) do { if (rc == LRH_OK) rc = (call); } while (0)
@@ -508,7 +518,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
   ProfScope ps(c, "fft1");
-  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->stream));
+  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
   return LRH_OK;
 }
 
@@ -523,14 +533,14 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
   SumsqArgs sa;
   sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.sumsq_mask = c->sumsq_mask;
   sa.first_nb = p->fft1_nb; sa.batch = batch; sa.avg = avg1; sa.c0 = p->fft1_sumsq_counter; sa.pa0 = p->fft1_sumsq_pa;
-  { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->stream)); }
+  { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
   const int nupd = (p->fft1_sumsq_counter + batch) / avg1;              // groups completed by this batch
   if (nupd > 0) {
     SlowsumArgs ua;
     ua.sumsq = c->d_sumsq; ua.slowsum = c->d_slowsum; ua.n = N; ua.bufsize = c->cfg.fft1_sumsq_bufsize; ua.avg2 = c->cfg.fft_avg2num;
     ua.nupd = nupd; ua.pa0 = p->fft1_sumsq_pa; ua.recalc0 = p->fft1_sumsq_recalc; ua.step = c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
     ProfScope ps(c, "slowsum");
-    HIPCHK(c, launch_slowsum(ua, c->stream));
+    HIPCHK(c, launch_slowsum(ua, c->cur));
     for (int e = 0; e < nupd; e++) {                                     // same recursion as the kernel (fft1.c:4568-4573)
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
       p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
@@ -555,10 +565,10 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
   a.xcd = (c->xcd_mask >> 1) & 1;
-  { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->stream)); }
+  { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
   // from now on the previous transform was routed with the current table
   if (c->pack_prev_stale) {
-    HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->cur));
     c->pack_prev_stale = false;
   }
   const int low = c->lowlevel_points;
@@ -603,7 +613,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
   }
   ProfScope ps(c, "blanker");
-  HIPCHK(c, launch_blanker(a, c->cfg.timf2pow_size / 32, c->stream));
+  HIPCHK(c, launch_blanker(a, c->cfg.timf2pow_size / 32, c->cur));
   return LRH_OK;
 }
 
@@ -632,20 +642,26 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
   a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
   a.xcd = (c->xcd_mask >> 2) & 1;
-  if (c->cfg.fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->stream)); }
+  if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
+  if (c->cfg.fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->cur)); }
   else {
     Fft2BigArgs g;
     g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
     g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
     g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
     ProfScope ps(c, "fft2");
-    HIPCHK(c, launch_fft2_big(c->cfg.fft2_n, g, batch, c->stream));
+    HIPCHK(c, launch_fft2_big(c->cfg.fft2_n, g, batch, c->cur));
   }
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
   { float *t = c->d_powersum2; c->d_powersum2 = c->d_powersum2_alt; c->d_powersum2_alt = t; }   // ping-pong: group 0 reads while the last group writes
-  { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->stream)); }
+  hipStream_t main_s = c->cur;
+  if (c->split_fft2_tail) {                      // power sums and waterfall lines only feed the GUI side: side stream
+    HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0));
+    c->cur = c->stream2;
+  }
+  { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
   const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
   if (nlines > 0) {
     int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
@@ -654,8 +670,10 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     w.npix = c->cfg.wf_xpixels; w.first = c->cfg.wf_first_xpoint; w.siz = N; w.hx = hx; w.hp = hp;
     w.ptr0 = p->wg_waterf_ptr; w.wf_size = c->cfg.wf_lines * c->cfg.wf_xpixels; w.line_stride = N;
     ProfScope ps(c, "waterfall");
-    HIPCHK(c, launch_waterfall(w, nlines, c->stream));
+    HIPCHK(c, launch_waterfall(w, nlines, c->cur));
   }
+  if (c->split_fft2_tail) HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2));
+  c->cur = main_s;
   for (int b = 0; b < batch; b++) {                                      // fft2.c:672, 703-705, 813-815, 1831-1845
     p->wg_waterf_sum_counter++;
     if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) {
@@ -727,18 +745,18 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
       s->mix1_phase = t1;
     }
     float *dn = c->d_ph + slot * c->ph_stride;
-    HIPCHK(c, hipMemcpyAsync(dn, hn, sizeof(float) * 2 * (size_t)batch * half, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream));
+    HIPCHK(c, hipMemcpyAsync(dn, hn, sizeof(float) * 2 * (size_t)batch * half, hipMemcpyHostToDevice, c->cur));
+    HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
     o.ph_new = dn; o.ph_old = dn + (size_t)batch * half;
     Mix1Args a;
     a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
     a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
     ProfScope ps(c, "mix1");
-    HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->stream));
-    HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+    HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->cur));
+    HIPCHK(c, launch_mix1_out(o, batch, c->cur));
   } else {
     ProfScope ps(c, "mix1");
-    HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+    HIPCHK(c, launch_mix1_out(o, batch, c->cur));
   }
   p->timf3_pa = (p->timf3_pa + batch * 2 * block2) & c->timf3_mask;      // mix1.c:991 / 1039
   return LRH_OK;
@@ -790,7 +808,7 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.timf3 = c->d_timf3; a.mask = c->cfg.timf3_size / 2 - 1; a.px_first = p->timf3_px / 2; a.step = c->M3;
   a.window = c->d_window3; a.tw = c->d_tw3; a.out = c->d_fft3;
   a.first_slot = p->fft3_pa / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
-  { ProfScope ps(c, "fft3"); HIPCHK(c, launch_fft3(c->cfg.fft3_n, a, batch, c->stream)); }
+  { ProfScope ps(c, "fft3"); HIPCHK(c, launch_fft3(c->cfg.fft3_n, a, batch, c->cur)); }
   p->timf3_px = (p->timf3_px + batch * 2 * c->M3) & c->timf3_mask;                      // fft3.c:784
   p->fft3_pa = (p->fft3_pa + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // fft3.c:797
   return LRH_OK;
@@ -809,8 +827,8 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   o.scratch = c->d_mix2_scratch; o.timf3 = c->d_baseb; o.mask2 = c->cfg.baseband_size - 1; o.pa_first = p->baseb_pa; o.block = c->Mm2;
   o.nm = c->Nm2; o.overlap = c->Im2 != 0; o.selected = 1; o.rotate = 0;
   ProfScope ps(c, "mix2");
-  HIPCHK(c, launch_mix2_back(c->cfg.mix2_n, a, batch, c->stream));
-  HIPCHK(c, launch_mix1_out(o, batch, c->stream));
+  HIPCHK(c, launch_mix2_back(c->cfg.mix2_n, a, batch, c->cur));
+  HIPCHK(c, launch_mix1_out(o, batch, c->cur));
   p->baseb_pa = (p->baseb_pa + batch * c->Mm2) & (c->cfg.baseband_size - 1);             // mix2.c:1079, 2057
   p->fft3_px = (p->fft3_px + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // mix2.c:2058
   return LRH_OK;
@@ -831,44 +849,114 @@ int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
   a.timf2w = c->d_timf2w; a.mask = c->timf2pow_mask; a.first = p->timf2_pb / 4; a.block = blk / 4;
   a.out = c->d_blockpower; a.out_mask = c->cfg.timf2_blockpower_size - 1; a.out_first = p->timf2_blockpower_pa;
   ProfScope ps(c, "blockpower");
-  HIPCHK(c, launch_blockpower(a, n, c->stream));
+  HIPCHK(c, launch_blockpower(a, n, c->cur));
   p->timf2_pb = (p->timf2_pb + n * blk) & c->timf2_mask;
   p->timf2_blockpower_pa = (p->timf2_blockpower_pa + n) & (c->cfg.timf2_blockpower_size - 1);
   return LRH_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- orchestration
-// single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round
+// single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round.
+// Device schedule when several rounds are requested (second fft on): the transform kernels of N = 16384 occupy one
+// workgroup per CU and are latency/compute bound, while fft1_c's sums, the blanker and the fft2 power sums are short
+// bandwidth-bound kernels that need no LDS -- so the latter run on a second stream underneath the former:
+//   main:  fft1(k+1) | fft2(k) mix1(k) | timf2(k+1) | fft1(k+2) ...
+//   side:  blanker(k) sumsq(k+1) slowsum(k+1) | powersum2(k) waterfall(k) | ...
+// Events carry exactly the data dependencies of the serial order; host bookkeeping is unchanged.
+static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 for everything the blanker has released
+{
+  int rc;
+  const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
+  int k = 0;
+  if (avail >= 4 * c->N2) k = 1 + (avail - 4 * c->N2) / (4 * c->M2);
+  while (k > 0) {
+    const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+    if ((rc = lrh_make_fft2(c, p, kb))) return rc;
+    if ((rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
+    k -= kb;
+  }
+  return LRH_OK;
+}
+
+static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side pointers, wcw.c:1037-1047
+{
+  const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
+  p->timf1p_px = (p->timf1p_px + B * c->M1 * 4 * C) & c->timf1_bytemask;
+  p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
+  p->fft1_na = p->fft1_pa / (2 * c->N1);
+  p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
+}
+
 int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
   int rc;
-  while (nblocks > 0) {
-    const int B = nblocks < batch ? nblocks : batch;
-    if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
-    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4 * (c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1)) & c->timf1_bytemask;
-    p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
-    p->fft1_na = p->fft1_pa / (2 * c->N1);
-    p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
-    if ((rc = lrh_fft1_c(c, p, B))) return rc;
-    if (!c->cfg.second_fft_enable) {           // wcw.c:1049-1081: fft1_c, then the narrowband side's fft1_mix1_fixed
-      if ((rc = lrh_fft1_mix1_fixed(c, p, B))) return rc;
+  const bool piped = c->pipeline && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
+  if (!piped) {
+    while (nblocks > 0) {
+      const int B = nblocks < batch ? nblocks : batch;
+      if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+      advance_fft1(c, p, B);
+      if ((rc = lrh_fft1_c(c, p, B))) return rc;
+      if (!c->cfg.second_fft_enable) {           // wcw.c:1049-1081: fft1_c, then the narrowband side's fft1_mix1_fixed
+        if ((rc = lrh_fft1_mix1_fixed(c, p, B))) return rc;
+        nblocks -= B;
+        continue;
+      }
+      if ((rc = lrh_make_timf2(c, p, B))) return rc;
+      if ((rc = lrh_first_noise_blanker(c, p))) return rc;
+      if ((rc = round_tail(c, p))) return rc;
       nblocks -= B;
-      continue;
     }
-    if ((rc = lrh_make_timf2(c, p, B))) return rc;
-    if ((rc = lrh_first_noise_blanker(c, p))) return rc;
-    const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
-    int k = 0;
-    if (avail >= 4 * c->N2) k = 1 + (avail - 4 * c->N2) / (4 * c->M2);
-    while (k > 0) {
-      const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
-      if ((rc = lrh_make_fft2(c, p, kb))) return rc;
-      if ((rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
-      k -= kb;
-    }
-    nblocks -= B;
+    return LRH_OK;
   }
+  // ---- two-stream schedule
+  hipStream_t S1 = c->stream, S2 = c->stream2;
+  auto on = [&](hipStream_t s) { c->cur = s; };
+  struct Restore { lrh_ctx *c; ~Restore() { c->cur = c->stream; } } restore{c};
+  // the side stream starts after everything already queued on the main stream
+  HIPCHK(c, hipEventRecord(c->ev_side, S1)); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_side, 0));
+  int left = nblocks, round = 0;
+  int B = left < batch ? left : batch;
+  // prologue: fft1(0) on the main stream, its sums on the side stream
+  on(S1); if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+  advance_fft1(c, p, B);
+  HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+  on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
+  if ((rc = lrh_fft1_c(c, p, B))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
+  while (left > 0) {
+    const int Bnext = (left - B) < batch ? (left - B) : batch;       // size of round k+1 (0 at the end)
+    // main: timf2(k)
+    on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
+    // side: blanker(k)
+    on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_timf2, 0));
+    if ((rc = lrh_first_noise_blanker(c, p))) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_blank, S2));
+    if (Bnext > 0) {
+      // main: fft1(k+1) once the sums of round k-1 (which read the ring slots it overwrites) are done
+      on(S1);
+      if (round >= 1) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_sumsq[(round + 1) & 1], 0));
+      if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
+      advance_fft1(c, p, Bnext);
+      HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+      // side: sumsq/slowsum(k+1)
+      on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
+      if ((rc = lrh_fft1_c(c, p, Bnext))) return rc;
+      HIPCHK(c, hipEventRecord(c->ev_sumsq[(round + 1) & 1], S2));
+    }
+    // main: fft2(k) + mix1(k) after the blanker released the data; their power sums / waterfall go to the side stream
+    on(S1); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
+    c->split_fft2_tail = true;
+    rc = round_tail(c, p);
+    c->split_fft2_tail = false;
+    if (rc) return rc;
+    left -= B; B = Bnext; round++;
+  }
+  // join: later API calls are ordered on the main stream only
+  HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
   return LRH_OK;
 }
 
@@ -914,7 +1002,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
   return LRH_OK;
 }
 
-int lrh_sync(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); return LRH_OK; }
+int lrh_sync(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); return LRH_OK; }
 
 int lrh_timer_start(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
 int lrh_timer_stop(lrh_ctx *c, float *ms)
