@@ -238,6 +238,139 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
   __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const float2 *__restrict__ tw, int tid) { Tw<0> t0; pass<0>(x, lds, tw, tid, t0); }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// BlockFftL: the same transform with every twiddle kept on chip, for the persistent kernels (k_fft1, k_timf2).
+//
+// Why: vmcnt retires loads, stores and atomics in issue order, so a twiddle gather issued after the output stores
+// of the previous transform cannot return before those stores have drained to L2/HBM -- at one workgroup per CU
+// that drain is fully exposed.  Here the per-pass tables live in LDS behind the exchange buffer (filled once per
+// workgroup) and the last pass of N >= 8192 (k = butterfly index, table too big) uses RL-1 per-thread registers
+// w^(s tid) times compile-time roots of unity.  All LDS addresses are one per-thread base plus constants.
+//   table of pass with completed length p, radix R:  cell[e*p + k] = w^(mult(e) k N/(pR)),  k < p
+//   mult = {1,2,3,4,8,12} (R=16), {1,2,3,4} (R=8), {1..R-1} otherwise -- the factors pass() combines.
+template <int LOG2N, int P, int DIR> struct BlockFftL {
+  using Plan = FftPlan<LOG2N, P>;
+  static constexpr int N = Plan::N, T = Plan::T, NPASS = Plan::NPASS;
+  static_assert(Plan::HALVES == 1, "full-round exchange only");
+  __host__ __device__ static constexpr int per(int R) { return R == 16 ? 6 : (R == 8 ? 4 : R - 1); }
+  static constexpr bool REG_LAST = NPASS > 1 && Plan::done(NPASS - 1) >= 4096;
+  static constexpr int NTAB = NPASS - (REG_LAST ? 1 : 0);          // passes 1 .. NTAB-1 read an LDS table
+  __host__ __device__ static constexpr int tab_off(int pass) { int o = 0; for (int i = 1; i < pass; i++) o += Plan::done(i) * per(Plan::radix(i)); return o; }
+  static constexpr int TW_CELLS = tab_off(NTAB) > 0 ? tab_off(NTAB) : 1;
+  static constexpr int LDS_CELLS = Plan::LDS_CELLS + TW_CELLS;     // exchange buffer, then the tables
+  static constexpr int NREG = REG_LAST ? Plan::RL - 1 : 0;
+  static_assert(!REG_LAST || P == 16, "register twiddles use the 16th roots of unity");
+  struct Regs { float2 w[NREG > 0 ? NREG : 1]; };
+
+  template <int PASS> __device__ __forceinline__ static void init_tab(float2 *twl, const float2 *__restrict__ tw, int tid)
+  {
+    if constexpr (PASS < NTAB) {
+      constexpr int R = Plan::radix(PASS), p = Plan::done(PASS), PER = per(R), stride = N / (p * R);
+      for (int idx = tid; idx < p * PER; idx += T) {
+        const int e = idx / p, k = idx & (p - 1);
+        const int mult = R == 16 ? (e < 3 ? e + 1 : 4 * (e - 2)) : (R == 8 ? (e < 3 ? e + 1 : 4) : e + 1);
+        twl[tab_off(PASS) + idx] = tw_dir<DIR>(tw[mult * k * stride]);
+      }
+      init_tab<PASS + 1>(twl, tw, tid);
+    }
+  }
+  // once per workgroup; the caller must __syncthreads() before the first run()
+  __device__ __forceinline__ static void init(float2 *lds, Regs &r, const float2 *__restrict__ tw, int tid)
+  {
+    init_tab<1>(lds + Plan::LDS_CELLS, tw, tid);
+    if constexpr (REG_LAST) {
+#pragma unroll
+      for (int s = 1; s <= NREG; s++) r.w[s - 1] = tw_dir<DIR>(tw[s * tid]);
+    } else r.w[0] = make_float2(1.f, 0.f);
+  }
+
+  template <int E> __device__ __forceinline__ static float2 mul_root(float2 v)       // v * exp(DIR 2 pi j E / 16)
+  {
+    if constexpr (E == 0) return v;
+    else if constexpr (E == 4) return mulj<DIR>(v);
+    else if constexpr (E == 8) return make_float2(-v.x, -v.y);
+    else return cmul(v, w16<DIR, E>());
+  }
+  template <int M, int S, int R> __device__ __forceinline__ static void reg_twiddle(float2 *u, const Regs &r)
+  {
+    if constexpr (S < R) {
+      u[S] = cmul(mul_root<(S * M) % 16>(u[S]), r.w[S - 1]);
+      reg_twiddle<M, S + 1, R>(u, r);
+    }
+  }
+  template <int M, int R, int NB> __device__ __forceinline__ static void reg_pass(float2 *x, const Regs &r)
+  {
+    if constexpr (M < NB) {
+      reg_twiddle<M, 1, R>(&x[M * R], r);
+      Dft<DIR, R>::run(&x[M * R]);
+      reg_pass<M + 1, R, NB>(x, r);
+    }
+  }
+
+  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const Regs &r, int tid)
+  {
+    constexpr int R = Plan::radix(PASS);
+    constexpr int p = Plan::done(PASS);
+    constexpr int NB = P / R, PER = per(R);
+    if constexpr (REG_LAST && PASS == NPASS - 1) {
+      static_assert((R - 1) * (NB - 1) < 10, "w16 covers exponents 0..9");
+      reg_pass<0, R, NB>(x, r);
+    } else {
+#pragma unroll
+      for (int m = 0; m < NB; m++) {
+        float2 *u = &x[m * R];
+        if constexpr (p > 1) {
+          const float2 *tab = lds + Plan::LDS_CELLS + tab_off(PASS) + ((tid + m * T) & (p - 1));
+          float2 w[PER];
+#pragma unroll
+          for (int e = 0; e < PER; e++) w[e] = tab[e * p];
+          if constexpr (R == 16) {
+#pragma unroll
+            for (int s = 1; s < 16; s++) {
+              const int a = s >> 2, b = s & 3;
+              u[s] = cmul(u[s], a == 0 ? w[b - 1] : (b == 0 ? w[2 + a] : cmul(w[2 + a], w[b - 1])));
+            }
+          } else if constexpr (R == 8) {
+#pragma unroll
+            for (int s = 1; s < 8; s++) u[s] = cmul(u[s], s < 4 ? w[s - 1] : (s == 4 ? w[3] : cmul(w[3], w[s - 5])));
+          } else {
+#pragma unroll
+            for (int s = 1; s < R; s++) u[s] = cmul(u[s], w[s - 1]);
+          }
+        }
+        Dft<DIR, R>::run(u);
+      }
+    }
+    if constexpr (PASS + 1 < NPASS) {
+      constexpr int R2 = Plan::radix(PASS + 1);
+      constexpr int NB2 = P / R2;
+      static_assert(p <= T && (T * R) % 16 == 0 && (N / R2) % 16 == 0 && T % 16 == 0, "linear padded addressing");
+      constexpr int QS = p >= 16 ? p + (p >> 4) : p;                 // padded distance between a butterfly's outputs
+      if (PASS > 0) __syncthreads();                                  // reads of the previous exchange are done
+      {
+        const int k = tid & (p - 1);
+        float2 *wr = lds + lds_pad((tid - k) * R + k);
+#pragma unroll
+        for (int m = 0; m < NB; m++)
+#pragma unroll
+          for (int q = 0; q < R; q++) wr[m * (T * R + T * R / 16) + q * QS] = x[m * R + q];
+      }
+      __syncthreads();
+      const float2 *rd = lds + lds_pad(tid);
+#pragma unroll
+      for (int m = 0; m < NB2; m++)
+#pragma unroll
+        for (int s = 0; s < R2; s++) {
+          const int c = m * T + s * (N / R2);
+          x[m * R2 + s] = rd[c + c / 16];
+        }
+      pass<PASS + 1>(x, lds, r, tid);
+    }
+  }
+
+  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const Regs &r, int tid) { pass<0>(x, lds, r, tid); }
+};
+
 // XCD-aware block order (8 XCDs, blocks dealt round-robin): consecutive work items go to blocks b, b+8, b+16 ...
 // so neighbours in time (which share half their input) run on the same XCD and meet in its L2.  Speed only.
 __device__ __forceinline__ int xcd_order(int b, int nb) { return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3); }

@@ -24,12 +24,32 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
+  using Fft = BlockFftL<LOG2N, P, +1>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
-  __shared__ float2 lds[Plan::LDS_CELLS];
+  __shared__ float2 lds[Fft::LDS_CELLS];
   const int tid0 = threadIdx.x;
-  // Persistent workgroups: with one 136 KiB workgroup per CU at N = 16384 nothing else can overlap the store tail
+  // Persistent workgroups: with one ~150 KiB workgroup per CU at N = 16384 nothing else can overlap the store tail
   // of transform t with the loads of transform t+1, so each workgroup walks over several transforms itself and
-  // fetches the raw samples of the next one before it starts computing the current one.
+  // fetches the raw samples of the next one before it starts computing the current one.  Everything that does not
+  // change between transforms stays on chip (twiddles in LDS / registers) or is fetched ahead of the stores (window
+  // values, filter correction): the only loads that follow a transform's stores are the next prefetch, which is
+  // not needed for a whole transform, so no wait ever covers a freshly issued store (vmcnt retires in order).
+  typename Fft::Regs twr;
+  Fft::init(lds, twr, a.tw, tid0);
+  float win[P];
+  auto load_window = [&](int tid) {
+#pragma unroll
+    for (int m = 0; m < P / R0; m++)
+#pragma unroll
+      for (int s = 0; s < R0; s++) win[m * R0 + s] = a.window[(tid + m * T) + s * (N / R0)];
+  };
+  auto out_index = [&](int tid, int e) {
+    const int k = (tid + (e / RL) * T) + (e % RL) * (N / RL);
+    int kk = (k + N / 2) & (N - 1);                     // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
+    if (a.direction < 0) kk = (N - kk) & (N - 1);       // fft1.c:3660-3679
+    return kk;
+  };
+  load_window(tid0);
   short2 nxt[P];
   auto fetch = [&](int bi, int tid) {
     const int p0 = a.p0_first + bi * a.step;
@@ -40,6 +60,11 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   };
   int bi = blockIdx.x;
   if (bi < a.batch) fetch(a.xcd ? xcd_order(bi, a.batch) : bi, tid0);
+  __syncthreads();                                       // twiddle tables are in place
+  // Retire the prologue's loads here: the compiler merges wait counts over both loop entries, and the first
+  // prefetch being the youngest load on this path would otherwise turn the loop-top wait into vmcnt(0) for every
+  // trip -- which also waits for the stores of the previous transform.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), other counters untouched
 #pragma unroll 1
   for (; bi < a.batch; bi += gridDim.x) {
     int tid = tid0;
@@ -47,29 +72,27 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     const int b = a.xcd ? xcd_order(bi, a.batch) : bi;
     float2 x[P];
 #pragma unroll
-    for (int m = 0; m < P / R0; m++)
-#pragma unroll
-      for (int s = 0; s < R0; s++) {
-        const int idx = (tid + m * T) + s * (N / R0);
-        const short2 v = nxt[m * R0 + s];
-        const float w = a.window[idx];
-        // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
-        x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));
-      }
+    for (int e = 0; e < P; e++) {
+      const short2 v = nxt[e];
+      // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
+      x[e] = make_float2((float)v.x * win[e], -((float)v.y * win[e]));
+    }
     const int bn = bi + gridDim.x;
     if (bn < a.batch) fetch(a.xcd ? xcd_order(bn, a.batch) : bn, tid);
-    BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
+    Fft::run(x, lds, twr, tid);
     float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+    // Tail: every load the next transform needs before its first wait (its window values) and this one's filter
+    // correction are issued BEFORE the stores, so that no later wait has to cover the stores.
+    load_window(tid);
+    float2 fc[P];
 #pragma unroll
-    for (int m = 0; m < P / RL; m++)
+    for (int e = 0; e < P; e++) fc[e] = a.filtercorr[out_index(tid, e)];
 #pragma unroll
-      for (int q = 0; q < RL; q++) {
-        const int k = (tid + m * T) + q * (N / RL);
-        int kk = (k + N / 2) & (N - 1);                 // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
-        float2 v = x[m * RL + q];
-        if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
-        out[kk] = cmul(v, a.filtercorr[kk]);
-      }
+    for (int e = 0; e < P; e++) {
+      float2 v = x[e];
+      if (a.direction < 0) v = make_float2(v.y, v.x);   // fft1.c:3660-3679
+      out[out_index(tid, e)] = cmul(v, fc[e]);
+    }
     __syncthreads();                                     // LDS is reused by the next transform
   }
 }
@@ -833,7 +856,7 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   }
 
 #define LRH_LAUNCH_FFT1(L, a, batch, st) \
-  hipLaunchKernelGGL((k_fft1<L>), dim3(persistent_grid(L, batch)), dim3(fft_threads(L)), 0, st, a)
+  hipLaunchKernelGGL((k_fft1<L>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
     if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(batch), dim3(fft_threads(L)), 0, st, a);      \
@@ -845,15 +868,14 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
 #define LRH_LAUNCH_MIX1(L, a, batch, st) \
   hipLaunchKernelGGL((k_mix1_back<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
 
-// workgroups that fit on the chip at once for an N = 2^log2n transform kernel (LDS and thread limits, 256 CUs)
-static int persistent_grid(int log2n, int batch)
+// workgroups that fit on the chip at once for a transform kernel (LDS and thread limits, 256 CUs)
+static int persistent_grid(int lds_bytes, int threads, int batch)
 {
-  const int n = 1 << log2n, threads = fft_threads(log2n);
-  const int lds = (n + (n >> 4)) * 8 / fft_halves(log2n);
-  int per_cu = 160 * 1024 / lds; if (per_cu > 2048 / threads) per_cu = 2048 / threads; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+  int per_cu = 160 * 1024 / lds_bytes; if (per_cu > 2048 / threads) per_cu = 2048 / threads; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
   const int g = 256 * per_cu;
   return batch < g ? batch : g;
 }
+template <int L> static int fftl_grid(int batch) { return persistent_grid(8 * BlockFftL<L, points_per_thread(L), 1>::LDS_CELLS, fft_threads(L), batch); }
 
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
 {

