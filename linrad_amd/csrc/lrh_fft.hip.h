@@ -244,8 +244,9 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
 // Why: vmcnt retires loads, stores and atomics in issue order, so a twiddle gather issued after the output stores
 // of the previous transform cannot return before those stores have drained to L2/HBM -- at one workgroup per CU
 // that drain is fully exposed.  Here the per-pass tables live in LDS behind the exchange buffer (filled once per
-// workgroup) and the last pass of N >= 8192 (k = butterfly index, table too big) uses RL-1 per-thread registers
-// w^(s tid) times compile-time roots of unity.  All LDS addresses are one per-thread base plus constants.
+// workgroup).  The last pass of N >= 8192 (k = butterfly index, a full table would not fit) reads one cell per
+// thread, w^tid, squares/cubes it and applies compile-time 16th roots of unity for the butterflies tid + m T.
+// All LDS addresses are one per-thread base plus constants.
 //   table of pass with completed length p, radix R:  cell[e*p + k] = w^(mult(e) k N/(pR)),  k < p
 //   mult = {1,2,3,4,8,12} (R=16), {1,2,3,4} (R=8), {1..R-1} otherwise -- the factors pass() combines.
 template <int LOG2N, int P, int DIR> struct BlockFftL {
@@ -253,14 +254,12 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
   static constexpr int N = Plan::N, T = Plan::T, NPASS = Plan::NPASS;
   static_assert(Plan::HALVES == 1, "full-round exchange only");
   __host__ __device__ static constexpr int per(int R) { return R == 16 ? 6 : (R == 8 ? 4 : R - 1); }
-  static constexpr bool REG_LAST = NPASS > 1 && Plan::done(NPASS - 1) >= 4096;
-  static constexpr int NTAB = NPASS - (REG_LAST ? 1 : 0);          // passes 1 .. NTAB-1 read an LDS table
+  static constexpr bool ROOT_LAST = NPASS > 1 && Plan::done(NPASS - 1) >= 4096;
+  static constexpr int NTAB = NPASS - (ROOT_LAST ? 1 : 0);         // passes 1 .. NTAB-1 read a full LDS table
   __host__ __device__ static constexpr int tab_off(int pass) { int o = 0; for (int i = 1; i < pass; i++) o += Plan::done(i) * per(Plan::radix(i)); return o; }
-  static constexpr int TW_CELLS = tab_off(NTAB) > 0 ? tab_off(NTAB) : 1;
+  static constexpr int TW_CELLS = tab_off(NTAB) + (ROOT_LAST ? T : 0) + 1;
   static constexpr int LDS_CELLS = Plan::LDS_CELLS + TW_CELLS;     // exchange buffer, then the tables
-  static constexpr int NREG = REG_LAST ? Plan::RL - 1 : 0;
-  static_assert(!REG_LAST || P == 16, "register twiddles use the 16th roots of unity");
-  struct Regs { float2 w[NREG > 0 ? NREG : 1]; };
+  static_assert(!ROOT_LAST || (P == 16 && Plan::RL <= 4), "last-pass roots: 16th roots of unity, powers up to 3");
 
   template <int PASS> __device__ __forceinline__ static void init_tab(float2 *twl, const float2 *__restrict__ tw, int tid)
   {
@@ -275,13 +274,10 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     }
   }
   // once per workgroup; the caller must __syncthreads() before the first run()
-  __device__ __forceinline__ static void init(float2 *lds, Regs &r, const float2 *__restrict__ tw, int tid)
+  __device__ __forceinline__ static void init(float2 *lds, const float2 *__restrict__ tw, int tid)
   {
     init_tab<1>(lds + Plan::LDS_CELLS, tw, tid);
-    if constexpr (REG_LAST) {
-#pragma unroll
-      for (int s = 1; s <= NREG; s++) r.w[s - 1] = tw_dir<DIR>(tw[s * tid]);
-    } else r.w[0] = make_float2(1.f, 0.f);
+    if constexpr (ROOT_LAST) lds[Plan::LDS_CELLS + tab_off(NTAB) + tid] = tw_dir<DIR>(tw[tid]);
   }
 
   template <int E> __device__ __forceinline__ static float2 mul_root(float2 v)       // v * exp(DIR 2 pi j E / 16)
@@ -291,36 +287,44 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     else if constexpr (E == 8) return make_float2(-v.x, -v.y);
     else return cmul(v, w16<DIR, E>());
   }
-  template <int M, int S, int R> __device__ __forceinline__ static void reg_twiddle(float2 *u, const Regs &r)
+  template <int M, int S, int R> __device__ __forceinline__ static void root_twiddle(float2 *u, const float2 *w)
   {
     if constexpr (S < R) {
-      u[S] = cmul(mul_root<(S * M) % 16>(u[S]), r.w[S - 1]);
-      reg_twiddle<M, S + 1, R>(u, r);
+      u[S] = cmul(mul_root<(S * M) % 16>(u[S]), w[S - 1]);
+      root_twiddle<M, S + 1, R>(u, w);
     }
   }
-  template <int M, int R, int NB> __device__ __forceinline__ static void reg_pass(float2 *x, const Regs &r)
+  template <int M, int R, int NB> __device__ __forceinline__ static void root_pass(float2 *x, const float2 *w)
   {
     if constexpr (M < NB) {
-      reg_twiddle<M, 1, R>(&x[M * R], r);
+      root_twiddle<M, 1, R>(&x[M * R], w);
       Dft<DIR, R>::run(&x[M * R]);
-      reg_pass<M + 1, R, NB>(x, r);
+      root_pass<M + 1, R, NB>(x, w);
     }
   }
 
-  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, const Regs &r, int tid)
+  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, int tid)
   {
     constexpr int R = Plan::radix(PASS);
     constexpr int p = Plan::done(PASS);
     constexpr int NB = P / R, PER = per(R);
-    if constexpr (REG_LAST && PASS == NPASS - 1) {
+    if constexpr (ROOT_LAST && PASS == NPASS - 1) {
       static_assert((R - 1) * (NB - 1) < 10, "w16 covers exponents 0..9");
-      reg_pass<0, R, NB>(x, r);
+      float2 w[3];
+      int tt_ = tid;
+      asm volatile("" : "+v"(tt_));
+      w[0] = lds[Plan::LDS_CELLS + tab_off(NTAB) + tt_];              // w^tid, then its square and cube
+      w[1] = cmul(w[0], w[0]);
+      w[2] = cmul(w[1], w[0]);
+      root_pass<0, R, NB>(x, w);
     } else {
+      int tt_ = tid;
+      asm volatile("" : "+v"(tt_));                                   // see the exchange below
 #pragma unroll
       for (int m = 0; m < NB; m++) {
         float2 *u = &x[m * R];
         if constexpr (p > 1) {
-          const float2 *tab = lds + Plan::LDS_CELLS + tab_off(PASS) + ((tid + m * T) & (p - 1));
+          const float2 *tab = lds + Plan::LDS_CELLS + tab_off(PASS) + ((tt_ + m * T) & (p - 1));
           float2 w[PER];
 #pragma unroll
           for (int e = 0; e < PER; e++) w[e] = tab[e * p];
@@ -347,16 +351,22 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
       static_assert(p <= T && (T * R) % 16 == 0 && (N / R2) % 16 == 0 && T % 16 == 0, "linear padded addressing");
       constexpr int QS = p >= 16 ? p + (p >> 4) : p;                 // padded distance between a butterfly's outputs
       if (PASS > 0) __syncthreads();                                  // reads of the previous exchange are done
+      // Fresh opaque copies of the thread index per exchange: LDS offsets beyond the 64 KiB immediate range need
+      // their own address registers, and common subexpressions shared between passes (or between the two
+      // transforms of k_timf2) would otherwise stay live across the butterflies and spill.
+      int tw_ = tid, tr_ = tid;
+      asm volatile("" : "+v"(tw_));
       {
-        const int k = tid & (p - 1);
-        float2 *wr = lds + lds_pad((tid - k) * R + k);
+        const int k = tw_ & (p - 1);
+        float2 *wr = lds + lds_pad((tw_ - k) * R + k);
 #pragma unroll
         for (int m = 0; m < NB; m++)
 #pragma unroll
           for (int q = 0; q < R; q++) wr[m * (T * R + T * R / 16) + q * QS] = x[m * R + q];
       }
       __syncthreads();
-      const float2 *rd = lds + lds_pad(tid);
+      asm volatile("" : "+v"(tr_));
+      const float2 *rd = lds + lds_pad(tr_);
 #pragma unroll
       for (int m = 0; m < NB2; m++)
 #pragma unroll
@@ -364,11 +374,11 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
           const int c = m * T + s * (N / R2);
           x[m * R2 + s] = rd[c + c / 16];
         }
-      pass<PASS + 1>(x, lds, r, tid);
+      pass<PASS + 1>(x, lds, tid);
     }
   }
 
-  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, const Regs &r, int tid) { pass<0>(x, lds, r, tid); }
+  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, int tid) { pass<0>(x, lds, tid); }
 };
 
 // XCD-aware block order (8 XCDs, blocks dealt round-robin): consecutive work items go to blocks b, b+8, b+16 ...

@@ -31,11 +31,10 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   // Persistent workgroups: with one ~150 KiB workgroup per CU at N = 16384 nothing else can overlap the store tail
   // of transform t with the loads of transform t+1, so each workgroup walks over several transforms itself and
   // fetches the raw samples of the next one before it starts computing the current one.  Everything that does not
-  // change between transforms stays on chip (twiddles in LDS / registers) or is fetched ahead of the stores (window
+  // change between transforms stays on chip (twiddles in LDS) or is fetched ahead of the stores (window
   // values, filter correction): the only loads that follow a transform's stores are the next prefetch, which is
   // not needed for a whole transform, so no wait ever covers a freshly issued store (vmcnt retires in order).
-  typename Fft::Regs twr;
-  Fft::init(lds, twr, a.tw, tid0);
+  Fft::init(lds, a.tw, tid0);
   float win[P];
   auto load_window = [&](int tid) {
 #pragma unroll
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     }
     const int bn = bi + gridDim.x;
     if (bn < a.batch) fetch(a.xcd ? xcd_order(bn, a.batch) : bn, tid);
-    Fft::run(x, lds, twr, tid);
+    Fft::run(x, lds, tid);
     float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
     // Tail: every load the next transform needs before its first wait (its window values) and this one's filter
     // correction are issued BEFORE the stores, so that no later wait has to cover the stores.
@@ -168,69 +167,135 @@ __global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
 // transform t-1 (timf2.c:1003-1026).  Second half of DFT(S)[n + N/2] = DFT(S (-1)^k)[n], so
 //     out_t[n] = ampfac * DFT( S_t + (-1)^k S_{t-1} )[n],  n < N/2
 // i.e. one transform of the combined spectrum, written once -- no read-modify-write of the timf2 ring.
+// One transform's outputs of stream ST (0 weak, 1 strong) to the planar rings.
+template <int LOG2N, int MODE, int ST>
+__device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x)[points_per_thread(LOG2N)], int pa, int tid)
+{
+  constexpr int P = points_per_thread(LOG2N);
+  using Plan = FftPlan<LOG2N, P>;
+  constexpr int N = Plan::N, T = Plan::T, RL = Plan::RL;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      if constexpr (MODE == 1) { if (q >= RL / 2) continue; }   // first half only: n = i + q N/RL < N/2  <=>  q < RL/2
+      const int n = (tid + m * T) + q * (N / RL);
+      float amp = a.ampfac; int pos = n; bool keep = true;
+      if constexpr (MODE == 2) {                          // centre part x inverted window (timf2.c:1031-1061)
+        keep = (n >= a.ia) && (n < N - a.ia); pos = n - a.ia; amp = a.invwin[n] * a.ampfac;
+      }
+      if (keep) {
+        const float2 v = x[m * RL + q];
+        const float2 o = make_float2(amp * v.x, amp * v.y);
+        if constexpr (MODE == 1) {
+          // pa is a multiple of N/2 here (launch_timf2 checks it): no wrap inside the half block, so the address
+          // is a uniform base plus the thread index
+          const size_t base = (size_t)(pa & a.mask) + m * T + q * (N / RL);
+          const unsigned int t = (unsigned int)tid;
+          if constexpr (ST == 0) { (a.timf2w + base)[t] = o; (a.pwr + base)[t] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
+          else (a.timf2s + base)[t] = o;
+        } else {
+          const int r = (pa + pos) & a.mask;
+          if constexpr (ST == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }
+          else a.timf2s[r] = o;
+        }
+      }
+    }
+}
+
 template <int LOG2N, int MODE>
 __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_timf2(Timf2Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
-  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
-  __shared__ float2 lds[Plan::LDS_CELLS];
-  const int tid0 = threadIdx.x, b = a.xcd ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const float2 *cur = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
-  const float2 *prv = a.spec + (size_t)((a.first_nb + b - 1) & a.nb_mask) * N;
+  using Fft = BlockFftL<LOG2N, P, -1>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, NB0 = P / R0;
+  __shared__ float2 lds[Fft::LDS_CELLS];
+  const int tid0 = threadIdx.x;
+  Fft::init(lds, a.tw, tid0);
   // weak/strong routing flags, packed by the host per first-pass butterfly: bit s of pack[i] is set when bin
-  // i + s*(N/R0) is weak (liminfo == 0, timf2.c:50).  One dword per thread instead of R0 float loads.
-  const unsigned int *packp = (b == 0) ? a.pack_prev : a.pack_cur;
-  const int pa = a.pa_first + b * a.step;
-  // weak stream (st = 0) then strong stream (st = 1), one at a time: 16 points/thread of one stream is all the
-  // register file holds at 1024 threads.  The spectra are re-read for the second stream (L2 hits).
-#pragma unroll 1
-  for (int st = 0; st < 2; st++) {
-    // opaque per-iteration copy of the thread index: without it LICM hoists every address and LDS index of the
-    // transform out of this two-trip loop and parks them in ~200 VGPRs (spills at 1024 threads)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    float2 x[P];
+  // i + s*(N/R0) is weak (liminfo == 0, timf2.c:50).  One dword per thread instead of R0 float loads; the same
+  // for every transform of the launch except the "previous" half of the very first one.
+  unsigned int wk_cur[NB0], wk_first[NB0];
 #pragma unroll
-    for (int m = 0; m < P / R0; m++) {
-      const unsigned int sel = st ? 0u : 0xffffffffu;
-      const unsigned int mc = a.pack_cur[tid + m * T] ^ ~sel;     // bit set -> bin belongs to this stream
-      const unsigned int mp = packp[tid + m * T] ^ ~sel;
+  for (int m = 0; m < NB0; m++) { wk_cur[m] = a.pack_cur[tid0 + m * T]; wk_first[m] = a.pack_prev[tid0 + m * T]; }
+  // Persistent workgroups walk over (transform, stream) items: weak stream then strong stream of each transform,
+  // 16 points/thread of one stream being all the register file holds at 1024 threads.  The masked spectrum loads
+  // of the NEXT item are issued before the stores of the current one (vmcnt retires in issue order: a load issued
+  // behind the stores would not return before they have drained), and the spectra are re-read for the second
+  // stream (L2 hits).  Bins routed to the other stream are not even fetched.
+  float2 c[P], pv[P];
+  auto issue = [&](int b, int st, int tid) {
+    const float2 *cur = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+    const float2 *prv = a.spec + (size_t)((a.first_nb + b - 1) & a.nb_mask) * N;
+#pragma unroll
+    for (int m = 0; m < NB0; m++) {
+      const unsigned int flip = st ? 0xffffffffu : 0u;
+      const unsigned int mc = wk_cur[m] ^ flip;           // bit set -> bin belongs to this stream
+      const unsigned int mp = (b == 0 ? wk_first[m] : wk_cur[m]) ^ flip;
 #pragma unroll
       for (int s = 0; s < R0; s++) {
-        const int k = (tid + m * T) + s * (N / R0);
-        // bins routed to the other stream are not even fetched: the strong stream usually touches a few lines only
-        float2 v = make_float2(0.f, 0.f);
-        if ((mc >> s) & 1u) v = cur[k];
+        const int ku = m * T + s * (N / R0);               // uniform part of the bin index; + tid per thread
+        const unsigned int t = (unsigned int)tid;
+        c[m * R0 + s] = make_float2(0.f, 0.f);
+        if ((mc >> s) & 1u) c[m * R0 + s] = (cur + ku)[t];
         if constexpr (MODE == 1) {
-          float2 pv = make_float2(0.f, 0.f);
-          if ((mp >> s) & 1u) pv = prv[k];
-          v = (k & 1) ? csub(v, pv) : cadd(v, pv);
+          pv[m * R0 + s] = make_float2(0.f, 0.f);
+          if ((mp >> s) & 1u) pv[m * R0 + s] = (prv + ku)[t];
         }
-        x[m * R0 + s] = v;
       }
     }
-    if (st) __syncthreads();
-    BlockFft<LOG2N, P, -1>::run(x, lds, a.tw, tid);
+  };
+  auto combine = [&](float2 (&x)[P], int tid) {
+    // sin^2 overlap: S_t + (-1)^k S_{t-1}; k = tid + even offsets, so the sign is one per thread
+    const float sg = (tid & 1) ? -1.f : 1.f;
 #pragma unroll
-    for (int m = 0; m < P / RL; m++)
+    for (int e = 0; e < P; e++) {
+      if constexpr (MODE == 1) x[e] = make_float2(c[e].x + sg * pv[e].x, c[e].y + sg * pv[e].y);
+      else x[e] = c[e];
+    }
+  };
+  // Pins the transform's live outputs in registers at this point: without it the last butterflies sink below the
+  // prefetch (towards the stores that use them) and their 16 inputs stay live across 32 loads in flight.
+  auto pin = [&](float2 (&x)[P]) {
+    constexpr int RL = Plan::RL;
 #pragma unroll
-      for (int q = 0; q < RL; q++) {
-        const int n = (tid + m * T) + q * (N / RL);
-        float amp = a.ampfac; int pos; bool keep;
-        if constexpr (MODE == 1) { keep = n < N / 2; pos = n; }
-        else if constexpr (MODE == 0) { keep = true; pos = n; }
-        else {                                            // centre part x inverted window (timf2.c:1031-1061)
-          keep = (n >= a.ia) && (n < N - a.ia); pos = n - a.ia; amp = a.invwin[n] * a.ampfac;
-        }
-        if (keep) {
-          const float2 v = x[m * RL + q];
-          const float2 o = make_float2(amp * v.x, amp * v.y);
-          const int r = (pa + pos) & a.mask;
-          if (st == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
-          else a.timf2s[r] = o;
-        }
-      }
+    for (int e = 0; e < P; e++)
+      if (MODE != 1 || (e % RL) < RL / 2) asm volatile("" : "+v"(x[e].x), "+v"(x[e].y));
+    asm volatile("" ::: "memory");
+  };
+  int bi = blockIdx.x;
+  if (bi < a.batch) issue(a.xcd ? xcd_order(bi, a.batch) : bi, 0, tid0);
+  __syncthreads();                                       // twiddle tables are in place
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): retire the prologue's loads here (see k_fft1)
+#pragma unroll 1
+  for (; bi < a.batch; bi += gridDim.x) {
+    // opaque per-iteration copy of the thread index: without it LICM hoists every address and LDS index of the
+    // transform out of the loop and parks them in ~200 VGPRs (spills at 1024 threads)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int b = a.xcd ? xcd_order(bi, a.batch) : bi;
+    const int pa = a.pa_first + b * a.step;
+    float2 x[P];
+    combine(x, tid);
+    Fft::run(x, lds, tid);
+    pin(x);
+    __builtin_amdgcn_sched_barrier(0);                   // keep the loads below out of the transform (register file)
+    issue(b, 1, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    timf2_store<LOG2N, MODE, 0>(a, x, pa, tid);
+    __syncthreads();                                     // LDS is reused by the next transform
+    combine(x, tid);
+    Fft::run(x, lds, tid);
+    pin(x);
+    __builtin_amdgcn_sched_barrier(0);
+    // unconditional (the last trip re-reads its own transform): a conditional prefetch would keep the old c/pv
+    // alive across the transform above
+    const int bn = min(bi + (int)gridDim.x, a.batch - 1);
+    issue(a.xcd ? xcd_order(bn, a.batch) : bn, 0, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    timf2_store<LOG2N, MODE, 1>(a, x, pa, tid);
+    __syncthreads();
   }
 }
 
@@ -859,9 +924,9 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   hipLaunchKernelGGL((k_fft1<L>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
-    if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(batch), dim3(fft_threads(L)), 0, st, a);      \
-    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0>), dim3(batch), dim3(fft_threads(L)), 0, st, a); \
-    else hipLaunchKernelGGL((k_timf2<L, 2>), dim3(batch), dim3(fft_threads(L)), 0, st, a);                  \
+    if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);      \
+    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
+    else hipLaunchKernelGGL((k_timf2<L, 2>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);                  \
   } while (0)
 #define LRH_LAUNCH_FFT2(L, a, batch, st) \
   hipLaunchKernelGGL((k_fft2<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
@@ -882,8 +947,9 @@ hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
   LRH_DISPATCH(LRH_LAUNCH_FFT1, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }
-hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st)
+hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t st)
 {
+  Timf2Args a = a0; a.batch = batch;
   LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }

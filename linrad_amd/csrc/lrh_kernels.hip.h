@@ -46,6 +46,7 @@ struct Timf2Args {
   const float *invwin;      // natural order N1 (mode 2)
   float ampfac;
   int xcd;
+  int batch;                // transforms in this launch (set by launch_timf2)
 };
 
 // ---- blanker ----
