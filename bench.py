@@ -118,8 +118,11 @@ def main():
     rx.timer_start()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                       # host-side enqueue time (the device runs behind it)
     ev_ms = rx.timer_stop()
     barrier()
+    host_ph = rx.profile_get("host:mix1_phases")
+    host_dsp = rx.profile_get("host:wideband_dsp")
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -173,7 +176,8 @@ def main():
                                    f"{args.rounds} x {args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
                        "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "rounds_per_step": args.rounds, "channels": world,
                        "parallelism": f"1 RF channel per GPU x{world}"},
-            "event_ms_per_step": round(ev_ms / args.steps, 4),
+            "event_ms_per_step": round(ev_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
+            "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4)},
             "roofline": roof, "cpu_baseline": cpu, "stages": stages,
             "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
                         "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <map>
 
 #include "../../include/linrad_hip.h"
@@ -88,6 +89,7 @@ struct lrh_ctx {
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool prof = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
   std::vector<hipEvent_t> ev_pool;
+  double host_ms_phases = 0, host_ms_dsp = 0; long host_n_phases = 0, host_n_dsp = 0;   // host CPU time, lrh_profile_get("host:...")
 };
 
 static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -729,25 +731,30 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
     HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
-    float *hn = c->h_ph + slot * c->ph_stride, *ho = hn + (size_t)batch * half;
+    const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
+    float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
     int point = 0;
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int b = 0; b < batch; b++) {
       int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
       point = s->mix1_point;
       float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
-      if (!overlap) {
-        for (int i = 0; i < half; i++) { hn[(size_t)b * half + i] = t1; t1 += t2; }
-      } else {
-        float r1 = s->mix1_old_phase;
-        float r2 = (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm);
-        for (int i = 0; i < half; i++) { hn[(size_t)b * half + i] = t1; ho[(size_t)b * half + i] = r1; r1 += r2; t1 += t2; }
+      float r1 = s->mix1_old_phase;
+      const float r2 = overlap ? (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm) : 0.f;
+      h_inc[b] = make_float2(t2, r2);
+      float2 *hs = h_start + (size_t)b * nchunks;
+      for (int i = 0; i < half; i++) {                    // the device replays the additions inside a chunk
+        if ((i & (LRH_PH_CHUNK - 1)) == 0) hs[i / LRH_PH_CHUNK] = make_float2(t1, r1);
+        r1 += r2; t1 += t2;
       }
       s->mix1_phase = t1;
     }
-    float *dn = c->d_ph + slot * c->ph_stride;
-    HIPCHK(c, hipMemcpyAsync(dn, hn, sizeof(float) * 2 * (size_t)batch * half, hipMemcpyHostToDevice, c->cur));
+    c->host_ms_phases += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); c->host_n_phases++;
+    // a few KiB per call, in stream order
+    float2 *d_inc = (float2 *)(c->d_ph + slot * c->ph_stride);
+    HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, sizeof(float2) * (size_t)batch * (1 + nchunks), hipMemcpyHostToDevice, c->cur));
     HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
-    o.ph_new = dn; o.ph_old = dn + (size_t)batch * half;
+    o.ph_inc = d_inc; o.ph_start = d_inc + batch; o.nchunks = nchunks;
     Mix1Args a;
     a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
     a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
@@ -891,6 +898,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
+  struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                     ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++; } } host_timer{c};
   int rc;
   const bool piped = c->pipeline && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
   if (!piped) {
@@ -1023,6 +1032,8 @@ int lrh_profile_enable(lrh_ctx *c, int on)
 int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *launches)
 {
   if (!c || !kernel) return LRH_EINVAL;
+  if (!strcmp(kernel, "host:mix1_phases")) { if (total_ms) *total_ms = c->host_ms_phases; if (launches) *launches = c->host_n_phases; return LRH_OK; }
+  if (!strcmp(kernel, "host:wideband_dsp")) { if (total_ms) *total_ms = c->host_ms_dsp; if (launches) *launches = c->host_n_dsp; return LRH_OK; }
   prof_collect(c);
   auto it = c->prof_tot.find(kernel);
   if (total_ms) *total_ms = it == c->prof_tot.end() ? 0 : it->second.ms;

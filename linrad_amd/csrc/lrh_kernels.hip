@@ -795,7 +795,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mi
     for (int q = 0; q < RL; q++) o[(tid + m * T) + q * (N / RL)] = x[m * RL + q];
 }
 
-// rotate + overlap into timf3 (mix1.c:141-195); phases come from the host's float recursion
+// rotate + overlap into timf3 (mix1.c:141-195); phases follow the host's float recursion (chunk starts uploaded)
 __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
 {
   const int half = a.overlap ? a.nm / 2 : a.nm;
@@ -812,14 +812,17 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
     if (b == batch - 1) a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + half + i];
     return;
   }
-  const float t1 = a.ph_new[(size_t)b * half + i];
+  // the same float additions as the reference's recursion (mix1.c:172-186), restarted every LRH_PH_CHUNK samples
+  const float2 inc = a.ph_inc[b];
+  const float2 st = a.ph_start[(size_t)b * a.nchunks + i / LRH_PH_CHUNK];
+  float t1 = st.x, r1 = st.y;
+  for (int j = 0; j < (i & (LRH_PH_CHUNK - 1)); j++) { t1 += inc.x; r1 += inc.y; }
   const float t3 = (float)sin((double)t1), t4 = (float)cos((double)t1);
   if (!a.overlap) {
     a.timf3[pos] = make_float2(t4 * nw.x - t3 * nw.y, t4 * nw.y + t3 * nw.x);
     return;
   }
   const float2 old = (b == 0) ? a.timf3[pos] : a.scratch[(size_t)(b - 1) * a.nm + half + i];
-  const float r1 = a.ph_old[(size_t)b * half + i];
   const float r3 = (float)sin((double)r1), r4 = (float)cos((double)r1);
   a.timf3[pos] = make_float2(r4 * old.x - r3 * old.y + t4 * nw.x - t3 * nw.y,
                              r4 * old.y + r3 * old.x + t4 * nw.y + t3 * nw.x);

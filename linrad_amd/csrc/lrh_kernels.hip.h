@@ -5,6 +5,8 @@
 
 namespace lrh {
 
+#define LRH_PH_CHUNK 64      // mix1 phases: the host uploads every 64th value of its float recursion, the kernel replays the rest
+
 
 // ---- fft1_b (+ filter correction of fft1_c) ----
 struct Fft1Args {
@@ -105,7 +107,10 @@ struct Mix1Args {
   int nm;
 };
 struct Mix1OutArgs {
-  const float2 *scratch; const float *ph_new, *ph_old;
+  const float2 *scratch;
+  const float2 *ph_inc;      // [batch] per-sample phase increments {new, old} of each transform
+  const float2 *ph_start;    // [batch][nchunks] phases {new, old} at samples 0, 64, 128, ... (LRH_PH_CHUNK)
+  int nchunks;
   float2 *timf3; int mask2;  // timf3 mask in complex samples
   int pa_first; int block;   // in complex samples
   int nm; int overlap; int selected;
