@@ -20,7 +20,20 @@
 
 namespace lrh {
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// complex multiply by a compile-time constant: left to the compiler (constants fold into literals / SGPRs)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// complex multiply of two register values in two packed instructions:
+//   t = (a.x b.x, a.x b.y);  r = (t.x - a.y b.y, t.y + a.y b.x)
+// hipcc's own lowering of the expression above takes three packed ops plus a v_mov to re-pair the halves.
+typedef float lrh_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+  const lrh_v2f av = {a.x, a.y}, bv = {b.x, b.y};      // (no __builtin_bit_cast: it goes through a stack slot that SROA keeps)
+  lrh_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiply by -j (DIR = -1, forward) or +j (DIR = +1)
@@ -59,9 +72,9 @@ template <int DIR> struct Dft<DIR, 8> {
     float2 y[8];
 #pragma unroll
     for (int b = 0; b < 4; b++) { float2 p = u[b], q = u[b + 4]; y[b] = cadd(p, q); y[4 + b] = csub(p, q); }   // y[c*4+b]
-    y[4 + 1] = cmul(y[4 + 1], make_float2(LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
+    y[4 + 1] = cmulc(y[4 + 1], make_float2(LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
     y[4 + 2] = mulj<DIR>(y[4 + 2]);
-    y[4 + 3] = cmul(y[4 + 3], make_float2(-LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
+    y[4 + 3] = cmulc(y[4 + 3], make_float2(-LRH_C8, DIR < 0 ? -LRH_C8 : LRH_C8));
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       bfly4<DIR>(y[c * 4 + 0], y[c * 4 + 1], y[c * 4 + 2], y[c * 4 + 3]);
@@ -76,15 +89,15 @@ template <int DIR> struct Dft<DIR, 16> {
     // s = 4a+b: radix-4 over a (b fixed), twiddle w16^(b c), radix-4 over b; output index c + 4d
 #pragma unroll
     for (int b = 0; b < 4; b++) bfly4<DIR>(u[b], u[b + 4], u[b + 8], u[b + 12]);   // u[4c+b] = y[b][c]
-    u[4 * 1 + 1] = cmul(u[4 * 1 + 1], w16<DIR, 1>());
-    u[4 * 1 + 2] = cmul(u[4 * 1 + 2], w16<DIR, 2>());
-    u[4 * 1 + 3] = cmul(u[4 * 1 + 3], w16<DIR, 3>());
-    u[4 * 2 + 1] = cmul(u[4 * 2 + 1], w16<DIR, 2>());
+    u[4 * 1 + 1] = cmulc(u[4 * 1 + 1], w16<DIR, 1>());
+    u[4 * 1 + 2] = cmulc(u[4 * 1 + 2], w16<DIR, 2>());
+    u[4 * 1 + 3] = cmulc(u[4 * 1 + 3], w16<DIR, 3>());
+    u[4 * 2 + 1] = cmulc(u[4 * 2 + 1], w16<DIR, 2>());
     u[4 * 2 + 2] = mulj<DIR>(u[4 * 2 + 2]);
-    u[4 * 2 + 3] = cmul(u[4 * 2 + 3], w16<DIR, 6>());
-    u[4 * 3 + 1] = cmul(u[4 * 3 + 1], w16<DIR, 3>());
-    u[4 * 3 + 2] = cmul(u[4 * 3 + 2], w16<DIR, 6>());
-    u[4 * 3 + 3] = cmul(u[4 * 3 + 3], w16<DIR, 9>());
+    u[4 * 2 + 3] = cmulc(u[4 * 2 + 3], w16<DIR, 6>());
+    u[4 * 3 + 1] = cmulc(u[4 * 3 + 1], w16<DIR, 3>());
+    u[4 * 3 + 2] = cmulc(u[4 * 3 + 2], w16<DIR, 6>());
+    u[4 * 3 + 3] = cmulc(u[4 * 3 + 3], w16<DIR, 9>());
     float2 v[16];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -285,21 +298,20 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     if constexpr (E == 0) return v;
     else if constexpr (E == 4) return mulj<DIR>(v);
     else if constexpr (E == 8) return make_float2(-v.x, -v.y);
-    else return cmul(v, w16<DIR, E>());
+    else return cmulc(v, w16<DIR, E>());
   }
-  template <int M, int S, int R> __device__ __forceinline__ static void root_twiddle(float2 *u, const float2 *w)
-  {
-    if constexpr (S < R) {
-      u[S] = cmul(mul_root<(S * M) % 16>(u[S]), w[S - 1]);
-      root_twiddle<M, S + 1, R>(u, w);
-    }
-  }
-  template <int M, int R, int NB> __device__ __forceinline__ static void root_pass(float2 *x, const float2 *w)
+  // butterfly M of the root pass: element S gets w^(S (tid + M T)) = w^(S tid) * (16th root)^(S M)
+  template <int M, int R, int NB> __device__ __forceinline__ static void root_pass(float2 *x, float2 w1, float2 w2, float2 w3)
   {
     if constexpr (M < NB) {
-      root_twiddle<M, 1, R>(&x[M * R], w);
-      Dft<DIR, R>::run(&x[M * R]);
-      root_pass<M + 1, R, NB>(x, w);
+      float2 *u = &x[M * R];
+      u[1] = cmul(u[1], mul_root<(1 * M) % 16>(w1));
+      if constexpr (R > 2) {
+        u[2] = cmul(u[2], mul_root<(2 * M) % 16>(w2));
+        u[3] = cmul(u[3], mul_root<(3 * M) % 16>(w3));
+      }
+      Dft<DIR, R>::run(u);
+      root_pass<M + 1, R, NB>(x, w1, w2, w3);
     }
   }
 
@@ -310,13 +322,12 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     constexpr int NB = P / R, PER = per(R);
     if constexpr (ROOT_LAST && PASS == NPASS - 1) {
       static_assert((R - 1) * (NB - 1) < 10, "w16 covers exponents 0..9");
-      float2 w[3];
       int tt_ = tid;
       asm volatile("" : "+v"(tt_));
-      w[0] = lds[Plan::LDS_CELLS + tab_off(NTAB) + tt_];              // w^tid, then its square and cube
-      w[1] = cmul(w[0], w[0]);
-      w[2] = cmul(w[1], w[0]);
-      root_pass<0, R, NB>(x, w);
+      const float2 w1 = lds[Plan::LDS_CELLS + tab_off(NTAB) + tt_];   // w^tid, then its square and cube
+      const float2 w2 = cmul(w1, w1);
+      const float2 w3 = cmul(w2, w1);
+      root_pass<0, R, NB>(x, w1, w2, w3);
     } else {
       int tt_ = tid;
       asm volatile("" : "+v"(tt_));                                   // see the exchange below
