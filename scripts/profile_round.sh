@@ -14,5 +14,5 @@ python3 bench.py --steps 50 --warmup 5 ${BENCH_ARGS} > $OUT/bench_plain.json 2> 
 find $OUT -name "*.csv" | head -20
 # keep the merge small: per-dispatch traces can be large
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
-python3 scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+python3 scripts/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -46,3 +46,34 @@ for tag in ("bench_stats", "bench_plain"):
                 print("   ", k, v)
         except Exception as e:  # noqa: BLE001
             print(tag, "unreadable", e)
+
+# ---- machine-readable HBM traffic per launch (read by bench.py's roofline.traffic)
+if len(sys.argv) > 2:
+    per = {}
+    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = first(f"{tag}/**/*counter_collection.csv")
+        if not f:
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == ctr:
+                a = acc[r["Kernel_Name"]]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+        for k, (v, n) in acc.items():
+            per.setdefault(k, {})[ctr + "_KiB"] = round(v / n, 1)
+    stage_of = {"k_fft1": "fft1", "k_sumsq": "sumsq", "k_slowsum": "slowsum", "k_timf2": "timf2", "k_blank_scan": "blanker",
+                "k_fft2<": "fft2", "k_powersum2": "powersum2", "k_mix1_back": "mix1"}
+    kernels = {}
+    for name, v in per.items():
+        for pat, stage in stage_of.items():
+            if pat in name and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+                kernels[stage] = dict(kernel=name.split("(")[0] + "(...)", **v,
+                                      traffic_bytes_per_launch=int(2 * v["FETCH_SIZE_KiB"] * 1024 + v["WRITE_SIZE_KiB"] * 1024))
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 10 --warmup 3 --no-cpu "
+                     "(scripts/profile_round.sh)",
+           "workload": {"fft1_n": 14, "fft2_n": 12, "batch": 1024},
+           "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced streaming "
+                         "read, MI355X_MICROARCH.md HBM section; k_sumsq confirms it: ~67 MB reported for 134 MB read)",
+           "kernels": kernels}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
