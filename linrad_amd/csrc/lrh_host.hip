@@ -24,6 +24,7 @@ hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st);
 hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
 hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
+hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -59,6 +60,7 @@ struct lrh_ctx {
   hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
   int pipeline = 1;                  // LRH_PIPELINE=0 turns the two-stream schedule off
+  bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
   std::string err;
   // device tables
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
@@ -295,6 +297,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   }
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
   if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
+  // one workgroup per waterfall averaging group keeps the power sums in registers; long groups would starve the chip
+  c->fft2_fused = cfg->second_fft_enable && cfg->fft2_n <= LRH_FFT2_FUSED_MAXLOG && cfg->waterfall_avgnum >= 1 && cfg->waterfall_avgnum <= 16;
+  if (const char *e = getenv("LRH_FFT2_FUSED")) c->fft2_fused = c->fft2_fused && atoi(e) != 0;
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
              cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
              !(c->Im == 0 || c->Im == c->Mm) || cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
@@ -644,6 +649,8 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
   a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
   a.xcd = (c->xcd_mask >> 2) & 1;
+  a.ps_in = c->d_powersum2; a.ps_out = c->d_powersum2_alt; a.wf_scratch = c->d_wf_scratch;
+  a.ps_counter = p->wg_waterf_sum_counter; a.ps_avgnum = c->fft2_fused ? c->cfg.waterfall_avgnum : 0;
   if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
   if (c->cfg.fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->cur)); }
   else {
@@ -663,7 +670,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0));
     c->cur = c->stream2;
   }
-  { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
+  if (!c->fft2_fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
   const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
   if (nlines > 0) {
     int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
@@ -996,7 +1003,13 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     }
     case LRH_RING_TIMF2_PWR: src = c->d_pwr; total = c->cfg.timf2pow_size; break;
     case LRH_RING_FFT2_FLOAT: src = c->d_fft2; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
-    case LRH_RING_FFT2_POWER: src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2; break;
+    case LRH_RING_FFT2_POWER:
+      src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2;
+      if (c->fft2_fused) {                               // the hot path keeps only the sums: |X|^2 of the requested span on demand
+        if (off > total || cnt > total - off) return LRH_EINVAL;
+        HIPCHK(c, launch_power_of(c->d_fft2 + off, c->d_power2 + off, cnt, c->stream));
+      }
+      break;
     case LRH_RING_FFT2_POWERSUM: src = c->d_powersum2; total = c->N2; break;
     case LRH_RING_WG_WATERF: src = c->d_waterf; esz = 2; total = (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels; break;
     case LRH_RING_TIMF3_FLOAT: src = c->d_timf3; total = c->cfg.timf3_size; break;

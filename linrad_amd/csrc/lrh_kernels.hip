@@ -565,39 +565,137 @@ __global__ void k_blank_update(BlankArgs a)
 // =====================================================================================================
 // fft2 (one workgroup per transform, N2 <= 16384)
 // =====================================================================================================
-template <int LOG2N>
-__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft2(Fft2Args a)
+// LDS (exchange + twiddle tables) admits three 256-thread workgroups per CU at N = 4096: three waves per SIMD, 168 VGPRs
+__host__ __device__ constexpr int fft2_min_waves(int log2n) { return log2n == 12 ? 3 : (log2n == 13 ? 2 : 1); }
+template <int LOG2N, bool FUSED>
+__global__ __launch_bounds__(fft_threads(LOG2N), fft2_min_waves(LOG2N)) void k_fft2(Fft2Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
+  using Fft = BlockFftL<LOG2N, P, +1>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
-  __shared__ float2 lds[Plan::LDS_CELLS];
-  const int tid = threadIdx.x, b = a.xcd ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int px = a.px_first + b * a.step;
-  float2 x[P];
+  static_assert(P == R0, "one first-pass butterfly per thread: element s is sample tid + s*N/R0");
+  constexpr int H = R0 / 2;                              // elements of the first half of the transform
+  __shared__ float2 lds[Fft::LDS_CELLS];
+  const int tid0 = threadIdx.x;
+  Fft::init(lds, a.tw, tid0);
+  // A workgroup takes a.run consecutive transforms.  With the 50 % overlap of the windowed fft2 (step = N/2) the
+  // second half of transform t is the first half of t+1 and belongs to the same thread (sample tid + s N/R0 with
+  // s >= R0/2), so its weak+strong sum stays in registers and every timf2 sample is fetched once per run instead of
+  // twice per transform pair.
+  const int g = a.xcd ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  int t_first = g * a.run, t_end = min(t_first + a.run, a.batch);
+  constexpr bool fused = FUSED;
+  bool ps_continue = false, ps_complete = false;
+  if (fused) {                                           // group arithmetic of k_powersum2
+    t_first = g == 0 ? 0 : g * a.ps_avgnum - a.ps_counter;
+    int count = a.ps_avgnum - (g == 0 ? a.ps_counter : 0);
+    ps_complete = count <= a.batch - t_first;
+    if (!ps_complete) count = a.batch - t_first;
+    t_end = t_first + count;
+    ps_continue = g == 0 && a.ps_counter > 0;
+  }
+  const bool overlap = a.step * 2 == N;
+  // Load order as in k_fft1: what the next transform needs first (its fresh half, the window values) is requested
+  // BEFORE the stores of the current one, so the stores drain underneath the next transform instead of in front of
+  // its first wait (vmcnt retires in issue order).
+  float2 keep[H];                                        // raw weak+strong sum of the half shared with the next transform
+  float2 fw[H], fs[H];                                   // weak / strong samples of the fresh half, in flight
+  float win[P];
+  auto load_half = [&](int px, int h, float2 (&dw)[H], float2 (&ds)[H], int tid) {
 #pragma unroll
-  for (int m = 0; m < P / R0; m++)
-#pragma unroll
-    for (int s = 0; s < R0; s++) {
-      const int idx = (tid + m * T) + s * (N / R0);
-      const int r = (px + idx) & a.mask;
-      const float2 vw = a.timf2w[r], vs = a.timf2s[r];
-      const float w = a.window[idx];
-      x[m * R0 + s] = make_float2(w * (vw.x + vs.x), w * (vw.y + vs.y));   // weak + strong (fft2.c:100-105)
+    for (int s = 0; s < H; s++) {
+      const int r = (px + tid + (h * H + s) * (N / R0)) & a.mask;
+      dw[s] = a.timf2w[r]; ds[s] = a.timf2s[r];
     }
-  BlockFft<LOG2N, P, +1>::run(x, lds, a.tw, tid);
-  const int na = (a.first_na + b) & a.na_mask;
-  float2 *out = a.out + (size_t)na * N;
-  float *pw = a.power + (size_t)na * N;
+  };
+  auto load_window = [&](int tid) {
 #pragma unroll
-  for (int m = 0; m < P / RL; m++)
+    for (int s = 0; s < P; s++) win[s] = a.window[tid + s * (N / R0)];
+  };
+  if (t_first < t_end) {
+    load_half(a.px_first + t_first * a.step, 0, fw, fs, tid0);
 #pragma unroll
-    for (int q = 0; q < RL; q++) {
-      const int k = (tid + m * T) + q * (N / RL);
-      const float2 v = x[m * RL + q];
-      out[k] = v;
-      pw[k] = v.x * v.x + v.y * v.y;
+    for (int s = 0; s < H; s++) keep[s] = make_float2(fw[s].x + fs[s].x, fw[s].y + fs[s].y);   // weak + strong (fft2.c:100-105)
+    load_half(a.px_first + t_first * a.step, 1, fw, fs, tid0);
+    load_window(tid0);
+  }
+  float acc[FUSED ? P : 1];                              // running sum |X|^2 of the averaging group (fused mode)
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) acc[m * RL + q] = ps_continue ? a.ps_in[(tid0 + m * T) + q * (N / RL)] : 0.f;
+  }
+  __syncthreads();                                       // twiddle tables are in place
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): retire the prologue's loads (see k_fft1)
+#pragma unroll 1
+  for (int b = t_first; b < t_end; b++) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                        // keep index math inside the loop
+    const int px = a.px_first + b * a.step;
+    float2 x[P];
+#pragma unroll
+    for (int s = 0; s < H; s++) {
+      const float2 fr = make_float2(fw[s].x + fs[s].x, fw[s].y + fs[s].y);
+      x[s] = make_float2(win[s] * keep[s].x, win[s] * keep[s].y);
+      x[H + s] = make_float2(win[H + s] * fr.x, win[H + s] * fr.y);
+      keep[s] = fr;
     }
+    Fft::run(x, lds, tid);
+    // pin the outputs, then prefetch for the next transform (the last trip re-reads its own samples: harmless)
+#pragma unroll
+    for (int e = 0; e < P; e++) asm volatile("" : "+v"(x[e].x), "+v"(x[e].y));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int pn = b + 1 < t_end ? px + a.step : px;
+    if (!overlap) {
+      load_half(pn, 0, fw, fs, tid);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int s = 0; s < H; s++) keep[s] = make_float2(fw[s].x + fs[s].x, fw[s].y + fs[s].y);
+    }
+    load_half(pn, 1, fw, fs, tid);
+    load_window(tid);
+    __builtin_amdgcn_sched_barrier(0);
+    const int na = (a.first_na + b) & a.na_mask;
+    float2 *out = a.out + (size_t)na * N;
+    float *pw = a.power + (size_t)na * N;
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int k = (tid + m * T) + q * (N / RL);
+        const float2 v = x[m * RL + q];
+        out[k] = v;
+        const float p2 = v.x * v.x + v.y * v.y;
+        if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
+        else pw[k] = p2;
+      }
+    __syncthreads();                                     // LDS is reused by the next transform
+  }
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int k = (tid0 + m * T) + q * (N / RL);
+        if (ps_complete) a.wf_scratch[(size_t)g * N + k] = acc[m * RL + q];
+        if (g == (int)gridDim.x - 1) a.ps_out[k] = acc[m * RL + q];
+      }
+  }
+}
+
+// fft2_power_float on demand (export of LRH_RING_FFT2_POWER when the fused path does not keep the ring)
+__global__ __launch_bounds__(256) void k_power_of(const float2 *src, float *dst, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float2 v = src[i]; dst[i] = v.x * v.x + v.y * v.y; }
+}
+hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_power_of, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+  return hipGetLastError();
 }
 
 // ---- fft2 for N2 > 16384: four-step through an HBM scratch -----------------------------------------------------
@@ -931,8 +1029,17 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
     else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
     else hipLaunchKernelGGL((k_timf2<L, 2>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);                  \
   } while (0)
-#define LRH_LAUNCH_FFT2(L, a, batch, st) \
-  hipLaunchKernelGGL((k_fft2<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
+#define LRH_LAUNCH_FFT2(L, a, batch, st)                                                                              \
+  do {                                                                                                                \
+    if constexpr (L <= LRH_FFT2_FUSED_MAXLOG) {                                                                       \
+      if (a.ps_avgnum > 0) {                                                                                          \
+        hipLaunchKernelGGL((k_fft2<L, true>), dim3((a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),           \
+                           dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a);                                      \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((k_fft2<L, false>), dim3((batch + a.run - 1) / a.run), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a); \
+  } while (0)
 #define LRH_LAUNCH_MIX1(L, a, batch, st) \
   hipLaunchKernelGGL((k_mix1_back<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
 
@@ -956,8 +1063,25 @@ hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t s
   LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }
-hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st)
+hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)
 {
+  Fft2Args a = a0; a.batch = batch;
+  // consecutive transforms per workgroup: one run per resident workgroup slot (tables and prologue amortised, a
+  // fraction (run+1)/(2 run) of the overlapped reads left), single transforms when the batch is small
+  {
+    int lds = 0, threads = 0;
+    switch (log2n) {
+#define LRH_FFT2_GEOM(L) case L: lds = 8 * BlockFftL<L, points_per_thread(L), 1>::LDS_CELLS; threads = fft_threads(L); break;
+      LRH_FFT2_GEOM(6) LRH_FFT2_GEOM(7) LRH_FFT2_GEOM(8) LRH_FFT2_GEOM(9) LRH_FFT2_GEOM(10) LRH_FFT2_GEOM(11)
+      LRH_FFT2_GEOM(12) LRH_FFT2_GEOM(13) LRH_FFT2_GEOM(14)
+#undef LRH_FFT2_GEOM
+      default: return hipErrorInvalidValue;
+    }
+    const int cap = persistent_grid(lds, threads, 1 << 30);
+    const char *e = getenv("LRH_FFT2_RUN");
+    int run = e ? atoi(e) : (batch + cap - 1) / cap;
+    a.run = run < 1 ? 1 : (run > 16 ? 16 : run);
+  }
   LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }

@@ -5,6 +5,7 @@
 
 namespace lrh {
 
+#define LRH_FFT2_FUSED_MAXLOG 13   // largest fft2 size whose register file also holds the 16 power accumulators
 #define LRH_PH_CHUNK 64      // mix1 phases: the host uploads every 64th value of its float recursion, the kernel replays the rest
 
 
@@ -79,6 +80,10 @@ struct Fft2Args {
   const float *window; const float2 *tw;
   float2 *out; float *power; int first_na, na_mask;
   int xcd;
+  int batch, run;           // transforms in this launch; consecutive transforms per workgroup (set by launch_fft2)
+  // fused power sums (fft2.c:655-670): with ps_avgnum > 0 a workgroup takes one waterfall averaging group instead of
+  // a fixed run, keeps sum |X|^2 in registers and writes the group line; `power` may then be null
+  const float *ps_in; float *ps_out; float *wf_scratch; int ps_counter; int ps_avgnum;
 };
 // four-step fft2 (N2 > 16384): N2 = NA*NB, column transforms of length NA, twiddle, row transforms of length NB
 struct Fft2BigArgs {
