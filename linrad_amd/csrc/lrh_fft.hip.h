@@ -20,33 +20,60 @@
 
 namespace lrh {
 
-// complex multiply by a compile-time constant: left to the compiler (constants fold into literals / SGPRs)
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex values travel as float2 (HIP's struct) between kernels and butterflies; inside the butterflies they are
+// native 2-vectors so that every complex add/sub is ONE packed instruction and nothing is left to the SLP
+// vectoriser, which pairs unrelated halves and then spends a v_mov per butterfly output re-pairing them.
+typedef float lrh_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lrh_v2f to_v(float2 a) { return lrh_v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(lrh_v2f a) { return make_float2(a.x, a.y); }
+
+// complex multiply by a compile-time constant c + js in two packed ops: (u.x,u.x)*(c,s) + (u.y,u.y)*(-s,c)
+__device__ __forceinline__ lrh_v2f cmulc_v(lrh_v2f u, float c, float s)
+{
+  const lrh_v2f t = lrh_v2f{u.x, u.x} * lrh_v2f{c, s};
+  return __builtin_elementwise_fma(lrh_v2f{u.y, u.y}, lrh_v2f{-s, c}, t);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return to_f2(cmulc_v(to_v(a), b.x, b.y)); }
 // complex multiply of two register values in two packed instructions:
 //   t = (a.x b.x, a.x b.y);  r = (t.x - a.y b.y, t.y + a.y b.x)
-// hipcc's own lowering of the expression above takes three packed ops plus a v_mov to re-pair the halves.
-typedef float lrh_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// hipcc's own lowering of the scalar expression takes three packed ops plus a v_mov to re-pair the halves, and the
+// per-lane negation is not folded from vector code either (a v_xor appears), hence the asm.
+__device__ __forceinline__ lrh_v2f cmul_v(lrh_v2f av, lrh_v2f bv)
 {
-  const lrh_v2f av = {a.x, a.y}, bv = {b.x, b.y};      // (no __builtin_bit_cast: it goes through a stack slot that SROA keeps)
   lrh_v2f t, r;
   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
-  return make_float2(r.x, r.y);
+  return r;
 }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return to_f2(cmul_v(to_v(a), to_v(b))); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiply by -j (DIR = -1, forward) or +j (DIR = +1)
 template <int DIR> __device__ __forceinline__ float2 mulj(float2 a) { return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x); }
 template <int DIR> __device__ __forceinline__ float2 tw_dir(float2 w) { return DIR < 0 ? w : make_float2(w.x, -w.y); }
+// s + mulj<DIR>(t) and s - mulj<DIR>(t) in one packed add each: swapped halves of t, one lane negated
+template <int DIR> __device__ __forceinline__ lrh_v2f add_mulj(lrh_v2f s, lrh_v2f t)
+{
+  lrh_v2f r;
+  if (DIR < 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(s), "v"(t));   // (s.x + t.y, s.y - t.x)
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(s), "v"(t));           // (s.x - t.y, s.y + t.x)
+  return r;
+}
+template <int DIR> __device__ __forceinline__ lrh_v2f sub_mulj(lrh_v2f s, lrh_v2f t) { return add_mulj<-DIR>(s, t); }
 
 template <int DIR> __device__ __forceinline__ void bfly2(float2 &a, float2 &b) { float2 t = csub(a, b); a = cadd(a, b); b = t; }
 
 // 4-point DFT, outputs in natural order: a,b,c,d <- X0..X3 of inputs x0..x3 = a,b,c,d
+template <int DIR> __device__ __forceinline__ void bfly4_v(lrh_v2f &a, lrh_v2f &b, lrh_v2f &c, lrh_v2f &d)
+{
+  const lrh_v2f s0 = a + c, s1 = a - c, s2 = b + d, t = b - d;
+  a = s0 + s2; c = s0 - s2; b = add_mulj<DIR>(s1, t); d = sub_mulj<DIR>(s1, t);
+}
 template <int DIR> __device__ __forceinline__ void bfly4(float2 &a, float2 &b, float2 &c, float2 &d)
 {
-  float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mulj<DIR>(csub(b, d));
-  a = cadd(s0, s2); c = csub(s0, s2); b = cadd(s1, s3); d = csub(s1, s3);
+  lrh_v2f av = to_v(a), bv = to_v(b), cv = to_v(c), dv = to_v(d);
+  bfly4_v<DIR>(av, bv, cv, dv);
+  a = to_f2(av); b = to_f2(bv); c = to_f2(cv); d = to_f2(dv);
 }
 
 #define LRH_C8 0.70710678118654752440f
@@ -84,29 +111,30 @@ template <int DIR> struct Dft<DIR, 8> {
   }
 };
 template <int DIR> struct Dft<DIR, 16> {
-  __device__ __forceinline__ static void run(float2 *u)
+  __device__ __forceinline__ static void run(float2 *uf)
   {
     // s = 4a+b: radix-4 over a (b fixed), twiddle w16^(b c), radix-4 over b; output index c + 4d
+    lrh_v2f u[16];
 #pragma unroll
-    for (int b = 0; b < 4; b++) bfly4<DIR>(u[b], u[b + 4], u[b + 8], u[b + 12]);   // u[4c+b] = y[b][c]
-    u[4 * 1 + 1] = cmulc(u[4 * 1 + 1], w16<DIR, 1>());
-    u[4 * 1 + 2] = cmulc(u[4 * 1 + 2], w16<DIR, 2>());
-    u[4 * 1 + 3] = cmulc(u[4 * 1 + 3], w16<DIR, 3>());
-    u[4 * 2 + 1] = cmulc(u[4 * 2 + 1], w16<DIR, 2>());
-    u[4 * 2 + 2] = mulj<DIR>(u[4 * 2 + 2]);
-    u[4 * 2 + 3] = cmulc(u[4 * 2 + 3], w16<DIR, 6>());
-    u[4 * 3 + 1] = cmulc(u[4 * 3 + 1], w16<DIR, 3>());
-    u[4 * 3 + 2] = cmulc(u[4 * 3 + 2], w16<DIR, 6>());
-    u[4 * 3 + 3] = cmulc(u[4 * 3 + 3], w16<DIR, 9>());
-    float2 v[16];
+    for (int q = 0; q < 16; q++) u[q] = to_v(uf[q]);
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4_v<DIR>(u[b], u[b + 4], u[b + 8], u[b + 12]);   // u[4c+b] = y[b][c]
+    constexpr float sg = DIR < 0 ? -1.f : 1.f;
+    u[4 * 1 + 1] = cmulc_v(u[4 * 1 + 1], LRH_C16A, sg * LRH_S16A);                   // w16^1
+    u[4 * 1 + 2] = cmulc_v(u[4 * 1 + 2], LRH_C8, sg * LRH_C8);                       // w16^2
+    u[4 * 1 + 3] = cmulc_v(u[4 * 1 + 3], LRH_S16A, sg * LRH_C16A);                   // w16^3
+    u[4 * 2 + 1] = cmulc_v(u[4 * 2 + 1], LRH_C8, sg * LRH_C8);                       // w16^2
+    u[4 * 2 + 2] = cmulc_v(u[4 * 2 + 2], 0.f, sg);                                   // w16^4 = +-j
+    u[4 * 2 + 3] = cmulc_v(u[4 * 2 + 3], -LRH_C8, sg * LRH_C8);                      // w16^6
+    u[4 * 3 + 1] = cmulc_v(u[4 * 3 + 1], LRH_S16A, sg * LRH_C16A);                   // w16^3
+    u[4 * 3 + 2] = cmulc_v(u[4 * 3 + 2], -LRH_C8, sg * LRH_C8);                      // w16^6
+    u[4 * 3 + 3] = cmulc_v(u[4 * 3 + 3], -LRH_C16A, -sg * LRH_S16A);                 // w16^9
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      bfly4<DIR>(u[4 * c + 0], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);          // over b -> d
+      bfly4_v<DIR>(u[4 * c + 0], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);          // over b -> d
 #pragma unroll
-      for (int d = 0; d < 4; d++) v[c + 4 * d] = u[4 * c + d];
+      for (int d = 0; d < 4; d++) uf[c + 4 * d] = to_f2(u[4 * c + d]);
     }
-#pragma unroll
-    for (int q = 0; q < 16; q++) u[q] = v[q];
   }
 };
 
