@@ -343,11 +343,15 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     }
   }
 
-  template <int PASS> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, int tid)
+  struct NoHook { __device__ __forceinline__ void operator()() const {} };
+  // `before_last` runs once, after the LDS reads that feed the last pass and before its butterflies: the place to
+  // issue the global loads the caller needs right after the transform (their latency hides behind the last pass)
+  template <int PASS, class Hook> __device__ __forceinline__ static void pass(float2 (&x)[P], float2 *lds, int tid, const Hook &before_last)
   {
     constexpr int R = Plan::radix(PASS);
     constexpr int p = Plan::done(PASS);
     constexpr int NB = P / R, PER = per(R);
+    if constexpr (PASS == NPASS - 1) before_last();
     if constexpr (ROOT_LAST && PASS == NPASS - 1) {
       static_assert((R - 1) * (NB - 1) < 10, "w16 covers exponents 0..9");
       int tt_ = tid;
@@ -413,11 +417,12 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
           const int c = m * T + s * (N / R2);
           x[m * R2 + s] = rd[c + c / 16];
         }
-      pass<PASS + 1>(x, lds, tid);
+      pass<PASS + 1>(x, lds, tid, before_last);
     }
   }
 
-  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, int tid) { pass<0>(x, lds, tid); }
+  __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, int tid) { pass<0>(x, lds, tid, NoHook()); }
+  template <class Hook> __device__ __forceinline__ static void run(float2 (&x)[P], float2 *lds, int tid, const Hook &before_last) { pass<0>(x, lds, tid, before_last); }
 };
 
 // XCD-aware block order (8 XCDs, blocks dealt round-robin): consecutive work items go to blocks b, b+8, b+16 ...

@@ -524,6 +524,22 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
+  a.stamps = nullptr;
+  if (getenv("LRH_STAMP")) {                              // diagnostics: dump the phase stamps of this launch to stderr
+    static unsigned long long *d_st = nullptr;
+    if (!d_st) hipMalloc(&d_st, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long));
+    hipMemsetAsync(d_st, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur);
+    a.stamps = d_st;
+    HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+    unsigned long long h[2 * LRH_STAMPS_PER_WG];
+    hipMemcpyAsync(h, d_st, sizeof h, hipMemcpyDeviceToHost, c->cur); hipStreamSynchronize(c->cur);
+    for (int w = 0; w < 2; w++) {
+      fprintf(stderr, "fft1 stamps wg%d:", w ? 128 : 0);
+      for (int i = 1; i < LRH_STAMPS_PER_WG && h[w * LRH_STAMPS_PER_WG + i]; i++) fprintf(stderr, " %llu", h[w * LRH_STAMPS_PER_WG + i] - h[w * LRH_STAMPS_PER_WG]);
+      fprintf(stderr, "\n");
+    }
+    return LRH_OK;
+  }
   ProfScope ps(c, "fft1");
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
   return LRH_OK;

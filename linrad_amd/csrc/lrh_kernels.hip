@@ -34,6 +34,12 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   // change between transforms stays on chip (twiddles in LDS) or is fetched ahead of the stores (window
   // values, filter correction): the only loads that follow a transform's stores are the next prefetch, which is
   // not needed for a whole transform, so no wait ever covers a freshly issued store (vmcnt retires in order).
+  int nstamp = 0;
+  auto stamp = [&]() {                                    // diagnostics only: one lane of two workgroups writes the shader clock
+    if (a.stamps && tid0 == 0 && (blockIdx.x == 0 || blockIdx.x == 128) && nstamp < LRH_STAMPS_PER_WG)
+      a.stamps[(blockIdx.x ? LRH_STAMPS_PER_WG : 0) + nstamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
   Fft::init(lds, a.tw, tid0);
   float win[P];
   auto load_window = [&](int tid) {
@@ -64,11 +70,13 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   // prefetch being the youngest load on this path would otherwise turn the loop-top wait into vmcnt(0) for every
   // trip -- which also waits for the stores of the previous transform.
   __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), other counters untouched
+  stamp();
 #pragma unroll 1
   for (; bi < a.batch; bi += gridDim.x) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));                        // keep index math inside the loop (see k_timf2)
     const int b = a.xcd ? xcd_order(bi, a.batch) : bi;
+    stamp();
     float2 x[P];
 #pragma unroll
     for (int e = 0; e < P; e++) {
@@ -78,21 +86,29 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     }
     const int bn = bi + gridDim.x;
     if (bn < a.batch) fetch(a.xcd ? xcd_order(bn, a.batch) : bn, tid);
-    Fft::run(x, lds, tid);
-    float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
-    // Tail: every load the next transform needs before its first wait (its window values) and this one's filter
-    // correction are issued BEFORE the stores, so that no later wait has to cover the stores.
-    load_window(tid);
+    // Every load the next transform needs before its first wait (its window values) and this one's filter correction
+    // are issued BEFORE the stores, so that no later wait has to cover the stores; the filter correction already
+    // before the last pass, whose butterflies hide its latency.
     float2 fc[P];
+    constexpr int EARLY = P / 2;                          // as many as the register file holds next to the last pass
+    Fft::run(x, lds, tid, [&]() {
 #pragma unroll
-    for (int e = 0; e < P; e++) fc[e] = a.filtercorr[out_index(tid, e)];
+      for (int e = 0; e < EARLY; e++) fc[e] = a.filtercorr[out_index(tid, e)];
+    });
+#pragma unroll
+    for (int e = EARLY; e < P; e++) fc[e] = a.filtercorr[out_index(tid, e)];
+    stamp();
+    float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+    load_window(tid);
 #pragma unroll
     for (int e = 0; e < P; e++) {
       float2 v = x[e];
       if (a.direction < 0) v = make_float2(v.y, v.x);   // fft1.c:3660-3679
       out[out_index(tid, e)] = cmul(v, fc[e]);
     }
+    stamp();
     __syncthreads();                                     // LDS is reused by the next transform
+    stamp();
   }
 }
 

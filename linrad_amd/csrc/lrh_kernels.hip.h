@@ -24,7 +24,9 @@ struct Fft1Args {
   int xcd;                  // XCD-aware block order on/off
   int batch;                // transforms in this launch (workgroups are persistent)
   int chan_count, chan_index; // frame layout {I0,Q0,I1,Q1,...}: sample s of this channel is short2 s*chan_count+chan_index
+  unsigned long long *stamps; // diagnostics (LRH_STAMP=1): s_memtime of workgroups 0 and 128 at phase boundaries, else null
 };
+#define LRH_STAMPS_PER_WG 64
 
 // ---- fft1_c power sums ----
 // Averaging groups are derived in-kernel: group g covers transforms [g*avg - c0, ...) of the batch (the first one
