@@ -96,7 +96,11 @@ typedef struct lrh_config {
   int mix2_n;                   /* log2 mix2.size (baseb_graph.c:1302-1323), <= fft3_n                     */
   int max_fft3n;                /* fft3 ring length in transforms (fft3_totsiz/fft3_block), pow2          */
   int baseband_size;            /* baseb_raw ring, complex samples, pow2                                   */
-  int reserved[6];
+  /* input sample format (fft1.c:413-635) */
+  int timf1_dword_input;        /* ui.rx_input_mode & DWORD_INPUT: timf1 holds int32 I,Q (18/24-bit hardware,
+                                   expanded .raw recordings) instead of int16                              */
+  int sample_shift;             /* ui.sample_shift: Q is taken sample_shift samples after I (fft1.c:470-482) */
+  int reserved[4];
 } lrh_config;
 
 /*

@@ -34,7 +34,7 @@ class LrhConfig(C.Structure):
         ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
         ("timf2_blockpower_size", C.c_int), ("timf1_frame_channels", C.c_int), ("timf1_channel_index", C.c_int),
         ("fft3_n", C.c_int), ("fft3_sinpow", C.c_int), ("mix2_n", C.c_int), ("max_fft3n", C.c_int),
-        ("baseband_size", C.c_int), ("reserved", C.c_int * 6),
+        ("baseband_size", C.c_int), ("timf1_dword_input", C.c_int), ("sample_shift", C.c_int), ("reserved", C.c_int * 4),
     ]
 
 
@@ -171,7 +171,7 @@ class StageAPI:
             mi = int(np.float32(ratio) * m2) & ~1
             self.mix2_interleave_points = mi
             self.fft3_interleave_points = mi * ((1 << cfg.fft3_n) // m2)
-        self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * 4 * max(1, cfg.timf1_frame_channels)
+        self.timf1_blockbytes = (self.N1 - self.fft1_interleave_points) * (8 if cfg.timf1_dword_input else 4) * max(1, cfg.timf1_frame_channels)
 
     def _proto(self, name, argtypes, restype=C.c_int):
         f = self._f(name)
@@ -227,7 +227,7 @@ class StageAPI:
 
     # ---- producer
     def timf1_write(self, iq, byte_offset=0):
-        iq = np.ascontiguousarray(iq, np.int16)
+        iq = np.ascontiguousarray(iq, np.int32 if self.cfg.timf1_dword_input else np.int16)
         self._chk(self._f("timf1_write")(self.ctx, iq.ctypes.data_as(C.c_void_p), int(byte_offset), int(iq.nbytes)),
                   "timf1_write")
 

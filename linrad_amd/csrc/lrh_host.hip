@@ -155,6 +155,7 @@ static void default_filtercorr(lrh_ctx *c)  // clear_fft1_filtercorr + make_filc
 {
   int N = c->N1;
   float start = 150 * (float)N * (float)pow((double)N, -0.4);
+  if (c->cfg.timf1_dword_input) { start *= 4096; start *= 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32 I/Q */
   start = (float)c->cfg.fft1_gain / start;
   c->h_filtercorr.assign(2 * N, 0.f); c->h_desired.assign(N, 1.f);
   for (int i = 0; i < N; i++) c->h_filtercorr[2 * i] = start;
@@ -517,10 +518,13 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
-  a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / 4 - 1;
+  const int esz = c->cfg.timf1_dword_input ? 8 : 4;       // bytes per complex sample (fft1.c:420 / :526)
+  a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / esz - 1; a.dword = c->cfg.timf1_dword_input != 0;
+  a.shift_i = c->cfg.sample_shift > 0 ? -c->cfg.sample_shift : 0;   // fft1.c:478-482
+  a.shift_q = c->cfg.sample_shift < 0 ? c->cfg.sample_shift : 0;    // fft1.c:472-476
   a.chan_count = C; a.chan_index = C > 1 ? c->cfg.timf1_channel_index : 0;
   // first sample of the transform, per channel: ref/2 - 2*C*I1 shorts (fft1.c:421-426; 2-ch: fft1.c:2052-2055)
-  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / (4 * C) - c->I1) & (a.ring_mask / C);
+  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / (esz * C) - c->I1) & (a.ring_mask / C);
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
@@ -911,7 +915,7 @@ static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 for everythin
 static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side pointers, wcw.c:1037-1047
 {
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
-  p->timf1p_px = (p->timf1p_px + B * c->M1 * 4 * C) & c->timf1_bytemask;
+  p->timf1p_px = (p->timf1p_px + B * c->M1 * (c->cfg.timf1_dword_input ? 8 : 4) * C) & c->timf1_bytemask;
   p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
   p->fft1_na = p->fft1_pa / (2 * c->N1);
   p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;

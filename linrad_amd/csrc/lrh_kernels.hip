@@ -11,6 +11,7 @@
 //
 // All spectra / time functions live in device rings; every kernel is HBM-bound, so the design rule is one pass
 // per stage with everything element-wise fused into the transform's load or store.
+#include <type_traits>
 #include "lrh_fft.hip.h"
 #include "lrh_kernels.hip.h"
 
@@ -19,9 +20,12 @@ namespace lrh {
 // =====================================================================================================
 // fft1
 // =====================================================================================================
-template <int LOG2N>
+// DW: int32 samples (DWORD_INPUT); SKEW: I and Q taken from different sample instants (ui.sample_shift != 0)
+template <int LOG2N, bool DW, bool SKEW>
 __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft1(Fft1Args a)
 {
+  using Raw = typename std::conditional<DW, int2, short2>::type;
+  using Comp = typename std::conditional<DW, int, short>::type;
   constexpr int P = points_per_thread(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
   using Fft = BlockFftL<LOG2N, P, +1>;
@@ -55,13 +59,21 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     return kk;
   };
   load_window(tid0);
-  short2 nxt[P];
+  Raw nxt[P];
   auto fetch = [&](int bi, int tid) {
     const int p0 = a.p0_first + bi * a.step;
 #pragma unroll
     for (int m = 0; m < P / R0; m++)
 #pragma unroll
-      for (int s = 0; s < R0; s++) nxt[m * R0 + s] = a.timf1[((p0 + (tid + m * T) + s * (N / R0)) * a.chan_count + a.chan_index) & a.ring_mask];
+      for (int s = 0; s < R0; s++) {
+        const int n = p0 + (tid + m * T) + s * (N / R0);
+        if constexpr (!SKEW) nxt[m * R0 + s] = ((const Raw *)a.timf1)[(n * a.chan_count + a.chan_index) & a.ring_mask];
+        else {
+          const Comp *c = (const Comp *)a.timf1;
+          nxt[m * R0 + s].x = c[2 * (((n + a.shift_i) * a.chan_count + a.chan_index) & a.ring_mask)];
+          nxt[m * R0 + s].y = c[2 * (((n + a.shift_q) * a.chan_count + a.chan_index) & a.ring_mask) + 1];
+        }
+      }
   };
   int bi = blockIdx.x;
   if (bi < a.batch) fetch(a.xcd ? xcd_order(bi, a.batch) : bi, tid0);
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     float2 x[P];
 #pragma unroll
     for (int e = 0; e < P; e++) {
-      const short2 v = nxt[e];
+      const Raw v = nxt[e];
       // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
       x[e] = make_float2((float)v.x * win[e], -((float)v.y * win[e]));
     }
@@ -1037,8 +1049,16 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
     default: return hipErrorInvalidValue;                                                                    \
   }
 
-#define LRH_LAUNCH_FFT1(L, a, batch, st) \
-  hipLaunchKernelGGL((k_fft1<L>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a)
+#define LRH_LAUNCH_FFT1_V(L, DW, SK, a, batch, st) \
+  hipLaunchKernelGGL((k_fft1<L, DW, SK>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a)
+#define LRH_LAUNCH_FFT1(L, a, batch, st)                                                    \
+  do {                                                                                      \
+    const bool sk = a.shift_i != 0 || a.shift_q != 0;                                       \
+    if (!a.dword && !sk) LRH_LAUNCH_FFT1_V(L, false, false, a, batch, st);                  \
+    else if (!a.dword) LRH_LAUNCH_FFT1_V(L, false, true, a, batch, st);                     \
+    else if (!sk) LRH_LAUNCH_FFT1_V(L, true, false, a, batch, st);                          \
+    else LRH_LAUNCH_FFT1_V(L, true, true, a, batch, st);                                    \
+  } while (0)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
     if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);      \

@@ -11,7 +11,9 @@ namespace lrh {
 
 // ---- fft1_b (+ filter correction of fft1_c) ----
 struct Fft1Args {
-  const short2 *timf1;      // interleaved int16 I,Q ring
+  const void *timf1;        // interleaved I,Q ring: int16 pairs, or int32 pairs when dword != 0 (DWORD_INPUT)
+  int dword;                // sample container: 0 int16, 1 int32 (fft1.c:420 / :526)
+  int shift_i, shift_q;     // ui.sample_shift as per-component sample offsets: I from n+shift_i, Q from n+shift_q (fft1.c:470-482)
   int ring_mask;            // in complex samples
   int p0_first;             // first sample of transform 0 = timf1p_ref/4 - I1 (fft1.c:421-426)
   int step;                 // new samples per transform (M1)

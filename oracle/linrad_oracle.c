@@ -119,6 +119,7 @@ static void default_filtercorr(lro_ctx *c)
 {
   int N = c->N1;
   float start = 150 * (float)N * (float)pow((double)N, -0.4);
+  if (c->cfg.timf1_dword_input) { start *= 4096; start *= 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32 I/Q */
   start = (float)c->cfg.fft1_gain / start;
   for (int i = 0; i < N; i++) { c->fft1_desired[i] = 1; c->fft1_filtercorr[2 * i] = start; c->fft1_filtercorr[2 * i + 1] = 0; }
   float t1 = 0.125F * (float)PI_L, t2 = 0, t3;
@@ -329,17 +330,23 @@ int lro_timf1_write(lro_ctx *c, const void *src, int off, int nbytes)
 static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
 {
   int N = c->N1, n = c->cfg.fft1_n, nn = N / 2;
-  int m = c->timf1_bytemask / 2;
-  int p0 = timf1p_ref / 2; p0 = (p0 - c->I1 * 2 + m + 1) & m;
-  int pa = p0, pb = (pa + N) & m;
+  const int dword = c->cfg.timf1_dword_input != 0, esz = dword ? 4 : 2;   /* fft1.c:420 / :526 */
+  const int32_t *t32 = (const int32_t *)c->timf1;
+  int m = c->timf1_bytemask / esz;
+  int p0 = timf1p_ref / esz; p0 = (p0 - c->I1 * 2 + m + 1) & m;
+  int pa = p0, pb = (pa + N) & m, pa1 = pa, pb1 = pb;
+  const int sh = c->cfg.sample_shift;
+  if (sh < 0) { pa1 = (pa + 2 * sh + m + 1) & m; pb1 = (pa1 + N) & m; }            /* fft1.c:472-476 */
+  else if (sh > 0) { pa = (pa - 2 * sh + m + 1) & m; pb = (pb - 2 * sh + m + 1) & m; } /* fft1.c:478-482 */
   float *z = c->tmp;
   int win = c->cfg.fft1_sinpow != 0;
-  for (int ia = 0; ia < nn; ia++) {           /* window, negate Q, natural order */
+  for (int ia = 0; ia < nn; ia++) {           /* window, negate Q, natural order; I from pa/pb, Q from pa1/pb1 */
     float wa = win ? c->fft1_window[2 * ia] : 1.0f, wb = win ? c->fft1_window[2 * ia + 1] : 1.0f;
-    float t1 = c->timf1[pa] * wa, t2 = c->timf1[pa + 1] * wa;
-    float t3 = c->timf1[pb] * wb, t4 = c->timf1[pb + 1] * wb;
+    float t1, t2, t3, t4;
+    if (dword) { t1 = t32[pa] * wa; t2 = t32[pa1 + 1] * wa; t3 = t32[pb] * wb; t4 = t32[pb1 + 1] * wb; }
+    else { t1 = c->timf1[pa] * wa; t2 = c->timf1[pa1 + 1] * wa; t3 = c->timf1[pb] * wb; t4 = c->timf1[pb1 + 1] * wb; }
     z[2 * ia] = t1; z[2 * ia + 1] = -t2; z[2 * (ia + nn)] = t3; z[2 * (ia + nn) + 1] = -t4;
-    pa = (pa + 2) & m; pb = (pb + 2) & m;
+    pa = (pa + 2) & m; pb = (pb + 2) & m; pa1 = (pa1 + 2) & m; pb1 = (pb1 + 2) & m;
   }
   dif_stages(N, n, z, c->fft1tab, +1, 2);
   for (unsigned i = 0; i < (unsigned)N; i++) {   /* bit reversal + half swap: make_permute(1,..) fft0.c:1147-1207 */
@@ -359,7 +366,7 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
 
 int lro_fft1_b(lro_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 {
-  int blockbytes = c->M1 * 4;
+  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4);
   for (int b = 0; b < batch; b++) {
     int nb = ((fft1_pa / (2 * c->N1)) + b) & c->fft1n_mask;
     float *out = c->fft1_float + (size_t)nb * 2 * c->N1;
@@ -858,7 +865,7 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   while (nblocks > 0) {
     int B = nblocks < batch ? nblocks : batch;
     if ((rc = lro_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
-    p->timf1p_px = (p->timf1p_px + B * c->M1 * 4) & c->timf1_bytemask;
+    p->timf1p_px = (p->timf1p_px + B * c->M1 * (c->cfg.timf1_dword_input ? 8 : 4)) & c->timf1_bytemask;
     p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
     p->fft1_na = p->fft1_pa / (2 * c->N1);
     for (int i = 0; i < B; i++) if (p->fft1_nm != c->fft1n_mask) p->fft1_nm++;

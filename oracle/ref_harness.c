@@ -117,6 +117,8 @@ int main(int argc, char **argv)
   int bp_block = AI("blockpower_block", 0), bp_size = AI("blockpower_size", 1024);
   int n3 = AI("fft3_n", 0), sinpow3 = AI("fft3_sinpow", 2), nm2 = AI("mix2_n", 0), maxfft3n = AI("max_fft3n", 8);
   int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
+  int dword = AI("dword", 0);                    /* ui.rx_input_mode & DWORD_INPUT: the input file holds int32 I,Q */
+  int sshift = AI("sample_shift", 0);            /* ui.sample_shift */
   const char *fin = arg(argc, argv, "in", NULL);
   const char *flim = arg(argc, argv, "liminfo", NULL);
   const char *fout = arg(argc, argv, "out", "ref_dump.bin");
@@ -126,8 +128,8 @@ int main(int argc, char **argv)
 
   /* ---- ui / genparm ---- */
   memset(&ui, 0, sizeof(ui));
-  ui.rx_input_mode = IQ_DATA; ui.rx_rf_channels = 1; ui.rx_ad_channels = 2;
-  ui.sample_shift = 0; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
+  ui.rx_input_mode = IQ_DATA | (dword ? DWORD_INPUT : 0); ui.rx_rf_channels = 1; ui.rx_ad_channels = 2;
+  ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
   genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
   genparm[SECOND_FFT_ENABLE] = second; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
@@ -185,7 +187,7 @@ int main(int argc, char **argv)
     free(tmpb);
   }
   fclose(fi);
-  timf1_blockbytes = fft1_new_points * 4;
+  timf1_blockbytes = fft1_new_points * (dword ? 8 : 4);
   timf1p_px = 0;
 
   /* spectrum averaging (fft1_c, update_fft1_slowsum) */

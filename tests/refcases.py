@@ -49,6 +49,14 @@ CASES = {
                          fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
                          strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
                          pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8),
+    # int32 input (DWORD_INPUT: 18/24-bit hardware, expanded .raw recordings) with an I/Q sample skew (fft1.c:470-635)
+    "n10_n12_dword": dict(n1=10, n2=12, mixred=6, nblk=48, avg1num=5, avg2num=4, att_n=8, gain=15, bln_interval=4, bln_avgnum=16,
+                          fq=2200.3, wf_avgnum=2, wf_mode=1, seed=18, timf2pow_log2=15, sumsq_blocks=8, sigma=256.0,
+                          strong=[(-300.25, 6000.0), (37.0, 2000.0)], weak=[(-100.0, 200.0), (411.3, 100.0)],
+                          pulse_period=1999, pulse_amp=100000.0, lim_halfwidth=3, dword=1, sample_shift=-1),
+    "n9_n11_shift": dict(n1=9, n2=11, mixred=5, nblk=40, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
+                         fq=900.0, wf_avgnum=1, wf_mode=1, seed=19, timf2pow_log2=14, sumsq_blocks=4,
+                         strong=[], weak=[(150.5, 45.0), (60.0, 120.0)], pulse_period=1499, lim_halfwidth=3, sample_shift=2),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
@@ -59,10 +67,12 @@ CASES = {
 def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
-             second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8)
+             second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
+             dword=0, sample_shift=0)
     d.update(CASES[name])
     if d["gain"] is None:
-        d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"])
+        # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
+        d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"] * (16384.0 / 49152.0 if d["dword"] else 1.0))
     return d
 
 
@@ -86,9 +96,12 @@ def make_input(d):
     if d["pulse_period"]:
         for s in range(d["pulse_period"] // 2, n - d["pulse_len"], d["pulse_period"]):
             x[s:s + d["pulse_len"]] += d["pulse_amp"] * np.exp(1j * rng.uniform(0, 6.28))
-    iq = np.empty(2 * n, np.int16)
-    iq[0::2] = np.clip(np.round(x.real), -32767, 32767)
-    iq[1::2] = np.clip(np.round(x.imag), -32767, 32767)
+    lim = 131071 if d["dword"] else 32767            # 18-bit content, or int16
+    iq = np.empty(2 * n, np.int32 if d["dword"] else np.int16)
+    iq[0::2] = np.clip(np.round(x.real), -lim, lim)
+    iq[1::2] = np.clip(np.round(x.imag), -lim, lim)
+    if d["dword"]:                                   # left-justified in 32 bits with the half-LSB bit, like expand_rawdat (csplit.c:20-73)
+        iq = (iq << 14) | 0x2000
     return iq
 
 
@@ -126,7 +139,7 @@ def lrh_config(d, iq, **kw):
         fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2 if d["second_fft"] else N1), max_batch=4,
         second_fft_enable=d["second_fft"], timf2_blockpower_block=d["blockpower_block"],
         timf2_blockpower_size=d["blockpower_size"], fft3_n=d["fft3_n"], fft3_sinpow=d["fft3_sinpow"], mix2_n=d["mix2_n"],
-        max_fft3n=d["max_fft3n"], baseband_size=4096)
+        max_fft3n=d["max_fft3n"], baseband_size=4096, timf1_dword_input=d["dword"], sample_shift=d["sample_shift"])
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -136,7 +149,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
