@@ -198,6 +198,11 @@ int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "ff
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
 int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */
 void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                         /* for device-resident producers */
+/* One read of an 18-bit .raw recording (rx_file_input, rxin.c:1643-1644): `packed_bytes` (multiple of 9) of packed
+   data, 9 bytes per four int32 components, are expanded like expand_rawdat (csplit.c:20-73: value left-justified in
+   32 bits, bit 13 set for the truncated half LSB) into the timf1 ring at byte_offset (multiple of 16, wraps).
+   Needs timf1_dword_input = 1.  The expansion runs on the device; only the packed bytes cross PCIe. */
+int lrh_timf1_write_packed18(lrh_ctx *ctx, const void *src, int byte_offset, int packed_bytes);
 
 /* ---- stages ---- */
 /* fft1_b (fft1def.h:363; fft1.c:3302, mode 7 semantics fft1.c:413-447 + fft0.c:161 + fft1.c:637) for `batch`

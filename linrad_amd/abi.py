@@ -140,6 +140,7 @@ class StageAPI:
         self._proto("set_waterfall_yfac", [vp, fp])
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
+        self._proto("timf1_write_packed18", [vp, vp, C.c_int, C.c_int])
         self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
         for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed", "make_fft3_all", "fft3_mix2"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
@@ -230,6 +231,12 @@ class StageAPI:
         iq = np.ascontiguousarray(iq, np.int32 if self.cfg.timf1_dword_input else np.int16)
         self._chk(self._f("timf1_write")(self.ctx, iq.ctypes.data_as(C.c_void_p), int(byte_offset), int(iq.nbytes)),
                   "timf1_write")
+
+    def timf1_write_packed18(self, packed, byte_offset=0):
+        """One read of an 18-bit .raw recording: packed bytes -> int32 ring (expand_rawdat, csplit.c:20-73)."""
+        packed = np.ascontiguousarray(packed, np.uint8)
+        self._chk(self._f("timf1_write_packed18")(self.ctx, packed.ctypes.data_as(C.c_void_p), int(byte_offset),
+                                                  int(packed.nbytes)), "timf1_write_packed18")
 
     # ---- stages (names = reference functions)
     def fft1_b(self, batch=1):

@@ -25,6 +25,7 @@ hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
 hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
 hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t st);
+hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -60,6 +61,7 @@ struct lrh_ctx {
   hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
   int pipeline = 1;                  // LRH_PIPELINE=0 turns the two-stream schedule off
+  unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
   std::string err;
   // device tables
@@ -250,6 +252,7 @@ void lrh_close(lrh_ctx *c)
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
+  if (c->d_pack18) hipFree(c->d_pack18);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
   for (auto &p : c->prof_pend) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -510,6 +513,25 @@ int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
   return LRH_OK;
 }
 void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
+
+int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_bytes)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !src || packed_bytes < 0 || packed_bytes % 9 || (off & 15)) return LRH_EINVAL;
+  if (!c->cfg.timf1_dword_input) return fail(c, LRH_ESTATE, "timf1_write_packed18 needs timf1_dword_input");
+  if ((long long)packed_bytes / 9 * 16 > c->cfg.timf1_bytes) return LRH_EINVAL;
+  if (!packed_bytes) return LRH_OK;
+  if ((size_t)packed_bytes > c->pack18_cap) {              // staging buffer for the packed bytes, grown on demand
+    if (c->d_pack18) hipFree(c->d_pack18);
+    c->d_pack18 = nullptr; c->pack18_cap = 0;
+    if (hipMalloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(packed18 staging)");
+    c->pack18_cap = packed_bytes;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_pack18, src, packed_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_expand18(c->d_pack18, packed_bytes / 9, c->d_timf1, (off & c->timf1_bytemask) / 16, c->cfg.timf1_bytes / 16 - 1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
+  return LRH_OK;
+}
 
 // ---------------------------------------------------------------------------------------------- fft1
 int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)

@@ -125,6 +125,31 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
 }
 
 // =====================================================================================================
+// recorded-IQ ingest: expand_rawdat (csplit.c:20-73), 18-bit packed -> left-justified int32 with the half-LSB bit
+// =====================================================================================================
+// One thread per 9-byte group: eight data bytes (four little-endian 16-bit top parts) and one byte holding the four
+// 2-bit bottom parts, first sample in the top bits.  Output: one 16-byte store into the ring.
+__global__ __launch_bounds__(256) void k_expand18(const unsigned char *packed, int ngroups, int4 *ring, int first_group, int group_mask)
+{
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const unsigned char *r = packed + (size_t)9 * g;
+  unsigned int m = r[8];
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const unsigned int n = ((m << (2 * k)) & 0xc0u) | 0x20u;                      // csplit.c:37-39 (m is an unsigned char there)
+    v[k] = (int)(((unsigned int)r[2 * k] << 16) | ((unsigned int)r[2 * k + 1] << 24) | (n << 8));
+  }
+  ring[(first_group + g) & group_mask] = make_int4(v[0], v[1], v[2], v[3]);
+}
+hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_expand18, dim3((ngroups + 255) / 256), dim3(256), 0, st, packed, ngroups, (int4 *)ring, first_group, group_mask);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
 // fft1_c power sums and slow average
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_sumsq(SumsqArgs a)

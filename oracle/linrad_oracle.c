@@ -323,6 +323,24 @@ int lro_timf1_write(lro_ctx *c, const void *src, int off, int nbytes)
   return LRH_OK;
 }
 
+/* expand_rawdat, csplit.c:20-73: 9 packed bytes -> four int32 components {0, (2 bits)|0x20, lo, hi} */
+int lro_timf1_write_packed18(lro_ctx *c, const void *src, int off, int packed_bytes)
+{
+  if (!c->cfg.timf1_dword_input || packed_bytes % 9 || (off & 15)) return LRH_EINVAL;
+  const unsigned char *r = src; unsigned char *d = (unsigned char *)c->timf1;
+  int i = off & c->timf1_bytemask;
+  for (int j = 0; j < packed_bytes; j += 9) {
+    unsigned char m = r[j + 8], n;
+    for (int k = 0; k < 4; k++) {
+      n = m & 0xc0; n |= 0x20;
+      d[i + 4 * k] = 0; d[i + 4 * k + 1] = n; d[i + 4 * k + 2] = r[j + 2 * k]; d[i + 4 * k + 3] = r[j + 2 * k + 1];
+      m <<= 2;
+    }
+    i = (i + 16) & c->timf1_bytemask;
+  }
+  return LRH_OK;
+}
+
 /* ------------------------------------------------------------------ fft1 */
 
 /* fft1_b mode 7: fft1win_dif_one (fft1.c:413-447) + bulk_of_dif (fft0.c:161) + dif_permute_one (fft1.c:637-650),
