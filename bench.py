@@ -66,6 +66,47 @@ def cpu_baseline(args, fft1_n, fft2_n):
             "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload, 1 thread, {dt:.1f} s"}
 
 
+def cpu_worker(fft1_n, fft2_n, nblk, channel):
+    """One single-thread oracle pipeline (child process of cpu_baseline_all_cores); prints its loop time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import open_oracle
+    from linrad_amd import lib as hiplib
+    cfg = chain_config(fft1_n, fft2_n, batch=min(32, nblk))
+    rx = setup_receiver(cfg, channel, open_oracle, hiplib)
+    rx.wideband_dsp(min(32, nblk), cfg.max_batch)
+    t0 = time.perf_counter()
+    rx.wideband_dsp(nblk, cfg.max_batch)
+    print(json.dumps({"seconds": time.perf_counter() - t0}))
+
+
+def cpu_baseline_all_cores(args, fft1_n, fft2_n):
+    """the same oracle on every host core.  The reference spreads one receiver over stage threads
+    (wcw.c:604-648); as its throughput on C cores cannot exceed C independent single-thread pipelines, that upper bound
+    is what is measured here: C child processes (at most 16), one channel each, started together.  None if a child fails."""
+    import subprocess
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = min(ncpu, 16)      # the reference's own topology ends near a dozen threads (6 fft1 workers + stage threads)
+    nblk = max(256, args.cpu_blocks // 8)
+    cmd = [sys.executable, os.path.abspath(__file__), "--fft1-n", str(fft1_n), "--fft2-n", str(fft2_n), "--cpu-blocks", str(nblk)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + ["--cpu-worker", str(ch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for ch in range(ncpu)]
+    times = []
+    for p_ in procs:
+        try:
+            out, _ = p_.communicate(timeout=300)
+            times.append(json.loads(out.strip().splitlines()[-1])["seconds"])
+        except Exception:  # noqa: BLE001
+            p_.kill()
+    if len(times) != ncpu:
+        return None
+    M1 = (1 << fft1_n) // 2
+    dt = max(times)
+    return {"value": round(ncpu * nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
+            "sample": f"{ncpu} processes x {nblk} fft1 blocks, one channel each, slowest {dt:.1f} s "
+                      f"(wall incl. start-up {time.perf_counter() - t0:.1f} s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +118,11 @@ def main():
     ap.add_argument("--fft2-n", type=int, default=12)
     ap.add_argument("--cpu-blocks", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:                        # child of cpu_baseline_all_cores: no GPU, no torch
+        cpu_worker(args.fft1_n, args.fft2_n, args.cpu_blocks, args.cpu_worker)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -158,9 +203,10 @@ def main():
                 "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                 "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
                 "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(args, args.fft1_n, args.fft2_n)
+        cpu_all = cpu_baseline_all_cores(args, args.fft1_n, args.fft2_n)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -178,7 +224,7 @@ def main():
                        "parallelism": f"1 RF channel per GPU x{world}"},
             "event_ms_per_step": round(ev_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
             "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4)},
-            "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "stages": stages,
             "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
                         "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},
         }
