@@ -66,6 +66,8 @@ struct lrh_ctx {
   std::string err;
   // device tables
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
+  float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
+  std::vector<float> h_mixwin, h_sin2win, h_cos2win;
   float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
   unsigned int *d_pack_cur = nullptr, *d_pack_prev = nullptr;
   int *d_wf_itab = nullptr;
@@ -245,7 +247,7 @@ void lrh_close(lrh_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1] }) if (ev) hipEventDestroy(ev);
-  void *dev[] = { c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+  void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
@@ -306,7 +308,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e = getenv("LRH_FFT2_FUSED")) c->fft2_fused = c->fft2_fused && atoi(e) != 0;
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
              cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
-             !(c->Im == 0 || c->Im == c->Mm) || cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
+             cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
              (size_t)cfg->max_batch * c->M1 + N1 > (size_t)cfg->timf2pow_size;
   if (bad) { delete c; return LRH_EINVAL; }
   c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
@@ -343,6 +345,33 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     for (int i = 0; i <= N2 / 2; i++) c->h_window2[i] = h[i];
     for (int i = N2 / 2 + 1; i < N2; i++) c->h_window2[i] = h[N2 - i];
   }
+  {                                                        // prepare_mixer, buf.c:55-111
+    const int sp = cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow, Nm = c->Nm;
+    c->h_mixwin.assign(Nm / 2 + 1, 0.f); c->h_sin2win.assign(Nm, 0.f); c->h_cos2win.assign(Nm, 0.f);
+    c->Xm = 0;
+    if (sp != 0 && sp != 2) {
+      half_window(Nm, sp, h, false);                       // make_window(3,..): inverted, fft0.c:883-891
+      c->h_mixwin[0] = 1; for (int i = 1; i <= Nm / 2; i++) c->h_mixwin[i] = 1 / h[i];
+      if (sp == 9) c->Xm = Nm / 8;
+      else if (sp == 8) c->Xm = Nm / 16;
+      else {
+        unsigned int i = c->Im / 2;
+        const float t1 = c->h_mixwin[i];
+        while (c->h_mixwin[i] < 30 * t1 && i > 0) { i--; c->Xm++; }
+        if (c->Xm > 0.75 * c->Mm) c->Xm = (int)(0.75 * c->Mm);
+        if (c->Xm > c->Im / 2) c->Xm = c->Im / 2;
+      }
+      float t1 = (float)(0.25 * PI_L / c->Xm);
+      unsigned int j = (Nm - c->Mm) / 2, k = j;
+      k += c->Xm / 2; j -= c->Xm / 2;
+      for (int i = 0; i < c->Xm; i++) {
+        c->h_cos2win[i] = (float)(c->h_mixwin[k] * pow(cos(t1), 2.0));
+        c->h_sin2win[i] = (float)(c->h_mixwin[j] * pow(sin(t1), 2.0));
+        k--; j++;
+        t1 = (float)(t1 + 0.5 * PI_L / c->Xm);
+      }
+    }
+  }
   c->h_fqwin.assign(c->Nm / 2 + 1, 0.f);
   { double e1 = 3.2, e2 = 13.0 / c->Nm; for (int i = 0; i <= c->Nm / 2; i++) { c->h_fqwin[i] = 0.5F * (float)erfc(e1); e1 -= e2; } }   // fft0.c:818-827
   default_filtercorr(c); default_yfac(c);
@@ -354,6 +383,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     for (size_t i = 0; i < itab.size(); i++) { int t = a3; if (t < 0) t = 0; if (t > N1 - 1) t = N1 - 1; itab[i] = t; a3 += a2; } }
   A(dev_alloc(c, &c->d_window1, N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
   A(dev_alloc(c, &c->d_fqwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_yfac, N1)); A(dev_alloc(c, &c->d_filtercorr, N1));
+  A(dev_alloc(c, &c->d_mixwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_sin2win, c->Nm)); A(dev_alloc(c, &c->d_cos2win, c->Nm));
   A(dev_alloc(c, &c->d_tw1, N1)); A(dev_alloc(c, &c->d_tw2, N2)); A(dev_alloc(c, &c->d_twm, c->Nm));
   const int fft2_la = cfg->fft2_n - cfg->fft2_n / 2, fft2_lb = cfg->fft2_n / 2;      // four-step split NA x NB
   std::vector<float2> tw2a, tw2b;
@@ -396,6 +426,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     hipStreamSynchronize(c->stream);
     A(upload(c, c->d_window1, win1.data(), N1)); A(upload(c, c->d_invwin1, inv1.data(), N1));
     A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
+    A(upload(c, c->d_mixwin, c->h_mixwin.data(), c->Nm / 2 + 1)); A(upload(c, c->d_sin2win, c->h_sin2win.data(), c->Nm)); A(upload(c, c->d_cos2win, c->h_cos2win.data(), c->Nm));
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
     if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
@@ -770,12 +801,14 @@ static int set_mix1_phases(lrh_ctx *c, float fq)
 // shared by fft2_mix1_fixed (mix1.c:934-993) and fft1_mix1_fixed (mix1.c:995-1042): src ring of transforms of `n2` bins
 static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi)
 {
-  const int Nm = c->Nm, overlap = c->Im != 0, half = overlap ? Nm / 2 : Nm, block2 = c->Mm;     // block in complex samples
+  const int Nm = c->Nm, overlap = c->Im != 0, half = c->Mm, block2 = c->Mm;     // block in complex samples = rotated samples per transform
   lrh_mix1_state *s = &c->ms;
   const int selected = s->mix1_selfreq >= 0;
   Mix1OutArgs o; memset(&o, 0, sizeof o);
   o.timf3 = c->d_timf3; o.mask2 = c->cfg.timf3_size / 2 - 1; o.pa_first = p->timf3_pa / 2; o.block = block2;
   o.nm = Nm; o.overlap = overlap; o.selected = selected; o.scratch = c->d_mix_scratch; o.rotate = 1;
+  o.xover = (overlap && c->Im != c->Mm) ? c->Xm : 0; o.im = c->Im; o.win = c->d_mixwin; o.sin2win = c->d_sin2win; o.cos2win = c->d_cos2win;
+  if (overlap && c->Im != c->Mm && c->Xm < 1) return fail(c, LRH_EINVAL, "mix1 window without a crossover region");
   if (selected) {
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;

@@ -124,6 +124,9 @@ struct Mix1OutArgs {
   int pa_first; int block;   // in complex samples
   int nm; int overlap; int selected;
   int rotate;                // 1: mix1 (phase rotation, mix1.c:172-186); 0: mix2 plain overlap-add (mix2.c:158-168)
+  // crossover-window mix1 (mix1.c:196-262): xover = mix1.crossover_points (> 0 selects it), im = interleave_points,
+  // win = inverted window (mode 3, nm/2+1 values), sin2win / cos2win = crossover functions (prepare_mixer, buf.c:95-109)
+  int xover, im; const float *win, *sin2win, *cos2win;
 };
 
 // ---- fft3 / mix2 (fft3.c:240-283, mix2.c:145-176) ----

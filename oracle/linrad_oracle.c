@@ -32,6 +32,7 @@ struct lro_ctx {
   float *fft1_desired;
   float *fft2_window;          /* mode 4, N2 */
   float *mix1_fqwin;           /* mode 5, Nm/2+1 */
+  float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
   float *liminfo;
   /* rings */
@@ -225,7 +226,6 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   }
   c->M1 = N1 - c->I1;
   if (cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2) { free(c); return LRH_EINVAL; }
-  if (!(c->Im == 0 || c->Im == c->Mm)) { free(c); return LRH_EINVAL; }   /* crossover-window mix1 (mix1.c:196-270): not restated yet */
   c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->fft1_sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
   c->timf2pow_mask = cfg->timf2pow_size - 1; c->timf2_mask = 4 * cfg->timf2pow_size - 1; c->fft2n_mask = cfg->max_fft2n - 1;
   c->timf3_mask = cfg->timf3_size - 1; c->timf1_bytemask = cfg->timf1_bytes - 1;
@@ -262,6 +262,32 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) lro_make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
   if (cfg->fft2_sinpow) lro_make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
   lro_make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
+  {                                                        /* prepare_mixer, buf.c:55-111 */
+    const int sp = cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow;
+    c->mix1_window = zal(4 * (c->Nm + 8)); c->mix1_sin2win = zal(4 * (c->Nm + 8)); c->mix1_cos2win = zal(4 * (c->Nm + 8));
+    c->Xm = 0;
+    if (sp != 0 && sp != 2) {
+      lro_make_window(3, c->Nm, sp, c->mix1_window);
+      if (sp == 9) c->Xm = c->Nm / 8;
+      else if (sp == 8) c->Xm = c->Nm / 16;
+      else {
+        unsigned int i = c->Im / 2;
+        float t1 = c->mix1_window[i];
+        while (c->mix1_window[i] < 30 * t1 && i > 0) { i--; c->Xm++; }
+        if (c->Xm > 0.75 * c->Mm) c->Xm = 0.75 * c->Mm;
+        if (c->Xm > c->Im / 2) c->Xm = c->Im / 2;
+      }
+      float t1 = 0.25 * PI_L / c->Xm;
+      unsigned int j = (c->Nm - c->Mm) / 2, k = j;
+      k += c->Xm / 2; j -= c->Xm / 2;
+      for (int i = 0; i < c->Xm; i++) {
+        c->mix1_cos2win[i] = c->mix1_window[k] * pow(cos(t1), 2.0);
+        c->mix1_sin2win[i] = c->mix1_window[j] * pow(sin(t1), 2.0);
+        k--; j++;
+        t1 += 0.5 * PI_L / c->Xm;
+      }
+    }
+  }
   default_filtercorr(c); default_yfac(c);
   /* blanker start state: buf.c:418-431, hires_graph.c:1157-1162 */
   c->bs.timf2_noise_floor = cfg->timf2_noise_floor;
@@ -276,7 +302,7 @@ void lro_close(lro_ctx *c)
 {
   if (!c) return;
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
-                c->fft2_window, c->mix1_fqwin, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
+                c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
                 c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
@@ -758,6 +784,48 @@ static int mix1_block(lro_ctx *c, lrh_ptrs *p, const float *zbase, int lim)
         t1 += t2;
       }
       s->mix1_phase = t1;
+    } else if (c->Im != c->Mm) {             /* other windows: crossover functions, mix1.c:196-262 (dfq = 0) */
+      const float *win = c->mix1_window, *w1t = c->mix1_sin2win, *w2t = c->mix1_cos2win;
+      int p0 = p->timf3_pa, X = c->Xm;
+      float r1 = s->mix1_old_phase;
+      float r2 = t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm;
+      int k = 2 * c->Im / 2;                 /* mm*interleave_points/2, mm = 2 */
+      k -= 2 * (X / 2);
+      int j = k / 2 + X;
+      int ia = 2 * X;
+      for (i = 0; i < ia; i += 2) {
+        float sn = sin(t1), cs = cos(t1), rs = sin(r1), rc2 = cos(r1);
+        float w1 = w1t[i >> 1], w2 = w2t[i >> 1];
+        float a1 = w2 * t3[p0], a2 = w2 * t3[p0 + 1];
+        t3[p0] = rc2 * a1 - rs * a2 + (cs * tmp[i + k] - sn * tmp[i + k + 1]) * w1;
+        t3[p0 + 1] = rc2 * a2 + rs * a1 + (cs * tmp[i + k + 1] + sn * tmp[i + k]) * w1;
+        t1 += t2; r1 += r2;
+        p0 = (p0 + 2) & c->timf3_mask;
+      }
+      int ib = c->Mm + 2 + 2 * (X / 2);
+      for (i = ia; i < ib; i += 2) {
+        float sn = sin(t1), cs = cos(t1), rw = win[j];
+        t3[p0] = (cs * tmp[i + k] - sn * tmp[i + k + 1]) * rw;
+        t3[p0 + 1] = (cs * tmp[i + k + 1] + sn * tmp[i + k]) * rw;
+        p0 = (p0 + 2) & c->timf3_mask;
+        t1 += t2; j++;
+      }
+      j--;
+      int ic = 2 * c->Mm;
+      for (i = ib; i < ic; i += 2) {
+        j--;
+        float sn = sin(t1), cs = cos(t1), rw = win[j];
+        t3[p0] = (cs * tmp[i + k] - sn * tmp[i + k + 1]) * rw;
+        t3[p0 + 1] = (cs * tmp[i + k + 1] + sn * tmp[i + k]) * rw;
+        t1 += t2;
+        p0 = (p0 + 2) & c->timf3_mask;
+      }
+      s->mix1_phase = t1;
+      int id = 2 * (X + c->Mm);
+      for (i = ic; i < id; i += 2) {
+        t3[p0] = tmp[i + k]; t3[p0 + 1] = tmp[i + k + 1];
+        p0 = (p0 + 2) & c->timf3_mask;
+      }
     } else {                                 /* sin^2, 50 % overlap: mix1.c:161-195 */
       float r1 = s->mix1_old_phase;
       float r2 = t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm;

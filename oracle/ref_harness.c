@@ -50,6 +50,7 @@ void lir_sleep(int us) { (void)us; }
 
 /* prototypes of reference functions not in the headers we include */
 void fft1_b(int timf1p_ref, float *out, float *tmp, int gpu_handle_number);
+void prepare_mixer(MIXER_VARIABLES *m, int nn);
 void fft1_c(void);
 void make_timf2(void);
 void first_noise_blanker(void);
@@ -311,9 +312,8 @@ int main(int argc, char **argv)
   mix1.sin2win = zalloc(sizeof(float) * (mix1.size + 32));
   mix1_fqwin = zalloc(sizeof(float) * (mix1.size + 32));
   make_window(5, mix1.size, 4, mix1_fqwin);
-  if (sinpow2 != 0 && sinpow2 != 2) make_window(3, mix1.size, sinpow2, mix1.window);
-  init_fft(0, mix1.n, mix1.size, mix1.table, mix1.permute);
-  mix1.crossover_points = 0;
+  rx_mode = 0;
+  prepare_mixer(&mix1, second ? SECOND_FFT_SINPOW : FIRST_FFT_SINPOW);   /* the reference's own, buf.c:55-111 */
   fftn_tmp = zalloc(sizeof(float) * (4 * mix1.size + 64));
   timf3_block = 2 * mix1.new_points;
   timf3_size = 16 * 2 * mix1.size; timf3_mask = timf3_size - 1;

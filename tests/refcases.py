@@ -57,6 +57,11 @@ CASES = {
     "n9_n11_shift": dict(n1=9, n2=11, mixred=5, nblk=40, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
                          fq=900.0, wf_avgnum=1, wf_mode=1, seed=19, timf2pow_log2=14, sumsq_blocks=4,
                          strong=[], weak=[(150.5, 45.0), (60.0, 120.0)], pulse_period=1499, lim_halfwidth=3, sample_shift=2),
+    # fft2 window sin^3: fft2 interleave from the formula, mix1 joins its blocks with crossover windows (mix1.c:196-262)
+    "n10_n12_xover": dict(n1=10, n2=12, mixred=5, nblk=64, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                          fq=2200.3, wf_avgnum=2, wf_mode=1, seed=21, timf2pow_log2=15, sumsq_blocks=8, sinpow2=3,
+                          strong=[(-300.25, 9000.0)], weak=[(38.6, 80.0), (37.0, 60.0), (411.3, 25.0)],
+                          pulse_period=1999, lim_halfwidth=3),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
