@@ -248,6 +248,10 @@ int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                 
 /* same span, device-to-device into a caller-owned device buffer (e.g. the RCCL exchange buffer of the
    cross-channel power sum, fft1.c:4138); synchronous on the context stream */
 int lrh_export_device(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);
+/* Same copy without the host-side wait: it is ordered on the context's stream, whose handle (a hipStream_t) lets the
+   caller chain its own device work -- e.g. an RCCL all-reduce of the exported block -- with stream/event waits only. */
+int lrh_export_device_async(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);
+void *lrh_stream(lrh_ctx *ctx);
 int lrh_sync(lrh_ctx *ctx);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */

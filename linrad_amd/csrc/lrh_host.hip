@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 #include <chrono>
@@ -95,7 +96,7 @@ struct lrh_ctx {
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool prof = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
   std::vector<hipEvent_t> ev_pool;
-  double host_ms_phases = 0, host_ms_dsp = 0; long host_n_phases = 0, host_n_dsp = 0;   // host CPU time, lrh_profile_get("host:...")
+  double host_ms_phases = 0, host_ms_dsp = 0, host_cpu_ms_dsp = 0, host_ms_wait = 0; long host_n_phases = 0, host_n_dsp = 0;   // host CPU time, lrh_profile_get("host:...")
 };
 
 static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -317,7 +318,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
-  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
   c->cur = c->stream;
   for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1] }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) c->pipeline = atoi(e2);
@@ -812,7 +813,8 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
   if (selected) {
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
-    HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
+    { const auto w0 = std::chrono::steady_clock::now(); HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
+      c->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); }
     const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
     float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
     int point = 0;
@@ -980,8 +982,10 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
-  struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                     ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++; } } host_timer{c};
+  struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double cpu0 = thread_cpu_ms();
+                     static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+                     ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;
+                                    c->host_cpu_ms_dsp += thread_cpu_ms() - cpu0; } } host_timer{c};
   int rc;
   const bool piped = c->pipeline && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
   if (!piped) {
@@ -1052,10 +1056,12 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 }
 
 // ---------------------------------------------------------------------------------------------- outputs
-static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind);
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait = true);
+int lrh_export_device_async(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice, false); }
+void *lrh_stream(lrh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lrh_export(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost); }
 int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice); }
-static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind)
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait)
 {
   if (!c || !dst) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
@@ -1095,7 +1101,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
   }
   if (off + cnt > total) return LRH_EINVAL;
   HIPCHK(c, hipMemcpyAsync(dst, (const char *)src + off * esz, cnt * esz, kind, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
 
@@ -1121,6 +1127,8 @@ int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *laun
 {
   if (!c || !kernel) return LRH_EINVAL;
   if (!strcmp(kernel, "host:mix1_phases")) { if (total_ms) *total_ms = c->host_ms_phases; if (launches) *launches = c->host_n_phases; return LRH_OK; }
+  if (!strcmp(kernel, "host:staging_wait")) { if (total_ms) *total_ms = c->host_ms_wait; if (launches) *launches = c->host_n_dsp; return LRH_OK; }
+  if (!strcmp(kernel, "host:wideband_dsp_cpu")) { if (total_ms) *total_ms = c->host_cpu_ms_dsp; if (launches) *launches = c->host_n_dsp; return LRH_OK; }
   if (!strcmp(kernel, "host:wideband_dsp")) { if (total_ms) *total_ms = c->host_ms_dsp; if (launches) *launches = c->host_n_dsp; return LRH_OK; }
   prof_collect(c);
   auto it = c->prof_tot.find(kernel);

@@ -51,6 +51,17 @@ class HipReceiver(StageAPI):
         self.lib.lrh_export_device.restype = C.c_int
         self._chk(self.lib.lrh_export_device(self.ctx, ring, C.c_void_p(dst_ptr), offset, count), "export_device")
 
+    def export_device_async(self, ring, dst_ptr, offset, count):
+        """Device-to-device copy ordered on the context's stream, no host wait (pair it with stream_handle())."""
+        self.lib.lrh_export_device_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
+        self.lib.lrh_export_device_async.restype = C.c_int
+        self._chk(self.lib.lrh_export_device_async(self.ctx, ring, C.c_void_p(dst_ptr), offset, count), "export_device_async")
+
+    def stream_handle(self):
+        """hipStream_t of the context as an integer (torch.cuda.ExternalStream takes it)."""
+        self.lib.lrh_stream.argtypes, self.lib.lrh_stream.restype = [C.c_void_p], C.c_void_p
+        return int(self.lib.lrh_stream(self.ctx) or 0)
+
     def sync(self):
         self._chk(self.lib.lrh_sync(self.ctx), "sync")
 
