@@ -38,11 +38,17 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   // change between transforms stays on chip (twiddles in LDS) or is fetched ahead of the stores (window
   // values, filter correction): the only loads that follow a transform's stores are the next prefetch, which is
   // not needed for a whole transform, so no wait ever covers a freshly issued store (vmcnt retires in order).
+  // diagnostics, compiled in with -DLRH_STAMP_BUILD only (the counter costs registers the N = 16384 kernel does not have):
+  // one lane of two workgroups writes the shader clock at the phase boundaries; run with LRH_STAMP=1
+#ifdef LRH_STAMP_BUILD
   int nstamp = 0;
-  auto stamp = [&]() {                                    // diagnostics only: one lane of two workgroups writes the shader clock
+  auto stamp = [&]() {
     if (a.stamps && tid0 == 0 && (blockIdx.x == 0 || blockIdx.x == 128) && nstamp < LRH_STAMPS_PER_WG)
       a.stamps[(blockIdx.x ? LRH_STAMPS_PER_WG : 0) + nstamp++] = __builtin_amdgcn_s_memtime();
   };
+#else
+  auto stamp = []() {};
+#endif
   stamp();
   Fft::init(lds, a.tw, tid0);
   float win[P];
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     // are issued BEFORE the stores, so that no later wait has to cover the stores; the filter correction already
     // before the last pass, whose butterflies hide its latency.
     float2 fc[P];
-    constexpr int EARLY = P / 2;                          // as many as the register file holds next to the last pass
+    constexpr int EARLY = (DW || SKEW) ? 0 : P / 2;       // as many as the register file holds next to the last pass
     Fft::run(x, lds, tid, [&]() {
 #pragma unroll
       for (int e = 0; e < EARLY; e++) fc[e] = a.filtercorr[out_index(tid, e)];
