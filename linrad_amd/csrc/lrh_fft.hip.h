@@ -287,7 +287,7 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
 // that drain is fully exposed.  Here the per-pass tables live in LDS behind the exchange buffer (filled once per
 // workgroup).  The last pass of N >= 8192 (k = butterfly index, a full table would not fit) reads one cell per
 // thread, w^tid, squares/cubes it and applies compile-time 16th roots of unity for the butterflies tid + m T.
-// All LDS addresses are one per-thread base plus constants.
+// All LDS addresses are one per-thread base plus constants.  run() may be called again without a barrier in between.
 //   table of pass with completed length p, radix R:  cell[e*p + k] = w^(mult(e) k N/(pR)),  k < p
 //   mult = {1,2,3,4,8,12} (R=16), {1,2,3,4} (R=8), {1..R-1} otherwise -- the factors pass() combines.
 template <int LOG2N, int P, int DIR> struct BlockFftL {
@@ -417,6 +417,11 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
           const int c = m * T + s * (N / R2);
           x[m * R2 + s] = rd[c + c / 16];
         }
+      // The barrier that protects the exchange buffer for the NEXT transform sits here, right behind the reads of the
+      // last exchange, where the waves were aligned a moment ago by the write->read barrier: the caller needs no
+      // barrier at the end of its loop, where the waves arrive spread by a whole pass of VALU contention
+      // (measured 6-7k of 27k cycles per transform in k_fft1).
+      if constexpr (PASS + 2 == NPASS) __syncthreads();
       pass<PASS + 1>(x, lds, tid, before_last);
     }
   }

@@ -124,9 +124,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
       if (a.direction < 0) v = make_float2(v.y, v.x);   // fft1.c:3660-3679
       out[out_index(tid, e)] = cmul(v, fc[e]);
     }
-    stamp();
-    __syncthreads();                                     // LDS is reused by the next transform
-    stamp();
+    stamp();                                             // no barrier: BlockFftL protects its buffer itself
   }
 }
 
@@ -342,8 +340,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
     __builtin_amdgcn_sched_barrier(0);                   // keep the loads below out of the transform (register file)
     issue(b, 1, tid);
     __builtin_amdgcn_sched_barrier(0);
-    timf2_store<LOG2N, MODE, 0>(a, x, pa, tid);
-    __syncthreads();                                     // LDS is reused by the next transform
+    timf2_store<LOG2N, MODE, 0>(a, x, pa, tid);         // no barrier: BlockFftL protects its buffer itself
     combine(x, tid);
     Fft::run(x, lds, tid);
     pin(x);
@@ -354,7 +351,6 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
     issue(a.xcd ? xcd_order(bn, a.batch) : bn, 0, tid);
     __builtin_amdgcn_sched_barrier(0);
     timf2_store<LOG2N, MODE, 1>(a, x, pa, tid);
-    __syncthreads();
   }
 }
 
@@ -731,7 +727,6 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft2_min_waves(LOG2N)) void k_f
         if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
         else pw[k] = p2;
       }
-    __syncthreads();                                     // LDS is reused by the next transform
   }
   if constexpr (FUSED) {
 #pragma unroll
