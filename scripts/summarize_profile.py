@@ -72,7 +72,7 @@ if len(sys.argv) > 2:
                                       traffic_bytes_per_launch=int(2 * v["FETCH_SIZE_KiB"] * 1024 + v["WRITE_SIZE_KiB"] * 1024))
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 10 --warmup 3 --no-cpu "
                      "(scripts/profile_round.sh)",
-           "workload": {"fft1_n": 14, "fft2_n": 12, "batch": 1024},
+           "workload": {"fft1_n": 14, "fft2_n": 12, "batch": int(os.environ.get("LRH_PROFILE_BATCH", "4096"))},
            "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced streaming "
                          "read, MI355X_MICROARCH.md HBM section; k_sumsq confirms it: ~67 MB reported for 134 MB read)",
            "kernels": kernels}
