@@ -620,12 +620,16 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
     SlowsumArgs ua;
     ua.sumsq = c->d_sumsq; ua.slowsum = c->d_slowsum; ua.n = N; ua.bufsize = c->cfg.fft1_sumsq_bufsize; ua.avg2 = c->cfg.fft_avg2num;
     ua.nupd = nupd; ua.pa0 = p->fft1_sumsq_pa; ua.recalc0 = p->fft1_sumsq_recalc; ua.step = c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
-    ProfScope ps(c, "slowsum");
-    HIPCHK(c, launch_slowsum(ua, c->cur));
+    // one full cycle of the rolling refresh takes last/step (+ wrap) updates: start the kernel's search that far back
+    const int cycle = last / (ua.step > 0 ? ua.step : 1) + 3;
+    ua.e0 = nupd > cycle ? nupd - cycle : 0; ua.recalc_e0 = ua.recalc0;
     for (int e = 0; e < nupd; e++) {                                     // same recursion as the kernel (fft1.c:4568-4573)
+      if (e == ua.e0) ua.recalc_e0 = p->fft1_sumsq_recalc;
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
       p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
     }
+    ProfScope ps(c, "slowsum");
+    HIPCHK(c, launch_slowsum(ua, c->cur));
     if (c->cfg.second_fft_enable) p->fft1_liminfo_cnt += nupd;          // fft1.c:4515-4518
     p->fft1_sumsq_pa = (p->fft1_sumsq_pa + nupd * N) & c->sumsq_mask;
   }

@@ -184,8 +184,10 @@ __global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
   // Every update recomputes a rolling window of bins from scratch (fft1.c:4567-4573), which overwrites the running
   // value there.  The value after the batch therefore depends only on the bin's last refresh and the sliding
   // updates after it: find that update first (integer bookkeeping only), then replay from it.
-  int e_start = 0, recalc = a.recalc0, recalc_at_start = a.recalc0; bool refreshed = false;
-  for (int e = 0; e < a.nupd; e++) {
+  // The host hands over a start e0 at least one full refresh cycle before the end when the call is long enough: every
+  // bin is refreshed inside it, so what happened before e0 cannot matter (e0 = 0: short call, whole history replayed).
+  int e_start = 0, recalc = a.recalc_e0, recalc_at_start = a.recalc0; bool refreshed = false;
+  for (int e = a.e0; e < a.nupd; e++) {
     const int before = recalc;
     if (recalc == last) recalc = 0;
     const int ia = recalc;
@@ -194,25 +196,31 @@ __global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
   }
   float slow = refreshed ? 0.f : a.slowsum[i];
   recalc = recalc_at_start;
-  for (int e = e_start; e < a.nupd; e++) {
+  int e = e_start;
+  if (refreshed) {                                     // the bin's last refresh: from scratch over the window (wide_graph.c:1016-1031)
     const int pa = (a.pa0 + e * a.n) & mask;
-    if (recalc == last) recalc = 0;
-    const int ia = recalc;
-    recalc += a.step; if (recalc > last) recalc = last;
-    if (i >= ia && i <= recalc) {                      // from scratch over the window (wide_graph.c:1016-1031)
-      int p0 = (pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
-      slow = a.sumsq[p0 + i];
-      p0 = (p0 + a.n) & mask;
-      for (int m = 1; m < a.avg2; m++) {
-        slow += a.sumsq[p0 + i];
-        if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL;
-        p0 = (p0 + a.n) & mask;
-      }
-    } else {                                           // sliding update (fft1.c:4574-4583)
-      const int pb = (pa - a.avg2 * a.n + a.bufsize) & mask;
-      slow += a.sumsq[pa + i] - a.sumsq[pb + i];
+    int p0 = (pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
+    slow = a.sumsq[p0 + i];
+    p0 = (p0 + a.n) & mask;
+    for (int m = 1; m < a.avg2; m++) {
+      slow += a.sumsq[p0 + i];
       if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL;
+      p0 = (p0 + a.n) & mask;
     }
+    e++;
+  }
+  // everything after it is the sliding update (fft1.c:4574-4583): same additions in the same order, but the loads do
+  // not depend on the running value, so eight updates' worth are in flight at a time
+  for (; e < a.nupd; e += 8) {
+    float va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int pa = (a.pa0 + (e + u) * a.n) & mask, pb = (pa - a.avg2 * a.n + a.bufsize) & mask;
+      va[u] = (e + u < a.nupd) ? a.sumsq[pa + i] : 0.f; vb[u] = (e + u < a.nupd) ? a.sumsq[pb + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (e + u < a.nupd) { slow += va[u] - vb[u]; if (slow < LRH_FFT1_SMALL) slow = LRH_FFT1_SMALL; }
   }
   a.slowsum[i] = slow;
 }

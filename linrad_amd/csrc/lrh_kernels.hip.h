@@ -40,6 +40,7 @@ struct SumsqArgs {
 struct SlowsumArgs {
   const float *sumsq; float *slowsum; int n; int bufsize; int avg2;
   int nupd; int pa0; int recalc0; int step;
+  int e0, recalc_e0;        // the search for a bin's last refresh starts at update e0 (recalc pointer there), see k_slowsum
 };
 
 // ---- make_timf2 ----

@@ -66,6 +66,18 @@ def test_hip_batched_matches_oracle(name, batch):
     assert np.abs(a["wf_lines"].astype(int) - b["wf_lines"].astype(int)).max() <= 2
 
 
+def test_hip_long_call_matches_oracle():
+    """One call spanning many averaging periods (32 fft1 blocks, avg1num 3: ten slow-average updates per call, more than
+    a full cycle of the rolling refresh): k_slowsum then starts its search one refresh cycle before the end."""
+    g = load_golden("n8_n10")
+    kw = dict(max_batch=32, max_fft1n=64, fft1_sumsq_bufsize=32 * 256)
+    a = run_case(_open_hip, "n8_n10", golden=g, batch=32, **kw)
+    b = run_case(_open_oracle, "n8_n10", golden=g, batch=32, **kw)
+    assert np.array_equal(a["itrace"][:, [0, 1, 2, 3, 6, 7, 8, 9, 10]], b["itrace"][:, [0, 1, 2, 3, 6, 7, 8, 9, 10]])
+    for key in ("fft1_sumsq", "fft1_slowsum", "fft1_float", "fft2_float"):
+        assert relerr(a[key], b[key]) < 1e-5, key
+
+
 def test_hip_fft3_mix2_matches_oracle():
     """fft3 ring against the reference golden (in test_hip_matches_reference_golden) and the mix2 filter/decimate output
     baseb_raw against the oracle restatement (the reference's fft3_mix2 cannot run head-less: parity unpinned there)."""
