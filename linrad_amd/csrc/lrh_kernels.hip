@@ -372,7 +372,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
 // of the call), so every decision equals the serial one.  Decisions go to a bit mask; k_blank_apply zeroes the
 // data afterwards (the scan itself only reads), which also keeps lanes from racing on guard samples.
 #define LRH_BLN_CHUNK 64
-#define LRH_BLN_BACK (4 * LRH_BLN_CHUNK)
+#define LRH_BLN_BACK 256
 
 __device__ __forceinline__ void bln_setbit(unsigned int *bits, int p) { atomicOr(&bits[p >> 5], 1u << (p & 31)); }
 
@@ -390,36 +390,22 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
   return 0;
 }
 
-__device__ __forceinline__ int bln_lds(int idx) { return idx + (idx >> 6); }   // lane stride 65 floats: conflict-free
-
 #define LRH_BLN_TILE (256 * LRH_BLN_CHUNK)
 #define LRH_BLN_WORDS (LRH_BLN_TILE / 32 + 2)
 
 __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 {
-  // the workgroup's 256 chunks plus the look-back halo, staged once with coalesced loads
-  constexpr int TILE = LRH_BLN_TILE + LRH_BLN_BACK;
-  __shared__ float tile[TILE + TILE / 64 + 4];
+  // A lane owns 64 consecutive samples and reads them straight from the power ring as 16-byte loads (its chunk starts
+  // on a 16-byte boundary: pbeg is a multiple of 4, blank1.c:706, and chunk c covers sequence positions 64c .. 64c+63,
+  // position 0 not being a sample).  No LDS staging: the kernel keeps 2 KiB of decision words in LDS only, so the
+  // chip holds every wave of a 4096-block call at once and the loads of one wave hide behind the others.
   __shared__ unsigned int wbits[LRH_BLN_WORDS];         // decisions for the ring words this tile overlaps
   __shared__ int wg_cnt;
   __shared__ double wg_sum[4];
   if (threadIdx.x == 0) wg_cnt = 0;
   for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) wbits[i] = 0;
-  const int qt = blockIdx.x * LRH_BLN_TILE + 1;          // first sequence position owned by this tile
-  const int q0 = qt - LRH_BLN_BACK;                      // sequence position of tile[0]
-  static_assert(TILE % (256 * 13) == 0, "staging loop is unrolled 13 loads deep");
-  for (int i0 = 0; i0 < TILE; i0 += 256 * 13) {          // 13 independent loads in flight per thread
-    float v[13];
-#pragma unroll
-    for (int u = 0; u < 13; u++) {
-      const int q = q0 + i0 + u * 256 + threadIdx.x;
-      v[u] = (q >= 1 && q <= a.total) ? a.pwr[(a.pbeg + q) & a.mask] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 13; u++) tile[bln_lds(i0 + u * 256 + threadIdx.x)] = v[u];
-  }
   __syncthreads();
-  if (a.debug == 1) return;
+  const int qt = blockIdx.x * LRH_BLN_TILE;              // first sequence position of this workgroup's tile
   // ring word that holds the tile's first position; bits of positions inside [w0*32, (w0+WORDS)*32) go to LDS
   const int w0 = ((a.pbeg + qt) & a.mask) >> 5;
   const int nwords_ring = (a.mask + 1) >> 5;
@@ -429,17 +415,19 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
     if (w < LRH_BLN_WORDS) atomicOr(&wbits[w], 1u << (p & 31));
     else atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31));  // guard reaching into a neighbour tile (rare)
   };
+  auto sample = [&](int q) -> float { return a.pwr[(a.pbeg + q) & a.mask]; };   // 1 <= q <= total
   const int c = blockIdx.x * 256 + threadIdx.x;
-  const int cs = c * LRH_BLN_CHUNK + 1;
-  const int ce = min(cs + LRH_BLN_CHUNK - 1, a.total);
+  const int cb = c * LRH_BLN_CHUNK;
+  const int cs = max(cb, 1);
+  const int ce = min(cb + LRH_BLN_CHUNK - 1, a.total);
   const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
   const int G = max(a.clr2, 1);
   int s = 1;
-  bool live = cs <= a.total;
+  bool live = cs <= ce;
   if (live) {
     int run = 0, steps = 0, q = cs - 1; bool found = false;
     while (q >= 1) {
-      const float v = tile[bln_lds(q - q0)];
+      const float v = sample(q);
       if (v > nfl) run = 0; else if (++run >= G) { found = true; break; }
       q--;
       if (++steps >= LRH_BLN_BACK) break;
@@ -450,7 +438,6 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0;
   float pulmax = 0;
   double s4 = 0;                                         // every-4th-sample power of the chunk before clearing
-  for (int q = (cs + 3) & ~3; q <= ce; q += 4) s4 += (double)tile[bln_lds(q - q0)];   // also for lanes the slow path redoes
   auto step = [&](int q, float v) {
     if (v > nfl && q >= erase_end) {
       if (ifirst == 0) pk = q;
@@ -472,14 +459,21 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
       }
     }
   };
-  if (live) {
-    for (int q = s; q < cs; q++) step(q, tile[bln_lds(q - q0)]);        // replay from the clean point (usually empty)
-    for (int qb = cs; qb <= ce; qb += 16) {                              // own chunk, 16 LDS reads in flight
-      float v[16];
+  if (live) for (int q = s; q < cs; q++) step(q, sample(q));            // replay from the clean point (usually empty)
+  const float4 *ring4 = reinterpret_cast<const float4 *>(a.pwr);
+#pragma unroll 1
+  for (int g = 0; g < LRH_BLN_CHUNK; g += 16) {                          // own chunk, four 16-byte loads in flight
+    float4 t[4];
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = tile[bln_lds(qb + u - q0)];
+    for (int u = 0; u < 4; u++) t[u] = ring4[((a.pbeg + cb + g + 4 * u) & a.mask) >> 2];
+    const float v[16] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w,
+                         t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, t[3].z, t[3].w};
 #pragma unroll
-      for (int u = 0; u < 16; u++) if (qb + u <= ce) step(qb + u, v[u]);
+    for (int u = 0; u < 16; u++) {
+      const int q = cb + g + u;
+      const bool mine = q >= cs && q <= ce;
+      if ((u & 3) == 0 && mine) s4 += (double)v[u];                      // also for lanes the slow path redoes
+      if (live && mine) step(q, v[u]);
     }
   }
   // one global atomic per workgroup for the count; chunk sums reduced in a fixed order
@@ -1254,7 +1248,7 @@ hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
 hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 {
   BlankArgs a = a0;
-  const int ntiles = (a.total + LRH_BLN_TILE - 1) / LRH_BLN_TILE;
+  const int ntiles = (a.total + LRH_BLN_TILE) / LRH_BLN_TILE;     // sequence positions 0 .. total
   const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
   const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
   if (a.mode != 0) {
