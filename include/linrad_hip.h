@@ -191,6 +191,10 @@ void lrh_ptrs_init(const lrh_ctx *ctx, lrh_ptrs *p);                    /* zero 
 int lrh_set_filtercorr(lrh_ctx *ctx, const float *fft1_filtercorr /* 2*N1, NULL: uncalibrated default
                                                                      of clear_fft1_filtercorr, fft1.c:4673-4724 */);
 int lrh_set_liminfo(lrh_ctx *ctx, const float *liminfo /* N1 floats, 0 = weak (timf2.c:50) */);
+/* I/Q mirror-image calibration, fft1_calibrate_flag & CALIQ (fft1.c:3598-3658): fft1_foldcorr, N1 complex floats in
+   the transform's bin order; every bin is orthogonalised against its mirror image before the filter correction.
+   NULL switches it off (the default: uncalibrated). */
+int lrh_set_foldcorr(lrh_ctx *ctx, const float *fft1_foldcorr);
 int lrh_set_waterfall_yfac(lrh_ctx *ctx, const float *wg_waterf_yfac /* N1 floats, NULL: make_wg_yfac default */);
 int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "fft1_window","fft2_window",
                                                                      "mix1_fqwin","fft1_filtercorr","wg_waterf_yfac" */

@@ -137,6 +137,7 @@ class StageAPI:
         self._proto("get_derived", [vp, ip, ip, ip, ip, ip])
         self._proto("set_filtercorr", [vp, fp])
         self._proto("set_liminfo", [vp, fp])
+        self._proto("set_foldcorr", [vp, fp])
         self._proto("set_waterfall_yfac", [vp, fp])
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
@@ -205,6 +206,15 @@ class StageAPI:
             fc = np.ascontiguousarray(fc, np.float32)
             assert fc.size == 2 * self.N1
             self._chk(self._f("set_filtercorr")(self.ctx, self._fptr(fc)), "set_filtercorr")
+
+    def set_foldcorr(self, foldcorr):
+        """fft1_foldcorr (N1 complex as 2*N1 floats) or None: I/Q mirror-image calibration (fft1.c:3598-3658)."""
+        if foldcorr is None:
+            self._chk(self._f("set_foldcorr")(self.ctx, None), "set_foldcorr")
+        else:
+            t = np.ascontiguousarray(foldcorr, np.float32)
+            assert t.size == 2 * self.N1
+            self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
 
     def set_liminfo(self, lim):
         lim = np.ascontiguousarray(lim, np.float32)

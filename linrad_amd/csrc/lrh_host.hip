@@ -26,6 +26,7 @@ hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
 hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st);
 hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t st);
+hipError_t launch_foldcorr(const FoldcorrArgs &a, int batch, hipStream_t st);
 hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
@@ -63,6 +64,7 @@ struct lrh_ctx {
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
   int pipeline = 1;                  // LRH_PIPELINE=0 turns the two-stream schedule off
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
+  float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
   std::string err;
   // device tables
@@ -256,6 +258,8 @@ void lrh_close(lrh_ctx *c)
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->d_pack18) hipFree(c->d_pack18);
+  if (c->d_foldcorr) hipFree(c->d_foldcorr);
+  if (c->d_unitcorr) hipFree(c->d_unitcorr);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
   for (auto &p : c->prof_pend) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -582,6 +586,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
+  if (c->d_foldcorr) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr does the rest
   a.stamps = nullptr;
   if (getenv("LRH_STAMP")) {                              // diagnostics: dump the phase stamps of this launch to stderr
     static unsigned long long *d_st = nullptr;
@@ -600,6 +605,29 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   }
   ProfScope ps(c, "fft1");
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+  if (c->d_foldcorr) {
+    FoldcorrArgs f;
+    f.spec = c->d_fft1; f.first_nb = a.first_nb; f.nb_mask = a.nb_mask; f.n = c->N1;
+    f.foldcorr = c->d_foldcorr; f.filtercorr = c->d_filtercorr; f.direction = c->cfg.fft1_direction;
+    HIPCHK(c, launch_foldcorr(f, batch, c->cur));
+  }
+  return LRH_OK;
+}
+
+int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
+{
+  if (!c) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  if (!fc) { if (c->d_foldcorr) hipFree(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
+  const size_t bytes = sizeof(float2) * c->N1;
+  if (!c->d_foldcorr && hipMalloc((void **)&c->d_foldcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(foldcorr)");
+  if (!c->d_unitcorr) {
+    if (hipMalloc((void **)&c->d_unitcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(unit filter table)");
+    std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
+    HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), bytes, hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipMemcpy(c->d_foldcorr, fc, bytes, hipMemcpyHostToDevice));
   return LRH_OK;
 }
 

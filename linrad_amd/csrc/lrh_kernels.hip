@@ -154,6 +154,45 @@ hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring,
 }
 
 // =====================================================================================================
+// I/Q mirror-image cancellation (CALIQ, fft1.c:3598-3658) followed by the filter correction of fft1_c
+// =====================================================================================================
+// Runs only with a calibration table: k_fft1 then stores the bare transform (unit filter table, direction +1) and
+// this pass orthogonalises each bin ib against its mirror N - ib, applies the direction flip of the reference's
+// combined branch and the filter correction.  One thread per mirror pair; thread 0 takes bins 0 and N/2.
+__global__ __launch_bounds__(256) void k_foldcorr(FoldcorrArgs a)
+{
+  const int ia = blockIdx.x * 256 + threadIdx.x;
+  if (ia >= a.n / 2) return;
+  float2 *out = a.spec + (size_t)((a.first_nb + blockIdx.y) & a.nb_mask) * a.n;
+  if (ia == 0) {                                          // bins 0 (pc) and N/2: no mirror partner (m = 1)
+    float2 z0 = out[0], zh = out[a.n / 2];
+    if (a.direction < 0) { z0 = make_float2(z0.y, z0.x); zh = make_float2(zh.y, zh.x); }   // fft1.c:3648-3653
+    out[0] = cmulc(z0, a.filtercorr[0]); out[a.n / 2] = cmulc(zh, a.filtercorr[a.n / 2]);
+    return;
+  }
+  const int ib = ia, ic = a.n - ia;
+  const float2 zb = out[ib], zc = out[ic], fa = a.foldcorr[ia], fcc = a.foldcorr[ic];
+  float2 nb, nc;
+  if (a.direction > 0) {                                  // fft1.c:3611-3627
+    const float t1 = zb.x * fa.x - zb.y * fa.y, t2 = zb.x * fa.y + zb.y * fa.x;
+    nb = make_float2(zb.x - (zc.x * fcc.x + zc.y * fcc.y), zb.y - (zc.x * fcc.y - zc.y * fcc.x));
+    nc = make_float2(zc.x - t1, zc.y + t2);
+  } else {                                                // fft1.c:3629-3647
+    const float t1 = zc.x - zb.x * fa.x + zb.y * fa.y;
+    const float t2 = zc.y + zb.x * fa.y + zb.y * fa.x;
+    const float t3 = zb.x - zc.x * fcc.x - zc.y * fcc.y;
+    const float t4 = zb.y - zc.x * fcc.y + zc.y * fcc.x;
+    nb = make_float2(t2, t1); nc = make_float2(t4, t3);
+  }
+  out[ib] = cmulc(nb, a.filtercorr[ib]); out[ic] = cmulc(nc, a.filtercorr[ic]);
+}
+hipError_t launch_foldcorr(const FoldcorrArgs &a, int batch, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_foldcorr, dim3((a.n / 2 + 255) / 256, batch), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
 // fft1_c power sums and slow average
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_sumsq(SumsqArgs a)

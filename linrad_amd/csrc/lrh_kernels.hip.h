@@ -30,6 +30,9 @@ struct Fft1Args {
 };
 #define LRH_STAMPS_PER_WG 64
 
+// ---- I/Q mirror-image cancellation + filter correction (fft1.c:3598-3658, 4119-4127) ----
+struct FoldcorrArgs { float2 *spec; int first_nb, nb_mask; int n; const float2 *foldcorr, *filtercorr; int direction; };
+
 // ---- fft1_c power sums ----
 // Averaging groups are derived in-kernel: group g covers transforms [g*avg - c0, ...) of the batch (the first one
 // continues a group started by an earlier call when c0 > 0) and lands in sumsq block (pa0 + g*n) & mask.

@@ -32,6 +32,7 @@ struct lro_ctx {
   float *fft1_desired;
   float *fft2_window;          /* mode 4, N2 */
   float *mix1_fqwin;           /* mode 5, Nm/2+1 */
+  float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
   float *liminfo;
@@ -304,7 +305,7 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw };
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -325,6 +326,13 @@ int lro_get_derived(const lro_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t
 
 int lro_set_filtercorr(lro_ctx *c, const float *fc) { if (fc) memcpy(c->fft1_filtercorr, fc, 8 * c->N1); else default_filtercorr(c); return LRH_OK; }
 int lro_set_liminfo(lro_ctx *c, const float *l) { memcpy(c->liminfo, l, 4 * c->N1); return LRH_OK; }
+int lro_set_foldcorr(lro_ctx *c, const float *foldcorr)
+{
+  if (!foldcorr) { free(c->fft1_foldcorr); c->fft1_foldcorr = NULL; return LRH_OK; }
+  if (!c->fft1_foldcorr) c->fft1_foldcorr = malloc(sizeof(float) * 2 * c->N1);
+  memcpy(c->fft1_foldcorr, foldcorr, sizeof(float) * 2 * c->N1);
+  return LRH_OK;
+}
 int lro_set_waterfall_yfac(lro_ctx *c, const float *y) { if (y) memcpy(c->wg_waterf_yfac, y, 4 * c->N1); else default_yfac(c); return LRH_OK; }
 
 int lro_get_table(lro_ctx *c, const char *name, float *dst, int count)
@@ -397,7 +405,30 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
     unsigned k = (bitrev(i, n) + nn) & (N - 1);
     out[2 * k] = z[2 * i]; out[2 * k + 1] = z[2 * i + 1];
   }
-  if (c->cfg.fft1_direction < 0) {              /* fft1.c:3660-3679 with fft1_first_sym_point = 0 */
+  if (c->fft1_foldcorr) {                       /* I/Q mirror-image cancellation, CALIQ (fft1.c:3607-3658), m = 1, pc = 0 */
+    const float *fc = c->fft1_foldcorr;
+    int ib = 1, ic = N - 1, ia;
+    if (c->cfg.fft1_direction > 0) {
+      for (ia = 1; ia < nn; ia++, ib++, ic--) {
+        float t1 = out[2 * ib] * fc[2 * ia] - out[2 * ib + 1] * fc[2 * ia + 1];
+        float t2 = out[2 * ib] * fc[2 * ia + 1] + out[2 * ib + 1] * fc[2 * ia];
+        out[2 * ib] -= out[2 * ic] * fc[2 * ic] + out[2 * ic + 1] * fc[2 * ic + 1];
+        out[2 * ib + 1] -= out[2 * ic] * fc[2 * ic + 1] - out[2 * ic + 1] * fc[2 * ic];
+        out[2 * ic] -= t1;
+        out[2 * ic + 1] += t2;
+      }
+    } else {
+      for (ia = 1; ia < nn; ia++, ib++, ic--) {
+        float t1 = out[2 * ic] - out[2 * ib] * fc[2 * ia] + out[2 * ib + 1] * fc[2 * ia + 1];
+        float t2 = out[2 * ic + 1] + out[2 * ib] * fc[2 * ia + 1] + out[2 * ib + 1] * fc[2 * ia];
+        float t3 = out[2 * ib] - out[2 * ic] * fc[2 * ic] - out[2 * ic + 1] * fc[2 * ic + 1];
+        float t4 = out[2 * ib + 1] - out[2 * ic] * fc[2 * ic + 1] + out[2 * ic + 1] * fc[2 * ic];
+        out[2 * ib + 1] = t1; out[2 * ib] = t2; out[2 * ic + 1] = t3; out[2 * ic] = t4;
+      }
+      float t = out[2 * ib]; out[2 * ib] = out[2 * ib + 1]; out[2 * ib + 1] = t;
+      t = out[0]; out[0] = out[1]; out[1] = t;
+    }
+  } else if (c->cfg.fft1_direction < 0) {       /* fft1.c:3660-3679 with fft1_first_sym_point = 0 */
     for (int ib = 1, ic = N - 1; ib < nn; ib++, ic--) {
       float t1 = out[2 * ic], t2 = out[2 * ic + 1];
       out[2 * ic + 1] = out[2 * ib]; out[2 * ic] = out[2 * ib + 1];

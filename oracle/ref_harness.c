@@ -120,6 +120,8 @@ int main(int argc, char **argv)
   int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
   int dword = AI("dword", 0);                    /* ui.rx_input_mode & DWORD_INPUT: the input file holds int32 I,Q */
   int sshift = AI("sample_shift", 0);            /* ui.sample_shift */
+  int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
+  const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
   const char *fin = arg(argc, argv, "in", NULL);
   const char *flim = arg(argc, argv, "liminfo", NULL);
   const char *fout = arg(argc, argv, "out", "ref_dump.bin");
@@ -140,7 +142,7 @@ int main(int argc, char **argv)
   fft1mode = (ui.rx_input_mode & (TWO_CHANNELS + IQ_DATA)) / 2;
   rx_channels = 1; twice_rxchan = 2; sw_onechan = 1; swfloat = 1; swmmx_fft2 = 0; swmmx_fft1 = 0;
   kill_all_flag = 0; lir_status = 0; fft1_correlation_flag = 0; fft1afc_flag = 0; no_of_spurs = 0;
-  ampinfo_flag = 0; audio_dump_flag = 0; fft1_use_gpu = 0; fft1_calibrate_flag = 0; fft1_direction = 1;
+  ampinfo_flag = 0; audio_dump_flag = 0; fft1_use_gpu = 0; fft1_calibrate_flag = 0; fft1_direction = direction;
   yieldflag_wdsp_fft1 = 0; yieldflag_timf2_fft1 = 0; yieldflag_fft2_fft2 = 0; yieldflag_ndsp_mix1 = 0;
 
   /* ---- fft1 sizes and tables (buf.c:193-304, 1395-1459) ---- */
@@ -173,6 +175,12 @@ int main(int argc, char **argv)
   make_permute(1, n1, N1, fft1_permute);
   make_window(1, N1, sinpow1, fft1_window);
   clear_fft1_filtercorr();
+  if (ffold) {                                    /* I/Q mirror-image calibration table (caliq.c), here from a file */
+    fft1_foldcorr = zalloc(sizeof(float) * (2 * N1 + 32));
+    FILE *ff = fopen(ffold, "rb"); if (!ff || fread(fft1_foldcorr, sizeof(float), 2 * N1, ff) != (size_t)(2 * N1)) { perror(ffold); return 2; }
+    fclose(ff);
+    fft1_calibrate_flag |= CALIQ;
+  }
 
   /* timf1 input ring */
   FILE *fi = fopen(fin, "rb"); if (!fi) { perror(fin); return 2; }

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from refcases import CASES, case_params, harness_args, make_input, make_liminfo  # noqa: E402
+from refcases import CASES, case_params, harness_args, make_foldcorr, make_input, make_liminfo  # noqa: E402
 from refdump import load_dump  # noqa: E402
 
 BIG_RINGS = ["fft1_float", "fft1_sumsq", "timf2_float", "timf2_pwr_float", "fft2_float", "fft2_power_float",
@@ -40,7 +40,12 @@ def run_case(name, **override):
         fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
         iq.tofile(fi)
         lim.tofile(fl)
-        subprocess.check_call([HARNESS] + harness_args(d, fi, fl, fo))
+        extra = []
+        if d["foldcorr_seed"]:
+            ff = os.path.join(td, "fold.bin")
+            make_foldcorr(d).tofile(ff)
+            extra = [f"foldcorr={ff}"]
+        subprocess.check_call([HARNESS] + harness_args(d, fi, fl, fo) + extra)
         ref = load_dump(fo)
     return d, iq, lim, ref
 
@@ -64,6 +69,8 @@ def main():
             out["__stride"] = np.array(stride)
         out["iq"] = iq
         out["liminfo"] = lim
+        if d["foldcorr_seed"]:
+            out["foldcorr"] = make_foldcorr(d)
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(name, os.path.getsize(path) // 1024, "KiB")

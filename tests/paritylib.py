@@ -30,6 +30,8 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
     api = open_fn(cfg)
     api.timf1_write(iq)
     api.set_liminfo(lim)
+    if "foldcorr" in g:
+        api.set_foldcorr(g["foldcorr"])
     api.set_mix1_selfreq(d["fq"])
     if d["fft3_n"]:
         n3 = 1 << d["fft3_n"]

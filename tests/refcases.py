@@ -62,6 +62,19 @@ CASES = {
                           fq=2200.3, wf_avgnum=2, wf_mode=1, seed=21, timf2pow_log2=15, sumsq_blocks=8, sinpow2=3,
                           strong=[(-300.25, 9000.0)], weak=[(38.6, 80.0), (37.0, 60.0), (411.3, 25.0)],
                           pulse_period=1999, lim_halfwidth=3),
+    # mirrored passband (fft1_direction = -1, fft1.c:3660-3679)
+    "n9_n11_dir": dict(n1=9, n2=11, mixred=5, nblk=40, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
+                       fq=900.0, wf_avgnum=1, wf_mode=1, seed=22, timf2pow_log2=14, sumsq_blocks=4, direction=-1,
+                       strong=[(-60.0, 2500.0)], weak=[(-150.5, 45.0), (33.0, 80.0)], pulse_period=1499, lim_halfwidth=4),
+    # I/Q mirror-image calibration (CALIQ, fft1.c:3598-3658) with a synthetic fft1_foldcorr, both passband directions
+    "n9_n11_iqcal": dict(n1=9, n2=11, mixred=5, nblk=40, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
+                         fq=900.0, wf_avgnum=1, wf_mode=1, seed=23, timf2pow_log2=14, sumsq_blocks=4, foldcorr_seed=5,
+                         strong=[(60.0, 8000.0)], weak=[(150.5, 45.0), (-33.0, 80.0)], pulse_period=1499, lim_halfwidth=3,
+                         lim_mirror=1),
+    "n8_n10_iqcal_rev": dict(n1=8, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=3, att_n=2, bln_interval=3, bln_avgnum=8,
+                             fq=333.37, wf_avgnum=2, wf_mode=1, seed=24, timf2pow_log2=13, sumsq_blocks=8, foldcorr_seed=6,
+                             direction=-1, strong=[(40.25, 9000.0)], weak=[(77.5, 60.0), (-90.0, 30.0)], pulse_period=997,
+                             lim_halfwidth=3, lim_mirror=1),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
@@ -73,7 +86,7 @@ def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
              second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
-             dword=0, sample_shift=0)
+             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0)
     d.update(CASES[name])
     if d["gain"] is None:
         # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
@@ -110,13 +123,25 @@ def make_input(d):
     return iq
 
 
+def make_foldcorr(d):
+    """Synthetic I/Q calibration table: a few per cent, smooth in frequency (what caliq.c fits), N1 complex as floats."""
+    N1 = 1 << d["n1"]
+    rng = np.random.default_rng(d["foldcorr_seed"])
+    k = np.arange(N1) / N1
+    z = 0.03 * np.exp(2j * np.pi * (rng.uniform() + 1.5 * k)) * (1 + 0.5 * np.cos(2 * np.pi * (k + rng.uniform())))
+    out = np.empty(2 * N1, np.float32)
+    out[0::2], out[1::2] = z.real, z.imag
+    return out
+
+
 def make_liminfo(d):
     """strong/weak routing table: bins within lim_halfwidth of a strong carrier are marked strong (input to the path)."""
     N1 = 1 << d["n1"]
     lim = np.zeros(N1, np.float32)
     for k, _ in d["strong"]:
-        c = int(round(N1 // 2 + k))
-        lim[max(0, c - d["lim_halfwidth"]):c + d["lim_halfwidth"] + 1] = 1.0
+        for kk in ([k, -k] if (d["lim_mirror"] or d["direction"] < 0) else [k]):   # mirrored passband / residual image
+            c = int(round(N1 // 2 + kk))
+            lim[max(0, c - d["lim_halfwidth"]):c + d["lim_halfwidth"] + 1] = 1.0
     return lim
 
 
@@ -144,7 +169,8 @@ def lrh_config(d, iq, **kw):
         fftx_points_per_hz=1.0, mix1_lowest_fq=0.0, mix1_highest_fq=float(N2 if d["second_fft"] else N1), max_batch=4,
         second_fft_enable=d["second_fft"], timf2_blockpower_block=d["blockpower_block"],
         timf2_blockpower_size=d["blockpower_size"], fft3_n=d["fft3_n"], fft3_sinpow=d["fft3_sinpow"], mix2_n=d["mix2_n"],
-        max_fft3n=d["max_fft3n"], baseband_size=4096, timf1_dword_input=d["dword"], sample_shift=d["sample_shift"])
+        max_fft3n=d["max_fft3n"], baseband_size=4096, timf1_dword_input=d["dword"], sample_shift=d["sample_shift"],
+        fft1_direction=d["direction"])
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -154,7 +180,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
