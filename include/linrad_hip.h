@@ -229,6 +229,20 @@ int lrh_fft2_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
 /* fft1_mix1_fixed (fft2def.h / mix1.c:995-1042): the second-fft-disabled chain picks mix1.size bins straight from
    fft1_float at fft1_px; needs second_fft_enable == 0 */
 int lrh_fft1_mix1_fixed(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+
+/* AFC variants (mix1.c:863-932, 1044-1097 with do_mix1_afc, mix1.c:648-768): the centre frequency comes per transform
+   from mix1_fq_mid[nx] instead of mix1_selfreq, and the slope / curvature / start tables the AFC reads back are kept
+   like the reference does.  The tables are rings of max_fft2n floats (max_fft1n with the second fft off) owned by
+   the caller, as the reference's globals are (buf.c:1089-1092; initial values -1, -1, 0, 0: buf.c:1255-1258).  The
+   caller supplies mix1_fq_mid for transform nx and for nx+1 (mix1.c:662-666); entries may be clamped (mix1.c:724-726).
+   do_mix1 discards the frequency drift it is handed (mix1.c:103), so the signal path equals the fixed variant at the
+   per-transform frequency; a frequency must be selected (lrh_set_mix1_selfreq >= 0) as in the reference. */
+typedef struct lrh_afc {
+  float *mix1_fq_mid, *mix1_fq_slope, *mix1_fq_curv, *mix1_fq_start;
+  float baseband_bw_hz;
+} lrh_afc;
+int lrh_fft2_mix1_afc(lrh_ctx *ctx, lrh_ptrs *p, int batch, lrh_afc *afc);
+int lrh_fft1_mix1_afc(lrh_ctx *ctx, lrh_ptrs *p, int batch, lrh_afc *afc);
 /* make_fft3_all, transform part (fft3def.h; fft3.c:215-283): windowed e^{+j} transform of timf3 at timf3_px with DC at
    fft3_size/2, `batch` transforms spaced fft3_new_points; the GUI power averages of fft3.c:470-760 are not built */
 int lrh_make_fft3_all(lrh_ctx *ctx, lrh_ptrs *p, int batch);

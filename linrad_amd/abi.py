@@ -76,6 +76,26 @@ class LrhMix1State(C.Structure):
     ]
 
 
+class LrhAfc(C.Structure):
+    """lrh_afc: the reference's per-transform AFC frequency tables (caller-owned rings)."""
+    _fields_ = [("mix1_fq_mid", C.POINTER(C.c_float)), ("mix1_fq_slope", C.POINTER(C.c_float)),
+                ("mix1_fq_curv", C.POINTER(C.c_float)), ("mix1_fq_start", C.POINTER(C.c_float)),
+                ("baseband_bw_hz", C.c_float)]
+
+
+class AfcTables:
+    """numpy-backed lrh_afc with the reference's initial values (buf.c:1255-1258)."""
+
+    def __init__(self, n, baseband_bw_hz):
+        self.mid = np.full(n, -1, np.float32)
+        self.start = np.full(n, -1, np.float32)
+        self.slope = np.zeros(n, np.float32)
+        self.curv = np.zeros(n, np.float32)
+        fp = C.POINTER(C.c_float)
+        self.c = LrhAfc(self.mid.ctypes.data_as(fp), self.slope.ctypes.data_as(fp), self.curv.ctypes.data_as(fp),
+                        self.start.ctypes.data_as(fp), float(baseband_bw_hz))
+
+
 class LrhSynth(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("noise_sigma", C.c_float), ("ncarriers", C.c_int),
@@ -145,6 +165,8 @@ class StageAPI:
         self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
         for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed", "make_fft3_all", "fft3_mix2"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
+        for n in ("fft2_mix1_afc", "fft1_mix1_afc"):
+            self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(LrhAfc)])
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
@@ -276,6 +298,12 @@ class StageAPI:
 
     def fft1_mix1_fixed(self, batch=1):
         self._chk(self._f("fft1_mix1_fixed")(self.ctx, C.byref(self.p), batch), "fft1_mix1_fixed")
+
+    def fft2_mix1_afc(self, afc, batch=1):
+        self._chk(self._f("fft2_mix1_afc")(self.ctx, C.byref(self.p), batch, C.byref(afc.c)), "fft2_mix1_afc")
+
+    def fft1_mix1_afc(self, afc, batch=1):
+        self._chk(self._f("fft1_mix1_afc")(self.ctx, C.byref(self.p), batch, C.byref(afc.c)), "fft1_mix1_afc")
 
     def make_fft3_all(self, batch=1):
         self._chk(self._f("make_fft3_all")(self.ctx, C.byref(self.p), batch), "make_fft3_all")

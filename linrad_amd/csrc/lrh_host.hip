@@ -832,7 +832,46 @@ static int set_mix1_phases(lrh_ctx *c, float fq)
 }
 
 // shared by fft2_mix1_fixed (mix1.c:934-993) and fft1_mix1_fixed (mix1.c:995-1042): src ring of transforms of `n2` bins
-static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi)
+// do_mix1_afc up to its call of do_mix1 (mix1.c:648-768): bookkeeping on the caller's per-transform frequency tables
+#define LRH_BWFAC 0.03
+static void afc_tables(lrh_ctx *c, lrh_afc *a, int nx, int na, int mask)
+{
+  float *fq = a->mix1_fq_mid, *dfq = a->mix1_fq_slope, *d2fq = a->mix1_fq_curv, *fqs = a->mix1_fq_start;
+  const int ka = (nx + mask) & mask, kb = (nx + 1) & mask;
+  float t1 = fq[nx] + dfq[ka], t2 = fq[kb], t3;
+  if (fabs(t2 - t1) < LRH_BWFAC * a->baseband_bw_hz) {
+    dfq[nx] = fq[kb] - fq[nx];
+    d2fq[nx] = dfq[nx] - dfq[ka];
+  } else {
+    float error = t2 - t1, curv = (float)(LRH_BWFAC * a->baseband_bw_hz);
+    if (error < 0) curv = -curv;
+    t3 = (float)(fabs(error) / 2);
+    int kk = nx, k = 0, ia = ka, ib = kb;
+    while (fabs(error) > t3 && kk != na) {
+      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
+      t1 = fq[kk] + dfq[kk];
+      error = fq[ib] - t1;
+      if (t1 < c->cfg.mix1_lowest_fq) t1 = c->cfg.mix1_lowest_fq;
+      if (t1 > c->cfg.mix1_highest_fq) t1 = c->cfg.mix1_highest_fq;
+      fq[ib] = t1;
+      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k++;
+    }
+    t3 = error; curv = -curv;
+    while (k > 0 && kk != na && t3 * error > 0) {
+      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
+      t1 = fq[kk] + dfq[kk];
+      error = fq[ib] - t1;
+      fq[ib] = t1;
+      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k--;
+    }
+  }
+  fqs[kb] = (float)(fq[nx] + 0.5 * dfq[nx] + 0.25 * d2fq[nx]);
+}
+
+// afc != nullptr: per-transform frequency from afc->mix1_fq_mid[nx] with the table bookkeeping after each transform;
+// nx0 / na / ring_mask describe the source ring position of the first transform (fft2_nx or fft1_nx).
+static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi,
+                    lrh_afc *afc = nullptr, int na = 0)
 {
   const int Nm = c->Nm, overlap = c->Im != 0, half = c->Mm, block2 = c->Mm;     // block in complex samples = rotated samples per transform
   lrh_mix1_state *s = &c->ms;
@@ -851,9 +890,12 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
     int point = 0;
     const auto host_t0 = std::chrono::steady_clock::now();
+    int *h_point = (int *)(h_start + (size_t)batch * nchunks);
     for (int b = 0; b < batch; b++) {
-      int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
-      point = s->mix1_point;
+      const int nx = (first + b) & mask;
+      int rc = set_mix1_phases(c, afc ? afc->mix1_fq_mid[nx] : (float)s->mix1_selfreq); if (rc) return rc;
+      if (afc) afc_tables(c, afc, nx, na, mask);
+      point = s->mix1_point; h_point[b] = point;
       float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
       float r1 = s->mix1_old_phase;
       const float r2 = overlap ? (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm) : 0.f;
@@ -868,12 +910,13 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     c->host_ms_phases += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); c->host_n_phases++;
     // a few KiB per call, in stream order
     float2 *d_inc = (float2 *)(c->d_ph + slot * c->ph_stride);
-    HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, sizeof(float2) * (size_t)batch * (1 + nchunks), hipMemcpyHostToDevice, c->cur));
+    HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, sizeof(float2) * (size_t)batch * (1 + nchunks) + sizeof(int) * (size_t)batch, hipMemcpyHostToDevice, c->cur));
     HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
     o.ph_inc = d_inc; o.ph_start = d_inc + batch; o.nchunks = nchunks;
     Mix1Args a;
     a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
     a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
+    a.points = afc ? (const int *)(d_inc + (size_t)batch * (1 + nchunks)) : nullptr;
     ProfScope ps(c, "mix1");
     HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->cur));
     HIPCHK(c, launch_mix1_out(o, batch, c->cur));
@@ -895,6 +938,33 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
   int rc = mix1_run(c, p, batch, c->d_fft2, c->N2, p->fft2_nx, c->fft2n_mask, lim_hi);
   if (rc) return rc;
   p->fft2_nx = (p->fft2_nx + batch) & c->fft2n_mask;                          // mix1.c:992
+  return LRH_OK;
+}
+
+int lrh_fft2_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_afc needs second_fft_enable");
+  if (c->ms.mix1_selfreq < 0) return fail(c, LRH_ESTATE, "fft2_mix1_afc needs a selected frequency");
+  int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+  int lim_hi = ratio * (c->N1 - 1); if (lim_hi > c->N2) lim_hi = c->N2;
+  int rc = mix1_run(c, p, batch, c->d_fft2, c->N2, p->fft2_nx, c->fft2n_mask, lim_hi, afc, p->fft2_na);
+  if (rc) return rc;
+  p->fft2_nx = (p->fft2_nx + batch) & c->fft2n_mask;                          // mix1.c:931
+  return LRH_OK;
+}
+
+int lrh_fft1_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_afc needs second_fft_enable == 0");
+  if (c->ms.mix1_selfreq < 0) return fail(c, LRH_ESTATE, "fft1_mix1_afc needs a selected frequency");
+  int rc = mix1_run(c, p, batch, c->d_fft1, c->N1, (p->fft1_px / (2 * c->N1)) & c->fft1n_mask, c->fft1n_mask, c->N1 - 1, afc, p->fft1_nb);
+  if (rc) return rc;
+  p->fft1_nx = (p->fft1_nx + batch) & c->fft1n_mask;                          // mix1.c:1095-1096
+  p->fft1_px = (p->fft1_px + batch * 2 * c->N1) & c->fft1_mask;
   return LRH_OK;
 }
 

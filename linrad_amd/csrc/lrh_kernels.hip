@@ -972,7 +972,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mi
     for (int s = 0; s < R0; s++) {
       const int i = (tid + m * T) + s * (N / R0);
       const int off = i < N / 2 ? i : i - N;                // upper half first, then the lower half
-      const int bin = a.point + off;
+      const int bin = (a.points ? a.points[b] : a.point) + off;
       const int d = off < 0 ? -off : off;
       const float w = a.fqwin[d == 0 ? N / 2 - 1 : N / 2 - d];
       float2 v = make_float2(0.f, 0.f);

@@ -117,6 +117,7 @@ struct Mix1Args {
   const float *fqwin; const float2 *tw;
   float2 *scratch;           // [batch][Nm] raw back transforms
   int point; int lim_hi;     // bins >= lim_hi are zeroed (mix1.c:957-958), bins < 0 zeroed
+  const int *points;         // per-transform mix1_point (AFC variants, mix1.c:880-882); null: `point` for all
   int nm;
 };
 struct Mix1OutArgs {

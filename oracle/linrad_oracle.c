@@ -783,13 +783,13 @@ static int set_mix1_phases(lro_ctx *c, float fq)
 
 /* gather of fft2_mix1_fixed (mix1.c:955-983) / fft1_mix1_fixed (mix1.c:1015-1030) + do_mix1 (mix1.c:55-195; dfq forced
    to 0 at mix1.c:103).  z: first float of the source transform, lim: float index limit mm*nn*fft1_last_point. */
-static int mix1_block(lro_ctx *c, lrh_ptrs *p, const float *zbase, int lim)
+static int mix1_block(lro_ctx *c, lrh_ptrs *p, const float *zbase, int lim, float fq)
 {
   int Nm = c->Nm, n = Nm, n2 = 2 * Nm, block = 2 * c->Mm;
   lrh_mix1_state *s = &c->ms;
   float *tmp = c->tmp, *t3 = c->timf3_float;
   if (s->mix1_selfreq >= 0) {
-    int rc = set_mix1_phases(c, (float)s->mix1_selfreq); if (rc) return rc;
+    int rc = set_mix1_phases(c, fq); if (rc) return rc;
     int k = s->mix1_point * 2;
     int ib = n; if (ib > lim - k) ib = lim - k; if (ib < 0) ib = 0;
     const float *z = zbase + k;
@@ -884,8 +884,71 @@ int lro_fft2_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
   int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
   int lim = 2 * ratio * (c->N1 - 1); if (lim > 2 * c->N2) lim = 2 * c->N2;   /* clamp only bites when N2 < N1 */
   for (int b = 0; b < batch; b++) {
-    int rc = mix1_block(c, p, c->fft2_float + (size_t)2 * p->fft2_nx * c->N2, lim); if (rc) return rc;
+    int rc = mix1_block(c, p, c->fft2_float + (size_t)2 * p->fft2_nx * c->N2, lim, (float)c->ms.mix1_selfreq); if (rc) return rc;
     p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
+  }
+  return LRH_OK;
+}
+
+/* do_mix1_afc, mix1.c:648-768, up to the call of do_mix1: bookkeeping on the per-transform frequency tables */
+#define BWFAC 0.03
+static void afc_tables(lro_ctx *c, lrh_afc *a, int nx, int na, int mask)
+{
+  float *fq = a->mix1_fq_mid, *dfq = a->mix1_fq_slope, *d2fq = a->mix1_fq_curv, *fqs = a->mix1_fq_start;
+  int ka = (nx + mask) & mask, kb = (nx + 1) & mask;
+  float t1 = fq[nx] + dfq[ka], t2 = fq[kb], t3;
+  if (fabs(t2 - t1) < BWFAC * a->baseband_bw_hz) {
+    dfq[nx] = fq[kb] - fq[nx];
+    d2fq[nx] = dfq[nx] - dfq[ka];
+  } else {
+    float error = t2 - t1, curv = BWFAC * a->baseband_bw_hz;
+    if (error < 0) curv = -curv;
+    t3 = fabs(error) / 2;
+    int kk = nx, k = 0, ia = ka, ib = kb;
+    while (fabs(error) > t3 && kk != na) {
+      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
+      t1 = fq[kk] + dfq[kk];
+      error = fq[ib] - t1;
+      if (t1 < c->cfg.mix1_lowest_fq) t1 = c->cfg.mix1_lowest_fq;
+      if (t1 > c->cfg.mix1_highest_fq) t1 = c->cfg.mix1_highest_fq;
+      fq[ib] = t1;
+      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k++;
+    }
+    t3 = error; curv = -curv;
+    while (k > 0 && kk != na && t3 * error > 0) {
+      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
+      t1 = fq[kk] + dfq[kk];
+      error = fq[ib] - t1;
+      fq[ib] = t1;
+      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k--;
+    }
+  }
+  fqs[kb] = fq[nx] + 0.5 * dfq[nx] + 0.25 * d2fq[nx];
+}
+
+/* fft2_mix1_afc, mix1.c:863-932 (fft1_first_point = 0: the gather equals the fixed variant's) */
+int lro_fft2_mix1_afc(lro_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
+{
+  if (!c->cfg.second_fft_enable || !afc || c->ms.mix1_selfreq < 0) return LRH_ESTATE;
+  int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+  int lim = 2 * ratio * (c->N1 - 1); if (lim > 2 * c->N2) lim = 2 * c->N2;
+  for (int b = 0; b < batch; b++) {
+    int rc = mix1_block(c, p, c->fft2_float + (size_t)2 * p->fft2_nx * c->N2, lim, afc->mix1_fq_mid[p->fft2_nx]); if (rc) return rc;
+    afc_tables(c, afc, p->fft2_nx, p->fft2_na, c->fft2n_mask);
+    p->fft2_nx = (p->fft2_nx + 1) & c->fft2n_mask;
+  }
+  return LRH_OK;
+}
+
+/* fft1_mix1_afc, mix1.c:1044-1097 */
+int lro_fft1_mix1_afc(lro_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
+{
+  if (c->cfg.second_fft_enable || !afc || c->ms.mix1_selfreq < 0) return LRH_ESTATE;
+  for (int b = 0; b < batch; b++) {
+    int rc = mix1_block(c, p, c->fft1_float + p->fft1_px, 2 * (c->N1 - 1), afc->mix1_fq_mid[p->fft1_nx]); if (rc) return rc;
+    afc_tables(c, afc, p->fft1_nx, p->fft1_nb, c->fft1n_mask);
+    p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
+    p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
   }
   return LRH_OK;
 }
@@ -895,7 +958,7 @@ int lro_fft1_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
 {
   if (c->cfg.second_fft_enable) return LRH_ESTATE;
   for (int b = 0; b < batch; b++) {
-    int rc = mix1_block(c, p, c->fft1_float + p->fft1_px, 2 * (c->N1 - 1)); if (rc) return rc;
+    int rc = mix1_block(c, p, c->fft1_float + p->fft1_px, 2 * (c->N1 - 1), (float)c->ms.mix1_selfreq); if (rc) return rc;
     p->fft1_nx = (p->fft1_nx + 1) & c->fft1n_mask;
     p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
   }

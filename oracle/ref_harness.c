@@ -57,6 +57,8 @@ void first_noise_blanker(void);
 void make_fft2(void);
 void fft2_mix1_fixed(void);
 void fft1_mix1_fixed(void);
+void fft2_mix1_afc(void);
+void fft1_mix1_afc(void);
 void compute_timf2_powersum(void);
 void make_fft3_all(void);
 void clear_fft1_filtercorr(void);
@@ -120,6 +122,8 @@ int main(int argc, char **argv)
   int lim_every = AI("lim_every", 0);            /* liminfo record stride in blocks (0: single record) */
   int dword = AI("dword", 0);                    /* ui.rx_input_mode & DWORD_INPUT: the input file holds int32 I,Q */
   int sshift = AI("sample_shift", 0);            /* ui.sample_shift */
+  int afc = AI("afc", 0);                        /* 1: fft2_mix1_afc / fft1_mix1_afc with a synthetic per-transform frequency */
+  double afc_bw = AF("afc_bw", 20.0);            /* baseband_bw_hz */
   int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
   const char *fin = arg(argc, argv, "in", NULL);
@@ -383,6 +387,16 @@ int main(int argc, char **argv)
 #define RUN_FFT3() do { if (n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * fft3_size && \
       ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) { make_fft3_all(); nfft3++; \
       fft3_px = (fft3_px + fft3_block) & fft3_mask; /* consumer side (fft3_mix2, mix2.c:2058) not run head-less */ } } while (0)
+  /* ---- AFC tables (buf.c:1089-1092, 1255-1258) and the synthetic frequency supplier for the afc variants ---- */
+  int afcn = second ? max_fft2n : max_fft1n;
+  mix1_fq_mid = zalloc(4 * afcn); mix1_fq_start = zalloc(4 * afcn); mix1_fq_curv = zalloc(4 * afcn); mix1_fq_slope = zalloc(4 * afcn);
+  for (int i = 0; i < afcn; i++) { mix1_fq_mid[i] = -1; mix1_fq_start[i] = -1; }
+  baseband_bw_hz = (float)afc_bw; fftxn_mask = afcn - 1;
+  int afc_t = 0;
+  float *afc_supplied = zalloc(4 * ((size_t)nblk * 64 + 64));
+#define AFC_FQ(t) ((float)(fq + 1.5 * sin(2 * PI_L * (t) / 23.0) + ((t) >= 30 && (t) < 60 ? 3.0 : 0.0)))
+#define AFC_SUPPLY(nx, mask) do { if (afc_t == 0) mix1_fq_mid[nx] = AFC_FQ(0); \
+      mix1_fq_mid[((nx) + 1) & (mask)] = AFC_FQ(afc_t + 1); afc_supplied[afc_t] = mix1_fq_mid[((nx) + 1) & (mask)]; afc_t++; } while (0)
   /* ---- run ---- */
   float *trace = zalloc(sizeof(float) * TR_COLS * nblk);
   int *itrace = zalloc(sizeof(int) * TR_COLS * nblk);
@@ -405,6 +419,7 @@ int main(int argc, char **argv)
     if (!second) {               /* second fft disabled: fft1_c, then the narrowband thread's fft1_mix1_fixed */
       while (fft1_na != fft1_nb) fft1_c();
       if (fq >= 0) {
+        if (afc) { AFC_SUPPLY(fft1_nx, fft1n_mask); fft1_mix1_afc(); } else
         fft1_mix1_fixed();
         float *m = mixtrace + 8 * nfft2;
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
@@ -426,6 +441,7 @@ int main(int argc, char **argv)
       while (make_fft2_status != FFT2_COMPLETE) make_fft2();
       if (wg_waterf_ptr != wptr) { memcpy(wf_lines + (size_t)nwf * wg_xpixels, wg_waterf + wptr, 2 * wg_xpixels); nwf++; }
       if (fq >= 0) {
+        if (afc) { AFC_SUPPLY(fft2_nx, fft2n_mask); fft2_mix1_afc(); } else
         fft2_mix1_fixed();
         float *m = mixtrace + 8 * nfft2;
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
@@ -464,6 +480,12 @@ int main(int argc, char **argv)
   PUTF("trace", trace, (size_t)TR_COLS * nblk);
   PUTI("itrace", itrace, (size_t)TR_COLS * nblk);
   PUTF("mixtrace", mixtrace, (size_t)8 * (nfft2 > 0 ? nfft2 : 1));
+  if (afc) {
+    PUTF("afc_fq0", &(float){AFC_FQ(0)}, 1);
+    PUTF("afc_supplied", afc_supplied, afc_t > 0 ? afc_t : 1);
+    PUTF("afc_fq_mid", mix1_fq_mid, afcn); PUTF("afc_fq_slope", mix1_fq_slope, afcn);
+    PUTF("afc_fq_curv", mix1_fq_curv, afcn); PUTF("afc_fq_start", mix1_fq_start, afcn);
+  }
   {
     int fin_[12] = { fft1_pa, fft1_nb, fft1_nx, timf2_pa, timf2p_fit, timf2_pn2, timf2_px, fft2_na, fft2_nx, timf3_pa, nfft2, nwf };
     PUTI("final", fin_, 12);

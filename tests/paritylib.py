@@ -37,6 +37,18 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
         n3 = 1 << d["fft3_n"]
         api.set_bg_filterfunc(np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))   # stand-in for make_bg_filter
     itrace, wf_lines, mixtrace = [], [], []
+    afc, afc_t = None, [0]
+    if d["afc"]:
+        # the reference harness supplied these per-transform frequencies (its AFC_SUPPLY macro); replay the same supply
+        afc = abi.AfcTables(cfg.max_fft2n if d["second_fft"] else cfg.max_fft1n, d["afc_bw"])
+
+    def mix1_afc(nx, mask, call):
+        t = afc_t[0]
+        if t == 0:
+            afc.mid[nx] = g["afc_fq0"][0]
+        afc.mid[(nx + 1) & mask] = g["afc_supplied"][t]
+        afc_t[0] += 1
+        call(afc, 1)
     nblk = d["nblk"]
     b = 0
     while b < nblk and not d["second_fft"]:
@@ -45,7 +57,10 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
         api.fft1_b(B)
         api.fft1_c(B)
         for _ in range(B):
-            api.fft1_mix1_fixed(1)
+            if afc is not None:
+                mix1_afc(api.p.fft1_nx, cfg.max_fft1n - 1, api.fft1_mix1_afc)
+            else:
+                api.fft1_mix1_fixed(1)
             ms = api.mix1_state()
             mixtrace.append([ms.mix1_point, ms.mix1_phase, ms.mix1_phase_rot, ms.mix1_phase_step,
                              ms.mix1_old_phase, ms.mix1_old_point, api.p.timf3_pa, api.p.fft1_nx])
@@ -66,7 +81,10 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
             api.make_fft2(1)
             if api.p.wg_waterf_ptr != wptr:
                 wf_lines.append(api.export(abi.RING_WG_WATERF, wptr, cfg.wf_xpixels))
-            api.fft2_mix1_fixed(1)
+            if afc is not None:
+                mix1_afc(api.p.fft2_nx, cfg.max_fft2n - 1, api.fft2_mix1_afc)
+            else:
+                api.fft2_mix1_fixed(1)
             if d["fft3_n"]:
                 k3 = api.fft3_available()
                 if k3:
@@ -89,6 +107,8 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
     if d["blockpower_block"]:
         out["timf2_blockpower"] = api.export(abi.RING_TIMF2_BLOCKPOWER)
         out["blockpower_ptrs"] = np.array([api.p.timf2_blockpower_pa, api.p.timf2_pb])
+    if afc is not None:
+        out["afc_tables"] = np.stack([afc.mid, afc.slope, afc.curv, afc.start])
     out["itrace"] = np.array(itrace, np.int64)
     out["wf_lines"] = np.array(wf_lines, np.int16).reshape(-1, cfg.wf_xpixels)
     out["mixtrace"] = np.array(mixtrace, np.float64).reshape(-1, 8)
@@ -139,6 +159,9 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
         e = relerr(out["timf2_blockpower"], g["timf2_blockpower"])
         rep["timf2_blockpower"] = e
         assert e <= tol, f"timf2_blockpower: {e:.3e}"
+    if "afc_tables" in out:
+        ref = np.stack([g["afc_fq_mid"], g["afc_fq_slope"], g["afc_fq_curv"], g["afc_fq_start"]])
+        assert np.array_equal(out["afc_tables"], ref), "AFC frequency tables differ from the reference's"
     gi, oi = golden_itrace(g), out["itrace"]
     assert gi.shape == oi.shape, (gi.shape, oi.shape)
     ptr_cols = [0, 1, 2, 3, 6, 7, 8, 9, 10]

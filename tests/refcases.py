@@ -75,6 +75,14 @@ CASES = {
                              fq=333.37, wf_avgnum=2, wf_mode=1, seed=24, timf2pow_log2=13, sumsq_blocks=8, foldcorr_seed=6,
                              direction=-1, strong=[(40.25, 9000.0)], weak=[(77.5, 60.0), (-90.0, 30.0)], pulse_period=997,
                              lim_halfwidth=3, lim_mirror=1),
+    # AFC variants of mix1 (fft2_mix1_afc / fft1_mix1_afc with do_mix1_afc's table bookkeeping): the frequency wanders
+    # +-1.5 bins and jumps by 3 bins for a while, which exercises the limited-curvature branch (mix1.c:706-747)
+    "n10_n12_afc": dict(n1=10, n2=12, mixred=6, nblk=48, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                        fq=2200.3, wf_avgnum=2, wf_mode=1, seed=25, timf2pow_log2=15, sumsq_blocks=8, afc=1,
+                        strong=[(-300.25, 9000.0)], weak=[(-100.0, 50.0), (152.0, 120.0)], pulse_period=1999, lim_halfwidth=3),
+    "n10_afc_mix1only": dict(n1=10, n2=10, mixred=4, nblk=64, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
+                             fq=700.3, wf_avgnum=1, wf_mode=1, seed=26, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
+                             afc=1, strong=[(-100.0, 3000.0)], weak=[(188.3, 400.0)], pulse_period=0, lim_halfwidth=3),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
@@ -86,7 +94,7 @@ def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
              second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
-             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0)
+             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0)
     d.update(CASES[name])
     if d["gain"] is None:
         # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
@@ -180,7 +188,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
