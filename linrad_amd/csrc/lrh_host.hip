@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <functional>
 #include <map>
 
 #include "../../include/linrad_hip.h"
@@ -62,7 +63,12 @@ struct lrh_ctx {
   hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
   hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
-  int pipeline = 1;                  // LRH_PIPELINE=0 turns the two-stream schedule off
+  int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
+  // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
+  // their device work here; lrh_wideband_dsp replays it later, on the stream it chooses.
+  std::vector<std::function<int(lrh_ctx *)>> *rec = nullptr;
+  bool ph_pending[LRH_NSTAGE] = {};  // staging slot handed to a deferred upload that has not been replayed yet
+  hipEvent_t ev_tail = nullptr;
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
@@ -109,6 +115,15 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
   return code;
 }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
+
+// Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
+// sees the context as `c`; everything else it touches is captured by value.
+#define LRH_DEVICE_WORK(c, body)                                                       \
+  do {                                                                                 \
+    auto op_ = [=](lrh_ctx *c) -> int { body; return LRH_OK; };                        \
+    if ((c)->rec) (c)->rec->push_back(op_);                                            \
+    else { const int rc_ = op_(c); if (rc_) return rc_; }                              \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------ profiling
 struct ProfScope {
@@ -249,7 +264,7 @@ void lrh_close(lrh_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1] }) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -324,7 +339,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
   if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
   c->cur = c->stream;
-  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1] }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) c->pipeline = atoi(e2);
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
   int rc = LRH_OK;
@@ -725,8 +740,8 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
     else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
   }
-  ProfScope ps(c, "blanker");
-  HIPCHK(c, launch_blanker(a, c->cfg.timf2pow_size / 32, c->cur));
+  const int ring_words = c->cfg.timf2pow_size / 32;
+  LRH_DEVICE_WORK(c, { ProfScope ps(c, "blanker"); HIPCHK(c, launch_blanker(a, ring_words, c->cur)); });
   return LRH_OK;
 }
 
@@ -757,38 +772,37 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.xcd = (c->xcd_mask >> 2) & 1;
   a.ps_in = c->d_powersum2; a.ps_out = c->d_powersum2_alt; a.wf_scratch = c->d_wf_scratch;
   a.ps_counter = p->wg_waterf_sum_counter; a.ps_avgnum = c->fft2_fused ? c->cfg.waterfall_avgnum : 0;
-  if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
-  if (c->cfg.fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(c->cfg.fft2_n, a, batch, c->cur)); }
-  else {
-    Fft2BigArgs g;
-    g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
-    g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
-    g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
-    ProfScope ps(c, "fft2");
-    HIPCHK(c, launch_fft2_big(c->cfg.fft2_n, g, batch, c->cur));
-  }
+  Fft2BigArgs g;
+  g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
+  g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
+  g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
   { float *t = c->d_powersum2; c->d_powersum2 = c->d_powersum2_alt; c->d_powersum2_alt = t; }   // ping-pong: group 0 reads while the last group writes
-  hipStream_t main_s = c->cur;
-  if (c->split_fft2_tail) {                      // power sums and waterfall lines only feed the GUI side: side stream
-    HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0));
-    c->cur = c->stream2;
-  }
-  if (!c->fft2_fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
   const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
+  WaterfallArgs w; memset(&w, 0, sizeof w);
   if (nlines > 0) {
     int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
-    WaterfallArgs w;
     w.ps = c->d_wf_scratch; w.yfac = c->d_yfac; w.itab = c->d_wf_itab; w.line = c->d_waterf;
     w.npix = c->cfg.wf_xpixels; w.first = c->cfg.wf_first_xpoint; w.siz = N; w.hx = hx; w.hp = hp;
     w.ptr0 = p->wg_waterf_ptr; w.wf_size = c->cfg.wf_lines * c->cfg.wf_xpixels; w.line_stride = N;
-    ProfScope ps(c, "waterfall");
-    HIPCHK(c, launch_waterfall(w, nlines, c->cur));
   }
-  if (c->split_fft2_tail) HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2));
-  c->cur = main_s;
+  const int fft2_n = c->cfg.fft2_n; const bool fused = c->fft2_fused;
+  LRH_DEVICE_WORK(c, {
+    if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
+    if (fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(fft2_n, a, batch, c->cur)); }
+    else { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2_big(fft2_n, g, batch, c->cur)); }
+    hipStream_t main_s = c->cur;
+    if (c->split_fft2_tail) {                      // power sums and waterfall lines only feed the GUI side: side stream
+      HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0));
+      c->cur = c->stream2;
+    }
+    if (!fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
+    if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }
+    if (c->split_fft2_tail) HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2));
+    c->cur = main_s;
+  });
   for (int b = 0; b < batch; b++) {                                      // fft2.c:672, 703-705, 813-815, 1831-1845
     p->wg_waterf_sum_counter++;
     if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) {
@@ -884,6 +898,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
   if (selected) {
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
+    if (c->ph_pending[slot]) return fail(c, LRH_ESTATE, "mix1 staging ring exhausted by deferred work");
     { const auto w0 = std::chrono::steady_clock::now(); HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
       c->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); }
     const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
@@ -910,19 +925,24 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     c->host_ms_phases += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); c->host_n_phases++;
     // a few KiB per call, in stream order
     float2 *d_inc = (float2 *)(c->d_ph + slot * c->ph_stride);
-    HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, sizeof(float2) * (size_t)batch * (1 + nchunks) + sizeof(int) * (size_t)batch, hipMemcpyHostToDevice, c->cur));
-    HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
     o.ph_inc = d_inc; o.ph_start = d_inc + batch; o.nchunks = nchunks;
     Mix1Args a;
     a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
     a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
     a.points = afc ? (const int *)(d_inc + (size_t)batch * (1 + nchunks)) : nullptr;
-    ProfScope ps(c, "mix1");
-    HIPCHK(c, launch_mix1_back(c->mix1_n, a, batch, c->cur));
-    HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+    const size_t up_bytes = sizeof(float2) * (size_t)batch * (1 + nchunks) + sizeof(int) * (size_t)batch;
+    const int mix1_n = c->mix1_n;
+    c->ph_pending[slot] = true;
+    LRH_DEVICE_WORK(c, {
+      HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->cur));
+      HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
+      c->ph_pending[slot] = false;
+      ProfScope ps(c, "mix1");
+      HIPCHK(c, launch_mix1_back(mix1_n, a, batch, c->cur));
+      HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+    });
   } else {
-    ProfScope ps(c, "mix1");
-    HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+    LRH_DEVICE_WORK(c, { ProfScope ps(c, "mix1"); HIPCHK(c, launch_mix1_out(o, batch, c->cur)); });
   }
   p->timf3_pa = (p->timf3_pa + batch * 2 * block2) & c->timf3_mask;      // mix1.c:991 / 1039
   return LRH_OK;
@@ -1108,10 +1128,78 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     }
     return LRH_OK;
   }
-  // ---- two-stream schedule
+  // ---- two-stream schedules
   hipStream_t S1 = c->stream, S2 = c->stream2;
   auto on = [&](hipStream_t s) { c->cur = s; };
-  struct Restore { lrh_ctx *c; ~Restore() { c->cur = c->stream; } } restore{c};
+  struct Restore { lrh_ctx *c; ~Restore() { c->cur = c->stream; c->rec = nullptr; c->split_fft2_tail = false; } } restore{c};
+  // Schedule 2 (lagged): the side kernels only find room next to k_timf2 (the two forward-transform kernels fill the
+  // register file), so the blanker, fft2 and mix1 of a round are enqueued one round late:
+  //   main:  timf2(k) | fft1(k+1) | fft2(k-1) mix1(k-1) | timf2(k+1) ...
+  //   side:  sumsq(k) slowsum(k) blanker(k-1) | waterfall(k-1) | sumsq(k+1) ...
+  // The stage functions do their pointer bookkeeping in the reference's order and park their launches in a queue
+  // (LRH_DEVICE_WORK); results are those of the serial order because every ring holds two rounds (checked here).
+  const long need2 = 2L * batch * c->M1 + 2L * c->N2 + c->cfg.blnfit_range + 4L * (c->cfg.blanker_pulsewidth + 2);
+  const bool lagged = c->pipeline >= 2 && need2 <= c->cfg.timf2pow_size &&
+                      (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n && nblocks >= 3 * batch;
+  if (lagged) {
+    std::vector<std::function<int(lrh_ctx *)>> qb, qt;     // parked launches: blanker / fft2+mix1 of the previous round
+    auto flush = [&](std::vector<std::function<int(lrh_ctx *)>> &q, hipStream_t st) -> int {
+      c->rec = nullptr; c->cur = st;
+      for (auto &op : q) { const int r = op(c); if (r) { q.clear(); return r; } }
+      q.clear(); return LRH_OK;
+    };
+    HIPCHK(c, hipEventRecord(c->ev_side, S1)); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_side, 0));
+    int left = nblocks, round = 0;
+    int B = left < batch ? left : batch;
+    bool have_prev = false, tail_flushed = false;
+    on(S1); if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+    advance_fft1(c, p, B);
+    HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+    auto side_blanker = [&]() -> int {        // blanker(k-1): after timf2(k-1) wrote and fft2(k-2) read its neighbourhood
+      if (tail_flushed) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail, 0));
+      const int r = flush(qb, S2); if (r) return r;
+      HIPCHK(c, hipEventRecord(c->ev_blank, S2));
+      return LRH_OK;
+    };
+    auto main_tail = [&]() -> int {           // fft2(k-1) + mix1(k-1) on the blanked data
+      HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
+      c->split_fft2_tail = true;
+      const int r = flush(qt, S1);
+      c->split_fft2_tail = false;
+      if (r) return r;
+      HIPCHK(c, hipEventRecord(c->ev_tail, S1)); tail_flushed = true;
+      return LRH_OK;
+    };
+    while (left > 0) {
+      const int Bnext = (left - B) < batch ? (left - B) : batch;
+      on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
+      if ((rc = lrh_fft1_c(c, p, B))) return rc;
+      HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
+      if (have_prev && (rc = side_blanker())) return rc;
+      on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
+      HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
+      // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
+      qb.push_back([](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_timf2, 0)); return LRH_OK; });
+      c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
+      if (rc) return rc;
+      if (Bnext > 0) {
+        on(S1);
+        if (round >= 1) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_sumsq[(round + 1) & 1], 0));
+        if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
+        advance_fft1(c, p, Bnext);
+        HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+      }
+      if (have_prev && (rc = main_tail())) return rc;
+      c->rec = &qt; rc = round_tail(c, p); c->rec = nullptr;
+      if (rc) return rc;
+      have_prev = true;
+      left -= B; B = Bnext; round++;
+    }
+    if ((rc = side_blanker())) return rc;
+    if ((rc = main_tail())) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
+    return LRH_OK;
+  }
   // the side stream starts after everything already queued on the main stream
   HIPCHK(c, hipEventRecord(c->ev_side, S1)); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_side, 0));
   int left = nblocks, round = 0;

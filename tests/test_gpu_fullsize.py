@@ -178,3 +178,30 @@ def test_interleaved_two_channel_frames_shard_per_context():
         assert rx2.p.timf1p_px == 2 * rx1.p.timf1p_px
         for ring in (abi.RING_FFT1_FLOAT, abi.RING_FFT2_FLOAT, abi.RING_TIMF3_FLOAT):
             assert _relerr(rx2.export(ring), rx1.export(ring)) < 2e-5, (ch, ring)
+
+
+@pytest.mark.parametrize("fft2_n", [12, 16])
+def test_stream_schedules_are_bit_identical(fft2_n, monkeypatch):
+    """LRH_PIPELINE 0 (serial), 1 (two streams) and 2 (blanker / fft2 / mix1 one round behind) only reorder launches:
+    every ring, pointer and the blanker state must come out bit for bit the same, over two consecutive calls."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(14, fft2_n, batch=16)
+    s = synth_defaults(N1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 14)
+    rings = (abi.RING_FFT1_SUMSQ, abi.RING_FFT1_SLOWSUM, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT,
+             abi.RING_FFT2_POWERSUM, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF)
+    res = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("LRH_PIPELINE", mode)
+        rx = _hip(cfg)
+        _feed(rx, iq, lim, 0.31 * (1 << fft2_n) + 0.3)
+        rx.wideband_dsp(64, 16)
+        rx.wideband_dsp(48, 16)
+        bs = rx.blanker_state()
+        res.append(([rx.export(r) for r in rings], rx.p.as_dict(),
+                    (bs.timf2_noise_floor, bs.stupid_bln_limit, bs.timf2_cleared_points, bs.last_call_cleared)))
+    for other in res[1:]:
+        assert other[1] == res[0][1] and other[2] == res[0][2]
+        for a, b in zip(res[0][0], other[0]):
+            assert np.array_equal(a, b)
