@@ -202,7 +202,7 @@ def main():
         for _ in range(max(3, min(args.steps, 10))):
             rx.wideband_dsp(args.batch, args.batch)
         rx.sync()
-        for k in ("fft1", "sumsq", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1"):
+        for k in ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1"):
             ms, n = rx.profile_get(k)
             if n:
                 stages[k] = {"ms_total": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 2)}
@@ -210,7 +210,10 @@ def main():
         dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
         nsteps_prof = stages["fft1"]["launches"]
         launches_per_step = stages[dom]["launches"] / nsteps_prof
-        alg_bytes_launch = ALG_BYTES[dom] * (args.batch * M1) / launches_per_step      # the profiling loop runs single batches
+        per_sample = ALG_BYTES[dom]
+        if dom == "timf2" and "sumsq" not in stages:           # fft1_c's power sums are computed inside k_timf2: both stages' bytes
+            per_sample += ALG_BYTES["sumsq"]
+        alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_step      # the profiling loop runs single batches
         avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] / 1e3
         achieved = alg_bytes_launch / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -18,7 +18,9 @@
 
 namespace lrh {
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st);
-hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st);
+hipError_t launch_timf2(int log2n, const Timf2Args &a, int batch, hipStream_t st, const SumsqArgs *ss = nullptr, float *ss_part = nullptr, int *ss_run = nullptr);
+hipError_t launch_sumsq_join(const SumsqArgs &a, const float *part, int run, hipStream_t st);
+int timf2_grid(int log2n, int batch);
 hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st);
 hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st);
 hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st);
@@ -59,10 +61,18 @@ struct lrh_ctx {
   std::vector<float> h_window3_ref;
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
+  hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
   hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
-  hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
+  hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_timf2b = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
+  // fft1_c's power sums inside k_timf2 (lrh_wideband_dsp, sin^2 window): fft1_c parks its arguments here, make_timf2
+  // picks them up, the join of split groups and the slow average follow from ss_queue
+  bool fuse_sumsq = true;            // LRH_FUSE_SUMSQ=0: separate k_sumsq pass
+  bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
+  float *d_ss_part = nullptr;
+  std::vector<std::function<int(lrh_ctx *)>> ss_queue;
+  bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
   // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
   // their device work here; lrh_wideband_dsp replays it later, on the stream it chooses.
@@ -264,11 +274,12 @@ void lrh_close(lrh_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
-  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail }) if (ev) hipEventDestroy(ev);
+  if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
+  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -337,10 +348,12 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
-  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
   c->cur = c->stream;
-  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) c->pipeline = atoi(e2);
+  if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
+  if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
   int rc = LRH_OK;
 #define A(call) do { if (rc == LRH_OK) rc = (call); } while (0)
@@ -439,6 +452,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
+  if (cfg->second_fft_enable && c->timf2_mode == 1 && timf2_grid(cfg->fft1_n, cfg->max_batch) > 0) A(dev_alloc(c, &c->d_ss_part, (size_t)2 * timf2_grid(cfg->fft1_n, cfg->max_batch) * N1));
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -657,7 +671,13 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
   SumsqArgs sa;
   sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.sumsq_mask = c->sumsq_mask;
   sa.first_nb = p->fft1_nb; sa.batch = batch; sa.avg = avg1; sa.c0 = p->fft1_sumsq_counter; sa.pa0 = p->fft1_sumsq_pa;
-  { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
+  if (c->ss_defer) {
+    if (c->ss_have) { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(c->ss_args, c->cur)); }   // nobody took the last ones
+    c->ss_args = sa; c->ss_have = true;
+  } else { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
+  std::vector<std::function<int(lrh_ctx *)>> *const rec0 = c->rec;
+  if (c->ss_defer) c->rec = &c->ss_queue;                // the slow average waits for the sums
+  struct RecBack { lrh_ctx *c; std::vector<std::function<int(lrh_ctx *)>> *r; ~RecBack() { c->rec = r; } } rec_back{c, rec0};
   const int nupd = (p->fft1_sumsq_counter + batch) / avg1;              // groups completed by this batch
   if (nupd > 0) {
     SlowsumArgs ua;
@@ -671,8 +691,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
       p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
     }
-    ProfScope ps(c, "slowsum");
-    HIPCHK(c, launch_slowsum(ua, c->cur));
+    LRH_DEVICE_WORK(c, { ProfScope ps(c, "slowsum"); HIPCHK(c, launch_slowsum(ua, c->cur)); });
     if (c->cfg.second_fft_enable) p->fft1_liminfo_cnt += nupd;          // fft1.c:4515-4518
     p->fft1_sumsq_pa = (p->fft1_sumsq_pa + nupd * N) & c->sumsq_mask;
   }
@@ -693,7 +712,19 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
   a.xcd = (c->xcd_mask >> 1) & 1;
-  { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
+  if (c->ss_have) {
+    const SumsqArgs &sa = c->ss_args;
+    c->ss_have = false;
+    if (a.mode == 1 && c->d_ss_part && sa.batch == batch && sa.first_nb == a.first_nb) {
+      { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur, &sa, c->d_ss_part, &c->ss_run)); }
+      const SumsqArgs ja = sa; const int run = c->ss_run;
+      c->ss_queue.insert(c->ss_queue.begin(), [ja, run](lrh_ctx *c) -> int {
+        ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, c->d_ss_part, run, c->cur)); return LRH_OK; });
+    } else {                                             // pointers out of step: separate pass after all
+      { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
+      { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
+    }
+  } else { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
   // from now on the previous transform was routed with the current table
   if (c->pack_prev_stale) {
     HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->cur));
@@ -932,15 +963,29 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     a.points = afc ? (const int *)(d_inc + (size_t)batch * (1 + nchunks)) : nullptr;
     const size_t up_bytes = sizeof(float2) * (size_t)batch * (1 + nchunks) + sizeof(int) * (size_t)batch;
     const int mix1_n = c->mix1_n;
-    c->ph_pending[slot] = true;
-    LRH_DEVICE_WORK(c, {
-      HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->cur));
-      HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
-      c->ph_pending[slot] = false;
-      ProfScope ps(c, "mix1");
-      HIPCHK(c, launch_mix1_back(mix1_n, a, batch, c->cur));
-      HIPCHK(c, launch_mix1_out(o, batch, c->cur));
-    });
+    if (c->rec && c->early_upload) {
+      // parked kernels: the table goes up now on the upload stream (behind the kernels that last read this slot,
+      // which ev_tail / ev_side cover) and the kernels wait for it when they are finally launched
+      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_tail, 0));
+      HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->stream3));
+      HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream3));
+      LRH_DEVICE_WORK(c, {
+        HIPCHK(c, hipStreamWaitEvent(c->cur, c->ph_ev[slot], 0));
+        ProfScope ps(c, "mix1");
+        HIPCHK(c, launch_mix1_back(mix1_n, a, batch, c->cur));
+        HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+      });
+    } else {
+      c->ph_pending[slot] = true;
+      LRH_DEVICE_WORK(c, {
+        HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->cur));
+        HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
+        c->ph_pending[slot] = false;
+        ProfScope ps(c, "mix1");
+        HIPCHK(c, launch_mix1_back(mix1_n, a, batch, c->cur));
+        HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+      });
+    }
   } else {
     LRH_DEVICE_WORK(c, { ProfScope ps(c, "mix1"); HIPCHK(c, launch_mix1_out(o, batch, c->cur)); });
   }
@@ -1110,18 +1155,32 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
                                     c->host_cpu_ms_dsp += thread_cpu_ms() - cpu0; } } host_timer{c};
   int rc;
   const bool piped = c->pipeline && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
+  // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
+  const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
+  struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); } } fuse_guard{c};
+  auto sums = [&](int B) -> int {                // fft1_c: launches at once, or parked for the next make_timf2
+    c->ss_defer = fuse; const int r = lrh_fft1_c(c, p, B); c->ss_defer = false; return r;
+  };
+  auto sums_follow = [&](hipStream_t st) -> int {   // what fft1_c left for after make_timf2 (join, slow average)
+    hipStream_t keep = c->cur; c->cur = st;
+    std::vector<std::function<int(lrh_ctx *)>> q; q.swap(c->ss_queue);
+    int r = LRH_OK;
+    for (auto &op : q) if ((r = op(c))) break;
+    c->cur = keep; return r;
+  };
   if (!piped) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
       if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
       advance_fft1(c, p, B);
-      if ((rc = lrh_fft1_c(c, p, B))) return rc;
+      if ((rc = c->cfg.second_fft_enable ? sums(B) : lrh_fft1_c(c, p, B))) return rc;
       if (!c->cfg.second_fft_enable) {           // wcw.c:1049-1081: fft1_c, then the narrowband side's fft1_mix1_fixed
         if ((rc = lrh_fft1_mix1_fixed(c, p, B))) return rc;
         nblocks -= B;
         continue;
       }
       if ((rc = lrh_make_timf2(c, p, B))) return rc;
+      if ((rc = sums_follow(c->cur))) return rc;
       if ((rc = lrh_first_noise_blanker(c, p))) return rc;
       if ((rc = round_tail(c, p))) return rc;
       nblocks -= B;
@@ -1149,6 +1208,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       q.clear(); return LRH_OK;
     };
     HIPCHK(c, hipEventRecord(c->ev_side, S1)); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_side, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_side, 0));
     int left = nblocks, round = 0;
     int B = left < batch ? left : batch;
     bool have_prev = false, tail_flushed = false;
@@ -1172,14 +1232,17 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     };
     while (left > 0) {
       const int Bnext = (left - B) < batch ? (left - B) : batch;
-      on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
-      if ((rc = lrh_fft1_c(c, p, B))) return rc;
-      HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
+      // side: the blanker first -- fft2(k-1) on the main stream waits for it, the sums have a whole round of slack
       if (have_prev && (rc = side_blanker())) return rc;
+      hipEvent_t ev_t2 = round & 1 ? c->ev_timf2b : c->ev_timf2;
+      if (!fuse) { on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0)); }
+      if ((rc = sums(B))) return rc;
       on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
-      HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
+      HIPCHK(c, hipEventRecord(ev_t2, S1));
+      if (fuse) { HIPCHK(c, hipStreamWaitEvent(S2, ev_t2, 0)); if ((rc = sums_follow(S2))) return rc; }
+      HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
       // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
-      qb.push_back([](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_timf2, 0)); return LRH_OK; });
+      qb.push_back([ev_t2](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, ev_t2, 0)); return LRH_OK; });
       c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
       if (rc) return rc;
       if (Bnext > 0) {
@@ -1209,8 +1272,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   advance_fft1(c, p, B);
   HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
   on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
-  if ((rc = lrh_fft1_c(c, p, B))) return rc;
-  HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
+  if ((rc = sums(B))) return rc;
+  if (!fuse) HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
   while (left > 0) {
     const int Bnext = (left - B) < batch ? (left - B) : batch;       // size of round k+1 (0 at the end)
     // main: timf2(k)
@@ -1218,6 +1281,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
     // side: blanker(k)
     on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_timf2, 0));
+    if (fuse) { if ((rc = sums_follow(S2))) return rc; HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2)); }
     if ((rc = lrh_first_noise_blanker(c, p))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_blank, S2));
     if (Bnext > 0) {
@@ -1229,8 +1293,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
       // side: sumsq/slowsum(k+1)
       on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
-      if ((rc = lrh_fft1_c(c, p, Bnext))) return rc;
-      HIPCHK(c, hipEventRecord(c->ev_sumsq[(round + 1) & 1], S2));
+      if ((rc = sums(Bnext))) return rc;
+      if (!fuse) HIPCHK(c, hipEventRecord(c->ev_sumsq[(round + 1) & 1], S2));
     }
     // main: fft2(k) + mix1(k) after the blanker released the data; their power sums / waterfall go to the side stream
     on(S1); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));

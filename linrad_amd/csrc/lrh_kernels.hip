@@ -214,6 +214,31 @@ __global__ __launch_bounds__(256) void k_sumsq(SumsqArgs a)
   dst[i] = acc;
 }
 
+// Averaging groups that k_timf2<.., SS> could not finish inside one workgroup's run: add the pieces in transform order.
+__global__ __launch_bounds__(256) void k_sumsq_join(SumsqArgs a, const float *part, int run)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  // blockIdx.y = w < nruns: the group that run w finds already begun, taken by the first run that starts inside it;
+  // blockIdx.y = nruns: the unfinished last group of the call when it began inside the last run
+  const int nruns = (a.batch + run - 1) / run, y = blockIdx.y;
+  const int g = y < nruns ? (y * run + a.c0) / a.avg : (a.batch - 1 + a.c0) / a.avg;
+  const int gs = g * a.avg - a.c0;                       // first transform of the group (< 0: it continues an earlier call)
+  const int start = gs < 0 ? 0 : gs;
+  int end = gs + a.avg; if (end > a.batch) end = a.batch;
+  const int w0 = start / run, w1 = (end - 1) / run;
+  if (y < nruns) { if (!(gs < y * run && (y == 0 || gs >= (y - 1) * run))) return; }
+  else if (!(gs >= (nruns - 1) * run && gs + a.avg > a.batch)) return;
+  float *dst = a.sumsq + ((a.pa0 + g * a.n) & a.sumsq_mask);
+  float acc = 0.f; bool first = gs >= 0;
+  if (!first) acc = dst[i];
+  for (int w = w0; w <= w1; w++) {
+    const float v = part[(size_t)(2 * w + (gs < w * run ? 0 : 1)) * a.n + i];
+    acc = first ? v : acc + v; first = false;
+  }
+  dst[i] = acc;
+}
+
 #define LRH_FFT1_SMALL 0.00000001F
 __global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
 {
@@ -307,7 +332,13 @@ __device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x
     }
 }
 
-template <int LOG2N, int MODE>
+// SS: fft1_c's power sums ride along (fft1.c:4115-4171).  The masked loads of the two streams together are exactly
+// the transform's spectrum, so sum |X|^2 costs two FMAs per bin here instead of a second pass over the fft1 ring.  A
+// workgroup then takes a run of consecutive transforms and keeps the running sums of the current averaging group in
+// registers; a group that lies inside one run goes straight to the fft1_sumsq ring (same additions in the same order
+// as the reference), the pieces of a group that straddles runs (or continues an earlier call) go to `ss_part` and
+// k_sumsq_join adds them up in order.
+template <int LOG2N, int MODE, bool SS>
 __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_timf2(Timf2Args a)
 {
   constexpr int P = points_per_thread(LOG2N);
@@ -350,14 +381,42 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
       }
     }
   };
+  float acc[SS ? P : 1];
+  if constexpr (SS) {
+#pragma unroll
+    for (int e = 0; e < P; e++) acc[e] = 0.f;
+  }
   auto combine = [&](float2 (&x)[P], int tid) {
     // sin^2 overlap: S_t + (-1)^k S_{t-1}; k = tid + even offsets, so the sign is one per thread
     const float sg = (tid & 1) ? -1.f : 1.f;
 #pragma unroll
     for (int e = 0; e < P; e++) {
+      if constexpr (SS) acc[e] += c[e].x * c[e].x + c[e].y * c[e].y;   // a bin is zero in one of the two streams
       if constexpr (MODE == 1) x[e] = make_float2(c[e].x + sg * pv[e].x, c[e].y + sg * pv[e].y);
       else x[e] = c[e];
     }
+    if constexpr (SS) {
+      // the sums are due here: left to the scheduler they sink into the transform and keep the spectrum alive with them
+#pragma unroll
+      for (int e = 0; e < P; e++) asm volatile("" : "+v"(acc[e]));
+    }
+  };
+  // end of an averaging group or of this workgroup's run: the sums leave the registers
+  auto flush_sums = [&](int b, int r0, int r1, int tid) {
+    const int gb = b + a.ss_c0, g = gb / a.ss_avg;
+    const bool group_end = gb - g * a.ss_avg == a.ss_avg - 1;
+    if (!group_end && b != r1 - 1) return;
+    const bool head = g * a.ss_avg - a.ss_c0 < r0;       // began in an earlier run (or an earlier call)
+    float *dst;
+    if (!head && group_end) dst = a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask);
+    else dst = a.ss_part + (size_t)(2 * blockIdx.x + (head ? 0 : 1)) * N;
+#pragma unroll
+    for (int m = 0; m < NB0; m++)
+#pragma unroll
+      for (int s = 0; s < R0; s++) {
+        (dst + m * T + s * (N / R0))[(unsigned int)tid] = acc[m * R0 + s];
+        acc[m * R0 + s] = 0.f;
+      }
   };
   // Pins the transform's live outputs in registers at this point: without it the last butterflies sink below the
   // prefetch (towards the stores that use them) and their 16 inputs stay live across 32 loads in flight.
@@ -368,17 +427,22 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
       if (MODE != 1 || (e % RL) < RL / 2) asm volatile("" : "+v"(x[e].x), "+v"(x[e].y));
     asm volatile("" ::: "memory");
   };
-  int bi = blockIdx.x;
-  if (bi < a.batch) issue(a.xcd ? xcd_order(bi, a.batch) : bi, 0, tid0);
+  // items: interleaved over the grid (XCD-aware order), or with SS a run of consecutive transforms per workgroup
+  const int stride = SS ? 1 : (int)gridDim.x;
+  const int r0 = SS ? (int)blockIdx.x * a.ss_run : 0;
+  const int r1 = SS ? min(r0 + a.ss_run, a.batch) : a.batch;
+  auto order = [&](int i) { return (!SS && a.xcd) ? xcd_order(i, a.batch) : i; };
+  int bi = SS ? r0 : (int)blockIdx.x;
+  if (bi < r1) issue(order(bi), 0, tid0);
   __syncthreads();                                       // twiddle tables are in place
   __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): retire the prologue's loads here (see k_fft1)
 #pragma unroll 1
-  for (; bi < a.batch; bi += gridDim.x) {
+  for (; bi < r1; bi += stride) {
     // opaque per-iteration copy of the thread index: without it LICM hoists every address and LDS index of the
     // transform out of the loop and parks them in ~200 VGPRs (spills at 1024 threads)
     int tid = tid0;
     asm volatile("" : "+v"(tid));
-    const int b = a.xcd ? xcd_order(bi, a.batch) : bi;
+    const int b = order(bi);
     const int pa = a.pa_first + b * a.step;
     float2 x[P];
     combine(x, tid);
@@ -389,13 +453,14 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
     __builtin_amdgcn_sched_barrier(0);
     timf2_store<LOG2N, MODE, 0>(a, x, pa, tid);         // no barrier: BlockFftL protects its buffer itself
     combine(x, tid);
+    if constexpr (SS) flush_sums(b, r0, r1, tid);
     Fft::run(x, lds, tid);
     pin(x);
     __builtin_amdgcn_sched_barrier(0);
     // unconditional (the last trip re-reads its own transform): a conditional prefetch would keep the old c/pv
     // alive across the transform above
-    const int bn = min(bi + (int)gridDim.x, a.batch - 1);
-    issue(a.xcd ? xcd_order(bn, a.batch) : bn, 0, tid);
+    const int bn = min(bi + stride, r1 - 1);
+    issue(order(bn), 0, tid);
     __builtin_amdgcn_sched_barrier(0);
     timf2_store<LOG2N, MODE, 1>(a, x, pa, tid);
   }
@@ -1156,9 +1221,13 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   } while (0)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
-    if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);      \
-    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
-    else hipLaunchKernelGGL((k_timf2<L, 2>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);                  \
+    if (a.ss_ring) {                                                                                        \
+      a.ss_run = (batch + fftl_grid<L>(batch) - 1) / fftl_grid<L>(batch);                                   \
+      hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3((batch + a.ss_run - 1) / a.ss_run), dim3(fft_threads(L)), 0, st, a); \
+    }                                                                                                       \
+    else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);      \
+    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
+    else hipLaunchKernelGGL((k_timf2<L, 2, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);                  \
   } while (0)
 #define LRH_LAUNCH_FFT2(L, a, batch, st)                                                                              \
   do {                                                                                                                \
@@ -1188,10 +1257,34 @@ hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
   LRH_DISPATCH(LRH_LAUNCH_FFT1, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }
-hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t st)
+#define LRH_TIMF2_GRID(L, out, batch) out = fftl_grid<L>(batch)
+int timf2_grid(int log2n, int batch)
+{
+  int g = 0;
+  switch (log2n) {
+    case 6: LRH_TIMF2_GRID(6, g, batch); break; case 7: LRH_TIMF2_GRID(7, g, batch); break; case 8: LRH_TIMF2_GRID(8, g, batch); break;
+    case 9: LRH_TIMF2_GRID(9, g, batch); break; case 10: LRH_TIMF2_GRID(10, g, batch); break; case 11: LRH_TIMF2_GRID(11, g, batch); break;
+    case 12: LRH_TIMF2_GRID(12, g, batch); break; case 13: LRH_TIMF2_GRID(13, g, batch); break; case 14: LRH_TIMF2_GRID(14, g, batch); break;
+    default: break;
+  }
+  return g;
+}
+// With `ss` (mode 1 only) the launch also produces fft1_c's power sums of the same transforms: see k_timf2<.., SS>.
+hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t st, const SumsqArgs *ss, float *ss_part, int *ss_run)
 {
   Timf2Args a = a0; a.batch = batch;
+  a.ss_ring = nullptr;
+  if (ss) {
+    if (a.mode != 1 || ss->batch != batch || ss->first_nb != a.first_nb || ss->n != (1 << log2n) || !ss_part) return hipErrorInvalidValue;
+    a.ss_ring = ss->sumsq; a.ss_part = ss_part; a.ss_mask = ss->sumsq_mask; a.ss_avg = ss->avg; a.ss_c0 = ss->c0; a.ss_pa0 = ss->pa0;
+  }
   LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
+  if (ss && ss_run) *ss_run = a.ss_run;
+  return hipGetLastError();
+}
+hipError_t launch_sumsq_join(const SumsqArgs &a, const float *part, int run, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_sumsq_join, dim3((a.n + 255) / 256, (a.batch + run - 1) / run + 1), dim3(256), 0, st, a, part, run);
   return hipGetLastError();
 }
 hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)

@@ -58,6 +58,9 @@ struct Timf2Args {
   float ampfac;
   int xcd;
   int batch;                // transforms in this launch (set by launch_timf2)
+  // fused fft1_c power sums (set by launch_timf2 when it is handed a SumsqArgs): ring, pieces of groups that straddle
+  // workgroup runs [grid][2][N], transforms per workgroup
+  float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0, ss_run;
 };
 
 // ---- blanker ----

@@ -205,3 +205,29 @@ def test_stream_schedules_are_bit_identical(fft2_n, monkeypatch):
         assert other[1] == res[0][1] and other[2] == res[0][2]
         for a, b in zip(res[0][0], other[0]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n1,batch,calls", [(10, 7, (23, 9, 40)), (14, 16, (48, 13)), (11, 300, (700, 300)), (9, 1, (11,))])
+def test_power_sums_inside_timf2_match_separate_pass(n1, batch, calls, monkeypatch):
+    """lrh_wideband_dsp computes fft1_c's power sums inside the timf2 kernel (averaging groups split over workgroup runs
+    are joined afterwards).  Against the separate k_sumsq pass: same sums up to the association of five float adds,
+    for batches that are no multiple of fft_avg1num, calls that end inside a group and one-transform runs."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(n1, n1 - 2, batch=batch)
+    s = synth_defaults(1 << n1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, n1)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LRH_FUSE_SUMSQ", mode)
+        rx = _hip(cfg)
+        _feed(rx, iq, lim, 100.3)
+        for n in calls:
+            rx.wideband_dsp(n, batch)
+        res.append((rx.export(abi.RING_FFT1_SUMSQ), rx.export(abi.RING_FFT1_SLOWSUM), rx.export(abi.RING_TIMF2_FLOAT), rx.p.as_dict()))
+    (sq1, sl1, t1, p1), (sq0, sl0, t0, p0) = res
+    assert p1 == p0
+    assert np.array_equal(t1, t0)                                        # the transform itself is untouched
+    assert np.max(np.abs(sq1 - sq0) / (np.abs(sq0) + 1e-30)) < 1e-6
+    assert np.max(np.abs(sl1 - sl0) / (np.abs(sl0) + 1e-30)) < 2e-6
+    assert np.count_nonzero(sq0) > 0
