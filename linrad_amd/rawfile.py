@@ -7,7 +7,7 @@ recordings, the header writer of modesub.c:1515-1600 with `compress_rawdat_disk`
 device expands (`lrh_timf1_write_packed18`) exactly like `expand_rawdat` (csplit.c:20-73).
 
 The header layout is restated from the reference source; the 18-bit packing is pinned against the compiled
-reference (tests/golden/rawdat_18bit.npz).  WAV input (`rcvr`/`auxi` chunks) is not handled here.
+reference (tests/golden/rawdat_18bit.npz).  WAV input (`rcvr`/`auxi` chunks): linrad_amd/wavfile.py.
 """
 import struct
 from dataclasses import dataclass, field

@@ -72,3 +72,47 @@ def test_recording_plays_through_the_chain(tmp_path, dword):
     for k in ("fft1", "fft2", "timf3"):
         a, b = hh[k].astype(np.float64), oo[k].astype(np.float64)
         assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b), k
+
+
+@pytest.mark.parametrize("fmt", ["pcm16", "pcm24"])
+def test_wav_recording_plays_through_the_chain(tmp_path, fmt):
+    """A .wav recording (16-bit as written by write_wav with a Perseus chunk; 24-bit PCM built by hand) through
+    WavReader into the HIP chain and the oracle: same ring image, same spectra."""
+    import struct
+    from linrad_amd import wavfile
+    dword = fmt == "pcm24"
+    d = case_params("n10_n12_dword" if dword else "n10_n12")
+    d["nblk"] = 24
+    iq, lim = make_input(d), make_liminfo(d)
+    path = tmp_path / "rec.wav"
+    if dword:
+        b = (iq.astype(np.int64) >> 8).astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()   # top 24 bits
+        body = b"WAVEfmt " + struct.pack("<ihhiihh", 16, 1, 2, 2_000_000, 12_000_000, 6, 24) + b"data" + struct.pack("<i", len(b)) + b
+        path.write_bytes(b"RIFF" + struct.pack("<i", len(body)) + body + b"\x7f" * 40)     # trailing non-sample bytes
+    else:
+        wavfile.write_wav(path, iq, 2_000_000, 2, proprietary=(b"rcvr", struct.pack("<IIq", 144_300_000, 4, 1_700_000_000)))
+    cfg = lrh_config(d, iq)
+    cfg.sample_shift = 0
+    out = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        rd = wavfile.WavReader(str(path))
+        assert rd.header.dword == dword and rd.header.rx_ad_speed == 2_000_000 and rd.header.rx_ad_channels == 2
+        if not dword:
+            assert rd.header.passband_center == pytest.approx(144.3)
+        nbytes = rd.feed(rx)
+        rx.set_liminfo(lim)
+        rx.set_mix1_selfreq(d["fq"])
+        rx.wideband_dsp(d["nblk"], 4)
+        out.append({k: rx.export(r) for r, k in ((abi.RING_TIMF1, "timf1"), (abi.RING_FFT1_FLOAT, "fft1"),
+                                                 (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_TIMF3_FLOAT, "timf3"))})
+    hh, oo = out
+    assert np.array_equal(hh["timf1"], oo["timf1"])
+    if dword:
+        n = nbytes // 4
+        assert np.array_equal(hh["timf1"].view(np.int32)[:n], (iq[:n] >> 8) << 8)          # 24 bits survive, left-justified
+    else:
+        assert np.array_equal(hh["timf1"][:nbytes // 2], iq[:nbytes // 2])
+    for k in ("fft1", "fft2", "timf3"):
+        a, b = hh[k].astype(np.float64), oo[k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b), k
