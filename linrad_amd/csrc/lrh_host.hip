@@ -335,7 +335,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
   if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
   // one workgroup per waterfall averaging group keeps the power sums in registers; long groups would starve the chip
-  c->fft2_fused = cfg->second_fft_enable && cfg->fft2_n <= LRH_FFT2_FUSED_MAXLOG && cfg->waterfall_avgnum >= 1 && cfg->waterfall_avgnum <= 16;
+  c->fft2_fused = cfg->second_fft_enable && (cfg->fft2_n <= LRH_FFT2_FUSED_MAXLOG || cfg->fft2_n > 14) && cfg->waterfall_avgnum >= 1 && cfg->waterfall_avgnum <= 16;
   if (const char *e = getenv("LRH_FFT2_FUSED")) c->fft2_fused = c->fft2_fused && atoi(e) != 0;
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
              cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
@@ -807,6 +807,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
   g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
   g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
+  g.ps_in = a.ps_in; g.ps_out = a.ps_out; g.wf_scratch = a.wf_scratch; g.ps_counter = a.ps_counter; g.ps_avgnum = a.ps_avgnum; g.batch = batch;
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;

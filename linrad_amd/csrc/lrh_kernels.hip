@@ -910,7 +910,10 @@ __global__ __launch_bounds__(1024) void k_fft2_cols(Fft2BigArgs a)
   }
 }
 
-template <int LA, int LB>
+// FUSED: blockIdx.y is a waterfall averaging group instead of a transform; the workgroup walks the group's
+// transforms and keeps sum |X|^2 of its bins in registers (k_fft2's scheme), so neither the fft2_power ring nor the
+// k_powersum2 pass over it is needed.
+template <int LA, int LB, bool FUSED>
 __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
 {
   constexpr int P = sub_ppt(LB);
@@ -919,30 +922,64 @@ __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
   constexpr int CS = Plan::LDS_CELLS + 1;
   __shared__ float2 lds[LRH_TILE * CS];
   const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
-  const int b = blockIdx.y, k1 = blockIdx.x * LRH_TILE + c;
-  const float2 *sc = a.scratch + (size_t)b * NA * NB;
-  float2 x[P];
+  const int k1 = blockIdx.x * LRH_TILE + c;
+  int t_first = blockIdx.y, t_end = t_first + 1;
+  bool ps_continue = false, ps_complete = false;
+  const int g = blockIdx.y;
+  if constexpr (FUSED) {                                 // group arithmetic of k_powersum2
+    t_first = g == 0 ? 0 : g * a.ps_avgnum - a.ps_counter;
+    int count = a.ps_avgnum - (g == 0 ? a.ps_counter : 0);
+    ps_complete = count <= a.batch - t_first;
+    if (!ps_complete) count = a.batch - t_first;
+    t_end = t_first + count;
+    ps_continue = g == 0 && a.ps_counter > 0;
+  }
+  float acc[FUSED ? P : 1];
+  if constexpr (FUSED) {
 #pragma unroll
-  for (int m = 0; m < P / R0; m++)
+    for (int m = 0; m < P / RL; m++)
 #pragma unroll
-    for (int s = 0; s < R0; s++) {
-      const int n2 = (l + m * T) + s * (NB / R0);
-      x[m * R0 + s] = sc[(size_t)n2 * NA + k1];
-    }
-  BlockFft<LB, P, +1>::run(x, lds + c * CS, a.tw_b, l);
-  const int na = (a.first_na + b) & a.na_mask;
-  float2 *out = a.out + (size_t)na * NA * NB;
-  float *pw = a.power + (size_t)na * NA * NB;
+      for (int q = 0; q < RL; q++) acc[m * RL + q] = ps_continue ? a.ps_in[k1 + NA * ((l + m * T) + q * (NB / RL))] : 0.f;
+  }
+#pragma unroll 1
+  for (int b = t_first; b < t_end; b++) {
+    const float2 *sc = a.scratch + (size_t)b * NA * NB;
+    float2 x[P];
 #pragma unroll
-  for (int m = 0; m < P / RL; m++)
+    for (int m = 0; m < P / R0; m++)
 #pragma unroll
-    for (int q = 0; q < RL; q++) {
-      const int k2 = (l + m * T) + q * (NB / RL);
-      const int k = k1 + NA * k2;
-      const float2 v = x[m * RL + q];
-      out[k] = v;
-      pw[k] = v.x * v.x + v.y * v.y;
-    }
+      for (int s = 0; s < R0; s++) {
+        const int n2 = (l + m * T) + s * (NB / R0);
+        x[m * R0 + s] = sc[(size_t)n2 * NA + k1];
+      }
+    BlockFft<LB, P, +1>::run(x, lds + c * CS, a.tw_b, l);
+    const int na = (a.first_na + b) & a.na_mask;
+    float2 *out = a.out + (size_t)na * NA * NB;
+    float *pw = a.power + (size_t)na * NA * NB;
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int k2 = (l + m * T) + q * (NB / RL);
+        const int k = k1 + NA * k2;
+        const float2 v = x[m * RL + q];
+        out[k] = v;
+        const float p2 = v.x * v.x + v.y * v.y;
+        if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
+        else pw[k] = p2;
+      }
+    if constexpr (FUSED) __syncthreads();                // the next transform reuses the exchange buffer
+  }
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) {
+        const int k = k1 + NA * ((l + m * T) + q * (NB / RL));
+        if (ps_complete) a.wf_scratch[(size_t)g * NA * NB + k] = acc[m * RL + q];
+        if (g == (int)gridDim.y - 1) a.ps_out[k] = acc[m * RL + q];
+      }
+  }
 }
 
 // fft2_powersum_float (fft2.c:655-670): group g = one waterfall averaging period; complete groups are parked in
@@ -1309,10 +1346,15 @@ hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)
   LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }
-template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a, int batch, hipStream_t st)
+template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, int batch, hipStream_t st)
 {
+  Fft2BigArgs a = a0; a.batch = batch;
   hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
-  hipLaunchKernelGGL((k_fft2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  if (a.ps_avgnum > 0)
+    hipLaunchKernelGGL((k_fft2_rows<LA, LB, true>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),
+                       dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_fft2_rows<LA, LB, false>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }
 hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st)
 {

@@ -103,6 +103,8 @@ struct Fft2BigArgs {
   const float2 *tw_a, *tw_b, *tw_big;         // forward tables of size NA, NB and N2
   float2 *scratch;                            // [batch][NB][NA]
   float2 *out; float *power; int first_na, na_mask;
+  // fused power sums as in Fft2Args (ps_avgnum > 0): the rows kernel takes one averaging group per blockIdx.y
+  const float *ps_in; float *ps_out; float *wf_scratch; int ps_counter; int ps_avgnum; int batch;
 };
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
