@@ -866,47 +866,69 @@ hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t 
 #define LRH_TILE 16
 __host__ __device__ constexpr int sub_ppt(int log2l) { return log2l >= 9 ? 8 : 4; }   // 64 threads per sub-transform
 
+// A workgroup takes a.run consecutive transforms of its column tile: the step twiddles are the same for all of
+// them (registers), the window values come from the cache, and with the 50 % overlap of the windowed fft2 (step = N/2) the second half of transform t
+// (n1 >= NA/2, which is element s >= R0/2 of the same thread) is the first half of t+1, so its weak+strong sum stays
+// in registers and a transform after the first costs half the loads.
 template <int LA, int LB>
-__global__ __launch_bounds__(1024) void k_fft2_cols(Fft2BigArgs a)
+__global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs a)
 {
   constexpr int P = sub_ppt(LA);
   using Plan = FftPlan<LA, P>;
-  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL, H = R0 / 2;
   constexpr int CS = Plan::LDS_CELLS + 1;               // odd column stride: tile columns land on different banks
   __shared__ float2 lds[LRH_TILE * CS];
-  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
-  const int b = blockIdx.y, n2 = blockIdx.x * LRH_TILE + c;
-  const int px = a.px_first + b * a.step;
-  float2 x[P];
-#pragma unroll
-  for (int m = 0; m < P / R0; m++)
-#pragma unroll
-    for (int s = 0; s < R0; s++) {
-      const int n1 = (l + m * T) + s * (NA / R0);
-      const int n = NB * n1 + n2;
-      const int r = (px + n) & a.mask;
-      const float2 vw = a.timf2w[r], vs = a.timf2s[r];
-      const float w = a.window[n];
-      x[m * R0 + s] = make_float2(w * (vw.x + vs.x), w * (vw.y + vs.y));
-    }
-  float2 *col = lds + c * CS;
-  BlockFft<LA, P, +1>::run(x, col, a.tw_a, l);
-  __syncthreads();
-  // twiddle w_N^(n2 k1) (e^{+j}: conjugate of the forward table), then park as col[k1]
+  const int c0 = threadIdx.x & (LRH_TILE - 1), l0 = threadIdx.x >> 4;
+  const int n20 = blockIdx.x * LRH_TILE + c0;
+  const int t_first = blockIdx.y * a.run, t_end = min(t_first + a.run, a.batch);
+  const bool overlap = a.step * 2 == NA * NB;
+  float2 twk[P], keep[P / 2];
 #pragma unroll
   for (int m = 0; m < P / RL; m++)
 #pragma unroll
-    for (int q = 0; q < RL; q++) {
-      const int k1 = (l + m * T) + q * (NA / RL);
-      const float2 w = a.tw_big[(n2 * k1) & (NA * NB - 1)];
-      col[k1] = cmul(x[m * RL + q], make_float2(w.x, -w.y));
+    for (int q = 0; q < RL; q++) {                       // w_N^(n2 k1), e^{+j}: conjugate of the forward table
+      const float2 w = a.tw_big[(n20 * ((l0 + m * T) + q * (NA / RL))) & (NA * NB - 1)];
+      twk[m * RL + q] = make_float2(w.x, -w.y);
     }
-  __syncthreads();
-  // store scratch[n2][k1], k1 fastest: thread t handles k1 = t mod NA of tile row t / NA, 1024/NA rows per sweep
-  float2 *sc = a.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
-  for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
-    const int cc = e / NA, k1 = e - cc * NA;
-    sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+#pragma unroll 1
+  for (int b = t_first; b < t_end; b++) {
+    // opaque per-iteration copies of the lane coordinates: keeps the address arithmetic inside the loop (see k_timf2)
+    int l = l0, n2 = n20, c = c0;
+    asm volatile("" : "+v"(l), "+v"(n2), "+v"(c));
+    float2 *col = lds + c * CS;
+    const int px = a.px_first + b * a.step;
+    const bool reuse = overlap && b > t_first;
+    float2 x[P];
+#pragma unroll
+    for (int m = 0; m < P / R0; m++)
+#pragma unroll
+      for (int s = 0; s < R0; s++) {
+        float2 raw;
+        if (s < H && reuse) raw = keep[m * H + s];
+        else {
+          const int r = (px + NB * ((l + m * T) + s * (NA / R0)) + n2) & a.mask;
+          const float2 vw = a.timf2w[r], vs = a.timf2s[r];
+          raw = make_float2(vw.x + vs.x, vw.y + vs.y);     // weak + strong (fft2.c:100-105)
+        }
+        const float w = a.window[NB * ((l + m * T) + s * (NA / R0)) + n2];      // cache hits after the first transform
+        x[m * R0 + s] = make_float2(w * raw.x, w * raw.y);
+        if (s >= H) keep[m * H + s - H] = raw;
+      }
+    BlockFft<LA, P, +1>::run(x, col, a.tw_a, l);
+    __syncthreads();
+    // step twiddle, then park as col[k1]
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) col[(l + m * T) + q * (NA / RL)] = cmul(x[m * RL + q], twk[m * RL + q]);
+    __syncthreads();
+    // store scratch[n2][k1], k1 fastest: thread t handles k1 = t mod NA of tile row t / NA, 1024/NA rows per sweep
+    float2 *sc = a.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
+    for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
+      const int cc = e / NA, k1 = e - cc * NA;
+      sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+    }
+    __syncthreads();                                     // the next transform reuses the buffer
   }
 }
 
@@ -1349,7 +1371,14 @@ hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)
 template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, int batch, hipStream_t st)
 {
   Fft2BigArgs a = a0; a.batch = batch;
-  hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  {
+    // transforms per workgroup: enough workgroups left to fill the chip a few times over
+    const int tiles = (1 << LB) / LRH_TILE;
+    const char *e = getenv("LRH_FFT2_COLS_RUN");
+    int run = e ? atoi(e) : batch * tiles / 512;
+    a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
+  }
+  hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
   if (a.ps_avgnum > 0)
     hipLaunchKernelGGL((k_fft2_rows<LA, LB, true>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),
                        dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);

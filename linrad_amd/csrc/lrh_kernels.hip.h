@@ -105,6 +105,7 @@ struct Fft2BigArgs {
   float2 *out; float *power; int first_na, na_mask;
   // fused power sums as in Fft2Args (ps_avgnum > 0): the rows kernel takes one averaging group per blockIdx.y
   const float *ps_in; float *ps_out; float *wf_scratch; int ps_counter; int ps_avgnum; int batch;
+  int run;                  // consecutive transforms per workgroup of the column step (set by launch_fft2_big)
 };
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;

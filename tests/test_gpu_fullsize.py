@@ -231,3 +231,28 @@ def test_power_sums_inside_timf2_match_separate_pass(n1, batch, calls, monkeypat
     assert np.max(np.abs(sq1 - sq0) / (np.abs(sq0) + 1e-30)) < 1e-6
     assert np.max(np.abs(sl1 - sl0) / (np.abs(sl0) + 1e-30)) < 2e-6
     assert np.count_nonzero(sq0) > 0
+
+
+@pytest.mark.parametrize("fft2_n", [15, 16])
+def test_four_step_fft2_runs_of_transforms_are_bit_identical(fft2_n, monkeypatch):
+    """N2 > 16384: a column-step workgroup that takes several consecutive transforms keeps the overlapping half of the
+    input in registers.  Same arithmetic on the same values: every run length must give the same bits as run = 1
+    (which test_fullsize_chain_matches_oracle pins against the oracle)."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(14, fft2_n, batch=16)
+    s = synth_defaults(N1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 14)
+    res = []
+    for run in ("1", "3", "8"):
+        monkeypatch.setenv("LRH_FFT2_COLS_RUN", run)
+        rx = _hip(cfg)
+        _feed(rx, iq, lim, 0.31 * (1 << fft2_n) + 0.3)
+        rx.wideband_dsp(64, 16)
+        rx.wideband_dsp(32, 16)
+        res.append([rx.export(r) for r in (abi.RING_FFT2_FLOAT, abi.RING_FFT2_POWERSUM, abi.RING_FFT2_POWER, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF)])
+        assert rx.p.fft2_na > 0
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+    assert np.count_nonzero(res[0][0]) > 0
