@@ -195,6 +195,11 @@ int lrh_set_liminfo(lrh_ctx *ctx, const float *liminfo /* N1 floats, 0 = weak (t
    the transform's bin order; every bin is orthogonalised against its mirror image before the filter correction.
    NULL switches it off (the default: uncalibrated). */
 int lrh_set_foldcorr(lrh_ctx *ctx, const float *fft1_foldcorr);
+/* Phasing of the second RF channel, pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:160-170): fft1_b ends by turning every bin of
+   channel 2 by (c1 - j c2) (fft1.c:4064-4080).  Channels are sharded one per context here, so the context that carries
+   the second channel is given the pair; (1, 0) = off (the default).  The constant is folded into the filter correction
+   that follows it in fft1_c. */
+int lrh_set_ch2_phasing(lrh_ctx *ctx, float c1, float c2);
 int lrh_set_waterfall_yfac(lrh_ctx *ctx, const float *wg_waterf_yfac /* N1 floats, NULL: make_wg_yfac default */);
 int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "fft1_window","fft2_window",
                                                                      "mix1_fqwin","fft1_filtercorr","wg_waterf_yfac" */

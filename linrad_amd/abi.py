@@ -158,6 +158,7 @@ class StageAPI:
         self._proto("set_filtercorr", [vp, fp])
         self._proto("set_liminfo", [vp, fp])
         self._proto("set_foldcorr", [vp, fp])
+        self._proto("set_ch2_phasing", [vp, C.c_float, C.c_float])
         self._proto("set_waterfall_yfac", [vp, fp])
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
@@ -237,6 +238,10 @@ class StageAPI:
             t = np.ascontiguousarray(foldcorr, np.float32)
             assert t.size == 2 * self.N1
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
+
+    def set_ch2_phasing(self, c1, c2):
+        """pg_ch2_c1 / pg_ch2_c2 for the context that carries the second RF channel (fft1.c:4064-4080)."""
+        self._chk(self._f("set_ch2_phasing")(self.ctx, float(c1), float(c2)), "set_ch2_phasing")
 
     def set_liminfo(self, lim):
         lim = np.ascontiguousarray(lim, np.float32)

@@ -72,6 +72,7 @@ struct lrh_ctx {
   bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
   float *d_ss_part = nullptr;
   std::vector<std::function<int(lrh_ctx *)>> ss_queue;
+  float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
   // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
@@ -502,14 +503,36 @@ void lrh_ptrs_init(const lrh_ctx *c, lrh_ptrs *p)
   p->fft1_lowlevel_fraction = .75f;        // buf.c:343
 }
 
+// device copy of the filter correction = table x channel phasing constant (both multiply every bin, one after the other,
+// fft1.c:4064-4080 then 4119-4127)
+static int upload_filtercorr(lrh_ctx *c)
+{
+  std::vector<float> eff(c->h_filtercorr);
+  if (c->ch2_c1 != 1.0f || c->ch2_c2 != 0.0f)
+    for (int i = 0; i < c->N1; i++) {
+      const float a = c->h_filtercorr[2 * i], b = c->h_filtercorr[2 * i + 1];
+      eff[2 * i] = a * c->ch2_c1 + b * c->ch2_c2;          // (a + jb)(c1 - j c2)
+      eff[2 * i + 1] = b * c->ch2_c1 - a * c->ch2_c2;
+    }
+  HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, eff.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
 int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 {
   if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c) return LRH_EINVAL;
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, c->h_filtercorr.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return LRH_OK;
+  return upload_filtercorr(c);
+}
+
+int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c) return LRH_EINVAL;
+  c->ch2_c1 = c1; c->ch2_c2 = c2;
+  return upload_filtercorr(c);
 }
 
 int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)

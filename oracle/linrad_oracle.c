@@ -33,6 +33,7 @@ struct lro_ctx {
   float *fft2_window;          /* mode 4, N2 */
   float *mix1_fqwin;           /* mode 5, Nm/2+1 */
   float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
+  float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
   float *liminfo;
@@ -326,6 +327,7 @@ int lro_get_derived(const lro_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t
 
 int lro_set_filtercorr(lro_ctx *c, const float *fc) { if (fc) memcpy(c->fft1_filtercorr, fc, 8 * c->N1); else default_filtercorr(c); return LRH_OK; }
 int lro_set_liminfo(lro_ctx *c, const float *l) { memcpy(c->liminfo, l, 4 * c->N1); return LRH_OK; }
+int lro_set_ch2_phasing(lro_ctx *c, float c1, float c2) { c->ch2_c1 = c1; c->ch2_c2 = c2; c->ch2_set = 1; return LRH_OK; }
 int lro_set_foldcorr(lro_ctx *c, const float *foldcorr)
 {
   if (!foldcorr) { free(c->fft1_foldcorr); c->fft1_foldcorr = NULL; return LRH_OK; }
@@ -436,6 +438,13 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
     }
     float t = out[2 * nn]; out[2 * nn] = out[2 * nn + 1]; out[2 * nn + 1] = t;
     t = out[0]; out[0] = out[1]; out[1] = t;
+  }
+  if (c->ch2_set && (c->ch2_c1 != 1.0F || c->ch2_c2 != 0.0F)) {   /* phasing of the second channel, fft1.c:4064-4080 (m = 0) */
+    for (int i = 0; i < N; i++) {
+      float t1 = out[2 * i], t2 = out[2 * i + 1];
+      out[2 * i] = t1 * c->ch2_c1 + t2 * c->ch2_c2;
+      out[2 * i + 1] = t2 * c->ch2_c1 - t1 * c->ch2_c2;
+    }
   }
 }
 

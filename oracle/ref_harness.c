@@ -125,6 +125,8 @@ int main(int argc, char **argv)
   int afc = AI("afc", 0);                        /* 1: fft2_mix1_afc / fft1_mix1_afc with a synthetic per-transform frequency */
   double afc_bw = AF("afc_bw", 20.0);            /* baseband_bw_hz */
   int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
+  int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
+  double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
   const char *fin = arg(argc, argv, "in", NULL);
   const char *flim = arg(argc, argv, "liminfo", NULL);
@@ -135,7 +137,9 @@ int main(int argc, char **argv)
 
   /* ---- ui / genparm ---- */
   memset(&ui, 0, sizeof(ui));
-  ui.rx_input_mode = IQ_DATA | (dword ? DWORD_INPUT : 0); ui.rx_rf_channels = 1; ui.rx_ad_channels = 2;
+  if (C != 1 && C != 2) { fprintf(stderr, "channels must be 1 or 2\n"); return 2; }
+  ui.rx_input_mode = IQ_DATA | (dword ? DWORD_INPUT : 0) | (C == 2 ? TWO_CHANNELS : 0); ui.rx_rf_channels = C; ui.rx_ad_channels = 2 * C;
+  pg_ch2_c1 = (float)ch2_c1; pg_ch2_c2 = (float)ch2_c2;
   ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
   genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
@@ -144,13 +148,13 @@ int main(int argc, char **argv)
   genparm[SECOND_FFT_ATT_N] = 8; genparm[MAX_NO_OF_SPURS] = 0; genparm[AFC_ENABLE] = 0; genparm[AFC_LOCK_RANGE] = 0;
   genparm[MIX1_BANDWIDTH_REDUCTION_N] = mixred; genparm[MIX1_NO_OF_CHANNELS] = 1;
   fft1mode = (ui.rx_input_mode & (TWO_CHANNELS + IQ_DATA)) / 2;
-  rx_channels = 1; twice_rxchan = 2; sw_onechan = 1; swfloat = 1; swmmx_fft2 = 0; swmmx_fft1 = 0;
+  rx_channels = C; twice_rxchan = 2 * C; sw_onechan = C == 1; swfloat = 1; swmmx_fft2 = 0; swmmx_fft1 = 0;
   kill_all_flag = 0; lir_status = 0; fft1_correlation_flag = 0; fft1afc_flag = 0; no_of_spurs = 0;
   ampinfo_flag = 0; audio_dump_flag = 0; fft1_use_gpu = 0; fft1_calibrate_flag = 0; fft1_direction = direction;
   yieldflag_wdsp_fft1 = 0; yieldflag_timf2_fft1 = 0; yieldflag_fft2_fft2 = 0; yieldflag_ndsp_mix1 = 0;
 
   /* ---- fft1 sizes and tables (buf.c:193-304, 1395-1459) ---- */
-  fft1_n = n1; fft1_size = N1; fft1_block = 2 * N1; fft1_muln = 1; fft1_mulblock = fft1_block;
+  fft1_n = n1; fft1_size = N1; fft1_block = 2 * C * N1; fft1_muln = 1; fft1_mulblock = fft1_block;
   {
     /* interleave: reference formula buf.c:303-304 with make_interleave_ratio (buf.c:113-136) */
     double ratio = 0;
@@ -172,9 +176,9 @@ int main(int argc, char **argv)
   fft1tab = zalloc(sizeof(COSIN_TABLE) * N1);
   fft1_permute = zalloc(sizeof(short) * N1 * 2);
   fft1_window = zalloc(sizeof(float) * (N1 + 32));
-  fft1_filtercorr = (float *)zalloc(sizeof(float) * (2 * N1 + 32)) + 8;
+  fft1_filtercorr = (float *)zalloc(sizeof(float) * (2 * C * N1 + 32)) + 8;
   fft1_desired = zalloc(sizeof(float) * N1);
-  fftw_tmp = zalloc(sizeof(float) * (4 * N1 + 64));
+  fftw_tmp = zalloc(sizeof(float) * (4 * C * N1 + 64));
   make_sincos(1, N1, fft1tab);
   make_permute(1, n1, N1, fft1_permute);
   make_window(1, N1, sinpow1, fft1_window);
@@ -200,7 +204,7 @@ int main(int argc, char **argv)
     free(tmpb);
   }
   fclose(fi);
-  timf1_blockbytes = fft1_new_points * (dword ? 8 : 4);
+  timf1_blockbytes = fft1_new_points * (dword ? 8 : 4) * C;
   timf1p_px = 0;
 
   /* spectrum averaging (fft1_c, update_fft1_slowsum) */
@@ -217,13 +221,13 @@ int main(int argc, char **argv)
   /* ---- timf2 / back transform (buf.c:371-430, 1297-1345) ---- */
   fft2_n = n2; fft2_size = N2;
   timf2pow_size = timf2pow_log2 ? (1 << timf2pow_log2) : 8 * (N2 > N1 ? N2 : N1);
-  timf2pow_mask = timf2pow_size - 1; timf2_size = 4 * timf2pow_size; timf2_mask = timf2_size - 1;
-  timf2_input_block = fft1_new_points * 4;
+  timf2pow_mask = timf2pow_size - 1; timf2_size = 4 * C * timf2pow_size; timf2_mask = timf2_size - 1;
+  timf2_input_block = fft1_new_points * 4 * C;
   timf2_pa = timf2_px = timf2_pn1 = timf2_pn2 = timf2_pb = timf2_pc = timf2_pt = 0; timf2p_fit = 0;
-  timf2_float = zalloc(sizeof(float) * (timf2_size + 8 * N1));
+  timf2_float = zalloc(sizeof(float) * (timf2_size + 8 * C * N1));
   timf2_pwr_float = zalloc(sizeof(float) * (timf2pow_size + 2 * N1));
-  timf2_tmp = zalloc(sizeof(float) * 8 * N1);
-  fft1_split_float = zalloc(sizeof(float) * 8 * N1);
+  timf2_tmp = zalloc(sizeof(float) * 8 * C * N1);
+  fft1_split_float = zalloc(sizeof(float) * 8 * C * N1);
   fft1_back_scramble = zalloc(sizeof(short) * N1);
   fft1_inverted_window = zalloc(sizeof(float) * (N1 + 32));
   liminfo = zalloc(sizeof(float) * N1);
@@ -375,7 +379,7 @@ int main(int argc, char **argv)
     PUTF("fft1_window", fft1_window, N1);
     put("fft1_permute", "u2", fft1_permute, N1, 2);
     PUTF("fft1tab", fft1tab, N1);                     /* N1/2 {sin,cos} pairs */
-    PUTF("fft1_filtercorr", fft1_filtercorr, 2 * N1);
+    PUTF("fft1_filtercorr", fft1_filtercorr, 2 * C * N1);
     PUTF("fft1_desired", fft1_desired, N1);
     put("fft1_back_scramble", "u2", fft1_back_scramble, N1, 2);
     PUTF("fft1_inverted_window", fft1_inverted_window, N1 / 2 + 1);
@@ -404,14 +408,14 @@ int main(int argc, char **argv)
   size_t max_fft2_calls = (size_t)nblk * (size_t)(fft1_new_points / (fft2_new_points > 0 ? fft2_new_points : 1) + 2) + 64;
   float *mixtrace = zalloc(sizeof(float) * 8 * max_fft2_calls);
   short *wf_lines = zalloc(2 * (size_t)wg_xpixels * max_fft2_calls);
-  float *fft1_first = zalloc(sizeof(float) * 2 * N1);    /* fft1_b output of block 0 before fft1_c */
+  float *fft1_first = zalloc(sizeof(float) * 2 * C * N1);    /* fft1_b output of block 0 before fft1_c */
   for (int b = 0; b < nblk && !harness_err; b++) {
     if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
       long r = b / lim_every; if (r >= nlimrec) r = nlimrec - 1;
       memcpy(liminfo, limrecs + r * N1, 4 * N1);
     }
     fft1_b(timf1p_px, &fft1_float[fft1_pa], fftw_tmp, 0);
-    if (b == 0) memcpy(fft1_first, &fft1_float[fft1_pa], 8 * N1);
+    if (b == 0) memcpy(fft1_first, &fft1_float[fft1_pa], 8 * C * N1);
     timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
     fft1_pa = (fft1_pa + fft1_mulblock) & fft1_mask;
     fft1_na = fft1_pa / fft1_block;
@@ -432,6 +436,12 @@ int main(int argc, char **argv)
       continue;
     }
     while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
+    if (C == 2) {                /* two channels: the goldens stop here (blanker / fft2 / mix1 of two channels are not driven) */
+      int *it2 = itrace + TR_COLS * b;
+      it2[0] = timf2_pa; it2[9] = fft1_sumsq_pa; it2[10] = fft1_sumsq_counter; it2[11] = fft1_lowlevel_points; it2[15] = fft1_liminfo_cnt;
+      (trace + TR_COLS * b)[5] = fft1_lowlevel_fraction;
+      continue;
+    }
     int pbeg = timf2p_fit;
     first_noise_blanker();
     if (bp_block > 0) compute_timf2_powersum();
@@ -462,7 +472,7 @@ int main(int argc, char **argv)
   }
 
   /* ---- dump results ---- */
-  PUTF("fft1_first_raw", fft1_first, 2 * N1);
+  PUTF("fft1_first_raw", fft1_first, 2 * C * N1);
   PUTF("fft1_float", fft1_float, (size_t)max_fft1n * fft1_block);
   PUTF("fft1_sumsq", fft1_sumsq, fft1_sumsq_bufsize);
   PUTF("fft1_slowsum", fft1_slowsum, N1);

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Two-RF-channel golden from the COMPILED REFERENCE (oracle/_ref/ref_harness channels=2): fft1_b (fft1win_dif_chan,
+dif_permute_chan, channel-2 phasing), fft1_c (|X0|^2 + |X1|^2), update_fft1_slowsum, make_timf2 (fft1back_two,
+two-channel fft1back_fp_finish).  Data only: the frame-interleaved int16 input {I0,Q0,I1,Q1}, liminfo, the reference's
+output rings.  Runs only in the build container.
+
+usage: python tests/golden/make_golden_2ch.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from refcases import case_params, harness_args, make_input, make_liminfo, twochan_case  # noqa: E402
+from refdump import load_dump  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+def main():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    for name in ("twochan_n10", "twochan_n9_sin3"):
+        d, frames, lim = twochan_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+            frames.tofile(fi)
+            lim.tofile(fl)
+            args = harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}"]
+            subprocess.check_call([HARNESS] + args)
+            ref = load_dump(fo)
+        out = {k: ref[k] for k in ("hdr", "fft1_filtercorr", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
+                                   "timf2_pwr_float", "itrace", "trace")}
+        out["frames"], out["liminfo"] = frames, lim
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

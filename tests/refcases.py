@@ -192,3 +192,31 @@ def harness_args(d, infile, limfile, outfile):
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
+
+
+# ---- two RF channels in one array (the reference's own layout); the build shards them one per context
+TWOCHAN = {
+    "twochan_n10": dict(base="n10_n12", nblk=40, seed2=112, sky_phase=0.7, ch2_c1=float(np.float32(np.cos(0.5))),
+                        ch2_c2=float(np.float32(np.sin(0.5)))),
+    "twochan_n9_sin3": dict(base="n9_n11_sin3", nblk=32, seed2=114, sky_phase=-1.1, ch2_c1=1.0, ch2_c2=0.0),
+}
+
+
+def twochan_case(name):
+    """params, frame-interleaved input {I0,Q0,I1,Q1} and liminfo of a two-channel case: channel 1 = the same carriers
+    and pulses turned by sky_phase, independent noise."""
+    t = TWOCHAN[name]
+    d = case_params(t["base"])
+    d.update(nblk=t["nblk"], ch2_c1=t["ch2_c1"], ch2_c2=t["ch2_c2"], fq=-1.0, second_fft=1)
+    x0 = make_input(d).astype(np.float64)
+    z0 = x0[0::2] + 1j * x0[1::2]
+    rng0 = np.random.default_rng(d["seed"])
+    n = z0.size
+    noise0 = rng0.normal(0, d["sigma"], n) + 1j * rng0.normal(0, d["sigma"], n)      # the first draws of make_input
+    rng = np.random.default_rng(t["seed2"])
+    z1 = (z0 - noise0) * np.exp(1j * t["sky_phase"]) + rng.normal(0, d["sigma"], n) + 1j * rng.normal(0, d["sigma"], n)
+    frames = np.empty(4 * n, np.int16)
+    frames[0::4], frames[1::4] = x0[0::2], x0[1::2]
+    frames[2::4] = np.clip(np.round(z1.real), -32767, 32767)
+    frames[3::4] = np.clip(np.round(z1.imag), -32767, 32767)
+    return d, frames, make_liminfo(d)

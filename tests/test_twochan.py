@@ -1,0 +1,81 @@
+"""Two RF channels: the reference keeps both in one array (fft1win_dif_chan / dif_permute_chan fft1.c:2041, 660;
+fft1_c's |X0|^2+|X1|^2 fft1.c:4132-4145; fft1back_two timf2.c:210; two-channel fft1back_fp_finish timf2.c:1067-1110),
+this build shards them one per context.  Golden = the COMPILED REFERENCE run with ui.rx_rf_channels = 2
+(tests/golden/make_golden_2ch.py); each context must reproduce its channel of the interleaved rings, and the two
+cross-channel sums (fft1_sumsq, timf2_pwr) must equal the sums of the per-context rings (the exchange of
+linrad_amd/multichan.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from linrad_amd import abi
+from refcases import lrh_config, twochan_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def _run(open_fn, name, frames_mode):
+    d, frames, lim = twochan_case(name)
+    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    assert np.array_equal(g["frames"], frames)
+    fr = frames.reshape(-1, 4)
+    out = []
+    for ch in (0, 1):
+        iq = np.ascontiguousarray(fr[:, 2 * ch:2 * ch + 2]).ravel()
+        cfg = lrh_config(d, iq)
+        if frames_mode:                       # the HIP path reads its channel out of the interleaved frames
+            cfg.timf1_bytes *= 2
+            cfg.timf1_frame_channels, cfg.timf1_channel_index = 2, ch
+        rx = open_fn(cfg)
+        rx.timf1_write(frames if frames_mode else iq)
+        rx.set_liminfo(lim)
+        if ch == 1:
+            rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
+        for _ in range(d["nblk"]):            # the harness's call pattern: one block through all three stages
+            rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1)
+        out.append(dict(fft1=rx.export(abi.RING_FFT1_FLOAT), sumsq=rx.export(abi.RING_FFT1_SUMSQ),
+                        slowsum=rx.export(abi.RING_FFT1_SLOWSUM), timf2=rx.export(abi.RING_TIMF2_FLOAT),
+                        pwr=rx.export(abi.RING_TIMF2_PWR), p=rx.p.as_dict(), M1=rx.N1 - rx.fft1_interleave_points))
+    return d, g, out
+
+
+def _check(d, g, out, tol):
+    N1 = 1 << d["n1"]
+    gf = g["fft1_float"].reshape(-1, N1, 2, 2)
+    for ch in (0, 1):
+        assert _rel(out[ch]["fft1"].reshape(-1, N1, 2), gf[:, :, ch, :]) < tol, ch
+    # cross-channel power sum: what the all-reduce of multichan.cross_channel_power_sum forms
+    assert _rel(out[0]["sumsq"] + out[1]["sumsq"], g["fft1_sumsq"]) < tol
+    assert _rel(out[0]["slowsum"] + out[1]["slowsum"], g["fft1_slowsum"]) < 10 * tol
+    assert out[0]["p"]["fft1_sumsq_pa"] == int(g["itrace"].reshape(-1, 16)[-1, 9])
+    # timf2: reference sample layout {w0Re,w0Im,w1Re,w1Im,s0Re,s0Im,s1Re,s1Im}; finished samples only (the newest half
+    # block of the reference ring holds a parked raw half)
+    pa = int(g["itrace"].reshape(-1, 16)[-1, 0]) // 8
+    assert pa == out[0]["p"]["timf2_pa"] // 4 and pa > 0
+    gt = g["timf2_float"].reshape(-1, 2, 2, 2)            # [sample][weak/strong][channel][re/im]
+    for ch in (0, 1):
+        t = out[ch]["timf2"].reshape(-1, 2, 2)             # [sample][weak/strong][re/im]
+        assert _rel(t[:pa], gt[:pa, :, ch, :]) < tol, ch
+        assert np.abs(gt[:pa, 1, ch, :]).max() > 0          # the strong route is exercised
+    assert _rel((out[0]["pwr"] + out[1]["pwr"])[:pa], g["timf2_pwr_float"][:pa]) < tol
+
+
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_oracle_channels_match_two_channel_reference(name):
+    from oracle_binding import open_oracle
+    d, g, out = _run(open_oracle, name, frames_mode=False)
+    _check(d, g, out, 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_hip_contexts_match_two_channel_reference(name):
+    from linrad_amd.lib import open_hip
+    d, g, out = _run(open_hip, name, frames_mode=True)
+    _check(d, g, out, 1e-5)
