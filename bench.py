@@ -66,6 +66,44 @@ def cpu_baseline(args, fft1_n, fft2_n):
             "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload, 1 thread, {dt:.1f} s"}
 
 
+def cpu_reference(args, fft1_n, fft2_n):
+    """The COMPILED REFERENCE itself (oracle/_ref/ref_harness: fventuri/linrad's own C files, -O2 -ffast-math, its
+    single-CPU call order wcw.c:1036-1118) on a bounded sample of the same workload, one thread.  None when the binary
+    is not there (it is built in the build container, where the reference sources are, and travels with the snapshot)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.access(exe, os.X_OK):
+        return None
+    from linrad_amd import lib as hiplib
+    from linrad_amd.workload import level_gain
+    N1, N2 = 1 << fft1_n, 1 << fft2_n
+    M1 = N1 // 2
+    nblk = max(256, args.cpu_blocks // 2)
+    s = hiplib.synth_defaults(N1, 0)
+    iq = hiplib.synth_iq(s, 0, nblk * M1 + 2 * N1)
+    lim = strong_liminfo(s, fft1_n)
+    per_block = max(2, 2 * (M1 // max(1, N2 // 2)) + 2)
+    pow2 = lambda v: 1 << int(np.ceil(np.log2(v)))  # noqa: E731
+    with tempfile.TemporaryDirectory() as td:
+        fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+        np.asarray(iq, np.int16).tofile(fi)
+        lim.tofile(fl)
+        cmd = [exe, f"n1={fft1_n}", f"n2={fft2_n}", "mixred=6", "att_n=6", f"gain={level_gain(fft1_n, 6)}", "avg1num=5", "avg2num=4",
+               f"nblk={nblk}", "max_fft1n=8", f"max_fft2n={pow2(per_block)}", "sumsq_blocks=16", "stupid=1", "bln_interval=152",
+               "bln_avgnum=1220", f"fq={0.31 * N2 + 0.3}", "wf_avgnum=8", f"wf_pixels={min(N2, 1024)}", "timing=1",
+               f"in={fi}", f"liminfo={fl}", f"out={fo}"]
+        try:
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, check=True).stdout
+            r = json.loads(out.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            return None
+    dt = r["loop_seconds"]
+    return {"value": round(nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload through the compiled reference "
+                      f"(fft1_b, fft1_c, make_timf2, first_noise_blanker, make_fft2, fft2_mix1_fixed), 1 thread, {dt:.1f} s"}
+
+
 def cpu_worker(fft1_n, fft2_n, nblk, channel):
     """One single-thread oracle pipeline (child process of cpu_baseline_all_cores); prints its loop time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -221,9 +259,10 @@ def main():
                 "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                 "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
                 "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
-    cpu = cpu_all = None
+    cpu = cpu_all = cpu_port = None
     if rank == 0 and not args.no_cpu:
-        cpu = cpu_baseline(args, args.fft1_n, args.fft2_n)
+        cpu_port = cpu_baseline(args, args.fft1_n, args.fft2_n)
+        cpu = cpu_reference(args, args.fft1_n, args.fft2_n) or cpu_port
         cpu_all = cpu_baseline_all_cores(args, args.fft1_n, args.fft2_n)
     if use_dist:
         dist.barrier()
@@ -244,7 +283,7 @@ def main():
             "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4),
                          "wideband_dsp_cpu_ms_per_call": round(host_dsp_cpu[0] / max(host_dsp_cpu[1], 1), 4),
                          "staging_wait_ms_per_call": round(host_wait[0] / max(host_wait[1], 1), 4)},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "stages": stages,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_all_cores": cpu_all, "stages": stages,
             "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
                         "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},
         }

@@ -23,6 +23,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <math.h>
+#include <time.h>
 
 #include "globdef.h"
 #include "uidef.h"
@@ -125,6 +126,7 @@ int main(int argc, char **argv)
   int afc = AI("afc", 0);                        /* 1: fft2_mix1_afc / fft1_mix1_afc with a synthetic per-transform frequency */
   double afc_bw = AF("afc_bw", 20.0);            /* baseband_bw_hz */
   int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
+  int timing = AI("timing", 0);                  /* 1: print the wall time of the block loop (bench.py cpu_baseline), skip the ring dumps */
   int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
@@ -409,6 +411,7 @@ int main(int argc, char **argv)
   float *mixtrace = zalloc(sizeof(float) * 8 * max_fft2_calls);
   short *wf_lines = zalloc(2 * (size_t)wg_xpixels * max_fft2_calls);
   float *fft1_first = zalloc(sizeof(float) * 2 * C * N1);    /* fft1_b output of block 0 before fft1_c */
+  struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
   for (int b = 0; b < nblk && !harness_err; b++) {
     if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
       long r = b / lim_every; if (r >= nlimrec) r = nlimrec - 1;
@@ -471,6 +474,13 @@ int main(int argc, char **argv)
     it[12] = timf2_noise_floor; it[13] = (int)hg.stupid_bln_limit; it[14] = nfft2; it[15] = fft1_liminfo_cnt;
   }
 
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  if (timing) {
+    printf("{\"loop_seconds\": %.6f, \"blocks\": %d, \"samples\": %ld, \"fft2\": %d, \"cleared\": %d}\n",
+           (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec), nblk, (long)nblk * fft1_new_points, nfft2, timf2_cleared_points);
+    fclose(fo);
+    return harness_err ? 3 : 0;
+  }
   /* ---- dump results ---- */
   PUTF("fft1_first_raw", fft1_first, 2 * C * N1);
   PUTF("fft1_float", fft1_float, (size_t)max_fft1n * fft1_block);
