@@ -100,7 +100,10 @@ typedef struct lrh_config {
   int timf1_dword_input;        /* ui.rx_input_mode & DWORD_INPUT: timf1 holds int32 I,Q (18/24-bit hardware,
                                    expanded .raw recordings) instead of int16                              */
   int sample_shift;             /* ui.sample_shift: Q is taken sample_shift samples after I (fft1.c:470-482) */
-  int reserved[4];
+  int blanker_channels;         /* 2: this context is one of two coupled RF channels (ui.rx_rf_channels = 2): the blanker
+                                   decides on the channel power sum and averages both channels' noise (blank1.c:1017,
+                                   1236-1300, 1510-1545, 1570); see lrh_blanker_begin.  0/1: single channel          */
+  int reserved[3];
 } lrh_config;
 
 /*
@@ -225,6 +228,24 @@ int lrh_fft1_c(lrh_ctx *ctx, lrh_ptrs *p, int batch);
 /* make_timf2 (fft1def.h:349; timf2.c:31-208, 689-1065) */
 int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
 /* first_noise_blanker (fft2def.h:64; blank1.c:684-1603), stupid blanker + noise statistics */
+/* ---- two coupled RF channels, one per context (cfg.blanker_channels = 2, cfg.timf1_channel_index = the channel) ----
+   The reference keeps both channels in one array: timf2_pwr_float holds |w0|^2+|w1|^2, the stupid blanker compares that sum
+   with the limit, clears both channels' samples, and the noise floor is the mean of the two channels' despiked powers.
+   With one channel per GPU these are two sum exchanges per call, which the caller performs (RCCL all-reduce in the
+   product, plain adds in tests):
+     lrh_blanker_begin        gathers the own power of the samples the coming call will scan into exchange buffer
+                              LRH_X_PWR (count floats; 0: the call will return early on the rate limit)
+     -> all-reduce(sum) LRH_X_PWR[0..count) over the two contexts
+     lrh_first_noise_blanker  scans the summed power, clears, leaves the own channel's every-4th-sample mean power
+                              (blank1.c:1512-1541) in slot timf1_channel_index of LRH_X_STAT (2 floats, other slot 0)
+     -> all-reduce(sum) LRH_X_STAT[0..2)
+     lrh_blanker_finish       the statistics / threshold update of blank1.c:1542-1601 with both channels' values  */
+enum { LRH_X_PWR = 0, LRH_X_STAT = 1 };
+int lrh_blanker_begin(lrh_ctx *ctx, const lrh_ptrs *p, int *count);
+int lrh_blanker_finish(lrh_ctx *ctx, lrh_ptrs *p);
+int lrh_exchange_ptr(lrh_ctx *ctx, int which, void **device_ptr);           /* for collectives on lrh_stream(ctx) */
+int lrh_exchange_read(lrh_ctx *ctx, int which, float *dst, size_t off, size_t count);   /* synchronous, for tests / host exchange */
+int lrh_exchange_write(lrh_ctx *ctx, int which, const float *src, size_t off, size_t count);
 int lrh_first_noise_blanker(lrh_ctx *ctx, lrh_ptrs *p);
 /* make_fft2 until FFT2_COMPLETE (fft2def.h:61; fft2.c:52-1848, mode 15), `batch` transforms.
    The caller checks (timf2_pn2-timf2_px) >= 4*N2 per transform as wcw.c:265-275 does. */

@@ -34,7 +34,7 @@ class LrhConfig(C.Structure):
         ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
         ("timf2_blockpower_size", C.c_int), ("timf1_frame_channels", C.c_int), ("timf1_channel_index", C.c_int),
         ("fft3_n", C.c_int), ("fft3_sinpow", C.c_int), ("mix2_n", C.c_int), ("max_fft3n", C.c_int),
-        ("baseband_size", C.c_int), ("timf1_dword_input", C.c_int), ("sample_shift", C.c_int), ("reserved", C.c_int * 4),
+        ("baseband_size", C.c_int), ("timf1_dword_input", C.c_int), ("sample_shift", C.c_int), ("blanker_channels", C.c_int), ("reserved", C.c_int * 3),
     ]
 
 
@@ -169,6 +169,11 @@ class StageAPI:
         for n in ("fft2_mix1_afc", "fft1_mix1_afc"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(LrhAfc)])
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
+        self._proto("blanker_begin", [vp, C.POINTER(LrhPtrs), ip])
+        self._proto("blanker_finish", [vp, C.POINTER(LrhPtrs)])
+        self._proto("exchange_ptr", [vp, C.c_int, C.POINTER(vp)])
+        self._proto("exchange_read", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
+        self._proto("exchange_write", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
@@ -238,6 +243,31 @@ class StageAPI:
             t = np.ascontiguousarray(foldcorr, np.float32)
             assert t.size == 2 * self.N1
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
+
+    # ---- two coupled RF channels (cfg.blanker_channels = 2): see include/linrad_hip.h
+    X_PWR, X_STAT = 0, 1
+
+    def blanker_begin(self):
+        n = C.c_int()
+        self._chk(self._f("blanker_begin")(self.ctx, C.byref(self.p), C.byref(n)), "blanker_begin")
+        return n.value
+
+    def blanker_finish(self):
+        self._chk(self._f("blanker_finish")(self.ctx, C.byref(self.p)), "blanker_finish")
+
+    def exchange_read(self, which, count, off=0):
+        out = np.empty(count, np.float32)
+        self._chk(self._f("exchange_read")(self.ctx, which, self._fptr(out), off, count), "exchange_read")
+        return out
+
+    def exchange_write(self, which, data, off=0):
+        data = np.ascontiguousarray(data, np.float32)
+        self._chk(self._f("exchange_write")(self.ctx, which, self._fptr(data), off, data.size), "exchange_write")
+
+    def exchange_ptr(self, which):
+        ptr = C.c_void_p()
+        self._chk(self._f("exchange_ptr")(self.ctx, which, C.byref(ptr)), "exchange_ptr")
+        return ptr.value
 
     def set_ch2_phasing(self, c1, c2):
         """pg_ch2_c1 / pg_ch2_c2 for the context that carries the second RF channel (fft1.c:4064-4080)."""

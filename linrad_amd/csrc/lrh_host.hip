@@ -33,6 +33,7 @@ hipError_t launch_foldcorr(const FoldcorrArgs &a, int batch, hipStream_t st);
 hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
+hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
 hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
@@ -73,6 +74,9 @@ struct lrh_ctx {
   float *d_ss_part = nullptr;
   std::vector<std::function<int(lrh_ctx *)>> ss_queue;
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
+  // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
+  float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
+  int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
   // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
@@ -280,7 +284,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -454,6 +458,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
   if (cfg->second_fft_enable && c->timf2_mode == 1 && timf2_grid(cfg->fft1_n, cfg->max_batch) > 0) A(dev_alloc(c, &c->d_ss_part, (size_t)2 * timf2_grid(cfg->fft1_n, cfg->max_batch) * N1));
+  if (cfg->blanker_channels == 2) { A(dev_alloc(c, &c->d_pwr_sum, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xbuf, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xstat, 2)); }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -775,9 +780,18 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   pend &= 0xfffffffc;
   const int total = (pend - pbeg + 1 + mask) & mask;
   if (total < c->cfg.blanker_min_points) return LRH_OK;                  // rate limit, blank1.c:712-715
+  const bool coupled = c->cfg.blanker_channels == 2;
   BlankArgs a; memset(&a, 0, sizeof a);
   a.pwr = c->d_pwr; a.timf2w = c->d_timf2w; a.mask_bits = c->d_blnbits; a.mask = mask;
   a.pbeg = pbeg; a.total = (pend - pbeg) & mask;
+  a.chans = 1;
+  if (coupled) {
+    if (c->fin_pending) return fail(c, LRH_ESTATE, "lrh_blanker_finish of the previous call is missing");
+    if (c->x_pbeg != pbeg || c->x_count != a.total) return fail(c, LRH_ESTATE, "lrh_blanker_begin was not called for this span");
+    HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr_sum, pbeg, a.total, mask, 1, c->cur));   // the exchanged sums take their ring places
+    c->x_count = -1;
+    a.pwr = c->d_pwr_sum; a.own = c->d_pwr; a.xstat = c->d_xstat; a.own_slot = c->cfg.timf1_channel_index & 1; a.chans = 2; a.phase = 1;
+  }
   a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
   a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials;
   p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
@@ -796,6 +810,67 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   }
   const int ring_words = c->cfg.timf2pow_size / 32;
   LRH_DEVICE_WORK(c, { ProfScope ps(c, "blanker"); HIPCHK(c, launch_blanker(a, ring_words, c->cur)); });
+  if (coupled) { c->fin_args = a; c->fin_args.phase = 2; c->fin_pending = true; }
+  return LRH_OK;
+}
+
+// ---- two coupled RF channels: see include/linrad_hip.h
+int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !p || !count) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  const int mask = c->timf2pow_mask, pbeg = p->timf2p_fit;
+  int pend = (p->timf2_pa / 4 - c->cfg.blnfit_range + mask) & mask;
+  pend &= 0xfffffffc;
+  *count = 0; c->x_count = -1;
+  if (((pend - pbeg + 1 + mask) & mask) < c->cfg.blanker_min_points) return LRH_OK;
+  c->x_pbeg = pbeg; c->x_count = (pend - pbeg) & mask;
+  HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr, pbeg, c->x_count, mask, 0, c->cur));
+  *count = c->x_count;
+  return LRH_OK;
+}
+int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !p) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2 || !c->fin_pending) return fail(c, LRH_ESTATE, "no coupled blanker call to finish");
+  c->fin_pending = false;
+  HIPCHK(c, launch_blanker(c->fin_args, c->cfg.timf2pow_size / 32, c->cur));
+  return LRH_OK;
+}
+static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
+{
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
+  else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
+  else return LRH_EINVAL;
+  return LRH_OK;
+}
+int lrh_exchange_ptr(lrh_ctx *c, int which, void **device_ptr)
+{
+  if (!c || !device_ptr) return LRH_EINVAL;
+  float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
+  *device_ptr = q; return LRH_OK;
+}
+int lrh_exchange_read(lrh_ctx *c, int which, float *dst, size_t off, size_t count)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !dst) return LRH_EINVAL;
+  float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
+  if (off + count > cap) return LRH_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(dst, q + off, 4 * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+int lrh_exchange_write(lrh_ctx *c, int which, const float *src, size_t off, size_t count)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !src) return LRH_EINVAL;
+  float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
+  if (off + count > cap) return LRH_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(q + off, src, 4 * count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
 
@@ -1173,6 +1248,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
+  if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "two coupled channels need the exchanges between the stage calls (lrh_blanker_begin)");
   struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double cpu0 = thread_cpu_ms();
                      static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
                      ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   const int cb = c * LRH_BLN_CHUNK;
   const int cs = max(cb, 1);
   const int ce = min(cb + LRH_BLN_CHUNK - 1, a.total);
-  const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));   // blank1.c:1017
   const int G = max(a.clr2, 1);
   int s = 1;
   bool live = cs <= ce;
@@ -606,7 +606,7 @@ __global__ void k_blank_serial(BlankArgs a)
   if (!a.st->need_slow) return;
   a.st->need_slow = 0; a.st->slow_calls++;
   for (int q = 1 - a.clr1 - 32; q <= a.total + a.clr2 + 32; q++) a.mask_bits[((a.pbeg + q) & a.mask) >> 5] = 0;
-  const float nfl = (float)a.st->limit, totnoise = (float)a.st->noise_floor;
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0; float pulmax = 0;
   for (int q = 1; q <= a.total; q++) {
     const int p = (a.pbeg + q) & a.mask;
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word
         const int q = (p - a.pbeg) & a.mask;              // sequence position 1..total (guards may fall outside)
         if ((q & 3) == 0 && q >= 4 && q <= a.total) removed += (double)a.pwr[p];
         a.pwr[p] = 0;
+        if (a.own) a.own[p] = 0;
         a.timf2w[p] = make_float2(0.f, 0.f);              // weak part only (blank1.c:1043-1045)
       }
     }
@@ -665,7 +666,8 @@ __global__ __launch_bounds__(256) void k_blank_stats(BlankArgs a)
   const int per = (a.nstat + a.npartials - 1) / a.npartials;
   const int j0 = blockIdx.x * per, j1 = min(j0 + per, a.nstat);
   double acc = 0;
-  for (int j = j0 + threadIdx.x; j < j1; j += 256) acc += (double)a.pwr[(a.pbeg + 4 * (j + 1)) & a.mask];
+  const float *ring = a.own ? a.own : a.pwr;            // two coupled channels: this channel's own power (blank1.c:1512-1523)
+  for (int j = j0 + threadIdx.x; j < j1; j += 256) acc += (double)ring[(a.pbeg + 4 * (j + 1)) & a.mask];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
@@ -686,6 +688,12 @@ __global__ void k_blank_update(BlankArgs a)
   if (threadIdx.x != 0) return;
   tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   BlankState *s = a.st;
+  float t1;
+  if (a.phase == 2) {                                    // second half of a coupled call: both channels' means have arrived
+    s->despiked_pwrinc[0] += a.xstat[0];                  // blank1.c:1538-1541
+    s->despiked_pwrinc[1] += a.xstat[1];
+    t1 = a.xstat[0] + a.xstat[1];
+  } else {
   if (a.debug == 3) {
     double sa = 0, sr = 0;
     for (int i = 0; i < a.npartials; i++) sa += reinterpret_cast<double *>(a.partials)[i];
@@ -697,16 +705,18 @@ __global__ void k_blank_update(BlankArgs a)
   s->last_cleared = cleared;
   s->cleared_acc += cleared;
   int k = a.m - cleared; if (k < a.m / 25) k = a.m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
-  float t1 = (float)tot;
+  t1 = (float)tot;
   t1 /= k; if (t1 < 10) t1 = 10;
+  if (a.phase == 1) { a.xstat[0] = a.xstat[1] = 0.f; a.xstat[a.own_slot & 1] = t1; return; }   // the partner's half comes by exchange
   s->despiked_pwrinc[0] += t1;
+  }
   if (!a.do_update) return;
   s->despiked_pwr[0] = s->despiked_pwrinc[0] / (a.interval * a.lowlevel_fraction);
   s->despiked_pwr[1] = s->despiked_pwrinc[1] / (a.interval * a.lowlevel_fraction);
   float rate = (float)(100. * (double)(float)s->cleared_acc / (double)a.blanker_points);
   if (rate > 99) rate = 99;
   s->stupid_rate = rate;
-  int nf = (int)((s->despiked_pwr[0] + s->despiked_pwr[1]) / 1);
+  int nf = (int)((s->despiked_pwr[0] + s->despiked_pwr[1]) / (a.chans > 1 ? a.chans : 1));
   if (a.mode == 1) {
     if (rate > 20) {
       if (nf < 30) nf = 30;
@@ -1448,9 +1458,26 @@ hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
   hipLaunchKernelGGL(k_waterfall, dim3((work + 255) / 256, nlines), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+// exchange buffer <-> ring span of the coupled two-channel blanker: x[q-1] = ring[(pbeg+q) & mask], q = 1..count
+__global__ __launch_bounds__(256) void k_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  if (to_ring) ring[(pbeg + 1 + i) & mask] = x[i]; else x[i] = ring[(pbeg + 1 + i) & mask];
+}
+hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st)
+{
+  if (count > 0) hipLaunchKernelGGL(k_span_copy, dim3((count + 255) / 256), dim3(256), 0, st, x, ring, pbeg, count, mask, to_ring);
+  return hipGetLastError();
+}
 hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 {
   BlankArgs a = a0;
+  if (a.phase == 2) {                                    // coupled call, second half: statistics / threshold update only
+    a.npartials = 0; a.nremoved = 0;
+    hipLaunchKernelGGL(k_blank_update, dim3(1), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   const int ntiles = (a.total + LRH_BLN_TILE) / LRH_BLN_TILE;     // sequence positions 0 .. total
   const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
   const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
@@ -1459,6 +1486,11 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
     hipLaunchKernelGGL(k_blank_apply, dim3(a.nremoved), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
+    if (a.own) {                                         // per-channel statistic from the own ring after clearing
+      a.nremoved = 0;
+      a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < ntiles ? a.nstat / 4096 : ntiles);
+      hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);
+    }
   } else {
     a.nremoved = 0;
     hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);

@@ -83,6 +83,11 @@ struct BlankArgs {
   int blanker_points;       // timf2_blanker_points after adding m
   int do_update; float lowlevel_fraction; int interval; int avgnum; float factor;
   int debug;                // tuning experiments only (LRH_BLN_DEBUG), 0 in normal operation
+  // two coupled RF channels, one per context (blank1.c:1017, 1236-1300, 1510-1545, 1570): `pwr` is then the exchanged
+  // channel power sum the decisions are taken on, `own` this channel's own power ring (cleared alongside, source of the
+  // per-channel noise statistic), xstat the two-float exchange buffer; phase 1 stops after the own statistic,
+  // phase 2 resumes with both channels' values (phase 0: single channel, everything in one go)
+  int chans; float *own; float *xstat; int own_slot; int phase;
 };
 
 // ---- fft2 ----

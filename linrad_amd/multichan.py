@@ -29,3 +29,63 @@ def reference_two_channel_sumsq(spec0, spec1):
     p0 = spec0[0::2].astype(np.float32) ** 2 + spec0[1::2].astype(np.float32) ** 2
     p1 = spec1[0::2].astype(np.float32) ** 2 + spec1[1::2].astype(np.float32) ** 2
     return p0 + p1
+
+
+# ---- two coupled RF channels (cfg.blanker_channels = 2): the blanker decides on the channel power sum -------------
+class _DevSpan:
+    """float32 device span as a __cuda_array_interface__ object, so that torch wraps it without a copy"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def exchange_sum(rx, which, count, dist, device=None):
+    """all-reduce(sum) of one exchange buffer of a StageAPI receiver across the channel ranks.
+
+    HIP receiver: in place on the device buffer (`lrh_exchange_ptr`; the collective runs on torch's current stream, so
+    the receiver is synced before and after).  CPU oracle (gloo tests): through host memory."""
+    import torch
+    if count == 0:
+        return
+    if device is not None:
+        rx.sync()
+        t = torch.as_tensor(_DevSpan(rx.exchange_ptr(which), count), device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+    else:
+        t = torch.from_numpy(rx.exchange_read(which, count))
+        dist.all_reduce(t)
+        rx.exchange_write(which, t.numpy())
+
+
+def coupled_blanker(rx, dist, device=None):
+    """first_noise_blanker of one of two coupled channels: power-sum exchange, scan, noise-statistic exchange, update
+    (include/linrad_hip.h; blank1.c:1017, 1236-1300, 1510-1545, 1570)."""
+    n = rx.blanker_begin()
+    exchange_sum(rx, rx.X_PWR, n, dist, device)
+    rx.first_noise_blanker()
+    if n:
+        exchange_sum(rx, rx.X_STAT, 2, dist, device)
+        rx.blanker_finish()
+    return n
+
+
+def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True):
+    """single-CPU order of wideband_dsp (wcw.c:1036-1118) for one of two coupled channels, `batch` fft1 blocks per round,
+    with the cross-channel exchanges between the stage calls."""
+    c = rx.cfg
+    N2, M2 = rx.N2, rx.N2 - rx.fft2_interleave_points
+    tmask = 4 * c.timf2pow_size - 1
+    while nblocks > 0:
+        b = min(batch, nblocks)
+        rx.fft1_b(b), rx.fft1_c(b), rx.make_timf2(b)
+        coupled_blanker(rx, dist, device)
+        avail = (rx.p.timf2_pn2 - rx.p.timf2_px + 4 * c.timf2pow_size) & tmask        # wcw.c:265-266
+        k = 0 if avail < 4 * N2 else 1 + (avail - 4 * N2) // (4 * M2)
+        while k > 0:
+            kb = min(k, c.max_fft2n)
+            rx.make_fft2(kb)
+            if mix1:
+                rx.fft2_mix1_fixed(kb)
+            k -= kb
+        nblocks -= b

@@ -33,6 +33,9 @@ struct lro_ctx {
   float *fft2_window;          /* mode 4, N2 */
   float *mix1_fqwin;           /* mode 5, Nm/2+1 */
   float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
+  /* two coupled channels (cfg.blanker_channels = 2): summed power ring the blanker decides on, exchange buffers, and
+     what lro_first_noise_blanker leaves for lro_blanker_finish */
+  float *pwr_sum, *xbuf; float xstat[2]; int x_pbeg, x_count, fin_pending, fin_do_update; float fin_llf;
   float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
@@ -239,6 +242,7 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->timf1 = zal(cfg->timf1_bytes); c->fft1_float = zal(sizeof(float) * cfg->max_fft1n * 2 * N1);
   c->fft1_sumsq = zal(4 * (size_t)cfg->fft1_sumsq_bufsize); c->fft1_slowsum = zal(4 * N1);
   c->timf2_float = zal(16 * (size_t)cfg->timf2pow_size); c->timf2_pwr = zal(4 * (size_t)cfg->timf2pow_size);
+  if (cfg->blanker_channels == 2) { c->pwr_sum = zal(4 * (size_t)cfg->timf2pow_size); c->xbuf = zal(4 * (size_t)cfg->timf2pow_size); c->x_count = -1; }
   c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
@@ -306,7 +310,7 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr };
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -586,22 +590,74 @@ int lro_make_timf2(lro_ctx *c, lrh_ptrs *p, int batch)
 /* first_noise_blanker, blank1.c:684-715 (range, rate limit), 1003-1087 (stupid blanker, 1 channel float),
    1458-1603 (pointers, every-4th-sample noise statistics, threshold update). Clever blanker needs a pulse
    calibration and is forced off without one (hires_graph.c:1196). */
+static int blanker_update(lro_ctx *c, lrh_ptrs *p, float t1, int do_update, float llf, int chans);
+
+/* two coupled channels, see include/linrad_hip.h: the own power of the span the next call scans goes to the exchange buffer */
+int lro_blanker_begin(lro_ctx *c, const lrh_ptrs *p, int *count)
+{
+  if (c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  const int mask = c->timf2pow_mask, pbeg = p->timf2p_fit;
+  int pend = (p->timf2_pa / 4 - c->cfg.blnfit_range + mask) & mask;
+  pend &= 0xfffffffc;
+  *count = 0; c->x_count = -1;
+  if (((pend - pbeg + 1 + mask) & mask) < c->cfg.blanker_min_points) return LRH_OK;
+  c->x_pbeg = pbeg; c->x_count = (pend - pbeg) & mask;
+  for (int q = 1; q <= c->x_count; q++) c->xbuf[q - 1] = c->timf2_pwr[(pbeg + q) & mask];
+  *count = c->x_count;
+  return LRH_OK;
+}
+int lro_blanker_finish(lro_ctx *c, lrh_ptrs *p)
+{
+  if (c->cfg.blanker_channels != 2 || !c->fin_pending) return LRH_ESTATE;
+  c->fin_pending = 0;
+  c->bs.timf2_despiked_pwrinc[0] += c->xstat[0];          /* blank1.c:1538-1540 */
+  c->bs.timf2_despiked_pwrinc[1] += c->xstat[1];
+  return blanker_update(c, p, c->xstat[0] + c->xstat[1], c->fin_do_update, c->fin_llf, 2);
+}
+int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
+{
+  if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
+  *ptr = which == LRH_X_PWR ? (void *)c->xbuf : (void *)c->xstat;
+  return LRH_OK;
+}
+int lro_exchange_read(lro_ctx *c, int which, float *dst, size_t off, size_t count)
+{
+  void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
+  if (off + count > (which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : 2)) return LRH_EINVAL;
+  memcpy(dst, (float *)q + off, 4 * count); return LRH_OK;
+}
+int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size_t count)
+{
+  void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
+  if (off + count > (which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : 2)) return LRH_EINVAL;
+  memcpy((float *)q + off, src, 4 * count); return LRH_OK;
+}
+
 int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
 {
   const int mm = 4, mask = c->timf2pow_mask;
+  const int coupled = c->cfg.blanker_channels == 2;    /* one of two channels: decisions on the exchanged power sum */
   lrh_blanker_state *s = &c->bs;
-  float *pw = c->timf2_pwr, *tf = c->timf2_float;
+  float *own = c->timf2_pwr, *tf = c->timf2_float;
+  float *pw = coupled ? c->pwr_sum : own;
   int pbeg = p->timf2p_fit;
   int pend = (p->timf2_pa / mm - c->cfg.blnfit_range + mask) & mask;
   pend &= 0xfffffffc;
   int total = (pend - pbeg + 1 + mask) & mask;
   if (total < c->cfg.blanker_min_points) return LRH_OK;
+  if (coupled) {
+    if (c->fin_pending) return LRH_ESTATE;               /* lro_blanker_finish of the previous call is missing */
+    if (c->x_pbeg != pbeg || c->x_count != ((pend - pbeg) & mask)) return LRH_ESTATE;   /* lro_blanker_begin not called for this span */
+    for (int q = 1; q <= c->x_count; q++) pw[(pbeg + q) & mask] = c->xbuf[q - 1];
+    c->x_count = -1;
+  }
+#define CLR(pos) do { pw[pos] = 0; own[pos] = 0; tf[4 * (pos)] = 0; tf[4 * (pos) + 1] = 0; } while (0)
   int cleared = 0;
   if (c->cfg.stupid_bln_mode != 0) {
     unsigned int nfl = s->stupid_bln_limit;
     int p0 = pbeg, ifirst = 0, pk = p0;
     int clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1, clr2 = c->cfg.blanker_pulsewidth + 1;
-    float pulmax = 0, totnoise = (float)s->timf2_noise_floor;
+    float pulmax = 0, totnoise = (float)(s->timf2_noise_floor * (coupled ? 2 : 1));    /* blank1.c:1017 */
     while (p0 != pend) {
       p0 = (p0 + 1) & mask;
       if (pw[p0] > nfl) {
@@ -609,7 +665,7 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
         if (pw[p0] > pulmax) pulmax = pw[p0];
         ifirst++;
         cleared++;
-        pw[p0] = 0; tf[4 * p0] = 0; tf[4 * p0 + 1] = 0;
+        CLR(p0);
       } else if (ifirst != 0) {
         ifirst = 0;
         float t1 = pulmax / totnoise;
@@ -618,13 +674,14 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
           if (t1 > 10000) t1 = 10000;          /* 40 dB cap */
           t1 = sqrt(t1) / 100;
           int pa = pk, i = clr1 * t1 + 0.5;
-          for (int j = 0; j < i; j++) { pa = (pa + mask) & mask; pw[pa] = 0; tf[4 * pa] = 0; tf[4 * pa + 1] = 0; cleared++; }
+          for (int j = 0; j < i; j++) { pa = (pa + mask) & mask; CLR(pa); cleared++; }
           pa = p0; i = clr2 * t1 + 0.5;
-          for (int j = 0; j < i; j++) { pw[pa] = 0; tf[4 * pa] = 0; tf[4 * pa + 1] = 0; pa = (pa + 1) & mask; cleared++; }
+          for (int j = 0; j < i; j++) { CLR(pa); pa = (pa + 1) & mask; cleared++; }
         }
       }
     }
   }
+#undef CLR
   s->last_call_cleared = cleared;
   p->timf2p_fit = pend;                       /* blank1.c:1464 */
   p->timf2_pn2 = mm * pend;
@@ -634,18 +691,35 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
   if (p->timf2_blanker_points == 0) return LRH_OK;
   int k = m - cleared; if (k < m / 25) k = m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
   float t1 = 0;
-  for (int p0 = pbeg; p0 != p->timf2p_fit;) { p0 = (p0 + 4) & mask; t1 += pw[p0]; }
+  /* one channel: the (cleared) power ring; two: each channel's own weak power, t3*t3+t4*t4 of blank1.c:1516-1523 */
+  for (int p0 = pbeg; p0 != p->timf2p_fit;) { p0 = (p0 + 4) & mask; t1 += coupled ? tf[4 * p0] * tf[4 * p0] + tf[4 * p0 + 1] * tf[4 * p0 + 1] : pw[p0]; }
   t1 /= k; if (t1 < 10) t1 = 10;
-  s->timf2_despiked_pwrinc[0] += t1;
   p->blanker_info_update_counter++;
+  int do_update = 0;
   if (p->blanker_info_update_counter >= c->cfg.blanker_info_update_interval) {
-    if (p->fft1_lowlevel_fraction < 0.1) { p->blanker_info_update_counter--; return LRH_OK; }
+    if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
+    else do_update = 1;
+  }
+  if (coupled) {                               /* the partner's value arrives by exchange: lro_blanker_finish goes on */
+    c->xstat[0] = c->xstat[1] = 0; c->xstat[c->cfg.timf1_channel_index & 1] = t1;
+    c->fin_pending = 1; c->fin_do_update = do_update; c->fin_llf = p->fft1_lowlevel_fraction;
+    return LRH_OK;
+  }
+  s->timf2_despiked_pwrinc[0] += t1;
+  return blanker_update(c, p, t1, do_update, p->fft1_lowlevel_fraction, 1);
+}
+
+/* statistics / threshold update, blank1.c:1542-1601; t1 = this call's mean power summed over the channels */
+static int blanker_update(lro_ctx *c, lrh_ptrs *p, float t1, int do_update, float llf, int chans)
+{
+  lrh_blanker_state *s = &c->bs;
+  if (do_update) {
     int iv = c->cfg.blanker_info_update_interval;
-    s->timf2_despiked_pwr[0] = s->timf2_despiked_pwrinc[0] / (iv * p->fft1_lowlevel_fraction);
-    s->timf2_despiked_pwr[1] = s->timf2_despiked_pwrinc[1] / (iv * p->fft1_lowlevel_fraction);
+    s->timf2_despiked_pwr[0] = s->timf2_despiked_pwrinc[0] / (iv * llf);
+    s->timf2_despiked_pwr[1] = s->timf2_despiked_pwrinc[1] / (iv * llf);
     s->stupid_blanker_rate = 100. * (float)s->timf2_cleared_points / p->timf2_blanker_points;
     if (s->stupid_blanker_rate > 99) s->stupid_blanker_rate = 99;
-    s->timf2_noise_floor = (s->timf2_despiked_pwr[0] + s->timf2_despiked_pwr[1]) / 1;
+    s->timf2_noise_floor = (s->timf2_despiked_pwr[0] + s->timf2_despiked_pwr[1]) / chans;
     if (c->cfg.stupid_bln_mode == 1) {
       if (s->stupid_blanker_rate > 20) {
         if (s->timf2_noise_floor < 30) s->timf2_noise_floor = 30;

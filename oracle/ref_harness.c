@@ -439,10 +439,17 @@ int main(int argc, char **argv)
       continue;
     }
     while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
-    if (C == 2) {                /* two channels: the goldens stop here (blanker / fft2 / mix1 of two channels are not driven) */
-      int *it2 = itrace + TR_COLS * b;
-      it2[0] = timf2_pa; it2[9] = fft1_sumsq_pa; it2[10] = fft1_sumsq_counter; it2[11] = fft1_lowlevel_points; it2[15] = fft1_liminfo_cnt;
-      (trace + TR_COLS * b)[5] = fft1_lowlevel_fraction;
+    if (C == 2) {                /* two channels: make_timf2, then (blanker2=1) the two-channel first_noise_blanker; fft2 / mix1 not driven */
+      int *it2 = itrace + TR_COLS * b; float *t2 = trace + TR_COLS * b;
+      int pbeg2 = timf2p_fit;
+      if (AI("blanker2", 0)) first_noise_blanker();
+      it2[0] = timf2_pa; it2[1] = timf2p_fit; it2[2] = timf2_pn2; it2[4] = pbeg2; it2[5] = timf2_cleared_points;
+      it2[6] = timf2_blanker_points; it2[7] = blanker_info_update_counter;
+      it2[9] = fft1_sumsq_pa; it2[10] = fft1_sumsq_counter; it2[11] = fft1_lowlevel_points; it2[12] = timf2_noise_floor;
+      it2[13] = (int)hg.stupid_bln_limit; it2[15] = fft1_liminfo_cnt;
+      t2[0] = (float)timf2_noise_floor; t2[1] = (float)hg.stupid_bln_limit; t2[2] = stupid_blanker_rate;
+      t2[3] = timf2_despiked_pwr[0]; t2[4] = timf2_despiked_pwrinc[0]; t2[5] = fft1_lowlevel_fraction;
+      t2[6] = timf2_despiked_pwr[1]; t2[7] = timf2_despiked_pwrinc[1];
       continue;
     }
     int pbeg = timf2p_fit;

@@ -35,8 +35,12 @@ def main():
             args = harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}"]
             subprocess.check_call([HARNESS] + args)
             ref = load_dump(fo)
+            subprocess.check_call([HARNESS] + args + ["blanker2=1"])       # second run: two-channel first_noise_blanker after every block
+            refb = load_dump(fo)
         out = {k: ref[k] for k in ("hdr", "fft1_filtercorr", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
                                    "timf2_pwr_float", "itrace", "trace")}
+        for k in ("timf2_float", "timf2_pwr_float", "itrace", "trace"):
+            out["bln_" + k] = refb[k]
         out["frames"], out["liminfo"] = frames, lim
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)

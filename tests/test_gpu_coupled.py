@@ -1,0 +1,43 @@
+"""GPU: the collective path of the coupled two-channel blanker.  One GPU is all a test box has, so the group has one rank:
+what is checked is the plumbing -- RCCL reducing the library's own device buffers in place (lrh_exchange_ptr wrapped as a
+torch tensor) gives the same bits as the exchange through host memory, and batched rounds work."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from linrad_amd import abi
+from refcases import lrh_config, twochan_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_exchange_equals_host_exchange():
+    import torch
+    import torch.distributed as dist
+    from linrad_amd.lib import open_hip
+    from linrad_amd.multichan import run_coupled
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+    try:
+        d, frames, lim = twochan_case("twochan_n10")
+        iq = np.ascontiguousarray(frames.reshape(-1, 4)[:, 0:2]).ravel()
+        res = []
+        for device in (torch.device("cuda:0"), None):
+            cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=0)
+            rx = open_hip(cfg)
+            rx.timf1_write(iq)
+            rx.set_liminfo(lim)
+            rx.set_mix1_selfreq(2200.3)
+            run_coupled(rx, d["nblk"], 4, dist, device=device)
+            bs = rx.blanker_state()
+            res.append((rx.export(abi.RING_TIMF2_FLOAT), rx.export(abi.RING_FFT2_FLOAT), rx.export(abi.RING_TIMF3_FLOAT),
+                        bs.timf2_noise_floor, bs.stupid_bln_limit, rx.p.as_dict()))
+        for a, b in zip(res[0][:3], res[1][:3]):
+            assert np.array_equal(a, b)
+        assert res[0][3:] == res[1][3:]
+        assert np.count_nonzero(res[0][2]) > 0 and (res[0][0].reshape(-1, 4)[:, :2] == 0).all(axis=1).sum() > 50
+    finally:
+        dist.destroy_process_group()

@@ -66,3 +66,61 @@ def test_two_channel_power_sum_over_gloo():
     # the channels really are different signals (independent noise, rotated carriers)
     assert not np.allclose(parts0[0], parts0[1], rtol=1e-3)
     assert np.all(sum0 >= 0) and np.count_nonzero(sum0) >= sum0.size - 2      # the two edge bins are filtered to zero
+
+
+def _coupled_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from linrad_amd import abi
+    from linrad_amd.multichan import run_coupled
+    from oracle_binding import open_oracle
+    from refcases import lrh_config, twochan_case
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d, frames, lim = twochan_case("twochan_n10")
+    iq = np.ascontiguousarray(frames.reshape(-1, 4)[:, 2 * rank:2 * rank + 2]).ravel()
+    cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=rank)
+    rx = open_oracle(cfg)
+    rx.timf1_write(iq)
+    rx.set_liminfo(lim)
+    if rank == 1:
+        rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
+    run_coupled(rx, d["nblk"], 1, dist, mix1=False)            # the golden's call pattern: block by block
+    bs = rx.blanker_state()
+    out = dict(timf2=rx.export(abi.RING_TIMF2_FLOAT), nf=bs.timf2_noise_floor, lim=bs.stupid_bln_limit, fit=rx.p.timf2p_fit,
+               fft2_na=rx.p.fft2_na, fft2=rx.export(abi.RING_FFT2_FLOAT))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_coupled_two_channel_blanker_over_gloo():
+    """One channel per rank, the blanker coupled through two all-reduces per call (multichan.coupled_blanker): every rank
+    must end with the compiled two-channel reference's blanker state and its channel of the blanked timf2 ring."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_coupled_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "twochan_n10.npz"))
+    it = g["bln_itrace"].reshape(-1, 16)
+    fit = int(it[-1, 1])
+    gt = g["bln_timf2_float"].reshape(-1, 2, 2, 2)
+    assert res[0]["nf"] == res[1]["nf"] and res[0]["lim"] == res[1]["lim"] and res[0]["fit"] == res[1]["fit"] == fit
+    assert abs(res[0]["nf"] - int(it[-1, 12])) <= 1
+    for ch in (0, 1):
+        t = res[ch]["timf2"].reshape(-1, 2, 2)[:fit]
+        ref = gt[:fit, :, ch, :]
+        same_cleared = np.array_equal((t[:, 0, :] == 0).all(axis=1), (ref[:, 0, :] == 0).all(axis=1))
+        if res[0]["nf"] == int(it[-1, 12]):
+            assert same_cleared
+            assert np.linalg.norm(t - ref) <= 2e-6 * np.linalg.norm(ref)
+        assert np.count_nonzero(res[ch]["fft2"]) > 0            # the chain went on behind the blanker (make_fft2 on the released data)

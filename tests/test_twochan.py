@@ -79,3 +79,87 @@ def test_hip_contexts_match_two_channel_reference(name):
     from linrad_amd.lib import open_hip
     d, g, out = _run(open_hip, name, frames_mode=True)
     _check(d, g, out, 1e-5)
+
+
+# ---- coupled blanker: decisions on the channel power sum, noise floor from both channels (blank1.c:1017, 1236-1300,
+# 1510-1545, 1570); the two sum exchanges are done by hand here (tests/test_multichan_gloo.py does them with gloo)
+def _run_coupled(open_fn, name, frames_mode):
+    d, frames, lim = twochan_case(name)
+    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    fr = frames.reshape(-1, 4)
+    rxs = []
+    for ch in (0, 1):
+        iq = np.ascontiguousarray(fr[:, 2 * ch:2 * ch + 2]).ravel()
+        cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=ch)
+        if frames_mode:
+            cfg.timf1_bytes *= 2
+            cfg.timf1_frame_channels = 2
+        rx = open_fn(cfg)
+        rx.timf1_write(frames if frames_mode else iq)
+        rx.set_liminfo(lim)
+        if ch == 1:
+            rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
+        rxs.append(rx)
+    trace = []
+    for _ in range(d["nblk"]):
+        for rx in rxs:
+            rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1)
+        n = [rx.blanker_begin() for rx in rxs]
+        assert n[0] == n[1]
+        if n[0]:
+            tot = rxs[0].exchange_read(abi.StageAPI.X_PWR, n[0]) + rxs[1].exchange_read(abi.StageAPI.X_PWR, n[0])
+            for rx in rxs:
+                rx.exchange_write(abi.StageAPI.X_PWR, tot)
+        for rx in rxs:
+            rx.first_noise_blanker()
+        if n[0]:
+            st = rxs[0].exchange_read(abi.StageAPI.X_STAT, 2) + rxs[1].exchange_read(abi.StageAPI.X_STAT, 2)
+            for rx in rxs:
+                rx.exchange_write(abi.StageAPI.X_STAT, st)
+                rx.blanker_finish()
+        bs = [rx.blanker_state() for rx in rxs]
+        trace.append([(b.timf2_noise_floor, b.stupid_bln_limit, b.timf2_cleared_points) for b in bs] + [rxs[0].p.timf2p_fit, rxs[0].p.timf2_pn2])
+    out = [dict(timf2=rx.export(abi.RING_TIMF2_FLOAT), pwr=rx.export(abi.RING_TIMF2_PWR), bs=rx.blanker_state(), p=rx.p.as_dict()) for rx in rxs]
+    return d, g, out, trace
+
+
+def _check_coupled(d, g, out, trace, tol):
+    it = g["bln_itrace"].reshape(-1, 16)
+    tr = g["bln_trace"].reshape(-1, 16)
+    for b, row in enumerate(trace):
+        for ch in (0, 1):                                   # both contexts carry the same, the reference's, blanker state
+            assert abs(row[ch][0] - it[b, 12]) <= 1 and abs(int(row[ch][1]) - it[b, 13]) <= 5, (b, ch)
+        assert row[2] == it[b, 1] and 2 * row[3] == it[b, 2]      # timf2p_fit; timf2_pn2 counts 8 floats per sample there
+    assert trace[-1][0] == trace[-1][1]
+    exact = all(row[0][0] == it[b, 12] for b, row in enumerate(trace))
+    fit = int(it[-1, 1])
+    gt = g["bln_timf2_float"].reshape(-1, 2, 2, 2)
+    gp = g["bln_timf2_pwr_float"]
+    cleared_ref = gp[:fit] == 0
+    for ch in (0, 1):
+        own_cleared = (out[ch]["timf2"].reshape(-1, 2, 2)[:fit, 0, :] == 0).all(axis=1)
+        if exact:
+            assert np.array_equal(own_cleared, cleared_ref), ch
+            assert _rel(out[ch]["timf2"].reshape(-1, 2, 2)[:fit], gt[:fit, :, ch, :]) < tol, ch
+        else:
+            inter, union = (own_cleared & cleared_ref).sum(), (own_cleared | cleared_ref).sum()
+            assert inter / max(union, 1) > 0.97, ch
+    assert cleared_ref.sum() > 50                            # the pulses are there
+    for ch in (0, 1):
+        assert abs(out[ch]["bs"].timf2_despiked_pwr[0] - tr[-1, 3]) <= 1e-4 * tr[-1, 3] + 0.5
+        assert abs(out[ch]["bs"].timf2_despiked_pwr[1] - tr[-1, 6]) <= 1e-4 * tr[-1, 6] + 0.5
+
+
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_oracle_coupled_blanker_matches_two_channel_reference(name):
+    from oracle_binding import open_oracle
+    d, g, out, trace = _run_coupled(open_oracle, name, frames_mode=False)
+    _check_coupled(d, g, out, trace, 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_hip_coupled_blanker_matches_two_channel_reference(name):
+    from linrad_amd.lib import open_hip
+    d, g, out, trace = _run_coupled(open_hip, name, frames_mode=True)
+    _check_coupled(d, g, out, trace, 1e-5)
