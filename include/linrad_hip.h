@@ -102,7 +102,9 @@ typedef struct lrh_config {
   int sample_shift;             /* ui.sample_shift: Q is taken sample_shift samples after I (fft1.c:470-482) */
   int blanker_channels;         /* 2: this context is one of two coupled RF channels (ui.rx_rf_channels = 2): the blanker
                                    decides on the channel power sum and averages both channels' noise (blank1.c:1017,
-                                   1236-1300, 1510-1545, 1570); see lrh_blanker_begin.  0/1: single channel          */
+                                   1236-1300, 1510-1545, 1570), see lrh_blanker_begin; the fft2 waterfall line comes from
+                                   both channels' sums, see lrh_fft2_xy_begin (default wg_waterf_yfac then carries the
+                                   rx_rf_channels^2 of wide_graph.c:985).  0/1: single channel                        */
   int reserved[3];
 } lrh_config;
 
@@ -174,6 +176,9 @@ typedef enum lrh_ring {
   LRH_RING_TIMF2_BLOCKPOWER,    /* float [timf2_blockpower_size]                                   */
   LRH_RING_FFT3,                /* float [max_fft3n][fft3_size][2]                                 */
   LRH_RING_BASEB_RAW,           /* float [baseband_size][2]                                        */
+  LRH_RING_FFT2_XYPOWER,        /* float [max_fft2n][N2][4] = TWOCHAN_POWER {x2,y2,im_xy,re_xy} (globdef.h:1371-1376);
+                                   two coupled channels only, filled by lrh_fft2_xy_finish                */
+  LRH_RING_FFT2_XYSUM,          /* float [N2][4]: fft2_xysum, the running sum of the current waterfall group */
   LRH_RING_COUNT
 } lrh_ring;
 
@@ -240,9 +245,25 @@ int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
                               (blank1.c:1512-1541) in slot timf1_channel_index of LRH_X_STAT (2 floats, other slot 0)
      -> all-reduce(sum) LRH_X_STAT[0..2)
      lrh_blanker_finish       the statistics / threshold update of blank1.c:1542-1601 with both channels' values  */
-enum { LRH_X_PWR = 0, LRH_X_STAT = 1 };
+enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2 };
 int lrh_blanker_begin(lrh_ctx *ctx, const lrh_ptrs *p, int *count);
 int lrh_blanker_finish(lrh_ctx *ctx, lrh_ptrs *p);
+/* Cross products of the two channels' fft2 spectra (make_fft2's two-channel branch, fft2.c:1622-1640: per transform and bin
+   TWOCHAN_POWER {x2 = |X|^2, y2 = |Y|^2, im_xy = Xim*Yre - Xre*Yim, re_xy = Xre*Yre + Xim*Yim},
+   summed over wg.waterfall_avgnum transforms in fft2_xysum) and the two-channel waterfall line, which shows the
+   polarisation-independent power  (x2+y2) + 2 (re_xy^2 + im_xy^2 - x2 y2) / (x2+y2)  of the sums (fft2.c:1700-1815).
+   A cross product needs both channels' bins, so with one channel per GPU this is an all-gather:
+     at = *p;  lrh_make_fft2(ctx, p, batch);        each context transforms its own channel (no waterfall line of its own
+                                                     when cfg.blanker_channels = 2; the pointers advance as usual)
+     lrh_fft2_xy_begin(ctx, &at, batch, &count)     copies the `batch` new transforms (fft2_float from at.fft2_na on) into
+                                                     slot cfg.timf1_channel_index of LRH_X_BINS: float [2][count],
+                                                     count = batch * 2 * N2
+     -> all-gather of the two slots (each context receives the other channel's slot)
+     lrh_fft2_xy_finish(ctx, &at, batch)            fills LRH_RING_FFT2_XYPOWER / _XYSUM and writes the waterfall lines that
+                                                     complete within the batch at at.wg_waterf_ptr downwards
+   Both contexts end with the same rings (like an all-reduce result); calling finish on one of them is enough for a GUI. */
+int lrh_fft2_xy_begin(lrh_ctx *ctx, const lrh_ptrs *at, int batch, size_t *count);
+int lrh_fft2_xy_finish(lrh_ctx *ctx, const lrh_ptrs *at, int batch);
 int lrh_exchange_ptr(lrh_ctx *ctx, int which, void **device_ptr);           /* for collectives on lrh_stream(ctx) */
 int lrh_exchange_read(lrh_ctx *ctx, int which, float *dst, size_t off, size_t count);   /* synchronous, for tests / host exchange */
 int lrh_exchange_write(lrh_ctx *ctx, int which, const float *src, size_t off, size_t count);

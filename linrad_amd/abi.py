@@ -13,7 +13,7 @@ LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2,
 
 (RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
  RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT,
- RING_TIMF2_BLOCKPOWER, RING_FFT3, RING_BASEB_RAW) = range(14)
+ RING_TIMF2_BLOCKPOWER, RING_FFT3, RING_BASEB_RAW, RING_FFT2_XYPOWER, RING_FFT2_XYSUM) = range(16)
 _RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16}
 
 
@@ -171,6 +171,8 @@ class StageAPI:
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
         self._proto("blanker_begin", [vp, C.POINTER(LrhPtrs), ip])
         self._proto("blanker_finish", [vp, C.POINTER(LrhPtrs)])
+        self._proto("fft2_xy_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
+        self._proto("fft2_xy_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("exchange_ptr", [vp, C.c_int, C.POINTER(vp)])
         self._proto("exchange_read", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
         self._proto("exchange_write", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
@@ -245,7 +247,21 @@ class StageAPI:
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
 
     # ---- two coupled RF channels (cfg.blanker_channels = 2): see include/linrad_hip.h
-    X_PWR, X_STAT = 0, 1
+    X_PWR, X_STAT, X_BINS = 0, 1, 2
+
+    def ptrs_copy(self):
+        """the pointer state as it is now (`at` of lrh_fft2_xy_begin / finish: taken before make_fft2)"""
+        q = LrhPtrs()
+        C.memmove(C.byref(q), C.byref(self.p), C.sizeof(LrhPtrs))
+        return q
+
+    def fft2_xy_begin(self, at, batch=1):
+        n = C.c_size_t()
+        self._chk(self._f("fft2_xy_begin")(self.ctx, C.byref(at), batch, C.byref(n)), "fft2_xy_begin")
+        return n.value
+
+    def fft2_xy_finish(self, at, batch=1):
+        self._chk(self._f("fft2_xy_finish")(self.ctx, C.byref(at), batch), "fft2_xy_finish")
 
     def blanker_begin(self):
         n = C.c_int()
@@ -394,7 +410,8 @@ class StageAPI:
                 RING_FFT2_POWERSUM: self.N2, RING_WG_WATERF: c.wf_lines * c.wf_xpixels,
                 RING_TIMF3_FLOAT: c.timf3_size, RING_TIMF2_BLOCKPOWER: c.timf2_blockpower_size,
                 RING_FFT3: c.max_fft3n * 2 * (1 << c.fft3_n) if c.fft3_n else 0,
-                RING_BASEB_RAW: 2 * c.baseband_size}[ring]
+                RING_BASEB_RAW: 2 * c.baseband_size, RING_FFT2_XYPOWER: c.max_fft2n * 4 * self.N2,
+                RING_FFT2_XYSUM: 4 * self.N2}[ring]
 
     def export(self, ring, offset=0, count=None):
         if count is None:

@@ -32,6 +32,7 @@ hipError_t launch_power_of(const float2 *src, float *dst, size_t n, hipStream_t 
 hipError_t launch_foldcorr(const FoldcorrArgs &a, int batch, hipStream_t st);
 hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
+hipError_t launch_xypower(const XyArgs &a, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -76,6 +77,7 @@ struct lrh_ctx {
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
+  float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
@@ -212,6 +214,7 @@ static void default_yfac(lrh_ctx *c)        // make_wg_yfac, wide_graph.c:955-10
   t1 /= (float)sqrt((float)(c->cfg.waterfall_avgnum));
   t1 *= (float)(1 << (2 * c->cfg.bckfft_att_n));
   t1 *= (float)(1 + 1 / (0.5 + c->cfg.fft1_sinpow));
+  if (c->cfg.blanker_channels == 2) t1 *= 4.0f;            // ui.rx_rf_channels^2, wide_graph.c:985
   c->h_yfac.assign(c->N1, 0.f);
   for (int i = 0; i < c->N1; i++)
     c->h_yfac[i] = (c->h_desired[i] > 0.3162278) ? t1 / (float)pow(c->h_desired[i], 2.0) : t1 * 10;
@@ -284,7 +287,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -458,7 +461,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
   if (cfg->second_fft_enable && c->timf2_mode == 1 && timf2_grid(cfg->fft1_n, cfg->max_batch) > 0) A(dev_alloc(c, &c->d_ss_part, (size_t)2 * timf2_grid(cfg->fft1_n, cfg->max_batch) * N1));
-  if (cfg->blanker_channels == 2) { A(dev_alloc(c, &c->d_pwr_sum, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xbuf, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xstat, 2)); }
+  if (cfg->blanker_channels == 2) { A(dev_alloc(c, &c->d_pwr_sum, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xbuf, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xstat, 2));
+    A(dev_alloc(c, &c->d_xbins, (size_t)2 * cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_xypower, (size_t)cfg->max_fft2n * N2));
+    A(dev_alloc(c, &c->d_xysum, N2)); A(dev_alloc(c, &c->d_xysum_alt, N2)); }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -844,6 +849,7 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
   else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
+  else if (which == LRH_X_BINS) { *ptr = (float *)c->d_xbins; *cap = (size_t)4 * c->cfg.max_fft2n * c->N2; }
   else return LRH_EINVAL;
   return LRH_OK;
 }
@@ -910,7 +916,8 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
   { float *t = c->d_powersum2; c->d_powersum2 = c->d_powersum2_alt; c->d_powersum2_alt = t; }   // ping-pong: group 0 reads while the last group writes
-  const int nlines = (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
+  // two coupled channels: the line comes from both channels' sums (lrh_fft2_xy_finish); the pointers advance as usual
+  const int nlines = c->cfg.blanker_channels == 2 ? 0 : (p->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
   WaterfallArgs w; memset(&w, 0, sizeof w);
   if (nlines > 0) {
     int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
@@ -944,6 +951,51 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     p->fft2_nb = (p->fft2_nb + 1) & c->fft2n_mask;
     if (p->fft2_nm != c->fft2n_mask) p->fft2_nm++;
   }
+  return LRH_OK;
+}
+
+// Two coupled channels (include/linrad_hip.h): the new transforms of the own channel go to their slot of LRH_X_BINS ...
+int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !at || !count || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  const int N = c->N2, na = at->fft2_na & c->fft2n_mask;
+  float2 *slot = c->d_xbins + (size_t)(c->cfg.timf1_channel_index & 1) * batch * N;
+  const int first = std::min(batch, c->cfg.max_fft2n - na);          // the ring span may wrap once
+  LRH_DEVICE_WORK(c, {
+    HIPCHK(c, hipMemcpyAsync(slot, c->d_fft2 + (size_t)na * N, (size_t)first * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
+    if (batch > first) HIPCHK(c, hipMemcpyAsync(slot + (size_t)first * N, c->d_fft2, (size_t)(batch - first) * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
+  });
+  *count = (size_t)batch * 2 * N;
+  return LRH_OK;
+}
+// ... and with the partner's slot in place: TWOCHAN_POWER per transform, fft2_xysum, and the waterfall lines that complete
+// within the batch (fft2.c:1622-1640, 1700-1815)
+int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !at || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  const int N = c->N2;
+  XyArgs a;
+  a.x = c->d_xbins; a.y = c->d_xbins + (size_t)batch * N; a.xypower = c->d_xypower; a.first_na = at->fft2_na; a.na_mask = c->fft2n_mask;
+  a.n = N; a.batch = batch; a.sum_in = c->d_xysum; a.sum_out = c->d_xysum_alt; a.lines = c->d_wf_scratch;
+  a.counter = at->wg_waterf_sum_counter; a.avgnum = c->cfg.waterfall_avgnum;
+  { float4 *t = c->d_xysum; c->d_xysum = c->d_xysum_alt; c->d_xysum_alt = t; }   // ping-pong: group 0 reads while the last group writes
+  const int nlines = (at->wg_waterf_sum_counter + batch) / c->cfg.waterfall_avgnum;
+  WaterfallArgs w; memset(&w, 0, sizeof w);
+  if (nlines > 0) {
+    int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
+    w.ps = c->d_wf_scratch; w.yfac = c->d_yfac; w.itab = c->d_wf_itab; w.line = c->d_waterf;
+    w.npix = c->cfg.wf_xpixels; w.first = c->cfg.wf_first_xpoint; w.siz = N; w.hx = hx; w.hp = hp;
+    w.ptr0 = at->wg_waterf_ptr; w.wf_size = c->cfg.wf_lines * c->cfg.wf_xpixels; w.line_stride = N;
+  }
+  LRH_DEVICE_WORK(c, {
+    if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of make_fft2 share wf_scratch
+    { ProfScope ps(c, "xypower"); HIPCHK(c, launch_xypower(a, c->cur)); }
+    if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }
+  });
   return LRH_OK;
 }
 
@@ -1451,6 +1503,8 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_TIMF2_BLOCKPOWER: src = c->d_blockpower; total = c->cfg.timf2_blockpower_size; break;
     case LRH_RING_FFT3: src = c->d_fft3; total = (size_t)c->cfg.max_fft3n * 2 * c->N3; break;
     case LRH_RING_BASEB_RAW: src = c->d_baseb; total = 2 * (size_t)c->cfg.baseband_size; break;
+    case LRH_RING_FFT2_XYPOWER: if (!c->d_xypower) return fail(c, LRH_ESTATE, "blanker_channels != 2"); src = c->d_xypower; total = (size_t)c->cfg.max_fft2n * 4 * c->N2; break;
+    case LRH_RING_FFT2_XYSUM: if (!c->d_xysum) return fail(c, LRH_ESTATE, "blanker_channels != 2"); src = c->d_xysum; total = 4 * (size_t)c->N2; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

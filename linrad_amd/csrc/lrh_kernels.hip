@@ -1035,6 +1035,43 @@ __global__ __launch_bounds__(256) void k_powersum2(Powersum2Args a)
   if (g == (int)gridDim.y - 1) a.powersum_out[i] = acc;
 }
 
+// Two coupled channels (fft2.c:1622-1640): per transform and bin the TWOCHAN_POWER cross products of the two channels'
+// spectra, summed over a waterfall averaging group (fft2_xysum) in the reference's order; group arithmetic of
+// k_powersum2.  A completed group leaves the power the two-channel waterfall line shows (fft2.c:1700-1712),
+// (x2+y2) + 2 (re_xy^2 + im_xy^2 - x2 y2) / (x2+y2), in `lines` for k_waterfall.  One bin per lane: 8 + 8 bytes in,
+// 16 bytes out per transform, all coalesced.
+__global__ __launch_bounds__(256) void k_xypower(XyArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int g = blockIdx.y;
+  const int start = g == 0 ? 0 : g * a.avgnum - a.counter;
+  int count = a.avgnum - (g == 0 ? a.counter : 0);
+  const bool complete = count <= a.batch - start;
+  if (!complete) count = a.batch - start;
+  const bool accumulate = g == 0 && a.counter > 0;
+  float4 acc = accumulate ? a.sum_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < count; b++) {
+    const size_t t = (size_t)(start + b) * a.n + i;
+    const float2 x = a.x[t], y = a.y[t];
+    float4 v;
+    v.x = x.x * x.x + x.y * x.y;
+    v.y = y.x * y.x + y.y * y.y;
+    v.z = -x.x * y.y + x.y * y.x;
+    v.w = x.x * y.x + x.y * y.y;
+    a.xypower[(size_t)((a.first_na + start + b) & a.na_mask) * a.n + i] = v;
+    if (b == 0 && !accumulate) acc = v;
+    else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  }
+  if (complete) {
+    const float t1 = acc.x + acc.y;
+    // t1 == 0 (a bin empty in both channels): the reference's 0/0 ends, through the int conversion of a NaN on x86
+    // (INT_MIN) and the clamp, at -32767, where a zero power ends too
+    a.lines[(size_t)g * a.n + i] = t1 > 0.f ? t1 + 2 * (acc.w * acc.w + acc.z * acc.z - acc.x * acc.y) / t1 : 0.f;
+  }
+  if (g == (int)gridDim.y - 1) a.sum_out[i] = acc;
+}
+
 // one waterfall line, 0.01 dB shorts (fft2.c:707-812); itab[] holds the reference's float-accumulated yfac index
 __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
 {
@@ -1449,6 +1486,12 @@ hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st)
 {
   const int ngroups = (a.counter + a.count + a.avgnum - 1) / a.avgnum;
   hipLaunchKernelGGL(k_powersum2, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_xypower(const XyArgs &a, hipStream_t st)
+{
+  const int ngroups = (a.counter + a.batch + a.avgnum - 1) / a.avgnum;
+  hipLaunchKernelGGL(k_xypower, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)

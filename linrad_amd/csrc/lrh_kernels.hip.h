@@ -116,6 +116,15 @@ struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
   const float *powersum_in; float *powersum_out; float *wf_scratch; int counter; int avgnum;
 };
+// two coupled channels: cross products of the channels' fft2 bins (TWOCHAN_POWER), sums per waterfall group
+struct XyArgs {
+  const float2 *x, *y;        // [batch][n] bins of channel 0 / channel 1 (the two slots of the exchange buffer)
+  float4 *xypower;            // ring [na_mask+1][n] {x2, y2, im_xy, re_xy}
+  int first_na, na_mask, n, batch;
+  const float4 *sum_in; float4 *sum_out;   // fft2_xysum, ping-pong like fft2_powersum
+  float *lines;               // [group][n] polarisation-independent power of each completed group, for k_waterfall
+  int counter, avgnum;
+};
 struct WaterfallArgs {
   const float *ps; const float *yfac; const int *itab; int16_t *line;
   int npix; int first; int siz; int hx; int hp;

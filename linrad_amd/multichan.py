@@ -58,6 +58,37 @@ def exchange_sum(rx, which, count, dist, device=None):
         rx.exchange_write(which, t.numpy())
 
 
+def exchange_gather(rx, which, count, dist, device=None):
+    """all-gather of the two `count`-float slots of an exchange buffer: slot r is the one rank r filled, afterwards every
+    rank holds both.  HIP receiver: in place on the device buffer (RCCL recognises the input as its own slot of the
+    output); CPU oracle (gloo tests): through host memory.  A group of one rank has nothing to fetch."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return
+    assert world == 2, "Linrad has at most two RF channels (SURVEY F4)"
+    if device is not None:
+        rx.sync()
+        t = torch.as_tensor(_DevSpan(rx.exchange_ptr(which), 2 * count), device=device)
+        dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
+        torch.cuda.synchronize(device)
+    else:
+        own = torch.from_numpy(rx.exchange_read(which, count, rank * count))
+        slots = [torch.empty_like(own), torch.empty_like(own)]
+        dist.all_gather(slots, own)
+        rx.exchange_write(which, slots[1 - rank].numpy(), (1 - rank) * count)
+
+
+def coupled_fft2(rx, batch, dist, device=None):
+    """make_fft2 of one of two coupled channels: the own transforms, then both channels' bins gathered for the cross
+    products, fft2_xysum and the polarisation-independent waterfall line (fft2.c:1622-1640, 1700-1815)."""
+    at = rx.ptrs_copy()
+    rx.make_fft2(batch)
+    n = rx.fft2_xy_begin(at, batch)
+    exchange_gather(rx, rx.X_BINS, n, dist, device)
+    rx.fft2_xy_finish(at, batch)
+
+
 def coupled_blanker(rx, dist, device=None):
     """first_noise_blanker of one of two coupled channels: power-sum exchange, scan, noise-statistic exchange, update
     (include/linrad_hip.h; blank1.c:1017, 1236-1300, 1510-1545, 1570)."""
@@ -70,9 +101,10 @@ def coupled_blanker(rx, dist, device=None):
     return n
 
 
-def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True):
+def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True, xy=False):
     """single-CPU order of wideband_dsp (wcw.c:1036-1118) for one of two coupled channels, `batch` fft1 blocks per round,
-    with the cross-channel exchanges between the stage calls."""
+    with the cross-channel exchanges between the stage calls (xy: also the fft2 cross products, an all-gather of the new
+    transforms' bins)."""
     c = rx.cfg
     N2, M2 = rx.N2, rx.N2 - rx.fft2_interleave_points
     tmask = 4 * c.timf2pow_size - 1
@@ -84,7 +116,10 @@ def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True):
         k = 0 if avail < 4 * N2 else 1 + (avail - 4 * N2) // (4 * M2)
         while k > 0:
             kb = min(k, c.max_fft2n)
-            rx.make_fft2(kb)
+            if xy:
+                coupled_fft2(rx, kb, dist, device)
+            else:
+                rx.make_fft2(kb)
             if mix1:
                 rx.fft2_mix1_fixed(kb)
             k -= kb

@@ -35,6 +35,7 @@ struct lro_ctx {
   float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
   /* two coupled channels (cfg.blanker_channels = 2): summed power ring the blanker decides on, exchange buffers, and
      what lro_first_noise_blanker leaves for lro_blanker_finish */
+  float *xbins, *fft2_xypower, *fft2_xysum;   /* LRH_X_BINS [2][max_fft2n][N2][2]; TWOCHAN_POWER rings (fft2.c:1622-1640) */
   float *pwr_sum, *xbuf; float xstat[2]; int x_pbeg, x_count, fin_pending, fin_do_update; float fin_llf;
   float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
@@ -145,6 +146,7 @@ static void default_yfac(lro_ctx *c)
   t1 /= (float)sqrt((float)(c->cfg.waterfall_avgnum));
   t1 *= (float)(1 << (2 * c->cfg.bckfft_att_n));
   t1 *= (float)(1 + 1 / (0.5 + c->cfg.fft1_sinpow));
+  if (c->cfg.blanker_channels == 2) t1 *= 4.0f;             /* ui.rx_rf_channels^2, wide_graph.c:985 */
   for (int i = 0; i < c->N1; i++)
     c->wg_waterf_yfac[i] = (c->fft1_desired[i] > 0.3162278) ? t1 / (float)pow(c->fft1_desired[i], 2.0) : t1 * 10;
   c->wg_waterf_yfac[0] = t1; c->wg_waterf_yfac[c->N1 - 1] = t1;
@@ -242,7 +244,9 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->timf1 = zal(cfg->timf1_bytes); c->fft1_float = zal(sizeof(float) * cfg->max_fft1n * 2 * N1);
   c->fft1_sumsq = zal(4 * (size_t)cfg->fft1_sumsq_bufsize); c->fft1_slowsum = zal(4 * N1);
   c->timf2_float = zal(16 * (size_t)cfg->timf2pow_size); c->timf2_pwr = zal(4 * (size_t)cfg->timf2pow_size);
-  if (cfg->blanker_channels == 2) { c->pwr_sum = zal(4 * (size_t)cfg->timf2pow_size); c->xbuf = zal(4 * (size_t)cfg->timf2pow_size); c->x_count = -1; }
+  if (cfg->blanker_channels == 2) { c->pwr_sum = zal(4 * (size_t)cfg->timf2pow_size); c->xbuf = zal(4 * (size_t)cfg->timf2pow_size); c->x_count = -1;
+    c->xbins = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2); c->fft2_xypower = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2);
+    c->fft2_xysum = zal(sizeof(float) * 4 * (size_t)N2); }
   c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
@@ -310,7 +314,7 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf };
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -614,22 +618,27 @@ int lro_blanker_finish(lro_ctx *c, lrh_ptrs *p)
   c->bs.timf2_despiked_pwrinc[1] += c->xstat[1];
   return blanker_update(c, p, c->xstat[0] + c->xstat[1], c->fin_do_update, c->fin_llf, 2);
 }
+static size_t exchange_cap(const lro_ctx *c, int which)
+{
+  return which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : which == LRH_X_STAT ? 2 : 4 * (size_t)c->cfg.max_fft2n * c->N2;
+}
 int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
 {
   if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
-  *ptr = which == LRH_X_PWR ? (void *)c->xbuf : (void *)c->xstat;
+  if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS) return LRH_EINVAL;
+  *ptr = which == LRH_X_PWR ? (void *)c->xbuf : which == LRH_X_STAT ? (void *)c->xstat : (void *)c->xbins;
   return LRH_OK;
 }
 int lro_exchange_read(lro_ctx *c, int which, float *dst, size_t off, size_t count)
 {
   void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
-  if (off + count > (which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : 2)) return LRH_EINVAL;
+  if (off + count > exchange_cap(c, which)) return LRH_EINVAL;
   memcpy(dst, (float *)q + off, 4 * count); return LRH_OK;
 }
 int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size_t count)
 {
   void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
-  if (off + count > (which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : 2)) return LRH_EINVAL;
+  if (off + count > exchange_cap(c, which)) return LRH_EINVAL;
   memcpy((float *)q + off, src, 4 * count); return LRH_OK;
 }
 
@@ -753,12 +762,13 @@ static void wf_geometry(const lro_ctx *c, int *hg_xpp, int *hg_ppx, int *wg_xpp,
 }
 
 /* FFT2_WATERFALL_LINE, fft2.c:707-815: short y = 1000*log10(powersum*yfac), clamp +-32767 */
-static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p)
+static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p, const float *ps)
 {
   int hx, hp, wx, wp, wfirst; wf_geometry(c, &hx, &hp, &wx, &wp, &wfirst);
   int npix = c->cfg.wf_xpixels, siz = c->N2;
   int16_t *line = c->wg_waterf + p->wg_waterf_ptr;
-  const float *ps = c->fft2_powersum, *yf = c->wg_waterf_yfac;
+  const float *yf = c->wg_waterf_yfac;
+  if (!ps) goto advance;                      /* coupled channels: the line is written by lro_fft2_xy_finish */
   float a2 = 1, a3; int y, itab, i;
   if (wx > 0) a2 = wx; else a2 = 1. / wp;
   a3 = wfirst + 0.5 * a2;
@@ -801,6 +811,7 @@ static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p)
       ia = ib; ib += hx; if (ib >= siz) ib = siz;
     }
   }
+advance:
   /* update_wg_waterf, fft1.c:104-113 */
   p->wg_waterf_ptr -= npix; if (p->wg_waterf_ptr < 0) p->wg_waterf_ptr += c->cfg.wf_lines * npix;
   p->wg_waterf_sum_counter = 0;
@@ -825,12 +836,57 @@ int lro_make_fft2(lro_ctx *c, lrh_ptrs *p, int batch)
     if (p->wg_waterf_sum_counter == 0) for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] = pwra[i]; }
     else                               for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] += pwra[i]; }
     p->wg_waterf_sum_counter++;
-    if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) fft2_waterfall_line(c, p);
+    if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) fft2_waterfall_line(c, p, c->cfg.blanker_channels == 2 ? NULL : c->fft2_powersum);
     p->timf2_px = (p->timf2_px + 4 * c->M2) & mask;
     p->fft2_na = (p->fft2_na + 1) & c->fft2n_mask;
     p->fft2_pa = 2 * p->fft2_na * N;
     p->fft2_nb = (p->fft2_nb + 1) & c->fft2n_mask;
     if (p->fft2_nm != c->fft2n_mask) p->fft2_nm++;
+  }
+  return LRH_OK;
+}
+
+/* Two coupled channels, see include/linrad_hip.h: the own new transforms go to slot timf1_channel_index of LRH_X_BINS ... */
+int lro_fft2_xy_begin(lro_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
+{
+  if (c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  if (batch < 1 || batch > c->cfg.max_fft2n || !count) return LRH_EINVAL;
+  const size_t per = (size_t)2 * c->N2;
+  float *slot = c->xbins + (size_t)(c->cfg.timf1_channel_index & 1) * batch * per;
+  for (int b = 0; b < batch; b++)
+    memcpy(slot + b * per, c->fft2_float + (size_t)((at->fft2_na + b) & c->fft2n_mask) * per, 4 * per);
+  *count = batch * per;
+  return LRH_OK;
+}
+/* ... and, once the partner's slot has arrived, the cross products and sums of fft2.c:1622-1640 and the waterfall
+   line of fft2.c:1700-1815, whose power is (x2+y2) + 2 (re_xy^2 + im_xy^2 - x2 y2) / (x2+y2) of the sums */
+int lro_fft2_xy_finish(lro_ctx *c, const lrh_ptrs *at, int batch)
+{
+  if (c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  if (batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  const int N = c->N2;
+  lrh_ptrs q = *at;
+  float *r = c->tmp;
+  for (int b = 0; b < batch; b++) {
+    const float *x = c->xbins + (size_t)b * 2 * N, *y = c->xbins + ((size_t)batch + b) * 2 * N;
+    float *ya = c->fft2_xypower + (size_t)4 * q.fft2_na * N, *s = c->fft2_xysum;
+    for (int i = 0; i < N; i++) {
+      ya[4 * i] = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+      ya[4 * i + 1] = y[2 * i] * y[2 * i] + y[2 * i + 1] * y[2 * i + 1];
+      ya[4 * i + 2] = -x[2 * i] * y[2 * i + 1] + x[2 * i + 1] * y[2 * i];
+      ya[4 * i + 3] = x[2 * i] * y[2 * i] + x[2 * i + 1] * y[2 * i + 1];
+      if (q.wg_waterf_sum_counter == 0) for (int k = 0; k < 4; k++) s[4 * i + k] = ya[4 * i + k];
+      else for (int k = 0; k < 4; k++) s[4 * i + k] += ya[4 * i + k];
+    }
+    q.wg_waterf_sum_counter++;
+    if (q.wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) {
+      for (int i = 0; i < N; i++) {
+        float t1 = s[4 * i] + s[4 * i + 1];
+        r[i] = t1 + 2 * (s[4 * i + 3] * s[4 * i + 3] + s[4 * i + 2] * s[4 * i + 2] - s[4 * i] * s[4 * i + 1]) / t1;
+      }
+      fft2_waterfall_line(c, &q, r);
+    }
+    q.fft2_na = (q.fft2_na + 1) & c->fft2n_mask;
   }
   return LRH_OK;
 }
@@ -1172,6 +1228,8 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
     case LRH_RING_TIMF2_BLOCKPOWER: src = c->timf2_blockpower; total = c->cfg.timf2_blockpower_size; break;
     case LRH_RING_FFT3: src = c->fft3; total = (size_t)c->cfg.max_fft3n * 2 * c->N3; break;
     case LRH_RING_BASEB_RAW: src = c->baseb_raw; total = 2 * (size_t)c->cfg.baseband_size; break;
+    case LRH_RING_FFT2_XYPOWER: if (!c->fft2_xypower) return LRH_ESTATE; src = c->fft2_xypower; total = (size_t)c->cfg.max_fft2n * 4 * c->N2; break;
+    case LRH_RING_FFT2_XYSUM: if (!c->fft2_xysum) return LRH_ESTATE; src = c->fft2_xysum; total = 4 * (size_t)c->N2; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

@@ -128,6 +128,8 @@ int main(int argc, char **argv)
   int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
   int timing = AI("timing", 0);                  /* 1: print the wall time of the block loop (bench.py cpu_baseline), skip the ring dumps */
   int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
+  int chain2 = AI("chain2", 0);                  /* channels=2 only: run on through the two-channel first_noise_blanker, make_fft2
+                                                    (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
   const char *fin = arg(argc, argv, "in", NULL);
@@ -265,7 +267,8 @@ int main(int argc, char **argv)
   timf2_oscilloscope_powermax_float = 0; timf2_show_pointer = -1; timf2_oscilloscope_interval = 15;
 
   /* ---- fft2 (mode 15) ---- */
-  fft2_float = zalloc(sizeof(float) * 2 * N2 * maxfft2n);
+  fft2_float = zalloc(sizeof(float) * 2 * C * N2 * maxfft2n);
+  if (C == 2) { fft2_xypower = zalloc(sizeof(TWOCHAN_POWER) * N2 * maxfft2n); fft2_xysum = zalloc(sizeof(TWOCHAN_POWER) * N2); }
   max_fft2n = maxfft2n; fft2n_mask = max_fft2n - 1;
   fft2_tab = zalloc(sizeof(COSIN_TABLE) * N2);
   fft2_bigpermute = zalloc(sizeof(int) * N2);
@@ -291,7 +294,7 @@ int main(int argc, char **argv)
     fft2_new_points = fft2_size - fft2_interleave_points;
     mix1.new_points = mix1.size - mix1.interleave_points;
   }
-  timf2_output_block = 4 * fft2_new_points;
+  timf2_output_block = 4 * C * fft2_new_points;
 
   /* waterfall line from fft2 (fft2.c:707-815) */
   wg_xpixels = wf_pix ? wf_pix : (N2 < 1024 ? N2 : 1024);
@@ -316,6 +319,7 @@ int main(int argc, char **argv)
     t1 /= (float)sqrt((float)(wg.waterfall_avgnum));
     t1 *= (float)(1 << (2 * genparm[FIRST_BCKFFT_ATT_N]));
     t1 *= (float)(1 + 1 / (0.5 + genparm[FIRST_FFT_SINPOW]));
+    t1 *= (float)(ui.rx_rf_channels * ui.rx_rf_channels);
     for (int i = 0; i < N1; i++)
       wg_waterf_yfac[i] = (fft1_desired[i] > 0.3162278) ? t1 / (float)pow(fft1_desired[i], 2.0) : t1 * 10;
     wg_waterf_yfac[0] = t1; wg_waterf_yfac[N1 - 1] = t1;
@@ -332,9 +336,9 @@ int main(int argc, char **argv)
   make_window(5, mix1.size, 4, mix1_fqwin);
   rx_mode = 0;
   prepare_mixer(&mix1, second ? SECOND_FFT_SINPOW : FIRST_FFT_SINPOW);   /* the reference's own, buf.c:55-111 */
-  fftn_tmp = zalloc(sizeof(float) * (4 * mix1.size + 64));
-  timf3_block = 2 * mix1.new_points;
-  timf3_size = 16 * 2 * mix1.size; timf3_mask = timf3_size - 1;
+  fftn_tmp = zalloc(sizeof(float) * (4 * C * mix1.size + 64));
+  timf3_block = 2 * C * mix1.new_points;
+  timf3_size = 16 * 2 * C * mix1.size; timf3_mask = timf3_size - 1;
   timf3_float = zalloc(sizeof(float) * (2 * timf3_size + 4 * mix1.size));
   timf3_pa = timf3_px = timf3_py = 0;
   fftx_points_per_hz = 1.0f; mix1_lowest_fq = 0; mix1_highest_fq = (float)(second ? N2 : N1);
@@ -439,7 +443,7 @@ int main(int argc, char **argv)
       continue;
     }
     while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
-    if (C == 2) {                /* two channels: make_timf2, then (blanker2=1) the two-channel first_noise_blanker; fft2 / mix1 not driven */
+    if (C == 2 && !chain2) {     /* two channels: make_timf2, then (blanker2=1) the two-channel first_noise_blanker; fft2 / mix1 only with chain2=1 */
       int *it2 = itrace + TR_COLS * b; float *t2 = trace + TR_COLS * b;
       int pbeg2 = timf2p_fit;
       if (AI("blanker2", 0)) first_noise_blanker();
@@ -455,7 +459,7 @@ int main(int argc, char **argv)
     int pbeg = timf2p_fit;
     first_noise_blanker();
     if (bp_block > 0) compute_timf2_powersum();
-    while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * fft2_size) {
+    while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * C * fft2_size) {     /* wcw.c:265-266 */
       int wptr = wg_waterf_ptr;
       make_fft2_status = FFT2_NOT_ACTIVE;
       while (make_fft2_status != FFT2_COMPLETE) make_fft2();
@@ -495,7 +499,8 @@ int main(int argc, char **argv)
   PUTF("fft1_slowsum", fft1_slowsum, N1);
   PUTF("timf2_float", timf2_float, timf2_size);
   PUTF("timf2_pwr_float", timf2_pwr_float, timf2pow_size);
-  PUTF("fft2_float", fft2_float, (size_t)2 * N2 * max_fft2n);
+  PUTF("fft2_float", fft2_float, (size_t)2 * C * N2 * max_fft2n);
+  if (C == 2) { PUTF("fft2_xypower", (float *)fft2_xypower, (size_t)4 * N2 * max_fft2n); PUTF("fft2_xysum", (float *)fft2_xysum, (size_t)4 * N2); }
   PUTF("fft2_power_float", fft2_power_float, (size_t)N2 * max_fft2n);
   PUTF("fft2_powersum_float", fft2_powersum_float, N2);
   PUTF("timf3_float", timf3_float, timf3_size);

@@ -43,8 +43,24 @@ def main():
             out["bln_" + k] = refb[k]
         out["frames"], out["liminfo"] = frames, lim
         path = os.path.join(HERE, f"{name}.npz")
-        np.savez_compressed(path, **out)
-        print(name, os.path.getsize(path) // 1024, "KiB")
+        if "--chain-only" not in sys.argv:
+            np.savez_compressed(path, **out)
+            print(name, os.path.getsize(path) // 1024, "KiB")
+        # third run: the whole two-channel chain (two-channel first_noise_blanker, make_fft2 with fft2_xypower / fft2_xysum
+        # and the polarisation-independent waterfall line, fft2_mix1_fixed); input = the same frames
+        d, frames, lim = twochan_case(name, chain=True)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+            frames.tofile(fi)
+            lim.tofile(fl)
+            args = harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}", "chain2=1"]
+            subprocess.check_call([HARNESS] + args)
+            refc = load_dump(fo)
+        outc = {k: refc[k] for k in ("hdr", "itrace", "trace", "fft2_float", "fft2_xypower", "fft2_xysum", "wf_lines", "timf3_float",
+                                     "mixtrace", "final", "wg_waterf_yfac", "timf2_pwr_float")}
+        path = os.path.join(HERE, f"{name}_chain.npz")
+        np.savez_compressed(path, **outc)
+        print(name + "_chain", os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

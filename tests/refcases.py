@@ -202,12 +202,15 @@ TWOCHAN = {
 }
 
 
-def twochan_case(name):
+def twochan_case(name, chain=False):
     """params, frame-interleaved input {I0,Q0,I1,Q1} and liminfo of a two-channel case: channel 1 = the same carriers
-    and pulses turned by sky_phase, independent noise."""
+    and pulses turned by sky_phase, independent noise.  chain: the run goes on through the two-channel
+    blanker, make_fft2 and fft2_mix1_fixed at the base case's frequency (harness chain2=1)."""
     t = TWOCHAN[name]
     d = case_params(t["base"])
-    d.update(nblk=t["nblk"], ch2_c1=t["ch2_c1"], ch2_c2=t["ch2_c2"], fq=-1.0, second_fft=1)
+    d.update(nblk=t["nblk"], ch2_c1=t["ch2_c1"], ch2_c2=t["ch2_c2"], fq=d["fq"] if chain else -1.0, second_fft=1)
+    if chain:
+        d.update(blockpower_block=0)
     x0 = make_input(d).astype(np.float64)
     z0 = x0[0::2] + 1j * x0[1::2]
     rng0 = np.random.default_rng(d["seed"])

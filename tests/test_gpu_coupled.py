@@ -41,3 +41,37 @@ def test_device_exchange_equals_host_exchange():
         assert np.count_nonzero(res[0][2]) > 0 and (res[0][0].reshape(-1, 4)[:, :2] == 0).all(axis=1).sum() > 50
     finally:
         dist.destroy_process_group()
+
+
+def test_gather_exchange_and_batched_cross_products():
+    """Plumbing of multichan.coupled_fft2 on the device path with a one-rank group: lrh_fft2_xy_begin leaves the batch's
+    transforms in the own slot of LRH_X_BINS, the gather leaves it alone, lrh_fft2_xy_finish forms x2 from it (the partner
+    slot was never filled, so every product with y is zero).  Parity of the products: tests/test_twochan.py."""
+    import torch
+    import torch.distributed as dist
+    from linrad_amd.lib import open_hip
+    from linrad_amd.multichan import coupled_fft2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+    try:
+        d, frames, lim = twochan_case("twochan_n10", chain=True)
+        iq = np.ascontiguousarray(frames.reshape(-1, 4)[:, 0:2]).ravel()
+        cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=0)
+        rx = open_hip(cfg)
+        rx.timf1_write(iq)
+        rx.set_liminfo(lim)
+        for _ in range(24):
+            rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1)
+        rx.p.timf2_pn2 = rx.p.timf2_pa                      # release everything (no blanker here: plumbing test)
+        k = rx.fft2_available()
+        assert k >= 3
+        coupled_fft2(rx, 3, dist, torch.device("cuda:0"))
+        own = rx.exchange_read(rx.X_BINS, 3 * 2 * rx.N2)
+        assert np.array_equal(own.reshape(3, -1), rx.export(abi.RING_FFT2_FLOAT).reshape(-1, 2 * rx.N2)[:3])
+        xyp = rx.export(abi.RING_FFT2_XYPOWER).reshape(-1, rx.N2, 4)[:3]
+        f = own.reshape(3, rx.N2, 2).astype(np.float32)
+        assert np.allclose(xyp[:, :, 0], f[:, :, 0] ** 2 + f[:, :, 1] ** 2, rtol=1e-6)
+        assert np.count_nonzero(xyp[:, :, 1:]) == 0          # the partner slot was never filled: y = 0
+    finally:
+        dist.destroy_process_group()

@@ -124,3 +124,63 @@ def test_coupled_two_channel_blanker_over_gloo():
             assert same_cleared
             assert np.linalg.norm(t - ref) <= 2e-6 * np.linalg.norm(ref)
         assert np.count_nonzero(res[ch]["fft2"]) > 0            # the chain went on behind the blanker (make_fft2 on the released data)
+
+
+def _chain_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from linrad_amd import abi
+    from linrad_amd.multichan import run_coupled
+    from oracle_binding import open_oracle
+    from refcases import lrh_config, twochan_case
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d, frames, lim = twochan_case("twochan_n10", chain=True)
+    iq = np.ascontiguousarray(frames.reshape(-1, 4)[:, 2 * rank:2 * rank + 2]).ravel()
+    cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=rank)
+    rx = open_oracle(cfg)
+    rx.timf1_write(iq)
+    rx.set_liminfo(lim)
+    rx.set_mix1_selfreq(d["fq"])
+    if rank == 1:
+        rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
+    run_coupled(rx, d["nblk"], 1, dist, xy=True)
+    out = dict(xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM), wf=rx.export(abi.RING_WG_WATERF),
+               timf3=rx.export(abi.RING_TIMF3_FLOAT), fft2_na=rx.p.fft2_na, wptr=rx.p.wg_waterf_ptr)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_two_channel_chain_over_gloo():
+    """The whole coupled chain with the collectives of linrad_amd/multichan.py: two all-reduces per blanker call and one
+    all-gather of the new fft2 bins per make_fft2.  Both ranks must end with the compiled two-channel reference's
+    fft2_xypower / fft2_xysum and waterfall lines, each with its own channel of timf3."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "twochan_n10_chain.npz"))
+    fin = g["final"]
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
+    for r in (0, 1):
+        assert res[r]["fft2_na"] == fin[7]
+        assert rel(res[r]["xyp"], g["fft2_xypower"]) < 4e-6 and rel(res[r]["xys"], g["fft2_xysum"]) < 4e-6
+    assert np.array_equal(res[0]["xyp"], res[1]["xyp"]) and np.array_equal(res[0]["wf"], res[1]["wf"])
+    npix = g["wf_lines"].size // fin[11]
+    lines = g["wf_lines"].reshape(-1, npix).astype(np.int32)
+    wf = res[0]["wf"].reshape(-1, npix).astype(np.int32)
+    # lines go downwards from the top of the ring (update_wg_waterf): line l sits at row (0 - l) mod wf_lines; the newest 8 survive
+    for l in range(max(0, len(lines) - wf.shape[0]), len(lines)):
+        diff = np.abs(wf[(-l) % wf.shape[0]] - lines[l])
+        assert diff.max() <= 2 and np.mean(diff != 0) < 0.02, (l, diff.max())
+    assert not np.array_equal(res[0]["timf3"], res[1]["timf3"]) and np.count_nonzero(res[0]["timf3"]) > 0

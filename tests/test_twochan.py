@@ -163,3 +163,107 @@ def test_hip_coupled_blanker_matches_two_channel_reference(name):
     from linrad_amd.lib import open_hip
     d, g, out, trace = _run_coupled(open_hip, name, frames_mode=True)
     _check_coupled(d, g, out, trace, 1e-5)
+
+
+# ---- the whole two-channel chain: coupled blanker -> make_fft2 per channel -> cross products / sums / polarisation-
+# independent waterfall line from both channels' bins (fft2.c:1622-1640, 1700-1815; the all-gather is done by hand here,
+# tests/test_multichan_gloo.py does it with gloo) -> fft2_mix1_fixed per channel
+def _run_chain(open_fn, name, frames_mode, batch=1):
+    d, frames, lim = twochan_case(name, chain=True)
+    g = np.load(os.path.join(HERE, "golden", f"{name}_chain.npz"))
+    fr = frames.reshape(-1, 4)
+    rxs = []
+    for ch in (0, 1):
+        iq = np.ascontiguousarray(fr[:, 2 * ch:2 * ch + 2]).ravel()
+        cfg = lrh_config(d, iq, blanker_channels=2, timf1_channel_index=ch)
+        if frames_mode:
+            cfg.timf1_bytes *= 2
+            cfg.timf1_frame_channels = 2
+        rx = open_fn(cfg)
+        rx.timf1_write(frames if frames_mode else iq)
+        rx.set_liminfo(lim)
+        rx.set_mix1_selfreq(d["fq"])
+        if ch == 1:
+            rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
+        rxs.append(rx)
+    wf_lines, nfft2 = [], 0
+    X = abi.StageAPI
+    for _ in range(d["nblk"]):
+        for rx in rxs:
+            rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1)
+        n = [rx.blanker_begin() for rx in rxs]
+        if n[0]:
+            tot = rxs[0].exchange_read(X.X_PWR, n[0]) + rxs[1].exchange_read(X.X_PWR, n[0])
+            for rx in rxs:
+                rx.exchange_write(X.X_PWR, tot)
+        for rx in rxs:
+            rx.first_noise_blanker()
+        if n[0]:
+            st = rxs[0].exchange_read(X.X_STAT, 2) + rxs[1].exchange_read(X.X_STAT, 2)
+            for rx in rxs:
+                rx.exchange_write(X.X_STAT, st)
+                rx.blanker_finish()
+        k = rxs[0].fft2_available()
+        assert k == rxs[1].fft2_available()
+        while k > 0:
+            kb = min(k, batch)
+            at = [rx.ptrs_copy() for rx in rxs]
+            cnt = []
+            for rx, a in zip(rxs, at):
+                rx.make_fft2(kb)
+                cnt.append(rx.fft2_xy_begin(a, kb))
+            assert cnt[0] == cnt[1] == kb * 2 * rxs[0].N2
+            own = [rx.exchange_read(X.X_BINS, cnt[0], ch * cnt[0]) for ch, rx in enumerate(rxs)]
+            for ch, rx in enumerate(rxs):                      # all-gather: each context receives the other channel's slot
+                rx.exchange_write(X.X_BINS, own[1 - ch], (1 - ch) * cnt[0])
+                rx.fft2_xy_finish(at[ch], kb)
+            wptr = at[0].wg_waterf_ptr
+            for _ in range((at[0].wg_waterf_sum_counter + kb) // d["wf_avgnum"]):
+                wf_lines.append([rx.export(abi.RING_WG_WATERF, wptr, rx.cfg.wf_xpixels) for rx in rxs])
+                wptr = (wptr - rxs[0].cfg.wf_xpixels) % (rxs[0].cfg.wf_lines * rxs[0].cfg.wf_xpixels)
+            for rx in rxs:
+                rx.fft2_mix1_fixed(kb)
+            nfft2 += kb
+            k -= kb
+    out = [dict(fft2=rx.export(abi.RING_FFT2_FLOAT), xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM),
+                timf3=rx.export(abi.RING_TIMF3_FLOAT), p=rx.p.as_dict(), bs=rx.blanker_state()) for rx in rxs]
+    return d, g, out, wf_lines, nfft2
+
+
+def _check_chain(d, g, out, wf_lines, nfft2, tol):
+    N2 = 1 << d["n2"]
+    fin = g["final"]
+    assert nfft2 == fin[10] and len(wf_lines) == fin[11] and nfft2 >= 4 and fin[11] >= 2
+    gf = g["fft2_float"].reshape(-1, N2, 2, 2)
+    gt = g["timf3_float"].reshape(-1, 2, 2)
+    for ch in (0, 1):
+        assert out[ch]["p"]["fft2_na"] == fin[7] and out[ch]["p"]["fft2_nx"] == fin[8] and 2 * out[ch]["p"]["timf3_pa"] == fin[9]
+        assert _rel(out[ch]["fft2"].reshape(-1, N2, 2), gf[:, :, ch, :]) < tol, ch
+        # timf3 is a weak band cut from the wide spectrum: relative bound, or the float32 floor of that spectrum (paritylib)
+        nm, a, b = N2 >> d["mixred"], out[ch]["timf3"].reshape(-1, 2).astype(np.float64), gt[:, ch, :].astype(np.float64)
+        wide = np.linalg.norm(gf[:, :, ch, :].astype(np.float64)) / np.sqrt(gf.shape[0])
+        floor = 4 * 6e-8 * wide * np.sqrt(nm / N2) * np.sqrt(a.size / nm / 2) * np.sqrt(nm)
+        assert np.abs(b).max() > 0 and (_rel(a, b) < tol or np.linalg.norm(a - b) <= floor), (ch, _rel(a, b), floor)
+        # cross products: both contexts hold the reference's rings
+        assert _rel(out[ch]["xyp"], g["fft2_xypower"]) < 2 * tol, ch
+        assert _rel(out[ch]["xys"], g["fft2_xysum"]) < 2 * tol, ch
+    assert np.abs(g["fft2_xypower"].reshape(-1, 4)[:, 2:]).max() > 0
+    gw = g["wf_lines"].reshape(len(wf_lines), -1).astype(np.int32)
+    for ch in (0, 1):
+        ow = np.array([ln[ch] for ln in wf_lines], np.int32)
+        diff = np.abs(ow - gw)
+        assert diff.max() <= 2 and np.mean(diff != 0) < 0.02, (ch, diff.max(), np.mean(diff != 0))
+    assert np.array_equal(np.array([ln[0] for ln in wf_lines]), np.array([ln[1] for ln in wf_lines]))
+
+
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_oracle_two_channel_chain_matches_reference(name):
+    from oracle_binding import open_oracle
+    _check_chain(*_run_chain(open_oracle, name, frames_mode=False), 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("twochan_n10", 1), ("twochan_n9_sin3", 1), ("twochan_n10", 3)])
+def test_hip_two_channel_chain_matches_reference(name, batch):
+    from linrad_amd.lib import open_hip
+    _check_chain(*_run_chain(open_hip, name, frames_mode=True, batch=batch), 1e-5)
