@@ -245,7 +245,7 @@ int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
                               (blank1.c:1512-1541) in slot timf1_channel_index of LRH_X_STAT (2 floats, other slot 0)
      -> all-reduce(sum) LRH_X_STAT[0..2)
      lrh_blanker_finish       the statistics / threshold update of blank1.c:1542-1601 with both channels' values  */
-enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2 };
+enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2, LRH_X_POL = 3 };
 int lrh_blanker_begin(lrh_ctx *ctx, const lrh_ptrs *p, int *count);
 int lrh_blanker_finish(lrh_ctx *ctx, lrh_ptrs *p);
 /* Cross products of the two channels' fft2 spectra (make_fft2's two-channel branch, fft2.c:1622-1640: per transform and bin
@@ -293,10 +293,24 @@ int lrh_fft1_mix1_afc(lrh_ctx *ctx, lrh_ptrs *p, int batch, lrh_afc *afc);
 /* make_fft3_all, transform part (fft3def.h; fft3.c:215-283): windowed e^{+j} transform of timf3 at timf3_px with DC at
    fft3_size/2, `batch` transforms spaced fft3_new_points; the GUI power averages of fft3.c:470-760 are not built */
 int lrh_make_fft3_all(lrh_ctx *ctx, lrh_ptrs *p, int batch);
-/* fft3_mix2, mixer_mode 1 part (mix2.c:145-176): mix2.size bins around fft3_size/2 times bg_filterfunc, fftback,
-   overlap-add into baseb_raw.  PARITY UNPINNED against the reference: fft3_mix2 cannot be run head-less (it continues
-   into the demodulators); checked against the oracle restatement only. */
+/* fft3_mix2, mixer_mode 1 part (mix2.c:145-176; two channels mix2.c:313-628): mix2.size bins around fft3_size/2 times
+   bg_filterfunc, fftback, overlap-add into baseb_raw.  The rest of the reference function (carrier filter, demodulators)
+   is not on this path; the harness stops the compiled reference at its thread-command check (mix2.c:749) to pin this part. */
 int lrh_fft3_mix2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
+/* Two coupled channels: fft3_mix2 first turns the channel pair (X, Y) into the wanted polarisation and its orthogonal,
+     A = c1 X + (c2 - j c3) Y   -> baseb_raw            B = c1 Y - (c2 + j c3) X   -> baseb_raw_orthog
+   (mix2.c:340-343, 377-380; pg.c1..c3 of pol_graph.c), the coherent combine of the two receivers.  One channel per GPU:
+   each context weighs its own bins into both sums, the sums are an all-reduce, and the context of channel 0 carries on
+   with A, that of channel 1 with B, so each runs one back transform and its LRH_RING_BASEB_RAW is the reference's
+   baseb_raw resp. baseb_raw_orthog:
+     lrh_set_pol(ctx, c1, c2, c3)                 once (and whenever the control plane changes the polarisation)
+     lrh_mix2_pol_begin(ctx, p, batch, &count)    own contributions of the `batch` transforms at p->fft3_px to
+                                                  LRH_X_POL: float [2 (A,B)][batch][mix2.size][2], count floats in all
+     -> all-reduce(sum) LRH_X_POL[0..count)
+     lrh_fft3_mix2(ctx, p, batch)                 filter, back transform, overlap-add of A (channel 0) or B (channel 1)
+   Without lrh_set_pol a coupled context filters its own channel, like a single-channel one. */
+int lrh_set_pol(lrh_ctx *ctx, float c1, float c2, float c3);
+int lrh_mix2_pol_begin(lrh_ctx *ctx, const lrh_ptrs *p, int batch, size_t *count);
 int lrh_set_bg_filterfunc(lrh_ctx *ctx, const float *bg_filterfunc /* fft3_size floats (baseb_graph.c:1246) */);
 /* compute_timf2_powersum (wcw.c:80-138): weak-signal power per block of released timf2 data, for the S/N meter */
 int lrh_compute_timf2_powersum(lrh_ctx *ctx, lrh_ptrs *p);

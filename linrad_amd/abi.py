@@ -173,6 +173,8 @@ class StageAPI:
         self._proto("blanker_finish", [vp, C.POINTER(LrhPtrs)])
         self._proto("fft2_xy_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
         self._proto("fft2_xy_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
+        self._proto("set_pol", [vp, C.c_float, C.c_float, C.c_float])
+        self._proto("mix2_pol_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
         self._proto("exchange_ptr", [vp, C.c_int, C.POINTER(vp)])
         self._proto("exchange_read", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
         self._proto("exchange_write", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
@@ -247,7 +249,7 @@ class StageAPI:
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
 
     # ---- two coupled RF channels (cfg.blanker_channels = 2): see include/linrad_hip.h
-    X_PWR, X_STAT, X_BINS = 0, 1, 2
+    X_PWR, X_STAT, X_BINS, X_POL = 0, 1, 2, 3
 
     def ptrs_copy(self):
         """the pointer state as it is now (`at` of lrh_fft2_xy_begin / finish: taken before make_fft2)"""
@@ -258,6 +260,15 @@ class StageAPI:
     def fft2_xy_begin(self, at, batch=1):
         n = C.c_size_t()
         self._chk(self._f("fft2_xy_begin")(self.ctx, C.byref(at), batch, C.byref(n)), "fft2_xy_begin")
+        return n.value
+
+    def set_pol(self, c1, c2, c3):
+        """pg.c1..c3: the polarisation fft3_mix2 turns the channel pair into (mix2.c:340-343)"""
+        self._chk(self._f("set_pol")(self.ctx, float(c1), float(c2), float(c3)), "set_pol")
+
+    def mix2_pol_begin(self, batch=1):
+        n = C.c_size_t()
+        self._chk(self._f("mix2_pol_begin")(self.ctx, C.byref(self.p), batch, C.byref(n)), "mix2_pol_begin")
         return n.value
 
     def fft2_xy_finish(self, at, batch=1):

@@ -33,6 +33,7 @@ hipError_t launch_foldcorr(const FoldcorrArgs &a, int batch, hipStream_t st);
 hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring, int first_group, int group_mask, hipStream_t st);
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_xypower(const XyArgs &a, hipStream_t st);
+hipError_t launch_pol(const PolArgs &a, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -77,6 +78,7 @@ struct lrh_ctx {
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
+  float2 *d_xpol = nullptr; float pol[3] = {1.f, 0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
@@ -287,7 +289,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -457,6 +459,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_window3, c->N3)); A(dev_alloc(c, &c->d_bgfilt, c->N3)); A(dev_alloc(c, &c->d_tw3, c->N3)); A(dev_alloc(c, &c->d_twm2, c->Nm2));
     A(dev_alloc(c, &c->d_fft3, (size_t)cfg->max_fft3n * c->N3)); A(dev_alloc(c, &c->d_baseb, (size_t)cfg->baseband_size + 2 * c->Nm2));
     A(dev_alloc(c, &c->d_mix2_scratch, (size_t)cfg->max_fft3n * c->Nm2));
+    if (cfg->blanker_channels == 2) A(dev_alloc(c, &c->d_xpol, (size_t)2 * cfg->max_fft3n * c->Nm2));
   }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
@@ -850,6 +853,7 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
   if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
   else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
   else if (which == LRH_X_BINS) { *ptr = (float *)c->d_xbins; *cap = (size_t)4 * c->cfg.max_fft2n * c->N2; }
+  else if (which == LRH_X_POL) { if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured"); *ptr = (float *)c->d_xpol; *cap = (size_t)4 * c->cfg.max_fft3n * c->Nm2; }
   else return LRH_EINVAL;
   return LRH_OK;
 }
@@ -1223,13 +1227,44 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
   return LRH_OK;
 }
 
+// two coupled channels (include/linrad_hip.h): polarisation transform of fft3_mix2, mix2.c:340-343, 377-380
+int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
+{
+  if (!c) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  c->pol[0] = c1; c->pol[1] = c2; c->pol[2] = c3; c->pol_set = true;
+  return LRH_OK;
+}
+int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
+{
+  if (!c || !p || !count || batch < 1) return LRH_EINVAL;
+  if (!c->N3 || !c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
+  if (c->cfg.blanker_channels != 2 || !c->pol_set) return fail(c, LRH_ESTATE, "lrh_set_pol first");
+  if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  PolArgs a;
+  a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1; a.nm = c->Nm2; a.batch = batch;
+  const float c1 = c->pol[0], c2 = c->pol[1], c3 = c->pol[2];
+  if ((c->cfg.timf1_channel_index & 1) == 0) { a.wa = make_float2(c1, 0.f); a.wb = make_float2(-c2, -c3); }   // A += c1 X,          B -= (c2 + j c3) X
+  else                                       { a.wa = make_float2(c2, -c3); a.wb = make_float2(c1, 0.f); }    // A += (c2 - j c3) Y, B += c1 Y
+  a.out = c->d_xpol;
+  { ProfScope ps(c, "pol"); HIPCHK(c, launch_pol(a, c->cur)); }
+  c->pol_batch = batch;
+  *count = (size_t)4 * batch * c->Nm2;
+  return LRH_OK;
+}
+
 int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
+  const bool pol = c->cfg.blanker_channels == 2 && c->pol_set;
+  if (pol && c->pol_batch != batch) return fail(c, LRH_ESTATE, "lrh_mix2_pol_begin and the all-reduce come first");
+  c->pol_batch = 0;
   Mix2Args a;
+  a.pol = pol ? c->d_xpol + (size_t)(c->cfg.timf1_channel_index & 1) * batch * c->Nm2 : nullptr;
   a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
   a.filt = c->d_bgfilt; a.tw = c->d_twm2; a.scratch = c->d_mix2_scratch; a.nm = c->Nm2;
   Mix1OutArgs o; memset(&o, 0, sizeof o);

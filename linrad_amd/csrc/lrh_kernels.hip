@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mi
     for (int s = 0; s < R0; s++) {
       const int i = (tid + m * T) + s * (N / R0);
       const int bin = a.n3 / 2 + (i < N / 2 ? i : i - N);     // positive offsets first, then -N/2..-1
-      const float2 v = z[bin];
+      const float2 v = a.pol ? a.pol[(size_t)b * N + (bin - a.n3 / 2 + N / 2)] : z[bin];
       const float w = a.filt[bin];
       x[m * R0 + s] = make_float2(v.x * w, v.y * w);
     }
@@ -1280,6 +1280,18 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mi
   for (int m = 0; m < P / RL; m++)
 #pragma unroll
     for (int q = 0; q < RL; q++) o[(tid + m * T) + q * (N / RL)] = x[m * RL + q];
+}
+
+// Two coupled channels, polarisation transform of fft3_mix2 (mix2.c:340-343, 377-380): this channel's bins times its
+// complex weight in A and in B; the two channels' shares are summed by the caller's all-reduce.
+__global__ __launch_bounds__(256) void k_pol(PolArgs a)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (j >= a.nm) return;
+  const float2 v = a.fft3[(size_t)((a.first_slot + b) & a.slot_mask) * a.n3 + (a.n3 / 2 - a.nm / 2 + j)];
+  const size_t o = (size_t)b * a.nm + j;
+  a.out[o] = make_float2(a.wa.x * v.x - a.wa.y * v.y, a.wa.x * v.y + a.wa.y * v.x);
+  a.out[(size_t)a.batch * a.nm + o] = make_float2(a.wb.x * v.x - a.wb.y * v.y, a.wb.x * v.y + a.wb.y * v.x);
 }
 
 // weak-signal power per block of released timf2 data (wcw.c:84-113), one workgroup per block
@@ -1486,6 +1498,11 @@ hipError_t launch_powersum2(const Powersum2Args &a, hipStream_t st)
 {
   const int ngroups = (a.counter + a.count + a.avgnum - 1) / a.avgnum;
   hipLaunchKernelGGL(k_powersum2, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_pol(const PolArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_pol, dim3((a.nm + 255) / 256, a.batch), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_xypower(const XyArgs &a, hipStream_t st)

@@ -163,6 +163,12 @@ struct Fft3Args {
 struct Mix2Args {
   const float2 *fft3; int n3; int first_slot, slot_mask;
   const float *filt; const float2 *tw; float2 *scratch; int nm;
+  const float2 *pol;          // two coupled channels: [batch][nm] polarisation-combined bins standing in for the spectrum; null: fft3
+};
+// own channel's share of the polarisation sums A and B (mix2.c:340-343): w_a, w_b complex weights of this channel
+struct PolArgs {
+  const float2 *fft3; int n3; int first_slot, slot_mask; int nm, batch;
+  float2 wa, wb; float2 *out;   // out [2][batch][nm]
 };
 
 // ---- compute_timf2_powersum (wcw.c:80-138) ----

@@ -89,6 +89,15 @@ def coupled_fft2(rx, batch, dist, device=None):
     rx.fft2_xy_finish(at, batch)
 
 
+def coupled_fft3_mix2(rx, batch, dist, device=None):
+    """fft3_mix2 of one of two coupled channels: the coherent combine A = c1 X + (c2 - j c3) Y, B = c1 Y - (c2 + j c3) X
+    (mix2.c:340-343, 377-380) as an all-reduce of the channels' weighted bins; rank 0 then filters and back-transforms A
+    (baseb_raw), rank 1 B (baseb_raw_orthog).  Needs rx.set_pol()."""
+    n = rx.mix2_pol_begin(batch)
+    exchange_sum(rx, rx.X_POL, n, dist, device)
+    rx.fft3_mix2(batch)
+
+
 def coupled_blanker(rx, dist, device=None):
     """first_noise_blanker of one of two coupled channels: power-sum exchange, scan, noise-statistic exchange, update
     (include/linrad_hip.h; blank1.c:1017, 1236-1300, 1510-1545, 1570)."""
@@ -101,7 +110,7 @@ def coupled_blanker(rx, dist, device=None):
     return n
 
 
-def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True, xy=False):
+def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True, xy=False, pol=False):
     """single-CPU order of wideband_dsp (wcw.c:1036-1118) for one of two coupled channels, `batch` fft1 blocks per round,
     with the cross-channel exchanges between the stage calls (xy: also the fft2 cross products, an all-gather of the new
     transforms' bins)."""
@@ -122,5 +131,11 @@ def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True, xy=False):
                 rx.make_fft2(kb)
             if mix1:
                 rx.fft2_mix1_fixed(kb)
+                k3 = rx.fft3_available() if pol else 0
+                while k3 > 0:
+                    k3b = min(k3, rx.cfg.max_fft3n // 2)
+                    rx.make_fft3_all(k3b)
+                    coupled_fft3_mix2(rx, k3b, dist, device)
+                    k3 -= k3b
             k -= kb
         nblocks -= b

@@ -35,6 +35,7 @@ struct lro_ctx {
   float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
   /* two coupled channels (cfg.blanker_channels = 2): summed power ring the blanker decides on, exchange buffers, and
      what lro_first_noise_blanker leaves for lro_blanker_finish */
+  float *xpol; float pol[3]; int pol_set, pol_batch;   /* LRH_X_POL [2][max_fft3n][Nm2][2]; pg.c1..c3 */
   float *xbins, *fft2_xypower, *fft2_xysum;   /* LRH_X_BINS [2][max_fft2n][N2][2]; TWOCHAN_POWER rings (fft2.c:1622-1640) */
   float *pwr_sum, *xbuf; float xstat[2]; int x_pbeg, x_count, fin_pending, fin_do_update; float fin_llf;
   float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
@@ -246,7 +247,8 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->timf2_float = zal(16 * (size_t)cfg->timf2pow_size); c->timf2_pwr = zal(4 * (size_t)cfg->timf2pow_size);
   if (cfg->blanker_channels == 2) { c->pwr_sum = zal(4 * (size_t)cfg->timf2pow_size); c->xbuf = zal(4 * (size_t)cfg->timf2pow_size); c->x_count = -1;
     c->xbins = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2); c->fft2_xypower = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2);
-    c->fft2_xysum = zal(sizeof(float) * 4 * (size_t)N2); }
+    c->fft2_xysum = zal(sizeof(float) * 4 * (size_t)N2);
+    if (cfg->fft3_n) c->xpol = zal(sizeof(float) * 4 * (size_t)cfg->max_fft3n * (1 << cfg->mix2_n)); }
   c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
@@ -314,7 +316,7 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum };
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   free(c);
 }
@@ -620,13 +622,15 @@ int lro_blanker_finish(lro_ctx *c, lrh_ptrs *p)
 }
 static size_t exchange_cap(const lro_ctx *c, int which)
 {
+  if (which == LRH_X_POL) return c->xpol ? 4 * (size_t)c->cfg.max_fft3n * c->Nm2 : 0;
   return which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : which == LRH_X_STAT ? 2 : 4 * (size_t)c->cfg.max_fft2n * c->N2;
 }
 int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
 {
   if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
-  if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS) return LRH_EINVAL;
-  *ptr = which == LRH_X_PWR ? (void *)c->xbuf : which == LRH_X_STAT ? (void *)c->xstat : (void *)c->xbins;
+  if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS && which != LRH_X_POL) return LRH_EINVAL;
+  if (which == LRH_X_POL && !c->xpol) return LRH_ESTATE;
+  *ptr = which == LRH_X_PWR ? (void *)c->xbuf : which == LRH_X_STAT ? (void *)c->xstat : which == LRH_X_BINS ? (void *)c->xbins : (void *)c->xpol;
   return LRH_OK;
 }
 int lro_exchange_read(lro_ctx *c, int which, float *dst, size_t off, size_t count)
@@ -1148,16 +1152,47 @@ int lro_make_fft3_all(lro_ctx *c, lrh_ptrs *p, int batch)
   return LRH_OK;
 }
 
-/* fft3_mix2, mixer_mode 1 (mix2.c:145-176) + pointers (mix2.c:1079, 2057-2059).  PARITY UNPINNED: the reference function
-   cannot be run head-less, this restates the 30 lines directly. */
+/* two coupled channels, see include/linrad_hip.h: the own channel's share of A = c1 X + (c2 - j c3) Y and
+   B = c1 Y - (c2 + j c3) X (mix2.c:340-343, 377-380) for mix2.size bins around fft3_size/2, bin j = fft3_size/2 - size/2 + j */
+int lro_set_pol(lro_ctx *c, float c1, float c2, float c3) { c->pol[0] = c1; c->pol[1] = c2; c->pol[2] = c3; c->pol_set = 1; return LRH_OK; }
+int lro_mix2_pol_begin(lro_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
+{
+  if (!c->N3 || c->cfg.blanker_channels != 2 || !c->pol_set) return LRH_ESTATE;
+  if (batch < 1 || batch > c->cfg.max_fft3n || !count) return LRH_EINVAL;
+  const int N = c->N3, size = c->Nm2, ch = c->cfg.timf1_channel_index & 1;
+  const float c1 = c->pol[0], c2 = c->pol[1], c3 = c->pol[2];
+  float *A = c->xpol, *B = c->xpol + (size_t)batch * 2 * size;
+  for (int b = 0; b < batch; b++) {
+    const float *f3 = c->fft3 + ((p->fft3_px + b * 2 * N) & (c->cfg.max_fft3n * 2 * N - 1));
+    for (int j = 0; j < size; j++) {
+      const float re = f3[2 * (N / 2 - size / 2 + j)], im = f3[2 * (N / 2 - size / 2 + j) + 1];
+      float *a = A + ((size_t)b * size + j) * 2, *o = B + ((size_t)b * size + j) * 2;
+      if (ch == 0) { a[0] = c1 * re; a[1] = c1 * im; o[0] = -c2 * re + c3 * im; o[1] = -c2 * im - c3 * re; }
+      else { a[0] = c2 * re + c3 * im; a[1] = c2 * im - c3 * re; o[0] = c1 * re; o[1] = c1 * im; }
+    }
+  }
+  c->pol_batch = batch;
+  *count = (size_t)4 * batch * size;
+  return LRH_OK;
+}
+
+/* fft3_mix2, mixer_mode 1 (mix2.c:145-176) + pointers (mix2.c:1079, 2057-2059); pinned by the compiled reference run up to
+   its thread-command check (mix2.c:749), golden n10_n12_fft3 and the two-channel chain goldens */
 int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
 {
   if (!c->N3) return LRH_ESTATE;
   int N = c->N3, size = c->Nm2, sizhalf = size / 2, nn = 2 * (size - 1), bmask = c->cfg.baseband_size - 1;
+  const int pol = c->cfg.blanker_channels == 2 && c->pol_set;
+  if (pol && c->pol_batch != batch) return LRH_ESTATE;      /* lro_mix2_pol_begin + all-reduce come first */
+  c->pol_batch = 0;
   for (int b = 0; b < batch; b++) {
     float *tmp = c->tmp;
     const float *f3 = c->fft3;
     int p0 = p->fft3_px + N, k = N / 2;
+    if (pol) {        /* the summed A (channel 0) or B (channel 1) stands in for the spectrum; addressed like fft3 around its centre */
+      f3 = c->xpol + ((size_t)(c->cfg.timf1_channel_index & 1) * batch + b) * 2 * size;
+      p0 = size;
+    }
     for (int i = 0; i < sizhalf; i++) { tmp[2 * i] = f3[p0 + 2 * i] * c->bg_filterfunc[k + i]; tmp[2 * i + 1] = f3[p0 + 2 * i + 1] * c->bg_filterfunc[k + i]; }
     for (int i = 0; i < sizhalf; i++) { tmp[nn - 2 * i] = f3[p0 - 2 * i - 2] * c->bg_filterfunc[k - i - 1]; tmp[nn - 2 * i + 1] = f3[p0 - 2 * i - 1] * c->bg_filterfunc[k - i - 1]; }
     dif_stages(size, c->cfg.mix2_n, tmp, c->mix2tab, -1, 2); bitrev_inplace(size, c->cfg.mix2_n, tmp, 2);

@@ -40,7 +40,11 @@
 /* ---- stand-ins for GUI / OS entry points of the reference program ---- */
 int harness_err = 0;
 void lirerr(int e) { fprintf(stderr, "lirerr(%d)\n", e); harness_err = e; }
-void lir_sched_yield(void) {}
+/* fft3_mix2 runs on into the demodulators; its filter / decimate / polarisation part ends at the thread-command check of
+   mix2.c:749.  The back transform in front of that check yields (fft0.c:495, yieldflag_ndsp_mix2), and the yield is this
+   OS stub: armed, it withdraws the thread's command the way the GUI thread would, so the function returns there. */
+static int mix2_trip = 0;
+void lir_sched_yield(void) { if (mix2_trip) thread_command_flag[THREAD_MIX2] = THRFLAG_IDLE; }
 void awake_screen(void) {}
 void lir_pixwrite(int x, int y, char *s) { (void)x; (void)y; (void)s; }
 void lir_text(int x, int y, char *s) { (void)x; (void)y; (void)s; }
@@ -62,6 +66,7 @@ void fft2_mix1_afc(void);
 void fft1_mix1_afc(void);
 void compute_timf2_powersum(void);
 void make_fft3_all(void);
+void fft3_mix2(void);
 void clear_fft1_filtercorr(void);
 void make_permute(int mo, int nz, int sz, unsigned short int *perm);
 void make_bigpermute(int mo, int nz, int sz, unsigned int *perm);
@@ -130,6 +135,8 @@ int main(int argc, char **argv)
   int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
   int chain2 = AI("chain2", 0);                  /* channels=2 only: run on through the two-channel first_noise_blanker, make_fft2
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
+  int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
+  double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
   const char *fin = arg(argc, argv, "in", NULL);
@@ -363,8 +370,8 @@ int main(int argc, char **argv)
       fft3_new_points = fft3_size - fft3_interleave_points;
     }
     genparm[THIRD_FFT_SINPOW] = sinpow3;
-    fft3_block = fft3_size * 2; fft3_totsiz = fft3_block * maxfft3n; fft3_mask = fft3_totsiz - 1;
-    fft3 = zalloc(sizeof(float) * fft3_totsiz); fft3_tmp = zalloc(sizeof(float) * (4 * fft3_size + 64));
+    fft3_block = fft3_size * 2 * C; fft3_totsiz = fft3_block * maxfft3n; fft3_mask = fft3_totsiz - 1;
+    fft3 = zalloc(sizeof(float) * fft3_totsiz); fft3_tmp = zalloc(sizeof(float) * (4 * C * fft3_size + 64));
     fft3_tab = zalloc(sizeof(COSIN_TABLE) * fft3_size); fft3_permute = zalloc(sizeof(short) * fft3_size * 2);
     fft3_window = zalloc(sizeof(float) * (fft3_size + 32));
     init_fft(1, fft3_n, fft3_size, fft3_tab, fft3_permute);
@@ -374,6 +381,20 @@ int main(int argc, char **argv)
     memset(&bg, 0, sizeof(bg)); bg.fft_avgnum = 1; bg.waterfall_avgnum = 1 << 30;
     bg_xpoints = 0; bg_show_pa = 0; bg_first_xpoint = 0; fft3_slowsum_recalc = 0; fft3_slowsum_cnt = 0; fft3_show_size = 1;
     bg_avg_counter = 0; bg_filter_points = 0; bg_waterf_sum_counter = 0;
+    if (mix2on) {                 /* baseb_graph.c:718-730, 899; buffers of fft3_mix2's mixer_mode 1 part */
+      mix2.table = zalloc(sizeof(COSIN_TABLE) * mix2.size); mix2.permute = zalloc(sizeof(short) * mix2.size * 2);
+      mix2.window = zalloc(sizeof(float) * (mix2.size + 32)); mix2.cos2win = zalloc(sizeof(float) * (mix2.size + 32));
+      mix2.sin2win = zalloc(sizeof(float) * (mix2.size + 32));
+      prepare_mixer(&mix2, THIRD_FFT_SINPOW);
+      mi2_tmp = zalloc(sizeof(float) * (4 * C * mix2.size + 64)); carr_tmp = zalloc(sizeof(float) * (4 * C * mix2.size + 64));
+      bg_filterfunc = zalloc(sizeof(float) * (fft3_size + 8)); bg_carrfilter = zalloc(sizeof(float) * (fft3_size + 8));
+      for (int i = 0; i < fft3_size; i++) { double u = (i - fft3_size / 2.0) / (fft3_size / 6.0); bg_filterfunc[i] = (float)exp(-u * u); }   /* stand-in for make_bg_filter's output */
+      baseband_size = 4096; baseband_mask = baseband_size - 1;
+      baseb_raw = zalloc(sizeof(float) * (2 * baseband_size + 8 * mix2.size)); baseb_raw_orthog = zalloc(sizeof(float) * (2 * baseband_size + 8 * mix2.size));
+      fft3_slowsum = zalloc(sizeof(float) * (2 * C * fft3_size + 64));   /* read (not used with pg.adapt != 0) by the two-channel branch, mix2.c:344 */
+      baseb_pa = 0; bg.mixer_mode = 1; fm_pilot_size = 0; genparm[CW_DECODE_ENABLE] = 0; yieldflag_ndsp_mix2 = 1;
+      memset(&pg, 0, sizeof(pg)); pg.c1 = (float)pol_c1; pg.c2 = (float)pol_c2; pg.c3 = (float)pol_c3; pg.adapt = 1; pg.avg = 1;
+    }
   }
 
   /* ---- dump tables ---- */
@@ -394,9 +415,11 @@ int main(int argc, char **argv)
     PUTF("wg_waterf_yfac", wg_waterf_yfac, N1);
   }
 
-#define RUN_FFT3() do { if (n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * fft3_size && \
+#define RUN_FFT3() do { if (n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * C * fft3_size && \
       ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) { make_fft3_all(); nfft3++; \
-      fft3_px = (fft3_px + fft3_block) & fft3_mask; /* consumer side (fft3_mix2, mix2.c:2058) not run head-less */ } } while (0)
+      if (mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; \
+        baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; /* = last_point, mix2.c:1079, 2056 */ } \
+      fft3_px = (fft3_px + fft3_block) & fft3_mask; /* mix2.c:2058; the rest of fft3_mix2 (demodulators) is not run */ } } while (0)
   /* ---- AFC tables (buf.c:1089-1092, 1255-1258) and the synthetic frequency supplier for the afc variants ---- */
   int afcn = second ? max_fft2n : max_fft1n;
   mix1_fq_mid = zalloc(4 * afcn); mix1_fq_start = zalloc(4 * afcn); mix1_fq_curv = zalloc(4 * afcn); mix1_fq_slope = zalloc(4 * afcn);
@@ -505,7 +528,9 @@ int main(int argc, char **argv)
   PUTF("fft2_powersum_float", fft2_powersum_float, N2);
   PUTF("timf3_float", timf3_float, timf3_size);
   if (n3 > 0) { PUTF("fft3", fft3, fft3_totsiz); PUTF("fft3_window", fft3_window, fft3_size);
-    int f3[4] = { nfft3, fft3_pa, timf3_px, fft3_interleave_points }; PUTI("fft3_ptrs", f3, 4); }
+    int f3[4] = { nfft3, fft3_pa, timf3_px, fft3_interleave_points }; PUTI("fft3_ptrs", f3, 4);
+    if (mix2on) { PUTF("baseb_raw", baseb_raw, 2 * baseband_size); PUTF("baseb_raw_orthog", baseb_raw_orthog, 2 * baseband_size);
+      PUTF("bg_filterfunc", bg_filterfunc, fft3_size); int bp_[2] = { baseb_pa, fft3_px }; PUTI("baseb_ptrs", bp_, 2); } }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);
   { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);

@@ -54,10 +54,12 @@ def main():
             frames.tofile(fi)
             lim.tofile(fl)
             args = harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}", "chain2=1"]
+            args += [f"pol_c{i + 1}={v!r}" for i, v in enumerate(d["pol"])]
             subprocess.check_call([HARNESS] + args)
             refc = load_dump(fo)
         outc = {k: refc[k] for k in ("hdr", "itrace", "trace", "fft2_float", "fft2_xypower", "fft2_xysum", "wf_lines", "timf3_float",
-                                     "mixtrace", "final", "wg_waterf_yfac", "timf2_pwr_float")}
+                                     "mixtrace", "final", "wg_waterf_yfac", "timf2_pwr_float", "fft3", "fft3_ptrs", "baseb_raw",
+                                     "baseb_raw_orthog", "bg_filterfunc", "baseb_ptrs")}
         path = os.path.join(HERE, f"{name}_chain.npz")
         np.savez_compressed(path, **outc)
         print(name + "_chain", os.path.getsize(path) // 1024, "KiB")

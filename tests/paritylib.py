@@ -35,7 +35,9 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
     api.set_mix1_selfreq(d["fq"])
     if d["fft3_n"]:
         n3 = 1 << d["fft3_n"]
-        api.set_bg_filterfunc(np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))   # stand-in for make_bg_filter
+        # stand-in for make_bg_filter's output; the golden carries the table the compiled reference ran with
+        api.set_bg_filterfunc(g["bg_filterfunc"] if "bg_filterfunc" in g else
+                              np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))
     itrace, wf_lines, mixtrace = [], [], []
     afc, afc_t = None, [0]
     if d["afc"]:
@@ -104,6 +106,7 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
         out["fft3"] = api.export(abi.RING_FFT3)
         out["baseb_raw"] = api.export(abi.RING_BASEB_RAW)
         out["fft3_ptrs"] = np.array([api.p.fft3_pa, api.p.timf3_px, api.fft3_interleave_points])
+        out["baseb_ptrs"] = np.array([api.p.baseb_pa, api.p.fft3_px])
     if d["blockpower_block"]:
         out["timf2_blockpower"] = api.export(abi.RING_TIMF2_BLOCKPOWER)
         out["blockpower_ptrs"] = np.array([api.p.timf2_blockpower_pa, api.p.timf2_pb])
@@ -154,6 +157,13 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
         e = relerr(a, b)
         rep["fft3"] = e
         assert e <= tol or np.linalg.norm(a - b) <= floor, f"fft3: rel {e:.3e}"
+        if "baseb_raw" in g:                                  # fft3_mix2's filter / decimate part, run by the compiled reference
+            assert np.array_equal(out["baseb_ptrs"], g["baseb_ptrs"]), "baseband pointers differ"
+            a, b = out["baseb_raw"].astype(np.float64), g["baseb_raw"].astype(np.float64)
+            e = relerr(a, b)
+            rep["baseb_raw"] = e
+            assert np.count_nonzero(b) > 500
+            assert e <= tol or np.linalg.norm(a - b) <= floor * np.sqrt(a.size / out["fft3"].size), f"baseb_raw: rel {e:.3e}"
     if "timf2_blockpower" in out:
         assert np.array_equal(out["blockpower_ptrs"], g["blockpower_ptrs"]), "timf2 powersum pointers differ"
         e = relerr(out["timf2_blockpower"], g["timf2_blockpower"])

@@ -44,11 +44,12 @@ CASES = {
                          fq=9000.4, wf_avgnum=1, wf_mode=4, seed=15, timf2pow_log2=18, sumsq_blocks=8,
                          strong=[(2048.0, 8000.0), (-1000.5, 600.0)], weak=[(500.0, 40.0)], pulse_period=7919,
                          lim_halfwidth=3, golden_stride=11),
-    # fft3 behind mix1 (make_fft3_all transform part pinned by the reference; mix2 filter/decimate vs the oracle only)
+    # fft3 behind mix1: make_fft3_all's transform part and fft3_mix2's filter / decimate part (mixer_mode 1), both run by
+    # the compiled reference (the harness makes fft3_mix2 return at its thread-command check, mix2.c:749)
     "n10_n12_fft3": dict(n1=10, n2=12, mixred=5, nblk=120, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
                          strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
-                         pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8),
+                         pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8, mix2=1),
     # int32 input (DWORD_INPUT: 18/24-bit hardware, expanded .raw recordings) with an I/Q sample skew (fft1.c:470-635)
     "n10_n12_dword": dict(n1=10, n2=12, mixred=6, nblk=48, avg1num=5, avg2num=4, att_n=8, gain=15, bln_interval=4, bln_avgnum=16,
                           fq=2200.3, wf_avgnum=2, wf_mode=1, seed=18, timf2pow_log2=15, sumsq_blocks=8, sigma=256.0,
@@ -94,7 +95,7 @@ def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
              second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
-             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0)
+             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0, mix2=0)
     d.update(CASES[name])
     if d["gain"] is None:
         # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
@@ -188,7 +189,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw", "mix2"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
@@ -197,8 +198,10 @@ def harness_args(d, infile, limfile, outfile):
 # ---- two RF channels in one array (the reference's own layout); the build shards them one per context
 TWOCHAN = {
     "twochan_n10": dict(base="n10_n12", nblk=40, seed2=112, sky_phase=0.7, ch2_c1=float(np.float32(np.cos(0.5))),
-                        ch2_c2=float(np.float32(np.sin(0.5)))),
-    "twochan_n9_sin3": dict(base="n9_n11_sin3", nblk=32, seed2=114, sky_phase=-1.1, ch2_c1=1.0, ch2_c2=0.0),
+                        ch2_c2=float(np.float32(np.sin(0.5))),
+                        chain=dict(nblk=72, fft3_n=6, mix2_n=4, max_fft3n=8, mix2=1, pol=(0.8, 0.36, -0.48))),
+    "twochan_n9_sin3": dict(base="n9_n11_sin3", nblk=32, seed2=114, sky_phase=-1.1, ch2_c1=1.0, ch2_c2=0.0,
+                            chain=dict(nblk=56, fft3_n=5, mix2_n=3, max_fft3n=8, mix2=1, pol=(0.6, -0.64, 0.48))),
 }
 
 
@@ -209,8 +212,8 @@ def twochan_case(name, chain=False):
     t = TWOCHAN[name]
     d = case_params(t["base"])
     d.update(nblk=t["nblk"], ch2_c1=t["ch2_c1"], ch2_c2=t["ch2_c2"], fq=d["fq"] if chain else -1.0, second_fft=1)
-    if chain:
-        d.update(blockpower_block=0)
+    if chain:        # longer run, fft3 + fft3_mix2 behind mix1 with the polarisation transform pg.c1..c3 = pol
+        d.update(blockpower_block=0, **t["chain"])
     x0 = make_input(d).astype(np.float64)
     z0 = x0[0::2] + 1j * x0[1::2]
     rng0 = np.random.default_rng(d["seed"])

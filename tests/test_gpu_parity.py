@@ -80,7 +80,7 @@ def test_hip_long_call_matches_oracle():
 
 def test_hip_fft3_mix2_matches_oracle():
     """fft3 ring against the reference golden (in test_hip_matches_reference_golden) and the mix2 filter/decimate output
-    baseb_raw against the oracle restatement (the reference's fft3_mix2 cannot run head-less: parity unpinned there)."""
+    baseb_raw against the oracle restatement (reference parity of the same part: golden n10_n12_fft3 in test_gpu_parity / test_oracle_golden)."""
     g = load_golden("n10_n12_fft3")
     a = run_case(_open_hip, "n10_n12_fft3", golden=g)
     b = run_case(_open_oracle, "n10_n12_fft3", golden=g)

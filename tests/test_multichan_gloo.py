@@ -144,10 +144,13 @@ def _chain_worker(rank, world, port, q):
     rx.timf1_write(iq)
     rx.set_liminfo(lim)
     rx.set_mix1_selfreq(d["fq"])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "twochan_n10_chain.npz"))
+    rx.set_bg_filterfunc(g["bg_filterfunc"])
+    rx.set_pol(*d["pol"])
     if rank == 1:
         rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
-    run_coupled(rx, d["nblk"], 1, dist, xy=True)
-    out = dict(xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM), wf=rx.export(abi.RING_WG_WATERF),
+    run_coupled(rx, d["nblk"], 1, dist, xy=True, pol=True)
+    out = dict(baseb=rx.export(abi.RING_BASEB_RAW), baseb_pa=rx.p.baseb_pa, xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM), wf=rx.export(abi.RING_WG_WATERF),
                timf3=rx.export(abi.RING_TIMF3_FLOAT), fft2_na=rx.p.fft2_na, wptr=rx.p.wg_waterf_ptr)
     dist.barrier()
     dist.destroy_process_group()
@@ -156,8 +159,9 @@ def _chain_worker(rank, world, port, q):
 
 def test_two_channel_chain_over_gloo():
     """The whole coupled chain with the collectives of linrad_amd/multichan.py: two all-reduces per blanker call and one
-    all-gather of the new fft2 bins per make_fft2.  Both ranks must end with the compiled two-channel reference's
-    fft2_xypower / fft2_xysum and waterfall lines, each with its own channel of timf3."""
+    all-gather of the new fft2 bins per make_fft2, one all-reduce of the polarisation sums per fft3_mix2.  Both ranks must end
+    with the compiled two-channel reference's fft2_xypower / fft2_xysum and waterfall lines, each with its own channel of
+    timf3; rank 0 with the reference's baseb_raw (wanted polarisation), rank 1 with baseb_raw_orthog."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -184,3 +188,6 @@ def test_two_channel_chain_over_gloo():
         diff = np.abs(wf[(-l) % wf.shape[0]] - lines[l])
         assert diff.max() <= 2 and np.mean(diff != 0) < 0.02, (l, diff.max())
     assert not np.array_equal(res[0]["timf3"], res[1]["timf3"]) and np.count_nonzero(res[0]["timf3"]) > 0
+    for r, key in ((0, "baseb_raw"), (1, "baseb_raw_orthog")):
+        assert res[r]["baseb_pa"] == g["baseb_ptrs"][0]
+        assert rel(res[r]["baseb"], g[key]) < 4e-6, (key, rel(res[r]["baseb"], g[key]))

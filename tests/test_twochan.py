@@ -183,6 +183,8 @@ def _run_chain(open_fn, name, frames_mode, batch=1):
         rx.timf1_write(frames if frames_mode else iq)
         rx.set_liminfo(lim)
         rx.set_mix1_selfreq(d["fq"])
+        rx.set_bg_filterfunc(g["bg_filterfunc"])
+        rx.set_pol(*d["pol"])
         if ch == 1:
             rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
         rxs.append(rx)
@@ -223,9 +225,23 @@ def _run_chain(open_fn, name, frames_mode, batch=1):
                 wptr = (wptr - rxs[0].cfg.wf_xpixels) % (rxs[0].cfg.wf_lines * rxs[0].cfg.wf_xpixels)
             for rx in rxs:
                 rx.fft2_mix1_fixed(kb)
+            # fft3, then fft3_mix2 with the polarisation sums A / B formed over both contexts (all-reduce by hand)
+            k3 = rxs[0].fft3_available()
+            while k3 > 0:
+                k3b = min(k3, max(1, batch), rxs[0].cfg.max_fft3n // 2)
+                cnt3 = []
+                for rx in rxs:
+                    rx.make_fft3_all(k3b)
+                    cnt3.append(rx.mix2_pol_begin(k3b))
+                assert cnt3[0] == cnt3[1] == 4 * k3b * (1 << d["mix2_n"])
+                tot = rxs[0].exchange_read(X.X_POL, cnt3[0]) + rxs[1].exchange_read(X.X_POL, cnt3[0])
+                for rx in rxs:
+                    rx.exchange_write(X.X_POL, tot)
+                    rx.fft3_mix2(k3b)
+                k3 -= k3b
             nfft2 += kb
             k -= kb
-    out = [dict(fft2=rx.export(abi.RING_FFT2_FLOAT), xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM),
+    out = [dict(fft3=rx.export(abi.RING_FFT3), baseb=rx.export(abi.RING_BASEB_RAW), fft2=rx.export(abi.RING_FFT2_FLOAT), xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM),
                 timf3=rx.export(abi.RING_TIMF3_FLOAT), p=rx.p.as_dict(), bs=rx.blanker_state()) for rx in rxs]
     return d, g, out, wf_lines, nfft2
 
@@ -248,6 +264,25 @@ def _check_chain(d, g, out, wf_lines, nfft2, tol):
         assert _rel(out[ch]["xyp"], g["fft2_xypower"]) < 2 * tol, ch
         assert _rel(out[ch]["xys"], g["fft2_xysum"]) < 2 * tol, ch
     assert np.abs(g["fft2_xypower"].reshape(-1, 4)[:, 2:]).max() > 0
+    # fft3 per channel; the polarisation pair: context 0 carries baseb_raw (A), context 1 baseb_raw_orthog (B)
+    N3 = 1 << d["fft3_n"]
+    g3 = g["fft3"].reshape(-1, N3, 2, 2)
+    assert g["fft3_ptrs"][0] >= 8
+    for ch, key in ((0, "baseb_raw"), (1, "baseb_raw_orthog")):
+        assert out[ch]["p"]["fft3_pa"] == g["fft3_ptrs"][1] // 2 and out[ch]["p"]["timf3_px"] == g["fft3_ptrs"][2] // 2
+        assert out[ch]["p"]["baseb_pa"] == g["baseb_ptrs"][0] and out[ch]["p"]["fft3_px"] == g["baseb_ptrs"][1] // 2
+        # float32 floor of a weak band cut from the wide spectrum (see timf3 above): rms e_s per timf3 sample; an
+        # unnormalised N3-point transform turns it into e_s sqrt(N3) per bin, the mix2.size-point back transform of the
+        # filtered bins into at most e_s sqrt(N3 Nm2) per sample, overlap-added twice
+        nm, Nm2 = N2 >> d["mixred"], 1 << d["mix2_n"]
+        wide = max(np.linalg.norm(gf[:, :, c_, :].astype(np.float64)) for c_ in (0, 1)) / np.sqrt(gf.shape[0])
+        e_s = 4 * 6e-8 * wide * np.sqrt(nm / N2)
+        a, b = out[ch]["fft3"].reshape(-1, N3, 2).astype(np.float64), g3[:, :, ch, :].astype(np.float64)
+        assert _rel(a, b) < tol or np.linalg.norm(a - b) <= e_s * np.sqrt(N3) * np.sqrt(a.size / 2), (ch, _rel(a, b))
+        a, b = out[ch]["baseb"].astype(np.float64), g[key].astype(np.float64)
+        assert np.count_nonzero(b) >= 100
+        assert _rel(a, b) < tol or np.linalg.norm(a - b) <= e_s * np.sqrt(2 * N3 * Nm2) * np.sqrt(np.count_nonzero(b) / 2), (key, _rel(a, b))
+    assert _rel(g["baseb_raw_orthog"], g["baseb_raw"]) > 0.5
     gw = g["wf_lines"].reshape(len(wf_lines), -1).astype(np.int32)
     for ch in (0, 1):
         ow = np.array([ln[ch] for ln in wf_lines], np.int32)
