@@ -201,7 +201,7 @@ TWOCHAN = {
                         ch2_c2=float(np.float32(np.sin(0.5))),
                         chain=dict(nblk=72, fft3_n=6, mix2_n=4, max_fft3n=8, mix2=1, pol=(0.8, 0.36, -0.48))),
     "twochan_n9_sin3": dict(base="n9_n11_sin3", nblk=32, seed2=114, sky_phase=-1.1, ch2_c1=1.0, ch2_c2=0.0,
-                            chain=dict(nblk=56, fft3_n=5, mix2_n=3, max_fft3n=8, mix2=1, pol=(0.6, -0.64, 0.48))),
+                            chain=dict(nblk=56, fft3_n=6, mix2_n=4, max_fft3n=8, mix2=1, pol=(0.6, -0.64, 0.48))),
 }
 
 
