@@ -133,6 +133,8 @@ int main(int argc, char **argv)
   int direction = AI("direction", 1);            /* fft1_direction (fg.passband_direction): -1 mirrors the spectrum */
   int timing = AI("timing", 0);                  /* 1: print the wall time of the block loop (bench.py cpu_baseline), skip the ring dumps */
   int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
+  int realin = AI("real", 0);                    /* 1: real samples (ui.rx_input_mode without IQ_DATA): fft1 version 2, the split-radix
+                                                    real transform fft1_reherm_dit_one (fft1_re.c:32), 2*N1 reals per transform */
   int chain2 = AI("chain2", 0);                  /* channels=2 only: run on through the two-channel first_noise_blanker, make_fft2
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
@@ -149,7 +151,8 @@ int main(int argc, char **argv)
   /* ---- ui / genparm ---- */
   memset(&ui, 0, sizeof(ui));
   if (C != 1 && C != 2) { fprintf(stderr, "channels must be 1 or 2\n"); return 2; }
-  ui.rx_input_mode = IQ_DATA | (dword ? DWORD_INPUT : 0) | (C == 2 ? TWO_CHANNELS : 0); ui.rx_rf_channels = C; ui.rx_ad_channels = 2 * C;
+  ui.rx_input_mode = (realin ? 0 : IQ_DATA) | (dword ? DWORD_INPUT : 0) | (C == 2 ? TWO_CHANNELS : 0); ui.rx_rf_channels = C; ui.rx_ad_channels = (realin ? 1 : 2) * C;
+  if (realin && C != 1) { fprintf(stderr, "real input: one channel only\n"); return 2; }
   pg_ch2_c1 = (float)ch2_c1; pg_ch2_c2 = (float)ch2_c2;
   ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
@@ -190,9 +193,10 @@ int main(int argc, char **argv)
   fft1_filtercorr = (float *)zalloc(sizeof(float) * (2 * C * N1 + 32)) + 8;
   fft1_desired = zalloc(sizeof(float) * N1);
   fftw_tmp = zalloc(sizeof(float) * (4 * C * N1 + 64));
-  make_sincos(1, N1, fft1tab);
-  make_permute(1, n1, N1, fft1_permute);
-  make_window(1, N1, sinpow1, fft1_window);
+  /* buf.c:1403-1433 with fft_cntrl[FFT1_CURMODE]: IQ -> version 7 {window 1, permute 1}; real -> version 2 {window 2, permute 2} */
+  make_sincos(realin ? 2 : 1, N1, fft1tab);
+  make_permute(fft_cntrl[FFT1_CURMODE].permute, n1, N1, fft1_permute);
+  make_window(fft_cntrl[FFT1_CURMODE].window, N1, sinpow1, fft1_window);
   clear_fft1_filtercorr();
   if (ffold) {                                    /* I/Q mirror-image calibration table (caliq.c), here from a file */
     fft1_foldcorr = zalloc(sizeof(float) * (2 * N1 + 32));
@@ -243,7 +247,8 @@ int main(int argc, char **argv)
   fft1_inverted_window = zalloc(sizeof(float) * (N1 + 32));
   liminfo = zalloc(sizeof(float) * N1);
   make_permute(0, n1, N1, fft1_back_scramble);
-  fft1_backtab = fft1tab;
+  if (fft_cntrl[FFT1_CURMODE].permute == 2) { fft1_backtab = zalloc(sizeof(COSIN_TABLE) * N1); make_sincos(0, N1, fft1_backtab); }   /* buf.c:1318-1326 */
+  else fft1_backtab = fft1tab;
   if (sinpow1 != 2 && sinpow1 != 0) make_window(3, N1, sinpow1, fft1_inverted_window);
   fft1_lowlevel_fraction = .75f;
   float *limrecs = NULL; long nlimrec = 0;
