@@ -105,7 +105,11 @@ typedef struct lrh_config {
                                    1236-1300, 1510-1545, 1570), see lrh_blanker_begin; the fft2 waterfall line comes from
                                    both channels' sums, see lrh_fft2_xy_begin (default wg_waterf_yfac then carries the
                                    rx_rf_channels^2 of wide_graph.c:985).  0/1: single channel                        */
-  int reserved[3];
+  int timf1_real_input;         /* 1: real samples (ui.rx_input_mode without IQ_DATA, "normal audio" / direct-sampling
+                                   hardware): one transform takes 2*fft1_size reals and yields fft1_size bins 0..fs/2, the
+                                   reference's default real version fft1_reherm_dit_one (fft1_re.c:32-131, fft1var.c:45,75);
+                                   one channel per frame, int16 or int32; timf1p_px advances 4*M1 bytes per block like I/Q */
+  int reserved[2];
 } lrh_config;
 
 /*

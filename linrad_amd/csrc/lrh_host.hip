@@ -34,6 +34,7 @@ hipError_t launch_expand18(const unsigned char *packed, int ngroups, void *ring,
 hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_xypower(const XyArgs &a, hipStream_t st);
 hipError_t launch_pol(const PolArgs &a, hipStream_t st);
+hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -196,7 +197,8 @@ static void default_filtercorr(lrh_ctx *c)  // clear_fft1_filtercorr + make_filc
 {
   int N = c->N1;
   float start = 150 * (float)N * (float)pow((double)N, -0.4);
-  if (c->cfg.timf1_dword_input) { start *= 4096; start *= 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32 I/Q */
+  const bool real = c->cfg.timf1_real_input != 0;
+  if (c->cfg.timf1_dword_input) { start *= 4096; start *= real ? 16 : 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32; real: permute == 2 */
   start = (float)c->cfg.fft1_gain / start;
   c->h_filtercorr.assign(2 * N, 0.f); c->h_desired.assign(N, 1.f);
   for (int i = 0; i < N; i++) c->h_filtercorr[2 * i] = start;
@@ -204,7 +206,7 @@ static void default_filtercorr(lrh_ctx *c)  // clear_fft1_filtercorr + make_filc
   int i = 0, k = N - 1;
   while (t2 < 0.5 * PI_L) {
     t3 = (float)(sin(t2) * sin(t2));
-    c->h_desired[i] = t3; c->h_filtercorr[2 * i] = t3 * start;
+    if (!real) { c->h_desired[i] = t3; c->h_filtercorr[2 * i] = t3 * start; }   // fft1.c:4707-4711: the low edge only for I/Q
     c->h_desired[k] = t3; c->h_filtercorr[2 * k] = t3 * start;
     t2 += t1; i++; k--;
   }
@@ -312,6 +314,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   *out = nullptr;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
+  if (cfg->timf1_real_input && (cfg->timf1_frame_channels > 1 || cfg->sample_shift != 0)) return LRH_EINVAL;   // one real channel per frame (fft1_reherm_dit_one)
   if (cfg->timf1_frame_channels > 1 && (!ispow2(cfg->timf1_frame_channels) || cfg->timf1_channel_index < 0 || cfg->timf1_channel_index >= cfg->timf1_frame_channels)) return LRH_EINVAL;
   if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
@@ -368,13 +371,21 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   int rc = LRH_OK;
 #define A(call) do { if (rc == LRH_OK) rc = (call); } while (0)
   // ---- tables
-  std::vector<float> h, win1(N1, 1.0f), inv1(N1, 1.0f);
-  c->h_window1_ref.assign(N1, 0.f); c->h_invwin1_ref.assign(N1 / 2 + 1, 0.f);
+  const bool real1 = cfg->timf1_real_input != 0;
+  std::vector<float> h, win1(real1 ? 2 * N1 : N1, 1.0f), inv1(N1, 1.0f);
+  c->h_window1_ref.assign(N1 + 1, 0.f); c->h_invwin1_ref.assign(N1 / 2 + 1, 0.f);
+  if (real1 && cfg->fft1_sinpow) {          // make_window(2,..): half window of the 2*N1-point transform, win[0..N1]; sample ia
+    half_window(2 * N1, cfg->fft1_sinpow, h, true);      // and sample 2*N1-1-ia both take win[ia] (fft1_re.c:47-57)
+    for (int i = 0; i < N1; i++) { win1[i] = h[i]; win1[2 * N1 - 1 - i] = h[i]; }
+    for (int i = 0; i <= N1; i++) c->h_window1_ref[i] = h[i];
+  }
   if (cfg->fft1_sinpow) {
     half_window(N1, cfg->fft1_sinpow, h, true);
+    if (!real1) {
     for (int i = 0; i <= N1 / 2; i++) win1[i] = h[i];
     for (int i = N1 / 2 + 1; i < N1; i++) win1[i] = h[N1 - i];
     for (int i = 0; i < N1 / 2; i++) { c->h_window1_ref[2 * i] = h[i]; c->h_window1_ref[2 * i + 1] = h[N1 / 2 - i]; }   // fft0.c:907-920
+    }
     if (cfg->fft1_sinpow != 2) {                                       // make_window(3,..) fft0.c:883-891
       half_window(N1, cfg->fft1_sinpow, h, false);
       c->h_invwin1_ref[0] = 1; for (int i = 1; i <= N1 / 2; i++) c->h_invwin1_ref[i] = 1 / h[i];
@@ -424,7 +435,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   std::vector<int> itab(cfg->wf_xpixels + 4);
   { float a2 = 1, a3; if (wx > 0) a2 = wx; else a2 = 1. / wp; a3 = wfirst + 0.5 * a2;
     for (size_t i = 0; i < itab.size(); i++) { int t = a3; if (t < 0) t = 0; if (t > N1 - 1) t = N1 - 1; itab[i] = t; a3 += a2; } }
-  A(dev_alloc(c, &c->d_window1, N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
+  A(dev_alloc(c, &c->d_window1, real1 ? 2 * N1 : N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
   A(dev_alloc(c, &c->d_fqwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_yfac, N1)); A(dev_alloc(c, &c->d_filtercorr, N1));
   A(dev_alloc(c, &c->d_mixwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_sin2win, c->Nm)); A(dev_alloc(c, &c->d_cos2win, c->Nm));
   A(dev_alloc(c, &c->d_tw1, N1)); A(dev_alloc(c, &c->d_tw2, N2)); A(dev_alloc(c, &c->d_twm, c->Nm));
@@ -472,7 +483,11 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
   if (rc == LRH_OK) {
     hipStreamSynchronize(c->stream);
-    A(upload(c, c->d_window1, win1.data(), N1)); A(upload(c, c->d_invwin1, inv1.data(), N1));
+    A(upload(c, c->d_window1, win1.data(), win1.size())); A(upload(c, c->d_invwin1, inv1.data(), N1));
+    if (real1) {                               // k_fft1 stores the bare transform, k_realsplit applies the filter correction
+      std::vector<float2> one(N1, make_float2(1.f, 0.f));
+      A(dev_alloc(c, &c->d_unitcorr, N1, false)); A(upload(c, c->d_unitcorr, one.data(), N1));
+    }
     A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
     A(upload(c, c->d_mixwin, c->h_mixwin.data(), c->Nm / 2 + 1)); A(upload(c, c->d_sin2win, c->h_sin2win.data(), c->Nm)); A(upload(c, c->d_cos2win, c->h_cos2win.data(), c->Nm));
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
@@ -651,7 +666,8 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
-  if (c->d_foldcorr) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr does the rest
+  a.real = c->cfg.timf1_real_input != 0;
+  if (c->d_foldcorr || a.real) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr / k_realsplit does the rest
   a.stamps = nullptr;
   if (getenv("LRH_STAMP")) {                              // diagnostics: dump the phase stamps of this launch to stderr
     static unsigned long long *d_st = nullptr;
@@ -670,6 +686,12 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   }
   ProfScope ps(c, "fft1");
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+  if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
+    RealSplitArgs r;
+    r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;
+    HIPCHK(c, launch_realsplit(r, batch, c->cur));
+    return LRH_OK;
+  }
   if (c->d_foldcorr) {
     FoldcorrArgs f;
     f.spec = c->d_fft1; f.first_nb = a.first_nb; f.nb_mask = a.nb_mask; f.n = c->N1;
@@ -685,6 +707,7 @@ int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
   hipSetDevice(c->cfg.device);
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
   if (!fc) { if (c->d_foldcorr) hipFree(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
+  if (c->cfg.timf1_real_input) return fail(c, LRH_ESTATE, "no I/Q mirror image with real samples (init_foldcorr is I/Q only, buf.c:1461)");
   const size_t bytes = sizeof(float2) * c->N1;
   if (!c->d_foldcorr && hipMalloc((void **)&c->d_foldcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(foldcorr)");
   if (!c->d_unitcorr) {

@@ -20,8 +20,10 @@ namespace lrh {
 // =====================================================================================================
 // fft1
 // =====================================================================================================
-// DW: int32 samples (DWORD_INPUT); SKEW: I and Q taken from different sample instants (ui.sample_shift != 0)
-template <int LOG2N, bool DW, bool SKEW>
+// DW: int32 samples (DWORD_INPUT); SKEW: I and Q taken from different sample instants (ui.sample_shift != 0);
+// REAL: real samples, the pair (x[2n], x[2n+1]) is one complex point with its own window value per component, nothing
+// negated, natural bin order, bare transform (k_realsplit finishes fft1_reherm_dit_one)
+template <int LOG2N, bool DW, bool SKEW, bool REAL = false>
 __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft1(Fft1Args a)
 {
   using Raw = typename std::conditional<DW, int2, short2>::type;
@@ -52,14 +54,19 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
   stamp();
   Fft::init(lds, a.tw, tid0);
   float win[P];
+  float winq[REAL ? P : 1];
   auto load_window = [&](int tid) {
 #pragma unroll
     for (int m = 0; m < P / R0; m++)
 #pragma unroll
-      for (int s = 0; s < R0; s++) win[m * R0 + s] = a.window[(tid + m * T) + s * (N / R0)];
+      for (int s = 0; s < R0; s++) {
+        if constexpr (REAL) { const float2 w = ((const float2 *)a.window)[(tid + m * T) + s * (N / R0)]; win[m * R0 + s] = w.x; winq[m * R0 + s] = w.y; }
+        else win[m * R0 + s] = a.window[(tid + m * T) + s * (N / R0)];
+      }
   };
   auto out_index = [&](int tid, int e) {
     const int k = (tid + (e / RL) * T) + (e % RL) * (N / RL);
+    if constexpr (REAL) return k;
     int kk = (k + N / 2) & (N - 1);                     // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
     if (a.direction < 0) kk = (N - kk) & (N - 1);       // fft1.c:3660-3679
     return kk;
@@ -100,7 +107,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     for (int e = 0; e < P; e++) {
       const Raw v = nxt[e];
       // Q negated before the e^{+j} transform: conj(FFT(x w)) (fft1.c:432-447)
-      x[e] = make_float2((float)v.x * win[e], -((float)v.y * win[e]));
+      if constexpr (REAL) x[e] = make_float2((float)v.x * win[e], (float)v.y * winq[e]);
+      else x[e] = make_float2((float)v.x * win[e], -((float)v.y * win[e]));
     }
     const int bn = bi + gridDim.x;
     if (bn < a.batch) fetch(a.xcd ? xcd_order(bn, a.batch) : bn, tid);
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     // are issued BEFORE the stores, so that no later wait has to cover the stores; the filter correction already
     // before the last pass, whose butterflies hide its latency.
     float2 fc[P];
-    constexpr int EARLY = (DW || SKEW) ? 0 : P / 2;       // as many as the register file holds next to the last pass
+    constexpr int EARLY = (DW || SKEW || REAL) ? 0 : P / 2;       // as many as the register file holds next to the last pass
     Fft::run(x, lds, tid, [&]() {
 #pragma unroll
       for (int e = 0; e < EARLY; e++) fc[e] = a.filtercorr[out_index(tid, e)];
@@ -126,6 +134,50 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     }
     stamp();                                             // no barrier: BlockFftL protects its buffer itself
   }
+}
+
+// Real input (fft1 version 2, fft1_reherm_dit_one, fft1_re.c:32-131), second half.  k_fft1<REAL> left
+// S[k] = sum_n (x[2n] w[2n] + j x[2n+1] w[2n+1]) e^{+2 pi j nk/N} = F[(N-k) mod N] in natural order; the 2N-point real
+// transform Z (kernel e^{-j}) follows from the even / odd split
+//   E_k = (F_k + conj F_{N-k}) / 2,  O_k = (F_k - conj F_{N-k}) / 2j,  Z_k = E_k + e^{-j pi k/N} O_k,  Z_{N-k} = conj(E_k - e^{-j pi k/N} O_k),
+//   Z_0 = Re F_0 + Im F_0,  Z_N = Re F_0 - Im F_0,  Z_{N/2} = conj F_{N/2}.
+// Layout of the reference (the real part goes to the imaginary slot): direction > 0: out[k] = (Im Z_k, Re Z_k), out[0] =
+// (Z_N, Z_0); direction < 0: out[N-k] = (Re Z_k, Im Z_k), out[0] = (Z_N, Z_N) (fft1_re.c:100-128).  One thread per pair
+// (k, N-k), in place, then the filter correction of fft1_c like k_fft1's store epilogue.
+__global__ __launch_bounds__(256) void k_realsplit(RealSplitArgs a)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x, N = a.n;
+  if (k >= N / 2) return;
+  float2 *out = a.spec + (size_t)((a.first_nb + blockIdx.y) & a.nb_mask) * N;
+  if (k == 0) {
+    const float2 s0 = out[0], sh = out[N / 2];
+    const float z0 = s0.x + s0.y, zn = s0.x - s0.y;
+    const float2 zh = make_float2(sh.x, -sh.y);
+    float2 o0, oh;
+    if (a.direction > 0) { o0 = make_float2(zn, z0); oh = make_float2(zh.y, zh.x); }
+    else { o0 = make_float2(zn, zn); oh = zh; }
+    out[0] = cmul(o0, a.filtercorr[0]); out[N / 2] = cmul(oh, a.filtercorr[N / 2]);
+    return;
+  }
+  const float2 sa = out[k], sb = out[N - k];              // F_{N-k}, F_k
+  const float2 e = make_float2(0.5f * (sb.x + sa.x), 0.5f * (sb.y - sa.y));
+  const float2 d = make_float2(0.5f * (sb.x - sa.x), 0.5f * (sb.y + sa.y));     // (F_k - conj F_{N-k}) / 2
+  const float2 o = make_float2(d.y, -d.x);                                       // / j
+  float sn, cs; sincospif((float)k / (float)N, &sn, &cs);
+  const float2 t = make_float2(cs * o.x + sn * o.y, cs * o.y - sn * o.x);        // e^{-j pi k/N} O_k
+  const float2 zk = make_float2(e.x + t.x, e.y + t.y), zm = make_float2(e.x - t.x, -(e.y - t.y));   // Z_k, Z_{N-k}
+  if (a.direction > 0) {
+    out[k] = cmul(make_float2(zk.y, zk.x), a.filtercorr[k]);
+    out[N - k] = cmul(make_float2(zm.y, zm.x), a.filtercorr[N - k]);
+  } else {
+    out[N - k] = cmul(zk, a.filtercorr[N - k]);
+    out[k] = cmul(zm, a.filtercorr[k]);
+  }
+}
+hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_realsplit, dim3((a.n / 2 + 255) / 256, batch), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 // =====================================================================================================
@@ -1332,7 +1384,9 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
 #define LRH_LAUNCH_FFT1(L, a, batch, st)                                                    \
   do {                                                                                      \
     const bool sk = a.shift_i != 0 || a.shift_q != 0;                                       \
-    if (!a.dword && !sk) LRH_LAUNCH_FFT1_V(L, false, false, a, batch, st);                  \
+    if (a.real && !a.dword) hipLaunchKernelGGL((k_fft1<L, false, false, true>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
+    else if (a.real) hipLaunchKernelGGL((k_fft1<L, true, false, true>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
+    else if (!a.dword && !sk) LRH_LAUNCH_FFT1_V(L, false, false, a, batch, st);                  \
     else if (!a.dword) LRH_LAUNCH_FFT1_V(L, false, true, a, batch, st);                     \
     else if (!sk) LRH_LAUNCH_FFT1_V(L, true, false, a, batch, st);                          \
     else LRH_LAUNCH_FFT1_V(L, true, true, a, batch, st);                                    \

@@ -17,7 +17,8 @@ struct Fft1Args {
   int ring_mask;            // in complex samples
   int p0_first;             // first sample of transform 0 = timf1p_ref/4 - I1 (fft1.c:421-426)
   int step;                 // new samples per transform (M1)
-  const float *window;      // natural order, N1 (all ones when sinpow = 0)
+  const float *window;      // natural order, N1 (all ones when sinpow = 0); real input: 2*N1, one value per real sample
+  int real;                 // real samples (fft1_reherm_dit_one): pairs (x[2n], x[2n+1]) packed as one complex point, bare transform out
   const float2 *filtercorr; // N1
   const float2 *tw;         // exp(-2 pi j m/N1)
   float2 *out;              // fft1_float ring
@@ -116,6 +117,9 @@ struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;
   const float *powersum_in; float *powersum_out; float *wf_scratch; int counter; int avgnum;
 };
+// real input, second half of fft1_reherm_dit_one (fft1_re.c:96-131): the N1-point transform of the packed pairs is split into
+// the 2*N1-point real transform, laid out like the reference does, and multiplied by the filter correction of fft1_c
+struct RealSplitArgs { float2 *spec; int first_nb, nb_mask, n; const float2 *filtercorr; int direction; };
 // two coupled channels: cross products of the channels' fft2 bins (TWOCHAN_POWER), sums per waterfall group
 struct XyArgs {
   const float2 *x, *y;        // [batch][n] bins of channel 0 / channel 1 (the two slots of the exchange buffer)

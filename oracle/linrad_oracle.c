@@ -79,6 +79,7 @@ void lro_make_window(int mo, int sz, int n, float *win)
 {
   double x, z, sumsq = 0, e1, e2;
   int i, size = sz;
+  if (mo == 2) size = 2 * sz;          /* half window of a 2*sz-point transform in natural order, win[0..sz] (fft0.c:838) */
   if (mo == 5) {
     e1 = 3.2; e2 = 13.0 / sz;
     for (i = 0; i <= sz / 2; i++) { win[i] = 0.5F * (float)erfc(e1); e1 -= e2; }
@@ -104,7 +105,9 @@ void lro_make_window(int mo, int sz, int n, float *win)
   }
   z = 1 / sqrt(2 * sumsq / size);      /* unit mean square, fft0.c:892-896 */
   for (i = 0; i <= size / 2; i++) h[i] *= (float)z;
-  if (mo == 4) {
+  if (mo == 2) {
+    for (i = 0; i <= size / 2; i++) win[i] = h[i];
+  } else if (mo == 4) {
     for (i = 0; i <= size / 2; i++) win[i] = h[i];
     for (i = size / 2 + 1; i < size; i++) win[i] = h[size - i];
   } else {                             /* mo 1: win[2i]=w[i], win[2i+1]=w[N/2-i], fft0.c:907-920 */
@@ -127,14 +130,15 @@ static void default_filtercorr(lro_ctx *c)
 {
   int N = c->N1;
   float start = 150 * (float)N * (float)pow((double)N, -0.4);
-  if (c->cfg.timf1_dword_input) { start *= 4096; start *= 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32 I/Q */
+  const int real = c->cfg.timf1_real_input != 0;
+  if (c->cfg.timf1_dword_input) { start *= 4096; start *= real ? 16 : 12; }   /* make_filcorrstart, fft1.c:4656-4663: left-justified int32; real: permute == 2 */
   start = (float)c->cfg.fft1_gain / start;
   for (int i = 0; i < N; i++) { c->fft1_desired[i] = 1; c->fft1_filtercorr[2 * i] = start; c->fft1_filtercorr[2 * i + 1] = 0; }
   float t1 = 0.125F * (float)PI_L, t2 = 0, t3;
   int i = 0, k = N - 1;
   while (t2 < 0.5 * PI_L) {
     t3 = (float)(sin(t2) * sin(t2));
-    c->fft1_desired[i] = t3; c->fft1_filtercorr[2 * i] = t3 * start;
+    if (!real) { c->fft1_desired[i] = t3; c->fft1_filtercorr[2 * i] = t3 * start; }     /* fft1.c:4707-4711: the low edge only for I/Q */
     c->fft1_desired[k] = t3; c->fft1_filtercorr[2 * k] = t3 * start;
     t2 += t1; i++; k--;
   }
@@ -270,7 +274,7 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   }
   c->tmp = zal(sizeof(float) * 8 * (NM > (1 << cfg->fft3_n) ? NM : (1 << cfg->fft3_n)));
   make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
-  if (cfg->fft1_sinpow) lro_make_window(1, N1, cfg->fft1_sinpow, c->fft1_window);
+  if (cfg->fft1_sinpow) lro_make_window(cfg->timf1_real_input ? 2 : 1, N1, cfg->fft1_sinpow, c->fft1_window);   /* fft_cntrl[].window, fft1var.c:45,50 */
   if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) lro_make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
   if (cfg->fft2_sinpow) lro_make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
   lro_make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
@@ -391,8 +395,40 @@ int lro_timf1_write_packed18(lro_ctx *c, const void *src, int off, int packed_by
 
 /* fft1_b mode 7: fft1win_dif_one (fft1.c:413-447) + bulk_of_dif (fft0.c:161) + dif_permute_one (fft1.c:637-650),
    then the direction flip of fft1.c:3660-3679.  Result: out[k] = conj(FFT(x*w))[(k - N/2) mod N]. */
+/* Real samples, fft1 version 2: fft1_reherm_dit_one (fft1_re.c:32-131).  2N reals from p0 = ref - 2*I1, sample ia and
+   sample 2N-1-ia both times fft1_window[ia] (mode 2), the real transform Z = sum x e^{-j 2 pi nk / 2N} (the reference runs
+   a split-radix real-to-Hermitian one, fft0.c:33; here the plain complex transform of (x, 0)), then
+     direction > 0:  out[k] = (Im Z_k, Re Z_k), k = 1..N-1;  out[0] = (Re Z_N, Re Z_0)
+     direction < 0:  out[N-k] = (Re Z_k, Im Z_k), k = 1..N-1;  out[0] = (Re Z_N, Re Z_N): the loop of fft1_re.c:123-128
+                     runs to k = N, where the "imaginary" slot tmp[2N-k] is the Nyquist term itself
+   and fft1_b is done (goto fft_done, fft1.c:3379: no CALIQ, no second flip). */
+static void fft1_one_real(lro_ctx *c, int timf1p_ref, float *out)
+{
+  const int N = c->N1, n = c->cfg.fft1_n;
+  const int dword = c->cfg.timf1_dword_input != 0, esz = dword ? 4 : 2;
+  const int32_t *t32 = (const int32_t *)c->timf1;
+  const int m = c->timf1_bytemask / esz;
+  int pa = (timf1p_ref / esz - c->I1 * 2 + m + 1) & m;
+  float *z = c->tmp;                            /* 4*N floats */
+  const int win = c->cfg.fft1_sinpow != 0;
+  for (int ia = 0; ia < 2 * N; ia++) {
+    const float w = win ? c->fft1_window[ia < N ? ia : 2 * N - 1 - ia] : 1.0f;
+    z[2 * ia] = (dword ? (float)t32[pa] : (float)c->timf1[pa]) * w; z[2 * ia + 1] = 0;
+    pa = (pa + 1) & m;
+  }
+  lro_fft_forward(n + 1, z);
+  if (c->cfg.fft1_direction > 0) {
+    out[0] = z[2 * N]; out[1] = z[0];
+    for (int k = 1; k < N; k++) { out[2 * k] = z[2 * k + 1]; out[2 * k + 1] = z[2 * k]; }
+  } else {
+    for (int k = 1; k < N; k++) { out[2 * (N - k)] = z[2 * k]; out[2 * (N - k) + 1] = z[2 * k + 1]; }
+    out[0] = z[2 * N]; out[1] = z[2 * N];
+  }
+}
+
 static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
 {
+  if (c->cfg.timf1_real_input) { fft1_one_real(c, timf1p_ref, out); return; }
   int N = c->N1, n = c->cfg.fft1_n, nn = N / 2;
   const int dword = c->cfg.timf1_dword_input != 0, esz = dword ? 4 : 2;   /* fft1.c:420 / :526 */
   const int32_t *t32 = (const int32_t *)c->timf1;

@@ -84,6 +84,15 @@ CASES = {
     "n10_afc_mix1only": dict(n1=10, n2=10, mixred=4, nblk=64, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                              fq=700.3, wf_avgnum=1, wf_mode=1, seed=26, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
                              afc=1, strong=[(-100.0, 3000.0)], weak=[(188.3, 400.0)], pulse_period=0, lim_halfwidth=3),
+    # real samples (ui.rx_input_mode without IQ_DATA): fft1 version 2 = fft1_reherm_dit_one (fft1_re.c:32), 2*N1 reals per
+    # transform, bins 0..fs/2; carriers are given in bins of that half spectrum.  Second case: int32 samples, mirrored passband
+    "n9_n11_real": dict(n1=9, n2=11, mixred=5, nblk=40, avg1num=2, avg2num=2, att_n=3, bln_interval=4, bln_avgnum=16,
+                        fq=1300.0, wf_avgnum=1, wf_mode=1, seed=31, timf2pow_log2=14, sumsq_blocks=4, real=1, gain=6,
+                        strong=[(100.3, 8000.0)], weak=[(325.2, 60.0), (33.0, 80.0)], pulse_period=1499, lim_halfwidth=3),
+    "n8_n10_real_dword_rev": dict(n1=8, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=3, att_n=6, gain=68, bln_interval=3, bln_avgnum=8,
+                                  fq=333.37, wf_avgnum=2, wf_mode=1, seed=32, timf2pow_log2=13, sumsq_blocks=8, real=1, dword=1,
+                                  direction=-1, sigma=256.0, strong=[(60.25, 6000.0)], weak=[(171.5, 200.0), (90.0, 100.0)],
+                                  pulse_period=997, pulse_amp=100000.0, lim_halfwidth=3),
     # second fft disabled (the reference's own default, uivar.c:371): fft1 -> fft1_c -> fft1_mix1_fixed
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
@@ -95,11 +104,13 @@ def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
              second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
-             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0, mix2=0)
+             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0, mix2=0, real=0)
     d.update(CASES[name])
     if d["gain"] is None:
         # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
         d["gain"] = level_gain(d["n1"], d["att_n"], d["sigma"] * (16384.0 / 49152.0 if d["dword"] else 1.0))
+        if d["real"]:            # 2*N1 reals of variance sigma^2 per transform carry the power of N1 complex samples of sigma per component
+            d["gain"] = max(1, d["gain"])
     return d
 
 
@@ -116,6 +127,18 @@ def make_input(d):
     M1 = N1 - interleave(d["n1"], d["sinpow1"])
     n = M1 * d["nblk"] + 2 * N1
     rng = np.random.default_rng(d["seed"])
+    if d["real"]:
+        # 2n real samples at twice the rate; a carrier at bin k of the N1-bin half spectrum is cos(2 pi k t / (2 N1))
+        t = np.arange(2 * n)
+        x = rng.normal(0, d["sigma"], 2 * n)
+        for k, a in d["strong"] + d["weak"]:
+            x += a * np.cos(2 * np.pi * k * t / (2 * N1) + rng.uniform(0, 6.28))
+        if d["pulse_period"]:
+            for s in range(d["pulse_period"] // 2, 2 * n - 4, 2 * d["pulse_period"]):     # two-sample impulses: flat spectrum
+                x[s:s + 2] += d["pulse_amp"] * np.cos(rng.uniform(0, 6.28)) * np.array([1.0, -0.5])
+        lim = 131071 if d["dword"] else 32767
+        out = np.clip(np.round(x), -lim, lim).astype(np.int32 if d["dword"] else np.int16)
+        return ((out << 14) | 0x2000) if d["dword"] else out
     t = np.arange(n)
     x = rng.normal(0, d["sigma"], n) + 1j * rng.normal(0, d["sigma"], n)
     for k, a in d["strong"] + d["weak"]:
@@ -147,7 +170,10 @@ def make_liminfo(d):
     """strong/weak routing table: bins within lim_halfwidth of a strong carrier are marked strong (input to the path)."""
     N1 = 1 << d["n1"]
     lim = np.zeros(N1, np.float32)
-    for k, _ in d["strong"]:
+    for k, _ in d["strong"] if d["real"] else []:       # real input: bins of the half spectrum 0..fs/2, mirrored passband counts down
+        c = int(round(N1 - k if d["direction"] < 0 else k))
+        lim[max(0, c - d["lim_halfwidth"]):c + d["lim_halfwidth"] + 1] = 1.0
+    for k, _ in [] if d["real"] else d["strong"]:
         for kk in ([k, -k] if (d["lim_mirror"] or d["direction"] < 0) else [k]):   # mirrored passband / residual image
             c = int(round(N1 // 2 + kk))
             lim[max(0, c - d["lim_halfwidth"]):c + d["lim_halfwidth"] + 1] = 1.0
@@ -179,7 +205,7 @@ def lrh_config(d, iq, **kw):
         second_fft_enable=d["second_fft"], timf2_blockpower_block=d["blockpower_block"],
         timf2_blockpower_size=d["blockpower_size"], fft3_n=d["fft3_n"], fft3_sinpow=d["fft3_sinpow"], mix2_n=d["mix2_n"],
         max_fft3n=d["max_fft3n"], baseband_size=4096, timf1_dword_input=d["dword"], sample_shift=d["sample_shift"],
-        fft1_direction=d["direction"])
+        fft1_direction=d["direction"], timf1_real_input=d["real"])
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -189,7 +215,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw", "mix2"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw", "mix2", "real"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
