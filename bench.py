@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--fft2-n", type=int, default=12)
     ap.add_argument("--cpu-blocks", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--real-input", action="store_true",
+                    help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker is not None:                        # child of cpu_baseline_all_cores: no GPU, no torch
@@ -180,6 +182,8 @@ def main():
     from linrad_amd import lib as hiplib
 
     cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
+    if args.real_input:
+        cfg.timf1_real_input = 1
     N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
     samples_per_step = args.batch * args.rounds * M1

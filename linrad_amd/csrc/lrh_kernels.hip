@@ -528,7 +528,11 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
 // of the call), so every decision equals the serial one.  Decisions go to a bit mask; k_blank_apply zeroes the
 // data afterwards (the scan itself only reads), which also keeps lanes from racing on guard samples.
 #define LRH_BLN_CHUNK 64
-#define LRH_BLN_BACK 256
+// How far back a lane searches for its clean restart point.  In the normal regime the point is one or two samples away;
+// when the limit sits below the noise (the stupid blanker "latched", SURVEY 8d: 99 % of the samples above the limit, a
+// clean sample every ~100) the search and the replay are ~100 samples per lane, and a miss -- which sends the whole call
+// to the one-thread serial pass, 200 ns per sample -- needs 4096 consecutive samples above the limit.
+#define LRH_BLN_BACK 4096
 
 __device__ __forceinline__ void bln_setbit(unsigned int *bits, int p) { atomicOr(&bits[p >> 5], 1u << (p & 31)); }
 

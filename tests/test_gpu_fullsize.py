@@ -256,3 +256,68 @@ def test_four_step_fft2_runs_of_transforms_are_bit_identical(fft2_n, monkeypatch
         for a, b in zip(res[0], other):
             assert np.array_equal(a, b)
     assert np.count_nonzero(res[0][0]) > 0
+
+
+def test_fullsize_real_input_matches_oracle_and_places_tones():
+    """Real samples at full size (fft1 version 2, fft1_reherm_dit_one; 2 x 16384 reals per transform): HIP vs oracle on the
+    spectrum, the power sums and timf2, and the property the real transform must have -- a cosine at bin k of the half
+    spectrum 0..fs/2 peaks at fft1 bin k, its image nowhere else (out = (Im Z_k, Re Z_k), fft1_re.c:100-113)."""
+    cfg = chain_config(14, 12, batch=8)
+    cfg.timf1_real_input = 1
+    cfg.stupid_bln_mode = 0
+    n = cfg.timf1_bytes // 2
+    t = np.arange(n)
+    rng = np.random.default_rng(5)
+    tones = [(1000, 3000.0), (9000.25, 800.0), (16000, 200.0)]
+    x = rng.normal(0, 30.0, n)
+    for k, a in tones:
+        x += a * np.cos(2 * np.pi * k * t / (2 * N1) + rng.uniform(0, 6.28))
+    x16 = np.clip(np.round(x), -32767, 32767).astype(np.int16)
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        rx.timf1_write(x16)
+        rx.set_liminfo(np.zeros(N1, np.float32))
+        rx.wideband_dsp(16, 8)
+        res.append({k: rx.export(ring) for ring, k in ((abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"),
+                                                       (abi.RING_TIMF2_FLOAT, "timf2"), (abi.RING_FFT2_FLOAT, "fft2"))})
+        res[-1]["timf2"] = res[-1]["timf2"][:rx.p.timf2_pa]      # finished samples (the half block behind timf2_pa is scratch, DESIGN 3)
+        assert rx.p.timf2_pa == 16 * (N1 // 2) * 4
+    h, o = res
+    for k in ("fft1", "sumsq", "timf2", "fft2"):
+        assert _relerr(h[k], o[k]) < 1e-5, (k, _relerr(h[k], o[k]))
+    p = (h["fft1"].reshape(-1, N1, 2).astype(np.float64) ** 2).sum(axis=2).mean(axis=0)
+    floor = np.median(p)
+    for k, a in tones:
+        kk = int(round(k))
+        assert p[kk - 1:kk + 2].max() > 1e3 * floor
+    mask = np.ones(N1, bool)
+    for k, _ in tones:
+        mask[max(0, int(k) - 4):int(k) + 6] = False
+    assert p[mask].max() < 50 * floor
+
+
+def test_latched_blanker_stays_on_the_parallel_path():
+    """Gain far above the level plan: the limit sits below the noise and ~99 % of the samples are cleared (the latch the
+    reference shows with its menu-default gain).  The decisions must still equal the serial scan's (oracle) and
+    must come from the parallel scan: the one-thread replay costs 200 ns per sample and would stall a real-time chain."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(14, 12, batch=16)
+    cfg.fft1_gain *= 12
+    s = synth_defaults(N1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 14)
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        _feed(rx, iq, lim, 0.31 * 4096 + 0.3)
+        rx.wideband_dsp(32, 16)
+        res.append((rx.export(abi.RING_TIMF2_PWR), rx.blanker_state(), rx.p.as_dict()))
+    (hp, hb, hpt), (op, ob, opt) = res
+    fit = hpt["timf2p_fit"]
+    assert fit == opt["timf2p_fit"] and fit > 100000
+    cleared_h, cleared_o = hp[:fit] == 0, op[:fit] == 0
+    assert cleared_o.mean() > 0.9                                   # latched
+    assert hb.slow_path_calls == 0
+    assert np.mean(cleared_h != cleared_o) < 1e-4                   # borderline float32 flips only
+    assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
