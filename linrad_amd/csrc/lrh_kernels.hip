@@ -656,10 +656,112 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   }
 }
 
-// exact serial replay, only when a lane of k_blank_scan could not find a clean restart point
+// Long runs.  A lane of k_blank_scan gives up when LRH_BLN_BACK samples in a row sit above the limit -- a strong signal the
+// selective limiter has not routed away yet, or a limit far below the noise.  Without pulse calibration (clr1 = 0,
+// clr2 = 1: guards reach no further than the sample that ends a run, blank1.c:1013-1014, 1058-1086) the serial scan
+// decomposes by runs of samples above the limit: every sample of a run is cleared, and the sample that ends it is cleared
+// too when the run's maximum is 34 dB over the noise.  The only long-range quantity is that maximum, so the replay is a
+// segmented max: chunk summaries in LDS, tile summaries in global memory (k_blank_runs_pre), then every lane decides its
+// own 64 samples with the incoming (in run?, maximum so far) looked up backwards (k_blank_runs).  Both kernels return at
+// once unless need_slow is set; with calibration (clr2 > 1) guards chain runs together and k_blank_serial stays.
+__device__ __forceinline__ bool bln_runs_mode(const BlankArgs &a) { return a.clr1 == 0 && a.clr2 == 1; }
+
+struct BlnChunk { float cmax, smax; int any_below, last_above, empty; };
+__device__ __forceinline__ BlnChunk bln_chunk_summary(const BlankArgs &a, int cs, int ce, float nfl)
+{
+  BlnChunk r; r.cmax = 0.f; r.smax = 0.f; r.any_below = 0; r.last_above = 0; r.empty = cs > ce;
+  for (int q = cs; q <= ce; q++) {
+    const float v = a.pwr[(a.pbeg + q) & a.mask];
+    if (v > nfl) { r.cmax = fmaxf(r.cmax, v); r.smax = fmaxf(r.smax, v); r.last_above = 1; }
+    else { r.any_below = 1; r.smax = 0.f; r.last_above = 0; }
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_blank_runs_pre(BlankArgs a)
+{
+  if (!a.st->need_slow || !bln_runs_mode(a)) return;
+  __shared__ float l_max[256], l_smax[256];
+  __shared__ int l_flags[256];
+  const int qt = blockIdx.x * LRH_BLN_TILE;
+  const int nwords_ring = (a.mask + 1) >> 5;
+  const int w0 = ((a.pbeg + qt) & a.mask) >> 5;
+  for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) a.mask_bits[(w0 + i) & (nwords_ring - 1)] = 0;   // what the scan left
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.st->call_cleared = 0;
+  const int cb = (blockIdx.x * 256 + threadIdx.x) * LRH_BLN_CHUNK;
+  const BlnChunk ch = bln_chunk_summary(a, max(cb, 1), min(cb + LRH_BLN_CHUNK - 1, a.total), (float)a.st->limit);
+  l_max[threadIdx.x] = ch.cmax; l_smax[threadIdx.x] = ch.smax;
+  l_flags[threadIdx.x] = ch.any_below | (ch.last_above << 1) | (ch.empty << 2);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float tmax = 0.f, smax = 0.f; int any = 0, last_above = 0;
+  for (int l = 0; l < 256; l++) {
+    const int f = l_flags[l];
+    if (f & 4) continue;
+    tmax = fmaxf(tmax, l_max[l]);
+    if (f & 1) { any = 1; smax = l_smax[l]; } else smax = fmaxf(smax, l_max[l]);
+    last_above = (f >> 1) & 1;
+  }
+  a.tiles[blockIdx.x] = make_float4((float)any, tmax, smax, (float)last_above);
+}
+
+__global__ __launch_bounds__(256) void k_blank_runs(BlankArgs a)
+{
+  if (!a.st->need_slow || !bln_runs_mode(a)) return;
+  __shared__ float l_max[256], l_smax[256];
+  __shared__ int l_flags[256];
+  __shared__ float t_max; __shared__ int t_run;
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
+  const int cb = (blockIdx.x * 256 + threadIdx.x) * LRH_BLN_CHUNK;
+  const int cs = max(cb, 1), ce = min(cb + LRH_BLN_CHUNK - 1, a.total);
+  const BlnChunk ch = bln_chunk_summary(a, cs, ce, nfl);
+  l_max[threadIdx.x] = ch.cmax; l_smax[threadIdx.x] = ch.smax;
+  l_flags[threadIdx.x] = ch.any_below | (ch.last_above << 1) | (ch.empty << 2);
+  if (threadIdx.x == 0) {                                  // state at the first sample of the tile
+    int run = 0; float m = 0.f;
+    for (int t = (int)blockIdx.x - 1; t >= 0; t--) {
+      const float4 ti = a.tiles[t];
+      if (ti.x != 0.f) { if (ti.w != 0.f) { run = 1; m = fmaxf(m, ti.z); } break; }
+      run = 1; m = fmaxf(m, ti.y);                          // every sample of that tile above the limit
+    }
+    t_run = run; t_max = m;
+  }
+  __syncthreads();
+  if (cs > ce) return;
+  int run = 0; float pm = 0.f; bool open = true;            // state at cs: look back over the earlier chunks of the tile
+  for (int l = (int)threadIdx.x - 1; l >= 0 && open; l--) {
+    const int f = l_flags[l];
+    if (f & 4) continue;
+    if (f & 1) { if (f & 2) { run = 1; pm = fmaxf(pm, l_smax[l]); } open = false; }
+    else { run = 1; pm = fmaxf(pm, l_max[l]); }
+  }
+  if (open && t_run) { run = 1; pm = fmaxf(pm, t_max); }
+  int cnt = 0;
+  for (int q = cs; q <= ce; q++) {
+    const int p = (a.pbeg + q) & a.mask;
+    const float v = a.pwr[p];
+    if (v > nfl) { run = 1; pm = fmaxf(pm, v); atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31)); cnt++; }
+    else if (run) {
+      run = 0;
+      int ib, ia;
+      const int ext = bln_guards(a, pm, totnoise, &ib, &ia);
+      pm = 0.f;
+      if (ext && ia > 0) { atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31)); cnt += ia; }   // ib = 0, ia <= 1: the ending sample itself
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.st->call_cleared, cnt);
+}
+__global__ void k_blank_runs_done(BlankArgs a)
+{
+  if (!a.st->need_slow || !bln_runs_mode(a)) return;
+  a.st->need_slow = 0; a.st->slow_calls++;
+}
+
+// exact serial replay for the calibrated blanker (clr2 > 1), only when a lane of k_blank_scan could not find a clean restart point
 __global__ void k_blank_serial(BlankArgs a)
 {
-  if (!a.st->need_slow) return;
+  if (!a.st->need_slow || bln_runs_mode(a)) return;
   a.st->need_slow = 0; a.st->slow_calls++;
   for (int q = 1 - a.clr1 - 32; q <= a.total + a.clr2 + 32; q++) a.mask_bits[((a.pbeg + q) & a.mask) >> 5] = 0;
   const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
@@ -1603,6 +1705,11 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
     a.npartials = ntiles; a.nremoved = (nwords + 255) / 256;
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
+    if (a.clr1 == 0 && a.clr2 == 1 && a.tiles) {         // long-run replay: three launches that return at once unless a lane gave up
+      hipLaunchKernelGGL(k_blank_runs_pre, dim3(ntiles), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_blank_runs_done, dim3(1), dim3(1), 0, st, a);
+    }
     hipLaunchKernelGGL(k_blank_apply, dim3(a.nremoved), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
     if (a.own) {                                         // per-channel statistic from the own ring after clearing
       a.nremoved = 0;

@@ -89,6 +89,7 @@ struct BlankArgs {
   // per-channel noise statistic), xstat the two-float exchange buffer; phase 1 stops after the own statistic,
   // phase 2 resumes with both channels' values (phase 0: single channel, everything in one go)
   int chans; float *own; float *xstat; int own_slot; int phase;
+  float4 *tiles;            // per-tile run summaries of the long-run replay (k_blank_runs_pre / k_blank_runs)
 };
 
 // ---- fft2 ----

@@ -321,3 +321,34 @@ def test_latched_blanker_stays_on_the_parallel_path():
     assert hb.slow_path_calls == 0
     assert np.mean(cleared_h != cleared_o) < 1e-4                   # borderline float32 flips only
     assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
+
+
+@pytest.mark.parametrize("amps", [(3000.0, 3000.0), (6000.0, 0.0)])
+def test_blanker_long_runs_replayed_in_parallel(amps):
+    """A strong signal the selective limiter has not routed away yet (liminfo all weak) keeps timf2_pwr above the limit for
+    tens of thousands of samples: k_blank_scan finds no clean restart point and the long-run replay (k_blank_runs) takes
+    over.  Two beating carriers make the runs end at the beat nulls, so run maxima cross chunk and tile borders and the
+    34 dB end-of-run guard is exercised; a single carrier never lets a run end.  Decisions = the serial scan's (oracle)."""
+    cfg = chain_config(14, 12, batch=16)
+    n = cfg.timf1_bytes // 4
+    t = np.arange(n)
+    rng = np.random.default_rng(9)
+    z = rng.normal(0, 64.0, n) + 1j * rng.normal(0, 64.0, n)
+    z += amps[0] * np.exp(2j * np.pi * 1000.0 * t / N1) + amps[1] * np.exp(2j * np.pi * (1000.0 + N1 / 20000.0) * t / N1 + 1.0j)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2], iq[1::2] = np.clip(np.round(z.real), -32767, 32767), np.clip(np.round(z.imag), -32767, 32767)
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        _feed(rx, iq, np.zeros(N1, np.float32), 0.31 * 4096 + 0.3)
+        rx.wideband_dsp(64, 16)
+        res.append((rx.export(abi.RING_TIMF2_PWR), rx.blanker_state(), rx.p.as_dict()))
+    (hp, hb, hpt), (op, ob, opt) = res
+    fit = hpt["timf2p_fit"]
+    assert fit == opt["timf2p_fit"] and fit > 400000
+    ch, co = hp[:fit] == 0, op[:fit] == 0
+    assert co.mean() > 0.5 and hb.slow_path_calls >= 1
+    if amps[1]:
+        assert 0.5 < co.mean() < 0.999                               # the runs do end
+    assert np.mean(ch != co) < 1e-4, np.mean(ch != co)
+    assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
