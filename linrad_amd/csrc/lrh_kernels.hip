@@ -528,11 +528,10 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
 // of the call), so every decision equals the serial one.  Decisions go to a bit mask; k_blank_apply zeroes the
 // data afterwards (the scan itself only reads), which also keeps lanes from racing on guard samples.
 #define LRH_BLN_CHUNK 64
-// How far back a lane searches for its clean restart point.  In the normal regime the point is one or two samples away;
-// when the limit sits below the noise (the stupid blanker "latched", SURVEY 8d: 99 % of the samples above the limit, a
-// clean sample every ~100) the search and the replay are ~100 samples per lane, and a miss -- which sends the whole call
-// to the one-thread serial pass, 200 ns per sample -- needs 4096 consecutive samples above the limit.
-#define LRH_BLN_BACK 4096
+// How far back a lane searches for its clean restart point.  In the normal regime the point is one or two samples away.
+// A miss hands the call to the long-run replay below (uncalibrated blanker: parallel, k_blank_runs) or to the one-thread
+// serial pass (calibrated); searching further back only pays while a miss is expensive.
+#define LRH_BLN_BACK 256
 
 __device__ __forceinline__ void bln_setbit(unsigned int *bits, int p) { atomicOr(&bits[p >> 5], 1u << (p & 31)); }
 
@@ -737,18 +736,22 @@ __global__ __launch_bounds__(256) void k_blank_runs(BlankArgs a)
   }
   if (open && t_run) { run = 1; pm = fmaxf(pm, t_max); }
   int cnt = 0;
+  int wcur = -1; unsigned int wacc = 0;                     // decision bits gathered per 32-sample ring word, one atomic per word
+  auto flush = [&]() { if (wacc) atomicOr(&a.mask_bits[wcur], wacc); wacc = 0; };
   for (int q = cs; q <= ce; q++) {
     const int p = (a.pbeg + q) & a.mask;
+    if ((p >> 5) != wcur) { flush(); wcur = p >> 5; }
     const float v = a.pwr[p];
-    if (v > nfl) { run = 1; pm = fmaxf(pm, v); atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31)); cnt++; }
+    if (v > nfl) { run = 1; pm = fmaxf(pm, v); wacc |= 1u << (p & 31); cnt++; }
     else if (run) {
       run = 0;
       int ib, ia;
       const int ext = bln_guards(a, pm, totnoise, &ib, &ia);
       pm = 0.f;
-      if (ext && ia > 0) { atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31)); cnt += ia; }   // ib = 0, ia <= 1: the ending sample itself
+      if (ext && ia > 0) { wacc |= 1u << (p & 31); cnt += ia; }   // ib = 0, ia <= 1: the ending sample itself
     }
   }
+  flush();
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.st->call_cleared, cnt);
 }
