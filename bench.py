@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--fft2-n", type=int, default=12)
     ap.add_argument("--cpu-blocks", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stream-host", action="store_true",
+                    help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
+                         "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -195,7 +198,28 @@ def main():
     lrh_stream = torch.cuda.ExternalStream(rx.stream_handle(), device=torch.device("cuda", local_rank)) if use_dist else None
     comm_stream = torch.cuda.Stream(device=torch.device("cuda", local_rank)) if use_dist else None
 
+    host_ring = None
+    if args.stream_host:
+        # the producer's side of the boundary: Linrad's timf1 arena, page-locked once; one step's worth of
+        # new samples is 4 bytes per complex sample
+        s0 = hiplib.synth_defaults(N1, channel_of_rank(rank))
+        host_ring = np.ascontiguousarray(hiplib.synth_iq(s0, 0, cfg.timf1_bytes // 4))
+        rx.host_register(host_ring)
+        if args.batch * args.rounds * M1 * 4 > cfg.timf1_bytes // 2:
+            raise SystemExit("--stream-host: one step's samples must fit half the timf1 ring (use --rounds 1)")
+    step_bytes = args.batch * args.rounds * M1 * 4
+    wr = [0]
+
     def step():
+        if host_ring is not None:
+            nb = min(step_bytes, cfg.timf1_bytes)
+            off = wr[0] % cfg.timf1_bytes
+            first = min(nb, cfg.timf1_bytes - off)
+            flat = host_ring.view(np.uint8)
+            rx.timf1_write_async(flat[off:off + first], off)
+            if nb > first:
+                rx.timf1_write_async(flat[:nb - first], 0)
+            wr[0] += nb
         rx.wideband_dsp(args.batch * args.rounds, args.batch)
         if use_dist:
             # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
@@ -206,6 +230,8 @@ def main():
                 cross_channel_power_sum(xchg, dist)
 
     def barrier():
+        if host_ring is not None:
+            rx.timf1_write_wait()
         rx.sync()
         torch.cuda.synchronize()
         if use_dist:
@@ -283,6 +309,7 @@ def main():
                                    f"{args.rounds} x {args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
                        "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "rounds_per_step": args.rounds, "channels": world,
                        "parallelism": f"1 RF channel per GPU x{world}"},
+            "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",
             "event_ms_per_step": round(ev_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
             "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4),
                          "wideband_dsp_cpu_ms_per_call": round(host_dsp_cpu[0] / max(host_dsp_cpu[1], 1), 4),

@@ -219,6 +219,16 @@ int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "ff
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
 int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */
 void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                         /* for device-resident producers */
+/* Streaming producer: the same copy without the host wait.  It runs on the context's own copy stream, behind the fft1
+   launches already enqueued (they may still read the ring) and ahead of every later lrh_fft1_b / lrh_wideband_dsp call
+   (which wait for it on the device), so the PCIe transfer of the next samples overlaps the chain working on the previous
+   ones.  `src` must stay untouched until lrh_timf1_write_wait returns (or the next lrh_sync); page-locked memory --
+   lrh_host_register on Linrad's timf1 arena once after get_buffers, lrh_host_unregister before free_buffers (buf.c:2105;
+   the shim never frees host memory) -- makes the copy a true DMA. */
+int lrh_timf1_write_async(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);
+int lrh_timf1_write_wait(lrh_ctx *ctx);
+int lrh_host_register(lrh_ctx *ctx, void *ptr, size_t bytes);
+int lrh_host_unregister(lrh_ctx *ctx, void *ptr);
 /* One read of an 18-bit .raw recording (rx_file_input, rxin.c:1643-1644): `packed_bytes` (multiple of 9) of packed
    data, 9 bytes per four int32 components, are expanded like expand_rawdat (csplit.c:20-73: value left-justified in
    32 bits, bit 13 set for the truncated half LSB) into the timf1 ring at byte_offset (multiple of 16, wraps).

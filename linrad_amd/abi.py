@@ -163,6 +163,11 @@ class StageAPI:
         self._proto("get_table", [vp, C.c_char_p, fp, C.c_int])
         self._proto("timf1_write", [vp, vp, C.c_int, C.c_int])
         self._proto("timf1_write_packed18", [vp, vp, C.c_int, C.c_int])
+        if prefix == "lrh":                  # streaming producer calls: HIP library only
+            self._proto("timf1_write_async", [vp, vp, C.c_int, C.c_int])
+            self._proto("timf1_write_wait", [vp])
+            self._proto("host_register", [vp, vp, C.c_size_t])
+            self._proto("host_unregister", [vp, vp])
         self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
         for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed", "make_fft3_all", "fft3_mix2"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
@@ -325,6 +330,20 @@ class StageAPI:
         iq = np.ascontiguousarray(iq, np.int32 if self.cfg.timf1_dword_input else np.int16)
         self._chk(self._f("timf1_write")(self.ctx, iq.ctypes.data_as(C.c_void_p), int(byte_offset), int(iq.nbytes)),
                   "timf1_write")
+
+    def timf1_write_async(self, iq, byte_offset=0):
+        """producer copy without the host wait (lrh_timf1_write_async); `iq` must stay alive and untouched until timf1_write_wait()"""
+        assert iq.flags["C_CONTIGUOUS"]
+        self._chk(self._f("timf1_write_async")(self.ctx, iq.ctypes.data_as(C.c_void_p), int(byte_offset), int(iq.nbytes)), "timf1_write_async")
+
+    def timf1_write_wait(self):
+        self._chk(self._f("timf1_write_wait")(self.ctx), "timf1_write_wait")
+
+    def host_register(self, arr):
+        self._chk(self._f("host_register")(self.ctx, arr.ctypes.data_as(C.c_void_p), int(arr.nbytes)), "host_register")
+
+    def host_unregister(self, arr):
+        self._chk(self._f("host_unregister")(self.ctx, arr.ctypes.data_as(C.c_void_p)), "host_unregister")
 
     def timf1_write_packed18(self, packed, byte_offset=0):
         """One read of an 18-bit .raw recording: packed bytes -> int32 ring (expand_rawdat, csplit.c:20-73)."""

@@ -65,6 +65,8 @@ struct lrh_ctx {
   std::vector<float> h_window3_ref;
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
+  hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
+  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; bool in_pending = false, fft1_read_valid = false;
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
   hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
@@ -287,6 +289,9 @@ void lrh_close(lrh_ctx *c)
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
+  if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
+  if (c->ev_in) hipEventDestroy(c->ev_in);
+  if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
@@ -368,6 +373,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
+  hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking);
+  hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_fft1_read, hipEventDisableTiming);
   int rc = LRH_OK;
 #define A(call) do { if (rc == LRH_OK) rc = (call); } while (0)
   // ---- tables
@@ -631,6 +638,44 @@ int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
 }
 void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
+int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
+  off &= c->timf1_bytemask;
+  const char *s = (const char *)src; char *d = (char *)c->d_timf1;
+  const int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
+  // the fft1 launches already enqueued may still read the ring span being overwritten: the copy goes behind the last of
+  // them (the event lrh_fft1_b records), not behind the rest of the chain
+  if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read, 0));
+  HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
+  if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+  HIPCHK(c, hipEventRecord(c->ev_in, c->stream_in));
+  c->in_pending = true;
+  return LRH_OK;
+}
+int lrh_timf1_write_wait(lrh_ctx *c)
+{
+  if (!c) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
+  return LRH_OK;
+}
+int lrh_host_register(lrh_ctx *c, void *ptr, size_t bytes)
+{
+  if (!c || !ptr || !bytes) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return LRH_OK;
+}
+int lrh_host_unregister(lrh_ctx *c, void *ptr)
+{
+  if (!c || !ptr) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  HIPCHK(c, hipHostUnregister(ptr));
+  return LRH_OK;
+}
+
 int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_bytes)
 {
   if (c) hipSetDevice(c->cfg.device);
@@ -655,6 +700,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 {
   if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
   if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (c->in_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0)); c->in_pending = false; }   // samples of lrh_timf1_write_async
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;       // bytes per complex sample (fft1.c:420 / :526)
@@ -687,6 +733,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   }
   ProfScope ps(c, "fft1");
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+  if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
   if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
     RealSplitArgs r;
     r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;

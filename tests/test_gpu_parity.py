@@ -116,3 +116,37 @@ def test_c_host_driver_runs():
     out = subprocess.run([exe, "12", "14", "0.5"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Msamples/s" in out.stdout and "blanker: noise floor" in out.stdout
+
+
+def test_async_producer_write_is_ordered_before_fft1():
+    """lrh_timf1_write_async + page-locked host memory: the copy runs on its own stream, later stage calls wait for it on the
+    device, and a second copy into the span an enqueued fft1 launch reads goes behind that launch."""
+    from linrad_amd import abi
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config
+    cfg = chain_config(fft1_n=12, fft2_n=10, batch=16)
+    s = synth_defaults(1 << cfg.fft1_n, 0)
+    n = cfg.timf1_bytes // 4
+    iq_a, iq_b = synth_iq(s, 0, n), synth_iq(s, 12345, n)
+    ref = []
+    for iq in (iq_a, iq_b):
+        rx = open_hip(cfg)
+        rx.timf1_write(iq)
+        rx.fft1_b(16)
+        ref.append(rx.export(abi.RING_FFT1_FLOAT))
+    rx = open_hip(cfg)
+    host_a, host_b = np.ascontiguousarray(iq_a), np.ascontiguousarray(iq_b)
+    rx.host_register(host_a)
+    rx.timf1_write_async(host_a)
+    rx.fft1_b(16)                                   # waits for the copy on the device
+    p_after = rx.ptrs_copy()
+    rx.timf1_write_async(host_b)                    # overwrites what the launch above reads: must queue behind it
+    out_a = rx.export(abi.RING_FFT1_FLOAT)
+    rx.p = type(rx.p)()                             # start over on the new ring content
+    rx._f("ptrs_init")(rx.ctx, __import__("ctypes").byref(rx.p))
+    rx.fft1_b(16)
+    out_b = rx.export(abi.RING_FFT1_FLOAT)
+    rx.timf1_write_wait()
+    rx.host_unregister(host_a)
+    assert p_after.fft1_pa != 0
+    assert np.array_equal(out_a, ref[0]) and np.array_equal(out_b, ref[1]) and not np.array_equal(ref[0], ref[1])
