@@ -289,6 +289,24 @@ def main():
                 "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                 "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
                 "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
+    if rank == 0 and roof is not None:
+        # context for the 8 TB/s nominal peak: what a plain device-to-device copy reaches on this box (read + write bytes)
+        try:
+            nbytes = 1 << 30
+            src = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            roof["device_copy_GBps"] = round(10 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception:  # noqa: BLE001
+            roof["device_copy_GBps"] = None
     cpu = cpu_all = cpu_port = None
     if rank == 0 and not args.no_cpu:
         cpu_port = cpu_baseline(args, args.fft1_n, args.fft2_n)
@@ -314,6 +332,7 @@ def main():
             "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4),
                          "wideband_dsp_cpu_ms_per_call": round(host_dsp_cpu[0] / max(host_dsp_cpu[1], 1), 4),
                          "staging_wait_ms_per_call": round(host_wait[0] / max(host_wait[1], 1), 4)},
+            "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_all_cores": cpu_all, "stages": stages,
             "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
                         "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},
