@@ -324,6 +324,12 @@ int lrh_fft3_mix2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
      lrh_fft3_mix2(ctx, p, batch)                 filter, back transform, overlap-add of A (channel 0) or B (channel 1)
    Without lrh_set_pol a coupled context filters its own channel, like a single-channel one. */
 int lrh_set_pol(lrh_ctx *ctx, float c1, float c2, float c3);
+/* The same step for more than two receivers (phased array, one channel per GPU; beyond the reference, which stops at two
+   channels -- parity unpinned past lrh_set_pol's case): this channel's complex weights in the two sums, A = sum_c wa_c X_c and
+   B = sum_c wb_c X_c (two beams).  lrh_set_pol(c1,c2,c3) is wa = c1, wb = -(c2 + j c3) on channel 0 and wa = c2 - j c3,
+   wb = c1 on channel 1.  Needs fft3 configured; works without cfg.blanker_channels (then every context carries on with A,
+   the context with timf1_channel_index 1 of a coupled pair with B). */
+int lrh_set_combine_weights(lrh_ctx *ctx, float wa_re, float wa_im, float wb_re, float wb_im);
 int lrh_mix2_pol_begin(lrh_ctx *ctx, const lrh_ptrs *p, int batch, size_t *count);
 int lrh_set_bg_filterfunc(lrh_ctx *ctx, const float *bg_filterfunc /* fft3_size floats (baseb_graph.c:1246) */);
 /* compute_timf2_powersum (wcw.c:80-138): weak-signal power per block of released timf2 data, for the S/N meter */

@@ -179,6 +179,7 @@ class StageAPI:
         self._proto("fft2_xy_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
         self._proto("fft2_xy_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("set_pol", [vp, C.c_float, C.c_float, C.c_float])
+        self._proto("set_combine_weights", [vp, C.c_float, C.c_float, C.c_float, C.c_float])
         self._proto("mix2_pol_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
         self._proto("exchange_ptr", [vp, C.c_int, C.POINTER(vp)])
         self._proto("exchange_read", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
@@ -270,6 +271,11 @@ class StageAPI:
     def set_pol(self, c1, c2, c3):
         """pg.c1..c3: the polarisation fft3_mix2 turns the channel pair into (mix2.c:340-343)"""
         self._chk(self._f("set_pol")(self.ctx, float(c1), float(c2), float(c3)), "set_pol")
+
+    def set_combine_weights(self, wa, wb=0j):
+        """this channel's complex weights in the two coherent sums A = sum_c wa_c X_c, B = sum_c wb_c X_c (phased array)"""
+        wa, wb = complex(wa), complex(wb)
+        self._chk(self._f("set_combine_weights")(self.ctx, wa.real, wa.imag, wb.real, wb.imag), "set_combine_weights")
 
     def mix2_pol_begin(self, batch=1):
         n = C.c_size_t()

@@ -81,7 +81,7 @@ struct lrh_ctx {
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
-  float2 *d_xpol = nullptr; float pol[3] = {1.f, 0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
+  float2 *d_xpol = nullptr; float2 pol_wa = {1.f, 0.f}, pol_wb = {0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
@@ -477,7 +477,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_window3, c->N3)); A(dev_alloc(c, &c->d_bgfilt, c->N3)); A(dev_alloc(c, &c->d_tw3, c->N3)); A(dev_alloc(c, &c->d_twm2, c->Nm2));
     A(dev_alloc(c, &c->d_fft3, (size_t)cfg->max_fft3n * c->N3)); A(dev_alloc(c, &c->d_baseb, (size_t)cfg->baseband_size + 2 * c->Nm2));
     A(dev_alloc(c, &c->d_mix2_scratch, (size_t)cfg->max_fft3n * c->Nm2));
-    if (cfg->blanker_channels == 2) A(dev_alloc(c, &c->d_xpol, (size_t)2 * cfg->max_fft3n * c->Nm2));
+    A(dev_alloc(c, &c->d_xpol, (size_t)2 * cfg->max_fft3n * c->Nm2));
   }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
@@ -920,6 +920,7 @@ int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
 }
 static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
 {
+  if (which == LRH_X_POL) { if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured"); *ptr = (float *)c->d_xpol; *cap = (size_t)4 * c->cfg.max_fft3n * c->Nm2; return LRH_OK; }
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
   else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
@@ -1303,21 +1304,28 @@ int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
 {
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
-  c->pol[0] = c1; c->pol[1] = c2; c->pol[2] = c3; c->pol_set = true;
+  if ((c->cfg.timf1_channel_index & 1) == 0) { c->pol_wa = make_float2(c1, 0.f); c->pol_wb = make_float2(-c2, -c3); }   // A += c1 X,          B -= (c2 + j c3) X
+  else                                       { c->pol_wa = make_float2(c2, -c3); c->pol_wb = make_float2(c1, 0.f); }    // A += (c2 - j c3) Y, B += c1 Y
+  c->pol_set = true;
+  return LRH_OK;
+}
+int lrh_set_combine_weights(lrh_ctx *c, float wa_re, float wa_im, float wb_re, float wb_im)
+{
+  if (!c) return LRH_EINVAL;
+  if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
+  c->pol_wa = make_float2(wa_re, wa_im); c->pol_wb = make_float2(wb_re, wb_im); c->pol_set = true;
   return LRH_OK;
 }
 int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
 {
   if (!c || !p || !count || batch < 1) return LRH_EINVAL;
   if (!c->N3 || !c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
-  if (c->cfg.blanker_channels != 2 || !c->pol_set) return fail(c, LRH_ESTATE, "lrh_set_pol first");
+  if (!c->pol_set) return fail(c, LRH_ESTATE, "lrh_set_pol / lrh_set_combine_weights first");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
   PolArgs a;
   a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1; a.nm = c->Nm2; a.batch = batch;
-  const float c1 = c->pol[0], c2 = c->pol[1], c3 = c->pol[2];
-  if ((c->cfg.timf1_channel_index & 1) == 0) { a.wa = make_float2(c1, 0.f); a.wb = make_float2(-c2, -c3); }   // A += c1 X,          B -= (c2 + j c3) X
-  else                                       { a.wa = make_float2(c2, -c3); a.wb = make_float2(c1, 0.f); }    // A += (c2 - j c3) Y, B += c1 Y
+  a.wa = c->pol_wa; a.wb = c->pol_wb;
   a.out = c->d_xpol;
   { ProfScope ps(c, "pol"); HIPCHK(c, launch_pol(a, c->cur)); }
   c->pol_batch = batch;
@@ -1331,11 +1339,12 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   hipSetDevice(c->cfg.device);
-  const bool pol = c->cfg.blanker_channels == 2 && c->pol_set;
+  const bool pol = c->pol_set;
   if (pol && c->pol_batch != batch) return fail(c, LRH_ESTATE, "lrh_mix2_pol_begin and the all-reduce come first");
   c->pol_batch = 0;
   Mix2Args a;
-  a.pol = pol ? c->d_xpol + (size_t)(c->cfg.timf1_channel_index & 1) * batch * c->Nm2 : nullptr;
+  const int slot = (c->cfg.blanker_channels == 2 && (c->cfg.timf1_channel_index & 1)) ? 1 : 0;   // B for the second channel of a coupled pair
+  a.pol = pol ? c->d_xpol + (size_t)slot * batch * c->Nm2 : nullptr;
   a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
   a.filt = c->d_bgfilt; a.tw = c->d_twm2; a.scratch = c->d_mix2_scratch; a.nm = c->Nm2;
   Mix1OutArgs o; memset(&o, 0, sizeof o);

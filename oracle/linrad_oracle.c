@@ -35,7 +35,7 @@ struct lro_ctx {
   float *fft1_foldcorr;        /* N1 complex, NULL: no I/Q mirror-image calibration (fft1_calibrate_flag & CALIQ) */
   /* two coupled channels (cfg.blanker_channels = 2): summed power ring the blanker decides on, exchange buffers, and
      what lro_first_noise_blanker leaves for lro_blanker_finish */
-  float *xpol; float pol[3]; int pol_set, pol_batch;   /* LRH_X_POL [2][max_fft3n][Nm2][2]; pg.c1..c3 */
+  float *xpol; float pol_w[4]; int pol_set, pol_batch;   /* this channel's weights (wa_re, wa_im, wb_re, wb_im) */   /* LRH_X_POL [2][max_fft3n][Nm2][2]; pg.c1..c3 */
   float *xbins, *fft2_xypower, *fft2_xysum;   /* LRH_X_BINS [2][max_fft2n][N2][2]; TWOCHAN_POWER rings (fft2.c:1622-1640) */
   float *pwr_sum, *xbuf; float xstat[2]; int x_pbeg, x_count, fin_pending, fin_do_update; float fin_llf;
   float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
@@ -252,7 +252,8 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   if (cfg->blanker_channels == 2) { c->pwr_sum = zal(4 * (size_t)cfg->timf2pow_size); c->xbuf = zal(4 * (size_t)cfg->timf2pow_size); c->x_count = -1;
     c->xbins = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2); c->fft2_xypower = zal(sizeof(float) * 4 * (size_t)cfg->max_fft2n * N2);
     c->fft2_xysum = zal(sizeof(float) * 4 * (size_t)N2);
-    if (cfg->fft3_n) c->xpol = zal(sizeof(float) * 4 * (size_t)cfg->max_fft3n * (1 << cfg->mix2_n)); }
+  }
+  if (cfg->fft3_n) c->xpol = zal(sizeof(float) * 4 * (size_t)cfg->max_fft3n * (1 << cfg->mix2_n));
   c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
@@ -663,6 +664,7 @@ static size_t exchange_cap(const lro_ctx *c, int which)
 }
 int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
 {
+  if (which == LRH_X_POL && ptr) { if (!c->xpol) return LRH_ESTATE; *ptr = c->xpol; return LRH_OK; }
   if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
   if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS && which != LRH_X_POL) return LRH_EINVAL;
   if (which == LRH_X_POL && !c->xpol) return LRH_ESTATE;
@@ -1190,21 +1192,32 @@ int lro_make_fft3_all(lro_ctx *c, lrh_ptrs *p, int batch)
 
 /* two coupled channels, see include/linrad_hip.h: the own channel's share of A = c1 X + (c2 - j c3) Y and
    B = c1 Y - (c2 + j c3) X (mix2.c:340-343, 377-380) for mix2.size bins around fft3_size/2, bin j = fft3_size/2 - size/2 + j */
-int lro_set_pol(lro_ctx *c, float c1, float c2, float c3) { c->pol[0] = c1; c->pol[1] = c2; c->pol[2] = c3; c->pol_set = 1; return LRH_OK; }
+int lro_set_pol(lro_ctx *c, float c1, float c2, float c3)
+{
+  if (c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  if ((c->cfg.timf1_channel_index & 1) == 0) { c->pol_w[0] = c1; c->pol_w[1] = 0; c->pol_w[2] = -c2; c->pol_w[3] = -c3; }
+  else { c->pol_w[0] = c2; c->pol_w[1] = -c3; c->pol_w[2] = c1; c->pol_w[3] = 0; }
+  c->pol_set = 1; return LRH_OK;
+}
+int lro_set_combine_weights(lro_ctx *c, float wa_re, float wa_im, float wb_re, float wb_im)
+{
+  if (!c->xpol) return LRH_ESTATE;
+  c->pol_w[0] = wa_re; c->pol_w[1] = wa_im; c->pol_w[2] = wb_re; c->pol_w[3] = wb_im; c->pol_set = 1; return LRH_OK;
+}
 int lro_mix2_pol_begin(lro_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
 {
-  if (!c->N3 || c->cfg.blanker_channels != 2 || !c->pol_set) return LRH_ESTATE;
+  if (!c->N3 || !c->pol_set) return LRH_ESTATE;
   if (batch < 1 || batch > c->cfg.max_fft3n || !count) return LRH_EINVAL;
-  const int N = c->N3, size = c->Nm2, ch = c->cfg.timf1_channel_index & 1;
-  const float c1 = c->pol[0], c2 = c->pol[1], c3 = c->pol[2];
+  const int N = c->N3, size = c->Nm2;
+  const float war = c->pol_w[0], wai = c->pol_w[1], wbr = c->pol_w[2], wbi = c->pol_w[3];
   float *A = c->xpol, *B = c->xpol + (size_t)batch * 2 * size;
   for (int b = 0; b < batch; b++) {
     const float *f3 = c->fft3 + ((p->fft3_px + b * 2 * N) & (c->cfg.max_fft3n * 2 * N - 1));
     for (int j = 0; j < size; j++) {
       const float re = f3[2 * (N / 2 - size / 2 + j)], im = f3[2 * (N / 2 - size / 2 + j) + 1];
       float *a = A + ((size_t)b * size + j) * 2, *o = B + ((size_t)b * size + j) * 2;
-      if (ch == 0) { a[0] = c1 * re; a[1] = c1 * im; o[0] = -c2 * re + c3 * im; o[1] = -c2 * im - c3 * re; }
-      else { a[0] = c2 * re + c3 * im; a[1] = c2 * im - c3 * re; o[0] = c1 * re; o[1] = c1 * im; }
+      a[0] = war * re - wai * im; a[1] = war * im + wai * re;
+      o[0] = wbr * re - wbi * im; o[1] = wbr * im + wbi * re;
     }
   }
   c->pol_batch = batch;
@@ -1218,7 +1231,7 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
 {
   if (!c->N3) return LRH_ESTATE;
   int N = c->N3, size = c->Nm2, sizhalf = size / 2, nn = 2 * (size - 1), bmask = c->cfg.baseband_size - 1;
-  const int pol = c->cfg.blanker_channels == 2 && c->pol_set;
+  const int pol = c->pol_set;
   if (pol && c->pol_batch != batch) return LRH_ESTATE;      /* lro_mix2_pol_begin + all-reduce come first */
   c->pol_batch = 0;
   for (int b = 0; b < batch; b++) {
@@ -1226,7 +1239,7 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
     const float *f3 = c->fft3;
     int p0 = p->fft3_px + N, k = N / 2;
     if (pol) {        /* the summed A (channel 0) or B (channel 1) stands in for the spectrum; addressed like fft3 around its centre */
-      f3 = c->xpol + ((size_t)(c->cfg.timf1_channel_index & 1) * batch + b) * 2 * size;
+      f3 = c->xpol + ((size_t)(c->cfg.blanker_channels == 2 ? (c->cfg.timf1_channel_index & 1) : 0) * batch + b) * 2 * size;
       p0 = size;
     }
     for (int i = 0; i < sizhalf; i++) { tmp[2 * i] = f3[p0 + 2 * i] * c->bg_filterfunc[k + i]; tmp[2 * i + 1] = f3[p0 + 2 * i + 1] * c->bg_filterfunc[k + i]; }

@@ -1,0 +1,143 @@
+"""Coherent combine of more than two receivers (BASELINE configs[4], phased array: one channel per GPU, A = sum_c w_c X_c over
+the mix2 band as one all-reduce per fft3_mix2 batch).  The reference stops at two channels, so there is nothing to
+pin against: the checks are the properties the step must have -- linearity (the combined baseband equals the weighted sum of
+the single-channel basebands) and the array gain of phase-aligned weights."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from linrad_amd import abi
+from refcases import case_params, lrh_config, make_input, make_liminfo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NCH = 4
+PHASE = [0.0, 0.9, -1.7, 2.4]
+
+
+def _channel_input(d, ch):
+    """the case's signal turned by the channel's sky phase, with the channel's own noise"""
+    iq = make_input(d).astype(np.float64)
+    z = iq[0::2] + 1j * iq[1::2]
+    rng0 = np.random.default_rng(d["seed"])
+    n = z.size
+    noise0 = rng0.normal(0, d["sigma"], n) + 1j * rng0.normal(0, d["sigma"], n)
+    rng = np.random.default_rng(1000 + ch)
+    zc = (z - noise0) * np.exp(1j * PHASE[ch]) + rng.normal(0, d["sigma"], n) + 1j * rng.normal(0, d["sigma"], n)
+    out = np.empty(2 * n, np.int16)
+    out[0::2], out[1::2] = np.clip(np.round(zc.real), -32767, 32767), np.clip(np.round(zc.imag), -32767, 32767)
+    return out
+
+
+def _open(open_fn, d, ch, weights=None):
+    iq = _channel_input(d, ch)
+    rx = open_fn(lrh_config(d, iq, stupid_bln_mode=0))
+    rx.timf1_write(iq)
+    rx.set_liminfo(make_liminfo(d))
+    rx.set_mix1_selfreq(d["fq"])
+    n3 = 1 << d["fft3_n"]
+    rx.set_bg_filterfunc(np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))
+    if weights is not None:
+        rx.set_combine_weights(*weights)
+    return rx
+
+
+def _drive(rxs, d, combine):
+    for _ in range(d["nblk"]):
+        for rx in rxs:
+            rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1), rx.first_noise_blanker()
+        k = rxs[0].fft2_available()
+        for _ in range(k):
+            for rx in rxs:
+                rx.make_fft2(1), rx.fft2_mix1_fixed(1)
+            k3 = rxs[0].fft3_available()
+            if not k3:
+                continue
+            for rx in rxs:
+                rx.make_fft3_all(k3)
+            if combine:
+                cnt = [rx.mix2_pol_begin(k3) for rx in rxs]
+                tot = sum(rx.exchange_read(rx.X_POL, cnt[0]) for rx in rxs)        # the all-reduce, by hand
+                for rx in rxs:
+                    rx.exchange_write(rx.X_POL, tot)
+            for rx in rxs:
+                rx.fft3_mix2(k3)
+
+
+def _check(open_fn, tol):
+    d = case_params("n10_n12_fft3")
+    d["nblk"] = 72
+    # the chain conjugates its input: a sky phase +p arrives in the baseband as -p, so e^{+jp} aligns it
+    w = [np.exp(1j * p) / NCH for p in PHASE]                       # phase-aligning weights: the array's beam on the source
+    w2 = [np.exp(1j * p + 2j * np.pi * c / NCH) / NCH for c, p in enumerate(PHASE)]    # second beam: a null on the source
+    single = [_open(open_fn, d, ch) for ch in range(NCH)]
+    _drive(single, d, combine=False)
+    base = [rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128) for rx in single]
+    comb = [_open(open_fn, d, ch, (w[ch], w2[ch])) for ch in range(NCH)]
+    _drive(comb, d, combine=True)
+    got = [rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128) for rx in comb]
+    want = sum(wc * b for wc, b in zip(w, base))
+    assert np.count_nonzero(want) > 200
+    for g in got:                                                   # every context carries the same sum A
+        assert np.linalg.norm(g - want) <= tol * np.linalg.norm(want)
+    # array gain: the aligned sum keeps the source and averages the noise down; a single channel scaled alike does not
+    used = np.abs(want) > 0
+    assert np.mean(np.abs(want[used]) ** 2) > 0.5 * np.mean(np.abs(base[0][used]) ** 2)
+    null = sum(wc * b for wc, b in zip(w2, base))
+    assert np.mean(np.abs(null[used]) ** 2) < 0.5 * np.mean(np.abs(want[used]) ** 2)
+
+
+def test_oracle_four_channel_coherent_combine():
+    from oracle_binding import open_oracle
+    _check(open_oracle, 2e-6)
+
+
+@pytest.mark.gpu
+def test_hip_four_channel_coherent_combine():
+    from linrad_amd.lib import open_hip
+    _check(open_hip, 2e-5)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from linrad_amd.multichan import coupled_fft3_mix2
+    from oracle_binding import open_oracle
+    import test_multichan_combine as t
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = case_params("n10_n12_fft3")
+    d["nblk"] = 48
+    rx = t._open(open_oracle, d, rank, (np.exp(1j * PHASE[rank]) / world, 0j))
+    for _ in range(d["nblk"]):
+        rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1), rx.first_noise_blanker()
+        for _ in range(rx.fft2_available()):
+            rx.make_fft2(1), rx.fft2_mix1_fixed(1)
+            k3 = rx.fft3_available()
+            if k3:
+                rx.make_fft3_all(k3)
+                coupled_fft3_mix2(rx, k3, dist)
+    out = rx.export(abi.RING_BASEB_RAW)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_three_rank_combine_over_gloo():
+    """world_size 3: the all-reduce of multichan.coupled_fft3_mix2 is not tied to two ranks; every rank ends with the same sum"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.count_nonzero(res[0]) > 100
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
