@@ -345,6 +345,12 @@ int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
 /* ---- host-visible side outputs ---- */
 int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems); /* synchronous */
 int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                                   /* synchronous */
+/* Payload of the NET_RXOUT_TIMF2 multicast (what MAP65 and slave Linrads receive; rxin.c:944-966, float form): for `count`
+   samples from timf2 position timf2_pt (in floats like the reference's pointer, a multiple of 4; wraps) one complex float
+   hg_map65_gain * (weak + hg.map65_strong * strong) each, formed on the device from the planar rings, so 8 bytes per
+   sample cross PCIe instead of 16.  The packet framing (NET_RX_STRUCT header, block numbers, 1392-byte payloads,
+   globdef.h:1283-1294) stays with the host's network thread.  Synchronous. */
+int lrh_export_timf2_net(lrh_ctx *ctx, float *dst, int timf2_pt, int count, float map65_gain, float map65_strong);
 /* same span, device-to-device into a caller-owned device buffer (e.g. the RCCL exchange buffer of the
    cross-channel power sum, fft1.c:4138); synchronous on the context stream */
 int lrh_export_device(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);

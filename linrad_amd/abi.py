@@ -191,6 +191,7 @@ class StageAPI:
         self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
         self._proto("export", [vp, C.c_int, vp, C.c_size_t, C.c_size_t])
         self._proto("get_blanker_state", [vp, C.POINTER(LrhBlankerState)])
+        self._proto("export_timf2_net", [vp, fp, C.c_int, C.c_int, C.c_float, C.c_float])
         self.ctx = vp()
         rc = self._f("open")(C.byref(cfg), C.byref(self.ctx))
         if rc != 0:
@@ -454,6 +455,12 @@ class StageAPI:
             count = self.ring_size(ring) - offset
         out = np.zeros(count, _RING_DTYPE.get(ring, np.float32))
         self._chk(self._f("export")(self.ctx, ring, out.ctypes.data_as(C.c_void_p), offset, count), "export")
+        return out
+
+    def export_timf2_net(self, timf2_pt, count, map65_gain=1.0, map65_strong=1.0):
+        """NET_RXOUT_TIMF2 payload (rxin.c:944-966): gain * (weak + strong_scale * strong) as `count` complex floats"""
+        out = np.empty(2 * count, np.float32)
+        self._chk(self._f("export_timf2_net")(self.ctx, self._fptr(out), int(timf2_pt), int(count), float(map65_gain), float(map65_strong)), "export_timf2_net")
         return out
 
     def blanker_state(self):

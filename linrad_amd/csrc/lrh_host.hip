@@ -35,6 +35,7 @@ hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st);
 hipError_t launch_xypower(const XyArgs &a, hipStream_t st);
 hipError_t launch_pol(const PolArgs &a, hipStream_t st);
 hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
+hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
@@ -81,6 +82,7 @@ struct lrh_ctx {
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
+  float2 *d_net = nullptr; size_t net_cap = 0;      // staging of lrh_export_timf2_net
   float2 *d_xpol = nullptr; float2 pol_wa = {1.f, 0.f}, pol_wb = {0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
@@ -301,6 +303,7 @@ void lrh_close(lrh_ctx *c)
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->d_pack18) hipFree(c->d_pack18);
+  if (c->d_net) hipFree(c->d_net);
   if (c->d_foldcorr) hipFree(c->d_foldcorr);
   if (c->d_unitcorr) hipFree(c->d_unitcorr);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
@@ -685,6 +688,7 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
   if (!packed_bytes) return LRH_OK;
   if ((size_t)packed_bytes > c->pack18_cap) {              // staging buffer for the packed bytes, grown on demand
     if (c->d_pack18) hipFree(c->d_pack18);
+  if (c->d_net) hipFree(c->d_net);
     c->d_pack18 = nullptr; c->pack18_cap = 0;
     if (hipMalloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(packed18 staging)");
     c->pack18_cap = packed_bytes;
@@ -1628,6 +1632,22 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
   return LRH_OK;
 }
 
+int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float gain, float strong)
+{
+  if (c) hipSetDevice(c->cfg.device);
+  if (!c || !dst || count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
+  if (!count) return LRH_OK;
+  if ((size_t)count > c->net_cap) {
+    if (c->d_net) hipFree(c->d_net);
+    c->d_net = nullptr; c->net_cap = 0;
+    if (hipMalloc((void **)&c->d_net, (size_t)count * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(timf2 net staging)");
+    c->net_cap = count;
+  }
+  HIPCHK(c, launch_timf2_net(c->d_timf2w, c->d_timf2s, c->timf2pow_mask, (timf2_pt & c->timf2_mask) / 4, count, gain, strong, c->d_net, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dst, c->d_net, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
 int lrh_sync(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); return LRH_OK; }
 
 int lrh_timer_start(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }

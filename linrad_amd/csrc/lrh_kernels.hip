@@ -174,6 +174,19 @@ __global__ __launch_bounds__(256) void k_realsplit(RealSplitArgs a)
     out[k] = cmul(zm, a.filtercorr[k]);
   }
 }
+// NET_RXOUT_TIMF2 payload, float form (rxin.c:949-956): gain * (weak + strong_scale * strong) per sample
+__global__ __launch_bounds__(256) void k_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float2 a = w[(first + i) & mask], b = s[(first + i) & mask];
+  dst[i] = make_float2(gain * (a.x + strong * b.x), gain * (a.y + strong * b.y));
+}
+hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_timf2_net, dim3((count + 255) / 256), dim3(256), 0, st, w, s, mask, first, count, gain, strong, dst);
+  return hipGetLastError();
+}
 hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st)
 {
   hipLaunchKernelGGL(k_realsplit, dim3((a.n / 2 + 255) / 256, batch), dim3(256), 0, st, a);

@@ -1322,3 +1322,16 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
 }
 
 int lro_get_blanker_state(lro_ctx *c, lrh_blanker_state *st) { *st = c->bs; return LRH_OK; }
+
+/* NET_RXOUT_TIMF2 payload, float form: rxin.c:949-956 with twice_rxchan = 2 */
+int lro_export_timf2_net(lro_ctx *c, float *dst, int timf2_pt, int count, float gain, float strong)
+{
+  if (count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
+  int pt = timf2_pt & c->timf2_mask;
+  for (int i = 0; i < count; i++) {
+    const float *zb = c->timf2_float + pt;
+    for (int nn = 0; nn < 2; nn++) dst[2 * i + nn] = gain * (zb[nn] + strong * zb[2 + nn]);
+    pt = (pt + 4) & c->timf2_mask;
+  }
+  return LRH_OK;
+}

@@ -150,3 +150,24 @@ def test_async_producer_write_is_ordered_before_fft1():
     rx.host_unregister(host_a)
     assert p_after.fft1_pa != 0
     assert np.array_equal(out_a, ref[0]) and np.array_equal(out_b, ref[1]) and not np.array_equal(ref[0], ref[1])
+
+
+def test_timf2_network_payload():
+    """NET_RXOUT_TIMF2 payload (what MAP65 / slave Linrads receive, rxin.c:944-966): gain * (weak + strong_scale * strong) per
+    sample, formed on the device from the planar rings; against the oracle's restatement and the formula on the exported ring,
+    across the ring wrap."""
+    from linrad_amd import abi
+    g = load_golden("n8_n10")
+    res = []
+    for fn in (_open_hip, _open_oracle):
+        out = run_case(fn, "n8_n10", golden=g)
+        rx = out["api"]
+        size = 4 * rx.cfg.timf2pow_size
+        pt = (size - 4 * 700) % size                               # 700 samples before the wrap, 1500 in all
+        net = rx.export_timf2_net(pt, 1500, 0.5, 0.25).reshape(-1, 2)
+        t = rx.export(abi.RING_TIMF2_FLOAT).reshape(-1, 4)
+        idx = (pt // 4 + np.arange(1500)) % rx.cfg.timf2pow_size
+        want = np.float32(0.5) * (t[idx, :2] + np.float32(0.25) * t[idx, 2:])
+        assert np.abs(want).max() > 10 and np.abs(net - want).max() <= 1e-6 * np.abs(want).max()
+        res.append(net)
+    assert relerr(res[0], res[1]) < 1e-5

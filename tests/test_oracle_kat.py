@@ -47,3 +47,16 @@ def test_forward_matches_numpy():
         assert np.linalg.norm(_fft(x, n) - ref) / np.linalg.norm(ref) < 5e-7
         refb = np.fft.ifft(x.astype(np.complex128)) * (1 << n)
         assert np.linalg.norm(_fft(x, n, False) - refb) / np.linalg.norm(refb) < 5e-7
+
+
+def test_timf2_network_payload_formula():
+    """NET_RXOUT_TIMF2 payload of the oracle = rxin.c:949-956 on its own timf2 ring"""
+    import numpy as np
+    from linrad_amd import abi
+    from oracle_binding import open_oracle
+    from paritylib import load_golden, run_case
+    g = load_golden("n8_n10")
+    rx = run_case(open_oracle, "n8_n10", golden=g)["api"]
+    net = rx.export_timf2_net(4 * 100, 1000, 2.0, 0.5).reshape(-1, 2)
+    t = rx.export(abi.RING_TIMF2_FLOAT).reshape(-1, 4)[100:1100]
+    assert np.array_equal(net, np.float32(2.0) * (t[:, :2] + np.float32(0.5) * t[:, 2:]))
