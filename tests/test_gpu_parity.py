@@ -171,3 +171,46 @@ def test_timf2_network_payload():
         assert np.abs(want).max() > 10 and np.abs(net - want).max() <= 1e-6 * np.abs(want).max()
         res.append(net)
     assert relerr(res[0], res[1]) < 1e-5
+
+
+def test_error_behaviour_and_ragged_calls():
+    """Return codes of calls out of order or out of range (LRH_EINVAL / LRH_ESTATE, the caller maps them to lirerr), and a
+    ragged call pattern (block count not a multiple of the batch, single blocks in between) against the oracle."""
+    from linrad_amd import abi
+    from linrad_amd.abi import LrhError
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config, strong_liminfo
+    from oracle_binding import open_oracle
+    cfg = chain_config(fft1_n=11, fft2_n=10, batch=8)
+    s = synth_defaults(1 << cfg.fft1_n, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    outs = []
+    for fn in (open_hip, open_oracle):
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
+        rx.set_mix1_selfreq(300.3)
+        for nb in (37, 1, 8, 5):                                   # 51 blocks in ragged calls
+            rx.wideband_dsp(nb, 8)
+        outs.append((rx.export(abi.RING_FFT1_SUMSQ), rx.export(abi.RING_TIMF2_PWR), rx.export(abi.RING_FFT2_FLOAT), rx.export(abi.RING_TIMF3_FLOAT), rx.p.as_dict()))
+    ints = [k for k, v in outs[0][4].items() if isinstance(v, int)]
+    assert {k: outs[0][4][k] for k in ints} == {k: outs[1][4][k] for k in ints}
+    for i, (a, b) in enumerate(zip(outs[0][:4], outs[1][:4])):
+        assert relerr(a, b) < (1e-4 if i == 3 else 2e-5), i           # timf3: a weak band on the float32 floor of the wide spectrum
+    rx = open_hip(cfg)
+    for call, code in ((lambda: rx.fft1_b(9), abi.LRH_EINVAL),                       # batch > max_batch
+                       (lambda: rx.make_fft2(cfg.max_fft2n + 1), abi.LRH_EINVAL),
+                       (lambda: rx.fft2_xy_begin(rx.ptrs_copy(), 1), abi.LRH_ESTATE),  # not one of two coupled channels
+                       (lambda: rx.blanker_begin(), abi.LRH_ESTATE),
+                       (lambda: rx.make_fft3_all(1), abi.LRH_ESTATE),                  # fft3 not configured
+                       (lambda: rx.set_combine_weights(1.0), abi.LRH_ESTATE),
+                       (lambda: rx.export(abi.RING_FFT2_XYSUM), abi.LRH_ESTATE),
+                       (lambda: rx.export(abi.RING_FFT1_SLOWSUM, 0, (1 << cfg.fft1_n) + 1), abi.LRH_EINVAL)):
+        with pytest.raises((LrhError, RuntimeError), match=f"rc={code}"):
+            call()
+    assert rx.export(abi.RING_FFT1_SLOWSUM, 0, 0).size == 0
+    creal = chain_config(fft1_n=11, fft2_n=10, batch=8)
+    creal.timf1_real_input = 1
+    rr = open_hip(creal)
+    with pytest.raises((LrhError, RuntimeError), match=f"rc={abi.LRH_ESTATE}"):
+        rr.set_foldcorr(np.zeros(2 << creal.fft1_n, np.float32))    # no I/Q image with real samples
