@@ -162,6 +162,10 @@ def main():
     ap.add_argument("--stream-host", action="store_true",
                     help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
                          "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")
+    ap.add_argument("--coupled", action="store_true",
+                    help="BASELINE configs[3]: ranks 0/1 are the two channels of a polarisation pair (ui.rx_rf_channels = 2 sharded): "
+                         "coupled blanker (2 all-reduces per call), fft2 cross products (all-gather), fft3 + polarisation transform "
+                         "in mix2 (all-reduce), stage calls driven from linrad_amd.multichan.run_coupled; not the headline metric")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -187,6 +191,12 @@ def main():
     cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
     if args.real_input:
         cfg.timf1_real_input = 1
+    if args.coupled:
+        if world > 2:
+            raise SystemExit("--coupled: a polarisation pair has two channels (Linrad's maximum, SURVEY F4)")
+        cfg.blanker_channels, cfg.timf1_channel_index = 2, rank
+        cfg.fft3_n, cfg.fft3_sinpow, cfg.mix2_n, cfg.max_fft3n, cfg.baseband_size = 10, 2, 8, 64, 1 << 16
+        cfg.timf3_size = max(cfg.timf3_size, 1 << 16)
     N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
     samples_per_step = args.batch * args.rounds * M1
@@ -210,7 +220,21 @@ def main():
     step_bytes = args.batch * args.rounds * M1 * 4
     wr = [0]
 
+    if args.coupled:
+        from linrad_amd.multichan import run_coupled
+        if dist is None:                                    # a one-rank group: the collectives are there, nothing to fetch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            use_dist = True
+        rx.set_pol(0.8, 0.36, -0.48)
+        dev = torch.device("cuda", local_rank)
+
     def step():
+        if args.coupled:
+            run_coupled(rx, args.batch * args.rounds, args.batch, dist, device=dev, xy=True, pol=True)
+            return
         if host_ring is not None:
             nb = min(step_bytes, cfg.timf1_bytes)
             off = wr[0] % cfg.timf1_bytes
@@ -262,7 +286,7 @@ def main():
     # ---- per-kernel timing with HIP events on the context stream (rank 0), same steps
     roof = None
     stages = {}
-    if rank == 0:
+    if rank == 0 and not args.coupled:
         rx.profile_enable(True)
         rx.wideband_dsp(args.batch, args.batch)                # first serial pass after the two-stream run: discarded
         rx.sync()
@@ -327,6 +351,7 @@ def main():
                                    f"{args.rounds} x {args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
                        "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "rounds_per_step": args.rounds, "channels": world,
                        "parallelism": f"1 RF channel per GPU x{world}"},
+            "mode": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan" if args.coupled else "lrh_wideband_dsp",
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",
             "event_ms_per_step": round(ev_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
             "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4),
