@@ -39,19 +39,28 @@ class _DevSpan:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def _lrh_stream(rx, device):
+    """the receiver's own HIP stream as a torch stream: a collective issued under it is ordered between the stage calls on the
+    device (RCCL's stream waits for it and it waits for RCCL), with no host wait on either side"""
+    import torch
+    st = getattr(rx, "_torch_stream", None)
+    if st is None:
+        st = rx._torch_stream = torch.cuda.ExternalStream(rx.stream_handle(), device=device)
+    return st
+
+
 def exchange_sum(rx, which, count, dist, device=None):
     """all-reduce(sum) of one exchange buffer of a StageAPI receiver across the channel ranks.
 
-    HIP receiver: in place on the device buffer (`lrh_exchange_ptr`; the collective runs on torch's current stream, so
-    the receiver is synced before and after).  CPU oracle (gloo tests): through host memory."""
+    HIP receiver: in place on the device buffer (`lrh_exchange_ptr`), stream-ordered on the receiver's own stream.
+    CPU oracle (gloo tests): through host memory."""
     import torch
     if count == 0:
         return
     if device is not None:
-        rx.sync()
         t = torch.as_tensor(_DevSpan(rx.exchange_ptr(which), count), device=device)
-        dist.all_reduce(t)
-        torch.cuda.synchronize(device)
+        with torch.cuda.stream(_lrh_stream(rx, device)):
+            dist.all_reduce(t)
     else:
         t = torch.from_numpy(rx.exchange_read(which, count))
         dist.all_reduce(t)
@@ -68,10 +77,9 @@ def exchange_gather(rx, which, count, dist, device=None):
         return
     assert world == 2, "Linrad has at most two RF channels (SURVEY F4)"
     if device is not None:
-        rx.sync()
         t = torch.as_tensor(_DevSpan(rx.exchange_ptr(which), 2 * count), device=device)
-        dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
-        torch.cuda.synchronize(device)
+        with torch.cuda.stream(_lrh_stream(rx, device)):
+            dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
     else:
         own = torch.from_numpy(rx.exchange_read(which, count, rank * count))
         slots = [torch.empty_like(own), torch.empty_like(own)]
