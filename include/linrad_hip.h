@@ -109,7 +109,9 @@ typedef struct lrh_config {
   int timf1_real_input;         /* 1: real samples (ui.rx_input_mode without IQ_DATA, "normal audio" / direct-sampling
                                    hardware): one transform takes 2*fft1_size reals and yields fft1_size bins 0..fs/2, the
                                    reference's default real version fft1_reherm_dit_one (fft1_re.c:32-131, fft1var.c:45,75);
-                                   one channel per frame, int16 or int32; timf1p_px advances 4*M1 bytes per block like I/Q */
+                                   int16 or int32; timf1p_px advances 4*M1 bytes per block and channel like I/Q; two real
+                                   channels per frame {a_k, b_k} (fft1_reherm_dit_two, fft1_re.c:133) with
+                                   timf1_frame_channels = 2, one per context                                         */
   int reserved[2];
 } lrh_config;
 

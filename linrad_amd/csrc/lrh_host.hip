@@ -322,7 +322,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   *out = nullptr;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
-  if (cfg->timf1_real_input && (cfg->timf1_frame_channels > 1 || cfg->sample_shift != 0)) return LRH_EINVAL;   // one real channel per frame (fft1_reherm_dit_one)
+  if (cfg->timf1_real_input && (cfg->timf1_frame_channels > 2 || cfg->sample_shift != 0)) return LRH_EINVAL;   // fft1_reherm_dit_one / _two: one or two real channels per frame
   if (cfg->timf1_frame_channels > 1 && (!ispow2(cfg->timf1_frame_channels) || cfg->timf1_channel_index < 0 || cfg->timf1_channel_index >= cfg->timf1_frame_channels)) return LRH_EINVAL;
   if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||

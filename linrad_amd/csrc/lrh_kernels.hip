@@ -80,6 +80,15 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
 #pragma unroll
       for (int s = 0; s < R0; s++) {
         const int n = p0 + (tid + m * T) + s * (N / R0);
+        if constexpr (REAL) {
+          if (a.chan_count > 1) {                          // frames {a_k, b_k, ..}: this channel's reals 2n and 2n+1 (fft1_re.c:146-156)
+            const Comp *c = (const Comp *)a.timf1;
+            const int cm = 2 * a.ring_mask + 1;
+            nxt[m * R0 + s].x = c[((2 * n) * a.chan_count + a.chan_index) & cm];
+            nxt[m * R0 + s].y = c[((2 * n + 1) * a.chan_count + a.chan_index) & cm];
+            continue;
+          }
+        }
         if constexpr (!SKEW) nxt[m * R0 + s] = ((const Raw *)a.timf1)[(n * a.chan_count + a.chan_index) & a.ring_mask];
         else {
           const Comp *c = (const Comp *)a.timf1;

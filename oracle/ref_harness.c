@@ -152,7 +152,6 @@ int main(int argc, char **argv)
   memset(&ui, 0, sizeof(ui));
   if (C != 1 && C != 2) { fprintf(stderr, "channels must be 1 or 2\n"); return 2; }
   ui.rx_input_mode = (realin ? 0 : IQ_DATA) | (dword ? DWORD_INPUT : 0) | (C == 2 ? TWO_CHANNELS : 0); ui.rx_rf_channels = C; ui.rx_ad_channels = (realin ? 1 : 2) * C;
-  if (realin && C != 1) { fprintf(stderr, "real input: one channel only\n"); return 2; }
   pg_ch2_c1 = (float)ch2_c1; pg_ch2_c2 = (float)ch2_c2;
   ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */

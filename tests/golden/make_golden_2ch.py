@@ -26,7 +26,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    for name in ("twochan_n10", "twochan_n9_sin3"):
+    for name in ("twochan_n10", "twochan_n9_sin3", "twochan_real_n9"):
         d, frames, lim = twochan_case(name)
         with tempfile.TemporaryDirectory() as td:
             fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
@@ -43,9 +43,11 @@ def main():
             out["bln_" + k] = refb[k]
         out["frames"], out["liminfo"] = frames, lim
         path = os.path.join(HERE, f"{name}.npz")
-        if "--chain-only" not in sys.argv:
+        if "--chain-only" not in sys.argv and ("--only" not in sys.argv or name in sys.argv):
             np.savez_compressed(path, **out)
             print(name, os.path.getsize(path) // 1024, "KiB")
+        if d["real"]:
+            continue
         # third run: the whole two-channel chain (two-channel first_noise_blanker, make_fft2 with fft2_xypower / fft2_xysum
         # and the polarisation-independent waterfall line, fft2_mix1_fixed); input = the same frames
         d, frames, lim = twochan_case(name, chain=True)

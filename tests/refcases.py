@@ -226,6 +226,9 @@ TWOCHAN = {
     "twochan_n10": dict(base="n10_n12", nblk=40, seed2=112, sky_phase=0.7, ch2_c1=float(np.float32(np.cos(0.5))),
                         ch2_c2=float(np.float32(np.sin(0.5))),
                         chain=dict(nblk=72, fft3_n=6, mix2_n=4, max_fft3n=8, mix2=1, pol=(0.8, 0.36, -0.48))),
+    # two real channels per frame {a_k, b_k} (fft1_reherm_dit_two, fft1_re.c:133): channel 1 = the carriers and pulses at
+    # 0.7 of channel 0's amplitude, independent noise
+    "twochan_real_n9": dict(base="n9_n11_real", nblk=40, seed2=115, sky_phase=0.0, ch2_c1=1.0, ch2_c2=0.0),
     "twochan_n9_sin3": dict(base="n9_n11_sin3", nblk=32, seed2=114, sky_phase=-1.1, ch2_c1=1.0, ch2_c2=0.0,
                             chain=dict(nblk=56, fft3_n=6, mix2_n=4, max_fft3n=8, mix2=1, pol=(0.6, -0.64, 0.48))),
 }
@@ -240,6 +243,15 @@ def twochan_case(name, chain=False):
     d.update(nblk=t["nblk"], ch2_c1=t["ch2_c1"], ch2_c2=t["ch2_c2"], fq=d["fq"] if chain else -1.0, second_fft=1)
     if chain:        # longer run, fft3 + fft3_mix2 behind mix1 with the polarisation transform pg.c1..c3 = pol
         d.update(blockpower_block=0, **t["chain"])
+    if d["real"]:
+        x0 = make_input(d).astype(np.float64)
+        rng0 = np.random.default_rng(d["seed"])
+        noise0 = rng0.normal(0, d["sigma"], x0.size)                                    # the first draws of make_input
+        rng = np.random.default_rng(t["seed2"])
+        x1 = 0.7 * (x0 - noise0) + rng.normal(0, d["sigma"], x0.size)
+        frames = np.empty(2 * x0.size, np.int16)
+        frames[0::2], frames[1::2] = x0, np.clip(np.round(x1), -32767, 32767)
+        return d, frames, make_liminfo(d)
     x0 = make_input(d).astype(np.float64)
     z0 = x0[0::2] + 1j * x0[1::2]
     rng0 = np.random.default_rng(d["seed"])

@@ -47,7 +47,7 @@ def test_open_rejects_bad_config_and_missing_gpu():
     assert lib.lrh_open(C.byref(bad), C.byref(ctx)) == abi.LRH_EINVAL
     bad = abi.default_config(10, 12, timf2pow_size=1000)       # not a power of two
     assert lib.lrh_open(C.byref(bad), C.byref(ctx)) == abi.LRH_EINVAL
-    for kw in (dict(fft1_n=15), dict(timf1_real_input=1, sample_shift=1), dict(timf1_real_input=1, timf1_frame_channels=2),
+    for kw in (dict(fft1_n=15), dict(timf1_real_input=1, sample_shift=1), dict(timf1_real_input=1, timf1_frame_channels=4, timf1_channel_index=1),
                dict(timf1_frame_channels=2, timf1_channel_index=2), dict(max_batch=0), dict(fft3_n=5, mix2_n=3)):
         bad = abi.default_config(kw.pop("fft1_n", 10), 12, **kw)   # sizes and modes the header says are not built / not valid
         assert lib.lrh_open(C.byref(bad), C.byref(ctx)) == abi.LRH_EINVAL, kw

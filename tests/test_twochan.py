@@ -27,7 +27,8 @@ def _run(open_fn, name, frames_mode):
     fr = frames.reshape(-1, 4)
     out = []
     for ch in (0, 1):
-        iq = np.ascontiguousarray(fr[:, 2 * ch:2 * ch + 2]).ravel()
+        # the channel's own stream: I/Q pairs out of frames {I0,Q0,I1,Q1}, or reals out of frames {a,b} (fft1_reherm_dit_two)
+        iq = np.ascontiguousarray(frames[ch::2]) if d["real"] else np.ascontiguousarray(fr[:, 2 * ch:2 * ch + 2]).ravel()
         cfg = lrh_config(d, iq)
         if frames_mode:                       # the HIP path reads its channel out of the interleaved frames
             cfg.timf1_bytes *= 2
@@ -66,7 +67,7 @@ def _check(d, g, out, tol):
     assert _rel((out[0]["pwr"] + out[1]["pwr"])[:pa], g["timf2_pwr_float"][:pa]) < tol
 
 
-@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"])
 def test_oracle_channels_match_two_channel_reference(name):
     from oracle_binding import open_oracle
     d, g, out = _run(open_oracle, name, frames_mode=False)
@@ -74,7 +75,7 @@ def test_oracle_channels_match_two_channel_reference(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"])
 def test_hip_contexts_match_two_channel_reference(name):
     from linrad_amd.lib import open_hip
     d, g, out = _run(open_hip, name, frames_mode=True)
