@@ -298,6 +298,10 @@ def main():
             ms, n = rx.profile_get(k)
             if n:
                 stages[k] = {"ms_total": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 2)}
+                if k in ALG_BYTES:                         # stand-alone stage rates (secondary metric): one batch per launch
+                    per = ALG_BYTES[k] + (ALG_BYTES["sumsq"] if k == "timf2" else 0.0)
+                    stages[k]["Msamples_per_s"] = round(args.batch * M1 / (ms / n * 1e-3) / 1e6, 1)
+                    stages[k]["alg_GBps"] = round(stages[k]["Msamples_per_s"] * per / 1e3, 1)
         rx.profile_enable(False)
         dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
         nsteps_prof = stages["fft1"]["launches"]
