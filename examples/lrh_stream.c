@@ -45,15 +45,24 @@ int main(int argc, char **argv)
   lrh_set_mix1_selfreq(rx, 0.31 * N2 + 0.3);
 
   const long total = (long)(seconds * fs);
-  const int chunk = 4 * M1;                     /* what one "soundcard read" delivers */
-  int16_t *buf = malloc(sizeof(int16_t) * 2 * chunk);
+  int chunk = 4 * M1;                           /* what one "soundcard read" delivers */
+  while ((cfg.timf1_bytes % (chunk * 4)) != 0) chunk /= 2;      /* a read never straddles the end of the ring here */
+  /* Linrad's timf1 arena (buf.c:744-770): the input thread writes into it, the device ring mirrors it.  Page-locked once,
+     like a maintainer would do after get_buffers(); the shim never frees it. */
+  char *timf1_char = NULL;
+  if (posix_memalign((void **)&timf1_char, 4096, cfg.timf1_bytes)) return 2;
+  memset(timf1_char, 0, cfg.timf1_bytes);
+  if ((rc = lrh_host_register(rx, timf1_char, cfg.timf1_bytes))) { fprintf(stderr, "lrh_host_register: %d\n", rc); return 2; }
   int timf1p_pa = 0;                            /* producer pointer, bytes */
   long done = 0, nfft2 = 0;
   double t0 = now();
   while (done < total) {
     /* ---- input thread: finish_rx_read ---- */
-    lrh_synth_iq(&sig, done, chunk, buf);
-    lrh_timf1_write(rx, buf, timf1p_pa, chunk * 4);
+    /* back-pressure once per lap: every copy of the previous lap has left the arena before it is written again
+       (a real producer also checks its distance to timf1p_px like rxin.c does) */
+    if (timf1p_pa == 0 && (rc = lrh_timf1_write_wait(rx))) goto fail;
+    lrh_synth_iq(&sig, done, chunk, (int16_t *)(timf1_char + timf1p_pa));
+    if ((rc = lrh_timf1_write_async(rx, timf1_char + timf1p_pa, timf1p_pa, chunk * 4))) goto fail;   /* no host wait: the next fft1 waits on the device */
     timf1p_pa = (timf1p_pa + chunk * 4) & (cfg.timf1_bytes - 1);
     done += chunk;
     /* ---- wideband_dsp: one block at a time while a full block is available (wcw.c:940-1047) ---- */
@@ -77,7 +86,9 @@ int main(int argc, char **argv)
          N1, N2, M1, M2, nm, done, dt, done / dt / 1e6, nfft2);
   printf("blanker: noise floor %d limit %u cleared %.2f %%; timf3[0..3] = %g %g %g %g\n", bs.timf2_noise_floor, bs.stupid_bln_limit,
          bs.stupid_blanker_rate, t3[0], t3[1], t3[2], t3[3]);
-  lrh_close(rx); free(buf); free(lim);
+  lrh_timf1_write_wait(rx);
+  lrh_host_unregister(rx, timf1_char);          /* before the arena is freed (free_buffers, buf.c:2105) */
+  lrh_close(rx); free(timf1_char); free(lim);
   return 0;
 fail:
   fprintf(stderr, "stage failed rc=%d: %s\n", rc, lrh_last_error(rx));
