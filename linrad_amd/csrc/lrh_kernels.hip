@@ -1729,8 +1729,8 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
   if (a.mode != 0) {
     a.npartials = ntiles; a.nremoved = (nwords + 255) / 256;
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
-    if (a.clr1 == 0 && a.clr2 == 1 && a.tiles) {         // long-run replay: three launches that return at once unless a lane gave up
+    if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);   // calibrated blanker only
+    else {         // long-run replay: three launches that return at once unless a lane gave up
       hipLaunchKernelGGL(k_blank_runs_pre, dim3(ntiles), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_blank_runs_done, dim3(1), dim3(1), 0, st, a);
