@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 // too when the run's maximum is 34 dB over the noise.  The only long-range quantity is that maximum, so the replay is a
 // segmented max: chunk summaries in LDS, tile summaries in global memory (k_blank_runs_pre), then every lane decides its
 // own 64 samples with the incoming (in run?, maximum so far) looked up backwards (k_blank_runs).  Both kernels return at
-// once unless need_slow is set; with calibration (clr2 > 1) guards chain runs together and k_blank_serial stays.
+// once unless need_slow is set (k_blank_update, the last kernel of the call, takes the flag down); with calibration (clr2 > 1) guards chain runs together and k_blank_serial stays.
 __device__ __forceinline__ bool bln_runs_mode(const BlankArgs &a) { return a.clr1 == 0 && a.clr2 == 1; }
 
 struct BlnChunk { float cmax, smax; int any_below, last_above, empty; };
@@ -777,11 +777,6 @@ __global__ __launch_bounds__(256) void k_blank_runs(BlankArgs a)
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.st->call_cleared, cnt);
 }
-__global__ void k_blank_runs_done(BlankArgs a)
-{
-  if (!a.st->need_slow || !bln_runs_mode(a)) return;
-  a.st->need_slow = 0; a.st->slow_calls++;
-}
 
 // exact serial replay for the calibrated blanker (clr2 > 1), only when a lane of k_blank_scan could not find a clean restart point
 __global__ void k_blank_serial(BlankArgs a)
@@ -871,6 +866,7 @@ __global__ void k_blank_update(BlankArgs a)
   if (threadIdx.x != 0) return;
   tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   BlankState *s = a.st;
+  if (s->need_slow) { s->need_slow = 0; s->slow_calls++; }   // the long-run replay served this call (k_blank_serial resets the flag itself)
   float t1;
   if (a.phase == 2) {                                    // second half of a coupled call: both channels' means have arrived
     s->despiked_pwrinc[0] += a.xstat[0];                  // blank1.c:1538-1541
@@ -1730,10 +1726,9 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
     a.npartials = ntiles; a.nremoved = (nwords + 255) / 256;
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
     if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);   // calibrated blanker only
-    else {         // long-run replay: three launches that return at once unless a lane gave up
+    else {         // long-run replay: two launches that return at once unless a lane gave up
       hipLaunchKernelGGL(k_blank_runs_pre, dim3(ntiles), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_blank_runs_done, dim3(1), dim3(1), 0, st, a);
+      hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);   // k_blank_update takes the flag down
     }
     hipLaunchKernelGGL(k_blank_apply, dim3(a.nremoved), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
     if (a.own) {                                         // per-channel statistic from the own ring after clearing
