@@ -87,6 +87,7 @@ struct lrh_ctx {
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
+  bool pipeline_forced = false;      // LRH_PIPELINE given: no automatic choice by batch size
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
   // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
   // their device work here; lrh_wideband_dsp replays it later, on the stream it chooses.
@@ -372,7 +373,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
   c->cur = c->stream;
   for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
-  if (const char *e2 = getenv("LRH_PIPELINE")) c->pipeline = atoi(e2);
+  if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
@@ -1425,7 +1426,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
                      ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;
                                     c->host_cpu_ms_dsp += thread_cpu_ms() - cpu0; } } host_timer{c};
   int rc;
-  const bool piped = c->pipeline && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
+  // Small rounds are bound by the host's launches (~100 us per round), not by the kernels: the plain serial order has the
+  // fewest stream operations and wins there (Msamples/s serial / lagged, fft1_size 16384: 82 / 80 at 1 block per round,
+  // 2170 / 1990 at 32, 9420 / 9100 at 256); the two-stream schedules pay off from ~3 M samples per round (15200 / 17000 at 512).
+  const bool small_rounds = !c->pipeline_forced && (long)batch * c->M1 < (3L << 20);
+  const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
   // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
   const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); } } fuse_guard{c};
