@@ -77,7 +77,8 @@ struct lrh_ctx {
   // picks them up, the join of split groups and the slow average follow from ss_queue
   bool fuse_sumsq = true;            // LRH_FUSE_SUMSQ=0: separate k_sumsq pass
   bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
-  float *d_ss_part = nullptr;
+  float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
+                                                                             // round k (side stream) may still read while timf2(k+1) writes
   std::vector<std::function<int(lrh_ctx *)>> ss_queue;
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
@@ -86,6 +87,8 @@ struct lrh_ctx {
   float2 *d_xpol = nullptr; float2 pol_wa = {1.f, 0.f}, pol_wb = {0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
+  int dbg_stamp = 0, dbg_bln = 0;    // LRH_STAMP / LRH_BLN_DEBUG, read once in lrh_open
+  unsigned long long *d_stamps = nullptr;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   bool pipeline_forced = false;      // LRH_PIPELINE given: no automatic choice by batch size
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
@@ -304,6 +307,7 @@ void lrh_close(lrh_ctx *c)
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->d_pack18) hipFree(c->d_pack18);
+  if (c->d_stamps) hipFree(c->d_stamps);
   if (c->d_net) hipFree(c->d_net);
   if (c->d_foldcorr) hipFree(c->d_foldcorr);
   if (c->d_unitcorr) hipFree(c->d_unitcorr);
@@ -370,12 +374,14 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
-  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { delete c; return LRH_EDEVICE; }
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
   c->cur = c->stream;
   for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
+  if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
+  if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
   hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking);
   hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_fft1_read, hipEventDisableTiming);
@@ -485,7 +491,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
-  if (cfg->second_fft_enable && c->timf2_mode == 1 && timf2_grid(cfg->fft1_n, cfg->max_batch) > 0) A(dev_alloc(c, &c->d_ss_part, (size_t)2 * timf2_grid(cfg->fft1_n, cfg->max_batch) * N1));
+  if (cfg->second_fft_enable && c->timf2_mode == 1 && timf2_grid(cfg->fft1_n, cfg->max_batch) > 0) { c->ss_part_stride = (size_t)2 * timf2_grid(cfg->fft1_n, cfg->max_batch) * N1; A(dev_alloc(c, &c->d_ss_part, 2 * c->ss_part_stride)); }
   if (cfg->blanker_channels == 2) { A(dev_alloc(c, &c->d_pwr_sum, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xbuf, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xstat, 2));
     A(dev_alloc(c, &c->d_xbins, (size_t)2 * cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_xypower, (size_t)cfg->max_fft2n * N2));
     A(dev_alloc(c, &c->d_xysum, N2)); A(dev_alloc(c, &c->d_xysum_alt, N2)); }
@@ -689,7 +695,6 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
   if (!packed_bytes) return LRH_OK;
   if ((size_t)packed_bytes > c->pack18_cap) {              // staging buffer for the packed bytes, grown on demand
     if (c->d_pack18) hipFree(c->d_pack18);
-  if (c->d_net) hipFree(c->d_net);
     c->d_pack18 = nullptr; c->pack18_cap = 0;
     if (hipMalloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(packed18 staging)");
     c->pack18_cap = packed_bytes;
@@ -721,23 +726,22 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
   a.real = c->cfg.timf1_real_input != 0;
   if (c->d_foldcorr || a.real) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr / k_realsplit does the rest
   a.stamps = nullptr;
-  if (getenv("LRH_STAMP")) {                              // diagnostics: dump the phase stamps of this launch to stderr
-    static unsigned long long *d_st = nullptr;
-    if (!d_st) hipMalloc(&d_st, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long));
-    hipMemsetAsync(d_st, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur);
-    a.stamps = d_st;
-    HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+  if (c->dbg_stamp) {                                     // diagnostics (LRH_STAMP=1, -DLRH_STAMP_BUILD): phase stamps of this launch to stderr
+    if (!c->d_stamps) HIPCHK(c, hipMalloc(&c->d_stamps, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur));
+    a.stamps = c->d_stamps;
+  }
+  ProfScope ps(c, "fft1");
+  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+  if (c->dbg_stamp) {
     unsigned long long h[2 * LRH_STAMPS_PER_WG];
-    hipMemcpyAsync(h, d_st, sizeof h, hipMemcpyDeviceToHost, c->cur); hipStreamSynchronize(c->cur);
+    HIPCHK(c, hipMemcpyAsync(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
     for (int w = 0; w < 2; w++) {
       fprintf(stderr, "fft1 stamps wg%d:", w ? 128 : 0);
       for (int i = 1; i < LRH_STAMPS_PER_WG && h[w * LRH_STAMPS_PER_WG + i]; i++) fprintf(stderr, " %llu", h[w * LRH_STAMPS_PER_WG + i] - h[w * LRH_STAMPS_PER_WG]);
       fprintf(stderr, "\n");
     }
-    return LRH_OK;
   }
-  ProfScope ps(c, "fft1");
-  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
   if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
   if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
     RealSplitArgs r;
@@ -828,10 +832,13 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     const SumsqArgs &sa = c->ss_args;
     c->ss_have = false;
     if (a.mode == 1 && c->d_ss_part && sa.batch == batch && sa.first_nb == a.first_nb) {
-      { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur, &sa, c->d_ss_part, &c->ss_run)); }
+      // the scratch of split groups alternates between two halves: in the two-stream schedules the join of this launch runs
+      // on the side stream and may still be reading when the next launch starts writing
+      float *const part = c->d_ss_part + (size_t)c->ss_flip * c->ss_part_stride; c->ss_flip ^= 1;
+      { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur, &sa, part, &c->ss_run)); }
       const SumsqArgs ja = sa; const int run = c->ss_run;
-      c->ss_queue.insert(c->ss_queue.begin(), [ja, run](lrh_ctx *c) -> int {
-        ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, c->d_ss_part, run, c->cur)); return LRH_OK; });
+      c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {
+        ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, part, run, c->cur)); return LRH_OK; });
     } else {                                             // pointers out of step: separate pass after all
       { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
       { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
@@ -887,7 +894,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   a.lowlevel_fraction = p->fft1_lowlevel_fraction;
   p->blanker_info_update_counter++;                                      // blank1.c:1550-1601
   a.do_update = 0;
-  { const char *e = getenv("LRH_BLN_DEBUG"); a.debug = e ? atoi(e) : 0; }
+  a.debug = c->dbg_bln;
   if (p->blanker_info_update_counter >= a.interval) {
     if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
     else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
@@ -1169,9 +1176,19 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     int point = 0;
     const auto host_t0 = std::chrono::steady_clock::now();
     int *h_point = (int *)(h_start + (size_t)batch * nchunks);
+    // the reference tests the range before it touches any state (mix1.c:787-796): every frequency of the batch first;
+    // a table entry that only becomes invalid through the AFC bookkeeping of an earlier transform of the same batch still
+    // ends the call, with the phase state put back (the caller's tables keep what the earlier transforms wrote, as after
+    // that many single calls of the reference)
+    for (int b = 0; b < batch; b++) {
+      const float fq = afc ? afc->mix1_fq_mid[(first + b) & mask] : (float)s->mix1_selfreq;
+      if (fq < c->cfg.mix1_lowest_fq || fq > c->cfg.mix1_highest_fq) { c->ph_next = slot; return LRH_ERANGE; }
+    }
+    const lrh_mix1_state ms_keep = *s;
     for (int b = 0; b < batch; b++) {
       const int nx = (first + b) & mask;
-      int rc = set_mix1_phases(c, afc ? afc->mix1_fq_mid[nx] : (float)s->mix1_selfreq); if (rc) return rc;
+      int rc = set_mix1_phases(c, afc ? afc->mix1_fq_mid[nx] : (float)s->mix1_selfreq);
+      if (rc) { *s = ms_keep; c->ph_next = slot; return rc; }
       if (afc) afc_tables(c, afc, nx, na, mask);
       point = s->mix1_point; h_point[b] = point;
       float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
@@ -1653,7 +1670,14 @@ int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
-int lrh_sync(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); return LRH_OK; }
+int lrh_sync(lrh_ctx *c)
+{
+  if (!c) return LRH_EINVAL;
+  hipSetDevice(c->cfg.device);
+  // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
+  for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2 }) if (s) HIPCHK(c, hipStreamSynchronize(s));
+  return LRH_OK;
+}
 
 int lrh_timer_start(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
 int lrh_timer_stop(lrh_ctx *c, float *ms)

@@ -38,6 +38,25 @@ def test_device_expansion_matches_reference_golden():
     assert np.array_equal(rx2.export(abi.RING_TIMF1), ro.export(abi.RING_TIMF1))
 
 
+def test_net_export_survives_a_growing_packed18_staging_buffer():
+    """lrh_export_timf2_net keeps its own staging buffer; a later, larger lrh_timf1_write_packed18 (which re-allocates its
+    staging) must not disturb it (round-1 advisor finding: a stray hipFree of the net buffer in the grow branch)."""
+    d = case_params("n10_n12_dword")
+    cfg = lrh_config(d, make_input(d), timf1_bytes=1 << int(G["ring_log2"]))
+    rx, ro = _hip(cfg), _oracle(cfg)
+    first = None
+    for r in (rx, ro):
+        r.timf1_write_packed18(G["packed"][:9 * 64], 0)              # small staging buffer first
+        r.wideband_dsp(8, 4)
+    a0 = rx.export_timf2_net(0, 1024, 2.0, 0.5)
+    rx.timf1_write_packed18(G["packed"], 0)                          # grows the packed18 staging
+    a1 = rx.export_timf2_net(0, 1024, 2.0, 0.5)                      # count <= net_cap: reuses the net staging
+    a2 = rx.export_timf2_net(0, 2048, 2.0, 0.5)                      # and grows it
+    assert np.array_equal(a0, a1) and np.array_equal(a0, a2[:2048])
+    ref = ro.export_timf2_net(0, 1024, 2.0, 0.5)
+    assert np.linalg.norm(a0 - ref) <= 1e-5 * max(np.linalg.norm(ref), 1e-30)
+
+
 @pytest.mark.parametrize("dword", [1, 0])
 def test_recording_plays_through_the_chain(tmp_path, dword):
     name = "n10_n12_dword" if dword else "n10_n12"
