@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- Msamples/s of complex IQ through fft1 -> timf2(+blank1) -> fft2 -> mix1 on MI355X, % of HBM roofline,
-with the CPU oracle timed beside it (BASELINE.json metric; contract in the task description).
+"""bench.py -- Msamples/s of complex IQ through fft1 -> timf2(+blank1) -> fft2 -> mix1 (-> fft3 -> mix2) on MI355X, fraction of
+the HBM roofline, with the reference's CPU path timed beside it (BASELINE.json metric; contract in the task description).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--fft2-n 12]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--fft2-n 16] [--fft3-n 12]
 
-One process per GPU (torch.distributed.run for N > 1): every rank runs its own RF channel (weak scaling, no data-path
-collective); the only exchange is the all-reduce of the per-bin channel power sums (fft1.c:4138 semantics).
-A "step" = lrh_wideband_dsp over one batch of B fft1 blocks of synthetic int16 IQ already resident in the device ring.
+Default workload (N = 1): BASELINE configs[2] made concrete as SURVEY 8d C3 -- fft1_size 16384, fft2_size 65536, stupid
+blanker, mix1 size fft2_size/64, fft3 + mix2 behind it, everything inside the timed region; the lighter configs[1]
+(fft2_size 4096, no fft3) is measured in the same run and reported as `secondary`.
+
+N > 1: one process per GPU.  Started by the driver (torch.distributed.run sets RANK / WORLD_SIZE) this process IS a rank; started
+by hand as `python bench.py --gpus N` it first spawns the N ranks itself, before anything touches the GPU, and exits with
+their status.  Every rank runs its own RF channel through the same chain (weak scaling, BASELINE configs[4]); the exchanges
+are the all-reduce of the per-bin channel power sums (fft1.c:4138) and the coherent combine of the channels' baseband bins
+(lrh_set_combine_weights + all-reduce between lrh_mix2_pol_begin and lrh_fft3_mix2), both inside the timed region.
+`--coupled` (N = 2) runs BASELINE configs[3], the polarisation pair with the coupled blanker and the fft2 cross products.
+A "step" = the chain over `rounds` x `batch` fft1 blocks of synthetic int16 IQ already resident in the device ring.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,7 +31,10 @@ sys.path.insert(0, ROOT)
 
 from linrad_amd import abi  # noqa: E402
 from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newest_sumsq_block  # noqa: E402
-from linrad_amd.workload import (ALG_BYTES, ALG_BYTES_CHAIN, HBM_PEAK_GBS, chain_config, strong_liminfo)  # noqa: E402
+from linrad_amd.workload import (ALG_BYTES, HBM_PEAK_GBS, alg_bytes_chain, chain_config, strong_liminfo, workload_name)  # noqa: E402
+
+METRIC = "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline"
+STAGES = ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol")
 
 
 def setup_receiver(cfg, channel, open_fn, synth_mod):
@@ -35,29 +48,29 @@ def setup_receiver(cfg, channel, open_fn, synth_mod):
     return rx
 
 
-def measured_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of this very command, FETCH doubled as the gfx950 guide prescribes); None when
-    the run's workload is not the profiled one."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        w = t["workload"]
-        if (w["fft1_n"], w["fft2_n"], w["batch"]) != (args.fft1_n, args.fft2_n, args.batch):
-            return None
-        return t["kernels"][kernel]["traffic_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        return None
+def measured_traffic(stage, wl):
+    """HBM bytes per launch of a stage's dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this very command, FETCH doubled as the gfx950 guide prescribes);
+    None when this run's workload has not been profiled."""
+    for name in ("r02_traffic.json",):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return t["workloads"][wl]["kernels"][stage]
+        except Exception:  # noqa: BLE001
+            continue
+    return None
 
 
-def cpu_baseline(args, fft1_n, fft2_n):
+# --------------------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(args, w):
     """The oracle (C restatement of the reference path, -O2 -ffast-math, 1 thread) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import open_oracle
     from linrad_amd import lib as hiplib
     nblk = args.cpu_blocks
-    cfg = chain_config(fft1_n, fft2_n, batch=min(32, nblk))
+    cfg = chain_config(w["fft1_n"], w["fft2_n"], batch=min(32, nblk), fft3_n=w["fft3_n"], mix2_n=w["mix2_n"])
     rx = setup_receiver(cfg, 0, open_oracle, hiplib)
-    M1 = (1 << fft1_n) // 2
+    M1 = (1 << w["fft1_n"]) // 2
     rx.wideband_dsp(min(32, nblk), cfg.max_batch)          # warm the caches / tables
     t0 = time.perf_counter()
     rx.wideband_dsp(nblk, cfg.max_batch)
@@ -66,50 +79,65 @@ def cpu_baseline(args, fft1_n, fft2_n):
             "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload, 1 thread, {dt:.1f} s"}
 
 
-def cpu_reference(args, fft1_n, fft2_n):
-    """The COMPILED REFERENCE itself (oracle/_ref/ref_harness: fventuri/linrad's own C files, -O2 -ffast-math, its
-    single-CPU call order wcw.c:1036-1118) on a bounded sample of the same workload, one thread.  None when the binary
-    is not there (it is built in the build container, where the reference sources are, and travels with the snapshot)."""
-    import subprocess
+def ref_harness_cmd(w, nblk, fi, fl, fo, threads=0):
+    from linrad_amd.workload import level_gain
+    N2 = 1 << w["fft2_n"]
+    M1 = (1 << w["fft1_n"]) // 2
+    per_block = max(2, 2 * (M1 // max(1, N2 // 2)) + 2)
+    pow2 = lambda v: 1 << int(np.ceil(np.log2(v)))  # noqa: E731
+    cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_harness"), f"n1={w['fft1_n']}", f"n2={w['fft2_n']}", "mixred=6", "att_n=6",
+           f"gain={level_gain(w['fft1_n'], 6)}", "avg1num=5", "avg2num=4", f"nblk={nblk}", "max_fft1n=8" if not threads else "max_fft1n=64",
+           f"max_fft2n={pow2(per_block)}", "sumsq_blocks=16", "stupid=1", "bln_interval=152", "bln_avgnum=1220",
+           f"fq={0.31 * N2 + 0.3}", "wf_avgnum=8", f"wf_pixels={min(N2, 1024)}", "timing=1", f"in={fi}", f"liminfo={fl}", f"out={fo}"]
+    if w["fft3_n"]:
+        cmd += [f"fft3_n={w['fft3_n']}", f"mix2_n={w['mix2_n']}", "max_fft3n=8", "mix2=1"]
+    if threads:
+        cmd += [f"threads={threads}"]
+    return cmd
+
+
+def cpu_reference(args, w, threads=0):
+    """The COMPILED REFERENCE itself (oracle/_ref/ref_harness: fventuri/linrad's own C files, -O2 -ffast-math) on a bounded
+    sample of the same workload.  threads = 0: its single-CPU call order (wcw.c:1036-1118), one thread.  threads = T: the
+    reference's own thread topology (wcw.c:604-648: up to 6 fft1_b workers, the timf2 thread with fft1_c / make_timf2 / the
+    blanker, the second-fft thread, the narrowband thread), stage functions unchanged, hand-offs by condition events like
+    lxsys.c:415-447.  None when the binary is not there (it is built in the build container, where the reference sources are,
+    and travels with the snapshot)."""
     import tempfile
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if not os.access(exe, os.X_OK):
         return None
     from linrad_amd import lib as hiplib
-    from linrad_amd.workload import level_gain
-    N1, N2 = 1 << fft1_n, 1 << fft2_n
+    N1 = 1 << w["fft1_n"]
     M1 = N1 // 2
     nblk = max(256, args.cpu_blocks // 2)
     s = hiplib.synth_defaults(N1, 0)
     iq = hiplib.synth_iq(s, 0, nblk * M1 + 2 * N1)
-    lim = strong_liminfo(s, fft1_n)
-    per_block = max(2, 2 * (M1 // max(1, N2 // 2)) + 2)
-    pow2 = lambda v: 1 << int(np.ceil(np.log2(v)))  # noqa: E731
+    lim = strong_liminfo(s, w["fft1_n"])
     with tempfile.TemporaryDirectory() as td:
         fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
         np.asarray(iq, np.int16).tofile(fi)
         lim.tofile(fl)
-        cmd = [exe, f"n1={fft1_n}", f"n2={fft2_n}", "mixred=6", "att_n=6", f"gain={level_gain(fft1_n, 6)}", "avg1num=5", "avg2num=4",
-               f"nblk={nblk}", "max_fft1n=8", f"max_fft2n={pow2(per_block)}", "sumsq_blocks=16", "stupid=1", "bln_interval=152",
-               "bln_avgnum=1220", f"fq={0.31 * N2 + 0.3}", "wf_avgnum=8", f"wf_pixels={min(N2, 1024)}", "timing=1",
-               f"in={fi}", f"liminfo={fl}", f"out={fo}"]
         try:
-            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, check=True).stdout
+            out = subprocess.run(ref_harness_cmd(w, nblk, fi, fl, fo, threads), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                 timeout=300, check=True).stdout
             r = json.loads(out.strip().splitlines()[-1])
         except Exception:  # noqa: BLE001
             return None
     dt = r["loop_seconds"]
-    return {"value": round(nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "reference",
-            "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload through the compiled reference "
-                      f"(fft1_b, fft1_c, make_timf2, first_noise_blanker, make_fft2, fft2_mix1_fixed), 1 thread, {dt:.1f} s"}
+    stages = "fft1_b, fft1_c, make_timf2, first_noise_blanker, make_fft2, fft2_mix1_fixed" + (", make_fft3_all, fft3_mix2" if w["fft3_n"] else "")
+    cores = int(r.get("threads", 1))
+    how = "1 thread" if not threads else f"{cores} threads in the reference's stage topology ({r.get('topology', '')})"
+    return {"value": round(nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload through the compiled reference ({stages}), {how}, {dt:.1f} s"}
 
 
-def cpu_worker(fft1_n, fft2_n, nblk, channel):
+def cpu_worker(w, nblk, channel):
     """One single-thread oracle pipeline (child process of cpu_baseline_all_cores); prints its loop time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import open_oracle
     from linrad_amd import lib as hiplib
-    cfg = chain_config(fft1_n, fft2_n, batch=min(32, nblk))
+    cfg = chain_config(w["fft1_n"], w["fft2_n"], batch=min(32, nblk), fft3_n=w["fft3_n"], mix2_n=w["mix2_n"])
     rx = setup_receiver(cfg, channel, open_oracle, hiplib)
     rx.wideband_dsp(min(32, nblk), cfg.max_batch)
     t0 = time.perf_counter()
@@ -117,17 +145,17 @@ def cpu_worker(fft1_n, fft2_n, nblk, channel):
     print(json.dumps({"seconds": time.perf_counter() - t0}))
 
 
-def cpu_baseline_all_cores(args, fft1_n, fft2_n):
-    """the same oracle on every host core.  The reference spreads one receiver over stage threads
-    (wcw.c:604-648); as its throughput on C cores cannot exceed C independent single-thread pipelines, that upper bound
-    is what is measured here: C child processes (at most 16), one channel each, started together.  None if a child fails."""
-    import subprocess
+def cpu_baseline_all_cores(args, w):
+    """Upper bound for any threading of the CPU path on this host: one independent single-thread oracle pipeline per core
+    (at most 16), one channel each, started together.  None if a child fails."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    ncpu = min(ncpu, 16)      # the reference's own topology ends near a dozen threads (6 fft1 workers + stage threads)
+    ncpu = min(ncpu, 16)
     nblk = max(256, args.cpu_blocks // 8)
-    cmd = [sys.executable, os.path.abspath(__file__), "--fft1-n", str(fft1_n), "--fft2-n", str(fft2_n), "--cpu-blocks", str(nblk)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--fft1-n", str(w["fft1_n"]), "--fft2-n", str(w["fft2_n"]), "--fft3-n", str(w["fft3_n"]),
+           "--cpu-blocks", str(nblk)]
     t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd + ["--cpu-worker", str(ch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    procs = [subprocess.Popen(cmd + ["--cpu-worker", str(ch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
              for ch in range(ncpu)]
     times = []
     for p_ in procs:
@@ -138,80 +166,81 @@ def cpu_baseline_all_cores(args, fft1_n, fft2_n):
             p_.kill()
     if len(times) != ncpu:
         return None
-    M1 = (1 << fft1_n) // 2
+    M1 = (1 << w["fft1_n"]) // 2
     dt = max(times)
     return {"value": round(ncpu * nblk * M1 / dt / 1e6, 4), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
             "sample": f"{ncpu} processes x {nblk} fft1 blocks, one channel each, slowest {dt:.1f} s "
                       f"(wall incl. start-up {time.perf_counter() - t0:.1f} s)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    # batch = fft1 blocks handed to every kernel launch.  Throughput grows with it (fuller waves of workgroups, launch and
-    # host overheads amortised: 23.3 Gsamples/s at 1024, 26.9 at 2048, 29.2 at 4096, 29.3 at 8192, round 1) at the price of
-    # batch*8192 samples of latency; 4096 blocks are 1.1 ms of signal at the rate the chain sustains.
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--rounds", type=int, default=4, help="batches of --batch fft1 blocks per step (pipelined on two streams)")
-    ap.add_argument("--fft1-n", type=int, default=14)
-    ap.add_argument("--fft2-n", type=int, default=12)
-    ap.add_argument("--cpu-blocks", type=int, default=16384)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--stream-host", action="store_true",
-                    help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
-                         "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")
-    ap.add_argument("--coupled", action="store_true",
-                    help="BASELINE configs[3]: ranks 0/1 are the two channels of a polarisation pair (ui.rx_rf_channels = 2 sharded): "
-                         "coupled blanker (2 all-reduces per call), fft2 cross products (all-gather), fft3 + polarisation transform "
-                         "in mix2 (all-reduce), stage calls driven from linrad_amd.multichan.run_coupled; not the headline metric")
-    ap.add_argument("--real-input", action="store_true",
-                    help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
-    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.cpu_worker is not None:                        # child of cpu_baseline_all_cores: no GPU, no torch
-        cpu_worker(args.fft1_n, args.fft2_n, args.cpu_blocks, args.cpu_worker)
-        return
+# --------------------------------------------------------------------------------------------------------- rank spawner
+def spawn_ranks(args):
+    """`python bench.py --gpus N` run by hand: start the N ranks as child processes, one per GPU, before anything in this
+    process touches the GPU (no HIP call, no torch.cuda call here), wait for them and pass their status on.  Rank 0's
+    JSON line goes to this process's stdout."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    print(f"bench.py: started {n} ranks, pids {[p.pid for p in procs]}, rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    rc, failed = 0, []
+    deadline = time.time() + args.spawn_timeout
+    alive = list(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.remove(r)
+            if code != 0:
+                failed.append((r, procs[r].pid, code))
+        if failed or time.time() > deadline:
+            for r in alive:                                    # a rank died (or the run overran): its peers would wait for ever
+                procs[r].terminate()
+            t_end = time.time() + 10
+            for r in alive:
+                try:
+                    procs[r].wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            if not failed:
+                failed.append((-1, 0, "timeout"))
+            break
+        time.sleep(0.05)
+    if failed:
+        for r, pid, code in failed:
+            print(f"bench.py: rank {r} (pid {pid}) exited with {code}", file=sys.stderr)
+        rc = 1
+    return rc
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    force_dist = os.environ.get("LRH_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # lazy communicator: an RCCL communicator on the device costs this pipeline ~6 % (measured, round 1) even when
-        # idle, so it is only created by the first collective, i.e. when there really is more than one rank
-        dist.init_process_group("nccl")
-    from linrad_amd import lib as hiplib
 
-    cfg = chain_config(args.fft1_n, args.fft2_n, batch=args.batch, device=local_rank)
+# --------------------------------------------------------------------------------------------------------- one measurement
+def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup, with_stage_times=True):
+    """Time `steps` steps of workload `w` on this rank's GPU; returns the fields of the JSON line that depend on it."""
+    N1, N2, M1 = 1 << w["fft1_n"], 1 << w["fft2_n"], (1 << w["fft1_n"]) // 2
+    coupled, combine = w["mode"] == "coupled", w["mode"] == "combine"
+    cfg = chain_config(w["fft1_n"], w["fft2_n"], batch=args.batch, device=local_rank, fft3_n=w["fft3_n"], mix2_n=w["mix2_n"], rounds=args.rounds)
     if args.real_input:
         cfg.timf1_real_input = 1
-    if args.coupled:
-        if world > 2:
-            raise SystemExit("--coupled: a polarisation pair has two channels (Linrad's maximum, SURVEY F4)")
-        cfg.blanker_channels, cfg.timf1_channel_index = 2, rank
-        cfg.fft3_n, cfg.fft3_sinpow, cfg.mix2_n, cfg.max_fft3n, cfg.baseband_size = 10, 2, 8, 64, 1 << 16
-        cfg.timf3_size = max(cfg.timf3_size, 1 << 16)
-    N1, N2, M1 = 1 << args.fft1_n, 1 << args.fft2_n, (1 << args.fft1_n) // 2
+    if coupled:
+        cfg.blanker_channels, cfg.timf1_channel_index = 2, rank & 1
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
     samples_per_step = args.batch * args.rounds * M1
+    dev = torch.device("cuda", local_rank)
     use_dist = dist is not None
-    xchg = torch.zeros(N1, dtype=torch.float32, device=f"cuda:{local_rank}") if use_dist else None
-
+    xchg = torch.zeros(N1, dtype=torch.float32, device=dev) if use_dist else None
     # the context's own stream, wrapped so that torch / RCCL work can be ordered against it without host waits
-    # (and a side stream for the collective: the legacy default stream would serialise with every blocking stream)
-    lrh_stream = torch.cuda.ExternalStream(rx.stream_handle(), device=torch.device("cuda", local_rank)) if use_dist else None
-    comm_stream = torch.cuda.Stream(device=torch.device("cuda", local_rank)) if use_dist else None
+    # (and a side stream for the power-sum all-reduce: the legacy default stream would serialise with every blocking stream)
+    lrh_stream = torch.cuda.ExternalStream(rx.stream_handle(), device=dev) if use_dist else None
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     host_ring = None
     if args.stream_host:
-        # the producer's side of the boundary: Linrad's timf1 arena, page-locked once; one step's worth of
-        # new samples is 4 bytes per complex sample
         s0 = hiplib.synth_defaults(N1, channel_of_rank(rank))
         host_ring = np.ascontiguousarray(hiplib.synth_iq(s0, 0, cfg.timf1_bytes // 4))
         rx.host_register(host_ring)
@@ -220,19 +249,29 @@ def main():
     step_bytes = args.batch * args.rounds * M1 * 4
     wr = [0]
 
-    if args.coupled:
+    if coupled:
         from linrad_amd.multichan import run_coupled
-        if dist is None:                                    # a one-rank group: the collectives are there, nothing to fetch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=0, world_size=1)
-            use_dist = True
         rx.set_pol(0.8, 0.36, -0.48)
-        dev = torch.device("cuda", local_rank)
+    if combine:
+        # phased array (BASELINE configs[4]): steer at the synthetic sky signal, whose phase on channel c is 0.7 c rad
+        # (SURVEY 8d); beam B is the same aperture pointed half a beam away
+        from linrad_amd.multichan import coupled_fft3_mix2
+        th = 0.7 * channel_of_rank(rank)
+        rx.set_combine_weights(np.exp(-1j * th) / world, np.exp(-1j * (th + np.pi * channel_of_rank(rank) / max(world, 1))) / world)
+
+    def narrow_tail():
+        """narrowband side with the coherent combine: fft3 of the own channel, the all-reduce of the weighted mix2 bins
+        (stream-ordered on the context's stream, no host wait), filter + back transform of the combined beam"""
+        k3 = rx.fft3_available()
+        cap = max(1, cfg.max_fft3n // 2)
+        while k3 > 0:
+            k3b = min(k3, cap)
+            rx.make_fft3_all(k3b)
+            coupled_fft3_mix2(rx, k3b, dist, dev)
+            k3 -= k3b
 
     def step():
-        if args.coupled:
+        if coupled:
             run_coupled(rx, args.batch * args.rounds, args.batch, dist, device=dev, xy=True, pol=True)
             return
         if host_ring is not None:
@@ -245,6 +284,8 @@ def main():
                 rx.timf1_write_async(flat[:nb - first], 0)
             wr[0] += nb
         rx.wideband_dsp(args.batch * args.rounds, args.batch)
+        if combine:
+            narrow_tail()
         if use_dist:
             # cross-channel power sum of the newest averaged spectrum (fft1.c:4138: sum over channels per bin)
             lrh_stream.wait_stream(comm_stream)             # the previous all-reduce is done with xchg
@@ -261,67 +302,113 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     rx.timer_start()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     t_enq = time.perf_counter() - t0                       # host-side enqueue time (the device runs behind it)
     ev_ms = rx.timer_stop()
     barrier()
-    host_ph = rx.profile_get("host:mix1_phases")
-    host_dsp = rx.profile_get("host:wideband_dsp")
-    host_dsp_cpu = rx.profile_get("host:wideband_dsp_cpu")
-    host_wait = rx.profile_get("host:staging_wait")
     dt = time.perf_counter() - t0
+    host = {k: rx.profile_get("host:" + k) for k in ("mix1_phases", "wideband_dsp", "wideband_dsp_cpu", "staging_wait")}
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_samples = world * args.steps * samples_per_step
-    value = total_samples / dt / 1e6
+    value = world * steps * samples_per_step / dt / 1e6
+    res = {"value": round(value, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup,
+           "event_ms_per_step": round(ev_ms / steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / steps, 4),
+           "host_cpu": {"mix1_phase_ms_per_call": round(host["mix1_phases"][0] / max(host["mix1_phases"][1], 1), 4),
+                        "wideband_dsp_ms_per_call": round(host["wideband_dsp"][0] / max(host["wideband_dsp"][1], 1), 4),
+                        "wideband_dsp_cpu_ms_per_call": round(host["wideband_dsp_cpu"][0] / max(host["wideband_dsp_cpu"][1], 1), 4),
+                        "staging_wait_ms_per_call": round(host["staging_wait"][0] / max(host["staging_wait"][1], 1), 4)},
+           "samples_per_step": samples_per_step, "workload": workload_name(w, args.batch),
+           "config_text": w["text"].format(N1=N1, N2=N2, Nm=N2 >> 6, N3=(1 << w["fft3_n"]) if w["fft3_n"] else 0,
+                                           Nm2=(1 << w["mix2_n"]) if w["mix2_n"] else 0, rounds=args.rounds, batch=args.batch,
+                                           samples=samples_per_step, world=world)}
 
-    # ---- per-kernel timing with HIP events on the context stream (rank 0), same steps
-    roof = None
-    stages = {}
-    if rank == 0 and not args.coupled:
-        rx.profile_enable(True)
-        rx.wideband_dsp(args.batch, args.batch)                # first serial pass after the two-stream run: discarded
+    # ---- per-kernel timing with HIP events on the streams the kernels are launched on (rank 0), in the SAME two-stream
+    # schedule as the timed loop (lrh_profile_enable(2)); a serial pass afterwards gives the stand-alone times
+    stages, alone, roof = {}, {}, None
+    if rank == 0 and with_stage_times and not coupled:
+        nprof = max(3, min(steps, 10))
+        rx.profile_enable(2)
+        for _ in range(nprof):
+            rx.wideband_dsp(args.batch * args.rounds, args.batch)
+            if combine:
+                k3 = rx.fft3_available()                   # keep the rings moving; the collective is not profiled here
+                while k3 > 0:
+                    k3b = min(k3, max(1, cfg.max_fft3n // 2))
+                    rx.make_fft3_all(k3b); rx.mix2_pol_begin(k3b); rx.fft3_mix2(k3b)
+                    k3 -= k3b
         rx.sync()
-        rx.profile_enable(True)                                # resets the accumulators
-        for _ in range(max(3, min(args.steps, 10))):
-            rx.wideband_dsp(args.batch, args.batch)
-        rx.sync()
-        for k in ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1"):
+        for k in STAGES:
             ms, n = rx.profile_get(k)
             if n:
                 stages[k] = {"ms_total": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 2)}
-                if k in ALG_BYTES:                         # stand-alone stage rates (secondary metric): one batch per launch
-                    per = ALG_BYTES[k] + (ALG_BYTES["sumsq"] if k == "timf2" else 0.0)
-                    stages[k]["Msamples_per_s"] = round(args.batch * M1 / (ms / n * 1e-3) / 1e6, 1)
-                    stages[k]["alg_GBps"] = round(stages[k]["Msamples_per_s"] * per / 1e3, 1)
-        rx.profile_enable(False)
+        rx.profile_enable(1)
+        rx.wideband_dsp(args.batch, args.batch)                # first serial pass after the two-stream run: discarded
+        rx.sync()
+        rx.profile_enable(1)                                   # resets the accumulators
+        for _ in range(nprof):
+            rx.wideband_dsp(args.batch, args.batch)
+        rx.sync()
+        for k in STAGES:
+            ms, n = rx.profile_get(k)
+            if n:
+                alone[k] = round(1e3 * ms / n, 2)
+        rx.profile_enable(0)
+        fused_sums = "sumsq" not in stages
+        for k, st in stages.items():
+            st["avg_us_alone"] = alone.get(k)
+            if k in ALG_BYTES:                             # stage rates (secondary metric): one batch per launch
+                per = ALG_BYTES[k] + (ALG_BYTES["sumsq"] if (k == "timf2" and fused_sums) else 0.0)
+                launches_per_round = st["launches"] / (nprof * args.rounds)
+                st["Msamples_per_s"] = round(args.batch * M1 / (st["avg_us"] * launches_per_round * 1e-6) / 1e6, 1)
+                st["alg_GBps"] = round(st["Msamples_per_s"] * per / 1e3, 1)
+                tr = measured_traffic(k, res["workload"])
+                if tr:
+                    st["counter_GBps"] = round(tr["traffic_bytes_per_launch"] / (st["avg_us"] * 1e-6) / 1e9, 1)
+                if st["alg_GBps"] > HBM_PEAK_GBS:
+                    st["note"] = ("algorithmic bytes (SURVEY 8d: every stage one full pass) exceed what this kernel moves: the overlapped half "
+                                  "of each transform stays in registers and the per-transform power ring is never written")
         dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
-        nsteps_prof = stages["fft1"]["launches"]
-        launches_per_step = stages[dom]["launches"] / nsteps_prof
-        per_sample = ALG_BYTES[dom]
-        if dom == "timf2" and "sumsq" not in stages:           # fft1_c's power sums are computed inside k_timf2: both stages' bytes
-            per_sample += ALG_BYTES["sumsq"]
-        alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_step      # the profiling loop runs single batches
-        avg_s = stages[dom]["ms_total"] / stages[dom]["launches"] / 1e3
+        per_sample = ALG_BYTES[dom] + (ALG_BYTES["sumsq"] if (dom == "timf2" and fused_sums) else 0.0)
+        launches_per_round = stages[dom]["launches"] / (nprof * args.rounds)
+        alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_round
+        avg_s = stages[dom]["avg_us"] * 1e-6
         achieved = alg_bytes_launch / avg_s / 1e9
+        tr = measured_traffic(dom, res["workload"])
+        traffic = tr["traffic_bytes_per_launch"] if tr else None
+        chain_alg = alg_bytes_chain(w)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, args),
-                "alg_bytes_per_launch": int(alg_bytes_launch), "avg_launch_us": round(avg_s * 1e6, 2),
-                "chain_alg_GBps": round(value * ALG_BYTES_CHAIN / 1e3, 1),
-                "chain_frac": round(value * ALG_BYTES_CHAIN / 1e3 / HBM_PEAK_GBS / world, 4)}
-    if rank == 0 and roof is not None:
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac_alg": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_counter": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "achieved_counter": round(traffic / avg_s / 1e9, 1) if traffic else None,
+                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_traffic.json) "
+                           "/ average launch time / 8 TB/s; frac (= frac_alg) prices the SURVEY 8d algorithmic bytes, part of which this "
+                           "kernel eliminates (overlap read-modify-write 32 B, liminfo floats 8 B of 92 B per sample)",
+                "timer": "HIP events around each launch on the stream it is launched on, two-stream schedule of the timed loop "
+                         "(lrh_profile_enable(2)); avg_launch_us_alone = same kernel in the serial order",
+                "alg_bytes_per_launch": int(alg_bytes_launch), "alg_bytes_per_sample": per_sample,
+                "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_alone": alone.get(dom),
+                "chain_alg_bytes_per_sample": chain_alg,
+                "chain_alg_GBps": round(value / world * chain_alg / 1e3, 1),
+                "chain_frac_alg": round(value / world * chain_alg / 1e3 / HBM_PEAK_GBS, 4)}
+        trs = [measured_traffic(k, res["workload"]) for k in stages]
+        if all(t is not None for t, k in zip(trs, stages) if k in ALG_BYTES):
+            # whole-round HBM traffic from the counters: sum over the profiled kernels x their launches per round
+            tot = sum(t["traffic_bytes_per_launch"] * stages[k]["launches"] / (nprof * args.rounds) for t, k in zip(trs, stages) if t)
+            roof["chain_counter_bytes_per_sample"] = round(tot / (args.batch * M1), 1)
+            roof["chain_frac_counter"] = round(value / world * 1e6 * tot / (args.batch * M1) / 1e9 / HBM_PEAK_GBS, 4)
         # context for the 8 TB/s nominal peak: what a plain device-to-device copy reaches on this box (read + write bytes)
         try:
             nbytes = 1 << 30
-            src = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             dst = torch.empty_like(src)
             dst.copy_(src)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -335,39 +422,162 @@ def main():
             del src, dst
         except Exception:  # noqa: BLE001
             roof["device_copy_GBps"] = None
-    cpu = cpu_all = cpu_port = None
-    if rank == 0 and not args.no_cpu:
-        cpu_port = cpu_baseline(args, args.fft1_n, args.fft2_n)
-        cpu = cpu_reference(args, args.fft1_n, args.fft2_n) or cpu_port
-        cpu_all = cpu_baseline_all_cores(args, args.fft1_n, args.fft2_n)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         bs = rx.blanker_state()
+        res["blanker"] = {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
+                          "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls}
+    res["roofline"], res["stages"] = roof, stages
+    if host_ring is not None:
+        rx.host_unregister(host_ring)
+    rx.close()
+    return res
+
+
+WORKLOADS = {
+    # BASELINE configs[2] as SURVEY 8d C3 makes it concrete
+    "c2": dict(mode="chain", fft3=True,
+               text="BASELINE configs[2] (SURVEY 8d C3): 1 channel/GPU complex-int16 IQ, fft1_size={N1} sin^2 50% overlap, timf2 + stupid blanker, "
+                    "fft2_size={N2} sin^2 (four-step), mix1 size {Nm}, fft3_size={N3} + mix2 size {Nm2}; {rounds} x {batch} fft1 blocks "
+                    "({samples} samples) per step, device-resident ring"),
+    # BASELINE configs[1]
+    "c1": dict(mode="chain", fft3=False,
+               text="BASELINE configs[1]: 1 channel/GPU complex-int16 IQ, fft1_size={N1} sin^2 50% overlap, timf2 + stupid blanker, "
+                    "fft2_size={N2} sin^2, mix1 size {Nm}; {rounds} x {batch} fft1 blocks ({samples} samples) per step, device-resident ring"),
+    # BASELINE configs[4]: the configs[2] chain per channel + the coherent combine
+    "c4": dict(mode="combine", fft3=True,
+               text="BASELINE configs[4]: {world}-channel phased array, one channel per GPU, each through fft1_size={N1} / timf2 + blanker / "
+                    "fft2_size={N2} / mix1 {Nm} / fft3 {N3}; RCCL all-reduce of the per-bin channel power sums and of the weighted mix2 bins "
+                    "(coherent combine, two beams, mix2 size {Nm2}) inside the timed region; {rounds} x {batch} fft1 blocks ({samples} samples) "
+                    "per channel and step"),
+    # BASELINE configs[3]
+    "c3": dict(mode="coupled", fft3=True,
+               text="BASELINE configs[3]: polarisation pair (ui.rx_rf_channels = 2 sharded one channel per GPU), fft1_size={N1}, coupled blanker "
+                    "(2 all-reduces per call), fft2_size={N2} cross products (all-gather), mix1 {Nm}, fft3 {N3} + polarisation transform in "
+                    "mix2 {Nm2} (all-reduce); {rounds} x {batch} fft1 blocks ({samples} samples) per channel and step"),
+}
+
+
+def make_workload(key, fft1_n, fft2_n, fft3_n, mix2_n):
+    w = dict(WORKLOADS[key], key=key, fft1_n=fft1_n, fft2_n=fft2_n)
+    w["fft3_n"], w["mix2_n"] = (fft3_n, mix2_n) if (w["fft3"] and fft3_n) else (0, 0)
+    return w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    # batch = fft1 blocks handed to every kernel launch.  Throughput grows with it (fuller waves of workgroups, launch and
+    # host overheads amortised: 23.3 Gsamples/s at 1024, 26.9 at 2048, 29.2 at 4096, 29.3 at 8192, round 1) at the price of
+    # batch*8192 samples of latency; 4096 blocks are 1.1 ms of signal at the rate the chain sustains.
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=4, help="batches of --batch fft1 blocks per step (pipelined on two streams)")
+    ap.add_argument("--fft1-n", type=int, default=14)
+    ap.add_argument("--fft2-n", type=int, default=None, help="log2 fft2_size; default 16 (configs[2]); 12 = configs[1]")
+    ap.add_argument("--fft3-n", type=int, default=12, help="log2 fft3_size behind mix1 (0: chain ends at mix1)")
+    ap.add_argument("--mix2-n", type=int, default=8)
+    ap.add_argument("--cpu-blocks", type=int, default=16384)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second workload of the default run")
+    ap.add_argument("--stream-host", action="store_true",
+                    help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
+                         "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")
+    ap.add_argument("--coupled", action="store_true",
+                    help="BASELINE configs[3] as the primary workload: ranks 0/1 are the two channels of a polarisation pair: coupled blanker "
+                         "(2 all-reduces per call), fft2 cross products (all-gather), fft3 + polarisation transform in mix2 (all-reduce)")
+    ap.add_argument("--real-input", action="store_true",
+                    help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    explicit_fft2 = args.fft2_n is not None
+    if args.fft2_n is None:
+        args.fft2_n = 16
+    if args.cpu_worker is not None:                        # child of cpu_baseline_all_cores: no GPU, no torch
+        cpu_worker(make_workload("c2" if args.fft3_n else "c1", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n), args.cpu_blocks, args.cpu_worker)
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # started by hand: become the launcher, never touch the GPU here
+        return spawn_ranks(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("LRH_BENCH_SAME_DEVICE") == "1":     # rehearsal of the N > 1 logic on a one-GPU box (backend gloo)
+        local_rank = 0
+    import torch
+    dist = None
+    force_dist = os.environ.get("LRH_BENCH_FORCE_DIST") == "1"      # exercise the collective path on a single GPU
+    backend = os.environ.get("LRH_BENCH_BACKEND", "nccl")
+    if world > 1 or force_dist or args.coupled:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        # lazy communicator: an RCCL communicator on the device costs this pipeline ~6 % (measured, round 1) even when
+        # idle, so it is only created by the first collective, i.e. when there really is more than one rank
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    from linrad_amd import lib as hiplib
+
+    if args.coupled and world > 2:
+        raise SystemExit("--coupled: a polarisation pair has two channels (Linrad's maximum, SURVEY F4)")
+    # primary workload: configs[2] on one GPU; one channel per GPU with the coherent combine on several (configs[4])
+    if args.coupled:
+        primary = make_workload("c3", args.fft1_n, args.fft2_n if explicit_fft2 else 12, 10, 8)
+    elif world > 1:
+        primary = make_workload("c4", args.fft1_n, args.fft2_n, args.fft3_n or 12, args.mix2_n)
+    else:
+        primary = make_workload("c2" if args.fft3_n else "c1", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n)
+        if args.fft2_n <= 14 and not args.fft3_n:
+            primary = make_workload("c1", args.fft1_n, args.fft2_n, 0, 0)
+    res = measure(args, primary, rank, local_rank, world, dist, torch, hiplib, args.steps, args.warmup)
+
+    # second workload of the default run: configs[1] beside configs[2] on one GPU; configs[3] (coupled pair) on two
+    secondary = None
+    default_run = not explicit_fft2 and not args.coupled and not args.stream_host and not args.real_input and not args.no_secondary
+    if default_run and world <= 2:
+        sw = make_workload("c1", args.fft1_n, 12, 0, 0) if world == 1 else make_workload("c3", args.fft1_n, 12, 10, 8)
+        try:
+            s = measure(args, sw, rank, local_rank, world, dist, torch, hiplib, max(5, args.steps // 5), max(2, args.warmup // 2))
+            secondary = {"config": {"workload": s["config_text"]}, "value": s["value"], "unit": "Msamples/s", "ms_per_step": s["ms_per_step"],
+                         "steps": s["steps"], "roofline": s["roofline"], "stages": s["stages"], "blanker": s.get("blanker")}
+        except Exception as e:  # noqa: BLE001
+            secondary = {"error": repr(e)}
+
+    cpu = cpu_all = cpu_port = cpu_threads = None
+    if rank == 0 and not args.no_cpu:
+        cw = dict(primary)
+        cpu_port = cpu_baseline(args, cw)
+        cpu = cpu_reference(args, cw) or cpu_port
+        cpu_threads = cpu_reference(args, cw, threads=-1)
+        cpu_all = cpu_baseline_all_cores(args, cw)
+    if dist is not None:
+        dist.barrier()
+        nranks = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        nranks = 1
+    if rank == 0:
+        value = res["value"]
+        N1, N2 = 1 << primary["fft1_n"], 1 << primary["fft2_n"]
         out = {
-            "metric": "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC, "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 1 channel/GPU complex-int16 IQ, fft1_size={N1} sin^2 50% overlap, "
-                                   f"timf2 + stupid blanker, fft2_size={N2} sin^2, mix1 size {N2 >> 6}; "
-                                   f"{args.rounds} x {args.batch} fft1 blocks ({samples_per_step} samples) per step, device-resident ring",
-                       "fft1_size": N1, "fft2_size": N2, "batch_blocks": args.batch, "rounds_per_step": args.rounds, "channels": world,
-                       "parallelism": f"1 RF channel per GPU x{world}"},
-            "mode": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan" if args.coupled else "lrh_wideband_dsp",
+            "config": {"workload": res["config_text"], "fft1_size": N1, "fft2_size": N2,
+                       "fft3_size": (1 << primary["fft3_n"]) if primary["fft3_n"] else 0, "batch_blocks": args.batch,
+                       "rounds_per_step": args.rounds, "channels": world, "parallelism": f"1 RF channel per GPU x{world}",
+                       "collective_world_size": nranks, "backend": (backend if dist is not None else None)},
+            "mode": {"chain": "lrh_wideband_dsp", "combine": "lrh_wideband_dsp + coherent combine (lrh_mix2_pol_begin / all-reduce / lrh_fft3_mix2)",
+                     "coupled": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan"}[primary["mode"]],
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",
-            "event_ms_per_step": round(ev_ms / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
-            "host_cpu": {"mix1_phase_ms_per_call": round(host_ph[0] / max(host_ph[1], 1), 4), "wideband_dsp_ms_per_call": round(host_dsp[0] / max(host_dsp[1], 1), 4),
-                         "wideband_dsp_cpu_ms_per_call": round(host_dsp_cpu[0] / max(host_dsp_cpu[1], 1), 4),
-                         "staging_wait_ms_per_call": round(host_wait[0] / max(host_wait[1], 1), 4)},
+            "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_all_cores": cpu_all, "stages": stages,
-            "blanker": {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
-                        "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls},
+            "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
+            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "secondary": secondary,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -342,7 +342,11 @@ int lrh_set_mix1_selfreq(lrh_ctx *ctx, double fq);        /* mix1_selfreq[0]; <0
 int lrh_get_mix1_state(lrh_ctx *ctx, lrh_mix1_state *st);
 
 /* Whole wideband chain for `nblocks` fft1 blocks in the order of wideband_dsp's single-CPU branch
-   (wcw.c:1036-1118), batched `batch` blocks at a time: the blanker and fft2/mix1 run once per batch. */
+   (wcw.c:1036-1118), batched `batch` blocks at a time: the blanker and fft2/mix1 run once per batch.  With fft3
+   configured (cfg.fft3_n > 0) and a frequency selected the narrowband side follows mix1 like do_fft3 / do_mix2 follow
+   EVENT_FFT3 / EVENT_MIX2 (wcw.c:1788,1828; fft3.c:35-60; mix2.c:41-80): every transform timf3 holds through
+   lrh_make_fft3_all and lrh_fft3_mix2 -- unless a coherent combine is set (lrh_set_pol / lrh_set_combine_weights): its
+   collective belongs between lrh_mix2_pol_begin and lrh_fft3_mix2, so the caller then runs those calls itself. */
 int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
 
 /* ---- host-visible side outputs ---- */
@@ -366,7 +370,9 @@ int lrh_sync(lrh_ctx *ctx);
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int lrh_timer_start(lrh_ctx *ctx);
 int lrh_timer_stop(lrh_ctx *ctx, float *elapsed_ms);      /* synchronises on the stop event */
-/* per-kernel accumulated time since the last reset, measured with hipEvents around each launch when enabled */
+/* per-kernel accumulated time since the last reset, measured with hipEvents around each launch when enabled.
+   on = 1: lrh_wideband_dsp falls back to its serial order (stand-alone kernel times); on = 2: the two-stream schedule is
+   kept, so a stage's time is what it takes next to the kernels it really shares the chip with */
 int lrh_profile_enable(lrh_ctx *ctx, int on);
 int lrh_profile_get(lrh_ctx *ctx, const char *kernel, double *total_ms, long *launches);
 

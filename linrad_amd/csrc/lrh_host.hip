@@ -88,6 +88,7 @@ struct lrh_ctx {
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   int dbg_stamp = 0, dbg_bln = 0;    // LRH_STAMP / LRH_BLN_DEBUG, read once in lrh_open
+  int env_fft2_run = 0, env_fft2_cols_run = 0;   // LRH_FFT2_RUN / LRH_FFT2_COLS_RUN: transforms per workgroup (0: automatic)
   unsigned long long *d_stamps = nullptr;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   bool pipeline_forced = false;      // LRH_PIPELINE given: no automatic choice by batch size
@@ -130,7 +131,7 @@ struct lrh_ctx {
   int fft1n_mask, fft1_mask, sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
   // timers / profiling
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  bool prof = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
+  bool prof = false, prof_keep_schedule = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
   std::vector<hipEvent_t> ev_pool;
   double host_ms_phases = 0, host_ms_dsp = 0, host_cpu_ms_dsp = 0, host_ms_wait = 0; long host_n_phases = 0, host_n_dsp = 0;   // host CPU time, lrh_profile_get("host:...")
 };
@@ -382,6 +383,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
+  if (const char *e7 = getenv("LRH_FFT2_RUN")) c->env_fft2_run = atoi(e7);
+  if (const char *e8 = getenv("LRH_FFT2_COLS_RUN")) c->env_fft2_cols_run = atoi(e8);
   hipEventCreate(&c->t0); hipEventCreate(&c->t1);
   hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking);
   hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_fft1_read, hipEventDisableTiming);
@@ -992,14 +995,14 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   Fft2Args a;
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
   a.window = c->d_window2; a.tw = c->d_tw2; a.out = c->d_fft2; a.power = c->d_power2; a.first_na = p->fft2_na; a.na_mask = c->fft2n_mask;
-  a.xcd = (c->xcd_mask >> 2) & 1;
+  a.xcd = (c->xcd_mask >> 2) & 1; a.run = c->env_fft2_run;
   a.ps_in = c->d_powersum2; a.ps_out = c->d_powersum2_alt; a.wf_scratch = c->d_wf_scratch;
   a.ps_counter = p->wg_waterf_sum_counter; a.ps_avgnum = c->fft2_fused ? c->cfg.waterfall_avgnum : 0;
   Fft2BigArgs g;
   g.timf2w = a.timf2w; g.timf2s = a.timf2s; g.mask = a.mask; g.px_first = a.px_first; g.step = a.step; g.window = a.window;
   g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
   g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
-  g.ps_in = a.ps_in; g.ps_out = a.ps_out; g.wf_scratch = a.wf_scratch; g.ps_counter = a.ps_counter; g.ps_avgnum = a.ps_avgnum; g.batch = batch;
+  g.ps_in = a.ps_in; g.ps_out = a.ps_out; g.wf_scratch = a.wf_scratch; g.ps_counter = a.ps_counter; g.ps_avgnum = a.ps_avgnum; g.batch = batch; g.run = c->env_fft2_cols_run;
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
@@ -1315,7 +1318,8 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.timf3 = c->d_timf3; a.mask = c->cfg.timf3_size / 2 - 1; a.px_first = p->timf3_px / 2; a.step = c->M3;
   a.window = c->d_window3; a.tw = c->d_tw3; a.out = c->d_fft3;
   a.first_slot = p->fft3_pa / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1;
-  { ProfScope ps(c, "fft3"); HIPCHK(c, launch_fft3(c->cfg.fft3_n, a, batch, c->cur)); }
+  const int fft3_n = c->cfg.fft3_n;
+  LRH_DEVICE_WORK(c, { ProfScope ps(c, "fft3"); HIPCHK(c, launch_fft3(fft3_n, a, batch, c->cur)); });
   p->timf3_px = (p->timf3_px + batch * 2 * c->M3) & c->timf3_mask;                      // fft3.c:784
   p->fft3_pa = (p->fft3_pa + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // fft3.c:797
   return LRH_OK;
@@ -1372,9 +1376,12 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   Mix1OutArgs o; memset(&o, 0, sizeof o);
   o.scratch = c->d_mix2_scratch; o.timf3 = c->d_baseb; o.mask2 = c->cfg.baseband_size - 1; o.pa_first = p->baseb_pa; o.block = c->Mm2;
   o.nm = c->Nm2; o.overlap = c->Im2 != 0; o.selected = 1; o.rotate = 0;
-  ProfScope ps(c, "mix2");
-  HIPCHK(c, launch_mix2_back(c->cfg.mix2_n, a, batch, c->cur));
-  HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+  const int mix2_n = c->cfg.mix2_n;
+  LRH_DEVICE_WORK(c, {
+    ProfScope ps(c, "mix2");
+    HIPCHK(c, launch_mix2_back(mix2_n, a, batch, c->cur));
+    HIPCHK(c, launch_mix1_out(o, batch, c->cur));
+  });
   p->baseb_pa = (p->baseb_pa + batch * c->Mm2) & (c->cfg.baseband_size - 1);             // mix2.c:1079, 2057
   p->fft3_px = (p->fft3_px + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // mix2.c:2058
   return LRH_OK;
@@ -1409,7 +1416,27 @@ int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
 //   main:  fft1(k+1) | fft2(k) mix1(k) | timf2(k+1) | fft1(k+2) ...
 //   side:  blanker(k) sumsq(k+1) slowsum(k+1) | powersum2(k) waterfall(k) | ...
 // Events carry exactly the data dependencies of the serial order; host bookkeeping is unchanged.
-static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 for everything the blanker has released
+// The narrowband side behind mix1 (wcw.c:1788, 1828: EVENT_FFT3 -> do_fft3, fft3.c:35-60 -> EVENT_MIX2 -> do_mix2, mix2.c:41-80):
+// every fft3 transform timf3 holds, then its filter / decimate step.  With a coherent combine configured (lrh_set_pol /
+// lrh_set_combine_weights) the caller's collective sits between lrh_mix2_pol_begin and lrh_fft3_mix2, so the caller runs
+// this part itself.
+static int narrow_tail(lrh_ctx *c, lrh_ptrs *p)
+{
+  if (!c->N3 || c->pol_set || c->ms.mix1_selfreq < 0) return LRH_OK;
+  int rc;
+  const int have = (p->timf3_pa - p->timf3_px + c->cfg.timf3_size) & c->timf3_mask;       // fft3.c:54-55
+  int k = have < 2 * c->N3 ? 0 : 1 + (have - 2 * c->N3) / (2 * c->M3);
+  const int cap = c->cfg.max_fft3n / 2 > 0 ? c->cfg.max_fft3n / 2 : 1;                    // producer and consumer share the fft3 ring
+  while (k > 0) {
+    const int kb = k < cap ? k : cap;
+    if ((rc = lrh_make_fft3_all(c, p, kb))) return rc;
+    if ((rc = lrh_fft3_mix2(c, p, kb))) return rc;
+    k -= kb;
+  }
+  return LRH_OK;
+}
+
+static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 (+ fft3 / mix2) for everything the blanker has released
 {
   int rc;
   const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
@@ -1419,6 +1446,7 @@ static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 for everythin
     const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
     if ((rc = lrh_make_fft2(c, p, kb))) return rc;
     if ((rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
+    if ((rc = narrow_tail(c, p))) return rc;
     k -= kb;
   }
   return LRH_OK;
@@ -1447,7 +1475,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // fewest stream operations and wins there (Msamples/s serial / lagged, fft1_size 16384: 82 / 80 at 1 block per round,
   // 2170 / 1990 at 32, 9420 / 9100 at 256); the two-stream schedules pay off from ~3 M samples per round (15200 / 17000 at 512).
   const bool small_rounds = !c->pipeline_forced && (long)batch * c->M1 < (3L << 20);
-  const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && !c->prof;
+  const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && (!c->prof || c->prof_keep_schedule);
   // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
   const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); } } fuse_guard{c};
@@ -1692,7 +1720,7 @@ int lrh_timer_stop(lrh_ctx *c, float *ms)
 int lrh_profile_enable(lrh_ctx *c, int on)
 {
   if (!c) return LRH_EINVAL;
-  prof_collect(c); c->prof = on != 0; c->prof_tot.clear();
+  prof_collect(c); c->prof = on != 0; c->prof_keep_schedule = on == 2; c->prof_tot.clear();
   return LRH_OK;
 }
 int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *launches)

@@ -1601,8 +1601,7 @@ hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)
       default: return hipErrorInvalidValue;
     }
     const int cap = persistent_grid(lds, threads, 1 << 30);
-    static const int env_run = [] { const char *e = getenv("LRH_FFT2_RUN"); return e ? atoi(e) : 0; }();   // tuning knob, read once
-    int run = env_run ? env_run : (batch + cap - 1) / cap;
+    int run = a0.run > 0 ? a0.run : (batch + cap - 1) / cap;     // a0.run: tuning knob LRH_FFT2_RUN (read by lrh_open)
     a.run = run < 1 ? 1 : (run > 16 ? 16 : run);
   }
   LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
@@ -1614,8 +1613,7 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
   {
     // transforms per workgroup: enough workgroups left to fill the chip a few times over
     const int tiles = (1 << LB) / LRH_TILE;
-    static const int env_run = [] { const char *e = getenv("LRH_FFT2_COLS_RUN"); return e ? atoi(e) : 0; }();
-    int run = env_run ? env_run : batch * tiles / 512;
+    int run = a0.run > 0 ? a0.run : batch * tiles / 512;         // a0.run: tuning knob LRH_FFT2_COLS_RUN (read by lrh_open)
     a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
   }
   hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);

@@ -6,6 +6,18 @@ from .abi import default_config
 # algorithmic HBM bytes per input complex sample, per stage (DESIGN.md "Roofline accounting")
 ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2": 64.0}
 ALG_BYTES_CHAIN = 184.0
+
+
+def alg_bytes_chain(w):
+    """algorithmic bytes per input sample of a bench workload: the 184 B of SURVEY 8d up to mix1, plus the narrowband side when
+    it is configured -- timf3 runs at 1/64 of the input rate (mix1 bandwidth reduction 6), fft3 reads and writes it with 50 %
+    overlap (8 + 8 bytes x 2), mix2 is a further decimation behind it: +0.5 B per input sample"""
+    return ALG_BYTES_CHAIN + (0.5 if w.get("fft3_n") else 0.0)
+
+
+def workload_name(w, batch):
+    """key of a bench workload in profiles/*_traffic.json"""
+    return f"n1_{w['fft1_n']}_n2_{w['fft2_n']}_n3_{w.get('fft3_n', 0)}_b{batch}"
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -16,8 +28,9 @@ def level_gain(n1, att_n, sigma=64.0, target_pwr=400.0):
     return max(1, int(round(np.sqrt(target_pwr / (2 * sigma * sigma)) / per_gain)))
 
 
-def chain_config(fft1_n=14, fft2_n=12, batch=256, device=0, fq_bin=None):
-    """1-channel full chain fft1 -> timf2 -> blank1 -> fft2 -> mix1 at BASELINE.json config sizes, batched."""
+def chain_config(fft1_n=14, fft2_n=12, batch=256, device=0, fq_bin=None, fft3_n=0, mix2_n=0, rounds=1):
+    """1-channel full chain fft1 -> timf2 -> blank1 -> fft2 -> mix1 (-> fft3 -> mix2 when fft3_n > 0) at BASELINE.json config
+    sizes, batched; `rounds` batches may be in flight before the narrowband side is drained (coherent-combine mode)."""
     N1, N2 = 1 << fft1_n, 1 << fft2_n
     M1 = N1 // 2
     samples_per_batch = batch * M1
@@ -34,6 +47,14 @@ def chain_config(fft1_n=14, fft2_n=12, batch=256, device=0, fq_bin=None):
         timf2_noise_floor_avgnum=avgnum, blanker_info_update_interval=max(1, avgnum // 8),
         blanker_min_points=N2 // 3, mix1_bandwidth_reduction_n=6,
         timf3_size=pow2(4 * k_fft2 * max(8, N2 >> 6) * 2), max_batch=batch)
+    if fft3_n:
+        N3, Nm, Nm2 = 1 << fft3_n, max(8, N2 >> 6), 1 << mix2_n
+        per_round = (samples_per_batch // (N2 // 2) + 2) * (Nm // 2)           # timf3 samples one batch produces
+        k_fft3 = per_round // (N3 // 2) + 2
+        cfg.fft3_n, cfg.fft3_sinpow, cfg.mix2_n = fft3_n, 2, mix2_n
+        cfg.max_fft3n = max(8, pow2(2 * k_fft3))
+        cfg.baseband_size = max(4 * Nm2, pow2(2 * max(1, rounds) * cfg.max_fft3n * (Nm2 // 2)))
+        cfg.timf3_size = max(cfg.timf3_size, pow2(2 * (2 * max(1, rounds) * per_round + 4 * N3)))
     return cfg
 
 

@@ -1287,6 +1287,17 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
       if ((rc = lro_make_fft2(c, p, kb))) return rc;
       if ((rc = lro_fft2_mix1_fixed(c, p, kb))) return rc;
+      if (c->N3 && !c->pol_set && c->ms.mix1_selfreq >= 0) {       /* do_fft3 / do_mix2 behind mix1 (fft3.c:35-60, mix2.c:41-80) */
+        const int have = (p->timf3_pa - p->timf3_px + c->cfg.timf3_size) & (c->cfg.timf3_size - 1);
+        int k3 = have < 2 * c->N3 ? 0 : 1 + (have - 2 * c->N3) / (2 * c->M3);
+        const int cap = c->cfg.max_fft3n / 2 > 0 ? c->cfg.max_fft3n / 2 : 1;
+        while (k3 > 0) {
+          const int k3b = k3 < cap ? k3 : cap;
+          if ((rc = lro_make_fft3_all(c, p, k3b))) return rc;
+          if ((rc = lro_fft3_mix2(c, p, k3b))) return rc;
+          k3 -= k3b;
+        }
+      }
       k -= kb;
     }
     nblocks -= B;

@@ -1,18 +1,25 @@
 #!/bin/bash
-# rocprofv3 evidence for one round: kernel-trace stats + PMC (FETCH_SIZE / WRITE_SIZE in separate passes).
-# usage (on the GPU box, via gpurun): scripts/profile_round.sh r01
-R=${1:-r01}
+# rocprofv3 evidence for one round: kernel-trace stats of the default bench run, and per workload the PMC passes
+# (FETCH_SIZE / WRITE_SIZE separately, never together with other trace domains).
+# usage (on the GPU box, via gpurun): scripts/profile_round.sh r02
+R=${1:-r02}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
-ARGS="--steps 10 --warmup 3 --no-cpu ${BENCH_ARGS}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/stats.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.log
-python3 bench.py --steps 50 --warmup 5 ${BENCH_ARGS} > $OUT/bench_plain.json 2> $OUT/plain.log
-find $OUT -name "*.csv" | head -20
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.log
+echo "stats pass done: $(tail -c 300 $OUT/stats.log | tr '\n' ' ')"
+pmc() {   # name, bench flags
+  local wl=$1; shift
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$wl -- python3 bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/bench_fetch_$wl.json 2> $OUT/fetch_$wl.log
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$wl -- python3 bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/bench_write_$wl.json 2> $OUT/write_$wl.log
+  echo "pmc passes of $wl done"
+}
+pmc n1_14_n2_16_n3_12_b4096 --no-secondary
+pmc n1_14_n2_12_n3_0_b4096 --fft2-n 12 --fft3-n 0
+python3 bench.py --steps 50 --warmup 5 > $OUT/bench_plain.json 2> $OUT/plain.log
 # keep the merge small: per-dispatch traces can be large
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
 python3 scripts/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*counter_collection.csv" -size +8M -delete

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Condense a scripts/profile_round.sh output directory into the summary that is committed under profiles/."""
+"""Condense a scripts/profile_round.sh output directory into the summaries that are committed under profiles/:
+   summary text on stdout; with a second argument, the machine-readable HBM traffic per stage launch and workload
+   (read by bench.py for roofline.traffic / frac_counter)."""
 import csv
 import glob
 import json
@@ -8,6 +10,21 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1]
+# stage (bench.py's HIP-event scopes) -> (anchor kernel: one dispatch per stage launch, all kernels of the stage)
+STAGE_KERNELS = {
+    "fft1": ("k_fft1<", ["k_fft1<", "k_realsplit", "k_foldcorr"]),
+    "timf2": ("k_timf2<", ["k_timf2<"]),
+    "sumsq": ("k_sumsq(", ["k_sumsq("]),
+    "sumsq_join": ("k_sumsq_join", ["k_sumsq_join"]),
+    "slowsum": ("k_slowsum", ["k_slowsum"]),
+    "blanker": ("k_blank_scan", ["k_blank_scan", "k_blank_runs_pre", "k_blank_runs(", "k_blank_serial", "k_blank_apply", "k_blank_stats", "k_blank_update"]),
+    "fft2": (("k_fft2_cols<", "k_fft2<"), ["k_fft2_cols<", "k_fft2_rows<", "k_fft2<"]),
+    "powersum2": ("k_powersum2", ["k_powersum2"]),
+    "waterfall": ("k_waterfall", ["k_waterfall"]),
+    "mix1": ("k_mix1_back<", ["k_mix1_back<", "k_mix1_out"]),
+    "fft3": ("k_fft3<", ["k_fft3<"]),
+    "mix2": ("k_mix2_back<", ["k_mix2_back<"]),
+}
 
 
 def first(pattern):
@@ -15,65 +32,71 @@ def first(pattern):
     return f[0] if f else None
 
 
-print("# rocprofv3 summary for", d)
-f = first("stats/**/*kernel_stats.csv")
-if f:
-    print("\n## kernel-trace --stats (bench.py --steps 10 --warmup 3 --no-cpu)")
-    print("%-58s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
-    for r in csv.DictReader(open(f)):
-        print("%-58s %6s %12.1f %10.2f %6s" % (r["Name"][:58], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
-                                               float(r["AverageNs"]) / 1e3, r["Percentage"]))
-for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+def counter_table(tag, ctr):
+    """kernel name -> [sum of the counter over all dispatches, dispatches]"""
     f = first(f"{tag}/**/*counter_collection.csv")
-    if not f:
-        continue
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == ctr:
-            a = acc[r["Kernel_Name"]]
-            a[0] += float(r["Counter_Value"])
-            a[1] += 1
-    print(f"\n## --pmc {ctr}: mean per dispatch (counter unit: KiB as reported by rocprofv3)")
-    for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
-        print("%-58s n=%4d mean=%14.1f" % (k[:58], n, v / n))
-for tag in ("bench_stats", "bench_plain"):
-    f = os.path.join(d, tag + ".json")
-    if os.path.exists(f):
-        try:
-            j = json.loads(open(f).read().strip().splitlines()[-1])
-            print(f"\n## {tag}: value {j['value']} {j['unit']}, ms/step {j['ms_per_step']}, roofline {j['roofline']}")
-            for k, v in j["stages"].items():
-                print("   ", k, v)
-        except Exception as e:  # noqa: BLE001
-            print(tag, "unreadable", e)
-
-# ---- machine-readable HBM traffic per launch (read by bench.py's roofline.traffic)
-if len(sys.argv) > 2:
-    per = {}
-    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        f = first(f"{tag}/**/*counter_collection.csv")
-        if not f:
-            continue
-        acc = defaultdict(lambda: [0.0, 0])
+    if f:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == ctr:
                 a = acc[r["Kernel_Name"]]
                 a[0] += float(r["Counter_Value"])
                 a[1] += 1
-        for k, (v, n) in acc.items():
-            per.setdefault(k, {})[ctr + "_KiB"] = round(v / n, 1)
-    stage_of = {"k_fft1": "fft1", "k_sumsq": "sumsq", "k_slowsum": "slowsum", "k_timf2": "timf2", "k_blank_scan": "blanker",
-                "k_fft2<": "fft2", "k_powersum2": "powersum2", "k_mix1_back": "mix1"}
+    return acc
+
+
+print("# rocprofv3 summary for", d)
+f = first("stats/**/*kernel_stats.csv")
+if f:
+    print("\n## kernel-trace --stats (python3 bench.py --steps 10 --warmup 3 --no-cpu: the default run, both workloads)")
+    print("%-58s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+    for r in csv.DictReader(open(f)):
+        print("%-58s %6s %12.1f %10.2f %6s" % (r["Name"][:58], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
+                                               float(r["AverageNs"]) / 1e3, r["Percentage"]))
+workloads = {}
+for wdir in sorted(glob.glob(os.path.join(d, "pmc_fetch_*"))):
+    wl = os.path.basename(wdir)[len("pmc_fetch_"):]
+    fetch, write = counter_table("pmc_fetch_" + wl, "FETCH_SIZE"), counter_table("pmc_write_" + wl, "WRITE_SIZE")
+    print(f"\n## workload {wl}: --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch in KiB as rocprofv3 reports them")
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch[k][0] + write[k][0])):
+        fv, fn = fetch.get(k, [0, 0]); wv, wn = write.get(k, [0, 0])
+        print("%-58s n=%4d fetch=%12.1f  n=%4d write=%12.1f" % (k.replace("void lrh::", "")[:58], fn, fv / max(fn, 1), wn, wv / max(wn, 1)))
     kernels = {}
-    for name, v in per.items():
-        for pat, stage in stage_of.items():
-            if pat in name and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
-                kernels[stage] = dict(kernel=name.split("(")[0] + "(...)", **v,
-                                      traffic_bytes_per_launch=int(2 * v["FETCH_SIZE_KiB"] * 1024 + v["WRITE_SIZE_KiB"] * 1024))
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 10 --warmup 3 --no-cpu "
-                     "(scripts/profile_round.sh)",
-           "workload": {"fft1_n": 14, "fft2_n": 12, "batch": int(os.environ.get("LRH_PROFILE_BATCH", "4096"))},
-           "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced streaming "
-                         "read, MI355X_MICROARCH.md HBM section; k_sumsq confirms it: ~67 MB reported for 134 MB read)",
-           "kernels": kernels}
+    for stage, (anchor, pats) in STAGE_KERNELS.items():
+        anchors = (anchor,) if isinstance(anchor, str) else anchor
+        nf = sum(v[1] for k, v in fetch.items() if any(a in k for a in anchors))
+        nw = sum(v[1] for k, v in write.items() if any(a in k for a in anchors))
+        if not nf or not nw:
+            continue
+        fsum = sum(v[0] for k, v in fetch.items() if any(p in k for p in pats))
+        wsum = sum(v[0] for k, v in write.items() if any(p in k for p in pats))
+        names = sorted({k.split("(")[0].replace("void lrh::", "") for k in fetch if any(p in k for p in pats)})
+        kernels[stage] = {"kernels": names, "FETCH_SIZE_KiB": round(fsum / nf, 1), "WRITE_SIZE_KiB": round(wsum / nw, 1), "stage_launches": nf,
+                          "traffic_bytes_per_launch": int(2 * fsum / nf * 1024 + wsum / nw * 1024)}
+    try:
+        bj = json.loads(open(os.path.join(d, f"bench_fetch_{wl}.json")).read().strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        bj = None
+    workloads[wl] = {"kernels": kernels, "config": bj["config"]["workload"] if bj else None}
+for tag in ("bench_stats", "bench_plain"):
+    f = os.path.join(d, tag + ".json")
+    if os.path.exists(f):
+        try:
+            j = json.loads(open(f).read().strip().splitlines()[-1])
+            print(f"\n## {tag}: value {j['value']} {j['unit']}, ms/step {j['ms_per_step']}\n   roofline {j['roofline']}")
+            for k, v in j["stages"].items():
+                print("   ", k, v)
+            if j.get("secondary"):
+                print("   secondary:", j["secondary"].get("value"), j["secondary"].get("config"), j["secondary"].get("roofline"))
+        except Exception as e:  # noqa: BLE001
+            print(tag, "unreadable", e)
+
+if len(sys.argv) > 2:
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes per workload, python3 bench.py --steps 5 "
+                     "--warmup 2 --no-cpu [workload flags] (scripts/profile_round.sh)",
+           "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced streaming read, "
+                         "MI355X_MICROARCH.md HBM section; calibrated in round 1 on k_sumsq's float2 reads: 67 MB reported for 134 MB read). "
+                         "A stage = the kernels bench.py's HIP-event scope of that name covers; per stage launch = sum over those kernels' "
+                         "dispatches / dispatches of the stage's first kernel",
+           "workloads": workloads}
     json.dump(out, open(sys.argv[2], "w"), indent=1)

@@ -34,8 +34,8 @@ def _feed(rx, iq, lim=None, fq=None):
         rx.set_mix1_selfreq(fq)
 
 
-@pytest.mark.parametrize("fft2_n,blanker", [(12, True), (16, True), (12, False)])
-def test_fullsize_chain_matches_oracle(fft2_n, blanker):
+@pytest.mark.parametrize("fft2_n,blanker,fft3_n", [(12, True, 0), (16, True, 0), (12, False, 0), (16, True, 12)])
+def test_fullsize_chain_matches_oracle(fft2_n, blanker, fft3_n):
     """48 fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (float32 tolerance 1e-5).
 
     With the blanker on, a sample whose power sits within float32 rounding of the limit may be cleared on one side
@@ -43,7 +43,10 @@ def test_fullsize_chain_matches_oracle(fft2_n, blanker):
     the rings downstream of one are then compared with a tolerance that covers the zeroed sample.  The blanker-off
     case keeps the strict tolerance everywhere."""
     from linrad_amd.lib import synth_defaults, synth_iq
-    cfg = chain_config(14, fft2_n, batch=16)
+    # fft3_n = 12: the bench's default workload (BASELINE configs[2]: fft2_size 65536 with fft3 / mix2 behind mix1, all of it
+    # inside lrh_wideband_dsp), long enough for a few fft3 transforms
+    nblk = 96 if fft3_n else 48
+    cfg = chain_config(14, fft2_n, batch=16, fft3_n=fft3_n, mix2_n=8 if fft3_n else 0, rounds=nblk // 16)
     if not blanker:
         cfg.stupid_bln_mode = 0
     s = synth_defaults(N1, 0)
@@ -51,14 +54,15 @@ def test_fullsize_chain_matches_oracle(fft2_n, blanker):
     lim = strong_liminfo(s, 14)
     fq = 0.31 * (1 << fft2_n) + 0.3
     res = []
+    rings = [(abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_PWR, "pwr"),
+             (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_TIMF3_FLOAT, "timf3"), (abi.RING_WG_WATERF, "wf")]
+    if fft3_n:
+        rings += [(abi.RING_FFT3, "fft3"), (abi.RING_BASEB_RAW, "baseb")]
     for fn in (_hip, _oracle):
         rx = fn(cfg)
         _feed(rx, iq, lim, fq)
-        rx.wideband_dsp(48, 16)
-        r = {k: rx.export(ring) for ring, k in ((abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"),
-                                                (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_PWR, "pwr"),
-                                                (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"),
-                                                (abi.RING_TIMF3_FLOAT, "timf3"), (abi.RING_WG_WATERF, "wf"))}
+        rx.wideband_dsp(nblk, 16)
+        r = {k: rx.export(ring) for ring, k in rings}
         r["p"] = rx.p.as_dict()
         r["bs"] = rx.blanker_state()
         res.append(r)
@@ -83,6 +87,9 @@ def test_fullsize_chain_matches_oracle(fft2_n, blanker):
     for k in ("fft2", "ps2"):
         assert _relerr(h[k], o[k]) < 1e-5 * loose, k
     assert _relerr(h["timf3"], o["timf3"]) < 2e-5 * loose
+    if fft3_n:
+        assert o["p"]["baseb_pa"] > 0 and np.count_nonzero(o["baseb"]) > 100
+        assert _relerr(h["fft3"], o["fft3"]) < 2e-5 * loose and _relerr(h["baseb"], o["baseb"]) < 2e-5 * loose
     d = np.abs(h["wf"].astype(int) - o["wf"].astype(int))
     assert d.max() <= (2 if loose == 1 else 200) and (d != 0).mean() < 0.05
 
@@ -185,12 +192,13 @@ def test_stream_schedules_are_bit_identical(fft2_n, monkeypatch):
     """LRH_PIPELINE 0 (serial), 1 (two streams) and 2 (blanker / fft2 / mix1 one round behind) only reorder launches:
     every ring, pointer and the blanker state must come out bit for bit the same, over two consecutive calls."""
     from linrad_amd.lib import synth_defaults, synth_iq
-    cfg = chain_config(14, fft2_n, batch=16)
+    # fft2_size 65536: with fft3 / mix2 behind mix1 (the bench's default workload), whose launches are parked with fft2 / mix1
+    cfg = chain_config(14, fft2_n, batch=16, fft3_n=12 if fft2_n == 16 else 0, mix2_n=8 if fft2_n == 16 else 0, rounds=4)
     s = synth_defaults(N1, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     lim = strong_liminfo(s, 14)
     rings = (abi.RING_FFT1_SUMSQ, abi.RING_FFT1_SLOWSUM, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT,
-             abi.RING_FFT2_POWERSUM, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF)
+             abi.RING_FFT2_POWERSUM, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF) + ((abi.RING_FFT3, abi.RING_BASEB_RAW) if fft2_n == 16 else ())
     res = []
     for mode in ("0", "1", "2"):
         monkeypatch.setenv("LRH_PIPELINE", mode)

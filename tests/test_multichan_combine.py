@@ -14,7 +14,7 @@ from refcases import case_params, lrh_config, make_input, make_liminfo
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NCH = 4
-PHASE = [0.0, 0.9, -1.7, 2.4]
+PHASE = [0.0, 0.9, -1.7, 2.4, 0.35, -2.6, 1.55, -0.8]       # sky phase per channel (up to the 8 of BASELINE configs[4])
 
 
 def _channel_input(d, ch):
@@ -66,12 +66,12 @@ def _drive(rxs, d, combine):
                 rx.fft3_mix2(k3)
 
 
-def _check(open_fn, tol):
+def _check(open_fn, tol, NCH=NCH):
     d = case_params("n10_n12_fft3")
     d["nblk"] = 72
     # the chain conjugates its input: a sky phase +p arrives in the baseband as -p, so e^{+jp} aligns it
-    w = [np.exp(1j * p) / NCH for p in PHASE]                       # phase-aligning weights: the array's beam on the source
-    w2 = [np.exp(1j * p + 2j * np.pi * c / NCH) / NCH for c, p in enumerate(PHASE)]    # second beam: a null on the source
+    w = [np.exp(1j * p) / NCH for p in PHASE[:NCH]]                 # phase-aligning weights: the array's beam on the source
+    w2 = [np.exp(1j * p + 2j * np.pi * c / NCH) / NCH for c, p in enumerate(PHASE[:NCH])]    # second beam: a null on the source
     single = [_open(open_fn, d, ch) for ch in range(NCH)]
     _drive(single, d, combine=False)
     base = [rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128) for rx in single]
@@ -94,10 +94,23 @@ def test_oracle_four_channel_coherent_combine():
     _check(open_oracle, 2e-6)
 
 
+def test_oracle_eight_channel_coherent_combine():
+    """BASELINE configs[4] has eight receivers"""
+    from oracle_binding import open_oracle
+    _check(open_oracle, 2e-6, 8)
+
+
 @pytest.mark.gpu
 def test_hip_four_channel_coherent_combine():
     from linrad_amd.lib import open_hip
     _check(open_hip, 2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_eight_channel_coherent_combine():
+    """eight contexts on one GPU, the all-reduce by hand: BASELINE configs[4]'s channel count through the HIP path"""
+    from linrad_amd.lib import open_hip
+    _check(open_hip, 2e-5, 8)
 
 
 def _worker(rank, world, port, q):
@@ -141,3 +154,76 @@ def test_three_rank_combine_over_gloo():
         assert p.exitcode == 0
     assert np.count_nonzero(res[0]) > 100
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
+def _worker8(rank, world, port, q):
+    """one rank of the bench's configs[4] mode: lrh_wideband_dsp-style driving (the oracle's wideband_dsp leaves the narrowband
+    side to the caller once combine weights are set), then fft3 / all-reduce of the weighted mix2 bins / mix2"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from linrad_amd.multichan import coupled_fft3_mix2
+    from oracle_binding import open_oracle
+    import test_multichan_combine as t
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = case_params("n10_n12_fft3")
+    d["nblk"] = 48
+    rx = t._open(open_oracle, d, rank, (np.exp(1j * PHASE[rank]) / world, np.exp(1j * PHASE[rank] + 2j * np.pi * rank / world) / world))
+    for _ in range(d["nblk"] // 4):
+        rx.wideband_dsp(4, 1)
+        k3 = rx.fft3_available()
+        while k3 > 0:
+            k3b = min(k3, max(1, rx.cfg.max_fft3n // 2))
+            rx.make_fft3_all(k3b)
+            coupled_fft3_mix2(rx, k3b, dist)
+            k3 -= k3b
+    out = rx.export(abi.RING_BASEB_RAW)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_eight_rank_combine_over_gloo():
+    """world_size 8 (BASELINE configs[4]): every rank ends with the same beam, and it is the weighted sum of the eight
+    single-channel basebands"""
+    import torch.multiprocessing as mp
+    from oracle_binding import open_oracle
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.count_nonzero(res[0]) > 100
+    for r in range(1, world):
+        assert np.array_equal(res[0], res[r])
+    d = case_params("n10_n12_fft3")
+    d["nblk"] = 48
+    single = [_open(open_oracle, d, ch) for ch in range(world)]
+    for rx in single:
+        rx.wideband_dsp(d["nblk"], 1)                          # no weights set: the narrowband side runs inside
+    want = sum(np.exp(1j * PHASE[ch]) / world * rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128)
+               for ch, rx in enumerate(single))
+    got = res[0].astype(np.float64).view(np.complex128)
+    assert np.linalg.norm(got - want) <= 2e-6 * np.linalg.norm(want)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` by hand starts two rank processes itself (the flag was parsed and ignored); without
+    GPUs they fail, and the launcher says so and exits non-zero instead of reporting a one-rank run"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the run would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "started 2 ranks" in r.stderr and "rank 1" in r.stderr
+    assert '"n_gpus"' not in r.stdout
