@@ -124,6 +124,8 @@ def cpu_reference(args, w, threads=0):
             r = json.loads(out.strip().splitlines()[-1])
         except Exception:  # noqa: BLE001
             return None
+    if threads and "threads" not in r:                     # a harness without the thread topology: nothing to report
+        return None
     dt = r["loop_seconds"]
     stages = "fft1_b, fft1_c, make_timf2, first_noise_blanker, make_fft2, fft2_mix1_fixed" + (", make_fft3_all, fft3_mix2" if w["fft3_n"] else "")
     cores = int(r.get("threads", 1))

@@ -67,7 +67,7 @@ int main(int argc, char **argv)
     done += chunk;
     /* ---- wideband_dsp: one block at a time while a full block is available (wcw.c:940-1047) ---- */
     while (((timf1p_pa - p.timf1p_px + cfg.timf1_bytes) & (cfg.timf1_bytes - 1)) >= timf1_blockbytes) {
-      if ((rc = lrh_fft1_b(rx, p.timf1p_px, p.fft1_pa, 1))) goto fail;
+      if ((rc = lrh_fft1_b(rx, 0, p.timf1p_px, p.fft1_pa, 1))) goto fail;
       p.timf1p_px = (p.timf1p_px + timf1_blockbytes) & (cfg.timf1_bytes - 1);
       p.fft1_pa = (p.fft1_pa + 2 * N1) & (cfg.max_fft1n * 2 * N1 - 1);
       p.fft1_na = p.fft1_pa / (2 * N1);

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 1
+#define LRH_ABI_VERSION 2      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread */
 
 enum {
   LRH_OK = 0,
@@ -239,12 +239,30 @@ int lrh_host_unregister(lrh_ctx *ctx, void *ptr);
    Needs timf1_dword_input = 1.  The expansion runs on the device; only the packed bytes cross PCIe. */
 int lrh_timf1_write_packed18(lrh_ctx *ctx, const void *src, int byte_offset, int packed_bytes);
 
+/* ---- threading ----
+   Linrad calls the stage functions from its stage threads: wideband_dsp (or up to six fft1_b workers, wcw.c:476-500),
+   timf2_routine (fft1_c, make_timf2, first_noise_blanker; wcw.c:401-441), second_fft (make_fft2; wcw.c:250-304) and
+   narrowband_dsp (fft2_mix1_*; wcw.c:1240-1405), ordered by its events EVENT_TIMF1 / TIMF2 / FFT2 / FFT1_READY
+   (thrdef.h:136-170).  Every entry point of this library may be called from any host thread at any time: a context
+   serialises its callers for the microseconds a call needs to do its pointer bookkeeping and enqueue its device work,
+   and the device executes the work in the order of the calls.  So the reference's event order is all a caller has to
+   keep, exactly as for the CPU functions; a stage call has "completed" for that purpose when it returns (its writes
+   are stream-ordered ahead of everything enqueued later).  One lrh_ptrs may be shared by the threads like the
+   reference's globals are -- each stage advances only its own fields -- or each thread may keep the fields it owns.
+   examples/lrh_threads.c drives a context this way. */
+
 /* ---- stages ---- */
 /* fft1_b (fft1def.h:363; fft1.c:3302, mode 7 semantics fft1.c:413-447 + fft0.c:161 + fft1.c:637) for `batch`
    consecutive blocks; block i reads at timf1p_ref + i*timf1_blockbytes and writes transform
    (fft1_pa/fft1_block + i) & fft1n_mask. The filter correction of fft1_c (fft1.c:4119-4127) is applied
-   in the store epilogue. The caller advances timf1p_px / fft1_pa / fft1_na as wcw.c:1036-1047. */
-int lrh_fft1_b(lrh_ctx *ctx, int timf1p_ref, int fft1_pa, int batch);
+   in the store epilogue. The caller advances timf1p_px / fft1_pa / fft1_na as wcw.c:1036-1047.
+   `handle` is the reference's gpu_handle_number (fft1.c:3302, wcw.c:500): 0 for the caller's own thread
+   (no_of_fft1b == 0, wcw.c:1036), 1..6 for the workers THREAD_FFT1B1..6 (MAX_FFT1_THREADS, thrdef.h:107).  A worker handle
+   has its own HIP stream, so transforms handed to different workers overlap on the device like the reference's
+   workers overlap on CPU cores; the next reader of fft1_float (lrh_fft1_c, lrh_make_timf2, lrh_fft1_mix1_*, lrh_export)
+   waits for them on the device.  The dispatcher retires workers in order before it advances fft1_pa
+   (wcw.c:1005-1032); here a worker call returns as soon as its launch is enqueued. */
+int lrh_fft1_b(lrh_ctx *ctx, int handle, int timf1p_ref, int fft1_pa, int batch);
 /* fft1_c (fft1def.h:364; fft1.c:4085-4524): power accumulation into fft1_sumsq, slow average
    (update_fft1_slowsum fft1.c:4526-4605 + new_fft1_averages wide_graph.c:1003-1052), fft1_nb/pb advance. */
 int lrh_fft1_c(lrh_ctx *ctx, lrh_ptrs *p, int batch);

@@ -168,7 +168,7 @@ class StageAPI:
             self._proto("timf1_write_wait", [vp])
             self._proto("host_register", [vp, vp, C.c_size_t])
             self._proto("host_unregister", [vp, vp])
-        self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int])
+        self._proto("fft1_b", [vp, C.c_int, C.c_int, C.c_int, C.c_int])
         for n in ("fft1_c", "make_timf2", "make_fft2", "fft2_mix1_fixed", "fft1_mix1_fixed", "make_fft3_all", "fft3_mix2"):
             self._proto(n, [vp, C.POINTER(LrhPtrs), C.c_int])
         for n in ("fft2_mix1_afc", "fft1_mix1_afc"):
@@ -359,10 +359,11 @@ class StageAPI:
                                                   int(packed.nbytes)), "timf1_write_packed18")
 
     # ---- stages (names = reference functions)
-    def fft1_b(self, batch=1):
-        """fft1_b for `batch` blocks, then the caller-side pointer advance of wcw.c:1036-1047."""
+    def fft1_b(self, batch=1, handle=0):
+        """fft1_b for `batch` blocks (handle = gpu_handle_number: 0 own thread, 1..6 worker), then the caller-side pointer
+        advance of wcw.c:1036-1047."""
         p = self.p
-        self._chk(self._f("fft1_b")(self.ctx, p.timf1p_px, p.fft1_pa, batch), "fft1_b")
+        self._chk(self._f("fft1_b")(self.ctx, handle, p.timf1p_px, p.fft1_pa, batch), "fft1_b")
         block = 2 * self.N1
         p.timf1p_px = (p.timf1p_px + batch * self.timf1_blockbytes) & (self.cfg.timf1_bytes - 1)
         p.fft1_pa = (p.fft1_pa + batch * block) & (self.cfg.max_fft1n * block - 1)

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <mutex>
 
 #include "../../include/linrad_hip.h"
 #include "lrh_kernels.hip.h"
@@ -49,11 +50,19 @@ using namespace lrh;
 #define FFT2_WATERFALL_ZERO 0.012
 #define LRH_NSTAGE 4
 #define LRH_BLN_PARTIALS 256
+#define LRH_MAX_HANDLES 6          /* MAX_FFT1_THREADS, thrdef.h:107: THREAD_FFT1B1..6 call fft1_b with gpu_handle_number = i (wcw.c:500) */
 
 struct ProfEntry { double ms = 0; long n = 0; };
 struct ProfPending { std::string name; hipEvent_t e0, e1; };
 
 struct lrh_ctx {
+  // Linrad calls the stage functions from its stage threads (wideband_dsp and up to six fft1_b workers, timf2_routine,
+  // second_fft, narrowband_dsp; thrdef.h:49-107): every entry point takes this lock while it does its bookkeeping and
+  // enqueues its device work.  The work itself is asynchronous, so the lock is held for microseconds; device-side order
+  // is the order of the calls (one main stream), which the caller's events already make the reference's order.
+  std::recursive_mutex mtx;
+  // fft1_b workers: handle h >= 1 launches on its own stream so that transforms of different workers overlap
+  hipStream_t hstream[LRH_MAX_HANDLES] = {}; hipEvent_t hev[LRH_MAX_HANDLES] = {}, hev_start = nullptr; bool hpending[LRH_MAX_HANDLES] = {}, hread[LRH_MAX_HANDLES] = {};
   lrh_config cfg;
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
@@ -101,7 +110,7 @@ struct lrh_ctx {
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
-  std::string err;
+  char err[256] = "";
   // device tables
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
   float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
@@ -138,11 +147,11 @@ struct lrh_ctx {
 
 static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 {
-  char buf[256];
-  snprintf(buf, sizeof buf, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
-  if (c) c->err = buf;
+  if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
   return code;
 }
+// entry of an API call: the context's lock (see lrh_ctx::mtx) and its device for this host thread
+#define LRH_ENTER(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); hipSetDevice((c)->cfg.device); }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
 // Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
@@ -297,6 +306,8 @@ void lrh_close(lrh_ctx *c)
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
   if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
+  for (int h = 0; h < LRH_MAX_HANDLES; h++) { if (c->hstream[h]) { hipStreamSynchronize(c->hstream[h]); hipStreamDestroy(c->hstream[h]); } if (c->hev[h]) hipEventDestroy(c->hev[h]); }
+  if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
@@ -321,7 +332,7 @@ void lrh_close(lrh_ctx *c)
   delete c;
 }
 
-const char *lrh_last_error(const lrh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *lrh_last_error(const lrh_ctx *c) { return c ? c->err : "null context"; }
 
 int lrh_open(const lrh_config *cfg, lrh_ctx **out)
 {
@@ -570,7 +581,7 @@ static int upload_filtercorr(lrh_ctx *c)
 
 int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
   return upload_filtercorr(c);
@@ -578,7 +589,7 @@ int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 
 int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   c->ch2_c1 = c1; c->ch2_c2 = c2;
   return upload_filtercorr(c);
@@ -586,7 +597,7 @@ int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
 
 int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !liminfo) return LRH_EINVAL;
   // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
   const int R0 = c->cfg.fft1_n >= 10 ? 16 : 4;        // first-pass radix of the N1 transform (lrh_fft.hip.h)
@@ -612,7 +623,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 
 int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (y) c->h_yfac.assign(y, y + c->N1); else default_yfac(c);
   HIPCHK(c, hipMemcpyAsync(c->d_yfac, c->h_yfac.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
@@ -622,6 +633,7 @@ int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
 
 int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
 {
+  LRH_ENTER(c);
   if (!c || !name || !dst) return LRH_EINVAL;
   const std::vector<float> *src = nullptr;
   if (!strcmp(name, "fft1_window")) src = &c->h_window1_ref;
@@ -639,7 +651,7 @@ int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
 
 int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
@@ -653,7 +665,7 @@ void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
@@ -661,6 +673,7 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
   // the fft1 launches already enqueued may still read the ring span being overwritten: the copy goes behind the last of
   // them (the event lrh_fft1_b records), not behind the rest of the chain
   if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read, 0));
+  for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h]) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));
   HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
   if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
   HIPCHK(c, hipEventRecord(c->ev_in, c->stream_in));
@@ -670,28 +683,28 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 int lrh_timf1_write_wait(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
   return LRH_OK;
 }
 int lrh_host_register(lrh_ctx *c, void *ptr, size_t bytes)
 {
   if (!c || !ptr || !bytes) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
   return LRH_OK;
 }
 int lrh_host_unregister(lrh_ctx *c, void *ptr)
 {
   if (!c || !ptr) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   HIPCHK(c, hipHostUnregister(ptr));
   return LRH_OK;
 }
 
 int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_bytes)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !src || packed_bytes < 0 || packed_bytes % 9 || (off & 15)) return LRH_EINVAL;
   if (!c->cfg.timf1_dword_input) return fail(c, LRH_ESTATE, "timf1_write_packed18 needs timf1_dword_input");
   if ((long long)packed_bytes / 9 * 16 > c->cfg.timf1_bytes) return LRH_EINVAL;
@@ -709,11 +722,35 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
 }
 
 // ---------------------------------------------------------------------------------------------- fft1
-int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
+// Transforms launched by fft1_b workers on their own streams: whoever reads fft1_float next on the main stream waits for them.
+static int join_handles(lrh_ctx *c)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
-  if (!c || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  if (c->in_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0)); c->in_pending = false; }   // samples of lrh_timf1_write_async
+  for (int h = 1; h < LRH_MAX_HANDLES; h++)
+    if (c->hpending[h]) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->hev[h], 0)); c->hpending[h] = false; }
+  return LRH_OK;
+}
+
+int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
+{
+  LRH_ENTER(c);
+  if (!c || batch < 1 || batch > c->cfg.max_batch || handle < 0 || handle >= LRH_MAX_HANDLES) return LRH_EINVAL;
+  // handle 0: the caller's own thread (no_of_fft1b == 0, wcw.c:1036), on the main stream.  handle h >= 1: worker THREAD_FFT1Bh
+  // (wcw.c:476-500), on its own stream -- behind everything already enqueued on the main stream (the earlier readers of the
+  // ring slots it overwrites, the previous lap) and ahead of the next reader of fft1_float (join_handles).
+  hipStream_t const keep_cur = c->cur;
+  struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep_cur};
+  if (handle > 0) {
+    if (c->rec) return fail(c, LRH_ESTATE, "fft1_b workers cannot run inside lrh_wideband_dsp");
+    if (!c->hstream[handle]) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->hstream[handle], hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->hev[handle], hipEventDisableTiming));
+      if (!c->hev_start) HIPCHK(c, hipEventCreateWithFlags(&c->hev_start, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->hev_start, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->hev_start, 0));
+    if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->ev_in, 0));      // every worker waits for the producer's copy
+    c->cur = c->hstream[handle];
+  } else if (c->in_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0)); c->in_pending = false; }   // samples of lrh_timf1_write_async
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;       // bytes per complex sample (fft1.c:420 / :526)
@@ -745,18 +782,20 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
       fprintf(stderr, "\n");
     }
   }
-  if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
+  if (handle == 0 && c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
   if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
     RealSplitArgs r;
     r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;
     HIPCHK(c, launch_realsplit(r, batch, c->cur));
-    return LRH_OK;
-  }
-  if (c->d_foldcorr) {
+  } else if (c->d_foldcorr) {
     FoldcorrArgs f;
     f.spec = c->d_fft1; f.first_nb = a.first_nb; f.nb_mask = a.nb_mask; f.n = c->N1;
     f.foldcorr = c->d_foldcorr; f.filtercorr = c->d_filtercorr; f.direction = c->cfg.fft1_direction;
     HIPCHK(c, launch_foldcorr(f, batch, c->cur));
+  }
+  if (handle > 0) {                                         // the worker's transforms: awaited by the next reader of fft1_float and by the producer
+    HIPCHK(c, hipEventRecord(c->hev[handle], c->cur));
+    c->hpending[handle] = true; c->hread[handle] = true;
   }
   return LRH_OK;
 }
@@ -764,7 +803,7 @@ int lrh_fft1_b(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
 {
   if (!c) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
   if (!fc) { if (c->d_foldcorr) hipFree(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
   if (c->cfg.timf1_real_input) return fail(c, LRH_ESTATE, "no I/Q mirror image with real samples (init_foldcorr is I/Q only, buf.c:1461)");
@@ -782,8 +821,9 @@ int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
 // fft1_c: power sums (fft1.c:4115-4171), counters (fft1.c:4507-4523), slow average (fft1.c:4526-4605)
 int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }
   const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
   if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
     return fail(c, LRH_EINVAL, "fft1_sumsq ring too short for this batch");
@@ -822,8 +862,9 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 // ---------------------------------------------------------------------------------------------- timf2
 int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
   a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
@@ -866,7 +907,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 // ---------------------------------------------------------------------------------------------- blanker
 int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   const int mask = c->timf2pow_mask;
   const int pbeg = p->timf2p_fit;
@@ -911,7 +952,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 // ---- two coupled RF channels: see include/linrad_hip.h
 int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !p || !count) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int mask = c->timf2pow_mask, pbeg = p->timf2p_fit;
@@ -926,7 +967,7 @@ int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
 }
 int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2 || !c->fin_pending) return fail(c, LRH_ESTATE, "no coupled blanker call to finish");
   c->fin_pending = false;
@@ -946,13 +987,14 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
 }
 int lrh_exchange_ptr(lrh_ctx *c, int which, void **device_ptr)
 {
+  LRH_ENTER(c);
   if (!c || !device_ptr) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   *device_ptr = q; return LRH_OK;
 }
 int lrh_exchange_read(lrh_ctx *c, int which, float *dst, size_t off, size_t count)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !dst) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   if (off + count > cap) return LRH_EINVAL;
@@ -962,7 +1004,7 @@ int lrh_exchange_read(lrh_ctx *c, int which, float *dst, size_t off, size_t coun
 }
 int lrh_exchange_write(lrh_ctx *c, int which, const float *src, size_t off, size_t count)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !src) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   if (off + count > cap) return LRH_EINVAL;
@@ -973,7 +1015,7 @@ int lrh_exchange_write(lrh_ctx *c, int which, const float *src, size_t off, size
 
 int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !st) return LRH_EINVAL;
   BlankState bs;
   HIPCHK(c, hipMemcpyAsync(&bs, c->d_bst, sizeof bs, hipMemcpyDeviceToHost, c->stream));
@@ -989,7 +1031,7 @@ int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
 // ---------------------------------------------------------------------------------------------- fft2
 int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   const int N = c->N2;
   Fft2Args a;
@@ -1048,7 +1090,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
 // Two coupled channels (include/linrad_hip.h): the new transforms of the own channel go to their slot of LRH_X_BINS ...
 int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !at || !count || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int N = c->N2, na = at->fft2_na & c->fft2n_mask;
@@ -1065,7 +1107,7 @@ int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
 // within the batch (fft2.c:1622-1640, 1700-1815)
 int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !at || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int N = c->N2;
@@ -1091,8 +1133,8 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 }
 
 // ---------------------------------------------------------------------------------------------- mix1
-int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
-int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
+int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { LRH_ENTER(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
+int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { LRH_ENTER(c); if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
 
 // set_mix1_phases, mix1.c:781-861 (float branch; the double branch belongs to correlation mode)
 static int set_mix1_phases(lrh_ctx *c, float fq)
@@ -1160,6 +1202,7 @@ static void afc_tables(lrh_ctx *c, lrh_afc *a, int nx, int na, int mask)
 static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi,
                     lrh_afc *afc = nullptr, int na = 0)
 {
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }
   const int Nm = c->Nm, overlap = c->Im != 0, half = c->Mm, block2 = c->Mm;     // block in complex samples = rotated samples per transform
   lrh_mix1_state *s = &c->ms;
   const int selected = s->mix1_selfreq >= 0;
@@ -1247,7 +1290,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
 
 int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_fixed needs second_fft_enable");
   int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
@@ -1260,7 +1303,7 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 
 int lrh_fft2_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_afc needs second_fft_enable");
   if (c->ms.mix1_selfreq < 0) return fail(c, LRH_ESTATE, "fft2_mix1_afc needs a selected frequency");
@@ -1274,7 +1317,7 @@ int lrh_fft2_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
 
 int lrh_fft1_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_afc needs second_fft_enable == 0");
   if (c->ms.mix1_selfreq < 0) return fail(c, LRH_ESTATE, "fft1_mix1_afc needs a selected frequency");
@@ -1287,7 +1330,7 @@ int lrh_fft1_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
 
 int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_fixed needs second_fft_enable == 0");
   int rc = mix1_run(c, p, batch, c->d_fft1, c->N1, (p->fft1_px / (2 * c->N1)) & c->fft1n_mask, c->fft1n_mask, c->N1 - 1);   // mix1.c:1017-1019
@@ -1302,7 +1345,7 @@ int lrh_set_bg_filterfunc(lrh_ctx *c, const float *f)
 {
   if (!c || !f) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   HIPCHK(c, hipMemcpyAsync(c->d_bgfilt, f, 4 * c->N3, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
@@ -1313,7 +1356,7 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   Fft3Args a;
   a.timf3 = c->d_timf3; a.mask = c->cfg.timf3_size / 2 - 1; a.px_first = p->timf3_px / 2; a.step = c->M3;
   a.window = c->d_window3; a.tw = c->d_tw3; a.out = c->d_fft3;
@@ -1328,6 +1371,7 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
 // two coupled channels (include/linrad_hip.h): polarisation transform of fft3_mix2, mix2.c:340-343, 377-380
 int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
 {
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   if ((c->cfg.timf1_channel_index & 1) == 0) { c->pol_wa = make_float2(c1, 0.f); c->pol_wb = make_float2(-c2, -c3); }   // A += c1 X,          B -= (c2 + j c3) X
@@ -1337,6 +1381,7 @@ int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
 }
 int lrh_set_combine_weights(lrh_ctx *c, float wa_re, float wa_im, float wb_re, float wb_im)
 {
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
   c->pol_wa = make_float2(wa_re, wa_im); c->pol_wb = make_float2(wb_re, wb_im); c->pol_set = true;
@@ -1348,7 +1393,7 @@ int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
   if (!c->N3 || !c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (!c->pol_set) return fail(c, LRH_ESTATE, "lrh_set_pol / lrh_set_combine_weights first");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   PolArgs a;
   a.fft3 = c->d_fft3; a.n3 = c->N3; a.first_slot = p->fft3_px / (2 * c->N3); a.slot_mask = c->cfg.max_fft3n - 1; a.nm = c->Nm2; a.batch = batch;
   a.wa = c->pol_wa; a.wb = c->pol_wb;
@@ -1364,7 +1409,7 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   const bool pol = c->pol_set;
   if (pol && c->pol_batch != batch) return fail(c, LRH_ESTATE, "lrh_mix2_pol_begin and the all-reduce come first");
   c->pol_batch = 0;
@@ -1390,7 +1435,7 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
 // compute_timf2_powersum, wcw.c:80-138
 int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   const int blk = c->cfg.timf2_blockpower_block;
   if (blk <= 0 || (blk & 3)) return fail(c, LRH_ESTATE, "timf2_blockpower_block not configured");
@@ -1464,7 +1509,7 @@ static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side poin
 int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "two coupled channels need the exchanges between the stage calls (lrh_blanker_begin)");
   struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double cpu0 = thread_cpu_ms();
                      static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -1492,7 +1537,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   if (!piped) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
-      if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+      if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
       advance_fft1(c, p, B);
       if ((rc = c->cfg.second_fft_enable ? sums(B) : lrh_fft1_c(c, p, B))) return rc;
       if (!c->cfg.second_fft_enable) {           // wcw.c:1049-1081: fft1_c, then the narrowband side's fft1_mix1_fixed
@@ -1533,7 +1578,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     int left = nblocks, round = 0;
     int B = left < batch ? left : batch;
     bool have_prev = false, tail_flushed = false;
-    on(S1); if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+    on(S1); if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
     advance_fft1(c, p, B);
     HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
     auto side_blanker = [&]() -> int {        // blanker(k-1): after timf2(k-1) wrote and fft2(k-2) read its neighbourhood
@@ -1569,7 +1614,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if (Bnext > 0) {
         on(S1);
         if (round >= 1) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_sumsq[(round + 1) & 1], 0));
-        if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
+        if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
         advance_fft1(c, p, Bnext);
         HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
       }
@@ -1589,7 +1634,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   int left = nblocks, round = 0;
   int B = left < batch ? left : batch;
   // prologue: fft1(0) on the main stream, its sums on the side stream
-  on(S1); if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+  on(S1); if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
   advance_fft1(c, p, B);
   HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
   on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0));
@@ -1609,7 +1654,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       // main: fft1(k+1) once the sums of round k-1 (which read the ring slots it overwrites) are done
       on(S1);
       if (round >= 1) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_sumsq[(round + 1) & 1], 0));
-      if ((rc = lrh_fft1_b(c, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
+      if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
       advance_fft1(c, p, Bnext);
       HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
       // side: sumsq/slowsum(k+1)
@@ -1639,7 +1684,8 @@ int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t c
 static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait)
 {
   if (!c || !dst) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }
   const void *src; size_t esz = 4, total;
   switch (ring) {
     case LRH_RING_TIMF1: src = c->d_timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;
@@ -1684,7 +1730,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
 
 int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float gain, float strong)
 {
-  if (c) hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   if (!c || !dst || count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
   if (!count) return LRH_OK;
   if ((size_t)count > c->net_cap) {
@@ -1701,16 +1747,17 @@ int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float 
 int lrh_sync(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;
-  hipSetDevice(c->cfg.device);
+  LRH_ENTER(c);
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
   for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2 }) if (s) HIPCHK(c, hipStreamSynchronize(s));
+  for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
   return LRH_OK;
 }
 
-int lrh_timer_start(lrh_ctx *c) { if (c) hipSetDevice(c->cfg.device); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
+int lrh_timer_start(lrh_ctx *c) { LRH_ENTER(c); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
 int lrh_timer_stop(lrh_ctx *c, float *ms)
 {
-  if (c) hipSetDevice(c->cfg.device);   // calls may come from any host thread
+  LRH_ENTER(c);
   if (!c || !ms) return LRH_EINVAL;
   HIPCHK(c, hipEventRecord(c->t1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->t1));
@@ -1719,12 +1766,14 @@ int lrh_timer_stop(lrh_ctx *c, float *ms)
 }
 int lrh_profile_enable(lrh_ctx *c, int on)
 {
+  LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   prof_collect(c); c->prof = on != 0; c->prof_keep_schedule = on == 2; c->prof_tot.clear();
   return LRH_OK;
 }
 int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *launches)
 {
+  LRH_ENTER(c);
   if (!c || !kernel) return LRH_EINVAL;
   if (!strcmp(kernel, "host:mix1_phases")) { if (total_ms) *total_ms = c->host_ms_phases; if (launches) *launches = c->host_n_phases; return LRH_OK; }
   if (!strcmp(kernel, "host:staging_wait")) { if (total_ms) *total_ms = c->host_ms_wait; if (launches) *launches = c->host_n_dsp; return LRH_OK; }

@@ -495,8 +495,9 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
   }
 }
 
-int lro_fft1_b(lro_ctx *c, int timf1p_ref, int fft1_pa, int batch)
+int lro_fft1_b(lro_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
 {
+  (void)handle;                                /* gpu_handle_number: which worker thread calls (fft1.c:3302); no meaning on the CPU */
   int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4);
   for (int b = 0; b < batch; b++) {
     int nb = ((fft1_pa / (2 * c->N1)) + b) & c->fft1n_mask;
@@ -1267,7 +1268,7 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   int rc;
   while (nblocks > 0) {
     int B = nblocks < batch ? nblocks : batch;
-    if ((rc = lro_fft1_b(c, p->timf1p_px, p->fft1_pa, B))) return rc;
+    if ((rc = lro_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
     p->timf1p_px = (p->timf1p_px + B * c->M1 * (c->cfg.timf1_dword_input ? 8 : 4)) & c->timf1_bytemask;
     p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
     p->fft1_na = p->fft1_pa / (2 * c->N1);
