@@ -42,18 +42,22 @@ static void lir_await_event(int n)
   pthread_mutex_unlock(&ev_mutex[n]);
 }
 
+/* a failed stage ends the run (lirerr posts EVENT_KILL_ALL and every loop polls kill_all_flag, lxsys.c:494-505): wake everybody */
+static volatile int failed;
+static void fail_all(void) { failed = 1; for (int i = 0; i < NEVENTS; i++) lir_set_event(i); }
+
 /* ---- the "globals" ---- */
 static lrh_ctx *rx;
 static lrh_config cfg;
 static volatile lrh_ptrs p;                  /* shared like the reference's pointer globals; volatile like thrdef.h's flags */
 static volatile int timf1p_pa;               /* producer pointer, bytes (rxin.c) */
 static volatile int input_done, wide_done, timf2_done, fft2_done;
-static volatile int failed;
 static int N1, N2, M1, M2, timf1_blockbytes, nblk_total, workers;
 static char *timf1_char;
 static lrh_synth sig;
 #define P ((lrh_ptrs *)&p)
-#define CHK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: rc=%d (%s)\n", #call, rc_, lrh_last_error(rx)); failed = 1; } } while (0)
+static void fail_all(void);
+#define CHK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: rc=%d (%s)\n", #call, rc_, lrh_last_error(rx)); fail_all(); } } while (0)
 
 static int timf1_avail(void) { return (timf1p_pa - p.timf1p_px + cfg.timf1_bytes) & (cfg.timf1_bytes - 1); }
 static int fft2_ready(void) { return ((p.timf2_pn2 - p.timf2_px + 4 * cfg.timf2pow_size) & (4 * cfg.timf2pow_size - 1)) >= 4 * N2; }   /* wcw.c:265 */
@@ -91,7 +95,7 @@ static void *fft1b_thread(void *arg)
   const int k = (int)(long)arg;
   for (;;) {
     lir_await_event(EVENT_DO_FFT1B1 + k);
-    if (job[k].busy < 0) return NULL;
+    if (job[k].busy < 0 || failed) return NULL;
     CHK(lrh_fft1_b(rx, k + 1, job[k].inptr, job[k].out, 1));      /* gpu_handle_number = worker number (wcw.c:500) */
     job[k].busy = 2;                                               /* finished: the dispatcher retires it in order */
     lir_set_event(EVENT_FFT1B_DONE);
@@ -122,9 +126,9 @@ static void *wideband_thread(void *arg)
       lir_set_event(EVENT_DO_FFT1B1 + next);
       next = (next + 1) % workers; inflight++;
     }
-    if (input_done && timf1_avail() < timf1_blockbytes) break;
+    if (failed || (input_done && timf1_avail() < timf1_blockbytes)) break;
   }
-  while (inflight > 0) { retire(oldest); oldest = (oldest + 1) % workers; inflight--; }
+  while (inflight > 0 && !failed) { retire(oldest); oldest = (oldest + 1) % workers; inflight--; }
   for (int k = 0; k < workers; k++) { job[k].busy = -1; lir_set_event(EVENT_DO_FFT1B1 + k); }
   wide_done = 1;
   lir_set_event(EVENT_TIMF2);
@@ -144,7 +148,7 @@ static void *timf2_thread(void *arg)
       if (fft2_ready()) lir_set_event(EVENT_FFT2);
       lir_set_event(EVENT_SPACE);
     }
-    if (wide_done && p.fft1_na == p.fft1_nb) break;
+    if (failed || (wide_done && p.fft1_na == p.fft1_nb)) break;
   }
   timf2_done = 1;
   lir_set_event(EVENT_FFT2);
@@ -162,7 +166,7 @@ static void *fft2_thread(void *arg)
       lir_set_event(EVENT_FFT1_READY);
       lir_set_event(EVENT_SPACE);
     }
-    if (timf2_done && !fft2_ready()) break;
+    if (failed || (timf2_done && !fft2_ready())) break;
   }
   fft2_done = 1;
   lir_set_event(EVENT_FFT1_READY);
@@ -176,7 +180,7 @@ static void *narrowband_thread(void *arg)
   for (;;) {
     lir_await_event(EVENT_FFT1_READY);
     while (p.fft2_nx != p.fft2_na && !failed) { CHK(lrh_fft2_mix1_fixed(rx, P, 1)); lir_set_event(EVENT_SPACE); }
-    if (fft2_done && p.fft2_nx == p.fft2_na) break;
+    if (failed || (fft2_done && p.fft2_nx == p.fft2_na)) break;
   }
   return NULL;
 }

@@ -50,7 +50,7 @@ using namespace lrh;
 #define FFT2_WATERFALL_ZERO 0.012
 #define LRH_NSTAGE 4
 #define LRH_BLN_PARTIALS 256
-#define LRH_MAX_HANDLES 6          /* MAX_FFT1_THREADS, thrdef.h:107: THREAD_FFT1B1..6 call fft1_b with gpu_handle_number = i (wcw.c:500) */
+#define LRH_MAX_HANDLES 7          /* handle 0 = the caller's own thread; 1..6 = THREAD_FFT1B1..6 (MAX_FFT1_THREADS, thrdef.h:107; gpu_handle_number, wcw.c:500) */
 
 struct ProfEntry { double ms = 0; long n = 0; };
 struct ProfPending { std::string name; hipEvent_t e0, e1; };

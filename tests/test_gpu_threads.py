@@ -15,7 +15,7 @@ def _run(tmp_path, threaded, nblk, extra=()):
     exe = os.path.join(ROOT, "examples", "lrh_threads")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "linrad_amd", "csrc"), "example"])   # gcc only; no-op when fresh
     out = tmp_path / f"dump_{threaded}.bin"
-    r = subprocess.run([exe, str(threaded), str(nblk), str(out), *map(str, extra)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(threaded), str(nblk), str(out), *map(str, extra)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     return np.fromfile(out, np.uint8), r.stdout
 
