@@ -79,7 +79,12 @@ def exchange_gather(rx, which, count, dist, device=None):
     if device is not None:
         t = torch.as_tensor(_DevSpan(rx.exchange_ptr(which), 2 * count), device=device)
         with torch.cuda.stream(_lrh_stream(rx, device)):
-            dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
+            if dist.get_backend() == "gloo":                # rehearsal on one GPU box: gloo has no in-place gather into one tensor
+                slots = [torch.empty(count, dtype=torch.float32, device=device) for _ in range(2)]
+                dist.all_gather(slots, t[rank * count:(rank + 1) * count].clone())
+                t[(1 - rank) * count:(2 - rank) * count].copy_(slots[1 - rank])
+            else:
+                dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
     else:
         own = torch.from_numpy(rx.exchange_read(which, count, rank * count))
         slots = [torch.empty_like(own), torch.empty_like(own)]
