@@ -129,6 +129,75 @@ def relerr(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
+def waterfall_itab(cfg):
+    """yfac index per pixel as lrh_open builds it (float-accumulated like fft2.c:713-729)"""
+    n1, n2 = 1 << cfg.fft1_n, 1 << cfg.fft2_n
+    r = max(1, n2 // n1)
+    mode = cfg.wf_mode
+    hx, hp = (1, 1) if mode == 1 else ((mode, 0) if mode > 1 else (0, -mode))
+    if hx > 0 and hx >= r:
+        wx, wp = hx // r, 0
+    else:
+        wx, wp = 0, max(1, hp * r if hp > 0 else r // (hx if hx > 0 else 1))
+    a2 = np.float32(wx) if wx > 0 else np.float32(1.0 / wp)
+    a3 = np.float32(cfg.wf_first_xpoint // r + 0.5 * a2)
+    itab = []
+    for _ in range(cfg.wf_xpixels):
+        itab.append(min(max(int(a3), 0), n1 - 1))
+        a3 = np.float32(a3 + a2)
+    return np.array(itab), hx, hp
+
+
+def waterfall_boundary_report(out, g, diff):
+    """SURVEY 8d gate for the quantised waterfall bins.  A line is (int)(1000 log10(sum * yfac)) of a waterfall averaging group's
+    power sum (fft2.c:728-733); the sums of the last lines are rebuilt here from the golden's per-transform power ring
+    (fft2_power_float, float32 adds in transform order like fft2.c:655-670), and for every bin of those lines where the HIP line
+    differs from the reference's the distance of the pre-rounding value to the nearest integer boundary is reported, next to the
+    float32 noise (in counts) a bin that far below the strongest one carries.  None where the mapping is not one data point or
+    one maximum per pixel, or the golden stores strided rings."""
+    cfg = out["cfg"]
+    if ("__stride" in g and int(g["__stride"]) > 1) or cfg.wf_mode < 1 or "fft2_power_float" not in g or not cfg.second_fft_enable:
+        return None
+    n2, avg, nring = 1 << cfg.fft2_n, cfg.waterfall_avgnum, cfg.max_fft2n
+    T = len(out["mixtrace"])                                   # fft2 transforms of the run
+    nlines = diff.shape[0]
+    power = g["fft2_power_float"].reshape(nring, n2)
+    yfac = out["api"].get_table("wg_waterf_yfac", 1 << cfg.fft1_n)
+    itab, hx, hp = waterfall_itab(cfg)
+    gw = g["wf_lines"].reshape(nlines, -1)
+    dists, noise, lines_checked, mism = [], [], 0, 0
+    peak = gw.max()
+    for line in range(nlines):
+        t0 = line * avg
+        if t0 < T - nring or t0 + avg > T:
+            continue
+        acc = power[t0 % nring].astype(np.float32).copy()
+        for t in range(t0 + 1, t0 + avg):
+            acc = (acc + power[t % nring]).astype(np.float32)
+        first = cfg.wf_first_xpoint
+        if cfg.wf_mode == 1:
+            ps = acc[first:first + cfg.wf_xpixels]
+        else:                                                      # maximum of hx data points per pixel (fft2.c:795-811)
+            ps = np.array([acc[min(first + t * hx, n2):min(first + (t + 1) * hx, n2)].max(initial=0.0) for t in range(cfg.wf_xpixels)], np.float32)
+        with np.errstate(divide="ignore"):
+            v = 1000.0 * np.log10((ps * yfac[itab[:ps.size]]).astype(np.float32).astype(np.float64))
+        y = np.clip(np.trunc(v), -32767, 32767)
+        if not np.array_equal(y.astype(np.int64), gw[line, :ps.size].astype(np.int64)):
+            continue                                               # the rebuilt sum is not this line's (ring position): skip it
+        lines_checked += 1
+        bad = np.nonzero(diff[line, :ps.size])[0]
+        mism += bad.size
+        for i in bad:
+            fr = v[i] - np.floor(v[i])
+            dists.append(float(min(fr, 1.0 - fr)))
+            noise.append(float(868e-6 * 10.0 ** ((peak - gw[line, i]) / 2000.0)))
+    dists, noise = np.array(dists), np.array(noise)
+    return {"lines_checked": lines_checked, "checked_mismatches": int(mism),
+            "within_1e-3": int(np.sum(dists <= 1e-3)), "max_distance": float(dists.max()) if dists.size else 0.0,
+            "beyond_noise": int(np.sum(dists > np.maximum(1e-3, 1.5 * noise))),
+            "distances": [round(float(x), 5) for x in dists[:24]], "float32_noise_counts": [round(float(x), 5) for x in noise[:24]]}
+
+
 def golden_itrace(g):
     """columns of the reference trace matching run_case's itrace"""
     it = g["itrace"].reshape(-1, 16)
@@ -145,8 +214,16 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
     Pointers / call pattern: exact.  Blanker: identical cleared-sample set.  Quantised waterfall bins: exact except
     where the pre-rounding value sits within float32 noise of an integer boundary (|diff| <= 1 there).
     """
-    rep = {}
-    rep = {}
+    rep = {"escapes": []}          # rings accepted on the absolute float32 floor instead of the relative tolerance
+
+    def gate(key, e, err, floor):
+        """relative tolerance, or the absolute float32 floor of the wide-band spectrum the ring was cut from; the report says which"""
+        rep[key] = e
+        rep.setdefault("abs_err", {})[key] = float(err)
+        rep.setdefault("abs_floor", {})[key] = float(floor)
+        if e > tol and err <= floor:
+            rep["escapes"].append(key)
+        assert e <= tol or err <= floor, f"{key}: rel {e:.3e}, abs {err:.3e} > floor {floor:.3e}"
     if "fft3" in out:
         assert np.array_equal(out["fft3_ptrs"], g["fft3_ptrs"][1:]), "fft3 pointers differ"
         a, b = out["fft3"].astype(np.float64), g["fft3"].astype(np.float64)
@@ -154,16 +231,12 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
         n2 = 1 << out["cfg"].fft2_n
         wide = np.linalg.norm(g["fft2_float"].astype(np.float64)) / np.sqrt(out["cfg"].max_fft2n)
         floor = 16 * 6e-8 * wide * np.sqrt(a.size / (2.0 * n2))
-        e = relerr(a, b)
-        rep["fft3"] = e
-        assert e <= tol or np.linalg.norm(a - b) <= floor, f"fft3: rel {e:.3e}"
+        gate("fft3", relerr(a, b), np.linalg.norm(a - b), floor)
         if "baseb_raw" in g:                                  # fft3_mix2's filter / decimate part, run by the compiled reference
             assert np.array_equal(out["baseb_ptrs"], g["baseb_ptrs"]), "baseband pointers differ"
             a, b = out["baseb_raw"].astype(np.float64), g["baseb_raw"].astype(np.float64)
-            e = relerr(a, b)
-            rep["baseb_raw"] = e
             assert np.count_nonzero(b) > 500
-            assert e <= tol or np.linalg.norm(a - b) <= floor * np.sqrt(a.size / out["fft3"].size), f"baseb_raw: rel {e:.3e}"
+            gate("baseb_raw", relerr(a, b), np.linalg.norm(a - b), floor * np.sqrt(a.size / out["fft3"].size))
     if "timf2_blockpower" in out:
         assert np.array_equal(out["blockpower_ptrs"], g["blockpower_ptrs"]), "timf2 powersum pointers differ"
         e = relerr(out["timf2_blockpower"], g["timf2_blockpower"])
@@ -220,13 +293,15 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
             nm = n2 >> cfg.mix1_bandwidth_reduction_n
             floor = 4 * 6e-8 * wide * np.sqrt(nm / n2) * np.sqrt(out[key].size / nm / 2) * np.sqrt(nm)
             err = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64))
-            assert e <= tol or err <= floor, f"{key}: rel {e:.3e}, abs {err:.3e} > floor {floor:.3e}"
+            gate(key, e, err, floor)
         else:
             assert e <= tol, f"{key}: relative RMS error {e:.3e} > {tol}"
+    a, b = sub("timf2_pwr_float", out["timf2_pwr_float"]) == 0, g["timf2_pwr_float"] == 0
+    inter, union = np.sum(a & b), max(np.sum(a | b), 1)
+    rep["cleared_jaccard"] = float(inter / union)
+    rep["blanker_flips"] = int(np.sum(a != b))
+    rep["cleared_samples"] = int(np.sum(b))
     if check_blanker_exact:
-        a, b = sub("timf2_pwr_float", out["timf2_pwr_float"]) == 0, g["timf2_pwr_float"] == 0
-        inter, union = np.sum(a & b), max(np.sum(a | b), 1)
-        rep["cleared_jaccard"] = float(inter / union)
         assert np.array_equal(a, b), f"cleared-sample set differs (Jaccard {inter / union:.6f})"
     gw, ow = g["wf_lines"].reshape(-1, out["cfg"].wf_xpixels), out["wf_lines"]
     assert gw.shape == ow.shape, (gw.shape, ow.shape)
@@ -238,8 +313,16 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, wf_max_misma
         # about 2e-6*10^(D/20) (two float32 transforms of different rounding order, each ~1e-6 of the peak), i.e.
         # 868*that in 0.01 dB counts.  Exact +-1 within 54 dB of the peak.
         allowed = 1 + np.floor(868e-6 * 10.0 ** ((gw.max() - gw.astype(np.float64)) / 2000.0))
+        rep["wf_bins"] = int(diff.size)
+        rep["wf_mismatches"] = int(np.count_nonzero(diff))
+        rep["wf_boundary"] = waterfall_boundary_report(out, g, diff)
         assert np.all(diff <= allowed), f"waterfall bins differ by up to {diff.max()} (beyond float32 noise)"
         assert np.mean(diff != 0) <= wf_max_mismatch, f"{np.mean(diff != 0):.4f} of waterfall bins differ"
+        wb = rep["wf_boundary"]
+        if wb is not None and wb["checked_mismatches"]:
+            # SURVEY 8d gate: a quantised bin may differ only where its pre-rounding value sits on a rounding boundary -- within
+            # 1e-3 counts, or within the float32 noise the bin's depth below the strongest bin allows (the bound `allowed` is built from)
+            assert wb["beyond_noise"] == 0, wb
     gm, om = g["mixtrace"].reshape(-1, 8), out["mixtrace"]
     if om.size:
         assert np.array_equal(gm[:len(om), [0, 5, 6, 7]], om[:, [0, 5, 6, 7]]), "mix1 point / pointer trace differs"

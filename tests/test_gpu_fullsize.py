@@ -36,12 +36,13 @@ def _feed(rx, iq, lim=None, fq=None):
 
 @pytest.mark.parametrize("fft2_n,blanker,fft3_n", [(12, True, 0), (16, True, 0), (12, False, 0), (16, True, 12)])
 def test_fullsize_chain_matches_oracle(fft2_n, blanker, fft3_n):
-    """48 fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (float32 tolerance 1e-5).
+    """48 (96 with fft3) fft1 blocks of the bench workload, batch 16, HIP vs oracle ring by ring (north-star tolerance 1e-5
+    relative RMS; see fullsize_compare for what a borderline blanker decision excludes)."""
+    h, o, cfg = run_fullsize(fft2_n, blanker, fft3_n)
+    print(fullsize_compare(h, o, cfg, blanker, fft3_n))
 
-    With the blanker on, a sample whose power sits within float32 rounding of the limit may be cleared on one side
-    only (the comparison `pwr > limit` of blank1.c:1030 is discontinuous).  Such flips must be few and borderline;
-    the rings downstream of one are then compared with a tolerance that covers the zeroed sample.  The blanker-off
-    case keeps the strict tolerance everywhere."""
+
+def run_fullsize(fft2_n, blanker, fft3_n):
     from linrad_amd.lib import synth_defaults, synth_iq
     # fft3_n = 12: the bench's default workload (BASELINE configs[2]: fft2_size 65536 with fft3 / mix2 behind mix1, all of it
     # inside lrh_wideband_dsp), long enough for a few fft3 transforms
@@ -66,32 +67,92 @@ def test_fullsize_chain_matches_oracle(fft2_n, blanker, fft3_n):
         r["p"] = rx.p.as_dict()
         r["bs"] = rx.blanker_state()
         res.append(r)
-    h, o = res
+    return res[0], res[1], cfg
+
+
+def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0):
+    """HIP against the oracle at full size, ring by ring, at the north-star tolerance wherever both sides took the same
+    blanker decisions.  A sample whose power sits within float32 rounding of the limit may be cleared on one side only
+    (`pwr > limit`, blank1.c:1030, is discontinuous); such flips must be few and borderline, and everything downstream is
+    then compared on the transforms / blocks / lines that contain no flipped sample -- at the same tolerance, not a
+    loosened one.  Returns the measured errors (tests/test_gpu_parity_report.py publishes them)."""
+    N2 = 1 << cfg.fft2_n
+    M2 = N2 // 2                                                       # sin^2 window: 50 % overlap
+    Mm = (N2 >> cfg.mix1_bandwidth_reduction_n) // 2                   # timf3 samples per fft2 transform
+    rep = {}
     ints = [k for k, v in h["p"].items() if isinstance(v, int)]
     assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
+    rep["noise_floor"] = (h["bs"].timf2_noise_floor, o["bs"].timf2_noise_floor)
     assert abs(h["bs"].timf2_noise_floor - o["bs"].timf2_noise_floor) <= 1
     for k in ("fft1", "sumsq", "slowsum"):
-        assert _relerr(h[k], o[k]) < 1e-5, k
+        rep[k] = _relerr(h[k], o[k])
+        assert rep[k] < 1e-5, k
     # blanker decisions: identical except for borderline samples
     limit = float(o["bs"].stupid_bln_limit)
     flips = np.nonzero((h["pwr"] == 0) != (o["pwr"] == 0))[0]
     border = [i for i in flips if abs(max(h["pwr"][i], o["pwr"][i]) - limit) <= 1e-3 * limit]
+    rep["blanker_flips"], rep["cleared"] = int(len(flips)), int(np.sum(o["pwr"] == 0))
+    rep["flip_margin"] = [float(abs(max(h["pwr"][i], o["pwr"][i]) - limit) / limit) for i in flips[:8]]
     assert len(flips) <= 8 and len(border) >= (1 if len(flips) else 0)
     assert all(min(abs(i - b) for b in border) <= cfg.blanker_pulsewidth + 2 for i in flips)
     if not blanker:
         assert len(flips) == 0
-    loose = 1000 if len(flips) else 1                   # one zeroed sample of ~limit power in a 4096-point transform
     keep = np.ones(len(o["pwr"]), bool)
     keep[flips] = False
-    assert _relerr(h["pwr"][keep], o["pwr"][keep]) < 5e-5   # despiked power: float32 floor of the cleaned pulses remains
-    for k in ("fft2", "ps2"):
-        assert _relerr(h[k], o[k]) < 1e-5 * loose, k
-    assert _relerr(h["timf3"], o["timf3"]) < 2e-5 * loose
+    rep["pwr"] = _relerr(h["pwr"][keep], o["pwr"][keep])
+    assert rep["pwr"] < 5e-5          # despiked power: float32 floor of the cleaned pulses remains (DESIGN.md 2)
+    # fft2 transform t reads timf2 samples [t M2, t M2 + N2) (the ring has not wrapped in this run): transforms with a flipped sample
+    ntr = o["p"]["fft2_na"]
+    assert ntr < cfg.max_fft2n and o["p"]["timf2_px"] == 4 * ntr * M2
+    hit = np.zeros(ntr + 2, bool)
+    for i in flips:
+        t1 = min(ntr - 1, i // M2)
+        hit[max(0, t1 - 1):t1 + 1] = True
+    rep["fft2_transforms"], rep["fft2_transforms_with_a_flip"] = int(ntr), int(hit[:ntr].sum())
+    ok = ~hit[:ntr]
+    f2h, f2o = h["fft2"].reshape(cfg.max_fft2n, -1)[:ntr], o["fft2"].reshape(cfg.max_fft2n, -1)[:ntr]
+    rep["fft2"] = _relerr(f2h[ok], f2o[ok])
+    assert rep["fft2"] < 1e-5
+    avg = cfg.waterfall_avgnum
+    last_group = range((ntr // avg) * avg if ntr % avg else ntr - avg, ntr)
+    if not any(hit[t] for t in last_group):
+        rep["ps2"] = _relerr(h["ps2"], o["ps2"])
+        assert rep["ps2"] < 1e-5
+    # timf3 block t (Mm samples) carries transform t's first half on top of transform t-1's second half (mix1.c:161-195)
+    nb3 = o["p"]["timf3_pa"] // (2 * Mm)
+    ok3 = np.array([not (hit[t] or (t > 0 and hit[t - 1])) for t in range(nb3)])
+    t3h, t3o = h["timf3"][:2 * Mm * nb3].reshape(nb3, -1), o["timf3"][:2 * Mm * nb3].reshape(nb3, -1)
+    rep["timf3"] = _relerr(t3h[ok3], t3o[ok3])
+    # weak band cut out of a spectrum that holds a carrier 50 dB up: the float32 floor of the wide spectrum (DESIGN.md 2)
+    wide = np.linalg.norm(f2o[ok].astype(np.float64)) / np.sqrt(max(1, ok.sum()))
+    floor3 = 4 * 6e-8 * wide * np.sqrt(ok3.sum() * Mm / N2) * np.sqrt(2.0)
+    err3 = np.linalg.norm(t3h[ok3].astype(np.float64) - t3o[ok3])
+    rep["timf3_abs"], rep["timf3_floor"], rep["timf3_escape"] = float(err3), float(floor3), bool(rep["timf3"] > 1e-5)
+    assert rep["timf3"] <= 1e-5 or err3 <= floor3, rep
     if fft3_n:
         assert o["p"]["baseb_pa"] > 0 and np.count_nonzero(o["baseb"]) > 100
-        assert _relerr(h["fft3"], o["fft3"]) < 2e-5 * loose and _relerr(h["baseb"], o["baseb"]) < 2e-5 * loose
-    d = np.abs(h["wf"].astype(int) - o["wf"].astype(int))
-    assert d.max() <= (2 if loose == 1 else 200) and (d != 0).mean() < 0.05
+        rep["fft3"], rep["baseb"] = _relerr(h["fft3"], o["fft3"]), _relerr(h["baseb"], o["baseb"])
+        if not len(flips):
+            e3 = np.linalg.norm(h["fft3"].astype(np.float64) - o["fft3"])
+            assert rep["fft3"] <= 1e-5 or e3 <= floor3 * np.sqrt(h["fft3"].size / max(1, t3h[ok3].size)), rep
+            eb = np.linalg.norm(h["baseb"].astype(np.float64) - o["baseb"])
+            assert rep["baseb"] <= 1e-5 or eb <= floor3, rep
+    # waterfall lines of groups without a flipped transform: exact up to bins on a rounding boundary
+    npx = cfg.wf_xpixels
+    nl = ntr // avg
+    wfh, wfo = h["wf"].astype(int), o["wf"].astype(int)
+    size = wfh.size
+    tot = bad = 0
+    dmax = 0
+    for line in range(nl):
+        if any(hit[t] for t in range(line * avg, (line + 1) * avg)):
+            continue
+        ptr = (-line * npx) % size                                       # lines are written downwards from 0 (fft1.c:104-113)
+        d = np.abs(wfh[ptr:ptr + npx] - wfo[ptr:ptr + npx])
+        tot += npx; bad += int(np.count_nonzero(d)); dmax = max(dmax, int(d.max()))
+    rep["wf_bins"], rep["wf_mismatches"], rep["wf_maxdiff"] = tot, bad, dmax
+    assert dmax <= 2 and bad <= 0.05 * max(tot, 1)
+    return rep
 
 
 def test_fullsize_reconstruction_identity():
