@@ -194,7 +194,9 @@ def waterfall_boundary_report(out, g, diff):
     dists, noise = np.array(dists), np.array(noise)
     return {"lines_checked": lines_checked, "checked_mismatches": int(mism),
             "within_1e-3": int(np.sum(dists <= 1e-3)), "max_distance": float(dists.max()) if dists.size else 0.0,
-            "beyond_noise": int(np.sum(dists > np.maximum(1e-3, 1.5 * noise))),
+            # the noise figure is an RMS estimate: a bin flips when its error exceeds the distance, so distances of a few sigma occur
+            "beyond_noise": int(np.sum(dists > np.maximum(1e-3, 4 * noise))),
+            "max_distance_over_noise": float(np.max(dists / noise)) if dists.size else 0.0,
             "distances": [round(float(x), 5) for x in dists[:24]], "float32_noise_counts": [round(float(x), 5) for x in noise[:24]]}
 
 
