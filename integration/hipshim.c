@@ -1,0 +1,175 @@
+/*
+ * hipshim.c -- Linrad-side glue for liblinrad_hip.so.  Our code, compiled inside the Linrad tree against Linrad's own headers.
+ *
+ * Linrad's stage functions are void f(void) over global rings and pointer variables (z_BUFFERS.txt).  With fft1 version 21 the
+ * rings from fft1_float to timf3 live on the MI355X; each stand-in below
+ *   hip_sync_in:   copies the pointer globals its stage reads into a local lrh_ptrs,
+ *   calls the library stage (which advances exactly the fields the reference function advances),
+ *   hip_sync_out:  copies those fields back into the globals,
+ * and brings the small host-visible products back for the rest of Linrad: the newest fft1_sumsq block and fft1_slowsum
+ * (wide graph, selective limiter), waterfall lines, blanker scalars, and timf3 -- from where fft3 / mix2 / the demodulators
+ * run on the CPU as before.  Every stage thread copies only the fields its own stage owns, so the threads of wcw.c do not
+ * disturb each other (the library itself may be called from any thread, include/linrad_hip.h "threading").
+ */
+#include <string.h>
+#include <stdlib.h>
+#include "globdef.h"
+#include "uidef.h"
+#include "fft1def.h"
+#include "fft2def.h"
+#include "fft3def.h"
+#include "screendef.h"
+#include "sigdef.h"
+#include "seldef.h"
+#include "blnkdef.h"
+#include "thrdef.h"
+#include "linrad_hip.h"
+#include "hipshim.h"
+
+static lrh_ctx *hip_rx;
+static float *hip_liminfo_sent;           /* the routing table the device holds (sellim.c updates liminfo[] on the host) */
+static int hip_n1, hip_n2;
+
+int hip_open(void)
+{
+  lrh_config c;
+  int rc;
+  lrh_config_defaults(&c, fft1_n, fft2_n);
+  c.device = gpu.fft1_device;
+  c.fft1_sinpow = genparm[FIRST_FFT_SINPOW]; c.fft1_gain = genparm[FIRST_FFT_GAIN]; c.fft1_direction = fft1_direction;
+  c.fft_avg1num = wg.fft_avg1num; c.fft_avg2num = wg_fft_avg2num;
+  c.timf1_bytes = timf1_bytes; c.max_fft1n = max_fft1n; c.fft1_sumsq_bufsize = fft1_sumsq_bufsize;
+  c.wg_xpoints = wg.xpoints;
+  c.slowsum_fresh_recalc = genparm[FIRST_FFT_BANDWIDTH] > 200 ? (wg_fft_avg2num < 100 ? 4 : 8) : 2;       /* fft1.c:4546-4567 */
+  c.bckfft_att_n = genparm[FIRST_BCKFFT_ATT_N]; c.timf2pow_size = timf2pow_size;
+  c.stupid_bln_mode = hg.stupid_bln_mode; c.stupid_bln_factor = hg.stupid_bln_factor;
+  c.blnfit_range = blnfit_range; c.blanker_pulsewidth = blanker_pulsewidth;
+  c.timf2_noise_floor_avgnum = timf2_noise_floor_avgnum; c.blanker_info_update_interval = blanker_info_update_interval;
+  c.blanker_min_points = (int)(min_delay_time * ui.rx_ad_speed);                                           /* blank1.c:712 */
+  c.timf2_noise_floor = timf2_noise_floor;
+  c.fft2_sinpow = genparm[SECOND_FFT_SINPOW]; c.max_fft2n = max_fft2n;
+  c.waterfall_avgnum = wg.waterfall_avgnum; c.wf_first_xpoint = hgwat_first_xpoint; c.wf_xpixels = wg_xpixels;
+  c.wf_mode = hgwat_xpoints_per_pixel == 1 || hgwat_pixels_per_xpoint == 1 ? 1 :
+              (hgwat_xpoints_per_pixel > 1 ? hgwat_xpoints_per_pixel : -hgwat_pixels_per_xpoint);        /* fft2.c:723-811 */
+  c.wf_lines = wg_waterf_size / wg_xpixels;
+  c.mix1_bandwidth_reduction_n = genparm[MIX1_BANDWIDTH_REDUCTION_N]; c.timf3_size = timf3_size;
+  c.fftx_points_per_hz = fftx_points_per_hz; c.mix1_lowest_fq = mix1_lowest_fq; c.mix1_highest_fq = mix1_highest_fq;
+  c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
+  c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
+  c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
+  if ((rc = lrh_open(&c, &hip_rx)) != 0) { hip_rx = NULL; return rc; }
+  hip_n1 = fft1_size; hip_n2 = fft2_size;
+  lrh_set_filtercorr(hip_rx, fft1_filtercorr);                /* the calibration Linrad loaded (fft1.c:4653-5386) */
+  hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
+  memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
+  lrh_set_liminfo(hip_rx, liminfo);
+  lrh_host_register(hip_rx, timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
+  return 0;
+}
+
+void hip_close(void)
+{
+  if (!hip_rx) return;
+  lrh_timf1_write_wait(hip_rx);
+  lrh_host_unregister(hip_rx, timf1_char);
+  lrh_close(hip_rx);
+  hip_rx = NULL;
+  free(hip_liminfo_sent); hip_liminfo_sent = NULL;
+}
+
+void hip_timf1_new(int pa, int nbytes)
+{
+  if (hip_rx && lrh_timf1_write_async(hip_rx, &timf1_char[pa], pa, nbytes) != 0) lirerr(1465);
+}
+
+int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
+{
+  /* the dispatcher's workers carry gpu_handle_number 0..5 (wcw.c:500), the no-worker path passes 0 too (wcw.c:1036) */
+  const int handle = no_of_fft1b > 0 ? gpu_handle_number + 1 : 0;
+  return lrh_fft1_b(hip_rx, handle, timf1p_ref, (int)(out - fft1_float), gpu_fft1_batch_size);
+}
+
+void hip_fft1_c(void)
+{
+  lrh_ptrs q;
+  int old_pa;
+  memset(&q, 0, sizeof q);
+  /* hip_sync_in: what fft1_c reads (fft1.c:4507-4523) */
+  q.fft1_nb = fft1_nb; q.fft1_pb = fft1_pb; q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
+  q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
+  old_pa = fft1_sumsq_pa;
+  if (lrh_fft1_c(hip_rx, &q, 1) != 0) { lirerr(1466); return; }
+  /* hip_sync_out */
+  fft1_nb = q.fft1_nb; fft1_pb = q.fft1_pb; fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
+  fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
+  if (q.fft1_sumsq_pa != old_pa) {            /* an averaging period completed: the wide graph and sellim.c read these on the host */
+    lrh_export(hip_rx, LRH_RING_FFT1_SUMSQ, &fft1_sumsq[old_pa], (size_t)old_pa, (size_t)hip_n1);
+    lrh_export(hip_rx, LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1);
+  }
+}
+
+void hip_make_timf2(void)
+{
+  lrh_ptrs q;
+  memset(&q, 0, sizeof q);
+  if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {     /* fft1_update_liminfo has run (wcw.c:1124-1133) */
+    memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
+    lrh_set_liminfo(hip_rx, liminfo);
+  }
+  q.fft1_px = fft1_px; q.fft1_nx = fft1_nx; q.timf2_pa = timf2_pa;
+  q.fft1_lowlevel_points = fft1_lowlevel_points; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
+  if (lrh_make_timf2(hip_rx, &q, 1) != 0) { lirerr(1467); return; }
+  fft1_px = q.fft1_px; fft1_nx = q.fft1_nx; timf2_pa = q.timf2_pa;            /* timf2.c:127-128, 205-207 */
+  fft1_lowlevel_points = q.fft1_lowlevel_points; fft1_lowlevel_fraction = q.fft1_lowlevel_fraction;
+}
+
+void hip_first_noise_blanker(void)
+{
+  lrh_ptrs q;
+  memset(&q, 0, sizeof q);
+  q.timf2p_fit = timf2p_fit; q.timf2_pn2 = timf2_pn2; q.timf2_pa = timf2_pa; q.timf2_blanker_points = timf2_blanker_points;
+  q.blanker_info_update_counter = blanker_info_update_counter; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
+  if (lrh_first_noise_blanker(hip_rx, &q) != 0) { lirerr(1468); return; }
+  timf2p_fit = q.timf2p_fit; timf2_pn2 = q.timf2_pn2; timf2_blanker_points = q.timf2_blanker_points;     /* blank1.c:1458-1476 */
+  if (q.blanker_info_update_counter == 0 && blanker_info_update_counter != 0) {   /* thresholds were updated (blank1.c:1550-1601) */
+    lrh_blanker_state bs;
+    if (lrh_get_blanker_state(hip_rx, &bs) == 0) {
+      timf2_noise_floor = bs.timf2_noise_floor; hg.stupid_bln_limit = bs.stupid_bln_limit;
+      stupid_blanker_rate = bs.stupid_blanker_rate;
+      timf2_despiked_pwr[0] = bs.timf2_despiked_pwr[0]; timf2_despiked_pwr[1] = bs.timf2_despiked_pwr[1];
+    }
+  }
+  blanker_info_update_counter = q.blanker_info_update_counter;
+}
+
+void hip_make_fft2(void)
+{
+  lrh_ptrs q;
+  int old_ptr;
+  memset(&q, 0, sizeof q);
+  q.timf2_px = timf2_px; q.fft2_na = fft2_na; q.fft2_pa = fft2_pa; q.fft2_nb = fft2_nb; q.fft2_nm = fft2_nm;
+  q.wg_waterf_sum_counter = wg_waterf_sum_counter; q.wg_waterf_ptr = wg_waterf_ptr; q.fft2_liminfo_cnt = fft2_liminfo_cnt;
+  old_ptr = wg_waterf_ptr;
+  if (lrh_make_fft2(hip_rx, &q, 1) != 0) { lirerr(1469); return; }
+  timf2_px = q.timf2_px; fft2_na = q.fft2_na; fft2_pa = q.fft2_pa; fft2_nb = q.fft2_nb; fft2_nm = q.fft2_nm;   /* fft2.c:1831-1845 */
+  wg_waterf_sum_counter = q.wg_waterf_sum_counter; wg_waterf_ptr = q.wg_waterf_ptr; fft2_liminfo_cnt = q.fft2_liminfo_cnt;
+  if (q.wg_waterf_ptr != old_ptr) {            /* a waterfall line completed (fft2.c:703-815): the screen thread draws it */
+    lrh_export(hip_rx, LRH_RING_WG_WATERF, &wg_waterf[old_ptr], (size_t)old_ptr, (size_t)wg_xpixels);
+    lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
+  }
+  make_fft2_status = FFT2_COMPLETE;           /* second_fft loops until this (wcw.c:280-285) */
+}
+
+void hip_fft2_mix1_fixed(void)
+{
+  lrh_ptrs q;
+  int old_pa;
+  memset(&q, 0, sizeof q);
+  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
+  q.fft2_nx = fft2_nx; q.timf3_pa = timf3_pa; q.fft2_na = fft2_na;
+  old_pa = timf3_pa;
+  if (lrh_fft2_mix1_fixed(hip_rx, &q, 1) != 0) { lirerr(1470); return; }
+  fft2_nx = q.fft2_nx; timf3_pa = q.timf3_pa;                                   /* mix1.c:991-992 */
+  /* timf3 is where the device hands back to the CPU: fft3, mix2 and the demodulators carry on from the host ring (audio rate) */
+  lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, &timf3_float[old_pa], (size_t)old_pa, (size_t)timf3_block);
+}

@@ -1,0 +1,22 @@
+/*
+ * hipshim.h -- Linrad-side glue for liblinrad_hip.so (include/linrad_hip.h): what integration/linrad_hip.patch makes Linrad call.
+ * Dropped into the Linrad source tree next to fft1.c together with hipshim.c; new fft1 version 21 ("HIP MI355X", fft_cntrl[21].gpu
+ * = GPU_HIP) selects it the way versions 18 / 19 select clFFT / cuFFT (fft1var.c:62-63, globdef.h:33-34).
+ */
+#ifndef HIPSHIM_H
+#define HIPSHIM_H
+#ifndef GPU_HIP
+#define GPU_HIP 3
+#endif
+extern int fft1_use_gpu;
+
+int  hip_open(void);                 /* wideband_dsp start, where create_clFFT_plan / cufftPlanMany are called (wcw.c:535-575) */
+void hip_close(void);                /* wideband_dsp exit, where destroy_clFFT_plan is called (wcw.c:1174-1183)              */
+void hip_timf1_new(int timf1p_pa, int nbytes);   /* finish_rx_read: one new block sits at timf1_char[timf1p_pa] (rxin.c:1425-1431) */
+int  hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number);   /* fft1_b case 21 (fft1.c:3519-3553)                      */
+void hip_fft1_c(void);               /* stand-ins for the stage functions of the same names                                     */
+void hip_make_timf2(void);
+void hip_first_noise_blanker(void);
+void hip_make_fft2(void);
+void hip_fft2_mix1_fixed(void);
+#endif

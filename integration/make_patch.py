@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Generates integration/linrad_hip.patch: the change set that makes liblinrad_hip.so selectable in Linrad as fft1 version 21.
+
+Run in the build container (needs the reference tree, default /root/reference):  python3 integration/make_patch.py
+The edits are anchored on single lines of the reference snapshot and are almost all pure insertions; the patch is written
+with zero context lines (diff -U0), so it holds our added lines, their line numbers and the two one-line replacements --
+no reference source is stored in this repository.  integration/check_patch.sh applies it to a scratch copy and compiles
+the touched objects.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+INC = '#include "hipshim.h"\n'
+
+
+def after_last_include(lines):
+    idx = max(i for i, l in enumerate(lines[:120]) if l.startswith("#include"))
+    lines.insert(idx + 1, INC)
+
+
+def insert(lines, anchor, new, where="after", start=0, nth=1):
+    """insert `new` (a string of whole lines) before/after the nth line at or behind `start` that matches the regex `anchor`"""
+    n = 0
+    for i in range(start, len(lines)):
+        if re.search(anchor, lines[i]):
+            n += 1
+            if n == nth:
+                pos = i + 1 if where == "after" else i
+                lines[pos:pos] = new.splitlines(keepends=True)
+                return i
+    raise SystemExit(f"anchor not found: {anchor}")
+
+
+def replace(lines, anchor, old, new):
+    for i, l in enumerate(lines):
+        if re.search(anchor, l):
+            assert old in l, (anchor, l)
+            lines[i] = l.replace(old, new)
+            return
+    raise SystemExit(f"anchor not found: {anchor}")
+
+
+def func_top(lines, signature, new):
+    """first statement of a function: right behind the opening brace that follows its signature line"""
+    for i, l in enumerate(lines):
+        if re.match(signature, l):
+            j = i
+            while "{" not in lines[j]:
+                j += 1
+            lines[j + 1:j + 1] = new.splitlines(keepends=True)
+            return
+    raise SystemExit(f"function not found: {signature}")
+
+
+def edit_globdef(L):
+    insert(L, r"^#define GPU_CUDA 2", "#define GPU_HIP 3\n")
+    replace(L, r"define MAX_FFT_VERSIONS", "21", "22")
+
+
+def edit_fft1var(L):
+    # fft_cntrl[21]: window storage 1, no permute table, max_n 14 (one workgroup transforms a block), gpu = GPU_HIP
+    insert(L, r'"Double precision"\}', ',{1,0,14,0,0,GPU_HIP,0,1,0,   "HIP MI355X"}                        //21\n')
+    replace(L, r"1 chan direct conversion \(IQ\)", "19, -1}", "19, 21}")
+
+
+def edit_buf(L):
+    # get_wideband_sizes: version 21 takes the GPU sizing branches (batch = 2^gpu.fft1_batch_n blocks per fft1_b call, buf.c:248-257)
+    insert(L, r"^if\(fft1_use_gpu\)\s*$", "if(fft_cntrl[FFT1_CURMODE].gpu == GPU_HIP)fft1_use_gpu=GPU_HIP;\n", where="before")
+
+
+def edit_wcw(L):
+    after_last_include(L)
+    i = insert(L, r"^void wideband_dsp\(void\)", "", where="after")
+    # context creation where the clFFT / cuFFT plans are made, before the worker threads start
+    insert(L, r"ui\.network_flag & NET_RXIN_TIMF2\) != 0 &&", "if(fft1_use_gpu == GPU_HIP)\n  {\n  if(hip_open() != 0)\n    {\n    lirerr(1463);\n    goto errexit;\n    }\n  }\n",
+           where="before", start=i)
+    insert(L, r"^errexit:;", "if(fft1_use_gpu == GPU_HIP)hip_close();\n", start=i)
+
+
+def edit_fft1(L):
+    after_last_include(L)
+    i = insert(L, r"^void fft1_b\(", "", where="after")
+    insert(L, r"^\s+default:\s*$", "    case 21:\n// HIP on MI355X: the transform, the correction of fft1_c and every ring behind it stay on the device.\n"
+           "    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
+           where="before", start=i)
+    func_top(L, r"^void fft1_c\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_c();return;}\n")
+
+
+def edit_timf2(L):
+    after_last_include(L)
+    func_top(L, r"^void make_timf2\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_make_timf2();return;}\n")
+
+
+def edit_blank1(L):
+    after_last_include(L)
+    func_top(L, r"^void first_noise_blanker\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_first_noise_blanker();return;}\n")
+
+
+def edit_fft2(L):
+    after_last_include(L)
+    func_top(L, r"^void make_fft2\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_make_fft2();return;}\n")
+
+
+def edit_mix1(L):
+    after_last_include(L)
+    func_top(L, r"^void fft2_mix1_fixed\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft2_mix1_fixed();return;}\n")
+
+
+def edit_rxin(L):
+    after_last_include(L)
+    i = insert(L, r"^void finish_rx_read\(", "", where="after")
+    # the block the input thread has just filled sits at timf1_char[timf1p_pa]: hand it to the device before the event is posted
+    insert(L, r"^// Set the EVENT_TIMF1 condition", "if(fft1_use_gpu == GPU_HIP)hip_timf1_new(timf1p_pa, snd[RXAD].block_bytes);\n", where="before", start=i)
+
+
+EDITS = {"globdef.h": edit_globdef, "fft1var.c": edit_fft1var, "buf.c": edit_buf, "wcw.c": edit_wcw, "fft1.c": edit_fft1,
+         "timf2.c": edit_timf2, "blank1.c": edit_blank1, "fft2.c": edit_fft2, "mix1.c": edit_mix1, "rxin.c": edit_rxin}
+
+
+def main():
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        for name, fn in EDITS.items():
+            src = os.path.join(REF, name)
+            L = open(src, encoding="latin-1").read().splitlines(keepends=True)
+            fn(L)
+            dst = os.path.join(td, name)
+            open(dst, "w", encoding="latin-1").write("".join(L))
+            r = subprocess.run(["diff", "-U0", "--label", "a/" + name, "--label", "b/" + name, src, dst], stdout=subprocess.PIPE, text=True, encoding="latin-1")
+            assert r.returncode == 1, (name, r.returncode)
+            out.append(r.stdout)
+    open(os.path.join(HERE, "linrad_hip.patch"), "w", encoding="latin-1").write("".join(out))
+    print("wrote", os.path.join(HERE, "linrad_hip.patch"), sum(o.count("\n") for o in out), "lines")
+
+
+if __name__ == "__main__":
+    main()
