@@ -126,7 +126,7 @@ struct lrh_ctx {
   int16_t *d_waterf = nullptr;
   float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
   float *d_ph = nullptr;              // phase tables [LRH_NSTAGE][2][max_fft2 batch][half]
-  BlankState *d_bst = nullptr; float *d_partials = nullptr; float4 *d_bln_tiles = nullptr;
+  BlankState *d_bst = nullptr; float *d_partials = nullptr; float4 *d_bln_tiles = nullptr; int *d_bln_counts = nullptr;
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
@@ -314,7 +314,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -509,7 +509,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (cfg->blanker_channels == 2) { A(dev_alloc(c, &c->d_pwr_sum, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xbuf, (size_t)cfg->timf2pow_size)); A(dev_alloc(c, &c->d_xstat, 2));
     A(dev_alloc(c, &c->d_xbins, (size_t)2 * cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_xypower, (size_t)cfg->max_fft2n * N2));
     A(dev_alloc(c, &c->d_xysum, N2)); A(dev_alloc(c, &c->d_xysum_alt, N2)); }
-  A(dev_alloc(c, &c->d_bln_tiles, (size_t)cfg->timf2pow_size / 16384 + 4));
+  A(dev_alloc(c, &c->d_bln_tiles, (size_t)cfg->timf2pow_size / 16384 + 4)); A(dev_alloc(c, &c->d_bln_counts, (size_t)cfg->timf2pow_size / 16384 + 4));
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -928,7 +928,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     a.pwr = c->d_pwr_sum; a.own = c->d_pwr; a.xstat = c->d_xstat; a.own_slot = c->cfg.timf1_channel_index & 1; a.chans = 2; a.phase = 1;
   }
   a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
-  a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials; a.tiles = c->d_bln_tiles;
+  a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials; a.tiles = c->d_bln_tiles; a.counts = c->d_bln_counts;
   p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
   const int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
   p->timf2_blanker_points += m;

@@ -561,6 +561,14 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
 {
   float t1 = pulmax / totnoise;
   *ib = 0; *ia = 0;
+  if (a.clr1 == 0 && a.clr2 == 1) {
+    // Without pulse calibration (blank1.c:1013-1014) the general form below reduces to: one sample behind the run when the
+    // ratio reaches 2500, none before it.  Exactly: ia = (int)((float)(sqrt((double)t1) / 100) + 0.5) is 1 iff the float
+    // quotient is >= 0.5f, i.e. sqrt(t1) >= 50 - 100 * 2^-26 (the tie rounds to even, 0.5f), i.e. t1 >= 2500 - 1.5e-4; the
+    // float below 2500 is 2500 - 2.4e-4, so the threshold in float is 2500 itself.  No double-precision square root per run.
+    if (t1 > 4) { *ia = t1 >= 2500.0f ? 1 : 0; return 1; }
+    return 0;
+  }
   if (t1 > 4) {
     if (t1 > 10000) t1 = 10000;                        // 40 dB cap (blank1.c:1056-1057)
     t1 = (float)(sqrt((double)t1) / 100);
@@ -576,16 +584,26 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
 
 __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 {
-  // A lane owns 64 consecutive samples and reads them straight from the power ring as 16-byte loads (its chunk starts
-  // on a 16-byte boundary: pbeg is a multiple of 4, blank1.c:706, and chunk c covers sequence positions 64c .. 64c+63,
-  // position 0 not being a sample).  No LDS staging: the kernel keeps 2 KiB of decision words in LDS only, so the
-  // chip holds every wave of a 4096-block call at once and the loads of one wave hide behind the others.
+  // Two phases per workgroup (tile of 256 chunks x 64 samples).
+  // 1. Cooperative, coalesced: every wave reads its 4096 samples (and the 256 before them, for the clean-point search) as
+  //    256-byte rows, one dword per lane, and turns each row into one 64-bit word of "above the limit" bits by ballot.  This
+  //    is the only pass over the power ring: 134 MB per 33.5 M samples, every line fetched once.  (Before: a lane walked its
+  //    own 64-sample chunk with 16-byte loads at a 256-byte lane stride -- 64 lines per wave instruction, each line requested
+  //    in two loop trips; FETCH_SIZE 1.6x the ring span.)
+  // 2. Per lane, exact replay of the serial scan (blank1.c:1023-1086) over its own chunk, event driven on the bit words: only
+  //    samples above the limit and the sample that ends a run matter, everything else leaves the serial state alone.  The
+  //    power of the few samples above the limit is read back from L2 for the run maximum.
   __shared__ unsigned int wbits[LRH_BLN_WORDS];         // decisions for the ring words this tile overlaps
+  __shared__ unsigned long long above[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];   // per wave: word k covers positions R0 - BACK + 64 k ..
+  // the power of the samples above the limit, compacted per wave in row order (phase 2 needs it for the run maxima and would
+  // otherwise wait for L2 once per event): value of bit l of row k sits at rowoff[k] + popcount(bits of the row below l)
+  constexpr int VCAP = 1024;
+  __shared__ float vals[4][VCAP];
+  __shared__ int rowoff[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];
   __shared__ int wg_cnt;
   __shared__ double wg_sum[4];
   if (threadIdx.x == 0) wg_cnt = 0;
   for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) wbits[i] = 0;
-  __syncthreads();
   const int qt = blockIdx.x * LRH_BLN_TILE;              // first sequence position of this workgroup's tile
   // ring word that holds the tile's first position; bits of positions inside [w0*32, (w0+WORDS)*32) go to LDS
   const int w0 = ((a.pbeg + qt) & a.mask) >> 5;
@@ -596,84 +614,121 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
     if (w < LRH_BLN_WORDS) atomicOr(&wbits[w], 1u << (p & 31));
     else atomicOr(&a.mask_bits[p >> 5], 1u << (p & 31));  // guard reaching into a neighbour tile (rare)
   };
-  auto sample = [&](int q) -> float { return a.pwr[(a.pbeg + q) & a.mask]; };   // 1 <= q <= total
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));   // blank1.c:1017
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int NBACK = LRH_BLN_BACK / 64, NROWS = LRH_BLN_CHUNK + NBACK;
+  const int base = qt + wv * 64 * LRH_BLN_CHUNK - LRH_BLN_BACK;          // position of bit 0 of word 0 of this wave
+  double s4 = 0;                                         // every-4th-sample power of the wave's own positions before clearing
+  int running = 0;                                       // wave-uniform: samples above the limit in the rows so far
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  constexpr int FL = 17;                                 // rows in flight per trip (NROWS = 68 = 4 x 17)
+  static_assert(NROWS % FL == 0, "row count");
+#pragma unroll 1
+  for (int k = 0; k < NROWS; k += FL) {
+    float v[FL]; bool ok[FL];
+#pragma unroll
+    for (int u = 0; u < FL; u++) {
+      const int q = base + 64 * (k + u) + lane;
+      ok[u] = q >= 1 && q <= a.total;
+      v[u] = ok[u] ? a.pwr[(a.pbeg + q) & a.mask] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < FL; u++) {
+      const bool up = ok[u] && v[u] > nfl;
+      const unsigned long long b = __ballot(up);
+      if (lane == 0) { above[wv][k + u] = b; rowoff[wv][k + u] = running; }
+      if (up) { const int at = running + __popcll(b & below); if (at < VCAP) vals[wv][at] = v[u]; }
+      running += __popcll(b);
+      if (k + u >= NBACK && ok[u] && (lane & 3) == 0) s4 += (double)v[u];     // positions 4, 8, .. of the own span (base is a multiple of 64)
+    }
+  }
+  __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int cb = c * LRH_BLN_CHUNK;
   const int cs = max(cb, 1);
   const int ce = min(cb + LRH_BLN_CHUNK - 1, a.total);
-  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));   // blank1.c:1017
+  auto bit = [&](int q) -> bool { const int r = q - base; return (above[wv][r >> 6] >> (r & 63)) & 1ull; };   // base <= q <= ce
+  // power of a sample that is above the limit (base <= q <= ce): from the wave's compact table, from the ring when that overflowed
+  auto sample = [&](int q) -> float {
+    const int r = q - base, l = r & 63;
+    const int at = rowoff[wv][r >> 6] + __popcll(above[wv][r >> 6] & (l ? (~0ull >> (64 - l)) : 0ull));
+    return at < VCAP ? vals[wv][at] : a.pwr[(a.pbeg + q) & a.mask];
+  };
+  // first position >= q above the limit, ce + 1 when there is none up to ce
+  auto next_above = [&](int q) -> int {
+    while (q <= ce) {
+      const int r = q - base;
+      const unsigned long long w = above[wv][r >> 6] >> (r & 63);
+      if (w) { const int n = q + __ffsll((long long)w) - 1; return n <= ce ? n : ce + 1; }
+      q += 64 - (r & 63);
+    }
+    return ce + 1;
+  };
   const int G = max(a.clr2, 1);
   int s = 1;
   bool live = cs <= ce;
-  if (live) {
+  if (live) {                                            // nearest earlier point where the serial state is provably clean
     int run = 0, steps = 0, q = cs - 1; bool found = false;
     while (q >= 1) {
-      const float v = sample(q);
-      if (v > nfl) run = 0; else if (++run >= G) { found = true; break; }
+      if (bit(q)) run = 0; else if (++run >= G) { found = true; break; }
       q--;
       if (++steps >= LRH_BLN_BACK) break;
     }
     if (found) s = q + G;
-    else if (q >= 1) { a.st->need_slow = 1; live = false; }  // no clean point in reach: exact serial pass takes over
+    else if (q >= 1) { a.st->need_slow = 1; live = false; }  // no clean point in reach: the long-run replay takes over
   }
-  int ifirst = 0, pk = 0, erase_end = 0, cnt = 0;
-  float pulmax = 0;
-  double s4 = 0;                                         // every-4th-sample power of the chunk before clearing
-  auto step = [&](int q, float v) {
-    if (v > nfl && q >= erase_end) {
-      if (ifirst == 0) pk = q;
-      if (v > pulmax) pulmax = v;
-      ifirst++;
-      if (q >= cs) { setbit(q); cnt++; }
-    } else if (ifirst != 0) {
-      ifirst = 0;
-      int ib, ia;
-      const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
-      pulmax = 0;
-      if (ext) {
-        if (q >= cs) {
-          for (int j = 1; j <= ib; j++) setbit(pk - j);
-          for (int j = 0; j < ia; j++) setbit(q + j);
-          cnt += ib + ia;
+  int cnt = 0;
+  if (a.debug == 7) live = false;
+  if (live) {
+    int ifirst = 0, pk = 0, erase_end = 0, last = -2;
+    float pulmax = 0;
+    int q = s;
+    for (;;) {
+      const int n = next_above(q);
+      if (ifirst != 0 && n != last + 1) {                // the run ended on the sample behind its last one (not above the limit, <= ce)
+        const int qe = last + 1;
+        ifirst = 0;
+        int ib, ia;
+        const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
+        pulmax = 0;
+        if (ext) {
+          if (qe >= cs) {
+            for (int j = 1; j <= ib; j++) setbit(pk - j);
+            for (int j = 0; j < ia; j++) setbit(qe + j);
+            cnt += ib + ia;
+          }
+          erase_end = qe + ia;
         }
-        erase_end = q + ia;
       }
-    }
-  };
-  if (live) for (int q = s; q < cs; q++) step(q, sample(q));            // replay from the clean point (usually empty)
-  const float4 *ring4 = reinterpret_cast<const float4 *>(a.pwr);
-#pragma unroll 1
-  for (int g = 0; g < LRH_BLN_CHUNK; g += 16) {                          // own chunk, four 16-byte loads in flight
-    float4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) t[u] = ring4[((a.pbeg + cb + g + 4 * u) & a.mask) >> 2];
-    const float v[16] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w,
-                         t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, t[3].z, t[3].w};
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int q = cb + g + u;
-      const bool mine = q >= cs && q <= ce;
-      if ((u & 3) == 0 && mine) s4 += (double)v[u];                      // also for lanes the slow path redoes
-      if (live && mine) step(q, v[u]);
+      if (n > ce) break;
+      if (n >= erase_end) {                              // above the limit and not erased ahead of its test (blank1.c:1030)
+        const float v = sample(n);
+        if (ifirst == 0) pk = n;
+        if (v > pulmax) pulmax = v;
+        ifirst++;
+        if (n >= cs) { setbit(n); cnt++; }
+        last = n;
+      }
+      q = n + 1;
     }
   }
-  // one global atomic per workgroup for the count; chunk sums reduced in a fixed order
+  // one global atomic per workgroup for the count; sums reduced in a fixed order
   if (cnt) atomicAdd(&wg_cnt, cnt);
   for (int off = 32; off > 0; off >>= 1) s4 += __shfl_xor(s4, off);
-  if ((threadIdx.x & 63) == 0) wg_sum[threadIdx.x >> 6] = s4;
+  if (lane == 0) wg_sum[wv] = s4;
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (wg_cnt) atomicAdd(&a.st->call_cleared, wg_cnt);
+    a.counts[blockIdx.x] = wg_cnt;
     reinterpret_cast<double *>(a.partials)[blockIdx.x] = (wg_sum[0] + wg_sum[1]) + (wg_sum[2] + wg_sum[3]);
   }
   // publish the decision words: interior words are owned by this tile alone (the mask is all zero between calls);
   // words within guard reach of either end can also be touched by the neighbours, so they are merged atomically
   const int edge = (max(a.clr1, a.clr2) >> 5) + 2;
   for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) {
-    const unsigned int wv = wbits[i];
-    if (!wv) continue;
+    const unsigned int wv2 = wbits[i];
+    if (!wv2) continue;
     const int wi = (w0 + i) & (nwords_ring - 1);
-    if (i < edge || i >= LRH_BLN_TILE / 32 - edge) atomicOr(&a.mask_bits[wi], wv); else a.mask_bits[wi] = wv;
+    if (i < edge || i >= LRH_BLN_TILE / 32 - edge) atomicOr(&a.mask_bits[wi], wv2); else a.mask_bits[wi] = wv2;
   }
 }
 
@@ -709,6 +764,7 @@ __global__ __launch_bounds__(256) void k_blank_runs_pre(BlankArgs a)
   const int w0 = ((a.pbeg + qt) & a.mask) >> 5;
   for (int i = threadIdx.x; i < LRH_BLN_WORDS; i += 256) a.mask_bits[(w0 + i) & (nwords_ring - 1)] = 0;   // what the scan left
   if (blockIdx.x == 0 && threadIdx.x == 0) a.st->call_cleared = 0;
+  if (threadIdx.x == 0) a.counts[blockIdx.x] = 0;        // the scan's count goes with its decisions
   const int cb = (blockIdx.x * 256 + threadIdx.x) * LRH_BLN_CHUNK;
   const BlnChunk ch = bln_chunk_summary(a, max(cb, 1), min(cb + LRH_BLN_CHUNK - 1, a.total), (float)a.st->limit);
   l_max[threadIdx.x] = ch.cmax; l_smax[threadIdx.x] = ch.smax;
@@ -783,6 +839,7 @@ __global__ void k_blank_serial(BlankArgs a)
 {
   if (!a.st->need_slow || bln_runs_mode(a)) return;
   a.st->need_slow = 0; a.st->slow_calls++;
+  for (int i = 0; i < a.ncounts; i++) a.counts[i] = 0;
   for (int q = 1 - a.clr1 - 32; q <= a.total + a.clr2 + 32; q++) a.mask_bits[((a.pbeg + q) & a.mask) >> 5] = 0;
   const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0; float pulmax = 0;
@@ -860,11 +917,15 @@ __global__ void k_blank_update(BlankArgs a)
   double tot = 0;
   for (int i = threadIdx.x; i < a.npartials; i += 256) tot += reinterpret_cast<double *>(a.partials)[i];
   for (int i = threadIdx.x; i < a.nremoved; i += 256) tot -= reinterpret_cast<double *>(a.partials)[a.npartials + i];
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
+  int ncl = 0;                                           // samples the scan cleared, per tile
+  for (int i = threadIdx.x; i < a.ncounts; i += 256) ncl += a.counts[i];
+  __shared__ int wcnt[4];
+  for (int off = 32; off > 0; off >>= 1) { tot += __shfl_xor(tot, off); ncl += __shfl_xor(ncl, off); }
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = tot; wcnt[threadIdx.x >> 6] = ncl; }
   __syncthreads();
   if (threadIdx.x != 0) return;
   tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  ncl = (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
   BlankState *s = a.st;
   if (s->need_slow) { s->need_slow = 0; s->slow_calls++; }   // the long-run replay served this call (k_blank_serial resets the flag itself)
   float t1;
@@ -879,7 +940,7 @@ __global__ void k_blank_update(BlankArgs a)
     for (int i = 0; i < a.nremoved; i++) sr += reinterpret_cast<double *>(a.partials)[a.npartials + i];
     printf("blank_update: npartials %d nremoved %d all %.1f removed %.1f tot %.1f m %d cleared %d total %d\n", a.npartials, a.nremoved, sa, sr, tot, a.m, s->call_cleared, a.total);
   }
-  const int cleared = s->call_cleared;
+  const int cleared = s->call_cleared + ncl;            // long-run / serial replay + the scan's tiles
   s->call_cleared = 0;
   s->last_cleared = cleared;
   s->cleared_acc += cleared;
@@ -1720,8 +1781,9 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
   const int ntiles = (a.total + LRH_BLN_TILE) / LRH_BLN_TILE;     // sequence positions 0 .. total
   const int first_pos = (a.pbeg + 1 - a.clr1 - 32) & a.mask;
   const int nwords = (a.total + a.clr1 + a.clr2 + 64 + 31) / 32 + 1;
+  a.ncounts = 0;
   if (a.mode != 0) {
-    a.npartials = ntiles; a.nremoved = (nwords + 255) / 256;
+    a.npartials = ntiles; a.nremoved = (nwords + 255) / 256; a.ncounts = ntiles;
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
     if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);   // calibrated blanker only
     else {         // long-run replay: two launches that return at once unless a lane gave up

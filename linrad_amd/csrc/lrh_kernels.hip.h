@@ -79,6 +79,7 @@ struct BlankArgs {
   int mode;                 // stupid_bln_mode
   BlankState *st;
   float *partials; int npartials; int nremoved;   // doubles: [npartials] sums, then [nremoved] removed power
+  int *counts; int ncounts;  // cleared samples per scan tile (summed by k_blank_update: 2048 atomics on one word cost 24 us)
   // statistics / update (blank1.c:1472-1601)
   int m; int nstat;         // m: points counted; nstat: samples in the every-4th sum
   int blanker_points;       // timf2_blanker_points after adding m
