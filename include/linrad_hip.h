@@ -219,6 +219,32 @@ int lrh_set_waterfall_yfac(lrh_ctx *ctx, const float *wg_waterf_yfac /* N1 float
 int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "fft1_window","fft2_window",
                                                                      "mix1_fqwin","fft1_filtercorr","wg_waterf_yfac" */
 
+/* ---- selective limiter on the device-resident spectra (sellim.c:738-1157 fft1_update_liminfo + sellim.c:38-157
+   selfreq_liminfo).  The reference runs it in wideband_dsp whenever fft1_c has completed an averaging period
+   (fft1_liminfo_cnt changed, wcw.c:1124-1128); it reads fft1_sumsq at fft1_sumsq_pa and fft1_slowsum, keeps liminfo[],
+   old_liminfo[] and the per-bin hold-off counters liminfo_wait[], and make_timf2 routes with the result.  Here all of that
+   stays on the device: one call = one run of the reference function; the routing words k_timf2 consumes are rebuilt on the
+   device in stream order, so the next lrh_make_timf2 routes with the new table and no spectrum or table crosses PCIe.
+   Host-visible by-product: the count of weak bins (fft1_lowlevel_points, timf2.c:37-52), read back asynchronously -- with
+   `exact_stats` the call waits for it (the reference's value at once); without, it is installed by the next call of this
+   function, i.e. the statistic (not the routing) lags one update, and nothing ever waits.
+   lrh_set_liminfo and this call may be mixed: both replace the table in force. */
+typedef struct lrh_sellim {
+  int struct_size;
+  int sellim_maxlevel;          /* genparm[SELLIM_MAXLEVEL] (uivar.c:371: 12000)                               */
+  int spek_avgnum;              /* wg.spek_avgnum                                                              */
+  float fft1_blocktime;         /* seconds between fft1 transforms: sets the one-second hold-off (sellim.c:771) */
+  float blanker_ston_fft1;      /* hg.blanker_ston_fft1 (hires_graph.c:710)                                    */
+  int sellim_par2, sellim_par3, sellim_par4, sellim_par5, sellim_par6, sellim_par7, sellim_par8;   /* hg.sellim_par* (hires_graph.c:1175-1189) */
+  int liminfo_group_points;     /* buf.c:816-824                                                               */
+  int fft1_first_point, fft1_last_point, fft1_first_inband, fft1_last_inband;   /* set_fft1_endpoints, fft1.c:4607-4650 */
+  int baseband_bw_fftxpts;      /* baseb_graph.c:1165 (an int in the reference, uidef.h:157)                   */
+  int ston_scale;               /* mg.scale_type == MG_SCALE_STON                                              */
+  int exact_stats;              /* 1: wait for the weak-bin count (see above)                                  */
+} lrh_sellim;
+int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
+int lrh_get_liminfo(lrh_ctx *ctx, float *liminfo /* N1 floats: the table in force */);     /* synchronous */
+
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
 int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */
 void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                         /* for device-resident producers */

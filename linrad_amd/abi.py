@@ -96,6 +96,28 @@ class AfcTables:
                         self.start.ctypes.data_as(fp), float(baseband_bw_hz))
 
 
+class LrhSellim(C.Structure):
+    """lrh_sellim: parameters of the selective limiter (fft1_update_liminfo, sellim.c:738)"""
+    _fields_ = [("struct_size", C.c_int), ("sellim_maxlevel", C.c_int), ("spek_avgnum", C.c_int), ("fft1_blocktime", C.c_float),
+                ("blanker_ston_fft1", C.c_float), ("sellim_par2", C.c_int), ("sellim_par3", C.c_int), ("sellim_par4", C.c_int),
+                ("sellim_par5", C.c_int), ("sellim_par6", C.c_int), ("sellim_par7", C.c_int), ("sellim_par8", C.c_int),
+                ("liminfo_group_points", C.c_int), ("fft1_first_point", C.c_int), ("fft1_last_point", C.c_int),
+                ("fft1_first_inband", C.c_int), ("fft1_last_inband", C.c_int), ("baseband_bw_fftxpts", C.c_int),
+                ("ston_scale", C.c_int), ("exact_stats", C.c_int)]
+
+
+def default_sellim(cfg, **kw):
+    """hires_graph.c:1175-1189 defaults, uncalibrated end points (fft1.c:4615-4618), 16 noise-floor groups"""
+    n1 = 1 << cfg.fft1_n
+    s = LrhSellim(C.sizeof(LrhSellim), 12000, cfg.fft_avg1num * cfg.fft_avg2num, 0.0008, 4.0, 0, 0, 0, 0, 0, 0, 0,
+                  n1 // 16, 0, n1 - 1, 0, n1 - 1, 40, 0, 1)
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
 class LrhSynth(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("noise_sigma", C.c_float), ("ncarriers", C.c_int),
@@ -186,6 +208,8 @@ class StageAPI:
         self._proto("exchange_write", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
+        self._proto("fft1_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
+        self._proto("get_liminfo", [vp, fp])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
         self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
         self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
@@ -316,6 +340,15 @@ class StageAPI:
         lim = np.ascontiguousarray(lim, np.float32)
         assert lim.size == self.N1
         self._chk(self._f("set_liminfo")(self.ctx, self._fptr(lim)), "set_liminfo")
+
+    def fft1_update_liminfo(self, par):
+        """one run of the selective limiter on the device-resident spectra (sellim.c:738-1157), see include/linrad_hip.h"""
+        self._chk(self._f("fft1_update_liminfo")(self.ctx, C.byref(self.p), C.byref(par)), "fft1_update_liminfo")
+
+    def get_liminfo(self):
+        out = np.empty(self.N1, np.float32)
+        self._chk(self._f("get_liminfo")(self.ctx, self._fptr(out)), "get_liminfo")
+        return out
 
     def set_waterfall_yfac(self, y=None):
         if y is None:

@@ -131,6 +131,9 @@ struct lrh_ctx {
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
   bool have_liminfo = false;
+  // selective limiter on the device (lrh_fft1_update_liminfo): the reference's liminfo / old_liminfo / liminfo_wait / fftt_tmp
+  float *d_liminfo = nullptr, *d_old_liminfo = nullptr, *d_sel_tmp = nullptr; unsigned char *d_sel_wait = nullptr; SellimState *d_sel_st = nullptr;
+  int *h_sel_low = nullptr; hipEvent_t ev_sel = nullptr; bool sel_pending = false;
   bool pack_prev_stale = false;   // d_pack_prev differs from d_pack_cur (a new liminfo table arrived since the last make_timf2)
   // pinned staging for mix1 phases
   float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
@@ -314,10 +317,12 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
+  if (c->h_sel_low) hipHostFree(c->h_sel_low);
+  if (c->ev_sel) hipEventDestroy(c->ev_sel);
   if (c->d_pack18) hipFree(c->d_pack18);
   if (c->d_stamps) hipFree(c->d_stamps);
   if (c->d_net) hipFree(c->d_net);
@@ -477,7 +482,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_tw2a, tw2a.size())); A(dev_alloc(c, &c->d_tw2b, tw2b.size()));
     A(dev_alloc(c, &c->d_fft2_scratch, (size_t)cfg->max_fft2n * N2, false));
   }
-  A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
+  A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1));
+  A(dev_alloc(c, &c->d_liminfo, N1)); A(dev_alloc(c, &c->d_old_liminfo, N1)); A(dev_alloc(c, &c->d_sel_tmp, N1)); A(dev_alloc(c, &c->d_sel_wait, N1)); A(dev_alloc(c, &c->d_sel_st, 1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
   // ---- rings
   A(dev_alloc(c, &c->d_timf1, cfg->timf1_bytes / 4)); A(dev_alloc(c, &c->d_fft1, (size_t)cfg->max_fft1n * N1));
   A(dev_alloc(c, &c->d_sumsq, cfg->fft1_sumsq_bufsize)); A(dev_alloc(c, &c->d_slowsum, N1));
@@ -614,10 +620,60 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->h_pack = pack;
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_liminfo, liminfo, 4 * c->N1, hipMemcpyHostToDevice, c->stream));   // the table lrh_fft1_update_liminfo carries on from
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sel_pending = false;
   c->lowlevel_points = low;
   c->pack_prev_stale = true;
   c->have_liminfo = true;
+  return LRH_OK;
+}
+
+// fft1_update_liminfo + selfreq_liminfo on the device (include/linrad_hip.h); k_sellim, k_pack_liminfo
+static int sellim_install(lrh_ctx *c)      // the weak-bin count of the last update, once its readback has arrived
+{
+  if (!c->sel_pending) return LRH_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_sel));
+  c->lowlevel_points = *c->h_sel_low;
+  c->sel_pending = false;
+  return LRH_OK;
+}
+int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+{
+  LRH_ENTER(c);
+  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
+      c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
+  if (!c->h_sel_low) {
+    if (hipHostMalloc((void **)&c->h_sel_low, sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
+  }
+  { const int rc = sellim_install(c); if (rc) return rc; }      // the previous update's count (statistic one update late unless exact_stats)
+  SellimArgs a;
+  a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
+  a.slowsum = c->d_slowsum; a.yfac = c->d_yfac; a.liminfo = c->d_liminfo; a.old_liminfo = c->d_old_liminfo; a.tmp = c->d_sel_tmp;
+  a.wait = c->d_sel_wait; a.pack = c->d_pack_cur; a.st = c->d_sel_st;
+  a.n = c->N1; a.n2 = c->N2; a.avg1 = c->cfg.fft_avg1num; a.r0 = c->cfg.fft1_n >= 10 ? 16 : 4;
+  a.maxlevel = q->sellim_maxlevel; a.spek_avgnum = q->spek_avgnum; a.blocktime = q->fft1_blocktime; a.ston = q->blanker_ston_fft1;
+  a.par2 = q->sellim_par2; a.par3 = q->sellim_par3; a.par4 = q->sellim_par4; a.par5 = q->sellim_par5; a.par6 = q->sellim_par6;
+  a.par7 = q->sellim_par7; a.par8 = q->sellim_par8; a.group_points = q->liminfo_group_points;
+  a.first_point = q->fft1_first_point; a.last_point = q->fft1_last_point; a.first_inband = q->fft1_first_inband; a.last_inband = q->fft1_last_inband;
+  a.bw_fftxpts = q->baseband_bw_fftxpts; a.ston_scale = q->ston_scale;
+  a.selfreq = c->ms.mix1_selfreq; a.points_per_hz = c->cfg.fftx_points_per_hz; a.second_fft = c->cfg.second_fft_enable;
+  { ProfScope ps(c, "sellim"); HIPCHK(c, launch_sellim(a, c->cur)); }
+  HIPCHK(c, hipMemcpyAsync(c->h_sel_low, &c->d_sel_st->low, sizeof(int), hipMemcpyDeviceToHost, c->cur));
+  HIPCHK(c, hipEventRecord(c->ev_sel, c->cur));
+  c->sel_pending = true; c->pack_prev_stale = true; c->have_liminfo = true;
+  if (q->exact_stats) return sellim_install(c);
+  return LRH_OK;
+}
+int lrh_get_liminfo(lrh_ctx *c, float *dst)
+{
+  LRH_ENTER(c);
+  if (!c || !dst) return LRH_EINVAL;
+  HIPCHK(c, hipMemcpyAsync(dst, c->d_liminfo, 4 * c->N1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
 
@@ -1751,7 +1807,7 @@ int lrh_sync(lrh_ctx *c)
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
   for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2 }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
-  return LRH_OK;
+  return sellim_install(c);
 }
 
 int lrh_timer_start(lrh_ctx *c) { LRH_ENTER(c); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }

@@ -1805,3 +1805,274 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 }
 
 }  // namespace lrh
+
+// =====================================================================================================
+// selective limiter on the device-resident spectra (control plane, once per averaging period)
+// =====================================================================================================
+// fft1_update_liminfo is a serial, data-dependent scan over the fft1 bins.  One workgroup: the power block and liminfo
+// sit in LDS, everything that is independent per bin (products with the slow average, group minima, hold-off counters,
+// the routing words) runs on all threads, and thread 0 walks the two scans exactly like the reference does -- but jumps over
+// the stretches where nothing can happen (bins below the limit / below the noise floor) with per-chunk "first hot bin"
+// tables the other threads have built.  Arithmetic as the reference (float, sqrt / pow in double).
+namespace lrh {
+#define LRH_SL_BIG 300000000000000000000000000000000000000.F
+__device__ __forceinline__ float sl_three_smallest(const float *v, int ia, int ib)
+{
+  float t1 = LRH_SL_BIG, t2 = LRH_SL_BIG, t3 = LRH_SL_BIG;
+  for (int i = ia; i < ib; i++) {
+    const float x = v[i];
+    if (x <= t3) {
+      if (x <= t1) { t3 = t2; t2 = t1; t1 = x; }
+      else if (x <= t2) { t3 = t2; t2 = x; }
+      else t3 = x;
+    }
+  }
+  return (float)(0.3333333 * (t1 + t2 + t3));
+}
+
+__global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
+{
+  extern __shared__ float sm[];
+  const int N = a.n, tid = threadIdx.x;
+  float *A = sm + 8;                       // power block, later fftt_tmp (the scans look two bins beyond their range)
+  float *B = A + N + 16;                   // liminfo
+  float *G = B + N + 8;                    // liminfo_group_min (at most N/16 + 2 groups... sized N/4 + 8)
+  int *hot = (int *)(G + N / 4 + 8);       // [256] first hot bin of a chunk, or N
+  __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
+  const int CH = (N + 255) / 256;          // bins per chunk
+  for (int i = tid; i < N; i += 256) { A[i] = a.sumsq[i]; B[i] = a.liminfo[i]; }
+  for (int i = tid; i < 8; i += 256) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
+  if (tid == 0) {
+    int tot = a.st->sumsq_tot + a.avg1;
+    if (tot > a.spek_avgnum) tot = a.spek_avgnum;
+    a.st->sumsq_tot = tot;
+    s_pass2 = tot >= a.spek_avgnum;
+    float t1 = (float)a.maxlevel, limit = t1 * t1 * a.avg1 * 1;
+    limit *= N; limit /= a.n2;
+    s_limit = limit;
+  }
+  __syncthreads();
+  const float limit = s_limit;
+  { int f = N; for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) if (A[i] > limit) { f = i; break; } hot[tid] = f; }
+  __syncthreads();
+  const int sel_ia = a.st->sel_ia, sel_ib = a.st->sel_ib, par7 = a.par7;
+  const int ix = a.first_point, iy = a.last_point - 1;
+  if (tid == 0) {
+    // ---- pass 1 (sellim.c:789-865): bins at or below the limit become weak; a run above it gets one attenuation over its
+    // whole width and tapered skirts.  `ia` walks upwards; nothing happens between runs except the zeroing.
+    auto next_hot = [&](int i) -> int {                     // first bin >= i above the limit (N if none)
+      while (i < N) {
+        const int c = i / CH;
+        if (hot[c] < N && hot[c] >= i) return hot[c];
+        const int e = min(N, (c + 1) * CH);
+        if (hot[c] < N) { for (; i < e; i++) if (A[i] > limit) return i; }   // past the chunk's first: look at the rest of it
+        i = e;
+      }
+      return N;
+    };
+    int ia = ix;
+    do {
+      int nh = next_hot(ia); if (nh > iy) nh = iy;           // the loop handles bins ia < iy
+      for (; ia < nh; ia++) if (ia > sel_ib || ia < sel_ia || par7 == 0) B[ia] = 0;
+      if (ia >= iy) break;
+      // ia is above the limit
+      float maxval = A[ia];
+      int ib = ia + 1;
+      while (A[ib] > limit && ib <= iy) { if (A[ib] > maxval) maxval = A[ib]; ib++; }
+      while (ia > ix && A[ia - 1] / A[ia] < 0.3) ia--;
+      while (ib < iy && A[ib + 1] / A[ib] < 0.3) ib++;
+      int ja = ia, jb = ib;
+      float t1 = B[ja], t2;
+      for (int j = ja + 1; j <= jb; j++) if (B[j] > 0 && B[j] < t1) t1 = B[j];
+      t2 = (float)sqrt((double)(limit / maxval));
+      if (t1 / t2 > 0.1 && t1 / t2 < 10) t2 = (float)(0.8 * t1 + 0.2 * t2);
+      if (ja > sel_ib || jb < sel_ia || par7 == 0)
+        for (int j = ja; j <= jb; j++) if (j > sel_ib || j < sel_ia || par7 == 0) B[j] = t2;
+      t1 = t2;
+      int j = 1 + (ib - ia) / 4;
+      while (ia > ix && j > 0) {
+        j--; ia--; ja = ia;
+        t1 = (float)pow((double)t1, 0.9);
+        if (B[ja] <= 0 || B[ja] > t1) { if (ja > sel_ib || ja < sel_ia || par7 == 0) B[ja] = t1; }
+        else break;
+      }
+      j = 1 + (ib - ia) / 4;
+      while (ib < iy && j > 0) {
+        j--; ib++; jb = ib;
+        t2 = (float)pow((double)t2, 0.9);
+        if (B[jb] <= 0 || B[jb] > t1) B[jb] = t2;
+        else break;
+      }
+      ia = ib;
+      ia++;
+    } while (ia < iy);
+  }
+  __syncthreads();
+  if (s_pass2) {
+    // ---- pass 2 (sellim.c:866-1147): noise floor of the slow average, everything above it joins the strong signals
+    const int gp = a.group_points;
+    for (int i = tid; i < N; i += 256) A[i] = a.tmp[i];
+    __syncthreads();
+    int ja = a.first_inband / gp, jb;
+    if (a.par2 == 0) {
+      jb = 1 + a.last_inband / gp;
+      if ((jb - ja) * gp > N) jb--;
+      for (int i = ja * gp + tid; i < jb * gp; i += 256) A[i] = a.yfac[i] * a.slowsum[i];
+      __syncthreads();
+      for (int j = ja + tid; j < jb; j += 256) G[j] = sl_three_smallest(A, j * gp, j * gp + gp);
+    } else {
+      // running boundaries: group 0 ends at (ja+1) gp, the last one is cut at last_inband + 1
+      jb = ja + 1;
+      { int ib = jb * gp; do { ib += gp; if (ib > a.last_inband) ib = a.last_inband + 1; jb++; } while (ib < a.last_inband); }
+      for (int i = tid; i < a.last_point; i += 256) A[i] = a.yfac[i] * a.slowsum[i];
+      __syncthreads();
+      for (int j = ja + tid; j < jb; j += 256) {
+        const int lo = j == ja ? a.first_inband : j * gp;
+        int hi = (j + 1) * gp; if (j > ja && hi > a.last_inband) hi = a.last_inband + 1;
+        G[j] = sl_three_smallest(A, lo, hi);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float t1 = 0, t2;
+      for (int j = ja; j < jb; j++) t1 += G[j];
+      t1 /= jb - ja;
+      int k = 0;
+      float nf = 0;
+      t1 *= (float)(2 * (1 + 2. / a.spek_avgnum));
+      for (int j = ja; j < jb; j++) if (G[j] < t1) { nf += G[j]; k++; }
+      if (a.par3 == 1) {
+        t2 = (float)(0.05 * nf / k);
+        int fg = ja, lg = jb;
+        while (G[fg] < t2) fg++;
+        while (G[lg - 1] < t2) lg--;
+        if (fg != ja || lg != jb) { k = 0; nf = 0; for (int j = fg; j < lg; j++) if (G[j] < t1) { nf += G[j]; k++; } }
+      }
+      if (nf < 0.0001) nf = 0.0001f;
+      if (k != 0) { nf *= (float)((1 + 2. / a.spek_avgnum) / k); nf *= a.ston; }
+      s_nf = nf; s_k = k;
+    }
+    __syncthreads();
+    const float nf = s_nf;
+    { int f = N; for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) if (A[i] > nf) { f = i; break; } hot[tid] = f; }
+    __syncthreads();
+    if (tid == 0) {
+      auto next_hot = [&](int i) -> int {                   // first bin >= i above the noise floor (N if none)
+        while (i < N) {
+          const int c = i / CH;
+          if (hot[c] < N && hot[c] >= i) return hot[c];
+          const int e = min(N, (c + 1) * CH);
+          if (hot[c] < N) { for (; i < e; i++) if (A[i] > nf) return i; }
+          i = e;
+        }
+        return N;
+      };
+      int ia = N;                                          // k == 0 cannot happen (one group is always below twice the mean); the reference
+      if (s_k != 0) {                                      // would then carry on with the group loop's leftover index, beyond the band
+        ia = 0;
+        while (ia < a.first_point || ia < 2) { if (B[ia] == 0) B[ia] = -1; ia++; }
+        while (A[ia] > nf && ia < N) { if (B[ia] == 0) B[ia] = -1; ia++; }
+        const float t1 = a.par4 == 0 ? 4.F : 3.F;
+        while (t1 * A[ia + 1] < A[ia] && ia < N) { ia++; if (B[ia] == 0) B[ia] = -1; }
+        for (;;) {
+          { int nh = next_hot(ia); if (nh > a.last_point) nh = a.last_point; if (nh > ia) ia = nh; }   // while(tmp[ia] <= nf && ia < last) ia++
+          if (ia >= a.last_point) break;
+          int ib = ia;
+          if (B[ia] == 0) B[ia] = -1;
+          while ((2.f * A[ib - 1] < A[ib] || 4.f * A[ib - 2] < A[ib]) && ib > a.first_point) { ib--; if (B[ib] == 0) B[ib] = -1; }
+          while (A[ia + 1] > nf && ia < a.last_point) { ia++; if (B[ia] == 0) B[ia] = -1; }
+          if (ia != a.last_point) {
+            while ((2.f * A[ia + 1] < A[ia] || 4.f * A[ia + 2] < A[ia]) && ia < a.last_point) { ia++; if (B[ia] == 0) B[ia] = -1; }
+            ia++;
+          }
+          if (ia >= a.last_point) break;
+        }
+      }
+      if (ia > N - 2) ia = N - 2;
+      s_ia = ia;
+    }
+    __syncthreads();
+    const int ia_end = s_ia;
+    for (int i = ia_end + tid; i < N; i += 256) { if (a.par8 == 0) B[i] = -1; else if (B[i] == 0) B[i] = -1; }
+    __syncthreads();
+    // hold-off and slow release (sellim.c:1121-1147), per bin
+    int k = (int)(1 + 1 / (a.avg1 * a.blocktime));
+    const unsigned int wait_n = k < 255 ? (unsigned)k : 255u;
+    for (int i = tid; i < N; i += 256) {
+      unsigned char w = a.wait[i];
+      float l = B[i];
+      if (l != 0) w = (unsigned char)wait_n;
+      else { if (w > 0) w--; if (w > 0) l = -1; }
+      const float o = a.old_liminfo[i];
+      if (o > 0) { const float t1 = (float)(o * 1.15); if (t1 < 1) { if (l > 0 && l > t1) l = t1; } }
+      a.wait[i] = w; B[i] = l;
+    }
+    for (int i = tid; i < N; i += 256) a.tmp[i] = A[i];
+    __syncthreads();
+  }
+  // ---- selfreq_liminfo (sellim.c:38-157, float path): the selected passband keeps its own routing
+  if (tid == 0 && a.selfreq >= 0) {
+    int ia = (int)(a.selfreq * a.points_per_hz);
+    int k = (int)(a.bw_fftxpts * .7);
+    if (a.par6 == 0) k += 3;
+    if (a.second_fft) { int ratio = a.n2 / N; if (ratio < 1) ratio = 1; ia /= ratio; k /= ratio; if (k < 3) k = 3; }
+    int ib = ia + k; ia -= k;
+    if (ia < 0) ia = 0;
+    if (ib >= N) ib = N - 1;
+    a.st->sel_ia = ia; a.st->sel_ib = ib;
+    if (a.ston_scale) { for (int i = ia; i <= ib; i++) B[i] = -1; }
+    else {
+      float t1 = 0, t2 = 2;
+      for (int i = ia; i <= ib; i++) { if (B[i] < 0) t1 = 1; if (B[i] > 0 && t2 > B[i]) t2 = B[i]; }
+      bool skip = false;
+      if (t2 > 1) { if (t1 == 0) skip = true; t2 = 1; }
+      if (!skip) {
+        t1 = 1 / t2;
+        t1 *= (float)sqrt((double)(float)(a.n2 / N));
+        if (a.par5 == 2) t2 = -1;
+        if (a.par5 == 1) { if (t1 < 0x7fff / a.maxlevel) t2 = 0; }
+        if (a.par5 == 0) { if (t1 < 0x7ffff / a.maxlevel) t2 = 0; }
+        for (int i = ia; i <= ib; i++) B[i] = t2;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    a.old_liminfo[i] = B[i];
+    a.liminfo[i] = (i < 2 || i >= N - 2) ? 0.f : B[i];       // sellim.c:1152-1155
+  }
+}
+
+// liminfo floats -> the routing words of k_timf2 (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count
+__global__ __launch_bounds__(256) void k_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st)
+{
+  __shared__ int red[4];
+  const int nb = n / r0;
+  int low = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    unsigned int m = 0;
+    for (int s = 0; s < r0; s++) if (liminfo[i + s * nb] == 0) { m |= 1u << s; low++; }
+    pack[i] = m;
+  }
+  for (int off = 32; off > 0; off >>= 1) low += __shfl_xor(low, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = low;
+  __syncthreads();
+  if (threadIdx.x == 0) st->low = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
+{
+  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * 256;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
+  if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_sellim, dim3(1), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
+  return hipGetLastError();
+}
+hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, stream, liminfo, pack, n, r0, st);
+  return hipGetLastError();
+}
+}  // namespace lrh

@@ -181,3 +181,22 @@ struct PolArgs {
 struct BlockpowerArgs { const float2 *timf2w; int mask; int first; int block; float *out; int out_mask; int out_first; };
 
 }  // namespace lrh
+
+// ---- selective limiter (fft1_update_liminfo + selfreq_liminfo, sellim.c:738-1157, 38-157) ----
+namespace lrh {
+struct SellimState { int sumsq_tot, sel_ia, sel_ib, low; };   // device resident between calls (the reference's globals)
+struct SellimArgs {
+  const float *sumsq;       // the fft1_sumsq block at fft1_sumsq_pa
+  const float *slowsum, *yfac;
+  float *liminfo, *old_liminfo, *tmp;    // N floats each (tmp: fftt_tmp, kept between calls like the reference's)
+  unsigned char *wait;      // liminfo_wait
+  unsigned int *pack;       // routing words k_timf2 consumes
+  SellimState *st;
+  int n, n2, avg1, r0;      // fft1_size, fft2_size, wg.fft_avg1num, first-pass radix of the back transform (pack layout)
+  int maxlevel, spek_avgnum; float blocktime, ston;
+  int par2, par3, par4, par5, par6, par7, par8, group_points, first_point, last_point, first_inband, last_inband, bw_fftxpts, ston_scale;
+  double selfreq; float points_per_hz; int second_fft;
+};
+hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
+hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream);
+}

@@ -42,6 +42,7 @@ struct lro_ctx {
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
   float *liminfo;
+  void *sellim;                /* state of lro_fft1_update_liminfo (old_liminfo, liminfo_wait, ...), see there */
   /* rings */
   int16_t *timf1;
   float *fft1_float, *fft1_sumsq, *fft1_slowsum;
@@ -323,6 +324,10 @@ void lro_close(lro_ctx *c)
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
                 c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
+  if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
+    struct { float *old; unsigned char *wait; float *tmp, *group_min; } *s = c->sellim;
+    free(s->old); free(s->wait); free(s->tmp - 8); free(s->group_min); free(s);
+  }
   free(c);
 }
 
@@ -1347,3 +1352,221 @@ int lro_export_timf2_net(lro_ctx *c, float *dst, int timf2_pt, int count, float 
   }
   return LRH_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Selective limiter: fft1_update_liminfo (sellim.c:738-1157) followed by selfreq_liminfo (sellim.c:38-157), float path,
+ * one RF channel, uncalibrated amplitude (the calibrated liminfo_amplitude_factor belongs to the clever blanker).
+ * State kept between calls like the reference's globals: liminfo[], old_liminfo[] (second half of the reference's
+ * array), liminfo_wait[], fft1_sumsq_tot, sel_ia / sel_ib.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define LRO_BIGFLOAT 300000000000000000000000000000000000000.F
+#define LRO_RELEASE_FACTOR 1.15
+#define LRO_SFAC 2.
+typedef struct { float *old; unsigned char *wait; float *tmp, *group_min; int sumsq_tot, sel_ia, sel_ib; } lro_sellim_state;
+static lro_sellim_state *sellim_state(lro_ctx *c)
+{
+  if (!c->sellim) {                       /* allocated on first use, freed by lro_close */
+    lro_sellim_state *s = calloc(1, sizeof *s);
+    s->old = calloc(c->N1, 4); s->wait = calloc(c->N1, 1); s->group_min = calloc(c->N1 + 4, 4);
+    s->tmp = (float *)calloc(c->N1 + 16, 4) + 8;      /* the reference's scans look two bins below and above their range */
+    c->sellim = s;
+  }
+  return (lro_sellim_state *)c->sellim;
+}
+
+/* minimum of a group as the mean of its three smallest values (sellim.c:886-915) */
+static float three_smallest(const float *v, int ia, int ib)
+{
+  float t1 = LRO_BIGFLOAT, t2 = LRO_BIGFLOAT, t3 = LRO_BIGFLOAT;
+  for (int i = ia; i < ib; i++) {
+    const float x = v[i];
+    if (x <= t3) {
+      if (x <= t1) { t3 = t2; t2 = t1; t1 = x; }
+      else if (x <= t2) { t3 = t2; t2 = x; }
+      else t3 = x;
+    }
+  }
+  return (float)(0.3333333 * (t1 + t2 + t3));
+}
+
+static void selfreq_liminfo(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *q)
+{
+  float *lim = c->liminfo;
+  const int N = c->N1;
+  if (c->ms.mix1_selfreq >= 0) {
+    int ia = (int)(c->ms.mix1_selfreq * c->cfg.fftx_points_per_hz);
+    int k = (int)(q->baseband_bw_fftxpts * .7);
+    if (q->sellim_par6 == 0) k += 3;
+    if (c->cfg.second_fft_enable) {
+      int ratio = c->N2 / c->N1; if (ratio < 1) ratio = 1;
+      ia /= ratio; k /= ratio; if (k < 3) k = 3;
+    }
+    int ib = ia + k; ia -= k;
+    if (ia < 0) ia = 0;
+    if (ib >= N) ib = N - 1;
+    st->sel_ia = ia; st->sel_ib = ib;
+    if (q->ston_scale) { for (int i = ia; i <= ib; i++) lim[i] = -1; }
+    else {
+      float t1 = 0, t2 = 2;
+      for (int i = ia; i <= ib; i++) { if (lim[i] < 0) t1 = 1; if (lim[i] > 0 && t2 > lim[i]) t2 = lim[i]; }
+      int skip = 0;
+      if (t2 > 1) { if (t1 == 0) skip = 1; t2 = 1; }
+      if (!skip) {
+        t1 = 1 / t2;
+        t1 *= (float)sqrt((float)(c->N2 / c->N1));
+        if (q->sellim_par5 == 2) t2 = -1;
+        if (q->sellim_par5 == 1) { if (t1 < 0x7fff / q->sellim_maxlevel) t2 = 0; }
+        if (q->sellim_par5 == 0) { if (t1 < 0x7ffff / q->sellim_maxlevel) t2 = 0; }
+        for (int i = ia; i <= ib; i++) lim[i] = t2;
+      }
+    }
+  }
+  for (int i = 0; i < N; i++) st->old[i] = lim[i];
+}
+
+int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+{
+  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  lro_sellim_state *st = sellim_state(c);
+  const int N = c->N1, avg1 = c->cfg.fft_avg1num;
+  float *lim = c->liminfo, *old = st->old, *tmp = st->tmp, *gmin = st->group_min;
+  const float *sumsq = c->fft1_sumsq + p->fft1_sumsq_pa;          /* the block at the *advanced* pointer (sellim.c:788, fft1.c:4519) */
+  const float *slow = c->fft1_slowsum, *yfac = c->wg_waterf_yfac;
+  const int par7 = q->sellim_par7;
+  st->sumsq_tot += avg1;
+  if (st->sumsq_tot > q->spek_avgnum) st->sumsq_tot = q->spek_avgnum;
+  int k = (int)(1 + 1 / (avg1 * q->fft1_blocktime));
+  const unsigned int wait_n = k < 255 ? (unsigned)k : 255u;
+  float t1 = (float)q->sellim_maxlevel, t2, limit;
+  limit = t1 * t1 * avg1 * 1;
+  limit *= N; limit /= c->N2;
+  int ia = q->fft1_first_point; const int ix = ia, iy = q->fft1_last_point - 1;
+  /* pass 1: strong narrow-band signals get a common attenuation over their whole width, with tapered skirts */
+  do {
+    if (sumsq[ia] > limit) {
+      float maxval = sumsq[ia];
+      int ib = ia + 1;
+      while (sumsq[ib] > limit && ib <= iy) { if (sumsq[ib] > maxval) maxval = sumsq[ib]; ib++; }
+      while (ia > ix && sumsq[ia - 1] / sumsq[ia] < 0.3) ia--;
+      while (ib < iy && sumsq[ib + 1] / sumsq[ib] < 0.3) ib++;
+      int ja = ia, jb = ib;
+      t1 = lim[ja];
+      for (int j = ja + 1; j <= jb; j++) if (lim[j] > 0 && lim[j] < t1) t1 = lim[j];
+      t2 = (float)sqrt(limit / maxval);
+      if (t1 / t2 > 0.1 && t1 / t2 < 10) t2 = (float)(0.8 * t1 + 0.2 * t2);
+      if (ja > st->sel_ib || jb < st->sel_ia || par7 == 0)
+        for (int j = ja; j <= jb; j++) if (j > st->sel_ib || j < st->sel_ia || par7 == 0) lim[j] = t2;
+      t1 = t2;
+      int j = 1 + (ib - ia) / 4;
+      while (ia > ix && j > 0) {
+        j--; ia--; ja = ia;
+        t1 = (float)pow(t1, 0.9);
+        if (lim[ja] <= 0 || lim[ja] > t1) { if (ja > st->sel_ib || ja < st->sel_ia || par7 == 0) lim[ja] = t1; }
+        else break;
+      }
+      j = 1 + (ib - ia) / 4;
+      while (ib < iy && j > 0) {
+        j--; ib++; jb = ib;
+        t2 = (float)pow(t2, 0.9);
+        if (lim[jb] <= 0 || lim[jb] > t1) lim[jb] = t2;
+        else break;
+      }
+      ia = ib;
+    } else {
+      if (ia > st->sel_ib || ia < st->sel_ia || par7 == 0) lim[ia] = 0;
+    }
+    ia++;
+  } while (ia < iy);
+  if (st->sumsq_tot >= q->spek_avgnum) {
+    /* pass 2: everything that rises out of the noise floor of the slow average goes to the strong path (liminfo = -1) */
+    const int gp = q->liminfo_group_points;
+    int ja = q->fft1_first_inband / gp, jb, ib;
+    if (q->sellim_par2 == 0) {
+      jb = 1 + q->fft1_last_inband / gp;
+      if ((jb - ja) * gp > N) jb--;
+      ia = ja * gp; ib = ia + gp;
+      for (int j = ja; j < jb; j++) {
+        for (int i = ia; i < ib; i++) tmp[i] = yfac[i] * slow[i];
+        gmin[j] = three_smallest(tmp, ia, ib);
+        ia += gp; ib += gp;
+      }
+    } else {
+      jb = ja + 1; ib = jb * gp;
+      for (int i = 0; i < ib; i++) tmp[i] = yfac[i] * slow[i];
+      gmin[ja] = three_smallest(tmp, q->fft1_first_inband, ib);
+      do {
+        ia = ib; ib += gp;
+        if (ib > q->fft1_last_inband) ib = q->fft1_last_inband + 1;
+        for (int i = ia; i < ib; i++) tmp[i] = yfac[i] * slow[i];
+        gmin[jb] = three_smallest(tmp, ia, ib);
+        jb++;
+      } while (ib < q->fft1_last_inband);
+      for (int i = ib; i < q->fft1_last_point; i++) tmp[i] = yfac[i] * slow[i];
+    }
+    t1 = 0;
+    for (int j = ja; j < jb; j++) t1 += gmin[j];
+    t1 /= jb - ja;
+    k = 0;
+    float noise_floor = 0;
+    t1 *= (float)(2 * (1 + 2. / q->spek_avgnum));
+    for (int j = ja; j < jb; j++) if (gmin[j] < t1) { noise_floor += gmin[j]; k++; }
+    if (q->sellim_par3 == 1) {
+      t2 = (float)(0.05 * noise_floor / k);
+      int first_group = ja, last_group = jb;
+      while (gmin[first_group] < t2) first_group++;
+      while (gmin[last_group - 1] < t2) last_group--;
+      if (first_group != ja || last_group != jb) {
+        k = 0; noise_floor = 0;
+        for (int j = first_group; j < last_group; j++) if (gmin[j] < t1) { noise_floor += gmin[j]; k++; }
+      }
+    }
+    if (noise_floor < 0.0001) noise_floor = 0.0001f;
+    if (k != 0) {
+      noise_floor *= (float)((1 + 2. / q->spek_avgnum) / k);
+      noise_floor *= q->blanker_ston_fft1;
+      ia = 0;
+      while (ia < q->fft1_first_point || ia < 2) { if (lim[ia] == 0) lim[ia] = -1; ia++; }
+      while (tmp[ia] > noise_floor && ia < N) { if (lim[ia] == 0) lim[ia] = -1; ia++; }
+      t1 = q->sellim_par4 == 0 ? 4.F : 3.F;
+      while (t1 * tmp[ia + 1] < tmp[ia] && ia < N) { ia++; if (lim[ia] == 0) lim[ia] = -1; }
+      for (;;) {
+        while (tmp[ia] <= noise_floor && ia < q->fft1_last_point) ia++;
+        if (ia >= q->fft1_last_point) break;
+        ib = ia;
+        if (lim[ia] == 0) lim[ia] = -1;
+        while ((LRO_SFAC * tmp[ib - 1] < tmp[ib] || LRO_SFAC * LRO_SFAC * tmp[ib - 2] < tmp[ib]) && ib > q->fft1_first_point) {
+          ib--; if (lim[ib] == 0) lim[ib] = -1;
+        }
+        while (tmp[ia + 1] > noise_floor && ia < q->fft1_last_point) { ia++; if (lim[ia] == 0) lim[ia] = -1; }
+        if (ia != q->fft1_last_point) {
+          while ((LRO_SFAC * tmp[ia + 1] < tmp[ia] || LRO_SFAC * LRO_SFAC * tmp[ia + 2] < tmp[ia]) && ia < q->fft1_last_point) {
+            ia++; if (lim[ia] == 0) lim[ia] = -1;
+          }
+          ia++;
+        }
+        if (ia >= q->fft1_last_point) break;
+      }
+    }
+    if (ia > N - 2) ia = N - 2;
+    if (q->sellim_par8 == 0) { while (ia < N) { lim[ia] = -1; ia++; } }
+    else { while (ia < N) { if (lim[ia] == 0) lim[ia] = -1; ia++; } }
+    /* hold-off: a bin stays with the strong signals for about a second after it was last classified, and a gain is
+       released slowly (sellim.c:1121-1147) */
+    for (int i = 0; i < N; i++) {
+      if (lim[i] != 0) st->wait[i] = (unsigned char)wait_n;
+      else {
+        if (st->wait[i] > 0) st->wait[i]--;
+        if (st->wait[i] > 0) lim[i] = -1;
+      }
+      if (old[i] > 0) {
+        t1 = (float)(old[i] * LRO_RELEASE_FACTOR);
+        if (t1 < 1) { if (lim[i] > 0 && lim[i] > t1) lim[i] = t1; }
+      }
+    }
+  }
+  selfreq_liminfo(c, st, q);
+  lim[0] = 0; lim[1] = 0; lim[N - 2] = 0; lim[N - 1] = 0;
+  return LRH_OK;
+}
+
+int lro_get_liminfo(lro_ctx *c, float *dst) { if (!c || !dst) return LRH_EINVAL; memcpy(dst, c->liminfo, 4 * c->N1); return LRH_OK; }

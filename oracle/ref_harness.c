@@ -73,6 +73,7 @@ void make_bigpermute(int mo, int nz, int sz, unsigned int *perm);
 void make_sincos(int mo, int sz, COSIN_TABLE *tab);
 void init_fft(int mo, int nz, int sz, COSIN_TABLE *tab, unsigned short int *perm);
 void set_fft1_endpoints(void);
+void fft1_update_liminfo(void);
 
 /* ---- container writer ---- */
 static FILE *fo;
@@ -137,6 +138,8 @@ int main(int argc, char **argv)
                                                     real transform fft1_reherm_dit_one (fft1_re.c:32), 2*N1 reals per transform */
   int chain2 = AI("chain2", 0);                  /* channels=2 only: run on through the two-channel first_noise_blanker, make_fft2
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
+  int sellim = AI("sellim", 0);                  /* 1: the selective limiter runs (fft1_update_liminfo, sellim.c:738) whenever fft1_c completes an
+                                                    averaging period, in the single-CPU order of wcw.c:1124-1128; make_timf2 routes with its table */
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
   double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
@@ -244,7 +247,16 @@ int main(int argc, char **argv)
   fft1_split_float = zalloc(sizeof(float) * 8 * C * N1);
   fft1_back_scramble = zalloc(sizeof(short) * N1);
   fft1_inverted_window = zalloc(sizeof(float) * (N1 + 32));
-  liminfo = zalloc(sizeof(float) * N1);
+  liminfo = zalloc(sizeof(float) * 2 * N1);      /* second half: old_liminfo (sellim.c:748) */
+  if (sellim) {                                  /* buf.c:816-824, 956-958, 1469, 1523, 1759-1760; hires_graph.c:1175-1189 */
+    int groups = AI("lim_groups", 16);
+    liminfo_group_points = N1 / groups; if (liminfo_group_points < 1) liminfo_group_points = 1;
+    liminfo_wait = zalloc(N1); liminfo_group_min = zalloc(sizeof(float) * (N1 + 8)); fftt_tmp = (float *)zalloc(sizeof(float) * (2 * N1 + 32)) + 8;
+    fft1_sumsq_tot = 0; sel_ia = 0; sel_ib = 0;
+    genparm[SELLIM_MAXLEVEL] = AI("maxlevel", 12000); fft1_blocktime = (float)AF("blocktime", 0.0008);
+    baseband_bw_fftxpts = AI("bw_fftxpts", 40);
+    memset(&mg, 0, sizeof mg);
+  }
   make_permute(0, n1, N1, fft1_back_scramble);
   if (fft_cntrl[FFT1_CURMODE].permute == 2) { fft1_backtab = zalloc(sizeof(COSIN_TABLE) * N1); make_sincos(0, N1, fft1_backtab); }   /* buf.c:1318-1326 */
   else fft1_backtab = fft1tab;
@@ -271,6 +283,9 @@ int main(int argc, char **argv)
   hg.stupid_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.stupid_bln_factor);
   hg.clever_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.clever_bln_factor);
   hg.timf2_oscilloscope = 0;
+  hg.sellim_par1 = 2; hg.sellim_par2 = AI("par2", 0); hg.sellim_par3 = AI("par3", 0); hg.sellim_par4 = AI("par4", 0);
+  hg.sellim_par5 = AI("par5", 0); hg.sellim_par6 = AI("par6", 0); hg.sellim_par7 = AI("par7", 0); hg.sellim_par8 = AI("par8", 0);
+  hg.blanker_ston_fft1 = (float)AF("ston_fft1", 4.0);
   blnfit_range = fitrange; blanker_pulsewidth = pulsewidth;
   blanker_flag = zalloc(timf2pow_size + 64);
   min_delay_time = (bln_minpts >= 0) ? (float)bln_minpts : (float)N2 / 3.0f;   /* x ui.rx_ad_speed(=1), buf.c:500-509 */
@@ -442,6 +457,9 @@ int main(int argc, char **argv)
   float *mixtrace = zalloc(sizeof(float) * 8 * max_fft2_calls);
   short *wf_lines = zalloc(2 * (size_t)wg_xpixels * max_fft2_calls);
   float *fft1_first = zalloc(sizeof(float) * 2 * C * N1);    /* fft1_b output of block 0 before fft1_c */
+  int local_fft1_liminfo_cnt = 0, nlimupd = 0;
+  float *limtrace = sellim ? zalloc(sizeof(float) * N1 * (size_t)(nblk / avg1 + 2)) : NULL;
+  int *limtrace_blk = zalloc(sizeof(int) * (nblk / avg1 + 2));
   struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
   for (int b = 0; b < nblk && !harness_err; b++) {
     if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
@@ -510,6 +528,11 @@ int main(int argc, char **argv)
     it[5] = timf2_cleared_points; it[6] = timf2_blanker_points; it[7] = blanker_info_update_counter;
     it[8] = fft2_na; it[9] = fft1_sumsq_pa; it[10] = fft1_sumsq_counter; it[11] = fft1_lowlevel_points;
     it[12] = timf2_noise_floor; it[13] = (int)hg.stupid_bln_limit; it[14] = nfft2; it[15] = fft1_liminfo_cnt;
+    if (sellim && fft1_liminfo_cnt != local_fft1_liminfo_cnt) {        /* wcw.c:1124-1128 */
+      fft1_update_liminfo();
+      local_fft1_liminfo_cnt = fft1_liminfo_cnt;
+      memcpy(limtrace + (size_t)nlimupd * N1, liminfo, 4 * N1); limtrace_blk[nlimupd] = b; nlimupd++;
+    }
   }
 
   clock_gettime(CLOCK_MONOTONIC, &ts1);
@@ -535,6 +558,14 @@ int main(int argc, char **argv)
     int f3[4] = { nfft3, fft3_pa, timf3_px, fft3_interleave_points }; PUTI("fft3_ptrs", f3, 4);
     if (mix2on) { PUTF("baseb_raw", baseb_raw, 2 * baseband_size); PUTF("baseb_raw_orthog", baseb_raw_orthog, 2 * baseband_size);
       PUTF("bg_filterfunc", bg_filterfunc, fft3_size); int bp_[2] = { baseb_pa, fft3_px }; PUTI("baseb_ptrs", bp_, 2); } }
+  if (sellim) {
+    PUTF("liminfo_trace", limtrace, (size_t)N1 * (nlimupd > 0 ? nlimupd : 1)); PUTI("liminfo_trace_blk", limtrace_blk, nlimupd > 0 ? nlimupd : 1);
+    int sp[16] = { nlimupd, genparm[SELLIM_MAXLEVEL], wg.spek_avgnum, liminfo_group_points, fft1_first_point, fft1_last_point, fft1_first_inband,
+                   fft1_last_inband, baseband_bw_fftxpts, hg.sellim_par2, hg.sellim_par3, hg.sellim_par4, hg.sellim_par5, hg.sellim_par6, hg.sellim_par7, hg.sellim_par8 };
+    PUTI("sellim_params", sp, 16);
+    float sf[2] = { fft1_blocktime, hg.blanker_ston_fft1 }; PUTF("sellim_fparams", sf, 2);
+    PUTF("liminfo_final", liminfo, N1);
+  }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);
   { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);

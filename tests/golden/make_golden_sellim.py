@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Goldens of the selective limiter from the COMPILED REFERENCE (harness sellim=1: fft1_update_liminfo of sellim.c:738 runs in
+the single-CPU order of wcw.c:1124-1128 and make_timf2 routes with its table).  Data only: the seeded input, the limiter's
+parameters, liminfo after every update, and the rings the routing shapes.  usage: python tests/golden/make_golden_sellim.py"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from refcases import SELLIM, harness_args, sellim_case  # noqa: E402
+from refdump import load_dump  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+KEEP = ["liminfo_trace", "liminfo_trace_blk", "sellim_params", "sellim_fparams", "liminfo_final", "fft1_sumsq", "fft1_slowsum",
+        "timf2_float", "timf2_pwr_float", "fft2_powersum_float", "timf3_float", "itrace", "trace", "final", "wg_waterf_yfac"]
+
+
+def main():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    for name in sys.argv[1:] or list(SELLIM):
+        d, sl, iq = sellim_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+            iq.tofile(fi)
+            args = [a for a in harness_args(d, fi, "none", fo) if not a.startswith("liminfo=")]
+            subprocess.check_call([HARNESS] + args + ["sellim=1"] + [f"{k}={v}" for k, v in sl.items()])
+            ref = load_dump(fo)
+        out = {k: ref[k] for k in KEEP if k in ref}
+        out["iq"] = iq
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        tr = out["liminfo_trace"].reshape(-1, 1 << d["n1"])
+        print(name, os.path.getsize(path) // 1024, "KiB;", tr.shape[0], "updates; strong bins per update:",
+              [int(np.count_nonzero(r)) for r in tr[::max(1, tr.shape[0] // 8)]], "attenuated:", int(np.count_nonzero(tr[-1] > 0)))
+
+
+if __name__ == "__main__":
+    main()

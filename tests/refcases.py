@@ -264,3 +264,36 @@ def twochan_case(name, chain=False):
     frames[2::4] = np.clip(np.round(z1.real), -32767, 32767)
     frames[3::4] = np.clip(np.round(z1.imag), -32767, 32767)
     return d, frames, make_liminfo(d)
+
+
+# ---- selective limiter on (harness sellim=1): fft1_update_liminfo runs after every averaging period and make_timf2 routes with its table
+SELLIM = {
+    # strong carrier above the SELLIM_MAXLEVEL limit (pass 1: attenuation with tapered skirts), medium carriers picked up by the
+    # noise-floor pass once spek_avgnum spectra have been seen, a keyed carrier that comes and goes (hold-off and slow release)
+    "sellim_n10_n12": dict(base="n10_n12", nblk=200, maxlevel=12000, lim_groups=16, blocktime=0.0008, ston_fft1=4.0, bw_fftxpts=40,
+                           keyed=(150.0, 7000.0, 60, 110), blockpower_block=0),
+    # other switches: par2 (running group minima), par3 (edge groups skipped), par4, par8, selected passband protected (par7)
+    "sellim_n9_n11_pars": dict(base="n9_n11_shift", nblk=160, maxlevel=4000, lim_groups=32, blocktime=0.002, ston_fft1=3.0, bw_fftxpts=24,
+                               par2=1, par3=1, par4=1, par7=1, par8=1, sample_shift=0, keyed=(-77.0, 5000.0, 40, 90),
+                               strong=[(101.0, 6000.0)], weak=[(150.5, 45.0), (60.0, 400.0)]),
+}
+
+
+def sellim_case(name):
+    """params + input of a selective-limiter case: the base case's signal plus a carrier keyed on for blocks [on, off)"""
+    t = dict(SELLIM[name])
+    d = case_params(t.pop("base"))
+    keyed = t.pop("keyed")
+    sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par2", "par3", "par4", "par5", "par6", "par7", "par8")}
+    d.update(t)
+    iq = make_input(d).astype(np.float64)
+    N1 = 1 << d["n1"]
+    M1 = N1 - interleave(d["n1"], d["sinpow1"])
+    k, a, on, off = keyed
+    n = iq.size // 2
+    tt = np.arange(n)
+    gate = ((tt >= on * M1) & (tt < off * M1)).astype(np.float64)
+    z = a * gate * np.exp(2j * np.pi * k * tt / N1)
+    iq[0::2] += z.real
+    iq[1::2] += z.imag
+    return d, sl, np.clip(np.round(iq), -32767, 32767).astype(np.int16)

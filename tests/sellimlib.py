@@ -1,0 +1,80 @@
+"""Selective-limiter parity machinery shared by the oracle (CPU) and HIP (GPU) tests: drive a SELLIM case block by block in
+the harness's order -- fft1_b, fft1_c, make_timf2, first_noise_blanker, fft2 / mix1 while data is released, then
+fft1_update_liminfo when fft1_c has completed an averaging period (wcw.c:1124-1128) -- and compare with the reference golden."""
+import os
+
+import numpy as np
+
+from linrad_amd import abi
+from linrad_amd.abi import default_sellim
+from refcases import lrh_config, sellim_case
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+
+
+def sellim_params(cfg, g):
+    sp, sf = g["sellim_params"], g["sellim_fparams"]
+    return default_sellim(cfg, sellim_maxlevel=int(sp[1]), spek_avgnum=int(sp[2]), liminfo_group_points=int(sp[3]),
+                          fft1_first_point=int(sp[4]), fft1_last_point=int(sp[5]), fft1_first_inband=int(sp[6]),
+                          fft1_last_inband=int(sp[7]), baseband_bw_fftxpts=int(sp[8]), sellim_par2=int(sp[9]), sellim_par3=int(sp[10]),
+                          sellim_par4=int(sp[11]), sellim_par5=int(sp[12]), sellim_par6=int(sp[13]), sellim_par7=int(sp[14]),
+                          sellim_par8=int(sp[15]), fft1_blocktime=float(sf[0]), blanker_ston_fft1=float(sf[1]), exact_stats=1)
+
+
+def run(open_fn, name, g):
+    d, _, iq = sellim_case(name)
+    assert np.array_equal(iq, g["iq"])
+    cfg = lrh_config(d, iq)
+    api = open_fn(cfg)
+    api.timf1_write(iq)
+    api.set_mix1_selfreq(d["fq"])
+    par = sellim_params(cfg, g)
+    trace, blks, low = [], [], []
+    cnt = 0
+    for b in range(d["nblk"]):
+        api.fft1_b(1), api.fft1_c(1), api.make_timf2(1)
+        api.first_noise_blanker()
+        for _ in range(api.fft2_available()):
+            api.make_fft2(1)
+            api.fft2_mix1_fixed(1)
+        low.append(api.p.fft1_lowlevel_points)
+        if api.p.fft1_liminfo_cnt != cnt:
+            api.fft1_update_liminfo(par)
+            cnt = api.p.fft1_liminfo_cnt
+            trace.append(api.get_liminfo())
+            blks.append(b)
+    return dict(api=api, cfg=cfg, d=d, trace=np.array(trace), blks=np.array(blks), low=np.array(low),
+                timf2=api.export(abi.RING_TIMF2_FLOAT), pwr=api.export(abi.RING_TIMF2_PWR), timf3=api.export(abi.RING_TIMF3_FLOAT),
+                slowsum=api.export(abi.RING_FFT1_SLOWSUM))
+
+
+def compare(out, g, tol, value_tol=2e-6):
+    """routing pattern (weak / strong-unity / strong-attenuated per bin) exact after every update; attenuation values to
+    value_tol; the weak-bin counts make_timf2 reports; the rings the routing shapes to tol"""
+    n1 = out["api"].N1
+    ref = g["liminfo_trace"].reshape(-1, n1)
+    assert np.array_equal(out["blks"], g["liminfo_trace_blk"][:len(out["blks"])]) and len(out["blks"]) == ref.shape[0]
+    got = out["trace"]
+    rep = {"updates": int(ref.shape[0]), "pattern_mismatch_bins": int(np.sum(np.sign(got) != np.sign(ref)))}
+    assert rep["pattern_mismatch_bins"] == 0, rep
+    pos = ref > 0
+    rep["attenuated_bins_last"] = int(pos[-1].sum())
+    rep["value_err"] = float(np.max(np.abs(got[pos] - ref[pos]) / ref[pos])) if pos.any() else 0.0
+    assert rep["value_err"] <= value_tol, rep
+    it = g["itrace"].reshape(-1, 16)
+    assert np.array_equal(out["low"], it[:, 11]), "fft1_lowlevel_points trace differs"
+
+    def rel(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    keep = np.ones(out["timf2"].size, bool)                   # sin^2 overlap: pending half beyond timf2_pa (paritylib)
+    keep[(out["api"].p.timf2_pa + np.arange(4 * (n1 // 2))) % keep.size] = False
+    rep["timf2"] = rel(out["timf2"] * keep, g["timf2_float"] * keep)
+    rep["slowsum"] = rel(out["slowsum"], g["fft1_slowsum"])
+    rep["cleared_equal"] = bool(np.array_equal(out["pwr"] == 0, g["timf2_pwr_float"] == 0))
+    assert rep["timf2"] <= tol and rep["slowsum"] <= tol, rep
+    return rep
