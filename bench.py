@@ -34,7 +34,7 @@ from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newes
 from linrad_amd.workload import (ALG_BYTES, HBM_PEAK_GBS, alg_bytes_chain, chain_config, strong_liminfo, workload_name)  # noqa: E402
 
 METRIC = "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline"
-STAGES = ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol")
+STAGES = ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
 
 
 def setup_receiver(cfg, channel, open_fn, synth_mod):
@@ -272,6 +272,17 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
             coupled_fft3_mix2(rx, k3b, dist, dev)
             k3 -= k3b
 
+    # the selective limiter decides the strong / weak routing from the device-resident power spectra once per step
+    # (fft1_update_liminfo, sellim.c:738; reference defaults, the one-second hold-off at the workload's sample rate); until its
+    # first run the table is the hand-made one of setup_receiver
+    sel = None
+    if args.sellim and not coupled:
+        from linrad_amd.abi import default_sellim
+        # blanker_ston_fft1 is a slider of the high-resolution graph (hires_graph.c:710).  The SURVEY 8d test signal carries 20000-LSB
+        # impulses whose spectrum ripples across the band at 36 x the noise power; 30 keeps that ripple with the weak signal (51 bins
+        # routed strong: the carriers and their skirts), the 4 of a quiet band would route 38 % of the bins
+        sel = default_sellim(cfg, fft1_blocktime=M1 / 160e6, blanker_ston_fft1=30.0, exact_stats=0)
+
     def step():
         if coupled:
             run_coupled(rx, args.batch * args.rounds, args.batch, dist, device=dev, xy=True, pol=True)
@@ -286,6 +297,8 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 rx.timf1_write_async(flat[:nb - first], 0)
             wr[0] += nb
         rx.wideband_dsp(args.batch * args.rounds, args.batch)
+        if sel is not None:
+            rx.fft1_update_liminfo(sel)
         if combine:
             narrow_tail()
         if use_dist:
@@ -304,6 +317,12 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         if use_dist:
             dist.barrier()
 
+    if sel is not None:
+        # part of the set-up, like the hand-made table it replaces: the limiter's noise-floor pass only starts once spek_avgnum
+        # spectra have been seen (sellim.c:866), until then the medium carriers stay in the weak stream and latch the blanker
+        for _ in range(6):
+            rx.wideband_dsp(args.batch, args.batch)
+            rx.fft1_update_liminfo(sel)
     for _ in range(warmup):
         step()
     barrier()
@@ -328,6 +347,8 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                         "wideband_dsp_cpu_ms_per_call": round(host["wideband_dsp_cpu"][0] / max(host["wideband_dsp_cpu"][1], 1), 4),
                         "staging_wait_ms_per_call": round(host["staging_wait"][0] / max(host["staging_wait"][1], 1), 4)},
            "samples_per_step": samples_per_step, "workload": workload_name(w, args.batch),
+           "routing": ("selective limiter on the device once per step (lrh_fft1_update_liminfo), strong bins now %d of %d" %
+                       (int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",
            "config_text": w["text"].format(N1=N1, N2=N2, Nm=N2 >> 6, N3=(1 << w["fft3_n"]) if w["fft3_n"] else 0,
                                            Nm2=(1 << w["mix2_n"]) if w["mix2_n"] else 0, rounds=args.rounds, batch=args.batch,
                                            samples=samples_per_step, world=world)}
@@ -340,6 +361,8 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         rx.profile_enable(2)
         for _ in range(nprof):
             rx.wideband_dsp(args.batch * args.rounds, args.batch)
+            if sel is not None:
+                rx.fft1_update_liminfo(sel)
             if combine:
                 k3 = rx.fft3_available()                   # keep the rings moving; the collective is not profiled here
                 while k3 > 0:
@@ -482,6 +505,8 @@ def main():
     ap.add_argument("--cpu-blocks", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second workload of the default run")
+    ap.add_argument("--no-sellim", dest="sellim", action="store_false",
+                    help="keep the hand-made routing table instead of running the selective limiter (lrh_fft1_update_liminfo) once per step")
     ap.add_argument("--stream-host", action="store_true",
                     help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
                          "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")
@@ -574,7 +599,7 @@ def main():
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
-            "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
+            "routing": res.get("routing"), "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
             "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "secondary": secondary,
         }
         print(json.dumps(out), flush=True)

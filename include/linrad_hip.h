@@ -226,8 +226,9 @@ int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "ff
    stays on the device: one call = one run of the reference function; the routing words k_timf2 consumes are rebuilt on the
    device in stream order, so the next lrh_make_timf2 routes with the new table and no spectrum or table crosses PCIe.
    Host-visible by-product: the count of weak bins (fft1_lowlevel_points, timf2.c:37-52), read back asynchronously -- with
-   `exact_stats` the call waits for it (the reference's value at once); without, it is installed by the next call of this
-   function, i.e. the statistic (not the routing) lags one update, and nothing ever waits.
+   `exact_stats` the call waits for it (the reference's value at once); without, a call installs the count of the update before
+   the previous one (lrh_sync installs the newest), i.e. the statistic (not the routing) lags two updates and the host never waits
+   for work it has only just enqueued.
    lrh_set_liminfo and this call may be mixed: both replace the table in force. */
 typedef struct lrh_sellim {
   int struct_size;

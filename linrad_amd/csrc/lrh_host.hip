@@ -133,7 +133,12 @@ struct lrh_ctx {
   bool have_liminfo = false;
   // selective limiter on the device (lrh_fft1_update_liminfo): the reference's liminfo / old_liminfo / liminfo_wait / fftt_tmp
   float *d_liminfo = nullptr, *d_old_liminfo = nullptr, *d_sel_tmp = nullptr; unsigned char *d_sel_wait = nullptr; SellimState *d_sel_st = nullptr;
-  int *h_sel_low = nullptr; hipEvent_t ev_sel = nullptr; bool sel_pending = false;
+  // weak-bin counts come back through a ring of pinned slots; without exact_stats the one installed is two updates old, so
+  // the host never waits for a step it has only just enqueued
+  int *h_sel_low = nullptr; hipEvent_t ev_sel = nullptr, ev_sel_slot[3] = {}; unsigned sel_seq = 0; bool sel_pending = false;
+  // the limiter runs on the side stream, beside whatever the main stream still has queued: behind the last k_timf2 (which reads the
+  // routing words it rewrites) and the sums it reads; the next lrh_make_timf2 waits for it on the device
+  hipEvent_t ev_timf2_done = nullptr, ev_sel_wait = nullptr; bool timf2_done_valid = false, sel_table_pending = false; hipStream_t sums_stream = nullptr;
   bool pack_prev_stale = false;   // d_pack_prev differs from d_pack_cur (a new liminfo table arrived since the last make_timf2)
   // pinned staging for mix1 phases
   float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
@@ -313,7 +318,7 @@ void lrh_close(lrh_ctx *c)
   if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
-  for (hipEvent_t ev : { c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : { c->ev_timf2_done, c->ev_sel_wait, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -323,6 +328,7 @@ void lrh_close(lrh_ctx *c)
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->h_sel_low) hipHostFree(c->h_sel_low);
   if (c->ev_sel) hipEventDestroy(c->ev_sel);
+  for (hipEvent_t e : c->ev_sel_slot) if (e) hipEventDestroy(e);
   if (c->d_pack18) hipFree(c->d_pack18);
   if (c->d_stamps) hipFree(c->d_stamps);
   if (c->d_net) hipFree(c->d_net);
@@ -393,7 +399,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
   if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
   c->cur = c->stream;
-  for (hipEvent_t *ev : { &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  for (hipEvent_t *ev : { &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
@@ -617,7 +623,8 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   }
   for (int i = 0; i < c->N1; i++) if (liminfo[i] == 0) low++;
   // d_pack_prev (routing of the transform before the next batch) is rolled forward by lrh_make_timf2
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  c->sel_table_pending = false;
   c->h_pack = pack;
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_liminfo, liminfo, 4 * c->N1, hipMemcpyHostToDevice, c->stream));   // the table lrh_fft1_update_liminfo carries on from
@@ -630,12 +637,13 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
 }
 
 // fft1_update_liminfo + selfreq_liminfo on the device (include/linrad_hip.h); k_sellim, k_pack_liminfo
-static int sellim_install(lrh_ctx *c)      // the weak-bin count of the last update, once its readback has arrived
+// installs the weak-bin count of update number `seq` (1-based) once its readback has arrived
+static int sellim_install(lrh_ctx *c, unsigned seq)
 {
-  if (!c->sel_pending) return LRH_OK;
-  HIPCHK(c, hipEventSynchronize(c->ev_sel));
-  c->lowlevel_points = *c->h_sel_low;
-  c->sel_pending = false;
+  if (!c->sel_pending || seq == 0 || seq > c->sel_seq || seq + 3 <= c->sel_seq) return LRH_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_sel_slot[seq % 3]));
+  c->lowlevel_points = c->h_sel_low[seq % 3];
+  if (seq == c->sel_seq) c->sel_pending = false;
   return LRH_OK;
 }
 int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
@@ -646,10 +654,11 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
       c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
   if (!c->h_sel_low) {
-    if (hipHostMalloc((void **)&c->h_sel_low, sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+    if (hipHostMalloc((void **)&c->h_sel_low, 3 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
+    for (hipEvent_t &e : c->ev_sel_slot) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  { const int rc = sellim_install(c); if (rc) return rc; }      // the previous update's count (statistic one update late unless exact_stats)
+  if (c->sel_seq >= 2) { const int rc = sellim_install(c, c->sel_seq - 1); if (rc) return rc; }      // the count of the update before the last (unless exact_stats)
   SellimArgs a;
   a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
   a.slowsum = c->d_slowsum; a.yfac = c->d_yfac; a.liminfo = c->d_liminfo; a.old_liminfo = c->d_old_liminfo; a.tmp = c->d_sel_tmp;
@@ -661,17 +670,24 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   a.first_point = q->fft1_first_point; a.last_point = q->fft1_last_point; a.first_inband = q->fft1_first_inband; a.last_inband = q->fft1_last_inband;
   a.bw_fftxpts = q->baseband_bw_fftxpts; a.ston_scale = q->ston_scale;
   a.selfreq = c->ms.mix1_selfreq; a.points_per_hz = c->cfg.fftx_points_per_hz; a.second_fft = c->cfg.second_fft_enable;
-  { ProfScope ps(c, "sellim"); HIPCHK(c, launch_sellim(a, c->cur)); }
-  HIPCHK(c, hipMemcpyAsync(c->h_sel_low, &c->d_sel_st->low, sizeof(int), hipMemcpyDeviceToHost, c->cur));
-  HIPCHK(c, hipEventRecord(c->ev_sel, c->cur));
-  c->sel_pending = true; c->pack_prev_stale = true; c->have_liminfo = true;
-  if (q->exact_stats) return sellim_install(c);
+  hipStream_t S = c->stream2;
+  if (c->sums_stream != S || c->prof) {                       // sums on the main stream (serial order), or per-kernel timing: plain stream order
+    HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
+  } else if (c->timf2_done_valid) HIPCHK(c, hipStreamWaitEvent(S, c->ev_timf2_done, 0));
+  { hipStream_t keep = c->cur; c->cur = S; { ProfScope ps(c, "sellim"); hipError_t e_ = launch_sellim(a, S); if (e_ != hipSuccess) { c->cur = keep; return fail(c, LRH_EDEVICE, "launch_sellim", e_); } } c->cur = keep; }
+  c->sel_seq++;
+  HIPCHK(c, hipMemcpyAsync(&c->h_sel_low[c->sel_seq % 3], &c->d_sel_st->low, sizeof(int), hipMemcpyDeviceToHost, S));
+  HIPCHK(c, hipEventRecord(c->ev_sel_slot[c->sel_seq % 3], S));
+  HIPCHK(c, hipEventRecord(c->ev_sel, S));
+  c->sel_pending = true; c->sel_table_pending = true; c->pack_prev_stale = true; c->have_liminfo = true;
+  if (q->exact_stats) return sellim_install(c, c->sel_seq);
   return LRH_OK;
 }
 int lrh_get_liminfo(lrh_ctx *c, float *dst)
 {
   LRH_ENTER(c);
   if (!c || !dst) return LRH_EINVAL;
+  if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
   HIPCHK(c, hipMemcpyAsync(dst, c->d_liminfo, 4 * c->N1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
@@ -906,7 +922,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
       if (p->fft1_sumsq_recalc == last) p->fft1_sumsq_recalc = 0;
       p->fft1_sumsq_recalc += ua.step; if (p->fft1_sumsq_recalc > last) p->fft1_sumsq_recalc = last;
     }
-    LRH_DEVICE_WORK(c, { ProfScope ps(c, "slowsum"); HIPCHK(c, launch_slowsum(ua, c->cur)); });
+    LRH_DEVICE_WORK(c, { ProfScope ps(c, "slowsum"); HIPCHK(c, launch_slowsum(ua, c->cur)); c->sums_stream = c->cur; });
     if (c->cfg.second_fft_enable) p->fft1_liminfo_cnt += nupd;          // fft1.c:4515-4518
     p->fft1_sumsq_pa = (p->fft1_sumsq_pa + nupd * N) & c->sumsq_mask;
   }
@@ -921,6 +937,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  if (c->sel_table_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_sel, 0)); c->sel_table_pending = false; }   // routing words from the side stream
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
   a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
@@ -949,6 +966,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->cur));
     c->pack_prev_stale = false;
   }
+  HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
   const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
     p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
@@ -1807,7 +1825,7 @@ int lrh_sync(lrh_ctx *c)
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
   for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2 }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
-  return sellim_install(c);
+  return sellim_install(c, c->sel_seq);
 }
 
 int lrh_timer_start(lrh_ctx *c) { LRH_ENTER(c); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }

@@ -1836,10 +1836,10 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
   const int N = a.n, tid = threadIdx.x;
   float *A = sm + 8;                       // power block, later fftt_tmp (the scans look two bins beyond their range)
   float *B = A + N + 16;                   // liminfo
-  float *G = B + N + 8;                    // liminfo_group_min (at most N/16 + 2 groups... sized N/4 + 8)
-  int *hot = (int *)(G + N / 4 + 8);       // [256] first hot bin of a chunk, or N
+  float *G = B + N + 8;                    // liminfo_group_min (at most N/16 groups; sized N/4 + 8)
+  unsigned int *hotw = (unsigned int *)(G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
   __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
-  const int CH = (N + 255) / 256;          // bins per chunk
+  const int NW = (N + 31) / 32;
   for (int i = tid; i < N; i += 256) { A[i] = a.sumsq[i]; B[i] = a.liminfo[i]; }
   for (int i = tid; i < 8; i += 256) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
   if (tid == 0) {
@@ -1853,41 +1853,60 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
   }
   __syncthreads();
   const float limit = s_limit;
-  { int f = N; for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) if (A[i] > limit) { f = i; break; } hot[tid] = f; }
-  __syncthreads();
   const int sel_ia = a.st->sel_ia, sel_ib = a.st->sel_ib, par7 = a.par7;
   const int ix = a.first_point, iy = a.last_point - 1;
+  auto build_bits = [&](float thr) {       // all threads: bit i = A[i] > thr
+    for (int w = tid; w < NW + 2; w += 256) {
+      unsigned int m = 0;
+      for (int b = 0; b < 32; b++) { const int i = 32 * w + b; if (i < N && A[i] > thr) m |= 1u << b; }
+      hotw[w] = m;
+    }
+  };
+  auto next_set = [&](int i) -> int {      // first bin >= i whose bit is set (N if none)
+    while (i < N) {
+      const unsigned int m = hotw[i >> 5] >> (i & 31);
+      if (m) return i + __ffs(m) - 1;
+      i = (i | 31) + 1;
+    }
+    return N;
+  };
+  auto next_clear = [&](int i) -> int {    // first bin >= i whose bit is clear (N if none)
+    while (i < N) {
+      const unsigned int m = ~hotw[i >> 5] >> (i & 31);
+      const int room = 32 - (i & 31);
+      if (m & (room == 32 ? 0xffffffffu : ((1u << room) - 1))) return i + __ffs(m) - 1;
+      i = (i | 31) + 1;
+    }
+    return N;
+  };
+  // ---- pass 1 (sellim.c:789-865): bins at or below the limit become weak; a run above the limit gets one attenuation over
+  // its whole width and tapered skirts.  The serial scan zeroes a bin when it passes it; here all bins at or below the limit
+  // are zeroed up front by all threads, and thread 0 only visits the runs -- reading, for the bins the serial scan has not
+  // reached yet at that moment, the previous update's value (still in a.liminfo) instead of the zero put there early.
+  build_bits(limit);
+  for (int i = ix + tid; i < iy; i += 256) if (!(A[i] > limit) && (i > sel_ib || i < sel_ia || par7 == 0)) B[i] = 0;
+  __syncthreads();
   if (tid == 0) {
-    // ---- pass 1 (sellim.c:789-865): bins at or below the limit become weak; a run above it gets one attenuation over its
-    // whole width and tapered skirts.  `ia` walks upwards; nothing happens between runs except the zeroing.
-    auto next_hot = [&](int i) -> int {                     // first bin >= i above the limit (N if none)
-      while (i < N) {
-        const int c = i / CH;
-        if (hot[c] < N && hot[c] >= i) return hot[c];
-        const int e = min(N, (c + 1) * CH);
-        if (hot[c] < N) { for (; i < e; i++) if (A[i] > limit) return i; }   // past the chunk's first: look at the rest of it
-        i = e;
-      }
-      return N;
-    };
     int ia = ix;
-    do {
-      int nh = next_hot(ia); if (nh > iy) nh = iy;           // the loop handles bins ia < iy
-      for (; ia < nh; ia++) if (ia > sel_ib || ia < sel_ia || par7 == 0) B[ia] = 0;
-      if (ia >= iy) break;
-      // ia is above the limit
+    for (;;) {
+      int nh = next_set(ia);
+      if (nh >= iy) break;                                   // the serial loop handles bins ia < iy
+      ia = nh;
+      const int done = ia;                                   // bins below `done` hold this update's values, the rest the previous one's
+      auto cur = [&](int j) -> float { return (j < done || A[j] > limit) ? B[j] : a.liminfo[j]; };   // a run's own bins are untouched so far
       float maxval = A[ia];
-      int ib = ia + 1;
-      while (A[ib] > limit && ib <= iy) { if (A[ib] > maxval) maxval = A[ib]; ib++; }
+      int ib = next_clear(ia + 1); if (ib > iy + 1) ib = iy + 1;       // while(sumsq[ib] > limit && ib <= iy) ib++
+      for (int j = ia + 1; j < ib; j++) if (A[j] > maxval) maxval = A[j];
       while (ia > ix && A[ia - 1] / A[ia] < 0.3) ia--;
       while (ib < iy && A[ib + 1] / A[ib] < 0.3) ib++;
       int ja = ia, jb = ib;
-      float t1 = B[ja], t2;
-      for (int j = ja + 1; j <= jb; j++) if (B[j] > 0 && B[j] < t1) t1 = B[j];
+      float t1 = cur(ja), t2;
+      for (int j = ja + 1; j <= jb; j++) { const float v = cur(j); if (v > 0 && v < t1) t1 = v; }
       t2 = (float)sqrt((double)(limit / maxval));
       if (t1 / t2 > 0.1 && t1 / t2 < 10) t2 = (float)(0.8 * t1 + 0.2 * t2);
-      if (ja > sel_ib || jb < sel_ia || par7 == 0)
-        for (int j = ja; j <= jb; j++) if (j > sel_ib || j < sel_ia || par7 == 0) B[j] = t2;
+      if (ja > sel_ib || jb < sel_ia || par7 == 0) {
+        for (int j = ja; j <= jb; j++) if (j > sel_ib || j < sel_ia || par7 == 0) B[j] = t2; else if (j >= done) B[j] = a.liminfo[j];
+      } else for (int j = max(ja, done); j <= jb; j++) B[j] = a.liminfo[j];        // left alone by the serial scan: previous values
       t1 = t2;
       int j = 1 + (ib - ia) / 4;
       while (ia > ix && j > 0) {
@@ -1900,12 +1919,13 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
       while (ib < iy && j > 0) {
         j--; ib++; jb = ib;
         t2 = (float)pow((double)t2, 0.9);
-        if (B[jb] <= 0 || B[jb] > t1) B[jb] = t2;
-        else break;
+        const float v = a.liminfo[jb];                       // not reached yet by the serial scan
+        if (v <= 0 || v > t1) B[jb] = t2;
+        else { B[jb] = v; break; }                           // the scan resumes behind this bin: it keeps its previous value
       }
-      ia = ib;
-      ia++;
-    } while (ia < iy);
+      ia = ib + 1;
+      if (ia >= iy) break;
+    }
   }
   __syncthreads();
   if (s_pass2) {
@@ -1954,35 +1974,30 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
     }
     __syncthreads();
     const float nf = s_nf;
-    { int f = N; for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) if (A[i] > nf) { f = i; break; } hot[tid] = f; }
+    build_bits(nf);
+    // Every bin above the noise floor from bin 2 up to last_point - 1 ends up marked by the serial scan (as a member of a
+    // run, of a skirt, or as the start of the next run): all threads mark them now; thread 0 then walks the runs only, for
+    // the skirts below and above each run and the end of the band.
+    if (s_k != 0) for (int i = 2 + tid; i < a.last_point; i += 256) if (A[i] > nf && B[i] == 0) B[i] = -1;
     __syncthreads();
     if (tid == 0) {
-      auto next_hot = [&](int i) -> int {                   // first bin >= i above the noise floor (N if none)
-        while (i < N) {
-          const int c = i / CH;
-          if (hot[c] < N && hot[c] >= i) return hot[c];
-          const int e = min(N, (c + 1) * CH);
-          if (hot[c] < N) { for (; i < e; i++) if (A[i] > nf) return i; }
-          i = e;
-        }
-        return N;
-      };
+      auto mark = [&](int i) { if (B[i] == 0) B[i] = -1; };
       int ia = N;                                          // k == 0 cannot happen (one group is always below twice the mean); the reference
       if (s_k != 0) {                                      // would then carry on with the group loop's leftover index, beyond the band
         ia = 0;
-        while (ia < a.first_point || ia < 2) { if (B[ia] == 0) B[ia] = -1; ia++; }
-        while (A[ia] > nf && ia < N) { if (B[ia] == 0) B[ia] = -1; ia++; }
+        while (ia < a.first_point || ia < 2) { mark(ia); ia++; }
+        { const int e = next_clear(ia); for (int i = max(ia, a.last_point); i < e; i++) mark(i); ia = e; }   // while(tmp[ia] > nf && ia < N)
         const float t1 = a.par4 == 0 ? 4.F : 3.F;
-        while (t1 * A[ia + 1] < A[ia] && ia < N) { ia++; if (B[ia] == 0) B[ia] = -1; }
+        while (t1 * A[ia + 1] < A[ia] && ia < N) { ia++; mark(ia); }
         for (;;) {
-          { int nh = next_hot(ia); if (nh > a.last_point) nh = a.last_point; if (nh > ia) ia = nh; }   // while(tmp[ia] <= nf && ia < last) ia++
+          { int nh = next_set(ia); if (nh > a.last_point) nh = a.last_point; if (nh > ia) ia = nh; }   // while(tmp[ia] <= nf && ia < last) ia++
           if (ia >= a.last_point) break;
           int ib = ia;
-          if (B[ia] == 0) B[ia] = -1;
-          while ((2.f * A[ib - 1] < A[ib] || 4.f * A[ib - 2] < A[ib]) && ib > a.first_point) { ib--; if (B[ib] == 0) B[ib] = -1; }
-          while (A[ia + 1] > nf && ia < a.last_point) { ia++; if (B[ia] == 0) B[ia] = -1; }
+          mark(ia);
+          while ((2.f * A[ib - 1] < A[ib] || 4.f * A[ib - 2] < A[ib]) && ib > a.first_point) { ib--; mark(ib); }
+          { int e = next_clear(ia + 1) - 1; if (e > a.last_point) e = a.last_point; if (e > ia) ia = e; mark(ia); }   // to the end of the run
           if (ia != a.last_point) {
-            while ((2.f * A[ia + 1] < A[ia] || 4.f * A[ia + 2] < A[ia]) && ia < a.last_point) { ia++; if (B[ia] == 0) B[ia] = -1; }
+            while ((2.f * A[ia + 1] < A[ia] || 4.f * A[ia + 2] < A[ia]) && ia < a.last_point) { ia++; mark(ia); }
             ia++;
           }
           if (ia >= a.last_point) break;
@@ -2062,7 +2077,7 @@ __global__ __launch_bounds__(256) void k_pack_liminfo(const float *liminfo, unsi
 
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
-  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * 256;
+  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
