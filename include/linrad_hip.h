@@ -403,6 +403,12 @@ int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                 
    sample cross PCIe instead of 16.  The packet framing (NET_RX_STRUCT header, block numbers, 1392-byte payloads,
    globdef.h:1283-1294) stays with the host's network thread.  Synchronous. */
 int lrh_export_timf2_net(lrh_ctx *ctx, float *dst, int timf2_pt, int count, float map65_gain, float map65_strong);
+/* Payload of the NET_RXOUT_FFT1 multicast (wcw.c:1024-1043, network.c:383-388): `batch` transforms as fft1_b leaves them -- window,
+   transform, DC at fft1_size/2, mirror-image calibration and passband direction, but NOT the filter correction of fft1_c -- for the
+   blocks starting at timf1p_ref, 2*fft1_size floats each.  The hot path folds the correction into the transform's store and never
+   holds this form, so it is recomputed from the timf1 ring (which keeps at least a second of input, buf.c:744-770): one extra
+   fft1 pass, only paid by installations that multicast this stage.  Synchronous. */
+int lrh_export_fft1_net(lrh_ctx *ctx, float *dst, int timf1p_ref, int batch);
 /* same span, device-to-device into a caller-owned device buffer (e.g. the RCCL exchange buffer of the
    cross-channel power sum, fft1.c:4138); synchronous on the context stream */
 int lrh_export_device(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);

@@ -216,6 +216,8 @@ class StageAPI:
         self._proto("export", [vp, C.c_int, vp, C.c_size_t, C.c_size_t])
         self._proto("get_blanker_state", [vp, C.POINTER(LrhBlankerState)])
         self._proto("export_timf2_net", [vp, fp, C.c_int, C.c_int, C.c_float, C.c_float])
+        if prefix == "lrh":
+            self._proto("export_fft1_net", [vp, fp, C.c_int, C.c_int])
         self.ctx = vp()
         rc = self._f("open")(C.byref(cfg), C.byref(self.ctx))
         if rc != 0:
@@ -495,6 +497,12 @@ class StageAPI:
         """NET_RXOUT_TIMF2 payload (rxin.c:944-966): gain * (weak + strong_scale * strong) as `count` complex floats"""
         out = np.empty(2 * count, np.float32)
         self._chk(self._f("export_timf2_net")(self.ctx, self._fptr(out), int(timf2_pt), int(count), float(map65_gain), float(map65_strong)), "export_timf2_net")
+        return out
+
+    def export_fft1_net(self, timf1p_ref, batch=1):
+        """NET_RXOUT_FFT1 payload (wcw.c:1024-1043): `batch` transforms as fft1_b leaves them, before fft1_c's filter correction"""
+        out = np.empty(2 * self.N1 * batch, np.float32)
+        self._chk(self._f("export_fft1_net")(self.ctx, self._fptr(out), int(timf1p_ref), int(batch)), "export_fft1_net")
         return out
 
     def blanker_state(self):

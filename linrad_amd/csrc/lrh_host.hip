@@ -93,6 +93,7 @@ struct lrh_ctx {
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
   float2 *d_net = nullptr; size_t net_cap = 0;      // staging of lrh_export_timf2_net
+  float2 *d_fft1net = nullptr; int fft1net_cap = 0; // staging of lrh_export_fft1_net: bare transforms, [pow2 >= batch][N1]
   float2 *d_xpol = nullptr; float2 pol_wa = {1.f, 0.f}, pol_wb = {0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
@@ -332,6 +333,7 @@ void lrh_close(lrh_ctx *c)
   if (c->d_pack18) hipFree(c->d_pack18);
   if (c->d_stamps) hipFree(c->d_stamps);
   if (c->d_net) hipFree(c->d_net);
+  if (c->d_fft1net) hipFree(c->d_fft1net);
   if (c->d_foldcorr) hipFree(c->d_foldcorr);
   if (c->d_unitcorr) hipFree(c->d_unitcorr);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
@@ -1818,6 +1820,54 @@ int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+// NET_RXOUT_FFT1 (wcw.c:1024-1043, network.c:383-388): the transform as fft1_b leaves it, i.e. before fft1_c's filter correction.
+// The hot path applies that correction in k_fft1's store, so the ring never holds the bare transform; a sender of this stage
+// gets it recomputed from the timf1 ring into a staging buffer (the same kernels with a unit filter table; the mirror-image
+// step and the direction flip, which belong to fft1_b, included) -- one extra fft1 pass, only for installations that multicast
+// this stage.
+int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
+{
+  LRH_ENTER(c);
+  if (!c || !dst || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  int cap = 1; while (cap < batch) cap <<= 1;
+  if (cap > c->fft1net_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_fft1net) hipFree(c->d_fft1net);
+    c->d_fft1net = nullptr; c->fft1net_cap = 0;
+    if (hipMalloc((void **)&c->d_fft1net, (size_t)cap * c->N1 * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(fft1 net staging)");
+    c->fft1net_cap = cap;
+  }
+  if (!c->d_unitcorr) {
+    if (hipMalloc((void **)&c->d_unitcorr, sizeof(float2) * c->N1) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(unit filter table)");
+    std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
+    HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), sizeof(float2) * c->N1, hipMemcpyHostToDevice));
+  }
+  if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  Fft1Args a;
+  const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
+  const int esz = c->cfg.timf1_dword_input ? 8 : 4;
+  a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / esz - 1; a.dword = c->cfg.timf1_dword_input != 0;
+  a.shift_i = c->cfg.sample_shift > 0 ? -c->cfg.sample_shift : 0; a.shift_q = c->cfg.sample_shift < 0 ? c->cfg.sample_shift : 0;
+  a.chan_count = C; a.chan_index = C > 1 ? c->cfg.timf1_channel_index : 0;
+  a.p0_first = ((timf1p_ref & c->timf1_bytemask) / (esz * C) - c->I1) & (a.ring_mask / C);
+  a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_unitcorr; a.tw = c->d_tw1; a.out = c->d_fft1net;
+  a.first_nb = 0; a.nb_mask = c->fft1net_cap - 1; a.direction = c->cfg.fft1_direction; a.xcd = 0; a.batch = batch;
+  a.real = c->cfg.timf1_real_input != 0; a.stamps = nullptr;
+  if (c->d_foldcorr || a.real) a.direction = 1;
+  HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->stream));
+  if (a.real) {
+    RealSplitArgs r; r.spec = c->d_fft1net; r.first_nb = 0; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_unitcorr; r.direction = c->cfg.fft1_direction;
+    HIPCHK(c, launch_realsplit(r, batch, c->stream));
+  } else if (c->d_foldcorr) {
+    FoldcorrArgs f; f.spec = c->d_fft1net; f.first_nb = 0; f.nb_mask = a.nb_mask; f.n = c->N1; f.foldcorr = c->d_foldcorr; f.filtercorr = c->d_unitcorr; f.direction = c->cfg.fft1_direction;
+    HIPCHK(c, launch_foldcorr(f, batch, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(dst, c->d_fft1net, (size_t)batch * c->N1 * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
 int lrh_sync(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;

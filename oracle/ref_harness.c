@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <time.h>
+#include <pthread.h>
+#include <unistd.h>
 
 #include "globdef.h"
 #include "uidef.h"
@@ -99,6 +101,110 @@ static const char *arg(int argc, char **argv, const char *k, const char *def)
 }
 #define AI(k, d) atoi(arg(argc, argv, k, #d))
 #define AF(k, d) atof(arg(argc, argv, k, #d))
+
+/* ---- timing=1 threads=T: the reference's own thread topology (wcw.c:604-648) around its unchanged stage functions.
+   THREAD_WIDEBAND_DSP dispatches every block to one of up to six THREAD_FFT1Bk workers and retires them in order (wcw.c:969-1047);
+   THREAD_TIMF2 runs fft1_c / make_timf2 for every finished transform and then the blanker (wcw.c:401-441); THREAD_SECOND_FFT runs
+   make_fft2 while a transform's worth of samples is released (wcw.c:250-304); the narrowband thread runs fft2_mix1_fixed and
+   what follows (wcw.c:1240-1405).  Hand-offs: binary auto-reset condition events like lxsys.c:415-447. ---- */
+enum { TEV_TIMF2, TEV_FFT2, TEV_READY, TEV_SPACE, TEV_DONE, TEV_DO, TNEV = TEV_DO + 6 };
+static pthread_mutex_t tev_m[TNEV]; static pthread_cond_t tev_c[TNEV]; static volatile int tev_f[TNEV];
+static void tev_set(int n) { pthread_mutex_lock(&tev_m[n]); tev_f[n] = 1; pthread_cond_signal(&tev_c[n]); pthread_mutex_unlock(&tev_m[n]); }
+static void tev_await(int n) { pthread_mutex_lock(&tev_m[n]); while (!tev_f[n]) pthread_cond_wait(&tev_c[n], &tev_m[n]); tev_f[n] = 0; pthread_mutex_unlock(&tev_m[n]); }
+static struct { int nblk, workers, C, n3, mix2on, N2, fq_ok; volatile int wide_done, timf2_done, fft2_done; volatile int nfft2; float *tmp[6];
+                struct { volatile int inptr, out, busy; } job[6]; } TH;
+static void *th_fft1b(void *arg)
+{
+  const int k = (int)(long)arg;
+  for (;;) {
+    tev_await(TEV_DO + k);
+    if (TH.job[k].busy < 0) return NULL;
+    fft1_b(TH.job[k].inptr, &fft1_float[TH.job[k].out], TH.tmp[k], k);
+    TH.job[k].busy = 2;
+    tev_set(TEV_DONE);
+  }
+}
+static void *th_timf2(void *arg)
+{
+  for (;;) {
+    tev_await(TEV_TIMF2);
+    while (fft1_na != fft1_nb) {
+      while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
+      first_noise_blanker();
+      if (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size) tev_set(TEV_FFT2);
+      tev_set(TEV_SPACE);
+    }
+    if (TH.wide_done && fft1_na == fft1_nb) break;
+  }
+  TH.timf2_done = 1; tev_set(TEV_FFT2);
+  return NULL;
+}
+static void *th_fft2(void *arg)
+{
+  for (;;) {
+    tev_await(TEV_FFT2);
+    while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size && ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask) < max_fft2n - 1) {
+      make_fft2_status = FFT2_NOT_ACTIVE;
+      while (make_fft2_status != FFT2_COMPLETE) make_fft2();
+      tev_set(TEV_READY); tev_set(TEV_SPACE);
+    }
+    if (TH.timf2_done && ((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) < 4 * TH.C * fft2_size) break;
+    if (((fft2_na - fft2_nx + max_fft2n) & fft2n_mask) >= max_fft2n - 1) { tev_set(TEV_READY); usleep(50); tev_set(TEV_FFT2); }
+  }
+  TH.fft2_done = 1; tev_set(TEV_READY);
+  return NULL;
+}
+static void *th_narrow(void *arg)
+{
+  for (;;) {
+    tev_await(TEV_READY);
+    while (fft2_nx != fft2_na) {
+      if (TH.fq_ok) fft2_mix1_fixed(); else fft2_nx = (fft2_nx + 1) & fft2n_mask;
+      TH.nfft2++;
+      if (TH.n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * TH.C * fft3_size &&
+                            ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) {
+        make_fft3_all();
+        if (TH.mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; }
+        fft3_px = (fft3_px + fft3_block) & fft3_mask;
+      }
+      tev_set(TEV_FFT2); tev_set(TEV_SPACE);
+    }
+    if (TH.fft2_done && fft2_nx == fft2_na) break;
+  }
+  return NULL;
+}
+static void th_retire(int k)
+{
+  while (TH.job[k].busy != 2) tev_await(TEV_DONE);
+  TH.job[k].busy = 0;
+  fft1_pa = (fft1_pa + fft1_mulblock) & fft1_mask;
+  fft1_na = fft1_pa / fft1_block;
+  if (fft1_nm != fft1n_mask) fft1_nm++;
+  tev_set(TEV_TIMF2);
+}
+static void run_reference_threads(void)        /* the dispatcher = this thread (THREAD_WIDEBAND_DSP) */
+{
+  pthread_t th[3 + 6];
+  int n = 0, next = 0, oldest = 0, inflight = 0, out = fft1_pa;
+  for (int i = 0; i < TNEV; i++) { pthread_mutex_init(&tev_m[i], NULL); pthread_cond_init(&tev_c[i], NULL); }
+  pthread_create(&th[n++], NULL, th_narrow, NULL); pthread_create(&th[n++], NULL, th_fft2, NULL); pthread_create(&th[n++], NULL, th_timf2, NULL);
+  for (int k = 0; k < TH.workers; k++) pthread_create(&th[n++], NULL, th_fft1b, (void *)(long)k);
+  for (int b = 0; b < TH.nblk; b++) {
+    /* room in the rings (Linrad counts overruns instead, wcw.c:770-785) */
+    while (((fft1_na - fft1_nx + max_fft1n) & fft1n_mask) + inflight >= max_fft1n - 2 ||
+           ((timf2_pa - timf2_px + timf2_size) & timf2_mask) > timf2_size / 2) tev_await(TEV_SPACE);
+    if (inflight == TH.workers) { th_retire(oldest); oldest = (oldest + 1) % TH.workers; inflight--; }
+    TH.job[next].inptr = timf1p_px; TH.job[next].out = out; TH.job[next].busy = 1;
+    out = (out + fft1_mulblock) & fft1_mask;
+    timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
+    tev_set(TEV_DO + next);
+    next = (next + 1) % TH.workers; inflight++;
+  }
+  while (inflight > 0) { th_retire(oldest); oldest = (oldest + 1) % TH.workers; inflight--; }
+  for (int k = 0; k < TH.workers; k++) { TH.job[k].busy = -1; tev_set(TEV_DO + k); }
+  TH.wide_done = 1; tev_set(TEV_TIMF2);
+  for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
+}
 
 /* per-block scalar trace */
 #define TR_COLS 16
@@ -461,6 +567,24 @@ int main(int argc, char **argv)
   float *limtrace = sellim ? zalloc(sizeof(float) * N1 * (size_t)(nblk / avg1 + 2)) : NULL;
   int *limtrace_blk = zalloc(sizeof(int) * (nblk / avg1 + 2));
   struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
+  int nthreads = AI("threads", 0);
+  if (timing && nthreads && second && C == 1) {
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int workers = nthreads > 0 ? nthreads - 3 : (int)ncpu - 3;
+    if (workers < 1) workers = 1;
+    if (workers > 6) workers = 6;                 /* MAX_FFT1_THREADS, thrdef.h:107 */
+    memset(&TH, 0, sizeof TH);
+    TH.nblk = nblk; TH.workers = workers; TH.C = C; TH.n3 = n3; TH.mix2on = mix2on; TH.N2 = N2; TH.fq_ok = fq >= 0;
+    for (int k = 0; k < workers; k++) TH.tmp[k] = zalloc(sizeof(float) * (4 * C * N1 + 64));
+    run_reference_threads();
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    printf("{\"loop_seconds\": %.6f, \"blocks\": %d, \"samples\": %ld, \"fft2\": %d, \"cleared\": %d, \"threads\": %d, "
+           "\"topology\": \"dispatcher + %d fft1_b workers + timf2 + second_fft + narrowband threads\"}\n",
+           (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec), nblk, (long)nblk * fft1_new_points, TH.nfft2, timf2_cleared_points,
+           workers + 4, workers);
+    fclose(fo);
+    return harness_err ? 3 : 0;
+  }
   for (int b = 0; b < nblk && !harness_err; b++) {
     if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
       long r = b / lim_every; if (r >= nlimrec) r = nlimrec - 1;

@@ -91,6 +91,19 @@ def test_hip_fft3_mix2_matches_oracle():
     assert relerr(a["baseb_raw"], b["baseb_raw"]) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["n8_n10", "n10_n12", "n9_n11_dir", "n9_n11_iqcal", "n10_n12_dword", "n9_n11_real"])
+def test_hip_fft1_net_payload_matches_reference(name):
+    """NET_RXOUT_FFT1 sends fft1_float as fft1_b leaves it (wcw.c:1024-1043), before fft1_c's filter correction: the golden keeps
+    that block of the compiled reference (fft1_first_raw); the HIP path recomputes it on request (lrh_export_fft1_net)"""
+    g = load_golden(name)
+    out = run_case(_open_hip, name, golden=g)
+    api = out["api"]
+    got = api.export_fft1_net(0, 1)
+    assert relerr(got, g["fft1_first_raw"]) < 1e-5
+    two = api.export_fft1_net(0, 2)
+    assert np.array_equal(two[:got.size], got)
+
+
 def test_hip_tables_match_reference():
     for name in CASES:
         g = load_golden(name)
