@@ -246,6 +246,35 @@ typedef struct lrh_sellim {
 int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
 int lrh_get_liminfo(lrh_ctx *ctx, float *liminfo /* N1 floats: the table in force */);     /* synchronous */
 
+/* ---- spur (carrier) subtraction in the fft2 spectra: eliminate_spurs (spur.c:36-494), called by make_fft2 between the transform
+   and the power sums (fft2.c:647-652) when spurs are being tracked.  Every spur has a phase-locked loop over the last spur_speknum
+   transforms of its SPUR_WIDTH = 7 bins (refine_pll_parameters spur.c:634-680, spur_phase_parameters spur.c:1427-1652): the new
+   transform's bins join the history, the loop's phase / frequency / drift / amplitude are refined, and amplitude x the reference
+   line shape spur_spectra at the predicted phase is subtracted from the new transform -- before mix1, the power sums and the
+   waterfall see it.  Built: this tracking / subtraction path, one RF channel, float spectra, on the device inside lrh_make_fft2.
+   Control plane, stays with the host like the AFC: finding spurs and the first lock (init_spur_elimination, store_new_spur,
+   spur_phase_lock, spursub.c) hand their result over with lrh_spur_set; a spur whose lock is lost (flag != 0, spur.c:238,
+   293-297) is kept in the reference's unlocked bookkeeping (history copied, flag counted up) and reported by lrh_spur_get
+   for the host to re-lock (spur_relock, spur.c:682) or drop. */
+#define LRH_SPUR_WIDTH 7            /* SPUR_WIDTH = SPUR_SIZE - 1 (globdef.h:173-174, seldef.h:6) */
+#define LRH_SPUR_SPECTRA (256 * 8)  /* NO_OF_SPUR_SPECTRA * SPUR_SIZE floats (globdef.h:175)      */
+typedef struct lrh_spur {
+  int spur_location;            /* first of the SPUR_WIDTH fft2 bins                              */
+  int spur_flag;                /* 0 locked; > 0 unlocked since that many transforms              */
+  float spur_freq;              /* bins, with decimals                                            */
+  float spur_d0pha, spur_d1pha, spur_d2pha;   /* PLL phase and its first two differences per transform */
+  float spur_ampl, spur_noise, spur_avgd2;
+} lrh_spur;
+/* spur_speknum (buf.c:1141: 0.1 genparm[SPUR_TIMECONSTANT] / fftx_blocktime, >= 4, 4 spur_speknum <= max_fft2n) and the table of
+   reference line shapes (init_spur_spectra, spursub.c:824-940: depends only on the fft2 window); the derived constants
+   (sp_numsub, sp_avgnum, spur_max_d2, spur_minston, spur_weiold / weinew, spur_linefit, buf.c:1149-1170; spur_freq_factor,
+   buf.c:480) follow from it.  max_spurs = genparm[MAX_NO_OF_SPURS]; 0 switches the feature off. */
+int lrh_spur_config(lrh_ctx *ctx, int max_spurs, int spur_speknum, const float *spur_spectra);
+/* the control plane's hand-over: n spurs with their loop state and, per spur, the history the loop works on -- spur_table
+   [max_fft2n][SPUR_WIDTH][2] (the bins of past transforms), spur_signal [max_fft2n][2], spur_ind [max_fft2n] (buf.c:1114-1131) */
+int lrh_spur_set(lrh_ctx *ctx, int n, const lrh_spur *spurs, const float *spur_table, const float *spur_signal, const int *spur_ind);
+int lrh_spur_get(lrh_ctx *ctx, int max, lrh_spur *spurs, int *n);          /* synchronous */
+
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
 int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */
 void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                         /* for device-resident producers */

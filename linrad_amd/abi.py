@@ -118,6 +118,13 @@ def default_sellim(cfg, **kw):
     return s
 
 
+class LrhSpur(C.Structure):
+    """lrh_spur: PLL state of one tracked spur (spur.c / seldef.h globals spur_location, spur_flag, spur_freq, spur_d0pha ...)"""
+    _fields_ = [("spur_location", C.c_int), ("spur_flag", C.c_int), ("spur_freq", C.c_float), ("spur_d0pha", C.c_float),
+                ("spur_d1pha", C.c_float), ("spur_d2pha", C.c_float), ("spur_ampl", C.c_float), ("spur_noise", C.c_float),
+                ("spur_avgd2", C.c_float)]
+
+
 class LrhSynth(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("noise_sigma", C.c_float), ("ncarriers", C.c_int),
@@ -209,6 +216,9 @@ class StageAPI:
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
         self._proto("fft1_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
+        self._proto("spur_config", [vp, C.c_int, C.c_int, fp])
+        self._proto("spur_set", [vp, C.c_int, C.POINTER(LrhSpur), fp, fp, ip])
+        self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
         self._proto("get_liminfo", [vp, fp])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
         self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
@@ -351,6 +361,24 @@ class StageAPI:
         out = np.empty(self.N1, np.float32)
         self._chk(self._f("get_liminfo")(self.ctx, self._fptr(out)), "get_liminfo")
         return out
+
+    def spur_config(self, max_spurs, spur_speknum, spur_spectra):
+        t = np.ascontiguousarray(spur_spectra, np.float32)
+        assert t.size == 2048
+        self._chk(self._f("spur_config")(self.ctx, int(max_spurs), int(spur_speknum), self._fptr(t)), "spur_config")
+
+    def spur_set(self, spurs, table, signal, ind):
+        """hand over the control plane's spurs: list of LrhSpur + per-spur histories (see include/linrad_hip.h)"""
+        arr = (LrhSpur * max(1, len(spurs)))(*spurs)
+        table, signal = np.ascontiguousarray(table, np.float32), np.ascontiguousarray(signal, np.float32)
+        ind = np.ascontiguousarray(ind, np.int32)
+        self._chk(self._f("spur_set")(self.ctx, len(spurs), arr, self._fptr(table), self._fptr(signal), ind.ctypes.data_as(C.POINTER(C.c_int))), "spur_set")
+
+    def spur_get(self, max_spurs=16):
+        arr = (LrhSpur * max_spurs)()
+        n = C.c_int()
+        self._chk(self._f("spur_get")(self.ctx, max_spurs, arr, C.byref(n)), "spur_get")
+        return [arr[i] for i in range(n.value)]
 
     def set_waterfall_yfac(self, y=None):
         if y is None:

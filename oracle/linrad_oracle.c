@@ -43,6 +43,7 @@ struct lro_ctx {
   float *wg_waterf_yfac;       /* N1 */
   float *liminfo;
   void *sellim;                /* state of lro_fft1_update_liminfo (old_liminfo, liminfo_wait, ...), see there */
+  void *spurs;                 /* lro_spurs: spurs being tracked (lro_spur_config / lro_spur_set), NULL: none */
   /* rings */
   int16_t *timf1;
   float *fft1_float, *fft1_sumsq, *fft1_slowsum;
@@ -866,6 +867,8 @@ advance:
   p->fft2_liminfo_cnt++;
 }
 
+static void lro_spur_hook(lro_ctx *c, int na);      /* eliminate_spurs, defined with the spur tracking at the end of this file */
+
 /* make_fft2 mode 15 until FFT2_COMPLETE: fft2.c:86-141 (load, window, big_fftforward), 647-705 (power),
    707-815 (waterfall), 1831-1845 (pointers) */
 int lro_make_fft2(lro_ctx *c, lrh_ptrs *p, int batch)
@@ -880,6 +883,7 @@ int lro_make_fft2(lro_ctx *c, lrh_ptrs *p, int batch)
     else
       for (int i = 0; i < N; i++) { z[2 * i] = tf[p0] + tf[p0 + 2]; z[2 * i + 1] = tf[p0 + 1] + tf[p0 + 3]; p0 = (p0 + 4) & mask; }
     dif_stages(N, n, z, c->fft2tab, +1, 2); bitrev_inplace(N, n, z, 2);
+    if (c->spurs) lro_spur_hook(c, p->fft2_na);                     /* FFT2_ELIMINATE_SPURS, fft2.c:647-652 */
     float *pwra = c->fft2_power + (size_t)p->fft2_na * N;
     if (p->wg_waterf_sum_counter == 0) for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] = pwra[i]; }
     else                               for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] += pwra[i]; }
@@ -1570,3 +1574,357 @@ int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 }
 
 int lro_get_liminfo(lro_ctx *c, float *dst) { if (!c || !dst) return LRH_EINVAL; memcpy(dst, c->liminfo, 4 * c->N1); return LRH_OK; }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Spur subtraction: eliminate_spurs (spur.c:36-494) for locked spurs, one channel, float spectra, with
+ * refine_pll_parameters (spur.c:634-680), spur_phase_parameters (spur.c:1427-1652), complex_lowpass / remove_phasejumps /
+ * average_slope (spursub.c:942-1068) and shift_spur_table (spursub.c:1070-1246).  Acquisition and re-lock stay with the
+ * control plane (lro_spur_set hands the loop state over; see include/linrad_hip.h).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define SPW LRH_SPUR_WIDTH
+#define SPSZ 8
+#define NSPEC 256
+typedef struct {
+  int max, n, speknum, avgnum, numsub;
+  float freq_factor, max_d2, minston, weiold, weinew, linefit;
+  float spectra[LRH_SPUR_SPECTRA];
+  lrh_spur *sp; float *table, *signal; int *ind;
+  float *sig, *der, *pha, *tmp;
+  float sp_d0, sp_d1, sp_d2;
+} lro_spurs;
+
+static void spur_complex_lowpass(const float *zin, float *zout, int nn, int siz)
+{
+  int avgnum = nn | 1;
+  if (avgnum > nn && avgnum > siz / 4) avgnum -= 2;
+  if (avgnum < 1) return;
+  float t1 = 0, t2 = 0, t3 = (float)(1.0 / avgnum);
+  for (int i = 0; i < avgnum; i++) { t1 += zin[2 * i]; t2 += zin[2 * i + 1]; }
+  int j = 1 + avgnum / 2;
+  const float r1 = t1 * t3, r2 = t2 * t3;
+  for (int i = 0; i < j; i++) { zout[2 * i] = r1; zout[2 * i + 1] = r2; }
+  int i = 0, k = avgnum;
+  while (k < siz) {
+    t1 += zin[2 * k] - zin[2 * i]; t2 += zin[2 * k + 1] - zin[2 * i + 1];
+    zout[2 * j] = t3 * t1; zout[2 * j + 1] = t3 * t2;
+    i++; j++; k++;
+  }
+  t1 *= t3; t2 *= t3;
+  while (j < siz) { zout[2 * j] = t1; zout[2 * j + 1] = t2; j++; }
+}
+static void spur_remove_phasejumps(float *z, int siz)
+{
+  float t1 = 0;
+  for (int i = 1; i < siz; i++) {
+    z[i] += t1;
+    if (z[i] - z[i - 1] > PI_L) { z[i] -= (float)(2 * PI_L); t1 -= (float)(2 * PI_L); }
+    if (z[i] - z[i - 1] < -PI_L) { z[i] += (float)(2 * PI_L); t1 += (float)(2 * PI_L); }
+  }
+}
+static float spur_average_slope(const float *z, int siz)
+{
+  const int k = siz / 2;
+  float t2 = 0, t3 = 0;
+  for (int i = 0; i < k; i++) { t2 += z[i]; t3 += z[k + i]; }
+  return (t3 - t2) / (k * k);
+}
+
+/* spur_phase_parameters, spur.c:1427-1652: phase, frequency and drift corrections sp_d0 / sp_d1 / sp_d2 from the de-rotated
+   history sp_sig, amplitude and noise of the spur */
+static void spur_phase_parameters(lro_spurs *S, lrh_spur *q)
+{
+  float *sig = S->sig, *der = S->der, *pha = S->pha, *tmp = S->tmp;
+  const int n = S->speknum, ns = S->numsub, av = S->avgnum;
+  float t1, t2, t3, r1, r2, a1, a2, b1, b2, d1, d2;
+  for (int i = 1; i < n; i++) {
+    t1 = sig[2 * i] * sig[2 * i - 2] + sig[2 * i + 1] * sig[2 * i - 1];
+    t2 = sig[2 * i + 1] * sig[2 * i - 2] - sig[2 * i] * sig[2 * i - 1];
+    r1 = (float)sqrt(t1 * t1 + t2 * t2);
+    if (r1 > 0.000000001) { der[2 * i - 2] = t1 / r1; der[2 * i - 1] = t2 / r1; }
+    else { der[2 * i - 2] = 0; der[2 * i - 1] = 0; }
+  }
+  spur_complex_lowpass(der, tmp, av, ns);
+  r1 = 0; r2 = 0;
+  for (int i = 1 + av / 2; i < ns - av / 2; i++) {
+    t1 = tmp[2 * i] * tmp[2 * i - 2] + tmp[2 * i + 1] * tmp[2 * i - 1];
+    t2 = tmp[2 * i + 1] * tmp[2 * i - 2] - tmp[2 * i] * tmp[2 * i - 1];
+    t3 = (float)sqrt(t1 * t1 + t2 * t2);
+    if (t3 > 0.00001) { r1 += t1 / t3; r2 += t2 / t3; }
+  }
+  S->sp_d2 = (float)atan2(r2, r1);
+  t1 = q->spur_d2pha + S->sp_d2;
+  if (fabs(t1) > S->max_d2 && fabs(S->sp_d2) > S->max_d2) S->sp_d2 = -q->spur_d2pha / n;
+  else {
+    t1 = S->weiold * q->spur_avgd2 + S->weinew * t1;
+    if (q->spur_noise > 0.000001 && fabs(q->spur_ampl) > 0.000001) { t2 = (float)(0.1 * fabs(q->spur_ampl) / q->spur_noise); t2 = 1 / (1 + t2); }
+    else t2 = 1;
+    S->sp_d2 = t2 * (t1 - q->spur_d2pha) + (1 - t2) * S->sp_d2;
+  }
+  for (int i = 0; i < ns; i++) pha[i] = (float)atan2(tmp[2 * i + 1], tmp[2 * i]);
+  spur_remove_phasejumps(pha, ns);
+  pha[ns] = 0;
+  for (int i = ns; i > 0; i--) pha[i - 1] = pha[i] - pha[i - 1];
+  t1 = (float)(S->sp_d2 * 0.5);
+  for (int i = 2; i < n; i++) pha[ns - i] -= i * (i - 1) * t1;
+  int na = n - av;
+  if (na < 10) na = n - av / 2;
+  if (na < 3) na = n;
+  const int ia = n - na;
+  S->sp_d1 = spur_average_slope(&pha[ia], na);
+  b1 = (float)cos(S->sp_d1); b2 = (float)sin(S->sp_d1);
+  a1 = b1; a2 = b2;
+  d1 = (float)cos(S->sp_d2); d2 = (float)sin(S->sp_d2);
+  t1 = 0; t2 = 0;
+  for (int i = ns; i >= 0; i--) {
+    r1 = a1 * sig[2 * i] + a2 * sig[2 * i + 1];
+    r2 = a1 * sig[2 * i + 1] - a2 * sig[2 * i];
+    tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+    t3 = (float)sqrt(r1 * r1 + r2 * r2);
+    if (t3 > 0) { t1 += r1 / t3; t2 += r2 / t3; r2 += t3 * t3; }
+    r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+    r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
+  }
+  S->sp_d0 = (float)atan2(t2, t1);
+  t3 = (float)sqrt(t1 * t1 + t2 * t2);
+  t1 /= t3; t2 /= t3;
+  a1 = 0; a2 = 0;
+  d1 = (float)(-0.5 * ns);
+  for (int i = 0; i < n; i++) {
+    r1 = t1 * tmp[2 * i] + t2 * tmp[2 * i + 1];
+    r2 = t1 * tmp[2 * i + 1] - t2 * tmp[2 * i];
+    tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+    a1 += r1;
+    if (r1 > 0 && fabs(r2) < fabs(r1)) a2 += (float)(d1 * r2 / fabs(r1));
+    else a2 += (float)(d1 * atan2(r2, r1));
+    d1 += 1;
+  }
+  a1 /= n;
+  q->spur_ampl = a1;
+  a2 /= S->linefit;
+  S->sp_d1 += a2;
+  d2 = (float)(-0.5 * ns * a2);
+  b1 = (float)cos(a2); b2 = (float)-sin(a2);
+  a1 = (float)cos(d2); a2 = (float)sin(d2);
+  t1 = 0;
+  for (int i = 0; i < n; i++) {
+    r1 = a1 * tmp[2 * i] - a2 * tmp[2 * i + 1];
+    r2 = a1 * tmp[2 * i + 1] + a2 * tmp[2 * i];
+    tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+    t1 += r1;
+    r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+  }
+  t1 /= n;
+  q->spur_ampl = t1;
+  t2 = 0;
+  for (int i = 0; i < n; i++) t2 += (tmp[2 * i] - t1) * (tmp[2 * i] - t1) + tmp[2 * i + 1] * tmp[2 * i + 1];
+  q->spur_noise = (float)sqrt(t2 / n);
+}
+
+/* refine_pll_parameters, spur.c:634-680 */
+static void spur_refine_pll(lro_spurs *S, lrh_spur *q, const float *zsig, int na, int mask)
+{
+  float phase = q->spur_d0pha, phase_slope = q->spur_d1pha, phase_curv = q->spur_d2pha, r1;
+  int ni = na;
+  phase_slope += phase_curv; phase += phase_slope;
+  float a1 = (float)cos(phase), a2 = (float)sin(phase), b1 = (float)cos(phase_slope), b2 = (float)sin(phase_slope);
+  float d1 = (float)cos(phase_curv), d2 = (float)sin(phase_curv);
+  for (int i = S->speknum - 1; i >= 0; i--) {
+    S->sig[2 * i] = a1 * zsig[2 * ni] + a2 * zsig[2 * ni + 1];
+    S->sig[2 * i + 1] = a1 * zsig[2 * ni + 1] - a2 * zsig[2 * ni];
+    r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+    r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
+    ni = (ni + mask) & mask;
+  }
+  spur_phase_parameters(S, q);
+  phase += S->sp_d0; phase_slope += S->sp_d1; phase_curv += S->sp_d2;
+  phase -= phase_slope; phase_slope -= phase_curv;
+  q->spur_d0pha = phase; q->spur_d1pha = phase_slope; q->spur_d2pha = phase_curv;
+}
+
+/* shift_spur_table, spursub.c:1070-1246 (one channel, float): the spur has drifted out of the centre of its SPUR_WIDTH bins */
+static void spur_shift_table(lro_spurs *S, lrh_spur *q, float *tab, int j, int na, int mask, int n2)
+{
+  const int nj = (na + 1) & mask, shift = j < 0 ? -1 : 1;
+  q->spur_location += shift;
+  if (q->spur_location < SPW) { q->spur_flag = 1; q->spur_location = 2 * SPW; return; }
+  if (q->spur_location > n2 - SPW) { q->spur_flag = 1; q->spur_location = n2 - 2 * SPW; return; }
+  int ni = (na - S->speknum + mask + 1) & mask;
+  while (ni != nj) {
+    float *t = tab + ni * SPW * 2;
+    if (shift == 1) { for (int i = 1; i < SPW; i++) { t[2 * i - 2] = t[2 * i]; t[2 * i - 1] = t[2 * i + 1]; } t[2 * SPW - 2] = 0; t[2 * SPW - 1] = 0; }
+    else { for (int i = SPW - 1; i > 0; i--) { t[2 * i] = t[2 * i - 2]; t[2 * i + 1] = t[2 * i - 1]; } t[0] = 0; t[1] = 0; }
+    ni = (ni + 1) & mask;
+  }
+}
+
+static int spur_index(float freq, int loc, int *jout)        /* the reference line shape for this frequency; -1: out of the window */
+{
+  int j = (int)(freq) + 2 - loc - SPSZ / 2;
+  *jout = j;
+  if (j < 0 || j > 1) return -1;
+  j = 1 - j;
+  int ind = (int)(NSPEC * (freq - (int)(freq)));
+  if (ind == NSPEC) ind = NSPEC - 1;
+  *jout = j;
+  return ind * SPSZ + j;
+}
+
+/* eliminate_spurs for the transform at ring slot na of fft2_float (spur.c:36-494) */
+static void spur_eliminate(lro_spurs *S, float *fftx, int na, int n2, int maxn)
+{
+  const int mask = maxn - 1;
+  const float ff = S->freq_factor;
+  for (int s = 0; s < S->n; s++) {
+    lrh_spur *q = &S->sp[s];
+    float *tab = S->table + (size_t)s * maxn * SPW * 2, *spt = tab + na * SPW * 2;
+    int *uind = S->ind + (size_t)s * maxn;
+    float *zsig = S->signal + (size_t)s * maxn * 2;
+    float *z;
+    int i, j, k, ind;
+    if (q->spur_flag == 1) {
+      j = (int)(q->spur_freq) + 2 - q->spur_location - SPSZ / 2;
+      if (j < 0 || j > 1) { if (j < -1) j = -1; if (j > 2) j = 2; spur_shift_table(S, q, tab, j, na, mask, n2); }
+    }
+    if (q->spur_flag != 0) {                 /* unlocked: keep the history, count; re-lock is the control plane's (spur.c:130-153) */
+      z = &fftx[2 * ((size_t)na * n2 + q->spur_location)];
+      for (i = 0; i < SPW; i++) { spt[2 * i] = z[2 * i]; spt[2 * i + 1] = z[2 * i + 1]; }
+      q->spur_flag++;
+      if (q->spur_flag > 1000000) q->spur_flag -= 2 * 3 * 5 * 7 * S->speknum;
+      continue;
+    }
+    float phase_slope = q->spur_d1pha + q->spur_d2pha, phase_curv, phase, ampl;
+    float rot = (float)(-0.5 * phase_slope / PI_L), freq, r1, r2, t1, t2;
+    i = (int)(q->spur_freq * ff - rot + 0.5);
+    rot += i;
+    freq = rot / ff;
+    q->spur_freq = freq;
+    int lost = 0;
+    for (;;) {
+      ind = spur_index(freq, q->spur_location, &j);
+      if (ind >= 0) break;
+      if (j < -1 || j > 2) { q->spur_flag = 1; lost = 1; break; }
+      spur_shift_table(S, q, tab, j, na, mask, n2);
+      if (q->spur_flag) { lost = 1; break; }                      /* shifted against the band edge */
+    }
+    if (lost) continue;
+    uind[na] = ind;
+    z = &fftx[2 * ((size_t)na * n2 + q->spur_location)];
+    r1 = 0; r2 = 0;
+    for (i = 0; i < SPW; i++) {
+      spt[2 * i] = z[2 * i]; r1 += z[2 * i] * S->spectra[ind + i];
+      spt[2 * i + 1] = z[2 * i + 1]; r2 += z[2 * i + 1] * S->spectra[ind + i];
+    }
+    if ((j ^ (q->spur_location & 1)) == 1) { r1 = -r1; r2 = -r2; }
+    zsig[2 * na] = r1; zsig[2 * na + 1] = r2;
+    int iter = 0, diffind;
+    freq = q->spur_freq;
+    for (;;) {
+      iter++;
+      spur_refine_pll(S, q, zsig, na, mask);
+      phase_slope = q->spur_d1pha; phase_curv = q->spur_d2pha;
+      phase_slope += phase_curv;
+      const int nx = (na - S->speknum + mask) & mask;
+      diffind = 0;
+      int ni = na, out = 0;
+      while (ni != nx) {
+        rot = (float)(-0.5 * phase_slope / PI_L);
+        i = (int)(freq * ff - rot + 0.5);
+        rot += i;
+        freq = rot / ff;
+        ind = spur_index(freq, q->spur_location, &j);
+        if (ind < 0) { out = 1; break; }
+        k = (uind[ni] - ind + NSPEC * SPSZ) & (NSPEC * SPSZ - 1);
+        if (k > NSPEC * SPSZ / 2) k = NSPEC * SPSZ - k;
+        if (k > diffind) diffind = k;
+        uind[ni] = ind;
+        if (k != 0) {
+          const float *tt = tab + ni * SPW * 2;
+          r1 = 0; r2 = 0;
+          for (i = 0; i < SPW; i++) { r1 += tt[2 * i] * S->spectra[ind + i]; r2 += tt[2 * i + 1] * S->spectra[ind + i]; }
+          if ((j ^ (q->spur_location & 1)) == 1) { r1 = -r1; r2 = -r2; }
+          zsig[2 * ni] = r1; zsig[2 * ni + 1] = r2;
+        }
+        phase_slope -= phase_curv;
+        ni = (ni + mask) & mask;
+      }
+      if (out) break;
+      if (!(diffind > 2.5 * SPSZ && iter < 5)) break;
+    }
+    if (diffind != 0) spur_refine_pll(S, q, zsig, na, mask);
+    if (fabs(q->spur_ampl) < S->minston * q->spur_noise) { q->spur_flag = 1; continue; }
+    /* subtract the spur from the new transform */
+    phase = q->spur_d0pha; phase_slope = q->spur_d1pha; phase_curv = q->spur_d2pha; ampl = q->spur_ampl;
+    phase_slope += phase_curv; phase += phase_slope;
+    q->spur_d0pha = phase; q->spur_d1pha = phase_slope;
+    if (q->spur_d0pha > PI_L) q->spur_d0pha -= (float)(2 * PI_L);
+    if (q->spur_d0pha < -PI_L) q->spur_d0pha += (float)(2 * PI_L);
+    if (q->spur_d1pha > PI_L) q->spur_d1pha -= (float)(2 * PI_L);
+    if (q->spur_d1pha < -PI_L) q->spur_d1pha += (float)(2 * PI_L);
+    if (q->spur_d2pha > PI_L) q->spur_d2pha -= (float)(2 * PI_L);
+    if (q->spur_d2pha < -PI_L) q->spur_d2pha += (float)(2 * PI_L);
+    q->spur_avgd2 = S->weiold * q->spur_avgd2 + S->weinew * phase_curv;
+    rot = (float)(-0.5 * phase_slope / PI_L);
+    i = (int)(q->spur_freq * ff - rot + 0.5);
+    rot += i;
+    freq = rot / ff;
+    q->spur_freq = freq;
+    lost = 0;
+    for (;;) {
+      ind = spur_index(freq, q->spur_location, &j);
+      if (ind >= 0) break;
+      if (j < -1 || j > 2) { q->spur_flag = 1; lost = 1; break; }
+      spur_shift_table(S, q, tab, j, na, mask, n2);
+      if (q->spur_flag) { lost = 1; break; }
+    }
+    if (lost) continue;
+    if ((j ^ (q->spur_location & 1)) == 1) { t1 = (float)(-cos(phase) * ampl); t2 = (float)(-sin(phase) * ampl); }
+    else { t1 = (float)(cos(phase) * ampl); t2 = (float)(sin(phase) * ampl); }
+    z = &fftx[2 * ((size_t)na * n2 + q->spur_location)];
+    for (i = 0; i < SPW; i++) { z[2 * i] -= S->spectra[ind + i] * t1; z[2 * i + 1] -= S->spectra[ind + i] * t2; }
+  }
+}
+
+int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const float *spectra)
+{
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
+  lro_spurs *S = c->spurs;
+  if (S) { free(S->sp); free(S->table); free(S->signal); free(S->ind); free(S->sig); free(S->der); free(S->pha); free(S->tmp); free(S); c->spurs = NULL; }
+  if (!max_spurs) return LRH_OK;
+  const int maxn = c->cfg.max_fft2n;
+  S = calloc(1, sizeof *S);
+  S->max = max_spurs; S->n = 0; S->speknum = speknum; S->numsub = speknum - 1; S->avgnum = speknum / 3; if (S->avgnum > 10) S->avgnum = 10;
+  S->freq_factor = (float)c->M2 / c->N2;                                   /* buf.c:480 */
+  S->max_d2 = (float)(PI_L * S->freq_factor / speknum);
+  S->minston = (float)(1 / sqrt(0.5 * (float)(speknum)));
+  { float t1 = (float)(0.5 * speknum); S->weiold = t1 / (1 + t1); S->weinew = 1 / (1 + t1);
+    t1 = (float)(-0.5 * S->numsub); S->linefit = 0; for (int i = 0; i < speknum; i++) { S->linefit += t1 * t1; t1 += 1; } }
+  memcpy(S->spectra, spectra, sizeof S->spectra);
+  S->sp = calloc(max_spurs, sizeof(lrh_spur)); S->table = calloc((size_t)max_spurs * maxn * SPW * 2, 4); S->signal = calloc((size_t)max_spurs * maxn * 2, 4);
+  S->ind = calloc((size_t)max_spurs * maxn, 4);
+  S->sig = calloc(2 * (maxn + 8), 4); S->der = calloc(2 * (maxn + 8), 4); S->pha = calloc(2 * (maxn + 8), 4); S->tmp = calloc(2 * (maxn + 8), 4);
+  c->spurs = S;
+  return LRH_OK;
+}
+int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const float *table, const float *signal, const int *ind)
+{
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S || n < 0 || n > S->max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
+  const int maxn = c->cfg.max_fft2n;
+  S->n = n;
+  if (n) { memcpy(S->sp, sp, n * sizeof *sp); memcpy(S->table, table, (size_t)n * maxn * SPW * 2 * 4); memcpy(S->signal, signal, (size_t)n * maxn * 2 * 4); memcpy(S->ind, ind, (size_t)n * maxn * 4); }
+  return LRH_OK;
+}
+int lro_spur_get(lro_ctx *c, int max, lrh_spur *sp, int *n)
+{
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S || !sp || !n) return LRH_EINVAL;
+  *n = S->n < max ? S->n : max;
+  memcpy(sp, S->sp, *n * sizeof *sp);
+  return LRH_OK;
+}
+
+static void lro_spur_hook(lro_ctx *c, int na)
+{
+  lro_spurs *S = c->spurs;
+  if (S->n > 0) spur_eliminate(S, c->fft2_float, na, c->N2, c->cfg.max_fft2n);
+}

@@ -76,6 +76,10 @@ void make_sincos(int mo, int sz, COSIN_TABLE *tab);
 void init_fft(int mo, int nz, int sz, COSIN_TABLE *tab, unsigned short int *perm);
 void set_fft1_endpoints(void);
 void fft1_update_liminfo(void);
+int store_new_spur(int pnt);
+int spur_phase_lock(int nx);
+void init_spur_spectra(void);
+void eliminate_spurs(void);
 
 /* ---- container writer ---- */
 static FILE *fo;
@@ -246,6 +250,10 @@ int main(int argc, char **argv)
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
   int sellim = AI("sellim", 0);                  /* 1: the selective limiter runs (fft1_update_liminfo, sellim.c:738) whenever fft1_c completes an
                                                     averaging period, in the single-CPU order of wcw.c:1124-1128; make_timf2 routes with its table */
+  int spur = AI("spur", 0);                      /* 1: a spur at fft2 bin spur_pnt (first of its SPUR_WIDTH bins) is acquired by the reference's own
+                                                    store_new_spur / spur_phase_lock once spur_start transforms exist, then tracked and subtracted
+                                                    by eliminate_spurs inside make_fft2 (fft2.c:647-652) */
+  int spur_pnt = AI("spur_pnt", 0), spur_start = AI("spur_start", 16), spur_spek = AI("spur_speknum", 0);
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
   double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
@@ -413,6 +421,34 @@ int main(int argc, char **argv)
   fft2_pa = 0; fft2_na = fft2_nb = fft2_nx = fft2_nm = 0; fft2_liminfo_cnt = 0;
   hg_redraw_counter = 0; hg.spek_avgnum = 1 << 30; fft2_blocktime = 0;
   fft2_to_fft1_ratio = N2 / N1; if (fft2_to_fft1_ratio < 1) fft2_to_fft1_ratio = 1;
+  float *spur_trace = NULL; int nspur_trace = 0, spur_locked_at = -1;
+  if (spur) {                                    /* buf.c:1100-1172, 1252, 1647 */
+    const int ms = 4;
+    genparm[MAX_NO_OF_SPURS] = ms; genparm[AFC_ENABLE] = 1;
+    max_fftxn = max_fft2n; fftxn_mask = max_fftxn - 1; fftx_size = fft2_size; fftx = fft2_float; fftx_pwr = fft2_power_float;
+    swmmx_fft2 = 0; no_of_spurs = 0;
+    spur_block = SPUR_WIDTH * max_fftxn * twice_rxchan;
+    spur_table = zalloc(sizeof(float) * ms * spur_block); spur_location = zalloc(4 * ms); spur_flag = zalloc(4 * ms);
+    spur_power = zalloc(4 * (SPUR_WIDTH + 1)); spur_d0pha = zalloc(4 * ms); spur_d1pha = zalloc(4 * ms); spur_d2pha = zalloc(4 * ms);
+    spur_ampl = zalloc(4 * ms); spur_noise = zalloc(4 * ms); spur_avgd2 = zalloc(4 * ms); spur_pol = zalloc(12 * ms);
+    spur_spectra = zalloc(4 * NO_OF_SPUR_SPECTRA * SPUR_SIZE + 64); spur_freq = zalloc(4 * ms);
+    spur_ind = zalloc(4 * ms * max_fftxn); spur_signal = zalloc(4 * max_fftxn * twice_rxchan * ms);
+    spursearch_spectrum = zalloc(4 * fftx_size); spursearch_powersum = zalloc(4 * fftx_size);
+    for (int i = 0; i < ms * max_fftxn; i++) spur_ind[i] = -1;
+    spur_freq_factor = (float)fft2_new_points / fft2_size;             /* buf.c:480 */
+    spur_speknum = spur_spek > 0 ? spur_spek : max_fftxn / 4;
+    if (spur_speknum < 4) spur_speknum = 4;
+    sp_sig = zalloc(8 * (max_fftxn + 8)); sp_der = zalloc(8 * (max_fftxn + 8)); sp_pha = zalloc(8 * (max_fftxn + 8)); sp_tmp = zalloc(8 * (max_fftxn + 8));
+    spursearch_sum_counter = 0;
+    sp_numsub = spur_speknum - 1; sp_avgnum = spur_speknum / 3; if (sp_avgnum > 10) sp_avgnum = 10;
+    spur_max_d2 = PI_L * spur_freq_factor / spur_speknum;
+    spur_minston = 1 / sqrt(0.5 * (float)(spur_speknum));
+    { float t1 = 0.5 * spur_speknum; spur_weiold = t1 / (1 + t1); spur_weinew = 1 / (1 + t1);
+      t1 = -0.5 * sp_numsub; spur_linefit = 0; for (int i = 0; i < spur_speknum; i++) { spur_linefit += t1 * t1; t1 += 1; } }
+    spur_search_first_point = 0; spur_search_last_point = fftx_size - 1;
+    init_spur_spectra();
+    spur_trace = zalloc(sizeof(float) * 12 * ((size_t)nblk * 8 + 64));
+  }
 
   /* mix1 sizes first: fft2 interleave is re-derived from mix1 (buf.c:432-455) */
   if (second) { mix1.n = n2 - mixred; if (mix1.n < 3) mix1.n = 3; mix1.size = 1 << mix1.n; }
@@ -630,8 +666,30 @@ int main(int argc, char **argv)
     if (bp_block > 0) compute_timf2_powersum();
     while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * C * fft2_size) {     /* wcw.c:265-266 */
       int wptr = wg_waterf_ptr;
+      if (spur) { ffts_na = fft2_na; ffts_nm = fft2_nm;          /* what the previous pass of second_fft left (wcw.c:288-289) */
+        spur_freq_factor = (float)fft2_new_points / fft2_size; spur_max_d2 = PI_L * spur_freq_factor / spur_speknum; }   /* buf.c:480, 1152 (fft2_new_points is known by now) */
       make_fft2_status = FFT2_NOT_ACTIVE;
       while (make_fft2_status != FFT2_COMPLETE) make_fft2();
+      if (spur && no_of_spurs == 0 && nfft2 + 1 == spur_start) {   /* acquisition, tail of init_spur_elimination (spursub.c:282-309) */
+        ffts_na = fft2_na; ffts_nm = fft2_nm;
+        spurno = 0; spur_ampl[0] = 1; spur_noise[0] = 0.001; spur_avgd2[0] = 0;
+        int rc1 = store_new_spur(spur_pnt), rc2 = rc1 ? -9 : spur_phase_lock(ffts_na);
+        fprintf(stderr, "spur acquisition at transform %d: store %d lock %d loc %d freq %.4f ampl %.4g noise %.4g d0 %.4f d1 %.4f d2 %.5f\n", nfft2, rc1, rc2,
+                spur_location[0], spur_freq[0], spur_ampl[0], spur_noise[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0]);
+        if (!rc1 && !rc2) {
+          no_of_spurs = 1; spur_locked_at = nfft2 + 1;
+          float st[12] = { (float)spur_location[0], (float)spur_flag[0], spur_freq[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0], spur_ampl[0], spur_noise[0], spur_avgd2[0],
+                           (float)fft2_na, (float)spur_speknum, spur_freq_factor };
+          PUTF("spur_init_state", st, 12);
+          PUTF("spur_init_table", spur_table, spur_block); PUTF("spur_init_signal", spur_signal, 2 * max_fftxn); PUTI("spur_init_ind", spur_ind, max_fftxn);
+          PUTF("spur_spectra", spur_spectra, NO_OF_SPUR_SPECTRA * SPUR_SIZE);
+          PUTF("spur_init_fft2", fft2_float, (size_t)2 * N2 * max_fft2n);
+        }
+      } else if (spur && no_of_spurs > 0) {
+        float *q = spur_trace + 12 * nspur_trace++;
+        q[0] = spur_location[0]; q[1] = spur_flag[0]; q[2] = spur_freq[0]; q[3] = spur_d0pha[0]; q[4] = spur_d1pha[0]; q[5] = spur_d2pha[0];
+        q[6] = spur_ampl[0]; q[7] = spur_noise[0]; q[8] = spur_avgd2[0]; q[9] = nfft2; q[10] = no_of_spurs;
+      }
       if (wg_waterf_ptr != wptr) { memcpy(wf_lines + (size_t)nwf * wg_xpixels, wg_waterf + wptr, 2 * wg_xpixels); nwf++; }
       if (fq >= 0) {
         if (afc) { AFC_SUPPLY(fft2_nx, fft2n_mask); fft2_mix1_afc(); } else
@@ -690,6 +748,7 @@ int main(int argc, char **argv)
     float sf[2] = { fft1_blocktime, hg.blanker_ston_fft1 }; PUTF("sellim_fparams", sf, 2);
     PUTF("liminfo_final", liminfo, N1);
   }
+  if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2); }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);
   { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);

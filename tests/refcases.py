@@ -297,3 +297,36 @@ def sellim_case(name):
     iq[0::2] += z.real
     iq[1::2] += z.imag
     return d, sl, np.clip(np.round(iq), -32767, 32767).astype(np.int16)
+
+
+# ---- spur subtraction on (harness spur=1): a carrier is acquired by the reference's own store_new_spur / spur_phase_lock and then
+# tracked and subtracted by eliminate_spurs inside make_fft2
+SPUR = {
+    # steady carrier inside the mix1 passband: the baseband loses it (timf3 shows the subtraction)
+    "spur_n10_n12": dict(base="n10_n12", nblk=160, max_fft2n=32, blockpower_block=0, spur_pnt=2193, spur_start=12, spur_speknum=8, tone=None),
+    # a carrier that drifts 0.35 fft2 bins during the run (across a bin boundary): frequency drift in the loop (d2pha) and shift_spur_table
+    "spur_n10_n12_drift": dict(base="n10_n12", nblk=200, max_fft2n=64, blockpower_block=0, spur_pnt=2597, spur_start=20, spur_speknum=12,
+                               tone=(2600.8, 0.35, 3000.0), fq=2590.3),
+}
+
+
+def spur_case(name):
+    t = dict(SPUR[name])
+    d = case_params(t.pop("base"))
+    sp = {k: t.pop(k) for k in ("spur_pnt", "spur_start", "spur_speknum")}
+    tone = t.pop("tone")
+    d.update(t)
+    iq = make_input(d).astype(np.float64)
+    lim = make_liminfo(d)
+    if tone is not None:                      # (fft2 bin at the start, drift in fft2 bins over the run, amplitude)
+        N1, N2 = 1 << d["n1"], 1 << d["n2"]
+        c = int(round(N1 // 2 + (tone[0] - N2 / 2) * N1 / N2))       # routed with the strong signals like the other carriers
+        lim[c - d["lim_halfwidth"]:c + d["lim_halfwidth"] + 1] = 1.0
+        n = iq.size // 2
+        tt = np.arange(n, dtype=np.float64)
+        f0 = (tone[0] - N2 / 2) / N2              # cycles per sample
+        df = tone[1] / N2 / n
+        ph = 2 * np.pi * (f0 * tt + 0.5 * df * tt * tt)
+        iq[0::2] += tone[2] * np.cos(ph)
+        iq[1::2] += tone[2] * np.sin(ph)
+    return d, sp, np.clip(np.round(iq), -32767, 32767).astype(np.int16), lim

@@ -1,0 +1,90 @@
+"""Spur-subtraction parity machinery shared by the oracle (CPU) and HIP (GPU) tests: drive a SPUR case in the harness's order, hand the
+reference's acquired spur over at the transform where the reference locked it (control plane), and compare the tracking loop's
+state after every transform and the rings behind the subtraction with the reference golden."""
+import os
+
+import numpy as np
+
+from linrad_amd import abi
+from linrad_amd.abi import LrhSpur
+from refcases import lrh_config, spur_case
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+
+
+def run(open_fn, name, g, batch=1):
+    d, sp, iq, lim = spur_case(name)
+    assert np.array_equal(iq, g["iq"])
+    cfg = lrh_config(d, iq)
+    api = open_fn(cfg)
+    api.timf1_write(iq)
+    api.set_liminfo(lim)
+    api.set_mix1_selfreq(d["fq"])
+    st = g["spur_init_state"]
+    speknum, start = int(st[10]), int(g["spur_locked"][0])
+    api.spur_config(4, speknum, g["spur_spectra"])
+    trace, nfft2, handed = [], 0, False
+    for b in range(d["nblk"]):
+        api.fft1_b(1), api.fft1_c(1), api.make_timf2(1)
+        api.first_noise_blanker()
+        k = api.fft2_available()
+        while k > 0:
+            kb = min(k, batch) if handed else 1
+            if not handed and nfft2 + 1 > start:
+                raise AssertionError("hand-over point missed")
+            if not handed:
+                kb = 1
+            api.make_fft2(kb)
+            api.fft2_mix1_fixed(kb)
+            nfft2 += kb
+            k -= kb
+            if handed:
+                s = api.spur_get()[0]
+                trace.append([s.spur_location, s.spur_flag, s.spur_freq, s.spur_d0pha, s.spur_d1pha, s.spur_d2pha, s.spur_ampl, s.spur_noise, s.spur_avgd2, nfft2 - 1])
+            elif nfft2 == start:                                  # the reference's acquisition result, handed over by the control plane
+                q = LrhSpur(int(st[0]), int(st[1]), *[float(x) for x in st[2:9]])
+                maxn = cfg.max_fft2n
+                api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
+                handed = True
+    return dict(api=api, cfg=cfg, d=d, trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
+                ps2=api.export(abi.RING_FFT2_POWERSUM))
+
+
+def compare(out, g, tol, batch=1):
+    ref = g["spur_trace"].reshape(-1, 12)
+    got = out["trace"]
+    if batch > 1:                                               # state is visible after every call only
+        ref = ref[np.isin(ref[:, 9], got[:, 9])]
+    assert got.shape[0] == ref.shape[0] and got.shape[0] > 10
+    assert np.array_equal(got[:, :2], ref[:, :2]), "spur_location / spur_flag trace differs"
+    rep = {"transforms": int(ref.shape[0]), "locations": sorted(set(int(x) for x in ref[:, 0]))}
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+    rep["freq_err_bins"] = float(np.max(np.abs(got[:, 2] - ref[:, 2])))
+    rep["phase_err_rad"] = float(np.max(np.abs(wrap(got[:, 3] - ref[:, 3]))))
+    rep["d1_err"] = float(np.max(np.abs(wrap(got[:, 4] - ref[:, 4]))))
+    rep["d2_err"] = float(np.max(np.abs(got[:, 5] - ref[:, 5])))
+    rep["ampl_rel"] = float(np.max(np.abs(got[:, 6] - ref[:, 6]) / np.abs(ref[:, 6])))
+    rep["noise_rel"] = float(np.max(np.abs(got[:, 7] - ref[:, 7]) / np.abs(ref[:, 7])))
+
+    def rel(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    rep["fft2"], rep["ps2"], rep["timf3"] = rel(out["fft2"], g["fft2_float"]), rel(out["ps2"], g["fft2_powersum_float"]), rel(out["timf3"], g["timf3_float"])
+    # the bins of the spur itself in the newest transforms: what is left after the subtraction, against the reference's residual
+    cfg = out["cfg"]
+    n2 = 1 << cfg.fft2_n
+    loc = int(ref[-1, 0])
+    f_h, f_r = out["fft2"].reshape(cfg.max_fft2n, n2, 2), g["fft2_float"].reshape(cfg.max_fft2n, n2, 2)
+    res_h, res_r = f_h[:, loc:loc + 7].astype(np.float64), f_r[:, loc:loc + 7].astype(np.float64)
+    rep["residual_vs_carrier"] = float(np.linalg.norm(res_r) / (np.sqrt(cfg.max_fft2n) * abs(ref[-1, 6])))
+    rep["residual_err_vs_carrier"] = float(np.linalg.norm(res_h - res_r) / (np.sqrt(cfg.max_fft2n) * abs(ref[-1, 6])))
+    assert rep["freq_err_bins"] < 1e-3 and rep["phase_err_rad"] < 20 * tol * 1e2 and rep["ampl_rel"] < 10 * tol, rep
+    assert rep["fft2"] < tol and rep["ps2"] < tol and rep["timf3"] < tol, rep
+    assert rep["residual_err_vs_carrier"] < tol, rep
+    return rep
