@@ -41,6 +41,7 @@ hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
+hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
 hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
 }  // namespace lrh
 using namespace lrh;
@@ -132,6 +133,8 @@ struct lrh_ctx {
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
   bool have_liminfo = false;
+  // spurs being tracked (lrh_spur_config / lrh_spur_set): loop state and histories on the device, k_spur between fft2 and its power sums
+  int spur_max = 0, spur_n = 0, spur_speknum = 0; lrh_spur *d_spurs = nullptr; float *d_spur_table = nullptr, *d_spur_signal = nullptr, *d_spur_scratch = nullptr, *d_spur_spectra = nullptr; int *d_spur_ind = nullptr;
   // selective limiter on the device (lrh_fft1_update_liminfo): the reference's liminfo / old_liminfo / liminfo_wait / fftt_tmp
   float *d_liminfo = nullptr, *d_old_liminfo = nullptr, *d_sel_tmp = nullptr; unsigned char *d_sel_wait = nullptr; SellimState *d_sel_st = nullptr;
   // weak-bin counts come back through a ring of pinned slots; without exact_stats the one installed is two updates old, so
@@ -332,6 +335,7 @@ void lrh_close(lrh_ctx *c)
   for (hipEvent_t e : c->ev_sel_slot) if (e) hipEventDestroy(e);
   if (c->d_pack18) hipFree(c->d_pack18);
   if (c->d_stamps) hipFree(c->d_stamps);
+  for (void *q_ : { (void *)c->d_spurs, (void *)c->d_spur_table, (void *)c->d_spur_signal, (void *)c->d_spur_scratch, (void *)c->d_spur_spectra, (void *)c->d_spur_ind }) if (q_) hipFree(q_);
   if (c->d_net) hipFree(c->d_net);
   if (c->d_fft1net) hipFree(c->d_fft1net);
   if (c->d_foldcorr) hipFree(c->d_foldcorr);
@@ -692,6 +696,54 @@ int lrh_get_liminfo(lrh_ctx *c, float *dst)
   if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
   HIPCHK(c, hipMemcpyAsync(dst, c->d_liminfo, 4 * c->N1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+
+// ---- spur subtraction (include/linrad_hip.h): configuration and the control plane's hand-over
+int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
+{
+  LRH_ENTER(c);
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
+  if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel, second fft on");
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_scratch, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
+    if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  c->spur_max = 0; c->spur_n = 0; c->spur_speknum = 0;
+  if (!max_spurs) return LRH_OK;
+  const size_t maxn = c->cfg.max_fft2n;
+  int rc = LRH_OK;
+  if ((rc = dev_alloc(c, &c->d_spurs, max_spurs)) || (rc = dev_alloc(c, &c->d_spur_table, max_spurs * maxn * 14)) || (rc = dev_alloc(c, &c->d_spur_signal, max_spurs * maxn * 2)) ||
+      (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_scratch, max_spurs * 8 * (maxn + 8))) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_spur_spectra, spectra, sizeof(float) * LRH_SPUR_SPECTRA, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->spur_max = max_spurs; c->spur_speknum = speknum;
+  return LRH_OK;
+}
+int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, const float *signal, const int *ind)
+{
+  LRH_ENTER(c);
+  if (!c || n < 0 || n > c->spur_max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  const size_t maxn = c->cfg.max_fft2n;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(c->d_spurs, sp, n * sizeof *sp, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_table, table, n * maxn * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_signal, signal, n * maxn * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_ind, ind, n * maxn * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->spur_n = n;
+  return LRH_OK;
+}
+int lrh_spur_get(lrh_ctx *c, int max, lrh_spur *sp, int *n)
+{
+  LRH_ENTER(c);
+  if (!c || !sp || !n || max < 0) return LRH_EINVAL;
+  *n = c->spur_n < max ? c->spur_n : max;
+  if (*n) {
+    HIPCHK(c, hipMemcpyAsync(sp, c->d_spurs, *n * sizeof *sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return LRH_OK;
 }
 
@@ -1134,7 +1186,24 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     w.npix = c->cfg.wf_xpixels; w.first = c->cfg.wf_first_xpoint; w.siz = N; w.hx = hx; w.hp = hp;
     w.ptr0 = p->wg_waterf_ptr; w.wf_size = c->cfg.wf_lines * c->cfg.wf_xpixels; w.line_stride = N;
   }
-  const int fft2_n = c->cfg.fft2_n; const bool fused = c->fft2_fused;
+  const int fft2_n = c->cfg.fft2_n;
+  // spurs tracked: eliminate_spurs sits between the transform and the power sums (FFT2_ELIMINATE_SPURS, fft2.c:647-652), so the sums
+  // cannot ride inside the transform kernel: transform, k_spur over the batch in order, |X|^2 of the cleaned bins, then the sums
+  const bool spurs = c->spur_n > 0;
+  const bool fused = c->fft2_fused && !spurs;
+  if (spurs) { a.ps_avgnum = 0; g.ps_avgnum = 0; }
+  SpurArgs sa; memset(&sa, 0, sizeof sa);
+  if (spurs) {
+    sa.fft2 = c->d_fft2; sa.n2 = N; sa.first_na = p->fft2_na; sa.na_mask = c->fft2n_mask; sa.batch = batch;
+    sa.nspurs = c->spur_n; sa.speknum = c->spur_speknum; sa.numsub = sa.speknum - 1; sa.avgnum = sa.speknum / 3; if (sa.avgnum > 10) sa.avgnum = 10;
+    sa.freq_factor = (float)c->M2 / (float)N;                             // buf.c:480
+    sa.max_d2 = (float)(PI_L * sa.freq_factor / sa.speknum);              // buf.c:1152-1170
+    sa.minston = (float)(1 / sqrt(0.5 * (float)(sa.speknum)));
+    { float t1 = (float)(0.5 * sa.speknum); sa.weiold = t1 / (1 + t1); sa.weinew = 1 / (1 + t1);
+      t1 = (float)(-0.5 * sa.numsub); sa.linefit = 0; for (int i = 0; i < sa.speknum; i++) { sa.linefit += t1 * t1; t1 += 1; } }
+    sa.spectra = c->d_spur_spectra; sa.spurs = c->d_spurs; sa.table = c->d_spur_table; sa.signal = c->d_spur_signal; sa.ind = c->d_spur_ind; sa.scratch = c->d_spur_scratch;
+  }
+  const int na0 = p->fft2_na, max2 = c->cfg.max_fft2n;
   LRH_DEVICE_WORK(c, {
     if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
     if (fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(fft2_n, a, batch, c->cur)); }
@@ -1143,6 +1212,14 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     if (c->split_fft2_tail) {                      // power sums and waterfall lines only feed the GUI side: side stream
       HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0));
       c->cur = c->stream2;
+    }
+    if (spurs) {
+      ProfScope ps(c, "spur");
+      HIPCHK(c, launch_spur(sa, main_s));
+      const int first = batch < max2 - na0 ? batch : max2 - na0;          // the batch's ring slots may wrap once
+      HIPCHK(c, launch_power_of(c->d_fft2 + (size_t)na0 * N, c->d_power2 + (size_t)na0 * N, (size_t)first * N, main_s));
+      if (batch > first) HIPCHK(c, launch_power_of(c->d_fft2, c->d_power2, (size_t)(batch - first) * N, main_s));
+      if (c->split_fft2_tail) { HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0)); }
     }
     if (!fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
     if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }
@@ -1783,7 +1860,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_FFT2_FLOAT: src = c->d_fft2; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
     case LRH_RING_FFT2_POWER:
       src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2;
-      if (c->fft2_fused) {                               // the hot path keeps only the sums: |X|^2 of the requested span on demand
+      if (c->fft2_fused && c->spur_n == 0) {             // the hot path keeps only the sums: |X|^2 of the requested span on demand
         if (off > total || cnt > total - off) return LRH_EINVAL;
         HIPCHK(c, launch_power_of(c->d_fft2 + off, c->d_power2 + off, cnt, c->stream));
       }

@@ -2091,3 +2091,283 @@ hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, 
   return hipGetLastError();
 }
 }  // namespace lrh
+
+// =====================================================================================================
+// spur subtraction (eliminate_spurs, spur.c:36-494; one RF channel, float spectra)
+// =====================================================================================================
+// A spur is a few bins and a phase-locked loop over the last spur_speknum transforms: tiny data, serial in the transform index
+// (the loop state after transform t feeds transform t+1).  One lane per spur walks the batch's transforms in order; the spurs run
+// side by side.  The arithmetic follows the reference statement by statement where rounding feeds back into the loop (float
+// accumulators, sin / cos / atan2 / sqrt evaluated in double like its libm calls).
+namespace lrh {
+struct DevSpur { int location, flag; float freq, d0pha, d1pha, d2pha, ampl, noise, avgd2; };   // = lrh_spur
+#define LRH_PI 3.1415926535897932
+
+struct SpurLoop {
+  const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; float *sig, *der, *pha, *tmp;
+  float sp_d0, sp_d1, sp_d2;
+  int maxn, mask;
+
+  __device__ void lowpass(const float *zin, float *zout, int nn, int siz) const {          // complex_lowpass, spursub.c:1020-1068
+    int avgnum = nn | 1;
+    if (avgnum > nn && avgnum > siz / 4) avgnum -= 2;
+    if (avgnum < 1) return;
+    float t1 = 0, t2 = 0; const float t3 = (float)(1.0 / avgnum);
+    for (int i = 0; i < avgnum; i++) { t1 += zin[2 * i]; t2 += zin[2 * i + 1]; }
+    int j = 1 + avgnum / 2;
+    for (int i = 0; i < j; i++) { zout[2 * i] = t1 * t3; zout[2 * i + 1] = t2 * t3; }
+    for (int i = 0, k = avgnum; k < siz; i++, j++, k++) {
+      t1 += zin[2 * k] - zin[2 * i]; t2 += zin[2 * k + 1] - zin[2 * i + 1];
+      zout[2 * j] = t3 * t1; zout[2 * j + 1] = t3 * t2;
+    }
+    t1 *= t3; t2 *= t3;
+    for (; j < siz; j++) { zout[2 * j] = t1; zout[2 * j + 1] = t2; }
+  }
+
+  __device__ void phase_parameters() {                                                     // spur_phase_parameters, spur.c:1427-1652
+    const int n = a.speknum, ns = a.numsub, av = a.avgnum;
+    float t1, t2, t3, r1, r2, a1, a2, b1, b2, d1, d2;
+    for (int i = 1; i < n; i++) {                        // phase steps between neighbouring transforms, amplitude divided out
+      t1 = sig[2 * i] * sig[2 * i - 2] + sig[2 * i + 1] * sig[2 * i - 1];
+      t2 = sig[2 * i + 1] * sig[2 * i - 2] - sig[2 * i] * sig[2 * i - 1];
+      r1 = (float)sqrt((double)(t1 * t1 + t2 * t2));
+      if (r1 > 0.000000001) { der[2 * i - 2] = t1 / r1; der[2 * i - 1] = t2 / r1; } else { der[2 * i - 2] = 0; der[2 * i - 1] = 0; }
+    }
+    lowpass(der, tmp, av, ns);
+    r1 = 0; r2 = 0;
+    for (int i = 1 + av / 2; i < ns - av / 2; i++) {     // second difference, again as a cross product
+      t1 = tmp[2 * i] * tmp[2 * i - 2] + tmp[2 * i + 1] * tmp[2 * i - 1];
+      t2 = tmp[2 * i + 1] * tmp[2 * i - 2] - tmp[2 * i] * tmp[2 * i - 1];
+      t3 = (float)sqrt((double)(t1 * t1 + t2 * t2));
+      if (t3 > 0.00001) { r1 += t1 / t3; r2 += t2 / t3; }
+    }
+    sp_d2 = (float)atan2((double)r2, (double)r1);
+    t1 = q.d2pha + sp_d2;
+    if (fabs((double)t1) > a.max_d2 && fabs((double)sp_d2) > a.max_d2) sp_d2 = -q.d2pha / n;
+    else {
+      t1 = a.weiold * q.avgd2 + a.weinew * t1;
+      if (q.noise > 0.000001 && fabs((double)q.ampl) > 0.000001) { t2 = (float)(0.1 * fabs((double)q.ampl) / q.noise); t2 = 1 / (1 + t2); } else t2 = 1;
+      sp_d2 = t2 * (t1 - q.d2pha) + (1 - t2) * sp_d2;
+    }
+    for (int i = 0; i < ns; i++) pha[i] = (float)atan2((double)tmp[2 * i + 1], (double)tmp[2 * i]);
+    { float c = 0;                                        // remove_phasejumps, spursub.c:996-1017
+      for (int i = 1; i < ns; i++) {
+        pha[i] += c;
+        if (pha[i] - pha[i - 1] > LRH_PI) { pha[i] -= (float)(2 * LRH_PI); c -= (float)(2 * LRH_PI); }
+        if (pha[i] - pha[i - 1] < -LRH_PI) { pha[i] += (float)(2 * LRH_PI); c += (float)(2 * LRH_PI); }
+      } }
+    pha[ns] = 0;
+    for (int i = ns; i > 0; i--) pha[i - 1] = pha[i] - pha[i - 1];
+    t1 = (float)(sp_d2 * 0.5);
+    for (int i = 2; i < n; i++) pha[ns - i] -= i * (i - 1) * t1;
+    int na_ = n - av;
+    if (na_ < 10) na_ = n - av / 2;
+    if (na_ < 3) na_ = n;
+    { const float *z = &pha[n - na_]; const int k = na_ / 2; t2 = 0; t3 = 0;             // average_slope, spursub.c:975-992
+      for (int i = 0; i < k; i++) { t2 += z[i]; t3 += z[k + i]; }
+      sp_d1 = (t3 - t2) / (k * k); }
+    b1 = (float)cos((double)sp_d1); b2 = (float)sin((double)sp_d1);
+    a1 = b1; a2 = b2;
+    d1 = (float)cos((double)sp_d2); d2 = (float)sin((double)sp_d2);
+    t1 = 0; t2 = 0;
+    for (int i = ns; i >= 0; i--) {                      // local oscillator with the derivatives found: what is left is the phase offset
+      r1 = a1 * sig[2 * i] + a2 * sig[2 * i + 1];
+      r2 = a1 * sig[2 * i + 1] - a2 * sig[2 * i];
+      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+      t3 = (float)sqrt((double)(r1 * r1 + r2 * r2));
+      if (t3 > 0) { t1 += r1 / t3; t2 += r2 / t3; }
+      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+      r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
+    }
+    sp_d0 = (float)atan2((double)t2, (double)t1);
+    t3 = (float)sqrt((double)(t1 * t1 + t2 * t2));
+    t1 /= t3; t2 /= t3;
+    a1 = 0; a2 = 0;
+    d1 = (float)(-0.5 * ns);
+    for (int i = 0; i < n; i++) {                        // straight-line fit of the residual phase: correction to the frequency
+      r1 = t1 * tmp[2 * i] + t2 * tmp[2 * i + 1];
+      r2 = t1 * tmp[2 * i + 1] - t2 * tmp[2 * i];
+      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+      a1 += r1;
+      if (r1 > 0 && fabs((double)r2) < fabs((double)r1)) a2 += (float)(d1 * r2 / fabs((double)r1));
+      else a2 += (float)(d1 * atan2((double)r2, (double)r1));
+      d1 += 1;
+    }
+    a2 /= a.linefit;
+    sp_d1 += a2;
+    d2 = (float)(-0.5 * ns * a2);
+    b1 = (float)cos((double)a2); b2 = (float)-sin((double)a2);
+    a1 = (float)cos((double)d2); a2 = (float)sin((double)d2);
+    t1 = 0;
+    for (int i = 0; i < n; i++) {
+      r1 = a1 * tmp[2 * i] - a2 * tmp[2 * i + 1];
+      r2 = a1 * tmp[2 * i + 1] + a2 * tmp[2 * i];
+      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
+      t1 += r1;
+      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+    }
+    t1 /= n;
+    q.ampl = t1;                                          // amplitude = mean of the in-phase part, noise = rms of the rest
+    t2 = 0;
+    for (int i = 0; i < n; i++) t2 += (tmp[2 * i] - t1) * (tmp[2 * i] - t1) + tmp[2 * i + 1] * tmp[2 * i + 1];
+    q.noise = (float)sqrt((double)(t2 / n));
+  }
+
+  __device__ void refine(int na) {                                                          // refine_pll_parameters, spur.c:634-680
+    float phase = q.d0pha, slope = q.d1pha, curv = q.d2pha, r1;
+    slope += curv; phase += slope;
+    float a1 = (float)cos((double)phase), a2 = (float)sin((double)phase), b1 = (float)cos((double)slope), b2 = (float)sin((double)slope);
+    const float d1 = (float)cos((double)curv), d2 = (float)sin((double)curv);
+    int ni = na;
+    for (int i = a.speknum - 1; i >= 0; i--) {           // history de-rotated with the loop's own oscillator, newest last
+      sig[2 * i] = a1 * zsig[2 * ni] + a2 * zsig[2 * ni + 1];
+      sig[2 * i + 1] = a1 * zsig[2 * ni + 1] - a2 * zsig[2 * ni];
+      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+      r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
+      ni = (ni + mask) & mask;
+    }
+    phase_parameters();
+    phase += sp_d0; slope += sp_d1; curv += sp_d2;
+    phase -= slope; slope -= curv;
+    q.d0pha = phase; q.d1pha = slope; q.d2pha = curv;
+  }
+
+  __device__ void shift_table(int j, int na) {                                              // shift_spur_table, spursub.c:1070-1246
+    const int nj = (na + 1) & mask, shift = j < 0 ? -1 : 1;
+    q.location += shift;
+    if (q.location < 7) { q.flag = 1; q.location = 14; return; }
+    if (q.location > a.n2 - 7) { q.flag = 1; q.location = a.n2 - 14; return; }
+    for (int ni = (na - a.speknum + maxn) & mask; ni != nj; ni = (ni + 1) & mask) {
+      float *t = tab + ni * 14;
+      if (shift == 1) { for (int i = 1; i < 7; i++) { t[2 * i - 2] = t[2 * i]; t[2 * i - 1] = t[2 * i + 1]; } t[12] = 0; t[13] = 0; }
+      else { for (int i = 6; i > 0; i--) { t[2 * i] = t[2 * i - 2]; t[2 * i + 1] = t[2 * i - 1]; } t[0] = 0; t[1] = 0; }
+    }
+  }
+
+  // line shape for a frequency: index into spectra, j (second return) = 0/1 sub-position; < 0: the spur left its window (raw j returned)
+  __device__ static int shape(float freq, int loc, int &j) {
+    j = (int)(freq) + 2 - loc - 4;
+    if (j < 0 || j > 1) return -1;
+    j = 1 - j;
+    int ind = (int)(256 * (freq - (int)(freq)));
+    if (ind == 256) ind = 255;
+    return ind * 8 + j;
+  }
+  // keep the spur inside its window, shifting the history when it has moved by one bin; false: lock lost
+  __device__ bool centre(float freq, int na, int &ind, int &j) {
+    for (;;) {
+      ind = shape(freq, q.location, j);
+      if (ind >= 0) return true;
+      if (j < -1 || j > 2) { q.flag = 1; return false; }
+      shift_table(j, na);
+      if (q.flag) return false;
+    }
+  }
+
+  __device__ void transform(int na) {                                                       // eliminate_spurs, one spur, one transform
+    const float ff = a.freq_factor;
+    float2 *z = a.fft2 + (size_t)na * a.n2;
+    float *spt = tab + na * 14;
+    int i, j, k, ind;
+    if (q.flag == 1) {
+      j = (int)(q.freq) + 2 - q.location - 4;
+      if (j < 0 || j > 1) { if (j < -1) j = -1; if (j > 2) j = 2; shift_table(j, na); }
+    }
+    if (q.flag != 0) {                                   // unlocked: history and counting only (re-lock is the control plane's)
+      for (i = 0; i < 7; i++) { const float2 v = z[q.location + i]; spt[2 * i] = v.x; spt[2 * i + 1] = v.y; }
+      q.flag++;
+      if (q.flag > 1000000) q.flag -= 2 * 3 * 5 * 7 * a.speknum;
+      return;
+    }
+    float slope = q.d1pha + q.d2pha, curv, phase, r1, r2, freq;
+    float rot = (float)(-0.5 * slope / LRH_PI);
+    i = (int)(q.freq * ff - rot + 0.5);
+    rot += i;
+    freq = rot / ff;
+    q.freq = freq;
+    if (!centre(freq, na, ind, j)) return;
+    uind[na] = ind;
+    r1 = 0; r2 = 0;
+    for (i = 0; i < 7; i++) {                            // the new bins join the history; their projection on the line shape joins spur_signal
+      const float2 v = z[q.location + i];
+      spt[2 * i] = v.x; r1 += v.x * a.spectra[ind + i];
+      spt[2 * i + 1] = v.y; r2 += v.y * a.spectra[ind + i];
+    }
+    if ((j ^ (q.location & 1)) == 1) { r1 = -r1; r2 = -r2; }
+    zsig[2 * na] = r1; zsig[2 * na + 1] = r2;
+    int iter = 0, diffind;
+    freq = q.freq;
+    for (;;) {
+      iter++;
+      refine(na);
+      slope = q.d1pha; curv = q.d2pha;
+      slope += curv;
+      const int nx = (na - a.speknum + mask) & mask;
+      diffind = 0;
+      bool left = false;
+      for (int ni = na; ni != nx; ni = (ni + mask) & mask) {   // with the refined oscillator the history may project on other line shapes
+        rot = (float)(-0.5 * slope / LRH_PI);
+        i = (int)(freq * ff - rot + 0.5);
+        rot += i;
+        freq = rot / ff;
+        ind = shape(freq, q.location, j);
+        if (ind < 0) { left = true; break; }
+        k = (uind[ni] - ind + 2048) & 2047;
+        if (k > 1024) k = 2048 - k;
+        if (k > diffind) diffind = k;
+        uind[ni] = ind;
+        if (k != 0) {
+          const float *t = tab + ni * 14;
+          r1 = 0; r2 = 0;
+          for (i = 0; i < 7; i++) { r1 += t[2 * i] * a.spectra[ind + i]; r2 += t[2 * i + 1] * a.spectra[ind + i]; }
+          if ((j ^ (q.location & 1)) == 1) { r1 = -r1; r2 = -r2; }
+          zsig[2 * ni] = r1; zsig[2 * ni + 1] = r2;
+        }
+        slope -= curv;
+      }
+      if (left || !(diffind > 2.5 * 8 && iter < 5)) break;
+    }
+    if (diffind != 0) refine(na);
+    if (fabs((double)q.ampl) < a.minston * q.noise) { q.flag = 1; return; }
+    // the loop is settled: advance it by one transform and take the carrier out of the new bins
+    phase = q.d0pha; slope = q.d1pha; curv = q.d2pha;
+    const float ampl = q.ampl;
+    slope += curv; phase += slope;
+    q.d0pha = phase; q.d1pha = slope;
+    if (q.d0pha > LRH_PI) q.d0pha -= (float)(2 * LRH_PI);
+    if (q.d0pha < -LRH_PI) q.d0pha += (float)(2 * LRH_PI);
+    if (q.d1pha > LRH_PI) q.d1pha -= (float)(2 * LRH_PI);
+    if (q.d1pha < -LRH_PI) q.d1pha += (float)(2 * LRH_PI);
+    if (q.d2pha > LRH_PI) q.d2pha -= (float)(2 * LRH_PI);
+    if (q.d2pha < -LRH_PI) q.d2pha += (float)(2 * LRH_PI);
+    q.avgd2 = a.weiold * q.avgd2 + a.weinew * curv;
+    rot = (float)(-0.5 * slope / LRH_PI);
+    i = (int)(q.freq * ff - rot + 0.5);
+    rot += i;
+    freq = rot / ff;
+    q.freq = freq;
+    if (!centre(freq, na, ind, j)) return;
+    float t1 = (float)(cos((double)phase) * ampl), t2 = (float)(sin((double)phase) * ampl);
+    if ((j ^ (q.location & 1)) == 1) { t1 = (float)(-cos((double)phase) * ampl); t2 = (float)(-sin((double)phase) * ampl); }
+    for (i = 0; i < 7; i++) { float2 v = z[q.location + i]; v.x -= a.spectra[ind + i] * t1; v.y -= a.spectra[ind + i] * t2; z[q.location + i] = v; }
+  }
+};
+
+__global__ __launch_bounds__(64) void k_spur(SpurArgs a)
+{
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.nspurs) return;
+  const int maxn = a.na_mask + 1;
+  DevSpur q = reinterpret_cast<DevSpur *>(a.spurs)[s];
+  float *scr = a.scratch + (size_t)s * 8 * (maxn + 8);
+  SpurLoop L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn,
+             scr, scr + 2 * (maxn + 8), scr + 4 * (maxn + 8), scr + 6 * (maxn + 8), 0.f, 0.f, 0.f, maxn, a.na_mask};
+  for (int b = 0; b < a.batch; b++) L.transform((a.first_na + b) & a.na_mask);
+  reinterpret_cast<DevSpur *>(a.spurs)[s] = q;
+}
+hipError_t launch_spur(const SpurArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_spur, dim3((a.nspurs + 63) / 64), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+}  // namespace lrh

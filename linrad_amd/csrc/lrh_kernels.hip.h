@@ -200,3 +200,17 @@ struct SellimArgs {
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
 hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream);
 }
+
+// ---- spur subtraction (eliminate_spurs, spur.c:36-494) ----
+namespace lrh {
+struct SpurArgs {
+  float2 *fft2; int n2, first_na, na_mask, batch;       // fft2_float ring, transforms first_na .. first_na + batch - 1
+  int nspurs, speknum, avgnum, numsub;
+  float freq_factor, max_d2, minston, weiold, weinew, linefit;
+  const float *spectra;                                  // [256][8] reference line shapes
+  void *spurs;                                           // lrh_spur [nspurs]
+  float *table, *signal; int *ind;                       // per spur: [maxn][7][2], [maxn][2], [maxn]
+  float *scratch;                                        // per spur 4 x 2 (maxn + 8) floats: sp_sig, sp_der, sp_pha, sp_tmp
+};
+hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
+}
