@@ -15,7 +15,7 @@ for f in glob.glob(sys.argv[1]+"/p*/**/*counter_collection.csv",recursive=True):
         k=r["Kernel_Name"].split("(")[0].replace("void lrh::","")[:24]
         a=acc[k][r["Counter_Name"]]; a[0]+=float(r["Counter_Value"]); a[1]+=1
 for k,v in acc.items():
-    if not any(s in k for s in ("k_fft1","k_timf2","k_fft2","k_blank_scan","k_sumsq")): continue
+    if not any(s in k for s in ("k_fft1","k_timf2","k_fft2","k_blank_scan","k_sumsq","k_sellim")): continue
     print(k)
     for c,(s,n) in sorted(v.items()): print("   %-24s %14.0f  (n=%d)"%(c,s/n,n))
 PY
