@@ -159,7 +159,38 @@ typedef struct lrh_blanker_state {
   int timf2_cleared_points;         /* since the last info update                                  */
   int last_call_cleared;            /* cleared_points of the most recent call                      */
   int slow_path_calls;              /* calls that fell back to the exact serial scan               */
+  /* linear ("clever") blanker, lrh_set_blanker_tables */
+  unsigned int clever_bln_limit;
+  float clever_blanker_rate;
+  int timf2_fitted_pulses;          /* since the last info update                                  */
+  int last_call_fitted;             /* fitted_pulses of the most recent call                       */
+  int last_call_rejected;           /* pulses of that call flagged 65 (bad_pulse, blank1.c:945)    */
 } lrh_blanker_state;
+
+/* ---- linear ("clever") noise blanker: first_noise_blanker's pulse search / fit / subtract part (blank1.c:765-1003 with
+   subtract_onechan_pulse :36-232 and set_flag :615-682).  It needs the pulse response of the calibrated receiver, which
+   init_blanker (buf.c:1786-2057) derives from the amplitude calibration fft1_desired at start-up: those tables are an INPUT
+   here, handed over once (the calibration itself -- cal*.c -- is outside this path).  One RF channel only (the two-channel
+   variant get_pulse_pol / subtract_twochan_pulse is not built: LRH_EINVAL with cfg.blanker_channels = 2).
+   With tables installed lrh_first_noise_blanker first runs the pulse search over the span, then the stupid blanker
+   (cfg.stupid_bln_mode) as before; timf2p_fit follows blank1.c:1458-1461 ((pf-16) & ~3: a pulse too close to the end of the
+   span is left for the next call), which makes that pointer data dependent: the call reads one int back, so
+   with clever mode on each lrh_first_noise_blanker waits for its own device work and lrh_wideband_dsp runs the serial schedule. */
+#define LRH_BLN_INFO_SIZE 7       /* blnkdef.h:5  */
+#define LRH_MAX_REFPULSES 256     /* blnkdef.h:6  */
+typedef struct lrh_bln_info { int size; float rest; float avgmax; } lrh_bln_info;   /* BLANKER_CONTROL_INFO, blnkdef.h:8-14 */
+typedef struct lrh_blanker_tables {
+  int clever_bln_mode;              /* hg.clever_bln_mode: 1 = limit follows the noise floor, 2 = fixed clever_bln_limit */
+  float clever_bln_factor;          /* hg.clever_bln_factor (mode 1)                                                    */
+  unsigned int clever_bln_limit;    /* hg.clever_bln_limit at start                                                     */
+  int refpul_size;                  /* power of two, 4..256                                                             */
+  int largest_blnfit;               /* 0..LRH_BLN_INFO_SIZE-1; cfg.blnfit_range must be bln[largest_blnfit].size/2 + cfg.blanker_pulsewidth */
+  float liminfo_amplitude_factor;
+  lrh_bln_info bln[LRH_BLN_INFO_SIZE];
+  const float *refpulse;            /* blanker_refpulse  [LRH_MAX_REFPULSES][refpul_size][2]                            */
+  const float *phasefunc;           /* blanker_phasefunc [refpul_size][2]                                               */
+  const int *pulindex;              /* blanker_pulindex  [LRH_MAX_REFPULSES]                                            */
+} lrh_blanker_tables;
 
 /* mix1 phase bookkeeping (seldef.h:205-214), host side, double-checked against mix1.c:781-861 */
 typedef struct lrh_mix1_state {
@@ -360,6 +391,8 @@ int lrh_exchange_ptr(lrh_ctx *ctx, int which, void **device_ptr);           /* f
 int lrh_exchange_read(lrh_ctx *ctx, int which, float *dst, size_t off, size_t count);   /* synchronous, for tests / host exchange */
 int lrh_exchange_write(lrh_ctx *ctx, int which, const float *src, size_t off, size_t count);
 int lrh_first_noise_blanker(lrh_ctx *ctx, lrh_ptrs *p);
+/* install / remove the linear blanker's tables (see lrh_blanker_tables); the arrays are copied */
+int lrh_set_blanker_tables(lrh_ctx *ctx, const lrh_blanker_tables *t);   /* NULL: clever blanker off again */
 /* make_fft2 until FFT2_COMPLETE (fft2def.h:61; fft2.c:52-1848, mode 15), `batch` transforms.
    The caller checks (timf2_pn2-timf2_px) >= 4*N2 per transform as wcw.c:265-275 does. */
 int lrh_make_fft2(lrh_ctx *ctx, lrh_ptrs *p, int batch);

@@ -65,7 +65,21 @@ class LrhBlankerState(C.Structure):
         ("timf2_despiked_pwr", C.c_float * 2), ("timf2_despiked_pwrinc", C.c_float * 2),
         ("stupid_blanker_rate", C.c_float), ("timf2_cleared_points", C.c_int),
         ("last_call_cleared", C.c_int), ("slow_path_calls", C.c_int),
+        ("clever_bln_limit", C.c_uint), ("clever_blanker_rate", C.c_float), ("timf2_fitted_pulses", C.c_int),
+        ("last_call_fitted", C.c_int), ("last_call_rejected", C.c_int),
     ]
+
+
+class LrhBlnInfo(C.Structure):
+    _fields_ = [("size", C.c_int), ("rest", C.c_float), ("avgmax", C.c_float)]
+
+
+class LrhBlankerTables(C.Structure):
+    """lrh_blanker_tables: the linear blanker's pulse-response tables as init_blanker (buf.c:1786-2057) leaves them"""
+    _fields_ = [("clever_bln_mode", C.c_int), ("clever_bln_factor", C.c_float), ("clever_bln_limit", C.c_uint),
+                ("refpul_size", C.c_int), ("largest_blnfit", C.c_int), ("liminfo_amplitude_factor", C.c_float),
+                ("bln", LrhBlnInfo * 7), ("refpulse", C.POINTER(C.c_float)), ("phasefunc", C.POINTER(C.c_float)),
+                ("pulindex", C.POINTER(C.c_int))]
 
 
 class LrhMix1State(C.Structure):
@@ -216,6 +230,7 @@ class StageAPI:
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
         self._proto("fft1_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
+        self._proto("set_blanker_tables", [vp, C.POINTER(LrhBlankerTables)])
         self._proto("spur_config", [vp, C.c_int, C.c_int, fp])
         self._proto("spur_set", [vp, C.c_int, C.POINTER(LrhSpur), fp, fp, ip])
         self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
@@ -361,6 +376,24 @@ class StageAPI:
         out = np.empty(self.N1, np.float32)
         self._chk(self._f("get_liminfo")(self.ctx, self._fptr(out)), "get_liminfo")
         return out
+
+    def set_blanker_tables(self, bln=None, refpulse=None, phasefunc=None, pulindex=None, largest_blnfit=0, clever_bln_factor=10.0,
+                           clever_bln_limit=0, clever_bln_mode=1, liminfo_amplitude_factor=1.0):
+        """install the linear blanker's tables (bln: rows of (size, rest, avgmax)); no arguments: clever blanker off"""
+        if bln is None:
+            self._chk(self._f("set_blanker_tables")(self.ctx, None), "set_blanker_tables")
+            return
+        t = LrhBlankerTables()
+        rp, pf = np.ascontiguousarray(refpulse, np.float32), np.ascontiguousarray(phasefunc, np.float32)
+        pi = np.ascontiguousarray(pulindex, np.int32)
+        t.refpul_size = pf.size // 2
+        assert rp.size == 2 * 256 * t.refpul_size and pi.size == 256
+        t.clever_bln_mode, t.clever_bln_factor, t.clever_bln_limit = int(clever_bln_mode), float(clever_bln_factor), int(clever_bln_limit)
+        t.largest_blnfit, t.liminfo_amplitude_factor = int(largest_blnfit), float(liminfo_amplitude_factor)
+        for i, row in enumerate(bln):
+            t.bln[i].size, t.bln[i].rest, t.bln[i].avgmax = int(row[0]), float(row[1]), float(row[2])
+        t.refpulse, t.phasefunc, t.pulindex = self._fptr(rp), self._fptr(pf), pi.ctypes.data_as(C.POINTER(C.c_int))
+        self._chk(self._f("set_blanker_tables")(self.ctx, C.byref(t)), "set_blanker_tables")
 
     def spur_config(self, max_spurs, spur_speknum, spur_spectra):
         t = np.ascontiguousarray(spur_spectra, np.float32)

@@ -61,6 +61,8 @@ struct lro_ctx {
   int fft1n_mask, fft1_mask, fft1_sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
   /* blanker scalars (blnkvar.c) */
   lrh_blanker_state bs;
+  /* linear blanker (lro_set_blanker_tables) */
+  lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
   double old_mix1_selfreq;
@@ -323,7 +325,8 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol };
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
+                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
     struct { float *old; unsigned char *wait; float *tmp, *group_min; } *s = c->sellim;
@@ -691,6 +694,172 @@ int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size
   memcpy((float *)q + off, src, 4 * count); return LRH_OK;
 }
 
+/* ---- linear ("clever") blanker: blank1.c:36-232 (subtract_onechan_pulse), :615-682 (set_flag), :765-1003 (search loop) ---- */
+int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
+{
+  free(c->bt_refpulse); free(c->bt_phasefunc); free(c->bt_pulindex); free(c->blanker_flag);
+  c->bt_refpulse = c->bt_phasefunc = NULL; c->bt_pulindex = NULL; c->blanker_flag = NULL; c->clever_on = 0;
+  if (!t) return LRH_OK;
+  if (c->cfg.blanker_channels == 2) return LRH_EINVAL;
+  int rs = t->refpul_size, pw = c->cfg.blanker_pulsewidth;
+  if (t->clever_bln_mode < 1 || t->clever_bln_mode > 2 || rs < 4 || rs > 256 || (rs & (rs - 1)) || t->largest_blnfit < 0 ||
+      t->largest_blnfit >= LRH_BLN_INFO_SIZE || !t->refpulse || !t->phasefunc || !t->pulindex || pw < 1 || 2 * pw >= rs) return LRH_EINVAL;
+  for (int i = 0; i <= t->largest_blnfit; i++)
+    if (t->bln[i].size < 4 || t->bln[i].size > rs || (t->bln[i].size & 1) || (i && t->bln[i].size <= t->bln[i - 1].size)) return LRH_EINVAL;
+  if (c->cfg.blnfit_range != t->bln[t->largest_blnfit].size / 2 + pw) return LRH_EINVAL;      /* buf.c:2057 */
+  for (int i = 0; i < LRH_MAX_REFPULSES; i++) if (t->pulindex[i] < 0 || t->pulindex[i] >= LRH_MAX_REFPULSES) return LRH_EINVAL;
+  c->bt = *t;
+  size_t nr = (size_t)2 * LRH_MAX_REFPULSES * rs;
+  c->bt_refpulse = malloc(4 * nr); c->bt_phasefunc = malloc(8 * rs); c->bt_pulindex = malloc(4 * LRH_MAX_REFPULSES);
+  c->blanker_flag = calloc(1, c->cfg.timf2pow_size);
+  memcpy(c->bt_refpulse, t->refpulse, 4 * nr); memcpy(c->bt_phasefunc, t->phasefunc, 8 * rs); memcpy(c->bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES);
+  c->bt.refpulse = c->bt_refpulse; c->bt.phasefunc = c->bt_phasefunc; c->bt.pulindex = c->bt_pulindex;
+  c->bs.clever_bln_limit = t->clever_bln_limit;
+  c->clever_on = 1;
+  return LRH_OK;
+}
+
+/* blank1.c:615-682: flag +-pulsewidth around p_max and on outwards for as long as the power keeps falling */
+static void clever_set_flag(lro_ctx *c, unsigned char value, int p_max, int pbeg, int pend)
+{
+  const int mask = c->timf2pow_mask;
+  const float *pw = c->timf2_pwr;
+  unsigned char *fl = c->blanker_flag;
+  fl[p_max] = value;
+  int pa = p_max, pb = p_max;
+  for (int i = 0; i < c->cfg.blanker_pulsewidth; i++) { pb = (pb + mask) & mask; pa = (pa + 1) & mask; fl[pa] = value; fl[pb] = value; }
+  int p0 = pb; pb = (pb + mask) & mask;
+  if (!(((pb - pbeg + mask) & mask) > mask / 2))
+    while (pw[pb] < pw[p0] && pb != pbeg) { fl[pb] = value; p0 = pb; pb = (pb + mask) & mask; }
+  p0 = pa; pa = (pa + 1) & mask;
+  if (!(((pend - pa + mask) & mask) > mask / 2))
+    while (pw[pa] < pw[p0] && pa != pend) { p0 = pa; fl[pa] = value; pa = (pa + 1) & mask; }
+}
+
+/* blank1.c:36-232.  Quirk kept: the restore after a failed subtraction (:190-208) adds the cross terms with the signs of the
+   subtraction, so the samples are NOT returned to their old values exactly when blanker_phase_c2 != 0. */
+static float clever_subtract(lro_ctx *c, int p_max, int sub_size)
+{
+  const int mask = c->timf2pow_mask, rs = c->bt.refpul_size, pwid = c->cfg.blanker_pulsewidth;
+  float *tf = c->timf2_float, *pw = c->timf2_pwr;
+  const float *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
+  float in[2 * 257];
+  int k = rs - 2 * pwid, i = 0;
+  for (int q = p_max - pwid; q <= p_max + pwid; q++) {
+    int pa = 4 * (q & mask);
+    float t1 = tf[pa], t2 = tf[pa + 1], t3 = phf[k], t4 = phf[k + 1];
+    in[i] = t1 * t3 + t2 * t4; in[i + 1] = t2 * t3 - t1 * t4; k += 2; i += 2;
+  }
+  int imax = pwid;
+  float c1 = 0, c2 = 0;
+  for (i = imax - 1; i <= imax + 1; i++) { float t1 = in[2 * i], t2 = in[2 * i + 1], t3 = sqrt(t1 * t1 + t2 * t2); c1 += t3 * t1; c2 += t3 * t2; }
+  float t1 = c1 * c1 + c2 * c2;
+  if (t1 < 32) return -1;
+  t1 = sqrt(t1); c1 /= t1; c2 /= t1;
+  int wid = 2 * pwid;
+  float t3 = 0, t4 = 0;
+  for (i = 0; i <= wid; i++) {
+    float a = in[2 * i], b = in[2 * i + 1];
+    in[2 * i] = c1 * a + c2 * b; in[2 * i + 1] = c1 * b - c2 * a;
+    t3 += in[2 * i] * in[2 * i]; t4 += in[2 * i + 1] * in[2 * i + 1];
+  }
+  if (t4 > 0.25 * t3) return -1.;
+  t4 = in[2 * imax - 2] - in[2 * imax + 2];
+  t3 = 2 * (in[2 * imax - 2] + in[2 * imax + 2] - 2 * in[2 * imax]);
+  if (t3 == 0) return -2.;
+  t4 /= t3;
+  if (t4 < 0) t4 = -sqrt(0.5) * sqrt(-t4); else t4 = sqrt(0.5) * sqrt(t4);
+  int j = LRH_MAX_REFPULSES * (t4 + 0.5) + 0.5;
+  if (j < 0) j = 0;
+  if (j >= LRH_MAX_REFPULSES) j = LRH_MAX_REFPULSES - 1;
+  int m = 2 * c->bt_pulindex[j] * rs;
+  c1 *= in[2 * imax] * c->bt.liminfo_amplitude_factor; c2 *= in[2 * imax] * c->bt.liminfo_amplitude_factor;
+  t3 = 0; t4 = 0;
+  k = rs - sub_size;
+  for (int q = p_max - sub_size / 2; q <= p_max + sub_size / 2; q++) {
+    int pos = q & mask, p0 = 4 * pos;
+    float r1 = rp[m + k], r2 = rp[m + k + 1];
+    float re = tf[p0] - c1 * r1 + c2 * r2, im = tf[p0 + 1] - c1 * r2 - c2 * r1;
+    tf[p0] = re; tf[p0 + 1] = im;
+    float pn = re * re + im * im;
+    t3 += pw[pos]; pw[pos] = pn; k += 2; t4 += pn;
+  }
+  float retval = t4 / t3;
+  if (retval > 0.5) {
+    k = rs - sub_size;
+    for (int q = p_max - sub_size / 2; q <= p_max + sub_size / 2; q++) {
+      int pos = q & mask, p0 = 4 * pos;
+      float r1 = rp[m + k], r2 = rp[m + k + 1];
+      float re = tf[p0] + c1 * r1 + c2 * r2, im = tf[p0 + 1] + c1 * r2 - c2 * r1;
+      tf[p0] = re; tf[p0 + 1] = im; pw[pos] = re * re + im * im; k += 2;
+    }
+    return -5;
+  }
+  return retval;
+}
+
+/* the search loop of first_noise_blanker, blank1.c:765-1003; returns pf (where the scan stopped) */
+static int clever_search(lro_ctx *c, int pbeg, int pend, int *fitted_out, int *rejected_out)
+{
+  const int mask = c->timf2pow_mask, R = c->cfg.blnfit_range;
+  lrh_blanker_state *s = &c->bs;
+  const float *pw = c->timf2_pwr;
+  unsigned char *fl = c->blanker_flag;
+  float avgpwr[LRH_BLN_INFO_SIZE];
+  for (int i = 0; i < LRH_BLN_INFO_SIZE; i++) avgpwr[i] = 0;
+  int p0 = pbeg, pf = pbeg, fitted = 0, rejected = 0;
+  fl[p0] = 0;
+  while (p0 != pend) { p0 = (p0 + 1) & mask; fl[p0] = 0; }
+  const unsigned int nfl = s->clever_bln_limit;
+  const float sizlim = 0.1 * s->timf2_noise_floor;
+  for (;;) {
+    while ((pw[pf] <= nfl || fl[pf] > 64) && pf != pend) pf = (pf + 1) & mask;
+    if (pf == pend) break;
+    p0 = (pf + mask) & mask;                       /* pf-1 (the reference lets -1 through: its first use is p0+1 masked) */
+    int p_max = pf, m = R;
+    float powermax = 10;
+    while (p0 != pend && m > 0) {
+      p0 = (p0 + 1) & mask;
+      if (pw[p0] > powermax && fl[p0] < 64) { fl[p0] = 1; powermax = pw[p0]; p_max = p0; m = R; }
+      m--;
+    }
+    if (m > 0) break;
+    int no_pulse = 0;
+    p0 = (p_max + mask) & mask;
+    if (fl[p0] >= 64) { pf = p_max; no_pulse = 1; }
+    else {
+      p0 = (p_max + 1) & mask;
+      if (p0 == pend) break;
+      if (fl[p0] >= 64) no_pulse = 1;            /* blank1.c:834: joins no_pulse WITHOUT moving pf to p_max */
+    }
+    if (no_pulse) {
+      while ((pw[pf] <= powermax || fl[pf] > 64) && pf != pend) { powermax = pw[pf]; pf = (pf + 1) & mask; }
+      if (pf == pend) break;
+      continue;
+    }
+    int bln_no = 0, pa = (p_max + 1) & mask, pb = (p_max + mask) & mask, k = 2;
+    for (;;) {
+      powermax = pw[p_max];
+      float t1 = powermax * c->bt.bln[bln_no].rest;
+      if (t1 < sizlim) break;
+      t1 = 0;
+      while (k < c->bt.bln[bln_no].size) { t1 += pw[pa] + pw[pb]; pa = (pa + 1) & mask; pb = (pb + mask) & mask; k += 2; }
+      avgpwr[bln_no] = t1 / powermax;
+      bln_no++;
+      if (bln_no > c->bt.largest_blnfit) break;
+    }
+    bln_no--;
+    while (bln_no >= 0 && avgpwr[bln_no] > c->bt.bln[bln_no].avgmax) bln_no--;
+    float rv = -1;
+    if (bln_no >= 0) rv = clever_subtract(c, p_max, c->bt.bln[bln_no].size);
+    if (rv < 0) { clever_set_flag(c, 65, p_max, pbeg, pend); rejected++; continue; }
+    fitted++;
+    clever_set_flag(c, 66, p_max, pbeg, pend);
+  }
+  *fitted_out = fitted; *rejected_out = rejected;
+  return pf;
+}
+
 int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
 {
   const int mm = 4, mask = c->timf2pow_mask;
@@ -710,7 +879,8 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
     c->x_count = -1;
   }
 #define CLR(pos) do { pw[pos] = 0; own[pos] = 0; tf[4 * (pos)] = 0; tf[4 * (pos) + 1] = 0; } while (0)
-  int cleared = 0;
+  int cleared = 0, fitted = 0, rejected = 0, pf = pend;
+  if (c->clever_on) pf = clever_search(c, pbeg, pend, &fitted, &rejected);
   if (c->cfg.stupid_bln_mode != 0) {
     unsigned int nfl = s->stupid_bln_limit;
     int p0 = pbeg, ifirst = 0, pk = p0;
@@ -740,14 +910,15 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
     }
   }
 #undef CLR
-  s->last_call_cleared = cleared;
-  p->timf2p_fit = pend;                       /* blank1.c:1464 */
+  s->last_call_cleared = cleared; s->last_call_fitted = fitted; s->last_call_rejected = rejected;
+  p->timf2p_fit = c->clever_on ? ((pf - 16 + mask) & (mask & ~3)) : pend;      /* blank1.c:1458-1465 */
   p->timf2_pn2 = mm * pend;
   int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
+  s->timf2_fitted_pulses += fitted;
   s->timf2_cleared_points += cleared;
   p->timf2_blanker_points += m;
   if (p->timf2_blanker_points == 0) return LRH_OK;
-  int k = m - cleared; if (k < m / 25) k = m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
+  int k = m - cleared - fitted; if (k < m / 25) k = m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
   float t1 = 0;
   /* one channel: the (cleared) power ring; two: each channel's own weak power, t3*t3+t4*t4 of blank1.c:1516-1523 */
   for (int p0 = pbeg; p0 != p->timf2p_fit;) { p0 = (p0 + 4) & mask; t1 += coupled ? tf[4 * p0] * tf[4 * p0] + tf[4 * p0 + 1] * tf[4 * p0 + 1] : pw[p0]; }
@@ -775,6 +946,8 @@ static int blanker_update(lro_ctx *c, lrh_ptrs *p, float t1, int do_update, floa
     int iv = c->cfg.blanker_info_update_interval;
     s->timf2_despiked_pwr[0] = s->timf2_despiked_pwrinc[0] / (iv * llf);
     s->timf2_despiked_pwr[1] = s->timf2_despiked_pwrinc[1] / (iv * llf);
+    s->clever_blanker_rate = 100. * (float)s->timf2_fitted_pulses / p->timf2_blanker_points;
+    if (s->clever_blanker_rate > 99) s->clever_blanker_rate = 99;
     s->stupid_blanker_rate = 100. * (float)s->timf2_cleared_points / p->timf2_blanker_points;
     if (s->stupid_blanker_rate > 99) s->stupid_blanker_rate = 99;
     s->timf2_noise_floor = (s->timf2_despiked_pwr[0] + s->timf2_despiked_pwr[1]) / chans;
@@ -790,9 +963,10 @@ static int blanker_update(lro_ctx *c, lrh_ptrs *p, float t1, int do_update, floa
       }
       s->stupid_bln_limit = s->timf2_noise_floor * c->cfg.stupid_bln_factor;
     }
+    if (c->clever_on && c->bt.clever_bln_mode == 1) s->clever_bln_limit = s->timf2_noise_floor * c->bt.clever_bln_factor;
     p->blanker_info_update_counter = 0;
     s->timf2_despiked_pwrinc[0] = 1; s->timf2_despiked_pwrinc[1] = 1;
-    s->timf2_cleared_points = 0; p->timf2_blanker_points = 0;
+    s->timf2_fitted_pulses = 0; s->timf2_cleared_points = 0; p->timf2_blanker_points = 0;
   }
   return LRH_OK;
 }

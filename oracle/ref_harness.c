@@ -42,6 +42,11 @@
 /* ---- stand-ins for GUI / OS entry points of the reference program ---- */
 int harness_err = 0;
 void lirerr(int e) { fprintf(stderr, "lirerr(%d)\n", e); harness_err = e; }
+/* the reference's block allocator (modesub.c:1886-1960) as plain callocs: init_blanker (buf.c:1771) registers its tables through it */
+void init_memalloc(MEM_INF *mm, size_t max) { (void)mm; (void)max; }
+void mem(int num, void *pointer, size_t size, int scratch_size) { (void)num; *(void **)pointer = (char *)calloc(1, size + scratch_size + 64) + ((scratch_size + 15) & ~15); }
+size_t memalloc(size_t **hh, char *s) { (void)s; *hh = (size_t *)calloc(1, 64); return 64; }
+void memcheck(int callno, MEM_INF *mm, size_t **hh) { (void)callno; (void)mm; (void)hh; }
 /* fft3_mix2 runs on into the demodulators; its filter / decimate / polarisation part ends at the thread-command check of
    mix2.c:749.  The back transform in front of that check yields (fft0.c:495, yieldflag_ndsp_mix2), and the yield is this
    OS stub: armed, it withdraws the thread's command the way the GUI thread would, so the function returns there. */
@@ -253,6 +258,10 @@ int main(int argc, char **argv)
   int spur = AI("spur", 0);                      /* 1: a spur at fft2 bin spur_pnt (first of its SPUR_WIDTH bins) is acquired by the reference's own
                                                     store_new_spur / spur_phase_lock once spur_start transforms exist, then tracked and subtracted
                                                     by eliminate_spurs inside make_fft2 (fft2.c:647-652) */
+  int clever = AI("clever", 0);                  /* 1: the linear ("clever") blanker: init_blanker (buf.c:1771-2057) builds the pulse tables from the amplitude
+                                                    calibration fft1_desired (file desired=, N1 floats), first_noise_blanker then fits and subtracts pulses */
+  double clever_factor = AF("clever_factor", 10.0);
+  const char *fdesired = arg(argc, argv, "desired", NULL);
   int spur_pnt = AI("spur_pnt", 0), spur_start = AI("spur_start", 16), spur_spek = AI("spur_speknum", 0);
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
   double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
@@ -402,6 +411,33 @@ int main(int argc, char **argv)
   hg.blanker_ston_fft1 = (float)AF("ston_fft1", 4.0);
   blnfit_range = fitrange; blanker_pulsewidth = pulsewidth;
   blanker_flag = zalloc(timf2pow_size + 64);
+  if (clever) {
+    /* init_blanker's calibrated branch (buf.c:1786-2057) run on a synthetic amplitude calibration: the pulse response tables
+       (bln[], blanker_refpulse, blanker_phasefunc, blanker_pulindex), blanker_pulsewidth and blnfit_range are the reference's own */
+    if (C != 1 || !fdesired) { fprintf(stderr, "clever=1 needs one channel and desired=<file>\n"); return 2; }
+    float *des = zalloc(sizeof(float) * N1), *keep = fft1_desired;
+    FILE *fd = fopen(fdesired, "rb"); if (!fd || fread(des, sizeof(float), N1, fd) != (size_t)N1) { perror(fdesired); return 2; }
+    fclose(fd);
+    int keepflag = fft1_calibrate_flag;
+    fft1_blockbytes = fft1_block * sizeof(float);
+    screen_width = 64; screen_height = 64;
+    fft1_desired = des; fft1_calibrate_flag |= CALAMP;
+    init_blanker();
+    fft1_desired = keep; fft1_calibrate_flag = keepflag;
+    memset(fft1_float, 0, sizeof(float) * max_fft1n * fft1_block);      /* init_blanker used it as scratch */
+    memset(fftw_tmp, 0, sizeof(float) * (4 * C * N1 + 64));
+    hg.clever_bln_mode = 1; hg.clever_bln_factor = (float)clever_factor;
+    hg.clever_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.clever_bln_factor);
+    fprintf(stderr, "init_blanker: refpul_size %d pulsewidth %d largest_blnfit %d blnfit_range %d\n", refpul_size, blanker_pulsewidth, largest_blnfit, blnfit_range);
+    float bl[4 * BLN_INFO_SIZE];
+    for (int i = 0; i < BLN_INFO_SIZE; i++) { bl[4 * i] = bln[i].size; bl[4 * i + 1] = bln[i].rest; bl[4 * i + 2] = bln[i].avgmax; bl[4 * i + 3] = bln[i].avgpwr; }
+    PUTF("bln", bl, 4 * BLN_INFO_SIZE);
+    int bi[5] = { refpul_size, blanker_pulsewidth, largest_blnfit, blnfit_range, MAX_REFPULSES }; PUTI("bln_ints", bi, 5);
+    PUTF("bln_fparams", ((float[]){ liminfo_amplitude_factor, hg.clever_bln_factor }), 2);
+    PUTF("blanker_refpulse", blanker_refpulse, (size_t)2 * MAX_REFPULSES * refpul_size);
+    PUTF("blanker_phasefunc", blanker_phasefunc, (size_t)2 * refpul_size);
+    PUTI("blanker_pulindex", blanker_pulindex, MAX_REFPULSES);
+  }
   min_delay_time = (bln_minpts >= 0) ? (float)bln_minpts : (float)N2 / 3.0f;   /* x ui.rx_ad_speed(=1), buf.c:500-509 */
   timf2_oscilloscope_counter = 0; timf2_oscilloscope_maxpoint = 0; timf2_oscilloscope_maxval_float = 0;
   timf2_oscilloscope_powermax_float = 0; timf2_show_pointer = -1; timf2_oscilloscope_interval = 15;
@@ -710,6 +746,7 @@ int main(int argc, char **argv)
     it[5] = timf2_cleared_points; it[6] = timf2_blanker_points; it[7] = blanker_info_update_counter;
     it[8] = fft2_na; it[9] = fft1_sumsq_pa; it[10] = fft1_sumsq_counter; it[11] = fft1_lowlevel_points;
     it[12] = timf2_noise_floor; it[13] = (int)hg.stupid_bln_limit; it[14] = nfft2; it[15] = fft1_liminfo_cnt;
+    t[6] = (float)hg.clever_bln_limit; t[7] = clever_blanker_rate; t[8] = (float)timf2_fitted_pulses;
     if (sellim && fft1_liminfo_cnt != local_fft1_liminfo_cnt) {        /* wcw.c:1124-1128 */
       fft1_update_liminfo();
       local_fft1_liminfo_cnt = fft1_liminfo_cnt;

@@ -330,3 +330,60 @@ def spur_case(name):
         iq[0::2] += tone[2] * np.cos(ph)
         iq[1::2] += tone[2] * np.sin(ph)
     return d, sp, np.clip(np.round(iq), -32767, 32767).astype(np.int16), lim
+
+
+# ---- linear ("clever") blanker on (harness clever=1): init_blanker (buf.c:1786-2057) derives the pulse tables from a synthetic amplitude
+# calibration fft1_desired; the input carries band-limited pulses of exactly that response at fractional positions (fitted and
+# subtracted), close pairs (unresolved: flagged 65, left to the stupid blanker) and a few rectangular pulses of another shape
+CLEVER = {
+    "clever_n10_n12": dict(base="n10_n12", nblk=96, blockpower_block=0, clever_factor=12.0, edge=0.18, pulses=60, pulse_seed=5, amp=(2500.0, 22000.0),
+                           pairs=6, rects=4, pulse_period=0),
+    # narrower passband (longer pulse response, larger fit sizes), lower threshold, the stupid blanker off: only fitted pulses leave
+    "clever_n9_n11_only": dict(base="n9_n11_shift", nblk=96, clever_factor=8.0, edge=0.3, pulses=40, pulse_seed=6, amp=(1500.0, 9000.0),
+                               pairs=3, rects=0, pulse_period=0, stupid=0, sample_shift=0),
+}
+
+
+def clever_desired(n1, edge):
+    """amplitude calibration target: flat passband, raised-cosine skirts over `edge` of the band at either side (fft1 bin order)"""
+    N1 = 1 << n1
+    x = np.arange(N1) / N1
+    w = np.ones(N1)
+    e = x < edge
+    w[e] = 0.5 - 0.5 * np.cos(np.pi * x[e] / edge)
+    e = x > 1 - edge
+    w[e] = 0.5 - 0.5 * np.cos(np.pi * (1 - x[e]) / edge)
+    return w.astype(np.float32)
+
+
+def clever_case(name):
+    t = dict(CLEVER[name])
+    d = case_params(t.pop("base"))
+    cl = {k: t.pop(k) for k in ("clever_factor", "edge", "pulses", "pulse_seed", "amp", "pairs", "rects")}
+    d.update(t)
+    iq = make_input(d).astype(np.float64)
+    N1 = 1 << d["n1"]
+    des = clever_desired(d["n1"], cl["edge"])
+    n = iq.size // 2
+    rng = np.random.default_rng(cl["pulse_seed"])
+    H = 256                                           # half length of the synthesised response
+    k = np.fft.fftfreq(N1)                            # bin i of fft1 (DC at N1/2) is baseband frequency (i - N1/2)/N1
+    spec = np.fft.ifftshift(des.astype(np.float64))
+
+    def shaped(frac):                                 # response to a unit impulse at fractional delay frac, centred at index H
+        h = np.fft.ifft(spec * np.exp(-2j * np.pi * k * (frac + H)))
+        return h[:2 * H] / np.abs(np.fft.ifft(spec)[0])
+
+    z = np.zeros(n, complex)
+    pos = np.sort(rng.choice(np.arange(4 * N1, n - 4 * N1, 64), cl["pulses"], replace=False))
+    for j, s in enumerate(pos):
+        a = np.exp(rng.uniform(np.log(cl["amp"][0]), np.log(cl["amp"][1])))
+        z[s - H:s + H] += a * np.exp(1j * rng.uniform(0, 6.28)) * shaped(rng.uniform(-0.5, 0.5))
+        if j < cl["pairs"]:                           # an unresolved second pulse a few samples later
+            off = int(rng.integers(3, 9))
+            z[s - H + off:s + H + off] += 0.7 * a * np.exp(1j * rng.uniform(0, 6.28)) * shaped(rng.uniform(-0.5, 0.5))
+    for s in rng.choice(np.arange(4 * N1, n - 4 * N1), cl["rects"], replace=False):
+        z[s:s + 3] += cl["amp"][1] * np.exp(1j * rng.uniform(0, 6.28))
+    iq[0::2] += z.real
+    iq[1::2] += z.imag
+    return d, cl, np.clip(np.round(iq), -32767, 32767).astype(np.int16), make_liminfo(d), des
