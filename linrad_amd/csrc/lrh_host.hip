@@ -38,6 +38,7 @@ hipError_t launch_pol(const PolArgs &a, hipStream_t st);
 hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
+hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
@@ -129,6 +130,9 @@ struct lrh_ctx {
   float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
   float *d_ph = nullptr;              // phase tables [LRH_NSTAGE][2][max_fft2 batch][half]
   BlankState *d_bst = nullptr; float *d_partials = nullptr; float4 *d_bln_tiles = nullptr; int *d_bln_counts = nullptr;
+  // linear ("clever") blanker: tables of lrh_set_blanker_tables, per-sample flags and candidate bit words
+  bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
+  unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
@@ -326,7 +330,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -699,6 +703,43 @@ int lrh_get_liminfo(lrh_ctx *c, float *dst)
   return LRH_OK;
 }
 
+// ---- linear ("clever") blanker tables (include/linrad_hip.h; init_blanker's products, buf.c:1786-2057)
+int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  for (void **q_ : { (void **)&c->d_bt_refpulse, (void **)&c->d_bt_phasefunc, (void **)&c->d_bt_pulindex, (void **)&c->d_bln_flag, (void **)&c->d_bln_cand })
+    if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  c->clever_on = false;
+  if (!t) return LRH_OK;
+  if (c->cfg.blanker_channels == 2) return fail(c, LRH_EINVAL, "linear blanker: one RF channel only");
+  const int rs = t->refpul_size, pw = c->cfg.blanker_pulsewidth;
+  if (t->clever_bln_mode < 1 || t->clever_bln_mode > 2 || rs < 4 || rs > 256 || (rs & (rs - 1)) || t->largest_blnfit < 0 ||
+      t->largest_blnfit >= LRH_BLN_INFO_SIZE || !t->refpulse || !t->phasefunc || !t->pulindex || pw < 1 || 2 * pw >= rs)
+    return fail(c, LRH_EINVAL, "linear blanker: bad table sizes");
+  for (int i = 0; i <= t->largest_blnfit; i++)
+    if (t->bln[i].size < 4 || t->bln[i].size > rs || (t->bln[i].size & 1) || (i && t->bln[i].size <= t->bln[i - 1].size)) return fail(c, LRH_EINVAL, "linear blanker: bad bln[] sizes");
+  if (c->cfg.blnfit_range != t->bln[t->largest_blnfit].size / 2 + pw) return fail(c, LRH_EINVAL, "cfg.blnfit_range != bln[largest_blnfit].size/2 + blanker_pulsewidth (buf.c:2057)");
+  for (int i = 0; i < LRH_MAX_REFPULSES; i++) if (t->pulindex[i] < 0 || t->pulindex[i] >= LRH_MAX_REFPULSES) return fail(c, LRH_EINVAL, "linear blanker: pulindex out of range");
+  if (c->cfg.timf2pow_size < 1024) return fail(c, LRH_EINVAL, "linear blanker: timf2pow_size < 1024");
+  const size_t nr = (size_t)2 * LRH_MAX_REFPULSES * rs;
+  int rc = LRH_OK;
+  if ((rc = dev_alloc(c, &c->d_bt_refpulse, nr)) || (rc = dev_alloc(c, &c->d_bt_phasefunc, (size_t)2 * rs)) || (rc = dev_alloc(c, &c->d_bt_pulindex, LRH_MAX_REFPULSES)) ||
+      (rc = dev_alloc(c, &c->d_bln_flag, (size_t)c->cfg.timf2pow_size)) || (rc = dev_alloc(c, &c->d_bln_cand, (size_t)c->cfg.timf2pow_size / 64))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_bt_refpulse, t->refpulse, 4 * nr, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_bt_phasefunc, t->phasefunc, 8 * (size_t)rs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_bln_flag, 0, c->cfg.timf2pow_size, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_bln_cand, 0, c->cfg.timf2pow_size / 8, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, clever_limit), &t->clever_bln_limit, sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bt = *t; c->bt.refpulse = nullptr; c->bt.phasefunc = nullptr; c->bt.pulindex = nullptr;
+  c->clever_on = true;
+  return LRH_OK;
+}
+
 // ---- spur subtraction (include/linrad_hip.h): configuration and the control plane's hand-over
 int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
 {
@@ -1058,9 +1099,26 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
   a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials; a.tiles = c->d_bln_tiles; a.counts = c->d_bln_counts;
   p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
+  if (c->clever_on) {
+    // the pulse search runs first (blank1.c:765-1003) and decides where the next call resumes: one int comes back, the call waits for it
+    if (c->rec) return fail(c, LRH_ESTATE, "linear blanker inside the deferred schedule");
+    if (a.total > c->cfg.timf2pow_size - 256) return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring");
+    CleverArgs ca; memset(&ca, 0, sizeof ca);
+    ca.pwr = c->d_pwr; ca.timf2w = c->d_timf2w; ca.flag = c->d_bln_flag; ca.cand = c->d_bln_cand; ca.mask = mask;
+    ca.pbeg = pbeg; ca.total = a.total; ca.R = c->cfg.blnfit_range; ca.pwid = c->cfg.blanker_pulsewidth; ca.rs = c->bt.refpul_size;
+    ca.largest = c->bt.largest_blnfit; ca.amp_factor = c->bt.liminfo_amplitude_factor;
+    ca.refpulse = c->d_bt_refpulse; ca.phasefunc = c->d_bt_phasefunc; ca.pulindex = c->d_bt_pulindex; ca.st = c->d_bst;
+    for (int i = 0; i < LRH_BLN_INFO_SIZE; i++) { ca.bln_size[i] = c->bt.bln[i].size; ca.bln_rest[i] = c->bt.bln[i].rest; ca.bln_avgmax[i] = c->bt.bln[i].avgmax; }
+    int out[3];
+    { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
+    HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
+    HIPCHK(c, hipStreamSynchronize(c->cur));
+    p->timf2p_fit = (out[0] - 16 + mask) & (mask & ~3);                  // blank1.c:1458-1461
+    a.post_stats = 1; a.fitted = out[1]; a.rejected = out[2]; a.clever_mode = c->bt.clever_bln_mode; a.clever_factor = c->bt.clever_bln_factor;
+  }
   const int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
   p->timf2_blanker_points += m;
-  a.m = m; a.nstat = a.total / 4; a.blanker_points = p->timf2_blanker_points;
+  a.m = m; a.nstat = (c->clever_on ? ((p->timf2p_fit - pbeg) & mask) : a.total) / 4; a.blanker_points = p->timf2_blanker_points;
   a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < LRH_BLN_PARTIALS ? a.nstat / 4096 : LRH_BLN_PARTIALS);
   a.interval = c->cfg.blanker_info_update_interval; a.avgnum = c->cfg.timf2_noise_floor_avgnum; a.factor = c->cfg.stupid_bln_factor;
   a.lowlevel_fraction = p->fft1_lowlevel_fraction;
@@ -1153,6 +1211,8 @@ int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
   st->timf2_despiked_pwrinc[0] = bs.despiked_pwrinc[0]; st->timf2_despiked_pwrinc[1] = bs.despiked_pwrinc[1];
   st->stupid_blanker_rate = bs.stupid_rate; st->timf2_cleared_points = bs.cleared_acc;
   st->last_call_cleared = bs.last_cleared; st->slow_path_calls = bs.slow_calls;
+  st->clever_bln_limit = bs.clever_limit; st->clever_blanker_rate = bs.clever_rate; st->timf2_fitted_pulses = bs.fitted_acc;
+  st->last_call_fitted = bs.last_fitted; st->last_call_rejected = bs.last_rejected;
   return LRH_OK;
 }
 
@@ -1673,7 +1733,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // fewest stream operations and wins there (Msamples/s serial / lagged, fft1_size 16384: 82 / 80 at 1 block per round,
   // 2170 / 1990 at 32, 9420 / 9100 at 256); the two-stream schedules pay off from ~3 M samples per round (15200 / 17000 at 512).
   const bool small_rounds = !c->pipeline_forced && (long)batch * c->M1 < (3L << 20);
-  const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && (!c->prof || c->prof_keep_schedule);
+  const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && (!c->prof || c->prof_keep_schedule) &&
+                     !c->clever_on;                // the linear blanker reads its resume point back: serial schedule
   // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
   const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); } } fuse_guard{c};

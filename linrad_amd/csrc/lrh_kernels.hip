@@ -16,6 +16,7 @@
 #include "lrh_kernels.hip.h"
 
 namespace lrh {
+constexpr int LRH_MAX_REFPULSES_K = 256;            // MAX_REFPULSES, blnkdef.h:6
 
 // =====================================================================================================
 // fft1
@@ -944,7 +945,8 @@ __global__ void k_blank_update(BlankArgs a)
   s->call_cleared = 0;
   s->last_cleared = cleared;
   s->cleared_acc += cleared;
-  int k = a.m - cleared; if (k < a.m / 25) k = a.m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
+  s->last_fitted = a.fitted; s->last_rejected = a.rejected; s->fitted_acc += a.fitted;
+  int k = a.m - cleared - a.fitted; if (k < a.m / 25) k = a.m / 25; k = (k + 2) / 4; if (k < 1) k = 1;
   t1 = (float)tot;
   t1 /= k; if (t1 < 10) t1 = 10;
   if (a.phase == 1) { a.xstat[0] = a.xstat[1] = 0.f; a.xstat[a.own_slot & 1] = t1; return; }   // the partner's half comes by exchange
@@ -953,6 +955,9 @@ __global__ void k_blank_update(BlankArgs a)
   if (!a.do_update) return;
   s->despiked_pwr[0] = s->despiked_pwrinc[0] / (a.interval * a.lowlevel_fraction);
   s->despiked_pwr[1] = s->despiked_pwrinc[1] / (a.interval * a.lowlevel_fraction);
+  float crate = (float)(100. * (double)(float)s->fitted_acc / (double)a.blanker_points);
+  if (crate > 99) crate = 99;
+  s->clever_rate = crate;
   float rate = (float)(100. * (double)(float)s->cleared_acc / (double)a.blanker_points);
   if (rate > 99) rate = 99;
   s->stupid_rate = rate;
@@ -969,8 +974,9 @@ __global__ void k_blank_update(BlankArgs a)
     s->limit = (unsigned int)((float)nf * a.factor);
   }
   s->noise_floor = nf;
+  if (a.clever_mode == 1) s->clever_limit = (unsigned int)((float)nf * a.clever_factor);      // blank1.c:1587-1590
   s->despiked_pwrinc[0] = 1; s->despiked_pwrinc[1] = 1;
-  s->cleared_acc = 0;
+  s->cleared_acc = 0; s->fitted_acc = 0;
 }
 
 // =====================================================================================================
@@ -1770,6 +1776,230 @@ hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask
   if (count > 0) hipLaunchKernelGGL(k_span_copy, dim3((count + 255) / 256), dim3(256), 0, st, x, ring, pbeg, count, mask, to_ring);
   return hipGetLastError();
 }
+// =====================================================================================================
+// linear ("clever") blanker: first_noise_blanker's pulse search / fit / subtract (blank1.c:765-1003)
+// =====================================================================================================
+// The reference walks the span once, sample by sample, and every pulse it handles changes the data the walk continues on
+// (subtracted samples, flags), so the ORDER of the events is part of the result.  What is parallel: finding the next sample
+// above the limit (bit words, 4096 samples per step), loading the neighbourhood of a pulse, the per-sample arithmetic of the
+// fit.  One wave runs the reference's control flow with all lanes in step (every branch below is wave-uniform), a pulse's
+// neighbourhood (+-128 samples: refpul_size <= 256) sits in LDS, sums run in the reference's order, and contraction to fma is
+// off so that the threshold decisions see the reference's roundings.
+// k_clever_prep: candidate bits (power above the limit) and the flag clear over exactly the span (blank1.c:768-774).
+__global__ __launch_bounds__(256) void k_clever_prep(CleverArgs a)
+{
+  const int lane = threadIdx.x & 63, wmask = ((a.mask + 1) >> 6) - 1;
+  const int first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
+  const float nfl = (float)a.st->clever_limit;
+  for (int w = (blockIdx.x * 256 + threadIdx.x) >> 6; w < nwords; w += gridDim.x * 4) {
+    const int pos = (((first_word + w) << 6) + lane) & a.mask;
+    const bool in = ((pos - a.pbeg) & a.mask) <= a.total;
+    const bool hot = in && a.pwr[pos] > nfl;
+    if (in) a.flag[pos] = 0;
+    const unsigned long long b = __ballot(hot);
+    if (lane == 0) a.cand[(first_word + w) & wmask] = b;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_clever(CleverArgs a)
+{
+#pragma clang fp contract(off)
+  constexpr int W = 128;                                  // half width of the pulse neighbourhood held in LDS
+  __shared__ float s_pw[2 * W + 8], s_old[2 * W + 8], s_spw[256], s_in[2 * 2 * W + 8], s_avg[8];
+  __shared__ float2 s_tf[2 * W + 8];
+  __shared__ unsigned char s_fl[2 * W + 8], s_sfl[256];
+  const int lane = threadIdx.x, mask = a.mask, total = a.total, R = a.R, pwid = a.pwid, rs = a.rs;
+  const int wmask = ((mask + 1) >> 6) - 1, first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + total + 64) >> 6;
+  BlankState *s = a.st;
+  const float nfl = (float)s->clever_limit;
+  const float sizlim = (float)(0.1 * (double)s->noise_floor);
+  if (lane < 8) s_avg[lane] = 0.f;
+  // offsets o count from pbeg (o = total is blnk_pend); they may go below 0 / above total where the reference's pointers do
+  auto POS = [&](int o) { return (a.pbeg + o) & mask; };
+  auto next_candidate = [&](int o_start) -> int {         // blank1.c:781-794: first sample >= o_start above the limit and not flagged
+    if (o_start >= total) return total;
+    const int pos0 = POS(o_start);
+    int w = pos0 >> 6;
+    bool first = true;
+    for (;;) {
+      const int rel = (w + lane - first_word) & wmask;
+      unsigned long long v = rel < nwords ? a.cand[(w + lane) & wmask] : 0ull;
+      if (first && lane == 0) v &= ~0ull << (pos0 & 63);
+      first = false;
+      const unsigned long long any = __ballot(v != 0ull);
+      if (any) {
+        const int L = __ffsll((long long)any) - 1;
+        const unsigned int lo = __shfl((unsigned int)v, L), hi = __shfl((unsigned int)(v >> 32), L);
+        const unsigned long long vv = ((unsigned long long)hi << 32) | lo;
+        const int pos = (((w + L) & wmask) << 6) + (__ffsll((long long)vv) - 1);
+        const int o = (pos - a.pbeg) & mask;
+        return o < total ? o : total;
+      }
+      w += 64;
+      if (((w - first_word) & wmask) >= nwords || ((w - first_word) & wmask) < 64) return total;
+    }
+  };
+  auto stage_search = [&](int base) {
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) { const int pos = POS(base + i); s_spw[i] = a.pwr[pos]; s_sfl[i] = a.flag[pos]; }
+    __syncthreads();
+  };
+  int pf = 0, fitted = 0, rejected = 0;
+  for (;;) {
+    __threadfence();                                      // the candidate words / rings as the previous pulse left them
+    pf = next_candidate(pf);
+    if (pf >= total) { pf = total; break; }
+    // ---- the maximum that stays the maximum for blnfit_range samples (blank1.c:795-824)
+    int o = pf - 1, p_max = pf, m = R, base = pf;
+    float powermax = 10.f;
+    stage_search(base);
+    while (o != total && m > 0) {
+      o++;
+      if (o - base >= 256) { base = o; stage_search(base); }
+      const float v = s_spw[o - base];
+      if (v > powermax && s_sfl[o - base] < 64) { powermax = v; p_max = o; m = R; }
+      m--;
+    }
+    if (m > 0) break;                                     // too close to the end of the span: next call
+    bool no_pulse = false;
+    if (a.flag[POS(p_max - 1)] >= 64) { pf = p_max; no_pulse = true; }
+    else {
+      if (p_max + 1 == total) break;
+      if (a.flag[POS(p_max + 1)] >= 64) no_pulse = true;
+    }
+    if (no_pulse) {                                       // blank1.c:833-856: next to a region already handled: walk on while the power does not rise
+      while (pf != total) {
+        const float v = a.pwr[POS(pf)];
+        if (!(v <= powermax || a.flag[POS(pf)] > 64)) break;
+        powermax = v; pf++;
+      }
+      if (pf == total) break;
+      continue;
+    }
+    // ---- neighbourhood of the pulse into LDS
+    __syncthreads();
+    for (int i = lane; i <= 2 * W; i += 64) { const int pos = POS(p_max - W + i); s_pw[i] = a.pwr[pos]; s_tf[i] = a.timf2w[pos]; s_fl[i] = a.flag[pos]; }
+    __syncthreads();
+    // ---- unresolved multiple pulses? mean power of the shells between successive fit sizes (blank1.c:909-951)
+    int bln_no = 0, ia = W + 1, ib = W - 1, k = 2;
+    for (;;) {
+      powermax = s_pw[W];
+      float t1 = powermax * a.bln_rest[bln_no];
+      if (t1 < sizlim) break;
+      t1 = 0.f;
+      while (k < a.bln_size[bln_no]) { t1 += s_pw[ia] + s_pw[ib]; ia++; ib--; k += 2; }
+      s_avg[bln_no] = t1 / powermax;
+      bln_no++;
+      if (bln_no > a.largest) break;
+    }
+    bln_no--;
+    __syncthreads();
+    while (bln_no >= 0 && s_avg[bln_no] > a.bln_avgmax[bln_no]) bln_no--;
+    // ---- subtract_onechan_pulse (blank1.c:36-232)
+    float rv = -1.f;
+    if (bln_no >= 0) {
+      const int sub = a.bln_size[bln_no];
+      for (int i = lane; i <= 2 * pwid; i += 64) {
+        const float2 t = s_tf[W - pwid + i];
+        const int kk = rs - 2 * pwid + 2 * i;
+        const float t3 = a.phasefunc[kk], t4 = a.phasefunc[kk + 1];
+        s_in[2 * i] = t.x * t3 + t.y * t4; s_in[2 * i + 1] = t.y * t3 - t.x * t4;
+      }
+      __syncthreads();
+      const int imax = pwid;
+      float c1 = 0.f, c2 = 0.f;
+      for (int i = imax - 1; i <= imax + 1; i++) { const float t1 = s_in[2 * i], t2 = s_in[2 * i + 1], t3 = sqrtf(t1 * t1 + t2 * t2); c1 += t3 * t1; c2 += t3 * t2; }
+      float t1 = c1 * c1 + c2 * c2;
+      bool go = !(t1 < 32.f);
+      float t3 = 0.f, t4 = 0.f;
+      if (go) {
+        t1 = sqrtf(t1); c1 /= t1; c2 /= t1;
+        __syncthreads();
+        for (int i = lane; i <= 2 * pwid; i += 64) {
+          const float x = s_in[2 * i], y = s_in[2 * i + 1];
+          s_in[2 * i] = c1 * x + c2 * y; s_in[2 * i + 1] = c1 * y - c2 * x;
+        }
+        __syncthreads();
+        for (int i = 0; i <= 2 * pwid; i++) { t3 += s_in[2 * i] * s_in[2 * i]; t4 += s_in[2 * i + 1] * s_in[2 * i + 1]; }
+        if ((double)t4 > 0.25 * (double)t3) go = false;   // too much power off the pulse's phase
+      }
+      if (go) {
+        t4 = s_in[2 * imax - 2] - s_in[2 * imax + 2];
+        t3 = 2 * (s_in[2 * imax - 2] + s_in[2 * imax + 2] - 2 * s_in[2 * imax]);
+        if (t3 == 0.f) { go = false; rv = -2.f; }
+      }
+      if (go) {
+        t4 /= t3;                                         // peak position within the sample by a parabola, then the reference pulse for it
+        if (t4 < 0) t4 = (float)(-sqrt(0.5) * sqrt((double)-t4)); else t4 = (float)(sqrt(0.5) * sqrt((double)t4));
+        int j = (int)(LRH_MAX_REFPULSES_K * ((double)t4 + 0.5) + 0.5);
+        if (j < 0) j = 0;
+        if (j >= LRH_MAX_REFPULSES_K) j = LRH_MAX_REFPULSES_K - 1;
+        const int mrp = 2 * a.pulindex[j] * rs;
+        c1 *= s_in[2 * imax] * a.amp_factor; c2 *= s_in[2 * imax] * a.amp_factor;
+        __syncthreads();
+        for (int jj = lane; jj <= sub; jj += 64) {
+          const int q = W - sub / 2 + jj, kk = rs - sub + 2 * jj;
+          const float r1 = a.refpulse[mrp + kk], r2 = a.refpulse[mrp + kk + 1];
+          const float2 x = s_tf[q];
+          const float re = x.x - c1 * r1 + c2 * r2, im = x.y - c1 * r2 - c2 * r1;
+          s_tf[q] = make_float2(re, im); s_old[q] = s_pw[q]; s_pw[q] = re * re + im * im;
+        }
+        __syncthreads();
+        t3 = 0.f; t4 = 0.f;
+        for (int q = W - sub / 2; q <= W + sub / 2; q++) { t3 += s_old[q]; t4 += s_pw[q]; }
+        rv = t4 / t3;
+        if (rv > 0.5f) {                                  // the fit removed too little: put the samples back (with the reference's signs, see the oracle)
+          __syncthreads();
+          for (int jj = lane; jj <= sub; jj += 64) {
+            const int q = W - sub / 2 + jj, kk = rs - sub + 2 * jj;
+            const float r1 = a.refpulse[mrp + kk], r2 = a.refpulse[mrp + kk + 1];
+            const float2 x = s_tf[q];
+            const float re = x.x + c1 * r1 + c2 * r2, im = x.y + c1 * r2 - c2 * r1;
+            s_tf[q] = make_float2(re, im); s_pw[q] = re * re + im * im;
+          }
+          rv = -5.f;
+        }
+        __syncthreads();
+        for (int jj = lane; jj <= sub; jj += 64) { const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj); a.timf2w[pos] = s_tf[q]; a.pwr[pos] = s_pw[q]; }
+      }
+    }
+    const unsigned char value = rv < 0.f ? 65 : 66;
+    if (rv < 0.f) rejected++; else fitted++;
+    // ---- set_flag (blank1.c:615-682): +-pulsewidth, then outwards for as long as the power keeps falling
+    __syncthreads();
+    auto PW = [&](int oo) -> float { const int d = oo - p_max; return (d >= -W && d <= W) ? s_pw[d + W] : a.pwr[POS(oo)]; };
+    auto SETF = [&](int oo) {
+      const int d = oo - p_max, pos = POS(oo);
+      if (d >= -W && d <= W) s_fl[d + W] = value;
+      if (lane == 0) { a.flag[pos] = value; if (oo >= 0 && oo <= total) atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63))); }
+    };
+    SETF(p_max);
+    int pa = p_max, pb = p_max;
+    for (int i = 0; i < pwid; i++) { pb--; pa++; SETF(pa); SETF(pb); }
+    int p0 = pb; pb--;
+    if (!(pb < 1)) while (PW(pb) < PW(p0) && pb != 0) { SETF(pb); p0 = pb; pb--; }
+    p0 = pa; pa++;
+    if (!(pa >= total)) while (PW(pa) < PW(p0) && pa != total) { p0 = pa; SETF(pa); pa++; }
+    __syncthreads();
+    // ---- candidate bits of the samples the subtraction rewrote
+    for (int i = lane; i <= 2 * W; i += 64) {
+      const int oo = p_max - W + i, pos = POS(oo);
+      if (oo < 0 || oo > total) continue;
+      if (s_pw[i] > nfl && s_fl[i] <= 64) atomicOr(&a.cand[pos >> 6], 1ull << (pos & 63));
+      else atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63)));
+    }
+  }
+  if (lane == 0) { s->clever_out[0] = POS(pf); s->clever_out[1] = fitted; s->clever_out[2] = rejected; }
+}
+
+hipError_t launch_clever(const CleverArgs &a, hipStream_t st)
+{
+  const int nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
+  hipLaunchKernelGGL(k_clever_prep, dim3((nwords + 3) / 4 < 1024 ? (nwords + 3) / 4 : 1024), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 {
   BlankArgs a = a0;
@@ -1791,7 +2021,7 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
       hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);   // k_blank_update takes the flag down
     }
     hipLaunchKernelGGL(k_blank_apply, dim3(a.nremoved), dim3(256), 0, st, a, first_pos >> 5, nwords, ring_words - 1);
-    if (a.own) {                                         // per-channel statistic from the own ring after clearing
+    if (a.own || a.post_stats) {                          // per-channel statistic from the own ring after clearing / statistic span shorter than the scan
       a.nremoved = 0;
       a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < ntiles ? a.nstat / 4096 : ntiles);
       hipLaunchKernelGGL(k_blank_stats, dim3(a.npartials), dim3(256), 0, st, a);

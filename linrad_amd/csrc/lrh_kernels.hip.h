@@ -71,6 +71,9 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   float stupid_rate; int cleared_acc; int last_cleared; int slow_calls;
   int call_cleared;          // scratch: cleared_points of the running call (atomic)
   int need_slow;             // scratch: a lane found no clean restart point
+  // linear ("clever") blanker
+  unsigned int clever_limit; float clever_rate; int fitted_acc; int last_fitted; int last_rejected;
+  int clever_out[3];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected
 };
 struct BlankArgs {
   float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
@@ -91,7 +94,22 @@ struct BlankArgs {
   // phase 2 resumes with both channels' values (phase 0: single channel, everything in one go)
   int chans; float *own; float *xstat; int own_slot; int phase;
   float4 *tiles;            // per-tile run summaries of the long-run replay (k_blank_runs_pre / k_blank_runs)
+  // linear blanker ran before this call's stupid pass: the every-4th-sample statistic ends at timf2p_fit (blank1.c:1458-1461),
+  // short of the scanned span, so it is summed after the clearing (post_stats); fitted / rejected pulses for the bookkeeping
+  int post_stats; int fitted, rejected; int clever_mode; float clever_factor;
 };
+
+// ---- linear ("clever") blanker: pulse search / fit / subtract of blank1.c:765-1003 ----
+struct CleverArgs {
+  float *pwr; float2 *timf2w; unsigned char *flag; unsigned long long *cand; int mask;    // mask: timf2pow_mask
+  int pbeg, total;          // span: ring positions pbeg .. pbeg+total (= blnk_pend)
+  int R, pwid, rs, largest; // blnfit_range, blanker_pulsewidth, refpul_size, largest_blnfit
+  float amp_factor;         // liminfo_amplitude_factor
+  const float *refpulse, *phasefunc; const int *pulindex;
+  int bln_size[7]; float bln_rest[7], bln_avgmax[7];
+  BlankState *st;
+};
+hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 
 // ---- fft2 ----
 struct Fft2Args {
