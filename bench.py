@@ -400,7 +400,9 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 if st["alg_GBps"] > HBM_PEAK_GBS:
                     st["note"] = ("algorithmic bytes (SURVEY 8d: every stage one full pass) exceed what this kernel moves: the overlapped half "
                                   "of each transform stays in registers and the per-transform power ring is never written")
-        dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: stages[k]["ms_total"])
+        # dominant kernel: largest stand-alone time per round.  The in-schedule durations of the side-stream stages (blanker, sums)
+        # are stretched by the kernels they overlap with (a scan of 53 us takes 300-500 us beside k_timf2) and say nothing about them
+        dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: (alone.get(k) or 0.0) * stages[k]["launches"])
         per_sample = ALG_BYTES[dom] + (ALG_BYTES["sumsq"] if (dom == "timf2" and fused_sums) else 0.0)
         launches_per_round = stages[dom]["launches"] / (nprof * args.rounds)
         alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_round

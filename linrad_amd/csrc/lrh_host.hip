@@ -39,6 +39,8 @@ hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
+hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
@@ -119,6 +121,9 @@ struct lrh_ctx {
   float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
   std::vector<float> h_mixwin, h_sin2win, h_cos2win;
   float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
+  // fft1_size 32768: four-step fft1 / timf2 (tables of size 256 / 128; scratch per fft1_b handle and for timf2, grown on demand)
+  float2 *d_tw1a = nullptr, *d_tw1b = nullptr, *d_fft1_scratch[8] = {}, *d_timf2_scratch = nullptr; size_t fft1_scratch_cap[8] = {}, timf2_scratch_cap = 0;
+  bool fft1_big = false;
   unsigned int *d_pack_cur = nullptr, *d_pack_prev = nullptr;
   int *d_wf_itab = nullptr;
   // device rings
@@ -330,7 +335,8 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_blockpower,
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
@@ -362,7 +368,10 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
   if (cfg->timf1_real_input && (cfg->timf1_frame_channels > 2 || cfg->sample_shift != 0)) return LRH_EINVAL;   // fft1_reherm_dit_one / _two: one or two real channels per frame
   if (cfg->timf1_frame_channels > 1 && (!ispow2(cfg->timf1_frame_channels) || cfg->timf1_channel_index < 0 || cfg->timf1_channel_index >= cfg->timf1_frame_channels)) return LRH_EINVAL;
-  if (cfg->fft1_n < 6 || cfg->fft1_n > 14 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384: four-step
+  if (cfg->fft1_n < 6 || cfg->fft1_n > 15 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384, fft1 = 32768: four-step
+  // fft1_size 32768 (buf.c:335): I/Q samples (int16 / int32) through a sin^2 window, the second fft's configuration; the variants
+  // that only exist as single-workgroup kernels (real input, I/Q skew, other windows) are refused
+  if (cfg->fft1_n == 15 && (cfg->timf1_real_input || cfg->sample_shift || cfg->fft1_sinpow != 2)) return LRH_EINVAL;
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
       !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || (cfg->timf2_blockpower_block > 0 && !ispow2(cfg->timf2_blockpower_size)) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
   lrh_ctx *c = new lrh_ctx();
@@ -498,6 +507,13 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_tw2a, tw2a.size())); A(dev_alloc(c, &c->d_tw2b, tw2b.size()));
     A(dev_alloc(c, &c->d_fft2_scratch, (size_t)cfg->max_fft2n * N2, false));
   }
+  std::vector<float2> tw1a, tw1b;
+  c->fft1_big = cfg->fft1_n == 15;
+  if (c->fft1_big) {
+    make_twiddles(256, tw1a); make_twiddles(128, tw1b);
+    A(dev_alloc(c, &c->d_tw1a, tw1a.size())); A(dev_alloc(c, &c->d_tw1b, tw1b.size()));
+    c->fuse_sumsq = false;                       // fft1_c's sums stay a separate pass (k_sumsq)
+  }
   A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1));
   A(dev_alloc(c, &c->d_liminfo, N1)); A(dev_alloc(c, &c->d_old_liminfo, N1)); A(dev_alloc(c, &c->d_sel_tmp, N1)); A(dev_alloc(c, &c->d_sel_wait, N1)); A(dev_alloc(c, &c->d_sel_st, 1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
   // ---- rings
@@ -547,6 +563,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
     if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
+    if (c->fft1_big) { A(upload(c, c->d_tw1a, tw1a.data(), tw1a.size())); A(upload(c, c->d_tw1b, tw1b.data(), tw1b.size())); }
     if (c->N3) {
       std::vector<float> ones(c->N3, 1.0f);
       A(upload(c, c->d_window3, win3.data(), c->N3)); A(upload(c, c->d_bgfilt, ones.data(), c->N3));
@@ -623,9 +640,11 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   if (!c || !liminfo) return LRH_EINVAL;
   // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
   const int R0 = c->cfg.fft1_n >= 10 ? 16 : 4;        // first-pass radix of the N1 transform (lrh_fft.hip.h)
-  const int nb = c->N1 / R0;
+  const int nb = c->fft1_big ? 0 : c->N1 / R0;
   std::vector<unsigned int> pack(c->N1, 0u);
   int low = 0;
+  if (c->fft1_big)                                     // four-step timf2: dense bits, bit (k & 31) of word k >> 5
+    for (int k = 0; k < c->N1; k++) if (liminfo[k] == 0) pack[k >> 5] |= 1u << (k & 31);
   for (int i = 0; i < nb; i++) {
     unsigned int m = 0;
     for (int s = 0; s < R0; s++) if (liminfo[i + s * nb] == 0) m |= 1u << s;
@@ -673,7 +692,7 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
   a.slowsum = c->d_slowsum; a.yfac = c->d_yfac; a.liminfo = c->d_liminfo; a.old_liminfo = c->d_old_liminfo; a.tmp = c->d_sel_tmp;
   a.wait = c->d_sel_wait; a.pack = c->d_pack_cur; a.st = c->d_sel_st;
-  a.n = c->N1; a.n2 = c->N2; a.avg1 = c->cfg.fft_avg1num; a.r0 = c->cfg.fft1_n >= 10 ? 16 : 4;
+  a.n = c->N1; a.n2 = c->N2; a.avg1 = c->cfg.fft_avg1num; a.r0 = c->fft1_big ? 0 : (c->cfg.fft1_n >= 10 ? 16 : 4);
   a.maxlevel = q->sellim_maxlevel; a.spek_avgnum = q->spek_avgnum; a.blocktime = q->fft1_blocktime; a.ston = q->blanker_ston_fft1;
   a.par2 = q->sellim_par2; a.par3 = q->sellim_par3; a.par4 = q->sellim_par4; a.par5 = q->sellim_par5; a.par6 = q->sellim_par6;
   a.par7 = q->sellim_par7; a.par8 = q->sellim_par8; a.group_points = q->liminfo_group_points;
@@ -939,6 +958,18 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     a.stamps = c->d_stamps;
   }
   ProfScope ps(c, "fft1");
+  if (c->fft1_big) {
+    const size_t need = (size_t)batch * c->N1;
+    if (c->fft1_scratch_cap[handle] < need) {
+      HIPCHK(c, hipStreamSynchronize(c->cur));
+      if (c->d_fft1_scratch[handle]) hipFree(c->d_fft1_scratch[handle]);
+      c->d_fft1_scratch[handle] = nullptr; c->fft1_scratch_cap[handle] = 0;
+      const int rc_ = dev_alloc(c, &c->d_fft1_scratch[handle], need, false); if (rc_) return rc_;
+      c->fft1_scratch_cap[handle] = need;
+    }
+    Fft1BigArgs g; g.f = a; g.tw_a = c->d_tw1a; g.tw_b = c->d_tw1b; g.tw_big = c->d_tw1; g.scratch = c->d_fft1_scratch[handle];
+    HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->cur));
+  } else
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
   if (c->dbg_stamp) {
     unsigned long long h[2 * LRH_STAMPS_PER_WG];
@@ -1040,10 +1071,25 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
   a.xcd = (c->xcd_mask >> 1) & 1;
+  auto plain_timf2 = [&]() -> int {
+    ProfScope ps(c, "timf2");
+    if (!c->fft1_big) { HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); return LRH_OK; }
+    const size_t need = (size_t)batch * 2 * c->N1;
+    if (c->timf2_scratch_cap < need) {
+      HIPCHK(c, hipStreamSynchronize(c->cur));
+      if (c->d_timf2_scratch) hipFree(c->d_timf2_scratch);
+      c->d_timf2_scratch = nullptr; c->timf2_scratch_cap = 0;
+      const int rc_ = dev_alloc(c, &c->d_timf2_scratch, need, false); if (rc_) return rc_;
+      c->timf2_scratch_cap = need;
+    }
+    Timf2BigArgs g; g.t = a; g.tw_a = c->d_tw1a; g.tw_b = c->d_tw1b; g.tw_big = c->d_tw1; g.scratch = c->d_timf2_scratch;
+    HIPCHK(c, launch_timf2_big(c->cfg.fft1_n, g, batch, c->cur));
+    return LRH_OK;
+  };
   if (c->ss_have) {
     const SumsqArgs &sa = c->ss_args;
     c->ss_have = false;
-    if (a.mode == 1 && c->d_ss_part && sa.batch == batch && sa.first_nb == a.first_nb) {
+    if (!c->fft1_big && a.mode == 1 && c->d_ss_part && sa.batch == batch && sa.first_nb == a.first_nb) {
       // the scratch of split groups alternates between two halves: in the two-stream schedules the join of this launch runs
       // on the side stream and may still be reading when the next launch starts writing
       float *const part = c->d_ss_part + (size_t)c->ss_flip * c->ss_part_stride; c->ss_flip ^= 1;
@@ -1053,9 +1099,9 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
         ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, part, run, c->cur)); return LRH_OK; });
     } else {                                             // pointers out of step: separate pass after all
       { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
-      { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
+      { const int rc_ = plain_timf2(); if (rc_) return rc_; }
     }
-  } else { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); }
+  } else { const int rc_ = plain_timf2(); if (rc_) return rc_; }
   // from now on the previous transform was routed with the current table
   if (c->pack_prev_stale) {
     HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->cur));

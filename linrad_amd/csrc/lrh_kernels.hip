@@ -1690,6 +1690,177 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
   else
     hipLaunchKernelGGL((k_fft2_rows<LA, LB, false>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }
+// ---- fft1 / timf2 for fft1_size 32768: four-step through an HBM scratch (same tiling as k_fft2_cols / k_fft2_rows) -------------
+// fft1: x[n] = (I w, -Q w)[n], n = NB n1 + n2; X[k1 + NA k2] = sum_n2 [ w_N^(n2 k1) sum_n1 x[NB n1 + n2] w_NA^(n1 k1) ] w_NB^(n2 k2), e^{+j}.
+template <int LA, int LB, bool DW>
+__global__ __launch_bounds__(1024, 4) void k_fft1_cols(Fft1BigArgs g)
+{
+  using Raw = typename std::conditional<DW, int2, short2>::type;
+  const Fft1Args &a = g.f;
+  constexpr int P = sub_ppt(LA);
+  using Plan = FftPlan<LA, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int n2 = blockIdx.x * LRH_TILE + c, b = blockIdx.y;
+  const int p0 = a.p0_first + b * a.step;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int i = NB * ((l + m * T) + s * (NA / R0)) + n2;
+      const Raw v = ((const Raw *)a.timf1)[((p0 + i) * a.chan_count + a.chan_index) & a.ring_mask];
+      const float w = a.window[i];
+      x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));      // Q negated before the e^{+j} transform (fft1.c:432-447)
+    }
+  float2 *col = lds + c * CS;
+  BlockFft<LA, P, +1>::run(x, col, g.tw_a, l);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k1 = (l + m * T) + q * (NA / RL);
+      const float2 w = g.tw_big[(n2 * k1) & (NA * NB - 1)];
+      col[k1] = cmul(x[m * RL + q], make_float2(w.x, -w.y));
+    }
+  __syncthreads();
+  float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
+  for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
+    const int cc = e / NA, k1 = e - cc * NA;
+    sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+  }
+}
+template <int LA, int LB>
+__global__ __launch_bounds__(1024) void k_fft1_rows(Fft1BigArgs g)
+{
+  const Fft1Args &a = g.f;
+  constexpr int P = sub_ppt(LB);
+  using Plan = FftPlan<LB, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, N = NA * NB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int k1 = blockIdx.x * LRH_TILE + c, b = blockIdx.y;
+  const float2 *sc = g.scratch + (size_t)b * NA * NB;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) x[m * R0 + s] = sc[(size_t)((l + m * T) + s * (NB / R0)) * NA + k1];
+  BlockFft<LB, P, +1>::run(x, lds + c * CS, g.tw_b, l);
+  float2 *out = a.out + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int k = k1 + NA * ((l + m * T) + q * (NB / RL));
+      int kk = (k + N / 2) & (N - 1);                     // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
+      float2 v = x[m * RL + q];
+      if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
+      out[kk] = cmul(v, a.filtercorr[kk]);
+    }
+}
+// timf2, sin^2 overlap (see k_timf2): out_t[n] = ampfac * DFT_{e^-j}( S_t + (-1)^k S_{t-1} )[n], n < N/2, per stream.
+// k = NB i1 + i2 in, n = o1 + NA o2 out; blockIdx.z = stream (0 weak, 1 strong); routing bits dense, one per bin.
+template <int LA, int LB>
+__global__ __launch_bounds__(1024, 4) void k_timf2_cols(Timf2BigArgs g)
+{
+  const Timf2Args &a = g.t;
+  constexpr int P = sub_ppt(LA);
+  using Plan = FftPlan<LA, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, N = NA * NB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int i2 = blockIdx.x * LRH_TILE + c, b = blockIdx.y, st = blockIdx.z;
+  const float2 *cur = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+  const float2 *prv = a.spec + (size_t)((a.first_nb + b - 1) & a.nb_mask) * N;
+  const unsigned int *pk_prev = b == 0 ? a.pack_prev : a.pack_cur;
+  const float sg = (i2 & 1) ? -1.f : 1.f;                // (-1)^k, k = NB i1 + i2, NB even
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) {
+      const int k = NB * ((l + m * T) + s * (NA / R0)) + i2;
+      const unsigned int wc = (a.pack_cur[k >> 5] >> (k & 31)) & 1u, wp = (pk_prev[k >> 5] >> (k & 31)) & 1u;   // 1: weak (liminfo == 0, timf2.c:50)
+      float2 v = make_float2(0.f, 0.f), pv = make_float2(0.f, 0.f);
+      if (wc != (unsigned int)st) v = cur[k];
+      if (wp != (unsigned int)st) pv = prv[k];
+      x[m * R0 + s] = make_float2(v.x + sg * pv.x, v.y + sg * pv.y);
+    }
+  float2 *col = lds + c * CS;
+  BlockFft<LA, P, -1>::run(x, col, g.tw_a, l);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int o1 = (l + m * T) + q * (NA / RL);
+      col[o1] = cmul(x[m * RL + q], g.tw_big[(i2 * o1) & (N - 1)]);
+    }
+  __syncthreads();
+  float2 *sc = g.scratch + ((size_t)b * 2 + st) * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
+  for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
+    const int cc = e / NA, o1 = e - cc * NA;
+    sc[(size_t)cc * NA + o1] = lds[cc * CS + o1];
+  }
+}
+template <int LA, int LB>
+__global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
+{
+  const Timf2Args &a = g.t;
+  constexpr int P = sub_ppt(LB);
+  using Plan = FftPlan<LB, P>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
+  constexpr int CS = Plan::LDS_CELLS + 1;
+  __shared__ float2 lds[LRH_TILE * CS];
+  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
+  const int o1 = blockIdx.x * LRH_TILE + c, b = blockIdx.y, st = blockIdx.z;
+  const float2 *sc = g.scratch + ((size_t)b * 2 + st) * NA * NB;
+  float2 x[P];
+#pragma unroll
+  for (int m = 0; m < P / R0; m++)
+#pragma unroll
+    for (int s = 0; s < R0; s++) x[m * R0 + s] = sc[(size_t)((l + m * T) + s * (NB / R0)) * NA + o1];
+  BlockFft<LB, P, -1>::run(x, lds + c * CS, g.tw_b, l);
+  const int pa = a.pa_first + b * a.step;
+#pragma unroll
+  for (int m = 0; m < P / RL; m++)
+#pragma unroll
+    for (int q = 0; q < RL; q++) {
+      const int o2 = (l + m * T) + q * (NB / RL);
+      if (o2 >= NB / 2) continue;                          // first half of the block only (n < N/2)
+      const int r = (pa + o1 + NA * o2) & a.mask;
+      const float2 v = x[m * RL + q];
+      const float2 o = make_float2(a.ampfac * v.x, a.ampfac * v.y);
+      if (st == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
+      else a.timf2s[r] = o;
+    }
+}
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st)
+{
+  if (log2n != 15 || a.f.real || a.f.shift_i || a.f.shift_q) return hipErrorInvalidValue;
+  constexpr int LA = 8, LB = 7;
+  const dim3 gc((1 << LB) / LRH_TILE, batch), gr((1 << LA) / LRH_TILE, batch);
+  if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  hipLaunchKernelGGL((k_fft1_rows<LA, LB>), gr, dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStream_t st)
+{
+  if (log2n != 15 || a0.t.mode != 1) return hipErrorInvalidValue;
+  constexpr int LA = 8, LB = 7;
+  Timf2BigArgs a = a0; a.t.batch = batch;
+  hipLaunchKernelGGL((k_timf2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  hipLaunchKernelGGL((k_timf2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st)
 {
   switch (log2n) {
@@ -2292,8 +2463,15 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
 __global__ __launch_bounds__(256) void k_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st)
 {
   __shared__ int red[4];
-  const int nb = n / r0;
   int low = 0;
+  if (r0 == 0) {                                         // four-step timf2 (fft1_size 32768): dense, bit (k & 31) of word k >> 5
+    for (int i = threadIdx.x; i < n / 32; i += 256) {
+      unsigned int m = 0;
+      for (int s = 0; s < 32; s++) if (liminfo[32 * i + s] == 0) { m |= 1u << s; low++; }
+      pack[i] = m;
+    }
+  }
+  const int nb = r0 ? n / r0 : 0;
   for (int i = threadIdx.x; i < nb; i += 256) {
     unsigned int m = 0;
     for (int s = 0; s < r0; s++) if (liminfo[i + s * nb] == 0) { m |= 1u << s; low++; }

@@ -64,6 +64,21 @@ struct Timf2Args {
   float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0, ss_run;
 };
 
+// fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): one block no longer fits a workgroup's LDS, so
+// fft1 and timf2 take the four-step form of the large fft2 (column transforms, step twiddle, row transforms through an HBM scratch)
+struct Fft1BigArgs {
+  Fft1Args f;                                   // ring, window, filter correction, output ring, direction (int16 / int32 I/Q, no skew, no real input)
+  const float2 *tw_a, *tw_b, *tw_big;           // forward tables of size NA, NB, N1
+  float2 *scratch;                              // [batch][NB][NA]
+};
+struct Timf2BigArgs {
+  Timf2Args t;                                  // spectra, rings, ampfac; mode 1 (sin^2 overlap) only; pack_cur / pack_prev are dense bit words here
+  const float2 *tw_a, *tw_b, *tw_big;
+  float2 *scratch;                              // [batch][2 streams][NB][NA]
+};
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
+hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
+
 // ---- blanker ----
 struct BlankState {          // device resident; mirrors lrh_blanker_state + scratch
   int noise_floor; unsigned int limit;

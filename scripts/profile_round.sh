@@ -9,10 +9,14 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.log
 echo "stats pass done: $(tail -c 300 $OUT/stats.log | tr '\n' ' ')"
+# The counter passes run the serial schedule: TCC counters are per device, so a side-stream kernel overlapping k_timf2 would be
+# charged k_timf2's traffic (seen: 100-200 MB "fetched" by blanker kernels that return at once).  Bytes per kernel do not depend on the schedule.
 pmc() {   # name, bench flags
   local wl=$1; shift
+  export LRH_PIPELINE=0
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$wl -- python3 bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/bench_fetch_$wl.json 2> $OUT/fetch_$wl.log
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$wl -- python3 bench.py --steps 5 --warmup 2 --no-cpu "$@" > $OUT/bench_write_$wl.json 2> $OUT/write_$wl.log
+  unset LRH_PIPELINE
   echo "pmc passes of $wl done"
 }
 pmc n1_14_n2_16_n3_12_b4096 --no-secondary

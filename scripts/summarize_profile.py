@@ -29,19 +29,24 @@ STAGE_KERNELS = {
 
 def first(pattern):
     f = glob.glob(os.path.join(d, pattern), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None      # gpurun merges runs into one tree: the newest
 
 
 def counter_table(tag, ctr):
-    """kernel name -> [sum of the counter over all dispatches, dispatches]"""
+    """kernel name -> [MEDIAN of the counter over the kernel's dispatches x dispatches, dispatches, mean].
+    The median, because the first calls of a run are not the steady state: while the blanker's noise floor settles its
+    long-run replay and its apply kernel move GBs (k_blank_runs_pre: 1.5 GB in each of the first 4 calls, 11 KiB afterwards),
+    which a mean would spread over every launch."""
     f = first(f"{tag}/**/*counter_collection.csv")
-    acc = defaultdict(lambda: [0.0, 0])
+    vals = defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == ctr:
-                a = acc[r["Kernel_Name"]]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
+                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    acc = defaultdict(lambda: [0.0, 0, 0.0])
+    for k, v in vals.items():
+        v.sort()
+        acc[k] = [v[len(v) // 2] * len(v), len(v), sum(v) / len(v)]
     return acc
 
 
@@ -57,10 +62,10 @@ workloads = {}
 for wdir in sorted(glob.glob(os.path.join(d, "pmc_fetch_*"))):
     wl = os.path.basename(wdir)[len("pmc_fetch_"):]
     fetch, write = counter_table("pmc_fetch_" + wl, "FETCH_SIZE"), counter_table("pmc_write_" + wl, "WRITE_SIZE")
-    print(f"\n## workload {wl}: --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch in KiB as rocprofv3 reports them")
+    print(f"\n## workload {wl}: --pmc FETCH_SIZE / WRITE_SIZE (separate passes, serial schedule), per dispatch in KiB as rocprofv3 reports them: median (mean)")
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch[k][0] + write[k][0])):
-        fv, fn = fetch.get(k, [0, 0]); wv, wn = write.get(k, [0, 0])
-        print("%-58s n=%4d fetch=%12.1f  n=%4d write=%12.1f" % (k.replace("void lrh::", "")[:58], fn, fv / max(fn, 1), wn, wv / max(wn, 1)))
+        fv, fn, fm = fetch.get(k, [0, 0, 0]); wv, wn, wm = write.get(k, [0, 0, 0])
+        print("%-50s n=%4d fetch=%10.1f (%10.1f)  n=%4d write=%10.1f (%10.1f)" % (k.replace("void lrh::", "")[:50], fn, fv / max(fn, 1), fm, wn, wv / max(wn, 1), wm))
     kernels = {}
     for stage, (anchor, pats) in STAGE_KERNELS.items():
         anchors = (anchor,) if isinstance(anchor, str) else anchor
@@ -96,7 +101,8 @@ if len(sys.argv) > 2:
                      "--warmup 2 --no-cpu [workload flags] (scripts/profile_round.sh)",
            "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced streaming read, "
                          "MI355X_MICROARCH.md HBM section; calibrated in round 1 on k_sumsq's float2 reads: 67 MB reported for 134 MB read). "
-                         "A stage = the kernels bench.py's HIP-event scope of that name covers; per stage launch = sum over those kernels' "
-                         "dispatches / dispatches of the stage's first kernel",
+                         "A stage = the kernels bench.py's HIP-event scope of that name covers; per stage launch = sum over those kernels of "
+                         "(median per dispatch x dispatches) / dispatches of the stage's first kernel; median because the first calls of a run "
+                         "(blanker start-up transient) move GBs that the steady state does not",
            "workloads": workloads}
     json.dump(out, open(sys.argv[2], "w"), indent=1)

@@ -91,7 +91,7 @@ def test_fullsize_clever_blanker_matches_oracle():
         res.append(r)
         rx.close()
     h, o = res
-    print("fitted / rejected", h["tot"], o["tot"], "stage ms (total, launches)", h["prof"])
+    print("fitted / rejected", h["tot"], o["tot"], "stage ms (total, launches)", h["prof"], "slow-path calls", h["bs"].slow_path_calls)
     ints = [kk for kk, v in h["p"].items() if isinstance(v, int)]
     assert {kk: h["p"][kk] for kk in ints} == {kk: o["p"][kk] for kk in ints}
     assert h["tot"] == o["tot"] and h["tot"][0] > 50
