@@ -225,5 +225,7 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
     assert r.returncode != 0
-    assert "started 2 ranks" in r.stderr and "rank 1" in r.stderr
+    import re
+    # whichever rank fails first is reported; its peer is terminated by the launcher
+    assert "started 2 ranks" in r.stderr and re.search(r"rank [01] \(pid \d+\) exited with", r.stderr), r.stderr[-800:]
     assert '"n_gpus"' not in r.stdout
