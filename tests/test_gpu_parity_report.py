@@ -42,6 +42,19 @@ def test_parity_report():
         h, o, cfg = run_fullsize(fft2_n, blanker, fft3_n)
         key = f"fft1_16384_fft2_{1 << fft2_n}{'_fft3_%d' % (1 << fft3_n) if fft3_n else ''}{'' if blanker else '_noblanker'}"
         report["fullsize_vs_oracle"][key] = _clean(fullsize_compare(h, o, cfg, blanker, fft3_n))
+    # the stages that ride on the path as device kernels since round 2, each against its own reference goldens
+    import cleverlib, sellimlib, spurlib
+    from refcases import CLEVER, SELLIM, SPUR
+    report["feature_cases"] = {}
+    for name in SELLIM:
+        g = sellimlib.load(name)
+        report["feature_cases"][name] = _clean(sellimlib.compare(sellimlib.run(open_hip, name, g), g, tol=1e-5, value_tol=1e-5))
+    for name in SPUR:
+        g = spurlib.load(name)
+        report["feature_cases"][name] = _clean(spurlib.compare(spurlib.run(open_hip, name, g), g, tol=1e-5))
+    for name in CLEVER:
+        g = cleverlib.load(name)
+        report["feature_cases"][name] = _clean(cleverlib.compare(cleverlib.run(open_hip, name, g), g, 1e-5))
     esc = {k: v["escapes"] for k, v in report["golden_cases"].items() if v["escapes"]}
     report["summary"] = {"cases": len(report["golden_cases"]), "cases_with_an_escape": esc,
                          "blanker_flips_total": sum(v["blanker_flips"] for v in report["golden_cases"].values()),
