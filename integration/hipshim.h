@@ -16,7 +16,8 @@ void hip_timf1_new(int timf1p_pa, int nbytes);   /* finish_rx_read: one new bloc
 int  hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number);   /* fft1_b case 21 (fft1.c:3519-3553)                      */
 void hip_fft1_c(void);               /* stand-ins for the stage functions of the same names                                     */
 void hip_make_timf2(void);
-void hip_first_noise_blanker(void);
+void hip_first_noise_blanker(void);   /* also installs / removes the linear blanker's tables when hg.clever_bln_mode changes */
+void hip_fft1_update_liminfo(void);   /* selective limiter on the device-resident power spectra (sellim.c:738)             */
 void hip_make_fft2(void);
 void hip_fft2_mix1_fixed(void);
 #endif

@@ -112,6 +112,11 @@ def edit_mix1(L):
     func_top(L, r"^void fft2_mix1_fixed\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft2_mix1_fixed();return;}\n")
 
 
+def edit_sellim(L):
+    after_last_include(L)
+    func_top(L, r"^void fft1_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_update_liminfo();return;}\n")
+
+
 def edit_rxin(L):
     after_last_include(L)
     i = insert(L, r"^void finish_rx_read\(", "", where="after")
@@ -120,7 +125,7 @@ def edit_rxin(L):
 
 
 EDITS = {"globdef.h": edit_globdef, "fft1var.c": edit_fft1var, "buf.c": edit_buf, "wcw.c": edit_wcw, "fft1.c": edit_fft1,
-         "timf2.c": edit_timf2, "blank1.c": edit_blank1, "fft2.c": edit_fft2, "mix1.c": edit_mix1, "rxin.c": edit_rxin}
+         "timf2.c": edit_timf2, "blank1.c": edit_blank1, "fft2.c": edit_fft2, "mix1.c": edit_mix1, "sellim.c": edit_sellim, "rxin.c": edit_rxin}
 
 
 def main():
