@@ -165,6 +165,7 @@ typedef struct lrh_blanker_state {
   int timf2_fitted_pulses;          /* since the last info update                                  */
   int last_call_fitted;             /* fitted_pulses of the most recent call                       */
   int last_call_rejected;           /* pulses of that call flagged 65 (bad_pulse, blank1.c:945)    */
+  int clever_serial_calls;          /* calls whose region-parallel replay was discarded for the one-wave replay */
 } lrh_blanker_state;
 
 /* ---- linear ("clever") noise blanker: first_noise_blanker's pulse search / fit / subtract part (blank1.c:765-1003 with
@@ -175,7 +176,10 @@ typedef struct lrh_blanker_state {
    With tables installed lrh_first_noise_blanker first runs the pulse search over the span, then the stupid blanker
    (cfg.stupid_bln_mode) as before; timf2p_fit follows blank1.c:1458-1461 ((pf-16) & ~3: a pulse too close to the end of the
    span is left for the next call), which makes that pointer data dependent: the call reads one int back, so
-   with clever mode on each lrh_first_noise_blanker waits for its own device work and lrh_wideband_dsp runs the serial schedule. */
+   with clever mode on each lrh_first_noise_blanker waits for its own device work and lrh_wideband_dsp runs the serial schedule.
+   On the device the span is cut into regions at quiet stretches of the candidate samples and the regions are replayed in parallel,
+   each exactly in the reference's order; if two regions' reach ever overlaps the span is restored and replayed by one wave
+   (lrh_blanker_state.clever_serial_calls counts those calls). */
 #define LRH_BLN_INFO_SIZE 7       /* blnkdef.h:5  */
 #define LRH_MAX_REFPULSES 256     /* blnkdef.h:6  */
 typedef struct lrh_bln_info { int size; float rest; float avgmax; } lrh_bln_info;   /* BLANKER_CONTROL_INFO, blnkdef.h:8-14 */

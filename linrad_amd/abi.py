@@ -66,7 +66,7 @@ class LrhBlankerState(C.Structure):
         ("stupid_blanker_rate", C.c_float), ("timf2_cleared_points", C.c_int),
         ("last_call_cleared", C.c_int), ("slow_path_calls", C.c_int),
         ("clever_bln_limit", C.c_uint), ("clever_blanker_rate", C.c_float), ("timf2_fitted_pulses", C.c_int),
-        ("last_call_fitted", C.c_int), ("last_call_rejected", C.c_int),
+        ("last_call_fitted", C.c_int), ("last_call_rejected", C.c_int), ("clever_serial_calls", C.c_int),
     ]
 
 

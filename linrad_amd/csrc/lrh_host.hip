@@ -138,6 +138,8 @@ struct lrh_ctx {
   // linear ("clever") blanker: tables of lrh_set_blanker_tables, per-sample flags and candidate bit words
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
+  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr;
+  size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
   std::vector<unsigned int> h_pack;
@@ -335,7 +337,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -422,6 +424,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
+  if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;   // tests: the one-wave replay of the linear blanker
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
   if (const char *e7 = getenv("LRH_FFT2_RUN")) c->env_fft2_run = atoi(e7);
@@ -1155,6 +1158,28 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     ca.largest = c->bt.largest_blnfit; ca.amp_factor = c->bt.liminfo_amplitude_factor;
     ca.refpulse = c->d_bt_refpulse; ca.phasefunc = c->d_bt_phasefunc; ca.pulindex = c->d_bt_pulindex; ca.st = c->d_bst;
     for (int i = 0; i < LRH_BLN_INFO_SIZE; i++) { ca.bln_size[i] = c->bt.bln[i].size; ca.bln_rest[i] = c->bt.bln[i].rest; ca.bln_avgmax[i] = c->bt.bln[i].avgmax; }
+    { const int wn = std::max(c->bt.bln[c->bt.largest_blnfit].size / 2, ca.pwid) + 1;
+      // A pulse reaches R samples ahead (the search) and wn to either side (the fit); the residue of a subtracted pulse can be a
+      // new candidate up to wn away with the same reach again.  Twice that keeps neighbouring extents apart on every signal tried
+      // (half of it -- R + 2 wn + 16 -- collided in most calls of the full-size test, and one collision sends the whole span to
+      // the one-wave replay).
+      ca.gap = std::max(64, 2 * (ca.R + 2 * wn)); }
+    ca.bk_margin = 256;
+    const size_t need = (size_t)a.total + 2 * ca.bk_margin + 1;
+    if (c->clv_cap < need) {
+      HIPCHK(c, hipStreamSynchronize(c->cur));
+      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf })
+        if (*q_) { hipFree(*q_); *q_ = nullptr; }
+      c->clv_cap = 0;
+      const size_t cap = need + need / 4;
+      const int maxr = (int)(cap / ca.gap) + 2;
+      int rc_ = LRH_OK;
+      if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 4)) ||
+          (rc_ = dev_alloc(c, &c->d_clv_bk_pwr, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_tf, cap, false))) return rc_;
+      c->clv_cap = cap; c->clv_max_regions = maxr;
+    }
+    ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
+    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.force_serial = c->clever_force_serial ? 1 : 0;
     int out[3];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
@@ -1258,7 +1283,7 @@ int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
   st->stupid_blanker_rate = bs.stupid_rate; st->timf2_cleared_points = bs.cleared_acc;
   st->last_call_cleared = bs.last_cleared; st->slow_path_calls = bs.slow_calls;
   st->clever_bln_limit = bs.clever_limit; st->clever_blanker_rate = bs.clever_rate; st->timf2_fitted_pulses = bs.fitted_acc;
-  st->last_call_fitted = bs.last_fitted; st->last_call_rejected = bs.last_rejected;
+  st->last_call_fitted = bs.last_fitted; st->last_call_rejected = bs.last_rejected; st->clever_serial_calls = bs.clever_serial_calls;
   return LRH_OK;
 }
 

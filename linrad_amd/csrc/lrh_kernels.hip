@@ -1956,20 +1956,75 @@ hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask
 // fit.  One wave runs the reference's control flow with all lanes in step (every branch below is wave-uniform), a pulse's
 // neighbourhood (+-128 samples: refpul_size <= 256) sits in LDS, sums run in the reference's order, and contraction to fma is
 // off so that the threshold decisions see the reference's roundings.
-// k_clever_prep: candidate bits (power above the limit) and the flag clear over exactly the span (blank1.c:768-774).
+// k_clever_prep: candidate bits (power above the limit) and the flag clear over exactly the span (blank1.c:768-774); phase 0 also
+// keeps a copy of the span's samples, phase 1 (only after a violation) puts them back first.
 __global__ __launch_bounds__(256) void k_clever_prep(CleverArgs a)
 {
+  if (a.phase == 1 && a.reg_ctl[1] == 0) return;
   const int lane = threadIdx.x & 63, wmask = ((a.mask + 1) >> 6) - 1;
   const int first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
   const float nfl = (float)a.st->clever_limit;
+  const int nbk = a.total + 2 * a.bk_margin + 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nbk; i += gridDim.x * 256) {
+    const int pos = (a.pbeg + i - a.bk_margin) & a.mask;
+    if (a.phase == 0) { a.bk_pwr[i] = a.pwr[pos]; a.bk_tf[i] = a.timf2w[pos]; }
+    else { a.pwr[pos] = a.bk_pwr[i]; a.timf2w[pos] = a.bk_tf[i]; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; }
+  // candidate bits straight from the backup in phase 1: no workgroup depends on another one's restored samples
   for (int w = (blockIdx.x * 256 + threadIdx.x) >> 6; w < nwords; w += gridDim.x * 4) {
     const int pos = (((first_word + w) << 6) + lane) & a.mask;
-    const bool in = ((pos - a.pbeg) & a.mask) <= a.total;
-    const bool hot = in && a.pwr[pos] > nfl;
+    const int o = (pos - a.pbeg) & a.mask;
+    const bool in = o <= a.total;
+    const float v = in ? (a.phase == 1 ? a.bk_pwr[o + a.bk_margin] : a.pwr[pos]) : 0.f;
+    const bool hot = in && v > nfl;
     if (in) a.flag[pos] = 0;
     const unsigned long long b = __ballot(hot);
     if (lane == 0) a.cand[(first_word + w) & wmask] = b;
   }
+}
+
+// Regions: a candidate starts a region when no candidate lies within `gap` samples before it.  gap >= 64, so only the lowest set
+// bit of a word can start one.  One workgroup; ordered list of the starts (offsets from pbeg) by a block-wide scan of per-thread counts.
+__global__ __launch_bounds__(1024) void k_clever_regions(CleverArgs a)
+{
+  __shared__ int cnt[1024];
+  const int wmask = ((a.mask + 1) >> 6) - 1, first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
+  const int back = (a.gap + 63) / 64 + 1;
+  const int per = (nwords + 1023) / 1024, w0 = threadIdx.x * per, w1 = min(w0 + per, nwords);
+  auto start_of = [&](int w) -> int {                    // offset of a region start in word w, or -1
+    const unsigned long long v = a.cand[(first_word + w) & wmask];
+    if (!v) return -1;
+    const int pos = ((first_word + w) << 6) + __ffsll((long long)v) - 1;
+    for (int k = 1; k <= back && w - k >= 0; k++) {
+      const unsigned long long u = a.cand[(first_word + w - k) & wmask];
+      if (u) { const int prev = ((first_word + w - k) << 6) + 63 - __clzll((long long)u); if (pos - prev < a.gap) return -1; break; }
+    }
+    return pos - a.pbeg;                                  // not masked: words count up from pbeg's word, so this is the offset
+  };
+  int n = 0;
+  for (int w = w0; w < w1; w++) if (start_of(w) >= 0) n++;
+  cnt[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {             // inclusive scan
+    const int v = threadIdx.x >= off ? cnt[threadIdx.x - off] : 0;
+    __syncthreads();
+    cnt[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int at = cnt[threadIdx.x] - n;
+  for (int w = w0; w < w1; w++) { const int o = start_of(w); if (o >= 0) { if (at < a.max_regions) a.reg_start[at] = o; at++; } }
+  if (threadIdx.x == 1023) { a.reg_ctl[0] = min(cnt[1023], a.max_regions); a.reg_ctl[1] = (cnt[1023] > a.max_regions || a.force_serial) ? 1 : 0; a.reg_ctl[2] = a.total; }
+}
+
+// extents must stay apart; the last region's stopping point is the call's
+__global__ void k_clever_check(CleverArgs a)
+{
+  const int n = a.reg_ctl[0];
+  int bad = 0;
+  for (int r = threadIdx.x; r + 1 < n; r += 64) if (a.reg_ext[2 * r + 1] >= a.reg_ext[2 * (r + 1)]) bad = 1;
+  if (__ballot(bad) && threadIdx.x == 0) a.reg_ctl[1] = 1;
+  if (threadIdx.x == 0 && a.reg_ctl[1] == 0) a.st->clever_out[0] = (a.pbeg + a.reg_ctl[2]) & a.mask;
 }
 
 __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
@@ -2015,11 +2070,18 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     for (int i = lane; i < 256; i += 64) { const int pos = POS(base + i); s_spw[i] = a.pwr[pos]; s_sfl[i] = a.flag[pos]; }
     __syncthreads();
   };
-  int pf = 0, fitted = 0, rejected = 0;
+  // phase 0: one region per wave (work list); phase 1: the whole span by the first wave, only when the extents collided
+  if (a.phase == 1 && (a.reg_ctl[1] == 0 || blockIdx.x != 0)) return;
+  const int nreg = a.phase == 1 ? 1 : a.reg_ctl[0];
+  for (int reg = blockIdx.x; reg < nreg; reg += gridDim.x) {
+  const int r_begin = a.phase == 1 ? 0 : a.reg_start[reg];
+  const int r_end = (a.phase == 1 || reg + 1 >= nreg) ? total : a.reg_start[reg + 1];
+  int ext_lo = r_begin, ext_hi = r_begin;
+  int pf = r_begin, fitted = 0, rejected = 0;
   for (;;) {
     __threadfence();                                      // the candidate words / rings as the previous pulse left them
     pf = next_candidate(pf);
-    if (pf >= total) { pf = total; break; }
+    if (pf >= r_end) { pf = r_end; break; }
     // ---- the maximum that stays the maximum for blnfit_range samples (blank1.c:795-824)
     int o = pf - 1, p_max = pf, m = R, base = pf;
     float powermax = 10.f;
@@ -2031,6 +2093,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
       if (v > powermax && s_sfl[o - base] < 64) { powermax = v; p_max = o; m = R; }
       m--;
     }
+    ext_hi = max(ext_hi, o);
     if (m > 0) break;                                     // too close to the end of the span: next call
     bool no_pulse = false;
     if (a.flag[POS(p_max - 1)] >= 64) { pf = p_max; no_pulse = true; }
@@ -2044,9 +2107,12 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
         if (!(v <= powermax || a.flag[POS(pf)] > 64)) break;
         powermax = v; pf++;
       }
+      ext_hi = max(ext_hi, pf); ext_lo = min(ext_lo, p_max - 1);
       if (pf == total) break;
       continue;
     }
+    // what the fit can read or change around p_max: the shells of the largest fit size, the phase window, the subtracted span
+    { const int wn = max(a.bln_size[a.largest] / 2, pwid) + 1; ext_lo = min(ext_lo, p_max - wn); ext_hi = max(ext_hi, p_max + wn); }
     // ---- neighbourhood of the pulse into LDS
     __syncthreads();
     for (int i = lane; i <= 2 * W; i += 64) { const int pos = POS(p_max - W + i); s_pw[i] = a.pwr[pos]; s_tf[i] = a.timf2w[pos]; s_fl[i] = a.flag[pos]; }
@@ -2151,6 +2217,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     if (!(pb < 1)) while (PW(pb) < PW(p0) && pb != 0) { SETF(pb); p0 = pb; pb--; }
     p0 = pa; pa++;
     if (!(pa >= total)) while (PW(pa) < PW(p0) && pa != total) { p0 = pa; SETF(pa); pa++; }
+    ext_lo = min(ext_lo, pb); ext_hi = max(ext_hi, pa);
     __syncthreads();
     // ---- candidate bits of the samples the subtraction rewrote
     for (int i = lane; i <= 2 * W; i += 64) {
@@ -2160,13 +2227,31 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
       else atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63)));
     }
   }
-  if (lane == 0) { s->clever_out[0] = POS(pf); s->clever_out[1] = fitted; s->clever_out[2] = rejected; }
+  if (lane == 0) {
+    if (a.phase == 1) { s->clever_out[0] = POS(pf); s->clever_out[1] = fitted; s->clever_out[2] = rejected; s->clever_serial_calls++; }
+    else {
+      a.reg_ext[2 * reg] = ext_lo; a.reg_ext[2 * reg + 1] = ext_hi;
+      if (fitted) atomicAdd(&s->clever_out[1], fitted);
+      if (rejected) atomicAdd(&s->clever_out[2], rejected);
+      if (reg == nreg - 1) a.reg_ctl[2] = pf;           // where the walk of the whole span stops (blank1.c:1458)
+    }
+  }
+  __syncthreads();
+  }
 }
 
-hipError_t launch_clever(const CleverArgs &a, hipStream_t st)
+hipError_t launch_clever(const CleverArgs &a0, hipStream_t st)
 {
+  CleverArgs a = a0;
   const int nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
-  hipLaunchKernelGGL(k_clever_prep, dim3((nwords + 3) / 4 < 1024 ? (nwords + 3) / 4 : 1024), dim3(256), 0, st, a);
+  const dim3 gp((nwords + 3) / 4 < 2048 ? (nwords + 3) / 4 : 2048);
+  a.phase = 0;
+  hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_clever_regions, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 2048 ? a.max_regions : 2048), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(64), 0, st, a);
+  a.phase = 1;                                           // both return at once unless the check found colliding extents
+  hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();
 }

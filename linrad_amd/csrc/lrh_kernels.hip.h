@@ -89,6 +89,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   // linear ("clever") blanker
   unsigned int clever_limit; float clever_rate; int fitted_acc; int last_fitted; int last_rejected;
   int clever_out[3];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected
+  int clever_serial_calls;   // calls that fell back to the one-wave replay
 };
 struct BlankArgs {
   float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
@@ -123,6 +124,15 @@ struct CleverArgs {
   const float *refpulse, *phasefunc; const int *pulindex;
   int bln_size[7]; float bln_rest[7], bln_avgmax[7];
   BlankState *st;
+  // region-parallel replay: pulses further apart than `gap` samples cannot see each other, so the span is cut into regions at the
+  // quiet stretches of the candidate bits and one wave replays each region; every wave reports the extent of samples it looked at
+  // or changed, k_clever_check verifies that neighbouring extents stay apart, and when they do not (a monotone run of hundreds of
+  // samples) the span is restored from the backup and replayed by one wave in the reference's order
+  int gap; int *reg_start; int max_regions; int *reg_ext;     // [max_regions] first candidate offset; [2*max_regions] lo, hi
+  int *reg_ctl;             // [0] number of regions, [1] violation flag, [2] pf of the last region
+  float *bk_pwr; float2 *bk_tf; int bk_margin;                // copies of offsets -bk_margin .. total + bk_margin
+  int phase;                // k_clever_prep: 0 first pass (+ backup), 1 restore if violated; k_clever: 0 parallel, 1 serial if violated
+  int force_serial;         // tests: report a violation whatever the extents say
 };
 hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 

@@ -9,13 +9,20 @@ from refcases import CLEVER
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("serial", [0, 1])
 @pytest.mark.parametrize("name", list(CLEVER))
-def test_hip_clever_blanker_matches_reference(name):
+def test_hip_clever_blanker_matches_reference(name, serial, monkeypatch):
+    """serial = 0: the region-parallel replay (one wave per quiet-gap-separated region, extents checked); serial = 1: the check is
+    made to fail (LRH_CLEVER_SERIAL), so the span is restored from the backup and replayed by one wave in the reference's order"""
     from linrad_amd.lib import open_hip
+    if serial:
+        monkeypatch.setenv("LRH_CLEVER_SERIAL", "1")
     g = cleverlib.load(name)
     out = cleverlib.run(open_hip, name, g)
     rep = cleverlib.compare(out, g, 1e-5)
-    print(name, rep)
+    nser = out["api"].blanker_state().clever_serial_calls
+    print(name, "serial" if serial else "regions", rep, "one-wave replays", nser)
+    assert nser >= 20 if serial else nser <= 2          # the blanker runs every third block or so (rate limit, blank1.c:712)
     out["api"].close()
 
 
@@ -91,7 +98,7 @@ def test_fullsize_clever_blanker_matches_oracle():
         res.append(r)
         rx.close()
     h, o = res
-    print("fitted / rejected", h["tot"], o["tot"], "stage ms (total, launches)", h["prof"], "slow-path calls", h["bs"].slow_path_calls)
+    print("fitted / rejected", h["tot"], o["tot"], "stage ms (total, launches)", h["prof"], "slow-path calls", h["bs"].slow_path_calls, "one-wave replays", h["bs"].clever_serial_calls)
     ints = [kk for kk, v in h["p"].items() if isinstance(v, int)]
     assert {kk: h["p"][kk] for kk in ints} == {kk: o["p"][kk] for kk in ints}
     assert h["tot"] == o["tot"] and h["tot"][0] > 50
