@@ -1420,65 +1420,81 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { LRH_ENTER(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
 int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { LRH_ENTER(c); if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
 
-// set_mix1_phases, mix1.c:781-861 (float branch; the double branch belongs to correlation mode)
-static int set_mix1_phases(lrh_ctx *c, float fq)
+// Tuning of one mix1 transform (what set_mix1_phases, mix1.c:781-861, decides; float branch -- the double branch belongs to
+// correlation mode).  The selected frequency splits into the fft bin the baseband block is cut around, the block-to-block phase
+// advance of that bin, and a per-sample rotation for the fraction of a bin that is left.  The operations and their float
+// roundings are the reference's: the phases feed serial recursions whose rounding shows in timf3 at the 1e-5 level.
+static int mix1_retune(lrh_ctx *c, float hz)
 {
-  lrh_mix1_state *s = &c->ms;
-  if (fq < c->cfg.mix1_lowest_fq || fq > c->cfg.mix1_highest_fq) return LRH_ERANGE;
-  const int size = c->Nm;
-  float t1 = fq * c->cfg.fftx_points_per_hz, t2;
-  int pnt = (int)(t1 + 0.5);
-  int k = pnt % size;
-  t2 = (float)(size * (pnt / size));
-  t2 = t1 - t2 - k;
-  t2 = t2 - (int)(t2);
-  s->mix1_phase_rot = (float)(t2 * 2 * PI_L / size);
-  k = (k * c->Mm) % size;
-  s->mix1_old_phase = s->mix1_phase;
-  s->mix1_phase += s->mix1_phase_step;
-  s->mix1_phase_step = (float)(k * 2 * PI_L / size);
-  s->mix1_old_point = (s->mix1_point != -1) ? s->mix1_point : pnt;
-  s->mix1_point = pnt;
-  if (s->mix1_phase > PI_L) s->mix1_phase = (float)(s->mix1_phase - 2 * PI_L);
-  if (s->mix1_phase < PI_L) s->mix1_phase = (float)(s->mix1_phase + 2 * PI_L);     // reference quirk (mix1.c:859-860)
+  lrh_mix1_state &m = c->ms;
+  if (hz < c->cfg.mix1_lowest_fq || hz > c->cfg.mix1_highest_fq) return LRH_ERANGE;
+  const int block_bins = c->Nm;
+  const float in_bins = hz * c->cfg.fftx_points_per_hz;
+  const int centre_bin = (int)(in_bins + 0.5);
+  const int bin_in_block = centre_bin % block_bins;
+  const float whole_blocks = (float)(block_bins * (centre_bin / block_bins));
+  float fraction = in_bins - whole_blocks - bin_in_block;
+  fraction = fraction - (int)(fraction);
+  m.mix1_phase_rot = (float)(fraction * 2 * PI_L / block_bins);
+  const int advance_bins = (bin_in_block * c->Mm) % block_bins;     // phase of that bin after the Mm new samples of a block
+  m.mix1_old_phase = m.mix1_phase;
+  m.mix1_phase += m.mix1_phase_step;
+  m.mix1_phase_step = (float)(advance_bins * 2 * PI_L / block_bins);
+  m.mix1_old_point = (m.mix1_point != -1) ? m.mix1_point : centre_bin;
+  m.mix1_point = centre_bin;
+  // the reference folds with "< pi" on the second test, so the phase always ends up raised by 2 pi (mix1.c:859-860); kept
+  if (m.mix1_phase > PI_L) m.mix1_phase = (float)(m.mix1_phase - 2 * PI_L);
+  if (m.mix1_phase < PI_L) m.mix1_phase = (float)(m.mix1_phase + 2 * PI_L);
   return LRH_OK;
 }
 
-// shared by fft2_mix1_fixed (mix1.c:934-993) and fft1_mix1_fixed (mix1.c:995-1042): src ring of transforms of `n2` bins
-// do_mix1_afc up to its call of do_mix1 (mix1.c:648-768): bookkeeping on the caller's per-transform frequency tables
+// Bookkeeping of the AFC's per-transform frequency tables that do_mix1_afc (mix1.c:648-768) does before it calls do_mix1: the
+// drift handed to the next transform may not change faster than a fraction of the baseband bandwidth per transform.  When the
+// supplied track asks for more, the tables ahead are rewritten: accelerate at the limit until half the miss is made up, then
+// brake at the limit for as many transforms.  `ring` wraps the caller's four tables (the reference's globals of the same names).
 #define LRH_BWFAC 0.03
-static void afc_tables(lrh_ctx *c, lrh_afc *a, int nx, int na, int mask)
+namespace {
+struct AfcRing {
+  float *mid, *slope, *curv, *start; int mask;
+  int next(int i) const { return (i + 1) & mask; }
+  int prev(int i) const { return (i + mask) & mask; }
+};
+}
+static void afc_tables(lrh_ctx *c, lrh_afc *afc, int now, int newest, int mask)
 {
-  float *fq = a->mix1_fq_mid, *dfq = a->mix1_fq_slope, *d2fq = a->mix1_fq_curv, *fqs = a->mix1_fq_start;
-  const int ka = (nx + mask) & mask, kb = (nx + 1) & mask;
-  float t1 = fq[nx] + dfq[ka], t2 = fq[kb], t3;
-  if (fabs(t2 - t1) < LRH_BWFAC * a->baseband_bw_hz) {
-    dfq[nx] = fq[kb] - fq[nx];
-    d2fq[nx] = dfq[nx] - dfq[ka];
+  const AfcRing r{afc->mix1_fq_mid, afc->mix1_fq_slope, afc->mix1_fq_curv, afc->mix1_fq_start, mask};
+  const int before = r.prev(now), after = r.next(now);
+  const float max_curv = (float)(LRH_BWFAC * afc->baseband_bw_hz);
+  float predicted = r.mid[now] + r.slope[before];
+  if (fabs(r.mid[after] - predicted) < LRH_BWFAC * afc->baseband_bw_hz) {
+    // the track is smooth enough: plain first and second differences
+    r.slope[now] = r.mid[after] - r.mid[now];
+    r.curv[now] = r.slope[now] - r.slope[before];
   } else {
-    float error = t2 - t1, curv = (float)(LRH_BWFAC * a->baseband_bw_hz);
-    if (error < 0) curv = -curv;
-    t3 = (float)(fabs(error) / 2);
-    int kk = nx, k = 0, ia = ka, ib = kb;
-    while (fabs(error) > t3 && kk != na) {
-      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
-      t1 = fq[kk] + dfq[kk];
-      error = fq[ib] - t1;
-      if (t1 < c->cfg.mix1_lowest_fq) t1 = c->cfg.mix1_lowest_fq;
-      if (t1 > c->cfg.mix1_highest_fq) t1 = c->cfg.mix1_highest_fq;
-      fq[ib] = t1;
-      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k++;
+    float miss = r.mid[after] - predicted;
+    float bend = miss < 0 ? -max_curv : max_curv;
+    const float half_miss = (float)(fabs(miss) / 2);
+    int at = now, from = before, to = after, steps = 0;
+    while (fabs(miss) > half_miss && at != newest) {           // accelerate, keeping the rewritten track inside the mix1 range
+      r.curv[at] = bend; r.slope[at] = r.slope[from] + bend;
+      predicted = r.mid[at] + r.slope[at];
+      miss = r.mid[to] - predicted;
+      if (predicted < c->cfg.mix1_lowest_fq) predicted = c->cfg.mix1_lowest_fq;
+      if (predicted > c->cfg.mix1_highest_fq) predicted = c->cfg.mix1_highest_fq;
+      r.mid[to] = predicted;
+      from = r.next(from); at = r.next(at); to = r.next(to); steps++;
     }
-    t3 = error; curv = -curv;
-    while (k > 0 && kk != na && t3 * error > 0) {
-      d2fq[kk] = curv; dfq[kk] = dfq[ia] + curv;
-      t1 = fq[kk] + dfq[kk];
-      error = fq[ib] - t1;
-      fq[ib] = t1;
-      ia = (ia + 1) & mask; kk = (kk + 1) & mask; ib = (ib + 1) & mask; k--;
+    const float miss_at_turn = miss;
+    bend = -bend;
+    while (steps > 0 && at != newest && miss_at_turn * miss > 0) {   // brake for as many transforms, or until the miss changes sign
+      r.curv[at] = bend; r.slope[at] = r.slope[from] + bend;
+      predicted = r.mid[at] + r.slope[at];
+      miss = r.mid[to] - predicted;
+      r.mid[to] = predicted;
+      from = r.next(from); at = r.next(at); to = r.next(to); steps--;
     }
   }
-  fqs[kb] = (float)(fq[nx] + 0.5 * dfq[nx] + 0.25 * d2fq[nx]);
+  r.start[after] = (float)(r.mid[now] + 0.5 * r.slope[now] + 0.25 * r.curv[now]);
 }
 
 // afc != nullptr: per-transform frequency from afc->mix1_fq_mid[nx] with the table bookkeeping after each transform;
@@ -1517,7 +1533,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     const lrh_mix1_state ms_keep = *s;
     for (int b = 0; b < batch; b++) {
       const int nx = (first + b) & mask;
-      int rc = set_mix1_phases(c, afc ? afc->mix1_fq_mid[nx] : (float)s->mix1_selfreq);
+      int rc = mix1_retune(c, afc ? afc->mix1_fq_mid[nx] : (float)s->mix1_selfreq);
       if (rc) { *s = ms_keep; c->ph_next = slot; return rc; }
       if (afc) afc_tables(c, afc, nx, na, mask);
       point = s->mix1_point; h_point[b] = point;

@@ -202,14 +202,15 @@ def test_error_behaviour_and_ragged_calls():
         rx = fn(cfg)
         rx.timf1_write(iq)
         rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
-        rx.set_mix1_selfreq(300.3)
+        rx.set_mix1_selfreq(576.3)                                 # on the 100-LSB carrier of the synthetic signal (fs/16)
         for nb in (37, 1, 8, 5):                                   # 51 blocks in ragged calls
             rx.wideband_dsp(nb, 8)
         outs.append((rx.export(abi.RING_FFT1_SUMSQ), rx.export(abi.RING_TIMF2_PWR), rx.export(abi.RING_FFT2_FLOAT), rx.export(abi.RING_TIMF3_FLOAT), rx.p.as_dict()))
     ints = [k for k, v in outs[0][4].items() if isinstance(v, int)]
     assert {k: outs[0][4][k] for k in ints} == {k: outs[1][4][k] for k in ints}
     for i, (a, b) in enumerate(zip(outs[0][:4], outs[1][:4])):
-        assert relerr(a, b) < (1e-4 if i == 3 else 2e-5), i           # timf3: a weak band on the float32 floor of the wide spectrum
+        # north-star tolerance; the despiked power keeps the float32 floor of the pulses it was cleaned of
+        assert relerr(a, b) < (5e-5 if i == 1 else 1e-5), (i, relerr(a, b))
     rx = open_hip(cfg)
     for call, code in ((lambda: rx.fft1_b(9), abi.LRH_EINVAL),                       # batch > max_batch
                        (lambda: rx.make_fft2(cfg.max_fft2n + 1), abi.LRH_EINVAL),
