@@ -147,7 +147,7 @@ __host__ __device__ constexpr int points_per_thread(int log2n) { return log2n >=
 __host__ __device__ constexpr int fft_halves(int log2n) { return 1; }
 __host__ __device__ constexpr int fft_threads(int log2n) { return (1 << log2n) / points_per_thread(log2n); }
 // waves per SIMD to ask for in __launch_bounds__ (N = 8192: two 512-thread workgroups per CU)
-__host__ __device__ constexpr int fft_min_waves(int log2n) { return (log2n == 13 || log2n == 12) ? 4 : 1; }
+__host__ __device__ constexpr int fft_min_waves(int log2n) { return log2n == 13 ? 2 : (log2n == 12 ? 3 : 1); }
 
 template <int LOG2N, int P> struct FftPlan {
   static constexpr int N = 1 << LOG2N;
