@@ -683,6 +683,7 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   LRH_ENTER(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (c->fft1_big) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 16384 (power block and table of one transform in LDS); use lrh_set_liminfo");
   if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
       c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
   if (!c->h_sel_low) {
@@ -2055,6 +2056,7 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
   LRH_ENTER(c);
   if (!c || !dst || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (c->fft1_big) return fail(c, LRH_EINVAL, "NET_RXOUT_FFT1 payload: fft1_size <= 16384");
   int cap = 1; while (cap < batch) cap <<= 1;
   if (cap > c->fft1net_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
