@@ -279,8 +279,23 @@ typedef struct lrh_sellim {
   int baseband_bw_fftxpts;      /* baseb_graph.c:1165 (an int in the reference, uidef.h:157)                   */
   int ston_scale;               /* mg.scale_type == MG_SCALE_STON                                              */
   int exact_stats;              /* 1: wait for the weak-bin count (see above)                                  */
+  /* lrh_fft2_update_liminfo only */
+  float blanker_ston_fft2;      /* hg.blanker_ston_fft2 (hires_graph.c:722)                                    */
+  float fft2_blocktime;         /* seconds between fft2 transforms (buf.c:456)                                 */
+  /* selfreq_liminfo's liminfo_amplitude_factor (sellim.c:119-155): the calibrated form needs the amplitude calibration */
+  const float *fft1_desired;    /* N1 floats, or NULL: uncalibrated form (share of strong bins in the passband) */
 } lrh_sellim;
 int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
+/* fft2_update_liminfo (sellim.c:159-736, hg.sellim_par1 = 2, the reference's setting; variants 0 and 1 are not built): after
+   make_fft2 has completed a waterfall line (fft2_liminfo_cnt, wcw.c:1129-1133) the summed fft2 power spectrum -- averaged over the
+   fft2 bins of every fft1 bin -- gives a second, finer look: group minima -> global noise floor -> bins above
+   0.5 * blanker_ston_fft2 * floor join the strong signals for the hold-off time, and a table that has grown beyond a quarter of
+   the passband is thinned.  Ends with selfreq_liminfo like the fft1 variant.  Same table, same hand-over to make_timf2. */
+int lrh_fft2_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
+/* liminfo_amplitude_factor as selfreq_liminfo left it (the linear blanker scales its reference pulse with it, blank1.c:143-144);
+   the limiter calls above keep it current on the device; a host that supplies tables itself (lrh_set_liminfo) sets it here */
+int lrh_get_liminfo_amplitude_factor(lrh_ctx *ctx, float *factor);   /* synchronous */
+int lrh_set_liminfo_amplitude_factor(lrh_ctx *ctx, float factor);
 int lrh_get_liminfo(lrh_ctx *ctx, float *liminfo /* N1 floats: the table in force */);     /* synchronous */
 
 /* ---- spur (carrier) subtraction in the fft2 spectra: eliminate_spurs (spur.c:36-494), called by make_fft2 between the transform

@@ -117,14 +117,15 @@ class LrhSellim(C.Structure):
                 ("sellim_par5", C.c_int), ("sellim_par6", C.c_int), ("sellim_par7", C.c_int), ("sellim_par8", C.c_int),
                 ("liminfo_group_points", C.c_int), ("fft1_first_point", C.c_int), ("fft1_last_point", C.c_int),
                 ("fft1_first_inband", C.c_int), ("fft1_last_inband", C.c_int), ("baseband_bw_fftxpts", C.c_int),
-                ("ston_scale", C.c_int), ("exact_stats", C.c_int)]
+                ("ston_scale", C.c_int), ("exact_stats", C.c_int), ("blanker_ston_fft2", C.c_float), ("fft2_blocktime", C.c_float),
+                ("fft1_desired", C.POINTER(C.c_float))]
 
 
 def default_sellim(cfg, **kw):
     """hires_graph.c:1175-1189 defaults, uncalibrated end points (fft1.c:4615-4618), 16 noise-floor groups"""
     n1 = 1 << cfg.fft1_n
     s = LrhSellim(C.sizeof(LrhSellim), 12000, cfg.fft_avg1num * cfg.fft_avg2num, 0.0008, 4.0, 0, 0, 0, 0, 0, 0, 0,
-                  n1 // 16, 0, n1 - 1, 0, n1 - 1, 40, 0, 1)
+                  n1 // 16, 0, n1 - 1, 0, n1 - 1, 40, 0, 1, 30.0, 0.0008 * (1 << cfg.fft2_n) / n1, None)
     for k, v in kw.items():
         if not hasattr(s, k):
             raise AttributeError(k)
@@ -235,6 +236,9 @@ class StageAPI:
         self._proto("spur_set", [vp, C.c_int, C.POINTER(LrhSpur), fp, fp, ip])
         self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
         self._proto("get_liminfo", [vp, fp])
+        self._proto("fft2_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
+        self._proto("get_liminfo_amplitude_factor", [vp, fp])
+        self._proto("set_liminfo_amplitude_factor", [vp, C.c_float])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
         self._proto("get_mix1_state", [vp, C.POINTER(LrhMix1State)])
         self._proto("wideband_dsp", [vp, C.POINTER(LrhPtrs), C.c_int, C.c_int])
@@ -371,6 +375,18 @@ class StageAPI:
     def fft1_update_liminfo(self, par):
         """one run of the selective limiter on the device-resident spectra (sellim.c:738-1157), see include/linrad_hip.h"""
         self._chk(self._f("fft1_update_liminfo")(self.ctx, C.byref(self.p), C.byref(par)), "fft1_update_liminfo")
+
+    def fft2_update_liminfo(self, par):
+        """fft2_update_liminfo (sellim.c:159, par1 = 2) on the device-resident fft2 power sums"""
+        self._chk(self._f("fft2_update_liminfo")(self.ctx, C.byref(self.p), C.byref(par)), "fft2_update_liminfo")
+
+    def liminfo_amplitude_factor(self):
+        f = C.c_float()
+        self._chk(self._f("get_liminfo_amplitude_factor")(self.ctx, C.byref(f)), "get_liminfo_amplitude_factor")
+        return f.value
+
+    def set_liminfo_amplitude_factor(self, f):
+        self._chk(self._f("set_liminfo_amplitude_factor")(self.ctx, float(f)), "set_liminfo_amplitude_factor")
 
     def get_liminfo(self):
         out = np.empty(self.N1, np.float32)

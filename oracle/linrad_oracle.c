@@ -62,6 +62,7 @@ struct lro_ctx {
   /* blanker scalars (blnkvar.c) */
   lrh_blanker_state bs;
   /* linear blanker (lro_set_blanker_tables) */
+  float amp_factor;            /* liminfo_amplitude_factor (sellim.c:119-155; blank1.c:143) */
   lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
@@ -312,6 +313,7 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   default_filtercorr(c); default_yfac(c);
   /* blanker start state: buf.c:418-431, hires_graph.c:1157-1162 */
   c->bs.timf2_noise_floor = cfg->timf2_noise_floor;
+  c->amp_factor = 1;                                    /* init_blanker, buf.c:1909 */
   c->bs.timf2_despiked_pwr[0] = (float)cfg->timf2_noise_floor; c->bs.timf2_despiked_pwrinc[0] = 1;
   c->bs.timf2_despiked_pwr[1] = 0; c->bs.timf2_despiked_pwrinc[1] = 0;
   c->bs.stupid_bln_limit = (unsigned int)((float)cfg->timf2_noise_floor * cfg->stupid_bln_factor);
@@ -329,8 +331,8 @@ void lro_close(lro_ctx *c)
                 c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
-    struct { float *old; unsigned char *wait; float *tmp, *group_min; } *s = c->sellim;
-    free(s->old); free(s->wait); free(s->tmp - 8); free(s->group_min); free(s);
+    struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; } *s = c->sellim;
+    free(s->old); free(s->wait); free(s->tmp - 8); free(s->group_min); free(s->ftmp - 8); free(s);
   }
   free(c);
 }
@@ -715,6 +717,7 @@ int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
   memcpy(c->bt_refpulse, t->refpulse, 4 * nr); memcpy(c->bt_phasefunc, t->phasefunc, 8 * rs); memcpy(c->bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES);
   c->bt.refpulse = c->bt_refpulse; c->bt.phasefunc = c->bt_phasefunc; c->bt.pulindex = c->bt_pulindex;
   c->bs.clever_bln_limit = t->clever_bln_limit;
+  c->amp_factor = t->liminfo_amplitude_factor;
   c->clever_on = 1;
   return LRH_OK;
 }
@@ -773,7 +776,7 @@ static float clever_subtract(lro_ctx *c, int p_max, int sub_size)
   if (j < 0) j = 0;
   if (j >= LRH_MAX_REFPULSES) j = LRH_MAX_REFPULSES - 1;
   int m = 2 * c->bt_pulindex[j] * rs;
-  c1 *= in[2 * imax] * c->bt.liminfo_amplitude_factor; c2 *= in[2 * imax] * c->bt.liminfo_amplitude_factor;
+  c1 *= in[2 * imax] * c->amp_factor; c2 *= in[2 * imax] * c->amp_factor;
   t3 = 0; t4 = 0;
   k = rs - sub_size;
   for (int q = p_max - sub_size / 2; q <= p_max + sub_size / 2; q++) {
@@ -1540,13 +1543,14 @@ int lro_export_timf2_net(lro_ctx *c, float *dst, int timf2_pt, int count, float 
 #define LRO_BIGFLOAT 300000000000000000000000000000000000000.F
 #define LRO_RELEASE_FACTOR 1.15
 #define LRO_SFAC 2.
-typedef struct { float *old; unsigned char *wait; float *tmp, *group_min; int sumsq_tot, sel_ia, sel_ib; } lro_sellim_state;
+typedef struct { float *old; unsigned char *wait; float *tmp, *group_min; int sumsq_tot, sel_ia, sel_ib; float *ftmp; } lro_sellim_state;
 static lro_sellim_state *sellim_state(lro_ctx *c)
 {
   if (!c->sellim) {                       /* allocated on first use, freed by lro_close */
     lro_sellim_state *s = calloc(1, sizeof *s);
     s->old = calloc(c->N1, 4); s->wait = calloc(c->N1, 1); s->group_min = calloc(c->N1 + 4, 4);
     s->tmp = (float *)calloc(c->N1 + 16, 4) + 8;      /* the reference's scans look two bins below and above their range */
+    s->ftmp = (float *)calloc(c->N1 + 16, 4) + 8;     /* fftf_tmp of fft2_update_liminfo: zero outside what it fills (buf.c:972) */
     c->sellim = s;
   }
   return (lro_sellim_state *)c->sellim;
@@ -1599,7 +1603,104 @@ static void selfreq_liminfo(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *
       }
     }
   }
+  /* liminfo_amplitude_factor (sellim.c:108-155): what the strong bins take away from a pulse's amplitude */
+  if (!c->cfg.second_fft_enable) c->amp_factor = 1;
+  else if (q->fft1_desired) {
+    float t1 = 0, tot = 0;
+    for (int i = 0; i < N; i++) tot += q->fft1_desired[i] * q->fft1_desired[i];       /* fft1_desired_totsum (calibration set-up) */
+    for (int i = q->fft1_first_point; i <= q->fft1_last_point; i++) if (lim[i] != 0) t1 += q->fft1_desired[i] * q->fft1_desired[i];
+    c->amp_factor = tot / (tot - t1);
+  } else {
+    int k = 0;
+    for (int i = q->fft1_first_inband; i <= q->fft1_last_inband; i++) if (lim[i] != 0) k++;
+    const int n = q->fft1_last_inband - q->fft1_first_inband + 1;
+    c->amp_factor = (float)(n) / (n - k);
+  }
+  if (c->amp_factor > 2) c->amp_factor = 0;
   for (int i = 0; i < N; i++) st->old[i] = lim[i];
+}
+
+int lro_get_liminfo_amplitude_factor(lro_ctx *c, float *f) { if (!c || !f) return LRH_EINVAL; *f = c->amp_factor; return LRH_OK; }
+int lro_set_liminfo_amplitude_factor(lro_ctx *c, float f) { if (!c) return LRH_EINVAL; c->amp_factor = f; return LRH_OK; }
+
+/* fft2_update_liminfo, sellim.c:159-736, case hg.sellim_par1 = 2 (535-731) */
+int lro_fft2_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+{
+  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return LRH_EINVAL;
+  const int N = c->N1, nn = c->N2 / c->N1, gp = q->liminfo_group_points;
+  if (nn < 1 || gp < 1 || N / gp < 1) return LRH_EINVAL;
+  lro_sellim_state *st = sellim_state(c);
+  float *lim = c->liminfo, *f = st->ftmp;
+  const int groups = N / gp;
+  float *reg_min = calloc(3 * (size_t)groups + 3, 4), *reg_ston = reg_min + groups + 1, *reg_noise = reg_ston + groups + 1;
+  unsigned wait_n = 1 + (1 + (q->fft2_blocktime * c->cfg.waterfall_avgnum)) / (c->cfg.fft_avg1num * q->fft1_blocktime);
+  if (wait_n > 255) wait_n = 255;
+  int i, j, k, ia, ib;
+  float t1, t2, t3, global_noise_floor;
+  for (i = q->fft1_first_point; i < q->fft1_last_point; i++) {       /* mean fft2 power over the width of an fft1 bin */
+    t1 = 0;
+    for (j = nn * i; j < nn * i + nn; j++) t1 += c->fft2_powersum[j];
+    f[i] = t1 * c->wg_waterf_yfac[i] / nn;
+  }
+  for (i = 0; i < groups; i++) {
+    ia = i * gp; ib = ia + gp;
+    t1 = 0;
+    for (j = ia; j < ib; j++) t1 += f[j];
+    t1 /= gp;
+    k = 0; t3 = LRO_BIGFLOAT; t1 *= 0.001F; t2 = 0;
+    for (j = ia; j < ib; j++) if (f[j] > t1) { k++; if (f[j] < t3) t3 = f[j]; if (f[j] > t2) t2 = f[j]; }
+    reg_min[i] = k < 2 ? -1 : t3;
+    reg_ston[i] = t2 / t3;
+  }
+  t1 = 0; k = 0;
+  for (i = 0; i < groups; i++) if (reg_ston[i] < 2000.F) { t1 += reg_min[i]; k++; }
+  if (k == 0) { free(reg_min); return LRH_OK; }                      /* sellim.c:604: returns without selfreq_liminfo */
+  t1 /= k;
+  global_noise_floor = 0; k = 0;
+  for (i = 0; i < groups; i++) if (reg_min[i] > 0.03F * t1 && reg_min[i] < 30.F * t1) { global_noise_floor += reg_min[i]; k++; }
+  if (k < 3) goto done;
+  global_noise_floor /= k;
+  t1 = 5 * global_noise_floor;
+  for (i = 0; i < groups; i++) {
+    ia = i * gp; ib = ia + gp; t2 = 0; k = 0;
+    for (j = ia; j < ib; j++) if (f[j] < t1) { k++; t2 += f[j]; }
+    reg_noise[i] = k > 2 ? t2 / k : -1;
+  }
+  t1 = 0; k = 0;
+  for (i = 0; i < groups; i++) if (reg_noise[i] > 0) { k++; t1 += reg_noise[i]; }
+  if (k < 3) goto done;
+  t1 /= k;
+  global_noise_floor = 0; k = 0;
+  for (i = 0; i < groups; i++) if (reg_noise[i] > 0.1F * t1 && reg_noise[i] < 10.F * t1) { global_noise_floor += reg_noise[i]; k++; }
+  if (k < 3) goto done;
+  global_noise_floor /= k;
+  t1 = 0.5 * q->blanker_ston_fft2 * global_noise_floor;
+  ia = q->fft1_first_point; if (ia < 2) ia = 2;
+  ib = q->fft1_last_point; if (ib < N - 2) ib = N - 2;              /* as written (sellim.c:668-669): at least N-2 */
+  k = 0;
+  for (i = ia; i < ib; i++) {                                        /* noise the stupid blanker leaves next to strong bins */
+    if (lim[i - 1] == 0 && lim[i] != 0) { if (f[i - 1] > f[i - 2]) f[i - 1] = f[i - 2]; }
+    if (lim[i + 1] == 0 && lim[i] != 0) { if (f[i + 1] > f[i + 2]) f[i + 1] = f[i + 2]; }
+    if (lim[i] != 0) k++;
+  }
+  if (k > (ib - ia) / 4) {                                           /* a quarter of the band strong: thin the table */
+    k = 0;
+    for (i = ia; i < ib; i++) { if (lim[i] < 0 && f[i] < t1) { lim[i] = 0; st->wait[i] = 0; } if (lim[i] != 0) k++; }
+    if (k > (ib - ia) / 4) {
+      t2 = 10.F * t1;
+      for (i = ia; i < ib; i++) if (lim[i] < 0 && f[i] < t2) { lim[i] = 0; st->wait[i] = 0; }
+    }
+  }
+  for (i = ia; i < ib; i++)                                           /* the fifth term repeats i-2 in the reference (sellim.c:723) */
+    if (LRO_SFAC * f[i - 2] > t1 || f[i - 1] > t1 || f[i] > t1 || f[i + 1] > t1 || LRO_SFAC * f[i - 2] > t1) {
+      if (lim[i] == 0) lim[i] = -1;
+      st->wait[i] = (unsigned char)wait_n;
+    }
+done:
+  free(reg_min);
+  selfreq_liminfo(c, st, q);
+  return LRH_OK;
 }
 
 int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)

@@ -255,6 +255,8 @@ int main(int argc, char **argv)
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
   int sellim = AI("sellim", 0);                  /* 1: the selective limiter runs (fft1_update_liminfo, sellim.c:738) whenever fft1_c completes an
                                                     averaging period, in the single-CPU order of wcw.c:1124-1128; make_timf2 routes with its table */
+  int sellim2 = AI("sellim2", 0);                /* 1 (with sellim=1): fft2_update_liminfo (sellim.c:159, hg.sellim_par1 = 2) whenever make_fft2 completes a waterfall
+                                                    line, after fft1_update_liminfo like wcw.c:1124-1133 */
   int spur = AI("spur", 0);                      /* 1: a spur at fft2 bin spur_pnt (first of its SPUR_WIDTH bins) is acquired by the reference's own
                                                     store_new_spur / spur_phase_lock once spur_start transforms exist, then tracked and subtracted
                                                     by eliminate_spurs inside make_fft2 (fft2.c:647-652) */
@@ -379,6 +381,9 @@ int main(int argc, char **argv)
     genparm[SELLIM_MAXLEVEL] = AI("maxlevel", 12000); fft1_blocktime = (float)AF("blocktime", 0.0008);
     baseband_bw_fftxpts = AI("bw_fftxpts", 40);
     memset(&mg, 0, sizeof mg);
+    liminfo_groups = groups;                       /* buf.c:816-820, 972-978 */
+    fftf_tmp = zalloc(sizeof(float) * ((size_t)N2 + N1 + 64));
+    reg_noise = zalloc(sizeof(float) * (groups + 8)); reg_min = zalloc(sizeof(float) * (groups + 8)); reg_ston = zalloc(sizeof(float) * (groups + 8));
   }
   make_permute(0, n1, N1, fft1_back_scramble);
   if (fft_cntrl[FFT1_CURMODE].permute == 2) { fft1_backtab = zalloc(sizeof(COSIN_TABLE) * N1); make_sincos(0, N1, fft1_backtab); }   /* buf.c:1318-1326 */
@@ -408,7 +413,7 @@ int main(int argc, char **argv)
   hg.timf2_oscilloscope = 0;
   hg.sellim_par1 = 2; hg.sellim_par2 = AI("par2", 0); hg.sellim_par3 = AI("par3", 0); hg.sellim_par4 = AI("par4", 0);
   hg.sellim_par5 = AI("par5", 0); hg.sellim_par6 = AI("par6", 0); hg.sellim_par7 = AI("par7", 0); hg.sellim_par8 = AI("par8", 0);
-  hg.blanker_ston_fft1 = (float)AF("ston_fft1", 4.0);
+  hg.blanker_ston_fft1 = (float)AF("ston_fft1", 4.0); hg.blanker_ston_fft2 = (float)AF("ston_fft2", 30.0);
   blnfit_range = fitrange; blanker_pulsewidth = pulsewidth;
   blanker_flag = zalloc(timf2pow_size + 64);
   if (clever) {
@@ -499,6 +504,7 @@ int main(int argc, char **argv)
     mix1.new_points = mix1.size - mix1.interleave_points;
   }
   timf2_output_block = 4 * C * fft2_new_points;
+  if (sellim2) fft2_blocktime = fft1_blocktime * (float)fft2_new_points / (float)fft1_new_points;   /* buf.c:456: both from timf1_sampling_speed */
 
   /* waterfall line from fft2 (fft2.c:707-815) */
   wg_xpixels = wf_pix ? wf_pix : (N2 < 1024 ? N2 : 1024);
@@ -638,6 +644,11 @@ int main(int argc, char **argv)
   int local_fft1_liminfo_cnt = 0, nlimupd = 0;
   float *limtrace = sellim ? zalloc(sizeof(float) * N1 * (size_t)(nblk / avg1 + 2)) : NULL;
   int *limtrace_blk = zalloc(sizeof(int) * (nblk / avg1 + 2));
+  int local_fft2_liminfo_cnt = 0, nlimupd2 = 0, namp = 0;
+  float *limtrace2 = (sellim && sellim2) ? zalloc(sizeof(float) * N1 * (size_t)(4 * nblk + 8)) : NULL;
+  int *limtrace2_blk = zalloc(sizeof(int) * (4 * nblk + 8));
+  float *amptrace = zalloc(sizeof(float) * (5 * nblk + 16));
+  fft2_liminfo_cnt = 0;
   struct timespec ts0, ts1; clock_gettime(CLOCK_MONOTONIC, &ts0);
   int nthreads = AI("threads", 0);
   if (timing && nthreads && second && C == 1) {
@@ -751,6 +762,13 @@ int main(int argc, char **argv)
       fft1_update_liminfo();
       local_fft1_liminfo_cnt = fft1_liminfo_cnt;
       memcpy(limtrace + (size_t)nlimupd * N1, liminfo, 4 * N1); limtrace_blk[nlimupd] = b; nlimupd++;
+      amptrace[namp++] = liminfo_amplitude_factor;
+    }
+    if (sellim && sellim2 && fft2_liminfo_cnt != local_fft2_liminfo_cnt) {   /* wcw.c:1129-1133 */
+      fft2_update_liminfo();
+      local_fft2_liminfo_cnt = fft2_liminfo_cnt;
+      memcpy(limtrace2 + (size_t)nlimupd2 * N1, liminfo, 4 * N1); limtrace2_blk[nlimupd2] = b; nlimupd2++;
+      amptrace[namp++] = liminfo_amplitude_factor;
     }
   }
 
@@ -784,6 +802,11 @@ int main(int argc, char **argv)
     PUTI("sellim_params", sp, 16);
     float sf[2] = { fft1_blocktime, hg.blanker_ston_fft1 }; PUTF("sellim_fparams", sf, 2);
     PUTF("liminfo_final", liminfo, N1);
+    PUTF("amp_factor_trace", amptrace, namp > 0 ? namp : 1);
+    if (sellim2) {
+      PUTF("liminfo_trace2", limtrace2, (size_t)N1 * (nlimupd2 > 0 ? nlimupd2 : 1)); PUTI("liminfo_trace2_blk", limtrace2_blk, nlimupd2 > 0 ? nlimupd2 : 1);
+      float s2[4] = { hg.blanker_ston_fft2, fft2_blocktime, (float)wg.waterfall_avgnum, (float)nlimupd2 }; PUTF("sellim2_fparams", s2, 4);
+    }
   }
   if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2); }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);

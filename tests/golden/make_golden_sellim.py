@@ -19,7 +19,8 @@ from refdump import load_dump  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["liminfo_trace", "liminfo_trace_blk", "sellim_params", "sellim_fparams", "liminfo_final", "fft1_sumsq", "fft1_slowsum",
-        "timf2_float", "timf2_pwr_float", "fft2_powersum_float", "timf3_float", "itrace", "trace", "final", "wg_waterf_yfac"]
+        "timf2_float", "timf2_pwr_float", "fft2_powersum_float", "timf3_float", "itrace", "trace", "final", "wg_waterf_yfac",
+        "amp_factor_trace", "liminfo_trace2", "liminfo_trace2_blk", "sellim2_fparams"]
 
 
 def main():
@@ -37,6 +38,11 @@ def main():
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         tr = out["liminfo_trace"].reshape(-1, 1 << d["n1"])
+        if "liminfo_trace2" in out:
+            t2 = out["liminfo_trace2"].reshape(-1, 1 << d["n1"])
+            print("   fft2_update_liminfo:", t2.shape[0], "updates; strong bins:", [int(np.count_nonzero(r)) for r in t2[::max(1, t2.shape[0] // 8)]],
+                  "differs from the table before it in", [int(np.count_nonzero(t2[i] != t2[i - 1])) for i in range(1, t2.shape[0], max(1, t2.shape[0] // 8))],
+                  "amp factors", sorted(set(np.round(out["amp_factor_trace"], 4).tolist()))[:6])
         print(name, os.path.getsize(path) // 1024, "KiB;", tr.shape[0], "updates; strong bins per update:",
               [int(np.count_nonzero(r)) for r in tr[::max(1, tr.shape[0] // 8)]], "attenuated:", int(np.count_nonzero(tr[-1] > 0)))
 

@@ -284,12 +284,21 @@ SELLIM = {
 }
 
 
+# both limiters (harness sellim=1 sellim2=1): fft2_update_liminfo (sellim.c:159, par1 = 2) after every waterfall line on top of fft1_update_liminfo
+SELLIM["sellim2_n10_n12"] = dict(base="n10_n12", nblk=200, maxlevel=12000, lim_groups=16, blocktime=0.0008, ston_fft1=4.0, bw_fftxpts=40,
+                                 keyed=(150.0, 7000.0, 60, 110), blockpower_block=0, sellim2=1, ston_fft2=30.0)
+SELLIM["sellim2_n9_n11_pars"] = dict(base="n9_n11_shift", nblk=160, maxlevel=4000, lim_groups=32, blocktime=0.002, ston_fft1=3.0, bw_fftxpts=24,
+                                     par2=1, par3=1, par4=1, par7=1, par8=1, sample_shift=0, keyed=(-77.0, 5000.0, 40, 90),
+                                     strong=[(101.0, 6000.0)], weak=[(150.5, 45.0), (60.0, 400.0)], sellim2=1, ston_fft2=8.0, wf_avgnum=3)
+
+
 def sellim_case(name):
     """params + input of a selective-limiter case: the base case's signal plus a carrier keyed on for blocks [on, off)"""
     t = dict(SELLIM[name])
     d = case_params(t.pop("base"))
     keyed = t.pop("keyed")
-    sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par2", "par3", "par4", "par5", "par6", "par7", "par8")}
+    sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par2", "par3", "par4", "par5", "par6", "par7", "par8",
+                                                 "sellim2", "ston_fft2")}
     d.update(t)
     iq = make_input(d).astype(np.float64)
     N1 = 1 << d["n1"]

@@ -22,7 +22,8 @@ def sellim_params(cfg, g):
                           fft1_first_point=int(sp[4]), fft1_last_point=int(sp[5]), fft1_first_inband=int(sp[6]),
                           fft1_last_inband=int(sp[7]), baseband_bw_fftxpts=int(sp[8]), sellim_par2=int(sp[9]), sellim_par3=int(sp[10]),
                           sellim_par4=int(sp[11]), sellim_par5=int(sp[12]), sellim_par6=int(sp[13]), sellim_par7=int(sp[14]),
-                          sellim_par8=int(sp[15]), fft1_blocktime=float(sf[0]), blanker_ston_fft1=float(sf[1]), exact_stats=1)
+                          sellim_par8=int(sp[15]), fft1_blocktime=float(sf[0]), blanker_ston_fft1=float(sf[1]), exact_stats=1,
+                          **({"blanker_ston_fft2": float(g["sellim2_fparams"][0]), "fft2_blocktime": float(g["sellim2_fparams"][1])} if "sellim2_fparams" in g else {}))
 
 
 def run(open_fn, name, g):
@@ -33,8 +34,9 @@ def run(open_fn, name, g):
     api.timf1_write(iq)
     api.set_mix1_selfreq(d["fq"])
     par = sellim_params(cfg, g)
-    trace, blks, low = [], [], []
-    cnt = 0
+    trace, blks, low, trace2, blks2, amp = [], [], [], [], [], []
+    cnt = cnt2 = 0
+    both = "liminfo_trace2" in g
     for b in range(d["nblk"]):
         api.fft1_b(1), api.fft1_c(1), api.make_timf2(1)
         api.first_noise_blanker()
@@ -47,7 +49,14 @@ def run(open_fn, name, g):
             cnt = api.p.fft1_liminfo_cnt
             trace.append(api.get_liminfo())
             blks.append(b)
-    return dict(api=api, cfg=cfg, d=d, trace=np.array(trace), blks=np.array(blks), low=np.array(low),
+            amp.append(api.liminfo_amplitude_factor())
+        if both and api.p.fft2_liminfo_cnt != cnt2:              # wcw.c:1129-1133
+            api.fft2_update_liminfo(par)
+            cnt2 = api.p.fft2_liminfo_cnt
+            trace2.append(api.get_liminfo())
+            blks2.append(b)
+            amp.append(api.liminfo_amplitude_factor())
+    return dict(api=api, cfg=cfg, d=d, trace=np.array(trace), blks=np.array(blks), low=np.array(low), trace2=np.array(trace2), blks2=np.array(blks2), amp=np.array(amp, np.float32),
                 timf2=api.export(abi.RING_TIMF2_FLOAT), pwr=api.export(abi.RING_TIMF2_PWR), timf3=api.export(abi.RING_TIMF3_FLOAT),
                 slowsum=api.export(abi.RING_FFT1_SLOWSUM))
 
@@ -67,6 +76,19 @@ def compare(out, g, tol, value_tol=2e-6):
     assert rep["value_err"] <= value_tol, rep
     it = g["itrace"].reshape(-1, 16)
     assert np.array_equal(out["low"], it[:, 11]), "fft1_lowlevel_points trace differs"
+    if "amp_factor_trace" in g:                             # liminfo_amplitude_factor after every update (selfreq_liminfo, sellim.c:119-155)
+        ra = g["amp_factor_trace"][:len(out["amp"])]
+        rep["amp_factor_err"] = float(np.max(np.abs(out["amp"] - ra))) if len(ra) else 0.0
+        assert len(ra) == len(out["amp"]) and rep["amp_factor_err"] <= 1e-6, rep
+    if "liminfo_trace2" in g:                               # fft2_update_liminfo's tables
+        ref2 = g["liminfo_trace2"].reshape(-1, n1)
+        assert np.array_equal(out["blks2"], g["liminfo_trace2_blk"][:len(out["blks2"])]) and len(out["blks2"]) == ref2.shape[0]
+        rep["updates2"] = int(ref2.shape[0])
+        rep["pattern_mismatch_bins2"] = int(np.sum(np.sign(out["trace2"]) != np.sign(ref2)))
+        assert rep["pattern_mismatch_bins2"] == 0, rep
+        pos2 = ref2 > 0
+        rep["value_err2"] = float(np.max(np.abs(out["trace2"][pos2] - ref2[pos2]) / ref2[pos2])) if pos2.any() else 0.0
+        assert rep["value_err2"] <= value_tol, rep
 
     def rel(a, b):
         a, b = a.astype(np.float64), b.astype(np.float64)
