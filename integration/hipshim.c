@@ -163,25 +163,85 @@ void hip_first_noise_blanker(void)
 
 /* fft1_update_liminfo (sellim.c:738): the table is formed on the device from the resident fft1_sumsq / fft1_slowsum; the host's
    liminfo[] is refreshed for the high-resolution graph, which draws it */
+static void hip_sellim_par(lrh_sellim *par, lrh_ptrs *q)
+{
+  memset(par, 0, sizeof *par); memset(q, 0, sizeof *q);
+  par->struct_size = (int)sizeof *par;
+  par->sellim_maxlevel = genparm[SELLIM_MAXLEVEL]; par->spek_avgnum = wg.spek_avgnum;
+  par->fft1_blocktime = fft1_blocktime; par->blanker_ston_fft1 = hg.blanker_ston_fft1;
+  par->sellim_par2 = hg.sellim_par2; par->sellim_par3 = hg.sellim_par3; par->sellim_par4 = hg.sellim_par4; par->sellim_par5 = hg.sellim_par5;
+  par->sellim_par6 = hg.sellim_par6; par->sellim_par7 = hg.sellim_par7; par->sellim_par8 = hg.sellim_par8;
+  par->liminfo_group_points = liminfo_group_points;
+  par->fft1_first_point = fft1_first_point; par->fft1_last_point = fft1_last_point;
+  par->fft1_first_inband = fft1_first_inband; par->fft1_last_inband = fft1_last_inband;
+  par->baseband_bw_fftxpts = baseband_bw_fftxpts; par->ston_scale = mg.scale_type == MG_SCALE_STON;
+  par->exact_stats = 0;
+  par->blanker_ston_fft2 = hg.blanker_ston_fft2; par->fft2_blocktime = fft2_blocktime;
+  par->fft1_desired = (fft1_calibrate_flag & CALAMP) == CALAMP ? fft1_desired : NULL;     /* sellim.c:134-143 */
+  q->fft1_sumsq_pa = fft1_sumsq_pa;
+  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);             /* selfreq_liminfo protects the selected passband (sellim.c:38) */
+}
+static void hip_liminfo_back(void)
+{
+  /* the host's liminfo[] for the high-resolution graph; nothing to upload later.  liminfo_amplitude_factor stays on the device,
+     where the linear blanker reads it (the host copy serves the GUI's "skip the smart blanker" test, sellim.c:156) */
+  if (lrh_get_liminfo(hip_rx, liminfo) == 0) memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
+  lrh_get_liminfo_amplitude_factor(hip_rx, &liminfo_amplitude_factor);
+}
 void hip_fft1_update_liminfo(void)
 {
   lrh_sellim par;
   lrh_ptrs q;
-  memset(&par, 0, sizeof par); memset(&q, 0, sizeof q);
-  par.struct_size = (int)sizeof par;
-  par.sellim_maxlevel = genparm[SELLIM_MAXLEVEL]; par.spek_avgnum = wg.spek_avgnum;
-  par.fft1_blocktime = fft1_blocktime; par.blanker_ston_fft1 = hg.blanker_ston_fft1;
-  par.sellim_par2 = hg.sellim_par2; par.sellim_par3 = hg.sellim_par3; par.sellim_par4 = hg.sellim_par4; par.sellim_par5 = hg.sellim_par5;
-  par.sellim_par6 = hg.sellim_par6; par.sellim_par7 = hg.sellim_par7; par.sellim_par8 = hg.sellim_par8;
-  par.liminfo_group_points = liminfo_group_points;
-  par.fft1_first_point = fft1_first_point; par.fft1_last_point = fft1_last_point;
-  par.fft1_first_inband = fft1_first_inband; par.fft1_last_inband = fft1_last_inband;
-  par.baseband_bw_fftxpts = baseband_bw_fftxpts; par.ston_scale = mg.scale_type == MG_SCALE_STON;
-  par.exact_stats = 0;
-  q.fft1_sumsq_pa = fft1_sumsq_pa;
-  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);             /* selfreq_liminfo protects the selected passband (sellim.c:38) */
+  hip_sellim_par(&par, &q);
   if (lrh_fft1_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1471); return; }
-  if (lrh_get_liminfo(hip_rx, liminfo) == 0) memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);   /* nothing to upload later */
+  hip_liminfo_back();
+}
+/* fft2_update_liminfo (sellim.c:159; the library builds the reference's setting hg.sellim_par1 = 2, other values keep the host code) */
+int hip_fft2_update_liminfo(void)
+{
+  lrh_sellim par;
+  lrh_ptrs q;
+  if (hg.sellim_par1 != 2) return 0;
+  hip_sellim_par(&par, &q);
+  if (lrh_fft2_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1473); return 1; }
+  hip_liminfo_back();
+  return 1;
+}
+
+/* the linear blanker's tables follow hg.clever_bln_mode (hires_graph.c:496-498 toggles it; init_blanker, buf.c:1771, built them) */
+static void hip_blanker_tables(void)
+{
+  lrh_blanker_tables t;
+  int i;
+  if (hg.clever_bln_mode == hip_clever_mode) return;
+  hip_clever_mode = hg.clever_bln_mode;
+  if (hg.clever_bln_mode == 0 || refpul_size == 0) { lrh_set_blanker_tables(hip_rx, NULL); return; }
+  memset(&t, 0, sizeof t);
+  t.clever_bln_mode = hg.clever_bln_mode; t.clever_bln_factor = hg.clever_bln_factor; t.clever_bln_limit = hg.clever_bln_limit;
+  t.refpul_size = refpul_size; t.largest_blnfit = largest_blnfit; t.liminfo_amplitude_factor = liminfo_amplitude_factor;
+  for (i = 0; i < BLN_INFO_SIZE && i < LRH_BLN_INFO_SIZE; i++) { t.bln[i].size = bln[i].size; t.bln[i].rest = bln[i].rest; t.bln[i].avgmax = bln[i].avgmax; }
+  t.refpulse = blanker_refpulse; t.phasefunc = blanker_phasefunc; t.pulindex = blanker_pulindex;
+  if (lrh_set_blanker_tables(hip_rx, &t) != 0) lirerr(1472);
+}
+
+void hip_first_noise_blanker(void)
+{
+  lrh_ptrs q;
+  memset(&q, 0, sizeof q);
+  q.timf2p_fit = timf2p_fit; q.timf2_pn2 = timf2_pn2; q.timf2_pa = timf2_pa; q.timf2_blanker_points = timf2_blanker_points;
+  q.blanker_info_update_counter = blanker_info_update_counter; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
+  hip_blanker_tables();
+  if (lrh_first_noise_blanker(hip_rx, &q) != 0) { lirerr(1468); return; }
+  timf2p_fit = q.timf2p_fit; timf2_pn2 = q.timf2_pn2; timf2_blanker_points = q.timf2_blanker_points;     /* blank1.c:1458-1476 */
+  if (q.blanker_info_update_counter == 0 && blanker_info_update_counter != 0) {   /* thresholds were updated (blank1.c:1550-1601) */
+    lrh_blanker_state bs;
+    if (lrh_get_blanker_state(hip_rx, &bs) == 0) {
+      timf2_noise_floor = bs.timf2_noise_floor; hg.stupid_bln_limit = bs.stupid_bln_limit;
+      stupid_blanker_rate = bs.stupid_blanker_rate; clever_blanker_rate = bs.clever_blanker_rate; hg.clever_bln_limit = bs.clever_bln_limit;
+      timf2_despiked_pwr[0] = bs.timf2_despiked_pwr[0]; timf2_despiked_pwr[1] = bs.timf2_despiked_pwr[1];
+    }
+  }
+  blanker_info_update_counter = q.blanker_info_update_counter;
 }
 
 void hip_make_fft2(void)

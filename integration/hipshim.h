@@ -18,6 +18,7 @@ void hip_fft1_c(void);               /* stand-ins for the stage functions of the
 void hip_make_timf2(void);
 void hip_first_noise_blanker(void);   /* also installs / removes the linear blanker's tables when hg.clever_bln_mode changes */
 void hip_fft1_update_liminfo(void);   /* selective limiter on the device-resident power spectra (sellim.c:738)             */
+int  hip_fft2_update_liminfo(void);   /* second limiter on the fft2 power sums (sellim.c:159); 0: not taken (hg.sellim_par1 != 2) */
 void hip_make_fft2(void);
 void hip_fft2_mix1_fixed(void);
 #endif

@@ -115,6 +115,7 @@ def edit_mix1(L):
 def edit_sellim(L):
     after_last_include(L)
     func_top(L, r"^void fft1_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_update_liminfo();return;}\n")
+    func_top(L, r"^void fft2_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP && hip_fft2_update_liminfo())return;\n")
 
 
 def edit_rxin(L):

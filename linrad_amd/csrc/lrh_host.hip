@@ -39,6 +39,7 @@ hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
+hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
 hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
@@ -138,6 +139,7 @@ struct lrh_ctx {
   // linear ("clever") blanker: tables of lrh_set_blanker_tables, per-sample flags and candidate bit words
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
+  float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
@@ -337,7 +339,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -574,7 +576,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     }
     A(upload(c, c->d_wf_itab, itab.data(), itab.size()));
     BlankState bs; memset(&bs, 0, sizeof bs);                          // buf.c:418-431, hires_graph.c:1157-1162
-    bs.noise_floor = cfg->timf2_noise_floor; bs.despiked_pwr[0] = (float)cfg->timf2_noise_floor; bs.despiked_pwrinc[0] = 1;
+    bs.noise_floor = cfg->timf2_noise_floor; bs.amp_factor = 1.f; bs.despiked_pwr[0] = (float)cfg->timf2_noise_floor; bs.despiked_pwrinc[0] = 1;
     bs.limit = (unsigned int)((float)cfg->timf2_noise_floor * cfg->stupid_bln_factor);
     A(upload(c, c->d_bst, &bs, 1));
   }
@@ -678,22 +680,10 @@ static int sellim_install(lrh_ctx *c, unsigned seq)
   if (seq == c->sel_seq) c->sel_pending = false;
   return LRH_OK;
 }
-int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+// what both limiter kernels need from the parameter block and the context
+static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
 {
-  LRH_ENTER(c);
-  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
-  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (c->fft1_big) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 16384 (power block and table of one transform in LDS); use lrh_set_liminfo");
-  if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
-      c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
-  if (!c->h_sel_low) {
-    if (hipHostMalloc((void **)&c->h_sel_low, 3 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
-    for (hipEvent_t &e : c->ev_sel_slot) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
-  if (c->sel_seq >= 2) { const int rc = sellim_install(c, c->sel_seq - 1); if (rc) return rc; }      // the count of the update before the last (unless exact_stats)
-  SellimArgs a;
-  a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
+  SellimArgs a; memset(&a, 0, sizeof a);
   a.slowsum = c->d_slowsum; a.yfac = c->d_yfac; a.liminfo = c->d_liminfo; a.old_liminfo = c->d_old_liminfo; a.tmp = c->d_sel_tmp;
   a.wait = c->d_sel_wait; a.pack = c->d_pack_cur; a.st = c->d_sel_st;
   a.n = c->N1; a.n2 = c->N2; a.avg1 = c->cfg.fft_avg1num; a.r0 = c->fft1_big ? 0 : (c->cfg.fft1_n >= 10 ? 16 : 4);
@@ -703,17 +693,96 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   a.first_point = q->fft1_first_point; a.last_point = q->fft1_last_point; a.first_inband = q->fft1_first_inband; a.last_inband = q->fft1_last_inband;
   a.bw_fftxpts = q->baseband_bw_fftxpts; a.ston_scale = q->ston_scale;
   a.selfreq = c->ms.mix1_selfreq; a.points_per_hz = c->cfg.fftx_points_per_hz; a.second_fft = c->cfg.second_fft_enable;
+  a.bst = c->d_bst; a.desired = nullptr; a.desired_totsum = 0;
+  if (q->fft1_desired) {                                  // calibrated amplitude factor: the table travels once (and again when it changes)
+    if (c->h_sel_desired.size() != (size_t)c->N1 || memcmp(c->h_sel_desired.data(), q->fft1_desired, 4 * (size_t)c->N1)) {
+      c->h_sel_desired.assign(q->fft1_desired, q->fft1_desired + c->N1);
+      if (!c->d_sel_desired) { const int rc = dev_alloc(c, &c->d_sel_desired, c->N1); if (rc) return rc; }
+      HIPCHK(c, hipStreamSynchronize(c->stream2));
+      HIPCHK(c, hipMemcpyAsync(c->d_sel_desired, c->h_sel_desired.data(), 4 * (size_t)c->N1, hipMemcpyHostToDevice, c->stream2));
+      float tot = 0;
+      for (int i = 0; i < c->N1; i++) tot += q->fft1_desired[i] * q->fft1_desired[i];
+      c->sel_desired_totsum = tot;
+    }
+    a.desired = c->d_sel_desired; a.desired_totsum = c->sel_desired_totsum;
+  }
+  a.powersum2 = c->d_powersum2; a.ston2 = q->blanker_ston_fft2; a.blocktime2 = q->fft2_blocktime; a.wf_avgnum = c->cfg.waterfall_avgnum;
+  *out = a;
+  return LRH_OK;
+}
+// `which` 1: fft1_update_liminfo, 2: fft2_update_liminfo
+static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
+{
+  if (!c->h_sel_low) {
+    if (hipHostMalloc((void **)&c->h_sel_low, 3 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
+    for (hipEvent_t &e : c->ev_sel_slot) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (c->sel_seq >= 2) { const int rc = sellim_install(c, c->sel_seq - 1); if (rc) return rc; }      // the count of the update before the last (unless exact_stats)
+  SellimArgs a;
+  { const int rc = sellim_args(c, q, &a); if (rc) return rc; }
   hipStream_t S = c->stream2;
-  if (c->sums_stream != S || c->prof) {                       // sums on the main stream (serial order), or per-kernel timing: plain stream order
+  if (which == 1) {
+    a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
+    if (c->sums_stream != S || c->prof) {                       // sums on the main stream (serial order), or per-kernel timing: plain stream order
+      HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
+    } else if (c->timf2_done_valid) HIPCHK(c, hipStreamWaitEvent(S, c->ev_timf2_done, 0));
+  } else {
+    if (!c->d_sel_ftmp) { const int rc = dev_alloc(c, &c->d_sel_ftmp, c->N1); if (rc) return rc; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    a.tmp = c->d_sel_ftmp;
+    // the power sums come from the fft2 kernels (main stream) or the power-sum kernel (side stream): behind both
     HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
-  } else if (c->timf2_done_valid) HIPCHK(c, hipStreamWaitEvent(S, c->ev_timf2_done, 0));
-  { hipStream_t keep = c->cur; c->cur = S; { ProfScope ps(c, "sellim"); hipError_t e_ = launch_sellim(a, S); if (e_ != hipSuccess) { c->cur = keep; return fail(c, LRH_EDEVICE, "launch_sellim", e_); } } c->cur = keep; }
+  }
+  { hipStream_t keep = c->cur; c->cur = S;
+    { ProfScope ps(c, "sellim"); hipError_t e_ = which == 1 ? launch_sellim(a, S) : launch_sellim2(a, S);
+      if (e_ != hipSuccess) { c->cur = keep; return fail(c, LRH_EDEVICE, "launch_sellim", e_); } }
+    c->cur = keep; }
   c->sel_seq++;
   HIPCHK(c, hipMemcpyAsync(&c->h_sel_low[c->sel_seq % 3], &c->d_sel_st->low, sizeof(int), hipMemcpyDeviceToHost, S));
   HIPCHK(c, hipEventRecord(c->ev_sel_slot[c->sel_seq % 3], S));
   HIPCHK(c, hipEventRecord(c->ev_sel, S));
   c->sel_pending = true; c->sel_table_pending = true; c->pack_prev_stale = true; c->have_liminfo = true;
   if (q->exact_stats) return sellim_install(c, c->sel_seq);
+  return LRH_OK;
+}
+int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+{
+  LRH_ENTER(c);
+  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (c->fft1_big) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 16384 (power block and table of one transform in LDS); use lrh_set_liminfo");
+  if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
+      c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
+  return sellim_run(c, p, q, 1);
+}
+int lrh_fft2_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
+{
+  LRH_ENTER(c);
+  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (c->fft1_big || !c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1)
+    return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size <= 16384");
+  if (q->liminfo_group_points < 16 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->fft1_first_inband < 0 ||
+      q->sellim_maxlevel < 1 || !(q->fft1_blocktime > 0)) return LRH_EINVAL;
+  return sellim_run(c, p, q, 2);
+}
+int lrh_get_liminfo_amplitude_factor(lrh_ctx *c, float *f)
+{
+  LRH_ENTER(c);
+  if (!c || !f) return LRH_EINVAL;
+  if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
+  HIPCHK(c, hipMemcpyAsync(f, (char *)c->d_bst + offsetof(BlankState, amp_factor), sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+int lrh_set_liminfo_amplitude_factor(lrh_ctx *c, float f)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, amp_factor), &f, sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
 int lrh_get_liminfo(lrh_ctx *c, float *dst)
@@ -757,6 +826,7 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
   HIPCHK(c, hipMemsetAsync(c->d_bln_flag, 0, c->cfg.timf2pow_size, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_bln_cand, 0, c->cfg.timf2pow_size / 8, c->stream));
   HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, clever_limit), &t->clever_bln_limit, sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, amp_factor), &t->liminfo_amplitude_factor, sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->bt = *t; c->bt.refpulse = nullptr; c->bt.phasefunc = nullptr; c->bt.pulindex = nullptr;
   c->clever_on = true;

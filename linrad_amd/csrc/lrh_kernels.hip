@@ -2172,7 +2172,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
         if (j < 0) j = 0;
         if (j >= LRH_MAX_REFPULSES_K) j = LRH_MAX_REFPULSES_K - 1;
         const int mrp = 2 * a.pulindex[j] * rs;
-        c1 *= s_in[2 * imax] * a.amp_factor; c2 *= s_in[2 * imax] * a.amp_factor;
+        { const float af = s->amp_factor; c1 *= s_in[2 * imax] * af; c2 *= s_in[2 * imax] * af; }     // liminfo_amplitude_factor (blank1.c:143-144)
         __syncthreads();
         for (int jj = lane; jj <= sub; jj += 64) {
           const int q = W - sub / 2 + jj, kk = rs - sub + 2 * jj;
@@ -2314,6 +2314,55 @@ __device__ __forceinline__ float sl_three_smallest(const float *v, int ia, int i
     }
   }
   return (float)(0.3333333 * (t1 + t2 + t3));
+}
+
+// selfreq_liminfo (sellim.c:38-157, float path): the selected passband keeps its own routing; then liminfo_amplitude_factor,
+// what the strong bins take away from a pulse's amplitude (:108-155).  Thread 0; B = the table in LDS.
+__device__ __forceinline__ void sl_selfreq(const SellimArgs &a, float *B, int tid)
+{
+  const int N = a.n;
+  if (tid == 0 && a.selfreq >= 0) {
+    int ia = (int)(a.selfreq * a.points_per_hz);
+    int k = (int)(a.bw_fftxpts * .7);
+    if (a.par6 == 0) k += 3;
+    if (a.second_fft) { int ratio = a.n2 / N; if (ratio < 1) ratio = 1; ia /= ratio; k /= ratio; if (k < 3) k = 3; }
+    int ib = ia + k; ia -= k;
+    if (ia < 0) ia = 0;
+    if (ib >= N) ib = N - 1;
+    a.st->sel_ia = ia; a.st->sel_ib = ib;
+    if (a.ston_scale) { for (int i = ia; i <= ib; i++) B[i] = -1; }
+    else {
+      float t1 = 0, t2 = 2;
+      for (int i = ia; i <= ib; i++) { if (B[i] < 0) t1 = 1; if (B[i] > 0 && t2 > B[i]) t2 = B[i]; }
+      bool skip = false;
+      if (t2 > 1) { if (t1 == 0) skip = true; t2 = 1; }
+      if (!skip) {
+        t1 = 1 / t2;
+        t1 *= (float)sqrt((double)(float)(a.n2 / N));
+        if (a.par5 == 2) t2 = -1;
+        if (a.par5 == 1) { if (t1 < 0x7fff / a.maxlevel) t2 = 0; }
+        if (a.par5 == 0) { if (t1 < 0x7ffff / a.maxlevel) t2 = 0; }
+        for (int i = ia; i <= ib; i++) B[i] = t2;
+      }
+    }
+  }
+  if (tid == 0) {
+    float f = 1.f;
+    if (a.second_fft) {
+      if (a.desired) {
+        float t1 = 0;
+        for (int i = a.first_point; i <= a.last_point; i++) if (B[i] != 0) t1 += a.desired[i] * a.desired[i];
+        f = a.desired_totsum / (a.desired_totsum - t1);
+      } else {
+        int k = 0;
+        for (int i = a.first_inband; i <= a.last_inband; i++) if (B[i] != 0) k++;
+        const int n = a.last_inband - a.first_inband + 1;
+        f = (float)(n) / (n - k);
+      }
+    }
+    if (f > 2) f = 0;
+    a.bst->amp_factor = f;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
@@ -2511,37 +2560,125 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
     for (int i = tid; i < N; i += 256) a.tmp[i] = A[i];
     __syncthreads();
   }
-  // ---- selfreq_liminfo (sellim.c:38-157, float path): the selected passband keeps its own routing
-  if (tid == 0 && a.selfreq >= 0) {
-    int ia = (int)(a.selfreq * a.points_per_hz);
-    int k = (int)(a.bw_fftxpts * .7);
-    if (a.par6 == 0) k += 3;
-    if (a.second_fft) { int ratio = a.n2 / N; if (ratio < 1) ratio = 1; ia /= ratio; k /= ratio; if (k < 3) k = 3; }
-    int ib = ia + k; ia -= k;
-    if (ia < 0) ia = 0;
-    if (ib >= N) ib = N - 1;
-    a.st->sel_ia = ia; a.st->sel_ib = ib;
-    if (a.ston_scale) { for (int i = ia; i <= ib; i++) B[i] = -1; }
-    else {
-      float t1 = 0, t2 = 2;
-      for (int i = ia; i <= ib; i++) { if (B[i] < 0) t1 = 1; if (B[i] > 0 && t2 > B[i]) t2 = B[i]; }
-      bool skip = false;
-      if (t2 > 1) { if (t1 == 0) skip = true; t2 = 1; }
-      if (!skip) {
-        t1 = 1 / t2;
-        t1 *= (float)sqrt((double)(float)(a.n2 / N));
-        if (a.par5 == 2) t2 = -1;
-        if (a.par5 == 1) { if (t1 < 0x7fff / a.maxlevel) t2 = 0; }
-        if (a.par5 == 0) { if (t1 < 0x7ffff / a.maxlevel) t2 = 0; }
-        for (int i = ia; i <= ib; i++) B[i] = t2;
-      }
-    }
-  }
+  sl_selfreq(a, B, tid);
   __syncthreads();
   for (int i = tid; i < N; i += 256) {
     a.old_liminfo[i] = B[i];
     a.liminfo[i] = (i < 2 || i >= N - 2) ? 0.f : B[i];       // sellim.c:1152-1155
   }
+}
+
+// fft2_update_liminfo, sellim.c:159-736, hg.sellim_par1 = 2 (:535-731).  Per fft1 bin the mean of the summed fft2 power over the
+// bin's width (A), group statistics -> global noise floor (thread 0 adds the groups in order: float sums), the neighbour fix-up
+// next to strong bins (serial: it reads what it has just lowered), thinning of an overgrown table, marking of everything within two
+// bins of power above 0.5 * ston * floor.  A persists between calls like the reference's fftf_tmp (zero outside the passband).
+__global__ __launch_bounds__(256) void k_sellim2(SellimArgs a)
+{
+  extern __shared__ float sm[];
+  const int N = a.n, tid = threadIdx.x, nn = a.n2 / a.n, gp = a.group_points, groups = N / gp;
+  float *A = sm + 8;
+  float *B = A + N + 16;
+  float *reg_min = B + N + 8, *reg_ston = reg_min + groups + 1, *reg_noise = reg_ston + groups + 1;   // 3 N/16 + 3 <= N/4 + 8
+  __shared__ float s_t1; __shared__ int s_go, s_k;
+  for (int i = tid; i < N; i += 256) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
+  for (int i = tid; i < 8; i += 256) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
+  __syncthreads();
+  for (int i = a.first_point + tid; i < a.last_point; i += 256) {
+    float t1 = 0;
+    for (int j = nn * i; j < nn * i + nn; j++) t1 += a.powersum2[j];
+    A[i] = t1 * a.yfac[i] / nn;
+  }
+  __syncthreads();
+  for (int g = tid; g < groups; g += 256) {
+    const int ia = g * gp, ib = ia + gp;
+    float t1 = 0;
+    for (int j = ia; j < ib; j++) t1 += A[j];
+    t1 /= gp;
+    int k = 0; float t3 = LRH_SL_BIG, t2 = 0; t1 *= 0.001F;
+    for (int j = ia; j < ib; j++) if (A[j] > t1) { k++; if (A[j] < t3) t3 = A[j]; if (A[j] > t2) t2 = A[j]; }
+    reg_min[g] = k < 2 ? -1.f : t3;
+    reg_ston[g] = t2 / t3;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s_go = 0;                                            // 0: return without selfreq (sellim.c:604); 1: fft2updx; 2: all the way
+    float t1 = 0; int k = 0;
+    for (int g = 0; g < groups; g++) if (reg_ston[g] < 2000.F) { t1 += reg_min[g]; k++; }
+    if (k != 0) {
+      s_go = 1;
+      t1 /= k;
+      float gnf = 0; k = 0;
+      for (int g = 0; g < groups; g++) if (reg_min[g] > 0.03F * t1 && reg_min[g] < 30.F * t1) { gnf += reg_min[g]; k++; }
+      if (k >= 3) { gnf /= k; s_t1 = 5 * gnf; s_go = 2; }
+    }
+  }
+  __syncthreads();
+  if (s_go == 2) {
+    const float lim5 = s_t1;
+    for (int g = tid; g < groups; g += 256) {
+      const int ia = g * gp, ib = ia + gp;
+      float t2 = 0; int k = 0;
+      for (int j = ia; j < ib; j++) if (A[j] < lim5) { k++; t2 += A[j]; }
+      reg_noise[g] = k > 2 ? t2 / k : -1.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_go = 1;
+      float t1 = 0; int k = 0;
+      for (int g = 0; g < groups; g++) if (reg_noise[g] > 0) { k++; t1 += reg_noise[g]; }
+      if (k >= 3) {
+        t1 /= k;
+        float gnf = 0; k = 0;
+        for (int g = 0; g < groups; g++) if (reg_noise[g] > 0.1F * t1 && reg_noise[g] < 10.F * t1) { gnf += reg_noise[g]; k++; }
+        if (k >= 3) { gnf /= k; s_t1 = (float)(0.5 * a.ston2 * gnf); s_go = 2; }
+      }
+    }
+    __syncthreads();
+  }
+  if (s_go == 2) {
+    const float t1 = s_t1;
+    int ia = a.first_point; if (ia < 2) ia = 2;
+    int ib = a.last_point; if (ib < N - 2) ib = N - 2;   // as written (sellim.c:668-669)
+    if (tid == 0) {
+      int k = 0;
+      for (int i = ia; i < ib; i++) {
+        if (B[i] != 0) {
+          if (B[i - 1] == 0 && A[i - 1] > A[i - 2]) A[i - 1] = A[i - 2];
+          if (B[i + 1] == 0 && A[i + 1] > A[i + 2]) A[i + 1] = A[i + 2];
+          k++;
+        }
+      }
+      s_k = k;
+    }
+    __syncthreads();
+    if (s_k > (ib - ia) / 4) {
+      __syncthreads();
+      if (tid == 0) s_k = 0;
+      __syncthreads();
+      int k = 0;
+      for (int i = ia + tid; i < ib; i += 256) { if (B[i] < 0 && A[i] < t1) { B[i] = 0; a.wait[i] = 0; } if (B[i] != 0) k++; }
+      if (k) atomicAdd(&s_k, k);
+      __syncthreads();
+      if (s_k > (ib - ia) / 4) {
+        const float t2 = 10.F * t1;
+        for (int i = ia + tid; i < ib; i += 256) if (B[i] < 0 && A[i] < t2) { B[i] = 0; a.wait[i] = 0; }
+      }
+      __syncthreads();
+    }
+    const unsigned wn = (unsigned)(1 + (1 + (a.blocktime2 * a.wf_avgnum)) / (a.avg1 * a.blocktime));
+    const unsigned char wait_n = (unsigned char)(wn > 255u ? 255u : wn);
+    for (int i = ia + tid; i < ib; i += 256)               // the fifth term repeats i-2 in the reference (sellim.c:723)
+      if (2. * A[i - 2] > t1 || A[i - 1] > t1 || A[i] > t1 || A[i + 1] > t1 || 2. * A[i - 2] > t1) {
+        if (B[i] == 0) B[i] = -1;
+        a.wait[i] = wait_n;
+      }
+    __syncthreads();
+  }
+  for (int i = tid; i < N; i += 256) a.tmp[i] = A[i];
+  if (s_go == 0) return;
+  sl_selfreq(a, B, tid);
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
 }
 
 // liminfo floats -> the routing words of k_timf2 (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count
@@ -2575,6 +2712,16 @@ hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
   if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_sellim, dim3(1), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
+  return hipGetLastError();
+}
+hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
+{
+  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute((const void *)k_sellim2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
+  if (lds > 160 * 1024 - 64 || a.group_points < 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(256), lds, st, a);
   hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
   return hipGetLastError();
 }

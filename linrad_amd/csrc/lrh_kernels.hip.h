@@ -90,6 +90,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   unsigned int clever_limit; float clever_rate; int fitted_acc; int last_fitted; int last_rejected;
   int clever_out[3];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected
   int clever_serial_calls;   // calls that fell back to the one-wave replay
+  float amp_factor;          // liminfo_amplitude_factor: the limiter kernels keep it current, k_clever scales its reference pulse with it
 };
 struct BlankArgs {
   float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
@@ -239,8 +240,13 @@ struct SellimArgs {
   int maxlevel, spek_avgnum; float blocktime, ston;
   int par2, par3, par4, par5, par6, par7, par8, group_points, first_point, last_point, first_inband, last_inband, bw_fftxpts, ston_scale;
   double selfreq; float points_per_hz; int second_fft;
+  // liminfo_amplitude_factor (selfreq_liminfo, sellim.c:108-155) goes to the blanker's device state; calibrated form with `desired`
+  BlankState *bst; const float *desired; float desired_totsum;
+  // fft2_update_liminfo (k_sellim2): summed fft2 power spectrum, hg.blanker_ston_fft2, seconds per fft2 transform, waterfall_avgnum
+  const float *powersum2; float ston2, blocktime2; int wf_avgnum;
 };
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
+hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
 hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream);
 }
 

@@ -20,7 +20,8 @@ from refdump import load_dump  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["bln", "bln_ints", "bln_fparams", "blanker_refpulse", "blanker_phasefunc", "blanker_pulindex", "timf2_float", "timf2_pwr_float",
-        "fft2_float", "fft2_powersum_float", "timf3_float", "trace", "itrace", "mixtrace", "final", "wf_lines"]
+        "fft2_float", "fft2_powersum_float", "timf3_float", "trace", "itrace", "mixtrace", "final", "wf_lines",
+        "liminfo_trace", "liminfo_trace_blk", "sellim_params", "sellim_fparams", "amp_factor_trace"]
 
 
 def main():
@@ -32,7 +33,10 @@ def main():
             iq.tofile(fi)
             lim.tofile(fl)
             des.tofile(fd)
-            r = subprocess.run([HARNESS] + harness_args(d, fi, fl, fo) + ["clever=1", f"desired={fd}", f"clever_factor={cl['clever_factor']}"],
+            args = harness_args(d, fi, fl, fo)
+            if cl["sellim"]:                 # the limiter builds the table: no initial liminfo file
+                args = [a for a in args if not a.startswith("liminfo=")] + ["sellim=1"] + [f"{k}={v}" for k, v in cl["sellim"].items()]
+            r = subprocess.run([HARNESS] + args + ["clever=1", f"desired={fd}", f"clever_factor={cl['clever_factor']}"],
                                stderr=subprocess.PIPE, text=True)
             assert r.returncode == 0, r.stderr
             ref = load_dump(fo)
@@ -45,6 +49,8 @@ def main():
         print(name, os.path.getsize(path) // 1024, "KiB;", r.stderr.strip().splitlines()[0][:150])
         print("   bln", ref["bln"].reshape(-1, 4)[:, :3].tolist())
         print("   fitted per period", tr[:, 8].tolist()[::4], "clever rate", sorted(set(np.round(tr[:, 7], 3)))[-3:], "limit", sorted(set(tr[:, 6]))[:4])
+        if "amp_factor_trace" in out:
+            print("   amplitude factors", sorted(set(np.round(out["amp_factor_trace"], 4).tolist()))[:8])
         print("   cleared", it[:, 5].tolist()[::8], "pfit-pend lag", sorted(set(((it[:, 0] // 4 - it[:, 1]) & (ref['timf2_pwr_float'].size - 1)).tolist()))[:6])
 
 

@@ -358,6 +358,13 @@ CLEVER = {
 }
 
 
+# linear blanker and selective limiter together: selfreq_liminfo's liminfo_amplitude_factor (sellim.c:119-155) scales the pulse the
+# blanker subtracts (blank1.c:143-144), so the two stages are coupled through one float that changes with every limiter update
+CLEVER["clever_sellim_n10_n12"] = dict(base="n10_n12", nblk=120, blockpower_block=0, clever_factor=12.0, edge=0.18, pulses=70, pulse_seed=7, amp=(2500.0, 22000.0),
+                                       pairs=4, rects=2, pulse_period=0,
+                                       sellim=dict(maxlevel=12000, lim_groups=16, blocktime=0.0008, ston_fft1=30.0, bw_fftxpts=40))
+
+
 def clever_desired(n1, edge):
     """amplitude calibration target: flat passband, raised-cosine skirts over `edge` of the band at either side (fft1 bin order)"""
     N1 = 1 << n1
@@ -374,6 +381,7 @@ def clever_case(name):
     t = dict(CLEVER[name])
     d = case_params(t.pop("base"))
     cl = {k: t.pop(k) for k in ("clever_factor", "edge", "pulses", "pulse_seed", "amp", "pairs", "rects")}
+    cl["sellim"] = t.pop("sellim", None)
     d.update(t)
     iq = make_input(d).astype(np.float64)
     N1 = 1 << d["n1"]
