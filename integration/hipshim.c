@@ -208,42 +208,6 @@ int hip_fft2_update_liminfo(void)
   return 1;
 }
 
-/* the linear blanker's tables follow hg.clever_bln_mode (hires_graph.c:496-498 toggles it; init_blanker, buf.c:1771, built them) */
-static void hip_blanker_tables(void)
-{
-  lrh_blanker_tables t;
-  int i;
-  if (hg.clever_bln_mode == hip_clever_mode) return;
-  hip_clever_mode = hg.clever_bln_mode;
-  if (hg.clever_bln_mode == 0 || refpul_size == 0) { lrh_set_blanker_tables(hip_rx, NULL); return; }
-  memset(&t, 0, sizeof t);
-  t.clever_bln_mode = hg.clever_bln_mode; t.clever_bln_factor = hg.clever_bln_factor; t.clever_bln_limit = hg.clever_bln_limit;
-  t.refpul_size = refpul_size; t.largest_blnfit = largest_blnfit; t.liminfo_amplitude_factor = liminfo_amplitude_factor;
-  for (i = 0; i < BLN_INFO_SIZE && i < LRH_BLN_INFO_SIZE; i++) { t.bln[i].size = bln[i].size; t.bln[i].rest = bln[i].rest; t.bln[i].avgmax = bln[i].avgmax; }
-  t.refpulse = blanker_refpulse; t.phasefunc = blanker_phasefunc; t.pulindex = blanker_pulindex;
-  if (lrh_set_blanker_tables(hip_rx, &t) != 0) lirerr(1472);
-}
-
-void hip_first_noise_blanker(void)
-{
-  lrh_ptrs q;
-  memset(&q, 0, sizeof q);
-  q.timf2p_fit = timf2p_fit; q.timf2_pn2 = timf2_pn2; q.timf2_pa = timf2_pa; q.timf2_blanker_points = timf2_blanker_points;
-  q.blanker_info_update_counter = blanker_info_update_counter; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
-  hip_blanker_tables();
-  if (lrh_first_noise_blanker(hip_rx, &q) != 0) { lirerr(1468); return; }
-  timf2p_fit = q.timf2p_fit; timf2_pn2 = q.timf2_pn2; timf2_blanker_points = q.timf2_blanker_points;     /* blank1.c:1458-1476 */
-  if (q.blanker_info_update_counter == 0 && blanker_info_update_counter != 0) {   /* thresholds were updated (blank1.c:1550-1601) */
-    lrh_blanker_state bs;
-    if (lrh_get_blanker_state(hip_rx, &bs) == 0) {
-      timf2_noise_floor = bs.timf2_noise_floor; hg.stupid_bln_limit = bs.stupid_bln_limit;
-      stupid_blanker_rate = bs.stupid_blanker_rate; clever_blanker_rate = bs.clever_blanker_rate; hg.clever_bln_limit = bs.clever_bln_limit;
-      timf2_despiked_pwr[0] = bs.timf2_despiked_pwr[0]; timf2_despiked_pwr[1] = bs.timf2_despiked_pwr[1];
-    }
-  }
-  blanker_info_update_counter = q.blanker_info_update_counter;
-}
-
 void hip_make_fft2(void)
 {
   lrh_ptrs q;
