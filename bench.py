@@ -281,7 +281,10 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         # blanker_ston_fft1 is a slider of the high-resolution graph (hires_graph.c:710).  The SURVEY 8d test signal carries 20000-LSB
         # impulses whose spectrum ripples across the band at 36 x the noise power; 30 keeps that ripple with the weak signal (51 bins
         # routed strong: the carriers and their skirts), the 4 of a quiet band would route 38 % of the bins
-        sel = default_sellim(cfg, fft1_blocktime=M1 / 160e6, blanker_ston_fft1=30.0, exact_stats=0)
+        sel = default_sellim(cfg, fft1_blocktime=M1 / 160e6, blanker_ston_fft1=30.0, exact_stats=0,
+                             blanker_ston_fft2=30.0, fft2_blocktime=(N2 // 2) / 160e6)
+        # inside lrh_wideband_dsp, at the end of every round: wideband_dsp's own limiter calls (wcw.c:1124-1133), once per pass of the loop
+        rx.wideband_limiter(sel, args.limiter2)
 
     def step():
         if coupled:
@@ -297,8 +300,6 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 rx.timf1_write_async(flat[:nb - first], 0)
             wr[0] += nb
         rx.wideband_dsp(args.batch * args.rounds, args.batch)
-        if sel is not None:
-            rx.fft1_update_liminfo(sel)
         if combine:
             narrow_tail()
         if use_dist:
@@ -322,7 +323,6 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         # spectra have been seen (sellim.c:866), until then the medium carriers stay in the weak stream and latch the blanker
         for _ in range(6):
             rx.wideband_dsp(args.batch, args.batch)
-            rx.fft1_update_liminfo(sel)
     for _ in range(warmup):
         step()
     barrier()
@@ -347,8 +347,9 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                         "wideband_dsp_cpu_ms_per_call": round(host["wideband_dsp_cpu"][0] / max(host["wideband_dsp_cpu"][1], 1), 4),
                         "staging_wait_ms_per_call": round(host["staging_wait"][0] / max(host["staging_wait"][1], 1), 4)},
            "samples_per_step": samples_per_step, "workload": workload_name(w, args.batch),
-           "routing": ("selective limiter on the device once per step (lrh_fft1_update_liminfo), strong bins now %d of %d" %
-                       (int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",
+           "routing": ("selective limiter on the device at the end of every round inside lrh_wideband_dsp (lrh_wideband_limiter: fft1_update_liminfo%s, "
+                       "wcw.c:1124-1133), strong bins now %d of %d" %
+                       (" + fft2_update_liminfo" if args.limiter2 else "", int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",
            "config_text": w["text"].format(N1=N1, N2=N2, Nm=N2 >> 6, N3=(1 << w["fft3_n"]) if w["fft3_n"] else 0,
                                            Nm2=(1 << w["mix2_n"]) if w["mix2_n"] else 0, rounds=args.rounds, batch=args.batch,
                                            samples=samples_per_step, world=world)}
@@ -361,8 +362,6 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         rx.profile_enable(2)
         for _ in range(nprof):
             rx.wideband_dsp(args.batch * args.rounds, args.batch)
-            if sel is not None:
-                rx.fft1_update_liminfo(sel)
             if combine:
                 k3 = rx.fft3_available()                   # keep the rings moving; the collective is not profiled here
                 while k3 > 0:
@@ -509,6 +508,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the second workload of the default run")
     ap.add_argument("--no-sellim", dest="sellim", action="store_false",
                     help="keep the hand-made routing table instead of running the selective limiter (lrh_fft1_update_liminfo) once per step")
+    ap.add_argument("--limiter2", action="store_true",
+                    help="also run the second limiter (fft2_update_liminfo) at the end of every round; lrh_wideband_dsp then leaves its one-round-late schedule")
     ap.add_argument("--stream-host", action="store_true",
                     help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
                          "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")

@@ -294,6 +294,12 @@ int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
 int lrh_fft2_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
 /* liminfo_amplitude_factor as selfreq_liminfo left it (the linear blanker scales its reference pulse with it, blank1.c:143-144);
    the limiter calls above keep it current on the device; a host that supplies tables itself (lrh_set_liminfo) sets it here */
+/* The limiter calls of wideband_dsp's loop (wcw.c:1124-1133) inside lrh_wideband_dsp: with parameters installed here every round
+   of that call ends with fft1_update_liminfo when fft1_c has completed an averaging period since the last look (fft1_liminfo_cnt),
+   and, with fft2_too, fft2_update_liminfo when make_fft2 has completed a waterfall line (fft2_liminfo_cnt) -- the reference's own
+   cadence in batched operation: once per pass of the loop, however many periods the pass covered.  par = NULL: off (the caller
+   makes the calls itself).  fft2_too keeps lrh_wideband_dsp off its one-round-late schedule (the fft2 of a round must have run). */
+int lrh_wideband_limiter(lrh_ctx *ctx, const lrh_sellim *par, int fft2_too);
 int lrh_get_liminfo_amplitude_factor(lrh_ctx *ctx, float *factor);   /* synchronous */
 int lrh_set_liminfo_amplitude_factor(lrh_ctx *ctx, float factor);
 int lrh_get_liminfo(lrh_ctx *ctx, float *liminfo /* N1 floats: the table in force */);     /* synchronous */

@@ -237,6 +237,7 @@ class StageAPI:
         self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
         self._proto("get_liminfo", [vp, fp])
         self._proto("fft2_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
+        self._proto("wideband_limiter", [vp, C.POINTER(LrhSellim), C.c_int])
         self._proto("get_liminfo_amplitude_factor", [vp, fp])
         self._proto("set_liminfo_amplitude_factor", [vp, C.c_float])
         self._proto("set_mix1_selfreq", [vp, C.c_double])
@@ -375,6 +376,10 @@ class StageAPI:
     def fft1_update_liminfo(self, par):
         """one run of the selective limiter on the device-resident spectra (sellim.c:738-1157), see include/linrad_hip.h"""
         self._chk(self._f("fft1_update_liminfo")(self.ctx, C.byref(self.p), C.byref(par)), "fft1_update_liminfo")
+
+    def wideband_limiter(self, par=None, fft2_too=False):
+        """the limiter calls of wideband_dsp's loop (wcw.c:1124-1133) inside every round of wideband_dsp; None: off"""
+        self._chk(self._f("wideband_limiter")(self.ctx, C.byref(par) if par is not None else None, int(bool(fft2_too))), "wideband_limiter")
 
     def fft2_update_liminfo(self, par):
         """fft2_update_liminfo (sellim.c:159, par1 = 2) on the device-resident fft2 power sums"""

@@ -82,6 +82,7 @@ struct lrh_ctx {
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
   hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
   hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; bool in_pending = false, fft1_read_valid = false;
+  hipStream_t stream_sel = nullptr;  // the limiter kernels: one workgroup for ~0.5 ms, kept off the side stream (the blanker of the next round queues there)
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
   hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
@@ -90,6 +91,8 @@ struct lrh_ctx {
   // fft1_c's power sums inside k_timf2 (lrh_wideband_dsp, sin^2 window): fft1_c parks its arguments here, make_timf2
   // picks them up, the join of split groups and the slow average follow from ss_queue
   bool fuse_sumsq = true;            // LRH_FUSE_SUMSQ=0: separate k_sumsq pass
+  bool sums_on_main = false;         // LRH_SUMS_MAIN (default: on for fft2_size <= 16384), see lrh_wideband_dsp
+  int spare_cus = 0;                 // LRH_SPARE_CUS: see persistent_grid (used while lrh_wideband_limiter is installed; measured: no gain, 8 spare units cost 7 % of k_fft1 / k_timf2)
   bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
@@ -139,6 +142,7 @@ struct lrh_ctx {
   // linear ("clever") blanker: tables of lrh_set_blanker_tables, per-sample flags and candidate bit words
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
+  lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
@@ -155,7 +159,7 @@ struct lrh_ctx {
   int *h_sel_low = nullptr; hipEvent_t ev_sel = nullptr, ev_sel_slot[3] = {}; unsigned sel_seq = 0; bool sel_pending = false;
   // the limiter runs on the side stream, beside whatever the main stream still has queued: behind the last k_timf2 (which reads the
   // routing words it rewrites) and the sums it reads; the next lrh_make_timf2 waits for it on the device
-  hipEvent_t ev_timf2_done = nullptr, ev_sel_wait = nullptr; bool timf2_done_valid = false, sel_table_pending = false; hipStream_t sums_stream = nullptr;
+  hipEvent_t ev_timf2_done = nullptr, ev_sel_wait = nullptr, ev_sel_wait2 = nullptr; bool timf2_done_valid = false, sel_table_pending = false; hipStream_t sums_stream = nullptr;
   bool pack_prev_stale = false;   // d_pack_prev differs from d_pack_cur (a new liminfo table arrived since the last make_timf2)
   // pinned staging for mix1 phases
   float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
@@ -329,13 +333,14 @@ void lrh_close(lrh_ctx *c)
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+  if (c->stream_sel) { hipStreamSynchronize(c->stream_sel); hipStreamDestroy(c->stream_sel); }
   if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
   if (c->stream_in) { hipStreamSynchronize(c->stream_in); hipStreamDestroy(c->stream_in); }
   for (int h = 0; h < LRH_MAX_HANDLES; h++) { if (c->hstream[h]) { hipStreamSynchronize(c->hstream[h]); hipStreamDestroy(c->hstream[h]); } if (c->hev[h]) hipEventDestroy(c->hev[h]); }
   if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
-  for (hipEvent_t ev : { c->ev_timf2_done, c->ev_sel_wait, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : { c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -426,6 +431,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
+  c->sums_on_main = cfg->fft2_n <= 14;
+  if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
+  if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;   // tests: the one-wave replay of the linear blanker
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
@@ -657,7 +665,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   }
   for (int i = 0; i < c->N1; i++) if (liminfo[i] == 0) low++;
   // d_pack_prev (routing of the transform before the next batch) is rolled forward by lrh_make_timf2
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   c->sel_table_pending = false;
   c->h_pack = pack;
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
@@ -680,6 +688,20 @@ static int sellim_install(lrh_ctx *c, unsigned seq)
   if (seq == c->sel_seq) c->sel_pending = false;
   return LRH_OK;
 }
+// the same without ever waiting: the newest update whose readback has arrived (the host runs rounds ahead of the device; a wait
+// here would let the device run dry once per round)
+static void sellim_poll(lrh_ctx *c)
+{
+  if (!c->sel_pending) return;
+  for (unsigned back = 0; back < 3 && back < c->sel_seq; back++) {
+    const unsigned seq = c->sel_seq - back;
+    if (hipEventQuery(c->ev_sel_slot[seq % 3]) == hipSuccess) {
+      c->lowlevel_points = c->h_sel_low[seq % 3];
+      if (back == 0) c->sel_pending = false;
+      return;
+    }
+  }
+}
 // what both limiter kernels need from the parameter block and the context
 static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
 {
@@ -694,12 +716,14 @@ static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
   a.bw_fftxpts = q->baseband_bw_fftxpts; a.ston_scale = q->ston_scale;
   a.selfreq = c->ms.mix1_selfreq; a.points_per_hz = c->cfg.fftx_points_per_hz; a.second_fft = c->cfg.second_fft_enable;
   a.bst = c->d_bst; a.desired = nullptr; a.desired_totsum = 0;
+  { static const int dbg = getenv("LRH_SELLIM_DEBUG") ? atoi(getenv("LRH_SELLIM_DEBUG")) : 0; a.debug = dbg; }
   if (q->fft1_desired) {                                  // calibrated amplitude factor: the table travels once (and again when it changes)
     if (c->h_sel_desired.size() != (size_t)c->N1 || memcmp(c->h_sel_desired.data(), q->fft1_desired, 4 * (size_t)c->N1)) {
       c->h_sel_desired.assign(q->fft1_desired, q->fft1_desired + c->N1);
       if (!c->d_sel_desired) { const int rc = dev_alloc(c, &c->d_sel_desired, c->N1); if (rc) return rc; }
-      HIPCHK(c, hipStreamSynchronize(c->stream2));
-      HIPCHK(c, hipMemcpyAsync(c->d_sel_desired, c->h_sel_desired.data(), 4 * (size_t)c->N1, hipMemcpyHostToDevice, c->stream2));
+      if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
+      HIPCHK(c, hipMemcpyAsync(c->d_sel_desired, c->h_sel_desired.data(), 4 * (size_t)c->N1, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
       float tot = 0;
       for (int i = 0; i < c->N1; i++) tot += q->fft1_desired[i] * q->fft1_desired[i];
       c->sel_desired_totsum = tot;
@@ -718,21 +742,24 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
     for (hipEvent_t &e : c->ev_sel_slot) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  if (c->sel_seq >= 2) { const int rc = sellim_install(c, c->sel_seq - 1); if (rc) return rc; }      // the count of the update before the last (unless exact_stats)
+  sellim_poll(c);                                           // the count of the newest finished update (unless exact_stats: see the end)
   SellimArgs a;
   { const int rc = sellim_args(c, q, &a); if (rc) return rc; }
-  hipStream_t S = c->stream2;
-  if (which == 1) {
-    a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
-    if (c->sums_stream != S || c->prof) {                       // sums on the main stream (serial order), or per-kernel timing: plain stream order
-      HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
-    } else if (c->timf2_done_valid) HIPCHK(c, hipStreamWaitEvent(S, c->ev_timf2_done, 0));
-  } else {
+  if (!c->stream_sel) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_sel, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel_wait2, hipEventDisableTiming));
+  }
+  hipStream_t S = c->stream_sel;
+  if (which == 1) a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
+  else {
     if (!c->d_sel_ftmp) { const int rc = dev_alloc(c, &c->d_sel_ftmp, c->N1); if (rc) return rc; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     a.tmp = c->d_sel_ftmp;
-    // the power sums come from the fft2 kernels (main stream) or the power-sum kernel (side stream): behind both
-    HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
   }
+  // behind everything queued so far on the main stream (the previous make_timf2 that read the routing words; the sums in the serial
+  // order) and, when this round's sums (first limiter) or the fft2 power sums (second) ran there, on the side stream -- not otherwise:
+  // the blanker of the previous round is queued there too and would hold the table back for nothing
+  HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
+  if (which == 2 || c->sums_stream == c->stream2) { HIPCHK(c, hipEventRecord(c->ev_sel_wait2, c->stream2)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait2, 0)); }
   { hipStream_t keep = c->cur; c->cur = S;
     { ProfScope ps(c, "sellim"); hipError_t e_ = which == 1 ? launch_sellim(a, S) : launch_sellim2(a, S);
       if (e_ != hipSuccess) { c->cur = keep; return fail(c, LRH_EDEVICE, "launch_sellim", e_); } }
@@ -766,6 +793,20 @@ int lrh_fft2_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
       q->sellim_maxlevel < 1 || !(q->fft1_blocktime > 0)) return LRH_EINVAL;
   return sellim_run(c, p, q, 2);
 }
+int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  c->wl_on = false;
+  if (!par) return LRH_OK;
+  if (par->struct_size != (int)sizeof *par) return LRH_EINVAL;
+  if (c->fft1_big || (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16))) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
+  c->wl_par = *par;
+  if (par->fft1_desired) { c->wl_desired.assign(par->fft1_desired, par->fft1_desired + c->N1); c->wl_par.fft1_desired = c->wl_desired.data(); }
+  c->wl_on = true; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;
+  return LRH_OK;
+}
 int lrh_get_liminfo_amplitude_factor(lrh_ctx *c, float *f)
 {
   LRH_ENTER(c);
@@ -780,7 +821,7 @@ int lrh_set_liminfo_amplitude_factor(lrh_ctx *c, float f)
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, amp_factor), &f, sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
@@ -801,7 +842,7 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_bt_refpulse, (void **)&c->d_bt_phasefunc, (void **)&c->d_bt_pulindex, (void **)&c->d_bln_flag, (void **)&c->d_bln_cand })
     if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->clever_on = false;
@@ -839,7 +880,7 @@ int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra
   LRH_ENTER(c);
   if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel, second fft on");
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_scratch, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
     if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->spur_max = 0; c->spur_n = 0; c->spur_speknum = 0;
@@ -1023,6 +1064,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   a.step = c->M1; a.window = c->d_window1; a.filtercorr = c->d_filtercorr; a.tw = c->d_tw1; a.out = c->d_fft1;
   a.first_nb = (fft1_pa / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask; a.direction = c->cfg.fft1_direction;
   a.xcd = c->xcd_mask & 1; a.batch = batch;
+  a.spare_cus = c->wl_on ? c->spare_cus : 0;                // the limiter inside lrh_wideband_dsp: leave it a compute unit per XCD to start on
   a.real = c->cfg.timf1_real_input != 0;
   if (c->d_foldcorr || a.real) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr / k_realsplit does the rest
   a.stamps = nullptr;
@@ -1076,7 +1118,7 @@ int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
 {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
-  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   if (!fc) { if (c->d_foldcorr) hipFree(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
   if (c->cfg.timf1_real_input) return fail(c, LRH_ESTATE, "no I/Q mirror image with real samples (init_foldcorr is I/Q only, buf.c:1461)");
   const size_t bytes = sizeof(float2) * c->N1;
@@ -1138,6 +1180,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   { const int rc_ = join_handles(c); if (rc_) return rc_; }
   if (c->sel_table_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_sel, 0)); c->sel_table_pending = false; }   // routing words from the side stream
+  if (c->h_sel_low) sellim_poll(c);                        // weak-bin count of the newest finished limiter update, if one has arrived
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
   a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
@@ -1145,6 +1188,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
   a.xcd = (c->xcd_mask >> 1) & 1;
+  a.spare_cus = c->wl_on ? c->spare_cus : 0;
   auto plain_timf2 = [&]() -> int {
     ProfScope ps(c, "timf2");
     if (!c->fft1_big) { HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur)); return LRH_OK; }
@@ -1906,6 +1950,27 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     for (auto &op : q) if ((r = op(c))) break;
     c->cur = keep; return r;
   };
+  // the limiter calls at the end of a pass of the reference's loop (wcw.c:1124-1133), when lrh_wideband_limiter installed them
+  // (cnt1 / sumsq_pa: fft1_c's counters as they stood after THIS round's sums -- schedule 1 has already booked the next round's)
+  // The first limiter only needs the round's power sums, so it is queued right behind them on the side stream -- queued at the end of
+  // the round it would sit behind the waterfall, i.e. behind fft2, and the next round's make_timf2 would wait 370 us for its table.
+  auto limiter1 = [&](int cnt1, int sumsq_pa) -> int {
+    if (!c->wl_on || !c->cfg.second_fft_enable || cnt1 == c->wl_cnt1) return LRH_OK;
+    std::vector<std::function<int(lrh_ctx *)>> *keep_rec = c->rec; hipStream_t keep_cur = c->cur;
+    c->rec = nullptr; c->cur = c->stream;
+    lrh_ptrs at = *p; at.fft1_sumsq_pa = sumsq_pa;
+    const int r = sellim_run(c, &at, &c->wl_par, 1); c->wl_cnt1 = cnt1;
+    c->rec = keep_rec; c->cur = keep_cur;
+    return r;
+  };
+  auto limiter2 = [&]() -> int {
+    if (!c->wl_on || !c->wl_fft2 || !c->cfg.second_fft_enable || p->fft2_liminfo_cnt == c->wl_cnt2) return LRH_OK;
+    std::vector<std::function<int(lrh_ctx *)>> *keep_rec = c->rec; hipStream_t keep_cur = c->cur;
+    c->rec = nullptr; c->cur = c->stream;
+    const int r = sellim_run(c, p, &c->wl_par, 2); c->wl_cnt2 = p->fft2_liminfo_cnt;
+    c->rec = keep_rec; c->cur = keep_cur;
+    return r;
+  };
   if (!piped) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
@@ -1921,6 +1986,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if ((rc = sums_follow(c->cur))) return rc;
       if ((rc = lrh_first_noise_blanker(c, p))) return rc;
       if ((rc = round_tail(c, p))) return rc;
+      if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa)) || (rc = limiter2())) return rc;
       nblocks -= B;
     }
     return LRH_OK;
@@ -1937,7 +2003,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // (LRH_DEVICE_WORK); results are those of the serial order because every ring holds two rounds (checked here).
   const long need2 = 2L * batch * c->M1 + 2L * c->N2 + c->cfg.blnfit_range + 4L * (c->cfg.blanker_pulsewidth + 2);
   const bool lagged = c->pipeline >= 2 && need2 <= c->cfg.timf2pow_size &&
-                      (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n && nblocks >= 3 * batch;
+                      (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n && nblocks >= 3 * batch &&
+                      !(c->wl_on && c->wl_fft2);          // the second limiter reads the power sums of this round's fft2
   if (lagged) {
     std::vector<std::function<int(lrh_ctx *)>> qb, qt;     // parked launches: blanker / fft2+mix1 of the previous round
     auto flush = [&](std::vector<std::function<int(lrh_ctx *)>> &q, hipStream_t st) -> int {
@@ -1977,8 +2044,13 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if ((rc = sums(B))) return rc;
       on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
       HIPCHK(c, hipEventRecord(ev_t2, S1));
-      if (fuse) { HIPCHK(c, hipStreamWaitEvent(S2, ev_t2, 0)); if ((rc = sums_follow(S2))) return rc; }
-      HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
+      // With the limiter in the call the sums' join and the slow average feed it and sit on the path to the next make_timf2: beside
+      // k_fft1 (which fills every register file) they would wait for it to end, so they go first on the main stream (26 us there)
+      // when the main stream's work between two make_timf2 is short enough for that wait to show (single-kernel fft2).
+      hipStream_t Ss = (fuse && c->wl_on && c->sums_on_main) ? S1 : S2;
+      if (fuse) { if (Ss == S2) HIPCHK(c, hipStreamWaitEvent(S2, ev_t2, 0)); if ((rc = sums_follow(Ss))) return rc; }
+      HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], Ss));
+      if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa))) return rc;
       // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
       qb.push_back([ev_t2](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, ev_t2, 0)); return LRH_OK; });
       c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
@@ -2014,6 +2086,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   if (!fuse) HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
   while (left > 0) {
     const int Bnext = (left - B) < batch ? (left - B) : batch;       // size of round k+1 (0 at the end)
+    const int lim_cnt = p->fft1_liminfo_cnt, lim_pa = p->fft1_sumsq_pa;   // fft1_c's counters after round k's sums
     // main: timf2(k)
     on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
@@ -2022,6 +2095,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     if (fuse) { if ((rc = sums_follow(S2))) return rc; HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2)); }
     if ((rc = lrh_first_noise_blanker(c, p))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_blank, S2));
+    if ((rc = limiter1(lim_cnt, lim_pa))) return rc;          // behind the blanker: fft2(k) on the main stream waits for that one
     if (Bnext > 0) {
       // main: fft1(k+1) once the sums of round k-1 (which read the ring slots it overwrites) are done
       on(S1);
@@ -2040,6 +2114,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     rc = round_tail(c, p);
     c->split_fft2_tail = false;
     if (rc) return rc;
+    if ((rc = limiter2())) return rc;
     left -= B; B = Bnext; round++;
   }
   // join: later API calls are ordered on the main stream only
@@ -2141,7 +2216,7 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
     HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), sizeof(float2) * c->N1, hipMemcpyHostToDevice));
   }
   if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
-  Fft1Args a;
+  Fft1Args a; a.spare_cus = 0;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;
   a.timf1 = c->d_timf1; a.ring_mask = c->cfg.timf1_bytes / esz - 1; a.dword = c->cfg.timf1_dword_input != 0;
@@ -2170,7 +2245,7 @@ int lrh_sync(lrh_ctx *c)
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
-  for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2 }) if (s) HIPCHK(c, hipStreamSynchronize(s));
+  for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2, c->stream_sel }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
   return sellim_install(c, c->sel_seq);
 }

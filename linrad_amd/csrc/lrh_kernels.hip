@@ -1574,12 +1574,12 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   }
 
 #define LRH_LAUNCH_FFT1_V(L, DW, SK, a, batch, st) \
-  hipLaunchKernelGGL((k_fft1<L, DW, SK>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a)
+  hipLaunchKernelGGL((k_fft1<L, DW, SK>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a)
 #define LRH_LAUNCH_FFT1(L, a, batch, st)                                                    \
   do {                                                                                      \
     const bool sk = a.shift_i != 0 || a.shift_q != 0;                                       \
-    if (a.real && !a.dword) hipLaunchKernelGGL((k_fft1<L, false, false, true>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
-    else if (a.real) hipLaunchKernelGGL((k_fft1<L, true, false, true>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
+    if (a.real && !a.dword) hipLaunchKernelGGL((k_fft1<L, false, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
+    else if (a.real) hipLaunchKernelGGL((k_fft1<L, true, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
     else if (!a.dword && !sk) LRH_LAUNCH_FFT1_V(L, false, false, a, batch, st);                  \
     else if (!a.dword) LRH_LAUNCH_FFT1_V(L, false, true, a, batch, st);                     \
     else if (!sk) LRH_LAUNCH_FFT1_V(L, true, false, a, batch, st);                          \
@@ -1588,12 +1588,12 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
 #define LRH_LAUNCH_TIMF2(L, a, batch, st)                                                                   \
   do {                                                                                                      \
     if (a.ss_ring) {                                                                                        \
-      a.ss_run = (batch + fftl_grid<L>(batch) - 1) / fftl_grid<L>(batch);                                   \
+      a.ss_run = (batch + fftl_grid<L>(batch, a.spare_cus) - 1) / fftl_grid<L>(batch, a.spare_cus);                                   \
       hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3((batch + a.ss_run - 1) / a.ss_run), dim3(fft_threads(L)), 0, st, a); \
     }                                                                                                       \
-    else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);      \
-    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a); \
-    else hipLaunchKernelGGL((k_timf2<L, 2, false>), dim3(fftl_grid<L>(batch)), dim3(fft_threads(L)), 0, st, a);                  \
+    else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a);      \
+    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
+    else hipLaunchKernelGGL((k_timf2<L, 2, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a);                  \
   } while (0)
 #define LRH_LAUNCH_FFT2(L, a, batch, st)                                                                              \
   do {                                                                                                                \
@@ -1610,13 +1610,16 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   hipLaunchKernelGGL((k_mix1_back<L>), dim3(batch), dim3(FftPlan<L, points_per_thread(L)>::T), 0, st, a)
 
 // workgroups that fit on the chip at once for a transform kernel (LDS and thread limits, 256 CUs)
-static int persistent_grid(int lds_bytes, int threads, int batch)
+// spare_cus: compute units left without a workgroup of a kernel that takes a whole unit's LDS, spread over the XCDs (workgroup i goes
+// to XCD i mod 8).  A one-workgroup side kernel with a large LDS footprint of its own (the limiter) otherwise waits for the whole
+// persistent kernel to end before it can start.
+static int persistent_grid(int lds_bytes, int threads, int batch, int spare_cus = 0)
 {
   int per_cu = 160 * 1024 / lds_bytes; if (per_cu > 2048 / threads) per_cu = 2048 / threads; if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
-  const int g = 256 * per_cu;
+  const int g = (256 - (per_cu == 1 ? spare_cus : 0)) * per_cu;
   return batch < g ? batch : g;
 }
-template <int L> static int fftl_grid(int batch) { return persistent_grid(8 * BlockFftL<L, points_per_thread(L), 1>::LDS_CELLS, fft_threads(L), batch); }
+template <int L> static int fftl_grid(int batch, int spare_cus = 0) { return persistent_grid(8 * BlockFftL<L, points_per_thread(L), 1>::LDS_CELLS, fft_threads(L), batch, spare_cus); }
 
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
 {
@@ -2302,6 +2305,9 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
 // tables the other threads have built.  Arithmetic as the reference (float, sqrt / pow in double).
 namespace lrh {
 #define LRH_SL_BIG 300000000000000000000000000000000000000.F
+// One workgroup, and every pass over the bins is a latency-bound stream through global memory or LDS: 1024 threads keep 16 loads in
+// flight per pass where 256 kept 64 trips of one (k_sellim 500-650 us -> see DESIGN.md 4.8).
+#define LRH_SL_THREADS 1024
 __device__ __forceinline__ float sl_three_smallest(const float *v, int ia, int ib)
 {
   float t1 = LRH_SL_BIG, t2 = LRH_SL_BIG, t3 = LRH_SL_BIG;
@@ -2346,18 +2352,25 @@ __device__ __forceinline__ void sl_selfreq(const SellimArgs &a, float *B, int ti
       }
     }
   }
+  __shared__ int s_strong;
+  if (tid == 0) s_strong = 0;
+  __syncthreads();                                         // also: the passband above is in place for everybody
+  if (a.second_fft && !a.desired) {                        // uncalibrated: the share of strong bins in the passband (a count: any order)
+    int k = 0;
+    for (int i = a.first_inband + tid; i <= a.last_inband; i += LRH_SL_THREADS) if (B[i] != 0) k++;
+    if (k) atomicAdd(&s_strong, k);
+  }
+  __syncthreads();
   if (tid == 0) {
     float f = 1.f;
     if (a.second_fft) {
-      if (a.desired) {
+      if (a.desired) {                                     // calibrated: a float sum, in the reference's order
         float t1 = 0;
         for (int i = a.first_point; i <= a.last_point; i++) if (B[i] != 0) t1 += a.desired[i] * a.desired[i];
         f = a.desired_totsum / (a.desired_totsum - t1);
       } else {
-        int k = 0;
-        for (int i = a.first_inband; i <= a.last_inband; i++) if (B[i] != 0) k++;
         const int n = a.last_inband - a.first_inband + 1;
-        f = (float)(n) / (n - k);
+        f = (float)(n) / (n - s_strong);
       }
     }
     if (f > 2) f = 0;
@@ -2365,7 +2378,27 @@ __device__ __forceinline__ void sl_selfreq(const SellimArgs &a, float *B, int ti
   }
 }
 
-__global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
+// the same by one wave: every lane keeps the three smallest of its share, then the triples are merged across the lanes (the three
+// smallest values of a set do not depend on the order they are met in)
+__device__ __forceinline__ float sl_three_smallest_wave(const float *v, int ia, int ib, int lane)
+{
+  float t1 = LRH_SL_BIG, t2 = LRH_SL_BIG, t3 = LRH_SL_BIG;
+  auto put = [&](float x) {
+    if (x <= t3) {
+      if (x <= t1) { t3 = t2; t2 = t1; t1 = x; }
+      else if (x <= t2) { t3 = t2; t2 = x; }
+      else t3 = x;
+    }
+  };
+  for (int i = ia + lane; i < ib; i += 64) put(v[i]);
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o1 = __shfl_xor(t1, off), o2 = __shfl_xor(t2, off), o3 = __shfl_xor(t3, off);
+    put(o1); put(o2); put(o3);
+  }
+  return (float)(0.3333333 * (t1 + t2 + t3));
+}
+
+__global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
 {
   extern __shared__ float sm[];
   const int N = a.n, tid = threadIdx.x;
@@ -2375,8 +2408,11 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
   unsigned int *hotw = (unsigned int *)(G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
   __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
   const int NW = (N + 31) / 32;
-  for (int i = tid; i < N; i += 256) { A[i] = a.sumsq[i]; B[i] = a.liminfo[i]; }
-  for (int i = tid; i < 8; i += 256) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
+  long long ts[10]; int nts = 0;
+  auto stamp = [&]() { if (a.debug && tid == 0 && nts < 10) ts[nts++] = wall_clock64(); };
+  stamp();
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { A[i] = a.sumsq[i]; B[i] = a.liminfo[i]; }
+  for (int i = tid; i < 8; i += LRH_SL_THREADS) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
   if (tid == 0) {
     int tot = a.st->sumsq_tot + a.avg1;
     if (tot > a.spek_avgnum) tot = a.spek_avgnum;
@@ -2390,27 +2426,37 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
   const float limit = s_limit;
   const int sel_ia = a.st->sel_ia, sel_ib = a.st->sel_ib, par7 = a.par7;
   const int ix = a.first_point, iy = a.last_point - 1;
-  auto build_bits = [&](float thr) {       // all threads: bit i = A[i] > thr
-    for (int w = tid; w < NW + 2; w += 256) {
-      unsigned int m = 0;
-      for (int b = 0; b < 32; b++) { const int i = 32 * w + b; if (i < N && A[i] > thr) m |= 1u << b; }
-      hotw[w] = m;
+  auto build_bits = [&](float thr) {       // all threads: bit i = A[i] > thr; a wave reads 64 consecutive bins (no bank conflicts) and votes
+    const int lane = tid & 63, wave = tid >> 6, nwaves = LRH_SL_THREADS / 64;
+    for (int r = wave; 64 * r < 32 * (NW + 2); r += nwaves) {
+      const int i = 64 * r + lane;
+      const unsigned long long m = __ballot(i < N && A[i] > thr);
+      if (lane == 0) { hotw[2 * r] = (unsigned int)m; if (2 * r + 1 < NW + 2) hotw[2 * r + 1] = (unsigned int)(m >> 32); }
     }
   };
+  // thread 0's jumps: a dependent LDS read costs ~100 cycles, so empty stretches are skipped four words (128 bins) per read
   auto next_set = [&](int i) -> int {      // first bin >= i whose bit is set (N if none)
-    while (i < N) {
-      const unsigned int m = hotw[i >> 5] >> (i & 31);
-      if (m) return i + __ffs(m) - 1;
-      i = (i | 31) + 1;
+    if (i >= N) return N;
+    { const unsigned int m = hotw[i >> 5] >> (i & 31); if (m) { const int r = i + __ffs(m) - 1; return r < N ? r : N; } }
+    int w = (i >> 5) + 1;
+    while (32 * w < N) {
+      if ((w & 3) == 0 && w + 3 < NW + 2) { const uint4 q = *reinterpret_cast<const uint4 *>(&hotw[w]); if (!(q.x | q.y | q.z | q.w)) { w += 4; continue; } }
+      const unsigned int m = hotw[w];
+      if (m) { const int r = 32 * w + __ffs(m) - 1; return r < N ? r : N; }
+      w++;
     }
     return N;
   };
   auto next_clear = [&](int i) -> int {    // first bin >= i whose bit is clear (N if none)
-    while (i < N) {
-      const unsigned int m = ~hotw[i >> 5] >> (i & 31);
-      const int room = 32 - (i & 31);
-      if (m & (room == 32 ? 0xffffffffu : ((1u << room) - 1))) return i + __ffs(m) - 1;
-      i = (i | 31) + 1;
+    if (i >= N) return N;
+    { const unsigned int m = ~hotw[i >> 5] >> (i & 31); const int room = 32 - (i & 31);
+      if (m & (room == 32 ? 0xffffffffu : ((1u << room) - 1))) { const int r = i + __ffs(m) - 1; return r < N ? r : N; } }
+    int w = (i >> 5) + 1;
+    while (32 * w < N) {
+      if ((w & 3) == 0 && w + 3 < NW + 2) { const uint4 q = *reinterpret_cast<const uint4 *>(&hotw[w]); if ((q.x & q.y & q.z & q.w) == 0xffffffffu) { w += 4; continue; } }
+      const unsigned int m = ~hotw[w];
+      if (m) { const int r = 32 * w + __ffs(m) - 1; return r < N ? r : N; }
+      w++;
     }
     return N;
   };
@@ -2418,8 +2464,9 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
   // its whole width and tapered skirts.  The serial scan zeroes a bin when it passes it; here all bins at or below the limit
   // are zeroed up front by all threads, and thread 0 only visits the runs -- reading, for the bins the serial scan has not
   // reached yet at that moment, the previous update's value (still in a.liminfo) instead of the zero put there early.
+  stamp();
   build_bits(limit);
-  for (int i = ix + tid; i < iy; i += 256) if (!(A[i] > limit) && (i > sel_ib || i < sel_ia || par7 == 0)) B[i] = 0;
+  for (int i = ix + tid; i < iy; i += LRH_SL_THREADS) if (!(A[i] > limit) && (i > sel_ib || i < sel_ia || par7 == 0)) B[i] = 0;
   __syncthreads();
   if (tid == 0) {
     int ia = ix;
@@ -2463,28 +2510,30 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
     }
   }
   __syncthreads();
+  stamp();
   if (s_pass2) {
     // ---- pass 2 (sellim.c:866-1147): noise floor of the slow average, everything above it joins the strong signals
     const int gp = a.group_points;
-    for (int i = tid; i < N; i += 256) A[i] = a.tmp[i];
+    for (int i = tid; i < N; i += LRH_SL_THREADS) A[i] = a.tmp[i];
     __syncthreads();
     int ja = a.first_inband / gp, jb;
     if (a.par2 == 0) {
       jb = 1 + a.last_inband / gp;
       if ((jb - ja) * gp > N) jb--;
-      for (int i = ja * gp + tid; i < jb * gp; i += 256) A[i] = a.yfac[i] * a.slowsum[i];
+      for (int i = ja * gp + tid; i < jb * gp; i += LRH_SL_THREADS) A[i] = a.yfac[i] * a.slowsum[i];
       __syncthreads();
-      for (int j = ja + tid; j < jb; j += 256) G[j] = sl_three_smallest(A, j * gp, j * gp + gp);
+      for (int j = ja + (tid >> 6); j < jb; j += LRH_SL_THREADS / 64) { const float m = sl_three_smallest_wave(A, j * gp, j * gp + gp, tid & 63); if ((tid & 63) == 0) G[j] = m; }
     } else {
       // running boundaries: group 0 ends at (ja+1) gp, the last one is cut at last_inband + 1
       jb = ja + 1;
       { int ib = jb * gp; do { ib += gp; if (ib > a.last_inband) ib = a.last_inband + 1; jb++; } while (ib < a.last_inband); }
-      for (int i = tid; i < a.last_point; i += 256) A[i] = a.yfac[i] * a.slowsum[i];
+      for (int i = tid; i < a.last_point; i += LRH_SL_THREADS) A[i] = a.yfac[i] * a.slowsum[i];
       __syncthreads();
-      for (int j = ja + tid; j < jb; j += 256) {
+      for (int j = ja + (tid >> 6); j < jb; j += LRH_SL_THREADS / 64) {
         const int lo = j == ja ? a.first_inband : j * gp;
         int hi = (j + 1) * gp; if (j > ja && hi > a.last_inband) hi = a.last_inband + 1;
-        G[j] = sl_three_smallest(A, lo, hi);
+        const float m = sl_three_smallest_wave(A, lo, hi, tid & 63);
+        if ((tid & 63) == 0) G[j] = m;
       }
     }
     __syncthreads();
@@ -2508,12 +2557,13 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
       s_nf = nf; s_k = k;
     }
     __syncthreads();
+    stamp();
     const float nf = s_nf;
     build_bits(nf);
     // Every bin above the noise floor from bin 2 up to last_point - 1 ends up marked by the serial scan (as a member of a
     // run, of a skirt, or as the start of the next run): all threads mark them now; thread 0 then walks the runs only, for
     // the skirts below and above each run and the end of the band.
-    if (s_k != 0) for (int i = 2 + tid; i < a.last_point; i += 256) if (A[i] > nf && B[i] == 0) B[i] = -1;
+    if (s_k != 0) for (int i = 2 + tid; i < a.last_point; i += LRH_SL_THREADS) if (A[i] > nf && B[i] == 0) B[i] = -1;
     __syncthreads();
     if (tid == 0) {
       auto mark = [&](int i) { if (B[i] == 0) B[i] = -1; };
@@ -2542,13 +2592,14 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
       s_ia = ia;
     }
     __syncthreads();
+    stamp();
     const int ia_end = s_ia;
-    for (int i = ia_end + tid; i < N; i += 256) { if (a.par8 == 0) B[i] = -1; else if (B[i] == 0) B[i] = -1; }
+    for (int i = ia_end + tid; i < N; i += LRH_SL_THREADS) { if (a.par8 == 0) B[i] = -1; else if (B[i] == 0) B[i] = -1; }
     __syncthreads();
     // hold-off and slow release (sellim.c:1121-1147), per bin
     int k = (int)(1 + 1 / (a.avg1 * a.blocktime));
     const unsigned int wait_n = k < 255 ? (unsigned)k : 255u;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += LRH_SL_THREADS) {
       unsigned char w = a.wait[i];
       float l = B[i];
       if (l != 0) w = (unsigned char)wait_n;
@@ -2557,14 +2608,22 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
       if (o > 0) { const float t1 = (float)(o * 1.15); if (t1 < 1) { if (l > 0 && l > t1) l = t1; } }
       a.wait[i] = w; B[i] = l;
     }
-    for (int i = tid; i < N; i += 256) a.tmp[i] = A[i];
+    for (int i = tid; i < N; i += LRH_SL_THREADS) a.tmp[i] = A[i];
     __syncthreads();
   }
+  stamp();
   sl_selfreq(a, B, tid);
   __syncthreads();
-  for (int i = tid; i < N; i += 256) {
+  stamp();
+  for (int i = tid; i < N; i += LRH_SL_THREADS) {
     a.old_liminfo[i] = B[i];
     a.liminfo[i] = (i < 2 || i >= N - 2) ? 0.f : B[i];       // sellim.c:1152-1155
+  }
+  stamp();
+  if (a.debug && tid == 0) {
+    printf("k_sellim ticks (10 ns):");
+    for (int i = 1; i < nts; i++) printf(" %lld", ts[i] - ts[i - 1]);
+    printf("  [load, pass1, groups+floor, pass2 scan, hold-off, selfreq, store]\n");
   }
 }
 
@@ -2572,7 +2631,7 @@ __global__ __launch_bounds__(256) void k_sellim(SellimArgs a)
 // bin's width (A), group statistics -> global noise floor (thread 0 adds the groups in order: float sums), the neighbour fix-up
 // next to strong bins (serial: it reads what it has just lowered), thinning of an overgrown table, marking of everything within two
 // bins of power above 0.5 * ston * floor.  A persists between calls like the reference's fftf_tmp (zero outside the passband).
-__global__ __launch_bounds__(256) void k_sellim2(SellimArgs a)
+__global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
 {
   extern __shared__ float sm[];
   const int N = a.n, tid = threadIdx.x, nn = a.n2 / a.n, gp = a.group_points, groups = N / gp;
@@ -2580,16 +2639,16 @@ __global__ __launch_bounds__(256) void k_sellim2(SellimArgs a)
   float *B = A + N + 16;
   float *reg_min = B + N + 8, *reg_ston = reg_min + groups + 1, *reg_noise = reg_ston + groups + 1;   // 3 N/16 + 3 <= N/4 + 8
   __shared__ float s_t1; __shared__ int s_go, s_k;
-  for (int i = tid; i < N; i += 256) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
-  for (int i = tid; i < 8; i += 256) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
+  for (int i = tid; i < 8; i += LRH_SL_THREADS) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
   __syncthreads();
-  for (int i = a.first_point + tid; i < a.last_point; i += 256) {
+  for (int i = a.first_point + tid; i < a.last_point; i += LRH_SL_THREADS) {
     float t1 = 0;
     for (int j = nn * i; j < nn * i + nn; j++) t1 += a.powersum2[j];
     A[i] = t1 * a.yfac[i] / nn;
   }
   __syncthreads();
-  for (int g = tid; g < groups; g += 256) {
+  for (int g = tid; g < groups; g += LRH_SL_THREADS) {
     const int ia = g * gp, ib = ia + gp;
     float t1 = 0;
     for (int j = ia; j < ib; j++) t1 += A[j];
@@ -2615,7 +2674,7 @@ __global__ __launch_bounds__(256) void k_sellim2(SellimArgs a)
   __syncthreads();
   if (s_go == 2) {
     const float lim5 = s_t1;
-    for (int g = tid; g < groups; g += 256) {
+    for (int g = tid; g < groups; g += LRH_SL_THREADS) {
       const int ia = g * gp, ib = ia + gp;
       float t2 = 0; int k = 0;
       for (int j = ia; j < ib; j++) if (A[j] < lim5) { k++; t2 += A[j]; }
@@ -2656,29 +2715,29 @@ __global__ __launch_bounds__(256) void k_sellim2(SellimArgs a)
       if (tid == 0) s_k = 0;
       __syncthreads();
       int k = 0;
-      for (int i = ia + tid; i < ib; i += 256) { if (B[i] < 0 && A[i] < t1) { B[i] = 0; a.wait[i] = 0; } if (B[i] != 0) k++; }
+      for (int i = ia + tid; i < ib; i += LRH_SL_THREADS) { if (B[i] < 0 && A[i] < t1) { B[i] = 0; a.wait[i] = 0; } if (B[i] != 0) k++; }
       if (k) atomicAdd(&s_k, k);
       __syncthreads();
       if (s_k > (ib - ia) / 4) {
         const float t2 = 10.F * t1;
-        for (int i = ia + tid; i < ib; i += 256) if (B[i] < 0 && A[i] < t2) { B[i] = 0; a.wait[i] = 0; }
+        for (int i = ia + tid; i < ib; i += LRH_SL_THREADS) if (B[i] < 0 && A[i] < t2) { B[i] = 0; a.wait[i] = 0; }
       }
       __syncthreads();
     }
     const unsigned wn = (unsigned)(1 + (1 + (a.blocktime2 * a.wf_avgnum)) / (a.avg1 * a.blocktime));
     const unsigned char wait_n = (unsigned char)(wn > 255u ? 255u : wn);
-    for (int i = ia + tid; i < ib; i += 256)               // the fifth term repeats i-2 in the reference (sellim.c:723)
+    for (int i = ia + tid; i < ib; i += LRH_SL_THREADS)               // the fifth term repeats i-2 in the reference (sellim.c:723)
       if (2. * A[i - 2] > t1 || A[i - 1] > t1 || A[i] > t1 || A[i + 1] > t1 || 2. * A[i - 2] > t1) {
         if (B[i] == 0) B[i] = -1;
         a.wait[i] = wait_n;
       }
     __syncthreads();
   }
-  for (int i = tid; i < N; i += 256) a.tmp[i] = A[i];
+  for (int i = tid; i < N; i += LRH_SL_THREADS) a.tmp[i] = A[i];
   if (s_go == 0) return;
   sl_selfreq(a, B, tid);
   __syncthreads();
-  for (int i = tid; i < N; i += 256) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
 }
 
 // liminfo floats -> the routing words of k_timf2 (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count
@@ -2711,7 +2770,7 @@ hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_sellim, dim3(1), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_sellim, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
   return hipGetLastError();
 }
@@ -2721,7 +2780,7 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64 || a.group_points < 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
   return hipGetLastError();
 }

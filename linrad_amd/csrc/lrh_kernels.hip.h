@@ -28,6 +28,7 @@ struct Fft1Args {
   int batch;                // transforms in this launch (workgroups are persistent)
   int chan_count, chan_index; // frame layout {I0,Q0,I1,Q1,...}: sample s of this channel is short2 s*chan_count+chan_index
   unsigned long long *stamps; // diagnostics (LRH_STAMP=1): s_memtime of workgroups 0 and 128 at phase boundaries, else null
+  int spare_cus;            // compute units left free for side-stream kernels (see persistent_grid)
 };
 #define LRH_STAMPS_PER_WG 64
 
@@ -62,6 +63,7 @@ struct Timf2Args {
   // fused fft1_c power sums (set by launch_timf2 when it is handed a SumsqArgs): ring, pieces of groups that straddle
   // workgroup runs [grid][2][N], transforms per workgroup
   float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0, ss_run;
+  int spare_cus;            // compute units left free for side-stream kernels (see persistent_grid)
 };
 
 // fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): one block no longer fits a workgroup's LDS, so
@@ -244,6 +246,7 @@ struct SellimArgs {
   BlankState *bst; const float *desired; float desired_totsum;
   // fft2_update_liminfo (k_sellim2): summed fft2 power spectrum, hg.blanker_ston_fft2, seconds per fft2 transform, waterfall_avgnum
   const float *powersum2; float ston2, blocktime2; int wf_avgnum;
+  int debug;                // LRH_SELLIM_DEBUG=1: thread 0 prints the phase times (100 MHz ticks)
 };
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);

@@ -63,6 +63,7 @@ struct lro_ctx {
   lrh_blanker_state bs;
   /* linear blanker (lro_set_blanker_tables) */
   float amp_factor;            /* liminfo_amplitude_factor (sellim.c:119-155; blank1.c:143) */
+  lrh_sellim wl_par; int wl_on, wl_fft2, wl_cnt1, wl_cnt2;   /* lro_wideband_limiter */
   lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
@@ -1487,8 +1488,22 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       }
       k -= kb;
     }
+    if (c->wl_on) {                             /* wcw.c:1124-1133 */
+      if (p->fft1_liminfo_cnt != c->wl_cnt1) { if ((rc = lro_fft1_update_liminfo(c, p, &c->wl_par))) return rc; c->wl_cnt1 = p->fft1_liminfo_cnt; }
+      if (c->wl_fft2 && p->fft2_liminfo_cnt != c->wl_cnt2) { if ((rc = lro_fft2_update_liminfo(c, p, &c->wl_par))) return rc; c->wl_cnt2 = p->fft2_liminfo_cnt; }
+    }
     nblocks -= B;
   }
+  return LRH_OK;
+}
+
+int lro_wideband_limiter(lro_ctx *c, const lrh_sellim *par, int fft2_too)
+{
+  if (!c) return LRH_EINVAL;
+  c->wl_on = 0;
+  if (!par) return LRH_OK;
+  if (par->struct_size != (int)sizeof *par) return LRH_EINVAL;
+  c->wl_par = *par; c->wl_on = 1; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;
   return LRH_OK;
 }
 

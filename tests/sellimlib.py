@@ -100,3 +100,32 @@ def compare(out, g, tol, value_tol=2e-6):
     rep["cleared_equal"] = bool(np.array_equal(out["pwr"] == 0, g["timf2_pwr_float"] == 0))
     assert rep["timf2"] <= tol and rep["slowsum"] <= tol, rep
     return rep
+
+
+def run_dsp(open_fn, name, g, batch=4, in_call=True, fft2_too=True, rounds=None, env=None):
+    """the same case through lrh_wideband_dsp in rounds of `batch` blocks: with the limiter calls inside the call
+    (lrh_wideband_limiter) or made by the caller after every round, the way wcw.c:1124-1133 makes them after every pass"""
+    d, _, iq = sellim_case(name)
+    cfg = lrh_config(d, iq, max_batch=batch)
+    api = open_fn(cfg)
+    api.timf1_write(iq)
+    api.set_mix1_selfreq(d["fq"])
+    par = sellim_params(cfg, g)
+    nr = rounds or d["nblk"] // batch
+    if in_call:
+        api.wideband_limiter(par, fft2_too)
+        api.wideband_dsp(nr * batch, batch)
+    else:
+        c1 = c2 = 0
+        for _ in range(nr):
+            api.wideband_dsp(batch, batch)
+            if api.p.fft1_liminfo_cnt != c1:
+                api.fft1_update_liminfo(par)
+                c1 = api.p.fft1_liminfo_cnt
+            if fft2_too and api.p.fft2_liminfo_cnt != c2:
+                api.fft2_update_liminfo(par)
+                c2 = api.p.fft2_liminfo_cnt
+    out = dict(lim=api.get_liminfo(), amp=api.liminfo_amplitude_factor(), timf2=api.export(abi.RING_TIMF2_FLOAT), pwr=api.export(abi.RING_TIMF2_PWR),
+               timf3=api.export(abi.RING_TIMF3_FLOAT), p=api.p.as_dict(), low=api.p.fft1_lowlevel_points)
+    api.close()
+    return out

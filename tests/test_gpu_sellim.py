@@ -19,8 +19,8 @@ def test_hip_selective_limiter_matches_reference(name):
 
 
 def test_limiter_statistic_may_lag():
-    """exact_stats = 0: nothing waits for the device; the routing is the same, the weak-bin count make_timf2 reports is the
-    previous update's"""
+    """exact_stats = 0: nothing waits for the device; the routing is the same, the weak-bin count make_timf2 reports is that of the
+    newest update whose readback has arrived"""
     from linrad_amd.lib import open_hip
     from linrad_amd.abi import default_sellim
     from refcases import lrh_config, sellim_case
@@ -46,5 +46,33 @@ def test_limiter_statistic_may_lag():
         outs.append((np.array(lows), np.array(tabs), rx.export(3)))
     (l1, t1, r1), (l0, t0, r0) = outs
     assert np.array_equal(t1, t0) and np.array_equal(r1, r0)           # tables and the timf2 ring: identical
-    avg1 = cfg.fft_avg1num
-    assert np.array_equal(l0[3 * avg1:], l1[avg1:-2 * avg1])           # the count: two updates late
+    # the count: never ahead of the exact run, and the same values in the same order (the newest finished update is installed whenever
+    # make_timf2 or the next update looks; how late that is depends on how far the host runs ahead of the device)
+    def distinct(a):
+        return [int(v) for k, v in enumerate(a) if k == 0 or v != a[k - 1]]
+    it = iter(distinct(l1))
+    assert all(v in it for v in distinct(l0)), (distinct(l0), distinct(l1))
+    assert all(l0[i] in l1[:i + 1] for i in range(len(l0)))
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1", "2"])
+def test_hip_wideband_dsp_makes_the_limiter_calls_itself(pipeline, monkeypatch):
+    """lrh_wideband_limiter: the limiter kernels at the end of every round inside lrh_wideband_dsp, in each of its schedules
+    (LRH_PIPELINE 0 serial, 1 two streams, 2 one round late -- which the second limiter switches off), against the oracle doing the same
+    and against the caller making the calls between single-round calls"""
+    import numpy as np
+    from linrad_amd.lib import open_hip
+    from oracle_binding import open_oracle
+    monkeypatch.setenv("LRH_PIPELINE", pipeline)
+    name = "sellim2_n10_n12"
+    g = sellimlib.load(name)
+    for fft2_too in (True, False):
+        h = sellimlib.run_dsp(open_hip, name, g, in_call=True, fft2_too=fft2_too)
+        e = sellimlib.run_dsp(open_hip, name, g, in_call=False, fft2_too=fft2_too)
+        o = sellimlib.run_dsp(open_oracle, name, g, in_call=True, fft2_too=fft2_too)
+        assert h["p"] == o["p"] and np.array_equal(np.sign(h["lim"]), np.sign(o["lim"])) and abs(h["amp"] - o["amp"]) <= 1e-6
+        assert np.array_equal(h["lim"], e["lim"]) and np.array_equal(h["timf2"], e["timf2"]) and np.array_equal(h["timf3"], e["timf3"])
+        keep = np.ones(h["timf2"].size, bool)
+        keep[(h["p"]["timf2_pa"] + np.arange(4 * 512)) % keep.size] = False
+        err = np.linalg.norm((h["timf2"] - o["timf2"]) * keep) / np.linalg.norm(o["timf2"] * keep)
+        assert err < 1e-5 and np.count_nonzero(h["lim"]) > 50, (err, fft2_too)
