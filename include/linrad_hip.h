@@ -231,6 +231,10 @@ typedef struct lrh_ctx lrh_ctx;
 /* ---- lifetime: replaces cufftPlanMany/cudaMalloc at wcw.c:553-575 and the never-freed
         buffers / destroy_clFFT_plan at wcw.c:1174-1183 ---- */
 int  lrh_abi_version(void);
+/* sizeof of the public structs as this library was compiled, for bindings that restate them (ctypes, cgo ...): index = the order of
+   the enum; 0 for an unknown index */
+enum { LRH_SZ_CONFIG = 0, LRH_SZ_PTRS, LRH_SZ_BLANKER_STATE, LRH_SZ_BLANKER_TABLES, LRH_SZ_MIX1_STATE, LRH_SZ_SELLIM, LRH_SZ_SPUR, LRH_SZ_AFC, LRH_SZ_SYNTH };
+size_t lrh_sizeof(int which);
 int  lrh_config_defaults(lrh_config *cfg, int fft1_n, int fft2_n);     /* fills reference defaults (uivar.c:371) */
 int  lrh_open(const lrh_config *cfg, lrh_ctx **out);
 void lrh_close(lrh_ctx *ctx);

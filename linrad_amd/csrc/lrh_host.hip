@@ -306,6 +306,12 @@ static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" {
 
 int lrh_abi_version(void) { return LRH_ABI_VERSION; }
+size_t lrh_sizeof(int which)
+{
+  static const size_t sz[] = { sizeof(lrh_config), sizeof(lrh_ptrs), sizeof(lrh_blanker_state), sizeof(lrh_blanker_tables), sizeof(lrh_mix1_state),
+                               sizeof(lrh_sellim), sizeof(lrh_spur), sizeof(lrh_afc), sizeof(lrh_synth) };
+  return which >= 0 && which < (int)(sizeof sz / sizeof sz[0]) ? sz[which] : 0;
+}
 
 int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
 {

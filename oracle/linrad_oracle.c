@@ -1497,6 +1497,13 @@ int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   return LRH_OK;
 }
 
+size_t lro_sizeof(int which)
+{
+  static const size_t sz[] = { sizeof(lrh_config), sizeof(lrh_ptrs), sizeof(lrh_blanker_state), sizeof(lrh_blanker_tables), sizeof(lrh_mix1_state),
+                               sizeof(lrh_sellim), sizeof(lrh_spur), sizeof(lrh_afc), sizeof(lrh_synth) };
+  return which >= 0 && which < (int)(sizeof sz / sizeof sz[0]) ? sz[which] : 0;
+}
+
 int lro_wideband_limiter(lro_ctx *c, const lrh_sellim *par, int fft2_too)
 {
   if (!c) return LRH_EINVAL;

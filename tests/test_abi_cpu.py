@@ -37,6 +37,17 @@ def test_struct_sizes_match_header():
     assert (cfg.fft1_n, cfg.fft2_n, cfg.fft1_sinpow, cfg.bckfft_att_n, cfg.mix1_bandwidth_reduction_n) == (14, 16, 2, 6, 6)
 
 
+def test_every_public_struct_has_the_same_size_on_both_sides():
+    """the ctypes restatements in linrad_amd/abi.py against sizeof in the compiled library (and in the oracle, built from the same header)"""
+    from oracle_binding import oracle_lib
+    order = [abi.LrhConfig, abi.LrhPtrs, abi.LrhBlankerState, abi.LrhBlankerTables, abi.LrhMix1State, abi.LrhSellim, abi.LrhSpur, abi.LrhAfc, abi.LrhSynth]
+    for lib, fn in ((hip_lib(), "lrh_sizeof"), (oracle_lib(), "lro_sizeof")):
+        f = getattr(lib, fn)
+        f.argtypes, f.restype = [C.c_int], C.c_size_t
+        assert [f(i) for i in range(len(order))] == [C.sizeof(t) for t in order], fn
+        assert f(len(order)) == 0
+
+
 def test_open_rejects_bad_config_and_missing_gpu():
     import torch
     lib = hip_lib()
