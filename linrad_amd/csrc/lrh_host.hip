@@ -1636,7 +1636,15 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     // phase recursions of do_mix1 in the reference's float arithmetic (mix1.c:143-154, 164-187); serial by nature, tiny
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
     if (c->ph_pending[slot]) return fail(c, LRH_ESTATE, "mix1 staging ring exhausted by deferred work");
-    { const auto w0 = std::chrono::steady_clock::now(); HIPCHK(c, hipEventSynchronize(c->ph_ev[slot]));
+    { const auto w0 = std::chrono::steady_clock::now();
+      // the host runs up to LRH_NSTAGE rounds ahead and then waits here for most of a round: asleep, not spinning inside
+      // hipEventSynchronize (which burnt a whole core: thread CPU time = wall time of the call)
+      for (;;) {
+        const hipError_t q = hipEventQuery(c->ph_ev[slot]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(c, LRH_EDEVICE, "hipEventQuery(staging)", q);
+        timespec ts{0, 40000}; nanosleep(&ts, nullptr);
+      }
       c->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); }
     const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
     float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
