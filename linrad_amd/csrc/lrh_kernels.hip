@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
   const int n20 = blockIdx.x * LRH_TILE + c0;
   const int t_first = blockIdx.y * a.run, t_end = min(t_first + a.run, a.batch);
   const bool overlap = a.step * 2 == NA * NB;
-  float2 twk[P], keep[P / 2];
+  float2 twk[P], keep[P / 2], pfw[P / 2], pfs[P / 2];
 #pragma unroll
   for (int m = 0; m < P / RL; m++)
 #pragma unroll
@@ -1161,6 +1161,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
       for (int s = 0; s < R0; s++) {
         float2 raw;
         if (s < H && reuse) raw = keep[m * H + s];
+        else if (s >= H && reuse) raw = make_float2(pfw[m * H + s - H].x + pfs[m * H + s - H].x, pfw[m * H + s - H].y + pfs[m * H + s - H].y);
         else {
           const int r = (px + NB * ((l + m * T) + s * (NA / R0)) + n2) & a.mask;
           const float2 vw = a.timf2w[r], vs = a.timf2s[r];
@@ -1177,6 +1178,17 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
     for (int m = 0; m < P / RL; m++)
 #pragma unroll
       for (int q = 0; q < RL; q++) col[(l + m * T) + q * (NA / RL)] = cmul(x[m * RL + q], twk[m * RL + q]);
+    // the next transform's new half (its first half is this one's second, kept in registers): in flight across the transposed store
+    if (overlap && b + 1 < t_end) {
+      const int pxn = px + a.step;
+#pragma unroll
+      for (int m = 0; m < P / R0; m++)
+#pragma unroll
+        for (int s = H; s < R0; s++) {
+          const int r = (pxn + NB * ((l + m * T) + s * (NA / R0)) + n2) & a.mask;
+          pfw[m * H + s - H] = a.timf2w[r]; pfs[m * H + s - H] = a.timf2s[r];
+        }
+    }
     __syncthreads();
     // store scratch[n2][k1], k1 fastest: thread t handles k1 = t mod NA of tile row t / NA, 1024/NA rows per sweep
     float2 *sc = a.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
