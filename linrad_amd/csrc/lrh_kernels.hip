@@ -2390,6 +2390,26 @@ __device__ __forceinline__ void sl_selfreq(const SellimArgs &a, float *B, int ti
   }
 }
 
+// the routing words k_timf2 consumes (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count, from the finished
+// table in LDS: the limiter kernels end with it (a separate one-workgroup launch cost 20-90 us on the path to the next make_timf2)
+__device__ __forceinline__ void sl_pack(const SellimArgs &a, const float *B, int tid)
+{
+  __shared__ int s_low;
+  if (tid == 0) s_low = 0;
+  __syncthreads();
+  const int nb = a.n / a.r0;
+  int low = 0;
+  for (int i = tid; i < nb; i += LRH_SL_THREADS) {
+    unsigned int m = 0;
+    for (int s = 0; s < a.r0; s++) if (B[i + s * nb] == 0) { m |= 1u << s; low++; }
+    a.pack[i] = m;
+  }
+  for (int off = 32; off > 0; off >>= 1) low += __shfl_xor(low, off);
+  if ((tid & 63) == 0 && low) atomicAdd(&s_low, low);
+  __syncthreads();
+  if (tid == 0) a.st->low = s_low;
+}
+
 // the same by one wave: every lane keeps the three smallest of its share, then the triples are merged across the lanes (the three
 // smallest values of a set do not depend on the order they are met in)
 __device__ __forceinline__ float sl_three_smallest_wave(const float *v, int ia, int ib, int lane)
@@ -2629,8 +2649,10 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
   stamp();
   for (int i = tid; i < N; i += LRH_SL_THREADS) {
     a.old_liminfo[i] = B[i];
-    a.liminfo[i] = (i < 2 || i >= N - 2) ? 0.f : B[i];       // sellim.c:1152-1155
+    const float v = (i < 2 || i >= N - 2) ? 0.f : B[i];      // sellim.c:1152-1155
+    a.liminfo[i] = v; B[i] = v;
   }
+  sl_pack(a, B, tid);
   stamp();
   if (a.debug && tid == 0) {
     printf("k_sellim ticks (10 ns):");
@@ -2750,6 +2772,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
   sl_selfreq(a, B, tid);
   __syncthreads();
   for (int i = tid; i < N; i += LRH_SL_THREADS) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
+  sl_pack(a, B, tid);
 }
 
 // liminfo floats -> the routing words of k_timf2 (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count
@@ -2782,8 +2805,8 @@ hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
+  if (a.r0 < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_sellim, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
-  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
   return hipGetLastError();
 }
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
@@ -2792,8 +2815,8 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64 || a.group_points < 16) return hipErrorInvalidValue;
+  if (a.r0 < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
-  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, st, a.liminfo, a.pack, a.n, a.r0, a.st);
   return hipGetLastError();
 }
 hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream)
