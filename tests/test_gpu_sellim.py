@@ -76,3 +76,49 @@ def test_hip_wideband_dsp_makes_the_limiter_calls_itself(pipeline, monkeypatch):
         keep[(h["p"]["timf2_pa"] + np.arange(4 * 512)) % keep.size] = False
         err = np.linalg.norm((h["timf2"] - o["timf2"]) * keep) / np.linalg.norm(o["timf2"] * keep)
         assert err < 1e-5 and np.count_nonzero(h["lim"]) > 50, (err, fft2_too)
+
+
+def test_fullsize_limiters_match_oracle():
+    """fft1_size 16384 / fft2_size 65536 (BASELINE sizes; the limiter kernels' LDS layout, bit words and group loops at their real
+    extent): both limiters inside lrh_wideband_dsp on the bench's synthetic signal, HIP against the oracle -- same table after the
+    run, same amplitude factor, same pointers, timf2 to the north-star tolerance"""
+    import numpy as np
+    from linrad_amd import abi
+    from linrad_amd.abi import default_sellim
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config
+    from oracle_binding import open_oracle
+    n1, nblk, batch = 16384, 96, 16
+    cfg = chain_config(14, 16, batch=batch, rounds=nblk // batch)
+    s = synth_defaults(n1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    res = []
+    for fn in (open_hip, open_oracle):
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_mix1_selfreq(0.31 * 65536 + 0.3)
+        par = default_sellim(cfg, fft1_blocktime=(n1 // 2) / 160e6, blanker_ston_fft1=30.0, blanker_ston_fft2=30.0, fft2_blocktime=32768 / 160e6, exact_stats=1)
+        rx.wideband_limiter(par, True)
+        rx.wideband_dsp(nblk, batch)
+        res.append(dict(lim=rx.get_liminfo(), amp=rx.liminfo_amplitude_factor(), p=rx.p.as_dict(), timf2=rx.export(abi.RING_TIMF2_FLOAT),
+                        bs=rx.blanker_state()))
+        rx.close()
+    h, o = res
+    ints = [k for k, v in h["p"].items() if isinstance(v, int)]
+    assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
+    strong = int(np.count_nonzero(o["lim"]))
+    mism = int(np.sum(np.sign(h["lim"]) != np.sign(o["lim"])))
+    print("strong bins", strong, "pattern mismatches", mism, "amp", h["amp"], o["amp"], "attenuated", int(np.sum(o["lim"] > 0)))
+    assert strong > 20 and mism == 0 and abs(h["amp"] - o["amp"]) <= 1e-6
+    pos = o["lim"] > 0
+    if pos.any():
+        assert np.max(np.abs(h["lim"][pos] - o["lim"][pos]) / o["lim"][pos]) <= 1e-5
+    keep = np.ones(h["timf2"].size, bool)
+    keep[(h["p"]["timf2_pa"] + np.arange(4 * (n1 // 2))) % keep.size] = False
+    flips = np.nonzero((((h["timf2"][0::4] == 0) & (h["timf2"][1::4] == 0)) != ((o["timf2"][0::4] == 0) & (o["timf2"][1::4] == 0))) & keep[0::4])[0]
+    for i in flips[:8]:
+        keep[4 * i:4 * i + 4] = False
+    assert len(flips) <= 8
+    err = np.linalg.norm((h["timf2"].astype(np.float64) - o["timf2"]) * keep) / np.linalg.norm(o["timf2"] * keep)
+    print("timf2", err, "flips", len(flips))
+    assert err < 1e-5
