@@ -684,7 +684,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   return LRH_OK;
 }
 
-// fft1_update_liminfo + selfreq_liminfo on the device (include/linrad_hip.h); k_sellim, k_pack_liminfo
+// fft1_update_liminfo + selfreq_liminfo on the device (include/linrad_hip.h); k_sellim / k_sellim2 (the routing words are their last step)
 // installs the weak-bin count of update number `seq` (1-based) once its readback has arrived
 static int sellim_install(lrh_ctx *c, unsigned seq)
 {

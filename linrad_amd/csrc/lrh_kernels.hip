@@ -2775,30 +2775,6 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
   sl_pack(a, B, tid);
 }
 
-// liminfo floats -> the routing words of k_timf2 (bit s of word i: bin i + s N/R0 is weak, timf2.c:50) and the weak-bin count
-__global__ __launch_bounds__(256) void k_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st)
-{
-  __shared__ int red[4];
-  int low = 0;
-  if (r0 == 0) {                                         // four-step timf2 (fft1_size 32768): dense, bit (k & 31) of word k >> 5
-    for (int i = threadIdx.x; i < n / 32; i += 256) {
-      unsigned int m = 0;
-      for (int s = 0; s < 32; s++) if (liminfo[32 * i + s] == 0) { m |= 1u << s; low++; }
-      pack[i] = m;
-    }
-  }
-  const int nb = r0 ? n / r0 : 0;
-  for (int i = threadIdx.x; i < nb; i += 256) {
-    unsigned int m = 0;
-    for (int s = 0; s < r0; s++) if (liminfo[i + s * nb] == 0) { m |= 1u << s; low++; }
-    pack[i] = m;
-  }
-  for (int off = 32; off > 0; off >>= 1) low += __shfl_xor(low, off);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = low;
-  __syncthreads();
-  if (threadIdx.x == 0) st->low = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
   const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
@@ -2817,11 +2793,6 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
   if (lds > 160 * 1024 - 64 || a.group_points < 16) return hipErrorInvalidValue;
   if (a.r0 < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
-  return hipGetLastError();
-}
-hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream)
-{
-  hipLaunchKernelGGL(k_pack_liminfo, dim3(1), dim3(256), 0, stream, liminfo, pack, n, r0, st);
   return hipGetLastError();
 }
 }  // namespace lrh

@@ -250,7 +250,6 @@ struct SellimArgs {
 };
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
-hipError_t launch_pack_liminfo(const float *liminfo, unsigned int *pack, int n, int r0, SellimState *st, hipStream_t stream);
 }
 
 // ---- spur subtraction (eliminate_spurs, spur.c:36-494) ----
