@@ -1272,7 +1272,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   if (c->clever_on) {
     // the pulse search runs first (blank1.c:765-1003) and decides where the next call resumes: one int comes back, the call waits for it
     if (c->rec) return fail(c, LRH_ESTATE, "linear blanker inside the deferred schedule");
-    if (a.total > c->cfg.timf2pow_size - 256) return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring");
+    if (a.total > c->cfg.timf2pow_size - 1024) return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring");   // the backup keeps 256 samples either side
     CleverArgs ca; memset(&ca, 0, sizeof ca);
     ca.pwr = c->d_pwr; ca.timf2w = c->d_timf2w; ca.flag = c->d_bln_flag; ca.cand = c->d_bln_cand; ca.mask = mask;
     ca.pbeg = pbeg; ca.total = a.total; ca.R = c->cfg.blnfit_range; ca.pwid = c->cfg.blanker_pulsewidth; ca.rs = c->bt.refpul_size;
