@@ -396,8 +396,14 @@ __device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x
           // is a uniform base plus the thread index
           const size_t base = (size_t)(pa & a.mask) + m * T + q * (N / RL);
           const unsigned int t = (unsigned int)tid;
-          if constexpr (ST == 0) { (a.timf2w + base)[t] = o; (a.pwr + base)[t] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
-          else (a.timf2s + base)[t] = o;
+          // written once and not read again before a whole round has passed: streaming stores leave the L2 to the spectra,
+          // whose second read (the previous transform's copy, one trip later) is what can hit there
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v2f ov = { o.x, o.y };
+          if constexpr (ST == 0) {
+            __builtin_nontemporal_store(ov, reinterpret_cast<v2f *>(a.timf2w + base) + t);
+            __builtin_nontemporal_store(o.x * o.x + o.y * o.y, (a.pwr + base) + t);   // weak power only (timf2.c:1010-1012)
+          } else __builtin_nontemporal_store(ov, reinterpret_cast<v2f *>(a.timf2s + base) + t);
         } else {
           const int r = (pa + pos) & a.mask;
           if constexpr (ST == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }
