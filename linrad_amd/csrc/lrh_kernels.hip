@@ -17,6 +17,14 @@
 
 namespace lrh {
 constexpr int LRH_MAX_REFPULSES_K = 256;            // MAX_REFPULSES, blnkdef.h:6
+// streaming store: a ring that is written once here and read next by another kernel, a whole launch later, need not displace what
+// this kernel re-reads from the L2
+__device__ __forceinline__ void store_stream(float2 *p, float2 v)
+{
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f ov = { v.x, v.y };
+  __builtin_nontemporal_store(ov, reinterpret_cast<v2f *>(p));
+}
 
 // =====================================================================================================
 // fft1
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ff
     for (int e = 0; e < P; e++) {
       float2 v = x[e];
       if (a.direction < 0) v = make_float2(v.y, v.x);   // fft1.c:3660-3679
-      out[out_index(tid, e)] = cmul(v, fc[e]);
+      store_stream(&out[out_index(tid, e)], cmul(v, fc[e]));
     }
     stamp();                                             // no barrier: BlockFftL protects its buffer itself
   }
@@ -1200,7 +1208,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
     float2 *sc = a.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
     for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
       const int cc = e / NA, k1 = e - cc * NA;
-      sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+      store_stream(&sc[(size_t)cc * NA + k1], lds[cc * CS + k1]);
     }
     __syncthreads();                                     // the next transform reuses the buffer
   }
@@ -1259,7 +1267,7 @@ __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
         const int k2 = (l + m * T) + q * (NB / RL);
         const int k = k1 + NA * k2;
         const float2 v = x[m * RL + q];
-        out[k] = v;
+        store_stream(&out[k], v);
         const float p2 = v.x * v.x + v.y * v.y;
         if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
         else pw[k] = p2;
