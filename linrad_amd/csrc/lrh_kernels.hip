@@ -19,6 +19,12 @@ namespace lrh {
 constexpr int LRH_MAX_REFPULSES_K = 256;            // MAX_REFPULSES, blnkdef.h:6
 // streaming store: a ring that is written once here and read next by another kernel, a whole launch later, need not displace what
 // this kernel re-reads from the L2
+__device__ __forceinline__ float2 load_stream(const float2 *p)      // last use of a line: it need not stay in the L2
+{
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+  return make_float2(v.x, v.y);
+}
 __device__ __forceinline__ void store_stream(float2 *p, float2 v)
 {
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1178,7 +1184,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
         else if (s >= H && reuse) raw = make_float2(pfw[m * H + s - H].x + pfs[m * H + s - H].x, pfw[m * H + s - H].y + pfs[m * H + s - H].y);
         else {
           const int r = (px + NB * ((l + m * T) + s * (NA / R0)) + n2) & a.mask;
-          const float2 vw = a.timf2w[r], vs = a.timf2s[r];
+          const float2 vw = load_stream(&a.timf2w[r]), vs = load_stream(&a.timf2s[r]);
           raw = make_float2(vw.x + vs.x, vw.y + vs.y);     // weak + strong (fft2.c:100-105)
         }
         const float w = a.window[NB * ((l + m * T) + s * (NA / R0)) + n2];      // cache hits after the first transform
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
 #pragma unroll
         for (int s = H; s < R0; s++) {
           const int r = (pxn + NB * ((l + m * T) + s * (NA / R0)) + n2) & a.mask;
-          pfw[m * H + s - H] = a.timf2w[r]; pfs[m * H + s - H] = a.timf2s[r];
+          pfw[m * H + s - H] = load_stream(&a.timf2w[r]); pfs[m * H + s - H] = load_stream(&a.timf2s[r]);
         }
     }
     __syncthreads();
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
 #pragma unroll
       for (int s = 0; s < R0; s++) {
         const int n2 = (l + m * T) + s * (NB / R0);
-        x[m * R0 + s] = sc[(size_t)n2 * NA + k1];
+        x[m * R0 + s] = load_stream(&sc[(size_t)n2 * NA + k1]);
       }
     BlockFft<LB, P, +1>::run(x, lds + c * CS, a.tw_b, l);
     const int na = (a.first_na + b) & a.na_mask;
