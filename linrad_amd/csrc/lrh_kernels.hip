@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft2_min_waves(LOG2N)) void k_f
       for (int q = 0; q < RL; q++) {
         const int k = (tid + m * T) + q * (N / RL);
         const float2 v = x[m * RL + q];
-        out[k] = v;
+        store_stream(&out[k], v);
         const float p2 = v.x * v.x + v.y * v.y;
         if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
         else pw[k] = p2;
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(1024, 4) void k_fft1_cols(Fft1BigArgs g)
   float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
   for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
     const int cc = e / NA, k1 = e - cc * NA;
-    sc[(size_t)cc * NA + k1] = lds[cc * CS + k1];
+    store_stream(&sc[(size_t)cc * NA + k1], lds[cc * CS + k1]);
   }
 }
 template <int LA, int LB>
@@ -1795,7 +1795,7 @@ __global__ __launch_bounds__(1024) void k_fft1_rows(Fft1BigArgs g)
       int kk = (k + N / 2) & (N - 1);                     // DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
       float2 v = x[m * RL + q];
       if (a.direction < 0) { kk = (N - kk) & (N - 1); v = make_float2(v.y, v.x); }   // fft1.c:3660-3679
-      out[kk] = cmul(v, a.filtercorr[kk]);
+      store_stream(&out[kk], cmul(v, a.filtercorr[kk]));
     }
 }
 // timf2, sin^2 overlap (see k_timf2): out_t[n] = ampfac * DFT_{e^-j}( S_t + (-1)^k S_{t-1} )[n], n < N/2, per stream.
@@ -1872,8 +1872,8 @@ __global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
       const int r = (pa + o1 + NA * o2) & a.mask;
       const float2 v = x[m * RL + q];
       const float2 o = make_float2(a.ampfac * v.x, a.ampfac * v.y);
-      if (st == 0) { a.timf2w[r] = o; a.pwr[r] = o.x * o.x + o.y * o.y; }   // weak power only (timf2.c:1010-1012)
-      else a.timf2s[r] = o;
+      if (st == 0) { store_stream(&a.timf2w[r], o); __builtin_nontemporal_store(o.x * o.x + o.y * o.y, &a.pwr[r]); }   // weak power only (timf2.c:1010-1012)
+      else store_stream(&a.timf2s[r], o);
     }
 }
 hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st)
