@@ -1639,10 +1639,12 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     { const auto w0 = std::chrono::steady_clock::now();
       // the host runs up to LRH_NSTAGE rounds ahead and then waits here for most of a round: asleep, not spinning inside
       // hipEventSynchronize (which burnt a whole core: thread CPU time = wall time of the call)
+      // (small rounds finish within tens of microseconds: poll that long first, a sleep would cost the round its own length)
       for (;;) {
         const hipError_t q = hipEventQuery(c->ph_ev[slot]);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(c, LRH_EDEVICE, "hipEventQuery(staging)", q);
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count() < 60.0) continue;
         timespec ts{0, 40000}; nanosleep(&ts, nullptr);
       }
       c->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); }
