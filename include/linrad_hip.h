@@ -267,9 +267,9 @@ int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "ff
    stays on the device: one call = one run of the reference function; the routing words k_timf2 consumes are rebuilt on the
    device in stream order, so the next lrh_make_timf2 routes with the new table and no spectrum or table crosses PCIe.
    Host-visible by-product: the count of weak bins (fft1_lowlevel_points, timf2.c:37-52), read back asynchronously -- with
-   `exact_stats` the call waits for it (the reference's value at once); without, a call installs the count of the update before
-   the previous one (lrh_sync installs the newest), i.e. the statistic (not the routing) lags two updates and the host never waits
-   for work it has only just enqueued.
+   `exact_stats` the call waits for it (the reference's value at once); without, the count of the newest update whose readback has
+   arrived is installed whenever lrh_make_timf2 or the next update looks (lrh_sync installs the newest), i.e. the statistic (not
+   the routing) lags by however far the host runs ahead of the device, and the host never waits for work it has only just enqueued.
    lrh_set_liminfo and this call may be mixed: both replace the table in force. */
 typedef struct lrh_sellim {
   int struct_size;
@@ -296,14 +296,14 @@ int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
    0.5 * blanker_ston_fft2 * floor join the strong signals for the hold-off time, and a table that has grown beyond a quarter of
    the passband is thinned.  Ends with selfreq_liminfo like the fft1 variant.  Same table, same hand-over to make_timf2. */
 int lrh_fft2_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
-/* liminfo_amplitude_factor as selfreq_liminfo left it (the linear blanker scales its reference pulse with it, blank1.c:143-144);
-   the limiter calls above keep it current on the device; a host that supplies tables itself (lrh_set_liminfo) sets it here */
 /* The limiter calls of wideband_dsp's loop (wcw.c:1124-1133) inside lrh_wideband_dsp: with parameters installed here every round
    of that call ends with fft1_update_liminfo when fft1_c has completed an averaging period since the last look (fft1_liminfo_cnt),
    and, with fft2_too, fft2_update_liminfo when make_fft2 has completed a waterfall line (fft2_liminfo_cnt) -- the reference's own
    cadence in batched operation: once per pass of the loop, however many periods the pass covered.  par = NULL: off (the caller
    makes the calls itself).  fft2_too keeps lrh_wideband_dsp off its one-round-late schedule (the fft2 of a round must have run). */
 int lrh_wideband_limiter(lrh_ctx *ctx, const lrh_sellim *par, int fft2_too);
+/* liminfo_amplitude_factor as selfreq_liminfo left it (the linear blanker scales its reference pulse with it, blank1.c:143-144);
+   the limiter calls above keep it current on the device; a host that supplies tables itself (lrh_set_liminfo) sets it here */
 int lrh_get_liminfo_amplitude_factor(lrh_ctx *ctx, float *factor);   /* synchronous */
 int lrh_set_liminfo_amplitude_factor(lrh_ctx *ctx, float factor);
 int lrh_get_liminfo(lrh_ctx *ctx, float *liminfo /* N1 floats: the table in force */);     /* synchronous */
