@@ -484,7 +484,13 @@ int lrh_get_mix1_state(lrh_ctx *ctx, lrh_mix1_state *st);
    configured (cfg.fft3_n > 0) and a frequency selected the narrowband side follows mix1 like do_fft3 / do_mix2 follow
    EVENT_FFT3 / EVENT_MIX2 (wcw.c:1788,1828; fft3.c:35-60; mix2.c:41-80): every transform timf3 holds through
    lrh_make_fft3_all and lrh_fft3_mix2 -- unless a coherent combine is set (lrh_set_pol / lrh_set_combine_weights): its
-   collective belongs between lrh_mix2_pol_begin and lrh_fft3_mix2, so the caller then runs those calls itself. */
+   collective belongs between lrh_mix2_pol_begin and lrh_fft3_mix2, so the caller then runs those calls itself.
+   The pointers in *p are final when the call returns.  Device work of the call's LAST batch (its blanker, fft2 / mix1 and narrowband
+   launches) may still be held back at that moment, because large batches run a schedule that issues them one batch late beside the
+   next batch's transforms: the next lrh_wideband_dsp issues them as if both calls had been one, and so does -- first thing -- every
+   other entry point that reads or changes what the chain has produced (lrh_export*, lrh_sync, the state getters, the stage and table
+   functions ...; not the producer-side lrh_timf1_write*).  A caller that passes one batch per call therefore gets the same schedule
+   as one that passes many.  LRH_PERSIST=0 in the environment makes every call issue all of its work before it returns. */
 int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
 
 /* ---- host-visible side outputs ---- */

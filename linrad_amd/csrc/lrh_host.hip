@@ -109,6 +109,9 @@ struct lrh_ctx {
   int env_fft2_run = 0, env_fft2_cols_run = 0;   // LRH_FFT2_RUN / LRH_FFT2_COLS_RUN: transforms per workgroup (0: automatic)
   unsigned long long *d_stamps = nullptr;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
+  // one-round-late schedule kept across calls: the parked launches (blanker / fft2 + mix1 of the last round) of the previous call
+  std::vector<std::function<int(lrh_ctx *)>> pend_b, pend_t; bool pend = false, pend_tail_flushed = false; int pend_batch = 0, in_dsp = 0;
+  bool persist = true;               // LRH_PERSIST=0: every call drains its pipeline before it returns
   bool pipeline_forced = false;      // LRH_PIPELINE given: no automatic choice by batch size
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
   // Deferred launches (schedule 2): while `rec` is set the stage functions do their host bookkeeping at once but append
@@ -180,7 +183,11 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
   return code;
 }
 // entry of an API call: the context's lock (see lrh_ctx::mtx) and its device for this host thread
-#define LRH_ENTER(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); hipSetDevice((c)->cfg.device); }
+#define LRH_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); hipSetDevice((c)->cfg.device); }
+// ... and, for every entry point that may look at or change what the chain has produced, the launches lrh_wideband_dsp still holds
+// back from its last round (one-round-late schedule kept across calls, see there) go out first
+static int flush_pending(lrh_ctx *c);
+#define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
 // Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
@@ -440,6 +447,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->sums_on_main = cfg->fft2_n <= 14;
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
+  if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;   // tests: the one-wave replay of the linear blanker
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
@@ -958,7 +966,7 @@ int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
 
 int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
 {
-  LRH_ENTER(c);
+  LRH_LOCK(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
@@ -972,7 +980,7 @@ void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 {
-  LRH_ENTER(c);
+  LRH_LOCK(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
@@ -990,7 +998,7 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 int lrh_timf1_write_wait(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;
-  LRH_ENTER(c);
+  LRH_LOCK(c);
   if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
   return LRH_OK;
 }
@@ -1538,7 +1546,7 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 }
 
 // ---------------------------------------------------------------------------------------------- mix1
-int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { LRH_ENTER(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
+int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { LRH_LOCK(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
 int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { LRH_ENTER(c); if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
 
 // Tuning of one mix1 transform (what set_mix1_phases, mix1.c:781-861, decides; float branch -- the double branch belongs to
@@ -1885,6 +1893,29 @@ int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
 }
 
 // ---------------------------------------------------------------------------------------------- orchestration
+// The launches the one-round-late schedule still holds when lrh_wideband_dsp returns (blanker, fft2 + mix1 + narrowband tail of its
+// last round): issued by the next lrh_wideband_dsp as if the rounds had been one call, or here, by the first other entry point that
+// needs the chain's results.
+static int flush_pending(lrh_ctx *c)
+{
+  if (!c->pend) return LRH_OK;
+  c->pend = false;
+  hipStream_t S1 = c->stream, S2 = c->stream2;
+  struct Restore { lrh_ctx *c; ~Restore() { c->cur = c->stream; c->rec = nullptr; c->split_fft2_tail = false; c->in_dsp--; c->pend_b.clear(); c->pend_t.clear(); } } restore{c};
+  c->in_dsp++;
+  if (c->pend_tail_flushed) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail, 0));
+  c->pend_tail_flushed = false;
+  c->rec = nullptr; c->cur = S2;
+  for (auto &op : c->pend_b) { const int r = op(c); if (r) return r; }
+  HIPCHK(c, hipEventRecord(c->ev_blank, S2));
+  HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
+  c->cur = S1; c->split_fft2_tail = true;
+  for (auto &op : c->pend_t) { const int r = op(c); if (r) return r; }
+  c->split_fft2_tail = false;
+  HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
+  return LRH_OK;
+}
+
 // single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round.
 // Device schedule when several rounds are requested (second fft on): the transform kernels of N = 16384 occupy one
 // workgroup per CU and are latency/compute bound, while fft1_c's sums, the blanker and the fft2 power sums are short
@@ -1940,13 +1971,14 @@ static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side poin
 int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  LRH_ENTER(c);
+  LRH_LOCK(c);
   if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "two coupled channels need the exchanges between the stage calls (lrh_blanker_begin)");
   struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double cpu0 = thread_cpu_ms();
                      static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
                      ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;
                                     c->host_cpu_ms_dsp += thread_cpu_ms() - cpu0; } } host_timer{c};
   int rc;
+  struct InDsp { lrh_ctx *c; InDsp(lrh_ctx *c_) : c(c_) { c->in_dsp++; } ~InDsp() { c->in_dsp--; } };
   // Small rounds are bound by the host's launches (~100 us per round), not by the kernels: the plain serial order has the
   // fewest stream operations and wins there (Msamples/s serial / lagged, fft1_size 16384: 82 / 80 at 1 block per round,
   // 2170 / 1990 at 32, 9420 / 9100 at 256); the two-stream schedules pay off from ~3 M samples per round (15200 / 17000 at 512).
@@ -1987,7 +2019,15 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     c->rec = keep_rec; c->cur = keep_cur;
     return r;
   };
-  if (!piped) {
+  // the one-round-late schedule, also for a single round per call when the previous call left its last round parked (or may park this one)
+  const long need2 = 2L * batch * c->M1 + 2L * c->N2 + c->cfg.blnfit_range + 4L * (c->cfg.blanker_pulsewidth + 2);
+  const bool lag_ok = c->pipeline >= 2 && !small_rounds && c->cfg.second_fft_enable && (!c->prof || c->prof_keep_schedule) && !c->clever_on &&
+                      need2 <= c->cfg.timf2pow_size && (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n &&
+                      !(c->wl_on && c->wl_fft2);          // the second limiter reads the power sums of this round's fft2
+  const bool lagged = lag_ok && (nblocks >= 3 * batch || (c->persist && nblocks % batch == 0 && nblocks >= batch));
+  if (c->pend && !(lagged && c->persist && batch == c->pend_batch)) { if ((rc = flush_pending(c))) return rc; }
+  InDsp in_dsp{c};
+  if (!piped && !lagged) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
       if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
@@ -2017,12 +2057,10 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   //   side:  sumsq(k) slowsum(k) blanker(k-1) | waterfall(k-1) | sumsq(k+1) ...
   // The stage functions do their pointer bookkeeping in the reference's order and park their launches in a queue
   // (LRH_DEVICE_WORK); results are those of the serial order because every ring holds two rounds (checked here).
-  const long need2 = 2L * batch * c->M1 + 2L * c->N2 + c->cfg.blnfit_range + 4L * (c->cfg.blanker_pulsewidth + 2);
-  const bool lagged = c->pipeline >= 2 && need2 <= c->cfg.timf2pow_size &&
-                      (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n && nblocks >= 3 * batch &&
-                      !(c->wl_on && c->wl_fft2);          // the second limiter reads the power sums of this round's fft2
   if (lagged) {
     std::vector<std::function<int(lrh_ctx *)>> qb, qt;     // parked launches: blanker / fft2+mix1 of the previous round
+    const bool carry = c->pend;                            // ... which may come from the previous call
+    if (carry) { qb.swap(c->pend_b); qt.swap(c->pend_t); c->pend = false; }
     auto flush = [&](std::vector<std::function<int(lrh_ctx *)>> &q, hipStream_t st) -> int {
       c->rec = nullptr; c->cur = st;
       for (auto &op : q) { const int r = op(c); if (r) { q.clear(); return r; } }
@@ -2032,7 +2070,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_side, 0));
     int left = nblocks, round = 0;
     int B = left < batch ? left : batch;
-    bool have_prev = false, tail_flushed = false;
+    bool have_prev = carry, tail_flushed = carry && c->pend_tail_flushed;
     on(S1); if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
     advance_fft1(c, p, B);
     HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
@@ -2083,6 +2121,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if (rc) return rc;
       have_prev = true;
       left -= B; B = Bnext; round++;
+    }
+    if (c->persist) {                                      // the last round stays parked: the next call (or flush_pending) issues it
+      c->pend_b.swap(qb); c->pend_t.swap(qt);
+      c->pend = true; c->pend_tail_flushed = tail_flushed; c->pend_batch = batch;
+      return LRH_OK;
     }
     if ((rc = side_blanker())) return rc;
     if ((rc = main_tail())) return rc;

@@ -487,3 +487,39 @@ def test_fft1_size_32768_chain_matches_oracle():
         errs["fft2"], errs["timf3"] = _relerr(h["fft2"], o["fft2"]), _relerr(h["timf3"], o["timf3"])
     print(errs, "flips", len(flips), "cleared", int(np.sum(o["pwr"] == 0)))
     assert all(v < 1e-5 for k, v in errs.items() if k != "pwr") and errs["pwr"] < 5e-5, errs
+
+
+def test_one_round_late_schedule_carries_over_calls(monkeypatch):
+    """The launches lrh_wideband_dsp holds back from its last round are issued by the next call (one round per call then runs the
+    same schedule as many rounds in one call) or by the first other entry point that needs the results: one call of 7 rounds,
+    7 calls of one round, the same with a state read after every call (a flush each time), and with LRH_PERSIST=0 (every call
+    drains) must leave every ring, pointer and the blanker state bit for bit the same."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    cfg = chain_config(14, 16, batch=16, fft3_n=12, mix2_n=8, rounds=8)
+    s = synth_defaults(N1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    lim = strong_liminfo(s, 14)
+    rings = (abi.RING_FFT1_SUMSQ, abi.RING_FFT1_SLOWSUM, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT,
+             abi.RING_FFT2_POWERSUM, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF, abi.RING_FFT3, abi.RING_BASEB_RAW)
+    monkeypatch.setenv("LRH_PIPELINE", "2")
+    res = []
+    for variant in ("one call", "call per round", "call per round + state read", "LRH_PERSIST=0"):
+        monkeypatch.setenv("LRH_PERSIST", "0" if variant == "LRH_PERSIST=0" else "1")
+        rx = _hip(cfg)
+        _feed(rx, iq, lim, 0.31 * 65536 + 0.3)
+        if variant == "one call":
+            rx.wideband_dsp(7 * 16, 16)
+        else:
+            for _ in range(7):
+                rx.wideband_dsp(16, 16)
+                if variant.endswith("state read"):
+                    rx.blanker_state()
+        bs = rx.blanker_state()
+        res.append(([rx.export(r) for r in rings], rx.p.as_dict(),
+                    (bs.timf2_noise_floor, bs.stupid_bln_limit, bs.timf2_cleared_points, bs.last_call_cleared)))
+        rx.close()
+    assert np.count_nonzero(res[0][0][-1]) > 100
+    for other in res[1:]:
+        assert other[1] == res[0][1] and other[2] == res[0][2]
+        for a, b in zip(res[0][0], other[0]):
+            assert np.array_equal(a, b)
