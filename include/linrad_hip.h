@@ -398,9 +398,19 @@ int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
      lrh_first_noise_blanker  scans the summed power, clears, leaves the own channel's every-4th-sample mean power
                               (blank1.c:1512-1541) in slot timf1_channel_index of LRH_X_STAT (2 floats, other slot 0)
      -> all-reduce(sum) LRH_X_STAT[0..2)
-     lrh_blanker_finish       the statistics / threshold update of blank1.c:1542-1601 with both channels' values  */
-enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2, LRH_X_POL = 3 };
+     lrh_blanker_finish       the statistics / threshold update of blank1.c:1542-1601 with both channels' values
+   With the linear blanker's tables installed (lrh_set_blanker_tables on both contexts) the pulse fit works on both channels at
+   once (get_pulse_pol, transform_timf2_pol, subtract_twochan_pulse, blank1.c:232-609, 984-992): it finds the polarisation of a
+   pulse from the two channels' samples around its peak and takes the fitted pulse out of both.  Both contexts then run the same
+   search on the same data and keep their own channel's result, which takes one more exchange before the scan:
+     lrh_blanker_begin        also copies the own weak samples from blnfit_range before the span to blnfit_range behind it into
+                              slot timf1_channel_index of LRH_X_WEAK (float [2][n][2]); `count` of LRH_X_PWR is then the span plus
+                              blnfit_range (the search reads the summed power that far ahead)
+     lrh_blanker_weak_span    n*2 = floats per slot of LRH_X_WEAK for this call (0: nothing to gather)
+     -> all-gather of the two slots of LRH_X_WEAK (beside the all-reduce of LRH_X_PWR)  */
+enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2, LRH_X_POL = 3, LRH_X_WEAK = 4 };
 int lrh_blanker_begin(lrh_ctx *ctx, const lrh_ptrs *p, int *count);
+int lrh_blanker_weak_span(lrh_ctx *ctx, size_t *count);
 int lrh_blanker_finish(lrh_ctx *ctx, lrh_ptrs *p);
 /* Cross products of the two channels' fft2 spectra (make_fft2's two-channel branch, fft2.c:1622-1640: per transform and bin
    TWOCHAN_POWER {x2 = |X|^2, y2 = |Y|^2, im_xy = Xim*Yre - Xre*Yim, re_xy = Xre*Yre + Xim*Yim},

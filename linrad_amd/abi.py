@@ -220,6 +220,7 @@ class StageAPI:
         self._proto("first_noise_blanker", [vp, C.POINTER(LrhPtrs)])
         self._proto("blanker_begin", [vp, C.POINTER(LrhPtrs), ip])
         self._proto("blanker_finish", [vp, C.POINTER(LrhPtrs)])
+        self._proto("blanker_weak_span", [vp, C.POINTER(C.c_size_t)])
         self._proto("fft2_xy_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
         self._proto("fft2_xy_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("set_pol", [vp, C.c_float, C.c_float, C.c_float])
@@ -312,7 +313,7 @@ class StageAPI:
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
 
     # ---- two coupled RF channels (cfg.blanker_channels = 2): see include/linrad_hip.h
-    X_PWR, X_STAT, X_BINS, X_POL = 0, 1, 2, 3
+    X_PWR, X_STAT, X_BINS, X_POL, X_WEAK = 0, 1, 2, 3, 4
 
     def ptrs_copy(self):
         """the pointer state as it is now (`at` of lrh_fft2_xy_begin / finish: taken before make_fft2)"""
@@ -345,6 +346,12 @@ class StageAPI:
     def blanker_begin(self):
         n = C.c_int()
         self._chk(self._f("blanker_begin")(self.ctx, C.byref(self.p), C.byref(n)), "blanker_begin")
+        return n.value
+
+    def blanker_weak_span(self):
+        """floats per slot of X_WEAK the coming first_noise_blanker wants gathered (linear blanker on two coupled channels; else 0)"""
+        n = C.c_size_t()
+        self._chk(self._f("blanker_weak_span")(self.ctx, C.byref(n)), "blanker_weak_span")
         return n.value
 
     def blanker_finish(self):

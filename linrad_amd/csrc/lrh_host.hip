@@ -43,6 +43,7 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
 hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
+hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
@@ -100,6 +101,7 @@ struct lrh_ctx {
   float ch2_c1 = 1.0f, ch2_c2 = 0.0f;   // lrh_set_ch2_phasing
   // two coupled RF channels (cfg.blanker_channels == 2): summed power ring, exchange buffers, state between the calls
   float *d_pwr_sum = nullptr, *d_xbuf = nullptr, *d_xstat = nullptr;
+  float2 *d_xweak = nullptr, *d_tf_partner = nullptr; int x_span = 0, xw_count = 0;   // linear blanker on two coupled channels: LRH_X_WEAK, the partner's samples in ring places
   float2 *d_net = nullptr; size_t net_cap = 0;      // staging of lrh_export_timf2_net
   float2 *d_fft1net = nullptr; int fft1net_cap = 0; // staging of lrh_export_fft1_net: bare transforms, [pow2 >= batch][N1]
   float2 *d_xpol = nullptr; float2 pol_wa = {1.f, 0.f}, pol_wb = {0.f, 0.f}; bool pol_set = false; int pol_batch = 0;   // LRH_X_POL [2][max_fft3n][Nm2]; pg.c1..c3
@@ -357,7 +359,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -857,11 +859,10 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-  for (void **q_ : { (void **)&c->d_bt_refpulse, (void **)&c->d_bt_phasefunc, (void **)&c->d_bt_pulindex, (void **)&c->d_bln_flag, (void **)&c->d_bln_cand })
+  for (void **q_ : { (void **)&c->d_bt_refpulse, (void **)&c->d_bt_phasefunc, (void **)&c->d_bt_pulindex, (void **)&c->d_bln_flag, (void **)&c->d_bln_cand, (void **)&c->d_xweak, (void **)&c->d_tf_partner })
     if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->clever_on = false;
   if (!t) return LRH_OK;
-  if (c->cfg.blanker_channels == 2) return fail(c, LRH_EINVAL, "linear blanker: one RF channel only");
   const int rs = t->refpul_size, pw = c->cfg.blanker_pulsewidth;
   if (t->clever_bln_mode < 1 || t->clever_bln_mode > 2 || rs < 4 || rs > 256 || (rs & (rs - 1)) || t->largest_blnfit < 0 ||
       t->largest_blnfit >= LRH_BLN_INFO_SIZE || !t->refpulse || !t->phasefunc || !t->pulindex || pw < 1 || 2 * pw >= rs)
@@ -875,6 +876,7 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
   int rc = LRH_OK;
   if ((rc = dev_alloc(c, &c->d_bt_refpulse, nr)) || (rc = dev_alloc(c, &c->d_bt_phasefunc, (size_t)2 * rs)) || (rc = dev_alloc(c, &c->d_bt_pulindex, LRH_MAX_REFPULSES)) ||
       (rc = dev_alloc(c, &c->d_bln_flag, (size_t)c->cfg.timf2pow_size)) || (rc = dev_alloc(c, &c->d_bln_cand, (size_t)c->cfg.timf2pow_size / 64))) return rc;
+  if (c->cfg.blanker_channels == 2 && ((rc = dev_alloc(c, &c->d_xweak, (size_t)2 * c->cfg.timf2pow_size)) || (rc = dev_alloc(c, &c->d_tf_partner, (size_t)c->cfg.timf2pow_size)))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_bt_refpulse, t->refpulse, 4 * nr, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_bt_phasefunc, t->phasefunc, 8 * (size_t)rs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES, hipMemcpyHostToDevice, c->stream));
@@ -1269,8 +1271,13 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   a.chans = 1;
   if (coupled) {
     if (c->fin_pending) return fail(c, LRH_ESTATE, "lrh_blanker_finish of the previous call is missing");
-    if (c->x_pbeg != pbeg || c->x_count != a.total) return fail(c, LRH_ESTATE, "lrh_blanker_begin was not called for this span");
-    HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr_sum, pbeg, a.total, mask, 1, c->cur));   // the exchanged sums take their ring places
+    if (c->x_pbeg != pbeg || c->x_count < 0 || c->x_span != a.total) return fail(c, LRH_ESTATE, "lrh_blanker_begin was not called for this span");
+    HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr_sum, pbeg, c->x_count, mask, 1, c->cur));   // the exchanged sums take their ring places
+    if (c->clever_on) {                                                   // and so do the partner channel's samples
+      if (c->xw_count <= 0) return fail(c, LRH_ESTATE, "lrh_blanker_begin ran before the blanker tables were installed");
+      const int nw = c->xw_count / 2;
+      HIPCHK(c, launch_span_copy2(c->d_xweak + (size_t)(1 - (c->cfg.timf1_channel_index & 1)) * nw, c->d_tf_partner, pbeg - c->cfg.blnfit_range, nw, mask, 1, c->cur));
+    }
     c->x_count = -1;
     a.pwr = c->d_pwr_sum; a.own = c->d_pwr; a.xstat = c->d_xstat; a.own_slot = c->cfg.timf1_channel_index & 1; a.chans = 2; a.phase = 1;
   }
@@ -1282,7 +1289,8 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     if (c->rec) return fail(c, LRH_ESTATE, "linear blanker inside the deferred schedule");
     if (a.total > c->cfg.timf2pow_size - 1024) return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring");   // the backup keeps 256 samples either side
     CleverArgs ca; memset(&ca, 0, sizeof ca);
-    ca.pwr = c->d_pwr; ca.timf2w = c->d_timf2w; ca.flag = c->d_bln_flag; ca.cand = c->d_bln_cand; ca.mask = mask;
+    ca.pwr = coupled ? c->d_pwr_sum : c->d_pwr; ca.timf2w = c->d_timf2w; ca.flag = c->d_bln_flag; ca.cand = c->d_bln_cand; ca.mask = mask;
+    if (coupled) { ca.twochan = 1; ca.chan = c->cfg.timf1_channel_index & 1; ca.timf2y = c->d_tf_partner; ca.pwr_own = c->d_pwr; }
     ca.pbeg = pbeg; ca.total = a.total; ca.R = c->cfg.blnfit_range; ca.pwid = c->cfg.blanker_pulsewidth; ca.rs = c->bt.refpul_size;
     ca.largest = c->bt.largest_blnfit; ca.amp_factor = c->bt.liminfo_amplitude_factor;
     ca.refpulse = c->d_bt_refpulse; ca.phasefunc = c->d_bt_phasefunc; ca.pulindex = c->d_bt_pulindex; ca.st = c->d_bst;
@@ -1308,7 +1316,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
       c->clv_cap = cap; c->clv_max_regions = maxr;
     }
     ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
-    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.force_serial = c->clever_force_serial ? 1 : 0;
+    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.force_serial = (c->clever_force_serial || coupled) ? 1 : 0;
     int out[3];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
@@ -1346,9 +1354,26 @@ int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
   pend &= 0xfffffffc;
   *count = 0; c->x_count = -1;
   if (((pend - pbeg + 1 + mask) & mask) < c->cfg.blanker_min_points) return LRH_OK;
-  c->x_pbeg = pbeg; c->x_count = (pend - pbeg) & mask;
+  c->x_pbeg = pbeg; c->x_span = (pend - pbeg) & mask; c->xw_count = 0;
+  // linear blanker: its search and fits read (and rewrite) up to blnfit_range samples beyond the span, and both channels' samples that far to either side
+  const int R = c->clever_on ? c->cfg.blnfit_range : 0;
+  if (c->clever_on && c->x_span > c->cfg.timf2pow_size - 1024) { c->x_count = -1; return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring"); }
+  c->x_count = c->x_span + R;
   HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr, pbeg, c->x_count, mask, 0, c->cur));
+  if (c->clever_on) {
+    const int nw = c->x_span + 2 * R + 1;
+    HIPCHK(c, launch_span_copy2(c->d_xweak + (size_t)(c->cfg.timf1_channel_index & 1) * nw, c->d_timf2w, pbeg - R, nw, mask, 0, c->cur));
+    c->xw_count = 2 * nw;
+  }
   *count = c->x_count;
+  return LRH_OK;
+}
+int lrh_blanker_weak_span(lrh_ctx *c, size_t *count)
+{
+  LRH_ENTER(c);
+  if (!c || !count) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  *count = c->x_count > 0 ? (size_t)c->xw_count : 0;
   return LRH_OK;
 }
 int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
@@ -1364,6 +1389,7 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
 {
   if (which == LRH_X_POL) { if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured"); *ptr = (float *)c->d_xpol; *cap = (size_t)4 * c->cfg.max_fft3n * c->Nm2; return LRH_OK; }
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  if (which == LRH_X_WEAK) { if (!c->d_xweak) return fail(c, LRH_ESTATE, "linear blanker tables not installed"); *ptr = (float *)c->d_xweak; *cap = (size_t)4 * c->cfg.timf2pow_size; return LRH_OK; }
   if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
   else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
   else if (which == LRH_X_BINS) { *ptr = (float *)c->d_xbins; *cap = (size_t)4 * c->cfg.max_fft2n * c->N2; }

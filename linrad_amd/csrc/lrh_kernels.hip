@@ -1982,6 +1982,18 @@ hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask
   if (count > 0) hipLaunchKernelGGL(k_span_copy, dim3((count + 255) / 256), dim3(256), 0, st, x, ring, pbeg, count, mask, to_ring);
   return hipGetLastError();
 }
+// the same for complex samples, x[i] = ring[(first + i) & mask]: the weak samples the two-channel linear blanker exchanges
+__global__ __launch_bounds__(256) void k_span_copy2(float2 *x, float2 *ring, int first, int count, int mask, int to_ring)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  if (to_ring) ring[(first + i) & mask] = x[i]; else x[i] = ring[(first + i) & mask];
+}
+hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int mask, int to_ring, hipStream_t st)
+{
+  if (count > 0) hipLaunchKernelGGL(k_span_copy2, dim3((count + 255) / 256), dim3(256), 0, st, x, ring, first, count, mask, to_ring);
+  return hipGetLastError();
+}
 // =====================================================================================================
 // linear ("clever") blanker: first_noise_blanker's pulse search / fit / subtract (blank1.c:765-1003)
 // =====================================================================================================
@@ -2067,8 +2079,10 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
 #pragma clang fp contract(off)
   constexpr int W = 128;                                  // half width of the pulse neighbourhood held in LDS
   __shared__ float s_pw[2 * W + 8], s_old[2 * W + 8], s_spw[256], s_in[2 * 2 * W + 8], s_avg[8];
-  __shared__ float2 s_tf[2 * W + 8];
+  __shared__ float2 s_tf[2 * W + 8], s_ty[2 * W + 8];
   __shared__ unsigned char s_fl[2 * W + 8], s_sfl[256];
+  // two coupled channels: X is channel 0, Y channel 1, whichever of them this context owns
+  float2 *const ring_x = (a.twochan && a.chan) ? a.timf2y : a.timf2w, *const ring_y = a.twochan ? (a.chan ? a.timf2w : a.timf2y) : nullptr;
   const int lane = threadIdx.x, mask = a.mask, total = a.total, R = a.R, pwid = a.pwid, rs = a.rs;
   const int wmask = ((mask + 1) >> 6) - 1, first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + total + 64) >> 6;
   BlankState *s = a.st;
@@ -2107,6 +2121,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
   };
   // phase 0: one region per wave (work list); phase 1: the whole span by the first wave, only when the extents collided
   if (a.phase == 1 && (a.reg_ctl[1] == 0 || blockIdx.x != 0)) return;
+  if (a.phase == 0 && a.reg_ctl[1] != 0) return;          // already known to go to the one-wave replay (too many regions, forced): nothing to undo
   const int nreg = a.phase == 1 ? 1 : a.reg_ctl[0];
   for (int reg = blockIdx.x; reg < nreg; reg += gridDim.x) {
   const int r_begin = a.phase == 1 ? 0 : a.reg_start[reg];
@@ -2150,7 +2165,10 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     { const int wn = max(a.bln_size[a.largest] / 2, pwid) + 1; ext_lo = min(ext_lo, p_max - wn); ext_hi = max(ext_hi, p_max + wn); }
     // ---- neighbourhood of the pulse into LDS
     __syncthreads();
-    for (int i = lane; i <= 2 * W; i += 64) { const int pos = POS(p_max - W + i); s_pw[i] = a.pwr[pos]; s_tf[i] = a.timf2w[pos]; s_fl[i] = a.flag[pos]; }
+    for (int i = lane; i <= 2 * W; i += 64) {
+      const int pos = POS(p_max - W + i); s_pw[i] = a.pwr[pos]; s_tf[i] = ring_x[pos]; s_fl[i] = a.flag[pos];
+      if (a.twochan) s_ty[i] = ring_y[pos];
+    }
     __syncthreads();
     // ---- unresolved multiple pulses? mean power of the shells between successive fit sizes (blank1.c:909-951)
     int bln_no = 0, ia = W + 1, ib = W - 1, k = 2;
@@ -2167,12 +2185,44 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     bln_no--;
     __syncthreads();
     while (bln_no >= 0 && s_avg[bln_no] > a.bln_avgmax[bln_no]) bln_no--;
-    // ---- subtract_onechan_pulse (blank1.c:36-232)
+    // ---- subtract_onechan_pulse (blank1.c:36-232); two coupled channels: get_pulse_pol, transform_timf2_pol, subtract_twochan_pulse (:232-609)
     float rv = -1.f;
     if (bln_no >= 0) {
       const int sub = a.bln_size[bln_no];
+      bool go = true;
+      float pc1 = 1.f, pc2 = 0.f, pc3 = 0.f;
+      if (a.twochan) {
+        // polarisation of the pulse from the channels' powers and cross product around the peak: sums in the reference's order, every lane the same
+        float x2 = 0.f, y2 = 0.f, re_xy = 0.f, im_xy = 0.f;
+        for (int i = 0; i <= 2 * pwid; i++) {
+          const float2 x = s_tf[W - pwid + i], y = s_ty[W - pwid + i];
+          x2 += x.x * x.x + x.y * x.y; y2 += y.x * y.x + y.y * y.y;
+          re_xy += x.x * y.x + x.y * y.y; im_xy += x.y * y.x - x.x * y.y;
+        }
+        float t1 = x2 + y2;
+        x2 /= t1; y2 /= t1; re_xy /= t1; im_xy /= t1;
+        const float t2 = re_xy * re_xy + im_xy * im_xy;
+        const float noi2 = x2 * y2 - t2;
+        if ((double)noi2 > 0.15) go = false;              // the two channels do not carry one common signal here
+        else {
+          const float x2s = x2 - noi2, y2s = y2 - noi2;
+          if (x2s > 0.f) {
+            pc1 = (float)sqrt((double)x2s);
+            if (y2s > 0.f && t2 > 0.f) {
+              const float sina = (float)sqrt((double)y2s);
+              pc2 = (float)((double)(sina * re_xy) / sqrt((double)t2)); pc3 = (float)((double)(sina * im_xy) / sqrt((double)t2));
+              t1 = (float)sqrt((double)(pc1 * pc1 + pc2 * pc2 + pc3 * pc3));
+              pc1 /= t1; pc2 /= t1; pc3 /= t1;
+            } else { if (x2 > y2) { pc1 = 1.f; pc2 = 0.f; } else { pc1 = 0.f; pc2 = 1.f; } pc3 = 0.f; }
+          } else { pc1 = 0.f; pc2 = 1.f; pc3 = 0.f; }
+        }
+      }
       for (int i = lane; i <= 2 * pwid; i += 64) {
-        const float2 t = s_tf[W - pwid + i];
+        float2 t = s_tf[W - pwid + i];
+        if (a.twochan) {                                  // the one signal that carries the pulse
+          const float2 y = s_ty[W - pwid + i];
+          t = make_float2(pc1 * t.x + pc2 * y.x - pc3 * y.y, pc1 * t.y + pc2 * y.y + pc3 * y.x);
+        }
         const int kk = rs - 2 * pwid + 2 * i;
         const float t3 = a.phasefunc[kk], t4 = a.phasefunc[kk + 1];
         s_in[2 * i] = t.x * t3 + t.y * t4; s_in[2 * i + 1] = t.y * t3 - t.x * t4;
@@ -2182,7 +2232,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
       float c1 = 0.f, c2 = 0.f;
       for (int i = imax - 1; i <= imax + 1; i++) { const float t1 = s_in[2 * i], t2 = s_in[2 * i + 1], t3 = sqrtf(t1 * t1 + t2 * t2); c1 += t3 * t1; c2 += t3 * t2; }
       float t1 = c1 * c1 + c2 * c2;
-      bool go = !(t1 < 32.f);
+      if (a.twochan ? sqrtf(t1) < 4.f : t1 < 32.f) go = false;       // blank1.c:274-275 / :101-103
       float t3 = 0.f, t4 = 0.f;
       if (go) {
         t1 = sqrtf(t1); c1 /= t1; c2 /= t1;
@@ -2201,38 +2251,63 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
         if (t3 == 0.f) { go = false; rv = -2.f; }
       }
       if (go) {
-        t4 /= t3;                                         // peak position within the sample by a parabola, then the reference pulse for it
-        if (t4 < 0) t4 = (float)(-sqrt(0.5) * sqrt((double)-t4)); else t4 = (float)(sqrt(0.5) * sqrt((double)t4));
+        // peak position within the sample by a parabola, then the reference pulse for it
+        if (a.twochan) { t4 /= 2 * t3; t4 = t4 < 0 ? (float)(-sqrt((double)-t4)) : (float)sqrt((double)t4); }
+        else { t4 /= t3; if (t4 < 0) t4 = (float)(-sqrt(0.5) * sqrt((double)-t4)); else t4 = (float)(sqrt(0.5) * sqrt((double)t4)); }
         int j = (int)(LRH_MAX_REFPULSES_K * ((double)t4 + 0.5) + 0.5);
         if (j < 0) j = 0;
         if (j >= LRH_MAX_REFPULSES_K) j = LRH_MAX_REFPULSES_K - 1;
         const int mrp = 2 * a.pulindex[j] * rs;
-        { const float af = s->amp_factor; c1 *= s_in[2 * imax] * af; c2 *= s_in[2 * imax] * af; }     // liminfo_amplitude_factor (blank1.c:143-144)
+        { const float af = s->amp_factor;                 // liminfo_amplitude_factor (blank1.c:143-144 / :323-324)
+          if (a.twochan) { c1 = c1 * s_in[2 * imax] * af; c2 = c2 * s_in[2 * imax] * af; } else { c1 *= s_in[2 * imax] * af; c2 *= s_in[2 * imax] * af; } }
         __syncthreads();
         for (int jj = lane; jj <= sub; jj += 64) {
           const int q = W - sub / 2 + jj, kk = rs - sub + 2 * jj;
           const float r1 = a.refpulse[mrp + kk], r2 = a.refpulse[mrp + kk + 1];
           const float2 x = s_tf[q];
-          const float re = x.x - c1 * r1 + c2 * r2, im = x.y - c1 * r2 - c2 * r1;
-          s_tf[q] = make_float2(re, im); s_old[q] = s_pw[q]; s_pw[q] = re * re + im * im;
+          s_old[q] = s_pw[q];
+          if (a.twochan) {
+            const float2 y = s_ty[q];
+            const float re_a = c1 * r1 - c2 * r2, im_a = c1 * r2 + c2 * r1;
+            const float re_x = x.x - pc1 * re_a, im_x = x.y - pc1 * im_a;
+            const float re_y = y.x - (pc2 * re_a + pc3 * im_a), im_y = y.y - (pc2 * im_a - pc3 * re_a);
+            s_tf[q] = make_float2(re_x, im_x); s_ty[q] = make_float2(re_y, im_y);
+            s_pw[q] = re_x * re_x + im_x * im_x + re_y * re_y + im_y * im_y;
+          } else {
+            const float re = x.x - c1 * r1 + c2 * r2, im = x.y - c1 * r2 - c2 * r1;
+            s_tf[q] = make_float2(re, im); s_pw[q] = re * re + im * im;
+          }
         }
         __syncthreads();
         t3 = 0.f; t4 = 0.f;
         for (int q = W - sub / 2; q <= W + sub / 2; q++) { t3 += s_old[q]; t4 += s_pw[q]; }
         rv = t4 / t3;
-        if (rv > 0.5f) {                                  // the fit removed too little: put the samples back (with the reference's signs, see the oracle)
+        if (rv > 0.5f) {                                  // the fit removed too little: put the samples back (one channel: with the reference's signs, see the oracle)
           __syncthreads();
           for (int jj = lane; jj <= sub; jj += 64) {
             const int q = W - sub / 2 + jj, kk = rs - sub + 2 * jj;
             const float r1 = a.refpulse[mrp + kk], r2 = a.refpulse[mrp + kk + 1];
             const float2 x = s_tf[q];
-            const float re = x.x + c1 * r1 + c2 * r2, im = x.y + c1 * r2 - c2 * r1;
-            s_tf[q] = make_float2(re, im); s_pw[q] = re * re + im * im;
+            if (a.twochan) {
+              const float2 y = s_ty[q];
+              const float re_a = c1 * r1 - c2 * r2, im_a = c1 * r2 + c2 * r1;
+              const float re_x = x.x + pc1 * re_a, im_x = x.y + pc1 * im_a;
+              const float re_y = y.x + (pc2 * re_a + pc3 * im_a), im_y = y.y + (pc2 * im_a - pc3 * re_a);
+              s_tf[q] = make_float2(re_x, im_x); s_ty[q] = make_float2(re_y, im_y);
+              s_pw[q] = re_x * re_x + im_x * im_x + re_y * re_y + im_y * im_y;
+            } else {
+              const float re = x.x + c1 * r1 + c2 * r2, im = x.y + c1 * r2 - c2 * r1;
+              s_tf[q] = make_float2(re, im); s_pw[q] = re * re + im * im;
+            }
           }
           rv = -5.f;
         }
         __syncthreads();
-        for (int jj = lane; jj <= sub; jj += 64) { const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj); a.timf2w[pos] = s_tf[q]; a.pwr[pos] = s_pw[q]; }
+        for (int jj = lane; jj <= sub; jj += 64) {
+          const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj);
+          ring_x[pos] = s_tf[q]; a.pwr[pos] = s_pw[q];
+          if (a.twochan) { ring_y[pos] = s_ty[q]; const float2 o = a.chan ? s_ty[q] : s_tf[q]; a.pwr_own[pos] = o.x * o.x + o.y * o.y; }
+        }
       }
     }
     const unsigned char value = rv < 0.f ? 65 : 66;

@@ -136,6 +136,9 @@ struct CleverArgs {
   float *bk_pwr; float2 *bk_tf; int bk_margin;                // copies of offsets -bk_margin .. total + bk_margin
   int phase;                // k_clever_prep: 0 first pass (+ backup), 1 restore if violated; k_clever: 0 parallel, 1 serial if violated
   int force_serial;         // tests: report a violation whatever the extents say
+  // two coupled channels (blank1.c:984-992): pwr is the ring of summed powers, timf2w the own channel (number `chan`), timf2y the
+  // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring.  One-wave replay only.
+  int twochan, chan; float2 *timf2y; float *pwr_own;
 };
 hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 

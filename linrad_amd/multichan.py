@@ -112,10 +112,14 @@ def coupled_fft3_mix2(rx, batch, dist, device=None):
 
 
 def coupled_blanker(rx, dist, device=None):
-    """first_noise_blanker of one of two coupled channels: power-sum exchange, scan, noise-statistic exchange, update
-    (include/linrad_hip.h; blank1.c:1017, 1236-1300, 1510-1545, 1570)."""
+    """first_noise_blanker of one of two coupled channels: power-sum exchange (with the linear blanker's tables installed also an
+    all-gather of the channels' weak samples), scan, noise-statistic exchange, update (include/linrad_hip.h; blank1.c:984-992, 1017,
+    1236-1300, 1510-1545, 1570)."""
     n = rx.blanker_begin()
     exchange_sum(rx, rx.X_PWR, n, dist, device)
+    nw = rx.blanker_weak_span() if n else 0            # linear blanker: both channels' weak samples around the span (blank1.c:984-992)
+    if nw:
+        exchange_gather(rx, rx.X_WEAK, nw, dist, device)
     rx.first_noise_blanker()
     if n:
         exchange_sum(rx, rx.X_STAT, 2, dist, device)

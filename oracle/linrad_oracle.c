@@ -38,6 +38,9 @@ struct lro_ctx {
   float *xpol; float pol_w[4]; int pol_set, pol_batch;   /* this channel's weights (wa_re, wa_im, wb_re, wb_im) */   /* LRH_X_POL [2][max_fft3n][Nm2][2]; pg.c1..c3 */
   float *xbins, *fft2_xypower, *fft2_xysum;   /* LRH_X_BINS [2][max_fft2n][N2][2]; TWOCHAN_POWER rings (fft2.c:1622-1640) */
   float *pwr_sum, *xbuf; float xstat[2]; int x_pbeg, x_count, fin_pending, fin_do_update; float fin_llf;
+  /* linear blanker on two coupled channels: both channels' weak samples around the span (exchange LRH_X_WEAK, all-gather) and the
+     partner channel's samples in ring places (2 floats per sample) */
+  float *xweak, *tf_partner; int x_span, xw_count;
   float ch2_c1, ch2_c2; int ch2_set;   /* pg_ch2_c1 / pg_ch2_c2 when this context carries the second RF channel */
   float *mix1_window, *mix1_sin2win, *mix1_cos2win; int Xm;   /* crossover-window mix1 (prepare_mixer, buf.c:55-111); Xm = crossover_points */
   float *wg_waterf_yfac;       /* N1 */
@@ -328,7 +331,7 @@ void lro_close(lro_ctx *c)
   void *v[] = { c->fft1tab, c->fft2tab, c->mix1tab, c->fft1_window, c->fft1_inverted_window, c->fft1_filtercorr, c->fft1_desired,
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
-                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
+                c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xweak, c->tf_partner, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
                 c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
@@ -657,9 +660,24 @@ int lro_blanker_begin(lro_ctx *c, const lrh_ptrs *p, int *count)
   pend &= 0xfffffffc;
   *count = 0; c->x_count = -1;
   if (((pend - pbeg + 1 + mask) & mask) < c->cfg.blanker_min_points) return LRH_OK;
-  c->x_pbeg = pbeg; c->x_count = (pend - pbeg) & mask;
+  c->x_pbeg = pbeg; c->x_span = (pend - pbeg) & mask; c->xw_count = 0;
+  /* linear blanker: its search and fits read (and rewrite) up to blnfit_range samples beyond the span, and +-blnfit_range of both channels' samples */
+  const int R = c->clever_on ? c->cfg.blnfit_range : 0;
+  c->x_count = c->x_span + R;
   for (int q = 1; q <= c->x_count; q++) c->xbuf[q - 1] = c->timf2_pwr[(pbeg + q) & mask];
+  if (c->clever_on) {
+    const int nw = c->x_span + 2 * R + 1, ci = c->cfg.timf1_channel_index & 1;
+    float *slot = c->xweak + (size_t)ci * 2 * nw;
+    for (int i = 0; i < nw; i++) { const int pos = (pbeg - R + i) & mask; slot[2 * i] = c->timf2_float[4 * pos]; slot[2 * i + 1] = c->timf2_float[4 * pos + 1]; }
+    c->xw_count = 2 * nw;
+  }
   *count = c->x_count;
+  return LRH_OK;
+}
+int lro_blanker_weak_span(lro_ctx *c, size_t *count)
+{
+  if (c->cfg.blanker_channels != 2 || !count) return LRH_ESTATE;
+  *count = c->x_count > 0 ? (size_t)c->xw_count : 0;
   return LRH_OK;
 }
 int lro_blanker_finish(lro_ctx *c, lrh_ptrs *p)
@@ -673,12 +691,14 @@ int lro_blanker_finish(lro_ctx *c, lrh_ptrs *p)
 static size_t exchange_cap(const lro_ctx *c, int which)
 {
   if (which == LRH_X_POL) return c->xpol ? 4 * (size_t)c->cfg.max_fft3n * c->Nm2 : 0;
+  if (which == LRH_X_WEAK) return c->xweak ? 4 * (size_t)c->cfg.timf2pow_size : 0;
   return which == LRH_X_PWR ? (size_t)c->cfg.timf2pow_size : which == LRH_X_STAT ? 2 : 4 * (size_t)c->cfg.max_fft2n * c->N2;
 }
 int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
 {
   if (which == LRH_X_POL && ptr) { if (!c->xpol) return LRH_ESTATE; *ptr = c->xpol; return LRH_OK; }
   if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
+  if (which == LRH_X_WEAK) { if (!c->xweak) return LRH_ESTATE; *ptr = c->xweak; return LRH_OK; }
   if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS && which != LRH_X_POL) return LRH_EINVAL;
   if (which == LRH_X_POL && !c->xpol) return LRH_ESTATE;
   *ptr = which == LRH_X_PWR ? (void *)c->xbuf : which == LRH_X_STAT ? (void *)c->xstat : which == LRH_X_BINS ? (void *)c->xbins : (void *)c->xpol;
@@ -700,10 +720,9 @@ int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size
 /* ---- linear ("clever") blanker: blank1.c:36-232 (subtract_onechan_pulse), :615-682 (set_flag), :765-1003 (search loop) ---- */
 int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
 {
-  free(c->bt_refpulse); free(c->bt_phasefunc); free(c->bt_pulindex); free(c->blanker_flag);
-  c->bt_refpulse = c->bt_phasefunc = NULL; c->bt_pulindex = NULL; c->blanker_flag = NULL; c->clever_on = 0;
+  free(c->bt_refpulse); free(c->bt_phasefunc); free(c->bt_pulindex); free(c->blanker_flag); free(c->xweak); free(c->tf_partner);
+  c->bt_refpulse = c->bt_phasefunc = NULL; c->bt_pulindex = NULL; c->blanker_flag = NULL; c->clever_on = 0; c->xweak = c->tf_partner = NULL;
   if (!t) return LRH_OK;
-  if (c->cfg.blanker_channels == 2) return LRH_EINVAL;
   int rs = t->refpul_size, pw = c->cfg.blanker_pulsewidth;
   if (t->clever_bln_mode < 1 || t->clever_bln_mode > 2 || rs < 4 || rs > 256 || (rs & (rs - 1)) || t->largest_blnfit < 0 ||
       t->largest_blnfit >= LRH_BLN_INFO_SIZE || !t->refpulse || !t->phasefunc || !t->pulindex || pw < 1 || 2 * pw >= rs) return LRH_EINVAL;
@@ -715,6 +734,7 @@ int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
   size_t nr = (size_t)2 * LRH_MAX_REFPULSES * rs;
   c->bt_refpulse = malloc(4 * nr); c->bt_phasefunc = malloc(8 * rs); c->bt_pulindex = malloc(4 * LRH_MAX_REFPULSES);
   c->blanker_flag = calloc(1, c->cfg.timf2pow_size);
+  if (c->cfg.blanker_channels == 2) { c->xweak = calloc(4, 4 * (size_t)c->cfg.timf2pow_size); c->tf_partner = calloc(4, 2 * (size_t)c->cfg.timf2pow_size); }
   memcpy(c->bt_refpulse, t->refpulse, 4 * nr); memcpy(c->bt_phasefunc, t->phasefunc, 8 * rs); memcpy(c->bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES);
   c->bt.refpulse = c->bt_refpulse; c->bt.phasefunc = c->bt_phasefunc; c->bt.pulindex = c->bt_pulindex;
   c->bs.clever_bln_limit = t->clever_bln_limit;
@@ -724,10 +744,9 @@ int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
 }
 
 /* blank1.c:615-682: flag +-pulsewidth around p_max and on outwards for as long as the power keeps falling */
-static void clever_set_flag(lro_ctx *c, unsigned char value, int p_max, int pbeg, int pend)
+static void clever_set_flag(lro_ctx *c, const float *pw, unsigned char value, int p_max, int pbeg, int pend)
 {
   const int mask = c->timf2pow_mask;
-  const float *pw = c->timf2_pwr;
   unsigned char *fl = c->blanker_flag;
   fl[p_max] = value;
   int pa = p_max, pb = p_max;
@@ -802,12 +821,99 @@ static float clever_subtract(lro_ctx *c, int p_max, int sub_size)
   return retval;
 }
 
+/* Two coupled channels, blank1.c:984-992: get_pulse_pol (:433-562) finds the polarisation of the pulse from the two channels'
+   samples around the peak, transform_timf2_pol (:565-609) forms the one signal that carries it, subtract_twochan_pulse (:232-430)
+   fits the reference pulse to that and takes its share out of both channels.  X is channel 0, Y channel 1; this context owns one
+   of them (ring stride 4) and holds the partner's samples of the exchanged span (stride 2).  pw is the ring of summed powers the
+   search runs on; the own channel's power ring follows the own samples.  Both contexts of a pair compute the same thing. */
+static float clever_subtract2(lro_ctx *c, float *pw, int p_max, int sub_size)
+{
+  const int mask = c->timf2pow_mask, rs = c->bt.refpul_size, pwid = c->cfg.blanker_pulsewidth, ci = c->cfg.timf1_channel_index & 1;
+  float *chp[2]; int chs[2];
+  chp[ci] = c->timf2_float; chs[ci] = 4; chp[1 - ci] = c->tf_partner; chs[1 - ci] = 2;
+  const float *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
+  float x2 = 0, y2 = 0, re_xy = 0, im_xy = 0;
+  for (int q = p_max - pwid; q <= p_max + pwid; q++) {
+    const int pos = q & mask;
+    const float re_x = chp[0][chs[0] * pos], im_x = chp[0][chs[0] * pos + 1], re_y = chp[1][chs[1] * pos], im_y = chp[1][chs[1] * pos + 1];
+    x2 += re_x * re_x + im_x * im_x; y2 += re_y * re_y + im_y * im_y;
+    re_xy += re_x * re_y + im_x * im_y; im_xy += im_x * re_y - re_x * im_y;
+  }
+  float t1 = x2 + y2;
+  x2 /= t1; y2 /= t1; re_xy /= t1; im_xy /= t1;
+  float t2 = re_xy * re_xy + im_xy * im_xy;
+  const float noi2 = x2 * y2 - t2;
+  if (noi2 > 0.15) return -1;
+  const float x2s = x2 - noi2, y2s = y2 - noi2;
+  float pc1, pc2, pc3;
+  if (x2s > 0) {
+    pc1 = sqrt(x2s);
+    if (y2s > 0 && t2 > 0) {
+      const float sina = sqrt(y2s);
+      pc2 = sina * re_xy / sqrt(t2); pc3 = sina * im_xy / sqrt(t2);
+      t1 = sqrt(pc1 * pc1 + pc2 * pc2 + pc3 * pc3);
+      pc1 /= t1; pc2 /= t1; pc3 /= t1;
+    } else { if (x2 > y2) { pc1 = 1; pc2 = 0; } else { pc1 = 0; pc2 = 1; } pc3 = 0; }
+  } else { pc1 = 0; pc2 = 1; pc3 = 0; }
+  float in[2 * 257];
+  int k = rs - 2 * pwid, i = 0;
+  for (int q = p_max - pwid; q <= p_max + pwid; q++) {
+    const int pos = q & mask;
+    const float re_x = chp[0][chs[0] * pos], im_x = chp[0][chs[0] * pos + 1], re_y = chp[1][chs[1] * pos], im_y = chp[1][chs[1] * pos + 1];
+    const float a = pc1 * re_x + pc2 * re_y - pc3 * im_y, b = pc1 * im_x + pc2 * im_y + pc3 * re_y;
+    const float t3 = phf[k], t4 = phf[k + 1];
+    in[i] = a * t3 + b * t4; in[i + 1] = b * t3 - a * t4; k += 2; i += 2;
+  }
+  const int imax = pwid, wid = 2 * pwid;
+  float c1 = 0, c2 = 0;
+  for (i = imax - 1; i <= imax + 1; i++) { const float a = in[2 * i], b = in[2 * i + 1], t3 = sqrt(a * a + b * b); c1 += t3 * a; c2 += t3 * b; }
+  t1 = sqrt(c1 * c1 + c2 * c2);
+  if (t1 < 4) return -1;
+  c1 /= t1; c2 /= t1;
+  float t3 = 0, t4 = 0;
+  for (i = 0; i <= wid; i++) {
+    const float a = in[2 * i], b = in[2 * i + 1];
+    in[2 * i] = c1 * a + c2 * b; in[2 * i + 1] = c1 * b - c2 * a;
+    t3 += in[2 * i] * in[2 * i]; t4 += in[2 * i + 1] * in[2 * i + 1];
+  }
+  if (t4 > 0.25 * t3) return -1.;
+  t4 = in[2 * imax - 2] - in[2 * imax + 2];
+  t3 = 2 * (in[2 * imax - 2] + in[2 * imax + 2] - 2 * in[2 * imax]);
+  if (t3 == 0) return -2.;
+  t4 /= 2 * t3;
+  if (t4 < 0) t4 = -sqrt(-t4); else t4 = sqrt(t4);
+  int j = LRH_MAX_REFPULSES * (t4 + 0.5) + 0.5;
+  if (j < 0) j = 0;
+  if (j >= LRH_MAX_REFPULSES) j = LRH_MAX_REFPULSES - 1;
+  const int m = 2 * c->bt_pulindex[j] * rs;
+  c1 = c1 * in[2 * imax] * c->amp_factor; c2 = c2 * in[2 * imax] * c->amp_factor;
+  for (int pass = 0; pass < 2; pass++) {                 /* 0: subtract; 1: put back when too little went away (:377-428) */
+    const float sg = pass ? 1.f : -1.f;
+    t3 = 0; t4 = 0;
+    k = rs - sub_size;
+    for (int q = p_max - sub_size / 2; q <= p_max + sub_size / 2; q++) {
+      const int pos = q & mask;
+      float *x = chp[0] + chs[0] * pos, *y = chp[1] + chs[1] * pos;
+      const float r1 = rp[m + k], r2 = rp[m + k + 1];
+      const float re_a = c1 * r1 - c2 * r2, im_a = c1 * r2 + c2 * r1;
+      const float re_x = x[0] + sg * (pc1 * re_a), im_x = x[1] + sg * (pc1 * im_a);
+      const float re_y = y[0] + sg * (pc2 * re_a + pc3 * im_a), im_y = y[1] + sg * (pc2 * im_a - pc3 * re_a);
+      x[0] = re_x; x[1] = im_x; y[0] = re_y; y[1] = im_y;
+      const float pn = re_x * re_x + im_x * im_x + re_y * re_y + im_y * im_y;
+      t3 += pw[pos]; pw[pos] = pn; t4 += pn; k += 2;
+      c->timf2_pwr[pos] = ci ? re_y * re_y + im_y * im_y : re_x * re_x + im_x * im_x;
+    }
+    if (pass) return -5;
+    if (!(t4 / t3 > 0.5)) break;
+  }
+  return t4 / t3;
+}
+
 /* the search loop of first_noise_blanker, blank1.c:765-1003; returns pf (where the scan stopped) */
-static int clever_search(lro_ctx *c, int pbeg, int pend, int *fitted_out, int *rejected_out)
+static int clever_search(lro_ctx *c, float *pw, int pbeg, int pend, int *fitted_out, int *rejected_out)
 {
   const int mask = c->timf2pow_mask, R = c->cfg.blnfit_range;
   lrh_blanker_state *s = &c->bs;
-  const float *pw = c->timf2_pwr;
   unsigned char *fl = c->blanker_flag;
   float avgpwr[LRH_BLN_INFO_SIZE];
   for (int i = 0; i < LRH_BLN_INFO_SIZE; i++) avgpwr[i] = 0;
@@ -855,10 +961,10 @@ static int clever_search(lro_ctx *c, int pbeg, int pend, int *fitted_out, int *r
     bln_no--;
     while (bln_no >= 0 && avgpwr[bln_no] > c->bt.bln[bln_no].avgmax) bln_no--;
     float rv = -1;
-    if (bln_no >= 0) rv = clever_subtract(c, p_max, c->bt.bln[bln_no].size);
-    if (rv < 0) { clever_set_flag(c, 65, p_max, pbeg, pend); rejected++; continue; }
+    if (bln_no >= 0) rv = c->cfg.blanker_channels == 2 ? clever_subtract2(c, pw, p_max, c->bt.bln[bln_no].size) : clever_subtract(c, p_max, c->bt.bln[bln_no].size);
+    if (rv < 0) { clever_set_flag(c, pw, 65, p_max, pbeg, pend); rejected++; continue; }
     fitted++;
-    clever_set_flag(c, 66, p_max, pbeg, pend);
+    clever_set_flag(c, pw, 66, p_max, pbeg, pend);
   }
   *fitted_out = fitted; *rejected_out = rejected;
   return pf;
@@ -878,13 +984,19 @@ int lro_first_noise_blanker(lro_ctx *c, lrh_ptrs *p)
   if (total < c->cfg.blanker_min_points) return LRH_OK;
   if (coupled) {
     if (c->fin_pending) return LRH_ESTATE;               /* lro_blanker_finish of the previous call is missing */
-    if (c->x_pbeg != pbeg || c->x_count != ((pend - pbeg) & mask)) return LRH_ESTATE;   /* lro_blanker_begin not called for this span */
+    if (c->x_pbeg != pbeg || c->x_count < 0 || c->x_span != ((pend - pbeg) & mask)) return LRH_ESTATE;   /* lro_blanker_begin not called for this span */
     for (int q = 1; q <= c->x_count; q++) pw[(pbeg + q) & mask] = c->xbuf[q - 1];
+    if (c->clever_on) {                                /* the partner's samples take their ring places */
+      if (c->xw_count <= 0) return LRH_ESTATE;
+      const int R = c->cfg.blnfit_range, nw = c->xw_count / 2;
+      const float *slot = c->xweak + (size_t)(1 - (c->cfg.timf1_channel_index & 1)) * 2 * nw;
+      for (int i = 0; i < nw; i++) { const int pos = (pbeg - R + i) & mask; c->tf_partner[2 * pos] = slot[2 * i]; c->tf_partner[2 * pos + 1] = slot[2 * i + 1]; }
+    }
     c->x_count = -1;
   }
 #define CLR(pos) do { pw[pos] = 0; own[pos] = 0; tf[4 * (pos)] = 0; tf[4 * (pos) + 1] = 0; } while (0)
   int cleared = 0, fitted = 0, rejected = 0, pf = pend;
-  if (c->clever_on) pf = clever_search(c, pbeg, pend, &fitted, &rejected);
+  if (c->clever_on) pf = clever_search(c, pw, pbeg, pend, &fitted, &rejected);
   if (c->cfg.stupid_bln_mode != 0) {
     unsigned int nfl = s->stupid_bln_limit;
     int p0 = pbeg, ifirst = 0, pk = p0;

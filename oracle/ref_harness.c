@@ -419,7 +419,7 @@ int main(int argc, char **argv)
   if (clever) {
     /* init_blanker's calibrated branch (buf.c:1786-2057) run on a synthetic amplitude calibration: the pulse response tables
        (bln[], blanker_refpulse, blanker_phasefunc, blanker_pulindex), blanker_pulsewidth and blnfit_range are the reference's own */
-    if (C != 1 || !fdesired) { fprintf(stderr, "clever=1 needs one channel and desired=<file>\n"); return 2; }
+    if (!fdesired || (C == 2 && (chain2 || !AI("blanker2", 0)))) { fprintf(stderr, "clever=1 needs desired=<file>; two channels: with blanker2=1, without chain2\n"); return 2; }
     float *des = zalloc(sizeof(float) * N1), *keep = fft1_desired;
     FILE *fd = fopen(fdesired, "rb"); if (!fd || fread(des, sizeof(float), N1, fd) != (size_t)N1) { perror(fdesired); return 2; }
     fclose(fd);
@@ -706,6 +706,7 @@ int main(int argc, char **argv)
       t2[0] = (float)timf2_noise_floor; t2[1] = (float)hg.stupid_bln_limit; t2[2] = stupid_blanker_rate;
       t2[3] = timf2_despiked_pwr[0]; t2[4] = timf2_despiked_pwrinc[0]; t2[5] = fft1_lowlevel_fraction;
       t2[6] = timf2_despiked_pwr[1]; t2[7] = timf2_despiked_pwrinc[1];
+      t2[8] = (float)hg.clever_bln_limit; t2[9] = clever_blanker_rate; t2[10] = (float)timf2_fitted_pulses;      /* get_pulse_pol / subtract_twochan_pulse at work (clever=1) */
       continue;
     }
     int pbeg = timf2p_fit;

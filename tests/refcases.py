@@ -271,6 +271,33 @@ def twochan_case(name, chain=False):
     return d, frames, make_liminfo(d)
 
 
+# ---- linear blanker on two coupled channels (harness channels=2 blanker2=1 clever=1): get_pulse_pol / transform_timf2_pol /
+# subtract_twochan_pulse (blank1.c:232-609).  Channel 1 = channel 0's carriers and pulses times gain * e^{j sky_phase} (one
+# polarisation for everything), independent noise.
+CLEVER2 = {
+    "clever2_n10": dict(base="clever_n10_n12", nblk=96, seed2=212, sky_phase=0.9, gain=0.75),
+    "clever2_n9_only": dict(base="clever_n9_n11_only", nblk=96, seed2=213, sky_phase=-2.0, gain=1.3),
+}
+
+
+def clever2_case(name):
+    """params, parameters of the clever case, frames {I0,Q0,I1,Q1}, liminfo, calibration target"""
+    t = CLEVER2[name]
+    d, cl, iq, lim, des = clever_case(t["base"])
+    d.update(nblk=t["nblk"], ch2_c1=1.0, ch2_c2=0.0, fq=-1.0, second_fft=1)
+    z0 = iq[0::2].astype(np.float64) + 1j * iq[1::2]
+    n = z0.size
+    rng0 = np.random.default_rng(d["seed"])
+    noise0 = rng0.normal(0, d["sigma"], n) + 1j * rng0.normal(0, d["sigma"], n)      # the first draws of make_input
+    rng = np.random.default_rng(t["seed2"])
+    z1 = (z0 - noise0) * t["gain"] * np.exp(1j * t["sky_phase"]) + rng.normal(0, d["sigma"], n) + 1j * rng.normal(0, d["sigma"], n)
+    frames = np.empty(4 * n, np.int16)
+    frames[0::4], frames[1::4] = iq[0::2], iq[1::2]
+    frames[2::4] = np.clip(np.round(z1.real), -32767, 32767)
+    frames[3::4] = np.clip(np.round(z1.imag), -32767, 32767)
+    return d, cl, frames, lim, des
+
+
 # ---- selective limiter on (harness sellim=1): fft1_update_liminfo runs after every averaging period and make_timf2 routes with its table
 SELLIM = {
     # strong carrier above the SELLIM_MAXLEVEL limit (pass 1: attenuation with tapered skirts), medium carriers picked up by the

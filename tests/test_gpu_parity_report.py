@@ -55,6 +55,14 @@ def test_parity_report():
     for name in CLEVER:
         g = cleverlib.load(name)
         report["feature_cases"][name] = _clean(cleverlib.compare(cleverlib.run(open_hip, name, g), g, 1e-5))
+    import clever2lib
+    from refcases import CLEVER2
+    for name in CLEVER2:                                   # the linear blanker on two coupled channels, one context per channel
+        g = clever2lib.load(name)
+        res = clever2lib.run(open_hip, name, g, frames_mode=False)
+        report["feature_cases"][name] = _clean(clever2lib.compare(res, g, 1e-5))
+        for rx in res["rxs"]:
+            rx.close()
     esc = {k: v["escapes"] for k, v in report["golden_cases"].items() if v["escapes"]}
     report["summary"] = {"cases": len(report["golden_cases"]), "cases_with_an_escape": esc,
                          "blanker_flips_total": sum(v["blanker_flips"] for v in report["golden_cases"].values()),

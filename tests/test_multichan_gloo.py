@@ -126,6 +126,67 @@ def test_coupled_two_channel_blanker_over_gloo():
         assert np.count_nonzero(res[ch]["fft2"]) > 0            # the chain went on behind the blanker (make_fft2 on the released data)
 
 
+def _clever2_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import cleverlib
+    from linrad_amd import abi
+    from linrad_amd.multichan import coupled_blanker
+    from oracle_binding import open_oracle
+    from refcases import clever2_case, lrh_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    name = "clever2_n10"
+    g = cleverlib.load(name)
+    d, cl, frames, lim, des = clever2_case(name)
+    bi = g["bln_ints"]
+    d = dict(d, pulsewidth=int(bi[1]), blnfit_range=int(bi[3]))
+    iq = np.ascontiguousarray(frames.reshape(-1, 4)[:, 2 * rank:2 * rank + 2]).ravel()
+    rx = open_oracle(lrh_config(d, iq, blanker_channels=2, timf1_channel_index=rank))
+    rx.timf1_write(iq)
+    rx.set_liminfo(lim)
+    cleverlib.install_tables(rx, g, d["noise_floor"])
+    fitted = []
+    for _ in range(d["nblk"]):
+        rx.fft1_b(1), rx.fft1_c(1), rx.make_timf2(1)
+        coupled_blanker(rx, dist)
+        fitted.append(rx.blanker_state().timf2_fitted_pulses)
+    out = dict(timf2=rx.export(abi.RING_TIMF2_FLOAT), fitted=fitted, fit=rx.p.timf2p_fit, pa=rx.p.timf2_pa, n1=rx.N1)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_coupled_linear_blanker_over_gloo():
+    """The linear blanker on two channels, one per rank: power-sum all-reduce plus the all-gather of the channels' weak samples
+    (multichan.coupled_blanker); both ranks run the same fits and end with the compiled two-channel reference's pulse counts and
+    their channel of its timf2 ring."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_clever2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(ROOT, "tests", "golden", "clever2_n10.npz"))
+    it, tr = g["itrace"].reshape(-1, 16), g["trace"].reshape(-1, 16)
+    assert res[0]["fitted"] == res[1]["fitted"] == tr[:, 10].astype(int).tolist() and max(res[0]["fitted"]) > 5
+    assert res[0]["fit"] == res[1]["fit"] == int(it[-1, 1])
+    gt = g["timf2_float"].reshape(-1, 2, 2, 2)
+    keep = np.ones(gt.shape[0], bool)
+    keep[(res[0]["pa"] // 4 + np.arange(res[0]["n1"] // 2)) % keep.size] = False
+    for ch in (0, 1):
+        t = res[ch]["timf2"].reshape(-1, 2, 2)[keep]
+        ref = gt[keep][:, :, ch, :]
+        assert np.linalg.norm(t - ref) <= 2e-6 * np.linalg.norm(ref)
+
+
 def _chain_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
