@@ -173,8 +173,9 @@ typedef struct lrh_blanker_state {
 /* ---- linear ("clever") noise blanker: first_noise_blanker's pulse search / fit / subtract part (blank1.c:765-1003 with
    subtract_onechan_pulse :36-232 and set_flag :615-682).  It needs the pulse response of the calibrated receiver, which
    init_blanker (buf.c:1786-2057) derives from the amplitude calibration fft1_desired at start-up: those tables are an INPUT
-   here, handed over once (the calibration itself -- cal*.c -- is outside this path).  One RF channel only (the two-channel
-   variant get_pulse_pol / subtract_twochan_pulse is not built: LRH_EINVAL with cfg.blanker_channels = 2).
+   here, handed over once (the calibration itself -- cal*.c -- is outside this path).  Two coupled channels
+   (cfg.blanker_channels = 2): install the same tables on both contexts; the fit is then the two-channel one (get_pulse_pol,
+   transform_timf2_pol, subtract_twochan_pulse, blank1.c:232-609) and takes one more exchange, see lrh_blanker_begin.
    With tables installed lrh_first_noise_blanker first runs the pulse search over the span, then the stupid blanker
    (cfg.stupid_bln_mode) as before; timf2p_fit follows blank1.c:1458-1461 ((pf-16) & ~3: a pulse too close to the end of the
    span is left for the next call), which makes that pointer data dependent: the call reads one int back, so
