@@ -2533,6 +2533,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
   float *B = A + N + 16;                   // liminfo
   float *G = B + N + 8;                    // liminfo_group_min (at most N/16 groups; sized N/4 + 8)
   unsigned int *hotw = (unsigned int *)(G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
+  unsigned int *touched = hotw + (N + 31) / 32 + 4;        // [N/32 + 2] pass 1: bins thread 0 has decided
   __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
   const int NW = (N + 31) / 32;
   long long ts[10]; int nts = 0;
@@ -2588,21 +2589,25 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
     return N;
   };
   // ---- pass 1 (sellim.c:789-865): bins at or below the limit become weak; a run above the limit gets one attenuation over
-  // its whole width and tapered skirts.  The serial scan zeroes a bin when it passes it; here all bins at or below the limit
-  // are zeroed up front by all threads, and thread 0 only visits the runs -- reading, for the bins the serial scan has not
-  // reached yet at that moment, the previous update's value (still in a.liminfo) instead of the zero put there early.
+  // its whole width and tapered skirts.  The serial scan zeroes a bin when it passes it and reads, ahead of itself, the previous
+  // update's values.  Here B keeps the previous values while thread 0 visits the runs only: a bin the scan has passed (below
+  // `done`) counts as zero when it is at or below the limit and thread 0 has not decided it (`touched`); afterwards all threads
+  // zero those bins for good.  No global reads inside the walk.
   stamp();
   build_bits(limit);
-  for (int i = ix + tid; i < iy; i += LRH_SL_THREADS) if (!(A[i] > limit) && (i > sel_ib || i < sel_ia || par7 == 0)) B[i] = 0;
+  for (int w = tid; w < NW + 2; w += LRH_SL_THREADS) touched[w] = 0u;
   __syncthreads();
+  auto zeroable = [&](int j) -> bool { return !(A[j] > limit) && (j > sel_ib || j < sel_ia || par7 == 0); };
   if (tid == 0) {
+    auto touch = [&](int j) { touched[j >> 5] |= 1u << (j & 31); };
+    auto is_touched = [&](int j) -> bool { return (touched[j >> 5] >> (j & 31)) & 1u; };
     int ia = ix;
     for (;;) {
       int nh = next_set(ia);
       if (nh >= iy) break;                                   // the serial loop handles bins ia < iy
       ia = nh;
       const int done = ia;                                   // bins below `done` hold this update's values, the rest the previous one's
-      auto cur = [&](int j) -> float { return (j < done || A[j] > limit) ? B[j] : a.liminfo[j]; };   // a run's own bins are untouched so far
+      auto cur = [&](int j) -> float { return (j < done && j >= ix && !is_touched(j) && zeroable(j)) ? 0.f : B[j]; };
       float maxval = A[ia];
       int ib = next_clear(ia + 1); if (ib > iy + 1) ib = iy + 1;       // while(sumsq[ib] > limit && ib <= iy) ib++
       for (int j = ia + 1; j < ib; j++) if (A[j] > maxval) maxval = A[j];
@@ -2614,28 +2619,36 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
       t2 = (float)sqrt((double)(limit / maxval));
       if (t1 / t2 > 0.1 && t1 / t2 < 10) t2 = (float)(0.8 * t1 + 0.2 * t2);
       if (ja > sel_ib || jb < sel_ia || par7 == 0) {
-        for (int j = ja; j <= jb; j++) if (j > sel_ib || j < sel_ia || par7 == 0) B[j] = t2; else if (j >= done) B[j] = a.liminfo[j];
-      } else for (int j = max(ja, done); j <= jb; j++) B[j] = a.liminfo[j];        // left alone by the serial scan: previous values
+        for (int j = ja; j <= jb; j++) {
+          if (j > sel_ib || j < sel_ia || par7 == 0) B[j] = t2;
+          else if (j < done) B[j] = cur(j);                  // inside the selected passband: what the scan left there
+          touch(j);
+        }
+      } else for (int j = ja; j <= jb; j++) { if (j < done) B[j] = cur(j); touch(j); }    // left alone by the serial scan
       t1 = t2;
       int j = 1 + (ib - ia) / 4;
       while (ia > ix && j > 0) {
         j--; ia--; ja = ia;
         t1 = (float)pow((double)t1, 0.9);
-        if (B[ja] <= 0 || B[ja] > t1) { if (ja > sel_ib || ja < sel_ia || par7 == 0) B[ja] = t1; }
+        const float v = cur(ja);
+        if (v <= 0 || v > t1) { if (ja > sel_ib || ja < sel_ia || par7 == 0) { B[ja] = t1; touch(ja); } }
         else break;
       }
       j = 1 + (ib - ia) / 4;
       while (ib < iy && j > 0) {
         j--; ib++; jb = ib;
         t2 = (float)pow((double)t2, 0.9);
-        const float v = a.liminfo[jb];                       // not reached yet by the serial scan
+        const float v = B[jb];                               // not reached yet by the serial scan: the previous update's value
+        touch(jb);
         if (v <= 0 || v > t1) B[jb] = t2;
-        else { B[jb] = v; break; }                           // the scan resumes behind this bin: it keeps its previous value
+        else break;                                          // the scan resumes behind this bin: it keeps its previous value
       }
       ia = ib + 1;
       if (ia >= iy) break;
     }
   }
+  __syncthreads();
+  for (int i = ix + tid; i < iy; i += LRH_SL_THREADS) if (zeroable(i) && !((touched[i >> 5] >> (i & 31)) & 1u)) B[i] = 0;
   __syncthreads();
   stamp();
   if (s_pass2) {
@@ -2726,16 +2739,25 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
     // hold-off and slow release (sellim.c:1121-1147), per bin
     int k = (int)(1 + 1 / (a.avg1 * a.blocktime));
     const unsigned int wait_n = k < 255 ? (unsigned)k : 255u;
-    for (int i = tid; i < N; i += LRH_SL_THREADS) {
-      unsigned char w = a.wait[i];
+    // (all global loads first: the byte stores to a.wait may alias anything as far as the compiler knows, so a load-use-store loop
+    // pays one memory round trip per iteration -- 24 us for 16 bins per thread against 3)
+    constexpr int PT = 16384 / LRH_SL_THREADS;               // N <= 16384 (launch_sellim)
+    unsigned char w_[PT]; float o_[PT];
+#pragma unroll
+    for (int q = 0; q < PT; q++) { const int i = tid + q * LRH_SL_THREADS; if (i < N) { w_[q] = a.wait[i]; o_[q] = a.old_liminfo[i]; } }
+#pragma unroll
+    for (int q = 0; q < PT; q++) {
+      const int i = tid + q * LRH_SL_THREADS;
+      if (i >= N) continue;
+      unsigned char w = w_[q];
       float l = B[i];
       if (l != 0) w = (unsigned char)wait_n;
       else { if (w > 0) w--; if (w > 0) l = -1; }
-      const float o = a.old_liminfo[i];
+      const float o = o_[q];
       if (o > 0) { const float t1 = (float)(o * 1.15); if (t1 < 1) { if (l > 0 && l > t1) l = t1; } }
       a.wait[i] = w; B[i] = l;
+      a.tmp[i] = A[i];
     }
-    for (int i = tid; i < N; i += LRH_SL_THREADS) a.tmp[i] = A[i];
     __syncthreads();
   }
   stamp();
@@ -2872,7 +2894,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
 
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
-  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
+  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + 2 * sizeof(int) * ((a.n + 31) / 32 + 4);
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
   if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
