@@ -149,7 +149,7 @@ struct lrh_ctx {
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
-  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr;
+  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
@@ -359,7 +359,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -1305,7 +1305,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     const size_t need = (size_t)a.total + 2 * ca.bk_margin + 1;
     if (c->clv_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf })
+      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
         if (*q_) { hipFree(*q_); *q_ = nullptr; }
       c->clv_cap = 0;
       const size_t cap = need + need / 4;
@@ -1313,10 +1313,11 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
       int rc_ = LRH_OK;
       if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 4)) ||
           (rc_ = dev_alloc(c, &c->d_clv_bk_pwr, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_tf, cap, false))) return rc_;
+      if (coupled && ((rc_ = dev_alloc(c, &c->d_clv_bk_pwo, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_ty, cap, false)))) return rc_;
       c->clv_cap = cap; c->clv_max_regions = maxr;
     }
     ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
-    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.force_serial = (c->clever_force_serial || coupled) ? 1 : 0;
+    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.bk_pwo = c->d_clv_bk_pwo; ca.bk_ty = c->d_clv_bk_ty; ca.force_serial = c->clever_force_serial ? 1 : 0;
     int out[3];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));

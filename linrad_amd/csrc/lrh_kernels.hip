@@ -2014,8 +2014,8 @@ __global__ __launch_bounds__(256) void k_clever_prep(CleverArgs a)
   const int nbk = a.total + 2 * a.bk_margin + 1;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nbk; i += gridDim.x * 256) {
     const int pos = (a.pbeg + i - a.bk_margin) & a.mask;
-    if (a.phase == 0) { a.bk_pwr[i] = a.pwr[pos]; a.bk_tf[i] = a.timf2w[pos]; }
-    else { a.pwr[pos] = a.bk_pwr[i]; a.timf2w[pos] = a.bk_tf[i]; }
+    if (a.phase == 0) { a.bk_pwr[i] = a.pwr[pos]; a.bk_tf[i] = a.timf2w[pos]; if (a.twochan) { a.bk_pwo[i] = a.pwr_own[pos]; a.bk_ty[i] = a.timf2y[pos]; } }
+    else { a.pwr[pos] = a.bk_pwr[i]; a.timf2w[pos] = a.bk_tf[i]; if (a.twochan) { a.pwr_own[pos] = a.bk_pwo[i]; a.timf2y[pos] = a.bk_ty[i]; } }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; }
   // candidate bits straight from the backup in phase 1: no workgroup depends on another one's restored samples

@@ -137,8 +137,8 @@ struct CleverArgs {
   int phase;                // k_clever_prep: 0 first pass (+ backup), 1 restore if violated; k_clever: 0 parallel, 1 serial if violated
   int force_serial;         // tests: report a violation whatever the extents say
   // two coupled channels (blank1.c:984-992): pwr is the ring of summed powers, timf2w the own channel (number `chan`), timf2y the
-  // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring.  One-wave replay only.
-  int twochan, chan; float2 *timf2y; float *pwr_own;
+  // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring (bk_ty / bk_pwo: their backups).
+  int twochan, chan; float2 *timf2y; float *pwr_own; float2 *bk_ty; float *bk_pwo;
 };
 hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 

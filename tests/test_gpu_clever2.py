@@ -9,16 +9,21 @@ from refcases import CLEVER2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("frames_mode", [False, True])
+@pytest.mark.parametrize("frames_mode,serial", [(False, 0), (True, 0), (False, 1)])
 @pytest.mark.parametrize("name", list(CLEVER2))
-def test_hip_two_channel_clever_blanker_matches_reference(name, frames_mode):
+def test_hip_two_channel_clever_blanker_matches_reference(name, frames_mode, serial, monkeypatch):
+    """serial = 0: the region-parallel replay; serial = 1 (LRH_CLEVER_SERIAL): the span restored from the backup -- both channels'
+    samples, summed and own power -- and replayed by one wave"""
     from linrad_amd.lib import open_hip
+    if serial:
+        monkeypatch.setenv("LRH_CLEVER_SERIAL", "1")
     g = clever2lib.load(name)
     res = clever2lib.run(open_hip, name, g, frames_mode=frames_mode)
     rep = clever2lib.compare(res, g, 1e-5)
-    print(name, rep)
+    nser = [rx.blanker_state().clever_serial_calls for rx in res["rxs"]]
+    print(name, "serial" if serial else "regions", rep, "one-wave replays", nser)
+    assert nser[0] == nser[1] and (nser[0] >= 20 if serial else nser[0] <= 2)
     for rx in res["rxs"]:
-        assert rx.blanker_state().clever_serial_calls > 0            # two channels: the one-wave replay
         rx.close()
 
 
