@@ -28,7 +28,7 @@
 
 static lrh_ctx *hip_rx;
 static float *hip_liminfo_sent;           /* the routing table the device holds (sellim.c updates liminfo[] on the host) */
-static int hip_n1, hip_n2;
+static int hip_n1, hip_n2, hip_max_batch;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
 
 int hip_open(void)
@@ -55,7 +55,7 @@ int hip_open(void)
   c.wf_lines = wg_waterf_size / wg_xpixels;
   c.mix1_bandwidth_reduction_n = genparm[MIX1_BANDWIDTH_REDUCTION_N]; c.timf3_size = timf3_size;
   c.fftx_points_per_hz = fftx_points_per_hz; c.mix1_lowest_fq = mix1_lowest_fq; c.mix1_highest_fq = mix1_highest_fq;
-  c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
+  c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1; hip_max_batch = c.max_batch;
   c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
   if ((rc = lrh_open(&c, &hip_rx)) != 0) { hip_rx = NULL; return rc; }
@@ -94,18 +94,28 @@ int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
 void hip_fft1_c(void)
 {
   lrh_ptrs q;
-  int old_pa;
+  int old_pa, n, room;
   memset(&q, 0, sizeof q);
   /* hip_sync_in: what fft1_c reads (fft1.c:4507-4523) */
   q.fft1_nb = fft1_nb; q.fft1_pb = fft1_pb; q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
   q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   old_pa = fft1_sumsq_pa;
-  if (lrh_fft1_c(hip_rx, &q, 1) != 0) { lirerr(1466); return; }
+  /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
+     make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
+     whatever its size (INTEGRATION.md "Call size"), and the limiter looks at fft1_liminfo_cnt only after that loop (wcw.c:1124). */
+  n = (fft1_na - fft1_nb + max_fft1n) & fft1n_mask;
+  room = ((timf2_px - timf2_pa + timf2_mask + 1) & timf2_mask) / timf2_input_block - 1;   /* what hip_make_timf2 can place (the callers test room for one, wcw.c:419) */
+  if (n > room) n = room;
+  if (n > hip_max_batch) n = hip_max_batch;
+  if (n < 1) n = 1;
+  if (lrh_fft1_c(hip_rx, &q, n) != 0) { lirerr(1466); return; }
   /* hip_sync_out */
   fft1_nb = q.fft1_nb; fft1_pb = q.fft1_pb; fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
   fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
-  if (q.fft1_sumsq_pa != old_pa) {            /* an averaging period completed: the wide graph and sellim.c read these on the host */
-    lrh_export(hip_rx, LRH_RING_FFT1_SUMSQ, &fft1_sumsq[old_pa], (size_t)old_pa, (size_t)hip_n1);
+  if (q.fft1_sumsq_pa != old_pa) {            /* averaging periods completed: the wide graph and sellim.c read these on the host */
+    int pa;
+    for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask)
+      lrh_export(hip_rx, LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)hip_n1);
     lrh_export(hip_rx, LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1);
   }
 }
@@ -113,6 +123,7 @@ void hip_fft1_c(void)
 void hip_make_timf2(void)
 {
   lrh_ptrs q;
+  int n;
   memset(&q, 0, sizeof q);
   if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {     /* fft1_update_liminfo has run (wcw.c:1124-1133) */
     memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
@@ -120,7 +131,11 @@ void hip_make_timf2(void)
   }
   q.fft1_px = fft1_px; q.fft1_nx = fft1_nx; q.timf2_pa = timf2_pa;
   q.fft1_lowlevel_points = fft1_lowlevel_points; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
-  if (lrh_make_timf2(hip_rx, &q, 1) != 0) { lirerr(1467); return; }
+  /* all the transforms hip_fft1_c has just passed (it left no more than the timf2 ring has room for) */
+  n = (fft1_nb - fft1_nx + max_fft1n) & fft1n_mask;
+  if (n > hip_max_batch) n = hip_max_batch;
+  if (n < 1) n = 1;
+  if (lrh_make_timf2(hip_rx, &q, n) != 0) { lirerr(1467); return; }
   fft1_px = q.fft1_px; fft1_nx = q.fft1_nx; timf2_pa = q.timf2_pa;            /* timf2.c:127-128, 205-207 */
   fft1_lowlevel_points = q.fft1_lowlevel_points; fft1_lowlevel_fraction = q.fft1_lowlevel_fraction;
 }
