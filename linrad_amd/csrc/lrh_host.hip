@@ -148,7 +148,7 @@ struct lrh_ctx {
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
-  float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
+  float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr, *d_sel_bigb = nullptr, *d_sel_bigg = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
@@ -359,7 +359,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -732,6 +732,10 @@ static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
   a.bw_fftxpts = q->baseband_bw_fftxpts; a.ston_scale = q->ston_scale;
   a.selfreq = c->ms.mix1_selfreq; a.points_per_hz = c->cfg.fftx_points_per_hz; a.second_fft = c->cfg.second_fft_enable;
   a.bst = c->d_bst; a.desired = nullptr; a.desired_totsum = 0;
+  if (c->fft1_big) {                                       // table and group minima in global memory (k_sellim<true>)
+    if (!c->d_sel_bigb) { int rc = dev_alloc(c, &c->d_sel_bigb, c->N1); if (!rc) rc = dev_alloc(c, &c->d_sel_bigg, c->N1 / 4 + 8); if (rc) return rc; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    a.big_b = c->d_sel_bigb; a.big_g = c->d_sel_bigg;
+  }
   { static const int dbg = getenv("LRH_SELLIM_DEBUG") ? atoi(getenv("LRH_SELLIM_DEBUG")) : 0; a.debug = dbg; }
   if (q->fft1_desired) {                                  // calibrated amplitude factor: the table travels once (and again when it changes)
     if (c->h_sel_desired.size() != (size_t)c->N1 || memcmp(c->h_sel_desired.data(), q->fft1_desired, 4 * (size_t)c->N1)) {
@@ -793,7 +797,6 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   LRH_ENTER(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (c->fft1_big) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 16384 (power block and table of one transform in LDS); use lrh_set_liminfo");
   if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
       c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
   return sellim_run(c, p, q, 1);
@@ -803,8 +806,8 @@ int lrh_fft2_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   LRH_ENTER(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (c->fft1_big || !c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1)
-    return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size <= 16384");
+  if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1)
+    return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size");
   if (q->liminfo_group_points < 16 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->fft1_first_inband < 0 ||
       q->sellim_maxlevel < 1 || !(q->fft1_blocktime > 0)) return LRH_EINVAL;
   return sellim_run(c, p, q, 2);
@@ -817,7 +820,7 @@ int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
   c->wl_on = false;
   if (!par) return LRH_OK;
   if (par->struct_size != (int)sizeof *par) return LRH_EINVAL;
-  if (c->fft1_big || (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16))) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
+  if (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16)) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
   c->wl_par = *par;
   if (par->fft1_desired) { c->wl_desired.assign(par->fft1_desired, par->fft1_desired + c->N1); c->wl_par.fft1_desired = c->wl_desired.data(); }
   c->wl_on = true; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;

@@ -2492,12 +2492,20 @@ __device__ __forceinline__ void sl_pack(const SellimArgs &a, const float *B, int
   __shared__ int s_low;
   if (tid == 0) s_low = 0;
   __syncthreads();
-  const int nb = a.n / a.r0;
   int low = 0;
-  for (int i = tid; i < nb; i += LRH_SL_THREADS) {
-    unsigned int m = 0;
-    for (int s = 0; s < a.r0; s++) if (B[i + s * nb] == 0) { m |= 1u << s; low++; }
-    a.pack[i] = m;
+  if (a.r0 == 0) {                                        // four-step timf2: dense bits, bit (k & 31) of word k >> 5 (lrh_set_liminfo)
+    for (int w = tid; w < a.n / 32; w += LRH_SL_THREADS) {
+      unsigned int m = 0;
+      for (int s = 0; s < 32; s++) if (B[32 * w + s] == 0) { m |= 1u << s; low++; }
+      a.pack[w] = m;
+    }
+  } else {
+    const int nb = a.n / a.r0;
+    for (int i = tid; i < nb; i += LRH_SL_THREADS) {
+      unsigned int m = 0;
+      for (int s = 0; s < a.r0; s++) if (B[i + s * nb] == 0) { m |= 1u << s; low++; }
+      a.pack[i] = m;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) low += __shfl_xor(low, off);
   if ((tid & 63) == 0 && low) atomicAdd(&s_low, low);
@@ -2525,14 +2533,17 @@ __device__ __forceinline__ float sl_three_smallest_wave(const float *v, int ia, 
   return (float)(0.3333333 * (t1 + t2 + t3));
 }
 
+// BIG (fft1_size 32768): the power block alone fills the LDS, so the table and the group minima live in global memory (two scratch
+// arrays of the context; one CU, every access an L1 / L2 hit) -- same code, thread 0's walks pay a cache latency per dependent read.
+template <bool BIG>
 __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
 {
   extern __shared__ float sm[];
   const int N = a.n, tid = threadIdx.x;
   float *A = sm + 8;                       // power block, later fftt_tmp (the scans look two bins beyond their range)
-  float *B = A + N + 16;                   // liminfo
-  float *G = B + N + 8;                    // liminfo_group_min (at most N/16 groups; sized N/4 + 8)
-  unsigned int *hotw = (unsigned int *)(G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
+  float *B = BIG ? a.big_b : A + N + 16;   // liminfo
+  float *G = BIG ? a.big_g : B + N + 8;    // liminfo_group_min (at most N/16 groups; sized N/4 + 8)
+  unsigned int *hotw = (unsigned int *)(BIG ? A + N + 16 : G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
   unsigned int *touched = hotw + (N + 31) / 32 + 4;        // [N/32 + 2] pass 1: bins thread 0 has decided
   __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
   const int NW = (N + 31) / 32;
@@ -2741,7 +2752,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
     const unsigned int wait_n = k < 255 ? (unsigned)k : 255u;
     // (all global loads first: the byte stores to a.wait may alias anything as far as the compiler knows, so a load-use-store loop
     // pays one memory round trip per iteration -- 24 us for 16 bins per thread against 3)
-    constexpr int PT = 16384 / LRH_SL_THREADS;               // N <= 16384 (launch_sellim)
+    constexpr int PT = (BIG ? 32768 : 16384) / LRH_SL_THREADS;   // N <= 16384, BIG: 32768 (launch_sellim)
     unsigned char w_[PT]; float o_[PT];
 #pragma unroll
     for (int q = 0; q < PT; q++) { const int i = tid + q * LRH_SL_THREADS; if (i < N) { w_[q] = a.wait[i]; o_[q] = a.old_liminfo[i]; } }
@@ -2782,13 +2793,14 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
 // bin's width (A), group statistics -> global noise floor (thread 0 adds the groups in order: float sums), the neighbour fix-up
 // next to strong bins (serial: it reads what it has just lowered), thinning of an overgrown table, marking of everything within two
 // bins of power above 0.5 * ston * floor.  A persists between calls like the reference's fftf_tmp (zero outside the passband).
+template <bool BIG>
 __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
 {
   extern __shared__ float sm[];
   const int N = a.n, tid = threadIdx.x, nn = a.n2 / a.n, gp = a.group_points, groups = N / gp;
   float *A = sm + 8;
-  float *B = A + N + 16;
-  float *reg_min = B + N + 8, *reg_ston = reg_min + groups + 1, *reg_noise = reg_ston + groups + 1;   // 3 N/16 + 3 <= N/4 + 8
+  float *B = BIG ? a.big_b : A + N + 16;
+  float *reg_min = BIG ? A + N + 16 : B + N + 8, *reg_ston = reg_min + groups + 1, *reg_noise = reg_ston + groups + 1;   // 3 N/16 + 3 <= N/4 + 8
   __shared__ float s_t1; __shared__ int s_go, s_k;
   for (int i = tid; i < N; i += LRH_SL_THREADS) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
   for (int i = tid; i < 8; i += LRH_SL_THREADS) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
@@ -2894,22 +2906,30 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
 
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
-  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + 2 * sizeof(int) * ((a.n + 31) / 32 + 4);
+  const bool big = a.n > 16384;
+  const size_t words = 2 * sizeof(int) * ((a.n + 31) / 32 + 4);
+  const size_t lds = big ? sizeof(float) * (size_t)(8 + a.n + 16) + words : sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + words;
   static bool once = false;
-  if (!once) { hipFuncSetAttribute((const void *)k_sellim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
-  if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
-  if (a.r0 < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_sellim, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
+  if (!once) { hipFuncSetAttribute((const void *)k_sellim<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+               hipFuncSetAttribute((const void *)k_sellim<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
+  if (lds > 160 * 1024 - 64 || a.n > 32768 || (big && (!a.big_b || !a.big_g))) return hipErrorInvalidValue;
+  if (a.r0 < (big ? 0 : 1)) return hipErrorInvalidValue;
+  if (big) hipLaunchKernelGGL(k_sellim<true>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
+  else hipLaunchKernelGGL(k_sellim<false>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   return hipGetLastError();
 }
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
 {
-  const size_t lds = sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
+  const bool big = a.n > 16384;
+  const size_t lds = big ? sizeof(float) * (size_t)(8 + a.n + 16 + 3 * (a.n / (a.group_points > 0 ? a.group_points : 1) + 1) + 8)
+                         : sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + sizeof(int) * ((a.n + 31) / 32 + 4);
   static bool once = false;
-  if (!once) { hipFuncSetAttribute((const void *)k_sellim2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
-  if (lds > 160 * 1024 - 64 || a.group_points < 16) return hipErrorInvalidValue;
-  if (a.r0 < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_sellim2, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
+  if (!once) { hipFuncSetAttribute((const void *)k_sellim2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+               hipFuncSetAttribute((const void *)k_sellim2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
+  if (lds > 160 * 1024 - 64 || a.group_points < 16 || a.n > 32768 || (big && !a.big_b)) return hipErrorInvalidValue;
+  if (a.r0 < (big ? 0 : 1)) return hipErrorInvalidValue;
+  if (big) hipLaunchKernelGGL(k_sellim2<true>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
+  else hipLaunchKernelGGL(k_sellim2<false>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   return hipGetLastError();
 }
 }  // namespace lrh

@@ -250,6 +250,7 @@ struct SellimArgs {
   // fft2_update_liminfo (k_sellim2): summed fft2 power spectrum, hg.blanker_ston_fft2, seconds per fft2 transform, waterfall_avgnum
   const float *powersum2; float ston2, blocktime2; int wf_avgnum;
   int debug;                // LRH_SELLIM_DEBUG=1: thread 0 prints the phase times (100 MHz ticks)
+  float *big_b, *big_g;     // fft1_size 32768: the table (n floats) and the group minima (n/4 + 8 floats) in global memory
 };
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);

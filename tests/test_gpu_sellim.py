@@ -78,26 +78,28 @@ def test_hip_wideband_dsp_makes_the_limiter_calls_itself(pipeline, monkeypatch):
         assert err < 1e-5 and np.count_nonzero(h["lim"]) > 50, (err, fft2_too)
 
 
-def test_fullsize_limiters_match_oracle():
+@pytest.mark.parametrize("fft1_n,fft2_n", [(14, 16), (15, 17)])
+def test_fullsize_limiters_match_oracle(fft1_n, fft2_n):
     """fft1_size 16384 / fft2_size 65536 (BASELINE sizes; the limiter kernels' LDS layout, bit words and group loops at their real
-    extent): both limiters inside lrh_wideband_dsp on the bench's synthetic signal, HIP against the oracle -- same table after the
-    run, same amplitude factor, same pointers, timf2 to the north-star tolerance"""
+    extent) and fft1_size 32768 / fft2_size 131072 (the reference's maximum: table and group minima in global memory, dense routing
+    bits for the four-step make_timf2): both limiters inside lrh_wideband_dsp on the bench's synthetic signal, HIP against the oracle
+    -- same table after the run, same amplitude factor, same pointers, timf2 to the north-star tolerance"""
     import numpy as np
     from linrad_amd import abi
     from linrad_amd.abi import default_sellim
     from linrad_amd.lib import open_hip, synth_defaults, synth_iq
     from linrad_amd.workload import chain_config
     from oracle_binding import open_oracle
-    n1, nblk, batch = 16384, 96, 16
-    cfg = chain_config(14, 16, batch=batch, rounds=nblk // batch)
+    n1, nblk, batch = 1 << fft1_n, 96, 16
+    cfg = chain_config(fft1_n, fft2_n, batch=batch, rounds=nblk // batch)
     s = synth_defaults(n1, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     res = []
     for fn in (open_hip, open_oracle):
         rx = fn(cfg)
         rx.timf1_write(iq)
-        rx.set_mix1_selfreq(0.31 * 65536 + 0.3)
-        par = default_sellim(cfg, fft1_blocktime=(n1 // 2) / 160e6, blanker_ston_fft1=30.0, blanker_ston_fft2=30.0, fft2_blocktime=32768 / 160e6, exact_stats=1)
+        rx.set_mix1_selfreq(0.31 * (1 << fft2_n) + 0.3)
+        par = default_sellim(cfg, fft1_blocktime=(n1 // 2) / 160e6, blanker_ston_fft1=30.0, blanker_ston_fft2=30.0, fft2_blocktime=(1 << fft2_n) / 2 / 160e6, exact_stats=1)
         rx.wideband_limiter(par, True)
         rx.wideband_dsp(nblk, batch)
         res.append(dict(lim=rx.get_liminfo(), amp=rx.liminfo_amplitude_factor(), p=rx.p.as_dict(), timf2=rx.export(abi.RING_TIMF2_FLOAT),
