@@ -45,9 +45,8 @@ typedef struct lrh_config {
   /* fft1 (fft1.c:413-650, buf.c:193-304) */
   int fft1_n;                   /* log2 fft1_size, 6..15 (buf.c:335: the reference's maximum with the second fft on).  Up to 14
                                    one workgroup transforms a block in LDS; 15 takes four-step fft1 / timf2 kernels through an HBM
-                                   scratch and is restricted to int16 / int32 I/Q input, no sample_shift, sin^2 window; the
-                                   NET_RXOUT_FFT1 export answers LRH_EINVAL at that size (the limiter kernels keep their table in
-                                   global memory there)                                                                        */
+                                   scratch and is restricted to int16 / int32 I/Q input, no sample_shift, sin^2 window (the
+                                   limiter kernels keep their table in global memory there)                                   */
   int fft1_sinpow;              /* genparm[FIRST_FFT_SINPOW] 0..9 (fft0.c:812-921)                 */
   int fft1_gain;                /* genparm[FIRST_FFT_GAIN] (fft1.c:4653-4671)                      */
   int fft1_direction;           /* +1 / -1 (fft1.c:3660-3679)                                      */

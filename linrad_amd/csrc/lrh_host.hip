@@ -2295,7 +2295,6 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
   LRH_ENTER(c);
   if (!c || !dst || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (c->fft1_big) return fail(c, LRH_EINVAL, "NET_RXOUT_FFT1 payload: fft1_size <= 16384");
   int cap = 1; while (cap < batch) cap <<= 1;
   if (cap > c->fft1net_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2321,6 +2320,18 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
   a.first_nb = 0; a.nb_mask = c->fft1net_cap - 1; a.direction = c->cfg.fft1_direction; a.xcd = 0; a.batch = batch;
   a.real = c->cfg.timf1_real_input != 0; a.stamps = nullptr;
   if (c->d_foldcorr || a.real) a.direction = 1;
+  if (c->fft1_big) {                                       // four-step fft1 through the scratch of handle 0 (this stream's)
+    const size_t need = (size_t)batch * c->N1;
+    if (c->fft1_scratch_cap[0] < need) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->d_fft1_scratch[0]) hipFree(c->d_fft1_scratch[0]);
+      c->d_fft1_scratch[0] = nullptr; c->fft1_scratch_cap[0] = 0;
+      const int rc_ = dev_alloc(c, &c->d_fft1_scratch[0], need, false); if (rc_) return rc_;
+      c->fft1_scratch_cap[0] = need;
+    }
+    Fft1BigArgs g; g.f = a; g.tw_a = c->d_tw1a; g.tw_b = c->d_tw1b; g.tw_big = c->d_tw1; g.scratch = c->d_fft1_scratch[0];
+    HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->stream));
+  } else
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->stream));
   if (a.real) {
     RealSplitArgs r; r.spec = c->d_fft1net; r.first_nb = 0; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_unitcorr; r.direction = c->cfg.fft1_direction;

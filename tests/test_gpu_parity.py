@@ -91,7 +91,7 @@ def test_hip_fft3_mix2_matches_oracle():
     assert relerr(a["baseb_raw"], b["baseb_raw"]) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["n8_n10", "n10_n12", "n9_n11_dir", "n9_n11_iqcal", "n10_n12_dword", "n9_n11_real"])
+@pytest.mark.parametrize("name", ["n8_n10", "n10_n12", "n9_n11_dir", "n9_n11_iqcal", "n10_n12_dword", "n9_n11_real", "n15_n17_big1"])
 def test_hip_fft1_net_payload_matches_reference(name):
     """NET_RXOUT_FFT1 sends fft1_float as fft1_b leaves it (wcw.c:1024-1043), before fft1_c's filter correction: the golden keeps
     that block of the compiled reference (fft1_first_raw); the HIP path recomputes it on request (lrh_export_fft1_net)"""
