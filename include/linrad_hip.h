@@ -43,10 +43,11 @@ typedef struct lrh_config {
   int device;                   /* HIP device ordinal                                              */
   int rx_rf_channels;           /* ui.rx_rf_channels; 1 per context (channels shard one per GPU)   */
   /* fft1 (fft1.c:413-650, buf.c:193-304) */
-  int fft1_n;                   /* log2 fft1_size, 6..15 (buf.c:335: the reference's maximum with the second fft on).  Up to 14
-                                   one workgroup transforms a block in LDS; 15 takes four-step fft1 / timf2 kernels through an HBM
-                                   scratch and is restricted to int16 / int32 I/Q input, no sample_shift, sin^2 window (the
-                                   limiter kernels keep their table in global memory there)                                   */
+  int fft1_n;                   /* log2 fft1_size, 6..15 (buf.c:335: the reference's maximum with the second fft on), 16 with
+                                   second_fft_enable = 0 (fft0.c:1162-1169: fft1_permute is unsigned short).  Up to 14 one
+                                   workgroup transforms a block in LDS; 15 and 16 take four-step fft1 / timf2 kernels through an
+                                   HBM scratch and are restricted to int16 / int32 I/Q input, no sample_shift, sin^2 window (the
+                                   limiter kernels keep their table in global memory at 15 and answer LRH_EINVAL at 16)        */
   int fft1_sinpow;              /* genparm[FIRST_FFT_SINPOW] 0..9 (fft0.c:812-921)                 */
   int fft1_gain;                /* genparm[FIRST_FFT_GAIN] (fft1.c:4653-4671)                      */
   int fft1_direction;           /* +1 / -1 (fft1.c:3660-3679)                                      */

@@ -392,10 +392,11 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
   if (cfg->timf1_real_input && (cfg->timf1_frame_channels > 2 || cfg->sample_shift != 0)) return LRH_EINVAL;   // fft1_reherm_dit_one / _two: one or two real channels per frame
   if (cfg->timf1_frame_channels > 1 && (!ispow2(cfg->timf1_frame_channels) || cfg->timf1_channel_index < 0 || cfg->timf1_channel_index >= cfg->timf1_frame_channels)) return LRH_EINVAL;
-  if (cfg->fft1_n < 6 || cfg->fft1_n > 15 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384, fft1 = 32768: four-step
+  if (cfg->fft1_n < 6 || cfg->fft1_n > 16 || cfg->fft2_n < 6 || cfg->fft2_n > 18) return LRH_EINVAL;   // fft2 > 16384, fft1 >= 32768: four-step
+  if (cfg->fft1_n == 16 && cfg->second_fft_enable) return LRH_EINVAL;                                  // 65536 only without the second fft (buf.c:335, fft0.c:1162-1169)
   // fft1_size 32768 (buf.c:335): I/Q samples (int16 / int32) through a sin^2 window, the second fft's configuration; the variants
   // that only exist as single-workgroup kernels (real input, I/Q skew, other windows) are refused
-  if (cfg->fft1_n == 15 && (cfg->timf1_real_input || cfg->sample_shift || cfg->fft1_sinpow != 2)) return LRH_EINVAL;
+  if (cfg->fft1_n >= 15 && (cfg->timf1_real_input || cfg->sample_shift || cfg->fft1_sinpow != 2)) return LRH_EINVAL;
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
       !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || (cfg->timf2_blockpower_block > 0 && !ispow2(cfg->timf2_blockpower_size)) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
   lrh_ctx *c = new lrh_ctx();
@@ -537,9 +538,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_fft2_scratch, (size_t)cfg->max_fft2n * N2, false));
   }
   std::vector<float2> tw1a, tw1b;
-  c->fft1_big = cfg->fft1_n == 15;
+  c->fft1_big = cfg->fft1_n >= 15;
   if (c->fft1_big) {
-    make_twiddles(256, tw1a); make_twiddles(128, tw1b);
+    make_twiddles(256, tw1a); make_twiddles(N1 / 256, tw1b);
     A(dev_alloc(c, &c->d_tw1a, tw1a.size())); A(dev_alloc(c, &c->d_tw1b, tw1b.size()));
     c->fuse_sumsq = false;                       // fft1_c's sums stay a separate pass (k_sumsq)
   }
@@ -797,6 +798,7 @@ int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   LRH_ENTER(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  if (c->N1 > 32768) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 32768; use lrh_set_liminfo");
   if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
       c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
   return sellim_run(c, p, q, 1);
@@ -820,7 +822,7 @@ int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
   c->wl_on = false;
   if (!par) return LRH_OK;
   if (par->struct_size != (int)sizeof *par) return LRH_EINVAL;
-  if (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16)) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
+  if (c->N1 > 32768 || (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16))) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
   c->wl_par = *par;
   if (par->fft1_desired) { c->wl_desired.assign(par->fft1_desired, par->fft1_desired + c->N1); c->wl_par.fft1_desired = c->wl_desired.data(); }
   c->wl_on = true; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;

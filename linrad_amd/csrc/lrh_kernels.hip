@@ -1876,14 +1876,18 @@ __global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
       else store_stream(&a.timf2s[r], o);
     }
 }
-hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st)
+template <int LA, int LB> static void launch_fft1_big_t(const Fft1BigArgs &a, int batch, hipStream_t st)
 {
-  if (log2n != 15 || a.f.real || a.f.shift_i || a.f.shift_q) return hipErrorInvalidValue;
-  constexpr int LA = 8, LB = 7;
   const dim3 gc((1 << LB) / LRH_TILE, batch), gr((1 << LA) / LRH_TILE, batch);
   if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
   else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
   hipLaunchKernelGGL((k_fft1_rows<LA, LB>), gr, dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+}
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st)
+{
+  if ((log2n != 15 && log2n != 16) || a.f.real || a.f.shift_i || a.f.shift_q) return hipErrorInvalidValue;
+  if (log2n == 15) launch_fft1_big_t<8, 7>(a, batch, st);
+  else launch_fft1_big_t<8, 8>(a, batch, st);             // 65536: the reference's maximum without the second fft (fft0.c:1162-1169)
   return hipGetLastError();
 }
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStream_t st)

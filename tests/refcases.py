@@ -102,6 +102,11 @@ CASES = {
     "n10_mix1only": dict(n1=10, n2=10, mixred=4, nblk=48, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
                          fq=700.3, wf_avgnum=1, wf_mode=1, seed=16, timf2pow_log2=13, sumsq_blocks=8, second_fft=0,
                          strong=[(-100.0, 3000.0)], weak=[(188.3, 400.0)], pulse_period=0, lim_halfwidth=3),
+    # fft1_size 65536, the reference's maximum, second fft off (fft0.c:1162-1169): four-step fft1 at 256 x 256, mix1 on the fft1 spectra
+    "n16_mix1only_big": dict(n1=16, n2=10, mixred=7, nblk=10, avg1num=3, avg2num=2, att_n=4, bln_interval=4, bln_avgnum=16,
+                             fq=45000.3, wf_avgnum=1, wf_mode=1, seed=29, timf2pow_log2=20, sumsq_blocks=4, second_fft=0,
+                             strong=[(-9000.0, 3000.0), (12345.5, 900.0)], weak=[(12400.25, 150.0)], pulse_period=0, lim_halfwidth=3,
+                             golden_stride=61),
 }
 
 

@@ -489,6 +489,38 @@ def test_fft1_size_32768_chain_matches_oracle():
     assert all(v < 1e-5 for k, v in errs.items() if k != "pwr") and errs["pwr"] < 5e-5, errs
 
 
+def test_fft1_size_65536_without_second_fft_matches_oracle():
+    """fft1_size 65536, the reference's maximum when the second fft is off (fft0.c:1162-1169: fft1_permute is unsigned short): the
+    four-step fft1 at 256 x 256, fft1_c's sums and fft1_mix1_fixed on the fft1 spectra (mix1.c:995-1042), through lrh_wideband_dsp
+    against the oracle.  With the second fft on lrh_open refuses the size (buf.c:335)."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    n1, nblk, batch = 65536, 24, 8
+    cfg = chain_config(16, 12, batch=batch, rounds=nblk // batch)
+    with pytest.raises(Exception):
+        _hip(cfg)                                        # second fft on: LRH_EINVAL
+    cfg.second_fft_enable = 0
+    cfg.mix1_bandwidth_reduction_n = 6                   # mix1 size 1024 on the fft1 spectra
+    cfg.timf3_size = 1 << 18
+    cfg.mix1_highest_fq = float(n1)                      # frequencies count fft1 bins now
+    s = synth_defaults(n1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    res = []
+    for fn in (_hip, _oracle):
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_mix1_selfreq(0.31 * n1 + 0.3)
+        rx.wideband_dsp(nblk, batch)
+        res.append({k: rx.export(ring) for ring, k in [(abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_FFT1_SLOWSUM, "slowsum"),
+                                                        (abi.RING_TIMF3_FLOAT, "timf3")]} | {"p": rx.p.as_dict()})
+        rx.close()
+    h, o = res
+    ints = [k for k, v in h["p"].items() if isinstance(v, int)]
+    assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
+    errs = {k: _relerr(h[k], o[k]) for k in ("fft1", "sumsq", "slowsum", "timf3")}
+    print(errs, "timf3 samples", int(np.count_nonzero(o["timf3"])) // 2)
+    assert np.count_nonzero(o["timf3"]) > 10000 and all(v < 1e-5 for v in errs.values()), errs
+
+
 def test_one_round_late_schedule_carries_over_calls(monkeypatch):
     """The launches lrh_wideband_dsp holds back from its last round are issued by the next call (one round per call then runs the
     same schedule as many rounds in one call) or by the first other entry point that needs the results: one call of 7 rounds,
