@@ -64,8 +64,8 @@ def edit_globdef(L):
 
 
 def edit_fft1var(L):
-    # fft_cntrl[21]: window storage 1, no permute table, max_n 15 (buf.c:335), gpu = GPU_HIP
-    insert(L, r'"Double precision"\}', ',{1,0,15,0,0,GPU_HIP,0,1,0,   "HIP MI355X"}                        //21\n')
+    # fft_cntrl[21]: window storage 1, no permute table, max_n 16 (65536 with the second fft off; buf.c:335 caps it at 15 with it on), gpu = GPU_HIP
+    insert(L, r'"Double precision"\}', ',{1,0,16,0,0,GPU_HIP,0,1,0,   "HIP MI355X"}                        //21\n')
     replace(L, r"1 chan direct conversion \(IQ\)", "19, -1}", "19, 21}")
 
 
