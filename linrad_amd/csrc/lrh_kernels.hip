@@ -2548,6 +2548,8 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
   float *G = BIG ? a.big_g : B + N + 8;    // liminfo_group_min (at most N/16 groups; sized N/4 + 8)
   unsigned int *hotw = (unsigned int *)(BIG ? A + N + 16 : G + N / 4 + 8);    // [N/32 + 2] one bit per bin: above the limit / above the noise floor
   unsigned int *touched = hotw + (N + 31) / 32 + 4;        // [N/32 + 2] pass 1: bins thread 0 has decided
+  unsigned int *l2set = touched + (N + 31) / 32 + 4;       // second level over hotw: bit w set = word w has a set bit / ...
+  unsigned int *l2clr = l2set + (N + 31) / 1024 + 2;       // ... = word w has a clear bit (thread 0 crosses an empty band in N/1024 reads)
   __shared__ int s_pass2; __shared__ float s_limit, s_nf; __shared__ int s_k, s_ia;
   const int NW = (N + 31) / 32;
   long long ts[10]; int nts = 0;
@@ -2576,31 +2578,41 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
       if (lane == 0) { hotw[2 * r] = (unsigned int)m; if (2 * r + 1 < NW + 2) hotw[2 * r + 1] = (unsigned int)(m >> 32); }
     }
   };
-  // thread 0's jumps: a dependent LDS read costs ~100 cycles, so empty stretches are skipped four words (128 bins) per read
+  // second level of the bit words (all threads, after build_bits and a barrier): one bit per word
+  auto build_l2 = [&]() {
+    const int nw2 = (NW + 31) / 32;
+    for (int v = tid; v < nw2; v += LRH_SL_THREADS) {
+      unsigned int ms = 0, mc = 0;
+      for (int b = 0; b < 32 && 32 * v + b < NW; b++) { const unsigned int h = hotw[32 * v + b]; if (h) ms |= 1u << b; if (~h) mc |= 1u << b; }
+      l2set[v] = ms; l2clr[v] = mc;
+    }
+  };
+  // thread 0's jumps: a dependent LDS read and its branch cost ~100 ns, so the walk finds the next interesting word through the
+  // second-level bits (1024 bins per read) instead of reading the words of an empty stretch one after the other
+  auto next_word = [&](const unsigned int *l2, int w) -> int {   // first word >= w whose second-level bit is set (NW if none)
+    while (w < NW) {
+      const unsigned int m2 = l2[w >> 5] >> (w & 31);
+      if (m2) return w + __ffs(m2) - 1;
+      w = (w | 31) + 1;
+    }
+    return NW;
+  };
   auto next_set = [&](int i) -> int {      // first bin >= i whose bit is set (N if none)
     if (i >= N) return N;
     { const unsigned int m = hotw[i >> 5] >> (i & 31); if (m) { const int r = i + __ffs(m) - 1; return r < N ? r : N; } }
-    int w = (i >> 5) + 1;
-    while (32 * w < N) {
-      if ((w & 3) == 0 && w + 3 < NW + 2) { const uint4 q = *reinterpret_cast<const uint4 *>(&hotw[w]); if (!(q.x | q.y | q.z | q.w)) { w += 4; continue; } }
-      const unsigned int m = hotw[w];
-      if (m) { const int r = 32 * w + __ffs(m) - 1; return r < N ? r : N; }
-      w++;
-    }
-    return N;
+    const int w = next_word(l2set, (i >> 5) + 1);
+    if (w >= NW) return N;
+    const int r = 32 * w + __ffs(hotw[w]) - 1;
+    return r < N ? r : N;
   };
   auto next_clear = [&](int i) -> int {    // first bin >= i whose bit is clear (N if none)
     if (i >= N) return N;
     { const unsigned int m = ~hotw[i >> 5] >> (i & 31); const int room = 32 - (i & 31);
       if (m & (room == 32 ? 0xffffffffu : ((1u << room) - 1))) { const int r = i + __ffs(m) - 1; return r < N ? r : N; } }
-    int w = (i >> 5) + 1;
-    while (32 * w < N) {
-      if ((w & 3) == 0 && w + 3 < NW + 2) { const uint4 q = *reinterpret_cast<const uint4 *>(&hotw[w]); if ((q.x & q.y & q.z & q.w) == 0xffffffffu) { w += 4; continue; } }
-      const unsigned int m = ~hotw[w];
-      if (m) { const int r = 32 * w + __ffs(m) - 1; return r < N ? r : N; }
-      w++;
-    }
-    return N;
+    const int w = next_word(l2clr, (i >> 5) + 1);
+    if (w >= NW) return N;
+    const int r = 32 * w + __ffs(~hotw[w]) - 1;
+    return r < N ? r : N;
   };
   // ---- pass 1 (sellim.c:789-865): bins at or below the limit become weak; a run above the limit gets one attenuation over
   // its whole width and tapered skirts.  The serial scan zeroes a bin when it passes it and reads, ahead of itself, the previous
@@ -2610,6 +2622,8 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
   stamp();
   build_bits(limit);
   for (int w = tid; w < NW + 2; w += LRH_SL_THREADS) touched[w] = 0u;
+  __syncthreads();
+  build_l2();
   __syncthreads();
   auto zeroable = [&](int j) -> bool { return !(A[j] > limit) && (j > sel_ib || j < sel_ia || par7 == 0); };
   if (tid == 0) {
@@ -2714,6 +2728,8 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
     stamp();
     const float nf = s_nf;
     build_bits(nf);
+    __syncthreads();
+    build_l2();
     // Every bin above the noise floor from bin 2 up to last_point - 1 ends up marked by the serial scan (as a member of a
     // run, of a skirt, or as the start of the next run): all threads mark them now; thread 0 then walks the runs only, for
     // the skirts below and above each run and the end of the band.
@@ -2910,7 +2926,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
   const bool big = a.n > 16384;
-  const size_t words = 2 * sizeof(int) * ((a.n + 31) / 32 + 4);
+  const size_t words = 2 * sizeof(int) * ((a.n + 31) / 32 + 4) + 2 * sizeof(int) * ((a.n + 31) / 1024 + 2);
   const size_t lds = big ? sizeof(float) * (size_t)(8 + a.n + 16) + words : sizeof(float) * (size_t)(8 + a.n + 16 + a.n + 8 + a.n / 4 + 8) + words;
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
