@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   __shared__ unsigned long long above[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];   // per wave: word k covers positions R0 - BACK + 64 k ..
   // the power of the samples above the limit, compacted per wave in row order (phase 2 needs it for the run maxima and would
   // otherwise wait for L2 once per event): value of bit l of row k sits at rowoff[k] + popcount(bits of the row below l)
-  constexpr int VCAP = 1024;
+  constexpr int VCAP = 512;                               // (with 1024 the workgroup took 22 KB of LDS: seven per CU, and the eighth of every CU ran alone in a second round)
   __shared__ float vals[4][VCAP];
   __shared__ int rowoff[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];
   __shared__ int wg_cnt;
