@@ -19,5 +19,5 @@ for k,v in acc.items():
     print(k)
     for c,(s,n) in sorted(v.items()): print("   %-24s %14.0f  (n=%d)"%(c,s/n,n))
 PY
-tail -3 $OUT/l1.txt $OUT/l2.txt $OUT/l3.txt
+for f in $OUT/l1.txt $OUT/l2.txt $OUT/l3.txt; do tail -n 3 $f; done >&2
 find $OUT -name "*.csv" -size +4M -delete
