@@ -13,6 +13,7 @@
  */
 #include <string.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include "globdef.h"
 #include "uidef.h"
 #include "fft1def.h"
@@ -28,13 +29,38 @@
 
 static lrh_ctx *hip_rx;
 static float *hip_liminfo_sent;           /* the routing table the device holds (sellim.c updates liminfo[] on the host) */
+/* liminfo[] / hip_liminfo_sent are touched by the wideband thread (the limiter hooks) and, with more than one CPU, by
+   THREAD_TIMF2 (hip_make_timf2, wcw.c:419-425): one lock around the whole read-compare-upload / download-publish sequences */
+static pthread_mutex_t hip_liminfo_lock = PTHREAD_MUTEX_INITIALIZER;
 static int hip_n1, hip_n2, hip_max_batch;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
+static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
+static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
+
+lrh_ctx *hip_context(void) { return hip_rx; }
+
+/* What version 21 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
+   rings that stay empty: two RF channels in one array (fft1.c:3874-4080; the library shards channels one context per GPU, which
+   Linrad's single process does not do), real-valued input (fft1_version rows 0 / 1 do not list version 21), the MMX / int16
+   back transform and second fft (their rings are short int), correlation spectra (fft1_corrsum), spur removal (acquisition
+   reads fft2_float on the host, spursub.c:619), and the network outputs that are memcpy'd from host rings (wcw.c:1038-1043). */
+static int hip_unsupported(void)
+{
+  if (ui.rx_rf_channels != 1) return 1;
+  if ((ui.rx_input_mode & IQ_DATA) == 0) return 2;
+  if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
+  if (fft1_correlation_flag != 0) return 4;
+  if (genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0) return 5;
+  if ((ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0) return 6;
+  if (genparm[MIX1_NO_OF_CHANNELS] != 1) return 7;
+  return 0;
+}
 
 int hip_open(void)
 {
   lrh_config c;
   int rc;
+  if ((rc = hip_unsupported()) != 0) return 100 + rc;
   lrh_config_defaults(&c, fft1_n, fft2_n);
   c.device = gpu.fft1_device;
   c.fft1_sinpow = genparm[FIRST_FFT_SINPOW]; c.fft1_gain = genparm[FIRST_FFT_GAIN]; c.fft1_direction = fft1_direction;
@@ -57,9 +83,10 @@ int hip_open(void)
   c.fftx_points_per_hz = fftx_points_per_hz; c.mix1_lowest_fq = mix1_lowest_fq; c.mix1_highest_fq = mix1_highest_fq;
   c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1; hip_max_batch = c.max_batch;
   c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
+  c.timf2_blockpower_block = timf2_blockpower_block; c.timf2_blockpower_size = timf2_blockpower_size;     /* compute_timf2_powersum, wcw.c:80 */
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
   if ((rc = lrh_open(&c, &hip_rx)) != 0) { hip_rx = NULL; return rc; }
-  hip_n1 = fft1_size; hip_n2 = fft2_size;
+  hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
   lrh_set_filtercorr(hip_rx, fft1_filtercorr);                /* the calibration Linrad loaded (fft1.c:4653-5386) */
   hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
@@ -77,6 +104,7 @@ void hip_close(void)
   lrh_close(hip_rx);
   hip_rx = NULL;
   free(hip_liminfo_sent); hip_liminfo_sent = NULL;
+  free(hip_afc_tmp); hip_afc_tmp = NULL;
 }
 
 void hip_timf1_new(int pa, int nbytes)
@@ -89,6 +117,33 @@ int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
   /* the dispatcher's workers carry gpu_handle_number 0..5 (wcw.c:500), the no-worker path passes 0 too (wcw.c:1036) */
   const int handle = no_of_fft1b > 0 ? gpu_handle_number + 1 : 0;
   return lrh_fft1_b(hip_rx, handle, timf1p_ref, (int)(out - fft1_float), gpu_fft1_batch_size);
+}
+
+/* make_afc (afc_graph.c:362) stays host code: with ag.mode_control != 0 it searches the power spectra fftx_pwr[transform][bin] of
+   the recent transforms in a window around the selected frequency (collect_initial_spectrum and friends, afcsub.c:60-90, 849;
+   one RF channel: powers only).  Those spectra live on the device, so the window -- not the spectra -- comes back: the new
+   transform's row when one has been made, every row of the ring when the operator has moved the frequency.  With
+   ag.mode_control == 0 make_afc only fills mix1_fq_mid with the selected frequency and nothing is fetched. */
+static void hip_afc_rows(int first_row, int rows)
+{
+  const int second = genparm[SECOND_FFT_ENABLE] != 0;
+  const int size = second ? hip_n2 : hip_n1, nmask = second ? fft2n_mask : fft1n_mask;
+  int centre, half, lo, hi, r, i;
+  if (genparm[AFC_ENABLE] == 0 || genparm[AFC_LOCK_RANGE] == 0 || ag.mode_control == 0 || mix1_selfreq[0] < 0 || fftx_pwr == NULL) return;
+  if (hip_afc_selfreq != mix1_selfreq[0]) { hip_afc_selfreq = mix1_selfreq[0]; first_row = 0; rows = nmask + 1; }
+  centre = (int)(mix1_selfreq[0] * fftx_points_per_hz);
+  half = 4 * max_afcf_points + 64;
+  lo = centre - half; if (lo < 0) lo = 0;
+  hi = centre + half; if (hi > size) hi = size;
+  if (hi <= lo) return;
+  for (r = 0; r < rows; r++) {
+    const int row = (first_row + r) & nmask;
+    if (second) { lrh_export(hip_rx, LRH_RING_FFT2_POWER, &fftx_pwr[(size_t)row * size + lo], (size_t)row * size + lo, (size_t)(hi - lo)); continue; }
+    /* second fft off: fftx_pwr = fft1_power, |corrected fft1 bin|^2 as fft1_c forms it (fft1.c:4431-4440) */
+    if (!hip_afc_tmp) hip_afc_tmp = malloc(sizeof(float) * 2 * (size_t)hip_n1);
+    lrh_export(hip_rx, LRH_RING_FFT1_FLOAT, hip_afc_tmp, 2 * ((size_t)row * size + lo), 2 * (size_t)(hi - lo));
+    for (i = 0; i < hi - lo; i++) fftx_pwr[(size_t)row * size + lo + i] = hip_afc_tmp[2 * i] * hip_afc_tmp[2 * i] + hip_afc_tmp[2 * i + 1] * hip_afc_tmp[2 * i + 1];
+  }
 }
 
 void hip_fft1_c(void)
@@ -104,7 +159,8 @@ void hip_fft1_c(void)
      make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
      whatever its size (INTEGRATION.md "Call size"), and the limiter looks at fft1_liminfo_cnt only after that loop (wcw.c:1124). */
   n = (fft1_na - fft1_nb + max_fft1n) & fft1n_mask;
-  room = ((timf2_px - timf2_pa + timf2_mask + 1) & timf2_mask) / timf2_input_block - 1;   /* what hip_make_timf2 can place (the callers test room for one, wcw.c:419) */
+  /* what hip_make_timf2 can place (the callers test room for one, wcw.c:419); with the second fft off nothing follows in timf2 */
+  room = genparm[SECOND_FFT_ENABLE] != 0 ? ((timf2_px - timf2_pa + timf2_mask + 1) & timf2_mask) / timf2_input_block - 1 : n;
   if (n > room) n = room;
   if (n > hip_max_batch) n = hip_max_batch;
   if (n < 1) n = 1;
@@ -112,6 +168,7 @@ void hip_fft1_c(void)
   /* hip_sync_out */
   fft1_nb = q.fft1_nb; fft1_pb = q.fft1_pb; fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
   fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
+  if (genparm[SECOND_FFT_ENABLE] == 0) hip_afc_rows((q.fft1_nb - n) & fft1n_mask, n);
   if (q.fft1_sumsq_pa != old_pa) {            /* averaging periods completed: the wide graph and sellim.c read these on the host */
     int pa;
     for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask)
@@ -125,10 +182,14 @@ void hip_make_timf2(void)
   lrh_ptrs q;
   int n;
   memset(&q, 0, sizeof q);
-  if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {     /* fft1_update_liminfo has run (wcw.c:1124-1133) */
+  /* host code has rewritten liminfo[] (fft2_update_liminfo with hg.sellim_par1 != 2, a GUI reset): the device gets the new table.
+     The limiter hooks below publish the device's own table under the same lock, so a half-published table is never taken for a change. */
+  pthread_mutex_lock(&hip_liminfo_lock);
+  if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {
     memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
-    lrh_set_liminfo(hip_rx, liminfo);
+    lrh_set_liminfo(hip_rx, hip_liminfo_sent);
   }
+  pthread_mutex_unlock(&hip_liminfo_lock);
   q.fft1_px = fft1_px; q.fft1_nx = fft1_nx; q.timf2_pa = timf2_pa;
   q.fft1_lowlevel_points = fft1_lowlevel_points; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
   /* all the transforms hip_fft1_c has just passed (it left no more than the timf2 ring has room for) */
@@ -171,6 +232,8 @@ void hip_first_noise_blanker(void)
       timf2_noise_floor = bs.timf2_noise_floor; hg.stupid_bln_limit = bs.stupid_bln_limit;
       stupid_blanker_rate = bs.stupid_blanker_rate; clever_blanker_rate = bs.clever_blanker_rate; hg.clever_bln_limit = bs.clever_bln_limit;
       timf2_despiked_pwr[0] = bs.timf2_despiked_pwr[0]; timf2_despiked_pwr[1] = bs.timf2_despiked_pwr[1];
+      timf2_despiked_pwrinc[0] = bs.timf2_despiked_pwrinc[0]; timf2_despiked_pwrinc[1] = bs.timf2_despiked_pwrinc[1];
+      timf2_cleared_points = bs.timf2_cleared_points; timf2_fitted_pulses = bs.timf2_fitted_pulses;
     }
   }
   blanker_info_update_counter = q.blanker_info_update_counter;
@@ -200,7 +263,9 @@ static void hip_liminfo_back(void)
 {
   /* the host's liminfo[] for the high-resolution graph; nothing to upload later.  liminfo_amplitude_factor stays on the device,
      where the linear blanker reads it (the host copy serves the GUI's "skip the smart blanker" test, sellim.c:156) */
-  if (lrh_get_liminfo(hip_rx, liminfo) == 0) memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
+  pthread_mutex_lock(&hip_liminfo_lock);
+  if (lrh_get_liminfo(hip_rx, hip_liminfo_sent) == 0) memcpy(liminfo, hip_liminfo_sent, sizeof(float) * (size_t)hip_n1);
+  pthread_mutex_unlock(&hip_liminfo_lock);
   lrh_get_liminfo_amplitude_factor(hip_rx, &liminfo_amplitude_factor);
 }
 void hip_fft1_update_liminfo(void)
@@ -238,7 +303,24 @@ void hip_make_fft2(void)
     lrh_export(hip_rx, LRH_RING_WG_WATERF, &wg_waterf[old_ptr], (size_t)old_ptr, (size_t)wg_xpixels);
     lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
   }
+  hip_afc_rows((q.fft2_na + fft2n_mask) & fft2n_mask, 1);
   make_fft2_status = FFT2_COMPLETE;           /* second_fft loops until this (wcw.c:280-285) */
+}
+
+/* timf3 is where the device hands back to the CPU: fft3, mix2 and the demodulators carry on from the host ring (audio rate).
+   The mixer's phase bookkeeping (set_mix1_phases, mix1.c:781-861) is host state of the library; the globals follow it because
+   make_afc and the baseband graph read them. */
+static void hip_mix1_back(int old_pa)
+{
+  lrh_mix1_state m;
+  int n = timf3_block, first = n;
+  if (old_pa + n > timf3_size) first = timf3_size - old_pa;
+  lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, &timf3_float[old_pa], (size_t)old_pa, (size_t)first);
+  if (first < n) lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, timf3_float, 0, (size_t)(n - first));
+  if (lrh_get_mix1_state(hip_rx, &m) == 0 && m.mix1_selfreq >= 0) {
+    mix1_point[0] = m.mix1_point; mix1_old_point[0] = m.mix1_old_point; mix1_phase[0] = m.mix1_phase;
+    mix1_phase_step[0] = m.mix1_phase_step; mix1_phase_rot[0] = m.mix1_phase_rot; mix1_old_phase[0] = m.mix1_old_phase;
+  }
 }
 
 void hip_fft2_mix1_fixed(void)
@@ -251,6 +333,79 @@ void hip_fft2_mix1_fixed(void)
   old_pa = timf3_pa;
   if (lrh_fft2_mix1_fixed(hip_rx, &q, 1) != 0) { lirerr(1470); return; }
   fft2_nx = q.fft2_nx; timf3_pa = q.timf3_pa;                                   /* mix1.c:991-992 */
-  /* timf3 is where the device hands back to the CPU: fft3, mix2 and the demodulators carry on from the host ring (audio rate) */
-  lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, &timf3_float[old_pa], (size_t)old_pa, (size_t)timf3_block);
+  hip_mix1_back(old_pa);
+}
+
+/* fft1_mix1_fixed (mix1.c:995-1042): the second fft is off -- Linrad's default in every rx mode (uivar.c:371-392, column 8) -- and
+   the narrowband thread cuts the baseband straight out of the fft1 spectra (call site wcw.c:1712) */
+void hip_fft1_mix1_fixed(void)
+{
+  lrh_ptrs q;
+  int old_pa;
+  memset(&q, 0, sizeof q);
+  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
+  q.fft1_nx = fft1_nx; q.fft1_px = fft1_px; q.fft1_nb = fft1_nb; q.timf3_pa = timf3_pa;
+  old_pa = timf3_pa;
+  if (lrh_fft1_mix1_fixed(hip_rx, &q, 1) != 0) { lirerr(1474); return; }
+  fft1_nx = q.fft1_nx; fft1_px = q.fft1_px; timf3_pa = q.timf3_pa;             /* mix1.c:1039-1041 */
+  hip_mix1_back(old_pa);
+}
+
+/* AFC variants (mix1.c:863-932, 1044-1097; call sites wcw.c:1700, 1737; AFC_ENABLE defaults to 1 for weak-signal CW): the
+   per-transform frequency tables are Linrad's own globals, filled by make_afc on the host and kept by do_mix1_afc's bookkeeping,
+   which the library restates (the caller's arrays are read and written in place) */
+static void hip_afc_tables(lrh_afc *a)
+{
+  a->mix1_fq_mid = mix1_fq_mid; a->mix1_fq_slope = mix1_fq_slope; a->mix1_fq_curv = mix1_fq_curv; a->mix1_fq_start = mix1_fq_start;
+  a->baseband_bw_hz = baseband_bw_hz;
+}
+void hip_fft2_mix1_afc(void)
+{
+  lrh_ptrs q;
+  lrh_afc a;
+  int old_pa;
+  if (mix1_selfreq[0] < 0) { hip_fft2_mix1_fixed(); return; }                   /* nothing selected: mix1_clear either way (mix1.c:924-927) */
+  memset(&q, 0, sizeof q);
+  hip_afc_tables(&a);
+  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
+  q.fft2_nx = fft2_nx; q.timf3_pa = timf3_pa; q.fft2_na = fft2_na;
+  old_pa = timf3_pa;
+  if (lrh_fft2_mix1_afc(hip_rx, &q, 1, &a) != 0) { lirerr(1475); return; }
+  fft2_nx = q.fft2_nx; timf3_pa = q.timf3_pa;                                   /* mix1.c:930-931 */
+  hip_mix1_back(old_pa);
+}
+void hip_fft1_mix1_afc(void)
+{
+  lrh_ptrs q;
+  lrh_afc a;
+  int old_pa;
+  if (mix1_selfreq[0] < 0) { hip_fft1_mix1_fixed(); return; }
+  memset(&q, 0, sizeof q);
+  hip_afc_tables(&a);
+  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
+  q.fft1_nx = fft1_nx; q.fft1_px = fft1_px; q.fft1_nb = fft1_nb; q.timf3_pa = timf3_pa;
+  old_pa = timf3_pa;
+  if (lrh_fft1_mix1_afc(hip_rx, &q, 1, &a) != 0) { lirerr(1476); return; }
+  fft1_nx = q.fft1_nx; fft1_px = q.fft1_px; timf3_pa = q.timf3_pa;             /* mix1.c:1094-1096 */
+  hip_mix1_back(old_pa);
+}
+
+/* compute_timf2_powersum (wcw.c:80-138; S/N meter, mg.scale_type == MG_SCALE_STON): the block powers are formed on the device
+   from the resident timf2 ring and the new ones come back for the meter graph */
+void hip_compute_timf2_powersum(void)
+{
+  lrh_ptrs q;
+  int old_pa, n;
+  memset(&q, 0, sizeof q);
+  q.timf2_pn2 = timf2_pn2; q.timf2_pb = timf2_pb; q.timf2_blockpower_pa = timf2_blockpower_pa;
+  old_pa = timf2_blockpower_pa;
+  if (lrh_compute_timf2_powersum(hip_rx, &q) != 0) { lirerr(1477); return; }
+  timf2_pb = q.timf2_pb; timf2_blockpower_pa = q.timf2_blockpower_pa;
+  n = (q.timf2_blockpower_pa - old_pa) & timf2_blockpower_mask;
+  while (n > 0) {
+    int k = n;
+    if (old_pa + k > timf2_blockpower_mask + 1) k = timf2_blockpower_mask + 1 - old_pa;
+    lrh_export(hip_rx, LRH_RING_TIMF2_BLOCKPOWER, &timf2_blockpower[old_pa], (size_t)old_pa, (size_t)k);
+    old_pa = (old_pa + k) & timf2_blockpower_mask; n -= k;
+  }
 }

@@ -10,6 +10,9 @@
 #endif
 extern int fft1_use_gpu;
 
+/* hip_open: 0, a negative LRH_E* of the library, or 100 + n when the running configuration is one version 21 does not serve
+   (two RF channels in one array, real input, MMX back transform / second fft, correlation spectra, spur removal, network output of
+   device-resident stages, several mix1 channels): the caller ends with lirerr(1463) */
 int  hip_open(void);                 /* wideband_dsp start, where create_clFFT_plan / cufftPlanMany are called (wcw.c:535-575) */
 void hip_close(void);                /* wideband_dsp exit, where destroy_clFFT_plan is called (wcw.c:1174-1183)              */
 void hip_timf1_new(int timf1p_pa, int nbytes);   /* finish_rx_read: one new block sits at timf1_char[timf1p_pa] (rxin.c:1425-1431) */
@@ -21,4 +24,9 @@ void hip_fft1_update_liminfo(void);   /* selective limiter on the device-residen
 int  hip_fft2_update_liminfo(void);   /* second limiter on the fft2 power sums (sellim.c:159); 0: not taken (hg.sellim_par1 != 2) */
 void hip_make_fft2(void);
 void hip_fft2_mix1_fixed(void);
+void hip_fft1_mix1_fixed(void);       /* second fft off (Linrad's default): mix1.c:995, call site wcw.c:1712                 */
+void hip_fft2_mix1_afc(void);         /* AFC on (default for weak-signal CW): mix1.c:863 / 1044, call sites wcw.c:1737 / 1700 */
+void hip_fft1_mix1_afc(void);
+void hip_compute_timf2_powersum(void);   /* wcw.c:80 (S/N meter)                                                              */
+struct lrh_ctx *hip_context(void);    /* the context behind the hooks (diagnostics, tests)                                    */
 #endif

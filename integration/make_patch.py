@@ -81,6 +81,7 @@ def edit_wcw(L):
     insert(L, r"ui\.network_flag & NET_RXIN_TIMF2\) != 0 &&", "if(fft1_use_gpu == GPU_HIP)\n  {\n  if(hip_open() != 0)\n    {\n    lirerr(1463);\n    goto errexit;\n    }\n  }\n",
            where="before", start=i)
     insert(L, r"^errexit:;", "if(fft1_use_gpu == GPU_HIP)hip_close();\n", start=i)
+    func_top(L, r"^void compute_timf2_powersum\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_compute_timf2_powersum();return;}\n")
 
 
 def edit_fft1(L):
@@ -110,6 +111,10 @@ def edit_fft2(L):
 def edit_mix1(L):
     after_last_include(L)
     func_top(L, r"^void fft2_mix1_fixed\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft2_mix1_fixed();return;}\n")
+    # the reference's default operating modes: second fft off (uivar.c:371-392 column 8) and AFC on (weak-signal CW)
+    func_top(L, r"^void fft1_mix1_fixed\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_mix1_fixed();return;}\n")
+    func_top(L, r"^void fft2_mix1_afc\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft2_mix1_afc();return;}\n")
+    func_top(L, r"^void fft1_mix1_afc\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_mix1_afc();return;}\n")
 
 
 def edit_sellim(L):

@@ -1,0 +1,42 @@
+#!/bin/bash
+# oracle/build_shim_harness.sh -- TEST INFRASTRUCTURE, build container only (needs the reference tree).
+#
+# Builds oracle/_ref/shim_harness: the head-less reference driver (oracle/ref_harness.c) linked with the reference objects as
+# integration/linrad_hip.patch leaves them + integration/hipshim.c compiled over the oracle's C ABI (oracle/shim_alias.h), so the
+# Linrad-side glue EXECUTES: fft1_b case 21 -> fft1_c -> make_timf2 -> first_noise_blanker -> make_fft2 -> fft2_mix1_* (and the
+# second-fft-off chain fft1_c -> fft1_mix1_*) run through the reference's own, patched, call sites with the device replaced by
+# liblinrad_oracle.so.  tests/test_shim_exec_cpu.py compares what Linrad would see on the host with the unpatched goldens.
+#
+# The patched copies of the reference sources live in a scratch directory under /tmp for the duration of the build; only
+# objects and the binary are written, and only into oracle/_ref/ (git-ignored).
+set -e
+REF=${REF:-/root/reference}
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(dirname "$HERE")"
+[ -d "$REF" ] || { echo "no reference tree at $REF"; exit 2; }
+[ -f "$ROOT/linrad_amd/liblinrad_hip.so" ] || { echo "build linrad_amd/liblinrad_hip.so first (lrh_config_defaults)"; exit 2; }
+make -C "$HERE" oracle >/dev/null
+T=$(mktemp -d /tmp/linrad_shim.XXXXXX)
+trap 'rm -rf "$T"' EXIT
+OUT="$HERE/_ref/shim"
+mkdir -p "$OUT"
+cp "$REF"/*.h "$T"/
+TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c"
+for f in $TOUCHED; do cp "$REF/$f" "$T/"; done
+(cd "$T" && patch -s -p1 --no-backup-if-mismatch < "$ROOT/integration/linrad_hip.patch")
+cp "$ROOT/integration/hipshim.c" "$ROOT/integration/hipshim.h" "$T"/
+DEFS="-DOSNUM=1 -DCPU=1 -DIA64=1 -DHAVE_OSS=0 -DHAVE_X11=0 -DHAVE_SHM=0 -DHAVE_SVGALIB=0 -DSERVER=0 -DOPENCL_PRESENT=0 -DHAVE_CUFFT=0 -DOSSD=0"
+CFLAGS="-O2 -ffast-math -fomit-frame-pointer -w $DEFS"
+# the object list of oracle/Makefile (REFSRC); patched where the patch touches a file, every file against the patched headers
+SRC="fft0 fft1 fft1_re timf2 blank1 fft2 mix1 fft3 mix2 wide_graph wcw buf sellim spur spursub llsq fft1var fft2var fft3var uivar screenvar sigvar selvar blnkvar calvar thrvar"
+OBJ=""
+for s in $SRC; do
+  if [ -f "$T/$s.c" ]; then src="$T/$s.c"; else src="$REF/$s.c"; fi
+  gcc $CFLAGS -I"$T" -I"$ROOT/include" -c "$src" -o "$OUT/$s.o"
+  OBJ="$OBJ $OUT/$s.o"
+done
+gcc -O2 -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" -c "$T/hipshim.c" -o "$OUT/hipshim.o"
+gcc -O1 -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim.o" \
+    -o "$HERE/_ref/shim_harness" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
+    -Wl,-rpath,"$HERE" -Wl,-rpath,"$ROOT/linrad_amd" -lm -lpthread -Wl,--unresolved-symbols=ignore-all
+echo "built $HERE/_ref/shim_harness"

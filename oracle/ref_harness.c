@@ -38,6 +38,13 @@
 #include "blnkdef.h"
 #include "thrdef.h"
 #include "graphcal.h"
+#ifdef SHIM_HARNESS
+/* oracle/_ref/shim_harness (oracle/build_shim_harness.sh): the same driver over the PATCHED reference objects, fft1 version 21;
+   integration/hipshim.c is linked over the oracle's C ABI (oracle/shim_alias.h), so the stage functions called below are the
+   reference's own entry points handing over to the glue.  The dump then holds what Linrad sees on the host (sums, lines,
+   pointers, scalars, timf3) plus, fetched at the end, the device-resident rings. */
+#include "hipshim.h"
+#endif
 
 /* ---- stand-ins for GUI / OS entry points of the reference program ---- */
 int harness_err = 0;
@@ -283,6 +290,9 @@ int main(int argc, char **argv)
   pg_ch2_c1 = (float)ch2_c1; pg_ch2_c2 = (float)ch2_c2;
   ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
+#ifdef SHIM_HARNESS
+  genparm[FIRST_FFT_VERNR] = 7;                                        /* -> fft_cntrl[21] "HIP MI355X" (the patch's new column) */
+#endif
   genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
   genparm[SECOND_FFT_ENABLE] = second; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
   genparm[SECOND_FFT_SINPOW] = sinpow2; genparm[SECOND_FFT_VERNR] = 0; /* -> fft_cntrl[15] */
@@ -633,6 +643,14 @@ int main(int argc, char **argv)
 #define AFC_FQ(t) ((float)(fq + 1.5 * sin(2 * PI_L * (t) / 23.0) + ((t) >= 30 && (t) < 60 ? 3.0 : 0.0)))
 #define AFC_SUPPLY(nx, mask) do { if (afc_t == 0) mix1_fq_mid[nx] = AFC_FQ(0); \
       mix1_fq_mid[((nx) + 1) & (mask)] = AFC_FQ(afc_t + 1); afc_supplied[afc_t] = mix1_fq_mid[((nx) + 1) & (mask)]; afc_t++; } while (0)
+#ifdef SHIM_HARNESS
+  /* what get_wideband_sizes (buf.c:247-257, patched) and wideband_dsp's start (wcw.c:576, patched) do with version 21 selected */
+  if (fft_cntrl[FFT1_CURMODE].gpu != GPU_HIP) { fprintf(stderr, "version 21 not selected: FFT1_CURMODE %d\n", FFT1_CURMODE); return 2; }
+  fft1_use_gpu = GPU_HIP; gpu_fft1_batch_size = 1; gpu.fft1_device = 0; no_of_fft1b = 0;
+  if (AI("shim_refuse", 0) == 1) ui.network_flag = NET_RXOUT_FFT1;      /* a mode version 21 must refuse */
+  { int rc = hip_open(); fprintf(stderr, "hip_open: %d\n", rc); if (rc != 0) { printf("{\"hip_open\": %d}\n", rc); fclose(fo); return AI("shim_refuse", 0) ? 0 : 3; } }
+  hip_timf1_new(0, timf1_bytes);                                        /* finish_rx_read's hand-over (rxin.c:1425, patched), the whole recording at once */
+#endif
   /* ---- run ---- */
   float *trace = zalloc(sizeof(float) * TR_COLS * nblk);
   int *itrace = zalloc(sizeof(int) * TR_COLS * nblk);
@@ -780,6 +798,18 @@ int main(int argc, char **argv)
     fclose(fo);
     return harness_err ? 3 : 0;
   }
+#ifdef SHIM_HARNESS
+  /* the rings Linrad never sees with version 21, fetched for the comparison; everything else below is the host's own copy as the
+     glue kept it (fft1_sumsq, fft1_slowsum, fft2_powersum_float, wg_waterf lines, timf3_float, timf2_blockpower, liminfo, scalars) */
+  lrh_export(hip_context(), LRH_RING_FFT1_FLOAT, fft1_float, 0, (size_t)max_fft1n * fft1_block);
+  if (second) {
+    lrh_export(hip_context(), LRH_RING_TIMF2_FLOAT, timf2_float, 0, timf2_size);
+    lrh_export(hip_context(), LRH_RING_TIMF2_PWR, timf2_pwr_float, 0, timf2pow_size);
+    lrh_export(hip_context(), LRH_RING_FFT2_FLOAT, fft2_float, 0, (size_t)2 * N2 * max_fft2n);
+    lrh_export(hip_context(), LRH_RING_FFT2_POWER, fft2_power_float, 0, (size_t)N2 * max_fft2n);
+  }
+  hip_close();
+#endif
   /* ---- dump results ---- */
   PUTF("fft1_first_raw", fft1_first, 2 * C * N1);
   PUTF("fft1_float", fft1_float, (size_t)max_fft1n * fft1_block);
