@@ -793,25 +793,37 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
   if (q->exact_stats) return sellim_install(c, c->sel_seq);
   return LRH_OK;
 }
+// One gate for every way the limiter's parameters reach the kernels (both update entry points, lrh_wideband_limiter): the kernels
+// index LDS and global arrays with these values and divide by group_points, so nothing unchecked may pass.  `second`: the
+// fft2 variant's extra demands (groups of at least 16 bins, a block time for the hold-off).
+static int sellim_check(lrh_ctx *c, const lrh_sellim *q, bool second)
+{
+  if (q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (c->N1 > 32768) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 32768; use lrh_set_liminfo");
+  const int gp = q->liminfo_group_points;
+  const bool ok = gp >= (second ? 16 : 4) && gp <= c->N1 &&
+                  q->fft1_first_point >= 0 && q->fft1_first_point <= q->fft1_last_point && q->fft1_last_point < c->N1 &&
+                  q->fft1_first_inband >= 0 && q->fft1_first_inband <= q->fft1_last_inband && q->fft1_last_inband < c->N1 &&
+                  q->sellim_maxlevel >= 1 && q->spek_avgnum >= 1 && q->fft1_blocktime > 0 && (!second || q->fft2_blocktime > 0);
+  if (!ok) return fail(c, LRH_EINVAL, "selective limiter: parameter out of range (group_points, first/last point or inband, maxlevel, spek_avgnum, blocktime)");
+  if (second && (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1))
+    return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size");
+  return LRH_OK;
+}
 int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 {
   LRH_ENTER(c);
-  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (!c || !p || !q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (c->N1 > 32768) return fail(c, LRH_EINVAL, "selective limiter on the device: fft1_size <= 32768; use lrh_set_liminfo");
-  if (q->liminfo_group_points < 1 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->sellim_maxlevel < 1 ||
-      c->N1 / q->liminfo_group_points > c->N1 / 4) return LRH_EINVAL;
+  { const int rc = sellim_check(c, q, false); if (rc) return rc; }
   return sellim_run(c, p, q, 1);
 }
 int lrh_fft2_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 {
   LRH_ENTER(c);
-  if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
+  if (!c || !p || !q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1)
-    return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size");
-  if (q->liminfo_group_points < 16 || q->fft1_last_point >= c->N1 || q->fft1_first_point < 0 || q->fft1_last_inband >= c->N1 || q->fft1_first_inband < 0 ||
-      q->sellim_maxlevel < 1 || !(q->fft1_blocktime > 0)) return LRH_EINVAL;
+  { const int rc = sellim_check(c, q, true); if (rc) return rc; }
   return sellim_run(c, p, q, 2);
 }
 int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
@@ -821,8 +833,7 @@ int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   c->wl_on = false;
   if (!par) return LRH_OK;
-  if (par->struct_size != (int)sizeof *par) return LRH_EINVAL;
-  if (c->N1 > 32768 || (fft2_too && (!c->cfg.second_fft_enable || c->N2 < c->N1 || par->liminfo_group_points < 16))) return fail(c, LRH_EINVAL, "lrh_wideband_limiter: sizes the limiter kernels do not take");
+  { int rc = sellim_check(c, par, false); if (!rc && fft2_too) rc = sellim_check(c, par, true); if (rc) return rc; }
   c->wl_par = *par;
   if (par->fft1_desired) { c->wl_desired.assign(par->fft1_desired, par->fft1_desired + c->N1); c->wl_par.fft1_desired = c->wl_desired.data(); }
   c->wl_on = true; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;

@@ -71,7 +71,7 @@ def main():
         out["liminfo"] = lim
         if d["foldcorr_seed"]:
             out["foldcorr"] = make_foldcorr(d)
-        path = os.path.join(HERE, f"{name}.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
         print(name, os.path.getsize(path) // 1024, "KiB")
 

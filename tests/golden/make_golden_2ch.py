@@ -42,7 +42,7 @@ def main():
         for k in ("timf2_float", "timf2_pwr_float", "itrace", "trace"):
             out["bln_" + k] = refb[k]
         out["frames"], out["liminfo"] = frames, lim
-        path = os.path.join(HERE, f"{name}.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         if "--chain-only" not in sys.argv and ("--only" not in sys.argv or name in sys.argv):
             np.savez_compressed(path, **out)
             print(name, os.path.getsize(path) // 1024, "KiB")
@@ -62,7 +62,7 @@ def main():
         outc = {k: refc[k] for k in ("hdr", "itrace", "trace", "fft2_float", "fft2_xypower", "fft2_xysum", "wf_lines", "timf3_float",
                                      "mixtrace", "final", "wg_waterf_yfac", "timf2_pwr_float", "fft3", "fft3_ptrs", "baseb_raw",
                                      "baseb_raw_orthog", "bg_filterfunc", "baseb_ptrs")}
-        path = os.path.join(HERE, f"{name}_chain.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}_chain.npz")
         np.savez_compressed(path, **outc)
         print(name + "_chain", os.path.getsize(path) // 1024, "KiB")
 

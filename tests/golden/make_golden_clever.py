@@ -42,7 +42,7 @@ def main():
             ref = load_dump(fo)
         out = {k: ref[k] for k in KEEP if k in ref}
         out["iq"], out["liminfo"], out["desired"] = iq, lim, des
-        path = os.path.join(HERE, f"{name}.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
         tr = ref["trace"].reshape(-1, 16)
         it = ref["itrace"].reshape(-1, 16)

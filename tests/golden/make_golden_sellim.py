@@ -35,7 +35,7 @@ def main():
             ref = load_dump(fo)
         out = {k: ref[k] for k in KEEP if k in ref}
         out["iq"] = iq
-        path = os.path.join(HERE, f"{name}.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
         tr = out["liminfo_trace"].reshape(-1, 1 << d["n1"])
         if "liminfo_trace2" in out:

@@ -37,7 +37,7 @@ def main():
         assert ref["spur_locked"][0] > 0, "the reference did not lock the spur: " + r.stderr
         out = {k: ref[k] for k in KEEP if k in ref}
         out["iq"], out["liminfo"] = iq, lim
-        path = os.path.join(HERE, f"{name}.npz")
+        path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
         tr = out["spur_trace"].reshape(-1, 12)
         print(name, os.path.getsize(path) // 1024, "KiB;", r.stderr.strip().splitlines()[-1][:150])

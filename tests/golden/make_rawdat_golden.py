@@ -28,7 +28,7 @@ def main():
         packed = np.fromfile(fp, np.uint8)
         subprocess.check_call([TOOL, "expand", f"in={fp}", f"out={fe}", f"pa={pa}", f"ring_log2={ring_log2}"])
         ring = np.fromfile(fe, np.uint8)
-    path = os.path.join(HERE, "rawdat_18bit.npz")
+    path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), "rawdat_18bit.npz")
     np.savez_compressed(path, samples=samples, packed=packed, ring=ring, pa=np.array(pa), ring_log2=np.array(ring_log2))
     print(path, os.path.getsize(path) // 1024, "KiB", packed.size, "packed bytes")
 
