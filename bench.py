@@ -34,7 +34,7 @@ from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newes
 from linrad_amd.workload import (ALG_BYTES, HBM_PEAK_GBS, alg_bytes_chain, chain_config, strong_liminfo, workload_name)  # noqa: E402
 
 METRIC = "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline"
-STAGES = ("fft1", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
+STAGES = ("fft1", "fft1w", "timf2s", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
 
 
 def setup_receiver(cfg, channel, open_fn, synth_mod):
@@ -229,6 +229,9 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     cfg = chain_config(w["fft1_n"], w["fft2_n"], batch=args.batch, device=local_rank, fft3_n=w["fft3_n"], mix2_n=w["mix2_n"], rounds=args.rounds)
     if args.real_input:
         cfg.timf1_real_input = 1
+    # nothing on this path reads the fft1_float ring (make_timf2 is its consumer): the fused forward transform then stores only the
+    # strong bins its second pass needs (cfg.fft1_float_sparse, include/linrad_hip.h); --fft1-float full keeps every bin
+    cfg.fft1_float_sparse = 0 if args.fft1_float == "full" else 1
     if coupled:
         cfg.blanker_channels, cfg.timf1_channel_index = 2, rank & 1
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
@@ -516,6 +519,11 @@ def main():
     ap.add_argument("--coupled", action="store_true",
                     help="BASELINE configs[3] as the primary workload: ranks 0/1 are the two channels of a polarisation pair: coupled blanker "
                          "(2 all-reduces per call), fft2 cross products (all-gather), fft3 + polarisation transform in mix2 (all-reduce)")
+    ap.add_argument("--combine", action="store_true",
+                    help="BASELINE configs[4]'s mode (one channel per rank + coherent combine) also on a single rank: the pre-flight of the multi-GPU "
+                         "run (with LRH_BENCH_FORCE_DIST=1 the collectives go through a one-rank RCCL group)")
+    ap.add_argument("--fft1-float", choices=("sparse", "full"), default="sparse",
+                    help="sparse (default): the fft1_float ring keeps only the strong bins (nobody on the path reads it); full: every bin is stored")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
@@ -546,6 +554,8 @@ def main():
         # lazy communicator: an RCCL communicator on the device costs this pipeline ~6 % (measured, round 1) even when
         # idle, so it is only created by the first collective, i.e. when there really is more than one rank
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != world or (world > 1 and world != args.gpus):
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, WORLD_SIZE {world}, --gpus {args.gpus}")
     from linrad_amd import lib as hiplib
 
     if args.coupled and world > 2:
@@ -553,7 +563,7 @@ def main():
     # primary workload: configs[2] on one GPU; one channel per GPU with the coherent combine on several (configs[4])
     if args.coupled:
         primary = make_workload("c3", args.fft1_n, args.fft2_n if explicit_fft2 else 12, 10, 8)
-    elif world > 1:
+    elif world > 1 or args.combine:
         primary = make_workload("c4", args.fft1_n, args.fft2_n, args.fft3_n or 12, args.mix2_n)
     else:
         primary = make_workload("c2" if args.fft3_n else "c1", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n)
@@ -563,7 +573,7 @@ def main():
 
     # second workload of the default run: configs[1] beside configs[2] on one GPU; configs[3] (coupled pair) on two
     secondary = None
-    default_run = not explicit_fft2 and not args.coupled and not args.stream_host and not args.real_input and not args.no_secondary
+    default_run = not explicit_fft2 and not args.coupled and not args.combine and not args.stream_host and not args.real_input and not args.no_secondary
     if default_run and world <= 2:
         sw = make_workload("c1", args.fft1_n, 12, 0, 0) if world == 1 else make_workload("c3", args.fft1_n, 12, 10, 8)
         try:
@@ -587,6 +597,8 @@ def main():
     else:
         nranks = 1
     if rank == 0:
+        if nranks != world or (world > 1 and world != args.gpus):      # the line must describe the group the collectives really ran in
+            raise SystemExit(f"bench.py: collectives ran in a group of {nranks}, WORLD_SIZE {world}, --gpus {args.gpus}")
         value = res["value"]
         N1, N2 = 1 << primary["fft1_n"], 1 << primary["fft2_n"]
         out = {
@@ -596,7 +608,8 @@ def main():
             "config": {"workload": res["config_text"], "fft1_size": N1, "fft2_size": N2,
                        "fft3_size": (1 << primary["fft3_n"]) if primary["fft3_n"] else 0, "batch_blocks": args.batch,
                        "rounds_per_step": args.rounds, "channels": world, "parallelism": f"1 RF channel per GPU x{world}",
-                       "collective_world_size": nranks, "backend": (backend if dist is not None else None)},
+                       "collective_world_size": nranks, "backend": (backend if dist is not None else None),
+                       "fft1_float": "strong bins only (cfg.fft1_float_sparse: no reader on this path)" if args.fft1_float == "sparse" else "every bin stored"},
             "mode": {"chain": "lrh_wideband_dsp", "combine": "lrh_wideband_dsp + coherent combine (lrh_mix2_pol_begin / all-reduce / lrh_fft3_mix2)",
                      "coupled": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan"}[primary["mode"]],
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",

@@ -115,7 +115,12 @@ typedef struct lrh_config {
                                    int16 or int32; timf1p_px advances 4*M1 bytes per block and channel like I/Q; two real
                                    channels per frame {a_k, b_k} (fft1_reherm_dit_two, fft1_re.c:133) with
                                    timf1_frame_channels = 2, one per context                                         */
-  int reserved[2];
+  int fft1_float_sparse;        /* 1: nobody reads the fft1_float ring (second fft on: make_timf2 is its only consumer on the path).  Inside
+                                   lrh_wideband_dsp at fft1_size 16384 the forward transform, fft1_c's sums and the weak half of make_timf2
+                                   then run as one kernel and only the strong bins of a spectrum reach the ring (the second, sparse pass
+                                   of make_timf2 reads them); LRH_RING_FFT1_FLOAT then holds those bins only.  0 (default): every bin is
+                                   stored as before (lrh_export, lrh_fft1_mix1_*, the AFC window of the Linrad glue read it)          */
+  int reserved[1];
 } lrh_config;
 
 /*

@@ -46,6 +46,15 @@ __device__ __forceinline__ lrh_v2f cmul_v(lrh_v2f av, lrh_v2f bv)
   return r;
 }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return to_f2(cmul_v(to_v(a), to_v(b))); }
+// a * conj(b), same two instructions with the negation moved:  t = (a.x b.x, -a.x b.y);  r = (t.x + a.y b.y, t.y + a.y b.x)
+__device__ __forceinline__ lrh_v2f cmul_conj_v(lrh_v2f av, lrh_v2f bv)
+{
+  lrh_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return r;
+}
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) { return to_f2(cmul_conj_v(to_v(a), to_v(b))); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiply by -j (DIR = -1, forward) or +j (DIR = +1)
@@ -87,6 +96,15 @@ template <int DIR, int E> __device__ __forceinline__ float2 w16()
   constexpr float s[10] = {0.f, LRH_S16A, LRH_C8, LRH_C16A, 1.f, LRH_C16A, LRH_C8, LRH_S16A, 0.f, -LRH_S16A};
   return make_float2(c[E], DIR < 0 ? -s[E] : s[E]);
 }
+
+// exp(DIR * 2 pi j * e / 32), any e (the last-pass roots of BlockFftL: order = points per thread)
+__host__ __device__ constexpr float lrh_cos32(int e)
+{
+  constexpr float q[9] = {1.f, 0.98078528040323044913f, LRH_C16A, 0.83146961230254523708f, LRH_C8, 0.55557023301960222474f, LRH_S16A, 0.19509032201612826785f, 0.f};
+  e &= 31;
+  return e <= 8 ? q[e] : (e <= 16 ? -q[16 - e] : (e <= 24 ? -q[e - 16] : q[32 - e]));
+}
+__host__ __device__ constexpr float lrh_sin32(int e) { return lrh_cos32(e - 8); }
 
 // R-point DFT of u[0..R) in place, natural order
 template <int DIR, int R> struct Dft;
@@ -143,7 +161,13 @@ template <int DIR> struct Dft<DIR, 16> {
 // Measured on MI355X (round 1): 32 points/thread + half-round exchanges at N = 16384 (512 threads, 68 KiB LDS, two
 // workgroups per CU) needs > 128 VGPRs, spills ~130 registers and runs 1.7-2.2x SLOWER than 16 points x 1024
 // threads with one workgroup per CU; the half-round path stays available (fft_halves) but is not selected.
+#ifndef LRH_P14
+#define LRH_P14 16          /* points per thread at N = 16384: 16 (1024 threads, 128 VGPRs) or 32 (512 threads, 256 VGPRs) */
+#endif
 __host__ __device__ constexpr int points_per_thread(int log2n) { return log2n >= 10 ? 16 : 4; }
+// k_fft1 / k_timf2 (BlockFftL, one persistent workgroup per CU at N = 16384)
+__host__ __device__ constexpr int points_fft1(int log2n) { return log2n == 14 ? LRH_P14 : points_per_thread(log2n); }
+__host__ __device__ constexpr int fft1_threads(int log2n) { return (1 << log2n) / points_fft1(log2n); }
 __host__ __device__ constexpr int fft_halves(int log2n) { return 1; }
 __host__ __device__ constexpr int fft_threads(int log2n) { return (1 << log2n) / points_per_thread(log2n); }
 // waves per SIMD to ask for in __launch_bounds__ (N = 8192: two 512-thread workgroups per CU)
@@ -290,8 +314,11 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
 // All LDS addresses are one per-thread base plus constants.  run() may be called again without a barrier in between.
 //   table of pass with completed length p, radix R:  cell[e*p + k] = w^(mult(e) k N/(pR)),  k < p
 //   mult = {1,2,3,4,8,12} (R=16), {1,2,3,4} (R=8), {1..R-1} otherwise -- the factors pass() combines.
-template <int LOG2N, int P, int DIR> struct BlockFftL {
+// CONJTAB: the tables in LDS were filled by the transform of the OTHER direction (BlockFftL<LOG2N, P, -DIR>::init) and are
+// conjugated as they are applied -- a kernel that runs forward and back transforms (k_fft1w) keeps one set of tables.
+template <int LOG2N, int P, int DIR, bool CONJTAB = false> struct BlockFftL {
   using Plan = FftPlan<LOG2N, P>;
+  __device__ __forceinline__ static float2 twmul(float2 u, float2 w) { return CONJTAB ? cmul_conj(u, w) : cmul(u, w); }
   static constexpr int N = Plan::N, T = Plan::T, NPASS = Plan::NPASS;
   static_assert(Plan::HALVES == 1, "full-round exchange only");
   __host__ __device__ static constexpr int per(int R) { return R == 16 ? 6 : (R == 8 ? 4 : R - 1); }
@@ -300,7 +327,7 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
   __host__ __device__ static constexpr int tab_off(int pass) { int o = 0; for (int i = 1; i < pass; i++) o += Plan::done(i) * per(Plan::radix(i)); return o; }
   static constexpr int TW_CELLS = tab_off(NTAB) + (ROOT_LAST ? T : 0) + 1;
   static constexpr int LDS_CELLS = Plan::LDS_CELLS + TW_CELLS;     // exchange buffer, then the tables
-  static_assert(!ROOT_LAST || (P == 16 && Plan::RL <= 4), "last-pass roots: 16th roots of unity, powers up to 3");
+  static_assert(!ROOT_LAST || ((P == 16 || P == 32) && Plan::RL <= 4), "last-pass roots: P-th roots of unity, powers up to 3");
 
   template <int PASS> __device__ __forceinline__ static void init_tab(float2 *twl, const float2 *__restrict__ tw, int tid)
   {
@@ -321,22 +348,25 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     if constexpr (ROOT_LAST) lds[Plan::LDS_CELLS + tab_off(NTAB) + tid] = tw_dir<DIR>(tw[tid]);
   }
 
-  template <int E> __device__ __forceinline__ static float2 mul_root(float2 v)       // v * exp(DIR 2 pi j E / 16)
+  template <int E> __device__ __forceinline__ static float2 mul_root(float2 v)       // v * exp(DIR 2 pi j E / P), E in units of 1/32 turn
   {
-    if constexpr (E == 0) return v;
-    else if constexpr (E == 4) return mulj<DIR>(v);
-    else if constexpr (E == 8) return make_float2(-v.x, -v.y);
-    else return cmulc(v, w16<DIR, E>());
+    constexpr int e = E & 31;
+    if constexpr (e == 0) return v;
+    else if constexpr (e == 8) return mulj<DIR>(v);
+    else if constexpr (e == 16) return make_float2(-v.x, -v.y);
+    else if constexpr (e == 24) return mulj<-DIR>(v);
+    else return cmulc(v, make_float2(lrh_cos32(e), DIR < 0 ? -lrh_sin32(e) : lrh_sin32(e)));
   }
   // butterfly M of the root pass: element S gets w^(S (tid + M T)) = w^(S tid) * (16th root)^(S M)
   template <int M, int R, int NB> __device__ __forceinline__ static void root_pass(float2 *x, float2 w1, float2 w2, float2 w3)
   {
     if constexpr (M < NB) {
       float2 *u = &x[M * R];
-      u[1] = cmul(u[1], mul_root<(1 * M) % 16>(w1));
+      constexpr int U = 32 / P;                         // butterfly M sits M T = M N/P bins further: M/P of a turn per unit of S
+      u[1] = cmul(u[1], mul_root<1 * M * U>(w1));
       if constexpr (R > 2) {
-        u[2] = cmul(u[2], mul_root<(2 * M) % 16>(w2));
-        u[3] = cmul(u[3], mul_root<(3 * M) % 16>(w3));
+        u[2] = cmul(u[2], mul_root<2 * M * U>(w2));
+        u[3] = cmul(u[3], mul_root<3 * M * U>(w3));
       }
       Dft<DIR, R>::run(u);
       root_pass<M + 1, R, NB>(x, w1, w2, w3);
@@ -353,10 +383,10 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
     constexpr int NB = P / R, PER = per(R);
     if constexpr (PASS == NPASS - 1) before_last();
     if constexpr (ROOT_LAST && PASS == NPASS - 1) {
-      static_assert((R - 1) * (NB - 1) < 10, "w16 covers exponents 0..9");
       int tt_ = tid;
       asm volatile("" : "+v"(tt_));
-      const float2 w1 = lds[Plan::LDS_CELLS + tab_off(NTAB) + tt_];   // w^tid, then its square and cube
+      float2 w1 = lds[Plan::LDS_CELLS + tab_off(NTAB) + tt_];         // w^tid, then its square and cube
+      if constexpr (CONJTAB) w1.y = -w1.y;
       const float2 w2 = cmul(w1, w1);
       const float2 w3 = cmul(w2, w1);
       root_pass<0, R, NB>(x, w1, w2, w3);
@@ -375,14 +405,14 @@ template <int LOG2N, int P, int DIR> struct BlockFftL {
 #pragma unroll
             for (int s = 1; s < 16; s++) {
               const int a = s >> 2, b = s & 3;
-              u[s] = cmul(u[s], a == 0 ? w[b - 1] : (b == 0 ? w[2 + a] : cmul(w[2 + a], w[b - 1])));
+              u[s] = twmul(u[s], a == 0 ? w[b - 1] : (b == 0 ? w[2 + a] : cmul(w[2 + a], w[b - 1])));
             }
           } else if constexpr (R == 8) {
 #pragma unroll
-            for (int s = 1; s < 8; s++) u[s] = cmul(u[s], s < 4 ? w[s - 1] : (s == 4 ? w[3] : cmul(w[3], w[s - 5])));
+            for (int s = 1; s < 8; s++) u[s] = twmul(u[s], s < 4 ? w[s - 1] : (s == 4 ? w[3] : cmul(w[3], w[s - 5])));
           } else {
 #pragma unroll
-            for (int s = 1; s < R; s++) u[s] = cmul(u[s], w[s - 1]);
+            for (int s = 1; s < R; s++) u[s] = twmul(u[s], w[s - 1]);
           }
         }
         Dft<DIR, R>::run(u);

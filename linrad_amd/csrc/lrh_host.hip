@@ -47,6 +47,7 @@ hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int 
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
+hipError_t launch_spur_patch(const SpurPatchArgs &a, int nspurs, int ngroups, hipStream_t st);
 hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
 }  // namespace lrh
 using namespace lrh;
@@ -95,6 +96,10 @@ struct lrh_ctx {
   bool sums_on_main = false;         // LRH_SUMS_MAIN (default: on for fft2_size <= 16384), see lrh_wideband_dsp
   int spare_cus = 0;                 // LRH_SPARE_CUS: see persistent_grid (used while lrh_wideband_limiter is installed; measured: no gain, 8 spare units cost 7 % of k_fft1 / k_timf2)
   bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
+  // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
+  // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
+  bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
+  bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
   std::vector<std::function<int(lrh_ctx *)>> ss_queue;
@@ -156,7 +161,7 @@ struct lrh_ctx {
   std::vector<unsigned int> h_pack;
   bool have_liminfo = false;
   // spurs being tracked (lrh_spur_config / lrh_spur_set): loop state and histories on the device, k_spur between fft2 and its power sums
-  int spur_max = 0, spur_n = 0, spur_speknum = 0; lrh_spur *d_spurs = nullptr; float *d_spur_table = nullptr, *d_spur_signal = nullptr, *d_spur_scratch = nullptr, *d_spur_spectra = nullptr; int *d_spur_ind = nullptr;
+  int spur_max = 0, spur_n = 0, spur_speknum = 0; lrh_spur *d_spurs = nullptr; float *d_spur_table = nullptr, *d_spur_signal = nullptr, *d_spur_spectra = nullptr; int *d_spur_ind = nullptr, *d_spur_touched = nullptr;
   // selective limiter on the device (lrh_fft1_update_liminfo): the reference's liminfo / old_liminfo / liminfo_wait / fftt_tmp
   float *d_liminfo = nullptr, *d_old_liminfo = nullptr, *d_sel_tmp = nullptr; unsigned char *d_sel_wait = nullptr; SellimState *d_sel_st = nullptr;
   // weak-bin counts come back through a ring of pinned slots; without exact_stats the one installed is two updates old, so
@@ -369,7 +374,7 @@ void lrh_close(lrh_ctx *c)
   for (hipEvent_t e : c->ev_sel_slot) if (e) hipEventDestroy(e);
   if (c->d_pack18) hipFree(c->d_pack18);
   if (c->d_stamps) hipFree(c->d_stamps);
-  for (void *q_ : { (void *)c->d_spurs, (void *)c->d_spur_table, (void *)c->d_spur_signal, (void *)c->d_spur_scratch, (void *)c->d_spur_spectra, (void *)c->d_spur_ind }) if (q_) hipFree(q_);
+  for (void *q_ : { (void *)c->d_spurs, (void *)c->d_spur_table, (void *)c->d_spur_signal, (void *)c->d_spur_touched, (void *)c->d_spur_spectra, (void *)c->d_spur_ind }) if (q_) hipFree(q_);
   if (c->d_net) hipFree(c->d_net);
   if (c->d_fft1net) hipFree(c->d_fft1net);
   if (c->d_foldcorr) hipFree(c->d_foldcorr);
@@ -447,6 +452,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
+  if (const char *e9 = getenv("LRH_FUSE_FFT1")) c->fuse_fft1 = atoi(e9) != 0;        // 0: k_fft1 + k_timf2 also where k_fft1w would run
   c->sums_on_main = cfg->fft2_n <= 14;
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
@@ -910,17 +916,17 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
 int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
 {
   LRH_ENTER(c);
-  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n || speknum > 2048))) return LRH_EINVAL;   // 2048: k_spur's LDS working set
   if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel, second fft on");
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-  for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_scratch, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
+  for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_touched, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
     if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->spur_max = 0; c->spur_n = 0; c->spur_speknum = 0;
   if (!max_spurs) return LRH_OK;
   const size_t maxn = c->cfg.max_fft2n;
   int rc = LRH_OK;
   if ((rc = dev_alloc(c, &c->d_spurs, max_spurs)) || (rc = dev_alloc(c, &c->d_spur_table, max_spurs * maxn * 14)) || (rc = dev_alloc(c, &c->d_spur_signal, max_spurs * maxn * 2)) ||
-      (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_scratch, max_spurs * 8 * (maxn + 8))) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
+      (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_touched, 2 * max_spurs)) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_spur_spectra, spectra, sizeof(float) * LRH_SPUR_SPECTRA, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->spur_max = max_spurs; c->spur_speknum = speknum;
@@ -1056,8 +1062,10 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
 
 // ---------------------------------------------------------------------------------------------- fft1
 // Transforms launched by fft1_b workers on their own streams: whoever reads fft1_float next on the main stream waits for them.
+static int launch_parked_fft1(lrh_ctx *c);
 static int join_handles(lrh_ctx *c)
 {
+  if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }   // a reader other than the fused make_timf2: the transform after all
   for (int h = 1; h < LRH_MAX_HANDLES; h++)
     if (c->hpending[h]) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->hev[h], 0)); c->hpending[h] = false; }
   return LRH_OK;
@@ -1105,6 +1113,11 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur));
     a.stamps = c->d_stamps;
   }
+  if (c->f1_defer && handle == 0 && c->cfg.fft1_n == 14 && !a.real && !a.dword && !a.shift_i && !a.shift_q && !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
+    if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
+    c->f1_args = a; c->f1_batch = batch; c->f1_have = true;    // lrh_make_timf2 takes it from here (k_fft1w)
+    return LRH_OK;
+  }
   ProfScope ps(c, "fft1");
   if (c->fft1_big) {
     const size_t need = (size_t)batch * c->N1;
@@ -1146,6 +1159,17 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   return LRH_OK;
 }
 
+static int launch_parked_fft1(lrh_ctx *c)
+{
+  c->f1_have = false;
+  hipStream_t keep = c->cur; c->cur = c->stream;          // parked on the main stream, issued there
+  struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep};
+  ProfScope ps(c, "fft1");
+  HIPCHK(c, launch_fft1(c->cfg.fft1_n, c->f1_args, c->f1_batch, c->cur));
+  if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }
+  return LRH_OK;
+}
+
 int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
 {
   if (!c) return LRH_EINVAL;
@@ -1169,7 +1193,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  if (!(c->ss_defer && c->f1_have)) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // parked sums behind a parked transform: make_timf2 decides
   const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
   if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
     return fail(c, LRH_EINVAL, "fft1_sumsq ring too short for this batch");
@@ -1177,7 +1201,10 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
   sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.sumsq_mask = c->sumsq_mask;
   sa.first_nb = p->fft1_nb; sa.batch = batch; sa.avg = avg1; sa.c0 = p->fft1_sumsq_counter; sa.pa0 = p->fft1_sumsq_pa;
   if (c->ss_defer) {
-    if (c->ss_have) { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(c->ss_args, c->cur)); }   // nobody took the last ones
+    if (c->ss_have) {                                      // nobody took the last ones
+      if (c->f1_have && c->f1_args.first_nb == c->ss_args.first_nb) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
+      ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(c->ss_args, c->cur));
+    }
     c->ss_args = sa; c->ss_have = true;
   } else { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
   std::vector<std::function<int(lrh_ctx *)>> *const rec0 = c->rec;
@@ -1210,7 +1237,11 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  // k_fft1w: the parked forward transform, the parked sums and this call's weak stream address the same transforms
+  const int nb_here = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask;
+  const bool fused1 = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->d_ss_part && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
+                      c->ss_args.batch == batch && c->ss_args.first_nb == nb_here && c->cur == c->stream;
+  if (!fused1) { const int rc_ = join_handles(c); if (rc_) return rc_; }
   if (c->sel_table_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_sel, 0)); c->sel_table_pending = false; }   // routing words from the side stream
   if (c->h_sel_low) sellim_poll(c);                        // weak-bin count of the newest finished limiter update, if one has arrived
   Timf2Args a;
@@ -1236,7 +1267,26 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     HIPCHK(c, launch_timf2_big(c->cfg.fft1_n, g, batch, c->cur));
     return LRH_OK;
   };
-  if (c->ss_have) {
+  if (fused1) {
+    const SumsqArgs sa = c->ss_args;
+    const Fft1Args &f = c->f1_args;
+    c->ss_have = false; c->f1_have = false;
+    float *const part = c->d_ss_part + (size_t)c->ss_flip * c->ss_part_stride; c->ss_flip ^= 1;
+    Fft1wArgs w; memset(&w, 0, sizeof w);
+    w.timf1 = f.timf1; w.ring_mask = f.ring_mask; w.p0_first = f.p0_first; w.step = f.step; w.chan_count = f.chan_count; w.chan_index = f.chan_index;
+    w.window = f.window; w.filtercorr = f.filtercorr; w.tw = f.tw;
+    w.spec = c->d_fft1; w.first_nb = a.first_nb; w.nb_mask = a.nb_mask; w.keep_spec = c->cfg.fft1_float_sparse ? 0 : 1;
+    w.pack_cur = a.pack_cur; w.pack_prev = a.pack_prev; w.timf2w = a.timf2w; w.pwr = a.pwr; w.pa_first = a.pa_first; w.mask = a.mask; w.ampfac = a.ampfac;
+    w.have_prev = c->timf2_primed ? 1 : 0;
+    w.ss_ring = sa.sumsq; w.ss_part = part; w.ss_mask = sa.sumsq_mask; w.ss_avg = sa.avg; w.ss_c0 = sa.c0; w.ss_pa0 = sa.pa0;
+    w.batch = batch; w.spare_cus = a.spare_cus;
+    { ProfScope ps(c, "fft1w"); HIPCHK(c, launch_fft1w(w, c->cur, &c->ss_run)); }
+    if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read
+    { ProfScope ps(c, "timf2s"); HIPCHK(c, launch_timf2_strong(a, batch, c->cur)); }
+    const SumsqArgs ja = sa; const int run = c->ss_run;
+    c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {
+      ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, part, run, c->cur)); return LRH_OK; });
+  } else if (c->ss_have) {
     const SumsqArgs &sa = c->ss_args;
     c->ss_have = false;
     if (!c->fft1_big && a.mode == 1 && c->d_ss_part && sa.batch == batch && sa.first_nb == a.first_nb) {
@@ -1258,6 +1308,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     c->pack_prev_stale = false;
   }
   HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
+  c->timf2_primed = true;
   const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
     p->fft1_px = (p->fft1_px + 2 * c->N1) & c->fft1_mask;
@@ -1492,9 +1543,11 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   const int fft2_n = c->cfg.fft2_n;
   // spurs tracked: eliminate_spurs sits between the transform and the power sums (FFT2_ELIMINATE_SPURS, fft2.c:647-652), so the sums
   // cannot ride inside the transform kernel: transform, k_spur over the batch in order, |X|^2 of the cleaned bins, then the sums
+  // spurs tracked: eliminate_spurs sits between the transform and the power sums (fft2.c:647-652).  The fused form stays: the transform
+  // kernel sums |X|^2 as always, k_spur takes the carriers out of the batch in order, and k_spur_patch redoes the sums of the few bins
+  // it touched; without the fused form: transform, k_spur, |X|^2 of the cleaned bins, k_powersum2
   const bool spurs = c->spur_n > 0;
-  const bool fused = c->fft2_fused && !spurs;
-  if (spurs) { a.ps_avgnum = 0; g.ps_avgnum = 0; }
+  const bool fused = c->fft2_fused;
   SpurArgs sa; memset(&sa, 0, sizeof sa);
   if (spurs) {
     sa.fft2 = c->d_fft2; sa.n2 = N; sa.first_na = p->fft2_na; sa.na_mask = c->fft2n_mask; sa.batch = batch;
@@ -1504,9 +1557,12 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     sa.minston = (float)(1 / sqrt(0.5 * (float)(sa.speknum)));
     { float t1 = (float)(0.5 * sa.speknum); sa.weiold = t1 / (1 + t1); sa.weinew = 1 / (1 + t1);
       t1 = (float)(-0.5 * sa.numsub); sa.linefit = 0; for (int i = 0; i < sa.speknum; i++) { sa.linefit += t1 * t1; t1 += 1; } }
-    sa.spectra = c->d_spur_spectra; sa.spurs = c->d_spurs; sa.table = c->d_spur_table; sa.signal = c->d_spur_signal; sa.ind = c->d_spur_ind; sa.scratch = c->d_spur_scratch;
+    sa.spectra = c->d_spur_spectra; sa.spurs = c->d_spurs; sa.table = c->d_spur_table; sa.signal = c->d_spur_signal; sa.ind = c->d_spur_ind; sa.touched = c->d_spur_touched;
   }
   const int na0 = p->fft2_na, max2 = c->cfg.max_fft2n;
+  SpurPatchArgs pa; memset(&pa, 0, sizeof pa);
+  pa.fft2 = c->d_fft2; pa.n = N; pa.first_na = p->fft2_na; pa.na_mask = c->fft2n_mask; pa.count = batch; pa.counter = s.counter; pa.avgnum = s.avgnum;
+  pa.touched = c->d_spur_touched; pa.powersum_in = s.powersum_in; pa.powersum_out = s.powersum_out; pa.wf_scratch = s.wf_scratch;
   LRH_DEVICE_WORK(c, {
     if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
     if (fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(fft2_n, a, batch, c->cur)); }
@@ -1519,9 +1575,12 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     if (spurs) {
       ProfScope ps(c, "spur");
       HIPCHK(c, launch_spur(sa, main_s));
-      const int first = batch < max2 - na0 ? batch : max2 - na0;          // the batch's ring slots may wrap once
-      HIPCHK(c, launch_power_of(c->d_fft2 + (size_t)na0 * N, c->d_power2 + (size_t)na0 * N, (size_t)first * N, main_s));
-      if (batch > first) HIPCHK(c, launch_power_of(c->d_fft2, c->d_power2, (size_t)(batch - first) * N, main_s));
+      if (fused) HIPCHK(c, launch_spur_patch(pa, sa.nspurs, (s.counter + batch + s.avgnum - 1) / s.avgnum, main_s));
+      else {
+        const int first = batch < max2 - na0 ? batch : max2 - na0;          // the batch's ring slots may wrap once
+        HIPCHK(c, launch_power_of(c->d_fft2 + (size_t)na0 * N, c->d_power2 + (size_t)na0 * N, (size_t)first * N, main_s));
+        if (batch > first) HIPCHK(c, launch_power_of(c->d_fft2, c->d_power2, (size_t)(batch - first) * N, main_s));
+      }
       if (c->split_fft2_tail) { HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0)); }
     }
     if (!fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
@@ -1674,7 +1733,7 @@ static void afc_tables(lrh_ctx *c, lrh_afc *afc, int now, int newest, int mask)
 static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi,
                     lrh_afc *afc = nullptr, int na = 0)
 {
-  { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  if (src == c->d_fft1) { const int rc_ = join_handles(c); if (rc_) return rc_; }     // second fft off: the fft1 workers' (or a parked) transforms
   const int Nm = c->Nm, overlap = c->Im != 0, half = c->Mm, block2 = c->Mm;     // block in complex samples = rotated samples per transform
   lrh_mix1_state *s = &c->ms;
   const int selected = s->mix1_selfreq >= 0;
@@ -2030,7 +2089,9 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
                      !c->clever_on;                // the linear blanker reads its resume point back: serial schedule
   // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
   const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
-  struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); } } fuse_guard{c};
+  // ... and fft1_b's transform rides there too (k_fft1w): parked by lrh_fft1_b, taken by lrh_make_timf2, issued as k_fft1 by whoever else reads the ring
+  struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); c->f1_defer = false; if (c->f1_have) launch_parked_fft1(c); } } fuse_guard{c};
+  c->f1_defer = fuse && c->fuse_fft1 && !c->fft1_big && c->cfg.fft1_n == 14;
   auto sums = [&](int B) -> int {                // fft1_c: launches at once, or parked for the next make_timf2
     c->ss_defer = fuse; const int r = lrh_fft1_c(c, p, B); c->ss_defer = false; return r;
   };
@@ -2261,7 +2322,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_FFT2_FLOAT: src = c->d_fft2; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
     case LRH_RING_FFT2_POWER:
       src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2;
-      if (c->fft2_fused && c->spur_n == 0) {             // the hot path keeps only the sums: |X|^2 of the requested span on demand
+      if (c->fft2_fused) {                               // the hot path keeps only the sums: |X|^2 of the requested span on demand
         if (off > total || cnt > total - off) return LRH_EINVAL;
         HIPCHK(c, launch_power_of(c->d_fft2 + off, c->d_power2 + off, cnt, c->stream));
       }

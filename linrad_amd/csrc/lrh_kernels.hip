@@ -39,11 +39,11 @@ __device__ __forceinline__ void store_stream(float2 *p, float2 v)
 // REAL: real samples, the pair (x[2n], x[2n+1]) is one complex point with its own window value per component, nothing
 // negated, natural bin order, bare transform (k_realsplit finishes fft1_reherm_dit_one)
 template <int LOG2N, bool DW, bool SKEW, bool REAL = false>
-__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft1(Fft1Args a)
+__global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_fft1(Fft1Args a)
 {
   using Raw = typename std::conditional<DW, int2, short2>::type;
   using Comp = typename std::conditional<DW, int, short>::type;
-  constexpr int P = points_per_thread(LOG2N);
+  constexpr int P = points_fft1(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
   using Fft = BlockFftL<LOG2N, P, +1>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(64) void k_slowsum(SlowsumArgs a)
 // i.e. one transform of the combined spectrum, written once -- no read-modify-write of the timf2 ring.
 // One transform's outputs of stream ST (0 weak, 1 strong) to the planar rings.
 template <int LOG2N, int MODE, int ST>
-__device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x)[points_per_thread(LOG2N)], int pa, int tid)
+__device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x)[points_fft1(LOG2N)], int pa, int tid)
 {
-  constexpr int P = points_per_thread(LOG2N);
+  constexpr int P = points_fft1(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
   constexpr int N = Plan::N, T = Plan::T, RL = Plan::RL;
 #pragma unroll
@@ -433,10 +433,13 @@ __device__ __forceinline__ void timf2_store(const Timf2Args &a, const float2 (&x
 // registers; a group that lies inside one run goes straight to the fft1_sumsq ring (same additions in the same order
 // as the reference), the pieces of a group that straddles runs (or continues an earlier call) go to `ss_part` and
 // k_sumsq_join adds them up in order.
-template <int LOG2N, int MODE, bool SS>
-__global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_timf2(Timf2Args a)
+// STRONG_ONLY: the weak stream (and the sums) of these transforms came out of k_fft1w, which left the strong bins of every spectrum
+// in the fft1 ring: only the strong stream is transformed here, one item per transform.
+template <int LOG2N, int MODE, bool SS, bool STRONG_ONLY = false>
+__global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_timf2(Timf2Args a)
 {
-  constexpr int P = points_per_thread(LOG2N);
+  static_assert(!STRONG_ONLY || (MODE == 1 && !SS), "strong-only pass: sin^2 overlap form, sums elsewhere");
+  constexpr int P = points_fft1(LOG2N);
   using Plan = FftPlan<LOG2N, P>;
   using Fft = BlockFftL<LOG2N, P, -1>;
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, NB0 = P / R0;
@@ -528,9 +531,28 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
   const int r1 = SS ? min(r0 + a.ss_run, a.batch) : a.batch;
   auto order = [&](int i) { return (!SS && a.xcd) ? xcd_order(i, a.batch) : i; };
   int bi = SS ? r0 : (int)blockIdx.x;
-  if (bi < r1) issue(order(bi), 0, tid0);
+  if (bi < r1) issue(order(bi), STRONG_ONLY ? 1 : 0, tid0);
   __syncthreads();                                       // twiddle tables are in place
   __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): retire the prologue's loads here (see k_fft1)
+  if constexpr (STRONG_ONLY) {
+#pragma unroll 1
+    for (; bi < r1; bi += stride) {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int b = order(bi);
+      const int pa = a.pa_first + b * a.step;
+      float2 x[P];
+      combine(x, tid);
+      Fft::run(x, lds, tid);
+      pin(x);
+      __builtin_amdgcn_sched_barrier(0);
+      const int bn = min(bi + stride, r1 - 1);
+      issue(order(bn), 1, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      timf2_store<LOG2N, MODE, 1>(a, x, pa, tid);
+    }
+    return;
+  }
 #pragma unroll 1
   for (; bi < r1; bi += stride) {
     // opaque per-iteration copy of the thread index: without it LICM hoists every address and LDS index of the
@@ -558,6 +580,147 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_ti
     issue(order(bn), 0, tid);
     __builtin_amdgcn_sched_barrier(0);
     timf2_store<LOG2N, MODE, 1>(a, x, pa, tid);
+  }
+}
+
+
+// =====================================================================================================
+// fft1 + fft1_c's sums + make_timf2's weak stream in one kernel (fft1_size 16384, sin^2 window, int16 I/Q)
+// =====================================================================================================
+// The forward transform leaves a thread exactly the bins its back transform starts from (bin = tid mod N/32 in both layouts), so
+// the spectrum never has to travel through HBM between the two: per transform 64 KB of samples come in and 96 KB of weak time
+// function + power go out, where k_fft1 + k_timf2 moved 128 KB out, 128-256 KB back in and 160 KB out.  512 threads x 32 points
+// (two waves per SIMD, 256 VGPRs): a thread holds the new spectrum, the weak part of the previous one (the overlap partner, see
+// k_timf2) and fft1_c's running sums at the same time -- what 128 VGPRs at 1024 threads could not.  One set of twiddle tables in
+// LDS serves both directions (BlockFftL CONJTAB).  The strong stream is a handful of bins: they are stored to the fft1 ring (all
+// bins when keep_spec is set: fft1_float for whoever asks) and k_timf2<.., STRONG_ONLY> transforms them afterwards.
+// A workgroup takes a run of consecutive transforms like k_timf2<.., SS>; the weak spectrum of the transform before its run is
+// recomputed from the samples, which are still in the ring (one extra forward transform per run).
+template <int LOG2N>
+__global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1w(Fft1wArgs a)
+{
+  constexpr int P = 32;
+  using Plan = FftPlan<LOG2N, P>;
+  using FftF = BlockFftL<LOG2N, P, +1>;
+  using FftB = BlockFftL<LOG2N, P, -1, true>;
+  constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, RL = Plan::RL, NB0 = P / R0, NBL = P / RL;
+  static_assert(RL == 4 && R0 == 16 && (N / RL) % T == 0 && (N / R0) % T == 0, "register maps below");
+  __shared__ float2 lds[FftF::LDS_CELLS];
+  const int tid0 = threadIdx.x;
+  const int r0 = (int)blockIdx.x * a.run, r1 = min(r0 + a.run, a.batch);
+  if (r0 >= r1) return;
+  FftF::init(lds, a.tw, tid0);
+  unsigned int wk_cur[NB0], wk_first[NB0];
+#pragma unroll
+  for (int m = 0; m < NB0; m++) { wk_cur[m] = a.pack_cur[tid0 + m * T]; wk_first[m] = a.pack_prev[tid0 + m * T]; }
+  // register e of the forward transform's output (bin k' = tid + (e / RL) T + (e % RL) N/RL of the bare transform) is fft1 bin
+  // kk = (k' + N/2) mod N (DC at N/2) = tid + J T with J = e / RL + (P / RL) ((e % RL + RL / 2) % RL), and the back transform wants
+  // bin tid + (m + NB0 s) T in register m R0 + s: the same thread, register (J % NB0) R0 + J / NB0
+  auto jof = [](int e) { return e / RL + (P / RL) * ((e % RL + RL / 2) % RL); };
+  short2 raw[P];
+  float win[P];
+  auto fetch = [&](int b, int tid) {                     // samples and window values of transform b (b = -1: the one before the launch)
+    const int p0 = a.p0_first + b * a.step;
+#pragma unroll
+    for (int m = 0; m < NB0; m++)
+#pragma unroll
+      for (int s = 0; s < R0; s++) {
+        const int n = p0 + (tid + m * T) + s * (N / R0);
+        raw[m * R0 + s] = ((const short2 *)a.timf1)[(n * a.chan_count + a.chan_index) & a.ring_mask];
+        win[m * R0 + s] = (a.window + m * T + s * (N / R0))[(unsigned int)tid];
+      }
+  };
+  // forward transform of the fetched samples, filter correction applied: x[e] = fft1_float bin tid + jof(e) T
+  auto forward = [&](float2 (&x)[P], int tid) {
+#pragma unroll
+    for (int e = 0; e < P; e++) x[e] = make_float2((float)raw[e].x * win[e], -((float)raw[e].y * win[e]));   // Q negated (fft1.c:432-447)
+    float2 fc[P];
+    constexpr int EARLY = P / 4;
+    FftF::run(x, lds, tid, [&]() {
+#pragma unroll
+      for (int e = 0; e < EARLY; e++) fc[e] = (a.filtercorr + jof(e) * T)[(unsigned int)tid];
+    });
+#pragma unroll
+    for (int e = EARLY; e < P; e++) fc[e] = (a.filtercorr + jof(e) * T)[(unsigned int)tid];
+#pragma unroll
+    for (int e = 0; e < P; e++) x[e] = cmul(x[e], fc[e]);
+  };
+  auto weak_bit = [&](const unsigned int (&wk)[NB0], int e) { const int J = jof(e); return (wk[J % NB0] >> (J / NB0)) & 1u; };
+  const float sg = (tid0 & 1) ? -1.f : 1.f;              // (-1)^bin: every register of a thread holds bins of the thread's parity
+  float2 pw[P];                                          // weak part of the previous transform, back-transform register order
+  float acc[P];
+#pragma unroll
+  for (int e = 0; e < P; e++) { pw[e] = make_float2(0.f, 0.f); acc[e] = 0.f; }
+  __syncthreads();                                       // twiddle tables are in place
+  if (r0 > 0 || a.have_prev) {
+    fetch(r0 - 1, tid0);
+    float2 x[P];
+    forward(x, tid0);
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      const int J = jof(e);
+      const bool weak = r0 > 0 ? weak_bit(wk_cur, e) : weak_bit(wk_first, e);   // routed with the table in force for that transform
+      pw[(J % NB0) * R0 + J / NB0] = weak ? x[e] : make_float2(0.f, 0.f);
+    }
+  }
+  fetch(r0, tid0);
+#pragma unroll 1
+  for (int b = r0; b < r1; b++) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                        // keep index math inside the loop (see k_timf2)
+    float2 x[P];
+    forward(x, tid);
+    // fft1_c: sum |X|^2 over the averaging group (fft1.c:4115-4171), same additions in the same order as k_timf2<.., SS>
+#pragma unroll
+    for (int e = 0; e < P; e++) acc[e] += x[e].x * x[e].x + x[e].y * x[e].y;
+    {
+      const int gb = b + a.ss_c0, g = gb / a.ss_avg;
+      const bool group_end = gb - g * a.ss_avg == a.ss_avg - 1;
+      if (group_end || b == r1 - 1) {
+        const bool head = g * a.ss_avg - a.ss_c0 < r0;   // began in an earlier run (or an earlier call)
+        float *dst = (!head && group_end) ? a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask) : a.ss_part + (size_t)(2 * blockIdx.x + (head ? 0 : 1)) * N;
+#pragma unroll
+        for (int e = 0; e < P; e++) { (dst + jof(e) * T)[(unsigned int)tid] = acc[e]; acc[e] = 0.f; }
+      }
+    }
+    // the spectrum ring: every bin when somebody reads fft1_float, else the strong bins the second pass needs
+    {
+      float2 *out = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+#pragma unroll
+      for (int e = 0; e < P; e++)
+        if (a.keep_spec || !weak_bit(wk_cur, e)) store_stream(&(out + jof(e) * T)[(unsigned int)tid], x[e]);
+    }
+    // weak stream: S_t + (-1)^k S_{t-1}, both routed with their own tables (k_timf2)
+    float2 c[P];
+#pragma unroll
+    for (int e = 0; e < P; e++) {
+      const int J = jof(e), ei = (J % NB0) * R0 + J / NB0;
+      const float2 v = weak_bit(wk_cur, e) ? x[e] : make_float2(0.f, 0.f);
+      c[ei] = make_float2(v.x + sg * pw[ei].x, v.y + sg * pw[ei].y);
+      pw[ei] = v;
+    }
+    FftB::run(c, lds, tid);
+#pragma unroll
+    for (int e = 0; e < P; e++)
+      if ((e % RL) < RL / 2) asm volatile("" : "+v"(c[e].x), "+v"(c[e].y));      // outputs pinned ahead of the prefetch (k_timf2)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(min(b + 1, r1 - 1), tid);                      // unconditional: the last trip re-reads its own samples
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const size_t base = (size_t)((a.pa_first + b * a.step) & a.mask);
+      typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int m = 0; m < NBL; m++)
+#pragma unroll
+        for (int q = 0; q < RL / 2; q++) {               // first half only: the second half is the next transform's partner
+          const float2 v = c[m * RL + q];
+          const v2f o = { a.ampfac * v.x, a.ampfac * v.y };
+          const size_t at = base + m * T + q * (N / RL);
+          __builtin_nontemporal_store(o, reinterpret_cast<v2f *>(a.timf2w + at) + (unsigned int)tid);
+          __builtin_nontemporal_store(o.x * o.x + o.y * o.y, (a.pwr + at) + (unsigned int)tid);
+        }
+    }
   }
 }
 
@@ -1606,12 +1769,12 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   }
 
 #define LRH_LAUNCH_FFT1_V(L, DW, SK, a, batch, st) \
-  hipLaunchKernelGGL((k_fft1<L, DW, SK>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a)
+  hipLaunchKernelGGL((k_fft1<L, DW, SK>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a)
 #define LRH_LAUNCH_FFT1(L, a, batch, st)                                                    \
   do {                                                                                      \
     const bool sk = a.shift_i != 0 || a.shift_q != 0;                                       \
-    if (a.real && !a.dword) hipLaunchKernelGGL((k_fft1<L, false, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
-    else if (a.real) hipLaunchKernelGGL((k_fft1<L, true, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
+    if (a.real && !a.dword) hipLaunchKernelGGL((k_fft1<L, false, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a); \
+    else if (a.real) hipLaunchKernelGGL((k_fft1<L, true, false, true>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a); \
     else if (!a.dword && !sk) LRH_LAUNCH_FFT1_V(L, false, false, a, batch, st);                  \
     else if (!a.dword) LRH_LAUNCH_FFT1_V(L, false, true, a, batch, st);                     \
     else if (!sk) LRH_LAUNCH_FFT1_V(L, true, false, a, batch, st);                          \
@@ -1621,11 +1784,11 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   do {                                                                                                      \
     if (a.ss_ring) {                                                                                        \
       a.ss_run = (batch + fftl_grid<L>(batch, a.spare_cus) - 1) / fftl_grid<L>(batch, a.spare_cus);                                   \
-      hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3((batch + a.ss_run - 1) / a.ss_run), dim3(fft_threads(L)), 0, st, a); \
+      hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3((batch + a.ss_run - 1) / a.ss_run), dim3(fft1_threads(L)), 0, st, a); \
     }                                                                                                       \
-    else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a);      \
-    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a); \
-    else hipLaunchKernelGGL((k_timf2<L, 2, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft_threads(L)), 0, st, a);                  \
+    else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a);      \
+    else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a); \
+    else hipLaunchKernelGGL((k_timf2<L, 2, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a);                  \
   } while (0)
 #define LRH_LAUNCH_FFT2(L, a, batch, st)                                                                              \
   do {                                                                                                                \
@@ -1651,7 +1814,7 @@ static int persistent_grid(int lds_bytes, int threads, int batch, int spare_cus 
   const int g = (256 - (per_cu == 1 ? spare_cus : 0)) * per_cu;
   return batch < g ? batch : g;
 }
-template <int L> static int fftl_grid(int batch, int spare_cus = 0) { return persistent_grid(8 * BlockFftL<L, points_per_thread(L), 1>::LDS_CELLS, fft_threads(L), batch, spare_cus); }
+template <int L> static int fftl_grid(int batch, int spare_cus = 0) { return persistent_grid(8 * BlockFftL<L, points_fft1(L), 1>::LDS_CELLS, fft1_threads(L), batch, spare_cus); }
 
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st)
 {
@@ -1681,6 +1844,22 @@ hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t s
   }
   LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
   if (ss && ss_run) *ss_run = a.ss_run;
+  return hipGetLastError();
+}
+// k_fft1w + the strong-only pass of k_timf2 (fft1_size 16384): `run` out = transforms per workgroup (for k_sumsq_join)
+hipError_t launch_fft1w(const Fft1wArgs &a0, hipStream_t st, int *run)
+{
+  Fft1wArgs a = a0;
+  const int grid = persistent_grid(8 * BlockFftL<14, 32, 1>::LDS_CELLS, 512, a.batch, a.spare_cus);
+  a.run = (a.batch + grid - 1) / grid;
+  if (run) *run = a.run;
+  hipLaunchKernelGGL((k_fft1w<14>), dim3((a.batch + a.run - 1) / a.run), dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_timf2_strong(const Timf2Args &a0, int batch, hipStream_t st)
+{
+  Timf2Args a = a0; a.batch = batch; a.ss_ring = nullptr;
+  hipLaunchKernelGGL((k_timf2<14, 1, false, true>), dim3(fftl_grid<14>(batch, a.spare_cus)), dim3(fft1_threads(14)), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_sumsq_join(const SumsqArgs &a, const float *part, int run, hipStream_t st)
@@ -2956,157 +3135,45 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
 // =====================================================================================================
 // spur subtraction (eliminate_spurs, spur.c:36-494; one RF channel, float spectra)
 // =====================================================================================================
-// A spur is a few bins and a phase-locked loop over the last spur_speknum transforms: tiny data, serial in the transform index
-// (the loop state after transform t feeds transform t+1).  One lane per spur walks the batch's transforms in order; the spurs run
-// side by side.  The arithmetic follows the reference statement by statement where rounding feeds back into the loop (float
-// accumulators, sin / cos / atan2 / sqrt evaluated in double like its libm calls).
+// A tracked spur is a phase-locked loop over the newest n = spur_speknum transforms of its seven bins: per transform the new
+// bins are projected on the line shape of the predicted frequency, the loop re-estimates phase / frequency / drift / amplitude
+// from the whole history, and amplitude x line shape at the predicted phase leaves the new transform.  Only the order of the
+// transforms is serial (the state after transform t feeds t + 1).  One WAVE per spur: lane m works on the history entry of age
+// m (ring slot na - m; n > 64: lanes take m, m + 64, ...).  What the reference does with running rotations and running sums over
+// the history is closed form per lane here (the oscillator's angle at age m is a quadratic in m, the smoothing a centred window,
+// the phase track a wave scan), and every sum over the history is a wave reduction; threshold decisions see the same quantities
+// to float32 rounding (goldens: loop state after every transform, spectra to 1e-5).
 namespace lrh {
 struct DevSpur { int location, flag; float freq, d0pha, d1pha, d2pha, ampl, noise, avgd2; };   // = lrh_spur
 #define LRH_PI 3.1415926535897932
 
-struct SpurLoop {
-  const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; float *sig, *der, *pha, *tmp;
-  float sp_d0, sp_d1, sp_d2;
-  int maxn, mask;
+__device__ __forceinline__ float wsum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__device__ __forceinline__ float2 wsum2(float2 v) { return make_float2(wsum(v.x), wsum(v.y)); }
+__device__ __forceinline__ float2 rot(float2 z, double ang)          // z e^{j ang}
+{
+  double sn, cs; sincos(ang, &sn, &cs);
+  const float c = (float)cs, s_ = (float)sn;
+  return make_float2(c * z.x - s_ * z.y, c * z.y + s_ * z.x);
+}
+__device__ __forceinline__ float2 unit_of(float2 z, float floor_)    // z / |z|, zero below the floor
+{
+  const float r = (float)sqrt((double)(z.x * z.x + z.y * z.y));
+  return r > floor_ ? make_float2(z.x / r, z.y / r) : make_float2(0.f, 0.f);
+}
+__device__ __forceinline__ float2 mulc(float2 a_, float2 b) { return make_float2(a_.x * b.x + a_.y * b.y, a_.y * b.x - a_.x * b.y); }   // a conj(b)
 
-  __device__ void lowpass(const float *zin, float *zout, int nn, int siz) const {          // complex_lowpass, spursub.c:1020-1068
-    int avgnum = nn | 1;
-    if (avgnum > nn && avgnum > siz / 4) avgnum -= 2;
-    if (avgnum < 1) return;
-    float t1 = 0, t2 = 0; const float t3 = (float)(1.0 / avgnum);
-    for (int i = 0; i < avgnum; i++) { t1 += zin[2 * i]; t2 += zin[2 * i + 1]; }
-    int j = 1 + avgnum / 2;
-    for (int i = 0; i < j; i++) { zout[2 * i] = t1 * t3; zout[2 * i + 1] = t2 * t3; }
-    for (int i = 0, k = avgnum; k < siz; i++, j++, k++) {
-      t1 += zin[2 * k] - zin[2 * i]; t2 += zin[2 * k + 1] - zin[2 * i + 1];
-      zout[2 * j] = t3 * t1; zout[2 * j + 1] = t3 * t2;
-    }
-    t1 *= t3; t2 *= t3;
-    for (; j < siz; j++) { zout[2 * j] = t1; zout[2 * j + 1] = t2; }
-  }
+// working set of one spur in LDS: h = history de-rotated by the loop's oscillator (index 0 oldest .. n-1 newest), d / g = step between
+// neighbours and its smoothed form (n - 1 values), t = phase track (n values), then scratch for the fits
+struct SpurWork { float2 *h, *d, *g; float *t; };
 
-  __device__ void phase_parameters() {                                                     // spur_phase_parameters, spur.c:1427-1652
-    const int n = a.speknum, ns = a.numsub, av = a.avgnum;
-    float t1, t2, t3, r1, r2, a1, a2, b1, b2, d1, d2;
-    for (int i = 1; i < n; i++) {                        // phase steps between neighbouring transforms, amplitude divided out
-      t1 = sig[2 * i] * sig[2 * i - 2] + sig[2 * i + 1] * sig[2 * i - 1];
-      t2 = sig[2 * i + 1] * sig[2 * i - 2] - sig[2 * i] * sig[2 * i - 1];
-      r1 = (float)sqrt((double)(t1 * t1 + t2 * t2));
-      if (r1 > 0.000000001) { der[2 * i - 2] = t1 / r1; der[2 * i - 1] = t2 / r1; } else { der[2 * i - 2] = 0; der[2 * i - 1] = 0; }
-    }
-    lowpass(der, tmp, av, ns);
-    r1 = 0; r2 = 0;
-    for (int i = 1 + av / 2; i < ns - av / 2; i++) {     // second difference, again as a cross product
-      t1 = tmp[2 * i] * tmp[2 * i - 2] + tmp[2 * i + 1] * tmp[2 * i - 1];
-      t2 = tmp[2 * i + 1] * tmp[2 * i - 2] - tmp[2 * i] * tmp[2 * i - 1];
-      t3 = (float)sqrt((double)(t1 * t1 + t2 * t2));
-      if (t3 > 0.00001) { r1 += t1 / t3; r2 += t2 / t3; }
-    }
-    sp_d2 = (float)atan2((double)r2, (double)r1);
-    t1 = q.d2pha + sp_d2;
-    if (fabs((double)t1) > a.max_d2 && fabs((double)sp_d2) > a.max_d2) sp_d2 = -q.d2pha / n;
-    else {
-      t1 = a.weiold * q.avgd2 + a.weinew * t1;
-      if (q.noise > 0.000001 && fabs((double)q.ampl) > 0.000001) { t2 = (float)(0.1 * fabs((double)q.ampl) / q.noise); t2 = 1 / (1 + t2); } else t2 = 1;
-      sp_d2 = t2 * (t1 - q.d2pha) + (1 - t2) * sp_d2;
-    }
-    for (int i = 0; i < ns; i++) pha[i] = (float)atan2((double)tmp[2 * i + 1], (double)tmp[2 * i]);
-    { float c = 0;                                        // remove_phasejumps, spursub.c:996-1017
-      for (int i = 1; i < ns; i++) {
-        pha[i] += c;
-        if (pha[i] - pha[i - 1] > LRH_PI) { pha[i] -= (float)(2 * LRH_PI); c -= (float)(2 * LRH_PI); }
-        if (pha[i] - pha[i - 1] < -LRH_PI) { pha[i] += (float)(2 * LRH_PI); c += (float)(2 * LRH_PI); }
-      } }
-    pha[ns] = 0;
-    for (int i = ns; i > 0; i--) pha[i - 1] = pha[i] - pha[i - 1];
-    t1 = (float)(sp_d2 * 0.5);
-    for (int i = 2; i < n; i++) pha[ns - i] -= i * (i - 1) * t1;
-    int na_ = n - av;
-    if (na_ < 10) na_ = n - av / 2;
-    if (na_ < 3) na_ = n;
-    { const float *z = &pha[n - na_]; const int k = na_ / 2; t2 = 0; t3 = 0;             // average_slope, spursub.c:975-992
-      for (int i = 0; i < k; i++) { t2 += z[i]; t3 += z[k + i]; }
-      sp_d1 = (t3 - t2) / (k * k); }
-    b1 = (float)cos((double)sp_d1); b2 = (float)sin((double)sp_d1);
-    a1 = b1; a2 = b2;
-    d1 = (float)cos((double)sp_d2); d2 = (float)sin((double)sp_d2);
-    t1 = 0; t2 = 0;
-    for (int i = ns; i >= 0; i--) {                      // local oscillator with the derivatives found: what is left is the phase offset
-      r1 = a1 * sig[2 * i] + a2 * sig[2 * i + 1];
-      r2 = a1 * sig[2 * i + 1] - a2 * sig[2 * i];
-      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
-      t3 = (float)sqrt((double)(r1 * r1 + r2 * r2));
-      if (t3 > 0) { t1 += r1 / t3; t2 += r2 / t3; }
-      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
-      r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
-    }
-    sp_d0 = (float)atan2((double)t2, (double)t1);
-    t3 = (float)sqrt((double)(t1 * t1 + t2 * t2));
-    t1 /= t3; t2 /= t3;
-    a1 = 0; a2 = 0;
-    d1 = (float)(-0.5 * ns);
-    for (int i = 0; i < n; i++) {                        // straight-line fit of the residual phase: correction to the frequency
-      r1 = t1 * tmp[2 * i] + t2 * tmp[2 * i + 1];
-      r2 = t1 * tmp[2 * i + 1] - t2 * tmp[2 * i];
-      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
-      a1 += r1;
-      if (r1 > 0 && fabs((double)r2) < fabs((double)r1)) a2 += (float)(d1 * r2 / fabs((double)r1));
-      else a2 += (float)(d1 * atan2((double)r2, (double)r1));
-      d1 += 1;
-    }
-    a2 /= a.linefit;
-    sp_d1 += a2;
-    d2 = (float)(-0.5 * ns * a2);
-    b1 = (float)cos((double)a2); b2 = (float)-sin((double)a2);
-    a1 = (float)cos((double)d2); a2 = (float)sin((double)d2);
-    t1 = 0;
-    for (int i = 0; i < n; i++) {
-      r1 = a1 * tmp[2 * i] - a2 * tmp[2 * i + 1];
-      r2 = a1 * tmp[2 * i + 1] + a2 * tmp[2 * i];
-      tmp[2 * i] = r1; tmp[2 * i + 1] = r2;
-      t1 += r1;
-      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
-    }
-    t1 /= n;
-    q.ampl = t1;                                          // amplitude = mean of the in-phase part, noise = rms of the rest
-    t2 = 0;
-    for (int i = 0; i < n; i++) t2 += (tmp[2 * i] - t1) * (tmp[2 * i] - t1) + tmp[2 * i + 1] * tmp[2 * i + 1];
-    q.noise = (float)sqrt((double)(t2 / n));
-  }
+struct SpurWave {
+  const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; SpurWork w; const int lane, n, maxn, mask;
 
-  __device__ void refine(int na) {                                                          // refine_pll_parameters, spur.c:634-680
-    float phase = q.d0pha, slope = q.d1pha, curv = q.d2pha, r1;
-    slope += curv; phase += slope;
-    float a1 = (float)cos((double)phase), a2 = (float)sin((double)phase), b1 = (float)cos((double)slope), b2 = (float)sin((double)slope);
-    const float d1 = (float)cos((double)curv), d2 = (float)sin((double)curv);
-    int ni = na;
-    for (int i = a.speknum - 1; i >= 0; i--) {           // history de-rotated with the loop's own oscillator, newest last
-      sig[2 * i] = a1 * zsig[2 * ni] + a2 * zsig[2 * ni + 1];
-      sig[2 * i + 1] = a1 * zsig[2 * ni + 1] - a2 * zsig[2 * ni];
-      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
-      r1 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r1;
-      ni = (ni + mask) & mask;
-    }
-    phase_parameters();
-    phase += sp_d0; slope += sp_d1; curv += sp_d2;
-    phase -= slope; slope -= curv;
-    q.d0pha = phase; q.d1pha = slope; q.d2pha = curv;
-  }
-
-  __device__ void shift_table(int j, int na) {                                              // shift_spur_table, spursub.c:1070-1246
-    const int nj = (na + 1) & mask, shift = j < 0 ? -1 : 1;
-    q.location += shift;
-    if (q.location < 7) { q.flag = 1; q.location = 14; return; }
-    if (q.location > a.n2 - 7) { q.flag = 1; q.location = a.n2 - 14; return; }
-    for (int ni = (na - a.speknum + maxn) & mask; ni != nj; ni = (ni + 1) & mask) {
-      float *t = tab + ni * 14;
-      if (shift == 1) { for (int i = 1; i < 7; i++) { t[2 * i - 2] = t[2 * i]; t[2 * i - 1] = t[2 * i + 1]; } t[12] = 0; t[13] = 0; }
-      else { for (int i = 6; i > 0; i--) { t[2 * i] = t[2 * i - 2]; t[2 * i + 1] = t[2 * i - 1]; } t[0] = 0; t[1] = 0; }
-    }
-  }
-
-  // line shape for a frequency: index into spectra, j (second return) = 0/1 sub-position; < 0: the spur left its window (raw j returned)
-  __device__ static int shape(float freq, int loc, int &j) {
+  __device__ int slot(int na, int age) const { return (na - age) & mask; }
+  // line shape for a frequency: offset into the table of shapes and the half-bin position j (0 / 1); -1 when the carrier has left the
+  // window of seven bins (then j tells which way, raw)
+  __device__ static int shape(float freq, int loc, int &j)
+  {
     j = (int)(freq) + 2 - loc - 4;
     if (j < 0 || j > 1) return -1;
     j = 1 - j;
@@ -3114,121 +3181,310 @@ struct SpurLoop {
     if (ind == 256) ind = 255;
     return ind * 8 + j;
   }
-  // keep the spur inside its window, shifting the history when it has moved by one bin; false: lock lost
-  __device__ bool centre(float freq, int na, int &ind, int &j) {
+  // the bin frequency the loop's phase slope stands for: the fractional part comes from the slope, the integer part stays nearest to `near`
+  __device__ float freq_of(float slope, float near) const
+  {
+    float r = (float)(-0.5 * slope / LRH_PI);
+    const int i = (int)(near * a.freq_factor - r + 0.5);
+    r += i;
+    return r / a.freq_factor;
+  }
+  // seven bins x line shape, sign by the parity of window position and sub-position
+  __device__ float2 project(const float *bins, int ind, int j) const
+  {
+    float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { const float sh = a.spectra[ind + i]; p.x += bins[2 * i] * sh; p.y += bins[2 * i + 1] * sh; }
+    if ((j ^ (q.location & 1)) == 1) { p.x = -p.x; p.y = -p.y; }
+    return p;
+  }
+  // the window of seven bins moves by one bin: every history row follows (shift_spur_table's job); false: the spur ran off the spectrum
+  __device__ bool move_window(int dir, int na)
+  {
+    q.location += dir;
+    if (q.location < 7) { q.flag = 1; q.location = 14; return false; }
+    if (q.location > a.n2 - 7) { q.flag = 1; q.location = a.n2 - 14; return false; }
+    for (int m = lane; m <= n; m += 64) {                  // ages 0 .. n: the n history rows and the one about to leave it
+      float *r = tab + slot(na, m) * 14;
+      float v[14];
+#pragma unroll
+      for (int i = 0; i < 14; i++) v[i] = r[i];
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const int src = i + dir;
+        r[2 * i] = (src >= 0 && src < 7) ? v[2 * src] : 0.f; r[2 * i + 1] = (src >= 0 && src < 7) ? v[2 * src + 1] : 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+  }
+  __device__ bool centre(float freq, int na, int &ind, int &j)
+  {
     for (;;) {
       ind = shape(freq, q.location, j);
       if (ind >= 0) return true;
       if (j < -1 || j > 2) { q.flag = 1; return false; }
-      shift_table(j, na);
-      if (q.flag) return false;
+      if (!move_window(j < 0 ? -1 : 1, na)) return false;
     }
   }
 
-  __device__ void transform(int na) {                                                       // eliminate_spurs, one spur, one transform
-    const float ff = a.freq_factor;
-    float2 *z = a.fft2 + (size_t)na * a.n2;
-    float *spt = tab + na * 14;
-    int i, j, k, ind;
-    if (q.flag == 1) {
-      j = (int)(q.freq) + 2 - q.location - 4;
-      if (j < 0 || j > 1) { if (j < -1) j = -1; if (j > 2) j = 2; shift_table(j, na); }
+  // one look at the history through the loop's oscillator: corrections (c0, c1, c2) to phase, slope and curvature; amplitude and noise
+  __device__ void estimate(int na, float &c0, float &c1, float &c2)
+  {
+    const int ns = n - 1, av = a.avgnum;
+    const double ph0 = (double)(float)(q.d0pha + (float)(q.d1pha + q.d2pha)), sl0 = (double)(float)(q.d1pha + q.d2pha), cv0 = (double)q.d2pha;
+    // history seen from the oscillator: age m is turned back by phase - m slope + m (m - 1) / 2 curvature
+    for (int m = lane; m < n; m += 64) {
+      const float2 z = make_float2(zsig[2 * slot(na, m)], zsig[2 * slot(na, m) + 1]);
+      w.h[ns - m] = rot(z, -(ph0 - m * sl0 + 0.5 * m * (m - 1) * cv0));
     }
-    if (q.flag != 0) {                                   // unlocked: history and counting only (re-lock is the control plane's)
-      for (i = 0; i < 7; i++) { const float2 v = z[q.location + i]; spt[2 * i] = v.x; spt[2 * i + 1] = v.y; }
+    __builtin_amdgcn_wave_barrier();
+    // step from each entry to the next, amplitude divided out
+    for (int i = lane; i < ns; i += 64) w.d[i] = unit_of(mulc(w.h[i + 1], w.h[i]), 0.000000001f);
+    __builtin_amdgcn_wave_barrier();
+    // centred window mean, the ends held (window: av made odd, shrunk by two when that would exceed av and a quarter of the history)
+    int wd = av | 1;
+    if (wd > av && wd > ns / 4) wd -= 2;
+    if (wd >= 1) {
+      const int hw = wd / 2; const float inv = (float)(1.0 / wd);
+      for (int i = lane; i < ns; i += 64) {
+        const int cidx = min(max(i, hw), ns - 1 - hw);
+        float2 sacc = make_float2(0.f, 0.f);
+        for (int k = cidx - hw; k <= cidx + hw; k++) { sacc.x += w.d[k].x; sacc.y += w.d[k].y; }
+        w.g[i] = make_float2(sacc.x * inv, sacc.y * inv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // curvature: mean direction of the change of the smoothed step
+    float2 bend = make_float2(0.f, 0.f);
+    for (int i = 1 + av / 2 + lane; i < ns - av / 2; i += 64) { const float2 u = unit_of(mulc(w.g[i], w.g[i - 1]), 0.00001f); bend.x += u.x; bend.y += u.y; }
+    bend = wsum2(bend);
+    c2 = (float)atan2((double)bend.y, (double)bend.x);
+    {
+      float tot = q.d2pha + c2;
+      if (fabs((double)tot) > a.max_d2 && fabs((double)c2) > a.max_d2) c2 = -q.d2pha / n;    // implausible: pull the drift back instead
+      else {
+        tot = a.weiold * q.avgd2 + a.weinew * tot;
+        float trust = 1.f;                                // strong spurs follow the averaged drift, weak ones the new estimate
+        if (q.noise > 0.000001 && fabs((double)q.ampl) > 0.000001) { trust = (float)(0.1 * fabs((double)q.ampl) / q.noise); trust = 1 / (1 + trust); }
+        c2 = trust * (tot - q.d2pha) + (1 - trust) * c2;
+      }
+    }
+    // phase track relative to the newest entry: unwrapped step angles summed from the new end, the curvature just found taken out
+    for (int base = 0, carry = 0; base < ns; base += 64) {              // unwrap: running count of 2 pi jumps between neighbours
+      const int i = base + lane;
+      const float cur = i < ns ? (float)atan2((double)w.g[i].y, (double)w.g[i].x) : 0.f;
+      float prev = __shfl_up(cur, 1, 64);
+      if (lane == 0) prev = base ? w.t[ns] : cur;                        // w.t[ns]: last raw angle of the previous chunk (parked below)
+      int jump = 0;
+      if (i < ns && i > 0) { if (cur - prev > LRH_PI) jump = -1; else if (cur - prev < -LRH_PI) jump = 1; }
+      int incl = jump;
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+      if (i < ns) w.t[i] = cur + (float)(2 * LRH_PI) * (float)(carry + incl);
+      carry += __shfl(incl, 63, 64);
+      const float last_raw = __shfl(cur, 63, 64);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) w.t[ns] = last_raw;
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    {                                                                     // suffix sums from the new end: track[k] = -sum_{m >= k} step[m]
+      float carry = 0.f;
+      const int nchunk = (ns + 63) / 64;
+      for (int ch = 0; ch < nchunk; ch++) {
+        const int i = ns - 1 - (ch * 64 + lane);                          // lane 0 takes the newest
+        const float v = i >= 0 ? w.t[i] : 0.f;
+        float incl = v;
+        for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+        const float tot = __shfl(incl, 63, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (i >= 0) { const int age = ns - i; w.t[i] = -(carry + incl) - (age >= 2 ? age * (age - 1) * (float)(c2 * 0.5) : 0.f); }
+        carry += tot;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // slope: difference of the means of the two halves of the newer part of the track
+    int len = n - av;
+    if (len < 10) len = n - av / 2;
+    if (len < 3) len = n;
+    {
+      const int k = len / 2, first = n - len;                             // track index n - 1 is the newest entry (value 0)
+      float lo = 0.f, hi = 0.f;
+      for (int i = lane; i < k; i += 64) { lo += (first + i < ns ? w.t[first + i] : 0.f); hi += (first + k + i < ns ? w.t[first + k + i] : 0.f); }
+      c1 = (wsum(hi) - wsum(lo)) / (k * k);
+    }
+    // what is left after slope and curvature is the phase offset: mean direction of the history turned by them
+    float2 dir = make_float2(0.f, 0.f);
+    for (int m = lane; m < n; m += 64) {
+      const int i = ns - m;
+      const float2 r = rot(w.h[i], -((1.0 - m) * (double)c1 + 0.5 * m * (m - 1) * (double)c2));
+      w.g[i] = r;                                                          // (the smoothed steps are done with; n slots)
+      const float2 u = unit_of(r, 0.f);
+      dir.x += u.x; dir.y += u.y;
+    }
+    dir = wsum2(dir);
+    c0 = (float)atan2((double)dir.y, (double)dir.x);
+    { const float nrm = (float)sqrt((double)(dir.x * dir.x + dir.y * dir.y)); dir.x /= nrm; dir.y /= nrm; }
+    __builtin_amdgcn_wave_barrier();
+    // straight-line fit of the residual phase across the history: a last correction of the slope
+    float fit = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float2 r = mulc(w.g[i], dir);
+      w.g[i] = r;
+      const float x = (float)(-0.5 * ns) + i;
+      if (r.x > 0 && fabs((double)r.y) < fabs((double)r.x)) fit += (float)(x * r.y / fabs((double)r.x));
+      else fit += (float)(x * atan2((double)r.y, (double)r.x));
+    }
+    const float tilt = wsum(fit) / a.linefit;
+    c1 += tilt;
+    __builtin_amdgcn_wave_barrier();
+    // amplitude = mean in-phase part with the tilt removed, noise = rms of what remains
+    float inph = 0.f;
+    for (int i = lane; i < n; i += 64) { const float2 r = rot(w.g[i], ((double)i - 0.5 * ns) * (double)tilt); w.g[i] = r; inph += r.x; }
+    const float ampl = wsum(inph) / n;
+    __builtin_amdgcn_wave_barrier();
+    float res = 0.f;
+    for (int i = lane; i < n; i += 64) { const float2 r = w.g[i]; res += (r.x - ampl) * (r.x - ampl) + r.y * r.y; }
+    q.ampl = ampl;
+    q.noise = (float)sqrt((double)(wsum(res) / n));
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the loop takes the corrections: they were found against the oscillator one step ahead
+  __device__ void refine(int na)
+  {
+    float c0, c1, c2;
+    float slope = q.d1pha + q.d2pha, phase = q.d0pha + slope, curv = q.d2pha;
+    estimate(na, c0, c1, c2);
+    phase += c0; slope += c1; curv += c2;
+    phase -= slope; slope -= curv;
+    q.d0pha = phase; q.d1pha = slope; q.d2pha = curv;
+  }
+
+  // one transform of a locked spur
+  __device__ void track(int na)
+  {
+    float2 *z = a.fft2 + (size_t)na * a.n2;
+    float *row = tab + na * 14;
+    int ind, j;
+    if (q.flag == 1) {                                   // unlocked a moment ago: keep the window on the last known frequency
+      j = (int)(q.freq) + 2 - q.location - 4;
+      if (j < 0 || j > 1) move_window(j < 0 ? -1 : 1, na);
+    }
+    if (q.flag != 0) {                                   // not locked: the history goes on, re-locking is the control plane's business
+      if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; }
       q.flag++;
-      if (q.flag > 1000000) q.flag -= 2 * 3 * 5 * 7 * a.speknum;
+      if (q.flag > 1000000) q.flag -= 2 * 3 * 5 * 7 * n;
+      __builtin_amdgcn_wave_barrier();
       return;
     }
-    float slope = q.d1pha + q.d2pha, curv, phase, r1, r2, freq;
-    float rot = (float)(-0.5 * slope / LRH_PI);
-    i = (int)(q.freq * ff - rot + 0.5);
-    rot += i;
-    freq = rot / ff;
-    q.freq = freq;
-    if (!centre(freq, na, ind, j)) return;
-    uind[na] = ind;
-    r1 = 0; r2 = 0;
-    for (i = 0; i < 7; i++) {                            // the new bins join the history; their projection on the line shape joins spur_signal
-      const float2 v = z[q.location + i];
-      spt[2 * i] = v.x; r1 += v.x * a.spectra[ind + i];
-      spt[2 * i + 1] = v.y; r2 += v.y * a.spectra[ind + i];
-    }
-    if ((j ^ (q.location & 1)) == 1) { r1 = -r1; r2 = -r2; }
-    zsig[2 * na] = r1; zsig[2 * na + 1] = r2;
-    int iter = 0, diffind;
-    freq = q.freq;
-    for (;;) {
-      iter++;
+    q.freq = freq_of(q.d1pha + q.d2pha, q.freq);
+    if (!centre(q.freq, na, ind, j)) return;
+    if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { uind[na] = ind; const float2 pr = project(row, ind, j); zsig[2 * na] = pr.x; zsig[2 * na + 1] = pr.y; }
+    __builtin_amdgcn_wave_barrier();
+    int moved = 0;
+    for (int iter = 1;; iter++) {
       refine(na);
-      slope = q.d1pha; curv = q.d2pha;
-      slope += curv;
-      const int nx = (na - a.speknum + mask) & mask;
-      diffind = 0;
+      // with the refined loop each history entry may belong to another line shape: frequency per age from the slope at that age
+      // (integer part carried along from entry to entry), projection redone where the shape changed
+      moved = 0;
       bool left = false;
-      for (int ni = na; ni != nx; ni = (ni + mask) & mask) {   // with the refined oscillator the history may project on other line shapes
-        rot = (float)(-0.5 * slope / LRH_PI);
-        i = (int)(freq * ff - rot + 0.5);
-        rot += i;
-        freq = rot / ff;
-        ind = shape(freq, q.location, j);
-        if (ind < 0) { left = true; break; }
-        k = (uind[ni] - ind + 2048) & 2047;
-        if (k > 1024) k = 2048 - k;
-        if (k > diffind) diffind = k;
-        uind[ni] = ind;
-        if (k != 0) {
-          const float *t = tab + ni * 14;
-          r1 = 0; r2 = 0;
-          for (i = 0; i < 7; i++) { r1 += t[2 * i] * a.spectra[ind + i]; r2 += t[2 * i + 1] * a.spectra[ind + i]; }
-          if ((j ^ (q.location & 1)) == 1) { r1 = -r1; r2 = -r2; }
-          zsig[2 * ni] = r1; zsig[2 * ni + 1] = r2;
+      float fq_near = q.freq;
+      for (int base = 0; base < n; base += 64) {
+        const int m = base + lane;
+        const float sl = (q.d1pha + q.d2pha) - m * q.d2pha;
+        // fractional part from this age's slope; integer part: nearest to the previous age's frequency, which changes by far less than a bin
+        float fq = freq_of(sl, fq_near);
+        const float prev = __shfl_up(fq, 1, 64);
+        if (lane > 0) fq = freq_of(sl, prev);
+        int jj; const int id = m < n ? shape(fq, q.location, jj) : 0;
+        if (__any(m < n && id < 0)) { left = true; break; }
+        if (m < n) {
+          const int sidx = slot(na, m);
+          int k = (uind[sidx] - id + 2048) & 2047;
+          if (k > 1024) k = 2048 - k;
+          moved = max(moved, k);
+          uind[sidx] = id;
+          if (k != 0) { const float2 pr = project(tab + sidx * 14, id, jj); zsig[2 * sidx] = pr.x; zsig[2 * sidx + 1] = pr.y; }
         }
-        slope -= curv;
+        fq_near = __shfl(fq, 63, 64);
       }
-      if (left || !(diffind > 2.5 * 8 && iter < 5)) break;
+      for (int o = 32; o > 0; o >>= 1) moved = max(moved, __shfl_xor(moved, o, 64));
+      __builtin_amdgcn_wave_barrier();
+      if (left || !(moved > 20 && iter < 5)) break;
     }
-    if (diffind != 0) refine(na);
-    if (fabs((double)q.ampl) < a.minston * q.noise) { q.flag = 1; return; }
-    // the loop is settled: advance it by one transform and take the carrier out of the new bins
-    phase = q.d0pha; slope = q.d1pha; curv = q.d2pha;
-    const float ampl = q.ampl;
-    slope += curv; phase += slope;
-    q.d0pha = phase; q.d1pha = slope;
-    if (q.d0pha > LRH_PI) q.d0pha -= (float)(2 * LRH_PI);
-    if (q.d0pha < -LRH_PI) q.d0pha += (float)(2 * LRH_PI);
-    if (q.d1pha > LRH_PI) q.d1pha -= (float)(2 * LRH_PI);
-    if (q.d1pha < -LRH_PI) q.d1pha += (float)(2 * LRH_PI);
-    if (q.d2pha > LRH_PI) q.d2pha -= (float)(2 * LRH_PI);
-    if (q.d2pha < -LRH_PI) q.d2pha += (float)(2 * LRH_PI);
+    if (moved != 0) refine(na);
+    if (fabs((double)q.ampl) < a.minston * q.noise) { q.flag = 1; return; }      // lost in the noise
+    // settled: the loop moves on by one transform and the carrier leaves the new bins
+    const float curv = q.d2pha, ampl = q.ampl;
+    const float slope = q.d1pha + curv, phase = q.d0pha + slope;
+    auto wrap = [](float v) { if (v > LRH_PI) v -= (float)(2 * LRH_PI); if (v < -LRH_PI) v += (float)(2 * LRH_PI); return v; };
+    q.d0pha = wrap(phase); q.d1pha = wrap(slope); q.d2pha = wrap(q.d2pha);
     q.avgd2 = a.weiold * q.avgd2 + a.weinew * curv;
-    rot = (float)(-0.5 * slope / LRH_PI);
-    i = (int)(q.freq * ff - rot + 0.5);
-    rot += i;
-    freq = rot / ff;
-    q.freq = freq;
-    if (!centre(freq, na, ind, j)) return;
-    float t1 = (float)(cos((double)phase) * ampl), t2 = (float)(sin((double)phase) * ampl);
-    if ((j ^ (q.location & 1)) == 1) { t1 = (float)(-cos((double)phase) * ampl); t2 = (float)(-sin((double)phase) * ampl); }
-    for (i = 0; i < 7; i++) { float2 v = z[q.location + i]; v.x -= a.spectra[ind + i] * t1; v.y -= a.spectra[ind + i] * t2; z[q.location + i] = v; }
+    q.freq = freq_of(slope, q.freq);
+    if (!centre(q.freq, na, ind, j)) return;
+    float cr = (float)(cos((double)phase) * ampl), ci = (float)(sin((double)phase) * ampl);
+    if ((j ^ (q.location & 1)) == 1) { cr = (float)(-cos((double)phase) * ampl); ci = (float)(-sin((double)phase) * ampl); }
+    if (lane < 7) { float2 v = z[q.location + lane]; const float sh = a.spectra[ind + lane]; v.x -= sh * cr; v.y -= sh * ci; z[q.location + lane] = v; }
+    __builtin_amdgcn_wave_barrier();
   }
 };
 
 __global__ __launch_bounds__(64) void k_spur(SpurArgs a)
 {
-  const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= a.nspurs) return;
+  extern __shared__ float spur_lds[];
+  const int s = blockIdx.x, lane = threadIdx.x, n = a.speknum;
   const int maxn = a.na_mask + 1;
   DevSpur q = reinterpret_cast<DevSpur *>(a.spurs)[s];
-  float *scr = a.scratch + (size_t)s * 8 * (maxn + 8);
-  SpurLoop L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn,
-             scr, scr + 2 * (maxn + 8), scr + 4 * (maxn + 8), scr + 6 * (maxn + 8), 0.f, 0.f, 0.f, maxn, a.na_mask};
-  for (int b = 0; b < a.batch; b++) L.transform((a.first_na + b) & a.na_mask);
-  reinterpret_cast<DevSpur *>(a.spurs)[s] = q;
+  SpurWork w;
+  w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n);
+  SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask};
+  int lo = q.location, hi = q.location;
+  for (int b = 0; b < a.batch; b++) {
+    L.track((a.first_na + b) & a.na_mask);
+    lo = min(lo, q.location); hi = max(hi, q.location);
+    __threadfence_block();
+  }
+  if (lane == 0) {
+    reinterpret_cast<DevSpur *>(a.spurs)[s] = q;
+    if (a.touched) { a.touched[2 * s] = lo; a.touched[2 * s + 1] = hi + 7; }   // bins whose power sums k_spur_patch redoes
+  }
 }
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_spur, dim3((a.nspurs + 63) / 64), dim3(64), 0, st, a);
+  const size_t lds = (size_t)a.speknum * (3 * sizeof(float2) + sizeof(float)) + 16;
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_spur, dim3(a.nspurs), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+
+// The transform kernels have already summed |X|^2 over the waterfall groups (k_fft2<.., fused>, k_fft2_rows) when k_spur takes the
+// carriers out: the sums of the few bins it touched are redone here from the cleaned spectra, same group arithmetic and the same
+// additions in the same order as the transform kernels (k_powersum2's), so that the fused form stays in use with spurs tracked.
+__global__ __launch_bounds__(64) void k_spur_patch(SpurPatchArgs a)
+{
+  const int s = blockIdx.x, g = blockIdx.y;
+  const int lo = max(a.touched[2 * s], 0), hi = min(a.touched[2 * s + 1], a.n);
+  const int start = g == 0 ? 0 : g * a.avgnum - a.counter;
+  int count = a.avgnum - (g == 0 ? a.counter : 0);
+  const bool complete = count <= a.count - start;
+  if (!complete) count = a.count - start;
+  const bool accumulate = g == 0 && a.counter > 0;
+  for (int i = lo + threadIdx.x; i < hi; i += 64) {
+    float acc = accumulate ? a.powersum_in[i] : 0.f;
+    for (int b = 0; b < count; b++) {
+      const float2 v = a.fft2[(size_t)((a.first_na + start + b) & a.na_mask) * a.n + i];
+      const float pw = v.x * v.x + v.y * v.y;
+      acc = (b == 0 && !accumulate) ? pw : acc + pw;
+    }
+    if (complete) a.wf_scratch[(size_t)g * a.n + i] = acc;
+    if (g == (int)gridDim.y - 1) a.powersum_out[i] = acc;
+  }
+}
+hipError_t launch_spur_patch(const SpurPatchArgs &a, int nspurs, int ngroups, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_spur_patch, dim3(nspurs, ngroups), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 }  // namespace lrh

@@ -66,6 +66,22 @@ struct Timf2Args {
   int spare_cus;            // compute units left free for side-stream kernels (see persistent_grid)
 };
 
+// ---- fft1_b + fft1_c's sums + the weak stream of make_timf2 in one kernel (k_fft1w, fft1_size 16384) ----
+struct Fft1wArgs {
+  const void *timf1; int ring_mask, p0_first, step, chan_count, chan_index;   // as Fft1Args (int16 I/Q, no skew)
+  const float *window; const float2 *filtercorr, *tw;
+  float2 *spec; int first_nb, nb_mask;          // fft1 ring: strong bins, or every bin with keep_spec
+  int keep_spec;
+  const unsigned int *pack_cur, *pack_prev;     // as Timf2Args
+  float2 *timf2w; float *pwr; int pa_first, mask; float ampfac;
+  int have_prev;                                // 0: the stream starts with this launch (nothing to overlap the first transform with)
+  float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0;   // as Timf2Args (k_sumsq_join finishes split groups)
+  int batch, run;                               // run: consecutive transforms per workgroup (set by launch_fft1w)
+  int spare_cus;
+};
+hipError_t launch_fft1w(const Fft1wArgs &a, hipStream_t st, int *run);
+hipError_t launch_timf2_strong(const Timf2Args &a, int batch, hipStream_t st);
+
 // fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): one block no longer fits a workgroup's LDS, so
 // fft1 and timf2 take the four-step form of the large fft2 (column transforms, step twiddle, row transforms through an HBM scratch)
 struct Fft1BigArgs {
@@ -265,7 +281,13 @@ struct SpurArgs {
   const float *spectra;                                  // [256][8] reference line shapes
   void *spurs;                                           // lrh_spur [nspurs]
   float *table, *signal; int *ind;                       // per spur: [maxn][7][2], [maxn][2], [maxn]
-  float *scratch;                                        // per spur 4 x 2 (maxn + 8) floats: sp_sig, sp_der, sp_pha, sp_tmp
+  int *touched;                                          // per spur [2]: first and one-past-last fft2 bin the batch's subtractions touched
 };
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
+// power sums of the touched bins redone from the cleaned spectra (group arithmetic of Powersum2Args)
+struct SpurPatchArgs {
+  const float2 *fft2; int n, first_na, na_mask, count, counter, avgnum;
+  const int *touched; const float *powersum_in; float *powersum_out, *wf_scratch;
+};
+hipError_t launch_spur_patch(const SpurPatchArgs &a, int nspurs, int ngroups, hipStream_t st);
 }

@@ -4,7 +4,10 @@ import numpy as np
 from .abi import default_config
 
 # algorithmic HBM bytes per input complex sample, per stage (DESIGN.md "Roofline accounting")
-ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2": 64.0}
+ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2": 64.0,
+             # k_fft1w = fft1 + fft1_c's sums + the weak stream of make_timf2 (spectrum in 16 + liminfo 8 + first write 8 + overlap
+             # read-modify-write 16 + power 4 = 52); its sparse second pass = the strong stream's first write 8 + read-modify-write 16
+             "fft1w": 24.0 + 16.0 + 52.0, "timf2s": 24.0}
 ALG_BYTES_CHAIN = 184.0
 
 

@@ -1,0 +1,96 @@
+"""GPU: k_fft1w -- forward transform, fft1_c's sums and the weak stream of make_timf2 as one kernel inside lrh_wideband_dsp
+(fft1_size 16384, sin^2 window, int16 I/Q) with the sparse strong-stream pass behind it -- against the two-kernel path it replaces
+(k_fft1 + k_timf2<.., SS>, LRH_FUSE_FFT1=0), and cfg.fft1_float_sparse against the full spectrum ring.  Parity with the oracle at
+these sizes is tests/test_gpu_fullsize.py (lrh_wideband_dsp takes the fused path there by default)."""
+import os
+
+import numpy as np
+import pytest
+
+from linrad_amd import abi
+from linrad_amd.workload import chain_config, strong_liminfo
+
+pytestmark = pytest.mark.gpu
+N1 = 16384
+RINGS = [(abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_FLOAT, "timf2"),
+         (abi.RING_TIMF2_PWR, "pwr"), (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_TIMF3_FLOAT, "timf3")]
+
+
+def _run(env, sparse=0, nblk=160, batch=32, calls=1, blanker=True, change_table_at=None):
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cfg = chain_config(14, 12, batch=batch, rounds=nblk // batch)
+        cfg.fft1_float_sparse = sparse
+        if not blanker:
+            cfg.stupid_bln_mode = 0
+        rx = open_hip(cfg)                                  # the environment is read here
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    s = synth_defaults(N1, 0)
+    rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+    lim = strong_liminfo(s, 14)
+    rx.set_liminfo(lim)
+    rx.set_mix1_selfreq(0.31 * 4096 + 0.3)
+    per = nblk // calls
+    for i in range(calls):
+        if change_table_at is not None and i == change_table_at:       # the routing table changes between two calls: the first transform of
+            lim2 = lim.copy(); lim2[3000:3010] = 1.0                   # the next call overlaps a partner routed with the OLD table
+            rx.set_liminfo(lim2)
+        rx.wideband_dsp(per, batch)
+    out = {k: rx.export(r) for r, k in RINGS}
+    out["p"] = rx.p.as_dict()
+    out["lim"] = rx.get_liminfo()
+    rx.close()
+    return out
+
+
+def _rel(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("pipeline", ["0", "2"])
+def test_fused_kernel_matches_the_two_kernel_path(pipeline):
+    """same job through k_fft1w + strong pass and through k_fft1 + k_timf2<.., SS>: every ring to float32 rounding (the 32-point and
+    the 16-point per thread forms of the transform factor their last-pass twiddles differently), pointers identical"""
+    a = _run({"LRH_FUSE_FFT1": "1", "LRH_PIPELINE": pipeline}, blanker=False)
+    b = _run({"LRH_FUSE_FFT1": "0", "LRH_PIPELINE": pipeline}, blanker=False)
+    assert a["p"] == b["p"]
+    rep = {k: _rel(a[k], b[k]) for _, k in RINGS}
+    print(rep)
+    assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["sumsq"]) > N1
+    for k, e in rep.items():
+        assert e < 2e-6, (k, e)
+
+
+def test_sparse_spectrum_ring_changes_nothing_downstream():
+    """cfg.fft1_float_sparse: only the strong bins reach the fft1 ring; every product of the chain is bit-identical to the full-ring run"""
+    full = _run({"LRH_FUSE_FFT1": "1"}, sparse=0)
+    sp = _run({"LRH_FUSE_FFT1": "1"}, sparse=1)
+    assert full["p"] == sp["p"]
+    for _, k in RINGS[1:]:
+        assert np.array_equal(full[k], sp[k]), k
+    strong = np.nonzero(full["lim"])[0]
+    f, s = full["fft1"].reshape(-1, N1, 2), sp["fft1"].reshape(-1, N1, 2)
+    assert strong.size > 10 and np.array_equal(f[:, strong], s[:, strong])
+    weak = np.nonzero(full["lim"] == 0)[0]
+    assert not np.any(s[:, weak])                          # never written: the ring's initial zeros
+
+
+@pytest.mark.parametrize("sparse", [0, 1])
+def test_fused_path_is_the_same_in_one_call_and_in_many(sparse):
+    """the overlap partner of a call's first transform is recomputed from the samples of the previous call's last block: five calls of
+    one round each, with the routing table changed in between, equal the two-kernel path call for call"""
+    # (blanker off for the comparison across the two paths: a sample within float32 rounding of the limit may be cleared in one only)
+    a = _run({"LRH_FUSE_FFT1": "1"}, sparse=sparse, calls=5, change_table_at=3, blanker=False)
+    b = _run({"LRH_FUSE_FFT1": "0"}, sparse=0, calls=5, change_table_at=3, blanker=False)
+    assert a["p"] == b["p"]
+    for _, k in RINGS[3:]:
+        assert _rel(a[k], b[k]) < (8e-6 if k == "pwr" else 2e-6), k      # pwr: a squared quantity, despiked (blanker on)
+    one = _run({"LRH_FUSE_FFT1": "1"}, sparse=sparse, calls=1)
+    many = _run({"LRH_FUSE_FFT1": "1"}, sparse=sparse, calls=5)
+    for _, k in RINGS[1:]:
+        assert np.array_equal(one[k], many[k]), k

@@ -89,6 +89,109 @@ def _check(open_fn, tol, NCH=NCH):
     assert np.mean(np.abs(null[used]) ** 2) < 0.5 * np.mean(np.abs(want[used]) ** 2)
 
 
+def _combined(open_fn, NCH):
+    """baseb_raw of every context of an NCH-channel array after the coherent combine (two beams), the all-reduce by hand"""
+    d = case_params("n10_n12_fft3")
+    d["nblk"] = 72
+    w = [np.exp(1j * p) / NCH for p in PHASE[:NCH]]
+    w2 = [np.exp(1j * p + 2j * np.pi * c / NCH) / NCH for c, p in enumerate(PHASE[:NCH])]
+    comb = [_open(open_fn, d, ch, (w[ch], w2[ch])) for ch in range(NCH)]
+    _drive(comb, d, combine=True)
+    out = [rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128) for rx in comb]
+    for rx in comb:
+        rx.close()
+    return out
+
+
+@pytest.mark.gpu
+def test_hip_eight_channel_combine_matches_the_oracle():
+    """BASELINE configs[4] held to the oracle, not to itself: eight HIP contexts (one per channel, the all-reduce of LRH_X_POL by
+    hand) against eight ORACLE contexts driven the same way -- the combined beam within the north-star's 1e-5.  (The reference
+    stops at two channels, so the oracle's combine is pinned by its two-channel case, tests/test_twochan.py, and by linearity.)"""
+    from linrad_amd.lib import open_hip
+    from oracle_binding import open_oracle
+    ref = _combined(open_oracle, 8)
+    got = _combined(open_hip, 8)
+    assert np.count_nonzero(ref[0]) > 200
+    err = max(np.linalg.norm(g - r) / np.linalg.norm(r) for g, r in zip(got, ref))
+    print("eight-channel combine, HIP vs oracle: relative RMS error", err)
+    assert err <= 1e-5, err
+
+
+def _fullsize_array(open_fn, hiplib, nch, nblocks=256, batch=32):
+    """the bench's configs[4] workload (fft1 16384 -> fft2 65536 -> mix1 1024 -> fft3 4096 -> mix2 256, SURVEY 8d signal with sky
+    phase 0.7 c on channel c, beam weights of bench.py) through lrh_wideband_dsp per channel + the combine step"""
+    from linrad_amd.workload import chain_config, strong_liminfo
+    cfg = chain_config(14, 16, batch=batch, fft3_n=12, mix2_n=8, rounds=nblocks // batch)
+    rxs = []
+    for ch in range(nch):
+        rx = open_fn(cfg)
+        s = hiplib.synth_defaults(1 << cfg.fft1_n, ch)
+        rx.timf1_write(hiplib.synth_iq(s, 0, cfg.timf1_bytes // 4))
+        rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
+        rx.set_mix1_selfreq(0.31 * (1 << cfg.fft2_n) + 0.3)
+        th = 0.7 * ch
+        rx.set_combine_weights(np.exp(-1j * th) / nch, np.exp(-1j * (th + np.pi * ch / nch)) / nch)
+        rxs.append(rx)
+    for _ in range(nblocks // batch):
+        for rx in rxs:
+            rx.wideband_dsp(batch, batch)
+        k3 = rxs[0].fft3_available()
+        while k3 > 0:
+            k3b = min(k3, max(1, cfg.max_fft3n // 2))
+            for rx in rxs:
+                rx.make_fft3_all(k3b)
+            cnt = [rx.mix2_pol_begin(k3b) for rx in rxs]
+            tot = sum(rx.exchange_read(rx.X_POL, cnt[0]) for rx in rxs)
+            for rx in rxs:
+                rx.exchange_write(rx.X_POL, tot)
+                rx.fft3_mix2(k3b)
+            k3 -= k3b
+    out = [rx.export(abi.RING_BASEB_RAW).astype(np.float64).view(np.complex128) for rx in rxs]
+    fft2 = rxs[0].export(abi.RING_FFT2_FLOAT).astype(np.float64)
+    for rx in rxs:
+        rx.close()
+    return out, fft2, cfg
+
+
+@pytest.mark.gpu
+def test_hip_eight_channel_fullsize_combine_matches_the_oracle():
+    """the same at BASELINE's full sizes (fft1 16384, fft2 65536): eight HIP contexts against eight oracle contexts on the bench's
+    own signal; every context ends with the same beam.  The baseband is a 256-bin cut out of a 65536-bin float32 spectrum that
+    carries an 8000-LSB carrier, so besides the relative gate the absolute float32 floor of that spectrum applies (paritylib)."""
+    from linrad_amd import lib as hiplib
+    from oracle_binding import open_oracle
+    got, _, cfg = _fullsize_array(hiplib.open_hip, hiplib, 8)
+    ref, fft2, _ = _fullsize_array(open_oracle, hiplib, 8)
+    assert np.count_nonzero(ref[0]) > 500
+    for g in got[1:]:
+        assert np.array_equal(g, got[0])
+    err = np.linalg.norm(got[0] - ref[0])
+    rel = err / np.linalg.norm(ref[0])
+    n2 = 1 << cfg.fft2_n
+    wide = np.linalg.norm(fft2) / np.sqrt(cfg.max_fft2n)
+    floor = 4 * 6e-8 * wide * np.sqrt(256.0 / n2) * np.sqrt(ref[0].size / 256.0)
+    print("full-size eight-channel combine, HIP vs oracle: relative", rel, "absolute", err, "float32 floor", floor)
+    assert rel <= 1e-5 or err <= floor, (rel, err, floor)
+
+
+@pytest.mark.gpu
+def test_bench_combine_step_runs_over_rccl_on_one_gpu():
+    """pre-flight of the multi-GPU run: bench.py's configs[4] mode (coherent combine: ExternalStream + in-place all-reduce on the
+    library's device buffers, the per-bin power-sum all-reduce) with backend nccl (= RCCL) and a one-rank group on this GPU, so that
+    the first 8-GPU run cannot die in plumbing; rank 0's line states the group size the collectives saw"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(LRH_BENCH_FORCE_DIST="1", LRH_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--combine", "--steps", "2", "--warmup", "1", "--batch", "256", "--rounds", "2",
+                        "--no-cpu", "--no-secondary"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["config"]["collective_world_size"] == 1 and out["config"]["backend"] == "nccl" and out["n_gpus"] == 1
+    assert "coherent combine" in out["mode"] and out["value"] > 100
+
+
 def test_oracle_four_channel_coherent_combine():
     from oracle_binding import open_oracle
     _check(open_oracle, 2e-6)
