@@ -232,6 +232,8 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     # nothing on this path reads the fft1_float ring (make_timf2 is its consumer): the fused forward transform then stores only the
     # strong bins its second pass needs (cfg.fft1_float_sparse, include/linrad_hip.h); --fft1-float full keeps every bin
     cfg.fft1_float_sparse = 0 if args.fft1_float == "full" else 1
+    # likewise fft2_float: power sums and waterfall lines are formed inside the transform kernels and mix1 cuts a band of mix1.size bins
+    cfg.fft2_float_sparse = 0 if args.fft2_float == "full" else 1
     if coupled:
         cfg.blanker_channels, cfg.timf1_channel_index = 2, rank & 1
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
@@ -524,6 +526,8 @@ def main():
                          "run (with LRH_BENCH_FORCE_DIST=1 the collectives go through a one-rank RCCL group)")
     ap.add_argument("--fft1-float", choices=("sparse", "full"), default="sparse",
                     help="sparse (default): the fft1_float ring keeps only the strong bins (nobody on the path reads it); full: every bin is stored")
+    ap.add_argument("--fft2-float", choices=("sparse", "full"), default="sparse",
+                    help="sparse (default): of every fft2 transform only the band mix1 cuts out is stored (cfg.fft2_float_sparse); full: every bin")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
@@ -609,7 +613,8 @@ def main():
                        "fft3_size": (1 << primary["fft3_n"]) if primary["fft3_n"] else 0, "batch_blocks": args.batch,
                        "rounds_per_step": args.rounds, "channels": world, "parallelism": f"1 RF channel per GPU x{world}",
                        "collective_world_size": nranks, "backend": (backend if dist is not None else None),
-                       "fft1_float": "strong bins only (cfg.fft1_float_sparse: no reader on this path)" if args.fft1_float == "sparse" else "every bin stored"},
+                       "fft1_float": "strong bins only (cfg.fft1_float_sparse: no reader on this path)" if args.fft1_float == "sparse" else "every bin stored",
+                       "fft2_float": "the band mix1 cuts out (cfg.fft2_float_sparse: power sums / waterfall inside the transform kernels)" if args.fft2_float == "sparse" else "every bin stored"},
             "mode": {"chain": "lrh_wideband_dsp", "combine": "lrh_wideband_dsp + coherent combine (lrh_mix2_pol_begin / all-reduce / lrh_fft3_mix2)",
                      "coupled": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan"}[primary["mode"]],
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",

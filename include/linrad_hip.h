@@ -120,7 +120,12 @@ typedef struct lrh_config {
                                    then run as one kernel and only the strong bins of a spectrum reach the ring (the second, sparse pass
                                    of make_timf2 reads them); LRH_RING_FFT1_FLOAT then holds those bins only.  0 (default): every bin is
                                    stored as before (lrh_export, lrh_fft1_mix1_*, the AFC window of the Linrad glue read it)          */
-  int reserved[1];
+  int fft2_float_sparse;        /* 1: nobody reads whole fft2 spectra: the power sums and waterfall lines are formed inside the transform
+                                   kernels and fft2_mix1_fixed cuts mix1.size bins around the selected frequency, so only that band
+                                   (+- 64 bins) of every transform is stored and LRH_RING_FFT2_FLOAT / _FFT2_POWER hold that band only.
+                                   The band follows lrh_set_mix1_selfreq at the time of each lrh_make_fft2.  Ignored (every bin stored)
+                                   while spurs are tracked, with two coupled channels, and without a selected frequency.  0 (default):
+                                   every bin is stored (lrh_export, lrh_fft2_mix1_afc, NET_RXOUT_FFT2, spur acquisition read it)    */
 } lrh_config;
 
 /*

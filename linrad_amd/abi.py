@@ -34,7 +34,7 @@ class LrhConfig(C.Structure):
         ("max_batch", C.c_int), ("second_fft_enable", C.c_int), ("timf2_blockpower_block", C.c_int),
         ("timf2_blockpower_size", C.c_int), ("timf1_frame_channels", C.c_int), ("timf1_channel_index", C.c_int),
         ("fft3_n", C.c_int), ("fft3_sinpow", C.c_int), ("mix2_n", C.c_int), ("max_fft3n", C.c_int),
-        ("baseband_size", C.c_int), ("timf1_dword_input", C.c_int), ("sample_shift", C.c_int), ("blanker_channels", C.c_int), ("timf1_real_input", C.c_int), ("fft1_float_sparse", C.c_int), ("reserved", C.c_int * 1),
+        ("baseband_size", C.c_int), ("timf1_dword_input", C.c_int), ("sample_shift", C.c_int), ("blanker_channels", C.c_int), ("timf1_real_input", C.c_int), ("fft1_float_sparse", C.c_int), ("fft2_float_sparse", C.c_int),
     ]
 
 

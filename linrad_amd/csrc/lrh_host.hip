@@ -99,6 +99,7 @@ struct lrh_ctx {
   // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
+  std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
@@ -1527,6 +1528,17 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   g.tw_a = c->d_tw2a; g.tw_b = c->d_tw2b; g.tw_big = c->d_tw2; g.scratch = c->d_fft2_scratch;
   g.out = a.out; g.power = a.power; g.first_na = a.first_na; g.na_mask = a.na_mask;
   g.ps_in = a.ps_in; g.ps_out = a.ps_out; g.wf_scratch = a.wf_scratch; g.ps_counter = a.ps_counter; g.ps_avgnum = a.ps_avgnum; g.batch = batch; g.run = c->env_fft2_cols_run;
+  // the band of every transform that reaches the ring: all of it, or what fft2_mix1_fixed will cut out (cfg.fft2_float_sparse)
+  a.keep_lo = 0; a.keep_hi = N;
+  if (c->cfg.fft2_float_sparse && c->fft2_fused && c->spur_n == 0 && c->cfg.blanker_channels != 2 && c->ms.mix1_selfreq >= 0) {
+    const int centre = (int)((float)c->ms.mix1_selfreq * c->cfg.fftx_points_per_hz + 0.5);
+    a.keep_lo = std::max(0, centre - c->Nm / 2 - 64); a.keep_hi = std::min(N, centre + c->Nm / 2 + 64);
+  }
+  g.keep_lo = a.keep_lo; g.keep_hi = a.keep_hi;
+  if (c->cfg.fft2_float_sparse) {
+    if (c->fft2_keep_lo.empty()) { c->fft2_keep_lo.assign(c->cfg.max_fft2n, 0); c->fft2_keep_hi.assign(c->cfg.max_fft2n, N); }
+    for (int b = 0; b < batch; b++) { c->fft2_keep_lo[(p->fft2_na + b) & c->fft2n_mask] = a.keep_lo; c->fft2_keep_hi[(p->fft2_na + b) & c->fft2n_mask] = a.keep_hi; }
+  }
   Powersum2Args s;
   s.power = c->d_power2; s.na_mask = c->fft2n_mask; s.first_na = p->fft2_na; s.count = batch; s.n = N;
   s.powersum_in = c->d_powersum2; s.powersum_out = c->d_powersum2_alt; s.wf_scratch = c->d_wf_scratch; s.counter = p->wg_waterf_sum_counter; s.avgnum = c->cfg.waterfall_avgnum;
@@ -1778,6 +1790,11 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
       if (rc) { *s = ms_keep; c->ph_next = slot; return rc; }
       if (afc) afc_tables(c, afc, nx, na, mask);
       point = s->mix1_point; h_point[b] = point;
+      if (src == c->d_fft2 && !c->fft2_keep_lo.empty()) {              // cfg.fft2_float_sparse: the band must be what lrh_make_fft2 kept of this transform
+        const int lo = std::max(0, point - Nm / 2), hi = std::min(lim_hi, point + Nm / 2);
+        if (lo < c->fft2_keep_lo[nx] || hi > c->fft2_keep_hi[nx]) { *s = ms_keep; c->ph_next = slot;
+          return fail(c, LRH_ESTATE, "fft2_float_sparse: the selected frequency has moved off the band stored for this transform"); }
+      }
       float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
       float r1 = s->mix1_old_phase;
       const float r2 = overlap ? (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm) : 0.f;

@@ -1261,13 +1261,23 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft2_min_waves(LOG2N)) void k_f
     const int na = (a.first_na + b) & a.na_mask;
     float2 *out = a.out + (size_t)na * N;
     float *pw = a.power + (size_t)na * N;
+    if (a.keep_lo <= 0 && a.keep_hi >= N) {             // every bin reaches the ring (uniform: no per-lane predicate on this path)
+#pragma unroll
+      for (int m = 0; m < P / RL; m++)
+#pragma unroll
+        for (int q = 0; q < RL; q++) store_stream(&out[(tid + m * T) + q * (N / RL)], x[m * RL + q]);
+    } else {                                             // cfg.fft2_float_sparse: the band mix1 will cut out
+#pragma unroll
+      for (int m = 0; m < P / RL; m++)
+#pragma unroll
+        for (int q = 0; q < RL; q++) { const int k = (tid + m * T) + q * (N / RL); if (k >= a.keep_lo && k < a.keep_hi) store_stream(&out[k], x[m * RL + q]); }
+    }
 #pragma unroll
     for (int m = 0; m < P / RL; m++)
 #pragma unroll
       for (int q = 0; q < RL; q++) {
         const int k = (tid + m * T) + q * (N / RL);
         const float2 v = x[m * RL + q];
-        store_stream(&out[k], v);
         const float p2 = v.x * v.x + v.y * v.y;
         if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
         else pw[k] = p2;
@@ -1429,6 +1439,17 @@ __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
     const int na = (a.first_na + b) & a.na_mask;
     float2 *out = a.out + (size_t)na * NA * NB;
     float *pw = a.power + (size_t)na * NA * NB;
+    if (a.keep_lo <= 0 && a.keep_hi >= NA * NB) {
+#pragma unroll
+      for (int m = 0; m < P / RL; m++)
+#pragma unroll
+        for (int q = 0; q < RL; q++) store_stream(&out[k1 + NA * ((l + m * T) + q * (NB / RL))], x[m * RL + q]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < P / RL; m++)
+#pragma unroll
+        for (int q = 0; q < RL; q++) { const int k = k1 + NA * ((l + m * T) + q * (NB / RL)); if (k >= a.keep_lo && k < a.keep_hi) store_stream(&out[k], x[m * RL + q]); }
+    }
 #pragma unroll
     for (int m = 0; m < P / RL; m++)
 #pragma unroll
@@ -1436,7 +1457,6 @@ __global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
         const int k2 = (l + m * T) + q * (NB / RL);
         const int k = k1 + NA * k2;
         const float2 v = x[m * RL + q];
-        store_stream(&out[k], v);
         const float p2 = v.x * v.x + v.y * v.y;
         if constexpr (FUSED) acc[m * RL + q] = (b == t_first && !ps_continue) ? p2 : acc[m * RL + q] + p2;   // "=" then "+=" (fft2.c:655-670)
         else pw[k] = p2;

@@ -168,6 +168,7 @@ struct Fft2Args {
   // fused power sums (fft2.c:655-670): with ps_avgnum > 0 a workgroup takes one waterfall averaging group instead of
   // a fixed run, keeps sum |X|^2 in registers and writes the group line; `power` may then be null
   const float *ps_in; float *ps_out; float *wf_scratch; int ps_counter; int ps_avgnum;
+  int keep_lo, keep_hi;     // bins [keep_lo, keep_hi) of a transform reach the fft2 ring (cfg.fft2_float_sparse: the band mix1 cuts out); 0, N: all
 };
 // four-step fft2 (N2 > 16384): N2 = NA*NB, column transforms of length NA, twiddle, row transforms of length NB
 struct Fft2BigArgs {
@@ -179,6 +180,7 @@ struct Fft2BigArgs {
   // fused power sums as in Fft2Args (ps_avgnum > 0): the rows kernel takes one averaging group per blockIdx.y
   const float *ps_in; float *ps_out; float *wf_scratch; int ps_counter; int ps_avgnum; int batch;
   int run;                  // consecutive transforms per workgroup of the column step (set by launch_fft2_big)
+  int keep_lo, keep_hi;     // as Fft2Args
 };
 struct Powersum2Args {
   const float *power; int na_mask; int first_na; int count; int n;

@@ -310,6 +310,7 @@ def test_power_sums_inside_timf2_match_separate_pass(n1, batch, calls, monkeypat
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     lim = strong_liminfo(s, n1)
     res = []
+    monkeypatch.setenv("LRH_FUSE_FFT1", "0")      # this test isolates the sums: k_fft1w (fft1_size 16384) has its own, tests/test_gpu_fused.py
     for mode in ("1", "0"):
         monkeypatch.setenv("LRH_FUSE_SUMSQ", mode)
         rx = _hip(cfg)

@@ -16,13 +16,14 @@ RINGS = [(abi.RING_FFT1_FLOAT, "fft1"), (abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RIN
          (abi.RING_TIMF2_PWR, "pwr"), (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_TIMF3_FLOAT, "timf3")]
 
 
-def _run(env, sparse=0, nblk=160, batch=32, calls=1, blanker=True, change_table_at=None):
+def _run(env, sparse=0, nblk=160, batch=32, calls=1, blanker=True, change_table_at=None, fft2_n=12, sparse2=0, fft3_n=0):
     from linrad_amd.lib import open_hip, synth_defaults, synth_iq
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        cfg = chain_config(14, 12, batch=batch, rounds=nblk // batch)
+        cfg = chain_config(14, fft2_n, batch=batch, rounds=nblk // batch, fft3_n=fft3_n, mix2_n=8 if fft3_n else 0)
         cfg.fft1_float_sparse = sparse
+        cfg.fft2_float_sparse = sparse2
         if not blanker:
             cfg.stupid_bln_mode = 0
         rx = open_hip(cfg)                                  # the environment is read here
@@ -33,7 +34,7 @@ def _run(env, sparse=0, nblk=160, batch=32, calls=1, blanker=True, change_table_
     rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
     lim = strong_liminfo(s, 14)
     rx.set_liminfo(lim)
-    rx.set_mix1_selfreq(0.31 * 4096 + 0.3)
+    rx.set_mix1_selfreq(0.31 * (1 << fft2_n) + 0.3)
     per = nblk // calls
     for i in range(calls):
         if change_table_at is not None and i == change_table_at:       # the routing table changes between two calls: the first transform of
@@ -41,6 +42,10 @@ def _run(env, sparse=0, nblk=160, batch=32, calls=1, blanker=True, change_table_
             rx.set_liminfo(lim2)
         rx.wideband_dsp(per, batch)
     out = {k: rx.export(r) for r, k in RINGS}
+    out["wf"] = rx.export(abi.RING_WG_WATERF)
+    if fft3_n:
+        out["baseb"] = rx.export(abi.RING_BASEB_RAW)
+    out["cfg"] = cfg
     out["p"] = rx.p.as_dict()
     out["lim"] = rx.get_liminfo()
     rx.close()
@@ -94,3 +99,42 @@ def test_fused_path_is_the_same_in_one_call_and_in_many(sparse):
     many = _run({"LRH_FUSE_FFT1": "1"}, sparse=sparse, calls=5)
     for _, k in RINGS[1:]:
         assert np.array_equal(one[k], many[k]), k
+
+
+@pytest.mark.parametrize("fft2_n,fft3_n", [(12, 0), (16, 12)])
+def test_sparse_fft2_ring_changes_nothing_downstream(fft2_n, fft3_n):
+    """cfg.fft2_float_sparse: of every fft2 transform only the band fft2_mix1_fixed cuts out reaches the ring; power sums, waterfall
+    lines, timf3 and the baseband are bit-identical to the full-ring run, and the stored band equals the full ring's"""
+    full = _run({}, sparse=1, sparse2=0, fft2_n=fft2_n, fft3_n=fft3_n, nblk=256 if fft3_n else 160)
+    sp = _run({}, sparse=1, sparse2=1, fft2_n=fft2_n, fft3_n=fft3_n, nblk=256 if fft3_n else 160)
+    assert full["p"] == sp["p"]
+    for k in ("ps2", "timf3", "wf", "pwr", "timf2") + (("baseb",) if fft3_n else ()):
+        assert np.array_equal(full[k], sp[k]), k
+    assert np.count_nonzero(sp["timf3"]) > 100 and np.any(sp["wf"])
+    n2 = 1 << fft2_n
+    centre, half = int(0.31 * n2 + 0.3 + 0.5), (n2 >> 6) // 2
+    f, s = full["fft2"].reshape(-1, n2, 2), sp["fft2"].reshape(-1, n2, 2)
+    assert np.array_equal(f[:, centre - half:centre + half], s[:, centre - half:centre + half])
+    assert not np.any(s[:, :centre - half - 64]) and not np.any(s[:, centre + half + 64:])
+
+
+def test_sparse_fft2_ring_refuses_a_band_it_did_not_keep():
+    """the selected frequency moves between lrh_make_fft2 and lrh_fft2_mix1_fixed: an error, not silence"""
+    from linrad_amd.abi import LrhError
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    cfg = chain_config(14, 12, batch=32)
+    cfg.fft2_float_sparse = 1
+    rx = open_hip(cfg)
+    rx.timf1_write(synth_iq(synth_defaults(N1, 0), 0, cfg.timf1_bytes // 4))
+    rx.set_liminfo(np.zeros(N1, np.float32))
+    rx.set_mix1_selfreq(1000.3)
+    rx.fft1_b(32), rx.fft1_c(32), rx.make_timf2(32), rx.first_noise_blanker()
+    k = rx.fft2_available()
+    assert k >= 1
+    rx.make_fft2(1)
+    rx.set_mix1_selfreq(3000.0)
+    with pytest.raises((LrhError, RuntimeError), match="fft2_float_sparse"):
+        rx.fft2_mix1_fixed(1)
+    rx.set_mix1_selfreq(1010.0)                           # within the 64-bin margin: served
+    rx.fft2_mix1_fixed(1)
+    rx.close()
