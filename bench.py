@@ -34,7 +34,7 @@ from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newes
 from linrad_amd.workload import (ALG_BYTES, HBM_PEAK_GBS, alg_bytes_chain, chain_config, strong_liminfo, workload_name)  # noqa: E402
 
 METRIC = "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline"
-STAGES = ("fft1", "fft1w", "timf2s", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
+STAGES = ("fft1", "fft1w", "timf2s", "spur", "clever", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
 
 
 def setup_receiver(cfg, channel, open_fn, synth_mod):
@@ -233,10 +233,25 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     # strong bins its second pass needs (cfg.fft1_float_sparse, include/linrad_hip.h); --fft1-float full keeps every bin
     cfg.fft1_float_sparse = 0 if args.fft1_float == "full" else 1
     # likewise fft2_float: power sums and waterfall lines are formed inside the transform kernels and mix1 cuts a band of mix1.size bins
-    cfg.fft2_float_sparse = 0 if args.fft2_float == "full" else 1
+    cfg.fft2_float_sparse = 0 if (args.fft2_float == "full" or args.spurs) else 1      # spur acquisition reads whole transforms
     if coupled:
         cfg.blanker_channels, cfg.timf1_channel_index = 2, rank & 1
+    clever_g = None
+    if args.clever:
+        # the linear blanker needs the calibrated receiver's pulse response (init_blanker, buf.c:1771-2057): the tables the compiled
+        # reference built from a synthetic amplitude calibration, carried as data by the golden fixture of the parity tests
+        clever_g = dict(np.load(os.path.join(ROOT, "tests", "golden", "clever_n10_n12.npz")))
+        cfg.blanker_pulsewidth, cfg.blnfit_range = int(clever_g["bln_ints"][1]), int(clever_g["bln_ints"][3])
+        # start value of the noise floor at the level the SURVEY 8d signal settles at (the reference's 200, buf.c:418, is a guess for an
+        # unknown receiver): with 200 the first calls see 0.5 % of all samples above the limit -- 10^5 pulse candidates per call in a
+        # handful of regions, minutes of one-wave walks before the floor has adapted; the steady state is what is timed either way
+        cfg.timf2_noise_floor = 500
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
+    if clever_g is not None:
+        bi, bf = clever_g["bln_ints"], clever_g["bln_fparams"]
+        rx.set_blanker_tables(bln=clever_g["bln"].reshape(-1, 4)[:, :3], refpulse=clever_g["blanker_refpulse"], phasefunc=clever_g["blanker_phasefunc"],
+                              pulindex=clever_g["blanker_pulindex"], largest_blnfit=int(bi[2]), clever_bln_factor=float(bf[1]),
+                              clever_bln_limit=int(np.float32(cfg.timf2_noise_floor) * np.float32(bf[1])), liminfo_amplitude_factor=float(bf[0]))
     samples_per_step = args.batch * args.rounds * M1
     dev = torch.device("cuda", local_rank)
     use_dist = dist is not None
@@ -328,6 +343,21 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         # spectra have been seen (sellim.c:866), until then the medium carriers stay in the weak stream and latch the blanker
         for _ in range(6):
             rx.wideband_dsp(args.batch, args.batch)
+    spur_info = None
+    if args.spurs and not coupled:
+        # the carriers of the SURVEY 8d signal are taken out by the spur loop: acquired on the device-resident spectra (lrh_spur_acquire)
+        # after one step, tracked and subtracted by k_spur inside every lrh_make_fft2 from then on
+        from linrad_amd.spurs import spur_spectra
+        step()
+        rx.sync()
+        rx.spur_config(args.spurs, args.spur_speknum, spur_spectra(2))
+        s0 = hiplib.synth_defaults(N1, channel_of_rank(rank))
+        order = np.argsort(-np.asarray(s0.carrier_amp[:s0.ncarriers]))
+        locked = 0
+        for i in order[:args.spurs]:
+            f2 = N2 / 2 + s0.carrier_bin[i] * N2 / s0.fft_size
+            locked += int(rx.spur_acquire(int(round(f2)) - 3))
+        spur_info = {"requested": args.spurs, "locked": locked, "spur_speknum": args.spur_speknum}
     for _ in range(warmup):
         step()
     barrier()
@@ -457,7 +487,13 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         bs = rx.blanker_state()
         res["blanker"] = {"noise_floor": bs.timf2_noise_floor, "limit": bs.stupid_bln_limit,
                           "cleared_rate_pct": round(bs.stupid_blanker_rate, 3), "slow_path_calls": bs.slow_path_calls}
+        if args.clever:
+            res["blanker"].update(clever_limit=bs.clever_bln_limit, clever_rate_pct=round(bs.clever_blanker_rate, 3), last_call_fitted=bs.last_call_fitted,
+                                  last_call_rejected=bs.last_call_rejected, one_wave_replays=bs.clever_serial_calls)
     res["roofline"], res["stages"] = roof, stages
+    if spur_info is not None:
+        spur_info["locked_at_end"] = sum(1 for q in rx.spur_get() if q.spur_flag == 0)
+        res["spurs"] = spur_info
     if host_ring is not None:
         rx.host_unregister(host_ring)
     rx.close()
@@ -528,6 +564,9 @@ def main():
                     help="sparse (default): the fft1_float ring keeps only the strong bins (nobody on the path reads it); full: every bin is stored")
     ap.add_argument("--fft2-float", choices=("sparse", "full"), default="sparse",
                     help="sparse (default): of every fft2 transform only the band mix1 cuts out is stored (cfg.fft2_float_sparse); full: every bin")
+    ap.add_argument("--clever", action="store_true", help="linear (\"clever\") blanker in front of the stupid one: pulse search, fit and subtraction (blank1.c:765-1003)")
+    ap.add_argument("--spurs", type=int, default=0, help="track and subtract this many of the signal's carriers (eliminate_spurs inside lrh_make_fft2)")
+    ap.add_argument("--spur-speknum", type=int, default=16)
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
@@ -621,7 +660,7 @@ def main():
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
             "routing": res.get("routing"), "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
-            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "secondary": secondary,
+            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
     return 0

@@ -348,6 +348,14 @@ int lrh_spur_config(lrh_ctx *ctx, int max_spurs, int spur_speknum, const float *
    [max_fft2n][SPUR_WIDTH][2] (the bins of past transforms), spur_signal [max_fft2n][2], spur_ind [max_fft2n] (buf.c:1114-1131) */
 int lrh_spur_set(lrh_ctx *ctx, int n, const lrh_spur *spurs, const float *spur_table, const float *spur_signal, const int *spur_ind);
 int lrh_spur_get(lrh_ctx *ctx, int max, lrh_spur *spurs, int *n);          /* synchronous */
+/* Acquisition on the device-resident spectra: store_new_spur (spursub.c:619-751: the seven bins from `pnt` of the
+   newest spur_speknum transforms join the history, the summed power gives the frequency with decimals) and spur_phase_lock
+   (spursub.c:1247-1426 with verify_spur_pll :1428-1843: up to five rounds of the loop on that history, accepted when the corrections
+   have died down and the residual over the window is spectrally flat) for the next free spur number.  p->fft2_na = ffts_na, the ring
+   position behind the newest transform (wcw.c:288-289).  *locked = 1: the spur is tracked from the next lrh_make_fft2 on
+   (no_of_spurs++, spursub.c:309); 0: no lock, nothing changed.  The search for candidates (spursearch_spectrum, spursub.c:36-260)
+   reads the summed power spectrum, which the host has anyway (LRH_RING_FFT2_POWERSUM).  Needs cfg.fft2_float_sparse = 0.  Synchronous. */
+int lrh_spur_acquire(lrh_ctx *ctx, const lrh_ptrs *p, int pnt, int *locked);
 
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */
 int lrh_timf1_write(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);   /* host -> device ring, wraps */

@@ -236,6 +236,7 @@ class StageAPI:
         self._proto("spur_config", [vp, C.c_int, C.c_int, fp])
         self._proto("spur_set", [vp, C.c_int, C.POINTER(LrhSpur), fp, fp, ip])
         self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
+        self._proto("spur_acquire", [vp, C.POINTER(LrhPtrs), C.c_int, ip])
         self._proto("get_liminfo", [vp, fp])
         self._proto("fft2_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
         self._proto("wideband_limiter", [vp, C.POINTER(LrhSellim), C.c_int])
@@ -434,6 +435,12 @@ class StageAPI:
         table, signal = np.ascontiguousarray(table, np.float32), np.ascontiguousarray(signal, np.float32)
         ind = np.ascontiguousarray(ind, np.int32)
         self._chk(self._f("spur_set")(self.ctx, len(spurs), arr, self._fptr(table), self._fptr(signal), ind.ctypes.data_as(C.POINTER(C.c_int))), "spur_set")
+
+    def spur_acquire(self, pnt):
+        """store_new_spur + spur_phase_lock on the resident fft2 spectra for the seven bins from `pnt` (spursub.c:619, 1247); True: locked and now tracked"""
+        locked = C.c_int()
+        self._chk(self._f("spur_acquire")(self.ctx, C.byref(self.p), int(pnt), C.byref(locked)), "spur_acquire")
+        return bool(locked.value)
 
     def spur_get(self, max_spurs=16):
         arr = (LrhSpur * max_spurs)()

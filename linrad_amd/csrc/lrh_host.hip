@@ -48,6 +48,7 @@ hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t s
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
 hipError_t launch_spur_patch(const SpurPatchArgs &a, int nspurs, int ngroups, hipStream_t st);
+hipError_t launch_spur_acquire(const SpurArgs &a, int pnt, int *result, hipStream_t st);
 hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
 }  // namespace lrh
 using namespace lrh;
@@ -927,10 +928,43 @@ int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra
   const size_t maxn = c->cfg.max_fft2n;
   int rc = LRH_OK;
   if ((rc = dev_alloc(c, &c->d_spurs, max_spurs)) || (rc = dev_alloc(c, &c->d_spur_table, max_spurs * maxn * 14)) || (rc = dev_alloc(c, &c->d_spur_signal, max_spurs * maxn * 2)) ||
-      (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_touched, 2 * max_spurs)) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
+      (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_touched, 2 * max_spurs + 2)) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_spur_spectra, spectra, sizeof(float) * LRH_SPUR_SPECTRA, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->spur_max = max_spurs; c->spur_speknum = speknum;
+  return LRH_OK;
+}
+// what k_spur / k_spur_acquire need from the context: the loop constants follow spur_speknum (buf.c:480, 1141-1170)
+static void spur_args(lrh_ctx *c, SpurArgs *out, int first_na, int batch)
+{
+  SpurArgs sa; memset(&sa, 0, sizeof sa);
+  const int N = c->N2;
+  sa.fft2 = c->d_fft2; sa.n2 = N; sa.first_na = first_na; sa.na_mask = c->fft2n_mask; sa.batch = batch;
+  sa.nspurs = c->spur_n; sa.speknum = c->spur_speknum; sa.numsub = sa.speknum - 1; sa.avgnum = sa.speknum / 3; if (sa.avgnum > 10) sa.avgnum = 10;
+  sa.freq_factor = (float)c->M2 / (float)N;
+  sa.max_d2 = (float)(PI_L * sa.freq_factor / sa.speknum);
+  sa.minston = (float)(1 / sqrt(0.5 * (float)(sa.speknum)));
+  { float t1 = (float)(0.5 * sa.speknum); sa.weiold = t1 / (1 + t1); sa.weinew = 1 / (1 + t1);
+    t1 = (float)(-0.5 * sa.numsub); sa.linefit = 0; for (int i = 0; i < sa.speknum; i++) { sa.linefit += t1 * t1; t1 += 1; } }
+  sa.spectra = c->d_spur_spectra; sa.spurs = c->d_spurs; sa.table = c->d_spur_table; sa.signal = c->d_spur_signal; sa.ind = c->d_spur_ind; sa.touched = c->d_spur_touched;
+  *out = sa;
+}
+// store_new_spur + spur_phase_lock (spursub.c:619, 1247) on the resident spectra: the control plane names the seven bins, the device
+// takes the history, reads the frequency off it and closes the loop; one int comes back
+int lrh_spur_acquire(lrh_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
+{
+  LRH_ENTER(c);
+  if (!c || !p || !locked) return LRH_EINVAL;
+  *locked = 0;
+  if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
+  if (c->spur_n >= c->spur_max || pnt < 1 || pnt + 9 > c->N2) return LRH_EINVAL;
+  if (c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "spur acquisition reads whole fft2 transforms: cfg.fft2_float_sparse must be 0");
+  SpurArgs sa; spur_args(c, &sa, p->fft2_na, 0);
+  HIPCHK(c, launch_spur_acquire(sa, pnt, c->d_spur_touched + 2 * c->spur_max, c->stream));
+  int res = 0;
+  HIPCHK(c, hipMemcpyAsync(&res, c->d_spur_touched + 2 * c->spur_max, sizeof res, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (res) { c->spur_n++; *locked = 1; }
   return LRH_OK;
 }
 int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, const float *signal, const int *ind)
@@ -1390,6 +1424,19 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
     HIPCHK(c, hipStreamSynchronize(c->cur));
+    { static const int dbg = getenv("LRH_CLEVER_DEBUG") ? atoi(getenv("LRH_CLEVER_DEBUG")) : 0;     // diagnostics: the regions of this call and where extents met
+      if (dbg) {
+        int ctl[4] = {0, 0, 0, 0}; hipMemcpy(ctl, c->d_clv_ctl, sizeof ctl, hipMemcpyDeviceToHost);
+        const int nr = std::min(ctl[0], c->clv_max_regions);
+        std::vector<int> st(nr), ex(2 * (size_t)nr);
+        if (nr) { hipMemcpy(st.data(), c->d_clv_start, nr * sizeof(int), hipMemcpyDeviceToHost); hipMemcpy(ex.data(), c->d_clv_ext, 2 * nr * sizeof(int), hipMemcpyDeviceToHost); }
+        int bad = 0, first_bad = -1;
+        for (int r = 0; r + 1 < nr; r++) if (ex[2 * r + 1] >= ex[2 * (r + 1)]) { if (first_bad < 0) first_bad = r; bad++; }
+        fprintf(stderr, "clever: total %d regions %d (max %d) serial %d gap %d colliding pairs %d", a.total, ctl[0], c->clv_max_regions, ctl[1], ca.gap, bad);
+        if (first_bad >= 0) fprintf(stderr, "  first: region %d start %d ext [%d, %d] | region %d start %d ext [%d, %d]", first_bad, st[first_bad], ex[2 * first_bad], ex[2 * first_bad + 1],
+                                    first_bad + 1, st[first_bad + 1], ex[2 * first_bad + 2], ex[2 * first_bad + 3]);
+        fprintf(stderr, "  fitted %d rejected %d\n", out[1], out[2]);
+      } }
     p->timf2p_fit = (out[0] - 16 + mask) & (mask & ~3);                  // blank1.c:1458-1461
     a.post_stats = 1; a.fitted = out[1]; a.rejected = out[2]; a.clever_mode = c->bt.clever_bln_mode; a.clever_factor = c->bt.clever_bln_factor;
   }
@@ -1561,16 +1608,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   const bool spurs = c->spur_n > 0;
   const bool fused = c->fft2_fused;
   SpurArgs sa; memset(&sa, 0, sizeof sa);
-  if (spurs) {
-    sa.fft2 = c->d_fft2; sa.n2 = N; sa.first_na = p->fft2_na; sa.na_mask = c->fft2n_mask; sa.batch = batch;
-    sa.nspurs = c->spur_n; sa.speknum = c->spur_speknum; sa.numsub = sa.speknum - 1; sa.avgnum = sa.speknum / 3; if (sa.avgnum > 10) sa.avgnum = 10;
-    sa.freq_factor = (float)c->M2 / (float)N;                             // buf.c:480
-    sa.max_d2 = (float)(PI_L * sa.freq_factor / sa.speknum);              // buf.c:1152-1170
-    sa.minston = (float)(1 / sqrt(0.5 * (float)(sa.speknum)));
-    { float t1 = (float)(0.5 * sa.speknum); sa.weiold = t1 / (1 + t1); sa.weinew = 1 / (1 + t1);
-      t1 = (float)(-0.5 * sa.numsub); sa.linefit = 0; for (int i = 0; i < sa.speknum; i++) { sa.linefit += t1 * t1; t1 += 1; } }
-    sa.spectra = c->d_spur_spectra; sa.spurs = c->d_spurs; sa.table = c->d_spur_table; sa.signal = c->d_spur_signal; sa.ind = c->d_spur_ind; sa.touched = c->d_spur_touched;
-  }
+  if (spurs) spur_args(c, &sa, p->fft2_na, batch);
   const int na0 = p->fft2_na, max2 = c->cfg.max_fft2n;
   SpurPatchArgs pa; memset(&pa, 0, sizeof pa);
   pa.fft2 = c->d_fft2; pa.n = N; pa.first_na = p->fft2_na; pa.na_mask = c->fft2n_mask; pa.count = batch; pa.counter = s.counter; pa.avgnum = s.avgnum;

@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
 // transforms and keeps sum |X|^2 of its bins in registers (k_fft2's scheme), so neither the fft2_power ring nor the
 // k_powersum2 pass over it is needed.
 template <int LA, int LB, bool FUSED>
-__global__ __launch_bounds__(1024) void k_fft2_rows(Fft2BigArgs a)
+__global__ __launch_bounds__(1024, 8) void k_fft2_rows(Fft2BigArgs a)    // two workgroups per CU: 64 VGPRs
 {
   constexpr int P = sub_ppt(LB);
   using Plan = FftPlan<LB, P>;
@@ -2328,7 +2328,11 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
   const int nreg = a.phase == 1 ? 1 : a.reg_ctl[0];
   for (int reg = blockIdx.x; reg < nreg; reg += gridDim.x) {
   const int r_begin = a.phase == 1 ? 0 : a.reg_start[reg];
-  const int r_end = (a.phase == 1 || reg + 1 >= nreg) ? total : a.reg_start[reg + 1];
+  // A region ends short of the next one's start by the reach of a subtraction: the next region rewrites samples up to half the largest
+  // fit size BEFORE its first candidate, and a residue there that exceeds the limit is a candidate the reference's walk never sees (it
+  // lies behind the walk by the time the pulse is handled) -- so it is nobody's: not the next region's (behind its start) and not this
+  // one's.  This region's own candidates cannot lie there: the gap to the next start is wider than any reach.
+  const int r_end = (a.phase == 1 || reg + 1 >= nreg) ? total : a.reg_start[reg + 1] - (a.bln_size[a.largest] / 2 + 1);
   int ext_lo = r_begin, ext_hi = r_begin;
   int pf = r_begin, fitted = 0, rejected = 0;
   for (;;) {
@@ -3184,7 +3188,7 @@ __device__ __forceinline__ float2 mulc(float2 a_, float2 b) { return make_float2
 
 // working set of one spur in LDS: h = history de-rotated by the loop's oscillator (index 0 oldest .. n-1 newest), d / g = step between
 // neighbours and its smoothed form (n - 1 values), t = phase track (n values), then scratch for the fits
-struct SpurWork { float2 *h, *d, *g; float *t; };
+struct SpurWork { float2 *h, *d, *g; float *t; float *row; };   // row: the newest transform's seven bins (the lanes that fetched them are not the lane that projects them)
 
 struct SpurWave {
   const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; SpurWork w; const int lane, n, maxn, mask;
@@ -3235,6 +3239,16 @@ struct SpurWave {
         r[2 * i] = (src >= 0 && src < 7) ? v[2 * src] : 0.f; r[2 * i + 1] = (src >= 0 && src < 7) ? v[2 * src + 1] : 0.f;
       }
     }
+    if (lane == 0) {                                       // the copy of the newest row
+      float v[14];
+#pragma unroll
+      for (int i = 0; i < 14; i++) v[i] = w.row[i];
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const int src = i + dir;
+        w.row[2 * i] = (src >= 0 && src < 7) ? v[2 * src] : 0.f; w.row[2 * i + 1] = (src >= 0 && src < 7) ? v[2 * src + 1] : 0.f;
+      }
+    }
     __builtin_amdgcn_wave_barrier();
     return true;
   }
@@ -3249,10 +3263,10 @@ struct SpurWave {
   }
 
   // one look at the history through the loop's oscillator: corrections (c0, c1, c2) to phase, slope and curvature; amplitude and noise
-  __device__ void estimate(int na, float &c0, float &c1, float &c2)
+  // (ph0, sl0, cv0): the oscillator's phase at the newest entry `na`, its step and the step's change per transform
+  __device__ void estimate(int na, double ph0, double sl0, double cv0, float &c0, float &c1, float &c2)
   {
     const int ns = n - 1, av = a.avgnum;
-    const double ph0 = (double)(float)(q.d0pha + (float)(q.d1pha + q.d2pha)), sl0 = (double)(float)(q.d1pha + q.d2pha), cv0 = (double)q.d2pha;
     // history seen from the oscillator: age m is turned back by phase - m slope + m (m - 1) / 2 curvature
     for (int m = lane; m < n; m += 64) {
       const float2 z = make_float2(zsig[2 * slot(na, m)], zsig[2 * slot(na, m) + 1]);
@@ -3374,10 +3388,125 @@ struct SpurWave {
   {
     float c0, c1, c2;
     float slope = q.d1pha + q.d2pha, phase = q.d0pha + slope, curv = q.d2pha;
-    estimate(na, c0, c1, c2);
+    estimate(na, (double)phase, (double)slope, (double)curv, c0, c1, c2);
     phase += c0; slope += c1; curv += c2;
     phase -= slope; slope -= curv;
     q.d0pha = phase; q.d1pha = slope; q.d2pha = curv;
+  }
+
+
+  // ---- acquisition (store_new_spur + spur_phase_lock with verify_spur_pll, spursub.c:619-751, 1247-1843): the carrier in the seven
+  // bins from `pnt` is taken into the history, its frequency read off the summed power of the newest n transforms, and the loop is
+  // closed on the history in up to five rounds; accepted when the corrections have died down and what the subtraction would leave
+  // behind is spectrally flat.  `na` = ring slot behind the newest transform.  Same one-wave form as the tracking.
+  __device__ bool acquire(int na, int pnt)
+  {
+    const int newest = (na - 1) & mask;
+    float pwr7[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) pwr7[i] = 0.f;
+    for (int m = lane; m < n; m += 64) {                   // rows of the history and the power of each bin
+      const float2 *z = a.fft2 + (size_t)slot(newest, m) * a.n2 + pnt;
+      float *r = tab + slot(newest, m) * 14;
+#pragma unroll
+      for (int i = 0; i < 7; i++) { const float2 v = z[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; pwr7[i] += v.x * v.x + v.y * v.y; }
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; i++) pwr7[i] = wsum(pwr7[i]);
+    { const float base = 0.5f * (pwr7[0] + pwr7[6]);       // the ends of the window stand for the noise floor; unit sum
+#pragma unroll
+      for (int i = 0; i < 7; i++) { pwr7[i] -= base; if (pwr7[i] < 0) pwr7[i] = 0; tot += pwr7[i]; }
+#pragma unroll
+      for (int i = 0; i < 7; i++) pwr7[i] /= tot; }
+    q.location = pnt; q.flag = 0; q.d0pha = 0; q.d1pha = 0; q.d2pha = 0; q.ampl = 1; q.noise = 0.001f; q.avgd2 = 0;
+    int k = 0; float peak = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; i++) if (peak < pwr7[i]) { peak = pwr7[i]; k = i; }
+    if (k == 0 || k == 6) return false;
+    {                                                       // parabola through the peak and its neighbours (amplitudes): the decimals
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int i = 1; i < 6; i++) if (i == k) { lo = (float)sqrt((double)pwr7[i - 1]); hi = (float)sqrt((double)pwr7[i + 1]); }
+      const float mid = (float)sqrt((double)peak);
+      float off; const float d = lo - hi, cur = 2 * (lo + hi - 2 * mid);
+      if (cur < 0) { off = d / cur; if (fabs((double)off) > 1) off /= (float)fabs((double)off); } else off = lo > hi ? -1.f : 1.f;
+      q.freq = pnt + k + off;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // first look: history weighted with the power spectrum, neighbouring bins with alternating sign
+    for (int m = lane; m < n; m += 64) {
+      const float *r = tab + slot(newest, m) * 14;
+      float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 6; i += 2) { z.x += pwr7[i] * r[2 * i] - pwr7[i + 1] * r[2 * i + 2]; z.y += pwr7[i] * r[2 * i + 1] - pwr7[i + 1] * r[2 * i + 3]; }
+      if (q.location & 1) { z.x = -z.x; z.y = -z.y; }
+      zsig[2 * slot(newest, m)] = z.x; zsig[2 * slot(newest, m) + 1] = z.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float c0, c1, c2;
+    estimate(newest, 0.0, 0.0, 0.0, c0, c1, c2);
+    const float need = (float)(3 / sqrt((double)(float)n));
+    if (q.ampl < need * q.noise) return false;
+    const float turns = q.freq * a.freq_factor;             // whole turns per transform: fixed during the verification
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+    auto wrap_all = [](float v) { while (v > LRH_PI) v -= (float)(2 * LRH_PI); while (v < -LRH_PI) v += (float)(2 * LRH_PI); return v; };
+    auto freq_at = [&](float sl) { float r = (float)(-0.5 * sl / LRH_PI); const int i = (int)(turns - r + 0.5); r += i; return r / a.freq_factor; };
+    auto half_pos = [&](float fq) { int j = (int)(fq) + 2 - q.location - 4; if (j < 0) j = 0; j = 1 - j; if (j < 0) j = 0; return j; };
+    for (int iter = 1; iter <= 5; iter++) {
+      for (int m = lane; m < n; m += 64) {                 // every entry on the line shape of the loop's frequency at its age
+        const float fq = freq_at(q.d1pha - m * q.d2pha);
+        const int j = half_pos(fq);
+        int id = (int)(256 * (fq - (int)(fq)));
+        if (id == 256) id = 255;
+        id = id * 8 + j;
+        const int sidx = slot(newest, m);
+        uind[sidx] = id;
+        const float2 pr = project(tab + sidx * 14, id, j);
+        zsig[2 * sidx] = pr.x; zsig[2 * sidx + 1] = pr.y;
+      }
+      __builtin_amdgcn_wave_barrier();
+      estimate(newest, (double)q.d0pha, (double)q.d1pha, (double)q.d2pha, c0, c1, c2);
+      if (q.ampl < need * q.noise) return false;
+      q.d0pha = wrap_all(q.d0pha + c0); q.d1pha = wrap_all(q.d1pha + c1); q.d2pha = wrap_all(q.d2pha + c2);
+      q.freq = freq_at(q.d1pha);
+      if (iter > 1 && fabs((double)c0) < 0.1 && fabs((double)c1) < 0.01 && fabs((double)c2) < 0.001 &&
+          fabs((double)e0) < 0.3 && fabs((double)e1) < 0.03 && fabs((double)e2) < 0.003) {
+        // residual after the subtraction over the window and one bin either side, mean square per bin
+        float res[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) res[i] = 0.f;
+        const float turns2 = q.freq * a.freq_factor;
+        for (int m = lane; m < n; m += 64) {
+          float r = (float)(-0.5 * (q.d1pha - m * q.d2pha) / LRH_PI); const int it = (int)(turns2 - r + 0.5); r += it;
+          const int j = half_pos(r / a.freq_factor);
+          const int sidx = slot(newest, m), id = uind[sidx];
+          float2 carrier = rot(make_float2(q.ampl, 0.f), (double)q.d0pha - m * (double)q.d1pha + 0.5 * m * (m - 1) * (double)q.d2pha);
+          if ((j ^ (q.location & 1)) == 1) { carrier.x = -carrier.x; carrier.y = -carrier.y; }
+          const float2 *z = a.fft2 + (size_t)sidx * a.n2 + q.location;
+#pragma unroll
+          for (int i = 0; i < 7; i++) {
+            const float sh = a.spectra[id + i]; const float2 v = z[i];
+            res[i + 1] += (float)((double)(v.x - sh * carrier.x) * (double)(v.x - sh * carrier.x) + (double)(v.y - sh * carrier.y) * (double)(v.y - sh * carrier.y));
+          }
+          res[0] += z[-1].x * z[-1].x + z[-1].y * z[-1].y;
+          res[8] += z[8].x * z[8].x + z[8].y * z[8].y;
+        }
+        float mean = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { res[i] = wsum(res[i]) / n; mean += res[i]; res[i] = (float)sqrt((double)res[i]); }
+        mean = (float)sqrt((double)(mean / 9));
+        float spread = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) spread += (res[i] - mean) * (res[i] - mean);
+        spread = (float)sqrt((double)(spread / 9));
+        if (spread > 0.5 * mean / sqrt((double)n) + 0.02 * q.ampl) return false;
+        q.avgd2 = q.d2pha;
+        return true;
+      }
+      e0 = c0; e1 = c1; e2 = c2;
+    }
+    return false;
   }
 
   // one transform of a locked spur
@@ -3398,10 +3527,12 @@ struct SpurWave {
       return;
     }
     q.freq = freq_of(q.d1pha + q.d2pha, q.freq);
-    if (!centre(q.freq, na, ind, j)) return;
-    if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; }
+    if (lane < 14) w.row[lane] = 0.f;                      // (a window move below shifts the copy along with the rows)
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { uind[na] = ind; const float2 pr = project(row, ind, j); zsig[2 * na] = pr.x; zsig[2 * na + 1] = pr.y; }
+    if (!centre(q.freq, na, ind, j)) return;
+    if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; w.row[2 * lane] = v.x; w.row[2 * lane + 1] = v.y; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { uind[na] = ind; const float2 pr = project(w.row, ind, j); zsig[2 * na] = pr.x; zsig[2 * na + 1] = pr.y; }
     __builtin_amdgcn_wave_barrier();
     int moved = 0;
     for (int iter = 1;; iter++) {
@@ -3411,22 +3542,22 @@ struct SpurWave {
       moved = 0;
       bool left = false;
       float fq_near = q.freq;
-      for (int base = 0; base < n; base += 64) {
+      for (int base = 0; base <= n; base += 64) {          // ages 0 .. n: one entry more than the estimate reads, like the reference's walk
         const int m = base + lane;
         const float sl = (q.d1pha + q.d2pha) - m * q.d2pha;
         // fractional part from this age's slope; integer part: nearest to the previous age's frequency, which changes by far less than a bin
         float fq = freq_of(sl, fq_near);
         const float prev = __shfl_up(fq, 1, 64);
         if (lane > 0) fq = freq_of(sl, prev);
-        int jj; const int id = m < n ? shape(fq, q.location, jj) : 0;
-        if (__any(m < n && id < 0)) { left = true; break; }
-        if (m < n) {
+        int jj; const int id = m <= n ? shape(fq, q.location, jj) : 0;
+        if (__any(m <= n && id < 0)) { left = true; break; }
+        if (m <= n) {
           const int sidx = slot(na, m);
           int k = (uind[sidx] - id + 2048) & 2047;
           if (k > 1024) k = 2048 - k;
           moved = max(moved, k);
           uind[sidx] = id;
-          if (k != 0) { const float2 pr = project(tab + sidx * 14, id, jj); zsig[2 * sidx] = pr.x; zsig[2 * sidx + 1] = pr.y; }
+          if (k != 0) { const float2 pr = project(m == 0 ? w.row : tab + sidx * 14, id, jj); zsig[2 * sidx] = pr.x; zsig[2 * sidx + 1] = pr.y; }
         }
         fq_near = __shfl(fq, 63, 64);
       }
@@ -3458,7 +3589,7 @@ __global__ __launch_bounds__(64) void k_spur(SpurArgs a)
   const int maxn = a.na_mask + 1;
   DevSpur q = reinterpret_cast<DevSpur *>(a.spurs)[s];
   SpurWork w;
-  w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n);
+  w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n); w.row = w.t + n + 2;
   SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask};
   int lo = q.location, hi = q.location;
   for (int b = 0; b < a.batch; b++) {
@@ -3473,9 +3604,30 @@ __global__ __launch_bounds__(64) void k_spur(SpurArgs a)
 }
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st)
 {
-  const size_t lds = (size_t)a.speknum * (3 * sizeof(float2) + sizeof(float)) + 16;
+  const size_t lds = (size_t)a.speknum * (3 * sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16;
   if (lds > 60 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_spur, dim3(a.nspurs), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+
+// store_new_spur + spur_phase_lock for spur number `a.nspurs` (the next free one): result[0] = 1 when the loop locked
+__global__ __launch_bounds__(64) void k_spur_acquire(SpurArgs a, int pnt, int *result)
+{
+  extern __shared__ float spur_lds[];
+  const int s = a.nspurs, lane = threadIdx.x, n = a.speknum;
+  const int maxn = a.na_mask + 1;
+  DevSpur q;
+  SpurWork w;
+  w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n); w.row = w.t + n + 2;
+  SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask};
+  const bool ok = L.acquire(a.first_na & a.na_mask, pnt);
+  if (lane == 0) { reinterpret_cast<DevSpur *>(a.spurs)[s] = q; result[0] = ok ? 1 : 0; }
+}
+hipError_t launch_spur_acquire(const SpurArgs &a, int pnt, int *result, hipStream_t st)
+{
+  const size_t lds = (size_t)a.speknum * (3 * sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16;
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_spur_acquire, dim3(1), dim3(64), lds, st, a, pnt, result);
   return hipGetLastError();
 }
 

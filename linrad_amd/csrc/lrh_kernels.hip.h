@@ -286,6 +286,7 @@ struct SpurArgs {
   int *touched;                                          // per spur [2]: first and one-past-last fft2 bin the batch's subtractions touched
 };
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
+hipError_t launch_spur_acquire(const SpurArgs &a, int pnt, int *result, hipStream_t st);   // a.nspurs = index of the new spur, a.first_na = ffts_na
 // power sums of the touched bins redone from the cleaned spectra (group arithmetic of Powersum2Args)
 struct SpurPatchArgs {
   const float2 *fft2; int n, first_na, na_mask, count, counter, avgnum;

@@ -1157,6 +1157,7 @@ advance:
   p->fft2_liminfo_cnt++;
 }
 
+
 static void lro_spur_hook(lro_ctx *c, int na);      /* eliminate_spurs, defined with the spur tracking at the end of this file */
 
 /* make_fft2 mode 15 until FFT2_COMPLETE: fft2.c:86-141 (load, window, big_fftforward), 647-705 (power),
@@ -2331,6 +2332,150 @@ int lro_spur_get(lro_ctx *c, int max, lrh_spur *sp, int *n)
   memcpy(sp, S->sp, *n * sizeof *sp);
   return LRH_OK;
 }
+
+/* ---- acquisition of a new spur on the resident fft2 spectra: store_new_spur (spursub.c:619-751, one channel, float) with
+   spurspek_norm (:472-493) and make_spur_freq (:592-616, parabolic_fit llsq.c:113-153), then spur_phase_lock (:1247-1426) with
+   verify_spur_pll (:1428-1843).  ffts_na = p->fft2_na: the ring position behind the newest transform (wcw.c:288-289).
+   *locked = 1: the spur joined the tracked ones (no_of_spurs++, spursub.c:309); 0: no lock (the reference returns without it). */
+static void spur_parabolic_fit(float *amp, float *pos, float y1, float y2, float y3)
+{
+  float t4 = y1 - y3, t3 = 2 * (y1 + y3 - 2 * y2);
+  if (t3 < 0) { *amp = y2 - 0.5F * t4 * t4 / t3; t4 = t4 / t3; if (fabs(t4) > 1) t4 /= (float)fabs(t4); *pos = t4; }
+  else if (y1 > y3) { *amp = y1; *pos = -1; }
+  else { *amp = y3; *pos = 1; }
+}
+int lro_spur_acquire(lro_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
+{
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S || !p || !locked) return LRH_EINVAL;
+  *locked = 0;
+  const int maxn = c->cfg.max_fft2n, mask = maxn - 1, n2 = c->N2, n = S->speknum, na = p->fft2_na & mask;
+  if (S->n >= S->max || pnt < 1 || pnt + SPW + 1 > n2) return LRH_EINVAL;
+  const int s = S->n;
+  lrh_spur *q = &S->sp[s];
+  float *tab = S->table + (size_t)s * maxn * SPW * 2, *zsig = S->signal + (size_t)s * maxn * 2;
+  int *uind = S->ind + (size_t)s * maxn;
+  const float *fftx = c->fft2_float;
+  float power[SPW];
+  memset(q, 0, sizeof *q);
+  q->spur_ampl = 1; q->spur_noise = 0.001f; q->spur_avgd2 = 0;               /* spursub.c:290-292 */
+  /* store_new_spur: the last speknum transforms' bins into the table, their summed power */
+  for (int i = 0; i < SPW; i++) power[i] = 0;
+  for (int np = (na - n + maxn) & mask; np != na; np = (np + 1) & mask) {
+    const float *z = &fftx[2 * ((size_t)np * n2 + pnt)];
+    float *t = tab + (size_t)np * SPW * 2;
+    for (int i = 0; i < SPW; i++) { t[2 * i] = z[2 * i]; t[2 * i + 1] = z[2 * i + 1]; power[i] += z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; }
+  }
+  { float t1 = 0.5f * (power[0] + power[SPW - 1]), t2 = 0;                   /* spurspek_norm */
+    for (int i = 0; i < SPW; i++) { power[i] -= t1; if (power[i] < 0) power[i] = 0; t2 += power[i]; }
+    for (int i = 0; i < SPW; i++) power[i] /= t2; }
+  q->spur_location = pnt;
+  { float t2 = 0; int k = 0;                                                 /* make_spur_freq */
+    for (int i = 0; i < SPW; i++) if (t2 < power[i]) { t2 = power[i]; k = i; }
+    if (k == 0 || k == SPW - 1) return LRH_OK;
+    float amp, pos;
+    spur_parabolic_fit(&amp, &pos, (float)sqrt(power[k - 1]), (float)sqrt(t2), (float)sqrt(power[k + 1]));
+    q->spur_freq = pnt + k + pos; }
+  /* spur_phase_lock: history weighted with the power spectrum, alternating signs of neighbouring bins */
+  { int izz = 0;
+    for (int np = (na - n + maxn) & mask; np != na; np = (np + 1) & mask) {
+      const float *t = tab + (size_t)np * SPW * 2;
+      float t1 = 0, t2 = 0;
+      for (int i = 0; i < SPW - 1; i += 2) { t1 += power[i] * t[2 * i] - power[i + 1] * t[2 * i + 2]; t2 += power[i] * t[2 * i + 1] - power[i + 1] * t[2 * i + 3]; }
+      if ((q->spur_location & 1) == 1) { t1 = -t1; t2 = -t2; }
+      zsig[2 * np] = t1; zsig[2 * np + 1] = t2;
+      S->sig[2 * izz] = t1; S->sig[2 * izz + 1] = t2; izz++;
+    } }
+  spur_phase_parameters(S, q);
+  if (q->spur_ampl < 3 * q->spur_noise / sqrt((float)(n))) return LRH_OK;
+  /* verify_spur_pll */
+  float average_rot = q->spur_freq * S->freq_factor, d0err = 0, d1err = 0, d2err = 0;
+  for (int iter = 1; iter <= 5; iter++) {
+    float a1 = (float)cos(q->spur_d0pha), a2 = (float)sin(q->spur_d0pha), b1 = (float)cos(q->spur_d1pha), b2 = (float)sin(q->spur_d1pha);
+    float d1 = (float)cos(q->spur_d2pha), d2 = (float)sin(q->spur_d2pha), slope = q->spur_d1pha, r1, r2;
+    const float curv = q->spur_d2pha;
+    int ni = (na + mask) & mask;
+    for (int izz = n - 1; izz >= 0; izz--) {
+      float rot = (float)(-0.5 * slope / PI_L);
+      int i = (int)(average_rot - rot + 0.5);
+      rot += i;
+      const float freq = rot / S->freq_factor;
+      int j = (int)(freq) + 2 - q->spur_location - SPSZ / 2;
+      if (j < 0) j = 0;
+      j = 1 - j;
+      if (j < 0) j = 0;
+      int ind = (int)(NSPEC * (freq - (int)(freq)));
+      if (ind == NSPEC) ind = NSPEC - 1;
+      ind = ind * SPSZ + j;
+      uind[ni] = ind;
+      const float *t = tab + (size_t)ni * SPW * 2;
+      r1 = 0; r2 = 0;
+      for (i = 0; i < SPW; i++) { r1 += S->spectra[ind + i] * t[2 * i]; r2 += S->spectra[ind + i] * t[2 * i + 1]; }
+      if ((j ^ (q->spur_location & 1)) == 1) { r1 = -r1; r2 = -r2; }
+      zsig[2 * ni] = r1; zsig[2 * ni + 1] = r2;
+      S->sig[2 * izz] = r1 * a1 + r2 * a2; S->sig[2 * izz + 1] = r2 * a1 - r1 * a2;
+      ni = (ni + mask) & mask;
+      r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+      r2 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r2;
+      slope -= curv;
+    }
+    spur_phase_parameters(S, q);
+    if (q->spur_ampl < 3 * q->spur_noise / sqrt((float)(n))) return LRH_OK;
+    q->spur_d0pha += S->sp_d0; q->spur_d1pha += S->sp_d1; q->spur_d2pha += S->sp_d2;
+    while (q->spur_d0pha > PI_L) q->spur_d0pha -= (float)(2 * PI_L);
+    while (q->spur_d0pha < -PI_L) q->spur_d0pha += (float)(2 * PI_L);
+    while (q->spur_d1pha > PI_L) q->spur_d1pha -= (float)(2 * PI_L);
+    while (q->spur_d1pha < -PI_L) q->spur_d1pha += (float)(2 * PI_L);
+    while (q->spur_d2pha > PI_L) q->spur_d2pha -= (float)(2 * PI_L);
+    while (q->spur_d2pha < -PI_L) q->spur_d2pha += (float)(2 * PI_L);
+    { float rot = (float)(-0.5 * q->spur_d1pha / PI_L); const int i = (int)(average_rot - rot + 0.5); rot += i; q->spur_freq = rot / S->freq_factor; }
+    if (iter > 1 && fabs(S->sp_d0) < 0.1 && fabs(S->sp_d1) < 0.01 && fabs(S->sp_d2) < 0.001 && fabs(d0err) < 0.3 && fabs(d1err) < 0.03 && fabs(d2err) < 0.003) {
+      /* what would be left after the subtraction, over the window and the bin on either side: its spectrum must be flat */
+      float errspek[SPW + 2];
+      for (int i = 0; i < SPW + 2; i++) errspek[i] = 0;
+      average_rot = q->spur_freq * S->freq_factor;
+      a1 = q->spur_ampl * (float)cos(q->spur_d0pha); a2 = q->spur_ampl * (float)sin(q->spur_d0pha);
+      b1 = (float)cos(q->spur_d1pha); b2 = (float)sin(q->spur_d1pha); d1 = (float)cos(q->spur_d2pha); d2 = (float)sin(q->spur_d2pha);
+      slope = q->spur_d1pha;
+      ni = (na + mask) & mask;
+      for (int izz = n - 1; izz >= 0; izz--) {
+        float rot = (float)(-0.5 * slope / PI_L);
+        int i = (int)(average_rot - rot + 0.5);
+        rot += i;
+        const float freq = rot / S->freq_factor;
+        int j = (int)(freq) + 2 - q->spur_location - SPSZ / 2;
+        if (j < 0) j = 0;
+        j = 1 - j;
+        if (j < 0) j = 0;
+        const int ind = uind[ni];
+        float t1 = a1, t2 = a2;
+        if ((j ^ (q->spur_location & 1)) == 1) { t1 = -a1; t2 = -a2; }
+        const float *z = &fftx[2 * ((size_t)ni * n2 + q->spur_location)];
+        for (i = 0; i < SPW; i++)
+          errspek[i + 1] += (float)(pow(z[2 * i] - S->spectra[ind + i] * t1, 2.0) + pow(z[2 * i + 1] - S->spectra[ind + i] * t2, 2.0));
+        errspek[0] += (float)(pow(z[-2], 2.0) + pow(z[-1], 2.0));
+        errspek[SPW + 1] += (float)(pow(z[2 * (SPW + 1)], 2.0) + pow(z[2 * (SPW + 1) + 1], 2.0));
+        ni = (ni + mask) & mask;
+        r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+        r2 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r2;
+        slope -= q->spur_d2pha;
+      }
+      r1 = 0;
+      for (int i = 0; i < SPW + 2; i++) { errspek[i] /= n; r1 += errspek[i]; errspek[i] = (float)sqrt(errspek[i]); }
+      r1 = (float)sqrt(r1 / (SPW + 2));
+      r2 = 0;
+      for (int i = 0; i < SPW + 2; i++) r2 += (float)pow(errspek[i] - r1, 2.0);
+      r2 = (float)sqrt(r2 / (SPW + 2));
+      if (r2 > 0.5 * r1 / sqrt((int)(n)) + 0.02 * q->spur_ampl) return LRH_OK;
+      q->spur_avgd2 = q->spur_d2pha;                                         /* spursub.c:1424 */
+      S->n++; *locked = 1;
+      return LRH_OK;
+    }
+    d0err = S->sp_d0; d1err = S->sp_d1; d2err = S->sp_d2;
+  }
+  return LRH_OK;
+}
+
 
 static void lro_spur_hook(lro_ctx *c, int na)
 {

@@ -16,7 +16,9 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
 
 
-def run(open_fn, name, g, batch=1):
+def run(open_fn, name, g, batch=1, acquire=False):
+    """acquire: the spur is found by the API's own store_new_spur / spur_phase_lock (spur_acquire) on the resident spectra instead of
+    being handed over with the reference's acquisition result"""
     d, sp, iq, lim = spur_case(name)
     assert np.array_equal(iq, g["iq"])
     cfg = lrh_config(d, iq)
@@ -45,12 +47,16 @@ def run(open_fn, name, g, batch=1):
             if handed:
                 s = api.spur_get()[0]
                 trace.append([s.spur_location, s.spur_flag, s.spur_freq, s.spur_d0pha, s.spur_d1pha, s.spur_d2pha, s.spur_ampl, s.spur_noise, s.spur_avgd2, nfft2 - 1])
+            elif nfft2 == start and acquire:
+                assert api.spur_acquire(sp["spur_pnt"]), "no lock"
+                handed = True
+                acq = api.spur_get()[0]
             elif nfft2 == start:                                  # the reference's acquisition result, handed over by the control plane
                 q = LrhSpur(int(st[0]), int(st[1]), *[float(x) for x in st[2:9]])
                 maxn = cfg.max_fft2n
                 api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
                 handed = True
-    return dict(api=api, cfg=cfg, d=d, trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
+    return dict(api=api, cfg=cfg, d=d, acq=(acq if acquire else None), trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
                 ps2=api.export(abi.RING_FFT2_POWERSUM))
 
 
@@ -87,4 +93,18 @@ def compare(out, g, tol, batch=1):
     assert rep["freq_err_bins"] < 1e-3 and rep["phase_err_rad"] < 20 * tol * 1e2 and rep["ampl_rel"] < 10 * tol, rep
     assert rep["fft2"] < tol and rep["ps2"] < tol and rep["timf3"] < tol, rep
     assert rep["residual_err_vs_carrier"] < tol, rep
+    return rep
+
+
+def compare_acquisition(out, g):
+    """the loop state right after the lock against the reference's own (spur_init_state of the golden)"""
+    st, a = g["spur_init_state"], out["acq"]
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+    rep = {"location": (a.spur_location, int(st[0])), "freq_err_bins": abs(a.spur_freq - st[2]), "phase_err": abs(wrap(a.spur_d0pha - st[3])),
+           "d1_err": abs(wrap(a.spur_d1pha - st[4])), "d2_err": abs(a.spur_d2pha - st[5]), "ampl_rel": abs(a.spur_ampl - st[6]) / abs(st[6]),
+           "noise_rel": abs(a.spur_noise - st[7]) / abs(st[7])}
+    assert a.spur_location == int(st[0]) and a.spur_flag == 0
+    assert rep["freq_err_bins"] < 1e-4 and rep["phase_err"] < 1e-3 and rep["d1_err"] < 1e-4 and rep["d2_err"] < 1e-5 and rep["ampl_rel"] < 1e-4 and rep["noise_rel"] < 1e-2, rep
     return rep

@@ -39,3 +39,24 @@ def test_spur_api_errors():
         rx.spur_config(4, rx.cfg.max_fft2n, np.zeros(2048, np.float32))      # 4 * speknum > max_fft2n
     rx.spur_config(0, 0, np.zeros(2048, np.float32))                        # off
     assert rx.spur_get() == []
+
+
+@pytest.mark.parametrize("name", list(SPUR))
+def test_hip_spur_acquisition_matches_reference(name):
+    """lrh_spur_acquire: store_new_spur + spur_phase_lock on the device-resident fft2 spectra at the transform where the reference
+    acquired; the loop state after the lock equals the reference's and the run it then tracks equals the golden like the handed-over one"""
+    from linrad_amd.lib import open_hip
+    g = spurlib.load(name)
+    out = spurlib.run(open_hip, name, g, acquire=True)
+    print(name, spurlib.compare_acquisition(out, g), spurlib.compare(out, g, tol=1e-5))
+
+
+def test_hip_spur_acquisition_refuses_noise():
+    """seven bins of plain noise: no lock, nothing tracked"""
+    from linrad_amd.lib import open_hip
+    name = "spur_n10_n12"
+    g = spurlib.load(name)
+    out = spurlib.run(open_hip, name, g, acquire=False)
+    rx = out["api"]
+    assert not rx.spur_acquire(700)
+    assert len(rx.spur_get()) == 1
