@@ -34,7 +34,7 @@ from linrad_amd.multichan import channel_of_rank, cross_channel_power_sum, newes
 from linrad_amd.workload import (ALG_BYTES, HBM_PEAK_GBS, alg_bytes_chain, chain_config, strong_liminfo, workload_name)  # noqa: E402
 
 METRIC = "Msamples/s complex IQ through fft1->timf2->fft2->mix1; % HBM roofline"
-STAGES = ("fft1", "fft1w", "timf2s", "spur", "clever", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
+STAGES = ("fft1", "fft1w", "timf2s", "spur", "clever", "xypower", "pol", "xcopy", "sumsq", "sumsq_join", "slowsum", "timf2", "blanker", "fft2", "powersum2", "waterfall", "mix1", "fft3", "mix2", "pol", "sellim")
 
 
 def setup_receiver(cfg, channel, open_fn, synth_mod):
@@ -48,17 +48,38 @@ def setup_receiver(cfg, channel, open_fn, synth_mod):
     return rx
 
 
+def source_sha16():
+    """hash of the kernel / host sources the library is built from (scripts/summarize_profile.py stores the same in the traffic file)"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("lrh_kernels.hip", "lrh_fft.hip.h", "lrh_kernels.hip.h", "lrh_host.hip"):
+        h.update(open(os.path.join(ROOT, "linrad_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_TRAFFIC = {}
+
+
 def measured_traffic(stage, wl):
-    """HBM bytes per launch of a stage's dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs of this very command, FETCH doubled as the gfx950 guide prescribes);
-    None when this run's workload has not been profiled."""
-    for name in ("r02_traffic.json",):
+    """HBM bytes per launch of a stage's kernels from the committed rocprofv3 PMC passes (profiles/r03_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this very command, FETCH doubled as the gfx950 guide prescribes).  None when this run's
+    workload has not been profiled -- or when the file was collected on other sources than the ones this library is built from
+    (the byte counts of a kernel that has changed since say nothing about it)."""
+    if "t" not in _TRAFFIC:
+        _TRAFFIC["t"] = None
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            return t["workloads"][wl]["kernels"][stage]
+            t = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+            if t.get("source_sha16") == source_sha16():
+                _TRAFFIC["t"] = t
+            else:
+                _TRAFFIC["stale"] = True
         except Exception:  # noqa: BLE001
-            continue
-    return None
+            pass
+    t = _TRAFFIC["t"]
+    try:
+        return t["workloads"][wl]["kernels"][stage] if t else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 # --------------------------------------------------------------------------------------------------------- CPU baselines
@@ -272,8 +293,10 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     wr = [0]
 
     if coupled:
-        from linrad_amd.multichan import run_coupled
+        from linrad_amd.multichan import install_exchange, run_coupled
         rx.set_pol(0.8, 0.36, -0.48)
+        if not args.coupled_stages:
+            install_exchange(rx, dist, dev)                # lrh_wideband_dsp asks for the collectives at its exchange points (lrh_set_exchange)
     if combine:
         # phased array (BASELINE configs[4]): steer at the synthetic sky signal, whose phase on channel c is 0.7 c rad
         # (SURVEY 8d); beam B is the same aperture pointed half a beam away
@@ -307,8 +330,11 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         rx.wideband_limiter(sel, args.limiter2)
 
     def step():
-        if coupled:
+        if coupled and args.coupled_stages:
             run_coupled(rx, args.batch * args.rounds, args.batch, dist, device=dev, xy=True, pol=True)
+            return
+        if coupled:
+            rx.wideband_dsp(args.batch * args.rounds, args.batch)
             return
         if host_ring is not None:
             nb = min(step_bytes, cfg.timf1_bytes)
@@ -392,7 +418,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     # ---- per-kernel timing with HIP events on the streams the kernels are launched on (rank 0), in the SAME two-stream
     # schedule as the timed loop (lrh_profile_enable(2)); a serial pass afterwards gives the stand-alone times
     stages, alone, roof = {}, {}, None
-    if rank == 0 and with_stage_times and not coupled:
+    if rank == 0 and with_stage_times and not (coupled and args.coupled_stages):
         nprof = max(3, min(steps, 10))
         rx.profile_enable(2)
         for _ in range(nprof):
@@ -450,7 +476,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 "frac_alg": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_counter": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "achieved_counter": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_traffic.json) "
+                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_traffic.json, same sources as this library) "
                            "/ average launch time / 8 TB/s; frac (= frac_alg) prices the SURVEY 8d algorithmic bytes, part of which this "
                            "kernel eliminates (overlap read-modify-write 32 B, liminfo floats 8 B of 92 B per sample)",
                 "timer": "HIP events around each launch on the stream it is launched on, two-stream schedule of the timed loop "
@@ -567,6 +593,7 @@ def main():
     ap.add_argument("--clever", action="store_true", help="linear (\"clever\") blanker in front of the stupid one: pulse search, fit and subtraction (blank1.c:765-1003)")
     ap.add_argument("--spurs", type=int, default=0, help="track and subtract this many of the signal's carriers (eliminate_spurs inside lrh_make_fft2)")
     ap.add_argument("--spur-speknum", type=int, default=16)
+    ap.add_argument("--coupled-stages", action="store_true", help="--coupled through the stage calls of linrad_amd.multichan.run_coupled instead of one lrh_wideband_dsp call per step")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
@@ -655,7 +682,7 @@ def main():
                        "fft1_float": "strong bins only (cfg.fft1_float_sparse: no reader on this path)" if args.fft1_float == "sparse" else "every bin stored",
                        "fft2_float": "the band mix1 cuts out (cfg.fft2_float_sparse: power sums / waterfall inside the transform kernels)" if args.fft2_float == "sparse" else "every bin stored"},
             "mode": {"chain": "lrh_wideband_dsp", "combine": "lrh_wideband_dsp + coherent combine (lrh_mix2_pol_begin / all-reduce / lrh_fft3_mix2)",
-                     "coupled": "two coupled channels (polarisation pair), stage calls + collectives from linrad_amd.multichan"}[primary["mode"]],
+                     "coupled": "two coupled channels (polarisation pair): lrh_wideband_dsp with the collectives registered through lrh_set_exchange (linrad_amd.multichan.install_exchange)"}[primary["mode"]],
             "input": "page-locked host ring over PCIe, lrh_timf1_write_async per step" if args.stream_host else "device-resident ring",
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},

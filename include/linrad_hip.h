@@ -124,7 +124,8 @@ typedef struct lrh_config {
                                    kernels and fft2_mix1_fixed cuts mix1.size bins around the selected frequency, so only that band
                                    (+- 64 bins) of every transform is stored and LRH_RING_FFT2_FLOAT / _FFT2_POWER hold that band only.
                                    The band follows lrh_set_mix1_selfreq at the time of each lrh_make_fft2.  Ignored (every bin stored)
-                                   while spurs are tracked, with two coupled channels, and without a selected frequency.  0 (default):
+                                   while spurs are tracked, with two coupled channels (there it only drops the per-transform cross
+                                   products LRH_RING_FFT2_XYPOWER: the group sums and the waterfall line remain), and without a selected frequency.  0 (default):
                                    every bin is stored (lrh_export, lrh_fft2_mix1_afc, NET_RXOUT_FFT2, spur acquisition read it)    */
 } lrh_config;
 
@@ -522,6 +523,21 @@ int lrh_get_mix1_state(lrh_ctx *ctx, lrh_mix1_state *st);
    functions ...; not the producer-side lrh_timf1_write*).  A caller that passes one batch per call therefore gets the same schedule
    as one that passes many.  LRH_PERSIST=0 in the environment makes every call issue all of its work before it returns. */
 int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
+/* Two coupled channels (cfg.blanker_channels = 2) through lrh_wideband_dsp: the exchanges that sit between the stage calls (see
+   lrh_blanker_begin, lrh_fft2_xy_begin, lrh_mix2_pol_begin) are made by a function the caller registers.  At each exchange point the
+   library has enqueued everything that fills the buffer on `stream` (the context's own stream, a hipStream_t) and calls
+       fn(user, which, op, device_ptr, count, stream)
+   which must enqueue the collective ON THAT STREAM (RCCL: ncclAllReduce / ncclAllGather with the stream; torch: under an
+   ExternalStream) and return 0 without waiting; the library then enqueues the consumers behind it.  op LRH_XOP_SUM: in-place all-reduce
+   (sum) of `count` floats at device_ptr; op LRH_XOP_GATHER: all-gather of the two slots of `count` floats each that start at device_ptr
+   (slot r is the one channel r filled: the caller's own slot is its send buffer).  Nothing waits on the host, so a whole call is enqueued
+   like a single-channel one: fft1 / sums / weak stream fused as usual, blanker_begin -> SUM(LRH_X_PWR) [-> GATHER(LRH_X_WEAK) with the
+   linear blanker's tables] -> blanker -> SUM(LRH_X_STAT) -> blanker_finish, make_fft2 -> GATHER(LRH_X_BINS) -> cross products and
+   waterfall line, mix1, fft3 -> SUM(LRH_X_POL) (after lrh_set_pol) -> mix2, once per batch.  fn = NULL removes it (the stage calls
+   remain available; lrh_wideband_dsp then refuses coupled contexts as before). */
+enum { LRH_XOP_SUM = 0, LRH_XOP_GATHER = 1 };
+typedef int (*lrh_exchange_fn)(void *user, int which, int op, void *device_ptr, size_t count, void *stream);
+int lrh_set_exchange(lrh_ctx *ctx, lrh_exchange_fn fn, void *user);
 
 /* ---- host-visible side outputs ---- */
 int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems); /* synchronous */

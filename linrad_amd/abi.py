@@ -566,6 +566,25 @@ class StageAPI:
         self._chk(self._f("get_mix1_state")(self.ctx, C.byref(st)), "get_mix1_state")
         return st
 
+    def set_exchange(self, fn):
+        """register the cross-channel exchange function of two coupled channels (lrh_set_exchange): fn(which, op, ptr, count, stream) -> 0;
+        None removes it.  The ctypes thunk is kept alive on the receiver."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+        f = self._f("set_exchange")
+        f.argtypes, f.restype = [C.c_void_p, proto, C.c_void_p], C.c_int
+        if fn is None:
+            self._xthunk = proto()
+        else:
+            def thunk(user, which, op, ptr, count, stream):
+                try:
+                    return int(fn(which, op, ptr, count, stream) or 0)
+                except Exception:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._xthunk = proto(thunk)
+        self._chk(f(self.ctx, self._xthunk, None), "set_exchange")
+
     def wideband_dsp(self, nblocks, batch):
         self._chk(self._f("wideband_dsp")(self.ctx, C.byref(self.p), nblocks, batch), "wideband_dsp")
 

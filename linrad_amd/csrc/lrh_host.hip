@@ -101,6 +101,7 @@ struct lrh_ctx {
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
+  lrh_exchange_fn xfn = nullptr; void *xuser = nullptr;     // lrh_set_exchange: collectives of two coupled channels inside lrh_wideband_dsp
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
@@ -1374,7 +1375,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   if (coupled) {
     if (c->fin_pending) return fail(c, LRH_ESTATE, "lrh_blanker_finish of the previous call is missing");
     if (c->x_pbeg != pbeg || c->x_count < 0 || c->x_span != a.total) return fail(c, LRH_ESTATE, "lrh_blanker_begin was not called for this span");
-    HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr_sum, pbeg, c->x_count, mask, 1, c->cur));   // the exchanged sums take their ring places
+    { ProfScope ps(c, "xcopy"); HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr_sum, pbeg, c->x_count, mask, 1, c->cur)); }   // the exchanged sums take their ring places
     if (c->clever_on) {                                                   // and so do the partner channel's samples
       if (c->xw_count <= 0) return fail(c, LRH_ESTATE, "lrh_blanker_begin ran before the blanker tables were installed");
       const int nw = c->xw_count / 2;
@@ -1475,7 +1476,7 @@ int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
   const int R = c->clever_on ? c->cfg.blnfit_range : 0;
   if (c->clever_on && c->x_span > c->cfg.timf2pow_size - 1024) { c->x_count = -1; return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring"); }
   c->x_count = c->x_span + R;
-  HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr, pbeg, c->x_count, mask, 0, c->cur));
+  { ProfScope ps(c, "xcopy"); HIPCHK(c, launch_span_copy(c->d_xbuf, c->d_pwr, pbeg, c->x_count, mask, 0, c->cur)); }
   if (c->clever_on) {
     const int nw = c->x_span + 2 * R + 1;
     HIPCHK(c, launch_span_copy2(c->d_xweak + (size_t)(c->cfg.timf1_channel_index & 1) * nw, c->d_timf2w, pbeg - R, nw, mask, 0, c->cur));
@@ -1662,6 +1663,7 @@ int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
   float2 *slot = c->d_xbins + (size_t)(c->cfg.timf1_channel_index & 1) * batch * N;
   const int first = std::min(batch, c->cfg.max_fft2n - na);          // the ring span may wrap once
   LRH_DEVICE_WORK(c, {
+    ProfScope ps(c, "xcopy");
     HIPCHK(c, hipMemcpyAsync(slot, c->d_fft2 + (size_t)na * N, (size_t)first * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
     if (batch > first) HIPCHK(c, hipMemcpyAsync(slot + (size_t)first * N, c->d_fft2, (size_t)(batch - first) * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
   });
@@ -1677,7 +1679,7 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int N = c->N2;
   XyArgs a;
-  a.x = c->d_xbins; a.y = c->d_xbins + (size_t)batch * N; a.xypower = c->d_xypower; a.first_na = at->fft2_na; a.na_mask = c->fft2n_mask;
+  a.x = c->d_xbins; a.y = c->d_xbins + (size_t)batch * N; a.xypower = c->cfg.fft2_float_sparse ? nullptr : c->d_xypower; a.first_na = at->fft2_na; a.na_mask = c->fft2n_mask;
   a.n = N; a.batch = batch; a.sum_in = c->d_xysum; a.sum_out = c->d_xysum_alt; a.lines = c->d_wf_scratch;
   a.counter = at->wg_waterf_sum_counter; a.avgnum = c->cfg.waterfall_avgnum;
   { float4 *t = c->d_xysum; c->d_xysum = c->d_xysum_alt; c->d_xysum_alt = t; }   // ping-pong: group 0 reads while the last group writes
@@ -2125,11 +2127,95 @@ static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side poin
   p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
 }
 
+int lrh_set_exchange(lrh_ctx *c, lrh_exchange_fn fn, void *user)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  c->xfn = fn; c->xuser = user;
+  return LRH_OK;
+}
+// one exchange point: everything that fills the buffer is on the main stream by now; the caller's function puts the collective there too
+static int exchange(lrh_ctx *c, int which, int op, size_t count)
+{
+  if (!count) return LRH_OK;
+  void *ptr = nullptr;
+  { const int rc = lrh_exchange_ptr(c, which, &ptr); if (rc) return rc; }
+  if (c->xfn(c->xuser, which, op, ptr, count, (void *)c->stream) != 0) return fail(c, LRH_EDEVICE, "the registered exchange function failed");
+  return LRH_OK;
+}
+static int narrow_tail(lrh_ctx *c, lrh_ptrs *p);
+// Two coupled channels: the single-CPU order of wideband_dsp with the cross-channel exchanges at their places (include/linrad_hip.h,
+// lrh_set_exchange).  Everything is enqueued on the main stream -- the exchanges order the two ranks' streams against each other, so the
+// side-stream overlap of the single-channel schedules has no place here -- and nothing waits on the host (the linear blanker's resume
+// point excepted, see lrh_first_noise_blanker).
+static int dsp_coupled(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
+{
+  int rc;
+  const bool fuse = c->fuse_sumsq && c->timf2_mode == 1 && c->d_ss_part;
+  struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); c->f1_defer = false; if (c->f1_have) launch_parked_fft1(c); c->in_dsp--; } } guard{c};
+  c->in_dsp++;
+  c->f1_defer = fuse && c->fuse_fft1 && !c->fft1_big && c->cfg.fft1_n == 14;
+  while (nblocks > 0) {
+    const int B = nblocks < batch ? nblocks : batch;
+    if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
+    advance_fft1(c, p, B);
+    c->ss_defer = fuse; rc = lrh_fft1_c(c, p, B); c->ss_defer = false;
+    if (rc) return rc;
+    if ((rc = lrh_make_timf2(c, p, B))) return rc;
+    { std::vector<std::function<int(lrh_ctx *)>> q; q.swap(c->ss_queue); for (auto &op : q) if ((rc = op(c))) return rc; }
+    int cnt = 0;
+    if ((rc = lrh_blanker_begin(c, p, &cnt))) return rc;
+    if (cnt > 0) {
+      if ((rc = exchange(c, LRH_X_PWR, LRH_XOP_SUM, (size_t)cnt))) return rc;
+      size_t nw = 0;
+      if ((rc = lrh_blanker_weak_span(c, &nw))) return rc;
+      if (nw && (rc = exchange(c, LRH_X_WEAK, LRH_XOP_GATHER, nw))) return rc;
+    }
+    if ((rc = lrh_first_noise_blanker(c, p))) return rc;
+    if (cnt > 0) {
+      if ((rc = exchange(c, LRH_X_STAT, LRH_XOP_SUM, 2))) return rc;
+      if ((rc = lrh_blanker_finish(c, p))) return rc;
+    }
+    const int avail = (p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask;   // wcw.c:265-266
+    int k = avail >= 4 * c->N2 ? 1 + (avail - 4 * c->N2) / (4 * c->M2) : 0;
+    while (k > 0) {
+      const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+      const lrh_ptrs at = *p;
+      size_t n = 0;
+      if ((rc = lrh_make_fft2(c, p, kb)) || (rc = lrh_fft2_xy_begin(c, &at, kb, &n)) || (rc = exchange(c, LRH_X_BINS, LRH_XOP_GATHER, n)) ||
+          (rc = lrh_fft2_xy_finish(c, &at, kb)) || (rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
+      if (c->N3 && c->ms.mix1_selfreq >= 0) {
+        if (!c->pol_set) { if ((rc = narrow_tail(c, p))) return rc; }
+        else {
+          const int have = (p->timf3_pa - p->timf3_px + c->cfg.timf3_size) & c->timf3_mask;
+          int k3 = have < 2 * c->N3 ? 0 : 1 + (have - 2 * c->N3) / (2 * c->M3);
+          const int cap = c->cfg.max_fft3n / 2 > 0 ? c->cfg.max_fft3n / 2 : 1;
+          while (k3 > 0) {
+            const int k3b = k3 < cap ? k3 : cap;
+            size_t np = 0;
+            if ((rc = lrh_make_fft3_all(c, p, k3b)) || (rc = lrh_mix2_pol_begin(c, p, k3b, &np)) || (rc = exchange(c, LRH_X_POL, LRH_XOP_SUM, np)) ||
+                (rc = lrh_fft3_mix2(c, p, k3b))) return rc;
+            k3 -= k3b;
+          }
+        }
+      }
+      k -= kb;
+    }
+    nblocks -= B;
+  }
+  return LRH_OK;
+}
+
 int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   LRH_LOCK(c);
-  if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "two coupled channels need the exchanges between the stage calls (lrh_blanker_begin)");
+  if (c->cfg.blanker_channels == 2) {
+    if (!c->xfn) return fail(c, LRH_ESTATE, "two coupled channels: register the exchange function (lrh_set_exchange) or make the stage calls with the exchanges between them (lrh_blanker_begin)");
+    if (c->pend) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; }
+    return dsp_coupled(c, p, nblocks, batch);
+  }
   struct HostTimer { lrh_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double cpu0 = thread_cpu_ms();
                      static double thread_cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
                      ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;

@@ -1512,17 +1512,26 @@ __global__ __launch_bounds__(256) void k_xypower(XyArgs a)
   if (!complete) count = a.batch - start;
   const bool accumulate = g == 0 && a.counter > 0;
   float4 acc = accumulate ? a.sum_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int b = 0; b < count; b++) {
-    const size_t t = (size_t)(start + b) * a.n + i;
-    const float2 x = a.x[t], y = a.y[t];
+  constexpr int AHEAD = 8;                               // loads of that many transforms in flight (the sums themselves stay in transform order)
+  for (int b0 = 0; b0 < count; b0 += AHEAD) {
+  float2 xs[AHEAD], ys[AHEAD];
+#pragma unroll
+  for (int u = 0; u < AHEAD; u++)
+    if (b0 + u < count) { const size_t t = (size_t)(start + b0 + u) * a.n + i; xs[u] = a.x[t]; ys[u] = a.y[t]; }
+#pragma unroll
+  for (int u = 0; u < AHEAD; u++) {
+    const int b = b0 + u;
+    if (b >= count) break;
+    const float2 x = xs[u], y = ys[u];
     float4 v;
     v.x = x.x * x.x + x.y * x.y;
     v.y = y.x * y.x + y.y * y.y;
     v.z = -x.x * y.y + x.y * y.x;
     v.w = x.x * y.x + x.y * y.y;
-    a.xypower[(size_t)((a.first_na + start + b) & a.na_mask) * a.n + i] = v;
+    if (a.xypower) a.xypower[(size_t)((a.first_na + start + b) & a.na_mask) * a.n + i] = v;   // null: cfg.fft2_float_sparse, only the sums are kept
     if (b == 0 && !accumulate) acc = v;
     else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  }
   }
   if (complete) {
     const float t1 = acc.x + acc.y;
@@ -2176,13 +2185,17 @@ hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
 // exchange buffer <-> ring span of the coupled two-channel blanker: x[q-1] = ring[(pbeg+q) & mask], q = 1..count
 __global__ __launch_bounds__(256) void k_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  if (to_ring) ring[(pbeg + 1 + i) & mask] = x[i]; else x[i] = ring[(pbeg + 1 + i) & mask];
+  // four independent elements per thread, a wave's four accesses each a whole 256-byte row
+  const int i0 = blockIdx.x * 1024 + threadIdx.x;
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u; if (i < count) v[u] = to_ring ? x[i] : ring[(pbeg + 1 + i) & mask]; }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u; if (i < count) { if (to_ring) ring[(pbeg + 1 + i) & mask] = v[u]; else x[i] = v[u]; } }
 }
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st)
 {
-  if (count > 0) hipLaunchKernelGGL(k_span_copy, dim3((count + 255) / 256), dim3(256), 0, st, x, ring, pbeg, count, mask, to_ring);
+  if (count > 0) hipLaunchKernelGGL(k_span_copy, dim3((count + 1023) / 1024), dim3(256), 0, st, x, ring, pbeg, count, mask, to_ring);
   return hipGetLastError();
 }
 // the same for complex samples, x[i] = ring[(first + i) & mask]: the weak samples the two-channel linear blanker exchanges

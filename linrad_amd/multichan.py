@@ -156,3 +156,50 @@ def run_coupled(rx, nblocks, batch, dist, device=None, mix1=True, xy=False, pol=
                     k3 -= k3b
             k -= kb
         nblocks -= b
+
+
+XOP_SUM, XOP_GATHER = 0, 1
+
+
+def install_exchange(rx, dist, device=None):
+    """Two coupled channels through lrh_wideband_dsp: register the collectives the library asks for at its exchange points
+    (include/linrad_hip.h, lrh_set_exchange).  HIP receiver (device given): the collective is issued under the stream the library
+    names -- its own -- wrapped as a torch stream, in place on the library's device buffer, no host wait.  CPU oracle (gloo tests):
+    the buffer is host memory."""
+    import ctypes
+    import torch
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    streams = {}
+
+    def fn(which, op, ptr, count, stream):
+        if world == 1:
+            return 0                                            # nobody to talk to: the buffers already hold the sums / both slots are ours
+        n = count if op == XOP_SUM else 2 * count
+        if device is not None:
+            st = streams.get(stream)
+            if st is None:
+                st = streams[stream] = torch.cuda.ExternalStream(stream, device=device)
+            t = torch.as_tensor(_DevSpan(ptr, n), device=device)
+            with torch.cuda.stream(st):
+                if op == XOP_SUM:
+                    dist.all_reduce(t)
+                elif dist.get_backend() == "gloo":
+                    slots = [torch.empty(count, dtype=torch.float32, device=device) for _ in range(2)]
+                    dist.all_gather(slots, t[rank * count:(rank + 1) * count].clone())
+                    t[(1 - rank) * count:(2 - rank) * count].copy_(slots[1 - rank])
+                else:
+                    dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
+            return 0
+        buf = (ctypes.c_float * n).from_address(ptr)
+        t = torch.frombuffer(buf, dtype=torch.float32)
+        if op == XOP_SUM:
+            dist.all_reduce(t)
+        else:
+            assert world == 2, "Linrad has at most two RF channels (SURVEY F4)"
+            own = t[rank * count:(rank + 1) * count].clone()
+            slots = [torch.empty_like(own), torch.empty_like(own)]
+            dist.all_gather(slots, own)
+            t[(1 - rank) * count:(2 - rank) * count] = slots[1 - rank]
+        return 0
+    rx.set_exchange(fn)

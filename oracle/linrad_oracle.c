@@ -67,6 +67,7 @@ struct lro_ctx {
   /* linear blanker (lro_set_blanker_tables) */
   float amp_factor;            /* liminfo_amplitude_factor (sellim.c:119-155; blank1.c:143) */
   lrh_sellim wl_par; int wl_on, wl_fft2, wl_cnt1, wl_cnt2;   /* lro_wideband_limiter */
+  lrh_exchange_fn xfn; void *xuser;                          /* lro_set_exchange */
   lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
@@ -1563,9 +1564,75 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
 /* ------------------------------------------------------------------ orchestration */
 
 /* single-CPU branch of wideband_dsp, wcw.c:1036-1118, batched */
+int lro_set_exchange(lro_ctx *c, lrh_exchange_fn fn, void *user)
+{
+  if (!c || c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  c->xfn = fn; c->xuser = user;
+  return LRH_OK;
+}
+static int lro_exchange(lro_ctx *c, int which, int op, size_t count)
+{
+  void *ptr = NULL;
+  if (!count) return LRH_OK;
+  int rc = lro_exchange_ptr(c, which, &ptr);
+  if (rc) return rc;
+  return c->xfn(c->xuser, which, op, ptr, count, NULL) ? LRH_EDEVICE : LRH_OK;
+}
+/* two coupled channels through one call: the stage order of include/linrad_hip.h (lrh_set_exchange) with the exchanges made by the
+   registered function on host memory */
+static int lro_dsp_coupled(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
+{
+  int rc;
+  const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
+  while (nblocks > 0) {
+    const int B = nblocks < batch ? nblocks : batch;
+    if ((rc = lro_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
+    p->timf1p_px = (p->timf1p_px + B * c->M1 * (c->cfg.timf1_dword_input ? 8 : 4) * C) & c->timf1_bytemask;
+    p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
+    p->fft1_na = p->fft1_pa / (2 * c->N1);
+    for (int i = 0; i < B; i++) if (p->fft1_nm != c->fft1n_mask) p->fft1_nm++;
+    if ((rc = lro_fft1_c(c, p, B)) || (rc = lro_make_timf2(c, p, B))) return rc;
+    int cnt = 0;
+    if ((rc = lro_blanker_begin(c, p, &cnt))) return rc;
+    if (cnt > 0) {
+      size_t nw = 0;
+      if ((rc = lro_exchange(c, LRH_X_PWR, LRH_XOP_SUM, (size_t)cnt)) || (rc = lro_blanker_weak_span(c, &nw))) return rc;
+      if (nw && (rc = lro_exchange(c, LRH_X_WEAK, LRH_XOP_GATHER, nw))) return rc;
+    }
+    if ((rc = lro_first_noise_blanker(c, p))) return rc;
+    if (cnt > 0 && ((rc = lro_exchange(c, LRH_X_STAT, LRH_XOP_SUM, 2)) || (rc = lro_blanker_finish(c, p)))) return rc;
+    const int avail = ((p->timf2_pn2 - p->timf2_px + 4 * c->cfg.timf2pow_size) & c->timf2_mask);
+    int k = avail >= 4 * c->N2 ? 1 + (avail - 4 * c->N2) / (4 * c->M2) : 0;
+    while (k > 0) {
+      const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+      const lrh_ptrs at = *p;
+      size_t n = 0;
+      if ((rc = lro_make_fft2(c, p, kb)) || (rc = lro_fft2_xy_begin(c, &at, kb, &n)) || (rc = lro_exchange(c, LRH_X_BINS, LRH_XOP_GATHER, n)) ||
+          (rc = lro_fft2_xy_finish(c, &at, kb)) || (rc = lro_fft2_mix1_fixed(c, p, kb))) return rc;
+      if (c->N3 && c->ms.mix1_selfreq >= 0) {
+        const int have = (p->timf3_pa - p->timf3_px + c->cfg.timf3_size) & (c->cfg.timf3_size - 1);
+        int k3 = have < 2 * c->N3 ? 0 : 1 + (have - 2 * c->N3) / (2 * c->M3);
+        const int cap = c->cfg.max_fft3n / 2 > 0 ? c->cfg.max_fft3n / 2 : 1;
+        while (k3 > 0) {
+          const int k3b = k3 < cap ? k3 : cap;
+          size_t np = 0;
+          if ((rc = lro_make_fft3_all(c, p, k3b))) return rc;
+          if (c->pol_set && ((rc = lro_mix2_pol_begin(c, p, k3b, &np)) || (rc = lro_exchange(c, LRH_X_POL, LRH_XOP_SUM, np)))) return rc;
+          if ((rc = lro_fft3_mix2(c, p, k3b))) return rc;
+          k3 -= k3b;
+        }
+      }
+      k -= kb;
+    }
+    nblocks -= B;
+  }
+  return LRH_OK;
+}
+
 int lro_wideband_dsp(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 {
   int rc;
+  if (c && c->cfg.blanker_channels == 2) return c->xfn ? lro_dsp_coupled(c, p, nblocks, batch) : LRH_ESTATE;
   while (nblocks > 0) {
     int B = nblocks < batch ? nblocks : batch;
     if ((rc = lro_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;

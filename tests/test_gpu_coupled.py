@@ -75,3 +75,54 @@ def test_gather_exchange_and_batched_cross_products():
         assert np.count_nonzero(xyp[:, :, 1:]) == 0          # the partner slot was never filled: y = 0
     finally:
         dist.destroy_process_group()
+
+
+def test_coupled_wideband_dsp_equals_the_stage_calls():
+    """lrh_wideband_dsp with cfg.blanker_channels = 2 and the exchange function registered (lrh_set_exchange): one call enqueues what
+    multichan.run_coupled does with stage calls and collectives in between -- same rings to float32 rounding (one-rank group: the collectives
+    have nobody to talk to, the sequencing and the fused kernels are what is compared), at the sizes of BASELINE configs[3]"""
+    import torch
+    import torch.distributed as dist
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.multichan import install_exchange, run_coupled
+    from linrad_amd.workload import chain_config, strong_liminfo
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        res = []
+        for entry in ("dsp", "stages"):
+            os.environ["LRH_FUSE_FFT1"] = "0"
+            cfg = chain_config(14, 12, batch=32, fft3_n=10, mix2_n=8, rounds=4)
+            cfg.blanker_channels, cfg.timf1_channel_index = 2, 0
+            rx = open_hip(cfg)
+            os.environ.pop("LRH_FUSE_FFT1", None)
+            sy = synth_defaults(1 << 14, 0)
+            rx.timf1_write(synth_iq(sy, 0, cfg.timf1_bytes // 4))
+            rx.set_liminfo(strong_liminfo(sy, 14))
+            rx.set_mix1_selfreq(0.31 * 4096 + 0.3)
+            rx.set_pol(0.8, 0.36, -0.48)
+            if entry == "dsp":
+                install_exchange(rx, dist, dev)
+                for _ in range(3):
+                    rx.wideband_dsp(128, 32)
+            else:
+                for _ in range(3):
+                    run_coupled(rx, 128, 32, dist, device=dev, xy=True, pol=True)
+            bs = rx.blanker_state()
+            res.append(([rx.export(r) for r in (abi.RING_FFT1_SUMSQ, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT, abi.RING_FFT2_XYSUM,
+                                                abi.RING_WG_WATERF, abi.RING_TIMF3_FLOAT, abi.RING_BASEB_RAW)], rx.p.as_dict(), (bs.timf2_noise_floor, bs.stupid_bln_limit)))
+            rx.close()
+        assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+        # (k_fft1w is switched off for this comparison, LRH_FUSE_FFT1=0 below: its spectra differ from k_fft1's in the last bit, and a blanker
+        # decision on a sample within float32 rounding of the limit then differs too; fused against unfused is tests/test_gpu_fused.py)
+        names = ("sumsq", "timf2", "pwr", "fft2", "xysum", "wf", "timf3", "baseb")
+        for nm, a, b in zip(names, res[0][0], res[1][0]):
+            if nm == "sumsq":                               # the sums ride inside k_timf2 in the one call: association of a group's adds
+                assert np.max(np.abs(a - b) / (np.abs(b) + 1e-30)) < 1e-6
+            else:
+                assert np.array_equal(a, b), nm
+        assert np.count_nonzero(res[0][0][-1]) > 50 and np.any(res[0][0][5])
+    finally:
+        dist.destroy_process_group()

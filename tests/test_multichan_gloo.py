@@ -187,7 +187,7 @@ def test_coupled_linear_blanker_over_gloo():
         assert np.linalg.norm(t - ref) <= 2e-6 * np.linalg.norm(ref)
 
 
-def _chain_worker(rank, world, port, q):
+def _chain_worker(rank, world, port, q, entry="stages"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -210,7 +210,12 @@ def _chain_worker(rank, world, port, q):
     rx.set_pol(*d["pol"])
     if rank == 1:
         rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
-    run_coupled(rx, d["nblk"], 1, dist, xy=True, pol=True)
+    if entry == "stages":
+        run_coupled(rx, d["nblk"], 1, dist, xy=True, pol=True)
+    else:                                                   # the same through one lrh_wideband_dsp call: the library asks for the collectives
+        from linrad_amd.multichan import install_exchange
+        install_exchange(rx, dist)
+        rx.wideband_dsp(d["nblk"], 1)
     out = dict(baseb=rx.export(abi.RING_BASEB_RAW), baseb_pa=rx.p.baseb_pa, xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM), wf=rx.export(abi.RING_WG_WATERF),
                timf3=rx.export(abi.RING_TIMF3_FLOAT), fft2_na=rx.p.fft2_na, wptr=rx.p.wg_waterf_ptr)
     dist.barrier()
@@ -218,7 +223,8 @@ def _chain_worker(rank, world, port, q):
     q.put((rank, out))
 
 
-def test_two_channel_chain_over_gloo():
+@pytest.mark.parametrize("entry", ["stages", "dsp"])
+def test_two_channel_chain_over_gloo(entry):
     """The whole coupled chain with the collectives of linrad_amd/multichan.py: two all-reduces per blanker call and one
     all-gather of the new fft2 bins per make_fft2, one all-reduce of the polarisation sums per fft3_mix2.  Both ranks must end
     with the compiled two-channel reference's fft2_xypower / fft2_xysum and waterfall lines, each with its own channel of
@@ -227,7 +233,7 @@ def test_two_channel_chain_over_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, q, entry)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in procs)
