@@ -383,8 +383,10 @@ int lrh_timf1_write_packed18(lrh_ctx *ctx, const void *src, int byte_offset, int
    timf2_routine (fft1_c, make_timf2, first_noise_blanker; wcw.c:401-441), second_fft (make_fft2; wcw.c:250-304) and
    narrowband_dsp (fft2_mix1_*; wcw.c:1240-1405), ordered by its events EVENT_TIMF1 / TIMF2 / FFT2 / FFT1_READY
    (thrdef.h:136-170).  Every entry point of this library may be called from any host thread at any time: a context
-   serialises its callers for the microseconds a call needs to do its pointer bookkeeping and enqueue its device work,
-   and the device executes the work in the order of the calls.  So the reference's event order is all a caller has to
+   serialises its callers while a call does its pointer bookkeeping and enqueues its device work (a batched lrh_wideband_dsp
+   that has run several rounds ahead of the device sleeps inside that lock until a staging slot is free -- milliseconds), and
+   the device executes the work in the order of the calls.  The producer side -- lrh_timf1_write_async / lrh_timf1_write_wait --
+   has a lock of its own and is never held up by a stage call: an input thread hands its block over at once.  So the reference's event order is all a caller has to
    keep, exactly as for the CPU functions; a stage call has "completed" for that purpose when it returns (its writes
    are stream-ordered ahead of everything enqueued later).  One lrh_ptrs may be shared by the threads like the
    reference's globals are -- each stage advances only its own fields -- or each thread may keep the fields it owns.
@@ -561,6 +563,9 @@ int lrh_export_device(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offs
    caller chain its own device work -- e.g. an RCCL all-reduce of the exported block -- with stream/event waits only. */
 int lrh_export_device_async(lrh_ctx *ctx, lrh_ring ring, void *dst_device, size_t offset_elems, size_t count_elems);
 void *lrh_stream(lrh_ctx *ctx);
+/* A consumer ordered only on lrh_stream (RCCL on a cached lrh_exchange_ptr, a torch ExternalStream) must call lrh_flush first: after a
+   batched lrh_wideband_dsp the launches of its last round may still be held back (see there); lrh_flush issues them without waiting. */
+int lrh_flush(lrh_ctx *ctx);
 int lrh_sync(lrh_ctx *ctx);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/linrad_hip.h"
@@ -70,7 +71,7 @@ struct lrh_ctx {
   // is the order of the calls (one main stream), which the caller's events already make the reference's order.
   std::recursive_mutex mtx;
   // fft1_b workers: handle h >= 1 launches on its own stream so that transforms of different workers overlap
-  hipStream_t hstream[LRH_MAX_HANDLES] = {}; hipEvent_t hev[LRH_MAX_HANDLES] = {}, hev_start = nullptr; bool hpending[LRH_MAX_HANDLES] = {}, hread[LRH_MAX_HANDLES] = {};
+  hipStream_t hstream[LRH_MAX_HANDLES] = {}; hipEvent_t hev[LRH_MAX_HANDLES] = {}, hev_start = nullptr; bool hpending[LRH_MAX_HANDLES] = {}; std::atomic<bool> hread[LRH_MAX_HANDLES] = {};
   lrh_config cfg;
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
@@ -84,7 +85,8 @@ struct lrh_ctx {
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
   hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
-  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; bool in_pending = false, fft1_read_valid = false;
+  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
+  std::mutex mtx_in;                  // the producer side (lrh_timf1_write_async / _wait) has a lock of its own: an input thread is never held up by a stage call that sleeps on the staging ring
   hipStream_t stream_sel = nullptr;  // the limiter kernels: one workgroup for ~0.5 ms, kept off the side stream (the blanker of the next round queues there)
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
@@ -1040,8 +1042,11 @@ void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 {
-  LRH_LOCK(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
+  // not the context's lock: what this touches besides its own stream are flags the stage calls set or take atomically and events that exist
+  // for the life of the context
+  std::lock_guard<std::mutex> lk_in(c->mtx_in);
+  hipSetDevice(c->cfg.device);
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
   const int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
@@ -1058,7 +1063,8 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 int lrh_timf1_write_wait(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;
-  LRH_LOCK(c);
+  std::lock_guard<std::mutex> lk_in(c->mtx_in);
+  hipSetDevice(c->cfg.device);
   if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
   return LRH_OK;
 }
@@ -1127,7 +1133,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->hev_start, 0));
     if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->ev_in, 0));      // every worker waits for the producer's copy
     c->cur = c->hstream[handle];
-  } else if (c->in_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0)); c->in_pending = false; }   // samples of lrh_timf1_write_async
+  } else if (c->in_pending.exchange(false)) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0));   // samples of lrh_timf1_write_async (a copy recorded meanwhile raises the flag again)
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;       // bytes per complex sample (fft1.c:420 / :526)
@@ -2558,6 +2564,15 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
   HIPCHK(c, hipMemcpyAsync(dst, c->d_fft1net, (size_t)batch * c->N1 * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
+}
+
+// Issue what lrh_wideband_dsp still holds back from its last round (the one-round-late schedule kept across calls) without waiting for it:
+// afterwards everything the calls so far have produced is ordered on the context's stream, which is what a consumer chained on that stream
+// (lrh_stream: a collective, a torch ExternalStream) needs.  Every entry point that reads or changes results does this by itself.
+int lrh_flush(lrh_ctx *c)
+{
+  LRH_ENTER(c);
+  return c ? LRH_OK : LRH_EINVAL;
 }
 
 int lrh_sync(lrh_ctx *c)
