@@ -29,7 +29,7 @@
 #include "linrad_hip.h"
 
 /* ---- events: binary, auto-reset, like lir_set_event / lir_await_event (lxsys.c:415-447) ---- */
-enum { EVENT_TIMF1, EVENT_TIMF2, EVENT_FFT2, EVENT_FFT1_READY, EVENT_SPACE, EVENT_DO_FFT1B1, EVENT_FFT1B_DONE = EVENT_DO_FFT1B1 + 6, NEVENTS };
+enum { EVENT_TIMF1, EVENT_TIMF2, EVENT_FFT2, EVENT_FFT1_READY, EVENT_DO_FFT1B1, EVENT_FFT1B_DONE = EVENT_DO_FFT1B1 + 6, NEVENTS };
 static pthread_mutex_t ev_mutex[NEVENTS];
 static pthread_cond_t ev_cond[NEVENTS];
 static int ev_flag[NEVENTS];
@@ -44,7 +44,8 @@ static void lir_await_event(int n)
 
 /* a failed stage ends the run (lirerr posts EVENT_KILL_ALL and every loop polls kill_all_flag, lxsys.c:494-505): wake everybody */
 static volatile int failed;
-static void fail_all(void) { failed = 1; for (int i = 0; i < NEVENTS; i++) lir_set_event(i); }
+static void space_freed(void);
+static void fail_all(void) { failed = 1; for (int i = 0; i < NEVENTS; i++) lir_set_event(i); space_freed(); }
 
 /* ---- the "globals" ---- */
 static lrh_ctx *rx;
@@ -61,14 +62,15 @@ static void fail_all(void);
 
 static int timf1_avail(void) { return (timf1p_pa - p.timf1p_px + cfg.timf1_bytes) & (cfg.timf1_bytes - 1); }
 static int fft2_ready(void) { return ((p.timf2_pn2 - p.timf2_px + 4 * cfg.timf2pow_size) & (4 * cfg.timf2pow_size - 1)) >= 4 * N2; }   /* wcw.c:265 */
-/* room check of the producers (the reference counts overruns instead: "BUFFER ERROR", wcw.c:770-785) */
-static int rings_have_room(void)
-{
-  const int fft1_used = (p.fft1_na - p.fft1_nx + cfg.max_fft1n) & (cfg.max_fft1n - 1);
-  const int timf2_used = (p.timf2_pa - p.timf2_px + 4 * cfg.timf2pow_size) & (4 * cfg.timf2pow_size - 1);
-  const int fft2_used = (p.fft2_na - p.fft2_nx + cfg.max_fft2n) & (cfg.max_fft2n - 1);
-  return fft1_used < cfg.max_fft1n / 2 && timf2_used < 2 * cfg.timf2pow_size && fft2_used < cfg.max_fft2n / 2;
-}
+/* Room in the rings: a producer waits until its consumer has moved on (the reference counts overruns instead: "BUFFER ERROR",
+   wcw.c:770-785).  One condition variable, broadcast, because several producers may wait at once. */
+static pthread_mutex_t sp_mutex = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t sp_cond = PTHREAD_COND_INITIALIZER;
+static void space_freed(void) { pthread_mutex_lock(&sp_mutex); pthread_cond_broadcast(&sp_cond); pthread_mutex_unlock(&sp_mutex); }
+#define AWAIT_SPACE(cond) do { pthread_mutex_lock(&sp_mutex); while (!(cond) && !failed) pthread_cond_wait(&sp_cond, &sp_mutex); pthread_mutex_unlock(&sp_mutex); } while (0)
+static int fft1_used(void) { return (p.fft1_na - p.fft1_nx + cfg.max_fft1n) & (cfg.max_fft1n - 1); }
+static int timf2_used(void) { return (p.timf2_pa - p.timf2_px + 4 * cfg.timf2pow_size) & (4 * cfg.timf2pow_size - 1); }
+static int fft2_used(void) { return (p.fft2_na - p.fft2_nx + cfg.max_fft2n) & (cfg.max_fft2n - 1); }
 
 /* ---- rx input thread ---- */
 static void *input_thread(void *arg)
@@ -76,7 +78,7 @@ static void *input_thread(void *arg)
   (void)arg;
   const int chunk = M1;                       /* one "soundcard read" */
   for (long done = 0; done < (long)nblk_total * M1 && !failed; done += chunk) {
-    while ((timf1_avail() > cfg.timf1_bytes / 2 || !rings_have_room()) && !failed) lir_await_event(EVENT_SPACE);
+    AWAIT_SPACE(timf1_avail() <= cfg.timf1_bytes / 2);
     if (timf1p_pa == 0) CHK(lrh_timf1_write_wait(rx));        /* once per lap: every copy of the previous lap has left the arena */
     lrh_synth_iq(&sig, done, chunk, (int16_t *)(timf1_char + timf1p_pa));
     CHK(lrh_timf1_write_async(rx, timf1_char + timf1p_pa, timf1p_pa, chunk * 4));
@@ -120,6 +122,9 @@ static void *wideband_thread(void *arg)
     lir_await_event(EVENT_TIMF1);
     while (timf1_avail() >= timf1_blockbytes && !failed) {
       if (inflight == workers) { retire(oldest); oldest = (oldest + 1) % workers; inflight--; }
+      /* the input thread may be a long way ahead (its copies do not wait for the stage calls): transforms handed out and not yet
+         consumed stay within half the fft1 ring */
+      AWAIT_SPACE(fft1_used() + inflight < cfg.max_fft1n / 2);
       job[next].inptr = p.timf1p_px; job[next].out = out; job[next].busy = 1;
       out = (out + 2 * N1) & (cfg.max_fft1n * 2 * N1 - 1);
       p.timf1p_px = (p.timf1p_px + timf1_blockbytes) & (cfg.timf1_bytes - 1);
@@ -142,11 +147,12 @@ static void *timf2_thread(void *arg)
   for (;;) {
     lir_await_event(EVENT_TIMF2);
     while (p.fft1_na != p.fft1_nb && !failed) {
+      AWAIT_SPACE(timf2_used() < 2 * cfg.timf2pow_size);
       CHK(lrh_fft1_c(rx, P, 1));
       CHK(lrh_make_timf2(rx, P, 1));
       CHK(lrh_first_noise_blanker(rx, P));       /* per block: see the header comment */
       if (fft2_ready()) lir_set_event(EVENT_FFT2);
-      lir_set_event(EVENT_SPACE);
+      space_freed();
     }
     if (failed || (wide_done && p.fft1_na == p.fft1_nb)) break;
   }
@@ -162,9 +168,10 @@ static void *fft2_thread(void *arg)
   for (;;) {
     lir_await_event(EVENT_FFT2);
     while (fft2_ready() && !failed) {
+      AWAIT_SPACE(fft2_used() < cfg.max_fft2n / 2);
       CHK(lrh_make_fft2(rx, P, 1));
       lir_set_event(EVENT_FFT1_READY);
-      lir_set_event(EVENT_SPACE);
+      space_freed();
     }
     if (failed || (timf2_done && !fft2_ready())) break;
   }
@@ -179,7 +186,7 @@ static void *narrowband_thread(void *arg)
   (void)arg;
   for (;;) {
     lir_await_event(EVENT_FFT1_READY);
-    while (p.fft2_nx != p.fft2_na && !failed) { CHK(lrh_fft2_mix1_fixed(rx, P, 1)); lir_set_event(EVENT_SPACE); }
+    while (p.fft2_nx != p.fft2_na && !failed) { CHK(lrh_fft2_mix1_fixed(rx, P, 1)); space_freed(); }
     if (failed || (fft2_done && p.fft2_nx == p.fft2_na)) break;
   }
   return NULL;

@@ -236,6 +236,9 @@ typedef enum lrh_ring {
   LRH_RING_FFT2_XYPOWER,        /* float [max_fft2n][N2][4] = TWOCHAN_POWER {x2,y2,im_xy,re_xy} (globdef.h:1371-1376);
                                    two coupled channels only, filled by lrh_fft2_xy_finish                */
   LRH_RING_FFT2_XYSUM,          /* float [N2][4]: fft2_xysum, the running sum of the current waterfall group */
+  LRH_RING_FFT1_CORRSUM,        /* float [fft1_sumsq_bufsize][2]: fft1_corrsum (correlation spectrum, lrh_set_correlation)   */
+  LRH_RING_FFT1_SLOWCORR,       /* float [N1][2]: fft1_slowcorr                                                               */
+  LRH_RING_FFT1_SLOWCORR_TOT,   /* double [N1][2]: fft1_slowcorr_tot (count in elements of 8 bytes)                           */
   LRH_RING_COUNT
 } lrh_ring;
 
@@ -431,7 +434,7 @@ int lrh_make_timf2(lrh_ctx *ctx, lrh_ptrs *p, int batch);
                               blnfit_range (the search reads the summed power that far ahead)
      lrh_blanker_weak_span    n*2 = floats per slot of LRH_X_WEAK for this call (0: nothing to gather)
      -> all-gather of the two slots of LRH_X_WEAK (beside the all-reduce of LRH_X_PWR)  */
-enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2, LRH_X_POL = 3, LRH_X_WEAK = 4 };
+enum { LRH_X_PWR = 0, LRH_X_STAT = 1, LRH_X_BINS = 2, LRH_X_POL = 3, LRH_X_WEAK = 4, LRH_X_SPEC = 5 };
 int lrh_blanker_begin(lrh_ctx *ctx, const lrh_ptrs *p, int *count);
 int lrh_blanker_weak_span(lrh_ctx *ctx, size_t *count);
 int lrh_blanker_finish(lrh_ctx *ctx, lrh_ptrs *p);
@@ -454,6 +457,26 @@ int lrh_fft2_xy_finish(lrh_ctx *ctx, const lrh_ptrs *at, int batch);
 int lrh_exchange_ptr(lrh_ctx *ctx, int which, void **device_ptr);           /* for collectives on lrh_stream(ctx) */
 int lrh_exchange_read(lrh_ctx *ctx, int which, float *dst, size_t off, size_t count);   /* synchronous, for tests / host exchange */
 int lrh_exchange_write(lrh_ctx *ctx, int which, const float *src, size_t off, size_t count);
+/* Correlation spectrum of the two channels (genparm[FFT1_CORRELATION_SPECTRUM] = 1, buf.c:1223-1233): beside fft1_sumsq, fft1_c forms
+   per bin fft1_corrsum = sum over the averaging period of 2 X conj(Y) (fft1.c:4146-4150, 4189-4193: re = 2 (Xre Yre + Xim Yim),
+   im = 2 (Xim Yre - Xre Yim), X = channel 0), and update_fft1_slowsum keeps its sliding sum over wg_fft_avg2num periods in
+   fft1_slowcorr (refreshed from scratch like fft1_slowsum, wide_graph.c:1033-1050, no floor) and the sum of everything since the last
+   reset in fft1_slowcorr_tot (double; slowcorr_tot_avgnum transforms; fft1.c:4584-4603).  A cross spectrum needs both channels' bins: with
+   one channel per context this is an all-gather of the new transforms, 8 bytes per bin and transform -- an opt-in for installations
+   that display the correlation spectrum:
+     lrh_set_correlation(ctx, 1)                        once (0: off, rings freed; also clears like clear_fft1_correlation, fft1.c:5386)
+     at = *p;  lrh_fft1_c(ctx, p, batch);               each context's own sums as always
+     lrh_fft1_corr_begin(ctx, &at, batch, &count)       the batch's transforms (ring slots from at.fft1_nb) into slot
+                                                        cfg.timf1_channel_index of LRH_X_SPEC: float [2][count], count = batch * 2 * N1
+     -> all-gather of the two slots
+     lrh_fft1_corr_finish(ctx, &at, batch)              fft1_corrsum of the periods the batch touches, fft1_slowcorr / _tot after every
+                                                        completed period, in the order of update_fft1_slowsum
+   Both contexts end with the same rings.  lrh_wideband_dsp makes these calls itself on coupled contexts when the mode is on.
+   (fft1_correlation_flag >= 2, the correlation receiver with its double-precision mixer, is not built.) */
+int lrh_set_correlation(lrh_ctx *ctx, int on);
+int lrh_fft1_corr_begin(lrh_ctx *ctx, const lrh_ptrs *at, int batch, size_t *count);
+int lrh_fft1_corr_finish(lrh_ctx *ctx, const lrh_ptrs *at, int batch);
+int lrh_get_slowcorr_tot_avgnum(lrh_ctx *ctx, int *n);
 int lrh_first_noise_blanker(lrh_ctx *ctx, lrh_ptrs *p);
 /* install / remove the linear blanker's tables (see lrh_blanker_tables); the arrays are copied */
 int lrh_set_blanker_tables(lrh_ctx *ctx, const lrh_blanker_tables *t);   /* NULL: clever blanker off again */

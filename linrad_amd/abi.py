@@ -13,8 +13,9 @@ LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2,
 
 (RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
  RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT,
- RING_TIMF2_BLOCKPOWER, RING_FFT3, RING_BASEB_RAW, RING_FFT2_XYPOWER, RING_FFT2_XYSUM) = range(16)
-_RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16}
+ RING_TIMF2_BLOCKPOWER, RING_FFT3, RING_BASEB_RAW, RING_FFT2_XYPOWER, RING_FFT2_XYSUM, RING_FFT1_CORRSUM, RING_FFT1_SLOWCORR,
+ RING_FFT1_SLOWCORR_TOT) = range(19)
+_RING_DTYPE = {RING_TIMF1: np.int16, RING_WG_WATERF: np.int16, RING_FFT1_SLOWCORR_TOT: np.float64}
 
 
 class LrhConfig(C.Structure):
@@ -222,6 +223,10 @@ class StageAPI:
         self._proto("blanker_finish", [vp, C.POINTER(LrhPtrs)])
         self._proto("blanker_weak_span", [vp, C.POINTER(C.c_size_t)])
         self._proto("fft2_xy_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
+        self._proto("set_correlation", [vp, C.c_int])
+        self._proto("fft1_corr_begin", [vp, C.POINTER(LrhPtrs), C.c_int, C.POINTER(C.c_size_t)])
+        self._proto("fft1_corr_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
+        self._proto("get_slowcorr_tot_avgnum", [vp, ip])
         self._proto("fft2_xy_finish", [vp, C.POINTER(LrhPtrs), C.c_int])
         self._proto("set_pol", [vp, C.c_float, C.c_float, C.c_float])
         self._proto("set_combine_weights", [vp, C.c_float, C.c_float, C.c_float, C.c_float])
@@ -314,13 +319,30 @@ class StageAPI:
             self._chk(self._f("set_foldcorr")(self.ctx, self._fptr(t)), "set_foldcorr")
 
     # ---- two coupled RF channels (cfg.blanker_channels = 2): see include/linrad_hip.h
-    X_PWR, X_STAT, X_BINS, X_POL, X_WEAK = 0, 1, 2, 3, 4
+    X_PWR, X_STAT, X_BINS, X_POL, X_WEAK, X_SPEC = 0, 1, 2, 3, 4, 5
 
     def ptrs_copy(self):
         """the pointer state as it is now (`at` of lrh_fft2_xy_begin / finish: taken before make_fft2)"""
         q = LrhPtrs()
         C.memmove(C.byref(q), C.byref(self.p), C.sizeof(LrhPtrs))
         return q
+
+    def set_correlation(self, on=True):
+        """correlation spectrum of two coupled channels (genparm[FFT1_CORRELATION_SPECTRUM] = 1): fft1_corrsum / fft1_slowcorr / _tot"""
+        self._chk(self._f("set_correlation")(self.ctx, int(bool(on))), "set_correlation")
+
+    def fft1_corr_begin(self, at, batch=1):
+        n = C.c_size_t()
+        self._chk(self._f("fft1_corr_begin")(self.ctx, C.byref(at), batch, C.byref(n)), "fft1_corr_begin")
+        return n.value
+
+    def fft1_corr_finish(self, at, batch=1):
+        self._chk(self._f("fft1_corr_finish")(self.ctx, C.byref(at), batch), "fft1_corr_finish")
+
+    def slowcorr_tot_avgnum(self):
+        n = C.c_int()
+        self._chk(self._f("get_slowcorr_tot_avgnum")(self.ctx, C.byref(n)), "get_slowcorr_tot_avgnum")
+        return n.value
 
     def fft2_xy_begin(self, at, batch=1):
         n = C.c_size_t()
@@ -599,7 +621,8 @@ class StageAPI:
                 RING_TIMF3_FLOAT: c.timf3_size, RING_TIMF2_BLOCKPOWER: c.timf2_blockpower_size,
                 RING_FFT3: c.max_fft3n * 2 * (1 << c.fft3_n) if c.fft3_n else 0,
                 RING_BASEB_RAW: 2 * c.baseband_size, RING_FFT2_XYPOWER: c.max_fft2n * 4 * self.N2,
-                RING_FFT2_XYSUM: 4 * self.N2}[ring]
+                RING_FFT2_XYSUM: 4 * self.N2, RING_FFT1_CORRSUM: 2 * c.fft1_sumsq_bufsize, RING_FFT1_SLOWCORR: 2 * self.N1,
+                RING_FFT1_SLOWCORR_TOT: 2 * self.N1}[ring]
 
     def export(self, ring, offset=0, count=None):
         if count is None:

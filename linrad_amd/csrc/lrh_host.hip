@@ -48,6 +48,7 @@ hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int 
 hipError_t launch_blockpower(const BlockpowerArgs &a, int nblocks, hipStream_t st);
 hipError_t launch_fft3(int log2n, const Fft3Args &a, int batch, hipStream_t st);
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st);
+hipError_t launch_corrsum(const CorrArgs &a, hipStream_t st);
 hipError_t launch_spur_patch(const SpurPatchArgs &a, int nspurs, int ngroups, hipStream_t st);
 hipError_t launch_spur_acquire(const SpurArgs &a, int pnt, int *result, hipStream_t st);
 hipError_t launch_mix2_back(int log2n, const Mix2Args &a, int batch, hipStream_t st);
@@ -103,6 +104,7 @@ struct lrh_ctx {
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
+  bool corr_on = false; int slowcorr_tot_avgnum = 0; float2 *d_xspec = nullptr, *d_corrsum = nullptr, *d_slowcorr = nullptr; double2 *d_slowcorr_tot = nullptr;   // lrh_set_correlation
   lrh_exchange_fn xfn = nullptr; void *xuser = nullptr;     // lrh_set_exchange: collectives of two coupled channels inside lrh_wideband_dsp
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
@@ -369,7 +371,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -1317,7 +1319,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     Fft1wArgs w; memset(&w, 0, sizeof w);
     w.timf1 = f.timf1; w.ring_mask = f.ring_mask; w.p0_first = f.p0_first; w.step = f.step; w.chan_count = f.chan_count; w.chan_index = f.chan_index;
     w.window = f.window; w.filtercorr = f.filtercorr; w.tw = f.tw;
-    w.spec = c->d_fft1; w.first_nb = a.first_nb; w.nb_mask = a.nb_mask; w.keep_spec = c->cfg.fft1_float_sparse ? 0 : 1;
+    w.spec = c->d_fft1; w.first_nb = a.first_nb; w.nb_mask = a.nb_mask; w.keep_spec = (c->cfg.fft1_float_sparse && !c->corr_on) ? 0 : 1;
     w.pack_cur = a.pack_cur; w.pack_prev = a.pack_prev; w.timf2w = a.timf2w; w.pwr = a.pwr; w.pa_first = a.pa_first; w.mask = a.mask; w.ampfac = a.ampfac;
     w.have_prev = c->timf2_primed ? 1 : 0;
     w.ss_ring = sa.sumsq; w.ss_part = part; w.ss_mask = sa.sumsq_mask; w.ss_avg = sa.avg; w.ss_c0 = sa.c0; w.ss_pa0 = sa.pa0;
@@ -1516,6 +1518,7 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
   if (which == LRH_X_PWR) { *ptr = c->d_xbuf; *cap = (size_t)c->cfg.timf2pow_size; }
   else if (which == LRH_X_STAT) { *ptr = c->d_xstat; *cap = 2; }
   else if (which == LRH_X_BINS) { *ptr = (float *)c->d_xbins; *cap = (size_t)4 * c->cfg.max_fft2n * c->N2; }
+  else if (which == LRH_X_SPEC) { if (!c->d_xspec) return fail(c, LRH_ESTATE, "lrh_set_correlation first"); *ptr = (float *)c->d_xspec; *cap = (size_t)4 * c->cfg.max_batch * c->N1; }
   else if (which == LRH_X_POL) { if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured"); *ptr = (float *)c->d_xpol; *cap = (size_t)4 * c->cfg.max_fft3n * c->Nm2; }
   else return LRH_EINVAL;
   return LRH_OK;
@@ -2133,6 +2136,54 @@ static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side poin
   p->fft1_nm = p->fft1_nm + B > c->fft1n_mask ? c->fft1n_mask : p->fft1_nm + B;
 }
 
+// ---- correlation spectrum of two coupled channels (include/linrad_hip.h): fft1_corrsum, fft1_slowcorr, fft1_slowcorr_tot
+int lrh_set_correlation(lrh_ctx *c, int on)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (void **q_ : { (void **)&c->d_xspec, (void **)&c->d_corrsum, (void **)&c->d_slowcorr, (void **)&c->d_slowcorr_tot }) if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  c->corr_on = false; c->slowcorr_tot_avgnum = 0;
+  if (!on) return LRH_OK;
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_xspec, (size_t)2 * c->cfg.max_batch * c->N1, false)) || (rc = dev_alloc(c, &c->d_corrsum, (size_t)c->cfg.fft1_sumsq_bufsize)) ||
+      (rc = dev_alloc(c, &c->d_slowcorr, (size_t)c->N1)) || (rc = dev_alloc(c, &c->d_slowcorr_tot, (size_t)c->N1))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->corr_on = true;
+  return LRH_OK;
+}
+int lrh_get_slowcorr_tot_avgnum(lrh_ctx *c, int *n) { LRH_LOCK(c); if (!c || !n) return LRH_EINVAL; *n = c->slowcorr_tot_avgnum; return LRH_OK; }
+int lrh_fft1_corr_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
+{
+  LRH_ENTER(c);
+  if (!c || !at || !count || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first");
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  const int N = c->N1, nb = at->fft1_nb & c->fft1n_mask;
+  float2 *slot = c->d_xspec + (size_t)(c->cfg.timf1_channel_index & 1) * batch * N;
+  const int first = std::min(batch, c->cfg.max_fft1n - nb);            // the ring span may wrap once
+  HIPCHK(c, hipMemcpyAsync(slot, c->d_fft1 + (size_t)nb * N, (size_t)first * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
+  if (batch > first) HIPCHK(c, hipMemcpyAsync(slot + (size_t)first * N, c->d_fft1, (size_t)(batch - first) * N * sizeof(float2), hipMemcpyDeviceToDevice, c->cur));
+  *count = (size_t)batch * 2 * N;
+  return LRH_OK;
+}
+int lrh_fft1_corr_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
+{
+  LRH_ENTER(c);
+  if (!c || !at || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first");
+  const int N = c->N1;
+  CorrArgs a; memset(&a, 0, sizeof a);
+  a.x = c->d_xspec; a.y = c->d_xspec + (size_t)batch * N; a.n = N; a.batch = batch;
+  a.corrsum = c->d_corrsum; a.sumsq_mask = c->sumsq_mask; a.avg = c->cfg.fft_avg1num; a.c0 = at->fft1_sumsq_counter; a.pa0 = at->fft1_sumsq_pa;
+  a.slowcorr = c->d_slowcorr; a.tot = c->d_slowcorr_tot; a.bufsize = c->cfg.fft1_sumsq_bufsize; a.avg2 = c->cfg.fft_avg2num;
+  a.nupd = (at->fft1_sumsq_counter + batch) / a.avg; a.recalc0 = at->fft1_sumsq_recalc; a.step = c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
+  { ProfScope ps(c, "corrsum"); HIPCHK(c, launch_corrsum(a, c->cur)); }
+  c->slowcorr_tot_avgnum += a.nupd * a.avg;
+  return LRH_OK;
+}
+
 int lrh_set_exchange(lrh_ctx *c, lrh_exchange_fn fn, void *user)
 {
   LRH_ENTER(c);
@@ -2166,10 +2217,15 @@ static int dsp_coupled(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     const int B = nblocks < batch ? nblocks : batch;
     if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
     advance_fft1(c, p, B);
+    const lrh_ptrs at1 = *p;
     c->ss_defer = fuse; rc = lrh_fft1_c(c, p, B); c->ss_defer = false;
     if (rc) return rc;
     if ((rc = lrh_make_timf2(c, p, B))) return rc;
     { std::vector<std::function<int(lrh_ctx *)>> q; q.swap(c->ss_queue); for (auto &op : q) if ((rc = op(c))) return rc; }
+    if (c->corr_on) {                                   // the spectra are in the ring by now (k_fft1w stores every bin in this mode)
+      size_t ns = 0;
+      if ((rc = lrh_fft1_corr_begin(c, &at1, B, &ns)) || (rc = exchange(c, LRH_X_SPEC, LRH_XOP_GATHER, ns)) || (rc = lrh_fft1_corr_finish(c, &at1, B))) return rc;
+    }
     int cnt = 0;
     if ((rc = lrh_blanker_begin(c, p, &cnt))) return rc;
     if (cnt > 0) {
@@ -2482,6 +2538,9 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     case LRH_RING_BASEB_RAW: src = c->d_baseb; total = 2 * (size_t)c->cfg.baseband_size; break;
     case LRH_RING_FFT2_XYPOWER: if (!c->d_xypower) return fail(c, LRH_ESTATE, "blanker_channels != 2"); src = c->d_xypower; total = (size_t)c->cfg.max_fft2n * 4 * c->N2; break;
     case LRH_RING_FFT2_XYSUM: if (!c->d_xysum) return fail(c, LRH_ESTATE, "blanker_channels != 2"); src = c->d_xysum; total = 4 * (size_t)c->N2; break;
+    case LRH_RING_FFT1_CORRSUM: if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first"); src = c->d_corrsum; total = 2 * (size_t)c->cfg.fft1_sumsq_bufsize; break;
+    case LRH_RING_FFT1_SLOWCORR: if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first"); src = c->d_slowcorr; total = 2 * (size_t)c->N1; break;
+    case LRH_RING_FFT1_SLOWCORR_TOT: if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first"); src = c->d_slowcorr_tot; total = 2 * (size_t)c->N1; esz = 8; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

@@ -585,6 +585,68 @@ __global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_t
 
 
 // =====================================================================================================
+// correlation spectrum (fft1_correlation_flag == 1)
+// =====================================================================================================
+// fft1_c's second sum (fft1.c:4146-4150, 4189-4193): per bin and averaging period 2 X conj(Y), "=" for the period's first transform
+// and "+=" after, in transform order -- k_sumsq's group arithmetic on the two channels' exchanged transforms.
+__global__ __launch_bounds__(256) void k_corrsum(CorrArgs a)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int g = blockIdx.y;
+  const int start = g == 0 ? 0 : g * a.avg - a.c0;
+  int count = a.avg - (g == 0 ? a.c0 : 0);
+  if (count > a.batch - start) count = a.batch - start;
+  const bool accumulate = g == 0 && a.c0 > 0;
+  float2 *dst = a.corrsum + ((a.pa0 + g * a.n) & a.sumsq_mask);
+  float2 acc = accumulate ? dst[i] : make_float2(0.f, 0.f);
+  for (int b = 0; b < count; b++) {
+    const size_t t = (size_t)(start + b) * a.n + i;
+    const float2 x = a.x[t], y = a.y[t];
+    const float re = 2 * (x.x * y.x + x.y * y.y), im = 2 * (x.y * y.x - x.x * y.y);
+    if (b == 0 && !accumulate) acc = make_float2(re, im); else { acc.x += re; acc.y += im; }
+  }
+  dst[i] = acc;
+}
+// update_fft1_slowsum's part for the correlation sums (fft1.c:4584-4603 with new_fft1_averages, wide_graph.c:1033-1050), one update
+// per completed averaging period, replayed per bin in order: inside the rolling refresh window the sliding sum is rebuilt from its
+// wg_fft_avg2num periods, outside it takes the newest period and drops the oldest; the grand total adds every period (double).
+__global__ __launch_bounds__(64) void k_slowcorr(CorrArgs a)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  const int mask = a.bufsize - 1, last = a.n - 1;
+  float2 slow = a.slowcorr[i];
+  double2 tot = a.tot[i];
+  int recalc = a.recalc0;
+  for (int e = 0; e < a.nupd; e++) {
+    const int pa = (a.pa0 + e * a.n) & mask;
+    if (recalc == last) recalc = 0;
+    const int ia = recalc;
+    recalc += a.step; if (recalc > last) recalc = last;
+    if (i >= ia && i <= recalc) {
+      int p0 = (pa - (a.avg2 - 1) * a.n + a.bufsize) & mask;
+      slow = a.corrsum[p0 + i];
+      for (int m = 1; m < a.avg2; m++) { p0 = (p0 + a.n) & mask; const float2 v = a.corrsum[p0 + i]; slow.x += v.x; slow.y += v.y; }
+    } else {
+      const int pb = (pa - a.avg2 * a.n + a.bufsize) & mask;
+      const float2 nw = a.corrsum[pa + i], od = a.corrsum[pb + i];
+      slow.x += nw.x - od.x; slow.y += nw.y - od.y;
+    }
+    const float2 nw = a.corrsum[pa + i];
+    tot.x += nw.x; tot.y += nw.y;
+  }
+  a.slowcorr[i] = slow; a.tot[i] = tot;
+}
+hipError_t launch_corrsum(const CorrArgs &a, hipStream_t st)
+{
+  const int groups = (a.c0 + a.batch + a.avg - 1) / a.avg;
+  hipLaunchKernelGGL(k_corrsum, dim3((a.n + 255) / 256, groups), dim3(256), 0, st, a);
+  if (a.nupd > 0) hipLaunchKernelGGL(k_slowcorr, dim3((a.n + 63) / 64), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// =====================================================================================================
 // fft1 + fft1_c's sums + make_timf2's weak stream in one kernel (fft1_size 16384, sin^2 window, int16 I/Q)
 // =====================================================================================================
 // The forward transform leaves a thread exactly the bins its back transform starts from (bin = tid mod N/32 in both layouts), so

@@ -48,6 +48,15 @@ struct SlowsumArgs {
   int e0, recalc_e0;        // the search for a bin's last refresh starts at update e0 (recalc pointer there), see k_slowsum
 };
 
+// ---- correlation spectrum of two coupled channels (fft1_corrsum, fft1_slowcorr, fft1_slowcorr_tot) ----
+struct CorrArgs {
+  const float2 *x, *y; int n, batch;            // the batch's transforms of channel 0 and channel 1 (LRH_X_SPEC slots), [batch][n]
+  float2 *corrsum; int sumsq_mask;              // ring [sumsq_bufsize] like fft1_sumsq, two floats per bin
+  int avg, c0, pa0;                             // fft_avg1num, fft1_sumsq_counter and fft1_sumsq_pa before the batch (SumsqArgs)
+  float2 *slowcorr; double2 *tot; int bufsize, avg2, nupd, recalc0, step;   // update_fft1_slowsum's walk (SlowsumArgs)
+};
+hipError_t launch_corrsum(const CorrArgs &a, hipStream_t st);
+
 // ---- make_timf2 ----
 struct Timf2Args {
   const float2 *spec; int first_nb, nb_mask;

@@ -203,3 +203,43 @@ def install_exchange(rx, dist, device=None):
             t[(1 - rank) * count:(2 - rank) * count] = slots[1 - rank]
         return 0
     rx.set_exchange(fn)
+
+
+def install_pair_exchange(rxs, device=None):
+    """Both channels of a coupled pair in ONE process (one context each, one caller thread each -- Linrad's two RF channels on one
+    GPU): the exchange points of lrh_wideband_dsp meet at a barrier and trade through device memory (HIP, device given) or host
+    memory (the CPU oracle).  Returns the barrier; run rxs[0].wideband_dsp and rxs[1].wideband_dsp on two threads."""
+    import ctypes
+    import threading
+    import torch
+    bar = threading.Barrier(2)
+    box = [None, None]
+
+    def make(ch):
+        def fn(which, op, ptr, count, stream):
+            n = count if op == XOP_SUM else 2 * count
+            if device is not None:
+                torch.cuda.ExternalStream(stream, device=device).synchronize()
+                t = torch.as_tensor(_DevSpan(ptr, n), device=device)
+            else:
+                t = torch.frombuffer((ctypes.c_float * n).from_address(ptr), dtype=torch.float32)
+            box[ch] = t
+            bar.wait()
+            other = box[1 - ch]
+            lo, hi = (1 - ch) * count, (2 - ch) * count
+            tmp = (box[0] + box[1]) if op == XOP_SUM else other[lo:hi].clone()
+            if device is not None:
+                torch.cuda.synchronize(device)
+            bar.wait()
+            if op == XOP_SUM:
+                t.copy_(tmp)
+            else:
+                t[lo:hi].copy_(tmp)
+            if device is not None:
+                torch.cuda.synchronize(device)
+            bar.wait()
+            return 0
+        return fn
+    for ch, rx in enumerate(rxs):
+        rx.set_exchange(make(ch))
+    return bar

@@ -68,6 +68,7 @@ struct lro_ctx {
   float amp_factor;            /* liminfo_amplitude_factor (sellim.c:119-155; blank1.c:143) */
   lrh_sellim wl_par; int wl_on, wl_fft2, wl_cnt1, wl_cnt2;   /* lro_wideband_limiter */
   lrh_exchange_fn xfn; void *xuser;                          /* lro_set_exchange */
+  int corr_on, slowcorr_tot_avgnum; float *xspec, *fft1_corrsum, *fft1_slowcorr; double *fft1_slowcorr_tot;   /* lro_set_correlation */
   lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
@@ -564,6 +565,73 @@ static void update_fft1_slowsum(lro_ctx *c, lrh_ptrs *p)
   }
 }
 
+/* ---- correlation spectrum (fft1_correlation_flag == 1): fft1_c's fft1_corrsum (fft1.c:4146-4150, 4189-4193) and update_fft1_slowsum's
+   fft1_slowcorr / fft1_slowcorr_tot (fft1.c:4584-4603, new_fft1_averages wide_graph.c:1033-1050), one channel per context with the
+   transforms exchanged through LRH_X_SPEC (include/linrad_hip.h) */
+int lro_set_correlation(lro_ctx *c, int on)
+{
+  if (!c || c->cfg.blanker_channels != 2) return LRH_ESTATE;
+  free(c->xspec); free(c->fft1_corrsum); free(c->fft1_slowcorr); free(c->fft1_slowcorr_tot);
+  c->xspec = NULL; c->fft1_corrsum = NULL; c->fft1_slowcorr = NULL; c->fft1_slowcorr_tot = NULL;
+  c->corr_on = 0; c->slowcorr_tot_avgnum = 0;
+  if (!on) return LRH_OK;
+  c->xspec = calloc((size_t)4 * c->cfg.max_batch * c->N1, sizeof(float)); c->fft1_corrsum = calloc((size_t)2 * c->cfg.fft1_sumsq_bufsize, sizeof(float));
+  c->fft1_slowcorr = calloc((size_t)2 * c->N1, sizeof(float)); c->fft1_slowcorr_tot = calloc((size_t)2 * c->N1, sizeof(double));
+  if (!c->xspec || !c->fft1_corrsum || !c->fft1_slowcorr || !c->fft1_slowcorr_tot) return LRH_ENOMEM;
+  c->corr_on = 1;
+  return LRH_OK;
+}
+int lro_get_slowcorr_tot_avgnum(lro_ctx *c, int *n) { if (!c || !n) return LRH_EINVAL; *n = c->slowcorr_tot_avgnum; return LRH_OK; }
+int lro_fft1_corr_begin(lro_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
+{
+  if (!c || !at || !count || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (!c->corr_on) return LRH_ESTATE;
+  const int N = c->N1;
+  float *slot = c->xspec + (size_t)(c->cfg.timf1_channel_index & 1) * batch * 2 * N;
+  for (int b = 0; b < batch; b++) memcpy(slot + (size_t)b * 2 * N, c->fft1_float + (size_t)((at->fft1_nb + b) & c->fft1n_mask) * 2 * N, sizeof(float) * 2 * N);
+  *count = (size_t)batch * 2 * N;
+  return LRH_OK;
+}
+int lro_fft1_corr_finish(lro_ctx *c, const lrh_ptrs *at, int batch)
+{
+  if (!c || !at || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  if (!c->corr_on) return LRH_ESTATE;
+  const int N = c->N1, last = N - 1, avg2 = c->cfg.fft_avg2num, bufsize = c->cfg.fft1_sumsq_bufsize, mask = c->fft1_sumsq_mask;
+  int counter = at->fft1_sumsq_counter, pa = at->fft1_sumsq_pa, recalc = at->fft1_sumsq_recalc;
+  for (int b = 0; b < batch; b++) {
+    const float *x = c->xspec + (size_t)b * 2 * N, *y = c->xspec + ((size_t)batch + b) * 2 * N;
+    float *cs = c->fft1_corrsum + 2 * (size_t)pa;
+    for (int i = 0; i < N; i++) {
+      const float re = 2 * (x[2 * i] * y[2 * i] + x[2 * i + 1] * y[2 * i + 1]), im = 2 * (x[2 * i + 1] * y[2 * i] - x[2 * i] * y[2 * i + 1]);
+      if (counter == 0) { cs[2 * i] = re; cs[2 * i + 1] = im; } else { cs[2 * i] += re; cs[2 * i + 1] += im; }
+    }
+    if (++counter < c->cfg.fft_avg1num) continue;
+    counter = 0;
+    /* update_fft1_slowsum's walk for the correlation sums: the same refresh window as fft1_slowsum */
+    const int pb = (pa - avg2 * N + bufsize) & mask;
+    if (recalc == last) recalc = 0;
+    const int ia = recalc;
+    recalc += c->cfg.wg_xpoints / c->cfg.slowsum_fresh_recalc;
+    if (recalc > last) recalc = last;
+    { int p0 = (pa - (avg2 - 1) * N + bufsize) & mask;
+      for (int i = ia; i <= recalc; i++) { c->fft1_slowcorr[2 * i] = c->fft1_corrsum[2 * (p0 + i)]; c->fft1_slowcorr[2 * i + 1] = c->fft1_corrsum[2 * (p0 + i) + 1]; }
+      p0 = (p0 + N) & mask;
+      for (int m = 1; m < avg2; m++) {
+        for (int i = ia; i <= recalc; i++) { c->fft1_slowcorr[2 * i] += c->fft1_corrsum[2 * (p0 + i)]; c->fft1_slowcorr[2 * i + 1] += c->fft1_corrsum[2 * (p0 + i) + 1]; }
+        p0 = (p0 + N) & mask;
+      } }
+    for (int i = 0; i < N; i++) {
+      if (i >= ia && i <= recalc) continue;
+      c->fft1_slowcorr[2 * i] += c->fft1_corrsum[2 * (pa + i)] - c->fft1_corrsum[2 * (pb + i)];
+      c->fft1_slowcorr[2 * i + 1] += c->fft1_corrsum[2 * (pa + i) + 1] - c->fft1_corrsum[2 * (pb + i) + 1];
+    }
+    for (int i = 0; i < N; i++) { c->fft1_slowcorr_tot[2 * i] += c->fft1_corrsum[2 * (pa + i)]; c->fft1_slowcorr_tot[2 * i + 1] += c->fft1_corrsum[2 * (pa + i) + 1]; }
+    c->slowcorr_tot_avgnum += c->cfg.fft_avg1num;
+    pa = (pa + N) & mask;
+  }
+  return LRH_OK;
+}
+
 /* fft1_c, fft1.c:4085-4201 + 4507-4523 (1 channel, fft1afc_flag <= 0); the complex multiply already done in lro_fft1_b */
 int lro_fft1_c(lro_ctx *c, lrh_ptrs *p, int batch)
 {
@@ -698,6 +766,7 @@ static size_t exchange_cap(const lro_ctx *c, int which)
 int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
 {
   if (which == LRH_X_POL && ptr) { if (!c->xpol) return LRH_ESTATE; *ptr = c->xpol; return LRH_OK; }
+  if (which == LRH_X_SPEC && ptr) { if (!c->xspec) return LRH_ESTATE; *ptr = c->xspec; return LRH_OK; }
   if (c->cfg.blanker_channels != 2 || !ptr) return LRH_ESTATE;
   if (which == LRH_X_WEAK) { if (!c->xweak) return LRH_ESTATE; *ptr = c->xweak; return LRH_OK; }
   if (which != LRH_X_PWR && which != LRH_X_STAT && which != LRH_X_BINS && which != LRH_X_POL) return LRH_EINVAL;
@@ -1591,7 +1660,10 @@ static int lro_dsp_coupled(lro_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     p->fft1_pa = (p->fft1_pa + B * 2 * c->N1) & c->fft1_mask;
     p->fft1_na = p->fft1_pa / (2 * c->N1);
     for (int i = 0; i < B; i++) if (p->fft1_nm != c->fft1n_mask) p->fft1_nm++;
-    if ((rc = lro_fft1_c(c, p, B)) || (rc = lro_make_timf2(c, p, B))) return rc;
+    const lrh_ptrs at1 = *p;
+    if ((rc = lro_fft1_c(c, p, B))) return rc;
+    if (c->corr_on) { size_t ns = 0; if ((rc = lro_fft1_corr_begin(c, &at1, B, &ns)) || (rc = lro_exchange(c, LRH_X_SPEC, LRH_XOP_GATHER, ns)) || (rc = lro_fft1_corr_finish(c, &at1, B))) return rc; }
+    if ((rc = lro_make_timf2(c, p, B))) return rc;
     int cnt = 0;
     if ((rc = lro_blanker_begin(c, p, &cnt))) return rc;
     if (cnt > 0) {
@@ -1714,6 +1786,9 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
     case LRH_RING_BASEB_RAW: src = c->baseb_raw; total = 2 * (size_t)c->cfg.baseband_size; break;
     case LRH_RING_FFT2_XYPOWER: if (!c->fft2_xypower) return LRH_ESTATE; src = c->fft2_xypower; total = (size_t)c->cfg.max_fft2n * 4 * c->N2; break;
     case LRH_RING_FFT2_XYSUM: if (!c->fft2_xysum) return LRH_ESTATE; src = c->fft2_xysum; total = 4 * (size_t)c->N2; break;
+    case LRH_RING_FFT1_CORRSUM: if (!c->corr_on) return LRH_ESTATE; src = c->fft1_corrsum; total = 2 * (size_t)c->cfg.fft1_sumsq_bufsize; break;
+    case LRH_RING_FFT1_SLOWCORR: if (!c->corr_on) return LRH_ESTATE; src = c->fft1_slowcorr; total = 2 * (size_t)c->N1; break;
+    case LRH_RING_FFT1_SLOWCORR_TOT: if (!c->corr_on) return LRH_ESTATE; src = c->fft1_slowcorr_tot; total = 2 * (size_t)c->N1; esz = 8; break;
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;

@@ -258,6 +258,8 @@ int main(int argc, char **argv)
   int C = AI("channels", 1);                     /* ui.rx_rf_channels; 2: frames {I0,Q0,I1,Q1}, run stops after make_timf2 */
   int realin = AI("real", 0);                    /* 1: real samples (ui.rx_input_mode without IQ_DATA): fft1 version 2, the split-radix
                                                     real transform fft1_reherm_dit_one (fft1_re.c:32), 2*N1 reals per transform */
+  int corr = AI("corr", 0);                      /* channels=2 only: genparm[FFT1_CORRELATION_SPECTRUM] = 1 -- fft1_c also forms the channels' cross spectrum
+                                                    fft1_corrsum (fft1.c:4146-4150, 4189-4193) and update_fft1_slowsum its averages fft1_slowcorr / _tot (:4584-4603) */
   int chain2 = AI("chain2", 0);                  /* channels=2 only: run on through the two-channel first_noise_blanker, make_fft2
                                                     (fft2_xypower / fft2_xysum, polarisation-independent waterfall) and fft2_mix1_fixed */
   int sellim = AI("sellim", 0);                  /* 1: the selective limiter runs (fft1_update_liminfo, sellim.c:738) whenever fft1_c completes an
@@ -300,7 +302,7 @@ int main(int argc, char **argv)
   genparm[MIX1_BANDWIDTH_REDUCTION_N] = mixred; genparm[MIX1_NO_OF_CHANNELS] = 1;
   fft1mode = (ui.rx_input_mode & (TWO_CHANNELS + IQ_DATA)) / 2;
   rx_channels = C; twice_rxchan = 2 * C; sw_onechan = C == 1; swfloat = 1; swmmx_fft2 = 0; swmmx_fft1 = 0;
-  kill_all_flag = 0; lir_status = 0; fft1_correlation_flag = 0; fft1afc_flag = 0; no_of_spurs = 0;
+  kill_all_flag = 0; lir_status = 0; fft1_correlation_flag = (corr && C == 2) ? 1 : 0; fft1afc_flag = 0; no_of_spurs = 0;
   ampinfo_flag = 0; audio_dump_flag = 0; fft1_use_gpu = 0; fft1_calibrate_flag = 0; fft1_direction = direction;
   yieldflag_wdsp_fft1 = 0; yieldflag_timf2_fft1 = 0; yieldflag_fft2_fft2 = 0; yieldflag_ndsp_mix1 = 0;
 
@@ -366,6 +368,11 @@ int main(int argc, char **argv)
   fft1_sumsq = zalloc(sizeof(float) * fft1_sumsq_bufsize);
   fft1_slowsum = zalloc(sizeof(float) * N1);
   fft1_sumsq_pa = 0; fft1_sumsq_counter = 0; change_fft1_flag = 0; latest_wg_spectrum = 0;
+  if (corr && C == 2) {                            /* buf.c:1223-1233, 1472, 1767 */
+    fft1_corrsum = zalloc(sizeof(float) * 2 * fft1_sumsq_bufsize); fft1_slowcorr = zalloc(sizeof(double) * 2 * N1);
+    fft1_slowcorr_tot = zalloc(sizeof(double) * 2 * N1);
+    slowcorr_tot_avgnum = 0; correlation_reset_flag = 0; fft1corr_reset_flag = 0;
+  }
   set_fft1_endpoints();            /* fft1_first_point=0, last=N1-1, recalc pointer, sym points */
   fft1_pa = fft1_pb = fft1_px = 0; fft1_na = fft1_nb = fft1_nx = 0; fft1_nm = 0; fft1_liminfo_cnt = 0;
   ag_pa = 0; ag_mask = 1023;
@@ -815,6 +822,8 @@ int main(int argc, char **argv)
   PUTF("fft1_float", fft1_float, (size_t)max_fft1n * fft1_block);
   PUTF("fft1_sumsq", fft1_sumsq, fft1_sumsq_bufsize);
   PUTF("fft1_slowsum", fft1_slowsum, N1);
+  if (fft1_correlation_flag == 1) { PUTF("fft1_corrsum", fft1_corrsum, (size_t)2 * fft1_sumsq_bufsize); PUTF("fft1_slowcorr", fft1_slowcorr, (size_t)2 * N1);
+    put("fft1_slowcorr_tot", "f8", fft1_slowcorr_tot, (size_t)2 * N1, 8); PUTI("slowcorr_tot_avgnum", &slowcorr_tot_avgnum, 1); }
   PUTF("timf2_float", timf2_float, timf2_size);
   PUTF("timf2_pwr_float", timf2_pwr_float, timf2pow_size);
   PUTF("fft2_float", fft2_float, (size_t)2 * C * N2 * max_fft2n);

@@ -35,12 +35,17 @@ def main():
             args = harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}"]
             subprocess.check_call([HARNESS] + args)
             ref = load_dump(fo)
+            subprocess.check_call([HARNESS] + args + ["corr=1"])            # correlation spectrum on (genparm[FFT1_CORRELATION_SPECTRUM] = 1)
+            refc1 = load_dump(fo)
             subprocess.check_call([HARNESS] + args + ["blanker2=1"])       # second run: two-channel first_noise_blanker after every block
             refb = load_dump(fo)
         out = {k: ref[k] for k in ("hdr", "fft1_filtercorr", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
                                    "timf2_pwr_float", "itrace", "trace")}
         for k in ("timf2_float", "timf2_pwr_float", "itrace", "trace"):
             out["bln_" + k] = refb[k]
+        for k in ("fft1_corrsum", "fft1_slowcorr", "fft1_slowcorr_tot", "slowcorr_tot_avgnum"):
+            out[k] = refc1[k]
+        assert np.array_equal(refc1["fft1_sumsq"], ref["fft1_sumsq"])      # the correlation sums ride beside the power sums, nothing else changes
         out["frames"], out["liminfo"] = frames, lim
         path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         if "--chain-only" not in sys.argv and ("--only" not in sys.argv or name in sys.argv):
