@@ -263,16 +263,18 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         # reference built from a synthetic amplitude calibration, carried as data by the golden fixture of the parity tests
         clever_g = dict(np.load(os.path.join(ROOT, "tests", "golden", "clever_n10_n12.npz")))
         cfg.blanker_pulsewidth, cfg.blnfit_range = int(clever_g["bln_ints"][1]), int(clever_g["bln_ints"][3])
-        # start value of the noise floor at the level the SURVEY 8d signal settles at (the reference's 200, buf.c:418, is a guess for an
-        # unknown receiver): with 200 the first calls see 0.5 % of all samples above the limit -- 10^5 pulse candidates per call in a
-        # handful of regions, minutes of one-wave walks before the floor has adapted; the steady state is what is timed either way
-        cfg.timf2_noise_floor = 500
     rx = setup_receiver(cfg, channel_of_rank(rank), hiplib.open_hip, hiplib)
-    if clever_g is not None:
+
+    def clever_on():
+        """The operator's click in the high-resolution graph (hires_graph.c:1160-1162): the linear blanker goes on in a receiver that
+        is already running -- noise floor measured, selective limiter past its start-up (its noise-floor pass waits for spek_avgnum
+        spectra, sellim.c:860; until then the carriers' skirts stay with the weak signal and most samples exceed any sensible limit,
+        a case the reference's sample walk and this library's region walk both take minutes over)."""
         bi, bf = clever_g["bln_ints"], clever_g["bln_fparams"]
+        floor = rx.blanker_state().timf2_noise_floor
         rx.set_blanker_tables(bln=clever_g["bln"].reshape(-1, 4)[:, :3], refpulse=clever_g["blanker_refpulse"], phasefunc=clever_g["blanker_phasefunc"],
                               pulindex=clever_g["blanker_pulindex"], largest_blnfit=int(bi[2]), clever_bln_factor=float(bf[1]),
-                              clever_bln_limit=int(np.float32(cfg.timf2_noise_floor) * np.float32(bf[1])), liminfo_amplitude_factor=float(bf[0]))
+                              clever_bln_limit=int(np.float32(floor) * np.float32(bf[1])), liminfo_amplitude_factor=rx.liminfo_amplitude_factor())
     samples_per_step = args.batch * args.rounds * M1
     dev = torch.device("cuda", local_rank)
     use_dist = dist is not None
@@ -386,6 +388,10 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         spur_info = {"requested": args.spurs, "locked": locked, "spur_speknum": args.spur_speknum}
     for _ in range(warmup):
         step()
+    if clever_g is not None:
+        clever_on()
+        for _ in range(2):
+            step()
     barrier()
     t0 = time.perf_counter()
     rx.timer_start()

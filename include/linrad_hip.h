@@ -286,7 +286,11 @@ int lrh_get_table(lrh_ctx *ctx, const char *name, float *dst, int count); /* "ff
    `exact_stats` the call waits for it (the reference's value at once); without, the count of the newest update whose readback has
    arrived is installed whenever lrh_make_timf2 or the next update looks (lrh_sync installs the newest), i.e. the statistic (not
    the routing) lags by however far the host runs ahead of the device, and the host never waits for work it has only just enqueued.
-   lrh_set_liminfo and this call may be mixed: both replace the table in force. */
+   lrh_set_liminfo and this call may be mixed: both replace the table in force.
+   The reference looks right after fft1_c has closed an averaging period (p->fft1_sumsq_counter == 0): the slot at fft1_sumsq_pa then
+   holds the sums of a ring lap ago, and those are what it reads.  A call in the middle of a period (p->fft1_sumsq_counter != 0:
+   batched rounds whose length is no multiple of fft_avg1num) would find the unfinished sums of the period in progress in that slot;
+   it reads the newest finished period (one slot back) instead. */
 typedef struct lrh_sellim {
   int struct_size;
   int sellim_maxlevel;          /* genparm[SELLIM_MAXLEVEL] (uivar.c:371: 12000)                               */

@@ -161,7 +161,7 @@ struct lrh_ctx {
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr, *d_sel_bigb = nullptr, *d_sel_bigg = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
-  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
+  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
@@ -371,7 +371,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -784,7 +784,11 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel_wait2, hipEventDisableTiming));
   }
   hipStream_t S = c->stream_sel;
-  if (which == 1) a.sumsq = c->d_sumsq + (p->fft1_sumsq_pa & c->sumsq_mask);     // the block at the advanced pointer (sellim.c:788, fft1.c:4519)
+  // the block at the advanced pointer (sellim.c:788, fft1.c:4519): the reference looks right after fft1_c has closed a period, when that slot
+  // still holds the sums of a ring lap ago.  A look in the middle of a period (batched rounds whose length is no multiple of
+  // fft_avg1num) would find the unfinished sums of the period in progress there, a spectrum at a fraction of its level: it takes
+  // the newest finished period instead.
+  if (which == 1) a.sumsq = c->d_sumsq + ((p->fft1_sumsq_pa - (p->fft1_sumsq_counter ? c->N1 : 0) + c->cfg.fft1_sumsq_bufsize) & c->sumsq_mask);
   else {
     if (!c->d_sel_ftmp) { const int rc = dev_alloc(c, &c->d_sel_ftmp, c->N1); if (rc) return rc; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     a.tmp = c->d_sel_ftmp;
@@ -1416,19 +1420,20 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     const size_t need = (size_t)a.total + 2 * ca.bk_margin + 1;
     if (c->clv_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
+      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pos, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
         if (*q_) { hipFree(*q_); *q_ = nullptr; }
       c->clv_cap = 0;
       const size_t cap = need + need / 4;
       const int maxr = (int)(cap / ca.gap) + 2;
       int rc_ = LRH_OK;
-      if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 4)) ||
+      if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 8 + 1024)) || (rc_ = dev_alloc(c, &c->d_clv_bk_pos, cap, false)) ||
+          (!c->d_clv_logged && (rc_ = dev_alloc(c, &c->d_clv_logged, (size_t)c->cfg.timf2pow_size / 64))) ||
           (rc_ = dev_alloc(c, &c->d_clv_bk_pwr, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_tf, cap, false))) return rc_;
       if (coupled && ((rc_ = dev_alloc(c, &c->d_clv_bk_pwo, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_ty, cap, false)))) return rc_;
       c->clv_cap = cap; c->clv_max_regions = maxr;
     }
     ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
-    ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.bk_pwo = c->d_clv_bk_pwo; ca.bk_ty = c->d_clv_bk_ty; ca.force_serial = c->clever_force_serial ? 1 : 0;
+    ca.logged = c->d_clv_logged; ca.bk_pos = c->d_clv_bk_pos; ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.bk_pwo = c->d_clv_bk_pwo; ca.bk_ty = c->d_clv_bk_ty; ca.force_serial = c->clever_force_serial ? 1 : 0;
     int out[3];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
@@ -2309,11 +2314,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // (cnt1 / sumsq_pa: fft1_c's counters as they stood after THIS round's sums -- schedule 1 has already booked the next round's)
   // The first limiter only needs the round's power sums, so it is queued right behind them on the side stream -- queued at the end of
   // the round it would sit behind the waterfall, i.e. behind fft2, and the next round's make_timf2 would wait 370 us for its table.
-  auto limiter1 = [&](int cnt1, int sumsq_pa) -> int {
+  auto limiter1 = [&](int cnt1, int sumsq_pa, int sumsq_counter) -> int {
     if (!c->wl_on || !c->cfg.second_fft_enable || cnt1 == c->wl_cnt1) return LRH_OK;
     std::vector<std::function<int(lrh_ctx *)>> *keep_rec = c->rec; hipStream_t keep_cur = c->cur;
     c->rec = nullptr; c->cur = c->stream;
-    lrh_ptrs at = *p; at.fft1_sumsq_pa = sumsq_pa;
+    lrh_ptrs at = *p; at.fft1_sumsq_pa = sumsq_pa; at.fft1_sumsq_counter = sumsq_counter;
     const int r = sellim_run(c, &at, &c->wl_par, 1); c->wl_cnt1 = cnt1;
     c->rec = keep_rec; c->cur = keep_cur;
     return r;
@@ -2351,10 +2356,10 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       // it goes out here on its own stream and runs beside the blanker, fft2 and mix1 (a small round is half limiter otherwise:
       // 224 -> 165 us per call of 4 blocks, 298 -> 182 at 64).  Not with the linear blanker, which reads the amplitude factor the limiter updates.
       const bool early1 = !c->clever_on;
-      if (early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa))) return rc;
+      if (early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) return rc;
       if ((rc = lrh_first_noise_blanker(c, p))) return rc;
       if ((rc = round_tail(c, p))) return rc;
-      if ((!early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa))) || (rc = limiter2())) return rc;
+      if ((!early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) || (rc = limiter2())) return rc;
       nblocks -= B;
     }
     return LRH_OK;
@@ -2416,7 +2421,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       hipStream_t Ss = (fuse && c->wl_on && c->sums_on_main) ? S1 : S2;
       if (fuse) { if (Ss == S2) HIPCHK(c, hipStreamWaitEvent(S2, ev_t2, 0)); if ((rc = sums_follow(Ss))) return rc; }
       HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], Ss));
-      if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa))) return rc;
+      if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) return rc;
       // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
       qb.push_back([ev_t2](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, ev_t2, 0)); return LRH_OK; });
       c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
@@ -2457,7 +2462,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   if (!fuse) HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2));
   while (left > 0) {
     const int Bnext = (left - B) < batch ? (left - B) : batch;       // size of round k+1 (0 at the end)
-    const int lim_cnt = p->fft1_liminfo_cnt, lim_pa = p->fft1_sumsq_pa;   // fft1_c's counters after round k's sums
+    const int lim_cnt = p->fft1_liminfo_cnt, lim_pa = p->fft1_sumsq_pa, lim_ctr = p->fft1_sumsq_counter;   // fft1_c's counters after round k's sums
     // main: timf2(k)
     on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_timf2, S1));
@@ -2466,7 +2471,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     if (fuse) { if ((rc = sums_follow(S2))) return rc; HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], S2)); }
     if ((rc = lrh_first_noise_blanker(c, p))) return rc;
     HIPCHK(c, hipEventRecord(c->ev_blank, S2));
-    if ((rc = limiter1(lim_cnt, lim_pa))) return rc;          // behind the blanker: fft2(k) on the main stream waits for that one
+    if ((rc = limiter1(lim_cnt, lim_pa, lim_ctr))) return rc;          // behind the blanker: fft2(k) on the main stream waits for that one
     if (Bnext > 0) {
       // main: fft1(k+1) once the sums of round k-1 (which read the ring slots it overwrites) are done
       on(S1);

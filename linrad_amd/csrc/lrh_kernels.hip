@@ -2281,43 +2281,49 @@ hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int 
 // fit.  One wave runs the reference's control flow with all lanes in step (every branch below is wave-uniform), a pulse's
 // neighbourhood (+-128 samples: refpul_size <= 256) sits in LDS, sums run in the reference's order, and contraction to fma is
 // off so that the threshold decisions see the reference's roundings.
-// k_clever_prep: candidate bits (power above the limit) and the flag clear over exactly the span (blank1.c:768-774); phase 0 also
-// keeps a copy of the span's samples, phase 1 (only after a violation) puts them back first.
+// k_clever_prep: candidate bits (power above the limit), the flag clear over exactly the span (blank1.c:768-774) and the clear of the
+// undo log's bits (span and margins); phase 1 runs only after a violation, behind k_clever_restore.
+constexpr int CLV_RBLOCKS_MAX = 1024;                    // blocks of the region kernels (their counts live in reg_ctl[8 ..])
 __global__ __launch_bounds__(256) void k_clever_prep(CleverArgs a)
 {
   if (a.phase == 1 && a.reg_ctl[1] == 0) return;
   const int lane = threadIdx.x & 63, wmask = ((a.mask + 1) >> 6) - 1;
   const int first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
   const float nfl = (float)a.st->clever_limit;
-  const int nbk = a.total + 2 * a.bk_margin + 1;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < nbk; i += gridDim.x * 256) {
-    const int pos = (a.pbeg + i - a.bk_margin) & a.mask;
-    if (a.phase == 0) { a.bk_pwr[i] = a.pwr[pos]; a.bk_tf[i] = a.timf2w[pos]; if (a.twochan) { a.bk_pwo[i] = a.pwr_own[pos]; a.bk_ty[i] = a.timf2y[pos]; } }
-    else { a.pwr[pos] = a.bk_pwr[i]; a.timf2w[pos] = a.bk_tf[i]; if (a.twochan) { a.pwr_own[pos] = a.bk_pwo[i]; a.timf2y[pos] = a.bk_ty[i]; } }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; }
-  // candidate bits straight from the backup in phase 1: no workgroup depends on another one's restored samples
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; a.reg_ctl[3] = 0; }
+  { const int mw = (a.bk_margin + 63) / 64 + 1;           // words of the margins either side
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords + 2 * mw; w += gridDim.x * 256) a.logged[(first_word - mw + w) & wmask] = 0ull; }
   for (int w = (blockIdx.x * 256 + threadIdx.x) >> 6; w < nwords; w += gridDim.x * 4) {
     const int pos = (((first_word + w) << 6) + lane) & a.mask;
     const int o = (pos - a.pbeg) & a.mask;
     const bool in = o <= a.total;
-    const float v = in ? (a.phase == 1 ? a.bk_pwr[o + a.bk_margin] : a.pwr[pos]) : 0.f;
+    const float v = in ? a.pwr[pos] : 0.f;
     const bool hot = in && v > nfl;
     if (in) a.flag[pos] = 0;
     const unsigned long long b = __ballot(hot);
     if (lane == 0) a.cand[(first_word + w) & wmask] = b;
   }
 }
+// after a violation: every sample the parallel pass rewrote goes back to what the call started with
+__global__ __launch_bounds__(256) void k_clever_restore(CleverArgs a)
+{
+  if (a.reg_ctl[1] == 0) return;
+  const int n = a.reg_ctl[3];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int pos = a.bk_pos[i];
+    a.pwr[pos] = a.bk_pwr[i]; a.timf2w[pos] = a.bk_tf[i];
+    if (a.twochan) { a.pwr_own[pos] = a.bk_pwo[i]; a.timf2y[pos] = a.bk_ty[i]; }
+  }
+}
 
 // Regions: a candidate starts a region when no candidate lies within `gap` samples before it.  gap >= 64, so only the lowest set
-// bit of a word can start one.  One workgroup; ordered list of the starts (offsets from pbeg) by a block-wide scan of per-thread counts.
-__global__ __launch_bounds__(1024) void k_clever_regions(CleverArgs a)
-{
-  __shared__ int cnt[1024];
-  const int wmask = ((a.mask + 1) >> 6) - 1, first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
-  const int back = (a.gap + 63) / 64 + 1;
-  const int per = (nwords + 1023) / 1024, w0 = threadIdx.x * per, w1 = min(w0 + per, nwords);
-  auto start_of = [&](int w) -> int {                    // offset of a region start in word w, or -1
+// bit of a word can start one.  Ordered list of the starts (offsets from pbeg): every block counts the starts in its stretch of words
+// (k_clever_count), then places them behind the blocks before it (k_clever_regions).
+struct CleverWords {
+  const CleverArgs &a; int wmask, first_word, nwords, back;
+  __device__ CleverWords(const CleverArgs &a_) : a(a_), wmask(((a_.mask + 1) >> 6) - 1), first_word(a_.pbeg >> 6), nwords(((a_.pbeg & 63) + a_.total + 64) >> 6), back((a_.gap + 63) / 64 + 1) {}
+  __device__ int start_of(int w) const                    // offset of a region start in word w, or -1
+  {
     const unsigned long long v = a.cand[(first_word + w) & wmask];
     if (!v) return -1;
     const int pos = ((first_word + w) << 6) + __ffsll((long long)v) - 1;
@@ -2326,20 +2332,53 @@ __global__ __launch_bounds__(1024) void k_clever_regions(CleverArgs a)
       if (u) { const int prev = ((first_word + w - k) << 6) + 63 - __clzll((long long)u); if (pos - prev < a.gap) return -1; break; }
     }
     return pos - a.pbeg;                                  // not masked: words count up from pbeg's word, so this is the offset
-  };
+  }
+  // every thread takes `per` consecutive words, threads and blocks in the order of the words
+  __device__ int per() const { return (nwords + (int)gridDim.x * 256 - 1) / ((int)gridDim.x * 256); }
+};
+__device__ __forceinline__ int clv_block_sum(int v, int *sh)        // sum over the 256 threads of a block
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int tot = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return tot;
+}
+__global__ __launch_bounds__(256) void k_clever_count(CleverArgs a)
+{
+  __shared__ int sh[4];
+  const CleverWords cw(a);
+  const int per = cw.per(), w0 = (blockIdx.x * 256 + threadIdx.x) * per, w1 = min(w0 + per, cw.nwords);
   int n = 0;
-  for (int w = w0; w < w1; w++) if (start_of(w) >= 0) n++;
+  for (int w = w0; w < w1; w++) if (cw.start_of(w) >= 0) n++;
+  const int tot = clv_block_sum(n, sh);
+  if (threadIdx.x == 0) a.reg_ctl[8 + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_clever_regions(CleverArgs a)
+{
+  __shared__ int sh[4], cnt[256];
+  const CleverWords cw(a);
+  const int per = cw.per(), w0 = (blockIdx.x * 256 + threadIdx.x) * per, w1 = min(w0 + per, cw.nwords);
+  int before = 0;                                         // regions of the blocks before this one
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += a.reg_ctl[8 + b];
+  before = clv_block_sum(before, sh);
+  int n = 0;
+  for (int w = w0; w < w1; w++) if (cw.start_of(w) >= 0) n++;
   cnt[threadIdx.x] = n;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {             // inclusive scan
+  for (int off = 1; off < 256; off <<= 1) {              // inclusive scan
     const int v = threadIdx.x >= off ? cnt[threadIdx.x - off] : 0;
     __syncthreads();
     cnt[threadIdx.x] += v;
     __syncthreads();
   }
-  int at = cnt[threadIdx.x] - n;
-  for (int w = w0; w < w1; w++) { const int o = start_of(w); if (o >= 0) { if (at < a.max_regions) a.reg_start[at] = o; at++; } }
-  if (threadIdx.x == 1023) { a.reg_ctl[0] = min(cnt[1023], a.max_regions); a.reg_ctl[1] = (cnt[1023] > a.max_regions || a.force_serial) ? 1 : 0; a.reg_ctl[2] = a.total; }
+  int at = before + cnt[threadIdx.x] - n;
+  for (int w = w0; w < w1; w++) { const int o = cw.start_of(w); if (o >= 0) { if (at < a.max_regions) a.reg_start[at] = o; at++; } }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+    const int tot = before + cnt[255];
+    a.reg_ctl[0] = min(tot, a.max_regions); a.reg_ctl[1] = (tot > a.max_regions || a.force_serial) ? 1 : 0; a.reg_ctl[2] = a.total;
+  }
 }
 
 // extents must stay apart; the last region's stopping point is the call's
@@ -2357,7 +2396,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
 #pragma clang fp contract(off)
   constexpr int W = 128;                                  // half width of the pulse neighbourhood held in LDS
   __shared__ float s_pw[2 * W + 8], s_old[2 * W + 8], s_spw[256], s_in[2 * 2 * W + 8], s_avg[8];
-  __shared__ float2 s_tf[2 * W + 8], s_ty[2 * W + 8];
+  __shared__ float2 s_tf[2 * W + 8], s_ty[2 * W + 8], s_otf[2 * W + 8], s_oty[2 * W + 8];
   __shared__ unsigned char s_fl[2 * W + 8], s_sfl[256];
   // two coupled channels: X is channel 0, Y channel 1, whichever of them this context owns
   float2 *const ring_x = (a.twochan && a.chan) ? a.timf2y : a.timf2w, *const ring_y = a.twochan ? (a.chan ? a.timf2w : a.timf2y) : nullptr;
@@ -2548,6 +2587,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
           const float r1 = a.refpulse[mrp + kk], r2 = a.refpulse[mrp + kk + 1];
           const float2 x = s_tf[q];
           s_old[q] = s_pw[q];
+          s_otf[q] = x; if (a.twochan) s_oty[q] = s_ty[q];         // as staged: what the undo log keeps
           if (a.twochan) {
             const float2 y = s_ty[q];
             const float re_a = c1 * r1 - c2 * r2, im_a = c1 * r2 + c2 * r1;
@@ -2585,8 +2625,30 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
           rv = -5.f;
         }
         __syncthreads();
-        for (int jj = lane; jj <= sub; jj += 64) {
+        for (int j0 = 0; j0 <= sub; j0 += 64) {
+          const int jj = j0 + lane;
+          const bool mine = jj <= sub;
           const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj);
+          if (a.phase == 0) {                             // undo log: the first wave to touch a sample in this call keeps its original
+            float opo = 0.f;
+            if (mine && a.twochan) opo = a.pwr_own[pos];
+            if (a.twochan) __threadfence();               // ... read before the atomic below goes out
+            const unsigned long long bit = 1ull << (pos & 63);
+            const bool first = mine && !(atomicOr(&a.logged[pos >> 6], bit) & bit);
+            const unsigned long long firsts = __ballot(first);
+            if (firsts) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&a.reg_ctl[3], __popcll(firsts));
+              base = __shfl(base, 0, 64);
+              if (first) {
+                const int e = base + __popcll(firsts & ((1ull << lane) - 1));
+                a.bk_pos[e] = pos; a.bk_pwr[e] = s_old[q];
+                if (a.twochan) { a.bk_tf[e] = a.chan ? s_oty[q] : s_otf[q]; a.bk_ty[e] = a.chan ? s_otf[q] : s_oty[q]; a.bk_pwo[e] = opo; }
+                else a.bk_tf[e] = s_otf[q];
+              }
+            }
+          }
+          if (!mine) continue;
           ring_x[pos] = s_tf[q]; a.pwr[pos] = s_pw[q];
           if (a.twochan) { ring_y[pos] = s_ty[q]; const float2 o = a.chan ? s_ty[q] : s_tf[q]; a.pwr_own[pos] = o.x * o.x + o.y * o.y; }
         }
@@ -2637,12 +2699,15 @@ hipError_t launch_clever(const CleverArgs &a0, hipStream_t st)
   CleverArgs a = a0;
   const int nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
   const dim3 gp((nwords + 3) / 4 < 2048 ? (nwords + 3) / 4 : 2048);
+  const int rblocks = std::max(1, std::min(CLV_RBLOCKS_MAX, (nwords + 1023) / 1024));      // >= 4 words per thread
   a.phase = 0;
   hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever_regions, dim3(1), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 2048 ? a.max_regions : 2048), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_clever_count, dim3(rblocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_clever_regions, dim3(rblocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 16384 ? a.max_regions : 16384), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(64), 0, st, a);
-  a.phase = 1;                                           // both return at once unless the check found colliding extents
+  a.phase = 1;                                           // all three return at once unless the check found colliding extents
+  hipLaunchKernelGGL(k_clever_restore, dim3(256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);
   return hipGetLastError();

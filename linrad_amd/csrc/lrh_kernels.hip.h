@@ -157,9 +157,13 @@ struct CleverArgs {
   // or changed, k_clever_check verifies that neighbouring extents stay apart, and when they do not (a monotone run of hundreds of
   // samples) the span is restored from the backup and replayed by one wave in the reference's order
   int gap; int *reg_start; int max_regions; int *reg_ext;     // [max_regions] first candidate offset; [2*max_regions] lo, hi
-  int *reg_ctl;             // [0] number of regions, [1] violation flag, [2] pf of the last region
-  float *bk_pwr; float2 *bk_tf; int bk_margin;                // copies of offsets -bk_margin .. total + bk_margin
-  int phase;                // k_clever_prep: 0 first pass (+ backup), 1 restore if violated; k_clever: 0 parallel, 1 serial if violated
+  int *reg_ctl;             // [0] number of regions, [1] violation flag, [2] pf of the last region, [3] undo log entries, [8 ..] per-block region counts (k_clever_regions)
+  // undo log instead of a copy of the span: the first wave to rewrite a ring sample in a call (bit in `logged`, taken with an atomic or)
+  // appends the sample's values as it staged them -- read before its own atomic, hence before any other wave's write, which comes after
+  // that wave's (losing) atomic -- so a replay finds the call's original samples whatever order the waves ran in.  One entry per sample
+  // at most: capacity = span + margins, never exceeded.  reg_ctl[3] counts the entries.
+  unsigned long long *logged; int *bk_pos; float *bk_pwr; float2 *bk_tf; int bk_margin;
+  int phase;                // k_clever_prep: 0 first pass, 1 after a violation (k_clever_restore has put the samples back); k_clever: 0 parallel, 1 serial if violated
   int force_serial;         // tests: report a violation whatever the extents say
   // two coupled channels (blank1.c:984-992): pwr is the ring of summed powers, timf2w the own channel (number `chan`), timf2y the
   // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring (bk_ty / bk_pwo: their backups).

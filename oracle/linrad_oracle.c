@@ -1986,7 +1986,9 @@ int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   lro_sellim_state *st = sellim_state(c);
   const int N = c->N1, avg1 = c->cfg.fft_avg1num;
   float *lim = c->liminfo, *old = st->old, *tmp = st->tmp, *gmin = st->group_min;
-  const float *sumsq = c->fft1_sumsq + p->fft1_sumsq_pa;          /* the block at the *advanced* pointer (sellim.c:788, fft1.c:4519) */
+  /* the block at the *advanced* pointer (sellim.c:788, fft1.c:4519); in the middle of a period (batched rounds: the reference never
+     looks then) that slot holds the unfinished sums of the period in progress, and the newest finished period is taken instead */
+  const float *sumsq = c->fft1_sumsq + ((p->fft1_sumsq_pa - (p->fft1_sumsq_counter ? N : 0) + c->cfg.fft1_sumsq_bufsize) & c->fft1_sumsq_mask);
   const float *slow = c->fft1_slowsum, *yfac = c->wg_waterf_yfac;
   const int par7 = q->sellim_par7;
   st->sumsq_tot += avg1;
