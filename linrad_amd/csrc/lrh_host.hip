@@ -162,6 +162,10 @@ struct lrh_ctx {
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr, *d_sel_bigb = nullptr, *d_sel_bigg = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
+  // deferred schedule of lrh_wideband_dsp: the search of a round is issued a round late, its resume point comes back through a pinned slot
+  // and the rest of that blanker call (statistics, dumb blanker) is issued when the next call -- which starts at the resume point -- comes
+  bool clv_wait = false, clv_issued = false, clv_defer = false; hipEvent_t ev_clv = nullptr, ev_amp = nullptr; int *h_clv_out = nullptr; float *d_clv_amp = nullptr; int clv_amp_seq = 0;
+  struct { BlankArgs a; int pbeg; float lowlevel; } clv_late;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
   // host tables (reference layouts, for lrh_get_table)
   std::vector<float> h_window1_ref, h_invwin1_ref, h_window2, h_fqwin, h_filtercorr, h_desired, h_yfac;
@@ -371,12 +375,15 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->h_sel_low) hipHostFree(c->h_sel_low);
+  if (c->h_clv_out) hipHostFree(c->h_clv_out);
+  if (c->ev_clv) hipEventDestroy(c->ev_clv);
+  if (c->ev_amp) hipEventDestroy(c->ev_amp);
   if (c->ev_sel) hipEventDestroy(c->ev_sel);
   for (hipEvent_t e : c->ev_sel_slot) if (e) hipEventDestroy(e);
   if (c->d_pack18) hipFree(c->d_pack18);
@@ -784,6 +791,14 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel_wait2, hipEventDisableTiming));
   }
   hipStream_t S = c->stream_sel;
+  if (which == 1 && c->clv_defer) {
+    // deferred linear blanker: the search of this round is issued a round from now and must see the amplitude factor as it is BEFORE this
+    // run (the serial order) -- a copy, taken on this stream ahead of the run, in the slot that search will read
+    if (!c->d_clv_amp) { const int rc = dev_alloc(c, &c->d_clv_amp, 2); if (rc) return rc; HIPCHK(c, hipEventCreateWithFlags(&c->ev_amp, hipEventDisableTiming)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    HIPCHK(c, hipMemcpyAsync(c->d_clv_amp + (c->clv_amp_seq & 1), (char *)c->d_bst + offsetof(BlankState, amp_factor), sizeof(float), hipMemcpyDeviceToDevice, S));
+    HIPCHK(c, hipEventRecord(c->ev_amp, S));
+    c->clv_amp_seq++;
+  }
   // the block at the advanced pointer (sellim.c:788, fft1.c:4519): the reference looks right after fft1_c has closed a period, when that slot
   // still holds the sums of a ring lap ago.  A look in the middle of a period (batched rounds whose length is no multiple of
   // fft_avg1num) would find the unfinished sums of the period in progress there, a spectrum at a fraction of its level: it takes
@@ -1369,10 +1384,51 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 }
 
 // ---------------------------------------------------------------------------------------------- blanker
+// second half of a blanker call: what follows the pulse search -- bookkeeping that needs the search's resume point, statistics, dumb blanker
+static int blanker_tail(lrh_ctx *c, lrh_ptrs *p, BlankArgs a, int pbeg, const int *out, float lowlevel_fraction, bool coupled)
+{
+  const int mask = c->timf2pow_mask;
+  if (out) {
+    p->timf2p_fit = (out[0] - 16 + mask) & (mask & ~3);                  // blank1.c:1458-1461
+    a.post_stats = 1; a.fitted = out[1]; a.rejected = out[2]; a.clever_mode = c->bt.clever_bln_mode; a.clever_factor = c->bt.clever_bln_factor;
+  }
+  const int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
+  p->timf2_blanker_points += m;
+  a.m = m; a.nstat = (out ? ((p->timf2p_fit - pbeg) & mask) : a.total) / 4; a.blanker_points = p->timf2_blanker_points;
+  a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < LRH_BLN_PARTIALS ? a.nstat / 4096 : LRH_BLN_PARTIALS);
+  a.interval = c->cfg.blanker_info_update_interval; a.avgnum = c->cfg.timf2_noise_floor_avgnum; a.factor = c->cfg.stupid_bln_factor;
+  a.lowlevel_fraction = lowlevel_fraction;
+  p->blanker_info_update_counter++;                                      // blank1.c:1550-1601
+  a.do_update = 0;
+  a.debug = c->dbg_bln;
+  if (p->blanker_info_update_counter >= a.interval) {
+    if (lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
+    else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
+  }
+  const int ring_words = c->cfg.timf2pow_size / 32;
+  LRH_DEVICE_WORK(c, { ProfScope ps(c, "blanker"); HIPCHK(c, launch_blanker(a, ring_words, c->cur)); });
+  if (coupled) { c->fin_args = a; c->fin_args.phase = 2; c->fin_pending = true; }
+  return LRH_OK;
+}
+// the search of the previous (deferred) call has been issued by now: wait for its resume point and issue the rest of that call on the side stream
+static int clever_late_finish(lrh_ctx *c, lrh_ptrs *p)
+{
+  if (!c->clv_issued) return fail(c, LRH_ESTATE, "linear blanker: the search of the previous round has not been issued");
+  HIPCHK(c, hipEventSynchronize(c->ev_clv));
+  c->clv_wait = false; c->clv_issued = false;
+  const int out[3] = { c->h_clv_out[0], c->h_clv_out[1], c->h_clv_out[2] };
+  std::vector<std::function<int(lrh_ctx *)>> *keep_rec = c->rec; hipStream_t keep_cur = c->cur;
+  c->rec = nullptr; c->cur = c->stream2;
+  int rc = blanker_tail(c, p, c->clv_late.a, c->clv_late.pbeg, out, c->clv_late.lowlevel, false);
+  if (!rc && hipEventRecord(c->ev_blank, c->stream2) != hipSuccess) rc = fail(c, LRH_EDEVICE, "hipEventRecord");    // fft2 of that round waits for this
+  c->rec = keep_rec; c->cur = keep_cur;
+  return rc;
+}
 int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
+  if (c->clv_wait) { const int rc_ = clever_late_finish(c, p); if (rc_) return rc_; }    // this call starts where that search stopped
   const int mask = c->timf2pow_mask;
   const int pbeg = p->timf2p_fit;
   int pend = (p->timf2_pa / 4 - c->cfg.blnfit_range + mask) & mask;     // blank1.c:705-710
@@ -1401,7 +1457,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
   if (c->clever_on) {
     // the pulse search runs first (blank1.c:765-1003) and decides where the next call resumes: one int comes back, the call waits for it
-    if (c->rec) return fail(c, LRH_ESTATE, "linear blanker inside the deferred schedule");
+    if (c->rec && coupled) return fail(c, LRH_ESTATE, "linear blanker of two coupled channels inside the deferred schedule");
     if (a.total > c->cfg.timf2pow_size - 1024) return fail(c, LRH_EINVAL, "linear blanker: span longer than the timf2 power ring");   // the backup keeps 256 samples either side
     CleverArgs ca; memset(&ca, 0, sizeof ca);
     ca.pwr = coupled ? c->d_pwr_sum : c->d_pwr; ca.timf2w = c->d_timf2w; ca.flag = c->d_bln_flag; ca.cand = c->d_bln_cand; ca.mask = mask;
@@ -1434,6 +1490,28 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     }
     ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
     ca.logged = c->d_clv_logged; ca.bk_pos = c->d_clv_bk_pos; ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.bk_pwo = c->d_clv_bk_pwo; ca.bk_ty = c->d_clv_bk_ty; ca.force_serial = c->clever_force_serial ? 1 : 0;
+    if (c->rec) {
+      // deferred schedule: the search is parked with the rest of the round's launches; the bookkeeping that depends on where it stops,
+      // the statistics and the dumb blanker follow when the next blanker call (or the end of lrh_wideband_dsp) asks for the resume point
+      if (!c->h_clv_out) {
+        if (hipHostMalloc((void **)&c->h_clv_out, 4 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_clv, hipEventDisableTiming));
+      }
+      // liminfo_amplitude_factor as the limiter run BEFORE this round's left it (the serial order: search, then this round's limiter): the
+      // in-call limiter of the round has already been enqueued on its own stream, behind a copy of the factor taken for this search
+      if (c->wl_on && c->d_clv_amp && c->clv_amp_seq > 0) ca.amp_dev = c->d_clv_amp + ((c->clv_amp_seq - 1) & 1);
+      hipEvent_t ev_amp = ca.amp_dev ? c->ev_amp : nullptr;
+      LRH_DEVICE_WORK(c, {
+        if (ev_amp) HIPCHK(c, hipStreamWaitEvent(c->cur, ev_amp, 0));
+        { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
+        HIPCHK(c, hipMemcpyAsync(c->h_clv_out, (char *)c->d_bst + offsetof(BlankState, clever_out), 3 * sizeof(int), hipMemcpyDeviceToHost, c->cur));
+        HIPCHK(c, hipEventRecord(c->ev_clv, c->cur));
+        c->clv_issued = true;
+      });
+      c->clv_late.a = a; c->clv_late.pbeg = pbeg; c->clv_late.lowlevel = p->fft1_lowlevel_fraction;
+      c->clv_wait = true; c->clv_issued = false;
+      return LRH_OK;
+    }
     int out[3];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
     HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
@@ -1451,26 +1529,9 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
                                     first_bad + 1, st[first_bad + 1], ex[2 * first_bad + 2], ex[2 * first_bad + 3]);
         fprintf(stderr, "  fitted %d rejected %d\n", out[1], out[2]);
       } }
-    p->timf2p_fit = (out[0] - 16 + mask) & (mask & ~3);                  // blank1.c:1458-1461
-    a.post_stats = 1; a.fitted = out[1]; a.rejected = out[2]; a.clever_mode = c->bt.clever_bln_mode; a.clever_factor = c->bt.clever_bln_factor;
+    return blanker_tail(c, p, a, pbeg, out, p->fft1_lowlevel_fraction, coupled);
   }
-  const int m = (p->timf2p_fit - pbeg + 1 + mask) & mask;
-  p->timf2_blanker_points += m;
-  a.m = m; a.nstat = (c->clever_on ? ((p->timf2p_fit - pbeg) & mask) : a.total) / 4; a.blanker_points = p->timf2_blanker_points;
-  a.npartials = a.nstat < 4096 ? 1 : (a.nstat / 4096 < LRH_BLN_PARTIALS ? a.nstat / 4096 : LRH_BLN_PARTIALS);
-  a.interval = c->cfg.blanker_info_update_interval; a.avgnum = c->cfg.timf2_noise_floor_avgnum; a.factor = c->cfg.stupid_bln_factor;
-  a.lowlevel_fraction = p->fft1_lowlevel_fraction;
-  p->blanker_info_update_counter++;                                      // blank1.c:1550-1601
-  a.do_update = 0;
-  a.debug = c->dbg_bln;
-  if (p->blanker_info_update_counter >= a.interval) {
-    if (p->fft1_lowlevel_fraction < 0.1) p->blanker_info_update_counter--;
-    else { a.do_update = 1; p->blanker_info_update_counter = 0; p->timf2_blanker_points = 0; }
-  }
-  const int ring_words = c->cfg.timf2pow_size / 32;
-  LRH_DEVICE_WORK(c, { ProfScope ps(c, "blanker"); HIPCHK(c, launch_blanker(a, ring_words, c->cur)); });
-  if (coupled) { c->fin_args = a; c->fin_args.phase = 2; c->fin_pending = true; }
-  return LRH_OK;
+  return blanker_tail(c, p, a, pbeg, nullptr, p->fft1_lowlevel_fraction, coupled);
 }
 
 // ---- two coupled RF channels: see include/linrad_hip.h
@@ -2333,11 +2394,13 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   };
   // the one-round-late schedule, also for a single round per call when the previous call left its last round parked (or may park this one)
   const long need2 = 2L * batch * c->M1 + 2L * c->N2 + c->cfg.blnfit_range + 4L * (c->cfg.blanker_pulsewidth + 2);
-  const bool lag_ok = c->pipeline >= 2 && !small_rounds && c->cfg.second_fft_enable && (!c->prof || c->prof_keep_schedule) && !c->clever_on &&
+  const bool lag_ok = c->pipeline >= 2 && !small_rounds && c->cfg.second_fft_enable && (!c->prof || c->prof_keep_schedule) && !(c->clever_on && c->cfg.blanker_channels == 2) &&
                       need2 <= c->cfg.timf2pow_size && (long)batch * c->M1 / c->M2 + 2 <= c->cfg.max_fft2n &&
                       !(c->wl_on && c->wl_fft2);          // the second limiter reads the power sums of this round's fft2
-  const bool lagged = lag_ok && (nblocks >= 3 * batch || (c->persist && nblocks % batch == 0 && nblocks >= batch));
-  if (c->pend && !(lagged && c->persist && batch == c->pend_batch)) { if ((rc = flush_pending(c))) return rc; }
+  // (the linear blanker's resume point comes back from the device a round late: nothing of it is carried from call to call)
+  const bool carry_ok = c->persist && !c->clever_on;
+  const bool lagged = lag_ok && (nblocks >= 3 * batch || (carry_ok && nblocks % batch == 0 && nblocks >= batch));
+  if (c->pend && !(lagged && carry_ok && batch == c->pend_batch)) { if ((rc = flush_pending(c))) return rc; }
   InDsp in_dsp{c};
   if (!piped && !lagged) {
     while (nblocks > 0) {
@@ -2375,6 +2438,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // The stage functions do their pointer bookkeeping in the reference's order and park their launches in a queue
   // (LRH_DEVICE_WORK); results are those of the serial order because every ring holds two rounds (checked here).
   if (lagged) {
+    struct ClvDefer { lrh_ctx *c; ClvDefer(lrh_ctx *c_) : c(c_) { c->clv_defer = c->clever_on; c->clv_amp_seq = 0; } ~ClvDefer() { c->clv_defer = false; } } clv_defer{c};
     std::vector<std::function<int(lrh_ctx *)>> qb, qt;     // parked launches: blanker / fft2+mix1 of the previous round
     const bool carry = c->pend;                            // ... which may come from the previous call
     if (carry) { qb.swap(c->pend_b); qt.swap(c->pend_t); c->pend = false; }
@@ -2439,12 +2503,13 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       have_prev = true;
       left -= B; B = Bnext; round++;
     }
-    if (c->persist) {                                      // the last round stays parked: the next call (or flush_pending) issues it
+    if (carry_ok) {                                        // the last round stays parked: the next call (or flush_pending) issues it
       c->pend_b.swap(qb); c->pend_t.swap(qt);
       c->pend = true; c->pend_tail_flushed = tail_flushed; c->pend_batch = batch;
       return LRH_OK;
     }
     if ((rc = side_blanker())) return rc;
+    if (c->clv_wait && (rc = clever_late_finish(c, p))) return rc;     // linear blanker: the last round's resume point, then its dumb blanker
     if ((rc = main_tail())) return rc;
     HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
     return LRH_OK;

@@ -2579,7 +2579,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
         if (j < 0) j = 0;
         if (j >= LRH_MAX_REFPULSES_K) j = LRH_MAX_REFPULSES_K - 1;
         const int mrp = 2 * a.pulindex[j] * rs;
-        { const float af = s->amp_factor;                 // liminfo_amplitude_factor (blank1.c:143-144 / :323-324)
+        { const float af = a.amp_dev ? *a.amp_dev : s->amp_factor;   // liminfo_amplitude_factor (blank1.c:143-144 / :323-324)
           if (a.twochan) { c1 = c1 * s_in[2 * imax] * af; c2 = c2 * s_in[2 * imax] * af; } else { c1 *= s_in[2 * imax] * af; c2 *= s_in[2 * imax] * af; } }
         __syncthreads();
         for (int jj = lane; jj <= sub; jj += 64) {

@@ -149,6 +149,7 @@ struct CleverArgs {
   int pbeg, total;          // span: ring positions pbeg .. pbeg+total (= blnk_pend)
   int R, pwid, rs, largest; // blnfit_range, blanker_pulsewidth, refpul_size, largest_blnfit
   float amp_factor;         // liminfo_amplitude_factor
+  const float *amp_dev;     // where the search reads it on the device (NULL: BlankState::amp_factor)
   const float *refpulse, *phasefunc; const int *pulindex;
   int bln_size[7]; float bln_rest[7], bln_avgmax[7];
   BlankState *st;
