@@ -161,9 +161,10 @@ struct lrh_ctx {
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr, *d_sel_bigb = nullptr, *d_sel_bigg = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
-  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
+  int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr, *d_clv_dbg = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   // deferred schedule of lrh_wideband_dsp: the search of a round is issued a round late, its resume point comes back through a pinned slot
   // and the rest of that blanker call (statistics, dumb blanker) is issued when the next call -- which starts at the resume point -- comes
+  int clv_first = 0;    // LRH_CLEVER_FIRST=1: the deferred search runs ahead of the round's forward transform instead of beside it (measured: slower)
   bool clv_wait = false, clv_issued = false, clv_defer = false; hipEvent_t ev_clv = nullptr, ev_amp = nullptr; int *h_clv_out = nullptr; float *d_clv_amp = nullptr; int clv_amp_seq = 0;
   struct { BlankArgs a; int pbeg; float lowlevel; } clv_late;
   size_t clv_cap = 0; int clv_max_regions = 0; bool clever_force_serial = false;   // region list / backup of the span, grown on demand
@@ -375,7 +376,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -471,7 +472,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
-  if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;   // tests: the one-wave replay of the linear blanker
+  if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
+  if (const char *e6 = getenv("LRH_CLEVER_FIRST")) c->clv_first = atoi(e6);   // tests: the one-wave replay of the linear blanker
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
   if (const char *e7 = getenv("LRH_FFT2_RUN")) c->env_fft2_run = atoi(e7);
@@ -1476,19 +1478,19 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
     const size_t need = (size_t)a.total + 2 * ca.bk_margin + 1;
     if (c->clv_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pos, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
+      for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_dbg, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pos, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
         if (*q_) { hipFree(*q_); *q_ = nullptr; }
       c->clv_cap = 0;
       const size_t cap = need + need / 4;
       const int maxr = (int)(cap / ca.gap) + 2;
       int rc_ = LRH_OK;
-      if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 8 + 1024)) || (rc_ = dev_alloc(c, &c->d_clv_bk_pos, cap, false)) ||
+      if ((rc_ = dev_alloc(c, &c->d_clv_start, maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ext, 2 * (size_t)maxr)) || (rc_ = dev_alloc(c, &c->d_clv_ctl, 8 + 1024)) || (getenv("LRH_CLEVER_DEBUG") && (rc_ = dev_alloc(c, &c->d_clv_dbg, 2 * (size_t)maxr))) || (rc_ = dev_alloc(c, &c->d_clv_bk_pos, cap, false)) ||
           (!c->d_clv_logged && (rc_ = dev_alloc(c, &c->d_clv_logged, (size_t)c->cfg.timf2pow_size / 64))) ||
           (rc_ = dev_alloc(c, &c->d_clv_bk_pwr, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_tf, cap, false))) return rc_;
       if (coupled && ((rc_ = dev_alloc(c, &c->d_clv_bk_pwo, cap, false)) || (rc_ = dev_alloc(c, &c->d_clv_bk_ty, cap, false)))) return rc_;
       c->clv_cap = cap; c->clv_max_regions = maxr;
     }
-    ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
+    ca.reg_start = c->d_clv_start; ca.reg_ext = c->d_clv_ext; ca.reg_dbg = c->d_clv_dbg; ca.reg_ctl = c->d_clv_ctl; ca.max_regions = c->clv_max_regions;
     ca.logged = c->d_clv_logged; ca.bk_pos = c->d_clv_bk_pos; ca.bk_pwr = c->d_clv_bk_pwr; ca.bk_tf = c->d_clv_bk_tf; ca.bk_pwo = c->d_clv_bk_pwo; ca.bk_ty = c->d_clv_bk_ty; ca.force_serial = c->clever_force_serial ? 1 : 0;
     if (c->rec) {
       // deferred schedule: the search is parked with the rest of the round's launches; the bookkeeping that depends on where it stops,
@@ -1528,6 +1530,14 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
         if (first_bad >= 0) fprintf(stderr, "  first: region %d start %d ext [%d, %d] | region %d start %d ext [%d, %d]", first_bad, st[first_bad], ex[2 * first_bad], ex[2 * first_bad + 1],
                                     first_bad + 1, st[first_bad + 1], ex[2 * first_bad + 2], ex[2 * first_bad + 3]);
         fprintf(stderr, "  fitted %d rejected %d\n", out[1], out[2]);
+        if (c->d_clv_dbg && nr) {
+          std::vector<int> dbg(2 * (size_t)nr); hipMemcpy(dbg.data(), c->d_clv_dbg, 2 * nr * sizeof(int), hipMemcpyDeviceToHost);
+          int hist[8] = {0}, worst = 0; long long ticks = 0;
+          for (int r = 0; r < nr; r++) { hist[std::min(7, dbg[2 * r] / 2)]++; ticks += dbg[2 * r + 1]; if (dbg[2 * r + 1] > dbg[2 * worst + 1]) worst = r; }
+          fprintf(stderr, "clever: candidates per region 0-1 %d, 2-3 %d, 4-5 %d, 6-7 %d, 8-9 %d, 10-11 %d, 12-13 %d, more %d; mean %.1f us per region, slowest region %d: %d candidates, %.1f us, %d samples\n",
+                  hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], 0.01 * ticks / nr, worst, dbg[2 * worst], 0.01 * dbg[2 * worst + 1],
+                  (worst + 1 < nr ? st[worst + 1] : a.total) - st[worst]);
+        }
       } }
     return blanker_tail(c, p, a, pbeg, out, p->fft1_lowlevel_fraction, coupled);
   }
@@ -2474,6 +2484,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       const int Bnext = (left - B) < batch ? (left - B) : batch;
       // side: the blanker first -- fft2(k-1) on the main stream waits for it, the sums have a whole round of slack
       if (have_prev && (rc = side_blanker())) return rc;
+      // Linear blanker: its search -- a few thousand one-wave workgroups waiting on memory -- takes 0.2 ms with the chip to itself and
+      // 0.55 ms beside k_fft1w, whose workgroups fill every CU's registers.  Tried and dropped: a stream confined to a share of the CUs
+      // (22.0 against 26.5 Gsamples/s), and holding the transform back until the search is through (this switch: 24.0 against 26.3 --
+      // the host then waits with nothing queued behind the search).
+      if (have_prev && c->clv_first && c->clv_wait && c->clv_issued) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_clv, 0));
       hipEvent_t ev_t2 = round & 1 ? c->ev_timf2b : c->ev_timf2;
       if (!fuse) { on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0)); }
       if ((rc = sums(B))) return rc;

@@ -2391,6 +2391,36 @@ __global__ void k_clever_check(CleverArgs a)
   if (threadIdx.x == 0 && a.reg_ctl[1] == 0) a.st->clever_out[0] = (a.pbeg + a.reg_ctl[2]) & a.mask;
 }
 
+// 64 consecutive ring positions from pos0 (lane 0's): the lanes' bits laid onto the one or two 64-bit words of a per-sample bitmap they
+// fall in -- one atomic per word instead of one per sample (atomics on the same word queue up behind each other in the L2)
+struct ClvWordPair { int wa, wb; unsigned long long ma, mb; };
+__device__ __forceinline__ ClvWordPair clv_words(int pos0, unsigned long long bits, int wmask)
+{
+  ClvWordPair r; const int sh = pos0 & 63;
+  r.wa = (pos0 >> 6) & wmask; r.wb = (r.wa + 1) & wmask;
+  r.ma = bits << sh; r.mb = sh ? bits >> (64 - sh) : 0ull;
+  return r;
+}
+__device__ __forceinline__ unsigned long long clv_bcast64(unsigned long long v)     // lane 0's value in every lane
+{
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// value of lane l (wave-uniform l) in every lane
+__device__ __forceinline__ float clv_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// sum of lds[first], lds[first + step], ... (count terms) added one after the other in that order, every lane the same result: the
+// lanes fetch 64 terms at a time and the additions run on registers (a chain of LDS round trips otherwise)
+__device__ __forceinline__ float clv_ordered_sum(const float *lds, int first, int step, int count, float acc, int lane)
+{
+#pragma clang fp contract(off)
+  for (int c0 = 0; c0 < count; c0 += 64) {
+    const int n = min(64, count - c0);
+    const float v = lane < n ? lds[first + (c0 + lane) * step] : 0.f;
+    for (int j = 0; j < n; j++) acc += clv_lane(v, j);
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
 {
 #pragma clang fp contract(off)
@@ -2415,7 +2445,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     bool first = true;
     for (;;) {
       const int rel = (w + lane - first_word) & wmask;
-      unsigned long long v = rel < nwords ? a.cand[(w + lane) & wmask] : 0ull;
+      unsigned long long v = rel < nwords ? __hip_atomic_load(&a.cand[(w + lane) & wmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       if (first && lane == 0) v &= ~0ull << (pos0 & 63);
       first = false;
       const unsigned long long any = __ballot(v != 0ull);
@@ -2449,28 +2479,46 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
   const int r_end = (a.phase == 1 || reg + 1 >= nreg) ? total : a.reg_start[reg + 1] - (a.bln_size[a.largest] / 2 + 1);
   int ext_lo = r_begin, ext_hi = r_begin;
   int pf = r_begin, fitted = 0, rejected = 0;
+  const long long t_begin = a.reg_dbg ? (long long)wall_clock64() : 0;
   for (;;) {
-    __threadfence();                                      // the candidate words / rings as the previous pulse left them
+    // (the ring samples and flags this wave has rewritten come back in program order; the candidate words it changes with atomics are
+    // read with atomic loads -- no fence: a device-scope fence writes the L2 back, ~100 us per pulse)
     pf = next_candidate(pf);
     if (pf >= r_end) { pf = r_end; break; }
     // ---- the maximum that stays the maximum for blnfit_range samples (blank1.c:795-824)
+    // the walk "o++; new maximum -> m = R; m--" until m == 0 or o == total, 64 positions at a time: running maximum and the place of
+    // its last rise by wave scans (strict >: the first of equal values keeps the place, as in the walk)
     int o = pf - 1, p_max = pf, m = R, base = pf;
     float powermax = 10.f;
     stage_search(base);
     while (o != total && m > 0) {
-      o++;
-      if (o - base >= 256) { base = o; stage_search(base); }
-      const float v = s_spw[o - base];
-      if (v > powermax && s_sfl[o - base] < 64) { powermax = v; p_max = o; m = R; }
-      m--;
+      if (o + 1 - base > 256 - 64) { base = o + 1; stage_search(base); }
+      const int oj = o + 1 + lane;
+      const bool valid = oj <= total;
+      const float v = (valid && s_sfl[oj - base] < 64) ? s_spw[oj - base] : -1.f;     // powers are >= 0: -1 never rises above anything
+      float run = v;                                      // inclusive prefix maximum over the lanes
+      for (int d = 1; d < 64; d <<= 1) { const float u = __shfl_up(run, d, 64); if (lane >= d) run = fmaxf(run, u); }
+      float before = __shfl_up(run, 1, 64);               // maximum of everything before this position, the walk's powermax included
+      before = lane == 0 ? powermax : fmaxf(before, powermax);
+      int last = v > before ? lane : -1;                  // lane of the last rise at or before this position
+      for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(last, d, 64); if (lane >= d) last = max(last, u); }
+      const int mj = last >= 0 ? R - 1 - (lane - last) : m - (lane + 1);
+      const unsigned long long stop = __ballot(valid && (mj <= 0 || oj == total));
+      const int js = stop ? __ffsll((long long)stop) - 1 : 63;
+      const int last_s = __shfl(last, js, 64);
+      powermax = fmaxf(powermax, __shfl(run, js, 64));
+      if (last_s >= 0) p_max = o + 1 + last_s;
+      m = __shfl(mj, js, 64);
+      o += js + 1;
     }
     ext_hi = max(ext_hi, o);
     if (m > 0) break;                                     // too close to the end of the span: next call
     bool no_pulse = false;
-    if (a.flag[POS(p_max - 1)] >= 64) { pf = p_max; no_pulse = true; }
+    auto FLAG = [&](int oo) -> int { return (oo >= base && oo < base + 256) ? (int)s_sfl[oo - base] : (int)a.flag[POS(oo)]; };
+    if (FLAG(p_max - 1) >= 64) { pf = p_max; no_pulse = true; }
     else {
       if (p_max + 1 == total) break;
-      if (a.flag[POS(p_max + 1)] >= 64) no_pulse = true;
+      if (FLAG(p_max + 1) >= 64) no_pulse = true;
     }
     if (no_pulse) {                                       // blank1.c:833-856: next to a region already handled: walk on while the power does not rise
       while (pf != total) {
@@ -2497,8 +2545,14 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
       powermax = s_pw[W];
       float t1 = powermax * a.bln_rest[bln_no];
       if (t1 < sizlim) break;
-      t1 = 0.f;
-      while (k < a.bln_size[bln_no]) { t1 += s_pw[ia] + s_pw[ib]; ia++; ib--; k += 2; }
+      { const int cnt = a.bln_size[bln_no] > k ? (a.bln_size[bln_no] - k + 1) / 2 : 0;    // pairs s_pw[ia] + s_pw[ib], added in the walk's order
+        t1 = 0.f;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+          const int n = min(64, cnt - c0);
+          const float pr = lane < n ? s_pw[ia + c0 + lane] + s_pw[ib - c0 - lane] : 0.f;
+          for (int j = 0; j < n; j++) t1 += clv_lane(pr, j);
+        }
+        ia += cnt; ib -= cnt; k += 2 * cnt; }
       s_avg[bln_no] = t1 / powermax;
       bln_no++;
       if (bln_no > a.largest) break;
@@ -2601,8 +2655,8 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
           }
         }
         __syncthreads();
-        t3 = 0.f; t4 = 0.f;
-        for (int q = W - sub / 2; q <= W + sub / 2; q++) { t3 += s_old[q]; t4 += s_pw[q]; }
+        t3 = clv_ordered_sum(s_old, W - sub / 2, 1, 2 * (sub / 2) + 1, 0.f, lane);
+        t4 = clv_ordered_sum(s_pw, W - sub / 2, 1, 2 * (sub / 2) + 1, 0.f, lane);
         rv = t4 / t3;
         if (rv > 0.5f) {                                  // the fit removed too little: put the samples back (one channel: with the reference's signs, see the oracle)
           __syncthreads();
@@ -2625,30 +2679,49 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
           rv = -5.f;
         }
         __syncthreads();
-        for (int j0 = 0; j0 <= sub; j0 += 64) {
-          const int jj = j0 + lane;
-          const bool mine = jj <= sub;
-          const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj);
-          if (a.phase == 0) {                             // undo log: the first wave to touch a sample in this call keeps its original
-            float opo = 0.f;
-            if (mine && a.twochan) opo = a.pwr_own[pos];
-            if (a.twochan) __threadfence();               // ... read before the atomic below goes out
-            const unsigned long long bit = 1ull << (pos & 63);
-            const bool first = mine && !(atomicOr(&a.logged[pos >> 6], bit) & bit);
-            const unsigned long long firsts = __ballot(first);
-            if (firsts) {
-              int base = 0;
-              if (lane == 0) base = atomicAdd(&a.reg_ctl[3], __popcll(firsts));
-              base = __shfl(base, 0, 64);
-              if (first) {
-                const int e = base + __popcll(firsts & ((1ull << lane) - 1));
-                a.bk_pos[e] = pos; a.bk_pwr[e] = s_old[q];
-                if (a.twochan) { a.bk_tf[e] = a.chan ? s_oty[q] : s_otf[q]; a.bk_ty[e] = a.chan ? s_otf[q] : s_oty[q]; a.bk_pwo[e] = opo; }
-                else a.bk_tf[e] = s_otf[q];
-              }
-            }
+        // undo log: the first wave to touch a sample in this call keeps its original.  One atomic or per word of the bitmap tells which
+        // of the samples are new to the log, one atomic add reserves their entries; then the samples go out.
+        unsigned long long firsts[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+        float opo[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int nfirst = 0;
+        if (a.phase == 0) {
+          if (a.twochan) {                                // the own channel's power ring is not staged: read before the atomics go out
+#pragma unroll
+            for (int it = 0; it < 5; it++) { const int jj = 64 * it + lane; if (jj <= sub) opo[it] = a.pwr_own[POS(p_max - sub / 2 + jj)]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
-          if (!mine) continue;
+          unsigned long long olda[5], oldb[5];
+#pragma unroll
+          for (int it = 0; it < 5; it++) {
+            olda[it] = 0ull; oldb[it] = 0ull;
+            if (64 * it > sub) continue;
+            const ClvWordPair wp = clv_words(POS(p_max - sub / 2 + 64 * it), __ballot(64 * it + lane <= sub), wmask);
+            if (lane == 0) { if (wp.ma) olda[it] = atomicOr(&a.logged[wp.wa], wp.ma); if (wp.mb) oldb[it] = atomicOr(&a.logged[wp.wb], wp.mb); }
+          }
+#pragma unroll
+          for (int it = 0; it < 5; it++) {
+            if (64 * it > sub) continue;
+            const int sh = POS(p_max - sub / 2 + 64 * it) & 63;
+            const unsigned long long oa = clv_bcast64(olda[it]), ob = clv_bcast64(oldb[it]);
+            const bool was = sh + lane < 64 ? (oa >> (sh + lane)) & 1 : (ob >> (sh + lane - 64)) & 1;
+            firsts[it] = __ballot(64 * it + lane <= sub && !was);
+            nfirst += __popcll(firsts[it]);
+          }
+          int base = 0;
+          if (nfirst) { if (lane == 0) base = atomicAdd(&a.reg_ctl[3], nfirst); base = __builtin_amdgcn_readfirstlane(base); }
+#pragma unroll
+          for (int it = 0; it < 5; it++) {
+            if ((firsts[it] >> lane) & 1) {
+              const int jj = 64 * it + lane, q = W - sub / 2 + jj, e = base + __popcll(firsts[it] & ((1ull << lane) - 1));
+              a.bk_pos[e] = POS(p_max - sub / 2 + jj); a.bk_pwr[e] = s_old[q];
+              if (a.twochan) { a.bk_tf[e] = a.chan ? s_oty[q] : s_otf[q]; a.bk_ty[e] = a.chan ? s_otf[q] : s_oty[q]; a.bk_pwo[e] = opo[it]; }
+              else a.bk_tf[e] = s_otf[q];
+            }
+            base += __popcll(firsts[it]);
+          }
+        }
+        for (int jj = lane; jj <= sub; jj += 64) {
+          const int q = W - sub / 2 + jj, pos = POS(p_max - sub / 2 + jj);
           ring_x[pos] = s_tf[q]; a.pwr[pos] = s_pw[q];
           if (a.twochan) { ring_y[pos] = s_ty[q]; const float2 o = a.chan ? s_ty[q] : s_tf[q]; a.pwr_own[pos] = o.x * o.x + o.y * o.y; }
         }
@@ -2659,10 +2732,10 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     // ---- set_flag (blank1.c:615-682): +-pulsewidth, then outwards for as long as the power keeps falling
     __syncthreads();
     auto PW = [&](int oo) -> float { const int d = oo - p_max; return (d >= -W && d <= W) ? s_pw[d + W] : a.pwr[POS(oo)]; };
-    auto SETF = [&](int oo) {
+    auto SETF = [&](int oo) {                             // inside the neighbourhood: in LDS, written out together below
       const int d = oo - p_max, pos = POS(oo);
       if (d >= -W && d <= W) s_fl[d + W] = value;
-      if (lane == 0) { a.flag[pos] = value; if (oo >= 0 && oo <= total) atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63))); }
+      else if (lane == 0) { a.flag[pos] = value; if (oo >= 0 && oo <= total) atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63))); }
     };
     SETF(p_max);
     int pa = p_max, pb = p_max;
@@ -2673,18 +2746,28 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
     if (!(pa >= total)) while (PW(pa) < PW(p0) && pa != total) { p0 = pa; SETF(pa); pa++; }
     ext_lo = min(ext_lo, pb); ext_hi = max(ext_hi, pa);
     __syncthreads();
+    // the flags just set are the run pb+1 .. pa-1
+    for (int oo = max(pb + 1, p_max - W) + lane; oo <= min(pa - 1, p_max + W); oo += 64) a.flag[POS(oo)] = value;
     // ---- candidate bits of the samples the subtraction rewrote
-    for (int i = lane; i <= 2 * W; i += 64) {
-      const int oo = p_max - W + i, pos = POS(oo);
-      if (oo < 0 || oo > total) continue;
-      if (s_pw[i] > nfl && s_fl[i] <= 64) atomicOr(&a.cand[pos >> 6], 1ull << (pos & 63));
-      else atomicAnd(&a.cand[pos >> 6], ~(1ull << (pos & 63)));
+    for (int c0 = 0; c0 <= 2 * W; c0 += 64) {
+      const int i = c0 + lane, oo = p_max - W + i;
+      const bool in = i <= 2 * W && oo >= 0 && oo <= total;
+      const bool hot = in && s_pw[min(i, 2 * W)] > nfl && s_fl[min(i, 2 * W)] <= 64;
+      const int pos0 = POS(p_max - W + c0);
+      const ClvWordPair off = clv_words(pos0, __ballot(in && !hot), wmask), on = clv_words(pos0, __ballot(hot), wmask);
+      if (lane == 0) {
+        if (off.ma) atomicAnd(&a.cand[off.wa], ~off.ma);
+        if (off.mb) atomicAnd(&a.cand[off.wb], ~off.mb);
+        if (on.ma) atomicOr(&a.cand[on.wa], on.ma);
+        if (on.mb) atomicOr(&a.cand[on.wb], on.mb);
+      }
     }
   }
   if (lane == 0) {
     if (a.phase == 1) { s->clever_out[0] = POS(pf); s->clever_out[1] = fitted; s->clever_out[2] = rejected; s->clever_serial_calls++; }
     else {
       a.reg_ext[2 * reg] = ext_lo; a.reg_ext[2 * reg + 1] = ext_hi;
+      if (a.reg_dbg) { a.reg_dbg[2 * reg] = fitted + rejected; a.reg_dbg[2 * reg + 1] = (int)((long long)wall_clock64() - t_begin); }
       if (fitted) atomicAdd(&s->clever_out[1], fitted);
       if (rejected) atomicAdd(&s->clever_out[2], rejected);
       if (reg == nreg - 1) a.reg_ctl[2] = pf;           // where the walk of the whole span stops (blank1.c:1458)

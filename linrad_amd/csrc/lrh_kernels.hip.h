@@ -158,6 +158,7 @@ struct CleverArgs {
   // or changed, k_clever_check verifies that neighbouring extents stay apart, and when they do not (a monotone run of hundreds of
   // samples) the span is restored from the backup and replayed by one wave in the reference's order
   int gap; int *reg_start; int max_regions; int *reg_ext;     // [max_regions] first candidate offset; [2*max_regions] lo, hi
+  int *reg_dbg;             // diagnostics (LRH_CLEVER_DEBUG), or NULL: [2*max_regions] candidates handled, wall clock ticks (100 MHz) per region
   int *reg_ctl;             // [0] number of regions, [1] violation flag, [2] pf of the last region, [3] undo log entries, [8 ..] per-block region counts (k_clever_regions)
   // undo log instead of a copy of the span: the first wave to rewrite a ring sample in a call (bit in `logged`, taken with an atomic or)
   // appends the sample's values as it staged them -- read before its own atomic, hence before any other wave's write, which comes after
