@@ -944,7 +944,7 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
 int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
 {
   LRH_ENTER(c);
-  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n || speknum > 2048))) return LRH_EINVAL;   // 2048: k_spur's LDS working set
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n || speknum > 1022))) return LRH_EINVAL;   // 1022: k_spur keeps speknum + 2 history entries in LDS (107 KB then)
   if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel, second fft on");
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_touched, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })

@@ -3394,17 +3394,61 @@ namespace lrh {
 struct DevSpur { int location, flag; float freq, d0pha, d1pha, d2pha, ampl, noise, avgd2; };   // = lrh_spur
 #define LRH_PI 3.1415926535897932
 
-__device__ __forceinline__ float wsum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+// Cross-lane steps as DPP operands of the VALU (a few cycles each) instead of __shfl's ds_bpermute (an LDS round trip, ~100 cycles):
+// one look at the history is a chain of ~60 such steps (8.5 -> 6.5 us per transform and spur at spur_speknum 16; what remains is the chain
+// itself: ~12 LDS hand-overs between the lanes, eight single-precision sincos / atan2 and the reductions, twice per transform).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }   // 0 where the source lane does not exist
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // l wave-uniform
+__device__ __forceinline__ float up1(float v) { return dpp_f<0x138>(v); }            // wave_shr:1 -- lane l gets lane l - 1's value (lane 0: 0)
+__device__ __forceinline__ float wsum(float v)
+{
+  v += dpp_f<0xb1>(v);                                     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4e>(v);                                     // quad_perm [2,3,0,1]
+  v += dpp_f<0x124>(v);                                    // row_ror:4
+  v += dpp_f<0x128>(v);                                    // row_ror:8: every lane holds the sum of its row of sixteen
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
 __device__ __forceinline__ float2 wsum2(float2 v) { return make_float2(wsum(v.x), wsum(v.y)); }
+__device__ __forceinline__ int wmax(int v)
+{
+  v = max(v, dpp_i<0xb1>(v)); v = max(v, dpp_i<0x4e>(v)); v = max(v, dpp_i<0x124>(v)); v = max(v, dpp_i<0x128>(v));     // values >= 0: the 0 of a missing lane is harmless
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// inclusive prefix sums over the lanes: within the rows of sixteen by row_shr 1, 2, 4, 8, then the totals of the rows before
+__device__ __forceinline__ float wscan(float v, int lane)
+{
+  v += dpp_f<0x111>(v); v += dpp_f<0x112>(v); v += dpp_f<0x114>(v); v += dpp_f<0x118>(v);
+  const float t0 = lane_f(v, 15), t1 = lane_f(v, 31), t2 = lane_f(v, 47);
+  const int row = lane >> 4;
+  return v + (row >= 1 ? t0 : 0.f) + (row >= 2 ? t1 : 0.f) + (row >= 3 ? t2 : 0.f);
+}
+__device__ __forceinline__ int wscan(int v, int lane)
+{
+  v += dpp_i<0x111>(v); v += dpp_i<0x112>(v); v += dpp_i<0x114>(v); v += dpp_i<0x118>(v);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = lane >> 4;
+  return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+// The reference calls the C library in double on float data and rounds the results to float.  Here the angle is reduced to (-pi, pi] in
+// double (three operations) and everything else runs in single precision: results agree to float rounding, and a lone wave -- which is
+// what a spur's loop is -- would spend a good part of its time in the double versions (~150 dependent instructions each)
+__device__ __forceinline__ void sincos_red(double ang, float &sn, float &cs)
+{
+  double t = ang * (0.5 / LRH_PI);
+  t -= rint(t);
+  sincosf((float)(t * (2 * LRH_PI)), &sn, &cs);
+}
 __device__ __forceinline__ float2 rot(float2 z, double ang)          // z e^{j ang}
 {
-  double sn, cs; sincos(ang, &sn, &cs);
-  const float c = (float)cs, s_ = (float)sn;
+  float s_, c; sincos_red(ang, s_, c);
   return make_float2(c * z.x - s_ * z.y, c * z.y + s_ * z.x);
 }
 __device__ __forceinline__ float2 unit_of(float2 z, float floor_)    // z / |z|, zero below the floor
 {
-  const float r = (float)sqrt((double)(z.x * z.x + z.y * z.y));
+  const float r = sqrtf(z.x * z.x + z.y * z.y);
   return r > floor_ ? make_float2(z.x / r, z.y / r) : make_float2(0.f, 0.f);
 }
 __device__ __forceinline__ float2 mulc(float2 a_, float2 b) { return make_float2(a_.x * b.x + a_.y * b.y, a_.y * b.x - a_.x * b.y); }   // a conj(b)
@@ -3414,7 +3458,7 @@ __device__ __forceinline__ float2 mulc(float2 a_, float2 b) { return make_float2
 struct SpurWork { float2 *h, *d, *g; float *t; float *row; };   // row: the newest transform's seven bins (the lanes that fetched them are not the lane that projects them)
 
 struct SpurWave {
-  const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; SpurWork w; const int lane, n, maxn, mask;
+  const SpurArgs &a; DevSpur &q; float *tab, *zsig; int *uind; SpurWork w; const int lane, n, maxn, mask; const float *spec;   // tab / zsig / uind / spec: the tables in global memory (acquisition) or their copies in LDS (tracking), ring of maxn = mask + 1 slots
 
   __device__ int slot(int na, int age) const { return (na - age) & mask; }
   // line shape for a frequency: offset into the table of shapes and the half-bin position j (0 / 1); -1 when the carrier has left the
@@ -3441,7 +3485,7 @@ struct SpurWave {
   {
     float2 p = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 7; i++) { const float sh = a.spectra[ind + i]; p.x += bins[2 * i] * sh; p.y += bins[2 * i + 1] * sh; }
+    for (int i = 0; i < 7; i++) { const float sh = spec[ind + i]; p.x += bins[2 * i] * sh; p.y += bins[2 * i + 1] * sh; }
     if ((j ^ (q.location & 1)) == 1) { p.x = -p.x; p.y = -p.y; }
     return p;
   }
@@ -3516,30 +3560,29 @@ struct SpurWave {
     float2 bend = make_float2(0.f, 0.f);
     for (int i = 1 + av / 2 + lane; i < ns - av / 2; i += 64) { const float2 u = unit_of(mulc(w.g[i], w.g[i - 1]), 0.00001f); bend.x += u.x; bend.y += u.y; }
     bend = wsum2(bend);
-    c2 = (float)atan2((double)bend.y, (double)bend.x);
+    c2 = (float)atan2f(bend.y, bend.x);
     {
       float tot = q.d2pha + c2;
-      if (fabs((double)tot) > a.max_d2 && fabs((double)c2) > a.max_d2) c2 = -q.d2pha / n;    // implausible: pull the drift back instead
+      if (fabsf(tot) > a.max_d2 && fabsf(c2) > a.max_d2) c2 = -q.d2pha / n;    // implausible: pull the drift back instead
       else {
         tot = a.weiold * q.avgd2 + a.weinew * tot;
         float trust = 1.f;                                // strong spurs follow the averaged drift, weak ones the new estimate
-        if (q.noise > 0.000001 && fabs((double)q.ampl) > 0.000001) { trust = (float)(0.1 * fabs((double)q.ampl) / q.noise); trust = 1 / (1 + trust); }
+        if (q.noise > 0.000001 && fabsf(q.ampl) > 0.000001) { trust = 0.1f * fabsf(q.ampl) / q.noise; trust = 1 / (1 + trust); }
         c2 = trust * (tot - q.d2pha) + (1 - trust) * c2;
       }
     }
     // phase track relative to the newest entry: unwrapped step angles summed from the new end, the curvature just found taken out
     for (int base = 0, carry = 0; base < ns; base += 64) {              // unwrap: running count of 2 pi jumps between neighbours
       const int i = base + lane;
-      const float cur = i < ns ? (float)atan2((double)w.g[i].y, (double)w.g[i].x) : 0.f;
-      float prev = __shfl_up(cur, 1, 64);
+      const float cur = i < ns ? (float)atan2f(w.g[i].y, w.g[i].x) : 0.f;
+      float prev = up1(cur);
       if (lane == 0) prev = base ? w.t[ns] : cur;                        // w.t[ns]: last raw angle of the previous chunk (parked below)
       int jump = 0;
       if (i < ns && i > 0) { if (cur - prev > LRH_PI) jump = -1; else if (cur - prev < -LRH_PI) jump = 1; }
-      int incl = jump;
-      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+      const int incl = wscan(jump, lane);
       if (i < ns) w.t[i] = cur + (float)(2 * LRH_PI) * (float)(carry + incl);
-      carry += __shfl(incl, 63, 64);
-      const float last_raw = __shfl(cur, 63, 64);
+      carry += __builtin_amdgcn_readlane(incl, 63);
+      const float last_raw = lane_f(cur, 63);
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) w.t[ns] = last_raw;
       __builtin_amdgcn_wave_barrier();
@@ -3551,9 +3594,8 @@ struct SpurWave {
       for (int ch = 0; ch < nchunk; ch++) {
         const int i = ns - 1 - (ch * 64 + lane);                          // lane 0 takes the newest
         const float v = i >= 0 ? w.t[i] : 0.f;
-        float incl = v;
-        for (int o = 1; o < 64; o <<= 1) { const float up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
-        const float tot = __shfl(incl, 63, 64);
+        const float incl = wscan(v, lane);
+        const float tot = lane_f(incl, 63);
         __builtin_amdgcn_wave_barrier();
         if (i >= 0) { const int age = ns - i; w.t[i] = -(carry + incl) - (age >= 2 ? age * (age - 1) * (float)(c2 * 0.5) : 0.f); }
         carry += tot;
@@ -3580,8 +3622,8 @@ struct SpurWave {
       dir.x += u.x; dir.y += u.y;
     }
     dir = wsum2(dir);
-    c0 = (float)atan2((double)dir.y, (double)dir.x);
-    { const float nrm = (float)sqrt((double)(dir.x * dir.x + dir.y * dir.y)); dir.x /= nrm; dir.y /= nrm; }
+    c0 = (float)atan2f(dir.y, dir.x);
+    { const float nrm = sqrtf(dir.x * dir.x + dir.y * dir.y); dir.x /= nrm; dir.y /= nrm; }
     __builtin_amdgcn_wave_barrier();
     // straight-line fit of the residual phase across the history: a last correction of the slope
     float fit = 0.f;
@@ -3589,8 +3631,8 @@ struct SpurWave {
       const float2 r = mulc(w.g[i], dir);
       w.g[i] = r;
       const float x = (float)(-0.5 * ns) + i;
-      if (r.x > 0 && fabs((double)r.y) < fabs((double)r.x)) fit += (float)(x * r.y / fabs((double)r.x));
-      else fit += (float)(x * atan2((double)r.y, (double)r.x));
+      if (r.x > 0 && fabsf(r.y) < fabsf(r.x)) fit += x * r.y / fabsf(r.x);
+      else fit += x * atan2f(r.y, r.x);
     }
     const float tilt = wsum(fit) / a.linefit;
     c1 += tilt;
@@ -3603,7 +3645,7 @@ struct SpurWave {
     float res = 0.f;
     for (int i = lane; i < n; i += 64) { const float2 r = w.g[i]; res += (r.x - ampl) * (r.x - ampl) + r.y * r.y; }
     q.ampl = ampl;
-    q.noise = (float)sqrt((double)(wsum(res) / n));
+    q.noise = sqrtf(wsum(res) / n);
     __builtin_amdgcn_wave_barrier();
   }
   // the loop takes the corrections: they were found against the oscillator one step ahead
@@ -3709,7 +3751,7 @@ struct SpurWave {
           const float2 *z = a.fft2 + (size_t)sidx * a.n2 + q.location;
 #pragma unroll
           for (int i = 0; i < 7; i++) {
-            const float sh = a.spectra[id + i]; const float2 v = z[i];
+            const float sh = spec[id + i]; const float2 v = z[i];
             res[i + 1] += (float)((double)(v.x - sh * carrier.x) * (double)(v.x - sh * carrier.x) + (double)(v.y - sh * carrier.y) * (double)(v.y - sh * carrier.y));
           }
           res[0] += z[-1].x * z[-1].x + z[-1].y * z[-1].y;
@@ -3733,17 +3775,22 @@ struct SpurWave {
   }
 
   // one transform of a locked spur
-  __device__ void track(int na)
+  // `pre`: lane l < 7 brings bin pre_loc + l of this transform, fetched while the previous transform was being worked on
+  __device__ void track(int na, float2 pre, int pre_loc)
   {
     float2 *z = a.fft2 + (size_t)na * a.n2;
-    float *row = tab + na * 14;
+    float *row = tab + slot(na, 0) * 14;
     int ind, j;
+    auto fetch = [&]() -> float2 {                         // the transform's seven bins at the window's place
+      if (pre_loc == q.location) return pre;
+      return lane < 7 ? z[q.location + lane] : make_float2(0.f, 0.f);
+    };
     if (q.flag == 1) {                                   // unlocked a moment ago: keep the window on the last known frequency
       j = (int)(q.freq) + 2 - q.location - 4;
       if (j < 0 || j > 1) move_window(j < 0 ? -1 : 1, na);
     }
     if (q.flag != 0) {                                   // not locked: the history goes on, re-locking is the control plane's business
-      if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; }
+      { const float2 v = fetch(); if (lane < 7) { row[2 * lane] = v.x; row[2 * lane + 1] = v.y; } }
       q.flag++;
       if (q.flag > 1000000) q.flag -= 2 * 3 * 5 * 7 * n;
       __builtin_amdgcn_wave_barrier();
@@ -3753,9 +3800,11 @@ struct SpurWave {
     if (lane < 14) w.row[lane] = 0.f;                      // (a window move below shifts the copy along with the rows)
     __builtin_amdgcn_wave_barrier();
     if (!centre(q.freq, na, ind, j)) return;
-    if (lane < 7) { const float2 v = z[q.location + lane]; row[2 * lane] = v.x; row[2 * lane + 1] = v.y; w.row[2 * lane] = v.x; w.row[2 * lane + 1] = v.y; }
+    const float2 bins = fetch();
+    const int bins_loc = q.location;
+    if (lane < 7) { row[2 * lane] = bins.x; row[2 * lane + 1] = bins.y; w.row[2 * lane] = bins.x; w.row[2 * lane + 1] = bins.y; }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { uind[na] = ind; const float2 pr = project(w.row, ind, j); zsig[2 * na] = pr.x; zsig[2 * na + 1] = pr.y; }
+    if (lane == 0) { const int s0 = slot(na, 0); uind[s0] = ind; const float2 pr = project(w.row, ind, j); zsig[2 * s0] = pr.x; zsig[2 * s0 + 1] = pr.y; }
     __builtin_amdgcn_wave_barrier();
     int moved = 0;
     for (int iter = 1;; iter++) {
@@ -3770,7 +3819,7 @@ struct SpurWave {
         const float sl = (q.d1pha + q.d2pha) - m * q.d2pha;
         // fractional part from this age's slope; integer part: nearest to the previous age's frequency, which changes by far less than a bin
         float fq = freq_of(sl, fq_near);
-        const float prev = __shfl_up(fq, 1, 64);
+        const float prev = up1(fq);
         if (lane > 0) fq = freq_of(sl, prev);
         int jj; const int id = m <= n ? shape(fq, q.location, jj) : 0;
         if (__any(m <= n && id < 0)) { left = true; break; }
@@ -3782,14 +3831,14 @@ struct SpurWave {
           uind[sidx] = id;
           if (k != 0) { const float2 pr = project(m == 0 ? w.row : tab + sidx * 14, id, jj); zsig[2 * sidx] = pr.x; zsig[2 * sidx + 1] = pr.y; }
         }
-        fq_near = __shfl(fq, 63, 64);
+        fq_near = lane_f(fq, 63);
       }
-      for (int o = 32; o > 0; o >>= 1) moved = max(moved, __shfl_xor(moved, o, 64));
+      moved = wmax(moved);
       __builtin_amdgcn_wave_barrier();
       if (left || !(moved > 20 && iter < 5)) break;
     }
     if (moved != 0) refine(na);
-    if (fabs((double)q.ampl) < a.minston * q.noise) { q.flag = 1; return; }      // lost in the noise
+    if (fabsf(q.ampl) < a.minston * q.noise) { q.flag = 1; return; }      // lost in the noise
     // settled: the loop moves on by one transform and the carrier leaves the new bins
     const float curv = q.d2pha, ampl = q.ampl;
     const float slope = q.d1pha + curv, phase = q.d0pha + slope;
@@ -3798,27 +3847,66 @@ struct SpurWave {
     q.avgd2 = a.weiold * q.avgd2 + a.weinew * curv;
     q.freq = freq_of(slope, q.freq);
     if (!centre(q.freq, na, ind, j)) return;
-    float cr = (float)(cos((double)phase) * ampl), ci = (float)(sin((double)phase) * ampl);
-    if ((j ^ (q.location & 1)) == 1) { cr = (float)(-cos((double)phase) * ampl); ci = (float)(-sin((double)phase) * ampl); }
-    if (lane < 7) { float2 v = z[q.location + lane]; const float sh = a.spectra[ind + lane]; v.x -= sh * cr; v.y -= sh * ci; z[q.location + lane] = v; }
+    float cr, ci; { float sn_, cs_; sincos_red((double)phase, sn_, cs_); cr = cs_ * ampl; ci = sn_ * ampl; }
+    if ((j ^ (q.location & 1)) == 1) { cr = -cr; ci = -ci; }
+    if (lane < 7) {                                        // (the bins are still in registers unless the window has moved since)
+      float2 v = bins_loc == q.location ? bins : z[q.location + lane];
+      const float sh = spec[ind + lane]; v.x -= sh * cr; v.y -= sh * ci; z[q.location + lane] = v;
+    }
     __builtin_amdgcn_wave_barrier();
   }
 };
 
+// LDS of k_spur: the loop's working set (SpurWork), the line-shape table, and the newest `slots` entries (a power of two >= speknum + 2)
+// of the spur's history -- rows of seven bins, projected signal, shape index -- which live in global memory between launches.  Nothing
+// on the path from one transform to the next waits for global memory: the history is read once, the transform's seven bins are
+// fetched one transform ahead, stores are not waited for.
+constexpr int SPUR_SPECTRA = 256 * 8;      // SPUR_SPECTRA (include/linrad_hip.h): 256 line shapes of 8 floats
+__host__ __device__ inline int spur_lds_slots(int speknum) { int l = 4; while (l < speknum + 2) l <<= 1; return l; }
+__host__ __device__ inline size_t spur_lds_bytes(int speknum, bool mirror)
+{
+  size_t b = (size_t)speknum * (3 * sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16;
+  if (mirror) b += sizeof(float) * (SPUR_SPECTRA + (size_t)spur_lds_slots(speknum) * 17);
+  return b;
+}
 __global__ __launch_bounds__(64) void k_spur(SpurArgs a)
 {
   extern __shared__ float spur_lds[];
   const int s = blockIdx.x, lane = threadIdx.x, n = a.speknum;
-  const int maxn = a.na_mask + 1;
+  const int gmax = a.na_mask + 1, L = spur_lds_slots(n);
   DevSpur q = reinterpret_cast<DevSpur *>(a.spurs)[s];
   SpurWork w;
   w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n); w.row = w.t + n + 2;
-  SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask};
+  float *spec = w.row + 16 + 4, *tab_l = spec + SPUR_SPECTRA, *zsig_l = tab_l + (size_t)L * 14;
+  int *uind_l = reinterpret_cast<int *>(zsig_l + 2 * L);
+  float *const g_tab = a.table + (size_t)s * gmax * 14, *const g_sig = a.signal + (size_t)s * gmax * 2;
+  int *const g_ind = a.ind + (size_t)s * gmax;
+  for (int i = lane; i < SPUR_SPECTRA; i += 64) spec[i] = a.spectra[i];
+  for (int m = lane; m <= n; m += 64) {                    // the history behind the first transform of this launch
+    const int gs = (a.first_na - 1 - m) & a.na_mask, ls = gs & (L - 1);
+#pragma unroll
+    for (int i = 0; i < 14; i++) tab_l[ls * 14 + i] = g_tab[gs * 14 + i];
+    zsig_l[2 * ls] = g_sig[2 * gs]; zsig_l[2 * ls + 1] = g_sig[2 * gs + 1]; uind_l[ls] = g_ind[gs];
+  }
+  __builtin_amdgcn_wave_barrier();
+  SpurWave T{a, q, tab_l, zsig_l, uind_l, w, lane, n, L, L - 1, spec};
   int lo = q.location, hi = q.location;
+  float2 pre = make_float2(0.f, 0.f); int pre_loc = q.location;
+  if (lane < 7) pre = a.fft2[(size_t)(a.first_na & a.na_mask) * a.n2 + pre_loc + lane];
   for (int b = 0; b < a.batch; b++) {
-    L.track((a.first_na + b) & a.na_mask);
+    const int na = (a.first_na + b) & a.na_mask;
+    float2 nxt = make_float2(0.f, 0.f); const int nxt_loc = q.location;
+    if (b + 1 < a.batch && lane < 7) nxt = a.fft2[(size_t)((a.first_na + b + 1) & a.na_mask) * a.n2 + nxt_loc + lane];
+    T.track(na, pre, pre_loc);
+    pre = nxt; pre_loc = nxt_loc;
     lo = min(lo, q.location); hi = max(hi, q.location);
-    __threadfence_block();
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int m = lane; m <= n; m += 64) {                    // the history as the next launch will want it
+    const int gs = (a.first_na + a.batch - 1 - m) & a.na_mask, ls = gs & (L - 1);
+#pragma unroll
+    for (int i = 0; i < 14; i++) g_tab[gs * 14 + i] = tab_l[ls * 14 + i];
+    g_sig[2 * gs] = zsig_l[2 * ls]; g_sig[2 * gs + 1] = zsig_l[2 * ls + 1]; g_ind[gs] = uind_l[ls];
   }
   if (lane == 0) {
     reinterpret_cast<DevSpur *>(a.spurs)[s] = q;
@@ -3827,8 +3915,12 @@ __global__ __launch_bounds__(64) void k_spur(SpurArgs a)
 }
 hipError_t launch_spur(const SpurArgs &a, hipStream_t st)
 {
-  const size_t lds = (size_t)a.speknum * (3 * sizeof(float2) + sizeof(float)) + 16 * sizeof(float) + 16;
-  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  const size_t lds = spur_lds_bytes(a.speknum, true);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;       // speknum <= 1022 (lrh_spur_config)
+  if (lds > 48 * 1024) {
+    static bool raised = false;
+    if (!raised) { const hipError_t e = hipFuncSetAttribute((const void *)k_spur, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); if (e != hipSuccess) return e; raised = true; }
+  }
   hipLaunchKernelGGL(k_spur, dim3(a.nspurs), dim3(64), lds, st, a);
   return hipGetLastError();
 }
@@ -3842,7 +3934,7 @@ __global__ __launch_bounds__(64) void k_spur_acquire(SpurArgs a, int pnt, int *r
   DevSpur q;
   SpurWork w;
   w.h = reinterpret_cast<float2 *>(spur_lds); w.d = w.h + n; w.g = w.d + n; w.t = reinterpret_cast<float *>(w.g + n); w.row = w.t + n + 2;
-  SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask};
+  SpurWave L{a, q, a.table + (size_t)s * maxn * 14, a.signal + (size_t)s * maxn * 2, a.ind + (size_t)s * maxn, w, lane, n, maxn, a.na_mask, a.spectra};
   const bool ok = L.acquire(a.first_na & a.na_mask, pnt);
   if (lane == 0) { reinterpret_cast<DevSpur *>(a.spurs)[s] = q; result[0] = ok ? 1 : 0; }
 }
