@@ -13,7 +13,7 @@ from refcases import CASES
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r02"
+ROUND = "r03"
 
 
 def _clean(v):
