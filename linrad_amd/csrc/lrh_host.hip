@@ -39,7 +39,6 @@ hipError_t launch_pol(const PolArgs &a, hipStream_t st);
 hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
-hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
 hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
@@ -164,6 +163,7 @@ struct lrh_ctx {
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr, *d_clv_dbg = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   // deferred schedule of lrh_wideband_dsp: the search of a round is issued a round late, its resume point comes back through a pinned slot
   // and the rest of that blanker call (statistics, dumb blanker) is issued when the next call -- which starts at the resume point -- comes
+  int clv_split = 0; hipEvent_t clv_ev_t2 = nullptr;   // LRH_CLEVER_SPLIT=1: candidate bits and region list a round ahead of the replay (clv_ev_t2: this round's make_timf2, set by the deferred schedule); measured: slower
   int clv_first = 0;    // LRH_CLEVER_FIRST=1: the deferred search runs ahead of the round's forward transform instead of beside it (measured: slower)
   bool clv_wait = false, clv_issued = false, clv_defer = false; hipEvent_t ev_clv = nullptr, ev_amp = nullptr; int *h_clv_out = nullptr; float *d_clv_amp = nullptr; int clv_amp_seq = 0;
   struct { BlankArgs a; int pbeg; float lowlevel; } clv_late;
@@ -473,7 +473,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
-  if (const char *e6 = getenv("LRH_CLEVER_FIRST")) c->clv_first = atoi(e6);   // tests: the one-wave replay of the linear blanker
+  if (const char *e6 = getenv("LRH_CLEVER_FIRST")) c->clv_first = atoi(e6);
+  if (const char *e7 = getenv("LRH_CLEVER_SPLIT")) c->clv_split = atoi(e7);   // tests: the one-wave replay of the linear blanker
   if (const char *e5 = getenv("LRH_STAMP")) c->dbg_stamp = atoi(e5);
   if (const char *e6 = getenv("LRH_BLN_DEBUG")) c->dbg_bln = atoi(e6);
   if (const char *e7 = getenv("LRH_FFT2_RUN")) c->env_fft2_run = atoi(e7);
@@ -1503,9 +1504,23 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
       // in-call limiter of the round has already been enqueued on its own stream, behind a copy of the factor taken for this search
       if (c->wl_on && c->d_clv_amp && c->clv_amp_seq > 0) ca.amp_dev = c->d_clv_amp + ((c->clv_amp_seq - 1) & 1);
       hipEvent_t ev_amp = ca.amp_dev ? c->ev_amp : nullptr;
+      // (LRH_CLEVER_SPLIT=1) Candidate bits and the list of regions only read the power ring: they may go out now, on the side stream
+      // behind the previous round's dumb blanker (whose update has made the limit final) and this round's make_timf2, so that the
+      // replay starts the next round with its list made.  Measured: the replay's stage shrinks (536 -> 374 us) but the bandwidth-bound
+      // front then runs beside fft2 of the previous round and costs it more (431 -> 490 us): 25.2 against 26.1 Gsamples/s.  Off.
+      int back_parts = 3;
+      if (c->clv_split && c->clv_ev_t2) {
+        hipStream_t keep_cur = c->cur; std::vector<std::function<int(lrh_ctx *)>> *keep_rec = c->rec;
+        c->cur = c->stream2; c->rec = nullptr;
+        hipError_t e_ = hipStreamWaitEvent(c->stream2, c->clv_ev_t2, 0);
+        if (e_ == hipSuccess) { ProfScope ps(c, "clever"); e_ = launch_clever(ca, c->stream2, 1); }
+        c->cur = keep_cur; c->rec = keep_rec;
+        if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, "launch_clever (front)", e_);
+        back_parts = 2;
+      }
       LRH_DEVICE_WORK(c, {
         if (ev_amp) HIPCHK(c, hipStreamWaitEvent(c->cur, ev_amp, 0));
-        { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
+        { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur, back_parts)); }
         HIPCHK(c, hipMemcpyAsync(c->h_clv_out, (char *)c->d_bst + offsetof(BlankState, clever_out), 3 * sizeof(int), hipMemcpyDeviceToHost, c->cur));
         HIPCHK(c, hipEventRecord(c->ev_clv, c->cur));
         c->clv_issued = true;
@@ -2503,7 +2518,9 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) return rc;
       // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
       qb.push_back([ev_t2](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, ev_t2, 0)); return LRH_OK; });
+      c->clv_ev_t2 = ev_t2;
       c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
+      c->clv_ev_t2 = nullptr;
       if (rc) return rc;
       if (Bnext > 0) {
         on(S1);

@@ -2777,22 +2777,29 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
   }
 }
 
-hipError_t launch_clever(const CleverArgs &a0, hipStream_t st)
+// The search in two halves: `front` = candidate bits, flag clear and the list of regions -- reads the power ring, touches no sample, so it
+// may run as soon as the span's samples exist and the limit is final; `back` = the replay, the check of the extents and the (normally idle)
+// one-wave replay.  parts: 1 front, 2 back, 3 both.
+hipError_t launch_clever(const CleverArgs &a0, hipStream_t st, int parts)
 {
   CleverArgs a = a0;
   const int nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
   const dim3 gp((nwords + 3) / 4 < 2048 ? (nwords + 3) / 4 : 2048);
   const int rblocks = std::max(1, std::min(CLV_RBLOCKS_MAX, (nwords + 1023) / 1024));      // >= 4 words per thread
   a.phase = 0;
-  hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever_count, dim3(rblocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever_regions, dim3(rblocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 16384 ? a.max_regions : 16384), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(64), 0, st, a);
-  a.phase = 1;                                           // all three return at once unless the check found colliding extents
-  hipLaunchKernelGGL(k_clever_restore, dim3(256), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);
+  if (parts & 1) {
+    hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_clever_count, dim3(rblocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_clever_regions, dim3(rblocks), dim3(256), 0, st, a);
+  }
+  if (parts & 2) {
+    hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 16384 ? a.max_regions : 16384), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(64), 0, st, a);
+    a.phase = 1;                                           // all three return at once unless the check found colliding extents
+    hipLaunchKernelGGL(k_clever_restore, dim3(256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);
+  }
   return hipGetLastError();
 }
 

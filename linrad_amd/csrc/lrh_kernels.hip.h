@@ -171,7 +171,7 @@ struct CleverArgs {
   // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring (bk_ty / bk_pwo: their backups).
   int twochan, chan; float2 *timf2y; float *pwr_own; float2 *bk_ty; float *bk_pwo;
 };
-hipError_t launch_clever(const CleverArgs &a, hipStream_t st);
+hipError_t launch_clever(const CleverArgs &a, hipStream_t st, int parts = 3);   // parts: 1 candidate bits + regions, 2 replay + check, 3 both
 
 // ---- fft2 ----
 struct Fft2Args {
