@@ -5,9 +5,12 @@ from .abi import default_config
 
 # algorithmic HBM bytes per input complex sample, per stage (DESIGN.md "Roofline accounting")
 ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2": 64.0,
-             # k_fft1w = fft1 + fft1_c's sums + the weak stream of make_timf2 (spectrum in 16 + liminfo 8 + first write 8 + overlap
-             # read-modify-write 16 + power 4 = 52); its sparse second pass = the strong stream's first write 8 + read-modify-write 16
-             "fft1w": 24.0 + 16.0 + 52.0, "timf2s": 24.0}
+             # k_fft1w = fft1 + fft1_c's sums + the weak stream of make_timf2 as ONE algorithm: what it has to move per new input sample
+             # is the samples in (4 B, each entering two overlapping transforms: 8), the weak stream out (8), its power (4) and the
+             # averaged power spectrum (4 B per bin and fft_avg1num = 5 blocks of N1/2 new samples: 1.6) -- the SURVEY 8d figures of the
+             # three stages it replaces (24 + 16 + 52) price a spectrum round trip through HBM that no longer exists.
+             # Its second pass (timf2s) writes the strong stream once (8); the handful of strong bins it reads is noise.
+             "fft1w": 8.0 + 8.0 + 4.0 + 1.6, "timf2s": 8.0}
 ALG_BYTES_CHAIN = 184.0
 
 
