@@ -2290,7 +2290,7 @@ __global__ __launch_bounds__(256) void k_clever_prep(CleverArgs a)
   const int lane = threadIdx.x & 63, wmask = ((a.mask + 1) >> 6) - 1;
   const int first_word = a.pbeg >> 6, nwords = ((a.pbeg & 63) + a.total + 64) >> 6;
   const float nfl = (float)a.st->clever_limit;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; a.reg_ctl[3] = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->clever_out[0] = (a.pbeg + a.total) & a.mask; a.st->clever_out[1] = 0; a.st->clever_out[2] = 0; if (a.phase == 0) { a.st->clever_out[3] = 0; a.reg_ctl[3] = 0; } }
   { const int mw = (a.bk_margin + 63) / 64 + 1;           // words of the margins either side
     for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords + 2 * mw; w += gridDim.x * 256) a.logged[(first_word - mw + w) & wmask] = 0ull; }
   for (int w = (blockIdx.x * 256 + threadIdx.x) >> 6; w < nwords; w += gridDim.x * 4) {
@@ -2382,13 +2382,18 @@ __global__ __launch_bounds__(256) void k_clever_regions(CleverArgs a)
 }
 
 // extents must stay apart; the last region's stopping point is the call's
-__global__ void k_clever_check(CleverArgs a)
+__global__ __launch_bounds__(1024) void k_clever_check(CleverArgs a)
 {
   const int n = a.reg_ctl[0];
   int bad = 0;
-  for (int r = threadIdx.x; r + 1 < n; r += 64) if (a.reg_ext[2 * r + 1] >= a.reg_ext[2 * (r + 1)]) bad = 1;
-  if (__ballot(bad) && threadIdx.x == 0) a.reg_ctl[1] = 1;
-  if (threadIdx.x == 0 && a.reg_ctl[1] == 0) a.st->clever_out[0] = (a.pbeg + a.reg_ctl[2]) & a.mask;
+  for (int r = threadIdx.x; r + 1 < n; r += 1024) if (a.reg_ext[2 * r + 1] >= a.reg_ext[2 * (r + 1)]) bad = 1;
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    if (bad) a.reg_ctl[1] = 1;
+    const int violated = a.reg_ctl[1];
+    if (!violated) a.st->clever_out[0] = (a.pbeg + a.reg_ctl[2]) & a.mask;
+    a.st->clever_out[3] = violated;                        // the host reads this with the resume point and issues the replay if it must
+  }
 }
 
 // 64 consecutive ring positions from pos0 (lane 0's): the lanes' bits laid onto the one or two 64-bit words of a per-sample bitmap they
@@ -2779,7 +2784,7 @@ __global__ __launch_bounds__(64) void k_clever(CleverArgs a)
 
 // The search in two halves: `front` = candidate bits, flag clear and the list of regions -- reads the power ring, touches no sample, so it
 // may run as soon as the span's samples exist and the limit is final; `back` = the replay, the check of the extents and the (normally idle)
-// one-wave replay.  parts: 1 front, 2 back, 3 both.
+// one-wave replay, which the host issues when the check reports a collision (clever_out[3]).  parts: 1 front, 2 back, 4 replay.
 hipError_t launch_clever(const CleverArgs &a0, hipStream_t st, int parts)
 {
   CleverArgs a = a0;
@@ -2794,8 +2799,10 @@ hipError_t launch_clever(const CleverArgs &a0, hipStream_t st, int parts)
   }
   if (parts & 2) {
     hipLaunchKernelGGL(k_clever, dim3(a.max_regions < 16384 ? a.max_regions : 16384), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(64), 0, st, a);
-    a.phase = 1;                                           // all three return at once unless the check found colliding extents
+    hipLaunchKernelGGL(k_clever_check, dim3(1), dim3(1024), 0, st, a);
+  }
+  if (parts & 4) {                                         // the extents collided (or the test switch asks for it): samples back, one wave over the span
+    a.phase = 1;
     hipLaunchKernelGGL(k_clever_restore, dim3(256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_clever_prep, gp, dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_clever, dim3(1), dim3(64), 0, st, a);

@@ -115,7 +115,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   int need_slow;             // scratch: a lane found no clean restart point
   // linear ("clever") blanker
   unsigned int clever_limit; float clever_rate; int fitted_acc; int last_fitted; int last_rejected;
-  int clever_out[3];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected
+  int clever_out[4];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected, [3] != 0: extents collided -- the host issues the one-wave replay
   int clever_serial_calls;   // calls that fell back to the one-wave replay
   float amp_factor;          // liminfo_amplitude_factor: the limiter kernels keep it current, k_clever scales its reference pulse with it
 };
@@ -171,7 +171,7 @@ struct CleverArgs {
   // partner's samples of the exchanged span in ring places, pwr_own the own channel's power ring (bk_ty / bk_pwo: their backups).
   int twochan, chan; float2 *timf2y; float *pwr_own; float2 *bk_ty; float *bk_pwo;
 };
-hipError_t launch_clever(const CleverArgs &a, hipStream_t st, int parts = 3);   // parts: 1 candidate bits + regions, 2 replay + check, 3 both
+hipError_t launch_clever(const CleverArgs &a, hipStream_t st, int parts = 3);   // parts: 1 candidate bits + regions, 2 region replay + check, 4 restore + one-wave replay (only after clever_out[3] came back set)
 
 // ---- fft2 ----
 struct Fft2Args {
