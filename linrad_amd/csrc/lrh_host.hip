@@ -40,7 +40,6 @@ hipError_t launch_realsplit(const RealSplitArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_net(const float2 *w, const float2 *s, int mask, int first, int count, float gain, float strong, float2 *dst, hipStream_t st);
 hipError_t launch_blanker(const BlankArgs &a, int ring_words, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);
-hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
 hipError_t launch_span_copy(float *x, float *ring, int pbeg, int count, int mask, int to_ring, hipStream_t st);
 hipError_t launch_span_copy2(float2 *x, float2 *ring, int first, int count, int mask, int to_ring, hipStream_t st);
@@ -102,6 +101,7 @@ struct lrh_ctx {
   // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
+  bool f1_is_big = false; Fft1BigArgs f1_big;   // fft1_size 32768: the column step has run, the row step is what is parked (k_fft1r_t2c takes it)
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
   bool corr_on = false; int slowcorr_tot_avgnum = 0; float2 *d_xspec = nullptr, *d_corrsum = nullptr, *d_slowcorr = nullptr; double2 *d_slowcorr_tot = nullptr;   // lrh_set_correlation
   lrh_exchange_fn xfn = nullptr; void *xuser = nullptr;     // lrh_set_exchange: collectives of two coupled channels inside lrh_wideband_dsp
@@ -565,7 +565,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (c->fft1_big) {
     make_twiddles(256, tw1a); make_twiddles(N1 / 256, tw1b);
     A(dev_alloc(c, &c->d_tw1a, tw1a.size())); A(dev_alloc(c, &c->d_tw1b, tw1b.size()));
-    c->fuse_sumsq = false;                       // fft1_c's sums stay a separate pass (k_sumsq)
+    if (cfg->fft1_n != 15) c->fuse_sumsq = false;   // 65536 (second fft off): fft1_c's sums stay a separate pass (k_sumsq); 32768: inside k_fft1r_t2c
   }
   A(dev_alloc(c, &c->d_pack_cur, N1)); A(dev_alloc(c, &c->d_pack_prev, N1));
   A(dev_alloc(c, &c->d_liminfo, N1)); A(dev_alloc(c, &c->d_old_liminfo, N1)); A(dev_alloc(c, &c->d_sel_tmp, N1)); A(dev_alloc(c, &c->d_sel_wait, N1)); A(dev_alloc(c, &c->d_sel_st, 1)); A(dev_alloc(c, &c->d_wf_itab, itab.size()));
@@ -1184,6 +1184,8 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     c->f1_args = a; c->f1_batch = batch; c->f1_have = true;    // lrh_make_timf2 takes it from here (k_fft1w)
     return LRH_OK;
   }
+  const bool defer_big = c->f1_defer && c->fft1_big && handle == 0 && c->cfg.fft1_n == 15 && !a.real && !a.shift_i && !a.shift_q && !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp;
+  if (defer_big && c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
   ProfScope ps(c, "fft1");
   if (c->fft1_big) {
     const size_t need = (size_t)batch * c->N1;
@@ -1195,6 +1197,12 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
       c->fft1_scratch_cap[handle] = need;
     }
     Fft1BigArgs g; g.f = a; g.tw_a = c->d_tw1a; g.tw_b = c->d_tw1b; g.tw_big = c->d_tw1; g.scratch = c->d_fft1_scratch[handle];
+    if (defer_big) {                                       // column step now, the row step rides in lrh_make_timf2's kernel
+      HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->cur, 1));
+      c->f1_big = g; c->f1_args = a; c->f1_batch = batch; c->f1_have = true; c->f1_is_big = true;
+      if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read
+      return LRH_OK;
+    }
     HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->cur));
   } else
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
@@ -1231,6 +1239,7 @@ static int launch_parked_fft1(lrh_ctx *c)
   hipStream_t keep = c->cur; c->cur = c->stream;          // parked on the main stream, issued there
   struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep};
   ProfScope ps(c, "fft1");
+  if (c->f1_is_big) { c->f1_is_big = false; HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, c->f1_big, c->f1_batch, c->cur, 2)); return LRH_OK; }   // the row step
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, c->f1_args, c->f1_batch, c->cur));
   if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }
   return LRH_OK;
@@ -1305,9 +1314,11 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   // k_fft1w: the parked forward transform, the parked sums and this call's weak stream address the same transforms
   const int nb_here = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask;
-  const bool fused1 = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->d_ss_part && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
-                      c->ss_args.batch == batch && c->ss_args.first_nb == nb_here && c->cur == c->stream;
-  if (!fused1) { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  const bool fused_any = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
+                         c->ss_args.batch == batch && c->ss_args.first_nb == nb_here && c->cur == c->stream;
+  const bool fused1 = fused_any && !c->f1_is_big && c->d_ss_part;
+  const bool fused15 = fused_any && c->f1_is_big;          // fft1_size 32768: row step + sums + column step of both streams (k_fft1r_t2c)
+  if (!fused1 && !fused15) { const int rc_ = join_handles(c); if (rc_) return rc_; }
   if (c->sel_table_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_sel, 0)); c->sel_table_pending = false; }   // routing words from the side stream
   if (c->h_sel_low) sellim_poll(c);                        // weak-bin count of the newest finished limiter update, if one has arrived
   Timf2Args a;
@@ -1333,7 +1344,20 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     HIPCHK(c, launch_timf2_big(c->cfg.fft1_n, g, batch, c->cur));
     return LRH_OK;
   };
-  if (fused1) {
+  if (fused15) {
+    const size_t need = (size_t)batch * 2 * c->N1;
+    if (c->timf2_scratch_cap < need) {
+      HIPCHK(c, hipStreamSynchronize(c->cur));
+      if (c->d_timf2_scratch) hipFree(c->d_timf2_scratch);
+      c->d_timf2_scratch = nullptr; c->timf2_scratch_cap = 0;
+      const int rc_ = dev_alloc(c, &c->d_timf2_scratch, need, false); if (rc_) return rc_;
+      c->timf2_scratch_cap = need;
+    }
+    Fft1rT2cArgs w; w.f1 = c->f1_big; w.ss = c->ss_args; w.groups_per_run = 0; w.keep_spec = (c->cfg.fft1_float_sparse && !c->corr_on) ? 0 : 1;
+    w.t2.t = a; w.t2.tw_a = c->d_tw1a; w.t2.tw_b = c->d_tw1b; w.t2.tw_big = c->d_tw1; w.t2.scratch = c->d_timf2_scratch;
+    c->ss_have = false; c->f1_have = false; c->f1_is_big = false;
+    { ProfScope ps(c, "fft1w"); HIPCHK(c, launch_fft1r_t2c(w, batch, c->cur)); }
+  } else if (fused1) {
     const SumsqArgs sa = c->ss_args;
     const Fft1Args &f = c->f1_args;
     c->ss_have = false; c->f1_have = false;
@@ -2392,10 +2416,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   const bool piped = c->pipeline && !small_rounds && c->cfg.second_fft_enable && nblocks > batch && (!c->prof || c->prof_keep_schedule) &&
                      !c->clever_on;                // the linear blanker reads its resume point back: serial schedule
   // fft1_c's sums ride inside make_timf2's kernel: fft1_c parks, make_timf2 picks up, the slow average follows
-  const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && c->d_ss_part;
+  const bool fuse15 = c->fft1_big && c->cfg.fft1_n == 15 && c->fuse_fft1;     // fft1_size 32768: k_fft1r_t2c needs no scratch of split groups
+  const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && (c->d_ss_part || fuse15);
   // ... and fft1_b's transform rides there too (k_fft1w): parked by lrh_fft1_b, taken by lrh_make_timf2, issued as k_fft1 by whoever else reads the ring
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); c->f1_defer = false; if (c->f1_have) launch_parked_fft1(c); } } fuse_guard{c};
-  c->f1_defer = fuse && c->fuse_fft1 && !c->fft1_big && c->cfg.fft1_n == 14;
+  c->f1_defer = fuse && c->fuse_fft1 && ((!c->fft1_big && c->cfg.fft1_n == 14) || fuse15);
   auto sums = [&](int B) -> int {                // fft1_c: launches at once, or parked for the next make_timf2
     c->ss_defer = fuse; const int r = lrh_fft1_c(c, p, B); c->ss_defer = false; return r;
   };

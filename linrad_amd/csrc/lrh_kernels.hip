@@ -1997,18 +1997,21 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
 }
 // ---- fft1 / timf2 for fft1_size 32768: four-step through an HBM scratch (same tiling as k_fft2_cols / k_fft2_rows) -------------
 // fft1: x[n] = (I w, -Q w)[n], n = NB n1 + n2; X[k1 + NA k2] = sum_n2 [ w_N^(n2 k1) sum_n1 x[NB n1 + n2] w_NA^(n1 k1) ] w_NB^(n2 k2), e^{+j}.
-template <int LA, int LB, bool DW>
+// TILE columns per workgroup: 16 (4 points per thread) or, for int16 samples, 32 with 8 points per thread -- 32 adjacent
+// short2 are a whole 128-byte line, 16 are half of one (the other half is fetched again by the neighbouring workgroup)
+template <int LA, int LB, bool DW, int TILE>
 __global__ __launch_bounds__(1024, 4) void k_fft1_cols(Fft1BigArgs g)
 {
   using Raw = typename std::conditional<DW, int2, short2>::type;
   const Fft1Args &a = g.f;
-  constexpr int P = sub_ppt(LA);
+  constexpr int P = (TILE << LA) / 1024;
   using Plan = FftPlan<LA, P>;
   constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   constexpr int CS = Plan::LDS_CELLS + 1;
-  __shared__ float2 lds[LRH_TILE * CS];
-  const int c = threadIdx.x & (LRH_TILE - 1), l = threadIdx.x >> 4;
-  const int n2 = blockIdx.x * LRH_TILE + c, b = blockIdx.y;
+  static_assert(TILE * T == 1024, "1024 threads");
+  __shared__ float2 lds[TILE * CS];
+  const int c = threadIdx.x & (TILE - 1), l = threadIdx.x / TILE;
+  const int n2 = blockIdx.x * TILE + c, b = blockIdx.y;
   const int p0 = a.p0_first + b * a.step;
   float2 x[P];
 #pragma unroll
@@ -2032,8 +2035,8 @@ __global__ __launch_bounds__(1024, 4) void k_fft1_cols(Fft1BigArgs g)
       col[k1] = cmul(x[m * RL + q], make_float2(w.x, -w.y));
     }
   __syncthreads();
-  float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * LRH_TILE * NA;
-  for (int e = threadIdx.x; e < LRH_TILE * NA; e += LRH_TILE * T) {
+  float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * TILE * NA;
+  for (int e = threadIdx.x; e < TILE * NA; e += TILE * T) {
     const int cc = e / NA, k1 = e - cc * NA;
     store_stream(&sc[(size_t)cc * NA + k1], lds[cc * CS + k1]);
   }
@@ -2146,18 +2149,203 @@ __global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
       else store_stream(&a.timf2s[r], o);
     }
 }
-template <int LA, int LB> static void launch_fft1_big_t(const Fft1BigArgs &a, int batch, hipStream_t st)
+template <int LA, int LB> static void launch_fft1_big_t(const Fft1BigArgs &a, int batch, hipStream_t st, int steps)
 {
   const dim3 gc((1 << LB) / LRH_TILE, batch), gr((1 << LA) / LRH_TILE, batch);
-  if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
-  else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false>), gc, dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
-  hipLaunchKernelGGL((k_fft1_rows<LA, LB>), gr, dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  if (steps & 1) {
+    if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true, LRH_TILE>), gc, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false, 32>), dim3((1 << LB) / 32, batch), dim3(1024), 0, st, a);
+  }
+  if (steps & 2) hipLaunchKernelGGL((k_fft1_rows<LA, LB>), gr, dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }
-hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st)
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st, int steps)
 {
   if ((log2n != 15 && log2n != 16) || a.f.real || a.f.shift_i || a.f.shift_q) return hipErrorInvalidValue;
-  if (log2n == 15) launch_fft1_big_t<8, 7>(a, batch, st);
-  else launch_fft1_big_t<8, 8>(a, batch, st);             // 65536: the reference's maximum without the second fft (fft0.c:1162-1169)
+  if (log2n == 15) launch_fft1_big_t<8, 7>(a, batch, st, steps);
+  else launch_fft1_big_t<8, 8>(a, batch, st, steps);      // 65536: the reference's maximum without the second fft (fft0.c:1162-1169)
+  return hipGetLastError();
+}
+
+// ---- fft1_size 32768: row step of fft1 + fft1_c's sums + column step of timf2 (both streams) -----------------------------------------
+// The row step of fft1 leaves X[k1 + NA k2] for fixed k1; timf2's column step wants S[NB i1 + i2] for fixed i2.  With DC moved to N/2
+// (a multiple of NB) bin k1 + NA k2 has i2 = k1 mod NB, i1 = 2 k2 + (k1 >= NB) (+ NA/2): the two rows k1 = i2 and i2 + NB together ARE
+// column i2.  A workgroup therefore takes sixteen columns i2 = thirty-two rows, transforms the rows (4 points per thread), applies the
+// filter correction, writes the spectrum (once: nothing reads it back on this path), adds |X|^2 into the running sums of the averaging
+// period, turns the tile through LDS and runs the sixteen 256-point column transforms of the weak and then of the strong stream on
+// S_t + (-1)^k S_{t-1} with the predecessor's bins kept in registers.  It walks a run of whole averaging periods (so the sums need no
+// joining) and starts each run by transforming the block before it once more for the predecessor (the launch's first block takes it
+// from the ring).  Saved against the separate kernels per transform of 32768 points: the spectrum read three times (k_sumsq, cur and
+// prev of k_timf2_cols), 786 KB of 3.1 MB.
+template <int LA, int LB>
+__global__ __launch_bounds__(1024, 4) void k_fft1r_t2c(Fft1rT2cArgs g)
+{
+  const Fft1Args &f = g.f1.f; const Timf2Args &t = g.t2.t; const SumsqArgs &ss = g.ss;
+  constexpr int PR = sub_ppt(LB), PC = sub_ppt(LA);
+  using PlanR = FftPlan<LB, PR>; using PlanC = FftPlan<LA, PC>;
+  constexpr int NA = 1 << LA, NB = 1 << LB, N = NA * NB;
+  constexpr int TR = PlanR::T, TC = PlanC::T, CSR = PlanR::LDS_CELLS + 1, CSC = PlanC::LDS_CELLS + 1;
+  constexpr int ROWS = 2 * LRH_TILE, TS = NA + 1;
+  static_assert(ROWS * TR == 1024 && LRH_TILE * TC == 1024, "1024 threads: 32 rows x 32, 16 columns x 64");
+  constexpr int XCH = ROWS * CSR > LRH_TILE * CSC ? ROWS * CSR : LRH_TILE * CSC;
+  __shared__ float2 xch[XCH];                             // exchange buffer of the row transforms, then of the column transforms
+  __shared__ float2 tile[LRH_TILE * TS];                  // the spectrum tile on its way from rows to columns: [column][i1]
+  const int i2b = blockIdx.x * LRH_TILE;
+  // rows: thread (rr, lr) -- rr & 15 = column of the tile, rr >> 4 = which of its two rows; columns: thread (cc, lc).
+  // The coordinates are re-derived from an opaque copy of the thread index in every trip of the block loop: otherwise LICM hoists
+  // the address arithmetic of every unrolled load and store out of it and the kernel spills (see k_timf2)
+  int rr, lr, k1, cc, lc, i2;
+  auto coords = [&]() {
+    int t_ = threadIdx.x; asm volatile("" : "+v"(t_));
+    rr = t_ & (ROWS - 1); lr = t_ / ROWS; k1 = i2b + (rr & (LRH_TILE - 1)) + (rr / LRH_TILE) * NB;
+    cc = t_ & (LRH_TILE - 1); lc = t_ / LRH_TILE; i2 = i2b + cc;
+  };
+  coords();
+  const float sg = ((threadIdx.x & (LRH_TILE - 1)) & 1) ? -1.f : 1.f;   // (-1)^k, k = NB i1 + i2 (i2b is even)
+  // the run: groups of the averaging periods like k_sumsq (group 0 continues a period begun by an earlier launch when c0 > 0)
+  const int ngroups = (ss.c0 + ss.batch + ss.avg - 1) / ss.avg;
+  const int g_first = blockIdx.y * g.groups_per_run, g_end = min(g_first + g.groups_per_run, ngroups);
+  if (g_first >= g_end) return;
+  float2 pv[PC];                                          // the predecessor's bins of this thread's column points
+  // what does not change from block to block is fetched once per run: filter correction and spectrum places of this thread's row
+  // bins, routing bits and twiddles of its column points -- inside the loop they were ~3.5 us of exposed global latency per block
+  float2 fc[PR];
+  auto kk_of = [&](int j) -> int {                        // spectrum place of row output j: DC at N/2 (make_permute mode 1, fft0.c:1196-1204)
+    return (k1 + NA * ((lr + (j / PlanR::RL) * TR) + (j % PlanR::RL) * (NB / PlanR::RL)) + N / 2) & (N - 1);
+  };
+#pragma unroll
+  for (int j = 0; j < PR; j++) fc[j] = f.filtercorr[kk_of(j)];
+  unsigned int wcm = 0, wpm0 = 0;                         // bit j: point j is weak in the current table / in the table before this launch (timf2.c:50)
+#pragma unroll
+  for (int m = 0; m < PC / PlanC::R0; m++)
+#pragma unroll
+    for (int s = 0; s < PlanC::R0; s++) {
+      const int j = m * PlanC::R0 + s, k = NB * ((lc + m * TC) + s * (NA / PlanC::R0)) + i2;
+      wcm |= ((t.pack_cur[k >> 5] >> (k & 31)) & 1u) << j; wpm0 |= ((t.pack_prev[k >> 5] >> (k & 31)) & 1u) << j;
+    }
+  float2 twc[PC];
+#pragma unroll
+  for (int m = 0; m < PC / PlanC::RL; m++)
+#pragma unroll
+    for (int q = 0; q < PlanC::RL; q++) twc[m * PlanC::RL + q] = g.t2.tw_big[(i2 * ((lc + m * TC) + q * (NA / PlanC::RL))) & (N - 1)];
+  // row inputs of a block
+  auto fetch = [&](int b, float2 (&x)[PR]) {
+    const float2 *sc = g.f1.scratch + (size_t)b * N;
+#pragma unroll
+    for (int m = 0; m < PR / PlanR::R0; m++)
+#pragma unroll
+      for (int s = 0; s < PlanR::R0; s++) x[m * PlanR::R0 + s] = sc[(size_t)((lr + m * TR) + s * (NB / PlanR::R0)) * NA + k1];
+  };
+  // the row step on x: this thread's bins of the spectrum in v[]
+  auto rows = [&](float2 (&x)[PR]) {                        // in place (the register file is what limits this kernel)
+    BlockFft<LB, PR, +1>::run(x, xch + rr * CSR, g.f1.tw_b, lr);
+#pragma unroll
+    for (int j = 0; j < PR; j++) x[j] = cmul(x[j], fc[j]);
+  };
+  auto to_tile = [&](const float2 (&v)[PR]) {
+    __syncthreads();                                      // the tile's previous readers are through
+#pragma unroll
+    for (int j = 0; j < PR; j++) { const int kk = kk_of(j); tile[(kk & (NB - 1)) % LRH_TILE * TS + (kk >> LB)] = v[j]; }
+    __syncthreads();
+  };
+  const int b_first = g_first == 0 ? 0 : g_first * ss.avg - ss.c0;
+  int b_last = g_end * ss.avg - ss.c0; if (b_last > ss.batch) b_last = ss.batch;          // one past the run's last block
+  float2 xn[PR];
+  if (b_first > 0) {                                      // the block before the run, for its spectrum only
+    float2 x[PR];
+    fetch(b_first - 1, x);
+    fetch(b_first, xn);
+    rows(x);
+    to_tile(x);
+#pragma unroll
+    for (int m = 0; m < PC / PlanC::R0; m++)
+#pragma unroll
+      for (int s = 0; s < PlanC::R0; s++) pv[m * PlanC::R0 + s] = tile[cc * TS + (lc + m * TC) + s * (NA / PlanC::R0)];
+  } else {
+    fetch(0, xn);
+    const float2 *prv = t.spec + (size_t)((t.first_nb - 1) & t.nb_mask) * N;
+#pragma unroll
+    for (int m = 0; m < PC / PlanC::R0; m++)
+#pragma unroll
+      for (int s = 0; s < PlanC::R0; s++) pv[m * PlanC::R0 + s] = prv[NB * ((lc + m * TC) + s * (NA / PlanC::R0)) + i2];
+  }
+  for (int gi = g_first; gi < g_end; gi++) {
+    const int start = gi == 0 ? 0 : gi * ss.avg - ss.c0;
+    int count = ss.avg - (gi == 0 ? ss.c0 : 0);
+    if (count > ss.batch - start) count = ss.batch - start;
+    const bool accumulate = gi == 0 && ss.c0 > 0;
+    float *dst = ss.sumsq + ((ss.pa0 + gi * N) & ss.sumsq_mask);
+    float acc[PR];
+    for (int bi = 0; bi < count; bi++) {
+      const int b = start + bi;
+      coords();
+      {
+        float2 x[PR];
+#pragma unroll
+        for (int j = 0; j < PR; j++) x[j] = xn[j];
+        if (b + 1 < b_last) fetch(b + 1, xn);            // the next block's inputs travel while this one is worked on
+        rows(x);
+        float2 *out = f.out + (size_t)((f.first_nb + b) & f.nb_mask) * N;
+        const bool keep = g.keep_spec || b == ss.batch - 1;
+#pragma unroll
+        for (int j = 0; j < PR; j++) {
+          const int kk = kk_of(j);
+          if (keep) store_stream(&out[kk], x[j]);
+          const float p2 = x[j].x * x[j].x + x[j].y * x[j].y;
+          if (bi == 0) acc[j] = accumulate ? dst[kk] + p2 : p2; else acc[j] += p2;   // "=" then "+=" (fft1.c:4126-4169)
+        }
+        to_tile(x);
+      }
+      // columns: S_t + (-1)^k S_{t-1}, each masked with the routing table that was in force for it
+      const unsigned int wpm = b == 0 ? wpm0 : wcm;
+#pragma unroll 1
+      for (int st = 0; st < 2; st++) {
+        float2 x2[PC];
+#pragma unroll
+        for (int m = 0; m < PC / PlanC::R0; m++)
+#pragma unroll
+          for (int s = 0; s < PlanC::R0; s++) {
+            const int j = m * PlanC::R0 + s;
+            const float2 cur = tile[cc * TS + (lc + m * TC) + s * (NA / PlanC::R0)];
+            const bool tc = ((wcm >> j) & 1u) != (unsigned int)st, tp = ((wpm >> j) & 1u) != (unsigned int)st;
+            x2[j] = make_float2((tc ? cur.x : 0.f) + sg * (tp ? pv[j].x : 0.f), (tc ? cur.y : 0.f) + sg * (tp ? pv[j].y : 0.f));
+          }
+        float2 *col = xch + cc * CSC;
+        BlockFft<LA, PC, -1>::run(x2, col, g.t2.tw_a, lc);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PC / PlanC::RL; m++)
+#pragma unroll
+          for (int q = 0; q < PlanC::RL; q++) col[(lc + m * TC) + q * (NA / PlanC::RL)] = cmul(x2[m * PlanC::RL + q], twc[m * PlanC::RL + q]);
+        __syncthreads();
+        float2 *sc2 = g.t2.scratch + ((size_t)b * 2 + st) * N + (size_t)i2b * NA;
+        for (int e = threadIdx.x; e < LRH_TILE * NA; e += 1024) {
+          const int c2 = e / NA, o1 = e - c2 * NA;
+          sc2[(size_t)c2 * NA + o1] = xch[c2 * CSC + o1];
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int m = 0; m < PC / PlanC::R0; m++)
+#pragma unroll
+        for (int s = 0; s < PlanC::R0; s++) pv[m * PlanC::R0 + s] = tile[cc * TS + (lc + m * TC) + s * (NA / PlanC::R0)];
+    }
+    if (count > 0) {
+#pragma unroll
+      for (int j = 0; j < PR; j++) dst[kk_of(j)] = acc[j];
+    }
+  }
+}
+hipError_t launch_fft1r_t2c(const Fft1rT2cArgs &a0, int batch, hipStream_t st)
+{
+  constexpr int LA = 8, LB = 7;
+  Fft1rT2cArgs a = a0; a.t2.t.batch = batch;
+  const int ngroups = (a.ss.c0 + a.ss.batch + a.ss.avg - 1) / a.ss.avg;
+  const int tiles = (1 << LB) / LRH_TILE;
+  int gpr = ngroups * tiles / 640;                        // ~2.5 workgroups per CU over the launch; a run costs one extra row step
+  if (gpr < 1) gpr = 1;
+  a.groups_per_run = gpr;
+  hipLaunchKernelGGL((k_fft1r_t2c<LA, LB>), dim3(tiles, (ngroups + gpr - 1) / gpr), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL((k_timf2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a.t2);
   return hipGetLastError();
 }
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStream_t st)

@@ -103,7 +103,11 @@ struct Timf2BigArgs {
   const float2 *tw_a, *tw_b, *tw_big;
   float2 *scratch;                              // [batch][2 streams][NB][NA]
 };
-hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st);
+hipError_t launch_fft1_big(int log2n, const Fft1BigArgs &a, int batch, hipStream_t st, int steps = 3);   // steps: 1 column step, 2 row step, 3 both
+// fft1_size 32768 inside lrh_wideband_dsp: the row step of fft1, fft1_c's sums and the column step of both timf2 streams as one kernel
+// (the spectrum is written once and never read back; k_timf2_rows follows)
+struct Fft1rT2cArgs { Fft1BigArgs f1; Timf2BigArgs t2; SumsqArgs ss; int groups_per_run; int keep_spec; };   // keep_spec 0: only the launch's last transform reaches the fft1 ring (the next launch's predecessor)
+hipError_t launch_fft1r_t2c(const Fft1rT2cArgs &a, int batch, hipStream_t st);
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a, int batch, hipStream_t st);
 
 // ---- blanker ----
