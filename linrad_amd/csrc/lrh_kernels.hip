@@ -2010,35 +2010,51 @@ __global__ __launch_bounds__(1024, 4) void k_fft1_cols(Fft1BigArgs g)
   constexpr int CS = Plan::LDS_CELLS + 1;
   static_assert(TILE * T == 1024, "1024 threads");
   __shared__ float2 lds[TILE * CS];
+  // a workgroup takes g.run consecutive blocks of its columns: window values and twiddles of its points do not depend on the block and
+  // are fetched once (they were two of the three loads per point), the next block's samples travel while the current one is transformed
   const int c = threadIdx.x & (TILE - 1), l = threadIdx.x / TILE;
-  const int n2 = blockIdx.x * TILE + c, b = blockIdx.y;
-  const int p0 = a.p0_first + b * a.step;
-  float2 x[P];
+  const int n2 = blockIdx.x * TILE + c;
+  const int b0 = blockIdx.y * g.run, b1 = min(b0 + g.run, a.batch);
+  float wv[P]; float2 tw[P];
 #pragma unroll
   for (int m = 0; m < P / R0; m++)
 #pragma unroll
-    for (int s = 0; s < R0; s++) {
-      const int i = NB * ((l + m * T) + s * (NA / R0)) + n2;
-      const Raw v = ((const Raw *)a.timf1)[((p0 + i) * a.chan_count + a.chan_index) & a.ring_mask];
-      const float w = a.window[i];
-      x[m * R0 + s] = make_float2((float)v.x * w, -((float)v.y * w));      // Q negated before the e^{+j} transform (fft1.c:432-447)
-    }
-  float2 *col = lds + c * CS;
-  BlockFft<LA, P, +1>::run(x, col, g.tw_a, l);
-  __syncthreads();
+    for (int s = 0; s < R0; s++) wv[m * R0 + s] = a.window[NB * ((l + m * T) + s * (NA / R0)) + n2];
 #pragma unroll
   for (int m = 0; m < P / RL; m++)
 #pragma unroll
-    for (int q = 0; q < RL; q++) {
-      const int k1 = (l + m * T) + q * (NA / RL);
-      const float2 w = g.tw_big[(n2 * k1) & (NA * NB - 1)];
-      col[k1] = cmul(x[m * RL + q], make_float2(w.x, -w.y));
+    for (int q = 0; q < RL; q++) { const float2 w = g.tw_big[(n2 * ((l + m * T) + q * (NA / RL))) & (NA * NB - 1)]; tw[m * RL + q] = make_float2(w.x, -w.y); }
+  Raw raw[P];
+  auto fetch = [&](int b) {
+    const int p0 = a.p0_first + b * a.step;
+#pragma unroll
+    for (int m = 0; m < P / R0; m++)
+#pragma unroll
+      for (int s = 0; s < R0; s++) {
+        const int i = NB * ((l + m * T) + s * (NA / R0)) + n2;
+        raw[m * R0 + s] = ((const Raw *)a.timf1)[((p0 + i) * a.chan_count + a.chan_index) & a.ring_mask];
+      }
+  };
+  if (b0 < b1) fetch(b0);
+  for (int b = b0; b < b1; b++) {
+    float2 x[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) x[j] = make_float2((float)raw[j].x * wv[j], -((float)raw[j].y * wv[j]));   // Q negated before the e^{+j} transform (fft1.c:432-447)
+    if (b + 1 < b1) fetch(b + 1);
+    float2 *col = lds + c * CS;
+    BlockFft<LA, P, +1>::run(x, col, g.tw_a, l);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < P / RL; m++)
+#pragma unroll
+      for (int q = 0; q < RL; q++) col[(l + m * T) + q * (NA / RL)] = cmul(x[m * RL + q], tw[m * RL + q]);
+    __syncthreads();
+    float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * TILE * NA;
+    for (int e = threadIdx.x; e < TILE * NA; e += TILE * T) {
+      const int cc = e / NA, k1 = e - cc * NA;
+      store_stream(&sc[(size_t)cc * NA + k1], lds[cc * CS + k1]);
     }
-  __syncthreads();
-  float2 *sc = g.scratch + (size_t)b * NA * NB + (size_t)blockIdx.x * TILE * NA;
-  for (int e = threadIdx.x; e < TILE * NA; e += TILE * T) {
-    const int cc = e / NA, k1 = e - cc * NA;
-    store_stream(&sc[(size_t)cc * NA + k1], lds[cc * CS + k1]);
+    __syncthreads();
   }
 }
 template <int LA, int LB>
@@ -2153,8 +2169,13 @@ template <int LA, int LB> static void launch_fft1_big_t(const Fft1BigArgs &a, in
 {
   const dim3 gc((1 << LB) / LRH_TILE, batch), gr((1 << LA) / LRH_TILE, batch);
   if (steps & 1) {
-    if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true, LRH_TILE>), gc, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false, 32>), dim3((1 << LB) / 32, batch), dim3(1024), 0, st, a);
+    Fft1BigArgs c = a; c.f.batch = batch;
+    const int tiles = (1 << LB) / (a.f.dword ? LRH_TILE : 32);
+    int run = batch * tiles / 1024; if (run < 1) run = 1; if (run > 16) run = 16;      // ~4 workgroups per CU over the launch
+    c.run = run;
+    const dim3 gcr(tiles, (batch + run - 1) / run);
+    if (a.f.dword) hipLaunchKernelGGL((k_fft1_cols<LA, LB, true, LRH_TILE>), gcr, dim3(1024), 0, st, c);
+    else hipLaunchKernelGGL((k_fft1_cols<LA, LB, false, 32>), gcr, dim3(1024), 0, st, c);
   }
   if (steps & 2) hipLaunchKernelGGL((k_fft1_rows<LA, LB>), gr, dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }

@@ -97,6 +97,7 @@ struct Fft1BigArgs {
   Fft1Args f;                                   // ring, window, filter correction, output ring, direction (int16 / int32 I/Q, no skew, no real input)
   const float2 *tw_a, *tw_b, *tw_big;           // forward tables of size NA, NB, N1
   float2 *scratch;                              // [batch][NB][NA]
+  int run;                                      // consecutive blocks per workgroup of the column step (set by launch_fft1_big)
 };
 struct Timf2BigArgs {
   Timf2Args t;                                  // spectra, rings, ampfac; mode 1 (sin^2 overlap) only; pack_cur / pack_prev are dense bit words here
