@@ -202,8 +202,12 @@ __device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
 // sequence exactly when i < N/(2R), i.e. for the first half of every thread's butterflies, and the next pass reads
 // cell i' + s*N/R' from the lower half exactly for s < R'/2.  So the redistribution splits into two independent
 // rounds that each move N/2 cells through the same N/2-cell buffer.
-template <int LOG2N, int P, int DIR> struct BlockFft {
+// WAVE: the T threads of a transform are the lanes of ONE wave (T <= 64, contiguous lanes): the exchange needs no workgroup barrier --
+// a wave's LDS operations execute in order -- only a fence against the compiler's reordering, and the waves of a workgroup that runs
+// several transforms side by side stop marching in lock step.
+template <int LOG2N, int P, int DIR, bool WAVE = false> struct BlockFft {
   using Plan = FftPlan<LOG2N, P>;
+  __device__ __forceinline__ static void sync() { if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); }
   static constexpr int N = Plan::N, T = Plan::T, HALVES = Plan::HALVES;
 
   // twiddles of one pass, fetched before the LDS exchange that feeds it so their L2 latency hides behind the exchange
@@ -277,7 +281,7 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
       float2 xn[P];
 #pragma unroll
       for (int h = 0; h < HALVES; h++) {
-        if (PASS > 0 || h > 0) __syncthreads();          // reads of the previous round are done
+        if (PASS > 0 || h > 0) sync();                  // reads of the previous round are done
 #pragma unroll
         for (int m = h * NB / HALVES; m < (h + 1) * NB / HALVES; m++) {
           const int i = tid + m * T;
@@ -286,7 +290,7 @@ template <int LOG2N, int P, int DIR> struct BlockFft {
 #pragma unroll
           for (int q = 0; q < R; q++) lds[lds_pad(j + q * p)] = x[m * R + q];
         }
-        __syncthreads();
+        sync();
 #pragma unroll
         for (int m = 0; m < NB2; m++) {
           const int i = tid + m * T - h * (N / 2);

@@ -2206,7 +2206,7 @@ __global__ __launch_bounds__(1024, 4) void k_fft1r_t2c(Fft1rT2cArgs g)
   constexpr int NA = 1 << LA, NB = 1 << LB, N = NA * NB;
   constexpr int TR = PlanR::T, TC = PlanC::T, CSR = PlanR::LDS_CELLS + 1, CSC = PlanC::LDS_CELLS + 1;
   constexpr int ROWS = 2 * LRH_TILE, TS = NA + 1;
-  static_assert(ROWS * TR == 1024 && LRH_TILE * TC == 1024, "1024 threads: 32 rows x 32, 16 columns x 64");
+  static_assert(ROWS * TR == 1024 && LRH_TILE * TC == 1024 && TC == 64, "1024 threads: 32 rows x 32, 16 columns x one wave");
   constexpr int XCH = ROWS * CSR > LRH_TILE * CSC ? ROWS * CSR : LRH_TILE * CSC;
   __shared__ float2 xch[XCH];                             // exchange buffer of the row transforms, then of the column transforms
   __shared__ float2 tile[LRH_TILE * TS];                  // the spectrum tile on its way from rows to columns: [column][i1]
@@ -2218,10 +2218,10 @@ __global__ __launch_bounds__(1024, 4) void k_fft1r_t2c(Fft1rT2cArgs g)
   auto coords = [&]() {
     int t_ = threadIdx.x; asm volatile("" : "+v"(t_));
     rr = t_ & (ROWS - 1); lr = t_ / ROWS; k1 = i2b + (rr & (LRH_TILE - 1)) + (rr / LRH_TILE) * NB;
-    cc = t_ & (LRH_TILE - 1); lc = t_ / LRH_TILE; i2 = i2b + cc;
+    cc = t_ / TC; lc = t_ & (TC - 1); i2 = i2b + cc;          // a column = one wave: its transform needs no workgroup barrier
   };
   coords();
-  const float sg = ((threadIdx.x & (LRH_TILE - 1)) & 1) ? -1.f : 1.f;   // (-1)^k, k = NB i1 + i2 (i2b is even)
+  const float sg = ((threadIdx.x / TC) & 1) ? -1.f : 1.f;   // (-1)^k, k = NB i1 + i2 (i2b is even)
   // the run: groups of the averaging periods like k_sumsq (group 0 continues a period begun by an earlier launch when c0 > 0)
   const int ngroups = (ss.c0 + ss.batch + ss.avg - 1) / ss.avg;
   const int g_first = blockIdx.y * g.groups_per_run, g_end = min(g_first + g.groups_per_run, ngroups);
@@ -2330,21 +2330,17 @@ __global__ __launch_bounds__(1024, 4) void k_fft1r_t2c(Fft1rT2cArgs g)
             const bool tc = ((wcm >> j) & 1u) != (unsigned int)st, tp = ((wpm >> j) & 1u) != (unsigned int)st;
             x2[j] = make_float2((tc ? cur.x : 0.f) + sg * (tp ? pv[j].x : 0.f), (tc ? cur.y : 0.f) + sg * (tp ? pv[j].y : 0.f));
           }
-        float2 *col = xch + cc * CSC;
-        BlockFft<LA, PC, -1>::run(x2, col, g.t2.tw_a, lc);
-        __syncthreads();
+        // the wave's own column: transform, twiddle, and out to the scratch straight from the registers (a register's outputs
+        // o1 = lc + const are 512 bytes of consecutive lanes) -- no LDS hand-over, no workgroup barrier
+        BlockFft<LA, PC, -1, true>::run(x2, xch + cc * CSC, g.t2.tw_a, lc);
+        float2 *sc2 = g.t2.scratch + ((size_t)b * 2 + st) * N + (size_t)i2 * NA;
 #pragma unroll
         for (int m = 0; m < PC / PlanC::RL; m++)
 #pragma unroll
-          for (int q = 0; q < PlanC::RL; q++) col[(lc + m * TC) + q * (NA / PlanC::RL)] = cmul(x2[m * PlanC::RL + q], twc[m * PlanC::RL + q]);
-        __syncthreads();
-        float2 *sc2 = g.t2.scratch + ((size_t)b * 2 + st) * N + (size_t)i2b * NA;
-        for (int e = threadIdx.x; e < LRH_TILE * NA; e += 1024) {
-          const int c2 = e / NA, o1 = e - c2 * NA;
-          sc2[(size_t)c2 * NA + o1] = xch[c2 * CSC + o1];
-        }
-        __syncthreads();
+          for (int q = 0; q < PlanC::RL; q++) store_stream(&sc2[(lc + m * TC) + q * (NA / PlanC::RL)], cmul(x2[m * PlanC::RL + q], twc[m * PlanC::RL + q]));
+        BlockFft<LA, PC, -1, true>::sync();               // the exchange buffer is free again (the wave's next transform)
       }
+      __syncthreads();                                    // (the row step of the next block reuses the exchange buffer of all waves)
 #pragma unroll
       for (int m = 0; m < PC / PlanC::R0; m++)
 #pragma unroll
@@ -2362,7 +2358,11 @@ hipError_t launch_fft1r_t2c(const Fft1rT2cArgs &a0, int batch, hipStream_t st)
   Fft1rT2cArgs a = a0; a.t2.t.batch = batch;
   const int ngroups = (a.ss.c0 + a.ss.batch + a.ss.avg - 1) / a.ss.avg;
   const int tiles = (1 << LB) / LRH_TILE;
-  int gpr = ngroups * tiles / 640;                        // ~2.5 workgroups per CU over the launch; a run costs one extra row step
+  // 120 VGPRs x 1024 threads: one workgroup per CU is resident, so the launch is one wave of workgroups, one per CU when the batch
+  // is long enough -- any other count leaves a partly filled last wave (656 workgroups ran as 3 waves at 85 %)
+  int cus = 256; { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+  const int runs_per_tile = cus / tiles > 0 ? cus / tiles : 1;
+  int gpr = (ngroups + runs_per_tile - 1) / runs_per_tile; // a run costs one extra row step
   if (gpr < 1) gpr = 1;
   a.groups_per_run = gpr;
   hipLaunchKernelGGL((k_fft1r_t2c<LA, LB>), dim3(tiles, (ngroups + gpr - 1) / gpr), dim3(1024), 0, st, a);
