@@ -138,3 +138,45 @@ def test_sparse_fft2_ring_refuses_a_band_it_did_not_keep():
     rx.set_mix1_selfreq(1010.0)                           # within the 64-bin margin: served
     rx.fft2_mix1_fixed(1)
     rx.close()
+
+
+def _run15(env, sparse, nblk=48, batch=16, calls=1):
+    """fft1_size 32768 / fft2_size 131072 through lrh_wideband_dsp (the four-step path)"""
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cfg = chain_config(15, 17, batch=batch, rounds=nblk // batch)
+        cfg.fft1_float_sparse = sparse
+        cfg.stupid_bln_mode = 0
+        rx = open_hip(cfg)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    s = synth_defaults(32768, 0)
+    rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+    rx.set_liminfo(strong_liminfo(s, 15))
+    rx.set_mix1_selfreq(0.31 * (1 << 17) + 0.3)
+    for _ in range(calls):
+        rx.wideband_dsp(nblk // calls, batch)
+    out = {k: rx.export(r) for r, k in RINGS}
+    out["p"] = rx.p.as_dict()
+    rx.close()
+    return out
+
+
+@pytest.mark.parametrize("calls", [1, 3])
+def test_fused_row_column_kernel_at_32768_equals_the_separate_kernels(calls):
+    """k_fft1r_t2c (row step of fft1 + fft1_c's sums + column step of both timf2 streams) against k_fft1_rows, k_sumsq and k_timf2_cols:
+    the same butterflies on the same data in the same order -- every ring bit for bit; the sums too (same additions in the same order).
+    With cfg.fft1_float_sparse the spectrum stays off the ring and nothing downstream changes."""
+    a = _run15({"LRH_FUSE_FFT1": "1"}, sparse=0, calls=calls)
+    b = _run15({"LRH_FUSE_FFT1": "0"}, sparse=0, calls=calls)
+    c = _run15({"LRH_FUSE_FFT1": "1"}, sparse=1, calls=calls)
+    assert a["p"] == b["p"] == c["p"]
+    assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["sumsq"]) > 32768
+    for _, k in RINGS:
+        assert np.array_equal(a[k], b[k]), k
+        if k != "fft1":
+            assert np.array_equal(a[k], c[k]), k
+    assert np.count_nonzero(c["fft1"]) < np.count_nonzero(a["fft1"])
