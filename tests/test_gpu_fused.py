@@ -165,14 +165,14 @@ def _run15(env, sparse, nblk=48, batch=16, calls=1):
     return out
 
 
-@pytest.mark.parametrize("calls", [1, 3])
-def test_fused_row_column_kernel_at_32768_equals_the_separate_kernels(calls):
+@pytest.mark.parametrize("calls,pipeline", [(1, "0"), (3, "0"), (1, "2")])
+def test_fused_row_column_kernel_at_32768_equals_the_separate_kernels(calls, pipeline):
     """k_fft1r_t2c (row step of fft1 + fft1_c's sums + column step of both timf2 streams) against k_fft1_rows, k_sumsq and k_timf2_cols:
     the same butterflies on the same data in the same order -- every ring bit for bit; the sums too (same additions in the same order).
     With cfg.fft1_float_sparse the spectrum stays off the ring and nothing downstream changes."""
-    a = _run15({"LRH_FUSE_FFT1": "1"}, sparse=0, calls=calls)
-    b = _run15({"LRH_FUSE_FFT1": "0"}, sparse=0, calls=calls)
-    c = _run15({"LRH_FUSE_FFT1": "1"}, sparse=1, calls=calls)
+    a = _run15({"LRH_FUSE_FFT1": "1", "LRH_PIPELINE": pipeline}, sparse=0, calls=calls)       # "2": the one-round-late two-stream schedule, forced
+    b = _run15({"LRH_FUSE_FFT1": "0", "LRH_PIPELINE": "0"}, sparse=0, calls=calls)
+    c = _run15({"LRH_FUSE_FFT1": "1", "LRH_PIPELINE": pipeline}, sparse=1, calls=calls)
     assert a["p"] == b["p"] == c["p"]
     assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["sumsq"]) > 32768
     for _, k in RINGS:
