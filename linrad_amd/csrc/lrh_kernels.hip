@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
 // transforms and keeps sum |X|^2 of its bins in registers (k_fft2's scheme), so neither the fft2_power ring nor the
 // k_powersum2 pass over it is needed.
 template <int LA, int LB, bool FUSED>
-__global__ __launch_bounds__(1024, 8) void k_fft2_rows(Fft2BigArgs a)    // two workgroups per CU: 64 VGPRs
+__global__ __launch_bounds__(1024, LB <= 8 ? 8 : 4) void k_fft2_rows(Fft2BigArgs a)    // row length <= 256: two workgroups per CU at 64 VGPRs; 512 (8 points per thread) spills 34 registers at that limit
 {
   constexpr int P = sub_ppt(LB);
   using Plan = FftPlan<LB, P>;
