@@ -100,7 +100,7 @@ struct lrh_ctx {
   bool ss_defer = false, ss_have = false; SumsqArgs ss_args; int ss_run = 1;
   // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
-  bool f1_defer = false, f1_have = false, fuse_fft1 = true; Fft1Args f1_args; int f1_batch = 0;
+  bool f1_defer = false, f1_have = false, fuse_fft1 = true, fuse_fft1_forced = false; Fft1Args f1_args; int f1_batch = 0;   // fuse_fft1_forced: LRH_FUSE_FFT1=1 given (tests: the fused kernel whatever the batch)
   bool f1_is_big = false; Fft1BigArgs f1_big;   // fft1_size 32768: the column step has run, the row step is what is parked (k_fft1r_t2c takes it)
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
   bool corr_on = false; int slowcorr_tot_avgnum = 0; float2 *d_xspec = nullptr, *d_corrsum = nullptr, *d_slowcorr = nullptr; double2 *d_slowcorr_tot = nullptr;   // lrh_set_correlation
@@ -467,7 +467,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
-  if (const char *e9 = getenv("LRH_FUSE_FFT1")) c->fuse_fft1 = atoi(e9) != 0;        // 0: k_fft1 + k_timf2 also where k_fft1w would run
+  if (const char *e9 = getenv("LRH_FUSE_FFT1")) { c->fuse_fft1 = atoi(e9) != 0; c->fuse_fft1_forced = c->fuse_fft1; }   // 0: k_fft1 + k_timf2 also where k_fft1w would run; 1: k_fft1w also for rounds of a few blocks
   c->sums_on_main = cfg->fft2_n <= 14;
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
@@ -2420,7 +2420,10 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   const bool fuse = c->fuse_sumsq && c->cfg.second_fft_enable && c->timf2_mode == 1 && (c->d_ss_part || fuse15);
   // ... and fft1_b's transform rides there too (k_fft1w): parked by lrh_fft1_b, taken by lrh_make_timf2, issued as k_fft1 by whoever else reads the ring
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); c->f1_defer = false; if (c->f1_have) launch_parked_fft1(c); } } fuse_guard{c};
-  c->f1_defer = fuse && c->fuse_fft1 && ((!c->fft1_big && c->cfg.fft1_n == 14) || fuse15);
+  // (a call of a few blocks is a chain of single-workgroup latencies: there one block through k_fft1w -- forward and back transform in
+  // one 512-thread workgroup -- takes longer than through k_fft1 and k_timf2 one after the other: 94 against 84 us per call of 1 block,
+  // 149 against 127 at 4, even at 64; the fused kernel from 32 blocks per round)
+  c->f1_defer = fuse && c->fuse_fft1 && ((!c->fft1_big && c->cfg.fft1_n == 14 && (batch >= 32 || c->fuse_fft1_forced || c->cfg.fft1_float_sparse)) || fuse15);   // (a sparse ring has no full spectrum for k_timf2's overlap: always fused)
   auto sums = [&](int B) -> int {                // fft1_c: launches at once, or parked for the next make_timf2
     c->ss_defer = fuse; const int r = lrh_fft1_c(c, p, B); c->ss_defer = false; return r;
   };

@@ -3,7 +3,7 @@
 out=gpurun_out/small_calls.txt; : > $out
 for pl in ${PIPELINES:-default 2 0}; do for b in ${BATCHES:-1 4 16 64 256}; do
   if [ "$pl" = default ]; then unset LRH_PIPELINE; else export LRH_PIPELINE=$pl; fi
-  timeout -k 5 200 python bench.py --no-cpu --no-secondary --fft2-n ${FFT2N:-16} --batch $b --rounds 1 --steps ${STEPS:-2000} --warmup 100 > gpurun_out/_s.json 2> gpurun_out/_s.log || { echo "pipeline $pl batch $b FAILED" >> $out; continue; }
+  timeout -k 5 200 python bench.py --no-cpu --no-secondary --fft1-float full --fft2-n ${FFT2N:-16} --batch $b --rounds 1 --steps ${STEPS:-2000} --warmup 100 > gpurun_out/_s.json 2> gpurun_out/_s.log || { echo "pipeline $pl batch $b FAILED" >> $out; continue; }
   python3 - $pl $b >> $out <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/_s.json").read().strip().splitlines()[-1])
@@ -15,7 +15,7 @@ cat $out
 if [ -n "$NOSELLIM" ]; then
   unset LRH_PIPELINE
   for b in ${BATCHES:-1 4 16 64 256}; do
-    timeout -k 5 200 python bench.py --no-cpu --no-secondary --no-sellim --fft2-n ${FFT2N:-16} --batch $b --rounds 1 --steps ${STEPS:-2000} --warmup 100 > gpurun_out/_s.json 2> gpurun_out/_s.log || continue
+    timeout -k 5 200 python bench.py --no-cpu --no-secondary --no-sellim --fft1-float full --fft2-n ${FFT2N:-16} --batch $b --rounds 1 --steps ${STEPS:-2000} --warmup 100 > gpurun_out/_s.json 2> gpurun_out/_s.log || continue
     python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/_s.json').read().strip().splitlines()[-1])
