@@ -180,3 +180,37 @@ def test_fused_row_column_kernel_at_32768_equals_the_separate_kernels(calls, pip
         if k != "fft1":
             assert np.array_equal(a[k], c[k]), k
     assert np.count_nonzero(c["fft1"]) < np.count_nonzero(a["fft1"])
+
+
+def test_rounds_of_a_few_blocks_between_fused_rounds():
+    """without LRH_FUSE_FFT1 the library picks the kernel by the round's length (k_fft1w from 32 blocks, k_fft1 + k_timf2 below): a
+    caller that mixes long and short rounds crosses from one to the other and back -- the overlap partner comes from the fft1 ring one
+    way and is recomputed from the samples the other way -- and must end where the two-kernel path ends"""
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        os.environ.pop("LRH_FUSE_FFT1", None) if "LRH_FUSE_FFT1" not in env else None
+        try:
+            cfg = chain_config(14, 12, batch=32, rounds=5)
+            cfg.stupid_bln_mode = 0
+            rx = open_hip(cfg)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        s = synth_defaults(N1, 0)
+        rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+        rx.set_liminfo(strong_liminfo(s, 14))
+        rx.set_mix1_selfreq(0.31 * 4096 + 0.3)
+        for nblk, batch in ((64, 32), (16, 8), (3, 1), (64, 32)):
+            rx.wideband_dsp(nblk, batch)
+        out = {k: rx.export(r) for r, k in RINGS}
+        out["p"] = rx.p.as_dict()
+        rx.close()
+        return out
+    a, b = run({}), run({"LRH_FUSE_FFT1": "0"})
+    assert a["p"] == b["p"]
+    for _, k in RINGS:
+        assert _rel(a[k], b[k]) < 2e-6, k
+    assert not np.array_equal(a["timf2"], b["timf2"])      # (the fused kernel did run: its last-pass twiddles round differently)
