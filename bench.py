@@ -424,7 +424,9 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
     # ---- per-kernel timing with HIP events on the streams the kernels are launched on (rank 0), in the SAME two-stream
     # schedule as the timed loop (lrh_profile_enable(2)); a serial pass afterwards gives the stand-alone times
     stages, alone, roof = {}, {}, None
-    if rank == 0 and with_stage_times and not (coupled and args.coupled_stages):
+    # (a coupled pair issues its collectives inside lrh_wideband_dsp: with two ranks BOTH must make the profiled calls, or rank 0 waits for
+    # a partner that has already left -- the stage-by-stage form, --coupled-stages, is not profiled)
+    if (rank == 0 or (coupled and world > 1)) and with_stage_times and not (coupled and args.coupled_stages):
         nprof = max(3, min(steps, 10))
         rx.profile_enable(2)
         for _ in range(nprof):
@@ -617,6 +619,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("LRH_BENCH_WATCHDOG"):               # diagnostics: every thread's Python stack to stderr after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LRH_BENCH_WATCHDOG"]), exit=True)
     if os.environ.get("LRH_BENCH_SAME_DEVICE") == "1":     # rehearsal of the N > 1 logic on a one-GPU box (backend gloo)
         local_rank = 0
     import torch

@@ -193,6 +193,31 @@ def test_bench_combine_step_runs_over_rccl_on_one_gpu():
     assert "coherent combine" in out["mode"] and out["value"] > 100
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--coupled", "--no-secondary"], []])
+def test_bench_two_ranks_on_one_gpu_over_gloo(flags):
+    """the N = 2 line of the scaling run, rehearsed on one GPU: two ranks under torch.distributed.run (backend gloo, both on device 0)
+    through bench.py's coupled pair (configs[3]: the collectives are issued inside lrh_wideband_dsp, so BOTH ranks must make the
+    profiled calls of the stage-timing pass too -- rank 0 alone waited for ever) and through the default --gpus 2 run (configs[4] with
+    configs[3] as its secondary object); a hang ends in the watchdog's stack dump, not in the driver's timeout"""
+    import json
+    import socket
+    import subprocess
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(LRH_BENCH_BACKEND="gloo", LRH_BENCH_SAME_DEVICE="1", LRH_BENCH_WATCHDOG="240", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--rounds", "2", "--no-cpu", *flags],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-2500:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["config"]["collective_world_size"] == 2 and out["value"] > 0
+    if flags:
+        assert "coupled" in out["mode"] and out["stages"]
+    else:
+        assert "coherent combine" in out["mode"] and out["secondary"].get("value", 0) > 0, out["secondary"]
+
+
 def test_oracle_four_channel_coherent_combine():
     from oracle_binding import open_oracle
     _check(open_oracle, 2e-6)
