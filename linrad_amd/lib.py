@@ -65,6 +65,12 @@ class HipReceiver(StageAPI):
     def sync(self):
         self._chk(self.lib.lrh_sync(self.ctx), "sync")
 
+    def flush(self):
+        """issue what lrh_wideband_dsp still holds back from its last round, without waiting (lrh_flush): afterwards the context's stream
+        carries everything the calls so far have produced -- what a consumer ordered only on that stream needs"""
+        self.lib.lrh_flush.argtypes, self.lib.lrh_flush.restype = [C.c_void_p], C.c_int
+        self._chk(self.lib.lrh_flush(self.ctx), "flush")
+
     def timer_start(self):
         self._chk(self.lib.lrh_timer_start(self.ctx), "timer_start")
 

@@ -536,7 +536,7 @@ def test_one_round_late_schedule_carries_over_calls(monkeypatch):
              abi.RING_FFT2_POWERSUM, abi.RING_TIMF3_FLOAT, abi.RING_WG_WATERF, abi.RING_FFT3, abi.RING_BASEB_RAW)
     monkeypatch.setenv("LRH_PIPELINE", "2")
     res = []
-    for variant in ("one call", "call per round", "call per round + state read", "LRH_PERSIST=0"):
+    for variant in ("one call", "call per round", "call per round + state read", "call per round + flush", "LRH_PERSIST=0"):
         monkeypatch.setenv("LRH_PERSIST", "0" if variant == "LRH_PERSIST=0" else "1")
         rx = _hip(cfg)
         _feed(rx, iq, lim, 0.31 * 65536 + 0.3)
@@ -547,9 +547,23 @@ def test_one_round_late_schedule_carries_over_calls(monkeypatch):
                 rx.wideband_dsp(16, 16)
                 if variant.endswith("state read"):
                     rx.blanker_state()
+                if variant.endswith("flush"):
+                    rx.flush()                              # lrh_flush: the parked round goes out, nothing is waited for
+        if variant.endswith("flush"):
+            # a consumer ordered only on the context's stream: after lrh_flush that stream carries the last round too, so a device
+            # copy of the timf3 ring enqueued on it (a torch ExternalStream, no further library call) sees the final samples
+            import torch
+            st = torch.cuda.ExternalStream(rx.stream_handle(), device=torch.device("cuda:0"))
+            peek = torch.empty(cfg.timf3_size, dtype=torch.float32, device="cuda:0")
+            with torch.cuda.stream(st):
+                rx.export_device_async(abi.RING_TIMF3_FLOAT, peek.data_ptr(), 0, cfg.timf3_size)
+            st.synchronize()
+            peeked = peek.cpu().numpy()
         bs = rx.blanker_state()
         res.append(([rx.export(r) for r in rings], rx.p.as_dict(),
                     (bs.timf2_noise_floor, bs.stupid_bln_limit, bs.timf2_cleared_points, bs.last_call_cleared)))
+        if variant.endswith("flush"):
+            assert np.array_equal(peeked, res[-1][0][rings.index(abi.RING_TIMF3_FLOAT)])
         rx.close()
     assert np.count_nonzero(res[0][0][-1]) > 100
     for other in res[1:]:
