@@ -165,7 +165,7 @@ def _run15(env, sparse, nblk=48, batch=16, calls=1):
     return out
 
 
-@pytest.mark.parametrize("calls,pipeline", [(1, "0"), (3, "0"), (1, "2")])
+@pytest.mark.parametrize("calls,pipeline", [(1, "0"), (3, "0"), (1, "2"), (3, "2")])
 def test_fused_row_column_kernel_at_32768_equals_the_separate_kernels(calls, pipeline):
     """k_fft1r_t2c (row step of fft1 + fft1_c's sums + column step of both timf2 streams) against k_fft1_rows, k_sumsq and k_timf2_cols:
     the same butterflies on the same data in the same order -- every ring bit for bit; the sums too (same additions in the same order).
