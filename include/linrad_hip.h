@@ -555,17 +555,20 @@ int lrh_wideband_dsp(lrh_ctx *ctx, lrh_ptrs *p, int nblocks, int batch);
 /* Two coupled channels (cfg.blanker_channels = 2) through lrh_wideband_dsp: the exchanges that sit between the stage calls (see
    lrh_blanker_begin, lrh_fft2_xy_begin, lrh_mix2_pol_begin) are made by a function the caller registers.  At each exchange point the
    library has enqueued everything that fills the buffer on `stream` (the context's own stream, a hipStream_t) and calls
-       fn(user, which, op, device_ptr, count, stream)
+       fn(user, which, op, device_ptr, count, stream, own)
    which must enqueue the collective ON THAT STREAM (RCCL: ncclAllReduce / ncclAllGather with the stream; torch: under an
    ExternalStream) and return 0 without waiting; the library then enqueues the consumers behind it.  op LRH_XOP_SUM: in-place all-reduce
    (sum) of `count` floats at device_ptr; op LRH_XOP_GATHER: all-gather of the two slots of `count` floats each that start at device_ptr
-   (slot r is the one channel r filled: the caller's own slot is its send buffer).  Nothing waits on the host, so a whole call is enqueued
+   (slot r is the one channel r filled: the caller's own slot is its send buffer -- unless `own` is not NULL: then the caller's `count`
+   floats lie at `own`, still where the stage before left them (LRH_X_BINS: the fft2 ring, which saves a device copy of every transform),
+   its own slot has NOT been filled and need not be, and the collective has to deliver the partner's slot only; fn(..., own) with a
+   plain all-gather: send buffer `own`, receive buffer device_ptr).  Nothing waits on the host, so a whole call is enqueued
    like a single-channel one: fft1 / sums / weak stream fused as usual, blanker_begin -> SUM(LRH_X_PWR) [-> GATHER(LRH_X_WEAK) with the
    linear blanker's tables] -> blanker -> SUM(LRH_X_STAT) -> blanker_finish, make_fft2 -> GATHER(LRH_X_BINS) -> cross products and
    waterfall line, mix1, fft3 -> SUM(LRH_X_POL) (after lrh_set_pol) -> mix2, once per batch.  fn = NULL removes it (the stage calls
    remain available; lrh_wideband_dsp then refuses coupled contexts as before). */
 enum { LRH_XOP_SUM = 0, LRH_XOP_GATHER = 1 };
-typedef int (*lrh_exchange_fn)(void *user, int which, int op, void *device_ptr, size_t count, void *stream);
+typedef int (*lrh_exchange_fn)(void *user, int which, int op, void *device_ptr, size_t count, void *stream, const void *own);
 int lrh_set_exchange(lrh_ctx *ctx, lrh_exchange_fn fn, void *user);
 
 /* ---- host-visible side outputs ---- */

@@ -589,17 +589,18 @@ class StageAPI:
         return st
 
     def set_exchange(self, fn):
-        """register the cross-channel exchange function of two coupled channels (lrh_set_exchange): fn(which, op, ptr, count, stream) -> 0;
+        """register the cross-channel exchange function of two coupled channels (lrh_set_exchange): fn(which, op, ptr, count, stream, own) -> 0
+        (own: where the caller's contribution to a gather lies when it is not in its slot, else None);
         None removes it.  The ctypes thunk is kept alive on the receiver."""
-        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
         f = self._f("set_exchange")
         f.argtypes, f.restype = [C.c_void_p, proto, C.c_void_p], C.c_int
         if fn is None:
             self._xthunk = proto()
         else:
-            def thunk(user, which, op, ptr, count, stream):
+            def thunk(user, which, op, ptr, count, stream, own):
                 try:
-                    return int(fn(which, op, ptr, count, stream) or 0)
+                    return int(fn(which, op, ptr, count, stream, own) or 0)
                 except Exception:  # noqa: BLE001
                     import traceback
                     traceback.print_exc()

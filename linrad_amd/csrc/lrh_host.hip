@@ -105,6 +105,7 @@ struct lrh_ctx {
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
   bool corr_on = false; int slowcorr_tot_avgnum = 0; float2 *d_xspec = nullptr, *d_corrsum = nullptr, *d_slowcorr = nullptr; double2 *d_slowcorr_tot = nullptr;   // lrh_set_correlation
   lrh_exchange_fn xfn = nullptr; void *xuser = nullptr;     // lrh_set_exchange: collectives of two coupled channels inside lrh_wideband_dsp
+  const float2 *xy_own_src = nullptr;                       // set by dsp_coupled around lrh_fft2_xy_finish: the own channel's transforms where they lie in the fft2 ring
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
@@ -1813,7 +1814,9 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int N = c->N2;
   XyArgs a;
-  a.x = c->d_xbins; a.y = c->d_xbins + (size_t)batch * N; a.xypower = c->cfg.fft2_float_sparse ? nullptr : c->d_xypower; a.first_na = at->fft2_na; a.na_mask = c->fft2n_mask;
+  a.x = c->d_xbins; a.y = c->d_xbins + (size_t)batch * N;
+  if (c->xy_own_src) { if (c->cfg.timf1_channel_index & 1) a.y = c->xy_own_src; else a.x = c->xy_own_src; }   // lrh_wideband_dsp: the own channel straight from the ring
+  a.xypower = c->cfg.fft2_float_sparse ? nullptr : c->d_xypower; a.first_na = at->fft2_na; a.na_mask = c->fft2n_mask;
   a.n = N; a.batch = batch; a.sum_in = c->d_xysum; a.sum_out = c->d_xysum_alt; a.lines = c->d_wf_scratch;
   a.counter = at->wg_waterf_sum_counter; a.avgnum = c->cfg.waterfall_avgnum;
   { float4 *t = c->d_xysum; c->d_xysum = c->d_xysum_alt; c->d_xysum_alt = t; }   // ping-pong: group 0 reads while the last group writes
@@ -2318,12 +2321,12 @@ int lrh_set_exchange(lrh_ctx *c, lrh_exchange_fn fn, void *user)
   return LRH_OK;
 }
 // one exchange point: everything that fills the buffer is on the main stream by now; the caller's function puts the collective there too
-static int exchange(lrh_ctx *c, int which, int op, size_t count)
+static int exchange(lrh_ctx *c, int which, int op, size_t count, const void *own = nullptr)
 {
   if (!count) return LRH_OK;
   void *ptr = nullptr;
   { const int rc = lrh_exchange_ptr(c, which, &ptr); if (rc) return rc; }
-  if (c->xfn(c->xuser, which, op, ptr, count, (void *)c->stream) != 0) return fail(c, LRH_EDEVICE, "the registered exchange function failed");
+  if (c->xfn(c->xuser, which, op, ptr, count, (void *)c->stream, own) != 0) return fail(c, LRH_EDEVICE, "the registered exchange function failed");
   return LRH_OK;
 }
 static int narrow_tail(lrh_ctx *c, lrh_ptrs *p);
@@ -2370,8 +2373,17 @@ static int dsp_coupled(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
       const lrh_ptrs at = *p;
       size_t n = 0;
-      if ((rc = lrh_make_fft2(c, p, kb)) || (rc = lrh_fft2_xy_begin(c, &at, kb, &n)) || (rc = exchange(c, LRH_X_BINS, LRH_XOP_GATHER, n)) ||
-          (rc = lrh_fft2_xy_finish(c, &at, kb)) || (rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
+      if ((rc = lrh_make_fft2(c, p, kb))) return rc;
+      // the batch's transforms as the collective's send buffer where they lie in the fft2 ring (no copy into the own slot: 537 MB per
+      // round of 4096 blocks), unless the span wraps around the ring
+      const int na_ = at.fft2_na & c->fft2n_mask;
+      if (na_ + kb <= c->cfg.max_fft2n) {
+        c->xy_own_src = c->d_fft2 + (size_t)na_ * c->N2; n = (size_t)kb * 2 * c->N2;
+        rc = exchange(c, LRH_X_BINS, LRH_XOP_GATHER, n, c->xy_own_src);
+      } else if (!(rc = lrh_fft2_xy_begin(c, &at, kb, &n))) rc = exchange(c, LRH_X_BINS, LRH_XOP_GATHER, n);
+      if (!rc) rc = lrh_fft2_xy_finish(c, &at, kb);
+      c->xy_own_src = nullptr;
+      if (rc || (rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
       if (c->N3 && c->ms.mix1_selfreq >= 0) {
         if (!c->pol_set) { if ((rc = narrow_tail(c, p))) return rc; }
         else {

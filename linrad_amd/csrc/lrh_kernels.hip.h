@@ -211,7 +211,7 @@ struct Powersum2Args {
 struct RealSplitArgs { float2 *spec; int first_nb, nb_mask, n; const float2 *filtercorr; int direction; };
 // two coupled channels: cross products of the channels' fft2 bins (TWOCHAN_POWER), sums per waterfall group
 struct XyArgs {
-  const float2 *x, *y;        // [batch][n] bins of channel 0 / channel 1 (the two slots of the exchange buffer)
+  const float2 *x, *y;        // [batch][n] bins of channel 0 / channel 1: the two slots of the exchange buffer, or for the own channel the span of the fft2 ring itself
   float4 *xypower;            // ring [na_mask+1][n] {x2, y2, im_xy, re_xy}
   int first_na, na_mask, n, batch;
   const float4 *sum_in; float4 *sum_out;   // fft2_xysum, ping-pong like fft2_powersum

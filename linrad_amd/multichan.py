@@ -172,7 +172,7 @@ def install_exchange(rx, dist, device=None):
     rank = dist.get_rank() if world > 1 else 0
     streams = {}
 
-    def fn(which, op, ptr, count, stream):
+    def fn(which, op, ptr, count, stream, own=None):
         if world == 1:
             return 0                                            # nobody to talk to: the buffers already hold the sums / both slots are ours
         n = count if op == XOP_SUM else 2 * count
@@ -184,12 +184,16 @@ def install_exchange(rx, dist, device=None):
             with torch.cuda.stream(st):
                 if op == XOP_SUM:
                     dist.all_reduce(t)
-                elif dist.get_backend() == "gloo":
-                    slots = [torch.empty(count, dtype=torch.float32, device=device) for _ in range(2)]
-                    dist.all_gather(slots, t[rank * count:(rank + 1) * count].clone())
-                    t[(1 - rank) * count:(2 - rank) * count].copy_(slots[1 - rank])
                 else:
-                    dist.all_gather_into_tensor(t, t[rank * count:(rank + 1) * count])
+                    # the rank's contribution: its slot (in-place all-gather), or -- `own` -- still where the library's previous stage
+                    # left it (then the send buffer is that span and the own slot is merely overwritten with the same values)
+                    mine = t[rank * count:(rank + 1) * count] if not own else torch.as_tensor(_DevSpan(own, count), device=device)
+                    if dist.get_backend() == "gloo":
+                        slots = [torch.empty(count, dtype=torch.float32, device=device) for _ in range(2)]
+                        dist.all_gather(slots, mine.clone())
+                        t[(1 - rank) * count:(2 - rank) * count].copy_(slots[1 - rank])
+                    else:
+                        dist.all_gather_into_tensor(t, mine)
             return 0
         buf = (ctypes.c_float * n).from_address(ptr)
         t = torch.frombuffer(buf, dtype=torch.float32)
@@ -197,9 +201,9 @@ def install_exchange(rx, dist, device=None):
             dist.all_reduce(t)
         else:
             assert world == 2, "Linrad has at most two RF channels (SURVEY F4)"
-            own = t[rank * count:(rank + 1) * count].clone()
-            slots = [torch.empty_like(own), torch.empty_like(own)]
-            dist.all_gather(slots, own)
+            mine = (t[rank * count:(rank + 1) * count] if not own else torch.frombuffer((ctypes.c_float * count).from_address(own), dtype=torch.float32)).clone()
+            slots = [torch.empty_like(mine), torch.empty_like(mine)]
+            dist.all_gather(slots, mine)
             t[(1 - rank) * count:(2 - rank) * count] = slots[1 - rank]
         return 0
     rx.set_exchange(fn)
@@ -216,18 +220,20 @@ def install_pair_exchange(rxs, device=None):
     box = [None, None]
 
     def make(ch):
-        def fn(which, op, ptr, count, stream):
+        def fn(which, op, ptr, count, stream, own=None):
             n = count if op == XOP_SUM else 2 * count
             if device is not None:
                 torch.cuda.ExternalStream(stream, device=device).synchronize()
                 t = torch.as_tensor(_DevSpan(ptr, n), device=device)
+                mine = torch.as_tensor(_DevSpan(own, count), device=device) if (own and op != XOP_SUM) else None
             else:
                 t = torch.frombuffer((ctypes.c_float * n).from_address(ptr), dtype=torch.float32)
-            box[ch] = t
+                mine = torch.frombuffer((ctypes.c_float * count).from_address(own), dtype=torch.float32) if (own and op != XOP_SUM) else None
+            box[ch] = (t, mine)
             bar.wait()
-            other = box[1 - ch]
+            other, other_mine = box[1 - ch]
             lo, hi = (1 - ch) * count, (2 - ch) * count
-            tmp = (box[0] + box[1]) if op == XOP_SUM else other[lo:hi].clone()
+            tmp = (box[0][0] + box[1][0]) if op == XOP_SUM else (other_mine.clone() if other_mine is not None else other[lo:hi].clone())
             if device is not None:
                 torch.cuda.synchronize(device)
             bar.wait()

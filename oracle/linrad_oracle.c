@@ -1645,7 +1645,7 @@ static int lro_exchange(lro_ctx *c, int which, int op, size_t count)
   if (!count) return LRH_OK;
   int rc = lro_exchange_ptr(c, which, &ptr);
   if (rc) return rc;
-  return c->xfn(c->xuser, which, op, ptr, count, NULL) ? LRH_EDEVICE : LRH_OK;
+  return c->xfn(c->xuser, which, op, ptr, count, NULL, NULL) ? LRH_EDEVICE : LRH_OK;   /* the oracle always fills its own slot */
 }
 /* two coupled channels through one call: the stage order of include/linrad_hip.h (lrh_set_exchange) with the exchanges made by the
    registered function on host memory */

@@ -169,7 +169,7 @@ def test_hip_coupled_blanker_matches_two_channel_reference(name):
 # ---- the whole two-channel chain: coupled blanker -> make_fft2 per channel -> cross products / sums / polarisation-
 # independent waterfall line from both channels' bins (fft2.c:1622-1640, 1700-1815; the all-gather is done by hand here,
 # tests/test_multichan_gloo.py does it with gloo) -> fft2_mix1_fixed per channel
-def _run_chain(open_fn, name, frames_mode, batch=1):
+def _chain_contexts(open_fn, name, frames_mode):
     d, frames, lim = twochan_case(name, chain=True)
     g = np.load(os.path.join(HERE, "golden", f"{name}_chain.npz"))
     fr = frames.reshape(-1, 4)
@@ -189,6 +189,11 @@ def _run_chain(open_fn, name, frames_mode, batch=1):
         if ch == 1:
             rx.set_ch2_phasing(d["ch2_c1"], d["ch2_c2"])
         rxs.append(rx)
+    return d, g, rxs
+
+
+def _run_chain(open_fn, name, frames_mode, batch=1):
+    d, g, rxs = _chain_contexts(open_fn, name, frames_mode)
     wf_lines, nfft2 = [], 0
     X = abi.StageAPI
     for _ in range(d["nblk"]):
@@ -303,3 +308,40 @@ def test_oracle_two_channel_chain_matches_reference(name):
 def test_hip_two_channel_chain_matches_reference(name, batch):
     from linrad_amd.lib import open_hip
     _check_chain(*_run_chain(open_hip, name, frames_mode=True, batch=batch), 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_pair_through_wideband_dsp_equals_the_stage_calls(monkeypatch):
+    """Both channels' contexts on one GPU, one caller thread each, ONE lrh_wideband_dsp call per context with the collectives traded
+    through device memory (linrad_amd.multichan.install_pair_exchange): inside that call the own channel's fft2 transforms go into the
+    gather and into k_xypower where they lie in the fft2 ring (`own` of lrh_exchange_fn), no copy into the exchange slot.  Every ring
+    must equal the stage-by-stage form with the exchanges made by hand, which the goldens of the compiled two-channel reference pin
+    (test_hip_two_channel_chain_matches_reference)."""
+    import threading
+    import torch
+    from linrad_amd.lib import open_hip
+    from linrad_amd.multichan import install_pair_exchange
+    monkeypatch.setenv("LRH_FUSE_FFT1", "0")                # the same kernels on both sides (k_fft1w rounds its last pass differently)
+    d, g, stage, wf_lines, nfft2 = _run_chain(open_hip, "twochan_n10", frames_mode=True)
+    _, _, rxs = _chain_contexts(open_hip, "twochan_n10", frames_mode=True)
+    install_pair_exchange(rxs, torch.device("cuda:0"))
+    err = []
+
+    def work(rx):
+        try:
+            rx.wideband_dsp(d["nblk"], 1)
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    th = [threading.Thread(target=work, args=(rx,)) for rx in rxs]
+    [t.start() for t in th]
+    for t in th:
+        t.join(180)
+        assert not t.is_alive()
+    assert not err, err
+    assert nfft2 >= 4
+    for ch, rx in enumerate(rxs):
+        assert rx.p.as_dict() == stage[ch]["p"]
+        for ring, key in ((abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_XYPOWER, "xyp"), (abi.RING_FFT2_XYSUM, "xys"), (abi.RING_TIMF3_FLOAT, "timf3"),
+                          (abi.RING_FFT3, "fft3"), (abi.RING_BASEB_RAW, "baseb")):
+            assert np.array_equal(rx.export(ring), stage[ch][key]), (ch, key)
+        rx.close()
