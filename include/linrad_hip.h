@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 2      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread */
+#define LRH_ABI_VERSION 3      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
+                                  3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
+                                     lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions only) */
 
 enum {
   LRH_OK = 0,
