@@ -2446,8 +2446,18 @@ hipError_t launch_xypower(const XyArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_xypower, dim3((a.n + 255) / 256, ngroups), dim3(256), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_waterfall(const WaterfallArgs &a, int nlines, hipStream_t st)
+hipError_t launch_waterfall(const WaterfallArgs &a0, int nlines, hipStream_t st)
 {
+  // more lines than the ring holds: the older ones share ring rows with the newest and would race with them, the reference's
+  // sequential update_wg_waterf leaves the newest; only those are converted
+  WaterfallArgs a = a0;
+  const int ring_lines = a.npix > 0 ? a.wf_size / a.npix : nlines;
+  if (nlines > ring_lines) {
+    const int skip = nlines - ring_lines;
+    a.ps += (size_t)skip * a.line_stride;
+    a.ptr0 = (int)(((long long)a.ptr0 - (long long)skip * a.npix) % a.wf_size); if (a.ptr0 < 0) a.ptr0 += a.wf_size;
+    nlines = ring_lines;
+  }
   int work = a.npix;
   if (!(a.hx == 1 || a.hp == 1) && a.hx == 0) work = (a.npix - a.hp + a.hp - 1) / a.hp + 1;
   hipLaunchKernelGGL(k_waterfall, dim3((work + 255) / 256, nlines), dim3(256), 0, st, a);

@@ -28,6 +28,12 @@ def test_library_exports_every_declared_symbol():
     assert lib.lrh_abi_version() == 3
 
 
+def test_graft_entry_build_accepts_the_library_it_built():
+    # the driver's build check: an incremental make, then the version the header declares against the one the library reports
+    import __graft_entry__ as g
+    g.build()
+
+
 def test_struct_sizes_match_header():
     lib = hip_lib()
     cfg = abi.LrhConfig()

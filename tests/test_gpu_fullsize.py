@@ -570,3 +570,41 @@ def test_one_round_late_schedule_carries_over_calls(monkeypatch):
         assert other[1] == res[0][1] and other[2] == res[0][2]
         for a, b in zip(res[0][0], other[0]):
             assert np.array_equal(a, b)
+
+
+def test_bench_shape_equals_rounds_of_256_blocks():
+    """The configuration bench.py times -- BASELINE configs[2] at 4096 fft1 blocks per round on the one-round-late two-stream
+    schedule, sparse fft1 / fft2 rings, fft3 and mix2 inside the call -- against the same contexts' rings after rounds of 256 blocks in
+    the serial order with both rings full (which the full-size oracle tests above reach in rounds of 16).  A block's transforms do not
+    depend on how many share a launch: everything downstream of the sums is bit for bit the same; the sums associate differently where
+    an averaging period straddles two workgroup runs (k_sumsq_join)."""
+    from linrad_amd.lib import synth_defaults, synth_iq
+    import os
+    nblk = 2 * 4096
+    s = synth_defaults(N1, 0)
+    res = []
+    for batch, sparse, pipeline in ((4096, 1, None), (256, 0, "0")):
+        old = os.environ.get("LRH_PIPELINE")
+        if pipeline is not None:
+            os.environ["LRH_PIPELINE"] = pipeline
+        try:
+            cfg = chain_config(14, 16, batch=4096, fft3_n=12, mix2_n=8, rounds=2)
+            cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
+            cfg.stupid_bln_mode = 0                          # (the blanker's statistics are per call: a property of the call pattern)
+            rx = _hip(cfg)
+        finally:
+            os.environ.pop("LRH_PIPELINE", None) if old is None else os.environ.__setitem__("LRH_PIPELINE", old)
+        _feed(rx, synth_iq(s, 0, cfg.timf1_bytes // 4), strong_liminfo(s, 14), 0.31 * 65536 + 0.3)
+        rx.wideband_dsp(nblk, batch)
+        res.append({k: rx.export(r) for r, k in ((abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_PWR, "pwr"),
+                                                 (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_WG_WATERF, "wf"), (abi.RING_TIMF3_FLOAT, "timf3"),
+                                                 (abi.RING_FFT3, "fft3"), (abi.RING_BASEB_RAW, "baseb"))} | {"p": rx.p.as_dict()})
+        rx.close()
+    a, b = res
+    assert a["p"] == b["p"]
+    assert np.count_nonzero(a["baseb"]) > 1000 and np.count_nonzero(a["timf3"]) > 1000
+    # the waterfall: a round of 4096 blocks ends 128 lines, twice what the ring holds -- the lines that stay are the newest 64
+    for k in ("pwr", "ps2", "wf", "timf3", "fft3", "baseb"):
+        assert np.array_equal(a[k], b[k]), (k, int(np.count_nonzero(a[k] != b[k])))
+    for k in ("sumsq", "slowsum"):
+        assert _relerr(a[k], b[k]) < 2e-6, k
