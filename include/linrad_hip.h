@@ -308,15 +308,21 @@ typedef struct lrh_sellim {
   /* lrh_fft2_update_liminfo only */
   float blanker_ston_fft2;      /* hg.blanker_ston_fft2 (hires_graph.c:722)                                    */
   float fft2_blocktime;         /* seconds between fft2 transforms (buf.c:456)                                 */
+  int sellim_par1;              /* hg.sellim_par1: 2 (hires_graph.c:1175, the reference's setting), 1 or 0     */
   /* selfreq_liminfo's liminfo_amplitude_factor (sellim.c:119-155): the calibrated form needs the amplitude calibration */
   const float *fft1_desired;    /* N1 floats, or NULL: uncalibrated form (share of strong bins in the passband) */
 } lrh_sellim;
 int lrh_fft1_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
-/* fft2_update_liminfo (sellim.c:159-736, hg.sellim_par1 = 2, the reference's setting; variants 0 and 1 are not built): after
+/* fft2_update_liminfo (sellim.c:159-736; hg.sellim_par1 = 2 is the reference's setting and what is described here): after
    make_fft2 has completed a waterfall line (fft2_liminfo_cnt, wcw.c:1129-1133) the summed fft2 power spectrum -- averaged over the
    fft2 bins of every fft1 bin -- gives a second, finer look: group minima -> global noise floor -> bins above
    0.5 * blanker_ston_fft2 * floor join the strong signals for the hold-off time, and a table that has grown beyond a quarter of
-   the passband is thinned.  Ends with selfreq_liminfo like the fft1 variant.  Same table, same hand-over to make_timf2. */
+   the passband is thinned.  Ends with selfreq_liminfo like the fft1 variant.  Same table, same hand-over to make_timf2.
+   sellim_par1 = 0 (sellim.c:170-281): the median of all fft2 bin powers is the noise floor; the band edges below 2 % of it and
+   every fft1 bin holding an fft2 bin above blanker_ston_fft2 * median join the strong signals.  sellim_par1 = 1 (sellim.c:283-533):
+   between attenuated carriers every weak-signal region of six bins or more gets a noise floor of its own (mean of the bins within
+   2 (1 + 2 / waterfall_avgnum) of its in-band minimum); bins above blanker_ston_fft2 * floor join, then whole regions and single bins
+   above the same factor times the length-weighted mean floor of all regions. */
 int lrh_fft2_update_liminfo(lrh_ctx *ctx, lrh_ptrs *p, const lrh_sellim *par);
 /* The limiter calls of wideband_dsp's loop (wcw.c:1124-1133) inside lrh_wideband_dsp: with parameters installed here every round
    of that call ends with fft1_update_liminfo when fft1_c has completed an averaging period since the last look (fft1_liminfo_cnt),

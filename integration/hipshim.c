@@ -182,7 +182,7 @@ void hip_make_timf2(void)
   lrh_ptrs q;
   int n;
   memset(&q, 0, sizeof q);
-  /* host code has rewritten liminfo[] (fft2_update_liminfo with hg.sellim_par1 != 2, a GUI reset): the device gets the new table.
+  /* host code has rewritten liminfo[] (a GUI reset): the device gets the new table.
      The limiter hooks below publish the device's own table under the same lock, so a half-published table is never taken for a change. */
   pthread_mutex_lock(&hip_liminfo_lock);
   if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {
@@ -254,7 +254,7 @@ static void hip_sellim_par(lrh_sellim *par, lrh_ptrs *q)
   par->fft1_first_inband = fft1_first_inband; par->fft1_last_inband = fft1_last_inband;
   par->baseband_bw_fftxpts = baseband_bw_fftxpts; par->ston_scale = mg.scale_type == MG_SCALE_STON;
   par->exact_stats = 0;
-  par->blanker_ston_fft2 = hg.blanker_ston_fft2; par->fft2_blocktime = fft2_blocktime;
+  par->blanker_ston_fft2 = hg.blanker_ston_fft2; par->fft2_blocktime = fft2_blocktime; par->sellim_par1 = hg.sellim_par1;
   par->fft1_desired = (fft1_calibrate_flag & CALAMP) == CALAMP ? fft1_desired : NULL;     /* sellim.c:134-143 */
   q->fft1_sumsq_pa = fft1_sumsq_pa;
   lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);             /* selfreq_liminfo protects the selected passband (sellim.c:38) */
@@ -276,12 +276,12 @@ void hip_fft1_update_liminfo(void)
   if (lrh_fft1_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1471); return; }
   hip_liminfo_back();
 }
-/* fft2_update_liminfo (sellim.c:159; the library builds the reference's setting hg.sellim_par1 = 2, other values keep the host code) */
+/* fft2_update_liminfo (sellim.c:159; all three settings of hg.sellim_par1 run on the device-resident fft2 power sums) */
 int hip_fft2_update_liminfo(void)
 {
   lrh_sellim par;
   lrh_ptrs q;
-  if (hg.sellim_par1 != 2) return 0;
+  if (hg.sellim_par1 < 0 || hg.sellim_par1 > 2) return 0;
   hip_sellim_par(&par, &q);
   if (lrh_fft2_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1473); return 1; }
   hip_liminfo_back();

@@ -119,14 +119,14 @@ class LrhSellim(C.Structure):
                 ("liminfo_group_points", C.c_int), ("fft1_first_point", C.c_int), ("fft1_last_point", C.c_int),
                 ("fft1_first_inband", C.c_int), ("fft1_last_inband", C.c_int), ("baseband_bw_fftxpts", C.c_int),
                 ("ston_scale", C.c_int), ("exact_stats", C.c_int), ("blanker_ston_fft2", C.c_float), ("fft2_blocktime", C.c_float),
-                ("fft1_desired", C.POINTER(C.c_float))]
+                ("sellim_par1", C.c_int), ("fft1_desired", C.POINTER(C.c_float))]
 
 
 def default_sellim(cfg, **kw):
     """hires_graph.c:1175-1189 defaults, uncalibrated end points (fft1.c:4615-4618), 16 noise-floor groups"""
     n1 = 1 << cfg.fft1_n
     s = LrhSellim(C.sizeof(LrhSellim), 12000, cfg.fft_avg1num * cfg.fft_avg2num, 0.0008, 4.0, 0, 0, 0, 0, 0, 0, 0,
-                  n1 // 16, 0, n1 - 1, 0, n1 - 1, 40, 0, 1, 30.0, 0.0008 * (1 << cfg.fft2_n) / n1, None)
+                  n1 // 16, 0, n1 - 1, 0, n1 - 1, 40, 0, 1, 30.0, 0.0008 * (1 << cfg.fft2_n) / n1, 2, None)
     for k, v in kw.items():
         if not hasattr(s, k):
             raise AttributeError(k)

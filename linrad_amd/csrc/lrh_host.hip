@@ -160,6 +160,7 @@ struct lrh_ctx {
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
   lrh_sellim wl_par{}; bool wl_on = false, wl_fft2 = false; int wl_cnt1 = 0, wl_cnt2 = 0; std::vector<float> wl_desired;   // lrh_wideband_limiter
+  float *d_sel_reg = nullptr; size_t sel_reg_cap = 0;
   float *d_sel_ftmp = nullptr, *d_sel_desired = nullptr, *d_sel_bigb = nullptr, *d_sel_bigg = nullptr; float sel_desired_totsum = 0; std::vector<float> h_sel_desired;   // fftf_tmp of fft2_update_liminfo; calibration of the amplitude factor
   int *d_clv_start = nullptr, *d_clv_ext = nullptr, *d_clv_ctl = nullptr, *d_clv_bk_pos = nullptr, *d_clv_dbg = nullptr; unsigned long long *d_clv_logged = nullptr; float *d_clv_bk_pwr = nullptr; float2 *d_clv_bk_tf = nullptr; float *d_clv_bk_pwo = nullptr; float2 *d_clv_bk_ty = nullptr;
   // deferred schedule of lrh_wideband_dsp: the search of a round is issued a round late, its resume point comes back through a pinned slot
@@ -377,7 +378,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -811,6 +812,18 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
   else {
     if (!c->d_sel_ftmp) { const int rc = dev_alloc(c, &c->d_sel_ftmp, c->N1); if (rc) return rc; HIPCHK(c, hipStreamSynchronize(c->stream)); }
     a.tmp = c->d_sel_ftmp;
+    a.par1 = q->sellim_par1;
+    if (a.par1 == 1) {                                      // the region list of variant 1 (reg_noise, reg_first_point, reg_length: buf.c:976-980), zero at first
+      const size_t cap = (size_t)c->N1 / q->liminfo_group_points + 8;
+      if (c->sel_reg_cap < cap) {
+        if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
+        if (c->d_sel_reg) { (void)hipFree(c->d_sel_reg); c->d_sel_reg = nullptr; c->sel_reg_cap = 0; }
+        const int rc = dev_alloc(c, &c->d_sel_reg, 3 * cap); if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->sel_reg_cap = cap;
+      }
+      a.reg_noise = c->d_sel_reg; a.reg_first = (int *)(c->d_sel_reg + c->sel_reg_cap); a.reg_len = (int *)(c->d_sel_reg + 2 * c->sel_reg_cap);
+    }
   }
   // behind everything queued so far on the main stream (the previous make_timf2 that read the routing words; the sums in the serial
   // order) and, when this round's sums (first limiter) or the fft2 power sums (second) ran there, on the side stream -- not otherwise:
@@ -844,6 +857,7 @@ static int sellim_check(lrh_ctx *c, const lrh_sellim *q, bool second)
   if (!ok) return fail(c, LRH_EINVAL, "selective limiter: parameter out of range (group_points, first/last point or inband, maxlevel, spek_avgnum, blocktime)");
   if (second && (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2 || c->N2 < c->N1))
     return fail(c, LRH_EINVAL, "fft2_update_liminfo: one channel, second fft on, fft2_size >= fft1_size");
+  if (second && (q->sellim_par1 < 0 || q->sellim_par1 > 2)) return fail(c, LRH_EINVAL, "fft2_update_liminfo: sellim_par1 is 0, 1 or 2 (hires_graph.c:1175)");
   return LRH_OK;
 }
 int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)

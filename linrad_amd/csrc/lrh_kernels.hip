@@ -3582,6 +3582,227 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2(SellimArgs a)
   sl_pack(a, B, tid);
 }
 
+// fft2_update_liminfo with hg.sellim_par1 = 0 (sellim.c:170-281): the noise floor is the median of all fft2 bin powers (times the fft1
+// bin's display factor).  The reference sorts the lower half of the spectrum by selection to read it off; here a radix select over the
+// float bit patterns finds the same order statistic in four histogram passes of one workgroup.  Then the band edges (first / last fft2
+// bin not below 2 % of the median), and every fft1 bin holding an fft2 bin above ston * median joins the strong signals.
+template <bool BIG>
+__global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_median(SellimArgs a)
+{
+  extern __shared__ float sm[];
+  const int N = a.n, N2 = a.n2, tid = threadIdx.x, nn = N2 / N;
+  float *B = BIG ? a.big_b : sm;
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_rank; __shared__ int s_lo, s_hi;
+  for (int i = tid; i < N; i += LRH_SL_THREADS) B[i] = a.liminfo[i];
+  if (tid == 0) { s_prefix = 0; s_rank = (unsigned)(N2 / 2 - 1); s_lo = N2 - 1; s_hi = 0; }
+  auto power = [&](int j) { return a.powersum2[j] * a.yfac[j / nn]; };
+  auto key = [&](int j) { const unsigned u = __float_as_uint(power(j)); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); };   // unsigned order = float order
+  for (int pass = 0; pass < 4; pass++) {
+    const int sh = 24 - 8 * pass;
+    for (int i = tid; i < 256; i += LRH_SL_THREADS) hist[i] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix, himask = pass == 0 ? 0u : 0xffffffffu << (sh + 8);
+    for (int j = tid; j < N2; j += LRH_SL_THREADS) { const unsigned k = key(j); if ((k & himask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u); }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned r = s_rank, d = 0;
+      while (d < 255 && r >= hist[d]) { r -= hist[d]; d++; }
+      s_rank = r; s_prefix = prefix | (d << sh);
+    }
+    __syncthreads();
+  }
+  const unsigned mk = s_prefix;
+  const float median = __uint_as_float(mk ^ ((mk >> 31) ? 0x80000000u : 0xffffffffu));
+  const float edge = median * 0.02F;
+  int ib0 = (nn + 1) * a.last_point; if (ib0 > N2) ib0 = N2;          // as written (sellim.c:239)
+  {
+    int lo = N2 - 1, hi = 0;                                          // hi: last bin (+1) below ib0 that is not under the edge limit; 1 at least
+    for (int j = tid; j < N2; j += LRH_SL_THREADS) {
+      const bool up = !(power(j) < edge);
+      if (up && j >= nn * a.first_point && j < lo) lo = j;
+      if (up && j < ib0 && j + 1 > hi) hi = j + 1;
+    }
+    atomicMin(&s_lo, lo); atomicMax(&s_hi, hi);
+  }
+  __syncthreads();
+  int first = (s_lo + nn / 2) / nn, last = ((s_hi < 1 ? 1 : s_hi) + nn / 2) / nn;
+  if (first < 5) first = 5;
+  if (last > N - 6) last = N - 6;
+  const unsigned wn = (unsigned)(1 + (1 + (a.blocktime2 * a.wf_avgnum)) / (a.avg1 * a.blocktime));
+  const unsigned char wait_n = (unsigned char)(wn > 255u ? 255u : wn);
+  const float limit = a.ston2 * median;
+  for (int i = tid; i < N; i += LRH_SL_THREADS) {
+    bool strong = i < first || i >= last;
+    if (!strong) for (int j = nn * i; j < nn * i + nn; j++) strong |= power(j) > limit;
+    if (strong) { B[i] = -1; a.wait[i] = wait_n; }
+  }
+  __syncthreads();
+  sl_selfreq(a, B, tid);
+  __syncthreads();
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
+  sl_pack(a, B, tid);
+}
+
+// fft2_update_liminfo with hg.sellim_par1 = 1 (sellim.c:283-533).  The attenuated carriers (liminfo > 0) cut the band into weak-signal
+// regions; thread 0 walks them through a bit map of the carriers (64 bins a step), and per region of six bins or more the workgroup
+// forms the fft2 power of every bin, thread 0 adds the bins under the limit in index order (a float sum: the order is the result), the
+// workgroup marks what stands ston above that floor, thread 0 keeps the region list.  After the walk: regions, then single bins, above
+// ston times the length-weighted mean floor.  The list (noise, first point, length) persists like the reference's arrays, and the
+// clean-up of a nearly full list keeps the reference's indexing (sellim.c:424, 447-460).
+template <bool BIG>
+__global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a)
+{
+  extern __shared__ float sm[];
+  const int N = a.n, tid = threadIdx.x, nn = a.n2 / a.n, G = N / a.group_points, last = a.last_point;
+  float *A = sm + 8;
+  float *B = BIG ? a.big_b : A + N + 16;
+  float *reg_noise = BIG ? A + N + 16 : B + N + 8;
+  int *reg_first = (int *)(reg_noise + G + 8), *reg_len = reg_first + G + 8;
+  unsigned long long *carrier = (unsigned long long *)(reg_len + G + 8 + ((G & 1) ? 1 : 0));      // bit i: liminfo[i] > 0
+  __shared__ int s_ia, s_ib, s_state, s_regs, s_first, s_last; __shared__ unsigned s_low; __shared__ float s_over;
+  const int nwords = (N + 63) / 64;
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
+  for (int i = tid; i < 8; i += LRH_SL_THREADS) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
+  for (int i = tid; i < G + 8; i += LRH_SL_THREADS) { reg_noise[i] = a.reg_noise[i]; reg_first[i] = a.reg_first[i]; reg_len[i] = a.reg_len[i]; }
+  __syncthreads();
+  for (int i0 = (tid / 64) * 64; i0 < nwords * 64; i0 += LRH_SL_THREADS) {
+    const int i = i0 + (tid & 63);
+    const unsigned long long w = __ballot(i < N && B[i] > 0);
+    if ((tid & 63) == 0) carrier[i0 / 64] = w;
+  }
+  const unsigned wn = (unsigned)(1 + (1 + (a.blocktime2 * a.wf_avgnum)) / (a.avg1 * a.blocktime));
+  const unsigned char wait_n = (unsigned char)(wn > 255u ? 255u : wn);
+  const float ston = a.ston2;
+  // first bin >= i (and < end) whose carrier bit equals `want`; end if none
+  auto next_bit = [&](int i, int end, bool want) {
+    while (i < end) {
+      unsigned long long w = carrier[i >> 6]; if (!want) w = ~w;
+      w &= ~0ull << (i & 63);
+      if (w) { const int j = (i & ~63) + __ffsll((long long)w) - 1; return j < end ? j : end; }
+      i = (i & ~63) + 64;
+    }
+    return end;
+  };
+  auto mark0 = [&](int b) { B[b] = -1; a.wait[b] = wait_n; carrier[b >> 6] &= ~(1ull << (b & 63)); };      // thread 0, any bin
+  auto drop = [&](int k, int n) { for (int j = k + 1; j < n; j++) { reg_noise[j - 1] = reg_noise[j]; reg_first[j - 1] = reg_first[j]; reg_len[j - 1] = reg_len[j]; } };
+  auto mean_noise = [&](int n, bool skip_negative) {
+    int k = 0; float t = 0;
+    for (int i = 0; i < n; i++) { if (skip_negative && reg_noise[i] < 0) continue; k += reg_len[i]; t += reg_noise[i] * reg_len[i]; }
+    return t / k;
+  };
+  if (tid == 0) { s_ia = a.first_point; s_regs = 0; }
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) {                                       // the next region of six bins or more, or the end of the band
+      int ia = s_ia, ib = 0, state = 0;
+      for (;;) {
+        ia = next_bit(ia, last, false);                   // while (liminfo[ia] > 0 && ia < last) ia++
+        if (ia >= last) break;
+        ib = next_bit(ia, last, true);                    // while (liminfo[ib] <= 0 && ib < last) ib++
+        if (ib - ia >= 6) { state = 1; break; }
+        ia = ib;
+      }
+      s_state = state; s_ia = ia + 1; s_ib = ib - 1; s_low = __float_as_uint(LRH_SL_BIG); s_first = N; s_last = -1;
+    }
+    __syncthreads();
+    if (!s_state) break;
+    const int ia = s_ia, ib = s_ib;
+    {
+      float lowest = LRH_SL_BIG;
+      for (int i = ia + tid; i < ib; i += LRH_SL_THREADS) {
+        float t = 0;
+        for (int j = nn * i; j < nn * i + nn; j++) t += a.powersum2[j];
+        t *= a.yfac[i];
+        A[i] = t;
+        if (t < lowest && i >= a.first_inband && i <= a.last_inband) lowest = t;
+      }
+      if (lowest < LRH_SL_BIG) atomicMin(&s_low, __float_as_uint(lowest < 0 ? 0.f : lowest));     // powers: the bit patterns order like the values
+    }
+    __syncthreads();
+    if (tid == 0) {
+      A[ia - 1] = A[ia]; A[ib] = A[ib - 1];
+      float limit = __uint_as_float(s_low);
+      limit *= 2 * (1 + 2. / a.wf_avgnum);
+      const int ja = ia < a.first_inband ? a.first_inband : ia, jb = ib > a.last_inband ? a.last_inband + 1 : ib;
+      float sum = 0; int cnt = 0;                          // not cleared when the limit is widened (sellim.c:356-371)
+      for (;;) {
+#pragma unroll 8
+        for (int i = ja; i < jb; i++) { const float v = A[i]; if (v < limit) { cnt++; sum += v; } }
+        if (cnt == 0 || cnt >= (jb - ja) / 4) break;
+        limit *= 3;
+      }
+      s_state = cnt ? 1 : 2;                               // 2: nothing under the limit, the region is passed over
+      if (cnt) { const float fl = sum / cnt; reg_noise[s_regs] = fl; reg_first[s_regs] = ia - 1; s_over = fl * ston; }
+    }
+    __syncthreads();
+    if (s_state == 1) {
+      const float over = s_over;
+      int f0 = N, f1 = -1;
+      for (int i = ia + tid; i < ib; i += LRH_SL_THREADS) if (A[i] > over) { if (i < f0) f0 = i; if (i > f1) f1 = i; B[i] = -1; a.wait[i] = wait_n; }
+      if (f1 >= 0) { atomicMin(&s_first, f0); atomicMax(&s_last, f1); }
+      __syncthreads();
+      if (tid == 0) {
+        int n = s_regs;
+        const float fl = reg_noise[n];
+        if (s_last < 0) reg_len[n++] = ib - ia + 1;
+        else {                                             // the quiet parts below the first and above the last bin taken out
+          reg_len[n++] = s_first - ia + 1;
+          if (ib - s_last > 4) { reg_noise[n] = fl; reg_first[n] = s_last + 1; reg_len[n] = ib - s_last; n++; }
+        }
+        if (n >= G - 2) {                                  // the list is nearly full (sellim.c:406-469)
+          float t1 = mean_noise(n, false) * ston;
+          for (int k = 0; k < n; k++)
+            if (reg_noise[k] > t1) {
+              for (int i = 0; i < G + 8 && i < reg_len[i]; i++) { const int b = i + reg_first[k]; if (b >= 0 && b < N) mark0(b); }   // entry i's own length ends it
+              drop(k, n);
+              n--;                                         // k moves on past the entry that slid into place
+            }
+          if (n >= 3 * G / 4) {
+            t1 /= ston;
+            while (n > 0) { if (reg_noise[0] < t1) drop(0, n); n--; }      // the count drops every pass (sellim.c:447-460)
+          }
+        }
+        s_regs = n;
+      }
+    }
+    if (tid == 0) s_ia = ib + 1;
+    __syncthreads();
+  }
+  const int regs0 = s_regs;
+  if (regs0 > 0) {
+    if (tid == 0) {
+      const float t1 = mean_noise(regs0, false) * ston;
+      int dropped = 0;
+      for (int k = 0; k < regs0; k++) if (reg_noise[k] > t1) { dropped = 1; reg_noise[k] = -1; }
+      s_state = dropped; s_over = t1;
+    }
+    __syncthreads();
+    if (s_state) {
+      for (int k = 0; k < regs0; k++)                      // a whole region above the common floor
+        if (reg_noise[k] < 0) for (int i = tid; i < reg_len[k]; i += LRH_SL_THREADS) { B[i + reg_first[k]] = -1; a.wait[i + reg_first[k]] = wait_n; }
+      __syncthreads();
+      if (tid == 0) {
+        float t1 = mean_noise(regs0, true);
+        int n = regs0;
+        for (int i = 0; i < n; i++) if (reg_noise[i] < 0) { drop(i, n); i--; n--; }
+        s_over = t1 * ston; s_regs = n;
+      }
+      __syncthreads();
+    }
+    const float t1 = s_over; const int n = s_regs;
+    for (int k = 0; k < n; k++)
+      for (int i = tid; i < reg_len[k]; i += LRH_SL_THREADS) { const int b = i + reg_first[k]; if (A[b] > t1) { B[b] = -1; a.wait[b] = wait_n; } }
+    __syncthreads();
+  }
+  for (int i = tid; i < N; i += LRH_SL_THREADS) a.tmp[i] = A[i];
+  for (int i = tid; i < G + 8; i += LRH_SL_THREADS) { a.reg_noise[i] = reg_noise[i]; a.reg_first[i] = reg_first[i]; a.reg_len[i] = reg_len[i]; }
+  sl_selfreq(a, B, tid);
+  __syncthreads();
+  for (int i = tid; i < N; i += LRH_SL_THREADS) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
+  sl_pack(a, B, tid);
+}
+
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
 {
   const bool big = a.n > 16384;
@@ -3604,8 +3825,35 @@ hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st)
   static bool once = false;
   if (!once) { hipFuncSetAttribute((const void *)k_sellim2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
                hipFuncSetAttribute((const void *)k_sellim2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); once = true; }
-  if (lds > 160 * 1024 - 64 || a.group_points < 16 || a.n > 32768 || (big && !a.big_b)) return hipErrorInvalidValue;
+  static bool once2 = false;
+  if (!once2) {
+    hipFuncSetAttribute((const void *)k_sellim2_median<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);   // 1 KiB of histogram is static
+    hipFuncSetAttribute((const void *)k_sellim2_median<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute((const void *)k_sellim2_regions<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    hipFuncSetAttribute((const void *)k_sellim2_regions<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (hipGetLastError() != hipSuccess) return hipErrorInvalidValue;
+    once2 = true;
+  }
+  if (a.group_points < 16 || a.n > 32768 || (big && !a.big_b)) return hipErrorInvalidValue;
   if (a.r0 < (big ? 0 : 1)) return hipErrorInvalidValue;
+  const int groups = a.n / a.group_points;
+  // the packing step's words sit behind the table in every variant (sl_pack)
+  if (a.par1 == 0) {
+    const size_t l0 = (big ? 64 : sizeof(float) * (size_t)(a.n + 8)) + sizeof(int) * ((a.n + 31) / 32 + 4);
+    if (a.n2 < a.n || a.n2 % a.n || l0 > 158 * 1024) return hipErrorInvalidValue;
+    if (big) hipLaunchKernelGGL(k_sellim2_median<true>, dim3(1), dim3(LRH_SL_THREADS), l0, st, a);
+    else hipLaunchKernelGGL(k_sellim2_median<false>, dim3(1), dim3(LRH_SL_THREADS), l0, st, a);
+    return hipGetLastError();
+  }
+  if (a.par1 == 1) {
+    const size_t l1 = sizeof(float) * (size_t)(8 + a.n + 16 + (big ? 0 : a.n + 8) + 3 * (groups + 8) + 2) + 8 * (size_t)((a.n + 63) / 64 + 1)
+                      + sizeof(int) * ((a.n + 31) / 32 + 4);
+    if (l1 > 160 * 1024 - 256 || !a.reg_noise || !a.reg_first || !a.reg_len) return hipErrorInvalidValue;
+    if (big) hipLaunchKernelGGL(k_sellim2_regions<true>, dim3(1), dim3(LRH_SL_THREADS), l1, st, a);
+    else hipLaunchKernelGGL(k_sellim2_regions<false>, dim3(1), dim3(LRH_SL_THREADS), l1, st, a);
+    return hipGetLastError();
+  }
+  if (lds > 160 * 1024 - 64) return hipErrorInvalidValue;
   if (big) hipLaunchKernelGGL(k_sellim2<true>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   else hipLaunchKernelGGL(k_sellim2<false>, dim3(1), dim3(LRH_SL_THREADS), lds, st, a);
   return hipGetLastError();

@@ -289,6 +289,8 @@ struct SellimArgs {
   const float *powersum2; float ston2, blocktime2; int wf_avgnum;
   int debug;                // LRH_SELLIM_DEBUG=1: thread 0 prints the phase times (100 MHz ticks)
   float *big_b, *big_g;     // fft1_size 32768: the table (n floats) and the group minima (n/4 + 8 floats) in global memory
+  int par1;                 // hg.sellim_par1 of fft2_update_liminfo: 2, 1 (k_sellim2_regions) or 0 (k_sellim2_median)
+  float *reg_noise; int *reg_first, *reg_len;   // par1 = 1: the region list, n / group_points + 8 entries each, kept between calls
 };
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st);
 hipError_t launch_sellim2(const SellimArgs &a, hipStream_t st);

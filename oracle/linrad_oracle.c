@@ -337,8 +337,8 @@ void lro_close(lro_ctx *c)
                 c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
-    struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; } *s = c->sellim;
-    free(s->old); free(s->wait); free(s->tmp - 8); free(s->group_min); free(s->ftmp - 8); free(s);
+    struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; float *rn; int *rf, *rl; } *s = c->sellim;
+    free(s->old); free(s->wait); free(s->tmp - 8); free(s->group_min); free(s->ftmp - 8); free(s->rn); free(s->rf); free(s->rl); free(s);
   }
   free(c);
 }
@@ -1820,7 +1820,8 @@ int lro_export_timf2_net(lro_ctx *c, float *dst, int timf2_pt, int count, float 
 #define LRO_BIGFLOAT 300000000000000000000000000000000000000.F
 #define LRO_RELEASE_FACTOR 1.15
 #define LRO_SFAC 2.
-typedef struct { float *old; unsigned char *wait; float *tmp, *group_min; int sumsq_tot, sel_ia, sel_ib; float *ftmp; } lro_sellim_state;
+typedef struct { float *old; unsigned char *wait; float *tmp, *group_min; int sumsq_tot, sel_ia, sel_ib; float *ftmp;
+                 float *reg_noise; int *reg_first, *reg_len; } lro_sellim_state;   /* reg_*: variant 1's region list, kept between calls like the reference's (buf.c:976-980) */
 static lro_sellim_state *sellim_state(lro_ctx *c)
 {
   if (!c->sellim) {                       /* allocated on first use, freed by lro_close */
@@ -1828,6 +1829,7 @@ static lro_sellim_state *sellim_state(lro_ctx *c)
     s->old = calloc(c->N1, 4); s->wait = calloc(c->N1, 1); s->group_min = calloc(c->N1 + 4, 4);
     s->tmp = (float *)calloc(c->N1 + 16, 4) + 8;      /* the reference's scans look two bins below and above their range */
     s->ftmp = (float *)calloc(c->N1 + 16, 4) + 8;     /* fftf_tmp of fft2_update_liminfo: zero outside what it fills (buf.c:972) */
+    s->reg_noise = calloc(c->N1 + 8, 4); s->reg_first = calloc(c->N1 + 8, sizeof(int)); s->reg_len = calloc(c->N1 + 8, sizeof(int));
     c->sellim = s;
   }
   return (lro_sellim_state *)c->sellim;
@@ -1900,11 +1902,160 @@ static void selfreq_liminfo(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *
 int lro_get_liminfo_amplitude_factor(lro_ctx *c, float *f) { if (!c || !f) return LRH_EINVAL; *f = c->amp_factor; return LRH_OK; }
 int lro_set_liminfo_amplitude_factor(lro_ctx *c, float f) { if (!c) return LRH_EINVAL; c->amp_factor = f; return LRH_OK; }
 
-/* fft2_update_liminfo, sellim.c:159-736, case hg.sellim_par1 = 2 (535-731) */
+/* hold-off count of the second limiter (sellim.c:207-209, 284-286, 536-538) */
+static unsigned sellim2_wait_n(const lro_ctx *c, const lrh_sellim *q)
+{
+  unsigned w = 1 + (1 + (q->fft2_blocktime * c->cfg.waterfall_avgnum)) / (c->cfg.fft_avg1num * q->fft1_blocktime);
+  return w > 255 ? 255 : w;
+}
+static void mark_strong(float *lim, unsigned char *wait, int i, unsigned wait_n) { lim[i] = -1; wait[i] = (unsigned char)wait_n; }
+
+/* hg.sellim_par1 = 0 (sellim.c:170-281): noise floor = the median of every fft2 bin's power (the reference sorts the lower half by
+   selection; any exact selection gives the same value), band edges where the spectrum stays below 2 % of it, and every fft1 bin with an
+   fft2 bin above blanker_ston_fft2 * median.  One channel (sw_onechan). */
+static int cmp_float(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return x < y ? -1 : x > y; }
+static void fft2_liminfo_median(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *q)
+{
+  const int N = c->N1, N2 = c->N2, nn = N2 / N;
+  float *lim = c->liminfo;
+  float *f = malloc(4 * (size_t)N2), *srt = malloc(4 * (size_t)N2);
+  for (int i = 0; i < N; i++) for (int j = nn * i; j < nn * i + nn; j++) f[j] = c->fft2_powersum[j] * c->wg_waterf_yfac[i];
+  memcpy(srt, f, 4 * (size_t)N2);
+  qsort(srt, N2, 4, cmp_float);
+  const float median = srt[N2 / 2 - 1];
+  const unsigned wait_n = sellim2_wait_n(c, q);
+  const float edge = median * 0.02F;
+  int ia = nn * q->fft1_first_point;
+  while (ia < N2 - 1 && f[ia] < edge) ia++;                       /* (the reference's scan has no end: a spectrum entirely below the limit is not a case) */
+  int first = (ia + nn / 2) / nn;
+  int ib = (nn + 1) * q->fft1_last_point;                          /* as written (sellim.c:239) */
+  if (ib > N2) ib = N2;
+  while (ib > 1 && f[ib - 1] < edge) ib--;
+  int last = (ib + nn / 2) / nn;
+  if (first < 5) first = 5;
+  if (last > N - 6) last = N - 6;
+  for (int i = 0; i < first; i++) mark_strong(lim, st->wait, i, wait_n);
+  for (int i = last; i < N; i++) mark_strong(lim, st->wait, i, wait_n);
+  const float limit = q->blanker_ston_fft2 * median;
+  for (int i = first; i < last; i++) {
+    int k = 0;
+    for (int j = nn * i; j < nn * i + nn; j++) if (f[j] > limit) k++;
+    if (k > 0) mark_strong(lim, st->wait, i, wait_n);
+  }
+  free(f); free(srt);
+}
+
+/* hg.sellim_par1 = 1 (sellim.c:283-533): every stretch of six or more bins that are not attenuated (liminfo <= 0) between attenuated
+   carriers is a weak-signal region with a noise floor of its own; the list of regions (noise, first point, length) lives between calls
+   like the reference's arrays, and the two clean-up loops that run when the list is nearly full keep the reference's indexing
+   (sellim.c:424: the length of entry i bounds the loop over i; sellim.c:447-460: the count drops every pass). */
+static void region_list_drop(lro_sellim_state *st, int k, int n)
+{
+  for (int j = k + 1; j < n; j++) { st->reg_noise[j - 1] = st->reg_noise[j]; st->reg_first[j - 1] = st->reg_first[j]; st->reg_len[j - 1] = st->reg_len[j]; }
+}
+static float region_mean_noise(const lro_sellim_state *st, int n, int skip_negative)
+{
+  int k = 0; float t = 0;
+  for (int i = 0; i < n; i++) { if (skip_negative && st->reg_noise[i] < 0) continue; k += st->reg_len[i]; t += st->reg_noise[i] * st->reg_len[i]; }
+  return t / k;
+}
+static void fft2_liminfo_regions(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *q)
+{
+  const int N = c->N1, nn = c->N2 / N, G = N / q->liminfo_group_points, last = q->fft1_last_point;
+  const int in_lo = q->fft1_first_inband, in_hi = q->fft1_last_inband;
+  float *lim = c->liminfo, *f = st->ftmp;
+  const unsigned wait_n = sellim2_wait_n(c, q);
+  const float ston = q->blanker_ston_fft2;
+  int reg_no = 0, ia = q->fft1_first_point;
+  for (;;) {
+    while (lim[ia] > 0 && ia < last) ia++;
+    if (ia == last) break;
+    int ib = ia;
+    while (lim[ib] <= 0 && ib < last) ib++;
+    if (ib - ia < 6) { ia = ib; continue; }                         /* too short to tell anything (sellim.c:297-300: ib--, then ia = ib + 1) */
+    ia++; ib--;                                                      /* the blanker's own noise next to the carriers stays out */
+    float lowest = LRO_BIGFLOAT;
+    for (int i = ia; i < ib; i++) {
+      float t = 0;
+      for (int j = nn * i; j < nn * i + nn; j++) t += c->fft2_powersum[j];
+      t *= c->wg_waterf_yfac[i];
+      f[i] = t;
+      if (t < lowest && i >= in_lo && i <= in_hi) lowest = t;
+    }
+    f[ia - 1] = f[ia]; f[ib] = f[ib - 1];
+    float limit = lowest;
+    limit *= 2 * (1 + 2. / c->cfg.waterfall_avgnum);
+    int ja = ia < in_lo ? in_lo : ia, jb = ib > in_hi ? in_hi + 1 : ib;
+    float sum = 0; int cnt = 0;                                      /* not cleared when the limit is widened (sellim.c:356-371) */
+    for (;;) {
+      for (int i = ja; i < jb; i++) if (f[i] < limit) { cnt++; sum += f[i]; }
+      if (cnt == 0 || cnt >= (jb - ja) / 4) break;
+      limit *= 3;
+    }
+    if (cnt != 0) {
+      const float floor_ = sum / cnt;
+      st->reg_noise[reg_no] = floor_; st->reg_first[reg_no] = ia - 1;
+      const float over = floor_ * ston;
+      int ja2 = -1, jb2 = 0;
+      for (int i = ia; i < ib; i++) if (f[i] > over) { if (ja2 < 0) ja2 = i; jb2 = i; mark_strong(lim, st->wait, i, wait_n); }
+      if (ja2 < 0) st->reg_len[reg_no++] = ib - ia + 1;
+      else {                                                         /* the quiet parts below the first and above the last bin taken out */
+        st->reg_len[reg_no++] = ja2 - ia + 1;
+        if (ib - jb2 > 4) { st->reg_noise[reg_no] = floor_; st->reg_first[reg_no] = jb2 + 1; st->reg_len[reg_no] = ib - jb2; reg_no++; }
+      }
+      if (reg_no >= G - 2) {                                         /* the list is nearly full: sellim.c:406-469 */
+        float t1 = region_mean_noise(st, reg_no, 0) * ston;
+        for (int k = 0; k < reg_no; k++)
+          if (st->reg_noise[k] > t1) {
+            for (int i = 0; i < G + 8 && i < st->reg_len[i]; i++) {  /* entry i's own length ends the loop (sellim.c:424); the list has G entries (+8 here) */
+              const int b = i + st->reg_first[k];
+              if (b >= 0 && b < N) mark_strong(lim, st->wait, b, wait_n);
+            }
+            region_list_drop(st, k, reg_no);
+            reg_no--;                                                /* and k moves on: the entry that slid into place is not looked at */
+          }
+        if (reg_no >= 3 * G / 4) {
+          t1 /= ston;
+          while (reg_no > 0) {                                       /* sellim.c:447-460: k stays at 0 and the count drops every pass */
+            if (st->reg_noise[0] < t1) region_list_drop(st, 0, reg_no);
+            reg_no--;
+          }
+        }
+      }
+    }
+    ia = ib + 1;
+  }
+  if (reg_no == 0) return;
+  float t1 = region_mean_noise(st, reg_no, 0) * ston;
+  int dropped = 0;
+  for (int k = 0; k < reg_no; k++)
+    if (st->reg_noise[k] > t1) {                                     /* a whole region above the common floor */
+      dropped = 1;
+      for (int i = 0; i < st->reg_len[k]; i++) mark_strong(lim, st->wait, i + st->reg_first[k], wait_n);
+      st->reg_noise[k] = -1;
+    }
+  if (dropped) {
+    t1 = region_mean_noise(st, reg_no, 1);                           /* sum and count taken before the list is compacted: same numbers */
+    for (int i = 0; i < reg_no; i++) if (st->reg_noise[i] < 0) { region_list_drop(st, i, reg_no); i--; reg_no--; }
+    t1 *= ston;
+  }
+  for (int k = 0; k < reg_no; k++)
+    for (int i = 0; i < st->reg_len[k]; i++) if (f[i + st->reg_first[k]] > t1) mark_strong(lim, st->wait, i + st->reg_first[k], wait_n);
+}
+
+/* fft2_update_liminfo, sellim.c:159-736: hg.sellim_par1 = 2 (535-731) below, 0 and 1 above */
 int lro_fft2_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 {
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return LRH_EINVAL;
+  if (q->sellim_par1 < 0 || q->sellim_par1 > 2) return LRH_EINVAL;
+  if (q->sellim_par1 != 2) {
+    if (q->liminfo_group_points < 1 || c->N2 < c->N1) return LRH_EINVAL;
+    lro_sellim_state *s = sellim_state(c);
+    if (q->sellim_par1 == 0) fft2_liminfo_median(c, s, q); else fft2_liminfo_regions(c, s, q);
+    selfreq_liminfo(c, s, q);
+    return LRH_OK;
+  }
   const int N = c->N1, nn = c->N2 / c->N1, gp = q->liminfo_group_points;
   if (nn < 1 || gp < 1 || N / gp < 1) return LRH_EINVAL;
   lro_sellim_state *st = sellim_state(c);

@@ -401,6 +401,7 @@ int main(int argc, char **argv)
     liminfo_groups = groups;                       /* buf.c:816-820, 972-978 */
     fftf_tmp = zalloc(sizeof(float) * ((size_t)N2 + N1 + 64));
     reg_noise = zalloc(sizeof(float) * (groups + 8)); reg_min = zalloc(sizeof(float) * (groups + 8)); reg_ston = zalloc(sizeof(float) * (groups + 8));
+    reg_first_point = zalloc(sizeof(int) * (groups + 8)); reg_length = zalloc(sizeof(int) * (groups + 8));   /* buf.c:979-980 (variant 1) */
   }
   make_permute(0, n1, N1, fft1_back_scramble);
   if (fft_cntrl[FFT1_CURMODE].permute == 2) { fft1_backtab = zalloc(sizeof(COSIN_TABLE) * N1); make_sincos(0, N1, fft1_backtab); }   /* buf.c:1318-1326 */
@@ -428,7 +429,7 @@ int main(int argc, char **argv)
   hg.stupid_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.stupid_bln_factor);
   hg.clever_bln_limit = (unsigned int)((float)timf2_noise_floor * hg.clever_bln_factor);
   hg.timf2_oscilloscope = 0;
-  hg.sellim_par1 = 2; hg.sellim_par2 = AI("par2", 0); hg.sellim_par3 = AI("par3", 0); hg.sellim_par4 = AI("par4", 0);
+  hg.sellim_par1 = AI("par1", 2); hg.sellim_par2 = AI("par2", 0); hg.sellim_par3 = AI("par3", 0); hg.sellim_par4 = AI("par4", 0);
   hg.sellim_par5 = AI("par5", 0); hg.sellim_par6 = AI("par6", 0); hg.sellim_par7 = AI("par7", 0); hg.sellim_par8 = AI("par8", 0);
   hg.blanker_ston_fft1 = (float)AF("ston_fft1", 4.0); hg.blanker_ston_fft2 = (float)AF("ston_fft2", 30.0);
   blnfit_range = fitrange; blanker_pulsewidth = pulsewidth;
@@ -846,6 +847,7 @@ int main(int argc, char **argv)
     if (sellim2) {
       PUTF("liminfo_trace2", limtrace2, (size_t)N1 * (nlimupd2 > 0 ? nlimupd2 : 1)); PUTI("liminfo_trace2_blk", limtrace2_blk, nlimupd2 > 0 ? nlimupd2 : 1);
       float s2[4] = { hg.blanker_ston_fft2, fft2_blocktime, (float)wg.waterfall_avgnum, (float)nlimupd2 }; PUTF("sellim2_fparams", s2, 4);
+      if (hg.sellim_par1 != 2) { int v1[1] = { hg.sellim_par1 }; PUTI("sellim2_par1", v1, 1); }
     }
   }
   if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2); }

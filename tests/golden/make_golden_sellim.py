@@ -20,7 +20,7 @@ from refdump import load_dump  # noqa: E402
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["liminfo_trace", "liminfo_trace_blk", "sellim_params", "sellim_fparams", "liminfo_final", "fft1_sumsq", "fft1_slowsum",
         "timf2_float", "timf2_pwr_float", "fft2_powersum_float", "timf3_float", "itrace", "trace", "final", "wg_waterf_yfac",
-        "amp_factor_trace", "liminfo_trace2", "liminfo_trace2_blk", "sellim2_fparams"]
+        "amp_factor_trace", "liminfo_trace2", "liminfo_trace2_blk", "sellim2_fparams", "sellim2_par1"]
 
 
 def main():

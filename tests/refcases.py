@@ -324,12 +324,21 @@ SELLIM["sellim2_n9_n11_pars"] = dict(base="n9_n11_shift", nblk=160, maxlevel=400
                                      strong=[(101.0, 6000.0)], weak=[(150.5, 45.0), (60.0, 400.0)], sellim2=1, ston_fft2=8.0, wf_avgnum=3)
 
 
+# the second limiter's older variants (hg.sellim_par1 = 0: median of all fft2 bins, sellim.c:170-281; 1: noise floor per weak-signal
+# region, sellim.c:283-533); the third case puts more strong carriers into the band than there is room for regions (sellim.c:406-469)
+SELLIM["sellim2v0_n10_n12"] = dict(SELLIM["sellim2_n10_n12"], par1=0, ston_fft2=40.0)
+SELLIM["sellim2v1_n10_n12"] = dict(SELLIM["sellim2_n10_n12"], par1=1, ston_fft2=20.0)
+SELLIM["sellim2v1_n9_n11_many"] = dict(base="n9_n11_shift", nblk=160, maxlevel=1500, lim_groups=16, blocktime=0.002, ston_fft1=3.0, bw_fftxpts=24,
+                                       sample_shift=0, keyed=(-77.0, 2500.0, 40, 90), sellim2=1, par1=1, ston_fft2=12.0, wf_avgnum=3,
+                                       strong=[(-200.0 + 37.0 * i, 2400.0 + 20.0 * i) for i in range(11)], weak=[(150.5, 45.0), (60.0, 400.0)])
+
+
 def sellim_case(name):
     """params + input of a selective-limiter case: the base case's signal plus a carrier keyed on for blocks [on, off)"""
     t = dict(SELLIM[name])
     d = case_params(t.pop("base"))
     keyed = t.pop("keyed")
-    sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par2", "par3", "par4", "par5", "par6", "par7", "par8",
+    sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par1", "par2", "par3", "par4", "par5", "par6", "par7", "par8",
                                                  "sellim2", "ston_fft2")}
     d.update(t)
     iq = make_input(d).astype(np.float64)

@@ -23,7 +23,8 @@ def sellim_params(cfg, g):
                           fft1_last_inband=int(sp[7]), baseband_bw_fftxpts=int(sp[8]), sellim_par2=int(sp[9]), sellim_par3=int(sp[10]),
                           sellim_par4=int(sp[11]), sellim_par5=int(sp[12]), sellim_par6=int(sp[13]), sellim_par7=int(sp[14]),
                           sellim_par8=int(sp[15]), fft1_blocktime=float(sf[0]), blanker_ston_fft1=float(sf[1]), exact_stats=1,
-                          **({"blanker_ston_fft2": float(g["sellim2_fparams"][0]), "fft2_blocktime": float(g["sellim2_fparams"][1])} if "sellim2_fparams" in g else {}))
+                          **({"blanker_ston_fft2": float(g["sellim2_fparams"][0]), "fft2_blocktime": float(g["sellim2_fparams"][1])} if "sellim2_fparams" in g else {}),
+                          **({"sellim_par1": int(g["sellim2_par1"][0])} if "sellim2_par1" in g else {}))
 
 
 def run(open_fn, name, g):

@@ -78,8 +78,8 @@ def test_hip_wideband_dsp_makes_the_limiter_calls_itself(pipeline, monkeypatch):
         assert err < 1e-5 and np.count_nonzero(h["lim"]) > 50, (err, fft2_too)
 
 
-@pytest.mark.parametrize("fft1_n,fft2_n", [(14, 16), (15, 17)])
-def test_fullsize_limiters_match_oracle(fft1_n, fft2_n):
+@pytest.mark.parametrize("fft1_n,fft2_n,par1", [(14, 16, 2), (15, 17, 2), (14, 16, 1), (15, 17, 1), (14, 16, 0), (15, 17, 0)])
+def test_fullsize_limiters_match_oracle(fft1_n, fft2_n, par1):
     """fft1_size 16384 / fft2_size 65536 (BASELINE sizes; the limiter kernels' LDS layout, bit words and group loops at their real
     extent) and fft1_size 32768 / fft2_size 131072 (the reference's maximum: table and group minima in global memory, dense routing
     bits for the four-step make_timf2): both limiters inside lrh_wideband_dsp on the bench's synthetic signal, HIP against the oracle
@@ -99,7 +99,8 @@ def test_fullsize_limiters_match_oracle(fft1_n, fft2_n):
         rx = fn(cfg)
         rx.timf1_write(iq)
         rx.set_mix1_selfreq(0.31 * (1 << fft2_n) + 0.3)
-        par = default_sellim(cfg, fft1_blocktime=(n1 // 2) / 160e6, blanker_ston_fft1=30.0, blanker_ston_fft2=30.0, fft2_blocktime=(1 << fft2_n) / 2 / 160e6, exact_stats=1)
+        par = default_sellim(cfg, fft1_blocktime=(n1 // 2) / 160e6, blanker_ston_fft1=30.0, blanker_ston_fft2=30.0, fft2_blocktime=(1 << fft2_n) / 2 / 160e6, exact_stats=1,
+                             sellim_par1=par1)      # hg.sellim_par1: the second limiter's three variants (sellim.c:169, 283, 535)
         rx.wideband_limiter(par, True)
         rx.wideband_dsp(nblk, batch)
         res.append(dict(lim=rx.get_liminfo(), amp=rx.liminfo_amplitude_factor(), p=rx.p.as_dict(), timf2=rx.export(abi.RING_TIMF2_FLOAT),
