@@ -28,7 +28,8 @@ extern "C" {
 
 #define LRH_ABI_VERSION 3      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
                                   3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
-                                     lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions only) */
+                                     lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions); lrh_exchange_fn takes the caller's own span;
+                                     lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart) */
 
 enum {
   LRH_OK = 0,
