@@ -327,7 +327,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         # impulses whose spectrum ripples across the band at 36 x the noise power; 30 keeps that ripple with the weak signal (51 bins
         # routed strong: the carriers and their skirts), the 4 of a quiet band would route 38 % of the bins
         sel = default_sellim(cfg, fft1_blocktime=M1 / 160e6, blanker_ston_fft1=30.0, exact_stats=0,
-                             blanker_ston_fft2=30.0, fft2_blocktime=(N2 // 2) / 160e6)
+                             blanker_ston_fft2=30.0, fft2_blocktime=(N2 // 2) / 160e6, sellim_par1=args.limiter2_par1)
         # inside lrh_wideband_dsp, at the end of every round: wideband_dsp's own limiter calls (wcw.c:1124-1133), once per pass of the loop
         rx.wideband_limiter(sel, args.limiter2)
 
@@ -416,7 +416,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
            "samples_per_step": samples_per_step, "workload": workload_name(w, args.batch),
            "routing": ("selective limiter on the device at the end of every round inside lrh_wideband_dsp (lrh_wideband_limiter: fft1_update_liminfo%s, "
                        "wcw.c:1124-1133), strong bins now %d of %d" %
-                       (" + fft2_update_liminfo" if args.limiter2 else "", int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",
+                       (" + fft2_update_liminfo (sellim_par1 = %d)" % args.limiter2_par1 if args.limiter2 else "", int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",
            "config_text": w["text"].format(N1=N1, N2=N2, Nm=N2 >> 6, N3=(1 << w["fft3_n"]) if w["fft3_n"] else 0,
                                            Nm2=(1 << w["mix2_n"]) if w["mix2_n"] else 0, rounds=args.rounds, batch=args.batch,
                                            samples=samples_per_step, world=world)}
@@ -585,6 +585,8 @@ def main():
                     help="keep the hand-made routing table instead of running the selective limiter (lrh_fft1_update_liminfo) once per step")
     ap.add_argument("--limiter2", action="store_true",
                     help="also run the second limiter (fft2_update_liminfo) at the end of every round; lrh_wideband_dsp then leaves its one-round-late schedule")
+    ap.add_argument("--limiter2-par1", type=int, default=2, choices=(0, 1, 2),
+                    help="with --limiter2: hg.sellim_par1, the second limiter's variant (2 = the reference's setting)")
     ap.add_argument("--stream-host", action="store_true",
                     help="PCIe-inclusive variant (never the headline value): every step first hands its samples over from "
                          "page-locked host memory with lrh_timf1_write_async, overlapped with the previous step's kernels")

@@ -3662,6 +3662,9 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
   unsigned long long *carrier = (unsigned long long *)(reg_len + G + 8 + ((G & 1) ? 1 : 0));      // bit i: liminfo[i] > 0
   __shared__ int s_ia, s_ib, s_state, s_regs, s_first, s_last; __shared__ unsigned s_low; __shared__ float s_over;
   const int nwords = (N + 63) / 64;
+  long long tph[6] = { 0, 0, 0, 0, 0, 0 }, tlast = 0; int nreg_dbg = 0;             // LRH_SELLIM_DEBUG: 100 MHz ticks per phase
+  auto phase = [&](int k) { if (a.debug && tid == 0) { const long long t = wall_clock64(); if (k >= 0) tph[k] += t - tlast; tlast = t; } };
+  phase(-1);
   for (int i = tid; i < N; i += LRH_SL_THREADS) { A[i] = a.tmp[i]; B[i] = a.liminfo[i]; }
   for (int i = tid; i < 8; i += LRH_SL_THREADS) { A[-8 + i] = 0.f; A[N + i] = 0.f; A[N + 8 + i] = 0.f; }
   for (int i = tid; i < G + 8; i += LRH_SL_THREADS) { reg_noise[i] = a.reg_noise[i]; reg_first[i] = a.reg_first[i]; reg_len[i] = a.reg_len[i]; }
@@ -3693,6 +3696,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
   };
   if (tid == 0) { s_ia = a.first_point; s_regs = 0; }
   __syncthreads();
+  phase(0);
   for (;;) {
     if (tid == 0) {                                       // the next region of six bins or more, or the end of the band
       int ia = s_ia, ib = 0, state = 0;
@@ -3706,7 +3710,9 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
       s_state = state; s_ia = ia + 1; s_ib = ib - 1; s_low = __float_as_uint(LRH_SL_BIG); s_first = N; s_last = -1;
     }
     __syncthreads();
+    phase(1);
     if (!s_state) break;
+    nreg_dbg++;
     const int ia = s_ia, ib = s_ib;
     {
       float lowest = LRH_SL_BIG;
@@ -3720,22 +3726,41 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
       if (lowest < LRH_SL_BIG) atomicMin(&s_low, __float_as_uint(lowest < 0 ? 0.f : lowest));     // powers: the bit patterns order like the values
     }
     __syncthreads();
-    if (tid == 0) {
-      A[ia - 1] = A[ia]; A[ib] = A[ib - 1];
+    phase(2);
+    if (tid < 64) {
+      // the bins under the limit, added in index order: a float sum that decides a threshold, so the order is part of the result.  One
+      // wave: the lanes load and test 64 bins at once, the sum then takes them lane by lane (x + 0 = x leaves it as it was)
+      if (tid == 0) { A[ia - 1] = A[ia]; A[ib] = A[ib - 1]; }
       float limit = __uint_as_float(s_low);
       limit *= 2 * (1 + 2. / a.wf_avgnum);
       const int ja = ia < a.first_inband ? a.first_inband : ia, jb = ib > a.last_inband ? a.last_inband + 1 : ib;
       float sum = 0; int cnt = 0;                          // not cleared when the limit is widened (sellim.c:356-371)
       for (;;) {
-#pragma unroll 8
-        for (int i = ja; i < jb; i++) { const float v = A[i]; if (v < limit) { cnt++; sum += v; } }
+        for (int base = ja; base < jb; base += 64) {
+          const int i = base + tid;
+          const float v = i < jb ? A[i] : LRH_SL_BIG;
+          const bool in = i < jb && v < limit;
+          const unsigned long long m = __ballot(in);
+          if (!m) continue;
+          cnt += __popcll(m);
+          const int mv = __float_as_int(in ? v : 0.f);
+          if (__popcll(m) < 20) {                            // few: only those
+            for (unsigned long long r = m; r; r &= r - 1) sum += __int_as_float(__builtin_amdgcn_readlane(mv, __ffsll((long long)r) - 1));
+          } else {
+#pragma unroll
+            for (int l = 0; l < 64; l++) sum += __int_as_float(__builtin_amdgcn_readlane(mv, l));
+          }
+        }
         if (cnt == 0 || cnt >= (jb - ja) / 4) break;
         limit *= 3;
       }
-      s_state = cnt ? 1 : 2;                               // 2: nothing under the limit, the region is passed over
-      if (cnt) { const float fl = sum / cnt; reg_noise[s_regs] = fl; reg_first[s_regs] = ia - 1; s_over = fl * ston; }
+      if (tid == 0) {
+        s_state = cnt ? 1 : 2;                             // 2: nothing under the limit, the region is passed over
+        if (cnt) { const float fl = sum / cnt; reg_noise[s_regs] = fl; reg_first[s_regs] = ia - 1; s_over = fl * ston; }
+      }
     }
     __syncthreads();
+    phase(3);
     if (s_state == 1) {
       const float over = s_over;
       int f0 = N, f1 = -1;
@@ -3768,6 +3793,7 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
     }
     if (tid == 0) s_ia = ib + 1;
     __syncthreads();
+    phase(4);
   }
   const int regs0 = s_regs;
   if (regs0 > 0) {
@@ -3801,6 +3827,10 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim2_regions(SellimArgs a
   __syncthreads();
   for (int i = tid; i < N; i += LRH_SL_THREADS) { a.old_liminfo[i] = B[i]; a.liminfo[i] = B[i]; }
   sl_pack(a, B, tid);
+  phase(5);
+  if (a.debug && tid == 0)
+    printf("k_sellim2_regions ticks (10 ns): %lld %lld %lld %lld %lld %lld  [load, walk, bin power, ordered sum, mark + list, tail]; %d regions, %d listed\n",
+           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], nreg_dbg, regs0);
 }
 
 hipError_t launch_sellim(const SellimArgs &a, hipStream_t st)
