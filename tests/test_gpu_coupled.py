@@ -77,8 +77,10 @@ def test_gather_exchange_and_batched_cross_products():
         dist.destroy_process_group()
 
 
-def test_coupled_wideband_dsp_equals_the_stage_calls():
-    """lrh_wideband_dsp with cfg.blanker_channels = 2 and the exchange function registered (lrh_set_exchange): one call enqueues what
+@pytest.mark.parametrize("batch,nblk,calls,fuse", [(32, 128, 3, "0"), (4096, 8192, 1, "0")])
+def test_coupled_wideband_dsp_equals_the_stage_calls(batch, nblk, calls, fuse):
+    """(second case: the call shape bench.py --coupled times -- 2 x 4096 blocks, sparse rings)
+    lrh_wideband_dsp with cfg.blanker_channels = 2 and the exchange function registered (lrh_set_exchange): one call enqueues what
     multichan.run_coupled does with stage calls and collectives in between -- same rings to float32 rounding (one-rank group: the collectives
     have nobody to talk to, the sequencing and the fused kernels are what is compared), at the sizes of BASELINE configs[3]"""
     import torch
@@ -93,9 +95,12 @@ def test_coupled_wideband_dsp_equals_the_stage_calls():
         dev = torch.device("cuda:0")
         res = []
         for entry in ("dsp", "stages"):
-            os.environ["LRH_FUSE_FFT1"] = "0"
-            cfg = chain_config(14, 12, batch=32, fft3_n=10, mix2_n=8, rounds=4)
+            if fuse is not None:
+                os.environ["LRH_FUSE_FFT1"] = fuse
+            cfg = chain_config(14, 12, batch=batch, fft3_n=10, mix2_n=8, rounds=max(2, nblk // batch))
             cfg.blanker_channels, cfg.timf1_channel_index = 2, 0
+            if batch >= 4096:
+                cfg.fft1_float_sparse = cfg.fft2_float_sparse = 1
             rx = open_hip(cfg)
             os.environ.pop("LRH_FUSE_FFT1", None)
             sy = synth_defaults(1 << 14, 0)
@@ -105,14 +110,16 @@ def test_coupled_wideband_dsp_equals_the_stage_calls():
             rx.set_pol(0.8, 0.36, -0.48)
             if entry == "dsp":
                 install_exchange(rx, dist, dev)
-                for _ in range(3):
-                    rx.wideband_dsp(128, 32)
+                for _ in range(calls):
+                    rx.wideband_dsp(nblk, batch)
             else:
-                for _ in range(3):
-                    run_coupled(rx, 128, 32, dist, device=dev, xy=True, pol=True)
+                for _ in range(calls):
+                    run_coupled(rx, nblk, batch, dist, device=dev, xy=True, pol=True)
             bs = rx.blanker_state()
-            res.append(([rx.export(r) for r in (abi.RING_FFT1_SUMSQ, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT, abi.RING_FFT2_XYSUM,
-                                                abi.RING_WG_WATERF, abi.RING_TIMF3_FLOAT, abi.RING_BASEB_RAW)], rx.p.as_dict(), (bs.timf2_noise_floor, bs.stupid_bln_limit)))
+            big = batch >= 4096                             # sparse rings there: the full-length ones stand in as zeros of the same shape
+            res.append(([np.zeros(1, np.float32) if (big and r in (abi.RING_TIMF2_FLOAT, abi.RING_FFT2_FLOAT)) else rx.export(r)
+                         for r in (abi.RING_FFT1_SUMSQ, abi.RING_TIMF2_FLOAT, abi.RING_TIMF2_PWR, abi.RING_FFT2_FLOAT, abi.RING_FFT2_XYSUM,
+                                   abi.RING_WG_WATERF, abi.RING_TIMF3_FLOAT, abi.RING_BASEB_RAW)], rx.p.as_dict(), (bs.timf2_noise_floor, bs.stupid_bln_limit)))
             rx.close()
         assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
         # (k_fft1w is switched off for this comparison, LRH_FUSE_FFT1=0 below: its spectra differ from k_fft1's in the last bit, and a blanker
