@@ -137,3 +137,70 @@ def test_fullsize_clever_blanker_matches_oracle(monkeypatch, deferred):
                 flips=int(len(flips)), timf3_blocks_compared=int(ok3.sum()), timf3_blocks=int(ntr))
     print(errs)
     assert errs["timf2"] < 1e-5 and errs["timf3"] < 1e-5 and errs["pwr"] < 1e-4
+
+
+def test_bench_shape_clever_blanker_matches_oracle():
+    """The linear blanker at the call size bench.py --clever times: one call of 4096 fft1 blocks (33.5 M samples, 2000 calibrated pulses
+    among them) after a 64-block call that leaves both sides the same noise floor and limits; the search rides the one-round-late
+    schedule (it is issued when the round is flushed).  HIP against the oracle: resume pointers, fitted / rejected pulses, limits, and the
+    timf2 ring to the north-star tolerance outside the few samples within float32 rounding of the stupid limit."""
+    from linrad_amd import abi
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config, strong_liminfo
+    from oracle_binding import open_oracle
+    from refcases import clever_desired
+    g = cleverlib.load("clever_n10_n12")
+    N1, batch, warm = 16384, 4096, 64
+    cfg = chain_config(14, 16, batch=batch, fft3_n=12, mix2_n=8, rounds=2)
+    cfg.blanker_pulsewidth, cfg.blnfit_range = int(g["bln_ints"][1]), int(g["bln_ints"][3])
+    s = synth_defaults(N1, 0)
+    s.pulse_period = 0
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4).astype(np.float32)
+    n = iq.size // 2
+    rng = np.random.default_rng(78)
+    des = clever_desired(14, 0.18).astype(np.float64)
+    spec, k, H = np.fft.ifftshift(des), np.fft.fftfreq(N1), 256
+    norm = np.abs(np.fft.ifft(spec)[0])
+    hi = min(n, (warm + batch + 2) * N1 // 2) - 4 * N1
+    for pos in np.sort(rng.choice(np.arange(4 * N1, hi, 64), 2000, replace=False)):
+        h = np.fft.ifft(spec * np.exp(-2j * np.pi * k * (rng.uniform(-0.5, 0.5) + H)))[:2 * H] / norm
+        z = np.exp(rng.uniform(np.log(2500.0), np.log(22000.0))) * np.exp(1j * rng.uniform(0, 6.28)) * h
+        iq[2 * (pos - H):2 * (pos + H):2] += z.real.astype(np.float32)
+        iq[2 * (pos - H) + 1:2 * (pos + H) + 1:2] += z.imag.astype(np.float32)
+    iq = np.clip(np.round(iq), -32767, 32767).astype(np.int16)
+    lim = strong_liminfo(s, 14)
+    res = []
+    for fn, sparse in ((open_hip, 1), (open_oracle, 0)):
+        cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_liminfo(lim)
+        rx.set_mix1_selfreq(0.31 * 65536 + 0.3)
+        rx.wideband_dsp(warm, warm)
+        first = rx.blanker_state()
+        cleverlib.install_tables(rx, g, first.timf2_noise_floor)
+        rx.wideband_dsp(batch, batch)
+        bs = rx.blanker_state()
+        res.append(dict(p=rx.p.as_dict(), bs=bs, first=first, timf2=rx.export(abi.RING_TIMF2_FLOAT), pwr=rx.export(abi.RING_TIMF2_PWR)))
+        rx.close()
+    h, o = res
+    print("fitted / rejected", (h["bs"].last_call_fitted, h["bs"].last_call_rejected), (o["bs"].last_call_fitted, o["bs"].last_call_rejected),
+          "one-wave replays", h["bs"].clever_serial_calls, "slow-path calls", h["bs"].slow_path_calls)
+    ints = [kk for kk, v in h["p"].items() if isinstance(v, int)]
+    assert {kk: h["p"][kk] for kk in ints} == {kk: o["p"][kk] for kk in ints}
+    assert h["first"].timf2_noise_floor == o["first"].timf2_noise_floor and h["first"].stupid_bln_limit == o["first"].stupid_bln_limit
+    assert o["bs"].last_call_fitted > 500
+    assert h["bs"].last_call_fitted == o["bs"].last_call_fitted and h["bs"].last_call_rejected == o["bs"].last_call_rejected
+    assert h["bs"].timf2_fitted_pulses == o["bs"].timf2_fitted_pulses
+    keep = np.ones(h["timf2"].size, bool)
+    keep[(h["p"]["timf2_pa"] + np.arange(4 * (N1 // 2))) % keep.size] = False
+    limit = float(o["first"].stupid_bln_limit)               # in force during the big call (the ring holds nothing older)
+    flips = np.nonzero(((h["pwr"] == 0) != (o["pwr"] == 0)) & keep[::4])[0]
+    margin = [abs(max(float(h["pwr"][i]), float(o["pwr"][i])) - limit) / limit for i in flips]
+    print("flips", len(flips), "largest margin", max(margin, default=0.0))
+    assert len(flips) <= 2 * (o["pwr"].size // 400000 + 1) and all(m <= 1e-4 for m in margin)
+    for i in flips:
+        keep[4 * i:4 * i + 4] = False
+    err = float(np.linalg.norm((h["timf2"].astype(np.float64) - o["timf2"]) * keep) / np.linalg.norm(o["timf2"] * keep))
+    print("timf2", err)
+    assert err < 1e-5
