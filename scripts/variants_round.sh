@@ -15,6 +15,8 @@ run coupled --coupled --no-secondary
 run coupled_stages --coupled --coupled-stages --no-secondary
 run spurs8 --spurs 8 --no-secondary --steps 5
 run limiter2 --limiter2 --no-secondary
+run limiter2_par1_1 --limiter2 --limiter2-par1 1 --no-secondary
+run limiter2_par1_0 --limiter2 --limiter2-par1 0 --no-secondary
 run streamhost --stream-host --rounds 1 --no-secondary
 run realinput --real-input --no-secondary
 run n15 --fft1-n 15 --fft2-n 17 --batch 2048 --no-secondary
