@@ -20,7 +20,7 @@ run limiter2_par1_0 --limiter2 --limiter2-par1 0 --no-secondary
 run streamhost --stream-host --rounds 1 --no-secondary
 run realinput --real-input --no-secondary
 run n15 --fft1-n 15 --fft2-n 17 --batch 2048 --no-secondary
-run one_round_per_call --rounds 1 --no-secondary
+run one_round_per_call --rounds 1 --no-secondary --steps 80 --warmup 8   # (a later --steps wins; ten one-round steps would time the pipeline's fill and drain)
 for v in clever coupled; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$v -- python3 bench.py --$v --no-cpu --no-secondary --steps 5 --warmup 3 > $OUT/var/${v}_stats.json 2> $OUT/var/${v}_stats.log
   f=$(find $OUT/stats_$v -name "*kernel_stats.csv" | head -1)

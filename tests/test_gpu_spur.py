@@ -60,3 +60,46 @@ def test_hip_spur_acquisition_refuses_noise():
     rx = out["api"]
     assert not rx.spur_acquire(700)
     assert len(rx.spur_get()) == 1
+
+
+def test_bench_shape_spur_tracking_equals_rounds_of_256_blocks(monkeypatch):
+    """The call bench.py --spurs 8 times (4096 fft1 blocks = 1024 transforms of 65536 points per round, eight carriers acquired on the device
+    after the first round, tracked and taken out inside lrh_make_fft2 from then on) against the same run in rounds of 256 blocks on the
+    serial schedule: the loop is a recursion over the transforms and owes nothing to how many share a launch -- same loop state after
+    the run, same power sums, waterfall and narrowband output, bit for bit."""
+    import os
+    from linrad_amd import abi
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.spurs import spur_spectra
+    from linrad_amd.workload import chain_config, strong_liminfo
+    N1, N2, nspur = 16384, 65536, 8
+    s = synth_defaults(N1, 0)
+    res = []
+    for batch, pipeline in ((4096, None), (256, "0")):
+        if pipeline is not None:
+            monkeypatch.setenv("LRH_PIPELINE", pipeline)
+        cfg = chain_config(14, 16, batch=4096, fft3_n=12, mix2_n=8, rounds=2)
+        cfg.fft1_float_sparse, cfg.fft2_float_sparse = 1, 0      # acquisition reads whole transforms
+        cfg.stupid_bln_mode = 0
+        rx = open_hip(cfg)
+        monkeypatch.delenv("LRH_PIPELINE", raising=False)
+        rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+        rx.set_liminfo(strong_liminfo(s, 14))
+        rx.set_mix1_selfreq(0.31 * N2 + 0.3)
+        rx.wideband_dsp(4096, batch)
+        rx.sync()
+        rx.spur_config(nspur, 16, spur_spectra(2))
+        order = np.argsort(-np.asarray(s.carrier_amp[:s.ncarriers]))
+        locked = sum(int(rx.spur_acquire(int(round(N2 / 2 + s.carrier_bin[i] * N2 / s.fft_size)) - 3)) for i in order[:nspur])
+        rx.wideband_dsp(2 * 4096, batch)
+        st = [(q.spur_location, q.spur_flag, q.spur_freq, q.spur_d0pha, q.spur_d1pha, q.spur_d2pha, q.spur_ampl, q.spur_noise, q.spur_avgd2) for q in rx.spur_get(16)]
+        res.append(dict(locked=locked, st=st, p=rx.p.as_dict(), ps2=rx.export(abi.RING_FFT2_POWERSUM), wf=rx.export(abi.RING_WG_WATERF),
+                        timf3=rx.export(abi.RING_TIMF3_FLOAT), baseb=rx.export(abi.RING_BASEB_RAW)))
+        rx.close()
+    a, b = res
+    print("locked", a["locked"], b["locked"], "spurs", len(a["st"]))
+    assert a["locked"] == b["locked"] >= 6 and len(a["st"]) == len(b["st"]) == a["locked"]
+    assert a["p"] == b["p"]
+    assert a["st"] == b["st"]
+    for k in ("ps2", "wf", "timf3", "baseb"):
+        assert np.array_equal(a[k], b[k]), (k, int(np.count_nonzero(a[k] != b[k])))
