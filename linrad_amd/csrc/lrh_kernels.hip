@@ -1458,10 +1458,13 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
 // FUSED: blockIdx.y is a waterfall averaging group instead of a transform; the workgroup walks the group's
 // transforms and keeps sum |X|^2 of its bins in registers (k_fft2's scheme), so neither the fft2_power ring nor the
 // k_powersum2 pass over it is needed.
-template <int LA, int LB, bool FUSED>
-__global__ __launch_bounds__(1024, LB <= 8 ? 8 : 4) void k_fft2_rows(Fft2BigArgs a)    // row length <= 256: two workgroups per CU at 64 VGPRs; 512 (8 points per thread) spills 34 registers at that limit
+// PPT: points per thread of a row transform.  sub_ppt(LB) (4 at 256 points: 64 threads a transform, 1024-thread workgroups, two per CU) or,
+// at 256 points, 16: 16 threads a transform, 256-thread workgroups -- one exchange instead of three, sixteen loads in flight per lane
+// instead of four, and four workgroups per CU in different phases of their load / transform / store cycle.
+template <int LA, int LB, bool FUSED, int PPT>
+__global__ __launch_bounds__(LRH_TILE * ((1 << LB) / PPT), PPT == 16 ? 4 : (LB <= 8 ? 8 : 4)) void k_fft2_rows(Fft2BigArgs a)    // row length <= 256: two workgroups per CU at 64 VGPRs; 512 (8 points per thread) spills 34 registers at that limit
 {
-  constexpr int P = sub_ppt(LB);
+  constexpr int P = PPT;
   using Plan = FftPlan<LB, P>;
   constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   constexpr int CS = Plan::LDS_CELLS + 1;
@@ -1989,11 +1992,23 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
     a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
   }
   hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  // rows of 256 points: 16 points per thread (k_fft2_rows' PPT; LRH_FFT2_ROWS_P16=0: the 4-point form, for comparison)
+  static const int rows16 = getenv("LRH_FFT2_ROWS_P16") ? atoi(getenv("LRH_FFT2_ROWS_P16")) : 1;
+  if constexpr (LB == 8) {
+    if (rows16) {
+      if (a.ps_avgnum > 0)
+        hipLaunchKernelGGL((k_fft2_rows<LA, LB, true, 16>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),
+                           dim3(LRH_TILE * ((1 << LB) / 16)), 0, st, a);
+      else
+        hipLaunchKernelGGL((k_fft2_rows<LA, LB, false, 16>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / 16)), 0, st, a);
+      return;
+    }
+  }
   if (a.ps_avgnum > 0)
-    hipLaunchKernelGGL((k_fft2_rows<LA, LB, true>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),
+    hipLaunchKernelGGL((k_fft2_rows<LA, LB, true, sub_ppt(LB)>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),
                        dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
   else
-    hipLaunchKernelGGL((k_fft2_rows<LA, LB, false>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+    hipLaunchKernelGGL((k_fft2_rows<LA, LB, false, sub_ppt(LB)>), dim3((1 << LA) / LRH_TILE, batch), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }
 // ---- fft1 / timf2 for fft1_size 32768: four-step through an HBM scratch (same tiling as k_fft2_cols / k_fft2_rows) -------------
 // fft1: x[n] = (I w, -Q w)[n], n = NB n1 + n2; X[k1 + NA k2] = sum_n2 [ w_N^(n2 k1) sum_n1 x[NB n1 + n2] w_NA^(n1 k1) ] w_NB^(n2 k2), e^{+j}.
