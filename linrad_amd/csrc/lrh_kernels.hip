@@ -2148,11 +2148,11 @@ __global__ __launch_bounds__(1024, 4) void k_timf2_cols(Timf2BigArgs g)
     sc[(size_t)cc * NA + o1] = lds[cc * CS + o1];
   }
 }
-template <int LA, int LB>
-__global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
+template <int LA, int LB, int PPT>
+__global__ __launch_bounds__(LRH_TILE * ((1 << LB) / PPT)) void k_timf2_rows(Timf2BigArgs g)     // PPT: see k_fft2_rows
 {
   const Timf2Args &a = g.t;
-  constexpr int P = sub_ppt(LB);
+  constexpr int P = PPT;
   using Plan = FftPlan<LB, P>;
   constexpr int NA = 1 << LA, NB = 1 << LB, T = Plan::T, R0 = Plan::R0, RL = Plan::RL;
   constexpr int CS = Plan::LDS_CELLS + 1;
@@ -2179,6 +2179,12 @@ __global__ __launch_bounds__(1024) void k_timf2_rows(Timf2BigArgs g)
       if (st == 0) { store_stream(&a.timf2w[r], o); __builtin_nontemporal_store(o.x * o.x + o.y * o.y, &a.pwr[r]); }   // weak power only (timf2.c:1010-1012)
       else store_stream(&a.timf2s[r], o);
     }
+}
+template <int LA, int LB> static void launch_timf2_rows(const Timf2BigArgs &a, int batch, hipStream_t st)
+{
+  static const int p16 = getenv("LRH_TIMF2_ROWS_P16") ? atoi(getenv("LRH_TIMF2_ROWS_P16")) : 1;   // 16 points per thread (0: sub_ppt, for comparison)
+  if (p16) hipLaunchKernelGGL((k_timf2_rows<LA, LB, 16>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / 16)), 0, st, a);
+  else hipLaunchKernelGGL((k_timf2_rows<LA, LB, sub_ppt(LB)>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
 }
 template <int LA, int LB> static void launch_fft1_big_t(const Fft1BigArgs &a, int batch, hipStream_t st, int steps)
 {
@@ -2381,7 +2387,7 @@ hipError_t launch_fft1r_t2c(const Fft1rT2cArgs &a0, int batch, hipStream_t st)
   if (gpr < 1) gpr = 1;
   a.groups_per_run = gpr;
   hipLaunchKernelGGL((k_fft1r_t2c<LA, LB>), dim3(tiles, (ngroups + gpr - 1) / gpr), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL((k_timf2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a.t2);
+  launch_timf2_rows<LA, LB>(a.t2, batch, st);
   return hipGetLastError();
 }
 hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStream_t st)
@@ -2390,7 +2396,7 @@ hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStr
   constexpr int LA = 8, LB = 7;
   Timf2BigArgs a = a0; a.t.batch = batch;
   hipLaunchKernelGGL((k_timf2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
-  hipLaunchKernelGGL((k_timf2_rows<LA, LB>), dim3((1 << LA) / LRH_TILE, batch, 2), dim3(LRH_TILE * ((1 << LB) / sub_ppt(LB))), 0, st, a);
+  launch_timf2_rows<LA, LB>(a, batch, st);
   return hipGetLastError();
 }
 
