@@ -468,9 +468,18 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 if st["alg_GBps"] > HBM_PEAK_GBS:
                     st["note"] = ("algorithmic bytes (SURVEY 8d: every stage one full pass) exceed what this kernel moves: the overlapped half "
                                   "of each transform stays in registers and the per-transform power ring is never written")
-        # dominant kernel: largest stand-alone time per round.  The in-schedule durations of the side-stream stages (blanker, sums)
-        # are stretched by the kernels they overlap with (a scan of 53 us takes 300-500 us beside k_timf2) and say nothing about them
-        dom = max((k for k in stages if k in ALG_BYTES), key=lambda k: (alone.get(k) or 0.0) * stages[k]["launches"])
+        # The HBM roofline is that of the stage which moves the most HBM bytes per round (counter bytes of the committed PMC passes when they
+        # belong to this build, else the algorithmic ones): the four-step fft2 on configs[2].  The stage with the longest stand-alone time
+        # -- since round 3 a near tie between fft2 (376 us) and k_fft1w (378 us), which is bound by its two 16384-point transforms' LDS
+        # exchanges and not by bytes -- is reported beside it as `longest_kernel` with its fp32 rate.  (In-schedule durations of the
+        # side-stream stages are stretched by the kernels they overlap with and say nothing about them.)
+        def bytes_per_round(k):
+            t = measured_traffic(k, res["workload"])
+            per_launch = t["traffic_bytes_per_launch"] if t else ALG_BYTES[k] * (args.batch * M1) / (stages[k]["launches"] / (nprof * args.rounds))
+            return per_launch * stages[k]["launches"]
+        cands = [k for k in stages if k in ALG_BYTES]
+        dom = max(cands, key=bytes_per_round)
+        longest = max(cands, key=lambda k: (alone.get(k) or 0.0) * stages[k]["launches"])
         per_sample = ALG_BYTES[dom] + (ALG_BYTES["sumsq"] if (dom == "timf2" and fused_sums) else 0.0)
         launches_per_round = stages[dom]["launches"] / (nprof * args.rounds)
         alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_round
@@ -493,7 +502,23 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_alone": alone.get(dom),
                 "chain_alg_bytes_per_sample": chain_alg,
                 "chain_alg_GBps": round(value / world * chain_alg / 1e3, 1),
-                "chain_frac_alg": round(value / world * chain_alg / 1e3 / HBM_PEAK_GBS, 4)}
+                "chain_frac_alg": round(value / world * chain_alg / 1e3 / HBM_PEAK_GBS, 4),
+                "selection": "the stage that moves the most HBM bytes per round; the stage with the longest stand-alone time is `longest_kernel`"}
+        if longest != dom:
+            lt = measured_traffic(longest, res["workload"])
+            lp = stages[longest]["launches"] / (nprof * args.rounds)
+            l_s = stages[longest]["avg_us"] * 1e-6
+            lk = {"kernel": longest, "avg_launch_us": stages[longest]["avg_us"], "avg_launch_us_alone": alone.get(longest),
+                  "hbm_frac_alg": round(ALG_BYTES[longest] * (args.batch * M1) / lp / l_s / 1e9 / HBM_PEAK_GBS, 4),
+                  "hbm_frac_counter": round(lt["traffic_bytes_per_launch"] / l_s / 1e9 / HBM_PEAK_GBS, 4) if lt else None}
+            if longest == "fft1w":
+                # two 16384-point complex transforms per block (forward, weak-stream back transform) at 5 N log2 N flops each; the guide's
+                # vector fp32 peak (157.3 TFLOP/s).  Neither bytes nor flops bound it: one 512-thread workgroup per CU in lock step through
+                # six LDS exchanges per block (profiles/r03_sq_counters.txt)
+                flops = 2 * 5.0 * N1 * w["fft1_n"] * args.batch / lp
+                lk.update({"bound": "valu_fp32 / LDS exchange latency", "fp32_TFLOPs": round(flops / l_s / 1e12, 1), "fp32_peak_TFLOPs": 157.3,
+                           "fp32_frac": round(flops / l_s / 1e12 / 157.3, 4)})
+            roof["longest_kernel"] = lk
         trs = [measured_traffic(k, res["workload"]) for k in stages]
         if all(t is not None for t, k in zip(trs, stages) if k in ALG_BYTES):
             # whole-round HBM traffic from the counters: sum over the profiled kernels x their launches per round
