@@ -455,10 +455,13 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 alone[k] = round(1e3 * ms / n, 2)
         rx.profile_enable(0)
         fused_sums = "sumsq" not in stages
+
+        def alg_of(k):                                       # algorithmic bytes per sample of a stage in the form this workload runs it
+            return ALG_BYTES["fft2_single"] if (k == "fft2" and w["fft2_n"] <= 14) else ALG_BYTES[k]
         for k, st in stages.items():
             st["avg_us_alone"] = alone.get(k)
             if k in ALG_BYTES:                             # stage rates (secondary metric): one batch per launch
-                per = ALG_BYTES[k] + (ALG_BYTES["sumsq"] if (k == "timf2" and fused_sums) else 0.0)
+                per = alg_of(k) + (ALG_BYTES["sumsq"] if (k == "timf2" and fused_sums) else 0.0)
                 launches_per_round = st["launches"] / (nprof * args.rounds)
                 st["Msamples_per_s"] = round(args.batch * M1 / (st["avg_us"] * launches_per_round * 1e-6) / 1e6, 1)
                 st["alg_GBps"] = round(st["Msamples_per_s"] * per / 1e3, 1)
@@ -468,19 +471,18 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 if st["alg_GBps"] > HBM_PEAK_GBS:
                     st["note"] = ("algorithmic bytes (SURVEY 8d: every stage one full pass) exceed what this kernel moves: the overlapped half "
                                   "of each transform stays in registers and the per-transform power ring is never written")
-        # The HBM roofline is that of the stage which moves the most HBM bytes per round (counter bytes of the committed PMC passes when they
-        # belong to this build, else the algorithmic ones): the four-step fft2 on configs[2].  The stage with the longest stand-alone time
+        # The HBM roofline is that of the stage which has to move the most HBM bytes per round (the algorithmic figures: deterministic, where
+        # stand-alone times and counter bytes of two stages lie within a percent of each other): fft2 on both configs.  The stage with the longest stand-alone time
         # -- since round 3 a near tie between fft2 (376 us) and k_fft1w (378 us), which is bound by its two 16384-point transforms' LDS
         # exchanges and not by bytes -- is reported beside it as `longest_kernel` with its fp32 rate.  (In-schedule durations of the
         # side-stream stages are stretched by the kernels they overlap with and say nothing about them.)
         def bytes_per_round(k):
-            t = measured_traffic(k, res["workload"])
-            per_launch = t["traffic_bytes_per_launch"] if t else ALG_BYTES[k] * (args.batch * M1) / (stages[k]["launches"] / (nprof * args.rounds))
+            per_launch = alg_of(k) * (args.batch * M1) / (stages[k]["launches"] / (nprof * args.rounds))
             return per_launch * stages[k]["launches"]
         cands = [k for k in stages if k in ALG_BYTES]
         dom = max(cands, key=bytes_per_round)
         longest = max(cands, key=lambda k: (alone.get(k) or 0.0) * stages[k]["launches"])
-        per_sample = ALG_BYTES[dom] + (ALG_BYTES["sumsq"] if (dom == "timf2" and fused_sums) else 0.0)
+        per_sample = alg_of(dom) + (ALG_BYTES["sumsq"] if (dom == "timf2" and fused_sums) else 0.0)
         launches_per_round = stages[dom]["launches"] / (nprof * args.rounds)
         alg_bytes_launch = per_sample * (args.batch * M1) / launches_per_round
         avg_s = stages[dom]["avg_us"] * 1e-6
@@ -509,7 +511,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
             lp = stages[longest]["launches"] / (nprof * args.rounds)
             l_s = stages[longest]["avg_us"] * 1e-6
             lk = {"kernel": longest, "avg_launch_us": stages[longest]["avg_us"], "avg_launch_us_alone": alone.get(longest),
-                  "hbm_frac_alg": round(ALG_BYTES[longest] * (args.batch * M1) / lp / l_s / 1e9 / HBM_PEAK_GBS, 4),
+                  "hbm_frac_alg": round(alg_of(longest) * (args.batch * M1) / lp / l_s / 1e9 / HBM_PEAK_GBS, 4),
                   "hbm_frac_counter": round(lt["traffic_bytes_per_launch"] / l_s / 1e9 / HBM_PEAK_GBS, 4) if lt else None}
             if longest == "fft1w":
                 # two 16384-point complex transforms per block (forward, weak-stream back transform) at 5 N log2 N flops each; the guide's

@@ -10,7 +10,12 @@ ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2":
              # averaged power spectrum (4 B per bin and fft_avg1num = 5 blocks of N1/2 new samples: 1.6) -- the SURVEY 8d figures of the
              # three stages it replaces (24 + 16 + 52) price a spectrum round trip through HBM that no longer exists.
              # Its second pass (timf2s) writes the strong stream once (8); the handful of strong bins it reads is noise.
-             "fft1w": 8.0 + 8.0 + 4.0 + 1.6, "timf2s": 8.0}
+             "fft1w": 8.0 + 8.0 + 4.0 + 1.6, "timf2s": 8.0,
+             # fft2 as ONE pass (fft2_size <= 16384: a transform fits a workgroup's LDS, k_fft2<n>): both timf2 streams in once (8 + 8; the
+             # overlapped half of a transform stays in registers), the spectrum out (8 B x 2 transforms per sample at 50 % overlap) and the
+             # averaged power (4 B x 2 / waterfall_avgnum = 1).  SURVEY 8d's 64 prices the four-step form: a scratch round trip and the
+             # overlapped read taken twice.  (With cfg.fft2_float_sparse only the band mix1 cuts out is stored: the counters show 20.)
+             "fft2_single": 8.0 + 8.0 + 16.0 + 1.0}
 ALG_BYTES_CHAIN = 184.0
 
 
