@@ -1111,6 +1111,92 @@ __global__ void k_blank_serial(BlankArgs a)
   a.st->call_cleared = cnt;
 }
 
+// The same walk by one wave (the form that is launched; k_blank_serial stays as the statement of it and for comparison, LRH_BLN_SERIAL=1).
+// The state of the walk (in a run? its start, its maximum; where the last guard ends) is uniform over the lanes; the lanes hold 64
+// consecutive powers each step, eight such steps in flight, and the walk moves by runs through the ballot of "above the limit": a run's
+// length is a count of trailing ones, its maximum a wave reduction, its mask bits three words formed by shifts and ORed into the (cleared)
+// mask without waiting for them.  One lane and one dependent global load per sample took 200 ns per sample -- 6.7 s for a 33.5 M-sample
+// call whose limit sits below the noise (the start-up of a calibrated receiver); this form takes a few ns per sample.
+__global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
+{
+  if (!a.st->need_slow || bln_runs_mode(a)) return;
+  const int lane = threadIdx.x;
+  const int wordmask = ((a.mask + 1) >> 5) - 1;
+  for (int i = lane; i < a.ncounts; i += 64) a.counts[i] = 0;
+  {
+    const int qlo = 1 - a.clr1 - 32, nq = a.total + a.clr2 + 32 - qlo + 1;
+    const int w0 = ((a.pbeg + qlo) & a.mask) >> 5;
+    for (int k = lane; k <= nq / 32 + 1; k += 64) a.mask_bits[(w0 + k) & wordmask] = 0;
+  }
+  __threadfence();                                       // the clears are in memory before any bit is ORed in
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
+  int ifirst = 0, pk = 0, erase_end = 0, cnt = 0; float pulmax = 0;
+  auto or_bits = [&](int p0, unsigned long long bits) {  // bit i of `bits` = ring position p0 + i (p0 + i taken modulo the ring by words)
+    const int off = p0 & 31, w = p0 >> 5;
+    const unsigned long long lo = bits << off, hi = off ? bits >> (64 - off) : 0ull;
+    const unsigned int part = lane == 0 ? (unsigned int)lo : (lane == 1 ? (unsigned int)(lo >> 32) : (unsigned int)hi);
+    if (lane < 3 && part) atomicOr(&a.mask_bits[(w + lane) & wordmask], part);
+  };
+  auto mark = [&](int q_first, int n) {                  // sequence positions q_first .. q_first + n - 1 (guards: a few samples)
+    for (int j = 0; j < n; j += 64) {
+      const int m = n - j < 64 ? n - j : 64;
+      or_bits((a.pbeg + q_first + j) & a.mask, m == 64 ? ~0ull : (1ull << m) - 1);
+    }
+  };
+  constexpr int DEPTH = 8;
+  for (int q0 = 1; q0 <= a.total; q0 += 64 * DEPTH) {
+    float v[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) { const int q = q0 + 64 * d + lane; v[d] = q <= a.total ? a.pwr[(a.pbeg + q) & a.mask] : 0.f; }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      const int qc = q0 + 64 * d;                        // first position of this step
+      if (qc > a.total) break;
+      const int valid = a.total - qc + 1 < 64 ? a.total - qc + 1 : 64;
+      const unsigned long long hot = __ballot(v[d] > nfl);
+      if (hot == 0 && ifirst == 0) continue;
+      unsigned long long run_bits = 0;                    // samples of this step that join a run
+      int pos = 0;
+      while (pos < valid) {
+        if (ifirst == 0) {                                // the next sample that starts a run: above the limit, at or behind the last guard's end
+          unsigned long long m = hot & (~0ull << pos);
+          const int skip = erase_end - qc;
+          if (skip >= 64) m = 0; else if (skip > 0) m &= ~0ull << skip;
+          if (m == 0) break;
+          pos = __ffsll((long long)m) - 1;
+          pk = qc + pos;
+        }
+        const unsigned long long rest = ~(hot >> pos);    // first zero above pos = the run's length within this step
+        int len = rest ? __ffsll((long long)rest) - 1 : 64 - pos;
+        if (len > valid - pos) len = valid - pos;
+        if (len > 0) {
+          const unsigned long long seg = (len == 64 ? ~0ull : (1ull << len) - 1) << pos;
+          float mx = ((seg >> lane) & 1) ? v[d] : 0.f;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+          if (mx > pulmax) pulmax = mx;
+          ifirst += len; cnt += len; run_bits |= seg;
+          pos += len;
+        }
+        if (pos >= valid) break;                          // the run goes on in the next step (or the call ends inside it: no guards then)
+        // the sample at pos ends the run
+        ifirst = 0;
+        int ib, ia;
+        const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
+        pulmax = 0;
+        if (ext) {
+          if (ib > 0) mark(pk - ib, ib);
+          if (ia > 0) mark(qc + pos, ia);
+          cnt += ib + ia; erase_end = qc + pos + ia;
+        }
+        pos++;
+      }
+      if (run_bits) or_bits((a.pbeg + qc) & a.mask, run_bits);
+    }
+  }
+  if (lane == 0) { a.st->need_slow = 0; a.st->slow_calls++; a.st->call_cleared = cnt; }
+}
+
 // one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word, and report how much
 // every-4th-sample power was removed (the noise statistic of blank1.c:1493-1497 is taken after clearing)
 __global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word, int nwords, int word_mask)
@@ -3065,7 +3151,11 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
   if (a.mode != 0) {
     a.npartials = ntiles; a.nremoved = (nwords + 255) / 256; a.ncounts = ntiles;
     hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
-    if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);   // calibrated blanker only
+    if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) {      // calibrated blanker only
+      const char *e_ = getenv("LRH_BLN_SERIAL"); const int one_lane = e_ ? atoi(e_) : 0;     // (read per call: the comparison test flips it)
+      if (one_lane) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
+      else hipLaunchKernelGGL(k_blank_serial_wave, dim3(1), dim3(64), 0, st, a);
+    }
     else {         // long-run replay: two launches that return at once unless a lane gave up
       hipLaunchKernelGGL(k_blank_runs_pre, dim3(ntiles), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_blank_runs, dim3(ntiles), dim3(256), 0, st, a);   // k_blank_update takes the flag down

@@ -447,6 +447,45 @@ def test_blanker_long_runs_replayed_in_parallel(amps):
     assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
 
 
+@pytest.mark.parametrize("amps", [(3000.0, 3000.0), (6000.0, 0.0), (0.0, 0.0)])
+def test_calibrated_blanker_long_runs_walk(amps, monkeypatch):
+    """The same signals with pulse calibration (blanker_pulsewidth 3: guards of clr1 = 2 before and up to clr2 = 4 samples behind a run,
+    blank1.c:1013-1014), where runs chain through their guards and the walk over a call that gave the lanes no clean restart point is
+    serial: k_blank_serial_wave (one wave, the walk moves by runs through the ballot of "above the limit") against the oracle's sample
+    walk, and bit for bit against the one-lane statement of the walk (LRH_BLN_SERIAL=1).  Third case: noise only with the limit below
+    the noise -- the start-up of a calibrated receiver: short runs everywhere."""
+    cfg = chain_config(14, 12, batch=16)
+    cfg.blanker_pulsewidth = 3
+    if not (amps[0] or amps[1]):
+        cfg.timf2_noise_floor = 30                                   # limit = 5 x floor, far below the noise power
+    n = cfg.timf1_bytes // 4
+    t = np.arange(n)
+    rng = np.random.default_rng(9)
+    z = rng.normal(0, 64.0, n) + 1j * rng.normal(0, 64.0, n)
+    z += amps[0] * np.exp(2j * np.pi * 1000.0 * t / N1) + amps[1] * np.exp(2j * np.pi * (1000.0 + N1 / 20000.0) * t / N1 + 1.0j)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2], iq[1::2] = np.clip(np.round(z.real), -32767, 32767), np.clip(np.round(z.imag), -32767, 32767)
+    res = []
+    for fn, one_lane in ((_hip, "0"), (_hip, "1"), (_oracle, "0")):
+        monkeypatch.setenv("LRH_BLN_SERIAL", one_lane)
+        rx = fn(cfg)
+        _feed(rx, iq, np.zeros(N1, np.float32), 0.31 * 4096 + 0.3)
+        rx.wideband_dsp(64, 16)
+        res.append((rx.export(abi.RING_TIMF2_PWR), rx.blanker_state(), rx.p.as_dict(), rx.export(abi.RING_TIMF2_FLOAT)))
+        rx.close()
+    (hp, hb, hpt, ht), (sp, sb, spt, st_), (op, ob, opt, _) = res
+    fit = hpt["timf2p_fit"]
+    assert fit == opt["timf2p_fit"] == spt["timf2p_fit"] and fit > 400000
+    assert hb.slow_path_calls >= 1 and sb.slow_path_calls == hb.slow_path_calls
+    assert np.array_equal(hp, sp) and np.array_equal(ht, st_)         # the wave's walk = the lane's walk
+    assert (hb.timf2_noise_floor, hb.stupid_bln_limit, hpt) == (sb.timf2_noise_floor, sb.stupid_bln_limit, spt)
+    ch, co = hp[:fit] == 0, op[:fit] == 0
+    print("cleared share", float(co.mean()), "slow-path calls", hb.slow_path_calls, "mismatch", float(np.mean(ch != co)))
+    assert co.mean() > 0.3
+    assert np.mean(ch != co) < 1e-4, np.mean(ch != co)
+    assert abs(hb.timf2_noise_floor - ob.timf2_noise_floor) <= max(2, 0.01 * ob.timf2_noise_floor)
+
+
 def test_fft1_size_32768_chain_matches_oracle():
     """fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): the four-step fft1 / timf2 kernels, fft2_size
     131072, through lrh_wideband_dsp in batches of 8, against the oracle; plus a worker handle (own stream, own scratch)."""
