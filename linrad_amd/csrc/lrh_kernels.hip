@@ -817,6 +817,13 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
   }
   if (t1 > 4) {
     if (t1 > 10000) t1 = 10000;                        // 40 dB cap (blank1.c:1056-1057)
+    // (int)(clr * (float)(sqrt((double)t1) / 100) + 0.5): the double square root and division are ~150 instructions, and the serial walk
+    // pays them per run.  The single-precision value differs from the reference's by a few ulp at most, which changes the truncated
+    // result only when clr * x + 0.5 lies within that of an integer: decided in float unless it is that close (then exactly as written).
+    const float xf = sqrtf(t1) * 0.01f;
+    const float fb = (float)a.clr1 * xf + 0.5f, fa = (float)a.clr2 * xf + 0.5f;
+    const float db = fb - floorf(fb), da = fa - floorf(fa);
+    if (db > 1e-3f && db < 1.f - 1e-3f && da > 1e-3f && da < 1.f - 1e-3f) { *ib = (int)fb; *ia = (int)fa; return 1; }
     t1 = (float)(sqrt((double)t1) / 100);
     *ib = (int)((float)a.clr1 * t1 + 0.5);
     *ia = (int)((float)a.clr2 * t1 + 0.5);
@@ -1131,16 +1138,29 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
   __threadfence();                                       // the clears are in memory before any bit is ORed in
   const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
   int ifirst = 0, pk = 0, erase_end = 0, cnt = 0; float pulmax = 0;
-  auto or_bits = [&](int p0, unsigned long long bits) {  // bit i of `bits` = ring position p0 + i (p0 + i taken modulo the ring by words)
-    const int off = p0 & 31, w = p0 >> 5;
+  // bit i of `bits` = sequence position q_base + i: three words ORed into the mask, nobody waits for them
+  auto or_bits = [&](int q_base, unsigned long long bits) {
+    const int p0 = (a.pbeg + q_base) & a.mask, off = p0 & 31, w = p0 >> 5;
     const unsigned long long lo = bits << off, hi = off ? bits >> (64 - off) : 0ull;
     const unsigned int part = lane == 0 ? (unsigned int)lo : (lane == 1 ? (unsigned int)(lo >> 32) : (unsigned int)hi);
     if (lane < 3 && part) atomicOr(&a.mask_bits[(w + lane) & wordmask], part);
   };
-  auto mark = [&](int q_first, int n) {                  // sequence positions q_first .. q_first + n - 1 (guards: a few samples)
-    for (int j = 0; j < n; j += 64) {
-      const int m = n - j < 64 ? n - j : 64;
-      or_bits((a.pbeg + q_first + j) & a.mask, m == 64 ? ~0ull : (1ull << m) - 1);
+  // The bits of the step before, the current step and the next one gather in registers (guards reach a few samples behind a run's start
+  // and beyond its end) and leave once per step: atomics on one mask word from run after run queue up in the L2 (a dozen per 32 samples
+  // when the limit sits in the noise: 120 ns per sample).  What falls outside the window -- the guard before a run that began steps ago --
+  // goes out directly.
+  unsigned long long acc[3] = { 0, 0, 0 };                // positions qc - 64 .., qc .., qc + 64 ..
+  int qc = 1;
+  auto mark = [&](int q_first, int n) {                  // sequence positions q_first .. q_first + n - 1
+    int r = q_first - (qc - 64);
+    if (r < 0 || r + n > 192) {
+      for (int j = 0; j < n; j += 64) { const int m = n - j < 64 ? n - j : 64; or_bits(q_first + j, m == 64 ? ~0ull : (1ull << m) - 1); }
+      return;
+    }
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const int lo = r > 64 * w ? r : 64 * w, hi = r + n < 64 * w + 64 ? r + n : 64 * w + 64;
+      if (lo < hi) acc[w] |= ((hi - lo == 64) ? ~0ull : (1ull << (hi - lo)) - 1) << (lo - 64 * w);
     }
   };
   constexpr int DEPTH = 8;
@@ -1150,12 +1170,14 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
     for (int d = 0; d < DEPTH; d++) { const int q = q0 + 64 * d + lane; v[d] = q <= a.total ? a.pwr[(a.pbeg + q) & a.mask] : 0.f; }
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) {
-      const int qc = q0 + 64 * d;                        // first position of this step
-      if (qc > a.total) break;
+      if (q0 + 64 * d > a.total) break;
+      if (q0 + 64 * d != qc) {                            // the window moves on by one step
+        if (acc[0]) or_bits(qc - 64, acc[0]);
+        acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0; qc += 64;
+      }
       const int valid = a.total - qc + 1 < 64 ? a.total - qc + 1 : 64;
       const unsigned long long hot = __ballot(v[d] > nfl);
       if (hot == 0 && ifirst == 0) continue;
-      unsigned long long run_bits = 0;                    // samples of this step that join a run
       int pos = 0;
       while (pos < valid) {
         if (ifirst == 0) {                                // the next sample that starts a run: above the limit, at or behind the last guard's end
@@ -1171,11 +1193,16 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
         if (len > valid - pos) len = valid - pos;
         if (len > 0) {
           const unsigned long long seg = (len == 64 ? ~0ull : (1ull << len) - 1) << pos;
-          float mx = ((seg >> lane) & 1) ? v[d] : 0.f;
+          if (len <= 12) {                                  // a short run: its samples one by one out of the lanes (uniform index)
+            for (int i = pos; i < pos + len; i++) { const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[d]), i)); if (x > pulmax) pulmax = x; }
+          } else {
+            float mx = ((seg >> lane) & 1) ? v[d] : 0.f;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-          if (mx > pulmax) pulmax = mx;
-          ifirst += len; cnt += len; run_bits |= seg;
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));   // the same in every lane: keep the walk's state scalar
+            if (mx > pulmax) pulmax = mx;
+          }
+          ifirst += len; cnt += len; acc[1] |= seg;
           pos += len;
         }
         if (pos >= valid) break;                          // the run goes on in the next step (or the call ends inside it: no guards then)
@@ -1191,9 +1218,10 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
         }
         pos++;
       }
-      if (run_bits) or_bits((a.pbeg + qc) & a.mask, run_bits);
     }
   }
+#pragma unroll
+  for (int w = 0; w < 3; w++) if (acc[w]) or_bits(qc - 64 + 64 * w, acc[w]);
   if (lane == 0) { a.st->need_slow = 0; a.st->slow_calls++; a.st->call_cleared = cnt; }
 }
 
