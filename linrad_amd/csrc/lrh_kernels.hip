@@ -823,7 +823,7 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
     const float xf = sqrtf(t1) * 0.01f;
     const float fb = (float)a.clr1 * xf + 0.5f, fa = (float)a.clr2 * xf + 0.5f;
     const float db = fb - floorf(fb), da = fa - floorf(fa);
-    if (db > 1e-3f && db < 1.f - 1e-3f && da > 1e-3f && da < 1.f - 1e-3f) { *ib = (int)fb; *ia = (int)fa; return 1; }
+    if (a.clr2 <= 256 && db > 1e-3f && db < 1.f - 1e-3f && da > 1e-3f && da < 1.f - 1e-3f) { *ib = (int)fb; *ia = (int)fa; return 1; }   // (clr x 4 ulp stays far below the 1e-3 margin)
     t1 = (float)(sqrt((double)t1) / 100);
     *ib = (int)((float)a.clr1 * t1 + 0.5);
     *ia = (int)((float)a.clr2 * t1 + 0.5);
