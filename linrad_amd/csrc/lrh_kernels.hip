@@ -800,6 +800,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1w(Fft1wArgs a)
 // A miss hands the call to the long-run replay below (uncalibrated blanker: parallel, k_blank_runs) or to the one-thread
 // serial pass (calibrated); searching further back only pays while a miss is expensive.
 #define LRH_BLN_BACK 256
+#define LRH_BLN_BACK2 4096
 
 __device__ __forceinline__ void bln_setbit(unsigned int *bits, int p) { atomicOr(&bits[p >> 5], 1u << (p & 31)); }
 
@@ -835,8 +836,15 @@ __device__ __forceinline__ int bln_guards(const BlankArgs &a, float pulmax, floa
 #define LRH_BLN_TILE (256 * LRH_BLN_CHUNK)
 #define LRH_BLN_WORDS (LRH_BLN_TILE / 32 + 2)
 
+// BACK: how far before a wave's span the powers are staged for the lanes' search of a clean restart point.  LRH_BLN_BACK (256) in the
+// scan every call runs; LRH_BLN_BACK2 (4096) in a second launch that returns at once unless a lane of the first gave up, and then redoes
+// the call with the long reach (same bits where the first succeeded: the decisions do not depend on where a replay starts).  With the
+// limit inside the noise -- the start-up of a calibrated receiver -- a clean point (clr2 samples in a row at or below the limit) is some
+// 200 samples away on average and every few hundredth lane finds none within 256: that call used to go to the serial walk as a whole.
+template <int BACK>
 __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
 {
+  if constexpr (BACK != LRH_BLN_BACK) { if (!a.st->need_slow || a.debug == 8) return; }
   // Two phases per workgroup (tile of 256 chunks x 64 samples).
   // 1. Cooperative, coalesced: every wave reads its 4096 samples (and the 256 before them, for the clean-point search) as
   //    256-byte rows, one dword per lane, and turns each row into one 64-bit word of "above the limit" bits by ballot.  This
@@ -847,12 +855,12 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   //    samples above the limit and the sample that ends a run matter, everything else leaves the serial state alone.  The
   //    power of the few samples above the limit is read back from L2 for the run maximum.
   __shared__ unsigned int wbits[LRH_BLN_WORDS];         // decisions for the ring words this tile overlaps
-  __shared__ unsigned long long above[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];   // per wave: word k covers positions R0 - BACK + 64 k ..
+  __shared__ unsigned long long above[4][LRH_BLN_CHUNK + BACK / 64];   // per wave: word k covers positions R0 - BACK + 64 k ..
   // the power of the samples above the limit, compacted per wave in row order (phase 2 needs it for the run maxima and would
   // otherwise wait for L2 once per event): value of bit l of row k sits at rowoff[k] + popcount(bits of the row below l)
   constexpr int VCAP = 512;                               // (with 1024 the workgroup took 22 KB of LDS: seven per CU, and the eighth of every CU ran alone in a second round)
   __shared__ float vals[4][VCAP];
-  __shared__ int rowoff[4][LRH_BLN_CHUNK + LRH_BLN_BACK / 64];
+  __shared__ int rowoff[4][LRH_BLN_CHUNK + BACK / 64];
   __shared__ int wg_cnt;
   __shared__ double wg_sum[4];
   if (threadIdx.x == 0) wg_cnt = 0;
@@ -869,12 +877,12 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
   };
   const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));   // blank1.c:1017
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  constexpr int NBACK = LRH_BLN_BACK / 64, NROWS = LRH_BLN_CHUNK + NBACK;
-  const int base = qt + wv * 64 * LRH_BLN_CHUNK - LRH_BLN_BACK;          // position of bit 0 of word 0 of this wave
+  constexpr int NBACK = BACK / 64, NROWS = LRH_BLN_CHUNK + NBACK;
+  const int base = qt + wv * 64 * LRH_BLN_CHUNK - BACK;          // position of bit 0 of word 0 of this wave
   double s4 = 0;                                         // every-4th-sample power of the wave's own positions before clearing
   int running = 0;                                       // wave-uniform: samples above the limit in the rows so far
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-  constexpr int FL = 17;                                 // rows in flight per trip (NROWS = 68 = 4 x 17)
+  constexpr int FL = NROWS % 17 == 0 ? 17 : 16;          // rows in flight per trip (NROWS = 68 = 4 x 17; 128 = 8 x 16 with the long reach)
   static_assert(NROWS % FL == 0, "row count");
 #pragma unroll 1
   for (int k = 0; k < NROWS; k += FL) {
@@ -925,10 +933,10 @@ __global__ __launch_bounds__(256) void k_blank_scan(BlankArgs a)
     while (q >= 1) {
       if (bit(q)) run = 0; else if (++run >= G) { found = true; break; }
       q--;
-      if (++steps >= LRH_BLN_BACK) break;
+      if (++steps >= BACK) break;
     }
     if (found) s = q + G;
-    else if (q >= 1) { a.st->need_slow = 1; live = false; }  // no clean point in reach: the long-run replay takes over
+    else if (q >= 1) { if constexpr (BACK == LRH_BLN_BACK) a.st->need_slow = 1; else a.st->need_slow2 = 1; live = false; }  // no clean point in reach: the long-run replay / the second scan / the serial walk takes over
   }
   int cnt = 0;
   if (a.debug == 7) live = false;
@@ -1090,8 +1098,8 @@ __global__ __launch_bounds__(256) void k_blank_runs(BlankArgs a)
 // exact serial replay for the calibrated blanker (clr2 > 1), only when a lane of k_blank_scan could not find a clean restart point
 __global__ void k_blank_serial(BlankArgs a)
 {
-  if (!a.st->need_slow || bln_runs_mode(a)) return;
-  a.st->need_slow = 0; a.st->slow_calls++;
+  if (!a.st->need_slow || !(a.st->need_slow2 || a.debug == 8) || bln_runs_mode(a)) return;     // (debug 8: no second scan, tests of this walk)
+  a.st->need_slow = 0; a.st->need_slow2 = 0; a.st->slow_calls++;
   for (int i = 0; i < a.ncounts; i++) a.counts[i] = 0;
   for (int q = 1 - a.clr1 - 32; q <= a.total + a.clr2 + 32; q++) a.mask_bits[((a.pbeg + q) & a.mask) >> 5] = 0;
   const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
@@ -1126,7 +1134,7 @@ __global__ void k_blank_serial(BlankArgs a)
 // call whose limit sits below the noise (the start-up of a calibrated receiver); this form takes a few ns per sample.
 __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
 {
-  if (!a.st->need_slow || bln_runs_mode(a)) return;
+  if (!a.st->need_slow || !(a.st->need_slow2 || a.debug == 8) || bln_runs_mode(a)) return;
   const int lane = threadIdx.x;
   const int wordmask = ((a.mask + 1) >> 5) - 1;
   for (int i = lane; i < a.ncounts; i += 64) a.counts[i] = 0;
@@ -1222,7 +1230,7 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
   }
 #pragma unroll
   for (int w = 0; w < 3; w++) if (acc[w]) or_bits(qc - 64 + 64 * w, acc[w]);
-  if (lane == 0) { a.st->need_slow = 0; a.st->slow_calls++; a.st->call_cleared = cnt; }
+  if (lane == 0) { a.st->need_slow = 0; a.st->need_slow2 = 0; a.st->slow_calls++; a.st->call_cleared = cnt; }
 }
 
 // one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word, and report how much
@@ -3178,8 +3186,9 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
   a.ncounts = 0;
   if (a.mode != 0) {
     a.npartials = ntiles; a.nremoved = (nwords + 255) / 256; a.ncounts = ntiles;
-    hipLaunchKernelGGL(k_blank_scan, dim3(ntiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_blank_scan<LRH_BLN_BACK>, dim3(ntiles), dim3(256), 0, st, a);
     if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) {      // calibrated blanker only
+      hipLaunchKernelGGL(k_blank_scan<LRH_BLN_BACK2>, dim3(ntiles), dim3(256), 0, st, a);      // returns at once unless a lane gave up
       const char *e_ = getenv("LRH_BLN_SERIAL"); const int one_lane = e_ ? atoi(e_) : 0;     // (read per call: the comparison test flips it)
       if (one_lane) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
       else hipLaunchKernelGGL(k_blank_serial_wave, dim3(1), dim3(64), 0, st, a);

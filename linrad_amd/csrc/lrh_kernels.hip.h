@@ -123,6 +123,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   int clever_out[4];         // what k_clever hands the host: ring position where the scan stopped (pf), pulses fitted, pulses rejected, [3] != 0: extents collided -- the host issues the one-wave replay
   int clever_serial_calls;   // calls that fell back to the one-wave replay
   float amp_factor;          // liminfo_amplitude_factor: the limiter kernels keep it current, k_clever scales its reference pulse with it
+  int need_slow2;            // scratch: ... and none within the long look-back of the second scan either: the serial walk takes the call
 };
 struct BlankArgs {
   float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask

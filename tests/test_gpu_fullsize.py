@@ -466,19 +466,23 @@ def test_calibrated_blanker_long_runs_walk(amps, monkeypatch):
     iq = np.empty(2 * n, np.int16)
     iq[0::2], iq[1::2] = np.clip(np.round(z.real), -32767, 32767), np.clip(np.round(z.imag), -32767, 32767)
     res = []
-    for fn, one_lane in ((_hip, "0"), (_hip, "1"), (_oracle, "0")):
+    # the library's order (second scan with the long look-back, then the walk if that gives up too); the walk alone (LRH_BLN_DEBUG=8: no
+    # second scan) on one wave and on one lane; the oracle
+    for fn, dbg, one_lane in ((_hip, "0", "0"), (_hip, "8", "0"), (_hip, "8", "1"), (_oracle, "0", "0")):
+        monkeypatch.setenv("LRH_BLN_DEBUG", dbg)
         monkeypatch.setenv("LRH_BLN_SERIAL", one_lane)
         rx = fn(cfg)
         _feed(rx, iq, np.zeros(N1, np.float32), 0.31 * 4096 + 0.3)
         rx.wideband_dsp(64, 16)
         res.append((rx.export(abi.RING_TIMF2_PWR), rx.blanker_state(), rx.p.as_dict(), rx.export(abi.RING_TIMF2_FLOAT)))
         rx.close()
-    (hp, hb, hpt, ht), (sp, sb, spt, st_), (op, ob, opt, _) = res
+    (hp, hb, hpt, ht), (wp, wb, wpt, wt), (sp, sb, spt, st_), (op, ob, opt, _) = res
     fit = hpt["timf2p_fit"]
-    assert fit == opt["timf2p_fit"] == spt["timf2p_fit"] and fit > 400000
-    assert hb.slow_path_calls >= 1 and sb.slow_path_calls == hb.slow_path_calls
-    assert np.array_equal(hp, sp) and np.array_equal(ht, st_)         # the wave's walk = the lane's walk
-    assert (hb.timf2_noise_floor, hb.stupid_bln_limit, hpt) == (sb.timf2_noise_floor, sb.stupid_bln_limit, spt)
+    assert fit == opt["timf2p_fit"] == spt["timf2p_fit"] == wpt["timf2p_fit"] and fit > 400000
+    assert hb.slow_path_calls >= 1 and sb.slow_path_calls == hb.slow_path_calls == wb.slow_path_calls
+    assert np.array_equal(wp, sp) and np.array_equal(wt, st_)         # the wave's walk = the lane's walk
+    assert np.array_equal(hp, wp) and np.array_equal(ht, wt)          # ... = what the second scan decides where it finds its restart points
+    assert (hb.timf2_noise_floor, hb.stupid_bln_limit, hpt) == (sb.timf2_noise_floor, sb.stupid_bln_limit, spt) == (wb.timf2_noise_floor, wb.stupid_bln_limit, wpt)
     ch, co = hp[:fit] == 0, op[:fit] == 0
     print("cleared share", float(co.mean()), "slow-path calls", hb.slow_path_calls, "mismatch", float(np.mean(ch != co)))
     assert co.mean() > 0.3
