@@ -176,7 +176,7 @@ __host__ __device__ constexpr int fft_min_waves(int log2n) { return log2n == 13 
 template <int LOG2N, int P> struct FftPlan {
   static constexpr int N = 1 << LOG2N;
   static constexpr int T = N / P;                       // threads per workgroup
-  static constexpr int MAXLOG = (P >= 16) ? 4 : 2;      // log2 of the largest radix
+  static constexpr int MAXLOG = (P >= 16) ? 4 : (P == 8 ? 3 : 2);      // log2 of the largest radix (8 points per thread: radix 8, e.g. 256 = 8 x 8 x 4 in three passes)
   static constexpr int FULL = LOG2N / MAXLOG;
   static constexpr int REM = LOG2N % MAXLOG;
   static constexpr int NPASS = FULL + (REM ? 1 : 0);
