@@ -47,11 +47,12 @@ lrh_ctx *hip_context(void) { return hip_rx; }
 static int hip_unsupported(void)
 {
   if (ui.rx_rf_channels != 1) return 1;
-  if ((ui.rx_input_mode & IQ_DATA) == 0) return 2;
+  if ((ui.rx_input_mode & IQ_DATA) == 0 && fft_cntrl[FFT1_CURMODE].permute != 2) return 2;   /* real samples: version 22, whose permute field gives Linrad's
+                                                                                                  filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
   if (fft1_correlation_flag != 0) return 4;
   if (genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0) return 5;
-  if ((ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0) return 6;
+  if ((ui.network_flag & NET_RXOUT_TIMF2) != 0 && !swfloat) return 6;      /* the int16 payload is built from the MMX ring (rxin.c:968-990) */
   if (genparm[MIX1_NO_OF_CHANNELS] != 1) return 7;
   return 0;
 }
@@ -85,6 +86,7 @@ int hip_open(void)
   c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
   c.timf2_blockpower_block = timf2_blockpower_block; c.timf2_blockpower_size = timf2_blockpower_size;     /* compute_timf2_powersum, wcw.c:80 */
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
+  c.timf1_real_input = (ui.rx_input_mode & IQ_DATA) == 0;          /* fft1_reherm_dit_one's job (fft1_re.c:32-131): 2 fft1_size reals per transform */
   if ((rc = lrh_open(&c, &hip_rx)) != 0) { hip_rx = NULL; return rc; }
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
   lrh_set_filtercorr(hip_rx, fft1_filtercorr);                /* the calibration Linrad loaded (fft1.c:4653-5386) */
@@ -256,7 +258,9 @@ static void hip_sellim_par(lrh_sellim *par, lrh_ptrs *q)
   par->exact_stats = 0;
   par->blanker_ston_fft2 = hg.blanker_ston_fft2; par->fft2_blocktime = fft2_blocktime; par->sellim_par1 = hg.sellim_par1;
   par->fft1_desired = (fft1_calibrate_flag & CALAMP) == CALAMP ? fft1_desired : NULL;     /* sellim.c:134-143 */
-  q->fft1_sumsq_pa = fft1_sumsq_pa;
+  /* in the middle of an averaging period (a batch of gpu_fft1_batch_size transforms need not end on one) the slot at fft1_sumsq_pa holds
+     unfinished sums: the counter tells the library to read the newest finished period instead (include/linrad_hip.h, lrh_sellim) */
+  q->fft1_sumsq_pa = fft1_sumsq_pa; q->fft1_sumsq_counter = fft1_sumsq_counter;
   lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);             /* selfreq_liminfo protects the selected passband (sellim.c:38) */
 }
 static void hip_liminfo_back(void)
@@ -408,4 +412,37 @@ void hip_compute_timf2_powersum(void)
     lrh_export(hip_rx, LRH_RING_TIMF2_BLOCKPOWER, &timf2_blockpower[old_pa], (size_t)old_pa, (size_t)k);
     old_pa = (old_pa + k) & timf2_blockpower_mask; n -= k;
   }
+}
+
+/* ---- network output of device-resident stages.  Linrad's senders read the host rings (the dispatcher's memcpy of a retired batch,
+   wcw.c:1024-1043; the network thread's walks from timf2_pt / fft2_pt, rxin.c:919-1060); with version 21 those rings stay empty, so each
+   hook fetches exactly the span the sender is about to read into its place in the host ring and the reference's packet code runs on
+   unchanged.  (lrh_export_timf2_net would halve the PCIe bytes of the timf2 payload by combining weak and strong on the device; that
+   needs the sender's loop itself replaced.) ---- */
+static void hip_ring_span(lrh_ring ring, float *host, int pt, int count, int size)
+{
+  while (count > 0) {
+    int k = count;
+    if (pt + k > size) k = size - pt;
+    if (lrh_export(hip_rx, ring, &host[pt], (size_t)pt, (size_t)k) != 0) { lirerr(1478); return; }
+    pt = (pt + k) & (size - 1); count -= k;
+  }
+}
+/* NET_RXOUT_FFT1: the batch of transforms as fft1_b leaves them -- before fft1_c's filter correction (network.c:383-388) -- for the blocks
+   that start at timf1p_ref, into fft1_float at fft1_pa where the memcpy expects them */
+void hip_net_fft1(int timf1p_ref, int pa)
+{
+  if (!hip_rx) return;
+  if (lrh_export_fft1_net(hip_rx, &fft1_float[pa], timf1p_ref, gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1) != 0) lirerr(1479);
+}
+/* NET_RXOUT_TIMF2, float format: `mm` floats of {weak, strong} samples from timf2_pt on (rxin.c:944-966 consumes 2*twice_rxchan floats per
+   twice_rxchan floats it sends, mm*2 bytes in all) */
+void hip_net_timf2(int pt, int mm)
+{
+  if (hip_rx && mm > 0) hip_ring_span(LRH_RING_TIMF2_FLOAT, timf2_float, pt & ~3, (mm + 3) & ~3, timf2_size);
+}
+/* NET_RXOUT_FFT2: `count` floats of fft2_float from fft2_pt on (rxin.c:1026-1035) */
+void hip_net_fft2(int pt, int count)
+{
+  if (hip_rx && count > 0) hip_ring_span(LRH_RING_FFT2_FLOAT, fft2_float, pt, count, max_fft2n * 2 * hip_n2);
 }

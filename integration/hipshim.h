@@ -28,5 +28,8 @@ void hip_fft1_mix1_fixed(void);       /* second fft off (Linrad's default): mix1
 void hip_fft2_mix1_afc(void);         /* AFC on (default for weak-signal CW): mix1.c:863 / 1044, call sites wcw.c:1737 / 1700 */
 void hip_fft1_mix1_afc(void);
 void hip_compute_timf2_powersum(void);   /* wcw.c:80 (S/N meter)                                                              */
+void hip_net_fft1(int timf1p_ref, int fft1_pa);   /* NET_RXOUT_FFT1: the retired batch into the host ring before the memcpy of wcw.c:1024-1043 */
+void hip_net_timf2(int timf2_pt, int mm);         /* NET_RXOUT_TIMF2 / _FFT2: the span the network thread is about to walk (rxin.c:944, 1026) */
+void hip_net_fft2(int fft2_pt, int count);
 struct lrh_ctx *hip_context(void);    /* the context behind the hooks (diagnostics, tests)                                    */
 #endif

@@ -60,13 +60,17 @@ def func_top(lines, signature, new):
 
 def edit_globdef(L):
     insert(L, r"^#define GPU_CUDA 2", "#define GPU_HIP 3\n")
-    replace(L, r"define MAX_FFT_VERSIONS", "21", "22")
+    replace(L, r"define MAX_FFT_VERSIONS", "21", "23")
 
 
 def edit_fft1var(L):
     # fft_cntrl[21]: window storage 1, no permute table, max_n 16 (65536 with the second fft off; buf.c:335 caps it at 15 with it on), gpu = GPU_HIP
-    insert(L, r'"Double precision"\}', ',{1,0,16,0,0,GPU_HIP,0,1,0,   "HIP MI355X"}                        //21\n')
+    insert(L, r'"Double precision"\}', ',{1,0,16,0,0,GPU_HIP,0,1,0,   "HIP MI355X"}                        //21\n'
+           # real samples ("normal audio" / direct sampling): permute 2 like the reference's own real version 2, which is what make_filcorrstart
+           # (fft1.c:4659) and the back-transform table (buf.c:1033, 1318) look at; the window storage mode is host-only and unused
+           ',{1,2,14,0,0,GPU_HIP,0,1,0,   "HIP MI355X real"}                   //22\n')
     replace(L, r"1 chan direct conversion \(IQ\)", "19, -1}", "19, 21}")
+    replace(L, r"1 chan normal audio", "4, -1,", "4, 22,")
 
 
 def edit_buf(L):
@@ -82,12 +86,18 @@ def edit_wcw(L):
            where="before", start=i)
     insert(L, r"^errexit:;", "if(fft1_use_gpu == GPU_HIP)hip_close();\n", start=i)
     func_top(L, r"^void compute_timf2_powersum\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_compute_timf2_powersum();return;}\n")
+    # NET_RXOUT_FFT1 (wcw.c:1024-1043): the multicast payload is memcpy'd from the host ring fft1_float, which version 21 leaves empty: the
+    # transforms of the batch just retired are brought into it first (worker path: the block worker k read; no-worker path: the block before timf1p_px)
+    i = insert(L, r"^void wideband_dsp\(void\)", "", where="after")
+    insert(L, r"memcpy\(&fft1_netsend_buffer\[fft1net_pa\],", "            if(fft1_use_gpu == GPU_HIP)hip_net_fft1(inptr_fft1b[k], fft1_pa);\n", where="before", start=i, nth=1)
+    insert(L, r"memcpy\(&fft1_netsend_buffer\[fft1net_pa\],", "          if(fft1_use_gpu == GPU_HIP)hip_net_fft1((timf1p_px-timf1_blockbytes+timf1_bytes)&timf1_bytemask, fft1_pa);\n",
+           where="before", start=i, nth=2)
 
 
 def edit_fft1(L):
     after_last_include(L)
     i = insert(L, r"^void fft1_b\(", "", where="after")
-    insert(L, r"^\s+default:\s*$", "    case 21:\n// HIP on MI355X: the transform, the correction of fft1_c and every ring behind it stay on the device.\n"
+    insert(L, r"^\s+default:\s*$", "    case 21:\n    case 22:\n// HIP on MI355X: the transform, the correction of fft1_c and every ring behind it stay on the device.\n"
            "    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
            where="before", start=i)
     func_top(L, r"^void fft1_c\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_c();return;}\n")
@@ -128,6 +138,10 @@ def edit_rxin(L):
     i = insert(L, r"^void finish_rx_read\(", "", where="after")
     # the block the input thread has just filled sits at timf1_char[timf1p_pa]: hand it to the device before the event is posted
     insert(L, r"^// Set the EVENT_TIMF1 condition", "if(fft1_use_gpu == GPU_HIP)hip_timf1_new(timf1p_pa, snd[RXAD].block_bytes);\n", where="before", start=i)
+    # NET_RXOUT_TIMF2 / NET_RXOUT_FFT2 (rxin.c:919-1060): the sender walks the host rings timf2_float / fft2_float from timf2_pt / fft2_pt;
+    # with version 21 the span it is about to walk is fetched from the device first
+    insert(L, r"net_rxdata_timf2\.userx_no=-ui\.rx_rf_channels;", "      if(fft1_use_gpu == GPU_HIP)hip_net_timf2(timf2_pt, mm);\n", where="before")
+    insert(L, r"charbuf=\(char\*\)\(fft2_float\);", "        if(fft1_use_gpu == GPU_HIP)hip_net_fft2(fft2_pt, mm/4);\n", where="before")
 
 
 EDITS = {"globdef.h": edit_globdef, "fft1var.c": edit_fft1var, "buf.c": edit_buf, "wcw.c": edit_wcw, "fft1.c": edit_fft1,

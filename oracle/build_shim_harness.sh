@@ -1,14 +1,21 @@
 #!/bin/bash
 # oracle/build_shim_harness.sh -- TEST INFRASTRUCTURE, build container only (needs the reference tree).
 #
-# Builds oracle/_ref/shim_harness: the head-less reference driver (oracle/ref_harness.c) linked with the reference objects as
-# integration/linrad_hip.patch leaves them + integration/hipshim.c compiled over the oracle's C ABI (oracle/shim_alias.h), so the
-# Linrad-side glue EXECUTES: fft1_b case 21 -> fft1_c -> make_timf2 -> first_noise_blanker -> make_fft2 -> fft2_mix1_* (and the
-# second-fft-off chain fft1_c -> fft1_mix1_*) run through the reference's own, patched, call sites with the device replaced by
-# liblinrad_oracle.so.  tests/test_shim_exec_cpu.py compares what Linrad would see on the host with the unpatched goldens.
+# Builds, from the reference objects as integration/linrad_hip.patch leaves them + the head-less driver oracle/ref_harness.c:
+#
+#   oracle/_ref/shim_harness      integration/hipshim.c compiled over the ORACLE's C ABI (oracle/shim_alias.h: lrh_* -> lro_*), so the
+#                                 Linrad-side glue executes without a GPU (tests/test_shim_exec_cpu.py)
+#   oracle/_ref/shim_harness_hip  the same objects, the same driver, hipshim.c compiled AS SHIPPED and linked to
+#                                 linrad_amd/liblinrad_hip.so -- what a patched xlinrad64 executes: patched call sites -> hipshim.c ->
+#                                 the HIP library with lrh_timf1_write_async, lrh_host_register and the pinned read-backs.  Runs on the GPU
+#                                 box only (tests/test_gpu_shim.py); it travels there like ref_harness (oracle/_ref is not gpurun-ignored)
+#                                 and finds the library through $ORIGIN.
+#
+# fft1_b case 21 -> fft1_c -> make_timf2 -> first_noise_blanker -> make_fft2 -> fft2_mix1_* (and the second-fft-off chain
+# fft1_c -> fft1_mix1_*) run through the reference's own, patched, call sites.
 #
 # The patched copies of the reference sources live in a scratch directory under /tmp for the duration of the build; only
-# objects and the binary are written, and only into oracle/_ref/ (git-ignored).
+# objects and the binaries are written, and only into oracle/_ref/ (git-ignored).
 set -e
 REF=${REF:-/root/reference}
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -21,7 +28,7 @@ trap 'rm -rf "$T"' EXIT
 OUT="$HERE/_ref/shim"
 mkdir -p "$OUT"
 cp "$REF"/*.h "$T"/
-TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c"
+TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c spursub.c"
 for f in $TOUCHED; do cp "$REF/$f" "$T/"; done
 (cd "$T" && patch -s -p1 --no-backup-if-mismatch < "$ROOT/integration/linrad_hip.patch")
 cp "$ROOT/integration/hipshim.c" "$ROOT/integration/hipshim.h" "$T"/
@@ -35,8 +42,16 @@ for s in $SRC; do
   gcc $CFLAGS -I"$T" -I"$ROOT/include" -c "$src" -o "$OUT/$s.o"
   OBJ="$OBJ $OUT/$s.o"
 done
+# (1) the glue over the oracle's ABI
 gcc -O2 -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" -c "$T/hipshim.c" -o "$OUT/hipshim.o"
 gcc -O1 -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim.o" \
     -o "$HERE/_ref/shim_harness" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
-    -Wl,-rpath,"$HERE" -Wl,-rpath,"$ROOT/linrad_amd" -lm -lpthread -Wl,--unresolved-symbols=ignore-all
+    -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
 echo "built $HERE/_ref/shim_harness"
+# (2) the glue as shipped, over liblinrad_hip.so (no alias header: lrh_* are the library's own entry points)
+gcc -O2 -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$ROOT/include" -c "$T/hipshim.c" -o "$OUT/hipshim_hip.o"
+gcc -O1 -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim_hip.o" \
+    -o "$HERE/_ref/shim_harness_hip" -L"$ROOT/linrad_amd" -llinrad_hip \
+    -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
+if nm -D --undefined-only "$HERE/_ref/shim_harness_hip" | grep -q ' lro_'; then echo "shim_harness_hip references the oracle"; exit 3; fi
+echo "built $HERE/_ref/shim_harness_hip"

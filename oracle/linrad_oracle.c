@@ -531,6 +531,16 @@ int lro_fft1_b(lro_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   return LRH_OK;
 }
 
+/* NET_RXOUT_FFT1 payload (wcw.c:1024-1043, network.c:383-388): the transforms as fft1_b leaves them, i.e. without the filter correction
+   that lro_fft1_b folds into its store; recomputed from the timf1 ring like lrh_export_fft1_net does */
+int lro_export_fft1_net(lro_ctx *c, float *dst, int timf1p_ref, int batch)
+{
+  if (!c || !dst || batch < 1) return LRH_EINVAL;
+  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4);
+  for (int b = 0; b < batch; b++) fft1_one(c, (timf1p_ref + b * blockbytes) & c->timf1_bytemask, dst + (size_t)b * 2 * c->N1);
+  return LRH_OK;
+}
+
 /* new_fft1_averages, wide_graph.c:1003-1032 */
 static void new_fft1_averages(lro_ctx *c, int ptr, int ia, int ib)
 {

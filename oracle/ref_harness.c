@@ -43,6 +43,7 @@
    integration/hipshim.c is linked over the oracle's C ABI (oracle/shim_alias.h), so the stage functions called below are the
    reference's own entry points handing over to the glue.  The dump then holds what Linrad sees on the host (sums, lines,
    pointers, scalars, timf3) plus, fetched at the end, the device-resident rings. */
+#include "linrad_hip.h"
 #include "hipshim.h"
 #endif
 
@@ -123,6 +124,14 @@ static const char *arg(int argc, char **argv, const char *k, const char *def)
    THREAD_TIMF2 runs fft1_c / make_timf2 for every finished transform and then the blanker (wcw.c:401-441); THREAD_SECOND_FFT runs
    make_fft2 while a transform's worth of samples is released (wcw.c:250-304); the narrowband thread runs fft2_mix1_fixed and
    what follows (wcw.c:1240-1405).  Hand-offs: binary auto-reset condition events like lxsys.c:415-447. ---- */
+/* the oracle (oracle/_ref/shim_harness: hipshim.c over lro_*, SHIM_ALIAS_H) is not thread safe -- the HIP library is, and that is what
+   shim_harness_hip puts under test -- so over the oracle the free-running stage threads take one lock around each stage call */
+#ifdef SHIM_ALIAS_H
+static pthread_mutex_t stage_big_lock = PTHREAD_MUTEX_INITIALIZER;
+#define SLOCK(call) do { pthread_mutex_lock(&stage_big_lock); call; pthread_mutex_unlock(&stage_big_lock); } while (0)
+#else
+#define SLOCK(call) do { call; } while (0)
+#endif
 enum { TEV_TIMF2, TEV_FFT2, TEV_READY, TEV_SPACE, TEV_DONE, TEV_DO, TNEV = TEV_DO + 6 };
 static pthread_mutex_t tev_m[TNEV]; static pthread_cond_t tev_c[TNEV]; static volatile int tev_f[TNEV];
 static void tev_set(int n) { pthread_mutex_lock(&tev_m[n]); tev_f[n] = 1; pthread_cond_signal(&tev_c[n]); pthread_mutex_unlock(&tev_m[n]); }
@@ -135,7 +144,7 @@ static void *th_fft1b(void *arg)
   for (;;) {
     tev_await(TEV_DO + k);
     if (TH.job[k].busy < 0) return NULL;
-    fft1_b(TH.job[k].inptr, &fft1_float[TH.job[k].out], TH.tmp[k], k);
+    SLOCK(fft1_b(TH.job[k].inptr, &fft1_float[TH.job[k].out], TH.tmp[k], k));
     TH.job[k].busy = 2;
     tev_set(TEV_DONE);
   }
@@ -145,8 +154,8 @@ static void *th_timf2(void *arg)
   for (;;) {
     tev_await(TEV_TIMF2);
     while (fft1_na != fft1_nb) {
-      while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
-      first_noise_blanker();
+      while (fft1_na != fft1_nb) { SLOCK(fft1_c()); SLOCK(make_timf2()); }
+      SLOCK(first_noise_blanker());
       if (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size) tev_set(TEV_FFT2);
       tev_set(TEV_SPACE);
     }
@@ -161,7 +170,7 @@ static void *th_fft2(void *arg)
     tev_await(TEV_FFT2);
     while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size && ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask) < max_fft2n - 1) {
       make_fft2_status = FFT2_NOT_ACTIVE;
-      while (make_fft2_status != FFT2_COMPLETE) make_fft2();
+      while (make_fft2_status != FFT2_COMPLETE) SLOCK(make_fft2());
       tev_set(TEV_READY); tev_set(TEV_SPACE);
     }
     if (TH.timf2_done && ((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) < 4 * TH.C * fft2_size) break;
@@ -175,7 +184,7 @@ static void *th_narrow(void *arg)
   for (;;) {
     tev_await(TEV_READY);
     while (fft2_nx != fft2_na) {
-      if (TH.fq_ok) fft2_mix1_fixed(); else fft2_nx = (fft2_nx + 1) & fft2n_mask;
+      if (TH.fq_ok) SLOCK(fft2_mix1_fixed()); else fft2_nx = (fft2_nx + 1) & fft2n_mask;
       TH.nfft2++;
       if (TH.n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * TH.C * fft3_size &&
                             ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) {
@@ -207,9 +216,13 @@ static void run_reference_threads(void)        /* the dispatcher = this thread (
   for (int k = 0; k < TH.workers; k++) pthread_create(&th[n++], NULL, th_fft1b, (void *)(long)k);
   for (int b = 0; b < TH.nblk; b++) {
     /* room in the rings (Linrad counts overruns instead, wcw.c:770-785) */
-    while (((fft1_na - fft1_nx + max_fft1n) & fft1n_mask) + inflight >= max_fft1n - 2 ||
-           ((timf2_pa - timf2_px + timf2_size) & timf2_mask) > timf2_size / 2) tev_await(TEV_SPACE);
-    if (inflight == TH.workers) { th_retire(oldest); oldest = (oldest + 1) % TH.workers; inflight--; }
+    for (;;) {
+      const int no_room = ((fft1_na - fft1_nx + max_fft1n) & fft1n_mask) + (inflight + 1) * fft1_muln >= max_fft1n - 1 ||
+                          ((timf2_pa - timf2_px + timf2_size) & timf2_mask) > timf2_size / 2;
+      if (inflight == TH.workers || (no_room && inflight > 0)) { th_retire(oldest); oldest = (oldest + 1) % TH.workers; inflight--; continue; }   /* a full ring empties only through retired transforms */
+      if (!no_room) break;
+      tev_await(TEV_SPACE);
+    }
     TH.job[next].inptr = timf1p_px; TH.job[next].out = out; TH.job[next].busy = 1;
     out = (out + fft1_mulblock) & fft1_mask;
     timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
@@ -221,6 +234,51 @@ static void run_reference_threads(void)        /* the dispatcher = this thread (
   TH.wide_done = 1; tev_set(TEV_TIMF2);
   for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
 }
+
+/* ---- shim_threads=1 (SHIM_HARNESS): every stage function is called from the thread Linrad calls it from with more than one CPU --
+   fft1_b from a worker (THREAD_FFT1B1, wcw.c:476-500), fft1_c / make_timf2 / first_noise_blanker / compute_timf2_powersum from
+   THREAD_TIMF2 (wcw.c:401-441), make_fft2 from THREAD_SECOND_FFT (wcw.c:250-304), fft2_mix1_* / fft1_mix1_* and what follows from the
+   narrowband thread (wcw.c:1240-1405), the limiter calls from THREAD_WIDEBAND_DSP (this thread, wcw.c:1124-1133) -- but handed over
+   in LOCK STEP: the caller waits for the stage to return, so the order of calls is the single-CPU one and every product can be held
+   against the unpatched goldens, while the library sees its context used from five host threads.  shim_threads=2 lets the same
+   threads run free (run_reference_threads above). ---- */
+enum { ST_WORKER, ST_TIMF2, ST_FFT2, ST_NARROW, ST_COUNT };
+static struct stage_thread { pthread_t th; pthread_mutex_t m; pthread_cond_t c; void (*fn)(void); int state; } ST[ST_COUNT];
+static int stage_threads_on = 0;
+static void *stage_main(void *a)
+{
+  struct stage_thread *t = a;
+  for (;;) {
+    pthread_mutex_lock(&t->m);
+    while (t->state != 1 && t->state != 3) pthread_cond_wait(&t->c, &t->m);
+    if (t->state == 3) { pthread_mutex_unlock(&t->m); return NULL; }
+    pthread_mutex_unlock(&t->m);
+    t->fn();
+    pthread_mutex_lock(&t->m); t->state = 2; pthread_cond_broadcast(&t->c); pthread_mutex_unlock(&t->m);
+  }
+}
+static void stage_start(void)
+{
+  for (int k = 0; k < ST_COUNT; k++) { pthread_mutex_init(&ST[k].m, NULL); pthread_cond_init(&ST[k].c, NULL); ST[k].state = 0; pthread_create(&ST[k].th, NULL, stage_main, &ST[k]); }
+  stage_threads_on = 1;
+}
+static void stage_stop(void)
+{
+  if (!stage_threads_on) return;
+  for (int k = 0; k < ST_COUNT; k++) { pthread_mutex_lock(&ST[k].m); ST[k].state = 3; pthread_cond_broadcast(&ST[k].c); pthread_mutex_unlock(&ST[k].m); pthread_join(ST[k].th, NULL); }
+  stage_threads_on = 0;
+}
+static void on_stage(int k, void (*fn)(void))
+{
+  if (!stage_threads_on) { fn(); return; }
+  struct stage_thread *t = &ST[k];
+  pthread_mutex_lock(&t->m); t->fn = fn; t->state = 1; pthread_cond_broadcast(&t->c);
+  while (t->state != 2) pthread_cond_wait(&t->c, &t->m);
+  t->state = 0; pthread_mutex_unlock(&t->m);
+}
+static struct { int inptr; float *out, *tmp; int handle; } fft1b_job;
+static void fft1b_stage(void) { fft1_b(fft1b_job.inptr, fft1b_job.out, fft1b_job.tmp, fft1b_job.handle); }
+#define ON(k, f) on_stage(k, f)
 
 /* per-block scalar trace */
 #define TR_COLS 16
@@ -293,7 +351,7 @@ int main(int argc, char **argv)
   ui.sample_shift = sshift; ui.rx_ad_speed = 1; ui.network_flag = 0; ui.operator_skil = 0;
   genparm[FIRST_FFT_SINPOW] = sinpow1; genparm[FIRST_FFT_VERNR] = 0;   /* -> fft_cntrl[7] radix-2 DIF C */
 #ifdef SHIM_HARNESS
-  genparm[FIRST_FFT_VERNR] = 7;                                        /* -> fft_cntrl[21] "HIP MI355X" (the patch's new column) */
+  genparm[FIRST_FFT_VERNR] = realin ? 4 : 7;                           /* -> fft_cntrl[21] "HIP MI355X" / [22] "HIP MI355X real" (the patch's new columns) */
 #endif
   genparm[FIRST_FFT_GAIN] = gain; genparm[FIRST_FFT_BANDWIDTH] = 100;
   genparm[SECOND_FFT_ENABLE] = second; genparm[FIRST_BCKFFT_VERNR] = 0; genparm[FIRST_BCKFFT_ATT_N] = att_n;
@@ -654,8 +712,15 @@ int main(int argc, char **argv)
 #ifdef SHIM_HARNESS
   /* what get_wideband_sizes (buf.c:247-257, patched) and wideband_dsp's start (wcw.c:576, patched) do with version 21 selected */
   if (fft_cntrl[FFT1_CURMODE].gpu != GPU_HIP) { fprintf(stderr, "version 21 not selected: FFT1_CURMODE %d\n", FFT1_CURMODE); return 2; }
-  fft1_use_gpu = GPU_HIP; gpu_fft1_batch_size = 1; gpu.fft1_device = 0; no_of_fft1b = 0;
-  if (AI("shim_refuse", 0) == 1) ui.network_flag = NET_RXOUT_FFT1;      /* a mode version 21 must refuse */
+  const int shim_threads = AI("shim_threads", 0);   /* 1: stage functions on Linrad's stage threads in lock step; 2: the same threads running free */
+  const int shim_batch = AI("shim_batch", 1);       /* gpu_fft1_batch_size = 2^gpu.fft1_batch_n transforms per fft1_b call (buf.c:248-264, 610-613) */
+  fft1_use_gpu = GPU_HIP; gpu_fft1_batch_size = shim_batch; gpu.fft1_device = 0; no_of_fft1b = shim_threads ? 1 : 0;
+  fft1_muln = shim_batch; fft1_mulblock = fft1_block * fft1_muln; timf1_blockbytes *= shim_batch;
+  if (shim_batch < 1 || (shim_batch & (shim_batch - 1)) || shim_batch > max_fft1n / 2 || nblk % shim_batch) { fprintf(stderr, "shim_batch: a power of two <= max_fft1n/2 that divides nblk\n"); return 2; }
+  if (AI("shim_refuse", 0) == 1) genparm[MIX1_NO_OF_CHANNELS] = 2;      /* a mode version 21 must refuse */
+  const int shim_net = AI("shim_net", 0);           /* 1: ui.network_flag asks for the FFT1 / TIMF2 / FFT2 multicasts: the hooks the patch puts in front of the senders'
+                                                       reads (wcw.c:1024-1043, rxin.c:944, 1026) are called where the senders would read, and the host rings they fill are dumped */
+  if (shim_net) ui.network_flag = NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2;
   { int rc = hip_open(); fprintf(stderr, "hip_open: %d\n", rc); if (rc != 0) { printf("{\"hip_open\": %d}\n", rc); fclose(fo); return AI("shim_refuse", 0) ? 0 : 3; } }
   hip_timf1_new(0, timf1_bytes);                                        /* finish_rx_read's hand-over (rxin.c:1425, patched), the whole recording at once */
 #endif
@@ -694,22 +759,44 @@ int main(int argc, char **argv)
     fclose(fo);
     return harness_err ? 3 : 0;
   }
-  for (int b = 0; b < nblk && !harness_err; b++) {
+#ifdef SHIM_HARNESS
+  if (shim_threads == 2) {                         /* free-running stage threads + fft1_b workers: final rings and pointers only */
+    if (!second || C != 1) { fprintf(stderr, "shim_threads=2: one channel, second fft on\n"); return 2; }
+    int workers = AI("shim_workers", 3);
+    if (workers < 1) workers = 1; if (workers > 6) workers = 6;
+    memset(&TH, 0, sizeof TH);
+    TH.nblk = nblk / shim_batch; TH.workers = workers; TH.C = C; TH.n3 = n3; TH.mix2on = mix2on; TH.N2 = N2; TH.fq_ok = fq >= 0;
+    no_of_fft1b = workers;
+    for (int k = 0; k < workers; k++) TH.tmp[k] = zalloc(sizeof(float) * (4 * C * N1 + 64));
+    run_reference_threads();
+    nfft2 = TH.nfft2;
+    goto run_done;
+  }
+  if (shim_threads == 1) stage_start();
+  const int blk_step = shim_batch;
+#else
+  const int blk_step = 1;
+#endif
+  for (int b = 0; b < nblk && !harness_err; b += blk_step) {
     if (lim_every > 0 && limrecs && (b % lim_every) == 0) {
       long r = b / lim_every; if (r >= nlimrec) r = nlimrec - 1;
       memcpy(liminfo, limrecs + r * N1, 4 * N1);
     }
-    fft1_b(timf1p_px, &fft1_float[fft1_pa], fftw_tmp, 0);
+    fft1b_job.inptr = timf1p_px; fft1b_job.out = &fft1_float[fft1_pa]; fft1b_job.tmp = fftw_tmp; fft1b_job.handle = 0;
+    ON(ST_WORKER, fft1b_stage);
+#ifdef SHIM_HARNESS
+    if (shim_net && b == 0) hip_net_fft1(timf1p_px, fft1_pa);            /* the dispatcher's NET_RXOUT_FFT1 branch (wcw.c:1038-1043, patched) */
+#endif
     if (b == 0) memcpy(fft1_first, &fft1_float[fft1_pa], 8 * C * N1);
     timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
     fft1_pa = (fft1_pa + fft1_mulblock) & fft1_mask;
     fft1_na = fft1_pa / fft1_block;
     if (fft1_nm != fft1n_mask) fft1_nm++;
     if (!second) {               /* second fft disabled: fft1_c, then the narrowband thread's fft1_mix1_fixed */
-      while (fft1_na != fft1_nb) fft1_c();
-      if (fq >= 0) {
-        if (afc) { AFC_SUPPLY(fft1_nx, fft1n_mask); fft1_mix1_afc(); } else
-        fft1_mix1_fixed();
+      while (fft1_na != fft1_nb) ON(ST_TIMF2, fft1_c);              /* THREAD_DO_FFT1C with more than one CPU (wcw.c:1070-1078) */
+      while (fq >= 0 && fft1_nx != fft1_nb) {                        /* narrowband_dsp: until fft1_nx has caught up (wcw.c:1690-1712) */
+        if (afc) { AFC_SUPPLY(fft1_nx, fft1n_mask); ON(ST_NARROW, fft1_mix1_afc); } else
+        ON(ST_NARROW, fft1_mix1_fixed);
         float *m = mixtrace + 8 * nfft2;
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
         m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft1_nx;
@@ -720,7 +807,7 @@ int main(int argc, char **argv)
       it0[9] = fft1_sumsq_pa; it0[10] = fft1_sumsq_counter; it0[15] = fft1_liminfo_cnt; it0[14] = nfft2; it0[8] = fft1_nx;
       continue;
     }
-    while (fft1_na != fft1_nb) { fft1_c(); make_timf2(); }
+    while (fft1_na != fft1_nb) { ON(ST_TIMF2, fft1_c); ON(ST_TIMF2, make_timf2); }
     if (C == 2 && !chain2) {     /* two channels: make_timf2, then (blanker2=1) the two-channel first_noise_blanker; fft2 / mix1 only with chain2=1 */
       int *it2 = itrace + TR_COLS * b; float *t2 = trace + TR_COLS * b;
       int pbeg2 = timf2p_fit;
@@ -736,14 +823,14 @@ int main(int argc, char **argv)
       continue;
     }
     int pbeg = timf2p_fit;
-    first_noise_blanker();
-    if (bp_block > 0) compute_timf2_powersum();
+    ON(ST_TIMF2, first_noise_blanker);
+    if (bp_block > 0) ON(ST_TIMF2, compute_timf2_powersum);
     while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * C * fft2_size) {     /* wcw.c:265-266 */
       int wptr = wg_waterf_ptr;
       if (spur) { ffts_na = fft2_na; ffts_nm = fft2_nm;          /* what the previous pass of second_fft left (wcw.c:288-289) */
         spur_freq_factor = (float)fft2_new_points / fft2_size; spur_max_d2 = PI_L * spur_freq_factor / spur_speknum; }   /* buf.c:480, 1152 (fft2_new_points is known by now) */
       make_fft2_status = FFT2_NOT_ACTIVE;
-      while (make_fft2_status != FFT2_COMPLETE) make_fft2();
+      while (make_fft2_status != FFT2_COMPLETE) ON(ST_FFT2, make_fft2);
       if (spur && no_of_spurs == 0 && nfft2 + 1 == spur_start) {   /* acquisition, tail of init_spur_elimination (spursub.c:282-309) */
         ffts_na = fft2_na; ffts_nm = fft2_nm;
         spurno = 0; spur_ampl[0] = 1; spur_noise[0] = 0.001; spur_avgd2[0] = 0;
@@ -766,8 +853,8 @@ int main(int argc, char **argv)
       }
       if (wg_waterf_ptr != wptr) { memcpy(wf_lines + (size_t)nwf * wg_xpixels, wg_waterf + wptr, 2 * wg_xpixels); nwf++; }
       if (fq >= 0) {
-        if (afc) { AFC_SUPPLY(fft2_nx, fft2n_mask); fft2_mix1_afc(); } else
-        fft2_mix1_fixed();
+        if (afc) { AFC_SUPPLY(fft2_nx, fft2n_mask); ON(ST_NARROW, fft2_mix1_afc); } else
+        ON(ST_NARROW, fft2_mix1_fixed);
         float *m = mixtrace + 8 * nfft2;
         m[0] = mix1_point[0]; m[1] = mix1_phase[0]; m[2] = mix1_phase_rot[0]; m[3] = mix1_phase_step[0];
         m[4] = mix1_old_phase[0]; m[5] = mix1_old_point[0]; m[6] = timf3_pa; m[7] = fft2_nx;
@@ -799,6 +886,10 @@ int main(int argc, char **argv)
     }
   }
 
+#ifdef SHIM_HARNESS
+  stage_stop();
+run_done:
+#endif
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   if (timing) {
     printf("{\"loop_seconds\": %.6f, \"blocks\": %d, \"samples\": %ld, \"fft2\": %d, \"cleared\": %d}\n",
@@ -810,7 +901,12 @@ int main(int argc, char **argv)
   /* the rings Linrad never sees with version 21, fetched for the comparison; everything else below is the host's own copy as the
      glue kept it (fft1_sumsq, fft1_slowsum, fft2_powersum_float, wg_waterf lines, timf3_float, timf2_blockpower, liminfo, scalars) */
   lrh_export(hip_context(), LRH_RING_FFT1_FLOAT, fft1_float, 0, (size_t)max_fft1n * fft1_block);
-  if (second) {
+  if (second && shim_net) {                          /* the network thread's walks (rxin.c:944-966, 1026-1035), a packet's worth at a time, from the pointers it keeps */
+    for (int pt = 0; pt < timf2_size; pt += 696) hip_net_timf2(pt, pt + 696 <= timf2_size ? 696 : timf2_size - pt);
+    for (int pt = 0; pt < 2 * N2 * max_fft2n; pt += 348) hip_net_fft2(pt, pt + 348 <= 2 * N2 * max_fft2n ? 348 : 2 * N2 * max_fft2n - pt);
+    lrh_export(hip_context(), LRH_RING_TIMF2_PWR, timf2_pwr_float, 0, timf2pow_size);
+    lrh_export(hip_context(), LRH_RING_FFT2_POWER, fft2_power_float, 0, (size_t)N2 * max_fft2n);
+  } else if (second) {
     lrh_export(hip_context(), LRH_RING_TIMF2_FLOAT, timf2_float, 0, timf2_size);
     lrh_export(hip_context(), LRH_RING_TIMF2_PWR, timf2_pwr_float, 0, timf2pow_size);
     lrh_export(hip_context(), LRH_RING_FFT2_FLOAT, fft2_float, 0, (size_t)2 * N2 * max_fft2n);

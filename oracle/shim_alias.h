@@ -18,6 +18,7 @@
 #define lrh_open lro_open
 #define lrh_close lro_close
 #define lrh_export lro_export
+#define lrh_export_fft1_net lro_export_fft1_net
 #define lrh_fft1_b lro_fft1_b
 #define lrh_fft1_c lro_fft1_c
 #define lrh_make_timf2 lro_make_timf2

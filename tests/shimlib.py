@@ -1,0 +1,209 @@
+"""Shared by tests/test_shim_exec_cpu.py (oracle/_ref/shim_harness: the Linrad-side glue over the oracle's ABI, build container) and
+tests/test_gpu_shim.py (oracle/_ref/shim_harness_hip: the same patched reference objects and the same glue linked to liblinrad_hip.so,
+GPU box): run the head-less driver of the PATCHED reference with fft1 version 21 selected and hold what Linrad sees on the host
+afterwards -- pointer globals after every block, blanker scalars, fft1_sumsq / fft1_slowsum, waterfall lines, fft2_powersum_float,
+timf3 (and fft3 / baseb_raw computed from it by the reference's own host code), the AFC tables, liminfo -- plus the device rings
+fetched at the end, against the goldens of the UNPATCHED compiled reference."""
+import os
+import subprocess
+import types
+
+
+import numpy as np
+
+from paritylib import compare_with_golden, golden_itrace, load_golden, relerr
+from refcases import case_params, clever_case, harness_args, lrh_config, sellim_case
+from refdump import load_dump
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_CASES = ["n10_n12", "n10_mix1only", "n10_n12_afc", "n10_afc_mix1only", "n10_n12_fft3", "n9_n11_sin3",
+                "n10_n12_dword",                                 # int32 samples with an I/Q sample skew (DWORD_INPUT, ui.sample_shift)
+                "n9_n11_real", "n8_n10_real_dword_rev"]          # real samples: fft1 version 22 (fft1_reherm_dit_one's job, fft1_re.c:32-131)
+
+
+def run_harness(harness, args, tmp_path, files, timeout=600):
+    paths = {}
+    for k, arr in files.items():
+        paths[k] = str(tmp_path / f"{k}.bin")
+        arr.tofile(paths[k])
+    fo = str(tmp_path / "out.bin")
+    r = subprocess.run([harness] + args(paths, fo), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "hip_open: 0" in r.stderr
+    return load_dump(fo)
+
+
+def check_golden_case(harness, tmp_path, name, extra=(), tol=1e-5):
+    """one golden case through the patched call sites; `extra`: more harness arguments (shim_threads=1 ...)"""
+    d, g = case_params(name), load_golden(name)
+    dump = run_harness(harness, lambda p, fo: harness_args(d, p["in"], p["lim"], fo) + list(extra), tmp_path, {"in": g["iq"], "lim": g["liminfo"]})
+    cfg = lrh_config(d, g["iq"], max_batch=1)
+    out = {k: dump[k] for k in ("fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float", "timf2_pwr_float", "fft2_float",
+                                "fft2_power_float", "fft2_powersum_float", "timf3_float")}
+    out["itrace"] = golden_itrace(dump)
+    out["wf_lines"] = dump["wf_lines"].reshape(-1, cfg.wf_xpixels)
+    out["mixtrace"] = dump["mixtrace"].reshape(-1, 8).astype(np.float64)[:int(dump["final"][10])]
+    out["cfg"] = cfg
+    out["api"] = types.SimpleNamespace(get_table=lambda t, n: g[t][:n])
+    if d["fft3_n"]:      # the reference's own make_fft3_all / fft3_mix2 ran on the host from the timf3 blocks the glue brought back
+        out.update(fft3=dump["fft3"], fft3_ptrs=dump["fft3_ptrs"][1:], baseb_raw=dump["baseb_raw"], baseb_ptrs=dump["baseb_ptrs"])
+    if d["blockpower_block"]:
+        out.update(timf2_blockpower=dump["timf2_blockpower"], blockpower_ptrs=dump["blockpower_ptrs"])
+    if d["afc"]:
+        out["afc_tables"] = np.stack([dump["afc_fq_mid"], dump["afc_fq_slope"], dump["afc_fq_curv"], dump["afc_fq_start"]])
+    # do_mix1 parks the raw second half of its newest block beyond timf3_pa until the next block adds to it (mix1.c:188-194);
+    # consumers read up to timf3_pa, and that is what comes back to the host: the parked half block is left out of the comparison
+    pa, blk = int(dump["final"][9]), int(dump["mixtrace"].reshape(-1, 8)[0, 6]) if dump["mixtrace"].size >= 8 else 0
+    g = dict(g)
+    if blk > 0:
+        idx = (pa + np.arange(blk)) % out["timf3_float"].size
+        out["timf3_float"] = out["timf3_float"].copy()
+        g["timf3_float"] = g["timf3_float"].copy()
+        out["timf3_float"][idx] = 0
+        g["timf3_float"][idx] = 0
+    # fft1_c accumulates the running averaging period in place at fft1_sumsq_pa (fft1.c:4126-4169); the graphs read completed
+    # periods, and completed periods are what the glue brings back: an unfinished one at the end of the run is left out
+    it = dump["itrace"].reshape(-1, 16)
+    if it[-1, 10] != 0:
+        n1 = 1 << d["n1"]
+        out["fft1_sumsq"] = out["fft1_sumsq"].copy()
+        g["fft1_sumsq"] = g["fft1_sumsq"].copy()
+        out["fft1_sumsq"][it[-1, 9]:it[-1, 9] + n1] = 0
+        g["fft1_sumsq"][it[-1, 9]:it[-1, 9] + n1] = 0
+    assert np.array_equal(dump["final"], g["final"]), "final ring pointers differ"
+    # (the HIP path never stores the raw half block the reference parks beyond timf2_pa, timf2.c:1018-1025; nothing reads it: masked)
+    rep = compare_with_golden(out, g, tol=tol, mask_pending_timf2=True)
+    if "shim_net=1" in extra:
+        # NET_RXOUT_FFT1 / TIMF2 / FFT2 on: the hooks in front of the senders' reads filled the host rings (timf2_float and fft2_float above came
+        # through hip_net_timf2 / hip_net_fft2 a packet's worth at a time); block 0 of fft1_float as the dispatcher's memcpy would have found it
+        # is the transform BEFORE fft1_c's filter correction (network.c:383-388)
+        rep["fft1_net"] = relerr(dump["fft1_first_raw"], g["fft1_first_raw"])
+        assert np.count_nonzero(g["fft1_first_raw"]) > 100 and rep["fft1_net"] <= tol, rep
+    # scalars the GUI reads, as the glue keeps them (blank1.c:1550-1601): noise floor and limit are in itrace; the despiked power here
+    t, gt = dump["trace"].reshape(-1, 16), g["trace"].reshape(-1, 16)
+    for col in (0, 1, 2, 3, 5):          # noise floor, limit, stupid_blanker_rate, despiked_pwr[0], fft1_lowlevel_fraction
+        assert np.allclose(t[:, col], gt[:, col], rtol=2e-5, atol=1e-6), (col, np.abs(t[:, col] - gt[:, col]).max())
+    return {k: v for k, v in rep.items() if k not in ("abs_err", "abs_floor", "wf_boundary")}
+
+
+def check_sellim_case(harness, tmp_path, extra=()):
+    """fft1_update_liminfo (sellim.c:738, patched) -> hip_fft1_update_liminfo: the table after every update, as the glue publishes it
+    into Linrad's liminfo[], has the reference's routing pattern; make_timf2 routes with it"""
+    name = "sellim_n10_n12"
+    d, sl, iq = sellim_case(name)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
+    dump = run_harness(harness, lambda p, fo: [a for a in harness_args(d, p["in"], "none", fo) if not a.startswith("liminfo=")] + ["sellim=1"] +
+                       [f"{k}={v}" for k, v in sl.items()] + list(extra), tmp_path, {"in": iq})
+    n1 = 1 << d["n1"]
+    got, ref = dump["liminfo_trace"].reshape(-1, n1), g["liminfo_trace"].reshape(-1, n1)
+    batch = max([int(a.split("=")[1]) for a in extra if a.startswith("shim_batch=")] + [1])
+    batched = batch > 1
+    if batched:
+        # gpu_fft1_batch_size = 4 transforms per fft1_b call with fft_avg1num = 5: the limiter hook (wcw.c:1124) then runs in the middle of an
+        # averaging period, where the library reads the newest FINISHED period provided the glue hands fft1_sumsq_counter over
+        # (hip_sellim_par).  Reference = the oracle driven through its own ABI in the same call pattern with the counter in lrh_ptrs.
+        ref = oracle_sellim_batched(name, g, batch)
+    assert got.shape == ref.shape and (batched or np.array_equal(dump["liminfo_trace_blk"], g["liminfo_trace_blk"]))
+    assert np.array_equal(np.sign(got), np.sign(ref)), int(np.sum(np.sign(got) != np.sign(ref)))
+    pos = ref > 0
+    assert np.max(np.abs(got[pos] - ref[pos]) / ref[pos]) <= 2e-6
+    if batched:
+        return
+    it, gi = dump["itrace"].reshape(-1, 16), g["itrace"].reshape(-1, 16)
+    for col in (0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 15):     # pointers, fft1_lowlevel_points, noise floor, limit, fft1_liminfo_cnt
+        assert np.array_equal(it[:, col], gi[:, col]), col
+    assert relerr(dump["fft1_slowsum"], g["fft1_slowsum"]) <= 1e-5
+    assert np.array_equal(dump["timf2_pwr_float"] == 0, g["timf2_pwr_float"] == 0)
+
+
+def oracle_sellim_batched(name, g, batch):
+    """liminfo after every limiter update with `batch` transforms per fft1_b / fft1_c / make_timf2 call, in the harness's order"""
+    import sellimlib
+    from oracle_binding import open_oracle
+    d, _, iq = sellim_case(name)
+    cfg = lrh_config(d, iq, max_batch=batch)
+    api = open_oracle(cfg)
+    api.timf1_write(iq)
+    api.set_mix1_selfreq(d["fq"])
+    par = sellimlib.sellim_params(cfg, g)
+    par.exact_stats = 0
+    trace, cnt = [], 0
+    for _ in range(d["nblk"] // batch):
+        api.fft1_b(batch), api.fft1_c(batch), api.make_timf2(batch)
+        api.first_noise_blanker()
+        for _ in range(api.fft2_available()):
+            api.make_fft2(1)
+            api.fft2_mix1_fixed(1)
+        if api.p.fft1_liminfo_cnt != cnt:
+            api.fft1_update_liminfo(par)
+            cnt = api.p.fft1_liminfo_cnt
+            trace.append(api.get_liminfo())
+    api.close()
+    return np.array(trace)
+
+
+def check_clever_case(harness, tmp_path, extra=()):
+    """init_blanker's tables (buf.c:1771-2057, built by the reference itself in the harness) are handed over by hip_first_noise_blanker
+    when hg.clever_bln_mode is set: resume pointer, fitted-pulse counter, thresholds equal the unpatched reference's call by call"""
+    name = "clever_n10_n12"
+    d, cl, iq, lim, des = clever_case(name)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
+    dump = run_harness(harness, lambda p, fo: harness_args(d, p["in"], p["lim"], fo) + ["clever=1", f"desired={p['des']}", f"clever_factor={cl['clever_factor']}"] + list(extra),
+                       tmp_path, {"in": iq, "lim": lim, "des": des})
+    it, gi = dump["itrace"].reshape(-1, 16), g["itrace"].reshape(-1, 16)
+    for col in (0, 1, 2, 3, 6, 8, 12, 13):                 # timf2_pa, timf2p_fit, timf2_pn2, timf2_px, blanker_points, fft2_na, noise floor, limit
+        assert np.array_equal(it[:, col], gi[:, col]), col
+    t, gt = dump["trace"].reshape(-1, 16), g["trace"].reshape(-1, 16)
+    upd = it[:, 7] == 0                                     # calls that ended with a threshold update: the glue reads the scalars back there
+    assert np.array_equal(t[upd, 7], gt[upd, 7]) and np.any(gt[upd, 7] > 0), "clever_blanker_rate"
+    n1 = 1 << d["n1"]
+    keep = np.ones(dump["timf2_float"].size, bool)
+    keep[(int(dump["final"][3]) + np.arange(4 * (n1 // 2))) % keep.size] = False
+    assert relerr(dump["timf2_float"] * keep, g["timf2_float"] * keep) <= 1e-5
+    assert np.array_equal((dump["timf2_pwr_float"] == 0) & keep[::4], (g["timf2_pwr_float"] == 0) & keep[::4])
+
+
+def check_refusal(harness, tmp_path):
+    """hip_open answers non-zero (-> lirerr(1463), wcw.c hunk) instead of letting host code run on rings that stay empty"""
+    name = "n10_n12"
+    d, g = case_params(name), load_golden(name)
+    paths = {}
+    for k, arr in (("in", g["iq"]), ("lim", g["liminfo"])):
+        paths[k] = str(tmp_path / f"{k}.bin")
+        arr.tofile(paths[k])
+    r = subprocess.run([harness] + harness_args(d, paths["in"], paths["lim"], str(tmp_path / "o.bin")) + ["shim_refuse=1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and '"hip_open": 10' in r.stdout, r.stdout + r.stderr
+
+
+def check_free_running(harness, refh, tmp_path, name, workers):
+    """timf2_routine on its own thread beside the dispatcher and its fft1_b workers, second_fft and narrowband threads, all running
+    free (oracle/ref_harness.c run_reference_threads; events like lxsys.c:415-447).  The blanker is off: its thresholds follow the
+    call pattern, which the scheduler decides here.  Reference = the unpatched compiled reference in its single-CPU order."""
+    d, g = dict(case_params(name)), load_golden(name)
+    d["stupid"] = 0
+    fin, flim = str(tmp_path / "in.bin"), str(tmp_path / "lim.bin")
+    g["iq"].tofile(fin)
+    g["liminfo"].tofile(flim)
+    dumps = []
+    for exe, extra, tag in ((refh, [], "ref"), (harness, ["shim_threads=2", f"shim_workers={workers}"], "hip")):
+        fo = str(tmp_path / f"{tag}.bin")
+        r = subprocess.run([exe] + harness_args(d, fin, flim, fo) + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        dumps.append(load_dump(fo))
+    ref, hip = dumps
+    ptrs = [0, 1, 2, 3, 6, 7, 8, 9]      # fft1_pa fft1_nb fft1_nx timf2_pa timf2_px fft2_na fft2_nx timf3_pa; timf2p_fit / timf2_pn2 follow the blanker's call pattern
+    assert np.array_equal(ref["final"][ptrs], hip["final"][ptrs]), (ref["final"], hip["final"])
+    n1 = 1 << d["n1"]
+    keep2 = np.ones(ref["timf2_float"].size, bool)                 # the raw half block parked beyond timf2_pa (timf2.c:1018-1025)
+    keep2[(int(ref["final"][3]) + np.arange(4 * (n1 // 2))) % keep2.size] = False
+    blk3 = int(ref["mixtrace"].reshape(-1, 8)[0, 6])
+    keep3 = np.ones(ref["timf3_float"].size, bool)                 # and the one beyond timf3_pa (mix1.c:188-194)
+    keep3[(int(ref["final"][9]) + np.arange(blk3)) % keep3.size] = False
+    errs = {"fft1_float": relerr(hip["fft1_float"], ref["fft1_float"]), "fft1_slowsum": relerr(hip["fft1_slowsum"], ref["fft1_slowsum"]),
+            "timf2_float": relerr(hip["timf2_float"] * keep2, ref["timf2_float"] * keep2),
+            "timf2_pwr": relerr(hip["timf2_pwr_float"] * keep2[::4], ref["timf2_pwr_float"] * keep2[::4]),
+            "fft2_float": relerr(hip["fft2_float"], ref["fft2_float"]), "fft2_powersum": relerr(hip["fft2_powersum_float"], ref["fft2_powersum_float"]),
+            "timf3": relerr(hip["timf3_float"] * keep3, ref["timf3_float"] * keep3)}
+    print(name, errs)
+    assert np.count_nonzero(ref["timf3_float"]) > 100
+    assert max(errs.values()) <= 1e-5, errs

@@ -1,7 +1,8 @@
 """GPU: k_fft1w -- forward transform, fft1_c's sums and the weak stream of make_timf2 as one kernel inside lrh_wideband_dsp
 (fft1_size 16384, sin^2 window, int16 I/Q) with the sparse strong-stream pass behind it -- against the two-kernel path it replaces
 (k_fft1 + k_timf2<.., SS>, LRH_FUSE_FFT1=0), and cfg.fft1_float_sparse against the full spectrum ring.  Parity with the oracle at
-these sizes is tests/test_gpu_fullsize.py (lrh_wideband_dsp takes the fused path there by default)."""
+these sizes is tests/test_gpu_fullsize.py: test_fullsize_fused_kernel_matches_oracle (rounds of 32 blocks, full and sparse rings, launch
+counters asserted) for this kernel, test_fullsize_chain_matches_oracle (rounds of 16 blocks) for the two-kernel path."""
 import os
 
 import numpy as np
