@@ -68,10 +68,14 @@ def measured_traffic(stage, wl):
     if "t" not in _TRAFFIC:
         _TRAFFIC["t"] = None
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-            if t.get("source_sha16") == source_sha16():
-                _TRAFFIC["t"] = t
-            else:
+            for fn in ("r04_traffic.json", "r03_traffic.json"):
+                f = os.path.join(ROOT, "profiles", fn)
+                if not os.path.exists(f):
+                    continue
+                t = json.load(open(f))
+                if t.get("source_sha16") == source_sha16():
+                    _TRAFFIC["t"], _TRAFFIC["file"] = t, fn
+                    break
                 _TRAFFIC["stale"] = True
         except Exception:  # noqa: BLE001
             pass
@@ -457,7 +461,9 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         fused_sums = "sumsq" not in stages
 
         def alg_of(k):                                       # algorithmic bytes per sample of a stage in the form this workload runs it
-            return ALG_BYTES["fft2_single"] if (k == "fft2" and w["fft2_n"] <= 14) else ALG_BYTES[k]
+            if k == "fft2":                                  # with cfg.fft2_float_sparse the spectrum (8 B x 2 transforms per sample) is not written
+                return ALG_BYTES["fft2_single" if w["fft2_n"] <= 14 else "fft2"] - (ALG_BYTES["fft2_spectrum_out"] if cfg.fft2_float_sparse else 0.0)
+            return ALG_BYTES[k]
         for k, st in stages.items():
             st["avg_us_alone"] = alone.get(k)
             if k in ALG_BYTES:                             # stage rates (secondary metric): one batch per launch
@@ -495,7 +501,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 "frac_alg": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_counter": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "achieved_counter": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_traffic.json, same sources as this library) "
+                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_traffic.json, same sources as this library) "
                            "/ average launch time / 8 TB/s; frac (= frac_alg) prices the SURVEY 8d algorithmic bytes, part of which this "
                            "kernel eliminates (overlap read-modify-write 32 B, liminfo floats 8 B of 92 B per sample)",
                 "timer": "HIP events around each launch on the stream it is launched on, two-stream schedule of the timed loop "
@@ -506,7 +512,7 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                 "chain_alg_GBps": round(value / world * chain_alg / 1e3, 1),
                 "chain_frac_alg": round(value / world * chain_alg / 1e3 / HBM_PEAK_GBS, 4),
                 "selection": "the stage that moves the most HBM bytes per round; the stage with the longest stand-alone time is `longest_kernel`"}
-        if longest != dom:
+        if True:                                             # always: the byte-dominant stage and the longest kernel are different questions
             lt = measured_traffic(longest, res["workload"])
             lp = stages[longest]["launches"] / (nprof * args.rounds)
             l_s = stages[longest]["avg_us"] * 1e-6
@@ -514,11 +520,11 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                   "hbm_frac_alg": round(alg_of(longest) * (args.batch * M1) / lp / l_s / 1e9 / HBM_PEAK_GBS, 4),
                   "hbm_frac_counter": round(lt["traffic_bytes_per_launch"] / l_s / 1e9 / HBM_PEAK_GBS, 4) if lt else None}
             if longest == "fft1w":
-                # two 16384-point complex transforms per block (forward, weak-stream back transform) at 5 N log2 N flops each; the guide's
-                # vector fp32 peak (157.3 TFLOP/s).  Neither bytes nor flops bound it: one 512-thread workgroup per CU in lock step through
-                # six LDS exchanges per block (profiles/r03_sq_counters.txt)
+                # two fft1_size-point complex transforms per block (forward, weak-stream back transform) at 5 N log2 N flops each; the guide's
+                # vector fp32 peak (157.3 TFLOP/s).  Neither bytes nor flops bound it: the transforms' register <-> LDS exchanges, the issue
+                # of its memory operations and five workgroup barriers per block at two waves per SIMD (profiles/r04_sq_counters.txt)
                 flops = 2 * 5.0 * N1 * w["fft1_n"] * args.batch / lp
-                lk.update({"bound": "valu_fp32 / LDS exchange latency", "fp32_TFLOPs": round(flops / l_s / 1e12, 1), "fp32_peak_TFLOPs": 157.3,
+                lk.update({"bound": "valu_fp32 / LDS exchange / memory issue", "fp32_TFLOPs": round(flops / l_s / 1e12, 1), "fp32_peak_TFLOPs": 157.3,
                            "fp32_frac": round(flops / l_s / 1e12 / 157.3, 4)})
             roof["longest_kernel"] = lk
         trs = [measured_traffic(k, res["workload"]) for k in stages]
@@ -693,6 +699,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             secondary = {"error": repr(e)}
 
+    # third object of the default run: the configuration the Linrad glue opens (integration/hipshim.c: cfg.fft1_float_sparse =
+    # cfg.fft2_float_sparse = 0 -- Linrad's graphs, fft1_mix1_* and the AFC read the full rings), same workload as the headline
+    full_rings = None
+    if default_run and world == 1 and args.fft1_float == "sparse" and args.fft2_float == "sparse":
+        fa = argparse.Namespace(**vars(args))
+        fa.fft1_float = fa.fft2_float = "full"
+        try:
+            s = measure(fa, primary, rank, local_rank, world, dist, torch, hiplib, max(5, args.steps // 5), max(2, args.warmup // 2))
+            full_rings = {"config": {"workload": s["config_text"], "fft1_float": "every bin stored", "fft2_float": "every bin stored",
+                                     "note": "cfg.fft1_float_sparse = cfg.fft2_float_sparse = 0: what integration/hipshim.c opens"},
+                          "value": s["value"], "unit": "Msamples/s", "ms_per_step": s["ms_per_step"], "steps": s["steps"],
+                          "roofline": s["roofline"], "stages": s["stages"]}
+        except Exception as e:  # noqa: BLE001
+            full_rings = {"error": repr(e)}
+
     cpu = cpu_all = cpu_port = cpu_threads = None
     if rank == 0 and not args.no_cpu:
         cw = dict(primary)
@@ -727,7 +748,7 @@ def main():
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
             "routing": res.get("routing"), "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
-            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary,
+            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary, "full_rings": full_rings,
         }
         print(json.dumps(out), flush=True)
     return 0

@@ -26,10 +26,11 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 3      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
+#define LRH_ABI_VERSION 4      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
                                   3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
                                      lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions); lrh_exchange_fn takes the caller's own span;
-                                     lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart) */
+                                     lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart)
+                                  4: lrh_spur_permute (addition) */
 
 enum {
   LRH_OK = 0,
@@ -365,6 +366,10 @@ int lrh_spur_config(lrh_ctx *ctx, int max_spurs, int spur_speknum, const float *
    [max_fft2n][SPUR_WIDTH][2] (the bins of past transforms), spur_signal [max_fft2n][2], spur_ind [max_fft2n] (buf.c:1114-1131) */
 int lrh_spur_set(lrh_ctx *ctx, int n, const lrh_spur *spurs, const float *spur_table, const float *spur_signal, const int *spur_ind);
 int lrh_spur_get(lrh_ctx *ctx, int max, lrh_spur *spurs, int *n);          /* synchronous */
+/* The control plane drops spurs or reorders its list (remove_spur spur.c:596-631: the last spur takes the place of a dropped one;
+   swap_spurs spursub.c:755: the list is kept in order of frequency, init_spur_elimination spursub.c:315-343): afterwards the device tracks
+   n spurs, number i being what was number src[i] (loop state and history move along).  n <= the current count.  Synchronous. */
+int lrh_spur_permute(lrh_ctx *ctx, int n, const int *src);
 /* Acquisition on the device-resident spectra: store_new_spur (spursub.c:619-751: the seven bins from `pnt` of the
    newest spur_speknum transforms join the history, the summed power gives the frequency with decimals) and spur_phase_lock
    (spursub.c:1247-1426 with verify_spur_pll :1428-1843: up to five rounds of the loop on that history, accepted when the corrections

@@ -11,7 +11,7 @@ ROOT="$(dirname "$HERE")"
 T=$(mktemp -d /tmp/linrad_patch.XXXXXX)
 trap 'rm -rf "$T"' EXIT
 cp "$REF"/*.h "$T"/
-TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c"
+TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c spursub.c spur.c"
 for f in $TOUCHED; do cp "$REF/$f" "$T/"; done
 (cd "$T" && patch -p1 --no-backup-if-mismatch < "$HERE/linrad_hip.patch")
 cp "$HERE/hipshim.c" "$HERE/hipshim.h" "$T"/

@@ -35,6 +35,7 @@ static pthread_mutex_t hip_liminfo_lock = PTHREAD_MUTEX_INITIALIZER;
 static int hip_n1, hip_n2, hip_max_batch;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
 static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
+static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins store_new_spur was last asked to take */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 lrh_ctx *hip_context(void) { return hip_rx; }
@@ -51,7 +52,10 @@ static int hip_unsupported(void)
                                                                                                   filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
   if (fft1_correlation_flag != 0) return 4;
-  if (genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0) return 5;
+  /* spur removal: served with the second fft on (eliminate_spurs inside make_fft2, acquisition through the hooks in spursub.c); with the
+     second fft off the reference's fft1_c subtracts spurs from fft1_float (fft1.c:4242, 4432-4476), which version 21 does not do --
+     buf.c:836 zeroes MAX_NO_OF_SPURS itself when the AFC is off */
+  if (genparm[SECOND_FFT_ENABLE] == 0 && genparm[MAX_NO_OF_SPURS] != 0) return 5;
   if ((ui.network_flag & NET_RXOUT_TIMF2) != 0 && !swfloat) return 6;      /* the int16 payload is built from the MMX ring (rxin.c:968-990) */
   if (genparm[MIX1_NO_OF_CHANNELS] != 1) return 7;
   return 0;
@@ -93,6 +97,8 @@ int hip_open(void)
   hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
   lrh_set_liminfo(hip_rx, liminfo);
+  hip_spurs_on = genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
+  if (hip_spurs_on && lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { lrh_close(hip_rx); hip_rx = NULL; return LRH_EINVAL; }
   lrh_host_register(hip_rx, timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
   return 0;
 }
@@ -292,6 +298,90 @@ int hip_fft2_update_liminfo(void)
   return 1;
 }
 
+/* ---- spur removal (genparm[MAX_NO_OF_SPURS] != 0, AFC on, second fft on).  Tracking and subtraction -- eliminate_spurs, spur.c:36-494 -- run
+   on the device inside lrh_make_fft2.  The control plane stays Linrad's: spur_removal (wcw.c:204-247) and init_spur_elimination
+   (spursub.c:181-343) decide where to look, using spursearch_spectrum, the power summed over 3 spur_speknum transforms that make_fft2
+   keeps (fft2.c:673-699) -- hip_spur_after_fft2 keeps it from the new transform's power row; the two functions it calls to take a
+   carrier on, store_new_spur (spursub.c:619: history of the seven bins from fftx) and spur_phase_lock (:1247: closes the loop on that
+   history), are one device call, lrh_spur_acquire, on the resident spectra; remove_spur / swap_spurs (spur.c:596, spursub.c:755), with
+   which it drops a weaker neighbour and keeps the list in order of frequency, become lrh_spur_permute.  The loop state comes back after
+   every transform for the spur display and those decisions.  Not done: initial_remove_spur (spursub.c:346: the carrier is also taken
+   out of the spur_speknum transforms already in the ring) -- subtraction starts with the next transform. ---- */
+static void hip_spur_state_back(void)
+{
+  lrh_spur sp[64];
+  int n = 0, i;
+  if (lrh_spur_get(hip_rx, 64, sp, &n) != 0) { lirerr(1480); return; }
+  for (i = 0; i < n && i < genparm[MAX_NO_OF_SPURS]; i++) {
+    spur_location[i] = sp[i].spur_location; spur_flag[i] = sp[i].spur_flag; spur_freq[i] = sp[i].spur_freq;
+    spur_d0pha[i] = sp[i].spur_d0pha; spur_d1pha[i] = sp[i].spur_d1pha; spur_d2pha[i] = sp[i].spur_d2pha;
+    spur_ampl[i] = sp[i].spur_ampl; spur_noise[i] = sp[i].spur_noise; spur_avgd2[i] = sp[i].spur_avgd2;
+  }
+}
+int hip_store_new_spur(int pnt) { hip_spur_pnt = pnt; return 0; }      /* the history is taken on the device, by hip_spur_phase_lock */
+int hip_spur_phase_lock(int nx)
+{
+  lrh_ptrs q;
+  int locked = 0;
+  if (hip_spur_pnt < 0) return 1;
+  memset(&q, 0, sizeof q);
+  q.fft2_na = nx;                                                      /* ffts_na: the ring position behind the newest transform (wcw.c:288-289) */
+  if (lrh_spur_acquire(hip_rx, &q, hip_spur_pnt, &locked) != 0) locked = 0;
+  hip_spur_pnt = -1;
+  if (!locked) return 1;
+  hip_spur_state_back();                                               /* spurno == no_of_spurs: the new spur's loop state for init_spur_elimination's ordering */
+  return 0;
+}
+void hip_remove_spur(int ia)                                           /* remove_spur(ia): the last spur (number no_of_spurs, already counted down) takes slot ia */
+{
+  int src[64], i;
+  for (i = 0; i < no_of_spurs && i < 64; i++) src[i] = i;
+  if (ia >= 0 && ia < no_of_spurs) src[ia] = no_of_spurs;
+  if (lrh_spur_permute(hip_rx, no_of_spurs, src) != 0) lirerr(1481);
+  hip_spur_state_back();
+}
+void hip_swap_spurs(int ia, int ib)
+{
+  int src[64], i, n = 0;
+  lrh_spur sp[64];
+  if (lrh_spur_get(hip_rx, 64, sp, &n) != 0 || ia >= n || ib >= n) return;
+  for (i = 0; i < n; i++) src[i] = i;
+  src[ia] = ib; src[ib] = ia;
+  if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481);
+  hip_spur_state_back();
+}
+/* after every transform: the loop state for the display; the search spectrum of make_fft2 (fft2.c:673-699) from the transform's power row;
+   a spur the device reports unlocked for spur_speknum transforms is dropped when the search is automatic (spur.c:141-151: spur_relock has
+   failed there; here the next pass of the search may take the carrier on again) */
+static void hip_spur_after_fft2(int na)
+{
+  int i;
+  if (no_of_spurs > 0) {
+    int n = 0, src[64];
+    hip_spur_state_back();
+    if (genparm[AFC_ENABLE] == 2) {
+      for (i = 0; i < no_of_spurs && i < 64; i++) if (spur_flag[i] < spur_speknum) src[n++] = i;
+      if (n != no_of_spurs) { if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481); no_of_spurs = n; hip_spur_state_back(); }
+    }
+  }
+  if (spursearch_spectrum == NULL || spursearch_powersum == NULL || fftx_pwr == NULL) return;
+  {
+    float *pwra = &fftx_pwr[(size_t)na * hip_n2];
+    const int lo = spur_search_first_point, cnt = spur_search_last_point - spur_search_first_point + 1;
+    if (cnt <= 0) return;
+    lrh_export(hip_rx, LRH_RING_FFT2_POWER, &pwra[lo], (size_t)na * hip_n2 + lo, (size_t)cnt);
+    if (spursearch_sum_counter > 3 * spur_speknum) {
+      spursearch_sum_counter = 0;
+      for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_spectrum[i] = spursearch_powersum[i] + pwra[i];
+      spursearch_spectrum_cleanup();
+    } else {
+      if (spursearch_sum_counter == 0) for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_powersum[i] = pwra[i];
+      else for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_powersum[i] += pwra[i];
+      spursearch_sum_counter++;
+    }
+  }
+}
+
 void hip_make_fft2(void)
 {
   lrh_ptrs q;
@@ -308,6 +398,7 @@ void hip_make_fft2(void)
     lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
   }
   hip_afc_rows((q.fft2_na + fft2n_mask) & fft2n_mask, 1);
+  if (hip_spurs_on) hip_spur_after_fft2((q.fft2_na + fft2n_mask) & fft2n_mask);
   make_fft2_status = FFT2_COMPLETE;           /* second_fft loops until this (wcw.c:280-285) */
 }
 

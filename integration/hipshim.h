@@ -31,5 +31,9 @@ void hip_compute_timf2_powersum(void);   /* wcw.c:80 (S/N meter)                
 void hip_net_fft1(int timf1p_ref, int fft1_pa);   /* NET_RXOUT_FFT1: the retired batch into the host ring before the memcpy of wcw.c:1024-1043 */
 void hip_net_timf2(int timf2_pt, int mm);         /* NET_RXOUT_TIMF2 / _FFT2: the span the network thread is about to walk (rxin.c:944, 1026) */
 void hip_net_fft2(int fft2_pt, int count);
+int  hip_store_new_spur(int pnt);     /* spur acquisition (spursub.c:619, 1247) on the device-resident fft2 spectra; remove_spur / swap_spurs */
+int  hip_spur_phase_lock(int nx);
+void hip_remove_spur(int ia);
+void hip_swap_spurs(int ia, int ib);
 struct lrh_ctx *hip_context(void);    /* the context behind the hooks (diagnostics, tests)                                    */
 #endif

@@ -49,7 +49,7 @@ def replace(lines, anchor, old, new):
 def func_top(lines, signature, new):
     """first statement of a function: right behind the opening brace that follows its signature line"""
     for i, l in enumerate(lines):
-        if re.match(signature, l):
+        if re.match(signature, l) and ";" not in l:          # the definition, not a prototype
             j = i
             while "{" not in lines[j]:
                 j += 1
@@ -133,6 +133,21 @@ def edit_sellim(L):
     func_top(L, r"^void fft2_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP && hip_fft2_update_liminfo())return;\n")
 
 
+def edit_spursub(L):
+    after_last_include(L)
+    # acquisition of a carrier (init_spur_elimination's two calls, spursub.c:304-309) on the device-resident spectra; the subtraction from
+    # the transforms already in the ring is skipped (they are on the device; the loop subtracts from the next transform on)
+    func_top(L, r"^int store_new_spur\(int pnt\)", "if(fft1_use_gpu == GPU_HIP)return hip_store_new_spur(pnt);\n")
+    func_top(L, r"^int spur_phase_lock\(int nx\)", "if(fft1_use_gpu == GPU_HIP)return hip_spur_phase_lock(nx);\n")
+    func_top(L, r"^void initial_remove_spur\(void\)", "if(fft1_use_gpu == GPU_HIP)return;\n")
+    func_top(L, r"^void swap_spurs\(int ia, int ib\)", "if(fft1_use_gpu == GPU_HIP){hip_swap_spurs(ia,ib);return;}\n")
+
+
+def edit_spur(L):
+    after_last_include(L)
+    func_top(L, r"^void remove_spur\(int ia\)", "if(fft1_use_gpu == GPU_HIP){hip_remove_spur(ia);return;}\n")
+
+
 def edit_rxin(L):
     after_last_include(L)
     i = insert(L, r"^void finish_rx_read\(", "", where="after")
@@ -145,7 +160,8 @@ def edit_rxin(L):
 
 
 EDITS = {"globdef.h": edit_globdef, "fft1var.c": edit_fft1var, "buf.c": edit_buf, "wcw.c": edit_wcw, "fft1.c": edit_fft1,
-         "timf2.c": edit_timf2, "blank1.c": edit_blank1, "fft2.c": edit_fft2, "mix1.c": edit_mix1, "sellim.c": edit_sellim, "rxin.c": edit_rxin}
+         "timf2.c": edit_timf2, "blank1.c": edit_blank1, "fft2.c": edit_fft2, "mix1.c": edit_mix1, "sellim.c": edit_sellim, "rxin.c": edit_rxin,
+         "spursub.c": edit_spursub, "spur.c": edit_spur}
 
 
 def main():

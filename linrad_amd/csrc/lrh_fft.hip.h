@@ -41,8 +41,14 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return to_f2(cmulc
 __device__ __forceinline__ lrh_v2f cmul_v(lrh_v2f av, lrh_v2f bv)
 {
   lrh_v2f t, r;
+#ifdef LRH_CMUL_ONE_ASM
+  // one statement: the compiler puts a hazard nop between two asm statements whose second reads the first's result (it cannot see
+  // what they are); the pair needs none.  Costs an early-clobber temporary: only where registers are to spare (k_fft1v).
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\tv_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r), "=&v"(t) : "v"(av), "v"(bv));
+#else
   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+#endif
   return r;
 }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return to_f2(cmul_v(to_v(a), to_v(b))); }
@@ -154,6 +160,139 @@ template <int DIR> struct Dft<DIR, 16> {
       for (int d = 0; d < 4; d++) uf[c + 4 * d] = to_f2(u[4 * c + d]);
     }
   }
+};
+
+// 8-point DFT on native 2-vectors: y[0..8) natural in, out[c + 2 d] (natural order) -- s = 4a + b: radix 2 over a, w8^(b c), radix 4 over b
+template <int DIR> __device__ __forceinline__ void dft8_v(lrh_v2f (&y)[8])
+{
+  constexpr float sg = DIR < 0 ? -1.f : 1.f;
+  lrh_v2f t[8];
+#pragma unroll
+  for (int b = 0; b < 4; b++) { t[b] = y[b] + y[b + 4]; t[4 + b] = y[b] - y[b + 4]; }   // t[4c + b]
+  t[4 + 1] = cmulc_v(t[4 + 1], LRH_C8, sg * LRH_C8);
+  t[4 + 2] = cmulc_v(t[4 + 2], 0.f, sg);
+  t[4 + 3] = cmulc_v(t[4 + 3], -LRH_C8, sg * LRH_C8);
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    bfly4_v<DIR>(t[4 * c + 0], t[4 * c + 1], t[4 * c + 2], t[4 * c + 3]);
+#pragma unroll
+    for (int d = 0; d < 4; d++) y[c + 2 * d] = t[4 * c + d];
+  }
+}
+// 32-point DFT in registers: s = 8a + b (a < 4, b < 8): radix 4 over a (b fixed), twiddle w32^(b c), radix 8 over b; output index c + 4 d
+template <int DIR> struct Dft<DIR, 32> {
+  __device__ __forceinline__ static void run(float2 *uf)
+  {
+    constexpr float sg = DIR < 0 ? -1.f : 1.f;
+    lrh_v2f u[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) u[q] = to_v(uf[q]);
+#pragma unroll
+    for (int b = 0; b < 8; b++) bfly4_v<DIR>(u[b], u[b + 8], u[b + 16], u[b + 24]);          // u[8c + b] = y[b][c]
+#pragma unroll
+    for (int c = 1; c < 4; c++)
+#pragma unroll
+      for (int b = 1; b < 8; b++) {
+        const int e = (b * c) & 31;
+        if (e == 8) u[8 * c + b] = cmulc_v(u[8 * c + b], 0.f, sg);
+        else if (e == 16) u[8 * c + b] = -u[8 * c + b];
+        else u[8 * c + b] = cmulc_v(u[8 * c + b], lrh_cos32(e), sg * lrh_sin32(e));
+      }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      lrh_v2f y[8];
+#pragma unroll
+      for (int b = 0; b < 8; b++) y[b] = u[8 * c + b];
+      dft8_v<DIR>(y);
+#pragma unroll
+      for (int d = 0; d < 8; d++) uf[c + 4 * d] = to_f2(y[d]);
+    }
+  }
+};
+
+// ---- staged DFTs in registers (k_fft1v): R = NC x ND.  a(): first stage in place -- afterwards u[ND c + b] holds the input of the second
+// stage; b(u, c, y): second stage of group c, y[d] = output number out(c, d).  in(i): the order in which a() consumes its inputs, so that a
+// caller that loads them in that order can start on the first butterfly while the last loads are still on their way; the second stage hands
+// out ND finished values at a time, which the caller can store while the next group is being computed.
+template <int DIR, int R> struct SDft;
+template <int DIR> struct SDft<DIR, 32> {
+  static constexpr int NC = 4, ND = 8;
+  __host__ __device__ static constexpr int in(int i) { return (i >> 2) + 8 * (i & 3); }
+  __host__ __device__ static constexpr int out(int c, int d) { return c + 4 * d; }
+  __device__ __forceinline__ static void a(lrh_v2f (&u)[32])
+  {
+    constexpr float sg = DIR < 0 ? -1.f : 1.f;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      bfly4_v<DIR>(u[b], u[b + 8], u[b + 16], u[b + 24]);
+#pragma unroll
+      for (int c = 1; c < 4; c++) {
+        const int e = (b * c) & 31;
+        if (e == 0) continue;
+        if (e == 8) u[8 * c + b] = cmulc_v(u[8 * c + b], 0.f, sg);
+        else u[8 * c + b] = cmulc_v(u[8 * c + b], lrh_cos32(e), sg * lrh_sin32(e));
+      }
+    }
+  }
+  __device__ __forceinline__ static void b(const lrh_v2f (&u)[32], int c, lrh_v2f (&y)[8])
+  {
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = u[8 * c + i];
+    dft8_v<DIR>(y);
+  }
+};
+template <int DIR> struct SDft<DIR, 16> {
+  static constexpr int NC = 4, ND = 4;
+  __host__ __device__ static constexpr int in(int i) { return (i >> 2) + 4 * (i & 3); }
+  __host__ __device__ static constexpr int out(int c, int d) { return c + 4 * d; }
+  __device__ __forceinline__ static void a(lrh_v2f (&u)[16])
+  {
+    constexpr float sg = DIR < 0 ? -1.f : 1.f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      bfly4_v<DIR>(u[b], u[b + 4], u[b + 8], u[b + 12]);
+#pragma unroll
+      for (int c = 1; c < 4; c++) {
+        const int e = 2 * ((b * c) & 15);                  // w16^(b c) in 32nds of a turn
+        if (e == 0) continue;
+        if (e == 8) u[4 * c + b] = cmulc_v(u[4 * c + b], 0.f, sg);
+        else u[4 * c + b] = cmulc_v(u[4 * c + b], lrh_cos32(e), sg * lrh_sin32(e));
+      }
+    }
+  }
+  __device__ __forceinline__ static void b(const lrh_v2f (&u)[16], int c, lrh_v2f (&y)[4])
+  {
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = u[4 * c + i];
+    bfly4_v<DIR>(y[0], y[1], y[2], y[3]);
+  }
+};
+template <int DIR> struct SDft<DIR, 8> {
+  static constexpr int NC = 2, ND = 4;
+  __host__ __device__ static constexpr int in(int i) { return (i >> 1) + 4 * (i & 1); }
+  __host__ __device__ static constexpr int out(int c, int d) { return c + 2 * d; }
+  __device__ __forceinline__ static void a(lrh_v2f (&u)[8])
+  {
+    constexpr float sg = DIR < 0 ? -1.f : 1.f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { const lrh_v2f p = u[b], q = u[b + 4]; u[b] = p + q; u[4 + b] = p - q; }
+    u[4 + 1] = cmulc_v(u[4 + 1], LRH_C8, sg * LRH_C8);
+    u[4 + 2] = cmulc_v(u[4 + 2], 0.f, sg);
+    u[4 + 3] = cmulc_v(u[4 + 3], -LRH_C8, sg * LRH_C8);
+  }
+  __device__ __forceinline__ static void b(const lrh_v2f (&u)[8], int c, lrh_v2f (&y)[4])
+  {
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = u[4 * c + i];
+    bfly4_v<DIR>(y[0], y[1], y[2], y[3]);
+  }
+};
+template <int DIR> struct SDft<DIR, 4> {
+  static constexpr int NC = 1, ND = 4;
+  __host__ __device__ static constexpr int in(int i) { return i; }
+  __host__ __device__ static constexpr int out(int c, int d) { return d; }
+  __device__ __forceinline__ static void a(lrh_v2f (&u)[4]) { bfly4_v<DIR>(u[0], u[1], u[2], u[3]); }
+  __device__ __forceinline__ static void b(const lrh_v2f (&u)[4], int, lrh_v2f (&y)[4]) { y[0] = u[0]; y[1] = u[1]; y[2] = u[2]; y[3] = u[3]; }
 };
 
 // ---- compile-time pass plan -------------------------------------------------------------

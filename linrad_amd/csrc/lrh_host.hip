@@ -101,6 +101,8 @@ struct lrh_ctx {
   // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true, fuse_fft1_forced = false; Fft1Args f1_args; int f1_batch = 0;   // fuse_fft1_forced: LRH_FUSE_FFT1=1 given (tests: the fused kernel whatever the batch)
+  bool fuse_v = true;                // LRH_FFT1V=0: k_fft1w (round 3) instead of k_fft1v where both exist (fft1_size 16384, int16)
+  float2 *d_filtercorr_v = nullptr;  // the filter correction in k_fft1v's thread order (upload_filtercorr)
   bool f1_is_big = false; Fft1BigArgs f1_big;   // fft1_size 32768: the column step has run, the row step is what is parked (k_fft1r_t2c takes it)
   std::vector<int> fft2_keep_lo, fft2_keep_hi;   // per fft2 ring slot: the band lrh_make_fft2 stored (cfg.fft2_float_sparse)
   bool corr_on = false; int slowcorr_tot_avgnum = 0; float2 *d_xspec = nullptr, *d_corrsum = nullptr, *d_slowcorr = nullptr; double2 *d_slowcorr_tot = nullptr;   // lrh_set_correlation
@@ -208,6 +210,7 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
 // ... and, for every entry point that may look at or change what the chain has produced, the launches lrh_wideband_dsp still holds
 // back from its last round (one-round-late schedule kept across calls, see there) go out first
 static int flush_pending(lrh_ctx *c);
+static int upload_filtercorr(lrh_ctx *c);
 #define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
@@ -375,7 +378,7 @@ void lrh_close(lrh_ctx *c)
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   for (hipEvent_t ev : { c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
-  void *dev[] = { c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+  void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
@@ -469,6 +472,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
+  if (const char *e9v = getenv("LRH_FFT1V")) c->fuse_v = atoi(e9v) != 0;
   if (const char *e9 = getenv("LRH_FUSE_FFT1")) { c->fuse_fft1 = atoi(e9) != 0; c->fuse_fft1_forced = c->fuse_fft1; }   // 0: k_fft1 + k_timf2 also where k_fft1w would run; 1: k_fft1w also for rounds of a few blocks
   c->sums_on_main = cfg->fft2_n <= 14;
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
@@ -553,6 +557,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     for (size_t i = 0; i < itab.size(); i++) { int t = a3; if (t < 0) t = 0; if (t > N1 - 1) t = N1 - 1; itab[i] = t; a3 += a2; } }
   A(dev_alloc(c, &c->d_window1, real1 ? 2 * N1 : N1)); A(dev_alloc(c, &c->d_invwin1, N1)); A(dev_alloc(c, &c->d_window2, N2));
   A(dev_alloc(c, &c->d_fqwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_yfac, N1)); A(dev_alloc(c, &c->d_filtercorr, N1));
+  if (cfg->fft1_n >= 12 && cfg->fft1_n <= 14) A(dev_alloc(c, &c->d_filtercorr_v, N1));
   A(dev_alloc(c, &c->d_mixwin, c->Nm / 2 + 1)); A(dev_alloc(c, &c->d_sin2win, c->Nm)); A(dev_alloc(c, &c->d_cos2win, c->Nm));
   A(dev_alloc(c, &c->d_tw1, N1)); A(dev_alloc(c, &c->d_tw2, N2)); A(dev_alloc(c, &c->d_twm, c->Nm));
   const int fft2_la = cfg->fft2_n - cfg->fft2_n / 2, fft2_lb = cfg->fft2_n / 2;      // four-step split NA x NB
@@ -615,7 +620,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     }
     A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
     A(upload(c, c->d_mixwin, c->h_mixwin.data(), c->Nm / 2 + 1)); A(upload(c, c->d_sin2win, c->h_sin2win.data(), c->Nm)); A(upload(c, c->d_cos2win, c->h_cos2win.data(), c->Nm));
-    A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload(c, c->d_filtercorr, (const float2 *)c->h_filtercorr.data(), N1));
+    A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload_filtercorr(c));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
     if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
     if (c->fft1_big) { A(upload(c, c->d_tw1a, tw1a.data(), tw1a.size())); A(upload(c, c->d_tw1b, tw1b.data(), tw1b.size())); }
@@ -669,6 +674,20 @@ static int upload_filtercorr(lrh_ctx *c)
       eff[2 * i + 1] = b * c->ch2_c1 - a * c->ch2_c2;
     }
   HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, eff.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+  std::vector<float> perm;
+  if (c->d_filtercorr_v) {
+    // k_fft1v: thread t ends its forward transform on the bins kk(t) + T j, j = 0..31 (T = N1 / 32; kk: Fft1vGeom / kk_of in lrh_kernels.hip);
+    // the table in that order, [j][t], makes the 32 loads of a thread whole cache lines per wave
+    const int T = c->N1 / 32, B2 = c->cfg.fft1_n - 10, R2 = 1 << B2, KB = 5 - B2, NKB = 1 << KB;
+    perm.resize(2 * (size_t)c->N1);
+    for (int j = 0; j < 32; j++)
+      for (int t = 0; t < T; t++) {                        // [j / 2][t][j & 1]: two bins of a thread per 16-byte load, a wave's loads whole lines
+        const int lam = t & 31, kk = (t >> 5) + R2 * (lam & (NKB - 1)) + 32 * (lam >> KB), f = kk + T * j;
+        const size_t at = 2 * ((size_t)(j >> 1) * T + t) + (j & 1);
+        perm[2 * at] = eff[2 * f]; perm[2 * at + 1] = eff[2 * f + 1];
+      }
+    HIPCHK(c, hipMemcpyAsync(c->d_filtercorr_v, perm.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -883,6 +902,9 @@ int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   c->wl_on = false;
   if (!par) return LRH_OK;
+  // a coupled pair's round-level order (dsp_coupled) makes no limiter calls: the reference's two-channel limiter works on the channels' summed
+  // spectra with its limit scaled by rx_rf_channels, which is not built -- said here, not ignored there
+  if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "lrh_wideband_limiter: not with two coupled channels (the limiter calls are the caller's there)");
   { int rc = sellim_check(c, par, false); if (!rc && fft2_too) rc = sellim_check(c, par, true); if (rc) return rc; }
   c->wl_par = *par;
   if (par->fft1_desired) { c->wl_desired.assign(par->fft1_desired, par->fft1_desired + c->N1); c->wl_par.fft1_desired = c->wl_desired.data(); }
@@ -1020,6 +1042,38 @@ int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, cons
     HIPCHK(c, hipMemcpyAsync(c->d_spur_table, table, n * maxn * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_spur_signal, signal, n * maxn * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_spur_ind, ind, n * maxn * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->spur_n = n;
+  return LRH_OK;
+}
+// remove_spur / swap_spurs (spur.c:596-631, spursub.c:755): the control plane drops a spur or reorders the list; loop state and histories follow on the device
+int lrh_spur_permute(lrh_ctx *c, int n, const int *src)
+{
+  LRH_ENTER(c);
+  if (!c || n < 0 || n > c->spur_n || (n && !src)) return LRH_EINVAL;
+  if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
+  for (int i = 0; i < n; i++) if (src[i] < 0 || src[i] >= c->spur_n) return LRH_EINVAL;
+  const size_t maxn = c->cfg.max_fft2n;
+  const int old_n = c->spur_n;
+  if (n) {
+    std::vector<lrh_spur> sp(old_n); std::vector<float> tab((size_t)old_n * maxn * 14), sig((size_t)old_n * maxn * 2); std::vector<int> ind((size_t)old_n * maxn);
+    HIPCHK(c, hipMemcpyAsync(sp.data(), c->d_spurs, old_n * sizeof(lrh_spur), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tab.data(), c->d_spur_table, tab.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sig.data(), c->d_spur_signal, sig.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ind.data(), c->d_spur_ind, ind.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<lrh_spur> sp2(n); std::vector<float> tab2((size_t)n * maxn * 14), sig2((size_t)n * maxn * 2); std::vector<int> ind2((size_t)n * maxn);
+    for (int i = 0; i < n; i++) {
+      sp2[i] = sp[src[i]];
+      memcpy(&tab2[(size_t)i * maxn * 14], &tab[(size_t)src[i] * maxn * 14], maxn * 14 * sizeof(float));
+      memcpy(&sig2[(size_t)i * maxn * 2], &sig[(size_t)src[i] * maxn * 2], maxn * 2 * sizeof(float));
+      memcpy(&ind2[(size_t)i * maxn], &ind[(size_t)src[i] * maxn], maxn * sizeof(int));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_spurs, sp2.data(), n * sizeof(lrh_spur), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_table, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_signal, sig2.data(), sig2.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_spur_ind, ind2.data(), ind2.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->spur_n = n;
@@ -1194,7 +1248,9 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur));
     a.stamps = c->d_stamps;
   }
-  if (c->f1_defer && handle == 0 && c->cfg.fft1_n == 14 && !a.real && !a.dword && !a.shift_i && !a.shift_q && !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
+  // k_fft1w: fft1_size 16384, int16; k_fft1v: 4096 / 8192 / 16384, int16 or int32
+  if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && !a.real && !a.shift_i && !a.shift_q &&
+      !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
     if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
     c->f1_args = a; c->f1_batch = batch; c->f1_have = true;    // lrh_make_timf2 takes it from here (k_fft1w)
     return LRH_OK;
@@ -1385,9 +1441,28 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     w.have_prev = c->timf2_primed ? 1 : 0;
     w.ss_ring = sa.sumsq; w.ss_part = part; w.ss_mask = sa.sumsq_mask; w.ss_avg = sa.avg; w.ss_c0 = sa.c0; w.ss_pa0 = sa.pa0;
     w.batch = batch; w.spare_cus = a.spare_cus;
-    { ProfScope ps(c, "fft1w"); HIPCHK(c, launch_fft1w(w, c->cur, &c->ss_run)); }
+    w.filtercorr_v = c->d_filtercorr_v; w.max_wg = (int)(c->ss_part_stride / (2 * (size_t)c->N1));
+    static const bool v_stamps = getenv("LRH_FFT1V_EXP") && (atoi(getenv("LRH_FFT1V_EXP")) & 2);
+    if (v_stamps) {
+      if (!c->d_stamps) HIPCHK(c, hipMalloc(&c->d_stamps, 64 * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 64 * sizeof(unsigned long long), c->cur));
+      w.stamps = c->d_stamps;
+    }
+    { ProfScope ps(c, "fft1w");
+      if (c->fuse_v) HIPCHK(c, launch_fft1v(c->cfg.fft1_n, f.dword != 0, w, c->cur, &c->ss_run));
+      else HIPCHK(c, launch_fft1w(w, c->cur, &c->ss_run)); }
+    if (v_stamps) {
+      static int printed = 0;
+      unsigned long long h[64];
+      HIPCHK(c, hipMemcpyAsync(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
+      if (printed++ < 3) for (int wv = 0; wv < 2; wv++) {
+        fprintf(stderr, "fft1v stamps wave%d:", wv ? 4 : 0);
+        for (int i = 1; i < 32 && h[wv * 32 + i]; i++) fprintf(stderr, " %llu", h[wv * 32 + i] - h[wv * 32]);
+        fprintf(stderr, "\n");
+      }
+    }
     if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read
-    { ProfScope ps(c, "timf2s"); HIPCHK(c, launch_timf2_strong(a, batch, c->cur)); }
+    { ProfScope ps(c, "timf2s"); HIPCHK(c, launch_timf2_strong(c->cfg.fft1_n, a, batch, c->cur)); }
     const SumsqArgs ja = sa; const int run = c->ss_run;
     c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {
       ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, part, run, c->cur)); return LRH_OK; });
@@ -2354,7 +2429,7 @@ static int dsp_coupled(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   const bool fuse = c->fuse_sumsq && c->timf2_mode == 1 && c->d_ss_part;
   struct FuseGuard { lrh_ctx *c; ~FuseGuard() { c->ss_defer = false; c->ss_queue.clear(); c->f1_defer = false; if (c->f1_have) launch_parked_fft1(c); c->in_dsp--; } } guard{c};
   c->in_dsp++;
-  c->f1_defer = fuse && c->fuse_fft1 && !c->fft1_big && c->cfg.fft1_n == 14;
+  c->f1_defer = fuse && c->fuse_fft1 && !c->fft1_big && (c->cfg.fft1_n == 14 || (c->fuse_v && c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 13));
   while (nblocks > 0) {
     const int B = nblocks < batch ? nblocks : batch;
     if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
@@ -2434,6 +2509,9 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
                      ~HostTimer() { c->host_ms_dsp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->host_n_dsp++;
                                     c->host_cpu_ms_dsp += thread_cpu_ms() - cpu0; } } host_timer{c};
   int rc;
+  // a call that fails between parking the linear blanker's search and picking its result up must not leave the search marked as parked:
+  // every later blanker call would answer LRH_ESTATE
+  struct ClvGuard { lrh_ctx *c; bool ok = false; ~ClvGuard() { if (!ok) { c->clv_wait = false; c->clv_issued = false; } } } clv_guard{c};
   struct InDsp { lrh_ctx *c; InDsp(lrh_ctx *c_) : c(c_) { c->in_dsp++; } ~InDsp() { c->in_dsp--; } };
   // Small rounds are bound by the host's launches (~100 us per round), not by the kernels: the plain serial order has the
   // fewest stream operations and wins there (Msamples/s serial / lagged, fft1_size 16384: 82 / 80 at 1 block per round,
@@ -2449,7 +2527,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // (a call of a few blocks is a chain of single-workgroup latencies: there one block through k_fft1w -- forward and back transform in
   // one 512-thread workgroup -- takes longer than through k_fft1 and k_timf2 one after the other: 94 against 84 us per call of 1 block,
   // 149 against 127 at 4, even at 64; the fused kernel from 32 blocks per round)
-  c->f1_defer = fuse && c->fuse_fft1 && ((!c->fft1_big && c->cfg.fft1_n == 14 && (batch >= 32 || c->fuse_fft1_forced || c->cfg.fft1_float_sparse)) || fuse15);   // (a sparse ring has no full spectrum for k_timf2's overlap: always fused)
+  c->f1_defer = fuse && c->fuse_fft1 && ((!c->fft1_big && (c->cfg.fft1_n == 14 || (c->fuse_v && c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 13)) && (batch >= 32 || c->fuse_fft1_forced || c->cfg.fft1_float_sparse)) || fuse15);   // (a sparse ring has no full spectrum for k_timf2's overlap: always fused)
   auto sums = [&](int B) -> int {                // fft1_c: launches at once, or parked for the next make_timf2
     c->ss_defer = fuse; const int r = lrh_fft1_c(c, p, B); c->ss_defer = false; return r;
   };
@@ -2514,7 +2592,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       if ((!early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) || (rc = limiter2())) return rc;
       nblocks -= B;
     }
-    return LRH_OK;
+    clv_guard.ok = true; return LRH_OK;
   }
   // ---- two-stream schedules
   hipStream_t S1 = c->stream, S2 = c->stream2;
@@ -2605,13 +2683,13 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     if (carry_ok) {                                        // the last round stays parked: the next call (or flush_pending) issues it
       c->pend_b.swap(qb); c->pend_t.swap(qt);
       c->pend = true; c->pend_tail_flushed = tail_flushed; c->pend_batch = batch;
-      return LRH_OK;
+      clv_guard.ok = true; return LRH_OK;
     }
     if ((rc = side_blanker())) return rc;
     if (c->clv_wait && (rc = clever_late_finish(c, p))) return rc;     // linear blanker: the last round's resume point, then its dumb blanker
     if ((rc = main_tail())) return rc;
     HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
-    return LRH_OK;
+    clv_guard.ok = true; return LRH_OK;
   }
   // the side stream starts after everything already queued on the main stream
   HIPCHK(c, hipEventRecord(c->ev_side, S1)); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_side, 0));
@@ -2659,7 +2737,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   }
   // join: later API calls are ordered on the main stream only
   HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
-  return LRH_OK;
+  clv_guard.ok = true; return LRH_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- outputs

@@ -787,6 +787,400 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1w(Fft1wArgs a)
 }
 
 // =====================================================================================================
+// k_fft1v: the job of k_fft1w with both transforms laid out along the machine (round 4)
+// =====================================================================================================
+// k_fft1w moves every point through the LDS six times per block, each time behind two workgroup barriers, eight waves in lock step.
+// Here the index of a transform is split the way the hardware is: 32 registers x 32 lanes x 2^B2 half-waves (B2 = log2 N - 10).
+// Cooley-Tukey with n = T n1 + 32 n2 + n3, k = k1 + 32 k2 + T k3 (T = N/32 threads, n1 and n3 five bits, n2 B2 bits):
+//   P1  32-point DFT over n1 -- the registers, as the coalesced load x[r] = in[tid + T r] leaves them;        times W_T^(n2 k1)
+//   X1  the B2 bits of n2 (which half-wave) trade places with B2 register bits: the one exchange of the transform that crosses waves
+//   P2  2^B2-point DFTs over n2
+//   X2  the 5 bits of n3 (lanes 0..4) trade places with the registers: a 32 x 32 transpose inside each half-wave -- wave-private LDS,
+//       no barrier, the waves drift apart;                                                                    times W_N^(n3 (k1 + 32 k2))
+//   P3  32-point DFT over n3: bin k1 + 32 k2 + T k3, k3 in the registers, (k1, k2) = where the thread sits.
+// The back transform starts from exactly that arrangement (its most significant digit is in the registers) and runs the mirror image --
+// 32-point DFT, wave-private transpose, 32-point DFT, cross-wave exchange, 2^B2-point DFTs -- which ends with sample tid + T r in
+// register r: the coalesced store.  Per block: two barriered exchanges and two wave-private ones (k_fft1w: six barriered), six passes
+// (eight), five barriers (twelve).  Twiddles: three small tables in LDS (W_N^(m v) for v < T and m in {1,2,3,4,8,12,16}, stored at
+// v ^ (v >> 5) so that both transforms read it without bank conflicts; W_T^(m n2); W_1024^(m m1)), combined by products of at most
+// three factors.  The exchange buffer is unpadded: every access pattern below is conflict free by construction
+// (ds_write_b64: 16 consecutive lanes on 16 consecutive cells; ds_read_b64: 32 lanes on 32 consecutive cells, or on cells q ^ lane).
+// Results equal k_fft1w's to float32 rounding (different factorisation); same arguments, same sums, same rings.
+// one SGPR base and a 32-bit byte offset in a VGPR: global_load / global_store in their saddr form, one v_add per access at most
+// (a 64-bit pointer per access costs an SGPR pair each -- k_fft1v would need ~200 -- or two VALU adds)
+template <typename V> __device__ __forceinline__ V gld(const void *base, unsigned int byte_off) { return *reinterpret_cast<const V *>(reinterpret_cast<const char *>(base) + byte_off); }
+// LDS cells of the exchanges as single 8-byte accesses the compiler may not pair: ds_read2_b64 / ds_write2_b64 run at half the rate of
+// ds_read_b64 and bank per 128 B instead of 256 B (MI355X_MICROARCH.md, LDS)
+typedef unsigned long long lds_cell_t;
+typedef __attribute__((address_space(3))) volatile lds_cell_t lds_vcell_t;
+typedef __attribute__((address_space(3))) char lds_byte_t;
+// addressed in BYTES from the start of the buffer: a per-thread base plus (or xor) a constant, nothing to shift per access
+__device__ __forceinline__ void lds_put(float2 *lds, int byte, float2 v)
+{
+  lds_cell_t u; __builtin_memcpy(&u, &v, 8);
+  *(lds_vcell_t *)((lds_byte_t *)lds + byte) = u;
+}
+__device__ __forceinline__ float2 lds_get(const float2 *lds, int byte)
+{
+  const lds_cell_t u = *(lds_vcell_t *)((lds_byte_t *)lds + byte);
+  float2 v; __builtin_memcpy(&v, &u, 8); return v;
+}
+template <int LOG2N> struct Fft1vGeom {
+  static constexpr int N = 1 << LOG2N, T = N / 32, B2 = LOG2N - 10, R2 = 1 << B2, KB = 5 - B2, NKB = 1 << KB;
+  static constexpr int TN_ENT = 7;
+  static constexpr int TN = N, T1 = TN + TN_ENT * T, TB1 = T1 + 10 * R2, LDS_CELLS = TB1 + 10 * 32;
+  static_assert(B2 >= 2 && B2 <= 4, "fft1_size 4096, 8192, 16384");
+};
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// w^n for n = 4a + b from the table values w^1..w^3 (wb) and w^4, w^8, .. (wa)
+__device__ __forceinline__ float2 tw_pow(const float2 *wb, const float2 *wa, int n)
+{
+  const int a = n >> 2, b = n & 3;
+  return a == 0 ? wb[b - 1] : (b == 0 ? wa[a - 1] : cmul(wa[a - 1], wb[b - 1]));
+}
+// EXP (diagnostics, LRH_FFT1V_EXP): bit 0 no workgroup barriers (timing experiment, wrong results), bit 1 shader-clock stamps at the phase
+// boundaries (printed by lrh_make_timf2)
+// KEEP: every bin of the spectrum goes to the fft1 ring (a.keep_spec), through one more LDS exchange; else the strong bins only
+template <int LOG2N, bool DW, bool KEEP, int EXP = 0>
+__global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
+{
+  using G = Fft1vGeom<LOG2N>;
+  using Raw = typename std::conditional<DW, int2, short2>::type;
+  constexpr int P = 32, N = G::N, T = G::T, R2 = G::R2, KB = G::KB, NKB = G::NKB, HP = P / 2;
+  using F32 = SDft<+1, 32>; using F2 = SDft<+1, R2>; using B32 = SDft<-1, 32>; using B2 = SDft<-1, R2>;
+  __shared__ float2 lds[G::LDS_CELLS];
+  const int tid0 = threadIdx.x;
+  const int r0 = (int)blockIdx.x * a.run, r1 = min(r0 + a.run, a.batch);
+  if (r0 >= r1) return;
+  for (int idx = tid0; idx < G::TN_ENT * T; idx += T) {
+    const int e = idx / T, v = idx % T, mult = e < 3 ? e + 1 : 4 * (e - 2);
+    lds[G::TN + e * T + (v ^ (v >> 5))] = tw_dir<+1>(a.tw[mult * v]);
+  }
+  for (int idx = tid0; idx < 10 * R2; idx += T) {
+    const int e = idx / R2, v = idx % R2, mult = e < 3 ? e + 1 : 4 * (e - 2);
+    lds[G::T1 + idx] = tw_dir<+1>(a.tw[(mult * v * 32) & (N - 1)]);
+  }
+  for (int idx = tid0; idx < 320; idx += T) {
+    const int e = idx / 32, v = idx % 32, mult = e < 3 ? e + 1 : 4 * (e - 2);
+    lds[G::TB1 + idx] = tw_dir<+1>(a.tw[(mult * v * (N / 1024)) & (N - 1)]);
+  }
+  // where the thread sits after the forward transform: bins kk + T j (fft1_float order, DC at N/2), j in the registers
+  auto kk_of = [](int tid) { const int lam = tid & 31; return (tid >> 5) + R2 * (lam & (NKB - 1)) + 32 * (lam >> KB); };
+  unsigned int wk_cur[2], wk_first[2];
+  { const int kk = kk_of(tid0);
+    wk_cur[0] = a.pack_cur[kk]; wk_cur[1] = a.pack_cur[kk + T]; wk_first[0] = a.pack_prev[kk]; wk_first[1] = a.pack_prev[kk + T]; }
+  auto weak_bit = [](const unsigned int (&wk)[2], int j) { return (wk[j & 1] >> (j >> 1)) & 1u; };
+  auto barrier = []() { if constexpr (!(EXP & 1)) __syncthreads(); };
+  // EXP == 2: shader-clock stamps of waves 0 and 4 of workgroup 0, second block of its run, at the phase boundaries
+  int nstamp = 0; bool stamping = false;
+  auto stamp = [&]() {
+    if constexpr ((EXP & 2) != 0) {
+      if (stamping && a.stamps && (tid0 == 0 || tid0 == 256) && nstamp < 32) a.stamps[(tid0 ? 32 : 0) + nstamp++] = __builtin_amdgcn_s_memtime();
+    }
+  };
+
+  Raw raw[P];
+  float win[P];
+  // (part, parts): the loads are spread over the back transform, a few at a time, so that the memory pipeline never holds a wave up at issue
+  auto fetch = [&](int b, int tid, int part = 0, int parts = 1) {
+    const int p0 = a.p0_first + b * a.step;
+#pragma unroll
+    for (int i = part * (P / parts); i < (part + 1) * (P / parts); i++) {   // in the order the first butterflies take them
+      const int r = F32::in(i);
+      const int n = p0 + tid + r * T;
+      raw[r] = ((const Raw *)a.timf1)[(n * a.chan_count + a.chan_index) & a.ring_mask];
+    }
+  };
+  // The kernel runs with the sin^2 window only (make_timf2's overlap form, timf2.c:1003-1026), whose value at sample tid + T r is
+  // c sin^2(pi (tid + T r) / N) = c/2 (1 - cos(2 pi tid / N + 2 pi r / 32)): two fused multiply-adds on one complex number per thread,
+  // e^(2 pi j tid / N), and the 32nd roots of unity -- no table loads, no 32 registers held over the run.  c is the table's own peak
+  // value (make_window's normalisation, fft0.c:812-921); the values equal the table's to float32 rounding.
+  const float whalf = 0.5f * a.window[N / 2];
+  auto window_at = [&](float2 wrot, int r) {             // wrot = (cos, sin)(2 pi tid / N): the first entry of the LDS table; compile-time r
+    const float cr = lrh_cos32(r), sr = lrh_sin32(r);
+    return whalf - whalf * (wrot.x * cr - wrot.y * sr);
+  };
+  (void)win;
+  // LDS byte addresses of the two kinds of exchange (see the header comment).  cross: cell (q2 32 + q) 32 + l for the element that sits in
+  // half-wave q2, register q, lane l before the exchange; wave: cell 32 l + (q ^ l) of the half-wave's 1024
+  auto cross_wr = [](int t) { return 8 * ((t >> 5) * 1024 + (t & 31)); };
+  auto wave_wr = [](int t) { return 8 * ((t >> 5) * 1024 + (t & 31) * 33); };
+  auto wave_rd = [](int t) { return 8 * ((t >> 5) * 1024 + (t & 31)); };
+  // second stage of a 32-point pass: hands out the finished values group by group, f(index, value)
+  auto second32 = [&](auto tag, lrh_v2f (&u)[P], auto f, auto half_way) {
+    using D = decltype(tag);
+#pragma unroll
+    for (int c = 0; c < D::NC; c++) {
+      if (c == D::NC / 2) half_way();
+      lrh_v2f y[D::ND];
+      D::b(u, c, y);
+#pragma unroll
+      for (int d = 0; d < D::ND; d++) f(D::out(c, d), y[d]);
+    }
+  };
+  // the NKB 2^B2-point transforms of a thread: first stages, then (after `between`) second stages handing out f(kb, index, value)
+  auto small_pass = [&](auto tag, lrh_v2f (&u)[P], auto between, auto f) {
+    using D = decltype(tag);
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++) {
+      lrh_v2f t[R2];
+#pragma unroll
+      for (int i = 0; i < R2; i++) t[i] = u[kb * R2 + i];
+      D::a(t);
+#pragma unroll
+      for (int i = 0; i < R2; i++) u[kb * R2 + i] = t[i];
+    }
+    between();
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++) {
+      lrh_v2f t[R2];
+#pragma unroll
+      for (int i = 0; i < R2; i++) t[i] = u[kb * R2 + i];
+#pragma unroll
+      for (int c = 0; c < D::NC; c++) {
+        lrh_v2f y[D::ND];
+        D::b(t, c, y);
+#pragma unroll
+        for (int d = 0; d < D::ND; d++) f(kb, D::out(c, d), y[d]);
+      }
+    }
+  };
+
+  // forward transform of the fetched samples; hands out f(k3, value): bare-transform bin kk + T k3.  `early` runs before the last pass
+  // (the place for loads the caller needs right after it)
+  auto forward = [&](int tid, auto after_load, auto early, auto half_way, auto f) {
+    lrh_v2f x[P];
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const float2 wrot = lds[G::TN + (t_ ^ (t_ >> 5))];
+#pragma unroll
+      for (int r = 0; r < P; r++) { const float w = window_at(wrot, r); x[r] = lrh_v2f{(float)raw[r].x * w, -((float)raw[r].y * w)}; } }   // Q negated (fft1.c:432-447)
+    after_load();
+    stamp();
+    F32::a(x);
+    stamp();
+    barrier();                                           // B_a: every wave is through with the previous block's exchange buffer
+    stamp();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const float2 *tb = lds + G::T1 + (t_ >> 5);
+      float2 wb[3], wa[7];
+#pragma unroll
+      for (int e = 0; e < 3; e++) wb[e] = tb[e * R2];
+#pragma unroll
+      for (int e = 0; e < 7; e++) wa[e] = tb[(3 + e) * R2];
+      const int wr = cross_wr(t_);
+      second32(F32(), x, [&](int k1, lrh_v2f v) { lds_put(lds, wr + k1 * 256, to_f2(k1 == 0 ? v : cmul_v(v, to_v(tw_pow(wb, wa, k1))))); }, []() {}); }
+    stamp();
+    barrier();                                           // B_b
+    stamp();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int rd0 = 8 * t_, rd1 = 8 * t_ + 8 * 8192;   // (a ds offset reaches 64 KB)
+#pragma unroll
+      for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int i = 0; i < R2; i++) { const int v = F2::in(i); x[kb * R2 + v] = to_v(lds_get(lds, (v < 8 ? rd0 : rd1) + 8 * ((v & 7) * 1024 + kb * R2 * 32))); } }
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int wb_ = wave_wr(t_);
+      small_pass(F2(), x, [&]() { stamp(); barrier(); stamp(); },          // B_c: the cross-wave reads are done, the half-waves take their cells back
+                 [&](int kb, int k2, lrh_v2f v) { lds_put(lds, wb_ ^ (8 * (kb + NKB * k2)), to_f2(v)); }); }
+    stamp();
+    wave_lds_sync();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int rb = wave_rd(t_);
+      const int kk = kk_of(t_);
+      const float2 *tb = lds + G::TN + (kk ^ (kk >> 5));
+      float2 wb[3], wa[3];
+#pragma unroll
+      for (int e = 0; e < 3; e++) { wb[e] = tb[e * T]; wa[e] = tb[(3 + e) * T]; }
+      const float2 w16 = tb[6 * T];
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const int n3 = F32::in(i);
+        const lrh_v2f v = to_v(lds_get(lds, rb ^ (8 * 33 * n3)));
+        if (n3 == 0) x[n3] = v;
+        else if (n3 == 16) x[n3] = cmul_v(v, to_v(w16));
+        else if (n3 < 16) x[n3] = cmul_v(v, to_v(tw_pow(wb, wa, n3)));
+        else x[n3] = cmul_v(v, cmul_v(to_v(w16), to_v(tw_pow(wb, wa, n3 - 16))));
+      } }
+    early();
+    stamp();
+    F32::a(x);
+    stamp();
+    second32(F32(), x, f, half_way);
+    stamp();
+  };
+  // back transform of the spectrum c[j] (bin kk + T j); hands out f(r, value): sample tid + T r of the transform (r = 0 .. 31)
+  auto backward = [&](lrh_v2f (&c)[P], int tid, auto mid, auto before_last, auto f) {
+    B32::a(c);
+    mid(0);
+    stamp();
+    wave_lds_sync();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int wb_ = wave_wr(t_);
+      second32(B32(), c, [&](int m1, lrh_v2f v) { lds_put(lds, wb_ ^ (8 * m1), to_f2(v)); }, []() {}); }
+    stamp();
+    wave_lds_sync();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int rb = wave_rd(t_);
+      const float2 *tb = lds + G::TB1 + (t_ & 31);
+      float2 wb[3], wa[7];
+#pragma unroll
+      for (int e = 0; e < 3; e++) wb[e] = tb[e * 32];
+#pragma unroll
+      for (int e = 0; e < 7; e++) wa[e] = tb[(3 + e) * 32];
+#pragma unroll
+      for (int i = 0; i < P; i++) {
+        const int b = B32::in(i);
+        const lrh_v2f v = to_v(lds_get(lds, rb ^ (8 * 33 * b)));
+        c[b] = b == 0 ? v : cmul_conj_v(v, to_v(tw_pow(wb, wa, b)));
+      } }
+    stamp();
+    mid(1);
+    B32::a(c);
+    stamp();
+    barrier();                                           // B_d: every half-wave has read its transpose
+    stamp();
+    mid(2);
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int wr = cross_wr(t_);
+      second32(B32(), c, [&](int m2, lrh_v2f v) { lds_put(lds, wr + m2 * 256, to_f2(v)); }, []() {}); }
+    stamp();
+    barrier();                                           // B_e
+    stamp();
+    { int t_ = tid; asm volatile("" : "+v"(t_));
+      const int rd0 = 8 * t_, rd1 = 8 * t_ + 8 * 8192;
+      const float2 *tb = lds + G::TN + (t_ ^ (t_ >> 5));
+      float2 wb[3], wa[3];
+#pragma unroll
+      for (int e = 0; e < 3; e++) { wb[e] = tb[e * T]; wa[e] = tb[(3 + e) * T]; }
+#pragma unroll
+      for (int mb = 0; mb < NKB; mb++)
+#pragma unroll
+        for (int i = 0; i < R2; i++) {
+          const int cc = B2::in(i);
+          const lrh_v2f v = to_v(lds_get(lds, (cc < 8 ? rd0 : rd1) + 8 * ((cc & 7) * 1024 + mb * R2 * 32)));
+          if (cc == 0) { c[mb * R2 + cc] = v; continue; }
+          const int e = (cc * mb) & 31;                  // W_N^(cc T mb) = a 32nd root of unity
+          const lrh_v2f w = to_v(tw_pow(wb, wa, cc));
+          c[mb * R2 + cc] = cmul_conj_v(v, e == 0 ? w : cmulc_v(w, lrh_cos32(e), lrh_sin32(e)));
+        } }
+    stamp();
+    mid(3);
+    before_last();
+    small_pass(B2(), c, []() {}, [&](int mb, int m3, lrh_v2f v) { f(mb + NKB * m3, v); });
+    stamp();
+  };
+
+  // The sin^2 overlap (timf2.c:1003-1026: the first half of block t is added onto the second half of block t-1) is carried in the time
+  // domain like the reference does: ov = second half of the previous weak back transform, P/2 samples per thread.  (k_fft1w carries the
+  // previous weak SPECTRUM and transforms S_t + (-1)^k S_(t-1): twice the registers.)
+  lrh_v2f ov[HP];
+  float acc[P];
+#pragma unroll
+  for (int e = 0; e < HP; e++) ov[e] = lrh_v2f{0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < P; e++) acc[e] = 0.f;
+  __syncthreads();                                       // twiddle tables are in place
+  // All workgroups start together and take the same time per block: left alone, every CU of the chip asks the memory system for its
+  // samples at the same moment and stores its results at the same moment, and in between the memory idles.  A start delay that differs
+  // from workgroup to workgroup spreads the phases over the block time.
+  for (int i = (int)(blockIdx.x & 15u) * a.stagger; i > 0; i--) __builtin_amdgcn_s_sleep(32);   // 32 x 64 cycles
+  if (r0 > 0 || a.have_prev) {                           // the block before the run once more: its second half is the first block's partner
+    fetch(r0 - 1, tid0);
+    lrh_v2f c[P];
+    forward(tid0, []() {}, []() {}, []() {}, [&](int k3, lrh_v2f v) {
+      const int j = k3 ^ 16;
+      const bool weak = r0 > 0 ? weak_bit(wk_cur, j) : weak_bit(wk_first, j);   // routed with the table in force for that transform
+      c[j] = weak ? cmul_v(v, to_v(gld<float2>(a.filtercorr_v, 8u * (unsigned int)(2 * (tid0 + (j >> 1) * T) + (j & 1))))) : lrh_v2f{0.f, 0.f};
+    });
+    backward(c, tid0, [](int) {}, []() {}, [&](int r, lrh_v2f v) { if (r >= HP) ov[r - HP] = v; });
+  }
+  fetch(r0, tid0);
+  // Retire the prologue's loads here (see k_fft1): the compiler merges the wait counts of both loop entries, and with the first fetch the
+  // youngest memory operation on this path the loop-top wait for the samples would allow only a handful of operations in flight on every
+  // trip -- i.e. wait for the previous block's STORES to be acknowledged (measured: 7-10 k cycles of a 48 k block)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), other counters untouched
+#pragma unroll 1
+  for (int b = r0; b < r1; b++) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                        // keep index math inside the loop (see k_timf2)
+    stamping = blockIdx.x == 0 && b == r0 + 1;
+    stamp();
+    const int kk = kk_of(tid);
+    float4 fc[P / 2];                                    // filter correction of the bins kk + T j, two per load, on its way behind the last forward pass
+    lrh_v2f c[P];
+    float2 *const out0 = a.spec + (size_t)((a.first_nb + b) & a.nb_mask) * N;
+    // (the last pass hands out k3 = c + 4 d group by group: c = 0, 1 are the even pairs j / 2, c = 2, 3 the odd ones)
+    forward(tid, []() {}, [&]() {
+#pragma unroll
+      for (int jp = 0; jp < P / 2; jp += 2) fc[jp] = gld<float4>(a.filtercorr_v, 16u * (unsigned int)(tid + jp * T));
+    }, [&]() {
+#pragma unroll
+      for (int jp = 1; jp < P / 2; jp += 2) fc[jp] = gld<float4>(a.filtercorr_v, 16u * (unsigned int)(tid + jp * T));
+    }, [&](int k3, lrh_v2f xv) {
+      const int j = k3 ^ 16;                             // fft1_float bin kk + T j (DC at N/2)
+      const lrh_v2f v = cmul_v(xv, (j & 1) ? lrh_v2f{fc[j >> 1].z, fc[j >> 1].w} : lrh_v2f{fc[j >> 1].x, fc[j >> 1].y});
+      // fft1_c: sum |X|^2 over the averaging group (fft1.c:4115-4171), order as k_timf2<.., SS>; the contraction written out, so that every
+      // instantiation of this kernel rounds alike (the full and the sparse ring must not differ downstream)
+      acc[j] += __builtin_fmaf(v.y, v.y, v.x * v.x);
+      const bool weak = weak_bit(wk_cur, j);
+      if constexpr (KEEP) { c[j] = v; return; }          // every bin goes to the ring: below, through the LDS
+      if (!weak) store_stream(reinterpret_cast<float2 *>(reinterpret_cast<char *>(out0) + 8u * (unsigned int)(kk + j * T)), to_f2(v));   // the strong bins: a handful
+      c[j] = weak ? v : lrh_v2f{0.f, 0.f};               // the weak stream's spectrum
+    });
+    if constexpr (KEEP) {
+      // fft1_float in full (cfg.fft1_float_sparse = 0: Linrad's graphs, fft1_mix1_*, the AFC, NET_RXOUT_FFT1 read it).  A thread holds bins
+      // kk + T j, of which a wave's lanes cover pairs 16 bins apart: stored from here a wave-instruction would touch 32 cache lines for 16
+      // bytes each.  One more trip through the exchange buffer -- cell f ^ ((f >> 5) & 15), free of bank conflicts on the way out and at
+      // most 2-way on the way in -- and every store is 64 consecutive bins.
+      auto cell = [](int f) { return 8 * (f ^ ((f >> 5) & 15)); };
+      barrier();
+      { int t_ = tid; asm volatile("" : "+v"(t_));
+        const int kk_ = kk_of(t_);
+#pragma unroll
+        for (int j = 0; j < P; j++) lds_put(lds, cell(kk_ + j * T), to_f2(c[j])); }
+      barrier();
+      { int t_ = tid; asm volatile("" : "+v"(t_));
+#pragma unroll
+        for (int r = 0; r < P; r++)
+          store_stream(reinterpret_cast<float2 *>(reinterpret_cast<char *>(out0) + 8u * (unsigned int)(t_ + r * T)), lds_get(lds, cell(t_ + r * T))); }
+      barrier();                                         // the half-waves take their cells back (back transform, first exchange)
+#pragma unroll
+      for (int j = 0; j < P; j++) if (!weak_bit(wk_cur, j)) c[j] = lrh_v2f{0.f, 0.f};
+    }
+    {
+      const int gb = b + a.ss_c0, g = gb / a.ss_avg;
+      const bool group_end = gb - g * a.ss_avg == a.ss_avg - 1;
+      if (group_end || b == r1 - 1) {
+        const bool head = g * a.ss_avg - a.ss_c0 < r0;   // began in an earlier run (or an earlier call)
+        float *dst = (!head && group_end) ? a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask) : a.ss_part + (size_t)(2 * blockIdx.x + (head ? 0 : 1)) * N;
+#pragma unroll
+        for (int j = 0; j < P; j++) { *reinterpret_cast<float *>(reinterpret_cast<char *>(dst) + 4u * (unsigned int)(kk + j * T)) = acc[j]; acc[j] = 0.f; }
+      }
+    }
+    stamp();
+    {
+      const size_t base = (size_t)((a.pa_first + b * a.step) & a.mask);
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      // the next block's samples are asked for ahead of this block's stores: vmcnt retires in order, and a wait of the next forward
+      // transform for its samples must not cover a store
+      // int16: the next block's samples are asked for in the middle of the back transform (32 registers; a quarter of a block of time for
+      // the memory); int32 (64 registers): ahead of its last pass.  Unconditional: the last trip re-reads its own samples
+      backward(c, tid, [&](int part) { if constexpr (!DW) fetch(min(b + 1, r1 - 1), tid, part, 4); },
+               [&]() { if constexpr (DW) fetch(min(b + 1, r1 - 1), tid); }, [&](int r, lrh_v2f v) {
+        if (r >= HP) { ov[r - HP] = v; return; }         // this block's second half waits for the next
+        const lrh_v2f o = (v + ov[r]) * a.ampfac;        // first half + the previous block's second half
+        const v2f ov_ = { o.x, o.y };
+        const unsigned int at = (unsigned int)(tid + r * T);
+        __builtin_nontemporal_store(ov_, reinterpret_cast<v2f *>(reinterpret_cast<char *>(a.timf2w + base) + 8u * at));
+        __builtin_nontemporal_store(o.x * o.x + o.y * o.y, reinterpret_cast<float *>(reinterpret_cast<char *>(a.pwr + base) + 4u * at));
+      });
+    }
+    stamp();
+    stamping = false;
+  }
+}
+
+// =====================================================================================================
 // blanker
 // =====================================================================================================
 // The reference scan is serial (blank1.c:1023-1086): a run of samples above the limit is cleared, and when it
@@ -2072,10 +2466,54 @@ hipError_t launch_fft1w(const Fft1wArgs &a0, hipStream_t st, int *run)
   hipLaunchKernelGGL((k_fft1w<14>), dim3((a.batch + a.run - 1) / a.run), dim3(512), 0, st, a);
   return hipGetLastError();
 }
-hipError_t launch_timf2_strong(const Timf2Args &a0, int batch, hipStream_t st)
+// k_fft1v: fft1_size 4096 / 8192 / 16384, int16 or int32 I/Q
+hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a0, hipStream_t st, int *run)
+{
+  Fft1wArgs a = a0;
+  const int lds = 8 * (log2n == 14 ? Fft1vGeom<14>::LDS_CELLS : (log2n == 13 ? Fft1vGeom<13>::LDS_CELLS : Fft1vGeom<12>::LDS_CELLS));
+  const int threads = (1 << log2n) / 32;
+  // 235+ VGPRs: two waves per SIMD, i.e. 512 threads per CU whatever the LDS would allow
+  int per_cu = 160 * 1024 / lds; if (per_cu > 512 / threads) per_cu = 512 / threads; if (per_cu < 1) per_cu = 1;
+  int grid = (256 - (per_cu == 1 ? a.spare_cus : 0)) * per_cu; if (grid > a.batch) grid = a.batch;
+  if (a.max_wg > 0 && grid > a.max_wg) grid = a.max_wg;
+  a.run = (a.batch + grid - 1) / grid;
+  if (run) *run = a.run;
+  const dim3 g((a.batch + a.run - 1) / a.run), t(threads);
+  static const int exp_ = getenv("LRH_FFT1V_EXP") ? atoi(getenv("LRH_FFT1V_EXP")) : 0;
+  static const int stagger_ = getenv("LRH_V_STAGGER") ? atoi(getenv("LRH_V_STAGGER")) : 0;
+  a.stagger = a.run >= 4 ? stagger_ : 0;
+  if (exp_ && log2n == 14 && !dword) {
+    if (exp_ == 1) hipLaunchKernelGGL((k_fft1v<14, false, false, 1>), g, t, 0, st, a);
+    else if (a.keep_spec) hipLaunchKernelGGL((k_fft1v<14, false, true, 2>), g, t, 0, st, a);
+    else hipLaunchKernelGGL((k_fft1v<14, false, false, 2>), g, t, 0, st, a);
+    return hipGetLastError();
+  }
+  switch (log2n * 4 + (dword ? 2 : 0) + (a.keep_spec ? 1 : 0)) {
+    case 56: hipLaunchKernelGGL((k_fft1v<14, false, false>), g, t, 0, st, a); break;
+    case 57: hipLaunchKernelGGL((k_fft1v<14, false, true>), g, t, 0, st, a); break;
+    case 58: hipLaunchKernelGGL((k_fft1v<14, true, false>), g, t, 0, st, a); break;
+    case 59: hipLaunchKernelGGL((k_fft1v<14, true, true>), g, t, 0, st, a); break;
+    case 52: hipLaunchKernelGGL((k_fft1v<13, false, false>), g, t, 0, st, a); break;
+    case 53: hipLaunchKernelGGL((k_fft1v<13, false, true>), g, t, 0, st, a); break;
+    case 54: hipLaunchKernelGGL((k_fft1v<13, true, false>), g, t, 0, st, a); break;
+    case 55: hipLaunchKernelGGL((k_fft1v<13, true, true>), g, t, 0, st, a); break;
+    case 48: hipLaunchKernelGGL((k_fft1v<12, false, false>), g, t, 0, st, a); break;
+    case 49: hipLaunchKernelGGL((k_fft1v<12, false, true>), g, t, 0, st, a); break;
+    case 50: hipLaunchKernelGGL((k_fft1v<12, true, false>), g, t, 0, st, a); break;
+    case 51: hipLaunchKernelGGL((k_fft1v<12, true, true>), g, t, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_timf2_strong(int log2n, const Timf2Args &a0, int batch, hipStream_t st)
 {
   Timf2Args a = a0; a.batch = batch; a.ss_ring = nullptr;
-  hipLaunchKernelGGL((k_timf2<14, 1, false, true>), dim3(fftl_grid<14>(batch, a.spare_cus)), dim3(fft1_threads(14)), 0, st, a);
+  switch (log2n) {
+    case 14: hipLaunchKernelGGL((k_timf2<14, 1, false, true>), dim3(fftl_grid<14>(batch, a.spare_cus)), dim3(fft1_threads(14)), 0, st, a); break;
+    case 13: hipLaunchKernelGGL((k_timf2<13, 1, false, true>), dim3(fftl_grid<13>(batch, a.spare_cus)), dim3(fft1_threads(13)), 0, st, a); break;
+    case 12: hipLaunchKernelGGL((k_timf2<12, 1, false, true>), dim3(fftl_grid<12>(batch, a.spare_cus)), dim3(fft1_threads(12)), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t launch_sumsq_join(const SumsqArgs &a, const float *part, int run, hipStream_t st)

@@ -79,6 +79,7 @@ struct Timf2Args {
 struct Fft1wArgs {
   const void *timf1; int ring_mask, p0_first, step, chan_count, chan_index;   // as Fft1Args (int16 I/Q, no skew)
   const float *window; const float2 *filtercorr, *tw;
+  const float2 *filtercorr_v;                   // k_fft1v: the same table in the order its threads hold the bins, [j][thread] (lrh_host.hip upload_filtercorr)
   float2 *spec; int first_nb, nb_mask;          // fft1 ring: strong bins, or every bin with keep_spec
   int keep_spec;
   const unsigned int *pack_cur, *pack_prev;     // as Timf2Args
@@ -86,10 +87,14 @@ struct Fft1wArgs {
   int have_prev;                                // 0: the stream starts with this launch (nothing to overlap the first transform with)
   float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0;   // as Timf2Args (k_sumsq_join finishes split groups)
   int batch, run;                               // run: consecutive transforms per workgroup (set by launch_fft1w)
+  int max_wg;                                   // workgroups the scratch of split groups ss_part has room for
+  unsigned long long *stamps;                   // diagnostics (LRH_FFT1V_EXP=2): 2 x 32 shader-clock stamps
+  int stagger;                                  // start delay per workgroup, (blockIdx & 15) x stagger x 2048 cycles (set by launch_fft1v)
   int spare_cus;
 };
 hipError_t launch_fft1w(const Fft1wArgs &a, hipStream_t st, int *run);
-hipError_t launch_timf2_strong(const Timf2Args &a, int batch, hipStream_t st);
+hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a, hipStream_t st, int *run);
+hipError_t launch_timf2_strong(int log2n, const Timf2Args &a, int batch, hipStream_t st);
 
 // fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): one block no longer fits a workgroup's LDS, so
 // fft1 and timf2 take the four-step form of the large fft2 (column transforms, step twiddle, row transforms through an HBM scratch)

@@ -15,7 +15,10 @@ ALG_BYTES = {"fft1": 24.0, "sumsq": 16.0, "timf2": 76.0, "blanker": 4.0, "fft2":
              # overlapped half of a transform stays in registers), the spectrum out (8 B x 2 transforms per sample at 50 % overlap) and the
              # averaged power (4 B x 2 / waterfall_avgnum = 1).  SURVEY 8d's 64 prices the four-step form: a scratch round trip and the
              # overlapped read taken twice.  (With cfg.fft2_float_sparse only the band mix1 cuts out is stored: the counters show 20.)
-             "fft2_single": 8.0 + 8.0 + 16.0 + 1.0}
+             "fft2_single": 8.0 + 8.0 + 16.0 + 1.0,
+             # the part of either fft2 figure that is the spectrum ring (8 B x 2 transforms per sample at 50 % overlap): not written with
+             # cfg.fft2_float_sparse (only the band mix1 cuts out is), so bench.py prices the stage without it in that mode
+             "fft2_spectrum_out": 16.0}
 ALG_BYTES_CHAIN = 184.0
 
 

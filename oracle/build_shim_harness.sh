@@ -28,7 +28,7 @@ trap 'rm -rf "$T"' EXIT
 OUT="$HERE/_ref/shim"
 mkdir -p "$OUT"
 cp "$REF"/*.h "$T"/
-TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c spursub.c"
+TOUCHED="fft1var.c buf.c wcw.c fft1.c timf2.c blank1.c fft2.c mix1.c sellim.c rxin.c spursub.c spur.c"
 for f in $TOUCHED; do cp "$REF/$f" "$T/"; done
 (cd "$T" && patch -s -p1 --no-backup-if-mismatch < "$ROOT/integration/linrad_hip.patch")
 cp "$ROOT/integration/hipshim.c" "$ROOT/integration/hipshim.h" "$T"/

@@ -2629,6 +2629,27 @@ int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const float *table, cons
   if (n) { memcpy(S->sp, sp, n * sizeof *sp); memcpy(S->table, table, (size_t)n * maxn * SPW * 2 * 4); memcpy(S->signal, signal, (size_t)n * maxn * 2 * 4); memcpy(S->ind, ind, (size_t)n * maxn * 4); }
   return LRH_OK;
 }
+/* remove_spur / swap_spurs (spur.c:596-631, spursub.c:755): spur i becomes what was spur src[i] */
+int lro_spur_permute(lro_ctx *c, int n, const int *src)
+{
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S || n < 0 || n > S->n || (n && !src)) return LRH_EINVAL;
+  const size_t maxn = c->cfg.max_fft2n;
+  for (int i = 0; i < n; i++) if (src[i] < 0 || src[i] >= S->n) return LRH_EINVAL;
+  if (n) {
+    lrh_spur *sp = malloc(n * sizeof *sp); float *tab = malloc((size_t)n * maxn * SPW * 2 * 4), *sig = malloc((size_t)n * maxn * 2 * 4); int *ind = malloc((size_t)n * maxn * 4);
+    for (int i = 0; i < n; i++) {
+      sp[i] = S->sp[src[i]];
+      memcpy(tab + (size_t)i * maxn * SPW * 2, S->table + (size_t)src[i] * maxn * SPW * 2, maxn * SPW * 2 * 4);
+      memcpy(sig + (size_t)i * maxn * 2, S->signal + (size_t)src[i] * maxn * 2, maxn * 2 * 4);
+      memcpy(ind + (size_t)i * maxn, S->ind + (size_t)src[i] * maxn, maxn * 4);
+    }
+    memcpy(S->sp, sp, n * sizeof *sp); memcpy(S->table, tab, (size_t)n * maxn * SPW * 2 * 4); memcpy(S->signal, sig, (size_t)n * maxn * 2 * 4); memcpy(S->ind, ind, (size_t)n * maxn * 4);
+    free(sp); free(tab); free(sig); free(ind);
+  }
+  S->n = n;
+  return LRH_OK;
+}
 int lro_spur_get(lro_ctx *c, int max, lrh_spur *sp, int *n)
 {
   lro_spurs *S = c ? c->spurs : NULL;

@@ -36,6 +36,10 @@
 #define lrh_get_liminfo_amplitude_factor lro_get_liminfo_amplitude_factor
 #define lrh_get_mix1_state lro_get_mix1_state
 #define lrh_set_blanker_tables lro_set_blanker_tables
+#define lrh_spur_config lro_spur_config
+#define lrh_spur_acquire lro_spur_acquire
+#define lrh_spur_get lro_spur_get
+#define lrh_spur_permute lro_spur_permute
 #define lrh_set_filtercorr lro_set_filtercorr
 #define lrh_set_liminfo lro_set_liminfo
 #define lrh_set_mix1_selfreq lro_set_mix1_selfreq

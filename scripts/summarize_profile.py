@@ -13,7 +13,7 @@ d = sys.argv[1]
 # stage (bench.py's HIP-event scopes) -> (anchor kernel: one dispatch per stage launch, all kernels of the stage)
 STAGE_KERNELS = {
     "fft1": ("k_fft1<", ["k_fft1<", "k_realsplit", "k_foldcorr"]),
-    "fft1w": ("k_fft1w<", ["k_fft1w<"]),
+    "fft1w": (("k_fft1w<", "k_fft1v<"), ["k_fft1w<", "k_fft1v<"]),
     "timf2s": ("k_timf2<14, 1, false, true>", ["k_timf2<14, 1, false, true>"]),
     "timf2": ("k_timf2<", ["k_timf2<"]),
     "spur": ("k_spur(", ["k_spur(", "k_spur_patch"]),

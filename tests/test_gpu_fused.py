@@ -215,3 +215,64 @@ def test_rounds_of_a_few_blocks_between_fused_rounds():
     for _, k in RINGS:
         assert _rel(a[k], b[k]) < 2e-6, k
     assert not np.array_equal(a["timf2"], b["timf2"])      # (the fused kernel did run: its last-pass twiddles round differently)
+
+
+def _run_n(env, fft1_n, fft2_n, dword, fn=None, nblk=96, batch=32, sparse=0):
+    """fft1_size 2^fft1_n through lrh_wideband_dsp in rounds of `batch`; int16 or int32 samples (the int16 signal left-justified in 32 bits,
+    like hardware that delivers 24-bit words does, fft1.c:4656-4663)"""
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cfg = chain_config(fft1_n, fft2_n, batch=batch, rounds=nblk // batch)
+        cfg.fft1_float_sparse = sparse
+        cfg.stupid_bln_mode = 0
+        cfg.timf1_dword_input = dword
+        if dword:
+            cfg.timf1_bytes *= 2
+        rx = (fn or open_hip)(cfg)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    n1 = 1 << fft1_n
+    s = synth_defaults(n1, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // (8 if dword else 4))
+    rx.timf1_write((iq.astype(np.int32) << 16) if dword else iq)
+    rx.set_liminfo(strong_liminfo(s, fft1_n))
+    rx.set_mix1_selfreq(0.31 * (1 << fft2_n) + 0.3)
+    launches = None
+    if fn is None:
+        rx.profile_enable(2)
+    rx.wideband_dsp(nblk, batch)
+    if fn is None:
+        launches = {k: rx.profile_get(k)[1] for k in ("fft1w", "fft1", "timf2", "timf2s")}
+        rx.profile_enable(0)
+    out = {k: rx.export(r) for r, k in RINGS}
+    out["p"] = rx.p.as_dict()
+    out["launches"] = launches
+    rx.close()
+    return out
+
+
+@pytest.mark.parametrize("fft1_n,fft2_n,dword", [(14, 12, 1), (13, 15, 0), (13, 12, 1), (12, 14, 0), (12, 10, 1)])
+def test_fused_kernel_at_other_sizes_and_int32_matches_the_two_kernel_path_and_the_oracle(fft1_n, fft2_n, dword):
+    """k_fft1v serves fft1_size 4096 / 8192 / 16384 (Linrad sizes fft1 from the bandwidth, buf.c:139-335: 4096 and 8192 are the common sizes at
+    2 - 10 Msps) and int32 samples (fft1.c:4656-4663): against k_fft1 + k_timf2<.., SS> ring by ring, against the oracle at 1e-5, and with the
+    sparse spectrum ring nothing downstream changes"""
+    from oracle_binding import open_oracle
+    a = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword)
+    b = _run_n({"LRH_FUSE_FFT1": "0"}, fft1_n, fft2_n, dword)
+    o = _run_n({}, fft1_n, fft2_n, dword, fn=open_oracle)
+    assert a["launches"]["fft1w"] == 3 and a["launches"]["fft1"] == 0 and b["launches"]["fft1w"] == 0, (a["launches"], b["launches"])
+    assert a["p"] == b["p"] == o["p"]
+    n1 = 1 << fft1_n
+    keep = np.ones(a["timf2"].size, bool)                  # the raw half block parked beyond timf2_pa (timf2.c:1018-1025): only the oracle stores it
+    keep[(a["p"]["timf2_pa"] + np.arange(4 * (n1 // 2))) % keep.size] = False
+    rep = {k: (_rel(a[k], b[k]), _rel(a[k] * (keep if k == "timf2" else 1), o[k] * (keep if k == "timf2" else 1))) for _, k in RINGS}
+    print(fft1_n, dword, rep)
+    assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["sumsq"]) > n1
+    for k, (e2, eo) in rep.items():
+        assert e2 < 2e-6 and eo < 1e-5, (k, e2, eo)
+    sp = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword, sparse=1)
+    for _, k in RINGS[1:]:
+        assert np.array_equal(a[k], sp[k]), k

@@ -125,3 +125,18 @@ def test_fullsize_limiters_match_oracle(fft1_n, fft2_n, par1):
     err = np.linalg.norm((h["timf2"].astype(np.float64) - o["timf2"]) * keep) / np.linalg.norm(o["timf2"] * keep)
     print("timf2", err, "flips", len(flips))
     assert err < 1e-5
+
+
+def test_wideband_limiter_is_refused_on_a_coupled_context():
+    """dsp_coupled, the round-level order of two coupled channels, makes no limiter calls: installing one there must fail instead of being
+    silently ignored (the reference's two-channel limiter works on the summed spectra, not built)"""
+    from linrad_amd.abi import LrhError, default_sellim
+    from linrad_amd.lib import open_hip
+    from linrad_amd.workload import chain_config
+    cfg = chain_config(10, 12, batch=4)
+    cfg.blanker_channels, cfg.timf1_frame_channels, cfg.timf1_channel_index = 2, 2, 0
+    rx = open_hip(cfg)
+    with pytest.raises((LrhError, RuntimeError)):
+        rx.wideband_limiter(default_sellim(cfg), False)
+    rx.wideband_limiter(None)
+    rx.close()
