@@ -27,7 +27,19 @@
 #include "linrad_hip.h"
 #include "hipshim.h"
 
-static lrh_ctx *hip_rx;
+/* One context per RF channel (ui.rx_rf_channels = 1 or 2): the library shards channels one per context, Linrad keeps both in every
+   array -- frames {I0,Q0,I1,Q1} in timf1, {ch0, ch1} per bin / sample behind it, pointers counted in floats of the two-channel arrays.
+   hip_rx is channel 0; HC contexts in hip_ctx[].  A pointer that counts floats is divided by HC on the way in and multiplied on the way
+   out (HIP_IN / HIP_OUT); transform numbers, the blanker's sample pointers (timf2p_fit) and the power-sum pointers are per channel anyway.
+   The sums Linrad forms over the channels -- fft1_sumsq, fft1_slowsum, the blanker's power and noise, the fft2 cross products -- are
+   the exchanges of include/linrad_hip.h ("two coupled RF channels"), made here through host memory (lrh_exchange_read / _write). */
+static lrh_ctx *hip_rx, *hip_ctx[2];
+static int HC = 1;
+#define HIP_IN(x) ((x) / HC)
+#define HIP_OUT(x) ((x) * HC)
+static float *hip_xa, *hip_xb; static size_t hip_xcap;      /* host scratch of the exchanges and of the channel interleaving */
+static float hip_ch2_c1 = 1, hip_ch2_c2 = 0;                /* pg_ch2_c1 / pg_ch2_c2 as last handed to channel 1's context (pol_graph.c:160-170) */
+static float *hip_scratch(size_t n) { if (n > hip_xcap) { free(hip_xa); free(hip_xb); hip_xa = malloc(n * sizeof(float)); hip_xb = malloc(n * sizeof(float)); hip_xcap = n; } return hip_xa; }
 static float *hip_liminfo_sent;           /* the routing table the device holds (sellim.c updates liminfo[] on the host) */
 /* liminfo[] / hip_liminfo_sent are touched by the wideband thread (the limiter hooks) and, with more than one CPU, by
    THREAD_TIMF2 (hip_make_timf2, wcw.c:419-425): one lock around the whole read-compare-upload / download-publish sequences */
@@ -39,6 +51,7 @@ static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins st
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 lrh_ctx *hip_context(void) { return hip_rx; }
+lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL; }
 
 /* What version 21 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
    rings that stay empty: two RF channels in one array (fft1.c:3874-4080; the library shards channels one context per GPU, which
@@ -47,7 +60,9 @@ lrh_ctx *hip_context(void) { return hip_rx; }
    reads fft2_float on the host, spursub.c:619), and the network outputs that are memcpy'd from host rings (wcw.c:1038-1043). */
 static int hip_unsupported(void)
 {
-  if (ui.rx_rf_channels != 1) return 1;
+  if (ui.rx_rf_channels != 1 && ui.rx_rf_channels != 2) return 1;
+  if (ui.rx_rf_channels == 2 && ((ui.rx_input_mode & IQ_DATA) == 0 || genparm[MAX_NO_OF_SPURS] != 0 ||
+      (ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0)) return 8;   /* two channels: I/Q input, no spur removal, no stage multicast */
   if ((ui.rx_input_mode & IQ_DATA) == 0 && fft_cntrl[FFT1_CURMODE].permute != 2) return 2;   /* real samples: version 22, whose permute field gives Linrad's
                                                                                                   filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
@@ -91,15 +106,30 @@ int hip_open(void)
   c.timf2_blockpower_block = timf2_blockpower_block; c.timf2_blockpower_size = timf2_blockpower_size;     /* compute_timf2_powersum, wcw.c:80 */
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
   c.timf1_real_input = (ui.rx_input_mode & IQ_DATA) == 0;          /* fft1_reherm_dit_one's job (fft1_re.c:32-131): 2 fft1_size reals per transform */
-  if ((rc = lrh_open(&c, &hip_rx)) != 0) { hip_rx = NULL; return rc; }
+  HC = ui.rx_rf_channels;
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
-  lrh_set_filtercorr(hip_rx, fft1_filtercorr);                /* the calibration Linrad loaded (fft1.c:4653-5386) */
+  hip_ctx[0] = hip_ctx[1] = NULL;
+  for (int ch = 0; ch < HC; ch++) {
+    if (HC == 2) {                                                 /* one context per channel, coupled (include/linrad_hip.h) */
+      c.blanker_channels = 2; c.timf1_frame_channels = 2; c.timf1_channel_index = ch;
+      c.timf3_size = timf3_size / 2; c.timf2_blockpower_block = timf2_blockpower_block / 2;
+    }
+    if ((rc = lrh_open(&c, &hip_ctx[ch])) != 0) { if (ch) lrh_close(hip_ctx[0]); hip_ctx[0] = hip_ctx[1] = NULL; hip_rx = NULL; return rc; }
+    if (HC == 1) lrh_set_filtercorr(hip_ctx[ch], fft1_filtercorr);  /* the calibration Linrad loaded (fft1.c:4653-5386) */
+    else {                                                         /* two channels: {ch0, ch1} per bin (fft1.c:4132-4145) */
+      float *f = hip_scratch(2 * (size_t)fft1_size);
+      for (int i = 0; i < fft1_size; i++) { f[2 * i] = fft1_filtercorr[4 * i + 2 * ch]; f[2 * i + 1] = fft1_filtercorr[4 * i + 2 * ch + 1]; }
+      lrh_set_filtercorr(hip_ctx[ch], f);
+    }
+    lrh_set_liminfo(hip_ctx[ch], liminfo);
+  }
+  hip_rx = hip_ctx[0];
+  hip_ch2_c1 = 1; hip_ch2_c2 = 0;
   hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
-  lrh_set_liminfo(hip_rx, liminfo);
   hip_spurs_on = genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
   if (hip_spurs_on && lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { lrh_close(hip_rx); hip_rx = NULL; return LRH_EINVAL; }
-  lrh_host_register(hip_rx, timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
+  for (int ch = 0; ch < HC; ch++) lrh_host_register(hip_ctx[ch], timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
   return 0;
 }
 
@@ -107,24 +137,30 @@ void hip_close(void)
 {
   if (!hip_rx) return;
   hip_clever_mode = 0;
-  lrh_timf1_write_wait(hip_rx);
-  lrh_host_unregister(hip_rx, timf1_char);
-  lrh_close(hip_rx);
-  hip_rx = NULL;
+  for (int ch = 0; ch < HC; ch++) { lrh_timf1_write_wait(hip_ctx[ch]); lrh_host_unregister(hip_ctx[ch], timf1_char); lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL; }
+  hip_rx = NULL; HC = 1;
+  free(hip_xa); free(hip_xb); hip_xa = hip_xb = NULL; hip_xcap = 0;
   free(hip_liminfo_sent); hip_liminfo_sent = NULL;
   free(hip_afc_tmp); hip_afc_tmp = NULL;
 }
 
 void hip_timf1_new(int pa, int nbytes)
 {
-  if (hip_rx && lrh_timf1_write_async(hip_rx, &timf1_char[pa], pa, nbytes) != 0) lirerr(1465);
+  for (int ch = 0; ch < HC && hip_rx; ch++)               /* two channels: both contexts hold the interleaved frames and read their own channel */
+    if (lrh_timf1_write_async(hip_ctx[ch], &timf1_char[pa], pa, nbytes) != 0) lirerr(1465);
 }
 
 int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
 {
   /* the dispatcher's workers carry gpu_handle_number 0..5 (wcw.c:500), the no-worker path passes 0 too (wcw.c:1036) */
   const int handle = no_of_fft1b > 0 ? gpu_handle_number + 1 : 0;
-  return lrh_fft1_b(hip_rx, handle, timf1p_ref, (int)(out - fft1_float), gpu_fft1_batch_size);
+  int rc = 0;
+  if (HC == 2 && (pg_ch2_c1 != hip_ch2_c1 || pg_ch2_c2 != hip_ch2_c2)) {       /* phasing of channel 2, fft1.c:4064-4080 (pol_graph.c:160-170 sets it) */
+    hip_ch2_c1 = pg_ch2_c1; hip_ch2_c2 = pg_ch2_c2;
+    lrh_set_ch2_phasing(hip_ctx[1], hip_ch2_c1, hip_ch2_c2);
+  }
+  for (int ch = 0; ch < HC && !rc; ch++) rc = lrh_fft1_b(hip_ctx[ch], handle, timf1p_ref, HIP_IN((int)(out - fft1_float)), gpu_fft1_batch_size);
+  return rc;
 }
 
 /* make_afc (afc_graph.c:362) stays host code: with ag.mode_control != 0 it searches the power spectra fftx_pwr[transform][bin] of
@@ -138,6 +174,7 @@ static void hip_afc_rows(int first_row, int rows)
   const int size = second ? hip_n2 : hip_n1, nmask = second ? fft2n_mask : fft1n_mask;
   int centre, half, lo, hi, r, i;
   if (genparm[AFC_ENABLE] == 0 || genparm[AFC_LOCK_RANGE] == 0 || ag.mode_control == 0 || mix1_selfreq[0] < 0 || fftx_pwr == NULL) return;
+  if (HC == 2) return;                                     /* two channels: make_afc searches TWOCHAN_POWER rows (afcsub.c): not fetched -- the AFC then holds the selected frequency */
   if (hip_afc_selfreq != mix1_selfreq[0]) { hip_afc_selfreq = mix1_selfreq[0]; first_row = 0; rows = nmask + 1; }
   centre = (int)(mix1_selfreq[0] * fftx_points_per_hz);
   half = 4 * max_afcf_points + 64;
@@ -160,7 +197,7 @@ void hip_fft1_c(void)
   int old_pa, n, room;
   memset(&q, 0, sizeof q);
   /* hip_sync_in: what fft1_c reads (fft1.c:4507-4523) */
-  q.fft1_nb = fft1_nb; q.fft1_pb = fft1_pb; q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
+  q.fft1_nb = fft1_nb; q.fft1_pb = HIP_IN(fft1_pb); q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
   q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   old_pa = fft1_sumsq_pa;
   /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
@@ -172,16 +209,28 @@ void hip_fft1_c(void)
   if (n > room) n = room;
   if (n > hip_max_batch) n = hip_max_batch;
   if (n < 1) n = 1;
-  if (lrh_fft1_c(hip_rx, &q, n) != 0) { lirerr(1466); return; }
+  { lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } } }
   /* hip_sync_out */
-  fft1_nb = q.fft1_nb; fft1_pb = q.fft1_pb; fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
+  fft1_nb = q.fft1_nb; fft1_pb = HIP_OUT(q.fft1_pb); fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
   fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
   if (genparm[SECOND_FFT_ENABLE] == 0) hip_afc_rows((q.fft1_nb - n) & fft1n_mask, n);
   if (q.fft1_sumsq_pa != old_pa) {            /* averaging periods completed: the wide graph and sellim.c read these on the host */
     int pa;
-    for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask)
+    for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask) {
       lrh_export(hip_rx, LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)hip_n1);
+      if (HC == 2) {                                       /* |X0|^2 + |X1|^2 (fft1.c:4132-4145) */
+        float *t = hip_scratch((size_t)hip_n1);
+        lrh_export(hip_ctx[1], LRH_RING_FFT1_SUMSQ, t, (size_t)pa, (size_t)hip_n1);
+        for (int i = 0; i < hip_n1; i++) fft1_sumsq[pa + i] += t[i];
+      }
+    }
     lrh_export(hip_rx, LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1);
+    if (HC == 2) {
+      float *t = hip_scratch((size_t)hip_n1);
+      lrh_export(hip_ctx[1], LRH_RING_FFT1_SLOWSUM, t, 0, (size_t)hip_n1);
+      for (int i = 0; i < hip_n1; i++) fft1_slowsum[i] += t[i];
+    }
   }
 }
 
@@ -195,18 +244,54 @@ void hip_make_timf2(void)
   pthread_mutex_lock(&hip_liminfo_lock);
   if (memcmp(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1)) {
     memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)hip_n1);
-    lrh_set_liminfo(hip_rx, hip_liminfo_sent);
+    for (int ch = 0; ch < HC; ch++) lrh_set_liminfo(hip_ctx[ch], hip_liminfo_sent);
   }
   pthread_mutex_unlock(&hip_liminfo_lock);
-  q.fft1_px = fft1_px; q.fft1_nx = fft1_nx; q.timf2_pa = timf2_pa;
+  q.fft1_px = HIP_IN(fft1_px); q.fft1_nx = fft1_nx; q.timf2_pa = HIP_IN(timf2_pa);
   q.fft1_lowlevel_points = fft1_lowlevel_points; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
   /* all the transforms hip_fft1_c has just passed (it left no more than the timf2 ring has room for) */
   n = (fft1_nb - fft1_nx + max_fft1n) & fft1n_mask;
   if (n > hip_max_batch) n = hip_max_batch;
   if (n < 1) n = 1;
-  if (lrh_make_timf2(hip_rx, &q, n) != 0) { lirerr(1467); return; }
-  fft1_px = q.fft1_px; fft1_nx = q.fft1_nx; timf2_pa = q.timf2_pa;            /* timf2.c:127-128, 205-207 */
+  { lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_make_timf2(hip_ctx[ch], &q, n) != 0) { lirerr(1467); return; } } }
+  fft1_px = HIP_OUT(q.fft1_px); fft1_nx = q.fft1_nx; timf2_pa = HIP_OUT(q.timf2_pa);            /* timf2.c:127-128, 205-207 */
   fft1_lowlevel_points = q.fft1_lowlevel_points; fft1_lowlevel_fraction = q.fft1_lowlevel_fraction;
+}
+
+/* Two channels: the blanker decides on the channels' power SUM and averages both channels' noise (blank1.c:1017, 1236-1300, 1510-1570);
+   with the tables of the linear blanker both contexts run the same pulse search on both channels' samples.  The sums and the gather
+   are the caller's (include/linrad_hip.h): here through host memory.  Both contexts advance the same pointers. */
+static int hip_xsum(int which, size_t count)
+{
+  float *a = hip_scratch(count), *b = hip_xb;
+  if (lrh_exchange_read(hip_ctx[0], which, a, 0, count) != 0 || lrh_exchange_read(hip_ctx[1], which, b, 0, count) != 0) return 1;
+  for (size_t i = 0; i < count; i++) a[i] += b[i];
+  return lrh_exchange_write(hip_ctx[0], which, a, 0, count) != 0 || lrh_exchange_write(hip_ctx[1], which, a, 0, count) != 0;
+}
+static int hip_xgather(int which, size_t count)            /* slot ch of context ch to slot ch of the other one */
+{
+  float *a = hip_scratch(count);
+  for (int ch = 0; ch < 2; ch++)
+    if (lrh_exchange_read(hip_ctx[ch], which, a, (size_t)ch * count, count) != 0 || lrh_exchange_write(hip_ctx[1 - ch], which, a, (size_t)ch * count, count) != 0) return 1;
+  return 0;
+}
+static int hip_coupled_blanker(lrh_ptrs *q)
+{
+  const lrh_ptrs q0 = *q;
+  int n[2] = { 0, 0 };
+  size_t nw = 0;
+  for (int ch = 0; ch < 2; ch++) if (lrh_blanker_begin(hip_ctx[ch], &q0, &n[ch]) != 0) return 1;
+  if (n[0] != n[1]) return 1;
+  if (n[0] > 0 && hip_xsum(LRH_X_PWR, (size_t)n[0]) != 0) return 1;
+  if (lrh_blanker_weak_span(hip_rx, &nw) != 0) return 1;
+  if (nw > 0 && hip_xgather(LRH_X_WEAK, nw) != 0) return 1;
+  for (int ch = 0; ch < 2; ch++) { *q = q0; if (lrh_first_noise_blanker(hip_ctx[ch], q) != 0) return 1; }
+  if (n[0] > 0) {
+    if (hip_xsum(LRH_X_STAT, 2) != 0) return 1;
+    for (int ch = 0; ch < 2; ch++) { lrh_ptrs t = *q; if (lrh_blanker_finish(hip_ctx[ch], &t) != 0) return 1; if (ch == 1) *q = t; }
+  }
+  return 0;
 }
 
 /* the linear blanker's tables follow hg.clever_bln_mode (hires_graph.c:496-498 toggles it; init_blanker, buf.c:1771, built them) */
@@ -216,24 +301,25 @@ static void hip_blanker_tables(void)
   int i;
   if (hg.clever_bln_mode == hip_clever_mode) return;
   hip_clever_mode = hg.clever_bln_mode;
-  if (hg.clever_bln_mode == 0 || refpul_size == 0) { lrh_set_blanker_tables(hip_rx, NULL); return; }
+  if (hg.clever_bln_mode == 0 || refpul_size == 0) { for (int ch = 0; ch < HC; ch++) lrh_set_blanker_tables(hip_ctx[ch], NULL); return; }
   memset(&t, 0, sizeof t);
   t.clever_bln_mode = hg.clever_bln_mode; t.clever_bln_factor = hg.clever_bln_factor; t.clever_bln_limit = hg.clever_bln_limit;
   t.refpul_size = refpul_size; t.largest_blnfit = largest_blnfit; t.liminfo_amplitude_factor = liminfo_amplitude_factor;
   for (i = 0; i < BLN_INFO_SIZE && i < LRH_BLN_INFO_SIZE; i++) { t.bln[i].size = bln[i].size; t.bln[i].rest = bln[i].rest; t.bln[i].avgmax = bln[i].avgmax; }
   t.refpulse = blanker_refpulse; t.phasefunc = blanker_phasefunc; t.pulindex = blanker_pulindex;
-  if (lrh_set_blanker_tables(hip_rx, &t) != 0) lirerr(1472);
+  for (int ch = 0; ch < HC; ch++) if (lrh_set_blanker_tables(hip_ctx[ch], &t) != 0) lirerr(1472);
 }
 
 void hip_first_noise_blanker(void)
 {
   lrh_ptrs q;
   memset(&q, 0, sizeof q);
-  q.timf2p_fit = timf2p_fit; q.timf2_pn2 = timf2_pn2; q.timf2_pa = timf2_pa; q.timf2_blanker_points = timf2_blanker_points;
+  q.timf2p_fit = timf2p_fit; q.timf2_pn2 = HIP_IN(timf2_pn2); q.timf2_pa = HIP_IN(timf2_pa); q.timf2_blanker_points = timf2_blanker_points;
   q.blanker_info_update_counter = blanker_info_update_counter; q.fft1_lowlevel_fraction = fft1_lowlevel_fraction;
   hip_blanker_tables();
-  if (lrh_first_noise_blanker(hip_rx, &q) != 0) { lirerr(1468); return; }
-  timf2p_fit = q.timf2p_fit; timf2_pn2 = q.timf2_pn2; timf2_blanker_points = q.timf2_blanker_points;     /* blank1.c:1458-1476 */
+  if (HC == 1) { if (lrh_first_noise_blanker(hip_rx, &q) != 0) { lirerr(1468); return; } }
+  else if (hip_coupled_blanker(&q) != 0) { lirerr(1468); return; }
+  timf2p_fit = q.timf2p_fit; timf2_pn2 = HIP_OUT(q.timf2_pn2); timf2_blanker_points = q.timf2_blanker_points;     /* blank1.c:1458-1476 */
   if (q.blanker_info_update_counter == 0 && blanker_info_update_counter != 0) {   /* thresholds were updated (blank1.c:1550-1601) */
     lrh_blanker_state bs;
     if (lrh_get_blanker_state(hip_rx, &bs) == 0) {
@@ -278,13 +364,18 @@ static void hip_liminfo_back(void)
   pthread_mutex_unlock(&hip_liminfo_lock);
   lrh_get_liminfo_amplitude_factor(hip_rx, &liminfo_amplitude_factor);
 }
-void hip_fft1_update_liminfo(void)
+int hip_fft1_update_liminfo(void)
 {
   lrh_sellim par;
   lrh_ptrs q;
+  /* two channels: the reference's limiter works on the channels' summed spectra with its limit scaled by rx_rf_channels (sellim.c:786);
+     hip_fft1_c has brought fft1_sumsq / fft1_slowsum (sums over both) to the host, Linrad's own code runs on them and hip_make_timf2
+     uploads the table it leaves in liminfo[] to both contexts */
+  if (HC == 2) return 0;
   hip_sellim_par(&par, &q);
-  if (lrh_fft1_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1471); return; }
+  if (lrh_fft1_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1471); return 1; }
   hip_liminfo_back();
+  return 1;
 }
 /* fft2_update_liminfo (sellim.c:159; all three settings of hg.sellim_par1 run on the device-resident fft2 power sums) */
 int hip_fft2_update_liminfo(void)
@@ -292,6 +383,7 @@ int hip_fft2_update_liminfo(void)
   lrh_sellim par;
   lrh_ptrs q;
   if (hg.sellim_par1 < 0 || hg.sellim_par1 > 2) return 0;
+  if (HC == 2) return 1;                                    /* two channels: not served (the fft2 sums live on the device; the first limiter carries on) */
   hip_sellim_par(&par, &q);
   if (lrh_fft2_update_liminfo(hip_rx, &q, &par) != 0) { lirerr(1473); return 1; }
   hip_liminfo_back();
@@ -387,15 +479,28 @@ void hip_make_fft2(void)
   lrh_ptrs q;
   int old_ptr;
   memset(&q, 0, sizeof q);
-  q.timf2_px = timf2_px; q.fft2_na = fft2_na; q.fft2_pa = fft2_pa; q.fft2_nb = fft2_nb; q.fft2_nm = fft2_nm;
+  q.timf2_px = HIP_IN(timf2_px); q.fft2_na = fft2_na; q.fft2_pa = HIP_IN(fft2_pa); q.fft2_nb = fft2_nb; q.fft2_nm = fft2_nm;
   q.wg_waterf_sum_counter = wg_waterf_sum_counter; q.wg_waterf_ptr = wg_waterf_ptr; q.fft2_liminfo_cnt = fft2_liminfo_cnt;
   old_ptr = wg_waterf_ptr;
-  if (lrh_make_fft2(hip_rx, &q, 1) != 0) { lirerr(1469); return; }
-  timf2_px = q.timf2_px; fft2_na = q.fft2_na; fft2_pa = q.fft2_pa; fft2_nb = q.fft2_nb; fft2_nm = q.fft2_nm;   /* fft2.c:1831-1845 */
+  if (HC == 1) { if (lrh_make_fft2(hip_rx, &q, 1) != 0) { lirerr(1469); return; } }
+  else {
+    /* two channels: each context transforms its own; the cross products TWOCHAN_POWER, their sums over the waterfall group and the
+       polarisation-independent waterfall line (fft2.c:1622-1640, 1700-1815) need both channels' bins: all-gather of LRH_X_BINS */
+    const lrh_ptrs at = q;
+    size_t cnt[2] = { 0, 0 };
+    for (int ch = 0; ch < 2; ch++) {
+      q = at;
+      if (lrh_make_fft2(hip_ctx[ch], &q, 1) != 0 || lrh_fft2_xy_begin(hip_ctx[ch], &at, 1, &cnt[ch]) != 0) { lirerr(1469); return; }
+    }
+    if (cnt[0] != cnt[1] || hip_xgather(LRH_X_BINS, cnt[0]) != 0) { lirerr(1469); return; }
+    for (int ch = 0; ch < 2; ch++) if (lrh_fft2_xy_finish(hip_ctx[ch], &at, 1) != 0) { lirerr(1469); return; }
+  }
+  timf2_px = HIP_OUT(q.timf2_px); fft2_na = q.fft2_na; fft2_pa = HIP_OUT(q.fft2_pa); fft2_nb = q.fft2_nb; fft2_nm = q.fft2_nm;   /* fft2.c:1831-1845 */
   wg_waterf_sum_counter = q.wg_waterf_sum_counter; wg_waterf_ptr = q.wg_waterf_ptr; fft2_liminfo_cnt = q.fft2_liminfo_cnt;
   if (q.wg_waterf_ptr != old_ptr) {            /* a waterfall line completed (fft2.c:703-815): the screen thread draws it */
     lrh_export(hip_rx, LRH_RING_WG_WATERF, &wg_waterf[old_ptr], (size_t)old_ptr, (size_t)wg_xpixels);
-    lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
+    if (HC == 1) lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
+    else lrh_export(hip_rx, LRH_RING_FFT2_XYSUM, fft2_xysum, 0, (size_t)4 * hip_n2);
   }
   hip_afc_rows((q.fft2_na + fft2n_mask) & fft2n_mask, 1);
   if (hip_spurs_on) hip_spur_after_fft2((q.fft2_na + fft2n_mask) & fft2n_mask);
@@ -409,6 +514,28 @@ static void hip_mix1_back(int old_pa)
 {
   lrh_mix1_state m;
   int n = timf3_block, first = n;
+  if (HC == 2) {                                           /* {ch0, ch1} per sample: each context's block, interleaved (timf3_block counts both) */
+    const int per = timf3_block / 2, size1 = timf3_size / 2;
+    int pa1 = old_pa / 2;
+    float *t = hip_scratch((size_t)per);
+    for (int ch = 0; ch < 2; ch++) {
+      int done = 0, p1 = pa1;
+      while (done < per) {
+        int k = per - done; if (p1 + k > size1) k = size1 - p1;
+        lrh_export(hip_ctx[ch], LRH_RING_TIMF3_FLOAT, t + done, (size_t)p1, (size_t)k);
+        done += k; p1 = (p1 + k) & (size1 - 1);
+      }
+      for (int i = 0; i < per / 2; i++) {
+        const int at = (old_pa + 4 * i) & timf3_mask;
+        timf3_float[at + 2 * ch] = t[2 * i]; timf3_float[at + 2 * ch + 1] = t[2 * i + 1];
+      }
+    }
+    if (lrh_get_mix1_state(hip_rx, &m) == 0 && m.mix1_selfreq >= 0) {
+      mix1_point[0] = m.mix1_point; mix1_old_point[0] = m.mix1_old_point; mix1_phase[0] = m.mix1_phase;
+      mix1_phase_step[0] = m.mix1_phase_step; mix1_phase_rot[0] = m.mix1_phase_rot; mix1_old_phase[0] = m.mix1_old_phase;
+    }
+    return;
+  }
   if (old_pa + n > timf3_size) first = timf3_size - old_pa;
   lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, &timf3_float[old_pa], (size_t)old_pa, (size_t)first);
   if (first < n) lrh_export(hip_rx, LRH_RING_TIMF3_FLOAT, timf3_float, 0, (size_t)(n - first));
@@ -423,11 +550,12 @@ void hip_fft2_mix1_fixed(void)
   lrh_ptrs q;
   int old_pa;
   memset(&q, 0, sizeof q);
-  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
-  q.fft2_nx = fft2_nx; q.timf3_pa = timf3_pa; q.fft2_na = fft2_na;
+  for (int ch = 0; ch < HC; ch++) lrh_set_mix1_selfreq(hip_ctx[ch], mix1_selfreq[0]);
+  q.fft2_nx = fft2_nx; q.timf3_pa = HIP_IN(timf3_pa); q.fft2_na = fft2_na;
   old_pa = timf3_pa;
-  if (lrh_fft2_mix1_fixed(hip_rx, &q, 1) != 0) { lirerr(1470); return; }
-  fft2_nx = q.fft2_nx; timf3_pa = q.timf3_pa;                                   /* mix1.c:991-992 */
+  { const lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft2_mix1_fixed(hip_ctx[ch], &q, 1) != 0) { lirerr(1470); return; } } }
+  fft2_nx = q.fft2_nx; timf3_pa = HIP_OUT(q.timf3_pa);                          /* mix1.c:991-992 */
   hip_mix1_back(old_pa);
 }
 
@@ -438,11 +566,12 @@ void hip_fft1_mix1_fixed(void)
   lrh_ptrs q;
   int old_pa;
   memset(&q, 0, sizeof q);
-  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
-  q.fft1_nx = fft1_nx; q.fft1_px = fft1_px; q.fft1_nb = fft1_nb; q.timf3_pa = timf3_pa;
+  for (int ch = 0; ch < HC; ch++) lrh_set_mix1_selfreq(hip_ctx[ch], mix1_selfreq[0]);
+  q.fft1_nx = fft1_nx; q.fft1_px = HIP_IN(fft1_px); q.fft1_nb = fft1_nb; q.timf3_pa = HIP_IN(timf3_pa);
   old_pa = timf3_pa;
-  if (lrh_fft1_mix1_fixed(hip_rx, &q, 1) != 0) { lirerr(1474); return; }
-  fft1_nx = q.fft1_nx; fft1_px = q.fft1_px; timf3_pa = q.timf3_pa;             /* mix1.c:1039-1041 */
+  { const lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_mix1_fixed(hip_ctx[ch], &q, 1) != 0) { lirerr(1474); return; } } }
+  fft1_nx = q.fft1_nx; fft1_px = HIP_OUT(q.fft1_px); timf3_pa = HIP_OUT(q.timf3_pa);             /* mix1.c:1039-1041 */
   hip_mix1_back(old_pa);
 }
 
@@ -462,11 +591,12 @@ void hip_fft2_mix1_afc(void)
   if (mix1_selfreq[0] < 0) { hip_fft2_mix1_fixed(); return; }                   /* nothing selected: mix1_clear either way (mix1.c:924-927) */
   memset(&q, 0, sizeof q);
   hip_afc_tables(&a);
-  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
-  q.fft2_nx = fft2_nx; q.timf3_pa = timf3_pa; q.fft2_na = fft2_na;
+  for (int ch = 0; ch < HC; ch++) lrh_set_mix1_selfreq(hip_ctx[ch], mix1_selfreq[0]);
+  q.fft2_nx = fft2_nx; q.timf3_pa = HIP_IN(timf3_pa); q.fft2_na = fft2_na;
   old_pa = timf3_pa;
-  if (lrh_fft2_mix1_afc(hip_rx, &q, 1, &a) != 0) { lirerr(1475); return; }
-  fft2_nx = q.fft2_nx; timf3_pa = q.timf3_pa;                                   /* mix1.c:930-931 */
+  { const lrh_ptrs q0 = q;                                 /* (the second context finds the tables as the first has left them: the same numbers once more) */
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft2_mix1_afc(hip_ctx[ch], &q, 1, &a) != 0) { lirerr(1475); return; } } }
+  fft2_nx = q.fft2_nx; timf3_pa = HIP_OUT(q.timf3_pa);                          /* mix1.c:930-931 */
   hip_mix1_back(old_pa);
 }
 void hip_fft1_mix1_afc(void)
@@ -477,11 +607,12 @@ void hip_fft1_mix1_afc(void)
   if (mix1_selfreq[0] < 0) { hip_fft1_mix1_fixed(); return; }
   memset(&q, 0, sizeof q);
   hip_afc_tables(&a);
-  lrh_set_mix1_selfreq(hip_rx, mix1_selfreq[0]);
-  q.fft1_nx = fft1_nx; q.fft1_px = fft1_px; q.fft1_nb = fft1_nb; q.timf3_pa = timf3_pa;
+  for (int ch = 0; ch < HC; ch++) lrh_set_mix1_selfreq(hip_ctx[ch], mix1_selfreq[0]);
+  q.fft1_nx = fft1_nx; q.fft1_px = HIP_IN(fft1_px); q.fft1_nb = fft1_nb; q.timf3_pa = HIP_IN(timf3_pa);
   old_pa = timf3_pa;
-  if (lrh_fft1_mix1_afc(hip_rx, &q, 1, &a) != 0) { lirerr(1476); return; }
-  fft1_nx = q.fft1_nx; fft1_px = q.fft1_px; timf3_pa = q.timf3_pa;             /* mix1.c:1094-1096 */
+  { const lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_mix1_afc(hip_ctx[ch], &q, 1, &a) != 0) { lirerr(1476); return; } } }
+  fft1_nx = q.fft1_nx; fft1_px = HIP_OUT(q.fft1_px); timf3_pa = HIP_OUT(q.timf3_pa);             /* mix1.c:1094-1096 */
   hip_mix1_back(old_pa);
 }
 
@@ -492,10 +623,21 @@ void hip_compute_timf2_powersum(void)
   lrh_ptrs q;
   int old_pa, n;
   memset(&q, 0, sizeof q);
-  q.timf2_pn2 = timf2_pn2; q.timf2_pb = timf2_pb; q.timf2_blockpower_pa = timf2_blockpower_pa;
+  q.timf2_pn2 = HIP_IN(timf2_pn2); q.timf2_pb = HIP_IN(timf2_pb); q.timf2_blockpower_pa = timf2_blockpower_pa;
   old_pa = timf2_blockpower_pa;
-  if (lrh_compute_timf2_powersum(hip_rx, &q) != 0) { lirerr(1477); return; }
-  timf2_pb = q.timf2_pb; timf2_blockpower_pa = q.timf2_blockpower_pa;
+  { const lrh_ptrs q0 = q;
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_compute_timf2_powersum(hip_ctx[ch], &q) != 0) { lirerr(1477); return; } } }
+  timf2_pb = HIP_OUT(q.timf2_pb); timf2_blockpower_pa = q.timf2_blockpower_pa;
+  if (HC == 2) {                                           /* {ch0, ch1} per block (wcw.c:112-134) */
+    n = (q.timf2_blockpower_pa - old_pa) & timf2_blockpower_mask;
+    while (n > 0) {
+      float t[2];
+      for (int ch = 0; ch < 2; ch++) lrh_export(hip_ctx[ch], LRH_RING_TIMF2_BLOCKPOWER, &t[ch], (size_t)old_pa, 1);
+      timf2_blockpower[2 * old_pa] = t[0]; timf2_blockpower[2 * old_pa + 1] = t[1];
+      old_pa = (old_pa + 1) & timf2_blockpower_mask; n--;
+    }
+    return;
+  }
   n = (q.timf2_blockpower_pa - old_pa) & timf2_blockpower_mask;
   while (n > 0) {
     int k = n;

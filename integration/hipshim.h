@@ -20,7 +20,7 @@ int  hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number);   /* fft1_b 
 void hip_fft1_c(void);               /* stand-ins for the stage functions of the same names                                     */
 void hip_make_timf2(void);
 void hip_first_noise_blanker(void);   /* also installs / removes the linear blanker's tables when hg.clever_bln_mode changes */
-void hip_fft1_update_liminfo(void);   /* selective limiter on the device-resident power spectra (sellim.c:738)             */
+int  hip_fft1_update_liminfo(void);   /* selective limiter on the device-resident power spectra (sellim.c:738); 0: not taken (two channels: Linrad's own code on the summed spectra) */
 int  hip_fft2_update_liminfo(void);   /* second limiter on the fft2 power sums (sellim.c:159); 0: not taken (hg.sellim_par1 != 2) */
 void hip_make_fft2(void);
 void hip_fft2_mix1_fixed(void);
@@ -35,5 +35,6 @@ int  hip_store_new_spur(int pnt);     /* spur acquisition (spursub.c:619, 1247) 
 int  hip_spur_phase_lock(int nx);
 void hip_remove_spur(int ia);
 void hip_swap_spurs(int ia, int ib);
-struct lrh_ctx *hip_context(void);    /* the context behind the hooks (diagnostics, tests)                                    */
+struct lrh_ctx *hip_context(void);
+struct lrh_ctx *hip_context_of(int channel);   /* two RF channels: one context each */    /* the context behind the hooks (diagnostics, tests)                                    */
 #endif

@@ -71,6 +71,7 @@ def edit_fft1var(L):
            ',{1,2,14,0,0,GPU_HIP,0,1,0,   "HIP MI355X real"}                   //22\n')
     replace(L, r"1 chan direct conversion \(IQ\)", "19, -1}", "19, 21}")
     replace(L, r"1 chan normal audio", "4, -1,", "4, 22,")
+    replace(L, r"2 chan direct conversion \(IQ\)", "20, -1}", "20, 21}")     # two RF channels: one context per channel behind the same hooks
 
 
 def edit_buf(L):
@@ -100,6 +101,9 @@ def edit_fft1(L):
     insert(L, r"^\s+default:\s*$", "    case 21:\n    case 22:\n// HIP on MI355X: the transform, the correction of fft1_c and every ring behind it stay on the device.\n"
            "    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
            where="before", start=i)
+    # the switch of the two-channel branch (fft1.c:3686-3900): the same case -- hip_fft1_b runs one context per channel
+    insert(L, r"^\s+default:\s*$", "    case 21:\n    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
+           where="before", start=i, nth=2)
     func_top(L, r"^void fft1_c\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_c();return;}\n")
 
 
@@ -129,7 +133,7 @@ def edit_mix1(L):
 
 def edit_sellim(L):
     after_last_include(L)
-    func_top(L, r"^void fft1_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_update_liminfo();return;}\n")
+    func_top(L, r"^void fft1_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP && hip_fft1_update_liminfo())return;\n")
     func_top(L, r"^void fft2_update_liminfo\(void\)", "if(fft1_use_gpu == GPU_HIP && hip_fft2_update_liminfo())return;\n")
 
 

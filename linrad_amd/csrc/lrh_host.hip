@@ -25,7 +25,7 @@ hipError_t launch_sumsq_join(const SumsqArgs &a, const float *part, int run, hip
 int timf2_grid(int log2n, int batch);
 hipError_t launch_fft2(int log2n, const Fft2Args &a, int batch, hipStream_t st);
 hipError_t launch_mix1_back(int log2n, const Mix1Args &a, int batch, hipStream_t st);
-hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st);
+hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st, int steps = 3);
 hipError_t launch_mix1_out(const Mix1OutArgs &a, int batch, hipStream_t st);
 hipError_t launch_sumsq(const SumsqArgs &a, hipStream_t st);
 hipError_t launch_slowsum(const SlowsumArgs &a, hipStream_t st);
@@ -122,6 +122,10 @@ struct lrh_ctx {
   float2 *d_xbins = nullptr; float4 *d_xypower = nullptr, *d_xysum = nullptr, *d_xysum_alt = nullptr;   // LRH_X_BINS [2][max_fft2n][N2]; TWOCHAN_POWER rings
   int x_pbeg = 0, x_count = -1; bool fin_pending = false; BlankArgs fin_args;
   int dbg_stamp = 0, dbg_bln = 0;    // LRH_STAMP / LRH_BLN_DEBUG, read once in lrh_open
+  // four-step fft2 in spans (LRH_FFT2_SPAN transforms each): the column step of span s+1 runs on the main stream beside the row step of
+  // span s on a stream of its own, and the scratch of a span (67 MB at 128 transforms of 65536) is re-used every third span: what the
+  // column step writes the row step reads while it is still in the 256 MB Infinity Cache, and a re-used line never reaches the HBM
+  int fft2_span = 0; hipStream_t stream_f2 = nullptr; hipEvent_t ev_f2c[3] = {}, ev_f2r[3] = {};
   int env_fft2_run = 0, env_fft2_cols_run = 0;   // LRH_FFT2_RUN / LRH_FFT2_COLS_RUN: transforms per workgroup (0: automatic)
   unsigned long long *d_stamps = nullptr;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
@@ -473,6 +477,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   if (const char *e9v = getenv("LRH_FFT1V")) c->fuse_v = atoi(e9v) != 0;
+  if (const char *e9s = getenv("LRH_FFT2_SPAN")) c->fft2_span = atoi(e9s);
   if (const char *e9 = getenv("LRH_FUSE_FFT1")) { c->fuse_fft1 = atoi(e9) != 0; c->fuse_fft1_forced = c->fuse_fft1; }   // 0: k_fft1 + k_timf2 also where k_fft1w would run; 1: k_fft1w also for rounds of a few blocks
   c->sums_on_main = cfg->fft2_n <= 14;
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
@@ -1841,6 +1846,38 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   LRH_DEVICE_WORK(c, {
     if (c->split_fft2_tail) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_ps2, 0));   // side-stream sums of the previous call read these rings
     if (fft2_n <= 14) { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2(fft2_n, a, batch, c->cur)); }
+    else if (c->fft2_span > 0 && g.ps_avgnum > 0 && batch >= 2 * c->fft2_span && 5 * (c->fft2_span + g.ps_avgnum) <= c->cfg.max_fft2n) {
+      ProfScope ps(c, "fft2");
+      if (!c->stream_f2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f2, hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2c[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_f2r[i], hipEventDisableTiming)); }
+      }
+      // spans end where a waterfall averaging group ends (the row step sums |X|^2 over whole groups): the first carries the group in
+      // progress, the last may leave one unfinished
+      const int avg = g.ps_avgnum;
+      const int span = (c->fft2_span + avg - 1) / avg * avg;
+      { static int said = 0; if (!said++ && getenv("LRH_FFT2_SPAN_DEBUG")) fprintf(stderr, "fft2 of %d transforms in spans of %d\n", batch, span); }
+      int b0 = 0;
+      int sp = 0;
+      while (b0 < batch) {
+        int b1 = b0 + span - (b0 == 0 ? g.ps_counter % avg : 0);          // (ps_counter + b1) % avg == 0
+        if (batch - b1 < span / 2) b1 = batch;
+        Fft2BigArgs gs = g;
+        const int slot = sp % 3;
+        gs.px_first = (g.px_first + b0 * g.step) & g.mask; gs.first_na = (g.first_na + b0) & g.na_mask;
+        gs.scratch = g.scratch + (size_t)slot * (span + span / 2) * N;
+        gs.ps_counter = b0 == 0 ? g.ps_counter : 0;
+        gs.wf_scratch = g.wf_scratch + (size_t)((g.ps_counter + b0) / avg) * N;
+        if (sp >= 3) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_f2r[slot], 0));          // the row step that read this scratch slot last
+        HIPCHK(c, launch_fft2_big(fft2_n, gs, b1 - b0, c->cur, 1));
+        HIPCHK(c, hipEventRecord(c->ev_f2c[slot], c->cur));
+        HIPCHK(c, hipStreamWaitEvent(c->stream_f2, c->ev_f2c[slot], 0));
+        HIPCHK(c, launch_fft2_big(fft2_n, gs, b1 - b0, c->stream_f2, 2));
+        HIPCHK(c, hipEventRecord(c->ev_f2r[slot], c->stream_f2));
+        b0 = b1; sp++;
+      }
+      for (int i = 0; i < 3 && i < sp; i++) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_f2r[(sp - 1 - i) % 3], 0));
+    }
     else { ProfScope ps(c, "fft2"); HIPCHK(c, launch_fft2_big(fft2_n, g, batch, c->cur)); }
     hipStream_t main_s = c->cur;
     if (c->split_fft2_tail) {                      // power sums and waterfall lines only feed the GUI side: side stream

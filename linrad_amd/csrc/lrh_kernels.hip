@@ -2542,7 +2542,7 @@ hipError_t launch_fft2(int log2n, const Fft2Args &a0, int batch, hipStream_t st)
   LRH_DISPATCH(LRH_LAUNCH_FFT2, log2n, 6, 14, a, batch, st);
   return hipGetLastError();
 }
-template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, int batch, hipStream_t st)
+template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, int batch, hipStream_t st, int steps)   // steps: 1 column step, 2 row step, 3 both
 {
   Fft2BigArgs a = a0; a.batch = batch;
   {
@@ -2551,7 +2551,8 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
     int run = a0.run > 0 ? a0.run : batch * tiles / 512;         // a0.run: tuning knob LRH_FFT2_COLS_RUN (read by lrh_open)
     a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
   }
-  hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  if (steps & 1) hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
+  if (!(steps & 2)) return;
   // rows of 256 points: 16 points per thread (k_fft2_rows' PPT; LRH_FFT2_ROWS_P16=0: the 4-point form, for comparison)
   static const int rows16 = getenv("LRH_FFT2_ROWS_P16") ? atoi(getenv("LRH_FFT2_ROWS_P16")) : 1;
   if constexpr (LB == 8) {
@@ -2960,13 +2961,13 @@ hipError_t launch_timf2_big(int log2n, const Timf2BigArgs &a0, int batch, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st)
+hipError_t launch_fft2_big(int log2n, const Fft2BigArgs &a, int batch, hipStream_t st, int steps)
 {
   switch (log2n) {
-    case 15: launch_fft2_big_t<8, 7>(a, batch, st); break;
-    case 16: launch_fft2_big_t<8, 8>(a, batch, st); break;
-    case 17: launch_fft2_big_t<9, 8>(a, batch, st); break;
-    case 18: launch_fft2_big_t<9, 9>(a, batch, st); break;
+    case 15: launch_fft2_big_t<8, 7>(a, batch, st, steps); break;
+    case 16: launch_fft2_big_t<8, 8>(a, batch, st, steps); break;
+    case 17: launch_fft2_big_t<9, 8>(a, batch, st, steps); break;
+    case 18: launch_fft2_big_t<9, 9>(a, batch, st, steps); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

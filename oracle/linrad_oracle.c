@@ -451,9 +451,12 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
   const int dword = c->cfg.timf1_dword_input != 0, esz = dword ? 4 : 2;   /* fft1.c:420 / :526 */
   const int32_t *t32 = (const int32_t *)c->timf1;
   int m = c->timf1_bytemask / esz;
-  int p0 = timf1p_ref / esz; p0 = (p0 - c->I1 * 2 + m + 1) & m;
-  int pa = p0, pb = (pa + N) & m, pa1 = pa, pb1 = pb;
-  const int sh = c->cfg.sample_shift;
+  /* frames of C channels {I0,Q0,I1,Q1,..} (fft1win_dif_chan, fft1.c:2041-2055: p0 = ref/2 - 4 I1, channel stride 4 shorts): this
+     context's channel is cfg.timf1_channel_index; one channel: C = 1 */
+  const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1, st = 2 * C;
+  int p0 = timf1p_ref / esz; p0 = (p0 - c->I1 * st + 2 * (C > 1 ? c->cfg.timf1_channel_index : 0) + 4 * (m + 1)) & m;
+  int pa = p0, pb = (pa + N * C) & m, pa1 = pa, pb1 = pb;
+  const int sh = C > 1 ? 0 : c->cfg.sample_shift;
   if (sh < 0) { pa1 = (pa + 2 * sh + m + 1) & m; pb1 = (pa1 + N) & m; }            /* fft1.c:472-476 */
   else if (sh > 0) { pa = (pa - 2 * sh + m + 1) & m; pb = (pb - 2 * sh + m + 1) & m; } /* fft1.c:478-482 */
   float *z = c->tmp;
@@ -464,7 +467,7 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
     if (dword) { t1 = t32[pa] * wa; t2 = t32[pa1 + 1] * wa; t3 = t32[pb] * wb; t4 = t32[pb1 + 1] * wb; }
     else { t1 = c->timf1[pa] * wa; t2 = c->timf1[pa1 + 1] * wa; t3 = c->timf1[pb] * wb; t4 = c->timf1[pb1 + 1] * wb; }
     z[2 * ia] = t1; z[2 * ia + 1] = -t2; z[2 * (ia + nn)] = t3; z[2 * (ia + nn) + 1] = -t4;
-    pa = (pa + 2) & m; pb = (pb + 2) & m; pa1 = (pa1 + 2) & m; pb1 = (pb1 + 2) & m;
+    pa = (pa + st) & m; pb = (pb + st) & m; pa1 = (pa1 + st) & m; pb1 = (pb1 + st) & m;
   }
   dif_stages(N, n, z, c->fft1tab, +1, 2);
   for (unsigned i = 0; i < (unsigned)N; i++) {   /* bit reversal + half swap: make_permute(1,..) fft0.c:1147-1207 */
@@ -515,7 +518,7 @@ static void fft1_one(lro_ctx *c, int timf1p_ref, float *out)
 int lro_fft1_b(lro_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
 {
   (void)handle;                                /* gpu_handle_number: which worker thread calls (fft1.c:3302); no meaning on the CPU */
-  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4);
+  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4) * (c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1);
   for (int b = 0; b < batch; b++) {
     int nb = ((fft1_pa / (2 * c->N1)) + b) & c->fft1n_mask;
     float *out = c->fft1_float + (size_t)nb * 2 * c->N1;

@@ -900,6 +900,27 @@ run_done:
 #ifdef SHIM_HARNESS
   /* the rings Linrad never sees with version 21, fetched for the comparison; everything else below is the host's own copy as the
      glue kept it (fft1_sumsq, fft1_slowsum, fft2_powersum_float, wg_waterf lines, timf3_float, timf2_blockpower, liminfo, scalars) */
+  if (C == 2) {
+    /* two channels: one context each; Linrad's arrays hold {ch0, ch1} per bin / sample (fft1.c:2041, timf2.c:210, fft2.c:1622) */
+    const size_t n1f = (size_t)max_fft1n * 2 * N1, n2f = (size_t)timf2pow_size * 4, nf2 = (size_t)2 * N2 * max_fft2n;
+    float *t = zalloc(sizeof(float) * (n1f > n2f ? (n1f > nf2 ? n1f : nf2) : (n2f > nf2 ? n2f : nf2)));
+    for (int ch = 0; ch < 2; ch++) {
+      lrh_export(hip_context_of(ch), LRH_RING_FFT1_FLOAT, t, 0, n1f);
+      for (size_t i = 0; i < n1f / 2; i++) { fft1_float[4 * i + 2 * ch] = t[2 * i]; fft1_float[4 * i + 2 * ch + 1] = t[2 * i + 1]; }
+      if (!second) continue;
+      lrh_export(hip_context_of(ch), LRH_RING_TIMF2_FLOAT, t, 0, n2f);
+      for (size_t i = 0; i < (size_t)timf2pow_size; i++) for (int ws = 0; ws < 2; ws++) for (int k = 0; k < 2; k++) timf2_float[8 * i + 4 * ws + 2 * ch + k] = t[4 * i + 2 * ws + k];
+      lrh_export(hip_context_of(ch), LRH_RING_TIMF2_PWR, t, 0, timf2pow_size);
+      for (size_t i = 0; i < (size_t)timf2pow_size; i++) timf2_pwr_float[i] = (ch ? timf2_pwr_float[i] : 0) + t[i];
+      lrh_export(hip_context_of(ch), LRH_RING_FFT2_FLOAT, t, 0, nf2);
+      for (size_t i = 0; i < nf2 / 2; i++) { fft2_float[4 * i + 2 * ch] = t[2 * i]; fft2_float[4 * i + 2 * ch + 1] = t[2 * i + 1]; }
+    }
+    if (second && chain2) {
+      lrh_export(hip_context(), LRH_RING_FFT2_XYPOWER, fft2_xypower, 0, (size_t)4 * N2 * max_fft2n);
+      lrh_export(hip_context(), LRH_RING_FFT2_XYSUM, fft2_xysum, 0, (size_t)4 * N2);
+    }
+    free(t);
+  } else {
   lrh_export(hip_context(), LRH_RING_FFT1_FLOAT, fft1_float, 0, (size_t)max_fft1n * fft1_block);
   if (second && shim_net) {                          /* the network thread's walks (rxin.c:944-966, 1026-1035), a packet's worth at a time, from the pointers it keeps */
     for (int pt = 0; pt < timf2_size; pt += 696) hip_net_timf2(pt, pt + 696 <= timf2_size ? 696 : timf2_size - pt);
@@ -911,6 +932,7 @@ run_done:
     lrh_export(hip_context(), LRH_RING_TIMF2_PWR, timf2_pwr_float, 0, timf2pow_size);
     lrh_export(hip_context(), LRH_RING_FFT2_FLOAT, fft2_float, 0, (size_t)2 * N2 * max_fft2n);
     lrh_export(hip_context(), LRH_RING_FFT2_POWER, fft2_power_float, 0, (size_t)N2 * max_fft2n);
+  }
   }
   hip_close();
 #endif

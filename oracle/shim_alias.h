@@ -40,6 +40,14 @@
 #define lrh_spur_acquire lro_spur_acquire
 #define lrh_spur_get lro_spur_get
 #define lrh_spur_permute lro_spur_permute
+#define lrh_blanker_begin lro_blanker_begin
+#define lrh_blanker_weak_span lro_blanker_weak_span
+#define lrh_blanker_finish lro_blanker_finish
+#define lrh_exchange_read lro_exchange_read
+#define lrh_exchange_write lro_exchange_write
+#define lrh_fft2_xy_begin lro_fft2_xy_begin
+#define lrh_fft2_xy_finish lro_fft2_xy_finish
+#define lrh_set_ch2_phasing lro_set_ch2_phasing
 #define lrh_set_filtercorr lro_set_filtercorr
 #define lrh_set_liminfo lro_set_liminfo
 #define lrh_set_mix1_selfreq lro_set_mix1_selfreq

@@ -241,3 +241,77 @@ def check_spur_case(harness, tmp_path, name="spur_n10_n12", tol=1e-5):
     rep = spurlib.compare(out, g, tol)
     assert np.array_equal(dump["final"], g["final"]) if "final" in g else True
     return rep
+
+
+def _run_2ch(harness, tmp_path, name, chain, extra):
+    from refcases import twochan_case
+    d, frames, lim = twochan_case(name, chain=chain)
+    args = ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}"] + list(extra)
+    if chain:
+        args += ["chain2=1"] + [f"pol_c{i + 1}={v!r}" for i, v in enumerate(d["pol"])]
+    dump = run_harness(harness, lambda p, fo: harness_args(d, p["in"], p["lim"], fo) + args, tmp_path, {"in": frames, "lim": lim})
+    return d, dump
+
+
+def check_twochan_case(harness, tmp_path, name="twochan_n10", tol=1e-5):
+    """ui.rx_rf_channels = 2 is served: the glue opens one context per channel (both on the one GPU) and makes the exchanges that Linrad's
+    single arrays make implicitly -- fft1_sumsq / fft1_slowsum as sums of the two contexts', the coupled blanker's power and noise sums, the
+    all-gather of the fft2 bins for the cross products -- through host memory.  Against the goldens of the compiled TWO-CHANNEL reference:
+    (a) fft1_b / fft1_c / make_timf2: both channels' spectra and time functions in Linrad's interleaved layout, the power sums;
+    (b) the same with the two-channel first_noise_blanker after every block: thresholds, pointers, cleared samples."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
+    d, dump = _run_2ch(harness, tmp_path, name, False, [])
+    n1 = 1 << d["n1"]
+    it, gi = dump["itrace"].reshape(-1, 16), g["itrace"].reshape(-1, 16)
+    assert np.array_equal(it[:, [0, 9, 10, 11, 15]], gi[:, [0, 9, 10, 11, 15]]), "pointer trace"
+    rep = {k: relerr(dump[k], g[k]) for k in ("fft1_float", "fft1_sumsq", "fft1_slowsum")}
+    pa = int(gi[-1, 0])                                     # finished samples only (the reference parks a raw half block beyond timf2_pa)
+    rep["timf2_float"] = relerr(dump["timf2_float"][:pa], g["timf2_float"][:pa])
+    rep["timf2_pwr"] = relerr(dump["timf2_pwr_float"][:pa // 8], g["timf2_pwr_float"][:pa // 8])
+    assert pa > 0 and np.abs(g["timf2_float"][:pa].reshape(-1, 2, 2, 2)[:, 1]).max() > 0
+    assert max(rep.values()) <= tol, rep
+    # (b) coupled blanker
+    d, dump = _run_2ch(harness, tmp_path, name, False, ["blanker2=1"])
+    it, gi = dump["itrace"].reshape(-1, 16), g["bln_itrace"].reshape(-1, 16)
+    assert np.array_equal(it[:, [0, 1, 2, 6, 7]], gi[:, [0, 1, 2, 6, 7]]), "blanker pointer trace"
+    assert np.abs(it[:, 12] - gi[:, 12]).max() <= 1 and np.abs(it[:, 13] - gi[:, 13]).max() <= 5, "noise floor / limit trace"
+    fit = int(gi[-1, 1])
+    got, ref = dump["timf2_float"].reshape(-1, 2, 2, 2)[:fit], g["bln_timf2_float"].reshape(-1, 2, 2, 2)[:fit]
+    cleared_g, cleared_r = (got[:, 0] == 0).all(axis=(1, 2)), g["bln_timf2_pwr_float"][:fit] == 0
+    rep["cleared"] = int(cleared_r.sum())
+    if np.array_equal(it[:, 12], gi[:, 12]):
+        assert np.array_equal(cleared_g, cleared_r) and rep["cleared"] > 50
+        rep["bln_timf2"] = relerr(got, ref)
+        assert rep["bln_timf2"] <= tol, rep
+    else:
+        assert (cleared_g & cleared_r).sum() / max((cleared_g | cleared_r).sum(), 1) > 0.97
+    return rep
+
+
+def check_twochan_chain(harness, tmp_path, name="twochan_n10", tol=1e-5):
+    """... and on through make_fft2 (each channel's transform, TWOCHAN_POWER cross products and their sums from both, the
+    polarisation-independent waterfall line, fft2.c:1622-1640, 1700-1815) and fft2_mix1_fixed; fft3 and fft3_mix2's polarisation
+    transform then run as the reference's own host code on the interleaved timf3 the glue brought back"""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}_chain.npz")))
+    d, dump = _run_2ch(harness, tmp_path, name, True, [])
+    assert np.array_equal(dump["final"], g["final"]), (dump["final"], g["final"])
+    n2 = 1 << d["n2"]
+    rep = {k: relerr(dump[k], g[k]) for k in ("fft2_float", "fft2_xypower", "fft2_xysum")}
+    assert rep["fft2_float"] <= tol and rep["fft2_xypower"] <= 2 * tol and rep["fft2_xysum"] <= 2 * tol, rep
+    gw, ow = g["wf_lines"].astype(np.int32), dump["wf_lines"].astype(np.int32)
+    assert gw.shape == ow.shape and np.abs(gw - ow).max() <= 2 and np.mean(gw != ow) < 0.02
+    # timf3 (interleaved {ch0, ch1}): the weak band under the float32 floor of the wide spectrum, as in tests/test_twochan.py
+    blk = int(dump["mixtrace"].reshape(-1, 8)[0, 6])
+    keep = np.ones(dump["timf3_float"].size, bool)
+    keep[(int(dump["final"][9]) + np.arange(blk)) % keep.size] = False
+    a, b = (dump["timf3_float"] * keep).astype(np.float64), (g["timf3_float"] * keep).astype(np.float64)
+    wide = np.linalg.norm(g["fft2_float"].astype(np.float64)) / np.sqrt(g["fft2_float"].size / (4 * n2))
+    nm = n2 >> d["mixred"]
+    floor = 4 * 6e-8 * wide * np.sqrt(nm / n2) * np.sqrt(a.size / nm / 2) * np.sqrt(nm)
+    rep["timf3"] = relerr(a, b)
+    assert np.abs(b).max() > 0 and (rep["timf3"] <= tol or np.linalg.norm(a - b) <= floor), rep
+    for k in ("fft3", "baseb_raw", "baseb_raw_orthog"):     # the reference's own host code on what the glue brought back
+        rep[k] = relerr(dump[k], g[k])
+        assert rep[k] <= 20 * tol, rep
+    assert np.array_equal(dump["fft3_ptrs"], g["fft3_ptrs"]) and np.array_equal(dump["baseb_ptrs"], g["baseb_ptrs"])
+    return rep

@@ -67,3 +67,9 @@ def test_free_running_stage_threads_with_fft1b_workers(harness, tmp_path, name, 
 @pytest.mark.parametrize("name", ["spur_n10_n12", "spur_n10_n12_drift"])
 def test_spur_removal_is_served_through_the_acquisition_hooks(harness, tmp_path, name):
     print(name, shimlib.check_spur_case(harness, tmp_path, name))
+
+
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+def test_two_rf_channels_are_served_as_two_contexts(harness, tmp_path, name):
+    print(name, shimlib.check_twochan_case(harness, tmp_path, name))
+    print(name, shimlib.check_twochan_chain(harness, tmp_path, name))
