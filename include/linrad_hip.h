@@ -423,7 +423,13 @@ int lrh_timf1_write_packed18(lrh_ctx *ctx, const void *src, int byte_offset, int
    has its own HIP stream, so transforms handed to different workers overlap on the device like the reference's
    workers overlap on CPU cores; the next reader of fft1_float (lrh_fft1_c, lrh_make_timf2, lrh_fft1_mix1_*, lrh_export)
    waits for them on the device.  The dispatcher retires workers in order before it advances fft1_pa
-   (wcw.c:1005-1032); here a worker call returns as soon as its launch is enqueued. */
+   (wcw.c:1005-1032); here a worker call returns as soon as its launch is enqueued.
+   timf1 must keep the ONE block behind timf1p_ref until the call's kernels have run (lrh_timf1_write_async orders itself behind
+   them): the fused fft1 + timf2 kernel rebuilds the overlap partner of the call's first transform from there instead of carrying
+   it in memory.  When a handle-0 call does not start where the previous one stopped, or the filter tables changed in between,
+   the ring does not hold that partner: with cfg.fft1_float_sparse = 0 the call runs as fft1 kernel + timf2 kernel (partner = the
+   previous spectrum in fft1_float, which is the reference's carry, timf2.c:1018-1025); with the sparse ring the overlap of that one
+   transform starts over as at the start of a stream. */
 int lrh_fft1_b(lrh_ctx *ctx, int handle, int timf1p_ref, int fft1_pa, int batch);
 /* fft1_c (fft1def.h:364; fft1.c:4085-4524): power accumulation into fft1_sumsq, slow average
    (update_fft1_slowsum fft1.c:4526-4605 + new_fft1_averages wide_graph.c:1003-1052), fft1_nb/pb advance. */

@@ -84,13 +84,13 @@ struct lrh_ctx {
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
   hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
-  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
+  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<hipEvent_t> ev_fft1_read_cur{nullptr}; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
   std::mutex mtx_in;                  // the producer side (lrh_timf1_write_async / _wait) has a lock of its own: an input thread is never held up by a stage call that sleeps on the staging ring
   hipStream_t stream_sel = nullptr;  // the limiter kernels: one workgroup for ~0.5 ms, kept off the side stream (the blanker of the next round queues there)
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
   hipStream_t cur = nullptr;         // stream the stage functions launch on (== stream outside the pipelined driver)
-  hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_timf2b = nullptr, ev_blank = nullptr, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
+  hipEvent_t ev_fft1 = nullptr, ev_timf2 = nullptr, ev_timf2b = nullptr, ev_blank = nullptr, ev_blank2[2] = {nullptr, nullptr}, ev_fft2 = nullptr, ev_side = nullptr, ev_ps2 = nullptr, ev_sumsq[2] = {nullptr, nullptr};
   bool split_fft2_tail = false;      // inside the two-stream schedule: powersum2 / waterfall go to the side stream
   // fft1_c's power sums inside k_timf2 (lrh_wideband_dsp, sin^2 window): fft1_c parks its arguments here, make_timf2
   // picks them up, the join of split groups and the slow average follow from ss_queue
@@ -109,6 +109,11 @@ struct lrh_ctx {
   lrh_exchange_fn xfn = nullptr; void *xuser = nullptr;     // lrh_set_exchange: collectives of two coupled channels inside lrh_wideband_dsp
   const float2 *xy_own_src = nullptr;                       // set by dsp_coupled around lrh_fft2_xy_finish: the own channel's transforms where they lie in the fft2 ring
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
+  // the fused kernels rebuild that partner from the timf1 ring (one block behind the first of the call): only right while the calls walk
+  // the ring without a gap and the tables have not changed in between
+  bool f1_end_valid = false;      // f1_end is where the previous handle-0 lrh_fft1_b stopped, under the tables in force now
+  int f1_end = 0;                 // frame index
+  bool f1_cont = false;           // the parked call starts where the previous one stopped
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
                                                                              // round k (side stream) may still read while timf2(k+1) writes
   std::vector<std::function<int(lrh_ctx *)>> ss_queue;
@@ -139,6 +144,14 @@ struct lrh_ctx {
   std::vector<std::function<int(lrh_ctx *)>> *rec = nullptr;
   bool ph_pending[LRH_NSTAGE] = {};  // staging slot handed to a deferred upload that has not been replayed yet
   hipEvent_t ev_tail = nullptr;
+  // Every event record and every wait is a packet the queue works off one after the other, ~4 us each with the next kernel held behind it
+  // (rocprofv3 timeline, profiles/r04_timeline.txt): the two-stream schedule does not record a second event where one already marks the
+  // same point of the main stream.  last_main_ev: an event recorded on the main stream with nothing enqueued there since (set and
+  // consumed within a few lines of each other, never carried across calls); ev_tail_cur: the event that stands for ev_tail.
+  hipEvent_t last_main_ev = nullptr, ev_tail_cur = nullptr;
+  // narrowband stream of the two-stream schedules: mix1 / fft3 / mix2 of a round -- a handful of small kernels, 66 us one after the other --
+  // run here beside the next round's fft1 instead of holding the main stream (LRH_NARROW_STREAM=0: on the main stream as before)
+  hipStream_t stream_nb = nullptr; hipEvent_t ev_f2done = nullptr, ev_nb = nullptr; bool nb_split = true, nb_pending = false; hipStream_t nb_keep = nullptr;
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
@@ -381,7 +394,8 @@ void lrh_close(lrh_ctx *c)
   if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
-  for (hipEvent_t ev : { c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
+  if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
+  for (hipEvent_t ev : { c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb, c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -472,7 +486,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (e != hipSuccess || ndev <= cfg->device) { int rc = fail(c, LRH_EDEVICE, "no HIP device", e); delete c; return rc; }
   if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
   c->cur = c->stream;
-  for (hipEvent_t *ev : { &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (hipStreamCreateWithFlags(&c->stream_nb, hipStreamNonBlocking) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
+  if (const char *e_ = getenv("LRH_NARROW_STREAM")) c->nb_split = atoi(e_) != 0;
+  for (hipEvent_t *ev : { &c->ev_blank2[0], &c->ev_blank2[1], &c->ev_f2done, &c->ev_nb, &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
@@ -702,6 +718,7 @@ int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
+  c->f1_end_valid = false;
   return upload_filtercorr(c);
 }
 
@@ -852,7 +869,8 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
   // behind everything queued so far on the main stream (the previous make_timf2 that read the routing words; the sums in the serial
   // order) and, when this round's sums (first limiter) or the fft2 power sums (second) ran there, on the side stream -- not otherwise:
   // the blanker of the previous round is queued there too and would hold the table back for nothing
-  HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0));
+  if (c->last_main_ev) HIPCHK(c, hipStreamWaitEvent(S, c->last_main_ev, 0));
+  else { HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0)); }
   if (which == 2 || c->sums_stream == c->stream2) { HIPCHK(c, hipEventRecord(c->ev_sel_wait2, c->stream2)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait2, 0)); }
   { hipStream_t keep = c->cur; c->cur = S;
     { ProfScope ps(c, "sellim"); hipError_t e_ = which == 1 ? launch_sellim(a, S) : launch_sellim2(a, S);
@@ -1150,7 +1168,7 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
   const int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
   // the fft1 launches already enqueued may still read the ring span being overwritten: the copy goes behind the last of
   // them (the event lrh_fft1_b records), not behind the rest of the chain
-  if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read, 0));
+  if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read_cur.load(), 0));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h]) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));
   HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
   if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
@@ -1257,9 +1275,13 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && !a.real && !a.shift_i && !a.shift_q &&
       !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
     if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
+    c->f1_cont = c->f1_end_valid && a.p0_first == c->f1_end;
+    c->f1_end = (a.p0_first + batch * a.step) & (a.ring_mask / C); c->f1_end_valid = true;
     c->f1_args = a; c->f1_batch = batch; c->f1_have = true;    // lrh_make_timf2 takes it from here (k_fft1w)
     return LRH_OK;
   }
+  if (handle == 0) { c->f1_end = (a.p0_first + batch * a.step) & (a.ring_mask / C); c->f1_end_valid = true; }
+  else c->f1_end_valid = false;                                // worker handles finish in any order
   const bool defer_big = c->f1_defer && c->fft1_big && handle == 0 && c->cfg.fft1_n == 15 && !a.real && !a.shift_i && !a.shift_q && !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp;
   if (defer_big && c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
   ProfScope ps(c, "fft1");
@@ -1276,7 +1298,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     if (defer_big) {                                       // column step now, the row step rides in lrh_make_timf2's kernel
       HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->cur, 1));
       c->f1_big = g; c->f1_args = a; c->f1_batch = batch; c->f1_have = true; c->f1_is_big = true;
-      if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read
+      if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->ev_fft1_read_cur = c->ev_fft1_read; c->fft1_read_valid = true; }   // timf1 has been read
       return LRH_OK;
     }
     HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, g, batch, c->cur));
@@ -1291,7 +1313,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
       fprintf(stderr, "\n");
     }
   }
-  if (handle == 0 && c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
+  if (handle == 0 && c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->ev_fft1_read_cur = c->ev_fft1_read; c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
   if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
     RealSplitArgs r;
     r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;
@@ -1317,7 +1339,7 @@ static int launch_parked_fft1(lrh_ctx *c)
   ProfScope ps(c, "fft1");
   if (c->f1_is_big) { c->f1_is_big = false; HIPCHK(c, launch_fft1_big(c->cfg.fft1_n, c->f1_big, c->f1_batch, c->cur, 2)); return LRH_OK; }   // the row step
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, c->f1_args, c->f1_batch, c->cur));
-  if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }
+  if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->ev_fft1_read_cur = c->ev_fft1_read; c->fft1_read_valid = true; }
   return LRH_OK;
 }
 
@@ -1392,7 +1414,13 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   const int nb_here = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask;
   const bool fused_any = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
                          c->ss_args.batch == batch && c->ss_args.first_nb == nb_here && c->cur == c->stream;
-  const bool fused1 = fused_any && !c->f1_is_big && c->d_ss_part;
+  // a gap in the walk over timf1 (or new tables) since the previous call: the ring no longer holds the partner's input.  With the whole
+  // spectrum kept the two-kernel path takes this call (its partner is the previous spectrum in the fft1 ring, the reference's own
+  // carry); with the sparse ring the call starts over like the first one of a stream (lrh_fft1_b in include/linrad_hip.h)
+  const bool partner_lost = c->timf2_primed && !c->f1_cont;
+  const bool keeps_spec = !(c->cfg.fft1_float_sparse && !c->corr_on);
+  const bool fused1 = fused_any && !c->f1_is_big && c->d_ss_part && !(partner_lost && keeps_spec);
+  bool read_alias = false;
   const bool fused15 = fused_any && c->f1_is_big;          // fft1_size 32768: row step + sums + column step of both streams (k_fft1r_t2c)
   if (!fused1 && !fused15) { const int rc_ = join_handles(c); if (rc_) return rc_; }
   if (c->sel_table_pending) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_sel, 0)); c->sel_table_pending = false; }   // routing words from the side stream
@@ -1443,7 +1471,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     w.window = f.window; w.filtercorr = f.filtercorr; w.tw = f.tw;
     w.spec = c->d_fft1; w.first_nb = a.first_nb; w.nb_mask = a.nb_mask; w.keep_spec = (c->cfg.fft1_float_sparse && !c->corr_on) ? 0 : 1;
     w.pack_cur = a.pack_cur; w.pack_prev = a.pack_prev; w.timf2w = a.timf2w; w.pwr = a.pwr; w.pa_first = a.pa_first; w.mask = a.mask; w.ampfac = a.ampfac;
-    w.have_prev = c->timf2_primed ? 1 : 0;
+    w.have_prev = (c->timf2_primed && !partner_lost) ? 1 : 0;
     w.ss_ring = sa.sumsq; w.ss_part = part; w.ss_mask = sa.sumsq_mask; w.ss_avg = sa.avg; w.ss_c0 = sa.c0; w.ss_pa0 = sa.pa0;
     w.batch = batch; w.spare_cus = a.spare_cus;
     w.filtercorr_v = c->d_filtercorr_v; w.max_wg = (int)(c->ss_part_stride / (2 * (size_t)c->N1));
@@ -1466,7 +1494,8 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
         fprintf(stderr, "\n");
       }
     }
-    if (c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->fft1_read_valid = true; }   // timf1 has been read
+    // timf1 has been read: ev_timf2_done, recorded below behind the strong stream's kernel, tells the producer (one record less between the two kernels)
+    read_alias = c->ev_fft1_read != nullptr;
     { ProfScope ps(c, "timf2s"); HIPCHK(c, launch_timf2_strong(c->cfg.fft1_n, a, batch, c->cur)); }
     const SumsqArgs ja = sa; const int run = c->ss_run;
     c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {
@@ -1489,10 +1518,12 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   } else { const int rc_ = plain_timf2(); if (rc_) return rc_; }
   // from now on the previous transform was routed with the current table
   if (c->pack_prev_stale) {
-    HIPCHK(c, hipMemcpyAsync(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice, c->cur));
+    // (a kernel of ours, not hipMemcpyAsync: the runtime's copy kernel left the stream idle for 25-30 us behind it, every round with the limiter on)
+    HIPCHK(c, launch_span_copy((float *)c->d_pack_prev, (float *)c->d_pack_cur, -1, c->N1, c->N1 - 1, 0, c->cur));
     c->pack_prev_stale = false;
   }
   HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
+  if (read_alias) { c->ev_fft1_read_cur = c->ev_timf2_done; c->fft1_read_valid = true; }
   c->timf2_primed = true;
   const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
@@ -1897,7 +1928,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     }
     if (!fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
     if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }
-    if (c->split_fft2_tail) HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2));
+    if (c->split_fft2_tail) { HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2)); c->last_main_ev = c->ev_fft2; }
     c->cur = main_s;
   });
   for (int b = 0; b < batch; b++) {                                      // fft2.c:672, 703-705, 813-815, 1831-1845
@@ -2122,7 +2153,8 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     if (c->rec && c->early_upload) {
       // parked kernels: the table goes up now on the upload stream (behind the kernels that last read this slot,
       // which ev_tail / ev_side cover) and the kernels wait for it when they are finally launched
-      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_tail, 0));
+      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_tail_cur ? c->ev_tail_cur : c->ev_tail, 0));
+      if (c->nb_pending) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_nb, 0));
       HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->stream3));
       HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream3));
       LRH_DEVICE_WORK(c, {
@@ -2325,16 +2357,17 @@ static int flush_pending(lrh_ctx *c)
   hipStream_t S1 = c->stream, S2 = c->stream2;
   struct Restore { lrh_ctx *c; ~Restore() { c->cur = c->stream; c->rec = nullptr; c->split_fft2_tail = false; c->in_dsp--; c->pend_b.clear(); c->pend_t.clear(); } } restore{c};
   c->in_dsp++;
-  if (c->pend_tail_flushed) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail, 0));
+  if (c->pend_tail_flushed) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail_cur ? c->ev_tail_cur : c->ev_tail, 0));
   c->pend_tail_flushed = false;
   c->rec = nullptr; c->cur = S2;
   for (auto &op : c->pend_b) { const int r = op(c); if (r) return r; }
   HIPCHK(c, hipEventRecord(c->ev_blank, S2));
   HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
   c->cur = S1; c->split_fft2_tail = true;
-  for (auto &op : c->pend_t) { const int r = op(c); if (r) return r; }
-  c->split_fft2_tail = false;
+  for (auto &op : c->pend_t) { const int r = op(c); if (r) { c->last_main_ev = nullptr; return r; } }
+  c->split_fft2_tail = false; c->last_main_ev = nullptr;
   HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
+  if (c->nb_pending) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_nb, 0));
   return LRH_OK;
 }
 
@@ -2373,9 +2406,27 @@ static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 (+ fft3 / mix
   if (avail >= 4 * c->N2) k = 1 + (avail - 4 * c->N2) / (4 * c->M2);
   while (k > 0) {
     const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
+    // (the stream switches are part of the recorded work: a parked round is issued -- and the split schedule known -- a round later)
+    // the narrowband kernels of the previous group may still read the fft2 slots this group overwrites (they have had a round's time)
+    LRH_DEVICE_WORK(c, { if (c->nb_pending && c->split_fft2_tail && c->nb_split) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_nb, 0)); });
     if ((rc = lrh_make_fft2(c, p, kb))) return rc;
-    if ((rc = lrh_fft2_mix1_fixed(c, p, kb))) return rc;
-    if ((rc = narrow_tail(c, p))) return rc;
+    LRH_DEVICE_WORK(c, {
+      if (c->split_fft2_tail && c->nb_split) {
+        if (c->last_main_ev) HIPCHK(c, hipStreamWaitEvent(c->stream_nb, c->last_main_ev, 0));      // make_fft2 has just recorded ev_fft2 there
+        else { HIPCHK(c, hipEventRecord(c->ev_f2done, c->cur)); HIPCHK(c, hipStreamWaitEvent(c->stream_nb, c->ev_f2done, 0)); }
+        c->nb_keep = c->cur; c->cur = c->stream_nb;
+      } else c->last_main_ev = nullptr;                     // the narrowband kernels follow on the main stream
+      });
+    rc = lrh_fft2_mix1_fixed(c, p, kb);
+    if (!rc) rc = narrow_tail(c, p);
+    if (rc && !c->rec && c->nb_keep) { c->cur = c->nb_keep; c->nb_keep = nullptr; }
+    if (rc) return rc;
+    LRH_DEVICE_WORK(c, {
+      if (c->nb_keep) {
+        HIPCHK(c, hipEventRecord(c->ev_nb, c->stream_nb)); c->nb_pending = true;
+        c->cur = c->nb_keep; c->nb_keep = nullptr;
+      } });
+    if (rc) return rc;
     k -= kb;
   }
   return LRH_OK;
@@ -2548,6 +2599,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   int rc;
   // a call that fails between parking the linear blanker's search and picking its result up must not leave the search marked as parked:
   // every later blanker call would answer LRH_ESTATE
+  struct NbJoin { lrh_ctx *c; ~NbJoin() { if (c->nb_pending) hipStreamWaitEvent(c->stream, c->ev_nb, 0); } } nb_join{c};   // later API calls are ordered on the main stream
   struct ClvGuard { lrh_ctx *c; bool ok = false; ~ClvGuard() { if (!ok) { c->clv_wait = false; c->clv_issued = false; } } } clv_guard{c};
   struct InDsp { lrh_ctx *c; InDsp(lrh_ctx *c_) : c(c_) { c->in_dsp++; } ~InDsp() { c->in_dsp--; } };
   // Small rounds are bound by the host's launches (~100 us per round), not by the kernels: the plain serial order has the
@@ -2658,36 +2710,48 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     bool have_prev = carry, tail_flushed = carry && c->pend_tail_flushed;
     on(S1); if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, B))) return rc;
     advance_fft1(c, p, B);
-    HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+    if (!fuse) HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+    // The threshold blanker only writes from where its span begins (it clears runs and the samples AHEAD of them, blank1.c:1049-1083),
+    // which is where the previous call's release point timf2_pn2 lies, and fft2 reads below that point: blanker(k) needs nothing of
+    // fft2(k-1) and goes out as soon as timf2(k) is on the stream.  It then has fft2(k-1) and fft1(k+1) + timf2(k+1) to finish in -- queued
+    // a round later it ran beside fft1 + timf2 alone and took 460 of their 440 us (80 us with the chip to itself), so fft2 waited for it
+    // every round.  The linear blanker's fit reaches back across its span's start and its launches wait for the host: a round late, as before.
+    static const bool early_env = !(getenv("LRH_BLANK_EARLY") && !atoi(getenv("LRH_BLANK_EARLY")));
+    const bool early_blank = early_env && !c->clever_on;
+    hipEvent_t ev_bl_tail = c->ev_blank, ev_bl_next = c->ev_blank;
     auto side_blanker = [&]() -> int {        // blanker(k-1): after timf2(k-1) wrote and fft2(k-2) read its neighbourhood
-      if (tail_flushed) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail, 0));
+      if (tail_flushed && !early_blank) HIPCHK(c, hipStreamWaitEvent(S2, c->ev_tail_cur ? c->ev_tail_cur : c->ev_tail, 0));
       const int r = flush(qb, S2); if (r) return r;
       HIPCHK(c, hipEventRecord(c->ev_blank, S2));
+      ev_bl_tail = c->ev_blank;
       return LRH_OK;
     };
     auto main_tail = [&]() -> int {           // fft2(k-1) + mix1(k-1) on the blanked data
-      HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
-      c->split_fft2_tail = true;
+      HIPCHK(c, hipStreamWaitEvent(S1, ev_bl_tail, 0));
+      c->split_fft2_tail = true; c->last_main_ev = nullptr;
       const int r = flush(qt, S1);
       c->split_fft2_tail = false;
-      if (r) return r;
-      HIPCHK(c, hipEventRecord(c->ev_tail, S1)); tail_flushed = true;
+      if (r) { c->last_main_ev = nullptr; return r; }
+      if (c->last_main_ev) c->ev_tail_cur = c->last_main_ev;     // fft2's own event is the last thing on the main stream
+      else { HIPCHK(c, hipEventRecord(c->ev_tail, S1)); c->ev_tail_cur = c->ev_tail; }
+      c->last_main_ev = nullptr; tail_flushed = true;
       return LRH_OK;
     };
     while (left > 0) {
       const int Bnext = (left - B) < batch ? (left - B) : batch;
       // side: the blanker first -- fft2(k-1) on the main stream waits for it, the sums have a whole round of slack
-      if (have_prev && (rc = side_blanker())) return rc;
+      if (have_prev && (!early_blank || round == 0) && (rc = side_blanker())) return rc;
       // Linear blanker: its search -- a few thousand one-wave workgroups waiting on memory -- takes 0.2 ms with the chip to itself and
       // 0.55 ms beside k_fft1w, whose workgroups fill every CU's registers.  Tried and dropped: a stream confined to a share of the CUs
       // (22.0 against 26.5 Gsamples/s), and holding the transform back until the search is through (this switch: 24.0 against 26.3 --
       // the host then waits with nothing queued behind the search).
       if (have_prev && c->clv_first && c->clv_wait && c->clv_issued) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_clv, 0));
-      hipEvent_t ev_t2 = round & 1 ? c->ev_timf2b : c->ev_timf2;
+      // (blanker issued at once: its wait is queued before lrh_make_timf2 records ev_timf2_done again, so that event serves)
+      hipEvent_t ev_t2 = early_blank ? c->ev_timf2_done : (round & 1 ? c->ev_timf2b : c->ev_timf2);
       if (!fuse) { on(S2); HIPCHK(c, hipStreamWaitEvent(S2, c->ev_fft1, 0)); }
       if ((rc = sums(B))) return rc;
       on(S1); if ((rc = lrh_make_timf2(c, p, B))) return rc;
-      HIPCHK(c, hipEventRecord(ev_t2, S1));
+      if (!early_blank) HIPCHK(c, hipEventRecord(ev_t2, S1));
       // With the limiter in the call the sums' join and the slow average feed it and sit on the path to the next make_timf2: beside
       // k_fft1 (which fills every register file) they would wait for it to end, so they go first on the main stream (26 us there)
       // when the main stream's work between two make_timf2 is short enough for that wait to show (single-kernel fft2).
@@ -2697,21 +2761,30 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       hipStream_t Ss = (fuse && ((c->wl_on && c->sums_on_main) || c->clever_on)) ? S1 : S2;
       if (fuse) { if (Ss == S2) HIPCHK(c, hipStreamWaitEvent(S2, ev_t2, 0)); if ((rc = sums_follow(Ss))) return rc; }
       HIPCHK(c, hipEventRecord(c->ev_sumsq[round & 1], Ss));
-      if ((rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) return rc;
+      if (early_blank && Ss == S2) c->last_main_ev = c->ev_timf2_done;   // nothing on the main stream since lrh_make_timf2 recorded it
+      rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter);
+      c->last_main_ev = nullptr;
+      if (rc) return rc;
       // bookkeeping of blanker(k): its launches wait for timf2(k) and are issued in the next round
       qb.push_back([ev_t2](lrh_ctx *c) -> int { HIPCHK(c, hipStreamWaitEvent(c->stream2, ev_t2, 0)); return LRH_OK; });
       c->clv_ev_t2 = ev_t2;
       c->rec = &qb; rc = lrh_first_noise_blanker(c, p); c->rec = nullptr;
       c->clv_ev_t2 = nullptr;
       if (rc) return rc;
+      if (early_blank) {
+        if ((rc = flush(qb, S2))) return rc;
+        ev_bl_next = c->ev_blank2[round & 1];
+        HIPCHK(c, hipEventRecord(ev_bl_next, S2));
+      }
       if (Bnext > 0) {
         on(S1);
         if (round >= 1) HIPCHK(c, hipStreamWaitEvent(S1, c->ev_sumsq[(round + 1) & 1], 0));
         if ((rc = lrh_fft1_b(c, 0, p->timf1p_px, p->fft1_pa, Bnext))) return rc;
         advance_fft1(c, p, Bnext);
-        HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
+        if (!fuse) HIPCHK(c, hipEventRecord(c->ev_fft1, S1));
       }
       if (have_prev && (rc = main_tail())) return rc;
+      ev_bl_tail = ev_bl_next;
       c->rec = &qt; rc = round_tail(c, p); c->rec = nullptr;
       if (rc) return rc;
       have_prev = true;
@@ -2767,7 +2840,7 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
     on(S1); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_blank, 0));
     c->split_fft2_tail = true;
     rc = round_tail(c, p);
-    c->split_fft2_tail = false;
+    c->split_fft2_tail = false; c->last_main_ev = nullptr;
     if (rc) return rc;
     if ((rc = limiter2())) return rc;
     left -= B; B = Bnext; round++;
@@ -2923,7 +2996,7 @@ int lrh_sync(lrh_ctx *c)
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
-  for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2, c->stream_sel }) if (s) HIPCHK(c, hipStreamSynchronize(s));
+  for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2, c->stream_nb, c->stream_sel }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
   return sellim_install(c, c->sel_seq);
 }

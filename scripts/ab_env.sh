@@ -1,8 +1,10 @@
 #!/bin/bash
-# A/B of an environment switch on the bench: scripts/ab_env.sh VAR "v1 v2 ..." [bench flags]
-VAR=$1; VALS=$2; shift 2
-for v in $VALS; do
-  env $VAR=$v timeout -k 10 240 python bench.py --no-cpu --no-secondary --steps 10 "$@" 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$VAR=$v', d['value'], d['ms_per_step'], {k:(v['avg_us'],v.get('avg_us_alone')) for k,v in d['stages'].items() if k in ('fft1w','timf2s','clever','blanker','fft2','spur')})" || break
-done
+# scripts/ab_env.sh VAR "v0 v1 ..." [reps] [bench args...] -- the same bench line with one environment switch at several values,
+# alternating, in one call on one box (run-to-run spread on this pool is 2-3 %: only alternating runs on the same box compare)
+VAR=$1; VALS=$2; REPS=${3:-2}; shift 3
+for i in $(seq $REPS); do for v in $VALS; do
+  env $VAR=$v python bench.py --no-cpu "$@" 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$VAR=$v', d['value'], d['ms_per_step'], (d.get('secondary') or {}).get('value'), (d.get('full_rings') or {}).get('value'))"
+done; done

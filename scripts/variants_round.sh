@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench's variants on one GPU, one JSON object per round: scripts/variants_round.sh r03   (on the GPU box, via gpurun)
 # -> gpurun_out/prof_$R/variants.json (+ rocprofv3 --stats of the two variants the review asked for: --clever, --coupled)
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
@@ -20,6 +20,8 @@ run limiter2_par1_0 --limiter2 --limiter2-par1 0 --no-secondary
 run streamhost --stream-host --rounds 1 --no-secondary
 run realinput --real-input --no-secondary
 run n15 --fft1-n 15 --fft2-n 17 --batch 2048 --no-secondary
+run n13 --fft1-n 13 --fft2-n 15 --no-secondary
+run n12 --fft1-n 12 --fft2-n 14 --no-secondary
 run one_round_per_call --rounds 1 --no-secondary --steps 80 --warmup 8   # (a later --steps wins; ten one-round steps would time the pipeline's fill and drain)
 for v in clever coupled; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$v -- python3 bench.py --$v --no-cpu --no-secondary --steps 5 --warmup 3 > $OUT/var/${v}_stats.json 2> $OUT/var/${v}_stats.log

@@ -276,3 +276,62 @@ def test_fused_kernel_at_other_sizes_and_int32_matches_the_two_kernel_path_and_t
     sp = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword, sparse=1)
     for _, k in RINGS[1:]:
         assert np.array_equal(a[k], sp[k]), k
+
+
+def _run_gap(fn, sparse, table):
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    cfg = chain_config(14, 12, batch=32, rounds=4)
+    cfg.fft1_float_sparse = sparse
+    cfg.stupid_bln_mode = 0
+    rx = (fn or open_hip)(cfg)
+    n1 = 1 << 14
+    s = synth_defaults(n1, 0)
+    rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+    rx.set_liminfo(strong_liminfo(s, 14))
+    rx.set_mix1_selfreq(0.31 * 4096 + 0.3)
+    if fn is None:
+        rx.profile_enable(2)
+    rx.wideband_dsp(32, 32)
+    if table:
+        fc = np.zeros(2 * n1, np.float32)
+        g = 1.0 / (150.0 * n1 * float(n1) ** -0.4)         # the level of the default table (make_filcorrstart, fft1.c:4653-4663)
+        fc[0::2] = g * (1.0 + 0.25 * np.cos(np.arange(n1) * 0.001))
+        fc[1::2] = 0.1 * g
+        rx.set_filtercorr(fc)
+    else:
+        rx.p.timf1p_px = (rx.p.timf1p_px + 5 * (n1 // 2) * 4 + 4 * 1234) & (cfg.timf1_bytes - 1)   # the producer skipped ahead
+    rx.wideband_dsp(64, 32)
+    launches = {k: rx.profile_get(k)[1] for k in ("fft1w", "fft1")} if fn is None else None
+    out = {k: rx.export(r) for r, k in RINGS}
+    out["p"] = rx.p.as_dict()
+    rx.close()
+    return out, launches
+
+
+@pytest.mark.parametrize("table", [0, 1])
+def test_a_gap_in_the_walk_over_timf1_does_not_reach_the_fused_kernels_partner(table):
+    """The fused kernel rebuilds the overlap partner of a call's first transform from the timf1 ring one block behind it.  After a jump of
+    timf1p_px, or new filter tables, that is no longer the transform the reference overlaps with (it carries the previous transform's back
+    half, timf2.c:1018-1025).  With the whole spectrum kept the library takes the two-kernel path for that one call and stays on the
+    oracle; with the sparse ring the call starts over like the first of a stream and only its first transform's share differs."""
+    from oracle_binding import open_oracle
+    a, la = _run_gap(None, 0, table)
+    o, _ = _run_gap(open_oracle, 0, table)
+    assert la == {"fft1w": 2, "fft1": 1}, la               # first call fused, the call after the gap in two kernels, then fused again
+    assert a["p"] == o["p"]
+    n1 = 1 << 14
+    keep = np.ones(a["timf2"].size, bool)
+    keep[(a["p"]["timf2_pa"] + np.arange(4 * (n1 // 2))) % keep.size] = False
+    for _, k in RINGS:
+        m = keep if k == "timf2" else 1
+        assert _rel(a[k] * m, o[k] * m) < 1e-5, k
+    sp, ls = _run_gap(None, 1, table)
+    assert ls == {"fft1w": 3, "fft1": 0}, ls
+    first = np.zeros(a["timf2"].size, bool)
+    first[32 * 4 * (n1 // 2) + np.arange(4 * (n1 // 2))] = True     # timf2 floats of transform 32, the first after the gap
+    weak = (np.arange(a["timf2"].size) & 2) == 0                      # [weak re, weak im, strong re, strong im] per sample
+    e_rest = _rel(sp["timf2"] * ~first, a["timf2"] * ~first)          # (that call ran as two kernels in `a`: rounding apart, not bit-equal)
+    e_weak = _rel(sp["timf2"] * (first & weak), a["timf2"] * (first & weak))
+    e_strong = _rel(sp["timf2"] * (first & ~weak), a["timf2"] * (first & ~weak))
+    print(table, e_rest, e_weak, e_strong)
+    assert e_rest < 2e-6 and e_weak > 0.1, (e_rest, e_weak, e_strong)
