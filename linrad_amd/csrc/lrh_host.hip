@@ -149,6 +149,10 @@ struct lrh_ctx {
   // same point of the main stream.  last_main_ev: an event recorded on the main stream with nothing enqueued there since (set and
   // consumed within a few lines of each other, never carried across calls); ev_tail_cur: the event that stands for ev_tail.
   hipEvent_t last_main_ev = nullptr, ev_tail_cur = nullptr;
+  // Small rounds (serial order): blanker + fft2 + mix1 (+ fft3 / mix2) of a round are a chain of short kernels the next round's fft1 and
+  // timf2 do not wait for; they go to the side stream and the main stream carries on.  st_n tails issued so far, ev_st[n & 1] behind tail n;
+  // any entry point other than lrh_wideband_dsp first orders the main stream behind the newest tail (LRH_ENTER).  LRH_SIDE_TAIL=0: off.
+  hipEvent_t ev_st[2] = {nullptr, nullptr}; unsigned st_n = 0; bool st_pending = false, st_on = true;
   // narrowband stream of the two-stream schedules: mix1 / fft3 / mix2 of a round -- a handful of small kernels, 66 us one after the other --
   // run here beside the next round's fft1 instead of holding the main stream (LRH_NARROW_STREAM=0: on the main stream as before)
   hipStream_t stream_nb = nullptr; hipEvent_t ev_f2done = nullptr, ev_nb = nullptr; bool nb_split = true, nb_pending = false; hipStream_t nb_keep = nullptr;
@@ -228,7 +232,9 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
 // back from its last round (one-round-late schedule kept across calls, see there) go out first
 static int flush_pending(lrh_ctx *c);
 static int upload_filtercorr(lrh_ctx *c);
-#define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; }
+static void join_side_tail(lrh_ctx *c);
+#define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; } \
+  if ((c) && (c)->st_pending && !(c)->in_dsp) join_side_tail(c)
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
 // Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
@@ -395,7 +401,7 @@ void lrh_close(lrh_ctx *c)
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
-  for (hipEvent_t ev : { c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb, c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb, c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -488,7 +494,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   c->cur = c->stream;
   if (hipStreamCreateWithFlags(&c->stream_nb, hipStreamNonBlocking) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
   if (const char *e_ = getenv("LRH_NARROW_STREAM")) c->nb_split = atoi(e_) != 0;
-  for (hipEvent_t *ev : { &c->ev_blank2[0], &c->ev_blank2[1], &c->ev_f2done, &c->ev_nb, &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (const char *e_ = getenv("LRH_SIDE_TAIL")) c->st_on = atoi(e_) != 0;
+  for (hipEvent_t *ev : { &c->ev_st[0], &c->ev_st[1], &c->ev_blank2[0], &c->ev_blank2[1], &c->ev_f2done, &c->ev_nb, &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
@@ -1509,7 +1516,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
       float *const part = c->d_ss_part + (size_t)c->ss_flip * c->ss_part_stride; c->ss_flip ^= 1;
       { ProfScope ps(c, "timf2"); HIPCHK(c, launch_timf2(c->cfg.fft1_n, a, batch, c->cur, &sa, part, &c->ss_run)); }
       const SumsqArgs ja = sa; const int run = c->ss_run;
-      c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {
+      if (run > 0) c->ss_queue.insert(c->ss_queue.begin(), [ja, run, part](lrh_ctx *c) -> int {      // (0: one workgroup wrote the ring itself)
         ProfScope ps(c, "sumsq_join"); HIPCHK(c, launch_sumsq_join(ja, part, run, c->cur)); return LRH_OK; });
     } else {                                             // pointers out of step: separate pass after all
       { ProfScope ps(c, "sumsq"); HIPCHK(c, launch_sumsq(sa, c->cur)); }
@@ -2371,6 +2378,12 @@ static int flush_pending(lrh_ctx *c)
   return LRH_OK;
 }
 
+static void join_side_tail(lrh_ctx *c)      // later work on the main stream sees what the side-stream tails of small rounds wrote
+{
+  if (c->st_pending) (void)hipStreamWaitEvent(c->stream, c->ev_st[(c->st_n - 1) & 1], 0);
+  c->st_pending = false;
+}
+
 // single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round.
 // Device schedule when several rounds are requested (second fft on): the transform kernels of N = 16384 occupy one
 // workgroup per CU and are latency/compute bound, while fft1_c's sums, the blanker and the fft2 power sums are short
@@ -2658,6 +2671,11 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   const bool lagged = lag_ok && (nblocks >= 3 * batch || (carry_ok && nblocks % batch == 0 && nblocks >= batch));
   if (c->pend && !(lagged && carry_ok && batch == c->pend_batch)) { if ((rc = flush_pending(c))) return rc; }
   InDsp in_dsp{c};
+  // ... where the tail comes up every other call at most (the blanker's rate limit, blank1.c:712-715).  With a tail per call the side stream
+  // is the longer of the two and the hand-over only adds to it: 140 against 128 us per call of 4 blocks, 174 against 146 at 16; 63 against 80 at 1.
+  const bool side_tail = c->st_on && !piped && !lagged && small_rounds && c->cfg.second_fft_enable && !c->clever_on && !c->prof && !(c->wl_on && c->wl_fft2) &&
+                         c->cfg.stupid_bln_mode != 0 && 2L * batch * c->M1 <= c->cfg.blanker_min_points && nblocks == batch;
+  if (!side_tail) join_side_tail(c);
   if (!piped && !lagged) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
@@ -2676,6 +2694,29 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
       // 224 -> 165 us per call of 4 blocks, 298 -> 182 at 64).  Not with the linear blanker, which reads the amplitude factor the limiter updates.
       const bool early1 = !c->clever_on;
       if (early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) return rc;
+      if (side_tail) {
+        // One block per call: fft1 + timf2 take 45 us, the blanker's five launches and fft2 + mix1 (every fourth call: blanker_min_points,
+        // fft2's 32768 new samples) another 90.  Nothing the next rounds' fft1 / timf2 / sums touch: timf2 writes above timf2_pa, the
+        // blanker and fft2 work below it.  The stage functions do their bookkeeping now and park the launches (as in schedule 2).
+        std::vector<std::function<int(lrh_ctx *)>> qs;
+        // (mix1's phase table goes up in stream order on the side stream: the upload stream of schedule 2 is ordered by events this path does not record)
+        const bool eu = c->early_upload; c->early_upload = false;
+        c->rec = &qs; rc = lrh_first_noise_blanker(c, p); if (!rc) rc = round_tail(c, p); c->rec = nullptr;
+        c->early_upload = eu;
+        if (rc) return rc;
+        if (!qs.empty()) {
+          hipStream_t S2 = c->stream2;
+          HIPCHK(c, hipStreamWaitEvent(S2, c->ev_timf2_done, 0));                          // recorded at the end of lrh_make_timf2
+          if (c->st_n >= 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_st[(c->st_n - 1) & 1], 0));   // the main stream stays within one tail of the side stream (rings)
+          c->cur = S2;
+          for (auto &op : qs) if ((rc = op(c))) break;
+          c->cur = c->stream;
+          if (rc) return rc;
+          HIPCHK(c, hipEventRecord(c->ev_st[c->st_n & 1], S2)); c->st_n++; c->st_pending = true;
+        }
+        nblocks -= B;
+        continue;
+      }
       if ((rc = lrh_first_noise_blanker(c, p))) return rc;
       if ((rc = round_tail(c, p))) return rc;
       if ((!early1 && (rc = limiter1(p->fft1_liminfo_cnt, p->fft1_sumsq_pa, p->fft1_sumsq_counter))) || (rc = limiter2())) return rc;

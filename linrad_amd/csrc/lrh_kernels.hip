@@ -505,14 +505,21 @@ __global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_t
     const bool group_end = gb - g * a.ss_avg == a.ss_avg - 1;
     if (!group_end && b != r1 - 1) return;
     const bool head = g * a.ss_avg - a.ss_c0 < r0;       // began in an earlier run (or an earlier call)
+    // ss_part == nullptr: one workgroup runs the whole launch (a call of one or two transforms), so nobody else holds a piece of any
+    // group: the piece of a group an earlier call began is added to the ring here, in k_sumsq_join's order, and that launch is saved
+    const bool direct = a.ss_part == nullptr;
     float *dst;
-    if (!head && group_end) dst = a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask);
+    if ((!head && group_end) || direct) dst = a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask);
     else dst = a.ss_part + (size_t)(2 * blockIdx.x + (head ? 0 : 1)) * N;
+    const bool add = direct && head;
 #pragma unroll
     for (int m = 0; m < NB0; m++)
 #pragma unroll
       for (int s = 0; s < R0; s++) {
-        (dst + m * T + s * (N / R0))[(unsigned int)tid] = acc[m * R0 + s];
+        float *const q = dst + m * T + s * (N / R0);
+        float v = acc[m * R0 + s];
+        if (add) v = q[(unsigned int)tid] + v;
+        q[(unsigned int)tid] = v;
         acc[m * R0 + s] = 0.f;
       }
   };
@@ -525,6 +532,41 @@ __global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_t
       if (MODE != 1 || (e % RL) < RL / 2) asm volatile("" : "+v"(x[e].x), "+v"(x[e].y));
     asm volatile("" ::: "memory");
   };
+  if constexpr (SS) {
+    if (a.ss_split) {
+      // One transform per call (Linrad's own call pattern, wcw.c:1036-1047): the two streams' transforms one after the other in one
+      // workgroup are two latencies of ~11 us; here one workgroup per stream.  A bin is zero in one of the two streams, so each
+      // workgroup holds exactly its own stream's bins of sum |X|^2 and writes those to the ring ("=" for the first transform of an
+      // averaging group, "+=" after: fft1.c:4126, 4169 -- the addition k_sumsq_join would make).
+      const int st = (int)blockIdx.x & 1;
+      issue(0, st, tid0);
+      __syncthreads();
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      float2 x[P];
+      combine(x, tid0);
+      {
+        const int g = a.ss_c0 / a.ss_avg;
+        const bool add = g * a.ss_avg - a.ss_c0 < 0;       // the group began in an earlier call
+        float *const dst = a.ss_ring + ((a.ss_pa0 + g * N) & a.ss_mask);
+#pragma unroll
+        for (int m = 0; m < NB0; m++) {
+          const unsigned int own = wk_cur[m] ^ (st ? 0xffffffffu : 0u);
+#pragma unroll
+          for (int s = 0; s < R0; s++)
+            if ((own >> s) & 1u) {
+              float *const q = dst + m * T + s * (N / R0);
+              float v = acc[m * R0 + s];
+              if (add) v = q[(unsigned int)tid0] + v;
+              q[(unsigned int)tid0] = v;
+            }
+        }
+      }
+      Fft::run(x, lds, tid0);
+      if (st) timf2_store<LOG2N, MODE, 1>(a, x, a.pa_first, tid0);
+      else timf2_store<LOG2N, MODE, 0>(a, x, a.pa_first, tid0);
+      return;
+    }
+  }
   // items: interleaved over the grid (XCD-aware order), or with SS a run of consecutive transforms per workgroup
   const int stride = SS ? 1 : (int)gridDim.x;
   const int r0 = SS ? (int)blockIdx.x * a.ss_run : 0;
@@ -2394,7 +2436,9 @@ __global__ __launch_bounds__(256) void k_blockpower(BlockpowerArgs a)
   do {                                                                                                      \
     if (a.ss_ring) {                                                                                        \
       a.ss_run = (batch + fftl_grid<L>(batch, a.spare_cus) - 1) / fftl_grid<L>(batch, a.spare_cus);                                   \
-      hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3((batch + a.ss_run - 1) / a.ss_run), dim3(fft1_threads(L)), 0, st, a); \
+      if (a.ss_run >= batch) a.ss_part = nullptr;      /* one workgroup: the sums go straight to the ring, no join */           \
+      a.ss_split = batch == 1 && L >= 12;                                                                         \
+      hipLaunchKernelGGL((k_timf2<L, 1, true>), dim3(a.ss_split ? 2 : (batch + a.ss_run - 1) / a.ss_run), dim3(fft1_threads(L)), 0, st, a); \
     }                                                                                                       \
     else if (a.mode == 1) hipLaunchKernelGGL((k_timf2<L, 1, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a);      \
     else if (a.mode == 0) hipLaunchKernelGGL((k_timf2<L, 0, false>), dim3(fftl_grid<L>(batch, a.spare_cus)), dim3(fft1_threads(L)), 0, st, a); \
@@ -2453,7 +2497,7 @@ hipError_t launch_timf2(int log2n, const Timf2Args &a0, int batch, hipStream_t s
     a.ss_ring = ss->sumsq; a.ss_part = ss_part; a.ss_mask = ss->sumsq_mask; a.ss_avg = ss->avg; a.ss_c0 = ss->c0; a.ss_pa0 = ss->pa0;
   }
   LRH_DISPATCH(LRH_LAUNCH_TIMF2, log2n, 6, 14, a, batch, st);
-  if (ss && ss_run) *ss_run = a.ss_run;
+  if (ss && ss_run) *ss_run = a.ss_part ? a.ss_run : 0;        // 0: nothing left for k_sumsq_join
   return hipGetLastError();
 }
 // k_fft1w + the strong-only pass of k_timf2 (fft1_size 16384): `run` out = transforms per workgroup (for k_sumsq_join)

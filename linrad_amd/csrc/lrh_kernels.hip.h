@@ -72,6 +72,7 @@ struct Timf2Args {
   // fused fft1_c power sums (set by launch_timf2 when it is handed a SumsqArgs): ring, pieces of groups that straddle
   // workgroup runs [grid][2][N], transforms per workgroup
   float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0, ss_run;
+  int ss_split;             // a launch of ONE transform: two workgroups, one per stream (each adds its own stream's bins to the sums)
   int spare_cus;            // compute units left free for side-stream kernels (see persistent_grid)
 };
 
