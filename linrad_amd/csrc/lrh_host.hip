@@ -84,7 +84,7 @@ struct lrh_ctx {
   int xcd_mask = 2;          // bit 0 fft1, 1 timf2, 2 fft2: XCD-aware block order (tuning knob LRH_XCD_MASK)
   hipStream_t stream = nullptr;      // main stream: every API call is ordered on it
   hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
-  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<hipEvent_t> ev_fft1_read_cur{nullptr}; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
+  hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<hipEvent_t> ev_fft1_read_cur{nullptr}; std::atomic<bool> read_alias_wanted{false}; hipEvent_t ev_in_guard = nullptr; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
   std::mutex mtx_in;                  // the producer side (lrh_timf1_write_async / _wait) has a lock of its own: an input thread is never held up by a stage call that sleeps on the staging ring
   hipStream_t stream_sel = nullptr;  // the limiter kernels: one workgroup for ~0.5 ms, kept off the side stream (the blanker of the next round queues there)
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
@@ -207,7 +207,10 @@ struct lrh_ctx {
   // the limiter runs on the side stream, beside whatever the main stream still has queued: behind the last k_timf2 (which reads the
   // routing words it rewrites) and the sums it reads; the next lrh_make_timf2 waits for it on the device
   hipEvent_t ev_timf2_done = nullptr, ev_sel_wait = nullptr, ev_sel_wait2 = nullptr; bool timf2_done_valid = false, sel_table_pending = false; hipStream_t sums_stream = nullptr;
-  bool pack_prev_stale = false;   // d_pack_prev differs from d_pack_cur (a new liminfo table arrived since the last make_timf2)
+  // Two buffers of routing words.  pack_prev_stale: a new table arrived since the last make_timf2 -- it went into the other buffer
+  // (pack_new_table swaps the pointers) and d_pack_prev is the table the previous transform was routed with; otherwise that table is
+  // d_pack_cur itself and d_pack_prev holds nothing of interest.  (Before: one copy kernel per table, on the path to the next fft2.)
+  bool pack_prev_stale = false;
   // pinned staging for mix1 phases
   float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
   // mix1 scalars
@@ -233,6 +236,11 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
 static int flush_pending(lrh_ctx *c);
 static int upload_filtercorr(lrh_ctx *c);
 static void join_side_tail(lrh_ctx *c);
+static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten (by a writer ordered behind the last make_timf2's kernels)
+{
+  if (!c->pack_prev_stale) std::swap(c->d_pack_cur, c->d_pack_prev);
+  c->pack_prev_stale = true;
+}
 #define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; } \
   if ((c) && (c)->st_pending && !(c)->in_dsp) join_side_tail(c)
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
@@ -400,6 +408,7 @@ void lrh_close(lrh_ctx *c)
   if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
+  if (c->ev_in_guard) hipEventDestroy(c->ev_in_guard);
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb, c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
@@ -671,7 +680,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   std::vector<float> lim(N1, 0.f);
   *out = c;
   rc = lrh_set_liminfo(c, lim.data());
-  if (rc == LRH_OK && hipMemcpy(c->d_pack_prev, c->d_pack_cur, 4 * c->N1, hipMemcpyDeviceToDevice) != hipSuccess) rc = LRH_EDEVICE;
+  c->pack_prev_stale = false;               // no transform before the first one
   c->have_liminfo = false;
   if (rc != LRH_OK) { *out = nullptr; lrh_close(c); }
   return rc;
@@ -758,12 +767,12 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   c->sel_table_pending = false;
   c->h_pack = pack;
+  pack_new_table(c);
   HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_liminfo, liminfo, 4 * c->N1, hipMemcpyHostToDevice, c->stream));   // the table lrh_fft1_update_liminfo carries on from
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sel_pending = false;
   c->lowlevel_points = low;
-  c->pack_prev_stale = true;
   c->have_liminfo = true;
   return LRH_OK;
 }
@@ -879,15 +888,16 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
   if (c->last_main_ev) HIPCHK(c, hipStreamWaitEvent(S, c->last_main_ev, 0));
   else { HIPCHK(c, hipEventRecord(c->ev_sel_wait, c->stream)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait, 0)); }
   if (which == 2 || c->sums_stream == c->stream2) { HIPCHK(c, hipEventRecord(c->ev_sel_wait2, c->stream2)); HIPCHK(c, hipStreamWaitEvent(S, c->ev_sel_wait2, 0)); }
+  pack_new_table(c); a.pack = c->d_pack_cur;                 // the new table's routing words go beside the ones the last make_timf2 used
   { hipStream_t keep = c->cur; c->cur = S;
     { ProfScope ps(c, "sellim"); hipError_t e_ = which == 1 ? launch_sellim(a, S) : launch_sellim2(a, S);
       if (e_ != hipSuccess) { c->cur = keep; return fail(c, LRH_EDEVICE, "launch_sellim", e_); } }
     c->cur = keep; }
   c->sel_seq++;
+  HIPCHK(c, hipEventRecord(c->ev_sel, S));                   // the table is there: the next make_timf2 does not wait for the read-back below
   HIPCHK(c, hipMemcpyAsync(&c->h_sel_low[c->sel_seq % 3], &c->d_sel_st->low, sizeof(int), hipMemcpyDeviceToHost, S));
   HIPCHK(c, hipEventRecord(c->ev_sel_slot[c->sel_seq % 3], S));
-  HIPCHK(c, hipEventRecord(c->ev_sel, S));
-  c->sel_pending = true; c->sel_table_pending = true; c->pack_prev_stale = true; c->have_liminfo = true;
+  c->sel_pending = true; c->sel_table_pending = true; c->have_liminfo = true;
   if (q->exact_stats) return sellim_install(c, c->sel_seq);
   return LRH_OK;
 }
@@ -1175,7 +1185,12 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
   const int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
   // the fft1 launches already enqueued may still read the ring span being overwritten: the copy goes behind the last of
   // them (the event lrh_fft1_b records), not behind the rest of the chain
-  if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read_cur.load(), 0));
+  if (c->read_alias_wanted) {
+    // another thread is inside lrh_wideband_dsp between its transform and the event that will stand for "timf1 has been read": order the
+    // copy behind whatever is on the main stream right now (an event of this path's own, recorded from here)
+    if (!c->ev_in_guard) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_guard, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_in_guard, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_in_guard, 0));
+  } else if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read_cur.load(), 0));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h]) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));
   HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
   if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
@@ -1320,7 +1335,13 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
       fprintf(stderr, "\n");
     }
   }
-  if (handle == 0 && c->ev_fft1_read) { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->ev_fft1_read_cur = c->ev_fft1_read; c->fft1_read_valid = true; }   // timf1 has been read: producer copies may follow
+  // timf1 has been read: producer copies may follow.  Inside lrh_wideband_dsp's serial order lrh_make_timf2 comes next on this stream and
+  // records ev_timf2_done anyway: that event tells the producer, and the transform is not followed by a record of its own (a packet the
+  // queue works off before the next kernel: 6 us of a 40 us call of one block)
+  if (handle == 0 && c->ev_fft1_read) {
+    if (c->in_dsp && c->cfg.second_fft_enable && c->cur == c->stream && !c->rec) c->read_alias_wanted = true;
+    else { HIPCHK(c, hipEventRecord(c->ev_fft1_read, c->cur)); c->ev_fft1_read_cur = c->ev_fft1_read; c->fft1_read_valid = true; }
+  }
   if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
     RealSplitArgs r;
     r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;
@@ -1434,7 +1455,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   if (c->h_sel_low) sellim_poll(c);                        // weak-bin count of the newest finished limiter update, if one has arrived
   Timf2Args a;
   a.spec = c->d_fft1; a.first_nb = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask; a.nb_mask = c->fft1n_mask;
-  a.pack_cur = c->d_pack_cur; a.pack_prev = c->d_pack_prev; a.tw = c->d_tw1;
+  a.pack_cur = c->d_pack_cur; a.pack_prev = c->pack_prev_stale ? c->d_pack_prev : c->d_pack_cur; a.tw = c->d_tw1;
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.pwr = c->d_pwr; a.pa_first = p->timf2_pa / 4; a.mask = c->timf2pow_mask; a.step = c->M1;
   a.mode = c->timf2_mode; a.ia = c->I1 / 2; a.invwin = c->d_invwin1;
   a.ampfac = (float)(1.0 / (1 << c->cfg.bckfft_att_n));
@@ -1524,13 +1545,9 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
     }
   } else { const int rc_ = plain_timf2(); if (rc_) return rc_; }
   // from now on the previous transform was routed with the current table
-  if (c->pack_prev_stale) {
-    // (a kernel of ours, not hipMemcpyAsync: the runtime's copy kernel left the stream idle for 25-30 us behind it, every round with the limiter on)
-    HIPCHK(c, launch_span_copy((float *)c->d_pack_prev, (float *)c->d_pack_cur, -1, c->N1, c->N1 - 1, 0, c->cur));
-    c->pack_prev_stale = false;
-  }
+  c->pack_prev_stale = false;                            // (the table in d_pack_cur is the previous transform's from here on: no copy)
   HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
-  if (read_alias) { c->ev_fft1_read_cur = c->ev_timf2_done; c->fft1_read_valid = true; }
+  if (read_alias || c->read_alias_wanted) { c->ev_fft1_read_cur = c->ev_timf2_done; c->fft1_read_valid = true; c->read_alias_wanted = false; }
   c->timf2_primed = true;
   const int low = c->lowlevel_points;
   for (int b = 0; b < batch; b++) {                                    // timf2.c:127-128, 205-207
