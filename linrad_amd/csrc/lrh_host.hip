@@ -179,6 +179,7 @@ struct lrh_ctx {
   float2 *d_timf3 = nullptr, *d_mix_scratch = nullptr;
   float *d_ph = nullptr;              // phase tables [LRH_NSTAGE][2][max_fft2 batch][half]
   BlankState *d_bst = nullptr; float *d_partials = nullptr; float4 *d_bln_tiles = nullptr; int *d_bln_counts = nullptr;
+  unsigned long long *d_bln_wbusy = nullptr; int4 *d_bln_wstate = nullptr;     // tile-parallel walk of the calibrated blanker (k_blank_walk_*)
   // linear ("clever") blanker: tables of lrh_set_blanker_tables, per-sample flags and candidate bit words
   bool clever_on = false; lrh_blanker_tables bt{}; float *d_bt_refpulse = nullptr, *d_bt_phasefunc = nullptr; int *d_bt_pulindex = nullptr;
   unsigned char *d_bln_flag = nullptr; unsigned long long *d_bln_cand = nullptr;
@@ -414,7 +415,7 @@ void lrh_close(lrh_ctx *c)
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
-                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
+                  c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) hipFree(p);
@@ -645,6 +646,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_xbins, (size_t)2 * cfg->max_fft2n * N2)); A(dev_alloc(c, &c->d_xypower, (size_t)cfg->max_fft2n * N2));
     A(dev_alloc(c, &c->d_xysum, N2)); A(dev_alloc(c, &c->d_xysum_alt, N2)); }
   A(dev_alloc(c, &c->d_bln_tiles, (size_t)cfg->timf2pow_size / 16384 + 4)); A(dev_alloc(c, &c->d_bln_counts, (size_t)cfg->timf2pow_size / 16384 + 4));
+  if (cfg->blanker_pulsewidth > 0) {                        // calibrated: guards chain the runs together, the long-run replay is the walk
+    A(dev_alloc(c, &c->d_bln_wbusy, (size_t)cfg->timf2pow_size / 64 + 64)); A(dev_alloc(c, &c->d_bln_wstate, 2 * ((size_t)cfg->timf2pow_size / LRH_BLN_WTILE + 2)));
+  }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -1636,6 +1640,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   }
   a.clr1 = (c->cfg.blanker_pulsewidth + 1) >> 1; a.clr2 = c->cfg.blanker_pulsewidth + 1;     // blank1.c:1013-1014
   a.mode = c->cfg.stupid_bln_mode; a.st = c->d_bst; a.partials = c->d_partials; a.tiles = c->d_bln_tiles; a.counts = c->d_bln_counts;
+  a.wbusy = c->d_bln_wbusy; a.wstate = c->d_bln_wstate;
   p->timf2p_fit = pend; p->timf2_pn2 = 4 * pend;                         // blank1.c:1464-1466
   if (c->clever_on) {
     // the pulse search runs first (blank1.c:765-1003) and decides where the next call resumes: one int comes back, the call waits for it

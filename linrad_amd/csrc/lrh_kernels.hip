@@ -1669,6 +1669,181 @@ __global__ __launch_bounds__(64) void k_blank_serial_wave(BlankArgs a)
   if (lane == 0) { a.st->need_slow = 0; a.st->need_slow2 = 0; a.st->slow_calls++; a.st->call_cleared = cnt; }
 }
 
+// ---- the same walk, tile-parallel ---------------------------------------------------------------------------------------------
+// The walk's state between two samples is small: either "inside a run" (its start, its maximum so far) or "outside", and then only the
+// end of the last guard matters (samples before it are skipped).  Outside a run at position z with no guard reaching z, the future does
+// not depend on the past at all.  So:
+//   1. k_blank_walk_spec, one wave per tile of LRH_BLN_WTILE positions: walk the tile as if it were entered outside a run with no guard
+//      pending; keep where that walk was busy (inside a run, on the sample that ends it, inside the guard behind it) and the state it
+//      leaves the tile in.  No decisions are written.
+//   2. k_blank_walk_chain, one wave, tiles in order: the state the call really enters each tile in.  Entered clean, the tile leaves as
+//      the speculative walk left it.  Otherwise (a run or a guard crosses the boundary) the true walk is followed into the tile until it
+//      stands outside a run, past its guard, on a position where the speculative walk was not busy: from there on the two are the same
+//      walk.  With the limit in the noise -- a run every few samples, the case that made the one-wave walk take 2.6 s for 33.5 M
+//      samples -- that happens within the first run or two; a tile that is one long run is crossed in 64 steps of 64.
+//   3. k_blank_walk_final, one wave per tile: the walk again from the true entry state, this time writing the decision bits and
+//      counting (run by run, as the serial walk counts: guards that overlap earlier decisions count again, blank1.c:1049-1083).
+// Same decisions, same count as k_blank_serial_wave (tests/test_gpu_fullsize.py: both against the oracle, and against each other).
+struct BlnWalk { int in_run, pk, erase_end; float pulmax; };
+// MODE 0: speculative (busy words out), 1: chase (busy words in; true = merged with the speculative walk), 2: final (mask bits, count)
+template <int MODE>
+__device__ __forceinline__ bool bln_walk(const BlankArgs &a, int q_first, int q_last, BlnWalk &s, unsigned long long *busy, int &cnt_out)
+{
+  const int lane = threadIdx.x & 63;
+  const int wordmask = ((a.mask + 1) >> 5) - 1;
+  const float nfl = (float)a.st->limit, totnoise = (float)(a.st->noise_floor * (a.chans > 1 ? a.chans : 1));
+  int ifirst = s.in_run, pk = s.pk, erase_end = s.erase_end, cnt = 0; float pulmax = s.pulmax;
+  auto or_bits = [&](int q_base, unsigned long long bits) {
+    const int p0 = (a.pbeg + q_base) & a.mask, off = p0 & 31, w = p0 >> 5;
+    const unsigned long long lo = bits << off, hi = off ? bits >> (64 - off) : 0ull;
+    const unsigned int part = lane == 0 ? (unsigned int)lo : (lane == 1 ? (unsigned int)(lo >> 32) : (unsigned int)hi);
+    if (lane < 3 && part) atomicOr(&a.mask_bits[(w + lane) & wordmask], part);
+  };
+  unsigned long long acc[3] = { 0, 0, 0 };
+  int qc = q_first;
+  auto mark = [&](int qf, int n) {
+    if constexpr (MODE != 2) return;
+    int r = qf - (qc - 64);
+    if (r < 0 || r + n > 192) {
+      for (int j = 0; j < n; j += 64) { const int m = n - j < 64 ? n - j : 64; or_bits(qf + j, m == 64 ? ~0ull : (1ull << m) - 1); }
+      return;
+    }
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const int lo = r > 64 * w ? r : 64 * w, hi = r + n < 64 * w + 64 ? r + n : 64 * w + 64;
+      if (lo < hi) acc[w] |= ((hi - lo == 64) ? ~0ull : (1ull << (hi - lo)) - 1) << (lo - 64 * w);
+    }
+  };
+  auto low = [](int n) -> unsigned long long { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : (1ull << n) - 1); };
+  constexpr int DEPTH = 8;
+  bool merged = false;
+  for (int q0 = q_first; q0 <= q_last && !merged; q0 += 64 * DEPTH) {
+    float v[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) { const int q = q0 + 64 * d + lane; v[d] = q <= q_last ? a.pwr[(a.pbeg + q) & a.mask] : 0.f; }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+      if (q0 + 64 * d > q_last || merged) break;
+      if (q0 + 64 * d != qc) {
+        if constexpr (MODE == 2) { if (acc[0]) or_bits(qc - 64, acc[0]); acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = 0; }
+        qc += 64;
+      }
+      const int step = (qc - q_first) >> 6;
+      const int valid = q_last - qc + 1 < 64 ? q_last - qc + 1 : 64;
+      const unsigned long long hot = __ballot(v[d] > nfl);
+      unsigned long long bw = 0;                           // MODE 0: this step's busy bits; MODE 1: the speculative walk's
+      if constexpr (MODE == 0) bw = low(erase_end - qc);   // the guard of a run that ended in an earlier step
+      if constexpr (MODE == 1) bw = busy[step];
+      int pos = 0;
+      if (!(hot == 0 && ifirst == 0)) while (pos < valid) {
+        if (ifirst == 0) {
+          const int skip = erase_end - qc;
+          const int c = skip > pos ? skip : pos;          // outside a run and past the guard from position c of this step on
+          if (c >= 64) break;
+          const unsigned long long m = hot & (~0ull << c);
+          if constexpr (MODE == 1) {
+            const unsigned long long fr = ~bw & (~0ull << c) & low(valid);
+            const int h = m ? __ffsll((long long)m) - 1 : 64, z = fr ? __ffsll((long long)fr) - 1 : 64;
+            if (z <= h && z < valid) { merged = true; break; }
+          }
+          if (m == 0) break;
+          pos = __ffsll((long long)m) - 1;
+          if (pos >= valid) break;
+          pk = qc + pos;
+        }
+        const unsigned long long rest = ~(hot >> pos);
+        int len = rest ? __ffsll((long long)rest) - 1 : 64 - pos;
+        if (len > valid - pos) len = valid - pos;
+        if (len > 0) {
+          const unsigned long long seg = (len == 64 ? ~0ull : (1ull << len) - 1) << pos;
+          if (len <= 12) {
+            for (int i = pos; i < pos + len; i++) { const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[d]), i)); if (x > pulmax) pulmax = x; }
+          } else {
+            float mx = ((seg >> lane) & 1) ? v[d] : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mx)));
+            if (mx > pulmax) pulmax = mx;
+          }
+          ifirst = 1; cnt += len;
+          if constexpr (MODE == 2) acc[1] |= seg;
+          if constexpr (MODE == 0) bw |= seg;
+          pos += len;
+        }
+        if (pos >= valid) break;
+        ifirst = 0;
+        int ib, ia;
+        const int ext = bln_guards(a, pulmax, totnoise, &ib, &ia);
+        pulmax = 0;
+        if constexpr (MODE == 0) bw |= 1ull << pos;       // the sample that ends the run
+        if (ext) {
+          if (ib > 0) mark(pk - ib, ib);
+          if (ia > 0) mark(qc + pos, ia);
+          cnt += ib + ia; erase_end = qc + pos + ia;
+          if constexpr (MODE == 0) bw |= low(pos + ia) & ~low(pos);
+        }
+        pos++;
+      }
+      else if constexpr (MODE == 1) {                      // nothing above the limit here: still outside a run; has the guard ended where the other walk is free?
+        const int skip = erase_end - qc;
+        if (skip < 64) { const unsigned long long fr = ~bw & (~0ull << (skip > 0 ? skip : 0)) & low(valid); if (fr) merged = true; }
+      }
+      if constexpr (MODE == 0) { if (lane == 0) busy[step] = bw; }
+    }
+  }
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int w = 0; w < 3; w++) if (acc[w]) or_bits(qc - 64 + 64 * w, acc[w]);
+  }
+  s.in_run = ifirst; s.pk = pk; s.erase_end = erase_end; s.pulmax = pulmax;
+  cnt_out = cnt;
+  return merged;
+}
+__device__ __forceinline__ bool bln_walk_wanted(const BlankArgs &a) { return a.st->need_slow && (a.st->need_slow2 || a.debug == 8) && !bln_runs_mode(a); }
+__device__ __forceinline__ int4 bln_pack(const BlnWalk &s) { return make_int4(s.in_run, s.pk, s.erase_end, __float_as_int(s.pulmax)); }
+__device__ __forceinline__ BlnWalk bln_unpack(int4 v) { BlnWalk s; s.in_run = v.x; s.pk = v.y; s.erase_end = v.z; s.pulmax = __int_as_float(v.w); return s; }
+
+__global__ __launch_bounds__(64) void k_blank_walk_spec(BlankArgs a)
+{
+  if (!bln_walk_wanted(a)) return;
+  const int lane = threadIdx.x, t = blockIdx.x;
+  const int q_first = 1 + t * LRH_BLN_WTILE, q_last = min(q_first + LRH_BLN_WTILE - 1, a.total);
+  const int wordmask = ((a.mask + 1) >> 5) - 1;
+  if (t == 0) for (int i = lane; i < a.ncounts; i += 64) a.counts[i] = 0;      // the scan's counts go with its decisions
+  {                                                     // ... and so do its bits: this tile's span of the mask (and the margins the guards reach, at the ends)
+    const int qlo = t == 0 ? 1 - a.clr1 - 32 : q_first, qhi = t == (int)gridDim.x - 1 ? a.total + a.clr2 + 32 : q_last;
+    const int w0 = ((a.pbeg + qlo) & a.mask) >> 5, nw = (qhi - qlo + 1) / 32 + 2;
+    for (int k = lane; k < nw; k += 64) a.mask_bits[(w0 + k) & wordmask] = 0;
+  }
+  BlnWalk s = { 0, 0, 0, 0.f };
+  int cnt;
+  bln_walk<0>(a, q_first, q_last, s, a.wbusy + (size_t)t * (LRH_BLN_WTILE / 64), cnt);
+  if (lane == 0) a.wstate[t] = bln_pack(s);
+}
+__global__ __launch_bounds__(64) void k_blank_walk_chain(BlankArgs a)
+{
+  if (!bln_walk_wanted(a)) return;
+  BlnWalk s = { 0, 0, 0, 0.f };
+  for (int t = 0; t < a.nwt; t++) {
+    const int q_first = 1 + t * LRH_BLN_WTILE, q_last = min(q_first + LRH_BLN_WTILE - 1, a.total);
+    if (threadIdx.x == 0) a.wstate[a.nwt + t] = bln_pack(s);
+    if (!s.in_run && s.erase_end <= q_first) { s = bln_unpack(a.wstate[t]); continue; }
+    int cnt;
+    if (bln_walk<1>(a, q_first, q_last, s, a.wbusy + (size_t)t * (LRH_BLN_WTILE / 64), cnt)) s = bln_unpack(a.wstate[t]);
+  }
+  if (threadIdx.x == 0) a.st->call_cleared = 0;
+}
+__global__ __launch_bounds__(64) void k_blank_walk_final(BlankArgs a)
+{
+  if (!bln_walk_wanted(a)) return;
+  const int t = blockIdx.x;
+  const int q_first = 1 + t * LRH_BLN_WTILE, q_last = min(q_first + LRH_BLN_WTILE - 1, a.total);
+  BlnWalk s = bln_unpack(a.wstate[a.nwt + t]);
+  int cnt = 0;
+  bln_walk<2>(a, q_first, q_last, s, nullptr, cnt);
+  if (threadIdx.x == 0 && cnt) atomicAdd(&a.st->call_cleared, cnt);
+}
+
 // one thread per 32-sample mask word: zero the flagged samples (weak I/Q + power), reset the word, and report how much
 // every-4th-sample power was removed (the noise statistic of blank1.c:1493-1497 is taken after clearing)
 __global__ __launch_bounds__(256) void k_blank_apply(BlankArgs a, int first_word, int nwords, int word_mask)
@@ -1731,7 +1906,7 @@ __global__ void k_blank_update(BlankArgs a)
   tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
   ncl = (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
   BlankState *s = a.st;
-  if (s->need_slow) { s->need_slow = 0; s->slow_calls++; }   // the long-run replay served this call (k_blank_serial resets the flag itself)
+  if (s->need_slow) { s->need_slow = 0; s->need_slow2 = 0; s->slow_calls++; }   // the long-run replay / the tile-parallel walk served this call (k_blank_serial resets the flags itself)
   float t1;
   if (a.phase == 2) {                                    // second half of a coupled call: both channels' means have arrived
     s->despiked_pwrinc[0] += a.xstat[0];                  // blank1.c:1538-1541
@@ -3673,8 +3848,14 @@ hipError_t launch_blanker(const BlankArgs &a0, int ring_words, hipStream_t st)
     if (!(a.clr1 == 0 && a.clr2 == 1 && a.tiles)) {      // calibrated blanker only
       hipLaunchKernelGGL(k_blank_scan<LRH_BLN_BACK2>, dim3(ntiles), dim3(256), 0, st, a);      // returns at once unless a lane gave up
       const char *e_ = getenv("LRH_BLN_SERIAL"); const int one_lane = e_ ? atoi(e_) : 0;     // (read per call: the comparison test flips it)
-      if (one_lane) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
-      else hipLaunchKernelGGL(k_blank_serial_wave, dim3(1), dim3(64), 0, st, a);
+      if (one_lane == 1) hipLaunchKernelGGL(k_blank_serial, dim3(1), dim3(1), 0, st, a);
+      else if (one_lane == 2 || !a.wbusy) hipLaunchKernelGGL(k_blank_serial_wave, dim3(1), dim3(64), 0, st, a);   // (LRH_BLN_SERIAL=2: the one-wave walk, for comparison)
+      else {                                              // tile-parallel walk: three launches that return at once unless both scans gave up
+        a.nwt = (a.total + LRH_BLN_WTILE - 1) / LRH_BLN_WTILE;
+        hipLaunchKernelGGL(k_blank_walk_spec, dim3(a.nwt), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_blank_walk_chain, dim3(1), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_blank_walk_final, dim3(a.nwt), dim3(64), 0, st, a);
+      }
     }
     else {         // long-run replay: two launches that return at once unless a lane gave up
       hipLaunchKernelGGL(k_blank_runs_pre, dim3(ntiles), dim3(256), 0, st, a);

@@ -131,6 +131,7 @@ struct BlankState {          // device resident; mirrors lrh_blanker_state + scr
   float amp_factor;          // liminfo_amplitude_factor: the limiter kernels keep it current, k_clever scales its reference pulse with it
   int need_slow2;            // scratch: ... and none within the long look-back of the second scan either: the serial walk takes the call
 };
+#define LRH_BLN_WTILE 4096
 struct BlankArgs {
   float *pwr; float2 *timf2w; unsigned int *mask_bits; int mask;   // mask: timf2pow_mask
   int pbeg, total;          // positions pbeg+1 .. pbeg+total are scanned
@@ -150,6 +151,10 @@ struct BlankArgs {
   // phase 2 resumes with both channels' values (phase 0: single channel, everything in one go)
   int chans; float *own; float *xstat; int own_slot; int phase;
   float4 *tiles;            // per-tile run summaries of the long-run replay (k_blank_runs_pre / k_blank_runs)
+  // tile-parallel form of the calibrated blanker's serial walk (k_blank_walk_*): one 64-bit word per 64 sequence positions ("the
+  // speculative walk was inside a run or a guard here"), and per tile of LRH_BLN_WTILE positions the state a walk leaves it in
+  // [0 .. nwt) and the state the true walk enters it in [nwt .. 2 nwt)
+  unsigned long long *wbusy; int4 *wstate; int nwt;
   // linear blanker ran before this call's stupid pass: the every-4th-sample statistic ends at timf2p_fit (blank1.c:1458-1461),
   // short of the scanned span, so it is summed after the clearing (post_stats); fitted / rejected pulses for the bookkeeping
   int post_stats; int fitted, rejected; int clever_mode; float clever_factor;

@@ -499,9 +499,11 @@ def test_blanker_long_runs_replayed_in_parallel(amps):
 def test_calibrated_blanker_long_runs_walk(amps, monkeypatch):
     """The same signals with pulse calibration (blanker_pulsewidth 3: guards of clr1 = 2 before and up to clr2 = 4 samples behind a run,
     blank1.c:1013-1014), where runs chain through their guards and the walk over a call that gave the lanes no clean restart point is
-    serial: k_blank_serial_wave (one wave, the walk moves by runs through the ballot of "above the limit") against the oracle's sample
-    walk, and bit for bit against the one-lane statement of the walk (LRH_BLN_SERIAL=1).  Third case: noise only with the limit below
-    the noise -- the start-up of a calibrated receiver: short runs everywhere."""
+    serial.  The library runs it tile-parallel (k_blank_walk_spec / _chain / _final: a speculative walk per tile, the true entry states
+    chained through the tiles, the walk again per tile from its true entry state); held here against the oracle's sample walk and, bit
+    for bit, against the one-wave walk (k_blank_serial_wave, LRH_BLN_SERIAL=2) and the one-lane statement of it (LRH_BLN_SERIAL=1).
+    Third case: noise only with the limit below the noise -- the start-up of a calibrated receiver: short runs everywhere, a run or a
+    guard across almost every tile boundary."""
     cfg = chain_config(14, 12, batch=16)
     cfg.blanker_pulsewidth = 3
     if not (amps[0] or amps[1]):
@@ -516,7 +518,7 @@ def test_calibrated_blanker_long_runs_walk(amps, monkeypatch):
     res = []
     # the library's order (second scan with the long look-back, then the walk if that gives up too); the walk alone (LRH_BLN_DEBUG=8: no
     # second scan) on one wave and on one lane; the oracle
-    for fn, dbg, one_lane in ((_hip, "0", "0"), (_hip, "8", "0"), (_hip, "8", "1"), (_oracle, "0", "0")):
+    for fn, dbg, one_lane in ((_hip, "0", "0"), (_hip, "8", "0"), (_hip, "8", "1"), (_oracle, "0", "0"), (_hip, "8", "2")):
         monkeypatch.setenv("LRH_BLN_DEBUG", dbg)
         monkeypatch.setenv("LRH_BLN_SERIAL", one_lane)
         rx = fn(cfg)
@@ -524,7 +526,9 @@ def test_calibrated_blanker_long_runs_walk(amps, monkeypatch):
         rx.wideband_dsp(64, 16)
         res.append((rx.export(abi.RING_TIMF2_PWR), rx.blanker_state(), rx.p.as_dict(), rx.export(abi.RING_TIMF2_FLOAT)))
         rx.close()
-    (hp, hb, hpt, ht), (wp, wb, wpt, wt), (sp, sb, spt, st_), (op, ob, opt, _) = res
+    (hp, hb, hpt, ht), (wp, wb, wpt, wt), (sp, sb, spt, st_), (op, ob, opt, _), (vp, vb, vpt, vt) = res
+    assert np.array_equal(wp, vp) and np.array_equal(wt, vt)          # the tile-parallel walk = the one-wave walk
+    assert (wb.timf2_noise_floor, wb.stupid_bln_limit, wb.slow_path_calls, wpt) == (vb.timf2_noise_floor, vb.stupid_bln_limit, vb.slow_path_calls, vpt)
     fit = hpt["timf2p_fit"]
     assert fit == opt["timf2p_fit"] == spt["timf2p_fit"] == wpt["timf2p_fit"] and fit > 400000
     assert hb.slow_path_calls >= 1 and sb.slow_path_calls == hb.slow_path_calls == wb.slow_path_calls
