@@ -417,7 +417,8 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
                         "wideband_dsp_ms_per_call": round(host["wideband_dsp"][0] / max(host["wideband_dsp"][1], 1), 4),
                         "wideband_dsp_cpu_ms_per_call": round(host["wideband_dsp_cpu"][0] / max(host["wideband_dsp_cpu"][1], 1), 4),
                         "staging_wait_ms_per_call": round(host["staging_wait"][0] / max(host["staging_wait"][1], 1), 4)},
-           "samples_per_step": samples_per_step, "workload": workload_name(w, args.batch),
+           "samples_per_step": samples_per_step,
+           "workload": workload_name(w, args.batch) + ("_full" if (args.fft1_float == "full" and args.fft2_float == "full") else ""),   # key into profiles/*_traffic.json
            "routing": ("selective limiter on the device at the end of every round inside lrh_wideband_dsp (lrh_wideband_limiter: fft1_update_liminfo%s, "
                        "wcw.c:1124-1133), strong bins now %d of %d" %
                        (" + fft2_update_liminfo (sellim_par1 = %d)" % args.limiter2_par1 if args.limiter2 else "", int(np.count_nonzero(rx.get_liminfo())), N1)) if sel is not None else "fixed table (strong carriers routed by hand)",

@@ -149,6 +149,7 @@ struct lrh_ctx {
   // same point of the main stream.  last_main_ev: an event recorded on the main stream with nothing enqueued there since (set and
   // consumed within a few lines of each other, never carried across calls); ev_tail_cur: the event that stands for ev_tail.
   hipEvent_t last_main_ev = nullptr, ev_tail_cur = nullptr;
+  double ph_last_wait_us = 0;     // how long mix1_run last waited for a staging slot
   // Small rounds (serial order): blanker + fft2 + mix1 (+ fft3 / mix2) of a round are a chain of short kernels the next round's fft1 and
   // timf2 do not wait for; they go to the side stream and the main stream carries on.  st_n tails issued so far, ev_st[n & 1] behind tail n;
   // any entry point other than lrh_wideband_dsp first orders the main stream behind the newest tail (LRH_ENTER).  LRH_SIDE_TAIL=0: off.
@@ -2125,14 +2126,21 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
       // the host runs up to LRH_NSTAGE rounds ahead and then waits here for most of a round: asleep, not spinning inside
       // hipEventSynchronize (which burnt a whole core: thread CPU time = wall time of the call)
       // (small rounds finish within tens of microseconds: poll that long first, a sleep would cost the round its own length)
+      // ... and after a long wait the next one is long too (the host is LRH_NSTAGE rounds ahead of rounds of ~1 ms): no polling phase then,
+      // and sleeps of a fifth of the last wait -- 60 us of spinning and a wake-up every 40 us were 1.2 of the 3.7 ms of CPU time per call of 8 rounds
+      const double last = c->ph_last_wait_us;
+      long nap_ns = last > 400.0 ? (long)(last * 200.0) : 40000; if (nap_ns > 250000) nap_ns = 250000;
       for (;;) {
         const hipError_t q = hipEventQuery(c->ph_ev[slot]);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(c, LRH_EDEVICE, "hipEventQuery(staging)", q);
-        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count() < 60.0) continue;
-        timespec ts{0, 40000}; nanosleep(&ts, nullptr);
+        const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        if (last <= 400.0 && waited < 60.0) continue;
+        if (last > 400.0 && waited > 0.7 * last) nap_ns = 40000;      // close to the expected end: short naps
+        timespec ts{0, nap_ns}; nanosleep(&ts, nullptr);
       }
-      c->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); }
+      c->ph_last_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+      c->host_ms_wait += c->ph_last_wait_us * 1e-3; }
     const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
     float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
     int point = 0;

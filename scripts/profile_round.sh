@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.log
+python3 scripts/timeline.py $OUT/stats > $OUT/timeline.txt 2>&1
 echo "stats pass done: $(tail -c 300 $OUT/stats.log | tr '\n' ' ')"
 # The counter passes run the serial schedule: TCC counters are per device, so a side-stream kernel overlapping k_timf2 would be
 # charged k_timf2's traffic (seen: 100-200 MB "fetched" by blanker kernels that return at once).  Bytes per kernel do not depend on the schedule.
@@ -21,6 +22,7 @@ pmc() {   # name, bench flags
 }
 pmc n1_14_n2_16_n3_12_b4096 --no-secondary
 pmc n1_14_n2_12_n3_0_b4096 --fft2-n 12 --fft3-n 0
+pmc n1_14_n2_16_n3_12_b4096_full --no-secondary --fft1-float full --fft2-float full     # what the Linrad glue opens (bench.py's full_rings object)
 python3 bench.py --steps 50 --warmup 5 > $OUT/bench_plain.json 2> $OUT/plain.log
 # keep the merge small: per-dispatch traces can be large
 python3 scripts/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
