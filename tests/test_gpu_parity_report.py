@@ -13,7 +13,7 @@ from refcases import CASES
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r03"
+ROUND = os.environ.get("LRH_ROUND", "r04")
 
 
 def _clean(v):
