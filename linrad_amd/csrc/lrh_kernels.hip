@@ -2188,6 +2188,87 @@ __global__ __launch_bounds__(1024, LA <= 8 ? 8 : 4) void k_fft2_cols(Fft2BigArgs
   }
 }
 
+// Column step of 256 points with 16 points per thread (round 4).  The 4-point form above moves a transform through the LDS four times
+// (three exchanges of the radix-4 passes and the transposed store, three barriers) with four loads in flight per lane.  Here
+// n1 = 16 a + b, k1 = ka + 16 kb: thread (column c, b) loads a = 0..15 (sixteen loads in flight, each 16-lane group a whole 128-byte
+// line), runs the 16-point transform over a in registers, multiplies by w_256^(b ka) -- and the ONE exchange that follows is at the same
+// time the transposition the store needs: thread (ka, column c2) reads b = 0..15, runs the transform over b and holds bins
+// ka + 16 kb of column c2, so that 16 consecutive lanes store 16 consecutive bins of scratch[n2][k1] (a whole line).  Cell
+// (b, ka, c) sits at ((b 16 + ka) 16 + (c ^ ka)): 16 writing lanes (c = 0..15) fill 16 consecutive cells, 32 reading lanes (ka = 0..15 of
+// two columns) hit 32 different 8-byte banks.  256 threads, 34 KB of LDS, four workgroups per CU in different phases of their cycle.
+template <int LB, int TILE>
+__global__ __launch_bounds__(16 * TILE, 64 / TILE) void k_fft2_cols16(Fft2BigArgs a)
+{
+  static_assert(TILE == 16 || TILE == 32, "tile columns");
+  constexpr int NA = 256, NB = 1 << LB, LT = TILE == 16 ? 4 : 5;
+  __shared__ float2 xch[16 * 16 * TILE];
+  __shared__ float2 twl[NA];                             // e^{+2 pi j k / 256}
+  const int tid0 = threadIdx.x;
+  if (tid0 < NA) { const float2 w = a.tw_a[tid0]; twl[tid0] = make_float2(w.x, -w.y); }
+  const int t_first = blockIdx.y * a.run, t_end = min(t_first + a.run, a.batch);
+  const bool overlap = a.step * 2 == NA * NB;
+  float2 twk[16], keep[8], pf[8];
+  {
+    const int n2s = blockIdx.x * TILE + (tid0 >> 4), ka = tid0 & 15;
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {                    // w_N^(n2 k1), e^{+j}: conjugate of the forward table
+      const float2 w = a.tw_big[(n2s * (ka + 16 * kb)) & (NA * NB - 1)];
+      twk[kb] = make_float2(w.x, -w.y);
+    }
+  }
+  // column index of a cell: 16 writing lanes (consecutive c, one ka) fill 16 consecutive cells; 32 reading lanes (ka = 0..15 of two
+  // neighbouring columns) hit 32 different 8-byte banks (with 32 columns the two columns share bit 4: the parity of ka tells them apart)
+  auto colx = [](int c, int ka) { return TILE == 16 ? (c ^ ka) : (c ^ ka ^ ((ka & 1) << 4)); };
+  __syncthreads();
+#pragma unroll 1
+  for (int t = t_first; t < t_end; t++) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                        // keeps the address arithmetic inside the loop (see k_timf2)
+    const int c = tid & (TILE - 1), b = tid >> LT;       // load role: column c, samples n1 = 16 a + b
+    const int n2 = blockIdx.x * TILE + c;
+    const int px = a.px_first + t * a.step;
+    const bool reuse = overlap && t > t_first;
+    float2 x[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      float2 raw;
+      if (reuse) raw = q < 8 ? keep[q] : pf[q - 8];
+      else {
+        const int r = (px + NB * (16 * q + b) + n2) & a.mask;
+        const float2 vw = load_stream(&a.timf2w[r]), vs = load_stream(&a.timf2s[r]);
+        raw = make_float2(vw.x + vs.x, vw.y + vs.y);     // weak + strong (fft2.c:100-105)
+      }
+      const float w = a.window[NB * (16 * q + b) + n2];   // cache hits after the first transform
+      x[q] = make_float2(w * raw.x, w * raw.y);
+      if (q >= 8) keep[q - 8] = raw;
+    }
+    Dft<+1, 16>::run(x);                                  // over a: x[ka]
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) x[ka] = cmul(x[ka], twl[(b * ka) & (NA - 1)]);
+#pragma unroll
+    for (int ka = 0; ka < 16; ka++) xch[((b * 16 + ka) << LT) + colx(c, ka)] = x[ka];
+    // the next transform's new half (its first half is this one's second, kept in registers): in flight across the exchange
+    if (overlap && t + 1 < t_end) {
+      const int pxn = px + a.step;
+#pragma unroll
+      for (int q = 8; q < 16; q++) {
+        const int r = (pxn + NB * (16 * q + b) + n2) & a.mask;
+        const float2 vw = load_stream(&a.timf2w[r]), vs = load_stream(&a.timf2s[r]);
+        pf[q - 8] = make_float2(vw.x + vs.x, vw.y + vs.y);
+      }
+    }
+    __syncthreads();
+    const int ka = tid & 15, c2 = tid >> 4;              // store role: bins ka + 16 kb of column c2
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) x[bb] = xch[((bb * 16 + ka) << LT) + colx(c2, ka)];
+    Dft<+1, 16>::run(x);                                  // over b: x[kb]
+    float2 *sc = a.scratch + (size_t)t * NA * NB + (size_t)blockIdx.x * TILE * NA + (size_t)c2 * NA + ka;
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) store_stream(&sc[16 * kb], cmul(x[kb], twk[kb]));
+    __syncthreads();                                     // the next transform reuses the buffer
+  }
+}
+
 // FUSED: blockIdx.y is a waterfall averaging group instead of a transform; the workgroup walks the group's
 // transforms and keeps sum |X|^2 of its bins in registers (k_fft2's scheme), so neither the fft2_power ring nor the
 // k_powersum2 pass over it is needed.
@@ -2770,6 +2851,17 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
     int run = a0.run > 0 ? a0.run : batch * tiles / 512;         // a0.run: tuning knob LRH_FFT2_COLS_RUN (read by lrh_open)
     a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
   }
+  // columns of 256 points: 16 points per thread (LRH_FFT2_COLS_P16=0: the 4-point form, for comparison)
+  static const int cols16 = getenv("LRH_FFT2_COLS_P16") ? atoi(getenv("LRH_FFT2_COLS_P16")) : 2;   // 2: 32 columns per workgroup (256-byte pieces of a row), 1: 16 columns
+  static const int cols16_wgs = getenv("LRH_FFT2_COLS_WGS") ? atoi(getenv("LRH_FFT2_COLS_WGS")) : 1024;    // workgroups aimed at (four of 256 threads fit a CU)
+  if ((steps & 1) && LA == 8 && cols16) {
+    const int tile = cols16 == 2 ? 32 : 16, tiles = (1 << LB) / tile;
+    int run = a0.run > 0 ? a0.run : batch * tiles / (cols16 == 2 ? cols16_wgs / 2 : cols16_wgs);
+    a.run = run < 1 ? 1 : (run > 32 ? 32 : run);
+    if (cols16 == 2) hipLaunchKernelGGL((k_fft2_cols16<LB, 32>), dim3(tiles, (batch + a.run - 1) / a.run), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_fft2_cols16<LB, 16>), dim3(tiles, (batch + a.run - 1) / a.run), dim3(256), 0, st, a);
+  }
+  else
   if (steps & 1) hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
   if (!(steps & 2)) return;
   // rows of 256 points: 16 points per thread (k_fft2_rows' PPT; LRH_FFT2_ROWS_P16=0: the 4-point form, for comparison)
