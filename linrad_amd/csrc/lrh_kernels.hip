@@ -2354,6 +2354,94 @@ __global__ __launch_bounds__(LRH_TILE * ((1 << LB) / PPT), PPT == 16 ? 4 : (LB <
   }
 }
 
+// Row step of 256 points in the layout of k_fft2_cols16 (round 4): 32 neighbouring k1 per workgroup (a 256-byte piece of every scratch row
+// per load instruction instead of 128), n2 = 16 q + b with b = thread / 32, the 16-point transform over q in registers, ONE exchange
+// (cell (b, ka, c) at (b 16 + ka) 32 + c: writers and readers both sweep consecutive cells), the 16-point transform over b, bins
+// k2 = ka + 16 kb of column k1 with ka = thread / 32 -- k1 stays along the lanes, so every store is a 256-byte piece of an output row.
+// The next transform's sixteen loads are issued behind the exchange.  Same sums, same order as k_fft2_rows<.., FUSED>.
+template <int LA, bool FUSED>
+__global__ __launch_bounds__(512, 2) void k_fft2_rows16x(Fft2BigArgs a)
+{
+  constexpr int NA = 1 << LA, NB = 256, TILE = 32;
+  __shared__ float2 xch[16 * 16 * TILE];
+  __shared__ float2 twl[NB];
+  const int tid0 = threadIdx.x;
+  if (tid0 < NB) { const float2 w = a.tw_b[tid0]; twl[tid0] = make_float2(w.x, -w.y); }
+  int t_first = blockIdx.y, t_end = t_first + 1;
+  bool ps_continue = false, ps_complete = false;
+  const int g = blockIdx.y;
+  if constexpr (FUSED) {                                 // group arithmetic of k_powersum2
+    t_first = g == 0 ? 0 : g * a.ps_avgnum - a.ps_counter;
+    int count = a.ps_avgnum - (g == 0 ? a.ps_counter : 0);
+    ps_complete = count <= a.batch - t_first;
+    if (!ps_complete) count = a.batch - t_first;
+    t_end = t_first + count;
+    ps_continue = g == 0 && a.ps_counter > 0;
+  }
+  const int k1 = blockIdx.x * TILE + (tid0 & (TILE - 1));
+  float acc[FUSED ? 16 : 1];
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) acc[kb] = ps_continue ? a.ps_in[k1 + NA * ((tid0 >> 5) + 16 * kb)] : 0.f;
+  }
+  float2 nx[16];
+  if (t_first < t_end) {
+    const float2 *sc = a.scratch + (size_t)t_first * NA * NB;
+#pragma unroll
+    for (int q = 0; q < 16; q++) nx[q] = load_stream(&sc[(size_t)(16 * q + (tid0 >> 5)) * NA + k1]);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int t = t_first; t < t_end; t++) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int c = tid & (TILE - 1), hi = tid >> 5;       // hi: b when loading, ka when storing
+    float2 x[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) x[q] = nx[q];
+    Dft<+1, 16>::run(x);                                  // over q: x[ka]
+#pragma unroll
+    for (int ka = 1; ka < 16; ka++) x[ka] = cmul(x[ka], twl[(hi * ka) & (NB - 1)]);
+#pragma unroll
+    for (int ka = 0; ka < 16; ka++) xch[((hi * 16 + ka) << 5) + c] = x[ka];
+    if (t + 1 < t_end) {
+      const float2 *sc = a.scratch + (size_t)(t + 1) * NA * NB;
+#pragma unroll
+      for (int q = 0; q < 16; q++) nx[q] = load_stream(&sc[(size_t)(16 * q + hi) * NA + k1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) x[bb] = xch[((bb * 16 + hi) << 5) + c];
+    Dft<+1, 16>::run(x);                                  // over b: x[kb], bin k2 = hi + 16 kb
+    const int na = (a.first_na + t) & a.na_mask;
+    float2 *out = a.out + (size_t)na * NA * NB;
+    float *pw = a.power + (size_t)na * NA * NB;
+    if (a.keep_lo <= 0 && a.keep_hi >= NA * NB) {
+#pragma unroll
+      for (int kb = 0; kb < 16; kb++) store_stream(&out[k1 + NA * (hi + 16 * kb)], x[kb]);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 16; kb++) { const int k = k1 + NA * (hi + 16 * kb); if (k >= a.keep_lo && k < a.keep_hi) store_stream(&out[k], x[kb]); }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {
+      const float2 v = x[kb];
+      const float p2 = v.x * v.x + v.y * v.y;
+      if constexpr (FUSED) acc[kb] = (t == t_first && !ps_continue) ? p2 : acc[kb] + p2;   // "=" then "+=" (fft2.c:655-670)
+      else pw[k1 + NA * (hi + 16 * kb)] = p2;
+    }
+    __syncthreads();                                     // the next transform reuses the exchange buffer
+  }
+  if constexpr (FUSED) {
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) {
+      const int k = k1 + NA * ((tid0 >> 5) + 16 * kb);
+      if (ps_complete) a.wf_scratch[(size_t)g * NA * NB + k] = acc[kb];
+      if (g == (int)gridDim.y - 1) a.ps_out[k] = acc[kb];
+    }
+  }
+}
+
 // fft2_powersum_float (fft2.c:655-670): group g = one waterfall averaging period; complete groups are parked in
 // wf_scratch for k_waterfall, the last (possibly partial) group is what fft2_powersum_float holds afterwards.
 __global__ __launch_bounds__(256) void k_powersum2(Powersum2Args a)
@@ -2865,8 +2953,15 @@ template <int LA, int LB> static void launch_fft2_big_t(const Fft2BigArgs &a0, i
   if (steps & 1) hipLaunchKernelGGL((k_fft2_cols<LA, LB>), dim3((1 << LB) / LRH_TILE, (batch + a.run - 1) / a.run), dim3(LRH_TILE * ((1 << LA) / sub_ppt(LA))), 0, st, a);
   if (!(steps & 2)) return;
   // rows of 256 points: 16 points per thread (k_fft2_rows' PPT; LRH_FFT2_ROWS_P16=0: the 4-point form, for comparison)
-  static const int rows16 = getenv("LRH_FFT2_ROWS_P16") ? atoi(getenv("LRH_FFT2_ROWS_P16")) : 1;
+  static const int rows16 = getenv("LRH_FFT2_ROWS_P16") ? atoi(getenv("LRH_FFT2_ROWS_P16")) : 2;   // 2: k_fft2_rows16x, 1: k_fft2_rows<.., 16>, 0: the 4-point form
   if constexpr (LB == 8) {
+    if (rows16 == 2) {                                   // 32 neighbouring bins per workgroup, one exchange, loads of the next transform behind it
+      if (a.ps_avgnum > 0)
+        hipLaunchKernelGGL((k_fft2_rows16x<LA, true>), dim3((1 << LA) / 32, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum), dim3(512), 0, st, a);
+      else
+        hipLaunchKernelGGL((k_fft2_rows16x<LA, false>), dim3((1 << LA) / 32, batch), dim3(512), 0, st, a);
+      return;
+    }
     if (rows16) {
       if (a.ps_avgnum > 0)
         hipLaunchKernelGGL((k_fft2_rows<LA, LB, true, 16>), dim3((1 << LA) / LRH_TILE, (a.ps_counter + batch + a.ps_avgnum - 1) / a.ps_avgnum),

@@ -21,8 +21,8 @@ STAGE_KERNELS = {
     "sumsq_join": ("k_sumsq_join", ["k_sumsq_join"]),
     "slowsum": ("k_slowsum", ["k_slowsum"]),
     "clever": ("k_clever_regions", ["k_clever_prep", "k_clever_count", "k_clever_regions", "k_clever(", "k_clever_check", "k_clever_restore"]),
-    "blanker": ("k_blank_scan", ["k_blank_scan", "k_blank_runs_pre", "k_blank_runs(", "k_blank_serial", "k_blank_apply", "k_blank_stats", "k_blank_update"]),
-    "fft2": (("k_fft2_cols<", "k_fft2<"), ["k_fft2_cols<", "k_fft2_rows<", "k_fft2<"]),
+    "blanker": ("k_blank_scan", ["k_blank_scan", "k_blank_runs_pre", "k_blank_runs(", "k_blank_serial", "k_blank_walk", "k_blank_apply", "k_blank_stats", "k_blank_update"]),
+    "fft2": (("k_fft2_cols<", "k_fft2_cols16<", "k_fft2<"), ["k_fft2_cols<", "k_fft2_cols16<", "k_fft2_rows<", "k_fft2_rows16x<", "k_fft2<"]),
     "powersum2": ("k_powersum2", ["k_powersum2"]),
     "waterfall": ("k_waterfall", ["k_waterfall"]),
     "mix1": ("k_mix1_back<", ["k_mix1_back<", "k_mix1_out"]),
