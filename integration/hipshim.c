@@ -50,6 +50,7 @@ static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
 static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins store_new_spur was last asked to take */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
+static int hip_xgather(int which, size_t count);
 lrh_ctx *hip_context(void) { return hip_rx; }
 lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL; }
 
@@ -66,7 +67,9 @@ static int hip_unsupported(void)
   if ((ui.rx_input_mode & IQ_DATA) == 0 && fft_cntrl[FFT1_CURMODE].permute != 2) return 2;   /* real samples: version 22, whose permute field gives Linrad's
                                                                                                   filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
-  if (fft1_correlation_flag != 0) return 4;
+  /* correlation spectrum: served for two I/Q channels (flag 1: fft1_corrsum / fft1_slowcorr / fft1_slowcorr_tot, fft1.c:4146-4150, 4584-4603);
+     the correlation receiver (flag >= 2, its double-precision mixer) is not built */
+  if (fft1_correlation_flag != 0 && !(fft1_correlation_flag == 1 && ui.rx_rf_channels == 2)) return 4;
   /* spur removal: served with the second fft on (eliminate_spurs inside make_fft2, acquisition through the hooks in spursub.c); with the
      second fft off the reference's fft1_c subtracts spurs from fft1_float (fft1.c:4242, 4432-4476), which version 21 does not do --
      buf.c:836 zeroes MAX_NO_OF_SPURS itself when the AFC is off */
@@ -129,6 +132,8 @@ int hip_open(void)
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
   hip_spurs_on = genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
   if (hip_spurs_on && lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { lrh_close(hip_rx); hip_rx = NULL; return LRH_EINVAL; }
+  if (HC == 2 && fft1_correlation_flag == 1)
+    for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_close(); return LRH_EINVAL; }
   for (int ch = 0; ch < HC; ch++) lrh_host_register(hip_ctx[ch], timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
   return 0;
 }
@@ -210,7 +215,17 @@ void hip_fft1_c(void)
   if (n > hip_max_batch) n = hip_max_batch;
   if (n < 1) n = 1;
   { lrh_ptrs q0 = q;
-    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } } }
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } }
+    if (HC == 2 && fft1_correlation_flag == 1) {       /* X conj(Y) needs both channels' bins: the all-gather of the batch's transforms, through host memory */
+      size_t cnt[2] = { 0, 0 };
+      if (correlation_reset_flag != fft1corr_reset_flag) {   /* the operator's reset (fft1.c:4586): host arrays by Linrad's own code, the device's by switching the mode on again */
+        clear_fft1_correlation();
+        for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { lirerr(1466); return; }
+      }
+      for (int ch = 0; ch < 2; ch++) if (lrh_fft1_corr_begin(hip_ctx[ch], &q0, n, &cnt[ch]) != 0) { lirerr(1466); return; }
+      if (cnt[0] != cnt[1] || hip_xgather(LRH_X_SPEC, cnt[0]) != 0) { lirerr(1466); return; }
+      for (int ch = 0; ch < 2; ch++) if (lrh_fft1_corr_finish(hip_ctx[ch], &q0, n) != 0) { lirerr(1466); return; }
+    } }
   /* hip_sync_out */
   fft1_nb = q.fft1_nb; fft1_pb = HIP_OUT(q.fft1_pb); fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
   fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
@@ -230,6 +245,13 @@ void hip_fft1_c(void)
       float *t = hip_scratch((size_t)hip_n1);
       lrh_export(hip_ctx[1], LRH_RING_FFT1_SLOWSUM, t, 0, (size_t)hip_n1);
       for (int i = 0; i < hip_n1; i++) fft1_slowsum[i] += t[i];
+    }
+    if (HC == 2 && fft1_correlation_flag == 1) {       /* both contexts hold the same rings: the wide graph's correlation display reads these (wide_graph.c) */
+      for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask)
+        lrh_export(hip_rx, LRH_RING_FFT1_CORRSUM, &fft1_corrsum[2 * pa], (size_t)2 * pa, (size_t)2 * hip_n1);
+      lrh_export(hip_rx, LRH_RING_FFT1_SLOWCORR, fft1_slowcorr, 0, (size_t)2 * hip_n1);
+      lrh_export(hip_rx, LRH_RING_FFT1_SLOWCORR_TOT, fft1_slowcorr_tot, 0, (size_t)2 * hip_n1);
+      lrh_get_slowcorr_tot_avgnum(hip_rx, &slowcorr_tot_avgnum);
     }
   }
 }

@@ -48,6 +48,10 @@
 #define lrh_fft2_xy_begin lro_fft2_xy_begin
 #define lrh_fft2_xy_finish lro_fft2_xy_finish
 #define lrh_set_ch2_phasing lro_set_ch2_phasing
+#define lrh_set_correlation lro_set_correlation
+#define lrh_fft1_corr_begin lro_fft1_corr_begin
+#define lrh_fft1_corr_finish lro_fft1_corr_finish
+#define lrh_get_slowcorr_tot_avgnum lro_get_slowcorr_tot_avgnum
 #define lrh_set_filtercorr lro_set_filtercorr
 #define lrh_set_liminfo lro_set_liminfo
 #define lrh_set_mix1_selfreq lro_set_mix1_selfreq

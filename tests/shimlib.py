@@ -260,7 +260,7 @@ def check_twochan_case(harness, tmp_path, name="twochan_n10", tol=1e-5):
     (a) fft1_b / fft1_c / make_timf2: both channels' spectra and time functions in Linrad's interleaved layout, the power sums;
     (b) the same with the two-channel first_noise_blanker after every block: thresholds, pointers, cleared samples."""
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
-    d, dump = _run_2ch(harness, tmp_path, name, False, [])
+    d, dump = _run_2ch(harness, tmp_path, name, False, ["corr=1"])      # genparm[FFT1_CORRELATION_SPECTRUM] = 1: the cross spectrum rides along
     n1 = 1 << d["n1"]
     it, gi = dump["itrace"].reshape(-1, 16), g["itrace"].reshape(-1, 16)
     assert np.array_equal(it[:, [0, 9, 10, 11, 15]], gi[:, [0, 9, 10, 11, 15]]), "pointer trace"
@@ -270,6 +270,10 @@ def check_twochan_case(harness, tmp_path, name="twochan_n10", tol=1e-5):
     rep["timf2_pwr"] = relerr(dump["timf2_pwr_float"][:pa // 8], g["timf2_pwr_float"][:pa // 8])
     assert pa > 0 and np.abs(g["timf2_float"][:pa].reshape(-1, 2, 2, 2)[:, 1]).max() > 0
     assert max(rep.values()) <= tol, rep
+    # the correlation spectrum (fft1.c:4146-4150, 4584-4603): the glue gathers both channels' transforms and brings the three arrays back
+    assert int(dump["slowcorr_tot_avgnum"][0]) == int(g["slowcorr_tot_avgnum"][0]) > 0
+    rep.update({k: relerr(dump[k], g[k]) for k in ("fft1_corrsum", "fft1_slowcorr", "fft1_slowcorr_tot")})
+    assert rep["fft1_corrsum"] <= tol and rep["fft1_slowcorr"] <= 4 * tol and rep["fft1_slowcorr_tot"] <= tol and np.count_nonzero(g["fft1_slowcorr"]) > 100, rep
     # (b) coupled blanker
     d, dump = _run_2ch(harness, tmp_path, name, False, ["blanker2=1"])
     it, gi = dump["itrace"].reshape(-1, 16), g["bln_itrace"].reshape(-1, 16)
