@@ -157,6 +157,11 @@ struct lrh_ctx {
   // narrowband stream of the two-stream schedules: mix1 / fft3 / mix2 of a round -- a handful of small kernels, 66 us one after the other --
   // run here beside the next round's fft1 instead of holding the main stream (LRH_NARROW_STREAM=0: on the main stream as before)
   hipStream_t stream_nb = nullptr; hipEvent_t ev_f2done = nullptr, ev_nb = nullptr; bool nb_split = true, nb_pending = false; hipStream_t nb_keep = nullptr;
+  // ev_nb: the newest of ev_nb_ring (an alias).  The next fft2 only has to wait for the narrowband group whose fft2 slots it is about to
+  // overwrite: with a ring of several rounds that group ended long ago, and the newest one -- starved beside k_fft1v, it ends 20-50 us after
+  // timf2s -- no longer holds fft2 up.  nb_first_total[j]: transforms fft2 had written when group j's first slot was written; f2_total: now.
+  hipEvent_t ev_nb_ring[4] = {nullptr, nullptr, nullptr, nullptr}; bool nb_ev_valid[4] = {false, false, false, false};
+  unsigned nb_seq = 0; long nb_first_total[4] = {0, 0, 0, 0}, f2_total = 0;
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
@@ -412,7 +417,7 @@ void lrh_close(lrh_ctx *c)
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   if (c->ev_in_guard) hipEventDestroy(c->ev_in_guard);
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
-  for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb, c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
@@ -506,7 +511,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (hipStreamCreateWithFlags(&c->stream_nb, hipStreamNonBlocking) != hipSuccess) { lrh_close(c); return LRH_EDEVICE; }
   if (const char *e_ = getenv("LRH_NARROW_STREAM")) c->nb_split = atoi(e_) != 0;
   if (const char *e_ = getenv("LRH_SIDE_TAIL")) c->st_on = atoi(e_) != 0;
-  for (hipEvent_t *ev : { &c->ev_st[0], &c->ev_st[1], &c->ev_blank2[0], &c->ev_blank2[1], &c->ev_f2done, &c->ev_nb, &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  for (hipEvent_t *ev : { &c->ev_st[0], &c->ev_st[1], &c->ev_blank2[0], &c->ev_blank2[1], &c->ev_f2done, &c->ev_nb_ring[0], &c->ev_nb_ring[1], &c->ev_nb_ring[2], &c->ev_nb_ring[3], &c->ev_timf2_done, &c->ev_sel_wait, &c->ev_fft1, &c->ev_timf2, &c->ev_blank, &c->ev_fft2, &c->ev_side, &c->ev_ps2, &c->ev_sumsq[0], &c->ev_sumsq[1], &c->ev_tail, &c->ev_timf2b }) hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (const char *e2 = getenv("LRH_PIPELINE")) { c->pipeline = atoi(e2); c->pipeline_forced = true; }
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
@@ -2455,7 +2460,20 @@ static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 (+ fft3 / mix
     const int kb = k < c->cfg.max_fft2n ? k : c->cfg.max_fft2n;
     // (the stream switches are part of the recorded work: a parked round is issued -- and the split schedule known -- a round later)
     // the narrowband kernels of the previous group may still read the fft2 slots this group overwrites (they have had a round's time)
-    LRH_DEVICE_WORK(c, { if (c->nb_pending && c->split_fft2_tail && c->nb_split) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_nb, 0)); });
+    int wait_idx = -1;
+    {
+      const unsigned kept = c->nb_seq < 4 ? c->nb_seq : 4;
+      for (unsigned dd = 1; dd <= kept; dd++) {
+        const int j = (int)((c->nb_seq - dd) & 3);
+        if (c->f2_total + kb - c->nb_first_total[j] > (long)c->cfg.max_fft2n) { wait_idx = j; break; }     // the newest group whose slots these transforms reach
+      }
+      if (wait_idx < 0 && c->nb_seq > 4) wait_idx = (int)(c->nb_seq & 3);      // groups no longer tracked: the oldest kept event is behind them
+      static const bool newest = getenv("LRH_NB_WAIT_NEWEST") && atoi(getenv("LRH_NB_WAIT_NEWEST"));     // (comparison: always the newest group, as before)
+      if (newest && c->nb_seq > 0) wait_idx = (int)((c->nb_seq - 1) & 3);
+    }
+    const int rec_idx = (int)(c->nb_seq & 3);
+    c->nb_first_total[rec_idx] = c->f2_total; c->nb_seq++; c->f2_total += kb;
+    LRH_DEVICE_WORK(c, { if (wait_idx >= 0 && c->nb_ev_valid[wait_idx] && c->split_fft2_tail && c->nb_split) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_nb_ring[wait_idx], 0)); });
     if ((rc = lrh_make_fft2(c, p, kb))) return rc;
     LRH_DEVICE_WORK(c, {
       if (c->split_fft2_tail && c->nb_split) {
@@ -2470,7 +2488,7 @@ static int round_tail(lrh_ctx *c, lrh_ptrs *p)      // fft2 + mix1 (+ fft3 / mix
     if (rc) return rc;
     LRH_DEVICE_WORK(c, {
       if (c->nb_keep) {
-        HIPCHK(c, hipEventRecord(c->ev_nb, c->stream_nb)); c->nb_pending = true;
+        HIPCHK(c, hipEventRecord(c->ev_nb_ring[rec_idx], c->stream_nb)); c->nb_ev_valid[rec_idx] = true; c->ev_nb = c->ev_nb_ring[rec_idx]; c->nb_pending = true;
         c->cur = c->nb_keep; c->nb_keep = nullptr;
       } });
     if (rc) return rc;
