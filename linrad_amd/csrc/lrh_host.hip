@@ -161,7 +161,7 @@ struct lrh_ctx {
   // overwrite: with a ring of several rounds that group ended long ago, and the newest one -- starved beside k_fft1v, it ends 20-50 us after
   // timf2s -- no longer holds fft2 up.  nb_first_total[j]: transforms fft2 had written when group j's first slot was written; f2_total: now.
   hipEvent_t ev_nb_ring[4] = {nullptr, nullptr, nullptr, nullptr}; bool nb_ev_valid[4] = {false, false, false, false};
-  unsigned nb_seq = 0; long nb_first_total[4] = {0, 0, 0, 0}, f2_total = 0;
+  unsigned nb_seq = 0; long nb_first_total[4] = {0, 0, 0, 0}, f2_total = 0; bool nb_join_pending = false;
   unsigned char *d_pack18 = nullptr; size_t pack18_cap = 0;   // staging for lrh_timf1_write_packed18
   float2 *d_foldcorr = nullptr, *d_unitcorr = nullptr;   // I/Q mirror-image calibration (lrh_set_foldcorr); unit filter table for the bare transform
   bool fft2_fused = false;           // waterfall power sums formed inside k_fft2 (fft2_power ring then rebuilt on export)
@@ -249,7 +249,7 @@ static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten 
   c->pack_prev_stale = true;
 }
 #define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; } \
-  if ((c) && (c)->st_pending && !(c)->in_dsp) join_side_tail(c)
+  if ((c) && ((c)->st_pending || (c)->nb_join_pending) && !(c)->in_dsp) join_side_tail(c)
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
 // Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
@@ -2417,10 +2417,12 @@ static int flush_pending(lrh_ctx *c)
   return LRH_OK;
 }
 
-static void join_side_tail(lrh_ctx *c)      // later work on the main stream sees what the side-stream tails of small rounds wrote
+static void join_side_tail(lrh_ctx *c)      // later work on the main stream sees what the side-stream tails of small rounds / the narrowband stream wrote
 {
   if (c->st_pending) (void)hipStreamWaitEvent(c->stream, c->ev_st[(c->st_n - 1) & 1], 0);
   c->st_pending = false;
+  if (c->nb_join_pending && c->nb_pending) (void)hipStreamWaitEvent(c->stream, c->ev_nb, 0);
+  c->nb_join_pending = false;
 }
 
 // single-CPU branch of wideband_dsp (wcw.c:1036-1118), `batch` fft1 blocks per round.
@@ -2664,7 +2666,9 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   int rc;
   // a call that fails between parking the linear blanker's search and picking its result up must not leave the search marked as parked:
   // every later blanker call would answer LRH_ESTATE
-  struct NbJoin { lrh_ctx *c; ~NbJoin() { if (c->nb_pending) hipStreamWaitEvent(c->stream, c->ev_nb, 0); } } nb_join{c};   // later API calls are ordered on the main stream
+  // later API calls are ordered on the main stream: the entry point that comes next orders it behind the narrowband stream (LRH_ENTER) -- not this
+  // call's end, or a caller that passes one round per call would have every call's first transform wait for the previous call's last mix1 / fft3 / mix2
+  struct NbJoin { lrh_ctx *c; ~NbJoin() { if (c->nb_pending) c->nb_join_pending = true; } } nb_join{c};
   struct ClvGuard { lrh_ctx *c; bool ok = false; ~ClvGuard() { if (!ok) { c->clv_wait = false; c->clv_issued = false; } } } clv_guard{c};
   struct InDsp { lrh_ctx *c; InDsp(lrh_ctx *c_) : c(c_) { c->in_dsp++; } ~InDsp() { c->in_dsp--; } };
   // Small rounds are bound by the host's launches (~100 us per round), not by the kernels: the plain serial order has the
@@ -2727,7 +2731,14 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   // is the longer of the two and the hand-over only adds to it: 140 against 128 us per call of 4 blocks, 174 against 146 at 16; 63 against 80 at 1.
   const bool side_tail = c->st_on && !piped && !lagged && small_rounds && c->cfg.second_fft_enable && !c->clever_on && !c->prof && !(c->wl_on && c->wl_fft2) &&
                          c->cfg.stupid_bln_mode != 0 && 2L * batch * c->M1 <= c->cfg.blanker_min_points && nblocks == batch;
-  if (!side_tail) join_side_tail(c);
+  {   // a schedule that does not continue the previous call's side work first orders the main stream behind it (the one-round-late schedule
+      // orders itself against the narrowband stream by events; the side-stream tails of small rounds follow one another on their stream)
+    const bool keep_nb = lagged && c->nb_join_pending, keep_st = side_tail && c->st_pending;
+    if (keep_nb) c->nb_join_pending = false;
+    if (keep_st) c->st_pending = false;
+    join_side_tail(c);
+    c->nb_join_pending = keep_nb; c->st_pending = keep_st;
+  }
   if (!piped && !lagged) {
     while (nblocks > 0) {
       const int B = nblocks < batch ? nblocks : batch;
