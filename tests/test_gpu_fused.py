@@ -335,3 +335,46 @@ def test_a_gap_in_the_walk_over_timf1_does_not_reach_the_fused_kernels_partner(t
     e_strong = _rel(sp["timf2"] * (first & ~weak), a["timf2"] * (first & ~weak))
     print(table, e_rest, e_weak, e_strong)
     assert e_rest < 2e-6 and e_weak > 0.1, (e_rest, e_weak, e_strong)
+
+
+def test_one_block_calls_with_the_tail_on_the_side_stream_equal_the_serial_order():
+    """One fft1 block per lrh_wideband_dsp call -- Linrad's own call pattern: the blanker (rate-limited to every fourth call), fft2, mix1, fft3 and
+    mix2 of such calls are issued on the side stream, the sums of the one-workgroup k_timf2 launch go straight to the ring and its two streams run as
+    two workgroups.  Bit for bit what the serial order gives (LRH_SIDE_TAIL=0), with the selective limiter in the call, stage calls and
+    exports in between (they order the main stream behind the tail), and a few larger rounds mixed in."""
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.abi import default_sellim
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            cfg = chain_config(14, 16, batch=4, rounds=32, fft3_n=12, mix2_n=8)
+            rx = open_hip(cfg)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        s = synth_defaults(N1, 0)
+        rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4))
+        rx.set_liminfo(strong_liminfo(s, 14))
+        rx.set_mix1_selfreq(0.31 * 65536 + 0.3)
+        rx.wideband_limiter(default_sellim(cfg, fft1_blocktime=8192 / 160e6, blanker_ston_fft1=30.0, exact_stats=1), False)   # exact_stats: the weak-bin count is read back at once (otherwise it arrives when it arrives)
+        mid = None
+        for i in range(96):
+            rx.wideband_dsp(1, 1)
+            if i == 40:
+                mid = rx.export(abi.RING_TIMF3_FLOAT).copy()        # an entry point other than lrh_wideband_dsp: joins the side stream
+            if i == 60:
+                rx.wideband_dsp(8, 4)
+        out = {k: rx.export(r) for r, k in RINGS}
+        out["mid"] = mid
+        out["p"] = rx.p.as_dict()
+        out["bs"] = rx.blanker_state().timf2_noise_floor
+        rx.close()
+        return out
+    a, b = run({"LRH_SIDE_TAIL": "1"}), run({"LRH_SIDE_TAIL": "0"})
+    assert a["p"] == b["p"] and a["bs"] == b["bs"]
+    assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["mid"]) > 10
+    assert np.array_equal(a["mid"], b["mid"])
+    for _, k in RINGS:
+        assert np.array_equal(a[k], b[k]), k
