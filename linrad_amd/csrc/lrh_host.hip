@@ -753,6 +753,7 @@ int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   c->ch2_c1 = c1; c->ch2_c2 = c2;
+  c->f1_end_valid = false;                               // the table the fused kernel's partner would be recomputed with has changed
   return upload_filtercorr(c);
 }
 
