@@ -54,11 +54,12 @@ static int hip_xgather(int which, size_t count);
 lrh_ctx *hip_context(void) { return hip_rx; }
 lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL; }
 
-/* What version 21 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
-   rings that stay empty: two RF channels in one array (fft1.c:3874-4080; the library shards channels one context per GPU, which
-   Linrad's single process does not do), real-valued input (fft1_version rows 0 / 1 do not list version 21), the MMX / int16
-   back transform and second fft (their rings are short int), correlation spectra (fft1_corrsum), spur removal (acquisition
-   reads fft2_float on the host, spursub.c:619), and the network outputs that are memcpy'd from host rings (wcw.c:1038-1043). */
+/* What versions 21 / 22 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
+   rings that stay empty: the MMX / int16 back transform and second fft (their rings are short int), the correlation receiver
+   (fft1_correlation_flag >= 2), spur removal with the second fft off (fft1_c would subtract from fft1_float on the host), the int16
+   NET_RXOUT_TIMF2 payload, more than one mix1 channel, and two RF channels together with real input, spur removal or stage multicast.
+   Served: I/Q and real input, one or two RF channels (one context per channel, exchanges through host memory) with their correlation
+   spectrum, spur removal with the second fft on, NET_RXOUT_FFT1 / TIMF2 (float) / FFT2. */
 static int hip_unsupported(void)
 {
   if (ui.rx_rf_channels != 1 && ui.rx_rf_channels != 2) return 1;
