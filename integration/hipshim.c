@@ -38,6 +38,9 @@ static int HC = 1;
 #define HIP_IN(x) ((x) / HC)
 #define HIP_OUT(x) ((x) * HC)
 static float *hip_xa, *hip_xb; static size_t hip_xcap;      /* host scratch of the exchanges and of the channel interleaving */
+/* two REAL channels: Linrad's frames are {a_k, b_k}; the library takes one channel's real samples as adjacent pairs (one complex point per
+   pair, fft1_reherm_dit_*'s packing), so the producer hook de-interleaves into one arena per channel -- half of timf1, same ring positions / 2 */
+static char *hip_deint[2]; static int hip_real2;
 static float hip_ch2_c1 = 1, hip_ch2_c2 = 0;                /* pg_ch2_c1 / pg_ch2_c2 as last handed to channel 1's context (pol_graph.c:160-170) */
 static float *hip_scratch(size_t n) { if (n > hip_xcap) { free(hip_xa); free(hip_xb); hip_xa = malloc(n * sizeof(float)); hip_xb = malloc(n * sizeof(float)); hip_xcap = n; } return hip_xa; }
 static float *hip_liminfo_sent;           /* the routing table the device holds (sellim.c updates liminfo[] on the host) */
@@ -57,14 +60,14 @@ lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL
 /* What versions 21 / 22 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
    rings that stay empty: the MMX / int16 back transform and second fft (their rings are short int), the correlation receiver
    (fft1_correlation_flag >= 2), spur removal with the second fft off (fft1_c would subtract from fft1_float on the host), the int16
-   NET_RXOUT_TIMF2 payload, more than one mix1 channel, and two RF channels together with real input, spur removal or stage multicast.
+   NET_RXOUT_TIMF2 payload, more than one mix1 channel, and two RF channels together with spur removal or stage multicast.
    Served: I/Q and real input, one or two RF channels (one context per channel, exchanges through host memory) with their correlation
    spectrum, spur removal with the second fft on, NET_RXOUT_FFT1 / TIMF2 (float) / FFT2. */
 static int hip_unsupported(void)
 {
   if (ui.rx_rf_channels != 1 && ui.rx_rf_channels != 2) return 1;
-  if (ui.rx_rf_channels == 2 && ((ui.rx_input_mode & IQ_DATA) == 0 || genparm[MAX_NO_OF_SPURS] != 0 ||
-      (ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0)) return 8;   /* two channels: I/Q input, no spur removal, no stage multicast */
+  if (ui.rx_rf_channels == 2 && (genparm[MAX_NO_OF_SPURS] != 0 ||
+      (ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0)) return 8;   /* two channels (I/Q or real): no spur removal, no stage multicast */
   if ((ui.rx_input_mode & IQ_DATA) == 0 && fft_cntrl[FFT1_CURMODE].permute != 2) return 2;   /* real samples: version 22, whose permute field gives Linrad's
                                                                                                   filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
@@ -111,11 +114,13 @@ int hip_open(void)
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
   c.timf1_real_input = (ui.rx_input_mode & IQ_DATA) == 0;          /* fft1_reherm_dit_one's job (fft1_re.c:32-131): 2 fft1_size reals per transform */
   HC = ui.rx_rf_channels;
+  hip_real2 = HC == 2 && (ui.rx_input_mode & IQ_DATA) == 0;
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
   hip_ctx[0] = hip_ctx[1] = NULL;
   for (int ch = 0; ch < HC; ch++) {
     if (HC == 2) {                                                 /* one context per channel, coupled (include/linrad_hip.h) */
       c.blanker_channels = 2; c.timf1_frame_channels = 2; c.timf1_channel_index = ch;
+      if (hip_real2) { c.timf1_frame_channels = 1; c.timf1_bytes = timf1_bytes / 2; }   /* its own de-interleaved arena */
       c.timf3_size = timf3_size / 2; c.timf2_blockpower_block = timf2_blockpower_block / 2;
     }
     if ((rc = lrh_open(&c, &hip_ctx[ch])) != 0) { if (ch) lrh_close(hip_ctx[0]); hip_ctx[0] = hip_ctx[1] = NULL; hip_rx = NULL; return rc; }
@@ -135,6 +140,8 @@ int hip_open(void)
   if (hip_spurs_on && lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { lrh_close(hip_rx); hip_rx = NULL; return LRH_EINVAL; }
   if (HC == 2 && fft1_correlation_flag == 1)
     for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_close(); return LRH_EINVAL; }
+  if (hip_real2) for (int ch = 0; ch < 2; ch++) { hip_deint[ch] = malloc((size_t)timf1_bytes / 2); if (!hip_deint[ch]) { hip_close(); return LRH_ENOMEM; } lrh_host_register(hip_ctx[ch], hip_deint[ch], (size_t)timf1_bytes / 2); }
+  else
   for (int ch = 0; ch < HC; ch++) lrh_host_register(hip_ctx[ch], timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
   return 0;
 }
@@ -143,7 +150,9 @@ void hip_close(void)
 {
   if (!hip_rx) return;
   hip_clever_mode = 0;
-  for (int ch = 0; ch < HC; ch++) { lrh_timf1_write_wait(hip_ctx[ch]); lrh_host_unregister(hip_ctx[ch], timf1_char); lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL; }
+  for (int ch = 0; ch < HC; ch++) if (hip_ctx[ch]) { lrh_timf1_write_wait(hip_ctx[ch]); lrh_host_unregister(hip_ctx[ch], hip_real2 && hip_deint[ch] ? (void *)hip_deint[ch] : (void *)timf1_char); lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL; }
+  for (int ch = 0; ch < 2; ch++) { free(hip_deint[ch]); hip_deint[ch] = NULL; }
+  hip_real2 = 0;
   hip_rx = NULL; HC = 1;
   free(hip_xa); free(hip_xb); hip_xa = hip_xb = NULL; hip_xcap = 0;
   free(hip_liminfo_sent); hip_liminfo_sent = NULL;
@@ -152,6 +161,17 @@ void hip_close(void)
 
 void hip_timf1_new(int pa, int nbytes)
 {
+  if (hip_real2 && hip_rx) {                                /* {a_k, b_k} -> a_k | b_k, each into its context's arena at the same ring position / 2 */
+    const int es = (ui.rx_input_mode & DWORD_INPUT) != 0 ? 4 : 2, n = nbytes / (2 * es);
+    for (int ch = 0; ch < 2; ch++) {
+      char *d = hip_deint[ch] + pa / 2;
+      const char *sp = &timf1_char[pa] + ch * es;
+      if (es == 2) for (int i = 0; i < n; i++) ((short *)d)[i] = *(const short *)(sp + 4 * i);
+      else for (int i = 0; i < n; i++) ((int *)d)[i] = *(const int *)(sp + 8 * i);
+      if (lrh_timf1_write_async(hip_ctx[ch], d, pa / 2, nbytes / 2) != 0) lirerr(1465);
+    }
+    return;
+  }
   for (int ch = 0; ch < HC && hip_rx; ch++)               /* two channels: both contexts hold the interleaved frames and read their own channel */
     if (lrh_timf1_write_async(hip_ctx[ch], &timf1_char[pa], pa, nbytes) != 0) lirerr(1465);
 }
@@ -161,11 +181,12 @@ int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
   /* the dispatcher's workers carry gpu_handle_number 0..5 (wcw.c:500), the no-worker path passes 0 too (wcw.c:1036) */
   const int handle = no_of_fft1b > 0 ? gpu_handle_number + 1 : 0;
   int rc = 0;
-  if (HC == 2 && (pg_ch2_c1 != hip_ch2_c1 || pg_ch2_c2 != hip_ch2_c2)) {       /* phasing of channel 2, fft1.c:4064-4080 (pol_graph.c:160-170 sets it) */
+  /* (two real channels: fft1_reherm_dit_two leaves through `goto fft_done` before the phasing step, fft1_re.c:133-231) */
+  if (HC == 2 && !hip_real2 && (pg_ch2_c1 != hip_ch2_c1 || pg_ch2_c2 != hip_ch2_c2)) {       /* phasing of channel 2, fft1.c:4064-4080 (pol_graph.c:160-170 sets it) */
     hip_ch2_c1 = pg_ch2_c1; hip_ch2_c2 = pg_ch2_c2;
     lrh_set_ch2_phasing(hip_ctx[1], hip_ch2_c1, hip_ch2_c2);
   }
-  for (int ch = 0; ch < HC && !rc; ch++) rc = lrh_fft1_b(hip_ctx[ch], handle, timf1p_ref, HIP_IN((int)(out - fft1_float)), gpu_fft1_batch_size);
+  for (int ch = 0; ch < HC && !rc; ch++) rc = lrh_fft1_b(hip_ctx[ch], handle, hip_real2 ? timf1p_ref / 2 : timf1p_ref, HIP_IN((int)(out - fft1_float)), gpu_fft1_batch_size);
   return rc;
 }
 

@@ -71,6 +71,7 @@ def edit_fft1var(L):
            ',{1,2,14,0,0,GPU_HIP,0,1,0,   "HIP MI355X real"}                   //22\n')
     replace(L, r"1 chan direct conversion \(IQ\)", "19, -1}", "19, 21}")
     replace(L, r"1 chan normal audio", "4, -1,", "4, 22,")
+    replace(L, r"2 chan normal audio", "4, -1,", "4, 22,")                    # two real channels per frame (fft1_reherm_dit_two, fft1_re.c:133-231)
     replace(L, r"2 chan direct conversion \(IQ\)", "20, -1}", "20, 21}")     # two RF channels: one context per channel behind the same hooks
 
 
@@ -102,7 +103,7 @@ def edit_fft1(L):
            "    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
            where="before", start=i)
     # the switch of the two-channel branch (fft1.c:3686-3900): the same case -- hip_fft1_b runs one context per channel
-    insert(L, r"^\s+default:\s*$", "    case 21:\n    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
+    insert(L, r"^\s+default:\s*$", "    case 21:\n    case 22:\n    multiplicity=gpu_fft1_batch_size;\n    if(hip_fft1_b(timf1p_ref, out, gpu_handle_number) != 0)lirerr(1464);\n    goto fft_done;\n\n",
            where="before", start=i, nth=2)
     func_top(L, r"^void fft1_c\(void\)", "if(fft1_use_gpu == GPU_HIP){hip_fft1_c();return;}\n")
 

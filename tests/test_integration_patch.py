@@ -30,6 +30,6 @@ def test_committed_patch_is_what_the_generator_writes(tmp_path):
     (work / "make_patch.py").write_text(src)
     subprocess.check_call([sys.executable, str(work / "make_patch.py"), REF], env=env)
     assert (work / "linrad_hip.patch").read_text(encoding="latin-1") == committed
-    # zero-context diff: apart from the four one-line replacements (version count, three fft1_version rows) nothing of the reference's text is stored
+    # zero-context diff: apart from the five one-line replacements (version count, four fft1_version rows) nothing of the reference's text is stored
     removed = [l for l in committed.splitlines() if l.startswith("-") and not l.startswith("---")]
-    assert len(removed) == 4
+    assert len(removed) == 5

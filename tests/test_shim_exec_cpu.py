@@ -69,7 +69,8 @@ def test_spur_removal_is_served_through_the_acquisition_hooks(harness, tmp_path,
     print(name, shimlib.check_spur_case(harness, tmp_path, name))
 
 
-@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3"])
+@pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"])
 def test_two_rf_channels_are_served_as_two_contexts(harness, tmp_path, name):
     print(name, shimlib.check_twochan_case(harness, tmp_path, name))
-    print(name, shimlib.check_twochan_chain(harness, tmp_path, name))
+    if "real" not in name:                                    # (the chain golden exists for the I/Q cases)
+        print(name, shimlib.check_twochan_chain(harness, tmp_path, name))
