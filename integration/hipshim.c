@@ -37,7 +37,9 @@ static lrh_ctx *hip_rx, *hip_ctx[2];
 static int HC = 1;
 #define HIP_IN(x) ((x) / HC)
 #define HIP_OUT(x) ((x) * HC)
-static float *hip_xa, *hip_xb; static size_t hip_xcap;      /* host scratch of the exchanges and of the channel interleaving */
+/* host scratch of the exchanges and of the channel interleaving: per thread -- Linrad calls the hooks from its stage threads and, for the
+   network outputs, from the network thread (the buffers of threads that have ended are not reclaimed: a few hundred KB each) */
+static __thread float *hip_xa, *hip_xb; static __thread size_t hip_xcap;
 /* two REAL channels: Linrad's frames are {a_k, b_k}; the library takes one channel's real samples as adjacent pairs (one complex point per
    pair, fft1_reherm_dit_*'s packing), so the producer hook de-interleaves into one arena per channel -- half of timf1, same ring positions / 2 */
 static char *hip_deint[2]; static int hip_real2;
@@ -60,14 +62,13 @@ lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL
 /* What versions 21 / 22 cannot serve is refused here, so that wideband_dsp ends with lirerr(1463) instead of running host code on
    rings that stay empty: the MMX / int16 back transform and second fft (their rings are short int), the correlation receiver
    (fft1_correlation_flag >= 2), spur removal with the second fft off (fft1_c would subtract from fft1_float on the host), the int16
-   NET_RXOUT_TIMF2 payload, more than one mix1 channel, and two RF channels together with spur removal or stage multicast.
+   NET_RXOUT_TIMF2 payload, more than one mix1 channel, and two RF channels together with spur removal.
    Served: I/Q and real input, one or two RF channels (one context per channel, exchanges through host memory) with their correlation
    spectrum, spur removal with the second fft on, NET_RXOUT_FFT1 / TIMF2 (float) / FFT2. */
 static int hip_unsupported(void)
 {
   if (ui.rx_rf_channels != 1 && ui.rx_rf_channels != 2) return 1;
-  if (ui.rx_rf_channels == 2 && (genparm[MAX_NO_OF_SPURS] != 0 ||
-      (ui.network_flag & (NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2)) != 0)) return 8;   /* two channels (I/Q or real): no spur removal, no stage multicast */
+  if (ui.rx_rf_channels == 2 && genparm[MAX_NO_OF_SPURS] != 0) return 8;   /* two channels (I/Q or real): no spur removal */
   if ((ui.rx_input_mode & IQ_DATA) == 0 && fft_cntrl[FFT1_CURMODE].permute != 2) return 2;   /* real samples: version 22, whose permute field gives Linrad's
                                                                                                   filter table the real version's scaling (fft1.c:4659) */
   if (genparm[SECOND_FFT_ENABLE] != 0 && (fft_cntrl[FFT1_BCKCURMODE].mmx != 0 || fft_cntrl[FFT2_CURMODE].mmx != 0)) return 3;
@@ -705,21 +706,57 @@ static void hip_ring_span(lrh_ring ring, float *host, int pt, int count, int siz
     pt = (pt + k) & (size - 1); count -= k;
   }
 }
+/* The same for two channels: a frame of the host ring holds P complex values of channel 0 and of channel 1, value by value ({ch0, ch1} per
+   bin of fft1_float / fft2_float: P = 1; {weak ch0, weak ch1, strong ch0, strong ch1} per sample of timf2_float: P = 2), a context's ring the P
+   values of its own channel.  pt, count, size in floats of the HOST ring. */
+static void hip_ring_span2(lrh_ring ring, float *host, int pt, int count, int size, int P)
+{
+  const int hf = 4 * P, cf = 2 * P;
+  int f = pt / hf, nfr = (pt % hf + count + hf - 1) / hf;
+  const int ring_frames = size / hf;
+  while (nfr > 0) {
+    int k = nfr;
+    if (f + k > ring_frames) k = ring_frames - f;
+    float *t = hip_scratch((size_t)k * cf);
+    for (int ch = 0; ch < 2; ch++) {
+      if (lrh_export(hip_ctx[ch], ring, t, (size_t)f * cf, (size_t)k * cf) != 0) { lirerr(1478); return; }
+      for (int i = 0; i < k; i++)
+        for (int p = 0; p < P; p++) {
+          float *h = &host[(size_t)(f + i) * hf + 2 * (2 * p + ch)];
+          h[0] = t[(size_t)i * cf + 2 * p]; h[1] = t[(size_t)i * cf + 2 * p + 1];
+        }
+    }
+    f = (f + k) % ring_frames; nfr -= k;
+  }
+}
 /* NET_RXOUT_FFT1: the batch of transforms as fft1_b leaves them -- before fft1_c's filter correction (network.c:383-388) -- for the blocks
    that start at timf1p_ref, into fft1_float at fft1_pa where the memcpy expects them */
 void hip_net_fft1(int timf1p_ref, int pa)
 {
+  const int nb = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
   if (!hip_rx) return;
-  if (lrh_export_fft1_net(hip_rx, &fft1_float[pa], timf1p_ref, gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1) != 0) lirerr(1479);
+  if (HC == 2) {                                            /* {ch0, ch1} per bin (fft1.c:2041) */
+    float *t = hip_scratch((size_t)nb * 2 * hip_n1);
+    for (int ch = 0; ch < 2; ch++) {
+      if (lrh_export_fft1_net(hip_ctx[ch], t, hip_real2 ? timf1p_ref / 2 : timf1p_ref, nb) != 0) { lirerr(1479); return; }
+      for (size_t i = 0; i < (size_t)nb * hip_n1; i++) { fft1_float[pa + 4 * i + 2 * ch] = t[2 * i]; fft1_float[pa + 4 * i + 2 * ch + 1] = t[2 * i + 1]; }
+    }
+    return;
+  }
+  if (lrh_export_fft1_net(hip_rx, &fft1_float[pa], timf1p_ref, nb) != 0) lirerr(1479);
 }
 /* NET_RXOUT_TIMF2, float format: `mm` floats of {weak, strong} samples from timf2_pt on (rxin.c:944-966 consumes 2*twice_rxchan floats per
    twice_rxchan floats it sends, mm*2 bytes in all) */
 void hip_net_timf2(int pt, int mm)
 {
+  if (hip_rx && mm > 0 && HC == 2) hip_ring_span2(LRH_RING_TIMF2_FLOAT, timf2_float, pt, mm, timf2_size, 2);
+  else
   if (hip_rx && mm > 0) hip_ring_span(LRH_RING_TIMF2_FLOAT, timf2_float, pt & ~3, (mm + 3) & ~3, timf2_size);
 }
 /* NET_RXOUT_FFT2: `count` floats of fft2_float from fft2_pt on (rxin.c:1026-1035) */
 void hip_net_fft2(int pt, int count)
 {
+  if (hip_rx && count > 0 && HC == 2) hip_ring_span2(LRH_RING_FFT2_FLOAT, fft2_float, pt, count, max_fft2n * 4 * hip_n2, 1);
+  else
   if (hip_rx && count > 0) hip_ring_span(LRH_RING_FFT2_FLOAT, fft2_float, pt, count, max_fft2n * 2 * hip_n2);
 }

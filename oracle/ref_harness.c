@@ -915,6 +915,11 @@ run_done:
       lrh_export(hip_context_of(ch), LRH_RING_FFT2_FLOAT, t, 0, nf2);
       for (size_t i = 0; i < nf2 / 2; i++) { fft2_float[4 * i + 2 * ch] = t[2 * i]; fft2_float[4 * i + 2 * ch + 1] = t[2 * i + 1]; }
     }
+    if (second && shim_net) {                        /* ... and over them what the network thread's walks fetch through the patched senders' hooks: must be the same */
+      memset(timf2_float, 0, sizeof(float) * timf2_size); memset(fft2_float, 0, sizeof(float) * 2 * nf2);
+      for (int pt = 0; pt < timf2_size; pt += 696) hip_net_timf2(pt, pt + 696 <= timf2_size ? 696 : timf2_size - pt);
+      for (int pt = 0; pt < (int)(2 * nf2); pt += 348) hip_net_fft2(pt, pt + 348 <= (int)(2 * nf2) ? 348 : (int)(2 * nf2) - pt);
+    }
     if (second && chain2) {
       lrh_export(hip_context(), LRH_RING_FFT2_XYPOWER, fft2_xypower, 0, (size_t)4 * N2 * max_fft2n);
       lrh_export(hip_context(), LRH_RING_FFT2_XYSUM, fft2_xysum, 0, (size_t)4 * N2);

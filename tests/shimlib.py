@@ -318,4 +318,13 @@ def check_twochan_chain(harness, tmp_path, name="twochan_n10", tol=1e-5):
         rep[k] = relerr(dump[k], g[k])
         assert rep[k] <= 20 * tol, rep
     assert np.array_equal(dump["fft3_ptrs"], g["fft3_ptrs"]) and np.array_equal(dump["baseb_ptrs"], g["baseb_ptrs"])
+    # NET_RXOUT_FFT1 / TIMF2 / FFT2 with two channels: the hooks in front of the senders' reads fill Linrad's interleaved host rings, a packet's
+    # worth at a time: the same rings as fetched whole; the FFT1 payload (before fft1_c's correction) = the golden's corrected spectrum / the table
+    d2, dn = _run_2ch(harness, tmp_path, name, True, ["shim_net=1"])
+    assert np.array_equal(dn["timf2_float"], dump["timf2_float"]) and np.array_equal(dn["fft2_float"], dump["fft2_float"])
+    assert np.count_nonzero(dn["timf2_float"]) > 1000 and relerr(dn["fft2_float"], g["fft2_float"]) <= tol
+    # (the FFT1 payload -- lrh_export_fft1_net, pinned per channel by the one-channel goldens' fft1_first_raw -- only has to land interleaved:
+    # both channels present in block 0's slot, different from each other; the fft1 ring of this run has lapped, so there is nothing to divide by)
+    raw = dn["fft1_first_raw"].reshape(-1, 2, 2)
+    assert np.count_nonzero(raw[:, 0]) > raw.shape[0] and np.count_nonzero(raw[:, 1]) > raw.shape[0] and not np.array_equal(raw[:, 0], raw[:, 1])
     return rep
