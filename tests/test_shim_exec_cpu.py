@@ -74,3 +74,5 @@ def test_two_rf_channels_are_served_as_two_contexts(harness, tmp_path, name):
     print(name, shimlib.check_twochan_case(harness, tmp_path, name))
     if "real" not in name:                                    # (the chain golden exists for the I/Q cases)
         print(name, shimlib.check_twochan_chain(harness, tmp_path, name))
+        # ... and from Linrad's stage threads (wideband, timf2, second fft, narrowband) in lock step: each hook copies its own pointers only
+        print(name, shimlib.check_twochan_chain(harness, tmp_path, name, extra=["shim_threads=1"]))
