@@ -48,6 +48,14 @@ gcc -O1 -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" -in
     -o "$HERE/_ref/shim_harness" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
     -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
 echo "built $HERE/_ref/shim_harness"
+# SAN=1: the same binary with AddressSanitizer + UBSan on the glue and the driver (CPU only: GPU sanitizers are not available on this pool)
+if [ -n "$SAN" ]; then
+  gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" -c "$T/hipshim.c" -o "$OUT/hipshim_asan.o"
+  gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim_asan.o" \
+      -o "$HERE/_ref/shim_harness_asan" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
+      -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
+  echo "built $HERE/_ref/shim_harness_asan"
+fi
 # (2) the glue as shipped, over liblinrad_hip.so (no alias header: lrh_* are the library's own entry points)
 gcc -O2 -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$ROOT/include" -c "$T/hipshim.c" -o "$OUT/hipshim_hip.o"
 gcc -O1 -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim_hip.o" \

@@ -555,7 +555,10 @@ int main(int argc, char **argv)
     spur_freq_factor = (float)fft2_new_points / fft2_size;             /* buf.c:480 */
     spur_speknum = spur_spek > 0 ? spur_spek : max_fftxn / 4;
     if (spur_speknum < 4) spur_speknum = 4;
-    sp_sig = zalloc(8 * (max_fftxn + 8)); sp_der = zalloc(8 * (max_fftxn + 8)); sp_pha = zalloc(8 * (max_fftxn + 8)); sp_tmp = zalloc(8 * (max_fftxn + 8));
+    /* the reference carves these out of its big fft scratch, fftx_size / 4 floats each (buf.c:1285-1293); spur_phase_lock / verify_spur_pll index them
+       beyond 2 * max_fftxn floats (AddressSanitizer: 48 bytes past arrays of max_fftxn + 8 complex values, into the neighbouring heap block) */
+    { const size_t nsp = sizeof(float) * (size_t)(fftx_size / 4 > 2 * (max_fftxn + 8) ? fftx_size / 4 : 2 * (max_fftxn + 8));
+      sp_sig = zalloc(nsp); sp_der = zalloc(nsp); sp_pha = zalloc(nsp); sp_tmp = zalloc(nsp); }
     spursearch_sum_counter = 0;
     sp_numsub = spur_speknum - 1; sp_avgnum = spur_speknum / 3; if (sp_avgnum > 10) sp_avgnum = 10;
     spur_max_d2 = PI_L * spur_freq_factor / spur_speknum;

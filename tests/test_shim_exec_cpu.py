@@ -22,9 +22,13 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree n
 
 @pytest.fixture(scope="module")
 def harness():
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "shim"], capture_output=True, text=True, timeout=900)
+    # LRH_SHIM_SANITIZE=1: the same cases through the AddressSanitizer / UBSan build of the glue and the driver (SAN=1 oracle/build_shim_harness.sh;
+    # run with ASAN_OPTIONS=detect_leaks=0 -- the reference objects are not instrumented and the harness does not free Linrad's arenas)
+    san = os.environ.get("LRH_SHIM_SANITIZE") == "1"
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "shim"] + (["SAN=1"] if san else []), capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **({"SAN": "1"} if san else {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    return HARNESS
+    return HARNESS + "_asan" if san else HARNESS
 
 
 @pytest.mark.parametrize("name", shimlib.GOLDEN_CASES)
