@@ -55,6 +55,12 @@ if [ -n "$SAN" ]; then
       -o "$HERE/_ref/shim_harness_asan" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
       -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
   echo "built $HERE/_ref/shim_harness_asan"
+  # ... and with ThreadSanitizer (glue + driver; the reference objects are not instrumented): the stage-thread modes of the harness
+  gcc -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" -c "$T/hipshim.c" -o "$OUT/hipshim_tsan.o"
+  gcc -O1 -g -fsanitize=thread -fno-omit-frame-pointer -w -no-pie $DEFS -DSHIM_HARNESS=1 -I"$T" -I"$HERE" -I"$ROOT/include" -include "$HERE/shim_alias.h" "$HERE/ref_harness.c" $OBJ "$OUT/hipshim_tsan.o" \
+      -o "$HERE/_ref/shim_harness_tsan" -L"$HERE" -llinrad_oracle -L"$ROOT/linrad_amd" -llinrad_hip \
+      -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../../linrad_amd' -lm -lpthread -Wl,--unresolved-symbols=ignore-all
+  echo "built $HERE/_ref/shim_harness_tsan"
 fi
 # (2) the glue as shipped, over liblinrad_hip.so (no alias header: lrh_* are the library's own entry points)
 gcc -O2 -Wall -Wno-unused-parameter $DEFS -I"$T" -I"$ROOT/include" -c "$T/hipshim.c" -o "$OUT/hipshim_hip.o"
