@@ -159,6 +159,59 @@ def cpu_reference(args, w, threads=0):
             "sample": f"{nblk} fft1 blocks ({nblk * M1} samples) of the same workload through the compiled reference ({stages}), {how}, {dt:.1f} s"}
 
 
+def glue_rate(args, w, batches=(1, 2, 4, 8, 16), workers=3):
+    """THE DROP-IN'S RATE: oracle/_ref/shim_harness_hip = the reference objects as integration/linrad_hip.patch leaves them + integration/hipshim.c
+    as shipped + liblinrad_hip.so, driven in Linrad's thread topology (dispatcher + fft1_b workers, THREAD_TIMF2, THREAD_SECOND_FFT, the
+    narrowband thread; wcw.c:401-441, 250-304, 476-500) with the samples entering through the finish_rx_read hook (rxin.c:1423) one dispatch
+    at a time and every host-visible product read back by the glue (fft1_sumsq / fft1_slowsum per averaging period, waterfall lines and
+    fft2_powersum_float per line, blanker scalars, every timf3 block; fft3 / mix2 then run as the reference's own host code).  One run per
+    gpu.fft1_batch_n = log2(batch) (buf.c:248-257).  PCIe-inclusive by construction; never the headline `value`.
+    None when the binary is not there (built in the build container, travels with the snapshot)."""
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_harness_hip")
+    if not os.access(exe, os.X_OK):
+        return None
+    from linrad_amd import lib as hiplib
+    N1 = 1 << w["fft1_n"]
+    M1 = N1 // 2
+    ring_log2 = 24 if w["fft1_n"] >= 13 else 22
+    nring = (1 << ring_log2) // 4
+    s = hiplib.synth_defaults(N1, 0)
+    iq = hiplib.synth_iq(s, 0, nring)
+    lim = strong_liminfo(s, w["fft1_n"])
+    runs = []
+    with tempfile.TemporaryDirectory() as td:
+        fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+        np.asarray(iq, np.int16).tofile(fi)
+        lim.tofile(fl)
+        for b in batches:
+            nblk = args.glue_blocks * (1 if b < 4 else 2 if b < 16 else 4)
+            cmd = [c for c in ref_harness_cmd(w, nblk, fi, fl, fo) if not c.startswith(("max_fft1n", "max_fft2n"))]
+            cmd[0] = exe
+            # rings as a patched Linrad sizes them for version 21 (integration/linrad_hip.patch, buf.c): fft1 ring of 256 transforms, timf2 of at
+            # least 64 fft1 blocks -- the stages behind fft1_b take what has accumulated in one library call, up to 64 blocks
+            t2log = int(np.log2(max(8 << max(w["fft2_n"], w["fft1_n"]), 256 * M1)))
+            cmd += ["max_fft1n=256", "max_fft2n=64", f"timf2pow_log2={t2log}", f"timf1_log2={ring_log2}", "shim_threads=2", f"shim_workers={workers}", f"shim_batch={b}", "warm=512"]
+            try:
+                out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, check=True).stdout
+                r = json.loads(out.strip().splitlines()[-1])
+            except subprocess.CalledProcessError as e:
+                runs.append({"fft1_batch_n": int(np.log2(b)), "error": (e.stderr or "")[-300:]})
+                continue
+            except Exception as e:  # noqa: BLE001
+                runs.append({"fft1_batch_n": int(np.log2(b)), "error": repr(e)})
+                continue
+            v = r["samples"] / r["loop_seconds"] / 1e6
+            runs.append({"fft1_batch_n": int(np.log2(b)), "blocks_per_fft1_b_call": b, "value": round(v, 1), "unit": "Msamples/s",
+                         "us_per_block": round(1e6 * r["loop_seconds"] / r["blocks"], 2), "blocks": r["blocks"], "seconds": round(r["loop_seconds"], 3),
+                         "realtime_factor": {k: round(v * 1e6 / rate, 2) for k, rate in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
+                         "stage_calls": r.get("stage_calls"), "threads": r.get("threads")})
+    return {"what": "patched reference objects + integration/hipshim.c + liblinrad_hip.so (oracle/_ref/shim_harness_hip timing=1 shim_threads=2): "
+                    "samples through the finish_rx_read hook, Linrad's stage threads, all read-backs of a running xlinrad64",
+            "config": w["text"].split(":")[0], "fft1_size": N1, "fft2_size": 1 << w["fft2_n"], "fft3_size": (1 << w["fft3_n"]) if w["fft3_n"] else 0,
+            "fft1_b_workers": workers, "runs": runs}
+
+
 def cpu_worker(w, nblk, channel):
     """One single-thread oracle pipeline (child process of cpu_baseline_all_cores); prints its loop time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -640,6 +693,9 @@ def main():
     ap.add_argument("--coupled-stages", action="store_true", help="--coupled through the stage calls of linrad_amd.multichan.run_coupled instead of one lrh_wideband_dsp call per step")
     ap.add_argument("--real-input", action="store_true",
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
+    ap.add_argument("--glue-blocks", type=int, default=8192, help="fft1 blocks per run of the drop-in measurement (`glue` object; x2 / x4 at the larger fft1_b batches)")
+    ap.add_argument("--no-glue", action="store_true", help="skip the `glue` object (patched reference + hipshim.c + liblinrad_hip.so)")
+    ap.add_argument("--glue-only", action="store_true", help="only the `glue` object, as one JSON line")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -648,6 +704,10 @@ def main():
         args.fft2_n = 16
     if args.cpu_worker is not None:                        # child of cpu_baseline_all_cores: no GPU, no torch
         cpu_worker(make_workload("c2" if args.fft3_n else "c1", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n), args.cpu_blocks, args.cpu_worker)
+        return 0
+    if args.glue_only:                                     # the harness processes own the GPU; nothing here touches it
+        print(json.dumps({"glue": [glue_rate(args, make_workload("c2", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n)),
+                                   glue_rate(args, make_workload("c1", args.fft1_n, 12, 0, 0))]}), flush=True)
         return 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # started by hand: become the launcher, never touch the GPU here
         return spawn_ranks(args)

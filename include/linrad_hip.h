@@ -26,11 +26,12 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 4      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
+#define LRH_ABI_VERSION 5      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
                                   3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
                                      lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions); lrh_exchange_fn takes the caller's own span;
                                      lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart)
-                                  4: lrh_spur_permute (addition) */
+                                  4: lrh_spur_permute (addition)
+                                  5: lrh_stage_wait, lrh_export_begin / _end (additions); lrh_export waits without holding the context's lock */
 
 enum {
   LRH_OK = 0,
@@ -592,7 +593,16 @@ typedef int (*lrh_exchange_fn)(void *user, int which, int op, void *device_ptr, 
 int lrh_set_exchange(lrh_ctx *ctx, lrh_exchange_fn fn, void *user);
 
 /* ---- host-visible side outputs ---- */
-int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems); /* synchronous */
+/* lrh_export: synchronous for the caller (dst is filled on return), ordered behind everything the calls so far have enqueued.  Spans of up to
+   512 KiB travel on a copy stream of the context's own into a page-locked slot and the caller waits for them WITHOUT holding the context's
+   lock: the other stage threads go on enqueueing meanwhile, and the wait covers the work queued up to this call, not what they add. */
+int lrh_export(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems);
+/* The same in two halves, for products nobody needs before the next call of the stage that made them (the averaged spectra the graphs draw):
+   lrh_export_begin enqueues the copy behind everything the calls so far have enqueued and returns a ticket at once; lrh_export_end(ticket) waits
+   for that copy (without the context's lock) and fills the `dst` given to begin, which must stay valid until then.  Ticket 0: the span was
+   fetched by begin itself (no slot free, or more than 512 KiB) and lrh_export_end has nothing to do.  At most 16 tickets at a time. */
+int lrh_export_begin(lrh_ctx *ctx, lrh_ring ring, void *dst, size_t offset_elems, size_t count_elems, int *ticket);
+int lrh_export_end(lrh_ctx *ctx, int ticket);
 int lrh_get_blanker_state(lrh_ctx *ctx, lrh_blanker_state *st);                                   /* synchronous */
 /* Payload of the NET_RXOUT_TIMF2 multicast (what MAP65 and slave Linrads receive; rxin.c:944-966, float form): for `count`
    samples from timf2 position timf2_pt (in floats like the reference's pointer, a multiple of 4; wraps) one complex float
@@ -617,6 +627,17 @@ void *lrh_stream(lrh_ctx *ctx);
    batched lrh_wideband_dsp the launches of its last round may still be held back (see there); lrh_flush issues them without waiting. */
 int lrh_flush(lrh_ctx *ctx);
 int lrh_sync(lrh_ctx *ctx);
+/* Back-pressure for a caller that drives the stages from its own threads, one per stage, as Linrad does (THREAD_TIMF2: fft1_c / make_timf2 /
+   the blanker, wcw.c:401-441; THREAD_SECOND_FFT: make_fft2, wcw.c:250-304; the narrowband thread: fft2_mix1_*, wcw.c:1240-1405).  The stage
+   calls only ENQUEUE device work, so a host that is faster than the device would run ahead of it by whatever the rings hold -- seconds in
+   Linrad's sizing -- and every hand-over would be a call of a single block.  lrh_stage_wait(ctx, stage) returns once the device has finished the
+   work the LAST call of that stage enqueued (at once if there was none).  It holds no lock while it waits: other threads keep enqueueing.
+   Called at the top of a stage's stand-in before it counts what has accumulated (integration/hipshim.c), the stage then takes everything that
+   arrived meanwhile in one call, and the call size follows the load: one block per call while the device keeps up, larger batches -- whose
+   device time hardly grows -- when it does not.
+   LRH_STAGE_TIMF2: behind lrh_make_timf2's kernels; LRH_STAGE_FFT2: behind lrh_make_fft2's; LRH_STAGE_MIX1: behind lrh_fft2_mix1_* / lrh_fft1_mix1_*. */
+enum { LRH_STAGE_TIMF2 = 0, LRH_STAGE_FFT2 = 1, LRH_STAGE_MIX1 = 2, LRH_STAGE_COUNT = 3 };
+int lrh_stage_wait(lrh_ctx *ctx, int stage);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int lrh_timer_start(lrh_ctx *ctx);

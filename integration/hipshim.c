@@ -56,6 +56,8 @@ static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins st
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 static int hip_xgather(int which, size_t count);
+static void hip_ss_collect(void);
+static void hip_wf_collect(void);
 lrh_ctx *hip_context(void) { return hip_rx; }
 lrh_ctx *hip_context_of(int ch) { return ch >= 0 && ch < HC ? hip_ctx[ch] : NULL; }
 
@@ -109,7 +111,16 @@ int hip_open(void)
   c.wf_lines = wg_waterf_size / wg_xpixels;
   c.mix1_bandwidth_reduction_n = genparm[MIX1_BANDWIDTH_REDUCTION_N]; c.timf3_size = timf3_size;
   c.fftx_points_per_hz = fftx_points_per_hz; c.mix1_lowest_fq = mix1_lowest_fq; c.mix1_highest_fq = mix1_highest_fq;
-  c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1; hip_max_batch = c.max_batch;
+  /* transforms per library call: fft1_b hands over gpu_fft1_batch_size at a time (buf.c:248-257); the stages behind it take whatever has
+     accumulated when their thread comes round (hip_fft1_c), up to what the rings allow -- the library wants max_fft1n >= 2 max_batch and a
+     batch of new points beside one transform in the timf2 ring */
+  c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
+  { int cap = 64;
+    if (cap > max_fft1n / 2) cap = max_fft1n / 2;
+    if (genparm[SECOND_FFT_ENABLE] != 0) while (cap > 1 && (long long)cap * fft1_new_points + fft1_size > (long long)timf2pow_size) cap >>= 1;
+    if (ui.rx_rf_channels == 2) cap = c.max_batch;          /* two channels: the exchange buffers are sized by the batch; one hand-over at a time */
+    if (cap > c.max_batch) c.max_batch = cap; }
+  hip_max_batch = c.max_batch;
   c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
   c.timf2_blockpower_block = timf2_blockpower_block; c.timf2_blockpower_size = timf2_blockpower_size;     /* compute_timf2_powersum, wcw.c:80 */
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
@@ -150,6 +161,7 @@ int hip_open(void)
 void hip_close(void)
 {
   if (!hip_rx) return;
+  hip_ss_collect(); hip_wf_collect();
   hip_clever_mode = 0;
   for (int ch = 0; ch < HC; ch++) if (hip_ctx[ch]) { lrh_timf1_write_wait(hip_ctx[ch]); lrh_host_unregister(hip_ctx[ch], hip_real2 && hip_deint[ch] ? (void *)hip_deint[ch] : (void *)timf1_char); lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL; }
   for (int ch = 0; ch < 2; ch++) { free(hip_deint[ch]); hip_deint[ch] = NULL; }
@@ -219,15 +231,32 @@ static void hip_afc_rows(int first_row, int rows)
   }
 }
 
+/* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
+static int hip_ss_ticket[8], hip_ss_n;
+static void hip_ss_collect(void)
+{
+  for (int i = 0; i < hip_ss_n; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[i]) != 0) lirerr(1466);
+  hip_ss_n = 0;
+}
+static void hip_ss_fetch(lrh_ring ring, float *dst, size_t off, size_t cnt)
+{
+  int t = 0;
+  if (hip_ss_n >= 8) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
+  if (lrh_export_begin(hip_rx, ring, dst, off, cnt, &t) != 0) { lirerr(1466); return; }
+  if (t) hip_ss_ticket[hip_ss_n++] = t;
+}
+
 void hip_fft1_c(void)
 {
   lrh_ptrs q;
   int old_pa, n, room;
   memset(&q, 0, sizeof q);
   /* hip_sync_in: what fft1_c reads (fft1.c:4507-4523) */
-  q.fft1_nb = fft1_nb; q.fft1_pb = HIP_IN(fft1_pb); q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
-  q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   old_pa = fft1_sumsq_pa;
+  /* back-pressure: not further ahead of the device than one call of this stage (lrh_stage_wait, include/linrad_hip.h) -- what arrives
+     meanwhile goes into this call */
+  for (int ch = 0; ch < HC; ch++) lrh_stage_wait(hip_ctx[ch], LRH_STAGE_TIMF2);
+  hip_ss_collect();                                          /* the previous call's spectra: on the host by now */
   /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
      make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
      whatever its size (INTEGRATION.md "Call size"), and the limiter looks at fft1_liminfo_cnt only after that loop (wcw.c:1124). */
@@ -236,7 +265,12 @@ void hip_fft1_c(void)
   room = genparm[SECOND_FFT_ENABLE] != 0 ? ((timf2_px - timf2_pa + timf2_mask + 1) & timf2_mask) / timf2_input_block - 1 : n;
   if (n > room) n = room;
   if (n > hip_max_batch) n = hip_max_batch;
+  { /* ... and the periods it completes, beside the wg_fft_avg2num the slow average reads, must fit the fft1_sumsq ring (lrh_fft1_c) */
+    const int lim = wg.fft_avg1num * (fft1_sumsq_bufsize / fft1_size - wg_fft_avg2num - 1) - fft1_sumsq_counter;
+    if (n > lim) n = lim; }
   if (n < 1) n = 1;
+  q.fft1_nb = fft1_nb; q.fft1_pb = HIP_IN(fft1_pb); q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
+  q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   { lrh_ptrs q0 = q;
     for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } }
     if (HC == 2 && fft1_correlation_flag == 1) {       /* X conj(Y) needs both channels' bins: the all-gather of the batch's transforms, through host memory */
@@ -255,9 +289,25 @@ void hip_fft1_c(void)
   if (genparm[SECOND_FFT_ENABLE] == 0) hip_afc_rows((q.fft1_nb - n) & fft1n_mask, n);
   if (q.fft1_sumsq_pa != old_pa) {            /* averaging periods completed: the wide graph and sellim.c read these on the host */
     int pa;
+    if (HC == 1) {
+      /* The completed periods lie one behind the other: as few read-backs as the ring's end and the slot size allow.  They are for the wide
+         graph (the limiter works on the device-resident sums), so this thread does not wait for them: they are collected by its next call
+         (hip_ss_collect) -- a wait here would drain the device once per call with the weak / strong split not even queued yet */
+      const int slot = (1 << 17) / hip_n1 > 0 ? (1 << 17) / hip_n1 * hip_n1 : hip_n1;     /* floats per read-back (512 KiB slots, include/linrad_hip.h) */
+      pa = old_pa;
+      while (pa != q.fft1_sumsq_pa) {
+        int k = ((q.fft1_sumsq_pa - pa) & fft1_sumsq_mask);
+        if (pa + k > fft1_sumsq_bufsize) k = fft1_sumsq_bufsize - pa;
+        if (k > slot) k = slot;
+        hip_ss_fetch(LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)k);
+        pa = (pa + k) & fft1_sumsq_mask;
+      }
+      hip_ss_fetch(LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1);
+      return;
+    } else
     for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask) {
       lrh_export(hip_rx, LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)hip_n1);
-      if (HC == 2) {                                       /* |X0|^2 + |X1|^2 (fft1.c:4132-4145) */
+      {                                                    /* |X0|^2 + |X1|^2 (fft1.c:4132-4145) */
         float *t = hip_scratch((size_t)hip_n1);
         lrh_export(hip_ctx[1], LRH_RING_FFT1_SUMSQ, t, (size_t)pa, (size_t)hip_n1);
         for (int i = 0; i < hip_n1; i++) fft1_sumsq[pa + i] += t[i];
@@ -519,15 +569,41 @@ static void hip_spur_after_fft2(int na)
   }
 }
 
+/* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
+static int hip_wf_ticket[6], hip_wf_n;
+static void hip_wf_collect(void)
+{
+  for (int i = 0; i < hip_wf_n; i++) if (lrh_export_end(hip_rx, hip_wf_ticket[i]) != 0) lirerr(1469);
+  hip_wf_n = 0;
+}
+static void hip_wf_fetch(int lag, lrh_ring ring, void *dst, size_t off, size_t cnt)
+{
+  int t = 0;
+  if (!lag || hip_wf_n >= 6) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
+  if (lrh_export_begin(hip_rx, ring, dst, off, cnt, &t) != 0) { lirerr(1469); return; }
+  if (t) hip_wf_ticket[hip_wf_n++] = t;
+}
+
 void hip_make_fft2(void)
 {
   lrh_ptrs q;
-  int old_ptr;
+  int old_ptr, nf = 1;
   memset(&q, 0, sizeof q);
   q.timf2_px = HIP_IN(timf2_px); q.fft2_na = fft2_na; q.fft2_pa = HIP_IN(fft2_pa); q.fft2_nb = fft2_nb; q.fft2_nm = fft2_nm;
   q.wg_waterf_sum_counter = wg_waterf_sum_counter; q.wg_waterf_ptr = wg_waterf_ptr; q.fft2_liminfo_cnt = fft2_liminfo_cnt;
   old_ptr = wg_waterf_ptr;
-  if (HC == 1) { if (lrh_make_fft2(hip_rx, &q, 1) != 0) { lirerr(1469); return; } }
+  if (HC == 1) {
+    /* every transform the blanker has released samples for goes through in one call (second_fft comes back for each one it is owed:
+       wcw.c:265-285 -- its test then fails after one pass), as far as the fft2 ring has room; not with spurs being tracked, whose loop
+       state Linrad looks at after every transform */
+    lrh_stage_wait(hip_rx, LRH_STAGE_FFT2);
+    hip_wf_collect();
+    nf = 1 + (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) - 4 * fft2_size) / timf2_output_block;
+    { const int room = max_fft2n - 1 - ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask); if (nf > room) nf = room; }
+    if (nf > max_fft2n / 2) nf = max_fft2n / 2;
+    if (hip_spurs_on || nf < 1) nf = 1;
+    q.timf2_px = HIP_IN(timf2_px); q.fft2_na = fft2_na;
+    if (lrh_make_fft2(hip_rx, &q, nf) != 0) { lirerr(1469); return; } }
   else {
     /* two channels: each context transforms its own; the cross products TWOCHAN_POWER, their sums over the waterfall group and the
        polarisation-independent waterfall line (fft2.c:1622-1640, 1700-1815) need both channels' bins: all-gather of LRH_X_BINS */
@@ -542,12 +618,20 @@ void hip_make_fft2(void)
   }
   timf2_px = HIP_OUT(q.timf2_px); fft2_na = q.fft2_na; fft2_pa = HIP_OUT(q.fft2_pa); fft2_nb = q.fft2_nb; fft2_nm = q.fft2_nm;   /* fft2.c:1831-1845 */
   wg_waterf_sum_counter = q.wg_waterf_sum_counter; wg_waterf_ptr = q.wg_waterf_ptr; fft2_liminfo_cnt = q.fft2_liminfo_cnt;
-  if (q.wg_waterf_ptr != old_ptr) {            /* a waterfall line completed (fft2.c:703-815): the screen thread draws it */
-    lrh_export(hip_rx, LRH_RING_WG_WATERF, &wg_waterf[old_ptr], (size_t)old_ptr, (size_t)wg_xpixels);
-    if (HC == 1) lrh_export(hip_rx, LRH_RING_FFT2_POWERSUM, fft2_powersum_float, 0, (size_t)hip_n2);
+  if (q.wg_waterf_ptr != old_ptr) {            /* waterfall lines completed (fft2.c:703-815; the pointer walks down, :813-815): the screen thread draws them */
+    int pt;
+    /* a call that found more than one transform owed is behind the device: the lines and the averaged spectrum (display data) are then
+       collected by this thread's next call instead of being waited for; a call of one transform brings them back at once */
+    const int lag = HC == 1 && nf > 1;
+    for (pt = old_ptr; pt != q.wg_waterf_ptr; pt = pt - wg_xpixels < 0 ? pt - wg_xpixels + wg_waterf_size : pt - wg_xpixels)
+      hip_wf_fetch(lag, LRH_RING_WG_WATERF, &wg_waterf[pt], (size_t)pt, (size_t)wg_xpixels);
+    if (HC == 1) {                             /* the averaged spectrum of the newest line (read-backs of up to 512 KiB wait without the context's lock) */
+      int at = 0;
+      while (at < hip_n2) { const int k = hip_n2 - at > (1 << 17) ? (1 << 17) : hip_n2 - at; hip_wf_fetch(lag, LRH_RING_FFT2_POWERSUM, &fft2_powersum_float[at], (size_t)at, (size_t)k); at += k; }
+    }
     else lrh_export(hip_rx, LRH_RING_FFT2_XYSUM, fft2_xysum, 0, (size_t)4 * hip_n2);
   }
-  hip_afc_rows((q.fft2_na + fft2n_mask) & fft2n_mask, 1);
+  hip_afc_rows((q.fft2_na - nf) & fft2n_mask, nf);
   if (hip_spurs_on) hip_spur_after_fft2((q.fft2_na + fft2n_mask) & fft2n_mask);
   make_fft2_status = FFT2_COMPLETE;           /* second_fft loops until this (wcw.c:280-285) */
 }
@@ -555,10 +639,10 @@ void hip_make_fft2(void)
 /* timf3 is where the device hands back to the CPU: fft3, mix2 and the demodulators carry on from the host ring (audio rate).
    The mixer's phase bookkeeping (set_mix1_phases, mix1.c:781-861) is host state of the library; the globals follow it because
    make_afc and the baseband graph read them. */
-static void hip_mix1_back(int old_pa)
+static void hip_mix1_back_n(int old_pa, int blocks)
 {
   lrh_mix1_state m;
-  int n = timf3_block, first = n;
+  int n = blocks * timf3_block, first = n;
   if (HC == 2) {                                           /* {ch0, ch1} per sample: each context's block, interleaved (timf3_block counts both) */
     const int per = timf3_block / 2, size1 = timf3_size / 2;
     int pa1 = old_pa / 2;
@@ -590,18 +674,30 @@ static void hip_mix1_back(int old_pa)
   }
 }
 
+static void hip_mix1_back(int old_pa) { hip_mix1_back_n(old_pa, 1); }
+
 void hip_fft2_mix1_fixed(void)
 {
   lrh_ptrs q;
-  int old_pa;
+  int old_pa, n = 1;
   memset(&q, 0, sizeof q);
   for (int ch = 0; ch < HC; ch++) lrh_set_mix1_selfreq(hip_ctx[ch], mix1_selfreq[0]);
+  if (HC == 1) {
+    /* every transform second_fft has finished goes through in one call, as far as timf3 has room (the narrowband thread comes back while
+       `fft2_na != fft2_nx`, wcw.c:1737-1745: that test then fails after one pass).  The read-back below waits for the device, so this
+       thread is never ahead of it: a call's size follows the load */
+    const int room = ((timf3_px - timf3_pa + timf3_mask) & timf3_mask) / timf3_block;
+    n = (fft2_na - fft2_nx + max_fft2n) & fft2n_mask;
+    if (n > room) n = room;
+    if (n > max_fft2n / 2) n = max_fft2n / 2;
+    if (n < 1) n = 1;
+  }
   q.fft2_nx = fft2_nx; q.timf3_pa = HIP_IN(timf3_pa); q.fft2_na = fft2_na;
   old_pa = timf3_pa;
   { const lrh_ptrs q0 = q;
-    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft2_mix1_fixed(hip_ctx[ch], &q, 1) != 0) { lirerr(1470); return; } } }
+    for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft2_mix1_fixed(hip_ctx[ch], &q, n) != 0) { lirerr(1470); return; } } }
   fft2_nx = q.fft2_nx; timf3_pa = HIP_OUT(q.timf3_pa);                          /* mix1.c:991-992 */
-  hip_mix1_back(old_pa);
+  hip_mix1_back_n(old_pa, n);
 }
 
 /* fft1_mix1_fixed (mix1.c:995-1042): the second fft is off -- Linrad's default in every rx mode (uivar.c:371-392, column 8) -- and

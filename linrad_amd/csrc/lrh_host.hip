@@ -58,6 +58,8 @@ using namespace lrh;
 #define FFT2_WATERFALL_ZERO 0.012
 #define LRH_NSTAGE 4
 #define LRH_BLN_PARTIALS 256
+#define LRH_NOUT 16                 /* read-back slots (export_impl) */
+#define LRH_OUT_SLOT_BYTES (1u << 19)
 #define LRH_MAX_HANDLES 7          /* handle 0 = the caller's own thread; 1..6 = THREAD_FFT1B1..6 (MAX_FFT1_THREADS, thrdef.h:107; gpu_handle_number, wcw.c:500) */
 
 struct ProfEntry { double ms = 0; long n = 0; };
@@ -70,7 +72,11 @@ struct lrh_ctx {
   // is the order of the calls (one main stream), which the caller's events already make the reference's order.
   std::recursive_mutex mtx;
   // fft1_b workers: handle h >= 1 launches on its own stream so that transforms of different workers overlap
-  hipStream_t hstream[LRH_MAX_HANDLES] = {}; hipEvent_t hev[LRH_MAX_HANDLES] = {}, hev_start = nullptr; bool hpending[LRH_MAX_HANDLES] = {}; std::atomic<bool> hread[LRH_MAX_HANDLES] = {};
+  hipStream_t hstream[LRH_MAX_HANDLES] = {}; hipEvent_t hev[LRH_MAX_HANDLES] = {}, hev_start = nullptr; std::atomic<bool> hpending[LRH_MAX_HANDLES] = {}; std::atomic<bool> hread[LRH_MAX_HANDLES] = {};
+  // what the workers' transforms have read of timf1 since the producer last waited for them: [rd_lo, rd_lo + rd_span) in ring bytes (mtx_w).
+  // lrh_timf1_write_async waits for the workers' events only when its copy would touch that span -- once per lap of the ring, not once per block
+  bool rd_any = false; long long rd_lo = 0, rd_span = 0;
+  std::mutex mtx_w; bool worker_fast = true;   // the workers' calls take this small lock (wparked, rd_*) instead of the context's; LRH_WORKER_FAST=0: they launch themselves, on their own streams
   lrh_config cfg;
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
@@ -111,7 +117,7 @@ struct lrh_ctx {
   bool timf2_primed = false;      // a transform has gone through make_timf2: the next one has an overlap partner
   // the fused kernels rebuild that partner from the timf1 ring (one block behind the first of the call): only right while the calls walk
   // the ring without a gap and the tables have not changed in between
-  bool f1_end_valid = false;      // f1_end is where the previous handle-0 lrh_fft1_b stopped, under the tables in force now
+  std::atomic<bool> f1_end_valid{false};      // f1_end is where the previous handle-0 lrh_fft1_b stopped, under the tables in force now
   int f1_end = 0;                 // frame index
   bool f1_cont = false;           // the parked call starts where the previous one stopped
   float *d_ss_part = nullptr; size_t ss_part_stride = 0; int ss_flip = 0;   // two halves, alternating per fused launch: the join of
@@ -229,6 +235,22 @@ struct lrh_ctx {
   bool prof = false, prof_keep_schedule = false; std::map<std::string, ProfEntry> prof_tot; std::vector<ProfPending> prof_pend;
   std::vector<hipEvent_t> ev_pool;
   double host_ms_phases = 0, host_ms_dsp = 0, host_cpu_ms_dsp = 0, host_ms_wait = 0; long host_n_phases = 0, host_n_dsp = 0;   // host CPU time, lrh_profile_get("host:...")
+  // Read-backs of a caller that drives the stages from several threads (Linrad's stage threads through integration/hipshim.c): the copy goes to
+  // a stream of its own behind an event on the main stream, into a page-locked slot, and the caller waits for it WITHOUT the context's lock --
+  // the other stage threads go on enqueueing, and the wait covers what was queued up to the export, not what they add meanwhile.
+  bool out_ok = true;               // LRH_OUT_STREAM=0: read-backs on the main stream, waited for under the lock (as before round 5)
+  void *out_dst[LRH_NOUT] = {}; size_t out_bytes[LRH_NOUT] = {};
+  hipStream_t stream_out = nullptr; void *h_out[LRH_NOUT] = {}; bool out_busy[LRH_NOUT] = {}; hipEvent_t ev_out_src[LRH_NOUT] = {}, ev_out_done[LRH_NOUT] = {};
+  // Transforms of the fft1_b workers in stage-call mode (handle >= 1, one call per dispatch of Linrad's wideband thread): a worker's call only
+  // NOTES its blocks here (mtx_w; no HIP call); the next reader of fft1_float on the main stream -- lrh_fft1_c of the stage thread, which
+  // Linrad wakes once the blocks have been retired in order -- issues everything noted so far as ONE launch per contiguous run, in stream
+  // order behind the earlier readers of the ring slots it overwrites.  Measured: with the workers launching themselves (own streams, events
+  // both ways) the host's HIP calls bound the drop-in at one block per call: 3 calls per block from each of 3 workers at 12 us apiece under
+  // contention (profiles/r05_glue.txt), the device idle 70 % of the time.
+  struct ParkedW { int timf1p_ref, fft1_pa, batch; };
+  std::vector<ParkedW> wparked; int w_next_nb = -1; std::mutex mtx_evin;
+  // lrh_stage_wait: the newest event behind each stage's device work, and whether one has been recorded
+  hipEvent_t ev_stage[LRH_STAGE_COUNT] = {}; bool stage_valid[LRH_STAGE_COUNT] = {};
 };
 
 static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -243,6 +265,8 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
 static int flush_pending(lrh_ctx *c);
 static int upload_filtercorr(lrh_ctx *c);
 static void join_side_tail(lrh_ctx *c);
+static int stage_mark(lrh_ctx *c, int stage);
+static int join_handles(lrh_ctx *c);
 static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten (by a writer ordered behind the last make_timf2's kernels)
 {
   if (!c->pack_prev_stale) std::swap(c->d_pack_cur, c->d_pack_prev);
@@ -417,6 +441,11 @@ void lrh_close(lrh_ctx *c)
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   if (c->ev_in_guard) hipEventDestroy(c->ev_in_guard);
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
+  if (c->stream_out) { hipStreamSynchronize(c->stream_out); hipStreamDestroy(c->stream_out); }
+  if (c->stream_f2) { hipStreamSynchronize(c->stream_f2); hipStreamDestroy(c->stream_f2); }
+  for (int i = 0; i < 3; i++) { if (c->ev_f2c[i]) hipEventDestroy(c->ev_f2c[i]); if (c->ev_f2r[i]) hipEventDestroy(c->ev_f2r[i]); }
+  for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) hipHostFree(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
+  for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
@@ -522,6 +551,8 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e7 = getenv("LRH_SUMS_MAIN")) c->sums_on_main = atoi(e7) != 0;
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
+  if (const char *e8 = getenv("LRH_OUT_STREAM")) c->out_ok = atoi(e8) != 0;
+  if (const char *e8 = getenv("LRH_WORKER_FAST")) c->worker_fast = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
   if (const char *e6 = getenv("LRH_CLEVER_FIRST")) c->clv_first = atoi(e6);
   if (const char *e7 = getenv("LRH_CLEVER_SPLIT")) c->clv_split = atoi(e7);   // tests: the one-wave replay of the linear blanker
@@ -1187,6 +1218,23 @@ void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 {
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
+  // The workers' noted transforms (lrh_ctx::wparked) and the ones already issued read the ring: a copy that reaches into what they have read
+  // since the last such wait -- once per lap of the ring, not once per block -- first has the noted ones issued and goes behind the main stream
+  bool guard = false;
+  { bool conflict = false;
+    { std::lock_guard<std::mutex> lkw(c->mtx_w);
+      if (c->rd_any) {
+        const long long ring = c->cfg.timf1_bytes, o = off & c->timf1_bytemask, d = ((o - c->rd_lo) % ring + ring) % ring;
+        conflict = c->rd_span >= ring || d < c->rd_span || d + nbytes > ring;
+        if (conflict) c->rd_any = false;
+      } }
+    if (conflict) {
+      LRH_ENTER(c);
+      { const int rc_ = join_handles(c); if (rc_) return rc_; }
+      if (!c->ev_in_guard) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_guard, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->ev_in_guard, c->stream));
+      guard = true;
+    } }
   // not the context's lock: what this touches besides its own stream are flags the stage calls set or take atomically and events that exist
   // for the life of the context
   std::lock_guard<std::mutex> lk_in(c->mtx_in);
@@ -1203,11 +1251,11 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
     if (!c->ev_in_guard) HIPCHK(c, hipEventCreateWithFlags(&c->ev_in_guard, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_in_guard, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_in_guard, 0));
   } else if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read_cur.load(), 0));
-  for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h]) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));
+  for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h].exchange(false)) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));   // workers that launch themselves (LRH_WORKER_FAST=0, the four-step sizes)
+  if (guard) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_in_guard, 0));
   HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
   if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
-  HIPCHK(c, hipEventRecord(c->ev_in, c->stream_in));
-  c->in_pending = true;
+  c->in_pending = true;                                      // (the reader records the event behind the copies it needs: wait_for_input)
   return LRH_OK;
 }
 int lrh_timf1_write_wait(lrh_ctx *c)
@@ -1255,35 +1303,59 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
 // ---------------------------------------------------------------------------------------------- fft1
 // Transforms launched by fft1_b workers on their own streams: whoever reads fft1_float next on the main stream waits for them.
 static int launch_parked_fft1(lrh_ctx *c);
+static int wait_for_input(lrh_ctx *c, hipStream_t S);
+static Fft1Args fft1_args_of(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch);
+// the blocks the fft1_b workers have noted (lrh_ctx::wparked): in ring order, one launch per contiguous run, on the main stream
+static int issue_parked_workers(lrh_ctx *c)
+{
+  std::vector<lrh_ctx::ParkedW> v;
+  { std::lock_guard<std::mutex> lkw(c->mtx_w); v.swap(c->wparked); }
+  if (v.empty()) return LRH_OK;
+  const int mask = c->fft1n_mask, blk = 2 * c->N1;
+  if (c->w_next_nb < 0) {                                    // first ever: the oldest is the one no other entry leads up to
+    c->w_next_nb = (v[0].fft1_pa / blk) & mask;
+    for (bool moved = true; moved;) { moved = false; for (auto &e : v) if ((((e.fft1_pa / blk) + e.batch) & mask) == c->w_next_nb) { c->w_next_nb = (e.fft1_pa / blk) & mask; moved = true; } }
+  }
+  const int base = c->w_next_nb;
+  std::sort(v.begin(), v.end(), [&](const lrh_ctx::ParkedW &x, const lrh_ctx::ParkedW &y) { return (((x.fft1_pa / blk) - base) & mask) < (((y.fft1_pa / blk) - base) & mask); });
+  const long long C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1, esz = c->cfg.timf1_dword_input ? 8 : 4;
+  hipStream_t keep = c->cur; c->cur = c->stream;
+  struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep};
+  if (c->in_pending.exchange(false)) { const int rc_ = wait_for_input(c, c->cur); if (rc_) return rc_; }
+  size_t i = 0;
+  while (i < v.size()) {
+    int batch = v[i].batch; size_t j = i + 1;
+    while (j < v.size() && batch + v[j].batch <= c->cfg.max_fft1n / 2 &&
+           ((v[j].fft1_pa / blk) & mask) == (((v[i].fft1_pa / blk) + batch) & mask) &&
+           (v[j].timf1p_ref & c->timf1_bytemask) == (int)(((long long)v[i].timf1p_ref + (long long)batch * c->M1 * esz * C) & c->timf1_bytemask)) { batch += v[j].batch; j++; }
+    const Fft1Args a = fft1_args_of(c, v[i].timf1p_ref, v[i].fft1_pa, batch);
+    HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
+    if (a.real) {                                             // fft1_reherm_dit_one, second half (fft1_re.c:96-131)
+      RealSplitArgs r;
+      r.spec = c->d_fft1; r.first_nb = a.first_nb; r.nb_mask = a.nb_mask; r.n = c->N1; r.filtercorr = c->d_filtercorr; r.direction = c->cfg.fft1_direction;
+      HIPCHK(c, launch_realsplit(r, batch, c->cur));
+    } else if (c->d_foldcorr) {
+      FoldcorrArgs f;
+      f.spec = c->d_fft1; f.first_nb = a.first_nb; f.nb_mask = a.nb_mask; f.n = c->N1;
+      f.foldcorr = c->d_foldcorr; f.filtercorr = c->d_filtercorr; f.direction = c->cfg.fft1_direction;
+      HIPCHK(c, launch_foldcorr(f, batch, c->cur));
+    }
+    c->w_next_nb = (a.first_nb + batch) & mask;
+    i = j;
+  }
+  return LRH_OK;
+}
 static int join_handles(lrh_ctx *c)
 {
   if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }   // a reader other than the fused make_timf2: the transform after all
+  { const int rc_ = issue_parked_workers(c); if (rc_) return rc_; }
   for (int h = 1; h < LRH_MAX_HANDLES; h++)
     if (c->hpending[h]) { HIPCHK(c, hipStreamWaitEvent(c->cur, c->hev[h], 0)); c->hpending[h] = false; }
   return LRH_OK;
 }
 
-int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
+static Fft1Args fft1_args_of(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch)
 {
-  LRH_ENTER(c);
-  if (!c || batch < 1 || batch > c->cfg.max_batch || handle < 0 || handle >= LRH_MAX_HANDLES) return LRH_EINVAL;
-  // handle 0: the caller's own thread (no_of_fft1b == 0, wcw.c:1036), on the main stream.  handle h >= 1: worker THREAD_FFT1Bh
-  // (wcw.c:476-500), on its own stream -- behind everything already enqueued on the main stream (the earlier readers of the
-  // ring slots it overwrites, the previous lap) and ahead of the next reader of fft1_float (join_handles).
-  hipStream_t const keep_cur = c->cur;
-  struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep_cur};
-  if (handle > 0) {
-    if (c->rec) return fail(c, LRH_ESTATE, "fft1_b workers cannot run inside lrh_wideband_dsp");
-    if (!c->hstream[handle]) {
-      HIPCHK(c, hipStreamCreateWithFlags(&c->hstream[handle], hipStreamNonBlocking));
-      HIPCHK(c, hipEventCreateWithFlags(&c->hev[handle], hipEventDisableTiming));
-      if (!c->hev_start) HIPCHK(c, hipEventCreateWithFlags(&c->hev_start, hipEventDisableTiming));
-    }
-    HIPCHK(c, hipEventRecord(c->hev_start, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->hev_start, 0));
-    if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->ev_in, 0));      // every worker waits for the producer's copy
-    c->cur = c->hstream[handle];
-  } else if (c->in_pending.exchange(false)) HIPCHK(c, hipStreamWaitEvent(c->cur, c->ev_in, 0));   // samples of lrh_timf1_write_async (a copy recorded meanwhile raises the flag again)
   Fft1Args a;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;       // bytes per complex sample (fft1.c:420 / :526)
@@ -1300,6 +1372,63 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   a.real = c->cfg.timf1_real_input != 0;
   if (c->d_foldcorr || a.real) { a.filtercorr = c->d_unitcorr; a.direction = 1; }   // bare transform: k_foldcorr / k_realsplit does the rest
   a.stamps = nullptr;
+  return a;
+}
+
+// a worker's transforms read [timf1p_ref - I1, + N1 + (batch-1) M1 samples) of the ring: note it for the producer (caller holds mtx_w)
+static void worker_read_note(lrh_ctx *c, int timf1p_ref, int batch)
+{
+  const long long C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1, esz = c->cfg.timf1_dword_input ? 8 : 4, ring = c->cfg.timf1_bytes;
+  const long long start = (((long long)(timf1p_ref & c->timf1_bytemask) - c->I1 * esz * C) % ring + ring) % ring, len = ((long long)c->N1 + (long long)(batch - 1) * c->M1) * esz * C;
+  if (!c->rd_any) { c->rd_any = true; c->rd_lo = start; c->rd_span = len; return; }
+  const long long d = ((start - c->rd_lo) % ring + ring) % ring;
+  // (a call that starts before the newest end is an earlier block dispatched to a slower worker: inside the span already)
+  if (d + len > c->rd_span) c->rd_span = d + len;
+}
+
+// the producer's copies (lrh_timf1_write_async, its own stream) in front of a reader on stream S: the event is recorded here, by the reader
+// -- one record per reader call instead of one per copy
+static int wait_for_input(lrh_ctx *c, hipStream_t S)
+{
+  std::lock_guard<std::mutex> lk(c->mtx_evin);
+  HIPCHK(c, hipEventRecord(c->ev_in, c->stream_in));
+  HIPCHK(c, hipStreamWaitEvent(S, c->ev_in, 0));
+  return LRH_OK;
+}
+
+int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
+{
+  if (c && handle > 0 && handle < LRH_MAX_HANDLES && batch >= 1 && batch <= c->cfg.max_batch && c->worker_fast &&
+      !c->corr_on && !c->fft1_big && !c->prof && !c->dbg_stamp && !c->in_dsp && !c->rec) {
+    // a worker's call: noted, issued by the next reader of fft1_float (lrh_ctx::wparked)
+    std::lock_guard<std::mutex> lkw(c->mtx_w);
+    c->wparked.push_back({timf1p_ref, fft1_pa, batch});
+    worker_read_note(c, timf1p_ref, batch);
+    c->f1_end_valid = false;                                 // worker handles finish in any order
+    return LRH_OK;
+  }
+  LRH_ENTER(c);
+  if (!c || batch < 1 || batch > c->cfg.max_batch || handle < 0 || handle >= LRH_MAX_HANDLES) return LRH_EINVAL;
+  // handle 0: the caller's own thread (no_of_fft1b == 0, wcw.c:1036), on the main stream.  handle h >= 1: worker THREAD_FFT1Bh
+  // (wcw.c:476-500), on its own stream -- behind everything already enqueued on the main stream (the earlier readers of the
+  // ring slots it overwrites, the previous lap) and ahead of the next reader of fft1_float (join_handles).
+  hipStream_t const keep_cur = c->cur;
+  struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep_cur};
+  if (handle > 0) {
+    if (c->rec) return fail(c, LRH_ESTATE, "fft1_b workers cannot run inside lrh_wideband_dsp");
+    if (!c->hstream[handle]) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->hstream[handle], hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->hev[handle], hipEventDisableTiming));
+      if (!c->hev_start) HIPCHK(c, hipEventCreateWithFlags(&c->hev_start, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->hev_start, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->hev_start, 0));
+    if (c->in_pending) { const int rc_ = wait_for_input(c, c->hstream[handle]); if (rc_) return rc_; }      // every worker waits for the producer's copy
+    { std::lock_guard<std::mutex> lkw(c->mtx_w); worker_read_note(c, timf1p_ref, batch); }
+    c->cur = c->hstream[handle];
+  } else if (c->in_pending.exchange(false)) { const int rc_ = wait_for_input(c, c->cur); if (rc_) return rc_; }   // samples of lrh_timf1_write_async (a copy enqueued meanwhile raises the flag again)
+  Fft1Args a = fft1_args_of(c, timf1p_ref, fft1_pa, batch);
+  const int C = a.chan_count;
   if (c->dbg_stamp) {                                     // diagnostics (LRH_STAMP=1, -DLRH_STAMP_BUILD): phase stamps of this launch to stderr
     if (!c->d_stamps) HIPCHK(c, hipMalloc(&c->d_stamps, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur));
@@ -1562,6 +1691,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   // from now on the previous transform was routed with the current table
   c->pack_prev_stale = false;                            // (the table in d_pack_cur is the previous transform's from here on: no copy)
   HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
+  c->stage_valid[LRH_STAGE_TIMF2] = true;                // lrh_stage_wait(LRH_STAGE_TIMF2) waits on ev_timf2_done itself: no second record
   if (read_alias || c->read_alias_wanted) { c->ev_fft1_read_cur = c->ev_timf2_done; c->fft1_read_valid = true; c->read_alias_wanted = false; }
   c->timf2_primed = true;
   const int low = c->lowlevel_points;
@@ -1970,6 +2100,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
     if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }
     if (c->split_fft2_tail) { HIPCHK(c, hipEventRecord(c->ev_ps2, c->stream2)); c->last_main_ev = c->ev_fft2; }
     c->cur = main_s;
+    { const int rcm_ = stage_mark(c, LRH_STAGE_FFT2); if (rcm_) return rcm_; }
   });
   for (int b = 0; b < batch; b++) {                                      // fft2.c:672, 703-705, 813-815, 1831-1845
     p->wg_waterf_sum_counter++;
@@ -2956,16 +3087,21 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 }
 
 // ---------------------------------------------------------------------------------------------- outputs
-static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait = true);
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait = true, int *ticket = nullptr);
+static int export_collect(lrh_ctx *c, int slot);
 int lrh_export_device_async(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice, false); }
 void *lrh_stream(lrh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int lrh_export(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost); }
 int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice); }
-static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait)
+static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait, int *ticket)
 {
+  if (ticket) *ticket = 0;
   if (!c || !dst) return LRH_EINVAL;
   LRH_ENTER(c);
-  { const int rc_ = join_handles(c); if (rc_) return rc_; }
+  // transforms of the fft1_b workers (their own streams) and a parked transform: only a reader of what fft1 itself leaves needs them --
+  // everything behind fft1_c / make_timf2 was enqueued by calls that have joined them already
+  if (ring == LRH_RING_TIMF1 || ring == LRH_RING_FFT1_FLOAT || ring == LRH_RING_FFT1_SUMSQ || ring == LRH_RING_FFT1_SLOWSUM || ring == LRH_RING_FFT1_CORRSUM ||
+      ring == LRH_RING_FFT1_SLOWCORR || ring == LRH_RING_FFT1_SLOWCORR_TOT || c->f1_have) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // (incl. the workers' noted blocks)
   const void *src; size_t esz = 4, total;
   switch (ring) {
     case LRH_RING_TIMF1: src = c->d_timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;
@@ -3006,8 +3142,70 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;
+  if (kind == hipMemcpyDeviceToHost && wait && cnt * esz <= LRH_OUT_SLOT_BYTES && cnt > 0 && !c->in_dsp && !c->rec && c->out_ok) {
+    // page-locked slot, copy stream, wait outside the lock (see lrh_ctx::stream_out)
+    int slot = -1;
+    for (int i = 0; i < LRH_NOUT; i++) if (!c->out_busy[i]) { slot = i; break; }
+    if (slot >= 0) {
+      if (!c->stream_out) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+      if (!c->h_out[slot]) {
+        if (hipHostMalloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc(read-back slot)");
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
+      }
+      c->out_busy[slot] = true;
+      hipError_t e_ = hipEventRecord(c->ev_out_src[slot], c->stream);
+      if (e_ == hipSuccess) e_ = hipStreamWaitEvent(c->stream_out, c->ev_out_src[slot], 0);
+      if (e_ == hipSuccess) e_ = hipMemcpyAsync(c->h_out[slot], (const char *)src + off * esz, cnt * esz, hipMemcpyDeviceToHost, c->stream_out);
+      if (e_ == hipSuccess) e_ = hipEventRecord(c->ev_out_done[slot], c->stream_out);
+      if (e_ != hipSuccess) { c->out_busy[slot] = false; return fail(c, LRH_EDEVICE, "read-back", e_); }
+      c->out_dst[slot] = dst; c->out_bytes[slot] = cnt * esz;
+      if (ticket) { *ticket = slot + 1; return LRH_OK; }     // lrh_export_begin: the caller collects it with lrh_export_end
+      lk_.unlock();
+      return export_collect(c, slot);
+    }
+  }
+  if (ticket) *ticket = 0;                                  // no slot (or a span beyond a slot's size): done here, nothing to collect
   HIPCHK(c, hipMemcpyAsync(dst, (const char *)src + off * esz, cnt * esz, kind, c->stream));
   if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRH_OK;
+}
+// second half of a read-back: called WITHOUT the context's lock
+static int export_collect(lrh_ctx *c, int slot)
+{
+  const hipError_t e_ = hipEventSynchronize(c->ev_out_done[slot]);
+  if (e_ == hipSuccess) memcpy(c->out_dst[slot], c->h_out[slot], c->out_bytes[slot]);
+  { std::lock_guard<std::recursive_mutex> lk(c->mtx); c->out_busy[slot] = false; }
+  if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(read-back)", e_);
+  return LRH_OK;
+}
+int lrh_export_begin(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, int *ticket)
+{
+  if (!ticket) return LRH_EINVAL;
+  return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost, true, ticket);
+}
+int lrh_export_end(lrh_ctx *c, int ticket)
+{
+  if (!c || ticket < 0 || ticket > LRH_NOUT) return LRH_EINVAL;
+  if (ticket == 0) return LRH_OK;
+  if (!c->out_busy[ticket - 1]) return fail(c, LRH_ESTATE, "lrh_export_end: no read-back under this ticket");
+  return export_collect(c, ticket - 1);
+}
+
+int lrh_stage_wait(lrh_ctx *c, int stage)
+{
+  if (!c || stage < 0 || stage >= LRH_STAGE_COUNT) return LRH_EINVAL;
+  hipEvent_t ev = nullptr;
+  { LRH_LOCK(c); if (c->stage_valid[stage]) ev = stage == LRH_STAGE_TIMF2 ? c->ev_timf2_done : c->ev_stage[stage]; }
+  // the event belongs to the context for its life; the thread that waits is the one that makes this stage's calls, so it is not re-recorded meanwhile
+  if (ev && hipEventSynchronize(ev) != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(stage)");
+  return LRH_OK;
+}
+static int stage_mark(lrh_ctx *c, int stage)          // behind the device work a stage call has just enqueued on c->cur (stage calls only, not inside lrh_wideband_dsp)
+{
+  if (c->in_dsp || c->rec) return LRH_OK;
+  if (!c->ev_stage[stage]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[stage], hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_stage[stage], c->cur));
+  c->stage_valid[stage] = true;
   return LRH_OK;
 }
 
@@ -3050,7 +3248,7 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
     std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
     HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), sizeof(float2) * c->N1, hipMemcpyHostToDevice));
   }
-  if (c->in_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+  if (c->in_pending) { const int rc_ = wait_for_input(c, c->stream); if (rc_) return rc_; }
   Fft1Args a; a.spare_cus = 0;
   const int C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1;
   const int esz = c->cfg.timf1_dword_input ? 8 : 4;
@@ -3100,6 +3298,7 @@ int lrh_sync(lrh_ctx *c)
 {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
+  { const int rc_ = join_handles(c); if (rc_) return rc_; }  // blocks the fft1_b workers have noted
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
   for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2, c->stream_nb, c->stream_sel }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));

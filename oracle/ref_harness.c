@@ -132,6 +132,14 @@ static pthread_mutex_t stage_big_lock = PTHREAD_MUTEX_INITIALIZER;
 #else
 #define SLOCK(call) do { call; } while (0)
 #endif
+/* timing=1 over the glue (shim_harness_hip, bench.py "glue"): samples enter through the producer hook block by block, and every stage call's
+   wall time is summed per stage (where the drop-in's time goes: the stage threads are Linrad's, the calls are the patched entry points) */
+enum { SG_INGEST, SG_FFT1B, SG_FFT1C, SG_TIMF2, SG_BLANK, SG_FFT2, SG_MIX1, SG_FFT3, SG_WAIT_DISP, SG_WAIT_IN, SG_N };
+static const char *sg_name[SG_N] = { "finish_rx_read_hook", "fft1_b", "fft1_c", "make_timf2", "first_noise_blanker", "make_fft2", "fft2_mix1_fixed", "fft3_mix2_host", "dispatcher_wait_room", "dispatcher_wait_input" };
+static volatile double sg_sec[SG_N]; static volatile long sg_calls[SG_N]; static int sg_on = 0, glue_ingest = 0;
+static pthread_mutex_t sg_m = PTHREAD_MUTEX_INITIALIZER;
+static inline double sg_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#define STAGE(k, call) do { if (sg_on) { const double t0_ = sg_now(); SLOCK(call); const double d_ = sg_now() - t0_; pthread_mutex_lock(&sg_m); sg_sec[k] += d_; sg_calls[k]++; pthread_mutex_unlock(&sg_m); } else SLOCK(call); } while (0)
 enum { TEV_TIMF2, TEV_FFT2, TEV_READY, TEV_SPACE, TEV_DONE, TEV_DO, TNEV = TEV_DO + 6 };
 static pthread_mutex_t tev_m[TNEV]; static pthread_cond_t tev_c[TNEV]; static volatile int tev_f[TNEV];
 static void tev_set(int n) { pthread_mutex_lock(&tev_m[n]); tev_f[n] = 1; pthread_cond_signal(&tev_c[n]); pthread_mutex_unlock(&tev_m[n]); }
@@ -144,7 +152,7 @@ static void *th_fft1b(void *arg)
   for (;;) {
     tev_await(TEV_DO + k);
     if (TH.job[k].busy < 0) return NULL;
-    SLOCK(fft1_b(TH.job[k].inptr, &fft1_float[TH.job[k].out], TH.tmp[k], k));
+    STAGE(SG_FFT1B, fft1_b(TH.job[k].inptr, &fft1_float[TH.job[k].out], TH.tmp[k], k));
     TH.job[k].busy = 2;
     tev_set(TEV_DONE);
   }
@@ -154,8 +162,8 @@ static void *th_timf2(void *arg)
   for (;;) {
     tev_await(TEV_TIMF2);
     while (fft1_na != fft1_nb) {
-      while (fft1_na != fft1_nb) { SLOCK(fft1_c()); SLOCK(make_timf2()); }
-      SLOCK(first_noise_blanker());
+      while (fft1_na != fft1_nb) { STAGE(SG_FFT1C, fft1_c()); STAGE(SG_TIMF2, make_timf2()); }
+      STAGE(SG_BLANK, first_noise_blanker());
       if (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size) tev_set(TEV_FFT2);
       tev_set(TEV_SPACE);
     }
@@ -170,7 +178,7 @@ static void *th_fft2(void *arg)
     tev_await(TEV_FFT2);
     while (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) >= 4 * TH.C * fft2_size && ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask) < max_fft2n - 1) {
       make_fft2_status = FFT2_NOT_ACTIVE;
-      while (make_fft2_status != FFT2_COMPLETE) SLOCK(make_fft2());
+      while (make_fft2_status != FFT2_COMPLETE) STAGE(SG_FFT2, make_fft2());
       tev_set(TEV_READY); tev_set(TEV_SPACE);
     }
     if (TH.timf2_done && ((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) < 4 * TH.C * fft2_size) break;
@@ -184,13 +192,17 @@ static void *th_narrow(void *arg)
   for (;;) {
     tev_await(TEV_READY);
     while (fft2_nx != fft2_na) {
-      if (TH.fq_ok) SLOCK(fft2_mix1_fixed()); else fft2_nx = (fft2_nx + 1) & fft2n_mask;
-      TH.nfft2++;
+      { const int nx0 = fft2_nx;
+        if (TH.fq_ok) STAGE(SG_MIX1, fft2_mix1_fixed()); else fft2_nx = (fft2_nx + 1) & fft2n_mask;
+        TH.nfft2 += (fft2_nx - nx0 + max_fft2n) & fft2n_mask; }           /* (the glue takes every finished transform in one call) */
+      if (TH.n3 <= 0) timf3_px = timf3_pa;                              /* no fft3 configured: the consumer of timf3 keeps up */
       if (TH.n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * TH.C * fft3_size &&
                             ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) {
+        const double t3_ = sg_on ? sg_now() : 0;
         make_fft3_all();
         if (TH.mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; }
         fft3_px = (fft3_px + fft3_block) & fft3_mask;
+        if (sg_on) { sg_sec[SG_FFT3] += sg_now() - t3_; sg_calls[SG_FFT3]++; }     /* this thread only */
       }
       tev_set(TEV_FFT2); tev_set(TEV_SPACE);
     }
@@ -198,6 +210,24 @@ static void *th_narrow(void *arg)
   }
   return NULL;
 }
+#ifdef SHIM_HARNESS
+/* the rx input thread (rxin.c: the sound-card / SDR reader): completes blocks in timf1 and hands each to finish_rx_read, whose patched tail
+   (rxin.c:1423) passes it to the device before EVENT_TIMF1 wakes the wideband thread -- here: one fft1_b dispatch's worth at a time, never more
+   than half the ring ahead of the dispatcher */
+static struct { pthread_mutex_t m; pthread_cond_t c; volatile long in_done, disp_done; long total, ring_blocks; int pa; } IN;
+static void *th_input(void *arg)
+{
+  for (long b = 0; b < IN.total; b++) {
+    pthread_mutex_lock(&IN.m);
+    while (IN.in_done - IN.disp_done >= IN.ring_blocks / 2) pthread_cond_wait(&IN.c, &IN.m);
+    pthread_mutex_unlock(&IN.m);
+    STAGE(SG_INGEST, hip_timf1_new(IN.pa, timf1_blockbytes));
+    IN.pa = (IN.pa + timf1_blockbytes) & timf1_bytemask;
+    pthread_mutex_lock(&IN.m); IN.in_done++; pthread_cond_broadcast(&IN.c); pthread_mutex_unlock(&IN.m);
+  }
+  return NULL;
+}
+#endif
 static void th_retire(int k)
 {
   while (TH.job[k].busy != 2) tev_await(TEV_DONE);
@@ -211,7 +241,17 @@ static void run_reference_threads(void)        /* the dispatcher = this thread (
 {
   pthread_t th[3 + 6];
   int n = 0, next = 0, oldest = 0, inflight = 0, out = fft1_pa;
-  for (int i = 0; i < TNEV; i++) { pthread_mutex_init(&tev_m[i], NULL); pthread_cond_init(&tev_c[i], NULL); }
+  for (int i = 0; i < TNEV; i++) { pthread_mutex_init(&tev_m[i], NULL); pthread_cond_init(&tev_c[i], NULL); tev_f[i] = 0; }
+  TH.wide_done = TH.timf2_done = TH.fft2_done = 0;                 /* (the function may run again on the state the previous run left: warm-up, then the timed run) */
+  for (int k = 0; k < 6; k++) TH.job[k].busy = 0;
+#ifdef SHIM_HARNESS
+  pthread_t thin; 
+  if (glue_ingest) {
+    pthread_mutex_init(&IN.m, NULL); pthread_cond_init(&IN.c, NULL);
+    IN.in_done = IN.disp_done = 0; IN.total = TH.nblk; IN.ring_blocks = timf1_bytes / timf1_blockbytes; IN.pa = timf1p_px;
+    pthread_create(&thin, NULL, th_input, NULL);
+  }
+#endif
   pthread_create(&th[n++], NULL, th_narrow, NULL); pthread_create(&th[n++], NULL, th_fft2, NULL); pthread_create(&th[n++], NULL, th_timf2, NULL);
   for (int k = 0; k < TH.workers; k++) pthread_create(&th[n++], NULL, th_fft1b, (void *)(long)k);
   for (int b = 0; b < TH.nblk; b++) {
@@ -221,8 +261,20 @@ static void run_reference_threads(void)        /* the dispatcher = this thread (
                           ((timf2_pa - timf2_px + timf2_size) & timf2_mask) > timf2_size / 2;
       if (inflight == TH.workers || (no_room && inflight > 0)) { th_retire(oldest); oldest = (oldest + 1) % TH.workers; inflight--; continue; }   /* a full ring empties only through retired transforms */
       if (!no_room) break;
-      tev_await(TEV_SPACE);
+      { const double tw_ = sg_on ? sg_now() : 0; tev_await(TEV_SPACE); if (sg_on) { pthread_mutex_lock(&sg_m); sg_sec[SG_WAIT_DISP] += sg_now() - tw_; sg_calls[SG_WAIT_DISP]++; pthread_mutex_unlock(&sg_m); } }
     }
+#ifdef SHIM_HARNESS
+    /* finish_rx_read's hand-over (rxin.c:1423, patched): the block the input thread has just completed at timf1p_pa -- the new samples of this
+       dispatch, [timf1p_px, timf1p_px + timf1_blockbytes) -- goes to the device before the wideband thread is told (EVENT_TIMF1) */
+    if (glue_ingest) {                                              /* EVENT_TIMF1: a block has come in */
+      const double tw_ = sg_on ? sg_now() : 0;
+      pthread_mutex_lock(&IN.m);
+      while (IN.in_done <= IN.disp_done) pthread_cond_wait(&IN.c, &IN.m);
+      IN.disp_done++; pthread_cond_broadcast(&IN.c);
+      pthread_mutex_unlock(&IN.m);
+      if (sg_on) { pthread_mutex_lock(&sg_m); sg_sec[SG_WAIT_IN] += sg_now() - tw_; sg_calls[SG_WAIT_IN]++; pthread_mutex_unlock(&sg_m); }
+    }
+#endif
     TH.job[next].inptr = timf1p_px; TH.job[next].out = out; TH.job[next].busy = 1;
     out = (out + fft1_mulblock) & fft1_mask;
     timf1p_px = (timf1p_px + timf1_blockbytes) & timf1_bytemask;
@@ -233,6 +285,9 @@ static void run_reference_threads(void)        /* the dispatcher = this thread (
   for (int k = 0; k < TH.workers; k++) { TH.job[k].busy = -1; tev_set(TEV_DO + k); }
   TH.wide_done = 1; tev_set(TEV_TIMF2);
   for (int i = 0; i < n; i++) pthread_join(th[i], NULL);
+#ifdef SHIM_HARNESS
+  if (glue_ingest) pthread_join(thin, NULL);
+#endif
 }
 
 /* ---- shim_threads=1 (SHIM_HARNESS): every stage function is called from the thread Linrad calls it from with more than one CPU --
@@ -725,6 +780,8 @@ int main(int argc, char **argv)
                                                        reads (wcw.c:1024-1043, rxin.c:944, 1026) are called where the senders would read, and the host rings they fill are dumped */
   if (shim_net) ui.network_flag = NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2;
   { int rc = hip_open(); fprintf(stderr, "hip_open: %d\n", rc); if (rc != 0) { printf("{\"hip_open\": %d}\n", rc); fclose(fo); return AI("shim_refuse", 0) ? 0 : 3; } }
+  glue_ingest = timing && shim_threads == 2;                            /* the timed glue: block by block from the dispatcher, like the input thread */
+  if (!glue_ingest)
   hip_timf1_new(0, timf1_bytes);                                        /* finish_rx_read's hand-over (rxin.c:1425, patched), the whole recording at once */
 #endif
   /* ---- run ---- */
@@ -771,6 +828,32 @@ int main(int argc, char **argv)
     TH.nblk = nblk / shim_batch; TH.workers = workers; TH.C = C; TH.n3 = n3; TH.mix2on = mix2on; TH.N2 = N2; TH.fq_ok = fq >= 0;
     no_of_fft1b = workers;
     for (int k = 0; k < workers; k++) TH.tmp[k] = zalloc(sizeof(float) * (4 * C * N1 + 64));
+    if (timing) {
+      /* THE DROP-IN'S RATE (bench.py "glue"): the patched reference objects + hipshim.c + liblinrad_hip.so, Linrad's thread topology
+         (dispatcher + fft1_b workers + THREAD_TIMF2 + THREAD_SECOND_FFT + the narrowband thread, wcw.c:401-441, 250-304, 476-500), samples
+         through the producer hook a dispatch at a time, every host-visible product brought back by the glue as in a running xlinrad64.
+         warm=W dispatches first (module load, lazily made streams and buffers), then the clock runs over the rest until every thread has
+         ended and the device is idle. */
+      const int warm = AI("warm", 64) / shim_batch > 0 ? AI("warm", 64) / shim_batch : 1;
+      const int total = TH.nblk;
+      if (total <= warm) { fprintf(stderr, "timing: nblk must exceed warm\n"); return 2; }
+      TH.nblk = warm; run_reference_threads(); lrh_sync(hip_context());
+      const int nfft2_warm = TH.nfft2;
+      for (int k = 0; k < SG_N; k++) { sg_sec[k] = 0; sg_calls[k] = 0; }
+      sg_on = 1;
+      clock_gettime(CLOCK_MONOTONIC, &ts0);
+      TH.nblk = total - warm; run_reference_threads(); lrh_sync(hip_context());
+      clock_gettime(CLOCK_MONOTONIC, &ts1);
+      const double dt = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+      printf("{\"loop_seconds\": %.6f, \"blocks\": %d, \"samples\": %ld, \"fft2\": %d, \"threads\": %d, \"fft1_batch\": %d, \"warm_blocks\": %d, "
+             "\"topology\": \"rx input thread (producer hook) + dispatcher + %d fft1_b workers + timf2 + second_fft + narrowband threads\", \"stage_calls\": {",
+             dt, (total - warm) * shim_batch, (long)(total - warm) * shim_batch * fft1_new_points, TH.nfft2 - nfft2_warm, workers + 5, shim_batch, warm * shim_batch, workers);
+      for (int k = 0; k < SG_N; k++) printf("%s\"%s\": {\"calls\": %ld, \"us_per_call\": %.2f, \"busy_frac\": %.3f}", k ? ", " : "", sg_name[k], sg_calls[k],
+                                            sg_calls[k] ? 1e6 * sg_sec[k] / sg_calls[k] : 0.0, sg_sec[k] / dt);
+      printf("}}\n");
+      hip_close(); fclose(fo);
+      return harness_err ? 3 : 0;
+    }
     run_reference_threads();
     nfft2 = TH.nfft2;
     goto run_done;

@@ -60,6 +60,13 @@ static inline int shim_no_wait(lro_ctx *c) { (void)c; return 0; }
 static inline int shim_no_register(lro_ctx *c, void *p, size_t n) { (void)c; (void)p; (void)n; return 0; }
 static inline int shim_no_unregister(lro_ctx *c, void *p) { (void)c; (void)p; return 0; }
 #define lrh_timf1_write_wait shim_no_wait
+#define lrh_sync shim_no_wait        /* the oracle's calls are synchronous */
+static inline int shim_no_stage_wait(lro_ctx *c, int stage) { (void)c; (void)stage; return 0; }
+#define lrh_stage_wait shim_no_stage_wait
+static inline int shim_export_begin(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, int *ticket) { *ticket = 0; return lro_export(c, ring, dst, off, cnt); }
+static inline int shim_export_end(lro_ctx *c, int ticket) { (void)c; (void)ticket; return 0; }
+#define lrh_export_begin shim_export_begin
+#define lrh_export_end shim_export_end
 #define lrh_host_register shim_no_register
 #define lrh_host_unregister shim_no_unregister
 #endif
