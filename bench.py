@@ -68,13 +68,14 @@ def measured_traffic(stage, wl):
     if "t" not in _TRAFFIC:
         _TRAFFIC["t"] = None
         try:
-            for fn in ("r04_traffic.json", "r03_traffic.json"):
+            for fn in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
                 f = os.path.join(ROOT, "profiles", fn)
                 if not os.path.exists(f):
                     continue
                 t = json.load(open(f))
                 if t.get("source_sha16") == source_sha16():
                     _TRAFFIC["t"], _TRAFFIC["file"] = t, fn
+                    _TRAFFIC["stale"] = False
                     break
                 _TRAFFIC["stale"] = True
         except Exception:  # noqa: BLE001
@@ -782,6 +783,17 @@ def main():
         cpu = cpu_reference(args, cw) or cpu_port
         cpu_threads = cpu_reference(args, cw, threads=-1)
         cpu_all = cpu_baseline_all_cores(args, cw)
+    # fourth object of the default run: the drop-in's own rate (patched reference objects + hipshim.c + liblinrad_hip.so as child
+    # processes, one per gpu.fft1_batch_n; this process is idle meanwhile) for configs[2] and configs[1]
+    glue = None
+    if rank == 0 and world == 1 and default_run and not args.no_glue:
+        try:
+            glue = [glue_rate(args, make_workload("c2", args.fft1_n, args.fft2_n, args.fft3_n, args.mix2_n)),
+                    glue_rate(args, make_workload("c1", args.fft1_n, 12, 0, 0))]
+            if glue[0] is None:
+                glue = None
+        except Exception as e:  # noqa: BLE001
+            glue = {"error": repr(e)}
     if dist is not None:
         dist.barrier()
         nranks = dist.get_world_size()
@@ -809,7 +821,7 @@ def main():
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
             "routing": res.get("routing"), "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
-            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary, "full_rings": full_rings,
+            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary, "full_rings": full_rings, "glue": glue,
         }
         print(json.dumps(out), flush=True)
     return 0

@@ -53,9 +53,15 @@ static int hip_n1, hip_n2, hip_max_batch;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
 static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
 static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins store_new_spur was last asked to take */
+static lrh_spur *hip_sp; static int *hip_spsrc; static int hip_spcap;   /* scratch of the spur hooks: genparm[MAX_NO_OF_SPURS] + 1 entries (buf.c:1102 clamps the parameter
+                                                                          to fftx_size / SPUR_WIDTH), allocated by hip_open; the hooks run on THREAD_SECOND_FFT / spur_removal only */
+static pthread_mutex_t hip_phasing_lock = PTHREAD_MUTEX_INITIALIZER;    /* hip_ch2_c1 / _c2: up to six fft1_b workers compare and update them */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 static int hip_xgather(int which, size_t count);
+static void hip_open_failed(void);
+static int hip_ss_ticket[8], hip_ss_n;     /* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
+static int hip_wf_ticket[6], hip_wf_n;     /* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
 static void hip_ss_collect(void);
 static void hip_wf_collect(void);
 lrh_ctx *hip_context(void) { return hip_rx; }
@@ -135,7 +141,7 @@ int hip_open(void)
       if (hip_real2) { c.timf1_frame_channels = 1; c.timf1_bytes = timf1_bytes / 2; }   /* its own de-interleaved arena */
       c.timf3_size = timf3_size / 2; c.timf2_blockpower_block = timf2_blockpower_block / 2;
     }
-    if ((rc = lrh_open(&c, &hip_ctx[ch])) != 0) { if (ch) lrh_close(hip_ctx[0]); hip_ctx[0] = hip_ctx[1] = NULL; hip_rx = NULL; return rc; }
+    if ((rc = lrh_open(&c, &hip_ctx[ch])) != 0) { hip_ctx[ch] = NULL; hip_rx = hip_ctx[0]; hip_open_failed(); return rc; }
     if (HC == 1) lrh_set_filtercorr(hip_ctx[ch], fft1_filtercorr);  /* the calibration Linrad loaded (fft1.c:4653-5386) */
     else {                                                         /* two channels: {ch0, ch1} per bin (fft1.c:4132-4145) */
       float *f = hip_scratch(2 * (size_t)fft1_size);
@@ -149,27 +155,46 @@ int hip_open(void)
   hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
   hip_spurs_on = genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
-  if (hip_spurs_on && lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { lrh_close(hip_rx); hip_rx = NULL; return LRH_EINVAL; }
+  if (hip_spurs_on) {
+    hip_spcap = genparm[MAX_NO_OF_SPURS] + 1;
+    hip_sp = malloc(sizeof(lrh_spur) * (size_t)hip_spcap); hip_spsrc = malloc(sizeof(int) * (size_t)hip_spcap);
+    if (!hip_sp || !hip_spsrc) { hip_open_failed(); return LRH_ENOMEM; }
+    if (lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { hip_open_failed(); return LRH_EINVAL; }
+  }
   if (HC == 2 && fft1_correlation_flag == 1)
-    for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_close(); return LRH_EINVAL; }
-  if (hip_real2) for (int ch = 0; ch < 2; ch++) { hip_deint[ch] = malloc((size_t)timf1_bytes / 2); if (!hip_deint[ch]) { hip_close(); return LRH_ENOMEM; } lrh_host_register(hip_ctx[ch], hip_deint[ch], (size_t)timf1_bytes / 2); }
+    for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_open_failed(); return LRH_EINVAL; }
+  if (hip_real2) for (int ch = 0; ch < 2; ch++) { hip_deint[ch] = malloc((size_t)timf1_bytes / 2); if (!hip_deint[ch]) { hip_open_failed(); return LRH_ENOMEM; } lrh_host_register(hip_ctx[ch], hip_deint[ch], (size_t)timf1_bytes / 2); }
   else
   for (int ch = 0; ch < HC; ch++) lrh_host_register(hip_ctx[ch], timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
   return 0;
 }
 
-void hip_close(void)
+/* Everything hip_open has made so far goes: contexts (hip_rx may still be NULL when the failure came before it was set), page-locks, scratch.
+   hip_close is the same with the pending read-backs collected first. */
+static void hip_release(void)
 {
-  if (!hip_rx) return;
-  hip_ss_collect(); hip_wf_collect();
   hip_clever_mode = 0;
-  for (int ch = 0; ch < HC; ch++) if (hip_ctx[ch]) { lrh_timf1_write_wait(hip_ctx[ch]); lrh_host_unregister(hip_ctx[ch], hip_real2 && hip_deint[ch] ? (void *)hip_deint[ch] : (void *)timf1_char); lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL; }
+  for (int ch = 0; ch < 2; ch++) if (hip_ctx[ch]) {
+    lrh_timf1_write_wait(hip_ctx[ch]);
+    lrh_host_unregister(hip_ctx[ch], hip_real2 && hip_deint[ch] ? (void *)hip_deint[ch] : (void *)timf1_char);    /* not registered yet: refused, harmless */
+    lrh_close(hip_ctx[ch]); hip_ctx[ch] = NULL;
+  }
   for (int ch = 0; ch < 2; ch++) { free(hip_deint[ch]); hip_deint[ch] = NULL; }
   hip_real2 = 0;
   hip_rx = NULL; HC = 1;
   free(hip_xa); free(hip_xb); hip_xa = hip_xb = NULL; hip_xcap = 0;
   free(hip_liminfo_sent); hip_liminfo_sent = NULL;
   free(hip_afc_tmp); hip_afc_tmp = NULL;
+  free(hip_sp); free(hip_spsrc); hip_sp = NULL; hip_spsrc = NULL; hip_spcap = 0;
+  hip_spurs_on = 0; hip_spur_pnt = -1;
+}
+static void hip_open_failed(void) { hip_ss_n = 0; hip_wf_n = 0; hip_release(); }
+
+void hip_close(void)
+{
+  if (!hip_rx) return;
+  hip_ss_collect(); hip_wf_collect();
+  hip_release();
 }
 
 void hip_timf1_new(int pa, int nbytes)
@@ -195,9 +220,13 @@ int hip_fft1_b(int timf1p_ref, float *out, int gpu_handle_number)
   const int handle = no_of_fft1b > 0 ? gpu_handle_number + 1 : 0;
   int rc = 0;
   /* (two real channels: fft1_reherm_dit_two leaves through `goto fft_done` before the phasing step, fft1_re.c:133-231) */
-  if (HC == 2 && !hip_real2 && (pg_ch2_c1 != hip_ch2_c1 || pg_ch2_c2 != hip_ch2_c2)) {       /* phasing of channel 2, fft1.c:4064-4080 (pol_graph.c:160-170 sets it) */
-    hip_ch2_c1 = pg_ch2_c1; hip_ch2_c2 = pg_ch2_c2;
-    lrh_set_ch2_phasing(hip_ctx[1], hip_ch2_c1, hip_ch2_c2);
+  if (HC == 2 && !hip_real2) {                               /* phasing of channel 2, fft1.c:4064-4080 (pol_graph.c:160-170 sets it) */
+    pthread_mutex_lock(&hip_phasing_lock);
+    if (pg_ch2_c1 != hip_ch2_c1 || pg_ch2_c2 != hip_ch2_c2) {
+      hip_ch2_c1 = pg_ch2_c1; hip_ch2_c2 = pg_ch2_c2;
+      lrh_set_ch2_phasing(hip_ctx[1], hip_ch2_c1, hip_ch2_c2);
+    }
+    pthread_mutex_unlock(&hip_phasing_lock);
   }
   for (int ch = 0; ch < HC && !rc; ch++) rc = lrh_fft1_b(hip_ctx[ch], handle, hip_real2 ? timf1p_ref / 2 : timf1p_ref, HIP_IN((int)(out - fft1_float)), gpu_fft1_batch_size);
   return rc;
@@ -231,8 +260,6 @@ static void hip_afc_rows(int first_row, int rows)
   }
 }
 
-/* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
-static int hip_ss_ticket[8], hip_ss_n;
 static void hip_ss_collect(void)
 {
   for (int i = 0; i < hip_ss_n; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[i]) != 0) lirerr(1466);
@@ -496,14 +523,26 @@ int hip_fft2_update_liminfo(void)
    out of the spur_speknum transforms already in the ring) -- subtraction starts with the next transform. ---- */
 static void hip_spur_state_back(void)
 {
-  lrh_spur sp[64];
+  lrh_spur *sp = hip_sp;
   int n = 0, i;
-  if (lrh_spur_get(hip_rx, 64, sp, &n) != 0) { lirerr(1480); return; }
+  if (lrh_spur_get(hip_rx, hip_spcap, sp, &n) != 0) { lirerr(1480); return; }
   for (i = 0; i < n && i < genparm[MAX_NO_OF_SPURS]; i++) {
     spur_location[i] = sp[i].spur_location; spur_flag[i] = sp[i].spur_flag; spur_freq[i] = sp[i].spur_freq;
     spur_d0pha[i] = sp[i].spur_d0pha; spur_d1pha[i] = sp[i].spur_d1pha; spur_d2pha[i] = sp[i].spur_d2pha;
     spur_ampl[i] = sp[i].spur_ampl; spur_noise[i] = sp[i].spur_noise; spur_avgd2[i] = sp[i].spur_avgd2;
   }
+}
+/* Linrad drops the LAST spur of its list by counting no_of_spurs down and nothing else (init_spur_elimination, spursub.c:331-335: remove_spur --
+   the hooked function -- is called only when the dropped one is not the last).  The device's list is therefore cut back to Linrad's count
+   before every acquisition and after every transform; otherwise it would keep subtracting the dropped carrier and the next acquisition
+   would land one slot past the one Linrad reads. */
+static void hip_spur_resync(void)
+{
+  int n = 0, i;
+  if (lrh_spur_get(hip_rx, hip_spcap, hip_sp, &n) != 0) { lirerr(1480); return; }
+  if (n <= no_of_spurs) return;
+  for (i = 0; i < no_of_spurs; i++) hip_spsrc[i] = i;
+  if (lrh_spur_permute(hip_rx, no_of_spurs, hip_spsrc) != 0) lirerr(1481);
 }
 int hip_store_new_spur(int pnt) { hip_spur_pnt = pnt; return 0; }      /* the history is taken on the device, by hip_spur_phase_lock */
 int hip_spur_phase_lock(int nx)
@@ -511,6 +550,7 @@ int hip_spur_phase_lock(int nx)
   lrh_ptrs q;
   int locked = 0;
   if (hip_spur_pnt < 0) return 1;
+  hip_spur_resync();
   memset(&q, 0, sizeof q);
   q.fft2_na = nx;                                                      /* ffts_na: the ring position behind the newest transform (wcw.c:288-289) */
   if (lrh_spur_acquire(hip_rx, &q, hip_spur_pnt, &locked) != 0) locked = 0;
@@ -521,17 +561,17 @@ int hip_spur_phase_lock(int nx)
 }
 void hip_remove_spur(int ia)                                           /* remove_spur(ia): the last spur (number no_of_spurs, already counted down) takes slot ia */
 {
-  int src[64], i;
-  for (i = 0; i < no_of_spurs && i < 64; i++) src[i] = i;
+  int *src = hip_spsrc, i;
+  if (no_of_spurs >= hip_spcap) { lirerr(1481); return; }
+  for (i = 0; i < no_of_spurs; i++) src[i] = i;
   if (ia >= 0 && ia < no_of_spurs) src[ia] = no_of_spurs;
   if (lrh_spur_permute(hip_rx, no_of_spurs, src) != 0) lirerr(1481);
   hip_spur_state_back();
 }
 void hip_swap_spurs(int ia, int ib)
 {
-  int src[64], i, n = 0;
-  lrh_spur sp[64];
-  if (lrh_spur_get(hip_rx, 64, sp, &n) != 0 || ia >= n || ib >= n) return;
+  int *src = hip_spsrc, i, n = 0;
+  if (lrh_spur_get(hip_rx, hip_spcap, hip_sp, &n) != 0 || ia >= n || ib >= n) return;
   for (i = 0; i < n; i++) src[i] = i;
   src[ia] = ib; src[ib] = ia;
   if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481);
@@ -543,11 +583,12 @@ void hip_swap_spurs(int ia, int ib)
 static void hip_spur_after_fft2(int na)
 {
   int i;
+  hip_spur_resync();
   if (no_of_spurs > 0) {
-    int n = 0, src[64];
+    int n = 0, *src = hip_spsrc;
     hip_spur_state_back();
     if (genparm[AFC_ENABLE] == 2) {
-      for (i = 0; i < no_of_spurs && i < 64; i++) if (spur_flag[i] < spur_speknum) src[n++] = i;
+      for (i = 0; i < no_of_spurs && i < hip_spcap; i++) if (spur_flag[i] < spur_speknum) src[n++] = i;
       if (n != no_of_spurs) { if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481); no_of_spurs = n; hip_spur_state_back(); }
     }
   }
@@ -569,8 +610,6 @@ static void hip_spur_after_fft2(int na)
   }
 }
 
-/* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
-static int hip_wf_ticket[6], hip_wf_n;
 static void hip_wf_collect(void)
 {
   for (int i = 0; i < hip_wf_n; i++) if (lrh_export_end(hip_rx, hip_wf_ticket[i]) != 0) lirerr(1469);

@@ -539,7 +539,7 @@ int lro_fft1_b(lro_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
 int lro_export_fft1_net(lro_ctx *c, float *dst, int timf1p_ref, int batch)
 {
   if (!c || !dst || batch < 1) return LRH_EINVAL;
-  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4);
+  int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4) * (c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1);   /* whole frames, as lro_fft1_b steps */
   for (int b = 0; b < batch; b++) fft1_one(c, (timf1p_ref + b * blockbytes) & c->timf1_bytemask, dst + (size_t)b * 2 * c->N1);
   return LRH_OK;
 }
