@@ -445,6 +445,20 @@ __global__ __launch_bounds__(fft1_threads(LOG2N), fft_min_waves(LOG2N)) void k_t
   constexpr int N = Plan::N, T = Plan::T, R0 = Plan::R0, NB0 = P / R0;
   __shared__ float2 lds[Fft::LDS_CELLS];
   const int tid0 = threadIdx.x;
+  if constexpr (STRONG_ONLY) {
+    if (a.sd_kmax > 0) {                                 // a handful of strong bins: k_timf2_sd (launched in front) has written this launch's samples
+      __shared__ int s_strong;
+      if (tid0 == 0) s_strong = 0;
+      __syncthreads();
+      int n = 0;
+#pragma unroll
+      for (int m = 0; m < NB0; m++) n += __popc(~(a.pack_cur[tid0 + m * T] & a.pack_prev[tid0 + m * T]) & ((1u << R0) - 1u));   // strong under either table, as k_timf2_sd counts
+      for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+      if ((tid0 & 63) == 0 && n) atomicAdd(&s_strong, n);
+      __syncthreads();
+      if (s_strong <= a.sd_kmax) return;                 // (before the tables go to the LDS: the launch then costs a few microseconds)
+    }
+  }
   Fft::init(lds, a.tw, tid0);
   // weak/strong routing flags, packed by the host per first-pass butterfly: bit s of pack[i] is set when bin
   // i + s*(N/R0) is weak (liminfo == 0, timf2.c:50).  One dword per thread instead of R0 float loads; the same
@@ -2896,6 +2910,10 @@ hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a0, hipStream_t 
 hipError_t launch_timf2_strong(int log2n, const Timf2Args &a0, int batch, hipStream_t st)
 {
   Timf2Args a = a0; a.batch = batch; a.ss_ring = nullptr;
+  // the direct sum first (it takes the launch when at most LRH_SD_KMAX bins are routed strong; LRH_SD=0: the transform kernel always)
+  const char *sde_ = getenv("LRH_SD"); const int sd_ = sde_ ? atoi(sde_) : 1;      // (read per launch: tests/test_gpu_fused.py flips it)
+  a.sd_kmax = sd_ ? LRH_SD_KMAX : 0;
+  if (a.sd_kmax) { const hipError_t e = launch_timf2_sd(log2n, a, st); if (e != hipSuccess) return e; }
   switch (log2n) {
     case 14: hipLaunchKernelGGL((k_timf2<14, 1, false, true>), dim3(fftl_grid<14>(batch, a.spare_cus)), dim3(fft1_threads(14)), 0, st, a); break;
     case 13: hipLaunchKernelGGL((k_timf2<13, 1, false, true>), dim3(fftl_grid<13>(batch, a.spare_cus)), dim3(fft1_threads(13)), 0, st, a); break;

@@ -74,6 +74,8 @@ struct Timf2Args {
   float *ss_ring, *ss_part; int ss_mask, ss_avg, ss_c0, ss_pa0, ss_run;
   int ss_split;             // a launch of ONE transform: two workgroups, one per stream (each adds its own stream's bins to the sums)
   int spare_cus;            // compute units left free for side-stream kernels (see persistent_grid)
+  int sd_kmax;              // strong-only pass: the launch has been offered to k_timf2_sd first, which takes it when no more than this many bins
+                            // are routed strong (0: not offered) -- the transform kernel then returns at once (set by launch_timf2_strong)
 };
 
 // ---- fft1_b + fft1_c's sums + the weak stream of make_timf2 in one kernel (k_fft1w, fft1_size 16384) ----
@@ -96,6 +98,8 @@ struct Fft1wArgs {
 hipError_t launch_fft1w(const Fft1wArgs &a, hipStream_t st, int *run);
 hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a, hipStream_t st, int *run);
 hipError_t launch_timf2_strong(int log2n, const Timf2Args &a, int batch, hipStream_t st);
+constexpr int LRH_SD_KMAX = 128;           // strong bins k_timf2_sd (lrh_timf2_sd.hip) takes; more: the transform kernel
+hipError_t launch_timf2_sd(int log2n, const Timf2Args &a, hipStream_t st);   // a.batch set; returns at once on the device when too many bins are strong
 
 // fft1_size 32768 (the reference's maximum with the second fft on, buf.c:335): one block no longer fits a workgroup's LDS, so
 // fft1 and timf2 take the four-step form of the large fft2 (column transforms, step twiddle, row transforms through an HBM scratch)

@@ -9,6 +9,14 @@
  * accumulators, truncating conversions) the reference order is kept on purpose.
  */
 #include "linrad_oracle.h"
+typedef float f32;                 /* the ABI's float, whatever the arithmetic below runs in */
+#ifdef LRO_F64
+/* liblinrad_oracle64.so (make oracle64): the same source with every `float` below a double -- tables, rings, accumulators.  It is the
+   "truth" the parity tests measure BOTH float32 implementations against (the compiled reference's goldens and the HIP path):
+   tests/golden/make_truth.py, tests/paritylib.py.  The ABI is unchanged: arrays cross the boundary as float32 (f32) and are
+   converted there; lro_export_f64 hands out the rings unrounded. */
+#define float double
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +28,14 @@
 #define FFT2_WATERFALL_ZERO 0.012 /* graphcal.h:8 */
 
 typedef struct { float sin, cos; } cosin_t;   /* COSIN_TABLE, globdef.h */
+/* arrays across the ABI: plain copies in the float32 build, conversions in the float64 one */
+static void in_f32(float *dst, const f32 *src, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = src[i]; }
+static void out_f32(f32 *dst, const float *src, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = (f32)src[i]; }
+#ifdef LRO_F64
+#define LRO_F32_ONLY(c) return LRH_ESTATE      /* entry points the truth build does not serve (their hand-over is float32 memory) */
+#else
+#define LRO_F32_ONLY(c) do { } while (0)
+#endif
 
 struct lro_ctx {
   lrh_config cfg;
@@ -53,6 +69,7 @@ struct lro_ctx {
   float *timf2_float, *timf2_pwr;
   float *fft2_float, *fft2_power, *fft2_powersum;
   int16_t *wg_waterf;
+  double *wf_pre;              /* float64 build only: the waterfall lines before the truncation to short, same places as wg_waterf */
   float *timf3_float;
   float *timf2_blockpower;
   /* fft3 / mix2 */
@@ -69,7 +86,7 @@ struct lro_ctx {
   lrh_sellim wl_par; int wl_on, wl_fft2, wl_cnt1, wl_cnt2;   /* lro_wideband_limiter */
   lrh_exchange_fn xfn; void *xuser;                          /* lro_set_exchange */
   int corr_on, slowcorr_tot_avgnum; float *xspec, *fft1_corrsum, *fft1_slowcorr; double *fft1_slowcorr_tot;   /* lro_set_correlation */
-  lrh_blanker_tables bt; float *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
+  lrh_blanker_tables bt; f32 *bt_refpulse, *bt_phasefunc; int *bt_pulindex; unsigned char *blanker_flag; int clever_on;
   /* mix1 scalars (selvar.c) */
   lrh_mix1_state ms;
   double old_mix1_selfreq;
@@ -86,7 +103,17 @@ static void make_sincos(int size, cosin_t *tab)
 
 /* make_window, fft0.c:812-921.  mo: 1 interleaved half storage, 3 inverted, 4 full symmetric,
    5 erfc edge (sz/2+1 points).  n: sin power 1..7, 8 Gaussian, 9 erfc. */
-void lro_make_window(int mo, int sz, int n, float *win)
+static void make_window(int mo, int sz, int n, float *win);
+void lro_make_window(int mo, int sz, int n, f32 *win)
+{
+  const size_t cnt = (size_t)(mo == 2 ? sz + 1 : (mo == 5 || mo == 3) ? sz / 2 + 1 : sz);
+  float *t = calloc(cnt + 2, sizeof(float));
+  in_f32(t, win, cnt);                 /* (n == 0 leaves the caller's array as it was) */
+  make_window(mo, sz, n, t);
+  out_f32(win, t, cnt);
+  free(t);
+}
+static void make_window(int mo, int sz, int n, float *win)
 {
   double x, z, sumsq = 0, e1, e2;
   int i, size = sz;
@@ -205,26 +232,36 @@ static void bitrev_inplace(int N, int n, float *x, int stride)
   }
 }
 
-void lro_fft_forward(int n, float *x)
+static void fft_natural(int n, float *x, int dir)
 {
   int N = 1 << n; cosin_t *tab = malloc(sizeof(cosin_t) * (N / 2 + 1)); make_sincos(N, tab);
-  dif_stages(N, n, x, tab, -1, 2); bitrev_inplace(N, n, x, 2); free(tab);
+  dif_stages(N, n, x, tab, dir, 2); bitrev_inplace(N, n, x, 2); free(tab);
 }
-void lro_fft_backward(int n, float *x)
+static void fft_abi(int n, f32 *x, int dir)
 {
-  int N = 1 << n; cosin_t *tab = malloc(sizeof(cosin_t) * (N / 2 + 1)); make_sincos(N, tab);
-  dif_stages(N, n, x, tab, +1, 2); bitrev_inplace(N, n, x, 2); free(tab);
+  const size_t cnt = (size_t)2 << n;
+  float *t = malloc(sizeof(float) * cnt);
+  in_f32(t, x, cnt); fft_natural(n, t, dir); out_f32(x, t, cnt); free(t);
 }
+void lro_fft_forward(int n, f32 *x) { fft_abi(n, x, -1); }
+void lro_fft_backward(int n, f32 *x) { fft_abi(n, x, +1); }
 
 /* ------------------------------------------------------------------ open / close */
 
 static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+#ifdef LRO_F64
+static void *zal(size_t n) { return calloc(2 * n + 64, 1); }     /* byte counts below are written for 4-byte floats */
+#else
 static void *zal(size_t n) { return calloc(n + 64, 1); }
+#endif
 
 int lro_open(const lrh_config *cfg, lro_ctx **out)
 {
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;
+#ifdef LRO_F64
+  if (cfg->blanker_channels == 2) return LRH_EINVAL;       /* the truth build serves the single-channel chain */
+#endif
   if (cfg->fft1_n < 6 || cfg->fft1_n > 16 || cfg->fft2_n < 6 || cfg->fft2_n > 22) return LRH_EINVAL;
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) ||
       !ispow2(cfg->timf2pow_size) || !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size)) return LRH_EINVAL;
@@ -268,6 +305,9 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   c->fft2_float = zal(sizeof(float) * 2 * N2 * cfg->max_fft2n); c->fft2_power = zal(sizeof(float) * N2 * cfg->max_fft2n);
   c->fft2_powersum = zal(4 * N2);
   c->wg_waterf = zal(2 * (size_t)cfg->wf_lines * cfg->wf_xpixels + 64);
+#ifdef LRO_F64
+  c->wf_pre = calloc((size_t)cfg->wf_lines * cfg->wf_xpixels + 16, sizeof(double));
+#endif
   c->timf3_float = zal(4 * (size_t)cfg->timf3_size + 16 * c->Nm);
   c->timf2_blockpower = zal(4 * (size_t)(cfg->timf2_blockpower_size > 0 ? cfg->timf2_blockpower_size : 1));
   if (cfg->fft3_n > 0) {
@@ -281,21 +321,21 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
     c->fft3_window = zal(4 * (c->N3 + 8)); c->fft3 = zal(sizeof(float) * 2 * c->N3 * cfg->max_fft3n);
     c->bg_filterfunc = zal(4 * c->N3); c->baseb_raw = zal(8 * (size_t)cfg->baseband_size + 16 * c->Nm2);
     make_sincos(c->N3, c->fft3tab); make_sincos(c->Nm2, c->mix2tab);
-    if (cfg->fft3_sinpow) lro_make_window(1, c->N3, cfg->fft3_sinpow, c->fft3_window);     /* baseb_graph.c:3680 */
+    if (cfg->fft3_sinpow) make_window(1, c->N3, cfg->fft3_sinpow, c->fft3_window);     /* baseb_graph.c:3680 */
     for (int i = 0; i < c->N3; i++) c->bg_filterfunc[i] = 1.0f;
   }
   c->tmp = zal(sizeof(float) * 8 * (NM > (1 << cfg->fft3_n) ? NM : (1 << cfg->fft3_n)));
   make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
-  if (cfg->fft1_sinpow) lro_make_window(cfg->timf1_real_input ? 2 : 1, N1, cfg->fft1_sinpow, c->fft1_window);   /* fft_cntrl[].window, fft1var.c:45,50 */
-  if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) lro_make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
-  if (cfg->fft2_sinpow) lro_make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
-  lro_make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
+  if (cfg->fft1_sinpow) make_window(cfg->timf1_real_input ? 2 : 1, N1, cfg->fft1_sinpow, c->fft1_window);   /* fft_cntrl[].window, fft1var.c:45,50 */
+  if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
+  if (cfg->fft2_sinpow) make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
+  make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
   {                                                        /* prepare_mixer, buf.c:55-111 */
     const int sp = cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow;
     c->mix1_window = zal(4 * (c->Nm + 8)); c->mix1_sin2win = zal(4 * (c->Nm + 8)); c->mix1_cos2win = zal(4 * (c->Nm + 8));
     c->Xm = 0;
     if (sp != 0 && sp != 2) {
-      lro_make_window(3, c->Nm, sp, c->mix1_window);
+      make_window(3, c->Nm, sp, c->mix1_window);
       if (sp == 9) c->Xm = c->Nm / 8;
       else if (sp == 8) c->Xm = c->Nm / 16;
       else {
@@ -334,7 +374,7 @@ void lro_close(lro_ctx *c)
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
                 c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xweak, c->tf_partner, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
-                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag };
+                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag, c->wf_pre };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
     struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; float *rn; int *rf, *rl; } *s = c->sellim;
@@ -357,19 +397,19 @@ int lro_get_derived(const lro_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t
   return LRH_OK;
 }
 
-int lro_set_filtercorr(lro_ctx *c, const float *fc) { if (fc) memcpy(c->fft1_filtercorr, fc, 8 * c->N1); else default_filtercorr(c); return LRH_OK; }
-int lro_set_liminfo(lro_ctx *c, const float *l) { memcpy(c->liminfo, l, 4 * c->N1); return LRH_OK; }
-int lro_set_ch2_phasing(lro_ctx *c, float c1, float c2) { c->ch2_c1 = c1; c->ch2_c2 = c2; c->ch2_set = 1; return LRH_OK; }
-int lro_set_foldcorr(lro_ctx *c, const float *foldcorr)
+int lro_set_filtercorr(lro_ctx *c, const f32 *fc) { if (fc) in_f32(c->fft1_filtercorr, fc, 2 * (size_t)c->N1); else default_filtercorr(c); return LRH_OK; }
+int lro_set_liminfo(lro_ctx *c, const f32 *l) { in_f32(c->liminfo, l, c->N1); return LRH_OK; }
+int lro_set_ch2_phasing(lro_ctx *c, f32 c1, f32 c2) { c->ch2_c1 = c1; c->ch2_c2 = c2; c->ch2_set = 1; return LRH_OK; }
+int lro_set_foldcorr(lro_ctx *c, const f32 *foldcorr)
 {
   if (!foldcorr) { free(c->fft1_foldcorr); c->fft1_foldcorr = NULL; return LRH_OK; }
   if (!c->fft1_foldcorr) c->fft1_foldcorr = malloc(sizeof(float) * 2 * c->N1);
-  memcpy(c->fft1_foldcorr, foldcorr, sizeof(float) * 2 * c->N1);
+  in_f32(c->fft1_foldcorr, foldcorr, 2 * (size_t)c->N1);
   return LRH_OK;
 }
-int lro_set_waterfall_yfac(lro_ctx *c, const float *y) { if (y) memcpy(c->wg_waterf_yfac, y, 4 * c->N1); else default_yfac(c); return LRH_OK; }
+int lro_set_waterfall_yfac(lro_ctx *c, const f32 *y) { if (y) in_f32(c->wg_waterf_yfac, y, c->N1); else default_yfac(c); return LRH_OK; }
 
-int lro_get_table(lro_ctx *c, const char *name, float *dst, int count)
+int lro_get_table(lro_ctx *c, const char *name, f32 *dst, int count)
 {
   const float *src = NULL; int n = 0;
   if (!strcmp(name, "fft1_window")) { src = c->fft1_window; n = c->N1; }
@@ -381,7 +421,7 @@ int lro_get_table(lro_ctx *c, const char *name, float *dst, int count)
   else if (!strcmp(name, "fft3_window")) { src = c->fft3_window; n = c->N3; }
   else return LRH_EINVAL;
   if (count > n) count = n;
-  memcpy(dst, src, 4 * (size_t)count); return count;
+  out_f32(dst, src, (size_t)count); return count;
 }
 
 int lro_timf1_write(lro_ctx *c, const void *src, int off, int nbytes)
@@ -434,7 +474,7 @@ static void fft1_one_real(lro_ctx *c, int timf1p_ref, float *out)
     z[2 * ia] = (dword ? (float)t32[pa] : (float)c->timf1[pa]) * w; z[2 * ia + 1] = 0;
     pa = (pa + 1) & m;
   }
-  lro_fft_forward(n + 1, z);
+  fft_natural(n + 1, z, -1);
   if (c->cfg.fft1_direction > 0) {
     out[0] = z[2 * N]; out[1] = z[0];
     for (int k = 1; k < N; k++) { out[2 * k] = z[2 * k + 1]; out[2 * k + 1] = z[2 * k]; }
@@ -536,11 +576,13 @@ int lro_fft1_b(lro_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
 
 /* NET_RXOUT_FFT1 payload (wcw.c:1024-1043, network.c:383-388): the transforms as fft1_b leaves them, i.e. without the filter correction
    that lro_fft1_b folds into its store; recomputed from the timf1 ring like lrh_export_fft1_net does */
-int lro_export_fft1_net(lro_ctx *c, float *dst, int timf1p_ref, int batch)
+int lro_export_fft1_net(lro_ctx *c, f32 *dst, int timf1p_ref, int batch)
 {
   if (!c || !dst || batch < 1) return LRH_EINVAL;
   int blockbytes = c->M1 * (c->cfg.timf1_dword_input ? 8 : 4) * (c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1);   /* whole frames, as lro_fft1_b steps */
-  for (int b = 0; b < batch; b++) fft1_one(c, (timf1p_ref + b * blockbytes) & c->timf1_bytemask, dst + (size_t)b * 2 * c->N1);
+  float *t = malloc(sizeof(float) * 2 * c->N1);
+  for (int b = 0; b < batch; b++) { fft1_one(c, (timf1p_ref + b * blockbytes) & c->timf1_bytemask, t); out_f32(dst + (size_t)b * 2 * c->N1, t, 2 * (size_t)c->N1); }
+  free(t);
   return LRH_OK;
 }
 
@@ -583,6 +625,7 @@ static void update_fft1_slowsum(lro_ctx *c, lrh_ptrs *p)
    transforms exchanged through LRH_X_SPEC (include/linrad_hip.h) */
 int lro_set_correlation(lro_ctx *c, int on)
 {
+  LRO_F32_ONLY(c);
   if (!c || c->cfg.blanker_channels != 2) return LRH_ESTATE;
   free(c->xspec); free(c->fft1_corrsum); free(c->fft1_slowcorr); free(c->fft1_slowcorr_tot);
   c->xspec = NULL; c->fft1_corrsum = NULL; c->fft1_slowcorr = NULL; c->fft1_slowcorr_tot = NULL;
@@ -787,14 +830,16 @@ int lro_exchange_ptr(lro_ctx *c, int which, void **ptr)
   *ptr = which == LRH_X_PWR ? (void *)c->xbuf : which == LRH_X_STAT ? (void *)c->xstat : which == LRH_X_BINS ? (void *)c->xbins : (void *)c->xpol;
   return LRH_OK;
 }
-int lro_exchange_read(lro_ctx *c, int which, float *dst, size_t off, size_t count)
+int lro_exchange_read(lro_ctx *c, int which, f32 *dst, size_t off, size_t count)
 {
+  LRO_F32_ONLY(c);
   void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
   if (off + count > exchange_cap(c, which)) return LRH_EINVAL;
   memcpy(dst, (float *)q + off, 4 * count); return LRH_OK;
 }
-int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size_t count)
+int lro_exchange_write(lro_ctx *c, int which, const f32 *src, size_t off, size_t count)
 {
+  LRO_F32_ONLY(c);
   void *q; int rc = lro_exchange_ptr(c, which, &q); if (rc) return rc;
   if (off + count > exchange_cap(c, which)) return LRH_EINVAL;
   memcpy((float *)q + off, src, 4 * count); return LRH_OK;
@@ -803,6 +848,7 @@ int lro_exchange_write(lro_ctx *c, int which, const float *src, size_t off, size
 /* ---- linear ("clever") blanker: blank1.c:36-232 (subtract_onechan_pulse), :615-682 (set_flag), :765-1003 (search loop) ---- */
 int lro_set_blanker_tables(lro_ctx *c, const lrh_blanker_tables *t)
 {
+  if (t) LRO_F32_ONLY(c);
   free(c->bt_refpulse); free(c->bt_phasefunc); free(c->bt_pulindex); free(c->blanker_flag); free(c->xweak); free(c->tf_partner);
   c->bt_refpulse = c->bt_phasefunc = NULL; c->bt_pulindex = NULL; c->blanker_flag = NULL; c->clever_on = 0; c->xweak = c->tf_partner = NULL;
   if (!t) return LRH_OK;
@@ -848,7 +894,7 @@ static float clever_subtract(lro_ctx *c, int p_max, int sub_size)
 {
   const int mask = c->timf2pow_mask, rs = c->bt.refpul_size, pwid = c->cfg.blanker_pulsewidth;
   float *tf = c->timf2_float, *pw = c->timf2_pwr;
-  const float *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
+  const f32 *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
   float in[2 * 257];
   int k = rs - 2 * pwid, i = 0;
   for (int q = p_max - pwid; q <= p_max + pwid; q++) {
@@ -914,7 +960,7 @@ static float clever_subtract2(lro_ctx *c, float *pw, int p_max, int sub_size)
   const int mask = c->timf2pow_mask, rs = c->bt.refpul_size, pwid = c->cfg.blanker_pulsewidth, ci = c->cfg.timf1_channel_index & 1;
   float *chp[2]; int chs[2];
   chp[ci] = c->timf2_float; chs[ci] = 4; chp[1 - ci] = c->tf_partner; chs[1 - ci] = 2;
-  const float *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
+  const f32 *phf = c->bt_phasefunc, *rp = c->bt_refpulse;
   float x2 = 0, y2 = 0, re_xy = 0, im_xy = 0;
   for (int q = p_max - pwid; q <= p_max + pwid; q++) {
     const int pos = q & mask;
@@ -1190,6 +1236,8 @@ static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p, const float *ps)
   int npix = c->cfg.wf_xpixels, siz = c->N2;
   int16_t *line = c->wg_waterf + p->wg_waterf_ptr;
   const float *yf = c->wg_waterf_yfac;
+  double *pre = c->wf_pre ? c->wf_pre + p->wg_waterf_ptr : NULL, v_;      /* float64 build: the values before the truncation to short */
+#define WF_PRE(k_, val_) do { if (pre && (k_) < npix) pre[k_] = (val_); } while (0)
   if (!ps) goto advance;                      /* coupled channels: the line is written by lro_fft2_xy_finish */
   float a2 = 1, a3; int y, itab, i;
   if (wx > 0) a2 = wx; else a2 = 1. / wp;
@@ -1198,27 +1246,27 @@ static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p, const float *ps)
     i = c->cfg.wf_first_xpoint;
     for (int ix = 0; ix < npix; ix++) {
       itab = a3; a3 += a2;
-      y = 1000. * log10(ps[i] * yf[itab]);
+      v_ = 1000. * log10(ps[i] * yf[itab]); y = v_; WF_PRE(ix, v_);
       if (y < -32767) y = -32767; if (y > 32767) y = 32767;
       line[ix] = y; i++;
     }
   } else if (hx == 0) {                       /* interpolate, fft2.c:739-783 */
     float yval, r1, der;
     i = c->cfg.wf_first_xpoint; itab = a3; a3 += a2;
-    y = 1000. * log10(ps[i] * yf[itab]); yval = y;
+    v_ = 1000. * log10(ps[i] * yf[itab]); y = v_; yval = y; WF_PRE(0, v_);
     if (y < -32767) y = -32767; if (y > 32767) y = 32767;
     line[0] = y; i++;
     int mlim = npix - hp, ix, k;
     for (ix = 0; ix < mlim; ix += hp) {
       itab = a3; a3 += a2;
       r1 = 1000. * log10(ps[i] * yf[itab]); der = (r1 - yval) / hp;
-      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; if (y < -32767) y = -32767; if (y > 32767) y = 32767; line[k] = y; }
+      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; WF_PRE(k, yval); if (y < -32767) y = -32767; if (y > 32767) y = 32767; line[k] = y; }
       yval = r1; i++;
     }
     if (i < siz) {
       itab = a3;
       r1 = 1000. * log10(ps[i] * yf[itab]); der = (r1 - yval) / hp;
-      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; if (y < -32767) y = -32767; if (y > 32767) y = 32767; if (k < npix) line[k] = y; }
+      for (k = ix + 1; k <= ix + hp; k++) { yval = yval + der; y = yval; WF_PRE(k, yval); if (y < -32767) y = -32767; if (y > 32767) y = 32767; if (k < npix) line[k] = y; }
     }
   } else {                                    /* max over a group, fft2.c:784-811 */
     int ia = c->cfg.wf_first_xpoint, ib = ia + hx;
@@ -1227,7 +1275,7 @@ static void fft2_waterfall_line(lro_ctx *c, lrh_ptrs *p, const float *ps)
       for (i = ia; i < ib; i++) { float r1 = ps[i]; if (r1 > r2) r2 = r1; }
       itab = a3; a3 += a2;
       float a1 = yf[itab];
-      y = 1000. * log10(a1 * r2);
+      v_ = 1000. * log10(a1 * r2); y = v_; WF_PRE(ix, v_);
       if (y < -32767) y = -32767; if (y > 32767) y = 32767;
       line[ix] = y;
       ia = ib; ib += hx; if (ib >= siz) ib = siz;
@@ -1323,12 +1371,12 @@ int lro_set_mix1_selfreq(lro_ctx *c, double fq) { c->ms.mix1_selfreq = fq; retur
 int lro_get_mix1_state(lro_ctx *c, lrh_mix1_state *st) { *st = c->ms; return LRH_OK; }
 
 /* set_mix1_phases, mix1.c:781-861 (float branch) */
-static int set_mix1_phases(lro_ctx *c, float fq)
+static int set_mix1_phases(lro_ctx *c, f32 fq)     /* host bookkeeping in float32 whatever the build: these scalars DEFINE what the mixer does */
 {
   lrh_mix1_state *s = &c->ms;
   if (fq < c->cfg.mix1_lowest_fq || fq > c->cfg.mix1_highest_fq) return LRH_ERANGE;
   int size = c->Nm;
-  float t1 = fq * c->cfg.fftx_points_per_hz, t2;
+  f32 t1 = fq * c->cfg.fftx_points_per_hz, t2;
   int pnt = t1 + 0.5;
   int k = pnt % size;
   t2 = size * (pnt / size);
@@ -1459,7 +1507,7 @@ int lro_fft2_mix1_fixed(lro_ctx *c, lrh_ptrs *p, int batch)
 #define BWFAC 0.03
 static void afc_tables(lro_ctx *c, lrh_afc *a, int nx, int na, int mask)
 {
-  float *fq = a->mix1_fq_mid, *dfq = a->mix1_fq_slope, *d2fq = a->mix1_fq_curv, *fqs = a->mix1_fq_start;
+  f32 *fq = a->mix1_fq_mid, *dfq = a->mix1_fq_slope, *d2fq = a->mix1_fq_curv, *fqs = a->mix1_fq_start;      /* the caller's tables: float32 in either build */
   int ka = (nx + mask) & mask, kb = (nx + 1) & mask;
   float t1 = fq[nx] + dfq[ka], t2 = fq[kb], t3;
   if (fabs(t2 - t1) < BWFAC * a->baseband_bw_hz) {
@@ -1548,7 +1596,7 @@ int lro_compute_timf2_powersum(lro_ctx *c, lrh_ptrs *p)
 
 /* ------------------------------------------------------------------ fft3 / mix2 */
 
-int lro_set_bg_filterfunc(lro_ctx *c, const float *f) { if (!c->N3) return LRH_ESTATE; memcpy(c->bg_filterfunc, f, 4 * c->N3); return LRH_OK; }
+int lro_set_bg_filterfunc(lro_ctx *c, const f32 *f) { if (!c->N3) return LRH_ESTATE; in_f32(c->bg_filterfunc, f, c->N3); return LRH_OK; }
 
 /* make_fft3_all, 1 channel, transform part (fft3.c:240-283): window (mode-1 storage), e^{+j} radix-2 DIF without the
    conjugation fft1 applies, permute with half swap (DC at N/2); pointers fft3.c:784, 797 */
@@ -1576,15 +1624,17 @@ int lro_make_fft3_all(lro_ctx *c, lrh_ptrs *p, int batch)
 
 /* two coupled channels, see include/linrad_hip.h: the own channel's share of A = c1 X + (c2 - j c3) Y and
    B = c1 Y - (c2 + j c3) X (mix2.c:340-343, 377-380) for mix2.size bins around fft3_size/2, bin j = fft3_size/2 - size/2 + j */
-int lro_set_pol(lro_ctx *c, float c1, float c2, float c3)
+int lro_set_pol(lro_ctx *c, f32 c1, f32 c2, f32 c3)
 {
+  LRO_F32_ONLY(c);
   if (c->cfg.blanker_channels != 2) return LRH_ESTATE;
   if ((c->cfg.timf1_channel_index & 1) == 0) { c->pol_w[0] = c1; c->pol_w[1] = 0; c->pol_w[2] = -c2; c->pol_w[3] = -c3; }
   else { c->pol_w[0] = c2; c->pol_w[1] = -c3; c->pol_w[2] = c1; c->pol_w[3] = 0; }
   c->pol_set = 1; return LRH_OK;
 }
-int lro_set_combine_weights(lro_ctx *c, float wa_re, float wa_im, float wb_re, float wb_im)
+int lro_set_combine_weights(lro_ctx *c, f32 wa_re, f32 wa_im, f32 wb_re, f32 wb_im)
 {
+  LRO_F32_ONLY(c);
   if (!c->xpol) return LRH_ESTATE;
   c->pol_w[0] = wa_re; c->pol_w[1] = wa_im; c->pol_w[2] = wb_re; c->pol_w[3] = wb_im; c->pol_set = 1; return LRH_OK;
 }
@@ -1648,6 +1698,7 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
 /* single-CPU branch of wideband_dsp, wcw.c:1036-1118, batched */
 int lro_set_exchange(lro_ctx *c, lrh_exchange_fn fn, void *user)
 {
+  LRO_F32_ONLY(c);
   if (!c || c->cfg.blanker_channels != 2) return LRH_ESTATE;
   c->xfn = fn; c->xuser = user;
   return LRH_OK;
@@ -1771,6 +1822,7 @@ size_t lro_sizeof(int which)
 
 int lro_wideband_limiter(lro_ctx *c, const lrh_sellim *par, int fft2_too)
 {
+  LRO_F32_ONLY(c);
   if (!c) return LRH_EINVAL;
   c->wl_on = 0;
   if (!par) return LRH_OK;
@@ -1805,14 +1857,45 @@ int lro_export(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt)
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;
+  if (esz == 4) { out_f32((f32 *)dst, (const float *)src + off, cnt); return LRH_OK; }      /* the float rings: converted in the float64 build */
   memcpy(dst, (const char *)src + off * esz, cnt * esz);
   return LRH_OK;
 }
+#ifdef LRO_F64
+int lro_export_wf_pre(lro_ctx *c, double *dst, size_t off, size_t cnt)
+{
+  if (!c || !dst || off + cnt > (size_t)c->cfg.wf_lines * c->cfg.wf_xpixels) return LRH_EINVAL;
+  memcpy(dst, c->wf_pre + off, cnt * sizeof(double)); return LRH_OK;
+}
+/* the float64 build's rings unrounded (float rings only) */
+int lro_export_f64(lro_ctx *c, lrh_ring ring, double *dst, size_t off, size_t cnt)
+{
+  const double *src; size_t total;
+  switch (ring) {
+    case LRH_RING_FFT1_FLOAT: src = c->fft1_float; total = (size_t)c->cfg.max_fft1n * 2 * c->N1; break;
+    case LRH_RING_FFT1_SUMSQ: src = c->fft1_sumsq; total = c->cfg.fft1_sumsq_bufsize; break;
+    case LRH_RING_FFT1_SLOWSUM: src = c->fft1_slowsum; total = c->N1; break;
+    case LRH_RING_TIMF2_FLOAT: src = c->timf2_float; total = 4 * (size_t)c->cfg.timf2pow_size; break;
+    case LRH_RING_TIMF2_PWR: src = c->timf2_pwr; total = c->cfg.timf2pow_size; break;
+    case LRH_RING_FFT2_FLOAT: src = c->fft2_float; total = (size_t)c->cfg.max_fft2n * 2 * c->N2; break;
+    case LRH_RING_FFT2_POWER: src = c->fft2_power; total = (size_t)c->cfg.max_fft2n * c->N2; break;
+    case LRH_RING_FFT2_POWERSUM: src = c->fft2_powersum; total = c->N2; break;
+    case LRH_RING_TIMF3_FLOAT: src = c->timf3_float; total = c->cfg.timf3_size; break;
+    case LRH_RING_TIMF2_BLOCKPOWER: src = c->timf2_blockpower; total = c->cfg.timf2_blockpower_size; break;
+    case LRH_RING_FFT3: src = c->fft3; total = (size_t)c->cfg.max_fft3n * 2 * c->N3; break;
+    case LRH_RING_BASEB_RAW: src = c->baseb_raw; total = 2 * (size_t)c->cfg.baseband_size; break;
+    default: return LRH_EINVAL;
+  }
+  if (off + cnt > total) return LRH_EINVAL;
+  memcpy(dst, src + off, cnt * sizeof(double));
+  return LRH_OK;
+}
+#endif
 
 int lro_get_blanker_state(lro_ctx *c, lrh_blanker_state *st) { *st = c->bs; return LRH_OK; }
 
 /* NET_RXOUT_TIMF2 payload, float form: rxin.c:949-956 with twice_rxchan = 2 */
-int lro_export_timf2_net(lro_ctx *c, float *dst, int timf2_pt, int count, float gain, float strong)
+int lro_export_timf2_net(lro_ctx *c, f32 *dst, int timf2_pt, int count, f32 gain, f32 strong)
 {
   if (count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
   int pt = timf2_pt & c->timf2_mask;
@@ -1912,8 +1995,8 @@ static void selfreq_liminfo(lro_ctx *c, lro_sellim_state *st, const lrh_sellim *
   for (int i = 0; i < N; i++) st->old[i] = lim[i];
 }
 
-int lro_get_liminfo_amplitude_factor(lro_ctx *c, float *f) { if (!c || !f) return LRH_EINVAL; *f = c->amp_factor; return LRH_OK; }
-int lro_set_liminfo_amplitude_factor(lro_ctx *c, float f) { if (!c) return LRH_EINVAL; c->amp_factor = f; return LRH_OK; }
+int lro_get_liminfo_amplitude_factor(lro_ctx *c, f32 *f) { if (!c || !f) return LRH_EINVAL; *f = c->amp_factor; return LRH_OK; }
+int lro_set_liminfo_amplitude_factor(lro_ctx *c, f32 f) { if (!c) return LRH_EINVAL; c->amp_factor = f; return LRH_OK; }
 
 /* hold-off count of the second limiter (sellim.c:207-209, 284-286, 536-538) */
 static unsigned sellim2_wait_n(const lro_ctx *c, const lrh_sellim *q)
@@ -1931,7 +2014,7 @@ static void fft2_liminfo_median(lro_ctx *c, lro_sellim_state *st, const lrh_sell
 {
   const int N = c->N1, N2 = c->N2, nn = N2 / N;
   float *lim = c->liminfo;
-  float *f = malloc(4 * (size_t)N2), *srt = malloc(4 * (size_t)N2);
+  float *f = malloc(sizeof(float) * (size_t)N2), *srt = malloc(sizeof(float) * (size_t)N2);
   for (int i = 0; i < N; i++) for (int j = nn * i; j < nn * i + nn; j++) f[j] = c->fft2_powersum[j] * c->wg_waterf_yfac[i];
   memcpy(srt, f, 4 * (size_t)N2);
   qsort(srt, N2, 4, cmp_float);
@@ -2059,6 +2142,7 @@ static void fft2_liminfo_regions(lro_ctx *c, lro_sellim_state *st, const lrh_sel
 /* fft2_update_liminfo, sellim.c:159-736: hg.sellim_par1 = 2 (535-731) below, 0 and 1 above */
 int lro_fft2_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 {
+  LRO_F32_ONLY(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return LRH_EINVAL;
   if (q->sellim_par1 < 0 || q->sellim_par1 > 2) return LRH_EINVAL;
@@ -2146,6 +2230,7 @@ done:
 
 int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
 {
+  LRO_F32_ONLY(c);
   if (!c || !p || !q || q->struct_size != (int)sizeof *q) return LRH_EINVAL;
   lro_sellim_state *st = sellim_state(c);
   const int N = c->N1, avg1 = c->cfg.fft_avg1num;
@@ -2291,7 +2376,7 @@ int lro_fft1_update_liminfo(lro_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
   return LRH_OK;
 }
 
-int lro_get_liminfo(lro_ctx *c, float *dst) { if (!c || !dst) return LRH_EINVAL; memcpy(dst, c->liminfo, 4 * c->N1); return LRH_OK; }
+int lro_get_liminfo(lro_ctx *c, f32 *dst) { if (!c || !dst) return LRH_EINVAL; out_f32(dst, c->liminfo, c->N1); return LRH_OK; }
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Spur subtraction: eliminate_spurs (spur.c:36-494) for locked spurs, one channel, float spectra, with
@@ -2602,8 +2687,9 @@ static void spur_eliminate(lro_spurs *S, float *fftx, int na, int n2, int maxn)
   }
 }
 
-int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const float *spectra)
+int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const f32 *spectra)
 {
+  LRO_F32_ONLY(c);
   if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
   lro_spurs *S = c->spurs;
   if (S) { free(S->sp); free(S->table); free(S->signal); free(S->ind); free(S->sig); free(S->der); free(S->pha); free(S->tmp); free(S); c->spurs = NULL; }
@@ -2623,8 +2709,9 @@ int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const float *spectra
   c->spurs = S;
   return LRH_OK;
 }
-int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const float *table, const float *signal, const int *ind)
+int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const f32 *table, const f32 *signal, const int *ind)
 {
+  LRO_F32_ONLY(c);
   lro_spurs *S = c ? c->spurs : NULL;
   if (!S || n < 0 || n > S->max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
   const int maxn = c->cfg.max_fft2n;
@@ -2675,6 +2762,7 @@ static void spur_parabolic_fit(float *amp, float *pos, float y1, float y2, float
 }
 int lro_spur_acquire(lro_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
 {
+  LRO_F32_ONLY(c);
   lro_spurs *S = c ? c->spurs : NULL;
   if (!S || !p || !locked) return LRH_EINVAL;
   *locked = 0;

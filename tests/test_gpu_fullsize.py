@@ -5,6 +5,16 @@ import pytest
 
 from linrad_amd import abi
 from linrad_amd.workload import chain_config, strong_liminfo
+from paritylib import truth_gate as _truth_gate, waterfall_gate
+
+# Here the float32 side HIP is held to is the ORACLE (the restatement), not the compiled reference: against the float64 truth the oracle's own
+# error is 1.02-1.05 of the reference's (tests/test_oracle_golden.py, timf3 of n9_n11_sin3), so a HIP / oracle error ratio inside that band
+# cannot be told from the reference's.  The golden tests (tests/test_gpu_parity.py), where the partner IS the compiled reference, use 1.0.
+ORACLE_FACTOR = 1.05
+
+
+def truth_gate(rep, key, hip, ref, truth, tol=1e-5):
+    return _truth_gate(rep, key, hip, ref, truth, tol, ORACLE_FACTOR)
 
 pytestmark = pytest.mark.gpu
 N1 = 16384
@@ -18,6 +28,11 @@ def _hip(cfg):
 def _oracle(cfg):
     from oracle_binding import open_oracle
     return open_oracle(cfg)
+
+
+def _truth(cfg):
+    from oracle_binding import open_truth      # the oracle's source with every float a double: the truth of paritylib.truth_gate
+    return open_truth(cfg)
 
 
 def _relerr(a, b):
@@ -78,7 +93,7 @@ def run_fullsize(fft2_n, blanker, fft3_n, batch=16, sparse=0):
              (abi.RING_TIMF2_FLOAT, "timf2"), (abi.RING_FFT2_FLOAT, "fft2"), (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_TIMF3_FLOAT, "timf3"), (abi.RING_WG_WATERF, "wf")]
     if fft3_n:
         rings += [(abi.RING_FFT3, "fft3"), (abi.RING_BASEB_RAW, "baseb")]
-    for fn in (_hip, _oracle):
+    for fn in (_hip, _oracle, _truth):
         cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse if fn is _hip else 0
         rx = fn(cfg)
         _feed(rx, iq, lim, fq)
@@ -88,12 +103,15 @@ def run_fullsize(fft2_n, blanker, fft3_n, batch=16, sparse=0):
         r = {k: rx.export(ring) for ring, k in rings}
         r["p"] = rx.p.as_dict()
         r["bs"] = rx.blanker_state()
+        if fn is _truth:
+            r["wf_pre"] = rx.export_wf_pre()
         if fn is _hip:
             r["launches"] = {k: rx.profile_get(k)[1] for k in ("fft1w", "fft1", "timf2", "timf2s")}
             rx.profile_enable(0)
         r["lim"], r["fq"] = lim, fq
         res.append(r)
     cfg.fft1_float_sparse = cfg.fft2_float_sparse = 0
+    res[1]["truth"] = res[2]               # the float64 build on the same calls: what both float32 sides are measured against above 1e-5
     return res[0], res[1], cfg
 
 
@@ -107,6 +125,7 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     M2 = N2 // 2                                                       # sin^2 window: 50 % overlap
     Mm = (N2 >> cfg.mix1_bandwidth_reduction_n) // 2                   # timf3 samples per fft2 transform
     rep = {}
+    T_ = o["truth"]                                                    # the float64 build on the same calls
     ints = [k for k, v in h["p"].items() if isinstance(v, int)]
     assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
     rep["noise_floor"] = (h["bs"].timf2_noise_floor, o["bs"].timf2_noise_floor)
@@ -130,10 +149,14 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     assert all(min(abs(i - b) for b in border) <= cfg.blanker_pulsewidth + 2 for i in flips)
     if not blanker:
         assert len(flips) == 0
+    # ... and the truth's own decisions: where the float64 build clears differently from the oracle it is no truth for what follows
+    tflips = np.nonzero((T_["pwr"] == 0) != (o["pwr"] == 0))[0]
+    rep["truth_flips"] = int(len(tflips))
+    assert len(tflips) <= 8
+    flips = np.union1d(flips, tflips)
     keep = np.ones(len(o["pwr"]), bool)
     keep[flips] = False
-    rep["pwr"] = _relerr(h["pwr"][keep], o["pwr"][keep])
-    assert rep["pwr"] < 2e-5          # despiked power: float32 floor of the cleaned pulses remains (measured 1.7e-5)
+    truth_gate(rep, "pwr", h["pwr"][keep], o["pwr"][keep], lambda: T_["pwr"][keep])
     # timf2 {wRe, wIm, sRe, sIm} sample by sample up to timf2_pa (beyond it the reference parks a raw half block, timf2.c:1018-1025)
     npa = o["p"]["timf2_pa"] // 4
     t2h, t2o = h["timf2"].reshape(-1, 4)[:npa], o["timf2"].reshape(-1, 4)[:npa]
@@ -141,11 +164,11 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     rep["timf2"] = _relerr(t2h[k2], t2o[k2])
     rep["timf2_weak"], rep["timf2_strong"] = _relerr(t2h[k2, :2], t2o[k2, :2]), _relerr(t2h[k2, 2:], t2o[k2, 2:])
     # the weak stream is what is left of a spectrum after carriers 40 dB up have been routed away: its own float32 error is the forward
-    # transform's rounding noise of the WHOLE spectrum (6e-8 of the strongest component per pass), so relative to the weak stream alone
-    # the figure reads 1.5e-5 on this signal; it is held to 1e-5 relative or to that absolute floor, like timf3 below
-    floor2 = 4 * 6e-8 * np.linalg.norm(t2o[k2].astype(np.float64))
-    rep["timf2_weak_abs"], rep["timf2_floor"] = float(np.linalg.norm(t2h[k2, :2].astype(np.float64) - t2o[k2, :2])), float(floor2)
-    assert rep["timf2"] < 1e-5 and rep["timf2_strong"] < 1e-5 and (rep["timf2_weak"] < 1e-5 or rep["timf2_weak_abs"] <= floor2), rep
+    # transform's rounding noise of the WHOLE spectrum, so relative to the weak stream alone the figure reads 1.5e-5 on this signal: above
+    # 1e-5 it must be no further from the float64 truth than the oracle's own float32 result (truth_gate)
+    t2t = T_["timf2"].reshape(-1, 4)[:npa]
+    assert rep["timf2"] < 1e-5 and rep["timf2_strong"] < 1e-5, rep
+    truth_gate(rep, "timf2_weak", t2h[k2, :2], t2o[k2, :2], lambda: t2t[k2, :2])
     # fft2 transform t reads timf2 samples [t M2, t M2 + N2) (the ring has not wrapped in this run): transforms with a flipped sample
     ntr = o["p"]["fft2_na"]
     assert ntr < cfg.max_fft2n and o["p"]["timf2_px"] == 4 * ntr * M2 and o["p"]["timf3_pa"] == 2 * Mm * ntr
@@ -155,14 +178,13 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
         hit[max(0, t1 - 1):t1 + 1] = True
     rep["fft2_transforms"], rep["fft2_transforms_with_a_flip"] = int(ntr), int(hit[:ntr].sum())
     ok = ~hit[:ntr]
-    f2h, f2o = h["fft2"].reshape(cfg.max_fft2n, -1)[:ntr], o["fft2"].reshape(cfg.max_fft2n, -1)[:ntr]
+    f2h, f2o, f2t = h["fft2"].reshape(cfg.max_fft2n, -1)[:ntr], o["fft2"].reshape(cfg.max_fft2n, -1)[:ntr], T_["fft2"].reshape(cfg.max_fft2n, -1)[:ntr]
     if sparse:                                                         # cfg.fft2_float_sparse: the band mix1 cuts out is what the ring holds
         centre, half = int(h["fq"] + 0.5), (N2 >> cfg.mix1_bandwidth_reduction_n) // 2
         band = slice(2 * (centre - half), 2 * (centre + half))
         assert not np.any(f2h[:, :2 * (centre - half - 64)]) and not np.any(f2h[:, 2 * (centre + half + 64):])
-        rep["fft2"] = _relerr(f2h[ok][:, band], f2o[ok][:, band])
-        # relative to the band alone a weak band under a strong carrier sits on the float32 floor of the whole transform (as timf3 does below)
-        assert rep["fft2"] < 1e-5 or np.linalg.norm(f2h[ok][:, band].astype(np.float64) - f2o[ok][:, band]) <= 4 * 6e-8 * np.linalg.norm(f2o[ok].astype(np.float64)) * np.sqrt(2 * half / N2) * np.sqrt(2.0), rep
+        # (relative to the band alone a weak band under a strong carrier carries the float32 noise of the whole transform)
+        truth_gate(rep, "fft2", f2h[ok][:, band], f2o[ok][:, band], lambda: f2t[ok][:, band])
     else:
         rep["fft2"] = _relerr(f2h[ok], f2o[ok])
         assert rep["fft2"] < 1e-5
@@ -174,14 +196,9 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     # timf3 block t (Mm samples) carries transform t's first half on top of transform t-1's second half (mix1.c:161-195)
     nb3 = o["p"]["timf3_pa"] // (2 * Mm)
     ok3 = np.array([not (hit[t] or (t > 0 and hit[t - 1])) for t in range(nb3)])
-    t3h, t3o = h["timf3"][:2 * Mm * nb3].reshape(nb3, -1), o["timf3"][:2 * Mm * nb3].reshape(nb3, -1)
-    rep["timf3"] = _relerr(t3h[ok3], t3o[ok3])
-    # weak band cut out of a spectrum that holds a carrier 50 dB up: the float32 floor of the wide spectrum
-    wide = np.linalg.norm(f2o[ok].astype(np.float64)) / np.sqrt(max(1, ok.sum()))
-    floor3 = 4 * 6e-8 * wide * np.sqrt(ok3.sum() * Mm / N2) * np.sqrt(2.0)
-    err3 = np.linalg.norm(t3h[ok3].astype(np.float64) - t3o[ok3])
-    rep["timf3_abs"], rep["timf3_floor"], rep["timf3_escape"] = float(err3), float(floor3), bool(rep["timf3"] > 1e-5)
-    assert rep["timf3"] <= 1e-5 or err3 <= floor3, rep
+    t3h, t3o, t3t = h["timf3"][:2 * Mm * nb3].reshape(nb3, -1), o["timf3"][:2 * Mm * nb3].reshape(nb3, -1), T_["timf3"][:2 * Mm * nb3].reshape(nb3, -1)
+    # (a weak band cut out of a spectrum that holds a carrier 50 dB up)
+    truth_gate(rep, "timf3", t3h[ok3], t3o[ok3], lambda: t3t[ok3])
     if fft3_n:
         assert o["p"]["baseb_pa"] > 0 and np.count_nonzero(o["baseb"]) > 100
         # fft3 transform j reads timf3 samples [j M3, j M3 + N3); its mix2 block j (Mm2 samples) also carries the second half of
@@ -194,35 +211,25 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
             j1 = min(n3 - 1, (t * Mm + Mm - 1) // M3)
             bad3[max(0, (t * Mm - N3) // M3 + 1 if t * Mm >= N3 else 0):j1 + 1] = True
         okf = ~bad3[:n3]
-        f3h, f3o = h["fft3"].reshape(cfg.max_fft3n, -1)[:n3], o["fft3"].reshape(cfg.max_fft3n, -1)[:n3]
+        f3h, f3o, f3t = h["fft3"].reshape(cfg.max_fft3n, -1)[:n3], o["fft3"].reshape(cfg.max_fft3n, -1)[:n3], T_["fft3"].reshape(cfg.max_fft3n, -1)[:n3]
         rep["fft3_transforms"], rep["fft3_transforms_with_a_flip"] = int(n3), int(bad3[:n3].sum())
-        rep["fft3"] = _relerr(f3h[okf], f3o[okf])
-        e3 = np.linalg.norm(f3h[okf].astype(np.float64) - f3o[okf])
-        fl3 = floor3 * np.sqrt(max(1, f3h[okf].size) / max(1, t3h[ok3].size))
-        rep["fft3_escape"] = bool(rep["fft3"] > 1e-5)
-        assert rep["fft3"] <= 1e-5 or e3 <= fl3, rep
+        truth_gate(rep, "fft3", f3h[okf], f3o[okf], lambda: f3t[okf])
         nbb = o["p"]["baseb_pa"] // Mm2
         okb = np.array([not (bad3[j] or (j > 0 and bad3[j - 1])) for j in range(nbb)])
-        bh, bo = h["baseb"][:2 * Mm2 * nbb].reshape(nbb, -1), o["baseb"][:2 * Mm2 * nbb].reshape(nbb, -1)
-        rep["baseb"] = _relerr(bh[okb], bo[okb])
-        eb = np.linalg.norm(bh[okb].astype(np.float64) - bo[okb])
-        rep["baseb_escape"] = bool(rep["baseb"] > 1e-5)
-        assert rep["baseb"] <= 1e-5 or eb <= floor3, rep
-    # waterfall lines of groups without a flipped transform: exact up to bins on a rounding boundary
+        bh, bo, bt = h["baseb"][:2 * Mm2 * nbb].reshape(nbb, -1), o["baseb"][:2 * Mm2 * nbb].reshape(nbb, -1), T_["baseb"][:2 * Mm2 * nbb].reshape(nbb, -1)
+        truth_gate(rep, "baseb", bh[okb], bo[okb], lambda: bt[okb])
+    # waterfall lines of groups without a flipped transform: both sides against the float64 truth's integers (paritylib.waterfall_gate)
     npx = cfg.wf_xpixels
     nl = ntr // avg
     wfh, wfo = h["wf"].astype(int), o["wf"].astype(int)
     size = wfh.size
-    tot = bad = 0
-    dmax = 0
-    for line in range(nl):
-        if any(hit[t] for t in range(line * avg, (line + 1) * avg)):
-            continue
-        ptr = (-line * npx) % size                                       # lines are written downwards from 0 (fft1.c:104-113)
-        d = np.abs(wfh[ptr:ptr + npx] - wfo[ptr:ptr + npx])
-        tot += npx; bad += int(np.count_nonzero(d)); dmax = max(dmax, int(d.max()))
-    rep["wf_bins"], rep["wf_mismatches"], rep["wf_maxdiff"] = tot, bad, dmax
-    assert dmax <= 2 and bad <= 0.05 * max(tot, 1)
+    at = [(-line * npx) % size for line in range(nl)                     # lines are written downwards from 0 (fft1.c:104-113)
+          if not any(hit[tr] for tr in range(line * avg, (line + 1) * avg))]
+    if at:
+        H, O, P = (np.stack([x[p:p + npx] for p in at]) for x in (wfh, wfo, T_["wf_pre"]))
+        d = np.abs(H - O)
+        rep["wf_bins"], rep["wf_mismatches"], rep["wf_maxdiff"] = int(d.size), int(np.count_nonzero(d)), int(d.max())
+        waterfall_gate(rep, H, O, P)
     return rep
 
 
@@ -556,7 +563,7 @@ def test_fft1_size_32768_chain_matches_oracle(batch, sparse):
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     lim = strong_liminfo(s, 15)
     res = []
-    for fn in (_hip, _oracle):
+    for fn in (_hip, _oracle, _truth):
         cfg.fft1_float_sparse = sparse if fn is _hip else 0
         rx = fn(cfg)
         _feed(rx, iq, lim, 0.31 * (1 << 17) + 0.3)
@@ -578,7 +585,7 @@ def test_fft1_size_32768_chain_matches_oracle(batch, sparse):
             assert np.array_equal(rx2.export(abi.RING_FFT1_FLOAT), res[-1]["fft1"])
             rx2.close()
         rx.close()
-    h, o = res
+    h, o, t = res
     ints = [k for k, v in h["p"].items() if isinstance(v, int)]
     assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
     flips = np.nonzero((h["pwr"] == 0) != (o["pwr"] == 0))[0]
@@ -588,11 +595,12 @@ def test_fft1_size_32768_chain_matches_oracle(batch, sparse):
     keep[(h["p"]["timf2_pa"] // 4 + np.arange(n1 // 2)) % keep.size] = False        # pending half block of the sin^2 overlap
     errs = {k: _relerr(h[k], o[k]) for k in (("sumsq",) if sparse else ("fft1", "sumsq"))}
     errs["timf2"] = _relerr(h["timf2"].reshape(-1, 4)[keep], o["timf2"].reshape(-1, 4)[keep])
-    errs["pwr"] = _relerr(h["pwr"][keep], o["pwr"][keep])
+    keep &= (t["pwr"] == 0) == (o["pwr"] == 0)                     # (where the float64 build decides like the oracle: its power is the truth there)
+    truth_gate(errs, "pwr", h["pwr"][keep], o["pwr"][keep], lambda: t["pwr"][keep])
     if len(flips) == 0:
         errs["fft2"], errs["timf3"] = _relerr(h["fft2"], o["fft2"]), _relerr(h["timf3"], o["timf3"])
     print(errs, "flips", len(flips), "cleared", int(np.sum(o["pwr"] == 0)))
-    assert all(v < 1e-5 for k, v in errs.items() if k != "pwr") and errs["pwr"] < 5e-5, errs
+    assert all(v < 1e-5 for k, v in errs.items() if k not in ("pwr", "above_tol")), errs
 
 
 def test_fft1_size_65536_without_second_fft_matches_oracle():
@@ -734,7 +742,7 @@ def test_bench_shape_blanker_matches_oracle():
     s = synth_defaults(N1, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     res = []
-    for fn, sparse in ((_hip, 1), (_oracle, 0)):
+    for fn, sparse in ((_hip, 1), (_oracle, 0), (_truth, 0)):
         cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
         rx = fn(cfg)
         _feed(rx, iq, strong_liminfo(s, 14), 0.31 * 65536 + 0.3)
@@ -745,7 +753,7 @@ def test_bench_shape_blanker_matches_oracle():
         res.append({"sumsq": rx.export(abi.RING_FFT1_SUMSQ), "slowsum": rx.export(abi.RING_FFT1_SLOWSUM), "pwr": rx.export(abi.RING_TIMF2_PWR),
                     "p": rx.p.as_dict(), "bs": rx.blanker_state(), "first": first, "start": start})
         rx.close()
-    h, o = res
+    h, o, t = res
     ints = [k for k, v in h["p"].items() if isinstance(v, int)]
     assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}
     assert h["first"].timf2_noise_floor == o["first"].timf2_noise_floor and h["first"].stupid_bln_limit == o["first"].stupid_bln_limit
@@ -763,5 +771,9 @@ def test_bench_shape_blanker_matches_oracle():
     assert len(flips) <= 2 * (o["pwr"].size // 400000 + 1) and all(m <= 1e-4 for m in margin)
     keep = np.ones(o["pwr"].size, bool)
     keep[flips] = False
-    assert _relerr(h["pwr"][keep], o["pwr"][keep]) < 5e-5      # measured 1.7e-5 at full size: the float32 floor of the cleaned pulses
+    keep &= (t["pwr"] == 0) == (o["pwr"] == 0)                # where the float64 build decides like the oracle, its despiked power is the truth
+    rep = {}
+    # (measured 1.7e-5 against the oracle at this size: what the cleaned pulses leave in float32 -- above 1e-5, so both sides against the truth)
+    truth_gate(rep, "pwr", h["pwr"][keep], o["pwr"][keep], lambda: t["pwr"][keep])
+    print(rep)
     assert abs(h["bs"].timf2_noise_floor - o["bs"].timf2_noise_floor) <= 0.01 * o["bs"].timf2_noise_floor

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from paritylib import RINGS, compare_with_golden, load_golden, relerr, run_case
+from paritylib import RINGS, compare_with_golden, load_golden, relerr, run_case, truth_gate, truth_of
 from refcases import CASES
 
 pytestmark = pytest.mark.gpu
@@ -25,7 +25,7 @@ def test_hip_matches_reference_golden(name):
     out = run_case(_open_hip, name, golden=g)
     floor_same = np.array_equal(out["itrace"][:, 4], g["itrace"].reshape(-1, 16)[:, 12])
     rep = compare_with_golden(out, g, tol=1e-5, check_blanker_exact=floor_same, floor_slack=0 if floor_same else 1,
-                              mask_pending_timf2=out["api"].fft1_interleave_points == out["api"].N1 // 2)
+                              mask_pending_timf2=out["api"].fft1_interleave_points == out["api"].N1 // 2, truth=lambda: truth_of(name, g))
     print(name, rep)
 
 
@@ -87,8 +87,10 @@ def test_hip_fft3_mix2_matches_oracle():
     assert (a["api"].p.fft3_pa, a["api"].p.fft3_px, a["api"].p.baseb_pa, a["api"].p.timf3_px) == \
            (b["api"].p.fft3_pa, b["api"].p.fft3_px, b["api"].p.baseb_pa, b["api"].p.timf3_px)
     assert np.count_nonzero(b["baseb_raw"]) > 500
-    assert relerr(a["fft3"], b["fft3"]) < 2e-5
-    assert relerr(a["baseb_raw"], b["baseb_raw"]) < 2e-5
+    t, rep = truth_of("n10_n12_fft3", g), {}
+    for k in ("fft3", "baseb_raw"):          # 1e-5, or no further from the float64 truth than the oracle's own float32 result
+        truth_gate(rep, k, a[k], b[k], t[k], factor=1.05)    # (the partner is the oracle: tests/test_gpu_fullsize.py ORACLE_FACTOR)
+    print(rep)
 
 
 @pytest.mark.parametrize("name", ["n8_n10", "n10_n12", "n9_n11_dir", "n9_n11_iqcal", "n10_n12_dword", "n9_n11_real", "n15_n17_big1"])
@@ -198,7 +200,8 @@ def test_error_behaviour_and_ragged_calls():
     s = synth_defaults(1 << cfg.fft1_n, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
     outs = []
-    for fn in (open_hip, open_oracle):
+    from oracle_binding import open_truth
+    for fn in (open_hip, open_oracle, open_truth):
         rx = fn(cfg)
         rx.timf1_write(iq)
         rx.set_liminfo(strong_liminfo(s, cfg.fft1_n))
@@ -208,9 +211,15 @@ def test_error_behaviour_and_ragged_calls():
         outs.append((rx.export(abi.RING_FFT1_SUMSQ), rx.export(abi.RING_TIMF2_PWR), rx.export(abi.RING_FFT2_FLOAT), rx.export(abi.RING_TIMF3_FLOAT), rx.p.as_dict()))
     ints = [k for k, v in outs[0][4].items() if isinstance(v, int)]
     assert {k: outs[0][4][k] for k in ints} == {k: outs[1][4][k] for k in ints}
-    for i, (a, b) in enumerate(zip(outs[0][:4], outs[1][:4])):
-        # north-star tolerance; the despiked power keeps the float32 floor of the pulses it was cleaned of
-        assert relerr(a, b) < (5e-5 if i == 1 else 1e-5), (i, relerr(a, b))
+    rep = {}
+    for i, (a, b, t) in enumerate(zip(outs[0][:4], outs[1][:4], outs[2][:4])):
+        # north-star tolerance; above it (the despiked power ring keeps float32 residue of the pulses it was cleaned of) both sides against the truth
+        if i == 1:
+            assert np.array_equal(a == 0, b == 0)
+            same = (t == 0) == (b == 0)                           # (where the float64 build clears like the oracle)
+            a, b, t = a[same], b[same], t[same]
+        truth_gate(rep, str(i), a, b, t, factor=1.05)
+    print(rep)
     rx = open_hip(cfg)
     for call, code in ((lambda: rx.fft1_b(9), abi.LRH_EINVAL),                       # batch > max_batch
                        (lambda: rx.make_fft2(cfg.max_fft2n + 1), abi.LRH_EINVAL),

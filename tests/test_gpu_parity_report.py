@@ -8,12 +8,12 @@ import os
 import numpy as np
 import pytest
 
-from paritylib import compare_with_golden, load_golden, run_case
+from paritylib import compare_with_golden, load_golden, run_case, truth_of
 from refcases import CASES
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("LRH_ROUND", "r04")
+ROUND = "r05"
 
 
 def _clean(v):
@@ -29,14 +29,14 @@ def _clean(v):
 def test_parity_report():
     from linrad_amd.lib import open_hip
     from test_gpu_fullsize import fullsize_compare, run_fullsize
-    report = {"tolerance": "relative RMS 1e-5 (north_star) per ring; pointers, cleared-sample sets and mix1 bookkeeping exact",
+    report = {"tolerance": "relative RMS 1e-5 (north_star) per ring -- a ring above it must be no further from the float64 build of the oracle than the reference's own float32 result (above_tol: hip_vs_truth <= ref_vs_truth); pointers, cleared-sample sets and mix1 bookkeeping exact; waterfall shorts against the float64 truth's integers (wf_vs_truth)",
               "golden_cases": {}, "fullsize_vs_oracle": {}}
     for name in CASES:
         g = load_golden(name)
         out = run_case(open_hip, name, golden=g)
         floor_same = np.array_equal(out["itrace"][:, 4], g["itrace"].reshape(-1, 16)[:, 12])
         rep = compare_with_golden(out, g, tol=1e-5, check_blanker_exact=floor_same, floor_slack=0 if floor_same else 1,
-                                  mask_pending_timf2=out["api"].fft1_interleave_points == out["api"].N1 // 2)
+                                  mask_pending_timf2=out["api"].fft1_interleave_points == out["api"].N1 // 2, truth=lambda: truth_of(name, g))
         report["golden_cases"][name] = _clean(rep)
     for fft2_n, blanker, fft3_n in ((12, True, 0), (16, True, 0), (12, False, 0), (16, True, 12)):
         h, o, cfg = run_fullsize(fft2_n, blanker, fft3_n)
@@ -63,13 +63,15 @@ def test_parity_report():
         report["feature_cases"][name] = _clean(clever2lib.compare(res, g, 1e-5))
         for rx in res["rxs"]:
             rx.close()
-    esc = {k: v["escapes"] for k, v in report["golden_cases"].items() if v["escapes"]}
-    report["summary"] = {"cases": len(report["golden_cases"]), "cases_with_an_escape": esc,
+    above = {k: v["above_tol"] for k, v in report["golden_cases"].items() if v.get("above_tol")}
+    report["summary"] = {"cases": len(report["golden_cases"]),
+                         "rings_above_1e-5_held_to_the_float64_truth": above,
                          "blanker_flips_total": sum(v["blanker_flips"] for v in report["golden_cases"].values()),
-                         "max_rel_err_excluding_escapes": max(v2 for v in report["golden_cases"].values() for k2, v2 in v.items()
-                                                              if isinstance(v2, float) and k2 not in v["escapes"] and k2.endswith(("float", "sumsq", "slowsum", "fft3", "raw")))}
+                         "max_rel_err_of_the_rings_within_tolerance": max(v2 for v in report["golden_cases"].values() for k2, v2 in v.items()
+                                                                          if isinstance(v2, float) and k2 not in v.get("above_tol", {}) and k2.endswith(("float", "sumsq", "slowsum", "fft3", "raw"))),
+                         "waterfall": {k: v["wf_vs_truth"] for k, v in report["golden_cases"].items() if "wf_vs_truth" in v}}
     outdir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, f"parity_{ROUND}.json"), "w") as f:
         json.dump(report, f, indent=1)
-    assert report["summary"]["max_rel_err_excluding_escapes"] <= 1e-5
+    assert report["summary"]["max_rel_err_of_the_rings_within_tolerance"] <= 1e-5
