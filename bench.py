@@ -52,7 +52,7 @@ def source_sha16():
     """hash of the kernel / host sources the library is built from (scripts/summarize_profile.py stores the same in the traffic file)"""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("lrh_kernels.hip", "lrh_fft.hip.h", "lrh_kernels.hip.h", "lrh_host.hip"):
+    for fn in ("lrh_kernels.hip", "lrh_fft.hip.h", "lrh_kernels.hip.h", "lrh_host.hip", "lrh_timf2_sd.hip"):
         h.update(open(os.path.join(ROOT, "linrad_amd", "csrc", fn), "rb").read())
     return h.hexdigest()[:16]
 

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for one round: kernel-trace stats of the default bench run, and per workload the PMC passes
 # (FETCH_SIZE / WRITE_SIZE separately, never together with other trace domains).
 # usage (on the GPU box, via gpurun): scripts/profile_round.sh r02
-R=${1:-r04}
+R=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R

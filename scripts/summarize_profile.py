@@ -14,7 +14,7 @@ d = sys.argv[1]
 STAGE_KERNELS = {
     "fft1": ("k_fft1<", ["k_fft1<", "k_realsplit", "k_foldcorr"]),
     "fft1w": (("k_fft1w<", "k_fft1v<"), ["k_fft1w<", "k_fft1v<"]),
-    "timf2s": ("k_timf2<14, 1, false, true>", ["k_timf2<14, 1, false, true>"]),
+    "timf2s": ("k_timf2<14, 1, false, true>", ["k_timf2<14, 1, false, true>", "k_timf2_sd<"]),   # the direct sum and the transform kernel behind it (one of them returns at once)
     "timf2": ("k_timf2<", ["k_timf2<"]),
     "spur": ("k_spur(", ["k_spur(", "k_spur_patch"]),
     "sumsq": ("k_sumsq(", ["k_sumsq("]),
@@ -108,7 +108,7 @@ if len(sys.argv) > 2:
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hsh = hashlib.sha256()
-    for fn in ("lrh_kernels.hip", "lrh_fft.hip.h", "lrh_kernels.hip.h", "lrh_host.hip"):
+    for fn in ("lrh_kernels.hip", "lrh_fft.hip.h", "lrh_kernels.hip.h", "lrh_host.hip", "lrh_timf2_sd.hip"):
         hsh.update(open(os.path.join(root, "linrad_amd", "csrc", fn), "rb").read())
     out = {"source_sha16": hsh.hexdigest()[:16],          # bench.py quotes these byte counts only for the library built from these sources
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes per workload, python3 bench.py --steps 5 "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench's variants on one GPU, one JSON object per round: scripts/variants_round.sh r03   (on the GPU box, via gpurun)
 # -> gpurun_out/prof_$R/variants.json (+ rocprofv3 --stats of the two variants the review asked for: --clever, --coupled)
-R=${1:-r04}
+R=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
