@@ -101,7 +101,8 @@ typedef struct lrh_config {
   int timf1_channel_index;      /* which of them this context (this GPU) processes                        */
   /* fft3 + mix2 (fft3.c:215-283, mix2.c:83-176): baseband filter / decimator behind mix1; fft3_n = 0 disables */
   int fft3_n;                   /* log2 fft3_size (baseb_graph.c:3332-3376), <= 14                         */
-  int fft3_sinpow;              /* genparm[THIRD_FFT_SINPOW]; mix2 supports 2 (50 % overlap-add) and 0     */
+  int fft3_sinpow;              /* genparm[THIRD_FFT_SINPOW]: 0 none, 2 sin^2 (50 % overlap-add, mix2.c:158-176), other windows
+                                   through the crossover functions of prepare_mixer (mix2.c:177-216)        */
   int mix2_n;                   /* log2 mix2.size (baseb_graph.c:1302-1323), <= fft3_n                     */
   int max_fft3n;                /* fft3 ring length in transforms (fft3_totsiz/fft3_block), pow2          */
   int baseband_size;            /* baseb_raw ring, complex samples, pow2                                   */

@@ -176,6 +176,8 @@ struct lrh_ctx {
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
   float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
   std::vector<float> h_mixwin, h_sin2win, h_cos2win;
+  float *d_mix2win = nullptr, *d_sin2win2 = nullptr, *d_cos2win2 = nullptr; int Xm2 = 0;   // ... and mix2's (THIRD_FFT_SINPOW neither 0 nor 2, mix2.c:177-216)
+  std::vector<float> h_mix2win, h_sin2win2, h_cos2win2;
   float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
   // fft1_size 32768: four-step fft1 / timf2 (tables of size 256 / 128; scratch per fft1_b handle and for timf2, grown on demand)
   float2 *d_tw1a = nullptr, *d_tw1b = nullptr, *d_fft1_scratch[8] = {}, *d_timf2_scratch = nullptr; size_t fft1_scratch_cap[8] = {}, timf2_scratch_cap = 0;
@@ -325,6 +327,37 @@ static void half_window(int size, int n, std::vector<float> &h, bool normalise)
   if (normalise) { z = 1 / sqrt(2 * sumsq / size); for (int i = 0; i <= size / 2; i++) h[i] *= (float)z; }
 }
 
+// prepare_mixer (buf.c:55-111): the inverted window (make_window mode 3) and the sin^2 / cos^2 crossover functions of a mixer whose window
+// is neither none nor sin^2; returns crossover_points
+static int prepare_mixer(int Nm, int Im, int Mm, int sp, std::vector<float> &win, std::vector<float> &sin2win, std::vector<float> &cos2win)
+{
+  std::vector<float> h;
+  win.assign(Nm / 2 + 1, 0.f); sin2win.assign(Nm, 0.f); cos2win.assign(Nm, 0.f);
+  int X = 0;
+  if (sp == 0 || sp == 2) return 0;
+  half_window(Nm, sp, h, false);                           // make_window(3,..): inverted, fft0.c:883-891
+  win[0] = 1; for (int i = 1; i <= Nm / 2; i++) win[i] = 1 / h[i];
+  if (sp == 9) X = Nm / 8;
+  else if (sp == 8) X = Nm / 16;
+  else {
+    unsigned int i = Im / 2;
+    const float t1 = win[i];
+    while (win[i] < 30 * t1 && i > 0) { i--; X++; }
+    if (X > 0.75 * Mm) X = (int)(0.75 * Mm);
+    if (X > Im / 2) X = Im / 2;
+  }
+  float t1 = (float)(0.25 * PI_L / X);
+  unsigned int j = (Nm - Mm) / 2, k = j;
+  k += X / 2; j -= X / 2;
+  for (int i = 0; i < X; i++) {
+    cos2win[i] = (float)(win[k] * pow(cos(t1), 2.0));
+    sin2win[i] = (float)(win[j] * pow(sin(t1), 2.0));
+    k--; j++;
+    t1 = (float)(t1 + 0.5 * PI_L / X);
+  }
+  return X;
+}
+
 static float interleave_ratio(int sinpow)   // make_interleave_ratio, buf.c:113-136
 {
   if (sinpow == 0) return 0;
@@ -447,7 +480,7 @@ void lrh_close(lrh_ctx *c)
   for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) hipHostFree(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
   for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
-  void *dev[] = { c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+  void *dev[] = { c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
@@ -517,7 +550,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     c->N3 = 1 << cfg->fft3_n; c->Nm2 = 1 << cfg->mix2_n;
     c->Im2 = (int)(interleave_ratio(cfg->fft3_sinpow) * c->Nm2); c->Im2 &= 0xfffffffe; c->Mm2 = c->Nm2 - c->Im2;
     c->I3 = c->Im2 * (c->N3 / c->Nm2); c->M3 = c->N3 - c->I3;
-    if (!(c->Im2 == 0 || c->Im2 == c->Mm2) || cfg->timf3_size < 4 * c->N3 || cfg->baseband_size < 4 * c->Nm2) { delete c; return LRH_EINVAL; }
+    if (cfg->timf3_size < 4 * c->N3 || cfg->baseband_size < 4 * c->Nm2) { delete c; return LRH_EINVAL; }
   }
   c->timf2_mode = c->I1 == 0 ? 0 : (c->I1 == N1 / 2 ? 1 : 2);
   if (const char *e = getenv("LRH_XCD_MASK")) c->xcd_mask = atoi(e);
@@ -594,33 +627,9 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     for (int i = 0; i <= N2 / 2; i++) c->h_window2[i] = h[i];
     for (int i = N2 / 2 + 1; i < N2; i++) c->h_window2[i] = h[N2 - i];
   }
-  {                                                        // prepare_mixer, buf.c:55-111
-    const int sp = cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow, Nm = c->Nm;
-    c->h_mixwin.assign(Nm / 2 + 1, 0.f); c->h_sin2win.assign(Nm, 0.f); c->h_cos2win.assign(Nm, 0.f);
-    c->Xm = 0;
-    if (sp != 0 && sp != 2) {
-      half_window(Nm, sp, h, false);                       // make_window(3,..): inverted, fft0.c:883-891
-      c->h_mixwin[0] = 1; for (int i = 1; i <= Nm / 2; i++) c->h_mixwin[i] = 1 / h[i];
-      if (sp == 9) c->Xm = Nm / 8;
-      else if (sp == 8) c->Xm = Nm / 16;
-      else {
-        unsigned int i = c->Im / 2;
-        const float t1 = c->h_mixwin[i];
-        while (c->h_mixwin[i] < 30 * t1 && i > 0) { i--; c->Xm++; }
-        if (c->Xm > 0.75 * c->Mm) c->Xm = (int)(0.75 * c->Mm);
-        if (c->Xm > c->Im / 2) c->Xm = c->Im / 2;
-      }
-      float t1 = (float)(0.25 * PI_L / c->Xm);
-      unsigned int j = (Nm - c->Mm) / 2, k = j;
-      k += c->Xm / 2; j -= c->Xm / 2;
-      for (int i = 0; i < c->Xm; i++) {
-        c->h_cos2win[i] = (float)(c->h_mixwin[k] * pow(cos(t1), 2.0));
-        c->h_sin2win[i] = (float)(c->h_mixwin[j] * pow(sin(t1), 2.0));
-        k--; j++;
-        t1 = (float)(t1 + 0.5 * PI_L / c->Xm);
-      }
-    }
-  }
+  // prepare_mixer(&mix1, ..) (buf.c:1290) and, with fft3 configured, prepare_mixer(&mix2, THIRD_FFT_SINPOW) (baseb_graph.c:899)
+  c->Xm = prepare_mixer(c->Nm, c->Im, c->Mm, cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow, c->h_mixwin, c->h_sin2win, c->h_cos2win);
+  if (cfg->fft3_n > 0) c->Xm2 = prepare_mixer(c->Nm2, c->Im2, c->Mm2, cfg->fft3_sinpow, c->h_mix2win, c->h_sin2win2, c->h_cos2win2);
   c->h_fqwin.assign(c->Nm / 2 + 1, 0.f);
   { double e1 = 3.2, e2 = 13.0 / c->Nm; for (int i = 0; i <= c->Nm / 2; i++) { c->h_fqwin[i] = 0.5F * (float)erfc(e1); e1 -= e2; } }   // fft0.c:818-827
   default_filtercorr(c); default_yfac(c);
@@ -675,6 +684,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     A(dev_alloc(c, &c->d_fft3, (size_t)cfg->max_fft3n * c->N3)); A(dev_alloc(c, &c->d_baseb, (size_t)cfg->baseband_size + 2 * c->Nm2));
     A(dev_alloc(c, &c->d_mix2_scratch, (size_t)cfg->max_fft3n * c->Nm2));
     A(dev_alloc(c, &c->d_xpol, (size_t)2 * cfg->max_fft3n * c->Nm2));
+    A(dev_alloc(c, &c->d_mix2win, c->Nm2 / 2 + 1)); A(dev_alloc(c, &c->d_sin2win2, c->Nm2)); A(dev_alloc(c, &c->d_cos2win2, c->Nm2));
   }
   c->ph_stride = (size_t)2 * c->mix_cap * c->Nm;
   A(dev_alloc(c, &c->d_ph, LRH_NSTAGE * c->ph_stride));
@@ -698,6 +708,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
     }
     A(upload(c, c->d_window2, c->h_window2.data(), N2)); A(upload(c, c->d_fqwin, c->h_fqwin.data(), c->Nm / 2 + 1));
     A(upload(c, c->d_mixwin, c->h_mixwin.data(), c->Nm / 2 + 1)); A(upload(c, c->d_sin2win, c->h_sin2win.data(), c->Nm)); A(upload(c, c->d_cos2win, c->h_cos2win.data(), c->Nm));
+    if (cfg->fft3_n > 0) { A(upload(c, c->d_mix2win, c->h_mix2win.data(), c->Nm2 / 2 + 1)); A(upload(c, c->d_sin2win2, c->h_sin2win2.data(), c->Nm2)); A(upload(c, c->d_cos2win2, c->h_cos2win2.data(), c->Nm2)); }
     A(upload(c, c->d_yfac, c->h_yfac.data(), N1)); A(upload_filtercorr(c));
     A(upload(c, c->d_tw1, tw1.data(), N1)); A(upload(c, c->d_tw2, tw2.data(), N2)); A(upload(c, c->d_twm, twm.data(), c->Nm));
     if (cfg->fft2_n > 14) { A(upload(c, c->d_tw2a, tw2a.data(), tw2a.size())); A(upload(c, c->d_tw2b, tw2b.data(), tw2b.size())); }
@@ -2492,6 +2503,10 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   Mix1OutArgs o; memset(&o, 0, sizeof o);
   o.scratch = c->d_mix2_scratch; o.timf3 = c->d_baseb; o.mask2 = c->cfg.baseband_size - 1; o.pa_first = p->baseb_pa; o.block = c->Mm2;
   o.nm = c->Nm2; o.overlap = c->Im2 != 0; o.selected = 1; o.rotate = 0;
+  if (c->Im2 != 0 && c->Im2 != c->Mm2) {                   // THIRD_FFT_SINPOW neither 0 nor 2: crossover functions (mix2.c:177-216)
+    if (c->Xm2 < 1) return fail(c, LRH_EINVAL, "mix2 window without a crossover region");
+    o.xover = c->Xm2; o.im = c->Im2; o.win = c->d_mix2win; o.sin2win = c->d_sin2win2; o.cos2win = c->d_cos2win2;
+  }
   const int mix2_n = c->cfg.mix2_n;
   LRH_DEVICE_WORK(c, {
     ProfScope ps(c, "mix2");

@@ -2619,31 +2619,37 @@ __global__ __launch_bounds__(256) void k_mix1_out(Mix1OutArgs a, int batch)
   if (i >= half) return;
   const int pos = (a.pa_first + b * a.block + i) & a.mask2;
   if (!a.selected) { a.timf3[pos] = make_float2(0.f, 0.f); return; }     // mix1_clear
-  if (a.xover > 0 && a.rotate) {
-    // Crossover windows (mix1.c:196-262, dfq = 0): sample i of the block comes from back-transform point i + k0;
-    // the first xover samples blend with the raw tail parked by the previous transform, the rest is divided by the
+  if (a.xover > 0) {
+    // Crossover windows (mix1.c:196-262, dfq = 0; mix2.c:177-216 without the rotation): sample i of the block comes from back-transform
+    // point i + k0; the first xover samples blend with the raw tail parked by the previous transform, the rest is divided by the
     // window (win = 1/window, walked up to the centre and down again), and xover raw points are parked beyond.
     const int X = a.xover, k0 = a.im / 2 - X / 2;
-    const float2 inc = a.ph_inc[b];
-    const float2 st = a.ph_start[(size_t)b * a.nchunks + i / LRH_PH_CHUNK];
-    float t1 = st.x, r1 = st.y;
-    for (int j = 0; j < (i & (LRH_PH_CHUNK - 1)); j++) { t1 += inc.x; r1 += inc.y; }
-    const float t3 = (float)sin((double)t1), t4 = (float)cos((double)t1);
+    float t3 = 0.f, t4 = 1.f, r1 = 0.f;
+    if (a.rotate) {
+      const float2 inc = a.ph_inc[b];
+      const float2 st = a.ph_start[(size_t)b * a.nchunks + i / LRH_PH_CHUNK];
+      float t1 = st.x; r1 = st.y;
+      for (int j = 0; j < (i & (LRH_PH_CHUNK - 1)); j++) { t1 += inc.x; r1 += inc.y; }
+      t3 = (float)sin((double)t1); t4 = (float)cos((double)t1);
+    }
     const float2 nw = a.scratch[(size_t)b * a.nm + i + k0];
     if (i < X) {
       const float2 raw = (b == 0) ? a.timf3[pos] : a.scratch[(size_t)(b - 1) * a.nm + a.block + i + k0];
-      const float r3 = (float)sin((double)r1), r4 = (float)cos((double)r1);
       const float w1 = a.sin2win[i], w2 = a.cos2win[i];
-      const float a1 = w2 * raw.x, a2 = w2 * raw.y;
-      a.timf3[pos] = make_float2(r4 * a1 - r3 * a2 + (t4 * nw.x - t3 * nw.y) * w1,
-                                 r4 * a2 + r3 * a1 + (t4 * nw.y + t3 * nw.x) * w1);
+      if (a.rotate) {
+        const float r3 = (float)sin((double)r1), r4 = (float)cos((double)r1);
+        const float a1 = w2 * raw.x, a2 = w2 * raw.y;
+        a.timf3[pos] = make_float2(r4 * a1 - r3 * a2 + (t4 * nw.x - t3 * nw.y) * w1,
+                                   r4 * a2 + r3 * a1 + (t4 * nw.y + t3 * nw.x) * w1);
+      } else a.timf3[pos] = make_float2(raw.x * w2 + nw.x * w1, raw.y * w2 + nw.y * w1);       // mix2.c:187-188
     } else {
-      const int ib = a.block / 2 + 1 + X / 2;              // complex index where the window walk turns (mix1.c:226)
+      const int ib = a.block / 2 + 1 + X / 2;              // complex index where the window walk turns (mix1.c:226, mix2.c:191)
       const int j = i < ib ? k0 + i : k0 + 2 * ib - 2 - i;
       const float rw = a.win[j];
-      a.timf3[pos] = make_float2((t4 * nw.x - t3 * nw.y) * rw, (t4 * nw.y + t3 * nw.x) * rw);
+      if (a.rotate) a.timf3[pos] = make_float2((t4 * nw.x - t3 * nw.y) * rw, (t4 * nw.y + t3 * nw.x) * rw);
+      else a.timf3[pos] = make_float2(nw.x * rw, nw.y * rw);
     }
-    if (b == batch - 1 && i < X)                           // raw tail for the next call (mix1.c:253-261)
+    if (b == batch - 1 && i < X)                           // raw tail for the next call (mix1.c:253-261, mix2.c:208-215)
       a.timf3[(a.pa_first + batch * a.block + i) & a.mask2] = a.scratch[(size_t)b * a.nm + a.block + i + k0];
     return;
   }

@@ -76,6 +76,7 @@ struct lro_ctx {
   int N3, I3, M3, Nm2, Im2, Mm2;
   cosin_t *fft3tab, *mix2tab;
   float *fft3_window, *fft3, *bg_filterfunc, *baseb_raw;
+  float *mix2_window, *mix2_sin2win, *mix2_cos2win; int Xm2;  /* crossover-window mix2 (prepare_mixer(&mix2, THIRD_FFT_SINPOW), baseb_graph.c:899) */
   float *tmp;                  /* scratch, 8*max(N1,N2) floats */
   /* masks */
   int fft1n_mask, fft1_mask, fft1_sumsq_mask, timf2pow_mask, timf2_mask, fft2n_mask, timf3_mask, timf1_bytemask;
@@ -255,6 +256,34 @@ static void *zal(size_t n) { return calloc(2 * n + 64, 1); }     /* byte counts 
 static void *zal(size_t n) { return calloc(n + 64, 1); }
 #endif
 
+/* prepare_mixer, buf.c:55-111: inverted window (mode 3) and the sin^2 / cos^2 crossover functions of a mixer whose window is neither
+   none nor sin^2; returns crossover_points */
+static int prepare_mixer(int size, int interleave, int newp, int sp, float *window, float *sin2win, float *cos2win)
+{
+  int X = 0;
+  if (sp == 0 || sp == 2) return 0;
+  make_window(3, size, sp, window);
+  if (sp == 9) X = size / 8;
+  else if (sp == 8) X = size / 16;
+  else {
+    unsigned int i = interleave / 2;
+    float t1 = window[i];
+    while (window[i] < 30 * t1 && i > 0) { i--; X++; }
+    if (X > 0.75 * newp) X = 0.75 * newp;
+    if (X > interleave / 2) X = interleave / 2;
+  }
+  float t1 = 0.25 * PI_L / X;
+  unsigned int j = (size - newp) / 2, k = j;
+  k += X / 2; j -= X / 2;
+  for (int i = 0; i < X; i++) {
+    cos2win[i] = window[k] * pow(cos(t1), 2.0);
+    sin2win[i] = window[j] * pow(sin(t1), 2.0);
+    k--; j++;
+    t1 += 0.5 * PI_L / X;
+  }
+  return X;
+}
+
 int lro_open(const lrh_config *cfg, lro_ctx **out)
 {
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
@@ -316,13 +345,14 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
     c->N3 = 1 << cfg->fft3_n; c->Nm2 = 1 << cfg->mix2_n;
     c->Im2 = (int)(interleave_ratio(cfg->fft3_sinpow) * c->Nm2); c->Im2 &= 0xfffffffe; c->Mm2 = c->Nm2 - c->Im2;
     c->I3 = c->Im2 * (c->N3 / c->Nm2); c->M3 = c->N3 - c->I3;
-    if (!(c->Im2 == 0 || c->Im2 == c->Mm2)) { free(c); return LRH_EINVAL; }
     c->fft3tab = zal(sizeof(cosin_t) * c->N3); c->mix2tab = zal(sizeof(cosin_t) * c->Nm2);
     c->fft3_window = zal(4 * (c->N3 + 8)); c->fft3 = zal(sizeof(float) * 2 * c->N3 * cfg->max_fft3n);
     c->bg_filterfunc = zal(4 * c->N3); c->baseb_raw = zal(8 * (size_t)cfg->baseband_size + 16 * c->Nm2);
     make_sincos(c->N3, c->fft3tab); make_sincos(c->Nm2, c->mix2tab);
     if (cfg->fft3_sinpow) make_window(1, c->N3, cfg->fft3_sinpow, c->fft3_window);     /* baseb_graph.c:3680 */
     for (int i = 0; i < c->N3; i++) c->bg_filterfunc[i] = 1.0f;
+    c->mix2_window = zal(4 * (c->Nm2 + 8)); c->mix2_sin2win = zal(4 * (c->Nm2 + 8)); c->mix2_cos2win = zal(4 * (c->Nm2 + 8));
+    c->Xm2 = prepare_mixer(c->Nm2, c->Im2, c->Mm2, cfg->fft3_sinpow, c->mix2_window, c->mix2_sin2win, c->mix2_cos2win);
   }
   c->tmp = zal(sizeof(float) * 8 * (NM > (1 << cfg->fft3_n) ? NM : (1 << cfg->fft3_n)));
   make_sincos(N1, c->fft1tab); make_sincos(N2, c->fft2tab); make_sincos(c->Nm, c->mix1tab);
@@ -330,31 +360,10 @@ int lro_open(const lrh_config *cfg, lro_ctx **out)
   if (cfg->fft1_sinpow != 0 && cfg->fft1_sinpow != 2) make_window(3, N1, cfg->fft1_sinpow, c->fft1_inverted_window);
   if (cfg->fft2_sinpow) make_window(4, N2, cfg->fft2_sinpow, c->fft2_window);
   make_window(5, c->Nm, 4, c->mix1_fqwin);            /* buf.c:1297 */
-  {                                                        /* prepare_mixer, buf.c:55-111 */
+  {                                                        /* prepare_mixer(&mix1, ..), buf.c:1290 */
     const int sp = cfg->second_fft_enable ? cfg->fft2_sinpow : cfg->fft1_sinpow;
     c->mix1_window = zal(4 * (c->Nm + 8)); c->mix1_sin2win = zal(4 * (c->Nm + 8)); c->mix1_cos2win = zal(4 * (c->Nm + 8));
-    c->Xm = 0;
-    if (sp != 0 && sp != 2) {
-      make_window(3, c->Nm, sp, c->mix1_window);
-      if (sp == 9) c->Xm = c->Nm / 8;
-      else if (sp == 8) c->Xm = c->Nm / 16;
-      else {
-        unsigned int i = c->Im / 2;
-        float t1 = c->mix1_window[i];
-        while (c->mix1_window[i] < 30 * t1 && i > 0) { i--; c->Xm++; }
-        if (c->Xm > 0.75 * c->Mm) c->Xm = 0.75 * c->Mm;
-        if (c->Xm > c->Im / 2) c->Xm = c->Im / 2;
-      }
-      float t1 = 0.25 * PI_L / c->Xm;
-      unsigned int j = (c->Nm - c->Mm) / 2, k = j;
-      k += c->Xm / 2; j -= c->Xm / 2;
-      for (int i = 0; i < c->Xm; i++) {
-        c->mix1_cos2win[i] = c->mix1_window[k] * pow(cos(t1), 2.0);
-        c->mix1_sin2win[i] = c->mix1_window[j] * pow(sin(t1), 2.0);
-        k--; j++;
-        t1 += 0.5 * PI_L / c->Xm;
-      }
-    }
+    c->Xm = prepare_mixer(c->Nm, c->Im, c->Mm, sp, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win);
   }
   default_filtercorr(c); default_yfac(c);
   /* blanker start state: buf.c:418-431, hires_graph.c:1157-1162 */
@@ -374,7 +383,7 @@ void lro_close(lro_ctx *c)
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
                 c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xweak, c->tf_partner, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
-                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag, c->wf_pre };
+                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag, c->wf_pre, c->mix2_window, c->mix2_sin2win, c->mix2_cos2win };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
     struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; float *rn; int *rf, *rl; } *s = c->sellim;
@@ -1680,12 +1689,25 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
     for (int i = 0; i < sizhalf; i++) { tmp[nn - 2 * i] = f3[p0 - 2 * i - 2] * c->bg_filterfunc[k - i - 1]; tmp[nn - 2 * i + 1] = f3[p0 - 2 * i - 1] * c->bg_filterfunc[k - i - 1]; }
     dif_stages(size, c->cfg.mix2_n, tmp, c->mix2tab, -1, 2); bitrev_inplace(size, c->cfg.mix2_n, tmp, 2);
     float *br = c->baseb_raw;
-    if (c->Im2 != 0) {                                   /* THIRD_FFT_SINPOW == 2: 50 % overlap-add */
+    if (c->cfg.fft3_sinpow == 2) {                       /* THIRD_FFT_SINPOW == 2: 50 % overlap-add, mix2.c:158-176 */
       for (int i = 0; i < sizhalf; i++) { br[2 * p->baseb_pa + 2 * i] += tmp[2 * i]; br[2 * p->baseb_pa + 2 * i + 1] += tmp[2 * i + 1]; }
       int q = (p->baseb_pa + sizhalf) & bmask;
       for (int i = 0; i < size; i++) br[2 * q + i] = tmp[size + i];
-    } else {                                             /* no window: transforms simply follow each other */
+    } else if (c->Im2 == 0) {                            /* no window: transforms simply follow each other */
       for (int i = 0; i < 2 * size; i++) br[2 * p->baseb_pa + i] = tmp[i];
+    } else {                                             /* other windows: crossover functions, mix2.c:177-216 */
+      const int X = c->Xm2;
+      int p0 = p->baseb_pa, k = c->Im2 - 2 * (X / 2), j = k / 2 + X, i;
+      const int ia = 2 * X, ib = c->Mm2 + 2 + 2 * (X / 2), ic = 2 * c->Mm2, id = 2 * (X + c->Mm2);
+      for (i = 0; i < ia; i += 2) {                      /* the raw tail the previous transform parked here, blended with this one's start */
+        br[2 * p0] = br[2 * p0] * c->mix2_cos2win[i >> 1] + tmp[i + k] * c->mix2_sin2win[i >> 1];
+        br[2 * p0 + 1] = br[2 * p0 + 1] * c->mix2_cos2win[i >> 1] + tmp[i + k + 1] * c->mix2_sin2win[i >> 1];
+        p0 = (p0 + 1) & bmask;
+      }
+      for (i = ia; i < ib; i += 2) { br[2 * p0] = tmp[i + k] * c->mix2_window[j]; br[2 * p0 + 1] = tmp[i + k + 1] * c->mix2_window[j]; p0 = (p0 + 1) & bmask; j++; }
+      j--;
+      for (i = ib; i < ic; i += 2) { j--; br[2 * p0] = tmp[i + k] * c->mix2_window[j]; br[2 * p0 + 1] = tmp[i + k + 1] * c->mix2_window[j]; p0 = (p0 + 1) & bmask; }
+      for (i = ic; i < id; i += 2) { br[2 * p0] = tmp[i + k]; br[2 * p0 + 1] = tmp[i + k + 1]; p0 = (p0 + 1) & bmask; }
     }
     p->baseb_pa = (p->baseb_pa + c->Mm2) & bmask;
     p->fft3_px = (p->fft3_px + 2 * N) & (c->cfg.max_fft3n * 2 * N - 1);

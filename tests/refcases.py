@@ -55,6 +55,12 @@ CASES = {
                          fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
                          strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
                          pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8, mix2=1),
+    # ... and with THIRD_FFT_SINPOW = 3: fft3 windowed sin^3, mix2's transforms joined through the crossover functions of
+    # prepare_mixer(&mix2, ..) (mix2.c:177-216; buf.c:55-111) instead of the sin^2 overlap-add
+    "n10_n12_fft3_sin3": dict(n1=10, n2=12, mixred=5, nblk=120, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                              fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
+                              strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
+                              pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=3, mix2_n=6, max_fft3n=8, mix2=1),
     # int32 input (DWORD_INPUT: 18/24-bit hardware, expanded .raw recordings) with an I/Q sample skew (fft1.c:470-635)
     "n10_n12_dword": dict(n1=10, n2=12, mixred=6, nblk=48, avg1num=5, avg2num=4, att_n=8, gain=15, bln_interval=4, bln_avgnum=16,
                           fq=2200.3, wf_avgnum=2, wf_mode=1, seed=18, timf2pow_log2=15, sumsq_blocks=8, sigma=256.0,

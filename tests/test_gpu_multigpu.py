@@ -47,7 +47,7 @@ def _spawn(target, world, *args):
 
 
 def _rank_setup(rank, world, port, rehearse):
-    """rehearse: the same ranks on ONE GPU (device 0 for all, backend gloo, the exchanges through host memory) -- everything of these tests
+    """rehearse: the same ranks on ONE GPU (device 0 for all, backend gloo on the library's device buffers) -- everything of these tests
     but RCCL itself, so that they are not first executed on the day a multi-GPU node shows up"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -58,7 +58,7 @@ def _rank_setup(rank, world, port, rehearse):
     torch.cuda.set_device(index)
     dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     assert dist.get_world_size() == world
-    return torch, dist, (None if rehearse else torch.device(f"cuda:{index}")), index
+    return torch, dist, torch.device(f"cuda:{index}"), index      # (gloo moves device tensors through host memory by itself)
 
 
 def _pair_worker(rank, world, port, q, name, rehearse):
