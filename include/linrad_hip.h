@@ -26,12 +26,13 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 5      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
+#define LRH_ABI_VERSION 6      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
                                   3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
                                      lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions); lrh_exchange_fn takes the caller's own span;
                                      lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart)
                                   4: lrh_spur_permute (addition)
-                                  5: lrh_stage_wait, lrh_export_begin / _end (additions); lrh_export waits without holding the context's lock */
+                                  5: lrh_stage_wait, lrh_export_begin / _end (additions); lrh_export waits without holding the context's lock
+                                  6: lrh_set_basebraw_fir (addition); lrh_ptrs.timf3_py (was reserved[0]); cfg.fft3_sinpow takes every window */
 
 enum {
   LRH_OK = 0,
@@ -166,7 +167,8 @@ typedef struct lrh_ptrs {
   int timf2_pb, timf2_blockpower_pa;
   /* make_fft3_all (fft3.c:784,797) and fft3_mix2 (mix2.c:1079,2057-2059) */
   int timf3_px, fft3_pa, fft3_px, baseb_pa;
-  int reserved[6];
+  int timf3_py;                 /* fft3_mix2 with bg.mixer_mode = 2: where the newest fft3 transform's samples start in timf3 (mix2.c:229, 2060) */
+  int reserved[5];
 } lrh_ptrs;
 
 /* device-resident blanker scalars (blnkdef.h:18-33, globdef.h:983) read back on demand */
@@ -556,6 +558,10 @@ int lrh_set_pol(lrh_ctx *ctx, float c1, float c2, float c3);
 int lrh_set_combine_weights(lrh_ctx *ctx, float wa_re, float wa_im, float wb_re, float wb_im);
 int lrh_mix2_pol_begin(lrh_ctx *ctx, const lrh_ptrs *p, int batch, size_t *count);
 int lrh_set_bg_filterfunc(lrh_ctx *ctx, const float *bg_filterfunc /* fft3_size floats (baseb_graph.c:1246) */);
+/* bg.mixer_mode = 2 (mix2.c:217-246): lrh_fft3_mix2 then forms baseb_raw with the FIR basebraw_fir[0 .. pts) (symmetric, centre pts / 2, odd pts;
+   make_bg_filter derives it from the filter function, baseb_graph.c:1560-1634) on the timf3 samples, decimating by fft3_size / mix2.size, instead
+   of filtering fft3's bins; p->timf3_py walks like timf3_px.  fir = NULL: back to mixer_mode 1.  One channel. */
+int lrh_set_basebraw_fir(lrh_ctx *ctx, const float *basebraw_fir, int basebraw_fir_pts);
 /* compute_timf2_powersum (wcw.c:80-138): weak-signal power per block of released timf2 data, for the S/N meter */
 int lrh_compute_timf2_powersum(lrh_ctx *ctx, lrh_ptrs *p);
 int lrh_set_mix1_selfreq(lrh_ctx *ctx, double fq);        /* mix1_selfreq[0]; <0 deselects               */

@@ -53,7 +53,7 @@ class LrhPtrs(C.Structure):
         ("wg_waterf_sum_counter", C.c_int), ("wg_waterf_ptr", C.c_int), ("fft2_liminfo_cnt", C.c_int),
         ("fft2_nx", C.c_int), ("timf3_pa", C.c_int), ("timf2_pb", C.c_int), ("timf2_blockpower_pa", C.c_int),
         ("timf3_px", C.c_int), ("fft3_pa", C.c_int), ("fft3_px", C.c_int), ("baseb_pa", C.c_int),
-        ("reserved", C.c_int * 6),
+        ("timf3_py", C.c_int), ("reserved", C.c_int * 5),
     ]
 
     def as_dict(self):
@@ -236,6 +236,7 @@ class StageAPI:
         self._proto("exchange_write", [vp, C.c_int, fp, C.c_size_t, C.c_size_t])
         self._proto("compute_timf2_powersum", [vp, C.POINTER(LrhPtrs)])
         self._proto("set_bg_filterfunc", [vp, fp])
+        self._proto("set_basebraw_fir", [vp, fp, C.c_int])
         self._proto("fft1_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
         self._proto("set_blanker_tables", [vp, C.POINTER(LrhBlankerTables)])
         self._proto("spur_config", [vp, C.c_int, C.c_int, fp])
@@ -557,6 +558,14 @@ class StageAPI:
         f = np.ascontiguousarray(f, np.float32)
         assert f.size == (1 << self.cfg.fft3_n)
         self._chk(self._f("set_bg_filterfunc")(self.ctx, self._fptr(f)), "set_bg_filterfunc")
+
+    def set_basebraw_fir(self, fir=None):
+        """bg.mixer_mode = 2: fft3_mix2 decimates timf3 with this FIR (mix2.c:217-246); None: back to the filter on fft3's bins"""
+        if fir is None:
+            self._chk(self._f("set_basebraw_fir")(self.ctx, None, 0), "set_basebraw_fir")
+        else:
+            fir = np.ascontiguousarray(fir, np.float32)
+            self._chk(self._f("set_basebraw_fir")(self.ctx, self._fptr(fir), int(fir.size)), "set_basebraw_fir")
 
     def fft3_available(self):
         """transforms make_fft3_all may run now (do_fft3 loop condition, fft3.c:54-55)"""

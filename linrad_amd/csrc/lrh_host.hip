@@ -176,6 +176,7 @@ struct lrh_ctx {
   float *d_window1 = nullptr, *d_invwin1 = nullptr, *d_window2 = nullptr, *d_fqwin = nullptr, *d_yfac = nullptr;
   float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
   std::vector<float> h_mixwin, h_sin2win, h_cos2win;
+  float *d_bbfir = nullptr; int bbfir_pts = 0;              // bg.mixer_mode = 2 (lrh_set_basebraw_fir); nullptr: mixer_mode 1
   float *d_mix2win = nullptr, *d_sin2win2 = nullptr, *d_cos2win2 = nullptr; int Xm2 = 0;   // ... and mix2's (THIRD_FFT_SINPOW neither 0 nor 2, mix2.c:177-216)
   std::vector<float> h_mix2win, h_sin2win2, h_cos2win2;
   float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
@@ -480,7 +481,7 @@ void lrh_close(lrh_ctx *c)
   for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) hipHostFree(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
   for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
-  void *dev[] = { c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+  void *dev[] = { c->d_bbfir, c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
@@ -2486,12 +2487,41 @@ int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
   return LRH_OK;
 }
 
+// bg.mixer_mode = 2 (mix2.c:217-246): the FIR make_bg_filter derives from the filter function (baseb_graph.c:1560-1634), handed over like bg_filterfunc
+int lrh_set_basebraw_fir(lrh_ctx *c, const float *fir, int pts)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (!c->N3 || c->pol_set) return fail(c, LRH_ESTATE, "fft3 not configured, or a coherent combine is set (the FIR decimator is the one-channel form)");
+  if (fir && (pts < 1 || !(pts & 1) || pts + pts / 2 > c->I3 + c->N3 / c->Nm2 + 1)) return LRH_EINVAL;   // the first FIR of a transform must not reach behind its samples
+  HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_nb) HIPCHK(c, hipStreamSynchronize(c->stream_nb));
+  if (c->d_bbfir) { hipFree(c->d_bbfir); c->d_bbfir = nullptr; }
+  c->bbfir_pts = 0;
+  if (!fir) return LRH_OK;
+  { const int rc_ = dev_alloc(c, &c->d_bbfir, pts, false); if (rc_) return rc_; }
+  HIPCHK(c, hipMemcpyAsync(c->d_bbfir, fir, sizeof(float) * pts, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bbfir_pts = pts;
+  return LRH_OK;
+}
+
 int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
 {
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   LRH_ENTER(c);
+  if (c->d_bbfir) {                                        // bg.mixer_mode == 2
+    Mix2FirArgs f;
+    f.timf3 = c->d_timf3; f.mask = c->cfg.timf3_size / 2 - 1; f.py_first = p->timf3_py / 2; f.step = c->M3;
+    f.n3 = c->N3; f.m3 = c->M3; f.nm2new = c->Mm2; f.resamp = c->N3 / c->Nm2; f.fir = c->d_bbfir; f.pts = c->bbfir_pts;
+    f.baseb = c->d_baseb; f.bmask = c->cfg.baseband_size - 1; f.pa_first = p->baseb_pa;
+    LRH_DEVICE_WORK(c, { ProfScope ps(c, "mix2"); HIPCHK(c, launch_mix2_fir(f, batch, c->cur)); });
+    p->baseb_pa = (p->baseb_pa + batch * c->Mm2) & (c->cfg.baseband_size - 1);
+    p->fft3_px = (p->fft3_px + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);
+    p->timf3_py = (p->timf3_py + batch * 2 * c->M3) & c->timf3_mask;                     // mix2.c:2060
+    return LRH_OK;
+  }
   const bool pol = c->pol_set;
   if (pol && c->pol_batch != batch) return fail(c, LRH_ESTATE, "lrh_mix2_pol_begin and the all-reduce come first");
   c->pol_batch = 0;
@@ -2515,6 +2545,7 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   });
   p->baseb_pa = (p->baseb_pa + batch * c->Mm2) & (c->cfg.baseband_size - 1);             // mix2.c:1079, 2057
   p->fft3_px = (p->fft3_px + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // mix2.c:2058
+  p->timf3_py = (p->timf3_py + batch * 2 * c->M3) & c->timf3_mask;                      // mix2.c:2060
   return LRH_OK;
 }
 

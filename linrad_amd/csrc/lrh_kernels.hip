@@ -2739,6 +2739,28 @@ __global__ __launch_bounds__(fft_threads(LOG2N), fft_min_waves(LOG2N)) void k_mi
     for (int q = 0; q < RL; q++) o[(tid + m * T) + q * (N / RL)] = x[m * RL + q];
 }
 
+// fft3_mix2 with bg.mixer_mode = 2 (mix2.c:217-246): baseband sample k (1 .. new_points) of a transform is a symmetric FIR on timf3 centred
+// 1 - pts + fft3_size - fft3_new_points + k resamp samples behind timf3_py, the taps added from the centre outwards in the reference's order
+__global__ __launch_bounds__(64) void k_mix2_fir(Mix2FirArgs a)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x + 1, b = blockIdx.y;
+  if (k > a.nm2new) return;
+  const int c0 = a.py_first + b * a.step + 1 - a.pts + a.n3 - a.m3 + k * a.resamp, h = a.pts / 2;
+  const float2 x0 = a.timf3[c0 & a.mask];
+  float t1 = x0.x * a.fir[h], t2 = x0.y * a.fir[h];
+  for (int i = h - 1, j = 1; i >= 0; i--, j++) {
+    const float2 xp = a.timf3[(c0 + j) & a.mask], xm = a.timf3[(c0 - j) & a.mask];
+    const float f = a.fir[i];
+    t1 += (xp.x + xm.x) * f; t2 += (xp.y + xm.y) * f;
+  }
+  a.baseb[(a.pa_first + b * a.nm2new + k - 1) & a.bmask] = make_float2(t1, t2);
+}
+hipError_t launch_mix2_fir(const Mix2FirArgs &a, int batch, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_mix2_fir, dim3((a.nm2new + 63) / 64, batch), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
 // Two coupled channels, polarisation transform of fft3_mix2 (mix2.c:340-343, 377-380): this channel's bins times its
 // complex weight in A and in B; the two channels' shares are summed by the caller's all-reduce.
 __global__ __launch_bounds__(256) void k_pol(PolArgs a)

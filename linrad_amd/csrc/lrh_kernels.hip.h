@@ -274,6 +274,15 @@ struct Mix2Args {
   const float *filt; const float2 *tw; float2 *scratch; int nm;
   const float2 *pol;          // two coupled channels: [batch][nm] polarisation-combined bins standing in for the spectrum; null: fft3
 };
+// bg.mixer_mode = 2: FIR decimator on timf3 (mix2.c:217-246)
+struct Mix2FirArgs {
+  const float2 *timf3; int mask;        // complex samples
+  int py_first, step;                   // timf3_py of the first transform (complex samples), fft3_new_points
+  int n3, m3, nm2new, resamp;           // fft3_size, fft3_new_points, mix2.new_points, fft3_size / mix2.size
+  const float *fir; int pts;
+  float2 *baseb; int bmask, pa_first;
+};
+hipError_t launch_mix2_fir(const Mix2FirArgs &a, int batch, hipStream_t st);
 // own channel's share of the polarisation sums A and B (mix2.c:340-343): w_a, w_b complex weights of this channel
 struct PolArgs {
   const float2 *fft3; int n3; int first_slot, slot_mask; int nm, batch;

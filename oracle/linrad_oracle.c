@@ -76,6 +76,7 @@ struct lro_ctx {
   int N3, I3, M3, Nm2, Im2, Mm2;
   cosin_t *fft3tab, *mix2tab;
   float *fft3_window, *fft3, *bg_filterfunc, *baseb_raw;
+  float *basebraw_fir; int basebraw_fir_pts;                  /* bg.mixer_mode = 2 (lro_set_basebraw_fir), NULL: mixer_mode 1 */
   float *mix2_window, *mix2_sin2win, *mix2_cos2win; int Xm2;  /* crossover-window mix2 (prepare_mixer(&mix2, THIRD_FFT_SINPOW), baseb_graph.c:899) */
   float *tmp;                  /* scratch, 8*max(N1,N2) floats */
   /* masks */
@@ -383,7 +384,7 @@ void lro_close(lro_ctx *c)
                 c->fft2_window, c->mix1_fqwin, c->mix1_window, c->mix1_sin2win, c->mix1_cos2win, c->wg_waterf_yfac, c->liminfo, c->timf1, c->fft1_float, c->fft1_sumsq, c->fft1_slowsum,
                 c->timf2_float, c->timf2_pwr, c->fft2_float, c->fft2_power, c->fft2_powersum, c->wg_waterf, c->timf3_float, c->tmp, c->timf2_blockpower,
                 c->fft3tab, c->mix2tab, c->fft3_window, c->fft3, c->bg_filterfunc, c->baseb_raw, c->fft1_foldcorr, c->pwr_sum, c->xbuf, c->xweak, c->tf_partner, c->xbins, c->fft2_xypower, c->fft2_xysum, c->xpol,
-                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag, c->wf_pre, c->mix2_window, c->mix2_sin2win, c->mix2_cos2win };
+                c->bt_refpulse, c->bt_phasefunc, c->bt_pulindex, c->blanker_flag, c->wf_pre, c->mix2_window, c->mix2_sin2win, c->mix2_cos2win, c->basebraw_fir };
   for (size_t i = 0; i < sizeof(v) / sizeof(v[0]); i++) free(v[i]);
   if (c->sellim) {                     /* lro_sellim_state, defined with lro_fft1_update_liminfo */
     struct { float *old; unsigned char *wait; float *tmp, *group_min; int a, b, d; float *ftmp; float *rn; int *rf, *rl; } *s = c->sellim;
@@ -1605,6 +1606,15 @@ int lro_compute_timf2_powersum(lro_ctx *c, lrh_ptrs *p)
 
 /* ------------------------------------------------------------------ fft3 / mix2 */
 
+int lro_set_basebraw_fir(lro_ctx *c, const f32 *fir, int pts)
+{
+  if (!c->N3 || c->pol_set) return LRH_ESTATE;
+  free(c->basebraw_fir); c->basebraw_fir = NULL; c->basebraw_fir_pts = 0;
+  if (!fir) return LRH_OK;
+  if (pts < 1 || !(pts & 1) || pts + pts / 2 > c->I3 + c->N3 / c->Nm2 + 1) return LRH_EINVAL;   /* the first FIR of a transform must not reach behind its samples */
+  c->basebraw_fir = malloc(sizeof(float) * pts); in_f32(c->basebraw_fir, fir, pts); c->basebraw_fir_pts = pts;
+  return LRH_OK;
+}
 int lro_set_bg_filterfunc(lro_ctx *c, const f32 *f) { if (!c->N3) return LRH_ESTATE; in_f32(c->bg_filterfunc, f, c->N3); return LRH_OK; }
 
 /* make_fft3_all, 1 channel, transform part (fft3.c:240-283): window (mode-1 storage), e^{+j} radix-2 DIF without the
@@ -1677,6 +1687,27 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
   const int pol = c->pol_set;
   if (pol && c->pol_batch != batch) return LRH_ESTATE;      /* lro_mix2_pol_begin + all-reduce come first */
   c->pol_batch = 0;
+  if (c->basebraw_fir) {                                 /* bg.mixer_mode == 2: FIR on timf3, decimating by fft3_size / mix2.size (mix2.c:217-246) */
+    const int pts = c->basebraw_fir_pts, resamp = N / size, m3 = c->timf3_mask, tsize = c->cfg.timf3_size;
+    const float *t3 = c->timf3_float, *fir = c->basebraw_fir;
+    for (int b = 0; b < batch; b++) {
+      int p0 = p->baseb_pa;
+      for (int k = 1; k <= c->Mm2; k++) {
+        int pa = (p->timf3_py + 2 * (1 - pts + N - c->M3 + k * resamp) + tsize) & m3, mm = pa;
+        float t1 = t3[pa] * fir[pts / 2], t2 = t3[pa + 1] * fir[pts / 2];
+        for (int i = pts / 2 - 1; i >= 0; i--) {
+          pa = (pa + 2) & m3; mm = (mm - 2 + tsize) & m3;
+          t1 += (t3[pa] + t3[mm]) * fir[i]; t2 += (t3[pa + 1] + t3[mm + 1]) * fir[i];
+        }
+        c->baseb_raw[2 * p0] = t1; c->baseb_raw[2 * p0 + 1] = t2;
+        p0 = (p0 + 1) & bmask;
+      }
+      p->baseb_pa = (p->baseb_pa + c->Mm2) & bmask;
+      p->fft3_px = (p->fft3_px + 2 * N) & (c->cfg.max_fft3n * 2 * N - 1);
+      p->timf3_py = (p->timf3_py + 2 * c->M3) & m3;                      /* mix2.c:2060 */
+    }
+    return LRH_OK;
+  }
   for (int b = 0; b < batch; b++) {
     float *tmp = c->tmp;
     const float *f3 = c->fft3;
@@ -1711,6 +1742,7 @@ int lro_fft3_mix2(lro_ctx *c, lrh_ptrs *p, int batch)
     }
     p->baseb_pa = (p->baseb_pa + c->Mm2) & bmask;
     p->fft3_px = (p->fft3_px + 2 * N) & (c->cfg.max_fft3n * 2 * N - 1);
+    p->timf3_py = (p->timf3_py + 2 * c->M3) & c->timf3_mask;              /* mix2.c:2060 */
   }
   return LRH_OK;
 }

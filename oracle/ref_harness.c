@@ -200,7 +200,7 @@ static void *th_narrow(void *arg)
                             ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) {
         const double t3_ = sg_on ? sg_now() : 0;
         make_fft3_all();
-        if (TH.mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; }
+        if (TH.mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; timf3_py = (timf3_py + 2 * TH.C * fft3_new_points) & timf3_mask; }
         fft3_px = (fft3_px + fft3_block) & fft3_mask;
         if (sg_on) { sg_sec[SG_FFT3] += sg_now() - t3_; sg_calls[SG_FFT3]++; }     /* this thread only */
       }
@@ -388,6 +388,7 @@ int main(int argc, char **argv)
   const char *fdesired = arg(argc, argv, "desired", NULL);
   int spur_pnt = AI("spur_pnt", 0), spur_start = AI("spur_start", 16), spur_spek = AI("spur_speknum", 0);
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
+  int mixer_mode = AI("mixer_mode", 1);          /* 2: bg.mixer_mode = 2, the FIR decimator on timf3 (mix2.c:217-246) instead of the filter on fft3's bins */
   double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
   double ch2_c1 = AF("ch2_c1", 1.0), ch2_c2 = AF("ch2_c2", 0.0);   /* pg_ch2_c1 / pg_ch2_c2 (pol_graph.c:165-170), fft1.c:4064-4080 */
   const char *ffold = arg(argc, argv, "foldcorr", NULL);   /* N1 complex floats: enables CALIQ with this fft1_foldcorr */
@@ -729,7 +730,17 @@ int main(int argc, char **argv)
       baseband_size = 4096; baseband_mask = baseband_size - 1;
       baseb_raw = zalloc(sizeof(float) * (2 * baseband_size + 8 * mix2.size)); baseb_raw_orthog = zalloc(sizeof(float) * (2 * baseband_size + 8 * mix2.size));
       fft3_slowsum = zalloc(sizeof(float) * (2 * C * fft3_size + 64));   /* read (not used with pg.adapt != 0) by the two-channel branch, mix2.c:344 */
-      baseb_pa = 0; bg.mixer_mode = 1; fm_pilot_size = 0; genparm[CW_DECODE_ENABLE] = 0; yieldflag_ndsp_mix2 = 1;
+      baseb_pa = 0; bg.mixer_mode = mixer_mode; fm_pilot_size = 0; genparm[CW_DECODE_ENABLE] = 0; yieldflag_ndsp_mix2 = 1;
+      timf3_py = 0;
+      if (mixer_mode == 2) {        /* stand-in for the FIR make_bg_filter derives from the filter function (baseb_graph.c:1560-1634): a Hann-windowed
+                                       low pass of fft3_size/4 + 1 points, half the baseband wide, unit sum; symmetric (centre = pts/2) like the reference's */
+        basebraw_fir_pts = fft3_size / 4 + 1;
+        basebraw_fir = zalloc(sizeof(float) * (fft3_size + 8));
+        double sum = 0; const int h = basebraw_fir_pts / 2;
+        for (int i = 0; i < basebraw_fir_pts; i++) { double x = (i - h) * 0.5 * mix2.size / fft3_size, sinc = fabs(x) < 1e-12 ? 1.0 : sin(PI_L * x) / (PI_L * x);
+          double w = 0.5 + 0.5 * cos(PI_L * (i - h) / (h + 1.0)); basebraw_fir[i] = (float)(sinc * w); sum += basebraw_fir[i]; }
+        for (int i = 0; i < basebraw_fir_pts; i++) basebraw_fir[i] = (float)(basebraw_fir[i] / sum);
+      }
       memset(&pg, 0, sizeof(pg)); pg.c1 = (float)pol_c1; pg.c2 = (float)pol_c2; pg.c3 = (float)pol_c3; pg.adapt = 1; pg.avg = 1;
     }
   }
@@ -754,8 +765,10 @@ int main(int argc, char **argv)
 
 #define RUN_FFT3() do { if (n3 > 0) while (((timf3_pa - timf3_px + timf3_size) & timf3_mask) >= 2 * C * fft3_size && \
       ((fft3_pa - fft3_px + fft3_totsiz) & fft3_mask) < fft3_totsiz - 2 * fft3_block) { make_fft3_all(); nfft3++; \
-      if (mix2on) { thread_command_flag[THREAD_MIX2] = THRFLAG_ACTIVE; mix2_trip = 1; fft3_mix2(); mix2_trip = 0; \
-        baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; /* = last_point, mix2.c:1079, 2056 */ } \
+      if (mix2on) { thread_command_flag[THREAD_MIX2] = mixer_mode == 2 ? THRFLAG_IDLE : THRFLAG_ACTIVE; /* (mode 2 has no back transform to yield in: the check of mix2.c:749 is the first one) */ \
+        mix2_trip = 1; fft3_mix2(); mix2_trip = 0; \
+        baseb_pa = (baseb_pa + mix2.new_points) & baseband_mask; /* = last_point, mix2.c:1079, 2056 */ \
+        timf3_py = (timf3_py + 2 * C * fft3_new_points) & timf3_mask; /* mix2.c:2060 */ } \
       fft3_px = (fft3_px + fft3_block) & fft3_mask; /* mix2.c:2058; the rest of fft3_mix2 (demodulators) is not run */ } } while (0)
   /* ---- AFC tables (buf.c:1089-1092, 1255-1258) and the synthetic frequency supplier for the afc variants ---- */
   int afcn = second ? max_fft2n : max_fft1n;
@@ -1044,7 +1057,8 @@ run_done:
   if (n3 > 0) { PUTF("fft3", fft3, fft3_totsiz); PUTF("fft3_window", fft3_window, fft3_size);
     int f3[4] = { nfft3, fft3_pa, timf3_px, fft3_interleave_points }; PUTI("fft3_ptrs", f3, 4);
     if (mix2on) { PUTF("baseb_raw", baseb_raw, 2 * baseband_size); PUTF("baseb_raw_orthog", baseb_raw_orthog, 2 * baseband_size);
-      PUTF("bg_filterfunc", bg_filterfunc, fft3_size); int bp_[2] = { baseb_pa, fft3_px }; PUTI("baseb_ptrs", bp_, 2); } }
+      PUTF("bg_filterfunc", bg_filterfunc, fft3_size); int bp_[2] = { baseb_pa, fft3_px }; PUTI("baseb_ptrs", bp_, 2);
+      if (mixer_mode == 2) { PUTF("basebraw_fir", basebraw_fir, basebraw_fir_pts); PUTI("timf3_py", &timf3_py, 1); } } }
   if (sellim) {
     PUTF("liminfo_trace", limtrace, (size_t)N1 * (nlimupd > 0 ? nlimupd : 1)); PUTI("liminfo_trace_blk", limtrace_blk, nlimupd > 0 ? nlimupd : 1);
     int sp[16] = { nlimupd, genparm[SELLIM_MAXLEVEL], wg.spek_avgnum, liminfo_group_points, fft1_first_point, fft1_last_point, fft1_first_inband,

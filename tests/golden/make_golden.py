@@ -29,7 +29,7 @@ KEEP = ["hdr", "fft1_window", "fft1_filtercorr", "fft2_window", "mix1_fqwin", "w
         "fft1_inverted_window", "fft1_first_raw", "fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float",
         "timf2_pwr_float", "fft2_float", "fft2_power_float", "fft2_powersum_float", "timf3_float", "wf_lines",
         "trace", "itrace", "mixtrace", "final", "timf2_blockpower", "blockpower_ptrs", "fft3", "fft3_window",
-        "fft3_ptrs", "baseb_raw", "bg_filterfunc", "baseb_ptrs", "afc_fq0", "afc_supplied", "afc_fq_mid", "afc_fq_slope", "afc_fq_curv", "afc_fq_start"]
+        "fft3_ptrs", "baseb_raw", "bg_filterfunc", "baseb_ptrs", "basebraw_fir", "timf3_py", "afc_fq0", "afc_supplied", "afc_fq_mid", "afc_fq_slope", "afc_fq_curv", "afc_fq_start"]
 
 
 def run_case(name, **override):

@@ -38,6 +38,8 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
         # stand-in for make_bg_filter's output; the golden carries the table the compiled reference ran with
         api.set_bg_filterfunc(g["bg_filterfunc"] if "bg_filterfunc" in g else
                               np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))
+        if d["mixer_mode"] == 2:                     # bg.mixer_mode = 2: the FIR the compiled reference ran with (stand-in for make_bg_filter's)
+            api.set_basebraw_fir(g["basebraw_fir"])
     itrace, wf_lines, mixtrace = [], [], []
     afc, afc_t = None, [0]
     if d["afc"]:
@@ -107,6 +109,7 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
         out["baseb_raw"] = api.export(abi.RING_BASEB_RAW)
         out["fft3_ptrs"] = np.array([api.p.fft3_pa, api.p.timf3_px, api.fft3_interleave_points])
         out["baseb_ptrs"] = np.array([api.p.baseb_pa, api.p.fft3_px])
+        out["timf3_py"] = api.p.timf3_py
     if d["blockpower_block"]:
         out["timf2_blockpower"] = api.export(abi.RING_TIMF2_BLOCKPOWER)
         out["blockpower_ptrs"] = np.array([api.p.timf2_blockpower_pa, api.p.timf2_pb])
@@ -231,6 +234,8 @@ def compare_with_golden(out, g, tol=1e-5, check_blanker_exact=True, floor_slack=
         gate("fft3", out["fft3"], g["fft3"])
         if "baseb_raw" in g:                                  # fft3_mix2's filter / decimate part, run by the compiled reference
             assert np.array_equal(out["baseb_ptrs"], g["baseb_ptrs"]), "baseband pointers differ"
+            if "timf3_py" in g:
+                assert out["timf3_py"] == int(g["timf3_py"][0]), "timf3_py differs"
             assert np.count_nonzero(g["baseb_raw"]) > 500
             gate("baseb_raw", out["baseb_raw"], g["baseb_raw"])
     if "timf2_blockpower" in out:

@@ -61,6 +61,11 @@ CASES = {
                               fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
                               strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
                               pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=3, mix2_n=6, max_fft3n=8, mix2=1),
+    # ... and with bg.mixer_mode = 2: baseb_raw from the FIR decimator on timf3 (mix2.c:217-246) instead of the filter on fft3's bins
+    "n10_n12_fft3_fir": dict(n1=10, n2=12, mixred=5, nblk=120, avg1num=5, avg2num=4, att_n=4, bln_interval=4, bln_avgnum=16,
+                             fq=2200.3, wf_avgnum=2, wf_mode=1, seed=17, timf2pow_log2=15, sumsq_blocks=8,
+                             strong=[(-300.25, 9000.0), (37.0, 1000.0)], weak=[(38.6, 60.0), (411.3, 25.0)],
+                             pulse_period=1999, lim_halfwidth=3, fft3_n=8, fft3_sinpow=2, mix2_n=6, max_fft3n=8, mix2=1, mixer_mode=2),
     # int32 input (DWORD_INPUT: 18/24-bit hardware, expanded .raw recordings) with an I/Q sample skew (fft1.c:470-635)
     "n10_n12_dword": dict(n1=10, n2=12, mixred=6, nblk=48, avg1num=5, avg2num=4, att_n=8, gain=15, bln_interval=4, bln_avgnum=16,
                           fq=2200.3, wf_avgnum=2, wf_mode=1, seed=18, timf2pow_log2=15, sumsq_blocks=8, sigma=256.0,
@@ -120,7 +125,7 @@ def case_params(name):
     d = dict(sinpow1=2, sinpow2=2, gain=None, stupid=1, max_fft1n=8, max_fft2n=4, wf_first=0, wf_pixels=0,
              pulsewidth=0, blnfit_range=48, noise_floor=200, sigma=64.0, pulse_amp=20000.0, pulse_len=3, golden_stride=1,
              second_fft=1, blockpower_block=0, blockpower_size=1024, fft3_n=0, fft3_sinpow=2, mix2_n=0, max_fft3n=8,
-             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0, mix2=0, real=0)
+             dword=0, sample_shift=0, direction=1, foldcorr_seed=0, lim_mirror=0, afc=0, afc_bw=20.0, mix2=0, real=0, mixer_mode=1)
     d.update(CASES[name])
     if d["gain"] is None:
         # DWORD input is left-justified (x 2^14) and make_filcorrstart divides by 4096*12 (fft1.c:4656-4663)
@@ -231,7 +236,7 @@ def harness_args(d, infile, limfile, outfile):
     keys = ["n1", "n2", "sinpow1", "sinpow2", "mixred", "att_n", "gain", "avg1num", "avg2num", "nblk", "max_fft1n",
             "max_fft2n", "sumsq_blocks", "stupid", "bln_interval", "bln_avgnum", "pulsewidth", "blnfit_range",
             "noise_floor", "fq", "wf_avgnum", "wf_first", "wf_pixels", "wf_mode", "timf2pow_log2", "second_fft",
-            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw", "mix2", "real"]
+            "blockpower_block", "blockpower_size", "fft3_n", "fft3_sinpow", "mix2_n", "max_fft3n", "dword", "sample_shift", "direction", "afc", "afc_bw", "mix2", "real", "mixer_mode"]
     a = [f"{k}={d[k]}" for k in keys]
     a += [f"in={infile}", f"liminfo={limfile}", f"out={outfile}"]
     return a
