@@ -32,7 +32,7 @@ extern "C" {
                                      lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart)
                                   4: lrh_spur_permute (addition)
                                   5: lrh_stage_wait, lrh_export_begin / _end (additions); lrh_export waits without holding the context's lock
-                                  6: lrh_set_basebraw_fir (addition); lrh_ptrs.timf3_py (was reserved[0]); cfg.fft3_sinpow takes every window */
+                                  6: lrh_set_basebraw_fir, lrh_spur_search_config / _get (additions); lrh_ptrs.timf3_py (was reserved[0]); cfg.fft3_sinpow takes every window */
 
 enum {
   LRH_OK = 0,
@@ -374,6 +374,16 @@ int lrh_spur_get(lrh_ctx *ctx, int max, lrh_spur *spurs, int *n);          /* sy
    swap_spurs spursub.c:755: the list is kept in order of frequency, init_spur_elimination spursub.c:315-343): afterwards the device tracks
    n spurs, number i being what was number src[i] (loop state and history move along).  n <= the current count.  Synchronous. */
 int lrh_spur_permute(lrh_ctx *ctx, int n, const int *src);
+/* The search for NEW spurs (spur_removal -> init_spur_elimination, wcw.c:204-247, spursub.c:181): make_fft2 sums the power rows of
+   3 spur_speknum transforms into spursearch_powersum and, with the next row, forms spursearch_spectrum and cleans it
+   (fft2.c:673-699; spursearch_spectrum_cleanup, spursub.c:40-175: noise floor off, every peak that does not look like a spur's line
+   shape wiped).  With a range configured lrh_make_fft2 does that on the device for every transform it makes -- behind the spur
+   subtraction, like the reference -- on a stream of its own; the control plane fetches the finished search spectrum
+   (spectrum[0 .. last - first], may be NULL), spur_search_threshold, the number of search spectra completed so far and
+   spursearch_sum_counter, and walks it as before (autospur_point, spursub.c:268-290).  (0, 0) switches the search off.
+   Needs lrh_spur_config and cfg.fft2_float_sparse = 0.  The getter is synchronous. */
+int lrh_spur_search_config(lrh_ctx *ctx, int spur_search_first_point, int spur_search_last_point);
+int lrh_spur_search_get(lrh_ctx *ctx, float *spursearch_spectrum, float *spur_search_threshold, int *completed, int *spursearch_sum_counter);
 /* Acquisition on the device-resident spectra: store_new_spur (spursub.c:619-751: the seven bins from `pnt` of the
    newest spur_speknum transforms join the history, the summed power gives the frequency with decimals) and spur_phase_lock
    (spursub.c:1247-1426 with verify_spur_pll :1428-1843: up to five rounds of the loop on that history, accepted when the corrections

@@ -56,6 +56,7 @@ static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins st
 static lrh_spur *hip_sp; static int *hip_spsrc; static int hip_spcap;   /* scratch of the spur hooks: genparm[MAX_NO_OF_SPURS] + 1 entries (buf.c:1102 clamps the parameter
                                                                           to fftx_size / SPUR_WIDTH), allocated by hip_open; the hooks run on THREAD_SECOND_FFT / spur_removal only */
 static pthread_mutex_t hip_phasing_lock = PTHREAD_MUTEX_INITIALIZER;    /* hip_ch2_c1 / _c2: up to six fft1_b workers compare and update them */
+extern float spur_search_threshold;       /* spursub.c:38 */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 static int hip_xgather(int which, size_t count);
@@ -160,6 +161,8 @@ int hip_open(void)
     hip_sp = malloc(sizeof(lrh_spur) * (size_t)hip_spcap); hip_spsrc = malloc(sizeof(int) * (size_t)hip_spcap);
     if (!hip_sp || !hip_spsrc) { hip_open_failed(); return LRH_ENOMEM; }
     if (lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { hip_open_failed(); return LRH_EINVAL; }
+    /* the search spectrum for new spurs is kept and cleaned on the device (fft2.c:673-699, spursearch_spectrum_cleanup) */
+    if (lrh_spur_search_config(hip_rx, spur_search_first_point, spur_search_last_point) != 0) { hip_open_failed(); return LRH_EINVAL; }
   }
   if (HC == 2 && fft1_correlation_flag == 1)
     for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_open_failed(); return LRH_EINVAL; }
@@ -592,22 +595,18 @@ static void hip_spur_after_fft2(int na)
       if (n != no_of_spurs) { if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481); no_of_spurs = n; hip_spur_state_back(); }
     }
   }
-  if (spursearch_spectrum == NULL || spursearch_powersum == NULL || fftx_pwr == NULL) return;
-  {
-    float *pwra = &fftx_pwr[(size_t)na * hip_n2];
-    const int lo = spur_search_first_point, cnt = spur_search_last_point - spur_search_first_point + 1;
-    if (cnt <= 0) return;
-    lrh_export(hip_rx, LRH_RING_FFT2_POWER, &pwra[lo], (size_t)na * hip_n2 + lo, (size_t)cnt);
-    if (spursearch_sum_counter > 3 * spur_speknum) {
-      spursearch_sum_counter = 0;
-      for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_spectrum[i] = spursearch_powersum[i] + pwra[i];
-      spursearch_spectrum_cleanup();
-    } else {
-      if (spursearch_sum_counter == 0) for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_powersum[i] = pwra[i];
-      else for (i = spur_search_first_point; i <= spur_search_last_point; i++) spursearch_powersum[i] += pwra[i];
-      spursearch_sum_counter++;
-    }
-  }
+  if (spursearch_spectrum == NULL) return;
+  /* make_fft2's counter walk (fft2.c:675-699); the library sums the power rows and cleans the finished spectrum itself: what comes back,
+     once per 3 spur_speknum + 2 transforms, is the search spectrum init_spur_elimination walks, its threshold, and the tail of
+     spursearch_spectrum_cleanup that re-arms the walk (spursub.c:173-174) */
+  if (spursearch_sum_counter > 3 * spur_speknum) {
+    const int lo = spur_search_first_point;
+    int done = 0, cnt = -1;
+    spursearch_sum_counter = 0;
+    if (lrh_spur_search_get(hip_rx, &spursearch_spectrum[lo], &spur_search_threshold, &done, &cnt) != 0 || cnt != 0) { lirerr(1482); return; }
+    if (autospur_point >= spur_search_last_point - SPUR_WIDTH / 2) autospur_point = spur_search_first_point + SPUR_WIDTH / 2 + 1;
+  } else spursearch_sum_counter++;
+  (void)na;
 }
 
 static void hip_wf_collect(void)

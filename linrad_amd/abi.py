@@ -243,6 +243,8 @@ class StageAPI:
         self._proto("spur_set", [vp, C.c_int, C.POINTER(LrhSpur), fp, fp, ip])
         self._proto("spur_get", [vp, C.c_int, C.POINTER(LrhSpur), ip])
         self._proto("spur_acquire", [vp, C.POINTER(LrhPtrs), C.c_int, ip])
+        self._proto("spur_search_config", [vp, C.c_int, C.c_int])
+        self._proto("spur_search_get", [vp, fp, fp, ip, ip])
         self._proto("get_liminfo", [vp, fp])
         self._proto("fft2_update_liminfo", [vp, C.POINTER(LrhPtrs), C.POINTER(LrhSellim)])
         self._proto("wideband_limiter", [vp, C.POINTER(LrhSellim), C.c_int])
@@ -464,6 +466,20 @@ class StageAPI:
         locked = C.c_int()
         self._chk(self._f("spur_acquire")(self.ctx, C.byref(self.p), int(pnt), C.byref(locked)), "spur_acquire")
         return bool(locked.value)
+
+    def spur_search_config(self, first_point, last_point):
+        """the search for new spurs on the resident power rows: make_fft2 keeps the sums over 3 spur_speknum transforms and cleans the
+        finished search spectrum (fft2.c:673-699, spursearch_spectrum_cleanup spursub.c:40); (0, 0): off"""
+        self._first_last = (int(first_point), int(last_point))
+        self._chk(self._f("spur_search_config")(self.ctx, int(first_point), int(last_point)), "spur_search_config")
+
+    def spur_search_get(self, spectrum=True):
+        """(spursearch_spectrum[first .. last] or None, spur_search_threshold, search spectra completed so far, spursearch_sum_counter)"""
+        a, b = self._first_last
+        out = np.zeros(b - a + 1, np.float32) if spectrum else None
+        thr, done, cnt = C.c_float(), C.c_int(), C.c_int()
+        self._chk(self._f("spur_search_get")(self.ctx, self._fptr(out) if spectrum else None, C.byref(thr), C.byref(done), C.byref(cnt)), "spur_search_get")
+        return out, thr.value, done.value, cnt.value
 
     def spur_get(self, max_spurs=16):
         arr = (LrhSpur * max_spurs)()

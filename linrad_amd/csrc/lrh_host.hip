@@ -177,6 +177,9 @@ struct lrh_ctx {
   float *d_mixwin = nullptr, *d_sin2win = nullptr, *d_cos2win = nullptr; int Xm = 0;   // crossover-window mix1 (prepare_mixer, buf.c:55-111)
   std::vector<float> h_mixwin, h_sin2win, h_cos2win;
   float *d_bbfir = nullptr; int bbfir_pts = 0;              // bg.mixer_mode = 2 (lrh_set_basebraw_fir); nullptr: mixer_mode 1
+  // the search for new spurs (lrh_spur_search_config): sums and search spectrum on the device, the cleanup on a stream of its own
+  float *d_ss_sum = nullptr, *d_ss_spec_base = nullptr, *d_ss_min = nullptr, *d_ss_out = nullptr; int ss_first = 0, ss_last = 0, ss_counter = 0, ss_completed = 0;
+  hipStream_t stream_ss = nullptr; hipEvent_t ev_ss_in = nullptr, ev_ss_done = nullptr; bool ss_busy = false;
   float *d_mix2win = nullptr, *d_sin2win2 = nullptr, *d_cos2win2 = nullptr; int Xm2 = 0;   // ... and mix2's (THIRD_FFT_SINPOW neither 0 nor 2, mix2.c:177-216)
   std::vector<float> h_mix2win, h_sin2win2, h_cos2win2;
   float2 *d_filtercorr = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twm = nullptr, *d_tw2a = nullptr, *d_tw2b = nullptr, *d_fft2_scratch = nullptr;
@@ -477,11 +480,14 @@ void lrh_close(lrh_ctx *c)
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
   if (c->stream_out) { hipStreamSynchronize(c->stream_out); hipStreamDestroy(c->stream_out); }
   if (c->stream_f2) { hipStreamSynchronize(c->stream_f2); hipStreamDestroy(c->stream_f2); }
+  if (c->stream_ss) { hipStreamSynchronize(c->stream_ss); hipStreamDestroy(c->stream_ss); }
+  if (c->ev_ss_in) hipEventDestroy(c->ev_ss_in);
+  if (c->ev_ss_done) hipEventDestroy(c->ev_ss_done);
   for (int i = 0; i < 3; i++) { if (c->ev_f2c[i]) hipEventDestroy(c->ev_f2c[i]); if (c->ev_f2r[i]) hipEventDestroy(c->ev_f2r[i]); }
   for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) hipHostFree(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
   for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
-  void *dev[] = { c->d_bbfir, c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
+  void *dev[] = { c->d_ss_sum, c->d_ss_spec_base, c->d_ss_min, c->d_ss_out, c->d_bbfir, c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
                   c->d_blnbits, c->d_fft2, c->d_power2, c->d_powersum2, c->d_powersum2_alt, c->d_wf_scratch, c->d_waterf, c->d_timf3, c->d_mix_scratch,
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
@@ -1092,6 +1098,71 @@ int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra
   c->spur_max = max_spurs; c->spur_speknum = speknum;
   return LRH_OK;
 }
+// The search for new spurs on the resident power rows (include/linrad_hip.h): make_fft2 keeps spursearch_powersum over 3 spur_speknum
+// transforms and, with the next one, forms spursearch_spectrum and cleans it (fft2.c:673-699, spursub.c:40-175).  The cleanup runs on a
+// stream of its own behind the transform that completed the sums: it is one workgroup's serial walk, not main-stream work.
+int lrh_spur_search_config(lrh_ctx *c, int first_point, int last_point)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
+  if (c->stream_ss) HIPCHK(c, hipStreamSynchronize(c->stream_ss));
+  for (float **q_ : { &c->d_ss_sum, &c->d_ss_spec_base, &c->d_ss_min, &c->d_ss_out }) if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  c->ss_counter = 0; c->ss_completed = 0; c->ss_busy = false;
+  if (first_point == 0 && last_point == 0) return LRH_OK;
+  if (first_point < 0 || last_point >= c->N2 || last_point - first_point < 64) return LRH_EINVAL;
+  if (c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "the spur search reads whole power rows: cfg.fft2_float_sparse must be 0");
+  int rc;
+  // (the reference's walk reads up to three bins before the first and 31 behind the last point of the range, spursub.c:48, 160-167)
+  if ((rc = dev_alloc(c, &c->d_ss_sum, (size_t)c->N2 + 64)) || (rc = dev_alloc(c, &c->d_ss_spec_base, (size_t)c->N2 + 128)) ||
+      (rc = dev_alloc(c, &c->d_ss_min, (size_t)c->N2 / 32 + 64)) || (rc = dev_alloc(c, &c->d_ss_out, 4))) return rc;
+  if (!c->stream_ss) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream_ss, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ss_in, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_ss_done, hipEventDisableTiming));
+  }
+  c->ss_first = first_point; c->ss_last = last_point;
+  return LRH_OK;
+}
+// one new power row (transform `na` of the ring), behind whatever `src` has enqueued so far
+static int spur_search_row(lrh_ctx *c, int na, hipStream_t src)
+{
+  if (!c->d_ss_sum) return LRH_OK;
+  SpurSearchArgs a; memset(&a, 0, sizeof a);
+  a.sum = c->d_ss_sum; a.spec = c->d_ss_spec_base + 32; a.mins = c->d_ss_min; a.z = c->d_fft2 + (size_t)na * c->N2;
+  a.first = c->ss_first; a.last = c->ss_last; a.spectra = c->d_spur_spectra; a.out = c->d_ss_out;
+  const double s3 = sqrt((float)(3 * c->spur_speknum));
+  a.noise_factor = pow(10., 0.7 / s3); a.thr_factor = pow(10., 1.5 / s3);
+  // the rows are element-wise and short: on the caller's stream, right behind the kernels that made the power row.  Only the cleanup
+  // goes to the stream of its own; the row that forms the next search spectrum waits for it (3 spur_speknum transforms later: long done)
+  if (c->ss_counter > 3 * c->spur_speknum) {
+    c->ss_counter = 0;
+    a.mode = 2;
+    if (c->ss_busy) { HIPCHK(c, hipStreamWaitEvent(src, c->ev_ss_done, 0)); c->ss_busy = false; }
+    HIPCHK(c, launch_spur_search_row(a, src));
+    HIPCHK(c, hipEventRecord(c->ev_ss_in, src)); HIPCHK(c, hipStreamWaitEvent(c->stream_ss, c->ev_ss_in, 0));
+    HIPCHK(c, launch_spur_search_cleanup(a, c->stream_ss));
+    HIPCHK(c, hipEventRecord(c->ev_ss_done, c->stream_ss)); c->ss_busy = true;
+    c->ss_completed++;
+  } else {
+    a.mode = c->ss_counter == 0 ? 0 : 1;
+    HIPCHK(c, launch_spur_search_row(a, src));
+    c->ss_counter++;
+  }
+  return LRH_OK;
+}
+int lrh_spur_search_get(lrh_ctx *c, float *spectrum, float *threshold, int *completed, int *sum_counter)
+{
+  LRH_ENTER(c);
+  if (!c) return LRH_EINVAL;
+  if (!c->d_ss_sum) return fail(c, LRH_ESTATE, "lrh_spur_search_config first");
+  HIPCHK(c, hipStreamSynchronize(c->stream_ss));
+  if (spectrum) HIPCHK(c, hipMemcpy(spectrum, c->d_ss_spec_base + 32 + c->ss_first, sizeof(float) * (size_t)(c->ss_last - c->ss_first + 1), hipMemcpyDeviceToHost));
+  if (threshold) { float o[2] = { 0, 0 }; HIPCHK(c, hipMemcpy(o, c->d_ss_out, sizeof o, hipMemcpyDeviceToHost)); *threshold = o[0]; }
+  if (completed) *completed = c->ss_completed;
+  if (sum_counter) *sum_counter = c->ss_counter;
+  return LRH_OK;
+}
+
 // what k_spur / k_spur_acquire need from the context: the loop constants follow spur_speknum (buf.c:480, 1141-1170)
 static void spur_args(lrh_ctx *c, SpurArgs *out, int first_na, int batch)
 {
@@ -2107,6 +2178,9 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
         if (batch > first) HIPCHK(c, launch_power_of(c->d_fft2, c->d_power2, (size_t)(batch - first) * N, main_s));
       }
       if (c->split_fft2_tail) { HIPCHK(c, hipEventRecord(c->ev_fft2, main_s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fft2, 0)); }
+    }
+    if (c->d_ss_sum) {                                     // the search for new spurs takes the batch's power rows one by one (fft2.c:673-699)
+      for (int b = 0; b < batch; b++) { const int rcs_ = spur_search_row(c, (na0 + b) & c->fft2n_mask, main_s); if (rcs_) return rcs_; }
     }
     if (!fused) { ProfScope ps(c, "powersum2"); HIPCHK(c, launch_powersum2(s, c->cur)); }
     if (nlines > 0) { ProfScope ps(c, "waterfall"); HIPCHK(c, launch_waterfall(w, nlines, c->cur)); }

@@ -274,6 +274,17 @@ struct Mix2Args {
   const float *filt; const float2 *tw; float2 *scratch; int nm;
   const float2 *pol;          // two coupled channels: [batch][nm] polarisation-combined bins standing in for the spectrum; null: fft3
 };
+// the search for new spurs: make_fft2's sums over 3 spur_speknum power rows (fft2.c:673-699) and spursearch_spectrum_cleanup (spursub.c:40-175)
+struct SpurSearchArgs {
+  float *sum, *spec, *mins;             // spursearch_powersum, spursearch_spectrum (fft2_size floats each), minima of the groups of 32 bins
+  const float2 *z;                      // the transform's spectrum behind the spur subtraction: the power row is |z|^2 (the fused fft2 kernels keep sums only)
+  int first, last, mode;                // mode 0: sum = row, 1: sum += row, 2: spec = sum + row (then the cleanup)
+  const float *spectra;                 // spur_spectra [256][8] (init_spur_spectra)
+  double noise_factor, thr_factor;      // 10^(0.7 / sqrt(3 spur_speknum)), 10^(1.5 / sqrt(3 spur_speknum))
+  float *out;                           // [0] spur_search_threshold, [1] the noise floor
+};
+hipError_t launch_spur_search_row(const SpurSearchArgs &a, hipStream_t st);
+hipError_t launch_spur_search_cleanup(const SpurSearchArgs &a, hipStream_t st);
 // bg.mixer_mode = 2: FIR decimator on timf3 (mix2.c:217-246)
 struct Mix2FirArgs {
   const float2 *timf3; int mask;        // complex samples

@@ -1300,6 +1300,7 @@ advance:
 
 
 static void lro_spur_hook(lro_ctx *c, int na);      /* eliminate_spurs, defined with the spur tracking at the end of this file */
+static void spur_search_row(lro_ctx *c, const float *pwra);
 
 /* make_fft2 mode 15 until FFT2_COMPLETE: fft2.c:86-141 (load, window, big_fftforward), 647-705 (power),
    707-815 (waterfall), 1831-1845 (pointers) */
@@ -1320,6 +1321,7 @@ int lro_make_fft2(lro_ctx *c, lrh_ptrs *p, int batch)
     if (p->wg_waterf_sum_counter == 0) for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] = pwra[i]; }
     else                               for (int i = 0; i < N; i++) { pwra[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1]; c->fft2_powersum[i] += pwra[i]; }
     p->wg_waterf_sum_counter++;
+    spur_search_row(c, pwra);                                        /* fft2.c:673-699 (genparm[MAX_NO_OF_SPURS] > 0) */
     if (p->wg_waterf_sum_counter >= c->cfg.waterfall_avgnum) fft2_waterfall_line(c, p, c->cfg.blanker_channels == 2 ? NULL : c->fft2_powersum);
     p->timf2_px = (p->timf2_px + 4 * c->M2) & mask;
     p->fft2_na = (p->fft2_na + 1) & c->fft2n_mask;
@@ -2448,6 +2450,9 @@ typedef struct {
   lrh_spur *sp; float *table, *signal; int *ind;
   float *sig, *der, *pha, *tmp;
   float sp_d0, sp_d1, sp_d2;
+  /* the search for new spurs (lro_spur_search_config): make_fft2's sums over 3 spur_speknum power rows (fft2.c:673-699) and the cleaned
+     search spectrum spursearch_spectrum_cleanup leaves (spursub.c:40-175) */
+  int ss_first, ss_last, ss_counter, ss_completed; float *ss_sum, *ss_spec, *ss_min; float ss_threshold;
 } lro_spurs;
 
 static void spur_complex_lowpass(const float *zin, float *zout, int nn, int siz)
@@ -2746,7 +2751,7 @@ int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const f32 *spectra)
   LRO_F32_ONLY(c);
   if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
   lro_spurs *S = c->spurs;
-  if (S) { free(S->sp); free(S->table); free(S->signal); free(S->ind); free(S->sig); free(S->der); free(S->pha); free(S->tmp); free(S); c->spurs = NULL; }
+  if (S) { free(S->sp); free(S->table); free(S->signal); free(S->ind); free(S->sig); free(S->der); free(S->pha); free(S->tmp); free(S->ss_sum); if (S->ss_spec) free(S->ss_spec - 8); free(S->ss_min); free(S); c->spurs = NULL; }
   if (!max_spurs) return LRH_OK;
   const int maxn = c->cfg.max_fft2n;
   S = calloc(1, sizeof *S);
@@ -2763,6 +2768,110 @@ int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const f32 *spectra)
   c->spurs = S;
   return LRH_OK;
 }
+/* ---- the search for new spurs on the resident power rows ---- */
+int lro_spur_search_config(lro_ctx *c, int first_point, int last_point)
+{
+  LRO_F32_ONLY(c);
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S) return LRH_ESTATE;
+  free(S->ss_sum); if (S->ss_spec) free(S->ss_spec - 8); free(S->ss_min); S->ss_sum = S->ss_spec = S->ss_min = NULL;
+  S->ss_counter = 0; S->ss_completed = 0; S->ss_threshold = 0;
+  if (first_point == 0 && last_point == 0) return LRH_OK;
+  if (first_point < 0 || last_point >= c->N2 || last_point - first_point < 64) return LRH_EINVAL;
+  S->ss_first = first_point; S->ss_last = last_point;
+  /* (the reference's walk reads up to three bins before the first and 31 behind the last point of the range, spursub.c:48, 160-167) */
+  S->ss_sum = calloc(c->N2 + 8, 4); S->ss_spec = (float *)calloc(c->N2 + 72, 4) + 8; S->ss_min = calloc(c->N2 / 32 + 8, 4);
+  return LRH_OK;
+}
+/* parabolic_fit, llsq.c:113-153 */
+static void parabolic_fit3(float *amp, float *pos, float y1, float y2, float y3)
+{
+  float t4 = y1 - y3, t3 = 2 * (y1 + y3 - 2 * y2);
+  if (t3 < 0) { *amp = y2 - 0.5F * t4 * t4 / t3; t4 = t4 / t3; if (fabs(t4) > 1) t4 /= (float)fabs(t4); *pos = t4; }
+  else if (y1 > y3) { *amp = y1; *pos = -1; }
+  else { *amp = y3; *pos = 1; }
+}
+/* spursearch_spectrum_cleanup, spursub.c:40-175: noise floor from the minima of groups of 32 bins, floor subtracted, and every peak above
+   the threshold that does not look like the reference line shape of a spur (it might be a wanted signal) wiped out of the search spectrum */
+static void spur_search_cleanup(lro_ctx *c, lro_spurs *S)
+{
+  float *sp = S->ss_spec, *mn = S->ss_min;
+  const int first = S->ss_first, last = S->ss_last;
+  int k = 0, i, j, ia, ib, nn;
+  float t1, noise, amp, pos, maxpow;
+  for (i = first; i < last; i += 32) { mn[k] = 1e30f; for (j = 0; j < 32; j++) if (sp[i + j] < mn[k]) mn[k] = sp[i + j]; k++; }
+  if (!k) return;
+  t1 = 0; for (i = 0; i < k; i++) t1 += mn[i];
+  t1 /= k;
+  noise = 0; j = 0;
+  for (i = 0; i < k; i++) if (mn[i] < t1) { noise += mn[i]; j++; }
+  noise /= j;
+  noise *= pow(10., 0.7 / sqrt((float)(3 * S->speknum)));
+  for (i = first; i < last; i++) { sp[i] -= noise; if (sp[i] < 0) sp[i] = 0; }
+  S->ss_threshold = noise * pow(10., 1.5 / sqrt((float)(3 * S->speknum)));
+  const float thr = S->ss_threshold;
+  ia = first;
+  for (;;) {
+    while (ia < last && sp[ia] < thr) ia++;
+    if (ia == last) break;
+    ib = ia + 1;
+    while (ib < last && sp[ib] > thr) ib++;
+    if (ib == last && ib - ia < SPSZ) break;
+    maxpow = 0; k = ia;
+    for (i = ia; i < ib; i++) if (sp[i] > maxpow) { maxpow = sp[i]; k = i; }
+    parabolic_fit3(&amp, &pos, sp[k - 1], sp[k], sp[k + 1]);
+    nn = k - SPSZ / 2 + 1;
+    if (pos < 0) { pos += 1; nn--; }
+    i = pos * NSPEC; if (i >= NSPEC) i = NSPEC - 1;
+    const float *spk = &S->spectra[i * SPSZ];
+    float refamp = fabs(spk[SPSZ / 2]);
+    if (refamp < fabs(spk[SPSZ / 2 - 1])) refamp = fabs(spk[SPSZ / 2 - 1]);
+    const float t2 = (float)sqrt(maxpow) / refamp;
+    float tot = 0, rem = 0, edge = 0;
+    int bad = 0;
+    for (i = 0; i < SPSZ; i++) {
+      if (sp[nn + i] < 0) { bad = 1; break; }
+      tot += sp[nn + i];
+      const float r1 = pow(sqrt(sp[nn + i]) - t2 * fabs(spk[i]), 2.0);
+      rem += r1;
+      if (edge < r1 && (i < 2 || i >= SPSZ - 2)) edge = r1;
+    }
+    if (bad || (edge / noise > 5 && tot / edge < 1000) || (edge / noise > 2 && tot / edge < 300) || rem / tot > 0.1) {
+      while ((sp[ia] > sp[ia - 1] || sp[ia] > sp[ia - 2] || sp[ia] > sp[ia - 3]) && ia > first) ia--;
+      while ((sp[ib] > sp[ib + 1] || sp[ib] > sp[ib + 2] || sp[ib] > sp[ib + 3]) && ib < last) ib++;
+      for (i = ia; i < ib; i++) sp[i] = -0.00000001;
+    }
+    ia = ib;
+  }
+}
+/* make_fft2's bookkeeping of the search spectrum for the new power row (fft2.c:673-699) */
+static void spur_search_row(lro_ctx *c, const float *pwra)
+{
+  lro_spurs *S = c->spurs;
+  if (!S || !S->ss_sum) return;
+  const int a = S->ss_first, b = S->ss_last;
+  if (S->ss_counter > 3 * S->speknum) {
+    S->ss_counter = 0;
+    for (int i = a; i <= b; i++) S->ss_spec[i] = S->ss_sum[i] + pwra[i];
+    spur_search_cleanup(c, S);
+    S->ss_completed++;
+  } else {
+    if (S->ss_counter == 0) for (int i = a; i <= b; i++) S->ss_sum[i] = pwra[i];
+    else for (int i = a; i <= b; i++) S->ss_sum[i] += pwra[i];
+    S->ss_counter++;
+  }
+}
+int lro_spur_search_get(lro_ctx *c, f32 *spectrum, f32 *threshold, int *completed, int *sum_counter)
+{
+  lro_spurs *S = c ? c->spurs : NULL;
+  if (!S || !S->ss_sum) return LRH_ESTATE;
+  if (spectrum) out_f32(spectrum, S->ss_spec + S->ss_first, (size_t)(S->ss_last - S->ss_first + 1));
+  if (threshold) *threshold = S->ss_threshold;
+  if (completed) *completed = S->ss_completed;
+  if (sum_counter) *sum_counter = S->ss_counter;
+  return LRH_OK;
+}
+
 int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const f32 *table, const f32 *signal, const int *ind)
 {
   LRO_F32_ONLY(c);

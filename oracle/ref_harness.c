@@ -93,6 +93,7 @@ int store_new_spur(int pnt);
 int spur_phase_lock(int nx);
 void init_spur_spectra(void);
 void eliminate_spurs(void);
+extern float spur_search_threshold;
 
 /* ---- container writer ---- */
 static FILE *fo;
@@ -595,6 +596,7 @@ int main(int argc, char **argv)
   hg_redraw_counter = 0; hg.spek_avgnum = 1 << 30; fft2_blocktime = 0;
   fft2_to_fft1_ratio = N2 / N1; if (fft2_to_fft1_ratio < 1) fft2_to_fft1_ratio = 1;
   float *spur_trace = NULL; int nspur_trace = 0, spur_locked_at = -1;
+  float *ss_last = NULL, ss_thr[64]; int ss_completed = 0, ss_at[64];       /* the search spectrum as the newest spursearch_spectrum_cleanup left it (fft2.c:676-683) */
   if (spur) {                                    /* buf.c:1100-1172, 1252, 1647 */
     const int ms = 4;
     genparm[MAX_NO_OF_SPURS] = ms; genparm[AFC_ENABLE] = 1;
@@ -624,6 +626,7 @@ int main(int argc, char **argv)
     spur_search_first_point = 0; spur_search_last_point = fftx_size - 1;
     init_spur_spectra();
     spur_trace = zalloc(sizeof(float) * 12 * ((size_t)nblk * 8 + 64));
+    ss_last = zalloc(4 * (size_t)fftx_size);
   }
 
   /* mix1 sizes first: fft2 interleave is re-derived from mix1 (buf.c:432-455) */
@@ -929,7 +932,13 @@ int main(int argc, char **argv)
       if (spur) { ffts_na = fft2_na; ffts_nm = fft2_nm;          /* what the previous pass of second_fft left (wcw.c:288-289) */
         spur_freq_factor = (float)fft2_new_points / fft2_size; spur_max_d2 = PI_L * spur_freq_factor / spur_speknum; }   /* buf.c:480, 1152 (fft2_new_points is known by now) */
       make_fft2_status = FFT2_NOT_ACTIVE;
+      const int ss_before = spursearch_sum_counter;
       while (make_fft2_status != FFT2_COMPLETE) ON(ST_FFT2, make_fft2);
+      if (spur && ss_before > 3 * spur_speknum && spursearch_sum_counter == 0) {      /* this transform completed a search spectrum */
+        memcpy(ss_last, spursearch_spectrum, 4 * (size_t)fftx_size);
+        if (ss_completed < 64) { ss_thr[ss_completed] = spur_search_threshold; ss_at[ss_completed] = nfft2; }
+        ss_completed++;
+      }
       if (spur && no_of_spurs == 0 && nfft2 + 1 == spur_start) {   /* acquisition, tail of init_spur_elimination (spursub.c:282-309) */
         ffts_na = fft2_na; ffts_nm = fft2_nm;
         spurno = 0; spur_ampl[0] = 1; spur_noise[0] = 0.001; spur_avgd2[0] = 0;
@@ -1073,7 +1082,10 @@ run_done:
       if (hg.sellim_par1 != 2) { int v1[1] = { hg.sellim_par1 }; PUTI("sellim2_par1", v1, 1); }
     }
   }
-  if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2); }
+  if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2);
+    PUTF("spursearch_spectrum", ss_last, fftx_size); PUTF("spursearch_thresholds", ss_thr, ss_completed < 64 ? (ss_completed > 0 ? ss_completed : 1) : 64);
+    int si[4] = { ss_completed, spursearch_sum_counter, spur_search_first_point, spur_search_last_point }; PUTI("spursearch_info", si, 4);
+    PUTI("spursearch_at", ss_at, ss_completed < 64 ? (ss_completed > 0 ? ss_completed : 1) : 64); }
   PUTF("timf2_blockpower", timf2_blockpower, bp_size);
   { int bp[2] = { timf2_blockpower_pa, timf2_pb }; PUTI("blockpower_ptrs", bp, 2); }
   put("wf_lines", "i2", wf_lines, (size_t)nwf * wg_xpixels, 2);

@@ -40,6 +40,8 @@
 #define lrh_spur_acquire lro_spur_acquire
 #define lrh_spur_get lro_spur_get
 #define lrh_spur_permute lro_spur_permute
+#define lrh_spur_search_config lro_spur_search_config
+#define lrh_spur_search_get lro_spur_search_get
 #define lrh_blanker_begin lro_blanker_begin
 #define lrh_blanker_weak_span lro_blanker_weak_span
 #define lrh_blanker_finish lro_blanker_finish

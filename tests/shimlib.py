@@ -251,7 +251,14 @@ def check_spur_case(harness, tmp_path, name="spur_n10_n12", tol=1e-5):
     out["timf3"] = dump["timf3_float"] * keep3
     g = dict(g)
     g["timf3_float"] = g["timf3_float"] * keep3
+    # the search spectrum for new spurs as the glue left it in Linrad's spursearch_spectrum: summed and cleaned on the device, fetched when
+    # make_fft2's counter says one is finished (hip_spur_after_fft2)
+    info = dump["spursearch_info"]
+    a_, b_ = int(info[2]), int(info[3])
+    out["ss"] = (dump["spursearch_spectrum"][a_:b_ + 1], float(dump["spursearch_thresholds"][min(int(info[0]), 64) - 1]), int(info[0]), int(info[1]))
+    out["ss_range"] = (a_, b_)
     rep = spurlib.compare(out, g, tol)
+    assert "search_spectrum_err" in rep
     assert np.array_equal(dump["final"], g["final"]) if "final" in g else True
     return rep
 

@@ -29,6 +29,8 @@ def run(open_fn, name, g, batch=1, acquire=False):
     st = g["spur_init_state"]
     speknum, start = int(st[10]), int(g["spur_locked"][0])
     api.spur_config(4, speknum, g["spur_spectra"])
+    first, last = (int(g["spursearch_info"][2]), int(g["spursearch_info"][3])) if "spursearch_info" in g else (0, (1 << cfg.fft2_n) - 1)
+    api.spur_search_config(first, last)                      # the search for further spurs runs beside the tracking (fft2.c:673-699)
     trace, nfft2, handed = [], 0, False
     for b in range(d["nblk"]):
         api.fft1_b(1), api.fft1_c(1), api.make_timf2(1)
@@ -56,7 +58,8 @@ def run(open_fn, name, g, batch=1, acquire=False):
                 maxn = cfg.max_fft2n
                 api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
                 handed = True
-    return dict(api=api, cfg=cfg, d=d, acq=(acq if acquire else None), trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
+    ss = api.spur_search_get()
+    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=(acq if acquire else None), trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
                 ps2=api.export(abi.RING_FFT2_POWERSUM))
 
 
@@ -93,6 +96,20 @@ def compare(out, g, tol, batch=1):
     assert rep["freq_err_bins"] < 1e-3 and rep["phase_err_rad"] < 20 * tol * 1e2 and rep["ampl_rel"] < 10 * tol, rep
     assert rep["fft2"] < tol and rep["ps2"] < tol and rep["timf3"] < tol, rep
     assert rep["residual_err_vs_carrier"] < tol, rep
+    if "spursearch_spectrum" in g and batch == 1:
+        # the search spectrum spursearch_spectrum_cleanup left last (spursub.c:40-175): the same peaks wiped (the -1e-8 marks), the same bins
+        # clamped to zero, what remains to float32 rounding of the three-spur_speknum sums; threshold, count of finished spectra, running counter
+        sp, thr, done, cnt = out["ss"]
+        a, b = out["ss_range"]
+        ref_sp = g["spursearch_spectrum"][a:b + 1]
+        info = g["spursearch_info"]
+        assert done == int(info[0]) and cnt == int(info[1]) and done >= 1, (done, cnt, info)
+        assert abs(thr - g["spursearch_thresholds"][min(done, 64) - 1]) <= 10 * tol * thr
+        assert np.array_equal(sp < 0, ref_sp < 0) and np.any(ref_sp < 0), "wiped peaks differ"
+        scale = float(np.max(ref_sp))
+        rep["search_spectrum_err"] = float(np.max(np.abs(sp - ref_sp)) / scale)
+        rep["search_zero_mismatch"] = int(np.count_nonzero((sp == 0) != (ref_sp == 0)))
+        assert rep["search_spectrum_err"] < tol and rep["search_zero_mismatch"] <= 2, rep
     return rep
 
 
