@@ -60,6 +60,7 @@ extern float spur_search_threshold;       /* spursub.c:38 */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
 static int hip_xgather(int which, size_t count);
+static void hip_spur_after_fft2(int na);
 static void hip_open_failed(void);
 static int hip_ss_ticket[8], hip_ss_n;     /* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
 static int hip_wf_ticket[6], hip_wf_n;     /* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
@@ -84,10 +85,10 @@ static int hip_unsupported(void)
   /* correlation spectrum: served for two I/Q channels (flag 1: fft1_corrsum / fft1_slowcorr / fft1_slowcorr_tot, fft1.c:4146-4150, 4584-4603);
      the correlation receiver (flag >= 2, its double-precision mixer) is not built */
   if (fft1_correlation_flag != 0 && !(fft1_correlation_flag == 1 && ui.rx_rf_channels == 2)) return 4;
-  /* spur removal: served with the second fft on (eliminate_spurs inside make_fft2, acquisition through the hooks in spursub.c); with the
-     second fft off the reference's fft1_c subtracts spurs from fft1_float (fft1.c:4242, 4432-4476), which version 21 does not do --
-     buf.c:836 zeroes MAX_NO_OF_SPURS itself when the AFC is off */
-  if (genparm[SECOND_FFT_ENABLE] == 0 && genparm[MAX_NO_OF_SPURS] != 0) return 5;
+  /* spur removal: eliminate_spurs inside make_fft2 with the second fft on, inside fft1_c with it off (fft1.c:4196-4244: the library takes the
+     carriers out of the fft1 transforms then), acquisition through the hooks in spursub.c -- buf.c:836 zeroes MAX_NO_OF_SPURS itself when
+     the AFC is off.  fft1_size above 16384 (the four-step transform) with spurs on the fft1 side: not served */
+  if (genparm[SECOND_FFT_ENABLE] == 0 && genparm[MAX_NO_OF_SPURS] != 0 && fft1_n > 14) return 5;
   if ((ui.network_flag & NET_RXOUT_TIMF2) != 0 && !swfloat) return 6;      /* the int16 payload is built from the MMX ring (rxin.c:968-990) */
   if (genparm[MIX1_NO_OF_CHANNELS] != 1) return 7;
   return 0;
@@ -155,14 +156,14 @@ int hip_open(void)
   hip_ch2_c1 = 1; hip_ch2_c2 = 0;
   hip_liminfo_sent = malloc(sizeof(float) * (size_t)fft1_size);
   memcpy(hip_liminfo_sent, liminfo, sizeof(float) * (size_t)fft1_size);
-  hip_spurs_on = genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
+  hip_spurs_on = genparm[AFC_ENABLE] != 0 && genparm[MAX_NO_OF_SPURS] != 0;
   if (hip_spurs_on) {
     hip_spcap = genparm[MAX_NO_OF_SPURS] + 1;
     hip_sp = malloc(sizeof(lrh_spur) * (size_t)hip_spcap); hip_spsrc = malloc(sizeof(int) * (size_t)hip_spcap);
     if (!hip_sp || !hip_spsrc) { hip_open_failed(); return LRH_ENOMEM; }
-    if (lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra) != 0) { hip_open_failed(); return LRH_EINVAL; }
+    if ((rc = lrh_spur_config(hip_rx, genparm[MAX_NO_OF_SPURS], spur_speknum, spur_spectra)) != 0) { hip_open_failed(); return rc; }
     /* the search spectrum for new spurs is kept and cleaned on the device (fft2.c:673-699, spursearch_spectrum_cleanup) */
-    if (lrh_spur_search_config(hip_rx, spur_search_first_point, spur_search_last_point) != 0) { hip_open_failed(); return LRH_EINVAL; }
+    if ((rc = lrh_spur_search_config(hip_rx, spur_search_first_point, spur_search_last_point)) != 0) { hip_open_failed(); return rc; }
   }
   if (HC == 2 && fft1_correlation_flag == 1)
     for (int ch = 0; ch < 2; ch++) if (lrh_set_correlation(hip_ctx[ch], 1) != 0) { hip_open_failed(); return LRH_EINVAL; }
@@ -295,6 +296,7 @@ void hip_fft1_c(void)
   room = genparm[SECOND_FFT_ENABLE] != 0 ? ((timf2_px - timf2_pa + timf2_mask + 1) & timf2_mask) / timf2_input_block - 1 : n;
   if (n > room) n = room;
   if (n > hip_max_batch) n = hip_max_batch;
+  if (hip_spurs_on && genparm[SECOND_FFT_ENABLE] == 0) n = 1;   /* spurs tracked in the fft1 transforms: Linrad looks at the loop state after every one */
   { /* ... and the periods it completes, beside the wg_fft_avg2num the slow average reads, must fit the fft1_sumsq ring (lrh_fft1_c) */
     const int lim = wg.fft_avg1num * (fft1_sumsq_bufsize / fft1_size - wg_fft_avg2num - 1) - fft1_sumsq_counter;
     if (n > lim) n = lim; }
@@ -317,6 +319,10 @@ void hip_fft1_c(void)
   fft1_nb = q.fft1_nb; fft1_pb = HIP_OUT(q.fft1_pb); fft1_sumsq_pa = q.fft1_sumsq_pa; fft1_sumsq_counter = q.fft1_sumsq_counter;
   fft1_liminfo_cnt = q.fft1_liminfo_cnt; fft1_sumsq_recalc = q.fft1_sumsq_recalc;
   if (genparm[SECOND_FFT_ENABLE] == 0) hip_afc_rows((q.fft1_nb - n) & fft1n_mask, n);
+  if (genparm[SECOND_FFT_ENABLE] == 0 && hip_spurs_on) {     /* what fft1_c's AFC branch leaves for spur_removal (fft1.c:4206-4207), then the spur display and the search walk */
+    ffts_na = (q.fft1_nb - 1) & fft1n_mask; ffts_nm = fft1_nm;
+    hip_spur_after_fft2(ffts_na);
+  }
   if (q.fft1_sumsq_pa != old_pa) {            /* averaging periods completed: the wide graph and sellim.c read these on the host */
     int pa;
     if (HC == 1) {

@@ -217,6 +217,7 @@ struct lrh_ctx {
   std::vector<unsigned int> h_pack;
   bool have_liminfo = false;
   // spurs being tracked (lrh_spur_config / lrh_spur_set): loop state and histories on the device, k_spur between fft2 and its power sums
+  float2 *spur_ring = nullptr; int spur_nx = 0, spur_maxn = 0; float spur_ff = 0;   // the transforms the spurs are taken from: fft2, or fft1 with the second fft off
   int spur_max = 0, spur_n = 0, spur_speknum = 0; lrh_spur *d_spurs = nullptr; float *d_spur_table = nullptr, *d_spur_signal = nullptr, *d_spur_spectra = nullptr; int *d_spur_ind = nullptr, *d_spur_touched = nullptr;
   // selective limiter on the device (lrh_fft1_update_liminfo): the reference's liminfo / old_liminfo / liminfo_wait / fftt_tmp
   float *d_liminfo = nullptr, *d_old_liminfo = nullptr, *d_sel_tmp = nullptr; unsigned char *d_sel_wait = nullptr; SellimState *d_sel_st = nullptr;
@@ -567,7 +568,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   bool bad = cfg->fft1_sumsq_bufsize < 2 * N1 || cfg->fft1_sumsq_bufsize < (cfg->fft_avg2num + 1) * N1 ||
              cfg->timf2pow_size < 2 * N1 || cfg->timf2pow_size < 2 * N2 || cfg->max_fft1n < 2 * cfg->max_batch ||
              cfg->timf3_size < 4 * c->Nm || cfg->timf1_bytes < 8 * N1 ||
-             (size_t)cfg->max_batch * c->M1 + N1 > (size_t)cfg->timf2pow_size;
+             (cfg->second_fft_enable && (size_t)cfg->max_batch * c->M1 + N1 > (size_t)cfg->timf2pow_size);   // (nothing goes into timf2 with the second fft off)
   if (bad) { delete c; return LRH_EINVAL; }
   c->fft1n_mask = cfg->max_fft1n - 1; c->fft1_mask = cfg->max_fft1n * 2 * N1 - 1; c->sumsq_mask = cfg->fft1_sumsq_bufsize - 1;
   c->timf2pow_mask = cfg->timf2pow_size - 1; c->timf2_mask = 4 * cfg->timf2pow_size - 1; c->fft2n_mask = cfg->max_fft2n - 1;
@@ -1082,14 +1083,19 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
 int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
 {
   LRH_ENTER(c);
-  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n || speknum > 1022))) return LRH_EINVAL;   // 1022: k_spur keeps speknum + 2 history entries in LDS (107 KB then)
-  if (!c->cfg.second_fft_enable || c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel, second fft on");
+  // the ring the spurs live in (fftx of spur.c): the fft2 transforms, or -- second fft off, fft1_c's AFC branch (fft1.c:4196-4244) -- the fft1 transforms
+  const bool second = c && c->cfg.second_fft_enable != 0;
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > (second ? c->cfg.max_fft2n : c->cfg.max_fft1n) || speknum > 1022))) return LRH_EINVAL;   // 1022: k_spur keeps speknum + 2 history entries in LDS (107 KB then)
+  if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel");
+  if (!second && (c->cfg.fft1_float_sparse || c->fft1_big)) return fail(c, LRH_ESTATE, "spur subtraction on the fft1 transforms: whole spectra in the ring, fft1_size up to 16384");
+  c->spur_ring = second ? c->d_fft2 : c->d_fft1; c->spur_nx = second ? c->N2 : c->N1; c->spur_maxn = second ? c->cfg.max_fft2n : c->cfg.max_fft1n;
+  c->spur_ff = second ? (float)c->M2 / (float)c->N2 : (float)c->M1 / (float)c->N1;
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_touched, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
     if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->spur_max = 0; c->spur_n = 0; c->spur_speknum = 0;
   if (!max_spurs) return LRH_OK;
-  const size_t maxn = c->cfg.max_fft2n;
+  const size_t maxn = c->spur_maxn;
   int rc = LRH_OK;
   if ((rc = dev_alloc(c, &c->d_spurs, max_spurs)) || (rc = dev_alloc(c, &c->d_spur_table, max_spurs * maxn * 14)) || (rc = dev_alloc(c, &c->d_spur_signal, max_spurs * maxn * 2)) ||
       (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_touched, 2 * max_spurs + 2)) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
@@ -1110,12 +1116,12 @@ int lrh_spur_search_config(lrh_ctx *c, int first_point, int last_point)
   for (float **q_ : { &c->d_ss_sum, &c->d_ss_spec_base, &c->d_ss_min, &c->d_ss_out }) if (*q_) { hipFree(*q_); *q_ = nullptr; }
   c->ss_counter = 0; c->ss_completed = 0; c->ss_busy = false;
   if (first_point == 0 && last_point == 0) return LRH_OK;
-  if (first_point < 0 || last_point >= c->N2 || last_point - first_point < 64) return LRH_EINVAL;
-  if (c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "the spur search reads whole power rows: cfg.fft2_float_sparse must be 0");
+  if (first_point < 0 || last_point >= c->spur_nx || last_point - first_point < 64) return LRH_EINVAL;
+  if (c->cfg.second_fft_enable && c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "the spur search reads whole power rows: cfg.fft2_float_sparse must be 0");
   int rc;
   // (the reference's walk reads up to three bins before the first and 31 behind the last point of the range, spursub.c:48, 160-167)
-  if ((rc = dev_alloc(c, &c->d_ss_sum, (size_t)c->N2 + 64)) || (rc = dev_alloc(c, &c->d_ss_spec_base, (size_t)c->N2 + 128)) ||
-      (rc = dev_alloc(c, &c->d_ss_min, (size_t)c->N2 / 32 + 64)) || (rc = dev_alloc(c, &c->d_ss_out, 4))) return rc;
+  if ((rc = dev_alloc(c, &c->d_ss_sum, (size_t)c->spur_nx + 64)) || (rc = dev_alloc(c, &c->d_ss_spec_base, (size_t)c->spur_nx + 128)) ||
+      (rc = dev_alloc(c, &c->d_ss_min, (size_t)c->spur_nx / 32 + 64)) || (rc = dev_alloc(c, &c->d_ss_out, 4))) return rc;
   if (!c->stream_ss) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream_ss, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ss_in, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_ss_done, hipEventDisableTiming));
@@ -1128,7 +1134,7 @@ static int spur_search_row(lrh_ctx *c, int na, hipStream_t src)
 {
   if (!c->d_ss_sum) return LRH_OK;
   SpurSearchArgs a; memset(&a, 0, sizeof a);
-  a.sum = c->d_ss_sum; a.spec = c->d_ss_spec_base + 32; a.mins = c->d_ss_min; a.z = c->d_fft2 + (size_t)na * c->N2;
+  a.sum = c->d_ss_sum; a.spec = c->d_ss_spec_base + 32; a.mins = c->d_ss_min; a.z = c->spur_ring + (size_t)na * c->spur_nx;
   a.first = c->ss_first; a.last = c->ss_last; a.spectra = c->d_spur_spectra; a.out = c->d_ss_out;
   const double s3 = sqrt((float)(3 * c->spur_speknum));
   a.noise_factor = pow(10., 0.7 / s3); a.thr_factor = pow(10., 1.5 / s3);
@@ -1167,10 +1173,10 @@ int lrh_spur_search_get(lrh_ctx *c, float *spectrum, float *threshold, int *comp
 static void spur_args(lrh_ctx *c, SpurArgs *out, int first_na, int batch)
 {
   SpurArgs sa; memset(&sa, 0, sizeof sa);
-  const int N = c->N2;
-  sa.fft2 = c->d_fft2; sa.n2 = N; sa.first_na = first_na; sa.na_mask = c->fft2n_mask; sa.batch = batch;
+  const int N = c->spur_nx;
+  sa.fft2 = c->spur_ring; sa.n2 = N; sa.first_na = first_na; sa.na_mask = c->spur_maxn - 1; sa.batch = batch;
   sa.nspurs = c->spur_n; sa.speknum = c->spur_speknum; sa.numsub = sa.speknum - 1; sa.avgnum = sa.speknum / 3; if (sa.avgnum > 10) sa.avgnum = 10;
-  sa.freq_factor = (float)c->M2 / (float)N;
+  sa.freq_factor = c->spur_ff;
   sa.max_d2 = (float)(PI_L * sa.freq_factor / sa.speknum);
   sa.minston = (float)(1 / sqrt(0.5 * (float)(sa.speknum)));
   { float t1 = (float)(0.5 * sa.speknum); sa.weiold = t1 / (1 + t1); sa.weinew = 1 / (1 + t1);
@@ -1186,8 +1192,9 @@ int lrh_spur_acquire(lrh_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
   if (!c || !p || !locked) return LRH_EINVAL;
   *locked = 0;
   if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
-  if (c->spur_n >= c->spur_max || pnt < 1 || pnt + 9 > c->N2) return LRH_EINVAL;
-  if (c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "spur acquisition reads whole fft2 transforms: cfg.fft2_float_sparse must be 0");
+  if (c->spur_n >= c->spur_max || pnt < 1 || pnt + 9 > c->spur_nx) return LRH_EINVAL;
+  if (c->cfg.second_fft_enable && c->cfg.fft2_float_sparse) return fail(c, LRH_ESTATE, "spur acquisition reads whole fft2 transforms: cfg.fft2_float_sparse must be 0");
+  if (!c->cfg.second_fft_enable) { const int rcj_ = join_handles(c); if (rcj_) return rcj_; }      // (the fft1_b workers' transforms)
   SpurArgs sa; spur_args(c, &sa, p->fft2_na, 0);
   HIPCHK(c, launch_spur_acquire(sa, pnt, c->d_spur_touched + 2 * c->spur_max, c->stream));
   int res = 0;
@@ -1201,7 +1208,7 @@ int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, cons
   LRH_ENTER(c);
   if (!c || n < 0 || n > c->spur_max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
-  const size_t maxn = c->cfg.max_fft2n;
+  const size_t maxn = c->spur_maxn;
   if (n) {
     HIPCHK(c, hipMemcpyAsync(c->d_spurs, sp, n * sizeof *sp, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_spur_table, table, n * maxn * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1219,7 +1226,7 @@ int lrh_spur_permute(lrh_ctx *c, int n, const int *src)
   if (!c || n < 0 || n > c->spur_n || (n && !src)) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   for (int i = 0; i < n; i++) if (src[i] < 0 || src[i] >= c->spur_n) return LRH_EINVAL;
-  const size_t maxn = c->cfg.max_fft2n;
+  const size_t maxn = c->spur_maxn;
   const int old_n = c->spur_n;
   if (n) {
     std::vector<lrh_spur> sp(old_n); std::vector<float> tab((size_t)old_n * maxn * 14), sig((size_t)old_n * maxn * 2); std::vector<int> ind((size_t)old_n * maxn);
@@ -1622,6 +1629,12 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
   const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
   if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
     return fail(c, LRH_EINVAL, "fft1_sumsq ring too short for this batch");
+  if (c->spur_max && !c->cfg.second_fft_enable) {
+    // the last step of fft1 when the AFC runs from fft1 (fft1afc_flag > 0, fft1.c:4196-4244, 4428-4460): eliminate_spurs on the new transforms
+    // in order, then the search spectrum's rows from their powers -- in front of the sums, which are formed from the cleaned spectra
+    if (c->spur_n > 0) { SpurArgs sp; spur_args(c, &sp, p->fft1_nb, batch); ProfScope ps(c, "spur"); HIPCHK(c, launch_spur(sp, c->cur)); }
+    for (int b = 0; b < batch; b++) { const int rcs_ = spur_search_row(c, (p->fft1_nb + b) & c->fft1n_mask, c->cur); if (rcs_) return rcs_; }
+  }
   SumsqArgs sa;
   sa.spec = c->d_fft1; sa.nb_mask = c->fft1n_mask; sa.n = N; sa.sumsq = c->d_sumsq; sa.sumsq_mask = c->sumsq_mask;
   sa.first_nb = p->fft1_nb; sa.batch = batch; sa.avg = avg1; sa.c0 = p->fft1_sumsq_counter; sa.pa0 = p->fft1_sumsq_pa;

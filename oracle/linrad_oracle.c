@@ -698,6 +698,8 @@ int lro_fft1_corr_finish(lro_ctx *c, const lrh_ptrs *at, int batch)
   return LRH_OK;
 }
 
+static void lro_spur_hook(lro_ctx *c, int na);      /* eliminate_spurs, defined with the spur tracking at the end of this file */
+static void spur_search_row(lro_ctx *c, const float *pwra);
 /* fft1_c, fft1.c:4085-4201 + 4507-4523 (1 channel, fft1afc_flag <= 0); the complex multiply already done in lro_fft1_b */
 int lro_fft1_c(lro_ctx *c, lrh_ptrs *p, int batch)
 {
@@ -705,6 +707,12 @@ int lro_fft1_c(lro_ctx *c, lrh_ptrs *p, int batch)
   for (int b = 0; b < batch; b++) {
     const float *z = c->fft1_float + (size_t)p->fft1_nb * 2 * N;
     float *sum = c->fft1_sumsq + p->fft1_sumsq_pa;
+    if (c->spurs && !c->cfg.second_fft_enable) {         /* the last step of fft1 when AFC runs from fft1 (fft1afc_flag > 0, fft1.c:4196-4244, 4428-4460): */
+      lro_spur_hook(c, p->fft1_nb);                      /* eliminate_spurs on the new transform, then the search spectrum's row of its powers */
+      float *pw = c->tmp;
+      for (int i = 0; i < N; i++) pw[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1];
+      spur_search_row(c, pw);
+    }
     if (p->fft1_sumsq_counter == 0) for (int i = 0; i < N; i++) sum[i] = z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1];
     else                            for (int i = 0; i < N; i++) sum[i] += z[2 * i] * z[2 * i] + z[2 * i + 1] * z[2 * i + 1];
     p->fft1_sumsq_counter++;
@@ -1299,8 +1307,6 @@ advance:
 }
 
 
-static void lro_spur_hook(lro_ctx *c, int na);      /* eliminate_spurs, defined with the spur tracking at the end of this file */
-static void spur_search_row(lro_ctx *c, const float *pwra);
 
 /* make_fft2 mode 15 until FFT2_COMPLETE: fft2.c:86-141 (load, window, big_fftforward), 647-705 (power),
    707-815 (waterfall), 1831-1845 (pointers) */
@@ -2453,6 +2459,8 @@ typedef struct {
   /* the search for new spurs (lro_spur_search_config): make_fft2's sums over 3 spur_speknum power rows (fft2.c:673-699) and the cleaned
      search spectrum spursearch_spectrum_cleanup leaves (spursub.c:40-175) */
   int ss_first, ss_last, ss_counter, ss_completed; float *ss_sum, *ss_spec, *ss_min; float ss_threshold;
+  /* the ring the spurs live in (fftx of spur.c): fft2_float with the second fft on, fft1_float with it off (fft1_c, fft1.c:4196-4244) */
+  float *fftx; int nx, maxn;
 } lro_spurs;
 
 static void spur_complex_lowpass(const float *zin, float *zout, int nn, int siz)
@@ -2749,14 +2757,16 @@ static void spur_eliminate(lro_spurs *S, float *fftx, int na, int n2, int maxn)
 int lro_spur_config(lro_ctx *c, int max_spurs, int speknum, const f32 *spectra)
 {
   LRO_F32_ONLY(c);
-  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > c->cfg.max_fft2n))) return LRH_EINVAL;
+  if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > (c->cfg.second_fft_enable ? c->cfg.max_fft2n : c->cfg.max_fft1n)))) return LRH_EINVAL;
   lro_spurs *S = c->spurs;
   if (S) { free(S->sp); free(S->table); free(S->signal); free(S->ind); free(S->sig); free(S->der); free(S->pha); free(S->tmp); free(S->ss_sum); if (S->ss_spec) free(S->ss_spec - 8); free(S->ss_min); free(S); c->spurs = NULL; }
   if (!max_spurs) return LRH_OK;
-  const int maxn = c->cfg.max_fft2n;
+  const int second = c->cfg.second_fft_enable != 0;
+  const int maxn = second ? c->cfg.max_fft2n : c->cfg.max_fft1n;
   S = calloc(1, sizeof *S);
+  S->fftx = second ? c->fft2_float : c->fft1_float; S->nx = second ? c->N2 : c->N1; S->maxn = maxn;
   S->max = max_spurs; S->n = 0; S->speknum = speknum; S->numsub = speknum - 1; S->avgnum = speknum / 3; if (S->avgnum > 10) S->avgnum = 10;
-  S->freq_factor = (float)c->M2 / c->N2;                                   /* buf.c:480 */
+  S->freq_factor = second ? (float)c->M2 / c->N2 : (float)c->M1 / c->N1;   /* buf.c:480 / 1118: new points / size of the transform the spurs are taken from */
   S->max_d2 = (float)(PI_L * S->freq_factor / speknum);
   S->minston = (float)(1 / sqrt(0.5 * (float)(speknum)));
   { float t1 = (float)(0.5 * speknum); S->weiold = t1 / (1 + t1); S->weinew = 1 / (1 + t1);
@@ -2777,10 +2787,10 @@ int lro_spur_search_config(lro_ctx *c, int first_point, int last_point)
   free(S->ss_sum); if (S->ss_spec) free(S->ss_spec - 8); free(S->ss_min); S->ss_sum = S->ss_spec = S->ss_min = NULL;
   S->ss_counter = 0; S->ss_completed = 0; S->ss_threshold = 0;
   if (first_point == 0 && last_point == 0) return LRH_OK;
-  if (first_point < 0 || last_point >= c->N2 || last_point - first_point < 64) return LRH_EINVAL;
+  if (first_point < 0 || last_point >= S->nx || last_point - first_point < 64) return LRH_EINVAL;
   S->ss_first = first_point; S->ss_last = last_point;
   /* (the reference's walk reads up to three bins before the first and 31 behind the last point of the range, spursub.c:48, 160-167) */
-  S->ss_sum = calloc(c->N2 + 8, 4); S->ss_spec = (float *)calloc(c->N2 + 72, 4) + 8; S->ss_min = calloc(c->N2 / 32 + 8, 4);
+  S->ss_sum = calloc(S->nx + 8, 4); S->ss_spec = (float *)calloc(S->nx + 72, 4) + 8; S->ss_min = calloc(S->nx / 32 + 8, 4);
   return LRH_OK;
 }
 /* parabolic_fit, llsq.c:113-153 */
@@ -2877,7 +2887,7 @@ int lro_spur_set(lro_ctx *c, int n, const lrh_spur *sp, const f32 *table, const 
   LRO_F32_ONLY(c);
   lro_spurs *S = c ? c->spurs : NULL;
   if (!S || n < 0 || n > S->max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
-  const int maxn = c->cfg.max_fft2n;
+  const int maxn = S->maxn;
   S->n = n;
   if (n) { memcpy(S->sp, sp, n * sizeof *sp); memcpy(S->table, table, (size_t)n * maxn * SPW * 2 * 4); memcpy(S->signal, signal, (size_t)n * maxn * 2 * 4); memcpy(S->ind, ind, (size_t)n * maxn * 4); }
   return LRH_OK;
@@ -2887,7 +2897,7 @@ int lro_spur_permute(lro_ctx *c, int n, const int *src)
 {
   lro_spurs *S = c ? c->spurs : NULL;
   if (!S || n < 0 || n > S->n || (n && !src)) return LRH_EINVAL;
-  const size_t maxn = c->cfg.max_fft2n;
+  const size_t maxn = S->maxn;
   for (int i = 0; i < n; i++) if (src[i] < 0 || src[i] >= S->n) return LRH_EINVAL;
   if (n) {
     lrh_spur *sp = malloc(n * sizeof *sp); float *tab = malloc((size_t)n * maxn * SPW * 2 * 4), *sig = malloc((size_t)n * maxn * 2 * 4); int *ind = malloc((size_t)n * maxn * 4);
@@ -2929,13 +2939,13 @@ int lro_spur_acquire(lro_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
   lro_spurs *S = c ? c->spurs : NULL;
   if (!S || !p || !locked) return LRH_EINVAL;
   *locked = 0;
-  const int maxn = c->cfg.max_fft2n, mask = maxn - 1, n2 = c->N2, n = S->speknum, na = p->fft2_na & mask;
+  const int maxn = S->maxn, mask = maxn - 1, n2 = S->nx, n = S->speknum, na = p->fft2_na & mask;      /* (p->fft2_na carries ffts_na: fft1_nb with the second fft off) */
   if (S->n >= S->max || pnt < 1 || pnt + SPW + 1 > n2) return LRH_EINVAL;
   const int s = S->n;
   lrh_spur *q = &S->sp[s];
   float *tab = S->table + (size_t)s * maxn * SPW * 2, *zsig = S->signal + (size_t)s * maxn * 2;
   int *uind = S->ind + (size_t)s * maxn;
-  const float *fftx = c->fft2_float;
+  const float *fftx = S->fftx;
   float power[SPW];
   memset(q, 0, sizeof *q);
   q->spur_ampl = 1; q->spur_noise = 0.001f; q->spur_avgd2 = 0;               /* spursub.c:290-292 */
@@ -3060,5 +3070,5 @@ int lro_spur_acquire(lro_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
 static void lro_spur_hook(lro_ctx *c, int na)
 {
   lro_spurs *S = c->spurs;
-  if (S->n > 0) spur_eliminate(S, c->fft2_float, na, c->N2, c->cfg.max_fft2n);
+  if (S->n > 0) spur_eliminate(S, S->fftx, na, S->nx, S->maxn);
 }

@@ -601,6 +601,11 @@ int main(int argc, char **argv)
     const int ms = 4;
     genparm[MAX_NO_OF_SPURS] = ms; genparm[AFC_ENABLE] = 1;
     max_fftxn = max_fft2n; fftxn_mask = max_fftxn - 1; fftx_size = fft2_size; fftx = fft2_float; fftx_pwr = fft2_power_float;
+    if (!second) {               /* second fft off: the spurs live in the fft1 transforms, fft1_c's AFC branch takes them out (buf.c:729, 930-945, 1089; fft1.c:4196-4244) */
+      fft1afc_flag = 1;
+      max_fftxn = max_fft1n; fftxn_mask = max_fftxn - 1; fftx_size = fft1_size; fftx = fft1_float;
+      fft1_power = zalloc(sizeof(float) * (size_t)max_fft1n * fft1_size); fftx_pwr = fft1_power;
+    }
     swmmx_fft2 = 0; no_of_spurs = 0;
     spur_block = SPUR_WIDTH * max_fftxn * twice_rxchan;
     spur_table = zalloc(sizeof(float) * ms * spur_block); spur_location = zalloc(4 * ms); spur_flag = zalloc(4 * ms);
@@ -610,7 +615,7 @@ int main(int argc, char **argv)
     spur_ind = zalloc(4 * ms * max_fftxn); spur_signal = zalloc(4 * max_fftxn * twice_rxchan * ms);
     spursearch_spectrum = zalloc(4 * fftx_size); spursearch_powersum = zalloc(4 * fftx_size);
     for (int i = 0; i < ms * max_fftxn; i++) spur_ind[i] = -1;
-    spur_freq_factor = (float)fft2_new_points / fft2_size;             /* buf.c:480 */
+    spur_freq_factor = second ? (float)fft2_new_points / fft2_size : (float)fft1_new_points / fft1_size;             /* buf.c:480, 1118 */
     spur_speknum = spur_spek > 0 ? spur_spek : max_fftxn / 4;
     if (spur_speknum < 4) spur_speknum = 4;
     /* the reference carves these out of its big fft scratch, fftx_size / 4 floats each (buf.c:1285-1293); spur_phase_lock / verify_spur_pll index them
@@ -895,7 +900,40 @@ int main(int argc, char **argv)
     fft1_na = fft1_pa / fft1_block;
     if (fft1_nm != fft1n_mask) fft1_nm++;
     if (!second) {               /* second fft disabled: fft1_c, then the narrowband thread's fft1_mix1_fixed */
-      while (fft1_na != fft1_nb) ON(ST_TIMF2, fft1_c);              /* THREAD_DO_FFT1C with more than one CPU (wcw.c:1070-1078) */
+      while (fft1_na != fft1_nb) {
+        const int ss_before = spursearch_sum_counter;
+        ON(ST_TIMF2, fft1_c);              /* THREAD_DO_FFT1C with more than one CPU (wcw.c:1070-1078) */
+        if (!spur) continue;
+        spur_max_d2 = PI_L * spur_freq_factor / spur_speknum;
+        if (ss_before > 3 * spur_speknum && spursearch_sum_counter == 0) {      /* this transform completed a search spectrum (fft1.c:4432-4440) */
+          memcpy(ss_last, spursearch_spectrum, 4 * (size_t)fftx_size);
+          if (ss_completed < 64) { ss_thr[ss_completed] = spur_search_threshold; ss_at[ss_completed] = b; }
+          ss_completed++;
+        }
+        if (no_of_spurs == 0 && b + 1 == spur_start) {    /* acquisition behind fft1_c (spur_removal, wcw.c:708-713) */
+          /* ffts_na: the slot behind the newest transform, as second_fft leaves it for the fft2 flavour (wcw.c:288-289), so that the history
+             store_new_spur takes ends with the newest transform.  Linrad's own fft1 flow leaves ffts_na at the newest transform itself
+             (fft1.c:4206), i.e. one short: an empty row then sits in the loop's first fits, a transient whose outcome hangs on the last bit
+             of libm (the same oracle binary kept lock on one host and lost it on another) -- no pin.  The glue passes Linrad's value through. */
+          ffts_na = fft1_nb; ffts_nm = fft1_nm;
+          spurno = 0; spur_ampl[0] = 1; spur_noise[0] = 0.001; spur_avgd2[0] = 0;
+          int rc1 = store_new_spur(spur_pnt), rc2 = rc1 ? -9 : spur_phase_lock(ffts_na);
+          fprintf(stderr, "spur acquisition at fft1 transform %d: store %d lock %d loc %d freq %.4f ampl %.4g noise %.4g d0 %.4f d1 %.4f d2 %.5f\n", b, rc1, rc2,
+                  spur_location[0], spur_freq[0], spur_ampl[0], spur_noise[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0]);
+          if (!rc1 && !rc2) {
+            no_of_spurs = 1; spur_locked_at = b + 1;
+            float st[12] = { (float)spur_location[0], (float)spur_flag[0], spur_freq[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0], spur_ampl[0], spur_noise[0], spur_avgd2[0],
+                             (float)ffts_na, (float)spur_speknum, spur_freq_factor };
+            PUTF("spur_init_state", st, 12);
+            PUTF("spur_init_table", spur_table, spur_block); PUTF("spur_init_signal", spur_signal, 2 * max_fftxn); PUTI("spur_init_ind", spur_ind, max_fftxn);
+            PUTF("spur_spectra", spur_spectra, NO_OF_SPUR_SPECTRA * SPUR_SIZE);
+          }
+        } else if (no_of_spurs > 0) {
+          float *q = spur_trace + 12 * nspur_trace++;
+          q[0] = spur_location[0]; q[1] = spur_flag[0]; q[2] = spur_freq[0]; q[3] = spur_d0pha[0]; q[4] = spur_d1pha[0]; q[5] = spur_d2pha[0];
+          q[6] = spur_ampl[0]; q[7] = spur_noise[0]; q[8] = spur_avgd2[0]; q[9] = b; q[10] = no_of_spurs;
+        }
+      }
       while (fq >= 0 && fft1_nx != fft1_nb) {                        /* narrowband_dsp: until fft1_nx has caught up (wcw.c:1690-1712) */
         if (afc) { AFC_SUPPLY(fft1_nx, fft1n_mask); ON(ST_NARROW, fft1_mix1_afc); } else
         ON(ST_NARROW, fft1_mix1_fixed);

@@ -20,7 +20,7 @@ from refdump import load_dump  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["spur_init_state", "spur_init_table", "spur_init_signal", "spur_init_ind", "spur_spectra", "spur_trace", "spur_locked",
-        "fft2_float", "fft2_powersum_float", "timf3_float", "wf_lines", "mixtrace", "final", "itrace",
+        "fft2_float", "fft2_powersum_float", "timf3_float", "wf_lines", "mixtrace", "final", "itrace", "fft1_float", "fft1_sumsq", "fft1_slowsum",
         "spursearch_spectrum", "spursearch_thresholds", "spursearch_info", "spursearch_at"]
 
 

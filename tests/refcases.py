@@ -373,6 +373,11 @@ SPUR = {
     # a carrier that drifts 0.35 fft2 bins during the run (across a bin boundary): frequency drift in the loop (d2pha) and shift_spur_table
     "spur_n10_n12_drift": dict(base="n10_n12", nblk=200, max_fft2n=64, blockpower_block=0, spur_pnt=2597, spur_start=20, spur_speknum=12,
                                tone=(2600.8, 0.35, 3000.0), fq=2590.3),
+    # the second fft off (Linrad's default in every mode, uivar.c:371): the spur lives in the fft1 transforms and fft1_c's AFC branch takes it
+    # out (fft1afc_flag = 1: fft1.c:4196-4244; the search spectrum from the fft1 powers, :4428-4460); the carrier at fft1 bin 412 sits inside
+    # the baseband that fft1_mix1_fixed cuts out
+    "spur_n10_fft1": dict(base="n10_mix1only", nblk=120, max_fft1n=32, spur_pnt=409, spur_start=12, spur_speknum=8, tone=None, fq=420.3,
+                          strong=[(-100.0, 600.0)]),
 }
 
 

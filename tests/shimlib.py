@@ -246,6 +246,8 @@ def check_spur_case(harness, tmp_path, name="spur_n10_n12", tol=1e-5):
     assert int(dump["spur_locked"][0]) == int(g["spur_locked"][0]) > 0, (dump["spur_locked"], g["spur_locked"])
     cfg = lrh_config(d, iq)
     out = dict(trace=dump["spur_trace"].reshape(-1, 12)[:, :10].astype(np.float64), cfg=cfg, fft2=dump["fft2_float"], ps2=dump["fft2_powersum_float"])
+    if not d["second_fft"]:                                          # the spur lives in the fft1 transforms (fft1_c's AFC branch, hip_fft1_c)
+        out = dict(trace=out["trace"], cfg=cfg, fft1=dump["fft1_float"], sumsq=dump["fft1_sumsq"])
     keep3 = np.ones(dump["timf3_float"].size, bool)                 # the half block parked beyond timf3_pa (mix1.c:188-194) stays on the device
     keep3[(int(dump["final"][9]) + np.arange(int(dump["mixtrace"].reshape(-1, 8)[0, 6]))) % keep3.size] = False
     out["timf3"] = dump["timf3_float"] * keep3

@@ -32,6 +32,8 @@ def run(open_fn, name, g, batch=1, acquire=False):
     first, last = (int(g["spursearch_info"][2]), int(g["spursearch_info"][3])) if "spursearch_info" in g else (0, (1 << cfg.fft2_n) - 1)
     api.spur_search_config(first, last)                      # the search for further spurs runs beside the tracking (fft2.c:673-699)
     trace, nfft2, handed = [], 0, False
+    if not d["second_fft"]:
+        return run_fft1(api, cfg, d, sp, g, acquire, first, last)
     for b in range(d["nblk"]):
         api.fft1_b(1), api.fft1_c(1), api.make_timf2(1)
         api.first_noise_blanker()
@@ -63,7 +65,76 @@ def run(open_fn, name, g, batch=1, acquire=False):
                 ps2=api.export(abi.RING_FFT2_POWERSUM))
 
 
+def run_fft1(api, cfg, d, sp, g, acquire, first, last):
+    """second fft off: the spur lives in the fft1 transforms; fft1_c takes it out of each new one (fft1.c:4196-4244) and keeps the search
+    spectrum from their powers; acquisition behind fft1_c, the history ending with the newest transform"""
+    st = g["spur_init_state"]
+    start = int(g["spur_locked"][0])
+    trace, handed, acq = [], False, None
+    for b in range(d["nblk"]):
+        api.fft1_b(1)
+        api.fft1_c(1)
+        if handed:
+            s = api.spur_get()[0]
+            trace.append([s.spur_location, s.spur_flag, s.spur_freq, s.spur_d0pha, s.spur_d1pha, s.spur_d2pha, s.spur_ampl, s.spur_noise, s.spur_avgd2, b])
+        elif b + 1 == start:
+            if acquire:
+                api.p.fft2_na = api.p.fft1_nb                      # ffts_na: the slot behind the newest transform (see oracle/ref_harness.c)
+                assert api.spur_acquire(sp["spur_pnt"]), "no lock"
+                acq = api.spur_get()[0]
+            else:
+                q = LrhSpur(int(st[0]), int(st[1]), *[float(x) for x in st[2:9]])
+                maxn = cfg.max_fft1n
+                api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
+            handed = True
+        api.fft1_mix1_fixed(1)
+    ss = api.spur_search_get()
+    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=acq, trace=np.array(trace, np.float64), fft1=api.export(abi.RING_FFT1_FLOAT),
+                sumsq=api.export(abi.RING_FFT1_SUMSQ), timf3=api.export(abi.RING_TIMF3_FLOAT))
+
+
+def compare_fft1(out, g, tol):
+    """loop state after every transform, the fft1 ring behind the subtraction, the power sums formed from it, timf3, the search spectrum"""
+    ref, got = g["spur_trace"].reshape(-1, 12), out["trace"]
+    assert got.shape[0] == ref.shape[0] and got.shape[0] > 10
+    assert np.array_equal(got[:, :2], ref[:, :2]), "spur_location / spur_flag trace differs"
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+
+    def rel(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    rep = {"transforms": int(ref.shape[0]), "freq_err_bins": float(np.max(np.abs(got[:, 2] - ref[:, 2]))),
+           "phase_err_rad": float(np.max(np.abs(wrap(got[:, 3] - ref[:, 3])))), "ampl_rel": float(np.max(np.abs(got[:, 6] - ref[:, 6]) / np.abs(ref[:, 6]))),
+           "fft1": rel(out["fft1"], g["fft1_float"]), "timf3": rel(out["timf3"], g["timf3_float"])}
+    it = g["itrace"].reshape(-1, 16)
+    keep = np.ones(out["sumsq"].size, bool)
+    if it[-1, 10] != 0:                                          # an unfinished averaging period at the end: fft1_c accumulates it in place
+        keep[it[-1, 9]:it[-1, 9] + (1 << out["cfg"].fft1_n)] = False
+    rep["sumsq"] = rel(out["sumsq"] * keep, g["fft1_sumsq"] * keep)
+    loc = int(ref[-1, 0])
+    n1 = 1 << out["cfg"].fft1_n
+    f_h, f_r = out["fft1"].reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64), g["fft1_float"].reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64)
+    rep["residual_vs_carrier"] = float(np.linalg.norm(f_r) / (np.sqrt(f_r.shape[0]) * abs(ref[-1, 6])))
+    rep["residual_err_vs_carrier"] = float(np.linalg.norm(f_h - f_r) / (np.sqrt(f_r.shape[0]) * abs(ref[-1, 6])))
+    assert rep["freq_err_bins"] < 1e-3 and rep["phase_err_rad"] < 20 * tol * 1e2 and rep["ampl_rel"] < 10 * tol, rep
+    assert rep["fft1"] < tol and rep["sumsq"] < tol and rep["timf3"] < tol and rep["residual_err_vs_carrier"] < tol, rep
+    assert rep["residual_vs_carrier"] < 0.1, rep                # the carrier is gone from the ring
+    sp, thr, done, cnt = out["ss"]
+    a, b = out["ss_range"]
+    ref_sp, info = g["spursearch_spectrum"][a:b + 1], g["spursearch_info"]
+    assert done == int(info[0]) and cnt == int(info[1]) and done >= 1, (done, cnt, info)
+    assert abs(thr - g["spursearch_thresholds"][min(done, 64) - 1]) <= 10 * tol * thr
+    assert np.array_equal(sp < 0, ref_sp < 0), "wiped peaks differ"
+    rep["search_spectrum_err"] = float(np.max(np.abs(sp - ref_sp)) / float(np.max(ref_sp)))
+    assert rep["search_spectrum_err"] < tol and np.count_nonzero((sp == 0) != (ref_sp == 0)) <= 2, rep
+    return rep
+
+
 def compare(out, g, tol, batch=1):
+    if "fft1" in out:
+        return compare_fft1(out, g, tol)
     ref = g["spur_trace"].reshape(-1, 12)
     got = out["trace"]
     if batch > 1:                                               # state is visible after every call only
