@@ -13,7 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not present (GPU box)")
 
 SCRIPTS = ["make_golden.py", "make_golden_2ch.py", "make_golden_clever.py", "make_golden_clever2.py", "make_golden_sellim.py",
-           "make_golden_spur.py", "make_rawdat_golden.py"]
+           "make_golden_spur.py", "make_rawdat_golden.py", "make_filehdr_golden.py"]
 
 
 @pytest.mark.parametrize("script", SCRIPTS)
@@ -34,7 +34,7 @@ def test_every_committed_golden_has_a_generator(tmp_path):
     """no orphan fixtures: each .npz under tests/golden/ is written by one of the scripts above (names from tests/refcases.py)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from refcases import CASES, CLEVER, CLEVER2, SELLIM, SPUR, TWOCHAN
-    names = set(CASES) | set(CLEVER) | set(CLEVER2) | set(SELLIM) | set(SPUR) | set(TWOCHAN) | {"rawdat_18bit"}
+    names = set(CASES) | set(CLEVER) | set(CLEVER2) | set(SELLIM) | set(SPUR) | set(TWOCHAN) | {"rawdat_18bit", "filehdr"}
     names |= {n + "_chain" for n, t in TWOCHAN.items() if "chain" in t}
     have = {f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz")}
     assert have == names, sorted(have ^ names)

@@ -88,3 +88,28 @@ def test_header_round_trip_and_legacy_layout(tmp_path):
     bad.seek(0)
     with pytest.raises(rawfile.RawFileError):
         rawfile.read_header(bad)
+
+
+def _filehdr_cases(prefix):
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filehdr.npz"))
+    return {k[:-6]: (g[k].tobytes(), json.loads(g[k[:-6] + "__ref"].tobytes().decode())) for k in g.files if k.startswith(prefix) and k.endswith("__file")}
+
+
+@pytest.mark.parametrize("name", ["raw_plain", "raw_perseus_rev", "raw_sdr14_dword", "raw_twochan", "raw_real_mono", "raw_oldformat"])
+def test_raw_header_reader_equals_the_compiled_references(name):
+    """tests/golden/filehdr.npz: the bytes of small .raw files and what the COMPILED REFERENCE's open_savefile (modesub.c:606-733, run
+    head-less by oracle/ref_files.c) left in Linrad's globals after reading them; linrad_amd.rawfile.read_header must read the same out
+    of the same bytes -- every header field and the position of the first data block"""
+    import io
+    blob, ref = _filehdr_cases("raw_")[name]
+    f = io.BytesIO(blob)
+    h = rawfile.read_header(f)
+    assert (h.rx_input_mode, h.rx_rf_channels, h.rx_ad_channels, h.rx_ad_speed, h.save_init_flag) == \
+           (ref["rx_input_mode"], ref["rx_rf_channels"], ref["rx_ad_channels"], ref["rx_ad_speed"], ref["save_init_flag"])
+    assert h.remember == ref["remember0"] and len(h.proprietary) == ref["remember1"]
+    assert (h.diskread_time, h.passband_center, h.passband_direction) == (ref["diskread_time"], ref["passband_center"], ref["passband_direction"])
+    assert h.data_offset == ref["file_pos"] == f.tell()
+    if ref["remember0"] == rawfile.REMEMBER_PERSEUS:          # the Perseus chunk's own fields, as the reference's RCVR struct holds them
+        import struct
+        assert struct.unpack_from("<I", h.proprietary, 0)[0] == ref["perseus_center_hz"] and struct.unpack_from("<q", h.proprietary, 8)[0] == ref["perseus_time"]

@@ -129,3 +129,23 @@ def test_reader_blocks_tail_and_writer_round_trip(tmp_path):
     b2 = list(r2.blocks())
     assert len(b2) == 2 and b2[0].dtype == np.int32 and b2[0].size == 2048
     assert np.array_equal(b2[1], W.convert_block(raw[6144:12288], BYTE_INPUT + DWORD_INPUT))
+
+
+@pytest.mark.parametrize("name", ["wav_pcm16", "wav_pcm16_rcvr", "wav_pcm16_auxi", "wav_pcm24_ext", "wav_pcm8_mono", "wav_float32", "wav_pcm32_list"])
+def test_wav_header_reader_equals_the_compiled_references(name):
+    """tests/golden/filehdr.npz: the bytes of small .wav files (PCM 8 / 16 / 24 / 32 bit, float, an extensible fmt chunk, rcvr and auxi
+    chunks, an unknown chunk to skip) and what the COMPILED REFERENCE's init_wavread (modesub.c:1022-1347, run head-less by
+    oracle/ref_files.c) made of them; linrad_amd.wavfile.read_wav_header must make the same of the same bytes"""
+    import io
+    import json
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filehdr.npz"))
+    blob, ref = g[name + "__file"].tobytes(), json.loads(g[name + "__ref"].tobytes().decode())
+    f = io.BytesIO(blob)
+    from linrad_amd import wavfile
+    h = wavfile.read_wav_header(f)
+    assert (h.rx_input_mode, h.rx_ad_channels, h.rx_ad_speed) == (ref["rx_input_mode"], ref["rx_ad_channels"], ref["rx_ad_speed"])
+    assert h.remember == ref["remember0"] and len(h.proprietary) == ref["remember1"]
+    assert h.diskread_time == ref["diskread_time"] and h.passband_center == ref["passband_center"] and bool(h.freq_from_file) == bool(ref["freq_from_file"])
+    assert h.data_offset == ref["file_pos"] == f.tell()
