@@ -192,7 +192,8 @@ def glue_rate(args, w, batches=(1, 2, 4, 8, 16), workers=3):
             # rings as a patched Linrad sizes them for version 21 (integration/linrad_hip.patch, buf.c): fft1 ring of 256 transforms, timf2 of at
             # least 64 fft1 blocks -- the stages behind fft1_b take what has accumulated in one library call, up to 64 blocks
             t2log = int(np.log2(max(8 << max(w["fft2_n"], w["fft1_n"]), 256 * M1)))
-            cmd += ["max_fft1n=256", "max_fft2n=64", f"timf2pow_log2={t2log}", f"timf1_log2={ring_log2}", "shim_threads=2", f"shim_workers={workers}", f"shim_batch={b}", "warm=512"]
+            cmd += ["max_fft1n=256", "max_fft2n=64", f"timf2pow_log2={t2log}", f"timf1_log2={ring_log2}", "shim_threads=2", f"shim_workers={workers}", f"shim_batch={b}", "warm=512",
+                    "shim_sparse=1"]                  # hip_open decides about the fft2 ring like in a patched xlinrad64 (AFC off here: sparse)
             try:
                 out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, check=True).stdout
                 r = json.loads(out.strip().splitlines()[-1])

@@ -50,6 +50,12 @@ static float *hip_liminfo_sent;           /* the routing table the device holds 
    THREAD_TIMF2 (hip_make_timf2, wcw.c:419-425): one lock around the whole read-compare-upload / download-publish sequences */
 static pthread_mutex_t hip_liminfo_lock = PTHREAD_MUTEX_INITIALIZER;
 static int hip_n1, hip_n2, hip_max_batch;
+/* -1: the fft2 spectrum ring is opened sparse (cfg.fft2_float_sparse: only the band fft2_mix1_fixed cuts out is stored, power sums and
+   waterfall lines come out of the transform kernels) when nothing on the host reads whole fft2 spectra -- AFC off (make_afc reads power
+   rows, fft2_mix1_afc whole spectra), no spur removal (acquisition and search read them), no NET_RXOUT_FFT2, one RF channel.
+   0: always every bin (the test harness sets it: it compares the device ring itself).  fft1_float is left full: the stage calls
+   run k_fft1 + k_timf2, which write and read whole spectra; the fused kernels that need no ring belong to lrh_wideband_dsp. */
+int hip_sparse_rings = -1;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
 static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
 static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins store_new_spur was last asked to take */
@@ -130,6 +136,8 @@ int hip_open(void)
     if (cap > c.max_batch) c.max_batch = cap; }
   hip_max_batch = c.max_batch;
   c.second_fft_enable = genparm[SECOND_FFT_ENABLE];
+  if (hip_sparse_rings != 0 && ui.rx_rf_channels == 1 && genparm[SECOND_FFT_ENABLE] != 0 && genparm[AFC_ENABLE] == 0 && genparm[MAX_NO_OF_SPURS] == 0 &&
+      (ui.network_flag & NET_RXOUT_FFT2) == 0) c.fft2_float_sparse = 1;
   c.timf2_blockpower_block = timf2_blockpower_block; c.timf2_blockpower_size = timf2_blockpower_size;     /* compute_timf2_powersum, wcw.c:80 */
   c.timf1_dword_input = (ui.rx_input_mode & DWORD_INPUT) != 0; c.sample_shift = ui.sample_shift;
   c.timf1_real_input = (ui.rx_input_mode & IQ_DATA) == 0;          /* fft1_reherm_dit_one's job (fft1_re.c:32-131): 2 fft1_size reals per transform */

@@ -35,6 +35,7 @@ int  hip_store_new_spur(int pnt);     /* spur acquisition (spursub.c:619, 1247) 
 int  hip_spur_phase_lock(int nx);
 void hip_remove_spur(int ia);
 void hip_swap_spurs(int ia, int ib);
+extern int hip_sparse_rings;         /* -1 (default): cfg.fft2_float_sparse when no host code reads whole fft2 spectra; 0: every bin always (hipshim.c) */
 struct lrh_ctx *hip_context(void);
 struct lrh_ctx *hip_context_of(int channel);   /* two RF channels: one context each */    /* the context behind the hooks (diagnostics, tests)                                    */
 #endif

@@ -800,6 +800,7 @@ int main(int argc, char **argv)
   const int shim_net = AI("shim_net", 0);           /* 1: ui.network_flag asks for the FFT1 / TIMF2 / FFT2 multicasts: the hooks the patch puts in front of the senders'
                                                        reads (wcw.c:1024-1043, rxin.c:944, 1026) are called where the senders would read, and the host rings they fill are dumped */
   if (shim_net) ui.network_flag = NET_RXOUT_FFT1 | NET_RXOUT_TIMF2 | NET_RXOUT_FFT2;
+  hip_sparse_rings = AI("shim_sparse", 0) ? -1 : 0;                     /* 0 (default here): the device rings themselves are compared below; 1: as a patched xlinrad64 opens them */
   { int rc = hip_open(); fprintf(stderr, "hip_open: %d\n", rc); if (rc != 0) { printf("{\"hip_open\": %d}\n", rc); fclose(fo); return AI("shim_refuse", 0) ? 0 : 3; } }
   glue_ingest = timing && shim_threads == 2;                            /* the timed glue: block by block from the dispatcher, like the input thread */
   if (!glue_ingest)

@@ -80,7 +80,10 @@ def check_golden_case(harness, tmp_path, name, extra=(), tol=1e-5, truth_factor=
         g["fft1_sumsq"][it[-1, 9]:it[-1, 9] + n1] = 0
     assert np.array_equal(dump["final"], g["final"]), "final ring pointers differ"
     # (the HIP path never stores the raw half block the reference parks beyond timf2_pa, timf2.c:1018-1025; nothing reads it: masked)
-    rep = compare_with_golden(out, g, tol=tol, mask_pending_timf2=True, truth=truth, truth_factor=truth_factor)
+    # shim_sparse=1: the glue opens the fft2 spectrum ring the way a patched xlinrad64 does (hipshim.c, hip_sparse_rings): only the band mix1
+    # cuts out exists on the device -- everything Linrad sees on the host (sums, waterfall lines, timf3, pointers) is compared as before
+    skip = ("fft2_float", "fft2_power_float") if "shim_sparse=1" in extra else ()
+    rep = compare_with_golden(out, g, tol=tol, mask_pending_timf2=True, truth=truth, truth_factor=truth_factor, skip=skip)
     if "shim_net=1" in extra:
         # NET_RXOUT_FFT1 / TIMF2 / FFT2 on: the hooks in front of the senders' reads filled the host rings (timf2_float and fft2_float above came
         # through hip_net_timf2 / hip_net_fft2 a packet's worth at a time); block 0 of fft1_float as the dispatcher's memcpy would have found it

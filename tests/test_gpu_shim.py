@@ -50,6 +50,14 @@ def test_patched_reference_over_the_hip_library_from_linrads_stage_threads(harne
     print(name, shimlib.check_golden_case(harness, tmp_path, name, extra=["shim_threads=1"]))
 
 
+@pytest.mark.parametrize("name", ["n10_n12", "n10_n12_fft3", "n9_n11_sin3"])
+def test_glue_opens_the_fft2_ring_sparse_when_nobody_reads_it(harness, tmp_path, name):
+    """hip_open with hip_sparse_rings = -1 (what a patched xlinrad64 runs with): AFC off, no spurs, no NET_RXOUT_FFT2 -> cfg.fft2_float_sparse,
+    the transform kernels of the headline keep the power sums and waterfall lines themselves and store only the band fft2_mix1_fixed cuts
+    out; everything Linrad sees on the host equals the unpatched reference's as before"""
+    print(name, shimlib.check_golden_case(harness, tmp_path, name, extra=["shim_sparse=1"]))
+
+
 def test_network_output_hooks_on_the_device(harness, tmp_path):
     """NET_RXOUT_FFT1 / TIMF2 / FFT2 (wcw.c:1024-1043, rxin.c:944-966, 1026-1035): the hooks in front of the senders' reads fetch the spans
     from the device rings; the FFT1 payload is the transform before fft1_c's correction (lrh_export_fft1_net)"""
