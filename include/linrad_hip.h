@@ -389,8 +389,9 @@ int lrh_spur_search_get(lrh_ctx *ctx, float *spursearch_spectrum, float *spur_se
    (spursub.c:1247-1426 with verify_spur_pll :1428-1843: up to five rounds of the loop on that history, accepted when the corrections
    have died down and the residual over the window is spectrally flat) for the next free spur number.  p->fft2_na = ffts_na, the ring
    position behind the newest transform (wcw.c:288-289).  *locked = 1: the spur is tracked from the next lrh_make_fft2 on
-   (no_of_spurs++, spursub.c:309); 0: no lock, nothing changed.  The search for candidates (spursearch_spectrum, spursub.c:36-260)
-   reads the summed power spectrum, which the host has anyway (LRH_RING_FFT2_POWERSUM).  Needs cfg.fft2_float_sparse = 0.  Synchronous. */
+   (no_of_spurs++, spursub.c:309) and the carrier has been taken out of the spur_speknum transforms the loop was closed on as well
+   (initial_remove_spur, spursub.c:346-470, the call that follows the lock in init_spur_elimination); 0: no lock, nothing changed.
+   The candidates come from the search spectrum (lrh_spur_search_get above).  Needs cfg.fft2_float_sparse = 0.  Synchronous. */
 int lrh_spur_acquire(lrh_ctx *ctx, const lrh_ptrs *p, int pnt, int *locked);
 
 /* ---- producer side: what finish_rx_read (rxin.c:1143-1436) makes visible in timf1 ---- */

@@ -58,6 +58,7 @@ static int hip_n1, hip_n2, hip_max_batch;
 int hip_sparse_rings = -1;
 static int hip_clever_mode;               /* hg.clever_bln_mode for which the blanker tables on the device were installed */
 static float *hip_afc_tmp;               /* scratch of hip_afc_rows */
+static int hip_dev_spurs;                     /* length of the device's spur list as the glue left it (acquire: +1, permute: n) */
 static int hip_spurs_on, hip_spur_pnt = -1;  /* spur removal served; the bins store_new_spur was last asked to take */
 static lrh_spur *hip_sp; static int *hip_spsrc; static int hip_spcap;   /* scratch of the spur hooks: genparm[MAX_NO_OF_SPURS] + 1 entries (buf.c:1102 clamps the parameter
                                                                           to fftx_size / SPUR_WIDTH), allocated by hip_open; the hooks run on THREAD_SECOND_FFT / spur_removal only */
@@ -67,6 +68,7 @@ static double hip_afc_selfreq = -2;       /* frequency around which the AFC's wi
 
 static int hip_xgather(int which, size_t count);
 static void hip_spur_after_fft2(int na);
+static void hip_spur_resync(void);
 static void hip_open_failed(void);
 static int hip_ss_ticket[8], hip_ss_n;     /* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
 static int hip_wf_ticket[6], hip_wf_n;     /* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
@@ -198,7 +200,7 @@ static void hip_release(void)
   free(hip_liminfo_sent); hip_liminfo_sent = NULL;
   free(hip_afc_tmp); hip_afc_tmp = NULL;
   free(hip_sp); free(hip_spsrc); hip_sp = NULL; hip_spsrc = NULL; hip_spcap = 0;
-  hip_spurs_on = 0; hip_spur_pnt = -1;
+  hip_spurs_on = 0; hip_spur_pnt = -1; hip_dev_spurs = 0;
 }
 static void hip_open_failed(void) { hip_ss_n = 0; hip_wf_n = 0; hip_release(); }
 
@@ -312,6 +314,7 @@ void hip_fft1_c(void)
   q.fft1_nb = fft1_nb; q.fft1_pb = HIP_IN(fft1_pb); q.fft1_sumsq_pa = fft1_sumsq_pa; q.fft1_sumsq_counter = fft1_sumsq_counter;
   q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   { lrh_ptrs q0 = q;
+    if (hip_spurs_on && genparm[SECOND_FFT_ENABLE] == 0) hip_spur_resync();   /* (the spur loop runs inside lrh_fft1_c then) */
     for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } }
     if (HC == 2 && fft1_correlation_flag == 1) {       /* X conj(Y) needs both channels' bins: the all-gather of the batch's transforms, through host memory */
       size_t cnt[2] = { 0, 0 };
@@ -536,8 +539,8 @@ int hip_fft2_update_liminfo(void)
    carrier on, store_new_spur (spursub.c:619: history of the seven bins from fftx) and spur_phase_lock (:1247: closes the loop on that
    history), are one device call, lrh_spur_acquire, on the resident spectra; remove_spur / swap_spurs (spur.c:596, spursub.c:755), with
    which it drops a weaker neighbour and keeps the list in order of frequency, become lrh_spur_permute.  The loop state comes back after
-   every transform for the spur display and those decisions.  Not done: initial_remove_spur (spursub.c:346: the carrier is also taken
-   out of the spur_speknum transforms already in the ring) -- subtraction starts with the next transform. ---- */
+   every transform for the spur display and those decisions.  initial_remove_spur (spursub.c:346: the carrier also leaves the
+   spur_speknum transforms the loop was closed on) is part of lrh_spur_acquire; the patch returns from Linrad's own at once. ---- */
 static void hip_spur_state_back(void)
 {
   lrh_spur *sp = hip_sp;
@@ -555,11 +558,11 @@ static void hip_spur_state_back(void)
    would land one slot past the one Linrad reads. */
 static void hip_spur_resync(void)
 {
-  int n = 0, i;
-  if (lrh_spur_get(hip_rx, hip_spcap, hip_sp, &n) != 0) { lirerr(1480); return; }
-  if (n <= no_of_spurs) return;
+  int i;
+  if (hip_dev_spurs <= no_of_spurs) return;
   for (i = 0; i < no_of_spurs; i++) hip_spsrc[i] = i;
   if (lrh_spur_permute(hip_rx, no_of_spurs, hip_spsrc) != 0) lirerr(1481);
+  hip_dev_spurs = no_of_spurs;
 }
 int hip_store_new_spur(int pnt) { hip_spur_pnt = pnt; return 0; }      /* the history is taken on the device, by hip_spur_phase_lock */
 int hip_spur_phase_lock(int nx)
@@ -573,6 +576,7 @@ int hip_spur_phase_lock(int nx)
   if (lrh_spur_acquire(hip_rx, &q, hip_spur_pnt, &locked) != 0) locked = 0;
   hip_spur_pnt = -1;
   if (!locked) return 1;
+  hip_dev_spurs++;
   hip_spur_state_back();                                               /* spurno == no_of_spurs: the new spur's loop state for init_spur_elimination's ordering */
   return 0;
 }
@@ -583,6 +587,7 @@ void hip_remove_spur(int ia)                                           /* remove
   for (i = 0; i < no_of_spurs; i++) src[i] = i;
   if (ia >= 0 && ia < no_of_spurs) src[ia] = no_of_spurs;
   if (lrh_spur_permute(hip_rx, no_of_spurs, src) != 0) lirerr(1481);
+  hip_dev_spurs = no_of_spurs;
   hip_spur_state_back();
 }
 void hip_swap_spurs(int ia, int ib)
@@ -606,7 +611,7 @@ static void hip_spur_after_fft2(int na)
     hip_spur_state_back();
     if (genparm[AFC_ENABLE] == 2) {
       for (i = 0; i < no_of_spurs && i < hip_spcap; i++) if (spur_flag[i] < spur_speknum) src[n++] = i;
-      if (n != no_of_spurs) { if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481); no_of_spurs = n; hip_spur_state_back(); }
+      if (n != no_of_spurs) { if (lrh_spur_permute(hip_rx, n, src) != 0) lirerr(1481); no_of_spurs = n; hip_dev_spurs = n; hip_spur_state_back(); }
     }
   }
   if (spursearch_spectrum == NULL) return;
@@ -654,6 +659,7 @@ void hip_make_fft2(void)
     { const int room = max_fft2n - 1 - ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask); if (nf > room) nf = room; }
     if (nf > max_fft2n / 2) nf = max_fft2n / 2;
     if (hip_spurs_on || nf < 1) nf = 1;
+    if (hip_spurs_on) hip_spur_resync();                     /* a spur Linrad dropped since the last transform must not be subtracted from this one */
     q.timf2_px = HIP_IN(timf2_px); q.fft2_na = fft2_na;
     if (lrh_make_fft2(hip_rx, &q, nf) != 0) { lirerr(1469); return; } }
   else {

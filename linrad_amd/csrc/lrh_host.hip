@@ -383,7 +383,7 @@ static void default_filtercorr(lrh_ctx *c)  // clear_fft1_filtercorr + make_filc
   float t1 = 0.125F * (float)PI_L, t2 = 0, t3;
   int i = 0, k = N - 1;
   while (t2 < 0.5 * PI_L) {
-    t3 = (float)(sin(t2) * sin(t2));
+    t3 = (float)(sin((double)t2) * sin((double)t2));        // (double sin as in C: in C++ sin(float) is the float overload, one ulp off in three entries per edge)
     if (!real) { c->h_desired[i] = t3; c->h_filtercorr[2 * i] = t3 * start; }   // fft1.c:4707-4711: the low edge only for I/Q
     c->h_desired[k] = t3; c->h_filtercorr[2 * k] = t3 * start;
     t2 += t1; i++; k--;
@@ -1136,7 +1136,7 @@ static int spur_search_row(lrh_ctx *c, int na, hipStream_t src)
   SpurSearchArgs a; memset(&a, 0, sizeof a);
   a.sum = c->d_ss_sum; a.spec = c->d_ss_spec_base + 32; a.mins = c->d_ss_min; a.z = c->spur_ring + (size_t)na * c->spur_nx;
   a.first = c->ss_first; a.last = c->ss_last; a.spectra = c->d_spur_spectra; a.out = c->d_ss_out;
-  const double s3 = sqrt((float)(3 * c->spur_speknum));
+  const double s3 = sqrt((double)(float)(3 * c->spur_speknum));
   a.noise_factor = pow(10., 0.7 / s3); a.thr_factor = pow(10., 1.5 / s3);
   // the rows are element-wise and short: on the caller's stream, right behind the kernels that made the power row.  Only the cleanup
   // goes to the stream of its own; the row that forms the next search spectrum waits for it (3 spur_speknum transforms later: long done)

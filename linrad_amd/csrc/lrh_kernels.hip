@@ -5323,6 +5323,17 @@ struct SpurWave {
         spread = (float)sqrt((double)(spread / 9));
         if (spread > 0.5 * mean / sqrt((double)n) + 0.02 * q.ampl) return false;
         q.avgd2 = q.d2pha;
+        // initial_remove_spur (spursub.c:346-470, called right behind the lock, :309): the carrier also leaves the transforms the loop was closed on
+        for (int m = lane; m < n; m += 64) {
+          float r = (float)(-0.5 * (q.d1pha - m * q.d2pha) / LRH_PI); const int it = (int)(turns2 - r + 0.5); r += it;
+          const int j = half_pos(r / a.freq_factor);
+          const int sidx = slot(newest, m), id = uind[sidx];
+          float2 carrier = rot(make_float2(q.ampl, 0.f), (double)q.d0pha - m * (double)q.d1pha + 0.5 * m * (m - 1) * (double)q.d2pha);
+          if ((j ^ (q.location & 1)) == 1) { carrier.x = -carrier.x; carrier.y = -carrier.y; }
+          float2 *z = a.fft2 + (size_t)sidx * a.n2 + q.location;
+#pragma unroll
+          for (int i = 0; i < 7; i++) { const float sh = spec[id + i]; float2 v = z[i]; v.x -= sh * carrier.x; v.y -= sh * carrier.y; z[i] = v; }
+        }
         return true;
       }
       e0 = c0; e1 = c1; e2 = c2;

@@ -3059,6 +3059,31 @@ int lro_spur_acquire(lro_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
       if (r2 > 0.5 * r1 / sqrt((int)(n)) + 0.02 * q->spur_ampl) return LRH_OK;
       q->spur_avgd2 = q->spur_d2pha;                                         /* spursub.c:1424 */
       S->n++; *locked = 1;
+      /* initial_remove_spur, spursub.c:346-470 (init_spur_elimination calls it right behind the lock, :309): the carrier also leaves the
+         spur_speknum transforms the loop was closed on -- the same backward walk once more, now writing */
+      a1 = q->spur_ampl * (float)cos(q->spur_d0pha); a2 = q->spur_ampl * (float)sin(q->spur_d0pha);
+      b1 = (float)cos(q->spur_d1pha); b2 = (float)sin(q->spur_d1pha); d1 = (float)cos(q->spur_d2pha); d2 = (float)sin(q->spur_d2pha);
+      slope = q->spur_d1pha;
+      ni = (na + mask) & mask;
+      for (int izz = n - 1; izz >= 0; izz--) {
+        float rot = (float)(-0.5 * slope / PI_L);
+        int i = (int)(average_rot - rot + 0.5);
+        rot += i;
+        const float freq = rot / S->freq_factor;
+        int j = (int)(freq) + 2 - q->spur_location - SPSZ / 2;
+        if (j < 0) j = 0;
+        j = 1 - j;
+        if (j < 0) j = 0;
+        const int ind = uind[ni];
+        float t1 = a1, t2 = a2;
+        if ((j ^ (q->spur_location & 1)) == 1) { t1 = -a1; t2 = -a2; }
+        float *z = (float *)&fftx[2 * ((size_t)ni * n2 + q->spur_location)];
+        for (i = 0; i < SPW; i++) { z[2 * i] -= S->spectra[ind + i] * t1; z[2 * i + 1] -= S->spectra[ind + i] * t2; }
+        ni = (ni + mask) & mask;
+        r1 = a1 * b1 + a2 * b2; a2 = a2 * b1 - a1 * b2; a1 = r1;
+        r2 = b1 * d1 + b2 * d2; b2 = b2 * d1 - b1 * d2; b1 = r2;
+        slope -= q->spur_d2pha;
+      }
       return LRH_OK;
     }
     d0err = S->sp_d0; d1err = S->sp_d1; d2err = S->sp_d2;

@@ -90,6 +90,7 @@ void init_fft(int mo, int nz, int sz, COSIN_TABLE *tab, unsigned short int *perm
 void set_fft1_endpoints(void);
 void fft1_update_liminfo(void);
 int store_new_spur(int pnt);
+void initial_remove_spur(void);
 int spur_phase_lock(int nx);
 void init_spur_spectra(void);
 void eliminate_spurs(void);
@@ -388,6 +389,13 @@ int main(int argc, char **argv)
   double clever_factor = AF("clever_factor", 10.0);
   const char *fdesired = arg(argc, argv, "desired", NULL);
   int spur_pnt = AI("spur_pnt", 0), spur_start = AI("spur_start", 16), spur_spek = AI("spur_speknum", 0);
+  /* spur_click<i>_at / _pnt (i = 1..4): at fft2 transform number _at the operator clicks the high-resolution graph at fft2 bin _pnt with the
+     spur button armed: the reference's whole init_spur_elimination (spursub.c:181-343) -- peak search in spursearch_spectrum around the click,
+     store_new_spur, spur_phase_lock, initial_remove_spur, then the ordering pass that drops the weaker of two spurs closer than four bins and
+     keeps the list sorted by frequency (remove_spur, swap_spurs) -- instead of the harness's own store / lock calls */
+  int click_at[4], click_pnt[4], nclick = 0;
+  for (int i = 1; i <= 4; i++) { char ka[32], kp[32]; snprintf(ka, sizeof ka, "spur_click%d_at", i); snprintf(kp, sizeof kp, "spur_click%d_pnt", i);
+    if (AI(ka, 0) > 0) { click_at[nclick] = AI(ka, 0); click_pnt[nclick] = AI(kp, 0); nclick++; } }
   int mix2on = AI("mix2", 0);                    /* 1: fft3_mix2's filter / decimate part (mixer_mode 1) after every make_fft3_all */
   int mixer_mode = AI("mixer_mode", 1);          /* 2: bg.mixer_mode = 2, the FIR decimator on timf3 (mix2.c:217-246) instead of the filter on fft3's bins */
   double pol_c1 = AF("pol_c1", 1.0), pol_c2 = AF("pol_c2", 0.0), pol_c3 = AF("pol_c3", 0.0);   /* pg.c1..c3 (two channels) */
@@ -595,7 +603,8 @@ int main(int argc, char **argv)
   fft2_pa = 0; fft2_na = fft2_nb = fft2_nx = fft2_nm = 0; fft2_liminfo_cnt = 0;
   hg_redraw_counter = 0; hg.spek_avgnum = 1 << 30; fft2_blocktime = 0;
   fft2_to_fft1_ratio = N2 / N1; if (fft2_to_fft1_ratio < 1) fft2_to_fft1_ratio = 1;
-  float *spur_trace = NULL; int nspur_trace = 0, spur_locked_at = -1;
+  float *spur_trace = NULL, *spur_trace_all = NULL, click_log[4 * 8]; int nspur_trace = 0, nspur_all = 0, spur_locked_at = -1;
+  memset(click_log, 0, sizeof click_log);
   float *ss_last = NULL, ss_thr[64]; int ss_completed = 0, ss_at[64];       /* the search spectrum as the newest spursearch_spectrum_cleanup left it (fft2.c:676-683) */
   if (spur) {                                    /* buf.c:1100-1172, 1252, 1647 */
     const int ms = 4;
@@ -631,6 +640,7 @@ int main(int argc, char **argv)
     spur_search_first_point = 0; spur_search_last_point = fftx_size - 1;
     init_spur_spectra();
     spur_trace = zalloc(sizeof(float) * 12 * ((size_t)nblk * 8 + 64));
+    spur_trace_all = zalloc(sizeof(float) * 40 * ((size_t)nblk * 8 + 64));
     ss_last = zalloc(4 * (size_t)fftx_size);
   }
 
@@ -923,6 +933,7 @@ int main(int argc, char **argv)
                   spur_location[0], spur_freq[0], spur_ampl[0], spur_noise[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0]);
           if (!rc1 && !rc2) {
             no_of_spurs = 1; spur_locked_at = b + 1;
+            initial_remove_spur();                        /* init_spur_elimination's next step (spursub.c:309) */
             float st[12] = { (float)spur_location[0], (float)spur_flag[0], spur_freq[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0], spur_ampl[0], spur_noise[0], spur_avgd2[0],
                              (float)ffts_na, (float)spur_speknum, spur_freq_factor };
             PUTF("spur_init_state", st, 12);
@@ -978,6 +989,31 @@ int main(int argc, char **argv)
         if (ss_completed < 64) { ss_thr[ss_completed] = spur_search_threshold; ss_at[ss_completed] = nfft2; }
         ss_completed++;
       }
+      if (spur && nclick) {
+        for (int c = 0; c < nclick; c++) if (nfft2 + 1 == click_at[c]) {
+          ffts_na = fft2_na; ffts_nm = fft2_nm;                    /* what second_fft leaves for spur_removal (wcw.c:288-303) */
+          no_of_scro = 1; scro[0].no = HIRES_GRAPH; scro[0].x1 = 0; scro[0].x2 = 1 << 30; scro[0].y1 = 0; scro[0].y2 = 1 << 30;
+          mouse_x = click_pnt[c]; mouse_y = 1; hg_first_xpixel = 0; hg_first_point = 0;
+          autospur_point = spur_search_first_point + SPUR_WIDTH / 2 + 1;      /* (the manual branch insists on it, spursub.c:189) */
+          const int before = no_of_spurs;
+          if (getenv("LRH_HARNESS_DEBUG")) { fprintf(stderr, "search spectrum (threshold %g, ffts_nm %d) around the click:", spur_search_threshold, ffts_nm);
+            for (int i = click_pnt[c] - 8; i <= click_pnt[c] + 8; i++) fprintf(stderr, " %.3g", spursearch_spectrum[i]); fprintf(stderr, "\n"); }
+          init_spur_elimination();
+          float *q = click_log + 8 * c;
+          q[0] = nfft2; q[1] = before; q[2] = no_of_spurs; for (int i = 0; i < 4 && i < no_of_spurs; i++) q[3 + i] = spur_location[i];
+          fprintf(stderr, "click %d at transform %d on bin %d: spurs %d -> %d, locations", c, nfft2, click_pnt[c], before, no_of_spurs);
+          for (int i = 0; i < no_of_spurs; i++) fprintf(stderr, " %d (ampl %.4g)", spur_location[i], spur_ampl[i]);
+          if (no_of_spurs == before && before < 4) { q[7] = spur_location[before];     /* the slot behind the list: what an acquisition that was dropped again left there */
+            fprintf(stderr, "; slot %d behind the list: location %d ampl %.4g", before, spur_location[before], spur_ampl[before]); }
+          fprintf(stderr, "\n");
+          if (spur_locked_at < 0 && no_of_spurs > 0) spur_locked_at = nfft2 + 1;
+        }
+        float *q = spur_trace_all + 40 * nspur_all++;
+        q[0] = nfft2; q[1] = no_of_spurs;
+        for (int i = 0; i < 4 && i < no_of_spurs; i++) { float *r = q + 2 + 9 * i;
+          r[0] = spur_location[i]; r[1] = spur_flag[i]; r[2] = spur_freq[i]; r[3] = spur_d0pha[i]; r[4] = spur_d1pha[i]; r[5] = spur_d2pha[i];
+          r[6] = spur_ampl[i]; r[7] = spur_noise[i]; r[8] = spur_avgd2[i]; }
+      } else
       if (spur && no_of_spurs == 0 && nfft2 + 1 == spur_start) {   /* acquisition, tail of init_spur_elimination (spursub.c:282-309) */
         ffts_na = fft2_na; ffts_nm = fft2_nm;
         spurno = 0; spur_ampl[0] = 1; spur_noise[0] = 0.001; spur_avgd2[0] = 0;
@@ -986,6 +1022,7 @@ int main(int argc, char **argv)
                 spur_location[0], spur_freq[0], spur_ampl[0], spur_noise[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0]);
         if (!rc1 && !rc2) {
           no_of_spurs = 1; spur_locked_at = nfft2 + 1;
+          initial_remove_spur();                          /* init_spur_elimination's next step (spursub.c:309) */
           float st[12] = { (float)spur_location[0], (float)spur_flag[0], spur_freq[0], spur_d0pha[0], spur_d1pha[0], spur_d2pha[0], spur_ampl[0], spur_noise[0], spur_avgd2[0],
                            (float)fft2_na, (float)spur_speknum, spur_freq_factor };
           PUTF("spur_init_state", st, 12);
@@ -1121,6 +1158,7 @@ run_done:
       if (hg.sellim_par1 != 2) { int v1[1] = { hg.sellim_par1 }; PUTI("sellim2_par1", v1, 1); }
     }
   }
+  if (spur && nclick) { PUTF("spur_trace_all", spur_trace_all, (size_t)40 * nspur_all); PUTF("spur_clicks", click_log, 32); PUTF("spur_spectra", spur_spectra, NO_OF_SPUR_SPECTRA * SPUR_SIZE); }
   if (spur) { PUTF("spur_trace", spur_trace, (size_t)12 * (nspur_trace > 0 ? nspur_trace : 1)); int sl[2] = { spur_locked_at, nspur_trace }; PUTI("spur_locked", sl, 2);
     PUTF("spursearch_spectrum", ss_last, fftx_size); PUTF("spursearch_thresholds", ss_thr, ss_completed < 64 ? (ss_completed > 0 ? ss_completed : 1) : 64);
     int si[4] = { ss_completed, spursearch_sum_counter, spur_search_first_point, spur_search_last_point }; PUTI("spursearch_info", si, 4);

@@ -15,18 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from refcases import SPUR, harness_args, make_liminfo, spur_case  # noqa: E402
+from refcases import SPUR, SPUR_CLICKS, harness_args, make_liminfo, spur_case  # noqa: E402
 from refdump import load_dump  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 KEEP = ["spur_init_state", "spur_init_table", "spur_init_signal", "spur_init_ind", "spur_spectra", "spur_trace", "spur_locked",
         "fft2_float", "fft2_powersum_float", "timf3_float", "wf_lines", "mixtrace", "final", "itrace", "fft1_float", "fft1_sumsq", "fft1_slowsum",
-        "spursearch_spectrum", "spursearch_thresholds", "spursearch_info", "spursearch_at"]
+        "spursearch_spectrum", "spursearch_thresholds", "spursearch_info", "spursearch_at", "spur_trace_all", "spur_clicks"]
 
 
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    for name in sys.argv[1:] or list(SPUR):
+    for name in sys.argv[1:] or list(SPUR) + list(SPUR_CLICKS):
         d, sp, iq, lim = spur_case(name)
         with tempfile.TemporaryDirectory() as td:
             fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
@@ -40,11 +40,17 @@ def main():
         out["iq"], out["liminfo"] = iq, lim
         path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
+        if name in SPUR_CLICKS:                       # the operator's clicks through init_spur_elimination: every spur's loop state after every transform
+            ta = out["spur_trace_all"].reshape(-1, 40)
+            print(name, os.path.getsize(path) // 1024, "KiB; transforms", ta.shape[0], "spurs held", sorted(set(ta[:, 1].astype(int))))
+            for ln in r.stderr.strip().splitlines():
+                if ln.startswith("click"):
+                    print("   " + ln[:200])
+            continue
         tr = out["spur_trace"].reshape(-1, 12)
         print(name, os.path.getsize(path) // 1024, "KiB;", r.stderr.strip().splitlines()[-1][:150])
         print("   transforms tracked", tr.shape[0], "flags", sorted(set(tr[:, 1].astype(int))), "locations", sorted(set(tr[:, 0].astype(int))),
               "freq %.3f -> %.3f" % (tr[0, 2], tr[-1, 2]), "ampl %.4g -> %.4g" % (tr[0, 6], tr[-1, 6]))
-
 
 if __name__ == "__main__":
     main()

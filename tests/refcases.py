@@ -381,14 +381,43 @@ SPUR = {
 }
 
 
+# the operator's clicks through the reference's whole init_spur_elimination (harness spur_click<i>_at / _pnt, spursub.c:181-343): the carrier of
+# the base case (fft2 bin 2196.0) is taken on; a weaker one 3.4 bins above it is clicked next -- its window lands within four bins of the
+# first (it is keyed on after the first lock: side by side the two are a broad peak, which spursearch_spectrum_cleanup wipes from the search
+# spectrum, spursub.c:152-170), the ordering pass drops the weaker (the new, LAST one: by counting no_of_spurs down, without remove_spur, spursub.c:331-335); a third
+# click takes a carrier BELOW the first: swap_spurs puts the list in order of frequency
+SPUR_CLICKS = {
+    "spur_n10_n12_clicks": dict(base="n10_n12", nblk=430, max_fft2n=32, blockpower_block=0, spur_speknum=8, tone=None,
+                                tones=[(3000.2, 0.0, 1000.0), (3002.9, 0.42, 800.0), (1300.3, 0.0, 500.0)], clicks=[(30, 3000), (84, 3003), (90, 1300)]),
+    # the second carrier the stronger of the two: the FIRST spur is the one dropped, remove_spur(0) moves the new one into its slot (spur.c:596)
+    "spur_n10_n12_clicks_strong": dict(base="n10_n12", nblk=430, max_fft2n=32, blockpower_block=0, spur_speknum=8, tone=None,
+                                       tones=[(3000.2, 0.0, 1000.0), (3002.6, 0.42, 2000.0), (1300.3, 0.0, 500.0)], clicks=[(30, 3000), (84, 3002), (90, 1300)]),
+}
+
+
 def spur_case(name):
-    t = dict(SPUR[name])
+    t = dict(SPUR[name] if name in SPUR else SPUR_CLICKS[name])
     d = case_params(t.pop("base"))
-    sp = {k: t.pop(k) for k in ("spur_pnt", "spur_start", "spur_speknum")}
+    if "clicks" in t:
+        sp = {"spur_speknum": t.pop("spur_speknum")}
+        for i, (at, pnt) in enumerate(t.pop("clicks")):
+            sp[f"spur_click{i + 1}_at"], sp[f"spur_click{i + 1}_pnt"] = at, pnt
+    else:
+        sp = {k: t.pop(k) for k in ("spur_pnt", "spur_start", "spur_speknum")}
     tone = t.pop("tone")
+    tones = t.pop("tones", [])
     d.update(t)
     iq = make_input(d).astype(np.float64)
     lim = make_liminfo(d)
+    for tn in tones:                          # steady extra carriers (fft2 bin, switched on at this fraction of the run, amplitude), routed strong
+        N1, N2 = 1 << d["n1"], 1 << d["n2"]
+        c = int(round(N1 // 2 + (tn[0] - N2 / 2) * N1 / N2))
+        lim[c - d["lim_halfwidth"]:c + d["lim_halfwidth"] + 1] = 1.0
+        tt = np.arange(iq.size // 2, dtype=np.float64)
+        ph = 2 * np.pi * ((tn[0] - N2 / 2) / N2) * tt
+        on = tt >= tn[1] * tt.size
+        iq[0::2] += tn[2] * np.cos(ph) * on
+        iq[1::2] += tn[2] * np.sin(ph) * on
     if tone is not None:                      # (fft2 bin at the start, drift in fft2 bins over the run, amplitude)
         N1, N2 = 1 << d["n1"], 1 << d["n2"]
         c = int(round(N1 // 2 + (tone[0] - N2 / 2) * N1 / N2))       # routed with the strong signals like the other carriers

@@ -268,6 +268,56 @@ def check_spur_case(harness, tmp_path, name="spur_n10_n12", tol=1e-5):
     return rep
 
 
+def check_spur_clicks_case(harness, tmp_path, name="spur_n10_n12_clicks", tol=1e-5):
+    """Linrad's whole init_spur_elimination (spursub.c:181-343) over the glue: the operator's click -> peak search in the search spectrum the
+    device summed and cleaned -> store_new_spur / spur_phase_lock (hooked: lrh_spur_acquire, which also takes the carrier out of the
+    transforms it locked on, initial_remove_spur) -> the ordering pass on the loop state the glue brought back: the weaker of two spurs closer
+    than four bins is dropped -- the LAST one by counting no_of_spurs down and nothing else (the glue cuts the device's list back before the
+    next transform, hip_spur_resync), another one through remove_spur (hooked) -- and swap_spurs (hooked) sorts by frequency.  Every spur's
+    loop state after every transform and the rings behind the subtraction against the unpatched reference's."""
+    from refcases import spur_case
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+    d, sp, iq, lim = spur_case(name)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
+    dump = run_harness(harness, lambda p, fo: harness_args(d, p["in"], p["lim"], fo) + ["spur=1"] + [f"{k}={v}" for k, v in sp.items()],
+                       tmp_path, {"in": iq, "lim": lim})
+    assert np.array_equal(dump["spur_clicks"], g["spur_clicks"]), (dump["spur_clicks"].reshape(4, 8), g["spur_clicks"].reshape(4, 8))
+    got, ref = dump["spur_trace_all"].reshape(-1, 40).astype(np.float64), g["spur_trace_all"].reshape(-1, 40).astype(np.float64)
+    assert got.shape == ref.shape and np.array_equal(got[:, :2], ref[:, :2]), "number of spurs after every transform"
+    rep = {"transforms": int(ref.shape[0]), "spurs_held": sorted(set(int(x) for x in ref[:, 1])), "clicks": g["spur_clicks"].reshape(4, 8)[:3, :3].astype(int).tolist()}
+    err = dict(freq=0.0, phase=0.0, d1=0.0, d2=0.0, ampl=0.0, noise=0.0)
+    for s_ in range(4):
+        on = ref[:, 1] > s_
+        if not on.any():
+            continue
+        a, b = got[on][:, 2 + 9 * s_:11 + 9 * s_], ref[on][:, 2 + 9 * s_:11 + 9 * s_]
+        assert np.array_equal(a[:, :2], b[:, :2]), f"spur {s_}: spur_location / spur_flag trace differs"
+        err["freq"] = max(err["freq"], float(np.max(np.abs(a[:, 2] - b[:, 2]))))
+        err["phase"] = max(err["phase"], float(np.max(np.abs(wrap(a[:, 3] - b[:, 3])))))
+        err["d1"] = max(err["d1"], float(np.max(np.abs(wrap(a[:, 4] - b[:, 4])))))
+        err["d2"] = max(err["d2"], float(np.max(np.abs(a[:, 5] - b[:, 5]))))
+        err["ampl"] = max(err["ampl"], float(np.max(np.abs(a[:, 6] - b[:, 6]) / np.abs(b[:, 6]))))
+        err["noise"] = max(err["noise"], float(np.max(np.abs(a[:, 7] - b[:, 7]) / np.abs(b[:, 7]))))
+    rep.update({k + "_err": v for k, v in err.items()})
+    assert err["freq"] < 1e-3 and err["phase"] < 20 * tol * 1e2 and err["d1"] < 1e-3 and err["ampl"] < 10 * tol and err["noise"] < 1e-3, rep
+    keep3 = np.ones(dump["timf3_float"].size, bool)                 # the half block parked beyond timf3_pa (mix1.c:188-194) stays on the device
+    keep3[(int(dump["final"][9]) + np.arange(int(dump["mixtrace"].reshape(-1, 8)[0, 6]))) % keep3.size] = False
+    rep["fft2"], rep["ps2"] = relerr(dump["fft2_float"], g["fft2_float"]), relerr(dump["fft2_powersum_float"], g["fft2_powersum_float"])
+    rep["timf3"] = relerr(dump["timf3_float"] * keep3, g["timf3_float"] * keep3)
+    assert rep["fft2"] < tol and rep["ps2"] < tol and rep["timf3"] < tol, rep
+    info = dump["spursearch_info"]
+    a_, b_ = int(info[2]), int(info[3])
+    assert np.array_equal(info, g["spursearch_info"])
+    sp_h, sp_r = dump["spursearch_spectrum"][a_:b_ + 1], g["spursearch_spectrum"][a_:b_ + 1]
+    assert np.array_equal(sp_h < 0, sp_r < 0), "wiped peaks differ"
+    rep["search_spectrum_err"] = float(np.max(np.abs(sp_h - sp_r)) / float(np.max(sp_r)))
+    assert rep["search_spectrum_err"] < tol, rep
+    assert np.array_equal(dump["final"], g["final"])
+    return rep
+
+
 def _run_2ch(harness, tmp_path, name, chain, extra):
     from refcases import twochan_case
     d, frames, lim = twochan_case(name, chain=chain)

@@ -31,7 +31,7 @@ def run(open_fn, name, g, batch=1, acquire=False):
     api.spur_config(4, speknum, g["spur_spectra"])
     first, last = (int(g["spursearch_info"][2]), int(g["spursearch_info"][3])) if "spursearch_info" in g else (0, (1 << cfg.fft2_n) - 1)
     api.spur_search_config(first, last)                      # the search for further spurs runs beside the tracking (fft2.c:673-699)
-    trace, nfft2, handed = [], 0, False
+    trace, nfft2, handed, unremoved = [], 0, False, None
     if not d["second_fft"]:
         return run_fft1(api, cfg, d, sp, g, acquire, first, last)
     for b in range(d["nblk"]):
@@ -45,23 +45,30 @@ def run(open_fn, name, g, batch=1, acquire=False):
             if not handed:
                 kb = 1
             api.make_fft2(kb)
-            api.fft2_mix1_fixed(kb)
             nfft2 += kb
             k -= kb
-            if handed:
-                s = api.spur_get()[0]
-                trace.append([s.spur_location, s.spur_flag, s.spur_freq, s.spur_d0pha, s.spur_d1pha, s.spur_d2pha, s.spur_ampl, s.spur_noise, s.spur_avgd2, nfft2 - 1])
-            elif nfft2 == start and acquire:
+            was_handed = handed
+            # acquisition behind the transform and ahead of mix1, where second_fft / spur_removal run it (wcw.c:288-303, 204-247): the lock takes
+            # the carrier out of the spur_speknum transforms it was closed on as well (initial_remove_spur, spursub.c:309, 346)
+            if not handed and nfft2 == start and acquire:
                 assert api.spur_acquire(sp["spur_pnt"]), "no lock"
                 handed = True
                 acq = api.spur_get()[0]
-            elif nfft2 == start:                                  # the reference's acquisition result, handed over by the control plane
+            elif not handed and nfft2 == start:                   # the reference's acquisition result, handed over by the control plane
                 q = LrhSpur(int(st[0]), int(st[1]), *[float(x) for x in st[2:9]])
                 maxn = cfg.max_fft2n
                 api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
                 handed = True
+                # (a hand-over does not rewrite the ring: the rows initial_remove_spur touched and what mix1 makes of the newest of them differ)
+                unremoved = dict(rows=[(api.p.fft2_na - 1 - m) % maxn for m in range(speknum)], timf3=(api.p.timf3_pa,))
+            api.fft2_mix1_fixed(kb)
+            if handed and not was_handed and not acquire:
+                unremoved["timf3"] += (api.p.timf3_pa,)
+            if was_handed:
+                s = api.spur_get()[0]
+                trace.append([s.spur_location, s.spur_flag, s.spur_freq, s.spur_d0pha, s.spur_d1pha, s.spur_d2pha, s.spur_ampl, s.spur_noise, s.spur_avgd2, nfft2 - 1])
     ss = api.spur_search_get()
-    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=(acq if acquire else None), trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
+    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=(acq if acquire else None), unremoved=unremoved, trace=np.array(trace, np.float64), fft2=api.export(abi.RING_FFT2_FLOAT), timf3=api.export(abi.RING_TIMF3_FLOAT),
                 ps2=api.export(abi.RING_FFT2_POWERSUM))
 
 
@@ -155,12 +162,21 @@ def compare(out, g, tol, batch=1):
     def rel(a, b):
         a, b = a.astype(np.float64), b.astype(np.float64)
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-    rep["fft2"], rep["ps2"], rep["timf3"] = rel(out["fft2"], g["fft2_float"]), rel(out["ps2"], g["fft2_powersum_float"]), rel(out["timf3"], g["timf3_float"])
+    h2, r2, h3, r3 = out["fft2"], g["fft2_float"], out["timf3"], g["timf3_float"]
+    if out.get("unremoved"):                                    # handed over, not acquired: see run()
+        n2_, u = 2 << out["cfg"].fft2_n, out["unremoved"]
+        h2, r2, h3, r3 = h2.copy(), r2.copy(), h3.copy(), r3.copy()
+        for row in u["rows"]:
+            h2[row * n2_:(row + 1) * n2_] = 0; r2[row * n2_:(row + 1) * n2_] = 0
+        a, b = u["timf3"]
+        idx = (a + np.arange(2 * ((b - a) % h3.size))) % h3.size   # (+ the half the next call overlaps onto it)
+        h3[idx] = 0; r3[idx] = 0
+    rep["fft2"], rep["ps2"], rep["timf3"] = rel(h2, r2), rel(out["ps2"], g["fft2_powersum_float"]), rel(h3, r3)
     # the bins of the spur itself in the newest transforms: what is left after the subtraction, against the reference's residual
     cfg = out["cfg"]
     n2 = 1 << cfg.fft2_n
     loc = int(ref[-1, 0])
-    f_h, f_r = out["fft2"].reshape(cfg.max_fft2n, n2, 2), g["fft2_float"].reshape(cfg.max_fft2n, n2, 2)
+    f_h, f_r = h2.reshape(cfg.max_fft2n, n2, 2), r2.reshape(cfg.max_fft2n, n2, 2)
     res_h, res_r = f_h[:, loc:loc + 7].astype(np.float64), f_r[:, loc:loc + 7].astype(np.float64)
     rep["residual_vs_carrier"] = float(np.linalg.norm(res_r) / (np.sqrt(cfg.max_fft2n) * abs(ref[-1, 6])))
     rep["residual_err_vs_carrier"] = float(np.linalg.norm(res_h - res_r) / (np.sqrt(cfg.max_fft2n) * abs(ref[-1, 6])))

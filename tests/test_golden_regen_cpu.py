@@ -33,8 +33,8 @@ def test_generator_reproduces_the_committed_goldens(script, tmp_path):
 def test_every_committed_golden_has_a_generator(tmp_path):
     """no orphan fixtures: each .npz under tests/golden/ is written by one of the scripts above (names from tests/refcases.py)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from refcases import CASES, CLEVER, CLEVER2, SELLIM, SPUR, TWOCHAN
-    names = set(CASES) | set(CLEVER) | set(CLEVER2) | set(SELLIM) | set(SPUR) | set(TWOCHAN) | {"rawdat_18bit", "filehdr"}
+    from refcases import CASES, CLEVER, CLEVER2, SELLIM, SPUR, SPUR_CLICKS, TWOCHAN
+    names = set(CASES) | set(CLEVER) | set(CLEVER2) | set(SELLIM) | set(SPUR) | set(SPUR_CLICKS) | set(TWOCHAN) | {"rawdat_18bit", "filehdr"}
     names |= {n + "_chain" for n, t in TWOCHAN.items() if "chain" in t}
     have = {f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz")}
     assert have == names, sorted(have ^ names)

@@ -81,6 +81,14 @@ def test_spur_removal_through_the_acquisition_hooks_on_the_device(harness, tmp_p
     print(name, shimlib.check_spur_case(harness, tmp_path, name))
 
 
+@pytest.mark.parametrize("name", ["spur_n10_n12_clicks", "spur_n10_n12_clicks_strong"])
+def test_linrads_own_spur_control_plane_over_the_glue_on_the_device(harness, tmp_path, name):
+    """init_spur_elimination (spursub.c:181-343) as a whole over liblinrad_hip.so: the operator's clicks -> peak search in the search spectrum the
+    device keeps -> lrh_spur_acquire (with initial_remove_spur) -> the weaker of a close pair dropped (the last of the list by counting
+    no_of_spurs down only: hip_spur_resync; the first through remove_spur) -> swap_spurs; three spurs' loop state after every transform"""
+    print(name, shimlib.check_spur_clicks_case(harness, tmp_path, name))
+
+
 @pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"])
 def test_two_rf_channels_as_two_contexts_on_one_gpu(harness, tmp_path, name):
     """ui.rx_rf_channels = 2 (fft1.c:3686-3900, 3874-4080; blank1.c:1236-1300; fft2.c:1622-1815): one context per channel behind the same

@@ -73,6 +73,13 @@ def test_spur_removal_is_served_through_the_acquisition_hooks(harness, tmp_path,
     print(name, shimlib.check_spur_case(harness, tmp_path, name))
 
 
+@pytest.mark.parametrize("name", ["spur_n10_n12_clicks", "spur_n10_n12_clicks_strong"])
+def test_linrads_own_spur_control_plane_over_the_glue(harness, tmp_path, name):
+    """init_spur_elimination (spursub.c:181-343) as a whole: clicks, the search spectrum, acquisition, initial_remove_spur, the weaker of a
+    close pair dropped (the last of the list by count only; another through remove_spur), swap_spurs"""
+    print(name, shimlib.check_spur_clicks_case(harness, tmp_path, name))
+
+
 @pytest.mark.parametrize("name", ["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"])
 def test_two_rf_channels_are_served_as_two_contexts(harness, tmp_path, name):
     print(name, shimlib.check_twochan_case(harness, tmp_path, name))
