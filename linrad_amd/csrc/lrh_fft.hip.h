@@ -111,6 +111,15 @@ __host__ __device__ constexpr float lrh_cos32(int e)
   return e <= 8 ? q[e] : (e <= 16 ? -q[16 - e] : (e <= 24 ? -q[e - 16] : q[32 - e]));
 }
 __host__ __device__ constexpr float lrh_sin32(int e) { return lrh_cos32(e - 8); }
+// exp(2 pi j e / 64), 0 <= e < 32 (k_fft1v<REAL>: the split's twiddle)
+__host__ __device__ constexpr float lrh_cos64(int e)
+{
+  constexpr float q[17] = {1.f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f, 0.92387953251128675613f, 0.88192126434835502971f,
+                           0.83146961230254523708f, 0.77301045336273696081f, 0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f,
+                           0.47139673682599764856f, 0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f, 0.f};
+  return e <= 16 ? q[e] : -q[32 - e];
+}
+__host__ __device__ constexpr float lrh_sin64(int e) { return e <= 16 ? lrh_cos64(16 - e) : lrh_cos64(e - 16); }
 
 // R-point DFT of u[0..R) in place, natural order
 template <int DIR, int R> struct Dft;

@@ -107,6 +107,7 @@ struct lrh_ctx {
   // the same for fft1_b itself: inside lrh_wideband_dsp (fft1_size 16384, sin^2 window, int16 I/Q) its launch is parked and make_timf2
   // runs forward transform, sums and weak stream as one kernel (k_fft1w); any other reader of fft1_float issues the parked launch first
   bool f1_defer = false, f1_have = false, fuse_fft1 = true, fuse_fft1_forced = false; Fft1Args f1_args; int f1_batch = 0;   // fuse_fft1_forced: LRH_FUSE_FFT1=1 given (tests: the fused kernel whatever the batch)
+  bool fuse_real = true;             // LRH_FUSE_REAL=0: real input through k_fft1<REAL> + k_realsplit + k_timf2 as before round 5
   bool fuse_v = true;                // LRH_FFT1V=0: k_fft1w (round 3) instead of k_fft1v where both exist (fft1_size 16384, int16)
   float2 *d_filtercorr_v = nullptr;  // the filter correction in k_fft1v's thread order (upload_filtercorr)
   bool f1_is_big = false; Fft1BigArgs f1_big;   // fft1_size 32768: the column step has run, the row step is what is parked (k_fft1r_t2c takes it)
@@ -586,6 +587,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (const char *e3 = getenv("LRH_EARLY_UPLOAD")) c->early_upload = atoi(e3) != 0;
   if (const char *e4 = getenv("LRH_FUSE_SUMSQ")) c->fuse_sumsq = atoi(e4) != 0;
   if (const char *e9v = getenv("LRH_FFT1V")) c->fuse_v = atoi(e9v) != 0;
+  if (const char *e9r = getenv("LRH_FUSE_REAL")) c->fuse_real = atoi(e9r) != 0;
   if (const char *e9s = getenv("LRH_FFT2_SPAN")) c->fft2_span = atoi(e9s);
   if (const char *e9 = getenv("LRH_FUSE_FFT1")) { c->fuse_fft1 = atoi(e9) != 0; c->fuse_fft1_forced = c->fuse_fft1; }   // 0: k_fft1 + k_timf2 also where k_fft1w would run; 1: k_fft1w also for rounds of a few blocks
   c->sums_on_main = cfg->fft2_n <= 14;
@@ -1525,7 +1527,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     a.stamps = c->d_stamps;
   }
   // k_fft1w: fft1_size 16384, int16; k_fft1v: 4096 / 8192 / 16384, int16 or int32
-  if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && !a.real && !a.shift_i && !a.shift_q &&
+  if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && (!a.real || (c->fuse_v && c->fuse_real && c->cfg.fft1_direction > 0)) && !a.shift_i && !a.shift_q &&
       !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
     if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
     c->f1_cont = c->f1_end_valid && a.p0_first == c->f1_end;
@@ -1747,7 +1749,8 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
       w.stamps = c->d_stamps;
     }
     { ProfScope ps(c, "fft1w");
-      if (c->fuse_v) HIPCHK(c, launch_fft1v(c->cfg.fft1_n, f.dword != 0, w, c->cur, &c->ss_run));
+      w.real_peak = f.real ? c->h_window1_ref[c->N1] : 0.f;
+      if (c->fuse_v) HIPCHK(c, launch_fft1v(c->cfg.fft1_n, f.dword != 0, f.real != 0, w, c->cur, &c->ss_run));
       else HIPCHK(c, launch_fft1w(w, c->cur, &c->ss_run)); }
     if (v_stamps) {
       static int printed = 0;

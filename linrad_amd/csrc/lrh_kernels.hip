@@ -897,12 +897,15 @@ __device__ __forceinline__ float2 tw_pow(const float2 *wb, const float2 *wa, int
 // EXP (diagnostics, LRH_FFT1V_EXP): bit 0 no workgroup barriers (timing experiment, wrong results), bit 1 shader-clock stamps at the phase
 // boundaries (printed by lrh_make_timf2)
 // KEEP: every bin of the spectrum goes to the fft1 ring (a.keep_spec), through one more LDS exchange; else the strong bins only
-template <int LOG2N, bool DW, bool KEEP, int EXP = 0>
+// REAL: real samples (fft1 version 2, fft1_reherm_dit_one, fft1_re.c:32-131): the pair (x[2n], x[2n+1]) is one complex point, each component with
+// its own window value, nothing negated; the N-point transform S is followed by one more exchange -- bin k needs S[N-k], which another thread holds --
+// and the even / odd split of k_realsplit; array index = transform index (no N/2 shift).  fft1_direction > 0 only.
+template <int LOG2N, bool DW, bool KEEP, int EXP = 0, bool REAL = false>
 __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
 {
   using G = Fft1vGeom<LOG2N>;
   using Raw = typename std::conditional<DW, int2, short2>::type;
-  constexpr int P = 32, N = G::N, T = G::T, R2 = G::R2, KB = G::KB, NKB = G::NKB, HP = P / 2;
+  constexpr int P = 32, N = G::N, T = G::T, R2 = G::R2, KB = G::KB, NKB = G::NKB, HP = P / 2, B2_ = G::B2;
   using F32 = SDft<+1, 32>; using F2 = SDft<+1, R2>; using B32 = SDft<-1, 32>; using B2 = SDft<-1, R2>;
   __shared__ float2 lds[G::LDS_CELLS];
   const int tid0 = threadIdx.x;
@@ -951,11 +954,20 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
   // c sin^2(pi (tid + T r) / N) = c/2 (1 - cos(2 pi tid / N + 2 pi r / 32)): two fused multiply-adds on one complex number per thread,
   // e^(2 pi j tid / N), and the 32nd roots of unity -- no table loads, no 32 registers held over the run.  c is the table's own peak
   // value (make_window's normalisation, fft0.c:812-921); the values equal the table's to float32 rounding.
-  const float whalf = 0.5f * a.window[N / 2];
+  const float whalf = REAL ? 0.5f * a.real_peak : 0.5f * a.window[N / 2];
   auto window_at = [&](float2 wrot, int r) {             // wrot = (cos, sin)(2 pi tid / N): the first entry of the LDS table; compile-time r
     const float cr = lrh_cos32(r), sr = lrh_sin32(r);
     return whalf - whalf * (wrot.x * cr - wrot.y * sr);
   };
+  // REAL: sample i of the 2N takes the half window's value at min(i, 2N - 1 - i) (fft1_re.c:47-57), c sin^2(pi i' / 2N): for the point
+  // n = tid + T r the two components sit at the angles theta + 2 pi r / 32 with theta = 2 pi tid / N (x[2n]) and theta + pi / N (x[2n+1]) in the
+  // first half, theta + pi / N and theta + 2 pi / N in the second: three rotations per thread, kept over the run
+  // (theta + pi / N and theta + 2 pi / N: the table's e^(j theta) turned by constants -- nothing kept over the run)
+  const float cpn1 = __builtin_cosf(3.14159265358979323846f / N), spn1 = __builtin_sinf(3.14159265358979323846f / N);
+  const float cpn2 = __builtin_cosf(2 * 3.14159265358979323846f / N), spn2 = __builtin_sinf(2 * 3.14159265358979323846f / N);
+  // ... and e^(-j pi kk / N), the thread's part of the split's twiddle e^(-j pi k / N), k = kk + T k3
+  float2 wsplit = make_float2(1.f, 0.f);
+  if constexpr (REAL) { float sn, cs; sincospif((float)kk_of(tid0) / (float)N, &sn, &cs); wsplit = make_float2(cs, sn); }
   (void)win;
   // LDS byte addresses of the two kinds of exchange (see the header comment).  cross: cell (q2 32 + q) 32 + l for the element that sits in
   // half-wave q2, register q, lane l before the exchange; wave: cell 32 l + (q ^ l) of the half-wave's 1024
@@ -1009,7 +1021,13 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
     { int t_ = tid; asm volatile("" : "+v"(t_));
       const float2 wrot = lds[G::TN + (t_ ^ (t_ >> 5))];
 #pragma unroll
-      for (int r = 0; r < P; r++) { const float w = window_at(wrot, r); x[r] = lrh_v2f{(float)raw[r].x * w, -((float)raw[r].y * w)}; } }   // Q negated (fft1.c:432-447)
+      for (int r = 0; r < P; r++) {
+        if constexpr (REAL) {
+          const float2 wr1 = make_float2(wrot.x * cpn1 - wrot.y * spn1, wrot.y * cpn1 + wrot.x * spn1), wr2 = make_float2(wrot.x * cpn2 - wrot.y * spn2, wrot.y * cpn2 + wrot.x * spn2);
+          const float w0 = window_at(r < HP ? wrot : wr1, r), w1 = window_at(r < HP ? wr1 : wr2, r);
+          x[r] = lrh_v2f{(float)raw[r].x * w0, (float)raw[r].y * w1};
+        } else { const float w = window_at(wrot, r); x[r] = lrh_v2f{(float)raw[r].x * w, -((float)raw[r].y * w)}; }   // Q negated (fft1.c:432-447)
+      } }
     after_load();
     stamp();
     F32::a(x);
@@ -1057,11 +1075,54 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
         else if (n3 < 16) x[n3] = cmul_v(v, to_v(tw_pow(wb, wa, n3)));
         else x[n3] = cmul_v(v, cmul_v(to_v(w16), to_v(tw_pow(wb, wa, n3 - 16))));
       } }
-    early();
+    if constexpr (!REAL) early();
     stamp();
     F32::a(x);
     stamp();
-    second32(F32(), x, f, half_way);
+    if constexpr (!REAL) second32(F32(), x, f, half_way);
+    else {
+      // S[kk + T k3] is in the registers; bin k wants S[N - k] as well: through the half-wave's own cells (32 k3 + lane: nobody else
+      // writes there), read back from the cells of the thread that holds kk' = (T - kk) mod T -- a lane permutation of another half-wave,
+      // so both directions touch 32 consecutive cells per half-wave
+      lrh_v2f z[P];                                      // the thread's own S[kk + T k3] stays in the registers (x is dead once the second stage has run)
+      { int t_ = tid; asm volatile("" : "+v"(t_));
+        const int wr = 8 * ((t_ >> 5) * 1024 + (t_ & 31));
+        second32(F32(), x, [&](int k3, lrh_v2f v) { z[k3] = v; lds_put(lds, wr + 256 * k3, to_f2(v)); }, []() {}); }
+      early();                                           // (the filter table's first half: asked for here, where x is gone)
+      barrier();                                         // B_f: every half-wave's S is in its cells
+      { int t_ = tid; asm volatile("" : "+v"(t_));
+        const int kk = kk_of(t_);
+        const int km = (T - kk) & (T - 1);               // kk' of the mirror bin; its owner: kk = hw | (lam & (NKB-1)) R2 ... inverted below
+        const int ot = (km & (R2 - 1)) * 32 + ((km >> B2_) & (NKB - 1)) + NKB * (km >> 5);
+        const int mir = 8 * ((ot >> 5) * 1024 + (ot & 31));
+        const bool kk0 = kk == 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+          const int k3 = F32::out(i / F32::ND, i % F32::ND);    // the order the complex form hands them out in (the filter table's loads follow it)
+          const int m3 = 31 - k3, m0 = (32 - k3) & 31;              // k3 of bin N - k: 31 - k3 (kk != 0), (32 - k3) mod 32 (kk == 0)
+          if (i == P / 2) half_way();                      // (the even pairs of the filter table are used up by now)
+          const float2 sa = to_f2(z[k3]);
+          const float2 sb = lds_get(lds, kk0 ? mir + 256 * m0 : mir + 256 * m3);
+          // k_realsplit's arithmetic: k < N/2: (sa, sb) = (S[k], S[N-k]) -> Z_k; k > N/2: the pair the other way round, angle pi (N-k) / N -> Z_(N-k') = conj(E - t)
+          const float cr = lrh_cos64(k3), sr = lrh_sin64(k3);        // e^(j pi k3 / 32)
+          const float cs = wsplit.x * cr - wsplit.y * sr, sn = wsplit.y * cr + wsplit.x * sr;   // (cos, sin)(pi k / N)
+          float2 o;
+          if (k3 < HP) {
+            const float ex = 0.5f * (sb.x + sa.x), ey = 0.5f * (sb.y - sa.y), dx = 0.5f * (sb.x - sa.x), dy = 0.5f * (sb.y + sa.y);
+            const float ox = dy, oy = -dx;
+            const float tx = cs * ox + sn * oy, ty = cs * oy - sn * ox;
+            o = make_float2(ey + ty, ex + tx);             // (Im Z_k, Re Z_k)
+            if (k3 == 0 && kk0) o = make_float2(sa.x - sa.y, sa.x + sa.y);    // (Z_N, Z_0)
+          } else {
+            const float ex = 0.5f * (sa.x + sb.x), ey = 0.5f * (sa.y - sb.y), dx = 0.5f * (sa.x - sb.x), dy = 0.5f * (sa.y + sb.y);
+            const float ox = dy, oy = -dx;
+            const float tx = -cs * ox + sn * oy, ty = -cs * oy - sn * ox;      // angle pi - pi k / N
+            o = make_float2(-(ey - ty), ex - tx);          // (Im, Re) of conj(E - t)
+          }
+          f(k3, to_v(o));
+        } }
+      barrier();                                         // B_g: the cells go back to their half-waves (back transform's first exchange)
+    }
     stamp();
   };
   // back transform of the spectrum c[j] (bin kk + T j); hands out f(r, value): sample tid + T r of the transform (r = 0 .. 31)
@@ -1144,7 +1205,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
     fetch(r0 - 1, tid0);
     lrh_v2f c[P];
     forward(tid0, []() {}, []() {}, []() {}, [&](int k3, lrh_v2f v) {
-      const int j = k3 ^ 16;
+      const int j = REAL ? k3 : k3 ^ 16;
       const bool weak = r0 > 0 ? weak_bit(wk_cur, j) : weak_bit(wk_first, j);   // routed with the table in force for that transform
       c[j] = weak ? cmul_v(v, to_v(gld<float2>(a.filtercorr_v, 8u * (unsigned int)(2 * (tid0 + (j >> 1) * T) + (j & 1))))) : lrh_v2f{0.f, 0.f};
     });
@@ -1173,7 +1234,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
 #pragma unroll
       for (int jp = 1; jp < P / 2; jp += 2) fc[jp] = gld<float4>(a.filtercorr_v, 16u * (unsigned int)(tid + jp * T));
     }, [&](int k3, lrh_v2f xv) {
-      const int j = k3 ^ 16;                             // fft1_float bin kk + T j (DC at N/2)
+      const int j = REAL ? k3 : k3 ^ 16;                 // fft1_float bin kk + T j (DC at N/2; real input: natural order)
       const lrh_v2f v = cmul_v(xv, (j & 1) ? lrh_v2f{fc[j >> 1].z, fc[j >> 1].w} : lrh_v2f{fc[j >> 1].x, fc[j >> 1].y});
       // fft1_c: sum |X|^2 over the averaging group (fft1.c:4115-4171), order as k_timf2<.., SS>; the contraction written out, so that every
       // instantiation of this kernel rounds alike (the full and the sparse ring must not differ downstream)
@@ -2897,7 +2958,7 @@ hipError_t launch_fft1w(const Fft1wArgs &a0, hipStream_t st, int *run)
   return hipGetLastError();
 }
 // k_fft1v: fft1_size 4096 / 8192 / 16384, int16 or int32 I/Q
-hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a0, hipStream_t st, int *run)
+hipError_t launch_fft1v(int log2n, bool dword, bool real, const Fft1wArgs &a0, hipStream_t st, int *run)
 {
   Fft1wArgs a = a0;
   const int lds = 8 * (log2n == 14 ? Fft1vGeom<14>::LDS_CELLS : (log2n == 13 ? Fft1vGeom<13>::LDS_CELLS : Fft1vGeom<12>::LDS_CELLS));
@@ -2912,10 +2973,28 @@ hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a0, hipStream_t 
   static const int exp_ = getenv("LRH_FFT1V_EXP") ? atoi(getenv("LRH_FFT1V_EXP")) : 0;
   static const int stagger_ = getenv("LRH_V_STAGGER") ? atoi(getenv("LRH_V_STAGGER")) : 0;
   a.stagger = a.run >= 4 ? stagger_ : 0;
-  if (exp_ && log2n == 14 && !dword) {
+  if (exp_ && log2n == 14 && !dword && !real) {
     if (exp_ == 1) hipLaunchKernelGGL((k_fft1v<14, false, false, 1>), g, t, 0, st, a);
     else if (a.keep_spec) hipLaunchKernelGGL((k_fft1v<14, false, true, 2>), g, t, 0, st, a);
     else hipLaunchKernelGGL((k_fft1v<14, false, false, 2>), g, t, 0, st, a);
+    return hipGetLastError();
+  }
+  if (real) {
+    switch (log2n * 4 + (dword ? 2 : 0) + (a.keep_spec ? 1 : 0)) {
+      case 56: hipLaunchKernelGGL((k_fft1v<14, false, false, 0, true>), g, t, 0, st, a); break;
+      case 57: hipLaunchKernelGGL((k_fft1v<14, false, true, 0, true>), g, t, 0, st, a); break;
+      case 58: hipLaunchKernelGGL((k_fft1v<14, true, false, 0, true>), g, t, 0, st, a); break;
+      case 59: hipLaunchKernelGGL((k_fft1v<14, true, true, 0, true>), g, t, 0, st, a); break;
+      case 52: hipLaunchKernelGGL((k_fft1v<13, false, false, 0, true>), g, t, 0, st, a); break;
+      case 53: hipLaunchKernelGGL((k_fft1v<13, false, true, 0, true>), g, t, 0, st, a); break;
+      case 54: hipLaunchKernelGGL((k_fft1v<13, true, false, 0, true>), g, t, 0, st, a); break;
+      case 55: hipLaunchKernelGGL((k_fft1v<13, true, true, 0, true>), g, t, 0, st, a); break;
+      case 48: hipLaunchKernelGGL((k_fft1v<12, false, false, 0, true>), g, t, 0, st, a); break;
+      case 49: hipLaunchKernelGGL((k_fft1v<12, false, true, 0, true>), g, t, 0, st, a); break;
+      case 50: hipLaunchKernelGGL((k_fft1v<12, true, false, 0, true>), g, t, 0, st, a); break;
+      case 51: hipLaunchKernelGGL((k_fft1v<12, true, true, 0, true>), g, t, 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
   }
   switch (log2n * 4 + (dword ? 2 : 0) + (a.keep_spec ? 1 : 0)) {

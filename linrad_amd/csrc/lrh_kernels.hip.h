@@ -94,9 +94,10 @@ struct Fft1wArgs {
   unsigned long long *stamps;                   // diagnostics (LRH_FFT1V_EXP=2): 2 x 32 shader-clock stamps
   int stagger;                                  // start delay per workgroup, (blockIdx & 15) x stagger x 2048 cycles (set by launch_fft1v)
   int spare_cus;
+  float real_peak;                                // k_fft1v<REAL>: the half window's peak value h[N] (make_window mode 2; the table on the device ends at h[N-1])
 };
 hipError_t launch_fft1w(const Fft1wArgs &a, hipStream_t st, int *run);
-hipError_t launch_fft1v(int log2n, bool dword, const Fft1wArgs &a, hipStream_t st, int *run);
+hipError_t launch_fft1v(int log2n, bool dword, bool real, const Fft1wArgs &a, hipStream_t st, int *run);
 hipError_t launch_timf2_strong(int log2n, const Timf2Args &a, int batch, hipStream_t st);
 constexpr int LRH_SD_KMAX = 128;           // strong bins k_timf2_sd (lrh_timf2_sd.hip) takes; more: the transform kernel
 hipError_t launch_timf2_sd(int log2n, const Timf2Args &a, hipStream_t st);   // a.batch set; returns at once on the device when too many bins are strong

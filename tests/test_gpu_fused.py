@@ -234,7 +234,7 @@ def test_rounds_of_a_few_blocks_between_fused_rounds():
     assert not np.array_equal(a["timf2"], b["timf2"])      # (the fused kernel did run: its last-pass twiddles round differently)
 
 
-def _run_n(env, fft1_n, fft2_n, dword, fn=None, nblk=96, batch=32, sparse=0):
+def _run_n(env, fft1_n, fft2_n, dword, fn=None, nblk=96, batch=32, sparse=0, real=0):
     """fft1_size 2^fft1_n through lrh_wideband_dsp in rounds of `batch`; int16 or int32 samples (the int16 signal left-justified in 32 bits,
     like hardware that delivers 24-bit words does, fft1.c:4656-4663)"""
     from linrad_amd.lib import open_hip, synth_defaults, synth_iq
@@ -245,6 +245,7 @@ def _run_n(env, fft1_n, fft2_n, dword, fn=None, nblk=96, batch=32, sparse=0):
         cfg.fft1_float_sparse = sparse
         cfg.stupid_bln_mode = 0
         cfg.timf1_dword_input = dword
+        cfg.timf1_real_input = real
         if dword:
             cfg.timf1_bytes *= 2
         rx = (fn or open_hip)(cfg)
@@ -254,6 +255,14 @@ def _run_n(env, fft1_n, fft2_n, dword, fn=None, nblk=96, batch=32, sparse=0):
     n1 = 1 << fft1_n
     s = synth_defaults(n1, 0)
     iq = synth_iq(s, 0, cfg.timf1_bytes // (8 if dword else 4))
+    if real:                                               # real samples: noise + cosines at bins of the half spectrum 0 .. fs/2 (the ring holds 2 reals where it held I and Q)
+        n = iq.size
+        t = np.arange(n, dtype=np.float64)
+        rng = np.random.default_rng(11)
+        x = rng.normal(0, 40.0, n)
+        for k, a_ in ((0.061 * n1, 5000.0), (0.31 * n1 + 0.45, 900.0), (0.5 * n1 + 3.25, 2500.0), (0.93 * n1 + 0.5, 300.0)):
+            x += a_ * np.cos(2 * np.pi * k * t / (2 * n1) + rng.uniform(0, 6.28))
+        iq = np.clip(np.round(x), -32767, 32767).astype(np.int16)
     rx.timf1_write((iq.astype(np.int32) << 16) if dword else iq)
     rx.set_liminfo(strong_liminfo(s, fft1_n))
     rx.set_mix1_selfreq(0.31 * (1 << fft2_n) + 0.3)
@@ -291,6 +300,31 @@ def test_fused_kernel_at_other_sizes_and_int32_matches_the_two_kernel_path_and_t
     for k, (e2, eo) in rep.items():
         assert e2 < _tol(k) and eo < 1e-5, (k, e2, eo)
     sp = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword, sparse=1)
+    for _, k in RINGS[1:]:
+        assert np.array_equal(a[k], sp[k]), k
+
+
+@pytest.mark.parametrize("fft1_n,fft2_n,dword", [(14, 12, 0), (13, 12, 1), (12, 14, 0)])
+def test_fused_kernel_with_real_samples_matches_the_two_kernel_path_and_the_oracle(fft1_n, fft2_n, dword):
+    """real input (fft1 version 2, fft1_reherm_dit_one, fft1_re.c:32-131) inside the fused kernel: k_fft1v<.., REAL> = the N-point transform of the sample
+    pairs + one more exchange for S[N-k] + k_realsplit's even / odd split, then the sums, the weak stream and the overlap as for I/Q.  Against
+    k_fft1<REAL> + k_realsplit + k_timf2<.., SS> (LRH_FUSE_REAL=0) ring by ring, against the oracle at 1e-5, sparse ring bit-identical downstream"""
+    from oracle_binding import open_oracle
+    a = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword, real=1)
+    b = _run_n({"LRH_FUSE_FFT1": "1", "LRH_FUSE_REAL": "0"}, fft1_n, fft2_n, dword, real=1)
+    o = _run_n({}, fft1_n, fft2_n, dword, fn=open_oracle, real=1)
+    assert a["launches"]["fft1w"] == 3 and a["launches"]["fft1"] == 0 and b["launches"]["fft1w"] == 0 and b["launches"]["fft1"] > 0, (a["launches"], b["launches"])
+    assert a["p"] == b["p"] == o["p"]
+    n1 = 1 << fft1_n
+    keep = np.ones(a["timf2"].size, bool)
+    keep[(a["p"]["timf2_pa"] + np.arange(4 * (n1 // 2))) % keep.size] = False
+    rep = {k: (_rel(a[k], b[k]), _rel(a[k] * (keep if k == "timf2" else 1), o[k] * (keep if k == "timf2" else 1))) for _, k in RINGS}
+    print(fft1_n, dword, rep)
+    assert np.count_nonzero(a["timf3"]) > 100 and np.count_nonzero(a["sumsq"]) > n1
+    for k, (e2, eo) in rep.items():
+        assert e2 < _tol(k) and eo < 1e-5, (k, e2, eo)
+    sp = _run_n({"LRH_FUSE_FFT1": "1"}, fft1_n, fft2_n, dword, sparse=1, real=1)
+    assert sp["launches"]["fft1w"] == 3
     for _, k in RINGS[1:]:
         assert np.array_equal(a[k], sp[k]), k
 
