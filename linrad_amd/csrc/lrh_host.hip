@@ -1527,7 +1527,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
     a.stamps = c->d_stamps;
   }
   // k_fft1w: fft1_size 16384, int16; k_fft1v: 4096 / 8192 / 16384, int16 or int32
-  if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && (!a.real || (c->fuse_v && c->fuse_real && c->cfg.fft1_direction > 0)) && !a.shift_i && !a.shift_q &&
+  if (c->f1_defer && handle == 0 && (c->fuse_v ? (c->cfg.fft1_n >= 12 && c->cfg.fft1_n <= 14) : (c->cfg.fft1_n == 14 && !a.dword)) && (!a.real || (c->fuse_v && c->fuse_real && c->cfg.fft1_direction > 0 && a.chan_count == 1)) && !a.shift_i && !a.shift_q &&
       !c->d_foldcorr && a.direction > 0 && !c->dbg_stamp) {
     if (c->f1_have) { const int rc_ = launch_parked_fft1(c); if (rc_) return rc_; }
     c->f1_cont = c->f1_end_valid && a.p0_first == c->f1_end;

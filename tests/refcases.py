@@ -337,7 +337,7 @@ SELLIM["sellim2_n9_n11_pars"] = dict(base="n9_n11_shift", nblk=160, maxlevel=400
 
 # the second limiter's older variants (hg.sellim_par1 = 0: median of all fft2 bins, sellim.c:170-281; 1: noise floor per weak-signal
 # region, sellim.c:283-533); the third case puts more strong carriers into the band than there is room for regions (sellim.c:406-469)
-SELLIM["sellim2v0_n10_n12"] = dict(SELLIM["sellim2_n10_n12"], par1=0, ston_fft2=40.0)
+SELLIM["sellim2v0_n10_n12"] = dict(SELLIM["sellim2_n10_n12"], par1=0, ston_fft2=42.0)
 SELLIM["sellim2v1_n10_n12"] = dict(SELLIM["sellim2_n10_n12"], par1=1, ston_fft2=20.0)
 SELLIM["sellim2v1_n9_n11_many"] = dict(base="n9_n11_shift", nblk=160, maxlevel=1500, lim_groups=16, blocktime=0.002, ston_fft1=3.0, bw_fftxpts=24,
                                        sample_shift=0, keyed=(-77.0, 2500.0, 40, 90), sellim2=1, par1=1, ston_fft2=12.0, wf_avgnum=3,

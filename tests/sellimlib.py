@@ -27,7 +27,21 @@ def sellim_params(cfg, g):
                           **({"sellim_par1": int(g["sellim2_par1"][0])} if "sellim2_par1" in g else {}))
 
 
-def run(open_fn, name, g):
+def median_decision_margin(api, cfg, par):
+    """hg.sellim_par1 = 0 (sellim.c:171-268): a bin goes strong when one of its fft2 sub-bins has powersum * wg_waterf_yfac above
+    blanker_ston_fft2 * the median of all of them.  Returns (min over the bins of |value / threshold - 1|, the median) for the call about to
+    be made: a golden whose decisions sit within float32 noise of that threshold pins rounding, not the algorithm (the start-up
+    transient, where the sums are at the noise floor of an empty fft2 input and two float32 implementations differ by 4e-4, is where
+    it happens) -- tests/golden/make_golden_sellim.py refuses such a case"""
+    n1, n2 = 1 << cfg.fft1_n, 1 << cfg.fft2_n
+    ps = api.export(abi.RING_FFT2_POWERSUM)[:n2].astype(np.float32)
+    f = (ps.reshape(n1, n2 // n1) * api.get_table("wg_waterf_yfac", n1)[:, None].astype(np.float32)).reshape(-1)
+    t1 = np.float32(par.blanker_ston_fft2) * np.sort(f)[n2 // 2 - 1]
+    med = float(np.sort(f)[n2 // 2 - 1])
+    return (float(np.min(np.abs(f / t1 - 1))) if t1 > 0 else 1.0), med
+
+
+def run(open_fn, name, g, margins=None):
     d, _, iq = sellim_case(name)
     assert np.array_equal(iq, g["iq"])
     cfg = lrh_config(d, iq)
@@ -52,6 +66,8 @@ def run(open_fn, name, g):
             blks.append(b)
             amp.append(api.liminfo_amplitude_factor())
         if both and api.p.fft2_liminfo_cnt != cnt2:              # wcw.c:1129-1133
+            if margins is not None:
+                margins.append(median_decision_margin(api, cfg, par))
             api.fft2_update_liminfo(par)
             cnt2 = api.p.fft2_liminfo_cnt
             trace2.append(api.get_liminfo())
