@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-glue > $OUT/bench_stats.json 2> $OUT/stats.log
 python3 scripts/timeline.py $OUT/stats > $OUT/timeline.txt 2>&1
 echo "stats pass done: $(tail -c 300 $OUT/stats.log | tr '\n' ' ')"
 # The counter passes run the serial schedule: TCC counters are per device, so a side-stream kernel overlapping k_timf2 would be
