@@ -153,6 +153,10 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     tflips = np.nonzero((T_["pwr"] == 0) != (o["pwr"] == 0))[0]
     rep["truth_flips"] = int(len(tflips))
     assert len(tflips) <= 8
+    # whose decisions are the float64 build's?  (a flip is a sample within float32 rounding of the limit: the side that agrees with the truth made
+    # the decision exact arithmetic makes)
+    rep["hip_vs_truth_flips"] = int(np.count_nonzero((h["pwr"] == 0) != (T_["pwr"] == 0)))
+    assert rep["hip_vs_truth_flips"] <= max(len(tflips), 2), rep       # HIP departs from the truth no more often than the float32 oracle does
     flips = np.union1d(flips, tflips)
     keep = np.ones(len(o["pwr"]), bool)
     keep[flips] = False
