@@ -17,6 +17,7 @@
 
 #include "../../include/linrad_hip.h"
 #include "lrh_kernels.hip.h"
+#include "lrh_phase.h"
 
 namespace lrh {
 hipError_t launch_fft1(int log2n, const Fft1Args &a, int batch, hipStream_t st);
@@ -142,7 +143,7 @@ struct lrh_ctx {
   unsigned long long *d_stamps = nullptr;
   bool early_upload = true;          // LRH_EARLY_UPLOAD=0: phase tables in stream order even when the kernels are parked
   // one-round-late schedule kept across calls: the parked launches (blanker / fft2 + mix1 of the last round) of the previous call
-  std::vector<std::function<int(lrh_ctx *)>> pend_b, pend_t; bool pend = false, pend_tail_flushed = false; int pend_batch = 0, in_dsp = 0;
+  std::vector<std::function<int(lrh_ctx *)>> pend_b, pend_t; bool pend = false, pend_tail_flushed = false; int pend_batch = 0, in_dsp = 0; double host_cpu_ms_wait = 0;
   bool persist = true;               // LRH_PERSIST=0: every call drains its pipeline before it returns
   bool pipeline_forced = false;      // LRH_PIPELINE given: no automatic choice by batch size
   int pipeline = 2;                  // LRH_PIPELINE: 0 serial, 1 two streams, 2 two streams with blanker / fft2 / mix1 one round behind
@@ -233,7 +234,7 @@ struct lrh_ctx {
   // d_pack_cur itself and d_pack_prev holds nothing of interest.  (Before: one copy kernel per table, on the path to the next fft2.)
   bool pack_prev_stale = false;
   // pinned staging for mix1 phases
-  float *h_ph = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
+  float *h_ph = nullptr; void *h_ph_dev = nullptr; hipEvent_t ph_ev[LRH_NSTAGE]; int ph_next = 0; size_t ph_stride = 0;
   // mix1 scalars
   lrh_mix1_state ms;
   // masks
@@ -282,7 +283,17 @@ static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten 
 }
 #define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; } \
   if ((c) && ((c)->st_pending || (c)->nb_join_pending) && !(c)->in_dsp) join_side_tail(c)
-#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
+// LRH_HOSTPROF=1 (diagnostics): host time per call site inside lrh_wideband_dsp, printed by lrh_close
+struct HostProfSite { double ns = 0; long n = 0; };
+static bool g_hostprof = getenv("LRH_HOSTPROF") && atoi(getenv("LRH_HOSTPROF"));
+static std::map<std::string, HostProfSite> g_hostprof_sites;
+static thread_local int g_hostprof_depth = 0;
+struct HostProfTimer {
+  const char *what; std::chrono::steady_clock::time_point t0; bool on;
+  HostProfTimer(const char *w, bool active) : what(w), on(active && g_hostprof && g_hostprof_depth++ == 0) { if (on) t0 = std::chrono::steady_clock::now(); else if (active && g_hostprof) {} }
+  ~HostProfTimer() { if (on) { auto &s = g_hostprof_sites[std::string(what).substr(0, 48)]; s.ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); s.n++; g_hostprof_depth--; } }
+};
+#define HIPCHK(c, call) do { hipError_t e_; { HostProfTimer hp_(#call, (c) && (c)->in_dsp > 0); e_ = (call); if (!hp_.on && (c) && (c)->in_dsp > 0 && g_hostprof) g_hostprof_depth--; } if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, #call, e_); } while (0)
 
 // Device work of a stage function: run now, or (schedule 2 of lrh_wideband_dsp) keep for later.  `body` may use HIPCHK and
 // sees the context as `c`; everything else it touches is captured by value.
@@ -469,6 +480,14 @@ int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
 void lrh_close(lrh_ctx *c)
 {
   if (!c) return;
+  if (g_hostprof && !g_hostprof_sites.empty()) {
+    std::vector<std::pair<std::string, HostProfSite>> v(g_hostprof_sites.begin(), g_hostprof_sites.end());
+    std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.second.ns > b.second.ns; });
+    double tot = 0; long n = 0; for (auto &e : v) { tot += e.second.ns; n += e.second.n; }
+    fprintf(stderr, "LRH_HOSTPROF: %ld calls, %.3f ms inside HIP calls of lrh_wideband_dsp (%d calls of it, %.3f ms wall, %.3f ms cpu, of which %.3f ms in the staging wait, %.3f ms phase tables)\n", n, tot * 1e-6, c->host_n_dsp, c->host_ms_dsp, c->host_cpu_ms_dsp, c->host_cpu_ms_wait, c->host_ms_phases);
+    for (size_t i = 0; i < v.size() && i < 40; i++) fprintf(stderr, "  %-48s %7ld x %7.2f us = %8.3f ms\n", v[i].first.c_str(), v[i].second.n, v[i].second.ns * 1e-3 / v[i].second.n, v[i].second.ns * 1e-6);
+    g_hostprof_sites.clear();
+  }
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream_sel) { hipStreamSynchronize(c->stream_sel); hipStreamDestroy(c->stream_sel); }
@@ -708,6 +727,7 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
   if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
+  if (rc == LRH_OK && hipHostGetDevicePointer(&c->h_ph_dev, c->h_ph, 0) != hipSuccess) c->h_ph_dev = nullptr;
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
   if (rc == LRH_OK) {
     hipStreamSynchronize(c->stream);
@@ -2366,6 +2386,8 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     const int slot = c->ph_next; c->ph_next = (c->ph_next + 1) % LRH_NSTAGE;
     if (c->ph_pending[slot]) return fail(c, LRH_ESTATE, "mix1 staging ring exhausted by deferred work");
     { const auto w0 = std::chrono::steady_clock::now();
+      timespec tc0; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &tc0);
+      struct WaitCpu { lrh_ctx *c; timespec t0; ~WaitCpu() { timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1); c->host_cpu_ms_wait += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6; } } wait_cpu{c, tc0};
       // the host runs up to LRH_NSTAGE rounds ahead and then waits here for most of a round: asleep, not spinning inside
       // hipEventSynchronize (which burnt a whole core: thread CPU time = wall time of the call)
       // (small rounds finish within tens of microseconds: poll that long first, a sleep would cost the round its own length)
@@ -2373,10 +2395,14 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
       // and sleeps of a fifth of the last wait -- 60 us of spinning and a wake-up every 40 us were 1.2 of the 3.7 ms of CPU time per call of 8 rounds
       const double last = c->ph_last_wait_us;
       long nap_ns = last > 400.0 ? (long)(last * 200.0) : 40000; if (nap_ns > 250000) nap_ns = 250000;
+      static const bool block_env = getenv("LRH_STAGE_BLOCK") && atoi(getenv("LRH_STAGE_BLOCK"));   // (measured: the runtime spins inside hipEventSynchronize all the same, 5.4 against 3.3 ms of CPU per call: off)
       for (;;) {
         const hipError_t q = hipEventQuery(c->ph_ev[slot]);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(c, LRH_EDEVICE, "hipEventQuery(staging)", q);
+        // a long wait is coming (the last one was): one blocking wait on the event (created with hipEventBlockingSync: the thread sleeps on the
+        // interrupt) instead of a dozen timed naps, each a system call and a wake-up -- 0.8 of the 3.3 ms of CPU time per call of 8 rounds
+        if (block_env && last > 400.0) { const hipError_t e = hipEventSynchronize(c->ph_ev[slot]); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(staging)", e); break; }
         const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         if (last <= 400.0 && waited < 60.0) continue;
         if (last > 400.0 && waited > 0.7 * last) nap_ns = 40000;      // close to the expected end: short naps
@@ -2385,10 +2411,11 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
       c->ph_last_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
       c->host_ms_wait += c->ph_last_wait_us * 1e-3; }
     const int nchunks = (half + LRH_PH_CHUNK - 1) / LRH_PH_CHUNK;
-    float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_start = h_inc + batch;
+    // the page-locked table of this round: per transform the increments (t2, r2), the phases at its first sample, the bin (k_phase_expand reads it)
+    float2 *h_inc = (float2 *)(c->h_ph + slot * c->ph_stride), *h_st = h_inc + batch;
     int point = 0;
     const auto host_t0 = std::chrono::steady_clock::now();
-    int *h_point = (int *)(h_start + (size_t)batch * nchunks);
+    int *h_point = (int *)(h_st + batch);
     // the reference tests the range before it touches any state (mix1.c:787-796): every frequency of the batch first;
     // a table entry that only becomes invalid through the AFC bookkeeping of an earlier transform of the same batch still
     // ends the call, with the phase state put back (the caller's tables keep what the earlier transforms wrote, as after
@@ -2409,33 +2436,36 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
         if (lo < c->fft2_keep_lo[nx] || hi > c->fft2_keep_hi[nx]) { *s = ms_keep; c->ph_next = slot;
           return fail(c, LRH_ESTATE, "fft2_float_sparse: the selected frequency has moved off the band stored for this transform"); }
       }
-      float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
-      float r1 = s->mix1_old_phase;
+      const float t2 = s->mix1_phase_rot, t1 = s->mix1_phase;
+      const float r1 = s->mix1_old_phase;
       const float r2 = overlap ? (float)(t2 - 2 * (s->mix1_old_point - s->mix1_point) * PI_L / Nm) : 0.f;
       h_inc[b] = make_float2(t2, r2);
-      float2 *hs = h_start + (size_t)b * nchunks;
-      for (int i = 0; i < half; i++) {                    // the device replays the additions inside a chunk
-        if ((i & (LRH_PH_CHUNK - 1)) == 0) hs[i / LRH_PH_CHUNK] = make_float2(t1, r1);
-        r1 += r2; t1 += t2;
-      }
-      s->mix1_phase = t1;
+      h_st[b] = make_float2(t1, r1);
+      // do_mix1 adds t2 to the phase once per output sample, in float (mix1.c:141-195): `half` additions, advanced in closed form, bit for bit
+      // (lrh_phase.h; the loop `r1 += r2; t1 += t2` cost 0.23 ms per round of 1024 transforms -- more than half of the call's host time);
+      // the phases at the chunk starts inside the transform, which the device replays from, are derived on the device by the same function
+      s->mix1_phase = lrh_phase_advance(t1, t2, half);
     }
     c->host_ms_phases += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); c->host_n_phases++;
-    // a few KiB per call, in stream order
     float2 *d_inc = (float2 *)(c->d_ph + slot * c->ph_stride);
     o.ph_inc = d_inc; o.ph_start = d_inc + batch; o.nchunks = nchunks;
     Mix1Args a;
     a.fft2 = src; a.n2 = n2; a.first_nx = first; a.nx_mask = mask; a.fqwin = c->d_fqwin; a.tw = c->d_twm;
     a.scratch = c->d_mix_scratch; a.point = point; a.nm = Nm; a.lim_hi = lim_hi;
-    a.points = afc ? (const int *)(d_inc + (size_t)batch * (1 + nchunks)) : nullptr;
-    const size_t up_bytes = sizeof(float2) * (size_t)batch * (1 + nchunks) + sizeof(int) * (size_t)batch;
+    int *const d_point = (int *)(d_inc + (size_t)batch * (1 + nchunks));
+    a.points = afc ? (const int *)d_point : nullptr;
     const int mix1_n = c->mix1_n;
+    // the device's view of the page-locked table
+    const char *const hdev = (const char *)c->h_ph_dev + ((const char *)h_inc - (const char *)c->h_ph);
+    const float2 *const g_inc = (const float2 *)hdev, *const g_st = g_inc + batch; const int *const g_point = (const int *)(g_st + batch);
+    float2 *const d_start = d_inc + batch;
+    if (!c->h_ph_dev) return fail(c, LRH_EDEVICE, "no device view of the page-locked phase table");
     if (c->rec && c->early_upload) {
       // parked kernels: the table goes up now on the upload stream (behind the kernels that last read this slot,
       // which ev_tail / ev_side cover) and the kernels wait for it when they are finally launched
       HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_tail_cur ? c->ev_tail_cur : c->ev_tail, 0));
       if (c->nb_pending) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_nb, 0));
-      HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->stream3));
+      HIPCHK(c, launch_phase_expand(g_inc, g_st, g_point, d_inc, d_start, d_point, batch, nchunks, LRH_PH_CHUNK, c->stream3));
       HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->stream3));
       LRH_DEVICE_WORK(c, {
         HIPCHK(c, hipStreamWaitEvent(c->cur, c->ph_ev[slot], 0));
@@ -2446,7 +2476,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
     } else {
       c->ph_pending[slot] = true;
       LRH_DEVICE_WORK(c, {
-        HIPCHK(c, hipMemcpyAsync(d_inc, h_inc, up_bytes, hipMemcpyHostToDevice, c->cur));
+        HIPCHK(c, launch_phase_expand(g_inc, g_st, g_point, d_inc, d_start, d_point, batch, nchunks, LRH_PH_CHUNK, c->cur));
         HIPCHK(c, hipEventRecord(c->ph_ev[slot], c->cur));
         c->ph_pending[slot] = false;
         ProfScope ps(c, "mix1");

@@ -96,6 +96,8 @@ struct Fft1wArgs {
   int spare_cus;
   float real_peak;                                // k_fft1v<REAL>: the half window's peak value h[N] (make_window mode 2; the table on the device ends at h[N-1])
 };
+hipError_t launch_phase_expand(const float2 *h_inc, const float2 *h_st, const int *h_point, float2 *d_inc, float2 *d_start, int *d_point, int batch, int nchunks, int chunk, hipStream_t st);
+hipError_t launch_copy_words(const unsigned int *src, unsigned int *dst, size_t n, hipStream_t st);   // n 32-bit words; src may be page-locked host memory
 hipError_t launch_fft1w(const Fft1wArgs &a, hipStream_t st, int *run);
 hipError_t launch_fft1v(int log2n, bool dword, bool real, const Fft1wArgs &a, hipStream_t st, int *run);
 hipError_t launch_timf2_strong(int log2n, const Timf2Args &a, int batch, hipStream_t st);

@@ -1,5 +1,6 @@
 // lrh_spursearch.hip -- the search spectrum for new spurs on the device-resident fft2 power rows (gfx950).
 #include "lrh_kernels.hip.h"
+#include "lrh_phase.h"
 
 namespace lrh {
 // make_fft2's bookkeeping of the search spectrum for one new power row (fft2.c:673-699): element-wise over the search range
@@ -102,6 +103,40 @@ hipError_t launch_spur_search_row(const SpurSearchArgs &a, hipStream_t st)
 hipError_t launch_spur_search_cleanup(const SpurSearchArgs &a, hipStream_t st)
 {
   hipLaunchKernelGGL(k_spur_search_cleanup, dim3(1), dim3(1024), 0, st, a);
+  return hipGetLastError();
+}
+
+// mix1's phase tables (lrh_host.hip mix1_run): the host writes, per transform, the phase increments (t2, r2), the two running phases at the transform's
+// first sample and the bin to cut at into a page-locked table; this kernel reads it from there (the host pays one launch, not a hipMemcpyAsync of
+// 75-88 us) and writes the table k_mix1_back / k_mix1_out read: increments, the phases at every LRH_PH_CHUNK-th sample -- derived with the same
+// closed-form advance the host walks from transform to transform with, bit for bit the float recursion of do_mix1 (mix1.c:141-195) -- and the bins
+__global__ __launch_bounds__(256) void k_phase_expand(const float2 *h_inc, const float2 *h_st, const int *h_point, float2 *d_inc, float2 *d_start, int *d_point,
+                                                      int batch, int nchunks, int chunk)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch * nchunks) return;
+  const int b = i / nchunks, cidx = i - b * nchunks;
+  const float2 inc = h_inc[b], st = h_st[b];
+  d_start[i] = make_float2(lrh_phase_advance(st.x, inc.x, cidx * chunk), lrh_phase_advance(st.y, inc.y, cidx * chunk));
+  if (cidx == 0) { d_inc[b] = inc; if (d_point) d_point[b] = h_point[b]; }
+}
+hipError_t launch_phase_expand(const float2 *h_inc, const float2 *h_st, const int *h_point, float2 *d_inc, float2 *d_start, int *d_point, int batch, int nchunks, int chunk, hipStream_t st)
+{
+  if (batch < 1) return hipSuccess;
+  hipLaunchKernelGGL(k_phase_expand, dim3((batch * nchunks + 255) / 256), dim3(256), 0, st, h_inc, h_st, h_point, d_inc, d_start, d_point, batch, nchunks, chunk);
+  return hipGetLastError();
+}
+
+// a few KiB from a page-locked host table to the device by a kernel: the host pays one launch (mix1's phase tables, lrh_host.hip mix1_run)
+__global__ __launch_bounds__(256) void k_copy_words(const unsigned int *src, unsigned int *dst, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t launch_copy_words(const unsigned int *src, unsigned int *dst, size_t n, hipStream_t st)
+{
+  if (n == 0) return hipSuccess;
+  int g = (int)((n + 255) / 256); if (g > 64) g = 64;
+  hipLaunchKernelGGL(k_copy_words, dim3(g), dim3(256), 0, st, src, dst, n);
   return hipGetLastError();
 }
 }  // namespace lrh
