@@ -2405,7 +2405,8 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
         if (block_env && last > 400.0) { const hipError_t e = hipEventSynchronize(c->ph_ev[slot]); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(staging)", e); break; }
         const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         if (last <= 400.0 && waited < 60.0) continue;
-        if (last > 400.0 && waited > 0.7 * last) nap_ns = 40000;      // close to the expected end: short naps
+        // a long wait (the last one was): one sleep to 85 % of it, then short naps -- every nap is a system call and a wake-up, 5-8 us of CPU each
+        if (last > 400.0) { const double left = 0.85 * last - waited; nap_ns = left > 30.0 ? (long)(left * 1000.0) : 30000; if (nap_ns > 2000000) nap_ns = 2000000; }
         timespec ts{0, nap_ns}; nanosleep(&ts, nullptr);
       }
       c->ph_last_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
