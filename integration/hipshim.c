@@ -95,8 +95,7 @@ static int hip_unsupported(void)
   if (fft1_correlation_flag != 0 && !(fft1_correlation_flag == 1 && ui.rx_rf_channels == 2)) return 4;
   /* spur removal: eliminate_spurs inside make_fft2 with the second fft on, inside fft1_c with it off (fft1.c:4196-4244: the library takes the
      carriers out of the fft1 transforms then), acquisition through the hooks in spursub.c -- buf.c:836 zeroes MAX_NO_OF_SPURS itself when
-     the AFC is off.  fft1_size above 16384 (the four-step transform) with spurs on the fft1 side: not served */
-  if (genparm[SECOND_FFT_ENABLE] == 0 && genparm[MAX_NO_OF_SPURS] != 0 && fft1_n > 14) return 5;
+     the AFC is off.  (Refusal 5 -- spurs on the fft1 side -- is gone: served at every fft1_size since round 5.) */
   if ((ui.network_flag & NET_RXOUT_TIMF2) != 0 && !swfloat) return 6;      /* the int16 payload is built from the MMX ring (rxin.c:968-990) */
   if (genparm[MIX1_NO_OF_CHANNELS] != 1) return 7;
   return 0;

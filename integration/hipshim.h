@@ -11,8 +11,8 @@
 extern int fft1_use_gpu;
 
 /* hip_open: 0, a negative LRH_E* of the library, or 100 + n when the running configuration is one version 21 does not serve
-   (two RF channels in one array, real input, MMX back transform / second fft, correlation spectra, spur removal, network output of
-   device-resident stages, several mix1 channels): the caller ends with lirerr(1463) */
+   (103 the MMX back transform / second fft, 104 the correlation receiver, 106 NET_RXOUT_TIMF2 in the int16 format, 107 several mix1 channels,
+   108 two RF channels together with spur removal): the caller ends with lirerr(1463) */
 int  hip_open(void);                 /* wideband_dsp start, where create_clFFT_plan / cufftPlanMany are called (wcw.c:535-575) */
 void hip_close(void);                /* wideband_dsp exit, where destroy_clFFT_plan is called (wcw.c:1174-1183)              */
 void hip_timf1_new(int timf1p_pa, int nbytes);   /* finish_rx_read: one new block sits at timf1_char[timf1p_pa] (rxin.c:1425-1431) */

@@ -1109,7 +1109,7 @@ int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra
   const bool second = c && c->cfg.second_fft_enable != 0;
   if (!c || max_spurs < 0 || (max_spurs && (!spectra || speknum < 4 || 4 * speknum > (second ? c->cfg.max_fft2n : c->cfg.max_fft1n) || speknum > 1022))) return LRH_EINVAL;   // 1022: k_spur keeps speknum + 2 history entries in LDS (107 KB then)
   if (c->cfg.blanker_channels == 2) return fail(c, LRH_ESTATE, "spur subtraction: one channel");
-  if (!second && (c->cfg.fft1_float_sparse || c->fft1_big)) return fail(c, LRH_ESTATE, "spur subtraction on the fft1 transforms: whole spectra in the ring, fft1_size up to 16384");
+  if (!second && c->cfg.fft1_float_sparse) return fail(c, LRH_ESTATE, "spur subtraction on the fft1 transforms: whole spectra in the ring");
   c->spur_ring = second ? c->d_fft2 : c->d_fft1; c->spur_nx = second ? c->N2 : c->N1; c->spur_maxn = second ? c->cfg.max_fft2n : c->cfg.max_fft1n;
   c->spur_ff = second ? (float)c->M2 / (float)c->N2 : (float)c->M1 / (float)c->N1;
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));

@@ -38,6 +38,9 @@ def main():
         assert ref["spur_locked"][0] > 0, "the reference did not lock the spur: " + r.stderr
         out = {k: ref[k] for k in KEEP if k in ref}
         out["iq"], out["liminfo"] = iq, lim
+        if iq.size > (1 << 20):                       # (the seeded input of the four-step case is 2 MB: tests/refcases.py regenerates it, the golden keeps a checksum)
+            del out["iq"]
+            out["iq_sum"] = np.array([int(iq.astype(np.int64).sum()), int((iq.astype(np.int64) * (np.arange(iq.size) % 251)).sum())], np.int64)
         path = os.path.join(os.environ.get("LRH_GOLDEN_OUT", HERE), f"{name}.npz")
         np.savez_compressed(path, **out)
         if name in SPUR_CLICKS:                       # the operator's clicks through init_spur_elimination: every spur's loop state after every transform

@@ -378,6 +378,9 @@ SPUR = {
     # the baseband that fft1_mix1_fixed cuts out
     "spur_n10_fft1": dict(base="n10_mix1only", nblk=120, max_fft1n=32, spur_pnt=409, spur_start=12, spur_speknum=8, tone=None, fq=420.3,
                           strong=[(-100.0, 600.0)]),
+    # ... and at a four-step fft1 size (fft1_size 32768, k_fft1_cols / k_fft1_rows): the spur loop and the search rows work on the same ring
+    "spur_n15_fft1": dict(base="n16_mix1only_big", n1=15, nblk=30, max_fft1n=16, spur_pnt=28726, spur_start=8, spur_speknum=4, tone=None, fq=28700.3,
+                          strong=[(-9000.0, 3000.0), (12345.5, 600.0)], weak=[(12400.25, 150.0)], golden_stride=1, sumsq_blocks=4),
 }
 
 

@@ -20,7 +20,10 @@ def run(open_fn, name, g, batch=1, acquire=False):
     """acquire: the spur is found by the API's own store_new_spur / spur_phase_lock (spur_acquire) on the resident spectra instead of
     being handed over with the reference's acquisition result"""
     d, sp, iq, lim = spur_case(name)
-    assert np.array_equal(iq, g["iq"])
+    if "iq" in g:
+        assert np.array_equal(iq, g["iq"])
+    else:                                                    # (large input: the golden holds two checksums of it)
+        assert int(iq.astype(np.int64).sum()) == int(g["iq_sum"][0]) and int((iq.astype(np.int64) * (np.arange(iq.size) % 251)).sum()) == int(g["iq_sum"][1])
     cfg = lrh_config(d, iq)
     api = open_fn(cfg)
     api.timf1_write(iq)
@@ -77,7 +80,7 @@ def run_fft1(api, cfg, d, sp, g, acquire, first, last):
     spectrum from their powers; acquisition behind fft1_c, the history ending with the newest transform"""
     st = g["spur_init_state"]
     start = int(g["spur_locked"][0])
-    trace, handed, acq = [], False, None
+    trace, handed, acq, unremoved = [], False, None, None
     for b in range(d["nblk"]):
         api.fft1_b(1)
         api.fft1_c(1)
@@ -93,10 +96,14 @@ def run_fft1(api, cfg, d, sp, g, acquire, first, last):
                 q = LrhSpur(int(st[0]), int(st[1]), *[float(x) for x in st[2:9]])
                 maxn = cfg.max_fft1n
                 api.spur_set([q], g["spur_init_table"][:maxn * 14], g["spur_init_signal"][:2 * maxn], g["spur_init_ind"][:maxn])
+                # (a hand-over does not rewrite the ring: what mix1 makes of the newest transform, from which initial_remove_spur took the carrier, differs)
+                unremoved = dict(rows=[(api.p.fft1_nb - 1 - m) % maxn for m in range(int(st[10]))], timf3=(api.p.timf3_pa,))
             handed = True
         api.fft1_mix1_fixed(1)
+        if unremoved is not None and len(unremoved["timf3"]) == 1:
+            unremoved["timf3"] += (api.p.timf3_pa,)
     ss = api.spur_search_get()
-    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=acq, trace=np.array(trace, np.float64), fft1=api.export(abi.RING_FFT1_FLOAT),
+    return dict(api=api, cfg=cfg, d=d, ss=ss, ss_range=(first, last), acq=acq, unremoved=unremoved, trace=np.array(trace, np.float64), fft1=api.export(abi.RING_FFT1_FLOAT),
                 sumsq=api.export(abi.RING_FFT1_SUMSQ), timf3=api.export(abi.RING_TIMF3_FLOAT))
 
 
@@ -112,9 +119,18 @@ def compare_fft1(out, g, tol):
     def rel(a, b):
         a, b = a.astype(np.float64), b.astype(np.float64)
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    h1, r1, h3, r3 = out["fft1"], g["fft1_float"], out["timf3"], g["timf3_float"]
+    if out.get("unremoved"):                                    # handed over, not acquired: see run()
+        n1_, u = 2 << out["cfg"].fft1_n, out["unremoved"]
+        h1, r1, h3, r3 = h1.copy(), r1.copy(), h3.copy(), r3.copy()
+        for row in u["rows"]:
+            h1[row * n1_:(row + 1) * n1_] = 0; r1[row * n1_:(row + 1) * n1_] = 0
+        a, b = u["timf3"]
+        idx = (a + np.arange(2 * ((b - a) % h3.size))) % h3.size
+        h3[idx] = 0; r3[idx] = 0
     rep = {"transforms": int(ref.shape[0]), "freq_err_bins": float(np.max(np.abs(got[:, 2] - ref[:, 2]))),
            "phase_err_rad": float(np.max(np.abs(wrap(got[:, 3] - ref[:, 3])))), "ampl_rel": float(np.max(np.abs(got[:, 6] - ref[:, 6]) / np.abs(ref[:, 6]))),
-           "fft1": rel(out["fft1"], g["fft1_float"]), "timf3": rel(out["timf3"], g["timf3_float"])}
+           "fft1": rel(h1, r1), "timf3": rel(h3, r3)}
     it = g["itrace"].reshape(-1, 16)
     keep = np.ones(out["sumsq"].size, bool)
     if it[-1, 10] != 0:                                          # an unfinished averaging period at the end: fft1_c accumulates it in place
@@ -122,7 +138,7 @@ def compare_fft1(out, g, tol):
     rep["sumsq"] = rel(out["sumsq"] * keep, g["fft1_sumsq"] * keep)
     loc = int(ref[-1, 0])
     n1 = 1 << out["cfg"].fft1_n
-    f_h, f_r = out["fft1"].reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64), g["fft1_float"].reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64)
+    f_h, f_r = h1.reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64), r1.reshape(-1, n1, 2)[:, loc:loc + 7].astype(np.float64)
     rep["residual_vs_carrier"] = float(np.linalg.norm(f_r) / (np.sqrt(f_r.shape[0]) * abs(ref[-1, 6])))
     rep["residual_err_vs_carrier"] = float(np.linalg.norm(f_h - f_r) / (np.sqrt(f_r.shape[0]) * abs(ref[-1, 6])))
     assert rep["freq_err_bins"] < 1e-3 and rep["phase_err_rad"] < 20 * tol * 1e2 and rep["ampl_rel"] < 10 * tol, rep

@@ -74,7 +74,7 @@ def test_linear_blanker_tables_through_the_glue_on_the_device(harness, tmp_path,
     shimlib.check_clever_case(harness, tmp_path, extra=extra)
 
 
-@pytest.mark.parametrize("name", ["spur_n10_n12", "spur_n10_n12_drift", "spur_n10_fft1"])
+@pytest.mark.parametrize("name", ["spur_n10_n12", "spur_n10_n12_drift", "spur_n10_fft1", "spur_n15_fft1"])
 def test_spur_removal_through_the_acquisition_hooks_on_the_device(harness, tmp_path, name):
     """store_new_spur / spur_phase_lock (spursub.c:619, 1247; hooked) -> lrh_spur_acquire on the resident fft2 spectra; eliminate_spurs inside
     lrh_make_fft2; the loop state the glue brings back after every transform against the unpatched reference's"""

@@ -68,7 +68,7 @@ def test_free_running_stage_threads_with_fft1b_workers(harness, tmp_path, name, 
     shimlib.check_free_running(harness, os.path.join(ROOT, "oracle", "_ref", "ref_harness"), tmp_path, name, workers)
 
 
-@pytest.mark.parametrize("name", ["spur_n10_n12", "spur_n10_n12_drift", "spur_n10_fft1"])
+@pytest.mark.parametrize("name", ["spur_n10_n12", "spur_n10_n12_drift", "spur_n10_fft1", "spur_n15_fft1"])
 def test_spur_removal_is_served_through_the_acquisition_hooks(harness, tmp_path, name):
     print(name, shimlib.check_spur_case(harness, tmp_path, name))
 
