@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
 #pragma unroll
       for (int r = 0; r < P; r++) {
         if constexpr (REAL) {
+#pragma clang fp contract(off)                               // (the prologue and the loop are two copies of this code: every product and sum rounded on its own, so that both round alike)
           const float2 wr1 = make_float2(wrot.x * cpn1 - wrot.y * spn1, wrot.y * cpn1 + wrot.x * spn1), wr2 = make_float2(wrot.x * cpn2 - wrot.y * spn2, wrot.y * cpn2 + wrot.x * spn2);
           const float w0 = window_at(r < HP ? wrot : wr1, r), w1 = window_at(r < HP ? wr1 : wr2, r);
           x[r] = lrh_v2f{(float)raw[r].x * w0, (float)raw[r].y * w1};
@@ -1098,6 +1099,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32, 1) void k_fft1v(Fft1wArgs a)
         const bool kk0 = kk == 0;
 #pragma unroll
         for (int i = 0; i < P; i++) {
+#pragma clang fp contract(off)                               // (as above: no fused multiply-adds the two copies of this loop could place differently)
           const int k3 = F32::out(i / F32::ND, i % F32::ND);    // the order the complex form hands them out in (the filter table's loads follow it)
           const int m3 = 31 - k3, m0 = (32 - k3) & 31;              // k3 of bin N - k: 31 - k3 (kk != 0), (32 - k3) mod 32 (kk == 0)
           if (i == P / 2) half_way();                      // (the even pairs of the filter table are used up by now)

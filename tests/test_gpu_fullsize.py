@@ -689,9 +689,9 @@ def test_one_round_late_schedule_carries_over_calls(monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("fft1_n,fft2_n,fft3_n", [(14, 16, 12), (14, 12, 0), (15, 17, 12)])
-def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n):
-    """The configurations bench.py times (the headline, configs[1] as its `secondary`, --fft1-n 15 --fft2-n 17).
+@pytest.mark.parametrize("fft1_n,fft2_n,fft3_n,real", [(14, 16, 12, 0), (14, 12, 0, 0), (15, 17, 12, 0), (14, 16, 12, 1)])
+def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n, real):
+    """The configurations bench.py times (the headline, configs[1] as its `secondary`, --fft1-n 15 --fft2-n 17, --real-input).
     The headline -- BASELINE configs[2] at 4096 fft1 blocks per round on the one-round-late two-stream
     schedule, sparse fft1 / fft2 rings, fft3 and mix2 inside the call -- against the same contexts' rings after rounds of 256 blocks in
     the serial order with both rings full (which the full-size oracle tests above reach in rounds of 16).  A block's transforms do not
@@ -710,6 +710,7 @@ def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n):
         try:
             cfg = chain_config(fft1_n, fft2_n, batch=4096, fft3_n=fft3_n, mix2_n=8 if fft3_n else 0, rounds=2)
             cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
+            cfg.timf1_real_input = real                      # --real-input: k_fft1v<.., REAL> (the same int16 stream read as real samples)
             cfg.stupid_bln_mode = 0                          # (the blanker's statistics are per call: a property of the call pattern)
             rx = _hip(cfg)
         finally:
