@@ -667,8 +667,11 @@ def main():
     # batch = fft1 blocks handed to every kernel launch.  Throughput grows with it (fuller waves of workgroups, launch and
     # host overheads amortised: 23.3 Gsamples/s at 1024, 26.9 at 2048, 29.2 at 4096, 29.3 at 8192, round 1) at the price of
     # batch*8192 samples of latency; 4096 blocks are 1.1 ms of signal at the rate the chain sustains.
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--rounds", type=int, default=8, help="batches of --batch fft1 blocks per step (pipelined on two streams; the pipeline fills and drains once per step: 22.6 / 23.5 / 23.7 Gsamples/s at 4 / 8 / 16)")
+    # Round 5: with the kernels twice as fast as then, what a round costs beside them shows again -- the prologue block of every workgroup's run in k_fft1v
+    # (1/16 of a run of 16), five kernel-to-kernel hand-overs on the main stream (~6 us each), the tails of the launches: 41.0 Gsamples/s at 4096 blocks per round,
+    # 45.4 at 8192 (same 268 435 456 samples per step: 4 rounds of 8192); 16384 does not fit the 32-bit ring offsets.
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--rounds", type=int, default=4, help="batches of --batch fft1 blocks per step (pipelined on two streams; the pipeline fills and drains once per step)")
     ap.add_argument("--fft1-n", type=int, default=14)
     ap.add_argument("--fft2-n", type=int, default=None, help="log2 fft2_size; default 16 (configs[2]); 12 = configs[1]")
     ap.add_argument("--fft3-n", type=int, default=12, help="log2 fft3_size behind mix1 (0: chain ends at mix1)")

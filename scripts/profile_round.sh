@@ -20,9 +20,9 @@ pmc() {   # name, bench flags
   unset LRH_PIPELINE
   echo "pmc passes of $wl done"
 }
-pmc n1_14_n2_16_n3_12_b4096 --no-secondary
-pmc n1_14_n2_12_n3_0_b4096 --fft2-n 12 --fft3-n 0
-pmc n1_14_n2_16_n3_12_b4096_full --no-secondary --fft1-float full --fft2-float full     # what the Linrad glue opens (bench.py's full_rings object)
+pmc n1_14_n2_16_n3_12_b8192 --no-secondary
+pmc n1_14_n2_12_n3_0_b8192 --fft2-n 12 --fft3-n 0
+pmc n1_14_n2_16_n3_12_b8192_full --no-secondary --fft1-float full --fft2-float full     # what the Linrad glue opens (bench.py's full_rings object)
 python3 bench.py --steps 50 --warmup 5 > $OUT/bench_plain.json 2> $OUT/plain.log
 # keep the merge small: per-dispatch traces can be large
 python3 scripts/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1

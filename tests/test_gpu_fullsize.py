@@ -689,8 +689,8 @@ def test_one_round_late_schedule_carries_over_calls(monkeypatch):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("fft1_n,fft2_n,fft3_n,real", [(14, 16, 12, 0), (14, 12, 0, 0), (15, 17, 12, 0), (14, 16, 12, 1)])
-def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n, real):
+@pytest.mark.parametrize("fft1_n,fft2_n,fft3_n,real,big", [(14, 16, 12, 0, 8192), (14, 16, 12, 0, 4096), (14, 12, 0, 0, 8192), (15, 17, 12, 0, 4096), (14, 16, 12, 1, 8192)])
+def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n, real, big):
     """The configurations bench.py times (the headline, configs[1] as its `secondary`, --fft1-n 15 --fft2-n 17, --real-input).
     The headline -- BASELINE configs[2] at 4096 fft1 blocks per round on the one-round-late two-stream
     schedule, sparse fft1 / fft2 rings, fft3 and mix2 inside the call -- against the same contexts' rings after rounds of 256 blocks in
@@ -699,16 +699,16 @@ def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n, real):
     an averaging period straddles two workgroup runs (k_sumsq_join)."""
     from linrad_amd.lib import synth_defaults, synth_iq
     import os
-    nblk = 2 * 4096
+    nblk = 2 * big                                           # (bench.py's default round: 8192 blocks since round 5, 4096 before)
     n1 = 1 << fft1_n
     s = synth_defaults(n1, 0)
     res = []
-    for batch, sparse, pipeline in ((4096, 1, None), (256, 0, "0")):
+    for batch, sparse, pipeline in ((big, 1, None), (256, 0, "0")):
         old = os.environ.get("LRH_PIPELINE")
         if pipeline is not None:
             os.environ["LRH_PIPELINE"] = pipeline
         try:
-            cfg = chain_config(fft1_n, fft2_n, batch=4096, fft3_n=fft3_n, mix2_n=8 if fft3_n else 0, rounds=2)
+            cfg = chain_config(fft1_n, fft2_n, batch=big, fft3_n=fft3_n, mix2_n=8 if fft3_n else 0, rounds=2)
             cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
             cfg.timf1_real_input = real                      # --real-input: k_fft1v<.., REAL> (the same int16 stream read as real samples)
             cfg.stupid_bln_mode = 0                          # (the blanker's statistics are per call: a property of the call pattern)
@@ -724,7 +724,7 @@ def test_bench_shape_equals_rounds_of_256_blocks(fft1_n, fft2_n, fft3_n, real):
     a, b = res
     assert a["p"] == b["p"]
     assert np.count_nonzero(a["timf3"]) > 1000 and (not fft3_n or np.count_nonzero(a["baseb"]) > 1000)
-    # the waterfall: a round of 4096 blocks ends 128 lines, twice what the ring holds -- the lines that stay are the newest 64
+    # the waterfall: a round of 4096 blocks ends 128 lines (8192: 256), more than the ring holds -- the lines that stay are the newest 64
     for k in ("pwr", "ps2", "wf", "timf3") + (("fft3", "baseb") if fft3_n else ()):
         assert np.array_equal(a[k], b[k]), (k, int(np.count_nonzero(a[k] != b[k])))
     for k in ("sumsq", "slowsum"):
