@@ -560,10 +560,11 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         chain_alg = alg_bytes_chain(w)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_file": ("profiles/" + _TRAFFIC["file"]) if (traffic and _TRAFFIC.get("file")) else None,
                 "frac_alg": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_counter": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "achieved_counter": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r04_traffic.json, same sources as this library) "
+                "primary": "frac_counter: HBM bytes the kernel really moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/%s, same sources as this library) " % (_TRAFFIC.get("file") or "r0N_traffic.json: none matches these sources") +
                            "/ average launch time / 8 TB/s; frac (= frac_alg) prices the SURVEY 8d algorithmic bytes, part of which this "
                            "kernel eliminates (overlap read-modify-write 32 B, liminfo floats 8 B of 92 B per sample)",
                 "timer": "HIP events around each launch on the stream it is launched on, two-stream schedule of the timed loop "
@@ -627,6 +628,80 @@ def measure(args, w, rank, local_rank, world, dist, torch, hiplib, steps, warmup
         rx.host_unregister(host_ring)
     rx.close()
     return res
+
+
+LINE_LIMIT = 6000          # bytes: the driver keeps an 8 KB tail of stdout and parses the LAST line (round 5's 22.9 KB line did not survive that)
+
+
+def compact_line(out):
+    """The ONE line the driver parses, from the full result `out` (which goes to gpurun_out/bench_detail.json and stderr): the contract's
+    fields, the roofline and cpu_baseline objects, and one number each for the objects measured beside the headline."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    roof = out.get("roofline") or {}
+    line = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = dict(out.get("config") or {})
+    cfg["workload"] = (cfg.get("workload") or "")[:420]
+    for k in ("fft1_float", "fft2_float"):
+        if k in cfg:
+            cfg[k] = "sparse" if not str(cfg[k]).startswith("every bin") else "full"
+    line["config"] = cfg
+    line["roofline"] = pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_counter", "achieved_counter", "alg_bytes_per_launch", "alg_bytes_per_sample",
+                                   "avg_launch_us", "avg_launch_us_alone", "chain_alg_bytes_per_sample", "chain_frac_alg", "chain_counter_bytes_per_sample", "chain_frac_counter",
+                                   "device_copy_GBps", "traffic_file"))
+    lk = roof.get("longest_kernel")
+    if lk:
+        line["roofline"]["longest_kernel"] = pick(lk, ("kernel", "avg_launch_us", "avg_launch_us_alone", "hbm_frac_counter", "fp32_frac"))
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = dict(pick(cb, ("value", "unit", "cores", "kind")), sample=(cb.get("sample") or "")[:200]) if cb else None
+    for k in ("cpu_baseline_port", "cpu_baseline_reference_threads", "cpu_baseline_all_cores"):
+        if out.get(k):
+            line[k] = pick(out[k], ("value", "cores", "kind"))
+    line["realtime_factor"] = out.get("realtime_factor")
+    line["event_ms_per_step"] = out.get("event_ms_per_step")
+    if out.get("blanker"):
+        line["blanker"] = pick(out["blanker"], ("noise_floor", "cleared_rate_pct"))
+    for k in ("full_rings", "secondary"):
+        o = out.get(k)
+        if o:
+            r = o.get("roofline") or {}
+            line[k] = dict(pick(o, ("value", "ms_per_step", "steps", "error")), frac=r.get("frac"), frac_counter=r.get("frac_counter"), kernel=r.get("kernel"))
+    if out.get("round_sweep"):
+        line["round_sweep"] = out["round_sweep"]
+    g = out.get("glue")
+    if isinstance(g, list):
+        line["glue"] = {"unit": "Msamples/s per gpu.fft1_batch_n (patched reference objects + hipshim.c + liblinrad_hip.so, PCIe inclusive)"}
+        for q in g:
+            if q:
+                line["glue"][q["config"]] = {str(r["fft1_batch_n"]): r.get("value", "error") for r in q["runs"]}
+    elif g:
+        line["glue"] = g
+    line["detail"] = "gpurun_out/bench_detail.json (stages, per-stage glue call tables, notes); also on stderr"
+    txt = json.dumps(line, allow_nan=False)
+    if len(txt) > LINE_LIMIT:                                # never again an unparseable line: drop the optional objects, largest first
+        for k in ("glue", "round_sweep", "realtime_factor", "cpu_baseline_all_cores", "cpu_baseline_reference_threads", "cpu_baseline_port", "blanker", "secondary", "full_rings"):
+            line.pop(k, None)
+            txt = json.dumps(line, allow_nan=False)
+            if len(txt) <= LINE_LIMIT:
+                break
+    return txt
+
+
+def round_sweep(args, primary, rank, local_rank, world, dist, torch, hiplib):
+    """The headline workload at rounds of 256 / 1024 / 4096 / 8192 fft1 blocks (the same samples per step): how much of `value` is the
+    amortisation of launches and pipeline fill over a long round (8192 blocks = 0.42 s of signal at 160 Msps)."""
+    total = args.batch * args.rounds
+    res = {}
+    for b in (256, 1024, 4096, 8192):
+        if b > total or total % b:
+            continue
+        a = argparse.Namespace(**vars(args))
+        a.batch, a.rounds = b, total // b
+        try:
+            res[str(b)] = measure(a, primary, rank, local_rank, world, dist, torch, hiplib, max(3, args.steps // 10), 2, with_stage_times=False)["value"]
+        except Exception as e:  # noqa: BLE001
+            res[str(b)] = repr(e)[:80]
+    return {"unit": "Msamples/s by fft1 blocks per round", **res}
 
 
 WORKLOADS = {
@@ -706,6 +781,7 @@ def main():
                     help="real samples (fft1 version 2): every fft1 block takes 2*M1 reals; value still counts M1 complex-rate samples per block")
     ap.add_argument("--glue-repeats", type=int, default=3, help="runs per fft1_batch_n of the drop-in measurement; the median is reported")
     ap.add_argument("--glue-blocks", type=int, default=8192, help="fft1 blocks per run of the drop-in measurement (`glue` object; x2 / x4 at the larger fft1_b batches)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the `round_sweep` object (the headline workload at rounds of 256 / 1024 / 4096 / 8192 blocks)")
     ap.add_argument("--no-glue", action="store_true", help="skip the `glue` object (patched reference + hipshim.c + liblinrad_hip.so)")
     ap.add_argument("--glue-only", action="store_true", help="only the `glue` object, as one JSON line")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help=argparse.SUPPRESS)
@@ -787,6 +863,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             full_rings = {"error": repr(e)}
 
+    sweep = None
+    if default_run and world == 1 and not args.no_sweep:
+        sweep = round_sweep(args, primary, rank, local_rank, world, dist, torch, hiplib)
+
     cpu = cpu_all = cpu_port = cpu_threads = None
     if rank == 0 and not args.no_cpu:
         cw = dict(primary)
@@ -832,9 +912,18 @@ def main():
             "event_ms_per_step": res["event_ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"], "host_cpu": res["host_cpu"],
             "realtime_factor": {k: round(value / world * 1e6 / r, 1) for k, r in (("10Msps", 10e6), ("40Msps", 40e6), ("160Msps", 160e6))},
             "routing": res.get("routing"), "roofline": res["roofline"], "cpu_baseline": cpu, "cpu_baseline_port": cpu_port, "cpu_baseline_reference_threads": cpu_threads,
-            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary, "full_rings": full_rings, "glue": glue,
+            "cpu_baseline_all_cores": cpu_all, "stages": res["stages"], "blanker": res.get("blanker"), "spurs": res.get("spurs"), "secondary": secondary, "full_rings": full_rings, "round_sweep": sweep, "glue": glue,
         }
-        print(json.dumps(out), flush=True)
+        # everything measured: a file (merged back from the GPU box) and stderr; stdout carries ONE short line (compact_line)
+        detail = json.dumps(out)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+                f.write(detail + "\n")
+        except OSError:
+            pass
+        print(detail, file=sys.stderr, flush=True)
+        print(compact_line(out), flush=True)
     return 0
 
 

@@ -40,7 +40,8 @@ enum {
   LRH_ENOMEM = -2,    /* device or host allocation failed                     */
   LRH_EDEVICE = -3,   /* HIP runtime error (no device, launch failure, ...)   */
   LRH_ESTATE = -4,    /* call out of order (e.g. table not set)               */
-  LRH_ERANGE = -5     /* frequency outside mix1 range (lirerr 1211/1212, mix1.c:787-796) */
+  LRH_ERANGE = -5,    /* frequency outside mix1 range (lirerr 1211/1212, mix1.c:787-796) */
+  LRH_EINTERNAL = -6  /* a C++ exception (allocation failure, ...) was caught at the C boundary: lrh_last_error has its text */
 };
 
 /* Sizes and parameters. Names follow the reference globals / genparm[] slots. */

@@ -9,7 +9,7 @@ tests can drive the CPU oracle (prefix ``lro``) through the very same calls.
 import ctypes as C
 import numpy as np
 
-LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE = 0, -1, -2, -3, -4, -5
+LRH_OK, LRH_EINVAL, LRH_ENOMEM, LRH_EDEVICE, LRH_ESTATE, LRH_ERANGE, LRH_EINTERNAL = 0, -1, -2, -3, -4, -5, -6
 
 (RING_TIMF1, RING_FFT1_FLOAT, RING_FFT1_SUMSQ, RING_FFT1_SLOWSUM, RING_TIMF2_FLOAT, RING_TIMF2_PWR,
  RING_FFT2_FLOAT, RING_FFT2_POWER, RING_FFT2_POWERSUM, RING_WG_WATERF, RING_TIMF3_FLOAT,

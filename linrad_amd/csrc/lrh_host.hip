@@ -15,6 +15,13 @@
 #include <atomic>
 #include <mutex>
 
+#include <exception>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <sys/syscall.h>
+
 #include "../../include/linrad_hip.h"
 #include "lrh_kernels.hip.h"
 #include "lrh_phase.h"
@@ -62,6 +69,54 @@ using namespace lrh;
 #define LRH_NOUT 16                 /* read-back slots (export_impl) */
 #define LRH_OUT_SLOT_BYTES (1u << 19)
 #define LRH_MAX_HANDLES 7          /* handle 0 = the caller's own thread; 1..6 = THREAD_FFT1B1..6 (MAX_FFT1_THREADS, thrdef.h:107; gpu_handle_number, wcw.c:500) */
+
+// LRH_CRASH_TRACE=1 (the test suite sets it): a fatal signal prints the C stack of the thread it was raised on, AFTER whatever handler was
+// installed before (Python's faulthandler under pytest), so the native frames are the last thing in the log.  Diagnostics only: without the
+// switch the library installs nothing.  (Round 5's GPU suite died of a SIGABRT raised on a thread of the HIP runtime with no message at all.)
+namespace {
+struct sigaction g_crash_prev[NSIG];
+void crash_write(const char *s) { if (write(2, s, strlen(s)) < 0) {} }
+void crash_handler(int sig, siginfo_t *si, void *uc)
+{
+  const struct sigaction prev = g_crash_prev[sig];
+  if ((prev.sa_flags & SA_SIGINFO) && prev.sa_sigaction) prev.sa_sigaction(sig, si, uc);      // faulthandler: dumps, puts SIG_DFL back, raises (held back while we are in here)
+  else if (!(prev.sa_flags & SA_SIGINFO) && prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN) prev.sa_handler(sig);
+  char line[160];
+  snprintf(line, sizeof line, "\n=== liblinrad_hip crash trace: signal %d, thread %ld (process %d) ===\n", sig, (long)syscall(SYS_gettid), (int)getpid());
+  crash_write(line);
+  void *bt[48]; const int n = backtrace(bt, 48);
+  backtrace_symbols_fd(bt, n, 2);
+  const int fd = open("/proc/self/maps", O_RDONLY);              // where the runtime libraries sit (two HIP runtimes in one process is a finding of its own)
+  if (fd >= 0) {
+    static char buf[1 << 16]; size_t have = 0; ssize_t r;
+    while ((r = read(fd, buf + have, sizeof buf - 1 - have)) > 0) {
+      have += (size_t)r; buf[have] = 0;
+      char *ls = buf, *nl;
+      while ((nl = strchr(ls, '\n'))) {
+        *nl = 0;
+        if (strstr(ls, " r-xp ") && (strstr(ls, "libamdhip64") || strstr(ls, "libhsa-runtime64") || strstr(ls, "liblinrad_hip"))) { crash_write(ls); crash_write("\n"); }
+        ls = nl + 1;
+      }
+      have = strlen(ls); memmove(buf, ls, have + 1);
+    }
+    close(fd);
+  }
+  crash_write("=== end of crash trace ===\n");
+  signal(sig, SIG_DFL); raise(sig);
+}
+struct CrashTraceInstall {
+  CrashTraceInstall() {
+    const char *e = getenv("LRH_CRASH_TRACE");
+    if (!e || !atoi(e)) return;
+    void *warm[4]; backtrace(warm, 4);                             // loads libgcc's unwinder now, not inside the handler
+    for (int sig : { SIGABRT, SIGSEGV, SIGBUS, SIGFPE, SIGILL }) {
+      struct sigaction sa; memset(&sa, 0, sizeof sa);
+      sa.sa_sigaction = crash_handler; sa.sa_flags = SA_SIGINFO | SA_ONSTACK; sigemptyset(&sa.sa_mask);
+      sigaction(sig, &sa, &g_crash_prev[sig]);
+    }
+  }
+} g_crash_trace_install;
+}  // namespace
 
 struct ProfEntry { double ms = 0; long n = 0; };
 struct ProfPending { std::string name; hipEvent_t e0, e1; };
@@ -267,6 +322,17 @@ static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSucces
   if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
   return code;
 }
+// A C host (xlinrad64 through integration/hipshim.c, ctypes) must get an error code, never std::terminate: every extern "C" entry point is a
+// function-try-block that ends in one of these ("return 0 or a negative code"; lxsys.c:494-505 is where Linrad reports them)
+static int lrh_caught(lrh_ctx *c, const char *what) noexcept
+{
+  if (c) snprintf(c->err, sizeof c->err, "C++ exception inside the library: %s", what ? what : "?");
+  fprintf(stderr, "liblinrad_hip: C++ exception caught at the C boundary: %s\n", what ? what : "?");
+  return LRH_EINTERNAL;
+}
+#define LRH_CATCH(c) catch (const std::exception &e_) { return lrh_caught(const_cast<lrh_ctx *>(c), e_.what()); } catch (...) { return lrh_caught(const_cast<lrh_ctx *>(c), "unknown exception"); }
+#define LRH_CATCH_NOCTX catch (const std::exception &e_) { return lrh_caught(nullptr, e_.what()); } catch (...) { return lrh_caught(nullptr, "unknown exception"); }
+#define LRH_CATCH_OPEN(out) catch (const std::exception &e_) { if (out) *(out) = nullptr; return lrh_caught(nullptr, e_.what()); } catch (...) { if (out) *(out) = nullptr; return lrh_caught(nullptr, "unknown exception"); }
 // entry of an API call: the context's lock (see lrh_ctx::mtx) and its device for this host thread
 #define LRH_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); hipSetDevice((c)->cfg.device); }
 // ... and, for every entry point that may look at or change what the chain has produced, the launches lrh_wideband_dsp still holds
@@ -312,7 +378,7 @@ struct ProfScope {
     hipEvent_t e; hipEventCreate(&e); return e;
   }
   ProfScope(lrh_ctx *c_, const char *n) : c(c_), name(n) { if (c->prof) { e0 = get(c); e1 = get(c); hipEventRecord(e0, c->cur); } }
-  ~ProfScope() { if (c->prof) { hipEventRecord(e1, c->cur); c->prof_pend.push_back({name, e0, e1}); } }
+  ~ProfScope() { if (c->prof) { hipEventRecord(e1, c->cur); try { c->prof_pend.push_back({name, e0, e1}); } catch (...) {} } }
 };
 static void prof_collect(lrh_ctx *c)
 {
@@ -450,14 +516,15 @@ extern "C" {
 
 int lrh_abi_version(void) { return LRH_ABI_VERSION; }
 size_t lrh_sizeof(int which)
-{
+try {
   static const size_t sz[] = { sizeof(lrh_config), sizeof(lrh_ptrs), sizeof(lrh_blanker_state), sizeof(lrh_blanker_tables), sizeof(lrh_mix1_state),
                                sizeof(lrh_sellim), sizeof(lrh_spur), sizeof(lrh_afc), sizeof(lrh_synth) };
   return which >= 0 && which < (int)(sizeof sz / sizeof sz[0]) ? sz[which] : 0;
 }
+LRH_CATCH_NOCTX
 
 int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
-{
+try {
   if (!c) return LRH_EINVAL;
   memset(c, 0, sizeof *c);
   int N1 = 1 << fft1_n, N2 = 1 << fft2_n, NM = N1 > N2 ? N1 : N2;
@@ -476,15 +543,16 @@ int lrh_config_defaults(lrh_config *c, int fft1_n, int fft2_n)
   c->fft3_n = 0; c->fft3_sinpow = 2; c->mix2_n = 0; c->max_fft3n = 8; c->baseband_size = 4096;
   return LRH_OK;
 }
+LRH_CATCH_NOCTX
 
 void lrh_close(lrh_ctx *c)
-{
+try {
   if (!c) return;
   if (g_hostprof && !g_hostprof_sites.empty()) {
     std::vector<std::pair<std::string, HostProfSite>> v(g_hostprof_sites.begin(), g_hostprof_sites.end());
     std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.second.ns > b.second.ns; });
     double tot = 0; long n = 0; for (auto &e : v) { tot += e.second.ns; n += e.second.n; }
-    fprintf(stderr, "LRH_HOSTPROF: %ld calls, %.3f ms inside HIP calls of lrh_wideband_dsp (%d calls of it, %.3f ms wall, %.3f ms cpu, of which %.3f ms in the staging wait, %.3f ms phase tables)\n", n, tot * 1e-6, c->host_n_dsp, c->host_ms_dsp, c->host_cpu_ms_dsp, c->host_cpu_ms_wait, c->host_ms_phases);
+    fprintf(stderr, "LRH_HOSTPROF: %ld calls, %.3f ms inside HIP calls of lrh_wideband_dsp (%ld calls of it, %.3f ms wall, %.3f ms cpu, of which %.3f ms in the staging wait, %.3f ms phase tables)\n", n, tot * 1e-6, c->host_n_dsp, c->host_ms_dsp, c->host_cpu_ms_dsp, c->host_cpu_ms_wait, c->host_ms_phases);
     for (size_t i = 0; i < v.size() && i < 40; i++) fprintf(stderr, "  %-48s %7ld x %7.2f us = %8.3f ms\n", v[i].first.c_str(), v[i].second.n, v[i].second.ns * 1e-3 / v[i].second.n, v[i].second.ns * 1e-6);
     g_hostprof_sites.clear();
   }
@@ -537,11 +605,12 @@ void lrh_close(lrh_ctx *c)
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
+catch (...) { lrh_caught(nullptr, "exception inside lrh_close"); }
 
 const char *lrh_last_error(const lrh_ctx *c) { return c ? c->err : "null context"; }
 
 int lrh_open(const lrh_config *cfg, lrh_ctx **out)
-{
+try {
   if (!cfg || !out || cfg->struct_size != (int)sizeof(lrh_config)) return LRH_EINVAL;
   *out = nullptr;
   if (cfg->rx_rf_channels != 1) return LRH_EINVAL;                      // channels shard one per context / GPU
@@ -767,13 +836,15 @@ int lrh_open(const lrh_config *cfg, lrh_ctx **out)
   if (rc != LRH_OK) { *out = nullptr; lrh_close(c); }
   return rc;
 }
+LRH_CATCH_OPEN(out)
 
 int lrh_get_derived(const lrh_ctx *c, int *i1, int *i2, int *ms, int *mi, int *t3b)
-{
+try {
   if (!c) return LRH_EINVAL;
   if (i1) *i1 = c->I1; if (i2) *i2 = c->I2; if (ms) *ms = c->Nm; if (mi) *mi = c->Im; if (t3b) *t3b = 2 * c->Mm;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 void lrh_ptrs_init(const lrh_ctx *c, lrh_ptrs *p)
 {
@@ -812,25 +883,27 @@ static int upload_filtercorr(lrh_ctx *c)
 }
 
 int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
   c->f1_end_valid = false;
   return upload_filtercorr(c);
 }
+LRH_CATCH(c)
 
 int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   c->ch2_c1 = c1; c->ch2_c2 = c2;
   c->f1_end_valid = false;                               // the table the fused kernel's partner would be recomputed with has changed
   return upload_filtercorr(c);
 }
+LRH_CATCH(c)
 
 int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
-{
+try {
   LRH_ENTER(c);
   if (!c || !liminfo) return LRH_EINVAL;
   // pack the weak flags per first-pass butterfly of the N1 transform (see k_timf2)
@@ -859,6 +932,7 @@ int lrh_set_liminfo(lrh_ctx *c, const float *liminfo)
   c->have_liminfo = true;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // fft1_update_liminfo + selfreq_liminfo on the device (include/linrad_hip.h); k_sellim / k_sellim2 (the routing words are their last step)
 // installs the weak-bin count of update number `seq` (1-based) once its readback has arrived
@@ -1003,23 +1077,25 @@ static int sellim_check(lrh_ctx *c, const lrh_sellim *q, bool second)
   return LRH_OK;
 }
 int lrh_fft1_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   { const int rc = sellim_check(c, q, false); if (rc) return rc; }
   return sellim_run(c, p, q, 1);
 }
+LRH_CATCH(c)
 int lrh_fft2_update_liminfo(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !q) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   { const int rc = sellim_check(c, q, true); if (rc) return rc; }
   return sellim_run(c, p, q, 2);
 }
+LRH_CATCH(c)
 int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -1034,8 +1110,9 @@ int lrh_wideband_limiter(lrh_ctx *c, const lrh_sellim *par, int fft2_too)
   c->wl_on = true; c->wl_fft2 = fft2_too != 0; c->wl_cnt1 = 0; c->wl_cnt2 = 0;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_get_liminfo_amplitude_factor(lrh_ctx *c, float *f)
-{
+try {
   LRH_ENTER(c);
   if (!c || !f) return LRH_EINVAL;
   if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
@@ -1043,8 +1120,9 @@ int lrh_get_liminfo_amplitude_factor(lrh_ctx *c, float *f)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_set_liminfo_amplitude_factor(lrh_ctx *c, float f)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -1053,8 +1131,9 @@ int lrh_set_liminfo_amplitude_factor(lrh_ctx *c, float f)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_get_liminfo(lrh_ctx *c, float *dst)
-{
+try {
   LRH_ENTER(c);
   if (!c || !dst) return LRH_EINVAL;
   if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
@@ -1062,10 +1141,11 @@ int lrh_get_liminfo(lrh_ctx *c, float *dst)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---- linear ("clever") blanker tables (include/linrad_hip.h; init_blanker's products, buf.c:1786-2057)
 int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -1100,10 +1180,11 @@ int lrh_set_blanker_tables(lrh_ctx *c, const lrh_blanker_tables *t)
   c->clever_on = true;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---- spur subtraction (include/linrad_hip.h): configuration and the control plane's hand-over
 int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra)
-{
+try {
   LRH_ENTER(c);
   // the ring the spurs live in (fftx of spur.c): the fft2 transforms, or -- second fft off, fft1_c's AFC branch (fft1.c:4196-4244) -- the fft1 transforms
   const bool second = c && c->cfg.second_fft_enable != 0;
@@ -1126,11 +1207,12 @@ int lrh_spur_config(lrh_ctx *c, int max_spurs, int speknum, const float *spectra
   c->spur_max = max_spurs; c->spur_speknum = speknum;
   return LRH_OK;
 }
+LRH_CATCH(c)
 // The search for new spurs on the resident power rows (include/linrad_hip.h): make_fft2 keeps spursearch_powersum over 3 spur_speknum
 // transforms and, with the next one, forms spursearch_spectrum and cleans it (fft2.c:673-699, spursub.c:40-175).  The cleanup runs on a
 // stream of its own behind the transform that completed the sums: it is one workgroup's serial walk, not main-stream work.
 int lrh_spur_search_config(lrh_ctx *c, int first_point, int last_point)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
@@ -1151,6 +1233,7 @@ int lrh_spur_search_config(lrh_ctx *c, int first_point, int last_point)
   c->ss_first = first_point; c->ss_last = last_point;
   return LRH_OK;
 }
+LRH_CATCH(c)
 // one new power row (transform `na` of the ring), behind whatever `src` has enqueued so far
 static int spur_search_row(lrh_ctx *c, int na, hipStream_t src)
 {
@@ -1179,7 +1262,7 @@ static int spur_search_row(lrh_ctx *c, int na, hipStream_t src)
   return LRH_OK;
 }
 int lrh_spur_search_get(lrh_ctx *c, float *spectrum, float *threshold, int *completed, int *sum_counter)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (!c->d_ss_sum) return fail(c, LRH_ESTATE, "lrh_spur_search_config first");
@@ -1190,6 +1273,7 @@ int lrh_spur_search_get(lrh_ctx *c, float *spectrum, float *threshold, int *comp
   if (sum_counter) *sum_counter = c->ss_counter;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // what k_spur / k_spur_acquire need from the context: the loop constants follow spur_speknum (buf.c:480, 1141-1170)
 static void spur_args(lrh_ctx *c, SpurArgs *out, int first_na, int batch)
@@ -1209,7 +1293,7 @@ static void spur_args(lrh_ctx *c, SpurArgs *out, int first_na, int batch)
 // store_new_spur + spur_phase_lock (spursub.c:619, 1247) on the resident spectra: the control plane names the seven bins, the device
 // takes the history, reads the frequency off it and closes the loop; one int comes back
 int lrh_spur_acquire(lrh_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !locked) return LRH_EINVAL;
   *locked = 0;
@@ -1225,8 +1309,9 @@ int lrh_spur_acquire(lrh_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
   if (res) { c->spur_n++; *locked = 1; }
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, const float *signal, const int *ind)
-{
+try {
   LRH_ENTER(c);
   if (!c || n < 0 || n > c->spur_max || (n && (!sp || !table || !signal || !ind))) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -1241,9 +1326,10 @@ int lrh_spur_set(lrh_ctx *c, int n, const lrh_spur *sp, const float *table, cons
   c->spur_n = n;
   return LRH_OK;
 }
+LRH_CATCH(c)
 // remove_spur / swap_spurs (spur.c:596-631, spursub.c:755): the control plane drops a spur or reorders the list; loop state and histories follow on the device
 int lrh_spur_permute(lrh_ctx *c, int n, const int *src)
-{
+try {
   LRH_ENTER(c);
   if (!c || n < 0 || n > c->spur_n || (n && !src)) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -1273,8 +1359,9 @@ int lrh_spur_permute(lrh_ctx *c, int n, const int *src)
   c->spur_n = n;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_spur_get(lrh_ctx *c, int max, lrh_spur *sp, int *n)
-{
+try {
   LRH_ENTER(c);
   if (!c || !sp || !n || max < 0) return LRH_EINVAL;
   *n = c->spur_n < max ? c->spur_n : max;
@@ -1284,9 +1371,10 @@ int lrh_spur_get(lrh_ctx *c, int max, lrh_spur *sp, int *n)
   }
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (y) c->h_yfac.assign(y, y + c->N1); else default_yfac(c);
@@ -1294,9 +1382,10 @@ int lrh_set_waterfall_yfac(lrh_ctx *c, const float *y)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !name || !dst) return LRH_EINVAL;
   const std::vector<float> *src = nullptr;
@@ -1312,9 +1401,10 @@ int lrh_get_table(lrh_ctx *c, const char *name, float *dst, int count)
   memcpy(dst, src->data(), 4 * (size_t)count);
   return count;
 }
+LRH_CATCH(c)
 
 int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
-{
+try {
   LRH_LOCK(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   off &= c->timf1_bytemask;
@@ -1325,10 +1415,11 @@ int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
   return LRH_OK;
 }
+LRH_CATCH(c)
 void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
-{
+try {
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
   // The workers' noted transforms (lrh_ctx::wparked) and the ones already issued read the ring: a copy that reaches into what they have read
   // since the last such wait -- once per lap of the ring, not once per block -- first has the noted ones issued and goes behind the main stream
@@ -1370,31 +1461,35 @@ int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
   c->in_pending = true;                                      // (the reader records the event behind the copies it needs: wait_for_input)
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_timf1_write_wait(lrh_ctx *c)
-{
+try {
   if (!c) return LRH_EINVAL;
   std::lock_guard<std::mutex> lk_in(c->mtx_in);
   hipSetDevice(c->cfg.device);
   if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_host_register(lrh_ctx *c, void *ptr, size_t bytes)
-{
+try {
   if (!c || !ptr || !bytes) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_host_unregister(lrh_ctx *c, void *ptr)
-{
+try {
   if (!c || !ptr) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipHostUnregister(ptr));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_bytes)
-{
+try {
   LRH_ENTER(c);
   if (!c || !src || packed_bytes < 0 || packed_bytes % 9 || (off & 15)) return LRH_EINVAL;
   if (!c->cfg.timf1_dword_input) return fail(c, LRH_ESTATE, "timf1_write_packed18 needs timf1_dword_input");
@@ -1411,6 +1506,7 @@ int lrh_timf1_write_packed18(lrh_ctx *c, const void *src, int off, int packed_by
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- fft1
 // Transforms launched by fft1_b workers on their own streams: whoever reads fft1_float next on the main stream waits for them.
@@ -1509,7 +1605,7 @@ static int wait_for_input(lrh_ctx *c, hipStream_t S)
 }
 
 int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
-{
+try {
   if (c && handle > 0 && handle < LRH_MAX_HANDLES && batch >= 1 && batch <= c->cfg.max_batch && c->worker_fast &&
       !c->corr_on && !c->fft1_big && !c->prof && !c->dbg_stamp && !c->in_dsp && !c->rec) {
     // a worker's call: noted, issued by the next reader of fft1_float (lrh_ctx::wparked)
@@ -1611,6 +1707,7 @@ int lrh_fft1_b(lrh_ctx *c, int handle, int timf1p_ref, int fft1_pa, int batch)
   }
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 static int launch_parked_fft1(lrh_ctx *c)
 {
@@ -1625,7 +1722,7 @@ static int launch_parked_fft1(lrh_ctx *c)
 }
 
 int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
-{
+try {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
@@ -1641,10 +1738,11 @@ int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
   HIPCHK(c, hipMemcpy(c->d_foldcorr, fc, bytes, hipMemcpyHostToDevice));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // fft1_c: power sums (fft1.c:4115-4171), counters (fft1.c:4507-4523), slow average (fft1.c:4526-4605)
 int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (!(c->ss_defer && c->f1_have)) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // parked sums behind a parked transform: make_timf2 decides
@@ -1691,10 +1789,11 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
   p->fft1_nb = (p->fft1_nb + batch) & c->fft1n_mask; p->fft1_pb = p->fft1_nb * 2 * N;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- timf2
 int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   // k_fft1w: the parked forward transform, the parked sums and this call's weak stream address the same transforms
@@ -1823,6 +1922,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
   }
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- blanker
 // second half of a blanker call: what follows the pulse search -- bookkeeping that needs the search's resume point, statistics, dumb blanker
@@ -1871,7 +1971,7 @@ static int clever_late_finish(lrh_ctx *c, lrh_ptrs *p)
   return rc;
 }
 int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   if (c->clv_wait) { const int rc_ = clever_late_finish(c, p); if (rc_) return rc_; }    // this call starts where that search stopped
@@ -2007,10 +2107,11 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
   }
   return blanker_tail(c, p, a, pbeg, nullptr, p->fft1_lowlevel_fraction, coupled);
 }
+LRH_CATCH(c)
 
 // ---- two coupled RF channels: see include/linrad_hip.h
 int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !count) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
@@ -2033,16 +2134,18 @@ int lrh_blanker_begin(lrh_ctx *c, const lrh_ptrs *p, int *count)
   *count = c->x_count;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_blanker_weak_span(lrh_ctx *c, size_t *count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !count) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   *count = c->x_count > 0 ? (size_t)c->xw_count : 0;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2 || !c->fin_pending) return fail(c, LRH_ESTATE, "no coupled blanker call to finish");
@@ -2050,6 +2153,7 @@ int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
   HIPCHK(c, launch_blanker(c->fin_args, c->cfg.timf2pow_size / 32, c->cur));
   return LRH_OK;
 }
+LRH_CATCH(c)
 static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
 {
   if (which == LRH_X_POL) { if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured"); *ptr = (float *)c->d_xpol; *cap = (size_t)4 * c->cfg.max_fft3n * c->Nm2; return LRH_OK; }
@@ -2064,14 +2168,15 @@ static int exchange_span(lrh_ctx *c, int which, float **ptr, size_t *cap)
   return LRH_OK;
 }
 int lrh_exchange_ptr(lrh_ctx *c, int which, void **device_ptr)
-{
+try {
   LRH_ENTER(c);
   if (!c || !device_ptr) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   *device_ptr = q; return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_exchange_read(lrh_ctx *c, int which, float *dst, size_t off, size_t count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !dst) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
@@ -2080,8 +2185,9 @@ int lrh_exchange_read(lrh_ctx *c, int which, float *dst, size_t off, size_t coun
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_exchange_write(lrh_ctx *c, int which, const float *src, size_t off, size_t count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !src) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
@@ -2090,9 +2196,10 @@ int lrh_exchange_write(lrh_ctx *c, int which, const float *src, size_t off, size
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
-{
+try {
   LRH_ENTER(c);
   if (!c || !st) return LRH_EINVAL;
   BlankState bs;
@@ -2107,10 +2214,11 @@ int lrh_get_blanker_state(lrh_ctx *c, lrh_blanker_state *st)
   st->last_call_fitted = bs.last_fitted; st->last_call_rejected = bs.last_rejected; st->clever_serial_calls = bs.clever_serial_calls;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- fft2
 int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   const int N = c->N2;
@@ -2237,10 +2345,11 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
   }
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // Two coupled channels (include/linrad_hip.h): the new transforms of the own channel go to their slot of LRH_X_BINS ...
 int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !at || !count || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
@@ -2255,10 +2364,11 @@ int lrh_fft2_xy_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
   *count = (size_t)batch * 2 * N;
   return LRH_OK;
 }
+LRH_CATCH(c)
 // ... and with the partner's slot in place: TWOCHAN_POWER per transform, fft2_xysum, and the waterfall lines that complete
 // within the batch (fft2.c:1622-1640, 1700-1815)
 int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !at || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
@@ -2285,10 +2395,11 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
   });
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- mix1
-int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) { LRH_LOCK(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; }
-int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) { LRH_ENTER(c); if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; }
+int lrh_set_mix1_selfreq(lrh_ctx *c, double fq) try { LRH_LOCK(c); if (!c) return LRH_EINVAL; c->ms.mix1_selfreq = fq; return LRH_OK; } LRH_CATCH(c)
+int lrh_get_mix1_state(lrh_ctx *c, lrh_mix1_state *st) try { LRH_ENTER(c); if (!c || !st) return LRH_EINVAL; *st = c->ms; return LRH_OK; } LRH_CATCH(c)
 
 // Tuning of one mix1 transform (what set_mix1_phases, mix1.c:781-861, decides; float branch -- the double branch belongs to
 // correlation mode).  The selected frequency splits into the fft bin the baseband block is cut around, the block-to-block phase
@@ -2493,7 +2604,7 @@ static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n
 }
 
 int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_fixed needs second_fft_enable");
@@ -2504,9 +2615,10 @@ int lrh_fft2_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
   p->fft2_nx = (p->fft2_nx + batch) & c->fft2n_mask;                          // mix1.c:992
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_fft2_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
   if (!c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft2_mix1_afc needs second_fft_enable");
@@ -2518,9 +2630,10 @@ int lrh_fft2_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
   p->fft2_nx = (p->fft2_nx + batch) & c->fft2n_mask;                          // mix1.c:931
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_fft1_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || !afc || !afc->mix1_fq_mid || !afc->mix1_fq_slope || !afc->mix1_fq_curv || !afc->mix1_fq_start || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_afc needs second_fft_enable == 0");
@@ -2531,9 +2644,10 @@ int lrh_fft1_mix1_afc(lrh_ctx *c, lrh_ptrs *p, int batch, lrh_afc *afc)
   p->fft1_px = (p->fft1_px + batch * 2 * c->N1) & c->fft1_mask;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->cfg.second_fft_enable) return fail(c, LRH_ESTATE, "fft1_mix1_fixed needs second_fft_enable == 0");
@@ -2543,10 +2657,11 @@ int lrh_fft1_mix1_fixed(lrh_ctx *c, lrh_ptrs *p, int batch)
   p->fft1_px = (p->fft1_px + batch * 2 * c->N1) & c->fft1_mask;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- fft3 / mix2
 int lrh_set_bg_filterfunc(lrh_ctx *c, const float *f)
-{
+try {
   if (!c || !f) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   LRH_ENTER(c);
@@ -2554,9 +2669,10 @@ int lrh_set_bg_filterfunc(lrh_ctx *c, const float *f)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
@@ -2571,10 +2687,11 @@ int lrh_make_fft3_all(lrh_ctx *c, lrh_ptrs *p, int batch)
   p->fft3_pa = (p->fft3_pa + batch * 2 * c->N3) & (c->cfg.max_fft3n * 2 * c->N3 - 1);   // fft3.c:797
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // two coupled channels (include/linrad_hip.h): polarisation transform of fft3_mix2, mix2.c:340-343, 377-380
 int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
@@ -2583,16 +2700,18 @@ int lrh_set_pol(lrh_ctx *c, float c1, float c2, float c3)
   c->pol_set = true;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_set_combine_weights(lrh_ctx *c, float wa_re, float wa_im, float wb_re, float wb_im)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (!c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
   c->pol_wa = make_float2(wa_re, wa_im); c->pol_wb = make_float2(wb_re, wb_im); c->pol_set = true;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
-{
+try {
   if (!c || !p || !count || batch < 1) return LRH_EINVAL;
   if (!c->N3 || !c->d_xpol) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (!c->pol_set) return fail(c, LRH_ESTATE, "lrh_set_pol / lrh_set_combine_weights first");
@@ -2607,10 +2726,11 @@ int lrh_mix2_pol_begin(lrh_ctx *c, const lrh_ptrs *p, int batch, size_t *count)
   *count = (size_t)4 * batch * c->Nm2;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // bg.mixer_mode = 2 (mix2.c:217-246): the FIR make_bg_filter derives from the filter function (baseb_graph.c:1560-1634), handed over like bg_filterfunc
 int lrh_set_basebraw_fir(lrh_ctx *c, const float *fir, int pts)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (!c->N3 || c->pol_set) return fail(c, LRH_ESTATE, "fft3 not configured, or a coherent combine is set (the FIR decimator is the one-channel form)");
@@ -2625,9 +2745,10 @@ int lrh_set_basebraw_fir(lrh_ctx *c, const float *fir, int pts)
   c->bbfir_pts = pts;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
-{
+try {
   if (!c || !p || batch < 1) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
@@ -2669,10 +2790,11 @@ int lrh_fft3_mix2(lrh_ctx *c, lrh_ptrs *p, int batch)
   p->timf3_py = (p->timf3_py + batch * 2 * c->M3) & c->timf3_mask;                      // mix2.c:2060
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // compute_timf2_powersum, wcw.c:80-138
 int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
-{
+try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
   const int blk = c->cfg.timf2_blockpower_block;
@@ -2690,6 +2812,7 @@ int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
   p->timf2_blockpower_pa = (p->timf2_blockpower_pa + n) & (c->cfg.timf2_blockpower_size - 1);
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- orchestration
 // The launches the one-round-late schedule still holds when lrh_wideband_dsp returns (blanker, fft2 + mix1 + narrowband tail of its
@@ -2809,7 +2932,7 @@ static void advance_fft1(lrh_ctx *c, lrh_ptrs *p, int B)     // caller-side poin
 
 // ---- correlation spectrum of two coupled channels (include/linrad_hip.h): fft1_corrsum, fft1_slowcorr, fft1_slowcorr_tot
 int lrh_set_correlation(lrh_ctx *c, int on)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
@@ -2824,9 +2947,10 @@ int lrh_set_correlation(lrh_ctx *c, int on)
   c->corr_on = true;
   return LRH_OK;
 }
-int lrh_get_slowcorr_tot_avgnum(lrh_ctx *c, int *n) { LRH_LOCK(c); if (!c || !n) return LRH_EINVAL; *n = c->slowcorr_tot_avgnum; return LRH_OK; }
+LRH_CATCH(c)
+int lrh_get_slowcorr_tot_avgnum(lrh_ctx *c, int *n) try { LRH_LOCK(c); if (!c || !n) return LRH_EINVAL; *n = c->slowcorr_tot_avgnum; return LRH_OK; } LRH_CATCH(c)
 int lrh_fft1_corr_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count)
-{
+try {
   LRH_ENTER(c);
   if (!c || !at || !count || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first");
@@ -2839,8 +2963,9 @@ int lrh_fft1_corr_begin(lrh_ctx *c, const lrh_ptrs *at, int batch, size_t *count
   *count = (size_t)batch * 2 * N;
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_fft1_corr_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !at || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first");
@@ -2854,15 +2979,17 @@ int lrh_fft1_corr_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
   c->slowcorr_tot_avgnum += a.nupd * a.avg;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 int lrh_set_exchange(lrh_ctx *c, lrh_exchange_fn fn, void *user)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   c->xfn = fn; c->xuser = user;
   return LRH_OK;
 }
+LRH_CATCH(c)
 // one exchange point: everything that fills the buffer is on the main stream by now; the caller's function puts the collective there too
 static int exchange(lrh_ctx *c, int which, int op, size_t count, const void *own = nullptr)
 {
@@ -2950,7 +3077,7 @@ static int dsp_coupled(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 }
 
 int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
-{
+try {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   LRH_LOCK(c);
   if (c->cfg.blanker_channels == 2) {
@@ -3252,14 +3379,15 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
   HIPCHK(c, hipEventRecord(c->ev_side, S2)); HIPCHK(c, hipStreamWaitEvent(S1, c->ev_side, 0));
   clv_guard.ok = true; return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- outputs
 static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait = true, int *ticket = nullptr);
 static int export_collect(lrh_ctx *c, int slot);
-int lrh_export_device_async(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice, false); }
+int lrh_export_device_async(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) try { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice, false); } LRH_CATCH(c)
 void *lrh_stream(lrh_ctx *c) { return c ? (void *)c->stream : nullptr; }
-int lrh_export(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost); }
-int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice); }
+int lrh_export(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) try { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost); } LRH_CATCH(c)
+int lrh_export_device(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt) try { return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToDevice); } LRH_CATCH(c)
 static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, hipMemcpyKind kind, bool wait, int *ticket)
 {
   if (ticket) *ticket = 0;
@@ -3346,20 +3474,22 @@ static int export_collect(lrh_ctx *c, int slot)
   return LRH_OK;
 }
 int lrh_export_begin(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, int *ticket)
-{
+try {
   if (!ticket) return LRH_EINVAL;
   return export_impl(c, ring, dst, off, cnt, hipMemcpyDeviceToHost, true, ticket);
 }
+LRH_CATCH(c)
 int lrh_export_end(lrh_ctx *c, int ticket)
-{
+try {
   if (!c || ticket < 0 || ticket > LRH_NOUT) return LRH_EINVAL;
   if (ticket == 0) return LRH_OK;
   if (!c->out_busy[ticket - 1]) return fail(c, LRH_ESTATE, "lrh_export_end: no read-back under this ticket");
   return export_collect(c, ticket - 1);
 }
+LRH_CATCH(c)
 
 int lrh_stage_wait(lrh_ctx *c, int stage)
-{
+try {
   if (!c || stage < 0 || stage >= LRH_STAGE_COUNT) return LRH_EINVAL;
   hipEvent_t ev = nullptr;
   { LRH_LOCK(c); if (c->stage_valid[stage]) ev = stage == LRH_STAGE_TIMF2 ? c->ev_timf2_done : c->ev_stage[stage]; }
@@ -3367,6 +3497,7 @@ int lrh_stage_wait(lrh_ctx *c, int stage)
   if (ev && hipEventSynchronize(ev) != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(stage)");
   return LRH_OK;
 }
+LRH_CATCH(c)
 static int stage_mark(lrh_ctx *c, int stage)          // behind the device work a stage call has just enqueued on c->cur (stage calls only, not inside lrh_wideband_dsp)
 {
   if (c->in_dsp || c->rec) return LRH_OK;
@@ -3377,7 +3508,7 @@ static int stage_mark(lrh_ctx *c, int stage)          // behind the device work 
 }
 
 int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float gain, float strong)
-{
+try {
   LRH_ENTER(c);
   if (!c || !dst || count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
   if (!count) return LRH_OK;
@@ -3392,13 +3523,14 @@ int lrh_export_timf2_net(lrh_ctx *c, float *dst, int timf2_pt, int count, float 
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 // NET_RXOUT_FFT1 (wcw.c:1024-1043, network.c:383-388): the transform as fft1_b leaves it, i.e. before fft1_c's filter correction.
 // The hot path applies that correction in k_fft1's store, so the ring never holds the bare transform; a sender of this stage
 // gets it recomputed from the timf1 ring into a staging buffer (the same kernels with a unit filter table; the mirror-image
 // step and the direction flip, which belong to fft1_b, included) -- one extra fft1 pass, only for installations that multicast
 // this stage.
 int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
-{
+try {
   LRH_ENTER(c);
   if (!c || !dst || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
@@ -3451,18 +3583,20 @@ int lrh_export_fft1_net(lrh_ctx *c, float *dst, int timf1p_ref, int batch)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // Issue what lrh_wideband_dsp still holds back from its last round (the one-round-late schedule kept across calls) without waiting for it:
 // afterwards everything the calls so far have produced is ordered on the context's stream, which is what a consumer chained on that stream
 // (lrh_stream: a collective, a torch ExternalStream) needs.  Every entry point that reads or changes results does this by itself.
 int lrh_flush(lrh_ctx *c)
-{
+try {
   LRH_ENTER(c);
   return c ? LRH_OK : LRH_EINVAL;
 }
+LRH_CATCH(c)
 
 int lrh_sync(lrh_ctx *c)
-{
+try {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
   { const int rc_ = join_handles(c); if (rc_) return rc_; }  // blocks the fft1_b workers have noted
@@ -3471,10 +3605,11 @@ int lrh_sync(lrh_ctx *c)
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
   return sellim_install(c, c->sel_seq);
 }
+LRH_CATCH(c)
 
-int lrh_timer_start(lrh_ctx *c) { LRH_ENTER(c); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; }
+int lrh_timer_start(lrh_ctx *c) try { LRH_ENTER(c); if (!c) return LRH_EINVAL; HIPCHK(c, hipEventRecord(c->t0, c->stream)); return LRH_OK; } LRH_CATCH(c)
 int lrh_timer_stop(lrh_ctx *c, float *ms)
-{
+try {
   LRH_ENTER(c);
   if (!c || !ms) return LRH_EINVAL;
   HIPCHK(c, hipEventRecord(c->t1, c->stream));
@@ -3482,15 +3617,17 @@ int lrh_timer_stop(lrh_ctx *c, float *ms)
   HIPCHK(c, hipEventElapsedTime(ms, c->t0, c->t1));
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_profile_enable(lrh_ctx *c, int on)
-{
+try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   prof_collect(c); c->prof = on != 0; c->prof_keep_schedule = on == 2; c->prof_tot.clear();
   return LRH_OK;
 }
+LRH_CATCH(c)
 int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *launches)
-{
+try {
   LRH_ENTER(c);
   if (!c || !kernel) return LRH_EINVAL;
   if (!strcmp(kernel, "host:mix1_phases")) { if (total_ms) *total_ms = c->host_ms_phases; if (launches) *launches = c->host_n_phases; return LRH_OK; }
@@ -3503,6 +3640,7 @@ int lrh_profile_get(lrh_ctx *c, const char *kernel, double *total_ms, long *laun
   if (launches) *launches = it == c->prof_tot.end() ? 0 : it->second.n;
   return LRH_OK;
 }
+LRH_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------- test signal
 static inline uint64_t splitmix64(uint64_t &x) { uint64_t z = (x += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
@@ -3523,7 +3661,7 @@ void lrh_synth_defaults(lrh_synth *s, int fft1_size, int channel)
 
 // Position-addressable: any (first_sample, nsamples) window of the same infinite sequence gives the same bytes.
 int lrh_synth_iq(const lrh_synth *s, int64_t first, int64_t n, int16_t *dst)
-{
+try {
   if (!s || !dst || n < 0 || s->ncarriers < 0 || s->ncarriers > 16 || s->fft_size <= 0) return LRH_EINVAL;
   const int64_t BLK = 4096;
   for (int64_t pos = first; pos < first + n;) {
@@ -3566,5 +3704,6 @@ int lrh_synth_iq(const lrh_synth *s, int64_t first, int64_t n, int16_t *dst)
   }
   return LRH_OK;
 }
+LRH_CATCH_NOCTX
 
 }  // extern "C"

@@ -7,6 +7,24 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# a fatal signal inside the native code prints the C stack of the thread it was raised on (liblinrad_hip's LRH_CRASH_TRACE handler, behind
+# pytest's faulthandler): the library reads the switch when it is loaded
+os.environ.setdefault("LRH_CRASH_TRACE", "1")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """which HIP / ROCr runtime files this process ended up with (torch bundles its own): gpurun_out/runtime_maps.txt"""
+    try:
+        with open("/proc/self/maps") as f:
+            libs = sorted({ln.split()[-1] for ln in f if " r-xp " in ln and any(k in ln for k in ("libamdhip64", "libhsa-runtime64", "liblinrad", "librccl"))})
+        if libs:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "runtime_maps.txt"), "w") as f:
+                f.write("\n".join(libs) + "\n")
+    except OSError:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
