@@ -75,7 +75,8 @@ using namespace lrh;
 // switch the library installs nothing.  (Round 5's GPU suite died of a SIGABRT raised on a thread of the HIP runtime with no message at all.)
 namespace {
 struct sigaction g_crash_prev[NSIG];
-void crash_write(const char *s) { if (write(2, s, strlen(s)) < 0) {} }
+int g_crash_fd[3] = {2, -1, -1};          // stderr, LRH_CRASH_TRACE_FD (pytest captures fd 2: its faulthandler writes to a duplicate of the real one, so do we), LRH_CRASH_TRACE_FILE
+void crash_write(const char *s) { for (int fd : g_crash_fd) if (fd >= 0 && write(fd, s, strlen(s)) < 0) {} }
 void crash_handler(int sig, siginfo_t *si, void *uc)
 {
   const struct sigaction prev = g_crash_prev[sig];
@@ -85,7 +86,7 @@ void crash_handler(int sig, siginfo_t *si, void *uc)
   snprintf(line, sizeof line, "\n=== liblinrad_hip crash trace: signal %d, thread %ld (process %d) ===\n", sig, (long)syscall(SYS_gettid), (int)getpid());
   crash_write(line);
   void *bt[48]; const int n = backtrace(bt, 48);
-  backtrace_symbols_fd(bt, n, 2);
+  for (int fd_ : g_crash_fd) if (fd_ >= 0) backtrace_symbols_fd(bt, n, fd_);
   const int fd = open("/proc/self/maps", O_RDONLY);              // where the runtime libraries sit (two HIP runtimes in one process is a finding of its own)
   if (fd >= 0) {
     static char buf[1 << 16]; size_t have = 0; ssize_t r;
@@ -108,6 +109,8 @@ struct CrashTraceInstall {
   CrashTraceInstall() {
     const char *e = getenv("LRH_CRASH_TRACE");
     if (!e || !atoi(e)) return;
+    if (const char *f = getenv("LRH_CRASH_TRACE_FD")) { const int fd = atoi(f); if (fd > 2 && fcntl(fd, F_GETFD) != -1) g_crash_fd[1] = fd; }
+    if (const char *f = getenv("LRH_CRASH_TRACE_FILE")) g_crash_fd[2] = open(f, O_WRONLY | O_CREAT | O_APPEND, 0644);
     void *warm[4]; backtrace(warm, 4);                             // loads libgcc's unwinder now, not inside the handler
     for (int sig : { SIGABRT, SIGSEGV, SIGBUS, SIGFPE, SIGILL }) {
       struct sigaction sa; memset(&sa, 0, sizeof sa);
@@ -117,6 +120,47 @@ struct CrashTraceInstall {
   }
 } g_crash_trace_install;
 }  // namespace
+
+// Device memory.  LRH_GUARD=1 (diagnostics; tests/test_gpu_stress.py): every allocation gets an address range of its own through the
+// virtual-memory calls, with an unmapped granule on either side and the buffer pushed against the upper one (16-byte steps), so that an
+// access past either end of a buffer is a page fault at the faulting kernel instead of a silent read of whatever the neighbour holds --
+// the pool's GPUs have no address sanitizer.  LRH_GUARD=2: the same without the 256 spare bytes dev_alloc adds.
+namespace {
+struct GuardRec { void *base; size_t va, mapped; hipMemGenericAllocationHandle_t h; };
+std::mutex g_guard_mtx; std::map<void *, GuardRec> g_guard;
+int guard_mode() { static const int m = getenv("LRH_GUARD") ? atoi(getenv("LRH_GUARD")) : 0; return m; }
+}
+static hipError_t lrh_dev_malloc(void **p, size_t bytes)
+{
+  if (!guard_mode()) return hipMalloc(p, bytes);
+  int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
+  hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+  size_t gran = 0; if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+  if (bytes == 0) bytes = 16;
+  GuardRec r; r.mapped = (bytes + gran - 1) / gran * gran; r.va = r.mapped + 2 * gran;
+  if ((e = hipMemAddressReserve(&r.base, r.va, gran, nullptr, 0)) != hipSuccess) return e;
+  if ((e = hipMemCreate(&r.h, r.mapped, &prop, 0)) != hipSuccess) { hipMemAddressFree(r.base, r.va); return e; }
+  char *lo = (char *)r.base + gran;
+  if ((e = hipMemMap(lo, r.mapped, 0, r.h, 0)) != hipSuccess) { hipMemRelease(r.h); hipMemAddressFree(r.base, r.va); return e; }
+  hipMemAccessDesc d; memset(&d, 0, sizeof d); d.location = prop.location; d.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(lo, r.mapped, &d, 1)) != hipSuccess) { hipMemUnmap(lo, r.mapped); hipMemRelease(r.h); hipMemAddressFree(r.base, r.va); return e; }
+  char *user = lo + r.mapped - (bytes + 15) / 16 * 16;
+  { std::lock_guard<std::mutex> lk(g_guard_mtx); g_guard[user] = r; }
+  *p = user;
+  return hipSuccess;
+}
+static hipError_t lrh_dev_free(void *p)
+{
+  if (!p) return hipSuccess;
+  GuardRec r; bool found = false;
+  { std::lock_guard<std::mutex> lk(g_guard_mtx); auto it = g_guard.find(p); if (it != g_guard.end()) { r = it->second; g_guard.erase(it); found = true; } }
+  if (!found) return hipFree(p);
+  hipDeviceSynchronize();
+  size_t gran = (r.va - r.mapped) / 2;
+  hipMemUnmap((char *)r.base + gran, r.mapped); hipMemRelease(r.h);
+  return hipMemAddressFree(r.base, r.va);
+}
 
 struct ProfEntry { double ms = 0; long n = 0; };
 struct ProfPending { std::string name; hipEvent_t e0, e1; };
@@ -499,9 +543,10 @@ static void wf_geometry(const lrh_ctx *c, int *hx, int *hp, int *wx, int *wp, in
 
 template <typename T> static int dev_alloc(lrh_ctx *c, T **p, size_t count, bool zero = true)
 {
-  hipError_t e = hipMalloc((void **)p, count * sizeof(T) + 256);
+  const size_t spare = guard_mode() == 2 ? 0 : 256;
+  hipError_t e = lrh_dev_malloc((void **)p, count * sizeof(T) + spare);
   if (e != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc", e);
-  if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + 256, c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
+  if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + spare, c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
   return LRH_OK;
 }
 template <typename T> static int upload(lrh_ctx *c, T *dst, const T *src, size_t count)
@@ -582,7 +627,7 @@ try {
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
-  for (void *p : dev) if (p) hipFree(p);
+  for (void *p : dev) if (p) lrh_dev_free(p);
   if (c->h_ph) hipHostFree(c->h_ph);
   if (c->h_sel_low) hipHostFree(c->h_sel_low);
   if (c->h_clv_out) hipHostFree(c->h_clv_out);
@@ -590,13 +635,13 @@ try {
   if (c->ev_amp) hipEventDestroy(c->ev_amp);
   if (c->ev_sel) hipEventDestroy(c->ev_sel);
   for (hipEvent_t e : c->ev_sel_slot) if (e) hipEventDestroy(e);
-  if (c->d_pack18) hipFree(c->d_pack18);
-  if (c->d_stamps) hipFree(c->d_stamps);
-  for (void *q_ : { (void *)c->d_spurs, (void *)c->d_spur_table, (void *)c->d_spur_signal, (void *)c->d_spur_touched, (void *)c->d_spur_spectra, (void *)c->d_spur_ind }) if (q_) hipFree(q_);
-  if (c->d_net) hipFree(c->d_net);
-  if (c->d_fft1net) hipFree(c->d_fft1net);
-  if (c->d_foldcorr) hipFree(c->d_foldcorr);
-  if (c->d_unitcorr) hipFree(c->d_unitcorr);
+  if (c->d_pack18) lrh_dev_free(c->d_pack18);
+  if (c->d_stamps) lrh_dev_free(c->d_stamps);
+  for (void *q_ : { (void *)c->d_spurs, (void *)c->d_spur_table, (void *)c->d_spur_signal, (void *)c->d_spur_touched, (void *)c->d_spur_spectra, (void *)c->d_spur_ind }) if (q_) lrh_dev_free(q_);
+  if (c->d_net) lrh_dev_free(c->d_net);
+  if (c->d_fft1net) lrh_dev_free(c->d_fft1net);
+  if (c->d_foldcorr) lrh_dev_free(c->d_foldcorr);
+  if (c->d_unitcorr) lrh_dev_free(c->d_unitcorr);
   for (int i = 0; i < LRH_NSTAGE; i++) if (c->ph_ev[i]) hipEventDestroy(c->ph_ev[i]);
   for (auto &p : c->prof_pend) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -1031,7 +1076,7 @@ static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
       const size_t cap = (size_t)c->N1 / q->liminfo_group_points + 8;
       if (c->sel_reg_cap < cap) {
         if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-        if (c->d_sel_reg) { (void)hipFree(c->d_sel_reg); c->d_sel_reg = nullptr; c->sel_reg_cap = 0; }
+        if (c->d_sel_reg) { (void)lrh_dev_free(c->d_sel_reg); c->d_sel_reg = nullptr; c->sel_reg_cap = 0; }
         const int rc = dev_alloc(c, &c->d_sel_reg, 3 * cap); if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->sel_reg_cap = cap;
@@ -1151,7 +1196,7 @@ try {
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_bt_refpulse, (void **)&c->d_bt_phasefunc, (void **)&c->d_bt_pulindex, (void **)&c->d_bln_flag, (void **)&c->d_bln_cand, (void **)&c->d_xweak, (void **)&c->d_tf_partner })
-    if (*q_) { hipFree(*q_); *q_ = nullptr; }
+    if (*q_) { lrh_dev_free(*q_); *q_ = nullptr; }
   c->clever_on = false;
   if (!t) return LRH_OK;
   const int rs = t->refpul_size, pw = c->cfg.blanker_pulsewidth;
@@ -1195,7 +1240,7 @@ try {
   c->spur_ff = second ? (float)c->M2 / (float)c->N2 : (float)c->M1 / (float)c->N1;
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   for (void **q_ : { (void **)&c->d_spurs, (void **)&c->d_spur_table, (void **)&c->d_spur_signal, (void **)&c->d_spur_touched, (void **)&c->d_spur_spectra, (void **)&c->d_spur_ind })
-    if (*q_) { hipFree(*q_); *q_ = nullptr; }
+    if (*q_) { lrh_dev_free(*q_); *q_ = nullptr; }
   c->spur_max = 0; c->spur_n = 0; c->spur_speknum = 0;
   if (!max_spurs) return LRH_OK;
   const size_t maxn = c->spur_maxn;
@@ -1217,7 +1262,7 @@ try {
   if (!c) return LRH_EINVAL;
   if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
   if (c->stream_ss) HIPCHK(c, hipStreamSynchronize(c->stream_ss));
-  for (float **q_ : { &c->d_ss_sum, &c->d_ss_spec_base, &c->d_ss_min, &c->d_ss_out }) if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  for (float **q_ : { &c->d_ss_sum, &c->d_ss_spec_base, &c->d_ss_min, &c->d_ss_out }) if (*q_) { lrh_dev_free(*q_); *q_ = nullptr; }
   c->ss_counter = 0; c->ss_completed = 0; c->ss_busy = false;
   if (first_point == 0 && last_point == 0) return LRH_OK;
   if (first_point < 0 || last_point >= c->spur_nx || last_point - first_point < 64) return LRH_EINVAL;
@@ -1496,9 +1541,9 @@ try {
   if ((long long)packed_bytes / 9 * 16 > c->cfg.timf1_bytes) return LRH_EINVAL;
   if (!packed_bytes) return LRH_OK;
   if ((size_t)packed_bytes > c->pack18_cap) {              // staging buffer for the packed bytes, grown on demand
-    if (c->d_pack18) hipFree(c->d_pack18);
+    if (c->d_pack18) lrh_dev_free(c->d_pack18);
     c->d_pack18 = nullptr; c->pack18_cap = 0;
-    if (hipMalloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(packed18 staging)");
+    if (lrh_dev_malloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(packed18 staging)");
     c->pack18_cap = packed_bytes;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_pack18, src, packed_bytes, hipMemcpyHostToDevice, c->stream));
@@ -1638,7 +1683,7 @@ try {
   Fft1Args a = fft1_args_of(c, timf1p_ref, fft1_pa, batch);
   const int C = a.chan_count;
   if (c->dbg_stamp) {                                     // diagnostics (LRH_STAMP=1, -DLRH_STAMP_BUILD): phase stamps of this launch to stderr
-    if (!c->d_stamps) HIPCHK(c, hipMalloc(&c->d_stamps, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long)));
+    if (!c->d_stamps) HIPCHK(c, lrh_dev_malloc((void **)&c->d_stamps, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 2 * LRH_STAMPS_PER_WG * sizeof(unsigned long long), c->cur));
     a.stamps = c->d_stamps;
   }
@@ -1660,7 +1705,7 @@ try {
     const size_t need = (size_t)batch * c->N1;
     if (c->fft1_scratch_cap[handle] < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      if (c->d_fft1_scratch[handle]) hipFree(c->d_fft1_scratch[handle]);
+      if (c->d_fft1_scratch[handle]) lrh_dev_free(c->d_fft1_scratch[handle]);
       c->d_fft1_scratch[handle] = nullptr; c->fft1_scratch_cap[handle] = 0;
       const int rc_ = dev_alloc(c, &c->d_fft1_scratch[handle], need, false); if (rc_) return rc_;
       c->fft1_scratch_cap[handle] = need;
@@ -1726,12 +1771,12 @@ try {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-  if (!fc) { if (c->d_foldcorr) hipFree(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
+  if (!fc) { if (c->d_foldcorr) lrh_dev_free(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
   if (c->cfg.timf1_real_input) return fail(c, LRH_ESTATE, "no I/Q mirror image with real samples (init_foldcorr is I/Q only, buf.c:1461)");
   const size_t bytes = sizeof(float2) * c->N1;
-  if (!c->d_foldcorr && hipMalloc((void **)&c->d_foldcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(foldcorr)");
+  if (!c->d_foldcorr && lrh_dev_malloc((void **)&c->d_foldcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(foldcorr)");
   if (!c->d_unitcorr) {
-    if (hipMalloc((void **)&c->d_unitcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(unit filter table)");
+    if (lrh_dev_malloc((void **)&c->d_unitcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(unit filter table)");
     std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
     HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), bytes, hipMemcpyHostToDevice));
   }
@@ -1825,7 +1870,7 @@ try {
     const size_t need = (size_t)batch * 2 * c->N1;
     if (c->timf2_scratch_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      if (c->d_timf2_scratch) hipFree(c->d_timf2_scratch);
+      if (c->d_timf2_scratch) lrh_dev_free(c->d_timf2_scratch);
       c->d_timf2_scratch = nullptr; c->timf2_scratch_cap = 0;
       const int rc_ = dev_alloc(c, &c->d_timf2_scratch, need, false); if (rc_) return rc_;
       c->timf2_scratch_cap = need;
@@ -1838,7 +1883,7 @@ try {
     const size_t need = (size_t)batch * 2 * c->N1;
     if (c->timf2_scratch_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
-      if (c->d_timf2_scratch) hipFree(c->d_timf2_scratch);
+      if (c->d_timf2_scratch) lrh_dev_free(c->d_timf2_scratch);
       c->d_timf2_scratch = nullptr; c->timf2_scratch_cap = 0;
       const int rc_ = dev_alloc(c, &c->d_timf2_scratch, need, false); if (rc_) return rc_;
       c->timf2_scratch_cap = need;
@@ -1863,7 +1908,7 @@ try {
     w.filtercorr_v = c->d_filtercorr_v; w.max_wg = (int)(c->ss_part_stride / (2 * (size_t)c->N1));
     static const bool v_stamps = getenv("LRH_FFT1V_EXP") && (atoi(getenv("LRH_FFT1V_EXP")) & 2);
     if (v_stamps) {
-      if (!c->d_stamps) HIPCHK(c, hipMalloc(&c->d_stamps, 64 * sizeof(unsigned long long)));
+      if (!c->d_stamps) HIPCHK(c, lrh_dev_malloc((void **)&c->d_stamps, 64 * sizeof(unsigned long long)));
       HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, 64 * sizeof(unsigned long long), c->cur));
       w.stamps = c->d_stamps;
     }
@@ -2024,7 +2069,7 @@ try {
     if (c->clv_cap < need) {
       HIPCHK(c, hipStreamSynchronize(c->cur));
       for (void **q_ : { (void **)&c->d_clv_start, (void **)&c->d_clv_ext, (void **)&c->d_clv_dbg, (void **)&c->d_clv_ctl, (void **)&c->d_clv_bk_pos, (void **)&c->d_clv_bk_pwr, (void **)&c->d_clv_bk_tf, (void **)&c->d_clv_bk_pwo, (void **)&c->d_clv_bk_ty })
-        if (*q_) { hipFree(*q_); *q_ = nullptr; }
+        if (*q_) { lrh_dev_free(*q_); *q_ = nullptr; }
       c->clv_cap = 0;
       const size_t cap = need + need / 4;
       const int maxr = (int)(cap / ca.gap) + 2;
@@ -2736,7 +2781,7 @@ try {
   if (!c->N3 || c->pol_set) return fail(c, LRH_ESTATE, "fft3 not configured, or a coherent combine is set (the FIR decimator is the one-channel form)");
   if (fir && (pts < 1 || !(pts & 1) || pts + pts / 2 > c->I3 + c->N3 / c->Nm2 + 1)) return LRH_EINVAL;   // the first FIR of a transform must not reach behind its samples
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_nb) HIPCHK(c, hipStreamSynchronize(c->stream_nb));
-  if (c->d_bbfir) { hipFree(c->d_bbfir); c->d_bbfir = nullptr; }
+  if (c->d_bbfir) { lrh_dev_free(c->d_bbfir); c->d_bbfir = nullptr; }
   c->bbfir_pts = 0;
   if (!fir) return LRH_OK;
   { const int rc_ = dev_alloc(c, &c->d_bbfir, pts, false); if (rc_) return rc_; }
@@ -2937,7 +2982,7 @@ try {
   if (!c) return LRH_EINVAL;
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (void **q_ : { (void **)&c->d_xspec, (void **)&c->d_corrsum, (void **)&c->d_slowcorr, (void **)&c->d_slowcorr_tot }) if (*q_) { hipFree(*q_); *q_ = nullptr; }
+  for (void **q_ : { (void **)&c->d_xspec, (void **)&c->d_corrsum, (void **)&c->d_slowcorr, (void **)&c->d_slowcorr_tot }) if (*q_) { lrh_dev_free(*q_); *q_ = nullptr; }
   c->corr_on = false; c->slowcorr_tot_avgnum = 0;
   if (!on) return LRH_OK;
   int rc;
@@ -3444,14 +3489,18 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     if (slot >= 0) {
       if (!c->stream_out) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
       if (!c->h_out[slot]) {
-        if (hipHostMalloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc(read-back slot)");
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
+        if (!c->ev_out_src[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming));
+        if (!c->ev_out_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
+        if (hipHostMalloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) { c->h_out[slot] = nullptr; return fail(c, LRH_ENOMEM, "hipHostMalloc(read-back slot)"); }
       }
       c->out_busy[slot] = true;
       hipError_t e_ = hipEventRecord(c->ev_out_src[slot], c->stream);
       if (e_ == hipSuccess) e_ = hipStreamWaitEvent(c->stream_out, c->ev_out_src[slot], 0);
       if (e_ == hipSuccess) e_ = hipMemcpyAsync(c->h_out[slot], (const char *)src + off * esz, cnt * esz, hipMemcpyDeviceToHost, c->stream_out);
       if (e_ == hipSuccess) e_ = hipEventRecord(c->ev_out_done[slot], c->stream_out);
+      // whatever is enqueued on the main stream from here on (by this or any other stage thread) may rewrite the span in place -- sums, a reused
+      // waterfall / sumsq slot, d_power2: it runs behind the copy, so the slot never holds torn or newer data
+      if (e_ == hipSuccess) e_ = hipStreamWaitEvent(c->stream, c->ev_out_done[slot], 0);
       if (e_ != hipSuccess) { c->out_busy[slot] = false; return fail(c, LRH_EDEVICE, "read-back", e_); }
       c->out_dst[slot] = dst; c->out_bytes[slot] = cnt * esz;
       if (ticket) { *ticket = slot + 1; return LRH_OK; }     // lrh_export_begin: the caller collects it with lrh_export_end
@@ -3513,9 +3562,9 @@ try {
   if (!c || !dst || count < 0 || count > c->cfg.timf2pow_size || (timf2_pt & 3)) return LRH_EINVAL;
   if (!count) return LRH_OK;
   if ((size_t)count > c->net_cap) {
-    if (c->d_net) hipFree(c->d_net);
+    if (c->d_net) lrh_dev_free(c->d_net);
     c->d_net = nullptr; c->net_cap = 0;
-    if (hipMalloc((void **)&c->d_net, (size_t)count * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(timf2 net staging)");
+    if (lrh_dev_malloc((void **)&c->d_net, (size_t)count * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(timf2 net staging)");
     c->net_cap = count;
   }
   HIPCHK(c, launch_timf2_net(c->d_timf2w, c->d_timf2s, c->timf2pow_mask, (timf2_pt & c->timf2_mask) / 4, count, gain, strong, c->d_net, c->stream));
@@ -3537,13 +3586,13 @@ try {
   int cap = 1; while (cap < batch) cap <<= 1;
   if (cap > c->fft1net_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->d_fft1net) hipFree(c->d_fft1net);
+    if (c->d_fft1net) lrh_dev_free(c->d_fft1net);
     c->d_fft1net = nullptr; c->fft1net_cap = 0;
-    if (hipMalloc((void **)&c->d_fft1net, (size_t)cap * c->N1 * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(fft1 net staging)");
+    if (lrh_dev_malloc((void **)&c->d_fft1net, (size_t)cap * c->N1 * sizeof(float2)) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(fft1 net staging)");
     c->fft1net_cap = cap;
   }
   if (!c->d_unitcorr) {
-    if (hipMalloc((void **)&c->d_unitcorr, sizeof(float2) * c->N1) != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc(unit filter table)");
+    if (lrh_dev_malloc((void **)&c->d_unitcorr, sizeof(float2) * c->N1) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(unit filter table)");
     std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
     HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), sizeof(float2) * c->N1, hipMemcpyHostToDevice));
   }
@@ -3563,7 +3612,7 @@ try {
     const size_t need = (size_t)batch * c->N1;
     if (c->fft1_scratch_cap[0] < need) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (c->d_fft1_scratch[0]) hipFree(c->d_fft1_scratch[0]);
+      if (c->d_fft1_scratch[0]) lrh_dev_free(c->d_fft1_scratch[0]);
       c->d_fft1_scratch[0] = nullptr; c->fft1_scratch_cap[0] = 0;
       const int rc_ = dev_alloc(c, &c->d_fft1_scratch[0], need, false); if (rc_) return rc_;
       c->fft1_scratch_cap[0] = need;

@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include "lrh_fft.hip.h"
 #include "lrh_kernels.hip.h"
+#pragma clang diagnostic ignored "-Winline-asm"   // the "m0" clobber of the index-register block below is deliberate (M0 is a reserved register: the note is all the warning says)
 
 namespace lrh {
 // =====================================================================================================
@@ -157,7 +158,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 32) void k_timf2_sd(Timf2Args a)
           const int k2 = (k0 + j) & 31;
           // A[k2] += v with the index register on source 0 and destination: the accumulators live in v[64:127]
           asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0,DST)\n\tv_add_f32 v64, v64, %3\n\tv_add_f32 v96, v96, %4\n\ts_set_gpr_idx_off"
-                       : "+{v[64:95]}"(Ar), "+{v[96:127]}"(Ai) : "s"(k2), "v"(v.x), "v"(v.y));      // (M0, which the index lives in, is the compiler's scratch register anyway)
+                       : "+{v[64:95]}"(Ar), "+{v[96:127]}"(Ai) : "s"(k2), "v"(v.x), "v"(v.y) : "m0");      // s_set_gpr_idx_on writes M0: declared, so the compiler keeps nothing live in it across the block
           if (j + 1 < len) w = cmul_v(w, g1);
         }
       }

@@ -25,8 +25,24 @@ def pytest_sessionfinish(session, exitstatus):
         pass
 
 
+import pytest  # noqa: E402
+
+
+@pytest.hookimpl(trylast=True)
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # pytest captures fd 2 while a test runs; its faulthandler plugin writes to a duplicate of the real stderr -- the library's crash trace goes
+    # to the same descriptor (and to a file the GPU box hands back)
+    try:
+        from _pytest.faulthandler import fault_handler_stderr_fd_key
+        os.environ["LRH_CRASH_TRACE_FD"] = str(config.stash[fault_handler_stderr_fd_key])
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        os.environ.setdefault("LRH_CRASH_TRACE_FILE", os.path.join(ROOT, "gpurun_out", "crash_trace.txt"))
+    except OSError:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
