@@ -657,6 +657,10 @@ def compact_line(out):
     for k in ("cpu_baseline_port", "cpu_baseline_reference_threads", "cpu_baseline_all_cores"):
         if out.get(k):
             line[k] = pick(out[k], ("value", "cores", "kind"))
+    if out.get("mode"):
+        line["mode"] = out["mode"][:160]
+    if out.get("stages"):
+        line["stage_us"] = {k: v.get("avg_us") for k, v in out["stages"].items()}      # average launch time per stage in the timed schedule (HIP events)
     line["realtime_factor"] = out.get("realtime_factor")
     line["event_ms_per_step"] = out.get("event_ms_per_step")
     if out.get("blanker"):
@@ -679,7 +683,7 @@ def compact_line(out):
     line["detail"] = "gpurun_out/bench_detail.json (stages, per-stage glue call tables, notes); also on stderr"
     txt = json.dumps(line, allow_nan=False)
     if len(txt) > LINE_LIMIT:                                # never again an unparseable line: drop the optional objects, largest first
-        for k in ("glue", "round_sweep", "realtime_factor", "cpu_baseline_all_cores", "cpu_baseline_reference_threads", "cpu_baseline_port", "blanker", "secondary", "full_rings"):
+        for k in ("glue", "round_sweep", "stage_us", "realtime_factor", "cpu_baseline_all_cores", "cpu_baseline_reference_threads", "cpu_baseline_port", "blanker", "secondary", "full_rings"):
             line.pop(k, None)
             txt = json.dumps(line, allow_nan=False)
             if len(txt) <= LINE_LIMIT:

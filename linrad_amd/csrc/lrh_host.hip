@@ -21,6 +21,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/syscall.h>
+#include <sys/stat.h>
 
 #include "../../include/linrad_hip.h"
 #include "lrh_kernels.hip.h"
@@ -74,6 +75,18 @@ using namespace lrh;
 // installed before (Python's faulthandler under pytest), so the native frames are the last thing in the log.  Diagnostics only: without the
 // switch the library installs nothing.  (Round 5's GPU suite died of a SIGABRT raised on a thread of the HIP runtime with no message at all.)
 namespace {
+// LRH_ALLOC_LOG=2: allocations / releases / context opens and closes go to a ring in memory instead of stderr (no change of timing); the crash
+// handler prints it, so a faulting address can be matched with the buffer -- live or released -- it lies in
+struct AllocRec { char op; const void *p; size_t bytes; };
+constexpr int ALLOC_RING = 1 << 15;
+AllocRec g_alloc_ring[ALLOC_RING]; std::atomic<unsigned> g_alloc_n{0};
+int alloc_log_mode() { static const int m = getenv("LRH_ALLOC_LOG") ? atoi(getenv("LRH_ALLOC_LOG")) : 0; return m; }
+void alloc_note(char op, const void *p, size_t bytes)
+{
+  const int m = alloc_log_mode();
+  if (m == 1) fprintf(stderr, "LRH_%s %p %zu\n", op == 'D' ? "ALLOC dev" : op == 'H' ? "ALLOC host" : op == 'd' ? "FREE dev" : op == 'h' ? "FREE host" : op == 'O' ? "OPEN ctx" : "CLOSE ctx", p, bytes);
+  else if (m == 2) { const unsigned i = g_alloc_n.fetch_add(1); g_alloc_ring[i % ALLOC_RING] = {op, p, bytes}; }
+}
 struct sigaction g_crash_prev[NSIG];
 int g_crash_fd[3] = {2, -1, -1};          // stderr, LRH_CRASH_TRACE_FD (pytest captures fd 2: its faulthandler writes to a duplicate of the real one, so do we), LRH_CRASH_TRACE_FILE
 void crash_write(const char *s) { for (int fd : g_crash_fd) if (fd >= 0 && write(fd, s, strlen(s)) < 0) {} }
@@ -85,6 +98,20 @@ void crash_handler(int sig, siginfo_t *si, void *uc)
   char line[160];
   snprintf(line, sizeof line, "\n=== liblinrad_hip crash trace: signal %d, thread %ld (process %d) ===\n", sig, (long)syscall(SYS_gettid), (int)getpid());
   crash_write(line);
+  { // what was last written to fd 2 when that is a regular file: pytest's capture file swallows the runtime's own last words
+    // ("Memory access fault by GPU node-..." of the ROCr fault handler) -- read them back through /proc
+    struct stat st_;
+    if (fstat(2, &st_) == 0 && S_ISREG(st_.st_mode) && st_.st_size > 0) {
+      const int f2 = open("/proc/self/fd/2", O_RDONLY);
+      if (f2 >= 0) {
+        static char tailbuf[4097];
+        const off_t from = st_.st_size > 4096 ? st_.st_size - 4096 : 0;
+        const ssize_t got = pread(f2, tailbuf, 4096, from);
+        if (got > 0) { tailbuf[got] = 0; for (int k = 1; k < 3; k++) if (g_crash_fd[k] >= 0) { if (write(g_crash_fd[k], "--- tail of the captured stderr ---\n", 36) < 0 || write(g_crash_fd[k], tailbuf, (size_t)got) < 0 || write(g_crash_fd[k], "\n--- end of captured stderr ---\n", 33) < 0) {} } }
+        close(f2);
+      }
+    }
+  }
   void *bt[48]; const int n = backtrace(bt, 48);
   for (int fd_ : g_crash_fd) if (fd_ >= 0) backtrace_symbols_fd(bt, n, fd_);
   const int fd = open("/proc/self/maps", O_RDONLY);              // where the runtime libraries sit (two HIP runtimes in one process is a finding of its own)
@@ -101,6 +128,11 @@ void crash_handler(int sig, siginfo_t *si, void *uc)
       have = strlen(ls); memmove(buf, ls, have + 1);
     }
     close(fd);
+  }
+  if (alloc_log_mode() == 2) {
+    const unsigned n = g_alloc_n.load(), first = n > ALLOC_RING ? n - ALLOC_RING : 0;
+    crash_write("allocation journal (D/H device/host allocation, d/h release, O/C context open/close):\n");
+    for (unsigned i = first; i < n; i++) { const AllocRec &r = g_alloc_ring[i % ALLOC_RING]; snprintf(line, sizeof line, "%c %p %zu\n", r.op, r.p, r.bytes); crash_write(line); }
   }
   crash_write("=== end of crash trace ===\n");
   signal(sig, SIG_DFL); raise(sig);
@@ -130,9 +162,21 @@ struct GuardRec { void *base; size_t va, mapped; hipMemGenericAllocationHandle_t
 std::mutex g_guard_mtx; std::map<void *, GuardRec> g_guard;
 int guard_mode() { static const int m = getenv("LRH_GUARD") ? atoi(getenv("LRH_GUARD")) : 0; return m; }
 }
+// LRH_POISON=1 (diagnostics; tests/test_gpu_stress.py): fresh device memory is filled with 0x7f bytes (floats 3.4e38, ints 2.1e9) before the
+// caller sees it -- a kernel that reads what nobody wrote then says so with a NaN / a wild index at once, instead of depending on what the
+// previous owner of the pages left behind (a fresh process mostly gets zeroes, the 150th context of a test session does not)
+static bool poison_on() { static const bool on = getenv("LRH_POISON") && atoi(getenv("LRH_POISON")); return on; }
+static hipError_t lrh_dev_malloc_raw(void **p, size_t bytes);
 static hipError_t lrh_dev_malloc(void **p, size_t bytes)
 {
-  if (!guard_mode()) return hipMalloc(p, bytes);
+  const hipError_t e_ = lrh_dev_malloc_raw(p, bytes);
+  if (e_ == hipSuccess && poison_on() && bytes) { hipMemset(*p, 0x7f, bytes); hipDeviceSynchronize(); }
+  return e_;
+}
+static bool alloc_log() { return alloc_log_mode() != 0; }   // diagnostics: every device allocation / release on stderr
+static hipError_t lrh_dev_malloc_raw(void **p, size_t bytes)
+{
+  if (!guard_mode()) { const hipError_t e_ = hipMalloc(p, bytes); if (alloc_log()) alloc_note('D', e_ == hipSuccess ? *p : nullptr, bytes); return e_; }
   int dev = 0; hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return e;
   hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -150,11 +194,21 @@ static hipError_t lrh_dev_malloc(void **p, size_t bytes)
   *p = user;
   return hipSuccess;
 }
+static hipError_t lrh_host_malloc(void **p, size_t bytes)
+{
+  const hipError_t e_ = hipHostMalloc(p, bytes);
+  if (e_ == hipSuccess && poison_on()) memset(*p, 0x7f, bytes);
+  if (alloc_log()) alloc_note('H', e_ == hipSuccess ? *p : nullptr, bytes);
+  return e_;
+}
+template <typename T> static hipError_t lrh_host_malloc(T **p, size_t bytes) { return lrh_host_malloc((void **)p, bytes); }
+static hipError_t lrh_host_free(void *p) { if (alloc_log()) alloc_note('h', p, 0); return hipHostFree(p); }
 static hipError_t lrh_dev_free(void *p)
 {
   if (!p) return hipSuccess;
   GuardRec r; bool found = false;
   { std::lock_guard<std::mutex> lk(g_guard_mtx); auto it = g_guard.find(p); if (it != g_guard.end()) { r = it->second; g_guard.erase(it); found = true; } }
+  if (alloc_log()) alloc_note('d', p, 0);
   if (!found) return hipFree(p);
   hipDeviceSynchronize();
   size_t gran = (r.va - r.mapped) / 2;
@@ -178,6 +232,7 @@ struct lrh_ctx {
   bool rd_any = false; long long rd_lo = 0, rd_span = 0;
   std::mutex mtx_w; bool worker_fast = true;   // the workers' calls take this small lock (wparked, rd_*) instead of the context's; LRH_WORKER_FAST=0: they launch themselves, on their own streams
   lrh_config cfg;
+  bool opening = false;       // inside lrh_open: dev_alloc's memsets are waited for once, before the tables go up
   int N1, I1, M1, N2, I2, M2, Nm, Im, Mm, mix1_n;
   int timf2_mode;
   int lowlevel_points = 0;   // liminfo[i]==0 count of the table in force (timf2.c:37-52)
@@ -546,7 +601,10 @@ template <typename T> static int dev_alloc(lrh_ctx *c, T **p, size_t count, bool
   const size_t spare = guard_mode() == 2 ? 0 : 256;
   hipError_t e = lrh_dev_malloc((void **)p, count * sizeof(T) + spare);
   if (e != hipSuccess) return fail(c, LRH_ENOMEM, "hipMalloc", e);
-  if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + spare, c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
+  // zeroed before anyone can see the pointer: the tables that follow go up with blocking copies on the null stream and the buffer's first kernels may
+  // run on any of the context's streams -- none of them is ordered behind a memset that is merely queued on the main stream (round 6: inside lrh_open
+  // one wait at the end covered it; the buffers made later -- spur state, blanker tables, scratch grown on demand -- had none)
+  if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + spare, c->stream); if (e == hipSuccess && !c->opening) e = hipStreamSynchronize(c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
   return LRH_OK;
 }
 template <typename T> static int upload(lrh_ctx *c, T *dst, const T *src, size_t count)
@@ -601,6 +659,7 @@ try {
     for (size_t i = 0; i < v.size() && i < 40; i++) fprintf(stderr, "  %-48s %7ld x %7.2f us = %8.3f ms\n", v[i].first.c_str(), v[i].second.n, v[i].second.ns * 1e-3 / v[i].second.n, v[i].second.ns * 1e-6);
     g_hostprof_sites.clear();
   }
+  if (alloc_log()) alloc_note('C', c, 0);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   if (c->stream_sel) { hipStreamSynchronize(c->stream_sel); hipStreamDestroy(c->stream_sel); }
@@ -618,7 +677,7 @@ try {
   if (c->ev_ss_in) hipEventDestroy(c->ev_ss_in);
   if (c->ev_ss_done) hipEventDestroy(c->ev_ss_done);
   for (int i = 0; i < 3; i++) { if (c->ev_f2c[i]) hipEventDestroy(c->ev_f2c[i]); if (c->ev_f2r[i]) hipEventDestroy(c->ev_f2r[i]); }
-  for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) hipHostFree(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
+  for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) lrh_host_free(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
   for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_ss_sum, c->d_ss_spec_base, c->d_ss_min, c->d_ss_out, c->d_bbfir, c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
@@ -628,9 +687,9 @@ try {
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
   for (void *p : dev) if (p) lrh_dev_free(p);
-  if (c->h_ph) hipHostFree(c->h_ph);
-  if (c->h_sel_low) hipHostFree(c->h_sel_low);
-  if (c->h_clv_out) hipHostFree(c->h_clv_out);
+  if (c->h_ph) lrh_host_free(c->h_ph);
+  if (c->h_sel_low) lrh_host_free(c->h_sel_low);
+  if (c->h_clv_out) lrh_host_free(c->h_clv_out);
   if (c->ev_clv) hipEventDestroy(c->ev_clv);
   if (c->ev_amp) hipEventDestroy(c->ev_amp);
   if (c->ev_sel) hipEventDestroy(c->ev_sel);
@@ -669,8 +728,9 @@ try {
   if (!ispow2(cfg->timf1_bytes) || !ispow2(cfg->max_fft1n) || !ispow2(cfg->fft1_sumsq_bufsize) || !ispow2(cfg->timf2pow_size) ||
       !ispow2(cfg->max_fft2n) || !ispow2(cfg->timf3_size) || (cfg->timf2_blockpower_block > 0 && !ispow2(cfg->timf2_blockpower_size)) || cfg->max_batch < 1 || cfg->wf_xpixels < 1 || cfg->wf_lines < 1) return LRH_EINVAL;
   lrh_ctx *c = new lrh_ctx();
+  if (alloc_log()) alloc_note('O', c, (size_t)cfg->fft1_n * 100 + cfg->fft2_n);
   memset(c->ph_ev, 0, sizeof c->ph_ev);
-  c->cfg = *cfg;
+  c->cfg = *cfg; c->opening = true;
   const int N1 = c->N1 = 1 << cfg->fft1_n, N2 = c->N2 = 1 << cfg->fft2_n;
   c->I1 = (int)(1 + interleave_ratio(cfg->fft1_sinpow) * N1); c->I1 &= 0xfffe;                           // buf.c:303-304
   if (cfg->second_fft_enable) {
@@ -840,11 +900,11 @@ try {
     A(dev_alloc(c, &c->d_bln_wbusy, (size_t)cfg->timf2pow_size / 64 + 64)); A(dev_alloc(c, &c->d_bln_wstate, 2 * ((size_t)cfg->timf2pow_size / LRH_BLN_WTILE + 2)));
   }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
-  if (rc == LRH_OK && hipHostMalloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
+  if (rc == LRH_OK && lrh_host_malloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   if (rc == LRH_OK && hipHostGetDevicePointer(&c->h_ph_dev, c->h_ph, 0) != hipSuccess) c->h_ph_dev = nullptr;
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
   if (rc == LRH_OK) {
-    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream); c->opening = false;
     A(upload(c, c->d_window1, win1.data(), win1.size())); A(upload(c, c->d_invwin1, inv1.data(), N1));
     if (real1) {                               // k_fft1 stores the bare transform, k_realsplit applies the filter correction
       std::vector<float2> one(N1, make_float2(1.f, 0.f));
@@ -1043,7 +1103,7 @@ static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
 static int sellim_run(lrh_ctx *c, lrh_ptrs *p, const lrh_sellim *q, int which)
 {
   if (!c->h_sel_low) {
-    if (hipHostMalloc((void **)&c->h_sel_low, 3 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+    if (lrh_host_malloc((void **)&c->h_sel_low, 3 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_sel, hipEventDisableTiming));
     for (hipEvent_t &e : c->ev_sel_slot) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -2086,7 +2146,7 @@ try {
       // deferred schedule: the search is parked with the rest of the round's launches; the bookkeeping that depends on where it stops,
       // the statistics and the dumb blanker follow when the next blanker call (or the end of lrh_wideband_dsp) asks for the resume point
       if (!c->h_clv_out) {
-        if (hipHostMalloc((void **)&c->h_clv_out, 4 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
+        if (lrh_host_malloc((void **)&c->h_clv_out, 4 * sizeof(int)) != hipSuccess) return fail(c, LRH_ENOMEM, "hipHostMalloc");
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_clv, hipEventDisableTiming));
       }
       // liminfo_amplitude_factor as the limiter run BEFORE this round's left it (the serial order: search, then this round's limiter): the
@@ -3491,7 +3551,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
       if (!c->h_out[slot]) {
         if (!c->ev_out_src[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming));
         if (!c->ev_out_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
-        if (hipHostMalloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) { c->h_out[slot] = nullptr; return fail(c, LRH_ENOMEM, "hipHostMalloc(read-back slot)"); }
+        if (lrh_host_malloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) { c->h_out[slot] = nullptr; return fail(c, LRH_ENOMEM, "lrh_host_malloc(read-back slot)"); }
       }
       c->out_busy[slot] = true;
       hipError_t e_ = hipEventRecord(c->ev_out_src[slot], c->stream);

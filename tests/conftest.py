@@ -10,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # a fatal signal inside the native code prints the C stack of the thread it was raised on (liblinrad_hip's LRH_CRASH_TRACE handler, behind
 # pytest's faulthandler): the library reads the switch when it is loaded
 os.environ.setdefault("LRH_CRASH_TRACE", "1")
+os.environ.setdefault("LRH_ALLOC_LOG", "2")     # allocation journal in memory (no output unless the crash trace prints it): a faulting address can be matched with a buffer
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -19,8 +20,19 @@ def pytest_sessionfinish(session, exitstatus):
             libs = sorted({ln.split()[-1] for ln in f if " r-xp " in ln and any(k in ln for k in ("libamdhip64", "libhsa-runtime64", "liblinrad", "librccl"))})
         if libs:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            ident = []
+            try:                                            # which box / GPU this was: a fault that comes and goes is first of all correlated with that
+                import glob
+                import socket
+                ident.append("host " + socket.gethostname())
+                for fn in sorted(glob.glob("/sys/class/drm/card*/device/unique_id")):
+                    ident.append(fn.split("/")[4] + " unique_id " + open(fn).read().strip())
+                for fn in sorted(glob.glob("/sys/class/drm/card*/device/current_compute_partition")):
+                    ident.append(fn.split("/")[4] + " compute_partition " + open(fn).read().strip())
+            except Exception:  # noqa: BLE001
+                pass
             with open(os.path.join(ROOT, "gpurun_out", "runtime_maps.txt"), "w") as f:
-                f.write("\n".join(libs) + "\n")
+                f.write("\n".join(libs + ident) + "\n")
     except OSError:
         pass
 

@@ -120,7 +120,7 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     blanker decisions.  A sample whose power sits within float32 rounding of the limit may be cleared on one side only
     (`pwr > limit`, blank1.c:1030, is discontinuous); such flips must be few and borderline, and everything downstream is
     then compared on the transforms / blocks / lines that contain no flipped sample -- at the same tolerance, not a
-    loosened one.  Returns the measured errors (tests/test_gpu_parity_report.py publishes them)."""
+    loosened one.  Returns the measured errors (scripts/parity_report.py publishes them)."""
     N2 = 1 << cfg.fft2_n
     M2 = N2 // 2                                                       # sin^2 window: 50 % overlap
     Mm = (N2 >> cfg.mix1_bandwidth_reduction_n) // 2                   # timf3 samples per fft2 transform

@@ -213,7 +213,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(flags):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 2 and out["config"]["collective_world_size"] == 2 and out["value"] > 0
     if flags:
-        assert "coupled" in out["mode"] and out["stages"]
+        assert "coupled" in out["mode"] and out["stage_us"]
     else:
         assert "coherent combine" in out["mode"] and out["secondary"].get("value", 0) > 0, out["secondary"]
 
