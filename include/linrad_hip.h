@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LRH_ABI_VERSION 6      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
+#define LRH_ABI_VERSION 7      /* 2: lrh_fft1_b takes the worker handle; every entry point may be called from any thread.
                                   3: lrh_config.fft1_float_sparse / fft2_float_sparse (were reserved, 0 = as before); lrh_set_exchange, lrh_spur_acquire,
                                      lrh_set_correlation / lrh_fft1_corr_begin / _finish, lrh_flush, rings LRH_RING_FFT1_CORRSUM .. _SLOWCORR_TOT (additions); lrh_exchange_fn takes the caller's own span;
                                      lrh_sellim.sellim_par1 (the struct grew: struct_size tells a caller built against the older header apart)
@@ -657,6 +657,11 @@ int lrh_sync(lrh_ctx *ctx);
    LRH_STAGE_TIMF2: behind lrh_make_timf2's kernels; LRH_STAGE_FFT2: behind lrh_make_fft2's; LRH_STAGE_MIX1: behind lrh_fft2_mix1_* / lrh_fft1_mix1_*. */
 enum { LRH_STAGE_TIMF2 = 0, LRH_STAGE_FFT2 = 1, LRH_STAGE_MIX1 = 2, LRH_STAGE_COUNT = 3 };
 int lrh_stage_wait(lrh_ctx *ctx, int stage);
+/* ... and the same with `lag` calls left in flight (0 .. 3): returns once the device has finished the call `lag` before the newest one of that
+   stage, so the stage's thread enqueues call n while the device still works on calls n-1 .. n-lag (round 6: with lag 0 a thread alternates
+   between enqueueing and waiting and the device idles while the host enqueues; wcw.c:401-441 -- Linrad's own stage threads never wait for each other
+   beyond the ring pointers either).  The products a lagged caller reads back belong to the call it has waited for. */
+int lrh_stage_wait_lag(lrh_ctx *ctx, int stage, int lag);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int lrh_timer_start(lrh_ctx *ctx);

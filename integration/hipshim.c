@@ -70,8 +70,13 @@ static int hip_xgather(int which, size_t count);
 static void hip_spur_after_fft2(int na);
 static void hip_spur_resync(void);
 static void hip_open_failed(void);
-static int hip_ss_ticket[8], hip_ss_n;     /* read-backs hip_fft1_c has started and its next call collects (THREAD_TIMF2 / the wideband thread only: one caller) */
-static int hip_wf_ticket[6], hip_wf_n;     /* read-backs hip_make_fft2 has started and its next call collects (THREAD_SECOND_FFT only) */
+/* Calls a stage thread leaves in flight on the device (lrh_stage_wait_lag): with 0 the thread alternates between enqueueing a call and waiting for it
+   -- the device idles while the host enqueues and the host idles while the device works; with 1 it enqueues call n while call n-1 runs
+   (round 6; Linrad's own stage threads only ever wait on the ring pointers, wcw.c:401-441, 250-304).  HIPSHIM_LAG overrides (0 .. 2). */
+static int hip_lag = 1;
+/* read-backs hip_fft1_c has started, per generation: the call that follows `hip_lag` later collects them (THREAD_TIMF2 / the wideband thread only: one caller) */
+static int hip_ss_ticket[3][8], hip_ss_n[3], hip_ss_gen;
+static int hip_wf_ticket[3][6], hip_wf_n[3], hip_wf_gen;     /* the same for hip_make_fft2 (THREAD_SECOND_FFT only) */
 static void hip_ss_collect(void);
 static void hip_wf_collect(void);
 lrh_ctx *hip_context(void) { return hip_rx; }
@@ -130,7 +135,8 @@ int hip_open(void)
      accumulated when their thread comes round (hip_fft1_c), up to what the rings allow -- the library wants max_fft1n >= 2 max_batch and a
      batch of new points beside one transform in the timf2 ring */
   c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
-  { int cap = 64;
+  { int cap = 128;                                          /* (round 6: 64 before; the fft1 ring of a patched Linrad holds 256 transforms, half of it may be in one call) */
+    { const char *e = getenv("HIPSHIM_MAX_BATCH"); if (e && atoi(e) > 0) cap = atoi(e); }
     if (cap > max_fft1n / 2) cap = max_fft1n / 2;
     if (genparm[SECOND_FFT_ENABLE] != 0) while (cap > 1 && (long long)cap * fft1_new_points + fft1_size > (long long)timf2pow_size) cap >>= 1;
     if (ui.rx_rf_channels == 2) cap = c.max_batch;          /* two channels: the exchange buffers are sized by the batch; one hand-over at a time */
@@ -145,6 +151,8 @@ int hip_open(void)
   HC = ui.rx_rf_channels;
   hip_real2 = HC == 2 && (ui.rx_input_mode & IQ_DATA) == 0;
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
+  { const char *e = getenv("HIPSHIM_LAG"); hip_lag = e ? atoi(e) : 1; if (hip_lag < 0) hip_lag = 0; if (hip_lag > 2) hip_lag = 2; }
+  hip_ss_gen = hip_wf_gen = 0;
   hip_ctx[0] = hip_ctx[1] = NULL;
   for (int ch = 0; ch < HC; ch++) {
     if (HC == 2) {                                                 /* one context per channel, coupled (include/linrad_hip.h) */
@@ -201,12 +209,12 @@ static void hip_release(void)
   free(hip_sp); free(hip_spsrc); hip_sp = NULL; hip_spsrc = NULL; hip_spcap = 0;
   hip_spurs_on = 0; hip_spur_pnt = -1; hip_dev_spurs = 0;
 }
-static void hip_open_failed(void) { hip_ss_n = 0; hip_wf_n = 0; hip_release(); }
+static void hip_open_failed(void) { memset(hip_ss_n, 0, sizeof hip_ss_n); memset(hip_wf_n, 0, sizeof hip_wf_n); hip_release(); }
 
 void hip_close(void)
 {
   if (!hip_rx) return;
-  hip_ss_collect(); hip_wf_collect();
+  for (int g = 0; g < 3; g++) { hip_ss_collect(); hip_wf_collect(); }      /* every generation still out */
   hip_release();
 }
 
@@ -273,17 +281,18 @@ static void hip_afc_rows(int first_row, int rows)
   }
 }
 
-static void hip_ss_collect(void)
+static void hip_ss_collect(void)                             /* moves on to the oldest generation and brings it in; the caller's new read-backs go there */
 {
-  for (int i = 0; i < hip_ss_n; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[i]) != 0) lirerr(1466);
-  hip_ss_n = 0;
+  hip_ss_gen = (hip_ss_gen + 1) % (hip_lag + 1);
+  for (int i = 0; i < hip_ss_n[hip_ss_gen]; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[hip_ss_gen][i]) != 0) lirerr(1466);
+  hip_ss_n[hip_ss_gen] = 0;
 }
 static void hip_ss_fetch(lrh_ring ring, float *dst, size_t off, size_t cnt)
 {
   int t = 0;
-  if (hip_ss_n >= 8) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
+  if (hip_ss_n[hip_ss_gen] >= 8) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
   if (lrh_export_begin(hip_rx, ring, dst, off, cnt, &t) != 0) { lirerr(1466); return; }
-  if (t) hip_ss_ticket[hip_ss_n++] = t;
+  if (t) hip_ss_ticket[hip_ss_gen][hip_ss_n[hip_ss_gen]++] = t;
 }
 
 void hip_fft1_c(void)
@@ -295,7 +304,7 @@ void hip_fft1_c(void)
   old_pa = fft1_sumsq_pa;
   /* back-pressure: not further ahead of the device than one call of this stage (lrh_stage_wait, include/linrad_hip.h) -- what arrives
      meanwhile goes into this call */
-  for (int ch = 0; ch < HC; ch++) lrh_stage_wait(hip_ctx[ch], LRH_STAGE_TIMF2);
+  for (int ch = 0; ch < HC; ch++) lrh_stage_wait_lag(hip_ctx[ch], LRH_STAGE_TIMF2, HC == 1 ? hip_lag : 0);   /* (two channels: the exchanges go through host memory, one call at a time) */
   hip_ss_collect();                                          /* the previous call's spectra: on the host by now */
   /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
      make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
@@ -629,15 +638,16 @@ static void hip_spur_after_fft2(int na)
 
 static void hip_wf_collect(void)
 {
-  for (int i = 0; i < hip_wf_n; i++) if (lrh_export_end(hip_rx, hip_wf_ticket[i]) != 0) lirerr(1469);
-  hip_wf_n = 0;
+  hip_wf_gen = (hip_wf_gen + 1) % (hip_lag + 1);
+  for (int i = 0; i < hip_wf_n[hip_wf_gen]; i++) if (lrh_export_end(hip_rx, hip_wf_ticket[hip_wf_gen][i]) != 0) lirerr(1469);
+  hip_wf_n[hip_wf_gen] = 0;
 }
 static void hip_wf_fetch(int lag, lrh_ring ring, void *dst, size_t off, size_t cnt)
 {
   int t = 0;
-  if (!lag || hip_wf_n >= 6) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
+  if (!lag || hip_wf_n[hip_wf_gen] >= 6) { lrh_export(hip_rx, ring, dst, off, cnt); return; }
   if (lrh_export_begin(hip_rx, ring, dst, off, cnt, &t) != 0) { lirerr(1469); return; }
-  if (t) hip_wf_ticket[hip_wf_n++] = t;
+  if (t) hip_wf_ticket[hip_wf_gen][hip_wf_n[hip_wf_gen]++] = t;
 }
 
 void hip_make_fft2(void)
@@ -652,7 +662,7 @@ void hip_make_fft2(void)
     /* every transform the blanker has released samples for goes through in one call (second_fft comes back for each one it is owed:
        wcw.c:265-285 -- its test then fails after one pass), as far as the fft2 ring has room; not with spurs being tracked, whose loop
        state Linrad looks at after every transform */
-    lrh_stage_wait(hip_rx, LRH_STAGE_FFT2);
+    lrh_stage_wait_lag(hip_rx, LRH_STAGE_FFT2, hip_lag);
     hip_wf_collect();
     nf = 1 + (((timf2_pn2 - timf2_px + timf2_size) & timf2_mask) - 4 * fft2_size) / timf2_output_block;
     { const int room = max_fft2n - 1 - ((fft2_na - fft2_nx + max_fft2n) & fft2n_mask); if (nf > room) nf = room; }

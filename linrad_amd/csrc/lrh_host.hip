@@ -67,7 +67,7 @@ using namespace lrh;
 #define FFT2_WATERFALL_ZERO 0.012
 #define LRH_NSTAGE 4
 #define LRH_BLN_PARTIALS 256
-#define LRH_NOUT 16                 /* read-back slots (export_impl) */
+#define LRH_NOUT 32                 /* read-back slots (export_impl) */
 #define LRH_OUT_SLOT_BYTES (1u << 19)
 #define LRH_MAX_HANDLES 7          /* handle 0 = the caller's own thread; 1..6 = THREAD_FFT1B1..6 (MAX_FFT1_THREADS, thrdef.h:107; gpu_handle_number, wcw.c:500) */
 
@@ -401,6 +401,7 @@ struct lrh_ctx {
   // Read-backs of a caller that drives the stages from several threads (Linrad's stage threads through integration/hipshim.c): the copy goes to
   // a stream of its own behind an event on the main stream, into a page-locked slot, and the caller waits for it WITHOUT the context's lock --
   // the other stage threads go on enqueueing, and the wait covers what was queued up to the export, not what they add meanwhile.
+  bool out_order = true;            // LRH_OUT_ORDER=0 (A/B measurements only): later main-stream work is NOT held behind a read-back's copy
   bool out_ok = true;               // LRH_OUT_STREAM=0: read-backs on the main stream, waited for under the lock (as before round 5)
   void *out_dst[LRH_NOUT] = {}; size_t out_bytes[LRH_NOUT] = {};
   hipStream_t stream_out = nullptr; void *h_out[LRH_NOUT] = {}; bool out_busy[LRH_NOUT] = {}; hipEvent_t ev_out_src[LRH_NOUT] = {}, ev_out_done[LRH_NOUT] = {};
@@ -414,6 +415,9 @@ struct lrh_ctx {
   std::vector<ParkedW> wparked; int w_next_nb = -1; std::mutex mtx_evin;
   // lrh_stage_wait: the newest event behind each stage's device work, and whether one has been recorded
   hipEvent_t ev_stage[LRH_STAGE_COUNT] = {}; bool stage_valid[LRH_STAGE_COUNT] = {};
+  // ... and a short history of them (round 6): lrh_stage_wait_lag(stage, k) waits for the call k before the newest, so that a stage thread keeps k + 1
+  // calls in flight -- one being enqueued while the device works the other off (LRH_STAGE_LAG overrides the caller's k; 0 = the newest, as before)
+  hipEvent_t ev_stage_ring[LRH_STAGE_COUNT][4] = {}; unsigned stage_seq[LRH_STAGE_COUNT] = {}; int stage_lag_env = -1;
 };
 
 static int fail(lrh_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -440,6 +444,7 @@ static int flush_pending(lrh_ctx *c);
 static int upload_filtercorr(lrh_ctx *c);
 static void join_side_tail(lrh_ctx *c);
 static int stage_mark(lrh_ctx *c, int stage);
+static int stage_ring_mark(lrh_ctx *c, int stage);
 static int join_handles(lrh_ctx *c);
 static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten (by a writer ordered behind the last make_timf2's kernels)
 {
@@ -679,6 +684,7 @@ try {
   for (int i = 0; i < 3; i++) { if (c->ev_f2c[i]) hipEventDestroy(c->ev_f2c[i]); if (c->ev_f2r[i]) hipEventDestroy(c->ev_f2r[i]); }
   for (int i = 0; i < LRH_NOUT; i++) { if (c->h_out[i]) lrh_host_free(c->h_out[i]); if (c->ev_out_src[i]) hipEventDestroy(c->ev_out_src[i]); if (c->ev_out_done[i]) hipEventDestroy(c->ev_out_done[i]); }
   for (int i = 0; i < LRH_STAGE_COUNT; i++) if (c->ev_stage[i]) hipEventDestroy(c->ev_stage[i]);
+  for (int i = 0; i < LRH_STAGE_COUNT; i++) for (int k = 0; k < 4; k++) if (c->ev_stage_ring[i][k]) hipEventDestroy(c->ev_stage_ring[i][k]);
   for (hipEvent_t ev : { c->ev_st[0], c->ev_st[1], c->ev_blank2[0], c->ev_blank2[1], c->ev_f2done, c->ev_nb_ring[0], c->ev_nb_ring[1], c->ev_nb_ring[2], c->ev_nb_ring[3], c->ev_timf2_done, c->ev_sel_wait, c->ev_sel_wait2, c->ev_fft1, c->ev_timf2, c->ev_blank, c->ev_fft2, c->ev_side, c->ev_ps2, c->ev_sumsq[0], c->ev_sumsq[1], c->ev_tail, c->ev_timf2b }) if (ev) hipEventDestroy(ev);
   void *dev[] = { c->d_ss_sum, c->d_ss_spec_base, c->d_ss_min, c->d_ss_out, c->d_bbfir, c->d_mix2win, c->d_sin2win2, c->d_cos2win2, c->d_filtercorr_v, c->d_mixwin, c->d_sin2win, c->d_cos2win, c->d_window1, c->d_invwin1, c->d_window2, c->d_fqwin, c->d_yfac, c->d_filtercorr, c->d_tw1, c->d_tw2, c->d_twm,
                   c->d_pack_cur, c->d_pack_prev, c->d_wf_itab, c->d_timf1, c->d_fft1, c->d_sumsq, c->d_slowsum, c->d_timf2w, c->d_timf2s, c->d_pwr,
@@ -788,6 +794,8 @@ try {
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
   if (const char *e8 = getenv("LRH_OUT_STREAM")) c->out_ok = atoi(e8) != 0;
+  if (const char *e8 = getenv("LRH_OUT_ORDER")) c->out_order = atoi(e8) != 0;
+  if (const char *e8 = getenv("LRH_STAGE_LAG")) { c->stage_lag_env = atoi(e8); if (c->stage_lag_env > 3) c->stage_lag_env = 3; }
   if (const char *e8 = getenv("LRH_WORKER_FAST")) c->worker_fast = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
   if (const char *e6 = getenv("LRH_CLEVER_FIRST")) c->clv_first = atoi(e6);
@@ -2015,6 +2023,7 @@ try {
   c->pack_prev_stale = false;                            // (the table in d_pack_cur is the previous transform's from here on: no copy)
   HIPCHK(c, hipEventRecord(c->ev_timf2_done, c->cur)); c->timf2_done_valid = true;
   c->stage_valid[LRH_STAGE_TIMF2] = true;                // lrh_stage_wait(LRH_STAGE_TIMF2) waits on ev_timf2_done itself: no second record
+  if (!c->in_dsp && !c->rec) { const int rcr_ = stage_ring_mark(c, LRH_STAGE_TIMF2); if (rcr_) return rcr_; }
   if (read_alias || c->read_alias_wanted) { c->ev_fft1_read_cur = c->ev_timf2_done; c->fft1_read_valid = true; c->read_alias_wanted = false; }
   c->timf2_primed = true;
   const int low = c->lowlevel_points;
@@ -3560,7 +3569,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
       if (e_ == hipSuccess) e_ = hipEventRecord(c->ev_out_done[slot], c->stream_out);
       // whatever is enqueued on the main stream from here on (by this or any other stage thread) may rewrite the span in place -- sums, a reused
       // waterfall / sumsq slot, d_power2: it runs behind the copy, so the slot never holds torn or newer data
-      if (e_ == hipSuccess) e_ = hipStreamWaitEvent(c->stream, c->ev_out_done[slot], 0);
+      if (e_ == hipSuccess && c->out_order) e_ = hipStreamWaitEvent(c->stream, c->ev_out_done[slot], 0);
       if (e_ != hipSuccess) { c->out_busy[slot] = false; return fail(c, LRH_EDEVICE, "read-back", e_); }
       c->out_dst[slot] = dst; c->out_bytes[slot] = cnt * esz;
       if (ticket) { *ticket = slot + 1; return LRH_OK; }     // lrh_export_begin: the caller collects it with lrh_export_end
@@ -3597,11 +3606,15 @@ try {
 }
 LRH_CATCH(c)
 
-int lrh_stage_wait(lrh_ctx *c, int stage)
+int lrh_stage_wait(lrh_ctx *c, int stage) { return lrh_stage_wait_lag(c, stage, 0); }
+int lrh_stage_wait_lag(lrh_ctx *c, int stage, int lag)
 try {
-  if (!c || stage < 0 || stage >= LRH_STAGE_COUNT) return LRH_EINVAL;
+  if (!c || stage < 0 || stage >= LRH_STAGE_COUNT || lag < 0 || lag > 3) return LRH_EINVAL;
   hipEvent_t ev = nullptr;
-  { LRH_LOCK(c); if (c->stage_valid[stage]) ev = stage == LRH_STAGE_TIMF2 ? c->ev_timf2_done : c->ev_stage[stage]; }
+  { LRH_LOCK(c);
+    if (c->stage_lag_env >= 0) lag = c->stage_lag_env;
+    if (lag == 0) { if (c->stage_valid[stage]) ev = stage == LRH_STAGE_TIMF2 ? c->ev_timf2_done : c->ev_stage[stage]; }
+    else if (c->stage_seq[stage] > (unsigned)lag) ev = c->ev_stage_ring[stage][(c->stage_seq[stage] - 1 - lag) & 3]; }   // the call `lag` before the newest (none yet: nothing to wait for)
   // the event belongs to the context for its life; the thread that waits is the one that makes this stage's calls, so it is not re-recorded meanwhile
   if (ev && hipEventSynchronize(ev) != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(stage)");
   return LRH_OK;
@@ -3613,6 +3626,14 @@ static int stage_mark(lrh_ctx *c, int stage)          // behind the device work 
   if (!c->ev_stage[stage]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[stage], hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(c->ev_stage[stage], c->cur));
   c->stage_valid[stage] = true;
+  return stage_ring_mark(c, stage);
+}
+static int stage_ring_mark(lrh_ctx *c, int stage)     // the same point of the stream in the history lrh_stage_wait_lag reads (one more record: ~3 us)
+{
+  hipEvent_t &ev = c->ev_stage_ring[stage][c->stage_seq[stage] & 3];
+  if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(ev, c->cur));
+  c->stage_seq[stage]++;
   return LRH_OK;
 }
 

@@ -65,6 +65,8 @@ static inline int shim_no_unregister(lro_ctx *c, void *p) { (void)c; (void)p; re
 #define lrh_sync shim_no_wait        /* the oracle's calls are synchronous */
 static inline int shim_no_stage_wait(lro_ctx *c, int stage) { (void)c; (void)stage; return 0; }
 #define lrh_stage_wait shim_no_stage_wait
+static inline int shim_no_stage_wait_lag(lro_ctx *c, int stage, int lag) { (void)c; (void)stage; (void)lag; return 0; }
+#define lrh_stage_wait_lag shim_no_stage_wait_lag
 static inline int shim_export_begin(lro_ctx *c, lrh_ring ring, void *dst, size_t off, size_t cnt, int *ticket) { *ticket = 0; return lro_export(c, ring, dst, off, cnt); }
 static inline int shim_export_end(lro_ctx *c, int ticket) { (void)c; (void)ticket; return 0; }
 #define lrh_export_begin shim_export_begin

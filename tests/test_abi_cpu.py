@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.lrh_abi_version() == 6
+    assert lib.lrh_abi_version() == 7
 
 
 def test_graft_entry_build_accepts_the_library_it_built():

@@ -157,6 +157,11 @@ def fullsize_compare(h, o, cfg, blanker=True, fft3_n=0, sparse=0):
     # the decision exact arithmetic makes)
     rep["hip_vs_truth_flips"] = int(np.count_nonzero((h["pwr"] == 0) != (T_["pwr"] == 0)))
     assert rep["hip_vs_truth_flips"] <= max(len(tflips), 2), rep       # HIP departs from the truth no more often than the float32 oracle does
+    # every flip on its own line of the report: which side cleared, the power the other side kept, the limit, how far apart, and whom the float64 build agrees with
+    rep["flips"] = [{"sample": int(i), "hip_cleared": bool(h["pwr"][i] == 0), "oracle_cleared": bool(o["pwr"][i] == 0), "truth_cleared": bool(T_["pwr"][i] == 0),
+                     "power_kept": float(max(h["pwr"][i], o["pwr"][i], T_["pwr"][i])), "limit": limit,
+                     "margin_rel": float(abs(max(h["pwr"][i], o["pwr"][i], T_["pwr"][i]) - limit) / limit),
+                     "agrees_with_truth": "hip" if (h["pwr"][i] == 0) == (T_["pwr"][i] == 0) else "oracle"} for i in np.union1d(flips, tflips)[:16]]
     flips = np.union1d(flips, tflips)
     keep = np.ones(len(o["pwr"]), bool)
     keep[flips] = False
