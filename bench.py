@@ -198,7 +198,11 @@ def glue_rate(args, w, batches=(1, 2, 4, 8, 16), workers=3):
                 # a run lasts 0.1 - 0.3 s: the median of three (the same input, a new process each) is what is reported, all three are listed
                 reps = []
                 for _ in range(max(1, args.glue_repeats)):
-                    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, check=True).stdout
+                    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, check=True)
+                    out = pr.stdout
+                    for ln in pr.stderr.splitlines():        # HIPSHIM_PROF=1: the glue's own phase times
+                        if ln.startswith("HIPSHIM_PROF"):
+                            print(f"[{w['key']} fft1_batch_n {int(np.log2(b))}] {ln}", file=sys.stderr)
                     reps.append(json.loads(out.strip().splitlines()[-1]))
                 reps.sort(key=lambda q: q["samples"] / q["loop_seconds"])
                 r = reps[len(reps) // 2]

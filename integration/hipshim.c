@@ -66,14 +66,24 @@ static pthread_mutex_t hip_phasing_lock = PTHREAD_MUTEX_INITIALIZER;    /* hip_c
 extern float spur_search_threshold;       /* spursub.c:38 */
 static double hip_afc_selfreq = -2;       /* frequency around which the AFC's window of power spectra was last brought back */
 
+/* HIPSHIM_PROF=1 (diagnostics): where hip_fft1_c's time goes, printed by hip_close */
+#include <time.h>
+#include <stdio.h>
+static int hip_prof; static double hip_t[8]; static long hip_tn;
+static double hip_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#define HIP_T(i, stmt) do { if (hip_prof) { const double t0_ = hip_now(); stmt; hip_t[i] += hip_now() - t0_; } else { stmt; } } while (0)
+static void *hip_reg[8]; static int hip_nreg;     /* host arrays page-locked for direct read-backs (hip_pin) */
+static void hip_pin(void *p, size_t bytes) { if (p && bytes && hip_nreg < 8 && lrh_host_register(hip_ctx[0], p, bytes) == 0) hip_reg[hip_nreg++] = p; }
 static int hip_xgather(int which, size_t count);
 static void hip_spur_after_fft2(int na);
 static void hip_spur_resync(void);
 static void hip_open_failed(void);
 /* Calls a stage thread leaves in flight on the device (lrh_stage_wait_lag): with 0 the thread alternates between enqueueing a call and waiting for it
    -- the device idles while the host enqueues and the host idles while the device works; with 1 it enqueues call n while call n-1 runs
-   (round 6; Linrad's own stage threads only ever wait on the ring pointers, wcw.c:401-441, 250-304).  HIPSHIM_LAG overrides (0 .. 2). */
-static int hip_lag = 1;
+   (round 6; Linrad's own stage threads only ever wait on the ring pointers, wcw.c:401-441, 250-304).  Measured (profiles/r06_glue_ab.txt): configs[1]
+   gains 15 % at fft1_batch_n 4 with one call in flight, configs[2] loses as much -- the stage threads share one stream and one lock, and what the
+   timf2 thread no longer waits for the narrowband thread then does.  Default 0 (as round 5); HIPSHIM_LAG sets it (0 .. 2). */
+static int hip_lag = 0;
 /* read-backs hip_fft1_c has started, per generation: the call that follows `hip_lag` later collects them (THREAD_TIMF2 / the wideband thread only: one caller) */
 static int hip_ss_ticket[3][8], hip_ss_n[3], hip_ss_gen;
 static int hip_wf_ticket[3][6], hip_wf_n[3], hip_wf_gen;     /* the same for hip_make_fft2 (THREAD_SECOND_FFT only) */
@@ -135,7 +145,7 @@ int hip_open(void)
      accumulated when their thread comes round (hip_fft1_c), up to what the rings allow -- the library wants max_fft1n >= 2 max_batch and a
      batch of new points beside one transform in the timf2 ring */
   c.max_batch = gpu_fft1_batch_size > 0 ? gpu_fft1_batch_size : 1;
-  { int cap = 128;                                          /* (round 6: 64 before; the fft1 ring of a patched Linrad holds 256 transforms, half of it may be in one call) */
+  { int cap = 64;                                           /* (HIPSHIM_MAX_BATCH: 128 measured no faster, profiles/r06_glue_ab.txt -- a call carries 27-40 blocks whatever the cap) */
     { const char *e = getenv("HIPSHIM_MAX_BATCH"); if (e && atoi(e) > 0) cap = atoi(e); }
     if (cap > max_fft1n / 2) cap = max_fft1n / 2;
     if (genparm[SECOND_FFT_ENABLE] != 0) while (cap > 1 && (long long)cap * fft1_new_points + fft1_size > (long long)timf2pow_size) cap >>= 1;
@@ -151,8 +161,9 @@ int hip_open(void)
   HC = ui.rx_rf_channels;
   hip_real2 = HC == 2 && (ui.rx_input_mode & IQ_DATA) == 0;
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
-  { const char *e = getenv("HIPSHIM_LAG"); hip_lag = e ? atoi(e) : 1; if (hip_lag < 0) hip_lag = 0; if (hip_lag > 2) hip_lag = 2; }
+  { const char *e = getenv("HIPSHIM_LAG"); hip_lag = e ? atoi(e) : 0; if (hip_lag < 0) hip_lag = 0; if (hip_lag > 2) hip_lag = 2; }
   hip_ss_gen = hip_wf_gen = 0;
+  hip_prof = getenv("HIPSHIM_PROF") != NULL; memset(hip_t, 0, sizeof hip_t); hip_tn = 0;
   hip_ctx[0] = hip_ctx[1] = NULL;
   for (int ch = 0; ch < HC; ch++) {
     if (HC == 2) {                                                 /* one context per channel, coupled (include/linrad_hip.h) */
@@ -187,6 +198,15 @@ int hip_open(void)
   if (hip_real2) for (int ch = 0; ch < 2; ch++) { hip_deint[ch] = malloc((size_t)timf1_bytes / 2); if (!hip_deint[ch]) { hip_open_failed(); return LRH_ENOMEM; } lrh_host_register(hip_ctx[ch], hip_deint[ch], (size_t)timf1_bytes / 2); }
   else
   for (int ch = 0; ch < HC; ch++) lrh_host_register(hip_ctx[ch], timf1_char, (size_t)timf1_bytes); /* the timf1 arena, page-locked once; the shim never frees it (buf.c:2105) */
+  /* ... and the host arrays the display data come back into (round 6): a read-back whose destination is page-locked is written by the copy engine
+     itself -- no staging slot, no memcpy on the stage thread that asked for it (THREAD_TIMF2 spent more than half of hip_fft1_c in those).  A span the
+     runtime refuses (pages shared with a neighbour that is registered already) simply stays pageable: the library then stages as before. */
+  if (HC == 1) {
+    hip_nreg = 0;
+    hip_pin(fft1_sumsq, sizeof(float) * (size_t)fft1_sumsq_bufsize); hip_pin(fft1_slowsum, sizeof(float) * (size_t)fft1_size);
+    if (genparm[SECOND_FFT_ENABLE] != 0) { hip_pin(wg_waterf, sizeof(short int) * (size_t)wg_waterf_size); hip_pin(fft2_powersum_float, sizeof(float) * (size_t)fft2_size); }
+    hip_pin(timf3_float, sizeof(float) * (size_t)timf3_size);
+  }
   return 0;
 }
 
@@ -195,6 +215,8 @@ int hip_open(void)
 static void hip_release(void)
 {
   hip_clever_mode = 0;
+  if (hip_ctx[0]) while (hip_nreg > 0) lrh_host_unregister(hip_ctx[0], hip_reg[--hip_nreg]);
+  hip_nreg = 0;
   for (int ch = 0; ch < 2; ch++) if (hip_ctx[ch]) {
     lrh_timf1_write_wait(hip_ctx[ch]);
     lrh_host_unregister(hip_ctx[ch], hip_real2 && hip_deint[ch] ? (void *)hip_deint[ch] : (void *)timf1_char);    /* not registered yet: refused, harmless */
@@ -214,6 +236,7 @@ static void hip_open_failed(void) { memset(hip_ss_n, 0, sizeof hip_ss_n); memset
 void hip_close(void)
 {
   if (!hip_rx) return;
+  if (hip_prof && hip_tn) fprintf(stderr, "HIPSHIM_PROF hip_fft1_c: %ld calls, %.1f blocks each; per call: stage wait %.1f us, collect %.1f, lrh_fft1_c %.1f, sumsq fetches %.1f (%.1f of them), slowsum fetch %.1f\n", hip_tn, hip_t[5] / hip_tn, hip_t[0] / hip_tn, hip_t[1] / hip_tn, hip_t[2] / hip_tn, hip_t[3] / hip_tn, hip_t[6] / hip_tn, hip_t[4] / hip_tn);
   for (int g = 0; g < 3; g++) { hip_ss_collect(); hip_wf_collect(); }      /* every generation still out */
   hip_release();
 }
@@ -304,8 +327,9 @@ void hip_fft1_c(void)
   old_pa = fft1_sumsq_pa;
   /* back-pressure: not further ahead of the device than one call of this stage (lrh_stage_wait, include/linrad_hip.h) -- what arrives
      meanwhile goes into this call */
-  for (int ch = 0; ch < HC; ch++) lrh_stage_wait_lag(hip_ctx[ch], LRH_STAGE_TIMF2, HC == 1 ? hip_lag : 0);   /* (two channels: the exchanges go through host memory, one call at a time) */
-  hip_ss_collect();                                          /* the previous call's spectra: on the host by now */
+  HIP_T(0, for (int ch = 0; ch < HC; ch++) lrh_stage_wait_lag(hip_ctx[ch], LRH_STAGE_TIMF2, HC == 1 ? hip_lag : 0));   /* (two channels: the exchanges go through host memory, one call at a time) */
+  hip_tn++;
+  HIP_T(1, hip_ss_collect());                                          /* the previous call's spectra: on the host by now */
   /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
      make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
      whatever its size (INTEGRATION.md "Call size"), and the limiter looks at fft1_liminfo_cnt only after that loop (wcw.c:1124). */
@@ -323,7 +347,9 @@ void hip_fft1_c(void)
   q.fft1_liminfo_cnt = fft1_liminfo_cnt; q.fft1_sumsq_recalc = fft1_sumsq_recalc;
   { lrh_ptrs q0 = q;
     if (hip_spurs_on && genparm[SECOND_FFT_ENABLE] == 0) hip_spur_resync();   /* (the spur loop runs inside lrh_fft1_c then) */
+    { const double t0_ = hip_prof ? hip_now() : 0;
     for (int ch = 0; ch < HC; ch++) { q = q0; if (lrh_fft1_c(hip_ctx[ch], &q, n) != 0) { lirerr(1466); return; } }
+    if (hip_prof) { hip_t[2] += hip_now() - t0_; hip_t[5] += n; } }
     if (HC == 2 && fft1_correlation_flag == 1) {       /* X conj(Y) needs both channels' bins: the all-gather of the batch's transforms, through host memory */
       size_t cnt[2] = { 0, 0 };
       if (correlation_reset_flag != fft1corr_reset_flag) {   /* the operator's reset (fft1.c:4586): host arrays by Linrad's own code, the device's by switching the mode on again */
@@ -354,10 +380,10 @@ void hip_fft1_c(void)
         int k = ((q.fft1_sumsq_pa - pa) & fft1_sumsq_mask);
         if (pa + k > fft1_sumsq_bufsize) k = fft1_sumsq_bufsize - pa;
         if (k > slot) k = slot;
-        hip_ss_fetch(LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)k);
+        HIP_T(3, hip_ss_fetch(LRH_RING_FFT1_SUMSQ, &fft1_sumsq[pa], (size_t)pa, (size_t)k)); hip_t[6] += 1;
         pa = (pa + k) & fft1_sumsq_mask;
       }
-      hip_ss_fetch(LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1);
+      HIP_T(4, hip_ss_fetch(LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1));
       return;
     } else
     for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask) {

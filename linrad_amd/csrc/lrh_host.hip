@@ -401,9 +401,10 @@ struct lrh_ctx {
   // Read-backs of a caller that drives the stages from several threads (Linrad's stage threads through integration/hipshim.c): the copy goes to
   // a stream of its own behind an event on the main stream, into a page-locked slot, and the caller waits for it WITHOUT the context's lock --
   // the other stage threads go on enqueueing, and the wait covers what was queued up to the export, not what they add meanwhile.
-  bool out_order = true;            // LRH_OUT_ORDER=0 (A/B measurements only): later main-stream work is NOT held behind a read-back's copy
   bool out_ok = true;               // LRH_OUT_STREAM=0: read-backs on the main stream, waited for under the lock (as before round 5)
   void *out_dst[LRH_NOUT] = {}; size_t out_bytes[LRH_NOUT] = {};
+  std::vector<std::pair<char *, size_t>> host_regs;   // spans made page-locked through lrh_host_register: a read-back whose destination lies in one is copied straight there
+  int out_ring[LRH_NOUT] = {};       // which ring a slot's copy reads: a stage that rewrites that ring queues its work behind the copy (order_behind_readbacks)
   hipStream_t stream_out = nullptr; void *h_out[LRH_NOUT] = {}; bool out_busy[LRH_NOUT] = {}; hipEvent_t ev_out_src[LRH_NOUT] = {}, ev_out_done[LRH_NOUT] = {};
   // Transforms of the fft1_b workers in stage-call mode (handle >= 1, one call per dispatch of Linrad's wideband thread): a worker's call only
   // NOTES its blocks here (mtx_w; no HIP call); the next reader of fft1_float on the main stream -- lrh_fft1_c of the stage thread, which
@@ -451,6 +452,20 @@ static void pack_new_table(lrh_ctx *c)      // before d_pack_cur is overwritten 
   if (!c->pack_prev_stale) std::swap(c->d_pack_cur, c->d_pack_prev);
   c->pack_prev_stale = true;
 }
+// Read-backs that are still out (lrh_export_begin without its lrh_export_end yet, or another stage thread inside lrh_export with the lock released) read
+// their source on the copy stream.  A stage that is about to REWRITE such a ring in place -- the sums of fft1_c, a reused sumsq / waterfall slot,
+// fft2_powersum, d_power2 -- first queues the main stream behind those copies (advisor, round 5: torn or newer rows otherwise).  Per ring: a caller that
+// collects its read-backs before its stage's next call, as the glue does, never pays for it; holding EVERY later kernel behind every copy cost the
+// drop-in 15-30 % (profiles/r06_glue_ab.txt).  Inside lrh_wideband_dsp kernels go to several streams: its entry waits on the host instead.
+#define RB(ring) (1u << (ring))
+static int order_behind_readbacks(lrh_ctx *c, unsigned ring_mask)
+{
+  if (!c->stream_out || c->in_dsp) return LRH_OK;
+  for (int i = 0; i < LRH_NOUT; i++)
+    if (c->out_busy[i] && ((ring_mask >> c->out_ring[i]) & 1u)) { const hipError_t e_ = hipStreamWaitEvent(c->stream, c->ev_out_done[i], 0); if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, "hipStreamWaitEvent(read-back)", e_); }
+  return LRH_OK;
+}
+#define LRH_WRITES(c, mask) do { const int rco_ = order_behind_readbacks(c, (mask)); if (rco_) return rco_; } while (0)
 #define LRH_ENTER(c) LRH_LOCK(c); if ((c) && (c)->pend && !(c)->in_dsp) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; } \
   if ((c) && ((c)->st_pending || (c)->nb_join_pending) && !(c)->in_dsp) join_side_tail(c)
 // LRH_HOSTPROF=1 (diagnostics): host time per call site inside lrh_wideband_dsp, printed by lrh_close
@@ -794,7 +809,6 @@ try {
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
   if (const char *e8 = getenv("LRH_OUT_STREAM")) c->out_ok = atoi(e8) != 0;
-  if (const char *e8 = getenv("LRH_OUT_ORDER")) c->out_order = atoi(e8) != 0;
   if (const char *e8 = getenv("LRH_STAGE_LAG")) { c->stage_lag_env = atoi(e8); if (c->stage_lag_env > 3) c->stage_lag_env = 3; }
   if (const char *e8 = getenv("LRH_WORKER_FAST")) c->worker_fast = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
@@ -1409,6 +1423,7 @@ int lrh_spur_acquire(lrh_ctx *c, const lrh_ptrs *p, int pnt, int *locked)
 try {
   LRH_ENTER(c);
   if (!c || !p || !locked) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT2_FLOAT) | RB(LRH_RING_FFT1_FLOAT));
   *locked = 0;
   if (!c->spur_max) return fail(c, LRH_ESTATE, "lrh_spur_config first");
   if (c->spur_n >= c->spur_max || pnt < 1 || pnt + 9 > c->spur_nx) return LRH_EINVAL;
@@ -1589,6 +1604,7 @@ try {
   if (!c || !ptr || !bytes) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  c->host_regs.push_back({(char *)ptr, bytes});
   return LRH_OK;
 }
 LRH_CATCH(c)
@@ -1596,6 +1612,9 @@ int lrh_host_unregister(lrh_ctx *c, void *ptr)
 try {
   if (!c || !ptr) return LRH_EINVAL;
   LRH_ENTER(c);
+  // read-backs still on their way into the span first (the copy engine writes there)
+  for (int i = 0; i < LRH_NOUT; i++) if (c->out_busy[i] && c->ev_out_done[i]) hipEventSynchronize(c->ev_out_done[i]);
+  for (size_t i = 0; i < c->host_regs.size(); i++) if (c->host_regs[i].first == (char *)ptr) { c->host_regs.erase(c->host_regs.begin() + i); break; }
   HIPCHK(c, hipHostUnregister(ptr));
   return LRH_OK;
 }
@@ -1730,6 +1749,7 @@ try {
   }
   LRH_ENTER(c);
   if (!c || batch < 1 || batch > c->cfg.max_batch || handle < 0 || handle >= LRH_MAX_HANDLES) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT1_FLOAT));
   // handle 0: the caller's own thread (no_of_fft1b == 0, wcw.c:1036), on the main stream.  handle h >= 1: worker THREAD_FFT1Bh
   // (wcw.c:476-500), on its own stream -- behind everything already enqueued on the main stream (the earlier readers of the
   // ring slots it overwrites, the previous lap) and ahead of the next reader of fft1_float (join_handles).
@@ -1858,6 +1878,7 @@ int lrh_fft1_c(lrh_ctx *c, lrh_ptrs *p, int batch)
 try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT1_FLOAT) | RB(LRH_RING_FFT1_SUMSQ) | RB(LRH_RING_FFT1_SLOWSUM) | RB(LRH_RING_FFT1_CORRSUM) | RB(LRH_RING_FFT1_SLOWCORR) | RB(LRH_RING_FFT1_SLOWCORR_TOT));
   if (!(c->ss_defer && c->f1_have)) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // parked sums behind a parked transform: make_timf2 decides
   const int N = c->N1, avg1 = c->cfg.fft_avg1num, last = N - 1;
   if ((p->fft1_sumsq_counter + batch + avg1 - 1) / avg1 + c->cfg.fft_avg2num + 1 > c->cfg.fft1_sumsq_bufsize / N)
@@ -1909,6 +1930,7 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT1_FLOAT) | RB(LRH_RING_FFT1_SUMSQ) | RB(LRH_RING_FFT1_SLOWSUM) | RB(LRH_RING_TIMF2_FLOAT) | RB(LRH_RING_TIMF2_PWR));
   // k_fft1w: the parked forward transform, the parked sums and this call's weak stream address the same transforms
   const int nb_here = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask;
   const bool fused_any = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
@@ -2088,6 +2110,7 @@ int lrh_first_noise_blanker(lrh_ctx *c, lrh_ptrs *p)
 try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_TIMF2_FLOAT) | RB(LRH_RING_TIMF2_PWR));
   if (c->clv_wait) { const int rc_ = clever_late_finish(c, p); if (rc_) return rc_; }    // this call starts where that search stopped
   const int mask = c->timf2pow_mask;
   const int pbeg = p->timf2p_fit;
@@ -2262,6 +2285,7 @@ int lrh_blanker_finish(lrh_ctx *c, lrh_ptrs *p)
 try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_TIMF2_FLOAT) | RB(LRH_RING_TIMF2_PWR));
   if (c->cfg.blanker_channels != 2 || !c->fin_pending) return fail(c, LRH_ESTATE, "no coupled blanker call to finish");
   c->fin_pending = false;
   HIPCHK(c, launch_blanker(c->fin_args, c->cfg.timf2pow_size / 32, c->cur));
@@ -2335,6 +2359,7 @@ int lrh_make_fft2(lrh_ctx *c, lrh_ptrs *p, int batch)
 try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT2_FLOAT) | RB(LRH_RING_FFT2_POWER) | RB(LRH_RING_FFT2_POWERSUM) | RB(LRH_RING_WG_WATERF) | RB(LRH_RING_FFT2_XYPOWER) | RB(LRH_RING_FFT2_XYSUM));
   const int N = c->N2;
   Fft2Args a;
   a.timf2w = c->d_timf2w; a.timf2s = c->d_timf2s; a.mask = c->timf2pow_mask; a.px_first = p->timf2_px / 4; a.step = c->M2;
@@ -2485,6 +2510,7 @@ int lrh_fft2_xy_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 try {
   LRH_ENTER(c);
   if (!c || !at || batch < 1 || batch > c->cfg.max_fft2n) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_FFT2_XYPOWER) | RB(LRH_RING_FFT2_XYSUM) | RB(LRH_RING_WG_WATERF));
   if (c->cfg.blanker_channels != 2) return fail(c, LRH_ESTATE, "blanker_channels != 2");
   const int N = c->N2;
   XyArgs a;
@@ -2597,6 +2623,7 @@ static void afc_tables(lrh_ctx *c, lrh_afc *afc, int now, int newest, int mask)
 static int mix1_run(lrh_ctx *c, lrh_ptrs *p, int batch, const float2 *src, int n2, int first, int mask, int lim_hi,
                     lrh_afc *afc = nullptr, int na = 0)
 {
+  LRH_WRITES(c, RB(LRH_RING_TIMF3_FLOAT));
   if (src == c->d_fft1) { const int rc_ = join_handles(c); if (rc_) return rc_; }     // second fft off: the fft1 workers' (or a parked) transforms
   const int Nm = c->Nm, overlap = c->Im != 0, half = c->Mm, block2 = c->Mm;     // block in complex samples = rotated samples per transform
   lrh_mix1_state *s = &c->ms;
@@ -2791,6 +2818,7 @@ try {
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   LRH_ENTER(c);
+  LRH_WRITES(c, RB(LRH_RING_FFT3));
   Fft3Args a;
   a.timf3 = c->d_timf3; a.mask = c->cfg.timf3_size / 2 - 1; a.px_first = p->timf3_px / 2; a.step = c->M3;
   a.window = c->d_window3; a.tw = c->d_tw3; a.out = c->d_fft3;
@@ -2867,6 +2895,7 @@ try {
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   if (batch > c->cfg.max_fft3n) return LRH_EINVAL;
   LRH_ENTER(c);
+  LRH_WRITES(c, RB(LRH_RING_BASEB_RAW));
   if (c->d_bbfir) {                                        // bg.mixer_mode == 2
     Mix2FirArgs f;
     f.timf3 = c->d_timf3; f.mask = c->cfg.timf3_size / 2 - 1; f.py_first = p->timf3_py / 2; f.step = c->M3;
@@ -2911,6 +2940,7 @@ int lrh_compute_timf2_powersum(lrh_ctx *c, lrh_ptrs *p)
 try {
   LRH_ENTER(c);
   if (!c || !p) return LRH_EINVAL;
+  LRH_WRITES(c, RB(LRH_RING_TIMF2_BLOCKPOWER));
   const int blk = c->cfg.timf2_blockpower_block;
   if (blk <= 0 || (blk & 3)) return fail(c, LRH_ESTATE, "timf2_blockpower_block not configured");
   const int avail = (p->timf2_pn2 - p->timf2_pb + 4 * c->cfg.timf2pow_size) & c->timf2_mask;
@@ -3081,6 +3111,7 @@ LRH_CATCH(c)
 int lrh_fft1_corr_finish(lrh_ctx *c, const lrh_ptrs *at, int batch)
 try {
   LRH_ENTER(c);
+  LRH_WRITES(c, RB(LRH_RING_FFT1_CORRSUM) | RB(LRH_RING_FFT1_SLOWCORR) | RB(LRH_RING_FFT1_SLOWCORR_TOT));
   if (!c || !at || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   if (!c->corr_on) return fail(c, LRH_ESTATE, "lrh_set_correlation first");
   const int N = c->N1;
@@ -3194,6 +3225,8 @@ int lrh_wideband_dsp(lrh_ctx *c, lrh_ptrs *p, int nblocks, int batch)
 try {
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
   LRH_LOCK(c);
+  // read-backs still out: this call's kernels go to several streams -- the host waits for the copies (a few hundred KB each, started by an earlier call)
+  if (c->stream_out && !c->in_dsp) for (int i_ = 0; i_ < LRH_NOUT; i_++) if (c->out_busy[i_]) HIPCHK(c, hipEventSynchronize(c->ev_out_done[i_]));
   if (c->cfg.blanker_channels == 2) {
     if (!c->xfn) return fail(c, LRH_ESTATE, "two coupled channels: register the exchange function (lrh_set_exchange) or make the stage calls with the exchanges between them (lrh_blanker_begin)");
     if (c->pend) { const int rcf_ = flush_pending(c); if (rcf_) return rcf_; }
@@ -3534,6 +3567,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
       src = c->d_power2; total = (size_t)c->cfg.max_fft2n * c->N2;
       if (c->fft2_fused) {                               // the hot path keeps only the sums: |X|^2 of the requested span on demand
         if (off > total || cnt > total - off) return LRH_EINVAL;
+        LRH_WRITES(c, RB(LRH_RING_FFT2_POWER));
         HIPCHK(c, launch_power_of(c->d_fft2 + off, c->d_power2 + off, cnt, c->stream));
       }
       break;
@@ -3551,27 +3585,24 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     default: return LRH_EINVAL;
   }
   if (off + cnt > total) return LRH_EINVAL;
-  if (kind == hipMemcpyDeviceToHost && wait && cnt * esz <= LRH_OUT_SLOT_BYTES && cnt > 0 && !c->in_dsp && !c->rec && c->out_ok) {
+  bool direct = false;                                     // destination page-locked by the caller (lrh_host_register): the copy engine writes it itself, no staging slot, no memcpy, no size limit
+  if (kind == hipMemcpyDeviceToHost) for (const auto &r : c->host_regs) if ((char *)dst >= r.first && (char *)dst + cnt * esz <= r.first + r.second) { direct = true; break; }
+  if (kind == hipMemcpyDeviceToHost && wait && (direct || cnt * esz <= LRH_OUT_SLOT_BYTES) && cnt > 0 && !c->in_dsp && !c->rec && c->out_ok) {
     // page-locked slot, copy stream, wait outside the lock (see lrh_ctx::stream_out)
     int slot = -1;
     for (int i = 0; i < LRH_NOUT; i++) if (!c->out_busy[i]) { slot = i; break; }
     if (slot >= 0) {
       if (!c->stream_out) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
-      if (!c->h_out[slot]) {
-        if (!c->ev_out_src[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming));
-        if (!c->ev_out_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
-        if (lrh_host_malloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) { c->h_out[slot] = nullptr; return fail(c, LRH_ENOMEM, "lrh_host_malloc(read-back slot)"); }
-      }
-      c->out_busy[slot] = true;
+      if (!c->ev_out_src[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_src[slot], hipEventDisableTiming));
+      if (!c->ev_out_done[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_out_done[slot], hipEventDisableTiming));
+      if (!direct && !c->h_out[slot] && lrh_host_malloc(&c->h_out[slot], LRH_OUT_SLOT_BYTES) != hipSuccess) { c->h_out[slot] = nullptr; return fail(c, LRH_ENOMEM, "lrh_host_malloc(read-back slot)"); }
+      c->out_busy[slot] = true; c->out_ring[slot] = (int)ring;   // (a stage that rewrites this ring queues behind the copy: order_behind_readbacks)
       hipError_t e_ = hipEventRecord(c->ev_out_src[slot], c->stream);
       if (e_ == hipSuccess) e_ = hipStreamWaitEvent(c->stream_out, c->ev_out_src[slot], 0);
-      if (e_ == hipSuccess) e_ = hipMemcpyAsync(c->h_out[slot], (const char *)src + off * esz, cnt * esz, hipMemcpyDeviceToHost, c->stream_out);
+      if (e_ == hipSuccess) e_ = hipMemcpyAsync(direct ? dst : c->h_out[slot], (const char *)src + off * esz, cnt * esz, hipMemcpyDeviceToHost, c->stream_out);
       if (e_ == hipSuccess) e_ = hipEventRecord(c->ev_out_done[slot], c->stream_out);
-      // whatever is enqueued on the main stream from here on (by this or any other stage thread) may rewrite the span in place -- sums, a reused
-      // waterfall / sumsq slot, d_power2: it runs behind the copy, so the slot never holds torn or newer data
-      if (e_ == hipSuccess && c->out_order) e_ = hipStreamWaitEvent(c->stream, c->ev_out_done[slot], 0);
       if (e_ != hipSuccess) { c->out_busy[slot] = false; return fail(c, LRH_EDEVICE, "read-back", e_); }
-      c->out_dst[slot] = dst; c->out_bytes[slot] = cnt * esz;
+      c->out_dst[slot] = direct ? nullptr : dst; c->out_bytes[slot] = cnt * esz;
       if (ticket) { *ticket = slot + 1; return LRH_OK; }     // lrh_export_begin: the caller collects it with lrh_export_end
       lk_.unlock();
       return export_collect(c, slot);
@@ -3586,7 +3617,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
 static int export_collect(lrh_ctx *c, int slot)
 {
   const hipError_t e_ = hipEventSynchronize(c->ev_out_done[slot]);
-  if (e_ == hipSuccess) memcpy(c->out_dst[slot], c->h_out[slot], c->out_bytes[slot]);
+  if (e_ == hipSuccess && c->out_dst[slot]) memcpy(c->out_dst[slot], c->h_out[slot], c->out_bytes[slot]);
   { std::lock_guard<std::recursive_mutex> lk(c->mtx); c->out_busy[slot] = false; }
   if (e_ != hipSuccess) return fail(c, LRH_EDEVICE, "hipEventSynchronize(read-back)", e_);
   return LRH_OK;
