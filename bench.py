@@ -68,7 +68,7 @@ def measured_traffic(stage, wl):
     if "t" not in _TRAFFIC:
         _TRAFFIC["t"] = None
         try:
-            for fn in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
+            for fn in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):
                 f = os.path.join(ROOT, "profiles", fn)
                 if not os.path.exists(f):
                     continue

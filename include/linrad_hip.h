@@ -662,6 +662,10 @@ int lrh_stage_wait(lrh_ctx *ctx, int stage);
    between enqueueing and waiting and the device idles while the host enqueues; wcw.c:401-441 -- Linrad's own stage threads never wait for each other
    beyond the ring pointers either).  The products a lagged caller reads back belong to the call it has waited for. */
 int lrh_stage_wait_lag(lrh_ctx *ctx, int stage, int lag);
+/* Self-test of the C boundary (no device needed): raises a C++ exception inside the library -- kind 0 std::bad_alloc, 1 std::out_of_range,
+   2 a value not derived from std::exception -- and returns what every entry point returns in that case: LRH_EINTERNAL, never a call of
+   std::terminate (a C host reports it like any other code, lxsys.c:494-505).  Any other kind: LRH_OK. */
+int lrh_selftest_exception(int kind);
 
 /* ---- measurement hooks (bench.py): HIP events on the context's own stream ---- */
 int lrh_timer_start(lrh_ctx *ctx);

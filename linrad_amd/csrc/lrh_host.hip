@@ -638,6 +638,15 @@ static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" {
 
 int lrh_abi_version(void) { return LRH_ABI_VERSION; }
+// what the C boundary makes of an exception (tests/test_abi_cpu.py; needs no device): the same function-try-block every entry point ends in
+int lrh_selftest_exception(int kind)
+try {
+  if (kind == 0) throw std::bad_alloc();
+  if (kind == 1) { std::vector<int> v; return v.at(3); }      // std::out_of_range out of the standard library
+  if (kind == 2) throw 42;                                   // not derived from std::exception
+  return LRH_OK;
+}
+LRH_CATCH_NOCTX
 size_t lrh_sizeof(int which)
 try {
   static const size_t sz[] = { sizeof(lrh_config), sizeof(lrh_ptrs), sizeof(lrh_blanker_state), sizeof(lrh_blanker_tables), sizeof(lrh_mix1_state),
@@ -1013,6 +1022,7 @@ int lrh_set_filtercorr(lrh_ctx *c, const float *fc)
 try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
+  { const int rcj_ = join_handles(c); if (rcj_) return rcj_; }    // blocks the fft1_b workers have noted are transformed with the table they were handed over under
   if (fc) c->h_filtercorr.assign(fc, fc + 2 * c->N1); else default_filtercorr(c);
   c->f1_end_valid = false;
   return upload_filtercorr(c);
@@ -1023,6 +1033,7 @@ int lrh_set_ch2_phasing(lrh_ctx *c, float c1, float c2)
 try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
+  { const int rcj_ = join_handles(c); if (rcj_) return rcj_; }    // (as in lrh_set_filtercorr: noted blocks go out under the old phasing)
   c->ch2_c1 = c1; c->ch2_c2 = c2;
   c->f1_end_valid = false;                               // the table the fused kernel's partner would be recomputed with has changed
   return upload_filtercorr(c);
@@ -1858,6 +1869,7 @@ int lrh_set_foldcorr(lrh_ctx *c, const float *fc)
 try {
   if (!c) return LRH_EINVAL;
   LRH_ENTER(c);
+  { const int rcj_ = join_handles(c); if (rcj_) return rcj_; }
   HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
   if (!fc) { if (c->d_foldcorr) lrh_dev_free(c->d_foldcorr); c->d_foldcorr = nullptr; return LRH_OK; }
   if (c->cfg.timf1_real_input) return fail(c, LRH_ESTATE, "no I/Q mirror image with real samples (init_foldcorr is I/Q only, buf.c:1461)");

@@ -2,12 +2,13 @@
 # rocprofv3 evidence for one round: kernel-trace stats of the default bench run, and per workload the PMC passes
 # (FETCH_SIZE / WRITE_SIZE separately, never together with other trace domains).
 # usage (on the GPU box, via gpurun): scripts/profile_round.sh r02
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-glue > $OUT/bench_stats.json 2> $OUT/stats.log
+cp gpurun_out/bench_detail.json $OUT/bench_stats_detail.json 2>/dev/null   # (stdout carries the short line only: the stage table is in the detail file)
 python3 scripts/timeline.py $OUT/stats > $OUT/timeline.txt 2>&1
 echo "stats pass done: $(tail -c 300 $OUT/stats.log | tr '\n' ' ')"
 # The counter passes run the serial schedule: TCC counters are per device, so a side-stream kernel overlapping k_timf2 would be
@@ -24,6 +25,7 @@ pmc n1_14_n2_16_n3_12_b8192 --no-secondary
 pmc n1_14_n2_12_n3_0_b8192 --fft2-n 12 --fft3-n 0
 pmc n1_14_n2_16_n3_12_b8192_full --no-secondary --fft1-float full --fft2-float full     # what the Linrad glue opens (bench.py's full_rings object)
 python3 bench.py --steps 50 --warmup 5 > $OUT/bench_plain.json 2> $OUT/plain.log
+cp gpurun_out/bench_detail.json $OUT/bench_plain_detail.json 2>/dev/null
 # keep the merge small: per-dispatch traces can be large
 python3 scripts/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

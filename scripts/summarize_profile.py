@@ -92,12 +92,14 @@ for wdir in sorted(glob.glob(os.path.join(d, "pmc_fetch_*"))):
         bj = None
     workloads[wl] = {"kernels": kernels, "config": bj["config"]["workload"] if bj else None}
 for tag in ("bench_stats", "bench_plain"):
-    f = os.path.join(d, tag + ".json")
+    f = os.path.join(d, tag + "_detail.json")               # bench.py's full result (gpurun_out/bench_detail.json of that run); stdout has the short line
+    if not os.path.exists(f):
+        f = os.path.join(d, tag + ".json")
     if os.path.exists(f):
         try:
             j = json.loads(open(f).read().strip().splitlines()[-1])
             print(f"\n## {tag}: value {j['value']} {j['unit']}, ms/step {j['ms_per_step']}\n   roofline {j['roofline']}")
-            for k, v in j["stages"].items():
+            for k, v in (j.get("stages") or j.get("stage_us") or {}).items():
                 print("   ", k, v)
             if j.get("secondary"):
                 print("   secondary:", j["secondary"].get("value"), j["secondary"].get("config"), j["secondary"].get("roofline"))

@@ -86,3 +86,16 @@ def test_synth_is_position_addressable_and_seeded():
     k = int(np.argmax(spec))
     assert k in (16384 - 6000, 16384 - 6001, 16384 - 5999)      # strongest carrier of the SURVEY 8(d) signal: bin -6000
     assert np.abs(a).max() == 32767                             # impulses clip
+
+
+def test_a_cpp_exception_inside_the_library_comes_back_as_an_error_code():
+    """every extern "C" entry point is a function-try-block (round 5's GPU suite showed std::terminate reachable from lrh_make_timf2): the
+    self-test raises inside the library and the C caller sees LRH_EINTERNAL"""
+    import ctypes as C
+    from linrad_amd.abi import LRH_EINTERNAL
+    from linrad_amd.lib import hip_lib
+    lib = hip_lib()
+    lib.lrh_selftest_exception.argtypes, lib.lrh_selftest_exception.restype = [C.c_int], C.c_int
+    for kind in (0, 1, 2):
+        assert lib.lrh_selftest_exception(kind) == LRH_EINTERNAL == -6
+    assert lib.lrh_selftest_exception(3) == 0
