@@ -55,13 +55,17 @@ def counter_table(tag, ctr):
 
 
 print("# rocprofv3 summary for", d)
-f = first("stats/**/*kernel_stats.csv")
-if f:
-    print("\n## kernel-trace --stats (python3 bench.py --steps 10 --warmup 3 --no-cpu: the default run, both workloads)")
-    print("%-58s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
-    for r in csv.DictReader(open(f)):
-        print("%-58s %6s %12.1f %10.2f %6s" % (r["Name"][:58], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
-                                               float(r["AverageNs"]) / 1e3, r["Percentage"]))
+for sub, title in (("stats_headline", "python3 bench.py --steps 10 --warmup 3 --no-cpu --no-secondary: the HEADLINE workload alone, rounds of 8192 fft1 blocks -- "
+                                      "one launch shape per kernel, the averages to hold against roofline.avg_launch_us"),
+                   ("stats", "python3 bench.py --steps 10 --warmup 3 --no-cpu --no-glue --no-sweep: the default run's three workloads -- headline, configs[1] (k_fft2<12>), "
+                             "full_rings (k_fft1v<.., KEEP>; the same fft2 kernels with the spectrum store) -- share the fft2 / timf2 / blanker kernel names")):
+    f = first(sub + "/**/*kernel_stats.csv")
+    if f:
+        print(f"\n## kernel-trace --stats ({title})")
+        print("%-58s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+        for r in csv.DictReader(open(f)):
+            print("%-58s %6s %12.1f %10.2f %6s" % (r["Name"][:58], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
+                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
 workloads = {}
 for wdir in sorted(glob.glob(os.path.join(d, "pmc_fetch_*"))):
     wl = os.path.basename(wdir)[len("pmc_fetch_"):]
@@ -91,7 +95,7 @@ for wdir in sorted(glob.glob(os.path.join(d, "pmc_fetch_*"))):
     except Exception:  # noqa: BLE001
         bj = None
     workloads[wl] = {"kernels": kernels, "config": bj["config"]["workload"] if bj else None}
-for tag in ("bench_stats", "bench_plain"):
+for tag in ("bench_stats_headline", "bench_stats", "bench_plain"):
     f = os.path.join(d, tag + "_detail.json")               # bench.py's full result (gpurun_out/bench_detail.json of that run); stdout has the short line
     if not os.path.exists(f):
         f = os.path.join(d, tag + ".json")

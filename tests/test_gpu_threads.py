@@ -70,3 +70,58 @@ def test_worker_handles_from_python_threads():
     rx.fft1_c(4)                                            # a reader of fft1_float: joins the worker streams
     assert np.array_equal(rx.export(abi.RING_FFT1_FLOAT), want)
     assert rx.lib.lrh_fft1_b(rx.ctx, 7, 0, 0, 1) == abi.LRH_EINVAL
+
+
+def test_read_backs_into_page_locked_destinations_and_lagged_stage_waits():
+    """round 6: (a) a read-back whose destination lies in a span the caller has page-locked (lrh_host_register) is written by the copy engine
+    itself -- same bytes as the staged path, any size; (b) lrh_export_begin / _end tickets of several generations stay valid while later
+    stage calls are enqueued (the stage that rewrites the ring queues behind the copies still out); (c) lrh_stage_wait_lag returns for every
+    lag 0..3, with and without that many calls behind it, and refuses a lag outside that"""
+    import ctypes as C
+    from linrad_amd import abi
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config
+    cfg = chain_config(fft1_n=12, fft2_n=10, batch=4)
+    s = synth_defaults(1 << 12, 0)
+    iq = synth_iq(s, 0, cfg.timf1_bytes // 4)
+    rx = open_hip(cfg)
+    lib = rx.lib
+    lib.lrh_stage_wait_lag.argtypes, lib.lrh_stage_wait_lag.restype = [C.c_void_p, C.c_int, C.c_int], C.c_int
+    lib.lrh_export_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    lib.lrh_export_begin.restype = C.c_int
+    lib.lrh_export_end.argtypes, lib.lrh_export_end.restype = [C.c_void_p, C.c_int], C.c_int
+    lib.lrh_host_unregister.argtypes, lib.lrh_host_unregister.restype = [C.c_void_p, C.c_void_p], C.c_int
+    for lag in range(4):
+        assert lib.lrh_stage_wait_lag(rx.ctx, 0, lag) == 0          # nothing enqueued yet: returns at once
+    assert lib.lrh_stage_wait_lag(rx.ctx, 0, 4) == abi.LRH_EINVAL and lib.lrh_stage_wait_lag(rx.ctx, 9, 0) == abi.LRH_EINVAL
+    rx.timf1_write(iq)
+    n1 = rx.N1
+    rows, tickets = [], []
+    pinned = np.zeros(cfg.fft1_sumsq_bufsize, np.float32)           # (a): one page-locked array takes the whole sumsq ring in one copy
+    rx.host_register(pinned)
+    for call in range(6):
+        pa = rx.p.fft1_sumsq_pa
+        rx.fft1_b(4)
+        rx.fft1_c(4)
+        rx.make_timf2(4)
+        rx.first_noise_blanker()
+        assert lib.lrh_stage_wait_lag(rx.ctx, 0, call % 4) == 0
+        if rx.p.fft1_sumsq_pa != pa:                                # (b) a ticket per completed period, collected two calls later
+            dst = np.zeros(n1, np.float32)
+            t = C.c_int()
+            assert lib.lrh_export_begin(rx.ctx, abi.RING_FFT1_SUMSQ, dst.ctypes.data_as(C.c_void_p), pa, n1, C.byref(t)) == 0
+            rows.append((pa, dst)); tickets.append(t.value)
+        while len(tickets) > 2:
+            assert lib.lrh_export_end(rx.ctx, tickets.pop(0)) == 0
+    for t in tickets:
+        assert lib.lrh_export_end(rx.ctx, t) == 0
+    full = rx.export(abi.RING_FFT1_SUMSQ)
+    assert rows and np.any(full)
+    t = C.c_int()
+    assert lib.lrh_export_begin(rx.ctx, abi.RING_FFT1_SUMSQ, pinned.ctypes.data_as(C.c_void_p), 0, pinned.size, C.byref(t)) == 0 and t.value > 0
+    assert lib.lrh_export_end(rx.ctx, t.value) == 0
+    assert np.array_equal(pinned, full)
+    for pa, dst in rows:                                            # (24 blocks: no row has been overwritten by a later lap)
+        assert np.array_equal(dst, full[pa:pa + n1]) and np.any(dst)
+    assert lib.lrh_host_unregister(rx.ctx, pinned.ctypes.data_as(C.c_void_p)) == 0
+    rx.close()
