@@ -403,6 +403,11 @@ struct lrh_ctx {
   // the other stage threads go on enqueueing, and the wait covers what was queued up to the export, not what they add meanwhile.
   bool out_ok = true;               // LRH_OUT_STREAM=0: read-backs on the main stream, waited for under the lock (as before round 5)
   void *out_dst[LRH_NOUT] = {}; size_t out_bytes[LRH_NOUT] = {};
+  // Page-locked staging of the library's own (round 6).  Every copy between the device and memory the library does not own -- a caller's table, a
+  // std::vector, a stack variable, a numpy array -- goes through it: the HIP runtime never has to pin somebody else's heap pages for a copy.
+  // (The round-5 GPU suite died of "Memory access fault by GPU ... on address <a page of the process's malloc heap>" in the one golden case that
+  // uploads a small caller table with hipMemcpyAsync)  h_stage: under the context's lock; h_stage_in: the producer's, under mtx_in.
+  char *h_stage = nullptr, *h_stage_in = nullptr;
   std::vector<std::pair<char *, size_t>> host_regs;   // spans made page-locked through lrh_host_register: a read-back whose destination lies in one is copied straight there
   int out_ring[LRH_NOUT] = {};       // which ring a slot's copy reads: a stage that rewrites that ring queues its work behind the copy (order_behind_readbacks)
   hipStream_t stream_out = nullptr; void *h_out[LRH_NOUT] = {}; bool out_busy[LRH_NOUT] = {}; hipEvent_t ev_out_src[LRH_NOUT] = {}, ev_out_done[LRH_NOUT] = {};
@@ -627,9 +632,45 @@ template <typename T> static int dev_alloc(lrh_ctx *c, T **p, size_t count, bool
   if (zero) { e = hipMemsetAsync(*p, 0, count * sizeof(T) + spare, c->stream); if (e == hipSuccess && !c->opening) e = hipStreamSynchronize(c->stream); if (e != hipSuccess) return fail(c, LRH_EDEVICE, "hipMemset", e); }
   return LRH_OK;
 }
+#define LRH_STAGE_BYTES (1u << 20)
+// host -> device and device -> host through the context's page-locked staging buffer, in pieces of LRH_STAGE_BYTES; both return with the data in
+// place (the stream is waited for: the buffer is free again and the caller's memory may go away).  A source / destination inside a span the caller has
+// page-locked itself (lrh_host_register) is copied directly.
+static bool host_span_registered(const lrh_ctx *c, const void *p, size_t bytes)
+{
+  for (const auto &r : c->host_regs) if ((const char *)p >= r.first && (const char *)p + bytes <= r.first + r.second) return true;
+  return false;
+}
+static hipError_t stage_h2d(lrh_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st, char *stage = nullptr)
+{
+  if (!bytes) return hipSuccess;
+  if (!stage) stage = c->h_stage;
+  if (!stage || host_span_registered(c, src, bytes)) { const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); return e != hipSuccess ? e : hipStreamSynchronize(st); }
+  for (size_t off = 0; off < bytes; off += LRH_STAGE_BYTES) {
+    const size_t n = bytes - off < LRH_STAGE_BYTES ? bytes - off : LRH_STAGE_BYTES;
+    memcpy(stage, (const char *)src + off, n);
+    hipError_t e = hipMemcpyAsync((char *)dst + off, stage, n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+static hipError_t stage_d2h(lrh_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+  if (!bytes) return hipSuccess;
+  if (!c->h_stage || host_span_registered(c, dst, bytes)) { const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); return e != hipSuccess ? e : hipStreamSynchronize(st); }
+  for (size_t off = 0; off < bytes; off += LRH_STAGE_BYTES) {
+    const size_t n = bytes - off < LRH_STAGE_BYTES ? bytes - off : LRH_STAGE_BYTES;
+    hipError_t e = hipMemcpyAsync(c->h_stage, (const char *)src + off, n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    memcpy((char *)dst + off, c->h_stage, n);
+  }
+  return hipSuccess;
+}
 template <typename T> static int upload(lrh_ctx *c, T *dst, const T *src, size_t count)
 {
-  HIPCHK(c, hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(c, stage_h2d(c, dst, src, count * sizeof(T), c->stream));
   return LRH_OK;
 }
 static int ispow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -716,8 +757,12 @@ try {
                   c->d_ph, c->d_bst, c->d_partials, c->d_bln_tiles, c->d_bln_counts, c->d_bln_wbusy, c->d_bln_wstate, c->d_bt_refpulse, c->d_bt_phasefunc, c->d_bt_pulindex, c->d_bln_flag, c->d_bln_cand, c->d_sel_ftmp, c->d_sel_reg, c->d_sel_desired, c->d_sel_bigb, c->d_sel_bigg, c->d_clv_amp, c->d_clv_dbg, c->d_clv_start, c->d_clv_ext, c->d_clv_ctl, c->d_clv_bk_pos, c->d_clv_logged, c->d_clv_bk_pwr, c->d_clv_bk_tf, c->d_clv_bk_pwo, c->d_clv_bk_ty, c->d_liminfo, c->d_old_liminfo, c->d_sel_tmp, c->d_sel_wait, c->d_sel_st, c->d_ss_part, c->d_pwr_sum, c->d_xbuf, c->d_xstat, c->d_xweak, c->d_tf_partner, c->d_xspec, c->d_corrsum, c->d_slowcorr, c->d_slowcorr_tot, c->d_xbins, c->d_xypower, c->d_xysum, c->d_xysum_alt, c->d_xpol, c->d_tw2a, c->d_tw2b, c->d_fft2_scratch, c->d_tw1a, c->d_tw1b, c->d_timf2_scratch, c->d_fft1_scratch[0], c->d_fft1_scratch[1], c->d_fft1_scratch[2], c->d_fft1_scratch[3],
                   c->d_fft1_scratch[4], c->d_fft1_scratch[5], c->d_fft1_scratch[6], c->d_blockpower,
                   c->d_window3, c->d_bgfilt, c->d_tw3, c->d_twm2, c->d_fft3, c->d_baseb, c->d_mix2_scratch };
+  for (auto &r : c->host_regs) hipHostUnregister(r.first);   // spans the caller left page-locked (lrh_host_register without its lrh_host_unregister): the context is their owner of record
+  c->host_regs.clear();
   for (void *p : dev) if (p) lrh_dev_free(p);
   if (c->h_ph) lrh_host_free(c->h_ph);
+  if (c->h_stage) lrh_host_free(c->h_stage);
+  if (c->h_stage_in) lrh_host_free(c->h_stage_in);
   if (c->h_sel_low) lrh_host_free(c->h_sel_low);
   if (c->h_clv_out) lrh_host_free(c->h_clv_out);
   if (c->ev_clv) hipEventDestroy(c->ev_clv);
@@ -931,6 +976,7 @@ try {
     A(dev_alloc(c, &c->d_bln_wbusy, (size_t)cfg->timf2pow_size / 64 + 64)); A(dev_alloc(c, &c->d_bln_wstate, 2 * ((size_t)cfg->timf2pow_size / LRH_BLN_WTILE + 2)));
   }
   A(dev_alloc(c, &c->d_bst, 1)); A(dev_alloc(c, &c->d_partials, 2 * ((size_t)cfg->timf2pow_size / 1024 + cfg->timf2pow_size / 8192 + LRH_BLN_PARTIALS + 16)));
+  if (rc == LRH_OK && lrh_host_malloc(&c->h_stage, LRH_STAGE_BYTES) != hipSuccess) { c->h_stage = nullptr; rc = fail(c, LRH_ENOMEM, "hipHostMalloc(staging)"); }
   if (rc == LRH_OK && lrh_host_malloc((void **)&c->h_ph, LRH_NSTAGE * c->ph_stride * sizeof(float)) != hipSuccess) rc = fail(c, LRH_ENOMEM, "hipHostMalloc");
   if (rc == LRH_OK && hipHostGetDevicePointer(&c->h_ph_dev, c->h_ph, 0) != hipSuccess) c->h_ph_dev = nullptr;
   for (int i = 0; i < LRH_NSTAGE && rc == LRH_OK; i++) if (hipEventCreateWithFlags(&c->ph_ev[i], hipEventDisableTiming) != hipSuccess) rc = LRH_EDEVICE;
@@ -999,7 +1045,7 @@ static int upload_filtercorr(lrh_ctx *c)
       eff[2 * i] = a * c->ch2_c1 + b * c->ch2_c2;          // (a + jb)(c1 - j c2)
       eff[2 * i + 1] = b * c->ch2_c1 - a * c->ch2_c2;
     }
-  HIPCHK(c, hipMemcpyAsync(c->d_filtercorr, eff.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_filtercorr, eff.data(), 8 * c->N1, c->stream));
   std::vector<float> perm;
   if (c->d_filtercorr_v) {
     // k_fft1v: thread t ends its forward transform on the bins kk(t) + T j, j = 0..31 (T = N1 / 32; kk: Fft1vGeom / kk_of in lrh_kernels.hip);
@@ -1012,7 +1058,7 @@ static int upload_filtercorr(lrh_ctx *c)
         const size_t at = 2 * ((size_t)(j >> 1) * T + t) + (j & 1);
         perm[2 * at] = eff[2 * f]; perm[2 * at + 1] = eff[2 * f + 1];
       }
-    HIPCHK(c, hipMemcpyAsync(c->d_filtercorr_v, perm.data(), 8 * c->N1, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_filtercorr_v, perm.data(), 8 * c->N1, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
@@ -1062,8 +1108,8 @@ try {
   c->sel_table_pending = false;
   c->h_pack = pack;
   pack_new_table(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_pack_cur, c->h_pack.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_liminfo, liminfo, 4 * c->N1, hipMemcpyHostToDevice, c->stream));   // the table lrh_fft1_update_liminfo carries on from
+  HIPCHK(c, stage_h2d(c, c->d_pack_cur, c->h_pack.data(), 4 * c->N1, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_liminfo, liminfo, 4 * c->N1, c->stream));   // the table lrh_fft1_update_liminfo carries on from
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sel_pending = false;
   c->lowlevel_points = low;
@@ -1120,7 +1166,7 @@ static int sellim_args(lrh_ctx *c, const lrh_sellim *q, SellimArgs *out)
       c->h_sel_desired.assign(q->fft1_desired, q->fft1_desired + c->N1);
       if (!c->d_sel_desired) { const int rc = dev_alloc(c, &c->d_sel_desired, c->N1); if (rc) return rc; }
       if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-      HIPCHK(c, hipMemcpyAsync(c->d_sel_desired, c->h_sel_desired.data(), 4 * (size_t)c->N1, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, stage_h2d(c, c->d_sel_desired, c->h_sel_desired.data(), 4 * (size_t)c->N1, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       float tot = 0;
       for (int i = 0; i < c->N1; i++) tot += q->fft1_desired[i] * q->fft1_desired[i];
@@ -1254,7 +1300,7 @@ try {
   LRH_ENTER(c);
   if (!c || !f) return LRH_EINVAL;
   if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
-  HIPCHK(c, hipMemcpyAsync(f, (char *)c->d_bst + offsetof(BlankState, amp_factor), sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, f, (char *)c->d_bst + offsetof(BlankState, amp_factor), sizeof(float), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -1265,7 +1311,7 @@ try {
   if (!c) return LRH_EINVAL;
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   HIPCHK(c, hipStreamSynchronize(c->stream2)); if (c->stream_sel) HIPCHK(c, hipStreamSynchronize(c->stream_sel));
-  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, amp_factor), &f, sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, (char *)c->d_bst + offsetof(BlankState, amp_factor), &f, sizeof(float), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -1275,7 +1321,7 @@ try {
   LRH_ENTER(c);
   if (!c || !dst) return LRH_EINVAL;
   if (c->sel_table_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sel, 0));
-  HIPCHK(c, hipMemcpyAsync(dst, c->d_liminfo, 4 * c->N1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, dst, c->d_liminfo, 4 * c->N1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -1306,13 +1352,13 @@ try {
   if ((rc = dev_alloc(c, &c->d_bt_refpulse, nr)) || (rc = dev_alloc(c, &c->d_bt_phasefunc, (size_t)2 * rs)) || (rc = dev_alloc(c, &c->d_bt_pulindex, LRH_MAX_REFPULSES)) ||
       (rc = dev_alloc(c, &c->d_bln_flag, (size_t)c->cfg.timf2pow_size)) || (rc = dev_alloc(c, &c->d_bln_cand, (size_t)c->cfg.timf2pow_size / 64))) return rc;
   if (c->cfg.blanker_channels == 2 && ((rc = dev_alloc(c, &c->d_xweak, (size_t)2 * c->cfg.timf2pow_size)) || (rc = dev_alloc(c, &c->d_tf_partner, (size_t)c->cfg.timf2pow_size)))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_bt_refpulse, t->refpulse, 4 * nr, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_bt_phasefunc, t->phasefunc, 8 * (size_t)rs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_bt_refpulse, t->refpulse, 4 * nr, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_bt_phasefunc, t->phasefunc, 8 * (size_t)rs, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_bt_pulindex, t->pulindex, 4 * LRH_MAX_REFPULSES, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_bln_flag, 0, c->cfg.timf2pow_size, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_bln_cand, 0, c->cfg.timf2pow_size / 8, c->stream));
-  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, clever_limit), &t->clever_bln_limit, sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync((char *)c->d_bst + offsetof(BlankState, amp_factor), &t->liminfo_amplitude_factor, sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, (char *)c->d_bst + offsetof(BlankState, clever_limit), &t->clever_bln_limit, sizeof(unsigned int), c->stream));
+  HIPCHK(c, stage_h2d(c, (char *)c->d_bst + offsetof(BlankState, amp_factor), &t->liminfo_amplitude_factor, sizeof(float), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->bt = *t; c->bt.refpulse = nullptr; c->bt.phasefunc = nullptr; c->bt.pulindex = nullptr;
   c->clever_on = true;
@@ -1340,7 +1386,7 @@ try {
   int rc = LRH_OK;
   if ((rc = dev_alloc(c, &c->d_spurs, max_spurs)) || (rc = dev_alloc(c, &c->d_spur_table, max_spurs * maxn * 14)) || (rc = dev_alloc(c, &c->d_spur_signal, max_spurs * maxn * 2)) ||
       (rc = dev_alloc(c, &c->d_spur_ind, max_spurs * maxn)) || (rc = dev_alloc(c, &c->d_spur_touched, 2 * max_spurs + 2)) || (rc = dev_alloc(c, &c->d_spur_spectra, LRH_SPUR_SPECTRA))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_spur_spectra, spectra, sizeof(float) * LRH_SPUR_SPECTRA, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_spur_spectra, spectra, sizeof(float) * LRH_SPUR_SPECTRA, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->spur_max = max_spurs; c->spur_speknum = speknum;
   return LRH_OK;
@@ -1405,8 +1451,8 @@ try {
   if (!c) return LRH_EINVAL;
   if (!c->d_ss_sum) return fail(c, LRH_ESTATE, "lrh_spur_search_config first");
   HIPCHK(c, hipStreamSynchronize(c->stream_ss));
-  if (spectrum) HIPCHK(c, hipMemcpy(spectrum, c->d_ss_spec_base + 32 + c->ss_first, sizeof(float) * (size_t)(c->ss_last - c->ss_first + 1), hipMemcpyDeviceToHost));
-  if (threshold) { float o[2] = { 0, 0 }; HIPCHK(c, hipMemcpy(o, c->d_ss_out, sizeof o, hipMemcpyDeviceToHost)); *threshold = o[0]; }
+  if (spectrum) HIPCHK(c, stage_d2h(c, spectrum, c->d_ss_spec_base + 32 + c->ss_first, sizeof(float) * (size_t)(c->ss_last - c->ss_first + 1), c->stream));
+  if (threshold) { float o[2] = { 0, 0 }; HIPCHK(c, stage_d2h(c, o, c->d_ss_out, sizeof o, c->stream)); *threshold = o[0]; }
   if (completed) *completed = c->ss_completed;
   if (sum_counter) *sum_counter = c->ss_counter;
   return LRH_OK;
@@ -1443,7 +1489,7 @@ try {
   SpurArgs sa; spur_args(c, &sa, p->fft2_na, 0);
   HIPCHK(c, launch_spur_acquire(sa, pnt, c->d_spur_touched + 2 * c->spur_max, c->stream));
   int res = 0;
-  HIPCHK(c, hipMemcpyAsync(&res, c->d_spur_touched + 2 * c->spur_max, sizeof res, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, &res, c->d_spur_touched + 2 * c->spur_max, sizeof res, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (res) { c->spur_n++; *locked = 1; }
   return LRH_OK;
@@ -1456,10 +1502,10 @@ try {
   if (c->rec) return fail(c, LRH_ESTATE, "not inside lrh_wideband_dsp");
   const size_t maxn = c->spur_maxn;
   if (n) {
-    HIPCHK(c, hipMemcpyAsync(c->d_spurs, sp, n * sizeof *sp, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_table, table, n * maxn * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_signal, signal, n * maxn * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_ind, ind, n * maxn * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spurs, sp, n * sizeof *sp, c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_table, table, n * maxn * 14 * sizeof(float), c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_signal, signal, n * maxn * 2 * sizeof(float), c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_ind, ind, n * maxn * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->spur_n = n;
@@ -1477,10 +1523,10 @@ try {
   const int old_n = c->spur_n;
   if (n) {
     std::vector<lrh_spur> sp(old_n); std::vector<float> tab((size_t)old_n * maxn * 14), sig((size_t)old_n * maxn * 2); std::vector<int> ind((size_t)old_n * maxn);
-    HIPCHK(c, hipMemcpyAsync(sp.data(), c->d_spurs, old_n * sizeof(lrh_spur), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tab.data(), c->d_spur_table, tab.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(sig.data(), c->d_spur_signal, sig.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ind.data(), c->d_spur_ind, ind.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, stage_d2h(c, sp.data(), c->d_spurs, old_n * sizeof(lrh_spur), c->stream));
+    HIPCHK(c, stage_d2h(c, tab.data(), c->d_spur_table, tab.size() * sizeof(float), c->stream));
+    HIPCHK(c, stage_d2h(c, sig.data(), c->d_spur_signal, sig.size() * sizeof(float), c->stream));
+    HIPCHK(c, stage_d2h(c, ind.data(), c->d_spur_ind, ind.size() * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<lrh_spur> sp2(n); std::vector<float> tab2((size_t)n * maxn * 14), sig2((size_t)n * maxn * 2); std::vector<int> ind2((size_t)n * maxn);
     for (int i = 0; i < n; i++) {
@@ -1489,10 +1535,10 @@ try {
       memcpy(&sig2[(size_t)i * maxn * 2], &sig[(size_t)src[i] * maxn * 2], maxn * 2 * sizeof(float));
       memcpy(&ind2[(size_t)i * maxn], &ind[(size_t)src[i] * maxn], maxn * sizeof(int));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_spurs, sp2.data(), n * sizeof(lrh_spur), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_table, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_signal, sig2.data(), sig2.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_spur_ind, ind2.data(), ind2.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spurs, sp2.data(), n * sizeof(lrh_spur), c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_table, tab2.data(), tab2.size() * sizeof(float), c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_signal, sig2.data(), sig2.size() * sizeof(float), c->stream));
+    HIPCHK(c, stage_h2d(c, c->d_spur_ind, ind2.data(), ind2.size() * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->spur_n = n;
@@ -1505,7 +1551,7 @@ try {
   if (!c || !sp || !n || max < 0) return LRH_EINVAL;
   *n = c->spur_n < max ? c->spur_n : max;
   if (*n) {
-    HIPCHK(c, hipMemcpyAsync(sp, c->d_spurs, *n * sizeof *sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, stage_d2h(c, sp, c->d_spurs, *n * sizeof *sp, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return LRH_OK;
@@ -1517,7 +1563,7 @@ try {
   LRH_ENTER(c);
   if (!c) return LRH_EINVAL;
   if (y) c->h_yfac.assign(y, y + c->N1); else default_yfac(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_yfac, c->h_yfac.data(), 4 * c->N1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_yfac, c->h_yfac.data(), 4 * c->N1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -1549,8 +1595,8 @@ try {
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
   int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
-  HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream));
-  if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, d + off, s, first, c->stream));
+  if (nbytes > first) HIPCHK(c, stage_h2d(c, d, s + first, nbytes - first, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
   return LRH_OK;
 }
@@ -1595,8 +1641,14 @@ try {
   } else if (c->fft1_read_valid) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_fft1_read_cur.load(), 0));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h].exchange(false)) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));   // workers that launch themselves (LRH_WORKER_FAST=0, the four-step sizes)
   if (guard) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_in_guard, 0));
-  HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
-  if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+  if (host_span_registered(c, s, (size_t)nbytes)) {         // the caller's page-locked arena (lrh_host_register): the copy engine reads it while the caller goes on
+    HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
+    if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+  } else {                                                   // pageable memory: through the producer's own staging buffer, done when this returns (the order on stream_in is the same)
+    if (!c->h_stage_in && lrh_host_malloc(&c->h_stage_in, LRH_STAGE_BYTES) != hipSuccess) { c->h_stage_in = nullptr; return fail(c, LRH_ENOMEM, "hipHostMalloc(producer staging)"); }
+    HIPCHK(c, stage_h2d(c, d + off, s, (size_t)first, c->stream_in, c->h_stage_in));
+    if (nbytes > first) HIPCHK(c, stage_h2d(c, d, s + first, (size_t)(nbytes - first), c->stream_in, c->h_stage_in));
+  }
   c->in_pending = true;                                      // (the reader records the event behind the copies it needs: wait_for_input)
   return LRH_OK;
 }
@@ -1615,7 +1667,7 @@ try {
   if (!c || !ptr || !bytes) return LRH_EINVAL;
   LRH_ENTER(c);
   HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-  c->host_regs.push_back({(char *)ptr, bytes});
+  { std::lock_guard<std::mutex> lk_in(c->mtx_in); c->host_regs.push_back({(char *)ptr, bytes}); }   // (the producer reads the list under its own lock)
   return LRH_OK;
 }
 LRH_CATCH(c)
@@ -1625,7 +1677,7 @@ try {
   LRH_ENTER(c);
   // read-backs still on their way into the span first (the copy engine writes there)
   for (int i = 0; i < LRH_NOUT; i++) if (c->out_busy[i] && c->ev_out_done[i]) hipEventSynchronize(c->ev_out_done[i]);
-  for (size_t i = 0; i < c->host_regs.size(); i++) if (c->host_regs[i].first == (char *)ptr) { c->host_regs.erase(c->host_regs.begin() + i); break; }
+  { std::lock_guard<std::mutex> lk_in(c->mtx_in); for (size_t i = 0; i < c->host_regs.size(); i++) if (c->host_regs[i].first == (char *)ptr) { c->host_regs.erase(c->host_regs.begin() + i); break; } }
   HIPCHK(c, hipHostUnregister(ptr));
   return LRH_OK;
 }
@@ -1644,7 +1696,7 @@ try {
     if (lrh_dev_malloc((void **)&c->d_pack18, packed_bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(packed18 staging)");
     c->pack18_cap = packed_bytes;
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_pack18, src, packed_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_pack18, src, packed_bytes, c->stream));
   HIPCHK(c, launch_expand18(c->d_pack18, packed_bytes / 9, c->d_timf1, (off & c->timf1_bytemask) / 16, c->cfg.timf1_bytes / 16 - 1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
   return LRH_OK;
@@ -1821,7 +1873,7 @@ try {
   HIPCHK(c, launch_fft1(c->cfg.fft1_n, a, batch, c->cur));
   if (c->dbg_stamp) {
     unsigned long long h[2 * LRH_STAMPS_PER_WG];
-    HIPCHK(c, hipMemcpyAsync(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
+    HIPCHK(c, stage_d2h(c, h, c->d_stamps, sizeof h, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
     for (int w = 0; w < 2; w++) {
       fprintf(stderr, "fft1 stamps wg%d:", w ? 128 : 0);
       for (int i = 1; i < LRH_STAMPS_PER_WG && h[w * LRH_STAMPS_PER_WG + i]; i++) fprintf(stderr, " %llu", h[w * LRH_STAMPS_PER_WG + i] - h[w * LRH_STAMPS_PER_WG]);
@@ -1878,9 +1930,9 @@ try {
   if (!c->d_unitcorr) {
     if (lrh_dev_malloc((void **)&c->d_unitcorr, bytes) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(unit filter table)");
     std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
-    HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), bytes, hipMemcpyHostToDevice));
+    HIPCHK(c, stage_h2d(c, c->d_unitcorr, one.data(), bytes, c->stream));
   }
-  HIPCHK(c, hipMemcpy(c->d_foldcorr, fc, bytes, hipMemcpyHostToDevice));
+  HIPCHK(c, stage_h2d(c, c->d_foldcorr, fc, bytes, c->stream));
   return LRH_OK;
 }
 LRH_CATCH(c)
@@ -2021,7 +2073,7 @@ try {
     if (v_stamps) {
       static int printed = 0;
       unsigned long long h[64];
-      HIPCHK(c, hipMemcpyAsync(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
+      HIPCHK(c, stage_d2h(c, h, c->d_stamps, sizeof h, c->cur)); HIPCHK(c, hipStreamSynchronize(c->cur));
       if (printed++ < 3) for (int wv = 0; wv < 2; wv++) {
         fprintf(stderr, "fft1v stamps wave%d:", wv ? 4 : 0);
         for (int i = 1; i < 32 && h[wv * 32 + i]; i++) fprintf(stderr, " %llu", h[wv * 32 + i] - h[wv * 32]);
@@ -2224,19 +2276,19 @@ try {
     }
     int out[4];
     { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur)); }
-    HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
+    HIPCHK(c, stage_d2h(c, out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, c->cur));
     HIPCHK(c, hipStreamSynchronize(c->cur));
     if (out[3]) {                                           // colliding extents: samples back from the undo log, one wave over the span
       { ProfScope ps(c, "clever"); HIPCHK(c, launch_clever(ca, c->cur, 4)); }
-      HIPCHK(c, hipMemcpyAsync(out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, hipMemcpyDeviceToHost, c->cur));
+      HIPCHK(c, stage_d2h(c, out, (char *)c->d_bst + offsetof(BlankState, clever_out), sizeof out, c->cur));
       HIPCHK(c, hipStreamSynchronize(c->cur));
     }
     { static const int dbg = getenv("LRH_CLEVER_DEBUG") ? atoi(getenv("LRH_CLEVER_DEBUG")) : 0;     // diagnostics: the regions of this call and where extents met
       if (dbg) {
-        int ctl[4] = {0, 0, 0, 0}; hipMemcpy(ctl, c->d_clv_ctl, sizeof ctl, hipMemcpyDeviceToHost);
+        int ctl[4] = {0, 0, 0, 0}; stage_d2h(c, ctl, c->d_clv_ctl, sizeof ctl, c->stream);
         const int nr = std::min(ctl[0], c->clv_max_regions);
         std::vector<int> st(nr), ex(2 * (size_t)nr);
-        if (nr) { hipMemcpy(st.data(), c->d_clv_start, nr * sizeof(int), hipMemcpyDeviceToHost); hipMemcpy(ex.data(), c->d_clv_ext, 2 * nr * sizeof(int), hipMemcpyDeviceToHost); }
+        if (nr) { stage_d2h(c, st.data(), c->d_clv_start, nr * sizeof(int), c->stream); stage_d2h(c, ex.data(), c->d_clv_ext, 2 * nr * sizeof(int), c->stream); }
         int bad = 0, first_bad = -1;
         for (int r = 0; r + 1 < nr; r++) if (ex[2 * r + 1] >= ex[2 * (r + 1)]) { if (first_bad < 0) first_bad = r; bad++; }
         fprintf(stderr, "clever: total %d regions %d (max %d) serial %d gap %d colliding pairs %d", a.total, ctl[0], c->clv_max_regions, ctl[1], ca.gap, bad);
@@ -2244,7 +2296,7 @@ try {
                                     first_bad + 1, st[first_bad + 1], ex[2 * first_bad + 2], ex[2 * first_bad + 3]);
         fprintf(stderr, "  fitted %d rejected %d\n", out[1], out[2]);
         if (c->d_clv_dbg && nr) {
-          std::vector<int> dbg(2 * (size_t)nr); hipMemcpy(dbg.data(), c->d_clv_dbg, 2 * nr * sizeof(int), hipMemcpyDeviceToHost);
+          std::vector<int> dbg(2 * (size_t)nr); stage_d2h(c, dbg.data(), c->d_clv_dbg, 2 * nr * sizeof(int), c->stream);
           int hist[8] = {0}, worst = 0; long long ticks = 0;
           for (int r = 0; r < nr; r++) { hist[std::min(7, dbg[2 * r] / 2)]++; ticks += dbg[2 * r + 1]; if (dbg[2 * r + 1] > dbg[2 * worst + 1]) worst = r; }
           fprintf(stderr, "clever: candidates per region 0-1 %d, 2-3 %d, 4-5 %d, 6-7 %d, 8-9 %d, 10-11 %d, 12-13 %d, more %d; mean %.1f us per region, slowest region %d: %d candidates, %.1f us, %d samples\n",
@@ -2331,7 +2383,7 @@ try {
   if (!c || !dst) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   if (off + count > cap) return LRH_EINVAL;
-  HIPCHK(c, hipMemcpyAsync(dst, q + off, 4 * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, dst, q + off, 4 * count, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -2342,7 +2394,7 @@ try {
   if (!c || !src) return LRH_EINVAL;
   float *q; size_t cap; const int rc = exchange_span(c, which, &q, &cap); if (rc) return rc;
   if (off + count > cap) return LRH_EINVAL;
-  HIPCHK(c, hipMemcpyAsync(q + off, src, 4 * count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, q + off, src, 4 * count, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -2353,7 +2405,7 @@ try {
   LRH_ENTER(c);
   if (!c || !st) return LRH_EINVAL;
   BlankState bs;
-  HIPCHK(c, hipMemcpyAsync(&bs, c->d_bst, sizeof bs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, &bs, c->d_bst, sizeof bs, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   st->timf2_noise_floor = bs.noise_floor; st->stupid_bln_limit = bs.limit;
   st->timf2_despiked_pwr[0] = bs.despiked_pwr[0]; st->timf2_despiked_pwr[1] = bs.despiked_pwr[1];
@@ -2818,7 +2870,7 @@ try {
   if (!c || !f) return LRH_EINVAL;
   if (!c->N3) return fail(c, LRH_ESTATE, "fft3 not configured");
   LRH_ENTER(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_bgfilt, f, 4 * c->N3, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_bgfilt, f, 4 * c->N3, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -2894,7 +2946,7 @@ try {
   c->bbfir_pts = 0;
   if (!fir) return LRH_OK;
   { const int rc_ = dev_alloc(c, &c->d_bbfir, pts, false); if (rc_) return rc_; }
-  HIPCHK(c, hipMemcpyAsync(c->d_bbfir, fir, sizeof(float) * pts, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, stage_h2d(c, c->d_bbfir, fir, sizeof(float) * pts, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->bbfir_pts = pts;
   return LRH_OK;
@@ -3568,6 +3620,19 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
       if (off + cnt > total || (off & 3) || (cnt & 3)) return LRH_EINVAL;
       const size_t s0 = off / 4, ns = cnt / 4;
       if (ns == 0) return LRH_OK;
+      if (kind == hipMemcpyDeviceToHost && c->h_stage) {   // through the staging buffer: weak samples in its first half, strong in the second, interleaved on the way out
+        const size_t per = LRH_STAGE_BYTES / 16;
+        float *out = (float *)dst;
+        for (size_t at = 0; at < ns; at += per) {
+          const size_t n = ns - at < per ? ns - at : per;
+          const float2 *hw = (const float2 *)c->h_stage, *hs = hw + per;
+          HIPCHK(c, hipMemcpyAsync(c->h_stage, c->d_timf2w + s0 + at, n * 8, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->h_stage + per * 8, c->d_timf2s + s0 + at, n * 8, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          for (size_t i = 0; i < n; i++) { float *o = out + 4 * (at + i); o[0] = hw[i].x; o[1] = hw[i].y; o[2] = hs[i].x; o[3] = hs[i].y; }
+        }
+        return LRH_OK;
+      }
       HIPCHK(c, hipMemcpy2DAsync(dst, 16, c->d_timf2w + s0, 8, 8, ns, kind, c->stream));
       HIPCHK(c, hipMemcpy2DAsync((char *)dst + 8, 16, c->d_timf2s + s0, 8, 8, ns, kind, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3621,6 +3686,7 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
     }
   }
   if (ticket) *ticket = 0;                                  // no slot (or a span beyond a slot's size): done here, nothing to collect
+  if (kind == hipMemcpyDeviceToHost) { HIPCHK(c, stage_d2h(c, dst, (const char *)src + off * esz, cnt * esz, c->stream)); return LRH_OK; }   // (a host destination is always waited for)
   HIPCHK(c, hipMemcpyAsync(dst, (const char *)src + off * esz, cnt * esz, kind, c->stream));
   if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
@@ -3692,7 +3758,7 @@ try {
     c->net_cap = count;
   }
   HIPCHK(c, launch_timf2_net(c->d_timf2w, c->d_timf2s, c->timf2pow_mask, (timf2_pt & c->timf2_mask) / 4, count, gain, strong, c->d_net, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dst, c->d_net, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, dst, c->d_net, (size_t)count * sizeof(float2), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }
@@ -3718,7 +3784,7 @@ try {
   if (!c->d_unitcorr) {
     if (lrh_dev_malloc((void **)&c->d_unitcorr, sizeof(float2) * c->N1) != hipSuccess) return fail(c, LRH_ENOMEM, "lrh_dev_malloc(unit filter table)");
     std::vector<float2> one(c->N1, make_float2(1.f, 0.f));
-    HIPCHK(c, hipMemcpy(c->d_unitcorr, one.data(), sizeof(float2) * c->N1, hipMemcpyHostToDevice));
+    HIPCHK(c, stage_h2d(c, c->d_unitcorr, one.data(), sizeof(float2) * c->N1, c->stream));
   }
   if (c->in_pending) { const int rc_ = wait_for_input(c, c->stream); if (rc_) return rc_; }
   Fft1Args a; a.spare_cus = 0;
@@ -3752,7 +3818,7 @@ try {
     FoldcorrArgs f; f.spec = c->d_fft1net; f.first_nb = 0; f.nb_mask = a.nb_mask; f.n = c->N1; f.foldcorr = c->d_foldcorr; f.filtercorr = c->d_unitcorr; f.direction = c->cfg.fft1_direction;
     HIPCHK(c, launch_foldcorr(f, batch, c->stream));
   }
-  HIPCHK(c, hipMemcpyAsync(dst, c->d_fft1net, (size_t)batch * c->N1 * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, stage_d2h(c, dst, c->d_fft1net, (size_t)batch * c->N1 * sizeof(float2), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRH_OK;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench's variants on one GPU, one JSON object per round: scripts/variants_round.sh r03   (on the GPU box, via gpurun)
 # -> gpurun_out/prof_$R/variants.json (+ rocprofv3 --stats of the two variants the review asked for: --clever, --coupled)
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
@@ -42,7 +42,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "var", "*.json"))):
         out[name] = {"error": repr(e)}
         continue
     out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"][:160],
-                 "stages_us": {k: [v["avg_us"], v.get("avg_us_alone")] for k, v in d.get("stages", {}).items()},
+                 "stages_us": d.get("stage_us") or {k: [v["avg_us"], v.get("avg_us_alone")] for k, v in d.get("stages", {}).items()},   # (the short line carries avg_us per stage)
                  "blanker": d.get("blanker"), "spurs": d.get("spurs"), "routing": d.get("routing")}
 json.dump(out, open(os.path.join(sys.argv[1], "variants.json"), "w"), indent=1)
 for k, v in out.items():
