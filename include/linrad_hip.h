@@ -404,7 +404,10 @@ void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                       
    ones.  `src` must stay untouched until lrh_timf1_write_wait returns (or the next lrh_sync); page-locked memory --
    lrh_host_register on Linrad's timf1 arena once after get_buffers, lrh_host_unregister before free_buffers (buf.c:2105;
    the shim never frees host memory) -- makes the copy a true DMA.  One producer style per context: the
-   synchronous lrh_timf1_write travels on the main stream and is not ordered against copies still queued here. */
+   synchronous lrh_timf1_write travels on the main stream and is not ordered against copies still queued here.
+   Round 6: a source that does NOT lie in a span registered with lrh_host_register is copied through a page-locked staging buffer of
+   the library and the call returns when the samples are on the device (same order on the copy stream): the library never lets the
+   HIP runtime pin pageable caller memory on the fly -- neither here nor in any table upload or read-back. */
 int lrh_timf1_write_async(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);
 int lrh_timf1_write_wait(lrh_ctx *ctx);
 int lrh_host_register(lrh_ctx *ctx, void *ptr, size_t bytes);
