@@ -876,7 +876,7 @@ def main():
         sweep = round_sweep(args, primary, rank, local_rank, world, dist, torch, hiplib)
 
     cpu = cpu_all = cpu_port = cpu_threads = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:            # (the contract: the CPU baseline is timed on rank 0 of the N = 1 run only)
         cw = dict(primary)
         cpu_port = cpu_baseline(args, cw)
         cpu = cpu_reference(args, cw) or cpu_port
