@@ -2587,6 +2587,12 @@ __global__ __launch_bounds__(256) void k_xypower(XyArgs a)
 }
 
 // one waterfall line, 0.01 dB shorts (fft2.c:707-812); itab[] holds the reference's float-accumulated yfac index
+// 1000 log10(power) and the conversion to int the way the reference's host code gets them (fft2.c:707-815 runs on x86): a bin or a group with NO power
+// -- silent input, a pixel beyond the end of the spectrum -- is log10(0) = -inf there, which cvttsd2si turns into INT_MIN and the clamp into -32767, and an
+// interpolation that meets it carries -inf / NaN on.  The device's double log10 returns a finite -2.065 for 0 (seen: -2065 in those pixels where the
+// reference has -32767; found by tests/test_gpu_random_configs.py), and its conversions saturate (+inf -> INT_MAX, NaN -> 0) where x86 answers INT_MIN.
+__device__ __forceinline__ double wf_db(float v) { return v == 0.f ? -(double)INFINITY : 1000. * log10((double)v); }
+__device__ __forceinline__ int wf_int(double v) { return (v != v || v >= 2147483648. || v < -2147483648.) ? (-2147483647 - 1) : (int)v; }
 __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
 {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -2598,7 +2604,7 @@ __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
   }
   if (a.hx == 1 || a.hp == 1) {
     if (t >= a.npix) return;
-    int y = (int)(1000. * log10((double)(a.ps[a.first + t] * a.yfac[a.itab[t]])));
+    int y = wf_int(wf_db(a.ps[a.first + t] * a.yfac[a.itab[t]]));
     if (y < -32767) y = -32767; if (y > 32767) y = 32767;
     a.line[t] = (int16_t)y;
   } else if (a.hx == 0) {
@@ -2608,19 +2614,19 @@ __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
     const bool tail = (t == nseg) && (i1 < a.siz);
     if (t > nseg || (t == nseg && !tail)) return;
     const int i0 = a.first + t;
-    float y0 = (float)(1000. * log10((double)(a.ps[i0] * a.yfac[a.itab[t]])));
+    float y0 = (float)wf_db(a.ps[i0] * a.yfac[a.itab[t]]);
     if (t == 0) {
-      int y = (int)(1000. * log10((double)(a.ps[i0] * a.yfac[a.itab[0]])));
+      int y = wf_int(wf_db(a.ps[i0] * a.yfac[a.itab[0]]));
       y0 = (float)y;                                        // yval=y with y already an int (fft2.c:745-746)
       if (y < -32767) y = -32767; if (y > 32767) y = 32767;
       a.line[0] = (int16_t)y;
     }
-    const float r1 = (float)(1000. * log10((double)(a.ps[i1] * a.yfac[a.itab[t + 1]])));
+    const float r1 = (float)wf_db(a.ps[i1] * a.yfac[a.itab[t + 1]]);
     const float der = (r1 - y0) / a.hp;
     float yval = y0;
     for (int k = t * a.hp + 1; k <= t * a.hp + a.hp; k++) {
       yval = yval + der;
-      int y = (int)yval;
+      int y = wf_int((double)yval);
       if (y < -32767) y = -32767; if (y > 32767) y = 32767;
       if (k < a.npix) a.line[k] = (int16_t)y;
     }
@@ -2631,7 +2637,7 @@ __global__ __launch_bounds__(256) void k_waterfall(WaterfallArgs a)
     if (ia > a.siz) ia = a.siz; if (ib >= a.siz) ib = a.siz;
     float r2 = 0;
     for (int i = ia; i < ib; i++) { const float r1 = a.ps[i]; if (r1 > r2) r2 = r1; }
-    int y = (int)(1000. * log10((double)(a.yfac[a.itab[t]] * r2)));
+    int y = wf_int(wf_db(a.yfac[a.itab[t]] * r2));
     if (y < -32767) y = -32767; if (y > 32767) y = 32767;
     a.line[t] = (int16_t)y;
   }

@@ -19,9 +19,10 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
 
 
-def run_case(open_fn, name, golden=None, stupid=None, batch=1, **cfg_kw):
-    """Drive the case block by block in the reference call pattern (ref_harness.c main loop)."""
-    d = case_params(name)
+def run_case(open_fn, name, golden=None, stupid=None, batch=1, params=None, **cfg_kw):
+    """Drive the case block by block in the reference call pattern (ref_harness.c main loop).
+    params: a case dictionary of refcases' form instead of the named one (tests/test_gpu_random_configs.py; `golden` then carries iq and liminfo)."""
+    d = dict(params) if params is not None else case_params(name)
     g = golden if golden is not None else load_golden(name)
     iq, lim = g["iq"], g["liminfo"]
     if stupid is not None:
