@@ -1,11 +1,12 @@
 """GPU: the chain at configurations nobody wrote down -- seeded random sizes, windows, averaging, blanker cadence, batch sizes, input formats and signals,
 HIP against the oracle (float rings at 1e-5 relative RMS or held to the float64 build like everywhere else; pointer traces, averaging counters and --
 where the noise floors agree -- the cleared-sample sets exact).  The goldens pin the restatement to the compiled reference at 21 hand-picked
-configurations; this walks between them."""
+configurations; this walks between them: 64 seeds in the suite (LRH_RANDOM_SEEDS for more; 200 were run in round 6).  First catch: the waterfall of a bin
+with NO power (k_waterfall's log10(0), see there)."""
 import numpy as np
 import pytest
 
-from paritylib import RINGS, relerr, run_case, truth_gate
+from paritylib import RINGS, relerr, run_case, truth_gate, waterfall_gate
 from refcases import case_params, make_input, make_liminfo
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +46,24 @@ def random_case(seed):
     d["fq"] = float(rng.uniform(0.15, 0.85) * NX)
     if d["sinpow1"] == 0:
         d["pulse_period"] = d["pulse_period"] or 997             # (no window: keep the blanker busy all the same)
+    if seed >= 12:                                              # the extended sweep (LRH_RANDOM_SEEDS): the variants that have goldens of their own
+        if second and rng.random() < 0.25 and n2 - d["mixred"] >= 6:
+            d.update(fft3_n=int(min(8, n2 - d["mixred"] + 2)), fft3_sinpow=int(rng.choice([2, 2, 3])), mix2_n=6, max_fft3n=8, mix2=1, nblk=max(d["nblk"], 100))
+            if d["fft3_n"] < 6 or d["mix2_n"] > d["fft3_n"]:
+                d.update(fft3_n=0, mix2_n=0, mix2=0)
+        if rng.random() < 0.12 and d["sinpow1"] in (0, 2) and d["direction"] > 0:
+            d.update(real=1, dword=int(rng.random() < 0.3))
+        if rng.random() < 0.08 and not d["real"]:
+            d["sample_shift"] = int(rng.choice([-1, 1]))
     from refcases import level_gain
     d["gain"] = level_gain(n1, d["att_n"], d["sigma"] * (16384.0 / 49152.0 if d["dword"] else 1.0))
     return d, int(rng.choice([1, 1, 2, 3, 4]))
 
 
-@pytest.mark.parametrize("seed", range(12))
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_SEEDS", "64"))))
 def test_random_configuration_matches_the_oracle(seed):
     d, batch = random_case(seed)
     iq, lim = make_input(d), make_liminfo(d)
@@ -66,8 +79,14 @@ def test_random_configuration_matches_the_oracle(seed):
     info = {k: d[k] for k in ("n1", "n2", "second_fft", "sinpow1", "sinpow2", "mixred", "nblk", "dword", "direction")}
     cols = [0, 1, 2, 3, 6, 7, 8, 9, 10]
     assert np.array_equal(a["itrace"][:, cols], b["itrace"][:, cols]), info
+    # the blanker's noise floor: the same, or -- where a start-up transient has the limit deep inside the noise and nearly every sample is cleared, so that ONE
+    # sample within float32 rounding of the limit moves the mean of the few survivors (seed 11: 1 flip of 117 509 decisions, floor 6314 against 6303) --
+    # within half a per cent; everything behind the blanker is then compared by the other seeds and the goldens, not here
     same_floor = np.array_equal(a["itrace"][:, 4], b["itrace"][:, 4])
-    assert np.abs(a["itrace"][:, 4] - b["itrace"][:, 4]).max(initial=0) <= 1, info
+    fa, fb = a["itrace"][:, 4].astype(float), b["itrace"][:, 4].astype(float)
+    assert np.all(np.abs(fa - fb) <= np.maximum(1.0, 5e-3 * fb)), info
+    if not same_floor and d["second_fft"]:
+        assert np.count_nonzero((a["timf2_pwr_float"] == 0) != (b["timf2_pwr_float"] == 0)) <= 8, info
     assert np.array_equal(a["mixtrace"][:, [0, 5, 6, 7]], b["mixtrace"][:, [0, 5, 6, 7]]), info          # mix1_point, old_point, timf3_pa, nx
     rep = {}
     half = a["api"].fft1_interleave_points == a["api"].N1 // 2
@@ -78,14 +97,35 @@ def test_random_configuration_matches_the_oracle(seed):
         keep = np.ones(x.size, bool)
         if key == "timf2_float" and half:                        # the raw half block the reference parks beyond timf2_pa (timf2.c:1018-1025)
             keep[(a["api"].p.timf2_pa + np.arange(4 * (a["api"].N1 // 2))) % x.size] = False
-        if key in ("timf2_float", "timf2_pwr_float") and not same_floor:
-            continue                                             # a noise floor one unit apart moves the limit: decisions may differ, held by the golden tests
-        truth_gate(rep, key, x[keep], y[keep], (lambda k=key, m=keep: t(k)[m]), tol=1e-5, factor=1.05)
+        if key.startswith(("timf2", "fft2", "timf3")) and not same_floor:
+            continue                                             # a noise floor apart moves the limit: decisions differ from there on
+        # (above 1e-5 both float32 sides are measured against the float64 build; 1.25: in these unplanned level plans the two float32 results sit 2-3e-5 from
+        # the truth and 15 % apart from each other -- seeds 18 and 65 of the extended sweep; the goldens and the full-size tests hold 1.0 / 1.05)
+        truth_gate(rep, key, x[keep], y[keep], (lambda k=key, m=keep: t(k)[m]), tol=1e-5, factor=1.25)
+    flips = 0
     if same_floor and d["second_fft"]:
         flips = np.count_nonzero((a["timf2_pwr_float"] == 0) != (b["timf2_pwr_float"] == 0))
         assert flips <= 2, (info, flips)                         # a sample within float32 rounding of the limit
-    if a["wf_lines"].size:
-        assert np.abs(a["wf_lines"].astype(int) - b["wf_lines"].astype(int)).max() <= 2, info
+    if a["wf_lines"].size and same_floor and flips == 0:
+        # the integer gate of the goldens: each side against the float64 build's values before truncation.  Not with a flipped blanker decision (one cleared
+        # impulse more or less is a flat 0.5 % in the weak bins of the lines it reaches: seeds 40 and 50 of the sweep) and not deeper than 80 dB below the
+        # line's strongest bin, where the float32 transform noise is tens of counts on BOTH sides (seed 53: -117 dB, |hip - truth| and |oracle - truth| alike)
+        t("wf_lines")
+        pre = np.array(truth["api"].wf_pre_lines, np.float64).reshape(-1, a["cfg"].wf_xpixels)
+        r_ = b["wf_lines"].astype(np.int64)
+        sel = (r_.max(axis=1, keepdims=True) - r_) < 8000
+        # line by line: a decision that flipped on a sample the ring has since overwritten (seed 50: one sample 5e-6 below the limit, cleared by the oracle,
+        # kept by HIP and by nobody's fault) still sits in the one or two lines its transforms went into -- at most two such lines, a per cent at most
+        odd = []
+        for ln in range(r_.shape[0]):
+            try:
+                waterfall_gate({}, a["wf_lines"][ln][sel[ln]], b["wf_lines"][ln][sel[ln]], pre[ln][sel[ln]])
+            except AssertionError:
+                odd.append(ln)
+        assert len(odd) <= max(2, r_.shape[0] // 40), (info, odd)      # (seed 82 of the sweep: 3 of 150 lines)
+        for ln in odd:
+            assert np.abs(a["wf_lines"][ln].astype(int) - b["wf_lines"][ln].astype(int))[sel[ln]].max() <= 10, (info, ln)
+        rep["wf_lines_with_a_flip"] = len(odd)
     print(info, "batch", batch, {k: float("%.2e" % v) for k, v in rep.items() if isinstance(v, float)})
 
 
@@ -99,6 +139,6 @@ def test_silent_input_matches_the_oracle(name):
     a = run_case(_open_hip, name, golden=g, params=d)
     b = run_case(_open_oracle, name, golden=g, params=d)
     assert np.array_equal(a["itrace"], b["itrace"]) and np.array_equal(a["mixtrace"], b["mixtrace"])
-    for _, key in RINGS:
-        assert not np.any(a[key]) and not np.any(b[key]), key
+    for _, key in RINGS:                                        # (fft1_slowsum carries the reference's 1e-8 floor, everything else is zero)
+        assert np.array_equal(a[key], b[key]) and np.all(np.abs(a[key]) <= 1e-7), key
     assert a["wf_lines"].size and np.array_equal(a["wf_lines"], b["wf_lines"]) and np.all(a["wf_lines"] == -32767)
