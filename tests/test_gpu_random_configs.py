@@ -142,3 +142,74 @@ def test_silent_input_matches_the_oracle(name):
     for _, key in RINGS:                                        # (fft1_slowsum carries the reference's 1e-8 floor, everything else is zero)
         assert np.array_equal(a[key], b[key]) and np.all(np.abs(a[key]) <= 1e-7), key
     assert a["wf_lines"].size and np.array_equal(a["wf_lines"], b["wf_lines"]) and np.all(a["wf_lines"] == -32767)
+
+
+def random_dsp_case(seed):
+    rng = np.random.default_rng(8100 + seed)
+    fft1_n = int(rng.choice([12, 13, 14]))
+    fft2_n = int(rng.integers(fft1_n - 2, 17))
+    batch = int(rng.choice([16, 24, 32, 40, 64]))
+    fft3 = bool(rng.random() < 0.4) and fft2_n >= 12
+    calls = [int(batch * rng.integers(1, 4) + (rng.integers(1, batch) if rng.random() < 0.5 else 0)) for _ in range(int(rng.integers(1, 4)))]   # ragged last rounds too
+    return dict(fft1_n=fft1_n, fft2_n=fft2_n, batch=batch, fft3_n=12 if fft3 else 0, mix2_n=8 if fft3 else 0, calls=calls, sparse=int(rng.random() < 0.5),
+                dword=int(rng.random() < 0.2), fq=float(rng.uniform(0.2, 0.8)))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_DSP_SEEDS", "10"))))
+def test_random_wideband_dsp_matches_the_oracle(seed):
+    """lrh_wideband_dsp -- the batched entry the bench measures, with its fused kernels from 32 blocks per round up and its one-round-late schedule -- at
+    random sizes, round lengths and call lengths (rounds that are not full, several calls on one context), against the oracle's lro_wideband_dsp:
+    pointers and counters exact, rings at 1e-5 or held to the float64 build"""
+    from linrad_amd import abi
+    from linrad_amd.lib import synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config, strong_liminfo
+    q = random_dsp_case(seed)
+    total = sum(q["calls"])
+    cfg = chain_config(q["fft1_n"], q["fft2_n"], batch=q["batch"], fft3_n=q["fft3_n"], mix2_n=q["mix2_n"], rounds=max(1, (max(q["calls"]) + q["batch"] - 1) // q["batch"]))
+    N1, M1 = 1 << q["fft1_n"], (1 << q["fft1_n"]) // 2
+    while cfg.timf1_bytes < 4 * (total * M1 + 2 * N1) * (2 if q["dword"] else 1):
+        cfg.timf1_bytes *= 2
+    cfg.timf1_dword_input = q["dword"]
+    s = synth_defaults(N1, 0)
+    iq16 = synth_iq(s, 0, cfg.timf1_bytes // (8 if q["dword"] else 4))
+    iq = ((iq16.astype(np.int32) << 14) | 0x2000) if q["dword"] else iq16
+    lim = strong_liminfo(s, q["fft1_n"])
+    rings = [(abi.RING_FFT1_SUMSQ, "sumsq"), (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF2_PWR, "pwr"), (abi.RING_TIMF2_FLOAT, "timf2"),
+             (abi.RING_FFT2_POWERSUM, "ps2"), (abi.RING_TIMF3_FLOAT, "timf3"), (abi.RING_WG_WATERF, "wf")] + ([(abi.RING_BASEB_RAW, "baseb")] if q["fft3_n"] else [])
+    res = {}
+    for name, fn in (("hip", _open_hip), ("ora", _open_oracle), ("truth", _open_truth)):
+        if name == "truth" and res.get("skip_truth"):
+            continue
+        cfg.fft1_float_sparse = cfg.fft2_float_sparse = q["sparse"] if name == "hip" else 0
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_liminfo(lim)
+        rx.set_mix1_selfreq(q["fq"] * (1 << q["fft2_n"]))
+        for n in q["calls"]:
+            rx.wideband_dsp(n, q["batch"])
+        res[name] = {k: rx.export(r) for r, k in rings}
+        res[name]["p"] = rx.p.as_dict()
+        res[name]["floor"] = rx.blanker_state().timf2_noise_floor
+        rx.close()
+    cfg.fft1_float_sparse = cfg.fft2_float_sparse = 0
+    h, o, T = res["hip"], res["ora"], res["truth"]
+    assert h["p"] == o["p"], (q, {k: (h["p"][k], o["p"][k]) for k in h["p"] if h["p"][k] != o["p"][k]})
+    assert abs(h["floor"] - o["floor"]) <= max(1, 5e-3 * o["floor"]), q
+    rep = {}
+    flips = int(np.count_nonzero((h["pwr"] == 0) != (o["pwr"] == 0)))
+    assert flips <= 4, (q, flips)
+    npa = o["p"]["timf2_pa"] // 4
+    ring = h["timf2"].size // 4
+    keep4 = np.ones(ring, bool)
+    keep4[(npa + np.arange(M1)) % ring] = False                 # the raw half block the reference parks beyond timf2_pa
+    for key in ("sumsq", "slowsum"):
+        truth_gate(rep, key, h[key], o[key], lambda k=key: T[k], tol=1e-5, factor=1.25)
+    same = flips == 0 and h["floor"] == o["floor"]
+    if same:
+        truth_gate(rep, "timf2", h["timf2"].reshape(-1, 4)[keep4], o["timf2"].reshape(-1, 4)[keep4], lambda: T["timf2"].reshape(-1, 4)[keep4], tol=1e-5, factor=1.25)
+        nz = (h["pwr"] != 0) & (T["pwr"] != 0)
+        truth_gate(rep, "pwr", h["pwr"][nz], o["pwr"][nz], lambda: T["pwr"][nz], tol=1e-5, factor=1.25)
+        for key in ("ps2", "timf3") + (("baseb",) if q["fft3_n"] else ()):
+            truth_gate(rep, key, h[key], o[key], lambda k=key: T[k], tol=1e-5, factor=1.25)
+        assert np.abs(h["wf"].astype(int) - o["wf"].astype(int)).max() <= 3, q
+    print(q, "flips", flips, {k: float("%.2e" % v) for k, v in rep.items() if isinstance(v, float)})
