@@ -216,3 +216,90 @@ def test_random_wideband_dsp_matches_the_oracle(seed):
         odd = int(np.count_nonzero((dw.reshape(-1, cfg.wf_xpixels) > 3).any(axis=1)))
         assert odd <= 3 and dw.max() <= 40, (q, odd, int(dw.max()))            # at most a few of the 64 lines carry such a flip
     print(q, "flips", flips, {k: float("%.2e" % v) for k, v in rep.items() if isinstance(v, float)})
+
+
+def random_sellim_case(seed):
+    """a selective-limiter case (refcases.SELLIM form) with random levels, switches and carriers on one of the small golden bases"""
+    rng = np.random.default_rng(6300 + seed)
+    base = str(rng.choice(["n10_n12", "n9_n11_shift"]))
+    n1 = 1024 if base == "n10_n12" else 512
+    maxlevel = int(rng.choice([1500, 4000, 12000]))
+    nblk = int(rng.choice([96, 128, 160, 200]))
+    on = int(rng.integers(10, nblk // 2))
+    t = dict(base=base, nblk=nblk, maxlevel=maxlevel, lim_groups=int(rng.choice([8, 16, 32, 64])), blocktime=float(rng.choice([0.0008, 0.002, 0.005])),
+             ston_fft1=float(rng.uniform(2.5, 6.0)), bw_fftxpts=int(rng.integers(8, 64)), seed=int(7000 + seed), sample_shift=0, blockpower_block=0,
+             keyed=(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(0.3, 1.6) * maxlevel), on, int(rng.integers(on + 5, nblk))),
+             par1=int(rng.integers(0, 3)), par2=int(rng.integers(0, 2)), par3=int(rng.integers(0, 2)), par4=int(rng.integers(0, 2)), par5=int(rng.integers(0, 3)),
+             par6=int(rng.integers(0, 2)), par7=int(rng.integers(0, 2)), par8=int(rng.integers(0, 2)), sellim2=int(rng.random() < 0.6),
+             ston_fft2=float(rng.uniform(8.0, 45.0)), wf_avgnum=int(rng.integers(1, 4)),
+             strong=[(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(0.2, 1.5) * maxlevel)) for _ in range(int(rng.integers(0, 5)))],
+             weak=[(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(30.0, 600.0))) for _ in range(int(rng.integers(0, 4)))])
+    return t, dict(batch=int(rng.choice([1, 4, 8])), in_call=bool(rng.random() < 0.5), fq=float(rng.uniform(0.1, 0.9)))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_SELLIM_SEEDS", "12"))))
+def test_random_selective_limiter_matches_the_oracle(seed):
+    """both limiters (sellim.c:159-1130) at random levels, hg.sellim_par1..8, group sizes, carriers coming and going: the routing table after every
+    round of blocks -- which bins are weak, strong, attenuated -- exact, the attenuations to 1e-5, the amplitude factor, the weak-bin counts and
+    the rings the routing shapes.  The limiter calls inside lrh_wideband_dsp or made by the caller between rounds (wcw.c:1124-1133)"""
+    import refcases
+    from linrad_amd import abi
+    from linrad_amd.abi import default_sellim
+    from refcases import interleave, lrh_config, sellim_case
+    t, how = random_sellim_case(seed)
+    name = f"random_sellim_{seed}"
+    refcases.SELLIM[name] = t
+    try:
+        d, sl, iq = sellim_case(name)
+    finally:
+        del refcases.SELLIM[name]
+    batch = how["batch"]
+    cfg = lrh_config(d, iq, max_batch=max(4, batch))
+    N1, N2 = 1 << d["n1"], 1 << d["n2"]
+    bt2 = float(np.float32(sl["blocktime"]) * np.float32(N2 - interleave(d["n2"], d["sinpow2"])) / np.float32(N1 - interleave(d["n1"], d["sinpow1"])))
+    res = []
+    for fn in (_open_hip, _open_oracle):
+        rx = fn(cfg)
+        rx.timf1_write(iq)
+        rx.set_mix1_selfreq(how["fq"] * N2)
+        par = default_sellim(cfg, sellim_maxlevel=sl["maxlevel"], liminfo_group_points=max(1, N1 // sl["lim_groups"]), fft1_blocktime=sl["blocktime"],
+                             blanker_ston_fft1=sl["ston_fft1"], baseband_bw_fftxpts=sl["bw_fftxpts"], blanker_ston_fft2=sl["ston_fft2"], fft2_blocktime=bt2,
+                             exact_stats=1, **{f"sellim_par{i}": sl[f"par{i}"] for i in range(1, 9)})
+        trace, amps, lows = [], [], []
+        nr = d["nblk"] // batch
+        if how["in_call"]:
+            rx.wideband_limiter(par, bool(sl["sellim2"]))
+        c1 = c2 = 0
+        for _ in range(nr):
+            rx.wideband_dsp(batch, batch)
+            if not how["in_call"]:
+                if rx.p.fft1_liminfo_cnt != c1:
+                    rx.fft1_update_liminfo(par)
+                    c1 = rx.p.fft1_liminfo_cnt
+                if sl["sellim2"] and rx.p.fft2_liminfo_cnt != c2:
+                    rx.fft2_update_liminfo(par)
+                    c2 = rx.p.fft2_liminfo_cnt
+            trace.append(rx.get_liminfo())
+            amps.append(rx.liminfo_amplitude_factor())
+            lows.append(rx.p.fft1_lowlevel_points)
+        res.append(dict(trace=np.array(trace), amp=np.array(amps, np.float32), low=np.array(lows), p=rx.p.as_dict(), timf2=rx.export(abi.RING_TIMF2_FLOAT),
+                        slowsum=rx.export(abi.RING_FFT1_SLOWSUM), timf3=rx.export(abi.RING_TIMF3_FLOAT)))
+        rx.close()
+    h, o = res
+    ctx = dict(seed=seed, case={k: v for k, v in t.items() if k not in ("strong", "weak")}, how=how)
+    bad = np.nonzero((np.sign(h["trace"]) != np.sign(o["trace"])).any(axis=1))[0]
+    assert bad.size == 0, (ctx, "first round with another routing pattern", int(bad[0]), np.nonzero(np.sign(h["trace"][bad[0]]) != np.sign(o["trace"][bad[0]]))[0][:8])
+    assert np.array_equal(h["low"], o["low"]), ctx
+    ints = [k for k, v in h["p"].items() if isinstance(v, int)]
+    assert {k: h["p"][k] for k in ints} == {k: o["p"][k] for k in ints}, ctx
+    pos = o["trace"] > 0
+    verr = float(np.max(np.abs(h["trace"][pos] - o["trace"][pos]) / o["trace"][pos])) if pos.any() else 0.0
+    aerr = float(np.max(np.abs(h["amp"] - o["amp"])))
+    assert verr <= 1e-5 and aerr <= 1e-6, (ctx, verr, aerr)
+    keep = np.ones(h["timf2"].size, bool)
+    keep[(h["p"]["timf2_pa"] + np.arange(4 * (N1 // 2))) % keep.size] = False
+    e2 = relerr(h["timf2"] * keep, o["timf2"] * keep)
+    e3 = relerr(h["timf3"], o["timf3"])
+    es = relerr(h["slowsum"], o["slowsum"])
+    print(ctx, "strong", int(np.count_nonzero(o["trace"][-1])), "attenuated", int(pos[-1].sum()), "table", verr, "amp", aerr, "timf2", e2, "timf3", e3, "slowsum", es)
+    assert e2 <= 1e-5 and e3 <= 1e-5 and es <= 1e-5, (ctx, e2, e3, es)
