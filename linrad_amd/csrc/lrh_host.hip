@@ -247,6 +247,17 @@ struct lrh_ctx {
   hipStream_t stream_in = nullptr;   // producer copies of lrh_timf1_write_async
   hipEvent_t ev_in = nullptr, ev_fft1_read = nullptr; std::atomic<hipEvent_t> ev_fft1_read_cur{nullptr}; std::atomic<bool> read_alias_wanted{false}, producer_seen{false}; hipEvent_t ev_in_guard = nullptr; std::atomic<bool> in_pending{false}, fft1_read_valid{false};
   std::mutex mtx_in;                  // the producer side (lrh_timf1_write_async / _wait) has a lock of its own: an input thread is never held up by a stage call that sleeps on the staging ring
+  // Producer copies out of a page-locked arena are noted here and issued merged -- by the producer once in_merge_bytes have gathered, by the next
+  // reader of timf1 (wait_for_input) or by lrh_timf1_write_wait / lrh_sync whichever comes first: a receiver that hands over one fft1 block per
+  // call (32 kB at fft1_size 16384) otherwise makes 7680 hipMemcpyAsync calls per 63 Msamples, and every one of them holds the runtime's locks
+  // against the stage threads' own calls (profiles/r06_glue_trace.txt).  Under mtx_in.  LRH_IN_MERGE_KB (0: every call copies at once)
+  struct InSpan { const char *src; int off, nbytes; };
+  std::vector<InSpan> in_spans; size_t in_span_bytes = 0, in_merge_bytes = 256u << 10;
+  // ... and a reader waits for the copies that carry ITS samples, not for everything the producer has queued by then (a producer that runs ahead
+  // -- a file played at full speed -- otherwise puts every transform behind a train of copies it does not need): after every issue an event
+  // goes into this ring with the count of bytes issued so far and the ring offset they end at
+  struct InMark { hipEvent_t ev = nullptr; long long total = -1; };
+  InMark in_marks[32]; unsigned in_mark_n = 0; long long in_total = 0; int in_off_end = 0;
   hipStream_t stream_sel = nullptr;  // the limiter kernels: one workgroup for ~0.5 ms, kept off the side stream (the blanker of the next round queues there)
   hipStream_t stream3 = nullptr;     // upload stream: mix1 phase tables of the lagged schedule travel a round ahead of their kernels
   hipStream_t stream2 = nullptr;     // side stream for the bandwidth-bound small kernels inside lrh_wideband_dsp
@@ -443,7 +454,35 @@ static int lrh_caught(lrh_ctx *c, const char *what) noexcept
 #define LRH_CATCH_NOCTX catch (const std::exception &e_) { return lrh_caught(nullptr, e_.what()); } catch (...) { return lrh_caught(nullptr, "unknown exception"); }
 #define LRH_CATCH_OPEN(out) catch (const std::exception &e_) { if (out) *(out) = nullptr; return lrh_caught(nullptr, e_.what()); } catch (...) { if (out) *(out) = nullptr; return lrh_caught(nullptr, "unknown exception"); }
 // entry of an API call: the context's lock (see lrh_ctx::mtx) and its device for this host thread
-#define LRH_LOCK(c) std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); hipSetDevice((c)->cfg.device); }
+// LRH_CALLPROF=1 (diagnostics): per entry point that takes the context's lock, the calls, the time spent waiting for the lock and the time from there
+// to the return, printed by lrh_close (where a stage thread's time goes when several of them share a context: profiles/r06_glue_trace.txt)
+static const bool g_callprof = getenv("LRH_CALLPROF") && atoi(getenv("LRH_CALLPROF"));
+struct CallProfSite { std::atomic<const char *> name{nullptr}; std::atomic<long long> calls{0}, wait_ns{0}, held_ns{0}; };
+static CallProfSite g_callprof_sites[128];
+struct CallProfScope {
+  const char *fn; std::chrono::steady_clock::time_point t0, t1; bool on;
+  explicit CallProfScope(const char *f) : fn(f), on(g_callprof) { if (on) t0 = t1 = std::chrono::steady_clock::now(); }
+  void locked() { if (on) t1 = std::chrono::steady_clock::now(); }
+  ~CallProfScope() {
+    if (!on) return;
+    const auto t2 = std::chrono::steady_clock::now();
+    for (auto &s : g_callprof_sites) {
+      const char *n = s.name.load();
+      if (!n) { const char *expect = nullptr; if (!s.name.compare_exchange_strong(expect, fn)) n = expect; else n = fn; }
+      if (n == fn) { s.calls++; s.wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(); s.held_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count(); return; }
+    }
+  }
+};
+static void callprof_print()
+{
+  if (!g_callprof) return;
+  for (auto &s : g_callprof_sites) {
+    const char *n = s.name.load(); const long long k = s.calls.exchange(0);
+    if (!n || !k) continue;
+    fprintf(stderr, "LRH_CALLPROF %-28s %8lld calls  lock wait %8.1f us  then %8.1f us  per call\n", n, k, 1e-3 * s.wait_ns.exchange(0) / k, 1e-3 * s.held_ns.exchange(0) / k);
+  }
+}
+#define LRH_LOCK(c) CallProfScope cps_(__func__); std::unique_lock<std::recursive_mutex> lk_; if (c) { lk_ = std::unique_lock<std::recursive_mutex>((c)->mtx); cps_.locked(); hipSetDevice((c)->cfg.device); }
 // ... and, for every entry point that may look at or change what the chain has produced, the launches lrh_wideband_dsp still holds
 // back from its last round (one-round-late schedule kept across calls, see there) go out first
 static int flush_pending(lrh_ctx *c);
@@ -721,6 +760,7 @@ LRH_CATCH_NOCTX
 void lrh_close(lrh_ctx *c)
 try {
   if (!c) return;
+  callprof_print();
   if (g_hostprof && !g_hostprof_sites.empty()) {
     std::vector<std::pair<std::string, HostProfSite>> v(g_hostprof_sites.begin(), g_hostprof_sites.end());
     std::sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.second.ns > b.second.ns; });
@@ -738,6 +778,7 @@ try {
   for (int h = 0; h < LRH_MAX_HANDLES; h++) { if (c->hstream[h]) { hipStreamSynchronize(c->hstream[h]); hipStreamDestroy(c->hstream[h]); } if (c->hev[h]) hipEventDestroy(c->hev[h]); }
   if (c->hev_start) hipEventDestroy(c->hev_start);
   if (c->ev_in) hipEventDestroy(c->ev_in);
+  for (auto &m : c->in_marks) if (m.ev) hipEventDestroy(m.ev);
   if (c->ev_fft1_read) hipEventDestroy(c->ev_fft1_read);
   if (c->ev_in_guard) hipEventDestroy(c->ev_in_guard);
   if (c->stream_nb) { hipStreamSynchronize(c->stream_nb); hipStreamDestroy(c->stream_nb); }
@@ -863,6 +904,7 @@ try {
   if (const char *e6 = getenv("LRH_SPARE_CUS")) { c->spare_cus = atoi(e6); if (c->spare_cus < 0 || c->spare_cus > 128) c->spare_cus = 0; }
   if (const char *e8 = getenv("LRH_PERSIST")) c->persist = atoi(e8) != 0;
   if (const char *e8 = getenv("LRH_OUT_STREAM")) c->out_ok = atoi(e8) != 0;
+  if (const char *e9 = getenv("LRH_IN_MERGE_KB")) { const long v = atol(e9); c->in_merge_bytes = v <= 0 ? 0 : (size_t)(v > (1 << 20) ? (1 << 20) : v) << 10; }
   if (const char *e8 = getenv("LRH_STAGE_LAG")) { c->stage_lag_env = atoi(e8); if (c->stage_lag_env > 3) c->stage_lag_env = 3; }
   if (const char *e8 = getenv("LRH_WORKER_FAST")) c->worker_fast = atoi(e8) != 0;
   if (const char *e5 = getenv("LRH_CLEVER_SERIAL")) c->clever_force_serial = atoi(e5) != 0;
@@ -1588,10 +1630,12 @@ try {
 }
 LRH_CATCH(c)
 
+static int flush_input_locked(lrh_ctx *c);
 int lrh_timf1_write(lrh_ctx *c, const void *src, int off, int nbytes)
 try {
   LRH_LOCK(c);
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
+  { std::lock_guard<std::mutex> lk_in(c->mtx_in); if (!c->in_spans.empty()) { const int rc_ = flush_input_locked(c); if (rc_) return rc_; } }   // (noted producer copies keep their place in front of this one)
   off &= c->timf1_bytemask;
   const char *s = (const char *)src; char *d = (char *)c->d_timf1;
   int first = nbytes < c->cfg.timf1_bytes - off ? nbytes : c->cfg.timf1_bytes - off;
@@ -1603,6 +1647,28 @@ try {
 LRH_CATCH(c)
 void *lrh_timf1_device_ptr(lrh_ctx *c) { return c ? c->d_timf1 : nullptr; }
 
+// `bytes` more have been issued on the producer's stream, ending at ring offset `off_end`: an event behind them (lrh_ctx::in_marks; the caller holds mtx_in)
+static int input_mark(lrh_ctx *c, long long bytes, int off_end)
+{
+  lrh_ctx::InMark &m = c->in_marks[c->in_mark_n % 32];
+  if (!m.ev) HIPCHK(c, hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+  c->in_total += bytes; c->in_off_end = off_end;
+  HIPCHK(c, hipEventRecord(m.ev, c->stream_in));
+  m.total = c->in_total; c->in_mark_n++;
+  return LRH_OK;
+}
+// the noted producer copies (lrh_ctx::in_spans) onto the producer's stream; the caller holds mtx_in
+static int flush_input_locked(lrh_ctx *c)
+{
+  for (const auto &sp : c->in_spans) {
+    const int first = sp.nbytes < c->cfg.timf1_bytes - sp.off ? sp.nbytes : c->cfg.timf1_bytes - sp.off;
+    HIPCHK(c, hipMemcpyAsync((char *)c->d_timf1 + sp.off, sp.src, first, hipMemcpyHostToDevice, c->stream_in));
+    if (sp.nbytes > first) HIPCHK(c, hipMemcpyAsync(c->d_timf1, sp.src + first, sp.nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+  }
+  if (!c->in_spans.empty()) { const int rc_ = input_mark(c, (long long)c->in_span_bytes, (c->in_spans.back().off + c->in_spans.back().nbytes) & c->timf1_bytemask); if (rc_) return rc_; }
+  c->in_spans.clear(); c->in_span_bytes = 0;
+  return LRH_OK;
+}
 int lrh_timf1_write_async(lrh_ctx *c, const void *src, int off, int nbytes)
 try {
   if (!c || !src || nbytes < 0 || nbytes > c->cfg.timf1_bytes) return LRH_EINVAL;
@@ -1642,12 +1708,23 @@ try {
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hread[h].exchange(false)) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->hev[h], 0));   // workers that launch themselves (LRH_WORKER_FAST=0, the four-step sizes)
   if (guard) HIPCHK(c, hipStreamWaitEvent(c->stream_in, c->ev_in_guard, 0));
   if (host_span_registered(c, s, (size_t)nbytes)) {         // the caller's page-locked arena (lrh_host_register): the copy engine reads it while the caller goes on
-    HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
-    if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+    if (c->in_merge_bytes) {                                 // noted; issued with its neighbours (lrh_ctx::in_spans)
+      if (!c->in_spans.empty() && c->in_spans.back().src + c->in_spans.back().nbytes == s && c->in_spans.back().off + c->in_spans.back().nbytes == off &&
+          off + nbytes <= c->cfg.timf1_bytes) c->in_spans.back().nbytes += nbytes;
+      else c->in_spans.push_back({s, off, nbytes});
+      c->in_span_bytes += (size_t)nbytes;
+      if (c->in_span_bytes >= c->in_merge_bytes) { const int rc_ = flush_input_locked(c); if (rc_) return rc_; }
+    } else {
+      HIPCHK(c, hipMemcpyAsync(d + off, s, first, hipMemcpyHostToDevice, c->stream_in));
+      if (nbytes > first) HIPCHK(c, hipMemcpyAsync(d, s + first, nbytes - first, hipMemcpyHostToDevice, c->stream_in));
+      { const int rc_ = input_mark(c, nbytes, (off + nbytes) & c->timf1_bytemask); if (rc_) return rc_; }
+    }
   } else {                                                   // pageable memory: through the producer's own staging buffer, done when this returns (the order on stream_in is the same)
+    { const int rc_ = flush_input_locked(c); if (rc_) return rc_; }
     if (!c->h_stage_in && lrh_host_malloc(&c->h_stage_in, LRH_STAGE_BYTES) != hipSuccess) { c->h_stage_in = nullptr; return fail(c, LRH_ENOMEM, "hipHostMalloc(producer staging)"); }
     HIPCHK(c, stage_h2d(c, d + off, s, (size_t)first, c->stream_in, c->h_stage_in));
     if (nbytes > first) HIPCHK(c, stage_h2d(c, d, s + first, (size_t)(nbytes - first), c->stream_in, c->h_stage_in));
+    { const int rc_ = input_mark(c, nbytes, (off + nbytes) & c->timf1_bytemask); if (rc_) return rc_; }
   }
   c->in_pending = true;                                      // (the reader records the event behind the copies it needs: wait_for_input)
   return LRH_OK;
@@ -1658,6 +1735,7 @@ try {
   if (!c) return LRH_EINVAL;
   std::lock_guard<std::mutex> lk_in(c->mtx_in);
   hipSetDevice(c->cfg.device);
+  { const int rc_ = flush_input_locked(c); if (rc_) return rc_; }
   if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
   return LRH_OK;
 }
@@ -1706,7 +1784,8 @@ LRH_CATCH(c)
 // ---------------------------------------------------------------------------------------------- fft1
 // Transforms launched by fft1_b workers on their own streams: whoever reads fft1_float next on the main stream waits for them.
 static int launch_parked_fft1(lrh_ctx *c);
-static int wait_for_input(lrh_ctx *c, hipStream_t S);
+static int wait_for_input(lrh_ctx *c, hipStream_t S, int need_end = -1);
+static int timf1_read_end(const lrh_ctx *c, int timf1p_ref, int batch);
 static Fft1Args fft1_args_of(lrh_ctx *c, int timf1p_ref, int fft1_pa, int batch);
 // the blocks the fft1_b workers have noted (lrh_ctx::wparked): in ring order, one launch per contiguous run, on the main stream
 static int issue_parked_workers(lrh_ctx *c)
@@ -1724,7 +1803,8 @@ static int issue_parked_workers(lrh_ctx *c)
   const long long C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1, esz = c->cfg.timf1_dword_input ? 8 : 4;
   hipStream_t keep = c->cur; c->cur = c->stream;
   struct CurBack { lrh_ctx *c; hipStream_t s; ~CurBack() { c->cur = s; } } cur_back{c, keep};
-  if (c->in_pending.exchange(false)) { const int rc_ = wait_for_input(c, c->cur); if (rc_) return rc_; }
+  if (c->in_pending) {                                       // (sorted in ring order: the last entry reads furthest)
+    const int rc_ = wait_for_input(c, c->cur, timf1_read_end(c, v.back().timf1p_ref, v.back().batch)); if (rc_) return rc_; }
   size_t i = 0;
   while (i < v.size()) {
     int batch = v[i].batch; size_t j = i + 1;
@@ -1789,13 +1869,38 @@ static void worker_read_note(lrh_ctx *c, int timf1p_ref, int batch)
   if (d + len > c->rd_span) c->rd_span = d + len;
 }
 
-// the producer's copies (lrh_timf1_write_async, its own stream) in front of a reader on stream S: the event is recorded here, by the reader
-// -- one record per reader call instead of one per copy
-static int wait_for_input(lrh_ctx *c, hipStream_t S)
+// ring offset (bytes) one past the last sample the transforms of [timf1p_ref, batch) read (fft1.c:421-426)
+static int timf1_read_end(const lrh_ctx *c, int timf1p_ref, int batch)
 {
+  const long long C = c->cfg.timf1_frame_channels > 1 ? c->cfg.timf1_frame_channels : 1, esz = c->cfg.timf1_dword_input ? 8 : 4, ring = c->cfg.timf1_bytes;
+  const long long start = (((long long)(timf1p_ref & c->timf1_bytemask) - c->I1 * esz * C) % ring + ring) % ring;
+  return (int)((start + ((long long)c->N1 + (long long)(batch - 1) * c->M1) * esz * C) % ring);
+}
+// the producer's copies (lrh_timf1_write_async, its own stream) in front of a reader on stream S.  need_end >= 0: the ring offset the reader's samples
+// end at -- it waits for the first issue that reaches it (lrh_ctx::in_marks); -1, or no mark to tell: for everything issued so far (an event recorded
+// here, by the reader).  The flag that sends readers here goes down only when this reader has waited for the newest issue.
+static int wait_for_input(lrh_ctx *c, hipStream_t S, int need_end)
+{
+  std::lock_guard<std::mutex> lk_in(c->mtx_in);
+  if (!c->in_spans.empty()) { const int rc_ = flush_input_locked(c); if (rc_) return rc_; }   // (what the producer has noted but not issued yet)
+  if (need_end >= 0 && c->in_mark_n > 0) {
+    const long long ring = c->cfg.timf1_bytes, ahead = ((c->in_off_end - need_end) % ring + ring) % ring;   // bytes issued beyond the reader's last
+    if (ahead <= ring / 2) {
+      const long long need_total = c->in_total - ahead;
+      const unsigned kept = c->in_mark_n < 32 ? c->in_mark_n : 32;
+      for (unsigned k = c->in_mark_n - kept; k != c->in_mark_n; k++) {
+        const lrh_ctx::InMark &m = c->in_marks[k % 32];
+        if (m.total < need_total) continue;
+        HIPCHK(c, hipStreamWaitEvent(S, m.ev, 0));
+        if (k + 1 == c->in_mark_n) c->in_pending = false;
+        return LRH_OK;
+      }
+    }
+  }
   std::lock_guard<std::mutex> lk(c->mtx_evin);
   HIPCHK(c, hipEventRecord(c->ev_in, c->stream_in));
   HIPCHK(c, hipStreamWaitEvent(S, c->ev_in, 0));
+  c->in_pending = false;
   return LRH_OK;
 }
 
@@ -1827,10 +1932,10 @@ try {
     }
     HIPCHK(c, hipEventRecord(c->hev_start, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->hstream[handle], c->hev_start, 0));
-    if (c->in_pending) { const int rc_ = wait_for_input(c, c->hstream[handle]); if (rc_) return rc_; }      // every worker waits for the producer's copy
+    if (c->in_pending) { const int rc_ = wait_for_input(c, c->hstream[handle], timf1_read_end(c, timf1p_ref, batch)); if (rc_) return rc_; }      // every worker waits for the producer's copy
     { std::lock_guard<std::mutex> lkw(c->mtx_w); worker_read_note(c, timf1p_ref, batch); }
     c->cur = c->hstream[handle];
-  } else if (c->in_pending.exchange(false)) { const int rc_ = wait_for_input(c, c->cur); if (rc_) return rc_; }   // samples of lrh_timf1_write_async (a copy enqueued meanwhile raises the flag again)
+  } else if (c->in_pending) { const int rc_ = wait_for_input(c, c->cur, timf1_read_end(c, timf1p_ref, batch)); if (rc_) return rc_; }   // samples of lrh_timf1_write_async
   Fft1Args a = fft1_args_of(c, timf1p_ref, fft1_pa, batch);
   const int C = a.chan_count;
   if (c->dbg_stamp) {                                     // diagnostics (LRH_STAMP=1, -DLRH_STAMP_BUILD): phase stamps of this launch to stderr
@@ -1994,7 +2099,9 @@ int lrh_make_timf2(lrh_ctx *c, lrh_ptrs *p, int batch)
 try {
   LRH_ENTER(c);
   if (!c || !p || batch < 1 || batch > c->cfg.max_batch) return LRH_EINVAL;
-  LRH_WRITES(c, RB(LRH_RING_FFT1_FLOAT) | RB(LRH_RING_FFT1_SUMSQ) | RB(LRH_RING_FFT1_SLOWSUM) | RB(LRH_RING_TIMF2_FLOAT) | RB(LRH_RING_TIMF2_PWR));
+  // (the sums only when they are parked for this call's kernel: a caller that has just begun to read this period's spectra back --
+  // the glue between lrh_fft1_c and this call -- must not have its weak stream queued behind those copies, 110 us per call at fft1_size 16384)
+  LRH_WRITES(c, RB(LRH_RING_FFT1_FLOAT) | (c->ss_have ? RB(LRH_RING_FFT1_SUMSQ) | RB(LRH_RING_FFT1_SLOWSUM) : 0u) | RB(LRH_RING_TIMF2_FLOAT) | RB(LRH_RING_TIMF2_PWR));
   // k_fft1w: the parked forward transform, the parked sums and this call's weak stream address the same transforms
   const int nb_here = (p->fft1_px / (2 * c->N1)) & c->fft1n_mask;
   const bool fused_any = c->f1_have && c->ss_have && c->timf2_mode == 1 && c->f1_batch == batch && c->f1_args.first_nb == nb_here &&
@@ -3840,6 +3947,7 @@ try {
   LRH_ENTER(c);
   { const int rc_ = join_handles(c); if (rc_) return rc_; }  // blocks the fft1_b workers have noted
   // every stream of the context: producer copies (the header lets the caller reuse `src` after this) and table uploads too
+  { std::lock_guard<std::mutex> lk_in(c->mtx_in); const int rc_ = flush_input_locked(c); if (rc_) return rc_; }
   for (hipStream_t s : { c->stream_in, c->stream3, c->stream, c->stream2, c->stream_nb, c->stream_sel }) if (s) HIPCHK(c, hipStreamSynchronize(s));
   for (int h = 1; h < LRH_MAX_HANDLES; h++) if (c->hstream[h]) HIPCHK(c, hipStreamSynchronize(c->hstream[h]));
   return sellim_install(c, c->sel_seq);

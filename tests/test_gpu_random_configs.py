@@ -226,7 +226,7 @@ def random_sellim_case(seed):
     maxlevel = int(rng.choice([1500, 4000, 12000]))
     nblk = int(rng.choice([96, 128, 160, 200]))
     on = int(rng.integers(10, nblk // 2))
-    t = dict(base=base, nblk=nblk, maxlevel=maxlevel, lim_groups=int(rng.choice([8, 16, 32, 64])), blocktime=float(rng.choice([0.0008, 0.002, 0.005])),
+    t = dict(base=base, nblk=nblk, maxlevel=maxlevel, lim_groups=int(rng.choice([16, 32, 64][:2 if n1 == 512 else 3])), max_fft1n=32, sumsq_blocks=16, blocktime=float(rng.choice([0.0008, 0.002, 0.005])),
              ston_fft1=float(rng.uniform(2.5, 6.0)), bw_fftxpts=int(rng.integers(8, 64)), seed=int(7000 + seed), sample_shift=0, blockpower_block=0,
              keyed=(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(0.3, 1.6) * maxlevel), on, int(rng.integers(on + 5, nblk))),
              par1=int(rng.integers(0, 3)), par2=int(rng.integers(0, 2)), par3=int(rng.integers(0, 2)), par4=int(rng.integers(0, 2)), par5=int(rng.integers(0, 3)),
@@ -234,7 +234,8 @@ def random_sellim_case(seed):
              ston_fft2=float(rng.uniform(8.0, 45.0)), wf_avgnum=int(rng.integers(1, 4)),
              strong=[(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(0.2, 1.5) * maxlevel)) for _ in range(int(rng.integers(0, 5)))],
              weak=[(float(rng.uniform(-0.45, 0.45) * n1), float(rng.uniform(30.0, 600.0))) for _ in range(int(rng.integers(0, 4)))])
-    return t, dict(batch=int(rng.choice([1, 4, 8])), in_call=bool(rng.random() < 0.5), fq=float(rng.uniform(0.1, 0.9)))
+    # (buf.c:816-820: 16 .. fft1_size / 16 groups)
+    return t, dict(batch=int(rng.choice([1, 2, 4, 8])), in_call=bool(rng.random() < 0.5), fq=float(rng.uniform(0.1, 0.9)))
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_SELLIM_SEEDS", "12"))))
@@ -257,6 +258,8 @@ def test_random_selective_limiter_matches_the_oracle(seed):
     cfg = lrh_config(d, iq, max_batch=max(4, batch))
     N1, N2 = 1 << d["n1"], 1 << d["n2"]
     bt2 = float(np.float32(sl["blocktime"]) * np.float32(N2 - interleave(d["n2"], d["sinpow2"])) / np.float32(N1 - interleave(d["n1"], d["sinpow1"])))
+    rings = [(abi.RING_TIMF2_FLOAT, "timf2"), (abi.RING_FFT1_SLOWSUM, "slowsum"), (abi.RING_TIMF3_FLOAT, "timf3")]
+    nr = d["nblk"] // batch
     res = []
     for fn in (_open_hip, _open_oracle):
         rx = fn(cfg)
@@ -266,7 +269,6 @@ def test_random_selective_limiter_matches_the_oracle(seed):
                              blanker_ston_fft1=sl["ston_fft1"], baseband_bw_fftxpts=sl["bw_fftxpts"], blanker_ston_fft2=sl["ston_fft2"], fft2_blocktime=bt2,
                              exact_stats=1, **{f"sellim_par{i}": sl[f"par{i}"] for i in range(1, 9)})
         trace, amps, lows = [], [], []
-        nr = d["nblk"] // batch
         if how["in_call"]:
             rx.wideband_limiter(par, bool(sl["sellim2"]))
         c1 = c2 = 0
@@ -282,9 +284,23 @@ def test_random_selective_limiter_matches_the_oracle(seed):
             trace.append(rx.get_liminfo())
             amps.append(rx.liminfo_amplitude_factor())
             lows.append(rx.p.fft1_lowlevel_points)
-        res.append(dict(trace=np.array(trace), amp=np.array(amps, np.float32), low=np.array(lows), p=rx.p.as_dict(), timf2=rx.export(abi.RING_TIMF2_FLOAT),
-                        slowsum=rx.export(abi.RING_FFT1_SLOWSUM), timf3=rx.export(abi.RING_TIMF3_FLOAT)))
+        res.append(dict(trace=np.array(trace), amp=np.array(amps, np.float32), low=np.array(lows), p=rx.p.as_dict(), **{k: rx.export(r) for r, k in rings}))
         rx.close()
+
+    def truth():
+        """the float64 build routed by the oracle's tables round by round (its own limiter could decide otherwise on a bin at the threshold)"""
+        if "t" not in truth.__dict__:
+            rx = _open_truth(cfg)
+            rx.timf1_write(iq)
+            rx.set_mix1_selfreq(how["fq"] * N2)
+            for r in range(nr):
+                if r:
+                    rx.set_liminfo(res[1]["trace"][r - 1])
+                    rx.set_liminfo_amplitude_factor(float(res[1]["amp"][r - 1]))
+                rx.wideband_dsp(batch, batch)
+            truth.t = {k: rx.export(r) for r, k in rings}
+            rx.close()
+        return truth.t
     h, o = res
     ctx = dict(seed=seed, case={k: v for k, v in t.items() if k not in ("strong", "weak")}, how=how)
     bad = np.nonzero((np.sign(h["trace"]) != np.sign(o["trace"])).any(axis=1))[0]
@@ -298,8 +314,8 @@ def test_random_selective_limiter_matches_the_oracle(seed):
     assert verr <= 1e-5 and aerr <= 1e-6, (ctx, verr, aerr)
     keep = np.ones(h["timf2"].size, bool)
     keep[(h["p"]["timf2_pa"] + np.arange(4 * (N1 // 2))) % keep.size] = False
-    e2 = relerr(h["timf2"] * keep, o["timf2"] * keep)
-    e3 = relerr(h["timf3"], o["timf3"])
-    es = relerr(h["slowsum"], o["slowsum"])
-    print(ctx, "strong", int(np.count_nonzero(o["trace"][-1])), "attenuated", int(pos[-1].sum()), "table", verr, "amp", aerr, "timf2", e2, "timf3", e3, "slowsum", es)
-    assert e2 <= 1e-5 and e3 <= 1e-5 and es <= 1e-5, (ctx, e2, e3, es)
+    rep = {}
+    truth_gate(rep, "timf2", h["timf2"] * keep, o["timf2"] * keep, lambda: truth()["timf2"] * keep, tol=1e-5, factor=1.25)
+    truth_gate(rep, "timf3", h["timf3"], o["timf3"], lambda: truth()["timf3"], tol=1e-5, factor=1.25)
+    truth_gate(rep, "slowsum", h["slowsum"], o["slowsum"], lambda: truth()["slowsum"], tol=1e-5, factor=1.25)
+    print(ctx, "strong", int(np.count_nonzero(o["trace"][-1])), "attenuated", int(pos[-1].sum()), "table", verr, "amp", aerr, rep)
