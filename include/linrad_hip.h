@@ -407,7 +407,12 @@ void *lrh_timf1_device_ptr(lrh_ctx *ctx);                                       
    synchronous lrh_timf1_write travels on the main stream and is not ordered against copies still queued here.
    Round 6: a source that does NOT lie in a span registered with lrh_host_register is copied through a page-locked staging buffer of
    the library and the call returns when the samples are on the device (same order on the copy stream): the library never lets the
-   HIP runtime pin pageable caller memory on the fly -- neither here nor in any table upload or read-back. */
+   HIP runtime pin pageable caller memory on the fly -- neither here nor in any table upload or read-back.
+   Calls out of a registered span are NOTED and issued merged: by the producer's own call once 256 kB have gathered (LRH_IN_MERGE_KB; 0: every
+   call copies at once), by the next reader of timf1 for what it reads, by lrh_timf1_write_wait / lrh_sync / lrh_host_unregister for all of it
+   -- a receiver that hands over one fft1 block per call would otherwise make a hipMemcpyAsync per 32 kB.  A reader waits for the issue that
+   carries ITS samples, not for everything a producer running ahead has queued (profiles/r06_glue_trace.txt).  The contract is the one above:
+   `src` untouched until lrh_timf1_write_wait / lrh_sync -- Linrad's timf1 ring, which keeps a block for a whole lap, does that by itself. */
 int lrh_timf1_write_async(lrh_ctx *ctx, const void *src, int byte_offset, int nbytes);
 int lrh_timf1_write_wait(lrh_ctx *ctx);
 int lrh_host_register(lrh_ctx *ctx, void *ptr, size_t bytes);

@@ -1755,7 +1755,11 @@ try {
   LRH_ENTER(c);
   // read-backs still on their way into the span first (the copy engine writes there)
   for (int i = 0; i < LRH_NOUT; i++) if (c->out_busy[i] && c->ev_out_done[i]) hipEventSynchronize(c->ev_out_done[i]);
-  { std::lock_guard<std::mutex> lk_in(c->mtx_in); for (size_t i = 0; i < c->host_regs.size(); i++) if (c->host_regs[i].first == (char *)ptr) { c->host_regs.erase(c->host_regs.begin() + i); break; } }
+  { std::lock_guard<std::mutex> lk_in(c->mtx_in);
+    // producer copies out of the span: the noted ones issued, all of them done before the pages are let go
+    { const int rc_ = flush_input_locked(c); if (rc_) return rc_; }
+    if (c->stream_in) HIPCHK(c, hipStreamSynchronize(c->stream_in));
+    for (size_t i = 0; i < c->host_regs.size(); i++) if (c->host_regs[i].first == (char *)ptr) { c->host_regs.erase(c->host_regs.begin() + i); break; } }
   HIPCHK(c, hipHostUnregister(ptr));
   return LRH_OK;
 }
@@ -3713,8 +3717,8 @@ static int export_impl(lrh_ctx *c, lrh_ring ring, void *dst, size_t off, size_t 
   LRH_ENTER(c);
   // transforms of the fft1_b workers (their own streams) and a parked transform: only a reader of what fft1 itself leaves needs them --
   // everything behind fft1_c / make_timf2 was enqueued by calls that have joined them already
-  if (ring == LRH_RING_TIMF1 || ring == LRH_RING_FFT1_FLOAT || ring == LRH_RING_FFT1_SUMSQ || ring == LRH_RING_FFT1_SLOWSUM || ring == LRH_RING_FFT1_CORRSUM ||
-      ring == LRH_RING_FFT1_SLOWCORR || ring == LRH_RING_FFT1_SLOWCORR_TOT || c->f1_have) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // (incl. the workers' noted blocks)
+  // (the sums of fft1_c are behind transforms that call has issued itself: a reader of them does not have to issue what the workers have noted since)
+  if (ring == LRH_RING_TIMF1 || ring == LRH_RING_FFT1_FLOAT || c->f1_have) { const int rc_ = join_handles(c); if (rc_) return rc_; }   // (incl. the workers' noted blocks)
   const void *src; size_t esz = 4, total;
   switch (ring) {
     case LRH_RING_TIMF1: src = c->d_timf1; esz = 2; total = c->cfg.timf1_bytes / 2; break;

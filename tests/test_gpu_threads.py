@@ -125,3 +125,55 @@ def test_read_backs_into_page_locked_destinations_and_lagged_stage_waits():
         assert np.array_equal(dst, full[pa:pa + n1]) and np.any(dst)
     assert lib.lrh_host_unregister(rx.ctx, pinned.ctypes.data_as(C.c_void_p)) == 0
     rx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("merge_kb", ["0", "16", "256"])
+def test_producer_running_ahead_block_by_block(merge_kb, monkeypatch):
+    """round 6: lrh_timf1_write_async out of a page-locked arena notes its copies and issues them merged (LRH_IN_MERGE_KB), and a reader waits for the
+    issue that carries its own samples.  A producer that hands over one block per call and runs a random distance ahead of the reader, three laps
+    of a small timf1 ring, against the same stream written synchronously block by block: transforms and sums bit-identical"""
+    import numpy as np
+    from linrad_amd import abi
+    from linrad_amd.lib import open_hip, synth_defaults, synth_iq
+    from linrad_amd.workload import chain_config
+    monkeypatch.setenv("LRH_IN_MERGE_KB", merge_kb)
+    cfg = chain_config(fft1_n=12, fft2_n=10, batch=16)
+    cfg.timf1_bytes = 1 << 18
+    nblk = 100
+    rx = open_hip(cfg)
+    bb, mask = rx.timf1_blockbytes, cfg.timf1_bytes - 1
+    ring_blocks = cfg.timf1_bytes // bb
+    per = bb // 2                                              # int16 values per block
+    arena = np.ascontiguousarray(synth_iq(synth_defaults(1 << cfg.fft1_n, 0), 0, nblk * per // 2))
+    assert arena.size == nblk * per and ring_blocks == 32
+    px0 = rx.p.timf1p_px
+
+    def result(r):
+        out = (r.export(abi.RING_FFT1_FLOAT), r.export(abi.RING_FFT1_SUMSQ), r.export(abi.RING_FFT1_SLOWSUM), r.p.as_dict())
+        r.close()
+        return out
+    for k in range(nblk):                                      # reference: block k on the device before its transform is asked for
+        rx.timf1_write(arena[k * per:(k + 1) * per], (px0 + k * bb) & mask)
+        rx.fft1_b(1), rx.fft1_c(1)
+    ref = result(rx)
+    rx = open_hip(cfg)
+    rx.host_register(arena)
+    rng = np.random.default_rng(5)
+    written = consumed = 0
+    while consumed < nblk:
+        for _ in range(int(rng.integers(0, 13))):
+            if written == nblk or written - consumed >= ring_blocks // 2:
+                break
+            rx.timf1_write_async(arena[written * per:(written + 1) * per], (px0 + written * bb) & mask)
+            written += 1
+        if written > consumed:
+            n = int(rng.integers(1, min(4, written - consumed) + 1))
+            rx.fft1_b(n), rx.fft1_c(n)
+            consumed += n
+    rx.timf1_write_wait()
+    rx.host_unregister(arena)
+    got = result(rx)
+    assert got[3] == ref[3]
+    for a, b, name in zip(got[:3], ref[:3], ("fft1_float", "fft1_sumsq", "fft1_slowsum")):
+        assert np.array_equal(a, b), name
