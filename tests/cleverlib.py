@@ -22,9 +22,10 @@ def install_tables(api, g, noise_floor):
                            clever_bln_limit=int(np.float32(noise_floor) * np.float32(bf[1])), liminfo_amplitude_factor=float(bf[0]))
 
 
-def run(open_fn, name, g):
-    d, cl, iq, lim, des = clever_case(name)
-    assert np.array_equal(iq, g["iq"])
+def run(open_fn, name, g, case=None):
+    """case: (d, cl, iq, lim, des) of another input on the golden's tables (the random tests); None: the golden's own case"""
+    d, cl, iq, lim, des = case if case is not None else clever_case(name)
+    assert case is not None or np.array_equal(iq, g["iq"])
     bi = g["bln_ints"]
     d = dict(d, pulsewidth=int(bi[1]), blnfit_range=int(bi[3]))
     cfg = lrh_config(d, iq)

@@ -16,10 +16,11 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
 
 
-def run(open_fn, name, g, batch=1, acquire=False):
+def run(open_fn, name, g, batch=1, acquire=False, case=None):
     """acquire: the spur is found by the API's own store_new_spur / spur_phase_lock (spur_acquire) on the resident spectra instead of
-    being handed over with the reference's acquisition result"""
-    d, sp, iq, lim = spur_case(name)
+    being handed over with the reference's acquisition result.  case: (d, sp, iq, lim) of another input (the random tests; g then carries the
+    line-shape table and the hand-over point only)"""
+    d, sp, iq, lim = case if case is not None else spur_case(name)
     if "iq" in g:
         assert np.array_equal(iq, g["iq"])
     else:                                                    # (large input: the golden holds two checksums of it)

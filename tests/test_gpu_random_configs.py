@@ -319,3 +319,104 @@ def test_random_selective_limiter_matches_the_oracle(seed):
     truth_gate(rep, "timf3", h["timf3"], o["timf3"], lambda: truth()["timf3"], tol=1e-5, factor=1.25)
     truth_gate(rep, "slowsum", h["slowsum"], o["slowsum"], lambda: truth()["slowsum"], tol=1e-5, factor=1.25)
     print(ctx, "strong", int(np.count_nonzero(o["trace"][-1])), "attenuated", int(pos[-1].sum()), "table", verr, "amp", aerr, rep)
+
+
+def random_clever_case(seed):
+    """another pulse train (count, amplitudes, unresolved pairs, rectangular hits, noise) on the tables one of the linear-blanker goldens carries"""
+    import refcases
+    rng = np.random.default_rng(9100 + seed)
+    base = str(rng.choice(["clever_n10_n12", "clever_n9_n11_only"]))
+    t = dict(refcases.CLEVER[base])
+    lo = float(rng.uniform(800.0, 4000.0))
+    t.update(pulses=int(rng.integers(5, 120)), pulse_seed=int(300 + seed), amp=(lo, lo * float(rng.uniform(2.0, 12.0))), pairs=int(rng.integers(0, 10)),
+             rects=int(rng.integers(0, 6)), seed=int(9200 + seed), nblk=int(rng.choice([64, 96, 128])))
+    t["pairs"] = min(t["pairs"], t["pulses"])
+    return base, t
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_CLEVER_SEEDS", "10"))))
+def test_random_linear_blanker_matches_the_oracle(seed):
+    """the linear ("clever") blanker (blank1.c:36-1087: pulse search, fit against the reference pulse at the fitted fractional delay, subtraction, the
+    rejected ones left to the stupid blanker) on random pulse trains: its scalars after every call -- pointers, cleared and fitted counts, noise floor,
+    both limits -- exact, the rings behind at 1e-5"""
+    import cleverlib
+    import refcases
+    base, t = random_clever_case(seed)
+    g = cleverlib.load(base)
+    name = f"random_clever_{seed}"
+    refcases.CLEVER[name] = t
+    try:
+        case = refcases.clever_case(name)
+    finally:
+        del refcases.CLEVER[name]
+    h = cleverlib.run(_open_hip, base, g, case=case)
+    o = cleverlib.run(_open_oracle, base, g, case=case)
+    names = ["timf2_pa", "timf2p_fit", "timf2_pn2", "cleared_points", "blanker_points", "noise_floor", "stupid_limit", "clever_limit", "fitted_pulses", "last_fitted", "last_rejected"]
+    ctx = dict(seed=seed, base=base, case={k: v for k, v in t.items() if k in ("pulses", "amp", "pairs", "rects", "nblk")})
+    for j, nm in enumerate(names):
+        bad = np.nonzero(h["rows"][:, j] != o["rows"][:, j])[0]
+        assert bad.size == 0, (ctx, nm, "first differs at call", int(bad[0]), int(h["rows"][bad[0], j]), int(o["rows"][bad[0], j]))
+    n1 = h["api"].N1
+    keep = np.ones(h["timf2"].size, bool)
+    keep[(h["api"].p.timf2_pa + np.arange(4 * (n1 // 2))) % keep.size] = False
+    e2, ep, e3 = relerr(h["timf2"] * keep, o["timf2"] * keep), relerr(h["pwr"] * keep[::4], o["pwr"] * keep[::4]), relerr(h["timf3"], o["timf3"])
+    print(ctx, "fitted", int(o["rows"][:, 9].sum()), "rejected", int(o["rows"][:, 10].sum()), "cleared", int(o["rows"][-1, 3]), "timf2", e2, "pwr", ep, "timf3", e3)
+    assert np.array_equal((h["pwr"] == 0) & keep[::4], (o["pwr"] == 0) & keep[::4]), ctx
+    assert e2 <= 1e-5 and ep <= 1e-5 and e3 <= 1e-5, (ctx, e2, ep, e3)
+    h["api"].close(), o["api"].close()
+
+
+def random_spur_case(seed):
+    """a carrier of random frequency, drift and level on the n10_n12 base, acquired by the API's own store_new_spur / spur_phase_lock"""
+    rng = np.random.default_rng(4400 + seed)
+    speknum = int(rng.choice([8, 12, 16]))
+    bin0 = float(rng.uniform(600.0, 3500.0))
+    t = dict(base="n10_n12", nblk=int(rng.choice([240, 320, 400])), max_fft2n=64, blockpower_block=0, spur_pnt=int(bin0) - 3, spur_start=int(rng.integers(speknum + 4, 30)),
+             spur_speknum=speknum, tone=(bin0, float(rng.uniform(-0.4, 0.4)), float(rng.uniform(400.0, 6000.0))), fq=bin0 + float(rng.uniform(-12.0, 12.0)), seed=int(4500 + seed))
+    return t, int(rng.choice([1, 2, 4]))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_SPUR_SEEDS", "8"))))
+def test_random_spur_is_acquired_and_tracked_like_the_oracle(seed):
+    """spur removal (spursub.c:181-343 store_new_spur / spur_phase_lock / initial_remove_spur, spur.c:36-494 eliminate_spurs) on a carrier of random
+    frequency, drift and level: the same lock decision, the same window and flag after every transform, frequency / phase / amplitude of the loop,
+    the fft2 ring behind the subtraction, its power sums and timf3"""
+    import refcases
+    import spurlib
+    t, batch = random_spur_case(seed)
+    name = f"random_spur_{seed}"
+    refcases.SPUR[name] = t
+    try:
+        case = refcases.spur_case(name)
+    finally:
+        del refcases.SPUR[name]
+    gg = spurlib.load("spur_n10_n12")
+    st = np.zeros(16); st[10] = t["spur_speknum"]
+    g = {"iq": case[2], "spur_init_state": st, "spur_locked": np.array([t["spur_start"]]), "spur_spectra": gg["spur_spectra"]}
+    res = []
+    for fn in (_open_hip, _open_oracle):
+        try:
+            res.append(spurlib.run(fn, name, g, batch=batch, acquire=True, case=case))
+        except AssertionError as e:
+            assert str(e) == "no lock"
+            res.append(None)
+    ctx = dict(seed=seed, tone=t["tone"], speknum=t["spur_speknum"], start=t["spur_start"], batch=batch)
+    assert (res[0] is None) == (res[1] is None), (ctx, "lock decisions differ", res[0] is None, res[1] is None)
+    if res[0] is None:
+        print(ctx, "no lock on either side")
+        return
+    h, o = res
+    assert h["trace"].shape == o["trace"].shape and h["trace"].shape[0] > 10, (ctx, h["trace"].shape, o["trace"].shape)
+    assert np.array_equal(h["trace"][:, :2], o["trace"][:, :2]), (ctx, "spur_location / spur_flag trace differs")
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+    locked = o["trace"][:, 1] == 0
+    ferr = float(np.max(np.abs(h["trace"][:, 2] - o["trace"][:, 2])))
+    perr = float(np.max(np.abs(wrap(h["trace"][locked, 3] - o["trace"][locked, 3])))) if locked.any() else 0.0
+    aerr = float(np.max(np.abs(h["trace"][locked, 6] - o["trace"][locked, 6]) / np.abs(o["trace"][locked, 6]))) if locked.any() else 0.0
+    e2, e3, ep = relerr(h["fft2"], o["fft2"]), relerr(h["timf3"], o["timf3"]), relerr(h["ps2"], o["ps2"])
+    print(ctx, "transforms", int(h["trace"].shape[0]), "locked", int(locked.sum()), "freq", ferr, "phase", perr, "ampl", aerr, "fft2", e2, "timf3", e3, "ps2", ep)
+    assert ferr <= 2e-3 and perr <= 2e-3 and aerr <= 2e-3, (ctx, ferr, perr, aerr)
+    assert e2 <= 1e-5 and e3 <= 1e-5 and ep <= 1e-5, (ctx, e2, e3, ep)
+    h["api"].close(), o["api"].close()
