@@ -4485,8 +4485,10 @@ __global__ __launch_bounds__(LRH_SL_THREADS) void k_sellim(SellimArgs a)
     } else {
       // running boundaries: group 0 ends at (ja+1) gp, the last one is cut at last_inband + 1
       jb = ja + 1;
-      { int ib = jb * gp; do { ib += gp; if (ib > a.last_inband) ib = a.last_inband + 1; jb++; } while (ib < a.last_inband); }
-      for (int i = tid; i < a.last_point; i += LRH_SL_THREADS) A[i] = a.yfac[i] * a.slowsum[i];
+      int ib_end = jb * gp;
+      do { ib_end += gp; if (ib_end > a.last_inband) ib_end = a.last_inband + 1; jb++; } while (ib_end < a.last_inband);
+      // (the group loop fills the spectrum up to the end of its last group, the tail loop behind it up to last_point - 1: sellim.c:925-983)
+      for (int i = tid; i < (ib_end > a.last_point ? ib_end : a.last_point); i += LRH_SL_THREADS) A[i] = a.yfac[i] * a.slowsum[i];
       __syncthreads();
       for (int j = ja + (tid >> 6); j < jb; j += LRH_SL_THREADS / 64) {
         const int lo = j == ja ? a.first_inband : j * gp;

@@ -2154,6 +2154,9 @@ static void fft2_liminfo_regions(lro_ctx *c, lro_sellim_state *st, const lrh_sel
       const float floor_ = sum / cnt;
       st->reg_noise[reg_no] = floor_; st->reg_first[reg_no] = ia - 1;
       const float over = floor_ * ston;
+      if (getenv("LRO_SELLIM_DEBUG")) { const int b_ = atoi(getenv("LRO_SELLIM_DEBUG")); if (b_ >= ia && b_ < ib)   /* (test diagnostics: how far a bin is from the decisions) */
+        { float near_ = 1e9f; int at_ = -1; for (int i = ja; i < jb; i++) if (fabsf(f[i] / limit - 1) < near_) { near_ = fabsf(f[i] / limit - 1); at_ = i; }
+          fprintf(stderr, "LRO_SELLIM_DEBUG region [%d,%d) lowest %.9g limit %.9g cnt %d floor %.9g over %.9g f[%d] %.9g ratio-1 %.3e; nearest to the floor's limit: bin %d at %.3e\n", ia, ib, lowest, limit, cnt, floor_, over, b_, f[b_], f[b_] / over - 1, at_, near_); } }
       int ja2 = -1, jb2 = 0;
       for (int i = ia; i < ib; i++) if (f[i] > over) { if (ja2 < 0) ja2 = i; jb2 = i; mark_strong(lim, st->wait, i, wait_n); }
       if (ja2 < 0) st->reg_len[reg_no++] = ib - ia + 1;
@@ -2197,6 +2200,7 @@ static void fft2_liminfo_regions(lro_ctx *c, lro_sellim_state *st, const lrh_sel
     for (int i = 0; i < reg_no; i++) if (st->reg_noise[i] < 0) { region_list_drop(st, i, reg_no); i--; reg_no--; }
     t1 *= ston;
   }
+  if (getenv("LRO_SELLIM_DEBUG")) { const int b_ = atoi(getenv("LRO_SELLIM_DEBUG")); fprintf(stderr, "LRO_SELLIM_DEBUG common limit %.9g f[%d] %.9g ratio-1 %.3e regions %d dropped %d\n", t1, b_, f[b_], f[b_] / t1 - 1, reg_no, dropped); }
   for (int k = 0; k < reg_no; k++)
     for (int i = 0; i < st->reg_len[k]; i++) if (f[i + st->reg_first[k]] > t1) mark_strong(lim, st->wait, i + st->reg_first[k], wait_n);
 }
