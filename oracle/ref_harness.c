@@ -497,6 +497,11 @@ int main(int argc, char **argv)
     slowcorr_tot_avgnum = 0; correlation_reset_flag = 0; fft1corr_reset_flag = 0;
   }
   set_fft1_endpoints();            /* fft1_first_point=0, last=N1-1, recalc pointer, sym points */
+  { /* an amplitude calibration moves the in-band end points inside the filter's skirts (fft1.c:4631-4637: fft1_desired < 0.5); a case may ask for that
+       without carrying a calibration */
+    int v_;
+    if ((v_ = AI("first_inband", -1)) >= 0) fft1_first_inband = v_;
+    if ((v_ = AI("last_inband", -1)) >= 0) fft1_last_inband = v_; }
   fft1_pa = fft1_pb = fft1_px = 0; fft1_na = fft1_nb = fft1_nx = 0; fft1_nm = 0; fft1_liminfo_cnt = 0;
   ag_pa = 0; ag_mask = 1023;
 

@@ -344,13 +344,18 @@ SELLIM["sellim2v1_n9_n11_many"] = dict(base="n9_n11_shift", nblk=160, maxlevel=1
                                        strong=[(-200.0 + 37.0 * i, 2400.0 + 20.0 * i) for i in range(11)], weak=[(150.5, 45.0), (60.0, 400.0)])
 
 
+# in-band end points inside the band (what an amplitude calibration sets, fft1.c:4631-4637) with the running group minima (par2) and the edge groups
+# skipped (par3): the noise-floor pass starts its first group at fft1_first_inband and cuts the last one at fft1_last_inband + 1 (sellim.c:925-983)
+SELLIM["sellim2_n9_n11_inband"] = dict(SELLIM["sellim2_n9_n11_pars"], first_inband=37, last_inband=470)
+
+
 def sellim_case(name):
     """params + input of a selective-limiter case: the base case's signal plus a carrier keyed on for blocks [on, off)"""
     t = dict(SELLIM[name])
     d = case_params(t.pop("base"))
     keyed = t.pop("keyed")
     sl = {k: t.pop(k) for k in list(t) if k in ("maxlevel", "lim_groups", "blocktime", "ston_fft1", "bw_fftxpts", "par1", "par2", "par3", "par4", "par5", "par6", "par7", "par8",
-                                                 "sellim2", "ston_fft2")}
+                                                 "sellim2", "ston_fft2", "first_inband", "last_inband")}
     d.update(t)
     iq = make_input(d).astype(np.float64)
     N1 = 1 << d["n1"]
