@@ -474,3 +474,58 @@ def test_random_spur_is_acquired_and_tracked_like_the_oracle(seed):
     assert ferr <= 2e-3 and perr <= 2e-3 and aerr <= 2e-3, (ctx, ferr, perr, aerr)
     assert e2 <= 1e-5 and e3c <= 1e-5 and ep <= 1e-5, (ctx, e2, e3, e3c, ep)
     h["api"].close(), o["api"].close()
+
+
+def random_twochan_case(seed):
+    """two RF channels (refcases.TWOCHAN form): the second one the first one's signals under a random sky phase with noise of its own, random
+    phasing of channel 2, polarisation of the baseband pair and run length"""
+    rng = np.random.default_rng(2200 + seed)
+    gname = str(rng.choice(["twochan_n10", "twochan_n9_sin3"]))
+    import refcases
+    t = dict(refcases.TWOCHAN[gname])
+    ang = float(rng.uniform(-3.1, 3.1))
+    v = rng.normal(0, 1, 3); v /= np.linalg.norm(v)
+    t.update(seed2=int(2300 + seed), sky_phase=float(rng.uniform(-3.1, 3.1)), ch2_c1=float(np.float32(np.cos(ang))), ch2_c2=float(np.float32(np.sin(ang))))
+    t["chain"] = dict(t["chain"], nblk=int(rng.choice([48, 64, 80])), pol=tuple(float(np.float32(x)) for x in v))
+    return gname, t, int(rng.choice([1, 2, 3]))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_TWOCHAN_SEEDS", "6"))))
+def test_random_two_channel_chain_matches_the_oracle(seed):
+    """two coupled contexts (one per RF channel) through the whole chain with the exchanges made by hand -- summed powers for the blanker, its
+    statistics, the other channel's fft2 bins for the cross products, the polarisation sums of fft3_mix2 -- on random sky phase, channel-2 phasing,
+    polarisation and run length: pointers and blanker state of both contexts exact, every ring at 1e-5"""
+    import refcases
+    import test_twochan as TC
+    gname, t, batch = random_twochan_case(seed)
+    name = f"random_twochan_{seed}"
+    refcases.TWOCHAN[name] = t
+    try:
+        _, _, h, wf_h, n_h = TC._run_chain(_open_hip, name, True, batch, golden_name=gname)
+        d, _, o, wf_o, n_o = TC._run_chain(_open_oracle, name, False, batch, golden_name=gname)
+    finally:
+        del refcases.TWOCHAN[name]
+    ctx = dict(seed=seed, base=gname, sky_phase=t["sky_phase"], pol=t["chain"]["pol"], nblk=t["chain"]["nblk"], batch=batch)
+    assert n_h == n_o and len(wf_h) == len(wf_o) and n_h >= 4, ctx
+    rep = {}
+    for ch in (0, 1):
+        assert h[ch]["p"] == o[ch]["p"], (ctx, ch, {k: (h[ch]["p"][k], o[ch]["p"][k]) for k in h[ch]["p"] if h[ch]["p"][k] != o[ch]["p"][k]})
+        flips = int(np.count_nonzero((h[ch]["pwr"] == 0) != (o[ch]["pwr"] == 0)))
+        bh, bo = h[ch]["bs"], o[ch]["bs"]
+        same = flips == 0 and bh.timf2_noise_floor == bo.timf2_noise_floor and bh.timf2_cleared_points == bo.timf2_cleared_points
+        rep[f"flips{ch}"] = flips
+        assert flips <= 2 and abs(bh.timf2_noise_floor - bo.timf2_noise_floor) <= max(1, 5e-3 * bo.timf2_noise_floor), (ctx, ch, flips, bh.timf2_noise_floor, bo.timf2_noise_floor)
+        if not same:                                            # a sample within rounding of the blanker's limit: what follows it is not compared (see the tests above)
+            continue
+        for key in ("fft2", "xyp", "xys", "timf3", "fft3", "baseb"):
+            a, b = h[ch][key].astype(np.float64), o[ch][key].astype(np.float64)
+            e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+            rep[f"{key}{ch}"] = float("%.2e" % e)
+            # (timf3 and what follows are a weak band cut from the wide spectrum: held to the float32 floor of that spectrum like in test_twochan._check_chain)
+            wide = np.linalg.norm(o[ch]["fft2"].astype(np.float64)) / np.sqrt(o[ch]["fft2"].size / (2 << d["n2"]))
+            floor = 4 * 6e-8 * wide * np.sqrt(a.size) if key in ("timf3", "fft3", "baseb") else 0.0
+            assert e <= 1e-5 * (2 if key in ("xyp", "xys") else 1) or np.linalg.norm(a - b) <= floor, (ctx, ch, key, e)
+    if all(rep[f"flips{ch}"] == 0 for ch in (0, 1)):
+        dw = np.abs(np.array(wf_h, np.int32) - np.array(wf_o, np.int32))
+        assert dw.max() <= 2 and np.mean(dw != 0) < 0.02, (ctx, int(dw.max()), float(np.mean(dw != 0)))
+    print(ctx, rep)

@@ -169,9 +169,10 @@ def test_hip_coupled_blanker_matches_two_channel_reference(name):
 # ---- the whole two-channel chain: coupled blanker -> make_fft2 per channel -> cross products / sums / polarisation-
 # independent waterfall line from both channels' bins (fft2.c:1622-1640, 1700-1815; the all-gather is done by hand here,
 # tests/test_multichan_gloo.py does it with gloo) -> fft2_mix1_fixed per channel
-def _chain_contexts(open_fn, name, frames_mode):
+def _chain_contexts(open_fn, name, frames_mode, golden_name=None):
+    """golden_name: the golden whose fft3 filter function is installed when `name` is a case of the random tests (refcases.TWOCHAN entry made on the fly)"""
     d, frames, lim = twochan_case(name, chain=True)
-    g = np.load(os.path.join(HERE, "golden", f"{name}_chain.npz"))
+    g = np.load(os.path.join(HERE, "golden", f"{golden_name or name}_chain.npz"))
     fr = frames.reshape(-1, 4)
     rxs = []
     for ch in (0, 1):
@@ -192,8 +193,8 @@ def _chain_contexts(open_fn, name, frames_mode):
     return d, g, rxs
 
 
-def _run_chain(open_fn, name, frames_mode, batch=1):
-    d, g, rxs = _chain_contexts(open_fn, name, frames_mode)
+def _run_chain(open_fn, name, frames_mode, batch=1, golden_name=None):
+    d, g, rxs = _chain_contexts(open_fn, name, frames_mode, golden_name)
     wf_lines, nfft2 = [], 0
     X = abi.StageAPI
     for _ in range(d["nblk"]):
@@ -248,7 +249,10 @@ def _run_chain(open_fn, name, frames_mode, batch=1):
             nfft2 += kb
             k -= kb
     out = [dict(fft3=rx.export(abi.RING_FFT3), baseb=rx.export(abi.RING_BASEB_RAW), fft2=rx.export(abi.RING_FFT2_FLOAT), xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM),
-                timf3=rx.export(abi.RING_TIMF3_FLOAT), p=rx.p.as_dict(), bs=rx.blanker_state()) for rx in rxs]
+                timf3=rx.export(abi.RING_TIMF3_FLOAT), p=rx.p.as_dict(), bs=rx.blanker_state(), pwr=rx.export(abi.RING_TIMF2_PWR), timf2=rx.export(abi.RING_TIMF2_FLOAT)) for rx in rxs]
+    if golden_name is not None:
+        for rx in rxs:
+            rx.close()
     return d, g, out, wf_lines, nfft2
 
 
