@@ -509,7 +509,8 @@ def test_random_two_channel_chain_matches_the_oracle(seed):
     assert n_h == n_o and len(wf_h) == len(wf_o) and n_h >= 4, ctx
     rep = {}
     for ch in (0, 1):
-        assert h[ch]["p"] == o[ch]["p"], (ctx, ch, {k: (h[ch]["p"][k], o[ch]["p"][k]) for k in h[ch]["p"] if h[ch]["p"][k] != o[ch]["p"][k]})
+        ph, po = ({k: v for k, v in q[ch]["p"].items() if k != "timf1p_px"} for q in (h, o))        # (the HIP contexts read their channel out of the interleaved frames: a ring of twice the bytes)
+        assert ph == po, (ctx, ch, {k: (ph[k], po[k]) for k in ph if ph[k] != po[k]})
         flips = int(np.count_nonzero((h[ch]["pwr"] == 0) != (o[ch]["pwr"] == 0)))
         bh, bo = h[ch]["bs"], o[ch]["bs"]
         same = flips == 0 and bh.timf2_noise_floor == bo.timf2_noise_floor and bh.timf2_cleared_points == bo.timf2_cleared_points
