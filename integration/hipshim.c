@@ -84,6 +84,10 @@ static void hip_open_failed(void);
    gains 15 % at fft1_batch_n 4 with one call in flight, configs[2] loses as much -- the stage threads share one stream and one lock, and what the
    timf2 thread no longer waits for the narrowband thread then does.  Default 0 (as round 5); HIPSHIM_LAG sets it (0 .. 2). */
 static int hip_lag = 0;
+/* Where hip_fft1_c collects the previous call's read-backs (lag 0): HIPSHIM_LATE=1 at the END of the call, behind this call's kernels and the start of its own
+   read-backs, when the copies have had a whole call to land (the library queues the sums of this call behind copies of the same rings that are still out,
+   order_behind_readbacks).  Measured (round 6, two boxes x two runs): nothing beyond the spread -- the wait moves into the stage wait.  Default 0: at the start. */
+static int hip_late = 0;
 /* read-backs hip_fft1_c has started, per generation: the call that follows `hip_lag` later collects them (THREAD_TIMF2 / the wideband thread only: one caller) */
 static int hip_ss_ticket[3][8], hip_ss_n[3], hip_ss_gen;
 static int hip_wf_ticket[3][6], hip_wf_n[3], hip_wf_gen;     /* the same for hip_make_fft2 (THREAD_SECOND_FFT only) */
@@ -161,6 +165,7 @@ int hip_open(void)
   HC = ui.rx_rf_channels;
   hip_real2 = HC == 2 && (ui.rx_input_mode & IQ_DATA) == 0;
   hip_n1 = fft1_size; hip_n2 = fft2_size; hip_afc_selfreq = -2;
+  { const char *e = getenv("HIPSHIM_LATE"); hip_late = e ? atoi(e) != 0 : 0; }
   { const char *e = getenv("HIPSHIM_LAG"); hip_lag = e ? atoi(e) : 0; if (hip_lag < 0) hip_lag = 0; if (hip_lag > 2) hip_lag = 2; }
   hip_ss_gen = hip_wf_gen = 0;
   hip_prof = getenv("HIPSHIM_PROF") != NULL; memset(hip_t, 0, sizeof hip_t); hip_tn = 0;
@@ -237,7 +242,11 @@ void hip_close(void)
 {
   if (!hip_rx) return;
   if (hip_prof && hip_tn) fprintf(stderr, "HIPSHIM_PROF hip_fft1_c: %ld calls, %.1f blocks each; per call: stage wait %.1f us, collect %.1f, lrh_fft1_c %.1f, sumsq fetches %.1f (%.1f of them), slowsum fetch %.1f\n", hip_tn, hip_t[5] / hip_tn, hip_t[0] / hip_tn, hip_t[1] / hip_tn, hip_t[2] / hip_tn, hip_t[3] / hip_tn, hip_t[6] / hip_tn, hip_t[4] / hip_tn);
-  for (int g = 0; g < 3; g++) { hip_ss_collect(); hip_wf_collect(); }      /* every generation still out */
+  for (int g = 0; g < 3; g++) {                               /* every generation still out */
+    for (int i = 0; i < hip_ss_n[g]; i++) lrh_export_end(hip_rx, hip_ss_ticket[g][i]);
+    for (int i = 0; i < hip_wf_n[g]; i++) lrh_export_end(hip_rx, hip_wf_ticket[g][i]);
+    hip_ss_n[g] = hip_wf_n[g] = 0;
+  }
   hip_release();
 }
 
@@ -310,6 +319,13 @@ static void hip_ss_collect(void)                             /* moves on to the 
   for (int i = 0; i < hip_ss_n[hip_ss_gen]; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[hip_ss_gen][i]) != 0) lirerr(1466);
   hip_ss_n[hip_ss_gen] = 0;
 }
+static void hip_ss_collect_late(void)                        /* two generations: this call's read-backs are in hip_ss_gen, the previous call's in the other one */
+{
+  const int prev = hip_ss_gen ^ 1;
+  for (int i = 0; i < hip_ss_n[prev]; i++) if (lrh_export_end(hip_rx, hip_ss_ticket[prev][i]) != 0) lirerr(1466);
+  hip_ss_n[prev] = 0;
+  hip_ss_gen = prev;                                          /* the next call's go there */
+}
 static void hip_ss_fetch(lrh_ring ring, float *dst, size_t off, size_t cnt)
 {
   int t = 0;
@@ -329,7 +345,7 @@ void hip_fft1_c(void)
      meanwhile goes into this call */
   HIP_T(0, for (int ch = 0; ch < HC; ch++) lrh_stage_wait_lag(hip_ctx[ch], LRH_STAGE_TIMF2, HC == 1 ? hip_lag : 0));   /* (two channels: the exchanges go through host memory, one call at a time) */
   hip_tn++;
-  HIP_T(1, hip_ss_collect());                                          /* the previous call's spectra: on the host by now */
+  if (!(hip_late && hip_lag == 0 && HC == 1)) HIP_T(1, hip_ss_collect());   /* the previous call's spectra: on the host by now (HIPSHIM_LATE: at the end of this call) */
   /* Every transform fft1_b has delivered goes through in one call: both callers loop `while(fft1_na != fft1_nb){do_fft1_c();
      make_timf2();}` (wcw.c:421-425, 1096-1101), which then ends after one pass -- a call costs the device a fixed latency chain
      whatever its size (INTEGRATION.md "Call size"), and the limiter looks at fft1_liminfo_cnt only after that loop (wcw.c:1124). */
@@ -384,6 +400,7 @@ void hip_fft1_c(void)
         pa = (pa + k) & fft1_sumsq_mask;
       }
       HIP_T(4, hip_ss_fetch(LRH_RING_FFT1_SLOWSUM, fft1_slowsum, 0, (size_t)hip_n1));
+      if (hip_late && hip_lag == 0) HIP_T(1, hip_ss_collect_late());
       return;
     } else
     for (pa = old_pa; pa != q.fft1_sumsq_pa; pa = (pa + hip_n1) & fft1_sumsq_mask) {
