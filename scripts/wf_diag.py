@@ -1,27 +1,40 @@
-import os, sys
+"""Diagnostics for the waterfall lines of tests/test_gpu_random_configs.py::test_random_configuration_matches_the_oracle: HIP, oracle and the float64 build for
+the given seeds, where the lines differ by more than a few counts.  usage (GPU box): python3 scripts/wf_diag.py seed [seed ...]"""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-from linrad_amd import abi
-from linrad_amd.lib import open_hip, synth_defaults, synth_iq
-from linrad_amd.workload import chain_config, strong_liminfo
-N1 = 16384
-s = synth_defaults(N1, 0)
-def run(batch, sparse, pipeline, persist="1"):
-    os.environ["LRH_PERSIST"] = persist
-    if pipeline is None: os.environ.pop("LRH_PIPELINE", None)
-    else: os.environ["LRH_PIPELINE"] = pipeline
-    cfg = chain_config(14, 16, batch=4096, fft3_n=12, mix2_n=8, rounds=2)
-    cfg.fft1_float_sparse = cfg.fft2_float_sparse = sparse
-    cfg.stupid_bln_mode = 0
-    rx = open_hip(cfg)
-    rx.timf1_write(synth_iq(s, 0, cfg.timf1_bytes // 4)); rx.set_liminfo(strong_liminfo(s, 14)); rx.set_mix1_selfreq(0.31 * 65536 + 0.3)
-    rx.wideband_dsp(2 * 4096, batch)
-    wf = rx.export(abi.RING_WG_WATERF); p = rx.p.as_dict(); rx.close()
-    return wf, p
-cases = {"b4096 lagged sparse": (4096, 1, None), "b4096 lagged full": (4096, 0, None), "b4096 serial full": (4096, 0, "0"), "b4096 lagged sparse nopersist": (4096, 1, None, "0"),
-         "b256 serial full": (256, 0, "0"), "b256 lagged full": (256, 0, "2"), "b1024 serial full": (1024, 0, "0")}
-res = {k: run(*v) for k, v in cases.items()}
-ref = res["b256 serial full"][0]
-for k, (wf, p) in res.items():
-    d = np.nonzero(wf != ref)[0]
-    print(k, "diff vs b256 serial:", d.size, "lines", np.unique(d // 1024)[:12], "wptr", p["wg_waterf_ptr"], "ctr", p["wg_waterf_sum_counter"])
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import test_gpu_random_configs as T  # noqa: E402
+from paritylib import run_case  # noqa: E402
+from refcases import make_input, make_liminfo  # noqa: E402
+
+for seed in [int(x) for x in sys.argv[1:]]:
+    d, batch = T.random_case(seed)
+    g = {"iq": make_input(d), "liminfo": make_liminfo(d)}
+    if d["foldcorr_seed"]:
+        from refcases import make_foldcorr
+        g["foldcorr"] = make_foldcorr(d)
+    if d["afc"]:
+        r3 = np.random.default_rng(5600 + seed)
+        tt = np.arange(64 * d["nblk"] + 64)
+        amp, per, at, step = r3.uniform(0.3, 2.0), r3.uniform(15, 60), int(r3.integers(10, 40)), r3.uniform(-3, 3)
+        f = (d["fq"] + amp * np.sin(2 * np.pi * tt / per) + step * ((tt >= at) & (tt < at + 30))).astype(np.float32)
+        g["afc_fq0"], g["afc_supplied"] = f[:1], f[1:]
+    a = run_case(T._open_hip, "random", golden=g, batch=batch, params=d)
+    b = run_case(T._open_oracle, "random", golden=g, batch=batch, params=d)
+    t = run_case(T._open_truth, "random", golden=g, batch=batch, params=d)
+    pre = np.array(t["api"].wf_pre_lines, np.float64).reshape(-1, a["cfg"].wf_xpixels)
+    ha, hb, ht = a["wf_lines"].astype(int), b["wf_lines"].astype(int), t["wf_lines"].astype(int)
+    print("seed", seed, {k: d[k] for k in ("n1", "n2", "sinpow1", "sinpow2", "wf_mode", "wf_avgnum", "stupid", "afc", "blockpower_block", "pulsewidth", "foldcorr_seed")}, "batch", batch, "lines", ha.shape)
+    print("  first_xpoint", a["cfg"].wf_first_xpoint, "xpixels", a["cfg"].wf_xpixels, "itrace equal", np.array_equal(a["itrace"], b["itrace"]))
+    for ln in range(min(ha.shape[0], 6)):
+        dv = np.abs(ha[ln] - hb[ln])
+        w = np.argsort(dv)[-5:][::-1]
+        print(f"  line {ln}: max |hip - oracle| {dv.max()} at pixels {w}: hip {ha[ln][w]} oracle {hb[ln][w]} truth {ht[ln][w]} pre {np.round(pre[ln][w], 1)}; line max {hb[ln].max()} min {hb[ln].min()}; pixels differing by > 3: {int((dv > 3).sum())}")
+    for key in ("fft2_powersum_float", "fft2_float", "timf2_float"):
+        x, y = a[key].astype(np.float64), b[key].astype(np.float64)
+        print(f"  {key} rel {np.linalg.norm(x - y) / np.linalg.norm(y):.2e}")

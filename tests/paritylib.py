@@ -41,7 +41,7 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, params=None, **cf
                               np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))
         if d["mixer_mode"] == 2:                     # bg.mixer_mode = 2: the FIR the compiled reference ran with (stand-in for make_bg_filter's)
             api.set_basebraw_fir(g["basebraw_fir"])
-    itrace, wf_lines, mixtrace = [], [], []
+    itrace, wf_lines, mixtrace, cleared = [], [], [], []
     afc, afc_t = None, [0]
     if d["afc"]:
         # the reference harness supplied these per-transform frequencies (its AFC_SUPPLY macro); replay the same supply
@@ -103,6 +103,7 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, params=None, **cf
         itrace.append([p.timf2_pa, p.timf2p_fit, p.timf2_pn2, p.timf2_px, bs.timf2_noise_floor,
                        bs.stupid_bln_limit, p.fft2_na, p.fft1_sumsq_pa, p.fft1_sumsq_counter,
                        p.fft1_lowlevel_points, p.fft1_liminfo_cnt])
+        cleared.append(bs.timf2_cleared_points)              # (a clearing decision that went the other way shows here even after the ring has moved on)
         b += B
     out = {key: api.export(ring) for ring, key in RINGS}
     if d["fft3_n"]:
@@ -117,6 +118,7 @@ def run_case(open_fn, name, golden=None, stupid=None, batch=1, params=None, **cf
     if afc is not None:
         out["afc_tables"] = np.stack([afc.mid, afc.slope, afc.curv, afc.start])
     out["itrace"] = np.array(itrace, np.int64)
+    out["cleared_trace"] = np.array(cleared, np.int64)
     out["wf_lines"] = np.array(wf_lines, np.int16).reshape(-1, cfg.wf_xpixels)
     out["mixtrace"] = np.array(mixtrace, np.float64).reshape(-1, 8)
     out["lowlevel_fraction"] = api.p.fft1_lowlevel_fraction

