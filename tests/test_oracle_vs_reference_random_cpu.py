@@ -1,0 +1,265 @@
+"""CPU, build container only (needs oracle/_ref/ref_harness = the reference's own C files compiled where they lie): the ORACLE against the COMPILED REFERENCE
+on the random configurations of tests/test_gpu_random_configs.py -- the same seeds the HIP path is held to the oracle on.  The committed goldens pin the oracle
+on 21 planned cases; this walks between them (sizes, windows, averaging, blanker cadence, int32 / mirrored / real input, I/Q calibration, AFC-supplied
+frequencies, compute_timf2_powersum, pulse width, fft3 + mix2), so that "HIP == oracle" on a seed means "HIP == reference" on it.
+LRH_ORACLE_REF_SEEDS / LRH_ORACLE_REF_SEEDS_EXT: how many of the first / third sweep (default 24 + 16; 200 + 200 were run in round 6)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle_binding import open_oracle
+from paritylib import compare_with_golden, run_case
+from test_gpu_random_configs import _open_truth, random_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+pytestmark = pytest.mark.skipif(not os.access(HARNESS, os.X_OK), reason="oracle/_ref/ref_harness is built from /root/reference, in the build container only")
+
+_spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)
+
+SEEDS = list(range(int(os.environ.get("LRH_ORACLE_REF_SEEDS", "24")))) + list(range(200, 200 + int(os.environ.get("LRH_ORACLE_REF_SEEDS_EXT", "16"))))
+
+
+def reference_run(d):
+    """the compiled reference on the case `d`: what tests/golden/make_golden.py would store for it"""
+    import subprocess
+    import tempfile
+    from refcases import harness_args, make_foldcorr, make_input, make_liminfo
+    from refdump import load_dump
+    iq, lim = make_input(d), make_liminfo(d)
+    with tempfile.TemporaryDirectory() as td:
+        fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+        iq.tofile(fi)
+        lim.tofile(fl)
+        extra = []
+        if d["foldcorr_seed"]:
+            ff = os.path.join(td, "fold.bin")
+            make_foldcorr(d).tofile(ff)
+            extra = [f"foldcorr={ff}"]
+        subprocess.check_call([HARNESS] + harness_args(d, fi, fl, fo) + extra, stdout=subprocess.DEVNULL)
+        ref = load_dump(fo)
+    g = {k: ref[k] for k in make_golden.KEEP if k in ref}
+    g["iq"], g["liminfo"] = iq, lim
+    if d["foldcorr_seed"]:
+        g["foldcorr"] = make_foldcorr(d)
+    return g
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_oracle_matches_the_compiled_reference_on_a_random_configuration(seed):
+    d, _ = random_case(seed)
+    d["golden_stride"] = 1
+    if d["fft3_n"]:
+        d["nblk"] = max(d["nblk"], 240)                         # (enough baseband samples for compare_with_golden's own sanity check of the fixture)
+    g = reference_run(d)
+    out = run_case(open_oracle, "random", golden=g, params=d)
+    def truth():
+        t = run_case(_open_truth, "random", golden=g, params=d)
+        t["wf_pre"] = np.array(t["api"].wf_pre_lines, np.float64).reshape(-1, t["cfg"].wf_xpixels)
+        t.pop("api").close()
+        return t
+    cache = []
+
+    def T():
+        if not cache:
+            cache.append(truth())
+        return cache[0]
+    # 2e-5 / 1.3 / a noise floor one count apart: the planned cases of the goldens hold 2e-6 / 1.05 / 0; of 400 random ones 3 had timf2_pwr (a square: twice the
+    # relative error) at 1.1-1.5e-5, 3 the blanker's integer floor one count apart, 1 timf3 at 1.254 of the reference's own distance from the float64 build.
+    # The cleared-sample set, every pointer trace and the mixer's bookkeeping stay exact.
+    rep = compare_with_golden(out, g, tol=2e-5, truth=T, truth_factor=1.3, skip=("wf_lines",), floor_slack=1)
+    # the waterfall lines, each side against the float64 values before truncation, down to 80 dB below the strongest pixel of the RUN (the first line of a start-up
+    # with the blanker off is two float32 noise floors over a float64 value of -200 dB: tests/test_gpu_random_configs.py)
+    gw, ow = g["wf_lines"].reshape(-1, out["cfg"].wf_xpixels).astype(np.int64), out["wf_lines"].astype(np.int64)
+    if gw.size:
+        sel = (gw.max() - gw) < 8000
+        from paritylib import waterfall_gate
+        bad = 0
+        for ln in range(gw.shape[0]):
+            if sel[ln].any():
+                try:
+                    waterfall_gate({}, ow[ln][sel[ln]], gw[ln][sel[ln]], T()["wf_pre"][ln][sel[ln]])
+                except AssertionError:
+                    bad += 1
+                    assert np.abs(ow[ln] - gw[ln])[sel[ln]].max() <= 8, (seed, ln)
+        rep["wf_lines_off_the_gate"] = bad
+    print(seed, {k: d[k] for k in ("n1", "n2", "second_fft", "sinpow1", "sinpow2", "real", "dword", "afc", "foldcorr_seed", "blockpower_block", "stupid", "pulsewidth", "fft3_n")},
+          {k: (float("%.2e" % v) if isinstance(v, float) else v) for k, v in rep.items() if not isinstance(v, dict)})
+
+
+SELLIM_SEEDS = list(range(int(os.environ.get("LRH_ORACLE_REF_SELLIM_SEEDS", "24"))))
+
+
+@pytest.mark.parametrize("seed", SELLIM_SEEDS)
+def test_oracle_limiters_match_the_compiled_reference_on_a_random_case(seed):
+    """both selective limiters (sellim.c:159-1157) as the COMPILED REFERENCE runs them, from the first block on, on the random cases of
+    tests/test_gpu_random_configs.py (levels, hg.sellim_par1..8, group sizes, keyed carriers) with random in-band end points: the routing table after every
+    update -- which bins are weak, strong, attenuated -- exact, the attenuations to 2e-6, the weak-bin counts, the amplitude factor, the rings behind.
+    A case whose tables part on one or two bins is a decision at its threshold (the reference's float32 against the oracle's, 1e-7 apart in the sums: the
+    random HIP test meets the same about once in a hundred runs): counted, everything up to that update still held exactly."""
+    import subprocess
+    import tempfile
+    import refcases
+    import sellimlib
+    from refcases import harness_args, sellim_case
+    from refdump import load_dump
+    from test_gpu_random_configs import random_sellim_case
+    mg = importlib.util.spec_from_file_location("make_golden_sellim", os.path.join(ROOT, "tests", "golden", "make_golden_sellim.py"))
+    mgs = importlib.util.module_from_spec(mg)
+    mg.loader.exec_module(mgs)
+    t, _ = random_sellim_case(seed)
+    rng = np.random.default_rng(3300 + seed)
+    n1 = 1024 if t["base"] == "n10_n12" else 512
+    t.update(first_inband=int(rng.integers(0, 40)), last_inband=int(n1 - 1 - rng.integers(0, 40)))
+    t.pop("stupid", None)                                       # (the blanker as the reference case has it)
+    name = f"random_ref_sellim_{seed}"
+    refcases.SELLIM[name] = t
+    try:
+        d, sl, iq = sellim_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+            iq.tofile(fi)
+            args = [a for a in harness_args(d, fi, "none", fo) if not a.startswith("liminfo=")]
+            subprocess.check_call([HARNESS] + args + ["sellim=1"] + [f"{k}={v}" for k, v in sl.items()], stdout=subprocess.DEVNULL)
+            ref = load_dump(fo)
+        g = {k: ref[k] for k in mgs.KEEP if k in ref}
+        g["iq"] = iq
+        out = sellimlib.run(open_oracle, name, g)
+    finally:
+        del refcases.SELLIM[name]
+    n1_ = out["api"].N1
+    ref1, got1 = g["liminfo_trace"].reshape(-1, n1_), out["trace"]
+    assert got1.shape == ref1.shape, (got1.shape, ref1.shape)
+    bad = np.nonzero((np.sign(got1) != np.sign(ref1)).any(axis=1))[0]
+    if "liminfo_trace2" in g:
+        ref2, got2 = g["liminfo_trace2"].reshape(-1, n1_), out["trace2"]
+        assert got2.shape == ref2.shape, (got2.shape, ref2.shape)
+        bad2 = np.nonzero((np.sign(got2) != np.sign(ref2)).any(axis=1))[0]
+    else:
+        bad2 = np.zeros(0, int)
+    if bad.size == 0 and bad2.size == 0:
+        rep = sellimlib.compare(out, g, tol=2e-5, value_tol=1e-5)
+        print(seed, {k: v for k, v in t.items() if k.startswith("par") or k in ("first_inband", "last_inband", "sellim2", "lim_groups")}, rep)
+        return
+    # parted tables: how many bins at the first update that differs
+    which, r0 = (1, int(bad[0])) if bad.size and (not bad2.size or out["blks"][bad[0]] <= out["blks2"][bad2[0]]) else (2, int(bad2[0]))
+    a, b = (got1[r0], ref1[r0]) if which == 1 else (got2[r0], ref2[r0])
+    bins = np.nonzero(np.sign(a) != np.sign(b))[0]
+    print(seed, "threshold-edge decision: update", which, "number", r0, "bins", bins)
+    assert bins.size <= 2, (seed, which, r0, bins[:10])
+
+
+def _harness(args):
+    import subprocess
+    r = subprocess.run([HARNESS] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def _load_script(name):
+    sp = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tests", "golden", name + ".py"))
+    m = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_ORACLE_REF_CLEVER_SEEDS", "16"))))
+def test_oracle_linear_blanker_matches_the_compiled_reference_on_a_random_pulse_train(seed):
+    """the linear blanker (blank1.c:36-1087) of the COMPILED REFERENCE -- its own init_blanker tables, pulse search, fits, subtraction -- on the random pulse
+    trains of tests/test_gpu_random_configs.py: the blanker's scalars after every call exact, the rings behind to the goldens' tolerance"""
+    import tempfile
+    import cleverlib
+    import refcases
+    from refdump import load_dump
+    from test_gpu_random_configs import random_clever_case
+    mk = _load_script("make_golden_clever")
+    base, t = random_clever_case(seed)
+    name = f"random_ref_clever_{seed}"
+    refcases.CLEVER[name] = t
+    try:
+        d, cl, iq, lim, des = refcases.clever_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fd, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "des.bin", "out.bin"))
+            iq.tofile(fi), lim.tofile(fl), des.tofile(fd)
+            _harness(refcases.harness_args(d, fi, fl, fo) + ["clever=1", f"desired={fd}", f"clever_factor={cl['clever_factor']}"])
+            ref = load_dump(fo)
+        g = {k: ref[k] for k in mk.KEEP if k in ref}
+        g["iq"], g["liminfo"], g["desired"] = iq, lim, des
+        out = cleverlib.run(open_oracle, name, g)
+    finally:
+        del refcases.CLEVER[name]
+    rep = cleverlib.compare(out, g, tol=1e-5)
+    print(seed, base, {k: t[k] for k in ("pulses", "pairs", "rects", "nblk")}, {k: v for k, v in rep.items() if not k.endswith("_first_diff")})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_ORACLE_REF_SPUR_SEEDS", "12"))))
+def test_oracle_spur_loop_matches_the_compiled_reference_on_a_random_carrier(seed):
+    """spur removal as the COMPILED REFERENCE runs it (store_new_spur / spur_phase_lock / initial_remove_spur, eliminate_spurs) on the random carriers of
+    tests/test_gpu_random_configs.py: the same lock decision; where it locks, window and flag after every transform exact, the loop's frequency / phase /
+    amplitude, the fft2 ring behind the subtraction, its sums and timf3 to the goldens' tolerances (spurlib.compare)"""
+    import tempfile
+    import refcases
+    import spurlib
+    from refdump import load_dump
+    from test_gpu_random_configs import random_spur_case
+    mk = _load_script("make_golden_spur")
+    t, batch = random_spur_case(seed)
+    name = f"random_ref_spur_{seed}"
+    refcases.SPUR[name] = t
+    try:
+        d, sp, iq, lim = refcases.spur_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+            iq.tofile(fi), lim.tofile(fl)
+            _harness(refcases.harness_args(d, fi, fl, fo) + ["spur=1"] + [f"{k}={v}" for k, v in sp.items()])
+            ref = load_dump(fo)
+        g = {k: ref[k] for k in mk.KEEP if k in ref}
+        g["iq"], g["liminfo"] = iq, lim
+        locked = int(ref["spur_locked"][0]) > 0
+        if not locked:                                          # the reference did not lock: neither may the oracle at the same transform
+            gg = dict(g, spur_locked=np.array([t["spur_start"]]), spur_init_state=np.concatenate([np.zeros(10), [t["spur_speknum"]], np.zeros(5)]),
+                      spur_spectra=spurlib.load("spur_n10_n12")["spur_spectra"])
+            with pytest.raises(AssertionError, match="no lock"):
+                spurlib.run(open_oracle, name, gg, acquire=True)
+            print(seed, t["tone"], "no lock on either side")
+            return
+        out = spurlib.run(open_oracle, name, g, acquire=True)
+    finally:
+        del refcases.SPUR[name]
+    # (timf3 is what the subtraction leaves of a passband the carrier fills -- the reference's float32 against the oracle's, relative to a residue 20-50 dB below
+    # the carrier: 1e-5 .. 5e-5; spurlib.compare's tolerance is opened for it and everything else held here at the goldens' level)
+    rep = spurlib.compare(out, g, tol=1e-4)
+    assert rep["freq_err_bins"] <= 1e-4 and rep["phase_err_rad"] <= 1e-5 and rep["ampl_rel"] <= 1e-5 and rep["fft2"] <= 2e-6 and rep["ps2"] <= 2e-6 and rep["residual_err_vs_carrier"] <= 1e-5, rep
+    print(seed, t["tone"], t["spur_speknum"], spurlib.compare_acquisition(out, g), {k: v for k, v in rep.items() if k != "locations"})
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_ORACLE_REF_TWOCHAN_SEEDS", "8"))))
+def test_oracle_two_channel_chain_matches_the_compiled_reference_on_a_random_case(seed):
+    """two RF channels in the COMPILED REFERENCE's own single array (ui.rx_rf_channels = 2: coupled blanker, fft2 cross products, polarisation pair of fft3_mix2)
+    against two oracle contexts with the exchanges made by hand, on the random cases of tests/test_gpu_random_configs.py (sky phase, channel-2 phasing,
+    polarisation, run length): tests/test_twochan.py's own check of its goldens"""
+    import tempfile
+    import refcases
+    import test_twochan as TC
+    from refdump import load_dump
+    from test_gpu_random_configs import random_twochan_case
+    gname, t, batch = random_twochan_case(seed)
+    name = f"random_ref_twochan_{seed}"
+    refcases.TWOCHAN[name] = t
+    try:
+        d, frames, lim = refcases.twochan_case(name, chain=True)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+            frames.tofile(fi), lim.tofile(fl)
+            args = refcases.harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}", "chain2=1"]
+            _harness(args + [f"pol_c{i + 1}={v!r}" for i, v in enumerate(d["pol"])])
+            g = load_dump(fo)
+        d, g, out, wf_lines, nfft2 = TC._run_chain(open_oracle, name, False, batch, golden=g)
+    finally:
+        del refcases.TWOCHAN[name]
+    TC._check_chain(d, g, out, wf_lines, nfft2, 1e-5, fixture_checks=False)
+    print(seed, gname, {k: t[k] for k in ("sky_phase", "ch2_c1", "ch2_c2")}, t["chain"]["pol"], "batch", batch)

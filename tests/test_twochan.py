@@ -169,10 +169,11 @@ def test_hip_coupled_blanker_matches_two_channel_reference(name):
 # ---- the whole two-channel chain: coupled blanker -> make_fft2 per channel -> cross products / sums / polarisation-
 # independent waterfall line from both channels' bins (fft2.c:1622-1640, 1700-1815; the all-gather is done by hand here,
 # tests/test_multichan_gloo.py does it with gloo) -> fft2_mix1_fixed per channel
-def _chain_contexts(open_fn, name, frames_mode, golden_name=None):
-    """golden_name: the golden whose fft3 filter function is installed when `name` is a case of the random tests (refcases.TWOCHAN entry made on the fly)"""
+def _chain_contexts(open_fn, name, frames_mode, golden_name=None, golden=None):
+    """golden_name: the golden whose fft3 filter function is installed when `name` is a case of the random tests (refcases.TWOCHAN entry made on the fly);
+    golden: the reference's dump itself (tests/test_oracle_vs_reference_random_cpu.py)"""
     d, frames, lim = twochan_case(name, chain=True)
-    g = np.load(os.path.join(HERE, "golden", f"{golden_name or name}_chain.npz"))
+    g = golden if golden is not None else np.load(os.path.join(HERE, "golden", f"{golden_name or name}_chain.npz"))
     fr = frames.reshape(-1, 4)
     rxs = []
     for ch in (0, 1):
@@ -193,8 +194,8 @@ def _chain_contexts(open_fn, name, frames_mode, golden_name=None):
     return d, g, rxs
 
 
-def _run_chain(open_fn, name, frames_mode, batch=1, golden_name=None):
-    d, g, rxs = _chain_contexts(open_fn, name, frames_mode, golden_name)
+def _run_chain(open_fn, name, frames_mode, batch=1, golden_name=None, golden=None):
+    d, g, rxs = _chain_contexts(open_fn, name, frames_mode, golden_name, golden)
     wf_lines, nfft2 = [], 0
     X = abi.StageAPI
     for _ in range(d["nblk"]):
@@ -250,13 +251,14 @@ def _run_chain(open_fn, name, frames_mode, batch=1, golden_name=None):
             k -= kb
     out = [dict(fft3=rx.export(abi.RING_FFT3), baseb=rx.export(abi.RING_BASEB_RAW), fft2=rx.export(abi.RING_FFT2_FLOAT), xyp=rx.export(abi.RING_FFT2_XYPOWER), xys=rx.export(abi.RING_FFT2_XYSUM),
                 timf3=rx.export(abi.RING_TIMF3_FLOAT), p=rx.p.as_dict(), bs=rx.blanker_state(), pwr=rx.export(abi.RING_TIMF2_PWR), timf2=rx.export(abi.RING_TIMF2_FLOAT)) for rx in rxs]
-    if golden_name is not None:
+    if golden_name is not None or golden is not None:
         for rx in rxs:
             rx.close()
     return d, g, out, wf_lines, nfft2
 
 
-def _check_chain(d, g, out, wf_lines, nfft2, tol):
+def _check_chain(d, g, out, wf_lines, nfft2, tol, fixture_checks=True):
+    """fixture_checks: the demands on the FIXTURE itself (enough fft3 transforms, a polarisation pair that differs) -- off for the random cases"""
     N2 = 1 << d["n2"]
     fin = g["final"]
     if wf_lines is not None:                                 # (None: the rings only -- a run through lrh_wideband_dsp hands no lines out on the way)
@@ -278,7 +280,7 @@ def _check_chain(d, g, out, wf_lines, nfft2, tol):
     # fft3 per channel; the polarisation pair: context 0 carries baseb_raw (A), context 1 baseb_raw_orthog (B)
     N3 = 1 << d["fft3_n"]
     g3 = g["fft3"].reshape(-1, N3, 2, 2)
-    assert g["fft3_ptrs"][0] >= 8
+    assert g["fft3_ptrs"][0] >= (8 if fixture_checks else 4)
     for ch, key in ((0, "baseb_raw"), (1, "baseb_raw_orthog")):
         assert out[ch]["p"]["fft3_pa"] == g["fft3_ptrs"][1] // 2 and out[ch]["p"]["timf3_px"] == g["fft3_ptrs"][2] // 2
         assert out[ch]["p"]["baseb_pa"] == g["baseb_ptrs"][0] and out[ch]["p"]["fft3_px"] == g["baseb_ptrs"][1] // 2
@@ -293,7 +295,7 @@ def _check_chain(d, g, out, wf_lines, nfft2, tol):
         a, b = out[ch]["baseb"].astype(np.float64), g[key].astype(np.float64)
         assert np.count_nonzero(b) >= 100
         assert _rel(a, b) < tol or np.linalg.norm(a - b) <= e_s * np.sqrt(2 * N3 * Nm2) * np.sqrt(np.count_nonzero(b) / 2), (key, _rel(a, b))
-    assert _rel(g["baseb_raw_orthog"], g["baseb_raw"]) > 0.5
+    assert not fixture_checks or _rel(g["baseb_raw_orthog"], g["baseb_raw"]) > 0.5
     if wf_lines is None:
         return
     gw = g["wf_lines"].reshape(len(wf_lines), -1).astype(np.int32)
