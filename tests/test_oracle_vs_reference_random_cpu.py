@@ -263,3 +263,35 @@ def test_oracle_two_channel_chain_matches_the_compiled_reference_on_a_random_cas
         del refcases.TWOCHAN[name]
     TC._check_chain(d, g, out, wf_lines, nfft2, 1e-5, fixture_checks=False)
     print(seed, gname, {k: t[k] for k in ("sky_phase", "ch2_c1", "ch2_c2")}, t["chain"]["pol"], "batch", batch)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_ORACLE_DSP_SEEDS", "24"))))
+def test_oracle_wideband_dsp_is_its_own_stage_calls_on_a_random_configuration(seed):
+    """lro_wideband_dsp -- what the GPU tests hold lrh_wideband_dsp to, and the bench's cpu_baseline port -- against the oracle's stage calls in the reference's
+    single-CPU order (which the tests above hold to the compiled reference), on the random configurations: every ring and pointer bit for bit"""
+    from paritylib import RINGS
+    from refcases import lrh_config, make_foldcorr, make_input, make_liminfo
+    d, batch = random_case(seed if seed < 12 else 188 + seed)
+    d.update(afc=0, blockpower_block=0)
+    g = {"iq": make_input(d), "liminfo": make_liminfo(d)}
+    if d["foldcorr_seed"]:
+        g["foldcorr"] = make_foldcorr(d)
+    B = batch                                                   # (blocks per pass: the stage calls take the same, gpu.fft1_batch_n of the reference's loop)
+    a = run_case(open_oracle, "random", golden=g, params=d, batch=B)
+    rx = open_oracle(lrh_config(d, g["iq"]))
+    rx.timf1_write(g["iq"])
+    rx.set_liminfo(g["liminfo"])
+    if d["foldcorr_seed"]:
+        rx.set_foldcorr(g["foldcorr"])
+    rx.set_mix1_selfreq(d["fq"])
+    if d["fft3_n"]:
+        n3 = 1 << d["fft3_n"]
+        rx.set_bg_filterfunc(np.exp(-((np.arange(n3) - n3 / 2) / (n3 / 6.0)) ** 2).astype(np.float32))
+    rx.wideband_dsp(d["nblk"], B)
+    pa, pb = a["api"].p.as_dict(), rx.p.as_dict()
+    assert pa == pb, {k: (pa[k], pb[k]) for k in pa if pa[k] != pb[k]}
+    for ring, key in RINGS:
+        if not d["second_fft"] and key.startswith(("timf2", "fft2")):
+            continue
+        assert np.array_equal(a[key], rx.export(ring)), (seed, key)
+    rx.close()
