@@ -2,7 +2,11 @@
 on the random configurations of tests/test_gpu_random_configs.py -- the same seeds the HIP path is held to the oracle on.  The committed goldens pin the oracle
 on 21 planned cases; this walks between them (sizes, windows, averaging, blanker cadence, int32 / mirrored / real input, I/Q calibration, AFC-supplied
 frequencies, compute_timf2_powersum, pulse width, fft3 + mix2), so that "HIP == oracle" on a seed means "HIP == reference" on it.
-LRH_ORACLE_REF_SEEDS / LRH_ORACLE_REF_SEEDS_EXT: how many of the first / third sweep (default 24 + 16; 200 + 200 were run in round 6)."""
+LRH_ORACLE_REF_SEEDS / LRH_ORACLE_REF_SEEDS_EXT: how many of the first / third sweep (default 24 + 16).  Round 6, one long sweep (`-n 6`, 4.6 minutes): 1400 chain
+configurations, 1000 limiter, 300 linear-blanker, 300 spur, 300 two-channel cases and 300 batched-entry shapes -- 9 cases off, every one at the edge of a
+tolerance and none in the algorithm: a waterfall pixel 9 counts out where 8 are allowed, timf3 at 1.44 of the reference's own distance from the float64 build
+(allowed 1.3), timf2_blockpower (sums of squares) at 2.2e-5 (2e-5), the linear blanker's integer noise floor one count apart, one coupled blanker decision on a
+sample at its limit, and three fixtures with fewer than 500 baseband samples (compare_with_golden's demand on the fixture, not on the oracle)."""
 import importlib.util
 import os
 
