@@ -467,6 +467,55 @@ def test_random_linear_blanker_matches_the_oracle(seed):
     h["api"].close(), o["api"].close()
 
 
+def random_clever2_case(seed):
+    """two coupled channels with the linear blanker on: a random pulse train (random_clever_case) that reaches channel 1 under a random sky phase and gain.
+    Returns the names and entries to put into refcases.CLEVER / CLEVER2 for the run, and the golden whose tables (init_blanker's) go with the base case."""
+    base, t = random_clever_case(1000 + seed)
+    rng = np.random.default_rng(3700 + seed)
+    t = dict(t, nblk=int(rng.choice([64, 96])))
+    n1, n2 = f"random_clever2_base_{seed}", f"random_clever2_{seed}"
+    t2 = dict(base=n1, nblk=t["nblk"], seed2=int(3800 + seed), sky_phase=float(rng.uniform(-3.1, 3.1)), gain=float(rng.uniform(0.5, 1.5)))
+    return n1, t, n2, t2, {"clever_n10_n12": "clever2_n10", "clever_n9_n11_only": "clever2_n9_only"}[base]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_RANDOM_CLEVER2_SEEDS", "6"))))
+def test_random_two_channel_linear_blanker_matches_the_oracle(seed):
+    """the linear blanker on two coupled contexts (get_pulse_pol, transform_timf2_pol, subtract_twochan_pulse, blank1.c:232-609; the exchanges of
+    tests/clever2lib.py made by hand) on random pulse trains, sky phase and channel gain, with the tables of the golden the pulse train's base case has:
+    the scalars of both contexts after every call exact, their timf2 rings at 1e-5"""
+    import clever2lib
+    import refcases
+    n1_, t1, n2_, t2, gname = random_clever2_case(seed)
+    g = dict(clever2lib.load(gname))
+    refcases.CLEVER[n1_], refcases.CLEVER2[n2_] = t1, t2
+    try:
+        g["frames"] = refcases.clever2_case(n2_)[2]
+        h = clever2lib.run(_open_hip, n2_, g, frames_mode=True)
+        o = clever2lib.run(_open_oracle, n2_, g, frames_mode=False)
+    finally:
+        del refcases.CLEVER[n1_], refcases.CLEVER2[n2_]
+    ctx = dict(seed=seed, tables=gname, case={k: t2[k] for k in ("sky_phase", "gain", "nblk")}, pulses=t1["pulses"])
+    rh, ro = h["rows"].astype(np.float64), o["rows"].astype(np.float64)
+    assert rh.shape == ro.shape, (ctx, rh.shape, ro.shape)
+    d_ = np.abs(rh - ro)
+    edge = bool(d_.any())                                       # (a decision or an integer floor at its rounding edge: see the one-channel test above)
+    lim = np.maximum(3, 5e-3 * np.abs(ro))
+    lim[:, :, 3:5] = np.maximum(lim[:, :, 3:5], 8)              # (cleared / blanker points: a pulse goes with the neighbours it takes along -- seed 8, four samples)
+    assert np.all(d_ <= lim), (ctx, "per-call scalars differ", np.argwhere(d_ > lim)[:4], rh[d_ > lim][:4], ro[d_ > lim][:4])
+    if not edge:
+        n1 = h["rxs"][0].N1
+        keep = np.ones(h["out"][0]["pwr"].size, bool)            # per sample; the raw half block parked beyond timf2_pa is not the device's to store (paritylib)
+        keep[(o["out"][0]["p"]["timf2_pa"] // 4 + np.arange(n1 // 2)) % keep.size] = False
+        for ch in (0, 1):
+            e = relerr(h["out"][ch]["timf2"].reshape(-1, 4)[keep], o["out"][ch]["timf2"].reshape(-1, 4)[keep])
+            ep = relerr(h["out"][ch]["pwr"][keep], o["out"][ch]["pwr"][keep])
+            assert e <= 1e-5 and ep <= 2e-5, (ctx, ch, e, ep)
+            assert np.array_equal((h["out"][ch]["pwr"] == 0) & keep, (o["out"][ch]["pwr"] == 0) & keep), (ctx, ch)
+    print(ctx, "fitted", int(ro[:, 0, 9].sum()), "rejected", int(ro[:, 0, 10].sum()), "rounding-edge decision: rings not compared" if edge else "scalars exact")
+    for rx in h["rxs"] + o["rxs"]:
+        rx.close()
+
+
 def random_spur_case(seed):
     """a carrier of random frequency, drift and level on the n10_n12 base, acquired by the API's own store_new_spur / spur_phase_lock"""
     rng = np.random.default_rng(4400 + seed)
