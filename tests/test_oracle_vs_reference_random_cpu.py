@@ -359,3 +359,46 @@ def test_oracle_two_channel_linear_blanker_matches_the_compiled_reference_on_a_r
     finally:
         del refcases.CLEVER[n1_], refcases.CLEVER2[n2_]
     print(seed, {k: t2[k] for k in ("sky_phase", "gain", "nblk")}, rep)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRH_ORACLE_REF_TWOCHAN1_SEEDS", "8"))))
+def test_oracle_two_channel_first_stages_match_the_compiled_reference_on_a_random_case(seed):
+    """two RF channels, I/Q or real, through fft1 (fft1win_dif_chan / fft1_reherm_dit_two), the channel power sums and make_timf2 (fft1back_two), and -- I/Q --
+    the coupled first_noise_blanker after every block, in the COMPILED REFERENCE's single array against two oracle contexts: tests/test_twochan.py's own
+    checks of its goldens, on random sky phase, channel-2 phasing and run length"""
+    import tempfile
+    import refcases
+    import test_twochan as TC
+    from refdump import load_dump
+    rng = np.random.default_rng(2600 + seed)
+    base = str(rng.choice(["twochan_n10", "twochan_n9_sin3", "twochan_real_n9"]))
+    t = dict(refcases.TWOCHAN[base])
+    ang = float(rng.uniform(-3.1, 3.1))
+    t.update(seed2=int(2700 + seed), nblk=int(rng.choice([24, 32, 40, 56])))
+    if base != "twochan_real_n9":
+        t.update(sky_phase=float(rng.uniform(-3.1, 3.1)), ch2_c1=float(np.float32(np.cos(ang))), ch2_c2=float(np.float32(np.sin(ang))))
+    name = f"random_ref_twochan1_{seed}"
+    refcases.TWOCHAN[name] = t
+    try:
+        d, frames, lim = refcases.twochan_case(name)
+        with tempfile.TemporaryDirectory() as td:
+            fi, fl, fo = (os.path.join(td, x) for x in ("in.bin", "lim.bin", "out.bin"))
+            frames.tofile(fi), lim.tofile(fl)
+            args = refcases.harness_args(d, fi, fl, fo) + ["channels=2", f"ch2_c1={d['ch2_c1']!r}", f"ch2_c2={d['ch2_c2']!r}"]
+            _harness(args)
+            ref = load_dump(fo)
+            g = {k: ref[k] for k in ("fft1_float", "fft1_sumsq", "fft1_slowsum", "timf2_float", "timf2_pwr_float", "itrace", "trace")}
+            if not d["real"]:
+                _harness(args + ["blanker2=1"])
+                refb = load_dump(fo)
+                for k in ("timf2_float", "timf2_pwr_float", "itrace", "trace"):
+                    g["bln_" + k] = refb[k]
+        g["frames"], g["liminfo"] = frames, lim
+        d1, _, out = TC._run(open_oracle, name, False, golden=g)
+        TC._check(d1, g, out, 2e-6)
+        if not d["real"]:
+            d2, _, out2, trace = TC._run_coupled(open_oracle, name, False, golden=g)
+            TC._check_coupled(d2, g, out2, trace, 2e-6)
+    finally:
+        del refcases.TWOCHAN[name]
+    print(seed, base, {k: t[k] for k in ("nblk", "sky_phase", "ch2_c1", "ch2_c2")})

@@ -20,9 +20,9 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def _run(open_fn, name, frames_mode):
+def _run(open_fn, name, frames_mode, golden=None):
     d, frames, lim = twochan_case(name)
-    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    g = golden if golden is not None else np.load(os.path.join(HERE, "golden", f"{name}.npz"))
     assert np.array_equal(g["frames"], frames)
     fr = frames.reshape(-1, 4)
     out = []
@@ -84,9 +84,9 @@ def test_hip_contexts_match_two_channel_reference(name):
 
 # ---- coupled blanker: decisions on the channel power sum, noise floor from both channels (blank1.c:1017, 1236-1300,
 # 1510-1545, 1570); the two sum exchanges are done by hand here (tests/test_multichan_gloo.py does them with gloo)
-def _run_coupled(open_fn, name, frames_mode):
+def _run_coupled(open_fn, name, frames_mode, golden=None):
     d, frames, lim = twochan_case(name)
-    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"))
+    g = golden if golden is not None else np.load(os.path.join(HERE, "golden", f"{name}.npz"))
     fr = frames.reshape(-1, 4)
     rxs = []
     for ch in (0, 1):
