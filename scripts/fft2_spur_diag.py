@@ -9,7 +9,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 import test_gpu_random_configs as T  # noqa: E402
-from linrad_amd import abi  # noqa: E402
 from paritylib import run_case  # noqa: E402
 from refcases import case_params, level_gain, make_liminfo  # noqa: E402
 
